@@ -1,0 +1,338 @@
+/*
+ * oracle/ref_shim.c — TEST INFRASTRUCTURE ONLY.
+ *
+ * A flat-array shim over the REAL reference (bpp v4.8.7) locus API, compiled
+ * against the reference's own bpp.h where it lies under /root/reference/src and
+ * linked with the reference's unmodified objects into oracle/_ref/libbppref.so
+ * (see oracle/Makefile).  Nothing of the reference is copied: this file only
+ * *calls* it.  It lets Python (ctypes) build a reference locus_t + gene tree
+ * from plain arrays and run, through the reference's public entry points,
+ *
+ *   locus_create                 locus.c:622
+ *   pll_set_tip_states           locus.c:561
+ *   pll_set_pattern_weights      locus.c:250
+ *   pll_set_frequencies          locus.c:889
+ *   pll_set_subst_params         locus.c:877
+ *   pll_compute_gamma_cats       gamma.c:221
+ *   locus_update_matrices        locus.c:2417   (JC69 2325, GTR/AA -> core_pmatrix.c:674)
+ *   locus_update_partials        locus.c:2530   (-> core_partials.c:585 and SIMD variants)
+ *   locus_root_loglikelihood     locus.c:2573   (-> core_likelihood.c:24 / :214)
+ *
+ * exactly as method.c:4137-4300 does at start-up and as every proposal does
+ * afterwards.  Used by tests/ (oracle pinning, golden generation) and by
+ * bench.py's cpu_baseline leg.  Never imported by the product.
+ */
+#include "bpp.h"
+#include <time.h>
+
+typedef struct refctx_s
+{
+  locus_t * locus;
+  gtree_t * gtree;
+  gnode_t * nodes;        /* tips first, then inner nodes (gtree.c:2433-2439 convention) */
+  gnode_t ** trav;        /* scratch traversal buffer */
+  unsigned int tips;
+  unsigned int inner;
+  unsigned int scaling;
+  const unsigned int * map;
+} refctx_t;
+
+/* global options the path reads (bpp.h:1142-1260); defaults as bpp.c sets them */
+void ref_set_globals(long alpha_cats, double alpha_a, double alpha_b, long scaling)
+{
+  opt_usedata = 1;
+  opt_clock = BPP_CLOCK_GLOBAL;
+  opt_bfbeta = 1;
+  opt_alpha_cats = alpha_cats;
+  opt_alpha_alpha = alpha_a;
+  opt_alpha_beta = alpha_b;
+  opt_scaling = scaling;
+}
+
+/* arch: 0 cpu, 1 sse, 2 avx, 4 avx2 (PLL_ATTRIB_ARCH_*, bpp.h:364-369) */
+refctx_t * ref_locus_new(unsigned int dtype, unsigned int model,
+                         unsigned int tips, unsigned int states,
+                         unsigned int sites, unsigned int rate_cats,
+                         unsigned int scaling, unsigned int arch)
+{
+  unsigned int i;
+  refctx_t * c = (refctx_t *)calloc(1, sizeof(refctx_t));
+  unsigned int inner = tips - 1;
+  unsigned int edges = 2*tips - 2;
+
+  ref_set_globals(rate_cats, opt_alpha_alpha > 0 ? opt_alpha_alpha : 1,
+                  opt_alpha_beta > 0 ? opt_alpha_beta : 1, scaling);
+
+  c->tips = tips;
+  c->inner = inner;
+  c->scaling = scaling;
+  c->map = (dtype == BPP_DATA_DNA) ? pll_map_nt : pll_map_aa;
+
+  /* buffer counts as method.c:4110-4146: 2*inner CLVs, 2*edges P-matrices,
+     2*inner scalers when scaling is on */
+  c->locus = locus_create(dtype, model, tips, 2*inner, states, sites, 1,
+                          2*edges, rate_cats, scaling ? 2*inner : 0, arch);
+
+  c->nodes = (gnode_t *)calloc(tips + inner, sizeof(gnode_t));
+  c->trav  = (gnode_t **)calloc(tips + inner, sizeof(gnode_t *));
+  c->gtree = (gtree_t *)calloc(1, sizeof(gtree_t));
+  c->gtree->tip_count = tips;
+  c->gtree->inner_count = inner;
+  c->gtree->edge_count = edges;
+  c->gtree->rate_mui = 1;
+  c->gtree->nodes = (gnode_t **)calloc(tips + inner, sizeof(gnode_t *));
+  for (i = 0; i < tips + inner; ++i)
+  {
+    c->gtree->nodes[i] = c->nodes + i;
+    c->nodes[i].node_index = i;
+    c->nodes[i].clv_index = i;
+    c->nodes[i].pmatrix_index = i;
+    c->nodes[i].scaler_index = (i >= tips && scaling) ? (int)(i - tips)
+                                                      : PLL_SCALE_BUFFER_NONE;
+  }
+  return c;
+}
+
+void ref_locus_free(refctx_t * c)
+{
+  locus_destroy(c->locus);
+  free(c->gtree->nodes);
+  free(c->gtree);
+  free(c->nodes);
+  free(c->trav);
+  free(c);
+}
+
+int ref_set_tip(refctx_t * c, unsigned int tip, const char * seq)
+{
+  return pll_set_tip_states(c->locus, tip, c->map, seq);
+}
+
+void ref_set_weights(refctx_t * c, const unsigned int * w)
+{
+  pll_set_pattern_weights(c->locus, w);
+}
+
+void ref_set_rate_mui(refctx_t * c, double mui) { c->gtree->rate_mui = mui; }
+
+void ref_set_freqs(refctx_t * c, const double * f)
+{
+  pll_set_frequencies(c->locus, 0, f);
+}
+
+void ref_set_qrates(refctx_t * c, const double * q)
+{
+  pll_set_subst_params(c->locus, 0, q);
+}
+
+/* as prop_gamma.c:93: rates := discrete-gamma means for alpha */
+void ref_set_alpha(refctx_t * c, double alpha)
+{
+  c->locus->rates_alpha = alpha;
+  pll_compute_gamma_cats(alpha, alpha, c->locus->rate_cats, c->locus->rates,
+                         PLL_GAMMA_RATES_MEAN);
+}
+
+void ref_set_rates(refctx_t * c, const double * rates)
+{
+  memcpy(c->locus->rates, rates, c->locus->rate_cats*sizeof(double));
+}
+
+void ref_get_rates(refctx_t * c, double * rates)
+{
+  memcpy(rates, c->locus->rates, c->locus->rate_cats*sizeof(double));
+}
+
+/* diploid bookkeeping as method.c:4173-4196 leaves it on the locus */
+void ref_set_diploid(refctx_t * c, int unphased_length,
+                     const unsigned long * resolution_count,
+                     const unsigned long * mapping, unsigned long mapping_len,
+                     const unsigned int * unphased_weights)
+{
+  locus_t * l = c->locus;
+  l->diploid = 1;
+  l->unphased_length = unphased_length;
+  l->diploid_resolution_count = (unsigned long *)malloc(unphased_length*sizeof(unsigned long));
+  memcpy(l->diploid_resolution_count, resolution_count, unphased_length*sizeof(unsigned long));
+  l->diploid_mapping = (unsigned long *)malloc(mapping_len*sizeof(unsigned long));
+  memcpy(l->diploid_mapping, mapping, mapping_len*sizeof(unsigned long));
+  l->likelihood_vector = (double *)malloc(l->sites*sizeof(double));
+  free(l->pattern_weights);
+  l->pattern_weights = (unsigned int *)malloc(unphased_length*sizeof(unsigned int));
+  memcpy(l->pattern_weights, unphased_weights, unphased_length*sizeof(unsigned int));
+}
+
+/* topology: left/right child per node (-1 for tips), node ages, root id */
+void ref_set_tree(refctx_t * c, const int * left, const int * right,
+                  const double * times, int root)
+{
+  unsigned int i, n = c->tips + c->inner;
+  for (i = 0; i < n; ++i)
+  {
+    c->nodes[i].left = c->nodes[i].right = NULL;
+    c->nodes[i].parent = NULL;
+  }
+  for (i = 0; i < n; ++i)
+  {
+    c->nodes[i].time = times[i];
+    if (left[i] >= 0)
+    {
+      c->nodes[i].left  = c->nodes + left[i];
+      c->nodes[i].right = c->nodes + right[i];
+      c->nodes[left[i]].parent  = c->nodes + i;
+      c->nodes[right[i]].parent = c->nodes + i;
+    }
+  }
+  c->gtree->root = c->nodes + root;
+}
+
+void ref_set_time(refctx_t * c, unsigned int node, double t) { c->nodes[node].time = t; }
+
+/* explicit buffer indices, as proposals toggle them (SWAP_*_INDEX, locus.c:24-26) */
+void ref_set_indices(refctx_t * c, unsigned int node, unsigned int clv_index,
+                     int scaler_index, unsigned int pmatrix_index)
+{
+  c->nodes[node].clv_index = clv_index;
+  c->nodes[node].scaler_index = scaler_index;
+  c->nodes[node].pmatrix_index = pmatrix_index;
+}
+
+/* locus_update_matrices on an explicit list of branches (child node ids) */
+void ref_update_matrices(refctx_t * c, const unsigned int * branches, unsigned int count)
+{
+  unsigned int i;
+  for (i = 0; i < count; ++i) c->trav[i] = c->nodes + branches[i];
+  locus_update_matrices(c->locus, c->gtree, c->trav, NULL, 0, count);
+}
+
+/* locus_update_partials on an explicit children-first list of inner node ids */
+void ref_update_partials(refctx_t * c, const unsigned int * inner, unsigned int count)
+{
+  unsigned int i;
+  for (i = 0; i < count; ++i) c->trav[i] = c->nodes + inner[i];
+  locus_update_partials(c->locus, c->trav, count);
+}
+
+double ref_root_loglikelihood(refctx_t * c)
+{
+  return locus_root_loglikelihood(c->locus, c->gtree->root,
+                                  c->locus->param_indices, NULL);
+}
+
+static unsigned int shim_postorder(gnode_t * n, gnode_t ** out, unsigned int k)
+{
+  if (!n->left) return k;
+  k = shim_postorder(n->left, out, k);
+  k = shim_postorder(n->right, out, k);
+  out[k++] = n;
+  return k;
+}
+
+/* the start-up sequence of method.c:4285-4297: all matrices, all partials, lnL */
+double ref_full_loglikelihood(refctx_t * c)
+{
+  unsigned int i, k = 0, n = c->tips + c->inner;
+  for (i = 0; i < n; ++i)
+    if (c->nodes[i].parent) c->trav[k++] = c->nodes + i;
+  locus_update_matrices(c->locus, c->gtree, c->trav, NULL, 0, k);
+  k = shim_postorder(c->gtree->root, c->trav, 0);
+  locus_update_partials(c->locus, c->trav, k);
+  return ref_root_loglikelihood(c);
+}
+
+void ref_get_clv(refctx_t * c, unsigned int clv_index, double * out)
+{
+  locus_t * l = c->locus;
+  memcpy(out, l->clv[clv_index],
+         (size_t)l->sites*l->rate_cats*l->states_padded*sizeof(double));
+}
+
+void ref_set_clv(refctx_t * c, unsigned int clv_index, const double * in)
+{
+  locus_t * l = c->locus;
+  memcpy(l->clv[clv_index], in,
+         (size_t)l->sites*l->rate_cats*l->states_padded*sizeof(double));
+}
+
+void ref_get_pmatrix(refctx_t * c, unsigned int pmatrix_index, double * out)
+{
+  locus_t * l = c->locus;
+  memcpy(out, l->pmatrix[pmatrix_index],
+         (size_t)l->rate_cats*l->states*l->states_padded*sizeof(double));
+}
+
+void ref_set_pmatrix(refctx_t * c, unsigned int pmatrix_index, const double * in)
+{
+  locus_t * l = c->locus;
+  memcpy(l->pmatrix[pmatrix_index], in,
+         (size_t)l->rate_cats*l->states*l->states_padded*sizeof(double));
+}
+
+void ref_get_scaler(refctx_t * c, unsigned int scaler_index, unsigned int * out)
+{
+  memcpy(out, c->locus->scale_buffer[scaler_index], c->locus->sites*sizeof(unsigned int));
+}
+
+void ref_get_eigen(refctx_t * c, double * evecs, double * inv_evecs, double * evals)
+{
+  locus_t * l = c->locus;
+  memcpy(evecs, l->eigenvecs[0], l->states*l->states_padded*sizeof(double));
+  memcpy(inv_evecs, l->inv_eigenvecs[0], l->states*l->states_padded*sizeof(double));
+  memcpy(evals, l->eigenvals[0], l->states*sizeof(double));
+}
+
+/* model tables that live in the reference as data (maps.c) */
+const double * ref_aa_rates_lg(void) { return pll_aa_rates_lg; }
+const double * ref_aa_freqs_lg(void) { return pll_aa_freqs_lg; }
+const unsigned int * ref_map_nt(void) { return pll_map_nt; }
+const unsigned int * ref_map_aa(void) { return pll_map_aa; }
+
+/* compress_site_patterns (compress.c:218) on `count` sequences of `*length`
+   columns; sequences are compressed in place, weights copied to w_out.
+   model_jc69 != 0 selects the JC69 relabel-merge (method.c:3433-3434). */
+int ref_compress(char ** seqs, int count, int * length, int dna, int model_jc69,
+                 unsigned int * w_out)
+{
+  int i;
+  unsigned int * w = compress_site_patterns(seqs, dna ? pll_map_nt : pll_map_aa,
+                                            count, length,
+                                            model_jc69 ? COMPRESS_JC69 : COMPRESS_GENERAL);
+  if (!w) return 0;
+  for (i = 0; i < *length; ++i) w_out[i] = w[i];
+  free(w);
+  return 1;
+}
+
+/* ---------------------------------------------------------------------------
+ * CPU-baseline leg: run a proposal "tape" through the reference's own update
+ * API on one core.  Each step of a locus = {set node times; locus_update_matrices
+ * on a branch list; locus_update_partials on a node list; root lnL}.  Tape
+ * format = the one bpp_amd's batched engine consumes (include/bpp_amd.h),
+ * flattened for one locus.  Returns elapsed seconds; lnl_out[step] = lnL.
+ * ------------------------------------------------------------------------- */
+double ref_run_tape(refctx_t * c, unsigned int nsteps,
+                    const unsigned int * time_off, const unsigned int * time_node,
+                    const double * time_val,
+                    const unsigned int * br_off, const unsigned int * br_node,
+                    const unsigned int * op_off, const unsigned int * op_node,
+                    double * lnl_out, unsigned int repeats)
+{
+  struct timespec t0, t1;
+  unsigned int s, i, r;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (r = 0; r < repeats; ++r)
+    for (s = 0; s < nsteps; ++s)
+    {
+      unsigned int k;
+      for (i = time_off[s]; i < time_off[s+1]; ++i)
+        c->nodes[time_node[i]].time = time_val[i];
+      for (k = 0, i = br_off[s]; i < br_off[s+1]; ++i) c->trav[k++] = c->nodes + br_node[i];
+      locus_update_matrices(c->locus, c->gtree, c->trav, NULL, 0, k);
+      for (k = 0, i = op_off[s]; i < op_off[s+1]; ++i) c->trav[k++] = c->nodes + op_node[i];
+      locus_update_partials(c->locus, c->trav, k);
+      lnl_out[s] = locus_root_loglikelihood(c->locus, c->gtree->root,
+                                            c->locus->param_indices, NULL);
+    }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (t1.tv_sec - t0.tv_sec) + 1e-9*(t1.tv_nsec - t0.tv_nsec);
+}
