@@ -1,0 +1,480 @@
+"""ctypes binding of libbpp_amd.so (include/bpp_amd.h) plus a thin host-side
+mirror of the reference's locus API so that tests read like the reference's own
+call sites (method.c:4137-4300, gtree.c:5447-5467).
+
+The library is the product; this module is plumbing.  It fails loudly when the
+HIP extension is missing or no GPU is visible — there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbpp_amd.so")
+
+DATA_DNA, DATA_AA = 0, 1
+MODEL_JC69, MODEL_GTR, MODEL_LG = 0, 7, 10
+ATTRIB_ARCH_HIP = 1 << 6
+SCALE_BUFFER_NONE = -1
+
+
+class BpaError(RuntimeError):
+    pass
+
+
+class Op(C.Structure):
+    """bpa_op_t: one pll_core_update_partial_ii call (core_partials.c:585)."""
+    _fields_ = [("parent_clv", C.c_uint32), ("parent_scaler", C.c_int32),
+                ("left_clv", C.c_uint32), ("left_pmatrix", C.c_uint32), ("left_scaler", C.c_int32),
+                ("right_clv", C.c_uint32), ("right_pmatrix", C.c_uint32), ("right_scaler", C.c_int32)]
+
+
+OP_DTYPE = np.dtype([("parent_clv", "<u4"), ("parent_scaler", "<i4"), ("left_clv", "<u4"),
+                     ("left_pmatrix", "<u4"), ("left_scaler", "<i4"), ("right_clv", "<u4"),
+                     ("right_pmatrix", "<u4"), ("right_scaler", "<i4")])
+
+
+class Batch(C.Structure):
+    _fields_ = [("nloci", C.c_uint), ("loci", C.POINTER(C.c_void_p)),
+                ("mat_off", C.POINTER(C.c_uint)), ("mat_pmatrix", C.POINTER(C.c_uint)),
+                ("mat_length", C.POINTER(C.c_double)),
+                ("op_off", C.POINTER(C.c_uint)), ("ops", C.POINTER(Op)),
+                ("root_clv", C.POINTER(C.c_uint)), ("root_scaler", C.POINTER(C.c_int))]
+
+
+_lib = None
+
+
+def lib():
+    """Load libbpp_amd.so; raise if it has not been built (python -m bpp_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BpaError(f"{LIB_PATH} is missing: run `python -m bpp_amd.build` (hipcc, gfx950). "
+                       "bpp_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u, i, d = C.c_void_p, C.c_uint, C.c_int, C.c_double
+    dp, up = C.POINTER(C.c_double), C.POINTER(C.c_uint)
+    sig = {
+        "bpa_version": (C.c_char_p, []),
+        "bpa_last_error": (C.c_char_p, []),
+        "bpa_device_count": (i, []),
+        "bpa_engine_create": (vp, [i, vp]),
+        "bpa_engine_destroy": (None, [vp]),
+        "bpa_engine_synchronize": (i, [vp]),
+        "bpa_engine_set_options": (None, [vp, i, d]),
+        "bpa_locus_create": (vp, [vp] + [u] * 11),
+        "bpa_locus_destroy": (None, [vp]),
+        "bpa_set_tip_states": (i, [vp, u, up, C.c_char_p]),
+        "bpa_set_pattern_weights": (None, [vp, up]),
+        "bpa_set_frequencies": (None, [vp, u, dp]),
+        "bpa_set_subst_params": (None, [vp, u, dp]),
+        "bpa_set_category_rates": (None, [vp, dp]),
+        "bpa_set_category_weights": (None, [vp, dp]),
+        "bpa_set_param_indices": (None, [vp, up]),
+        "bpa_set_diploid": (i, [vp, i, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong), C.c_ulong, up]),
+        "bpa_map_nt": (up, []),
+        "bpa_map_aa": (up, []),
+        "bpa_locus_update_matrices": (i, [vp, up, dp, u]),
+        "bpa_locus_update_partials": (i, [vp, C.POINTER(Op), u]),
+        "bpa_locus_root_loglikelihood": (d, [vp, u, i, up, dp]),
+        "bpa_core_update_pmatrix": (i, [vp, C.POINTER(dp), u, u, dp, dp, up, up, C.POINTER(dp),
+                                        C.POINTER(dp), C.POINTER(dp), u, u]),
+        "bpa_update_eigen": (i, [vp, dp, dp, dp, dp, dp, u]),
+        "bpa_compute_gamma_cats": (i, [d, d, u, dp]),
+        "bpa_compress_site_patterns": (i, [C.POINTER(C.c_char_p), up, i, C.POINTER(i), i, up]),
+        "bpa_locus_get_clv": (i, [vp, u, dp]),
+        "bpa_locus_set_clv": (i, [vp, u, dp]),
+        "bpa_locus_get_pmatrix": (i, [vp, u, dp]),
+        "bpa_locus_set_pmatrix": (i, [vp, u, dp]),
+        "bpa_locus_get_scaler": (i, [vp, u, up]),
+        "bpa_locus_get_eigen": (i, [vp, u, dp, dp, dp]),
+        "bpa_plan_create": (vp, [vp, C.POINTER(Batch)]),
+        "bpa_plan_destroy": (None, [vp]),
+        "bpa_plan_set_lengths": (i, [vp, dp]),
+        "bpa_plan_launch": (i, [vp]),
+        "bpa_plan_get_lnl": (i, [vp, dp]),
+        "bpa_plan_lnl_device": (vp, [vp]),
+        "bpa_batch_evaluate": (i, [vp, C.POINTER(Batch), dp]),
+        "bpa_plan_work": (i, [vp, dp, dp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
+        "bpa_engine_enable_timing": (None, [vp, i]),
+        "bpa_engine_timing": (i, [vp, dp, dp, dp, C.POINTER(C.c_ulong)]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_create",
+            "bpa_engine_destroy", "bpa_engine_synchronize", "bpa_engine_set_options",
+            "bpa_locus_create", "bpa_locus_destroy", "bpa_set_tip_states",
+            "bpa_set_pattern_weights", "bpa_set_frequencies", "bpa_set_subst_params",
+            "bpa_set_category_rates", "bpa_set_category_weights", "bpa_set_param_indices",
+            "bpa_set_diploid", "bpa_map_nt", "bpa_map_aa", "bpa_locus_update_matrices",
+            "bpa_locus_update_partials", "bpa_locus_root_loglikelihood",
+            "bpa_core_update_pmatrix", "bpa_update_eigen", "bpa_compute_gamma_cats",
+            "bpa_compress_site_patterns", "bpa_locus_get_clv", "bpa_locus_set_clv",
+            "bpa_locus_get_pmatrix", "bpa_locus_set_pmatrix", "bpa_locus_get_scaler",
+            "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
+            "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate",
+            "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing"]
+
+
+def _err():
+    return lib().bpa_last_error().decode()
+
+
+def _chk(ok):
+    if not ok:
+        raise BpaError(_err())
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def map_nt():
+    return np.ctypeslib.as_array(lib().bpa_map_nt(), shape=(256,)).copy()
+
+
+def map_aa():
+    return np.ctypeslib.as_array(lib().bpa_map_aa(), shape=(256,)).copy()
+
+
+def compute_gamma_cats(alpha, beta, categories):
+    """pll_compute_gamma_cats, PLL_GAMMA_RATES_MEAN (gamma.c:221)."""
+    out = np.zeros(categories)
+    _chk(lib().bpa_compute_gamma_cats(alpha, beta, categories, _dp(out)))
+    return out
+
+
+def compress_site_patterns(seqs, dna=True, jc69=False):
+    """compress_site_patterns (compress.c:218): returns (compressed seqs, weights)."""
+    L = lib()
+    count, length = len(seqs), len(seqs[0])
+    bufs = [C.create_string_buffer(s.encode() if isinstance(s, str) else s, length + 1) for s in seqs]
+    arr = (C.c_char_p * count)(*[C.cast(b, C.c_char_p) for b in bufs])
+    ln = C.c_int(length)
+    w = np.zeros(length, dtype=np.uint32)
+    n = L.bpa_compress_site_patterns(arr, L.bpa_map_nt() if dna else L.bpa_map_aa(), count,
+                                     C.byref(ln), int(jc69), _up(w))
+    if not n:
+        raise BpaError("compress_site_patterns failed")
+    return [b.raw[:n].decode() for b in bufs], w[:n].copy()
+
+
+class Engine:
+    """One per process/GPU.  Raises when no GPU is visible."""
+
+    def __init__(self, device=0, stream=None):
+        L = lib()
+        self.h = L.bpa_engine_create(device, stream)
+        if not self.h:
+            raise BpaError(_err())
+        self.loci = []
+
+    def set_options(self, usedata=1, bfbeta=1.0):
+        lib().bpa_engine_set_options(self.h, int(usedata), float(bfbeta))
+
+    def synchronize(self):
+        _chk(lib().bpa_engine_synchronize(self.h))
+
+    def enable_timing(self, on=True):
+        lib().bpa_engine_enable_timing(self.h, int(on))
+
+    def timing(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        n = C.c_ulong()
+        _chk(lib().bpa_engine_timing(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return {"pmatrix_ms": a.value, "partials_ms": b.value, "reduce_ms": c.value,
+                "launches": n.value}
+
+    def update_eigen(self, freqs, subst, states):
+        ev, iev, evals = np.zeros((states, states)), np.zeros((states, states)), np.zeros(states)
+        _chk(lib().bpa_update_eigen(self.h, _dp(ev), _dp(iev), _dp(evals), _dp(_f64(freqs)),
+                                    _dp(_f64(subst)), states))
+        return ev, iev, evals
+
+    def core_update_pmatrix(self, states, rates, branch_lengths, evals, evecs, ievecs,
+                            param_indices=None):
+        """pll_core_update_pmatrix (core_pmatrix.c:785) for one eigensystem."""
+        rates, bl = _f64(rates), _f64(branch_lengths)
+        R, n = len(rates), len(bl)
+        out = np.zeros((n, R, states, states))
+        dp = C.POINTER(C.c_double)
+        pm = (dp * n)(*[_dp(out[i]) for i in range(n)])
+        evals, evecs, ievecs = _f64(evals), _f64(evecs), _f64(ievecs)
+        one = lambda a: (dp * 1)(_dp(a))
+        pi = _u32(np.zeros(R) if param_indices is None else param_indices)
+        mi = _u32(np.arange(n))
+        _chk(lib().bpa_core_update_pmatrix(self.h, pm, states, R, _dp(rates), _dp(bl), _up(mi),
+                                           _up(pi), one(evals), one(evecs), one(ievecs), n, 0))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().bpa_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Locus:
+    """Device twin of locus_t; constructor = locus_create (locus.c:622)."""
+
+    def __init__(self, engine, dtype, model, tips, clv_buffers, states, sites, rate_matrices,
+                 prob_matrices, rate_cats, scale_buffers, attributes=ATTRIB_ARCH_HIP):
+        self.engine = engine
+        self.dtype, self.model, self.tips, self.clv_buffers = dtype, model, tips, clv_buffers
+        self.states, self.sites, self.rate_matrices = states, sites, rate_matrices
+        self.prob_matrices, self.rate_cats, self.scale_buffers = prob_matrices, rate_cats, scale_buffers
+        self.h = lib().bpa_locus_create(engine.h, dtype, model, tips, clv_buffers, states, sites,
+                                        rate_matrices, prob_matrices, rate_cats, scale_buffers,
+                                        attributes)
+        if not self.h:
+            raise BpaError(_err())
+        engine.loci.append(self)
+
+    # --- setters (pll_set_* of locus.c) ---
+    def set_tip_states(self, tip_index, sequence, map_=None):
+        L = lib()
+        if map_ is None:
+            mp = L.bpa_map_nt() if self.states == 4 else L.bpa_map_aa()
+        else:
+            self._map = _u32(map_)
+            mp = _up(self._map)
+        seq = sequence.encode() if isinstance(sequence, str) else sequence
+        if len(seq) != self.sites:
+            raise BpaError("sequence length != sites")
+        _chk(L.bpa_set_tip_states(self.h, tip_index, mp, seq))
+
+    def set_pattern_weights(self, w):
+        w = _u32(w)
+        assert len(w) == self.sites
+        lib().bpa_set_pattern_weights(self.h, _up(w))
+
+    def set_frequencies(self, index, f):
+        lib().bpa_set_frequencies(self.h, index, _dp(_f64(f)))
+
+    def set_subst_params(self, index, p):
+        lib().bpa_set_subst_params(self.h, index, _dp(_f64(p)))
+
+    def set_category_rates(self, rates):
+        lib().bpa_set_category_rates(self.h, _dp(_f64(rates)))
+
+    def set_category_weights(self, w):
+        lib().bpa_set_category_weights(self.h, _dp(_f64(w)))
+
+    def set_diploid(self, resolution_count, mapping, unphased_weights):
+        rc = np.ascontiguousarray(resolution_count, dtype=np.uint64)
+        mp = np.ascontiguousarray(mapping, dtype=np.uint64)
+        uw = _u32(unphased_weights)
+        ulp = C.POINTER(C.c_ulong)
+        _chk(lib().bpa_set_diploid(self.h, len(rc), rc.ctypes.data_as(ulp), mp.ctypes.data_as(ulp),
+                                   len(mp), _up(uw)))
+
+    # --- update API with explicit indices ---
+    def update_matrices(self, pmatrix_indices, branch_lengths):
+        pi, bl = _u32(pmatrix_indices), _f64(branch_lengths)
+        _chk(lib().bpa_locus_update_matrices(self.h, _up(pi), _dp(bl), len(pi)))
+
+    def update_partials(self, ops):
+        ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
+        _chk(lib().bpa_locus_update_partials(self.h, ops.ctypes.data_as(C.POINTER(Op)), len(ops)))
+
+    def root_loglikelihood(self, root_clv, root_scaler=SCALE_BUFFER_NONE, persite=False):
+        ps = np.zeros(self.sites) if persite else None
+        v = lib().bpa_locus_root_loglikelihood(self.h, root_clv, root_scaler, None,
+                                               _dp(ps) if persite else None)
+        if v != v:
+            raise BpaError(_err())
+        return (v, ps) if persite else v
+
+    # --- buffer access in the reference's layouts ---
+    def get_clv(self, idx):
+        out = np.zeros((self.sites, self.rate_cats, self.states))
+        _chk(lib().bpa_locus_get_clv(self.h, idx, _dp(out)))
+        return out
+
+    def set_clv(self, idx, clv):
+        clv = _f64(clv)
+        assert clv.shape == (self.sites, self.rate_cats, self.states)
+        _chk(lib().bpa_locus_set_clv(self.h, idx, _dp(clv)))
+
+    def get_pmatrix(self, idx):
+        out = np.zeros((self.rate_cats, self.states, self.states))
+        _chk(lib().bpa_locus_get_pmatrix(self.h, idx, _dp(out)))
+        return out
+
+    def set_pmatrix(self, idx, p):
+        p = _f64(p)
+        assert p.shape == (self.rate_cats, self.states, self.states)
+        _chk(lib().bpa_locus_set_pmatrix(self.h, idx, _dp(p)))
+
+    def get_scaler(self, idx):
+        out = np.zeros(self.sites, dtype=np.uint32)
+        _chk(lib().bpa_locus_get_scaler(self.h, idx, _up(out)))
+        return out
+
+    def get_eigen(self, index=0):
+        S = self.states
+        ev, iev, evals = np.zeros((S, S)), np.zeros((S, S)), np.zeros(S)
+        _chk(lib().bpa_locus_get_eigen(self.h, index, _dp(ev), _dp(iev), _dp(evals)))
+        return ev, iev, evals
+
+
+# ---------------------------------------------------------------------------
+# gene-tree side of the boundary: the gnode_t / gtree_t fields the path reads
+# (bpp.h:692-774) and the reference-named update calls on them.
+# ---------------------------------------------------------------------------
+class GNode:
+    __slots__ = ("left", "right", "parent", "time", "length", "clv_index", "scaler_index",
+                 "pmatrix_index", "node_index")
+
+    def __init__(self, node_index):
+        self.left = self.right = self.parent = None
+        self.time = 0.0
+        self.length = 0.0
+        self.node_index = node_index
+        self.clv_index = node_index
+        self.scaler_index = SCALE_BUFFER_NONE
+        self.pmatrix_index = node_index
+
+
+class GTree:
+    """tips first, then inner nodes (gtree.c:2433-2439); rate_mui as gtree_t."""
+
+    def __init__(self, left, right, times, root, scaling=False):
+        n = len(left)
+        self.tip_count = (n + 1) // 2
+        self.inner_count = self.tip_count - 1
+        self.edge_count = 2 * self.tip_count - 2
+        self.nodes = [GNode(i) for i in range(n)]
+        self.rate_mui = 1.0
+        for i in range(n):
+            nd = self.nodes[i]
+            nd.time = float(times[i])
+            if left[i] >= 0:
+                nd.left, nd.right = self.nodes[left[i]], self.nodes[right[i]]
+                nd.left.parent = nd.right.parent = nd
+                if scaling:
+                    nd.scaler_index = i - self.tip_count
+        self.root = self.nodes[root]
+
+    def postorder(self):
+        out, stack = [], [(self.root, 0)]
+        while stack:
+            nd, st = stack.pop()
+            if nd.left is None:
+                continue
+            if st == 0:
+                stack += [(nd, 1), (nd.right, 0), (nd.left, 0)]
+            else:
+                out.append(nd)
+        return out
+
+    def branches(self):
+        return [nd for nd in self.nodes if nd.parent is not None]
+
+
+def node_op(node):
+    l, r = node.left, node.right
+    return (node.clv_index, node.scaler_index, l.clv_index, l.pmatrix_index, l.scaler_index,
+            r.clv_index, r.pmatrix_index, r.scaler_index)
+
+
+def branch_length(gtree, node):
+    """strict clock, locus.c:2350; also stored in node.length as the reference does."""
+    node.length = (node.parent.time - node.time) * gtree.rate_mui
+    return node.length
+
+
+def locus_update_matrices(locus, gtree, traversal, count=None):
+    """locus_update_matrices (locus.c:2417): traversal = branches (child nodes)."""
+    trav = traversal if count is None else traversal[:count]
+    locus.update_matrices([nd.pmatrix_index for nd in trav], [branch_length(gtree, nd) for nd in trav])
+
+
+def locus_update_partials(locus, traversal, count=None):
+    """locus_update_partials (locus.c:2530): traversal children-first."""
+    trav = traversal if count is None else traversal[:count]
+    locus.update_partials(np.array([node_op(nd) for nd in trav], dtype=OP_DTYPE))
+
+
+def locus_root_loglikelihood(locus, root, persite=False):
+    """locus_root_loglikelihood (locus.c:2573)."""
+    return locus.root_loglikelihood(root.clv_index, root.scaler_index, persite)
+
+
+class Plan:
+    """A resident batched proposal step (bpa_plan_t)."""
+
+    def __init__(self, engine, loci, mat_off, mat_pmatrix, mat_length, op_off, ops, root_clv,
+                 root_scaler=None):
+        L = lib()
+        self.engine = engine
+        self.n = len(loci)
+        self._keep = dict(
+            loci=(C.c_void_p * self.n)(*[l.h for l in loci]),
+            mat_off=_u32(mat_off), mat_pmatrix=_u32(mat_pmatrix), mat_length=_f64(mat_length),
+            op_off=_u32(op_off), ops=np.ascontiguousarray(ops, dtype=OP_DTYPE),
+            root_clv=_u32(root_clv),
+            root_scaler=np.ascontiguousarray(
+                np.full(self.n, SCALE_BUFFER_NONE) if root_scaler is None else root_scaler,
+                dtype=np.int32))
+        k = self._keep
+        b = Batch(self.n, k["loci"], _up(k["mat_off"]), _up(k["mat_pmatrix"]), _dp(k["mat_length"]),
+                  _up(k["op_off"]), k["ops"].ctypes.data_as(C.POINTER(Op)), _up(k["root_clv"]),
+                  k["root_scaler"].ctypes.data_as(C.POINTER(C.c_int)))
+        self.h = L.bpa_plan_create(engine.h, C.byref(b))
+        if not self.h:
+            raise BpaError(_err())
+
+    def set_lengths(self, lengths):
+        lengths = _f64(lengths)
+        _chk(lib().bpa_plan_set_lengths(self.h, _dp(lengths)))
+
+    def launch(self):
+        _chk(lib().bpa_plan_launch(self.h))
+
+    def lnl(self):
+        out = np.zeros(self.n)
+        _chk(lib().bpa_plan_get_lnl(self.h, _dp(out)))
+        return out
+
+    def work(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        n, p = C.c_ulong(), C.c_ulong()
+        lib().bpa_plan_work(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(n), C.byref(p))
+        return {"bytes_partials": a.value, "flops_partials": b.value, "bytes_pmatrix": c.value,
+                "node_updates": n.value, "pattern_updates": p.value}
+
+    def close(self):
+        if self.h and self.engine.h:
+            lib().bpa_plan_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

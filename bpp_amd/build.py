@@ -1,0 +1,51 @@
+"""Build libbpp_amd.so in-tree with hipcc for gfx950 (MI355X).
+
+    python -m bpp_amd.build
+
+Cross-compiles without a GPU.  -ffp-contract=off is part of the numerical
+contract (CLVs bit-identical to the reference's AVX2 back-end): the only fused
+multiply-adds are explicit __builtin_fma calls.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libbpp_amd.so")
+SOURCES = ["engine.hip", "host_math.cpp"]
+DEPS = ["kernels.hpp", "device_types.hpp", os.path.join(ROOT, "include", "bpp_amd.h")]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    files = [os.path.join(CSRC, s) for s in SOURCES] + \
+            [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in DEPS] + [__file__]
+    return any(os.path.getmtime(f) > t for f in files)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return OUT
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+           "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+           "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

