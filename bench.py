@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the likelihood hot path on the configuration BASELINE.json's
+metric is quoted on: A00, synthetic 10 000 loci x 1 000 sites, 4 taxa, JC69, 1 rate
+category (configs[1]) — per GPU (weak scaling: every rank owns its own 10 000 loci).
+
+A "step" is one A00 MCMC iteration's worth of hot-path work for all loci of the rank:
+the batched proposal steps of bpp_amd/schedule.py (3 GAGE + 6 GSPR + 3 TAU + 1 MIX for
+4 taxa; each = P-matrices -> root-path partials -> root lnL for every locus in one fused
+launch sequence; TAU/MIX steps also produce the all-loci lnL sum that is all-reduced
+across ranks).  All descriptors and loci are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3] [--loci L]
+
+N>1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+CONFIGS = {
+    "c2": dict(taxa=4, model="jc69", rate_cats=1, sites=1000, loci=10000, taus=(0.001, 0.002, 0.003),
+               name="C2: A00, 10000 loci x 1000 sites, 4 taxa, JC69, 1 rate cat"),
+    "c3": dict(taxa=8, model="gtr", rate_cats=4, sites=1000, loci=10000, taus=(0.0011, 0.0025, 0.005),
+               name="C3: A00, 10000 loci x 1000 sites, 8 taxa, GTR+G4"),
+}
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(data, steps_init, steps_iter, n_iter, budget_s=12.0, sample=192):
+    """The same tape on the host CPU, one core, on a bounded sample of the loci:
+    through the REAL reference's update API when oracle/_ref travelled
+    (kind "reference"), else through the oracle's C loop (kind "port")."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib as O
+    import tape
+    sample = min(sample, len(data))
+    use_ref = O.have_ref()
+    per_locus = []
+    t_start = time.time()
+    # calibrate repeats on the first locus, then spend ~budget_s overall
+    reps = 200
+    done = 0
+    for li in range(sample):
+        sub_full = tape.locus_subtape(steps_init + steps_iter, li)
+        sub_init = tape.locus_subtape(steps_init, li)
+        if use_ref:
+            rl = tape.ref_locus_for(data[li])
+            _, t_full = tape.ref_replay(rl, tape.ref_tape_arrays(sub_full), repeats=reps)
+            _, t_init = tape.ref_replay(rl, tape.ref_tape_arrays(sub_init), repeats=reps)
+            rl.free()
+        else:
+            _, t_full = tape.oracle_tape_run(data[li], sub_full, repeats=reps)
+            _, t_init = tape.oracle_tape_run(data[li], sub_init, repeats=reps)
+        per_locus.append(max(t_full - t_init, 1e-12) / (reps * n_iter))
+        done += 1
+        if li == 0:
+            est = (t_full + t_init)
+            reps = int(max(20, min(20000, reps * budget_s / max(est * sample, 1e-9))))
+        if time.time() - t_start > 2.5 * budget_s:
+            break
+    sec_per_locus_iter = float(np.mean(per_locus))
+    return dict(sec_per_locus_iter=sec_per_locus_iter, kind="reference" if use_ref else "port",
+                cores=1, sampled_loci=done, repeats=reps, seconds=time.time() - t_start)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's)")
+    ap.add_argument("--tape-iters", type=int, default=4, help="distinct A00 iterations in the resident tape")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-timing-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    cfg = CONFIGS[args.config]
+    nloci = args.loci or cfg["loci"]
+
+    import bpp_amd
+    from bpp_amd import synth
+    from bpp_amd.schedule import A00Schedule, TreeState
+
+    dist = None
+    sum_buf = None
+    stream = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        dist = dist_
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        stream = torch.cuda.current_stream().cuda_stream
+        sum_buf = torch.zeros(4, dtype=torch.float64, device="cuda")
+
+    eng = bpp_amd.Engine(local_rank, stream)
+
+    # ---- synthetic input (this rank's shard: its own nloci loci), resident in HBM
+    t0 = time.time()
+    data = synth.make_dataset(nloci, cfg["sites"], cfg["taxa"], cfg["model"], cfg["rate_cats"],
+                              seed=12345 + 1000 * rank)
+    npat = sum(len(d["weights"]) for d in data)
+    log(f"dataset: {nloci} loci, {npat} patterns ({npat / nloci:.2f}/locus) in {time.time() - t0:.1f}s")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    loci = []
+    for d in data:
+        S, R = d["states"], d["rate_cats"]
+        tips, sites = len(d["seqs"]), len(d["seqs"][0])
+        inner, edges = tips - 1, 2 * tips - 2
+        mdl = {"jc69": bpp_amd.MODEL_JC69, "gtr": bpp_amd.MODEL_GTR}[d["model"]]
+        loc = bpp_amd.Locus(eng, bpp_amd.DATA_DNA, mdl, tips, 2 * inner, S, sites, 1, 2 * edges, R, 0)
+        for i, s in enumerate(d["seqs"]):
+            loc.set_tip_states(i, s)
+        loc.set_pattern_weights(d["weights"])
+        if d["model"] != "jc69":
+            loc.set_frequencies(0, d["freqs"])
+            loc.set_subst_params(0, d["exch"])
+        loc.set_category_rates(d["rates"])
+        loci.append(loc)
+
+    # ---- the proposal tape (host MCMC control stand-in), then resident plans
+    t0 = time.time()
+    trees = [TreeState(d["left"], d["right"], d["times"], d["root"]) for d in data]
+    sch = A00Schedule(trees, seed=1 + rank, taus=cfg["taus"])
+    init = sch.initial_step()
+    iters = [sch.iteration() for _ in range(args.tape_iters)]
+    log(f"tape: {args.tape_iters} iterations x {len(iters[0])} batched steps in {time.time() - t0:.1f}s")
+
+    def mkplan(st):
+        p = bpp_amd.Plan(eng, [loci[i] for i in st.loci], st.mat_off, st.mat_pmatrix, st.mat_length,
+                         st.op_off, st.ops, st.root_clv, st.root_scaler)
+        if st.global_decision is not None:
+            p.enable_sum(sum_buf.data_ptr() if sum_buf is not None else None)
+        return p
+
+    p_init = mkplan(init)
+    plans = [[mkplan(st) for st in it] for it in iters]
+    p_init.launch()
+    lnl0 = p_init.lnl()
+    log(f"start-up lnL (sum over loci) = {lnl0.sum():.6f}")
+
+    # work per tape iteration (algorithmic)
+    work = [[p.work() for p in it] for it in plans]
+    it_pattern_updates = np.mean([sum(w["pattern_updates"] for w in it) for it in work])
+    it_node_updates = np.mean([sum(w["node_updates"] for w in it) for it in work])
+    it_bytes_partials = np.mean([sum(w["bytes_partials"] for w in it) for it in work])
+    it_flops = np.mean([sum(w["flops_partials"] for w in it) for it in work])
+    launches_per_iter = np.mean([len(it) for it in plans])
+
+    def run_iteration(i):
+        for st, p in zip(iters[i % len(iters)], plans[i % len(plans)]):
+            p.launch()
+            if dist is not None and st.global_decision is not None:
+                dist.all_reduce(sum_buf)       # the per-proposal reduction (threads.c:544-591) over xGMI
+
+    def sync():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        else:
+            eng.synchronize()
+
+    for i in range(args.warmup):
+        run_iteration(i)
+    sync()
+    if not args.no_timing_events:
+        eng.enable_timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run_iteration(args.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    tm = eng.timing() if not args.no_timing_events else None
+    eng.enable_timing(False)
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    total_loci = nloci * world
+    iters_per_s_10k = (total_loci / 10000.0) * args.steps / elapsed
+    site_lnl_updates_per_s = it_pattern_updates * world * args.steps / elapsed
+
+    roofline = None
+    if tm and tm["launches"]:
+        kernel_ms = tm["partials_ms"] / tm["launches"]
+        bytes_per_launch = it_bytes_partials / launches_per_iter
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel="partials_lnl_s4_kernel", achieved=round(achieved, 2),
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
+                        traffic=None, avg_kernel_us=round(1e3 * kernel_ms, 3),
+                        algorithmic_bytes_per_launch=round(bytes_per_launch),
+                        launches=tm["launches"],
+                        pmatrix_kernel_us=round(1e3 * tm["pmatrix_ms"] / tm["launches"], 3),
+                        reduce_kernel_us=round(1e3 * tm["reduce_ms"] / tm["launches"], 3),
+                        note="working set (~30 MB) is cache-resident: latency/launch bound, not HBM bound (SURVEY §7)")
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        n_cpu_iter = min(2, len(iters))
+        cb = cpu_baseline(data, [init], [s for it in iters[:n_cpu_iter] for s in it], n_cpu_iter)
+        v = 1.0 / (cb["sec_per_locus_iter"] * 10000.0)
+        cpu = dict(value=round(v, 3), unit="iterations/s (10k-locus A00 iterations, hot path only)",
+                   cores=cb["cores"], kind=cb["kind"],
+                   sample=f"{cb['sampled_loci']} loci x {n_cpu_iter} tape iterations x {cb['repeats']} repeats "
+                          f"({cb['seconds']:.1f}s), same tape as the GPU, AVX2 back-end, 1 thread")
+
+    if rank == 0:
+        out = {
+            "metric": "MCMC iterations/sec (A00), 10k loci per GPU, likelihood hot path",
+            "value": round(iters_per_s_10k, 3),
+            "unit": "iterations/s (one iteration = A00 proposal schedule over 10 000 loci)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg["name"] + f"; {nloci} loci/GPU, {npat / nloci:.2f} patterns/locus, "
+                       f"{launches_per_iter:.0f} batched proposal steps/iteration "
+                       f"({it_node_updates / nloci:.1f} node updates + {launches_per_iter:.0f} lnL evals per locus)",
+                       "parallelism": f"loci sharded over {world} GPU(s), RCCL all-reduce of the lnL sum per TAU/MIX step"},
+            "site_lnl_updates_per_s": round(site_lnl_updates_per_s),
+            "node_updates_per_iteration": round(float(it_node_updates)),
+            "gflops_partials": round(it_flops * args.steps / elapsed / 1e9, 2),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+
+    for it in plans:
+        for p in it:
+            p.close()
+    p_init.close()
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

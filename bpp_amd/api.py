@@ -96,6 +96,8 @@ def lib():
         "bpa_plan_launch": (i, [vp]),
         "bpa_plan_get_lnl": (i, [vp, dp]),
         "bpa_plan_lnl_device": (vp, [vp]),
+        "bpa_plan_enable_sum": (i, [vp, vp]),
+        "bpa_plan_get_sum": (i, [vp, dp]),
         "bpa_batch_evaluate": (i, [vp, C.POINTER(Batch), dp]),
         "bpa_plan_work": (i, [vp, dp, dp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
         "bpa_engine_enable_timing": (None, [vp, i]),
@@ -120,6 +122,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_locus_get_pmatrix", "bpa_locus_set_pmatrix", "bpa_locus_get_scaler",
             "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
             "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate",
+            "bpa_plan_enable_sum", "bpa_plan_get_sum",
             "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing"]
 
 
@@ -460,6 +463,14 @@ class Plan:
         out = np.zeros(self.n)
         _chk(lib().bpa_plan_get_lnl(self.h, _dp(out)))
         return out
+
+    def enable_sum(self, device_ptr=None):
+        _chk(lib().bpa_plan_enable_sum(self.h, device_ptr))
+
+    def lnl_sum(self):
+        v = C.c_double()
+        _chk(lib().bpa_plan_get_sum(self.h, C.byref(v)))
+        return v.value
 
     def work(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()

@@ -125,7 +125,8 @@ struct bpa_plan
   bool has_mats = false, has_lnl = true;
   DevBuf<uint32_t> task_locus, task_pat_off, thr_task, mat_off, mat_task, mat_pmatrix, op_off, root_clv;
   DevBuf<int32_t>  root_scaler;
-  DevBuf<double>   mat_length, site_term, lnl;
+  DevBuf<double>   mat_length, site_term, lnl, lnl_sum;
+  double * sum_out = nullptr;         // where the per-launch sum of lnl[] goes (own buffer or caller's)
   DevBuf<OpDev>    ops;
   std::vector<uint32_t> h_locus;      // host copy of task -> locus id
   double bytes_partials = 0, bytes_pmatrix = 0, flops_partials = 0;
@@ -134,7 +135,7 @@ struct bpa_plan
   {
     task_locus.free(); task_pat_off.free(); thr_task.free(); mat_off.free(); mat_task.free();
     mat_pmatrix.free(); op_off.free(); root_clv.free(); root_scaler.free(); mat_length.free();
-    site_term.free(); lnl.free(); ops.free();
+    site_term.free(); lnl.free(); ops.free(); lnl_sum.free();
   }
   ~bpa_plan() { free_all(); }
 };
@@ -597,6 +598,11 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     hipLaunchKernelGGL(lnl_reduce_kernel, dim3((d.ntasks + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d);
     HIPCHK(hipGetLastError());
   }
+  if ((mode & 4) && p->sum_out)
+  {
+    hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, d.lnl, d.ntasks, p->sum_out);
+    HIPCHK(hipGetLastError());
+  }
   if (ts) HIPCHK(hipEventRecord(ts->ev[3], e->stream));
   return 1;
 }
@@ -642,6 +648,25 @@ extern "C" int bpa_plan_get_lnl(bpa_plan_t * p, double * lnl)
 }
 
 extern "C" void * bpa_plan_lnl_device(bpa_plan_t * p) { return p->lnl.p; }
+
+extern "C" int bpa_plan_enable_sum(bpa_plan_t * p, void * device_out)
+{
+  if (!set_device(p->eng)) return 0;
+  if (device_out) { p->sum_out = (double *)device_out; return 1; }
+  if (!p->lnl_sum.reserve(1)) return fail("out of device memory (plan)");
+  p->sum_out = p->lnl_sum.p;
+  return 1;
+}
+
+extern "C" int bpa_plan_get_sum(bpa_plan_t * p, double * sum)
+{
+  bpa_engine * e = p->eng;
+  if (!set_device(e)) return 0;
+  if (!p->sum_out) return fail("bpa_plan_get_sum: call bpa_plan_enable_sum first");
+  HIPCHK(hipMemcpyAsync(sum, p->sum_out, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 1;
+}
 
 extern "C" int bpa_plan_work(bpa_plan_t * p, double * bytes_partials, double * flops_partials,
                              double * bytes_pmatrix, unsigned long * node_updates,

@@ -295,6 +295,25 @@ __global__ void __launch_bounds__(BPA_BLOCK) lnl_reduce_kernel(const PlanDev P)
   P.lnl[t] = P.bfbeta*logl;
 }
 
+// sum over the tasks of a plan, deterministic (fixed strided order + LDS tree): the
+// quantity threads.c:544-559 / 583-591 reduces over workers for the all-loci
+// proposals (TAU: logl_diff, MIX: lnacceptance) and that is all-reduced across GPUs.
+__global__ void __launch_bounds__(1024) lnl_sum_kernel(const double * __restrict__ lnl, uint32_t n,
+                                                       double * __restrict__ out)
+{
+  __shared__ double sh[1024];
+  double acc = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) acc += lnl[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t w = 512; w > 0; w >>= 1)
+  {
+    if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
 // ================================================================== K4 / K5 ==
 // P(t) for one (branch, rate category).  4-state: one lane does the 16 entries.
 __device__ __forceinline__ void pmatrix_identity(double * p, int S)

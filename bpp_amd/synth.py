@@ -1,0 +1,154 @@
+"""Synthetic multi-locus alignments of the shapes BASELINE.json names:
+gene trees drawn from the multispecies coalescent on a fixed species tree (one
+sequence per species), sequences evolved down each gene tree under JC69 /
+GTR+Gamma / an amino-acid model + Gamma, then site-pattern compression with the
+semantics of compress_site_patterns (compress.c:218; JC69 relabel-merge for JC69).
+
+This is the bench/test input generator (the reference's own simulator is DNA-only
+and does not travel to the GPU box).  Plain numpy; deterministic for a seed.
+"""
+import numpy as np
+
+from . import api
+
+NT = "ACGT"
+AA = "ARNDCQEGHILKMFPSTWYV"
+
+# species trees as nested tuples (name | (left, right, tau)); theta is global
+SPECIES_TREES = {
+    # (((A,B):0.001, C):0.002, D):0.003   — SURVEY.md App. B sim.ctl
+    4: ((("A", "B", 0.001), "C", 0.002), "D", 0.003),
+    # balanced 8 taxa, tau_root 0.005
+    8: (((("A", "B", 0.001), ("C", "D", 0.0012), 0.0025), (("E", "F", 0.0011), ("G", "H", 0.0013), 0.003), 0.005)),
+    # ((((A,B),C),(D,E)),F), tau_root 0.05 (amino-acid set)
+    6: (((("A", "B", 0.01), "C", 0.02), ("D", "E", 0.015), 0.035), "F", 0.05),
+}
+
+
+def _msc_gene_tree(stree, theta, rng):
+    """one gene tree under the MSC; returns (left, right, times, root) with tips in
+    species order and inner nodes numbered by increasing age"""
+    tips = []
+
+    def names(t):
+        if isinstance(t, str):
+            tips.append(t)
+        else:
+            names(t[0]); names(t[1])
+    names(stree)
+    n = len(tips)
+    left, right, times = [-1] * (2 * n - 1), [-1] * (2 * n - 1), [0.0] * (2 * n - 1)
+    events = []          # (time, a, b)
+    tip_id = {name: i for i, name in enumerate(tips)}
+
+    def pop(t, end):
+        """coalesce the lineages of subtree t inside its own population up to `end`"""
+        if isinstance(t, str):
+            lin, start = [tip_id[t]], 0.0
+        else:
+            lin = pop(t[0], t[2]) + pop(t[1], t[2])
+            start = t[2]
+        now = start
+        while len(lin) > 1:
+            k = len(lin)
+            now += rng.exponential(theta / (k * (k - 1)))     # rate k(k-1)/theta
+            if end is not None and now >= end:
+                break
+            i, j = rng.choice(k, 2, replace=False)
+            events.append((now, lin[i], lin[j]))
+            new = ("ev", len(events) - 1)
+            lin = [x for q, x in enumerate(lin) if q not in (i, j)] + [new]
+        return lin
+
+    pop(stree, None)
+    order = sorted(range(len(events)), key=lambda e: events[e][0])
+    ident = {}
+    for rank, e in enumerate(order):
+        ident[e] = n + rank
+
+    def nid(x):
+        return x if isinstance(x, int) else ident[x[1]]
+    for e in order:
+        t, a, b = events[e]
+        i = ident[e]
+        left[i], right[i], times[i] = nid(a), nid(b), t
+    return left, right, times, 2 * n - 2
+
+
+def _discrete_gamma(alpha, cats):
+    return api.compute_gamma_cats(alpha, alpha, cats) if cats > 1 else np.ones(1)
+
+
+def _q_matrix(freqs, exch):
+    S = len(freqs)
+    Q = np.zeros((S, S))
+    k = 0
+    for i in range(S):
+        for j in range(i + 1, S):
+            Q[i, j] = exch[k] * freqs[j]
+            Q[j, i] = exch[k] * freqs[i]
+            k += 1
+    Q[np.diag_indices(S)] = -Q.sum(1)
+    return Q / -(freqs * np.diag(Q)).sum()
+
+
+def _evolve(left, right, times, root, sites, rng, freqs, Q, site_rate):
+    """states[node, site]"""
+    S = len(freqs)
+    n = len(left)
+    states = np.zeros((n, sites), dtype=np.int8)
+    states[root] = rng.choice(S, sites, p=freqs)
+    lam, V = np.linalg.eig(Q)
+    Vi = np.linalg.inv(V)
+    urates = np.unique(site_rate)
+    stack = [root]
+    while stack:
+        p = stack.pop()
+        for c in (left[p], right[p]):
+            if c < 0:
+                continue
+            t = times[p] - times[c]
+            out = np.empty(sites, dtype=np.int8)
+            for r in urates:
+                m = site_rate == r
+                P = np.real((V * np.exp(lam * t * r)) @ Vi)
+                P = np.clip(P, 0, None)
+                cum = np.cumsum(P / P.sum(1, keepdims=True), axis=1)
+                u = rng.random(m.sum())
+                out[m] = (u[:, None] > cum[states[p][m]]).sum(1).clip(0, S - 1)
+            states[c] = out
+            stack.append(c)
+    return states
+
+
+def make_dataset(nloci, sites, taxa=4, model="jc69", rate_cats=1, alpha=0.5, theta=None, seed=12345,
+                 freqs=None, exch=None):
+    """returns a list of loci: dict(seqs (compressed), weights, left, right, times, root, ...)"""
+    rng = np.random.default_rng(seed)
+    stree = SPECIES_TREES[taxa]
+    dna = model in ("jc69", "gtr")
+    S = 4 if dna else 20
+    if theta is None:
+        theta = 0.002 if dna else 0.02
+    if model == "jc69":
+        freqs, exch = np.full(4, 0.25), np.ones(6)
+    elif model == "gtr":
+        freqs = np.array([0.3, 0.2, 0.2, 0.3]) if freqs is None else np.asarray(freqs)
+        exch = np.array([1, 2, 1, 0.5, 1.5, 1.0]) if exch is None else np.asarray(exch)
+    else:
+        assert freqs is not None and exch is not None, "amino-acid model needs freqs + exchangeabilities"
+        freqs, exch = np.asarray(freqs), np.asarray(exch)
+    Q = _q_matrix(freqs, exch)
+    rates = _discrete_gamma(alpha, rate_cats)
+    alphabet = NT if dna else AA
+    out = []
+    for _ in range(nloci):
+        left, right, times, root = _msc_gene_tree(stree, theta, rng)
+        site_rate = rates[rng.integers(0, rate_cats, sites)]
+        st = _evolve(left, right, times, root, sites, rng, freqs, Q, site_rate)
+        seqs = ["".join(alphabet[c] for c in st[i]) for i in range(taxa)]
+        pats, w = api.compress_site_patterns(seqs, dna, model == "jc69")
+        out.append(dict(seqs=pats, weights=w, left=left, right=right, times=times, root=root,
+                        states=S, rate_cats=rate_cats, model=model, freqs=freqs, exch=exch,
+                        rates=rates, raw_sites=sites))
+    return out

@@ -191,6 +191,13 @@ int          bpa_plan_launch(bpa_plan_t *);
 int          bpa_plan_get_lnl(bpa_plan_t *, double * lnl);
 /* device address of the nloci log-likelihoods / of their sum (double)             */
 void *       bpa_plan_lnl_device(bpa_plan_t *);
+/* Sum of the plan's log-likelihoods over its loci, produced on the device by every
+   launch — the per-proposal reduction of threads.c:544-559,583-591 that all-loci
+   proposals (tau, mixing) need, and the only quantity exchanged between GPUs.
+   device_out: where to write it (e.g. a buffer RCCL all-reduces), or NULL for an
+   internal one read back with bpa_plan_get_sum.                                    */
+int          bpa_plan_enable_sum(bpa_plan_t *, void * device_out);
+int          bpa_plan_get_sum(bpa_plan_t *, double * sum);
 /* convenience: create + launch + get + destroy                                    */
 int          bpa_batch_evaluate(bpa_engine_t *, const bpa_batch_t *, double * lnl);
 

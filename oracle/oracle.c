@@ -692,3 +692,55 @@ int orc_compress(char ** seqs, int count, int * length, const unsigned * map,
   free(keys); free(cols); free(out);
   return 1;
 }
+
+/* --------------------------------------------------------------- tape ------
+ * Replay of a proposal tape in the explicit-index form the batched engine
+ * consumes (include/bpp_amd.h: bpa_batch_t) for ONE locus, with this file's
+ * kernels: per step the listed P-matrices (JC69 closed form or eigen form),
+ * the listed node updates, then the root log-likelihood — the body of every
+ * proposal of the reference (gtree.c:5447-5467).  CPU-baseline "port" leg and
+ * parity checker.  clv[]: tips first then inner buffers; pmat[]/scaler[] by
+ * buffer index.  Returns elapsed seconds for `repeats` passes.               */
+#include <time.h>
+typedef struct { unsigned parent_clv; int parent_scaler; unsigned left_clv, left_pmatrix;
+                 int left_scaler; unsigned right_clv, right_pmatrix; int right_scaler; } orc_op_t;
+
+double orc_run_tape(unsigned states, unsigned sites, unsigned rate_cats, int jc69, int order,
+                    double ** clv, double ** pmat, unsigned ** scaler,
+                    const double * rates, const double * rate_weights, const double * freqs,
+                    const double * eigenvals, const double * eigenvecs, const double * inv_eigenvecs,
+                    const unsigned * weights, unsigned nsteps,
+                    const unsigned * mat_off, const unsigned * mat_pmatrix, const double * mat_length,
+                    const unsigned * op_off, const orc_op_t * ops,
+                    const unsigned * root_clv, const int * root_scaler,
+                    double * lnl_out, unsigned repeats)
+{
+  struct timespec t0, t1;
+  unsigned r, s, i;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (r = 0; r < repeats; ++r)
+    for (s = 0; s < nsteps; ++s)
+    {
+      for (i = mat_off[s]; i < mat_off[s+1]; ++i)
+      {
+        if (jc69) orc_pmatrix_jc69(rate_cats, rates, mat_length[i], pmat[mat_pmatrix[i]]);
+        else orc_pmatrix_eigen(states, rate_cats, rates, mat_length[i], eigenvals, eigenvecs,
+                               inv_eigenvecs, pmat[mat_pmatrix[i]], 0);
+      }
+      for (i = op_off[s]; i < op_off[s+1]; ++i)
+      {
+        const orc_op_t * o = ops + i;
+        orc_update_partial_ii(states, sites, rate_cats, clv[o->parent_clv],
+                              o->parent_scaler >= 0 ? scaler[o->parent_scaler] : NULL,
+                              clv[o->left_clv], clv[o->right_clv],
+                              pmat[o->left_pmatrix], pmat[o->right_pmatrix],
+                              o->left_scaler >= 0 ? scaler[o->left_scaler] : NULL,
+                              o->right_scaler >= 0 ? scaler[o->right_scaler] : NULL, order);
+      }
+      lnl_out[s] = orc_root_loglikelihood(states, sites, rate_cats, clv[root_clv[s]],
+                                          root_scaler[s] >= 0 ? scaler[root_scaler[s]] : NULL,
+                                          freqs, rate_weights, weights, NULL, order);
+    }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (t1.tv_sec - t0.tv_sec) + 1e-9*(t1.tv_nsec - t0.tv_nsec);
+}
