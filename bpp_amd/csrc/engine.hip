@@ -466,6 +466,9 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
       {
         if (b->mat_pmatrix[i] >= l->prob_matrices) return fail("plan: pmatrix index out of range");
         if (!(b->mat_length[i] >= 0)) return fail("plan: negative branch length");   // assert(t >= 0), core_pmatrix.c:723
+        // two branches of one locus writing the same buffer in one step would race
+        for (unsigned j = b->mat_off[t]; j < i; ++j)
+          if (b->mat_pmatrix[j] == b->mat_pmatrix[i]) return fail("plan: a P-matrix buffer is listed twice for one locus");
         mat_task[i] = t;
         p->bytes_pmatrix += R*S*S*8;
       }

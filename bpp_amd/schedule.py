@@ -84,6 +84,19 @@ class TreeState:
         return (i, self.left[i], self.right[i], self.parent[i], self.clv[i], self.scaler[i], self.pmat[i],
                 self.time[i])
 
+    def swap_ids(self, a, b):
+        """exchange the tree positions of node ids a and b (buffer indices stay with the ids):
+        what gtree.c:6129-6175 does so that the root node object stays the root"""
+        m = lambda x: b if x == a else a if x == b else x
+        n = self.n
+        left = [m(self.left[m(i)]) if self.left[m(i)] >= 0 else -1 for i in range(n)]
+        right = [m(self.right[m(i)]) if self.right[m(i)] >= 0 else -1 for i in range(n)]
+        parent = [m(self.parent[m(i)]) if self.parent[m(i)] >= 0 else -1 for i in range(n)]
+        time = [self.time[m(i)] for i in range(n)]
+        self.left, self.right, self.parent, self.time = left, right, parent, time
+        self.root = m(self.root)
+        return m
+
     def inner_nodes(self):
         return [i for i in range(self.n) if self.left[i] >= 0]
 
@@ -227,13 +240,20 @@ class A00Schedule:
                     tr.right[pc] = p
             else:
                 tr.root = p
-            branches = [x for x in (a, c, p, s) if tr.parent[x] >= 0]
-            branches = list(dict.fromkeys(branches))
             nodes = set(tr.path_to_root(p))
             if g >= 0:
                 nodes |= set(tr.path_to_root(g))
-            allnodes = self._emit(step, li, tr, branches, nodes, [a, c, p, s] + ([g] if g >= 0 else []) +
-                                  ([pc] if pc >= 0 else []), root_before, snap)
+            bset = [a, c, p, s]
+            if tr.root != root_before:
+                # the root node keeps its identity (and its never-used P-matrix slot): the new
+                # top node and the old root object trade places (gtree.c:6129-6175); the node
+                # that lands in the old root's position must be recomputed into its own buffers
+                newtop = tr.root
+                m = tr.swap_ids(newtop, root_before)
+                nodes = {m(x) for x in nodes} | set(tr.path_to_root(newtop))
+                bset = [m(x) for x in bset]
+            branches = list(dict.fromkeys(x for x in bset if tr.parent[x] >= 0))
+            allnodes = self._emit(step, li, tr, branches, nodes, range(tr.n), root_before, snap)
             self._decide(step, tr, snap, root_before, allnodes, u[li, 2] < P_ACCEPT)
         return step.finish()
 

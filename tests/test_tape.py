@@ -42,9 +42,14 @@ def test_trees_stay_valid():
                 assert tr.parent[c] == v and tr.time[v] > tr.time[c]
                 seen.add(c)
         assert tr.parent[tr.root] == -1 and len(seen) == tr.n - 1
-        # double buffers: every inner node sits in one of its two CLV slots
+        # double buffers: every inner node sits in one of its two CLV / P-matrix slots, no two
+        # branches share a P-matrix buffer, and the root object is still the root (gtree.c:6129-6175)
+        assert tr.root == tr.n - 1
         for v in range(tr.tips, tr.n):
-            assert tr.clv[v] in (v, v + tr.inner) or tr.clv[v] - tr.tips in ((v - tr.tips), (v - tr.tips + tr.inner) % (2 * tr.inner))
+            assert tr.clv[v] in (v, v + tr.inner)
+        pm = [tr.pmat[b] for b in range(tr.n) if tr.parent[b] >= 0]
+        assert len(set(pm)) == len(pm) and max(pm) < 2 * tr.edges
+        assert all(tr.pmat[b] in (b, b + tr.edges) for b in range(tr.n - 1))
 
 
 def test_oracle_c_loop_equals_python_replay():
