@@ -165,14 +165,30 @@ def main():
     it_pattern_updates = np.mean([sum(w["pattern_updates"] for w in it) for it in work])
     it_node_updates = np.mean([sum(w["node_updates"] for w in it) for it in work])
     it_bytes_partials = np.mean([sum(w["bytes_partials"] for w in it) for it in work])
+    it_bytes_pmatrix = np.mean([sum(w["bytes_pmatrix"] for w in it) for it in work])
     it_flops = np.mean([sum(w["flops_partials"] for w in it) for it in work])
     launches_per_iter = np.mean([len(it) for it in plans])
 
-    def run_iteration(i):
-        for st, p in zip(iters[i % len(iters)], plans[i % len(plans)]):
-            p.launch()
+    # launch segments: consecutive steps up to and including an all-loci step (TAU/MIX), whose
+    # summed lnL is then all-reduced across ranks — the per-proposal reduction of
+    # threads.c:544-591, over xGMI.  One GPU: the whole iteration is one host call.
+    segments = []
+    for sts, pls in zip(iters, plans):
+        segs, cur = [], []
+        for st, p in zip(sts, pls):
+            cur.append(p)
             if dist is not None and st.global_decision is not None:
-                dist.all_reduce(sum_buf)       # the per-proposal reduction (threads.c:544-591) over xGMI
+                segs.append((bpp_amd.PlanSequence(cur), True))
+                cur = []
+        if cur:
+            segs.append((bpp_amd.PlanSequence(cur), False))
+        segments.append(segs)
+
+    def run_iteration(i):
+        for seq, reduce_after in segments[i % len(segments)]:
+            seq.launch()
+            if reduce_after:
+                dist.all_reduce(sum_buf)
 
     def sync():
         if dist is not None:
@@ -210,15 +226,15 @@ def main():
     roofline = None
     if tm and tm["launches"]:
         kernel_ms = tm["partials_ms"] / tm["launches"]
-        bytes_per_launch = it_bytes_partials / launches_per_iter
+        # the fused step kernel does K4 (P-matrix writes) + K1 + K2: algorithmic bytes of all three
+        bytes_per_launch = (it_bytes_partials + it_bytes_pmatrix) / launches_per_iter
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        roofline = dict(bound="hbm", kernel="partials_lnl_s4_kernel", achieved=round(achieved, 2),
+        roofline = dict(bound="hbm", kernel="step_s4_fused_kernel<64,1>", achieved=round(achieved, 2),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
                         traffic=None, avg_kernel_us=round(1e3 * kernel_ms, 3),
                         algorithmic_bytes_per_launch=round(bytes_per_launch),
                         launches=tm["launches"],
-                        pmatrix_kernel_us=round(1e3 * tm["pmatrix_ms"] / tm["launches"], 3),
-                        reduce_kernel_us=round(1e3 * tm["reduce_ms"] / tm["launches"], 3),
+                        timing="hipExtLaunchKernelGGL start/stop events on the engine stream, every launch of the timed region",
                         note="working set (~30 MB) is cache-resident: latency/launch bound, not HBM bound (SURVEY §7)")
 
     cpu = None

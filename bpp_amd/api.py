@@ -94,6 +94,7 @@ def lib():
         "bpa_plan_destroy": (None, [vp]),
         "bpa_plan_set_lengths": (i, [vp, dp]),
         "bpa_plan_launch": (i, [vp]),
+        "bpa_plans_launch": (i, [C.POINTER(vp), u]),
         "bpa_plan_get_lnl": (i, [vp, dp]),
         "bpa_plan_lnl_device": (vp, [vp]),
         "bpa_plan_enable_sum": (i, [vp, vp]),
@@ -122,7 +123,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_locus_get_pmatrix", "bpa_locus_set_pmatrix", "bpa_locus_get_scaler",
             "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
             "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate",
-            "bpa_plan_enable_sum", "bpa_plan_get_sum",
+            "bpa_plan_enable_sum", "bpa_plan_get_sum", "bpa_plans_launch",
             "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing"]
 
 
@@ -426,6 +427,19 @@ def locus_update_partials(locus, traversal, count=None):
 def locus_root_loglikelihood(locus, root, persite=False):
     """locus_root_loglikelihood (locus.c:2573)."""
     return locus.root_loglikelihood(root.clv_index, root.scaler_index, persite)
+
+
+class PlanSequence:
+    """several resident plans launched back to back with one host call (bpa_plans_launch)"""
+
+    def __init__(self, plans):
+        self.plans = list(plans)
+        self.arr = (C.c_void_p * len(self.plans))(*[p.h for p in self.plans])
+        self._fn = lib().bpa_plans_launch
+
+    def launch(self):
+        if not self._fn(self.arr, len(self.plans)):
+            raise BpaError(_err())
 
 
 class Plan:

@@ -68,6 +68,27 @@ struct OpDev
   int32_t  right_scaler;
 };
 
+// Flattened descriptors of the fused single-launch path: everything a lane needs is
+// one 16-byte-aligned record away (no pointer chasing through the locus table).
+struct TaskRec            // 96-byte header followed by nops OpDev records
+{
+  double *   clv;
+  double *   pmat;
+  uint32_t * scaler;
+  const uint8_t *  tips;
+  const uint32_t * weights;
+  const double *   par;
+  uint32_t   np, tips_n, rate_cats, lane0;       // lane0: global lane of pattern 0
+  uint32_t   nops, root_clv; int32_t root_scaler; uint32_t task;
+  uint32_t   unphased_length, pat_off, locus, pad;
+};
+struct MatRec             // one (branch, all rate categories) P-matrix update
+{
+  double *       dst;     // pmat + pmatrix_index*R*16
+  const double * par;
+  uint32_t       rate_cats, model, entry, pad;   // entry: index into mat_length[]
+};
+
 // a resident batched step (bpa_plan_t) as the kernels see it
 struct PlanDev
 {
@@ -85,6 +106,18 @@ struct PlanDev
   const int32_t *  root_scaler; // [T]
   double *         site_term;   // [P] per-pattern weighted log-likelihood (or likelihood for diploid loci)
   double *         lnl;         // [T]
+  // fused single-launch path (all loci of the plan fit a workgroup): workgroup b owns the
+  // whole tasks blk_task_off[b]..blk_task_off[b+1); lane l of it owns pattern
+  // (lane_task[b*BS+l], b*BS + l - task_lane0[task]) or nothing (0xffffffff)
+  const uint32_t * blk_task_off;// [B+1]
+  const uint32_t * lane_task;   // [B*BS]
+  const uint32_t * task_lane0;  // [T] global lane index of the task's pattern 0
+  const uint32_t * lane_rec;    // [B*BS] offset (16-byte units) of the lane's TaskRec in recs, or 0xffffffff
+  const uint4 *    recs;        // TaskRec records
+  const MatRec *   mat_recs;    // [M]
+  const uint32_t * task_rec;    // [T] record offset of task t
+  uint32_t         nblocks;     // B (0: fused path not available)
+  uint32_t         flags;       // bit0: compute P-matrices, bit1: node updates + site terms, bit2: per-locus lnL
   uint32_t         ntasks;
   uint32_t         npatterns;
   uint32_t         nmat;

@@ -4,6 +4,7 @@
 // Reference boundary: the locus API of bpp v4.8.7 (locus.c:622-2631); see the
 // header for the function-by-function mapping.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -94,7 +95,7 @@ struct bpa_locus
   std::unique_ptr<bpa_plan> scratch;  // single-locus calls reuse one small plan
 };
 
-struct TimingSlot { hipEvent_t ev[4]; };
+struct TimingSlot { hipEvent_t ev[4]; int ev_used = 4; };   // 2: only ev[1],ev[2] (kernel-attached)
 
 struct bpa_engine
 {
@@ -124,6 +125,11 @@ struct bpa_plan
   unsigned states = 0, rmax = 1;
   bool has_mats = false, has_lnl = true;
   DevBuf<uint32_t> task_locus, task_pat_off, thr_task, mat_off, mat_task, mat_pmatrix, op_off, root_clv;
+  DevBuf<uint32_t> blk_task_off, lane_task, task_lane0, lane_rec, task_rec;
+  DevBuf<uint4>    recs;
+  DevBuf<MatRec>   mat_recs;
+  unsigned fused_rt = 0;              // compile-time rate-category count of the fused kernel (0 = runtime)
+  unsigned fused_bs = 0;              // workgroup size of the fused single-launch path (0 = not available)
   DevBuf<int32_t>  root_scaler;
   DevBuf<double>   mat_length, site_term, lnl, lnl_sum;
   double * sum_out = nullptr;         // where the per-launch sum of lnl[] goes (own buffer or caller's)
@@ -136,13 +142,17 @@ struct bpa_plan
     task_locus.free(); task_pat_off.free(); thr_task.free(); mat_off.free(); mat_task.free();
     mat_pmatrix.free(); op_off.free(); root_clv.free(); root_scaler.free(); mat_length.free();
     site_term.free(); lnl.free(); ops.free(); lnl_sum.free();
+    blk_task_off.free(); lane_task.free(); task_lane0.free(); lane_rec.free(); task_rec.free(); recs.free(); mat_recs.free();
   }
   ~bpa_plan() { free_all(); }
 };
 
+static thread_local int g_cur_device = -1;
 static int set_device(bpa_engine * e)
 {
+  if (g_cur_device == e->device) return 1;       // hipSetDevice on every launch costs ~1 us
   HIPCHK(hipSetDevice(e->device));
+  g_cur_device = e->device;
   return 1;
 }
 
@@ -520,6 +530,78 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   p->has_mats = nmat > 0;
   p->has_lnl = b->root_clv != nullptr;
 
+  // fused single-launch path: pack whole loci into workgroups (4-state loci that fit one)
+  p->fused_bs = 0; d.nblocks = 0; d.flags = 0;
+  d.blk_task_off = d.lane_task = d.task_lane0 = nullptr;
+  unsigned maxnp = 0;
+  for (unsigned t = 0; t < T; ++t) maxnp = std::max(maxnp, b->loci[t]->sites);
+  if (p->states == 4 && maxnp <= 256)
+  {
+    const unsigned BS = maxnp <= 64 ? 64 : 256;
+    std::vector<uint32_t> blk_off{0}, lane_task, lane0(T);
+    unsigned used = 0;
+    for (unsigned t = 0; t < T; ++t)
+    {
+      const unsigned np = b->loci[t]->sites;
+      if (used + np > BS)
+      {
+        lane_task.resize(blk_off.size()*BS, 0xffffffffu);
+        blk_off.push_back(t); used = 0;
+      }
+      lane0[t] = (uint32_t)((blk_off.size() - 1)*BS + used);
+      for (unsigned n = 0; n < np; ++n) lane_task.push_back(t);
+      used += np;
+    }
+    lane_task.resize(blk_off.size()*BS, 0xffffffffu);
+    blk_off.push_back(T);
+    if (!upload(p->blk_task_off, blk_off.data(), blk_off.size())) return 0;
+    if (!upload(p->lane_task, lane_task.data(), lane_task.size())) return 0;
+    if (!upload(p->task_lane0, lane0.data(), T)) return 0;
+    d.blk_task_off = p->blk_task_off.p; d.lane_task = p->lane_task.p; d.task_lane0 = p->task_lane0.p;
+    d.nblocks = (uint32_t)blk_off.size() - 1;
+    p->fused_bs = BS;
+
+    // flattened records: TaskRec header (6 x 16 B) + the task's node updates (2 x 16 B each,
+    // at least two slots so the eager loads of the first two stay in bounds)
+    static_assert(sizeof(TaskRec) == 96 && sizeof(OpDev) == 32 && sizeof(MatRec) == 32, "record layout");
+    std::vector<uint4> recs;
+    std::vector<uint32_t> task_rec(T), lane_rec(lane_task.size(), 0xffffffffu);
+    std::vector<MatRec> mrecs(nmat);
+    bool all1 = true, all4 = true;
+    for (unsigned t = 0; t < T; ++t)
+    {
+      const bpa_locus * l = b->loci[t];
+      const unsigned nops_t = b->op_off ? b->op_off[t+1] - b->op_off[t] : 0;
+      all1 = all1 && l->rate_cats == 1; all4 = all4 && l->rate_cats == 4;
+      TaskRec r{};
+      r.clv = l->dev.clv; r.pmat = l->dev.pmat; r.scaler = l->dev.scaler; r.tips = l->dev.tips;
+      r.weights = l->dev.weights; r.par = l->dev.par;
+      r.np = l->sites; r.tips_n = l->tips; r.rate_cats = l->rate_cats; r.lane0 = lane0[t];
+      r.nops = nops_t; r.root_clv = rc[t]; r.root_scaler = rs[t]; r.task = t;
+      r.unphased_length = l->dev.unphased_length; r.pat_off = pat_off[t]; r.locus = l->id; r.pad = 0;
+      task_rec[t] = (uint32_t)recs.size();
+      const size_t units = 6 + 2*std::max(nops_t, 2u);
+      recs.resize(recs.size() + units, uint4{0, 0, 0, 0});
+      std::memcpy(&recs[task_rec[t]], &r, sizeof(r));
+      if (nops_t) std::memcpy(&recs[task_rec[t] + 6], b->ops + b->op_off[t], nops_t*sizeof(OpDev));
+      for (unsigned n = 0; n < l->sites; ++n) lane_rec[lane0[t] + n] = task_rec[t];
+      if (b->mat_off)
+        for (unsigned i = b->mat_off[t]; i < b->mat_off[t+1]; ++i)
+        {
+          MatRec & m = mrecs[i];
+          m.dst = l->dev.pmat + (size_t)b->mat_pmatrix[i]*l->rate_cats*16;
+          m.par = l->dev.par; m.rate_cats = l->rate_cats; m.model = l->dev.model; m.entry = i; m.pad = 0;
+        }
+    }
+    if (!upload(p->recs, recs.data(), recs.size())) return 0;
+    if (!upload(p->lane_rec, lane_rec.data(), lane_rec.size())) return 0;
+    if (!upload(p->task_rec, task_rec.data(), T)) return 0;
+    if (!upload(p->mat_recs, mrecs.data(), nmat)) return 0;
+    d.recs = p->recs.p; d.lane_rec = p->lane_rec.p; d.task_rec = p->task_rec.p; d.mat_recs = p->mat_recs.p;
+    p->fused_rt = all1 ? 1 : (all4 ? 4 : 0);
+    d.pad = p->rmax;
+  }
+
   hipLaunchKernelGGL(build_thr_task_kernel, dim3((P + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream,
                      p->task_pat_off.p, T, P, p->thr_task.p);
   HIPCHK(hipGetLastError());
@@ -546,6 +628,7 @@ static int timing_drain(bpa_engine * e)
   {
     for (int j = 0; j < 3; ++j)
     {
+      if (e->slots[i].ev_used == 2 && j != 1) continue;
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, e->slots[i].ev[j], e->slots[i].ev[j+1]));
       e->acc_ms[j] += ms;
@@ -570,6 +653,33 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     ts = next_slot(e);
     if (!ts) { if (!timing_drain(e)) return 0; ts = next_slot(e); }
   }
+  if (p->fused_bs)
+  {
+    // one launch: P-matrices -> node updates + site terms -> per-locus lnL.  With timing on,
+    // the dispatch carries its own start/stop events (exact kernel time, as rocprofv3 sees it).
+    d.flags = (((mode & 1) && p->has_mats) ? 1u : 0u) | ((mode & 2) ? 2u : 0u) | ((mode & 4) ? 4u : 0u);
+    hipEvent_t k0 = ts ? ts->ev[1] : nullptr, k1 = ts ? ts->ev[2] : nullptr;
+    const dim3 grid(d.nblocks);
+#define BPA_FUSED(BS_, RT_) hipExtLaunchKernelGGL((step_s4_fused_kernel<BS_, RT_>), grid, dim3(BS_), 0, e->stream, k0, k1, 0, d)
+    if (p->fused_bs == 64)
+    {
+      if (p->fused_rt == 1) BPA_FUSED(64, 1); else if (p->fused_rt == 4) BPA_FUSED(64, 4); else BPA_FUSED(64, 0);
+    }
+    else
+    {
+      if (p->fused_rt == 1) BPA_FUSED(256, 1); else if (p->fused_rt == 4) BPA_FUSED(256, 4); else BPA_FUSED(256, 0);
+    }
+#undef BPA_FUSED
+    HIPCHK(hipGetLastError());
+    if ((mode & 4) && p->sum_out)
+    {
+      hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, d.lnl, d.ntasks, p->sum_out);
+      HIPCHK(hipGetLastError());
+    }
+    if (ts) ts->ev_used = 2;
+    return 1;
+  }
+  if (ts) ts->ev_used = 4;
   if (ts) HIPCHK(hipEventRecord(ts->ev[0], e->stream));
   if ((mode & 1) && p->has_mats)
   {
@@ -638,6 +748,13 @@ extern "C" int bpa_plan_launch(bpa_plan_t * p)
 {
   if (!p->eng->usedata) return 1;                 // opt_usedata == 0 (locus.c:2424)
   return plan_launch_mode(p, 1 | 2 | (p->has_lnl ? 4 : 0));
+}
+
+extern "C" int bpa_plans_launch(bpa_plan_t * const * plans, unsigned count)
+{
+  for (unsigned i = 0; i < count; ++i)
+    if (!bpa_plan_launch(plans[i])) return 0;
+  return 1;
 }
 
 extern "C" int bpa_plan_get_lnl(bpa_plan_t * p, double * lnl)

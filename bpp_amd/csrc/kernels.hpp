@@ -90,53 +90,53 @@ __device__ __forceinline__ void matvec4(const double * __restrict__ m, const dou
   }
 }
 
-__global__ void __launch_bounds__(BPA_BLOCK) partials_lnl_s4_kernel(const PlanDev P)
+// node updates of task t for pattern n, then the pattern's root term: returns
+// w[n]*(log(site lh) + scaler*log(2^-256))  — or the bare site likelihood for diploid loci
+__device__ __forceinline__ double walk_s4(const PlanDev & P, const uint32_t t, const uint32_t n,
+                                          const LocusDev & L, const bool do_ops)
 {
-  const uint32_t g = blockIdx.x*BPA_BLOCK + threadIdx.x;
-  if (g >= P.npatterns) return;
-  const uint32_t t = P.thr_task[g];
-  const uint32_t n = g - P.task_pat_off[t];
-  const LocusDev L = P.loci[P.task_locus[t]];
   const uint32_t R = L.rate_cats, np = L.np;
-
-  const uint32_t op_end = P.op_off[t+1];
-  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
+  if (do_ops)
   {
-    const OpDev op = P.ops[o];
-    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*np + n)*4;
-    bool all_small = true;
-    for (uint32_t k = 0; k < R; ++k)
+    const uint32_t op_end = P.op_off[t+1];
+    for (uint32_t o = P.op_off[t]; o < op_end; ++o)
     {
-      double lv[4], rv[4], x[4], y[4];
-      load_child4(L, op.left_clv,  k, n, lv);
-      load_child4(L, op.right_clv, k, n, rv);
-      matvec4(L.pmat + ((size_t)op.left_pmatrix*R  + k)*16, lv, x);
-      matvec4(L.pmat + ((size_t)op.right_pmatrix*R + k)*16, rv, y);
-      double2 o0, o1;
-      o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
-      all_small = all_small && (o0.x < BPA_SCALE_THRESHOLD) && (o0.y < BPA_SCALE_THRESHOLD)
-                            && (o1.x < BPA_SCALE_THRESHOLD) && (o1.y < BPA_SCALE_THRESHOLD);
-      double2 * dst = reinterpret_cast<double2 *>(out + (size_t)k*np*4);
-      dst[0] = o0; dst[1] = o1;
-    }
-    if (op.parent_scaler >= 0)
-    {
-      // fill_parent_scaler (core_partials.c:24-46) + per-pattern scaling (core_partials_avx.c:516-529)
-      uint32_t s = 0;
-      if (op.left_scaler  >= 0) s += L.scaler[(size_t)op.left_scaler*np  + n];
-      if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + n];
-      if (all_small)
+      const OpDev op = P.ops[o];
+      double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*np + n)*4;
+      bool all_small = true;
+      for (uint32_t k = 0; k < R; ++k)
       {
-        for (uint32_t k = 0; k < R; ++k)
-        {
-          double2 * dst = reinterpret_cast<double2 *>(out + (size_t)k*np*4);
-          double2 a = dst[0], b = dst[1];
-          a.x *= BPA_SCALE_FACTOR; a.y *= BPA_SCALE_FACTOR; b.x *= BPA_SCALE_FACTOR; b.y *= BPA_SCALE_FACTOR;
-          dst[0] = a; dst[1] = b;
-        }
-        s += 1;
+        double lv[4], rv[4], x[4], y[4];
+        load_child4(L, op.left_clv,  k, n, lv);
+        load_child4(L, op.right_clv, k, n, rv);
+        matvec4(L.pmat + ((size_t)op.left_pmatrix*R  + k)*16, lv, x);
+        matvec4(L.pmat + ((size_t)op.right_pmatrix*R + k)*16, rv, y);
+        double2 o0, o1;
+        o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
+        all_small = all_small && (o0.x < BPA_SCALE_THRESHOLD) && (o0.y < BPA_SCALE_THRESHOLD)
+                              && (o1.x < BPA_SCALE_THRESHOLD) && (o1.y < BPA_SCALE_THRESHOLD);
+        double2 * dst = reinterpret_cast<double2 *>(out + (size_t)k*np*4);
+        dst[0] = o0; dst[1] = o1;
       }
-      L.scaler[(size_t)op.parent_scaler*np + n] = s;
+      if (op.parent_scaler >= 0)
+      {
+        // fill_parent_scaler (core_partials.c:24-46) + per-pattern scaling (core_partials_avx.c:516-529)
+        uint32_t s = 0;
+        if (op.left_scaler  >= 0) s += L.scaler[(size_t)op.left_scaler*np  + n];
+        if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + n];
+        if (all_small)
+        {
+          for (uint32_t k = 0; k < R; ++k)
+          {
+            double2 * dst = reinterpret_cast<double2 *>(out + (size_t)k*np*4);
+            double2 a = dst[0], b = dst[1];
+            a.x *= BPA_SCALE_FACTOR; a.y *= BPA_SCALE_FACTOR; b.x *= BPA_SCALE_FACTOR; b.y *= BPA_SCALE_FACTOR;
+            dst[0] = a; dst[1] = b;
+          }
+          s += 1;
+        }
+        L.scaler[(size_t)op.parent_scaler*np + n] = s;
+      }
     }
   }
 
@@ -153,20 +153,25 @@ __global__ void __launch_bounds__(BPA_BLOCK) partials_lnl_s4_kernel(const PlanDe
     const double tr = dot4_pair(f[0], f[1], f[2], f[3], c);
     term += tr*par[par_rate_weights(R) + k];
   }
-  if (L.unphased_length)
-    P.site_term[g] = term;                       // K3: likelihood, scalers ignored
-  else
+  if (L.unphased_length) return term;            // K3: likelihood, scalers ignored
+  double lt = log(term);
+  const int32_t rs = P.root_scaler[t];
+  if (rs >= 0)
   {
-    double lt = log(term);
-    const int32_t rs = P.root_scaler[t];
-    if (rs >= 0)
-    {
-      const uint32_t sc = L.scaler[(size_t)rs*np + n];
-      if (sc) lt += sc*BPA_LOG_SCALE_THRESHOLD;
-    }
-    lt *= L.weights[n];
-    P.site_term[g] = lt;
+    const uint32_t sc = L.scaler[(size_t)rs*np + n];
+    if (sc) lt += sc*BPA_LOG_SCALE_THRESHOLD;
   }
+  return lt*L.weights[n];
+}
+
+__global__ void __launch_bounds__(BPA_BLOCK) partials_lnl_s4_kernel(const PlanDev P)
+{
+  const uint32_t g = blockIdx.x*BPA_BLOCK + threadIdx.x;
+  if (g >= P.npatterns) return;
+  const uint32_t t = P.thr_task[g];
+  const uint32_t n = g - P.task_pat_off[t];
+  const LocusDev L = P.loci[P.task_locus[t]];
+  P.site_term[g] = walk_s4(P, t, n, L, true);
 }
 
 // ============================================================ K1+K2, generic S ==
@@ -268,12 +273,9 @@ __global__ void __launch_bounds__(BPA_BLOCK) partials_lnl_sN_kernel(const PlanDe
 // ====================================================== per-locus lnL reduction ==
 // Sum of the per-pattern terms in pattern order (core_likelihood.c:206-210); the
 // diploid branch averages the phase resolutions first (locus.c:2600-2614).
-__global__ void __launch_bounds__(BPA_BLOCK) lnl_reduce_kernel(const PlanDev P)
+template <typename TERMPTR>
+__device__ __forceinline__ double reduce_locus(const LocusDev & L, TERMPTR term)
 {
-  const uint32_t t = blockIdx.x*BPA_BLOCK + threadIdx.x;
-  if (t >= P.ntasks) return;
-  const LocusDev & L = P.loci[P.task_locus[t]];
-  const double * term = P.site_term + P.task_pat_off[t];
   double logl = 0;
   if (L.unphased_length)
   {
@@ -292,7 +294,15 @@ __global__ void __launch_bounds__(BPA_BLOCK) lnl_reduce_kernel(const PlanDev P)
     const uint32_t np = L.np;
     for (uint32_t n = 0; n < np; ++n) logl += term[n];
   }
-  P.lnl[t] = P.bfbeta*logl;
+  return logl;
+}
+
+__global__ void __launch_bounds__(BPA_BLOCK) lnl_reduce_kernel(const PlanDev P)
+{
+  const uint32_t t = blockIdx.x*BPA_BLOCK + threadIdx.x;
+  if (t >= P.ntasks) return;
+  const LocusDev & L = P.loci[P.task_locus[t]];
+  P.lnl[t] = P.bfbeta*reduce_locus(L, P.site_term + P.task_pat_off[t]);
 }
 
 // sum over the tasks of a plan, deterministic (fixed strided order + LDS tree): the
@@ -347,11 +357,8 @@ __device__ __forceinline__ void pmatrix_eigen_row(double * __restrict__ prow, in
   }
 }
 
-__global__ void __launch_bounds__(BPA_BLOCK) pmatrix_s4_kernel(const PlanDev P, const uint32_t rmax)
+__device__ __forceinline__ void pmatrix_s4_entry(const PlanDev & P, const uint32_t e, const uint32_t k)
 {
-  const uint32_t tid = blockIdx.x*BPA_BLOCK + threadIdx.x;
-  const uint32_t e = tid / rmax, k = tid % rmax;
-  if (e >= P.nmat) return;
   const LocusDev & L = P.loci[P.task_locus[P.mat_task[e]]];
   const uint32_t R = L.rate_cats;
   if (k >= R) return;
@@ -389,6 +396,250 @@ __global__ void __launch_bounds__(BPA_BLOCK) pmatrix_s4_kernel(const PlanDev P, 
   double2 * dst = reinterpret_cast<double2 *>(p);
 #pragma unroll
   for (int i = 0; i < 8; ++i) { double2 v; v.x = q[2*i]; v.y = q[2*i+1]; dst[i] = v; }
+}
+
+__global__ void __launch_bounds__(BPA_BLOCK) pmatrix_s4_kernel(const PlanDev P, const uint32_t rmax)
+{
+  const uint32_t tid = blockIdx.x*BPA_BLOCK + threadIdx.x;
+  const uint32_t e = tid / rmax, k = tid % rmax;
+  if (e >= P.nmat) return;
+  pmatrix_s4_entry(P, e, k);
+}
+
+// ==================================================== fused proposal step, S=4 ==
+// One launch per proposal step: a workgroup owns whole loci.
+//   phase A  lanes produce the step's P-matrices (K4/K5) into the loci's HBM buffers;
+//            workgroup barrier (stores are write-through; readers are on the same CU);
+//   phase B  one lane per site pattern walks the node updates and forms its root term
+//            (K1+K2); a parent that is the next update's child is forwarded in registers;
+//   phase C  one lane per locus adds the terms in pattern order (the reference's order,
+//            core_likelihood.c:206-210) from LDS.
+// Latency is the enemy here (config 2: 5 patterns x 2 updates per locus), so the
+// descriptors are flattened (TaskRec/MatRec) and every load that does not depend on
+// phase A is issued before it.
+__device__ __forceinline__ void pmatrix_s4_rec(const MatRec & m, const double * __restrict__ mat_length, const uint32_t k)
+{
+  const uint32_t R = m.rate_cats;
+  const double * par = m.par;
+  const double t = mat_length[m.entry];
+  const double rate = par[par_rates(R) + k];
+  double q[16];
+  const double bl = t*rate;
+  if (m.model == 0 /* JC69, locus.c:2342-2414 */)
+  {
+    double a = 1.0, b = 0.0;
+    if (!(bl < 1e-100))
+    {
+      a = (1 + 3*exp(-4*bl/3))/4;
+      b = (1 - a)/3;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q[i] = ((i >> 2) == (i & 3)) ? a : b;
+  }
+  else if (bl < 1e-100)
+    pmatrix_identity(q, 4);
+  else
+  {
+    const uint32_t mi = (uint32_t)par[par_param_idx(R) + k];
+    const double * pm = par + par_matrix(R, 4, mi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      pmatrix_eigen_row<4>(q + 4*j, j, t, rate, pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4), false);
+  }
+  double2 * dst = reinterpret_cast<double2 *>(m.dst + (size_t)k*16);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { double2 v; v.x = q[2*i]; v.y = q[2*i+1]; dst[i] = v; }
+}
+
+__device__ __forceinline__ void load_vec4(const TaskRec & T, const uint32_t clv_index, const uint32_t k,
+                                          const uint32_t n, double v[4])
+{
+  if (clv_index < T.tips_n)
+  {
+    const uint32_t code = T.tips[(size_t)clv_index*T.np + n];
+    v[0] = (code & 1u) ? 1.0 : 0.0;
+    v[1] = (code & 2u) ? 1.0 : 0.0;
+    v[2] = (code & 4u) ? 1.0 : 0.0;
+    v[3] = (code & 8u) ? 1.0 : 0.0;
+  }
+  else
+  {
+    const double2 * p = reinterpret_cast<const double2 *>(
+        T.clv + (((size_t)(clv_index - T.tips_n)*T.rate_cats + k)*T.np + n)*4);
+    const double2 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+  }
+}
+
+// RT > 0: compile-time rate-category count, parent CLVs forwarded in registers; RT == 0: runtime
+template <int BS, int RT>
+__global__ void __launch_bounds__(BS) step_s4_fused_kernel(const PlanDev P)
+{
+  __shared__ double s_term[BS];
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  const uint32_t gl = b*BS + lane;
+  // ---- loads that do not depend on phase A, issued first
+  const uint32_t t0 = P.blk_task_off[b], t1 = P.blk_task_off[b+1];
+  const uint32_t ro = P.lane_rec[gl];
+  const bool active = ro != 0xffffffffu;
+  TaskRec T{};
+  OpDev op0{}, op1{};
+  const uint4 * rp = P.recs + (active ? ro : 0u);
+  if (active)
+  {
+    uint4 * dst = reinterpret_cast<uint4 *>(&T);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(TaskRec)/16); ++i) dst[i] = rp[i];
+    // the first two node updates ride along with the header
+    uint4 * o0 = reinterpret_cast<uint4 *>(&op0), * o1 = reinterpret_cast<uint4 *>(&op1);
+    o0[0] = rp[6]; o0[1] = rp[7]; o1[0] = rp[8]; o1[1] = rp[9];
+  }
+  uint32_t sum_rec = 0xffffffffu;
+  if ((P.flags & 4u) && lane < t1 - t0) sum_rec = P.task_rec[t0 + lane];
+
+  // ---- phase A: P-matrices of this workgroup's loci
+  if (P.flags & 1u)
+  {
+    const uint32_t e0 = P.mat_off[t0], e1 = P.mat_off[t1];
+    if (RT == 1)
+    {
+      for (uint32_t e = e0 + lane; e < e1; e += BS) pmatrix_s4_rec(P.mat_recs[e], P.mat_length, 0);
+    }
+    else
+    {
+      const uint32_t rmax = RT ? (uint32_t)RT : P.pad;
+      const uint32_t cnt = (e1 - e0)*rmax;
+      for (uint32_t i = lane; i < cnt; i += BS)
+      {
+        const MatRec m = P.mat_recs[e0 + i/rmax];
+        const uint32_t k = i % rmax;
+        if (k < m.rate_cats) pmatrix_s4_rec(m, P.mat_length, k);
+      }
+    }
+    __syncthreads();
+  }
+  if (!(P.flags & 6u)) return;
+
+  // ---- phase B: node updates + root term of this lane's pattern
+  double term = 0;
+  if (active)
+  {
+    const uint32_t n = gl - T.lane0, np = T.np;
+    const uint32_t R = RT ? (uint32_t)RT : T.rate_cats;
+    constexpr int RF = RT ? RT : 1;
+    double fwd[RF][4];                // last parent CLV of this pattern (RT > 0 only)
+    uint32_t fwd_clv = 0xffffffffu;
+    if (P.flags & 2u)
+    {
+      for (uint32_t o = 0; o < T.nops; ++o)
+      {
+        OpDev op;
+        if (o == 0) op = op0;
+        else if (o == 1) op = op1;
+        else
+        {
+          uint4 * d = reinterpret_cast<uint4 *>(&op);
+          d[0] = rp[6 + 2*o]; d[1] = rp[7 + 2*o];
+        }
+        double * out = T.clv + (((size_t)(op.parent_clv - T.tips_n)*R)*np + n)*4;
+        bool all_small = true;
+        double res[RF][4];
+#pragma unroll
+        for (uint32_t k = 0; k < (RT ? (uint32_t)RT : R); ++k)
+        {
+          double lv[4], rv[4], x[4], y[4];
+          if (RT && op.left_clv == fwd_clv) { lv[0] = fwd[RT ? k : 0][0]; lv[1] = fwd[RT ? k : 0][1]; lv[2] = fwd[RT ? k : 0][2]; lv[3] = fwd[RT ? k : 0][3]; }
+          else load_vec4(T, op.left_clv, k, n, lv);
+          if (RT && op.right_clv == fwd_clv) { rv[0] = fwd[RT ? k : 0][0]; rv[1] = fwd[RT ? k : 0][1]; rv[2] = fwd[RT ? k : 0][2]; rv[3] = fwd[RT ? k : 0][3]; }
+          else load_vec4(T, op.right_clv, k, n, rv);
+          matvec4(T.pmat + ((size_t)op.left_pmatrix*R  + k)*16, lv, x);
+          matvec4(T.pmat + ((size_t)op.right_pmatrix*R + k)*16, rv, y);
+          double2 o0, o1;
+          o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
+          all_small = all_small && (o0.x < BPA_SCALE_THRESHOLD) && (o0.y < BPA_SCALE_THRESHOLD)
+                                && (o1.x < BPA_SCALE_THRESHOLD) && (o1.y < BPA_SCALE_THRESHOLD);
+          if (RT) { res[RT ? k : 0][0] = o0.x; res[RT ? k : 0][1] = o0.y; res[RT ? k : 0][2] = o1.x; res[RT ? k : 0][3] = o1.y; }
+          else
+          {
+            double2 * dst = reinterpret_cast<double2 *>(out + (size_t)k*np*4);
+            dst[0] = o0; dst[1] = o1;
+          }
+        }
+        bool rescale = false;
+        if (op.parent_scaler >= 0)
+        {
+          uint32_t s = 0;
+          if (op.left_scaler  >= 0) s += T.scaler[(size_t)op.left_scaler*np  + n];
+          if (op.right_scaler >= 0) s += T.scaler[(size_t)op.right_scaler*np + n];
+          if (all_small) { rescale = true; s += 1; }
+          T.scaler[(size_t)op.parent_scaler*np + n] = s;
+        }
+        if (RT)
+        {
+#pragma unroll
+          for (int k = 0; k < RF; ++k)
+          {
+            if (rescale) { res[k][0] *= BPA_SCALE_FACTOR; res[k][1] *= BPA_SCALE_FACTOR; res[k][2] *= BPA_SCALE_FACTOR; res[k][3] *= BPA_SCALE_FACTOR; }
+            double2 * dst = reinterpret_cast<double2 *>(out + (size_t)k*np*4);
+            double2 a, c; a.x = res[k][0]; a.y = res[k][1]; c.x = res[k][2]; c.y = res[k][3];
+            dst[0] = a; dst[1] = c;
+            fwd[k][0] = res[k][0]; fwd[k][1] = res[k][1]; fwd[k][2] = res[k][2]; fwd[k][3] = res[k][3];
+          }
+          fwd_clv = op.parent_clv;
+        }
+        else if (rescale)
+        {
+          for (uint32_t k = 0; k < R; ++k)
+          {
+            double2 * dst = reinterpret_cast<double2 *>(out + (size_t)k*np*4);
+            double2 a = dst[0], c = dst[1];
+            a.x *= BPA_SCALE_FACTOR; a.y *= BPA_SCALE_FACTOR; c.x *= BPA_SCALE_FACTOR; c.y *= BPA_SCALE_FACTOR;
+            dst[0] = a; dst[1] = c;
+          }
+        }
+      }
+    }
+    // K2 / K3 at the root (core_likelihood_avx.c:117-150, 251-275)
+    const double * par = T.par;
+#pragma unroll
+    for (uint32_t k = 0; k < (RT ? (uint32_t)RT : R); ++k)
+    {
+      double c[4];
+      if (RT && T.root_clv == fwd_clv) { c[0] = fwd[RT ? k : 0][0]; c[1] = fwd[RT ? k : 0][1]; c[2] = fwd[RT ? k : 0][2]; c[3] = fwd[RT ? k : 0][3]; }
+      else load_vec4(T, T.root_clv, k, n, c);
+      const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+      const double * f = par + par_matrix(R, 4, m) + pm_freqs(4);
+      const double tr = dot4_pair(f[0], f[1], f[2], f[3], c);
+      term += tr*par[par_rate_weights(R) + k];
+    }
+    if (!T.unphased_length)
+    {
+      double lt = log(term);
+      if (T.root_scaler >= 0)
+      {
+        const uint32_t sc = T.scaler[(size_t)T.root_scaler*np + n];
+        if (sc) lt += sc*BPA_LOG_SCALE_THRESHOLD;
+      }
+      term = lt*T.weights[n];
+    }
+    P.site_term[T.pat_off + n] = term;
+  }
+  if (!(P.flags & 4u)) return;
+
+  // ---- phase C: per-locus sum in pattern order
+  s_term[lane] = term;
+  __syncthreads();
+  if (sum_rec != 0xffffffffu)
+  {
+    const TaskRec * S = reinterpret_cast<const TaskRec *>(P.recs + sum_rec);
+    const uint32_t np = S->np, l0 = S->lane0 - b*BS;
+    double logl = 0;
+    if (S->unphased_length)
+      logl = reduce_locus(P.loci[S->locus], s_term + l0);
+    else
+      for (uint32_t n = 0; n < np; ++n) logl += s_term[l0 + n];
+    P.lnl[S->task] = P.bfbeta*logl;
+  }
 }
 
 // generic S: one lane per (branch, rate, row)

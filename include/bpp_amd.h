@@ -187,6 +187,8 @@ void         bpa_plan_destroy(bpa_plan_t *);
 int          bpa_plan_set_lengths(bpa_plan_t *, const double * mat_length);
 /* enqueue the step on the engine's stream; results stay on the device             */
 int          bpa_plan_launch(bpa_plan_t *);
+/* enqueue several steps back to back (one host call)                               */
+int          bpa_plans_launch(bpa_plan_t * const * plans, unsigned count);
 /* copy the nloci log-likelihoods of the last launch to the host (synchronises)    */
 int          bpa_plan_get_lnl(bpa_plan_t *, double * lnl);
 /* device address of the nloci log-likelihoods / of their sum (double)             */
