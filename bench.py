@@ -32,6 +32,8 @@ CONFIGS = {
                name="C2: A00, 10000 loci x 1000 sites, 4 taxa, JC69, 1 rate cat"),
     "c3": dict(taxa=8, model="gtr", rate_cats=4, sites=1000, loci=10000, taus=(0.0011, 0.0025, 0.005),
                name="C3: A00, 10000 loci x 1000 sites, 8 taxa, GTR+G4"),
+    "c4": dict(taxa=6, model="lg", rate_cats=4, sites=500, loci=2000, taus=(0.01, 0.015, 0.02, 0.035, 0.05),
+               name="C4: A00, 2000 loci x 500 aa sites, 6 taxa, LG+G4"),
 }
 
 
@@ -128,8 +130,9 @@ def main():
         S, R = d["states"], d["rate_cats"]
         tips, sites = len(d["seqs"]), len(d["seqs"][0])
         inner, edges = tips - 1, 2 * tips - 2
-        mdl = {"jc69": bpp_amd.MODEL_JC69, "gtr": bpp_amd.MODEL_GTR}[d["model"]]
-        loc = bpp_amd.Locus(eng, bpp_amd.DATA_DNA, mdl, tips, 2 * inner, S, sites, 1, 2 * edges, R, 0)
+        mdl = {"jc69": bpp_amd.MODEL_JC69, "gtr": bpp_amd.MODEL_GTR, "lg": bpp_amd.MODEL_LG}[d["model"]]
+        loc = bpp_amd.Locus(eng, bpp_amd.DATA_DNA if S == 4 else bpp_amd.DATA_AA, mdl, tips, 2 * inner, S,
+                            sites, 1, 2 * edges, R, 0)
         for i, s in enumerate(d["seqs"]):
             loc.set_tip_states(i, s)
         loc.set_pattern_weights(d["weights"])
@@ -227,9 +230,10 @@ def main():
     if tm and tm["launches"]:
         kernel_ms = tm["partials_ms"] / tm["launches"]
         # the fused step kernel does K4 (P-matrix writes) + K1 + K2: algorithmic bytes of all three
-        bytes_per_launch = (it_bytes_partials + it_bytes_pmatrix) / launches_per_iter
+        fused = cfg["model"] != "lg"
+        bytes_per_launch = (it_bytes_partials + (it_bytes_pmatrix if fused else 0)) / launches_per_iter
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        roofline = dict(bound="hbm", kernel="step_s4_fused_kernel<64,1>", achieved=round(achieved, 2),
+        roofline = dict(bound="hbm", kernel=("step_s4_fused_kernel" if cfg["model"] != "lg" else "partials_lnl_tiled_kernel<20,128>"), achieved=round(achieved, 2),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
                         traffic=None, avg_kernel_us=round(1e3 * kernel_ms, 3),
                         algorithmic_bytes_per_launch=round(bytes_per_launch),
@@ -262,6 +266,8 @@ def main():
             "site_lnl_updates_per_s": round(site_lnl_updates_per_s),
             "node_updates_per_iteration": round(float(it_node_updates)),
             "gflops_partials": round(it_flops * args.steps / elapsed / 1e9, 2),
+            "kernel_tflops": (round(it_flops / launches_per_iter / (tm["partials_ms"] / tm["launches"] * 1e-3) / 1e12, 3)
+                              if tm and tm["launches"] else None),
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -116,6 +116,9 @@ struct PlanDev
   const uint4 *    recs;        // TaskRec records
   const MatRec *   mat_recs;    // [M]
   const uint32_t * task_rec;    // [T] record offset of task t
+  // tiled path (20 states): workgroup b owns patterns tile_n0[b] .. +TILE of task tile_task[b]
+  const uint32_t * tile_task;   // [NT]
+  const uint32_t * tile_n0;     // [NT]
   uint32_t         nblocks;     // B (0: fused path not available)
   uint32_t         flags;       // bit0: compute P-matrices, bit1: node updates + site terms, bit2: per-locus lnL
   uint32_t         ntasks;

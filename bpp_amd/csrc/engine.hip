@@ -127,6 +127,8 @@ struct bpa_plan
   DevBuf<uint32_t> task_locus, task_pat_off, thr_task, mat_off, mat_task, mat_pmatrix, op_off, root_clv;
   DevBuf<uint32_t> blk_task_off, lane_task, task_lane0, lane_rec, task_rec;
   DevBuf<uint4>    recs;
+  DevBuf<uint32_t> tile_task, tile_n0;
+  unsigned ntiles = 0;                // tiled 20-state path
   DevBuf<MatRec>   mat_recs;
   unsigned fused_rt = 0;              // compile-time rate-category count of the fused kernel (0 = runtime)
   unsigned fused_bs = 0;              // workgroup size of the fused single-launch path (0 = not available)
@@ -142,7 +144,7 @@ struct bpa_plan
     task_locus.free(); task_pat_off.free(); thr_task.free(); mat_off.free(); mat_task.free();
     mat_pmatrix.free(); op_off.free(); root_clv.free(); root_scaler.free(); mat_length.free();
     site_term.free(); lnl.free(); ops.free(); lnl_sum.free();
-    blk_task_off.free(); lane_task.free(); task_lane0.free(); lane_rec.free(); task_rec.free(); recs.free(); mat_recs.free();
+    blk_task_off.free(); lane_task.free(); task_lane0.free(); lane_rec.free(); task_rec.free(); recs.free(); mat_recs.free(); tile_task.free(); tile_n0.free();
   }
   ~bpa_plan() { free_all(); }
 };
@@ -530,6 +532,18 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   p->has_mats = nmat > 0;
   p->has_lnl = b->root_clv != nullptr;
 
+  // tiled path (20 states): one workgroup per 128-pattern tile of one locus
+  p->ntiles = 0; d.tile_task = d.tile_n0 = nullptr;
+  if (p->states == 20)
+  {
+    std::vector<uint32_t> tt, tn;
+    for (unsigned t = 0; t < T; ++t)
+      for (unsigned n0 = 0; n0 < b->loci[t]->sites; n0 += 128) { tt.push_back(t); tn.push_back(n0); }
+    if (!upload(p->tile_task, tt.data(), tt.size()) || !upload(p->tile_n0, tn.data(), tn.size())) return 0;
+    d.tile_task = p->tile_task.p; d.tile_n0 = p->tile_n0.p;
+    p->ntiles = (unsigned)tt.size();
+  }
+
   // fused single-launch path: pack whole loci into workgroups (4-state loci that fit one)
   p->fused_bs = 0; d.nblocks = 0; d.flags = 0;
   d.blk_task_off = d.lane_task = d.task_lane0 = nullptr;
@@ -701,6 +715,12 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     const unsigned blocks = (d.npatterns + BPA_BLOCK - 1)/BPA_BLOCK;
     if (p->states == 4)
       hipLaunchKernelGGL(partials_lnl_s4_kernel, dim3(blocks), dim3(BPA_BLOCK), 0, e->stream, d);
+    else if (p->ntiles && !getenv("BPA_S20_GENERIC"))
+    {
+      d.flags = 4u;                                      // always produce the site terms
+      const size_t lds = (size_t)2*p->rmax*400*sizeof(double);
+      hipLaunchKernelGGL((partials_lnl_tiled_kernel<20, 128>), dim3(p->ntiles), dim3(128), lds, e->stream, d);
+    }
     else
       hipLaunchKernelGGL(partials_lnl_sN_kernel<20>, dim3(blocks), dim3(BPA_BLOCK), 0, e->stream, d);
     HIPCHK(hipGetLastError());

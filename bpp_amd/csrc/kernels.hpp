@@ -270,6 +270,104 @@ __global__ void __launch_bounds__(BPA_BLOCK) partials_lnl_sN_kernel(const PlanDe
   }
 }
 
+// ============================================== K1+K2, 20 states, LDS-staged P ==
+// One workgroup = one tile of TILE consecutive patterns of ONE locus; one lane = one
+// pattern.  For every node update the two children's P-matrices (R x 20 x 20 each) are
+// staged once per workgroup into LDS with coalesced loads and then read by all lanes at
+// the same address (LDS broadcast, conflict-free), so the inner loop is
+// v_fma_f64(P from LDS, child CLV in registers): FP64 VALU at LDS-broadcast rate, no
+// per-lane P traffic to L1/L2.  Child CLVs come from state-major planes (lanes =
+// consecutive patterns: coalesced 8 B/lane).  Summation order = the reference's AVX2
+// back-end (four FMA lane accumulators, core_partials_avx2.c:666-745): bit-identical CLVs.
+template <int S, int TILE>
+__global__ void __launch_bounds__(TILE) partials_lnl_tiled_kernel(const PlanDev P)
+{
+  extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2][R][S][S]
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  const uint32_t t = P.tile_task[b];
+  const uint32_t n = P.tile_n0[b] + lane;
+  const LocusDev L = P.loci[P.task_locus[t]];
+  const uint32_t R = L.rate_cats, np = L.np;
+  const bool active = n < np;
+  constexpr uint32_t SS = S*S;
+
+  const uint32_t op_end = P.op_off[t+1];
+  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
+  {
+    const OpDev op = P.ops[o];
+    __syncthreads();                                   // previous update's LDS reads are done
+    {
+      const double2 * gl = reinterpret_cast<const double2 *>(L.pmat + (size_t)op.left_pmatrix*R*SS);
+      const double2 * gr = reinterpret_cast<const double2 *>(L.pmat + (size_t)op.right_pmatrix*R*SS);
+      double2 * sl = reinterpret_cast<double2 *>(s_p);
+      double2 * sr = reinterpret_cast<double2 *>(s_p + (size_t)R*SS);
+      for (uint32_t i = lane; i < R*SS/2; i += TILE) { sl[i] = gl[i]; sr[i] = gr[i]; }
+    }
+    __syncthreads();
+    if (active)
+    {
+      double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*np + n;
+      bool all_small = true;
+      for (uint32_t k = 0; k < R; ++k)
+      {
+        double lv[S], rv[S];
+        load_childN<S, uint32_t>(L, op.left_clv,  k, n, lv);
+        load_childN<S, uint32_t>(L, op.right_clv, k, n, rv);
+        const double * lm = s_p + (size_t)k*SS;
+        const double * rm = s_p + (size_t)(R + k)*SS;
+        double * dst = out + (size_t)k*S*np;
+#pragma unroll 4
+        for (int i = 0; i < S; ++i)
+        {
+          const double x = dot_fma4<S>(lm + i*S, lv);
+          const double y = dot_fma4<S>(rm + i*S, rv);
+          const double v = x*y;
+          all_small = all_small && (v < BPA_SCALE_THRESHOLD);
+          dst[(size_t)i*np] = v;
+        }
+      }
+      if (op.parent_scaler >= 0)
+      {
+        uint32_t s = 0;
+        if (op.left_scaler  >= 0) s += L.scaler[(size_t)op.left_scaler*np  + n];
+        if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + n];
+        if (all_small)
+        {
+          for (uint32_t e = 0; e < R*S; ++e) out[(size_t)e*np] *= BPA_SCALE_FACTOR;
+          s += 1;
+        }
+        L.scaler[(size_t)op.parent_scaler*np + n] = s;
+      }
+    }
+  }
+  if (!active || !(P.flags & 4u)) return;
+
+  // K2 / K3 (core_likelihood_avx2.c:45-87)
+  const uint32_t root = P.root_clv[t];
+  const double * par = L.par;
+  double term = 0;
+  for (uint32_t k = 0; k < R; ++k)
+  {
+    double c[S];
+    load_childN<S, uint32_t>(L, root, k, n, c);
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+    const double tr = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
+    term = __builtin_fma(tr, par[par_rate_weights(R) + k], term);
+  }
+  if (!L.unphased_length)
+  {
+    double lt = log(term);
+    const int32_t rs = P.root_scaler[t];
+    if (rs >= 0)
+    {
+      const uint32_t sc = L.scaler[(size_t)rs*np + n];
+      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
+    }
+    term = lt*L.weights[n];
+  }
+  P.site_term[P.task_pat_off[t] + n] = term;
+}
+
 // ====================================================== per-locus lnL reduction ==
 // Sum of the per-pattern terms in pattern order (core_likelihood.c:206-210); the
 // diploid branch averages the phase resolutions first (locus.c:2600-2614).

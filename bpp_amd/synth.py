@@ -121,6 +121,15 @@ def _evolve(left, right, times, root, sites, rng, freqs, Q, site_rate):
     return states
 
 
+def lg_model():
+    """(exchangeabilities[190], frequencies[20]) of the LG model (data table)"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "lg_model.json")) as f:
+        g = json.load(f)
+    return np.array(g["rates"]), np.array(g["freqs"])
+
+
 def make_dataset(nloci, sites, taxa=4, model="jc69", rate_cats=1, alpha=0.5, theta=None, seed=12345,
                  freqs=None, exch=None):
     """returns a list of loci: dict(seqs (compressed), weights, left, right, times, root, ...)"""
@@ -136,7 +145,8 @@ def make_dataset(nloci, sites, taxa=4, model="jc69", rate_cats=1, alpha=0.5, the
         freqs = np.array([0.3, 0.2, 0.2, 0.3]) if freqs is None else np.asarray(freqs)
         exch = np.array([1, 2, 1, 0.5, 1.5, 1.0]) if exch is None else np.asarray(exch)
     else:
-        assert freqs is not None and exch is not None, "amino-acid model needs freqs + exchangeabilities"
+        if freqs is None or exch is None:
+            exch, freqs = lg_model()
         freqs, exch = np.asarray(freqs), np.asarray(exch)
     Q = _q_matrix(freqs, exch)
     rates = _discrete_gamma(alpha, rate_cats)
