@@ -233,13 +233,28 @@ def main():
         fused = cfg["model"] != "lg"
         bytes_per_launch = (it_bytes_partials + (it_bytes_pmatrix if fused else 0)) / launches_per_iter
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        roofline = dict(bound="hbm", kernel=("step_s4_fused_kernel" if cfg["model"] != "lg" else "partials_lnl_tiled_kernel<20,128>"), achieved=round(achieved, 2),
+        roofline = dict(bound="hbm", kernel=("step_jc69_kernel<64>" if cfg["model"] == "jc69" else "step_s4_fused_kernel<64,4>" if cfg["model"] != "lg" else "partials_lnl_tiled_kernel<20,128>"), achieved=round(achieved, 2),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
                         traffic=None, avg_kernel_us=round(1e3 * kernel_ms, 3),
                         algorithmic_bytes_per_launch=round(bytes_per_launch),
                         launches=tm["launches"],
                         timing="hipExtLaunchKernelGGL start/stop events on the engine stream, every launch of the timed region",
-                        note="working set (~30 MB) is cache-resident: latency/launch bound, not HBM bound (SURVEY §7)")
+                        note=("52k lanes per launch: latency/launch bound (4.2 us empty-grid floor), not HBM bound (SURVEY §7)"
+                              if args.config == "c2" else None))
+
+    # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (collected by
+    # tools/profile_c2.sh on this same command): 2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md
+    # §HBM) + WRITE_SIZE, both reported in KB
+    if roofline is not None and args.config == "c2":
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "c2_pmc_hbm_bytes.json")))
+            pm = json.load(open(cands[-1]))
+            key = [k for k in pm["FETCH_SIZE"] if "step_" in k][0]
+            roofline["traffic"] = round((2 * pm["FETCH_SIZE"][key]["mean_KB"] + pm["WRITE_SIZE"][key]["mean_KB"]) * 1024)
+            roofline["traffic_source"] = os.path.relpath(cands[-1], ROOT) + " (separate --pmc passes; FETCH_SIZE doubled per the gfx950 note)"
+        except Exception:
+            pass
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:

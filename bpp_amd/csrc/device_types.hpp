@@ -119,6 +119,7 @@ struct PlanDev
   // tiled path (20 states): workgroup b owns patterns tile_n0[b] .. +TILE of task tile_task[b]
   const uint32_t * tile_task;   // [NT]
   const uint32_t * tile_n0;     // [NT]
+  unsigned long long * dbg;     // optional per-workgroup timestamps (profiling aid, normally null)
   uint32_t         nblocks;     // B (0: fused path not available)
   uint32_t         flags;       // bit0: compute P-matrices, bit1: node updates + site terms, bit2: per-locus lnL
   uint32_t         ntasks;

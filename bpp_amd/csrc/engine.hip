@@ -128,8 +128,10 @@ struct bpa_plan
   DevBuf<uint32_t> blk_task_off, lane_task, task_lane0, lane_rec, task_rec;
   DevBuf<uint4>    recs;
   DevBuf<uint32_t> tile_task, tile_n0;
+  DevBuf<unsigned long long> dbg;
   unsigned ntiles = 0;                // tiled 20-state path
   DevBuf<MatRec>   mat_recs;
+  bool fused_jc69 = false;            // JC69, one rate category: the latency-optimised kernel
   unsigned fused_rt = 0;              // compile-time rate-category count of the fused kernel (0 = runtime)
   unsigned fused_bs = 0;              // workgroup size of the fused single-launch path (0 = not available)
   DevBuf<int32_t>  root_scaler;
@@ -528,6 +530,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   d.mat_off = p->mat_off.p; d.mat_task = p->mat_task.p; d.mat_pmatrix = p->mat_pmatrix.p;
   d.mat_length = p->mat_length.p; d.op_off = p->op_off.p; d.ops = p->ops.p;
   d.root_clv = p->root_clv.p; d.root_scaler = p->root_scaler.p; d.site_term = p->site_term.p;
+  d.dbg = nullptr;
   d.lnl = p->lnl.p; d.ntasks = T; d.npatterns = P; d.nmat = nmat; d.pad = 0;
   p->has_mats = nmat > 0;
   p->has_lnl = b->root_clv != nullptr;
@@ -581,7 +584,8 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
     std::vector<uint4> recs;
     std::vector<uint32_t> task_rec(T), lane_rec(lane_task.size(), 0xffffffffu);
     std::vector<MatRec> mrecs(nmat);
-    bool all1 = true, all4 = true;
+    static_assert(sizeof(OpSlot) == 48, "op slot layout");
+    bool all1 = true, all4 = true, all_jc = true;
     for (unsigned t = 0; t < T; ++t)
     {
       const bpa_locus * l = b->loci[t];
@@ -594,10 +598,26 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
       r.nops = nops_t; r.root_clv = rc[t]; r.root_scaler = rs[t]; r.task = t;
       r.unphased_length = l->dev.unphased_length; r.pat_off = pat_off[t]; r.locus = l->id; r.pad = 0;
       task_rec[t] = (uint32_t)recs.size();
-      const size_t units = 6 + 2*std::max(nops_t, 2u);
+      // 48-byte op slots: the update + for each child the entry of this step's branch-length
+      // list when that child's P-matrix is updated in this very step (-1 otherwise); at least
+      // three slots so the eager loads of the first three stay in bounds
+      const size_t units = 6 + 3*std::max(nops_t, 3u);
       recs.resize(recs.size() + units, uint4{0, 0, 0, 0});
       std::memcpy(&recs[task_rec[t]], &r, sizeof(r));
-      if (nops_t) std::memcpy(&recs[task_rec[t] + 6], b->ops + b->op_off[t], nops_t*sizeof(OpDev));
+      for (unsigned o = 0; o < nops_t; ++o)
+      {
+        OpSlot sl{};
+        std::memcpy(&sl.op, b->ops + b->op_off[t] + o, sizeof(OpDev));
+        sl.left_e = sl.right_e = -1;
+        if (b->mat_off)
+          for (unsigned i = b->mat_off[t]; i < b->mat_off[t+1]; ++i)
+          {
+            if (b->mat_pmatrix[i] == sl.op.left_pmatrix)  sl.left_e = (int32_t)i;
+            if (b->mat_pmatrix[i] == sl.op.right_pmatrix) sl.right_e = (int32_t)i;
+          }
+        std::memcpy(&recs[task_rec[t] + 6 + 3*o], &sl, sizeof(sl));
+      }
+      all_jc = all_jc && l->dev.model == 0;
       for (unsigned n = 0; n < l->sites; ++n) lane_rec[lane0[t] + n] = task_rec[t];
       if (b->mat_off)
         for (unsigned i = b->mat_off[t]; i < b->mat_off[t+1]; ++i)
@@ -613,6 +633,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
     if (!upload(p->mat_recs, mrecs.data(), nmat)) return 0;
     d.recs = p->recs.p; d.lane_rec = p->lane_rec.p; d.task_rec = p->task_rec.p; d.mat_recs = p->mat_recs.p;
     p->fused_rt = all1 ? 1 : (all4 ? 4 : 0);
+    p->fused_jc69 = all1 && all_jc && !getenv("BPA_NO_JC69_FAST");
     d.pad = p->rmax;
   }
 
@@ -675,7 +696,12 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     hipEvent_t k0 = ts ? ts->ev[1] : nullptr, k1 = ts ? ts->ev[2] : nullptr;
     const dim3 grid(d.nblocks);
 #define BPA_FUSED(BS_, RT_) hipExtLaunchKernelGGL((step_s4_fused_kernel<BS_, RT_>), grid, dim3(BS_), 0, e->stream, k0, k1, 0, d)
-    if (p->fused_bs == 64)
+    if (p->fused_jc69)
+    {
+      if (p->fused_bs == 64) hipExtLaunchKernelGGL((step_jc69_kernel<64>), grid, dim3(64), 0, e->stream, k0, k1, 0, d);
+      else                   hipExtLaunchKernelGGL((step_jc69_kernel<256>), grid, dim3(256), 0, e->stream, k0, k1, 0, d);
+    }
+    else if (p->fused_bs == 64)
     {
       if (p->fused_rt == 1) BPA_FUSED(64, 1); else if (p->fused_rt == 4) BPA_FUSED(64, 4); else BPA_FUSED(64, 0);
     }
@@ -768,6 +794,34 @@ extern "C" int bpa_plan_launch(bpa_plan_t * p)
 {
   if (!p->eng->usedata) return 1;                 // opt_usedata == 0 (locus.c:2424)
   return plan_launch_mode(p, 1 | 2 | (p->has_lnl ? 4 : 0));
+}
+
+// profiling aid (tools/): per-workgroup wall-clock stamps of the fused JC69 kernel.
+// out[0..7]: mean over workgroups of (stamp i - earliest stamp 0) in microseconds; out[8]: span
+extern "C" int bpa_plan_probe(bpa_plan_t * p, double * out)
+{
+  bpa_engine * e = p->eng;
+  if (!set_device(e) || !p->fused_bs) return fail("probe: fused plans only");
+  const unsigned B = p->pd.nblocks;
+  if (!p->dbg.reserve((size_t)B*8)) return fail("oom");
+  HIPCHK(hipMemset(p->dbg.p, 0, (size_t)B*8*8));
+  p->pd.dbg = p->dbg.p;
+  int ok = bpa_plan_launch(p);
+  p->pd.dbg = nullptr;
+  if (!ok) return 0;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  std::vector<unsigned long long> h((size_t)B*8);
+  HIPCHK(hipMemcpy(h.data(), p->dbg.p, h.size()*8, hipMemcpyDeviceToHost));
+  unsigned long long first = ~0ull, last = 0;
+  for (unsigned b = 0; b < B; ++b) { first = std::min(first, h[b*8]); for (int i = 0; i < 8; ++i) last = std::max(last, h[b*8+i]); }
+  for (int i = 0; i < 8; ++i)
+  {
+    double acc = 0; unsigned cnt = 0;
+    for (unsigned b = 0; b < B; ++b) if (h[b*8+i]) { acc += (double)(h[b*8+i] - first)*0.01; ++cnt; }
+    out[i] = cnt ? acc/cnt : -1;
+  }
+  out[8] = (double)(last - first)*0.01;
+  return 1;
 }
 
 extern "C" int bpa_plans_launch(bpa_plan_t * const * plans, unsigned count)

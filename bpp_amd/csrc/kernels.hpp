@@ -34,6 +34,9 @@
 
 static constexpr int BPA_BLOCK = 256;
 
+// profiling aid: drain outstanding memory ops, then stamp the 100-MHz wall clock
+#define BPA_STAMP(P, b, lane, i) do { if ((P).dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if ((lane) == 0) (P).dbg[(size_t)(b)*8 + (i)] = wall_clock64(); } } while (0)
+
 // ------------------------------------------------------------------ helpers --
 __device__ __forceinline__ double dot4_pair(const double m0, const double m1, const double m2,
                                             const double m3, const double * v)
@@ -590,7 +593,7 @@ __global__ void __launch_bounds__(BS) step_s4_fused_kernel(const PlanDev P)
     for (int i = 0; i < (int)(sizeof(TaskRec)/16); ++i) dst[i] = rp[i];
     // the first two node updates ride along with the header
     uint4 * o0 = reinterpret_cast<uint4 *>(&op0), * o1 = reinterpret_cast<uint4 *>(&op1);
-    o0[0] = rp[6]; o0[1] = rp[7]; o1[0] = rp[8]; o1[1] = rp[9];
+    o0[0] = rp[6]; o0[1] = rp[7]; o1[0] = rp[9]; o1[1] = rp[10];      // 48-byte op slots
   }
   uint32_t sum_rec = 0xffffffffu;
   if ((P.flags & 4u) && lane < t1 - t0) sum_rec = P.task_rec[t0 + lane];
@@ -637,7 +640,7 @@ __global__ void __launch_bounds__(BS) step_s4_fused_kernel(const PlanDev P)
         else
         {
           uint4 * d = reinterpret_cast<uint4 *>(&op);
-          d[0] = rp[6 + 2*o]; d[1] = rp[7 + 2*o];
+          d[0] = rp[6 + 3*o]; d[1] = rp[7 + 3*o];
         }
         double * out = T.clv + (((size_t)(op.parent_clv - T.tips_n)*R)*np + n)*4;
         bool all_small = true;
@@ -738,6 +741,297 @@ __global__ void __launch_bounds__(BS) step_s4_fused_kernel(const PlanDev P)
       for (uint32_t n = 0; n < np; ++n) logl += s_term[l0 + n];
     P.lnl[S->task] = P.bfbeta*logl;
   }
+}
+
+// ============================================ fused proposal step, JC69, R = 1 ==
+// Configs 1/2/5 (JC69, one rate category, a handful of patterns per locus) are pure
+// latency: what matters is the length of one lane's dependent-load chain.  Under JC69 a
+// P-matrix is two numbers, a (diagonal) and b, so the lanes that need a branch updated in
+// this very step compute (a, b) themselves from the branch length carried in the op slot
+// (locus.c:2342-2414, same expression => same bits) instead of waiting for phase A and a
+// workgroup barrier; matrices not touched in this step are read back as their (a, b) pair
+// (16 B instead of 128).  All inputs of the first three node updates that do not depend on
+// an earlier update of the step are loaded up front, in one wave of requests; the updates
+// then run out of registers (results forwarded).  The full 4x4 matrices are still written
+// to HBM for later steps, off the critical path, at the end of the kernel.  Arithmetic is
+// the same mat-vec on the same 16 values in the same order: CLVs stay bit-identical.
+struct OpSlot { OpDev op; int32_t left_e, right_e, pad0, pad1; };   // 48 B; *_e: entry of mat_length[] when the child's
+                                                                    // P-matrix is updated in this very step, else -1
+
+__device__ __forceinline__ void jc69_ab(const double len, const double rate, double & a, double & b)
+{
+  const double bl = len*rate;
+  a = 1.0; b = 0.0;
+  if (!(bl < 1e-100))
+  {
+    a = (1 + 3*exp(-4*bl/3))/4;
+    b = (1 - a)/3;
+  }
+}
+
+__device__ __forceinline__ void matvec4_ab(const double a, const double b, const double v[4], double x[4])
+{
+  // rows (a b b b), (b a b b), (b b a b), (b b b a) in the AVX order (p0+p1)+(p2+p3)
+  x[0] = dot4_pair(a, b, b, b, v);
+  x[1] = dot4_pair(b, a, b, b, v);
+  x[2] = dot4_pair(b, b, a, b, v);
+  x[3] = dot4_pair(b, b, b, a, v);
+}
+
+__device__ __forceinline__ void expand_code(const uint32_t code, double v[4])
+{
+  v[0] = (code & 1u) ? 1.0 : 0.0; v[1] = (code & 2u) ? 1.0 : 0.0;
+  v[2] = (code & 4u) ? 1.0 : 0.0; v[3] = (code & 8u) ? 1.0 : 0.0;
+}
+
+template <int BS>
+__global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
+{
+  constexpr int NPRE = 3;                       // node updates whose inputs are preloaded
+  __shared__ double s_term[BS];
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  const uint32_t gl = b*BS + lane;
+  BPA_STAMP(P, b, lane, 0);
+  const uint32_t t0 = P.blk_task_off[b], t1 = P.blk_task_off[b+1];
+  const uint32_t ro = P.lane_rec[gl];
+  const bool active = ro != 0xffffffffu;
+  BPA_STAMP(P, b, lane, 1);
+  // the tail's first P-matrix record (K4), requested now
+  const bool do_mats = (P.flags & 1u) != 0;
+  const uint32_t e0 = do_mats ? P.mat_off[t0] : 0u, e1 = do_mats ? P.mat_off[t1] : 0u;
+  MatRec m0{};
+  double m0_len = 0, m0_rate = 0;
+  const bool have_m0 = e0 + lane < e1;
+  if (have_m0)
+  {
+    const uint4 * mp = reinterpret_cast<const uint4 *>(P.mat_recs + e0 + lane);
+    uint4 * md = reinterpret_cast<uint4 *>(&m0);
+    md[0] = mp[0]; md[1] = mp[1];
+    m0_len = P.mat_length[e0 + lane];          // entry == its own index
+  }
+  // phase C bookkeeping, fetched now so that it has long arrived when needed
+  uint32_t c_np = 0, c_l0 = 0, c_task = 0, c_unph = 0, c_locus = 0;
+  const bool summer = (P.flags & 4u) && lane < t1 - t0;
+  if (summer)
+  {
+    const TaskRec * S = reinterpret_cast<const TaskRec *>(P.recs + P.task_rec[t0 + lane]);
+    c_np = S->np; c_l0 = S->lane0 - b*BS; c_task = S->task; c_unph = S->unphased_length; c_locus = S->locus;
+  }
+
+  if (have_m0) m0_rate = m0.par[par_rates(1)];
+
+  double term = 0;
+  if (active && (P.flags & 6u))
+  {
+    const uint4 * rp = P.recs + ro;
+    TaskRec T;
+    OpSlot sl[NPRE];
+    {
+      uint4 * dst = reinterpret_cast<uint4 *>(&T);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dst[i] = rp[i];
+      uint4 * ds = reinterpret_cast<uint4 *>(sl);
+#pragma unroll
+      for (int i = 0; i < 3*NPRE; ++i) ds[i] = rp[6 + i];
+    }
+    BPA_STAMP(P, b, lane, 2);
+    const uint32_t n = gl - T.lane0, np = T.np, tips = T.tips_n;
+    const uint32_t nops = (P.flags & 2u) ? T.nops : 0u;
+    const double * par = T.par;
+
+    // ---- one wave of independent input loads
+    const double rate = par[par_rates(1)];
+    const double rw = par[par_rate_weights(1)];
+    const double2 f01 = *reinterpret_cast<const double2 *>(par + par_matrix(1, 4, 0) + pm_freqs(4));   // param_idx 0 (R = 1)
+    const double2 f23 = *reinterpret_cast<const double2 *>(par + par_matrix(1, 4, 0) + pm_freqs(4) + 2);
+    const uint32_t wgt = T.weights[n];
+    double inl[NPRE][4], inr[NPRE][4];          // child vectors (tips expanded / inner from HBM)
+    double abl[NPRE][2], abr[NPRE][2];          // (a, b) of the two branches
+    uint32_t fwl[NPRE], fwr[NPRE];              // 0..NPRE-1: forwarded from that earlier update; 0xff: in inl/inr
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i)
+    {
+      fwl[i] = fwr[i] = 0xffu;
+      if ((uint32_t)i < nops)
+      {
+        const OpDev & op = sl[i].op;
+#pragma unroll
+        for (int j = 0; j < i; ++j)
+        {
+          if (sl[j].op.parent_clv == op.left_clv)  fwl[i] = j;
+          if (sl[j].op.parent_clv == op.right_clv) fwr[i] = j;
+        }
+        if (fwl[i] == 0xffu)
+        {
+          if (op.left_clv < tips) expand_code(T.tips[(size_t)op.left_clv*np + n], inl[i]);
+          else
+          {
+            const double2 * p = reinterpret_cast<const double2 *>(T.clv + ((size_t)(op.left_clv - tips)*np + n)*4);
+            const double2 u = p[0], w = p[1];
+            inl[i][0] = u.x; inl[i][1] = u.y; inl[i][2] = w.x; inl[i][3] = w.y;
+          }
+        }
+        if (fwr[i] == 0xffu)
+        {
+          if (op.right_clv < tips) expand_code(T.tips[(size_t)op.right_clv*np + n], inr[i]);
+          else
+          {
+            const double2 * p = reinterpret_cast<const double2 *>(T.clv + ((size_t)(op.right_clv - tips)*np + n)*4);
+            const double2 u = p[0], w = p[1];
+            inr[i][0] = u.x; inr[i][1] = u.y; inr[i][2] = w.x; inr[i][3] = w.y;
+          }
+        }
+        // abl/abr hold either the stored (a, b) pair or, in [0], the fresh branch length
+        if (sl[i].left_e < 0)
+        {
+          const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.left_pmatrix*16);
+          abl[i][0] = ab.x; abl[i][1] = ab.y;
+        }
+        else abl[i][0] = P.mat_length[sl[i].left_e];
+        if (sl[i].right_e < 0)
+        {
+          const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.right_pmatrix*16);
+          abr[i][0] = ab.x; abr[i][1] = ab.y;
+        }
+        else abr[i][0] = P.mat_length[sl[i].right_e];
+      }
+    }
+
+    BPA_STAMP(P, b, lane, 3);
+    // ---- node updates out of registers
+    double res[NPRE][4];
+    uint32_t last_clv = 0xffffffffu;
+    double last[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i)
+    {
+      if ((uint32_t)i < nops)
+      {
+        const OpDev & op = sl[i].op;
+        double lv[4], rv[4], x[4], y[4], al, bl_, ar, br;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+          lv[q] = inl[i][q]; rv[q] = inr[i][q];
+#pragma unroll
+          for (int j = 0; j < i; ++j)
+          {
+            if (fwl[i] == (uint32_t)j) lv[q] = res[j][q];
+            if (fwr[i] == (uint32_t)j) rv[q] = res[j][q];
+          }
+        }
+        if (sl[i].left_e < 0)  { al = abl[i][0]; bl_ = abl[i][1]; } else jc69_ab(abl[i][0], rate, al, bl_);
+        if (sl[i].right_e < 0) { ar = abr[i][0]; br = abr[i][1]; } else jc69_ab(abr[i][0], rate, ar, br);
+        matvec4_ab(al, bl_, lv, x);
+        matvec4_ab(ar, br, rv, y);
+        res[i][0] = x[0]*y[0]; res[i][1] = x[1]*y[1]; res[i][2] = x[2]*y[2]; res[i][3] = x[3]*y[3];
+        if (op.parent_scaler >= 0)
+        {
+          uint32_t s = 0;
+          if (op.left_scaler  >= 0) s += T.scaler[(size_t)op.left_scaler*np  + n];
+          if (op.right_scaler >= 0) s += T.scaler[(size_t)op.right_scaler*np + n];
+          if (res[i][0] < BPA_SCALE_THRESHOLD && res[i][1] < BPA_SCALE_THRESHOLD &&
+              res[i][2] < BPA_SCALE_THRESHOLD && res[i][3] < BPA_SCALE_THRESHOLD)
+          {
+            res[i][0] *= BPA_SCALE_FACTOR; res[i][1] *= BPA_SCALE_FACTOR; res[i][2] *= BPA_SCALE_FACTOR; res[i][3] *= BPA_SCALE_FACTOR;
+            s += 1;
+          }
+          T.scaler[(size_t)op.parent_scaler*np + n] = s;
+        }
+        double2 * dst = reinterpret_cast<double2 *>(T.clv + ((size_t)(op.parent_clv - tips)*np + n)*4);
+        double2 u, w; u.x = res[i][0]; u.y = res[i][1]; w.x = res[i][2]; w.y = res[i][3];
+        dst[0] = u; dst[1] = w;
+        last_clv = op.parent_clv;
+        last[0] = res[i][0]; last[1] = res[i][1]; last[2] = res[i][2]; last[3] = res[i][3];
+      }
+    }
+    // ---- further node updates (deeper trees): same arithmetic, inputs loaded at use
+    for (uint32_t o = NPRE; o < nops; ++o)
+    {
+      OpSlot s;
+      uint4 * d = reinterpret_cast<uint4 *>(&s);
+      d[0] = rp[6 + 3*o]; d[1] = rp[7 + 3*o]; d[2] = rp[8 + 3*o];
+      const OpDev & op = s.op;
+      double lv[4], rv[4], x[4], y[4], al, bl_, ar, br;
+      if (op.left_clv == last_clv) { lv[0] = last[0]; lv[1] = last[1]; lv[2] = last[2]; lv[3] = last[3]; }
+      else load_vec4(T, op.left_clv, 0, n, lv);
+      if (op.right_clv == last_clv) { rv[0] = last[0]; rv[1] = last[1]; rv[2] = last[2]; rv[3] = last[3]; }
+      else load_vec4(T, op.right_clv, 0, n, rv);
+      if (s.left_e < 0)  { const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.left_pmatrix*16);  al = ab.x; bl_ = ab.y; }
+      else jc69_ab(P.mat_length[s.left_e], rate, al, bl_);
+      if (s.right_e < 0) { const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.right_pmatrix*16); ar = ab.x; br = ab.y; }
+      else jc69_ab(P.mat_length[s.right_e], rate, ar, br);
+      matvec4_ab(al, bl_, lv, x);
+      matvec4_ab(ar, br, rv, y);
+      double r0 = x[0]*y[0], r1 = x[1]*y[1], r2 = x[2]*y[2], r3 = x[3]*y[3];
+      if (op.parent_scaler >= 0)
+      {
+        uint32_t sc = 0;
+        if (op.left_scaler  >= 0) sc += T.scaler[(size_t)op.left_scaler*np  + n];
+        if (op.right_scaler >= 0) sc += T.scaler[(size_t)op.right_scaler*np + n];
+        if (r0 < BPA_SCALE_THRESHOLD && r1 < BPA_SCALE_THRESHOLD && r2 < BPA_SCALE_THRESHOLD && r3 < BPA_SCALE_THRESHOLD)
+        { r0 *= BPA_SCALE_FACTOR; r1 *= BPA_SCALE_FACTOR; r2 *= BPA_SCALE_FACTOR; r3 *= BPA_SCALE_FACTOR; sc += 1; }
+        T.scaler[(size_t)op.parent_scaler*np + n] = sc;
+      }
+      double2 * dst = reinterpret_cast<double2 *>(T.clv + ((size_t)(op.parent_clv - tips)*np + n)*4);
+      double2 u, w; u.x = r0; u.y = r1; w.x = r2; w.y = r3;
+      dst[0] = u; dst[1] = w;
+      last_clv = op.parent_clv; last[0] = r0; last[1] = r1; last[2] = r2; last[3] = r3;
+    }
+
+    BPA_STAMP(P, b, lane, 4);
+    // ---- K2 / K3 at the root (core_likelihood_avx.c:117-150)
+    double c[4];
+    if (T.root_clv == last_clv) { c[0] = last[0]; c[1] = last[1]; c[2] = last[2]; c[3] = last[3]; }
+    else load_vec4(T, T.root_clv, 0, n, c);
+    const double tr = dot4_pair(f01.x, f01.y, f23.x, f23.y, c);
+    term = 0 + tr*rw;
+    if (!T.unphased_length)
+    {
+      double lt = log(term);
+      if (T.root_scaler >= 0)
+      {
+        const uint32_t sc = T.scaler[(size_t)T.root_scaler*np + n];
+        if (sc) lt += sc*BPA_LOG_SCALE_THRESHOLD;
+      }
+      term = lt*wgt;
+    }
+    P.site_term[T.pat_off + n] = term;
+  }
+
+  BPA_STAMP(P, b, lane, 5);
+  // ---- phase C: per-locus sum in pattern order
+  if (P.flags & 4u)
+  {
+    s_term[lane] = term;
+    __syncthreads();
+    if (summer)
+    {
+      double logl = 0;
+      if (c_unph) logl = reduce_locus(P.loci[c_locus], s_term + c_l0);
+      else for (uint32_t q = 0; q < c_np; ++q) logl += s_term[c_l0 + q];
+      P.lnl[c_task] = P.bfbeta*logl;
+    }
+  }
+  BPA_STAMP(P, b, lane, 6);
+
+  // ---- tail: the step's full 4x4 matrices go to HBM for later steps (K4)
+  if (have_m0)
+  {
+    double a, bb;
+    jc69_ab(m0_len, m0_rate, a, bb);
+    double2 * dst = reinterpret_cast<double2 *>(m0.dst);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+      double2 v;
+      v.x = ((2*i) >> 2) == ((2*i) & 3) ? a : bb;
+      v.y = ((2*i + 1) >> 2) == ((2*i + 1) & 3) ? a : bb;
+      dst[i] = v;
+    }
+    for (uint32_t e = e0 + lane + BS; e < e1; e += BS) pmatrix_s4_rec(P.mat_recs[e], P.mat_length, 0);
+  }
+  BPA_STAMP(P, b, lane, 7);
 }
 
 // generic S: one lane per (branch, rate, row)
