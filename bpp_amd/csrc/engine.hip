@@ -129,7 +129,8 @@ struct bpa_plan
   DevBuf<uint4>    recs;
   DevBuf<uint32_t> tile_task, tile_n0;
   DevBuf<unsigned long long> dbg;
-  unsigned ntiles = 0;                // tiled 20-state path
+  unsigned ntiles = 0, tile = 128;    // tiled 20-state path
+  bool s20_mfma = true;
   DevBuf<MatRec>   mat_recs;
   bool fused_jc69 = false;            // JC69, one rate category: the latency-optimised kernel
   unsigned fused_rt = 0;              // compile-time rate-category count of the fused kernel (0 = runtime)
@@ -537,11 +538,13 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
 
   // tiled path (20 states): one workgroup per 128-pattern tile of one locus
   p->ntiles = 0; d.tile_task = d.tile_n0 = nullptr;
+  p->s20_mfma = getenv("BPA_S20_MFMA") != nullptr;       // experimental, see kernels.hpp
+  p->tile = p->s20_mfma ? 32 : 128;
   if (p->states == 20)
   {
     std::vector<uint32_t> tt, tn;
     for (unsigned t = 0; t < T; ++t)
-      for (unsigned n0 = 0; n0 < b->loci[t]->sites; n0 += 128) { tt.push_back(t); tn.push_back(n0); }
+      for (unsigned n0 = 0; n0 < b->loci[t]->sites; n0 += p->tile) { tt.push_back(t); tn.push_back(n0); }
     if (!upload(p->tile_task, tt.data(), tt.size()) || !upload(p->tile_n0, tn.data(), tn.size())) return 0;
     d.tile_task = p->tile_task.p; d.tile_n0 = p->tile_n0.p;
     p->ntiles = (unsigned)tt.size();
@@ -741,9 +744,14 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     const unsigned blocks = (d.npatterns + BPA_BLOCK - 1)/BPA_BLOCK;
     if (p->states == 4)
       hipLaunchKernelGGL(partials_lnl_s4_kernel, dim3(blocks), dim3(BPA_BLOCK), 0, e->stream, d);
-    else if (p->ntiles && !getenv("BPA_S20_GENERIC"))
+    else if (p->ntiles && p->s20_mfma)
     {
       d.flags = 4u;                                      // always produce the site terms
+      hipLaunchKernelGGL((partials_lnl_mfma20_kernel<32>), dim3(p->ntiles), dim3(64), 0, e->stream, d);
+    }
+    else if (p->ntiles && p->tile == 128 && !getenv("BPA_S20_GENERIC"))
+    {
+      d.flags = 4u;
       const size_t lds = (size_t)2*p->rmax*400*sizeof(double);
       hipLaunchKernelGGL((partials_lnl_tiled_kernel<20, 128>), dim3(p->ntiles), dim3(128), lds, e->stream, d);
     }

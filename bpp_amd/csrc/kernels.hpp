@@ -371,6 +371,186 @@ __global__ void __launch_bounds__(TILE) partials_lnl_tiled_kernel(const PlanDev 
   P.site_term[P.task_pat_off[t] + n] = term;
 }
 
+// ================================================= K1+K2, 20 states, FP64 MFMA ==
+// The 20-state node update is a real dense contraction: parent[i][n] = (sum_j Pl[i][j] L[j][n]) *
+// (sum_j Pr[i][j] R[j][n]).  It runs on the matrix cores with v_mfma_f64_4x4x4_4b_f64
+// (4 independent 4x4x4 blocks per instruction; measured 67.6 TFLOP/s on MI355X vs 42 for
+// v_fma_f64): blocks = four groups of 4 site patterns, A = a 4-row x 4-column piece of P
+// (replicated over the blocks), B = 4 states x 16 patterns of the child CLV, so 20 states
+// tile exactly (5 row tiles, no padding in M).  Lane layout (tools/mfma_layout.hip):
+//   A[blk][i][k] @ lane k*16+blk*4+i   B[blk][k][j] @ lane k*16+blk*4+j   D[blk][i][j] @ lane i*16+blk*4+j
+// i.e. for B and D, lane & 15 = pattern within the group of 16 and lane >> 4 = k resp. row.
+// The instruction accumulates k = 0..3 as an ascending fma chain seeded with C
+// (tools/mfma_order.hip, bit-exact), so the reference's AVX2 summation order is kept
+// exactly: lane-accumulator a (a = 0..3) takes the columns j = a, a+4, a+8, a+12 in one
+// MFMA and j = a+16 (k = 1..3 zero-padded: fma(0,0,acc) = acc) in a second one; then
+// (acc0+acc1)+(acc2+acc3) and the product on the VALU (core_partials_avx2.c:666-745).
+// 8 MFMAs per (4 rows x 16 patterns) instead of the minimal 5: at 62 % of the MFMA peak the
+// kernel is still far above what HBM can feed (3.3 flop/B), so exactness is free.
+// One wave (= one workgroup) = one tile of TILE = 32 patterns of one locus.  For every
+// (update, rate) the wave stages the two 20x20 P-matrices in 6.4 KB of LDS (A operands: one
+// ds_read_b64 per MFMA) and requests all CLV operands of the tile in one burst.
+// STATUS (round 1): correct and bit-exact (same tests as the VALU kernel), but at config-4
+// sizes it is latency-bound (short per-wave chains of load -> 160 MFMA -> store) and
+// 1.3x slower than the LDS-broadcast VALU kernel above, which therefore stays the default;
+// opt in with BPA_S20_MFMA=1.  Variants tried: A in registers, 128-pattern tiles (542 us),
+// A in LDS (578 us), A in registers + 32-pattern tiles (827 us) vs VALU 437 us per launch.
+// Children written by other lanes of the same wave are re-read after s_waitcnt vmcnt(0).
+// A operands come from the wave's LDS copy of the two P-matrices (row-major 20x20 each)
+__device__ __forceinline__ double tile_dot20(const double * __restrict__ sp, const uint32_t rowoff,
+                                             const uint32_t kq, const double (&b)[4], const double (&b2)[4])
+{
+  double acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+  {
+    const double a0 = sp[rowoff + a + 4*kq];
+    const double a1 = kq == 0 ? sp[rowoff + 16 + a] : 0.0;
+    acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b[a], 0.0, 0, 0, 0);
+    acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b2[a], acc[a], 0, 0, 0);
+  }
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+__device__ __forceinline__ void load_b20(const LocusDev & L, const uint32_t clv_index, const uint32_t k,
+                                         const uint32_t pat, const uint32_t kq, double (&b)[4], double (&b2)[4])
+{
+  if (clv_index < L.tips_n)
+  {
+    const uint32_t code = reinterpret_cast<const uint32_t *>(L.tips)[(size_t)clv_index*L.np + pat];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+    {
+      b[a]  = ((code >> (a + 4*kq)) & 1u) ? 1.0 : 0.0;
+      b2[a] = (kq == 0 && ((code >> (16 + a)) & 1u)) ? 1.0 : 0.0;
+    }
+  }
+  else
+  {
+    const double * p = L.clv + (((size_t)(clv_index - L.tips_n)*L.rate_cats + k)*20)*L.np + pat;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+    {
+      b[a]  = p[(size_t)(a + 4*kq)*L.np];
+      b2[a] = kq == 0 ? p[(size_t)(16 + a)*L.np] : 0.0;
+    }
+  }
+}
+
+template <int TILE>
+__global__ void __launch_bounds__(64) partials_lnl_mfma20_kernel(const PlanDev P)
+{
+  constexpr int S = 20;
+  __shared__ __attribute__((aligned(16))) double s_p[2*S*S];
+  const uint32_t b = blockIdx.x, l = threadIdx.x;
+  const uint32_t t = P.tile_task[b], n0 = P.tile_n0[b];
+  const LocusDev L = P.loci[P.task_locus[t]];
+  const uint32_t R = L.rate_cats, np = L.np;
+  const uint32_t kq = l >> 4, pl = l & 15, ri = l & 3;
+  const uint32_t npat = min((uint32_t)TILE, np - n0), ngroups = (npat + 15)/16;
+
+  const uint32_t op_end = P.op_off[t+1];
+  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
+  {
+    const OpDev op = P.ops[o];
+    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*np;
+    uint32_t small = 0xffffffffu;                 // bit g: everything this lane produced for group g is < 2^-256
+    for (uint32_t k = 0; k < R; ++k)
+    {
+      {
+        const double2 * lm = reinterpret_cast<const double2 *>(L.pmat + ((size_t)op.left_pmatrix*R  + k)*S*S);
+        const double2 * rm = reinterpret_cast<const double2 *>(L.pmat + ((size_t)op.right_pmatrix*R + k)*S*S);
+        __syncthreads();                                 // (one wave) previous rate's LDS reads are done
+        double2 * sl = reinterpret_cast<double2 *>(s_p), * sr = reinterpret_cast<double2 *>(s_p + S*S);
+        for (uint32_t i = l; i < S*S/2; i += 64) { sl[i] = lm[i]; sr[i] = rm[i]; }
+        __syncthreads();
+      }
+      // all CLV operands of the tile first (one wave of independent loads), then the MFMAs
+      constexpr int NG = TILE/16;
+      double bl[NG][4], bl2[NG][4], br[NG][4], br2[NG][4];
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+      {
+        const uint32_t pat = n0 + 16*g + pl;
+        const uint32_t pc = pat < np ? pat : np - 1;
+        load_b20(L, op.left_clv,  k, pc, kq, bl[g], bl2[g]);
+        load_b20(L, op.right_clv, k, pc, kq, br[g], br2[g]);
+      }
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+      {
+        const uint32_t pat = n0 + 16*g + pl;
+        const bool valid = pat < np;
+        bool sm = true;
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+        {
+          const double x = tile_dot20(s_p,       (4*r + ri)*S, kq, bl[g], bl2[g]);
+          const double y = tile_dot20(s_p + S*S, (4*r + ri)*S, kq, br[g], br2[g]);
+          const double v = x*y;
+          sm = sm && (v < BPA_SCALE_THRESHOLD);
+          if (valid) out[((size_t)k*S + 4*r + kq)*np + pat] = v;      // D: row = lane >> 4
+        }
+        if (!sm) small &= ~(1u << g);
+      }
+    }
+    if (op.parent_scaler >= 0)
+    {
+      // a pattern's 20*R entries sit in the 4 lanes with the same (lane & 15)
+      small &= __shfl_xor(small, 16);
+      small &= __shfl_xor(small, 32);
+      for (uint32_t g = 0; g < ngroups; ++g)
+      {
+        const uint32_t pat = n0 + 16*g + pl;
+        if (pat >= np) continue;
+        const bool rescale = (small >> g) & 1u;
+        if (rescale)
+          for (uint32_t k = 0; k < R; ++k)
+#pragma unroll
+            for (int r = 0; r < 5; ++r) out[((size_t)k*S + 4*r + kq)*np + pat] *= BPA_SCALE_FACTOR;
+        if (kq == 0)
+        {
+          uint32_t s = rescale ? 1u : 0u;
+          if (op.left_scaler  >= 0) s += L.scaler[(size_t)op.left_scaler*np  + pat];
+          if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + pat];
+          L.scaler[(size_t)op.parent_scaler*np + pat] = s;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next update reads these through other lanes
+  }
+  if (!(P.flags & 4u)) return;
+
+  // K2 / K3 (core_likelihood_avx2.c:45-87): one lane per pattern
+  const uint32_t root = P.root_clv[t];
+  const double * par = L.par;
+  for (uint32_t q = l; q < npat; q += 64)
+  {
+    const uint32_t n = n0 + q;
+    double term = 0;
+    for (uint32_t k = 0; k < R; ++k)
+    {
+      double c[S];
+      load_childN<S, uint32_t>(L, root, k, n, c);
+      const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+      const double tr = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
+      term = __builtin_fma(tr, par[par_rate_weights(R) + k], term);
+    }
+    if (!L.unphased_length)
+    {
+      double lt = log(term);
+      const int32_t rs = P.root_scaler[t];
+      if (rs >= 0)
+      {
+        const uint32_t sc = L.scaler[(size_t)rs*np + n];
+        if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
+      }
+      term = lt*L.weights[n];
+    }
+    P.site_term[P.task_pat_off[t] + n] = term;
+  }
+}
+
 // ====================================================== per-locus lnL reduction ==
 // Sum of the per-pattern terms in pattern order (core_likelihood.c:206-210); the
 // diploid branch averages the phase resolutions first (locus.c:2600-2614).

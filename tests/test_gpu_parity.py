@@ -390,3 +390,29 @@ def test_against_the_reference_itself(engine, spec):
     got = full_eval(loc, gt)
     assert rel(got, want) < LNL_RTOL_TIGHT
     rl.free()
+
+
+def test_mfma_20_state_kernel_is_bit_exact(engine, monkeypatch):
+    """the FP64-MFMA variant of the 20-state node update (opt-in) reproduces the reference's
+    AVX2 summation order exactly: same CLVs, scalers and lnL bits as the default kernel"""
+    c = load_golden("loci.json")
+    for idx in (6, 7, 11):                      # the three 20-state golden loci (11: with scaling)
+        case = c[idx]
+        S, R = case["states"], case["rate_cats"]
+        ol, _ = __import__("test_oracle_pin").oracle_locus(case)
+        monkeypatch.setenv("BPA_S20_MFMA", "1")
+        loc, gt = golden_case(engine, case)
+        for nd in gt.branches():
+            loc.set_pmatrix(nd.pmatrix_index, ol.pmat[nd.node_index])
+        locus_update_partials(loc, gt.postorder())
+        lnl_mfma = locus_root_loglikelihood(loc, gt.root)
+        for nd in gt.postorder():
+            assert (loc.get_clv(nd.clv_index) == ol.clv[nd.node_index]).all()
+            if case["scaling"]:
+                assert (loc.get_scaler(nd.scaler_index) == ol.scaler[nd.node_index]).all()
+        monkeypatch.delenv("BPA_S20_MFMA")
+        loc2, gt2 = golden_case(engine, case)
+        for nd in gt2.branches():
+            loc2.set_pmatrix(nd.pmatrix_index, ol.pmat[nd.node_index])
+        locus_update_partials(loc2, gt2.postorder())
+        assert locus_root_loglikelihood(loc2, gt2.root) == lnl_mfma
