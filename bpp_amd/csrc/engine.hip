@@ -91,7 +91,7 @@ struct bpa_locus
   std::vector<int>      eigen_valid;  // locus->eigen_decomp_valid (locus.c:735)
   bool par_dirty = true, tips_dirty = true, weights_dirty = true, queued = false, alive = true;
   size_t code_bytes() const { return states == 4 ? 1 : 4; }
-  bool needs_eigen() const { return !(dtype == BPA_DATA_DNA && model == BPA_DNA_MODEL_JC69); }
+  bool needs_eigen() const { return !(dtype == BPA_DATA_DNA && model < BPA_DNA_MODEL_GTR); }   // locus.c:2426-2454
   std::unique_ptr<bpa_plan> scratch;  // single-locus calls reuse one small plan
 };
 
@@ -230,8 +230,8 @@ extern "C" bpa_locus_t * bpa_locus_create(bpa_engine_t * e, unsigned dtype, unsi
   if (!e) { fail("bpa_locus_create: null engine"); return nullptr; }
   if (!((dtype == BPA_DATA_DNA && states == 4) || (dtype == BPA_DATA_AA && states == 20)))
   { fail("bpa_locus_create: only DNA (4 states) and amino-acid (20 states) data"); return nullptr; }
-  if (dtype == BPA_DATA_DNA && model != BPA_DNA_MODEL_JC69 && model != BPA_DNA_MODEL_GTR)
-  { fail("bpa_locus_create: DNA model not supported yet (JC69 and GTR are)"); return nullptr; }
+  if (dtype == BPA_DATA_DNA && model > BPA_DNA_MODEL_GTR)
+  { fail("bpa_locus_create: unknown DNA model"); return nullptr; }
   if (dtype == BPA_DATA_AA && (model < BPA_AA_MODEL_MIN || model > BPA_AA_MODEL_MAX))
   { fail("bpa_locus_create: unknown amino-acid model"); return nullptr; }
   if (!tips || !sites || !rate_cats || !rate_matrices || !prob_matrices)
@@ -256,7 +256,8 @@ extern "C" bpa_locus_t * bpa_locus_create(bpa_engine_t * e, unsigned dtype, unsi
   { fail("bpa_locus_create: out of device memory"); delete l; return nullptr; }
   d.dip_count = d.dip_map = d.dip_weights = nullptr;
   d.np = sites; d.tips_n = tips; d.rate_cats = rate_cats; d.states = states;
-  d.model = (dtype == BPA_DATA_DNA && model == BPA_DNA_MODEL_JC69) ? 0u : 1u;
+  // 0 JC69, 1..6 closed-form 4x4 models (BPA_DNA_MODEL_*), 100 = eigendecomposition (GTR, amino acids)
+  d.model = (dtype == BPA_DATA_DNA && model < BPA_DNA_MODEL_GTR) ? model : 100u;
   d.dtype = dtype; d.rate_matrices = rate_matrices; d.unphased_length = 0;
 
   // defaults of locus_create (locus.c:727-848): param_indices 0, rates 1 (the

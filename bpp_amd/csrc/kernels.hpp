@@ -638,6 +638,78 @@ __device__ __forceinline__ void pmatrix_eigen_row(double * __restrict__ prow, in
   }
 }
 
+// K7: closed-form P(t) of K80 / F81 / HKY / T92 / TN93 / F84 (locus.c:1981-2323), state
+// order A,C,G,T, written P = I + (...)expm1(...) like the reference and evaluated in its order.
+// model = BPA_DNA_MODEL_* (1..6); f = frequencies, q = substitution parameters of the locus.
+__device__ __forceinline__ void pmatrix_dna_closed(const uint32_t model, const double * __restrict__ f,
+                                                   const double * __restrict__ q, const double bl, double * p)
+{
+  if (model == 1)
+  {
+    const double kappa = q[1]/q[0];
+    const double e1 = expm1(-4*bl/(kappa + 2));
+    if (fabs(kappa - 1) < 1e-20)
+    {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) p[i] = ((i >> 2) == (i & 3)) ? 1. + 3/4.*e1 : -e1/4;
+    }
+    else
+    {
+      const double e2 = expm1(-2*bl*(kappa + 1)/(kappa + 2));
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        p[i] = ((i >> 2) == (i & 3)) ? 1 + (e1 + 2*e2)/4 : ((((i >> 2) ^ (i & 3)) == 2) ? (e1 - 2*e2)/4 : -e1/4);
+    }
+  }
+  else if (model == 2)
+  {
+    double beta = 1;
+    for (int j = 0; j < 4; ++j) beta -= f[j]*f[j];
+    beta = 1./beta;
+    const double e = exp(-beta*bl), em1 = expm1(-beta*bl);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) p[i] = ((i >> 2) == (i & 3)) ? e - f[i & 3]*em1 : -f[i & 3]*em1;
+  }
+  else if (model == 4)
+  {
+    const double GC = f[3] + f[2];
+    const double e1 = expm1(-bl);
+    const double e2 = expm1(-(q[0]/q[1] + 1)*bl/2);
+    const double a = -(1 - GC)/2*e1, g = -GC/2*e1;
+    p[0]  = a;                           p[1]  = GC/2*e1 - GC*e2;           p[2]  = g;                 p[3]  = 1 + 0.5*(1 - GC)*e1 + GC*e2;
+    p[4]  = a;                           p[5]  = 1 + GC/2*e1 + (1 - GC)*e2; p[6]  = g;                 p[7]  = (1 - GC)/2*e1 - (1 - GC)*e2;
+    p[8]  = 1 + 0.5*(1 - GC)*e1 + GC*e2; p[9]  = g;                         p[10] = GC/2*e1 - GC*e2;   p[11] = a;
+    p[12] = (1 - GC)/2*e1 - (1 - GC)*e2; p[13] = g;                         p[14] = 1 + GC/2*e1 + (1 - GC)*e2; p[15] = a;
+  }
+  else
+  {
+    const double A = f[0], C = f[1], G = f[2], T = f[3], Y = T + C, R = A + G;
+    double bt, a1t, a2t;
+    if (model == 3)
+    {
+      const double kappa = q[1]/q[0];
+      const double mr = 1/(2*T*C*kappa + 2*A*G*kappa + 2*Y*R);
+      bt = bl*mr; a1t = a2t = kappa*bt;
+    }
+    else if (model == 6)
+    {
+      const double kappa = q[0]/q[1];
+      const double mr = 1/(2*T*C*kappa + 2*A*G*kappa + 2*Y*R);
+      bt = bl*mr; a1t = (1 + kappa/Y)*bt; a2t = (1 + kappa/R)*bt;
+    }
+    else
+    {
+      const double mr = 1/(2*T*C*q[0] + 2*A*G*q[1] + 2*Y*R);
+      bt = bl*mr; a1t = (q[0]/q[2])*bt; a2t = (q[1]/q[2])*bt;
+    }
+    const double e1 = expm1(-bt), e2 = expm1(-(R*a2t + Y*bt)), e3 = expm1(-(Y*a1t + R*bt));
+    p[0]  = 1 + Y*A/R*e1 + G/R*e2;  p[1]  = -C*e1;                 p[2]  = Y*G/R*e1 - G/R*e2;     p[3]  = -T*e1;
+    p[4]  = -A*e1;                  p[5]  = 1 + (R*C*e1 + T*e3)/Y; p[6]  = -G*e1;                 p[7]  = (R*e1 - e3)*T/Y;
+    p[8]  = Y*A/R*e1 - A/R*e2;      p[9]  = -C*e1;                 p[10] = 1 + Y*G/R*e1 + A/R*e2; p[11] = -T*e1;
+    p[12] = -A*e1;                  p[13] = (R*e1 - e3)*C/Y;       p[14] = -G*e1;                 p[15] = 1 + (R*T*e1 + C*e3)/Y;
+  }
+}
+
 __device__ __forceinline__ void pmatrix_s4_entry(const PlanDev & P, const uint32_t e, const uint32_t k)
 {
   const LocusDev & L = P.loci[P.task_locus[P.mat_task[e]]];
@@ -659,6 +731,12 @@ __device__ __forceinline__ void pmatrix_s4_entry(const PlanDev & P, const uint32
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) q[i] = ((i >> 2) == (i & 3)) ? a : b;
+  }
+  else if (L.model >= 1 && L.model <= 6)
+  {
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+    const double * pm = par + par_matrix(R, 4, m);
+    pmatrix_dna_closed(L.model, pm + pm_freqs(4), pm + pm_subst(4), t*rate, q);
   }
   else
   {
@@ -716,6 +794,12 @@ __device__ __forceinline__ void pmatrix_s4_rec(const MatRec & m, const double * 
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) q[i] = ((i >> 2) == (i & 3)) ? a : b;
+  }
+  else if (m.model >= 1 && m.model <= 6)
+  {
+    const uint32_t mi = (uint32_t)par[par_param_idx(R) + k];
+    const double * pm = par + par_matrix(R, 4, mi);
+    pmatrix_dna_closed(m.model, pm + pm_freqs(4), pm + pm_subst(4), bl, q);
   }
   else if (bl < 1e-100)
     pmatrix_identity(q, 4);

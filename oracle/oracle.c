@@ -249,6 +249,87 @@ void orc_pmatrix_jc69(unsigned rate_cats, const double * rates, double t, double
   }
 }
 
+/* --------------------------------------------------------------- K7 --------
+ * Closed-form 4x4 P(t) of the other nucleotide models, state order A,C,G,T:
+ * K80 (locus.c:2240-2323), F81 (2172-2238), HKY / F84 / TN93 (2060-2170), T92 (1981-2058).
+ * Written with expm1 as the reference does (P = I + ...), entry by entry in the same
+ * evaluation order so the values are bit-identical.  model: 1 K80, 2 F81, 3 HKY, 4 T92,
+ * 5 TN93, 6 F84 (bpp.h:216-221); q = locus->subst_params, f = locus->frequencies.       */
+void orc_pmatrix_dna(unsigned model, const double * f, const double * q, unsigned rate_cats,
+                     const double * rates, double t, double * pmat)
+{
+  unsigned k, i, j;
+  for (k = 0; k < rate_cats; ++k)
+  {
+    double * p = pmat + k*16;
+    const double bl = t*rates[k];
+    if (model == 1)                                   /* K80: kappa = q[1]/q[0] */
+    {
+      const double kappa = q[1]/q[0];
+      const double e1 = expm1(-4*bl/(kappa + 2));
+      if (fabs(kappa - 1) < 1e-20)
+        for (i = 0; i < 4; ++i) for (j = 0; j < 4; ++j) p[4*i + j] = (i == j) ? 1. + 3/4.*e1 : -e1/4;
+      else
+      {
+        const double e2 = expm1(-2*bl*(kappa + 1)/(kappa + 2));
+        for (i = 0; i < 4; ++i)
+          for (j = 0; j < 4; ++j)
+            p[4*i + j] = (i == j) ? 1 + (e1 + 2*e2)/4            /* same base          */
+                       : ((i ^ j) == 2) ? (e1 - 2*e2)/4           /* transition A<->G, C<->T */
+                       : -e1/4;                                   /* transversion       */
+      }
+    }
+    else if (model == 2)                              /* F81 */
+    {
+      double beta = 1;
+      for (j = 0; j < 4; ++j) beta -= f[j]*f[j];
+      beta = 1./beta;
+      {
+        const double e = exp(-beta*bl), em1 = expm1(-beta*bl);
+        for (i = 0; i < 4; ++i) for (j = 0; j < 4; ++j) p[4*i + j] = (i == j) ? e - f[j]*em1 : -f[j]*em1;
+      }
+    }
+    else if (model == 4)                              /* T92: GC content + kappa */
+    {
+      const double GC = f[3] + f[2];
+      const double e1 = expm1(-bl);
+      const double e2 = expm1(-(q[0]/q[1] + 1)*bl/2);
+      const double a = -(1 - GC)/2*e1, g = -GC/2*e1;
+      p[0]  = a;                       p[1]  = GC/2*e1 - GC*e2;          p[2]  = g;                     p[3]  = 1 + 0.5*(1 - GC)*e1 + GC*e2;
+      p[4]  = a;                       p[5]  = 1 + GC/2*e1 + (1 - GC)*e2; p[6]  = g;                     p[7]  = (1 - GC)/2*e1 - (1 - GC)*e2;
+      p[8]  = 1 + 0.5*(1 - GC)*e1 + GC*e2; p[9]  = g;                     p[10] = GC/2*e1 - GC*e2;       p[11] = a;
+      p[12] = (1 - GC)/2*e1 - (1 - GC)*e2; p[13] = g;                     p[14] = 1 + GC/2*e1 + (1 - GC)*e2; p[15] = a;
+    }
+    else                                              /* HKY (3), TN93 (5), F84 (6) */
+    {
+      const double A = f[0], C = f[1], G = f[2], T = f[3], Y = T + C, R = A + G;
+      double bt, a1t, a2t, e1, e2, e3;
+      if (model == 3)
+      {
+        const double kappa = q[1]/q[0];
+        const double mr = 1/(2*T*C*kappa + 2*A*G*kappa + 2*Y*R);
+        bt = bl*mr; a1t = a2t = kappa*bt;
+      }
+      else if (model == 6)
+      {
+        const double kappa = q[0]/q[1];
+        const double mr = 1/(2*T*C*kappa + 2*A*G*kappa + 2*Y*R);
+        bt = bl*mr; a1t = (1 + kappa/Y)*bt; a2t = (1 + kappa/R)*bt;
+      }
+      else
+      {
+        const double mr = 1/(2*T*C*q[0] + 2*A*G*q[1] + 2*Y*R);
+        bt = bl*mr; a1t = (q[0]/q[2])*bt; a2t = (q[1]/q[2])*bt;
+      }
+      e1 = expm1(-bt); e2 = expm1(-(R*a2t + Y*bt)); e3 = expm1(-(Y*a1t + R*bt));
+      p[0]  = 1 + Y*A/R*e1 + G/R*e2;  p[1]  = -C*e1;             p[2]  = Y*G/R*e1 - G/R*e2;     p[3]  = -T*e1;
+      p[4]  = -A*e1;                  p[5]  = 1 + (R*C*e1 + T*e3)/Y; p[6]  = -G*e1;               p[7]  = (R*e1 - e3)*T/Y;
+      p[8]  = Y*A/R*e1 - A/R*e2;      p[9]  = -C*e1;             p[10] = 1 + Y*G/R*e1 + A/R*e2; p[11] = -T*e1;
+      p[12] = -A*e1;                  p[13] = (R*e1 - e3)*C/Y;   p[14] = -G*e1;                 p[15] = 1 + (R*T*e1 + C*e3)/Y;
+    }
+  }
+}
+
 /* --------------------------------------------------------------- K6 --------
  * pll_update_eigen (core_pmatrix.c:186-297).  Symmetrised rate matrix
  * A_ij = r_ij sqrt(pi_i pi_j), A_ii = -sum_j r_ij pi_j, scaled to mean rate 1;

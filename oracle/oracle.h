@@ -50,6 +50,8 @@ double orc_diploid_loglikelihood(const double * persite_lh, int unphased_length,
                                  const unsigned long * mapping,
                                  const unsigned * unphased_weights);
 void   orc_pmatrix_jc69(unsigned rate_cats, const double * rates, double t, double * pmat);
+void   orc_pmatrix_dna(unsigned model, const double * f, const double * q, unsigned rate_cats,
+                       const double * rates, double t, double * pmat);
 void   orc_update_eigen(unsigned states, const double * freqs, const double * subst_params,
                         double * eigenvecs, double * inv_eigenvecs, double * eigenvals);
 void   orc_pmatrix_eigen(unsigned states, unsigned rate_cats, const double * rates, double t,

@@ -21,6 +21,7 @@ ORDER_SEQ, ORDER_PAIR, ORDER_FMA4 = 0, 1, 2
 ARCH_CPU, ARCH_SSE, ARCH_AVX, ARCH_AVX2 = 0, 1, 2, 4
 DATA_DNA, DATA_AA = 0, 1
 MODEL_JC69, MODEL_GTR, MODEL_LG = 0, 7, 10
+DNA_MODELS = {"jc69": 0, "k80": 1, "f81": 2, "hky": 3, "t92": 4, "tn93": 5, "f84": 6, "gtr": 7}
 
 dp = C.POINTER(C.c_double)
 up = C.POINTER(C.c_uint)
@@ -149,6 +150,17 @@ def orc_pmatrix_jc69(rates, t):
     return out
 
 
+def orc_pmatrix_dna(model, freqs, qrates, rates, t):
+    """closed-form K80/F81/HKY/T92/TN93/F84 P(t) (locus.c:1981-2323)"""
+    L = oracle()
+    rates = np.ascontiguousarray(rates, dtype=np.float64)
+    out = np.zeros((len(rates), 4, 4))
+    L.orc_pmatrix_dna(DNA_MODELS[model], _d(np.ascontiguousarray(freqs, dtype=np.float64)),
+                      _d(np.ascontiguousarray(qrates, dtype=np.float64)), len(rates), _d(rates),
+                      C.c_double(t), _d(out))
+    return out
+
+
 def orc_eigen(freqs, qrates):
     L = oracle()
     S = len(freqs)
@@ -240,12 +252,14 @@ class OracleLocus:
         self.pmat = [None] * n
         for i, s in enumerate(seqs):
             self.clv[i] = orc_tipclv(states, rate_cats, s, self.dna)
-        if model != "jc69":
+        if model not in DNA_MODELS or model == "gtr":
             self.eig = orc_eigen(self.freqs, self.qrates)
 
     def pmatrix(self, t):
         if self.model == "jc69":
             return orc_pmatrix_jc69(self.rates, t)
+        if self.model in DNA_MODELS and self.model != "gtr":
+            return orc_pmatrix_dna(self.model, self.freqs, self.qrates, self.rates, t)
         ev, iev, evals = self.eig
         return orc_pmatrix_eigen(self.rates, t, evals, ev, iev)
 
@@ -275,7 +289,7 @@ class RefLocus:
         L = ref()
         self.L = L
         dtype = DATA_DNA if states == 4 else DATA_AA
-        mdl = {"jc69": MODEL_JC69, "gtr": MODEL_GTR, "lg": MODEL_LG, "aa": MODEL_LG}[model]
+        mdl = DNA_MODELS[model] if model in DNA_MODELS else MODEL_LG
         self.S, self.R = states, rate_cats
         self.tips, self.sites = len(seqs), len(seqs[0])
         self.h = C.c_void_p(L.ref_locus_new(dtype, mdl, self.tips, states, self.sites, rate_cats,

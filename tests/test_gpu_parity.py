@@ -37,7 +37,7 @@ def make_locus(engine, S, R, model, seqs, weights, freqs=None, qrates=None, rate
     tips, sites = len(seqs), len(seqs[0])
     inner, edges = tips - 1, 2 * tips - 2
     dtype = DATA_DNA if S == 4 else DATA_AA
-    mdl = {"jc69": MODEL_JC69, "gtr": MODEL_GTR, "lg": MODEL_LG}[model]
+    mdl = O.DNA_MODELS[model] if model in O.DNA_MODELS else MODEL_LG
     # buffer counts of method.c:4110-4146
     loc = Locus(engine, dtype, mdl, tips, 2 * inner, S, sites, 1, 2 * edges, R, 2 * inner if scaling else 0)
     for i, s in enumerate(seqs):
@@ -198,7 +198,7 @@ def test_illegal_state_and_bad_indices(engine):
     with pytest.raises(bpp_amd.BpaError):
         loc.update_matrices([0], [-0.1])
     with pytest.raises(bpp_amd.BpaError):
-        Locus(engine, DATA_DNA, 3, 2, 2, 4, 3, 1, 4, 1, 0)      # HKY: not supported yet
+        Locus(engine, DATA_DNA, 8, 2, 2, 4, 3, 1, 4, 1, 0)      # unknown DNA model
 
 
 def test_zero_branch_is_identity(engine):
@@ -416,3 +416,25 @@ def test_mfma_20_state_kernel_is_bit_exact(engine, monkeypatch):
             loc2.set_pmatrix(nd.pmatrix_index, ol.pmat[nd.node_index])
         locus_update_partials(loc2, gt2.postorder())
         assert locus_root_loglikelihood(loc2, gt2.root) == lnl_mfma
+
+
+@pytest.mark.parametrize("model", ["k80", "f81", "hky", "t92", "tn93", "f84"])
+def test_closed_form_dna_models(engine, model):
+    """K7 (locus.c:1981-2323) on the device vs the oracle (which equals the reference bit for bit)"""
+    rng = np.random.default_rng(len(model) * 31 + ord(model[0]))
+    tips, sites, R = 7, 90, 4
+    seqs = rand_seqs(tips, sites, NT, rng, extra="-NRY")
+    w = rng.integers(1, 500, sites)
+    left, right, times, root = rand_tree(tips, rng, 0.2)
+    freqs = rng.dirichlet([5] * 4)
+    q = np.concatenate([rng.random(3) + 0.5, np.ones(3)])
+    rates = bpp_amd.compute_gamma_cats(0.6, 0.6, R)
+    loc = make_locus(engine, 4, R, model, seqs, w, freqs, q, rates)
+    gt = GTree(left, right, times, root)
+    lnl = full_eval(loc, gt)
+    ol = O.OracleLocus(4, R, seqs, w, model=model, freqs=freqs, qrates=q, rates=rates)
+    assert rel(lnl, ol.full_lnl(left, right, times, root)) < LNL_RTOL_TIGHT
+    for nd in gt.branches():
+        g_, w_ = loc.get_pmatrix(nd.pmatrix_index), ol.pmat[nd.node_index]
+        assert ulps(g_, w_).max() <= PMAT_ULPS or np.abs(g_ - w_).max() < PMAT_ATOL
+        assert np.allclose(g_.sum(-1), 1.0, atol=1e-14)

@@ -185,3 +185,40 @@ def test_compress_vs_reference():
             b, wb = O.ref_compress(seqs, True, jc)
             assert len(wa) == len(wb) and sorted(wa) == sorted(wb)
             assert canon(a, wa, jc) == canon(b, wb, jc)
+
+
+@needs_ref
+@pytest.mark.parametrize("model", ["k80", "f81", "hky", "t92", "tn93", "f84"])
+def test_closed_form_models_vs_reference(model):
+    """K7: locus_update_matrices_{k80,f81,tn93,t92} (locus.c:1981-2323), bit-exact"""
+    rng = np.random.default_rng(len(model) * 31 + ord(model[0]))
+    tips, sites, R = 6, 40, 4
+    seqs = rand_seqs(tips, sites, NT, rng, extra="-N")
+    w = rng.integers(1, 50, sites)
+    left, right, times, root = rand_tree(tips, rng, 0.3)
+    times[tips] = times[tips] if times[tips] > 0 else 1e-3
+    freqs = rng.dirichlet([5] * 4)
+    q = np.concatenate([rng.random(3) + 0.5, np.ones(3)])
+    if model == "k80":
+        q[:2] = [1.0, 1.0] if rng.random() < 0.0 else q[:2]
+    rl = O.RefLocus(4, R, seqs, w, model=model, freqs=freqs, qrates=q, alpha=0.7)
+    rl.set_tree(left, right, times, root)
+    lr = rl.full_lnl()
+    ol = O.OracleLocus(4, R, seqs, w, model=model, freqs=freqs, qrates=q, rates=rl.rates())
+    lo = ol.full_lnl(left, right, times, root)
+    for i in range(2 * tips - 2):
+        assert (rl.pmatrix(i) == ol.pmat[i]).all()
+    assert lo == lr
+    rl.free()
+
+
+@needs_ref
+def test_k80_kappa_one_branch_vs_reference():
+    seqs, w = ["ACGT", "AGGT", "ACTT"], [1, 2, 3, 4]
+    q = [2.0, 2.0, 1, 1, 1, 1]                                   # kappa == 1: the JC69-like branch (locus.c:2287)
+    rl = O.RefLocus(4, 1, seqs, w, model="k80", freqs=[0.25] * 4, qrates=q)
+    rl.set_tree([-1, -1, -1, 0, 3], [-1, -1, -1, 1, 2], [0, 0, 0, 0.1, 0.25], 4)
+    lr = rl.full_lnl()
+    ol = O.OracleLocus(4, 1, seqs, w, model="k80", freqs=[0.25] * 4, qrates=q)
+    assert ol.full_lnl([-1, -1, -1, 0, 3], [-1, -1, -1, 1, 2], [0, 0, 0, 0.1, 0.25], 4) == lr
+    rl.free()
