@@ -111,8 +111,13 @@ def main():
         import torch
         import torch.distributed as dist_
         dist = dist_
+        # BENCH_DIST_BACKEND=gloo + BENCH_FORCE_DEVICE=0 let the N>1 code path be exercised on a
+        # one-GPU box (two ranks sharing device 0); the driver's runs use nccl (= RCCL), one GPU per rank
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if "BENCH_FORCE_DEVICE" in os.environ:
+            local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
         stream = torch.cuda.current_stream().cuda_stream
         sum_buf = torch.zeros(4, dtype=torch.float64, device="cuda")
 
@@ -239,13 +244,13 @@ def main():
                         algorithmic_bytes_per_launch=round(bytes_per_launch),
                         launches=tm["launches"],
                         timing="hipExtLaunchKernelGGL start/stop events on the engine stream, every launch of the timed region",
-                        note=("52k lanes per launch: latency/launch bound (4.2 us empty-grid floor), not HBM bound (SURVEY §7)"
+                        note=("52k lanes per launch: latency/launch bound (2.3 us empty-grid floor), cache-resident working set, not HBM bound (SURVEY §7)"
                               if args.config == "c2" else None))
 
     # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (collected by
     # tools/profile_c2.sh on this same command): 2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md
     # §HBM) + WRITE_SIZE, both reported in KB
-    if roofline is not None and args.config == "c2":
+    if roofline is not None and args.config == "c2" and args.loci is None:
         try:
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "c2_pmc_hbm_bytes.json")))

@@ -12,7 +12,9 @@
 //   tip "CLVs" are never materialised: tip t keeps its state code per pattern
 //       (uint8 for 4 states, uint32 for 20) and is expanded to 0.0/1.0 in registers
 //       — arithmetic identical to the reference's one-hot tip CLVs (locus.c:525-559).
-//   P-matrix p                                      : pmat[((p*R + k)*S + i)*S + j]   (reference layout)
+//   P-matrix p                                      : pmat[((p*R + k)*S + i)*S + j]   (reference layout);
+//       JC69 loci keep only the pair (a, b) per (matrix, rate): pmat[(p*R + k)*2 + {0,1}]
+//   weights | tips | parameters (| JC69 (a,b) table) of a locus are one contiguous block (1-3 cache lines)
 //   scaler s                                        : scaler[s*Np + n]
 //   parameters (doubles)                            : rates[R] | rate_weights[R] | param_idx[R] |
 //                                                     per rate matrix m: freqs[S] | subst[S(S-1)/2] |
@@ -40,6 +42,8 @@ struct LocusDev
   uint32_t   dtype;
   uint32_t   rate_matrices;
   uint32_t   unphased_length; // 0 when not diploid
+  uint32_t   pstride;         // doubles per (P-matrix, rate): 16, or 2 for JC69 loci, whose matrices are
+  uint32_t   pad_;            // kept as their (diagonal a, off-diagonal b) pair (locus.c:2384-2411)
 };
 
 // offsets inside the parameter block
@@ -80,7 +84,7 @@ struct TaskRec            // 96-byte header followed by nops OpDev records
   const double *   par;
   uint32_t   np, tips_n, rate_cats, lane0;       // lane0: global lane of pattern 0
   uint32_t   nops, root_clv; int32_t root_scaler; uint32_t task;
-  uint32_t   unphased_length, pat_off, locus, pad;
+  uint32_t   unphased_length, pat_off, locus, pstride;
 };
 struct MatRec             // one (branch, all rate categories) P-matrix update
 {

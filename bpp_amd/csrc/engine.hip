@@ -246,14 +246,24 @@ extern "C" bpa_locus_t * bpa_locus_create(bpa_engine_t * e, unsigned dtype, unsi
 
   const size_t S = states, R = rate_cats, Np = sites;
   LocusDev & d = l->dev;
-  d.clv    = (double *)e->arena.alloc(std::max<size_t>(clv_buffers, 1)*R*Np*S*sizeof(double));
-  d.pmat   = (double *)e->arena.alloc((size_t)prob_matrices*R*S*S*sizeof(double));
-  d.scaler = scale_buffers ? (uint32_t *)e->arena.alloc((size_t)scale_buffers*Np*sizeof(uint32_t)) : nullptr;
-  d.tips   = (uint8_t *)e->arena.alloc((size_t)tips*Np*l->code_bytes());
-  d.weights= (uint32_t *)e->arena.alloc(Np*sizeof(uint32_t));
-  d.par    = (double *)e->arena.alloc(par_size(R, S, rate_matrices)*sizeof(double));
-  if (!d.clv || !d.pmat || (scale_buffers && !d.scaler) || !d.tips || !d.weights || !d.par)
+  const bool jc69 = dtype == BPA_DATA_DNA && model == BPA_DNA_MODEL_JC69;
+  d.pstride = jc69 ? 2u : (uint32_t)(S*S);
+  // one contiguous hot block per locus: parameters | pattern weights | tip codes (| JC69 (a,b) table),
+  // so that a proposal step touches 1-3 cache lines for them instead of 4-8
+  auto up16 = [](size_t x) { return (x + 15)/16*16; };
+  const size_t par_bytes = up16(par_size(R, S, rate_matrices)*sizeof(double));
+  const size_t w_bytes = up16(Np*sizeof(uint32_t)), tip_bytes = up16((size_t)tips*Np*l->code_bytes());
+  const size_t pm_bytes = (size_t)prob_matrices*R*d.pstride*sizeof(double);
+  char * hot = (char *)e->arena.alloc(par_bytes + w_bytes + tip_bytes + (jc69 ? pm_bytes : 0), 128);
+  d.clv    = (double *)e->arena.alloc(std::max<size_t>(clv_buffers, 1)*R*Np*S*sizeof(double), 128);
+  d.scaler = scale_buffers ? (uint32_t *)e->arena.alloc((size_t)scale_buffers*Np*sizeof(uint32_t), 128) : nullptr;
+  if (!hot || !d.clv || (scale_buffers && !d.scaler))
   { fail("bpa_locus_create: out of device memory"); delete l; return nullptr; }
+  d.par = (double *)hot;
+  d.weights = (uint32_t *)(hot + par_bytes);
+  d.tips = (uint8_t *)(hot + par_bytes + w_bytes);
+  d.pmat = jc69 ? (double *)(hot + par_bytes + w_bytes + tip_bytes) : (double *)e->arena.alloc(pm_bytes, 128);
+  if (!d.pmat) { fail("bpa_locus_create: out of device memory"); delete l; return nullptr; }
   d.dip_count = d.dip_map = d.dip_weights = nullptr;
   d.np = sites; d.tips_n = tips; d.rate_cats = rate_cats; d.states = states;
   // 0 JC69, 1..6 closed-form 4x4 models (BPA_DNA_MODEL_*), 100 = eigendecomposition (GTR, amino acids)
@@ -600,7 +610,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
       r.weights = l->dev.weights; r.par = l->dev.par;
       r.np = l->sites; r.tips_n = l->tips; r.rate_cats = l->rate_cats; r.lane0 = lane0[t];
       r.nops = nops_t; r.root_clv = rc[t]; r.root_scaler = rs[t]; r.task = t;
-      r.unphased_length = l->dev.unphased_length; r.pat_off = pat_off[t]; r.locus = l->id; r.pad = 0;
+      r.unphased_length = l->dev.unphased_length; r.pat_off = pat_off[t]; r.locus = l->id; r.pstride = l->dev.pstride;
       task_rec[t] = (uint32_t)recs.size();
       // 48-byte op slots: the update + for each child the entry of this step's branch-length
       // list when that child's P-matrix is updated in this very step (-1 otherwise); at least
@@ -627,7 +637,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
         for (unsigned i = b->mat_off[t]; i < b->mat_off[t+1]; ++i)
         {
           MatRec & m = mrecs[i];
-          m.dst = l->dev.pmat + (size_t)b->mat_pmatrix[i]*l->rate_cats*16;
+          m.dst = l->dev.pmat + (size_t)b->mat_pmatrix[i]*l->rate_cats*l->dev.pstride;
           m.par = l->dev.par; m.rate_cats = l->rate_cats; m.model = l->dev.model; m.entry = i; m.pad = 0;
         }
     }
@@ -1014,8 +1024,15 @@ extern "C" int bpa_locus_get_pmatrix(bpa_locus_t * l, unsigned idx, double * out
 {
   if (!sync_for_access(l)) return 0;
   if (idx >= l->prob_matrices) return fail("pmatrix index out of range");
-  const size_t n = (size_t)l->rate_cats*l->states*l->states;
-  HIPCHK(hipMemcpy(out, l->dev.pmat + idx*n, n*8, hipMemcpyDeviceToHost));
+  const size_t R = l->rate_cats, S = l->states, ps = l->dev.pstride;
+  std::vector<double> tmp(R*ps);
+  HIPCHK(hipMemcpy(tmp.data(), l->dev.pmat + idx*R*ps, tmp.size()*8, hipMemcpyDeviceToHost));
+  if (ps == 2)                                     // JC69: expand (a, b) to the reference's 4x4 layout
+    for (size_t k = 0; k < R; ++k)
+      for (size_t i = 0; i < 16; ++i) out[k*16 + i] = ((i >> 2) == (i & 3)) ? tmp[2*k] : tmp[2*k+1];
+  else
+    std::copy(tmp.begin(), tmp.end(), out);
+  (void)S;
   return 1;
 }
 
@@ -1023,8 +1040,20 @@ extern "C" int bpa_locus_set_pmatrix(bpa_locus_t * l, unsigned idx, const double
 {
   if (!sync_for_access(l)) return 0;
   if (idx >= l->prob_matrices) return fail("pmatrix index out of range");
-  const size_t n = (size_t)l->rate_cats*l->states*l->states;
-  HIPCHK(hipMemcpy(l->dev.pmat + idx*n, in, n*8, hipMemcpyHostToDevice));
+  const size_t R = l->rate_cats, ps = l->dev.pstride;
+  std::vector<double> tmp(R*ps);
+  if (ps == 2)
+    for (size_t k = 0; k < R; ++k)
+    {
+      const double a = in[k*16], b = in[k*16 + 1];
+      for (size_t i = 0; i < 16; ++i)
+        if (in[k*16 + i] != (((i >> 2) == (i & 3)) ? a : b))
+          return fail("bpa_locus_set_pmatrix: a JC69 locus only holds matrices of the form a on the diagonal, b elsewhere");
+      tmp[2*k] = a; tmp[2*k+1] = b;
+    }
+  else
+    std::copy(in, in + R*ps, tmp.begin());
+  HIPCHK(hipMemcpy(l->dev.pmat + idx*R*ps, tmp.data(), tmp.size()*8, hipMemcpyHostToDevice));
   return 1;
 }
 

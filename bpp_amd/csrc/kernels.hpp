@@ -93,6 +93,27 @@ __device__ __forceinline__ void matvec4(const double * __restrict__ m, const dou
   }
 }
 
+__device__ __forceinline__ void matvec4_ab(const double a, const double b, const double v[4], double x[4])
+{
+  // rows (a b b b), (b a b b), (b b a b), (b b b a) in the AVX order (p0+p1)+(p2+p3)
+  x[0] = dot4_pair(a, b, b, b, v);
+  x[1] = dot4_pair(b, a, b, b, v);
+  x[2] = dot4_pair(b, b, a, b, v);
+  x[3] = dot4_pair(b, b, b, a, v);
+}
+
+// P-matrix (matrix index p, rate k) times v; JC69 loci store the (a, b) pair only
+__device__ __forceinline__ void matvec4_p(const double * __restrict__ pmat, const uint32_t pstride,
+                                          const size_t pk, const double v[4], double x[4])
+{
+  if (pstride == 2)
+  {
+    const double2 ab = *reinterpret_cast<const double2 *>(pmat + pk*2);
+    matvec4_ab(ab.x, ab.y, v, x);
+  }
+  else matvec4(pmat + pk*16, v, x);
+}
+
 // node updates of task t for pattern n, then the pattern's root term: returns
 // w[n]*(log(site lh) + scaler*log(2^-256))  — or the bare site likelihood for diploid loci
 __device__ __forceinline__ double walk_s4(const PlanDev & P, const uint32_t t, const uint32_t n,
@@ -112,8 +133,8 @@ __device__ __forceinline__ double walk_s4(const PlanDev & P, const uint32_t t, c
         double lv[4], rv[4], x[4], y[4];
         load_child4(L, op.left_clv,  k, n, lv);
         load_child4(L, op.right_clv, k, n, rv);
-        matvec4(L.pmat + ((size_t)op.left_pmatrix*R  + k)*16, lv, x);
-        matvec4(L.pmat + ((size_t)op.right_pmatrix*R + k)*16, rv, y);
+        matvec4_p(L.pmat, L.pstride, (size_t)op.left_pmatrix*R  + k, lv, x);
+        matvec4_p(L.pmat, L.pstride, (size_t)op.right_pmatrix*R + k, rv, y);
         double2 o0, o1;
         o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
         all_small = all_small && (o0.x < BPA_SCALE_THRESHOLD) && (o0.y < BPA_SCALE_THRESHOLD)
@@ -718,19 +739,19 @@ __device__ __forceinline__ void pmatrix_s4_entry(const PlanDev & P, const uint32
   const double * par = L.par;
   const double t = P.mat_length[e];
   const double rate = par[par_rates(R) + k];
-  double * p = L.pmat + ((size_t)P.mat_pmatrix[e]*R + k)*16;
+  double * p = L.pmat + ((size_t)P.mat_pmatrix[e]*R + k)*L.pstride;
   double q[16];
-  if (L.model == 0 /* JC69, locus.c:2342-2414 */)
+  if (L.model == 0 /* JC69, locus.c:2342-2414: stored as the pair (a, b) */)
   {
     const double bl = t*rate;
-    double a = 1.0, b = 0.0;
+    double2 ab; ab.x = 1.0; ab.y = 0.0;
     if (!(bl < 1e-100))
     {
-      a = (1 + 3*exp(-4*bl/3))/4;
-      b = (1 - a)/3;
+      ab.x = (1 + 3*exp(-4*bl/3))/4;
+      ab.y = (1 - ab.x)/3;
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) q[i] = ((i >> 2) == (i & 3)) ? a : b;
+    *reinterpret_cast<double2 *>(p) = ab;
+    return;
   }
   else if (L.model >= 1 && L.model <= 6)
   {
@@ -784,16 +805,16 @@ __device__ __forceinline__ void pmatrix_s4_rec(const MatRec & m, const double * 
   const double rate = par[par_rates(R) + k];
   double q[16];
   const double bl = t*rate;
-  if (m.model == 0 /* JC69, locus.c:2342-2414 */)
+  if (m.model == 0 /* JC69, locus.c:2342-2414: stored as the pair (a, b) */)
   {
-    double a = 1.0, b = 0.0;
+    double2 ab; ab.x = 1.0; ab.y = 0.0;
     if (!(bl < 1e-100))
     {
-      a = (1 + 3*exp(-4*bl/3))/4;
-      b = (1 - a)/3;
+      ab.x = (1 + 3*exp(-4*bl/3))/4;
+      ab.y = (1 - ab.x)/3;
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) q[i] = ((i >> 2) == (i & 3)) ? a : b;
+    *reinterpret_cast<double2 *>(m.dst + (size_t)k*2) = ab;
+    return;
   }
   else if (m.model >= 1 && m.model <= 6)
   {
@@ -917,8 +938,8 @@ __global__ void __launch_bounds__(BS) step_s4_fused_kernel(const PlanDev P)
           else load_vec4(T, op.left_clv, k, n, lv);
           if (RT && op.right_clv == fwd_clv) { rv[0] = fwd[RT ? k : 0][0]; rv[1] = fwd[RT ? k : 0][1]; rv[2] = fwd[RT ? k : 0][2]; rv[3] = fwd[RT ? k : 0][3]; }
           else load_vec4(T, op.right_clv, k, n, rv);
-          matvec4(T.pmat + ((size_t)op.left_pmatrix*R  + k)*16, lv, x);
-          matvec4(T.pmat + ((size_t)op.right_pmatrix*R + k)*16, rv, y);
+          matvec4_p(T.pmat, T.pstride, (size_t)op.left_pmatrix*R  + k, lv, x);
+          matvec4_p(T.pmat, T.pstride, (size_t)op.right_pmatrix*R + k, rv, y);
           double2 o0, o1;
           o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
           all_small = all_small && (o0.x < BPA_SCALE_THRESHOLD) && (o0.y < BPA_SCALE_THRESHOLD)
@@ -1033,15 +1054,6 @@ __device__ __forceinline__ void jc69_ab(const double len, const double rate, dou
   }
 }
 
-__device__ __forceinline__ void matvec4_ab(const double a, const double b, const double v[4], double x[4])
-{
-  // rows (a b b b), (b a b b), (b b a b), (b b b a) in the AVX order (p0+p1)+(p2+p3)
-  x[0] = dot4_pair(a, b, b, b, v);
-  x[1] = dot4_pair(b, a, b, b, v);
-  x[2] = dot4_pair(b, b, a, b, v);
-  x[3] = dot4_pair(b, b, b, a, v);
-}
-
 __device__ __forceinline__ void expand_code(const uint32_t code, double v[4])
 {
   v[0] = (code & 1u) ? 1.0 : 0.0; v[1] = (code & 2u) ? 1.0 : 0.0;
@@ -1148,13 +1160,13 @@ __global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
         // abl/abr hold either the stored (a, b) pair or, in [0], the fresh branch length
         if (sl[i].left_e < 0)
         {
-          const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.left_pmatrix*16);
+          const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.left_pmatrix*2);
           abl[i][0] = ab.x; abl[i][1] = ab.y;
         }
         else abl[i][0] = P.mat_length[sl[i].left_e];
         if (sl[i].right_e < 0)
         {
-          const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.right_pmatrix*16);
+          const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.right_pmatrix*2);
           abr[i][0] = ab.x; abr[i][1] = ab.y;
         }
         else abr[i][0] = P.mat_length[sl[i].right_e];
@@ -1221,9 +1233,9 @@ __global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
       else load_vec4(T, op.left_clv, 0, n, lv);
       if (op.right_clv == last_clv) { rv[0] = last[0]; rv[1] = last[1]; rv[2] = last[2]; rv[3] = last[3]; }
       else load_vec4(T, op.right_clv, 0, n, rv);
-      if (s.left_e < 0)  { const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.left_pmatrix*16);  al = ab.x; bl_ = ab.y; }
+      if (s.left_e < 0)  { const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.left_pmatrix*2);  al = ab.x; bl_ = ab.y; }
       else jc69_ab(P.mat_length[s.left_e], rate, al, bl_);
-      if (s.right_e < 0) { const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.right_pmatrix*16); ar = ab.x; br = ab.y; }
+      if (s.right_e < 0) { const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.right_pmatrix*2); ar = ab.x; br = ab.y; }
       else jc69_ab(P.mat_length[s.right_e], rate, ar, br);
       matvec4_ab(al, bl_, lv, x);
       matvec4_ab(ar, br, rv, y);
@@ -1279,20 +1291,12 @@ __global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
   }
   BPA_STAMP(P, b, lane, 6);
 
-  // ---- tail: the step's full 4x4 matrices go to HBM for later steps (K4)
+  // ---- tail: the step's P-matrices (their (a, b) pairs) go to HBM for later steps (K4)
   if (have_m0)
   {
-    double a, bb;
-    jc69_ab(m0_len, m0_rate, a, bb);
-    double2 * dst = reinterpret_cast<double2 *>(m0.dst);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-    {
-      double2 v;
-      v.x = ((2*i) >> 2) == ((2*i) & 3) ? a : bb;
-      v.y = ((2*i + 1) >> 2) == ((2*i + 1) & 3) ? a : bb;
-      dst[i] = v;
-    }
+    double2 ab;
+    jc69_ab(m0_len, m0_rate, ab.x, ab.y);
+    *reinterpret_cast<double2 *>(m0.dst) = ab;
     for (uint32_t e = e0 + lane + BS; e < e1; e += BS) pmatrix_s4_rec(P.mat_recs[e], P.mat_length, 0);
   }
   BPA_STAMP(P, b, lane, 7);
