@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--tape-iters", type=int, default=4, help="distinct A00 iterations in the resident tape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing-events", action="store_true")
+    ap.add_argument("--host-in-loop", action="store_true",
+                    help="copy the per-locus lnL of every step back to the host before launching the next "
+                         "(what a host-resident accept/reject needs; PCIe-inclusive rate, reported in DESIGN.md)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -193,6 +196,11 @@ def main():
         segments.append(segs)
 
     def run_iteration(i):
+        if args.host_in_loop:
+            for p in plans[i % len(plans)]:
+                p.launch()
+                p.lnl()                      # sync + 8 B/locus D2H, as host MCMC control would need
+            return
         for seq, reduce_after in segments[i % len(segments)]:
             seq.launch()
             if reduce_after:

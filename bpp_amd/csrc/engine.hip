@@ -13,6 +13,7 @@
 #include <vector>
 #include <algorithm>
 #include <memory>
+#include <mutex>
 
 #include "bpp_amd.h"
 #include "device_types.hpp"
@@ -116,6 +117,9 @@ struct bpa_engine
   size_t slots_used = 0;
   double acc_ms[3] = {0, 0, 0};
   unsigned long acc_launches = 0;
+  // calls for different loci may come from different host threads (threads.c:87-200 shards loci
+  // over pthreads): engine-wide state (dirty list, locus table, stream order, timing) is serialised
+  std::recursive_mutex mtx;
 };
 
 struct bpa_plan
@@ -205,6 +209,7 @@ extern "C" void bpa_engine_destroy(bpa_engine_t * e)
 
 extern "C" int bpa_engine_synchronize(bpa_engine_t * e)
 {
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   if (!set_device(e)) return 0;
   HIPCHK(hipStreamSynchronize(e->stream));
   return 1;
@@ -212,6 +217,7 @@ extern "C" int bpa_engine_synchronize(bpa_engine_t * e)
 
 extern "C" void bpa_engine_set_options(bpa_engine_t * e, int usedata, double bfbeta)
 {
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   e->usedata = usedata; e->bfbeta = bfbeta;
 }
 
@@ -228,6 +234,7 @@ extern "C" bpa_locus_t * bpa_locus_create(bpa_engine_t * e, unsigned dtype, unsi
                                           unsigned scale_buffers, unsigned attributes)
 {
   if (!e) { fail("bpa_locus_create: null engine"); return nullptr; }
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   if (!((dtype == BPA_DATA_DNA && states == 4) || (dtype == BPA_DATA_AA && states == 20)))
   { fail("bpa_locus_create: only DNA (4 states) and amino-acid (20 states) data"); return nullptr; }
   if (dtype == BPA_DATA_DNA && model > BPA_DNA_MODEL_GTR)
@@ -307,6 +314,7 @@ extern "C" void bpa_locus_destroy(bpa_locus_t * l)
 extern "C" int bpa_set_tip_states(bpa_locus_t * l, unsigned tip_index, const unsigned * map,
                                   const char * sequence)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   if (tip_index >= l->tips) return fail("bpa_set_tip_states: tip index out of range");
   const size_t Np = l->sites;
   for (size_t n = 0; n < Np; ++n)
@@ -322,12 +330,14 @@ extern "C" int bpa_set_tip_states(bpa_locus_t * l, unsigned tip_index, const uns
 
 extern "C" void bpa_set_pattern_weights(bpa_locus_t * l, const unsigned * w)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   std::copy(w, w + l->sites, l->weights.begin());
   l->weights_dirty = true; mark_dirty(l);
 }
 
 extern "C" void bpa_set_frequencies(bpa_locus_t * l, unsigned index, const double * f)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   const unsigned S = l->states, R = l->rate_cats;
   std::copy(f, f + S, l->par.begin() + par_matrix(R, S, index) + pm_freqs(S));
   l->eigen_valid[index] = 0;                    // locus.c:895
@@ -336,6 +346,7 @@ extern "C" void bpa_set_frequencies(bpa_locus_t * l, unsigned index, const doubl
 
 extern "C" void bpa_set_subst_params(bpa_locus_t * l, unsigned index, const double * p)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   const unsigned S = l->states, R = l->rate_cats;
   std::copy(p, p + S*(S-1)/2, l->par.begin() + par_matrix(R, S, index) + pm_subst(S));
   l->eigen_valid[index] = 0;                    // locus.c:883
@@ -344,18 +355,21 @@ extern "C" void bpa_set_subst_params(bpa_locus_t * l, unsigned index, const doub
 
 extern "C" void bpa_set_category_rates(bpa_locus_t * l, const double * rates)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   std::copy(rates, rates + l->rate_cats, l->par.begin() + par_rates(l->rate_cats));
   l->par_dirty = true; mark_dirty(l);
 }
 
 extern "C" void bpa_set_category_weights(bpa_locus_t * l, const double * w)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   std::copy(w, w + l->rate_cats, l->par.begin() + par_rate_weights(l->rate_cats));
   l->par_dirty = true; mark_dirty(l);
 }
 
 extern "C" void bpa_set_param_indices(bpa_locus_t * l, const unsigned * idx)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   for (unsigned k = 0; k < l->rate_cats; ++k) l->par[par_param_idx(l->rate_cats) + k] = (double)idx[k];
   l->par_dirty = true; mark_dirty(l);
 }
@@ -365,6 +379,7 @@ extern "C" int bpa_set_diploid(bpa_locus_t * l, int unphased_length,
                                const unsigned long * mapping, unsigned long mapping_len,
                                const unsigned * unphased_weights)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   bpa_engine * e = l->eng;
   if (!set_device(e)) return 0;
   std::vector<uint32_t> cnt(unphased_length), map(mapping_len), w(unphased_length);
@@ -788,6 +803,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
 extern "C" bpa_plan_t * bpa_plan_create(bpa_engine_t * e, const bpa_batch_t * b)
 {
   if (!e || !b) { fail("bpa_plan_create: null argument"); return nullptr; }
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   bpa_plan * p = new bpa_plan();
   if (!plan_build(p, e, b)) { delete p; return nullptr; }
   return p;
@@ -796,13 +812,16 @@ extern "C" bpa_plan_t * bpa_plan_create(bpa_engine_t * e, const bpa_batch_t * b)
 extern "C" void bpa_plan_destroy(bpa_plan_t * p)
 {
   if (!p) return;
+  std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
   (void)hipSetDevice(p->eng->device);
+  g_cur_device = p->eng->device;
   (void)hipStreamSynchronize(p->eng->stream);
   delete p;
 }
 
 extern "C" int bpa_plan_set_lengths(bpa_plan_t * p, const double * len)
 {
+  std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
   if (!set_device(p->eng)) return 0;
   HIPCHK(hipMemcpyAsync(p->mat_length.p, len, p->pd.nmat*sizeof(double), hipMemcpyHostToDevice, p->eng->stream));
   HIPCHK(hipStreamSynchronize(p->eng->stream));
@@ -811,6 +830,7 @@ extern "C" int bpa_plan_set_lengths(bpa_plan_t * p, const double * len)
 
 extern "C" int bpa_plan_launch(bpa_plan_t * p)
 {
+  std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
   if (!p->eng->usedata) return 1;                 // opt_usedata == 0 (locus.c:2424)
   return plan_launch_mode(p, 1 | 2 | (p->has_lnl ? 4 : 0));
 }
@@ -819,6 +839,7 @@ extern "C" int bpa_plan_launch(bpa_plan_t * p)
 // out[0..7]: mean over workgroups of (stamp i - earliest stamp 0) in microseconds; out[8]: span
 extern "C" int bpa_plan_probe(bpa_plan_t * p, double * out)
 {
+  std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
   bpa_engine * e = p->eng;
   if (!set_device(e) || !p->fused_bs) return fail("probe: fused plans only");
   const unsigned B = p->pd.nblocks;
@@ -852,6 +873,7 @@ extern "C" int bpa_plans_launch(bpa_plan_t * const * plans, unsigned count)
 
 extern "C" int bpa_plan_get_lnl(bpa_plan_t * p, double * lnl)
 {
+  std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
   bpa_engine * e = p->eng;
   if (!set_device(e)) return 0;
   if (!e->usedata) { std::fill(lnl, lnl + p->pd.ntasks, 0.0); return 1; }
@@ -864,6 +886,7 @@ extern "C" void * bpa_plan_lnl_device(bpa_plan_t * p) { return p->lnl.p; }
 
 extern "C" int bpa_plan_enable_sum(bpa_plan_t * p, void * device_out)
 {
+  std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
   if (!set_device(p->eng)) return 0;
   if (device_out) { p->sum_out = (double *)device_out; return 1; }
   if (!p->lnl_sum.reserve(1)) return fail("out of device memory (plan)");
@@ -873,6 +896,7 @@ extern "C" int bpa_plan_enable_sum(bpa_plan_t * p, void * device_out)
 
 extern "C" int bpa_plan_get_sum(bpa_plan_t * p, double * sum)
 {
+  std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
   bpa_engine * e = p->eng;
   if (!set_device(e)) return 0;
   if (!p->sum_out) return fail("bpa_plan_get_sum: call bpa_plan_enable_sum first");
@@ -904,6 +928,7 @@ extern "C" int bpa_batch_evaluate(bpa_engine_t * e, const bpa_batch_t * b, doubl
 
 extern "C" void bpa_engine_enable_timing(bpa_engine_t * e, int on)
 {
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   (void)hipSetDevice(e->device);
   (void)timing_drain(e);
   e->timing = on != 0;
@@ -913,6 +938,7 @@ extern "C" void bpa_engine_enable_timing(bpa_engine_t * e, int on)
 extern "C" int bpa_engine_timing(bpa_engine_t * e, double * pmatrix_ms, double * partials_ms,
                                  double * reduce_ms, unsigned long * launches)
 {
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   if (!set_device(e)) return 0;
   if (!timing_drain(e)) return 0;
   if (pmatrix_ms) *pmatrix_ms = e->acc_ms[0];
@@ -944,12 +970,14 @@ static int scratch_run(bpa_locus * l, const unsigned * pm_idx, const double * le
 extern "C" int bpa_locus_update_matrices(bpa_locus_t * l, const unsigned * pmatrix_indices,
                                          const double * branch_lengths, unsigned count)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   if (!l->eng->usedata || !count) return 1;
   return scratch_run(l, pmatrix_indices, branch_lengths, count, nullptr, 0, false, 0, -1);
 }
 
 extern "C" int bpa_locus_update_partials(bpa_locus_t * l, const bpa_op_t * ops, unsigned count)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   if (!l->eng->usedata || !count) return 1;
   return scratch_run(l, nullptr, nullptr, 0, ops, count, false, 0, -1);
 }
@@ -957,6 +985,7 @@ extern "C" int bpa_locus_update_partials(bpa_locus_t * l, const bpa_op_t * ops, 
 extern "C" double bpa_locus_root_loglikelihood(bpa_locus_t * l, unsigned root_clv, int root_scaler,
                                                const unsigned * freqs_indices, double * persite_lnl)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   bpa_engine * e = l->eng;
   if (!e->usedata) return 0.0;
   if (freqs_indices)
@@ -984,6 +1013,7 @@ static int sync_for_access(bpa_locus * l)
 
 extern "C" int bpa_locus_get_clv(bpa_locus_t * l, unsigned idx, double * out)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   if (!sync_for_access(l)) return 0;
   const size_t S = l->states, R = l->rate_cats, Np = l->sites;
   if (idx >= l->tips + l->clv_buffers) return fail("clv index out of range");
@@ -1008,6 +1038,7 @@ extern "C" int bpa_locus_get_clv(bpa_locus_t * l, unsigned idx, double * out)
 
 extern "C" int bpa_locus_set_clv(bpa_locus_t * l, unsigned idx, const double * in)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   if (!sync_for_access(l)) return 0;
   const size_t S = l->states, R = l->rate_cats, Np = l->sites;
   if (idx < l->tips || idx >= l->tips + l->clv_buffers) return fail("bpa_locus_set_clv: only inner buffers can be written (tips are state codes)");
@@ -1022,6 +1053,7 @@ extern "C" int bpa_locus_set_clv(bpa_locus_t * l, unsigned idx, const double * i
 
 extern "C" int bpa_locus_get_pmatrix(bpa_locus_t * l, unsigned idx, double * out)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   if (!sync_for_access(l)) return 0;
   if (idx >= l->prob_matrices) return fail("pmatrix index out of range");
   const size_t R = l->rate_cats, S = l->states, ps = l->dev.pstride;
@@ -1038,6 +1070,7 @@ extern "C" int bpa_locus_get_pmatrix(bpa_locus_t * l, unsigned idx, double * out
 
 extern "C" int bpa_locus_set_pmatrix(bpa_locus_t * l, unsigned idx, const double * in)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   if (!sync_for_access(l)) return 0;
   if (idx >= l->prob_matrices) return fail("pmatrix index out of range");
   const size_t R = l->rate_cats, ps = l->dev.pstride;
@@ -1059,6 +1092,7 @@ extern "C" int bpa_locus_set_pmatrix(bpa_locus_t * l, unsigned idx, const double
 
 extern "C" int bpa_locus_get_scaler(bpa_locus_t * l, unsigned idx, unsigned * out)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   if (!sync_for_access(l)) return 0;
   if (idx >= l->scale_buffers) return fail("scaler index out of range");
   HIPCHK(hipMemcpy(out, l->dev.scaler + (size_t)idx*l->sites, l->sites*4, hipMemcpyDeviceToHost));
@@ -1067,6 +1101,7 @@ extern "C" int bpa_locus_get_scaler(bpa_locus_t * l, unsigned idx, unsigned * ou
 
 extern "C" int bpa_locus_get_eigen(bpa_locus_t * l, unsigned index, double * evecs, double * ievecs, double * evals)
 {
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   if (!sync_for_access(l)) return 0;
   if (index >= l->rate_matrices) return fail("rate matrix index out of range");
   const unsigned S = l->states, R = l->rate_cats;
@@ -1087,6 +1122,7 @@ extern "C" int bpa_core_update_pmatrix(bpa_engine_t * e, double ** pmatrix, unsi
                                        double * const * inv_eigenvecs, unsigned count,
                                        unsigned attrib)
 {
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   (void)attrib;
   if (!set_device(e)) return 0;
   if (states != 4 && states != 20) return fail("bpa_core_update_pmatrix: 4 or 20 states");
@@ -1133,6 +1169,7 @@ extern "C" int bpa_update_eigen(bpa_engine_t * e, double * eigenvecs, double * i
                                 double * eigenvals, const double * freqs,
                                 const double * subst_params, unsigned states)
 {
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   if (!set_device(e)) return 0;
   if (states != 4 && states != 20) return fail("bpa_update_eigen: 4 or 20 states");
   const size_t S = states;

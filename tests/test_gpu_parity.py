@@ -438,3 +438,37 @@ def test_closed_form_dna_models(engine, model):
         g_, w_ = loc.get_pmatrix(nd.pmatrix_index), ol.pmat[nd.node_index]
         assert ulps(g_, w_).max() <= PMAT_ULPS or np.abs(g_ - w_).max() < PMAT_ATOL
         assert np.allclose(g_.sum(-1), 1.0, atol=1e-14)
+
+
+def test_concurrent_calls_on_different_loci(engine):
+    """the reference's threading contract (threads.c:87-200): calls for different
+    loci may come concurrently from different host threads"""
+    import threading
+    rng = np.random.default_rng(8)
+    cases = []
+    for i in range(16):
+        tips, sites = int(rng.integers(3, 9)), int(rng.integers(5, 80))
+        seqs = rand_seqs(tips, sites, NT, rng, extra="-")
+        w = rng.integers(1, 100, sites)
+        left, right, times, root = rand_tree(tips, rng, 0.05)
+        loc = make_locus(engine, 4, 1, "jc69", seqs, w)
+        gt = GTree(left, right, times, root)
+        want = O.OracleLocus(4, 1, seqs, w).full_lnl(left, right, times, root)
+        cases.append((loc, gt, want))
+    errs = []
+
+    def work(chunk):
+        try:
+            for _ in range(20):
+                for loc, gt, want in chunk:
+                    got = full_eval(loc, gt)
+                    if rel(got, want) > LNL_RTOL_TIGHT:
+                        errs.append((got, want))
+        except Exception as ex:          # noqa: BLE001
+            errs.append(ex)
+    ts = [threading.Thread(target=work, args=(cases[i::4],)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs[:3]
