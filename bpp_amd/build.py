@@ -14,6 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libbpp_amd.so")
+HOST_OUT = os.path.join(HERE, "libbpp_amd_host.so")      # host-side MCMC control in C (gcc), links libbpp_amd.so
+HOST_SRC = os.path.join(CSRC, "host", "a00_driver.c")
 SOURCES = ["engine.hip", "host_math.cpp"]
 DEPS = ["kernels.hpp", "device_types.hpp", os.path.join(ROOT, "include", "bpp_amd.h")]
 
@@ -34,8 +36,21 @@ def stale():
     return any(os.path.getmtime(f) > t for f in files)
 
 
+def build_host(force=False, verbose=False):
+    deps = [HOST_SRC, os.path.join(ROOT, "include", "bpp_amd_host.h"), os.path.join(ROOT, "include", "bpp_amd.h"), OUT]
+    if not force and os.path.exists(HOST_OUT) and all(os.path.getmtime(f) <= os.path.getmtime(HOST_OUT) for f in deps):
+        return HOST_OUT
+    cmd = ["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"),
+           HOST_SRC, "-o", HOST_OUT, "-L", HERE, "-lbpp_amd", "-Wl,-rpath,$ORIGIN", "-lm"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return HOST_OUT
+
+
 def build(force=False, verbose=False):
     if not force and not stale():
+        build_host(False, verbose)
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
            "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-Wno-pass-failed",
@@ -44,6 +59,7 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    build_host(True, verbose)
     return OUT
 
 

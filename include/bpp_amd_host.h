@@ -1,0 +1,80 @@
+/*
+ * bpp_amd_host.h — host-side MCMC control in C over the likelihood boundary.
+ *
+ * BASELINE.json north_star: "host MCMC control flow stays in C and calls HIP through a thin
+ * C-ABI shim".  This is that host side, reduced to what drives the likelihood path: a
+ * lock-step gene-tree sampler that, like BPP's A00 iteration (method.c:5490-5602), sweeps
+ * every locus with gene-node age proposals (GAGE, gtree.c:4585), subtree prune/regraft
+ * proposals (GSPR, gtree.c:6531) and an all-loci mixing step (prop_mixing.c:52), keeps the
+ * gnode_t fields the reference keeps (left/right/parent/time/clv_index/scaler_index/
+ * pmatrix_index), toggles the double buffers before every evaluation exactly as the
+ * reference does (SWAP_CLV_INDEX / SWAP_PMAT_INDEX / SWAP_SCALER_INDEX, locus.c:24-26) and
+ * toggles back on rejection.  "Step j of every locus" is handed to a likelihood back-end as
+ * one batch.  Two back-ends exist: libbpp_amd.so (this repo's product, a00_backend_hip) and,
+ * for tests only, the real reference's locus API (oracle/ref_shim.c: ref_backend_eval) —
+ * the same driver, the same seeds, the same trajectory on both is the drop-in check.
+ *
+ * The acceptance rule is Metropolis on the likelihood ratio (times the proposal's Hastings
+ * factor for the root-age and mixing multipliers); BPP's MSC prior density is out of scope
+ * (SURVEY.md §8f rank 1).
+ */
+#ifndef BPP_AMD_HOST_H
+#define BPP_AMD_HOST_H
+
+#include "bpp_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* gene tree of one locus: tips 0..tips-1, inner nodes after; the root node object stays
+   the root (gtree.c:6129-6175), so pmatrix indices never collide */
+typedef struct a00_tree
+{
+  int      tips, n, root;
+  int *    left, * right, * parent;      /* [n], -1 = none          */
+  double * time;                         /* [n] node ages           */
+  int *    clv, * pmat, * scaler;        /* [n] current buffer indices (gnode_t fields) */
+  double   rate_mui;                     /* gtree_t.rate_mui        */
+  double   lnl;                          /* current log-likelihood  */
+} a00_tree_t;
+
+/* one proposal step for a set of loci, in node terms */
+typedef struct a00_step
+{
+  unsigned             nloci;
+  const unsigned *     locus;            /* [nloci] index of the locus            */
+  a00_tree_t * const * tree;             /* [nloci] its tree, proposal installed  */
+  const unsigned *     br_off;           /* [nloci+1] */
+  const int *          branches;         /* child node ids whose P-matrix changes */
+  const unsigned *     nd_off;           /* [nloci+1] */
+  const int *          nodes;            /* inner node ids to recompute, children first */
+} a00_step_t;
+
+typedef int (*a00_eval_fn)(void * ctx, const a00_step_t * step, double * lnl /* [nloci] */);
+
+typedef struct a00_driver a00_driver_t;
+
+a00_driver_t * a00_create(unsigned nloci, a00_eval_fn eval, void * ctx, unsigned long seed);
+void           a00_destroy(a00_driver_t *);
+/* install the start tree of locus i (arrays are copied); scaling != 0 gives inner nodes scalers */
+int            a00_set_tree(a00_driver_t *, unsigned i, int tips, const int * left, const int * right,
+                            const double * times, int root, int scaling);
+const a00_tree_t * a00_tree(const a00_driver_t *, unsigned i);
+/* start-up evaluation: all matrices, all partials, lnL (method.c:4285-4297) */
+int            a00_initialize(a00_driver_t *);
+/* one iteration: GAGE over inner nodes, GSPR over non-root nodes, one MIX step */
+int            a00_iterate(a00_driver_t *);
+double         a00_total_lnl(const a00_driver_t *);
+void           a00_counters(const a00_driver_t *, unsigned long * proposals, unsigned long * accepted,
+                            unsigned long * steps);
+
+/* likelihood back-end on libbpp_amd.so: loci[i] must have been created with the buffer
+   counts of method.c:4110-4146 (2*inner CLVs, 2*edges P-matrices, 2*inner scalers)       */
+typedef struct a00_hip_ctx { bpa_engine_t * engine; bpa_locus_t ** loci; } a00_hip_ctx_t;
+int a00_backend_hip(void * ctx /* a00_hip_ctx_t* */, const a00_step_t * step, double * lnl);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -361,3 +361,43 @@ double ref_run_tape(refctx_t * c, unsigned nsteps,
   clock_gettime(CLOCK_MONOTONIC, &t1);
   return (t1.tv_sec - t0.tv_sec) + 1e-9*(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---------------------------------------------------------------------------
+ * Likelihood back-end for the C host driver (include/bpp_amd_host.h, a00_eval_fn) on the
+ * REAL reference: the driver's tree state is copied onto gnode_t and the step goes through
+ * locus_update_matrices / locus_update_partials / locus_root_loglikelihood.  ctx = array of
+ * refctx_t*, one per locus.  Tests only: the same driver and seeds must give the same
+ * trajectory here and on libbpp_amd.so.
+ * ------------------------------------------------------------------------- */
+#include "bpp_amd_host.h"
+
+int ref_backend_eval(void * vctx, const a00_step_t * s, double * lnl)
+{
+  refctx_t ** ctx = (refctx_t **)vctx;
+  unsigned i, j, k;
+  for (i = 0; i < s->nloci; ++i)
+  {
+    refctx_t * c = ctx[s->locus[i]];
+    const a00_tree_t * t = s->tree[i];
+    int x;
+    for (x = 0; x < t->n; ++x)
+    {
+      gnode_t * g = c->nodes + x;
+      g->left   = t->left[x]   >= 0 ? c->nodes + t->left[x]   : NULL;
+      g->right  = t->right[x]  >= 0 ? c->nodes + t->right[x]  : NULL;
+      g->parent = t->parent[x] >= 0 ? c->nodes + t->parent[x] : NULL;
+      g->time = t->time[x];
+      g->clv_index = (unsigned int)t->clv[x];
+      g->scaler_index = t->scaler[x];
+      g->pmatrix_index = (unsigned int)t->pmat[x];
+    }
+    c->gtree->root = c->nodes + t->root;
+    c->gtree->rate_mui = t->rate_mui;
+    for (k = 0, j = s->br_off[i]; j < s->br_off[i+1]; ++j) c->trav[k++] = c->nodes + s->branches[j];
+    locus_update_matrices(c->locus, c->gtree, c->trav, NULL, 0, k);
+    for (k = 0, j = s->nd_off[i]; j < s->nd_off[i+1]; ++j) c->trav[k++] = c->nodes + s->nodes[j];
+    locus_update_partials(c->locus, c->trav, k);
+    lnl[i] = locus_root_loglikelihood(c->locus, c->gtree->root, c->locus->param_indices, NULL);
+  }
+  return 1;
+}

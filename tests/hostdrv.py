@@ -1,0 +1,108 @@
+"""ctypes harness for the C host driver (include/bpp_amd_host.h, bpp_amd/libbpp_amd_host.so)."""
+import ctypes as C
+import os
+import numpy as np
+
+import bpp_amd
+from bpp_amd import build as _build
+
+HOST_SO = _build.HOST_OUT
+
+
+class A00Tree(C.Structure):
+    _fields_ = [("tips", C.c_int), ("n", C.c_int), ("root", C.c_int),
+                ("left", C.POINTER(C.c_int)), ("right", C.POINTER(C.c_int)), ("parent", C.POINTER(C.c_int)),
+                ("time", C.POINTER(C.c_double)),
+                ("clv", C.POINTER(C.c_int)), ("pmat", C.POINTER(C.c_int)), ("scaler", C.POINTER(C.c_int)),
+                ("rate_mui", C.c_double), ("lnl", C.c_double)]
+
+
+class HipCtx(C.Structure):
+    _fields_ = [("engine", C.c_void_p), ("loci", C.POINTER(C.c_void_p))]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        bpp_amd.lib()                      # libbpp_amd.so first (rpath $ORIGIN also finds it)
+        L = C.CDLL(HOST_SO)
+        L.a00_create.restype = C.c_void_p
+        L.a00_create.argtypes = [C.c_uint, C.c_void_p, C.c_void_p, C.c_ulong]
+        L.a00_destroy.argtypes = [C.c_void_p]
+        L.a00_set_tree.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_double), C.c_int, C.c_int]
+        L.a00_tree.restype = C.POINTER(A00Tree)
+        L.a00_tree.argtypes = [C.c_void_p, C.c_uint]
+        L.a00_initialize.argtypes = [C.c_void_p]
+        L.a00_iterate.argtypes = [C.c_void_p]
+        L.a00_total_lnl.restype = C.c_double
+        L.a00_total_lnl.argtypes = [C.c_void_p]
+        L.a00_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]
+        _lib = L
+    return _lib
+
+
+class Driver:
+    def __init__(self, data, eval_fn_addr, ctx_addr, seed=1, scaling=False):
+        L = lib()
+        self.n = len(data)
+        self.h = C.c_void_p(L.a00_create(self.n, eval_fn_addr, ctx_addr, seed))
+        for i, d in enumerate(data):
+            l = np.ascontiguousarray(d["left"], dtype=np.int32)
+            r = np.ascontiguousarray(d["right"], dtype=np.int32)
+            t = np.ascontiguousarray(d["times"], dtype=np.float64)
+            ok = L.a00_set_tree(self.h, i, len(d["seqs"]), l.ctypes.data_as(C.POINTER(C.c_int)),
+                                r.ctypes.data_as(C.POINTER(C.c_int)), t.ctypes.data_as(C.POINTER(C.c_double)),
+                                int(d["root"]), int(scaling))
+            assert ok
+
+    def initialize(self):
+        assert lib().a00_initialize(self.h), bpp_amd.lib().bpa_last_error()
+
+    def iterate(self):
+        assert lib().a00_iterate(self.h), bpp_amd.lib().bpa_last_error()
+
+    def total_lnl(self):
+        return lib().a00_total_lnl(self.h)
+
+    def counters(self):
+        p, a, s = C.c_ulong(), C.c_ulong(), C.c_ulong()
+        lib().a00_counters(self.h, C.byref(p), C.byref(a), C.byref(s))
+        return p.value, a.value, s.value
+
+    def tree(self, i):
+        t = lib().a00_tree(self.h, i).contents
+        n = t.n
+        g = lambda p: [p[k] for k in range(n)]
+        return dict(tips=t.tips, root=t.root, left=g(t.left), right=g(t.right), parent=g(t.parent),
+                    time=g(t.time), clv=g(t.clv), pmat=g(t.pmat), scaler=g(t.scaler), lnl=t.lnl)
+
+    def close(self):
+        if self.h:
+            lib().a00_destroy(self.h)
+            self.h = None
+
+
+def reference_driver(data, seed=1, scaling=False):
+    """driver on the REAL reference's locus API (oracle/ref_shim.c: ref_backend_eval)"""
+    import oraclelib as O
+    import tape
+    rls = [tape.ref_locus_for(d, scaling) for d in data]
+    arr = (C.c_void_p * len(rls))(*[rl.h for rl in rls])
+    fn = C.cast(O.ref().ref_backend_eval, C.c_void_p)
+    drv = Driver(data, fn, C.cast(arr, C.c_void_p), seed, scaling)
+    drv._keep = (rls, arr)
+    return drv
+
+
+def hip_driver(engine, loci, data, seed=1, scaling=False):
+    """driver on libbpp_amd.so (a00_backend_hip)"""
+    arr = (C.c_void_p * len(loci))(*[l.h for l in loci])
+    ctx = HipCtx(engine.h, arr)
+    fn = C.cast(lib().a00_backend_hip, C.c_void_p)
+    drv = Driver(data, fn, C.cast(C.pointer(ctx), C.c_void_p), seed, scaling)
+    drv._keep = (arr, ctx)
+    return drv

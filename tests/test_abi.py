@@ -84,3 +84,17 @@ def test_compress_edge_cases():
     assert sorted(w) == [2, 2, 2, 2]
     with pytest.raises(bpp_amd.BpaError):
         bpp_amd.compress_site_patterns(["AC!T", "ACGT"], True, False)   # illegal character
+
+
+def test_host_driver_library_exports():
+    """bpp_amd/libbpp_amd_host.so (C host side) exports what include/bpp_amd_host.h declares"""
+    import ctypes
+    from bpp_amd import build
+    bpp_amd.lib()
+    L = ctypes.CDLL(build.HOST_OUT)
+    src = open(os.path.join(ROOT, "include", "bpp_amd_host.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(a00_[a-z0-9_]+)\s*\(", src)))
+    assert "a00_iterate" in names and "a00_backend_hip" in names
+    for n in names:
+        assert hasattr(L, n), n

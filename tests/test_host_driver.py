@@ -1,0 +1,48 @@
+"""The C host driver (host MCMC control in C, include/bpp_amd_host.h) on the REAL
+reference's locus API: it keeps trees valid, its incremental log-likelihoods equal a
+from-scratch evaluation (the reference's check_logl invariant, method.c:4699-4717), and it
+accepts/rejects.  GPU twin: tests/test_gpu_host_driver.py."""
+import numpy as np
+import pytest
+
+from bpp_amd import synth
+import oraclelib as O
+import hostdrv
+from common import rel
+
+pytestmark = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+
+
+@pytest.mark.parametrize("taxa,model,R,scaling", [(4, "jc69", 1, False), (8, "gtr", 4, False), (6, "jc69", 2, True)])
+def test_driver_on_reference_backend(taxa, model, R, scaling):
+    data = synth.make_dataset(10, 300, taxa, model, R, seed=31, theta=0.004 if taxa == 6 else None)
+    drv = hostdrv.reference_driver(data, seed=7, scaling=scaling)
+    drv.initialize()
+    l0 = drv.total_lnl()
+    want0 = sum(O.OracleLocus(d["states"], R, d["seqs"], d["weights"], model=model,
+                              freqs=None if model == "jc69" else d["freqs"],
+                              qrates=None if model == "jc69" else d["exch"], rates=d["rates"],
+                              scaling=scaling).full_lnl(d["left"], d["right"], d["times"], d["root"]) for d in data)
+    assert rel(l0, want0) < 1e-13
+    for _ in range(4):
+        drv.iterate()
+    props, acc, steps = drv.counters()
+    assert steps == 1 + 4 * ((taxa - 1) + (2 * taxa - 2) + 1)
+    assert 0.05 < acc / props < 0.98
+    total = 0.0
+    for i, d in enumerate(data):
+        t = drv.tree(i)
+        # valid tree, root object still the root, buffers in their own pairs
+        assert t["root"] == 2 * taxa - 2 and t["parent"][t["root"]] == -1
+        for v in range(taxa, 2 * taxa - 1):
+            assert t["time"][v] > max(t["time"][t["left"][v]], t["time"][t["right"][v]])
+            assert t["clv"][v] in (v, v + taxa - 1)
+        ol = O.OracleLocus(d["states"], R, d["seqs"], d["weights"], model=model,
+                           freqs=None if model == "jc69" else d["freqs"],
+                           qrates=None if model == "jc69" else d["exch"], rates=d["rates"], scaling=scaling)
+        full = ol.full_lnl(t["left"], t["right"], t["time"], t["root"])
+        assert rel(t["lnl"], full) < 1e-12
+        total += t["lnl"]
+    assert rel(drv.total_lnl(), total) < 1e-13
+    assert drv.total_lnl() > l0 - 50        # a likelihood-driven sampler does not run away downhill
+    drv.close()
