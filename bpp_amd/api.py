@@ -101,7 +101,16 @@ def lib():
         "bpa_plan_get_sum": (i, [vp, dp]),
         "bpa_batch_evaluate": (i, [vp, C.POINTER(Batch), dp]),
         "bpa_plan_work": (i, [vp, dp, dp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
+        "bpa_sampler_create": (vp, [vp, C.POINTER(vp), u, C.c_ulong]),
+        "bpa_sampler_destroy": (None, [vp]),
+        "bpa_sampler_set_tree": (i, [vp, u, C.POINTER(i), C.POINTER(i), dp, i]),
+        "bpa_sampler_initialize": (i, [vp]),
+        "bpa_sampler_iterate": (i, [vp, u]),
+        "bpa_sampler_get_tree": (i, [vp, u, C.POINTER(i), C.POINTER(i), C.POINTER(i), dp, C.POINTER(i),
+                                     C.POINTER(i), C.POINTER(i), dp]),
+        "bpa_sampler_summary": (i, [vp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
         "bpa_engine_enable_timing": (None, [vp, i]),
+        "bpa_engine_set_timing_stride": (None, [vp, u]),
         "bpa_engine_timing": (i, [vp, dp, dp, dp, C.POINTER(C.c_ulong)]),
     }
     for name, (res, args) in sig.items():
@@ -124,7 +133,9 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
             "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate",
             "bpa_plan_enable_sum", "bpa_plan_get_sum", "bpa_plans_launch",
-            "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing"]
+            "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride",
+            "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
+            "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary"]
 
 
 def _err():
@@ -198,7 +209,8 @@ class Engine:
     def synchronize(self):
         _chk(lib().bpa_engine_synchronize(self.h))
 
-    def enable_timing(self, on=True):
+    def enable_timing(self, on=True, stride=1):
+        lib().bpa_engine_set_timing_stride(self.h, int(stride))
         lib().bpa_engine_enable_timing(self.h, int(on))
 
     def timing(self):
@@ -427,6 +439,54 @@ def locus_update_partials(locus, traversal, count=None):
 def locus_root_loglikelihood(locus, root, persite=False):
     """locus_root_loglikelihood (locus.c:2573)."""
     return locus.root_loglikelihood(root.clv_index, root.scaler_index, persite)
+
+
+class Sampler:
+    """device-resident per-locus proposal control (bpa_sampler_t)"""
+
+    def __init__(self, engine, loci, data, seed=1):
+        L = lib()
+        self.engine, self.n = engine, len(loci)
+        self._arr = (C.c_void_p * self.n)(*[l.h for l in loci])
+        self.h = L.bpa_sampler_create(engine.h, self._arr, self.n, seed)
+        if not self.h:
+            raise BpaError(_err())
+        ip = C.POINTER(C.c_int)
+        for k, d in enumerate(data):
+            l = np.ascontiguousarray(d["left"], dtype=np.int32)
+            r = np.ascontiguousarray(d["right"], dtype=np.int32)
+            t = _f64(d["times"])
+            _chk(L.bpa_sampler_set_tree(self.h, k, l.ctypes.data_as(ip), r.ctypes.data_as(ip), _dp(t), int(d["root"])))
+        self.ntips = [len(d["seqs"]) for d in data]
+
+    def initialize(self):
+        _chk(lib().bpa_sampler_initialize(self.h))
+
+    def iterate(self, iterations=1):
+        _chk(lib().bpa_sampler_iterate(self.h, iterations))
+
+    def tree(self, k):
+        n = 2 * self.ntips[k] - 1
+        ip = C.POINTER(C.c_int)
+        a = [np.zeros(n, dtype=np.int32) for _ in range(5)]
+        t = np.zeros(n)
+        root, lnl = C.c_int(), C.c_double()
+        _chk(lib().bpa_sampler_get_tree(self.h, k, a[0].ctypes.data_as(ip), a[1].ctypes.data_as(ip),
+                                        a[2].ctypes.data_as(ip), _dp(t), a[3].ctypes.data_as(ip),
+                                        a[4].ctypes.data_as(ip), C.byref(root), C.byref(lnl)))
+        return dict(left=list(a[0]), right=list(a[1]), parent=list(a[2]), time=list(t), clv=list(a[3]),
+                    pmat=list(a[4]), root=root.value, lnl=lnl.value)
+
+    def summary(self):
+        tot = C.c_double()
+        p, a, l = C.c_ulong(), C.c_ulong(), C.c_ulong()
+        _chk(lib().bpa_sampler_summary(self.h, C.byref(tot), C.byref(p), C.byref(a), C.byref(l)))
+        return dict(total_lnl=tot.value, proposals=p.value, accepted=a.value, launches=l.value)
+
+    def close(self):
+        if self.h and self.engine.h:
+            lib().bpa_sampler_destroy(self.h)
+        self.h = None
 
 
 class PlanSequence:

@@ -113,6 +113,7 @@ struct bpa_engine
   double bfbeta = 1.0;
   // timing
   bool timing = false;
+  unsigned timing_stride = 1, timing_phase = 0;   // events on every stride-th launch only
   std::vector<TimingSlot> slots;
   size_t slots_used = 0;
   double acc_ms[3] = {0, 0, 0};
@@ -583,7 +584,9 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   for (unsigned t = 0; t < T; ++t) maxnp = std::max(maxnp, b->loci[t]->sites);
   if (p->states == 4 && maxnp <= 256)
   {
-    const unsigned BS = maxnp <= 64 ? 64 : 256;
+    // workgroup size (lanes = patterns, whole loci per workgroup)
+    unsigned BS = maxnp <= 16 ? 256 : (maxnp <= 64 ? 64 : 256);     // measured: config 2 +3 % with 256, config 3 +8 % with 64
+    if (const char * ov = getenv("BPA_FUSED_BS")) { const unsigned v = (unsigned)atoi(ov); if ((v == 64 || v == 256) && maxnp <= v) BS = v; }
     std::vector<uint32_t> blk_off{0}, lane_task, lane0(T);
     unsigned used = 0;
     for (unsigned t = 0; t < T; ++t)
@@ -712,7 +715,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
   d.loci = e->d_loci.p;
   d.bfbeta = e->bfbeta;
   TimingSlot * ts = nullptr;
-  if (e->timing)
+  if (e->timing && (e->timing_phase++ % e->timing_stride) == 0)
   {
     ts = next_slot(e);
     if (!ts) { if (!timing_drain(e)) return 0; ts = next_slot(e); }
@@ -933,6 +936,12 @@ extern "C" void bpa_engine_enable_timing(bpa_engine_t * e, int on)
   (void)timing_drain(e);
   e->timing = on != 0;
   e->acc_ms[0] = e->acc_ms[1] = e->acc_ms[2] = 0; e->acc_launches = 0;
+}
+
+extern "C" void bpa_engine_set_timing_stride(bpa_engine_t * e, unsigned stride)
+{
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  e->timing_stride = stride ? stride : 1; e->timing_phase = 0;
 }
 
 extern "C" int bpa_engine_timing(bpa_engine_t * e, double * pmatrix_ms, double * partials_ms,
@@ -1187,3 +1196,6 @@ extern "C" int bpa_update_eigen(bpa_engine_t * e, double * eigenvecs, double * i
   f.free(); q.free(); ev.free(); evec.free(); ievec.free();
   return ok;
 }
+
+// device-resident per-locus proposal control
+#include "sampler.hpp"

@@ -26,7 +26,8 @@ struct a00_driver
   a00_tree_t * trees;
   a00_eval_fn eval;
   void * ctx;
-  unsigned long long rng;
+  a00_rng_t * rng;                      /* one stream per locus */
+  a00_rng_t grng;                       /* global stream (mixing step) */
   /* step scratch */
   unsigned * s_locus; a00_tree_t ** s_tree; unsigned * s_br_off, * s_nd_off;
   int * s_br, * s_nd; size_t cap_br, cap_nd;
@@ -36,12 +37,6 @@ struct a00_driver
   unsigned long proposals, accepted, steps;
 };
 
-/* 64-bit LCG (Knuth MMIX) -> uniform in (0,1) */
-static double rndu(a00_driver_t * d)
-{
-  d->rng = d->rng*6364136223846793005ULL + 1442695040888963407ULL;
-  return ((d->rng >> 11) + 0.5)*(1.0/9007199254740992.0);
-}
 
 /* the reference's buffer toggles (locus.c:24-26) */
 static void swap_clv(a00_tree_t * t, int i)
@@ -76,7 +71,11 @@ static void restore(a00_driver_t * d, unsigned i)
 a00_driver_t * a00_create(unsigned nloci, a00_eval_fn eval, void * ctx, unsigned long seed)
 {
   a00_driver_t * d = (a00_driver_t *)calloc(1, sizeof(*d));
-  d->nloci = nloci; d->eval = eval; d->ctx = ctx; d->rng = 0x9E3779B97F4A7C15ULL ^ seed;
+  unsigned q;
+  d->nloci = nloci; d->eval = eval; d->ctx = ctx;
+  d->rng = (a00_rng_t *)calloc(nloci, sizeof(a00_rng_t));
+  for (q = 0; q < nloci; ++q) d->rng[q] = a00_rng_seed(seed, q);
+  d->grng = a00_rng_seed(seed, A00_GLOBAL_STREAM);
   d->trees = (a00_tree_t *)calloc(nloci, sizeof(a00_tree_t));
   d->s_locus = (unsigned *)calloc(nloci, sizeof(unsigned));
   d->s_tree = (a00_tree_t **)calloc(nloci, sizeof(a00_tree_t *));
@@ -102,7 +101,7 @@ void a00_destroy(a00_driver_t * d)
     free(d->u_left[i]); free(d->u_right[i]); free(d->u_parent[i]); free(d->u_clv[i]); free(d->u_pmat[i]);
     free(d->u_scaler[i]); free(d->u_time[i]);
   }
-  free(d->trees); free(d->s_locus); free(d->s_tree); free(d->s_br_off); free(d->s_nd_off); free(d->s_br);
+  free(d->rng); free(d->trees); free(d->s_locus); free(d->s_tree); free(d->s_br_off); free(d->s_nd_off); free(d->s_br);
   free(d->s_nd); free(d->s_lnl); free(d->s_hast); free(d->u_left); free(d->u_right); free(d->u_parent);
   free(d->u_clv); free(d->u_pmat); free(d->u_scaler); free(d->u_time); free(d->u_root); free(d);
 }
@@ -205,8 +204,9 @@ static void decide(a00_driver_t * d, unsigned n)
   {
     const unsigned i = d->s_locus[s]; a00_tree_t * t = d->trees + i;
     const double lnacc = d->s_lnl[s] - t->lnl + d->s_hast[s];
+    const double u = a00_rndu(&d->rng[i]);
     d->proposals++;
-    if (lnacc >= 0 || rndu(d) < exp(lnacc)) { t->lnl = d->s_lnl[s]; d->accepted++; }
+    if (lnacc >= 0 || u < exp(lnacc)) { t->lnl = d->s_lnl[s]; d->accepted++; }
     else restore(d, i);                                  /* swap indices, ages, topology back */
   }
 }
@@ -218,9 +218,10 @@ static int gage_step(a00_driver_t * d, int k)
   step_begin(d);
   for (i = 0; i < d->nloci; ++i)
   {
-    a00_tree_t * t = d->trees + i; int v = -1, c = 0, j, nb = 0, nn, p; double lo, u = rndu(d);
+    a00_tree_t * t = d->trees + i; int v = -1, c = 0, j, nb = 0, nn, p; double lo, u;
     for (j = 0; j < t->n; ++j) if (t->left[j] >= 0 && c++ == k) { v = j; break; }
     if (v < 0) continue;
+    u = a00_rndu(&d->rng[i]);
     snapshot(d, i);
     lo = fmax(t->time[t->left[v]], t->time[t->right[v]]);
     p = t->parent[v];
@@ -264,9 +265,10 @@ static int gspr_step(a00_driver_t * d, int k)
     a00_tree_t * t = d->trees + i;
     int a = -1, c = 0, j, p, s, g, pc, tgt, ntg = 0, targets[MAXN], banned[MAXN], stack[MAXN], sp = 0;
     int bset[4], br[4], nb = 0, nd[2*MAXN], nn = 0, root_before;
-    double lo, tnew, u1 = rndu(d), u2 = rndu(d);
+    double lo, tnew, u1, u2;
     for (j = 0; j < t->n; ++j) if (j != t->root && c++ == k) { a = j; break; }
     if (a < 0) continue;
+    u1 = a00_rndu(&d->rng[i]); u2 = a00_rndu(&d->rng[i]);
     snapshot(d, i);
     root_before = t->root;
     p = t->parent[a]; s = t->left[p] == a ? t->right[p] : t->left[p]; g = t->parent[p];
@@ -315,7 +317,8 @@ static int gspr_step(a00_driver_t * d, int k)
 static int mix_step(a00_driver_t * d)
 {
   unsigned i; int br[MAXN], nd[MAXN]; double sum = 0, lnacc; long ninner = 0;
-  const double lnc = 0.1*(rndu(d) - 0.5), c = exp(lnc);
+  const double lnc = 0.1*(a00_rndu(&d->grng) - 0.5), c = exp(lnc);
+  const double uacc = a00_rndu(&d->grng);
   step_begin(d);
   for (i = 0; i < d->nloci; ++i)
   {
@@ -332,7 +335,7 @@ static int mix_step(a00_driver_t * d)
   for (i = 0; i < d->nloci; ++i) sum += d->s_lnl[i] - d->trees[i].lnl;
   lnacc = sum + (double)ninner*lnc;                       /* multiplier proposal on ninner ages */
   d->proposals++;
-  if (lnacc >= 0 || rndu(d) < exp(lnacc)) { d->accepted++; for (i = 0; i < d->nloci; ++i) d->trees[i].lnl = d->s_lnl[i]; }
+  if (lnacc >= 0 || uacc < exp(lnacc)) { d->accepted++; for (i = 0; i < d->nloci; ++i) d->trees[i].lnl = d->s_lnl[i]; }
   else for (i = 0; i < d->nloci; ++i) restore(d, i);
   return 1;
 }

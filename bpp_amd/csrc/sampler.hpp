@@ -1,0 +1,572 @@
+// sampler.hpp — device-resident per-locus proposal control.
+//
+// The C host driver (csrc/host/a00_driver.c) sweeps every locus with GAGE / GSPR proposals,
+// one batched launch + one host round trip per proposal.  Here the same state machine runs
+// on the device: the gene tree of a locus (the gnode_t fields), its CLV buffers and its P-matrix
+// (a,b) table are loaded into LDS once, ALL per-locus proposals of an iteration (tips-1 age
+// moves, 2 tips-2 prune/regraft moves) are proposed, evaluated, accepted or rolled back there —
+// same arithmetic, same per-locus random stream, same buffer toggling as the host driver — and
+// the state goes back to HBM once.  The all-loci mixing step is a second launch whose single
+// decision is taken on the device from the summed log-likelihood difference.  An iteration is
+// 4 launches instead of 3 tips - 2 + 1 host round trips.
+//
+// Scope (round 1): JC69, one rate category, no scalers, up to 8 tips, loci of <= 64 patterns.
+// Parity: identical trajectory to the host driver on libbpp_amd.so, which is identical to the
+// host driver on the real reference (tests/test_gpu_sampler.py).
+//
+// Included at the end of engine.hip (same translation unit: uses its engine/locus structs).
+#pragma once
+#include "bpp_amd_host.h"
+
+namespace smp {
+
+constexpr int MAXTIPS = 8;
+constexpr int MAXN    = 16;               // 2*MAXTIPS-1 nodes, padded
+constexpr int MAXBUF  = 2*(MAXTIPS - 1);  // inner CLV buffers
+constexpr int MAXPM   = 2*(2*MAXTIPS - 2);// P-matrix buffers
+constexpr int TPB     = 16;               // loci per workgroup (64 lanes)
+constexpr int BS      = 64;
+
+struct Tree                                // one per locus, in HBM and (while sweeping) in LDS
+{
+  int8_t   left[MAXN], right[MAXN], parent[MAXN], clv[MAXN], pmat[MAXN];
+  double   time[MAXN];
+  double   lnl;
+  a00_rng_t rng;
+  int32_t  root, tips;
+  uint32_t proposals, accepted;
+};
+static_assert(sizeof(Tree) % 16 == 0, "Tree is copied as uint4");
+
+struct Op { int8_t parent, lc, lp, rc, rp; };      // buffer indices of one node update
+
+struct TaskLDS
+{
+  Tree   tr, undo;
+  double ab[MAXPM][2];
+  Op     ops[MAXBUF];
+  int32_t nops, active;
+  double hast;
+};
+
+struct Args
+{
+  const LocusDev * loci;       // engine locus table
+  const uint32_t * task_locus; // [T]
+  const uint32_t * blk_task_off, * lane_task, * task_lane0;
+  Tree * trees, * snap;        // [T] current / pre-mix snapshot
+  double * mix_delta;          // [T] lnL(proposed) - lnL(current) of the mixing step
+  const uint32_t * mix_flag;   // epoch of the last REJECTED mixing step
+  uint32_t epoch;              // restore from snap when *mix_flag == epoch
+  uint32_t mode;               // 0 sweep (GAGE+GSPR), 1 mix, 2 only settle a pending mix decision, 3 start-up evaluation
+  uint32_t nsteps_gage, nsteps_gspr;
+  double   mix_c;
+};
+
+// a00_rndu of bpp_amd_host.h, callable on the device (same integer recurrence, same conversion)
+__host__ __device__ inline double rndu(a00_rng_t * r)
+{
+  *r = *r*6364136223846793005ULL + 1442695040888963407ULL;
+  return (double)((*r >> 11) + 0.5)*(1.0/9007199254740992.0);
+}
+
+__device__ __forceinline__ void swap_clv(Tree & t, int i)
+{
+  const int inner = t.tips - 1;
+  t.clv[i] = (int8_t)(t.tips + (t.clv[i] - t.tips + inner) % (2*inner));
+}
+__device__ __forceinline__ void swap_pmat(Tree & t, int i)
+{
+  const int edges = 2*t.tips - 2;
+  t.pmat[i] = (int8_t)((t.pmat[i] + edges) % (2*edges));
+}
+__device__ __forceinline__ int path_to_root(const Tree & t, int v, int8_t * out)
+{
+  int k = 0;
+  for (; v >= 0; v = t.parent[v]) out[k++] = (int8_t)v;
+  return k;
+}
+__device__ void swap_ids(Tree & t, int a, int b)
+{
+  const int n = 2*t.tips - 1;
+  int8_t L[MAXN], R[MAXN], P[MAXN]; double T[MAXN];
+#define SMP_M(x) ((x) == a ? b : (x) == b ? a : (x))
+  for (int i = 0; i < n; ++i)
+  {
+    const int o = SMP_M(i);
+    L[i] = t.left[o] >= 0 ? (int8_t)SMP_M(t.left[o]) : (int8_t)-1;
+    R[i] = t.right[o] >= 0 ? (int8_t)SMP_M(t.right[o]) : (int8_t)-1;
+    P[i] = t.parent[o] >= 0 ? (int8_t)SMP_M(t.parent[o]) : (int8_t)-1;
+    T[i] = t.time[o];
+  }
+  for (int i = 0; i < n; ++i) { t.left[i] = L[i]; t.right[i] = R[i]; t.parent[i] = P[i]; t.time[i] = T[i]; }
+  t.root = SMP_M(t.root);
+#undef SMP_M
+}
+
+// install a proposal: toggle buffers, fresh (a,b) of the changed branches, node-update list
+// (children first = by age) — step_add of a00_driver.c
+__device__ void install(TaskLDS & S, const int8_t * br, int nb, int8_t * nd, int nn, double rate, double mui)
+{
+  Tree & t = S.tr;
+  for (int a = 0; a < nn; ++a) for (int b = a + 1; b < nn; ++b) if (nd[b] == nd[a]) { nd[b] = nd[--nn]; --b; }
+  for (int a = 1; a < nn; ++a)
+  {
+    const int8_t v = nd[a]; int b = a;
+    for (; b > 0 && t.time[nd[b-1]] > t.time[v]; --b) nd[b] = nd[b-1];
+    nd[b] = v;
+  }
+  for (int a = 0; a < nb; ++a)
+  {
+    const int x = br[a];
+    swap_pmat(t, x);
+    const double len = (t.time[t.parent[x]] - t.time[x])*mui;                // locus.c:2350
+    double A, B;
+    jc69_ab(len, rate, A, B);
+    S.ab[t.pmat[x]][0] = A; S.ab[t.pmat[x]][1] = B;
+  }
+  for (int a = 0; a < nn; ++a) swap_clv(t, nd[a]);
+  for (int a = 0; a < nn; ++a)
+  {
+    const int x = nd[a], l = t.left[x], r = t.right[x];
+    S.ops[a].parent = t.clv[x]; S.ops[a].lc = t.clv[l]; S.ops[a].lp = t.pmat[l];
+    S.ops[a].rc = t.clv[r]; S.ops[a].rp = t.pmat[r];
+  }
+  S.nops = nn;
+}
+
+// GAGE on the k-th inner node (gage_step of a00_driver.c)
+__device__ bool propose_gage(TaskLDS & S, int k, double rate)
+{
+  Tree & t = S.tr;
+  const int n = 2*t.tips - 1;
+  int v = -1, c = 0;
+  for (int j = 0; j < n; ++j) if (t.left[j] >= 0 && c++ == k) { v = j; break; }
+  if (v < 0) return false;
+  const double u = rndu(&t.rng);
+  S.undo = t;
+  const double lo = fmax(t.time[t.left[v]], t.time[t.right[v]]);
+  const int p = t.parent[v];
+  S.hast = 0;
+  if (p >= 0) t.time[v] = lo + (0.02 + 0.96*u)*(t.time[p] - lo);
+  else { const double c_ = exp(0.6*(u - 0.5)); t.time[v] = lo + (t.time[v] - lo)*c_; S.hast = log(c_); }
+  int8_t br[4], nd[MAXN]; int nb = 0;
+  br[nb++] = t.left[v]; br[nb++] = t.right[v]; if (p >= 0) br[nb++] = (int8_t)v;
+  const int nn = path_to_root(t, v, nd);
+  install(S, br, nb, nd, nn, rate, 1.0);
+  return true;
+}
+
+// GSPR on the k-th non-root node (gspr_step of a00_driver.c)
+__device__ bool propose_gspr(TaskLDS & S, int k, double rate)
+{
+  Tree & t = S.tr;
+  const int n = 2*t.tips - 1;
+  int a = -1, c = 0;
+  for (int j = 0; j < n; ++j) if (j != t.root && c++ == k) { a = j; break; }
+  if (a < 0) return false;
+  const double u1 = rndu(&t.rng), u2 = rndu(&t.rng);
+  S.undo = t;
+  const int root_before = t.root;
+  const int p = t.parent[a], s = t.left[p] == a ? t.right[p] : t.left[p], g = t.parent[p];
+  t.parent[s] = (int8_t)g;
+  if (g >= 0) { if (t.left[g] == p) t.left[g] = (int8_t)s; else t.right[g] = (int8_t)s; } else t.root = s;
+  bool banned[MAXN]; int8_t stack[MAXN], targets[MAXN]; int sp = 0, ntg = 0;
+  for (int j = 0; j < n; ++j) banned[j] = false;
+  banned[p] = true; stack[sp++] = (int8_t)a;
+  while (sp) { const int x = stack[--sp]; banned[x] = true; if (t.left[x] >= 0) { stack[sp++] = t.left[x]; stack[sp++] = t.right[x]; } }
+  for (int j = 0; j < n; ++j) if (!banned[j]) targets[ntg++] = (int8_t)j;
+  int tgt = targets[(int)(u1*ntg) % ntg];
+  int pc = t.parent[tgt];
+  double lo = fmax(t.time[a], t.time[tgt]);
+  if (pc >= 0 && t.time[pc] <= lo) { tgt = s; pc = t.parent[s]; lo = fmax(t.time[a], t.time[tgt]); }
+  const double tnew = pc >= 0 ? lo + (0.02 + 0.96*u2)*(t.time[pc] - lo) : lo + (0.1 + u2)*fmax(lo, 1e-4)*0.5;
+  t.time[p] = tnew; t.left[p] = (int8_t)a; t.right[p] = (int8_t)tgt; t.parent[a] = (int8_t)p; t.parent[tgt] = (int8_t)p;
+  t.parent[p] = (int8_t)pc;
+  if (pc >= 0) { if (t.left[pc] == tgt) t.left[pc] = (int8_t)p; else t.right[pc] = (int8_t)p; } else t.root = p;
+  int8_t nd[2*MAXN + MAXN]; int nn = path_to_root(t, p, nd);
+  if (g >= 0) nn += path_to_root(t, g, nd + nn);
+  int bset[4] = {a, tgt, p, s};
+  if (t.root != root_before)
+  {
+    const int newtop = t.root;
+    swap_ids(t, newtop, root_before);
+    for (int j = 0; j < nn; ++j) nd[j] = (int8_t)(nd[j] == newtop ? root_before : nd[j] == root_before ? newtop : nd[j]);
+    for (int j = 0; j < 4; ++j) bset[j] = bset[j] == newtop ? root_before : bset[j] == root_before ? newtop : bset[j];
+    nn += path_to_root(t, newtop, nd + nn);
+  }
+  int8_t br[4]; int nb = 0;
+  for (int j = 0; j < 4; ++j)
+  {
+    bool dup = false;
+    for (int q = 0; q < nb; ++q) if (br[q] == bset[j]) dup = true;
+    if (!dup && t.parent[bset[j]] >= 0) br[nb++] = (int8_t)bset[j];
+  }
+  S.hast = 0;
+  install(S, br, nb, nd, nn, rate, 1.0);
+  return true;
+}
+
+__global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
+{
+  __shared__ TaskLDS s_task[TPB];
+  __shared__ double  s_clv[MAXBUF][BS][4];
+  __shared__ double  s_term[BS];
+  const uint32_t b = blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
+  const uint32_t t0 = A.blk_task_off[b], t1 = A.blk_task_off[b+1];
+  const uint32_t task = A.lane_task[gl];
+  const bool active = task != 0xffffffffu;
+  const uint32_t ts = active ? task - t0 : 0u;
+  const bool leader = active && gl == A.task_lane0[task];
+  const bool restore_mix = A.epoch != 0 && *A.mix_flag == A.epoch;      // epoch 0: nothing pending
+
+  // ---- load: tree (or its pre-mix snapshot), (a,b) table, this lane's CLV buffers and constants
+  LocusDev L{};
+  uint32_t n = 0, tipcodes = 0, wgt = 0;
+  double f0 = 0, f1 = 0, f2 = 0, f3 = 0, rw = 0, rate = 1;
+  if (active)
+  {
+    L = A.loci[A.task_locus[task]];
+    n = gl - A.task_lane0[task];
+    const double * par = L.par;
+    rate = par[par_rates(1)]; rw = par[par_rate_weights(1)];
+    const double * f = par + par_matrix(1, 4, 0) + pm_freqs(4);
+    f0 = f[0]; f1 = f[1]; f2 = f[2]; f3 = f[3];
+    wgt = L.weights[n];
+    for (uint32_t tip = 0; tip < L.tips_n; ++tip) tipcodes |= (uint32_t)(L.tips[(size_t)tip*L.np + n] & 15u) << (4*tip);
+    const uint32_t nbuf = 2*(L.tips_n - 1);
+    for (uint32_t c = 0; c < nbuf; ++c)
+    {
+      const double2 * p = reinterpret_cast<const double2 *>(L.clv + ((size_t)c*L.np + n)*4);
+      const double2 u = p[0], w = p[1];
+      s_clv[c][lane][0] = u.x; s_clv[c][lane][1] = u.y; s_clv[c][lane][2] = w.x; s_clv[c][lane][3] = w.y;
+    }
+  }
+  if (leader)
+  {
+    TaskLDS & S = s_task[ts];
+    const uint4 * src = reinterpret_cast<const uint4 *>((restore_mix ? A.snap : A.trees) + task);
+    uint4 * dst = reinterpret_cast<uint4 *>(&S.tr);
+    for (uint32_t i = 0; i < sizeof(Tree)/16; ++i) dst[i] = src[i];
+    if (restore_mix) { S.tr.rng = A.trees[task].rng; S.tr.proposals = A.trees[task].proposals; S.tr.accepted = A.trees[task].accepted; }
+    const uint32_t npm = 2*(2*L.tips_n - 2);
+    for (uint32_t i = 0; i < npm; ++i) { S.ab[i][0] = L.pmat[2*i]; S.ab[i][1] = L.pmat[2*i+1]; }
+    S.nops = 0; S.active = 0;
+  }
+  __syncthreads();
+
+  const uint32_t nprop = A.mode == 0 ? A.nsteps_gage + A.nsteps_gspr : (A.mode == 1 || A.mode == 3 ? 1u : 0u);
+  for (uint32_t step = 0; step < nprop; ++step)
+  {
+    // ---- phase 1: the locus's leader lane proposes
+    if (leader)
+    {
+      TaskLDS & S = s_task[ts];
+      bool ok;
+      if (A.mode == 0) ok = step < A.nsteps_gage ? propose_gage(S, (int)step, rate) : propose_gspr(S, (int)(step - A.nsteps_gage), rate);
+      else
+      {
+        // mixing (mix_step of a00_driver.c) or start-up: every branch, every inner node
+        Tree & t = S.tr;
+        const int nn_ = 2*t.tips - 1;
+        if (A.mode == 1) { A.snap[task] = t; }
+        int8_t br[MAXN], nd[MAXN]; int nb = 0, nn = 0;
+        for (int k = 0; k < nn_; ++k)
+        {
+          if (t.left[k] >= 0) { if (A.mode == 1) t.time[k] *= A.mix_c; nd[nn++] = (int8_t)k; }
+          if (t.parent[k] >= 0) br[nb++] = (int8_t)k;
+        }
+        if (A.mode == 3) { for (int k = 0; k < nb; ++k) swap_pmat(t, br[k]); for (int k = 0; k < nn; ++k) swap_clv(t, nd[k]); }
+        S.hast = 0;
+        install(S, br, nb, nd, nn, rate, 1.0);
+        ok = true;
+      }
+      S.active = ok ? 1 : 0;
+      if (!ok) S.nops = 0;
+    }
+    __syncthreads();
+    // ---- phase 2: one lane per pattern runs the node updates out of LDS
+    double term = 0;
+    if (active && s_task[ts].active)
+    {
+      const TaskLDS & S = s_task[ts];
+      const uint32_t tips = L.tips_n;
+      for (int o = 0; o < S.nops; ++o)
+      {
+        const Op op = S.ops[o];
+        double lv[4], rv[4], x[4], y[4];
+        if ((uint32_t)op.lc < tips) expand_code((tipcodes >> (4*op.lc)) & 15u, lv);
+        else { const double * c = s_clv[op.lc - tips][lane]; lv[0] = c[0]; lv[1] = c[1]; lv[2] = c[2]; lv[3] = c[3]; }
+        if ((uint32_t)op.rc < tips) expand_code((tipcodes >> (4*op.rc)) & 15u, rv);
+        else { const double * c = s_clv[op.rc - tips][lane]; rv[0] = c[0]; rv[1] = c[1]; rv[2] = c[2]; rv[3] = c[3]; }
+        matvec4_ab(S.ab[op.lp][0], S.ab[op.lp][1], lv, x);
+        matvec4_ab(S.ab[op.rp][0], S.ab[op.rp][1], rv, y);
+        double * out = s_clv[op.parent - tips][lane];
+        out[0] = x[0]*y[0]; out[1] = x[1]*y[1]; out[2] = x[2]*y[2]; out[3] = x[3]*y[3];
+      }
+      const double * c = s_clv[S.tr.clv[S.tr.root] - tips][lane];
+      const double tr_ = dot4_pair(f0, f1, f2, f3, c);
+      term = log(0 + tr_*rw)*wgt;
+    }
+    s_term[lane] = term;
+    __syncthreads();
+    // ---- phase 3: the leader sums in pattern order and decides
+    if (leader && s_task[ts].active)
+    {
+      TaskLDS & S = s_task[ts];
+      double lnl = 0;
+      for (uint32_t q = 0; q < L.np; ++q) lnl += s_term[lane + q];
+      if (A.mode == 0)
+      {
+        const double lnacc = lnl - S.tr.lnl + S.hast;
+        const double u = rndu(&S.tr.rng);
+        S.tr.proposals++;
+        if (lnacc >= 0 || u < exp(lnacc)) { S.tr.lnl = lnl; S.tr.accepted++; }
+        else
+        {
+          const a00_rng_t r = S.tr.rng; const uint32_t pr = S.tr.proposals, ac = S.tr.accepted;
+          S.tr = S.undo; S.tr.rng = r; S.tr.proposals = pr; S.tr.accepted = ac;
+        }
+      }
+      else
+      {
+        A.mix_delta[task] = A.mode == 1 ? lnl - S.tr.lnl : 0.0;
+        S.tr.lnl = lnl;
+      }
+    }
+    // (the next phase 1 is run by the same lane that ran this phase 3; followers wait at its barrier)
+  }
+  __syncthreads();
+
+  // ---- store
+  if (leader)
+  {
+    TaskLDS & S = s_task[ts];
+    uint4 * dst = reinterpret_cast<uint4 *>(A.trees + task);
+    const uint4 * src = reinterpret_cast<const uint4 *>(&S.tr);
+    for (uint32_t i = 0; i < sizeof(Tree)/16; ++i) dst[i] = src[i];
+    const uint32_t npm = 2*(2*L.tips_n - 2);
+    for (uint32_t i = 0; i < npm; ++i) { L.pmat[2*i] = S.ab[i][0]; L.pmat[2*i+1] = S.ab[i][1]; }
+  }
+  if (active && nprop)
+  {
+    const uint32_t nbuf = 2*(L.tips_n - 1);
+    for (uint32_t c = 0; c < nbuf; ++c)
+    {
+      double2 * p = reinterpret_cast<double2 *>(L.clv + ((size_t)c*L.np + n)*4);
+      double2 u, w; u.x = s_clv[c][lane][0]; u.y = s_clv[c][lane][1]; w.x = s_clv[c][lane][2]; w.y = s_clv[c][lane][3];
+      p[0] = u; p[1] = w;
+    }
+  }
+}
+
+// the single decision of the mixing step (prop_mixing.c:203-205): flag := epoch when REJECTED
+__global__ void mix_decide_kernel(const double * __restrict__ sum, double lnc, double ninner, double u,
+                                  uint32_t epoch, uint32_t * flag, uint32_t * counters)
+{
+  if (threadIdx.x || blockIdx.x) return;
+  const double lnacc = sum[0] + ninner*lnc;
+  const bool accept = lnacc >= 0 || u < exp(lnacc);
+  counters[0] += 1; counters[1] += accept ? 1u : 0u;
+  if (!accept) *flag = epoch;
+}
+
+} // namespace smp
+
+// ------------------------------------------------------------------------------------ host ---
+struct bpa_sampler
+{
+  bpa_engine * eng = nullptr;
+  unsigned nloci = 0, maxtips = 0;
+  std::vector<bpa_locus *> loci;
+  DevBuf<uint32_t> task_locus, blk_task_off, lane_task, task_lane0, flag, counters;
+  DevBuf<smp::Tree> trees, snap;
+  DevBuf<double> mix_delta, mix_sum;
+  std::vector<smp::Tree> h_trees;
+  unsigned nblocks = 0, epoch = 0;
+  bool mix_pending = false;             // a mixing decision taken on the device has not been applied yet
+  a00_rng_t grng = 0;
+  unsigned long seed = 0, launches = 0;
+  double ninner_total = 0;
+  bool uploaded = false;
+};
+
+extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * const * loci, unsigned nloci,
+                                              unsigned long seed)
+{
+  if (!e || !loci || !nloci) { fail("bpa_sampler_create: null argument"); return nullptr; }
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  bpa_sampler * s = new bpa_sampler();
+  s->eng = e; s->nloci = nloci; s->seed = seed; s->grng = a00_rng_seed(seed, A00_GLOBAL_STREAM);
+  s->loci.assign(loci, loci + nloci);
+  for (unsigned i = 0; i < nloci; ++i)
+  {
+    const bpa_locus * l = loci[i];
+    const bool ok = l && l->eng == e && l->alive && l->states == 4 && l->rate_cats == 1 && l->dev.model == 0 &&
+                    l->scale_buffers == 0 && !l->dev.unphased_length && l->tips >= 2 && l->tips <= (unsigned)smp::MAXTIPS &&
+                    l->sites <= (unsigned)smp::BS && l->clv_buffers == 2*(l->tips - 1) && l->prob_matrices == 2*(2*l->tips - 2);
+    if (!ok)
+    {
+      fail("bpa_sampler_create: loci must be JC69, 1 rate category, no scalers, not diploid, <= 8 tips, <= 64 patterns, "
+           "with the buffer counts of method.c:4110-4146");
+      delete s; return nullptr;
+    }
+    s->maxtips = std::max(s->maxtips, l->tips);
+  }
+  s->h_trees.assign(nloci, smp::Tree{});
+  return s;
+}
+
+extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
+{
+  if (!s) return;
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  (void)hipSetDevice(s->eng->device); g_cur_device = s->eng->device;
+  (void)hipStreamSynchronize(s->eng->stream);
+  s->task_locus.free(); s->blk_task_off.free(); s->lane_task.free(); s->task_lane0.free(); s->flag.free();
+  s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free();
+  delete s;
+}
+
+extern "C" int bpa_sampler_set_tree(bpa_sampler_t * s, unsigned i, const int * left, const int * right,
+                                    const double * times, int root)
+{
+  if (i >= s->nloci) return fail("bpa_sampler_set_tree: locus index out of range");
+  const int tips = (int)s->loci[i]->tips, n = 2*tips - 1;
+  smp::Tree & t = s->h_trees[i];
+  std::memset(&t, 0, sizeof(t));
+  for (int k = 0; k < smp::MAXN; ++k) { t.left[k] = t.right[k] = t.parent[k] = -1; t.clv[k] = t.pmat[k] = (int8_t)k; }
+  for (int k = 0; k < n; ++k)
+  {
+    t.left[k] = (int8_t)left[k]; t.right[k] = (int8_t)right[k]; t.time[k] = times[k];
+    if (left[k] >= 0) { t.parent[left[k]] = (int8_t)k; t.parent[right[k]] = (int8_t)k; }
+  }
+  t.root = root; t.tips = tips; t.rng = a00_rng_seed(s->seed, i); t.lnl = 0;
+  s->uploaded = false;
+  return 1;
+}
+
+static int sampler_upload(bpa_sampler * s)
+{
+  bpa_engine * e = s->eng;
+  if (s->uploaded) return 1;
+  if (!set_device(e) || !flush(e)) return 0;
+  const unsigned T = s->nloci;
+  std::vector<uint32_t> locus(T), blk_off{0}, lane_task, lane0(T);
+  unsigned used = 0, ntask = 0;
+  s->ninner_total = 0;
+  for (unsigned t = 0; t < T; ++t)
+  {
+    const unsigned np = s->loci[t]->sites;
+    locus[t] = s->loci[t]->id;
+    s->ninner_total += s->loci[t]->tips - 1;
+    if (used + np > (unsigned)smp::BS || ntask == (unsigned)smp::TPB)
+    { lane_task.resize(blk_off.size()*smp::BS, 0xffffffffu); blk_off.push_back(t); used = 0; ntask = 0; }
+    lane0[t] = (uint32_t)((blk_off.size() - 1)*smp::BS + used);
+    for (unsigned n = 0; n < np; ++n) lane_task.push_back(t);
+    used += np; ++ntask;
+  }
+  lane_task.resize(blk_off.size()*smp::BS, 0xffffffffu);
+  blk_off.push_back(T);
+  s->nblocks = (unsigned)blk_off.size() - 1;
+  uint32_t zero2[2] = {0, 0};
+  if (!upload(s->task_locus, locus.data(), T) || !upload(s->blk_task_off, blk_off.data(), blk_off.size()) ||
+      !upload(s->lane_task, lane_task.data(), lane_task.size()) || !upload(s->task_lane0, lane0.data(), T) ||
+      !upload(s->trees, s->h_trees.data(), T) || !upload(s->snap, s->h_trees.data(), T) ||
+      !upload(s->flag, zero2, 1) || !upload(s->counters, zero2, 2) || !s->mix_delta.reserve(T) || !s->mix_sum.reserve(1))
+    return 0;
+  s->epoch = 0; s->mix_pending = false;
+  s->uploaded = true;
+  return 1;
+}
+
+static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c)
+{
+  bpa_engine * e = s->eng;
+  smp::Args a{};
+  a.loci = e->d_loci.p; a.task_locus = s->task_locus.p; a.blk_task_off = s->blk_task_off.p;
+  a.lane_task = s->lane_task.p; a.task_lane0 = s->task_lane0.p; a.trees = s->trees.p; a.snap = s->snap.p;
+  a.mix_delta = s->mix_delta.p; a.mix_flag = s->flag.p; a.mode = mode;
+  // the first sweep/settle launch after a mixing decision applies it (restore from the snapshot
+  // when it was a rejection); every other launch passes epoch 0 = nothing pending
+  a.epoch = (s->mix_pending && (mode == 0 || mode == 2)) ? s->epoch : 0u;
+  if (mode == 0 || mode == 2) s->mix_pending = false;
+  a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2; a.mix_c = mix_c;
+  hipLaunchKernelGGL(smp::sweep_kernel, dim3(s->nblocks), dim3(smp::BS), 0, e->stream, a);
+  HIPCHK(hipGetLastError());
+  s->launches++;
+  return 1;
+}
+
+extern "C" int bpa_sampler_initialize(bpa_sampler_t * s)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (!sampler_upload(s)) return 0;
+  return sampler_launch(s, 3, 1.0);
+}
+
+extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
+{
+  bpa_engine * e = s->eng;
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  if (!sampler_upload(s)) return 0;
+  for (unsigned it = 0; it < iterations; ++it)
+  {
+    if (!sampler_launch(s, 0, 1.0)) return 0;                    // GAGE + GSPR of every locus (settles a pending mix first)
+    const double lnc = 0.1*(a00_rndu(&s->grng) - 0.5), c = std::exp(lnc);
+    const double uacc = a00_rndu(&s->grng);
+    if (!sampler_launch(s, 1, c)) return 0;                      // mixing proposal of every locus
+    hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, s->mix_sum.p);
+    s->epoch++;
+    hipLaunchKernelGGL(smp::mix_decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, lnc, s->ninner_total, uacc,
+                       s->epoch, s->flag.p, s->counters.p);
+    HIPCHK(hipGetLastError());
+    s->mix_pending = true;
+  }
+  return 1;
+}
+
+// settle a pending mixing decision and bring the trees to the host
+static int sampler_download(bpa_sampler * s)
+{
+  bpa_engine * e = s->eng;
+  if (!sampler_upload(s)) return 0;
+  if (!sampler_launch(s, 2, 1.0)) return 0;
+  HIPCHK(hipMemcpyAsync(s->h_trees.data(), s->trees.p, s->nloci*sizeof(smp::Tree), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 1;
+}
+
+extern "C" int bpa_sampler_get_tree(bpa_sampler_t * s, unsigned i, int * left, int * right, int * parent,
+                                    double * times, int * clv, int * pmat, int * root, double * lnl)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (i >= s->nloci) return fail("bpa_sampler_get_tree: locus index out of range");
+  if (i == 0 || !s->uploaded) { if (!sampler_download(s)) return 0; }      // refreshed when locus 0 is asked for
+  const smp::Tree & t = s->h_trees[i];
+  const int n = 2*t.tips - 1;
+  for (int k = 0; k < n; ++k)
+  {
+    if (left) left[k] = t.left[k]; if (right) right[k] = t.right[k]; if (parent) parent[k] = t.parent[k];
+    if (times) times[k] = t.time[k]; if (clv) clv[k] = t.clv[k]; if (pmat) pmat[k] = t.pmat[k];
+  }
+  if (root) *root = t.root;
+  if (lnl) *lnl = t.lnl;
+  return 1;
+}
+
+extern "C" int bpa_sampler_summary(bpa_sampler_t * s, double * total_lnl, unsigned long * proposals,
+                                   unsigned long * accepted, unsigned long * launches)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (!sampler_download(s)) return 0;
+  uint32_t c[2];
+  HIPCHK(hipMemcpy(c, s->counters.p, 8, hipMemcpyDeviceToHost));
+  double tot = 0; unsigned long pr = c[0], ac = c[1];
+  for (const auto & t : s->h_trees) { tot += t.lnl; pr += t.proposals; ac += t.accepted; }
+  if (total_lnl) *total_lnl = tot;
+  if (proposals) *proposals = pr;
+  if (accepted) *accepted = ac;
+  if (launches) *launches = s->launches;
+  return 1;
+}

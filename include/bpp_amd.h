@@ -203,6 +203,28 @@ int          bpa_plan_get_sum(bpa_plan_t *, double * sum);
 /* convenience: create + launch + get + destroy                                    */
 int          bpa_batch_evaluate(bpa_engine_t *, const bpa_batch_t *, double * lnl);
 
+/* ------------------------------------- device-resident proposal control (next) --- */
+/* The per-locus proposals of an iteration (gene-node ages, gtree.c:4585; prune/regraft,
+   gtree.c:6531) and the all-loci mixing step (prop_mixing.c:52) with the gene trees, their
+   buffer-index bookkeeping, the random streams and the accept/reject decisions resident on
+   the device: the state machine of include/bpp_amd_host.h (same arithmetic, same streams,
+   same trajectory) without a host round trip per proposal.  Round-1 scope: JC69, one rate
+   category, no scalers, <= 8 tips, <= 64 patterns per locus.  Trees use the node numbering of
+   a00_tree_t (tips first; arrays of 2*tips-1 entries).                                      */
+typedef struct bpa_sampler bpa_sampler_t;
+bpa_sampler_t * bpa_sampler_create(bpa_engine_t *, bpa_locus_t * const * loci, unsigned nloci,
+                                   unsigned long seed);
+void bpa_sampler_destroy(bpa_sampler_t *);
+int  bpa_sampler_set_tree(bpa_sampler_t *, unsigned i, const int * left, const int * right,
+                          const double * times, int root);
+int  bpa_sampler_initialize(bpa_sampler_t *);                 /* all matrices, partials, lnL */
+int  bpa_sampler_iterate(bpa_sampler_t *, unsigned iterations); /* asynchronous on the engine stream */
+/* current state of locus i (any output may be NULL); asking for locus 0 refreshes the host copy */
+int  bpa_sampler_get_tree(bpa_sampler_t *, unsigned i, int * left, int * right, int * parent,
+                          double * times, int * clv, int * pmat, int * root, double * lnl);
+int  bpa_sampler_summary(bpa_sampler_t *, double * total_lnl, unsigned long * proposals,
+                         unsigned long * accepted, unsigned long * launches);
+
 /* ------------------------------------------------------ work / measurement --- */
 /* Algorithmic work of one launch of the plan, by the formulas of SURVEY.md §8(d):
    K1 node update: bytes = 3*Np*R*S*8 + 2*R*S^2*8 (+12*Np with scaling),
@@ -215,6 +237,8 @@ int  bpa_plan_work(bpa_plan_t *, double * bytes_partials, double * flops_partial
    P-matrix, partials(+site lnL) and per-locus reduction kernels and the number of
    launches since timing was enabled.                                              */
 void bpa_engine_enable_timing(bpa_engine_t *, int on);
+/* attach the events to every stride-th launch only (each event pair costs ~4 us of stream time) */
+void bpa_engine_set_timing_stride(bpa_engine_t *, unsigned stride);
 int  bpa_engine_timing(bpa_engine_t *, double * pmatrix_ms, double * partials_ms,
                        double * reduce_ms, unsigned long * launches);
 

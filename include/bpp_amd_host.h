@@ -27,6 +27,24 @@
 extern "C" {
 #endif
 
+/* Random numbers: every locus owns a stream (so that loci can be advanced independently, on the
+   host or on the device, with identical results) and the all-loci mixing step a global one.
+   64-bit LCG (Knuth MMIX constants); a00_rndu gives a uniform in (0,1).  A GAGE proposal always
+   consumes 2 numbers of its locus's stream (proposal, acceptance), a GSPR proposal 3.           */
+typedef unsigned long long a00_rng_t;
+static inline a00_rng_t a00_rng_seed(unsigned long seed, unsigned stream)
+{
+  a00_rng_t z = 0x9E3779B97F4A7C15ULL*(a00_rng_t)(stream + 1) ^ (a00_rng_t)seed*0xD1B54A32D192ED03ULL;
+  z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 29;
+  return z | 1ULL;
+}
+static inline double a00_rndu(a00_rng_t * r)
+{
+  *r = *r*6364136223846793005ULL + 1442695040888963407ULL;
+  return (double)((*r >> 11) + 0.5)*(1.0/9007199254740992.0);
+}
+#define A00_GLOBAL_STREAM 0xFFFFFFFFu
+
 /* gene tree of one locus: tips 0..tips-1, inner nodes after; the root node object stays
    the root (gtree.c:6129-6175), so pmatrix indices never collide */
 typedef struct a00_tree
