@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's)")
     ap.add_argument("--tape-iters", type=int, default=4, help="distinct A00 iterations in the resident tape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sampler", action="store_true", help="skip the device-resident sampler section")
     ap.add_argument("--no-timing-events", action="store_true")
     ap.add_argument("--event-stride", type=int, default=7,
                     help="attach the kernel start/stop events to every n-th launch of the timed region "
@@ -273,6 +274,27 @@ def main():
         except Exception:
             pass
 
+    # ---- extra (not `value`): the same loci under device-resident proposal control — a real sampler
+    # (proposals, accept/reject, rollback on the device; bpa_sampler_t), 4 launches per iteration
+    sampler = None
+    if world == 1 and args.config == "c2" and not args.no_sampler:
+        smp = bpp_amd.Sampler(eng, loci, data, seed=1)
+        smp.initialize()
+        smp.iterate(args.warmup)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        smp.iterate(args.steps)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        sm = smp.summary()
+        sampler = dict(iterations_per_s=round(args.steps / dt * nloci / 10000.0, 1), ms_per_iteration=round(1e3 * dt / args.steps, 4),
+                       launches_per_iteration=4, proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
+                       acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
+                       note="GAGE+GSPR per locus and one all-loci MIX per iteration, Metropolis on the likelihood ratio, "
+                            "decisions taken on the device; same trajectory as the C host driver on the reference "
+                            "(tests/test_gpu_sampler.py, tests/test_gpu_host_driver.py); no TAU step, no MSC prior")
+        smp.close()
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         n_cpu_iter = min(2, len(iters))
@@ -302,6 +324,7 @@ def main():
                               if tm and tm["launches"] else None),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "device_resident_sampler": sampler,
         }
         print(json.dumps(out), flush=True)
 

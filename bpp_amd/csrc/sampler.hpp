@@ -80,55 +80,62 @@ __device__ __forceinline__ void swap_pmat(Tree & t, int i)
   const int edges = 2*t.tips - 2;
   t.pmat[i] = (int8_t)((t.pmat[i] + edges) % (2*edges));
 }
-__device__ __forceinline__ int path_to_root(const Tree & t, int v, int8_t * out)
+// node sets are 16-bit masks (n <= 15): no private arrays, nothing spills to scratch
+__device__ __forceinline__ uint32_t path_mask(const Tree & t, int v)
 {
-  int k = 0;
-  for (; v >= 0; v = t.parent[v]) out[k++] = (int8_t)v;
-  return k;
+  uint32_t m = 0;
+  for (; v >= 0; v = t.parent[v]) m |= 1u << v;
+  return m;
 }
+// exchange the tree positions of node ids a and b, in place (buffer indices stay with the ids)
 __device__ void swap_ids(Tree & t, int a, int b)
 {
   const int n = 2*t.tips - 1;
-  int8_t L[MAXN], R[MAXN], P[MAXN]; double T[MAXN];
-#define SMP_M(x) ((x) == a ? b : (x) == b ? a : (x))
   for (int i = 0; i < n; ++i)
   {
-    const int o = SMP_M(i);
-    L[i] = t.left[o] >= 0 ? (int8_t)SMP_M(t.left[o]) : (int8_t)-1;
-    R[i] = t.right[o] >= 0 ? (int8_t)SMP_M(t.right[o]) : (int8_t)-1;
-    P[i] = t.parent[o] >= 0 ? (int8_t)SMP_M(t.parent[o]) : (int8_t)-1;
-    T[i] = t.time[o];
+    const int8_t l = t.left[i], r = t.right[i], p = t.parent[i];
+    t.left[i]   = l == a ? (int8_t)b : l == b ? (int8_t)a : l;
+    t.right[i]  = r == a ? (int8_t)b : r == b ? (int8_t)a : r;
+    t.parent[i] = p == a ? (int8_t)b : p == b ? (int8_t)a : p;
   }
-  for (int i = 0; i < n; ++i) { t.left[i] = L[i]; t.right[i] = R[i]; t.parent[i] = P[i]; t.time[i] = T[i]; }
-  t.root = SMP_M(t.root);
-#undef SMP_M
+  const int8_t l = t.left[a], r = t.right[a], p = t.parent[a]; const double tm = t.time[a];
+  t.left[a] = t.left[b]; t.right[a] = t.right[b]; t.parent[a] = t.parent[b]; t.time[a] = t.time[b];
+  t.left[b] = l; t.right[b] = r; t.parent[b] = p; t.time[b] = tm;
+  t.root = t.root == a ? b : t.root == b ? a : t.root;
 }
 
-// install a proposal: toggle buffers, fresh (a,b) of the changed branches, node-update list
-// (children first = by age) — step_add of a00_driver.c
-__device__ void install(TaskLDS & S, const int8_t * br, int nb, int8_t * nd, int nn, double rate, double mui)
+// install a proposal: toggle buffers, fresh (a,b) of the changed branches (mask brm), node-update
+// list of the nodes in mask ndm in children-first order (= by age) — step_add of a00_driver.c
+__device__ void install(TaskLDS & S, uint32_t brm, uint32_t ndm, double rate)
 {
   Tree & t = S.tr;
-  for (int a = 0; a < nn; ++a) for (int b = a + 1; b < nn; ++b) if (nd[b] == nd[a]) { nd[b] = nd[--nn]; --b; }
-  for (int a = 1; a < nn; ++a)
+  while (brm)
   {
-    const int8_t v = nd[a]; int b = a;
-    for (; b > 0 && t.time[nd[b-1]] > t.time[v]; --b) nd[b] = nd[b-1];
-    nd[b] = v;
-  }
-  for (int a = 0; a < nb; ++a)
-  {
-    const int x = br[a];
+    const int x = __ffs(brm) - 1; brm &= brm - 1;
     swap_pmat(t, x);
-    const double len = (t.time[t.parent[x]] - t.time[x])*mui;                // locus.c:2350
+    const double len = (t.time[t.parent[x]] - t.time[x])*1.0;                // rate_mui = 1 (locus.c:2350)
     double A, B;
     jc69_ab(len, rate, A, B);
     S.ab[t.pmat[x]][0] = A; S.ab[t.pmat[x]][1] = B;
   }
-  for (int a = 0; a < nn; ++a) swap_clv(t, nd[a]);
+  int nn = 0;
+  while (ndm)
+  {
+    // the youngest remaining node next (a parent is always older than its children)
+    int best = -1; double tb = 0;
+    for (uint32_t m = ndm; m; m &= m - 1)
+    {
+      const int x = __ffs(m) - 1;
+      if (best < 0 || t.time[x] < tb) { best = x; tb = t.time[x]; }
+    }
+    ndm &= ~(1u << best);
+    swap_clv(t, best);
+    S.ops[nn].parent = (int8_t)best;            // node ids for now; buffer indices below, once all toggles are done
+    ++nn;
+  }
   for (int a = 0; a < nn; ++a)
   {
-    const int x = nd[a], l = t.left[x], r = t.right[x];
+    const int x = S.ops[a].parent, l = t.left[x], r = t.right[x];
     S.ops[a].parent = t.clv[x]; S.ops[a].lc = t.clv[l]; S.ops[a].lp = t.pmat[l];
     S.ops[a].rc = t.clv[r]; S.ops[a].rp = t.pmat[r];
   }
@@ -144,16 +151,14 @@ __device__ bool propose_gage(TaskLDS & S, int k, double rate)
   for (int j = 0; j < n; ++j) if (t.left[j] >= 0 && c++ == k) { v = j; break; }
   if (v < 0) return false;
   const double u = rndu(&t.rng);
-  S.undo = t;
   const double lo = fmax(t.time[t.left[v]], t.time[t.right[v]]);
   const int p = t.parent[v];
   S.hast = 0;
   if (p >= 0) t.time[v] = lo + (0.02 + 0.96*u)*(t.time[p] - lo);
   else { const double c_ = exp(0.6*(u - 0.5)); t.time[v] = lo + (t.time[v] - lo)*c_; S.hast = log(c_); }
-  int8_t br[4], nd[MAXN]; int nb = 0;
-  br[nb++] = t.left[v]; br[nb++] = t.right[v]; if (p >= 0) br[nb++] = (int8_t)v;
-  const int nn = path_to_root(t, v, nd);
-  install(S, br, nb, nd, nn, rate, 1.0);
+  uint32_t brm = (1u << t.left[v]) | (1u << t.right[v]);
+  if (p >= 0) brm |= 1u << v;
+  install(S, brm, path_mask(t, v), rate);
   return true;
 }
 
@@ -166,17 +171,27 @@ __device__ bool propose_gspr(TaskLDS & S, int k, double rate)
   for (int j = 0; j < n; ++j) if (j != t.root && c++ == k) { a = j; break; }
   if (a < 0) return false;
   const double u1 = rndu(&t.rng), u2 = rndu(&t.rng);
-  S.undo = t;
   const int root_before = t.root;
   const int p = t.parent[a], s = t.left[p] == a ? t.right[p] : t.left[p], g = t.parent[p];
   t.parent[s] = (int8_t)g;
   if (g >= 0) { if (t.left[g] == p) t.left[g] = (int8_t)s; else t.right[g] = (int8_t)s; } else t.root = s;
-  bool banned[MAXN]; int8_t stack[MAXN], targets[MAXN]; int sp = 0, ntg = 0;
-  for (int j = 0; j < n; ++j) banned[j] = false;
-  banned[p] = true; stack[sp++] = (int8_t)a;
-  while (sp) { const int x = stack[--sp]; banned[x] = true; if (t.left[x] >= 0) { stack[sp++] = t.left[x]; stack[sp++] = t.right[x]; } }
-  for (int j = 0; j < n; ++j) if (!banned[j]) targets[ntg++] = (int8_t)j;
-  int tgt = targets[(int)(u1*ntg) % ntg];
+  // regraft targets: every node outside a's subtree, except p
+  uint32_t banned = (1u << a) | (1u << p);
+  for (int pass = 0; pass < n; ++pass)
+  {
+    uint32_t add = 0;
+    for (uint32_t m = banned & ~(1u << p); m; m &= m - 1)
+    {
+      const int x = __ffs(m) - 1;
+      if (t.left[x] >= 0) add |= (1u << t.left[x]) | (1u << t.right[x]);
+    }
+    if (!(add & ~banned)) break;
+    banned |= add;
+  }
+  const uint32_t allowed = ~banned & ((1u << n) - 1u);
+  const int ntg = __popc(allowed);
+  int pick = (int)(u1*ntg) % ntg, tgt = -1;
+  for (uint32_t m = allowed; m; m &= m - 1) if (pick-- == 0) { tgt = __ffs(m) - 1; break; }
   int pc = t.parent[tgt];
   double lo = fmax(t.time[a], t.time[tgt]);
   if (pc >= 0 && t.time[pc] <= lo) { tgt = s; pc = t.parent[s]; lo = fmax(t.time[a], t.time[tgt]); }
@@ -184,26 +199,23 @@ __device__ bool propose_gspr(TaskLDS & S, int k, double rate)
   t.time[p] = tnew; t.left[p] = (int8_t)a; t.right[p] = (int8_t)tgt; t.parent[a] = (int8_t)p; t.parent[tgt] = (int8_t)p;
   t.parent[p] = (int8_t)pc;
   if (pc >= 0) { if (t.left[pc] == tgt) t.left[pc] = (int8_t)p; else t.right[pc] = (int8_t)p; } else t.root = p;
-  int8_t nd[2*MAXN + MAXN]; int nn = path_to_root(t, p, nd);
-  if (g >= 0) nn += path_to_root(t, g, nd + nn);
-  int bset[4] = {a, tgt, p, s};
+  uint32_t ndm = path_mask(t, p);
+  if (g >= 0) ndm |= path_mask(t, g);
+  uint32_t bset = (1u << a) | (1u << tgt) | (1u << p) | (1u << s);
   if (t.root != root_before)
   {
+    // the root node object keeps its identity (gtree.c:6129-6175): rename the two ids in the sets
     const int newtop = t.root;
     swap_ids(t, newtop, root_before);
-    for (int j = 0; j < nn; ++j) nd[j] = (int8_t)(nd[j] == newtop ? root_before : nd[j] == root_before ? newtop : nd[j]);
-    for (int j = 0; j < 4; ++j) bset[j] = bset[j] == newtop ? root_before : bset[j] == root_before ? newtop : bset[j];
-    nn += path_to_root(t, newtop, nd + nn);
+    const uint32_t bn = 1u << newtop, br_ = 1u << root_before;
+    auto ren = [&](uint32_t m) { const uint32_t hn = m & bn, hr = m & br_; m &= ~(bn | br_); if (hn) m |= br_; if (hr) m |= bn; return m; };
+    ndm = ren(ndm) | path_mask(t, newtop);
+    bset = ren(bset);
   }
-  int8_t br[4]; int nb = 0;
-  for (int j = 0; j < 4; ++j)
-  {
-    bool dup = false;
-    for (int q = 0; q < nb; ++q) if (br[q] == bset[j]) dup = true;
-    if (!dup && t.parent[bset[j]] >= 0) br[nb++] = (int8_t)bset[j];
-  }
+  uint32_t brm = 0;
+  for (uint32_t m = bset; m; m &= m - 1) { const int x = __ffs(m) - 1; if (t.parent[x] >= 0) brm |= 1u << x; }
   S.hast = 0;
-  install(S, br, nb, nd, nn, rate, 1.0);
+  install(S, brm, ndm, rate);
   return true;
 }
 
@@ -213,7 +225,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   __shared__ double  s_clv[MAXBUF][BS][4];
   __shared__ double  s_term[BS];
   const uint32_t b = blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
-  const uint32_t t0 = A.blk_task_off[b], t1 = A.blk_task_off[b+1];
+  const uint32_t t0 = A.blk_task_off[b], ntask = A.blk_task_off[b+1] - t0;
   const uint32_t task = A.lane_task[gl];
   const bool active = task != 0xffffffffu;
   const uint32_t ts = active ? task - t0 : 0u;
@@ -221,36 +233,43 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   const bool restore_mix = A.epoch != 0 && *A.mix_flag == A.epoch;      // epoch 0: nothing pending
 
   // ---- load: tree (or its pre-mix snapshot), (a,b) table, this lane's CLV buffers and constants
-  LocusDev L{};
-  uint32_t n = 0, tipcodes = 0, wgt = 0;
+  uint32_t np = 0, tips = 0, n = 0, tipcodes = 0, wgt = 0;
   double f0 = 0, f1 = 0, f2 = 0, f3 = 0, rw = 0, rate = 1;
+  double * g_clv = nullptr, * g_pmat = nullptr;
   if (active)
   {
-    L = A.loci[A.task_locus[task]];
+    const LocusDev & L = A.loci[A.task_locus[task]];
+    np = L.np; tips = L.tips_n; g_clv = L.clv; g_pmat = L.pmat;
     n = gl - A.task_lane0[task];
     const double * par = L.par;
     rate = par[par_rates(1)]; rw = par[par_rate_weights(1)];
     const double * f = par + par_matrix(1, 4, 0) + pm_freqs(4);
     f0 = f[0]; f1 = f[1]; f2 = f[2]; f3 = f[3];
     wgt = L.weights[n];
-    for (uint32_t tip = 0; tip < L.tips_n; ++tip) tipcodes |= (uint32_t)(L.tips[(size_t)tip*L.np + n] & 15u) << (4*tip);
-    const uint32_t nbuf = 2*(L.tips_n - 1);
+    const uint8_t * tp = L.tips;
+    for (uint32_t tip = 0; tip < tips; ++tip) tipcodes |= (uint32_t)(tp[(size_t)tip*np + n] & 15u) << (4*tip);
+    const uint32_t nbuf = 2*(tips - 1);
     for (uint32_t c = 0; c < nbuf; ++c)
     {
-      const double2 * p = reinterpret_cast<const double2 *>(L.clv + ((size_t)c*L.np + n)*4);
+      const double2 * p = reinterpret_cast<const double2 *>(g_clv + ((size_t)c*np + n)*4);
       const double2 u = p[0], w = p[1];
       s_clv[c][lane][0] = u.x; s_clv[c][lane][1] = u.y; s_clv[c][lane][2] = w.x; s_clv[c][lane][3] = w.y;
     }
   }
+  // trees of this workgroup's loci: all lanes copy, 16 B at a time
+  {
+    constexpr uint32_t U = sizeof(Tree)/16;
+    const Tree * src = (restore_mix ? A.snap : A.trees) + t0;
+    for (uint32_t i = lane; i < ntask*U; i += BS)
+      reinterpret_cast<uint4 *>(&s_task[i/U].tr)[i % U] = reinterpret_cast<const uint4 *>(src + i/U)[i % U];
+  }
+  __syncthreads();
   if (leader)
   {
     TaskLDS & S = s_task[ts];
-    const uint4 * src = reinterpret_cast<const uint4 *>((restore_mix ? A.snap : A.trees) + task);
-    uint4 * dst = reinterpret_cast<uint4 *>(&S.tr);
-    for (uint32_t i = 0; i < sizeof(Tree)/16; ++i) dst[i] = src[i];
     if (restore_mix) { S.tr.rng = A.trees[task].rng; S.tr.proposals = A.trees[task].proposals; S.tr.accepted = A.trees[task].accepted; }
-    const uint32_t npm = 2*(2*L.tips_n - 2);
-    for (uint32_t i = 0; i < npm; ++i) { S.ab[i][0] = L.pmat[2*i]; S.ab[i][1] = L.pmat[2*i+1]; }
+    const uint32_t npm = 2*(2*tips - 2);
+    for (uint32_t i = 0; i < npm; ++i) { S.ab[i][0] = g_pmat[2*i]; S.ab[i][1] = g_pmat[2*i+1]; }
     S.nops = 0; S.active = 0;
   }
   __syncthreads();
@@ -258,6 +277,13 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   const uint32_t nprop = A.mode == 0 ? A.nsteps_gage + A.nsteps_gspr : (A.mode == 1 || A.mode == 3 ? 1u : 0u);
   for (uint32_t step = 0; step < nprop; ++step)
   {
+    // ---- undo copy of every tree of the workgroup (all lanes, 16 B at a time)
+    {
+      constexpr uint32_t U = sizeof(Tree)/16;
+      for (uint32_t i = lane; i < ntask*U; i += BS)
+        reinterpret_cast<uint4 *>(&s_task[i/U].undo)[i % U] = reinterpret_cast<const uint4 *>(&s_task[i/U].tr)[i % U];
+    }
+    __syncthreads();
     // ---- phase 1: the locus's leader lane proposes
     if (leader)
     {
@@ -269,16 +295,20 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
         // mixing (mix_step of a00_driver.c) or start-up: every branch, every inner node
         Tree & t = S.tr;
         const int nn_ = 2*t.tips - 1;
-        if (A.mode == 1) { A.snap[task] = t; }
-        int8_t br[MAXN], nd[MAXN]; int nb = 0, nn = 0;
+        if (A.mode == 1) A.snap[task] = t;
+        uint32_t brm = 0, ndm = 0;
         for (int k = 0; k < nn_; ++k)
         {
-          if (t.left[k] >= 0) { if (A.mode == 1) t.time[k] *= A.mix_c; nd[nn++] = (int8_t)k; }
-          if (t.parent[k] >= 0) br[nb++] = (int8_t)k;
+          if (t.left[k] >= 0) { if (A.mode == 1) t.time[k] *= A.mix_c; ndm |= 1u << k; }
+          if (t.parent[k] >= 0) brm |= 1u << k;
         }
-        if (A.mode == 3) { for (int k = 0; k < nb; ++k) swap_pmat(t, br[k]); for (int k = 0; k < nn; ++k) swap_clv(t, nd[k]); }
+        if (A.mode == 3)
+        {
+          for (uint32_t m = brm; m; m &= m - 1) swap_pmat(t, __ffs(m) - 1);       // start-up evaluates in place:
+          for (uint32_t m = ndm; m; m &= m - 1) swap_clv(t, __ffs(m) - 1);        // toggle twice = no toggle
+        }
         S.hast = 0;
-        install(S, br, nb, nd, nn, rate, 1.0);
+        install(S, brm, ndm, rate);
         ok = true;
       }
       S.active = ok ? 1 : 0;
@@ -290,7 +320,6 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     if (active && s_task[ts].active)
     {
       const TaskLDS & S = s_task[ts];
-      const uint32_t tips = L.tips_n;
       for (int o = 0; o < S.nops; ++o)
       {
         const Op op = S.ops[o];
@@ -315,18 +344,14 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     {
       TaskLDS & S = s_task[ts];
       double lnl = 0;
-      for (uint32_t q = 0; q < L.np; ++q) lnl += s_term[lane + q];
+      for (uint32_t q = 0; q < np; ++q) lnl += s_term[lane + q];
       if (A.mode == 0)
       {
         const double lnacc = lnl - S.tr.lnl + S.hast;
         const double u = rndu(&S.tr.rng);
         S.tr.proposals++;
-        if (lnacc >= 0 || u < exp(lnacc)) { S.tr.lnl = lnl; S.tr.accepted++; }
-        else
-        {
-          const a00_rng_t r = S.tr.rng; const uint32_t pr = S.tr.proposals, ac = S.tr.accepted;
-          S.tr = S.undo; S.tr.rng = r; S.tr.proposals = pr; S.tr.accepted = ac;
-        }
+        if (lnacc >= 0 || u < exp(lnacc)) { S.tr.lnl = lnl; S.tr.accepted++; S.active = 1; }
+        else S.active = 2;                               // rejected: restore below
       }
       else
       {
@@ -334,26 +359,38 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
         S.tr.lnl = lnl;
       }
     }
-    // (the next phase 1 is run by the same lane that ran this phase 3; followers wait at its barrier)
+    __syncthreads();
+    // ---- rejected proposals: topology, ages and buffer indices come back from the undo copy (all lanes)
+    if (A.mode == 0)
+    {
+      constexpr uint32_t U = (uint32_t)(offsetof(Tree, lnl)/16);      // everything before lnl/rng/counters
+      for (uint32_t i = lane; i < ntask*U; i += BS)
+        if (s_task[i/U].active == 2)
+          reinterpret_cast<uint4 *>(&s_task[i/U].tr)[i % U] = reinterpret_cast<const uint4 *>(&s_task[i/U].undo)[i % U];
+      __syncthreads();
+      if (leader && s_task[ts].active == 2) s_task[ts].tr.root = s_task[ts].undo.root;
+    }
   }
   __syncthreads();
 
   // ---- store
+  {
+    constexpr uint32_t U = sizeof(Tree)/16;
+    for (uint32_t i = lane; i < ntask*U; i += BS)
+      reinterpret_cast<uint4 *>(A.trees + t0 + i/U)[i % U] = reinterpret_cast<const uint4 *>(&s_task[i/U].tr)[i % U];
+  }
   if (leader)
   {
-    TaskLDS & S = s_task[ts];
-    uint4 * dst = reinterpret_cast<uint4 *>(A.trees + task);
-    const uint4 * src = reinterpret_cast<const uint4 *>(&S.tr);
-    for (uint32_t i = 0; i < sizeof(Tree)/16; ++i) dst[i] = src[i];
-    const uint32_t npm = 2*(2*L.tips_n - 2);
-    for (uint32_t i = 0; i < npm; ++i) { L.pmat[2*i] = S.ab[i][0]; L.pmat[2*i+1] = S.ab[i][1]; }
+    const TaskLDS & S = s_task[ts];
+    const uint32_t npm = 2*(2*tips - 2);
+    for (uint32_t i = 0; i < npm; ++i) { g_pmat[2*i] = S.ab[i][0]; g_pmat[2*i+1] = S.ab[i][1]; }
   }
   if (active && nprop)
   {
-    const uint32_t nbuf = 2*(L.tips_n - 1);
+    const uint32_t nbuf = 2*(tips - 1);
     for (uint32_t c = 0; c < nbuf; ++c)
     {
-      double2 * p = reinterpret_cast<double2 *>(L.clv + ((size_t)c*L.np + n)*4);
+      double2 * p = reinterpret_cast<double2 *>(g_clv + ((size_t)c*np + n)*4);
       double2 u, w; u.x = s_clv[c][lane][0]; u.y = s_clv[c][lane][1]; w.x = s_clv[c][lane][2]; w.y = s_clv[c][lane][3];
       p[0] = u; p[1] = w;
     }
@@ -492,6 +529,18 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c)
   a.epoch = (s->mix_pending && (mode == 0 || mode == 2)) ? s->epoch : 0u;
   if (mode == 0 || mode == 2) s->mix_pending = false;
   a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2; a.mix_c = mix_c;
+  if (const char * dbg = getenv("BPA_SMP_STEPS")) { unsigned g = 0, q = 0; if (sscanf(dbg, "%u,%u", &g, &q) == 2) { a.nsteps_gage = g; a.nsteps_gspr = q; } }
+  if (getenv("BPA_SMP_TRACE"))
+  {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipExtLaunchKernelGGL(smp::sweep_kernel, dim3(s->nblocks), dim3(smp::BS), 0, e->stream, e0, e1, 0, a);
+    (void)hipStreamSynchronize(e->stream);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    fprintf(stderr, "[smp] mode %u gage %u gspr %u epoch %u blocks %u: %.1f us\n", mode, a.nsteps_gage, a.nsteps_gspr, a.epoch, s->nblocks, ms*1e3);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    s->launches++;
+    return 1;
+  }
   hipLaunchKernelGGL(smp::sweep_kernel, dim3(s->nblocks), dim3(smp::BS), 0, e->stream, a);
   HIPCHK(hipGetLastError());
   s->launches++;
@@ -513,6 +562,7 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
   for (unsigned it = 0; it < iterations; ++it)
   {
     if (!sampler_launch(s, 0, 1.0)) return 0;                    // GAGE + GSPR of every locus (settles a pending mix first)
+    if (getenv("BPA_SMP_NOMIX")) continue;
     const double lnc = 0.1*(a00_rndu(&s->grng) - 0.5), c = std::exp(lnc);
     const double uacc = a00_rndu(&s->grng);
     if (!sampler_launch(s, 1, c)) return 0;                      // mixing proposal of every locus

@@ -1,0 +1,11 @@
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import bpp_amd
+from bpp_amd import synth
+import tape
+eng = bpp_amd.Engine(0)
+data = synth.make_dataset(10000, 1000, 4, "jc69", 1, seed=12345)
+loci = tape.make_engine_loci(eng, data)
+smp = bpp_amd.Sampler(eng, loci, data, seed=1)
+smp.initialize(); smp.iterate(3); eng.synchronize()
