@@ -126,7 +126,12 @@ def main():
             local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
-        stream = torch.cuda.current_stream().cuda_stream
+        # the engine and the collectives share ONE explicit torch stream, so that an all-reduce is
+        # ordered after the kernel that produced the sum (torch's default stream has handle 0, which
+        # the engine would replace by a private stream)
+        tstream = torch.cuda.Stream()
+        torch.cuda.set_stream(tstream)
+        stream = tstream.cuda_stream
         sum_buf = torch.zeros(4, dtype=torch.float64, device="cuda")
 
     eng = bpp_amd.Engine(local_rank, stream)
@@ -233,11 +238,22 @@ def main():
     tm = eng.timing() if not args.no_timing_events else None
     eng.enable_timing(False)
 
+    allreduce_check = None
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # self-check of the N>1 data path (outside the timed region): the device-side sum of the last
+        # all-loci step, all-reduced, must equal the sum over ranks of the per-locus values
+        last = [p for st, p in zip(iters[-1], plans[-1]) if st.global_decision is not None][-1]
+        last.launch()
+        dist.all_reduce(sum_buf)
+        torch.cuda.synchronize()
+        got = float(sum_buf[0].item())
+        want = torch.tensor([float(last.lnl().sum())], dtype=torch.float64, device="cuda")
+        dist.all_reduce(want)
+        allreduce_check = "ok" if abs(got - float(want.item())) <= 1e-9 * abs(got) else f"MISMATCH {got} vs {float(want.item())}"
 
     ms_per_step = 1e3 * elapsed / args.steps
     total_loci = nloci * world
@@ -325,6 +341,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "device_resident_sampler": sampler,
+            "allreduce_check": allreduce_check,
         }
         print(json.dumps(out), flush=True)
 
