@@ -79,6 +79,72 @@ def cpu_baseline(data, steps_init, steps_iter, n_iter, budget_s=12.0, sample=192
                 cores=1, sampled_loci=done, repeats=reps, seconds=time.time() - t_start)
 
 
+SIM_CTL = """seed = 12345
+seqfile = syn.txt
+Imapfile = syn.Imap.txt
+species&tree = 4  A B C D
+                  1 1 1 1
+                  (((A #0.002, B #0.002):0.001 #0.002, C #0.002):0.002 #0.002, D #0.002):0.003 #0.002;
+phase = 0 0 0 0
+loci&length = {nloci} {sites}
+clock = 1
+locusrate = 0
+model = 0
+"""
+A00_CTL = """seed = 1
+seqfile = syn.txt
+Imapfile = syn.Imap.txt
+jobname = out
+speciesdelimitation = 0
+speciestree = 0
+species&tree = 4  A B C D
+                  1 1 1 1
+                  (((A, B), C), D);
+phase = 0 0 0 0
+usedata = 1
+nloci = {nloci}
+model = jc69
+cleandata = 0
+thetaprior = gamma 2 1000
+tauprior = gamma 2 500
+finetune = 1
+print = 1 0 0 0
+burnin = 0
+sampfreq = 1
+nsample = {nsample}
+{threads}
+"""
+
+
+def bpp_program_baseline(nloci, sites, threads_list, n1=20, n2=120):
+    """The unmodified reference PROGRAM (oracle/_ref/bpp, built in place from /root/reference) on this
+    box's host cores: data from its own simulator (SURVEY.md App. B control files), A00 JC69, whole
+    MCMC iterations/s from the differential wall time of an n1- and an n2-iteration run, per thread
+    count.  This includes BPP's MCMC control (MSC prior, proposals), which this repo does not build."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib as O
+    if not os.path.exists(O.REF_BIN):
+        return None
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "sim.ctl"), "w").write(SIM_CTL.format(nloci=nloci, sites=sites))
+        subprocess.run([O.REF_BIN, "--simulate", "sim.ctl"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=300)
+        for th in threads_list:
+            tl = f"threads = {th} 1 1" if th > 1 else ""
+            ts = []
+            for ns in (n1, n2):
+                open(os.path.join(d, "a00.ctl"), "w").write(A00_CTL.format(nloci=nloci, nsample=ns, threads=tl))
+                t0 = time.perf_counter()
+                subprocess.run([O.REF_BIN, "--cfile", "a00.ctl"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=900)
+                ts.append(time.perf_counter() - t0)
+            out[th] = round((n2 - n1) / max(ts[1] - ts[0], 1e-9) * nloci / 10000.0, 2)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +155,8 @@ def main():
     ap.add_argument("--tape-iters", type=int, default=4, help="distinct A00 iterations in the resident tape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true", help="skip the device-resident sampler section")
+    ap.add_argument("--no-bpp-program", action="store_true",
+                    help="skip timing the unmodified reference program (1 thread and many threads) on the host cores")
     ap.add_argument("--no-timing-events", action="store_true")
     ap.add_argument("--event-stride", type=int, default=7,
                     help="attach the kernel start/stop events to every n-th launch of the timed region "
@@ -321,9 +389,23 @@ def main():
                    sample=f"{cb['sampled_loci']} loci x {n_cpu_iter} tape iterations x {cb['repeats']} repeats "
                           f"({cb['seconds']:.1f}s), same tape as the GPU, AVX2 back-end, 1 thread")
 
+    bpp_prog = None
+    if rank == 0 and world == 1 and args.config == "c2" and not args.no_cpu_baseline and not args.no_bpp_program:
+        try:
+            ncores = os.cpu_count() or 1
+            many = max(2, min(64, ncores // 2))
+            r = bpp_program_baseline(nloci, cfg["sites"], [1, many])
+            if r:
+                bpp_prog = dict(unit="whole MCMC iterations/s of the unmodified reference program (10k loci, A00 JC69), "
+                                     "incl. its MCMC control", threads={str(k): v for k, v in r.items()},
+                                host_logical_cores=ncores, kind="reference",
+                                sample="bpp --simulate data (seed 12345), differential wall time of 20- vs 120-iteration runs")
+        except Exception as ex:       # noqa: BLE001
+            bpp_prog = dict(error=str(ex)[:200])
+
     if rank == 0:
         out = {
-            "metric": "MCMC iterations/sec (A00), 10k loci per GPU, likelihood hot path",
+            "metric": "MCMC iterations/sec (A00) + site-lnL updates/sec, 10k loci per GPU (likelihood hot path)",
             "value": round(iters_per_s_10k, 3),
             "unit": "iterations/s (one iteration = A00 proposal schedule over 10 000 loci)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -340,6 +422,7 @@ def main():
                               if tm and tm["launches"] else None),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "reference_program_on_host": bpp_prog,
             "device_resident_sampler": sampler,
             "allreduce_check": allreduce_check,
         }
