@@ -104,6 +104,8 @@ def lib():
         "bpa_sampler_create": (vp, [vp, C.POINTER(vp), u, C.c_ulong]),
         "bpa_sampler_destroy": (None, [vp]),
         "bpa_sampler_set_tree": (i, [vp, u, C.POINTER(i), C.POINTER(i), dp, i]),
+        "bpa_sampler_set_taus": (i, [vp, dp, u]),
+        "bpa_sampler_get_taus": (i, [vp, dp]),
         "bpa_sampler_initialize": (i, [vp]),
         "bpa_sampler_iterate": (i, [vp, u]),
         "bpa_sampler_get_tree": (i, [vp, u, C.POINTER(i), C.POINTER(i), C.POINTER(i), dp, C.POINTER(i),
@@ -135,6 +137,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_plan_enable_sum", "bpa_plan_get_sum", "bpa_plans_launch",
             "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride",
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
+            "bpa_sampler_set_taus", "bpa_sampler_get_taus",
             "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary"]
 
 
@@ -458,6 +461,17 @@ class Sampler:
             t = _f64(d["times"])
             _chk(L.bpa_sampler_set_tree(self.h, k, l.ctypes.data_as(ip), r.ctypes.data_as(ip), _dp(t), int(d["root"])))
         self.ntips = [len(d["seqs"]) for d in data]
+
+    def set_taus(self, taus):
+        t = _f64(taus)
+        self._ntaus = len(t)
+        _chk(lib().bpa_sampler_set_taus(self.h, _dp(t), len(t)))
+
+    def taus(self):
+        out = np.zeros(getattr(self, "_ntaus", 0))
+        if len(out):
+            _chk(lib().bpa_sampler_get_taus(self.h, _dp(out)))
+        return list(out)
 
     def initialize(self):
         _chk(lib().bpa_sampler_initialize(self.h))

@@ -35,6 +35,7 @@ struct a00_driver
   /* per-locus undo snapshot (whole small tree) */
   int ** u_left, ** u_right, ** u_parent, ** u_clv, ** u_pmat, ** u_scaler; double ** u_time; int * u_root;
   unsigned long proposals, accepted, steps;
+  double taus[8]; unsigned ntaus;
 };
 
 
@@ -313,6 +314,64 @@ static int gspr_step(a00_driver_t * d, int k)
   return 1;
 }
 
+int a00_set_taus(a00_driver_t * d, const double * taus, unsigned n)
+{
+  unsigned i;
+  if (n > 8) return 0;
+  for (i = 0; i < n; ++i) d->taus[i] = taus[i];
+  d->ntaus = n;
+  return 1;
+}
+unsigned a00_get_taus(const a00_driver_t * d, double * taus)
+{
+  unsigned i;
+  for (i = 0; i < d->ntaus; ++i) taus[i] = d->taus[i];
+  return d->ntaus;
+}
+
+/* TAU j: rubber-band rescaling of the gene-node ages around tau_j in every locus (stree.c:5512);
+   loci without a node in the band are left out of the step; ONE decision for all loci */
+static int tau_step(a00_driver_t * d, unsigned j)
+{
+  unsigned i, n = 0; double sum = 0;
+  const double tau = d->taus[j], lo = j ? d->taus[j-1] : 0.0, hi = j + 1 < d->ntaus ? d->taus[j+1] : -1.0;
+  const double tnew = a00_tau_proposal(a00_rndu(&d->grng), lo, tau, hi);
+  const double uacc = a00_rndu(&d->grng);
+  step_begin(d);
+  for (i = 0; i < d->nloci; ++i)
+  {
+    a00_tree_t * t = d->trees + i; int br[MAXN], nd[MAXN], nb = 0, nn = 0, k, v, moved = 0;
+    char isbr[MAXN], isnd[MAXN];
+    snapshot(d, i);
+    memset(isbr, 0, (size_t)t->n); memset(isnd, 0, (size_t)t->n);
+    for (k = 0; k < t->n; ++k)
+      if (t->left[k] >= 0)
+      {
+        const double tn = a00_rubber_band(t->time[k], lo, tau, tnew, hi);
+        if (tn != t->time[k])
+        {
+          t->time[k] = tn; ++moved;
+          isbr[t->left[k]] = isbr[t->right[k]] = 1; if (t->parent[k] >= 0) isbr[k] = 1;
+          for (v = k; v >= 0; v = t->parent[v]) isnd[v] = 1;              /* gtree_return_partials */
+        }
+      }
+    if (!moved) continue;
+    for (k = 0; k < t->n; ++k) { if (isbr[k]) br[nb++] = k; if (isnd[k]) nd[nn++] = k; }
+    step_add(d, n, i, br, nb, nd, nn);
+    ++n;
+  }
+  if (!step_eval(d, n)) return 0;
+  for (i = 0; i < n; ++i) sum += d->s_lnl[i] - d->trees[d->s_locus[i]].lnl;
+  d->proposals++;
+  if (sum >= 0 || uacc < exp(sum))
+  {
+    d->accepted++; d->taus[j] = tnew;
+    for (i = 0; i < n; ++i) d->trees[d->s_locus[i]].lnl = d->s_lnl[i];
+  }
+  else for (i = 0; i < n; ++i) restore(d, d->s_locus[i]);
+  return 1;
+}
+
 /* MIX: every age of every locus times c; ONE decision from the summed difference (prop_mixing.c:203-205) */
 static int mix_step(a00_driver_t * d)
 {
@@ -335,7 +394,12 @@ static int mix_step(a00_driver_t * d)
   for (i = 0; i < d->nloci; ++i) sum += d->s_lnl[i] - d->trees[i].lnl;
   lnacc = sum + (double)ninner*lnc;                       /* multiplier proposal on ninner ages */
   d->proposals++;
-  if (lnacc >= 0 || uacc < exp(lnacc)) { d->accepted++; for (i = 0; i < d->nloci; ++i) d->trees[i].lnl = d->s_lnl[i]; }
+  if (lnacc >= 0 || uacc < exp(lnacc))
+  {
+    d->accepted++;
+    for (i = 0; i < d->nloci; ++i) d->trees[i].lnl = d->s_lnl[i];
+    for (i = 0; i < d->ntaus; ++i) d->taus[i] *= c;                  /* the species tree is scaled too */
+  }
   else for (i = 0; i < d->nloci; ++i) restore(d, i);
   return 1;
 }
@@ -346,6 +410,7 @@ int a00_iterate(a00_driver_t * d)
   for (i = 0; i < d->nloci; ++i) if (d->trees[i].tips > maxtips) maxtips = d->trees[i].tips;
   for (k = 0; k < maxtips - 1; ++k)   if (!gage_step(d, k)) return 0;
   for (k = 0; k < 2*maxtips - 2; ++k) if (!gspr_step(d, k)) return 0;
+  for (k = 0; k < (int)d->ntaus; ++k) if (!tau_step(d, (unsigned)k)) return 0;
   return mix_step(d);
 }
 

@@ -58,9 +58,12 @@ struct Args
   double * mix_delta;          // [T] lnL(proposed) - lnL(current) of the mixing step
   const uint32_t * mix_flag;   // epoch of the last REJECTED mixing step
   uint32_t epoch;              // restore from snap when *mix_flag == epoch
-  uint32_t mode;               // 0 sweep (GAGE+GSPR), 1 mix, 2 only settle a pending mix decision, 3 start-up evaluation
+  uint32_t mode;               // 0 sweep (GAGE+GSPR), 1 mix, 2 only settle a pending decision, 3 start-up evaluation, 4 tau
   uint32_t nsteps_gage, nsteps_gspr;
   double   mix_c;
+  const double * taus;         // [ntaus] species-tree divergence times (device-resident, mode 4)
+  uint32_t ntaus, tau_j;
+  double   tau_u;              // the proposal's uniform number (mode 4)
 };
 
 // a00_rndu of bpp_amd_host.h, callable on the device (same integer recurrence, same conversion)
@@ -68,6 +71,18 @@ __host__ __device__ inline double rndu(a00_rng_t * r)
 {
   *r = *r*6364136223846793005ULL + 1442695040888963407ULL;
   return (double)((*r >> 11) + 0.5)*(1.0/9007199254740992.0);
+}
+
+// a00_rubber_band / a00_tau_proposal of bpp_amd_host.h for the device (same expressions)
+__host__ __device__ inline double rubber_band(double t, double lo, double tau, double tnew, double hi)
+{
+  if (t > lo && t <= tau) return lo + (t - lo)*(tnew - lo)/(tau - lo);
+  if (t > tau && (hi < 0 || t < hi)) return hi < 0 ? tnew + (t - tau) : hi - (hi - t)*(hi - tnew)/(hi - tau);
+  return t;
+}
+__host__ __device__ inline double tau_proposal(double u, double lo, double tau, double hi)
+{
+  return lo + (0.05 + 0.9*u)*((hi < 0 ? 2*tau - lo : hi) - lo);
 }
 
 __device__ __forceinline__ void swap_clv(Tree & t, int i)
@@ -277,7 +292,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   }
   __syncthreads();
 
-  const uint32_t nprop = A.mode == 0 ? A.nsteps_gage + A.nsteps_gspr : (A.mode == 1 || A.mode == 3 ? 1u : 0u);
+  const uint32_t nprop = A.mode == 0 ? A.nsteps_gage + A.nsteps_gspr : (A.mode == 2 ? 0u : 1u);
   for (uint32_t step = 0; step < nprop; ++step)
   {
     // ---- undo copy of every tree of the workgroup (all lanes, 16 B at a time)
@@ -293,6 +308,32 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       TaskLDS & S = s_task[ts];
       bool ok;
       if (A.mode == 0) ok = step < A.nsteps_gage ? propose_gage(S, (int)step, rate) : propose_gspr(S, (int)(step - A.nsteps_gage), rate);
+      else if (A.mode == 4)
+      {
+        // TAU j (tau_step of a00_driver.c): rubber band around tau_j, dirty branches and root paths
+        Tree & t = S.tr;
+        const int nn_ = 2*t.tips - 1;
+        A.snap[task] = t;
+        const uint32_t j = A.tau_j;
+        const double tau = A.taus[j], lo = j ? A.taus[j-1] : 0.0, hi = j + 1 < A.ntaus ? A.taus[j+1] : -1.0;
+        const double tnew = tau_proposal(A.tau_u, lo, tau, hi);
+        uint32_t brm = 0, ndm = 0;
+        for (int k = 0; k < nn_; ++k)
+          if (t.left[k] >= 0)
+          {
+            const double tn = rubber_band(t.time[k], lo, tau, tnew, hi);
+            if (tn != t.time[k])
+            {
+              t.time[k] = tn;
+              brm |= (1u << t.left[k]) | (1u << t.right[k]);
+              if (t.parent[k] >= 0) brm |= 1u << k;
+              ndm |= path_mask(t, k);
+            }
+          }
+        S.hast = 0;
+        ok = ndm != 0;
+        if (ok) install(S, brm, ndm, rate); else A.mix_delta[task] = 0.0;
+      }
       else
       {
         // mixing (mix_step of a00_driver.c) or start-up: every branch, every inner node
@@ -358,7 +399,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       }
       else
       {
-        A.mix_delta[task] = A.mode == 1 ? lnl - S.tr.lnl : 0.0;
+        A.mix_delta[task] = A.mode == 3 ? 0.0 : lnl - S.tr.lnl;
         S.tr.lnl = lnl;
       }
     }
@@ -400,15 +441,24 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   }
 }
 
-// the single decision of the mixing step (prop_mixing.c:203-205): flag := epoch when REJECTED
-__global__ void mix_decide_kernel(const double * __restrict__ sum, double lnc, double ninner, double u,
-                                  uint32_t epoch, uint32_t * flag, uint32_t * counters)
+// the single decision of an all-loci step (prop_mixing.c:203-205, stree.c:6280): flag := epoch when
+// REJECTED; on acceptance the species-tree times follow (mix: all times c; tau j: the proposed value)
+__global__ void decide_kernel(const double * __restrict__ sum, double lnc, double ninner, double u,
+                              uint32_t epoch, uint32_t * flag, uint32_t * counters,
+                              double * taus, uint32_t ntaus, int tau_j, double tau_u, double mix_c)
 {
   if (threadIdx.x || blockIdx.x) return;
   const double lnacc = sum[0] + ninner*lnc;
   const bool accept = lnacc >= 0 || u < exp(lnacc);
   counters[0] += 1; counters[1] += accept ? 1u : 0u;
-  if (!accept) *flag = epoch;
+  if (!accept) { *flag = epoch; return; }
+  if (tau_j < 0) { for (uint32_t i = 0; i < ntaus; ++i) taus[i] *= mix_c; }
+  else
+  {
+    const uint32_t j = (uint32_t)tau_j;
+    const double tau = taus[j], lo = j ? taus[j-1] : 0.0, hi = j + 1 < ntaus ? taus[j+1] : -1.0;
+    taus[j] = tau_proposal(tau_u, lo, tau, hi);
+  }
 }
 
 } // namespace smp
@@ -421,7 +471,8 @@ struct bpa_sampler
   std::vector<bpa_locus *> loci;
   DevBuf<uint32_t> task_locus, blk_task_off, lane_task, task_lane0, flag, counters;
   DevBuf<smp::Tree> trees, snap;
-  DevBuf<double> mix_delta, mix_sum;
+  DevBuf<double> mix_delta, mix_sum, taus;
+  std::vector<double> h_taus;
   std::vector<smp::Tree> h_trees;
   unsigned nblocks = 0, epoch = 0;
   bool mix_pending = false;             // a mixing decision taken on the device has not been applied yet
@@ -464,7 +515,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   (void)hipSetDevice(s->eng->device); g_cur_device = s->eng->device;
   (void)hipStreamSynchronize(s->eng->stream);
   s->task_locus.free(); s->blk_task_off.free(); s->lane_task.free(); s->task_lane0.free(); s->flag.free();
-  s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free();
+  s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free();
   delete s;
 }
 
@@ -513,24 +564,26 @@ static int sampler_upload(bpa_sampler * s)
   if (!upload(s->task_locus, locus.data(), T) || !upload(s->blk_task_off, blk_off.data(), blk_off.size()) ||
       !upload(s->lane_task, lane_task.data(), lane_task.size()) || !upload(s->task_lane0, lane0.data(), T) ||
       !upload(s->trees, s->h_trees.data(), T) || !upload(s->snap, s->h_trees.data(), T) ||
-      !upload(s->flag, zero2, 1) || !upload(s->counters, zero2, 2) || !s->mix_delta.reserve(T) || !s->mix_sum.reserve(1))
+      !upload(s->flag, zero2, 1) || !upload(s->counters, zero2, 2) || !s->mix_delta.reserve(T) || !s->mix_sum.reserve(1) ||
+      !s->taus.reserve(8) || (!s->h_taus.empty() && !upload(s->taus, s->h_taus.data(), s->h_taus.size())))
     return 0;
   s->epoch = 0; s->mix_pending = false;
   s->uploaded = true;
   return 1;
 }
 
-static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c)
+static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, unsigned tau_j = 0, double tau_u = 0)
 {
   bpa_engine * e = s->eng;
   smp::Args a{};
   a.loci = e->d_loci.p; a.task_locus = s->task_locus.p; a.blk_task_off = s->blk_task_off.p;
   a.lane_task = s->lane_task.p; a.task_lane0 = s->task_lane0.p; a.trees = s->trees.p; a.snap = s->snap.p;
   a.mix_delta = s->mix_delta.p; a.mix_flag = s->flag.p; a.mode = mode;
-  // the first sweep/settle launch after a mixing decision applies it (restore from the snapshot
-  // when it was a rejection); every other launch passes epoch 0 = nothing pending
-  a.epoch = (s->mix_pending && (mode == 0 || mode == 2)) ? s->epoch : 0u;
-  if (mode == 0 || mode == 2) s->mix_pending = false;
+  // the first launch after an all-loci decision applies it (restore from the snapshot when it was a
+  // rejection); every other launch passes epoch 0 = nothing pending
+  a.epoch = s->mix_pending ? s->epoch : 0u;
+  s->mix_pending = false;
+  a.taus = s->taus.p; a.ntaus = (uint32_t)s->h_taus.size(); a.tau_j = tau_j; a.tau_u = tau_u;
   a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2; a.mix_c = mix_c;
   if (const char * dbg = getenv("BPA_SMP_STEPS")) { unsigned g = 0, q = 0; if (sscanf(dbg, "%u,%u", &g, &q) == 2) { a.nsteps_gage = g; a.nsteps_gspr = q; } }
   if (getenv("BPA_SMP_TRACE"))
@@ -550,6 +603,26 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c)
   return 1;
 }
 
+extern "C" int bpa_sampler_set_taus(bpa_sampler_t * s, const double * taus, unsigned n)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (n > 8) return fail("bpa_sampler_set_taus: at most 8 divergence times");
+  s->h_taus.assign(taus, taus + n);
+  s->uploaded = false;
+  return 1;
+}
+
+extern "C" int bpa_sampler_get_taus(bpa_sampler_t * s, double * taus)
+{
+  bpa_engine * e = s->eng;
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  if (!set_device(e)) return 0;
+  if (s->h_taus.empty() || !s->uploaded) { for (size_t i = 0; i < s->h_taus.size(); ++i) taus[i] = s->h_taus[i]; return 1; }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(taus, s->taus.p, s->h_taus.size()*sizeof(double), hipMemcpyDeviceToHost));
+  return 1;
+}
+
 extern "C" int bpa_sampler_initialize(bpa_sampler_t * s)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
@@ -566,13 +639,24 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
   {
     if (!sampler_launch(s, 0, 1.0)) return 0;                    // GAGE + GSPR of every locus (settles a pending mix first)
     if (getenv("BPA_SMP_NOMIX")) continue;
+    for (unsigned j = 0; j < s->h_taus.size(); ++j)               // one rubber-band step per species divergence
+    {
+      const double uprop = a00_rndu(&s->grng), uacc_t = a00_rndu(&s->grng);
+      if (!sampler_launch(s, 4, 1.0, j, uprop)) return 0;
+      hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, s->mix_sum.p);
+      s->epoch++;
+      hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, 0.0, 0.0, uacc_t,
+                         s->epoch, s->flag.p, s->counters.p, s->taus.p, (uint32_t)s->h_taus.size(), (int)j, uprop, 1.0);
+      HIPCHK(hipGetLastError());
+      s->mix_pending = true;
+    }
     const double lnc = 0.1*(a00_rndu(&s->grng) - 0.5), c = std::exp(lnc);
     const double uacc = a00_rndu(&s->grng);
     if (!sampler_launch(s, 1, c)) return 0;                      // mixing proposal of every locus
     hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, s->mix_sum.p);
     s->epoch++;
-    hipLaunchKernelGGL(smp::mix_decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, lnc, s->ninner_total, uacc,
-                       s->epoch, s->flag.p, s->counters.p);
+    hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, lnc, s->ninner_total, uacc,
+                       s->epoch, s->flag.p, s->counters.p, s->taus.p, (uint32_t)s->h_taus.size(), -1, 0.0, c);
     HIPCHK(hipGetLastError());
     s->mix_pending = true;
   }

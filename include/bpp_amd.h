@@ -217,6 +217,9 @@ bpa_sampler_t * bpa_sampler_create(bpa_engine_t *, bpa_locus_t * const * loci, u
 void bpa_sampler_destroy(bpa_sampler_t *);
 int  bpa_sampler_set_tree(bpa_sampler_t *, unsigned i, const int * left, const int * right,
                           const double * times, int root);
+/* species-tree divergence times (ascending, <= 8) for the TAU rubber-band steps; device-resident */
+int  bpa_sampler_set_taus(bpa_sampler_t *, const double * taus, unsigned n);
+int  bpa_sampler_get_taus(bpa_sampler_t *, double * taus);
 int  bpa_sampler_initialize(bpa_sampler_t *);                 /* all matrices, partials, lnL */
 int  bpa_sampler_iterate(bpa_sampler_t *, unsigned iterations); /* asynchronous on the engine stream */
 /* current state of locus i (any output may be NULL); asking for locus 0 refreshes the host copy */

@@ -79,9 +79,28 @@ void           a00_destroy(a00_driver_t *);
 int            a00_set_tree(a00_driver_t *, unsigned i, int tips, const int * left, const int * right,
                             const double * times, int root, int scaling);
 const a00_tree_t * a00_tree(const a00_driver_t *, unsigned i);
+/* species-tree divergence times (ascending) for the TAU step (stree.c:5512 propose_tau): one all-loci
+   proposal per tau per iteration; the gene-node ages between the neighbouring taus are rescaled
+   ("rubber band", stree.c:4338-4779), the touched branches/root paths re-evaluated
+   (gtree_return_partials, gtree.c:145-175) and ONE decision taken from the summed difference
+   (threads.c:544-559).  Without taus the iteration has no TAU steps.  n <= 8.                    */
+int            a00_set_taus(a00_driver_t *, const double * taus, unsigned n);
+unsigned       a00_get_taus(const a00_driver_t *, double * taus);
+/* the rubber-band map shared by host and device: new age of a gene node of age t when tau -> tnew,
+   with lo / hi the neighbouring taus (hi < 0: none above) */
+static inline double a00_rubber_band(double t, double lo, double tau, double tnew, double hi)
+{
+  if (t > lo && t <= tau) return lo + (t - lo)*(tnew - lo)/(tau - lo);
+  if (t > tau && (hi < 0 || t < hi)) return hi < 0 ? tnew + (t - tau) : hi - (hi - t)*(hi - tnew)/(hi - tau);
+  return t;
+}
+static inline double a00_tau_proposal(double u, double lo, double tau, double hi)
+{
+  return lo + (0.05 + 0.9*u)*((hi < 0 ? 2*tau - lo : hi) - lo);
+}
 /* start-up evaluation: all matrices, all partials, lnL (method.c:4285-4297) */
 int            a00_initialize(a00_driver_t *);
-/* one iteration: GAGE over inner nodes, GSPR over non-root nodes, one MIX step */
+/* one iteration: GAGE over inner nodes, GSPR over non-root nodes, one TAU step per tau, one MIX step */
 int            a00_iterate(a00_driver_t *);
 double         a00_total_lnl(const a00_driver_t *);
 void           a00_counters(const a00_driver_t *, unsigned long * proposals, unsigned long * accepted,

@@ -36,6 +36,9 @@ def lib():
                                    C.POINTER(C.c_double), C.c_int, C.c_int]
         L.a00_tree.restype = C.POINTER(A00Tree)
         L.a00_tree.argtypes = [C.c_void_p, C.c_uint]
+        L.a00_set_taus.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint]
+        L.a00_get_taus.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.a00_get_taus.restype = C.c_uint
         L.a00_initialize.argtypes = [C.c_void_p]
         L.a00_iterate.argtypes = [C.c_void_p]
         L.a00_total_lnl.restype = C.c_double
@@ -58,6 +61,15 @@ class Driver:
                                 r.ctypes.data_as(C.POINTER(C.c_int)), t.ctypes.data_as(C.POINTER(C.c_double)),
                                 int(d["root"]), int(scaling))
             assert ok
+
+    def set_taus(self, taus):
+        a = (C.c_double * len(taus))(*taus)
+        assert lib().a00_set_taus(self.h, a, len(taus))
+
+    def taus(self):
+        a = (C.c_double * 8)()
+        n = lib().a00_get_taus(self.h, a)
+        return [a[i] for i in range(n)]
 
     def initialize(self):
         assert lib().a00_initialize(self.h), bpp_amd.lib().bpa_last_error()

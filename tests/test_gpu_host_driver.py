@@ -22,12 +22,15 @@ def test_same_trajectory_on_gpu_and_reference(engine, taxa, model, R, scaling, n
     loci = tape.make_engine_loci(engine, data, scaling)
     g = hostdrv.hip_driver(engine, loci, data, seed=11, scaling=scaling)
     r = hostdrv.reference_driver(data, seed=11, scaling=scaling)
+    taus = {4: (0.001, 0.002, 0.003), 8: (0.0011, 0.0025, 0.005), 6: (0.01, 0.02, 0.035, 0.05)}[taxa]
+    g.set_taus(taus); r.set_taus(taus)
     g.initialize(); r.initialize()
     assert rel(g.total_lnl(), r.total_lnl()) < 1e-13
     for it in range(5):
         g.iterate(); r.iterate()
         assert rel(g.total_lnl(), r.total_lnl()) < 1e-12, it
         assert g.counters() == r.counters(), it            # identical accept/reject history
+    assert g.taus() == r.taus() and g.taus() != list(taus)
     for i in range(nloci):
         a, b = g.tree(i), r.tree(i)
         for key in ("root", "left", "right", "parent", "clv", "pmat", "scaler"):

@@ -24,6 +24,8 @@ def test_sampler_equals_host_driver(taxa, nloci, iters):
     loci_b = tape.make_engine_loci(eng, data)
     host = hostdrv.hip_driver(eng, loci_a, data, seed=23)
     dev = bpp_amd.Sampler(eng, loci_b, data, seed=23)
+    taus = (0.001, 0.002, 0.003) if taxa == 4 else (0.0011, 0.0025, 0.005)
+    host.set_taus(taus); dev.set_taus(taus)
     host.initialize(); dev.initialize()
     s = dev.summary()
     assert rel(s["total_lnl"], host.total_lnl()) < 1e-13
@@ -33,6 +35,7 @@ def test_sampler_equals_host_driver(taxa, nloci, iters):
         hp, ha, _ = host.counters()
         assert (s["proposals"], s["accepted"]) == (hp, ha), it
         assert rel(s["total_lnl"], host.total_lnl()) < 1e-11, it
+    assert np.allclose(dev.taus(), host.taus(), rtol=1e-12, atol=0) and dev.taus() != list(taus)
     for i in range(nloci):
         a, b = dev.tree(i), host.tree(i)
         assert a["root"] == b["root"]
@@ -48,7 +51,7 @@ def test_sampler_equals_host_driver(taxa, nloci, iters):
         full = O.OracleLocus(4, 1, d["seqs"], d["weights"]).full_lnl(list(t["left"]), list(t["right"]), list(t["time"]), t["root"])
         assert rel(have, full) < 1e-12 and rel(t["lnl"], full) < 1e-12
     # 4 launches per iteration instead of 3 tips - 2 host round trips
-    assert dev.summary()["launches"] <= 1 + 2 * iters + 2 * (iters + 2) + nloci
+    assert dev.summary()["launches"] <= 1 + (2 + len(taus)) * iters + 2 * (iters + 2) + nloci
     host.close(); dev.close(); eng.close()
 
 

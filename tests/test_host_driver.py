@@ -17,6 +17,8 @@ pytestmark = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built"
 def test_driver_on_reference_backend(taxa, model, R, scaling):
     data = synth.make_dataset(10, 300, taxa, model, R, seed=31, theta=0.004 if taxa == 6 else None)
     drv = hostdrv.reference_driver(data, seed=7, scaling=scaling)
+    taus = {4: (0.001, 0.002, 0.003), 8: (0.0011, 0.0025, 0.005), 6: (0.01, 0.02, 0.035, 0.05)}[taxa]
+    drv.set_taus(taus)
     drv.initialize()
     l0 = drv.total_lnl()
     want0 = sum(O.OracleLocus(d["states"], R, d["seqs"], d["weights"], model=model,
@@ -27,7 +29,9 @@ def test_driver_on_reference_backend(taxa, model, R, scaling):
     for _ in range(4):
         drv.iterate()
     props, acc, steps = drv.counters()
-    assert steps == 1 + 4 * ((taxa - 1) + (2 * taxa - 2) + 1)
+    assert 1 + 4 * ((taxa - 1) + (2 * taxa - 2) + 1) <= steps <= 1 + 4 * ((taxa - 1) + (2 * taxa - 2) + 1 + len(taus))
+    new = drv.taus()
+    assert len(new) == len(taus) and all(b > a for a, b in zip(new, new[1:])) and new != list(taus)
     assert 0.05 < acc / props < 0.98
     total = 0.0
     for i, d in enumerate(data):
