@@ -363,6 +363,8 @@ def main():
     sampler = None
     if world == 1 and args.config == "c2" and not args.no_sampler:
         smp = bpp_amd.Sampler(eng, loci, data, seed=1)
+        smp_taus = cfg["taus"]
+        smp.set_taus(smp_taus)
         smp.initialize()
         smp.iterate(args.warmup)
         eng.synchronize()
@@ -372,11 +374,13 @@ def main():
         dt = time.perf_counter() - t0
         sm = smp.summary()
         sampler = dict(iterations_per_s=round(args.steps / dt * nloci / 10000.0, 1), ms_per_iteration=round(1e3 * dt / args.steps, 4),
-                       launches_per_iteration=4, proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
+                       launches_per_iteration=4 + 3 * len(smp_taus), proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
                        acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
-                       note="GAGE+GSPR per locus and one all-loci MIX per iteration, Metropolis on the likelihood ratio, "
-                            "decisions taken on the device; same trajectory as the C host driver on the reference "
-                            "(tests/test_gpu_sampler.py, tests/test_gpu_host_driver.py); no TAU step, no MSC prior")
+                       taus_after=[float(x) for x in smp.taus()],
+                       note="GAGE+GSPR per locus, one rubber-band TAU step per species divergence and one all-loci MIX "
+                            "per iteration, Metropolis on the likelihood ratio, decisions taken on the device; same "
+                            "trajectory as the C host driver on the reference (tests/test_gpu_sampler.py, "
+                            "tests/test_gpu_host_driver.py); no MSC prior")
         smp.close()
 
     cpu = None

@@ -169,6 +169,7 @@ static int set_device(bpa_engine * e)
 // ------------------------------------------------------------------ engine --
 extern "C" const char * bpa_version(void) { return "bpp_amd 0.1 (gfx950)"; }
 extern "C" const char * bpa_last_error(void) { return g_err.c_str(); }
+extern "C" void bpa_internal_set_error(const char * msg) { g_err = msg ? msg : ""; }   // host_input.cpp
 
 extern "C" int bpa_device_count(void)
 {

@@ -210,12 +210,30 @@ extern "C" int bpa_compute_gamma_cats(double alpha, double beta, unsigned catego
 // Renamed codes 1..4 share the code space of un-renamed columns exactly as in the
 // reference (a column A,C,M = 1,2,3 merges with a renamed A,G,T): pattern counts are
 // the contract.  The class representative is its lowest-index member; patterns are
-// emitted in lexicographic key order (the reference's order depends on rand()).
+// emitted in lexicographic key order, which is the order the reference's multikey quicksort
+// (compress.c:35-101) ends in; its rand() pivots only decide which member represents a class.
 extern "C" int bpa_compress_site_patterns(char ** sequences, const unsigned * map, int count,
                                           int * length, int jc69, unsigned * weights)
 {
   if (!sequences || !map || count <= 0 || !length || *length <= 0 || map[0]) return 0;
   const int len = *length;
+  // sort key of a character: its state code; when the codes do not fit a byte (amino acids) the rank
+  // of the code by the first character carrying it (remap_range, compress.c:104-128) — the order of
+  // the emitted patterns is then the reference's
+  uint32_t code[256];
+  {
+    uint32_t mx = 0;
+    for (int c = 0; c < 256; ++c) mx = std::max<uint32_t>(mx, map[c]);
+    uint32_t k = 1;
+    for (int c = 0; c < 256; ++c) code[c] = mx < 256 ? map[c] : 0;
+    if (mx >= 256)
+      for (int c = 0; c < 256; ++c)
+        if (map[c] && !code[c])
+        {
+          for (int e = c; e < 256; ++e) if (map[e] == map[c]) code[e] = k;
+          ++k;
+        }
+  }
   std::vector<uint32_t> keys((size_t)len*count);
   for (int i = 0; i < len; ++i)
   {
@@ -223,7 +241,7 @@ extern "C" int bpa_compress_site_patterns(char ** sequences, const unsigned * ma
     bool simple = jc69 != 0;
     for (int j = 0; j < count; ++j)
     {
-      key[j] = map[(unsigned char)sequences[j][i]];
+      key[j] = code[(unsigned char)sequences[j][i]];
       if (!key[j]) return 0;
       if (!(key[j] == 1 || key[j] == 2 || key[j] == 4 || key[j] == 8 || key[j] == 15)) simple = false;
     }

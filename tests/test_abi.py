@@ -30,6 +30,19 @@ def test_library_exports_every_declared_symbol():
     assert sorted(api.EXPORTED) == names      # the ctypes table covers the whole header
 
 
+def test_input_header_symbols_exported():
+    """include/bpp_amd_input.h (the input side, host-only) is exported and bound as a whole"""
+    from bpp_amd import seqio
+    src = open(os.path.join(ROOT, "include", "bpp_amd_input.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(bpa_[a-z0-9_]+)\s*\(", src)))
+    L = bpp_amd.lib()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/bpp_amd_input.h but not exported"
+    assert sorted(seqio.INPUT_EXPORTED) == names
+
+
 def test_version_string():
     assert b"gfx950" in bpp_amd.lib().bpa_version()
 
@@ -67,7 +80,7 @@ def test_compress_pattern_counts():
     for g in load_golden("compress.json"):
         pats, w = bpp_amd.compress_site_patterns(g["seqs"], g["dna"], g["jc69"])
         assert len(w) == len(g["weights"])
-        assert sorted(w) == sorted(g["weights"])
+        assert list(w) == list(g["weights"])          # same pattern ORDER as the reference (compress.c:35-101)
         assert int(w.sum()) == len(g["seqs"][0])
         assert all(len(p) == len(w) for p in pats)
 
