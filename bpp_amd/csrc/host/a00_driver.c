@@ -1,17 +1,10 @@
 /*
  * a00_driver.c — host-side MCMC control in plain C over the likelihood boundary
- * (include/bpp_amd_host.h).  Mirrors the way BPP's proposals drive the locus API:
- *
- *   propose_ages   gtree.c:4585-5532  set node->time, SWAP_PMAT_INDEX on the 2-3 touched
- *                  branches, SWAP_CLV_INDEX/SWAP_SCALER_INDEX on the path to the root,
- *                  locus_update_matrices, locus_update_partials, locus_root_loglikelihood,
- *                  accept or swap everything back
- *   propose_spr    gtree.c:6531-7610  prune + regraft (the root node object stays the root,
- *                  gtree.c:6129-6175), 3-4 branches, one or two root paths
- *   proposal_mixing prop_mixing.c:52-221  every age times c, everything recomputed, ONE
- *                  decision from the summed log-likelihood difference
- *
- * with the per-locus loops hoisted into lock-step batches ("step j of every locus").
+ * (include/bpp_amd_host.h): gene trees of all loci under the multispecies coalescent on a fixed
+ * species tree, the per-locus loops of BPP's proposals hoisted into lock-step batches ("step j of
+ * every locus").  Each move states the reference routine it follows; the window kernels are uniform
+ * where BPP draws from a Bactrian-Laplace (legacy_rnd_symmetrical, random.c:230) — same target
+ * distribution, our own random streams.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -35,7 +28,15 @@ struct a00_driver
   /* per-locus undo snapshot (whole small tree) */
   int ** u_left, ** u_right, ** u_parent, ** u_clv, ** u_pmat, ** u_scaler; double ** u_time; int * u_root;
   unsigned long proposals, accepted, steps;
-  double taus[8]; unsigned ntaus;
+  /* species tree (stree->nodes order: tips, then inner populations, children before parents) */
+  int S, npop, sp_parent[A00_MAXPOP], sp_left[A00_MAXPOP], sp_right[A00_MAXPOP];
+  double tau[A00_MAXPOP], theta[A00_MAXPOP];
+  unsigned anc[A00_MAXPOP];             /* bit q: q is p or an ancestor of p (stree->pptable) */
+  double ft_gage, ft_gspr, ft_tau, ft_mix;
+  double tau_alpha, tau_beta;           /* gamma prior on the root tau (0,0: flat) */
+  double * s_logpr;                     /* proposed MSC density per slot */
+  double * p_logpr, * p_delta; int * p_slot;     /* all-loci steps: per locus */
+  int ** u_pop;
 };
 
 
@@ -59,6 +60,7 @@ static void snapshot(a00_driver_t * d, unsigned i)
   memcpy(d->u_parent[i], t->parent, n*sizeof(int)); memcpy(d->u_time[i], t->time, n*sizeof(double));
   memcpy(d->u_clv[i], t->clv, n*sizeof(int));     memcpy(d->u_pmat[i], t->pmat, n*sizeof(int));
   memcpy(d->u_scaler[i], t->scaler, n*sizeof(int)); d->u_root[i] = t->root;
+  memcpy(d->u_pop[i], t->pop, n*sizeof(int));
 }
 static void restore(a00_driver_t * d, unsigned i)
 {
@@ -67,6 +69,7 @@ static void restore(a00_driver_t * d, unsigned i)
   memcpy(t->parent, d->u_parent[i], n*sizeof(int)); memcpy(t->time, d->u_time[i], n*sizeof(double));
   memcpy(t->clv, d->u_clv[i], n*sizeof(int));     memcpy(t->pmat, d->u_pmat[i], n*sizeof(int));
   memcpy(t->scaler, d->u_scaler[i], n*sizeof(int)); t->root = d->u_root[i];
+  memcpy(t->pop, d->u_pop[i], n*sizeof(int));
 }
 
 a00_driver_t * a00_create(unsigned nloci, a00_eval_fn eval, void * ctx, unsigned long seed)
@@ -84,6 +87,10 @@ a00_driver_t * a00_create(unsigned nloci, a00_eval_fn eval, void * ctx, unsigned
   d->s_nd_off = (unsigned *)calloc(nloci + 1, sizeof(unsigned));
   d->s_lnl = (double *)calloc(nloci, sizeof(double));
   d->s_hast = (double *)calloc(nloci, sizeof(double));
+  d->s_logpr = (double *)calloc(nloci, sizeof(double));
+  d->p_logpr = (double *)calloc(nloci, sizeof(double)); d->p_delta = (double *)calloc(nloci, sizeof(double));
+  d->p_slot = (int *)calloc(nloci, sizeof(int)); d->u_pop = (int **)calloc(nloci, sizeof(int *));
+  d->ft_gage = 0.004; d->ft_gspr = 0.004; d->ft_tau = 0.001; d->ft_mix = 0.3;
   d->u_left = (int **)calloc(nloci, sizeof(int *)); d->u_right = (int **)calloc(nloci, sizeof(int *));
   d->u_parent = (int **)calloc(nloci, sizeof(int *)); d->u_clv = (int **)calloc(nloci, sizeof(int *));
   d->u_pmat = (int **)calloc(nloci, sizeof(int *)); d->u_scaler = (int **)calloc(nloci, sizeof(int *));
@@ -98,11 +105,13 @@ void a00_destroy(a00_driver_t * d)
   for (i = 0; i < d->nloci; ++i)
   {
     a00_tree_t * t = d->trees + i;
-    free(t->left); free(t->right); free(t->parent); free(t->time); free(t->clv); free(t->pmat); free(t->scaler);
+    free(t->left); free(t->right); free(t->parent); free(t->time); free(t->clv); free(t->pmat); free(t->scaler); free(t->pop);
+    free(d->u_pop[i]);
     free(d->u_left[i]); free(d->u_right[i]); free(d->u_parent[i]); free(d->u_clv[i]); free(d->u_pmat[i]);
     free(d->u_scaler[i]); free(d->u_time[i]);
   }
   free(d->rng); free(d->trees); free(d->s_locus); free(d->s_tree); free(d->s_br_off); free(d->s_nd_off); free(d->s_br);
+  free(d->s_logpr); free(d->p_logpr); free(d->p_delta); free(d->p_slot); free(d->u_pop);
   free(d->s_nd); free(d->s_lnl); free(d->s_hast); free(d->u_left); free(d->u_right); free(d->u_parent);
   free(d->u_clv); free(d->u_pmat); free(d->u_scaler); free(d->u_time); free(d->u_root); free(d);
 }
@@ -119,6 +128,8 @@ int a00_set_tree(a00_driver_t * d, unsigned i, int tips, const int * left, const
 #undef DUP
   t->parent = (int *)malloc((size_t)n*sizeof(int)); t->clv = (int *)malloc((size_t)n*sizeof(int));
   t->pmat = (int *)malloc((size_t)n*sizeof(int)); t->scaler = (int *)malloc((size_t)n*sizeof(int));
+  t->pop = (int *)malloc((size_t)n*sizeof(int)); d->u_pop[i] = (int *)malloc((size_t)n*sizeof(int));
+  for (k = 0; k < n; ++k) t->pop[k] = k < tips ? k : -1;
   for (k = 0; k < n; ++k) t->parent[k] = -1;
   for (k = 0; k < n; ++k)
   {
@@ -179,13 +190,122 @@ static int path_to_root(const a00_tree_t * t, int v, int * out)
   return k;
 }
 
+/* ------------------------------------------------------------------ species tree and MSC --- */
+int a00_set_species_tree(a00_driver_t * d, int species, const int * parent, const double * tau, const double * theta)
+{
+  int p, q, np = 2*species - 1;
+  if (species < 1 || np > A00_MAXPOP) return 0;
+  for (p = 0; p < np; ++p)
+  {
+    if (p == np - 1 ? parent[p] != -1 : (parent[p] <= p || parent[p] >= np || parent[p] < species)) return 0;
+    if (!(theta[p] > 0) || (p < species ? tau[p] != 0 : !(tau[p] > 0))) return 0;
+    if (parent[p] >= 0 && !(tau[parent[p]] > tau[p])) return 0;
+  }
+  d->S = species; d->npop = np;
+  for (p = 0; p < np; ++p) { d->sp_parent[p] = parent[p]; d->sp_left[p] = d->sp_right[p] = -1; d->tau[p] = tau[p]; d->theta[p] = theta[p]; }
+  for (p = 0; p < np - 1; ++p) { q = parent[p]; if (d->sp_left[q] < 0) d->sp_left[q] = p; else if (d->sp_right[q] < 0) d->sp_right[q] = p; else return 0; }
+  for (p = species; p < np; ++p) if (d->sp_right[p] < 0) return 0;
+  for (p = 0; p < np; ++p) { d->anc[p] = 0; for (q = p; q >= 0; q = parent[q]) d->anc[p] |= 1u << q; }
+  return 1;
+}
+
+int a00_set_tip_species(a00_driver_t * d, unsigned i, const int * species)
+{
+  a00_tree_t * t = d->trees + i; int k;
+  if (i >= d->nloci || !t->pop) return 0;
+  for (k = 0; k < t->tips; ++k) { if (species[k] < 0 || species[k] >= d->S) return 0; t->pop[k] = species[k]; }
+  return 1;
+}
+
+void a00_set_tau_prior(a00_driver_t * d, double alpha, double beta) { d->tau_alpha = alpha; d->tau_beta = beta; }
+
+/* log prior ratio of the taus when the root tau goes old -> new, the others keeping their place in
+   (0, root): gamma(alpha, beta) on the root, uniform Dirichlet below it (propose_tau, stree.c:5655-5657:
+   (alpha - 1 - candidate_count + 1) log(new/old) - beta (new - old), candidate_count = inner populations) */
+static double root_tau_prior_ratio(const a00_driver_t * d, double oldt, double newt)
+{
+  if (!(d->tau_alpha > 0)) return 0;
+  return (d->tau_alpha - 1 - (d->S - 1) + 1)*log(newt/oldt) - d->tau_beta*(newt - oldt);
+}
+
+void a00_set_finetune(a00_driver_t * d, double gage, double gspr, double tau, double mix)
+{ d->ft_gage = gage; d->ft_gspr = gspr; d->ft_tau = tau; d->ft_mix = mix; }
+
+unsigned a00_get_taus(const a00_driver_t * d, double * tau)
+{
+  int p;
+  for (p = 0; p < d->npop; ++p) tau[p] = d->tau[p];
+  return (unsigned)d->npop;
+}
+
+/* youngest population that is an ancestor (or self) of both */
+static int lca_pop(const a00_driver_t * d, int p, int q)
+{
+  while (!((d->anc[q] >> p) & 1u)) p = d->sp_parent[p];
+  return p;
+}
+/* the ancestor (or self) of population p that holds time t (gtree.c:4790-4797) */
+static int climb(const a00_driver_t * d, int p, double t)
+{
+  while (d->sp_parent[p] >= 0 && d->tau[d->sp_parent[p]] <= t) p = d->sp_parent[p];
+  return p;
+}
+
+/* gtree_logprob (gtree.c:3957): the sum over populations, in stree->nodes order, of
+   gtree_update_logprob_contrib; NAN if the tree does not fit the species tree */
+static double tree_logpr(const a00_driver_t * d, const a00_tree_t * t)
+{
+  int nin[A00_MAXPOP], nc[A00_MAXPOP], p, k; double times[MAXN], logpr = 0;
+  for (p = 0; p < d->npop; ++p) nin[p] = 0;
+  for (k = 0; k < t->tips; ++k) nin[t->pop[k]]++;
+  for (p = 0; p < d->npop; ++p)
+  {
+    int n = 0, a, b;
+    if (p >= d->S) nin[p] = (nin[d->sp_left[p]] - nc[d->sp_left[p]]) + (nin[d->sp_right[p]] - nc[d->sp_right[p]]);
+    for (k = t->tips; k < t->n; ++k)
+      if (t->pop[k] == p)
+      {
+        const double v = t->time[k];
+        if (v < d->tau[p] || (d->sp_parent[p] >= 0 && v >= d->tau[d->sp_parent[p]])) return NAN;
+        for (a = n++; a > 0 && times[a-1] > v; --a) times[a] = times[a-1];
+        times[a] = v; (void)b;
+      }
+    nc[p] = n;
+    if (n >= nin[p] && n > 0) return NAN;
+    logpr += a00_msc_contrib(d->tau[p], d->sp_parent[p] >= 0 ? d->tau[d->sp_parent[p]] : -1.0, d->theta[p], 1.0, nin[p], times, n);
+  }
+  return logpr;
+}
+
+double a00_locus_logpr(const a00_driver_t * d, unsigned i) { return tree_logpr(d, d->trees + i); }
+
+/* populations of the inner nodes from topology and ages; 0 if an age is below the tau of the
+   common population of its children */
+static int assign_pops(const a00_driver_t * d, a00_tree_t * t)
+{
+  int order[MAXN], n = 0, a, b, k;
+  for (k = t->tips; k < t->n; ++k) order[n++] = k;
+  for (a = 1; a < n; ++a) { int v = order[a]; for (b = a; b > 0 && t->time[order[b-1]] > t->time[v]; --b) order[b] = order[b-1]; order[b] = v; }
+  for (a = 0; a < n; ++a)
+  {
+    const int v = order[a], c = lca_pop(d, t->pop[t->left[v]], t->pop[t->right[v]]);
+    if (t->time[v] < d->tau[c]) return 0;
+    t->pop[v] = climb(d, c, t->time[v]);
+  }
+  return 1;
+}
+
 int a00_initialize(a00_driver_t * d)
 {
   unsigned i; int br[MAXN], nd[MAXN];
+  if (!d->npop) return 0;                                /* a00_set_species_tree first */
   step_begin(d);
   for (i = 0; i < d->nloci; ++i)
   {
     a00_tree_t * t = d->trees + i; int nb = 0, nn = 0, k;
+    if (!assign_pops(d, t)) return 0;
+    t->logpr = tree_logpr(d, t);
+    if (t->logpr != t->logpr) return 0;
     for (k = 0; k < t->n; ++k) { if (t->parent[k] >= 0) br[nb++] = k; if (t->left[k] >= 0) nd[nn++] = k; }
     /* start-up evaluates into the current buffers: toggle twice = no toggle */
     for (k = 0; k < nb; ++k) swap_pmat(t, br[k]);
@@ -197,39 +317,44 @@ int a00_initialize(a00_driver_t * d)
   return 1;
 }
 
-/* per-locus Metropolis decision on the likelihood ratio */
+/* per-locus Metropolis-Hastings decision on  MSC density x likelihood  (gtree.c:5476-5480) */
 static void decide(a00_driver_t * d, unsigned n)
 {
   unsigned s;
   for (s = 0; s < n; ++s)
   {
     const unsigned i = d->s_locus[s]; a00_tree_t * t = d->trees + i;
-    const double lnacc = d->s_lnl[s] - t->lnl + d->s_hast[s];
+    const double lnacc = (d->s_logpr[s] - t->logpr) + (d->s_lnl[s] - t->lnl) + d->s_hast[s];
     const double u = a00_rndu(&d->rng[i]);
     d->proposals++;
-    if (lnacc >= 0 || u < exp(lnacc)) { t->lnl = d->s_lnl[s]; d->accepted++; }
-    else restore(d, i);                                  /* swap indices, ages, topology back */
+    if (lnacc >= 0 || u < exp(lnacc)) { t->lnl = d->s_lnl[s]; t->logpr = d->s_logpr[s]; d->accepted++; }
+    else restore(d, i);                                  /* swap indices, ages, populations, topology back */
   }
 }
 
-/* GAGE: the k-th inner node of every locus (gtree.c:4585) */
+/* GAGE: the k-th inner node of every locus (propose_ages, gtree.c:4585-5532, the MSC branch) */
 static int gage_step(a00_driver_t * d, int k)
 {
   unsigned i, n = 0; int br[4], nd[MAXN];
   step_begin(d);
   for (i = 0; i < d->nloci; ++i)
   {
-    a00_tree_t * t = d->trees + i; int v = -1, c = 0, j, nb = 0, nn, p; double lo, u;
+    a00_tree_t * t = d->trees + i; int v = -1, c = 0, j, nb = 0, nn, p, l, r; double lo, hi, u, tnew;
     for (j = 0; j < t->n; ++j) if (t->left[j] >= 0 && c++ == k) { v = j; break; }
     if (v < 0) continue;
     u = a00_rndu(&d->rng[i]);
+    l = t->left[v]; r = t->right[v]; p = t->parent[v];
+    lo = fmax(t->time[l], t->time[r]);
+    if (t->pop[l] != t->pop[r]) lo = fmax(lo, d->tau[lca_pop(d, t->pop[l], t->pop[r])]);
+    hi = p >= 0 ? t->time[p] : 999.0;
+    if (!(hi > lo)) { (void)a00_rndu(&d->rng[i]); continue; }
     snapshot(d, i);
-    lo = fmax(t->time[t->left[v]], t->time[t->right[v]]);
-    p = t->parent[v];
+    tnew = a00_reflect(t->time[v] + d->ft_gage*(u - 0.5), lo, hi);
+    t->time[v] = tnew;
+    t->pop[v] = climb(d, t->pop[l], tnew);
     d->s_hast[n] = 0;
-    if (p >= 0) t->time[v] = lo + (0.02 + 0.96*u)*(t->time[p] - lo);
-    else { const double c_ = exp(0.6*(u - 0.5)); t->time[v] = lo + (t->time[v] - lo)*c_; d->s_hast[n] = log(c_); }
-    br[nb++] = t->left[v]; br[nb++] = t->right[v]; if (p >= 0) br[nb++] = v;
+    d->s_logpr[n] = tree_logpr(d, t);
+    br[nb++] = l; br[nb++] = r; if (p >= 0) br[nb++] = v;
     nn = path_to_root(t, v, nd);
     step_add(d, n, i, br, nb, nd, nn);
     ++n;
@@ -242,21 +367,28 @@ static int gage_step(a00_driver_t * d, int k)
 /* exchange the tree positions of node ids a and b (buffer indices stay with the ids) */
 static void swap_ids(a00_tree_t * t, int a, int b)
 {
-  int i; int L[MAXN], R[MAXN], P[MAXN]; double T[MAXN];
+  int i; int L[MAXN], R[MAXN], P[MAXN], Q[MAXN]; double T[MAXN];
 #define M(x) ((x) == a ? b : (x) == b ? a : (x))
   for (i = 0; i < t->n; ++i)
   {
     const int o = M(i);
     L[i] = t->left[o] >= 0 ? M(t->left[o]) : -1; R[i] = t->right[o] >= 0 ? M(t->right[o]) : -1;
-    P[i] = t->parent[o] >= 0 ? M(t->parent[o]) : -1; T[i] = t->time[o];
+    P[i] = t->parent[o] >= 0 ? M(t->parent[o]) : -1; T[i] = t->time[o]; Q[i] = t->pop[o];
   }
   memcpy(t->left, L, (size_t)t->n*sizeof(int)); memcpy(t->right, R, (size_t)t->n*sizeof(int));
   memcpy(t->parent, P, (size_t)t->n*sizeof(int)); memcpy(t->time, T, (size_t)t->n*sizeof(double));
+  memcpy(t->pop, Q, (size_t)t->n*sizeof(int));
   t->root = M(t->root);
 #undef M
 }
 
-/* GSPR: the k-th non-root node of every locus is pruned and regrafted (gtree.c:6531) */
+static int count_tips(const a00_tree_t * t, int v)
+{
+  return t->left[v] < 0 ? 1 : count_tips(t, t->left[v]) + count_tips(t, t->right[v]);
+}
+
+/* GSPR: the k-th non-root node of every locus is pruned and regrafted (propose_spr, gtree.c:6531-7610,
+   the MSC branch with the plain target choice) */
 static int gspr_step(a00_driver_t * d, int k)
 {
   unsigned i, n = 0;
@@ -264,28 +396,45 @@ static int gspr_step(a00_driver_t * d, int k)
   for (i = 0; i < d->nloci; ++i)
   {
     a00_tree_t * t = d->trees + i;
-    int a = -1, c = 0, j, p, s, g, pc, tgt, ntg = 0, targets[MAXN], banned[MAXN], stack[MAXN], sp = 0;
+    int a = -1, c = 0, j, p, s, g, pc, tgt, ntg = 0, nsrc = 1, targets[MAXN], pop0, popt, leaves, gl[A00_MAXPOP];
     int bset[4], br[4], nb = 0, nd[2*MAXN], nn = 0, root_before;
     double lo, tnew, u1, u2;
     for (j = 0; j < t->n; ++j) if (j != t->root && c++ == k) { a = j; break; }
     if (a < 0) continue;
     u1 = a00_rndu(&d->rng[i]); u2 = a00_rndu(&d->rng[i]);
+    p = t->parent[a]; s = t->left[p] == a ? t->right[p] : t->left[p]; g = t->parent[p];
+    /* youngest population from a's upwards that holds gene tips outside a's subtree (gtree.c:6664-6669) */
+    for (j = 0; j < d->npop; ++j) gl[j] = 0;
+    for (j = 0; j < t->tips; ++j) { int q; for (q = t->pop[j]; q >= 0; q = d->sp_parent[q]) gl[q]++; }
+    leaves = count_tips(t, a);
+    for (pop0 = t->pop[a]; gl[pop0] <= leaves && d->sp_parent[pop0] >= 0; pop0 = d->sp_parent[pop0]) ;
+    lo = fmax(t->time[a], d->tau[pop0]);
+    tnew = a00_reflect(t->time[p] + d->ft_gspr*(u1 - 0.5), lo, 999.0);
+    popt = climb(d, t->pop[a], tnew);
+    /* targets: the branches crossing tnew inside popt; above the root only the root */
+    if (tnew >= t->time[t->root]) targets[ntg++] = t->root;
+    else
+      for (j = 0; j < t->n; ++j)
+        if (j != a && j != t->root && t->time[j] <= tnew && t->time[t->parent[j]] > tnew && ((d->anc[t->pop[j]] >> popt) & 1u))
+          targets[ntg++] = j == p ? s : j;
+    /* sources: the branches the reverse move could pick at the old age (gtree.c:6760-6775) */
+    if (p != t->root)
+      for (j = 0; j < t->n; ++j)
+        if (j != a && j != t->root && j != s && j != p && t->time[j] <= t->time[p] && t->time[t->parent[j]] > t->time[p] &&
+            ((d->anc[t->pop[j]] >> t->pop[p]) & 1u))
+          ++nsrc;
+    if (!ntg) { (void)a00_rndu(&d->rng[i]); continue; }
+    tgt = targets[(int)(u2*ntg) % ntg];
+    if (tgt == p) tgt = s;                                /* the father is the root and stays it: only its age moves */
     snapshot(d, i);
     root_before = t->root;
-    p = t->parent[a]; s = t->left[p] == a ? t->right[p] : t->left[p]; g = t->parent[p];
     /* prune: the sibling takes p's place */
     t->parent[s] = g;
     if (g >= 0) { if (t->left[g] == p) t->left[g] = s; else t->right[g] = s; } else t->root = s;
-    /* regraft target: any node outside a's subtree (and not p) */
-    memset(banned, 0, (size_t)t->n*sizeof(int)); banned[p] = 1; stack[sp++] = a;
-    while (sp) { const int x = stack[--sp]; banned[x] = 1; if (t->left[x] >= 0) { stack[sp++] = t->left[x]; stack[sp++] = t->right[x]; } }
-    for (j = 0; j < t->n; ++j) if (!banned[j]) targets[ntg++] = j;
-    tgt = targets[(int)(u1*ntg) % ntg];
+    /* regraft p (with a below it) on the branch above tgt, at age tnew in population popt */
     pc = t->parent[tgt];
-    lo = fmax(t->time[a], t->time[tgt]);
-    if (pc >= 0 && t->time[pc] <= lo) { tgt = s; pc = t->parent[s]; lo = fmax(t->time[a], t->time[tgt]); }
-    tnew = pc >= 0 ? lo + (0.02 + 0.96*u2)*(t->time[pc] - lo) : lo + (0.1 + u2)*fmax(lo, 1e-4)*0.5;
-    t->time[p] = tnew; t->left[p] = a; t->right[p] = tgt; t->parent[a] = p; t->parent[tgt] = p; t->parent[p] = pc;
+    t->time[p] = tnew; t->pop[p] = popt;
+    t->left[p] = a; t->right[p] = tgt; t->parent[a] = p; t->parent[tgt] = p; t->parent[p] = pc;
     if (pc >= 0) { if (t->left[pc] == tgt) t->left[pc] = p; else t->right[pc] = p; } else t->root = p;
     nn = path_to_root(t, p, nd);
     if (g >= 0) nn += path_to_root(t, g, nd + nn);
@@ -305,7 +454,8 @@ static int gspr_step(a00_driver_t * d, int k)
       for (q = 0; q < nb; ++q) if (br[q] == bset[j]) dup = 1;
       if (!dup && t->parent[bset[j]] >= 0) br[nb++] = bset[j];
     }
-    d->s_hast[n] = 0;
+    d->s_hast[n] = log((double)ntg/(double)nsrc);
+    d->s_logpr[n] = tree_logpr(d, t);
     step_add(d, n, i, br, nb, nd, nn);
     ++n;
   }
@@ -314,93 +464,99 @@ static int gspr_step(a00_driver_t * d, int k)
   return 1;
 }
 
-int a00_set_taus(a00_driver_t * d, const double * taus, unsigned n)
-{
-  unsigned i;
-  if (n > 8) return 0;
-  for (i = 0; i < n; ++i) d->taus[i] = taus[i];
-  d->ntaus = n;
-  return 1;
-}
-unsigned a00_get_taus(const a00_driver_t * d, double * taus)
-{
-  unsigned i;
-  for (i = 0; i < d->ntaus; ++i) taus[i] = d->taus[i];
-  return d->ntaus;
-}
-
-/* TAU j: rubber-band rescaling of the gene-node ages around tau_j in every locus (stree.c:5512);
-   loci without a node in the band are left out of the step; ONE decision for all loci */
-static int tau_step(a00_driver_t * d, unsigned j)
+/* TAU of inner population q: sliding window reflected into (older child's tau, parent's tau); the gene
+   nodes of q and of its two children between those bounds move with it (rubber band,
+   propose_tau_update_gtrees stree.c:4338-4479); ONE decision for all loci from
+   sum(dlogpr + dlnL) + below*log(minfactor) + above*log(maxfactor)   (stree.c:6280) */
+static int tau_step(a00_driver_t * d, int q)
 {
   unsigned i, n = 0; double sum = 0;
-  const double tau = d->taus[j], lo = j ? d->taus[j-1] : 0.0, hi = j + 1 < d->ntaus ? d->taus[j+1] : -1.0;
-  const double tnew = a00_tau_proposal(a00_rndu(&d->grng), lo, tau, hi);
+  const int cl = d->sp_left[q], cr = d->sp_right[q], pq = d->sp_parent[q];
+  const double old = d->tau[q], lo = fmax(d->tau[cl], d->tau[cr]), hi = pq >= 0 ? d->tau[pq] : 999.0;
+  const double tnew = a00_reflect(old + d->ft_tau*(a00_rndu(&d->grng) - 0.5), lo, hi);
   const double uacc = a00_rndu(&d->grng);
+  const double minf = (tnew - lo)/(old - lo), maxf = (tnew - hi)/(old - hi), lminf = log(minf), lmaxf = log(maxf);
   step_begin(d);
+  d->tau[q] = tnew;
   for (i = 0; i < d->nloci; ++i)
   {
-    a00_tree_t * t = d->trees + i; int br[MAXN], nd[MAXN], nb = 0, nn = 0, k, v, moved = 0;
+    a00_tree_t * t = d->trees + i; int br[MAXN], nd[MAXN], nb = 0, nn = 0, k, v, above = 0, below = 0;
     char isbr[MAXN], isnd[MAXN];
     snapshot(d, i);
     memset(isbr, 0, (size_t)t->n); memset(isnd, 0, (size_t)t->n);
-    for (k = 0; k < t->n; ++k)
-      if (t->left[k] >= 0)
-      {
-        const double tn = a00_rubber_band(t->time[k], lo, tau, tnew, hi);
-        if (tn != t->time[k])
-        {
-          t->time[k] = tn; ++moved;
-          isbr[t->left[k]] = isbr[t->right[k]] = 1; if (t->parent[k] >= 0) isbr[k] = 1;
-          for (v = k; v >= 0; v = t->parent[v]) isnd[v] = 1;              /* gtree_return_partials */
-        }
-      }
-    if (!moved) continue;
+    for (k = t->tips; k < t->n; ++k)
+    {
+      const int pk = t->pop[k]; const double tk = t->time[k];
+      if ((pk != q && pk != cl && pk != cr) || tk < lo || tk > hi) continue;
+      if (tk >= old) { t->time[k] = hi + maxf*(tk - hi); ++above; } else { t->time[k] = lo + minf*(tk - lo); ++below; }
+      isbr[t->left[k]] = isbr[t->right[k]] = 1; if (t->parent[k] >= 0) isbr[k] = 1;
+      for (v = k; v >= 0; v = t->parent[v]) isnd[v] = 1;              /* gtree_return_partials, gtree.c:145-175 */
+    }
+    d->p_logpr[i] = tree_logpr(d, t);
+    d->p_delta[i] = (d->p_logpr[i] - t->logpr) + below*lminf + above*lmaxf;
+    d->p_slot[i] = -1;
+    if (!(above + below)) continue;
     for (k = 0; k < t->n; ++k) { if (isbr[k]) br[nb++] = k; if (isnd[k]) nd[nn++] = k; }
+    d->p_slot[i] = (int)n;
     step_add(d, n, i, br, nb, nd, nn);
     ++n;
   }
   if (!step_eval(d, n)) return 0;
-  for (i = 0; i < n; ++i) sum += d->s_lnl[i] - d->trees[d->s_locus[i]].lnl;
+  for (i = 0; i < d->nloci; ++i)
+    sum += d->p_slot[i] >= 0 ? (d->s_lnl[d->p_slot[i]] - d->trees[i].lnl) + d->p_delta[i] : d->p_delta[i];
+  if (pq < 0) sum += root_tau_prior_ratio(d, old, tnew);
   d->proposals++;
   if (sum >= 0 || uacc < exp(sum))
   {
-    d->accepted++; d->taus[j] = tnew;
-    for (i = 0; i < n; ++i) d->trees[d->s_locus[i]].lnl = d->s_lnl[i];
+    d->accepted++;
+    for (i = 0; i < d->nloci; ++i) { d->trees[i].logpr = d->p_logpr[i]; if (d->p_slot[i] >= 0) d->trees[i].lnl = d->s_lnl[d->p_slot[i]]; }
   }
-  else for (i = 0; i < n; ++i) restore(d, d->s_locus[i]);
+  else
+  {
+    d->tau[q] = old;
+    for (i = 0; i < d->nloci; ++i) if (d->p_slot[i] >= 0) restore(d, i);
+  }
   return 1;
 }
 
-/* MIX: every age of every locus times c; ONE decision from the summed difference (prop_mixing.c:203-205) */
+/* MIX: every gene-node age of every locus and every tau times c; ONE decision from
+   sum(dlogpr + dlnL) + (ages + taus)*log c   (prop_mixing.c:203-205; thetas stay) */
 static int mix_step(a00_driver_t * d)
 {
-  unsigned i; int br[MAXN], nd[MAXN]; double sum = 0, lnacc; long ninner = 0;
-  const double lnc = 0.1*(a00_rndu(&d->grng) - 0.5), c = exp(lnc);
+  unsigned i; int br[MAXN], nd[MAXN], p; double sum = 0, lnacc, oldtau[A00_MAXPOP];
+  const double lnc = d->ft_mix*(a00_rndu(&d->grng) - 0.5), c = exp(lnc);
   const double uacc = a00_rndu(&d->grng);
   step_begin(d);
+  for (p = 0; p < d->npop; ++p) { oldtau[p] = d->tau[p]; d->tau[p] *= c; }
   for (i = 0; i < d->nloci; ++i)
   {
     a00_tree_t * t = d->trees + i; int nb = 0, nn = 0, k;
     snapshot(d, i);
     for (k = 0; k < t->n; ++k)
     {
-      if (t->left[k] >= 0) { t->time[k] *= c; nd[nn++] = k; ++ninner; }
+      if (t->left[k] >= 0) { t->time[k] *= c; nd[nn++] = k; }
       if (t->parent[k] >= 0) br[nb++] = k;
     }
+    d->p_logpr[i] = tree_logpr(d, t);
+    d->p_delta[i] = (d->p_logpr[i] - t->logpr) + (double)nn*lnc;
     step_add(d, i, i, br, nb, nd, nn);
   }
   if (!step_eval(d, d->nloci)) return 0;
-  for (i = 0; i < d->nloci; ++i) sum += d->s_lnl[i] - d->trees[i].lnl;
-  lnacc = sum + (double)ninner*lnc;                       /* multiplier proposal on ninner ages */
+  for (i = 0; i < d->nloci; ++i) sum += (d->s_lnl[i] - d->trees[i].lnl) + d->p_delta[i];
+  lnacc = sum + (double)(d->S - 1)*lnc;
+  if (d->tau_alpha > 0)                    /* all taus scale together: the Dirichlet part is unchanged */
+    lnacc += (d->tau_alpha - 1)*lnc - d->tau_beta*(d->tau[d->npop-1] - oldtau[d->npop-1]) - (double)(d->S - 2)*lnc;
   d->proposals++;
   if (lnacc >= 0 || uacc < exp(lnacc))
   {
     d->accepted++;
-    for (i = 0; i < d->nloci; ++i) d->trees[i].lnl = d->s_lnl[i];
-    for (i = 0; i < d->ntaus; ++i) d->taus[i] *= c;                  /* the species tree is scaled too */
+    for (i = 0; i < d->nloci; ++i) { d->trees[i].lnl = d->s_lnl[i]; d->trees[i].logpr = d->p_logpr[i]; }
   }
-  else for (i = 0; i < d->nloci; ++i) restore(d, i);
+  else
+  {
+    for (p = 0; p < d->npop; ++p) d->tau[p] = oldtau[p];
+    for (i = 0; i < d->nloci; ++i) restore(d, i);
+  }
   return 1;
 }
 
@@ -410,8 +566,16 @@ int a00_iterate(a00_driver_t * d)
   for (i = 0; i < d->nloci; ++i) if (d->trees[i].tips > maxtips) maxtips = d->trees[i].tips;
   for (k = 0; k < maxtips - 1; ++k)   if (!gage_step(d, k)) return 0;
   for (k = 0; k < 2*maxtips - 2; ++k) if (!gspr_step(d, k)) return 0;
-  for (k = 0; k < (int)d->ntaus; ++k) if (!tau_step(d, (unsigned)k)) return 0;
+  for (k = d->S; k < d->npop; ++k)    if (!tau_step(d, k)) return 0;
   return mix_step(d);
+}
+
+int a00_backend_prior(void * ctx, const a00_step_t * step, double * lnl)
+{
+  unsigned i;
+  (void)ctx;
+  for (i = 0; i < step->nloci; ++i) lnl[i] = 0;
+  return 1;
 }
 
 double a00_total_lnl(const a00_driver_t * d)

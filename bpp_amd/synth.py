@@ -25,6 +25,39 @@ SPECIES_TREES = {
 }
 
 
+def species_tree_arrays(taxa, theta=None):
+    """(parent, tau, theta) of SPECIES_TREES[taxa] in stree->nodes order: the species in the order
+    their names appear (= the gene-tree tip order of make_dataset), then the inner populations with
+    children before parents, the root last; one theta for all populations"""
+    stree = SPECIES_TREES[taxa]
+    if theta is None:
+        theta = 0.002 if taxa != 6 else 0.02
+    tips = []
+
+    def names(t):
+        if isinstance(t, str):
+            tips.append(t)
+        else:
+            names(t[0]); names(t[1])
+    names(stree)
+    inner = []                      # (tau, left id, right id) in post-order
+
+    def walk(t):
+        if isinstance(t, str):
+            return tips.index(t)
+        l, r = walk(t[0]), walk(t[1])
+        inner.append((t[2], l, r))
+        return len(tips) + len(inner) - 1
+    walk(stree)
+    n = len(tips) + len(inner)
+    parent, tau = [-1] * n, [0.0] * n
+    for k, (tv, l, r) in enumerate(inner):
+        me = len(tips) + k
+        tau[me] = tv
+        parent[l] = parent[r] = me
+    return parent, tau, [theta] * n
+
+
 def _msc_gene_tree(stree, theta, rng):
     """one gene tree under the MSC; returns (left, right, times, root) with tips in
     species order and inner nodes numbered by increasing age"""

@@ -3,24 +3,38 @@
  *
  * BASELINE.json north_star: "host MCMC control flow stays in C and calls HIP through a thin
  * C-ABI shim".  This is that host side, reduced to what drives the likelihood path: a
- * lock-step gene-tree sampler that, like BPP's A00 iteration (method.c:5490-5602), sweeps
- * every locus with gene-node age proposals (GAGE, gtree.c:4585), subtree prune/regraft
- * proposals (GSPR, gtree.c:6531) and an all-loci mixing step (prop_mixing.c:52), keeps the
- * gnode_t fields the reference keeps (left/right/parent/time/clv_index/scaler_index/
- * pmatrix_index), toggles the double buffers before every evaluation exactly as the
- * reference does (SWAP_CLV_INDEX / SWAP_PMAT_INDEX / SWAP_SCALER_INDEX, locus.c:24-26) and
- * toggles back on rejection.  "Step j of every locus" is handed to a likelihood back-end as
- * one batch.  Two back-ends exist: libbpp_amd.so (this repo's product, a00_backend_hip) and,
- * for tests only, the real reference's locus API (oracle/ref_shim.c: ref_backend_eval) —
- * the same driver, the same seeds, the same trajectory on both is the drop-in check.
+ * lock-step sampler of the gene trees of all loci under the multispecies coalescent on a fixed
+ * species tree, with the moves of BPP's A00 iteration (method.c:5490-5602) that call the
+ * likelihood:
  *
- * The acceptance rule is Metropolis on the likelihood ratio (times the proposal's Hastings
- * factor for the root-age and mixing multipliers); BPP's MSC prior density is out of scope
- * (SURVEY.md §8f rank 1).
+ *   GAGE  gene-node age, sliding window reflected into (max(children, tau of the children's
+ *         common population), parent)                              propose_ages, gtree.c:4585
+ *   GSPR  subtree prune and regraft: new age of the father, target drawn among the branches
+ *         crossing it in the same population, Hastings ratio targets/sources
+ *                                                                   propose_spr, gtree.c:6531
+ *   TAU   species divergence time with the rubber band on the gene nodes of the three
+ *         populations around it, ONE decision for all loci
+ *                                   propose_tau / propose_tau_update_gtrees, stree.c:5512/4338
+ *   MIX   all ages and taus times c, ONE decision              proposal_mixing, prop_mixing.c:52
+ *
+ * It keeps the gnode_t fields the reference keeps (left/right/parent/time/pop/clv_index/
+ * scaler_index/pmatrix_index), toggles the double buffers before every evaluation exactly as the
+ * reference does (SWAP_CLV_INDEX / SWAP_PMAT_INDEX / SWAP_SCALER_INDEX, locus.c:24-26) and toggles
+ * back on rejection.  "Step j of every locus" is handed to a likelihood back-end as one batch.
+ * Back-ends: libbpp_amd.so (the product, a00_backend_hip); for tests the real reference's locus
+ * API (oracle/ref_shim.c: ref_backend_eval) — same driver, same seeds, same trajectory on both is
+ * the drop-in check — and a00_backend_prior (lnL = 0, BPP's usedata = 0).
+ *
+ * Acceptance: Metropolis-Hastings on  MSC density x likelihood.  The MSC density of a gene tree is
+ * gtree_logprob (gtree.c:3957) = the sum over populations of gtree_update_logprob_contrib
+ * (gtree.c:3859), a00_msc_logpr below, bit-equal to the reference's (tests/test_msc_density.py).
+ * The taus carry BPP's gamma/Dirichlet prior (a00_set_tau_prior); thetas are fixed — theta moves are
+ * model-space logic outside the likelihood path.
  */
 #ifndef BPP_AMD_HOST_H
 #define BPP_AMD_HOST_H
 
+#include <math.h>
 #include "bpp_amd.h"
 
 #ifdef __cplusplus
@@ -55,6 +69,8 @@ typedef struct a00_tree
   int *    clv, * pmat, * scaler;        /* [n] current buffer indices (gnode_t fields) */
   double   rate_mui;                     /* gtree_t.rate_mui        */
   double   lnl;                          /* current log-likelihood  */
+  int *    pop;                          /* [n] gnode_t.pop: species of a tip, population an inner node coalesces in */
+  double   logpr;                        /* current MSC density, gtree_t.logpr */
 } a00_tree_t;
 
 /* one proposal step for a set of loci, in node terms */
@@ -79,28 +95,62 @@ void           a00_destroy(a00_driver_t *);
 int            a00_set_tree(a00_driver_t *, unsigned i, int tips, const int * left, const int * right,
                             const double * times, int root, int scaling);
 const a00_tree_t * a00_tree(const a00_driver_t *, unsigned i);
-/* species-tree divergence times (ascending) for the TAU step (stree.c:5512 propose_tau): one all-loci
-   proposal per tau per iteration; the gene-node ages between the neighbouring taus are rescaled
-   ("rubber band", stree.c:4338-4779), the touched branches/root paths re-evaluated
-   (gtree_return_partials, gtree.c:145-175) and ONE decision taken from the summed difference
-   (threads.c:544-559).  Without taus the iteration has no TAU steps.  n <= 8.                    */
-int            a00_set_taus(a00_driver_t *, const double * taus, unsigned n);
-unsigned       a00_get_taus(const a00_driver_t *, double * taus);
-/* the rubber-band map shared by host and device: new age of a gene node of age t when tau -> tnew,
-   with lo / hi the neighbouring taus (hi < 0: none above) */
-static inline double a00_rubber_band(double t, double lo, double tau, double tnew, double hi)
+/* The species tree: `species` tips (populations 0..species-1) and species-1 inner populations
+   after them, children before parents (the root last); parent[] (-1 for the root), tau[] (0 for
+   tips) and theta[] have 2*species-1 entries, stree->nodes order (tips first).  species <= 8.
+   Must be set before a00_initialize.                                                             */
+#define A00_MAXPOP 15
+int            a00_set_species_tree(a00_driver_t *, int species, const int * parent, const double * tau,
+                                    const double * theta);
+/* species of the tips of locus i (default: tip k belongs to species k) */
+int            a00_set_tip_species(a00_driver_t *, unsigned i, const int * species);
+/* window widths of the four moves (defaults 0.004, 0.004, 0.001, 0.3) */
+void           a00_set_finetune(a00_driver_t *, double gage, double gspr, double tau, double mix);
+/* prior on the divergence times as BPP's 'tauprior = gamma a b': gamma(alpha, beta) on the root tau, the
+   others uniform below it (stree.c:5655-5657); alpha = 0 (default): flat */
+void           a00_set_tau_prior(a00_driver_t *, double alpha, double beta);
+/* current tau[] (2*species-1 entries); returns the number of populations */
+unsigned       a00_get_taus(const a00_driver_t *, double * tau);
+/* MSC density of the current gene tree of locus i, recomputed from scratch */
+double         a00_locus_logpr(const a00_driver_t *, unsigned i);
+
+/* reflection of x into (a,b) (reflect, gtree.c:3983) */
+static inline double a00_reflect(double x, double a, double b)
 {
-  if (t > lo && t <= tau) return lo + (t - lo)*(tnew - lo)/(tau - lo);
-  if (t > tau && (hi < 0 || t < hi)) return hi < 0 ? tnew + (t - tau) : hi - (hi - t)*(hi - tnew)/(hi - tau);
-  return t;
+  const double w = b - a; double e; long n;
+  if (!(w > 0)) return a;
+  if (x >= a && x <= b) return x;
+  e = x < a ? a - x : x - b;
+  n = (long)(e/w);
+  e -= (double)n*w;
+  /* an even number of whole widths keeps the side the walk left from */
+  if ((x < a) == ((n & 1) == 0)) return a + e;
+  return b - e;
 }
-static inline double a00_tau_proposal(double u, double lo, double tau, double hi)
+/* gtree_update_logprob_contrib (gtree.c:3859-3955) for one population: tau = its start, ptau = its
+   parent's tau (< 0 for the root), nin = lineages entering, times[ncoal] the coalescent times in it
+   SORTED ascending; heredity multiplies theta as in the reference.  Same operations, same order. */
+static inline double a00_msc_contrib(double tau, double ptau, double theta, double heredity, int nin,
+                                     const double * times, int ncoal)
 {
-  return lo + (0.05 + 0.9*u)*((hi < 0 ? 2*tau - lo : hi) - lo);
+  double T2h = 0, prev = tau, logpr = 0; int k, n = nin;
+  /* intervals end at every coalescence and at the parent's tau; the one after the last possible
+     coalescence (n == 1) is not visited */
+  int steps = ncoal + (ptau >= 0 ? 1 : 0);
+  if (nin == steps) --steps;
+  for (k = 0; k < steps; ++k, --n)
+  {
+    const double t = k < ncoal ? times[k] : ptau;
+    T2h += n*(n - 1)*(t - prev);
+    prev = t;
+  }
+  if (ncoal) logpr += ncoal*log(2.0/(heredity*theta));
+  if (T2h) logpr -= T2h/(theta*heredity);
+  return logpr;
 }
 /* start-up evaluation: all matrices, all partials, lnL (method.c:4285-4297) */
 int            a00_initialize(a00_driver_t *);
-/* one iteration: GAGE over inner nodes, GSPR over non-root nodes, one TAU step per tau, one MIX step */
+/* one iteration: GAGE over inner nodes, GSPR over non-root nodes, one TAU step per inner population, one MIX step */
 int            a00_iterate(a00_driver_t *);
 double         a00_total_lnl(const a00_driver_t *);
 void           a00_counters(const a00_driver_t *, unsigned long * proposals, unsigned long * accepted,
@@ -110,6 +160,8 @@ void           a00_counters(const a00_driver_t *, unsigned long * proposals, uns
    counts of method.c:4110-4146 (2*inner CLVs, 2*edges P-matrices, 2*inner scalers)       */
 typedef struct a00_hip_ctx { bpa_engine_t * engine; bpa_locus_t ** loci; } a00_hip_ctx_t;
 int a00_backend_hip(void * ctx /* a00_hip_ctx_t* */, const a00_step_t * step, double * lnl);
+/* lnL = 0 for every locus: the sampler then draws gene trees from the MSC prior (BPP's usedata = 0) */
+int a00_backend_prior(void * ctx, const a00_step_t * step, double * lnl);
 
 #ifdef __cplusplus
 }

@@ -142,3 +142,67 @@ int ref_msa_print_phylip(const char * path, msa_t ** l, long nloci)
   fclose(fp);
   return 1;
 }
+
+/* ---------------------------------------------------------------------------
+ * MSC density: gtree_logprob (gtree.c:3957) = sum over populations of
+ * gtree_update_logprob_contrib (gtree.c:3859) on a hand-built species tree: the
+ * populations in stree->nodes order with, for locus 0, their coalescent-event
+ * lists, seqin_count and coal_count as gtree.c keeps them.  pop[] gives the
+ * population of every gene node (tips: their species).
+ * ------------------------------------------------------------------------- */
+double ref_msc_logpr(int species, const int * parent, const double * tau, const double * theta,
+                     int tips, const int * left, const int * right, const double * time, const int * pop,
+                     double * contrib_out)
+{
+  int np = 2*species - 1, n = 2*tips - 1, p, k;
+  double logpr;
+  stree_t * st = (stree_t *)calloc(1, sizeof(stree_t));
+  gnode_t * gn = (gnode_t *)calloc((size_t)n, sizeof(gnode_t));
+  st->tip_count = (unsigned int)species; st->inner_count = (unsigned int)(species - 1); st->hybrid_count = 0;
+  st->nodes = (snode_t **)calloc((size_t)np, sizeof(snode_t *));
+  for (p = 0; p < np; ++p)
+  {
+    snode_t * s = st->nodes[p] = (snode_t *)calloc(1, sizeof(snode_t));
+    s->tau = tau[p]; s->theta = theta[p]; s->node_index = (unsigned int)p;
+    s->coalevent = (dlist_t **)calloc(1, sizeof(dlist_t *)); s->coalevent[0] = dlist_create();
+    s->seqin_count = (int *)calloc(1, sizeof(int)); s->coal_count = (int *)calloc(1, sizeof(int));
+    s->C2ji = (double *)calloc(1, sizeof(double)); s->old_C2ji = (double *)calloc(1, sizeof(double));
+    s->logpr_contrib = (double *)calloc(1, sizeof(double)); s->old_logpr_contrib = (double *)calloc(1, sizeof(double));
+  }
+  for (p = 0; p < np; ++p)
+    if (parent[p] >= 0)
+    {
+      snode_t * q = st->nodes[parent[p]];
+      st->nodes[p]->parent = q;
+      if (!q->left) q->left = st->nodes[p]; else q->right = st->nodes[p];
+    }
+  st->root = st->nodes[np - 1];
+  for (k = 0; k < n; ++k)
+  {
+    gn[k].time = time[k];
+    if (left[k] >= 0) { dlist_append(st->nodes[pop[k]]->coalevent[0], (void *)(gn + k)); st->nodes[pop[k]]->coal_count[0]++; }
+    else st->nodes[pop[k]]->seqin_count[0]++;
+  }
+  for (p = species; p < np; ++p)      /* children precede parents in this ordering */
+  {
+    snode_t * s = st->nodes[p];
+    s->seqin_count[0] = (s->left->seqin_count[0] - s->left->coal_count[0]) + (s->right->seqin_count[0] - s->right->coal_count[0]);
+  }
+  opt_est_theta = 1; opt_msci = 0; opt_migration = 0; opt_datefile = NULL;
+  if (!global_sortbuffer_r)
+  {
+    global_sortbuffer_r = (double **)calloc(1, sizeof(double *));
+    global_sortbuffer_r[0] = (double *)calloc(4096, sizeof(double));
+  }
+  logpr = gtree_logprob(st, 1.0, 0, 0);
+  if (contrib_out) for (p = 0; p < np; ++p) contrib_out[p] = st->nodes[p]->logpr_contrib[0];
+  for (p = 0; p < np; ++p)
+  {
+    snode_t * s = st->nodes[p];
+    dlist_clear(s->coalevent[0], NULL); dlist_destroy(s->coalevent[0]); free(s->coalevent);
+    free(s->seqin_count); free(s->coal_count); free(s->C2ji); free(s->old_C2ji); free(s->logpr_contrib); free(s->old_logpr_contrib);
+    free(s);
+  }
+  free(st->nodes); free(st); free(gn);
+  return logpr;
+}

@@ -14,7 +14,8 @@ class A00Tree(C.Structure):
                 ("left", C.POINTER(C.c_int)), ("right", C.POINTER(C.c_int)), ("parent", C.POINTER(C.c_int)),
                 ("time", C.POINTER(C.c_double)),
                 ("clv", C.POINTER(C.c_int)), ("pmat", C.POINTER(C.c_int)), ("scaler", C.POINTER(C.c_int)),
-                ("rate_mui", C.c_double), ("lnl", C.c_double)]
+                ("rate_mui", C.c_double), ("lnl", C.c_double),
+                ("pop", C.POINTER(C.c_int)), ("logpr", C.c_double)]
 
 
 class HipCtx(C.Structure):
@@ -36,7 +37,13 @@ def lib():
                                    C.POINTER(C.c_double), C.c_int, C.c_int]
         L.a00_tree.restype = C.POINTER(A00Tree)
         L.a00_tree.argtypes = [C.c_void_p, C.c_uint]
-        L.a00_set_taus.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_uint]
+        L.a00_set_species_tree.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double)]
+        L.a00_set_tip_species.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_int)]
+        L.a00_set_finetune.argtypes = [C.c_void_p] + [C.c_double] * 4
+        L.a00_set_tau_prior.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.a00_locus_logpr.restype = C.c_double
+        L.a00_locus_logpr.argtypes = [C.c_void_p, C.c_uint]
         L.a00_get_taus.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.a00_get_taus.restype = C.c_uint
         L.a00_initialize.argtypes = [C.c_void_p]
@@ -62,14 +69,29 @@ class Driver:
                                 int(d["root"]), int(scaling))
             assert ok
 
-    def set_taus(self, taus):
-        a = (C.c_double * len(taus))(*taus)
-        assert lib().a00_set_taus(self.h, a, len(taus))
+    def set_species_tree(self, parent, tau, theta):
+        n = len(parent)
+        self.species = (n + 1) // 2
+        ok = lib().a00_set_species_tree(self.h, self.species, (C.c_int * n)(*parent), (C.c_double * n)(*tau),
+                                        (C.c_double * n)(*theta))
+        assert ok, "bad species tree"
+
+    def set_tip_species(self, i, species):
+        assert lib().a00_set_tip_species(self.h, i, (C.c_int * len(species))(*species))
+
+    def set_finetune(self, gage, gspr, tau, mix):
+        lib().a00_set_finetune(self.h, gage, gspr, tau, mix)
+
+    def set_tau_prior(self, alpha, beta):
+        lib().a00_set_tau_prior(self.h, alpha, beta)
 
     def taus(self):
-        a = (C.c_double * 8)()
+        a = (C.c_double * 15)()
         n = lib().a00_get_taus(self.h, a)
         return [a[i] for i in range(n)]
+
+    def logpr(self, i):
+        return lib().a00_locus_logpr(self.h, i)
 
     def initialize(self):
         assert lib().a00_initialize(self.h), bpp_amd.lib().bpa_last_error()
@@ -90,7 +112,8 @@ class Driver:
         n = t.n
         g = lambda p: [p[k] for k in range(n)]
         return dict(tips=t.tips, root=t.root, left=g(t.left), right=g(t.right), parent=g(t.parent),
-                    time=g(t.time), clv=g(t.clv), pmat=g(t.pmat), scaler=g(t.scaler), lnl=t.lnl)
+                    time=g(t.time), clv=g(t.clv), pmat=g(t.pmat), scaler=g(t.scaler), lnl=t.lnl,
+                    pop=g(t.pop), logpr=t.logpr)
 
     def close(self):
         if self.h:
@@ -118,3 +141,9 @@ def hip_driver(engine, loci, data, seed=1, scaling=False):
     drv = Driver(data, fn, C.cast(C.pointer(ctx), C.c_void_p), seed, scaling)
     drv._keep = (arr, ctx)
     return drv
+
+
+def prior_driver(data, seed=1):
+    """driver with lnL = 0 (a00_backend_prior): samples gene trees from the MSC prior"""
+    fn = C.cast(lib().a00_backend_prior, C.c_void_p)
+    return Driver(data, fn, None, seed, False)

@@ -17,8 +17,11 @@ pytestmark = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built"
 def test_driver_on_reference_backend(taxa, model, R, scaling):
     data = synth.make_dataset(10, 300, taxa, model, R, seed=31, theta=0.004 if taxa == 6 else None)
     drv = hostdrv.reference_driver(data, seed=7, scaling=scaling)
-    taus = {4: (0.001, 0.002, 0.003), 8: (0.0011, 0.0025, 0.005), 6: (0.01, 0.02, 0.035, 0.05)}[taxa]
-    drv.set_taus(taus)
+    theta = 0.004 if taxa == 6 else 0.002
+    parent, tau0, thetas = synth.species_tree_arrays(taxa, theta)
+    drv.set_species_tree(parent, tau0, thetas)
+    if taxa == 6:
+        drv.set_finetune(0.02, 0.02, 0.005, 0.3)
     drv.initialize()
     l0 = drv.total_lnl()
     want0 = sum(O.OracleLocus(d["states"], R, d["seqs"], d["weights"], model=model,
@@ -29,9 +32,10 @@ def test_driver_on_reference_backend(taxa, model, R, scaling):
     for _ in range(4):
         drv.iterate()
     props, acc, steps = drv.counters()
-    assert 1 + 4 * ((taxa - 1) + (2 * taxa - 2) + 1) <= steps <= 1 + 4 * ((taxa - 1) + (2 * taxa - 2) + 1 + len(taus))
+    assert 1 + 4 * ((taxa - 1) + 1) <= steps <= 1 + 4 * ((taxa - 1) + (2 * taxa - 2) + 1 + (taxa - 1))
     new = drv.taus()
-    assert len(new) == len(taus) and all(b > a for a, b in zip(new, new[1:])) and new != list(taus)
+    assert len(new) == 2 * taxa - 1 and new != list(tau0) and new[:taxa] == [0.0] * taxa
+    assert all(new[parent[p]] > new[p] for p in range(2 * taxa - 2))
     assert 0.05 < acc / props < 0.98
     total = 0.0
     for i, d in enumerate(data):
@@ -46,6 +50,13 @@ def test_driver_on_reference_backend(taxa, model, R, scaling):
                            qrates=None if model == "jc69" else d["exch"], rates=d["rates"], scaling=scaling)
         full = ol.full_lnl(t["left"], t["right"], t["time"], t["root"])
         assert rel(t["lnl"], full) < 1e-12
+        # every node sits in the population its age and descendants put it in; the carried MSC density
+        # is the from-scratch one (check_logpr, method.c:4719)
+        for v in range(taxa, 2 * taxa - 1):
+            pv = t["pop"][v]
+            assert new[pv] <= t["time"][v] and (parent[pv] < 0 or t["time"][v] < new[parent[pv]])
+        assert t["pop"][:taxa] == list(range(taxa))
+        assert rel(t["logpr"], drv.logpr(i)) < 1e-12 and np.isfinite(t["logpr"])
         total += t["lnl"]
     assert rel(drv.total_lnl(), total) < 1e-13
     assert drv.total_lnl() > l0 - 50        # a likelihood-driven sampler does not run away downhill
