@@ -363,8 +363,10 @@ def main():
     sampler = None
     if world == 1 and args.config == "c2" and not args.no_sampler:
         smp = bpp_amd.Sampler(eng, loci, data, seed=1)
-        smp_taus = cfg["taus"]
-        smp.set_taus(smp_taus)
+        sp_parent, sp_tau, sp_theta = synth.species_tree_arrays(cfg["taxa"])
+        smp_taus = sp_tau[cfg["taxa"]:]
+        smp.set_species_tree(sp_parent, sp_tau, sp_theta)
+        smp.set_tau_prior(3.0, 3.0 / sp_tau[-1])
         smp.initialize()
         smp.iterate(args.warmup)
         eng.synchronize()
@@ -376,11 +378,12 @@ def main():
         sampler = dict(iterations_per_s=round(args.steps / dt * nloci / 10000.0, 1), ms_per_iteration=round(1e3 * dt / args.steps, 4),
                        launches_per_iteration=4 + 3 * len(smp_taus), proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
                        acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
-                       taus_after=[float(x) for x in smp.taus()],
-                       note="GAGE+GSPR per locus, one rubber-band TAU step per species divergence and one all-loci MIX "
-                            "per iteration, Metropolis on the likelihood ratio, decisions taken on the device; same "
-                            "trajectory as the C host driver on the reference (tests/test_gpu_sampler.py, "
-                            "tests/test_gpu_host_driver.py); no MSC prior")
+                       taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
+                       note="multispecies-coalescent sampler on a fixed species tree: population-aware GAGE+GSPR per locus, one "
+                            "rubber-band TAU step per species divergence and one all-loci MIX per iteration, "
+                            "Metropolis-Hastings on MSC density x likelihood (density bit-equal to gtree_logprob), "
+                            "decisions taken on the device; same trajectory as the C host driver on the reference "
+                            "(tests/test_gpu_sampler.py, tests/test_gpu_host_driver.py); thetas fixed")
         smp.close()
 
     cpu = None

@@ -104,8 +104,12 @@ def lib():
         "bpa_sampler_create": (vp, [vp, C.POINTER(vp), u, C.c_ulong]),
         "bpa_sampler_destroy": (None, [vp]),
         "bpa_sampler_set_tree": (i, [vp, u, C.POINTER(i), C.POINTER(i), dp, i]),
-        "bpa_sampler_set_taus": (i, [vp, dp, u]),
+        "bpa_sampler_set_species_tree": (i, [vp, i, C.POINTER(i), dp, dp]),
+        "bpa_sampler_set_tip_species": (i, [vp, u, C.POINTER(i)]),
+        "bpa_sampler_set_finetune": (None, [vp, d, d, d, d]),
+        "bpa_sampler_set_tau_prior": (None, [vp, d, d]),
         "bpa_sampler_get_taus": (i, [vp, dp]),
+        "bpa_sampler_get_tree_msc": (i, [vp, u, C.POINTER(i), dp]),
         "bpa_sampler_initialize": (i, [vp]),
         "bpa_sampler_iterate": (i, [vp, u]),
         "bpa_sampler_get_tree": (i, [vp, u, C.POINTER(i), C.POINTER(i), C.POINTER(i), dp, C.POINTER(i),
@@ -137,7 +141,8 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_plan_enable_sum", "bpa_plan_get_sum", "bpa_plans_launch",
             "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride",
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
-            "bpa_sampler_set_taus", "bpa_sampler_get_taus",
+            "bpa_sampler_set_species_tree", "bpa_sampler_set_tip_species", "bpa_sampler_set_finetune",
+            "bpa_sampler_set_tau_prior", "bpa_sampler_get_taus", "bpa_sampler_get_tree_msc",
             "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary"]
 
 
@@ -462,13 +467,25 @@ class Sampler:
             _chk(L.bpa_sampler_set_tree(self.h, k, l.ctypes.data_as(ip), r.ctypes.data_as(ip), _dp(t), int(d["root"])))
         self.ntips = [len(d["seqs"]) for d in data]
 
-    def set_taus(self, taus):
-        t = _f64(taus)
-        self._ntaus = len(t)
-        _chk(lib().bpa_sampler_set_taus(self.h, _dp(t), len(t)))
+    def set_species_tree(self, parent, tau, theta):
+        """a00_set_species_tree's arrays (bpp_amd.synth.species_tree_arrays makes them)"""
+        par = np.ascontiguousarray(parent, dtype=np.int32)
+        self._npop = len(par)
+        _chk(lib().bpa_sampler_set_species_tree(self.h, (len(par) + 1) // 2, par.ctypes.data_as(C.POINTER(C.c_int)),
+                                                _dp(_f64(tau)), _dp(_f64(theta))))
+
+    def set_tip_species(self, k, species):
+        sp = np.ascontiguousarray(species, dtype=np.int32)
+        _chk(lib().bpa_sampler_set_tip_species(self.h, k, sp.ctypes.data_as(C.POINTER(C.c_int))))
+
+    def set_finetune(self, gage, gspr, tau, mix):
+        lib().bpa_sampler_set_finetune(self.h, gage, gspr, tau, mix)
+
+    def set_tau_prior(self, alpha, beta):
+        lib().bpa_sampler_set_tau_prior(self.h, alpha, beta)
 
     def taus(self):
-        out = np.zeros(getattr(self, "_ntaus", 0))
+        out = np.zeros(getattr(self, "_npop", 0))
         if len(out):
             _chk(lib().bpa_sampler_get_taus(self.h, _dp(out)))
         return list(out)
@@ -488,8 +505,10 @@ class Sampler:
         _chk(lib().bpa_sampler_get_tree(self.h, k, a[0].ctypes.data_as(ip), a[1].ctypes.data_as(ip),
                                         a[2].ctypes.data_as(ip), _dp(t), a[3].ctypes.data_as(ip),
                                         a[4].ctypes.data_as(ip), C.byref(root), C.byref(lnl)))
+        pop, logpr = np.zeros(n, dtype=np.int32), C.c_double()
+        _chk(lib().bpa_sampler_get_tree_msc(self.h, k, pop.ctypes.data_as(ip), C.byref(logpr)))
         return dict(left=list(a[0]), right=list(a[1]), parent=list(a[2]), time=list(t), clv=list(a[3]),
-                    pmat=list(a[4]), root=root.value, lnl=lnl.value)
+                    pmat=list(a[4]), root=root.value, lnl=lnl.value, pop=list(pop), logpr=logpr.value)
 
     def summary(self):
         tot = C.c_double()

@@ -10,7 +10,7 @@
 // decision is taken on the device from the summed log-likelihood difference.  An iteration is
 // 4 launches instead of 3 tips - 2 + 1 host round trips.
 //
-// Scope (round 1): JC69, one rate category, no scalers, up to 8 tips, loci of <= 64 patterns.
+// Scope (round 1): JC69, one rate category, no scalers, up to 8 tips / 8 species, loci of <= 64 patterns.
 // Parity: identical trajectory to the host driver on libbpp_amd.so, which is identical to the
 // host driver on the real reference (tests/test_gpu_sampler.py).
 //
@@ -24,21 +24,34 @@ constexpr int MAXTIPS = 8;
 constexpr int MAXN    = 16;               // 2*MAXTIPS-1 nodes, padded
 constexpr int MAXBUF  = 2*(MAXTIPS - 1);  // inner CLV buffers
 constexpr int MAXPM   = 2*(2*MAXTIPS - 2);// P-matrix buffers
+constexpr int MAXPOP  = 16;               // A00_MAXPOP populations, padded
 constexpr int TPB     = 16;               // loci per workgroup (64 lanes)
 constexpr int BS      = 64;
 
 struct Tree                                // one per locus, in HBM and (while sweeping) in LDS
 {
-  int8_t   left[MAXN], right[MAXN], parent[MAXN], clv[MAXN], pmat[MAXN];
+  int8_t   left[MAXN], right[MAXN], parent[MAXN], clv[MAXN], pmat[MAXN], pop[MAXN];
   double   time[MAXN];
-  double   lnl;
+  double   lnl, logpr;                     // everything from here on survives a rejected proposal
   a00_rng_t rng;
   int32_t  root, tips;
   uint32_t proposals, accepted;
+  uint64_t pad_;
 };
-static_assert(sizeof(Tree) % 16 == 0, "Tree is copied as uint4");
+static_assert(sizeof(Tree) % 16 == 0 && offsetof(Tree, lnl) % 16 == 0, "Tree is copied as uint4");
 
 struct Op { int8_t parent, lc, lp, rc, rp; };      // buffer indices of one node update
+
+// the species tree (a00_set_species_tree): stree->nodes order, children before parents; the taus live in
+// device memory (the TAU and MIX decisions move them), everything else is constant
+struct Species
+{
+  int32_t  S, npop;
+  int8_t   parent[MAXPOP], left[MAXPOP], right[MAXPOP];
+  uint16_t anc[MAXPOP];                    // bit q: q is p or an ancestor of p
+  double   theta[MAXPOP], log2theta[MAXPOP];   // log(2/theta) from the host's libm (a00_msc_contrib)
+  double   ft_gage, ft_gspr, ft_tau, ft_mix, tau_alpha, tau_beta;
+};
 
 struct TaskLDS
 {
@@ -46,7 +59,8 @@ struct TaskLDS
   double ab[MAXPM][2];
   Op     ops[MAXBUF];
   int32_t nops, active;
-  double hast;
+  double hast, logpr_new;
+  int8_t nin[MAXPOP], nc[MAXPOP], gl[MAXPOP];     // lineages entering / coalescences / gene tips below, per population
 };
 
 struct Args
@@ -54,16 +68,18 @@ struct Args
   const LocusDev * loci;       // engine locus table
   const uint32_t * task_locus; // [T]
   const uint32_t * blk_task_off, * lane_task, * task_lane0;
-  Tree * trees, * snap;        // [T] current / pre-mix snapshot
-  double * mix_delta;          // [T] lnL(proposed) - lnL(current) of the mixing step
-  const uint32_t * mix_flag;   // epoch of the last REJECTED mixing step
+  Tree * trees, * snap;        // [T] current / pre-step snapshot of an all-loci step
+  double * mix_delta;          // [T] this locus's term of the all-loci acceptance ratio
+  const uint32_t * mix_flag;   // epoch of the last REJECTED all-loci step
   uint32_t epoch;              // restore from snap when *mix_flag == epoch
   uint32_t mode;               // 0 sweep (GAGE+GSPR), 1 mix, 2 only settle a pending decision, 3 start-up evaluation, 4 tau
   uint32_t nsteps_gage, nsteps_gspr;
-  double   mix_c;
-  const double * taus;         // [ntaus] species-tree divergence times (device-resident, mode 4)
-  uint32_t ntaus, tau_j;
-  double   tau_u;              // the proposal's uniform number (mode 4)
+  double   mix_c, mix_lnc;
+  const double * taus;         // [npop] divergence times (device-resident)
+  uint32_t tau_q;              // population of the TAU step (mode 4)
+  double   tau_u;              // its window uniform
+  double   bfbeta;             // 0 with opt_usedata == 0 (locus.c:2581): the sampler then draws from the MSC prior
+  Species  sp;
 };
 
 // a00_rndu of bpp_amd_host.h, callable on the device (same integer recurrence, same conversion)
@@ -72,17 +88,17 @@ __host__ __device__ inline double rndu(a00_rng_t * r)
   *r = *r*6364136223846793005ULL + 1442695040888963407ULL;
   return (double)((*r >> 11) + 0.5)*(1.0/9007199254740992.0);
 }
-
-// a00_rubber_band / a00_tau_proposal of bpp_amd_host.h for the device (same expressions)
-__host__ __device__ inline double rubber_band(double t, double lo, double tau, double tnew, double hi)
+// a00_reflect of bpp_amd_host.h
+__host__ __device__ inline double reflect(double x, double a, double b)
 {
-  if (t > lo && t <= tau) return lo + (t - lo)*(tnew - lo)/(tau - lo);
-  if (t > tau && (hi < 0 || t < hi)) return hi < 0 ? tnew + (t - tau) : hi - (hi - t)*(hi - tnew)/(hi - tau);
-  return t;
-}
-__host__ __device__ inline double tau_proposal(double u, double lo, double tau, double hi)
-{
-  return lo + (0.05 + 0.9*u)*((hi < 0 ? 2*tau - lo : hi) - lo);
+  const double w = b - a;
+  if (!(w > 0)) return a;
+  if (x >= a && x <= b) return x;
+  double e = x < a ? a - x : x - b;
+  const long n = (long)(e/w);
+  e -= (double)n*w;
+  if ((x < a) == ((n & 1) == 0)) return a + e;
+  return b - e;
 }
 
 __device__ __forceinline__ void swap_clv(Tree & t, int i)
@@ -105,6 +121,18 @@ __device__ __forceinline__ uint32_t path_mask(const Tree & t, int v)
   for (; v >= 0; v = t.parent[v]) m |= 1u << v;
   return m;
 }
+// the nodes of the subtree below (and including) v
+__device__ __forceinline__ uint32_t subtree_mask(const Tree & t, int v)
+{
+  uint32_t m = 1u << v;
+  for (;;)
+  {
+    uint32_t add = 0;
+    for (uint32_t q = m; q; q &= q - 1) { const int x = __ffs(q) - 1; if (t.left[x] >= 0) add |= (1u << t.left[x]) | (1u << t.right[x]); }
+    if (!(add & ~m)) return m;
+    m |= add;
+  }
+}
 // exchange the tree positions of node ids a and b, in place (buffer indices stay with the ids)
 __device__ void swap_ids(Tree & t, int a, int b)
 {
@@ -116,10 +144,64 @@ __device__ void swap_ids(Tree & t, int a, int b)
     t.right[i]  = r == a ? (int8_t)b : r == b ? (int8_t)a : r;
     t.parent[i] = p == a ? (int8_t)b : p == b ? (int8_t)a : p;
   }
-  const int8_t l = t.left[a], r = t.right[a], p = t.parent[a]; const double tm = t.time[a];
-  t.left[a] = t.left[b]; t.right[a] = t.right[b]; t.parent[a] = t.parent[b]; t.time[a] = t.time[b];
-  t.left[b] = l; t.right[b] = r; t.parent[b] = p; t.time[b] = tm;
+  const int8_t l = t.left[a], r = t.right[a], p = t.parent[a], q = t.pop[a]; const double tm = t.time[a];
+  t.left[a] = t.left[b]; t.right[a] = t.right[b]; t.parent[a] = t.parent[b]; t.time[a] = t.time[b]; t.pop[a] = t.pop[b];
+  t.left[b] = l; t.right[b] = r; t.parent[b] = p; t.time[b] = tm; t.pop[b] = q;
   t.root = t.root == a ? b : t.root == b ? a : t.root;
+}
+
+// ---- species tree helpers (lca_pop / climb of a00_driver.c); tau = this workgroup's LDS copy
+__device__ __forceinline__ int lca_pop(const Species & sp, int p, int q)
+{
+  while (!((sp.anc[q] >> p) & 1u)) p = sp.parent[p];
+  return p;
+}
+__device__ __forceinline__ int climb(const Species & sp, const double * tau, int p, double t)
+{
+  while (sp.parent[p] >= 0 && tau[sp.parent[p]] <= t) p = sp.parent[p];
+  return p;
+}
+
+// MSC density of the tree in S.tr: tree_logpr of a00_driver.c = gtree_logprob (gtree.c:3957), the
+// populations in order, each one's coalescent times visited in ascending order (selection instead
+// of a sort buffer: same intervals, same order of additions as a00_msc_contrib)
+__device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau)
+{
+  const Tree & t = S.tr;
+  const int n = 2*t.tips - 1;
+  double logpr = 0;
+  for (int p = 0; p < sp.npop; ++p) S.nin[p] = 0;
+  for (int k = 0; k < t.tips; ++k) S.nin[t.pop[k]]++;
+  for (int p = 0; p < sp.npop; ++p)
+  {
+    if (p >= sp.S) S.nin[p] = (int8_t)((S.nin[sp.left[p]] - S.nc[sp.left[p]]) + (S.nin[sp.right[p]] - S.nc[sp.right[p]]));
+    uint32_t mask = 0;
+    for (int k = t.tips; k < n; ++k) if (t.pop[k] == p) mask |= 1u << k;
+    const int ncoal = __popc(mask), nin = S.nin[p];
+    S.nc[p] = (int8_t)ncoal;
+    const double ptau = sp.parent[p] >= 0 ? tau[sp.parent[p]] : -1.0;
+    int steps = ncoal + (ptau >= 0 ? 1 : 0);
+    if (nin == steps) --steps;
+    double T2h = 0, prev = tau[p];
+    int nn = nin;
+    for (int k = 0; k < steps; ++k, --nn)
+    {
+      double tk = ptau;
+      if (k < ncoal)
+      {
+        int best = -1;
+        for (uint32_t m = mask; m; m &= m - 1) { const int x = __ffs(m) - 1; if (best < 0 || t.time[x] < t.time[best]) best = x; }
+        tk = t.time[best]; mask &= ~(1u << best);
+      }
+      T2h += nn*(nn - 1)*(tk - prev);
+      prev = tk;
+    }
+    double c = 0;
+    if (ncoal) c += ncoal*sp.log2theta[p];
+    if (T2h) c -= T2h/(sp.theta[p]*1.0);
+    logpr += c;
+  }
+  return logpr;
 }
 
 // install a proposal: toggle buffers, fresh (a,b) of the changed branches (mask brm), node-update
@@ -160,8 +242,8 @@ __device__ void install(TaskLDS & S, uint32_t brm, uint32_t ndm, double rate)
   S.nops = nn;
 }
 
-// GAGE on the k-th inner node (gage_step of a00_driver.c)
-__device__ bool propose_gage(TaskLDS & S, int k, double rate)
+// GAGE on the k-th inner node (gage_step of a00_driver.c; propose_ages, gtree.c:4585)
+__device__ bool propose_gage(TaskLDS & S, int k, double rate, const Species & sp, const double * tau)
 {
   Tree & t = S.tr;
   const int n = 2*t.tips - 1;
@@ -169,19 +251,24 @@ __device__ bool propose_gage(TaskLDS & S, int k, double rate)
   for (int j = 0; j < n; ++j) if (t.left[j] >= 0 && c++ == k) { v = j; break; }
   if (v < 0) return false;
   const double u = rndu(&t.rng);
-  const double lo = fmax(t.time[t.left[v]], t.time[t.right[v]]);
-  const int p = t.parent[v];
+  const int l = t.left[v], r = t.right[v], p = t.parent[v];
+  double lo = fmax(t.time[l], t.time[r]);
+  if (t.pop[l] != t.pop[r]) lo = fmax(lo, tau[lca_pop(sp, t.pop[l], t.pop[r])]);
+  const double hi = p >= 0 ? t.time[p] : 999.0;
+  if (!(hi > lo)) { (void)rndu(&t.rng); return false; }
+  const double tnew = reflect(t.time[v] + sp.ft_gage*(u - 0.5), lo, hi);
+  t.time[v] = tnew;
+  t.pop[v] = (int8_t)climb(sp, tau, t.pop[l], tnew);
   S.hast = 0;
-  if (p >= 0) t.time[v] = lo + (0.02 + 0.96*u)*(t.time[p] - lo);
-  else { const double c_ = exp(0.6*(u - 0.5)); t.time[v] = lo + (t.time[v] - lo)*c_; S.hast = log(c_); }
-  uint32_t brm = (1u << t.left[v]) | (1u << t.right[v]);
+  S.logpr_new = tree_logpr(S, sp, tau);
+  uint32_t brm = (1u << l) | (1u << r);
   if (p >= 0) brm |= 1u << v;
   install(S, brm, path_mask(t, v), rate);
   return true;
 }
 
-// GSPR on the k-th non-root node (gspr_step of a00_driver.c)
-__device__ bool propose_gspr(TaskLDS & S, int k, double rate)
+// GSPR on the k-th non-root node (gspr_step of a00_driver.c; propose_spr, gtree.c:6531)
+__device__ bool propose_gspr(TaskLDS & S, int k, double rate, const Species & sp, const double * tau)
 {
   Tree & t = S.tr;
   const int n = 2*t.tips - 1;
@@ -191,30 +278,38 @@ __device__ bool propose_gspr(TaskLDS & S, int k, double rate)
   const double u1 = rndu(&t.rng), u2 = rndu(&t.rng);
   const int root_before = t.root;
   const int p = t.parent[a], s = t.left[p] == a ? t.right[p] : t.left[p], g = t.parent[p];
+  // youngest population from a's upwards that holds gene tips outside a's subtree
+  const int leaves = __popc(subtree_mask(t, a) & ((1u << t.tips) - 1u));
+  int pop0 = t.pop[a];
+  while (S.gl[pop0] <= leaves && sp.parent[pop0] >= 0) pop0 = sp.parent[pop0];
+  const double lo = fmax(t.time[a], tau[pop0]);
+  const double tnew = reflect(t.time[p] + sp.ft_gspr*(u1 - 0.5), lo, 999.0);
+  const int popt = climb(sp, tau, t.pop[a], tnew);
+  // targets (bit j = branch above node j; the father's own branch stands for the sibling's) and sources
+  uint32_t tmask = 0; int nsrc = 1;
+  if (tnew >= t.time[t.root]) tmask = 1u << t.root;
+  else
+    for (int j = 0; j < n; ++j)
+      if (j != a && j != t.root && t.time[j] <= tnew && t.time[t.parent[j]] > tnew && ((sp.anc[t.pop[j]] >> popt) & 1u))
+        tmask |= 1u << j;
+  if (p != t.root)
+  {
+    const double tp = t.time[p]; const int pp = t.pop[p];
+    for (int j = 0; j < n; ++j)
+      if (j != a && j != t.root && j != s && j != p && t.time[j] <= tp && t.time[t.parent[j]] > tp && ((sp.anc[t.pop[j]] >> pp) & 1u))
+        ++nsrc;
+  }
+  const int ntg = __popc(tmask);
+  if (!ntg) { (void)rndu(&t.rng); return false; }
+  int pick = (int)(u2*ntg) % ntg, tgt = -1;
+  for (uint32_t m = tmask; m; m &= m - 1) if (pick-- == 0) { tgt = __ffs(m) - 1; break; }
+  if (tgt == p) tgt = s;
+  // prune: the sibling takes p's place; regraft p (with a below it) above tgt at tnew in popt
   t.parent[s] = (int8_t)g;
   if (g >= 0) { if (t.left[g] == p) t.left[g] = (int8_t)s; else t.right[g] = (int8_t)s; } else t.root = s;
-  // regraft targets: every node outside a's subtree, except p
-  uint32_t banned = (1u << a) | (1u << p);
-  for (int pass = 0; pass < n; ++pass)
-  {
-    uint32_t add = 0;
-    for (uint32_t m = banned & ~(1u << p); m; m &= m - 1)
-    {
-      const int x = __ffs(m) - 1;
-      if (t.left[x] >= 0) add |= (1u << t.left[x]) | (1u << t.right[x]);
-    }
-    if (!(add & ~banned)) break;
-    banned |= add;
-  }
-  const uint32_t allowed = ~banned & ((1u << n) - 1u);
-  const int ntg = __popc(allowed);
-  int pick = (int)(u1*ntg) % ntg, tgt = -1;
-  for (uint32_t m = allowed; m; m &= m - 1) if (pick-- == 0) { tgt = __ffs(m) - 1; break; }
-  int pc = t.parent[tgt];
-  double lo = fmax(t.time[a], t.time[tgt]);
-  if (pc >= 0 && t.time[pc] <= lo) { tgt = s; pc = t.parent[s]; lo = fmax(t.time[a], t.time[tgt]); }
-  const double tnew = pc >= 0 ? lo + (0.02 + 0.96*u2)*(t.time[pc] - lo) : lo + (0.1 + u2)*fmax(lo, 1e-4)*0.5;
-  t.time[p] = tnew; t.left[p] = (int8_t)a; t.right[p] = (int8_t)tgt; t.parent[a] = (int8_t)p; t.parent[tgt] = (int8_t)p;
+  const int pc = t.parent[tgt];
+  t.time[p] = tnew; t.pop[p] = (int8_t)popt;
+  t.left[p] = (int8_t)a; t.right[p] = (int8_t)tgt; t.parent[a] = (int8_t)p; t.parent[tgt] = (int8_t)p;
   t.parent[p] = (int8_t)pc;
   if (pc >= 0) { if (t.left[pc] == tgt) t.left[pc] = (int8_t)p; else t.right[pc] = (int8_t)p; } else t.root = p;
   uint32_t ndm = path_mask(t, p);
@@ -232,7 +327,8 @@ __device__ bool propose_gspr(TaskLDS & S, int k, double rate)
   }
   uint32_t brm = 0;
   for (uint32_t m = bset; m; m &= m - 1) { const int x = __ffs(m) - 1; if (t.parent[x] >= 0) brm |= 1u << x; }
-  S.hast = 0;
+  S.hast = log((double)ntg/(double)nsrc);
+  S.logpr_new = tree_logpr(S, sp, tau);
   install(S, brm, ndm, rate);
   return true;
 }
@@ -242,6 +338,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   __shared__ TaskLDS s_task[TPB];
   __shared__ double  s_clv[MAXBUF][BS][4];
   __shared__ double  s_term[BS];
+  __shared__ double  s_tau[MAXPOP];
   const uint32_t b = blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
   const uint32_t t0 = A.blk_task_off[b], ntask = A.blk_task_off[b+1] - t0;
   const uint32_t task = A.lane_task[gl];
@@ -249,11 +346,13 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   const uint32_t ts = active ? task - t0 : 0u;
   const bool leader = active && gl == A.task_lane0[task];
   const bool restore_mix = A.epoch != 0 && *A.mix_flag == A.epoch;      // epoch 0: nothing pending
+  const Species & sp = A.sp;
 
-  // ---- load: tree (or its pre-mix snapshot), (a,b) table, this lane's CLV buffers and constants
+  // ---- load: tree (or its pre-step snapshot), (a,b) table, this lane's CLV buffers and constants
   uint32_t np = 0, tips = 0, n = 0, tipcodes = 0, wgt = 0;
   double f0 = 0, f1 = 0, f2 = 0, f3 = 0, rw = 0, rate = 1;
   double * g_clv = nullptr, * g_pmat = nullptr;
+  if (lane < (uint32_t)MAXPOP) s_tau[lane] = lane < (uint32_t)sp.npop ? A.taus[lane] : 0.0;
   if (active)
   {
     const LocusDev & L = A.loci[A.task_locus[task]];
@@ -282,12 +381,31 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       reinterpret_cast<uint4 *>(&s_task[i/U].tr)[i % U] = reinterpret_cast<const uint4 *>(src + i/U)[i % U];
   }
   __syncthreads();
+  // the proposed species tree of an all-loci step is this workgroup's copy of the taus
+  double lminf = 0, lmaxf = 0, tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1;
+  if (A.mode == 4)
+  {
+    const int q = (int)A.tau_q, pq = sp.parent[q];
+    tq_old = s_tau[q]; tq_lo = fmax(s_tau[sp.left[q]], s_tau[sp.right[q]]); tq_hi = pq >= 0 ? s_tau[pq] : 999.0;
+    const double tnew = reflect(tq_old + sp.ft_tau*(A.tau_u - 0.5), tq_lo, tq_hi);
+    minf = (tnew - tq_lo)/(tq_old - tq_lo); maxf = (tnew - tq_hi)/(tq_old - tq_hi);
+    lminf = log(minf); lmaxf = log(maxf);
+    __syncthreads();
+    if (lane == 0) s_tau[q] = tnew;
+  }
+  else if (A.mode == 1)
+  {
+    __syncthreads();
+    if (lane < (uint32_t)sp.npop) s_tau[lane] *= A.mix_c;
+  }
   if (leader)
   {
     TaskLDS & S = s_task[ts];
     if (restore_mix) { S.tr.rng = A.trees[task].rng; S.tr.proposals = A.trees[task].proposals; S.tr.accepted = A.trees[task].accepted; }
     const uint32_t npm = 2*(2*tips - 2);
     for (uint32_t i = 0; i < npm; ++i) { S.ab[i][0] = g_pmat[2*i]; S.ab[i][1] = g_pmat[2*i+1]; }
+    for (int p = 0; p < sp.npop; ++p) S.gl[p] = 0;
+    for (uint32_t k = 0; k < tips; ++k) for (int q = S.tr.pop[k]; q >= 0; q = sp.parent[q]) S.gl[q]++;
     S.nops = 0; S.active = 0;
   }
   __syncthreads();
@@ -307,32 +425,29 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     {
       TaskLDS & S = s_task[ts];
       bool ok;
-      if (A.mode == 0) ok = step < A.nsteps_gage ? propose_gage(S, (int)step, rate) : propose_gspr(S, (int)(step - A.nsteps_gage), rate);
+      if (A.mode == 0)
+        ok = step < A.nsteps_gage ? propose_gage(S, (int)step, rate, sp, s_tau) : propose_gspr(S, (int)(step - A.nsteps_gage), rate, sp, s_tau);
       else if (A.mode == 4)
       {
-        // TAU j (tau_step of a00_driver.c): rubber band around tau_j, dirty branches and root paths
+        // TAU q (tau_step of a00_driver.c): the gene nodes of q and its children between the bounds move
         Tree & t = S.tr;
-        const int nn_ = 2*t.tips - 1;
+        const int nn_ = 2*t.tips - 1, q = (int)A.tau_q, cl = sp.left[q], cr = sp.right[q];
         A.snap[task] = t;
-        const uint32_t j = A.tau_j;
-        const double tau = A.taus[j], lo = j ? A.taus[j-1] : 0.0, hi = j + 1 < A.ntaus ? A.taus[j+1] : -1.0;
-        const double tnew = tau_proposal(A.tau_u, lo, tau, hi);
-        uint32_t brm = 0, ndm = 0;
-        for (int k = 0; k < nn_; ++k)
-          if (t.left[k] >= 0)
-          {
-            const double tn = rubber_band(t.time[k], lo, tau, tnew, hi);
-            if (tn != t.time[k])
-            {
-              t.time[k] = tn;
-              brm |= (1u << t.left[k]) | (1u << t.right[k]);
-              if (t.parent[k] >= 0) brm |= 1u << k;
-              ndm |= path_mask(t, k);
-            }
-          }
-        S.hast = 0;
+        uint32_t brm = 0, ndm = 0; int above = 0, below = 0;
+        for (int k = t.tips; k < nn_; ++k)
+        {
+          const int pk = t.pop[k]; const double tk = t.time[k];
+          if ((pk != q && pk != cl && pk != cr) || tk < tq_lo || tk > tq_hi) continue;
+          if (tk >= tq_old) { t.time[k] = tq_hi + maxf*(tk - tq_hi); ++above; } else { t.time[k] = tq_lo + minf*(tk - tq_lo); ++below; }
+          brm |= (1u << t.left[k]) | (1u << t.right[k]);
+          if (t.parent[k] >= 0) brm |= 1u << k;
+          ndm |= path_mask(t, k);
+        }
+        S.logpr_new = tree_logpr(S, sp, s_tau);
+        S.hast = (S.logpr_new - t.logpr) + below*lminf + above*lmaxf;      // p_delta of the host driver
         ok = ndm != 0;
-        if (ok) install(S, brm, ndm, rate); else A.mix_delta[task] = 0.0;
+        if (ok) install(S, brm, ndm, rate);
+        else { A.mix_delta[task] = S.hast; t.logpr = S.logpr_new; }
       }
       else
       {
@@ -340,10 +455,10 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
         Tree & t = S.tr;
         const int nn_ = 2*t.tips - 1;
         if (A.mode == 1) A.snap[task] = t;
-        uint32_t brm = 0, ndm = 0;
+        uint32_t brm = 0, ndm = 0; int ninner = 0;
         for (int k = 0; k < nn_; ++k)
         {
-          if (t.left[k] >= 0) { if (A.mode == 1) t.time[k] *= A.mix_c; ndm |= 1u << k; }
+          if (t.left[k] >= 0) { if (A.mode == 1) t.time[k] *= A.mix_c; ndm |= 1u << k; ++ninner; }
           if (t.parent[k] >= 0) brm |= 1u << k;
         }
         if (A.mode == 3)
@@ -351,7 +466,8 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
           for (uint32_t m = brm; m; m &= m - 1) swap_pmat(t, __ffs(m) - 1);       // start-up evaluates in place:
           for (uint32_t m = ndm; m; m &= m - 1) swap_clv(t, __ffs(m) - 1);        // toggle twice = no toggle
         }
-        S.hast = 0;
+        S.logpr_new = tree_logpr(S, sp, s_tau);
+        S.hast = A.mode == 1 ? (S.logpr_new - t.logpr) + (double)ninner*A.mix_lnc : 0.0;
         install(S, brm, ndm, rate);
         ok = true;
       }
@@ -389,25 +505,26 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       TaskLDS & S = s_task[ts];
       double lnl = 0;
       for (uint32_t q = 0; q < np; ++q) lnl += s_term[lane + q];
+      lnl = A.bfbeta == 1.0 ? lnl : A.bfbeta == 0.0 ? 0.0 : A.bfbeta*lnl;
       if (A.mode == 0)
       {
-        const double lnacc = lnl - S.tr.lnl + S.hast;
+        const double lnacc = (S.logpr_new - S.tr.logpr) + (lnl - S.tr.lnl) + S.hast;
         const double u = rndu(&S.tr.rng);
         S.tr.proposals++;
-        if (lnacc >= 0 || u < exp(lnacc)) { S.tr.lnl = lnl; S.tr.accepted++; S.active = 1; }
+        if (lnacc >= 0 || u < exp(lnacc)) { S.tr.lnl = lnl; S.tr.logpr = S.logpr_new; S.tr.accepted++; S.active = 1; }
         else S.active = 2;                               // rejected: restore below
       }
       else
       {
-        A.mix_delta[task] = A.mode == 3 ? 0.0 : lnl - S.tr.lnl;
-        S.tr.lnl = lnl;
+        A.mix_delta[task] = A.mode == 3 ? 0.0 : (lnl - S.tr.lnl) + S.hast;
+        S.tr.lnl = lnl; S.tr.logpr = S.logpr_new;
       }
     }
     __syncthreads();
-    // ---- rejected proposals: topology, ages and buffer indices come back from the undo copy (all lanes)
+    // ---- rejected proposals: topology, ages, populations and buffer indices come back from the undo copy (all lanes)
     if (A.mode == 0)
     {
-      constexpr uint32_t U = (uint32_t)(offsetof(Tree, lnl)/16);      // everything before lnl/rng/counters
+      constexpr uint32_t U = (uint32_t)(offsetof(Tree, lnl)/16);      // everything before lnl/logpr/rng/counters
       for (uint32_t i = lane; i < ntask*U; i += BS)
         if (s_task[i/U].active == 2)
           reinterpret_cast<uint4 *>(&s_task[i/U].tr)[i % U] = reinterpret_cast<const uint4 *>(&s_task[i/U].undo)[i % U];
@@ -441,24 +558,33 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   }
 }
 
-// the single decision of an all-loci step (prop_mixing.c:203-205, stree.c:6280): flag := epoch when
-// REJECTED; on acceptance the species-tree times follow (mix: all times c; tau j: the proposed value)
-__global__ void decide_kernel(const double * __restrict__ sum, double lnc, double ninner, double u,
-                              uint32_t epoch, uint32_t * flag, uint32_t * counters,
-                              double * taus, uint32_t ntaus, int tau_j, double tau_u, double mix_c)
+// the single decision of an all-loci step (tau_step / mix_step of a00_driver.c; stree.c:6280,
+// prop_mixing.c:203-205): flag := epoch when REJECTED; on acceptance the device-resident taus follow
+__global__ void decide_kernel(const double * __restrict__ sum, double u, uint32_t epoch, uint32_t * flag,
+                              uint32_t * counters, double * taus, Species sp, int tau_q, double tau_u,
+                              double mix_c, double mix_lnc)
 {
   if (threadIdx.x || blockIdx.x) return;
-  const double lnacc = sum[0] + ninner*lnc;
+  double lnacc = sum[0], tnew = 0;
+  const int root = sp.npop - 1;
+  if (tau_q >= 0)
+  {
+    const int pq = sp.parent[tau_q];
+    const double old = taus[tau_q], lo = fmax(taus[sp.left[tau_q]], taus[sp.right[tau_q]]), hi = pq >= 0 ? taus[pq] : 999.0;
+    tnew = reflect(old + sp.ft_tau*(tau_u - 0.5), lo, hi);
+    if (pq < 0 && sp.tau_alpha > 0) lnacc += (sp.tau_alpha - 1 - (sp.S - 1) + 1)*log(tnew/old) - sp.tau_beta*(tnew - old);
+  }
+  else
+  {
+    lnacc += (double)(sp.S - 1)*mix_lnc;
+    if (sp.tau_alpha > 0)
+      lnacc += (sp.tau_alpha - 1)*mix_lnc - sp.tau_beta*(taus[root]*mix_c - taus[root]) - (double)(sp.S - 2)*mix_lnc;
+  }
   const bool accept = lnacc >= 0 || u < exp(lnacc);
   counters[0] += 1; counters[1] += accept ? 1u : 0u;
   if (!accept) { *flag = epoch; return; }
-  if (tau_j < 0) { for (uint32_t i = 0; i < ntaus; ++i) taus[i] *= mix_c; }
-  else
-  {
-    const uint32_t j = (uint32_t)tau_j;
-    const double tau = taus[j], lo = j ? taus[j-1] : 0.0, hi = j + 1 < ntaus ? taus[j+1] : -1.0;
-    taus[j] = tau_proposal(tau_u, lo, tau, hi);
-  }
+  if (tau_q >= 0) taus[tau_q] = tnew;
+  else for (int p = 0; p < sp.npop; ++p) taus[p] *= mix_c;
 }
 
 } // namespace smp
@@ -472,13 +598,13 @@ struct bpa_sampler
   DevBuf<uint32_t> task_locus, blk_task_off, lane_task, task_lane0, flag, counters;
   DevBuf<smp::Tree> trees, snap;
   DevBuf<double> mix_delta, mix_sum, taus;
+  smp::Species sp{};                    // species tree (host copy; the taus below are only the start values)
   std::vector<double> h_taus;
   std::vector<smp::Tree> h_trees;
   unsigned nblocks = 0, epoch = 0;
   bool mix_pending = false;             // a mixing decision taken on the device has not been applied yet
   a00_rng_t grng = 0;
   unsigned long seed = 0, launches = 0;
-  double ninner_total = 0;
   bool uploaded = false;
 };
 
@@ -505,6 +631,7 @@ extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * co
     s->maxtips = std::max(s->maxtips, l->tips);
   }
   s->h_trees.assign(nloci, smp::Tree{});
+  s->sp.ft_gage = 0.004; s->sp.ft_gspr = 0.004; s->sp.ft_tau = 0.001; s->sp.ft_mix = 0.3;      // a00_create's defaults
   return s;
 }
 
@@ -526,7 +653,7 @@ extern "C" int bpa_sampler_set_tree(bpa_sampler_t * s, unsigned i, const int * l
   const int tips = (int)s->loci[i]->tips, n = 2*tips - 1;
   smp::Tree & t = s->h_trees[i];
   std::memset(&t, 0, sizeof(t));
-  for (int k = 0; k < smp::MAXN; ++k) { t.left[k] = t.right[k] = t.parent[k] = -1; t.clv[k] = t.pmat[k] = (int8_t)k; }
+  for (int k = 0; k < smp::MAXN; ++k) { t.left[k] = t.right[k] = t.parent[k] = -1; t.clv[k] = t.pmat[k] = (int8_t)k; t.pop[k] = (int8_t)(k < tips ? k : -1); }
   for (int k = 0; k < n; ++k)
   {
     t.left[k] = (int8_t)left[k]; t.right[k] = (int8_t)right[k]; t.time[k] = times[k];
@@ -543,15 +670,32 @@ static int sampler_upload(bpa_sampler * s)
   if (s->uploaded) return 1;
   if (!set_device(e) || !flush(e)) return 0;
   const unsigned T = s->nloci;
+  if (!s->sp.npop) return fail("bpa_sampler: set the species tree first (bpa_sampler_set_species_tree)");
+  // populations of the inner nodes (assign_pops of a00_driver.c): common population of the children, then up to the age
+  for (unsigned i = 0; i < T; ++i)
+  {
+    smp::Tree & t = s->h_trees[i];
+    const int n = 2*t.tips - 1;
+    std::vector<int> order;
+    for (int k = t.tips; k < n; ++k) order.push_back(k);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return t.time[a] < t.time[b]; });
+    for (int k = 0; k < t.tips; ++k) if (t.pop[k] < 0 || t.pop[k] >= s->sp.S) return fail("bpa_sampler: tip species out of range");
+    for (int v : order)
+    {
+      int c = t.pop[t.left[v]];
+      while (!((s->sp.anc[t.pop[t.right[v]]] >> c) & 1u)) c = s->sp.parent[c];
+      if (t.time[v] < s->h_taus[c]) return fail("bpa_sampler: a gene-tree node is younger than the divergence of its descendants' species");
+      while (s->sp.parent[c] >= 0 && s->h_taus[s->sp.parent[c]] <= t.time[v]) c = s->sp.parent[c];
+      t.pop[v] = (int8_t)c;
+    }
+  }
   std::vector<uint32_t> locus(T), blk_off{0}, lane_task, lane0(T);
   unsigned used = 0, ntask = 0;
-  s->ninner_total = 0;
   for (unsigned t = 0; t < T; ++t)
   {
     const unsigned np = s->loci[t]->sites;
     locus[t] = s->loci[t]->id;
-    s->ninner_total += s->loci[t]->tips - 1;
-    if (used + np > (unsigned)smp::BS || ntask == (unsigned)smp::TPB)
+        if (used + np > (unsigned)smp::BS || ntask == (unsigned)smp::TPB)
     { lane_task.resize(blk_off.size()*smp::BS, 0xffffffffu); blk_off.push_back(t); used = 0; ntask = 0; }
     lane0[t] = (uint32_t)((blk_off.size() - 1)*smp::BS + used);
     for (unsigned n = 0; n < np; ++n) lane_task.push_back(t);
@@ -565,14 +709,14 @@ static int sampler_upload(bpa_sampler * s)
       !upload(s->lane_task, lane_task.data(), lane_task.size()) || !upload(s->task_lane0, lane0.data(), T) ||
       !upload(s->trees, s->h_trees.data(), T) || !upload(s->snap, s->h_trees.data(), T) ||
       !upload(s->flag, zero2, 1) || !upload(s->counters, zero2, 2) || !s->mix_delta.reserve(T) || !s->mix_sum.reserve(1) ||
-      !s->taus.reserve(8) || (!s->h_taus.empty() && !upload(s->taus, s->h_taus.data(), s->h_taus.size())))
+      !upload(s->taus, s->h_taus.data(), s->h_taus.size()))
     return 0;
   s->epoch = 0; s->mix_pending = false;
   s->uploaded = true;
   return 1;
 }
 
-static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, unsigned tau_j = 0, double tau_u = 0)
+static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double mix_lnc = 0, unsigned tau_q = 0, double tau_u = 0)
 {
   bpa_engine * e = s->eng;
   smp::Args a{};
@@ -583,7 +727,8 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, unsigned
   // rejection); every other launch passes epoch 0 = nothing pending
   a.epoch = s->mix_pending ? s->epoch : 0u;
   s->mix_pending = false;
-  a.taus = s->taus.p; a.ntaus = (uint32_t)s->h_taus.size(); a.tau_j = tau_j; a.tau_u = tau_u;
+  a.bfbeta = e->usedata ? e->bfbeta : 0.0;
+  a.taus = s->taus.p; a.tau_q = tau_q; a.tau_u = tau_u; a.sp = s->sp; a.mix_lnc = mix_lnc;
   a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2; a.mix_c = mix_c;
   if (const char * dbg = getenv("BPA_SMP_STEPS")) { unsigned g = 0, q = 0; if (sscanf(dbg, "%u,%u", &g, &q) == 2) { a.nsteps_gage = g; a.nsteps_gspr = q; } }
   if (getenv("BPA_SMP_TRACE"))
@@ -603,24 +748,67 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, unsigned
   return 1;
 }
 
-extern "C" int bpa_sampler_set_taus(bpa_sampler_t * s, const double * taus, unsigned n)
+extern "C" int bpa_sampler_set_species_tree(bpa_sampler_t * s, int species, const int * parent, const double * tau,
+                                            const double * theta)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
-  if (n > 8) return fail("bpa_sampler_set_taus: at most 8 divergence times");
-  s->h_taus.assign(taus, taus + n);
+  const int np = 2*species - 1;
+  if (species < 1 || species > smp::MAXTIPS) return fail("bpa_sampler_set_species_tree: 1..8 species");
+  smp::Species & sp = s->sp;
+  for (int p = 0; p < np; ++p)
+  {
+    const bool okp = p == np - 1 ? parent[p] == -1 : (parent[p] > p && parent[p] < np && parent[p] >= species);
+    const bool okt = theta[p] > 0 && (p < species ? tau[p] == 0 : tau[p] > 0) && (parent[p] < 0 || !okp || tau[parent[p]] > tau[p]);
+    if (!okp || !okt) return fail("bpa_sampler_set_species_tree: populations must come tips first, children before parents, "
+                                  "with theta > 0 and tau increasing towards the root");
+  }
+  sp.S = species; sp.npop = np;
+  for (int p = 0; p < smp::MAXPOP; ++p) { sp.parent[p] = sp.left[p] = sp.right[p] = -1; sp.anc[p] = 0; sp.theta[p] = 1; sp.log2theta[p] = 0; }
+  s->h_taus.assign(smp::MAXPOP, 0.0);
+  for (int p = 0; p < np; ++p)
+  {
+    sp.parent[p] = (int8_t)parent[p]; sp.theta[p] = theta[p]; sp.log2theta[p] = std::log(2.0/(1.0*theta[p]));
+    s->h_taus[p] = tau[p];
+  }
+  for (int p = 0; p < np - 1; ++p)
+  {
+    const int q = parent[p];
+    if (sp.left[q] < 0) sp.left[q] = (int8_t)p; else if (sp.right[q] < 0) sp.right[q] = (int8_t)p;
+    else return fail("bpa_sampler_set_species_tree: a population has more than two children");
+  }
+  for (int p = species; p < np; ++p) if (sp.right[p] < 0) return fail("bpa_sampler_set_species_tree: an inner population needs two children");
+  for (int p = 0; p < np; ++p) for (int q = p; q >= 0; q = parent[q]) sp.anc[p] |= (uint16_t)(1u << q);
   s->uploaded = false;
   return 1;
 }
+
+extern "C" int bpa_sampler_set_tip_species(bpa_sampler_t * s, unsigned i, const int * species)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (i >= s->nloci) return fail("bpa_sampler_set_tip_species: locus index out of range");
+  smp::Tree & t = s->h_trees[i];
+  if (!t.tips) return fail("bpa_sampler_set_tip_species: set the tree first");
+  for (int k = 0; k < t.tips; ++k) t.pop[k] = (int8_t)species[k];
+  s->uploaded = false;
+  return 1;
+}
+
+extern "C" void bpa_sampler_set_finetune(bpa_sampler_t * s, double gage, double gspr, double tau, double mix)
+{ s->sp.ft_gage = gage; s->sp.ft_gspr = gspr; s->sp.ft_tau = tau; s->sp.ft_mix = mix; }
+
+extern "C" void bpa_sampler_set_tau_prior(bpa_sampler_t * s, double alpha, double beta)
+{ s->sp.tau_alpha = alpha; s->sp.tau_beta = beta; }
 
 extern "C" int bpa_sampler_get_taus(bpa_sampler_t * s, double * taus)
 {
   bpa_engine * e = s->eng;
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   if (!set_device(e)) return 0;
-  if (s->h_taus.empty() || !s->uploaded) { for (size_t i = 0; i < s->h_taus.size(); ++i) taus[i] = s->h_taus[i]; return 1; }
+  const size_t np = (size_t)s->sp.npop;
+  if (!s->uploaded) { for (size_t i = 0; i < np; ++i) taus[i] = s->h_taus[i]; return (int)np; }
   HIPCHK(hipStreamSynchronize(e->stream));
-  HIPCHK(hipMemcpy(taus, s->taus.p, s->h_taus.size()*sizeof(double), hipMemcpyDeviceToHost));
-  return 1;
+  HIPCHK(hipMemcpy(taus, s->taus.p, np*sizeof(double), hipMemcpyDeviceToHost));
+  return (int)np;
 }
 
 extern "C" int bpa_sampler_initialize(bpa_sampler_t * s)
@@ -639,24 +827,24 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
   {
     if (!sampler_launch(s, 0, 1.0)) return 0;                    // GAGE + GSPR of every locus (settles a pending mix first)
     if (getenv("BPA_SMP_NOMIX")) continue;
-    for (unsigned j = 0; j < s->h_taus.size(); ++j)               // one rubber-band step per species divergence
+    for (int q = s->sp.S; q < s->sp.npop; ++q)                    // one rubber-band step per species divergence
     {
       const double uprop = a00_rndu(&s->grng), uacc_t = a00_rndu(&s->grng);
-      if (!sampler_launch(s, 4, 1.0, j, uprop)) return 0;
+      if (!sampler_launch(s, 4, 1.0, 0.0, (unsigned)q, uprop)) return 0;
       hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, s->mix_sum.p);
       s->epoch++;
-      hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, 0.0, 0.0, uacc_t,
-                         s->epoch, s->flag.p, s->counters.p, s->taus.p, (uint32_t)s->h_taus.size(), (int)j, uprop, 1.0);
+      hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, uacc_t, s->epoch, s->flag.p,
+                         s->counters.p, s->taus.p, s->sp, q, uprop, 1.0, 0.0);
       HIPCHK(hipGetLastError());
       s->mix_pending = true;
     }
-    const double lnc = 0.1*(a00_rndu(&s->grng) - 0.5), c = std::exp(lnc);
+    const double lnc = s->sp.ft_mix*(a00_rndu(&s->grng) - 0.5), c = std::exp(lnc);
     const double uacc = a00_rndu(&s->grng);
-    if (!sampler_launch(s, 1, c)) return 0;                      // mixing proposal of every locus
+    if (!sampler_launch(s, 1, c, lnc)) return 0;                 // mixing proposal of every locus
     hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, s->mix_sum.p);
     s->epoch++;
-    hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, lnc, s->ninner_total, uacc,
-                       s->epoch, s->flag.p, s->counters.p, s->taus.p, (uint32_t)s->h_taus.size(), -1, 0.0, c);
+    hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, uacc, s->epoch, s->flag.p,
+                       s->counters.p, s->taus.p, s->sp, -1, 0.0, c, lnc);
     HIPCHK(hipGetLastError());
     s->mix_pending = true;
   }
@@ -689,6 +877,17 @@ extern "C" int bpa_sampler_get_tree(bpa_sampler_t * s, unsigned i, int * left, i
   }
   if (root) *root = t.root;
   if (lnl) *lnl = t.lnl;
+  return 1;
+}
+
+extern "C" int bpa_sampler_get_tree_msc(bpa_sampler_t * s, unsigned i, int * pop, double * logpr)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (i >= s->nloci) return fail("bpa_sampler_get_tree_msc: locus index out of range");
+  if (i == 0 || !s->uploaded) { if (!sampler_download(s)) return 0; }
+  const smp::Tree & t = s->h_trees[i];
+  if (pop) for (int k = 0; k < 2*t.tips - 1; ++k) pop[k] = t.pop[k];
+  if (logpr) *logpr = t.logpr;
   return 1;
 }
 

@@ -204,27 +204,35 @@ int          bpa_plan_get_sum(bpa_plan_t *, double * sum);
 int          bpa_batch_evaluate(bpa_engine_t *, const bpa_batch_t *, double * lnl);
 
 /* ------------------------------------- device-resident proposal control (next) --- */
-/* The per-locus proposals of an iteration (gene-node ages, gtree.c:4585; prune/regraft,
-   gtree.c:6531) and the all-loci mixing step (prop_mixing.c:52) with the gene trees, their
-   buffer-index bookkeeping, the random streams and the accept/reject decisions resident on
-   the device: the state machine of include/bpp_amd_host.h (same arithmetic, same streams,
-   same trajectory) without a host round trip per proposal.  Round-1 scope: JC69, one rate
-   category, no scalers, <= 8 tips, <= 64 patterns per locus.  Trees use the node numbering of
-   a00_tree_t (tips first; arrays of 2*tips-1 entries).                                      */
+/* The multispecies-coalescent sampler of include/bpp_amd_host.h with everything resident on the
+   device: the per-locus proposals of an iteration (gene-node ages, gtree.c:4585; prune/regraft,
+   gtree.c:6531), the all-loci steps (tau with its rubber band, stree.c:5512; mixing,
+   prop_mixing.c:52), the MSC density (gtree_logprob, gtree.c:3957), the gene trees with their
+   populations and buffer-index bookkeeping, the random streams and the accept/reject decisions:
+   same arithmetic, same streams, same trajectory as the host driver, without a host round trip per
+   proposal.  Round-1 scope: JC69, one rate category, no scalers, <= 8 tips, <= 8 species, <= 64
+   patterns per locus.  Trees use the node numbering of a00_tree_t (tips first; arrays of 2*tips-1
+   entries); the species tree that of a00_set_species_tree.                                       */
 typedef struct bpa_sampler bpa_sampler_t;
 bpa_sampler_t * bpa_sampler_create(bpa_engine_t *, bpa_locus_t * const * loci, unsigned nloci,
                                    unsigned long seed);
 void bpa_sampler_destroy(bpa_sampler_t *);
 int  bpa_sampler_set_tree(bpa_sampler_t *, unsigned i, const int * left, const int * right,
                           const double * times, int root);
-/* species-tree divergence times (ascending, <= 8) for the TAU rubber-band steps; device-resident */
-int  bpa_sampler_set_taus(bpa_sampler_t *, const double * taus, unsigned n);
-int  bpa_sampler_get_taus(bpa_sampler_t *, double * taus);
+/* the species tree (a00_set_species_tree's arguments: tips first, children before parents; arrays of
+   2*species-1 entries); the taus then live on the device.  Required before initialize.            */
+int  bpa_sampler_set_species_tree(bpa_sampler_t *, int species, const int * parent, const double * tau,
+                                  const double * theta);
+int  bpa_sampler_set_tip_species(bpa_sampler_t *, unsigned i, const int * species);   /* default: tip k = species k */
+void bpa_sampler_set_finetune(bpa_sampler_t *, double gage, double gspr, double tau, double mix);
+void bpa_sampler_set_tau_prior(bpa_sampler_t *, double alpha, double beta);           /* a00_set_tau_prior */
+int  bpa_sampler_get_taus(bpa_sampler_t *, double * tau);     /* 2*species-1 entries; returns their number */
 int  bpa_sampler_initialize(bpa_sampler_t *);                 /* all matrices, partials, lnL */
 int  bpa_sampler_iterate(bpa_sampler_t *, unsigned iterations); /* asynchronous on the engine stream */
 /* current state of locus i (any output may be NULL); asking for locus 0 refreshes the host copy */
 int  bpa_sampler_get_tree(bpa_sampler_t *, unsigned i, int * left, int * right, int * parent,
                           double * times, int * clv, int * pmat, int * root, double * lnl);
+int  bpa_sampler_get_tree_msc(bpa_sampler_t *, unsigned i, int * pop, double * logpr);
 int  bpa_sampler_summary(bpa_sampler_t *, double * total_lnl, unsigned long * proposals,
                          unsigned long * accepted, unsigned long * launches);
 

@@ -24,8 +24,11 @@ def test_sampler_equals_host_driver(taxa, nloci, iters):
     loci_b = tape.make_engine_loci(eng, data)
     host = hostdrv.hip_driver(eng, loci_a, data, seed=23)
     dev = bpp_amd.Sampler(eng, loci_b, data, seed=23)
-    taus = (0.001, 0.002, 0.003) if taxa == 4 else (0.0011, 0.0025, 0.005)
-    host.set_taus(taus); dev.set_taus(taus)
+    parent, tau0, thetas = synth.species_tree_arrays(taxa)
+    for drv in (host, dev):
+        drv.set_species_tree(parent, tau0, thetas)
+        drv.set_tau_prior(3.0, 3.0 / tau0[-1])
+        drv.set_finetune(0.003, 0.005, 0.0008, 0.2)
     host.initialize(); dev.initialize()
     s = dev.summary()
     assert rel(s["total_lnl"], host.total_lnl()) < 1e-13
@@ -35,14 +38,14 @@ def test_sampler_equals_host_driver(taxa, nloci, iters):
         hp, ha, _ = host.counters()
         assert (s["proposals"], s["accepted"]) == (hp, ha), it
         assert rel(s["total_lnl"], host.total_lnl()) < 1e-11, it
-    assert np.allclose(dev.taus(), host.taus(), rtol=1e-12, atol=0) and dev.taus() != list(taus)
+    assert np.allclose(dev.taus(), host.taus(), rtol=1e-12, atol=0) and dev.taus() != list(tau0)
     for i in range(nloci):
         a, b = dev.tree(i), host.tree(i)
         assert a["root"] == b["root"]
-        for key in ("left", "right", "parent", "clv", "pmat"):
+        for key in ("left", "right", "parent", "clv", "pmat", "pop"):
             assert [int(x) for x in a[key]] == [int(x) for x in b[key]], (i, key)
         assert np.allclose(a["time"], b["time"], rtol=1e-12, atol=0)
-        assert rel(a["lnl"], b["lnl"]) < 1e-11
+        assert rel(a["lnl"], b["lnl"]) < 1e-11 and rel(a["logpr"], b["logpr"]) < 1e-11
     # the device state is the state of the explicit-index API: buffers hold what the indices say
     for i in range(0, nloci, max(1, nloci // 10)):
         t = dev.tree(i)
@@ -50,9 +53,37 @@ def test_sampler_equals_host_driver(taxa, nloci, iters):
         have = loci_b[i].root_loglikelihood(int(t["clv"][t["root"]]), -1)
         full = O.OracleLocus(4, 1, d["seqs"], d["weights"]).full_lnl(list(t["left"]), list(t["right"]), list(t["time"]), t["root"])
         assert rel(have, full) < 1e-12 and rel(t["lnl"], full) < 1e-12
+        assert rel(t["logpr"], host.logpr(i)) < 1e-11
     # 4 launches per iteration instead of 3 tips - 2 host round trips
-    assert dev.summary()["launches"] <= 1 + (2 + len(taus)) * iters + 2 * (iters + 2) + nloci
+    assert dev.summary()["launches"] <= 1 + (2 + taxa - 1) * iters + 2 * (iters + 2) + nloci
     host.close(); dev.close(); eng.close()
+
+
+def test_device_sampler_draws_from_the_msc_prior():
+    """usedata = 0 (bpa_engine_set_options: lnL = 0, locus.c:2581): the device sampler's gene trees must
+    follow the multispecies coalescent — node-age moments against direct simulation"""
+    taxa, theta, nloci = 4, 0.002, 2000
+    eng = bpp_amd.Engine(0)
+    data = synth.make_dataset(nloci, 40, taxa, "jc69", 1, seed=3, theta=theta)
+    loci = tape.make_engine_loci(eng, data)
+    eng.set_options(usedata=0, bfbeta=1.0)
+    dev = bpp_amd.Sampler(eng, loci, data, seed=5)
+    dev.set_species_tree(*synth.species_tree_arrays(taxa, theta))
+    dev.set_finetune(4 * theta, 4 * theta, 0.0, 0.0)
+    dev.initialize()
+    dev.iterate(15)
+    ages = []
+    for _ in range(8):
+        dev.iterate(3)
+        ages += [sorted(dev.tree(i)["time"][taxa:]) for i in range(nloci)]
+    ages = np.array(ages)
+    rng = np.random.default_rng(1)
+    sim = np.array([sorted(synth._msc_gene_tree(synth.SPECIES_TREES[taxa], theta, rng)[2][taxa:]) for _ in range(40000)])
+    for j in range(taxa - 1):
+        assert abs(ages[:, j].mean() - sim[:, j].mean()) < 0.04 * sim[:, j].mean(), (j, ages[:, j].mean(), sim[:, j].mean())
+        assert abs(ages[:, j].std() - sim[:, j].std()) < 0.08 * sim[:, j].std(), j
+    eng.set_options(usedata=1, bfbeta=1.0)
+    dev.close(); eng.close()
 
 
 def test_sampler_rejects_unsupported_loci(engine):
