@@ -61,6 +61,9 @@ struct TaskLDS
   int32_t nops, active;
   double hast, logpr_new;
   int8_t nin[MAXPOP], nc[MAXPOP], gl[MAXPOP];     // lineages entering / coalescences / gene tips below, per population
+  int8_t nin_new[MAXPOP], nc_new[MAXPOP];
+  double contrib[MAXPOP], contrib_new[MAXPOP];    // per-population terms of the MSC density: current / proposed
+  uint32_t chain;                                 // populations whose term the proposal changes
 };
 
 struct Args
@@ -164,21 +167,31 @@ __device__ __forceinline__ int climb(const Species & sp, const double * tau, int
 
 // MSC density of the tree in S.tr: tree_logpr of a00_driver.c = gtree_logprob (gtree.c:3957), the
 // populations in order, each one's coalescent times visited in ascending order (selection instead
-// of a sort buffer: same intervals, same order of additions as a00_msc_contrib)
-__device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau)
+// of a sort buffer: same intervals, same order of additions as a00_msc_contrib).  Only the
+// populations in `mask` are recomputed (into the *_new fields); the others keep their term — the
+// terms are pure functions of the tree, so the sum equals the host's from-scratch one bit for bit.
+__device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau, uint32_t mask)
 {
   const Tree & t = S.tr;
   const int n = 2*t.tips - 1;
   double logpr = 0;
-  for (int p = 0; p < sp.npop; ++p) S.nin[p] = 0;
-  for (int k = 0; k < t.tips; ++k) S.nin[t.pop[k]]++;
+  S.chain = mask;
   for (int p = 0; p < sp.npop; ++p)
   {
-    if (p >= sp.S) S.nin[p] = (int8_t)((S.nin[sp.left[p]] - S.nc[sp.left[p]]) + (S.nin[sp.right[p]] - S.nc[sp.right[p]]));
-    uint32_t mask = 0;
-    for (int k = t.tips; k < n; ++k) if (t.pop[k] == p) mask |= 1u << k;
-    const int ncoal = __popc(mask), nin = S.nin[p];
-    S.nc[p] = (int8_t)ncoal;
+    if (!((mask >> p) & 1u)) { logpr += S.contrib[p]; continue; }
+    int nin;
+    if (p >= sp.S)
+    {
+      const int l = sp.left[p], r = sp.right[p];
+      const int nl = ((mask >> l) & 1u) ? S.nin_new[l] - S.nc_new[l] : S.nin[l] - S.nc[l];
+      const int nr = ((mask >> r) & 1u) ? S.nin_new[r] - S.nc_new[r] : S.nin[r] - S.nc[r];
+      nin = nl + nr;
+    }
+    else nin = S.nin[p];                          // gene tips of the species: fixed
+    uint32_t nodes = 0;
+    for (int k = t.tips; k < n; ++k) if (t.pop[k] == p) nodes |= 1u << k;
+    const int ncoal = __popc(nodes);
+    S.nin_new[p] = (int8_t)nin; S.nc_new[p] = (int8_t)ncoal;
     const double ptau = sp.parent[p] >= 0 ? tau[sp.parent[p]] : -1.0;
     int steps = ncoal + (ptau >= 0 ? 1 : 0);
     if (nin == steps) --steps;
@@ -190,8 +203,8 @@ __device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau
       if (k < ncoal)
       {
         int best = -1;
-        for (uint32_t m = mask; m; m &= m - 1) { const int x = __ffs(m) - 1; if (best < 0 || t.time[x] < t.time[best]) best = x; }
-        tk = t.time[best]; mask &= ~(1u << best);
+        for (uint32_t m = nodes; m; m &= m - 1) { const int x = __ffs(m) - 1; if (best < 0 || t.time[x] < t.time[best]) best = x; }
+        tk = t.time[best]; nodes &= ~(1u << best);
       }
       T2h += nn*(nn - 1)*(tk - prev);
       prev = tk;
@@ -199,9 +212,25 @@ __device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau
     double c = 0;
     if (ncoal) c += ncoal*sp.log2theta[p];
     if (T2h) c -= T2h/(sp.theta[p]*1.0);
+    S.contrib_new[p] = c;
     logpr += c;
   }
   return logpr;
+}
+// the proposal stands: its terms become the current ones
+__device__ __forceinline__ void commit_logpr(TaskLDS & S)
+{
+  for (uint32_t m = S.chain; m; m &= m - 1)
+  {
+    const int p = __ffs(m) - 1;
+    S.contrib[p] = S.contrib_new[p]; S.nin[p] = S.nin_new[p]; S.nc[p] = S.nc_new[p];
+  }
+}
+// populations on the path between two populations one of which is an ancestor (or self) of the other
+__device__ __forceinline__ uint32_t pop_chain(const Species & sp, int a, int b)
+{
+  const int lower = ((sp.anc[a] >> b) & 1u) ? a : b, higher = lower == a ? b : a;
+  return sp.anc[lower] & ~(sp.anc[higher] & ~(1u << higher));
 }
 
 // install a proposal: toggle buffers, fresh (a,b) of the changed branches (mask brm), node-update
@@ -257,10 +286,11 @@ __device__ bool propose_gage(TaskLDS & S, int k, double rate, const Species & sp
   const double hi = p >= 0 ? t.time[p] : 999.0;
   if (!(hi > lo)) { (void)rndu(&t.rng); return false; }
   const double tnew = reflect(t.time[v] + sp.ft_gage*(u - 0.5), lo, hi);
+  const int oldpop = t.pop[v];
   t.time[v] = tnew;
   t.pop[v] = (int8_t)climb(sp, tau, t.pop[l], tnew);
   S.hast = 0;
-  S.logpr_new = tree_logpr(S, sp, tau);
+  S.logpr_new = tree_logpr(S, sp, tau, pop_chain(sp, oldpop, t.pop[v]));
   uint32_t brm = (1u << l) | (1u << r);
   if (p >= 0) brm |= 1u << v;
   install(S, brm, path_mask(t, v), rate);
@@ -308,6 +338,7 @@ __device__ bool propose_gspr(TaskLDS & S, int k, double rate, const Species & sp
   t.parent[s] = (int8_t)g;
   if (g >= 0) { if (t.left[g] == p) t.left[g] = (int8_t)s; else t.right[g] = (int8_t)s; } else t.root = s;
   const int pc = t.parent[tgt];
+  const uint32_t chain = pop_chain(sp, t.pop[p], popt);
   t.time[p] = tnew; t.pop[p] = (int8_t)popt;
   t.left[p] = (int8_t)a; t.right[p] = (int8_t)tgt; t.parent[a] = (int8_t)p; t.parent[tgt] = (int8_t)p;
   t.parent[p] = (int8_t)pc;
@@ -328,7 +359,7 @@ __device__ bool propose_gspr(TaskLDS & S, int k, double rate, const Species & sp
   uint32_t brm = 0;
   for (uint32_t m = bset; m; m &= m - 1) { const int x = __ffs(m) - 1; if (t.parent[x] >= 0) brm |= 1u << x; }
   S.hast = log((double)ntg/(double)nsrc);
-  S.logpr_new = tree_logpr(S, sp, tau);
+  S.logpr_new = tree_logpr(S, sp, tau, chain);
   install(S, brm, ndm, rate);
   return true;
 }
@@ -406,6 +437,9 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     for (uint32_t i = 0; i < npm; ++i) { S.ab[i][0] = g_pmat[2*i]; S.ab[i][1] = g_pmat[2*i+1]; }
     for (int p = 0; p < sp.npop; ++p) S.gl[p] = 0;
     for (uint32_t k = 0; k < tips; ++k) for (int q = S.tr.pop[k]; q >= 0; q = sp.parent[q]) S.gl[q]++;
+    for (int p = 0; p < sp.npop; ++p) S.nin[p] = 0;
+    for (uint32_t k = 0; k < tips; ++k) S.nin[S.tr.pop[k]]++;
+    if (A.mode == 0) { (void)tree_logpr(S, sp, s_tau, (1u << sp.npop) - 1u); commit_logpr(S); }     // the current terms
     S.nops = 0; S.active = 0;
   }
   __syncthreads();
@@ -443,7 +477,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
           if (t.parent[k] >= 0) brm |= 1u << k;
           ndm |= path_mask(t, k);
         }
-        S.logpr_new = tree_logpr(S, sp, s_tau);
+        S.logpr_new = tree_logpr(S, sp, s_tau, (1u << sp.npop) - 1u);
         S.hast = (S.logpr_new - t.logpr) + below*lminf + above*lmaxf;      // p_delta of the host driver
         ok = ndm != 0;
         if (ok) install(S, brm, ndm, rate);
@@ -466,7 +500,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
           for (uint32_t m = brm; m; m &= m - 1) swap_pmat(t, __ffs(m) - 1);       // start-up evaluates in place:
           for (uint32_t m = ndm; m; m &= m - 1) swap_clv(t, __ffs(m) - 1);        // toggle twice = no toggle
         }
-        S.logpr_new = tree_logpr(S, sp, s_tau);
+        S.logpr_new = tree_logpr(S, sp, s_tau, (1u << sp.npop) - 1u);
         S.hast = A.mode == 1 ? (S.logpr_new - t.logpr) + (double)ninner*A.mix_lnc : 0.0;
         install(S, brm, ndm, rate);
         ok = true;
@@ -511,7 +545,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
         const double lnacc = (S.logpr_new - S.tr.logpr) + (lnl - S.tr.lnl) + S.hast;
         const double u = rndu(&S.tr.rng);
         S.tr.proposals++;
-        if (lnacc >= 0 || u < exp(lnacc)) { S.tr.lnl = lnl; S.tr.logpr = S.logpr_new; S.tr.accepted++; S.active = 1; }
+        if (lnacc >= 0 || u < exp(lnacc)) { S.tr.lnl = lnl; S.tr.logpr = S.logpr_new; S.tr.accepted++; S.active = 1; commit_logpr(S); }
         else S.active = 2;                               // rejected: restore below
       }
       else
