@@ -135,7 +135,8 @@ struct bpa_plan
   DevBuf<uint32_t> tile_task, tile_n0;
   DevBuf<unsigned long long> dbg;
   unsigned ntiles = 0, tile = 128;    // tiled 20-state path
-  bool s20_mfma = true;
+  bool s20_mfma = false, s20_scalarp = false, s20_tiledk = true;
+  std::string s20_kernel;
   DevBuf<MatRec>   mat_recs;
   bool fused_jc69 = false;            // JC69, one rate category: the latency-optimised kernel
   unsigned fused_rt = 0;              // compile-time rate-category count of the fused kernel (0 = runtime)
@@ -566,8 +567,19 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
 
   // tiled path (20 states): one workgroup per 128-pattern tile of one locus
   p->ntiles = 0; d.tile_task = d.tile_n0 = nullptr;
-  p->s20_mfma = getenv("BPA_S20_MFMA") != nullptr;       // experimental, see kernels.hpp
-  p->tile = p->s20_mfma ? 32 : 128;
+  // 20-state partials kernel (kernels.hpp): default = LDS-staged P, one wave per rate category
+  // (partials_lnl_tiledk_kernel); BPA_S20_KERNEL selects the others for A/B timing:
+  //   tiled (first version, one wave runs all categories) | mfma (first MFMA version) | mfmak (MFMA, wave per
+  //   category) | scalarp / scalark (P through the scalar path) | generic (no staging)
+  {
+    const char * v = getenv("BPA_S20_KERNEL");
+    p->s20_kernel = v ? v : "tiledk";
+  }
+  p->s20_mfma = p->s20_kernel == "mfma";
+  p->s20_scalarp = p->s20_kernel == "scalarp";
+  p->s20_tiledk = p->s20_kernel == "tiledk" || p->s20_kernel == "mfmak" || p->s20_kernel == "scalark" || p->s20_kernel == "tiledk1" || p->s20_kernel == "tiledkb";
+  if (p->s20_tiledk && p->rmax > 4) { p->s20_tiledk = false; p->s20_kernel = "tiled"; }     // 64 x R lanes must fit a 256-lane workgroup
+  p->tile = p->s20_mfma ? 32 : (p->s20_scalarp || p->s20_tiledk) ? 64 : 128;
   if (p->states == 20)
   {
     std::vector<uint32_t> tt, tn;
@@ -764,7 +776,10 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     else
     {
       const unsigned n = d.nmat*p->rmax*20;
-      hipLaunchKernelGGL(pmatrix_sN_kernel<20>, dim3((n + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d, p->rmax);
+      if (getenv("BPA_PMAT_ROWS"))      // one lane per row (the first version), kept for A/B timing
+        hipLaunchKernelGGL(pmatrix_sN_kernel<20>, dim3((n + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d, p->rmax);
+      else
+        hipLaunchKernelGGL(pmatrix_wg_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d, p->rmax);
     }
     HIPCHK(hipGetLastError());
   }
@@ -779,7 +794,24 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       d.flags = 4u;                                      // always produce the site terms
       hipLaunchKernelGGL((partials_lnl_mfma20_kernel<32>), dim3(p->ntiles), dim3(64), 0, e->stream, d);
     }
-    else if (p->ntiles && p->tile == 128 && !getenv("BPA_S20_GENERIC"))
+    else if (p->ntiles && p->s20_tiledk)
+    {
+      d.flags = 4u; d.pad = p->rmax;
+      const size_t lds = ((size_t)2*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double);
+      const dim3 grid(p->ntiles), block(64*p->rmax);
+      if (p->s20_kernel == "mfmak")        hipLaunchKernelGGL(partials_lnl_mfma20k_kernel, grid, block, lds, e->stream, d);
+      else if (p->s20_kernel == "scalark" && p->rmax <= 4)
+                                           hipLaunchKernelGGL((partials_lnl_scalark_kernel<20>), grid, block, 0, e->stream, d);
+      else if (p->s20_kernel == "tiledk1") hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 1>), grid, block, lds, e->stream, d);
+      else if (p->s20_kernel == "tiledkb") hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 4>), grid, block, lds, e->stream, d);
+      else                                 hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 3>), grid, block, lds, e->stream, d);
+    }
+    else if (p->ntiles && p->s20_scalarp)
+    {
+      d.flags = 4u;
+      hipLaunchKernelGGL((partials_lnl_scalarp_kernel<20>), dim3(p->ntiles), dim3(64), 0, e->stream, d);
+    }
+    else if (p->ntiles && p->tile == 128 && p->s20_kernel == "tiled")
     {
       d.flags = 4u;
       const size_t lds = (size_t)2*p->rmax*400*sizeof(double);
@@ -792,7 +824,10 @@ static int plan_launch_mode(bpa_plan * p, int mode)
   if (ts) HIPCHK(hipEventRecord(ts->ev[2], e->stream));
   if (mode & 4)
   {
-    hipLaunchKernelGGL(lnl_reduce_kernel, dim3((d.ntasks + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d);
+    if (getenv("BPA_REDUCE_THREAD"))
+      hipLaunchKernelGGL(lnl_reduce_kernel, dim3((d.ntasks + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d);
+    else
+      hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(d.ntasks), dim3(64), 0, e->stream, d);
     HIPCHK(hipGetLastError());
   }
   if ((mode & 4) && p->sum_out)

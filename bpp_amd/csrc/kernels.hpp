@@ -392,6 +392,509 @@ __global__ void __launch_bounds__(TILE) partials_lnl_tiled_kernel(const PlanDev 
   P.site_term[P.task_pat_off[t] + n] = term;
 }
 
+// ============================ K1+K2, 20 states, LDS-staged P, one wave per rate category ==
+// As partials_lnl_tiled_kernel, but a workgroup = 64 patterns x R rate categories: wave k of the
+// workgroup owns the k-th plane of every CLV of its 64 patterns.  The planes of a node update are
+// independent (K1 couples the categories only through the scaling test), so the serial chain of a
+// wave is R times shorter and R times more waves are in flight to hide the CLV load latency —
+// config 4 has only ~2 tiles of 64 patterns per locus.  The root term is combined across the
+// waves in category order (same fma chain as the one-wave version); same arithmetic per element.
+template <int S, int V>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((V == 2 || V == 3) ? 4 : 1, (V == 2 || V == 3) ? 4 : 8)))
+partials_lnl_tiledk_kernel(const PlanDev P)
+{
+  extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2][R][S][S], then [R][64] scratch
+  const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, k = threadIdx.x >> 6;
+  const uint32_t t = P.tile_task[b];
+  const uint32_t n = P.tile_n0[b] + lane;
+  const LocusDev L = P.loci[P.task_locus[t]];
+  const uint32_t R = L.rate_cats, np = L.np, nthr = blockDim.x;
+  const bool active = n < np && k < R;
+  constexpr uint32_t SS = S*S;
+  double * s_x = s_p + (size_t)2*P.pad*SS;                          // P.pad = largest R of the plan
+
+  const uint32_t op_end = P.op_off[t+1];
+  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
+  {
+    const OpDev op = P.ops[o];
+    __syncthreads();                                   // previous update's LDS reads are done
+    {
+      const double2 * gl = reinterpret_cast<const double2 *>(L.pmat + (size_t)op.left_pmatrix*R*SS);
+      const double2 * gr = reinterpret_cast<const double2 *>(L.pmat + (size_t)op.right_pmatrix*R*SS);
+      double2 * sl = reinterpret_cast<double2 *>(s_p);
+      double2 * sr = reinterpret_cast<double2 *>(s_p + (size_t)R*SS);
+      for (uint32_t i = threadIdx.x; i < R*SS/2; i += nthr) { sl[i] = gl[i]; sr[i] = gr[i]; }
+    }
+    __syncthreads();
+    double * out = L.clv + ((((size_t)(op.parent_clv - L.tips_n)*R) + k)*S)*np + n;
+    bool all_small = true;
+    if (active)
+    {
+      double lv[S], rv[S];
+      load_childN<S, uint32_t>(L, op.left_clv,  k, n, lv);
+      load_childN<S, uint32_t>(L, op.right_clv, k, n, rv);
+      const double * lm = s_p + (size_t)k*SS;
+      const double * rm = s_p + (size_t)(R + k)*SS;
+      if (V == 4)
+      {
+        // both P rows of an output state are requested in one burst of LDS reads (20 ds_read_b128) and
+        // consumed as they land: one LDS round trip per 40 FMAs instead of one per two
+#pragma unroll 1
+        for (int i = 0; i < S; ++i)
+        {
+          double pl[S], pr[S];
+          const double2 * ql = reinterpret_cast<const double2 *>(lm + i*S);
+          const double2 * qr = reinterpret_cast<const double2 *>(rm + i*S);
+#pragma unroll
+          for (int j = 0; j < S/2; ++j) { const double2 a = ql[j]; pl[2*j] = a.x; pl[2*j+1] = a.y; }
+#pragma unroll
+          for (int j = 0; j < S/2; ++j) { const double2 a = qr[j]; pr[2*j] = a.x; pr[2*j+1] = a.y; }
+          __builtin_amdgcn_sched_barrier(0);
+          const double x = dot_fma4<S>(pl, lv);
+          const double y = dot_fma4<S>(pr, rv);
+          const double v = x*y;
+          all_small = all_small && (v < BPA_SCALE_THRESHOLD);
+          out[(size_t)i*np] = v;
+        }
+      }
+      else
+      {
+#pragma unroll 2
+        for (int i = 0; i < S; ++i)
+        {
+          const double x = dot_fma4<S>(lm + i*S, lv);
+          const double y = dot_fma4<S>(rm + i*S, rv);
+          const double v = x*y;
+          all_small = all_small && (v < BPA_SCALE_THRESHOLD);
+          out[(size_t)i*np] = v;
+        }
+      }
+    }
+    if (op.parent_scaler >= 0)                         // uniform: the scaling test couples the categories
+    {
+      reinterpret_cast<uint32_t *>(s_x)[k*64 + lane] = all_small ? 1u : 0u;
+      __syncthreads();
+      if (active)
+      {
+        bool all = true;
+        for (uint32_t q = 0; q < R; ++q) all = all && reinterpret_cast<const uint32_t *>(s_x)[q*64 + lane] != 0u;
+        if (all) for (int i = 0; i < S; ++i) out[(size_t)i*np] *= BPA_SCALE_FACTOR;
+        if (k == 0)
+        {
+          uint32_t sc = all ? 1u : 0u;
+          if (op.left_scaler  >= 0) sc += L.scaler[(size_t)op.left_scaler*np  + n];
+          if (op.right_scaler >= 0) sc += L.scaler[(size_t)op.right_scaler*np + n];
+          L.scaler[(size_t)op.parent_scaler*np + n] = sc;
+        }
+      }
+    }
+  }
+  if (!(P.flags & 4u)) return;
+
+  // K2 / K3 (core_likelihood_avx2.c:45-87): every wave its category's term, wave 0 the fma chain over them
+  const uint32_t root = P.root_clv[t];
+  const double * par = L.par;
+  __syncthreads();
+  if (active)
+  {
+    double c[S];
+    load_childN<S, uint32_t>(L, root, k, n, c);
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+    s_x[k*64 + lane] = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
+  }
+  __syncthreads();
+  if (!active || k) return;
+  double term = 0;
+  for (uint32_t q = 0; q < R; ++q) term = __builtin_fma(s_x[q*64 + lane], par[par_rate_weights(R) + q], term);
+  if (!L.unphased_length)
+  {
+    double lt = log(term);
+    const int32_t rs = P.root_scaler[t];
+    if (rs >= 0)
+    {
+      const uint32_t sc = L.scaler[(size_t)rs*np + n];
+      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
+    }
+    term = lt*L.weights[n];
+  }
+  P.site_term[P.task_pat_off[t] + n] = term;
+}
+
+// ====================================== K1+K2, 20 states, P through the scalar path ==
+// One wave (= one workgroup) = one tile of 64 consecutive patterns of ONE locus; one lane = one
+// pattern.  Everything about the node update except the CLV values is wave-uniform, so the two
+// P-matrices are read through the scalar data path (constant address space -> s_load_dwordx*
+// into SGPRs, served by the scalar cache / L2) and enter v_fma_f64 as its SGPR operand: no LDS
+// traffic, no staging barriers, no per-lane P loads; the vector memory pipe carries only the
+// coalesced CLV planes.  The P-matrices were written by an earlier launch (pmatrix_sN_kernel), so the
+// scalar cache cannot hold stale lines.  Summation order = dot_fma4 (the reference's AVX2 order).
+typedef const double __attribute__((address_space(4))) * cdouble_p;
+
+template <int S>
+__device__ __forceinline__ double dot_fma4_c(cdouble_p row, const double * v)
+{
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+  for (int j = 0; j < S; j += 4)
+  {
+    a0 = __builtin_fma(row[j+0], v[j+0], a0);
+    a1 = __builtin_fma(row[j+1], v[j+1], a1);
+    a2 = __builtin_fma(row[j+2], v[j+2], a2);
+    a3 = __builtin_fma(row[j+3], v[j+3], a3);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+template <int S>
+__global__ void __launch_bounds__(64) partials_lnl_scalarp_kernel(const PlanDev P)
+{
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  const uint32_t t = P.tile_task[b];
+  const uint32_t n = P.tile_n0[b] + lane;
+  const LocusDev L = P.loci[P.task_locus[t]];
+  const uint32_t R = L.rate_cats, np = L.np;
+  const bool active = n < np;
+  constexpr uint32_t SS = S*S;
+  const uint32_t nn = active ? n : np - 1;               // idle lanes shadow the last pattern (no divergence, no stores)
+
+  const uint32_t op_end = P.op_off[t+1];
+  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
+  {
+    const OpDev op = P.ops[o];
+    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*np + nn;
+    bool all_small = true;
+    for (uint32_t k = 0; k < R; ++k)
+    {
+      double lv[S], rv[S];
+      load_childN<S, uint32_t>(L, op.left_clv,  k, nn, lv);
+      load_childN<S, uint32_t>(L, op.right_clv, k, nn, rv);
+      cdouble_p lm = (cdouble_p)(L.pmat + ((size_t)op.left_pmatrix*R  + k)*SS);
+      cdouble_p rm = (cdouble_p)(L.pmat + ((size_t)op.right_pmatrix*R + k)*SS);
+      double * dst = out + (size_t)k*S*np;
+#pragma unroll 2
+      for (int i = 0; i < S; ++i)
+      {
+        const double x = dot_fma4_c<S>(lm + i*S, lv);
+        const double y = dot_fma4_c<S>(rm + i*S, rv);
+        const double v = x*y;
+        all_small = all_small && (v < BPA_SCALE_THRESHOLD);
+        if (active) dst[(size_t)i*np] = v;
+      }
+    }
+    if (op.parent_scaler >= 0 && active)
+    {
+      uint32_t s = 0;
+      if (op.left_scaler  >= 0) s += L.scaler[(size_t)op.left_scaler*np  + n];
+      if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + n];
+      if (all_small)
+      {
+        for (uint32_t e = 0; e < R*S; ++e) out[(size_t)e*np] *= BPA_SCALE_FACTOR;
+        s += 1;
+      }
+      L.scaler[(size_t)op.parent_scaler*np + n] = s;
+    }
+  }
+  if (!active || !(P.flags & 4u)) return;
+
+  // K2 / K3 (core_likelihood_avx2.c:45-87)
+  const uint32_t root = P.root_clv[t];
+  const double * par = L.par;
+  double term = 0;
+  for (uint32_t k = 0; k < R; ++k)
+  {
+    double c[S];
+    load_childN<S, uint32_t>(L, root, k, n, c);
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+    const double tr = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
+    term = __builtin_fma(tr, par[par_rate_weights(R) + k], term);
+  }
+  if (!L.unphased_length)
+  {
+    double lt = log(term);
+    const int32_t rs = P.root_scaler[t];
+    if (rs >= 0)
+    {
+      const uint32_t sc = L.scaler[(size_t)rs*np + n];
+      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
+    }
+    term = lt*L.weights[n];
+  }
+  P.site_term[P.task_pat_off[t] + n] = term;
+}
+
+// ======================= K1+K2, 20 states, FP64 MFMA, one wave per rate category ==
+// The contraction parent[i][n] = (sum_j Pl[i][j] L[j][n]) (sum_j Pr[i][j] R[j][n]) on the matrix cores
+// with v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction: blocks = four groups of
+// 4 patterns, A = a 4-row x 4-column piece of P replicated over the blocks, B = 4 states x 16
+// patterns; 20 states = 5 row tiles, no padding in M).  Both operands live in VGPRs, so unlike the
+// LDS-broadcast VALU kernels (one LDS access per v_fma_f64: the LDS pipe, shared by the four SIMDs,
+// caps them near a quarter of the FP64 rate) the P-matrix costs ONE LDS read per (row tile,
+// accumulator) and rate category — 16x fewer.  A workgroup = 64 patterns x R categories, wave k owns
+// the k-th plane.  Lane layout (tools/mfma_layout.hip):
+//   A[blk][i][kk] @ lane kk*16+blk*4+i   B[blk][kk][j] @ lane kk*16+blk*4+j   D[blk][i][j] @ lane i*16+blk*4+j
+// Bit-exactness: the instruction accumulates kk = 0..3 as an ascending fma chain seeded with C
+// (tools/mfma_order.hip), which IS the reference's AVX2 lane accumulator over its first four
+// column blocks: accumulator a takes columns a, a+4, a+8, a+12 in one MFMA; its fifth term
+// (column a+16) is one v_fma_f64 in the D layout; then (acc0+acc1)+(acc2+acc3) and the product
+// (core_partials_avx2.c:666-745).  5 row tiles x 4 accumulators = 20 MFMAs per child per 16 patterns:
+// every MFMA slot is useful work.
+__device__ __forceinline__ void load_b20k(const LocusDev & L, const uint32_t clv_index, const uint32_t k,
+                                          const uint32_t pat, const uint32_t kq, double (&b)[4], double (&bt)[4])
+{
+  if (clv_index < L.tips_n)
+  {
+    const uint32_t code = reinterpret_cast<const uint32_t *>(L.tips)[(size_t)clv_index*L.np + pat];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+    {
+      b[a]  = ((code >> (a + 4*kq)) & 1u) ? 1.0 : 0.0;
+      bt[a] = ((code >> (16 + a)) & 1u) ? 1.0 : 0.0;
+    }
+  }
+  else
+  {
+    const double * p = L.clv + (((size_t)(clv_index - L.tips_n)*L.rate_cats + k)*20)*L.np + pat;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+    {
+      b[a]  = p[(size_t)(a + 4*kq)*L.np];
+      bt[a] = p[(size_t)(16 + a)*L.np];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) partials_lnl_mfma20k_kernel(const PlanDev P)
+{
+  constexpr int S = 20, SS = 400, NG = 4;
+  extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2][R][S][S], then [R][64] scratch
+  const uint32_t b = blockIdx.x, l = threadIdx.x & 63u;
+  const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t t = P.tile_task[b], n0 = P.tile_n0[b];
+  const LocusDev L = P.loci[P.task_locus[t]];
+  const uint32_t R = L.rate_cats, np = L.np, nthr = blockDim.x;
+  const uint32_t kq = l >> 4, pl = l & 15, ri = l & 3;
+  const bool wave_on = k < R;
+  double * s_x = s_p + (size_t)2*P.pad*SS;
+
+  const uint32_t op_end = P.op_off[t+1];
+  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
+  {
+    const OpDev op = P.ops[o];
+    __syncthreads();                                   // previous update's LDS reads are done
+    {
+      const double2 * gl = reinterpret_cast<const double2 *>(L.pmat + (size_t)op.left_pmatrix*R*SS);
+      const double2 * gr = reinterpret_cast<const double2 *>(L.pmat + (size_t)op.right_pmatrix*R*SS);
+      double2 * sl = reinterpret_cast<double2 *>(s_p);
+      double2 * sr = reinterpret_cast<double2 *>(s_p + (size_t)R*SS);
+      for (uint32_t i = threadIdx.x; i < R*SS/2; i += nthr) { sl[i] = gl[i]; sr[i] = gr[i]; }
+    }
+    __syncthreads();
+    double * out = L.clv + ((((size_t)(op.parent_clv - L.tips_n)*R) + k)*S)*np;
+    uint32_t small = 0xfu;                             // bit g: everything this lane produced for group g is < 2^-256
+    if (wave_on)
+    {
+      const double * lm = s_p + (size_t)k*SS;
+      const double * rm = s_p + (size_t)(R + k)*SS;
+      // 16 patterns at a time: their CLV operands (B and the tail column's), then the five row tiles
+#pragma unroll 2
+      for (int g = 0; g < NG; ++g)
+      {
+        const uint32_t pat = n0 + 16*g + pl;
+        const uint32_t pc = pat < np ? pat : np - 1;
+        double bl[4], blt[4], br[4], brt[4];
+        load_b20k(L, op.left_clv,  k, pc, kq, bl, blt);
+        load_b20k(L, op.right_clv, k, pc, kq, br, brt);
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+        {
+          // A operands of this row tile: the MFMA piece P[4r+ri][a+4kq] and the tail column P[4r+kq][16+a]
+          const double2 * pl0 = reinterpret_cast<const double2 *>(lm + (4*r + ri)*S + 4*kq);
+          const double2 * pr0 = reinterpret_cast<const double2 *>(rm + (4*r + ri)*S + 4*kq);
+          const double2 * pl1 = reinterpret_cast<const double2 *>(lm + (4*r + kq)*S + 16);
+          const double2 * pr1 = reinterpret_cast<const double2 *>(rm + (4*r + kq)*S + 16);
+          const double2 l01 = pl0[0], l23 = pl0[1], r01 = pr0[0], r23 = pr0[1];
+          const double2 lt01 = pl1[0], lt23 = pl1[1], rt01 = pr1[0], rt23 = pr1[1];
+          const double al[4] = {l01.x, l01.y, l23.x, l23.y}, ar[4] = {r01.x, r01.y, r23.x, r23.y};
+          const double alt[4] = {lt01.x, lt01.y, lt23.x, lt23.y}, art[4] = {rt01.x, rt01.y, rt23.x, rt23.y};
+          double xa[4], ya[4];
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+          {
+            xa[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(al[a], bl[a], 0.0, 0, 0, 0);
+            ya[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(ar[a], br[a], 0.0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+          {
+            xa[a] = __builtin_fma(alt[a], blt[a], xa[a]);
+            ya[a] = __builtin_fma(art[a], brt[a], ya[a]);
+          }
+          const double x = (xa[0] + xa[1]) + (xa[2] + xa[3]);
+          const double y = (ya[0] + ya[1]) + (ya[2] + ya[3]);
+          const double v = x*y;
+          if (!(v < BPA_SCALE_THRESHOLD)) small &= ~(1u << g);
+          if (pat < np) out[(size_t)(4*r + kq)*np + pat] = v;            // D: row = lane >> 4
+        }
+      }
+    }
+    if (op.parent_scaler >= 0)                         // uniform: the scaling test couples rows, lanes and categories
+    {
+      small &= __shfl_xor(small, 16);
+      small &= __shfl_xor(small, 32);                  // the 4 lanes of a pattern hold its 20 rows
+      __syncthreads();
+      if (kq == 0) reinterpret_cast<uint32_t *>(s_x)[k*16 + pl] = small;
+      __syncthreads();
+      if (wave_on)
+      {
+        uint32_t all = 0xfu;
+        for (uint32_t q = 0; q < R; ++q) all &= reinterpret_cast<const uint32_t *>(s_x)[q*16 + pl];
+        for (int g = 0; g < NG; ++g)
+        {
+          const uint32_t pat = n0 + 16*g + pl;
+          if (pat >= np) continue;
+          const bool rescale = (all >> g) & 1u;
+          if (rescale)
+#pragma unroll
+            for (int r = 0; r < 5; ++r) out[(size_t)(4*r + kq)*np + pat] *= BPA_SCALE_FACTOR;
+          if (k == 0 && kq == 0)
+          {
+            uint32_t sc = rescale ? 1u : 0u;
+            if (op.left_scaler  >= 0) sc += L.scaler[(size_t)op.left_scaler*np  + pat];
+            if (op.right_scaler >= 0) sc += L.scaler[(size_t)op.right_scaler*np + pat];
+            L.scaler[(size_t)op.parent_scaler*np + pat] = sc;
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next update reads these through other lanes
+  }
+  if (!(P.flags & 4u)) return;
+
+  // K2 / K3 (core_likelihood_avx2.c:45-87): every wave its category's term, wave 0 the fma chain over them
+  const uint32_t root = P.root_clv[t];
+  const double * par = L.par;
+  const uint32_t n = n0 + l;
+  const bool active = wave_on && n < np;
+  __syncthreads();
+  if (active)
+  {
+    double c[S];
+    load_childN<S, uint32_t>(L, root, k, n, c);
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+    s_x[k*64 + l] = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
+  }
+  __syncthreads();
+  if (!active || k) return;
+  double term = 0;
+  for (uint32_t q = 0; q < R; ++q) term = __builtin_fma(s_x[q*64 + l], par[par_rate_weights(R) + q], term);
+  if (!L.unphased_length)
+  {
+    double lt = log(term);
+    const int32_t rs = P.root_scaler[t];
+    if (rs >= 0)
+    {
+      const uint32_t sc = L.scaler[(size_t)rs*np + n];
+      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
+    }
+    term = lt*L.weights[n];
+  }
+  P.site_term[P.task_pat_off[t] + n] = term;
+}
+
+// ========================= K1+K2, 20 states, scalar-path P, one wave per rate category ==
+// partials_lnl_tiledk_kernel with the P-matrices read through the scalar path instead of LDS: an
+// LDS broadcast read per v_fma_f64 caps the LDS-staged kernels at about a quarter of the FP64 rate
+// (one 512-byte LDS access per 4 cycles per CU against four SIMDs' FMAs); SGPR operands cost no LDS
+// bandwidth and no staging barriers.  LDS only carries the scaling flags and the root terms.
+template <int S>
+__global__ void __launch_bounds__(256) partials_lnl_scalark_kernel(const PlanDev P)
+{
+  __shared__ double s_x[4][64];
+  const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
+  const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform, in an SGPR
+  const uint32_t t = P.tile_task[b];
+  const uint32_t n = P.tile_n0[b] + lane;
+  const LocusDev L = P.loci[P.task_locus[t]];
+  const uint32_t R = L.rate_cats, np = L.np;
+  const bool wave_on = k < R;
+  const bool active = n < np && wave_on;
+  constexpr uint32_t SS = S*S;
+  const uint32_t nn = n < np ? n : np - 1;               // idle lanes shadow the last pattern: no divergence in the FMA loop
+
+  const uint32_t op_end = P.op_off[t+1];
+  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
+  {
+    const OpDev op = P.ops[o];
+    double * out = L.clv + ((((size_t)(op.parent_clv - L.tips_n)*R) + k)*S)*np + nn;
+    bool all_small = true;
+    if (wave_on)
+    {
+      double lv[S], rv[S];
+      load_childN<S, uint32_t>(L, op.left_clv,  k, nn, lv);
+      load_childN<S, uint32_t>(L, op.right_clv, k, nn, rv);
+      cdouble_p lm = (cdouble_p)(L.pmat + ((size_t)op.left_pmatrix*R  + k)*SS);
+      cdouble_p rm = (cdouble_p)(L.pmat + ((size_t)op.right_pmatrix*R + k)*SS);
+#pragma unroll 2
+      for (int i = 0; i < S; ++i)
+      {
+        const double x = dot_fma4_c<S>(lm + i*S, lv);
+        const double y = dot_fma4_c<S>(rm + i*S, rv);
+        const double v = x*y;
+        all_small = all_small && (v < BPA_SCALE_THRESHOLD);
+        if (active) out[(size_t)i*np] = v;
+      }
+    }
+    if (op.parent_scaler >= 0)                         // uniform: the scaling test couples the categories
+    {
+      __syncthreads();
+      reinterpret_cast<uint32_t *>(&s_x[k & 3u][0])[lane] = all_small ? 1u : 0u;
+      __syncthreads();
+      if (active)
+      {
+        bool all = true;
+        for (uint32_t q = 0; q < R; ++q) all = all && reinterpret_cast<const uint32_t *>(&s_x[q][0])[lane] != 0u;
+        if (all) for (int i = 0; i < S; ++i) out[(size_t)i*np] *= BPA_SCALE_FACTOR;
+        if (k == 0)
+        {
+          uint32_t sc = all ? 1u : 0u;
+          if (op.left_scaler  >= 0) sc += L.scaler[(size_t)op.left_scaler*np  + n];
+          if (op.right_scaler >= 0) sc += L.scaler[(size_t)op.right_scaler*np + n];
+          L.scaler[(size_t)op.parent_scaler*np + n] = sc;
+        }
+      }
+    }
+  }
+  if (!(P.flags & 4u)) return;
+
+  // K2 / K3 (core_likelihood_avx2.c:45-87): every wave its category's term, wave 0 the fma chain over them
+  const uint32_t root = P.root_clv[t];
+  const double * par = L.par;
+  __syncthreads();
+  if (active)
+  {
+    double c[S];
+    load_childN<S, uint32_t>(L, root, k, n, c);
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+    s_x[k][lane] = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
+  }
+  __syncthreads();
+  if (!active || k) return;
+  double term = 0;
+  for (uint32_t q = 0; q < R; ++q) term = __builtin_fma(s_x[q][lane], par[par_rate_weights(R) + q], term);
+  if (!L.unphased_length)
+  {
+    double lt = log(term);
+    const int32_t rs = P.root_scaler[t];
+    if (rs >= 0)
+    {
+      const uint32_t sc = L.scaler[(size_t)rs*np + n];
+      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
+    }
+    term = lt*L.weights[n];
+  }
+  P.site_term[P.task_pat_off[t] + n] = term;
+}
+
 // ================================================= K1+K2, 20 states, FP64 MFMA ==
 // The 20-state node update is a real dense contraction: parent[i][n] = (sum_j Pl[i][j] L[j][n]) *
 // (sum_j Pr[i][j] R[j][n]).  It runs on the matrix cores with v_mfma_f64_4x4x4_4b_f64
@@ -597,6 +1100,31 @@ __device__ __forceinline__ double reduce_locus(const LocusDev & L, TERMPTR term)
     for (uint32_t n = 0; n < np; ++n) logl += term[n];
   }
   return logl;
+}
+
+// one wave per locus: the terms are fetched 64 at a time (coalesced) and added in pattern order —
+// the reference's sequential sum (core_likelihood.c:85) — by broadcasting them lane by lane
+__global__ void __launch_bounds__(64) lnl_reduce_wave_kernel(const PlanDev P)
+{
+  const uint32_t t = blockIdx.x, lane = threadIdx.x;
+  const LocusDev & L = P.loci[P.task_locus[t]];
+  const double * term = P.site_term + P.task_pat_off[t];
+  if (L.unphased_length)
+  {
+    if (lane == 0) P.lnl[t] = P.bfbeta*reduce_locus(L, term);
+    return;
+  }
+  const uint32_t np = L.np;
+  double logl = 0;
+  for (uint32_t base = 0; base < np; base += 64)
+  {
+    const double v = base + lane < np ? term[base + lane] : 0.0;
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const uint32_t cnt = np - base < 64u ? np - base : 64u;
+    for (uint32_t q = 0; q < cnt; ++q)
+      logl += __hiloint2double(__builtin_amdgcn_readlane(hi, (int)q), __builtin_amdgcn_readlane(lo, (int)q));
+  }
+  if (lane == 0) P.lnl[t] = P.bfbeta*logl;
 }
 
 __global__ void __launch_bounds__(BPA_BLOCK) lnl_reduce_kernel(const PlanDev P)
@@ -1325,6 +1853,51 @@ __global__ void __launch_bounds__(BPA_BLOCK) pmatrix_sN_kernel(const PlanDev P, 
   const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
   const double * pm = par + par_matrix(R, S, m);
   pmatrix_eigen_row<S>(prow, (int)j, t, rate, pm + pm_evals(S), pm + pm_evecs(S), pm + pm_ievecs(S), false);
+}
+
+// K5 for S = 20, one workgroup per branch: lanes = output elements.  The eigenvector matrices of the
+// rate matrix are staged once per workgroup (coalesced), the S expm1 per category are computed once
+// (not once per row), every lane accumulates its element in the reference's order
+// (temp = inv_eigenvecs*expd, then pmat += temp*eigenvecs, core_pmatrix.c:741-756) and the matrix is
+// written with consecutive lanes on consecutive addresses.
+template <int S>
+__global__ void __launch_bounds__(256) pmatrix_wg_kernel(const PlanDev P, const uint32_t rmax)
+{
+  __shared__ double s_ev[S*S], s_iev[S*S], s_e[4][S];
+  const uint32_t e = blockIdx.x, tid = threadIdx.x;
+  const LocusDev & L = P.loci[P.task_locus[P.mat_task[e]]];
+  const uint32_t R = L.rate_cats;
+  const double * par = L.par;
+  const double t = P.mat_length[e];
+  double * pbase = L.pmat + (size_t)P.mat_pmatrix[e]*R*S*S;
+  // the categories of BPP's loci share one rate matrix (param_indices all 0, locus.c:852); a locus
+  // with several is handled category by category
+  for (uint32_t k0 = 0; k0 < R; )
+  {
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k0];
+    uint32_t k1 = k0 + 1;
+    while (k1 < R && k1 - k0 < 4 && (uint32_t)par[par_param_idx(R) + k1] == m) ++k1;
+    const double * pm = par + par_matrix(R, S, m);
+    __syncthreads();
+    for (uint32_t i = tid; i < S*S; i += 256) { s_ev[i] = pm[pm_evecs(S) + i]; s_iev[i] = pm[pm_ievecs(S) + i]; }
+    if (tid < (k1 - k0)*S)
+    {
+      const uint32_t k = k0 + tid/S, mm = tid % S;
+      s_e[tid/S][mm] = expm1(pm[pm_evals(S) + mm]*(t*par[par_rates(R) + k]));
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < (k1 - k0)*S*S; idx += 256)
+    {
+      const uint32_t kk = idx/(S*S), j = (idx % (S*S))/S, c = idx % S, k = k0 + kk;
+      double acc = (j == c) ? 1.0 : 0.0;
+      if (t*par[par_rates(R) + k] < 1e-100) { pbase[(size_t)k*S*S + j*S + c] = acc; continue; }
+#pragma unroll
+      for (int mm = 0; mm < S; ++mm) acc += (s_iev[j*S + mm]*s_e[kk][mm])*s_ev[mm*S + c];
+      pbase[(size_t)k*S*S + j*S + c] = acc;
+    }
+    k0 = k1;
+  }
+  (void)rmax;
 }
 
 // pll_core_update_pmatrix (core_pmatrix.c:785) over staged host arrays:

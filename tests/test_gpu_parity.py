@@ -392,15 +392,16 @@ def test_against_the_reference_itself(engine, spec):
     rl.free()
 
 
-def test_mfma_20_state_kernel_is_bit_exact(engine, monkeypatch):
-    """the FP64-MFMA variant of the 20-state node update (opt-in) reproduces the reference's
-    AVX2 summation order exactly: same CLVs, scalers and lnL bits as the default kernel"""
+@pytest.mark.parametrize("kernel", ["mfmak", "mfma", "tiled", "tiledk1", "tiledkb", "scalarp", "scalark", "generic"])
+def test_20_state_kernel_variants_are_bit_exact(engine, monkeypatch, kernel):
+    """every 20-state node-update kernel (BPA_S20_KERNEL; the FP64-MFMA ones included) reproduces the
+    reference's AVX2 summation order exactly: same CLVs, scalers and lnL bits as the default kernel"""
     c = load_golden("loci.json")
     for idx in (6, 7, 11):                      # the three 20-state golden loci (11: with scaling)
         case = c[idx]
         S, R = case["states"], case["rate_cats"]
         ol, _ = __import__("test_oracle_pin").oracle_locus(case)
-        monkeypatch.setenv("BPA_S20_MFMA", "1")
+        monkeypatch.setenv("BPA_S20_KERNEL", kernel)
         loc, gt = golden_case(engine, case)
         for nd in gt.branches():
             loc.set_pmatrix(nd.pmatrix_index, ol.pmat[nd.node_index])
@@ -410,7 +411,7 @@ def test_mfma_20_state_kernel_is_bit_exact(engine, monkeypatch):
             assert (loc.get_clv(nd.clv_index) == ol.clv[nd.node_index]).all()
             if case["scaling"]:
                 assert (loc.get_scaler(nd.scaler_index) == ol.scaler[nd.node_index]).all()
-        monkeypatch.delenv("BPA_S20_MFMA")
+        monkeypatch.delenv("BPA_S20_KERNEL")
         loc2, gt2 = golden_case(engine, case)
         for nd in gt2.branches():
             loc2.set_pmatrix(nd.pmatrix_index, ol.pmat[nd.node_index])
