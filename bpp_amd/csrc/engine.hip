@@ -577,9 +577,10 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   }
   p->s20_mfma = p->s20_kernel == "mfma";
   p->s20_scalarp = p->s20_kernel == "scalarp";
-  p->s20_tiledk = p->s20_kernel == "tiledk" || p->s20_kernel == "mfmak" || p->s20_kernel == "scalark" || p->s20_kernel == "tiledk1" || p->s20_kernel == "tiledkb";
+  p->s20_tiledk = p->s20_kernel == "tiledk" || p->s20_kernel == "mfmak" || p->s20_kernel == "scalark" || p->s20_kernel == "tiledk1" || p->s20_kernel == "tiledkb" || p->s20_kernel == "tiledk2";
   if (p->s20_tiledk && p->rmax > 4) { p->s20_tiledk = false; p->s20_kernel = "tiled"; }     // 64 x R lanes must fit a 256-lane workgroup
   p->tile = p->s20_mfma ? 32 : (p->s20_scalarp || p->s20_tiledk) ? 64 : 128;
+  if (p->s20_kernel == "tiledk2") p->tile = 128;                   // two 64-pattern sub-tiles per workgroup
   if (p->states == 20)
   {
     std::vector<uint32_t> tt, tn;
@@ -746,6 +747,14 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       if (p->fused_bs == 64) hipExtLaunchKernelGGL((step_jc69_kernel<64>), grid, dim3(64), 0, e->stream, k0, k1, 0, d);
       else                   hipExtLaunchKernelGGL((step_jc69_kernel<256>), grid, dim3(256), 0, e->stream, k0, k1, 0, d);
     }
+    else if (p->fused_bs == 64 && p->fused_rt == 4 && (d.flags & 1u) && (d.flags & 6u) && getenv("BPA_FUSED_SPLIT"))
+    {
+      // phase A on its own (no events), then B+C with the lighter register footprint
+      PlanDev da = d; da.flags = 1u;
+      hipLaunchKernelGGL((step_s4_fused_kernel<64, 4, 1>), grid, dim3(64), 0, e->stream, da);
+      d.flags &= 6u;
+      hipExtLaunchKernelGGL((step_s4_fused_kernel<64, 4, 6>), grid, dim3(64), 0, e->stream, k0, k1, 0, d);
+    }
     else if (p->fused_bs == 64)
     {
       if (p->fused_rt == 1) BPA_FUSED(64, 1); else if (p->fused_rt == 4) BPA_FUSED(64, 4); else BPA_FUSED(64, 0);
@@ -802,6 +811,9 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       if (p->s20_kernel == "mfmak")        hipLaunchKernelGGL(partials_lnl_mfma20k_kernel, grid, block, lds, e->stream, d);
       else if (p->s20_kernel == "scalark" && p->rmax <= 4)
                                            hipLaunchKernelGGL((partials_lnl_scalark_kernel<20>), grid, block, 0, e->stream, d);
+      else if (p->s20_kernel == "tiledk2")
+        hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 3, 2>), grid, dim3(128*p->rmax),
+                           ((size_t)2*p->rmax*400 + (size_t)2*p->rmax*64)*sizeof(double), e->stream, d);
       else if (p->s20_kernel == "tiledk1") hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 1>), grid, block, lds, e->stream, d);
       else if (p->s20_kernel == "tiledkb") hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 4>), grid, block, lds, e->stream, d);
       else                                 hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 3>), grid, block, lds, e->stream, d);

@@ -399,19 +399,21 @@ __global__ void __launch_bounds__(TILE) partials_lnl_tiled_kernel(const PlanDev 
 // wave is R times shorter and R times more waves are in flight to hide the CLV load latency —
 // config 4 has only ~2 tiles of 64 patterns per locus.  The root term is combined across the
 // waves in category order (same fma chain as the one-wave version); same arithmetic per element.
-template <int S, int V>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((V == 2 || V == 3) ? 4 : 1, (V == 2 || V == 3) ? 4 : 8)))
+// NT = 64-pattern sub-tiles per workgroup (NT x R waves share one staging of the P-matrices)
+template <int S, int V, int NT = 1>
+__global__ void __launch_bounds__(256*NT) __attribute__((amdgpu_waves_per_eu((V == 2 || V == 3) ? 4 : 1, (V == 2 || V == 3) ? 4 : 8)))
 partials_lnl_tiledk_kernel(const PlanDev P)
 {
-  extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2][R][S][S], then [R][64] scratch
-  const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, k = threadIdx.x >> 6;
+  extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2][R][S][S], then [NT][R][64] scratch
+  const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const uint32_t k = NT == 1 ? w : w % P.pad, sub = NT == 1 ? 0u : w / P.pad;
   const uint32_t t = P.tile_task[b];
-  const uint32_t n = P.tile_n0[b] + lane;
+  const uint32_t n = P.tile_n0[b] + sub*64 + lane;
   const LocusDev L = P.loci[P.task_locus[t]];
   const uint32_t R = L.rate_cats, np = L.np, nthr = blockDim.x;
   const bool active = n < np && k < R;
   constexpr uint32_t SS = S*S;
-  double * s_x = s_p + (size_t)2*P.pad*SS;                          // P.pad = largest R of the plan
+  double * s_x = s_p + (size_t)2*P.pad*SS + (size_t)sub*P.pad*64;    // P.pad = largest R of the plan
 
   const uint32_t op_end = P.op_off[t+1];
   for (uint32_t o = P.op_off[t]; o < op_end; ++o)
@@ -1385,8 +1387,11 @@ __device__ __forceinline__ void load_vec4(const TaskRec & T, const uint32_t clv_
   }
 }
 
-// RT > 0: compile-time rate-category count, parent CLVs forwarded in registers; RT == 0: runtime
-template <int BS, int RT>
+// RT > 0: compile-time rate-category count, parent CLVs forwarded in registers; RT == 0: runtime.
+// PH = phases compiled in (1 = A, 6 = B+C, 7 = all): the eigen/closed-form P-matrix code of phase A is
+// what sets the kernel's register count, so loci that take that path run A and B+C as two launches
+// and B+C keeps twice the waves in flight.
+template <int BS, int RT, int PH = 7>
 __global__ void __launch_bounds__(BS) step_s4_fused_kernel(const PlanDev P)
 {
   __shared__ double s_term[BS];
@@ -1412,7 +1417,7 @@ __global__ void __launch_bounds__(BS) step_s4_fused_kernel(const PlanDev P)
   if ((P.flags & 4u) && lane < t1 - t0) sum_rec = P.task_rec[t0 + lane];
 
   // ---- phase A: P-matrices of this workgroup's loci
-  if (P.flags & 1u)
+  if ((PH & 1) && (P.flags & 1u))
   {
     const uint32_t e0 = P.mat_off[t0], e1 = P.mat_off[t1];
     if (RT == 1)
@@ -1432,7 +1437,7 @@ __global__ void __launch_bounds__(BS) step_s4_fused_kernel(const PlanDev P)
     }
     __syncthreads();
   }
-  if (!(P.flags & 6u)) return;
+  if (!(PH & 6) || !(P.flags & 6u)) return;
 
   // ---- phase B: node updates + root term of this lane's pattern
   double term = 0;
@@ -1863,7 +1868,7 @@ __global__ void __launch_bounds__(BPA_BLOCK) pmatrix_sN_kernel(const PlanDev P, 
 template <int S>
 __global__ void __launch_bounds__(256) pmatrix_wg_kernel(const PlanDev P, const uint32_t rmax)
 {
-  __shared__ double s_ev[S*S], s_iev[S*S], s_e[4][S];
+  __shared__ __attribute__((aligned(16))) double s_ev[S*S], s_iev[S*S], s_tmp[4][S*S], s_e[4][S];
   const uint32_t e = blockIdx.x, tid = threadIdx.x;
   const LocusDev & L = P.loci[P.task_locus[P.mat_task[e]]];
   const uint32_t R = L.rate_cats;
@@ -1871,29 +1876,46 @@ __global__ void __launch_bounds__(256) pmatrix_wg_kernel(const PlanDev P, const 
   const double t = P.mat_length[e];
   double * pbase = L.pmat + (size_t)P.mat_pmatrix[e]*R*S*S;
   // the categories of BPP's loci share one rate matrix (param_indices all 0, locus.c:852); a locus
-  // with several is handled category by category
+  // with several is handled in groups of categories with the same matrix
   for (uint32_t k0 = 0; k0 < R; )
   {
     const uint32_t m = (uint32_t)par[par_param_idx(R) + k0];
     uint32_t k1 = k0 + 1;
     while (k1 < R && k1 - k0 < 4 && (uint32_t)par[par_param_idx(R) + k1] == m) ++k1;
+    const uint32_t nk = k1 - k0;
     const double * pm = par + par_matrix(R, S, m);
     __syncthreads();
     for (uint32_t i = tid; i < S*S; i += 256) { s_ev[i] = pm[pm_evecs(S) + i]; s_iev[i] = pm[pm_ievecs(S) + i]; }
-    if (tid < (k1 - k0)*S)
+    if (tid < nk*S)
     {
       const uint32_t k = k0 + tid/S, mm = tid % S;
       s_e[tid/S][mm] = expm1(pm[pm_evals(S) + mm]*(t*par[par_rates(R) + k]));
     }
     __syncthreads();
-    for (uint32_t idx = tid; idx < (k1 - k0)*S*S; idx += 256)
+    // temp = inv_eigenvecs * expd (core_pmatrix.c:741-747), once per element
+    for (uint32_t i = tid; i < nk*S*S; i += 256) s_tmp[i/(S*S)][i % (S*S)] = s_iev[i % (S*S)]*s_e[i/(S*S)][i % S];
+    __syncthreads();
+    // pmat = I + temp * eigenvecs (core_pmatrix.c:749-756): one lane = 4 consecutive columns of a row
+    constexpr uint32_t Q = S/4;
+    for (uint32_t idx = tid; idx < nk*S*Q; idx += 256)
     {
-      const uint32_t kk = idx/(S*S), j = (idx % (S*S))/S, c = idx % S, k = k0 + kk;
-      double acc = (j == c) ? 1.0 : 0.0;
-      if (t*par[par_rates(R) + k] < 1e-100) { pbase[(size_t)k*S*S + j*S + c] = acc; continue; }
+      const uint32_t kk = idx/(S*Q), j = (idx % (S*Q))/Q, c0 = 4*(idx % Q), k = k0 + kk;
+      double acc[4] = {j == c0 ? 1.0 : 0.0, j == c0 + 1 ? 1.0 : 0.0, j == c0 + 2 ? 1.0 : 0.0, j == c0 + 3 ? 1.0 : 0.0};
+      if (!(t*par[par_rates(R) + k] < 1e-100))
+      {
+        const double * tr = &s_tmp[kk][j*S];
 #pragma unroll
-      for (int mm = 0; mm < S; ++mm) acc += (s_iev[j*S + mm]*s_e[kk][mm])*s_ev[mm*S + c];
-      pbase[(size_t)k*S*S + j*S + c] = acc;
+        for (int mm = 0; mm < S; ++mm)
+        {
+          const double tv = tr[mm];
+          const double2 * ev = reinterpret_cast<const double2 *>(&s_ev[mm*S + c0]);
+          const double2 a = ev[0], c = ev[1];
+          acc[0] += tv*a.x; acc[1] += tv*a.y; acc[2] += tv*c.x; acc[3] += tv*c.y;
+        }
+      }
+      double2 * dst = reinterpret_cast<double2 *>(pbase + (size_t)k*S*S + j*S + c0);
+      double2 o0, o1; o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
+      dst[0] = o0; dst[1] = o1;
     }
     k0 = k1;
   }

@@ -1,17 +1,40 @@
 #!/bin/bash
-# rocprofv3 profile of bench.py for one config (c3 / c4) on the GPU box; outputs under gpurun_out/
-# usage: tools/profile_cfg.sh <config> <tag> [env assignments...]   (run through gpurun from the repo root)
+# rocprofv3 profile of bench.py for one config on the GPU box: kernel trace + separate --pmc passes
+# (FETCH_SIZE / WRITE_SIZE / SQ+MFMA), reduced to one small JSON under gpurun_out/.
+# usage: tools/profile_cfg.sh <config> <tag> [ENV=VAL ...]   (run through gpurun from the repo root)
 set -u
 CFG=${1:-c4}; TAG=${2:-r1}; shift 2
 for kv in "$@"; do export "$kv"; done
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_${CFG}_$TAG
-mkdir -p $OUT
+W=/tmp/prof_${CFG}_$TAG
+rm -rf $W; mkdir -p $W $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --config $CFG --steps 6 --warmup 2 --no-cpu-baseline"
-$BENCH > $OUT/bench_plain.json 2> $OUT/plain.log
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o $CFG -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.log
-rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -o $CFG -- $BENCH > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log
-rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -o $CFG -- $BENCH > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -f csv -d $OUT/pmc_sq -o $CFG -- $BENCH > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.log
-find $OUT -name "*.csv" | head -30
+STEPS=${STEPS:-6}
+BENCH="python $R/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline"
+$BENCH > $W/bench_plain.json 2> $W/plain.log
+rocprofv3 --kernel-trace --stats -f csv -d $W/trace -o p -- $BENCH > $W/bench_trace.json 2> $W/trace.log
+rocprofv3 --pmc FETCH_SIZE -f csv -d $W/pmc_fetch -o p -- $BENCH > /dev/null 2> $W/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE -f csv -d $W/pmc_write -o p -- $BENCH > /dev/null 2> $W/pmc_write.log
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CYCLES -f csv -d $W/pmc_sq -o p -- $BENCH > /dev/null 2> $W/pmc_sq.log
+python3 - <<PY
+import csv, collections, glob, json
+out = {"config": "$CFG", "tag": "$TAG", "env": "$*", "command": "$BENCH"}
+try:
+    out["bench_unprofiled"] = json.loads(open("$W/bench_plain.json").read())
+except Exception as e:
+    out["bench_unprofiled"] = str(e)
+ks = glob.glob("$W/trace/**/*kernel_stats.csv", recursive=True)
+out["kernel_stats"] = [r for r in csv.DictReader(open(ks[0]))][:8] if ks else None
+pm = {}
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for f in glob.glob("$W/%s/**/*counter_collection.csv" % sub, recursive=True):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, d in acc.items():
+            if any(w in k for w in ("partials", "step_", "pmatrix", "reduce")):
+                pm.setdefault(k, {}).update({c: {"mean": sum(v)/len(v), "dispatches": len(v)} for c, v in d.items()})
+out["pmc_per_dispatch"] = pm
+json.dump(out, open("$R/gpurun_out/profile_${CFG}_$TAG.json", "w"), indent=1)
+print("wrote profile_${CFG}_$TAG.json")
+PY
