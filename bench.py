@@ -367,6 +367,7 @@ def main():
         smp_taus = sp_tau[cfg["taxa"]:]
         smp.set_species_tree(sp_parent, sp_tau, sp_theta)
         smp.set_tau_prior(3.0, 3.0 / sp_tau[-1])
+        smp.set_theta_prior(2.0, 2.0 / sp_theta[0], 0.5 * sp_theta[0])
         smp.initialize()
         smp.iterate(args.warmup)
         eng.synchronize()
@@ -376,14 +377,16 @@ def main():
         dt = time.perf_counter() - t0
         sm = smp.summary()
         sampler = dict(iterations_per_s=round(args.steps / dt * nloci / 10000.0, 1), ms_per_iteration=round(1e3 * dt / args.steps, 4),
-                       launches_per_iteration=4 + 3 * len(smp_taus), proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
+                       launches_per_iteration=4 + 6 * len(smp_taus), proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
                        acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
                        taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
-                       note="multispecies-coalescent sampler on a fixed species tree: population-aware GAGE+GSPR per locus, one "
-                            "rubber-band TAU step per species divergence and one all-loci MIX per iteration, "
-                            "Metropolis-Hastings on MSC density x likelihood (density bit-equal to gtree_logprob), "
-                            "decisions taken on the device; same trajectory as the C host driver on the reference "
-                            "(tests/test_gpu_sampler.py, tests/test_gpu_host_driver.py); thetas fixed")
+                       thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],
+                       note="the A00 sampler (species tree fixed) resident on the device: population-aware GAGE+GSPR per "
+                            "locus, a THETA step per population, a rubber-band TAU step per divergence and one MIX step "
+                            "per iteration, Metropolis-Hastings on priors x MSC density x likelihood (density bit-equal "
+                            "to gtree_logprob); reproduces the unmodified program's posterior "
+                            "(tests/test_a00_posterior.py) and the C host driver's trajectory on the reference "
+                            "(tests/test_gpu_sampler.py, tests/test_gpu_host_driver.py)")
         smp.close()
 
     cpu = None

@@ -108,6 +108,8 @@ def lib():
         "bpa_sampler_set_tip_species": (i, [vp, u, C.POINTER(i)]),
         "bpa_sampler_set_finetune": (None, [vp, d, d, d, d]),
         "bpa_sampler_set_tau_prior": (None, [vp, d, d]),
+        "bpa_sampler_set_theta_prior": (None, [vp, d, d, d]),
+        "bpa_sampler_get_thetas": (i, [vp, dp]),
         "bpa_sampler_get_taus": (i, [vp, dp]),
         "bpa_sampler_get_tree_msc": (i, [vp, u, C.POINTER(i), dp]),
         "bpa_sampler_initialize": (i, [vp]),
@@ -143,6 +145,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
             "bpa_sampler_set_species_tree", "bpa_sampler_set_tip_species", "bpa_sampler_set_finetune",
             "bpa_sampler_set_tau_prior", "bpa_sampler_get_taus", "bpa_sampler_get_tree_msc",
+            "bpa_sampler_set_theta_prior", "bpa_sampler_get_thetas",
             "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary"]
 
 
@@ -484,10 +487,19 @@ class Sampler:
     def set_tau_prior(self, alpha, beta):
         lib().bpa_sampler_set_tau_prior(self.h, alpha, beta)
 
+    def set_theta_prior(self, alpha, beta, finetune):
+        lib().bpa_sampler_set_theta_prior(self.h, alpha, beta, finetune)
+
     def taus(self):
         out = np.zeros(getattr(self, "_npop", 0))
         if len(out):
             _chk(lib().bpa_sampler_get_taus(self.h, _dp(out)))
+        return list(out)
+
+    def thetas(self):
+        out = np.zeros(getattr(self, "_npop", 0))
+        if len(out):
+            _chk(lib().bpa_sampler_get_thetas(self.h, _dp(out)))
         return list(out)
 
     def initialize(self):

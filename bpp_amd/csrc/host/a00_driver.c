@@ -34,6 +34,8 @@ struct a00_driver
   unsigned anc[A00_MAXPOP];             /* bit q: q is p or an ancestor of p (stree->pptable) */
   double ft_gage, ft_gspr, ft_tau, ft_mix;
   double tau_alpha, tau_beta;           /* gamma prior on the root tau (0,0: flat) */
+  double theta_alpha, theta_beta, ft_theta;   /* gamma prior on every theta (alpha 0: thetas fixed, no THETA steps) */
+  int has_theta[A00_MAXPOP];
   double * s_logpr;                     /* proposed MSC density per slot */
   double * p_logpr, * p_delta; int * p_slot;     /* all-loci steps: per locus */
   int ** u_pop;
@@ -218,6 +220,14 @@ int a00_set_tip_species(a00_driver_t * d, unsigned i, const int * species)
 }
 
 void a00_set_tau_prior(a00_driver_t * d, double alpha, double beta) { d->tau_alpha = alpha; d->tau_beta = beta; }
+void a00_set_theta_prior(a00_driver_t * d, double alpha, double beta, double finetune)
+{ d->theta_alpha = alpha; d->theta_beta = beta; d->ft_theta = finetune; }
+unsigned a00_get_thetas(const a00_driver_t * d, double * theta)
+{
+  int p;
+  for (p = 0; p < d->npop; ++p) theta[p] = d->theta[p];
+  return (unsigned)d->npop;
+}
 
 /* log prior ratio of the taus when the root tau goes old -> new, the others keeping their place in
    (0, root): gamma(alpha, beta) on the root, uniform Dirichlet below it (propose_tau, stree.c:5655-5657:
@@ -299,6 +309,13 @@ int a00_initialize(a00_driver_t * d)
 {
   unsigned i; int br[MAXN], nd[MAXN];
   if (!d->npop) return 0;                                /* a00_set_species_tree first */
+  /* populations that can hold a coalescence: the inner ones, and a species with two sequences in some locus */
+  { int p; for (p = 0; p < d->npop; ++p) d->has_theta[p] = p >= d->S; }
+  for (i = 0; i < d->nloci; ++i)
+  {
+    int cnt[A00_MAXPOP] = {0}, k;
+    for (k = 0; k < d->trees[i].tips; ++k) if (++cnt[d->trees[i].pop[k]] >= 2) d->has_theta[d->trees[i].pop[k]] = 1;
+  }
   step_begin(d);
   for (i = 0; i < d->nloci; ++i)
   {
@@ -464,6 +481,31 @@ static int gspr_step(a00_driver_t * d, int k)
   return 1;
 }
 
+/* THETA of population p: sliding window reflected at 0, gamma(alpha, beta) prior; only the MSC density
+   changes — no likelihood call; ONE decision from sum(dlogpr) + prior ratio (stree.c:3464-3560 family) */
+static int theta_step(a00_driver_t * d, int p)
+{
+  unsigned i; double sum = 0;
+  const double old = d->theta[p];
+  const double tnew = a00_reflect(old + d->ft_theta*(a00_rndu(&d->grng) - 0.5), 0.0, 999.0);
+  const double uacc = a00_rndu(&d->grng);
+  d->theta[p] = tnew;
+  for (i = 0; i < d->nloci; ++i)
+  {
+    d->p_logpr[i] = tree_logpr(d, d->trees + i);
+    sum += d->p_logpr[i] - d->trees[i].logpr;
+  }
+  sum += (d->theta_alpha - 1)*log(tnew/old) - d->theta_beta*(tnew - old);
+  d->proposals++;
+  if (tnew > 0 && (sum >= 0 || uacc < exp(sum)))
+  {
+    d->accepted++;
+    for (i = 0; i < d->nloci; ++i) d->trees[i].logpr = d->p_logpr[i];
+  }
+  else d->theta[p] = old;
+  return 1;
+}
+
 /* TAU of inner population q: sliding window reflected into (older child's tau, parent's tau); the gene
    nodes of q and of its two children between those bounds move with it (rubber band,
    propose_tau_update_gtrees stree.c:4338-4479); ONE decision for all loci from
@@ -566,6 +608,8 @@ int a00_iterate(a00_driver_t * d)
   for (i = 0; i < d->nloci; ++i) if (d->trees[i].tips > maxtips) maxtips = d->trees[i].tips;
   for (k = 0; k < maxtips - 1; ++k)   if (!gage_step(d, k)) return 0;
   for (k = 0; k < 2*maxtips - 2; ++k) if (!gspr_step(d, k)) return 0;
+  if (d->theta_alpha > 0)
+    for (k = 0; k < d->npop; ++k)     if (d->has_theta[k] && !theta_step(d, k)) return 0;
   for (k = d->S; k < d->npop; ++k)    if (!tau_step(d, k)) return 0;
   return mix_step(d);
 }

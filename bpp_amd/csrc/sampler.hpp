@@ -49,8 +49,8 @@ struct Species
   int32_t  S, npop;
   int8_t   parent[MAXPOP], left[MAXPOP], right[MAXPOP];
   uint16_t anc[MAXPOP];                    // bit q: q is p or an ancestor of p
-  double   theta[MAXPOP], log2theta[MAXPOP];   // log(2/theta) from the host's libm (a00_msc_contrib)
   double   ft_gage, ft_gspr, ft_tau, ft_mix, tau_alpha, tau_beta;
+  double   ft_theta, theta_alpha, theta_beta;
 };
 
 struct TaskLDS
@@ -75,11 +75,11 @@ struct Args
   double * mix_delta;          // [T] this locus's term of the all-loci acceptance ratio
   const uint32_t * mix_flag;   // epoch of the last REJECTED all-loci step
   uint32_t epoch;              // restore from snap when *mix_flag == epoch
-  uint32_t mode;               // 0 sweep (GAGE+GSPR), 1 mix, 2 only settle a pending decision, 3 start-up evaluation, 4 tau
+  uint32_t mode;               // 0 sweep (GAGE+GSPR), 1 mix, 2 only settle a pending decision, 3 start-up evaluation, 4 tau, 5 theta
   uint32_t nsteps_gage, nsteps_gspr;
   double   mix_c, mix_lnc;
-  const double * taus;         // [npop] divergence times (device-resident)
-  uint32_t tau_q;              // population of the TAU step (mode 4)
+  const double * taus;         // device-resident species-tree parameters: [MAXPOP] tau | [MAXPOP] theta | [MAXPOP] log(2/theta)
+  uint32_t tau_q;              // population of the TAU (mode 4) / THETA (mode 5) step
   double   tau_u;              // its window uniform
   double   bfbeta;             // 0 with opt_usedata == 0 (locus.c:2581): the sampler then draws from the MSC prior
   Species  sp;
@@ -210,8 +210,8 @@ __device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau
       prev = tk;
     }
     double c = 0;
-    if (ncoal) c += ncoal*sp.log2theta[p];
-    if (T2h) c -= T2h/(sp.theta[p]*1.0);
+    if (ncoal) c += ncoal*tau[2*MAXPOP + p];
+    if (T2h) c -= T2h/(tau[MAXPOP + p]*1.0);
     S.contrib_new[p] = c;
     logpr += c;
   }
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   __shared__ TaskLDS s_task[TPB];
   __shared__ double  s_clv[MAXBUF][BS][4];
   __shared__ double  s_term[BS];
-  __shared__ double  s_tau[MAXPOP];
+  __shared__ double  s_tau[3*MAXPOP];                    // tau | theta | log(2/theta) of this launch's (proposed) species tree
   const uint32_t b = blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
   const uint32_t t0 = A.blk_task_off[b], ntask = A.blk_task_off[b+1] - t0;
   const uint32_t task = A.lane_task[gl];
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   uint32_t np = 0, tips = 0, n = 0, tipcodes = 0, wgt = 0;
   double f0 = 0, f1 = 0, f2 = 0, f3 = 0, rw = 0, rate = 1;
   double * g_clv = nullptr, * g_pmat = nullptr;
-  if (lane < (uint32_t)MAXPOP) s_tau[lane] = lane < (uint32_t)sp.npop ? A.taus[lane] : 0.0;
+  if (lane < (uint32_t)(3*MAXPOP)) s_tau[lane] = A.taus[lane];
   if (active)
   {
     const LocusDev & L = A.loci[A.task_locus[task]];
@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     wgt = L.weights[n];
     const uint8_t * tp = L.tips;
     for (uint32_t tip = 0; tip < tips; ++tip) tipcodes |= (uint32_t)(tp[(size_t)tip*np + n] & 15u) << (4*tip);
-    const uint32_t nbuf = 2*(tips - 1);
+    const uint32_t nbuf = (A.mode == 2 || A.mode == 5) ? 0u : 2*(tips - 1);        // no likelihood work in those modes
     for (uint32_t c = 0; c < nbuf; ++c)
     {
       const double2 * p = reinterpret_cast<const double2 *>(g_clv + ((size_t)c*np + n)*4);
@@ -428,6 +428,13 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   {
     __syncthreads();
     if (lane < (uint32_t)sp.npop) s_tau[lane] *= A.mix_c;
+  }
+  else if (A.mode == 5)
+  {
+    const double told = s_tau[MAXPOP + A.tau_q];
+    const double tnew = reflect(told + sp.ft_theta*(A.tau_u - 0.5), 0.0, 999.0);
+    __syncthreads();
+    if (lane == 0) { s_tau[MAXPOP + A.tau_q] = tnew; s_tau[2*MAXPOP + A.tau_q] = log(2.0/(1.0*tnew)); }
   }
   if (leader)
   {
@@ -461,6 +468,16 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       bool ok;
       if (A.mode == 0)
         ok = step < A.nsteps_gage ? propose_gage(S, (int)step, rate, sp, s_tau) : propose_gspr(S, (int)(step - A.nsteps_gage), rate, sp, s_tau);
+      else if (A.mode == 5)
+      {
+        // THETA p (theta_step of a00_driver.c): only the density changes, no likelihood work
+        Tree & t = S.tr;
+        A.snap[task] = t;
+        S.logpr_new = tree_logpr(S, sp, s_tau, (1u << sp.npop) - 1u);
+        A.mix_delta[task] = S.logpr_new - t.logpr;
+        t.logpr = S.logpr_new;
+        ok = false;
+      }
       else if (A.mode == 4)
       {
         // TAU q (tau_step of a00_driver.c): the gene nodes of q and its children between the bounds move
@@ -580,7 +597,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     const uint32_t npm = 2*(2*tips - 2);
     for (uint32_t i = 0; i < npm; ++i) { g_pmat[2*i] = S.ab[i][0]; g_pmat[2*i+1] = S.ab[i][1]; }
   }
-  if (active && nprop)
+  if (active && nprop && A.mode != 5)
   {
     const uint32_t nbuf = 2*(tips - 1);
     for (uint32_t c = 0; c < nbuf; ++c)
@@ -595,17 +612,25 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
 // the single decision of an all-loci step (tau_step / mix_step of a00_driver.c; stree.c:6280,
 // prop_mixing.c:203-205): flag := epoch when REJECTED; on acceptance the device-resident taus follow
 __global__ void decide_kernel(const double * __restrict__ sum, double u, uint32_t epoch, uint32_t * flag,
-                              uint32_t * counters, double * taus, Species sp, int tau_q, double tau_u,
+                              uint32_t * counters, double * taus, Species sp, int tau_q, int theta_p, double win_u,
                               double mix_c, double mix_lnc)
 {
   if (threadIdx.x || blockIdx.x) return;
   double lnacc = sum[0], tnew = 0;
   const int root = sp.npop - 1;
-  if (tau_q >= 0)
+  bool valid = true;
+  if (theta_p >= 0)
+  {
+    const double old = taus[MAXPOP + theta_p];
+    tnew = reflect(old + sp.ft_theta*(win_u - 0.5), 0.0, 999.0);
+    lnacc += (sp.theta_alpha - 1)*log(tnew/old) - sp.theta_beta*(tnew - old);
+    valid = tnew > 0;
+  }
+  else if (tau_q >= 0)
   {
     const int pq = sp.parent[tau_q];
     const double old = taus[tau_q], lo = fmax(taus[sp.left[tau_q]], taus[sp.right[tau_q]]), hi = pq >= 0 ? taus[pq] : 999.0;
-    tnew = reflect(old + sp.ft_tau*(tau_u - 0.5), lo, hi);
+    tnew = reflect(old + sp.ft_tau*(win_u - 0.5), lo, hi);
     if (pq < 0 && sp.tau_alpha > 0) lnacc += (sp.tau_alpha - 1 - (sp.S - 1) + 1)*log(tnew/old) - sp.tau_beta*(tnew - old);
   }
   else
@@ -614,10 +639,11 @@ __global__ void decide_kernel(const double * __restrict__ sum, double u, uint32_
     if (sp.tau_alpha > 0)
       lnacc += (sp.tau_alpha - 1)*mix_lnc - sp.tau_beta*(taus[root]*mix_c - taus[root]) - (double)(sp.S - 2)*mix_lnc;
   }
-  const bool accept = lnacc >= 0 || u < exp(lnacc);
+  const bool accept = valid && (lnacc >= 0 || u < exp(lnacc));
   counters[0] += 1; counters[1] += accept ? 1u : 0u;
   if (!accept) { *flag = epoch; return; }
-  if (tau_q >= 0) taus[tau_q] = tnew;
+  if (theta_p >= 0) { taus[MAXPOP + theta_p] = tnew; taus[2*MAXPOP + theta_p] = log(2.0/(1.0*tnew)); }
+  else if (tau_q >= 0) taus[tau_q] = tnew;
   else for (int p = 0; p < sp.npop; ++p) taus[p] *= mix_c;
 }
 
@@ -633,6 +659,7 @@ struct bpa_sampler
   DevBuf<smp::Tree> trees, snap;
   DevBuf<double> mix_delta, mix_sum, taus;
   smp::Species sp{};                    // species tree (host copy; the taus below are only the start values)
+  bool has_theta[smp::MAXPOP] = {};     // populations that can hold a coalescence (a00_initialize)
   std::vector<double> h_taus;
   std::vector<smp::Tree> h_trees;
   unsigned nblocks = 0, epoch = 0;
@@ -723,6 +750,13 @@ static int sampler_upload(bpa_sampler * s)
       t.pop[v] = (int8_t)c;
     }
   }
+  for (int p = 0; p < smp::MAXPOP; ++p) s->has_theta[p] = p >= s->sp.S && p < s->sp.npop;
+  for (unsigned i = 0; i < T; ++i)
+  {
+    int cnt[smp::MAXPOP] = {0};
+    const smp::Tree & t = s->h_trees[i];
+    for (int k = 0; k < t.tips; ++k) if (++cnt[t.pop[k]] >= 2) s->has_theta[t.pop[k]] = true;
+  }
   std::vector<uint32_t> locus(T), blk_off{0}, lane_task, lane0(T);
   unsigned used = 0, ntask = 0;
   for (unsigned t = 0; t < T; ++t)
@@ -797,12 +831,15 @@ extern "C" int bpa_sampler_set_species_tree(bpa_sampler_t * s, int species, cons
                                   "with theta > 0 and tau increasing towards the root");
   }
   sp.S = species; sp.npop = np;
-  for (int p = 0; p < smp::MAXPOP; ++p) { sp.parent[p] = sp.left[p] = sp.right[p] = -1; sp.anc[p] = 0; sp.theta[p] = 1; sp.log2theta[p] = 0; }
-  s->h_taus.assign(smp::MAXPOP, 0.0);
+  for (int p = 0; p < smp::MAXPOP; ++p) { sp.parent[p] = sp.left[p] = sp.right[p] = -1; sp.anc[p] = 0; }
+  s->h_taus.assign(3*smp::MAXPOP, 0.0);
+  for (int p = 0; p < smp::MAXPOP; ++p) s->h_taus[smp::MAXPOP + p] = 1.0;
   for (int p = 0; p < np; ++p)
   {
-    sp.parent[p] = (int8_t)parent[p]; sp.theta[p] = theta[p]; sp.log2theta[p] = std::log(2.0/(1.0*theta[p]));
+    sp.parent[p] = (int8_t)parent[p];
     s->h_taus[p] = tau[p];
+    s->h_taus[smp::MAXPOP + p] = theta[p];
+    s->h_taus[2*smp::MAXPOP + p] = std::log(2.0/(1.0*theta[p]));      // the host driver's libm value (a00_msc_contrib)
   }
   for (int p = 0; p < np - 1; ++p)
   {
@@ -833,6 +870,21 @@ extern "C" void bpa_sampler_set_finetune(bpa_sampler_t * s, double gage, double 
 extern "C" void bpa_sampler_set_tau_prior(bpa_sampler_t * s, double alpha, double beta)
 { s->sp.tau_alpha = alpha; s->sp.tau_beta = beta; }
 
+extern "C" void bpa_sampler_set_theta_prior(bpa_sampler_t * s, double alpha, double beta, double finetune)
+{ s->sp.theta_alpha = alpha; s->sp.theta_beta = beta; s->sp.ft_theta = finetune; }
+
+extern "C" int bpa_sampler_get_thetas(bpa_sampler_t * s, double * theta)
+{
+  bpa_engine * e = s->eng;
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  if (!set_device(e)) return 0;
+  const size_t np = (size_t)s->sp.npop;
+  if (!s->uploaded) { for (size_t i = 0; i < np; ++i) theta[i] = s->h_taus[smp::MAXPOP + i]; return (int)np; }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(theta, s->taus.p + smp::MAXPOP, np*sizeof(double), hipMemcpyDeviceToHost));
+  return (int)np;
+}
+
 extern "C" int bpa_sampler_get_taus(bpa_sampler_t * s, double * taus)
 {
   bpa_engine * e = s->eng;
@@ -861,6 +913,19 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
   {
     if (!sampler_launch(s, 0, 1.0)) return 0;                    // GAGE + GSPR of every locus (settles a pending mix first)
     if (getenv("BPA_SMP_NOMIX")) continue;
+    if (s->sp.theta_alpha > 0)
+      for (int p = 0; p < s->sp.npop; ++p)                        // one THETA step per population that can hold a coalescence
+      {
+        if (!s->has_theta[p]) continue;
+        const double uprop = a00_rndu(&s->grng), uacc_t = a00_rndu(&s->grng);
+        if (!sampler_launch(s, 5, 1.0, 0.0, (unsigned)p, uprop)) return 0;
+        hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, s->mix_sum.p);
+        s->epoch++;
+        hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, uacc_t, s->epoch, s->flag.p,
+                           s->counters.p, s->taus.p, s->sp, -1, p, uprop, 1.0, 0.0);
+        HIPCHK(hipGetLastError());
+        s->mix_pending = true;
+      }
     for (int q = s->sp.S; q < s->sp.npop; ++q)                    // one rubber-band step per species divergence
     {
       const double uprop = a00_rndu(&s->grng), uacc_t = a00_rndu(&s->grng);
@@ -868,7 +933,7 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
       hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, s->mix_sum.p);
       s->epoch++;
       hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, uacc_t, s->epoch, s->flag.p,
-                         s->counters.p, s->taus.p, s->sp, q, uprop, 1.0, 0.0);
+                         s->counters.p, s->taus.p, s->sp, q, -1, uprop, 1.0, 0.0);
       HIPCHK(hipGetLastError());
       s->mix_pending = true;
     }
@@ -878,7 +943,7 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
     hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, s->mix_sum.p);
     s->epoch++;
     hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, uacc, s->epoch, s->flag.p,
-                       s->counters.p, s->taus.p, s->sp, -1, 0.0, c, lnc);
+                       s->counters.p, s->taus.p, s->sp, -1, -1, 0.0, c, lnc);
     HIPCHK(hipGetLastError());
     s->mix_pending = true;
   }

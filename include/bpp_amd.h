@@ -226,6 +226,8 @@ int  bpa_sampler_set_species_tree(bpa_sampler_t *, int species, const int * pare
 int  bpa_sampler_set_tip_species(bpa_sampler_t *, unsigned i, const int * species);   /* default: tip k = species k */
 void bpa_sampler_set_finetune(bpa_sampler_t *, double gage, double gspr, double tau, double mix);
 void bpa_sampler_set_tau_prior(bpa_sampler_t *, double alpha, double beta);           /* a00_set_tau_prior */
+void bpa_sampler_set_theta_prior(bpa_sampler_t *, double alpha, double beta, double finetune); /* a00_set_theta_prior */
+int  bpa_sampler_get_thetas(bpa_sampler_t *, double * theta); /* 2*species-1 entries; returns their number */
 int  bpa_sampler_get_taus(bpa_sampler_t *, double * tau);     /* 2*species-1 entries; returns their number */
 int  bpa_sampler_initialize(bpa_sampler_t *);                 /* all matrices, partials, lnL */
 int  bpa_sampler_iterate(bpa_sampler_t *, unsigned iterations); /* asynchronous on the engine stream */

@@ -28,8 +28,9 @@
  * Acceptance: Metropolis-Hastings on  MSC density x likelihood.  The MSC density of a gene tree is
  * gtree_logprob (gtree.c:3957) = the sum over populations of gtree_update_logprob_contrib
  * (gtree.c:3859), a00_msc_logpr below, bit-equal to the reference's (tests/test_msc_density.py).
- * The taus carry BPP's gamma/Dirichlet prior (a00_set_tau_prior); thetas are fixed — theta moves are
- * model-space logic outside the likelihood path.
+ * The taus carry BPP's gamma/Dirichlet prior (a00_set_tau_prior) and the thetas BPP's gamma prior with a
+ * THETA step per population (a00_set_theta_prior): with both on, the sampler targets the A00 posterior
+ * of BPP (species tree fixed, JC69 or whatever the back-end's loci use).
  */
 #ifndef BPP_AMD_HOST_H
 #define BPP_AMD_HOST_H
@@ -109,6 +110,10 @@ void           a00_set_finetune(a00_driver_t *, double gage, double gspr, double
 /* prior on the divergence times as BPP's 'tauprior = gamma a b': gamma(alpha, beta) on the root tau, the
    others uniform below it (stree.c:5655-5657); alpha = 0 (default): flat */
 void           a00_set_tau_prior(a00_driver_t *, double alpha, double beta);
+/* thetas: BPP's 'thetaprior = gamma a b' with a sliding-window THETA step per population that can hold a
+   coalescence, after the gene-tree moves of every iteration; alpha = 0 (default): thetas stay fixed */
+void           a00_set_theta_prior(a00_driver_t *, double alpha, double beta, double finetune);
+unsigned       a00_get_thetas(const a00_driver_t *, double * theta);
 /* current tau[] (2*species-1 entries); returns the number of populations */
 unsigned       a00_get_taus(const a00_driver_t *, double * tau);
 /* MSC density of the current gene tree of locus i, recomputed from scratch */
@@ -150,7 +155,8 @@ static inline double a00_msc_contrib(double tau, double ptau, double theta, doub
 }
 /* start-up evaluation: all matrices, all partials, lnL (method.c:4285-4297) */
 int            a00_initialize(a00_driver_t *);
-/* one iteration: GAGE over inner nodes, GSPR over non-root nodes, one TAU step per inner population, one MIX step */
+/* one iteration: GAGE over inner nodes, GSPR over non-root nodes, THETA per population (if a prior is set),
+   one TAU step per inner population, one MIX step */
 int            a00_iterate(a00_driver_t *);
 double         a00_total_lnl(const a00_driver_t *);
 void           a00_counters(const a00_driver_t *, unsigned long * proposals, unsigned long * accepted,

@@ -42,6 +42,9 @@ def lib():
         L.a00_set_tip_species.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_int)]
         L.a00_set_finetune.argtypes = [C.c_void_p] + [C.c_double] * 4
         L.a00_set_tau_prior.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.a00_set_theta_prior.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.a00_get_thetas.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.a00_get_thetas.restype = C.c_uint
         L.a00_locus_logpr.restype = C.c_double
         L.a00_locus_logpr.argtypes = [C.c_void_p, C.c_uint]
         L.a00_get_taus.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -84,6 +87,14 @@ class Driver:
 
     def set_tau_prior(self, alpha, beta):
         lib().a00_set_tau_prior(self.h, alpha, beta)
+
+    def set_theta_prior(self, alpha, beta, finetune):
+        lib().a00_set_theta_prior(self.h, alpha, beta, finetune)
+
+    def thetas(self):
+        a = (C.c_double * 15)()
+        n = lib().a00_get_thetas(self.h, a)
+        return [a[i] for i in range(n)]
 
     def taus(self):
         a = (C.c_double * 15)()

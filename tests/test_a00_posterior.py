@@ -1,0 +1,84 @@
+"""End-to-end known answer: the posterior of the UNMODIFIED reference program (bpp A00, JC69; fixture
+tests/golden/a00_posterior.json from tests/golden/make_golden_a00.py) on a synthetic 30-locus data set,
+against this repo's sampler on the same data and priors (thetaprior gamma 2 500, tauprior gamma 2 400).
+Different proposal kernels and random numbers, same target: means and spreads of every theta, every tau
+and the log-likelihood must agree within Monte-Carlo error.
+
+ * CPU: the C host driver on the REAL reference's locus API (skipped where oracle/_ref is absent);
+ * GPU: the device-resident sampler (bpa_sampler_t) — every proposal, density and decision on the device.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from bpp_amd import synth
+import oraclelib as O
+import hostdrv
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NAMES = ["theta_AB", "theta_ABC", "theta_root", "tau_AB", "tau_ABC", "tau_root", "lnL"]
+
+
+def setup(drv, gold):
+    c = gold["config"]
+    parent, tau, thetas = synth.species_tree_arrays(c["taxa"], c["theta"])
+    drv.set_species_tree(parent, tau, thetas)
+    drv.set_tau_prior(*c["tau_prior"])
+    drv.set_theta_prior(c["theta_prior"][0], c["theta_prior"][1], 0.004)
+    drv.set_finetune(0.004, 0.004, 0.0012, 0.3)
+
+
+def compare(samples, gold):
+    S = np.array(samples)
+    for k, nm in enumerate(NAMES):
+        ref = gold["posterior"][nm]
+        x = S[:, k]
+        tol = 0.25 * ref["sd"] if nm != "lnL" else 0.2 * ref["sd"]      # a quarter of a posterior sd: MC error of both chains
+        assert abs(x.mean() - ref["mean"]) < tol, (nm, x.mean(), ref["mean"])
+        assert abs(x.std() - ref["sd"]) < 0.2 * ref["sd"], (nm, x.std(), ref["sd"])
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return json.load(open(os.path.join(HERE, "golden", "a00_posterior.json")))
+
+
+def dataset(gold):
+    c = gold["config"]
+    return synth.make_dataset(c["nloci"], c["sites"], c["taxa"], "jc69", 1, seed=c["seed"], theta=c["theta"])
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_host_driver_on_reference_backend_reproduces_bpp_posterior(gold):
+    data = dataset(gold)
+    drv = hostdrv.reference_driver(data, seed=5)
+    setup(drv, gold)
+    drv.initialize()
+    S = []
+    for it in range(16000):
+        drv.iterate()
+        if it >= 3000 and it % 2 == 0:
+            S.append(drv.thetas()[4:] + drv.taus()[4:] + [drv.total_lnl()])
+    compare(S, gold)
+    drv.close()
+
+
+@pytest.mark.gpu
+def test_device_sampler_reproduces_bpp_posterior(gold):
+    import bpp_amd
+    import tape
+    data = dataset(gold)
+    eng = bpp_amd.Engine(0)
+    loci = tape.make_engine_loci(eng, data)
+    dev = bpp_amd.Sampler(eng, loci, data, seed=9)
+    setup(dev, gold)
+    dev.initialize()
+    dev.iterate(3000)
+    S = []
+    for _ in range(6500):
+        dev.iterate(2)
+        S.append(dev.thetas()[4:] + dev.taus()[4:] + [dev.summary()["total_lnl"]])
+    compare(S, gold)
+    dev.close(); eng.close()

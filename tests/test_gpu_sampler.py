@@ -28,6 +28,7 @@ def test_sampler_equals_host_driver(taxa, nloci, iters):
     for drv in (host, dev):
         drv.set_species_tree(parent, tau0, thetas)
         drv.set_tau_prior(3.0, 3.0 / tau0[-1])
+        drv.set_theta_prior(2.0, 1000.0, 0.001)
         drv.set_finetune(0.003, 0.005, 0.0008, 0.2)
     host.initialize(); dev.initialize()
     s = dev.summary()
@@ -39,6 +40,8 @@ def test_sampler_equals_host_driver(taxa, nloci, iters):
         assert (s["proposals"], s["accepted"]) == (hp, ha), it
         assert rel(s["total_lnl"], host.total_lnl()) < 1e-11, it
     assert np.allclose(dev.taus(), host.taus(), rtol=1e-12, atol=0) and dev.taus() != list(tau0)
+    assert np.allclose(dev.thetas(), host.thetas(), rtol=1e-12, atol=0) and dev.thetas() != list(thetas)
+    assert dev.thetas()[:taxa] == list(thetas[:taxa])          # one sequence per species: those thetas never move
     for i in range(nloci):
         a, b = dev.tree(i), host.tree(i)
         assert a["root"] == b["root"]
@@ -55,7 +58,7 @@ def test_sampler_equals_host_driver(taxa, nloci, iters):
         assert rel(have, full) < 1e-12 and rel(t["lnl"], full) < 1e-12
         assert rel(t["logpr"], host.logpr(i)) < 1e-11
     # 4 launches per iteration instead of 3 tips - 2 host round trips
-    assert dev.summary()["launches"] <= 1 + (2 + taxa - 1) * iters + 2 * (iters + 2) + nloci
+    assert dev.summary()["launches"] <= 1 + (2 + 2 * (taxa - 1)) * iters + 2 * (iters + 2) + nloci
     host.close(); dev.close(); eng.close()
 
 

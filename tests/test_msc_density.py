@@ -162,3 +162,31 @@ def test_joint_prior_of_taus_and_gene_trees():
     assert abs(root.std() - np.sqrt(alpha) / beta) < 0.12 * np.sqrt(alpha) / beta, root.std()
     assert abs((s[:, 1] / root).mean() - 2 / 3) < 0.03 and abs((s[:, 0] / root).mean() - 1 / 3) < 0.03
     drv.close()
+
+
+def test_theta_moves_reproduce_the_theta_prior():
+    """no data: the gene trees integrate out of MSC(G | theta, tau), so every theta that can hold a coalescence
+    must come out with its gamma prior's moments (the THETA step's density ratio over all loci and the prior
+    ratio), jointly with moving taus and gene trees"""
+    taxa, nloci, a, b = 4, 3, 8.0, 2000.0
+    rng = np.random.default_rng(4)
+    parent, tau, thetas = synth.species_tree_arrays(taxa, 0.004)
+    start = [synth._msc_gene_tree(synth.SPECIES_TREES[taxa], 0.004, rng) for _ in range(nloci)]
+    data = [dict(seqs=["A"] * taxa, left=l, right=r, times=t, root=rt) for l, r, t, rt in start]
+    drv = hostdrv.prior_driver(data, seed=31)
+    drv.set_species_tree(parent, tau, thetas)
+    drv.set_tau_prior(12.0, 3000.0)
+    drv.set_theta_prior(a, b, 0.006)
+    drv.set_finetune(0.01, 0.01, 0.003, 0.8)
+    drv.initialize()
+    th = []
+    for it in range(16000):
+        drv.iterate()
+        if it >= 500:
+            th.append(drv.thetas())
+    th = np.array(th)
+    assert (th[:, :taxa] == 0.004).all()                    # one sequence per species: no theta there, never moved
+    for p in range(taxa, 2 * taxa - 1):
+        assert abs(th[:, p].mean() - a / b) < 0.05 * a / b, (p, th[:, p].mean())
+        assert abs(th[:, p].std() - np.sqrt(a) / b) < 0.12 * np.sqrt(a) / b, (p, th[:, p].std())
+    drv.close()
