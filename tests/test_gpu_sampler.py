@@ -62,6 +62,58 @@ def test_sampler_equals_host_driver(taxa, nloci, iters):
     host.close(); dev.close(); eng.close()
 
 
+def test_several_sequences_per_species():
+    """two species with three sequences each: tip populations hold coalescences (and a theta that moves),
+    gene nodes cross the species boundary both ways; device == host driver, step for step"""
+    eng = bpp_amd.Engine(0)
+    rng = np.random.default_rng(8)
+    nloci, tips = 120, 6
+    species = [0, 0, 0, 1, 1, 1]
+    parent, tau0, thetas = [2, 2, -1], [0.0, 0.0, 0.003], [0.002, 0.003, 0.004]
+    data = []
+    for _ in range(nloci):
+        # ((a1,a2),a3) and ((b1,b2),b3) inside their species or deeper, joined above the divergence
+        t = sorted(rng.uniform(0.0002, 0.0028, 4))
+        left = [-1] * 6 + [0, 6, 3, 8, 7]
+        right = [-1] * 6 + [1, 2, 4, 5, 9]
+        times = [0.0] * 6 + [t[0], t[2], t[1], t[3], 0.003 + rng.uniform(0.0005, 0.004)]
+        seqs = ["".join(rng.choice(list("ACGT"), 60)) for _ in range(2)]
+        seqs = [seqs[0]] * 3 + [seqs[1]] * 3
+        seqs = ["".join(c if rng.random() > 0.05 else rng.choice(list("ACGT")) for c in s) for s in seqs]
+        pats, w = bpp_amd.compress_site_patterns(seqs, True, True)
+        data.append(dict(seqs=pats, weights=w, left=left, right=right, times=times, root=10, states=4, rate_cats=1,
+                         model="jc69", rates=np.ones(1)))
+    loci_a = tape.make_engine_loci(eng, data)
+    loci_b = tape.make_engine_loci(eng, data)
+    host = hostdrv.hip_driver(eng, loci_a, data, seed=4)
+    dev = bpp_amd.Sampler(eng, loci_b, data, seed=4)
+    for drv in (host, dev):
+        drv.set_species_tree(parent, tau0, thetas)
+        for i in range(nloci):
+            drv.set_tip_species(i, species)
+        drv.set_tau_prior(3.0, 1000.0)
+        drv.set_theta_prior(2.0, 700.0, 0.002)
+        drv.set_finetune(0.003, 0.004, 0.0008, 0.2)
+    host.initialize(); dev.initialize()
+    for it in range(8):
+        host.iterate(); dev.iterate(1)
+        s = dev.summary()
+        hp, ha, _ = host.counters()
+        assert (s["proposals"], s["accepted"]) == (hp, ha), it
+    assert np.allclose(dev.thetas(), host.thetas(), rtol=1e-12, atol=0) and all(a != b for a, b in zip(dev.thetas(), thetas))
+    assert np.allclose(dev.taus(), host.taus(), rtol=1e-12, atol=0)
+    moved = 0
+    for i in range(nloci):
+        a, b = dev.tree(i), host.tree(i)
+        for key in ("left", "right", "parent", "clv", "pmat", "pop"):
+            assert [int(x) for x in a[key]] == [int(x) for x in b[key]], (i, key)
+        assert np.allclose(a["time"], b["time"], rtol=1e-12, atol=0)
+        assert rel(a["logpr"], b["logpr"]) < 1e-11 and rel(a["lnl"], b["lnl"]) < 1e-11
+        moved += sum(int(x) == 2 for x in a["pop"][6:]) != 1          # more than the root node above the divergence
+    assert moved > 0
+    host.close(); dev.close(); eng.close()
+
+
 def test_device_sampler_draws_from_the_msc_prior():
     """usedata = 0 (bpa_engine_set_options: lnL = 0, locus.c:2581): the device sampler's gene trees must
     follow the multispecies coalescent — node-age moments against direct simulation"""
