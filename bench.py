@@ -361,8 +361,16 @@ def main():
     # ---- extra (not `value`): the same loci under device-resident proposal control — a real sampler
     # (proposals, accept/reject, rollback on the device; bpa_sampler_t), 4 launches per iteration
     sampler = None
-    if world == 1 and args.config == "c2" and not args.no_sampler:
+    if args.config == "c2" and not args.no_sampler:
         smp = bpp_amd.Sampler(eng, loci, data, seed=1)
+        if world > 1:
+            # loci sharded, one all-reduced double per THETA / TAU / MIX step (RCCL on the engine's stream)
+            smp_sum = torch.zeros(1, dtype=torch.float64, device=f"cuda:{local_rank}")
+
+            def smp_allreduce(ptr, stream):
+                dist.all_reduce(smp_sum)
+                return True
+            smp.set_allreduce(smp_allreduce, smp_sum.data_ptr(), rank * nloci)
         sp_parent, sp_tau, sp_theta = synth.species_tree_arrays(cfg["taxa"])
         smp_taus = sp_tau[cfg["taxa"]:]
         smp.set_species_tree(sp_parent, sp_tau, sp_theta)
@@ -371,12 +379,19 @@ def main():
         smp.initialize()
         smp.iterate(args.warmup)
         eng.synchronize()
+        if world > 1:
+            dist.barrier()
         t0 = time.perf_counter()
         smp.iterate(args.steps)
         eng.synchronize()
         dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
         sm = smp.summary()
-        sampler = dict(iterations_per_s=round(args.steps / dt * nloci / 10000.0, 1), ms_per_iteration=round(1e3 * dt / args.steps, 4),
+        sampler = dict(iterations_per_s=round(args.steps / dt * nloci * world / 10000.0, 1), ms_per_iteration=round(1e3 * dt / args.steps, 4),
+                       n_gpus=world,
                        launches_per_iteration=4 + 6 * len(smp_taus), proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
                        acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
                        taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],

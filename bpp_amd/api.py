@@ -110,6 +110,7 @@ def lib():
         "bpa_sampler_set_tau_prior": (None, [vp, d, d]),
         "bpa_sampler_set_theta_prior": (None, [vp, d, d, d]),
         "bpa_sampler_get_thetas": (i, [vp, dp]),
+        "bpa_sampler_set_allreduce": (i, [vp, vp, vp, vp, u]),
         "bpa_sampler_get_taus": (i, [vp, dp]),
         "bpa_sampler_get_tree_msc": (i, [vp, u, C.POINTER(i), dp]),
         "bpa_sampler_initialize": (i, [vp]),
@@ -145,7 +146,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
             "bpa_sampler_set_species_tree", "bpa_sampler_set_tip_species", "bpa_sampler_set_finetune",
             "bpa_sampler_set_tau_prior", "bpa_sampler_get_taus", "bpa_sampler_get_tree_msc",
-            "bpa_sampler_set_theta_prior", "bpa_sampler_get_thetas",
+            "bpa_sampler_set_theta_prior", "bpa_sampler_get_thetas", "bpa_sampler_set_allreduce",
             "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary"]
 
 
@@ -489,6 +490,13 @@ class Sampler:
 
     def set_theta_prior(self, alpha, beta, finetune):
         lib().bpa_sampler_set_theta_prior(self.h, alpha, beta, finetune)
+
+    def set_allreduce(self, fn, device_sum_ptr, first_locus):
+        """fn(device_ptr:int, stream:int) -> truthy; enqueues the sum all-reduce of the device double (section 8e)"""
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+        self._ar = proto(lambda ctx, p, st: 1 if fn(p, st) else 0)
+        _chk(lib().bpa_sampler_set_allreduce(self.h, C.cast(self._ar, C.c_void_p), None,
+                                             C.c_void_p(device_sum_ptr), first_locus))
 
     def taus(self):
         out = np.zeros(getattr(self, "_npop", 0))

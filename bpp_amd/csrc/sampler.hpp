@@ -660,6 +660,10 @@ struct bpa_sampler
   DevBuf<double> mix_delta, mix_sum, taus;
   smp::Species sp{};                    // species tree (host copy; the taus below are only the start values)
   bool has_theta[smp::MAXPOP] = {};     // populations that can hold a coalescence (a00_initialize)
+  bpa_allreduce_fn allreduce = nullptr; // several GPUs: sum the all-loci steps' device scalar over the ranks
+  void * allreduce_ctx = nullptr;
+  double * sum_ext = nullptr;           // caller-owned device scalar for that sum (NULL: internal)
+  unsigned locus_offset = 0;            // global index of this rank's first locus (random streams)
   std::vector<double> h_taus;
   std::vector<smp::Tree> h_trees;
   unsigned nblocks = 0, epoch = 0;
@@ -720,7 +724,7 @@ extern "C" int bpa_sampler_set_tree(bpa_sampler_t * s, unsigned i, const int * l
     t.left[k] = (int8_t)left[k]; t.right[k] = (int8_t)right[k]; t.time[k] = times[k];
     if (left[k] >= 0) { t.parent[left[k]] = (int8_t)k; t.parent[right[k]] = (int8_t)k; }
   }
-  t.root = root; t.tips = tips; t.rng = a00_rng_seed(s->seed, i); t.lnl = 0;
+  t.root = root; t.tips = tips; t.rng = a00_rng_seed(s->seed, s->locus_offset + i); t.lnl = 0;
   s->uploaded = false;
   return 1;
 }
@@ -904,6 +908,31 @@ extern "C" int bpa_sampler_initialize(bpa_sampler_t * s)
   return sampler_launch(s, 3, 1.0);
 }
 
+// the all-loci steps' acceptance term: summed over this rank's loci on the device, then over the ranks
+static int sampler_sum(bpa_sampler * s)
+{
+  bpa_engine * e = s->eng;
+  double * out = s->sum_ext ? s->sum_ext : s->mix_sum.p;
+  hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, out);
+  HIPCHK(hipGetLastError());
+  if (s->allreduce && !s->allreduce(s->allreduce_ctx, out, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
+  return 1;
+}
+
+extern "C" int bpa_sampler_set_allreduce(bpa_sampler_t * s, bpa_allreduce_fn fn, void * ctx, double * device_sum,
+                                         unsigned first_locus)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  s->allreduce = fn; s->allreduce_ctx = ctx; s->sum_ext = device_sum;
+  if (first_locus != s->locus_offset)
+  {
+    s->locus_offset = first_locus;
+    for (unsigned i = 0; i < s->nloci; ++i) s->h_trees[i].rng = a00_rng_seed(s->seed, first_locus + i);
+    s->uploaded = false;
+  }
+  return 1;
+}
+
 extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
 {
   bpa_engine * e = s->eng;
@@ -919,9 +948,9 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
         if (!s->has_theta[p]) continue;
         const double uprop = a00_rndu(&s->grng), uacc_t = a00_rndu(&s->grng);
         if (!sampler_launch(s, 5, 1.0, 0.0, (unsigned)p, uprop)) return 0;
-        hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, s->mix_sum.p);
+        if (!sampler_sum(s)) return 0;
         s->epoch++;
-        hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, uacc_t, s->epoch, s->flag.p,
+        hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->sum_ext ? s->sum_ext : s->mix_sum.p, uacc_t, s->epoch, s->flag.p,
                            s->counters.p, s->taus.p, s->sp, -1, p, uprop, 1.0, 0.0);
         HIPCHK(hipGetLastError());
         s->mix_pending = true;
@@ -930,9 +959,9 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
     {
       const double uprop = a00_rndu(&s->grng), uacc_t = a00_rndu(&s->grng);
       if (!sampler_launch(s, 4, 1.0, 0.0, (unsigned)q, uprop)) return 0;
-      hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, s->mix_sum.p);
+      if (!sampler_sum(s)) return 0;
       s->epoch++;
-      hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, uacc_t, s->epoch, s->flag.p,
+      hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->sum_ext ? s->sum_ext : s->mix_sum.p, uacc_t, s->epoch, s->flag.p,
                          s->counters.p, s->taus.p, s->sp, q, -1, uprop, 1.0, 0.0);
       HIPCHK(hipGetLastError());
       s->mix_pending = true;
@@ -940,9 +969,9 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
     const double lnc = s->sp.ft_mix*(a00_rndu(&s->grng) - 0.5), c = std::exp(lnc);
     const double uacc = a00_rndu(&s->grng);
     if (!sampler_launch(s, 1, c, lnc)) return 0;                 // mixing proposal of every locus
-    hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, s->mix_sum.p);
+    if (!sampler_sum(s)) return 0;
     s->epoch++;
-    hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->mix_sum.p, uacc, s->epoch, s->flag.p,
+    hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->sum_ext ? s->sum_ext : s->mix_sum.p, uacc, s->epoch, s->flag.p,
                        s->counters.p, s->taus.p, s->sp, -1, -1, 0.0, c, lnc);
     HIPCHK(hipGetLastError());
     s->mix_pending = true;

@@ -1,0 +1,56 @@
+"""one rank of the sharded device-resident sampler (tests/test_gpu_dist_sampler.py): its contiguous share of the
+loci, the all-loci steps' sum all-reduced through torch.distributed (gloo here so that two ranks can share the
+one GPU of the test box; bench.py uses nccl = RCCL)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+
+def main():
+    rank, world, out = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[1]
+    import torch
+    import torch.distributed as dist
+    import bpp_amd
+    from bpp_amd import synth
+    import tape
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    data = synth.make_dataset(160, 300, 4, "jc69", 1, seed=3)
+    per = len(data) // world
+    first = rank * per
+    mine = data[first:first + per]
+    eng = bpp_amd.Engine(0)
+    loci = tape.make_engine_loci(eng, mine)
+    smp = bpp_amd.Sampler(eng, loci, mine, seed=7)
+    t = torch.zeros(1, dtype=torch.float64, device="cuda")
+
+    def allreduce(ptr, stream):
+        eng.synchronize()                       # gloo is host-driven: the device sum must be complete
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        return True
+    if world > 1:
+        smp.set_allreduce(allreduce, t.data_ptr(), first)
+    parent, tau, theta = synth.species_tree_arrays(4)
+    smp.set_species_tree(parent, tau, theta)
+    smp.set_tau_prior(3.0, 1000.0)
+    smp.set_theta_prior(2.0, 1000.0, 0.001)
+    smp.set_finetune(0.003, 0.005, 0.0008, 0.2)
+    smp.initialize()
+    smp.iterate(12)
+    res = dict(rank=rank, first=first, taus=smp.taus(), thetas=smp.thetas(), summary=smp.summary(),
+               times=[[float(x) for x in smp.tree(i)["time"]] for i in range(per)],
+               lnl=[smp.tree(i)["lnl"] for i in range(per)])
+    with open(f"{out}.{rank}.json", "w") as f:
+        json.dump(res, f)
+    smp.close(); eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

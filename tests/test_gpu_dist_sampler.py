@@ -1,0 +1,41 @@
+"""SURVEY.md section 8(e) for the device-resident sampler: loci sharded over ranks, ONE all-reduced double per
+all-loci step (THETA, TAU, MIX), nothing else exchanged; same seed on every rank.  Two ranks (sharing the test
+box's single GPU, gloo) must walk the single-rank trajectory: same taus, thetas, gene trees."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run(world, out, port):
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_sampler_worker.py"), out], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    return [json.load(open(f"{out}.{r}.json")) for r in range(world)]
+
+
+def test_two_ranks_walk_the_single_rank_trajectory(tmp_path):
+    one = run(1, str(tmp_path / "one"), 29611)[0]
+    two = run(2, str(tmp_path / "two"), 29612 + os.getpid() % 500)
+    for r in two:
+        assert np.allclose(r["taus"], one["taus"], rtol=1e-10, atol=0) and r["taus"] != [0, 0, 0, 0, 0.001, 0.002, 0.003]
+        assert np.allclose(r["thetas"], one["thetas"], rtol=1e-10, atol=0)
+    assert two[0]["taus"] == two[1]["taus"] and two[0]["thetas"] == two[1]["thetas"]      # replicated decisions
+    times = two[0]["times"] + two[1]["times"]
+    lnl = two[0]["lnl"] + two[1]["lnl"]
+    assert len(times) == len(one["times"])
+    for a, b in zip(times, one["times"]):
+        assert np.allclose(a, b, rtol=1e-10, atol=0)
+    assert np.allclose(lnl, one["lnl"], rtol=1e-10, atol=0)
+    tot = sum(r["summary"]["total_lnl"] for r in two)
+    assert abs(tot - one["summary"]["total_lnl"]) < 1e-9 * abs(tot)
