@@ -137,6 +137,7 @@ struct bpa_plan
   unsigned ntiles = 0, tile = 128;    // tiled 20-state path
   bool s20_mfma = false, s20_scalarp = false, s20_tiledk = true;
   std::string s20_kernel;
+  bool fused_klane = false;
   DevBuf<MatRec>   mat_recs;
   bool fused_jc69 = false;            // JC69, one rate category: the latency-optimised kernel
   unsigned fused_rt = 0;              // compile-time rate-category count of the fused kernel (0 = runtime)
@@ -601,11 +602,24 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
     // workgroup size (lanes = patterns, whole loci per workgroup)
     unsigned BS = maxnp <= 16 ? 256 : (maxnp <= 64 ? 64 : 256);     // measured: config 2 +3 % with 256, config 3 +8 % with 64
     if (const char * ov = getenv("BPA_FUSED_BS")) { const unsigned v = (unsigned)atoi(ov); if ((v == 64 || v == 256) && maxnp <= v) BS = v; }
+    // one lane per (pattern, rate category) when every locus has several categories, no scalers and no
+    // phase averaging (step_s4_klane_kernel)
+    bool klane = p->rmax > 1 && !getenv("BPA_NO_KLANE");
+    unsigned maxlanes = 0;
+    for (unsigned t = 0; t < T && klane; ++t)
+    {
+      const bpa_locus * l = b->loci[t];
+      klane = l->rate_cats > 1 && l->scale_buffers == 0 && !l->dev.unphased_length && (!b->root_scaler || b->root_scaler[t] < 0);
+      maxlanes = std::max(maxlanes, l->sites*l->rate_cats);
+    }
+    klane = klane && maxlanes <= 256;
+    if (klane) BS = maxlanes <= 128 ? 128 : 256;
+    p->fused_klane = klane;
     std::vector<uint32_t> blk_off{0}, lane_task, lane0(T);
     unsigned used = 0;
     for (unsigned t = 0; t < T; ++t)
     {
-      const unsigned np = b->loci[t]->sites;
+      const unsigned np = b->loci[t]->sites*(klane ? b->loci[t]->rate_cats : 1u);      // lanes of this locus
       if (used + np > BS)
       {
         lane_task.resize(blk_off.size()*BS, 0xffffffffu);
@@ -664,7 +678,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
         std::memcpy(&recs[task_rec[t] + 6 + 3*o], &sl, sizeof(sl));
       }
       all_jc = all_jc && l->dev.model == 0;
-      for (unsigned n = 0; n < l->sites; ++n) lane_rec[lane0[t] + n] = task_rec[t];
+      for (unsigned n = 0; n < l->sites*(klane ? l->rate_cats : 1u); ++n) lane_rec[lane0[t] + n] = task_rec[t];
       if (b->mat_off)
         for (unsigned i = b->mat_off[t]; i < b->mat_off[t+1]; ++i)
         {
@@ -742,7 +756,23 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     hipEvent_t k0 = ts ? ts->ev[1] : nullptr, k1 = ts ? ts->ev[2] : nullptr;
     const dim3 grid(d.nblocks);
 #define BPA_FUSED(BS_, RT_) hipExtLaunchKernelGGL((step_s4_fused_kernel<BS_, RT_>), grid, dim3(BS_), 0, e->stream, k0, k1, 0, d)
-    if (p->fused_jc69)
+    if (p->fused_klane)
+    {
+      // phase A on its own (its code is what needs the registers), then B + C; the events bracket B + C
+      if (d.flags & 1u)
+      {
+        PlanDev da = d; da.flags = 1u;
+        if (p->fused_bs == 128) hipLaunchKernelGGL((step_s4_klane_kernel<128, true>), grid, dim3(128), 0, e->stream, da);
+        else                    hipLaunchKernelGGL((step_s4_klane_kernel<256, true>), grid, dim3(256), 0, e->stream, da);
+      }
+      d.flags &= 6u;
+      if (d.flags)
+      {
+        if (p->fused_bs == 128) hipExtLaunchKernelGGL((step_s4_klane_kernel<128, false>), grid, dim3(128), 0, e->stream, k0, k1, 0, d);
+        else                    hipExtLaunchKernelGGL((step_s4_klane_kernel<256, false>), grid, dim3(256), 0, e->stream, k0, k1, 0, d);
+      }
+    }
+    else if (p->fused_jc69)
     {
       if (p->fused_bs == 64) hipExtLaunchKernelGGL((step_jc69_kernel<64>), grid, dim3(64), 0, e->stream, k0, k1, 0, d);
       else                   hipExtLaunchKernelGGL((step_jc69_kernel<256>), grid, dim3(256), 0, e->stream, k0, k1, 0, d);

@@ -1561,6 +1561,118 @@ __global__ void __launch_bounds__(BS) step_s4_fused_kernel(const PlanDev P)
   }
 }
 
+// ================================= fused proposal step, S=4, one lane per (pattern, rate) ==
+// step_s4_fused_kernel gives a lane all R rate categories of its pattern: R x (two CLVs, two 4x4
+// matrices, the result) live at once, ~170 VGPRs, two waves per SIMD, and config 3 (29 patterns x 4
+// categories per locus) is latency-bound at a third of the HBM rate.  Here a lane owns ONE plane of ONE
+// pattern (lane = k*np + n inside its locus, so a wave reads contiguous CLV planes): a quarter of the
+// state per lane, R times the lanes to hide the P-matrix and CLV latencies.  The categories of a
+// pattern meet only in the root term — combined through LDS in category order (same additions as the
+// one-lane version) — and in the scaling test: loci with scalers stay on step_s4_fused_kernel.
+// WITH_A: phase A (the P-matrix code, which alone needs ~160 VGPRs) compiled in; the engine launches
+// <BS, true> restricted to phase A and then <BS, false> for B + C with twice the waves in flight
+template <int BS, bool WITH_A>
+__global__ void __launch_bounds__(BS) step_s4_klane_kernel(const PlanDev P)
+{
+  __shared__ double s_term[BS], s_tr[BS];
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  const uint32_t gl = b*BS + lane;
+  const uint32_t t0 = P.blk_task_off[b], t1 = P.blk_task_off[b+1];
+  const uint32_t ro = P.lane_rec[gl];
+  const bool active = ro != 0xffffffffu;
+  TaskRec T{};
+  const uint4 * rp = P.recs + (active ? ro : 0u);
+  if (active)
+  {
+    uint4 * dst = reinterpret_cast<uint4 *>(&T);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(TaskRec)/16); ++i) dst[i] = rp[i];
+  }
+  uint32_t sum_rec = 0xffffffffu;
+  if ((P.flags & 4u) && lane < t1 - t0) sum_rec = P.task_rec[t0 + lane];
+
+  // ---- phase A: P-matrices of this workgroup's loci
+  if (WITH_A && (P.flags & 1u))
+  {
+    const uint32_t e0 = P.mat_off[t0], e1 = P.mat_off[t1];
+    const uint32_t rmax = P.pad;
+    const uint32_t cnt = (e1 - e0)*rmax;
+    for (uint32_t i = lane; i < cnt; i += BS)
+    {
+      const MatRec m = P.mat_recs[e0 + i/rmax];
+      const uint32_t k = i % rmax;
+      if (k < m.rate_cats) pmatrix_s4_rec(m, P.mat_length, k);
+    }
+    __syncthreads();
+  }
+  if (WITH_A || !(P.flags & 6u)) return;
+
+  // ---- phase B: node updates of this lane's (pattern, category) + its root term
+  double tr = 0;
+  uint32_t n = 0, k = 0, np = 0, R = 1;
+  if (active)
+  {
+    np = T.np; R = T.rate_cats;
+    const uint32_t q = gl - T.lane0;
+    k = q/np; n = q - k*np;
+    double fwd[4] = {0, 0, 0, 0};
+    uint32_t fwd_clv = 0xffffffffu;
+    if (P.flags & 2u)
+    {
+      for (uint32_t o = 0; o < T.nops; ++o)
+      {
+        OpDev op;
+        uint4 * d = reinterpret_cast<uint4 *>(&op);
+        d[0] = rp[6 + 3*o]; d[1] = rp[7 + 3*o];
+        double lv[4], rv[4], x[4], y[4];
+        if (op.left_clv == fwd_clv) { lv[0] = fwd[0]; lv[1] = fwd[1]; lv[2] = fwd[2]; lv[3] = fwd[3]; }
+        else load_vec4(T, op.left_clv, k, n, lv);
+        if (op.right_clv == fwd_clv) { rv[0] = fwd[0]; rv[1] = fwd[1]; rv[2] = fwd[2]; rv[3] = fwd[3]; }
+        else load_vec4(T, op.right_clv, k, n, rv);
+        matvec4_p(T.pmat, T.pstride, (size_t)op.left_pmatrix*R  + k, lv, x);
+        matvec4_p(T.pmat, T.pstride, (size_t)op.right_pmatrix*R + k, rv, y);
+        double2 o0, o1;
+        o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
+        double2 * dst = reinterpret_cast<double2 *>(T.clv + ((((size_t)(op.parent_clv - T.tips_n)*R) + k)*np + n)*4);
+        dst[0] = o0; dst[1] = o1;
+        fwd[0] = o0.x; fwd[1] = o0.y; fwd[2] = o1.x; fwd[3] = o1.y;
+        fwd_clv = op.parent_clv;
+      }
+    }
+    // K2 at the root (core_likelihood_avx.c:117-150): this category's frequency-weighted sum
+    const double * par = T.par;
+    double c[4];
+    if (T.root_clv == fwd_clv) { c[0] = fwd[0]; c[1] = fwd[1]; c[2] = fwd[2]; c[3] = fwd[3]; }
+    else load_vec4(T, T.root_clv, k, n, c);
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+    const double * f = par + par_matrix(R, 4, m) + pm_freqs(4);
+    tr = dot4_pair(f[0], f[1], f[2], f[3], c);
+  }
+  s_tr[lane] = tr;
+  __syncthreads();
+  double term = 0;
+  if (active && k == 0)
+  {
+    const double * par = T.par;
+    for (uint32_t q = 0; q < R; ++q) term += s_tr[lane + q*np]*par[par_rate_weights(R) + q];
+    term = log(term)*T.weights[n];
+    P.site_term[T.pat_off + n] = term;
+  }
+  if (!(P.flags & 4u)) return;
+
+  // ---- phase C: per-locus sum in pattern order (the k = 0 lanes are the first np lanes of a locus)
+  s_term[lane] = term;
+  __syncthreads();
+  if (sum_rec != 0xffffffffu)
+  {
+    const TaskRec * S = reinterpret_cast<const TaskRec *>(P.recs + sum_rec);
+    const uint32_t snp = S->np, l0 = S->lane0 - b*BS;
+    double logl = 0;
+    for (uint32_t q = 0; q < snp; ++q) logl += s_term[l0 + q];
+    P.lnl[S->task] = P.bfbeta*logl;
+  }
+}
+
 // ============================================ fused proposal step, JC69, R = 1 ==
 // Configs 1/2/5 (JC69, one rate category, a handful of patterns per locus) are pure
 // latency: what matters is the length of one lane's dependent-load chain.  Under JC69 a
