@@ -611,12 +611,11 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
 
 // the single decision of an all-loci step (tau_step / mix_step of a00_driver.c; stree.c:6280,
 // prop_mixing.c:203-205): flag := epoch when REJECTED; on acceptance the device-resident taus follow
-__global__ void decide_kernel(const double * __restrict__ sum, double u, uint32_t epoch, uint32_t * flag,
-                              uint32_t * counters, double * taus, Species sp, int tau_q, int theta_p, double win_u,
-                              double mix_c, double mix_lnc)
+__device__ void decide(double lnacc, double u, uint32_t epoch, uint32_t * flag,
+                       uint32_t * counters, double * taus, const Species & sp, int tau_q, int theta_p, double win_u,
+                       double mix_c, double mix_lnc)
 {
-  if (threadIdx.x || blockIdx.x) return;
-  double lnacc = sum[0], tnew = 0;
+  double tnew = 0;
   const int root = sp.npop - 1;
   bool valid = true;
   if (theta_p >= 0)
@@ -645,6 +644,33 @@ __global__ void decide_kernel(const double * __restrict__ sum, double u, uint32_
   if (theta_p >= 0) { taus[MAXPOP + theta_p] = tnew; taus[2*MAXPOP + theta_p] = log(2.0/(1.0*tnew)); }
   else if (tau_q >= 0) taus[tau_q] = tnew;
   else for (int p = 0; p < sp.npop; ++p) taus[p] *= mix_c;
+}
+
+__global__ void decide_kernel(const double * __restrict__ sum, double u, uint32_t epoch, uint32_t * flag,
+                              uint32_t * counters, double * taus, Species sp, int tau_q, int theta_p, double win_u,
+                              double mix_c, double mix_lnc)
+{
+  if (threadIdx.x || blockIdx.x) return;
+  decide(sum[0], u, epoch, flag, counters, taus, sp, tau_q, theta_p, win_u, mix_c, mix_lnc);
+}
+
+// one GPU: the sum of lnl_sum_kernel (same order of additions) and the decision in ONE launch
+__global__ void __launch_bounds__(1024) sum_decide_kernel(const double * __restrict__ term, uint32_t n, double u,
+                                                          uint32_t epoch, uint32_t * flag, uint32_t * counters, double * taus,
+                                                          Species sp, int tau_q, int theta_p, double win_u, double mix_c,
+                                                          double mix_lnc)
+{
+  __shared__ double sh[1024];
+  double acc = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) acc += term[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t w = 512; w > 0; w >>= 1)
+  {
+    if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) decide(sh[0], u, epoch, flag, counters, taus, sp, tau_q, theta_p, win_u, mix_c, mix_lnc);
 }
 
 } // namespace smp
@@ -919,6 +945,25 @@ static int sampler_sum(bpa_sampler * s)
   return 1;
 }
 
+// sum this step's per-locus terms (over the ranks too when an all-reduce is installed) and decide
+static int sampler_decide(bpa_sampler * s, double uacc, int tau_q, int theta_p, double win_u, double mix_c, double mix_lnc)
+{
+  bpa_engine * e = s->eng;
+  s->epoch++;
+  if (!s->allreduce)
+    hipLaunchKernelGGL(smp::sum_decide_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, uacc, s->epoch,
+                       s->flag.p, s->counters.p, s->taus.p, s->sp, tau_q, theta_p, win_u, mix_c, mix_lnc);
+  else
+  {
+    if (!sampler_sum(s)) return 0;
+    hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->sum_ext ? s->sum_ext : s->mix_sum.p, uacc, s->epoch,
+                       s->flag.p, s->counters.p, s->taus.p, s->sp, tau_q, theta_p, win_u, mix_c, mix_lnc);
+  }
+  HIPCHK(hipGetLastError());
+  s->mix_pending = true;
+  return 1;
+}
+
 extern "C" int bpa_sampler_set_allreduce(bpa_sampler_t * s, bpa_allreduce_fn fn, void * ctx, double * device_sum,
                                          unsigned first_locus)
 {
@@ -948,33 +993,18 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
         if (!s->has_theta[p]) continue;
         const double uprop = a00_rndu(&s->grng), uacc_t = a00_rndu(&s->grng);
         if (!sampler_launch(s, 5, 1.0, 0.0, (unsigned)p, uprop)) return 0;
-        if (!sampler_sum(s)) return 0;
-        s->epoch++;
-        hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->sum_ext ? s->sum_ext : s->mix_sum.p, uacc_t, s->epoch, s->flag.p,
-                           s->counters.p, s->taus.p, s->sp, -1, p, uprop, 1.0, 0.0);
-        HIPCHK(hipGetLastError());
-        s->mix_pending = true;
+        if (!sampler_decide(s, uacc_t, -1, p, uprop, 1.0, 0.0)) return 0;
       }
     for (int q = s->sp.S; q < s->sp.npop; ++q)                    // one rubber-band step per species divergence
     {
       const double uprop = a00_rndu(&s->grng), uacc_t = a00_rndu(&s->grng);
       if (!sampler_launch(s, 4, 1.0, 0.0, (unsigned)q, uprop)) return 0;
-      if (!sampler_sum(s)) return 0;
-      s->epoch++;
-      hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->sum_ext ? s->sum_ext : s->mix_sum.p, uacc_t, s->epoch, s->flag.p,
-                         s->counters.p, s->taus.p, s->sp, q, -1, uprop, 1.0, 0.0);
-      HIPCHK(hipGetLastError());
-      s->mix_pending = true;
+      if (!sampler_decide(s, uacc_t, q, -1, uprop, 1.0, 0.0)) return 0;
     }
     const double lnc = s->sp.ft_mix*(a00_rndu(&s->grng) - 0.5), c = std::exp(lnc);
     const double uacc = a00_rndu(&s->grng);
     if (!sampler_launch(s, 1, c, lnc)) return 0;                 // mixing proposal of every locus
-    if (!sampler_sum(s)) return 0;
-    s->epoch++;
-    hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, s->sum_ext ? s->sum_ext : s->mix_sum.p, uacc, s->epoch, s->flag.p,
-                       s->counters.p, s->taus.p, s->sp, -1, -1, 0.0, c, lnc);
-    HIPCHK(hipGetLastError());
-    s->mix_pending = true;
+    if (!sampler_decide(s, uacc, -1, -1, 0.0, c, lnc)) return 0;
   }
   return 1;
 }
