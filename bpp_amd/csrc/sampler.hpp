@@ -20,6 +20,9 @@
 
 namespace smp {
 
+// section timing of the leader lane (BPA_SMP_DBG & 8): cycles of workgroup 0's first locus, per section
+#define SMP_PROF(S_, i_, t0_) do { if ((S_).prof_on) { const long long t1_ = clock64(); (S_).prof[i_] += t1_ - (t0_); (t0_) = t1_; } } while (0)
+
 constexpr int MAXTIPS = 8;
 constexpr int MAXN    = 16;               // 2*MAXTIPS-1 nodes, padded
 constexpr int MAXBUF  = 2*(MAXTIPS - 1);  // inner CLV buffers
@@ -64,6 +67,7 @@ struct TaskLDS
   int8_t nin_new[MAXPOP], nc_new[MAXPOP];
   double contrib[MAXPOP], contrib_new[MAXPOP];    // per-population terms of the MSC density: current / proposed
   uint32_t chain;                                 // populations whose term the proposal changes
+  int32_t prof_on; long long prof[8];
 };
 
 struct Args
@@ -81,6 +85,7 @@ struct Args
   const double * taus;         // device-resident species-tree parameters: [MAXPOP] tau | [MAXPOP] theta | [MAXPOP] log(2/theta)
   uint32_t tau_q;              // population of the TAU (mode 4) / THETA (mode 5) step
   double   tau_u;              // its window uniform
+  uint32_t dbg;                // timing experiments only (BPA_SMP_DBG): 1 skip the node updates, 2 skip the density, 4 skip the proposal
   double   bfbeta;             // 0 with opt_usedata == 0 (locus.c:2581): the sampler then draws from the MSC prior
   Species  sp;
 };
@@ -176,6 +181,10 @@ __device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau
   const int n = 2*t.tips - 1;
   double logpr = 0;
   S.chain = mask;
+  // the populations of all inner nodes in one unrolled pass (independent LDS reads)
+  int8_t pk[MAXN];
+#pragma unroll
+  for (int k = 0; k < MAXN; ++k) pk[k] = t.pop[k];
   for (int p = 0; p < sp.npop; ++p)
   {
     if (!((mask >> p) & 1u)) { logpr += S.contrib[p]; continue; }
@@ -189,7 +198,8 @@ __device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau
     }
     else nin = S.nin[p];                          // gene tips of the species: fixed
     uint32_t nodes = 0;
-    for (int k = t.tips; k < n; ++k) if (t.pop[k] == p) nodes |= 1u << k;
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k) if (k >= t.tips && k < n && pk[k] == p) nodes |= 1u << k;
     const int ncoal = __popc(nodes);
     S.nin_new[p] = (int8_t)nin; S.nc_new[p] = (int8_t)ncoal;
     const double ptau = sp.parent[p] >= 0 ? tau[sp.parent[p]] : -1.0;
@@ -275,6 +285,7 @@ __device__ void install(TaskLDS & S, uint32_t brm, uint32_t ndm, double rate)
 __device__ bool propose_gage(TaskLDS & S, int k, double rate, const Species & sp, const double * tau)
 {
   Tree & t = S.tr;
+  long long tp = clock64();
   const int n = 2*t.tips - 1;
   int v = -1, c = 0;
   for (int j = 0; j < n; ++j) if (t.left[j] >= 0 && c++ == k) { v = j; break; }
@@ -290,10 +301,13 @@ __device__ bool propose_gage(TaskLDS & S, int k, double rate, const Species & sp
   t.time[v] = tnew;
   t.pop[v] = (int8_t)climb(sp, tau, t.pop[l], tnew);
   S.hast = 0;
+  SMP_PROF(S, 0, tp);
   S.logpr_new = tree_logpr(S, sp, tau, pop_chain(sp, oldpop, t.pop[v]));
+  SMP_PROF(S, 1, tp);
   uint32_t brm = (1u << l) | (1u << r);
   if (p >= 0) brm |= 1u << v;
   install(S, brm, path_mask(t, v), rate);
+  SMP_PROF(S, 2, tp);
   return true;
 }
 
@@ -301,6 +315,7 @@ __device__ bool propose_gage(TaskLDS & S, int k, double rate, const Species & sp
 __device__ bool propose_gspr(TaskLDS & S, int k, double rate, const Species & sp, const double * tau)
 {
   Tree & t = S.tr;
+  long long tp = clock64();
   const int n = 2*t.tips - 1;
   int a = -1, c = 0;
   for (int j = 0; j < n; ++j) if (j != t.root && c++ == k) { a = j; break; }
@@ -315,19 +330,23 @@ __device__ bool propose_gspr(TaskLDS & S, int k, double rate, const Species & sp
   const double lo = fmax(t.time[a], tau[pop0]);
   const double tnew = reflect(t.time[p] + sp.ft_gspr*(u1 - 0.5), lo, 999.0);
   const int popt = climb(sp, tau, t.pop[a], tnew);
-  // targets (bit j = branch above node j; the father's own branch stands for the sibling's) and sources
+  // targets (bit j = branch above node j; the father's own branch stands for the sibling's) and sources, in ONE
+  // fully unrolled scan: the LDS reads of all nodes are independent and go out together
   uint32_t tmask = 0; int nsrc = 1;
-  if (tnew >= t.time[t.root]) tmask = 1u << t.root;
-  else
-    for (int j = 0; j < n; ++j)
-      if (j != a && j != t.root && t.time[j] <= tnew && t.time[t.parent[j]] > tnew && ((sp.anc[t.pop[j]] >> popt) & 1u))
-        tmask |= 1u << j;
-  if (p != t.root)
   {
-    const double tp = t.time[p]; const int pp = t.pop[p];
-    for (int j = 0; j < n; ++j)
-      if (j != a && j != t.root && j != s && j != p && t.time[j] <= tp && t.time[t.parent[j]] > tp && ((sp.anc[t.pop[j]] >> pp) & 1u))
-        ++nsrc;
+    const double tp = t.time[p], troot = t.time[t.root]; const int pp = t.pop[p], root = t.root;
+    const bool above_root = tnew >= troot, src_on = p != root;
+#pragma unroll
+    for (int j = 0; j < MAXN - 1; ++j)
+    {
+      const int pj = t.parent[j];
+      const double tj = t.time[j], tpj = t.time[pj < 0 ? 0 : pj];
+      const uint32_t aj = sp.anc[t.pop[j] & (MAXPOP - 1)];
+      const bool in = j < n && j != a && j != root;
+      if (in && !above_root && tj <= tnew && tpj > tnew && ((aj >> popt) & 1u)) tmask |= 1u << j;
+      if (in && src_on && j != s && j != p && tj <= tp && tpj > tp && ((aj >> pp) & 1u)) ++nsrc;
+    }
+    if (above_root) tmask = 1u << root;
   }
   const int ntg = __popc(tmask);
   if (!ntg) { (void)rndu(&t.rng); return false; }
@@ -358,9 +377,13 @@ __device__ bool propose_gspr(TaskLDS & S, int k, double rate, const Species & sp
   }
   uint32_t brm = 0;
   for (uint32_t m = bset; m; m &= m - 1) { const int x = __ffs(m) - 1; if (t.parent[x] >= 0) brm |= 1u << x; }
+  SMP_PROF(S, 3, tp);
   S.hast = log((double)ntg/(double)nsrc);
+  SMP_PROF(S, 4, tp);
   S.logpr_new = tree_logpr(S, sp, tau, chain);
+  SMP_PROF(S, 5, tp);
   install(S, brm, ndm, rate);
+  SMP_PROF(S, 6, tp);
   return true;
 }
 
@@ -377,7 +400,15 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   const uint32_t ts = active ? task - t0 : 0u;
   const bool leader = active && gl == A.task_lane0[task];
   const bool restore_mix = A.epoch != 0 && *A.mix_flag == A.epoch;      // epoch 0: nothing pending
-  const Species & sp = A.sp;
+  // the species tree is indexed with run-time population numbers all over the leader's code: out of LDS, not
+  // out of the kernel-argument segment (a dynamic index into a by-value argument is a global load each time)
+  __shared__ Species s_sp;
+  {
+    const uint32_t * src = reinterpret_cast<const uint32_t *>(&A.sp);
+    uint32_t * dst = reinterpret_cast<uint32_t *>(&s_sp);
+    for (uint32_t i = lane; i < sizeof(Species)/4; i += BS) dst[i] = src[i];
+  }
+  const Species & sp = s_sp;
 
   // ---- load: tree (or its pre-step snapshot), (a,b) table, this lane's CLV buffers and constants
   uint32_t np = 0, tips = 0, n = 0, tipcodes = 0, wgt = 0;
@@ -448,6 +479,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     for (uint32_t k = 0; k < tips; ++k) S.nin[S.tr.pop[k]]++;
     if (A.mode == 0) { (void)tree_logpr(S, sp, s_tau, (1u << sp.npop) - 1u); commit_logpr(S); }     // the current terms
     S.nops = 0; S.active = 0;
+    S.prof_on = (A.dbg & 8u) && b == 0 && ts == 0; for (int i = 0; i < 8; ++i) S.prof[i] = 0;
   }
   __syncthreads();
 
@@ -466,7 +498,8 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     {
       TaskLDS & S = s_task[ts];
       bool ok;
-      if (A.mode == 0)
+      if (A.mode == 0 && (A.dbg & 4u)) ok = false;
+      else if (A.mode == 0)
         ok = step < A.nsteps_gage ? propose_gage(S, (int)step, rate, sp, s_tau) : propose_gspr(S, (int)(step - A.nsteps_gage), rate, sp, s_tau);
       else if (A.mode == 5)
       {
@@ -528,7 +561,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     __syncthreads();
     // ---- phase 2: one lane per pattern runs the node updates out of LDS
     double term = 0;
-    if (active && s_task[ts].active)
+    if (active && s_task[ts].active && !(A.dbg & 1u))
     {
       const TaskLDS & S = s_task[ts];
       for (int o = 0; o < S.nops; ++o)
@@ -557,6 +590,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       double lnl = 0;
       for (uint32_t q = 0; q < np; ++q) lnl += s_term[lane + q];
       lnl = A.bfbeta == 1.0 ? lnl : A.bfbeta == 0.0 ? 0.0 : A.bfbeta*lnl;
+      long long tp3 = clock64();
       if (A.mode == 0)
       {
         const double lnacc = (S.logpr_new - S.tr.logpr) + (lnl - S.tr.lnl) + S.hast;
@@ -564,6 +598,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
         S.tr.proposals++;
         if (lnacc >= 0 || u < exp(lnacc)) { S.tr.lnl = lnl; S.tr.logpr = S.logpr_new; S.tr.accepted++; S.active = 1; commit_logpr(S); }
         else S.active = 2;                               // rejected: restore below
+        SMP_PROF(S, 7, tp3);
       }
       else
       {
@@ -596,6 +631,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     const TaskLDS & S = s_task[ts];
     const uint32_t npm = 2*(2*tips - 2);
     for (uint32_t i = 0; i < npm; ++i) { g_pmat[2*i] = S.ab[i][0]; g_pmat[2*i+1] = S.ab[i][1]; }
+    if (S.prof_on) for (int i = 0; i < 8; ++i) A.mix_delta[i] = (double)S.prof[i];
   }
   if (active && nprop && A.mode != 5)
   {
@@ -826,6 +862,7 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
   a.epoch = s->mix_pending ? s->epoch : 0u;
   s->mix_pending = false;
   a.bfbeta = e->usedata ? e->bfbeta : 0.0;
+  if (const char * dv = getenv("BPA_SMP_DBG")) a.dbg = (uint32_t)atoi(dv);
   a.taus = s->taus.p; a.tau_q = tau_q; a.tau_u = tau_u; a.sp = s->sp; a.mix_lnc = mix_lnc;
   a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2; a.mix_c = mix_c;
   if (const char * dbg = getenv("BPA_SMP_STEPS")) { unsigned g = 0, q = 0; if (sscanf(dbg, "%u,%u", &g, &q) == 2) { a.nsteps_gage = g; a.nsteps_gspr = q; } }
@@ -836,6 +873,12 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
     (void)hipStreamSynchronize(e->stream);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     fprintf(stderr, "[smp] mode %u gage %u gspr %u epoch %u blocks %u: %.1f us\n", mode, a.nsteps_gage, a.nsteps_gspr, a.epoch, s->nblocks, ms*1e3);
+    if ((a.dbg & 8u) && mode == 0)
+    {
+      double pr[8]; (void)hipMemcpy(pr, s->mix_delta.p, sizeof pr, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[smp] cycles of one locus: gage pre %.0f density %.0f install %.0f | gspr pre %.0f log %.0f density %.0f install %.0f | decide %.0f\n",
+              pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     s->launches++;
     return 1;
