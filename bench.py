@@ -338,7 +338,7 @@ def main():
         fused = cfg["model"] != "lg" and not klane
         bytes_per_launch = (it_bytes_partials + (it_bytes_pmatrix if fused else 0)) / launches_per_iter
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        roofline = dict(bound="hbm", kernel=("step_jc69_kernel<256>" if cfg["model"] == "jc69" else "step_s4_klane_kernel<128,false>" if klane else "step_s4_fused_kernel<64,4>" if cfg["model"] != "lg" else "partials_lnl_tiledk_kernel<20,3>"), achieved=round(achieved, 2),
+        roofline = dict(bound="hbm", kernel=("step_jc69_kernel<256>" if cfg["model"] == "jc69" else "step_s4_klane_kernel<256,false>" if klane else "step_s4_fused_kernel<64,4>" if cfg["model"] != "lg" else "partials_lnl_tiledk_kernel<20,3>"), achieved=round(achieved, 2),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
                         traffic=None, avg_kernel_us=round(1e3 * kernel_ms, 3),
                         algorithmic_bytes_per_launch=round(bytes_per_launch),
@@ -350,13 +350,14 @@ def main():
     # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (collected by
     # tools/profile_c2.sh on this same command): 2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md
     # §HBM) + WRITE_SIZE, both reported in KB
-    if roofline is not None and args.config == "c2" and args.loci is None:
+    if roofline is not None and args.loci is None:
         try:
             import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "c2_pmc_hbm_bytes.json")))
-            pm = json.load(open(cands[-1]))
-            key = [k for k in pm["FETCH_SIZE"] if "step_" in k][0]
-            roofline["traffic"] = round((2 * pm["FETCH_SIZE"][key]["mean_KB"] + pm["WRITE_SIZE"][key]["mean_KB"]) * 1024)
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"profile_{args.config}.json")))
+            pm = json.load(open(cands[-1]))["pmc_per_dispatch"]
+            want = roofline["kernel"].split("<")[0]
+            key = [k for k in pm if want in k and "FETCH_SIZE" in pm[k]][0]
+            roofline["traffic"] = round((2 * pm[key]["FETCH_SIZE"]["mean"] + pm[key]["WRITE_SIZE"]["mean"]) * 1024)
             roofline["traffic_source"] = os.path.relpath(cands[-1], ROOT) + " (separate --pmc passes; FETCH_SIZE doubled per the gfx950 note)"
         except Exception:
             pass
