@@ -105,3 +105,32 @@ def test_frogs_lnl_reference_vs_oracle_on_loader_output(G):
                                 d["unphased_weights"])
         assert got == want, (got, want)
         rl.free()
+
+
+ANOPH = "/root/reference/examples/anopheles"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ANOPH, "loci_realign.txt")), reason="reference examples not present")
+def test_anopheles_config5_pipeline_matches_reference(G):
+    """BASELINE config 5 (examples/anopheles: 100 loci x 12 sequences, cleandata = 1, JC69): reader -> missing
+    sequences -> ambiguous sites cut in the reference's swap order -> compression; labels, kept sites, pattern
+    order and weights element by element against the reference's own routines on the same file"""
+    from test_input import same_patterns
+    path = os.path.join(ANOPH, "loci_realign.txt")
+    want = G.pipeline(G.L, path, 0, True, True, None, None)["loci"]
+    msas = seqio.read_phylip(path)
+    assert len(msas) == len(want) == 100
+    npat = []
+    for m, w in zip(msas, want):
+        assert m.labels == w["labels"] and (m.count, m.length) == (w["count"], w["length"])
+        assert m.remove_missing_sequences() == w["removed"]
+        assert m.remove_ambiguous() == w["clean_ok"] == 1
+        assert m.sequences == w["clean"]
+        wt = m.compress(True)
+        assert list(wt) == w["a1"]["weights"]
+        same_patterns(m.sequences, w["a1"]["seqs"], True)
+        npat.append(len(wt))
+    assert 3 <= min(npat) and max(npat) <= 40 and 10 < np.mean(npat) < 16       # SURVEY section 8: 3-30, mean 13.2
+    species = ["G", "C", "R", "L", "A", "Q"]
+    im = seqio.Imap(os.path.join(ANOPH, "Imap.txt"))
+    assert sorted(set(species[im.species_of(lab, species)] for lab in msas[0].labels)) == sorted(species)
