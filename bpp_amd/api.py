@@ -16,6 +16,7 @@ DATA_DNA, DATA_AA = 0, 1
 MODEL_JC69, MODEL_GTR, MODEL_LG = 0, 7, 10
 ATTRIB_ARCH_HIP = 1 << 6
 SCALE_BUFFER_NONE = -1
+PARAM_FREQS, PARAM_SUBST, PARAM_RATES = 1, 2, 4
 
 
 class BpaError(RuntimeError):
@@ -100,6 +101,8 @@ def lib():
         "bpa_plan_enable_sum": (i, [vp, vp]),
         "bpa_plan_get_sum": (i, [vp, dp]),
         "bpa_batch_evaluate": (i, [vp, C.POINTER(Batch), dp]),
+        "bpa_plan_set_params": (i, [vp, i, dp]),
+        "bpa_plan_set_params_device": (i, [vp, i, vp]),
         "bpa_plan_work": (i, [vp, dp, dp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
         "bpa_sampler_create": (vp, [vp, C.POINTER(vp), u, C.c_ulong]),
         "bpa_sampler_destroy": (None, [vp]),
@@ -142,6 +145,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
             "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate",
             "bpa_plan_enable_sum", "bpa_plan_get_sum", "bpa_plans_launch",
+            "bpa_plan_set_params", "bpa_plan_set_params_device",
             "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride",
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
             "bpa_sampler_set_species_tree", "bpa_sampler_set_tip_species", "bpa_sampler_set_finetune",
@@ -590,6 +594,14 @@ class Plan:
         out = np.zeros(self.n)
         _chk(lib().bpa_plan_get_lnl(self.h, _dp(out)))
         return out
+
+    def set_params(self, which, values):
+        """batched substitution-parameter proposal: which = PARAM_FREQS | PARAM_SUBST | PARAM_RATES, values[locus][...]"""
+        v = _f64(values)
+        _chk(lib().bpa_plan_set_params(self.h, which, _dp(v)))
+
+    def set_params_device(self, which, device_ptr):
+        _chk(lib().bpa_plan_set_params_device(self.h, which, C.c_void_p(device_ptr)))
 
     def enable_sum(self, device_ptr=None):
         _chk(lib().bpa_plan_enable_sum(self.h, device_ptr))

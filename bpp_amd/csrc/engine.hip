@@ -91,6 +91,7 @@ struct bpa_locus
   std::vector<uint32_t> weights;
   std::vector<int>      eigen_valid;  // locus->eigen_decomp_valid (locus.c:735)
   bool par_dirty = true, tips_dirty = true, weights_dirty = true, queued = false, alive = true;
+  bool host_par_stale = false;        // bpa_plan_set_params_device moved the device block ahead of `par`
   size_t code_bytes() const { return states == 4 ? 1 : 4; }
   bool needs_eigen() const { return !(dtype == BPA_DATA_DNA && model < BPA_DNA_MODEL_GTR); }   // locus.c:2426-2454
   std::unique_ptr<bpa_plan> scratch;  // single-locus calls reuse one small plan
@@ -143,7 +144,7 @@ struct bpa_plan
   unsigned fused_rt = 0;              // compile-time rate-category count of the fused kernel (0 = runtime)
   unsigned fused_bs = 0;              // workgroup size of the fused single-launch path (0 = not available)
   DevBuf<int32_t>  root_scaler;
-  DevBuf<double>   mat_length, site_term, lnl, lnl_sum;
+  DevBuf<double>   mat_length, site_term, lnl, lnl_sum, param_stage;
   double * sum_out = nullptr;         // where the per-launch sum of lnl[] goes (own buffer or caller's)
   DevBuf<OpDev>    ops;
   std::vector<uint32_t> h_locus;      // host copy of task -> locus id
@@ -153,7 +154,7 @@ struct bpa_plan
   {
     task_locus.free(); task_pat_off.free(); thr_task.free(); mat_off.free(); mat_task.free();
     mat_pmatrix.free(); op_off.free(); root_clv.free(); root_scaler.free(); mat_length.free();
-    site_term.free(); lnl.free(); ops.free(); lnl_sum.free();
+    site_term.free(); lnl.free(); ops.free(); lnl_sum.free(); param_stage.free();
     blk_task_off.free(); lane_task.free(); task_lane0.free(); lane_rec.free(); task_rec.free(); recs.free(); mat_recs.free(); tile_task.free(); tile_n0.free();
   }
   ~bpa_plan() { free_all(); }
@@ -339,9 +340,27 @@ extern "C" void bpa_set_pattern_weights(bpa_locus_t * l, const unsigned * w)
   l->weights_dirty = true; mark_dirty(l);
 }
 
+// a per-locus setter after bpa_plan_set_params_device: bring the host mirror level with the device block first
+static void refresh_host_par(bpa_locus * l)
+{
+  if (!l->host_par_stale) return;
+  bpa_engine * e = l->eng;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  const unsigned S = l->states, R = l->rate_cats;
+  (void)hipMemcpy(l->par.data(), l->dev.par, 3*R*sizeof(double), hipMemcpyDeviceToHost);
+  for (unsigned m = 0; m < l->rate_matrices; ++m)
+  {
+    const size_t off = par_matrix(R, S, m);
+    (void)hipMemcpy(l->par.data() + off, l->dev.par + off, (S + S*(S-1)/2)*sizeof(double), hipMemcpyDeviceToHost);
+  }
+  l->host_par_stale = false;
+}
+
 extern "C" void bpa_set_frequencies(bpa_locus_t * l, unsigned index, const double * f)
 {
   std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
+  refresh_host_par(l);
   const unsigned S = l->states, R = l->rate_cats;
   std::copy(f, f + S, l->par.begin() + par_matrix(R, S, index) + pm_freqs(S));
   l->eigen_valid[index] = 0;                    // locus.c:895
@@ -351,6 +370,7 @@ extern "C" void bpa_set_frequencies(bpa_locus_t * l, unsigned index, const doubl
 extern "C" void bpa_set_subst_params(bpa_locus_t * l, unsigned index, const double * p)
 {
   std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
+  refresh_host_par(l);
   const unsigned S = l->states, R = l->rate_cats;
   std::copy(p, p + S*(S-1)/2, l->par.begin() + par_matrix(R, S, index) + pm_subst(S));
   l->eigen_valid[index] = 0;                    // locus.c:883
@@ -360,6 +380,7 @@ extern "C" void bpa_set_subst_params(bpa_locus_t * l, unsigned index, const doub
 extern "C" void bpa_set_category_rates(bpa_locus_t * l, const double * rates)
 {
   std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
+  refresh_host_par(l);
   std::copy(rates, rates + l->rate_cats, l->par.begin() + par_rates(l->rate_cats));
   l->par_dirty = true; mark_dirty(l);
 }
@@ -367,6 +388,7 @@ extern "C" void bpa_set_category_rates(bpa_locus_t * l, const double * rates)
 extern "C" void bpa_set_category_weights(bpa_locus_t * l, const double * w)
 {
   std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
+  refresh_host_par(l);
   std::copy(w, w + l->rate_cats, l->par.begin() + par_rate_weights(l->rate_cats));
   l->par_dirty = true; mark_dirty(l);
 }
@@ -964,6 +986,48 @@ extern "C" int bpa_plan_get_lnl(bpa_plan_t * p, double * lnl)
 }
 
 extern "C" void * bpa_plan_lnl_device(bpa_plan_t * p) { return p->lnl.p; }
+
+static int plan_set_params(bpa_plan * p, int which, const double * host_values, const double * dev_values)
+{
+  bpa_engine * e = p->eng;
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  if (!set_device(e)) return 0;
+  if (which != 1 && which != 2 && which != 4) return fail("bpa_plan_set_params: which = 1 (frequencies), 2 (substitution parameters) or 4 (category rates)");
+  const unsigned T = p->pd.ntasks;
+  unsigned len = 0;
+  for (unsigned t = 0; t < T; ++t)
+  {
+    const bpa_locus * l = e->loci[p->h_locus[t]];
+    const unsigned n = which == 1 ? l->states : which == 2 ? l->states*(l->states - 1)/2 : l->rate_cats;
+    if (t && n != len) return fail("bpa_plan_set_params: the loci of the plan must agree in states / rate categories");
+    len = n;
+  }
+  if (!flush(e)) return 0;                                  // pending per-locus setters go first
+  if (host_values)
+  {
+    // the host copy stays the mirror of the device block (flush uploads from it)
+    for (unsigned t = 0; t < T; ++t)
+    {
+      bpa_locus * l = e->loci[p->h_locus[t]];
+      const unsigned S = l->states, R = l->rate_cats;
+      const size_t off = which == 4 ? par_rates(R) : par_matrix(R, S, 0) + (which == 1 ? pm_freqs(S) : pm_subst(S));
+      std::copy(host_values + (size_t)t*len, host_values + (size_t)(t + 1)*len, l->par.begin() + off);
+    }
+    if (!p->param_stage.reserve((size_t)T*len)) return fail("out of device memory (parameter stage)");
+    HIPCHK(hipMemcpyAsync(p->param_stage.p, host_values, (size_t)T*len*sizeof(double), hipMemcpyHostToDevice, e->stream));
+    dev_values = p->param_stage.p;
+  }
+  else for (unsigned t = 0; t < T; ++t) e->loci[p->h_locus[t]]->host_par_stale = true;      // the device block is ahead of the mirror
+  hipLaunchKernelGGL(params_install_kernel, dim3((T + 63)/64), dim3(64), 0, e->stream, e->d_loci.p, p->task_locus.p, T,
+                     (uint32_t)which, dev_values, len);
+  HIPCHK(hipGetLastError());
+  return 1;
+}
+
+extern "C" int bpa_plan_set_params(bpa_plan_t * p, int which, const double * values)
+{ return values ? plan_set_params(p, which, values, nullptr) : fail("bpa_plan_set_params: null values"); }
+extern "C" int bpa_plan_set_params_device(bpa_plan_t * p, int which, const double * device_values)
+{ return device_values ? plan_set_params(p, which, nullptr, device_values) : fail("bpa_plan_set_params_device: null values"); }
 
 extern "C" int bpa_plan_enable_sum(bpa_plan_t * p, void * device_out)
 {

@@ -2238,6 +2238,27 @@ __global__ void __launch_bounds__(64) eigen_kernel(const LocusDev * loci, const 
   }
 }
 
+// Batched substitution-parameter proposal (bpa_plan_set_params): one lane per locus of the plan installs its
+// new values (which: 1 base frequencies of rate matrix 0, 2 its exchangeabilities, 4 category rates) in the
+// locus's parameter block and, when the rate matrix changed, refreshes its eigensystem in place
+// (pll_update_eigen on the next locus_update_matrices, locus.c:2462-2476) — K6 on the device, no host trip.
+__global__ void __launch_bounds__(64) params_install_kernel(const LocusDev * loci, const uint32_t * task_locus, uint32_t ntasks,
+                                                           uint32_t which, const double * __restrict__ values, uint32_t len)
+{
+  const uint32_t t = blockIdx.x*64 + threadIdx.x;
+  if (t >= ntasks) return;
+  const LocusDev & L = loci[task_locus[t]];
+  const uint32_t R = L.rate_cats, S = L.states;
+  const double * v = values + (size_t)t*len;
+  double * pm = L.par + par_matrix(R, S, 0);
+  if (which == 4u) { for (uint32_t k = 0; k < R; ++k) L.par[par_rates(R) + k] = v[k]; return; }
+  if (which == 1u) for (uint32_t i = 0; i < S; ++i) pm[pm_freqs(S) + i] = v[i];
+  if (which == 2u) for (uint32_t i = 0; i < S*(S-1)/2; ++i) pm[pm_subst(S) + i] = v[i];
+  if (L.model == 0) return;                       // JC69: no eigensystem
+  if (S == 4) update_eigen_dev<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
+  else        update_eigen_dev<20>(pm + pm_freqs(20), pm + pm_subst(20), pm + pm_evals(20), pm + pm_evecs(20), pm + pm_ievecs(20));
+}
+
 // pll_update_eigen over staged arrays (bpa_update_eigen)
 __global__ void eigen_lib_kernel(uint32_t S, const double * freqs, const double * subst,
                                  double * evals, double * evecs, double * ievecs)

@@ -200,6 +200,15 @@ void *       bpa_plan_lnl_device(bpa_plan_t *);
    internal one read back with bpa_plan_get_sum.                                    */
 int          bpa_plan_enable_sum(bpa_plan_t *, void * device_out);
 int          bpa_plan_get_sum(bpa_plan_t *, double * sum);
+/* Batched substitution-parameter proposal for the plan's loci (the per-locus proposals of locus.c:2782-3419
+   — base frequencies, exchangeabilities — and prop_gamma.c:52-224 — alpha, whose category rates the caller
+   computes with bpa_compute_gamma_cats as BPP does): which = 1 frequencies of rate matrix 0 (states values per
+   locus), 2 substitution parameters (states(states-1)/2), 4 category rates (rate_cats); values packed
+   [locus of the plan][value].  ONE transfer (or none: the _device form takes device memory), one kernel that
+   installs them and refreshes the touched eigensystems on the device (K6, pll_update_eigen).  The next launch
+   of a plan that updates all matrices and partials then evaluates the proposal.                            */
+int          bpa_plan_set_params(bpa_plan_t *, int which, const double * values);
+int          bpa_plan_set_params_device(bpa_plan_t *, int which, const double * device_values);
 /* convenience: create + launch + get + destroy                                    */
 int          bpa_batch_evaluate(bpa_engine_t *, const bpa_batch_t *, double * lnl);
 
