@@ -113,7 +113,7 @@ class TreeState:
 class Step:
     """one batched proposal step over a subset of loci (explicit indices, ready for bpa_plan)"""
     __slots__ = ("kind", "loci", "mat_off", "mat_pmatrix", "mat_length", "op_off", "ops", "root_clv",
-                 "root_scaler", "pre", "post", "global_decision", "_index")
+                 "root_scaler", "pre", "post", "global_decision", "_index", "params")
 
     def __init__(self, kind):
         self.kind = kind
@@ -124,6 +124,9 @@ class Step:
         self.pre, self.post = [], []        # per locus: node records before compute / after (reverts)
         self.global_decision = None
         self._index = None
+        # substitution parameters to install BEFORE this step is evaluated: [(which, values[nloci, len])] with
+        # which = 1 base frequencies, 2 exchangeabilities, 4 category rates (bpa_plan_set_params); rows of ALL loci
+        self.params = []
 
     def finish(self):
         self.ops = np.array(self.ops, dtype=OP_DTYPE) if self.ops else np.zeros(0, dtype=OP_DTYPE)
@@ -133,12 +136,22 @@ class Step:
 class A00Schedule:
     """builds the tape: `iterations` x (GAGE, GSPR, TAU, MIX) steps for all loci"""
 
-    def __init__(self, trees, rate_mui=None, seed=1, taus=(0.001, 0.002, 0.003)):
+    def __init__(self, trees, rate_mui=None, seed=1, taus=(0.001, 0.002, 0.003), subst=None):
+        """subst: dict(freqs[nloci,S], exch[nloci,S(S-1)/2], alpha[nloci], rate_cats, gamma=fn(alpha, cats)) turns on the
+        per-locus substitution-parameter proposals of a GTR+Gamma analysis (3 frequency, 5 exchangeability and 1
+        alpha move per locus and iteration: locus.c:2782-3419, prop_gamma.c:52-224), each a full recompute"""
         self.trees = trees
         self.nloci = len(trees)
         self.mui = [1.0] * self.nloci if rate_mui is None else list(rate_mui)
         self.rng = np.random.default_rng(seed)
         self.taus = list(taus)
+        self.subst = None
+        self.revert = set()               # parameter kinds whose current values must be re-installed (rejections)
+        if subst is not None:
+            self.subst = dict(gamma=subst["gamma"], rate_cats=int(subst["rate_cats"]))
+            self.cur = {1: np.array(subst["freqs"], dtype=np.float64), 2: np.array(subst["exch"], dtype=np.float64),
+                        "alpha": np.array(subst["alpha"], dtype=np.float64)}
+            self.cur[4] = np.array([self.subst["gamma"](a, self.subst["rate_cats"]) for a in self.cur["alpha"]])
 
     # ---- helpers
     def _emit(self, step, li, tr, branches, nodes, touched, root_before, snap):
@@ -320,6 +333,60 @@ class A00Schedule:
             self.taus = [t * c for t in self.taus]
         return step.finish()
 
+    # ---- FREQ / QRATE / ALPHA: per-locus substitution-parameter proposals, each evaluated by a full recompute
+    def _param_step(self, kind, which, proposed, alpha=None):
+        step = Step(kind)
+        # rejected proposals of OTHER kinds are put back first; this kind's own array already carries current values
+        step.params = [(w, self.cur[w].copy()) for w in sorted(self.revert) if w != which] + [(which, proposed)]
+        self.revert.clear()
+        u = self.rng.random(self.nloci)
+        rejected = False
+        for li, tr in enumerate(self.trees):
+            snap = tr.snapshot(range(tr.n))
+            root_before = tr.root
+            branches = [i for i in range(tr.n) if tr.parent[i] >= 0]
+            allnodes = self._emit(step, li, tr, branches, tr.inner_nodes(), [], root_before, snap)
+            accept = bool(u[li] < P_ACCEPT)
+            self._decide(step, tr, snap, root_before, allnodes, accept)
+            if accept:
+                self.cur[which][li] = proposed[li]
+                if alpha is not None:
+                    self.cur["alpha"][li] = alpha[li]
+            else:
+                rejected = True
+        if rejected:
+            self.revert.add(which)
+        return step.finish()
+
+    def freq_step(self, k):
+        """move mass between frequency k and the last one (locus.c:2782-2900)"""
+        f = self.cur[1].copy()
+        S = f.shape[1]
+        d = 0.04 * (self.rng.random(self.nloci) - 0.5)
+        d = np.clip(d, 0.01 - f[:, k], f[:, S - 1] - 0.01)
+        f[:, k] += d
+        f[:, S - 1] -= d
+        return self._param_step("FREQ", 1, f)
+
+    def qrate_step(self, k):
+        """multiplier on exchangeability k; the last one stays the reference (locus.c:3100-3250)"""
+        q = self.cur[2].copy()
+        q[:, k] *= np.exp(0.3 * (self.rng.random(self.nloci) - 0.5))
+        return self._param_step("QRATE", 2, q)
+
+    def alpha_step(self):
+        """multiplier on alpha; the category rates follow through pll_compute_gamma_cats (prop_gamma.c:52-224)"""
+        a = self.cur["alpha"] * np.exp(0.4 * (self.rng.random(self.nloci) - 0.5))
+        r = np.array([self.subst["gamma"](x, self.subst["rate_cats"]) for x in a])
+        return self._param_step("ALPHA", 4, r, alpha=a)
+
+    def flush_params(self, step):
+        """a tree step after rejected parameter proposals: the current values go back in first"""
+        if self.revert:
+            step.params = [(w, self.cur[w].copy()) for w in sorted(self.revert)]
+            self.revert.clear()
+        return step
+
     def initial_step(self):
         """start-up: all matrices, all partials, lnL (method.c:4285-4297) — no toggling"""
         step = Step("INIT")
@@ -346,6 +413,12 @@ class A00Schedule:
         nmax = max(tr.tips for tr in self.trees)
         steps = [self.gage_step(k) for k in range(nmax - 1)]
         steps += [self.gspr_step(k) for k in range(2 * nmax - 2)]
-        steps += [self.tau_step(j) for j in range(len(self.taus))]
-        steps.append(self.mix_step())
+        if self.subst is not None:
+            nex = self.cur[2].shape[1]
+            steps += [self.freq_step(k) for k in range(self.cur[1].shape[1] - 1)]
+            steps += [self.qrate_step(k) for k in range(nex - 1)]
+            if self.subst["rate_cats"] > 1:
+                steps.append(self.alpha_step())
+        steps += [self.flush_params(self.tau_step(j)) for j in range(len(self.taus))]
+        steps.append(self.flush_params(self.mix_step()))
         return [s for s in steps if s.loci]

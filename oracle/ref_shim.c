@@ -336,12 +336,20 @@ static void apply_records(refctx_t * c, const ref_rec_t * r, unsigned n, int roo
   c->gtree->root = c->nodes + root;
 }
 
-double ref_run_tape(refctx_t * c, unsigned nsteps,
-                    const unsigned * pre_off, const ref_rec_t * pre, const int * pre_root,
-                    const unsigned * post_off, const ref_rec_t * post, const int * post_root,
-                    const unsigned * br_off, const unsigned * br_node,
-                    const unsigned * op_off, const unsigned * op_node,
-                    double * lnl_out, unsigned repeats)
+/* par_*: substitution parameters installed before a step is evaluated (the frequency / exchangeability / alpha
+   proposals of locus.c:2782-3419 and prop_gamma.c): entries par_off[s]..par_off[s+1] of step s, each
+   (which: 1 frequencies, 2 substitution parameters, 4 category rates; offset of its values in par_val).
+   Frequencies and substitution parameters go through pll_set_frequencies / pll_set_subst_params, which
+   invalidate the eigensystem: the next locus_update_matrices recomputes it (pll_update_eigen) — inside the
+   timed loop, every repeat.  par_off == NULL: none. */
+double ref_run_tape_params(refctx_t * c, unsigned nsteps,
+                           const unsigned * pre_off, const ref_rec_t * pre, const int * pre_root,
+                           const unsigned * post_off, const ref_rec_t * post, const int * post_root,
+                           const unsigned * br_off, const unsigned * br_node,
+                           const unsigned * op_off, const unsigned * op_node,
+                           const unsigned * par_off, const int * par_which, const unsigned * par_voff,
+                           const double * par_val,
+                           double * lnl_out, unsigned repeats)
 {
   struct timespec t0, t1;
   unsigned s, i, r, k;
@@ -349,6 +357,14 @@ double ref_run_tape(refctx_t * c, unsigned nsteps,
   for (r = 0; r < repeats; ++r)
     for (s = 0; s < nsteps; ++s)
     {
+      if (par_off)
+        for (i = par_off[s]; i < par_off[s+1]; ++i)
+        {
+          const double * v = par_val + par_voff[i];
+          if (par_which[i] == 1) pll_set_frequencies(c->locus, 0, v);
+          else if (par_which[i] == 2) pll_set_subst_params(c->locus, 0, v);
+          else memcpy(c->locus->rates, v, c->locus->rate_cats*sizeof(double));
+        }
       apply_records(c, pre + pre_off[s], pre_off[s+1] - pre_off[s], pre_root[s]);
       for (k = 0, i = br_off[s]; i < br_off[s+1]; ++i) c->trav[k++] = c->nodes + br_node[i];
       locus_update_matrices(c->locus, c->gtree, c->trav, NULL, 0, k);
@@ -360,6 +376,17 @@ double ref_run_tape(refctx_t * c, unsigned nsteps,
     }
   clock_gettime(CLOCK_MONOTONIC, &t1);
   return (t1.tv_sec - t0.tv_sec) + 1e-9*(t1.tv_nsec - t0.tv_nsec);
+}
+
+double ref_run_tape(refctx_t * c, unsigned nsteps,
+                    const unsigned * pre_off, const ref_rec_t * pre, const int * pre_root,
+                    const unsigned * post_off, const ref_rec_t * post, const int * post_root,
+                    const unsigned * br_off, const unsigned * br_node,
+                    const unsigned * op_off, const unsigned * op_node,
+                    double * lnl_out, unsigned repeats)
+{
+  return ref_run_tape_params(c, nsteps, pre_off, pre, pre_root, post_off, post, post_root, br_off, br_node,
+                             op_off, op_node, NULL, NULL, NULL, NULL, lnl_out, repeats);
 }
 
 /* ---------------------------------------------------------------------------

@@ -35,10 +35,22 @@ def make_engine_loci(engine, data, scaling=False):
     return loci
 
 
-def make_schedule(data, seed=1, scaling=False, taus=None):
+def make_schedule(data, seed=1, scaling=False, taus=None, subst=False):
+    """subst: add the per-locus frequency / exchangeability / alpha proposals of a GTR(+Gamma) analysis"""
     trees = [TreeState(d["left"], d["right"], d["times"], d["root"], scaling) for d in data]
     kw = {} if taus is None else {"taus": taus}
+    if subst:
+        R = data[0]["rate_cats"]
+        kw["subst"] = dict(freqs=[d["freqs"] for d in data], exch=[d["exch"] for d in data],
+                           alpha=[0.5] * len(data), rate_cats=R,
+                           gamma=lambda a, cats: bpp_amd.compute_gamma_cats(a, a, cats) if cats > 1 else np.ones(1))
     return A00Schedule(trees, seed=seed, **kw)
+
+
+def apply_params(all_loci_plan, step):
+    """the step's substitution-parameter installs (rows for ALL loci) through a plan that holds every locus"""
+    for which, vals in step.params:
+        all_loci_plan.set_params(which, vals)
 
 
 def plan_for_step(engine, loci, step):
@@ -49,6 +61,7 @@ def plan_for_step(engine, loci, step):
 def locus_subtape(steps, li):
     """the steps that involve locus li, flattened for ref_run_tape / oracle replay"""
     out = []
+    carried = []                  # installs of steps this locus sits out (TAU): they ride on its next step
     for si, st in enumerate(steps):
         idx = getattr(st, "_index", None)
         if idx is None:
@@ -57,13 +70,16 @@ def locus_subtape(steps, li):
                 st._index = idx
             except AttributeError:
                 pass
+        if li not in idx:
+            carried += [(w, v[li]) for w, v in st.params]
         if li in idx:
             t = idx[li]
-            out.append(dict(kind=st.kind, pre=st.pre[t], post=st.post[t],
+            out.append(dict(kind=st.kind, pre=st.pre[t], post=st.post[t], params=carried + [(w, v[li]) for w, v in st.params],
                             mat=(st.mat_pmatrix[st.mat_off[t]:st.mat_off[t + 1]],
                                  st.mat_length[st.mat_off[t]:st.mat_off[t + 1]]),
                             ops=st.ops[st.op_off[t]:st.op_off[t + 1]],
                             root_clv=st.root_clv[t], root_scaler=st.root_scaler[t], task=t, step=si))
+            carried = []
     return out
 
 
@@ -78,6 +94,15 @@ def oracle_replay(d, sub, scaling=False):
     clv = {i: ol.clv[i] for i in range(tips)}
     pm, sc, out = {}, {}, []
     for s in sub:
+        for which, v in s.get("params", ()):
+            if which == 1:
+                ol.freqs = np.asarray(v, float)
+            elif which == 2:
+                ol.qrates = np.asarray(v, float)
+            else:
+                ol.rates = np.asarray(v, float)
+            if which in (1, 2):
+                ol.eig = O.orc_eigen(ol.freqs, ol.qrates)
         for p, t in zip(*s["mat"]):
             pm[p] = ol.pmatrix(t)
         for op in s["ops"]:
@@ -102,7 +127,13 @@ def _recs(lst):
 def ref_tape_arrays(sub):
     pre_off, post_off, br_off, op_off = [0], [0], [0], [0]
     pre, post, pre_root, post_root, br, opn = [], [], [], [], [], []
+    par_off, par_which, par_voff, par_val = [0], [], [], []
     for s in sub:
+        for which, v in s.get("params", ()):
+            par_which.append(which)
+            par_voff.append(len(par_val))
+            par_val += [float(x) for x in v]
+        par_off.append(len(par_which))
         pre += s["pre"]["records"]
         pre_off.append(len(pre))
         pre_root.append(s["pre"]["root"])
@@ -117,7 +148,9 @@ def ref_tape_arrays(sub):
     i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
     return dict(n=len(sub), pre_off=u(pre_off), pre=_recs(pre), pre_root=i32(pre_root),
                 post_off=u(post_off), post=_recs(post), post_root=i32(post_root),
-                br_off=u(br_off), br=u(br), op_off=u(op_off), op=u(opn))
+                br_off=u(br_off), br=u(br), op_off=u(op_off), op=u(opn),
+                par_off=u(par_off), par_which=i32(par_which), par_voff=u(par_voff),
+                par_val=np.ascontiguousarray(par_val, dtype=np.float64), has_params=bool(par_which))
 
 
 def ref_locus_for(d, scaling=False, arch=O.ARCH_AVX2):
@@ -137,12 +170,19 @@ def ref_replay(rl, arrays, repeats=1):
     out = np.zeros(a["n"])
     up, ip = C.POINTER(C.c_uint), C.POINTER(C.c_int)
     vp = C.c_void_p
-    secs = L.ref_run_tape(rl.h, a["n"], a["pre_off"].ctypes.data_as(up), a["pre"].ctypes.data_as(vp),
-                          a["pre_root"].ctypes.data_as(ip), a["post_off"].ctypes.data_as(up),
-                          a["post"].ctypes.data_as(vp), a["post_root"].ctypes.data_as(ip),
-                          a["br_off"].ctypes.data_as(up), a["br"].ctypes.data_as(up),
-                          a["op_off"].ctypes.data_as(up), a["op"].ctypes.data_as(up),
-                          out.ctypes.data_as(C.POINTER(C.c_double)), repeats)
+    dp = C.POINTER(C.c_double)
+    L.ref_run_tape_params.restype = C.c_double
+    par = a.get("has_params", False)
+    secs = L.ref_run_tape_params(rl.h, a["n"], a["pre_off"].ctypes.data_as(up), a["pre"].ctypes.data_as(vp),
+                                 a["pre_root"].ctypes.data_as(ip), a["post_off"].ctypes.data_as(up),
+                                 a["post"].ctypes.data_as(vp), a["post_root"].ctypes.data_as(ip),
+                                 a["br_off"].ctypes.data_as(up), a["br"].ctypes.data_as(up),
+                                 a["op_off"].ctypes.data_as(up), a["op"].ctypes.data_as(up),
+                                 a["par_off"].ctypes.data_as(up) if par else None,
+                                 a["par_which"].ctypes.data_as(ip) if par else None,
+                                 a["par_voff"].ctypes.data_as(up) if par else None,
+                                 a["par_val"].ctypes.data_as(dp) if par else None,
+                                 out.ctypes.data_as(dp), repeats)
     return out, secs
 
 

@@ -50,3 +50,30 @@ def test_tape_gpu_vs_oracle(engine, taxa, model, R, scaling, nloci):
         want = ol.full_lnl(tr.left, tr.right, tr.time, tr.root)
         have = loci[li].root_loglikelihood(tr.clv[tr.root], tr.scaler[tr.root])
         assert rel(have, want) < 1e-12
+
+
+@pytest.mark.parametrize("taxa,R,nloci", [(8, 4, 50), (4, 1, 80)])
+def test_gtr_tape_with_substitution_parameter_proposals(engine, taxa, R, nloci):
+    """the GTR(+Gamma) tape of BASELINE config 3's kind: tree moves plus per-locus frequency / exchangeability / alpha
+    proposals (bpa_plan_set_params: batched install + eigensystem refresh on the device), GPU == oracle step by step"""
+    data = synth.make_dataset(nloci, 300, taxa, "gtr", R, seed=8)
+    loci = tape.make_engine_loci(engine, data)
+    sch = tape.make_schedule(data, seed=12, subst=True)
+    steps = [sch.initial_step()]
+    for _ in range(2):
+        steps += sch.iteration()
+    allp = tape.plan_for_step(engine, loci, steps[0])          # holds every locus: carrier of the parameter installs
+    got = []
+    for st in steps:
+        tape.apply_params(allp, st)
+        p = tape.plan_for_step(engine, loci, st)
+        p.launch()
+        got.append(p.lnl())
+        p.close()
+    assert sum(1 for s in steps if s.params) >= 2 * (3 + 5)
+    for li in range(0, nloci, 5):
+        sub = tape.locus_subtape(steps, li)
+        want = tape.oracle_replay(data[li], sub)
+        mine = np.array([got[s["step"]][s["task"]] for s in sub])
+        assert np.all(np.abs(mine - want) <= 1e-12 * np.abs(want)), (li, np.max(np.abs(mine - want) / np.abs(want)))
+    allp.close()

@@ -79,3 +79,31 @@ def test_tape_oracle_equals_reference(taxa, model, R, scaling):
         rl.free()
         assert (lo == lr).all()
         assert np.isfinite(lo).all()
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("taxa,R", [(8, 4), (4, 1)])
+def test_gtr_tape_with_substitution_parameter_proposals(taxa, R):
+    """GTR(+Gamma): 3 frequency, 5 exchangeability and (R > 1) 1 alpha proposal per locus and iteration, each a full
+    recompute with a fresh eigensystem, rejections putting the old values back — oracle == reference bit for bit"""
+    data = synth.make_dataset(5, 250, taxa, "gtr", R, seed=11)
+    sch = tape.make_schedule(data, seed=2, subst=True)
+    steps = [sch.initial_step()]
+    for _ in range(2):
+        steps += sch.iteration()
+    kinds = [s.kind for s in steps]
+    assert kinds.count("FREQ") == 6 and kinds.count("QRATE") == 10 and kinds.count("ALPHA") == (2 if R > 1 else 0)
+    assert any(s.params and s.kind in ("TAU", "MIX", "QRATE", "ALPHA", "FREQ") for s in steps)
+    for li in range(5):
+        sub = tape.locus_subtape(steps, li)
+        assert sum(len(x["params"]) for x in sub) >= 16
+        lo = tape.oracle_replay(data[li], sub)
+        rl = tape.ref_locus_for(data[li])
+        lr, _ = tape.ref_replay(rl, tape.ref_tape_arrays(sub))
+        rl.free()
+        assert np.isfinite(lo).all() and (lo == lr).all(), np.max(np.abs(lo - lr))
+    # the parameter moves really move the likelihood
+    sub = tape.locus_subtape(steps, 0)
+    lo = tape.oracle_replay(data[0], sub)
+    fq = [i for i, x in enumerate(sub) if x["kind"] in ("FREQ", "QRATE", "ALPHA")]
+    assert len(set(np.round(lo[fq], 9))) > len(fq) // 2
