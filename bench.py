@@ -162,6 +162,8 @@ def main():
                     help="attach the kernel start/stop events to every n-th launch of the timed region "
                          "(an event pair costs ~4 us of stream time per launch; 7 is co-prime with the 13 steps "
                          "of an iteration, so every step type is sampled)")
+    ap.add_argument("--no-subst-proposals", action="store_true",
+                    help="GTR configs: leave the per-locus frequency / exchangeability / alpha proposals out of the tape")
     ap.add_argument("--host-in-loop", action="store_true",
                     help="copy the per-locus lnL of every step back to the host before launching the next "
                          "(what a host-resident accept/reject needs; PCIe-inclusive rate, reported in DESIGN.md)")
@@ -231,7 +233,13 @@ def main():
     # ---- the proposal tape (host MCMC control stand-in), then resident plans
     t0 = time.time()
     trees = [TreeState(d["left"], d["right"], d["times"], d["root"]) for d in data]
-    sch = A00Schedule(trees, seed=1 + rank, taus=cfg["taus"])
+    subst = None
+    if cfg["model"] == "gtr" and not args.no_subst_proposals:
+        # the per-locus frequency / exchangeability / alpha proposals of a GTR+Gamma analysis
+        R_ = cfg["rate_cats"]
+        subst = dict(freqs=[d["freqs"] for d in data], exch=[d["exch"] for d in data], alpha=[0.5] * nloci, rate_cats=R_,
+                     gamma=lambda a, cats: bpp_amd.compute_gamma_cats(a, a, cats) if cats > 1 else np.ones(1))
+    sch = A00Schedule(trees, seed=1 + rank, taus=cfg["taus"], subst=subst)
     init = sch.initial_step()
     iters = [sch.iteration() for _ in range(args.tape_iters)]
     log(f"tape: {args.tape_iters} iterations x {len(iters[0])} batched steps in {time.time() - t0:.1f}s")
@@ -245,6 +253,9 @@ def main():
 
     p_init = mkplan(init)
     plans = [[mkplan(st) for st in it] for it in iters]
+    # parameter installs of the tape, resident in HBM: (which, device address) per step, applied through p_init
+    # (which holds every locus) right before the step's launch
+    staged = [[[(w, eng.stage(v)) for w, v in st.params] for st in it] for it in iters]
     p_init.launch()
     lnl0 = p_init.lnl()
     log(f"start-up lnL (sum over loci) = {lnl0.sum():.6f}")
@@ -262,24 +273,33 @@ def main():
     # summed lnL is then all-reduced across ranks — the per-proposal reduction of
     # threads.c:544-591, over xGMI.  One GPU: the whole iteration is one host call.
     segments = []
-    for sts, pls in zip(iters, plans):
-        segs, cur = [], []
-        for st, p in zip(sts, pls):
+    for sts, pls, stg in zip(iters, plans, staged):
+        segs, cur, pre = [], [], []
+        for st, p, installs in zip(sts, pls, stg):
+            if installs and cur:
+                segs.append((pre, bpp_amd.PlanSequence(cur), False))
+                cur, pre = [], []
+            if installs:
+                pre = installs
             cur.append(p)
             if dist is not None and st.global_decision is not None:
-                segs.append((bpp_amd.PlanSequence(cur), True))
-                cur = []
+                segs.append((pre, bpp_amd.PlanSequence(cur), True))
+                cur, pre = [], []
         if cur:
-            segs.append((bpp_amd.PlanSequence(cur), False))
+            segs.append((pre, bpp_amd.PlanSequence(cur), False))
         segments.append(segs)
 
     def run_iteration(i):
         if args.host_in_loop:
-            for p in plans[i % len(plans)]:
+            for p, installs in zip(plans[i % len(plans)], staged[i % len(plans)]):
+                for w, dptr in installs:
+                    p_init.set_params_device(w, dptr)
                 p.launch()
                 p.lnl()                      # sync + 8 B/locus D2H, as host MCMC control would need
             return
-        for seq, reduce_after in segments[i % len(segments)]:
+        for pre, seq, reduce_after in segments[i % len(segments)]:
+            for w, dptr in pre:
+                p_init.set_params_device(w, dptr)
             seq.launch()
             if reduce_after:
                 dist.all_reduce(sum_buf)
@@ -355,8 +375,9 @@ def main():
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"profile_{args.config}.json")))
             pm = json.load(open(cands[-1]))["pmc_per_dispatch"]
-            want = roofline["kernel"].split("<")[0]
-            key = [k for k in pm if want in k and "FETCH_SIZE" in pm[k]][0]
+            want = roofline["kernel"].replace(" ", "")
+            key = [k for k in pm if want in k.replace(" ", "") and "FETCH_SIZE" in pm[k]]
+            key = (key or [k for k in pm if want.split("<")[0] in k and "FETCH_SIZE" in pm[k]])[0]
             roofline["traffic"] = round((2 * pm[key]["FETCH_SIZE"]["mean"] + pm[key]["WRITE_SIZE"]["mean"]) * 1024)
             roofline["traffic_source"] = os.path.relpath(cands[-1], ROOT) + " (separate --pmc passes; FETCH_SIZE doubled per the gfx950 note)"
         except Exception:

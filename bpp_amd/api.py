@@ -101,6 +101,7 @@ def lib():
         "bpa_plan_enable_sum": (i, [vp, vp]),
         "bpa_plan_get_sum": (i, [vp, dp]),
         "bpa_batch_evaluate": (i, [vp, C.POINTER(Batch), dp]),
+        "bpa_engine_stage": (vp, [vp, vp, C.c_size_t]),
         "bpa_plan_set_params": (i, [vp, i, dp]),
         "bpa_plan_set_params_device": (i, [vp, i, vp]),
         "bpa_plan_work": (i, [vp, dp, dp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
@@ -145,7 +146,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
             "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate",
             "bpa_plan_enable_sum", "bpa_plan_get_sum", "bpa_plans_launch",
-            "bpa_plan_set_params", "bpa_plan_set_params_device",
+            "bpa_plan_set_params", "bpa_plan_set_params_device", "bpa_engine_stage",
             "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride",
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
             "bpa_sampler_set_species_tree", "bpa_sampler_set_tip_species", "bpa_sampler_set_finetune",
@@ -222,6 +223,10 @@ class Engine:
     def set_options(self, usedata=1, bfbeta=1.0):
         lib().bpa_engine_set_options(self.h, int(usedata), float(bfbeta))
 
+    def stage(self, array):
+        """copy a host array into engine-owned device memory (a tape resident in HBM); returns the device address"""
+        return _stage(self, array)
+
     def synchronize(self):
         _chk(lib().bpa_engine_synchronize(self.h))
 
@@ -268,6 +273,14 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+
+def _stage(engine, array):
+    a = np.ascontiguousarray(array)
+    p = lib().bpa_engine_stage(engine.h, a.ctypes.data_as(C.c_void_p), a.nbytes)
+    if not p:
+        raise BpaError(_err())
+    return p
 
 
 class Locus:

@@ -106,6 +106,7 @@ struct bpa_engine
   bool own_stream = false;
   Arena arena;
   std::vector<bpa_locus *> loci;
+  std::vector<void *> staged;           // bpa_engine_stage allocations (freed with the engine)
   std::vector<bpa_locus *> dirty;     // loci whose host-side state must be flushed
   DevBuf<LocusDev> d_loci;
   bool table_dirty = true;
@@ -207,9 +208,21 @@ extern "C" void bpa_engine_destroy(bpa_engine_t * e)
   for (auto * l : e->loci) delete l;
   e->arena.release();
   e->d_loci.free(); e->d_eigen_list.free();
+  for (void * q : e->staged) (void)hipFree(q);
   for (auto & s : e->slots) for (auto & ev : s.ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
   delete e;
+}
+
+extern "C" void * bpa_engine_stage(bpa_engine_t * e, const void * host, size_t bytes)
+{
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  if (!set_device(e) || !host || !bytes) { fail("bpa_engine_stage: bad arguments"); return nullptr; }
+  void * q = nullptr;
+  HIPCHK_PTR(hipMalloc(&q, bytes));
+  if (hipMemcpy(q, host, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(q); fail("bpa_engine_stage: copy failed"); return nullptr; }
+  e->staged.push_back(q);
+  return q;
 }
 
 extern "C" int bpa_engine_synchronize(bpa_engine_t * e)

@@ -207,6 +207,9 @@ int          bpa_plan_get_sum(bpa_plan_t *, double * sum);
    [locus of the plan][value].  ONE transfer (or none: the _device form takes device memory), one kernel that
    installs them and refreshes the touched eigensystems on the device (K6, pll_update_eigen).  The next launch
    of a plan that updates all matrices and partials then evaluates the proposal.                            */
+/* a caller-side tape resident in HBM: copy `bytes` from the host into device memory owned by the engine (freed
+   with it) and return the device address, e.g. the value arrays bpa_plan_set_params_device reads            */
+void *       bpa_engine_stage(bpa_engine_t *, const void * host, size_t bytes);
 int          bpa_plan_set_params(bpa_plan_t *, int which, const double * values);
 int          bpa_plan_set_params_device(bpa_plan_t *, int which, const double * device_values);
 /* convenience: create + launch + get + destroy                                    */
