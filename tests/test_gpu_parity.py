@@ -473,3 +473,44 @@ def test_concurrent_calls_on_different_loci(engine):
     for t in ts:
         t.join()
     assert not errs, errs[:3]
+
+
+def test_concurrent_callers_on_different_loci(engine):
+    """SURVEY section 8b, threading: BPP's worker threads call the locus API for DIFFERENT loci concurrently
+    (threads.c:87-200).  Eight threads hammer their own loci through the single-locus calls; every result must
+    equal the serial one (the engine serialises internally; ctypes releases the GIL around each call)."""
+    import threading
+    rng = np.random.default_rng(17)
+    cases = []
+    for i in range(32):
+        tips, sites = int(rng.integers(3, 9)), int(rng.integers(5, 60))
+        seqs = rand_seqs(tips, sites, NT, rng, extra="-N")
+        w = rng.integers(1, 50, sites)
+        model = "jc69" if i % 2 else "gtr"
+        fr = None if model == "jc69" else rng.dirichlet(np.full(4, 10.0))
+        qr = None if model == "jc69" else np.append(np.exp(rng.normal(0, 0.3, 5)), 1.0)
+        R = 1 if model == "jc69" else 4
+        rates = None if R == 1 else bpp_amd.compute_gamma_cats(0.7, 0.7, 4)
+        loc = make_locus(engine, 4, R, model, seqs, w, fr, qr, rates)
+        trees = [GTree(*rand_tree(tips, rng, 0.02)) for _ in range(6)]
+        cases.append((loc, trees))
+    serial = [[full_eval(loc, gt) for gt in trees] for loc, trees in cases]
+    out = [[None] * 6 for _ in cases]
+    errs = []
+
+    def worker(k):
+        try:
+            for rep in range(3):
+                for i in range(k, len(cases), 8):
+                    loc, trees = cases[i]
+                    for j, gt in enumerate(trees):
+                        out[i][j] = full_eval(loc, gt)
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert out == serial
