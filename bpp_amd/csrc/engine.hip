@@ -677,7 +677,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
     // at least two slots so the eager loads of the first two stay in bounds)
     static_assert(sizeof(TaskRec) == 96 && sizeof(OpDev) == 32 && sizeof(MatRec) == 32, "record layout");
     std::vector<uint4> recs;
-    std::vector<uint32_t> task_rec(T), lane_rec(lane_task.size(), 0xffffffffu);
+    std::vector<uint32_t> task_rec(T + 1), lane_rec(lane_task.size(), 0xffffffffu);      // [T]: end of the last record
     std::vector<MatRec> mrecs(nmat);
     static_assert(sizeof(OpSlot) == 48, "op slot layout");
     bool all1 = true, all4 = true, all_jc = true;
@@ -724,7 +724,8 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
     }
     if (!upload(p->recs, recs.data(), recs.size())) return 0;
     if (!upload(p->lane_rec, lane_rec.data(), lane_rec.size())) return 0;
-    if (!upload(p->task_rec, task_rec.data(), T)) return 0;
+    task_rec[T] = (uint32_t)recs.size();
+    if (!upload(p->task_rec, task_rec.data(), T + 1)) return 0;
     if (!upload(p->mat_recs, mrecs.data(), nmat)) return 0;
     d.recs = p->recs.p; d.lane_rec = p->lane_rec.p; d.task_rec = p->task_rec.p; d.mat_recs = p->mat_recs.p;
     p->fused_rt = all1 ? 1 : (all4 ? 4 : 0);
@@ -809,8 +810,14 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     }
     else if (p->fused_jc69)
     {
-      if (p->fused_bs == 64) hipExtLaunchKernelGGL((step_jc69_kernel<64>), grid, dim3(64), 0, e->stream, k0, k1, 0, d);
-      else                   hipExtLaunchKernelGGL((step_jc69_kernel<256>), grid, dim3(256), 0, e->stream, k0, k1, 0, d);
+      static const bool late = getenv("BPA_JC69_LATE") != nullptr;       // A/B: the exponentials on the update lanes, tail at the end
+      if (late)
+      {
+        if (p->fused_bs == 64) hipExtLaunchKernelGGL((step_jc69_kernel<64, false>), grid, dim3(64), 0, e->stream, k0, k1, 0, d);
+        else                   hipExtLaunchKernelGGL((step_jc69_kernel<256, false>), grid, dim3(256), 0, e->stream, k0, k1, 0, d);
+      }
+      else if (p->fused_bs == 64) hipExtLaunchKernelGGL((step_jc69_kernel<64, true>), grid, dim3(64), 0, e->stream, k0, k1, 0, d);
+      else                        hipExtLaunchKernelGGL((step_jc69_kernel<256, true>), grid, dim3(256), 0, e->stream, k0, k1, 0, d);
     }
     else if (p->fused_bs == 64 && p->fused_rt == 4 && (d.flags & 1u) && (d.flags & 6u) && getenv("BPA_FUSED_SPLIT"))
     {

@@ -1705,11 +1705,17 @@ __device__ __forceinline__ void expand_code(const uint32_t code, double v[4])
   v[2] = (code & 4u) ? 1.0 : 0.0; v[3] = (code & 8u) ? 1.0 : 0.0;
 }
 
-template <int BS>
+// EARLY: the step's fresh (a, b) pairs are produced by the first lanes of the workgroup (one branch each, from the
+// MatRec and branch length they fetched at kernel entry) while the update lanes are still waiting for their records,
+// handed over through LDS and written to HBM right there: the exponentials (up to six per lane before) and the old
+// tail leave the update lanes' critical path for one workgroup barrier that overlaps the record fetch.
+template <int BS, bool EARLY = true>
 __global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
 {
   constexpr int NPRE = 3;                       // node updates whose inputs are preloaded
+  constexpr uint32_t NAB = 2*BS;                // fresh (a, b) pairs a workgroup can hand over through LDS
   __shared__ double s_term[BS];
+  __shared__ double2 s_ab[EARLY ? NAB : 1];
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
   const uint32_t gl = b*BS + lane;
   BPA_STAMP(P, b, lane, 0);
@@ -1741,20 +1747,46 @@ __global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
 
   if (have_m0) m0_rate = m0.par[par_rates(1)];
 
-  double term = 0;
-  if (active && (P.flags & 6u))
+  const bool work = active && (P.flags & 6u);
+  // (tried: the workgroup's contiguous records staged in LDS by all lanes, in parallel with the lane -> record lookup,
+  //  to save one dependent hop: 12.0 us instead of 10.85 — the barrier then waits for the slowest lane's share)
+  const uint4 * rp = P.recs + (active ? ro : 0u);
+  TaskRec T{};
+  OpSlot sl[NPRE];
+  if (work)
   {
-    const uint4 * rp = P.recs + ro;
-    TaskRec T;
-    OpSlot sl[NPRE];
+    uint4 * dst = reinterpret_cast<uint4 *>(&T);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dst[i] = rp[i];
+    uint4 * ds = reinterpret_cast<uint4 *>(sl);
+#pragma unroll
+    for (int i = 0; i < 3*NPRE; ++i) ds[i] = rp[6 + i];
+  }
+  const bool use_lds = EARLY && do_mats;
+  if (EARLY)
+  {
+    // K4 for this step's branches (locus.c:2342-2414), one branch per lane, while the records are in flight
+    if (have_m0)
     {
-      uint4 * dst = reinterpret_cast<uint4 *>(&T);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) dst[i] = rp[i];
-      uint4 * ds = reinterpret_cast<uint4 *>(sl);
-#pragma unroll
-      for (int i = 0; i < 3*NPRE; ++i) ds[i] = rp[6 + i];
+      double2 ab;
+      jc69_ab(m0_len, m0_rate, ab.x, ab.y);
+      *reinterpret_cast<double2 *>(m0.dst) = ab;
+      s_ab[lane] = ab;
+      for (uint32_t e = e0 + lane + BS; e < e1; e += BS)
+      {
+        const MatRec m = P.mat_recs[e];
+        double2 ab2;
+        jc69_ab(P.mat_length[m.entry], m.par[par_rates(1)], ab2.x, ab2.y);
+        *reinterpret_cast<double2 *>(m.dst) = ab2;
+        if (e - e0 < NAB) s_ab[e - e0] = ab2;
+      }
     }
+    if (do_mats) __syncthreads();
+  }
+
+  double term = 0;
+  if (work)
+  {
     BPA_STAMP(P, b, lane, 2);
     const uint32_t n = gl - T.lane0, np = T.np, tips = T.tips_n;
     const uint32_t nops = (P.flags & 2u) ? T.nops : 0u;
@@ -1808,12 +1840,14 @@ __global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
           const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.left_pmatrix*2);
           abl[i][0] = ab.x; abl[i][1] = ab.y;
         }
+        else if (use_lds && (uint32_t)sl[i].left_e - e0 < NAB) { const double2 ab = s_ab[(uint32_t)sl[i].left_e - e0]; abl[i][0] = ab.x; abl[i][1] = ab.y; }
         else abl[i][0] = P.mat_length[sl[i].left_e];
         if (sl[i].right_e < 0)
         {
           const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.right_pmatrix*2);
           abr[i][0] = ab.x; abr[i][1] = ab.y;
         }
+        else if (use_lds && (uint32_t)sl[i].right_e - e0 < NAB) { const double2 ab = s_ab[(uint32_t)sl[i].right_e - e0]; abr[i][0] = ab.x; abr[i][1] = ab.y; }
         else abr[i][0] = P.mat_length[sl[i].right_e];
       }
     }
@@ -1841,8 +1875,8 @@ __global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
             if (fwr[i] == (uint32_t)j) rv[q] = res[j][q];
           }
         }
-        if (sl[i].left_e < 0)  { al = abl[i][0]; bl_ = abl[i][1]; } else jc69_ab(abl[i][0], rate, al, bl_);
-        if (sl[i].right_e < 0) { ar = abr[i][0]; br = abr[i][1]; } else jc69_ab(abr[i][0], rate, ar, br);
+        if (sl[i].left_e < 0 || (use_lds && (uint32_t)sl[i].left_e - e0 < NAB))   { al = abl[i][0]; bl_ = abl[i][1]; } else jc69_ab(abl[i][0], rate, al, bl_);
+        if (sl[i].right_e < 0 || (use_lds && (uint32_t)sl[i].right_e - e0 < NAB)) { ar = abr[i][0]; br = abr[i][1]; } else jc69_ab(abr[i][0], rate, ar, br);
         matvec4_ab(al, bl_, lv, x);
         matvec4_ab(ar, br, rv, y);
         res[i][0] = x[0]*y[0]; res[i][1] = x[1]*y[1]; res[i][2] = x[2]*y[2]; res[i][3] = x[3]*y[3];
@@ -1879,8 +1913,10 @@ __global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
       if (op.right_clv == last_clv) { rv[0] = last[0]; rv[1] = last[1]; rv[2] = last[2]; rv[3] = last[3]; }
       else load_vec4(T, op.right_clv, 0, n, rv);
       if (s.left_e < 0)  { const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.left_pmatrix*2);  al = ab.x; bl_ = ab.y; }
+      else if (use_lds && (uint32_t)s.left_e - e0 < NAB) { const double2 ab = s_ab[(uint32_t)s.left_e - e0]; al = ab.x; bl_ = ab.y; }
       else jc69_ab(P.mat_length[s.left_e], rate, al, bl_);
       if (s.right_e < 0) { const double2 ab = *reinterpret_cast<const double2 *>(T.pmat + (size_t)op.right_pmatrix*2); ar = ab.x; br = ab.y; }
+      else if (use_lds && (uint32_t)s.right_e - e0 < NAB) { const double2 ab = s_ab[(uint32_t)s.right_e - e0]; ar = ab.x; br = ab.y; }
       else jc69_ab(P.mat_length[s.right_e], rate, ar, br);
       matvec4_ab(al, bl_, lv, x);
       matvec4_ab(ar, br, rv, y);
@@ -1937,7 +1973,7 @@ __global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
   BPA_STAMP(P, b, lane, 6);
 
   // ---- tail: the step's P-matrices (their (a, b) pairs) go to HBM for later steps (K4)
-  if (have_m0)
+  if (!EARLY && have_m0)
   {
     double2 ab;
     jc69_ab(m0_len, m0_rate, ab.x, ab.y);
