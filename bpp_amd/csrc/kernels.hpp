@@ -432,11 +432,29 @@ partials_lnl_tiledk_kernel(const PlanDev P)
     bool all_small = true;
     if (active)
     {
-      double lv[S], rv[S];
-      load_childN<S, uint32_t>(L, op.left_clv,  k, n, lv);
-      load_childN<S, uint32_t>(L, op.right_clv, k, n, rv);
       const double * lm = s_p + (size_t)k*SS;
       const double * rm = s_p + (size_t)(R + k)*SS;
+      // Tip children (the tip-code fast path, core_partials.c:48-583 in spirit): a tip's CLV is the 0/1 expansion of
+      // its state code, so for an unambiguous state s the reference's dot product adds exact zeros to P[i][s] — the
+      // result IS P[i][s], bit for bit, and the 20 multiply-adds and 19 of the 20 P reads are skipped.  Taken when
+      // every lane of the wave holds an unambiguous code (wave-uniform branch); ambiguity codes take the full dot.
+      int ls = -1, rs = -1;
+      bool lfast = false, rfast = false;
+      if (op.left_clv < L.tips_n)
+      {
+        const uint32_t code = reinterpret_cast<const uint32_t *>(L.tips)[(size_t)op.left_clv*np + n];
+        ls = __ffs(code) - 1;
+        lfast = __all(__popc(code) == 1);
+      }
+      if (op.right_clv < L.tips_n)
+      {
+        const uint32_t code = reinterpret_cast<const uint32_t *>(L.tips)[(size_t)op.right_clv*np + n];
+        rs = __ffs(code) - 1;
+        rfast = __all(__popc(code) == 1);
+      }
+      double lv[S], rv[S];
+      if (!lfast) load_childN<S, uint32_t>(L, op.left_clv,  k, n, lv);
+      if (!rfast) load_childN<S, uint32_t>(L, op.right_clv, k, n, rv);
       if (V == 4)
       {
         // both P rows of an output state are requested in one burst of LDS reads (20 ds_read_b128) and
@@ -452,8 +470,8 @@ partials_lnl_tiledk_kernel(const PlanDev P)
 #pragma unroll
           for (int j = 0; j < S/2; ++j) { const double2 a = qr[j]; pr[2*j] = a.x; pr[2*j+1] = a.y; }
           __builtin_amdgcn_sched_barrier(0);
-          const double x = dot_fma4<S>(pl, lv);
-          const double y = dot_fma4<S>(pr, rv);
+          const double x = lfast ? lm[i*S + ls] : dot_fma4<S>(pl, lv);
+          const double y = rfast ? rm[i*S + rs] : dot_fma4<S>(pr, rv);
           const double v = x*y;
           all_small = all_small && (v < BPA_SCALE_THRESHOLD);
           out[(size_t)i*np] = v;
@@ -464,8 +482,8 @@ partials_lnl_tiledk_kernel(const PlanDev P)
 #pragma unroll 2
         for (int i = 0; i < S; ++i)
         {
-          const double x = dot_fma4<S>(lm + i*S, lv);
-          const double y = dot_fma4<S>(rm + i*S, rv);
+          const double x = lfast ? lm[i*S + ls] : dot_fma4<S>(lm + i*S, lv);
+          const double y = rfast ? rm[i*S + rs] : dot_fma4<S>(rm + i*S, rv);
           const double v = x*y;
           all_small = all_small && (v < BPA_SCALE_THRESHOLD);
           out[(size_t)i*np] = v;
