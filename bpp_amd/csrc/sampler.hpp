@@ -390,7 +390,10 @@ __device__ bool propose_gspr(TaskLDS & S, int k, double rate, const Species & sp
 __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
 {
   __shared__ TaskLDS s_task[TPB];
-  __shared__ double  s_clv[MAXBUF][BS][4];
+  // CLV buffers of the workgroup's 64 lanes: 2*(tips-1) of them, sized at launch — with the fixed 8-tip size a
+  // workgroup needed 52 KB of LDS, three fitted a CU, and config 2's 839 workgroups ran in two rounds on 768 slots
+  extern __shared__ __attribute__((aligned(16))) double s_clv_raw[];
+  double (*s_clv)[BS][4] = reinterpret_cast<double (*)[BS][4]>(s_clv_raw);
   __shared__ double  s_term[BS];
   __shared__ double  s_tau[3*MAXPOP];                    // tau | theta | log(2/theta) of this launch's (proposed) species tree
   const uint32_t b = blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
@@ -869,7 +872,7 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
   if (getenv("BPA_SMP_TRACE"))
   {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipExtLaunchKernelGGL(smp::sweep_kernel, dim3(s->nblocks), dim3(smp::BS), 0, e->stream, e0, e1, 0, a);
+    hipExtLaunchKernelGGL(smp::sweep_kernel, dim3(s->nblocks), dim3(smp::BS), (size_t)2*(s->maxtips - 1)*smp::BS*4*sizeof(double), e->stream, e0, e1, 0, a);
     (void)hipStreamSynchronize(e->stream);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     fprintf(stderr, "[smp] mode %u gage %u gspr %u epoch %u blocks %u: %.1f us\n", mode, a.nsteps_gage, a.nsteps_gspr, a.epoch, s->nblocks, ms*1e3);
@@ -883,7 +886,7 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
     s->launches++;
     return 1;
   }
-  hipLaunchKernelGGL(smp::sweep_kernel, dim3(s->nblocks), dim3(smp::BS), 0, e->stream, a);
+  hipLaunchKernelGGL(smp::sweep_kernel, dim3(s->nblocks), dim3(smp::BS), (size_t)2*(s->maxtips - 1)*smp::BS*4*sizeof(double), e->stream, a);
   HIPCHK(hipGetLastError());
   s->launches++;
   return 1;
