@@ -465,6 +465,16 @@ def locus_update_partials(locus, traversal, count=None):
     locus.update_partials(np.array([node_op(nd) for nd in trav], dtype=OP_DTYPE))
 
 
+def locus_update_all_matrices(locus, gtree):
+    """locus_update_all_matrices (locus.c:1922): every branch of the gene tree."""
+    locus_update_matrices(locus, gtree, gtree.branches())
+
+
+def locus_update_all_partials(locus, gtree):
+    """locus_update_all_partials (locus.c:2523, the post-order recursion of 2482): every inner node."""
+    locus_update_partials(locus, gtree.postorder())
+
+
 def locus_root_loglikelihood(locus, root, persite=False):
     """locus_root_loglikelihood (locus.c:2573)."""
     return locus.root_loglikelihood(root.clv_index, root.scaler_index, persite)

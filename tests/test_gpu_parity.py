@@ -54,8 +54,8 @@ def make_locus(engine, S, R, model, seqs, weights, freqs=None, qrates=None, rate
 
 def full_eval(loc, gt):
     """the start-up sequence of method.c:4285-4297"""
-    locus_update_matrices(loc, gt, gt.branches())
-    locus_update_partials(loc, gt.postorder())
+    bpp_amd.locus_update_all_matrices(loc, gt)
+    bpp_amd.locus_update_all_partials(loc, gt)
     return locus_root_loglikelihood(loc, gt.root)
 
 
