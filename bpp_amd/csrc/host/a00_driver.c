@@ -263,7 +263,7 @@ static int climb(const a00_driver_t * d, int p, double t)
 
 /* gtree_logprob (gtree.c:3957): the sum over populations, in stree->nodes order, of
    gtree_update_logprob_contrib; NAN if the tree does not fit the species tree */
-static double tree_logpr(const a00_driver_t * d, const a00_tree_t * t)
+static double tree_logpr_stats(const a00_driver_t * d, const a00_tree_t * t, int * nc_out, double * t2h_out)
 {
   int nin[A00_MAXPOP], nc[A00_MAXPOP], p, k; double times[MAXN], logpr = 0;
   for (p = 0; p < d->npop; ++p) nin[p] = 0;
@@ -282,10 +282,15 @@ static double tree_logpr(const a00_driver_t * d, const a00_tree_t * t)
       }
     nc[p] = n;
     if (n >= nin[p] && n > 0) return NAN;
-    logpr += a00_msc_contrib(d->tau[p], d->sp_parent[p] >= 0 ? d->tau[d->sp_parent[p]] : -1.0, d->theta[p], 1.0, nin[p], times, n);
+    {
+      const double T2h = a00_msc_t2h(d->tau[p], d->sp_parent[p] >= 0 ? d->tau[d->sp_parent[p]] : -1.0, nin[p], times, n);
+      if (nc_out) { nc_out[p] = n; t2h_out[p] = T2h; }
+      logpr += a00_msc_term(n, T2h, d->theta[p], 1.0);
+    }
   }
   return logpr;
 }
+static double tree_logpr(const a00_driver_t * d, const a00_tree_t * t) { return tree_logpr_stats(d, t, NULL, NULL); }
 
 double a00_locus_logpr(const a00_driver_t * d, unsigned i) { return tree_logpr(d, d->trees + i); }
 
@@ -481,28 +486,37 @@ static int gspr_step(a00_driver_t * d, int k)
   return 1;
 }
 
-/* THETA of population p: sliding window reflected at 0, gamma(alpha, beta) prior; only the MSC density
-   changes — no likelihood call; ONE decision from sum(dlogpr) + prior ratio (stree.c:3464-3560 family) */
-static int theta_step(a00_driver_t * d, int p)
+/* THETA: every population that can hold a coalescence gets a sliding-window proposal (reflected at 0) with a
+   gamma(alpha, beta) prior; only the MSC density changes — no likelihood call.  Given the gene trees the thetas are
+   independent (the density is a sum of per-population terms), so all are proposed from the same state and each is
+   decided on its own  sum over loci of [term(theta') - term(theta)] + prior ratio  (stree.c:3464-3560 family). */
+static int theta_step_all(a00_driver_t * d)
 {
-  unsigned i; double sum = 0;
-  const double old = d->theta[p];
-  const double tnew = a00_reflect(old + d->ft_theta*(a00_rndu(&d->grng) - 0.5), 0.0, 999.0);
-  const double uacc = a00_rndu(&d->grng);
-  d->theta[p] = tnew;
+  unsigned i; int p;
+  double tnew[A00_MAXPOP], uacc[A00_MAXPOP], sum[A00_MAXPOP];
+  for (p = 0; p < d->npop; ++p)
+  {
+    sum[p] = 0; tnew[p] = d->theta[p];
+    if (!d->has_theta[p]) continue;
+    tnew[p] = a00_reflect(d->theta[p] + d->ft_theta*(a00_rndu(&d->grng) - 0.5), 0.0, 999.0);
+    uacc[p] = a00_rndu(&d->grng);
+  }
   for (i = 0; i < d->nloci; ++i)
   {
-    d->p_logpr[i] = tree_logpr(d, d->trees + i);
-    sum += d->p_logpr[i] - d->trees[i].logpr;
+    int nc[A00_MAXPOP]; double t2h[A00_MAXPOP];
+    (void)tree_logpr_stats(d, d->trees + i, nc, t2h);
+    for (p = 0; p < d->npop; ++p)
+      if (d->has_theta[p]) sum[p] += a00_msc_term(nc[p], t2h[p], tnew[p], 1.0) - a00_msc_term(nc[p], t2h[p], d->theta[p], 1.0);
   }
-  sum += (d->theta_alpha - 1)*log(tnew/old) - d->theta_beta*(tnew - old);
-  d->proposals++;
-  if (tnew > 0 && (sum >= 0 || uacc < exp(sum)))
+  for (p = 0; p < d->npop; ++p)
   {
-    d->accepted++;
-    for (i = 0; i < d->nloci; ++i) d->trees[i].logpr = d->p_logpr[i];
+    double lnacc;
+    if (!d->has_theta[p]) continue;
+    lnacc = sum[p] + ((d->theta_alpha - 1)*log(tnew[p]/d->theta[p]) - d->theta_beta*(tnew[p] - d->theta[p]));
+    d->proposals++;
+    if (tnew[p] > 0 && (lnacc >= 0 || uacc[p] < exp(lnacc))) { d->accepted++; d->theta[p] = tnew[p]; }
   }
-  else d->theta[p] = old;
+  for (i = 0; i < d->nloci; ++i) d->trees[i].logpr = tree_logpr(d, d->trees + i);
   return 1;
 }
 
@@ -608,8 +622,7 @@ int a00_iterate(a00_driver_t * d)
   for (i = 0; i < d->nloci; ++i) if (d->trees[i].tips > maxtips) maxtips = d->trees[i].tips;
   for (k = 0; k < maxtips - 1; ++k)   if (!gage_step(d, k)) return 0;
   for (k = 0; k < 2*maxtips - 2; ++k) if (!gspr_step(d, k)) return 0;
-  if (d->theta_alpha > 0)
-    for (k = 0; k < d->npop; ++k)     if (d->has_theta[k] && !theta_step(d, k)) return 0;
+  if (d->theta_alpha > 0 && !theta_step_all(d)) return 0;
   for (k = d->S; k < d->npop; ++k)    if (!tau_step(d, k)) return 0;
   return mix_step(d);
 }

@@ -85,6 +85,7 @@ struct Args
   const double * taus;         // device-resident species-tree parameters: [MAXPOP] tau | [MAXPOP] theta | [MAXPOP] log(2/theta)
   uint32_t tau_q;              // population of the TAU (mode 4) / THETA (mode 5) step
   double   tau_u;              // its window uniform
+  int8_t * pop_nc; double * pop_t2h;      // [T][MAXPOP] sufficient statistics of every locus's density, written by the sweep
   uint32_t dbg;                // timing experiments only (BPA_SMP_DBG): 1 skip the node updates, 2 skip the density, 4 skip the proposal
   double   bfbeta;             // 0 with opt_usedata == 0 (locus.c:2581): the sampler then draws from the MSC prior
   Species  sp;
@@ -175,7 +176,7 @@ __device__ __forceinline__ int climb(const Species & sp, const double * tau, int
 // of a sort buffer: same intervals, same order of additions as a00_msc_contrib).  Only the
 // populations in `mask` are recomputed (into the *_new fields); the others keep their term — the
 // terms are pure functions of the tree, so the sum equals the host's from-scratch one bit for bit.
-__device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau, uint32_t mask)
+__device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau, uint32_t mask, double * t2h_out = nullptr)
 {
   const Tree & t = S.tr;
   const int n = 2*t.tips - 1;
@@ -223,6 +224,7 @@ __device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau
     if (ncoal) c += ncoal*tau[2*MAXPOP + p];
     if (T2h) c -= T2h/(tau[MAXPOP + p]*1.0);
     S.contrib_new[p] = c;
+    if (t2h_out) t2h_out[p] = T2h;
     logpr += c;
   }
   return logpr;
@@ -635,6 +637,12 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     const uint32_t npm = 2*(2*tips - 2);
     for (uint32_t i = 0; i < npm; ++i) { g_pmat[2*i] = S.ab[i][0]; g_pmat[2*i+1] = S.ab[i][1]; }
     if (S.prof_on) for (int i = 0; i < 8; ++i) A.mix_delta[i] = (double)S.prof[i];
+    if (A.mode == 0)
+    {
+      // the sufficient statistics of the final state, for the THETA kernels (kept out of LDS: a workgroup must stay under 40 KB)
+      (void)tree_logpr(s_task[ts], sp, s_tau, (1u << sp.npop) - 1u, A.pop_t2h + (size_t)task*MAXPOP);
+      for (int p = 0; p < sp.npop; ++p) A.pop_nc[(size_t)task*MAXPOP + p] = s_task[ts].nc_new[p];
+    }
   }
   if (active && nprop && A.mode != 5)
   {
@@ -712,6 +720,70 @@ __global__ void __launch_bounds__(1024) sum_decide_kernel(const double * __restr
   if (threadIdx.x == 0) decide(sh[0], u, epoch, flag, counters, taus, sp, tau_q, theta_p, win_u, mix_c, mix_lnc);
 }
 
+// THETA (theta_step_all of a00_driver.c): one workgroup per population.  The per-locus terms come from the sufficient
+// statistics the sweep left behind (no tree is loaded), are summed in a fixed order and the population's own decision
+// is taken right here — the thetas are conditionally independent given the gene trees.  ext_sum != NULL: the sums were
+// made (and all-reduced over the ranks) beforehand, only decide.
+__device__ __forceinline__ double msc_term(int ncoal, double T2h, double theta, double l2t)
+{
+  double c = 0;
+  if (ncoal) c += ncoal*l2t;
+  if (T2h) c -= T2h/(theta*1.0);
+  return c;
+}
+struct ThetaArgs { double win_u[MAXPOP], uacc[MAXPOP]; uint32_t on[MAXPOP]; };
+
+__global__ void __launch_bounds__(1024) theta_sum_decide_kernel(const int8_t * __restrict__ pop_nc, const double * __restrict__ pop_t2h,
+                                                                uint32_t T, double * taus, Species sp, ThetaArgs ta,
+                                                                uint32_t * counters, double * sums_out, const double * ext_sum,
+                                                                int decide_on)
+{
+  __shared__ double sh[1024];
+  const int p = (int)blockIdx.x;
+  if (!ta.on[p]) return;
+  const double told = taus[MAXPOP + p], l2t_old = taus[2*MAXPOP + p];
+  const double tnew = reflect(told + sp.ft_theta*(ta.win_u[p] - 0.5), 0.0, 999.0);
+  const double l2t_new = log(2.0/(1.0*tnew));
+  double total;
+  if (ext_sum) total = ext_sum[p];
+  else
+  {
+    double acc = 0;
+    for (uint32_t i = threadIdx.x; i < T; i += 1024)
+    {
+      const int nc = pop_nc[(size_t)i*MAXPOP + p]; const double t2h = pop_t2h[(size_t)i*MAXPOP + p];
+      acc += msc_term(nc, t2h, tnew, l2t_new) - msc_term(nc, t2h, told, l2t_old);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t w = 512; w > 0; w >>= 1)
+    {
+      if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+      __syncthreads();
+    }
+    total = sh[0];
+    if (threadIdx.x == 0 && sums_out) sums_out[p] = total;
+  }
+  if (threadIdx.x || !decide_on) return;
+  const double lnacc = total + ((sp.theta_alpha - 1)*log(tnew/told) - sp.theta_beta*(tnew - told));
+  const bool accept = tnew > 0 && (lnacc >= 0 || ta.uacc[p] < exp(lnacc));
+  atomicAdd(&counters[0], 1u); if (accept) atomicAdd(&counters[1], 1u);
+  if (accept) { taus[MAXPOP + p] = tnew; taus[2*MAXPOP + p] = l2t_new; }
+}
+
+// after the THETA decisions: every locus's density from its statistics and the current thetas (populations in order:
+// the additions of tree_logpr)
+__global__ void __launch_bounds__(256) theta_refresh_kernel(const int8_t * __restrict__ pop_nc, const double * __restrict__ pop_t2h,
+                                                            uint32_t T, const double * __restrict__ taus, int npop, Tree * trees)
+{
+  const uint32_t i = blockIdx.x*256 + threadIdx.x;
+  if (i >= T) return;
+  double logpr = 0;
+  for (int p = 0; p < npop; ++p)
+    logpr += msc_term(pop_nc[(size_t)i*MAXPOP + p], pop_t2h[(size_t)i*MAXPOP + p], taus[MAXPOP + p], taus[2*MAXPOP + p]);
+  trees[i].logpr = logpr;
+}
+
 } // namespace smp
 
 // ------------------------------------------------------------------------------------ host ---
@@ -722,7 +794,8 @@ struct bpa_sampler
   std::vector<bpa_locus *> loci;
   DevBuf<uint32_t> task_locus, blk_task_off, lane_task, task_lane0, flag, counters;
   DevBuf<smp::Tree> trees, snap;
-  DevBuf<double> mix_delta, mix_sum, taus;
+  DevBuf<double> mix_delta, mix_sum, taus, pop_t2h, theta_sums;
+  DevBuf<int8_t> pop_nc;
   smp::Species sp{};                    // species tree (host copy; the taus below are only the start values)
   bool has_theta[smp::MAXPOP] = {};     // populations that can hold a coalescence (a00_initialize)
   bpa_allreduce_fn allreduce = nullptr; // several GPUs: sum the all-loci steps' device scalar over the ranks
@@ -772,7 +845,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   (void)hipSetDevice(s->eng->device); g_cur_device = s->eng->device;
   (void)hipStreamSynchronize(s->eng->stream);
   s->task_locus.free(); s->blk_task_off.free(); s->lane_task.free(); s->task_lane0.free(); s->flag.free();
-  s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free();
+  s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free();
   delete s;
 }
 
@@ -846,7 +919,8 @@ static int sampler_upload(bpa_sampler * s)
       !upload(s->lane_task, lane_task.data(), lane_task.size()) || !upload(s->task_lane0, lane0.data(), T) ||
       !upload(s->trees, s->h_trees.data(), T) || !upload(s->snap, s->h_trees.data(), T) ||
       !upload(s->flag, zero2, 1) || !upload(s->counters, zero2, 2) || !s->mix_delta.reserve(T) || !s->mix_sum.reserve(1) ||
-      !upload(s->taus, s->h_taus.data(), s->h_taus.size()))
+      !upload(s->taus, s->h_taus.data(), s->h_taus.size()) || !s->pop_t2h.reserve((size_t)T*smp::MAXPOP) ||
+      !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP))
     return 0;
   s->epoch = 0; s->mix_pending = false;
   s->uploaded = true;
@@ -865,6 +939,7 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
   a.epoch = s->mix_pending ? s->epoch : 0u;
   s->mix_pending = false;
   a.bfbeta = e->usedata ? e->bfbeta : 0.0;
+  a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p;
   if (const char * dv = getenv("BPA_SMP_DBG")) a.dbg = (uint32_t)atoi(dv);
   a.taus = s->taus.p; a.tau_q = tau_q; a.tau_u = tau_u; a.sp = s->sp; a.mix_lnc = mix_lnc;
   a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2; a.mix_c = mix_c;
@@ -1034,13 +1109,35 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
     if (!sampler_launch(s, 0, 1.0)) return 0;                    // GAGE + GSPR of every locus (settles a pending mix first)
     if (getenv("BPA_SMP_NOMIX")) continue;
     if (s->sp.theta_alpha > 0)
-      for (int p = 0; p < s->sp.npop; ++p)                        // one THETA step per population that can hold a coalescence
+    {
+      // THETA for every population that can hold a coalescence, from the statistics the sweep just stored: the sums and
+      // the (independent) decisions in one launch, then every locus's density with the new thetas
+      smp::ThetaArgs ta{};
+      for (int p = 0; p < s->sp.npop; ++p)
+        if (s->has_theta[p]) { ta.on[p] = 1u; ta.win_u[p] = a00_rndu(&s->grng); ta.uacc[p] = a00_rndu(&s->grng); }
+      if (!s->allreduce)
+        hipLaunchKernelGGL(smp::theta_sum_decide_kernel, dim3(s->sp.npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p,
+                           s->nloci, s->taus.p, s->sp, ta, s->counters.p, (double *)nullptr, (const double *)nullptr, 1);
+      else
       {
-        if (!s->has_theta[p]) continue;
-        const double uprop = a00_rndu(&s->grng), uacc_t = a00_rndu(&s->grng);
-        if (!sampler_launch(s, 5, 1.0, 0.0, (unsigned)p, uprop)) return 0;
-        if (!sampler_decide(s, uacc_t, -1, p, uprop, 1.0, 0.0)) return 0;
+        hipLaunchKernelGGL(smp::theta_sum_decide_kernel, dim3(s->sp.npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p,
+                           s->nloci, s->taus.p, s->sp, ta, s->counters.p, s->theta_sums.p, (const double *)nullptr, 0);
+        double * ar = s->sum_ext ? s->sum_ext : s->mix_sum.p;          // the double the callback's collective addresses
+        for (int p = 0; p < s->sp.npop; ++p)
+        {
+          if (!s->has_theta[p]) continue;
+          HIPCHK(hipMemcpyAsync(ar, s->theta_sums.p + p, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+          if (!s->allreduce(s->allreduce_ctx, ar, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
+          HIPCHK(hipMemcpyAsync(s->theta_sums.p + p, ar, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        }
+        hipLaunchKernelGGL(smp::theta_sum_decide_kernel, dim3(s->sp.npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p,
+                           s->nloci, s->taus.p, s->sp, ta, s->counters.p, (double *)nullptr, (const double *)s->theta_sums.p, 1);
       }
+      hipLaunchKernelGGL(smp::theta_refresh_kernel, dim3((s->nloci + 255)/256), dim3(256), 0, e->stream, s->pop_nc.p, s->pop_t2h.p,
+                         s->nloci, s->taus.p, (int)s->sp.npop, s->trees.p);
+      HIPCHK(hipGetLastError());
+      s->launches += 2;
+    }
     for (int q = s->sp.S; q < s->sp.npop; ++q)                    // one rubber-band step per species divergence
     {
       const double uprop = a00_rndu(&s->grng), uacc_t = a00_rndu(&s->grng);

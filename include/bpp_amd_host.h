@@ -135,10 +135,9 @@ static inline double a00_reflect(double x, double a, double b)
 /* gtree_update_logprob_contrib (gtree.c:3859-3955) for one population: tau = its start, ptau = its
    parent's tau (< 0 for the root), nin = lineages entering, times[ncoal] the coalescent times in it
    SORTED ascending; heredity multiplies theta as in the reference.  Same operations, same order. */
-static inline double a00_msc_contrib(double tau, double ptau, double theta, double heredity, int nin,
-                                     const double * times, int ncoal)
+static inline double a00_msc_t2h(double tau, double ptau, int nin, const double * times, int ncoal)
 {
-  double T2h = 0, prev = tau, logpr = 0; int k, n = nin;
+  double T2h = 0, prev = tau; int k, n = nin;
   /* intervals end at every coalescence and at the parent's tau; the one after the last possible
      coalescence (n == 1) is not visited */
   int steps = ncoal + (ptau >= 0 ? 1 : 0);
@@ -149,9 +148,20 @@ static inline double a00_msc_contrib(double tau, double ptau, double theta, doub
     T2h += n*(n - 1)*(t - prev);
     prev = t;
   }
+  return T2h;
+}
+/* the population's term from its sufficient statistics (coalescences, total 2h coalescent waiting time) */
+static inline double a00_msc_term(int ncoal, double T2h, double theta, double heredity)
+{
+  double logpr = 0;
   if (ncoal) logpr += ncoal*log(2.0/(heredity*theta));
   if (T2h) logpr -= T2h/(theta*heredity);
   return logpr;
+}
+static inline double a00_msc_contrib(double tau, double ptau, double theta, double heredity, int nin,
+                                     const double * times, int ncoal)
+{
+  return a00_msc_term(ncoal, a00_msc_t2h(tau, ptau, nin, times, ncoal), theta, heredity);
 }
 /* start-up evaluation: all matrices, all partials, lnL (method.c:4285-4297) */
 int            a00_initialize(a00_driver_t *);
