@@ -61,8 +61,10 @@ struct TaskLDS
   Tree   tr, undo;
   double ab[MAXPM][2];
   Op     ops[MAXBUF];
-  int32_t nops, active;
-  double hast, logpr_new;
+  int32_t nops, active;                           // active: 0 nothing to evaluate, 1 evaluate + decide, 2 rejected, 3 density only
+  double hast, hast2, logpr_new;
+  uint32_t brm;                                   // branches whose (a,b) the proposal changes (bit = node below the branch)
+  uint16_t pnodes[MAXPOP];                        // inner nodes of each population of the proposed tree
   int8_t nin[MAXPOP], nc[MAXPOP], gl[MAXPOP];     // lineages entering / coalescences / gene tips below, per population
   int8_t nin_new[MAXPOP], nc_new[MAXPOP];
   double contrib[MAXPOP], contrib_new[MAXPOP];    // per-population terms of the MSC density: current / proposed
@@ -79,12 +81,13 @@ struct Args
   double * mix_delta;          // [T] this locus's term of the all-loci acceptance ratio
   const uint32_t * mix_flag;   // epoch of the last REJECTED all-loci step
   uint32_t epoch;              // restore from snap when *mix_flag == epoch
-  uint32_t mode;               // 0 sweep (GAGE+GSPR), 1 mix, 2 only settle a pending decision, 3 start-up evaluation, 4 tau, 5 theta
+  uint32_t mode;               // 0 sweep (GAGE+GSPR), 1 mix, 2 only settle a pending decision, 3 start-up evaluation, 4 tau
   uint32_t nsteps_gage, nsteps_gspr;
   double   mix_c, mix_lnc;
   const double * taus;         // device-resident species-tree parameters: [MAXPOP] tau | [MAXPOP] theta | [MAXPOP] log(2/theta)
-  uint32_t tau_q;              // population of the TAU (mode 4) / THETA (mode 5) step
+  uint32_t tau_q;              // population of the TAU (mode 4) step
   double   tau_u;              // its window uniform
+  const double * lograt;       // [MAXN][MAXN] log(i/j): the Hastings ratios of GSPR (lograt_kernel)
   int8_t * pop_nc; double * pop_t2h;      // [T][MAXPOP] sufficient statistics of every locus's density, written by the sweep
   uint32_t dbg;                // timing experiments only (BPA_SMP_DBG): 1 skip the node updates, 2 skip the density, 4 skip the proposal
   double   bfbeta;             // 0 with opt_usedata == 0 (locus.c:2581): the sampler then draws from the MSC prior
@@ -176,19 +179,23 @@ __device__ __forceinline__ int climb(const Species & sp, const double * tau, int
 // of a sort buffer: same intervals, same order of additions as a00_msc_contrib).  Only the
 // populations in `mask` are recomputed (into the *_new fields); the others keep their term — the
 // terms are pure functions of the tree, so the sum equals the host's from-scratch one bit for bit.
-__device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau, uint32_t mask, double * t2h_out = nullptr)
+// Three parts: the leader lane counts (density_prepare), the lanes of the locus take one population
+// each for the floating-point part (lanes_density: the wave runs ONE term's instructions instead of the
+// union of every leader's population loop), the leader adds the terms up in population order (density_sum).
+template<int NT>                                    // NT: upper bound of the tips (the unrolled passes cover 2 NT - 1 nodes)
+__device__ void density_prepare(TaskLDS & S, const Species & sp, uint32_t mask)
 {
+  constexpr int NN = 2*NT - 1;
   const Tree & t = S.tr;
   const int n = 2*t.tips - 1;
-  double logpr = 0;
   S.chain = mask;
   // the populations of all inner nodes in one unrolled pass (independent LDS reads)
-  int8_t pk[MAXN];
+  int8_t pk[NN];
 #pragma unroll
-  for (int k = 0; k < MAXN; ++k) pk[k] = t.pop[k];
-  for (int p = 0; p < sp.npop; ++p)
+  for (int k = 0; k < NN; ++k) pk[k] = t.pop[k];
+  for (uint32_t m = mask; m; m &= m - 1)             // ascending = children before parents
   {
-    if (!((mask >> p) & 1u)) { logpr += S.contrib[p]; continue; }
+    const int p = __ffs(m) - 1;
     int nin;
     if (p >= sp.S)
     {
@@ -200,33 +207,56 @@ __device__ double tree_logpr(TaskLDS & S, const Species & sp, const double * tau
     else nin = S.nin[p];                          // gene tips of the species: fixed
     uint32_t nodes = 0;
 #pragma unroll
-    for (int k = 0; k < MAXN; ++k) if (k >= t.tips && k < n && pk[k] == p) nodes |= 1u << k;
-    const int ncoal = __popc(nodes);
-    S.nin_new[p] = (int8_t)nin; S.nc_new[p] = (int8_t)ncoal;
-    const double ptau = sp.parent[p] >= 0 ? tau[sp.parent[p]] : -1.0;
-    int steps = ncoal + (ptau >= 0 ? 1 : 0);
-    if (nin == steps) --steps;
-    double T2h = 0, prev = tau[p];
-    int nn = nin;
-    for (int k = 0; k < steps; ++k, --nn)
-    {
-      double tk = ptau;
-      if (k < ncoal)
-      {
-        int best = -1;
-        for (uint32_t m = nodes; m; m &= m - 1) { const int x = __ffs(m) - 1; if (best < 0 || t.time[x] < t.time[best]) best = x; }
-        tk = t.time[best]; nodes &= ~(1u << best);
-      }
-      T2h += nn*(nn - 1)*(tk - prev);
-      prev = tk;
-    }
-    double c = 0;
-    if (ncoal) c += ncoal*tau[2*MAXPOP + p];
-    if (T2h) c -= T2h/(tau[MAXPOP + p]*1.0);
-    S.contrib_new[p] = c;
-    if (t2h_out) t2h_out[p] = T2h;
-    logpr += c;
+    for (int k = 0; k < NN; ++k) if (k >= t.tips && k < n && pk[k] == p) nodes |= 1u << k;
+    S.nin_new[p] = (int8_t)nin; S.nc_new[p] = (int8_t)__popc(nodes); S.pnodes[p] = (uint16_t)nodes;
   }
+}
+// the term of population p (any lane of the locus)
+__device__ void density_term(TaskLDS & S, const Species & sp, const double * tau, int p, double * t2h_out)
+{
+  const Tree & t = S.tr;
+  uint32_t nodes = S.pnodes[p];
+  const int ncoal = S.nc_new[p], nin = S.nin_new[p];
+  const double ptau = sp.parent[p] >= 0 ? tau[sp.parent[p]] : -1.0;
+  int steps = ncoal + (ptau >= 0 ? 1 : 0);
+  if (nin == steps) --steps;
+  double T2h = 0, prev = tau[p];
+  int nn = nin;
+  for (int k = 0; k < steps; ++k, --nn)
+  {
+    double tk = ptau;
+    if (k < ncoal)
+    {
+      int best = -1;
+      for (uint32_t m = nodes; m; m &= m - 1) { const int x = __ffs(m) - 1; if (best < 0 || t.time[x] < t.time[best]) best = x; }
+      tk = t.time[best]; nodes &= ~(1u << best);
+    }
+    T2h += nn*(nn - 1)*(tk - prev);
+    prev = tk;
+  }
+  double c = 0;
+  if (ncoal) c += ncoal*tau[2*MAXPOP + p];
+  if (T2h) c -= T2h/(tau[MAXPOP + p]*1.0);
+  S.contrib_new[p] = c;
+  if (t2h_out) t2h_out[p] = T2h;
+}
+__device__ __forceinline__ int nth_bit(uint32_t m, int j)
+{
+  for (int i = 0; i < j; ++i) m &= m - 1;
+  return __ffs(m) - 1;
+}
+// lane n of the locus's np lanes: the terms of the n-th, (n+np)-th ... population of the mask
+__device__ __forceinline__ void lanes_density(TaskLDS & S, const Species & sp, const double * tau, uint32_t n, uint32_t np,
+                                              double * t2h_out = nullptr)
+{
+  const uint32_t mask = S.chain;
+  const int cnt = __popc(mask);
+  for (int j = (int)n; j < cnt; j += (int)np) density_term(S, sp, tau, nth_bit(mask, j), t2h_out);
+}
+__device__ __forceinline__ double density_sum(const TaskLDS & S, const Species & sp)
+{
+  double logpr = 0;
+  for (int p = 0; p < sp.npop; ++p) logpr += ((S.chain >> p) & 1u) ? S.contrib_new[p] : S.contrib[p];
   return logpr;
 }
 // the proposal stands: its terms become the current ones
@@ -245,20 +275,14 @@ __device__ __forceinline__ uint32_t pop_chain(const Species & sp, int a, int b)
   return sp.anc[lower] & ~(sp.anc[higher] & ~(1u << higher));
 }
 
-// install a proposal: toggle buffers, fresh (a,b) of the changed branches (mask brm), node-update
-// list of the nodes in mask ndm in children-first order (= by age) — step_add of a00_driver.c
-__device__ void install(TaskLDS & S, uint32_t brm, uint32_t ndm, double rate)
+// install a proposal: toggle buffers, node-update list of the nodes in mask ndm in children-first order
+// (= by age) — step_add of a00_driver.c; the fresh (a,b) of the changed branches (mask brm) are left to the
+// lanes of the locus (lanes_branches)
+__device__ void install(TaskLDS & S, uint32_t brm, uint32_t ndm)
 {
   Tree & t = S.tr;
-  while (brm)
-  {
-    const int x = __ffs(brm) - 1; brm &= brm - 1;
-    swap_pmat(t, x);
-    const double len = (t.time[t.parent[x]] - t.time[x])*1.0;                // rate_mui = 1 (locus.c:2350)
-    double A, B;
-    jc69_ab(len, rate, A, B);
-    S.ab[t.pmat[x]][0] = A; S.ab[t.pmat[x]][1] = B;
-  }
+  S.brm = brm;
+  for (; brm; brm &= brm - 1) swap_pmat(t, __ffs(brm) - 1);
   int nn = 0;
   while (ndm)
   {
@@ -283,8 +307,25 @@ __device__ void install(TaskLDS & S, uint32_t brm, uint32_t ndm, double rate)
   S.nops = nn;
 }
 
+// lane n of the locus's np lanes: (a,b) of the n-th, (n+np)-th ... changed branch, into its (already toggled) buffer
+__device__ __forceinline__ void lanes_branches(TaskLDS & S, double rate, uint32_t n, uint32_t np)
+{
+  const Tree & t = S.tr;
+  const uint32_t brm = S.brm;
+  const int cnt = __popc(brm);
+  for (int j = (int)n; j < cnt; j += (int)np)
+  {
+    const int x = nth_bit(brm, j);
+    const double len = (t.time[t.parent[x]] - t.time[x])*1.0;                // rate_mui = 1 (locus.c:2350)
+    double A, B;
+    jc69_ab(len, rate, A, B);
+    S.ab[t.pmat[x]][0] = A; S.ab[t.pmat[x]][1] = B;
+  }
+}
+
 // GAGE on the k-th inner node (gage_step of a00_driver.c; propose_ages, gtree.c:4585)
-__device__ bool propose_gage(TaskLDS & S, int k, double rate, const Species & sp, const double * tau)
+template<int NT>
+__device__ bool propose_gage(TaskLDS & S, int k, const Species & sp, const double * tau)
 {
   Tree & t = S.tr;
   long long tp = clock64();
@@ -304,17 +345,26 @@ __device__ bool propose_gage(TaskLDS & S, int k, double rate, const Species & sp
   t.pop[v] = (int8_t)climb(sp, tau, t.pop[l], tnew);
   S.hast = 0;
   SMP_PROF(S, 0, tp);
-  S.logpr_new = tree_logpr(S, sp, tau, pop_chain(sp, oldpop, t.pop[v]));
+  density_prepare<NT>(S, sp, pop_chain(sp, oldpop, t.pop[v]));
   SMP_PROF(S, 1, tp);
   uint32_t brm = (1u << l) | (1u << r);
   if (p >= 0) brm |= 1u << v;
-  install(S, brm, path_mask(t, v), rate);
+  install(S, brm, path_mask(t, v));
   SMP_PROF(S, 2, tp);
   return true;
 }
 
 // GSPR on the k-th non-root node (gspr_step of a00_driver.c; propose_spr, gtree.c:6531)
-__device__ bool propose_gspr(TaskLDS & S, int k, double rate, const Species & sp, const double * tau)
+// log(targets/sources) for every pair of counts, once per sampler: a GSPR proposal reads its Hastings ratio instead of
+// spending ~2.5 k cycles of the leader lane on a division and a logarithm
+__global__ void lograt_kernel(double * tab)
+{
+  const int i = threadIdx.x / MAXN, j = threadIdx.x % MAXN;
+  tab[threadIdx.x] = (i && j) ? log((double)i/(double)j) : 0.0;
+}
+
+template<int NT>
+__device__ bool propose_gspr(TaskLDS & S, int k, const Species & sp, const double * tau, const double * lograt)
 {
   Tree & t = S.tr;
   long long tp = clock64();
@@ -339,7 +389,7 @@ __device__ bool propose_gspr(TaskLDS & S, int k, double rate, const Species & sp
     const double tp = t.time[p], troot = t.time[t.root]; const int pp = t.pop[p], root = t.root;
     const bool above_root = tnew >= troot, src_on = p != root;
 #pragma unroll
-    for (int j = 0; j < MAXN - 1; ++j)
+    for (int j = 0; j < 2*NT - 1; ++j)
     {
       const int pj = t.parent[j];
       const double tj = t.time[j], tpj = t.time[pj < 0 ? 0 : pj];
@@ -380,15 +430,16 @@ __device__ bool propose_gspr(TaskLDS & S, int k, double rate, const Species & sp
   uint32_t brm = 0;
   for (uint32_t m = bset; m; m &= m - 1) { const int x = __ffs(m) - 1; if (t.parent[x] >= 0) brm |= 1u << x; }
   SMP_PROF(S, 3, tp);
-  S.hast = log((double)ntg/(double)nsrc);
+  S.hast = lograt[ntg*(2*NT) + nsrc];
   SMP_PROF(S, 4, tp);
-  S.logpr_new = tree_logpr(S, sp, tau, chain);
+  density_prepare<NT>(S, sp, chain);
   SMP_PROF(S, 5, tp);
-  install(S, brm, ndm, rate);
+  install(S, brm, ndm);
   SMP_PROF(S, 6, tp);
   return true;
 }
 
+template<int NT>
 __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
 {
   __shared__ TaskLDS s_task[TPB];
@@ -420,6 +471,8 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   double f0 = 0, f1 = 0, f2 = 0, f3 = 0, rw = 0, rate = 1;
   double * g_clv = nullptr, * g_pmat = nullptr;
   if (lane < (uint32_t)(3*MAXPOP)) s_tau[lane] = A.taus[lane];
+  __shared__ double s_lograt[(2*NT)*(2*NT)];
+  if (A.mode == 0) for (uint32_t i = lane; i < (uint32_t)((2*NT)*(2*NT)); i += BS) s_lograt[i] = A.lograt[(i/(2*NT))*MAXN + i % (2*NT)];
   if (active)
   {
     const LocusDev & L = A.loci[A.task_locus[task]];
@@ -432,7 +485,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     wgt = L.weights[n];
     const uint8_t * tp = L.tips;
     for (uint32_t tip = 0; tip < tips; ++tip) tipcodes |= (uint32_t)(tp[(size_t)tip*np + n] & 15u) << (4*tip);
-    const uint32_t nbuf = (A.mode == 2 || A.mode == 5) ? 0u : 2*(tips - 1);        // no likelihood work in those modes
+    const uint32_t nbuf = A.mode == 2 ? 0u : 2*(tips - 1);        // no likelihood work when only settling
     for (uint32_t c = 0; c < nbuf; ++c)
     {
       const double2 * p = reinterpret_cast<const double2 *>(g_clv + ((size_t)c*np + n)*4);
@@ -465,13 +518,6 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     __syncthreads();
     if (lane < (uint32_t)sp.npop) s_tau[lane] *= A.mix_c;
   }
-  else if (A.mode == 5)
-  {
-    const double told = s_tau[MAXPOP + A.tau_q];
-    const double tnew = reflect(told + sp.ft_theta*(A.tau_u - 0.5), 0.0, 999.0);
-    __syncthreads();
-    if (lane == 0) { s_tau[MAXPOP + A.tau_q] = tnew; s_tau[2*MAXPOP + A.tau_q] = log(2.0/(1.0*tnew)); }
-  }
   if (leader)
   {
     TaskLDS & S = s_task[ts];
@@ -482,13 +528,24 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     for (uint32_t k = 0; k < tips; ++k) for (int q = S.tr.pop[k]; q >= 0; q = sp.parent[q]) S.gl[q]++;
     for (int p = 0; p < sp.npop; ++p) S.nin[p] = 0;
     for (uint32_t k = 0; k < tips; ++k) S.nin[S.tr.pop[k]]++;
-    if (A.mode == 0) { (void)tree_logpr(S, sp, s_tau, (1u << sp.npop) - 1u); commit_logpr(S); }     // the current terms
+    if (A.mode == 0) density_prepare<NT>(S, sp, (1u << sp.npop) - 1u);      // the current terms: counts here, terms by the lanes below
     S.nops = 0; S.active = 0;
     S.prof_on = (A.dbg & 8u) && b == 0 && ts == 0; for (int i = 0; i < 8; ++i) S.prof[i] = 0;
   }
   __syncthreads();
+  if (A.mode == 0)
+  {
+    if (active) lanes_density(s_task[ts], sp, s_tau, n, np);
+    __syncthreads();
+    if (leader) commit_logpr(s_task[ts]);
+    __syncthreads();
+  }
 
   const uint32_t nprop = A.mode == 0 ? A.nsteps_gage + A.nsteps_gspr : (A.mode == 2 ? 0u : 1u);
+  // phase timing of workgroup 0 (BPA_SMP_DBG & 16): undo copy | proposal | lanes' share | node updates | decision | roll-back
+  const bool ph_on = (A.dbg & 16u) && b == 0 && lane == 0;
+  long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = ph_on ? clock64() : 0;
+#define SMP_PHASE(i_) do { if (ph_on) { const long long t1_ = clock64(); ph[i_] += t1_ - ph_t; ph_t = t1_; } } while (0)
   for (uint32_t step = 0; step < nprop; ++step)
   {
     // ---- undo copy of every tree of the workgroup (all lanes, 16 B at a time)
@@ -498,24 +555,15 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
         reinterpret_cast<uint4 *>(&s_task[i/U].undo)[i % U] = reinterpret_cast<const uint4 *>(&s_task[i/U].tr)[i % U];
     }
     __syncthreads();
+    SMP_PHASE(0);
     // ---- phase 1: the locus's leader lane proposes
     if (leader)
     {
       TaskLDS & S = s_task[ts];
-      bool ok;
+      bool ok; int act = 1;
       if (A.mode == 0 && (A.dbg & 4u)) ok = false;
       else if (A.mode == 0)
-        ok = step < A.nsteps_gage ? propose_gage(S, (int)step, rate, sp, s_tau) : propose_gspr(S, (int)(step - A.nsteps_gage), rate, sp, s_tau);
-      else if (A.mode == 5)
-      {
-        // THETA p (theta_step of a00_driver.c): only the density changes, no likelihood work
-        Tree & t = S.tr;
-        A.snap[task] = t;
-        S.logpr_new = tree_logpr(S, sp, s_tau, (1u << sp.npop) - 1u);
-        A.mix_delta[task] = S.logpr_new - t.logpr;
-        t.logpr = S.logpr_new;
-        ok = false;
-      }
+        ok = step < A.nsteps_gage ? propose_gage<NT>(S, (int)step, sp, s_tau) : propose_gspr<NT>(S, (int)(step - A.nsteps_gage), sp, s_tau, s_lograt);
       else if (A.mode == 4)
       {
         // TAU q (tau_step of a00_driver.c): the gene nodes of q and its children between the bounds move
@@ -532,11 +580,11 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
           if (t.parent[k] >= 0) brm |= 1u << k;
           ndm |= path_mask(t, k);
         }
-        S.logpr_new = tree_logpr(S, sp, s_tau, (1u << sp.npop) - 1u);
-        S.hast = (S.logpr_new - t.logpr) + below*lminf + above*lmaxf;      // p_delta of the host driver
-        ok = ndm != 0;
-        if (ok) install(S, brm, ndm, rate);
-        else { A.mix_delta[task] = S.hast; t.logpr = S.logpr_new; }
+        density_prepare<NT>(S, sp, (1u << sp.npop) - 1u);
+        S.hast = below*lminf; S.hast2 = above*lmaxf;     // p_delta of the host driver = (density difference + hast) + hast2, below
+        ok = true;
+        if (ndm) install(S, brm, ndm);
+        else { S.brm = 0; S.nops = 0; act = 3; }         // no gene node moves here: only the density changes
       }
       else
       {
@@ -555,18 +603,29 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
           for (uint32_t m = brm; m; m &= m - 1) swap_pmat(t, __ffs(m) - 1);       // start-up evaluates in place:
           for (uint32_t m = ndm; m; m &= m - 1) swap_clv(t, __ffs(m) - 1);        // toggle twice = no toggle
         }
-        S.logpr_new = tree_logpr(S, sp, s_tau, (1u << sp.npop) - 1u);
-        S.hast = A.mode == 1 ? (S.logpr_new - t.logpr) + (double)ninner*A.mix_lnc : 0.0;
-        install(S, brm, ndm, rate);
+        density_prepare<NT>(S, sp, (1u << sp.npop) - 1u);
+        S.hast = (double)ninner*A.mix_lnc;
+        install(S, brm, ndm);
         ok = true;
       }
-      S.active = ok ? 1 : 0;
+      S.active = ok ? act : 0;
       if (!ok) S.nops = 0;
     }
     __syncthreads();
+    SMP_PHASE(1);
+    // ---- phase 1b: the lanes of the locus share the floating-point part of the proposal — one density term, one
+    // branch's exponential each
+    if (active && s_task[ts].active)
+    {
+      TaskLDS & S = s_task[ts];
+      lanes_density(S, sp, s_tau, n, np);
+      lanes_branches(S, rate, n, np);
+    }
+    __syncthreads();
+    SMP_PHASE(2);
     // ---- phase 2: one lane per pattern runs the node updates out of LDS
     double term = 0;
-    if (active && s_task[ts].active && !(A.dbg & 1u))
+    if (active && s_task[ts].active == 1 && !(A.dbg & 1u))
     {
       const TaskLDS & S = s_task[ts];
       for (int o = 0; o < S.nops; ++o)
@@ -588,14 +647,24 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     }
     s_term[lane] = term;
     __syncthreads();
+    SMP_PHASE(3);
     // ---- phase 3: the leader sums in pattern order and decides
-    if (leader && s_task[ts].active)
+    if (leader && s_task[ts].active == 3)
+    {
+      // TAU without a moving gene node in this locus
+      TaskLDS & S = s_task[ts];
+      S.logpr_new = density_sum(S, sp);
+      A.mix_delta[task] = ((S.logpr_new - S.tr.logpr) + S.hast) + S.hast2;
+      S.tr.logpr = S.logpr_new;
+    }
+    else if (leader && s_task[ts].active)
     {
       TaskLDS & S = s_task[ts];
       double lnl = 0;
       for (uint32_t q = 0; q < np; ++q) lnl += s_term[lane + q];
       lnl = A.bfbeta == 1.0 ? lnl : A.bfbeta == 0.0 ? 0.0 : A.bfbeta*lnl;
       long long tp3 = clock64();
+      S.logpr_new = density_sum(S, sp);
       if (A.mode == 0)
       {
         const double lnacc = (S.logpr_new - S.tr.logpr) + (lnl - S.tr.lnl) + S.hast;
@@ -607,11 +676,14 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       }
       else
       {
-        A.mix_delta[task] = A.mode == 3 ? 0.0 : (lnl - S.tr.lnl) + S.hast;
+        const double dpr = S.logpr_new - S.tr.logpr;
+        const double h = A.mode == 4 ? (dpr + S.hast) + S.hast2 : dpr + S.hast;
+        A.mix_delta[task] = A.mode == 3 ? 0.0 : (lnl - S.tr.lnl) + h;
         S.tr.lnl = lnl; S.tr.logpr = S.logpr_new;
       }
     }
     __syncthreads();
+    SMP_PHASE(4);
     // ---- rejected proposals: topology, ages, populations and buffer indices come back from the undo copy (all lanes)
     if (A.mode == 0)
     {
@@ -622,10 +694,26 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       __syncthreads();
       if (leader && s_task[ts].active == 2) s_task[ts].tr.root = s_task[ts].undo.root;
     }
+    SMP_PHASE(5);
   }
   __syncthreads();
+  if (ph_on) for (int i = 0; i < 6; ++i) A.mix_delta[8 + i] = (double)ph[i];
+#undef SMP_PHASE
 
   // ---- store
+  if (A.mode == 0)
+  {
+    // the sufficient statistics of the final state, for the THETA kernels (not kept in LDS along the way: a workgroup
+    // must stay under 40 KB)
+    if (leader)
+    {
+      TaskLDS & S = s_task[ts];
+      density_prepare<NT>(S, sp, (1u << sp.npop) - 1u);
+      for (int p = 0; p < sp.npop; ++p) A.pop_nc[(size_t)task*MAXPOP + p] = S.nc_new[p];
+    }
+    __syncthreads();
+    if (active) lanes_density(s_task[ts], sp, s_tau, n, np, A.pop_t2h + (size_t)task*MAXPOP);
+  }
   {
     constexpr uint32_t U = sizeof(Tree)/16;
     for (uint32_t i = lane; i < ntask*U; i += BS)
@@ -637,14 +725,8 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     const uint32_t npm = 2*(2*tips - 2);
     for (uint32_t i = 0; i < npm; ++i) { g_pmat[2*i] = S.ab[i][0]; g_pmat[2*i+1] = S.ab[i][1]; }
     if (S.prof_on) for (int i = 0; i < 8; ++i) A.mix_delta[i] = (double)S.prof[i];
-    if (A.mode == 0)
-    {
-      // the sufficient statistics of the final state, for the THETA kernels (kept out of LDS: a workgroup must stay under 40 KB)
-      (void)tree_logpr(s_task[ts], sp, s_tau, (1u << sp.npop) - 1u, A.pop_t2h + (size_t)task*MAXPOP);
-      for (int p = 0; p < sp.npop; ++p) A.pop_nc[(size_t)task*MAXPOP + p] = s_task[ts].nc_new[p];
-    }
   }
-  if (active && nprop && A.mode != 5)
+  if (active && nprop)
   {
     const uint32_t nbuf = 2*(tips - 1);
     for (uint32_t c = 0; c < nbuf; ++c)
@@ -794,7 +876,7 @@ struct bpa_sampler
   std::vector<bpa_locus *> loci;
   DevBuf<uint32_t> task_locus, blk_task_off, lane_task, task_lane0, flag, counters;
   DevBuf<smp::Tree> trees, snap;
-  DevBuf<double> mix_delta, mix_sum, taus, pop_t2h, theta_sums;
+  DevBuf<double> mix_delta, mix_sum, taus, pop_t2h, theta_sums, lograt;
   DevBuf<int8_t> pop_nc;
   smp::Species sp{};                    // species tree (host copy; the taus below are only the start values)
   bool has_theta[smp::MAXPOP] = {};     // populations that can hold a coalescence (a00_initialize)
@@ -845,7 +927,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   (void)hipSetDevice(s->eng->device); g_cur_device = s->eng->device;
   (void)hipStreamSynchronize(s->eng->stream);
   s->task_locus.free(); s->blk_task_off.free(); s->lane_task.free(); s->task_lane0.free(); s->flag.free();
-  s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free();
+  s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free();
   delete s;
 }
 
@@ -920,8 +1002,10 @@ static int sampler_upload(bpa_sampler * s)
       !upload(s->trees, s->h_trees.data(), T) || !upload(s->snap, s->h_trees.data(), T) ||
       !upload(s->flag, zero2, 1) || !upload(s->counters, zero2, 2) || !s->mix_delta.reserve(T) || !s->mix_sum.reserve(1) ||
       !upload(s->taus, s->h_taus.data(), s->h_taus.size()) || !s->pop_t2h.reserve((size_t)T*smp::MAXPOP) ||
-      !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP))
+      !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP) || !s->lograt.reserve(smp::MAXN*smp::MAXN))
     return 0;
+  hipLaunchKernelGGL(smp::lograt_kernel, dim3(1), dim3(smp::MAXN*smp::MAXN), 0, e->stream, s->lograt.p);
+  HIPCHK(hipGetLastError());
   s->epoch = 0; s->mix_pending = false;
   s->uploaded = true;
   return 1;
@@ -939,21 +1023,30 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
   a.epoch = s->mix_pending ? s->epoch : 0u;
   s->mix_pending = false;
   a.bfbeta = e->usedata ? e->bfbeta : 0.0;
-  a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p;
+  a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p; a.lograt = s->lograt.p;
   if (const char * dv = getenv("BPA_SMP_DBG")) a.dbg = (uint32_t)atoi(dv);
   a.taus = s->taus.p; a.tau_q = tau_q; a.tau_u = tau_u; a.sp = s->sp; a.mix_lnc = mix_lnc;
   a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2; a.mix_c = mix_c;
   if (const char * dbg = getenv("BPA_SMP_STEPS")) { unsigned g = 0, q = 0; if (sscanf(dbg, "%u,%u", &g, &q) == 2) { a.nsteps_gage = g; a.nsteps_gspr = q; } }
+  // the unrolled node passes of the leader's code are sized by the largest tree: 4-tip loci get their own instance
+  void (*kern)(const smp::Args) = s->maxtips <= 4 ? smp::sweep_kernel<4> : smp::sweep_kernel<smp::MAXTIPS>;
+  const size_t lds = (size_t)2*(s->maxtips - 1)*smp::BS*4*sizeof(double);
   if (getenv("BPA_SMP_TRACE"))
   {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipExtLaunchKernelGGL(smp::sweep_kernel, dim3(s->nblocks), dim3(smp::BS), (size_t)2*(s->maxtips - 1)*smp::BS*4*sizeof(double), e->stream, e0, e1, 0, a);
+    hipExtLaunchKernelGGL(kern, dim3(s->nblocks), dim3(smp::BS), lds, e->stream, e0, e1, 0, a);
     (void)hipStreamSynchronize(e->stream);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     fprintf(stderr, "[smp] mode %u gage %u gspr %u epoch %u blocks %u: %.1f us\n", mode, a.nsteps_gage, a.nsteps_gspr, a.epoch, s->nblocks, ms*1e3);
     if ((a.dbg & 8u) && mode == 0)
     {
       double pr[8]; (void)hipMemcpy(pr, s->mix_delta.p, sizeof pr, hipMemcpyDeviceToHost);
+      if (a.dbg & 16u)
+      {
+        double ph[6]; (void)hipMemcpy(ph, s->mix_delta.p + 8, sizeof ph, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[smp] cycles of workgroup 0: undo copy %.0f proposal %.0f lanes %.0f node updates %.0f decision %.0f roll-back %.0f\n",
+                ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+      }
       fprintf(stderr, "[smp] cycles of one locus: gage pre %.0f density %.0f install %.0f | gspr pre %.0f log %.0f density %.0f install %.0f | decide %.0f\n",
               pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
     }
@@ -961,7 +1054,7 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
     s->launches++;
     return 1;
   }
-  hipLaunchKernelGGL(smp::sweep_kernel, dim3(s->nblocks), dim3(smp::BS), (size_t)2*(s->maxtips - 1)*smp::BS*4*sizeof(double), e->stream, a);
+  hipLaunchKernelGGL(kern, dim3(s->nblocks), dim3(smp::BS), lds, e->stream, a);
   HIPCHK(hipGetLastError());
   s->launches++;
   return 1;
