@@ -384,7 +384,7 @@ def main():
             pass
 
     # ---- extra (not `value`): the same loci under device-resident proposal control — a real sampler
-    # (proposals, accept/reject, rollback on the device; bpa_sampler_t), 4 launches per iteration
+    # (proposals, accept/reject, rollback on the device; bpa_sampler_t)
     sampler = None
     if args.config == "c2" and not args.no_sampler:
         smp = bpp_amd.Sampler(eng, loci, data, seed=1)
@@ -417,7 +417,7 @@ def main():
         sm = smp.summary()
         sampler = dict(iterations_per_s=round(args.steps / dt * nloci * world / 10000.0, 1), ms_per_iteration=round(1e3 * dt / args.steps, 4),
                        n_gpus=world,
-                       launches_per_iteration=4 + 6 * len(smp_taus), proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
+                       launches_per_iteration=3 + (2 if world == 1 else 3) * (len(smp_taus) + 1),   # sweep, THETA x2, (TAU.. + MIX) x (step + sum/decide) proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
                        acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
                        taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
                        thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],

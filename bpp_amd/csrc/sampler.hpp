@@ -43,7 +43,12 @@ struct Tree                                // one per locus, in HBM and (while s
 };
 static_assert(sizeof(Tree) % 16 == 0 && offsetof(Tree, lnl) % 16 == 0, "Tree is copied as uint4");
 
-struct Op { int8_t parent, lc, lp, rc, rp; };      // buffer indices of one node update
+// buffer indices of one node update, one byte each in a 64-bit word: parent | left clv | left pmat | right clv | right pmat
+typedef uint64_t Op;
+__device__ __forceinline__ Op make_op(int parent, int lc, int lp, int rc, int rp)
+{
+  return (uint64_t)(uint32_t)parent | (uint64_t)(uint32_t)lc << 8 | (uint64_t)(uint32_t)lp << 16 | (uint64_t)(uint32_t)rc << 24 | (uint64_t)(uint32_t)rp << 32;
+}
 
 // the species tree (a00_set_species_tree): stree->nodes order, children before parents; the taus live in
 // device memory (the TAU and MIX decisions move them), everything else is constant
@@ -65,18 +70,31 @@ struct TaskLDS
   double hast, hast2, logpr_new;
   uint32_t brm;                                   // branches whose (a,b) the proposal changes (bit = node below the branch)
   uint16_t pnodes[MAXPOP];                        // inner nodes of each population of the proposed tree
-  int8_t nin[MAXPOP], nc[MAXPOP], gl[MAXPOP];     // lineages entering / coalescences / gene tips below, per population
+  alignas(16) int8_t nin[MAXPOP];                 // lineages entering / coalescences / gene tips below, per population
+  alignas(16) int8_t gl[MAXPOP];
+  int8_t nc[MAXPOP];
   int8_t nin_new[MAXPOP], nc_new[MAXPOP];
   double contrib[MAXPOP], contrib_new[MAXPOP];    // per-population terms of the MSC density: current / proposed
   uint32_t chain;                                 // populations whose term the proposal changes
   int32_t prof_on; long long prof[8];
 };
 
+// what a lane / a locus needs at every launch and never changes, flattened at upload: one 16-byte load per lane and
+// one record per locus instead of the chain lane -> task -> locus table -> parameter block -> weights / tip codes
+struct LaneRec { uint32_t task, wgt, tipcodes, n_np_tips; };       // task 0xffffffff: idle lane; n | np << 8 | tips << 16
+struct TaskRec
+{
+  double * clv, * pmat;
+  double rate, rw, f0, f1, f2, f3;
+  alignas(16) int8_t gl[MAXPOP];       // gene tips below each population
+  alignas(16) int8_t nin[MAXPOP];      // gene tips of each species (0 for the inner populations)
+};
+
 struct Args
 {
-  const LocusDev * loci;       // engine locus table
-  const uint32_t * task_locus; // [T]
-  const uint32_t * blk_task_off, * lane_task, * task_lane0;
+  const LaneRec * lane_rec;    // [blocks*BS]
+  const TaskRec * task_rec;    // [T]
+  const uint32_t * blk_task_off;
   Tree * trees, * snap;        // [T] current / pre-step snapshot of an all-loci step
   double * mix_delta;          // [T] this locus's term of the all-loci acceptance ratio
   const uint32_t * mix_flag;   // epoch of the last REJECTED all-loci step
@@ -115,13 +133,13 @@ __host__ __device__ inline double reflect(double x, double a, double b)
 
 __device__ __forceinline__ void swap_clv(Tree & t, int i)
 {
-  const int inner = t.tips - 1;
-  t.clv[i] = (int8_t)(t.tips + (t.clv[i] - t.tips + inner) % (2*inner));
+  const int inner = t.tips - 1, c = t.clv[i] + inner;                     // the other of the node's two buffers
+  t.clv[i] = (int8_t)(c >= t.tips + 2*inner ? c - 2*inner : c);
 }
 __device__ __forceinline__ void swap_pmat(Tree & t, int i)
 {
-  const int edges = 2*t.tips - 2;
-  t.pmat[i] = (int8_t)((t.pmat[i] + edges) % (2*edges));
+  const int edges = 2*t.tips - 2, c = t.pmat[i] + edges;
+  t.pmat[i] = (int8_t)(c >= 2*edges ? c - 2*edges : c);
 }
 // node sets are 16-bit masks (n <= 15): no private arrays, nothing spills to scratch.
 // (Tried: the integer tree arrays packed into 64-bit registers of the leader lane instead of LDS —
@@ -295,14 +313,13 @@ __device__ void install(TaskLDS & S, uint32_t brm, uint32_t ndm)
     }
     ndm &= ~(1u << best);
     swap_clv(t, best);
-    S.ops[nn].parent = (int8_t)best;            // node ids for now; buffer indices below, once all toggles are done
+    S.ops[nn] = (Op)best;                       // node ids for now; buffer indices below, once all toggles are done
     ++nn;
   }
   for (int a = 0; a < nn; ++a)
   {
-    const int x = S.ops[a].parent, l = t.left[x], r = t.right[x];
-    S.ops[a].parent = t.clv[x]; S.ops[a].lc = t.clv[l]; S.ops[a].lp = t.pmat[l];
-    S.ops[a].rc = t.clv[r]; S.ops[a].rp = t.pmat[r];
+    const int x = (int)S.ops[a], l = t.left[x], r = t.right[x];
+    S.ops[a] = make_op(t.clv[x], t.clv[l], t.pmat[l], t.clv[r], t.pmat[r]);
   }
   S.nops = nn;
 }
@@ -330,9 +347,8 @@ __device__ bool propose_gage(TaskLDS & S, int k, const Species & sp, const doubl
   Tree & t = S.tr;
   long long tp = clock64();
   const int n = 2*t.tips - 1;
-  int v = -1, c = 0;
-  for (int j = 0; j < n; ++j) if (t.left[j] >= 0 && c++ == k) { v = j; break; }
-  if (v < 0) return false;
+  const int v = t.tips + k;                          // the k-th inner node: tips are nodes 0..tips-1 (bpa_sampler_set_tree checks)
+  if (v >= n) return false;
   const double u = rndu(&t.rng);
   const int l = t.left[v], r = t.right[v], p = t.parent[v];
   double lo = fmax(t.time[l], t.time[r]);
@@ -369,9 +385,8 @@ __device__ bool propose_gspr(TaskLDS & S, int k, const Species & sp, const doubl
   Tree & t = S.tr;
   long long tp = clock64();
   const int n = 2*t.tips - 1;
-  int a = -1, c = 0;
-  for (int j = 0; j < n; ++j) if (j != t.root && c++ == k) { a = j; break; }
-  if (a < 0) return false;
+  const int a = k < t.root ? k : k + 1;              // the k-th node that is not the root
+  if (a >= n) return false;
   const double u1 = rndu(&t.rng), u2 = rndu(&t.rng);
   const int root_before = t.root;
   const int p = t.parent[a], s = t.left[p] == a ? t.right[p] : t.left[p], g = t.parent[p];
@@ -449,12 +464,14 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   double (*s_clv)[BS][4] = reinterpret_cast<double (*)[BS][4]>(s_clv_raw);
   __shared__ double  s_term[BS];
   __shared__ double  s_tau[3*MAXPOP];                    // tau | theta | log(2/theta) of this launch's (proposed) species tree
+  const long long ph_start = clock64();
   const uint32_t b = blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
   const uint32_t t0 = A.blk_task_off[b], ntask = A.blk_task_off[b+1] - t0;
-  const uint32_t task = A.lane_task[gl];
+  const LaneRec lrec = A.lane_rec[gl];
+  const uint32_t task = lrec.task;
   const bool active = task != 0xffffffffu;
   const uint32_t ts = active ? task - t0 : 0u;
-  const bool leader = active && gl == A.task_lane0[task];
+  const bool leader = active && (lrec.n_np_tips & 255u) == 0;
   const bool restore_mix = A.epoch != 0 && *A.mix_flag == A.epoch;      // epoch 0: nothing pending
   // the species tree is indexed with run-time population numbers all over the leader's code: out of LDS, not
   // out of the kernel-argument segment (a dynamic index into a by-value argument is a global load each time)
@@ -475,16 +492,17 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   if (A.mode == 0) for (uint32_t i = lane; i < (uint32_t)((2*NT)*(2*NT)); i += BS) s_lograt[i] = A.lograt[(i/(2*NT))*MAXN + i % (2*NT)];
   if (active)
   {
-    const LocusDev & L = A.loci[A.task_locus[task]];
-    np = L.np; tips = L.tips_n; g_clv = L.clv; g_pmat = L.pmat;
-    n = gl - A.task_lane0[task];
-    const double * par = L.par;
-    rate = par[par_rates(1)]; rw = par[par_rate_weights(1)];
-    const double * f = par + par_matrix(1, 4, 0) + pm_freqs(4);
-    f0 = f[0]; f1 = f[1]; f2 = f[2]; f3 = f[3];
-    wgt = L.weights[n];
-    const uint8_t * tp = L.tips;
-    for (uint32_t tip = 0; tip < tips; ++tip) tipcodes |= (uint32_t)(tp[(size_t)tip*np + n] & 15u) << (4*tip);
+    const TaskRec & R = A.task_rec[task];
+    n = lrec.n_np_tips & 255u; np = (lrec.n_np_tips >> 8) & 255u; tips = lrec.n_np_tips >> 16;
+    wgt = lrec.wgt; tipcodes = lrec.tipcodes;
+    g_clv = R.clv; g_pmat = R.pmat; rate = R.rate; rw = R.rw; f0 = R.f0; f1 = R.f1; f2 = R.f2; f3 = R.f3;
+    // the (a,b) table of the locus: its lanes share the copy
+    for (uint32_t i = n; i < 4*(2*tips - 2); i += np) (&s_task[ts].ab[0][0])[i] = g_pmat[i];
+    if (n == 0)
+    {
+      *reinterpret_cast<uint4 *>(s_task[ts].gl)  = *reinterpret_cast<const uint4 *>(R.gl);
+      *reinterpret_cast<uint4 *>(s_task[ts].nin) = *reinterpret_cast<const uint4 *>(R.nin);
+    }
     const uint32_t nbuf = A.mode == 2 ? 0u : 2*(tips - 1);        // no likelihood work when only settling
     for (uint32_t c = 0; c < nbuf; ++c)
     {
@@ -522,12 +540,6 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   {
     TaskLDS & S = s_task[ts];
     if (restore_mix) { S.tr.rng = A.trees[task].rng; S.tr.proposals = A.trees[task].proposals; S.tr.accepted = A.trees[task].accepted; }
-    const uint32_t npm = 2*(2*tips - 2);
-    for (uint32_t i = 0; i < npm; ++i) { S.ab[i][0] = g_pmat[2*i]; S.ab[i][1] = g_pmat[2*i+1]; }
-    for (int p = 0; p < sp.npop; ++p) S.gl[p] = 0;
-    for (uint32_t k = 0; k < tips; ++k) for (int q = S.tr.pop[k]; q >= 0; q = sp.parent[q]) S.gl[q]++;
-    for (int p = 0; p < sp.npop; ++p) S.nin[p] = 0;
-    for (uint32_t k = 0; k < tips; ++k) S.nin[S.tr.pop[k]]++;
     if (A.mode == 0) density_prepare<NT>(S, sp, (1u << sp.npop) - 1u);      // the current terms: counts here, terms by the lanes below
     S.nops = 0; S.active = 0;
     S.prof_on = (A.dbg & 8u) && b == 0 && ts == 0; for (int i = 0; i < 8; ++i) S.prof[i] = 0;
@@ -545,6 +557,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   // phase timing of workgroup 0 (BPA_SMP_DBG & 16): undo copy | proposal | lanes' share | node updates | decision | roll-back
   const bool ph_on = (A.dbg & 16u) && b == 0 && lane == 0;
   long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = ph_on ? clock64() : 0;
+  if (ph_on) A.mix_delta[14] = (double)(ph_t - ph_start);
 #define SMP_PHASE(i_) do { if (ph_on) { const long long t1_ = clock64(); ph[i_] += t1_ - ph_t; ph_t = t1_; } } while (0)
   for (uint32_t step = 0; step < nprop; ++step)
   {
@@ -630,7 +643,9 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       const TaskLDS & S = s_task[ts];
       for (int o = 0; o < S.nops; ++o)
       {
-        const Op op = S.ops[o];
+        const Op opw = S.ops[o];
+        const struct { uint32_t parent, lc, lp, rc, rp; } op = {(uint32_t)opw & 255u, (uint32_t)(opw >> 8) & 255u, (uint32_t)(opw >> 16) & 255u,
+                                                                (uint32_t)(opw >> 24) & 255u, (uint32_t)(opw >> 32) & 255u};
         double lv[4], rv[4], x[4], y[4];
         if ((uint32_t)op.lc < tips) expand_code((tipcodes >> (4*op.lc)) & 15u, lv);
         else { const double * c = s_clv[op.lc - tips][lane]; lv[0] = c[0]; lv[1] = c[1]; lv[2] = c[2]; lv[3] = c[3]; }
@@ -698,6 +713,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   }
   __syncthreads();
   if (ph_on) for (int i = 0; i < 6; ++i) A.mix_delta[8 + i] = (double)ph[i];
+  const long long ph_store = clock64();
 #undef SMP_PHASE
 
   // ---- store
@@ -722,12 +738,11 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   if (leader)
   {
     const TaskLDS & S = s_task[ts];
-    const uint32_t npm = 2*(2*tips - 2);
-    for (uint32_t i = 0; i < npm; ++i) { g_pmat[2*i] = S.ab[i][0]; g_pmat[2*i+1] = S.ab[i][1]; }
     if (S.prof_on) for (int i = 0; i < 8; ++i) A.mix_delta[i] = (double)S.prof[i];
   }
   if (active && nprop)
   {
+    for (uint32_t i = n; i < 4*(2*tips - 2); i += np) g_pmat[i] = (&s_task[ts].ab[0][0])[i];
     const uint32_t nbuf = 2*(tips - 1);
     for (uint32_t c = 0; c < nbuf; ++c)
     {
@@ -736,6 +751,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       p[0] = u; p[1] = w;
     }
   }
+  if (ph_on) A.mix_delta[15] = (double)(clock64() - ph_store);
 }
 
 // the single decision of an all-loci step (tau_step / mix_step of a00_driver.c; stree.c:6280,
@@ -874,7 +890,9 @@ struct bpa_sampler
   bpa_engine * eng = nullptr;
   unsigned nloci = 0, maxtips = 0;
   std::vector<bpa_locus *> loci;
-  DevBuf<uint32_t> task_locus, blk_task_off, lane_task, task_lane0, flag, counters;
+  DevBuf<uint32_t> blk_task_off, flag, counters;
+  DevBuf<smp::LaneRec> lane_rec;
+  DevBuf<smp::TaskRec> task_rec;
   DevBuf<smp::Tree> trees, snap;
   DevBuf<double> mix_delta, mix_sum, taus, pop_t2h, theta_sums, lograt;
   DevBuf<int8_t> pop_nc;
@@ -926,7 +944,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   (void)hipSetDevice(s->eng->device); g_cur_device = s->eng->device;
   (void)hipStreamSynchronize(s->eng->stream);
-  s->task_locus.free(); s->blk_task_off.free(); s->lane_task.free(); s->task_lane0.free(); s->flag.free();
+  s->blk_task_off.free(); s->lane_rec.free(); s->task_rec.free(); s->flag.free();
   s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free();
   delete s;
 }
@@ -942,6 +960,8 @@ extern "C" int bpa_sampler_set_tree(bpa_sampler_t * s, unsigned i, const int * l
   for (int k = 0; k < n; ++k)
   {
     t.left[k] = (int8_t)left[k]; t.right[k] = (int8_t)right[k]; t.time[k] = times[k];
+    if ((left[k] < 0) != (k < tips) || (right[k] < 0) != (k < tips) || left[k] >= n || right[k] >= n)
+      return fail("bpa_sampler_set_tree: nodes 0..tips-1 are the tips (no children), the others have two");
     if (left[k] >= 0) { t.parent[left[k]] = (int8_t)k; t.parent[right[k]] = (int8_t)k; }
   }
   t.root = root; t.tips = tips; t.rng = a00_rng_seed(s->seed, s->locus_offset + i); t.lnl = 0;
@@ -981,24 +1001,42 @@ static int sampler_upload(bpa_sampler * s)
     const smp::Tree & t = s->h_trees[i];
     for (int k = 0; k < t.tips; ++k) if (++cnt[t.pop[k]] >= 2) s->has_theta[t.pop[k]] = true;
   }
-  std::vector<uint32_t> locus(T), blk_off{0}, lane_task, lane0(T);
+  std::vector<uint32_t> blk_off{0};
+  std::vector<smp::LaneRec> lane_rec;
+  std::vector<smp::TaskRec> task_rec(T);
+  const smp::LaneRec idle{0xffffffffu, 0, 0, 0};
   unsigned used = 0, ntask = 0;
   for (unsigned t = 0; t < T; ++t)
   {
-    const unsigned np = s->loci[t]->sites;
-    locus[t] = s->loci[t]->id;
-        if (used + np > (unsigned)smp::BS || ntask == (unsigned)smp::TPB)
-    { lane_task.resize(blk_off.size()*smp::BS, 0xffffffffu); blk_off.push_back(t); used = 0; ntask = 0; }
-    lane0[t] = (uint32_t)((blk_off.size() - 1)*smp::BS + used);
-    for (unsigned n = 0; n < np; ++n) lane_task.push_back(t);
+    const bpa_locus * l = s->loci[t];
+    const unsigned np = l->sites, tips = l->tips;
+    if (used + np > (unsigned)smp::BS || ntask == (unsigned)smp::TPB)
+    { lane_rec.resize(blk_off.size()*smp::BS, idle); blk_off.push_back(t); used = 0; ntask = 0; }
+    for (unsigned n = 0; n < np; ++n)
+    {
+      uint32_t codes = 0;
+      for (unsigned tip = 0; tip < tips; ++tip) codes |= (uint32_t)(l->tipcodes[(size_t)tip*np + n] & 15u) << (4*tip);
+      lane_rec.push_back(smp::LaneRec{t, l->weights[n], codes, n | np << 8 | tips << 16});
+    }
     used += np; ++ntask;
+    smp::TaskRec & r = task_rec[t];
+    const double * f = l->par.data() + par_matrix(1, 4, 0) + pm_freqs(4);
+    r.clv = l->dev.clv; r.pmat = l->dev.pmat; r.rate = l->par[par_rates(1)]; r.rw = l->par[par_rate_weights(1)];
+    r.f0 = f[0]; r.f1 = f[1]; r.f2 = f[2]; r.f3 = f[3];
+    const smp::Tree & tr = s->h_trees[t];
+    for (int p = 0; p < smp::MAXPOP; ++p) r.gl[p] = r.nin[p] = 0;
+    for (unsigned k = 0; k < tips; ++k)
+    {
+      r.nin[tr.pop[k]]++;
+      for (int q = tr.pop[k]; q >= 0; q = s->sp.parent[q]) r.gl[q]++;
+    }
   }
-  lane_task.resize(blk_off.size()*smp::BS, 0xffffffffu);
+  lane_rec.resize(blk_off.size()*smp::BS, idle);
   blk_off.push_back(T);
   s->nblocks = (unsigned)blk_off.size() - 1;
   uint32_t zero2[2] = {0, 0};
-  if (!upload(s->task_locus, locus.data(), T) || !upload(s->blk_task_off, blk_off.data(), blk_off.size()) ||
-      !upload(s->lane_task, lane_task.data(), lane_task.size()) || !upload(s->task_lane0, lane0.data(), T) ||
+  if (!upload(s->blk_task_off, blk_off.data(), blk_off.size()) ||
+      !upload(s->lane_rec, lane_rec.data(), lane_rec.size()) || !upload(s->task_rec, task_rec.data(), T) ||
       !upload(s->trees, s->h_trees.data(), T) || !upload(s->snap, s->h_trees.data(), T) ||
       !upload(s->flag, zero2, 1) || !upload(s->counters, zero2, 2) || !s->mix_delta.reserve(T) || !s->mix_sum.reserve(1) ||
       !upload(s->taus, s->h_taus.data(), s->h_taus.size()) || !s->pop_t2h.reserve((size_t)T*smp::MAXPOP) ||
@@ -1015,8 +1053,8 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
 {
   bpa_engine * e = s->eng;
   smp::Args a{};
-  a.loci = e->d_loci.p; a.task_locus = s->task_locus.p; a.blk_task_off = s->blk_task_off.p;
-  a.lane_task = s->lane_task.p; a.task_lane0 = s->task_lane0.p; a.trees = s->trees.p; a.snap = s->snap.p;
+  a.lane_rec = s->lane_rec.p; a.task_rec = s->task_rec.p; a.blk_task_off = s->blk_task_off.p;
+  a.trees = s->trees.p; a.snap = s->snap.p;
   a.mix_delta = s->mix_delta.p; a.mix_flag = s->flag.p; a.mode = mode;
   // the first launch after an all-loci decision applies it (restore from the snapshot when it was a
   // rejection); every other launch passes epoch 0 = nothing pending
@@ -1038,14 +1076,20 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
     (void)hipStreamSynchronize(e->stream);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     fprintf(stderr, "[smp] mode %u gage %u gspr %u epoch %u blocks %u: %.1f us\n", mode, a.nsteps_gage, a.nsteps_gspr, a.epoch, s->nblocks, ms*1e3);
+    if ((a.dbg & 16u) && mode != 0)
+    {
+      double ph[8]; (void)hipMemcpy(ph, s->mix_delta.p + 8, sizeof ph, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[smp] cycles of workgroup 0: load %.0f undo copy %.0f proposal %.0f lanes %.0f node updates %.0f decision %.0f store %.0f\n",
+              ph[6], ph[0], ph[1], ph[2], ph[3], ph[4], ph[7]);
+    }
     if ((a.dbg & 8u) && mode == 0)
     {
       double pr[8]; (void)hipMemcpy(pr, s->mix_delta.p, sizeof pr, hipMemcpyDeviceToHost);
       if (a.dbg & 16u)
       {
-        double ph[6]; (void)hipMemcpy(ph, s->mix_delta.p + 8, sizeof ph, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[smp] cycles of workgroup 0: undo copy %.0f proposal %.0f lanes %.0f node updates %.0f decision %.0f roll-back %.0f\n",
-                ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+        double ph[8]; (void)hipMemcpy(ph, s->mix_delta.p + 8, sizeof ph, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[smp] cycles of workgroup 0: load %.0f undo copy %.0f proposal %.0f lanes %.0f node updates %.0f decision %.0f roll-back %.0f store %.0f\n",
+                ph[6], ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[7]);
       }
       fprintf(stderr, "[smp] cycles of one locus: gage pre %.0f density %.0f install %.0f | gspr pre %.0f log %.0f density %.0f install %.0f | decide %.0f\n",
               pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
