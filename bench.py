@@ -185,7 +185,9 @@ def main():
     dist = None
     sum_buf = None
     stream = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: the N>1 code path (launch segments + an all-reduce per all-loci step) in a one-rank group —
+    # what the collectives' enqueue costs on the host, measurable on a one-GPU box
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):
         import torch
         import torch.distributed as dist_
         dist = dist_
@@ -195,6 +197,8 @@ def main():
         if "BENCH_FORCE_DEVICE" in os.environ:
             local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
         torch.cuda.set_device(local_rank)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend, rank=rank, world_size=world)
         # the engine and the collectives share ONE explicit torch stream, so that an all-reduce is
         # ordered after the kernel that produced the sum (torch's default stream has handle 0, which
@@ -321,8 +325,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         run_iteration(args.warmup + i)
+    enqueue_s = time.perf_counter() - t0          # host time to enqueue the timed region (GPU still running)
     sync()
     elapsed = time.perf_counter() - t0
+    log(f"host enqueue {1e3 * enqueue_s / args.steps:.4f} ms/step of {1e3 * elapsed / args.steps:.4f} ms/step")
     tm = eng.timing() if not args.no_timing_events else None
     eng.enable_timing(False)
 
@@ -476,8 +482,6 @@ def main():
             "device_resident_sampler": sampler,
             "allreduce_check": allreduce_check,
         }
-        print(json.dumps(out), flush=True)
-
     for it in plans:
         for p in it:
             p.close()
@@ -485,6 +489,12 @@ def main():
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
+        # RCCL writes its version banner to the C stdout buffer, which a pipe only flushes at exit: push it out now so
+        # that the JSON line is the LAST line on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
