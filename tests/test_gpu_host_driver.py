@@ -61,3 +61,88 @@ def test_driver_incremental_equals_scratch_on_gpu(engine):
         assert rel(t["lnl"], full) < 1e-12
         assert rel(t["logpr"], g.logpr(i)) < 1e-12
     g.close()
+
+
+def _msc_start_tree(tip_species, parent, tau, theta, rng):
+    """a gene tree drawn from the MSC for tips with the given species (several per species allowed): tips
+    0..n-1, inner nodes by increasing age, root last"""
+    npop, n = len(parent), len(tip_species)
+    kids = {p: [c for c in range(npop) if parent[c] == p] for p in range(npop)}
+    events = []
+
+    def run(p):
+        lin = [k for k in range(n) if tip_species[k] == p]
+        for c in kids[p]:
+            lin += run(c)
+        now, end = tau[p], (tau[parent[p]] if parent[p] >= 0 else None)
+        while len(lin) > 1:
+            k = len(lin)
+            now += rng.exponential(theta[p] / (k * (k - 1)))
+            if end is not None and now >= end:
+                break
+            i, j = rng.choice(k, 2, replace=False)
+            events.append((now, lin[i], lin[j]))
+            lin = [x for q, x in enumerate(lin) if q not in (i, j)] + [("ev", len(events) - 1)]
+        return lin
+
+    run(npop - 1)
+    order = sorted(range(len(events)), key=lambda e: events[e][0])
+    ident = {e: n + rank for rank, e in enumerate(order)}
+    nid = lambda x: x if isinstance(x, int) else ident[x[1]]
+    left, right, times = [-1] * (2 * n - 1), [-1] * (2 * n - 1), [0.0] * (2 * n - 1)
+    for e in order:
+        t, a, b = events[e]
+        left[ident[e]], right[ident[e]], times[ident[e]] = nid(a), nid(b), t
+    return left, right, times, 2 * n - 2
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref did not travel")
+def test_anopheles_a00_on_gpu_and_reference(engine):
+    """BASELINE config 5's data (examples/anopheles: 100 loci x 12 sequences, 6 species, two sequences each, JC69,
+    cleandata = 1; priors and step lengths of anopheles-bpp-msci.ctl) under the MSC on the tree (R,((C,G),((A,Q),L)))
+    of the control file: the C host driver over libbpp_amd.so and over the real reference's locus API — same seeds,
+    same decisions, same gene trees, same thetas and taus."""
+    import json
+    import os
+    from bpp_amd import seqio
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    species = ["G", "C", "R", "L", "A", "Q"]
+    recs = seqio.load_dataset(os.path.join(G, "anopheles", "loci_realign.txt"), os.path.join(G, "anopheles", "Imap.txt"),
+                              species, None, model="jc69", cleandata=True)
+    parent = [6, 6, 10, 8, 7, 7, 9, 8, 9, 10, -1]
+    tau0 = [0.0] * 6 + [0.004, 0.004, 0.008, 0.012, 0.016]
+    thetas = [0.02] * 11
+    rng = np.random.default_rng(77)
+    data = []
+    for r in recs:
+        left, right, times, root = _msc_start_tree(r["species"], parent, tau0, thetas, rng)
+        data.append(dict(seqs=r["seqs"], weights=r["weights"], left=left, right=right, times=times, root=root, states=4,
+                         rate_cats=1, model="jc69", rates=np.ones(1)))
+    loci = tape.make_engine_loci(engine, data)
+    g = hostdrv.hip_driver(engine, loci, data, seed=21)
+    r_ = hostdrv.reference_driver(data, seed=21)
+    for drv in (g, r_):
+        drv.set_species_tree(parent, tau0, thetas)
+        for i, r in enumerate(recs):
+            drv.set_tip_species(i, r["species"])
+        drv.set_tau_prior(2.0, 10.0)                           # tauprior = gamma 2 10
+        drv.set_theta_prior(2.0, 100.0, 0.002)                 # thetaprior = gamma 2 100; finetune theta 0.002
+        drv.set_finetune(0.003, 0.003, 0.00002, 0.9)           # GBtj, GBspr, tau, mix of the control file
+    g.initialize(); r_.initialize()
+    assert rel(g.total_lnl(), r_.total_lnl()) < 1e-13
+    lnl0 = g.total_lnl()
+    for it in range(6):
+        g.iterate(); r_.iterate()
+        assert rel(g.total_lnl(), r_.total_lnl()) < 1e-12, it
+        assert g.counters() == r_.counters(), it
+    assert g.taus() == r_.taus() and g.thetas() == r_.thetas()
+    assert g.total_lnl() != lnl0 and g.thetas() != thetas
+    props, acc, _ = g.counters()
+    assert 0.1 < acc / props < 0.95
+    for i in range(len(data)):
+        a, b = g.tree(i), r_.tree(i)
+        for key in ("root", "left", "right", "parent", "clv", "pmat", "pop"):
+            assert a[key] == b[key]
+        assert a["time"] == b["time"] and a["logpr"] == b["logpr"]
+        assert rel(a["lnl"], b["lnl"]) < 1e-12
+    g.close(); r_.close()

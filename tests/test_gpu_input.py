@@ -67,3 +67,28 @@ def test_frogs_unphased_gtr(engine, gold):
         ol = O.OracleLocus(4, 1, w["a1"]["seqs"], w["a1"]["weights"], model="gtr", freqs=freqs, qrates=qr)
         want = ol.full_lnl(left, right, times, root)
         assert rel(got, want) < LNL_RTOL, (got, want)
+
+
+def test_anopheles_config5_files_to_lnl(engine):
+    """BASELINE config 5 (examples/anopheles: 100 loci x 12 sequences, JC69, cleandata = 1, the settings of
+    anopheles-bpp-msci.ctl): files -> cleaned, compressed device loci -> lnL on the fixture's gene trees, against the
+    REAL reference's locus_root_loglikelihood on its own patterns (tests/golden/anopheles_pipeline.json)."""
+    with open(os.path.join(G, "anopheles_pipeline.json")) as f:
+        gold = json.load(f)
+    recs = seqio.load_dataset(os.path.join(G, "anopheles", "loci_realign.txt"), os.path.join(G, "anopheles", "Imap.txt"),
+                              gold["species"], None, model="jc69", cleandata=True)
+    assert len(recs) == len(gold["loci"]) == 100
+    total = 0.0
+    for r, w in zip(recs, gold["loci"]):
+        assert r["labels"] == w["labels"] and list(r["weights"]) == w["weights"]      # bit-exact compressed pattern counts
+        assert set(r["species"]) <= set(range(6))
+        loc = seqio.make_locus(engine, r)
+        t = w["tree"]
+        gt = GTree(t["left"], t["right"], [float.fromhex(x) for x in t["times"]], t["root"])
+        locus_update_matrices(loc, gt, gt.branches())
+        locus_update_partials(loc, gt.postorder())
+        got = locus_root_loglikelihood(loc, gt.root)
+        want = float.fromhex(w["lnl"])
+        assert rel(got, want) < LNL_RTOL, (got, want)
+        total += got
+    assert rel(total, float.fromhex(gold["total_lnl"])) < 1e-12
