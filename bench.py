@@ -394,12 +394,12 @@ def main():
     sampler = None
     if args.config == "c2" and not args.no_sampler:
         smp = bpp_amd.Sampler(eng, loci, data, seed=1)
-        if world > 1:
-            # loci sharded, one all-reduced double per THETA / TAU / MIX step (RCCL on the engine's stream)
-            smp_sum = torch.zeros(1, dtype=torch.float64, device=f"cuda:{local_rank}")
+        if dist is not None:
+            # loci sharded; one small sum all-reduce per THETA (all populations together) / TAU / MIX step (RCCL on the engine's stream)
+            smp_sum = torch.zeros(16, dtype=torch.float64, device=f"cuda:{local_rank}")      # BPA_SAMPLER_SUMS
 
-            def smp_allreduce(ptr, stream):
-                dist.all_reduce(smp_sum)
+            def smp_allreduce(ptr, count, stream):
+                dist.all_reduce(smp_sum[:count])
                 return True
             smp.set_allreduce(smp_allreduce, smp_sum.data_ptr(), rank * nloci)
         sp_parent, sp_tau, sp_theta = synth.species_tree_arrays(cfg["taxa"])
@@ -410,20 +410,20 @@ def main():
         smp.initialize()
         smp.iterate(args.warmup)
         eng.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
         smp.iterate(args.steps)
         eng.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist is not None:
             tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         sm = smp.summary()
         sampler = dict(iterations_per_s=round(args.steps / dt * nloci * world / 10000.0, 1), ms_per_iteration=round(1e3 * dt / args.steps, 4),
                        n_gpus=world,
-                       launches_per_iteration=3 + (2 if world == 1 else 3) * (len(smp_taus) + 1),   # sweep, THETA x2, (TAU.. + MIX) x (step + sum/decide) proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
+                       launches_per_iteration=(3 if dist is None else 4) + (2 if dist is None else 3) * (len(smp_taus) + 1),   # sweep, THETA x2, (TAU.. + MIX) x (step + sum/decide) proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
                        acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
                        taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
                        thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],

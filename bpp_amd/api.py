@@ -519,9 +519,10 @@ class Sampler:
         lib().bpa_sampler_set_theta_prior(self.h, alpha, beta, finetune)
 
     def set_allreduce(self, fn, device_sum_ptr, first_locus):
-        """fn(device_ptr:int, stream:int) -> truthy; enqueues the sum all-reduce of the device double (section 8e)"""
-        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
-        self._ar = proto(lambda ctx, p, st: 1 if fn(p, st) else 0)
+        """fn(device_ptr:int, count:int, stream:int) -> truthy; enqueues the sum all-reduce of `count` device doubles
+        (section 8e); device_sum_ptr: device memory for SAMPLER_SUMS doubles"""
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p)
+        self._ar = proto(lambda ctx, p, n, st: 1 if fn(p, n, st) else 0)
         _chk(lib().bpa_sampler_set_allreduce(self.h, C.cast(self._ar, C.c_void_p), None,
                                              C.c_void_p(device_sum_ptr), first_locus))
 
@@ -580,6 +581,9 @@ class PlanSequence:
     def launch(self):
         if not self._fn(self.arr, len(self.plans)):
             raise BpaError(_err())
+
+
+SAMPLER_SUMS = 16            # BPA_SAMPLER_SUMS
 
 
 class Plan:

@@ -838,7 +838,7 @@ __global__ void __launch_bounds__(1024) theta_sum_decide_kernel(const int8_t * _
 {
   __shared__ double sh[1024];
   const int p = (int)blockIdx.x;
-  if (!ta.on[p]) return;
+  if (!ta.on[p]) { if (threadIdx.x == 0 && sums_out) sums_out[p] = 0.0; return; }
   const double told = taus[MAXPOP + p], l2t_old = taus[2*MAXPOP + p];
   const double tnew = reflect(told + sp.ft_theta*(ta.win_u[p] - 0.5), 0.0, 999.0);
   const double l2t_new = log(2.0/(1.0*tnew));
@@ -1199,7 +1199,7 @@ static int sampler_sum(bpa_sampler * s)
   double * out = s->sum_ext ? s->sum_ext : s->mix_sum.p;
   hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, out);
   HIPCHK(hipGetLastError());
-  if (s->allreduce && !s->allreduce(s->allreduce_ctx, out, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
+  if (s->allreduce && !s->allreduce(s->allreduce_ctx, out, 1u, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
   return 1;
 }
 
@@ -1259,14 +1259,12 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
       {
         hipLaunchKernelGGL(smp::theta_sum_decide_kernel, dim3(s->sp.npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p,
                            s->nloci, s->taus.p, s->sp, ta, s->counters.p, s->theta_sums.p, (const double *)nullptr, 0);
-        double * ar = s->sum_ext ? s->sum_ext : s->mix_sum.p;          // the double the callback's collective addresses
-        for (int p = 0; p < s->sp.npop; ++p)
-        {
-          if (!s->has_theta[p]) continue;
-          HIPCHK(hipMemcpyAsync(ar, s->theta_sums.p + p, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-          if (!s->allreduce(s->allreduce_ctx, ar, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
-          HIPCHK(hipMemcpyAsync(s->theta_sums.p + p, ar, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-        }
+        // all populations' sums in ONE collective, in the memory the callback's collective addresses
+        double * ar = s->sum_ext ? s->sum_ext : s->theta_sums.p;
+        const size_t nb = (size_t)s->sp.npop*sizeof(double);
+        if (ar != s->theta_sums.p) HIPCHK(hipMemcpyAsync(ar, s->theta_sums.p, nb, hipMemcpyDeviceToDevice, e->stream));
+        if (!s->allreduce(s->allreduce_ctx, ar, (unsigned)s->sp.npop, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
+        if (ar != s->theta_sums.p) HIPCHK(hipMemcpyAsync(s->theta_sums.p, ar, nb, hipMemcpyDeviceToDevice, e->stream));
         hipLaunchKernelGGL(smp::theta_sum_decide_kernel, dim3(s->sp.npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p,
                            s->nloci, s->taus.p, s->sp, ta, s->counters.p, (double *)nullptr, (const double *)s->theta_sums.p, 1);
       }

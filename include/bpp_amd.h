@@ -243,14 +243,16 @@ int  bpa_sampler_get_thetas(bpa_sampler_t *, double * theta); /* 2*species-1 ent
 int  bpa_sampler_get_taus(bpa_sampler_t *, double * tau);     /* 2*species-1 entries; returns their number */
 /* Several GPUs (threads.c:544-591): every rank samples its own loci with the same seed, so
    the global stream gives all ranks the same window and acceptance numbers; the only exchange is the sum of an
-   all-loci step's per-locus terms.  After summing its loci into ONE device double the sampler calls fn(ctx,
-   that address, the engine's hipStream_t); fn must enqueue a sum all-reduce over the ranks on that stream
-   (RCCL: ncclAllReduce(p, p, 1, ncclDouble, ncclSum, comm, stream)) and return non-zero.  device_sum: a
-   caller-owned device double to use for the sum (e.g. memory a framework's collective can address) or NULL.
-   first_locus: global index of this rank's first locus — the per-locus random streams are keyed by global index,
-   so a sharded run walks the trajectory of the single-GPU run.                                             */
-typedef int (*bpa_allreduce_fn)(void * ctx, double * device_scalar, void * stream);
-int  bpa_sampler_set_allreduce(bpa_sampler_t *, bpa_allreduce_fn fn, void * ctx, double * device_sum,
+   all-loci step's per-locus terms.  After summing its loci into device doubles the sampler calls fn(ctx, their
+   address, count, the engine's hipStream_t); fn must enqueue a sum all-reduce over the ranks on that stream
+   (RCCL: ncclAllReduce(p, p, count, ncclDouble, ncclSum, comm, stream)) and return non-zero.  count is 1 for a TAU or
+   MIX step and the number of populations for the THETA step (one sum per theta: one collective for all of them).
+   device_sums: caller-owned device memory for BPA_SAMPLER_SUMS doubles to use for the sums (e.g. memory a
+   framework's collective can address) or NULL.  first_locus: global index of this rank's first locus — the
+   per-locus random streams are keyed by global index, so a sharded run walks the trajectory of the single-GPU run. */
+#define BPA_SAMPLER_SUMS 16
+typedef int (*bpa_allreduce_fn)(void * ctx, double * device_sums, unsigned count, void * stream);
+int  bpa_sampler_set_allreduce(bpa_sampler_t *, bpa_allreduce_fn fn, void * ctx, double * device_sums,
                                unsigned first_locus);
 int  bpa_sampler_initialize(bpa_sampler_t *);                 /* all matrices, partials, lnL */
 int  bpa_sampler_iterate(bpa_sampler_t *, unsigned iterations); /* asynchronous on the engine stream */

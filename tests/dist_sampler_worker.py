@@ -25,11 +25,11 @@ def main():
     eng = bpp_amd.Engine(0)
     loci = tape.make_engine_loci(eng, mine)
     smp = bpp_amd.Sampler(eng, loci, mine, seed=7)
-    t = torch.zeros(1, dtype=torch.float64, device="cuda")
+    t = torch.zeros(16, dtype=torch.float64, device="cuda")        # BPA_SAMPLER_SUMS
 
-    def allreduce(ptr, stream):
-        eng.synchronize()                       # gloo is host-driven: the device sum must be complete
-        dist.all_reduce(t)
+    def allreduce(ptr, count, stream):
+        eng.synchronize()                       # gloo is host-driven: the device sums must be complete
+        dist.all_reduce(t[:count])
         torch.cuda.synchronize()
         return True
     if world > 1:
