@@ -93,6 +93,36 @@ struct MatRec             // one (branch, all rate categories) P-matrix update
   uint32_t       rate_cats, model, entry, pad;   // entry: index into mat_length[]
 };
 
+// ---- compact step records of the JC69 path (step_jc69_v2_kernel) ------------------------------------------------
+// Everything that does not change from step to step lives in two ENGINE-level tables that every plan shares and
+// that stay in L2 — one 16-byte entry per lane (pattern weight, the pattern's tip codes, position in the locus) and
+// one 64-byte entry per locus ("slot": buffer addresses, sizes) — so a step only brings 16 B per locus + 16 B per
+// node update + 8 B per fresh P-matrix from HBM, and the lane -> record hop is an index calculation.
+struct LaneStatic { uint32_t slot, wgt, tipcodes, n_np_tips; };   // slot 0xffffffff: idle lane; n | np << 9 | tips << 18
+struct SlotStatic
+{
+  double *   clv;
+  double *   pmat;
+  uint32_t * scaler;
+  const double * par;
+  uint32_t   np, tips_n, lane0, locus;       // lane0: global lane of pattern 0
+  uint32_t   unphased_length, pad0, pad1, pad2;
+};
+struct StepRec                               // 16 B, followed by the step's StepOps (16 B each)
+{
+  uint32_t task;                             // index of the locus in this plan, 0xffffffff: not part of it
+  uint32_t pat_off;
+  uint8_t  root_clv; int8_t root_scaler; uint8_t nops, pad0;
+  uint32_t pad1;
+};
+struct StepOp                                // bpa_op_t with byte indices (<= 8 tips: 22 CLVs, 28 P-matrices)
+{
+  uint8_t parent_clv, left_clv, right_clv, left_pmatrix, right_pmatrix;
+  int8_t  parent_scaler, left_scaler, right_scaler;
+  int32_t left_e, right_e;                   // entry of mat_length[] when that child's P-matrix is updated in this step, else -1
+};
+struct MatRec2 { uint32_t slot, pmatrix; };  // a fresh P-matrix of the step: (a, b) pair pmatrix of that slot
+
 // a resident batched step (bpa_plan_t) as the kernels see it
 struct PlanDev
 {
@@ -123,6 +153,15 @@ struct PlanDev
   // tiled path (20 states): workgroup b owns patterns tile_n0[b] .. +TILE of task tile_task[b]
   const uint32_t * tile_task;   // [NT]
   const uint32_t * tile_n0;     // [NT]
+  // compact JC69 path
+  const LaneStatic * lane_tab;  // engine table [B2*256]
+  const SlotStatic * slot_tab;  // engine table [slots]
+  const uint32_t * blk_slot_off;// engine table [B2+1]
+  const uint4 *    recs2;       // [slots*rec2_units] StepRec + StepOps
+  const MatRec2 *  mat2;        // [M]
+  const uint32_t * blk_mat_off; // [B2+1] fresh P-matrices of the workgroup's loci
+  uint32_t         rec2_units;  // 16-byte units per slot record
+  uint32_t         nblocks2;
   unsigned long long * dbg;     // optional per-workgroup timestamps (profiling aid, normally null)
   uint32_t         nblocks;     // B (0: fused path not available)
   uint32_t         flags;       // bit0: compute P-matrices, bit1: node updates + site terms, bit2: per-locus lnL

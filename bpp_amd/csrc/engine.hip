@@ -110,6 +110,16 @@ struct bpa_engine
   std::vector<bpa_locus *> dirty;     // loci whose host-side state must be flushed
   DevBuf<LocusDev> d_loci;
   bool table_dirty = true;
+  // engine-level packing of the JC69 / one-category loci for step_jc69_v2_kernel (device_types.hpp): shared by all plans
+  bool pack_dirty = true;               // a locus appeared / went away / changed its tip states or weights
+  unsigned pack_epoch = 0;              // bumped when the slot numbering or a slot's shape changes: older plans fall back
+  std::vector<int32_t> slot_of;         // locus id -> slot (-1: not packed)
+  std::vector<uint32_t> pack_shape;     // (locus id, np, tips) per slot, to detect a change of the numbering
+  DevBuf<LaneStatic> d_lane_tab;
+  DevBuf<SlotStatic> d_slot_tab;
+  DevBuf<uint32_t>   d_blk_slot_off;
+  std::vector<uint32_t> h_blk_slot_off;
+  unsigned pack_blocks = 0, pack_slots = 0;
   DevBuf<uint32_t> d_eigen_list;
   int usedata = 1;
   double bfbeta = 1.0;
@@ -142,6 +152,11 @@ struct bpa_plan
   bool fused_klane = false;
   DevBuf<MatRec>   mat_recs;
   bool fused_jc69 = false;            // JC69, one rate category: the latency-optimised kernel
+  bool jc69_v2 = false;               // ... on the compact records over the engine's packing (valid while pack_epoch is)
+  unsigned pack_epoch = 0;
+  DevBuf<uint4>    recs2;
+  DevBuf<MatRec2>  mat2;
+  DevBuf<uint32_t> blk_mat_off;
   unsigned fused_rt = 0;              // compile-time rate-category count of the fused kernel (0 = runtime)
   unsigned fused_bs = 0;              // workgroup size of the fused single-launch path (0 = not available)
   DevBuf<int32_t>  root_scaler;
@@ -157,6 +172,7 @@ struct bpa_plan
     mat_pmatrix.free(); op_off.free(); root_clv.free(); root_scaler.free(); mat_length.free();
     site_term.free(); lnl.free(); ops.free(); lnl_sum.free(); param_stage.free();
     blk_task_off.free(); lane_task.free(); task_lane0.free(); lane_rec.free(); task_rec.free(); recs.free(); mat_recs.free(); tile_task.free(); tile_n0.free();
+    recs2.free(); mat2.free(); blk_mat_off.free();
   }
   ~bpa_plan() { free_all(); }
 };
@@ -326,7 +342,7 @@ extern "C" bpa_locus_t * bpa_locus_create(bpa_engine_t * e, unsigned dtype, unsi
 extern "C" void bpa_locus_destroy(bpa_locus_t * l)
 {
   // arena memory is released with the engine; the slot stays so ids remain stable
-  if (l) { l->alive = false; l->scratch.reset(); }
+  if (l) { l->alive = false; l->scratch.reset(); l->eng->pack_dirty = true; }
 }
 
 extern "C" int bpa_set_tip_states(bpa_locus_t * l, unsigned tip_index, const unsigned * map,
@@ -456,6 +472,7 @@ static int flush(bpa_engine * e)
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(e->d_loci.p, tab.data(), tab.size()*sizeof(LocusDev), hipMemcpyHostToDevice));
     e->table_dirty = false;
+    e->pack_dirty = true;
   }
   if (e->dirty.empty()) return 1;
   std::vector<uint32_t> eig;
@@ -464,9 +481,9 @@ static int flush(bpa_engine * e)
   {
     l->queued = false;
     if (l->tips_dirty)
-    { HIPCHK(hipMemcpy(l->dev.tips, l->tipcodes.data(), l->tipcodes.size(), hipMemcpyHostToDevice)); l->tips_dirty = false; }
+    { HIPCHK(hipMemcpy(l->dev.tips, l->tipcodes.data(), l->tipcodes.size(), hipMemcpyHostToDevice)); l->tips_dirty = false; e->pack_dirty = true; }
     if (l->weights_dirty)
-    { HIPCHK(hipMemcpy(l->dev.weights, l->weights.data(), l->weights.size()*4, hipMemcpyHostToDevice)); l->weights_dirty = false; }
+    { HIPCHK(hipMemcpy(l->dev.weights, l->weights.data(), l->weights.size()*4, hipMemcpyHostToDevice)); l->weights_dirty = false; e->pack_dirty = true; }
     bool need_eig = false;
     if (l->needs_eigen())
       for (int v : l->eigen_valid) if (!v) need_eig = true;
@@ -504,6 +521,59 @@ static int upload(DevBuf<T> & b, const T * src, size_t n)
 {
   if (!b.reserve(n)) return fail("out of device memory (plan)");
   if (n) HIPCHK(hipMemcpy(b.p, src, n*sizeof(T), hipMemcpyHostToDevice));
+  return 1;
+}
+
+// The engine's packing for step_jc69_v2_kernel: every JC69 / one-category / 4-state locus of <= 8 tips and < 256
+// patterns gets a slot (in locus order), whole loci fill workgroups of 256 lanes, and the per-lane and per-slot
+// constants go into two device tables shared by all plans.  Rebuilt (after flush) when a locus came, went or changed
+// its tip states / weights; the epoch moves only when the slot numbering or a slot's shape did.
+constexpr unsigned PACK_BS = 256;
+static int engine_pack(bpa_engine * e)
+{
+  if (e->table_dirty || e->slot_of.size() != e->loci.size()) e->pack_dirty = true;       // a locus was created since
+  if (!e->pack_dirty) return 1;
+  std::vector<uint32_t> shape, blk{0};
+  std::vector<LaneStatic> lanes;
+  std::vector<SlotStatic> slots;
+  std::vector<int32_t> slot_of(e->loci.size(), -1);
+  const LaneStatic idle{0xffffffffu, 0, 0, 0};
+  unsigned used = 0;
+  for (bpa_locus * l : e->loci)
+  {
+    const bool ok = l->alive && l->states == 4 && l->rate_cats == 1 && l->dev.model == 0 && l->tips <= 8 && l->sites < PACK_BS &&
+                    l->tips + l->clv_buffers < 256 && l->prob_matrices < 256 && l->scale_buffers < 128;
+    if (!ok) continue;
+    const unsigned np = l->sites, slot = (unsigned)slots.size();
+    if (used + np > PACK_BS) { lanes.resize(blk.size()*PACK_BS, idle); blk.push_back(slot); used = 0; }
+    SlotStatic st{};
+    st.clv = l->dev.clv; st.pmat = l->dev.pmat; st.scaler = l->dev.scaler; st.par = l->dev.par;
+    st.np = np; st.tips_n = l->tips; st.lane0 = (uint32_t)((blk.size() - 1)*PACK_BS + used); st.locus = l->id;
+    st.unphased_length = l->dev.unphased_length;
+    slots.push_back(st);
+    slot_of[l->id] = (int32_t)slot;
+    shape.push_back(l->id); shape.push_back(np); shape.push_back(l->tips);
+    for (unsigned n = 0; n < np; ++n)
+    {
+      uint32_t codes = 0;
+      for (unsigned tip = 0; tip < l->tips; ++tip) codes |= (uint32_t)(l->tipcodes[(size_t)tip*np + n] & 15u) << (4*tip);
+      lanes.push_back(LaneStatic{slot, l->weights[n], codes, n | np << 9 | l->tips << 18});
+    }
+    used += np;
+  }
+  lanes.resize(blk.size()*PACK_BS, idle);
+  blk.push_back((uint32_t)slots.size());
+  // kernels in flight may still read the old tables
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (!upload(e->d_lane_tab, lanes.data(), lanes.size()) || !upload(e->d_slot_tab, slots.data(), slots.size()) ||
+      !upload(e->d_blk_slot_off, blk.data(), blk.size()))
+    return 0;
+  if (shape != e->pack_shape) { e->pack_epoch++; e->pack_shape.swap(shape); }
+  e->slot_of.swap(slot_of);
+  e->h_blk_slot_off.swap(blk);
+  e->pack_blocks = (unsigned)e->h_blk_slot_off.size() - 1;
+  e->pack_slots = (unsigned)slots.size();
+  e->pack_dirty = false;
   return 1;
 }
 
@@ -731,6 +801,69 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
     p->fused_rt = all1 ? 1 : (all4 ? 4 : 0);
     p->fused_jc69 = all1 && all_jc && !getenv("BPA_NO_JC69_FAST");
     d.pad = p->rmax;
+
+    // compact records over the engine's packing (step_jc69_v2_kernel): the plan's loci must be packed and come in slot order
+    p->jc69_v2 = false;
+    if (p->fused_jc69 && !getenv("BPA_JC69_V1"))
+    {
+      if (!engine_pack(e)) return 0;
+      bool ok = e->pack_slots > 0;
+      int prev = -1;
+      unsigned maxops = 0;
+      for (unsigned t = 0; t < T && ok; ++t)
+      {
+        const int sl = e->slot_of[b->loci[t]->id];
+        ok = sl > prev;
+        prev = sl;
+        maxops = std::max(maxops, b->op_off ? b->op_off[t+1] - b->op_off[t] : 0u);
+      }
+      if (ok)
+      {
+        const unsigned units = 1 + std::max(maxops, 3u);
+        std::vector<uint4> r2((size_t)e->pack_slots*units, uint4{0, 0, 0, 0});
+        for (unsigned sl = 0; sl < e->pack_slots; ++sl) reinterpret_cast<StepRec *>(&r2[(size_t)sl*units])->task = 0xffffffffu;
+        std::vector<MatRec2> m2(nmat);
+        std::vector<uint32_t> slot_mat0(e->pack_slots + 1, 0);          // first fresh matrix of the slot's locus (prefix)
+        for (unsigned t = 0; t < T; ++t)
+        {
+          const bpa_locus * l = b->loci[t];
+          const unsigned sl = (unsigned)e->slot_of[l->id];
+          const unsigned nops_t = b->op_off ? b->op_off[t+1] - b->op_off[t] : 0;
+          StepRec h{};
+          h.task = t; h.pat_off = pat_off[t]; h.root_clv = (uint8_t)rc[t]; h.root_scaler = (int8_t)rs[t]; h.nops = (uint8_t)nops_t;
+          std::memcpy(&r2[(size_t)sl*units], &h, sizeof(h));
+          for (unsigned o = 0; o < nops_t; ++o)
+          {
+            const bpa_op_t & s = b->ops[b->op_off[t] + o];
+            StepOp q{};
+            q.parent_clv = (uint8_t)s.parent_clv; q.left_clv = (uint8_t)s.left_clv; q.right_clv = (uint8_t)s.right_clv;
+            q.left_pmatrix = (uint8_t)s.left_pmatrix; q.right_pmatrix = (uint8_t)s.right_pmatrix;
+            q.parent_scaler = (int8_t)s.parent_scaler; q.left_scaler = (int8_t)s.left_scaler; q.right_scaler = (int8_t)s.right_scaler;
+            q.left_e = q.right_e = -1;
+            if (b->mat_off)
+              for (unsigned i = b->mat_off[t]; i < b->mat_off[t+1]; ++i)
+              {
+                if (b->mat_pmatrix[i] == s.left_pmatrix)  q.left_e = (int32_t)i;
+                if (b->mat_pmatrix[i] == s.right_pmatrix) q.right_e = (int32_t)i;
+              }
+            std::memcpy(&r2[(size_t)sl*units + 1 + o], &q, sizeof(q));
+          }
+          if (b->mat_off)
+          {
+            for (unsigned i = b->mat_off[t]; i < b->mat_off[t+1]; ++i) m2[i] = MatRec2{sl, b->mat_pmatrix[i]};
+            slot_mat0[sl + 1] = b->mat_off[t+1] - b->mat_off[t];
+          }
+        }
+        // the plan's loci are in slot order, so are their fresh matrices: a workgroup's are one range
+        for (unsigned sl = 0; sl < e->pack_slots; ++sl) slot_mat0[sl + 1] += slot_mat0[sl];
+        std::vector<uint32_t> bm(e->pack_blocks + 1);
+        for (unsigned k = 0; k <= e->pack_blocks; ++k) bm[k] = slot_mat0[e->h_blk_slot_off[k]];
+        if (!upload(p->recs2, r2.data(), r2.size()) || !upload(p->mat2, m2.data(), nmat) || !upload(p->blk_mat_off, bm.data(), bm.size()))
+          return 0;
+        d.recs2 = p->recs2.p; d.mat2 = p->mat2.p; d.blk_mat_off = p->blk_mat_off.p; d.rec2_units = units;
+        p->jc69_v2 = true; p->pack_epoch = e->pack_epoch;
+      }
+    }
   }
 
   hipLaunchKernelGGL(build_thr_task_kernel, dim3((P + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream,
@@ -807,6 +940,11 @@ static int plan_launch_mode(bpa_plan * p, int mode)
         if (p->fused_bs == 128) hipExtLaunchKernelGGL((step_s4_klane_kernel<128, false>), grid, dim3(128), 0, e->stream, k0, k1, 0, d);
         else                    hipExtLaunchKernelGGL((step_s4_klane_kernel<256, false>), grid, dim3(256), 0, e->stream, k0, k1, 0, d);
       }
+    }
+    else if (p->jc69_v2 && !d.dbg && engine_pack(e) && p->pack_epoch == e->pack_epoch)       // (the stamps of bpa_plan_probe live in the first version)
+    {
+      d.lane_tab = e->d_lane_tab.p; d.slot_tab = e->d_slot_tab.p; d.blk_slot_off = e->d_blk_slot_off.p; d.nblocks2 = e->pack_blocks;
+      hipExtLaunchKernelGGL((step_jc69_v2_kernel<PACK_BS>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, k0, k1, 0, d);
     }
     else if (p->fused_jc69)
     {

@@ -2001,6 +2001,244 @@ __global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
   BPA_STAMP(P, b, lane, 7);
 }
 
+// The same step on the compact records (device_types.hpp): hop 1 is the engine's lane table (L2-resident, shared by
+// all plans: weight, tip codes, position), hop 2 the slot's static entry (L2-resident) next to the step's 16 + 16*ops
+// bytes from HBM, hop 3 the inner CLVs — tip states and weights need no load at all, the record address is slot *
+// stride.  Workgroups are the ENGINE's packing (the same loci in the same workgroup in every plan: a locus's CLVs
+// stay in the L2 of the XCD that works on it); loci that are not part of the plan leave their lanes idle.
+// Arithmetic: the very statements of step_jc69_kernel.
+template <int BS>
+__global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
+{
+  constexpr int NPRE = 3;
+  constexpr uint32_t NAB = 2*BS;
+  __shared__ double s_term[BS];
+  __shared__ double2 s_ab[NAB];
+  static_assert(sizeof(LaneStatic) == 16 && sizeof(SlotStatic) == 64 && sizeof(StepRec) == 16 && sizeof(StepOp) == 16 && sizeof(MatRec2) == 8, "compact records");
+  const uint32_t b = blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
+  const uint32_t s0 = P.blk_slot_off[b], s1 = P.blk_slot_off[b+1];
+  const LaneStatic ls = P.lane_tab[gl];
+  const bool has_slot = ls.slot != 0xffffffffu;
+  const bool do_mats = (P.flags & 1u) != 0;
+  const uint32_t e0 = do_mats ? P.blk_mat_off[b] : 0u, e1 = do_mats ? P.blk_mat_off[b+1] : 0u;
+  // K4 for this step's branches (locus.c:2342-2414), one branch per lane: requested now
+  const bool have_m0 = e0 + lane < e1;
+  MatRec2 m0{0, 0};
+  double m0_len = 0;
+  if (have_m0) { m0 = P.mat2[e0 + lane]; m0_len = P.mat_length[e0 + lane]; }
+  // phase C bookkeeping
+  const bool summer = (P.flags & 4u) && lane < s1 - s0;
+  uint32_t c_np = 0, c_l0 = 0, c_task = 0xffffffffu, c_unph = 0, c_locus = 0;
+  if (summer)
+  {
+    const SlotStatic & C = P.slot_tab[s0 + lane];
+    c_np = C.np; c_l0 = C.lane0 - b*BS; c_unph = C.unphased_length; c_locus = C.locus;
+    c_task = reinterpret_cast<const StepRec *>(P.recs2 + (size_t)(s0 + lane)*P.rec2_units)->task;
+  }
+  // this lane's records
+  SlotStatic S{};
+  StepRec hdr{};
+  hdr.task = 0xffffffffu;
+  StepOp sl[NPRE];
+  const uint4 * rp = P.recs2 + (size_t)(has_slot ? ls.slot : 0u)*P.rec2_units;
+  if (has_slot && (P.flags & 6u))
+  {
+    const uint4 * sp = reinterpret_cast<const uint4 *>(P.slot_tab + ls.slot);
+    uint4 * sd = reinterpret_cast<uint4 *>(&S);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sd[i] = sp[i];
+    *reinterpret_cast<uint4 *>(&hdr) = rp[0];
+    uint4 * ds = reinterpret_cast<uint4 *>(sl);
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) ds[i] = rp[1 + i];
+  }
+  if (have_m0)
+  {
+    const SlotStatic & M = P.slot_tab[m0.slot];
+    double2 ab;
+    jc69_ab(m0_len, M.par[par_rates(1)], ab.x, ab.y);
+    *reinterpret_cast<double2 *>(M.pmat + (size_t)m0.pmatrix*2) = ab;
+    s_ab[lane] = ab;
+    for (uint32_t e = e0 + lane + BS; e < e1; e += BS)
+    {
+      const MatRec2 m = P.mat2[e];
+      const SlotStatic & M2 = P.slot_tab[m.slot];
+      double2 ab2;
+      jc69_ab(P.mat_length[e], M2.par[par_rates(1)], ab2.x, ab2.y);
+      *reinterpret_cast<double2 *>(M2.pmat + (size_t)m.pmatrix*2) = ab2;
+      if (e - e0 < NAB) s_ab[e - e0] = ab2;
+    }
+  }
+
+  const bool work = has_slot && hdr.task != 0xffffffffu && (P.flags & 6u);
+  const uint32_t n = ls.n_np_tips & 511u, np = (ls.n_np_tips >> 9) & 511u, tips = ls.n_np_tips >> 18;
+  const uint32_t nops = (work && (P.flags & 2u)) ? hdr.nops : 0u;
+  double inl[NPRE][4], inr[NPRE][4];          // child vectors (tips expanded / inner from HBM)
+  uint32_t fwl[NPRE], fwr[NPRE];              // 0..NPRE-1: forwarded from that earlier update; 0xff: in inl/inr
+  double rate = 1, rw = 0;
+  double2 f01{0, 0}, f23{0, 0};
+  if (work)
+  {
+    // ---- one wave of independent input loads (before the workgroup waits for the fresh (a, b) pairs)
+    const double * par = S.par;
+    rate = par[par_rates(1)];
+    rw = par[par_rate_weights(1)];
+    f01 = *reinterpret_cast<const double2 *>(par + par_matrix(1, 4, 0) + pm_freqs(4));   // param_idx 0 (R = 1)
+    f23 = *reinterpret_cast<const double2 *>(par + par_matrix(1, 4, 0) + pm_freqs(4) + 2);
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i)
+    {
+      fwl[i] = fwr[i] = 0xffu;
+      if ((uint32_t)i < nops)
+      {
+        const StepOp & op = sl[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j)
+        {
+          if (sl[j].parent_clv == op.left_clv)  fwl[i] = j;
+          if (sl[j].parent_clv == op.right_clv) fwr[i] = j;
+        }
+        if (fwl[i] == 0xffu)
+        {
+          if (op.left_clv < tips) expand_code((ls.tipcodes >> (4*op.left_clv)) & 15u, inl[i]);
+          else
+          {
+            const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((size_t)(op.left_clv - tips)*np + n)*4);
+            const double2 u = p[0], w = p[1];
+            inl[i][0] = u.x; inl[i][1] = u.y; inl[i][2] = w.x; inl[i][3] = w.y;
+          }
+        }
+        if (fwr[i] == 0xffu)
+        {
+          if (op.right_clv < tips) expand_code((ls.tipcodes >> (4*op.right_clv)) & 15u, inr[i]);
+          else
+          {
+            const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((size_t)(op.right_clv - tips)*np + n)*4);
+            const double2 u = p[0], w = p[1];
+            inr[i][0] = u.x; inr[i][1] = u.y; inr[i][2] = w.x; inr[i][3] = w.y;
+          }
+        }
+      }
+    }
+  }
+  if (do_mats) __syncthreads();
+
+  double term = 0;
+  if (work)
+  {
+    // (a, b) of a branch: fresh from this step (LDS, or computed here when the workgroup has more than NAB of them)
+    // or the stored pair
+    auto pair_of = [&](int32_t e, uint32_t pm, double & a_, double & b_)
+    {
+      if (e < 0) { const double2 ab = *reinterpret_cast<const double2 *>(S.pmat + (size_t)pm*2); a_ = ab.x; b_ = ab.y; }
+      else if (do_mats && (uint32_t)e - e0 < NAB) { const double2 ab = s_ab[(uint32_t)e - e0]; a_ = ab.x; b_ = ab.y; }
+      else jc69_ab(P.mat_length[e], rate, a_, b_);
+    };
+    double res[NPRE][4];
+    uint32_t last_clv = 0xffffffffu;
+    double last[4] = {0, 0, 0, 0};
+    auto finish = [&](const StepOp & op, double & r0, double & r1, double & r2, double & r3)
+    {
+      if (op.parent_scaler >= 0)
+      {
+        uint32_t sc = 0;
+        if (op.left_scaler  >= 0) sc += S.scaler[(size_t)op.left_scaler*np  + n];
+        if (op.right_scaler >= 0) sc += S.scaler[(size_t)op.right_scaler*np + n];
+        if (r0 < BPA_SCALE_THRESHOLD && r1 < BPA_SCALE_THRESHOLD && r2 < BPA_SCALE_THRESHOLD && r3 < BPA_SCALE_THRESHOLD)
+        { r0 *= BPA_SCALE_FACTOR; r1 *= BPA_SCALE_FACTOR; r2 *= BPA_SCALE_FACTOR; r3 *= BPA_SCALE_FACTOR; sc += 1; }
+        S.scaler[(size_t)op.parent_scaler*np + n] = sc;
+      }
+      double2 * dst = reinterpret_cast<double2 *>(S.clv + ((size_t)(op.parent_clv - tips)*np + n)*4);
+      double2 u, w; u.x = r0; u.y = r1; w.x = r2; w.y = r3;
+      dst[0] = u; dst[1] = w;
+      last_clv = op.parent_clv; last[0] = r0; last[1] = r1; last[2] = r2; last[3] = r3;
+    };
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i)
+    {
+      if ((uint32_t)i < nops)
+      {
+        const StepOp & op = sl[i];
+        double lv[4], rv[4], x[4], y[4], al, bl_, ar, br;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+          lv[q] = inl[i][q]; rv[q] = inr[i][q];
+#pragma unroll
+          for (int j = 0; j < i; ++j)
+          {
+            if (fwl[i] == (uint32_t)j) lv[q] = res[j][q];
+            if (fwr[i] == (uint32_t)j) rv[q] = res[j][q];
+          }
+        }
+        pair_of(op.left_e, op.left_pmatrix, al, bl_);
+        pair_of(op.right_e, op.right_pmatrix, ar, br);
+        matvec4_ab(al, bl_, lv, x);
+        matvec4_ab(ar, br, rv, y);
+        res[i][0] = x[0]*y[0]; res[i][1] = x[1]*y[1]; res[i][2] = x[2]*y[2]; res[i][3] = x[3]*y[3];
+        finish(op, res[i][0], res[i][1], res[i][2], res[i][3]);
+      }
+    }
+    // ---- further node updates (deeper trees): same arithmetic, inputs loaded at use
+    auto vec_of = [&](uint32_t c, double v[4])
+    {
+      if (c == last_clv) { v[0] = last[0]; v[1] = last[1]; v[2] = last[2]; v[3] = last[3]; }
+      else if (c < tips) expand_code((ls.tipcodes >> (4*c)) & 15u, v);
+      else
+      {
+        const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((size_t)(c - tips)*np + n)*4);
+        const double2 u = p[0], w = p[1];
+        v[0] = u.x; v[1] = u.y; v[2] = w.x; v[3] = w.y;
+      }
+    };
+    for (uint32_t o = NPRE; o < nops; ++o)
+    {
+      StepOp op;
+      *reinterpret_cast<uint4 *>(&op) = rp[1 + o];
+      double lv[4], rv[4], x[4], y[4], al, bl_, ar, br;
+      vec_of(op.left_clv, lv);
+      vec_of(op.right_clv, rv);
+      pair_of(op.left_e, op.left_pmatrix, al, bl_);
+      pair_of(op.right_e, op.right_pmatrix, ar, br);
+      matvec4_ab(al, bl_, lv, x);
+      matvec4_ab(ar, br, rv, y);
+      double r0 = x[0]*y[0], r1 = x[1]*y[1], r2 = x[2]*y[2], r3 = x[3]*y[3];
+      finish(op, r0, r1, r2, r3);
+    }
+
+    // ---- K2 / K3 at the root (core_likelihood_avx.c:117-150)
+    double c[4];
+    vec_of(hdr.root_clv, c);
+    const double tr = dot4_pair(f01.x, f01.y, f23.x, f23.y, c);
+    term = 0 + tr*rw;
+    if (!S.unphased_length)
+    {
+      double lt = log(term);
+      if (hdr.root_scaler >= 0)
+      {
+        const uint32_t sc = S.scaler[(size_t)hdr.root_scaler*np + n];
+        if (sc) lt += sc*BPA_LOG_SCALE_THRESHOLD;
+      }
+      term = lt*ls.wgt;
+    }
+    P.site_term[hdr.pat_off + n] = term;
+  }
+
+  // ---- phase C: per-locus sum in pattern order
+  if (P.flags & 4u)
+  {
+    s_term[lane] = term;
+    __syncthreads();
+    if (summer && c_task != 0xffffffffu)
+    {
+      double logl = 0;
+      if (c_unph) logl = reduce_locus(P.loci[c_locus], s_term + c_l0);
+      else for (uint32_t q = 0; q < c_np; ++q) logl += s_term[c_l0 + q];
+      P.lnl[c_task] = P.bfbeta*logl;
+    }
+  }
+}
+
 // generic S: one lane per (branch, rate, row)
 template <int S>
 __global__ void __launch_bounds__(BPA_BLOCK) pmatrix_sN_kernel(const PlanDev P, const uint32_t rmax)
