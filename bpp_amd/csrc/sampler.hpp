@@ -106,7 +106,9 @@ struct Args
   uint32_t tau_q;              // population of the TAU (mode 4) step
   double   tau_u;              // its window uniform
   const double * lograt;       // [MAXN][MAXN] log(i/j): the Hastings ratios of GSPR (lograt_kernel)
-  int8_t * pop_nc; double * pop_t2h;      // [T][MAXPOP] sufficient statistics of every locus's density, written by the sweep
+  int8_t * pop_nc; double * pop_t2h;      // [MAXPOP][T] sufficient statistics of every locus's density, written by the sweep (population-major:
+                                          // the THETA kernels read one population's run of loci)
+  uint32_t ntasks;
   uint32_t dbg;                // timing experiments only (BPA_SMP_DBG): 1 skip the node updates, 2 skip the density, 4 skip the proposal
   double   bfbeta;             // 0 with opt_usedata == 0 (locus.c:2581): the sampler then draws from the MSC prior
   Species  sp;
@@ -230,7 +232,7 @@ __device__ void density_prepare(TaskLDS & S, const Species & sp, uint32_t mask)
   }
 }
 // the term of population p (any lane of the locus)
-__device__ void density_term(TaskLDS & S, const Species & sp, const double * tau, int p, double * t2h_out)
+__device__ void density_term(TaskLDS & S, const Species & sp, const double * tau, int p, double * t2h_out, uint32_t t2h_stride)
 {
   const Tree & t = S.tr;
   uint32_t nodes = S.pnodes[p];
@@ -256,7 +258,7 @@ __device__ void density_term(TaskLDS & S, const Species & sp, const double * tau
   if (ncoal) c += ncoal*tau[2*MAXPOP + p];
   if (T2h) c -= T2h/(tau[MAXPOP + p]*1.0);
   S.contrib_new[p] = c;
-  if (t2h_out) t2h_out[p] = T2h;
+  if (t2h_out) t2h_out[(size_t)p*t2h_stride] = T2h;
 }
 __device__ __forceinline__ int nth_bit(uint32_t m, int j)
 {
@@ -265,11 +267,11 @@ __device__ __forceinline__ int nth_bit(uint32_t m, int j)
 }
 // lane n of the locus's np lanes: the terms of the n-th, (n+np)-th ... population of the mask
 __device__ __forceinline__ void lanes_density(TaskLDS & S, const Species & sp, const double * tau, uint32_t n, uint32_t np,
-                                              double * t2h_out = nullptr)
+                                              double * t2h_out = nullptr, uint32_t t2h_stride = 0)
 {
   const uint32_t mask = S.chain;
   const int cnt = __popc(mask);
-  for (int j = (int)n; j < cnt; j += (int)np) density_term(S, sp, tau, nth_bit(mask, j), t2h_out);
+  for (int j = (int)n; j < cnt; j += (int)np) density_term(S, sp, tau, nth_bit(mask, j), t2h_out, t2h_stride);
 }
 __device__ __forceinline__ double density_sum(const TaskLDS & S, const Species & sp)
 {
@@ -725,10 +727,10 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     {
       TaskLDS & S = s_task[ts];
       density_prepare<NT>(S, sp, (1u << sp.npop) - 1u);
-      for (int p = 0; p < sp.npop; ++p) A.pop_nc[(size_t)task*MAXPOP + p] = S.nc_new[p];
+      for (int p = 0; p < sp.npop; ++p) A.pop_nc[(size_t)p*A.ntasks + task] = S.nc_new[p];
     }
     __syncthreads();
-    if (active) lanes_density(s_task[ts], sp, s_tau, n, np, A.pop_t2h + (size_t)task*MAXPOP);
+    if (active) lanes_density(s_task[ts], sp, s_tau, n, np, A.pop_t2h + task, A.ntasks);
   }
   {
     constexpr uint32_t U = sizeof(Tree)/16;
@@ -849,7 +851,7 @@ __global__ void __launch_bounds__(1024) theta_sum_decide_kernel(const int8_t * _
     double acc = 0;
     for (uint32_t i = threadIdx.x; i < T; i += 1024)
     {
-      const int nc = pop_nc[(size_t)i*MAXPOP + p]; const double t2h = pop_t2h[(size_t)i*MAXPOP + p];
+      const int nc = pop_nc[(size_t)p*T + i]; const double t2h = pop_t2h[(size_t)p*T + i];
       acc += msc_term(nc, t2h, tnew, l2t_new) - msc_term(nc, t2h, told, l2t_old);
     }
     sh[threadIdx.x] = acc;
@@ -878,7 +880,7 @@ __global__ void __launch_bounds__(256) theta_refresh_kernel(const int8_t * __res
   if (i >= T) return;
   double logpr = 0;
   for (int p = 0; p < npop; ++p)
-    logpr += msc_term(pop_nc[(size_t)i*MAXPOP + p], pop_t2h[(size_t)i*MAXPOP + p], taus[MAXPOP + p], taus[2*MAXPOP + p]);
+    logpr += msc_term(pop_nc[(size_t)p*T + i], pop_t2h[(size_t)p*T + i], taus[MAXPOP + p], taus[2*MAXPOP + p]);
   trees[i].logpr = logpr;
 }
 
@@ -1061,7 +1063,7 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
   a.epoch = s->mix_pending ? s->epoch : 0u;
   s->mix_pending = false;
   a.bfbeta = e->usedata ? e->bfbeta : 0.0;
-  a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p; a.lograt = s->lograt.p;
+  a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p; a.lograt = s->lograt.p; a.ntasks = s->nloci;
   if (const char * dv = getenv("BPA_SMP_DBG")) a.dbg = (uint32_t)atoi(dv);
   a.taus = s->taus.p; a.tau_q = tau_q; a.tau_u = tau_u; a.sp = s->sp; a.mix_lnc = mix_lnc;
   a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2; a.mix_c = mix_c;
