@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--no-bpp-program", action="store_true",
                     help="skip timing the unmodified reference program (1 thread and many threads) on the host cores")
     ap.add_argument("--no-timing-events", action="store_true")
+    ap.add_argument("--sum-launch", action="store_true",
+                    help="produce the total of an all-loci step with a launch of its own (default: per-workgroup partial sums written by the step kernel)")
     ap.add_argument("--event-stride", type=int, default=7,
                     help="attach the kernel start/stop events to every n-th launch of the timed region "
                          "(an event pair costs ~4 us of stream time per launch; 7 is co-prime with the 13 steps "
@@ -206,7 +208,8 @@ def main():
         tstream = torch.cuda.Stream()
         torch.cuda.set_stream(tstream)
         stream = tstream.cuda_stream
-        sum_buf = torch.zeros(4, dtype=torch.float64, device="cuda")
+        sum_buf = torch.zeros(4096, dtype=torch.float64, device="cuda")     # room for the per-workgroup partial sums
+        sum_view = sum_buf[:1]
 
     eng = bpp_amd.Engine(local_rank, stream)
 
@@ -252,11 +255,22 @@ def main():
         p = bpp_amd.Plan(eng, [loci[i] for i in st.loci], st.mat_off, st.mat_pmatrix, st.mat_length,
                          st.op_off, st.ops, st.root_clv, st.root_scaler)
         if st.global_decision is not None:
-            p.enable_sum(sum_buf.data_ptr() if sum_buf is not None else None)
+            # the sum an all-loci proposal is decided on (and the ranks all-reduce): written by the step kernel as
+            # per-workgroup partial sums where the plan runs on the engine's packing (no launch of its own), else the
+            # plain total; --sum-launch forces the total as its own launch
+            if args.sum_launch:
+                p.enable_sum(sum_buf.data_ptr() if sum_buf is not None else None)
+            else:
+                n = p.enable_partial_sums(sum_buf.data_ptr() if sum_buf is not None else None,
+                                          sum_buf.numel() if sum_buf is not None else 0)
+                sum_parts.append(n)
         return p
 
+    sum_parts = []
     p_init = mkplan(init)
     plans = [[mkplan(st) for st in it] for it in iters]
+    if sum_buf is not None and sum_parts:
+        sum_view = sum_buf[:max(sum_parts)]
     # parameter installs of the tape, resident in HBM: (which, device address) per step, applied through p_init
     # (which holds every locus) right before the step's launch
     staged = [[[(w, eng.stage(v)) for w, v in st.params] for st in it] for it in iters]
@@ -306,7 +320,7 @@ def main():
                 p_init.set_params_device(w, dptr)
             seq.launch()
             if reduce_after:
-                dist.all_reduce(sum_buf)
+                dist.all_reduce(sum_view)
 
     def sync():
         if dist is not None:
@@ -342,9 +356,9 @@ def main():
         # all-loci step, all-reduced, must equal the sum over ranks of the per-locus values
         last = [p for st, p in zip(iters[-1], plans[-1]) if st.global_decision is not None][-1]
         last.launch()
-        dist.all_reduce(sum_buf)
+        dist.all_reduce(sum_view)
         torch.cuda.synchronize()
-        got = float(sum_buf[0].item())
+        got = float(sum_view.sum().item())
         want = torch.tensor([float(last.lnl().sum())], dtype=torch.float64, device="cuda")
         dist.all_reduce(want)
         allreduce_check = "ok" if abs(got - float(want.item())) <= 1e-9 * abs(got) else f"MISMATCH {got} vs {float(want.item())}"

@@ -100,6 +100,7 @@ def lib():
         "bpa_plan_lnl_device": (vp, [vp]),
         "bpa_plan_enable_sum": (i, [vp, vp]),
         "bpa_plan_get_sum": (i, [vp, dp]),
+        "bpa_plan_enable_partial_sums": (i, [vp, vp, C.POINTER(C.c_uint)]),
         "bpa_batch_evaluate": (i, [vp, C.POINTER(Batch), dp]),
         "bpa_engine_stage": (vp, [vp, vp, C.c_size_t]),
         "bpa_plan_set_params": (i, [vp, i, dp]),
@@ -145,7 +146,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_locus_get_pmatrix", "bpa_locus_set_pmatrix", "bpa_locus_get_scaler",
             "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
             "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate",
-            "bpa_plan_enable_sum", "bpa_plan_get_sum", "bpa_plans_launch",
+            "bpa_plan_enable_sum", "bpa_plan_enable_partial_sums", "bpa_plan_get_sum", "bpa_plans_launch",
             "bpa_plan_set_params", "bpa_plan_set_params_device", "bpa_engine_stage",
             "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride",
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
@@ -632,6 +633,12 @@ class Plan:
 
     def enable_sum(self, device_ptr=None):
         _chk(lib().bpa_plan_enable_sum(self.h, device_ptr))
+
+    def enable_partial_sums(self, device_ptr=None, capacity=0):
+        """the plan's sum as per-workgroup partial sums written by the step kernel itself; returns their number"""
+        n = C.c_uint(capacity)
+        _chk(lib().bpa_plan_enable_partial_sums(self.h, device_ptr, C.byref(n)))
+        return n.value
 
     def lnl_sum(self):
         v = C.c_double()

@@ -162,9 +162,10 @@ struct PlanDev
   const uint32_t * blk_mat_off; // [B2+1] fresh P-matrices of the workgroup's loci
   uint32_t         rec2_units;  // 16-byte units per slot record
   uint32_t         nblocks2;
+  double *         wg_part;     // [B2] flags bit 3: workgroup b's sum of its loci's lnL (bpa_plan_enable_partial_sums)
   unsigned long long * dbg;     // optional per-workgroup timestamps (profiling aid, normally null)
   uint32_t         nblocks;     // B (0: fused path not available)
-  uint32_t         flags;       // bit0: compute P-matrices, bit1: node updates + site terms, bit2: per-locus lnL
+  uint32_t         flags;       // bit0: compute P-matrices, bit1: node updates + site terms, bit2: per-locus lnL, bit3 (v2 kernel): + per-workgroup sums of them
   uint32_t         ntasks;
   uint32_t         npatterns;
   uint32_t         nmat;

@@ -162,6 +162,7 @@ struct bpa_plan
   DevBuf<int32_t>  root_scaler;
   DevBuf<double>   mat_length, site_term, lnl, lnl_sum, param_stage;
   double * sum_out = nullptr;         // where the per-launch sum of lnl[] goes (own buffer or caller's)
+  unsigned sum_parts = 0;             // > 0: sum_out receives that many partial sums (bpa_plan_enable_partial_sums)
   DevBuf<OpDev>    ops;
   std::vector<uint32_t> h_locus;      // host copy of task -> locus id
   double bytes_partials = 0, bytes_pmatrix = 0, flops_partials = 0;
@@ -924,6 +925,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     d.flags = (((mode & 1) && p->has_mats) ? 1u : 0u) | ((mode & 2) ? 2u : 0u) | ((mode & 4) ? 4u : 0u);
     hipEvent_t k0 = ts ? ts->ev[1] : nullptr, k1 = ts ? ts->ev[2] : nullptr;
     const dim3 grid(d.nblocks);
+    bool summed = false;                 // the step kernel delivered the plan's (partial) sums itself
 #define BPA_FUSED(BS_, RT_) hipExtLaunchKernelGGL((step_s4_fused_kernel<BS_, RT_>), grid, dim3(BS_), 0, e->stream, k0, k1, 0, d)
     if (p->fused_klane)
     {
@@ -944,6 +946,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     else if (p->jc69_v2 && !d.dbg && engine_pack(e) && p->pack_epoch == e->pack_epoch)       // (the stamps of bpa_plan_probe live in the first version)
     {
       d.lane_tab = e->d_lane_tab.p; d.slot_tab = e->d_slot_tab.p; d.blk_slot_off = e->d_blk_slot_off.p; d.nblocks2 = e->pack_blocks;
+      if ((mode & 4) && p->sum_out && p->sum_parts == e->pack_blocks) { d.flags |= 8u; d.wg_part = p->sum_out; summed = true; }
       hipExtLaunchKernelGGL((step_jc69_v2_kernel<PACK_BS>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, k0, k1, 0, d);
     }
     else if (p->fused_jc69)
@@ -975,10 +978,11 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     }
 #undef BPA_FUSED
     HIPCHK(hipGetLastError());
-    if ((mode & 4) && p->sum_out)
+    if ((mode & 4) && p->sum_out && !summed)
     {
       hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, d.lnl, d.ntasks, p->sum_out);
       HIPCHK(hipGetLastError());
+      if (p->sum_parts > 1) HIPCHK(hipMemsetAsync(p->sum_out + 1, 0, (p->sum_parts - 1)*sizeof(double), e->stream));
     }
     if (ts) ts->ev_used = 2;
     return 1;
@@ -1056,6 +1060,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
   {
     hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, d.lnl, d.ntasks, p->sum_out);
     HIPCHK(hipGetLastError());
+    if (p->sum_parts > 1) HIPCHK(hipMemsetAsync(p->sum_out + 1, 0, (p->sum_parts - 1)*sizeof(double), e->stream));
   }
   if (ts) HIPCHK(hipEventRecord(ts->ev[3], e->stream));
   return 1;
@@ -1191,9 +1196,30 @@ extern "C" int bpa_plan_enable_sum(bpa_plan_t * p, void * device_out)
 {
   std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
   if (!set_device(p->eng)) return 0;
+  p->sum_parts = 0;
   if (device_out) { p->sum_out = (double *)device_out; return 1; }
   if (!p->lnl_sum.reserve(1)) return fail("out of device memory (plan)");
   p->sum_out = p->lnl_sum.p;
+  return 1;
+}
+
+extern "C" int bpa_plan_enable_partial_sums(bpa_plan_t * p, void * device_out, unsigned * count)
+{
+  std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
+  bpa_engine * e = p->eng;
+  if (!set_device(e) || !count) return fail("bpa_plan_enable_partial_sums: null argument");
+  // one value per workgroup of the engine's packing when the plan runs on it, else the total alone
+  unsigned want = 1;
+  if (p->jc69_v2 && engine_pack(e) && p->pack_epoch == e->pack_epoch) want = e->pack_blocks;
+  if (device_out && *count < want) want = 1;
+  if (device_out) p->sum_out = (double *)device_out;
+  else
+  {
+    if (!p->lnl_sum.reserve(want)) return fail("out of device memory (plan)");
+    p->sum_out = p->lnl_sum.p;
+  }
+  p->sum_parts = want;
+  *count = want;
   return 1;
 }
 
@@ -1203,8 +1229,12 @@ extern "C" int bpa_plan_get_sum(bpa_plan_t * p, double * sum)
   bpa_engine * e = p->eng;
   if (!set_device(e)) return 0;
   if (!p->sum_out) return fail("bpa_plan_get_sum: call bpa_plan_enable_sum first");
-  HIPCHK(hipMemcpyAsync(sum, p->sum_out, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  std::vector<double> parts(std::max(1u, p->sum_parts));
+  HIPCHK(hipMemcpyAsync(parts.data(), p->sum_out, parts.size()*sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  double total = 0;
+  for (double v : parts) total += v;
+  *sum = total;
   return 1;
 }
 

@@ -2028,6 +2028,7 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
   if (have_m0) { m0 = P.mat2[e0 + lane]; m0_len = P.mat_length[e0 + lane]; }
   // phase C bookkeeping
   const bool summer = (P.flags & 4u) && lane < s1 - s0;
+  double c_lnl = 0;
   uint32_t c_np = 0, c_l0 = 0, c_task = 0xffffffffu, c_unph = 0, c_locus = 0;
   if (summer)
   {
@@ -2235,6 +2236,21 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
       if (c_unph) logl = reduce_locus(P.loci[c_locus], s_term + c_l0);
       else for (uint32_t q = 0; q < c_np; ++q) logl += s_term[c_l0 + q];
       P.lnl[c_task] = P.bfbeta*logl;
+      c_lnl = P.bfbeta*logl;
+    }
+    // ---- partial sums of the plan's total (bpa_plan_enable_partial_sums): this workgroup's loci in slot order; the
+    // consumer (a decision kernel, or the host after the all-reduce over the GPUs) adds the workgroups' values up
+    if (P.flags & 8u)
+    {
+      __shared__ double s_lnl[BS];
+      s_lnl[lane] = c_lnl;
+      __syncthreads();
+      if (lane == 0)
+      {
+        double part = 0;
+        for (uint32_t q = 0; q < s1 - s0; ++q) part += s_lnl[q];
+        P.wg_part[b] = part;
+      }
     }
   }
 }

@@ -199,6 +199,13 @@ void *       bpa_plan_lnl_device(bpa_plan_t *);
    device_out: where to write it (e.g. a buffer RCCL all-reduces), or NULL for an
    internal one read back with bpa_plan_get_sum.                                    */
 int          bpa_plan_enable_sum(bpa_plan_t *, void * device_out);
+/* The same sum delivered as partial sums by the step kernel itself, without a launch of its own (4.3 us each, 14 % of
+   a config-2 iteration): *count doubles — one per workgroup — whose total is the plan's sum; the consumer (a decision
+   kernel, or the host after ONE all-reduce of the *count doubles over the GPUs) adds them up.  device_out: where to
+   write them, with its capacity in *count on entry, or NULL for an internal buffer; on return *count is the number
+   in use (1 = the plain total, for plans that do not run on the engine's packing or when the capacity is too small). */
+int          bpa_plan_enable_partial_sums(bpa_plan_t *, void * device_out, unsigned * count);
+/* the total of the last launch (adds the partial sums on the host when there are several; synchronises) */
 int          bpa_plan_get_sum(bpa_plan_t *, double * sum);
 /* Batched substitution-parameter proposal for the plan's loci (the per-locus proposals of locus.c:2782-3419
    — base frequencies, exchangeabilities — and prop_gamma.c:52-224 — alpha, whose category rates the caller

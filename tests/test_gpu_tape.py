@@ -27,11 +27,15 @@ def test_tape_gpu_vs_oracle(engine, taxa, model, R, scaling, nloci):
     for st in steps:
         p = tape.plan_for_step(engine, loci, st)
         if st.global_decision is not None:
-            p.enable_sum()
+            # the all-loci reduction: as one total (own launch) and as the step kernel's per-workgroup partial sums
+            if len(got) % 2:
+                p.enable_sum()
+            else:
+                assert p.enable_partial_sums() >= 1
         p.launch()
         lnl = p.lnl()
         if st.global_decision is not None:
-            assert rel(p.lnl_sum(), float(np.sum(lnl))) < 1e-13       # the all-loci reduction
+            assert rel(p.lnl_sum(), float(np.sum(lnl))) < 1e-13
         got.append(lnl)
         p.close()
     check = range(nloci) if nloci <= 60 else range(0, nloci, 7)
