@@ -270,7 +270,12 @@ def main():
     p_init = mkplan(init)
     plans = [[mkplan(st) for st in it] for it in iters]
     if sum_buf is not None and sum_parts:
-        sum_view = sum_buf[:max(sum_parts)]
+        # every rank must all-reduce the same number of doubles: the largest count over the ranks (a rank's own
+        # workgroup count depends on its loci; the entries past it stay zero)
+        import torch
+        cnt = torch.tensor([max(sum_parts)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+        sum_view = sum_buf[:int(cnt.item())]
     # parameter installs of the tape, resident in HBM: (which, device address) per step, applied through p_init
     # (which holds every locus) right before the step's launch
     staged = [[[(w, eng.stage(v)) for w, v in st.params] for st in it] for it in iters]
