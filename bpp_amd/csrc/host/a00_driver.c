@@ -6,6 +6,9 @@
  * where BPP draws from a Bactrian-Laplace (legacy_rnd_symmetrical, random.c:230) — same target
  * distribution, our own random streams.
  */
+#define _POSIX_C_SOURCE 199309L     /* clock_gettime (the A00_PROF step profile) */
+#include <time.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
@@ -653,8 +656,13 @@ void a00_counters(const a00_driver_t * d, unsigned long * proposals, unsigned lo
  * back-end on libbpp_amd.so: node terms -> explicit buffer indices (what locus_update_matrices
  * / locus_update_partials read off gnode_t, locus.c:2350, 2549-2569) -> one batched launch
  * ---------------------------------------------------------------------------------------- */
+/* A00_PROF=1: where a step's wall time goes (marshalling here / bpa_batch_evaluate), printed every 130 steps */
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9*ts.tv_nsec; }
+
 int a00_backend_hip(void * vctx, const a00_step_t * s, double * lnl)
 {
+  static int prof = -1; static double t_marsh = 0, t_eval = 0, t_last = 0, t_between = 0; static unsigned calls = 0;
+  const double t0 = (prof < 0 ? (prof = getenv("A00_PROF") != NULL) : prof) ? now_s() : 0;
   a00_hip_ctx_t * c = (a00_hip_ctx_t *)vctx;
   const unsigned n = s->nloci, nbr = s->br_off[n], nnd = s->nd_off[n];
   unsigned i, j; int ok;
@@ -686,7 +694,19 @@ int a00_backend_hip(void * vctx, const a00_step_t * s, double * lnl)
   }
   b.nloci = n; b.loci = loci; b.mat_off = s->br_off; b.mat_pmatrix = mp; b.mat_length = ml;
   b.op_off = s->nd_off; b.ops = ops; b.root_clv = rc; b.root_scaler = rs;
-  ok = bpa_batch_evaluate(c->engine, &b, lnl);
+  {
+    const double t1 = prof ? now_s() : 0;
+    ok = bpa_batch_evaluate(c->engine, &b, lnl);
+    if (prof)
+    {
+      const double t2 = now_s();
+      if (t_last > 0) t_between += t0 - t_last;
+      t_marsh += t1 - t0; t_eval += t2 - t1; t_last = t2;
+      if (++calls % 130 == 0)
+        fprintf(stderr, "[a00] per step: driver %.3f ms, marshalling %.3f ms, bpa_batch_evaluate %.3f ms\n",
+                1e3*t_between/calls, 1e3*t_marsh/calls, 1e3*t_eval/calls);
+    }
+  }
   free(loci); free(mp); free(ml); free(ops); free(rc); free(rs);
   return ok;
 }
