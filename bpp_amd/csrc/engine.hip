@@ -830,6 +830,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
         prev = sl;
         maxops = std::max(maxops, b->op_off ? b->op_off[t+1] - b->op_off[t] : 0u);
       }
+      ok = ok && maxops <= 255;                      // StepRec counts a locus's updates in a byte
       if (ok)
       {
         const unsigned units = 1 + std::max(maxops, 3u);
@@ -1307,6 +1308,7 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
     maxops = std::max(maxops, b->op_off ? b->op_off[t+1] - b->op_off[t] : 0u);
     npat += l->sites;
   }
+  if (maxops > 255) return 1;                    // StepRec counts a locus's updates in a byte
   const unsigned nmat = b->mat_off ? b->mat_off[T] : 0;
   const unsigned units = 1 + std::max(maxops, 3u);
   const size_t o_recs = 0, n_recs = (size_t)e->pack_slots*units*16;
