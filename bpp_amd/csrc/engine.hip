@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <algorithm>
 #include <memory>
 #include <mutex>
@@ -607,6 +608,11 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   const unsigned T = b->nloci;
   if (!T) return fail("plan: empty batch");
   p->eng = e;
+  p->bytes_partials = p->bytes_pmatrix = p->flops_partials = 0; p->node_updates = p->pattern_updates = 0;     // (a plan object may be rebuilt)
+  p->fused_klane = p->fused_jc69 = p->jc69_v2 = false; p->fused_rt = 0;
+  static const bool prof = getenv("BPA_PLAN_PROF") != nullptr;
+  auto tprev = std::chrono::steady_clock::now();
+  auto lap = [&](const char * what) { if (!prof) return; const auto tn = std::chrono::steady_clock::now(); fprintf(stderr, "[plan] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(tn - tprev).count()); tprev = tn; };
   std::vector<uint32_t> locus(T), pat_off(T + 1, 0), mat_task;
   p->states = b->loci[0]->states;
   p->rmax = 1;
@@ -652,6 +658,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
       p->bytes_partials += Np*R*S*8 + 4*Np;            // K2
     }
   }
+  lap("validate");
   const unsigned P = pat_off[T];
   p->h_locus = locus;
   std::vector<int32_t> rs(T, BPA_SCALE_BUFFER_NONE);
@@ -674,6 +681,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   if (!p->thr_task.reserve(P) || !p->site_term.reserve(P) || !p->lnl.reserve(T))
     return fail("out of device memory (plan)");
 
+  lap("csr uploads");
   PlanDev & d = p->pd;
   d.task_locus = p->task_locus.p; d.task_pat_off = p->task_pat_off.p; d.thr_task = p->thr_task.p;
   d.mat_off = p->mat_off.p; d.mat_task = p->mat_task.p; d.mat_pmatrix = p->mat_pmatrix.p;
@@ -805,6 +813,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
           m.par = l->dev.par; m.rate_cats = l->rate_cats; m.model = l->dev.model; m.entry = i; m.pad = 0;
         }
     }
+    lap("records (host)");
     if (!upload(p->recs, recs.data(), recs.size())) return 0;
     if (!upload(p->lane_rec, lane_rec.data(), lane_rec.size())) return 0;
     task_rec[T] = (uint32_t)recs.size();
@@ -812,6 +821,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
     if (!upload(p->mat_recs, mrecs.data(), nmat)) return 0;
     d.recs = p->recs.p; d.lane_rec = p->lane_rec.p; d.task_rec = p->task_rec.p; d.mat_recs = p->mat_recs.p;
     p->fused_rt = all1 ? 1 : (all4 ? 4 : 0);
+    lap("records (upload)");
     p->fused_jc69 = all1 && all_jc && !getenv("BPA_NO_JC69_FAST");
     d.pad = p->rmax;
 
@@ -880,6 +890,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
     }
   }
 
+  lap("v2 / rest");
   hipLaunchKernelGGL(build_thr_task_kernel, dim3((P + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream,
                      p->task_pat_off.p, T, P, p->thr_task.p);
   HIPCHK(hipGetLastError());
@@ -1160,8 +1171,6 @@ extern "C" int bpa_plan_get_lnl(bpa_plan_t * p, double * lnl)
   if (nb > e->h_stage_bytes)
   {
     if (e->h_stage) (void)hipHostFree(e->h_stage);
-  if (e->h_step) (void)hipHostFree(e->h_step);
-  e->d_step.free(); e->d_step_terms.free(); e->d_step_lnl.free();
     e->h_stage = nullptr; e->h_stage_bytes = 0;
     const size_t want = std::max<size_t>(nb, 1u << 16);
     if (hipHostMalloc(&e->h_stage, want, hipHostMallocDefault) == hipSuccess) e->h_stage_bytes = want;
@@ -1415,6 +1424,9 @@ extern "C" int bpa_batch_evaluate(bpa_engine_t * e, const bpa_batch_t * b, doubl
   bool handled = false;
   if (!batch_evaluate_packed(e, b, lnl, handled)) return 0;
   if (handled) return 1;
+  // general path: a transient plan.  (Tried: ONE plan object per engine rebuilt in place so that its ~25 device buffers
+  // are allocated once — the blocking pageable uploads into buffers the previous step's kernels had just used then
+  // stalled the following launch for 17-27 ms, ten times slower overall: the one-image scheme above is the way.)
   bpa_plan * p = bpa_plan_create(e, b);
   if (!p) return 0;
   int ok = bpa_plan_launch(p) && (lnl ? bpa_plan_get_lnl(p, lnl) : bpa_engine_synchronize(e));
