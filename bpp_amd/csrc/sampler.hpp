@@ -105,6 +105,7 @@ struct Args
   const double * taus;         // device-resident species-tree parameters: [MAXPOP] tau | [MAXPOP] theta | [MAXPOP] log(2/theta)
   uint32_t tau_q;              // population of the TAU (mode 4) step
   double   tau_u;              // its window uniform
+  double * part_out;           // [blocks] an all-loci step's terms summed per workgroup (task order): what the decision kernel adds up
   const double * lograt;       // [MAXN][MAXN] log(i/j): the Hastings ratios of GSPR (lograt_kernel)
   int8_t * pop_nc; double * pop_t2h;      // [MAXPOP][T] sufficient statistics of every locus's density, written by the sweep (population-major:
                                           // the THETA kernels read one population's run of loci)
@@ -671,7 +672,8 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       // TAU without a moving gene node in this locus
       TaskLDS & S = s_task[ts];
       S.logpr_new = density_sum(S, sp);
-      A.mix_delta[task] = ((S.logpr_new - S.tr.logpr) + S.hast) + S.hast2;
+      const double dl = ((S.logpr_new - S.tr.logpr) + S.hast) + S.hast2;
+      A.mix_delta[task] = dl; S.hast = dl;
       S.tr.logpr = S.logpr_new;
     }
     else if (leader && s_task[ts].active)
@@ -695,7 +697,8 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       {
         const double dpr = S.logpr_new - S.tr.logpr;
         const double h = A.mode == 4 ? (dpr + S.hast) + S.hast2 : dpr + S.hast;
-        A.mix_delta[task] = A.mode == 3 ? 0.0 : (lnl - S.tr.lnl) + h;
+        const double dl = A.mode == 3 ? 0.0 : (lnl - S.tr.lnl) + h;
+        A.mix_delta[task] = dl; S.hast = dl;
         S.tr.lnl = lnl; S.tr.logpr = S.logpr_new;
       }
     }
@@ -718,6 +721,13 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   const long long ph_store = clock64();
 #undef SMP_PHASE
 
+  // ---- an all-loci step leaves the sum of its loci's terms (task order): 839 values for the decision kernel instead of 10 000
+  if ((A.mode == 1 || A.mode == 4) && lane == 0)
+  {
+    double part = 0;
+    for (uint32_t k = 0; k < ntask; ++k) part += s_task[k].hast;
+    A.part_out[b] = part;
+  }
   // ---- store
   if (A.mode == 0)
   {
@@ -896,7 +906,7 @@ struct bpa_sampler
   DevBuf<smp::LaneRec> lane_rec;
   DevBuf<smp::TaskRec> task_rec;
   DevBuf<smp::Tree> trees, snap;
-  DevBuf<double> mix_delta, mix_sum, taus, pop_t2h, theta_sums, lograt;
+  DevBuf<double> mix_delta, mix_sum, taus, pop_t2h, theta_sums, lograt, wg_part;
   DevBuf<int8_t> pop_nc;
   smp::Species sp{};                    // species tree (host copy; the taus below are only the start values)
   bool has_theta[smp::MAXPOP] = {};     // populations that can hold a coalescence (a00_initialize)
@@ -947,7 +957,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   (void)hipSetDevice(s->eng->device); g_cur_device = s->eng->device;
   (void)hipStreamSynchronize(s->eng->stream);
   s->blk_task_off.free(); s->lane_rec.free(); s->task_rec.free(); s->flag.free();
-  s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free();
+  s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free(); s->wg_part.free();
   delete s;
 }
 
@@ -1042,7 +1052,7 @@ static int sampler_upload(bpa_sampler * s)
       !upload(s->trees, s->h_trees.data(), T) || !upload(s->snap, s->h_trees.data(), T) ||
       !upload(s->flag, zero2, 1) || !upload(s->counters, zero2, 2) || !s->mix_delta.reserve(T) || !s->mix_sum.reserve(1) ||
       !upload(s->taus, s->h_taus.data(), s->h_taus.size()) || !s->pop_t2h.reserve((size_t)T*smp::MAXPOP) ||
-      !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP) || !s->lograt.reserve(smp::MAXN*smp::MAXN))
+      !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP) || !s->lograt.reserve(smp::MAXN*smp::MAXN) || !s->wg_part.reserve(s->nblocks))
     return 0;
   hipLaunchKernelGGL(smp::lograt_kernel, dim3(1), dim3(smp::MAXN*smp::MAXN), 0, e->stream, s->lograt.p);
   HIPCHK(hipGetLastError());
@@ -1063,7 +1073,7 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
   a.epoch = s->mix_pending ? s->epoch : 0u;
   s->mix_pending = false;
   a.bfbeta = e->usedata ? e->bfbeta : 0.0;
-  a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p; a.lograt = s->lograt.p; a.ntasks = s->nloci;
+  a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p; a.lograt = s->lograt.p; a.ntasks = s->nloci; a.part_out = s->wg_part.p;
   if (const char * dv = getenv("BPA_SMP_DBG")) a.dbg = (uint32_t)atoi(dv);
   a.taus = s->taus.p; a.tau_q = tau_q; a.tau_u = tau_u; a.sp = s->sp; a.mix_lnc = mix_lnc;
   a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2; a.mix_c = mix_c;
@@ -1199,7 +1209,7 @@ static int sampler_sum(bpa_sampler * s)
 {
   bpa_engine * e = s->eng;
   double * out = s->sum_ext ? s->sum_ext : s->mix_sum.p;
-  hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, out);
+  hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->wg_part.p, s->nblocks, out);
   HIPCHK(hipGetLastError());
   if (s->allreduce && !s->allreduce(s->allreduce_ctx, out, 1u, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
   return 1;
@@ -1211,7 +1221,7 @@ static int sampler_decide(bpa_sampler * s, double uacc, int tau_q, int theta_p, 
   bpa_engine * e = s->eng;
   s->epoch++;
   if (!s->allreduce)
-    hipLaunchKernelGGL(smp::sum_decide_kernel, dim3(1), dim3(1024), 0, e->stream, s->mix_delta.p, s->nloci, uacc, s->epoch,
+    hipLaunchKernelGGL(smp::sum_decide_kernel, dim3(1), dim3(1024), 0, e->stream, s->wg_part.p, s->nblocks, uacc, s->epoch,
                        s->flag.p, s->counters.p, s->taus.p, s->sp, tau_q, theta_p, win_u, mix_c, mix_lnc);
   else
   {
