@@ -917,6 +917,9 @@ struct bpa_sampler
   std::vector<double> h_taus;
   std::vector<smp::Tree> h_trees;
   unsigned nblocks = 0, epoch = 0;
+  // diagnostic switches, read once at creation: BPA_SMP_DBG (bit mask, see Args::dbg), BPA_SMP_STEPS=g,q (proposal counts),
+  // BPA_SMP_TRACE (per-launch times on stderr), BPA_SMP_NOMIX (sweeps only)
+  uint32_t env_dbg = 0; int env_gage = -1, env_gspr = -1; bool env_trace = false, env_nomix = false;
   bool mix_pending = false;             // a mixing decision taken on the device has not been applied yet
   a00_rng_t grng = 0;
   unsigned long seed = 0, launches = 0;
@@ -946,6 +949,9 @@ extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * co
     s->maxtips = std::max(s->maxtips, l->tips);
   }
   s->h_trees.assign(nloci, smp::Tree{});
+  if (const char * dv = getenv("BPA_SMP_DBG")) s->env_dbg = (uint32_t)atoi(dv);
+  if (const char * st = getenv("BPA_SMP_STEPS")) { unsigned g = 0, q = 0; if (sscanf(st, "%u,%u", &g, &q) == 2) { s->env_gage = (int)g; s->env_gspr = (int)q; } }
+  s->env_trace = getenv("BPA_SMP_TRACE") != nullptr; s->env_nomix = getenv("BPA_SMP_NOMIX") != nullptr;
   s->sp.ft_gage = 0.004; s->sp.ft_gspr = 0.004; s->sp.ft_tau = 0.001; s->sp.ft_mix = 0.3;      // a00_create's defaults
   return s;
 }
@@ -1074,14 +1080,14 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
   s->mix_pending = false;
   a.bfbeta = e->usedata ? e->bfbeta : 0.0;
   a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p; a.lograt = s->lograt.p; a.ntasks = s->nloci; a.part_out = s->wg_part.p;
-  if (const char * dv = getenv("BPA_SMP_DBG")) a.dbg = (uint32_t)atoi(dv);
+  a.dbg = s->env_dbg;
   a.taus = s->taus.p; a.tau_q = tau_q; a.tau_u = tau_u; a.sp = s->sp; a.mix_lnc = mix_lnc;
   a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2; a.mix_c = mix_c;
-  if (const char * dbg = getenv("BPA_SMP_STEPS")) { unsigned g = 0, q = 0; if (sscanf(dbg, "%u,%u", &g, &q) == 2) { a.nsteps_gage = g; a.nsteps_gspr = q; } }
+  if (s->env_gage >= 0) { a.nsteps_gage = (uint32_t)s->env_gage; a.nsteps_gspr = (uint32_t)s->env_gspr; }
   // the unrolled node passes of the leader's code are sized by the largest tree: 4-tip loci get their own instance
   void (*kern)(const smp::Args) = s->maxtips <= 4 ? smp::sweep_kernel<4> : smp::sweep_kernel<smp::MAXTIPS>;
   const size_t lds = (size_t)2*(s->maxtips - 1)*smp::BS*4*sizeof(double);
-  if (getenv("BPA_SMP_TRACE"))
+  if (s->env_trace)
   {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     hipExtLaunchKernelGGL(kern, dim3(s->nblocks), dim3(smp::BS), lds, e->stream, e0, e1, 0, a);
@@ -1256,7 +1262,7 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
   for (unsigned it = 0; it < iterations; ++it)
   {
     if (!sampler_launch(s, 0, 1.0)) return 0;                    // GAGE + GSPR of every locus (settles a pending mix first)
-    if (getenv("BPA_SMP_NOMIX")) continue;
+    if (s->env_nomix) continue;
     if (s->sp.theta_alpha > 0)
     {
       // THETA for every population that can hold a coalescence, from the statistics the sweep just stored: the sums and
