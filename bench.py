@@ -383,7 +383,7 @@ def main():
         fused = cfg["model"] != "lg" and not klane
         bytes_per_launch = (it_bytes_partials + (it_bytes_pmatrix if fused else 0)) / launches_per_iter
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        roofline = dict(bound="hbm", kernel=(("step_jc69_kernel<256>" if os.environ.get("BPA_JC69_V1") else "step_jc69_v2_kernel<256>") if cfg["model"] == "jc69" else "step_s4_klane_kernel<256,false>" if klane else "step_s4_fused_kernel<64,4>" if cfg["model"] != "lg" else "partials_lnl_tiledk_kernel<20,3>"), achieved=round(achieved, 2),
+        roofline = dict(bound="hbm", kernel=(("step_jc69_kernel<256>" if os.environ.get("BPA_JC69_V1") else "step_jc69_v2_kernel<256>") if cfg["model"] == "jc69" else ("step_s4_klane_kernel<256,false>" if os.environ.get("BPA_KLANE_V1") else "step_s4_klane_v2_kernel<256,false>") if klane else "step_s4_fused_kernel<64,4>" if cfg["model"] != "lg" else "partials_lnl_tiledk_kernel<20,3>"), achieved=round(achieved, 2),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
                         traffic=None, avg_kernel_us=round(1e3 * kernel_ms, 3),
                         algorithmic_bytes_per_launch=round(bytes_per_launch),

@@ -98,7 +98,8 @@ struct MatRec             // one (branch, all rate categories) P-matrix update
 // that stay in L2 — one 16-byte entry per lane (pattern weight, the pattern's tip codes, position in the locus) and
 // one 64-byte entry per locus ("slot": buffer addresses, sizes) — so a step only brings 16 B per locus + 16 B per
 // node update + 8 B per fresh P-matrix from HBM, and the lane -> record hop is an index calculation.
-struct LaneStatic { uint32_t slot, wgt, tipcodes, n_np_tips; };   // slot 0xffffffff: idle lane; n | np << 9 | tips << 18
+struct LaneStatic { uint32_t slot, wgt, tipcodes, n_np_tips; };   // slot 0xffffffff: idle lane; n | np << 9 | tips << 18 | k << 23 | R << 26
+                                                                  // (a locus takes np*R lanes: lane k*np + n = pattern n, rate category k)
 struct SlotStatic
 {
   double *   clv;
@@ -106,7 +107,7 @@ struct SlotStatic
   uint32_t * scaler;
   const double * par;
   uint32_t   np, tips_n, lane0, locus;       // lane0: global lane of pattern 0
-  uint32_t   unphased_length, pad0, pad1, pad2;
+  uint32_t   unphased_length, rate_cats, model, pstride;
 };
 struct StepRec                               // 16 B, followed by the step's StepOps (16 B each)
 {

@@ -162,6 +162,7 @@ struct bpa_plan
   DevBuf<MatRec>   mat_recs;
   bool fused_jc69 = false;            // JC69, one rate category: the latency-optimised kernel
   bool jc69_v2 = false;               // ... on the compact records over the engine's packing (valid while pack_epoch is)
+  bool klane_v2 = false;              // the multi-category kernel on them
   unsigned pack_epoch = 0;
   DevBuf<uint4>    recs2;
   DevBuf<MatRec2>  mat2;
@@ -538,8 +539,8 @@ static int upload(DevBuf<T> & b, const T * src, size_t n)
   return 1;
 }
 
-// The engine's packing for step_jc69_v2_kernel: every JC69 / one-category / 4-state locus of <= 8 tips and < 256
-// patterns gets a slot (in locus order), whole loci fill workgroups of 256 lanes, and the per-lane and per-slot
+// The engine's packing for step_jc69_v2_kernel / step_s4_klane_v2_kernel: every 4-state locus of <= 8 tips and < 256
+// lanes (patterns x rate categories) gets a slot (in locus order), whole loci fill workgroups of 256 lanes, and the per-lane and per-slot
 // constants go into two device tables shared by all plans.  Rebuilt (after flush) when a locus came, went or changed
 // its tip states / weights; the epoch moves only when the slot numbering or a slot's shape did.
 constexpr unsigned PACK_BS = 256;       // measured on config 2: 128 lanes 7.6 us, 256 6.9 us, 512 7.8 us per launch
@@ -555,25 +556,28 @@ static int engine_pack(bpa_engine * e)
   unsigned used = 0;
   for (bpa_locus * l : e->loci)
   {
-    const bool ok = l->alive && l->states == 4 && l->rate_cats == 1 && l->dev.model == 0 && l->tips <= 8 && l->sites < PACK_BS &&
+    // a locus takes sites * rate_cats lanes (lane k*np + n: pattern n, category k — one category: the JC69 / generic
+    // one-category layout)
+    const bool ok = l->alive && l->states == 4 && l->rate_cats <= 8 && l->tips <= 8 && l->sites*l->rate_cats < PACK_BS &&
                     l->tips + l->clv_buffers < 256 && l->prob_matrices < 256 && l->scale_buffers < 128;
     if (!ok) continue;
-    const unsigned np = l->sites, slot = (unsigned)slots.size();
-    if (used + np > PACK_BS) { lanes.resize(blk.size()*PACK_BS, idle); blk.push_back(slot); used = 0; }
+    const unsigned np = l->sites, R = l->rate_cats, slot = (unsigned)slots.size();
+    if (used + np*R > PACK_BS) { lanes.resize(blk.size()*PACK_BS, idle); blk.push_back(slot); used = 0; }
     SlotStatic st{};
     st.clv = l->dev.clv; st.pmat = l->dev.pmat; st.scaler = l->dev.scaler; st.par = l->dev.par;
     st.np = np; st.tips_n = l->tips; st.lane0 = (uint32_t)((blk.size() - 1)*PACK_BS + used); st.locus = l->id;
-    st.unphased_length = l->dev.unphased_length;
+    st.unphased_length = l->dev.unphased_length; st.rate_cats = R; st.model = l->dev.model; st.pstride = l->dev.pstride;
     slots.push_back(st);
     slot_of[l->id] = (int32_t)slot;
-    shape.push_back(l->id); shape.push_back(np); shape.push_back(l->tips);
-    for (unsigned n = 0; n < np; ++n)
-    {
-      uint32_t codes = 0;
-      for (unsigned tip = 0; tip < l->tips; ++tip) codes |= (uint32_t)(l->tipcodes[(size_t)tip*np + n] & 15u) << (4*tip);
-      lanes.push_back(LaneStatic{slot, l->weights[n], codes, n | np << 9 | l->tips << 18});
-    }
-    used += np;
+    shape.push_back(l->id); shape.push_back(np*R); shape.push_back(l->tips);
+    for (unsigned k = 0; k < R; ++k)
+      for (unsigned n = 0; n < np; ++n)
+      {
+        uint32_t codes = 0;
+        for (unsigned tip = 0; tip < l->tips; ++tip) codes |= (uint32_t)(l->tipcodes[(size_t)tip*np + n] & 15u) << (4*tip);
+        lanes.push_back(LaneStatic{slot, l->weights[n], codes, n | np << 9 | l->tips << 18 | k << 23 | R << 26});
+      }
+    used += np*R;
   }
   lanes.resize(blk.size()*PACK_BS, idle);
   blk.push_back((uint32_t)slots.size());
@@ -609,7 +613,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   if (!T) return fail("plan: empty batch");
   p->eng = e;
   p->bytes_partials = p->bytes_pmatrix = p->flops_partials = 0; p->node_updates = p->pattern_updates = 0;     // (a plan object may be rebuilt)
-  p->fused_klane = p->fused_jc69 = p->jc69_v2 = false; p->fused_rt = 0;
+  p->fused_klane = p->fused_jc69 = p->jc69_v2 = p->klane_v2 = false; p->fused_rt = 0;
   static const bool prof = getenv("BPA_PLAN_PROF") != nullptr;
   auto tprev = std::chrono::steady_clock::now();
   auto lap = [&](const char * what) { if (!prof) return; const auto tn = std::chrono::steady_clock::now(); fprintf(stderr, "[plan] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(tn - tprev).count()); tprev = tn; };
@@ -826,8 +830,8 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
     d.pad = p->rmax;
 
     // compact records over the engine's packing (step_jc69_v2_kernel): the plan's loci must be packed and come in slot order
-    p->jc69_v2 = false;
-    if (p->fused_jc69 && !getenv("BPA_JC69_V1"))
+    p->jc69_v2 = p->klane_v2 = false;
+    if ((p->fused_jc69 && !getenv("BPA_JC69_V1")) || (p->fused_klane && !getenv("BPA_KLANE_V1")))
     {
       if (!engine_pack(e)) return 0;
       bool ok = e->pack_slots > 0;
@@ -885,7 +889,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
         if (!upload(p->recs2, r2.data(), r2.size()) || !upload(p->mat2, m2.data(), nmat) || !upload(p->blk_mat_off, bm.data(), bm.size()))
           return 0;
         d.recs2 = p->recs2.p; d.mat2 = p->mat2.p; d.blk_mat_off = p->blk_mat_off.p; d.rec2_units = units;
-        p->jc69_v2 = true; p->pack_epoch = e->pack_epoch;
+        p->jc69_v2 = p->fused_jc69; p->klane_v2 = !p->fused_jc69; p->pack_epoch = e->pack_epoch;
       }
     }
   }
@@ -951,7 +955,24 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     const dim3 grid(d.nblocks);
     bool summed = false;                 // the step kernel delivered the plan's (partial) sums itself
 #define BPA_FUSED(BS_, RT_) hipExtLaunchKernelGGL((step_s4_fused_kernel<BS_, RT_>), grid, dim3(BS_), 0, e->stream, k0, k1, 0, d)
-    if (p->fused_klane)
+    if (p->klane_v2 && engine_pack(e) && p->pack_epoch == e->pack_epoch)
+    {
+      // the multi-category kernel on the compact records: P-matrix phase as its own launch, then updates + sums
+      d.lane_tab = e->d_lane_tab.p; d.slot_tab = e->d_slot_tab.p; d.blk_slot_off = e->d_blk_slot_off.p; d.nblocks2 = e->pack_blocks;
+      const dim3 g2(e->pack_blocks);
+      if (d.flags & 1u)
+      {
+        PlanDev da = d; da.flags = 1u;
+        hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, true>), g2, dim3(PACK_BS), 0, e->stream, da);
+      }
+      d.flags &= 6u;
+      if (d.flags)
+      {
+        if ((mode & 4) && p->sum_out && p->sum_parts == e->pack_blocks) { d.flags |= 8u; d.wg_part = p->sum_out; summed = true; }
+        hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), g2, dim3(PACK_BS), 0, e->stream, k0, k1, 0, d);
+      }
+    }
+    else if (p->fused_klane)
     {
       // phase A on its own (its code is what needs the registers), then B + C; the events bracket B + C
       if (d.flags & 1u)
@@ -1250,7 +1271,7 @@ extern "C" int bpa_plan_enable_partial_sums(bpa_plan_t * p, void * device_out, u
   if (!set_device(e) || !count) return fail("bpa_plan_enable_partial_sums: null argument");
   // one value per workgroup of the engine's packing when the plan runs on it, else the total alone
   unsigned want = 1;
-  if (p->jc69_v2 && engine_pack(e) && p->pack_epoch == e->pack_epoch) want = e->pack_blocks;
+  if ((p->jc69_v2 || p->klane_v2) && engine_pack(e) && p->pack_epoch == e->pack_epoch) want = e->pack_blocks;
   if (device_out && *count < want) want = 1;
   if (device_out) p->sum_out = (double *)device_out;
   else
@@ -1304,9 +1325,11 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
   if (!flush(e) || !engine_pack(e)) return 0;
   if (!e->pack_slots || e->timing) return 1;
   const unsigned T = b->nloci;
-  // eligibility: every locus packed, in slot order
+  // eligibility: every locus packed, in slot order, and all of one kind — JC69 with one rate category (step_jc69_v2_kernel)
+  // or several categories without scalers / phase averaging (step_s4_klane_v2_kernel)
   int prev = -1;
-  unsigned maxops = 0, npat = 0;
+  unsigned maxops = 0, npat = 0, rmax = 1;
+  bool all_jc = true, all_kl = true;
   for (unsigned t = 0; t < T; ++t)
   {
     const bpa_locus * l = b->loci[t];
@@ -1316,7 +1339,12 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
     prev = sl;
     maxops = std::max(maxops, b->op_off ? b->op_off[t+1] - b->op_off[t] : 0u);
     npat += l->sites;
+    rmax = std::max(rmax, l->rate_cats);
+    all_jc = all_jc && l->rate_cats == 1 && l->dev.model == 0;
+    all_kl = all_kl && l->rate_cats > 1 && l->scale_buffers == 0 && !l->dev.unphased_length && (!b->root_scaler || b->root_scaler[t] < 0);
   }
+  static const bool no_klane = getenv("BPA_KLANE_V1") != nullptr || getenv("BPA_NO_KLANE") != nullptr;
+  if (!all_jc && (!all_kl || no_klane)) return 1;
   if (maxops > 255) return 1;                    // StepRec counts a locus's updates in a byte
   const unsigned nmat = b->mat_off ? b->mat_off[T] : 0;
   const unsigned units = 1 + std::max(maxops, 3u);
@@ -1397,8 +1425,22 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
   d.blk_mat_off = reinterpret_cast<const uint32_t *>(e->d_step.p + o_bm);
   d.rec2_units = units;
   d.lane_tab = e->d_lane_tab.p; d.slot_tab = e->d_slot_tab.p; d.blk_slot_off = e->d_blk_slot_off.p; d.nblocks2 = e->pack_blocks;
-  d.flags = (nmat ? 1u : 0u) | 2u | 4u;
-  hipLaunchKernelGGL((step_jc69_v2_kernel<PACK_BS>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, d);
+  if (all_jc)
+  {
+    d.flags = (nmat ? 1u : 0u) | 2u | 4u;
+    hipLaunchKernelGGL((step_jc69_v2_kernel<PACK_BS>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, d);
+  }
+  else
+  {
+    d.pad = rmax;
+    if (nmat)
+    {
+      d.flags = 1u;
+      hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, true>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, d);
+    }
+    d.flags = 2u | 4u;
+    hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, d);
+  }
   HIPCHK(hipGetLastError());
   handled = true;
   if (!lnl) { HIPCHK(hipStreamSynchronize(e->stream)); return 1; }

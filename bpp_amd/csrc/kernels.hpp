@@ -2072,7 +2072,7 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
   }
 
   const bool work = has_slot && hdr.task != 0xffffffffu && (P.flags & 6u);
-  const uint32_t n = ls.n_np_tips & 511u, np = (ls.n_np_tips >> 9) & 511u, tips = ls.n_np_tips >> 18;
+  const uint32_t n = ls.n_np_tips & 511u, np = (ls.n_np_tips >> 9) & 511u, tips = (ls.n_np_tips >> 18) & 31u;
   const uint32_t nops = (work && (P.flags & 2u)) ? hdr.nops : 0u;
   double inl[NPRE][4], inr[NPRE][4];          // child vectors (tips expanded / inner from HBM)
   uint32_t fwl[NPRE], fwr[NPRE];              // 0..NPRE-1: forwarded from that earlier update; 0xff: in inl/inr
@@ -2251,6 +2251,138 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
         for (uint32_t q = 0; q < s1 - s0; ++q) part += s_lnl[q];
         P.wg_part[b] = part;
       }
+    }
+  }
+}
+
+// step_s4_klane_kernel on the compact records over the engine's packing (device_types.hpp; see step_jc69_v2_kernel):
+// several rate categories, any 4-state model, no scalers, no phase averaging.  WITH_A: the P-matrix phase as its own
+// launch (its eigen / closed-form code needs twice the registers of the node updates).
+template <int BS, bool WITH_A>
+__global__ void __launch_bounds__(BS) step_s4_klane_v2_kernel(const PlanDev P)
+{
+  __shared__ double s_term[BS], s_tr[BS];
+  const uint32_t b = blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
+  if (WITH_A)
+  {
+    if (!(P.flags & 1u)) return;
+    const uint32_t e0 = P.blk_mat_off[b], e1 = P.blk_mat_off[b+1], rmax = P.pad;
+    for (uint32_t i = lane; i < (e1 - e0)*rmax; i += BS)
+    {
+      const uint32_t e = e0 + i/rmax, k = i % rmax;
+      const MatRec2 m2 = P.mat2[e];
+      const SlotStatic & M = P.slot_tab[m2.slot];
+      if (k >= M.rate_cats) continue;
+      MatRec m;
+      m.dst = M.pmat + (size_t)m2.pmatrix*M.rate_cats*M.pstride; m.par = M.par; m.rate_cats = M.rate_cats; m.model = M.model; m.entry = e; m.pad = 0;
+      pmatrix_s4_rec(m, P.mat_length, k);
+    }
+    return;
+  }
+  const uint32_t s0 = P.blk_slot_off[b], s1 = P.blk_slot_off[b+1];
+  const LaneStatic ls = P.lane_tab[gl];
+  const bool has_slot = ls.slot != 0xffffffffu;
+  const bool summer = (P.flags & 4u) && lane < s1 - s0;
+  uint32_t c_np = 0, c_l0 = 0, c_task = 0xffffffffu;
+  double c_lnl = 0;
+  if (summer)
+  {
+    const SlotStatic & C = P.slot_tab[s0 + lane];
+    c_np = C.np; c_l0 = C.lane0 - b*BS;
+    c_task = reinterpret_cast<const StepRec *>(P.recs2 + (size_t)(s0 + lane)*P.rec2_units)->task;
+  }
+  SlotStatic S{};
+  StepRec hdr{};
+  hdr.task = 0xffffffffu;
+  const uint4 * rp = P.recs2 + (size_t)(has_slot ? ls.slot : 0u)*P.rec2_units;
+  if (has_slot && (P.flags & 6u))
+  {
+    const uint4 * sp = reinterpret_cast<const uint4 *>(P.slot_tab + ls.slot);
+    uint4 * sd = reinterpret_cast<uint4 *>(&S);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sd[i] = sp[i];
+    *reinterpret_cast<uint4 *>(&hdr) = rp[0];
+  }
+  const bool work = has_slot && hdr.task != 0xffffffffu && (P.flags & 6u);
+  const uint32_t n = ls.n_np_tips & 511u, np = (ls.n_np_tips >> 9) & 511u, tips = (ls.n_np_tips >> 18) & 31u;
+  const uint32_t k = (ls.n_np_tips >> 23) & 7u, R = ls.n_np_tips >> 26;
+
+  // ---- node updates of this lane's (pattern, category) + its root term
+  double tr = 0;
+  if (work)
+  {
+    double fwd[4] = {0, 0, 0, 0};
+    uint32_t fwd_clv = 0xffffffffu;
+    auto vec_of = [&](uint32_t c, double v[4])
+    {
+      if (c == fwd_clv) { v[0] = fwd[0]; v[1] = fwd[1]; v[2] = fwd[2]; v[3] = fwd[3]; }
+      else if (c < tips) expand_code((ls.tipcodes >> (4*c)) & 15u, v);
+      else
+      {
+        const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((((size_t)(c - tips)*R) + k)*np + n)*4);
+        const double2 u = p[0], w = p[1];
+        v[0] = u.x; v[1] = u.y; v[2] = w.x; v[3] = w.y;
+      }
+    };
+    if (P.flags & 2u)
+    {
+      for (uint32_t o = 0; o < hdr.nops; ++o)
+      {
+        StepOp op;
+        *reinterpret_cast<uint4 *>(&op) = rp[1 + o];
+        double lv[4], rv[4], x[4], y[4];
+        vec_of(op.left_clv, lv);
+        vec_of(op.right_clv, rv);
+        matvec4_p(S.pmat, S.pstride, (size_t)op.left_pmatrix*R  + k, lv, x);
+        matvec4_p(S.pmat, S.pstride, (size_t)op.right_pmatrix*R + k, rv, y);
+        double2 o0, o1;
+        o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
+        double2 * dst = reinterpret_cast<double2 *>(S.clv + ((((size_t)(op.parent_clv - tips)*R) + k)*np + n)*4);
+        dst[0] = o0; dst[1] = o1;
+        fwd[0] = o0.x; fwd[1] = o0.y; fwd[2] = o1.x; fwd[3] = o1.y;
+        fwd_clv = op.parent_clv;
+      }
+    }
+    // K2 at the root (core_likelihood_avx.c:117-150): this category's frequency-weighted sum
+    const double * par = S.par;
+    double c[4];
+    vec_of(hdr.root_clv, c);
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+    const double * f = par + par_matrix(R, 4, m) + pm_freqs(4);
+    tr = dot4_pair(f[0], f[1], f[2], f[3], c);
+  }
+  s_tr[lane] = tr;
+  __syncthreads();
+  double term = 0;
+  if (work && k == 0)
+  {
+    const double * par = S.par;
+    for (uint32_t q = 0; q < R; ++q) term += s_tr[lane + q*np]*par[par_rate_weights(R) + q];
+    term = log(term)*ls.wgt;
+    P.site_term[hdr.pat_off + n] = term;
+  }
+  if (!(P.flags & 4u)) return;
+
+  // ---- per-locus sum in pattern order (the k = 0 lanes are the first np lanes of a locus)
+  s_term[lane] = term;
+  __syncthreads();
+  if (summer && c_task != 0xffffffffu)
+  {
+    double logl = 0;
+    for (uint32_t q = 0; q < c_np; ++q) logl += s_term[c_l0 + q];
+    P.lnl[c_task] = P.bfbeta*logl;
+    c_lnl = P.bfbeta*logl;
+  }
+  if (P.flags & 8u)
+  {
+    __shared__ double s_lnl[BS];
+    s_lnl[lane] = c_lnl;
+    __syncthreads();
+    if (lane == 0)
+    {
+      double part = 0;
+      for (uint32_t q = 0; q < s1 - s0; ++q) part += s_lnl[q];
+      P.wg_part[b] = part;
     }
   }
 }
