@@ -107,3 +107,40 @@ def test_subsets_orders_and_repacking():
     for p in (p_all, p_new):
         p.close()
     eng.close()
+
+
+def test_mixed_models_share_the_packing():
+    """JC69 and GTR+G4 loci interleaved in one engine: each kind's plans (whole, subsets, out of order) and the
+    one-image bpa_batch_evaluate agree with the oracle; a plan that mixes the kinds takes the general path"""
+    eng = bpp_amd.Engine(0)
+    jc = synth.make_dataset(60, 300, 4, "jc69", 1, seed=31)
+    gt = synth.make_dataset(60, 300, 8, "gtr", 4, seed=32)
+    data = [d for pair in zip(jc, gt) for d in pair]                   # jc, gtr, jc, gtr, ...
+    loci = tape.make_engine_loci(eng, data)
+
+    def oracle(d):
+        if d["model"] == "jc69":
+            return oracle_lnl(d)
+        ol = O.OracleLocus(4, 4, d["seqs"], d["weights"], model="gtr", freqs=d["freqs"], qrates=d["exch"], rates=d["rates"])
+        return ol.full_lnl(d["left"], d["right"], d["times"], d["root"])
+    want = np.array([oracle(d) for d in data])
+    jcs, gts = list(range(0, len(data), 2)), list(range(1, len(data), 2))
+    for idx in (jcs, gts, gts[::3], jcs[5:40:2], gts[::-1][:7], jcs + gts, list(range(len(data)))):
+        p = make_plan(eng, loci, data, idx)
+        n = p.enable_partial_sums()
+        p.launch()
+        got = p.lnl()
+        assert np.all(np.abs(got - want[idx]) <= 1e-12 * np.abs(want[idx])), idx[:4]
+        assert n >= 1 and rel(p.lnl_sum(), float(np.sum(got))) < 1e-13
+        p.close()
+    for idx in (gts, jcs, gts[4:50:5], list(range(len(data)))):
+        mo, mp, ml, oo, ops, root = full_step(data, idx)
+        keep = dict(loci=(C.c_void_p * len(idx))(*[loci[i].h for i in idx]), mo=api._u32(mo), mp=api._u32(mp), ml=api._f64(ml),
+                    oo=api._u32(oo), ops=np.ascontiguousarray(ops), root=api._u32(root),
+                    rs=np.full(len(root), api.SCALE_BUFFER_NONE, dtype=np.int32))
+        b = api.Batch(len(root), keep["loci"], api._up(keep["mo"]), api._up(keep["mp"]), api._dp(keep["ml"]), api._up(keep["oo"]),
+                      keep["ops"].ctypes.data_as(C.POINTER(api.Op)), api._up(keep["root"]), keep["rs"].ctypes.data_as(C.POINTER(C.c_int)))
+        out = np.zeros(len(root))
+        assert api.lib().bpa_batch_evaluate(eng.h, C.byref(b), api._dp(out)), api._err()
+        assert np.all(np.abs(out - want[idx]) <= 1e-12 * np.abs(want[idx]))
+    eng.close()
