@@ -7,7 +7,8 @@ import numpy as np
 import bpp_amd
 from bpp_amd import synth
 import hostdrv, tape
-for taxa, nloci, iters in ((4, 2000, 150), (8, 600, 60)):
+SCALE = int(os.environ.get("SOAK_SCALE", "1"))
+for taxa, nloci, iters in ((4, 2000, 150*SCALE), (8, 600, 60*SCALE)):
     eng = bpp_amd.Engine(0)
     data = synth.make_dataset(nloci, 500, taxa, "jc69", 1, seed=41)
     la, lb = tape.make_engine_loci(eng, data), tape.make_engine_loci(eng, data)
