@@ -96,7 +96,7 @@ struct MatRec             // one (branch, all rate categories) P-matrix update
 // ---- compact step records of the JC69 path (step_jc69_v2_kernel) ------------------------------------------------
 // Everything that does not change from step to step lives in two ENGINE-level tables that every plan shares and
 // that stay in L2 — one 16-byte entry per lane (pattern weight, the pattern's tip codes, position in the locus) and
-// one 64-byte entry per locus ("slot": buffer addresses, sizes) — so a step only brings 16 B per locus + 16 B per
+// one 80-byte entry per locus ("slot": buffer addresses, sizes) — so a step only brings 16 B per locus + 16 B per
 // node update + 8 B per fresh P-matrix from HBM, and the lane -> record hop is an index calculation.
 struct LaneStatic { uint32_t slot, wgt, tipcodes, n_np_tips; };   // slot 0xffffffff: idle lane; n | np << 9 | tips << 18 | k << 23 | R << 26
                                                                   // (a locus takes np*R lanes: lane k*np + n = pattern n, rate category k)
@@ -108,6 +108,8 @@ struct SlotStatic
   const double * par;
   uint32_t   np, tips_n, lane0, locus;       // lane0: global lane of pattern 0
   uint32_t   unphased_length, rate_cats, model, pstride;
+  const uint8_t * tips;                      // tip state codes [tips][np]: read by loci of more than 8 tips (their codes do not fit the lane entry)
+  uint64_t   pad;
 };
 struct StepRec                               // 16 B, followed by the step's StepOps (16 B each)
 {

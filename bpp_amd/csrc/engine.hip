@@ -539,7 +539,7 @@ static int upload(DevBuf<T> & b, const T * src, size_t n)
   return 1;
 }
 
-// The engine's packing for step_jc69_v2_kernel / step_s4_klane_v2_kernel: every 4-state locus of <= 8 tips and < 256
+// The engine's packing for step_jc69_v2_kernel / step_s4_klane_v2_kernel: every 4-state locus of < 256
 // lanes (patterns x rate categories) gets a slot (in locus order), whole loci fill workgroups of 256 lanes, and the per-lane and per-slot
 // constants go into two device tables shared by all plans.  Rebuilt (after flush) when a locus came, went or changed
 // its tip states / weights; the epoch moves only when the slot numbering or a slot's shape did.
@@ -558,7 +558,7 @@ static int engine_pack(bpa_engine * e)
   {
     // a locus takes sites * rate_cats lanes (lane k*np + n: pattern n, category k — one category: the JC69 / generic
     // one-category layout)
-    const bool ok = l->alive && l->states == 4 && l->rate_cats <= 8 && l->tips <= 8 && l->sites*l->rate_cats < PACK_BS &&
+    const bool ok = l->alive && l->states == 4 && l->rate_cats <= 8 && l->sites*l->rate_cats < PACK_BS &&
                     l->tips + l->clv_buffers < 256 && l->prob_matrices < 256 && l->scale_buffers < 128;
     if (!ok) continue;
     const unsigned np = l->sites, R = l->rate_cats, slot = (unsigned)slots.size();
@@ -566,16 +566,16 @@ static int engine_pack(bpa_engine * e)
     SlotStatic st{};
     st.clv = l->dev.clv; st.pmat = l->dev.pmat; st.scaler = l->dev.scaler; st.par = l->dev.par;
     st.np = np; st.tips_n = l->tips; st.lane0 = (uint32_t)((blk.size() - 1)*PACK_BS + used); st.locus = l->id;
-    st.unphased_length = l->dev.unphased_length; st.rate_cats = R; st.model = l->dev.model; st.pstride = l->dev.pstride;
+    st.unphased_length = l->dev.unphased_length; st.rate_cats = R; st.model = l->dev.model; st.pstride = l->dev.pstride; st.tips = l->dev.tips;
     slots.push_back(st);
     slot_of[l->id] = (int32_t)slot;
     shape.push_back(l->id); shape.push_back(np*R); shape.push_back(l->tips);
     for (unsigned k = 0; k < R; ++k)
       for (unsigned n = 0; n < np; ++n)
       {
-        uint32_t codes = 0;
-        for (unsigned tip = 0; tip < l->tips; ++tip) codes |= (uint32_t)(l->tipcodes[(size_t)tip*np + n] & 15u) << (4*tip);
-        lanes.push_back(LaneStatic{slot, l->weights[n], codes, n | np << 9 | l->tips << 18 | k << 23 | R << 26});
+        uint32_t codes = 0;                           // <= 8 tips: their codes ride in the lane entry
+        for (unsigned tip = 0; tip < l->tips && tip < 8; ++tip) codes |= (uint32_t)(l->tipcodes[(size_t)tip*np + n] & 15u) << (4*tip);
+        lanes.push_back(LaneStatic{slot, l->weights[n], codes, n | np << 9 | std::min(l->tips, 31u) << 18 | k << 23 | R << 26});
       }
     used += np*R;
   }

@@ -2014,7 +2014,7 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
   constexpr uint32_t NAB = 2*BS;
   __shared__ double s_term[BS];
   __shared__ double2 s_ab[NAB];
-  static_assert(sizeof(LaneStatic) == 16 && sizeof(SlotStatic) == 64 && sizeof(StepRec) == 16 && sizeof(StepOp) == 16 && sizeof(MatRec2) == 8, "compact records");
+  static_assert(sizeof(LaneStatic) == 16 && sizeof(SlotStatic) == 80 && sizeof(StepRec) == 16 && sizeof(StepOp) == 16 && sizeof(MatRec2) == 8, "compact records");
   const uint32_t b = blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
   const uint32_t s0 = P.blk_slot_off[b], s1 = P.blk_slot_off[b+1];
   const LaneStatic ls = P.lane_tab[gl];
@@ -2047,7 +2047,7 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
     const uint4 * sp = reinterpret_cast<const uint4 *>(P.slot_tab + ls.slot);
     uint4 * sd = reinterpret_cast<uint4 *>(&S);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sd[i] = sp[i];
+    for (int i = 0; i < (int)(sizeof(SlotStatic)/16); ++i) sd[i] = sp[i];
     *reinterpret_cast<uint4 *>(&hdr) = rp[0];
     uint4 * ds = reinterpret_cast<uint4 *>(sl);
 #pragma unroll
@@ -2072,7 +2072,7 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
   }
 
   const bool work = has_slot && hdr.task != 0xffffffffu && (P.flags & 6u);
-  const uint32_t n = ls.n_np_tips & 511u, np = (ls.n_np_tips >> 9) & 511u, tips = (ls.n_np_tips >> 18) & 31u;
+  const uint32_t n = ls.n_np_tips & 511u, np = (ls.n_np_tips >> 9) & 511u, tips = S.tips_n;      // (the lane entry's own tips field is 5 bits)
   const uint32_t nops = (work && (P.flags & 2u)) ? hdr.nops : 0u;
   double inl[NPRE][4], inr[NPRE][4];          // child vectors (tips expanded / inner from HBM)
   uint32_t fwl[NPRE], fwr[NPRE];              // 0..NPRE-1: forwarded from that earlier update; 0xff: in inl/inr
@@ -2101,7 +2101,7 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
         }
         if (fwl[i] == 0xffu)
         {
-          if (op.left_clv < tips) expand_code((ls.tipcodes >> (4*op.left_clv)) & 15u, inl[i]);
+          if (op.left_clv < tips) expand_code(tips <= 8 ? (ls.tipcodes >> (4*op.left_clv)) & 15u : (uint32_t)S.tips[(size_t)op.left_clv*np + n], inl[i]);
           else
           {
             const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((size_t)(op.left_clv - tips)*np + n)*4);
@@ -2111,7 +2111,7 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
         }
         if (fwr[i] == 0xffu)
         {
-          if (op.right_clv < tips) expand_code((ls.tipcodes >> (4*op.right_clv)) & 15u, inr[i]);
+          if (op.right_clv < tips) expand_code(tips <= 8 ? (ls.tipcodes >> (4*op.right_clv)) & 15u : (uint32_t)S.tips[(size_t)op.right_clv*np + n], inr[i]);
           else
           {
             const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((size_t)(op.right_clv - tips)*np + n)*4);
@@ -2184,7 +2184,7 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
     auto vec_of = [&](uint32_t c, double v[4])
     {
       if (c == last_clv) { v[0] = last[0]; v[1] = last[1]; v[2] = last[2]; v[3] = last[3]; }
-      else if (c < tips) expand_code((ls.tipcodes >> (4*c)) & 15u, v);
+      else if (c < tips) expand_code(tips <= 8 ? (ls.tipcodes >> (4*c)) & 15u : (uint32_t)S.tips[(size_t)c*np + n], v);
       else
       {
         const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((size_t)(c - tips)*np + n)*4);
@@ -2300,11 +2300,11 @@ __global__ void __launch_bounds__(BS) step_s4_klane_v2_kernel(const PlanDev P)
     const uint4 * sp = reinterpret_cast<const uint4 *>(P.slot_tab + ls.slot);
     uint4 * sd = reinterpret_cast<uint4 *>(&S);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sd[i] = sp[i];
+    for (int i = 0; i < (int)(sizeof(SlotStatic)/16); ++i) sd[i] = sp[i];
     *reinterpret_cast<uint4 *>(&hdr) = rp[0];
   }
   const bool work = has_slot && hdr.task != 0xffffffffu && (P.flags & 6u);
-  const uint32_t n = ls.n_np_tips & 511u, np = (ls.n_np_tips >> 9) & 511u, tips = (ls.n_np_tips >> 18) & 31u;
+  const uint32_t n = ls.n_np_tips & 511u, np = (ls.n_np_tips >> 9) & 511u, tips = S.tips_n;
   const uint32_t k = (ls.n_np_tips >> 23) & 7u, R = ls.n_np_tips >> 26;
 
   // ---- node updates of this lane's (pattern, category) + its root term
@@ -2316,7 +2316,7 @@ __global__ void __launch_bounds__(BS) step_s4_klane_v2_kernel(const PlanDev P)
     auto vec_of = [&](uint32_t c, double v[4])
     {
       if (c == fwd_clv) { v[0] = fwd[0]; v[1] = fwd[1]; v[2] = fwd[2]; v[3] = fwd[3]; }
-      else if (c < tips) expand_code((ls.tipcodes >> (4*c)) & 15u, v);
+      else if (c < tips) expand_code(tips <= 8 ? (ls.tipcodes >> (4*c)) & 15u : (uint32_t)S.tips[(size_t)c*np + n], v);
       else
       {
         const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((((size_t)(c - tips)*R) + k)*np + n)*4);
