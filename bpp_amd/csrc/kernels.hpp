@@ -1207,6 +1207,34 @@ __device__ __forceinline__ void pmatrix_eigen_row(double * __restrict__ prow, in
   }
 }
 
+// all four rows of a 4-state P(t), inference form: the four expm1 are taken once (not once per row); same products,
+// same order of additions as pmatrix_eigen_row<4>
+__device__ __forceinline__ void pmatrix_eigen_4x4(double * __restrict__ q, double t, double rate,
+                                                  const double * __restrict__ evals,
+                                                  const double * __restrict__ evecs,
+                                                  const double * __restrict__ ievecs)
+{
+  const double bl = t*rate;
+  double ex[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) ex[m] = expm1(evals[m]*bl);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+  {
+    double tmp[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) tmp[m] = ievecs[j*4 + m]*ex[m];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+    {
+      double acc = (j == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc += tmp[m]*evecs[m*4 + c];
+      q[4*j + c] = acc;
+    }
+  }
+}
+
 // K7: closed-form P(t) of K80 / F81 / HKY / T92 / TN93 / F84 (locus.c:1981-2323), state
 // order A,C,G,T, written P = I + (...)expm1(...) like the reference and evaluated in its order.
 // model = BPA_DNA_MODEL_* (1..6); f = frequencies, q = substitution parameters of the locus.
@@ -1316,9 +1344,7 @@ __device__ __forceinline__ void pmatrix_s4_entry(const PlanDev & P, const uint32
     {
       const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
       const double * pm = par + par_matrix(R, 4, m);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        pmatrix_eigen_row<4>(q + 4*j, j, t, rate, pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4), false);
+      pmatrix_eigen_4x4(q, t, rate, pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
     }
   }
   double2 * dst = reinterpret_cast<double2 *>(p);
@@ -1376,9 +1402,7 @@ __device__ __forceinline__ void pmatrix_s4_rec(const MatRec & m, const double * 
   {
     const uint32_t mi = (uint32_t)par[par_param_idx(R) + k];
     const double * pm = par + par_matrix(R, 4, mi);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      pmatrix_eigen_row<4>(q + 4*j, j, t, rate, pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4), false);
+    pmatrix_eigen_4x4(q, t, rate, pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
   }
   double2 * dst = reinterpret_cast<double2 *>(m.dst + (size_t)k*16);
 #pragma unroll
