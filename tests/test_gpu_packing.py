@@ -64,6 +64,17 @@ def test_subsets_orders_and_repacking():
         assert np.all(np.abs(got - want[idx]) <= 1e-13 * np.abs(want[idx])), idx[:5]
         assert n >= 1 and rel(p.lnl_sum(), float(np.sum(got))) < 1e-13
         p.close()
+    # partial sums into caller memory: enough room -> one value per workgroup; too little -> the plain total in slot 0
+    dev = eng.stage(np.zeros(64))
+    p = make_plan(eng, loci, data, every)
+    n = p.enable_partial_sums(dev, 64)
+    assert 1 < n <= 64
+    p.launch()
+    assert rel(p.lnl_sum(), float(np.sum(p.lnl()))) < 1e-13
+    assert p.enable_partial_sums(dev, 1) == 1
+    p.launch()
+    assert rel(p.lnl_sum(), float(np.sum(want))) < 1e-12
+    p.close()
     # a plan outlives a change of the slot numbering: new loci at the end, then one destroyed
     p_all = make_plan(eng, loci, data, every)
     p_all.launch()
