@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--no-bpp-program", action="store_true",
                     help="skip timing the unmodified reference program (1 thread and many threads) on the host cores")
     ap.add_argument("--no-timing-events", action="store_true")
+    ap.add_argument("--rccl-sums", action="store_true",
+                    help="N > 1: all-reduce the sums with RCCL (torch.distributed) instead of the one-shot p2p exchange")
     ap.add_argument("--sum-launch", action="store_true",
                     help="produce the total of an all-loci step with a launch of its own (default: per-workgroup partial sums written by the step kernel)")
     ap.add_argument("--event-stride", type=int, default=7,
@@ -276,6 +278,36 @@ def main():
         cnt = torch.tensor([max(sum_parts)], dtype=torch.int64, device="cuda")
         dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
         sum_view = sum_buf[:int(cnt.item())]
+
+    # ---- how the sums travel between the ranks: the one-shot all-reduce over xGMI peer mappings (bpa_p2p_*: one hop,
+    # one small kernel) when its start-up self-test against RCCL passes on EVERY rank, else RCCL (torch.distributed)
+    p2p = None
+    if dist is not None and not args.rccl_sums and sum_view.numel() <= 512:
+        import torch
+        ok = 1
+        try:
+            p2p = bpp_amd.P2P(eng, rank, world, 512)
+            handles = [None] * world
+            dist.all_gather_object(handles, p2p.handle)
+            p2p.connect(handles)
+            for k in range(6):
+                x = torch.arange(sum_view.numel(), dtype=torch.float64, device="cuda") * (0.5 + rank) + k + 1e-3 * rank
+                y = x.clone()
+                torch.cuda.current_stream().synchronize()
+                p2p.allreduce(x.data_ptr(), x.numel())
+                dist.all_reduce(y)
+                torch.cuda.synchronize()
+                if p2p.status() != 0 or not torch.allclose(x, y, rtol=1e-12, atol=0):
+                    ok = 0
+                    break
+        except Exception as exc:          # no peer mapping on this system: RCCL it is
+            log(f"p2p all-reduce unavailable ({exc})")
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            p2p = None
+        log("sums between ranks: " + ("one-shot p2p all-reduce (self-test against RCCL passed)" if p2p else "RCCL all-reduce"))
     # parameter installs of the tape, resident in HBM: (which, device address) per step, applied through p_init
     # (which holds every locus) right before the step's launch
     staged = [[[(w, eng.stage(v)) for w, v in st.params] for st in it] for it in iters]
@@ -325,7 +357,10 @@ def main():
                 p_init.set_params_device(w, dptr)
             seq.launch()
             if reduce_after:
-                dist.all_reduce(sum_view)
+                if p2p is not None:
+                    p2p.allreduce(sum_buf.data_ptr(), sum_view.numel())
+                else:
+                    dist.all_reduce(sum_view)
 
     def sync():
         if dist is not None:
@@ -336,20 +371,31 @@ def main():
         else:
             eng.synchronize()
 
-    for i in range(args.warmup):
-        run_iteration(i)
-    sync()
-    if not args.no_timing_events:
-        eng.enable_timing(True, stride=args.event_stride)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_iteration(args.warmup + i)
-    enqueue_s = time.perf_counter() - t0          # host time to enqueue the timed region (GPU still running)
-    sync()
-    elapsed = time.perf_counter() - t0
-    log(f"host enqueue {1e3 * enqueue_s / args.steps:.4f} ms/step of {1e3 * elapsed / args.steps:.4f} ms/step")
-    tm = eng.timing() if not args.no_timing_events else None
-    eng.enable_timing(False)
+    while True:
+        for i in range(args.warmup):
+            run_iteration(i)
+        sync()
+        if not args.no_timing_events:
+            eng.enable_timing(True, stride=args.event_stride)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            run_iteration(args.warmup + i)
+        enqueue_s = time.perf_counter() - t0          # host time to enqueue the timed region (GPU still running)
+        sync()
+        elapsed = time.perf_counter() - t0
+        log(f"host enqueue {1e3 * enqueue_s / args.steps:.4f} ms/step of {1e3 * elapsed / args.steps:.4f} ms/step")
+        tm = eng.timing() if not args.no_timing_events else None
+        eng.enable_timing(False)
+        if p2p is None:
+            break
+        # a p2p exchange that timed out on ANY rank voids the run: measure again over RCCL
+        import torch
+        bad = torch.tensor([1 if p2p.status() != 0 else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) == 0:
+            break
+        log("p2p all-reduce timed out: repeating the measurement over RCCL")
+        p2p = None
 
     allreduce_check = None
     if dist is not None:
@@ -361,7 +407,10 @@ def main():
         # all-loci step, all-reduced, must equal the sum over ranks of the per-locus values
         last = [p for st, p in zip(iters[-1], plans[-1]) if st.global_decision is not None][-1]
         last.launch()
-        dist.all_reduce(sum_view)
+        if p2p is not None:
+            p2p.allreduce(sum_buf.data_ptr(), sum_view.numel())
+        else:
+            dist.all_reduce(sum_view)
         torch.cuda.synchronize()
         got = float(sum_view.sum().item())
         want = torch.tensor([float(last.lnl().sum())], dtype=torch.float64, device="cuda")
@@ -500,11 +549,14 @@ def main():
             "reference_program_on_host": bpp_prog,
             "device_resident_sampler": sampler,
             "allreduce_check": allreduce_check,
+            "allreduce": (None if dist is None else "p2p one-shot over xGMI peer mappings (bpa_p2p_*), self-tested against RCCL at start-up" if p2p is not None else "RCCL (torch.distributed)"),
         }
     for it in plans:
         for p in it:
             p.close()
     p_init.close()
+    if p2p is not None:
+        p2p.close()
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

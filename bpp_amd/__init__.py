@@ -3,7 +3,7 @@ the update API of BPP's locus_t / gnode_t hot path.  See DESIGN.md.
 
 The product is libbpp_amd.so (C ABI: include/bpp_amd.h); this package is the
 ctypes plumbing around it and the in-tree build driver."""
-from .api import (BpaError, Engine, Locus, Plan, PlanSequence, Sampler, GNode, GTree, Op, OP_DTYPE, lib,
+from .api import (BpaError, Engine, Locus, Plan, PlanSequence, Sampler, P2P, GNode, GTree, Op, OP_DTYPE, lib,
                   locus_update_matrices, locus_update_partials, locus_root_loglikelihood,
                   locus_update_all_matrices, locus_update_all_partials,
                   compute_gamma_cats, compress_site_patterns, map_nt, map_aa,

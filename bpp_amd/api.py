@@ -101,6 +101,11 @@ def lib():
         "bpa_plan_enable_sum": (i, [vp, vp]),
         "bpa_plan_get_sum": (i, [vp, dp]),
         "bpa_plan_enable_partial_sums": (i, [vp, vp, C.POINTER(C.c_uint)]),
+        "bpa_p2p_create": (vp, [vp, i, i, u, vp]),
+        "bpa_p2p_connect": (i, [vp, vp]),
+        "bpa_p2p_allreduce": (i, [vp, vp, u]),
+        "bpa_p2p_status": (i, [vp]),
+        "bpa_p2p_destroy": (None, [vp]),
         "bpa_batch_evaluate": (i, [vp, C.POINTER(Batch), dp]),
         "bpa_engine_stage": (vp, [vp, vp, C.c_size_t]),
         "bpa_plan_set_params": (i, [vp, i, dp]),
@@ -146,7 +151,8 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_locus_get_pmatrix", "bpa_locus_set_pmatrix", "bpa_locus_get_scaler",
             "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
             "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate",
-            "bpa_plan_enable_sum", "bpa_plan_enable_partial_sums", "bpa_plan_get_sum", "bpa_plans_launch",
+            "bpa_plan_enable_sum", "bpa_plan_enable_partial_sums", "bpa_plan_get_sum",
+            "bpa_p2p_create", "bpa_p2p_connect", "bpa_p2p_allreduce", "bpa_p2p_status", "bpa_p2p_destroy", "bpa_plans_launch",
             "bpa_plan_set_params", "bpa_plan_set_params_device", "bpa_engine_stage",
             "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride",
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
@@ -585,6 +591,42 @@ class PlanSequence:
 
 
 SAMPLER_SUMS = 16            # BPA_SAMPLER_SUMS
+P2P_HANDLE_BYTES = 64        # BPA_P2P_HANDLE_BYTES
+
+
+class P2P:
+    """one-shot sum all-reduce of up to 512 doubles between the GPUs of a node (bpa_p2p_*): create on every rank,
+    exchange the `handle` bytes, connect with all of them in rank order"""
+
+    def __init__(self, engine, rank, world, max_doubles=512):
+        self.engine = engine
+        buf = C.create_string_buffer(P2P_HANDLE_BYTES)
+        self.h = lib().bpa_p2p_create(engine.h, rank, world, max_doubles, buf)
+        if not self.h:
+            raise BpaError(_err())
+        self.handle = buf.raw
+
+    def connect(self, handles):
+        blob = b"".join(handles)
+        _chk(lib().bpa_p2p_connect(self.h, blob))
+
+    def allreduce(self, device_ptr, n):
+        if not lib().bpa_p2p_allreduce(self.h, device_ptr, n):
+            raise BpaError(_err())
+
+    def status(self):
+        return lib().bpa_p2p_status(self.h)
+
+    def close(self):
+        if self.h:
+            lib().bpa_p2p_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Plan:

@@ -1746,3 +1746,4 @@ extern "C" int bpa_update_eigen(bpa_engine_t * e, double * eigenvecs, double * i
 
 // device-resident per-locus proposal control
 #include "sampler.hpp"
+#include "p2p.hpp"

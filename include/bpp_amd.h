@@ -287,6 +287,23 @@ void bpa_engine_set_timing_stride(bpa_engine_t *, unsigned stride);
 int  bpa_engine_timing(bpa_engine_t *, double * pmatrix_ms, double * partials_ms,
                        double * reduce_ms, unsigned long * launches);
 
+/* ---- several GPUs of one node: one-shot sum all-reduce of a few hundred doubles over xGMI peer mappings -----------
+   The only exchange of a sharded run is the sum an all-loci proposal is decided on (SURVEY.md section 8e;
+   threads.c:544-591), a few times per MCMC iteration and on the critical path.  Every rank stores its values into a
+   mailbox of every rank (fine-grained device memory shared through hipIpc handles), raises a flag, waits for all flags
+   in its own mailbox and adds the vectors up in rank order: one hop instead of a ring's 2(N-1), the same bits on every
+   rank.  Set-up: every rank creates its end, the BPA_P2P_HANDLE_BYTES-byte handles are exchanged by the caller
+   (any side channel: MPI, torch.distributed.all_gather_object) and passed, in rank order, to bpa_p2p_connect.
+   bpa_p2p_allreduce enqueues on the engine's stream; waits inside it are bounded — bpa_p2p_status() (synchronises)
+   returns 0 when every exchange so far completed, 1 after a time-out (the object is then unusable: use RCCL).       */
+#define BPA_P2P_HANDLE_BYTES 64
+typedef struct bpa_p2p bpa_p2p_t;
+bpa_p2p_t *  bpa_p2p_create(bpa_engine_t *, int rank, int world, unsigned max_doubles, void * handle_out);
+int          bpa_p2p_connect(bpa_p2p_t *, const void * handles);
+int          bpa_p2p_allreduce(bpa_p2p_t *, double * device_values, unsigned n);
+int          bpa_p2p_status(bpa_p2p_t *);
+void         bpa_p2p_destroy(bpa_p2p_t *);
+
 #ifdef __cplusplus
 }
 #endif
