@@ -20,6 +20,9 @@ __global__ void __launch_bounds__(512) allreduce_kernel(double * data, unsigned 
                                                         unsigned char * mine, int rank, int world, unsigned long long seq,
                                                         size_t slot_bytes, int * err, unsigned long long spin_limit)
 {
+  // after a time-out the exchange is void on this rank: later calls return at once (the peers time out once, too),
+  // so a broken link costs seconds, not seconds per step
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
   const unsigned tid = threadIdx.x, par = (unsigned)(seq & 1ull);
   const size_t my_slot = ((size_t)par*world + rank)*slot_bytes;          // this rank's slot inside every mailbox
   if (tid < n)
