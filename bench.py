@@ -538,7 +538,7 @@ def main():
             "config": {"workload": cfg["name"] + f"; {nloci} loci/GPU, {npat / nloci:.2f} patterns/locus, "
                        f"{launches_per_iter:.0f} batched proposal steps/iteration "
                        f"({it_node_updates / nloci:.1f} node updates + {launches_per_iter:.0f} lnL evals per locus)",
-                       "parallelism": f"loci sharded over {world} GPU(s), RCCL all-reduce of the lnL sum per TAU/MIX step"},
+                       "parallelism": (f"loci sharded over {world} GPU(s), " + ("one-shot p2p all-reduce over xGMI (RCCL-checked at start-up)" if p2p is not None else "RCCL all-reduce") + " of the lnL sum per TAU/MIX step" if world > 1 or dist is not None else "1 GPU")},
             "site_lnl_updates_per_s": round(site_lnl_updates_per_s),
             "node_updates_per_iteration": round(float(it_node_updates)),
             "gflops_partials": round(it_flops * args.steps / elapsed / 1e9, 2),
