@@ -467,7 +467,10 @@ def main():
             smp_sum = torch.zeros(16, dtype=torch.float64, device=f"cuda:{local_rank}")      # BPA_SAMPLER_SUMS
 
             def smp_allreduce(ptr, count, stream):
-                dist.all_reduce(smp_sum[:count])
+                if p2p is not None:
+                    p2p.allreduce(ptr, count)
+                else:
+                    dist.all_reduce(smp_sum[:count])
                 return True
             smp.set_allreduce(smp_allreduce, smp_sum.data_ptr(), rank * nloci)
         sp_parent, sp_tau, sp_theta = synth.species_tree_arrays(cfg["taxa"])
@@ -501,6 +504,8 @@ def main():
                             "to gtree_logprob); reproduces the unmodified program's posterior "
                             "(tests/test_a00_posterior.py) and the C host driver's trajectory on the reference "
                             "(tests/test_gpu_sampler.py, tests/test_gpu_host_driver.py)")
+        if p2p is not None and p2p.status() != 0:
+            sampler = dict(error="a p2p exchange timed out during the sampler section: its numbers are void (rerun with --rccl-sums)")
         smp.close()
 
     cpu = None
