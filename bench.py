@@ -344,6 +344,8 @@ def main():
             segs.append((pre, bpp_amd.PlanSequence(cur), False))
         segments.append(segs)
 
+    sum_ptr, sum_n = (sum_buf.data_ptr(), sum_view.numel()) if sum_buf is not None else (None, 0)
+
     def run_iteration(i):
         if args.host_in_loop:
             for p, installs in zip(plans[i % len(plans)], staged[i % len(plans)]):
@@ -355,12 +357,12 @@ def main():
         for pre, seq, reduce_after in segments[i % len(segments)]:
             for w, dptr in pre:
                 p_init.set_params_device(w, dptr)
+            if reduce_after and p2p is not None:
+                seq.launch_exchange(p2p, sum_ptr, sum_n)
+                continue
             seq.launch()
             if reduce_after:
-                if p2p is not None:
-                    p2p.allreduce(sum_buf.data_ptr(), sum_view.numel())
-                else:
-                    dist.all_reduce(sum_view)
+                dist.all_reduce(sum_view)
 
     def sync():
         if dist is not None:

@@ -105,6 +105,7 @@ def lib():
         "bpa_p2p_connect": (i, [vp, vp]),
         "bpa_p2p_allreduce": (i, [vp, vp, u]),
         "bpa_p2p_status": (i, [vp]),
+        "bpa_plans_launch_exchange": (i, [vp, u, vp, vp, u]),
         "bpa_p2p_destroy": (None, [vp]),
         "bpa_batch_evaluate": (i, [vp, C.POINTER(Batch), dp]),
         "bpa_engine_stage": (vp, [vp, vp, C.c_size_t]),
@@ -152,7 +153,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
             "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate",
             "bpa_plan_enable_sum", "bpa_plan_enable_partial_sums", "bpa_plan_get_sum",
-            "bpa_p2p_create", "bpa_p2p_connect", "bpa_p2p_allreduce", "bpa_p2p_status", "bpa_p2p_destroy", "bpa_plans_launch",
+            "bpa_p2p_create", "bpa_p2p_connect", "bpa_p2p_allreduce", "bpa_p2p_status", "bpa_p2p_destroy", "bpa_plans_launch_exchange", "bpa_plans_launch",
             "bpa_plan_set_params", "bpa_plan_set_params_device", "bpa_engine_stage",
             "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride",
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
@@ -587,6 +588,11 @@ class PlanSequence:
 
     def launch(self):
         if not self._fn(self.arr, len(self.plans)):
+            raise BpaError(_err())
+
+    def launch_exchange(self, p2p, device_ptr, n):
+        """launch, then the p2p all-reduce of the n doubles at device_ptr — one host call"""
+        if not lib().bpa_plans_launch_exchange(self.arr, len(self.plans), p2p.h, device_ptr, n):
             raise BpaError(_err())
 
 

@@ -125,6 +125,11 @@ extern "C" int bpa_p2p_allreduce(bpa_p2p_t * p, double * device_values, unsigned
   return 1;
 }
 
+extern "C" int bpa_plans_launch_exchange(bpa_plan_t * const * plans, unsigned count, bpa_p2p_t * p, double * device_values, unsigned n)
+{
+  return bpa_plans_launch(plans, count) && bpa_p2p_allreduce(p, device_values, n);
+}
+
 extern "C" int bpa_p2p_status(bpa_p2p_t * p)
 {
   std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);

@@ -301,6 +301,8 @@ typedef struct bpa_p2p bpa_p2p_t;
 bpa_p2p_t *  bpa_p2p_create(bpa_engine_t *, int rank, int world, unsigned max_doubles, void * handle_out);
 int          bpa_p2p_connect(bpa_p2p_t *, const void * handles);
 int          bpa_p2p_allreduce(bpa_p2p_t *, double * device_values, unsigned n);
+/* bpa_plans_launch followed by bpa_p2p_allreduce in one host call (a sharded step: launch, then exchange its sums) */
+int          bpa_plans_launch_exchange(bpa_plan_t * const * plans, unsigned count, bpa_p2p_t *, double * device_values, unsigned n);
 int          bpa_p2p_status(bpa_p2p_t *);
 void         bpa_p2p_destroy(bpa_p2p_t *);
 
