@@ -10,6 +10,17 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built library (the .so files are git-ignored): build in-tree, as __graft_entry__.build()
+    # does (hipcc cross-compiles for gfx950 without a GPU); the oracle and the in-place reference build too when possible
+    from bpp_amd import build as _build
+    if not os.path.exists(_build.OUT) or not os.path.exists(_build.HOST_OUT):
+        import shutil
+        if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+            try:
+                import __graft_entry__
+                __graft_entry__.build()
+            except Exception as exc:       # the tests that need the library will say so
+                print(f"[conftest] build failed: {exc}", file=sys.stderr)
 
 
 @pytest.fixture(scope="session")
