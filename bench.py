@@ -496,7 +496,7 @@ def main():
         sm = smp.summary()
         sampler = dict(iterations_per_s=round(args.steps / dt * nloci * world / 10000.0, 1), ms_per_iteration=round(1e3 * dt / args.steps, 4),
                        n_gpus=world,
-                       launches_per_iteration=(3 if dist is None else 4) + (2 if dist is None else 3) * (len(smp_taus) + 1),   # sweep, THETA x2, (TAU.. + MIX) x (step + sum/decide) proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
+                       launches_per_iteration=(2 if dist is None else 3) + (2 if dist is None else 3) * (len(smp_taus) + 1),   # sweep, THETA, (TAU.. + MIX) x (step + sum/decide) proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
                        acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
                        taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
                        thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],

@@ -110,6 +110,7 @@ struct Args
   int8_t * pop_nc; double * pop_t2h;      // [MAXPOP][T] sufficient statistics of every locus's density, written by the sweep (population-major:
                                           // the THETA kernels read one population's run of loci)
   uint32_t ntasks;
+  uint32_t refresh_logpr;      // the thetas moved since the trees' densities were stored: recompute them from the statistics first
   uint32_t dbg;                // timing experiments only (BPA_SMP_DBG): 1 skip the node updates, 2 skip the density, 4 skip the proposal
   double   bfbeta;             // 0 with opt_usedata == 0 (locus.c:2581): the sampler then draws from the MSC prior
   Species  sp;
@@ -457,6 +458,15 @@ __device__ bool propose_gspr(TaskLDS & S, int k, const Species & sp, const doubl
   return true;
 }
 
+// a population's term of the MSC density from its sufficient statistics (a00_msc_term of bpp_amd_host.h)
+__device__ __forceinline__ double msc_term(int ncoal, double T2h, double theta, double l2t)
+{
+  double c = 0;
+  if (ncoal) c += ncoal*l2t;
+  if (T2h) c -= T2h/(theta*1.0);
+  return c;
+}
+
 template<int NT>
 __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
 {
@@ -522,6 +532,22 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       reinterpret_cast<uint4 *>(&s_task[i/U].tr)[i % U] = reinterpret_cast<const uint4 *>(src + i/U)[i % U];
   }
   __syncthreads();
+  if (A.refresh_logpr)
+  {
+    // THETA moved thetas after these densities were stored: every tree's density again, from its statistics — one
+    // population's term per lane, added up in population order (what theta_step_all of a00_driver.c recomputes)
+    if (active)
+      for (int p = (int)n; p < sp.npop; p += (int)np)
+        s_task[ts].contrib_new[p] = msc_term(A.pop_nc[(size_t)p*A.ntasks + task], A.pop_t2h[(size_t)p*A.ntasks + task], s_tau[MAXPOP + p], s_tau[2*MAXPOP + p]);
+    __syncthreads();
+    if (leader)
+    {
+      double lp = 0;
+      for (int p = 0; p < sp.npop; ++p) lp += s_task[ts].contrib_new[p];
+      s_task[ts].tr.logpr = lp;
+    }
+    __syncthreads();
+  }
   // the proposed species tree of an all-loci step is this workgroup's copy of the taus
   double lminf = 0, lmaxf = 0, tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1;
   if (A.mode == 4)
@@ -834,13 +860,6 @@ __global__ void __launch_bounds__(1024) sum_decide_kernel(const double * __restr
 // statistics the sweep left behind (no tree is loaded), are summed in a fixed order and the population's own decision
 // is taken right here — the thetas are conditionally independent given the gene trees.  ext_sum != NULL: the sums were
 // made (and all-reduced over the ranks) beforehand, only decide.
-__device__ __forceinline__ double msc_term(int ncoal, double T2h, double theta, double l2t)
-{
-  double c = 0;
-  if (ncoal) c += ncoal*l2t;
-  if (T2h) c -= T2h/(theta*1.0);
-  return c;
-}
 struct ThetaArgs { double win_u[MAXPOP], uacc[MAXPOP]; uint32_t on[MAXPOP]; };
 
 __global__ void __launch_bounds__(1024) theta_sum_decide_kernel(const int8_t * __restrict__ pop_nc, const double * __restrict__ pop_t2h,
@@ -881,18 +900,6 @@ __global__ void __launch_bounds__(1024) theta_sum_decide_kernel(const int8_t * _
   if (accept) { taus[MAXPOP + p] = tnew; taus[2*MAXPOP + p] = l2t_new; }
 }
 
-// after the THETA decisions: every locus's density from its statistics and the current thetas (populations in order:
-// the additions of tree_logpr)
-__global__ void __launch_bounds__(256) theta_refresh_kernel(const int8_t * __restrict__ pop_nc, const double * __restrict__ pop_t2h,
-                                                            uint32_t T, const double * __restrict__ taus, int npop, Tree * trees)
-{
-  const uint32_t i = blockIdx.x*256 + threadIdx.x;
-  if (i >= T) return;
-  double logpr = 0;
-  for (int p = 0; p < npop; ++p)
-    logpr += msc_term(pop_nc[(size_t)p*T + i], pop_t2h[(size_t)p*T + i], taus[MAXPOP + p], taus[2*MAXPOP + p]);
-  trees[i].logpr = logpr;
-}
 
 } // namespace smp
 
@@ -917,6 +924,7 @@ struct bpa_sampler
   std::vector<double> h_taus;
   std::vector<smp::Tree> h_trees;
   unsigned nblocks = 0, epoch = 0;
+  bool logpr_stale = false;     // thetas moved since the trees' densities were stored (Args::refresh_logpr)
   // diagnostic switches, read once at creation: BPA_SMP_DBG (bit mask, see Args::dbg), BPA_SMP_STEPS=g,q (proposal counts),
   // BPA_SMP_TRACE (per-launch times on stderr), BPA_SMP_NOMIX (sweeps only)
   uint32_t env_dbg = 0; int env_gage = -1, env_gspr = -1; bool env_trace = false, env_nomix = false;
@@ -1079,6 +1087,7 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
   a.epoch = s->mix_pending ? s->epoch : 0u;
   s->mix_pending = false;
   a.bfbeta = e->usedata ? e->bfbeta : 0.0;
+  a.refresh_logpr = s->logpr_stale ? 1u : 0u; s->logpr_stale = false;
   a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p; a.lograt = s->lograt.p; a.ntasks = s->nloci; a.part_out = s->wg_part.p;
   a.dbg = s->env_dbg;
   a.taus = s->taus.p; a.tau_q = tau_q; a.tau_u = tau_u; a.sp = s->sp; a.mix_lnc = mix_lnc;
@@ -1286,10 +1295,9 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
         hipLaunchKernelGGL(smp::theta_sum_decide_kernel, dim3(s->sp.npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p,
                            s->nloci, s->taus.p, s->sp, ta, s->counters.p, (double *)nullptr, (const double *)s->theta_sums.p, 1);
       }
-      hipLaunchKernelGGL(smp::theta_refresh_kernel, dim3((s->nloci + 255)/256), dim3(256), 0, e->stream, s->pop_nc.p, s->pop_t2h.p,
-                         s->nloci, s->taus.p, (int)s->sp.npop, s->trees.p);
+      s->logpr_stale = true;        // the next launch (any mode) recomputes every tree's density with the new thetas
       HIPCHK(hipGetLastError());
-      s->launches += 2;
+      s->launches += 1;
     }
     for (int q = s->sp.S; q < s->sp.npop; ++q)                    // one rubber-band step per species divergence
     {
