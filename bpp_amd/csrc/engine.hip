@@ -75,6 +75,10 @@ template <typename T> struct DevBuf
     return true;
   }
   void free() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf & operator=(const DevBuf &) = delete;
+  ~DevBuf() { free(); }                 // (owners that must free with their device current do so explicitly first)
 };
 
 // ------------------------------------------------------------------ objects --
