@@ -1,7 +1,8 @@
-"""bpa_p2p_*: the one-shot all-reduce between processes (here: two ranks sharing the test box's GPU; the mailboxes travel
+"""bpa_p2p_*: the one-shot all-reduce between processes (here: two and eight ranks sharing the test box's GPU; the mailboxes travel
 as hipIpc handles exactly as between the GPUs of a node) — bit-equal to the rank-order sum, also back to back."""
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -12,15 +13,16 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_two_rank_p2p_allreduce():
+@pytest.mark.parametrize("world", [2, 8])
+def test_p2p_allreduce_between_processes(world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "p2p_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert sorted(d["rank"] for d in lines) == [0, 1]
+    lines = [json.loads(m) for m in re.findall(r"\{[^{}]*\}", r.stdout)]          # (the ranks' lines may run together)
+    assert sorted(d["rank"] for d in lines) == list(range(world))
     assert all(d["worst"] == 0.0 and d["chained_ok"] for d in lines)
-    assert [d["timed_out"] for d in sorted(lines, key=lambda d: d["rank"])] == [True, None]       # bounded wait
+    assert [d["timed_out"] for d in sorted(lines, key=lambda d: d["rank"])] == [True] + [None]*(world - 1)       # bounded wait
