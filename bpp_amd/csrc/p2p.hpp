@@ -3,7 +3,7 @@
 // The only exchange of a sharded run is the sum an all-loci proposal is decided on: 8 bytes to ~2 KB, four to five
 // times per MCMC iteration, on the critical path of every step that follows.  A ring collective pays 2(N-1) hops of
 // latency for it; here every rank stores its values straight into a mailbox of EVERY rank through xGMI peer mappings
-// (hipIpc handles of fine-grained device memory), raises a sequence flag with system-scope release, waits for the N
+// (hipIpc handles of uncached / fine-grained device memory), raises a sequence flag with system-scope release, waits for the N
 // flags in its own mailbox and adds the N vectors up in rank order — one hop, one kernel, the same bits on every rank.
 // Mailboxes are double-buffered by sequence parity: a rank can only be one exchange ahead of the slowest.  Waits are
 // bounded: a flag that does not arrive sets an error the host reads back (bench.py then repeats the run over RCCL,
@@ -82,7 +82,14 @@ extern "C" bpa_p2p_t * bpa_p2p_create(bpa_engine_t * e, int rank, int world, uns
   const size_t bytes = 2*(size_t)world*p->slot_bytes;
   int zero = 0;
   hipIpcMemHandle_t h;
-  if (hipExtMallocWithFlags((void **)&p->mail, bytes, hipDeviceMallocFinegrained) != hipSuccess || hipMemset(p->mail, 0, bytes) != hipSuccess ||
+  // uncached device memory (never held in an L2: what a kernel polls must be what a peer wrote over xGMI), else fine-grained
+  if (hipExtMallocWithFlags((void **)&p->mail, bytes, hipDeviceMallocUncached) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    p->mail = nullptr;
+    if (hipExtMallocWithFlags((void **)&p->mail, bytes, hipDeviceMallocFinegrained) != hipSuccess) p->mail = nullptr;
+  }
+  if (!p->mail || hipMemset(p->mail, 0, bytes) != hipSuccess ||
       hipDeviceSynchronize() != hipSuccess || hipIpcGetMemHandle(&h, p->mail) != hipSuccess || !upload(p->d_err, &zero, 1))
   {
     fail(std::string("bpa_p2p_create: ") + hipGetErrorString(hipGetLastError()));
