@@ -444,7 +444,7 @@ def main():
                               if args.config == "c2" else None))
 
     # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (collected by
-    # tools/profile_c2.sh on this same command): 2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md
+    # tools/profile_cfg.sh on this same command): 2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md
     # §HBM) + WRITE_SIZE, both reported in KB
     if roofline is not None and args.loci is None:
         try:
