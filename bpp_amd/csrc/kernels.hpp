@@ -2344,7 +2344,9 @@ __global__ void __launch_bounds__(BS) step_s4_klane_v2_kernel(const PlanDev P)
       else
       {
         const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((((size_t)(c - tips)*R) + k)*np + n)*4);
-        const double2 u = p[0], w = p[1];
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        const d2v uu = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p)), ww = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p) + 1);
+        double2 u, w; u.x = uu.x; u.y = uu.y; w.x = ww.x; w.y = ww.y;
         v[0] = u.x; v[1] = u.y; v[2] = w.x; v[3] = w.y;
       }
     };
@@ -2362,7 +2364,8 @@ __global__ void __launch_bounds__(BS) step_s4_klane_v2_kernel(const PlanDev P)
         double2 o0, o1;
         o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
         double2 * dst = reinterpret_cast<double2 *>(S.clv + ((((size_t)(op.parent_clv - tips)*R) + k)*np + n)*4);
-        dst[0] = o0; dst[1] = o1;
+        { typedef double d2v __attribute__((ext_vector_type(2))); d2v a0, a1; a0.x = o0.x; a0.y = o0.y; a1.x = o1.x; a1.y = o1.y;
+          __builtin_nontemporal_store(a0, reinterpret_cast<d2v *>(dst)); __builtin_nontemporal_store(a1, reinterpret_cast<d2v *>(dst) + 1); }
         fwd[0] = o0.x; fwd[1] = o0.y; fwd[2] = o1.x; fwd[3] = o1.y;
         fwd_clv = op.parent_clv;
       }

@@ -1,4 +1,4 @@
-"""bpa_p2p_*: the one-shot all-reduce between processes (here: two and eight ranks sharing the test box's GPU; the mailboxes travel
+"""bpa_p2p_*: the one-shot all-reduce between processes (here: two ranks sharing the test box's GPU; the mailboxes travel
 as hipIpc handles exactly as between the GPUs of a node) — bit-equal to the rank-order sum, also back to back."""
 import json
 import os
@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world", [2, 8])
+# (eight ranks on ONE GPU also pass — tools note in DESIGN section 7 — but depend on how the driver time-slices eight
+# processes whose kernels wait for each other; between GPUs of a node every rank has its own device)
+@pytest.mark.parametrize("world", [2])
 def test_p2p_allreduce_between_processes(world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
