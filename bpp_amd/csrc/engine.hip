@@ -100,6 +100,13 @@ struct bpa_locus
   size_t code_bytes() const { return states == 4 ? 1 : 4; }
   bool needs_eigen() const { return !(dtype == BPA_DATA_DNA && model < BPA_DNA_MODEL_GTR); }   // locus.c:2426-2454
   std::unique_ptr<bpa_plan> scratch;  // single-locus calls reuse one small plan
+  // the single-locus update API is lazy: locus_update_matrices / locus_update_partials (locus.c:2417, 2530) only
+  // queue their work here; it runs — as ONE launch together with the root term — when locus_root_loglikelihood
+  // (locus.c:2573) asks for the value, or before anything else touches the locus (flush)
+  std::vector<unsigned> pend_pm;
+  std::vector<double>   pend_len;
+  std::vector<bpa_op_t> pend_ops;
+  bool pending = false;
 };
 
 struct TimingSlot { hipEvent_t ev[4]; int ev_used = 4; };   // 2: only ev[1],ev[2] (kernel-attached)
@@ -113,6 +120,7 @@ struct bpa_engine
   std::vector<bpa_locus *> loci;
   std::vector<void *> staged;           // bpa_engine_stage allocations (freed with the engine)
   std::vector<bpa_locus *> dirty;     // loci whose host-side state must be flushed
+  std::vector<bpa_locus *> pending;   // loci with queued single-locus updates (bpa_locus::pend_*)
   DevBuf<LocusDev> d_loci;
   bool table_dirty = true;
   // pinned staging for the per-locus results a host-side accept/reject reads back after every step: a copy into
@@ -192,12 +200,13 @@ struct bpa_plan
   ~bpa_plan() { free_all(); }
 };
 
-static thread_local int g_cur_device = -1;
+// hipSetDevice on every launch costs ~1 us; hipGetDevice is a thread-local read.  (No cache of our own: the caller —
+// another engine on this thread, torch, user code — may have changed the current device since our last call.)
 static int set_device(bpa_engine * e)
 {
-  if (g_cur_device == e->device) return 1;       // hipSetDevice on every launch costs ~1 us
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur == e->device) return 1;
   HIPCHK(hipSetDevice(e->device));
-  g_cur_device = e->device;
   return 1;
 }
 
@@ -360,8 +369,14 @@ extern "C" bpa_locus_t * bpa_locus_create(bpa_engine_t * e, unsigned dtype, unsi
 
 extern "C" void bpa_locus_destroy(bpa_locus_t * l)
 {
-  // arena memory is released with the engine; the slot stays so ids remain stable
-  if (l) { l->alive = false; l->scratch.reset(); l->eng->pack_dirty = true; }
+  // arena memory is released with the engine (a bump arena: BPP creates its loci once, method.c:4137, and destroys
+  // them at exit, method.c:6506); the slot stays so ids remain stable
+  if (!l) return;
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
+  (void)set_device(l->eng);
+  (void)hipStreamSynchronize(l->eng->stream);        // the scratch plan's buffers may be in use
+  l->alive = false; l->pending = false; l->pend_pm.clear(); l->pend_len.clear(); l->pend_ops.clear();
+  l->scratch.reset(); l->eng->pack_dirty = true;
 }
 
 extern "C" int bpa_set_tip_states(bpa_locus_t * l, unsigned tip_index, const unsigned * map,
@@ -408,6 +423,7 @@ static void refresh_host_par(bpa_locus * l)
 extern "C" void bpa_set_frequencies(bpa_locus_t * l, unsigned index, const double * f)
 {
   std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
+  if (index >= l->rate_matrices) { fail("bpa_set_frequencies: rate-matrix index out of range"); return; }
   refresh_host_par(l);
   const unsigned S = l->states, R = l->rate_cats;
   std::copy(f, f + S, l->par.begin() + par_matrix(R, S, index) + pm_freqs(S));
@@ -418,6 +434,7 @@ extern "C" void bpa_set_frequencies(bpa_locus_t * l, unsigned index, const doubl
 extern "C" void bpa_set_subst_params(bpa_locus_t * l, unsigned index, const double * p)
 {
   std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
+  if (index >= l->rate_matrices) { fail("bpa_set_subst_params: rate-matrix index out of range"); return; }
   refresh_host_par(l);
   const unsigned S = l->states, R = l->rate_cats;
   std::copy(p, p + S*(S-1)/2, l->par.begin() + par_matrix(R, S, index) + pm_subst(S));
@@ -444,6 +461,7 @@ extern "C" void bpa_set_category_weights(bpa_locus_t * l, const double * w)
 extern "C" void bpa_set_param_indices(bpa_locus_t * l, const unsigned * idx)
 {
   std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
+  refresh_host_par(l);
   for (unsigned k = 0; k < l->rate_cats; ++k) l->par[par_param_idx(l->rate_cats) + k] = (double)idx[k];
   l->par_dirty = true; mark_dirty(l);
 }
@@ -479,7 +497,16 @@ extern "C" int bpa_set_diploid(bpa_locus_t * l, int unphased_length,
 }
 
 // flush host-side state of dirty loci; refresh eigensystems that were invalidated
+static int run_all_queued(bpa_engine * e);
+static int flush_state(bpa_engine * e);
 static int flush(bpa_engine * e)
+{
+  if (!flush_state(e)) return 0;
+  // queued single-locus updates (the lazy update API) run before anything else touches the buffers
+  return e->pending.empty() ? 1 : run_all_queued(e);
+}
+
+static int flush_state(bpa_engine * e)
 {
   if (!set_device(e)) return 0;
   if (e->table_dirty)
@@ -629,10 +656,14 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   const unsigned nmat = b->mat_off ? b->mat_off[T] : 0;
   const unsigned nops = b->op_off ? b->op_off[T] : 0;
   mat_task.resize(nmat);
+  std::vector<uint8_t> seen(e->loci.size(), 0);
   for (unsigned t = 0; t < T; ++t)
   {
     const bpa_locus * l = b->loci[t];
     if (!l || l->eng != e || !l->alive) return fail("plan: locus does not belong to this engine");
+    // two tasks on one locus would write the same CLV / P-matrix / scaler buffers concurrently
+    if (seen[l->id]) return fail("plan: a locus is listed twice in one batch");
+    seen[l->id] = 1;
     if (l->states != p->states) return fail("plan: all loci of one batch must have the same number of states");
     locus[t] = l->id;
     pat_off[t+1] = pat_off[t] + l->sites;
@@ -1128,8 +1159,7 @@ extern "C" void bpa_plan_destroy(bpa_plan_t * p)
 {
   if (!p) return;
   std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
-  (void)hipSetDevice(p->eng->device);
-  g_cur_device = p->eng->device;
+  (void)set_device(p->eng);
   (void)hipStreamSynchronize(p->eng->stream);
   delete p;
 }
@@ -1138,6 +1168,8 @@ extern "C" int bpa_plan_set_lengths(bpa_plan_t * p, const double * len)
 {
   std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
   if (!set_device(p->eng)) return 0;
+  for (unsigned i = 0; i < p->pd.nmat; ++i)
+    if (!(len[i] >= 0)) return fail("plan: negative branch length");   // assert(t >= 0), core_pmatrix.c:723
   HIPCHK(hipMemcpyAsync(p->mat_length.p, len, p->pd.nmat*sizeof(double), hipMemcpyHostToDevice, p->eng->stream));
   HIPCHK(hipStreamSynchronize(p->eng->stream));
   return 1;
@@ -1509,6 +1541,11 @@ extern "C" int bpa_engine_timing(bpa_engine_t * e, double * pmatrix_ms, double *
 }
 
 // ------------------------------------------------- single-locus update API ---
+// The three calls are lazy: a proposal of the reference is locus_update_matrices -> locus_update_partials ->
+// locus_root_loglikelihood on ONE locus (gtree.c:5447-5467, 7484-7566; stree.c:4727-4749), and only the last one
+// returns anything.  The first two queue their work on the locus; the third runs the whole step as one launch
+// (through the one-image path of bpa_batch_evaluate when the locus sits on the engine's packing, a scratch plan
+// otherwise) and reads the value back — one launch and one synchronisation per proposal instead of three.
 static int scratch_run(bpa_locus * l, const unsigned * pm_idx, const double * lens, unsigned nmat,
                        const bpa_op_t * ops, unsigned nops, bool lnl, unsigned root_clv, int root_scaler)
 {
@@ -1527,24 +1564,96 @@ static int scratch_run(bpa_locus * l, const unsigned * pm_idx, const double * le
   return plan_launch_mode(l->scratch.get(), mode);
 }
 
+static void queue_locus(bpa_locus * l)
+{
+  if (!l->pending) { l->pending = true; l->eng->pending.push_back(l); }
+}
+
+// run what is queued on l (and, with want_lnl, the root term at root_clv / root_scaler: *lnl receives it).
+// persite: the caller wants the per-pattern terms, which only the scratch plan keeps.
+static int run_queued(bpa_locus * l, bool want_lnl, unsigned root_clv, int root_scaler, double * lnl, bool persite)
+{
+  bpa_engine * e = l->eng;
+  // take the queue first: the paths below flush the engine, which must not see this locus as pending again
+  std::vector<unsigned> pm; std::vector<double> len; std::vector<bpa_op_t> ops;
+  pm.swap(l->pend_pm); len.swap(l->pend_len); ops.swap(l->pend_ops);
+  l->pending = false;
+  const unsigned nmat = (unsigned)pm.size(), nops = (unsigned)ops.size();
+  if (!nmat && !nops && !want_lnl) return 1;
+  if (want_lnl && !persite)
+  {
+    unsigned mat_off[2] = {0, nmat}, op_off[2] = {0, nops};
+    bpa_locus * arr[1] = {l};
+    bpa_batch_t b{};
+    b.nloci = 1; b.loci = arr;
+    b.mat_off = mat_off; b.mat_pmatrix = pm.data(); b.mat_length = len.data();
+    b.op_off = op_off; b.ops = ops.data();
+    b.root_clv = &root_clv; b.root_scaler = &root_scaler;
+    bool handled = false;
+    if (!batch_evaluate_packed(e, &b, lnl, handled)) return 0;
+    if (handled) return 1;
+  }
+  if (!scratch_run(l, pm.data(), len.data(), nmat, ops.data(), nops, want_lnl, root_clv, root_scaler)) return 0;
+  if (want_lnl && !bpa_plan_get_lnl(l->scratch.get(), lnl)) return 0;
+  return 1;
+}
+
+// everything queued on any locus of the engine (called by flush: before a plan launch, a buffer access, ...)
+static int run_all_queued(bpa_engine * e)
+{
+  while (!e->pending.empty())
+  {
+    std::vector<bpa_locus *> todo;
+    todo.swap(e->pending);
+    for (bpa_locus * l : todo)
+      if (l->pending && l->alive && !run_queued(l, false, 0, BPA_SCALE_BUFFER_NONE, nullptr, false)) return 0;
+  }
+  return 1;
+}
+
 extern "C" int bpa_locus_update_matrices(bpa_locus_t * l, const unsigned * pmatrix_indices,
                                          const double * branch_lengths, unsigned count)
 {
+  if (!l) return fail("bpa_locus_update_matrices: null locus");
   std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   if (!l->eng->usedata || !count) return 1;
-  return scratch_run(l, pmatrix_indices, branch_lengths, count, nullptr, 0, false, 0, -1);
+  for (unsigned i = 0; i < count; ++i)
+  {
+    if (pmatrix_indices[i] >= l->prob_matrices) return fail("plan: pmatrix index out of range");
+    if (!(branch_lengths[i] >= 0)) return fail("plan: negative branch length");     // assert(t >= 0), core_pmatrix.c:723
+    for (unsigned j = 0; j < i; ++j)
+      if (pmatrix_indices[j] == pmatrix_indices[i]) return fail("plan: a P-matrix buffer is listed twice for one locus");
+  }
+  // matrices after node updates: the queued step is complete, a new one starts
+  if (!l->pend_ops.empty() && !run_queued(l, false, 0, BPA_SCALE_BUFFER_NONE, nullptr, false)) return 0;
+  for (unsigned i = 0; i < count; ++i)
+  {
+    size_t j = 0;
+    while (j < l->pend_pm.size() && l->pend_pm[j] != pmatrix_indices[i]) ++j;
+    if (j < l->pend_pm.size()) l->pend_len[j] = branch_lengths[i];                 // a later call overwrites the buffer
+    else { l->pend_pm.push_back(pmatrix_indices[i]); l->pend_len.push_back(branch_lengths[i]); }
+  }
+  queue_locus(l);
+  return 1;
 }
 
 extern "C" int bpa_locus_update_partials(bpa_locus_t * l, const bpa_op_t * ops, unsigned count)
 {
+  if (!l) return fail("bpa_locus_update_partials: null locus");
   std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   if (!l->eng->usedata || !count) return 1;
-  return scratch_run(l, nullptr, nullptr, 0, ops, count, false, 0, -1);
+  for (unsigned i = 0; i < count; ++i)
+    if (!validate_op(l, ops[i])) return 0;
+  if (l->pend_ops.size() + count > 255 && !run_queued(l, false, 0, BPA_SCALE_BUFFER_NONE, nullptr, false)) return 0;
+  l->pend_ops.insert(l->pend_ops.end(), ops, ops + count);
+  queue_locus(l);
+  return 1;
 }
 
 extern "C" double bpa_locus_root_loglikelihood(bpa_locus_t * l, unsigned root_clv, int root_scaler,
                                                const unsigned * freqs_indices, double * persite_lnl)
 {
+  if (!l) { fail("bpa_locus_root_loglikelihood: null locus"); return NAN; }
   std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
   bpa_engine * e = l->eng;
   if (!e->usedata) return 0.0;
@@ -1552,9 +1661,10 @@ extern "C" double bpa_locus_root_loglikelihood(bpa_locus_t * l, unsigned root_cl
     for (unsigned k = 0; k < l->rate_cats; ++k)
       if ((double)freqs_indices[k] != l->par[par_param_idx(l->rate_cats) + k])
       { fail("bpa_locus_root_loglikelihood: freqs_indices must equal the locus's param_indices"); return NAN; }
-  if (!scratch_run(l, nullptr, nullptr, 0, nullptr, 0, true, root_clv, root_scaler)) return NAN;
+  if (root_clv < l->tips || root_clv >= l->tips + l->clv_buffers) { fail("plan: root clv index out of range"); return NAN; }
+  if (root_scaler >= (int)l->scale_buffers) { fail("plan: root scaler index out of range"); return NAN; }
   double v = NAN;
-  if (!bpa_plan_get_lnl(l->scratch.get(), &v)) return NAN;
+  if (!run_queued(l, true, root_clv, root_scaler, &v, persite_lnl != nullptr)) return NAN;
   if (persite_lnl)
   {
     if (hipMemcpy(persite_lnl, l->scratch->site_term.p, l->sites*sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)

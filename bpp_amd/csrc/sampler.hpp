@@ -968,7 +968,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
 {
   if (!s) return;
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
-  (void)hipSetDevice(s->eng->device); g_cur_device = s->eng->device;
+  (void)set_device(s->eng);
   (void)hipStreamSynchronize(s->eng->stream);
   s->blk_task_off.free(); s->lane_rec.free(); s->task_rec.free(); s->flag.free();
   s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free(); s->wg_part.free();
@@ -1068,6 +1068,20 @@ static int sampler_upload(bpa_sampler * s)
       !upload(s->taus, s->h_taus.data(), s->h_taus.size()) || !s->pop_t2h.reserve((size_t)T*smp::MAXPOP) ||
       !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP) || !s->lograt.reserve(smp::MAXN*smp::MAXN) || !s->wg_part.reserve(s->nblocks))
     return 0;
+  if (s->allreduce)
+  {
+    // Sharded run: which populations can hold a coalescence is a property of ALL loci, not of this rank's — every rank
+    // draws two numbers of the shared global stream per such population (bpa_sampler_iterate), so the mask must be the
+    // same everywhere or the ranks' streams drift apart.  OR over the ranks = sum of 0/1 through the caller's collective.
+    double m[smp::MAXPOP];
+    for (int p = 0; p < smp::MAXPOP; ++p) m[p] = s->has_theta[p] ? 1.0 : 0.0;
+    double * ar = s->sum_ext ? s->sum_ext : s->theta_sums.p;
+    HIPCHK(hipMemcpyAsync(ar, m, sizeof m, hipMemcpyHostToDevice, e->stream));
+    if (!s->allreduce(s->allreduce_ctx, ar, (unsigned)smp::MAXPOP, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
+    HIPCHK(hipMemcpyAsync(m, ar, sizeof m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int p = 0; p < smp::MAXPOP; ++p) s->has_theta[p] = m[p] > 0.5;
+  }
   hipLaunchKernelGGL(smp::lograt_kernel, dim3(1), dim3(smp::MAXN*smp::MAXN), 0, e->stream, s->lograt.p);
   HIPCHK(hipGetLastError());
   s->epoch = 0; s->mix_pending = false;

@@ -1,0 +1,185 @@
+"""Helpers for the drop-in check (test infrastructure): run the unmodified reference program (oracle/_ref/bpp) and the
+same objects linked against libbpp_amd.so through integration/locus_hip.c (oracle/_ref/bpp_hip) on one control file and
+compare what they print.  Control files are written here (options of the reference's examples with `seed = 1`,
+`finetune = 1` — v4.8.7 rejects the examples' own finetune lines, BASELINE.md — and short chains)."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "bpp")
+HIP_BIN = os.path.join(ROOT, "oracle", "_ref", "bpp_hip")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+FROGS_CTL = """seed = 1
+seqfile = frogs.txt
+Imapfile = frogs.Imap.txt
+jobname = out
+speciesdelimitation = 0
+speciestree = 0
+species&tree = 4  K  C  L  H
+                  9  7 14  2
+                 (((K, C), L), H);
+phase =   1  1  1  1
+usedata = 1
+nloci = 5
+cleandata = 0
+thetaprior = gamma 2 2000
+tauprior = gamma 2 1000
+finetune = 1
+print = 1 0 0 0
+burnin = {burnin}
+sampfreq = {sampfreq}
+nsample = {nsample}
+{extra}
+"""
+
+ANOPHELES_CTL = """seed = 1
+seqfile = loci_realign.txt
+Imapfile = Imap.txt
+jobname = out
+speciesdelimitation = 0
+species&tree = 6  G  C  R  L  A  Q
+                  2  2  2  2  2  2
+      {tree}
+usedata = 1
+nloci = 100
+cleandata = 1
+thetaprior = gamma 2 100
+tauprior = gamma 2 10
+{phiprior}
+finetune = 1
+print = 1 0 0 0
+burnin = {burnin}
+sampfreq = {sampfreq}
+nsample = {nsample}
+{extra}
+"""
+ANOPHELES_MSCI_TREE = ("((R, (Q)h[&phi=0.3,&tau-parent=no]) g, (f[&tau-parent=yes,&phi=0.3], "
+                       "(((((G, C)b)f[&tau-parent=no], A)e, h[&tau-parent=yes])d, L)c)a)o;")
+ANOPHELES_MSC_TREE = "(R, ((C, G), ((A, Q), L)));"
+
+SIM_CTL = """seed = {seed}
+seqfile = syn.txt
+Imapfile = syn.Imap.txt
+species&tree = {species}
+phase = {phase}
+loci&length = {nloci} {sites}
+clock = 1
+locusrate = 0
+model = {simmodel}
+{extra}
+"""
+SPECIES4_SIM = """4  A B C D
+                  1 1 1 1
+                  (((A #0.002, B #0.002):0.001 #0.002, C #0.002):0.002 #0.002, D #0.002):0.003 #0.002;"""
+SPECIES4 = """4  A B C D
+                  1 1 1 1
+                  (((A, B), C), D);"""
+SPECIES8_SIM = """8  A B C D E F G H
+                  1 1 1 1 1 1 1 1
+                  (((A #0.002, B #0.002):0.001 #0.002, (C #0.002, D #0.002):0.0015 #0.002):0.003 #0.002, ((E #0.002, F #0.002):0.001 #0.002, (G #0.002, H #0.002):0.002 #0.002):0.0035 #0.002):0.005 #0.002;"""
+SPECIES8 = """8  A B C D E F G H
+                  1 1 1 1 1 1 1 1
+                  (((A, B), (C, D)), ((E, F), (G, H)));"""
+
+A00_CTL = """seed = 1
+seqfile = syn.txt
+Imapfile = syn.Imap.txt
+jobname = out
+speciesdelimitation = 0
+speciestree = 0
+species&tree = {species}
+phase = {phase}
+usedata = 1
+nloci = {nloci}
+model = {model}
+{alpha}
+cleandata = 0
+thetaprior = gamma 2 1000
+tauprior = gamma 2 {taub}
+finetune = 1
+print = 1 0 0 0
+burnin = {burnin}
+sampfreq = {sampfreq}
+nsample = {nsample}
+{extra}
+"""
+
+
+def have_binaries():
+    return os.path.exists(REF_BIN) and os.path.exists(HIP_BIN)
+
+
+def run_program(binary, ctl_text, files, timeout=900, env=None):
+    """run `binary --cfile a.ctl` in a fresh directory holding `files` (name -> source path or text); returns
+    (stdout, {name: text of the output files})"""
+    d = tempfile.mkdtemp(prefix="bpphip_")
+    try:
+        for name, src in files.items():
+            if os.path.exists(src):
+                shutil.copy(src, os.path.join(d, name))
+            else:
+                open(os.path.join(d, name), "w").write(src)
+        open(os.path.join(d, "a.ctl"), "w").write(ctl_text)
+        e = dict(os.environ)
+        e.update(env or {})
+        r = subprocess.run([binary, "--cfile", "a.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           timeout=timeout, env=e, text=True)
+        outs = {}
+        for fn in os.listdir(d):
+            if fn.startswith("out."):
+                outs[fn] = open(os.path.join(d, fn), errors="replace").read()
+        return r.returncode, r.stdout, outs
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def simulate(ctl_text, timeout=600):
+    """the reference's own simulator (`bpp --simulate`): returns {file name: text} of the alignment and the Imap"""
+    d = tempfile.mkdtemp(prefix="bppsim_")
+    try:
+        open(os.path.join(d, "sim.ctl"), "w").write(ctl_text)
+        subprocess.run([REF_BIN, "--simulate", "sim.ctl"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=timeout)
+        return {fn: open(os.path.join(d, fn)).read() for fn in ("syn.txt", "syn.Imap.txt")}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def log_l0(stdout):
+    m = re.search(r"log-L0[^=]*=\s*(-?[0-9.eE+-]+)", stdout)
+    if m:
+        return float(m.group(1))
+    m = re.search(r"Initial MSC density and log-likelihood of observing data:\s*\n?\s*log-PG0\s*=\s*\S+\s+log-L0\s*=\s*(\S+)", stdout)
+    return float(m.group(1)) if m else None
+
+
+def mcmc_table(text):
+    """the sample file: header row + one row per sample; returns (header list, rows of floats)"""
+    lines = [ln for ln in text.splitlines() if ln.strip()]
+    head = lines[0].split()
+    rows = [[float(x) for x in ln.split()] for ln in lines[1:]]
+    return head, rows
+
+
+def compare_runs(ctl_text, files, timeout=900):
+    """both programs on the same control file; returns a dict with the two log-L0, the lnL columns' largest relative
+    difference, the largest relative difference over all columns, and whether mcmc.txt is byte-identical"""
+    rc0, out0, f0 = run_program(REF_BIN, ctl_text, files, timeout)
+    assert rc0 == 0, out0[-2000:]
+    rc1, out1, f1 = run_program(HIP_BIN, ctl_text, files, timeout)
+    assert rc1 == 0, out1[-2000:]
+    assert "Likelihood back-end: bpp_amd" in out1
+    m0, m1 = f0["out.mcmc.txt"], f1["out.mcmc.txt"]
+    h0, r0 = mcmc_table(m0)
+    h1, r1 = mcmc_table(m1)
+    assert h0 == h1 and len(r0) == len(r1) and len(r0) > 0
+    k = h0.index("lnL")
+    rel = lambda a, b: abs(a - b)/max(abs(a), abs(b), 1e-300)
+    lnl_err = max(rel(a[k], b[k]) for a, b in zip(r0, r1))
+    all_err = max(rel(x, y) for a, b in zip(r0, r1) for x, y in zip(a, b))
+    return dict(logl0_ref=log_l0(out0), logl0_hip=log_l0(out1), lnl_err=lnl_err, all_err=all_err,
+                identical=(m0 == m1), samples=len(r0), stdout_hip=out1)

@@ -1,0 +1,85 @@
+"""The drop-in boundary, executed: the reference's OWN program — every object of /root/reference/src unmodified,
+method.c's MCMC loop and all proposals included — linked against libbpp_amd.so through integration/locus_hip.c
+(oracle/_ref/bpp_hip, recipe in oracle/Makefile) runs A00 next to the unmodified program (oracle/_ref/bpp) on the same
+control file and seed.  Checked: log-L0 and the lnL column of mcmc.txt to 1e-10 relative (both are printed with 6 / 3
+decimals, so this is equality of what the two programs print), every other column likewise, and whether the sample
+file is byte-identical (reported; asserted where it has been observed to hold).
+
+The binaries are built in the build container (the reference sources do not travel); on the GPU box they are used as
+they come.  SURVEY.md section 8b; reference call sites method.c:4137-4300, gtree.c:5447-5467, 7484-7566,
+stree.c:4727-4749, prop_mixing.c:117-131, locus.c:2704-3295."""
+import os
+import pytest
+import bpphip as B
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not B.have_binaries(), reason="oracle/_ref/bpp{,_hip} not built (needs /root/reference)")]
+
+G = B.GOLDEN
+FROGS = {"frogs.txt": os.path.join(G, "frogs", "frogs.txt"), "frogs.Imap.txt": os.path.join(G, "frogs", "frogs.Imap.txt")}
+ANOPH = {"loci_realign.txt": os.path.join(G, "anopheles", "loci_realign.txt"), "Imap.txt": os.path.join(G, "anopheles", "Imap.txt")}
+
+
+def check(res, logl0=None):
+    assert res["logl0_ref"] is not None and res["logl0_hip"] is not None
+    assert abs(res["logl0_ref"] - res["logl0_hip"]) <= 1e-10*abs(res["logl0_ref"]), res
+    if logl0 is not None:
+        assert abs(res["logl0_hip"] - logl0) <= 1e-10*abs(logl0)
+    assert res["lnl_err"] <= 1e-10, res
+    assert res["all_err"] <= 1e-10, res
+    print(f"samples {res['samples']}  log-L0 {res['logl0_hip']}  max rel diff lnL {res['lnl_err']:.1e}  "
+          f"all columns {res['all_err']:.1e}  mcmc.txt byte-identical: {res['identical']}")
+
+
+def test_frogs_a00():
+    """BASELINE config 1: examples/frogs A00 (5 loci, unphased diploids: 42-60 tips after phasing, the diploid
+    averaging of locus.c:2586-2615), known log-L0 = -7370.742841"""
+    res = B.compare_runs(B.FROGS_CTL.format(burnin=40, sampfreq=2, nsample=80, extra=""), FROGS)
+    check(res, -7370.742841)
+    assert res["identical"]
+
+
+def test_frogs_a00_scaling():
+    """the same with `scaling = 1` (per-pattern scalers through every proposal's index toggling)"""
+    res = B.compare_runs(B.FROGS_CTL.format(burnin=10, sampfreq=2, nsample=30, extra="scaling = 1"), FROGS)
+    check(res)
+
+
+def test_anopheles_msci_a00():
+    """BASELINE config 5: examples/anopheles MSC-I A00 (100 loci x 12 sequences, cleandata = 1, the introgression
+    model of anopheles-bpp-msci.ctl: its species-tree moves are the reference's own code, its likelihood ours);
+    log-L0 = -82303.942488 with this control file in the build container)"""
+    ctl = B.ANOPHELES_CTL.format(tree=B.ANOPHELES_MSCI_TREE, phiprior="phiprior = 1 1", burnin=10, sampfreq=2, nsample=25, extra="")
+    res = B.compare_runs(ctl, ANOPH)
+    check(res)
+    assert res["identical"]
+
+
+def test_synthetic_c2_like_200_loci():
+    """a config-2-like set from the reference's own simulator: 200 loci x 1 000 sites, 4 species, JC69"""
+    files = B.simulate(B.SIM_CTL.format(seed=12345, species=B.SPECIES4_SIM, phase="0 0 0 0", nloci=200, sites=1000, simmodel=0, extra=""))
+    ctl = B.A00_CTL.format(species=B.SPECIES4, phase="0 0 0 0", nloci=200, model="jc69", alpha="", taub=500,
+                           burnin=20, sampfreq=2, nsample=60, extra="")
+    res = B.compare_runs(ctl, files)
+    check(res, -299317.884924)
+    assert res["identical"]
+
+
+def test_synthetic_gtr_gamma():
+    """a config-3-like set: 40 loci x 500 sites, 8 species, GTR+G4 — the frequency / exchangeability / alpha proposals
+    live inside locus.c (locus.c:2782-3419) and prop_gamma.c and reach the library through the same three calls"""
+    files = B.simulate(B.SIM_CTL.format(seed=7, species=B.SPECIES8_SIM, phase="0 0 0 0 0 0 0 0", nloci=40, sites=500, simmodel=7,
+                                        extra="alpha_siterate = 1 0.5 4\nqrates = 1 1 2 1 0.5 1.5 1\nbasefreqs = 1 0.3 0.2 0.2 0.3\nmodelparafile = syn.para.txt\n"))
+    ctl = B.A00_CTL.format(species=B.SPECIES8, phase="0 0 0 0 0 0 0 0", nloci=40, model="gtr", alpha="alphaprior = 1 1 4",
+                           taub=300, burnin=10, sampfreq=2, nsample=30, extra="")
+    res = B.compare_runs(ctl, files)
+    check(res)
+
+
+def test_threads_2():
+    """threads.c shards the loci over pthreads: calls for different loci arrive concurrently"""
+    files = B.simulate(B.SIM_CTL.format(seed=3, species=B.SPECIES4_SIM, phase="0 0 0 0", nloci=64, sites=400, simmodel=0, extra=""))
+    ctl = B.A00_CTL.format(species=B.SPECIES4, phase="0 0 0 0", nloci=64, model="jc69", alpha="", taub=500,
+                           burnin=10, sampfreq=2, nsample=30, extra="threads = 2 1 1")
+    res = B.compare_runs(ctl, files)
+    check(res)
