@@ -35,6 +35,14 @@ OP_DTYPE = np.dtype([("parent_clv", "<u4"), ("parent_scaler", "<i4"), ("left_clv
                      ("right_pmatrix", "<u4"), ("right_scaler", "<i4")])
 
 
+class GTreeView(C.Structure):
+    """bpa_gtree_view_t: the gnode_t fields the reference's all-nodes recursions read, one entry per node"""
+    _fields_ = [("nodes", C.c_uint), ("root", C.c_int), ("left", C.POINTER(C.c_int)), ("right", C.POINTER(C.c_int)),
+                ("parent", C.POINTER(C.c_int)), ("time", C.POINTER(C.c_double)),
+                ("clv_index", C.POINTER(C.c_uint)), ("scaler_index", C.POINTER(C.c_int)),
+                ("pmatrix_index", C.POINTER(C.c_uint)), ("rate_mui", C.c_double)]
+
+
 class Batch(C.Structure):
     _fields_ = [("nloci", C.c_uint), ("loci", C.POINTER(C.c_void_p)),
                 ("mat_off", C.POINTER(C.c_uint)), ("mat_pmatrix", C.POINTER(C.c_uint)),
@@ -80,6 +88,8 @@ def lib():
         "bpa_locus_update_matrices": (i, [vp, up, dp, u]),
         "bpa_locus_update_partials": (i, [vp, C.POINTER(Op), u]),
         "bpa_locus_root_loglikelihood": (d, [vp, u, i, up, dp]),
+        "bpa_locus_update_all_matrices": (i, [vp, C.POINTER(GTreeView), dp]),
+        "bpa_locus_update_all_partials": (i, [vp, C.POINTER(GTreeView)]),
         "bpa_core_update_pmatrix": (i, [vp, C.POINTER(dp), u, u, dp, dp, up, up, C.POINTER(dp),
                                         C.POINTER(dp), C.POINTER(dp), u, u]),
         "bpa_update_eigen": (i, [vp, dp, dp, dp, dp, dp, u]),
@@ -147,6 +157,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_set_category_rates", "bpa_set_category_weights", "bpa_set_param_indices",
             "bpa_set_diploid", "bpa_map_nt", "bpa_map_aa", "bpa_locus_update_matrices",
             "bpa_locus_update_partials", "bpa_locus_root_loglikelihood",
+            "bpa_locus_update_all_matrices", "bpa_locus_update_all_partials",
             "bpa_core_update_pmatrix", "bpa_update_eigen", "bpa_compute_gamma_cats",
             "bpa_compress_site_patterns", "bpa_locus_get_clv", "bpa_locus_set_clv",
             "bpa_locus_get_pmatrix", "bpa_locus_set_pmatrix", "bpa_locus_get_scaler",
@@ -473,14 +484,38 @@ def locus_update_partials(locus, traversal, count=None):
     locus.update_partials(np.array([node_op(nd) for nd in trav], dtype=OP_DTYPE))
 
 
+def _view(gtree):
+    """bpa_gtree_view_t of a GTree (keeps the arrays alive on the returned object)"""
+    nd = gtree.nodes
+    idx = lambda x: -1 if x is None else x.node_index
+    a = dict(left=np.array([idx(x.left) for x in nd], dtype=np.int32), right=np.array([idx(x.right) for x in nd], dtype=np.int32),
+             parent=np.array([idx(x.parent) for x in nd], dtype=np.int32), time=np.array([x.time for x in nd], dtype=np.float64),
+             clv=np.array([x.clv_index for x in nd], dtype=np.uint32), scaler=np.array([x.scaler_index for x in nd], dtype=np.int32),
+             pmat=np.array([x.pmatrix_index for x in nd], dtype=np.uint32))
+    ip = C.POINTER(C.c_int)
+    v = GTreeView(len(nd), gtree.root.node_index, a["left"].ctypes.data_as(ip), a["right"].ctypes.data_as(ip),
+                  a["parent"].ctypes.data_as(ip), _dp(a["time"]), _up(a["clv"]), a["scaler"].ctypes.data_as(ip),
+                  _up(a["pmat"]), float(gtree.rate_mui))
+    v._keep = a
+    return v
+
+
 def locus_update_all_matrices(locus, gtree):
-    """locus_update_all_matrices (locus.c:1922): every branch of the gene tree."""
-    locus_update_matrices(locus, gtree, gtree.branches())
+    """locus_update_all_matrices (locus.c:1922): every branch of the gene tree (bpa_locus_update_all_matrices);
+    node.length is stored as the reference stores it."""
+    v = _view(gtree)
+    lengths = np.zeros(len(gtree.nodes))
+    _chk(lib().bpa_locus_update_all_matrices(locus.h, C.byref(v), _dp(lengths)))
+    for nd in gtree.nodes:
+        if nd.parent is not None:
+            nd.length = float(lengths[nd.node_index])
 
 
 def locus_update_all_partials(locus, gtree):
-    """locus_update_all_partials (locus.c:2523, the post-order recursion of 2482): every inner node."""
-    locus_update_partials(locus, gtree.postorder())
+    """locus_update_all_partials (locus.c:2523, the post-order recursion of 2482): every inner node
+    (bpa_locus_update_all_partials)."""
+    v = _view(gtree)
+    _chk(lib().bpa_locus_update_all_partials(locus.h, C.byref(v)))
 
 
 def locus_root_loglikelihood(locus, root, persite=False):

@@ -1673,6 +1673,71 @@ extern "C" double bpa_locus_root_loglikelihood(bpa_locus_t * l, unsigned root_cl
   return v;
 }
 
+// locus_update_all_matrices (locus.c:1922) / locus_update_all_partials (locus.c:2523) over a flat view of the gene tree
+static int check_view(const bpa_locus * l, const bpa_gtree_view_t * g)
+{
+  if (!g || !g->left || !g->right || !g->parent || !g->clv_index || !g->pmatrix_index || !g->scaler_index)
+    return fail("gene-tree view: null array");
+  if (g->nodes != 2*l->tips - 1) return fail("gene-tree view: node count must be 2*tips - 1");
+  if (g->root < 0 || (unsigned)g->root >= g->nodes || g->left[g->root] < 0) return fail("gene-tree view: bad root");
+  for (unsigned i = 0; i < g->nodes; ++i)
+  {
+    const int a = g->left[i], b = g->right[i];
+    if ((a < 0) != (b < 0)) return fail("gene-tree view: a node has one child");
+    if (a >= (int)g->nodes || b >= (int)g->nodes || g->parent[i] >= (int)g->nodes) return fail("gene-tree view: node index out of range");
+    if (a >= 0 && (g->parent[a] != (int)i || g->parent[b] != (int)i)) return fail("gene-tree view: parent / child fields disagree");
+  }
+  return 1;
+}
+
+extern "C" int bpa_locus_update_all_matrices(bpa_locus_t * l, const bpa_gtree_view_t * g, double * lengths_out)
+{
+  if (!l) return fail("bpa_locus_update_all_matrices: null locus");
+  if (!g || !g->time) return fail("gene-tree view: null array");
+  if (!check_view(l, g)) return 0;
+  std::vector<unsigned> idx; std::vector<double> len; std::vector<int> stack;
+  // pre-order from root->left, then root->right (locus_update_all_matrices_jc69, locus.c:1905-1919)
+  stack.push_back(g->right[g->root]); stack.push_back(g->left[g->root]);
+  while (!stack.empty())
+  {
+    const int x = stack.back(); stack.pop_back();
+    if (idx.size() >= g->nodes) return fail("gene-tree view: not a tree");
+    const double t = (g->time[g->parent[x]] - g->time[x])*g->rate_mui;           // locus.c:1826
+    idx.push_back(g->pmatrix_index[x]); len.push_back(t);
+    if (lengths_out) lengths_out[x] = t;
+    if (g->left[x] >= 0) { stack.push_back(g->right[x]); stack.push_back(g->left[x]); }
+  }
+  return bpa_locus_update_matrices(l, idx.data(), len.data(), (unsigned)idx.size());
+}
+
+extern "C" int bpa_locus_update_all_partials(bpa_locus_t * l, const bpa_gtree_view_t * g)
+{
+  if (!l) return fail("bpa_locus_update_all_partials: null locus");
+  if (!check_view(l, g)) return 0;
+  // post-order: left subtree, right subtree, node (locus_update_all_partials_recursive, locus.c:2482-2521)
+  std::vector<bpa_op_t> ops;
+  std::vector<std::pair<int, int>> stack{{g->root, 0}};
+  while (!stack.empty())
+  {
+    const int x = stack.back().first, st = stack.back().second;
+    stack.pop_back();
+    if (g->left[x] < 0) continue;
+    if (st == 0)
+    {
+      if (stack.size() > 4*(size_t)g->nodes) return fail("gene-tree view: not a tree");
+      stack.push_back({x, 1}); stack.push_back({g->right[x], 0}); stack.push_back({g->left[x], 0});
+      continue;
+    }
+    const int a = g->left[x], b = g->right[x];
+    bpa_op_t o;
+    o.parent_clv = g->clv_index[x]; o.parent_scaler = g->scaler_index[x];
+    o.left_clv = g->clv_index[a];   o.left_pmatrix = g->pmatrix_index[a];  o.left_scaler = g->scaler_index[a];
+    o.right_clv = g->clv_index[b];  o.right_pmatrix = g->pmatrix_index[b]; o.right_scaler = g->scaler_index[b];
+    ops.push_back(o);
+  }
+  return bpa_locus_update_partials(l, ops.data(), (unsigned)ops.size());
+}
+
 // ---------------------------------------------- buffer access (ref. layouts) ---
 static int sync_for_access(bpa_locus * l)
 {

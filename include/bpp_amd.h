@@ -128,6 +128,35 @@ int  bpa_locus_update_partials(bpa_locus_t *, const bpa_op_t * ops, unsigned cou
 double bpa_locus_root_loglikelihood(bpa_locus_t *, unsigned root_clv, int root_scaler,
                                     const unsigned * freqs_indices, double * persite_lnl);
 
+/* The lazy contract of the three calls above: locus_update_matrices / locus_update_partials only queue their work on
+   the locus; it runs — as ONE launch together with the root term — when bpa_locus_root_loglikelihood asks for the
+   value, or before anything else reads or writes the locus's buffers (a plan launch, a buffer access, a sampler).
+   A proposal of the reference (matrices -> partials -> lnL on one locus: gtree.c:5447-5467, 7484-7566,
+   stree.c:4727-4749) is then one launch and one synchronisation instead of three.                                */
+
+/* locus_update_all_matrices (locus.c:1922) / locus_update_all_partials (locus.c:2523): the gene tree crosses the
+   boundary as a flat view of the gnode_t fields the reference's recursions read (bpp.h:692-732), one entry per node
+   (tips first; left/right = -1 for tips, parent = -1 for the root).  Branch lengths are the strict clock's
+   (parent.time - time) * rate_mui (locus.c:1826) for every node but the root, visited in the reference's pre-order
+   from root->left then root->right; lengths_out (nodes entries, or NULL) receives them as the reference stores
+   them in node->length.  Partials: every inner node in the post-order of locus.c:2482-2521.  Relaxed clocks derive
+   the length from species-tree rates (locus.c:1105-1193): the caller computes it and uses bpa_locus_update_matrices. */
+typedef struct bpa_gtree_view
+{
+  unsigned         nodes;                /* 2*tips - 1 */
+  int              root;
+  const int *      left;
+  const int *      right;
+  const int *      parent;
+  const double *   time;
+  const unsigned * clv_index;
+  const int *      scaler_index;
+  const unsigned * pmatrix_index;
+  double           rate_mui;             /* gtree_t.rate_mui (bpp.h:757) */
+} bpa_gtree_view_t;
+int  bpa_locus_update_all_matrices(bpa_locus_t *, const bpa_gtree_view_t *, double * lengths_out);
+int  bpa_locus_update_all_partials(bpa_locus_t *, const bpa_gtree_view_t *);
+
 /* pll_core_update_pmatrix (core_pmatrix.c:785, bpp.h:2349): library form over
    host arrays (expm1(lambda*rate*t), identity when t == 0); evaluated on the
    device of `engine`.                                                          */
