@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the likelihood hot path on the configuration BASELINE.json's
-metric is quoted on: A00, synthetic 10 000 loci x 1 000 sites, 4 taxa, JC69, 1 rate
-category (configs[1]) — per GPU (weak scaling: every rank owns its own 10 000 loci).
+"""bench.py — BASELINE.json's metric on the configuration it is quoted on (configs[1]): MCMC iterations/s of A00 on
+synthetic 10 000 loci x 1 000 sites, 4 taxa, JC69, 1 rate category, at N GPUs.
 
-A "step" is one A00 MCMC iteration's worth of hot-path work for all loci of the rank:
-the batched proposal steps of bpp_amd/schedule.py (3 GAGE + 6 GSPR + 3 TAU + 1 MIX for
-4 taxa; each = P-matrices -> root-path partials -> root lnL for every locus in one fused
-launch sequence; TAU/MIX steps also produce the all-loci lnL sum that is all-reduced
-across ranks).  All descriptors and loci are resident in HBM before the timed region.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4] [--scaling weak|strong] ...
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3] [--loci L]
+A "step" is ONE MCMC ITERATION of the device-resident A00 sampler over all loci (config c2): per locus tips-1 gene-node
+age proposals and 2 tips-2 prune/regraft proposals (the sweep, one launch), a theta step per population, a rubber-band tau
+step per divergence and one mixing step — every proposal, density, likelihood and accept/reject on the GPU
+(bpa_sampler_t; same posterior as the unmodified program, tests/test_a00_posterior.py).  `value` is that rate; `roofline`
+is the sweep kernel's.  Next to it, as before:
 
-N>1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).
+  likelihood_only   the hot path alone on a pre-recorded proposal tape (bpp_amd/schedule.py; accept/reject by a seeded
+                    coin): resident batched plans, the per-locus steps of an iteration as one chain launch, the all-loci
+                    steps one launch each.  This is also what `--config c3|c4` time (`value` then: tape iterations/s of
+                    that config's own loci), and what `other_configs` carries for c3 / c4 in the default run.
+  cpu_baseline      the same tape through the REAL reference's locus API (oracle/_ref, AVX2), one core and all cores.
+  reference_program_on_host   the unmodified program's whole MCMC iterations/s over a sweep of thread counts.
+
+N > 1 (torch.distributed, one rank per GPU): loci sharded, no data-path collective; the only exchange is the sum an
+all-loci step is decided on.  --scaling weak (default; every rank owns the config's loci, `value` in 10k-locus
+iterations/s x N) or strong (ONE data set of the config's loci dealt out by the reference's zig-zag, threads.c:265-353).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -42,41 +50,73 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(data, steps_init, steps_iter, n_iter, budget_s=12.0, sample=192):
-    """The same tape on the host CPU, one core, on a bounded sample of the loci:
-    through the REAL reference's update API when oracle/_ref travelled
-    (kind "reference"), else through the oracle's C loop (kind "port")."""
+# ------------------------------------------------------------------------------------------------ CPU baselines ---
+def cpu_baseline(data, steps_init, steps_iter, n_iter, budget_s=10.0, sample=192):
+    """The same tape on the host CPU through the REAL reference's update API when oracle/_ref travelled (kind
+    "reference"), else through the oracle's C loop (kind "port"), on a bounded sample of the loci: one core, then —
+    loci are independent, as threads.c shards them — all host cores at once (one locus per worker at a time)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib as O
     import tape
+    from concurrent.futures import ThreadPoolExecutor
     sample = min(sample, len(data))
     use_ref = O.have_ref()
-    per_locus = []
     t_start = time.time()
-    # calibrate repeats on the first locus, then spend ~budget_s overall
-    reps = 200
-    done = 0
-    for li in range(sample):
+
+    def prep(li):
         sub_full = tape.locus_subtape(steps_init + steps_iter, li)
         sub_init = tape.locus_subtape(steps_init, li)
         if use_ref:
-            rl = tape.ref_locus_for(data[li])
-            _, t_full = tape.ref_replay(rl, tape.ref_tape_arrays(sub_full), repeats=reps)
-            _, t_init = tape.ref_replay(rl, tape.ref_tape_arrays(sub_init), repeats=reps)
-            rl.free()
+            return (tape.ref_locus_for(data[li]), tape.ref_tape_arrays(sub_full), tape.ref_tape_arrays(sub_init))
+        return (data[li], sub_full, sub_init)
+
+    def run(job, reps):
+        if use_ref:
+            rl, full, init = job
+            _, t_full = tape.ref_replay(rl, full, repeats=reps)
+            _, t_init = tape.ref_replay(rl, init, repeats=reps)
         else:
-            _, t_full = tape.oracle_tape_run(data[li], sub_full, repeats=reps)
-            _, t_init = tape.oracle_tape_run(data[li], sub_init, repeats=reps)
+            d, full, init = job
+            _, t_full = tape.oracle_tape_run(d, full, repeats=reps)
+            _, t_init = tape.oracle_tape_run(d, init, repeats=reps)
+        return t_full, t_init
+
+    def run_full(job, reps):
+        if use_ref:
+            tape.ref_replay(job[0], job[1], repeats=reps)
+        else:
+            tape.oracle_tape_run(job[0], job[1], repeats=reps)
+
+    jobs = [prep(li) for li in range(sample)]
+    # ---- one core: calibrate the repeats on the first locus, then ~budget_s/2
+    t_full, t_init = run(jobs[0], 50)
+    reps = int(max(5, min(20000, 50 * (0.5 * budget_s) / max((t_full + t_init) * sample, 1e-9))))
+    per_locus, legs = [], []
+    for job in jobs:
+        t_full, t_init = run(job, reps)
+        legs.append((t_full, t_init))
         per_locus.append(max(t_full - t_init, 1e-12) / (reps * n_iter))
-        done += 1
-        if li == 0:
-            est = (t_full + t_init)
-            reps = int(max(20, min(20000, reps * budget_s / max(est * sample, 1e-9))))
-        if time.time() - t_start > 2.5 * budget_s:
+        if time.time() - t_start > 1.5 * budget_s:
             break
-    sec_per_locus_iter = float(np.mean(per_locus))
-    return dict(sec_per_locus_iter=sec_per_locus_iter, kind="reference" if use_ref else "port",
-                cores=1, sampled_loci=done, repeats=reps, seconds=time.time() - t_start)
+    one = float(np.mean(per_locus))
+    # ---- all cores: the C calls release the GIL; every worker replays whole loci (full tape), wall time of the sample;
+    # the start-up evaluation's share of a replay is known from the one-core leg
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, len(jobs)))
+    share_iter = float(np.sum([max(f - i, 0.0) for f, i in legs]) / max(np.sum([f for f, _ in legs]), 1e-12))
+    reps_all = int(max(5, min(20000, reps * min(workers, 16))))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(lambda j: run_full(j, reps_all), jobs))
+    wall = time.perf_counter() - t0
+    all_sec_per_locus_iter = wall * share_iter / (len(jobs) * reps_all * n_iter)
+    if use_ref:
+        for rl, _, _ in jobs:
+            rl.free()
+    return dict(sec_per_locus_iter=one, kind="reference" if use_ref else "port", cores=1, sampled_loci=len(per_locus),
+                repeats=reps, seconds=time.time() - t_start,
+                all_cores=dict(sec_per_locus_iter=all_sec_per_locus_iter, workers=workers, host_logical_cores=cores,
+                               repeats=reps_all, sampled_loci=len(jobs)))
 
 
 SIM_CTL = """seed = 12345
@@ -116,11 +156,11 @@ nsample = {nsample}
 """
 
 
-def bpp_program_baseline(nloci, sites, threads_list, n1=20, n2=120):
-    """The unmodified reference PROGRAM (oracle/_ref/bpp, built in place from /root/reference) on this
-    box's host cores: data from its own simulator (SURVEY.md App. B control files), A00 JC69, whole
-    MCMC iterations/s from the differential wall time of an n1- and an n2-iteration run, per thread
-    count.  This includes BPP's MCMC control (MSC prior, proposals), which this repo does not build."""
+def bpp_program_baseline(nloci, sites, threads_list, n1=20, n2=100, reps=3, budget_s=150.0):
+    """The unmodified reference PROGRAM (oracle/_ref/bpp, built in place from /root/reference) on this box's host
+    cores: data from its own simulator, A00 JC69, whole MCMC iterations/s from the differential wall time of an n1-
+    and an n2-iteration run, per thread count: median and spread of `reps` measurements (north_star's comparison is
+    with the multi-thread AVX2 program: the best thread count is what counts)."""
     import subprocess
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -128,100 +168,35 @@ def bpp_program_baseline(nloci, sites, threads_list, n1=20, n2=120):
     if not os.path.exists(O.REF_BIN):
         return None
     out = {}
+    t_start = time.time()
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "sim.ctl"), "w").write(SIM_CTL.format(nloci=nloci, sites=sites))
         subprocess.run([O.REF_BIN, "--simulate", "sim.ctl"], cwd=d, check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL, timeout=300)
+
+        def wall(ns, tl):
+            open(os.path.join(d, "a00.ctl"), "w").write(A00_CTL.format(nloci=nloci, nsample=ns, threads=tl))
+            t0 = time.perf_counter()
+            subprocess.run([O.REF_BIN, "--cfile", "a00.ctl"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=900)
+            return time.perf_counter() - t0
+
         for th in threads_list:
             tl = f"threads = {th} 1 1" if th > 1 else ""
-            ts = []
-            for ns in (n1, n2):
-                open(os.path.join(d, "a00.ctl"), "w").write(A00_CTL.format(nloci=nloci, nsample=ns, threads=tl))
-                t0 = time.perf_counter()
-                subprocess.run([O.REF_BIN, "--cfile", "a00.ctl"], cwd=d, check=True, stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=900)
-                ts.append(time.perf_counter() - t0)
-            out[th] = round((n2 - n1) / max(ts[1] - ts[0], 1e-9) * nloci / 10000.0, 2)
+            rates = []
+            for _ in range(reps if th > 1 else 1):
+                if time.time() - t_start > budget_s and rates:
+                    break
+                t1, t2 = wall(n1, tl), wall(n2, tl)
+                rates.append((n2 - n1) / max(t2 - t1, 1e-9) * nloci / 10000.0)
+            out[th] = dict(median=round(float(np.median(rates)), 2), min=round(min(rates), 2), max=round(max(rates), 2),
+                           runs=len(rates))
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--loci", type=int, default=None, help="loci per GPU (default: the config's)")
-    ap.add_argument("--tape-iters", type=int, default=4, help="distinct A00 iterations in the resident tape")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sampler", action="store_true", help="skip the device-resident sampler section")
-    ap.add_argument("--no-bpp-program", action="store_true",
-                    help="skip timing the unmodified reference program (1 thread and many threads) on the host cores")
-    ap.add_argument("--no-timing-events", action="store_true")
-    ap.add_argument("--rccl-sums", action="store_true",
-                    help="N > 1: all-reduce the sums with RCCL (torch.distributed) instead of the one-shot p2p exchange")
-    ap.add_argument("--sum-launch", action="store_true",
-                    help="produce the total of an all-loci step with a launch of its own (default: per-workgroup partial sums written by the step kernel)")
-    ap.add_argument("--event-stride", type=int, default=7,
-                    help="attach the kernel start/stop events to every n-th launch of the timed region "
-                         "(an event pair costs ~4 us of stream time per launch; 7 is co-prime with the 13 steps "
-                         "of an iteration, so every step type is sampled)")
-    ap.add_argument("--no-subst-proposals", action="store_true",
-                    help="GTR configs: leave the per-locus frequency / exchangeability / alpha proposals out of the tape")
-    ap.add_argument("--host-in-loop", action="store_true",
-                    help="copy the per-locus lnL of every step back to the host before launching the next "
-                         "(what a host-resident accept/reject needs; PCIe-inclusive rate, reported in DESIGN.md)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    cfg = CONFIGS[args.config]
-    nloci = args.loci or cfg["loci"]
-
+# ------------------------------------------------------------------------------------------------ the workload ---
+def make_loci(eng, data):
     import bpp_amd
-    from bpp_amd import synth
-    from bpp_amd.schedule import A00Schedule, TreeState
-
-    dist = None
-    sum_buf = None
-    stream = None
-    # BENCH_FORCE_DIST=1: the N>1 code path (launch segments + an all-reduce per all-loci step) in a one-rank group —
-    # what the collectives' enqueue costs on the host, measurable on a one-GPU box
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):
-        import torch
-        import torch.distributed as dist_
-        dist = dist_
-        # BENCH_DIST_BACKEND=gloo + BENCH_FORCE_DEVICE=0 let the N>1 code path be exercised on a
-        # one-GPU box (two ranks sharing device 0); the driver's runs use nccl (= RCCL), one GPU per rank
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-        if "BENCH_FORCE_DEVICE" in os.environ:
-            local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
-        torch.cuda.set_device(local_rank)
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend, rank=rank, world_size=world)
-        # the engine and the collectives share ONE explicit torch stream, so that an all-reduce is
-        # ordered after the kernel that produced the sum (torch's default stream has handle 0, which
-        # the engine would replace by a private stream)
-        tstream = torch.cuda.Stream()
-        torch.cuda.set_stream(tstream)
-        stream = tstream.cuda_stream
-        sum_buf = torch.zeros(4096, dtype=torch.float64, device="cuda")     # room for the per-workgroup partial sums
-        sum_view = sum_buf[:1]
-
-    eng = bpp_amd.Engine(local_rank, stream)
-
-    # ---- synthetic input (this rank's shard: its own nloci loci), resident in HBM
-    t0 = time.time()
-    data = synth.make_dataset(nloci, cfg["sites"], cfg["taxa"], cfg["model"], cfg["rate_cats"],
-                              seed=12345 + 1000 * rank)
-    npat = sum(len(d["weights"]) for d in data)
-    log(f"dataset: {nloci} loci, {npat} patterns ({npat / nloci:.2f}/locus) in {time.time() - t0:.1f}s")
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     loci = []
     for d in data:
         S, R = d["states"], d["rate_cats"]
@@ -238,60 +213,87 @@ def main():
             loc.set_subst_params(0, d["exch"])
         loc.set_category_rates(d["rates"])
         loci.append(loc)
+    return loci
 
-    # ---- the proposal tape (host MCMC control stand-in), then resident plans
-    t0 = time.time()
-    trees = [TreeState(d["left"], d["right"], d["times"], d["root"]) for d in data]
-    subst = None
-    if cfg["model"] == "gtr" and not args.no_subst_proposals:
-        # the per-locus frequency / exchangeability / alpha proposals of a GTR+Gamma analysis
-        R_ = cfg["rate_cats"]
-        subst = dict(freqs=[d["freqs"] for d in data], exch=[d["exch"] for d in data], alpha=[0.5] * nloci, rate_cats=R_,
-                     gamma=lambda a, cats: bpp_amd.compute_gamma_cats(a, a, cats) if cats > 1 else np.ones(1))
-    sch = A00Schedule(trees, seed=1 + rank, taus=cfg["taus"], subst=subst)
-    init = sch.initial_step()
-    iters = [sch.iteration() for _ in range(args.tape_iters)]
-    log(f"tape: {args.tape_iters} iterations x {len(iters[0])} batched steps in {time.time() - t0:.1f}s")
 
-    def mkplan(st):
-        p = bpp_amd.Plan(eng, [loci[i] for i in st.loci], st.mat_off, st.mat_pmatrix, st.mat_length,
-                         st.op_off, st.ops, st.root_clv, st.root_scaler)
-        if st.global_decision is not None:
-            # the sum an all-loci proposal is decided on (and the ranks all-reduce): written by the step kernel as
-            # per-workgroup partial sums where the plan runs on the engine's packing (no launch of its own), else the
-            # plain total; --sum-launch forces the total as its own launch
-            if args.sum_launch:
-                p.enable_sum(sum_buf.data_ptr() if sum_buf is not None else None)
-            else:
-                n = p.enable_partial_sums(sum_buf.data_ptr() if sum_buf is not None else None,
-                                          sum_buf.numel() if sum_buf is not None else 0)
-                sum_parts.append(n)
-        return p
+def dominant_kernel(cfg):
+    if cfg["model"] == "jc69":
+        return "step_jc69_v2_chain_kernel<256> + step_jc69_v2_kernel<256>" if not os.environ.get("BPA_NO_CHAIN") else "step_jc69_v2_kernel<256>"
+    if cfg["model"] == "gtr":
+        return "step_s4_klane_v2_kernel<256,false>"
+    return "partials_lnl_tiledk_kernel<20,3>"
 
-    sum_parts = []
-    p_init = mkplan(init)
-    plans = [[mkplan(st) for st in it] for it in iters]
-    if sum_buf is not None and sum_parts:
-        # every rank must all-reduce the same number of doubles: the largest count over the ranks (a rank's own
-        # workgroup count depends on its loci; the entries past it stay zero)
+
+def traffic_from_profiles(config, kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ (tools/profile_cfg.sh on
+    this same command): 2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, both in KB"""
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"profile_{config}.json")))
+        pm = json.load(open(cands[-1]))["pmc_per_dispatch"]
+        want = kernel.split(" + ")[0].replace(" ", "")
+        key = [k for k in pm if want in k.replace(" ", "") and "FETCH_SIZE" in pm[k]]
+        key = (key or [k for k in pm if want.split("<")[0] in k and "FETCH_SIZE" in pm[k]])[0]
+        return (round((2 * pm[key]["FETCH_SIZE"]["mean"] + pm[key]["WRITE_SIZE"]["mean"]) * 1024),
+                os.path.relpath(cands[-1], ROOT) + f" ({key.split('(')[0]}; separate --pmc passes; FETCH_SIZE doubled per the gfx950 note)")
+    except Exception:
+        return None, None
+
+
+class Dist:
+    """torch.distributed + the stream the engine and the collectives share"""
+
+    def __init__(self, world, rank, local_rank):
         import torch
-        cnt = torch.tensor([max(sum_parts)], dtype=torch.int64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
-        sum_view = sum_buf[:int(cnt.item())]
+        import torch.distributed as dist
+        self.torch, self.dist, self.world, self.rank = torch, dist, world, rank
+        # BENCH_DIST_BACKEND=gloo + BENCH_FORCE_DEVICE=0 let the N>1 code path be exercised on a one-GPU box (two ranks
+        # sharing device 0); the driver's runs use nccl (= RCCL), one GPU per rank
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if "BENCH_FORCE_DEVICE" in os.environ:
+            local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
+        self.local_rank = local_rank
+        torch.cuda.set_device(local_rank)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        # ONE explicit torch stream for the engine and the collectives, so that an all-reduce is ordered after the
+        # kernel that produced the sum (torch's default stream has handle 0, which the engine would replace)
+        self.tstream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.tstream)
+        self.stream = self.tstream.cuda_stream
+        self.p2p = None
 
-    # ---- how the sums travel between the ranks: the one-shot all-reduce over xGMI peer mappings (bpa_p2p_*: one hop,
-    # one small kernel) when its start-up self-test against RCCL passes on EVERY rank, else RCCL (torch.distributed)
-    p2p = None
-    if dist is not None and not args.rccl_sums and sum_view.numel() <= 512:
-        import torch
+    def max(self, x):
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_int(self, x):
+        t = self.torch.tensor([x], dtype=self.torch.int64, device="cuda")
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+        self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def setup_p2p(self, eng, n):
+        """the one-shot all-reduce over xGMI peer mappings (bpa_p2p_*), used only when its start-up self-test against
+        RCCL passes on EVERY rank"""
+        import bpp_amd
+        torch, dist = self.torch, self.dist
         ok = 1
+        p2p = None
         try:
-            p2p = bpp_amd.P2P(eng, rank, world, 512)
-            handles = [None] * world
+            p2p = bpp_amd.P2P(eng, self.rank, self.world, 512)
+            handles = [None] * self.world
             dist.all_gather_object(handles, p2p.handle)
             p2p.connect(handles)
             for k in range(6):
-                x = torch.arange(sum_view.numel(), dtype=torch.float64, device="cuda") * (0.5 + rank) + k + 1e-3 * rank
+                x = torch.arange(n, dtype=torch.float64, device="cuda") * (0.5 + self.rank) + k + 1e-3 * self.rank
                 y = x.clone()
                 torch.cuda.current_stream().synchronize()
                 p2p.allreduce(x.data_ptr(), x.numel())
@@ -307,26 +309,75 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) != 1:
             p2p = None
+        elif p2p is not None:
+            p2p.set_timeout_ms(200)       # inside timed regions a lost flag costs 0.2 s once, then the run is repeated over RCCL
+        self.p2p = p2p
         log("sums between ranks: " + ("one-shot p2p all-reduce (self-test against RCCL passed)" if p2p else "RCCL all-reduce"))
+
+
+def run_tape(eng, cfg, config_key, data, loci, args, D, steps, warmup):
+    """the likelihood hot path alone on a resident proposal tape; returns the section's dict"""
+    import bpp_amd
+    from bpp_amd.schedule import A00Schedule, TreeState
+    nloci = len(data)
+    rank = D.rank if D else 0
+    world = D.world if D else 1
+    t0 = time.time()
+    trees = [TreeState(d["left"], d["right"], d["times"], d["root"]) for d in data]
+    subst = None
+    if cfg["model"] == "gtr" and not args.no_subst_proposals:
+        # the per-locus frequency / exchangeability / alpha proposals of a GTR+Gamma analysis (SURVEY section 8d)
+        R_ = cfg["rate_cats"]
+        subst = dict(freqs=[d["freqs"] for d in data], exch=[d["exch"] for d in data], alpha=[0.5] * nloci, rate_cats=R_,
+                     gamma=lambda a, cats: bpp_amd.compute_gamma_cats(a, a, cats) if cats > 1 else np.ones(1))
+    sch = A00Schedule(trees, seed=1 + rank, taus=cfg["taus"], subst=subst)
+    init = sch.initial_step()
+    iters = [sch.iteration() for _ in range(args.tape_iters)]
+    log(f"{config_key} tape: {args.tape_iters} iterations x {len(iters[0])} batched steps in {time.time() - t0:.1f}s")
+
+    sum_buf = D.torch.zeros(4096, dtype=D.torch.float64, device="cuda") if D else None   # room for the per-workgroup partial sums
+    sum_parts = []
+
+    def mkplan(st):
+        p = bpp_amd.Plan(eng, [loci[i] for i in st.loci], st.mat_off, st.mat_pmatrix, st.mat_length,
+                         st.op_off, st.ops, st.root_clv, st.root_scaler)
+        if st.global_decision is not None:
+            # the sum an all-loci proposal is decided on (and the ranks all-reduce): written by the step kernel as
+            # per-workgroup partial sums where the plan runs on the engine's packing (no launch of its own), else the
+            # plain total; --sum-launch forces the total as its own launch
+            if args.sum_launch:
+                p.enable_sum(sum_buf.data_ptr() if sum_buf is not None else None)
+            else:
+                sum_parts.append(p.enable_partial_sums(sum_buf.data_ptr() if sum_buf is not None else None,
+                                                       sum_buf.numel() if sum_buf is not None else 0))
+        return p
+
+    p_init = mkplan(init)
+    plans = [[mkplan(st) for st in it] for it in iters]
+    sum_view = sum_buf[:1] if sum_buf is not None else None
+    if D and sum_parts:
+        # every rank must all-reduce the same number of doubles: the largest count over the ranks
+        cnt = D.torch.tensor([max(sum_parts)], dtype=D.torch.int64, device="cuda")
+        D.dist.all_reduce(cnt, op=D.dist.ReduceOp.MAX)
+        sum_view = sum_buf[:int(cnt.item())]
+    p2p = D.p2p if (D and sum_view is not None and sum_view.numel() <= 512) else None
+
     # parameter installs of the tape, resident in HBM: (which, device address) per step, applied through p_init
     # (which holds every locus) right before the step's launch
     staged = [[[(w, eng.stage(v)) for w, v in st.params] for st in it] for it in iters]
     p_init.launch()
     lnl0 = p_init.lnl()
-    log(f"start-up lnL (sum over loci) = {lnl0.sum():.6f}")
+    log(f"{config_key} start-up lnL (sum over this rank's loci) = {lnl0.sum():.6f}")
 
-    # work per tape iteration (algorithmic)
     work = [[p.work() for p in it] for it in plans]
     it_pattern_updates = np.mean([sum(w["pattern_updates"] for w in it) for it in work])
     it_node_updates = np.mean([sum(w["node_updates"] for w in it) for it in work])
-    it_bytes_partials = np.mean([sum(w["bytes_partials"] for w in it) for it in work])
-    it_bytes_pmatrix = np.mean([sum(w["bytes_pmatrix"] for w in it) for it in work])
     it_flops = np.mean([sum(w["flops_partials"] for w in it) for it in work])
-    launches_per_iter = np.mean([len(it) for it in plans])
+    steps_per_iter = float(np.mean([len(it) for it in plans]))
 
-    # launch segments: consecutive steps up to and including an all-loci step (TAU/MIX), whose
-    # summed lnL is then all-reduced across ranks — the per-proposal reduction of
-    # threads.c:544-591, over xGMI.  One GPU: the whole iteration is one host call.
+    # launch segments: consecutive steps up to and including an all-loci step (TAU/MIX), whose summed lnL is then
+    # all-reduced across ranks — the per-proposal reduction of threads.c:544-591.  Inside a segment bpa_plans_launch
+    # sends the consecutive per-locus steps out as one chain launch.  One GPU: the whole iteration is one host call.
     segments = []
     for sts, pls, stg in zip(iters, plans, staged):
         segs, cur, pre = [], [], []
@@ -337,13 +388,12 @@ def main():
             if installs:
                 pre = installs
             cur.append(p)
-            if dist is not None and st.global_decision is not None:
+            if D is not None and st.global_decision is not None:
                 segs.append((pre, bpp_amd.PlanSequence(cur), True))
                 cur, pre = [], []
         if cur:
             segs.append((pre, bpp_amd.PlanSequence(cur), False))
         segments.append(segs)
-
     sum_ptr, sum_n = (sum_buf.data_ptr(), sum_view.numel()) if sum_buf is not None else (None, 0)
 
     def run_iteration(i):
@@ -362,211 +412,348 @@ def main():
                 continue
             seq.launch()
             if reduce_after:
-                dist.all_reduce(sum_view)
+                D.dist.all_reduce(sum_view)
 
-    def sync():
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-        else:
-            eng.synchronize()
-
+    sync = D.sync if D else eng.synchronize
     while True:
-        for i in range(args.warmup):
+        for i in range(warmup):
             run_iteration(i)
         sync()
         if not args.no_timing_events:
             eng.enable_timing(True, stride=args.event_stride)
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            run_iteration(args.warmup + i)
+        for i in range(steps):
+            run_iteration(warmup + i)
         enqueue_s = time.perf_counter() - t0          # host time to enqueue the timed region (GPU still running)
         sync()
         elapsed = time.perf_counter() - t0
-        log(f"host enqueue {1e3 * enqueue_s / args.steps:.4f} ms/step of {1e3 * elapsed / args.steps:.4f} ms/step")
+        log(f"{config_key} tape: host enqueue {1e3 * enqueue_s / steps:.4f} ms/step of {1e3 * elapsed / steps:.4f} ms/step")
         tm = eng.timing() if not args.no_timing_events else None
         eng.enable_timing(False)
         if p2p is None:
             break
         # a p2p exchange that timed out on ANY rank voids the run: measure again over RCCL
-        import torch
-        bad = torch.tensor([1 if p2p.status() != 0 else 0], dtype=torch.int64, device="cuda")
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        bad = D.torch.tensor([1 if p2p.status() != 0 else 0], dtype=D.torch.int64, device="cuda")
+        D.dist.all_reduce(bad, op=D.dist.ReduceOp.MAX)
         if int(bad.item()) == 0:
             break
         log("p2p all-reduce timed out: repeating the measurement over RCCL")
-        p2p = None
+        p2p = D.p2p = None
 
     allreduce_check = None
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # self-check of the N>1 data path (outside the timed region): the device-side sum of the last
-        # all-loci step, all-reduced, must equal the sum over ranks of the per-locus values
+    if D is not None:
+        elapsed = D.max(elapsed)
+        # self-check of the N>1 data path (outside the timed region): the device-side sum of the last all-loci step,
+        # all-reduced, must equal the sum over ranks of the per-locus values
         last = [p for st, p in zip(iters[-1], plans[-1]) if st.global_decision is not None][-1]
         last.launch()
         if p2p is not None:
             p2p.allreduce(sum_buf.data_ptr(), sum_view.numel())
         else:
-            dist.all_reduce(sum_view)
-        torch.cuda.synchronize()
+            D.dist.all_reduce(sum_view)
+        D.torch.cuda.synchronize()
         got = float(sum_view.sum().item())
-        want = torch.tensor([float(last.lnl().sum())], dtype=torch.float64, device="cuda")
-        dist.all_reduce(want)
+        want = D.torch.tensor([float(last.lnl().sum())], dtype=D.torch.float64, device="cuda")
+        D.dist.all_reduce(want)
         allreduce_check = "ok" if abs(got - float(want.item())) <= 1e-9 * abs(got) else f"MISMATCH {got} vs {float(want.item())}"
 
-    ms_per_step = 1e3 * elapsed / args.steps
-    total_loci = nloci * world
-    iters_per_s_10k = (total_loci / 10000.0) * args.steps / elapsed
-    site_lnl_updates_per_s = it_pattern_updates * world * args.steps / elapsed
-
+    ms_per_step = 1e3 * elapsed / steps
+    total_loci = D.sum_int(nloci) if D else nloci
     roofline = None
     if tm and tm["launches"]:
-        kernel_ms = tm["partials_ms"] / tm["launches"]
-        # the fused step kernel does K4 (P-matrix writes) + K1 + K2: algorithmic bytes of all three
-        # which kernel the engine's events bracket: the single fused step kernel (JC69: K4 + K1 + K2), or — where the
-        # P-matrix phase runs as its own launch (GTR+G: eigen code, 20 states) — the K1 + K2 kernel alone
-        klane = cfg["model"] == "gtr" and not os.environ.get("BPA_NO_KLANE")
-        fused = cfg["model"] != "lg" and not klane
-        bytes_per_launch = (it_bytes_partials + (it_bytes_pmatrix if fused else 0)) / launches_per_iter
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        roofline = dict(bound="hbm", kernel=(("step_jc69_kernel<256>" if os.environ.get("BPA_JC69_V1") else "step_jc69_v2_kernel<256>") if cfg["model"] == "jc69" else ("step_s4_klane_kernel<256,false>" if os.environ.get("BPA_KLANE_V1") else "step_s4_klane_v2_kernel<256,false>") if klane else "step_s4_fused_kernel<64,4>" if cfg["model"] != "lg" else "partials_lnl_tiledk_kernel<20,3>"), achieved=round(achieved, 2),
-                        peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
-                        traffic=None, avg_kernel_us=round(1e3 * kernel_ms, 3),
-                        algorithmic_bytes_per_launch=round(bytes_per_launch),
-                        launches=tm["launches"],
-                        timing=f"hipExtLaunchKernelGGL start/stop events on the engine stream, every {args.event_stride}-th launch of the timed region",
-                        note=("52k lanes per launch: latency/launch bound (2.3 us empty-grid floor), cache-resident working set, not HBM bound (SURVEY §7)"
-                              if args.config == "c2" else None))
+        # achieved = algorithmic bytes of the kernels the events bracketed / their time: the chain
+        # and step kernels (K4 + K1 + K2) for JC69, the K1 + K2 kernel where the P-matrix phase is its own launch
+        kern = dominant_kernel(cfg)
+        achieved = tm["bytes"] / (tm["partials_ms"] * 1e-3) / 1e9
+        traffic, src = traffic_from_profiles(config_key, kern) if args.loci is None else (None, None)
+        roofline = dict(bound="hbm", kernel=kern, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=src,
+                        avg_kernel_us=round(1e3 * tm["partials_ms"] / tm["launches"], 3),
+                        avg_us_per_proposal_step=round(1e3 * tm["partials_ms"] / max(tm["steps"], 1), 3),
+                        algorithmic_bytes_per_launch=round(tm["bytes"] / tm["launches"]),
+                        launches=tm["launches"], proposal_steps=tm["steps"],
+                        timing=f"hipExtLaunchKernelGGL start/stop events on the engine stream, every {args.event_stride}-th launch of the timed region")
+    out = dict(
+        workload=cfg["name"] + f"; {nloci} loci on this rank, {sum(len(d['weights']) for d in data) / nloci:.2f} patterns/locus, "
+                 f"{steps_per_iter:.0f} batched proposal steps/iteration ({it_node_updates / nloci:.1f} node updates + "
+                 f"{steps_per_iter:.0f} lnL evals per locus)",
+        steps=steps, warmup=warmup, ms_per_step=round(ms_per_step, 5),
+        iterations_per_s=round(steps / elapsed, 3),
+        iterations_per_s_10k_loci=round((total_loci / 10000.0) * steps / elapsed, 3),
+        loci_total=total_loci,
+        site_lnl_updates_per_s=round(it_pattern_updates * (total_loci / nloci) * steps / elapsed),
+        node_updates_per_iteration=round(float(it_node_updates)),
+        gflops_partials=round(it_flops * (total_loci / nloci) * steps / elapsed / 1e9, 2),
+        roofline=roofline, allreduce_check=allreduce_check,
+        note="pre-recorded proposal tape, accept/reject by a seeded coin: the likelihood path alone (no MCMC decision)")
+    for it in plans:
+        for p in it:
+            p.close()
+    p_init.close()
+    return out, (init, iters)
 
-    # HBM traffic per launch from the rocprofv3 PMC passes committed under profiles/ (collected by
-    # tools/profile_cfg.sh on this same command): 2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md
-    # §HBM) + WRITE_SIZE, both reported in KB
-    if roofline is not None and args.loci is None:
-        try:
-            import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"profile_{args.config}.json")))
-            pm = json.load(open(cands[-1]))["pmc_per_dispatch"]
-            want = roofline["kernel"].replace(" ", "")
-            key = [k for k in pm if want in k.replace(" ", "") and "FETCH_SIZE" in pm[k]]
-            key = (key or [k for k in pm if want.split("<")[0] in k and "FETCH_SIZE" in pm[k]])[0]
-            roofline["traffic"] = round((2 * pm[key]["FETCH_SIZE"]["mean"] + pm[key]["WRITE_SIZE"]["mean"]) * 1024)
-            roofline["traffic_source"] = os.path.relpath(cands[-1], ROOT) + " (separate --pmc passes; FETCH_SIZE doubled per the gfx950 note)"
-        except Exception:
-            pass
 
-    # ---- extra (not `value`): the same loci under device-resident proposal control — a real sampler
-    # (proposals, accept/reject, rollback on the device; bpa_sampler_t)
-    sampler = None
-    if args.config == "c2" and not args.no_sampler:
-        smp = bpp_amd.Sampler(eng, loci, data, seed=1)
-        if dist is not None:
-            # loci sharded; one small sum all-reduce per THETA (all populations together) / TAU / MIX step (RCCL on the engine's stream)
-            smp_sum = torch.zeros(16, dtype=torch.float64, device=f"cuda:{local_rank}")      # BPA_SAMPLER_SUMS
+def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
+    """BASELINE's metric proper: whole A00 MCMC iterations/s with every decision on the device"""
+    import bpp_amd
+    from bpp_amd import synth
+    nloci = len(data)
+    world = D.world if D else 1
+    smp = bpp_amd.Sampler(eng, loci, data, seed=1)
+    if D is not None:
+        # loci sharded; one small sum all-reduce per THETA (all populations together) / TAU / MIX step on the engine's stream
+        smp_sum = D.torch.zeros(16, dtype=D.torch.float64, device=f"cuda:{D.local_rank}")      # BPA_SAMPLER_SUMS
 
-            def smp_allreduce(ptr, count, stream):
-                if p2p is not None:
-                    p2p.allreduce(ptr, count)
-                else:
-                    dist.all_reduce(smp_sum[:count])
-                return True
-            smp.set_allreduce(smp_allreduce, smp_sum.data_ptr(), rank * nloci)
-        sp_parent, sp_tau, sp_theta = synth.species_tree_arrays(cfg["taxa"])
-        smp_taus = sp_tau[cfg["taxa"]:]
-        smp.set_species_tree(sp_parent, sp_tau, sp_theta)
-        smp.set_tau_prior(3.0, 3.0 / sp_tau[-1])
-        smp.set_theta_prior(2.0, 2.0 / sp_theta[0], 0.5 * sp_theta[0])
-        smp.initialize()
-        smp.iterate(args.warmup)
-        eng.synchronize()
-        if dist is not None:
-            dist.barrier()
+        def smp_allreduce(ptr, count, stream):
+            if D.p2p is not None:
+                D.p2p.allreduce(ptr, count)
+            else:
+                D.dist.all_reduce(smp_sum[:count])
+            return True
+        smp.set_allreduce(smp_allreduce, smp_sum.data_ptr(), first_locus)
+    sp_parent, sp_tau, sp_theta = synth.species_tree_arrays(cfg["taxa"])
+    smp.set_species_tree(sp_parent, sp_tau, sp_theta)
+    smp.set_tau_prior(3.0, 3.0 / sp_tau[-1])
+    smp.set_theta_prior(2.0, 2.0 / sp_theta[0], 0.5 * sp_theta[0])
+    smp.initialize()
+    sync = D.sync if D else eng.synchronize
+    while True:
+        smp.iterate(warmup)
+        sync()
+        w0 = smp.work()
+        smp.enable_timing(args.event_stride if not args.no_timing_events else 0)
         t0 = time.perf_counter()
-        smp.iterate(args.steps)
-        eng.synchronize()
+        smp.iterate(steps)
+        sync()
         dt = time.perf_counter() - t0
-        if dist is not None:
-            tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
-        sm = smp.summary()
-        sampler = dict(iterations_per_s=round(args.steps / dt * nloci * world / 10000.0, 1), ms_per_iteration=round(1e3 * dt / args.steps, 4),
-                       n_gpus=world,
-                       launches_per_iteration=(2 if dist is None else 3) + (2 if dist is None else 3) * (len(smp_taus) + 1),   # sweep, THETA, (TAU.. + MIX) x (step + sum/decide) proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
-                       acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
-                       taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
-                       thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],
-                       note="the A00 sampler (species tree fixed) resident on the device: population-aware GAGE+GSPR per "
-                            "locus, a THETA step per population, a rubber-band TAU step per divergence and one MIX step "
-                            "per iteration, Metropolis-Hastings on priors x MSC density x likelihood (density bit-equal "
-                            "to gtree_logprob); reproduces the unmodified program's posterior "
-                            "(tests/test_a00_posterior.py) and the C host driver's trajectory on the reference "
-                            "(tests/test_gpu_sampler.py, tests/test_gpu_host_driver.py)")
-        if p2p is not None and p2p.status() != 0:
-            sampler = dict(error="a p2p exchange timed out during the sampler section: its numbers are void (rerun with --rccl-sums)")
-        smp.close()
+        tm = smp.timing()
+        smp.enable_timing(0)
+        w1 = smp.work()
+        if D is None or D.p2p is None:
+            break
+        bad = D.torch.tensor([1 if D.p2p.status() != 0 else 0], dtype=D.torch.int64, device="cuda")
+        D.dist.all_reduce(bad, op=D.dist.ReduceOp.MAX)
+        if int(bad.item()) == 0:
+            break
+        log("p2p all-reduce timed out during the sampler section: repeating it over RCCL")
+        D.p2p = None
+    if D is not None:
+        dt = D.max(dt)
+    total_loci = D.sum_int(nloci) if D else nloci
+    sm = smp.summary()
+    npop_inner = cfg["taxa"] - 1
+    roofline = None
+    if tm["sweep_launches"]:
+        sweeps = max(w1["sweeps"] - w0["sweeps"], 1)
+        bytes_per_sweep = (w1["bytes"] - w0["bytes"]) / sweeps
+        us = 1e3 * tm["sweep_ms"] / tm["sweep_launches"]
+        achieved = bytes_per_sweep / (us * 1e-6) / 1e9
+        traffic, src = traffic_from_profiles("c2", "sweep_kernel") if args.loci is None else (None, None)
+        roofline = dict(bound="hbm", kernel=f"smp::sweep_kernel<{4 if cfg['taxa'] <= 4 else 8}>", achieved=round(achieved, 2),
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=src,
+                        avg_kernel_us=round(us, 3), algorithmic_bytes_per_launch=round(bytes_per_sweep),
+                        launches=tm["sweep_launches"],
+                        node_updates_per_launch=round((w1["node_updates"] - w0["node_updates"]) / sweeps),
+                        allloci_step_avg_us=(round(1e3 * tm["allloci_ms"] / tm["allloci_launches"], 3) if tm["allloci_launches"] else None),
+                        timing=f"hipExtLaunchKernelGGL start/stop events on the engine stream, every {args.event_stride}-th sweep / all-loci launch of the timed region",
+                        note=f"one launch = the {3 * cfg['taxa'] - 3} per-locus proposals of an iteration for every locus, proposal control included; "
+                             "algorithmic bytes = K1 + K2 + K4 of the node updates the proposals actually ran (device counters); the working "
+                             "set lives in LDS for the whole launch: latency-bound by the leader lanes' serial proposal code, not by HBM")
+    out = dict(iterations_per_s=round(steps / dt, 3), iterations_per_s_10k_loci=round(steps / dt * total_loci / 10000.0, 3),
+               ms_per_iteration=round(1e3 * dt / steps, 5), steps=steps, warmup=warmup, n_gpus=world, loci_total=total_loci,
+               proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
+               launches_per_iteration=(2 if D is None else 3) + (2 if D is None else 3) * (npop_inner + 1),
+               acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
+               taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
+               thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],
+               roofline=roofline,
+               note="the A00 sampler (species tree fixed) resident on the device: population-aware GAGE+GSPR per locus, a THETA "
+                    "step per population, a rubber-band TAU step per divergence and one MIX step per iteration, "
+                    "Metropolis-Hastings on priors x MSC density x likelihood (density bit-equal to gtree_logprob); reproduces "
+                    "the unmodified program's posterior (tests/test_a00_posterior.py) and the C host driver's trajectory on "
+                    "the reference (tests/test_gpu_sampler.py, tests/test_gpu_host_driver.py)")
+    if D is not None and D.p2p is not None and D.p2p.status() != 0:
+        out = dict(error="a p2p exchange timed out during the sampler section: its numbers are void (rerun without --p2p-sums)")
+    smp.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--loci", type=int, default=None, help="loci of the data set (default: the config's)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank owns its own data set of the config's size; strong = ONE data set of the "
+                         "config's size, loci dealt to the ranks by the reference's zig-zag (threads.c:265-353)")
+    ap.add_argument("--tape-iters", type=int, default=4, help="distinct A00 iterations in the resident tape")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sampler", action="store_true", help="c2: skip the device-resident sampler (`value` is then the tape's)")
+    ap.add_argument("--no-tape", action="store_true", help="c2: skip the likelihood-only tape section")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the c3 / c4 tape sections of the default run")
+    ap.add_argument("--no-bpp-program", action="store_true",
+                    help="skip timing the unmodified reference program (thread sweep) on the host cores")
+    ap.add_argument("--no-timing-events", action="store_true")
+    ap.add_argument("--p2p-sums", action="store_true",
+                    help="N > 1: exchange the sums with the one-shot p2p all-reduce over xGMI peer mappings (self-tested "
+                         "against RCCL at start-up) instead of RCCL (torch.distributed), the default")
+    ap.add_argument("--sum-launch", action="store_true",
+                    help="produce the total of an all-loci step with a launch of its own (default: per-workgroup partial sums written by the step kernel)")
+    ap.add_argument("--event-stride", type=int, default=7,
+                    help="attach the kernel start/stop events to every n-th launch of the timed region")
+    ap.add_argument("--no-subst-proposals", action="store_true",
+                    help="GTR configs: leave the per-locus frequency / exchangeability / alpha proposals out of the tape")
+    ap.add_argument("--host-in-loop", action="store_true",
+                    help="tape: copy the per-locus lnL of every step back to the host before launching the next")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        sys.exit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    cfg = CONFIGS[args.config]
+    nloci_cfg = args.loci or cfg["loci"]
+
+    import bpp_amd
+    from bpp_amd import synth, shard
+
+    # BENCH_FORCE_DIST=1: the N>1 code path (launch segments + an all-reduce per all-loci step) in a one-rank group
+    D = Dist(world, rank, local_rank) if (world > 1 or os.environ.get("BENCH_FORCE_DIST")) else None
+    if D is not None:
+        local_rank = D.local_rank
+    eng = bpp_amd.Engine(local_rank, D.stream if D else None)
+
+    # ---- synthetic input, resident in HBM
+    t0 = time.time()
+    first_locus = 0
+    if args.scaling == "strong" and world > 1:
+        # ONE data set; the reference's zig-zag deal by work = tips x patterns (threads.c:265-353)
+        full = synth.make_dataset(nloci_cfg, cfg["sites"], cfg["taxa"], cfg["model"], cfg["rate_cats"], seed=12345)
+        mine = shard.partition([len(d["seqs"]) * len(d["weights"]) for d in full], world)[rank]
+        data = [full[i] for i in mine]
+        first_locus = int(1 << 20) * rank          # distinct per-locus random streams on every rank
+        del full
+    else:
+        data = synth.make_dataset(nloci_cfg, cfg["sites"], cfg["taxa"], cfg["model"], cfg["rate_cats"], seed=12345 + 1000 * rank)
+        first_locus = rank * nloci_cfg
+    nloci = len(data)
+    npat = sum(len(d["weights"]) for d in data)
+    log(f"dataset: {nloci} loci on rank 0, {npat} patterns ({npat / nloci:.2f}/locus) in {time.time() - t0:.1f}s ({args.scaling})")
+    loci = make_loci(eng, data)
+    if D is not None and args.p2p_sums:
+        D.setup_p2p(eng, 256)
+
+    tape_sec = sampler_sec = None
+    tape_steps = None
+    if not (args.config == "c2" and args.no_tape):
+        tape_sec, tape_steps = run_tape(eng, cfg, args.config, data, loci, args, D, args.steps, args.warmup)
+    if args.config == "c2" and not args.no_sampler:
+        sampler_sec = run_sampler(eng, cfg, data, loci, args, D, first_locus, args.steps, args.warmup)
+        if "error" in sampler_sec:
+            log(sampler_sec["error"])
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and tape_steps is not None:
+        init, iters = tape_steps
         n_cpu_iter = min(2, len(iters))
         cb = cpu_baseline(data, [init], [s for it in iters[:n_cpu_iter] for s in it], n_cpu_iter)
-        v = 1.0 / (cb["sec_per_locus_iter"] * 10000.0)
-        cpu = dict(value=round(v, 3), unit="iterations/s (10k-locus A00 iterations, hot path only)",
+        scale = nloci_cfg if args.config != "c2" else 10000.0
+        ac = cb["all_cores"]
+        cpu = dict(value=round(1.0 / (cb["sec_per_locus_iter"] * scale), 3),
+                   unit=f"iterations/s ({int(scale)}-locus A00 iterations, likelihood hot path only: the tape of `likelihood_only`)",
                    cores=cb["cores"], kind=cb["kind"],
                    sample=f"{cb['sampled_loci']} loci x {n_cpu_iter} tape iterations x {cb['repeats']} repeats "
-                          f"({cb['seconds']:.1f}s), same tape as the GPU, AVX2 back-end, 1 thread")
+                          f"({cb['seconds']:.1f}s incl. the all-cores leg), same tape as the GPU, AVX2 back-end",
+                   all_cores=dict(value=round(1.0 / (ac["sec_per_locus_iter"] * scale), 3), cores=ac["workers"],
+                                  host_logical_cores=ac["host_logical_cores"],
+                                  sample=f"{ac['sampled_loci']} loci x {n_cpu_iter} tape iterations x {ac['repeats']} repeats, "
+                                         f"one locus per worker thread at a time (loci are independent: threads.c:87-200)"))
 
     bpp_prog = None
     if rank == 0 and world == 1 and args.config == "c2" and not args.no_cpu_baseline and not args.no_bpp_program:
         try:
             ncores = os.cpu_count() or 1
-            many = max(2, min(64, ncores // 2))
-            r = bpp_program_baseline(nloci, cfg["sites"], [1, many])
+            sweep = [1] + [t for t in (8, 16, 32, 64, 128) if t <= ncores]
+            r = bpp_program_baseline(nloci_cfg, cfg["sites"], sweep)
             if r:
-                bpp_prog = dict(unit="whole MCMC iterations/s of the unmodified reference program (10k loci, A00 JC69), "
-                                     "incl. its MCMC control", threads={str(k): v for k, v in r.items()},
+                best = max((k for k in r if k > 1), key=lambda k: r[k]["median"], default=1)
+                bpp_prog = dict(unit="whole MCMC iterations/s of the unmodified reference program (10k loci, A00 JC69), incl. its MCMC control",
+                                threads={str(k): v for k, v in r.items()}, best_threads=best, best_median=r[best]["median"],
                                 host_logical_cores=ncores, kind="reference",
-                                sample="bpp --simulate data (seed 12345), differential wall time of 20- vs 120-iteration runs")
+                                sample="bpp --simulate data (seed 12345), differential wall time of 20- vs 100-iteration runs, "
+                                       "median / min / max of 3 measurements per thread count (1 thread: one)")
         except Exception as ex:       # noqa: BLE001
             bpp_prog = dict(error=str(ex)[:200])
 
+    # ---- the other single-GPU configurations of BASELINE.json on the same box (tape = likelihood path)
+    others = None
+    if args.config == "c2" and world == 1 and D is None and not args.no_other_configs:
+        others = {}
+        for key, k_steps, k_warm in (("c3", 12, 2), ("c4", 6, 1)):
+            try:
+                oc = CONFIGS[key]
+                t0 = time.time()
+                e2 = bpp_amd.Engine(local_rank, None)
+                d2 = synth.make_dataset(oc["loci"], oc["sites"], oc["taxa"], oc["model"], oc["rate_cats"], seed=12345)
+                l2 = make_loci(e2, d2)
+                a2 = argparse.Namespace(**vars(args))
+                a2.tape_iters = 2
+                a2.loci = None
+                sec, _ = run_tape(e2, oc, key, d2, l2, a2, None, k_steps, k_warm)
+                sec["unit"] = f"iterations/s (one iteration = the A00 proposal schedule over this config's {oc['loci']} loci)"
+                sec["seconds"] = round(time.time() - t0, 1)
+                others[key] = sec
+                e2.close()
+            except Exception as ex:       # noqa: BLE001
+                others[key] = dict(error=str(ex)[:300])
+
     if rank == 0:
+        headline_sampler = sampler_sec is not None and "error" not in sampler_sec
+        parallelism = "1 GPU"
+        if D is not None:
+            parallelism = (f"loci sharded over {world} GPU(s) ({args.scaling}), " +
+                           ("one-shot p2p all-reduce over xGMI (RCCL-checked at start-up)" if D.p2p is not None else "RCCL all-reduce") +
+                           " of the sums the THETA / TAU / MIX steps are decided on")
+        if headline_sampler:
+            value = sampler_sec["iterations_per_s_10k_loci"] if args.scaling == "weak" else sampler_sec["iterations_per_s"]
+            ms_per_step = sampler_sec["ms_per_iteration"]
+            roofline = sampler_sec.pop("roofline")
+            metric = "MCMC iterations/sec (A00), every decision on the device"
+        else:
+            value = (tape_sec["iterations_per_s_10k_loci"] if (args.config == "c2" and args.scaling == "weak") else tape_sec["iterations_per_s"])
+            ms_per_step = tape_sec["ms_per_step"]
+            roofline = tape_sec["roofline"]
+            metric = "A00 iterations/sec of the likelihood hot path (proposal tape)"
+        loci_unit = 10000 if args.config == "c2" else nloci_cfg
         out = {
-            "metric": "MCMC iterations/sec (A00) + site-lnL updates/sec, 10k loci per GPU (likelihood hot path)",
-            "value": round(iters_per_s_10k, 3),
-            "unit": "iterations/s (one iteration = A00 proposal schedule over 10 000 loci)",
+            "metric": metric + " + site-lnL updates/sec, 10k loci, 1/2/4/8 GPU",
+            "value": value,
+            "unit": (f"iterations/s (one iteration = one A00 MCMC iteration over {loci_unit} loci" +
+                     ("; weak scaling: N data sets of that size, value = N x per-rank rate)" if (D is not None and args.scaling == "weak") else ")")),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg["name"] + f"; {nloci} loci/GPU, {npat / nloci:.2f} patterns/locus, "
-                       f"{launches_per_iter:.0f} batched proposal steps/iteration "
-                       f"({it_node_updates / nloci:.1f} node updates + {launches_per_iter:.0f} lnL evals per locus)",
-                       "parallelism": (f"loci sharded over {world} GPU(s), " + ("one-shot p2p all-reduce over xGMI (RCCL-checked at start-up)" if p2p is not None else "RCCL all-reduce") + " of the lnL sum per TAU/MIX step" if world > 1 or dist is not None else "1 GPU")},
-            "site_lnl_updates_per_s": round(site_lnl_updates_per_s),
-            "node_updates_per_iteration": round(float(it_node_updates)),
-            "gflops_partials": round(it_flops * args.steps / elapsed / 1e9, 2),
-            "kernel_tflops": (round(it_flops / launches_per_iter / (tm["partials_ms"] / tm["launches"] * 1e-3) / 1e12, 3)
-                              if tm and tm["launches"] else None),
+            "config": {"workload": cfg["name"] + f"; {nloci} loci on rank 0, {npat / nloci:.2f} patterns/locus" +
+                       (f"; {3 * cfg['taxa'] - 3} gene-tree proposals per locus + {2 * cfg['taxa'] - 1} theta + {cfg['taxa'] - 1} tau + 1 mixing step per iteration" if headline_sampler else ""),
+                       "parallelism": parallelism},
+            "site_lnl_updates_per_s": tape_sec["site_lnl_updates_per_s"] if tape_sec else None,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "reference_program_on_host": bpp_prog,
-            "device_resident_sampler": sampler,
-            "allreduce_check": allreduce_check,
-            "allreduce": (None if dist is None else "p2p one-shot over xGMI peer mappings (bpa_p2p_*), self-tested against RCCL at start-up" if p2p is not None else "RCCL (torch.distributed)"),
+            "device_resident_sampler": sampler_sec,
+            "likelihood_only": tape_sec,
+            "other_configs": others,
+            "allreduce_check": tape_sec["allreduce_check"] if tape_sec else None,
+            "allreduce": (None if D is None else "p2p one-shot over xGMI peer mappings (bpa_p2p_*), self-tested against RCCL at start-up" if D.p2p is not None else "RCCL (torch.distributed)"),
         }
-    for it in plans:
-        for p in it:
-            p.close()
-    p_init.close()
-    if p2p is not None:
-        p2p.close()
+    if D is not None and D.p2p is not None:
+        D.p2p.close()
     eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if D is not None:
+        D.dist.destroy_process_group()
         # RCCL writes its version banner to the C stdout buffer, which a pipe only flushes at exit: push it out now so
         # that the JSON line is the LAST line on stdout
         import ctypes

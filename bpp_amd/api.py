@@ -115,6 +115,7 @@ def lib():
         "bpa_p2p_connect": (i, [vp, vp]),
         "bpa_p2p_allreduce": (i, [vp, vp, u]),
         "bpa_p2p_status": (i, [vp]),
+        "bpa_p2p_set_timeout": (None, [vp, u]),
         "bpa_plans_launch_exchange": (i, [vp, u, vp, vp, u]),
         "bpa_p2p_destroy": (None, [vp]),
         "bpa_batch_evaluate": (i, [vp, C.POINTER(Batch), dp]),
@@ -139,9 +140,13 @@ def lib():
         "bpa_sampler_get_tree": (i, [vp, u, C.POINTER(i), C.POINTER(i), C.POINTER(i), dp, C.POINTER(i),
                                      C.POINTER(i), C.POINTER(i), dp]),
         "bpa_sampler_summary": (i, [vp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
+        "bpa_sampler_enable_timing": (i, [vp, u]),
+        "bpa_sampler_timing": (i, [vp, dp, C.POINTER(C.c_ulong), dp, C.POINTER(C.c_ulong)]),
+        "bpa_sampler_work": (i, [vp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
         "bpa_engine_enable_timing": (None, [vp, i]),
         "bpa_engine_set_timing_stride": (None, [vp, u]),
         "bpa_engine_timing": (i, [vp, dp, dp, dp, C.POINTER(C.c_ulong)]),
+        "bpa_engine_timing_work": (i, [vp, C.POINTER(C.c_ulong), dp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -164,14 +169,15 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
             "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate",
             "bpa_plan_enable_sum", "bpa_plan_enable_partial_sums", "bpa_plan_get_sum",
-            "bpa_p2p_create", "bpa_p2p_connect", "bpa_p2p_allreduce", "bpa_p2p_status", "bpa_p2p_destroy", "bpa_plans_launch_exchange", "bpa_plans_launch",
+            "bpa_p2p_create", "bpa_p2p_connect", "bpa_p2p_allreduce", "bpa_p2p_status", "bpa_p2p_destroy", "bpa_p2p_set_timeout", "bpa_plans_launch_exchange", "bpa_plans_launch",
             "bpa_plan_set_params", "bpa_plan_set_params_device", "bpa_engine_stage",
-            "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride",
+            "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride", "bpa_engine_timing_work",
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
             "bpa_sampler_set_species_tree", "bpa_sampler_set_tip_species", "bpa_sampler_set_finetune",
             "bpa_sampler_set_tau_prior", "bpa_sampler_get_taus", "bpa_sampler_get_tree_msc",
             "bpa_sampler_set_theta_prior", "bpa_sampler_get_thetas", "bpa_sampler_set_allreduce",
-            "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary"]
+            "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary",
+            "bpa_sampler_enable_timing", "bpa_sampler_timing", "bpa_sampler_work"]
 
 
 def _err():
@@ -257,8 +263,10 @@ class Engine:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         n = C.c_ulong()
         _chk(lib().bpa_engine_timing(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        st, by = C.c_ulong(), C.c_double()
+        _chk(lib().bpa_engine_timing_work(self.h, C.byref(st), C.byref(by)))
         return {"pmatrix_ms": a.value, "partials_ms": b.value, "reduce_ms": c.value,
-                "launches": n.value}
+                "launches": n.value, "steps": st.value, "bytes": by.value}
 
     def update_eigen(self, freqs, subst, states):
         ev, iev, evals = np.zeros((states, states)), np.zeros((states, states)), np.zeros(states)
@@ -607,6 +615,23 @@ class Sampler:
         _chk(lib().bpa_sampler_summary(self.h, C.byref(tot), C.byref(p), C.byref(a), C.byref(l)))
         return dict(total_lnl=tot.value, proposals=p.value, accepted=a.value, launches=l.value)
 
+    def enable_timing(self, stride=1):
+        """HIP events on every stride-th sweep / all-loci launch (0: off)"""
+        _chk(lib().bpa_sampler_enable_timing(self.h, int(stride)))
+
+    def timing(self):
+        a, b = C.c_double(), C.c_double()
+        na, nb = C.c_ulong(), C.c_ulong()
+        _chk(lib().bpa_sampler_timing(self.h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
+        return dict(sweep_ms=a.value, sweep_launches=na.value, allloci_ms=b.value, allloci_launches=nb.value)
+
+    def work(self):
+        """algorithmic work of the sweep launches so far"""
+        by = C.c_double()
+        nu, pu, sw = C.c_ulong(), C.c_ulong(), C.c_ulong()
+        _chk(lib().bpa_sampler_work(self.h, C.byref(by), C.byref(nu), C.byref(pu), C.byref(sw)))
+        return dict(bytes=by.value, node_updates=nu.value, pattern_updates=pu.value, sweeps=sw.value)
+
     def close(self):
         if self.h and self.engine.h:
             lib().bpa_sampler_destroy(self.h)
@@ -657,6 +682,10 @@ class P2P:
 
     def status(self):
         return lib().bpa_p2p_status(self.h)
+
+    def set_timeout_ms(self, ms):
+        """bound of a wait inside an exchange (default 3 s)"""
+        lib().bpa_p2p_set_timeout(self.h, int(ms))
 
     def close(self):
         if self.h:

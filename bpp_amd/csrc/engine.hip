@@ -109,7 +109,7 @@ struct bpa_locus
   bool pending = false;
 };
 
-struct TimingSlot { hipEvent_t ev[4]; int ev_used = 4; };   // 2: only ev[1],ev[2] (kernel-attached)
+struct TimingSlot { hipEvent_t ev[4]; int ev_used = 4; unsigned steps = 1; double bytes = 0; };   // ev_used 2: only ev[1],ev[2] (kernel-attached); steps / bytes: proposal steps and algorithmic bytes the launch covers
 
 struct bpa_engine
 {
@@ -150,7 +150,8 @@ struct bpa_engine
   std::vector<TimingSlot> slots;
   size_t slots_used = 0;
   double acc_ms[3] = {0, 0, 0};
-  unsigned long acc_launches = 0;
+  unsigned long acc_launches = 0, acc_steps = 0;      // launches that carried events, proposal steps they covered
+  double acc_bytes = 0;                               // algorithmic bytes of the kernels the events bracketed
   // calls for different loci may come from different host threads (threads.c:87-200 shards loci
   // over pthreads): engine-wide state (dirty list, locus table, stream order, timing) is serialised
   std::recursive_mutex mtx;
@@ -962,6 +963,7 @@ static int timing_drain(bpa_engine * e)
       e->acc_ms[j] += ms;
     }
     e->acc_launches++;
+    e->acc_steps += e->slots[i].steps; e->acc_bytes += e->slots[i].bytes;
   }
   e->slots_used = 0;
   return 1;
@@ -1064,10 +1066,17 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       HIPCHK(hipGetLastError());
       if (p->sum_parts > 1) HIPCHK(hipMemsetAsync(p->sum_out + 1, 0, (p->sum_parts - 1)*sizeof(double), e->stream));
     }
-    if (ts) ts->ev_used = 2;
+    if (ts)
+    {
+      // what the event pair brackets: the one fused kernel (K4 + K1 + K2), or — where the P-matrix phase is its own
+      // launch (the multi-category kernels) — K1 + K2 alone
+      const bool split_a = p->klane_v2 || p->fused_klane;
+      ts->ev_used = 2; ts->steps = 1;
+      ts->bytes = ((mode & 2) ? p->bytes_partials : 0.0) + ((!split_a && (mode & 1) && p->has_mats) ? p->bytes_pmatrix : 0.0);
+    }
     return 1;
   }
-  if (ts) ts->ev_used = 4;
+  if (ts) { ts->ev_used = 4; ts->steps = 1; ts->bytes = (mode & 2) ? p->bytes_partials : 0.0; }
   if (ts) HIPCHK(hipEventRecord(ts->ev[0], e->stream));
   if ((mode & 1) && p->has_mats)
   {
@@ -1211,10 +1220,70 @@ extern "C" int bpa_plan_probe(bpa_plan_t * p, double * out)
   return 1;
 }
 
+// Can this resident plan be a link of a chain launch (step_jc69_v2_chain_kernel)?  JC69 on the compact records of
+// the current packing, a per-locus step (no plan total: an all-loci step is decided on a sum over ALL loci and is a
+// launch of its own).
+static bool chainable(bpa_plan * p)
+{
+  bpa_engine * e = p->eng;
+  return p->fused_bs && p->jc69_v2 && !p->pd.dbg && !p->sum_out && p->has_lnl && p->pack_epoch == e->pack_epoch;
+}
+
+// plans[0..count) as ONE launch
+static int chain_launch(bpa_plan * const * plans, unsigned count)
+{
+  bpa_engine * e = plans[0]->eng;
+  ChainDev c{};
+  c.base = plans[0]->pd;
+  c.base.loci = e->d_loci.p; c.base.bfbeta = e->bfbeta;
+  c.base.lane_tab = e->d_lane_tab.p; c.base.slot_tab = e->d_slot_tab.p; c.base.blk_slot_off = e->d_blk_slot_off.p; c.base.nblocks2 = e->pack_blocks;
+  c.nsteps = count;
+  double bytes = 0;
+  for (unsigned i = 0; i < count; ++i)
+  {
+    const bpa_plan * p = plans[i];
+    ChainStep & st = c.st[i];
+    st.recs2 = p->pd.recs2; st.mat2 = p->pd.mat2; st.mat_length = p->pd.mat_length; st.blk_mat_off = p->pd.blk_mat_off;
+    st.site_term = p->pd.site_term; st.lnl = p->pd.lnl; st.wg_part = nullptr; st.rec2_units = p->pd.rec2_units;
+    st.flags = (p->has_mats ? 1u : 0u) | 2u | 4u;
+    bytes += p->bytes_partials + p->bytes_pmatrix;
+  }
+  TimingSlot * ts = nullptr;
+  if (e->timing && (e->timing_phase++ % e->timing_stride) == 0)
+  {
+    ts = next_slot(e);
+    if (!ts) { if (!timing_drain(e)) return 0; ts = next_slot(e); }
+  }
+  hipEvent_t k0 = ts ? ts->ev[1] : nullptr, k1 = ts ? ts->ev[2] : nullptr;
+  hipExtLaunchKernelGGL((step_jc69_v2_chain_kernel<PACK_BS>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, k0, k1, 0, c);
+  HIPCHK(hipGetLastError());
+  if (ts) { ts->ev_used = 2; ts->steps = count; ts->bytes = bytes; }
+  return 1;
+}
+
 extern "C" int bpa_plans_launch(bpa_plan_t * const * plans, unsigned count)
 {
-  for (unsigned i = 0; i < count; ++i)
+  if (!count) return 1;
+  bpa_engine * e = plans[0]->eng;
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  static const bool no_chain = getenv("BPA_NO_CHAIN") != nullptr;
+  if (!e->usedata) return 1;
+  unsigned i = 0;
+  while (i < count)
+  {
+    // the longest run of consecutive chainable plans of this engine
+    unsigned j = i;
+    if (!no_chain && plans[i]->eng == e && flush(e) && engine_pack(e))
+      while (j < count && j - i < (unsigned)BPA_CHAIN_MAX && plans[j]->eng == e && chainable(plans[j])) ++j;
+    if (j - i >= 2)
+    {
+      if (!set_device(e) || !chain_launch(plans + i, j - i)) return 0;
+      i = j;
+      continue;
+    }
     if (!bpa_plan_launch(plans[i])) return 0;
+    ++i;
+  }
   return 1;
 }
 
@@ -1518,13 +1587,25 @@ extern "C" void bpa_engine_enable_timing(bpa_engine_t * e, int on)
   (void)hipSetDevice(e->device);
   (void)timing_drain(e);
   e->timing = on != 0;
-  e->acc_ms[0] = e->acc_ms[1] = e->acc_ms[2] = 0; e->acc_launches = 0;
+  e->acc_ms[0] = e->acc_ms[1] = e->acc_ms[2] = 0; e->acc_launches = 0; e->acc_steps = 0; e->acc_bytes = 0;
 }
 
 extern "C" void bpa_engine_set_timing_stride(bpa_engine_t * e, unsigned stride)
 {
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   e->timing_stride = stride ? stride : 1; e->timing_phase = 0;
+}
+
+// what the timed launches covered: proposal steps (a chain launch covers several) and the algorithmic bytes (SURVEY.md
+// section 8d) of the kernels whose time bpa_engine_timing reports as partials_ms — roofline.achieved = bytes / partials_ms
+extern "C" int bpa_engine_timing_work(bpa_engine_t * e, unsigned long * steps, double * bytes)
+{
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  if (!set_device(e)) return 0;
+  if (!timing_drain(e)) return 0;
+  if (steps) *steps = e->acc_steps;
+  if (bytes) *bytes = e->acc_bytes;
+  return 1;
 }
 
 extern "C" int bpa_engine_timing(bpa_engine_t * e, double * pmatrix_ms, double * partials_ms,

@@ -2031,17 +2031,18 @@ __global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
 // stride.  Workgroups are the ENGINE's packing (the same loci in the same workgroup in every plan: a locus's CLVs
 // stay in the L2 of the XCD that works on it); loci that are not part of the plan leave their lanes idle.
 // Arithmetic: the very statements of step_jc69_kernel.
+// One step of the workgroup's loci.  ls / S: the lane's entries of the engine's tables (S valid when the lane has a
+// slot), loaded by the caller — once per launch, whether the launch is one step (step_jc69_v2_kernel) or a chain of
+// steps (step_jc69_v2_chain_kernel).
 template <int BS>
-__global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
+__device__ __forceinline__ void jc69_v2_step(const PlanDev & P, const LaneStatic & ls, const SlotStatic & S,
+                                             double * s_term, double2 * s_ab, double * s_lnl)
 {
   constexpr int NPRE = 3;
   constexpr uint32_t NAB = 2*BS;
-  __shared__ double s_term[BS];
-  __shared__ double2 s_ab[NAB];
   static_assert(sizeof(LaneStatic) == 16 && sizeof(SlotStatic) == 80 && sizeof(StepRec) == 16 && sizeof(StepOp) == 16 && sizeof(MatRec2) == 8, "compact records");
-  const uint32_t b = blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
   const uint32_t s0 = P.blk_slot_off[b], s1 = P.blk_slot_off[b+1];
-  const LaneStatic ls = P.lane_tab[gl];
   const bool has_slot = ls.slot != 0xffffffffu;
   const bool do_mats = (P.flags & 1u) != 0;
   const uint32_t e0 = do_mats ? P.blk_mat_off[b] : 0u, e1 = do_mats ? P.blk_mat_off[b+1] : 0u;
@@ -2061,17 +2062,12 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
     c_task = reinterpret_cast<const StepRec *>(P.recs2 + (size_t)(s0 + lane)*P.rec2_units)->task;
   }
   // this lane's records
-  SlotStatic S{};
   StepRec hdr{};
   hdr.task = 0xffffffffu;
   StepOp sl[NPRE];
   const uint4 * rp = P.recs2 + (size_t)(has_slot ? ls.slot : 0u)*P.rec2_units;
   if (has_slot && (P.flags & 6u))
   {
-    const uint4 * sp = reinterpret_cast<const uint4 *>(P.slot_tab + ls.slot);
-    uint4 * sd = reinterpret_cast<uint4 *>(&S);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(SlotStatic)/16); ++i) sd[i] = sp[i];
     *reinterpret_cast<uint4 *>(&hdr) = rp[0];
     uint4 * ds = reinterpret_cast<uint4 *>(sl);
 #pragma unroll
@@ -2266,7 +2262,6 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
     // consumer (a decision kernel, or the host after the all-reduce over the GPUs) adds the workgroups' values up
     if (P.flags & 8u)
     {
-      __shared__ double s_lnl[BS];
       s_lnl[lane] = c_lnl;
       __syncthreads();
       if (lane == 0)
@@ -2276,6 +2271,72 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
         P.wg_part[b] = part;
       }
     }
+  }
+}
+
+template <int BS>
+__device__ __forceinline__ void jc69_v2_statics(const PlanDev & P, LaneStatic & ls, SlotStatic & S)
+{
+  ls = P.lane_tab[blockIdx.x*BS + threadIdx.x];
+  if (ls.slot != 0xffffffffu)
+  {
+    const uint4 * sp = reinterpret_cast<const uint4 *>(P.slot_tab + ls.slot);
+    uint4 * sd = reinterpret_cast<uint4 *>(&S);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(SlotStatic)/16); ++i) sd[i] = sp[i];
+  }
+}
+
+template <int BS>
+__global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
+{
+  __shared__ double s_term[BS], s_lnl[BS];
+  __shared__ double2 s_ab[2*BS];
+  LaneStatic ls; SlotStatic S{};
+  jc69_v2_statics<BS>(P, ls, S);
+  jc69_v2_step<BS>(P, ls, S, s_term, s_ab, s_lnl);
+}
+
+// A CHAIN of steps in one launch: the per-locus proposals of an iteration (GAGE, GSPR: gtree.c:4585, 6531) need nothing
+// from other loci, so a workgroup walks its loci through all of them without coming back to the host — the shape of
+// threads.c:87-200, where a worker walks its loci's proposals without a barrier.  Step k + 1 of a locus reads what step k
+// wrote: CLVs by the same lane, (a, b) pairs by lanes of the same workgroup (the engine's packing never splits a locus),
+// so a workgroup barrier between steps orders them; the tables' entries are loaded once.  Each step keeps its own
+// records and its own result arrays (ChainStep), i.e. a chain of resident plans is launched, not a new kind of plan.
+struct ChainStep
+{
+  const uint4 *    recs2;
+  const MatRec2 *  mat2;
+  const double *   mat_length;
+  const uint32_t * blk_mat_off;
+  double *         site_term;
+  double *         lnl;
+  double *         wg_part;
+  uint32_t         rec2_units, flags;
+};
+constexpr int BPA_CHAIN_MAX = 24;
+struct ChainDev
+{
+  PlanDev   base;                       // the engine's tables (lane_tab, slot_tab, blk_slot_off, loci, bfbeta)
+  uint32_t  nsteps, pad;
+  ChainStep st[BPA_CHAIN_MAX];
+};
+
+template <int BS>
+__global__ void __launch_bounds__(BS) step_jc69_v2_chain_kernel(const ChainDev C)
+{
+  __shared__ double s_term[BS], s_lnl[BS];
+  __shared__ double2 s_ab[2*BS];
+  LaneStatic ls; SlotStatic S{};
+  jc69_v2_statics<BS>(C.base, ls, S);
+  for (uint32_t k = 0; k < C.nsteps; ++k)
+  {
+    PlanDev P = C.base;
+    const ChainStep & st = C.st[k];
+    P.recs2 = st.recs2; P.mat2 = st.mat2; P.mat_length = st.mat_length; P.blk_mat_off = st.blk_mat_off;
+    P.site_term = st.site_term; P.lnl = st.lnl; P.wg_part = st.wg_part; P.rec2_units = st.rec2_units; P.flags = st.flags;
+    jc69_v2_step<BS>(P, ls, S, s_term, s_ab, s_lnl);
+    __syncthreads();                    // the next step reuses the LDS arrays and reads this step's (a, b) pairs
   }
 }
 

@@ -67,6 +67,7 @@ struct bpa_p2p
   DevBuf<unsigned char *> d_peer;
   DevBuf<int> d_err;
   unsigned long long seq = 0;
+  unsigned long long spin_limit = 300000000ull;    // bound of a wait in ticks of the 100 MHz counter: 3 s (bpa_p2p_set_timeout)
   bool connected = false;
 };
 
@@ -127,9 +128,15 @@ extern "C" int bpa_p2p_allreduce(bpa_p2p_t * p, double * device_values, unsigned
   if (!set_device(p->eng)) return 0;
   p->seq++;
   hipLaunchKernelGGL(p2p::allreduce_kernel, dim3(1), dim3(512), 0, p->eng->stream, device_values, n, p->d_peer.p, p->mail, p->rank, p->world,
-                     p->seq, p->slot_bytes, p->d_err.p, 300000000ull /* 3 s at 100 MHz */);
+                     p->seq, p->slot_bytes, p->d_err.p, p->spin_limit);
   HIPCHK(hipGetLastError());
   return 1;
+}
+
+extern "C" void bpa_p2p_set_timeout(bpa_p2p_t * p, unsigned milliseconds)
+{
+  std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
+  p->spin_limit = (unsigned long long)(milliseconds ? milliseconds : 1u)*100000ull;
 }
 
 extern "C" int bpa_plans_launch_exchange(bpa_plan_t * const * plans, unsigned count, bpa_p2p_t * p, double * device_values, unsigned n)

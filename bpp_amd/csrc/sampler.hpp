@@ -39,7 +39,7 @@ struct Tree                                // one per locus, in HBM and (while s
   a00_rng_t rng;
   int32_t  root, tips;
   uint32_t proposals, accepted;
-  uint64_t pad_;
+  uint32_t sw_nupd, sw_nbr;                // work of the sweep launches: node updates run / fresh branches (bpa_sampler_work)
 };
 static_assert(sizeof(Tree) % 16 == 0 && offsetof(Tree, lnl) % 16 == 0, "Tree is copied as uint4");
 
@@ -568,7 +568,8 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   if (leader)
   {
     TaskLDS & S = s_task[ts];
-    if (restore_mix) { S.tr.rng = A.trees[task].rng; S.tr.proposals = A.trees[task].proposals; S.tr.accepted = A.trees[task].accepted; }
+    if (restore_mix) { S.tr.rng = A.trees[task].rng; S.tr.proposals = A.trees[task].proposals; S.tr.accepted = A.trees[task].accepted;
+                       S.tr.sw_nupd = A.trees[task].sw_nupd; S.tr.sw_nbr = A.trees[task].sw_nbr; }
     if (A.mode == 0) density_prepare<NT>(S, sp, (1u << sp.npop) - 1u);      // the current terms: counts here, terms by the lanes below
     S.nops = 0; S.active = 0;
     S.prof_on = (A.dbg & 8u) && b == 0 && ts == 0; for (int i = 0; i < 8; ++i) S.prof[i] = 0;
@@ -712,6 +713,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       S.logpr_new = density_sum(S, sp);
       if (A.mode == 0)
       {
+        S.tr.sw_nupd += (uint32_t)S.nops; S.tr.sw_nbr += (uint32_t)__popc(S.brm);
         const double lnacc = (S.logpr_new - S.tr.logpr) + (lnl - S.tr.lnl) + S.hast;
         const double u = rndu(&S.tr.rng);
         S.tr.proposals++;
@@ -917,6 +919,11 @@ struct bpa_sampler
   DevBuf<int8_t> pop_nc;
   smp::Species sp{};                    // species tree (host copy; the taus below are only the start values)
   bool has_theta[smp::MAXPOP] = {};     // populations that can hold a coalescence (a00_initialize)
+  // kernel timing (bpa_sampler_enable_timing): start / stop events attached to every stride-th launch, by kind
+  struct Timed { hipEvent_t e0, e1; int kind; };
+  std::vector<Timed> timed;
+  unsigned timing_stride = 0, timing_phase = 0;      // 0: off
+  double timed_ms[2] = {0, 0}; unsigned long timed_n[2] = {0, 0};     // 0 sweep (GAGE + GSPR of every locus), 1 all-loci step (TAU / MIX)
   bpa_allreduce_fn allreduce = nullptr; // several GPUs: sum the all-loci steps' device scalar over the ranks
   void * allreduce_ctx = nullptr;
   double * sum_ext = nullptr;           // caller-owned device scalar for that sum (NULL: internal)
@@ -930,7 +937,7 @@ struct bpa_sampler
   uint32_t env_dbg = 0; int env_gage = -1, env_gspr = -1; bool env_trace = false, env_nomix = false;
   bool mix_pending = false;             // a mixing decision taken on the device has not been applied yet
   a00_rng_t grng = 0;
-  unsigned long seed = 0, launches = 0;
+  unsigned long seed = 0, launches = 0, sweeps = 0;
   bool uploaded = false;
 };
 
@@ -970,6 +977,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   (void)set_device(s->eng);
   (void)hipStreamSynchronize(s->eng->stream);
+  for (auto & t : s->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   s->blk_task_off.free(); s->lane_rec.free(); s->task_rec.free(); s->flag.free();
   s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free(); s->wg_part.free();
   delete s;
@@ -1089,6 +1097,21 @@ static int sampler_upload(bpa_sampler * s)
   return 1;
 }
 
+static int sampler_timing_drain(bpa_sampler * s)
+{
+  if (s->timed.empty()) return 1;
+  HIPCHK(hipStreamSynchronize(s->eng->stream));
+  for (auto & t : s->timed)
+  {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, t.e0, t.e1));
+    s->timed_ms[t.kind] += ms; s->timed_n[t.kind]++;
+    (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1);
+  }
+  s->timed.clear();
+  return 1;
+}
+
 static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double mix_lnc = 0, unsigned tau_q = 0, double tau_u = 0)
 {
   bpa_engine * e = s->eng;
@@ -1139,7 +1162,16 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
     s->launches++;
     return 1;
   }
-  hipLaunchKernelGGL(kern, dim3(s->nblocks), dim3(smp::BS), lds, e->stream, a);
+  if (s->timing_stride && (mode == 0 || mode == 1 || mode == 4) && (s->timing_phase++ % s->timing_stride) == 0)
+  {
+    if (s->timed.size() >= 4096 && !sampler_timing_drain(s)) return 0;
+    bpa_sampler::Timed t{nullptr, nullptr, mode == 0 ? 0 : 1};
+    HIPCHK(hipEventCreate(&t.e0)); HIPCHK(hipEventCreate(&t.e1));
+    hipExtLaunchKernelGGL(kern, dim3(s->nblocks), dim3(smp::BS), lds, e->stream, t.e0, t.e1, 0, a);
+    s->timed.push_back(t);
+  }
+  else
+    hipLaunchKernelGGL(kern, dim3(s->nblocks), dim3(smp::BS), lds, e->stream, a);
   HIPCHK(hipGetLastError());
   s->launches++;
   return 1;
@@ -1285,6 +1317,7 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
   for (unsigned it = 0; it < iterations; ++it)
   {
     if (!sampler_launch(s, 0, 1.0)) return 0;                    // GAGE + GSPR of every locus (settles a pending mix first)
+    s->sweeps++;
     if (s->env_nomix) continue;
     if (s->sp.theta_alpha > 0)
     {
@@ -1364,6 +1397,49 @@ extern "C" int bpa_sampler_get_tree_msc(bpa_sampler_t * s, unsigned i, int * pop
   const smp::Tree & t = s->h_trees[i];
   if (pop) for (int k = 0; k < 2*t.tips - 1; ++k) pop[k] = t.pop[k];
   if (logpr) *logpr = t.logpr;
+  return 1;
+}
+
+extern "C" int bpa_sampler_enable_timing(bpa_sampler_t * s, unsigned stride)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (!set_device(s->eng) || !sampler_timing_drain(s)) return 0;
+  s->timing_stride = stride; s->timing_phase = 0;
+  s->timed_ms[0] = s->timed_ms[1] = 0; s->timed_n[0] = s->timed_n[1] = 0;
+  return 1;
+}
+
+extern "C" int bpa_sampler_timing(bpa_sampler_t * s, double * sweep_ms, unsigned long * sweep_launches,
+                                  double * allloci_ms, unsigned long * allloci_launches)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (!set_device(s->eng) || !sampler_timing_drain(s)) return 0;
+  if (sweep_ms) *sweep_ms = s->timed_ms[0];
+  if (sweep_launches) *sweep_launches = s->timed_n[0];
+  if (allloci_ms) *allloci_ms = s->timed_ms[1];
+  if (allloci_launches) *allloci_launches = s->timed_n[1];
+  return 1;
+}
+
+// algorithmic work of the sweep launches so far, by the formulas of SURVEY.md section 8d (JC69, one rate category:
+// K1 96 Np + 256 B per node update, K2 36 Np B per evaluated proposal, K4 128 B per fresh P-matrix)
+extern "C" int bpa_sampler_work(bpa_sampler_t * s, double * bytes, unsigned long * node_updates,
+                                unsigned long * pattern_updates, unsigned long * sweeps)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (!sampler_download(s)) return 0;
+  double by = 0; unsigned long nu = 0, pu = 0;
+  for (unsigned i = 0; i < s->nloci; ++i)
+  {
+    const smp::Tree & t = s->h_trees[i];
+    const double np = s->loci[i]->sites;
+    by += t.sw_nupd*(96.0*np + 256.0) + t.proposals*36.0*np + t.sw_nbr*128.0;
+    nu += t.sw_nupd; pu += (unsigned long)t.sw_nupd*s->loci[i]->sites;
+  }
+  if (bytes) *bytes = by;
+  if (node_updates) *node_updates = nu;
+  if (pattern_updates) *pattern_updates = pu;
+  if (sweeps) *sweeps = s->sweeps;
   return 1;
 }
 

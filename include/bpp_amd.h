@@ -216,7 +216,10 @@ void         bpa_plan_destroy(bpa_plan_t *);
 int          bpa_plan_set_lengths(bpa_plan_t *, const double * mat_length);
 /* enqueue the step on the engine's stream; results stay on the device             */
 int          bpa_plan_launch(bpa_plan_t *);
-/* enqueue several steps back to back (one host call)                               */
+/* enqueue several steps back to back (one host call).  Consecutive per-locus steps — JC69 plans on the engine's
+   packing without a plan total (bpa_plan_enable_sum / _partial_sums mark the all-loci steps) — go out as ONE chain
+   launch in which a workgroup walks its loci through all of them (threads.c:87-200: a worker walks its loci's
+   proposals without a barrier); results land in each plan's own arrays as if launched one by one.               */
 int          bpa_plans_launch(bpa_plan_t * const * plans, unsigned count);
 /* copy the nloci log-likelihoods of the last launch to the host (synchronises)    */
 int          bpa_plan_get_lnl(bpa_plan_t *, double * lnl);
@@ -298,6 +301,16 @@ int  bpa_sampler_get_tree(bpa_sampler_t *, unsigned i, int * left, int * right, 
 int  bpa_sampler_get_tree_msc(bpa_sampler_t *, unsigned i, int * pop, double * logpr);
 int  bpa_sampler_summary(bpa_sampler_t *, double * total_lnl, unsigned long * proposals,
                          unsigned long * accepted, unsigned long * launches);
+/* measurement: HIP start/stop events on every stride-th launch of the sampler's likelihood-carrying kernels
+   (stride 0 = off); bpa_sampler_timing returns the milliseconds and launch counts accumulated since, by kind: the
+   sweep (the per-locus GAGE + GSPR proposals of an iteration, one launch) and the all-loci steps (TAU, MIX)       */
+int  bpa_sampler_enable_timing(bpa_sampler_t *, unsigned stride);
+int  bpa_sampler_timing(bpa_sampler_t *, double * sweep_ms, unsigned long * sweep_launches,
+                        double * allloci_ms, unsigned long * allloci_launches);
+/* algorithmic work of all sweep launches so far (K1 bytes per node update actually run, K2 per
+   evaluated proposal, K4 per fresh P-matrix), their node and pattern-node updates, and the number of sweeps        */
+int  bpa_sampler_work(bpa_sampler_t *, double * bytes, unsigned long * node_updates,
+                      unsigned long * pattern_updates, unsigned long * sweeps);
 
 /* ------------------------------------------------------ work / measurement --- */
 /* Algorithmic work of one launch of the plan, by the formulas of SURVEY.md §8(d):
@@ -315,6 +328,9 @@ void bpa_engine_enable_timing(bpa_engine_t *, int on);
 void bpa_engine_set_timing_stride(bpa_engine_t *, unsigned stride);
 int  bpa_engine_timing(bpa_engine_t *, double * pmatrix_ms, double * partials_ms,
                        double * reduce_ms, unsigned long * launches);
+/* what those timed launches covered: the proposal steps (a chain launch of bpa_plans_launch covers several) and the
+   algorithmic bytes, by the formulas above, of the kernels partials_ms is the time of                              */
+int  bpa_engine_timing_work(bpa_engine_t *, unsigned long * steps, double * bytes);
 
 /* ---- several GPUs of one node: one-shot sum all-reduce of a few hundred doubles over xGMI peer mappings -----------
    The only exchange of a sharded run is the sum an all-loci proposal is decided on (SURVEY.md section 8e;
@@ -332,6 +348,9 @@ int          bpa_p2p_connect(bpa_p2p_t *, const void * handles);
 int          bpa_p2p_allreduce(bpa_p2p_t *, double * device_values, unsigned n);
 /* bpa_plans_launch followed by bpa_p2p_allreduce in one host call (a sharded step: launch, then exchange its sums) */
 int          bpa_plans_launch_exchange(bpa_plan_t * const * plans, unsigned count, bpa_p2p_t *, double * device_values, unsigned n);
+/* bound of a wait inside an exchange (default 3 000 ms): after a time-out every later exchange returns at once and
+   bpa_p2p_status reports 1 — inside a timed region choose milliseconds, so a lost flag voids the run, not the clock */
+void         bpa_p2p_set_timeout(bpa_p2p_t *, unsigned milliseconds);
 int          bpa_p2p_status(bpa_p2p_t *);
 void         bpa_p2p_destroy(bpa_p2p_t *);
 

@@ -34,8 +34,16 @@ def main():
         return True
     if world > 1:
         smp.set_allreduce(allreduce, t.data_ptr(), first)
-    parent, tau, theta = synth.species_tree_arrays(4)
-    smp.set_species_tree(parent, tau, theta)
+    if os.environ.get("DIST_MIXED"):
+        # three species ((0,1),2); the gene tips A,B,C,D sit in species 0,0,1,2 in the first half of the loci and in
+        # 0,1,1,2 in the second: which tip species can hold a coalescence differs between the two ranks' shares
+        parent, tau, theta = [3, 3, 4, 4, -1], [0, 0, 0, 0.001, 0.003], [0.002]*5
+        smp.set_species_tree(parent, tau, theta)
+        for i in range(per):
+            smp.set_tip_species(i, [0, 0, 1, 2] if first + i < len(data)//2 else [0, 1, 1, 2])
+    else:
+        parent, tau, theta = synth.species_tree_arrays(4)
+        smp.set_species_tree(parent, tau, theta)
     smp.set_tau_prior(3.0, 1000.0)
     smp.set_theta_prior(2.0, 1000.0, 0.001)
     smp.set_finetune(0.003, 0.005, 0.0008, 0.2)

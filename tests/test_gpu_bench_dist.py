@@ -1,6 +1,8 @@
 """bench.py's N > 1 path end to end on the one-GPU test box: two ranks (gloo instead of RCCL, both on device 0) run the
-sharded tape with the per-step all-reduce of the partial sums and the sharded device-resident sampler; the line rank 0
-prints must be the last line on stdout, carry the whole-job rate and pass its own all-reduce self-check."""
+sharded device-resident sampler (the headline) and the sharded tape with the per-step all-reduce of the partial sums —
+under weak scaling (every rank its own data set) and strong scaling (ONE data set dealt out by the reference's zig-zag,
+threads.c:265-353), over the default exchange (the framework's collective) and over the one-shot p2p exchange; the line
+rank 0 prints must be the last line on stdout, carry the whole-job rate and pass its own all-reduce self-check."""
 import json
 import os
 import socket
@@ -13,20 +15,31 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_bench_line():
+def run_bench(extra):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--loci", "1500", "--no-cpu-baseline"]
+           "--loci", "1500", "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = r.stdout.strip().splitlines()[-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+@pytest.mark.parametrize("p2p", [False, True])
+def test_two_rank_bench_line(scaling, p2p):
+    d, err = run_bench(["--scaling", scaling] + (["--p2p-sums"] if p2p else []))
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == scaling and d["value"] > 0
     assert d["allreduce_check"] == "ok"
-    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
-    smp = d["device_resident_sampler"]
+    assert ("p2p" in d["allreduce"]) == p2p, (d["allreduce"], err[-1500:])
+    assert d["roofline"]["frac"] > 0 and "sweep_kernel" in d["roofline"]["kernel"] and d["cpu_baseline"] is None
+    smp, tp = d["device_resident_sampler"], d["likelihood_only"]
+    # strong: the 1 500 loci are shared out (750 each); weak: 1 500 per rank
+    total = 1500 if scaling == "strong" else 3000
+    assert smp["loci_total"] == total and tp["loci_total"] == total
     assert smp["n_gpus"] == 2 and smp["iterations_per_s"] > 0 and 0.2 < smp["acceptance"] < 0.9
+    assert d["value"] == (smp["iterations_per_s"] if scaling == "strong" else smp["iterations_per_s_10k_loci"])
+    assert tp["roofline"]["frac"] > 0 and tp["roofline"]["proposal_steps"] >= tp["roofline"]["launches"]

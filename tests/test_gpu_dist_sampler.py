@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run(world, out, port):
+def run(world, out, port, **extra):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_sampler_worker.py"), out], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
@@ -39,3 +39,20 @@ def test_two_ranks_walk_the_single_rank_trajectory(tmp_path):
     assert np.allclose(lnl, one["lnl"], rtol=1e-10, atol=0)
     tot = sum(r["summary"]["total_lnl"] for r in two)
     assert abs(tot - one["summary"]["total_lnl"]) < 1e-9 * abs(tot)
+
+
+def test_ranks_with_different_sampling_configurations(tmp_path):
+    """which populations can hold a coalescence (and so get a THETA step, two draws of the shared global stream each) is
+    a property of ALL loci: here species 0 has two sequences only in rank 0's loci and species 1 only in rank 1's —
+    the mask is OR-ed over the ranks at upload, so both ranks keep drawing the same numbers and walk the single-rank
+    trajectory"""
+    one = run(1, str(tmp_path / "one"), 29711, DIST_MIXED="1")[0]
+    two = run(2, str(tmp_path / "two"), 29712 + os.getpid() % 500, DIST_MIXED="1")
+    assert two[0]["taus"] == two[1]["taus"] and two[0]["thetas"] == two[1]["thetas"]
+    for r in two:
+        assert np.allclose(r["taus"], one["taus"], rtol=1e-10, atol=0)
+        assert np.allclose(r["thetas"], one["thetas"], rtol=1e-10, atol=0)
+    # both tip species' thetas moved (a rank without such loci still takes part in their steps)
+    assert one["thetas"][0] != 0.002 and one["thetas"][1] != 0.002 and one["thetas"][2] == 0.002
+    lnl = two[0]["lnl"] + two[1]["lnl"]
+    assert np.allclose(lnl, one["lnl"], rtol=1e-10, atol=0)

@@ -81,3 +81,50 @@ def test_gtr_tape_with_substitution_parameter_proposals(engine, taxa, R, nloci):
         mine = np.array([got[s["step"]][s["task"]] for s in sub])
         assert np.all(np.abs(mine - want) <= 1e-12 * np.abs(want)), (li, np.max(np.abs(mine - want) / np.abs(want)))
     allp.close()
+
+
+@pytest.mark.parametrize("taxa,scaling,nloci", [(4, False, 700), (8, True, 90)])
+def test_chain_launch_equals_step_by_step(taxa, scaling, nloci):
+    """bpa_plans_launch sends consecutive per-locus steps out as ONE chain launch (step_jc69_v2_chain_kernel): every
+    step's per-locus lnL, and the CLVs / scalers / P-matrices left behind, are the bits of the launches one by one"""
+    data = synth.make_dataset(nloci, 500, taxa, "jc69", 1, seed=33)
+    runs = []
+    for chained in (False, True):
+        eng = bpp_amd.Engine(0)
+        loci = tape.make_engine_loci(eng, data, scaling)
+        sch = tape.make_schedule(data, seed=9, scaling=scaling)
+        steps = [sch.initial_step()]
+        for _ in range(2):
+            steps += sch.iteration()
+        plans = []
+        for st in steps:
+            p = tape.plan_for_step(eng, loci, st)
+            if st.global_decision is not None:
+                p.enable_partial_sums()                  # an all-loci step: its own launch, never a link of a chain
+            plans.append(p)
+        if chained:
+            eng.enable_timing(True)
+            bpp_amd.PlanSequence(plans).launch()
+            tm = eng.timing()
+            eng.enable_timing(False)
+            per_locus = sum(1 for st in steps if st.global_decision is None)
+            # chains cover the per-locus steps: fewer launches than steps, every step accounted for
+            assert tm["steps"] == len(steps) and tm["launches"] <= len(steps) - per_locus + 2*3 and tm["bytes"] > 0
+        else:
+            for p in plans:
+                p.launch()
+        lnl = [p.lnl() for p in plans]
+        tr = sch.trees[0]
+        clv = [loci[0].get_clv(len(data[0]["seqs"]) + c) for c in range(2*(taxa - 1))]
+        pm = [loci[0].get_pmatrix(c) for c in range(2*(2*taxa - 2))]
+        sc = [loci[0].get_scaler(c) for c in range(2*(taxa - 1))] if scaling else []
+        runs.append((lnl, clv, pm, sc, loci[0].root_loglikelihood(tr.clv[tr.root], tr.scaler[tr.root])))
+        for p in plans:
+            p.close()
+        eng.close()
+    a, b = runs
+    assert all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
+    assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+    assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
+    assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+    assert a[4] == b[4]
