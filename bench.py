@@ -521,6 +521,7 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
         smp.iterate(warmup)
         sync()
         w0 = smp.work()
+        l0 = smp.summary()["launches"]
         smp.enable_timing(args.event_stride if not args.no_timing_events else 0)
         t0 = time.perf_counter()
         smp.iterate(steps)
@@ -528,6 +529,7 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
         dt = time.perf_counter() - t0
         tm = smp.timing()
         smp.enable_timing(0)
+        l1 = smp.summary()["launches"]
         w1 = smp.work()
         if D is None or D.p2p is None:
             break
@@ -562,7 +564,7 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
     out = dict(iterations_per_s=round(steps / dt, 3), iterations_per_s_10k_loci=round(steps / dt * total_loci / 10000.0, 3),
                ms_per_iteration=round(1e3 * dt / steps, 5), steps=steps, warmup=warmup, n_gpus=world, loci_total=total_loci,
                proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
-               launches_per_iteration=(2 if D is None else 3) + (2 if D is None else 3) * (npop_inner + 1),
+               launches_per_iteration=round((l1 - l0 - 1) / steps, 2),      # (-1: the settle launch of the first summary)
                acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
                taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
                thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],

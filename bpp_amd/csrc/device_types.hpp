@@ -109,8 +109,8 @@ struct SlotStatic
   uint32_t   np, tips_n, lane0, locus;       // lane0: global lane of pattern 0
   uint32_t   unphased_length, rate_cats, model, pstride;
   const uint8_t * tips;                      // tip state codes [tips][np]: read by loci of more than 8 tips (their codes do not fit the lane entry)
-  uint64_t   pad;
-};
+  double     rate0;                          // the locus's first category rate (the only one of a JC69 / one-category locus): the P-matrix
+};                                           // lanes of step_jc69_v2_kernel read it here instead of chasing par
 struct StepRec                               // 16 B, followed by the step's StepOps (16 B each)
 {
   uint32_t task;                             // index of the locus in this plan, 0xffffffff: not part of it

@@ -547,6 +547,7 @@ static int flush_state(bpa_engine * e)
         HIPCHK(hipMemcpy(l->dev.par + off, l->par.data() + off, (S + S*(S-1)/2)*sizeof(double), hipMemcpyHostToDevice));
       }
       l->par_dirty = false;
+      if (l->rate_cats == 1 && l->dev.model == 0) e->pack_dirty = true;       // the slot table carries a JC69 locus's rate
     }
     if (need_eig) { eig.push_back(l->id); std::fill(l->eigen_valid.begin(), l->eigen_valid.end(), 1); }
   }
@@ -599,6 +600,7 @@ static int engine_pack(bpa_engine * e)
     st.clv = l->dev.clv; st.pmat = l->dev.pmat; st.scaler = l->dev.scaler; st.par = l->dev.par;
     st.np = np; st.tips_n = l->tips; st.lane0 = (uint32_t)((blk.size() - 1)*PACK_BS + used); st.locus = l->id;
     st.unphased_length = l->dev.unphased_length; st.rate_cats = R; st.model = l->dev.model; st.pstride = l->dev.pstride; st.tips = l->dev.tips;
+    st.rate0 = l->par[par_rates(R)];
     slots.push_back(st);
     slot_of[l->id] = (int32_t)slot;
     shape.push_back(l->id); shape.push_back(np*R); shape.push_back(l->tips);

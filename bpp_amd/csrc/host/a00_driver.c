@@ -2,9 +2,14 @@
  * a00_driver.c — host-side MCMC control in plain C over the likelihood boundary
  * (include/bpp_amd_host.h): gene trees of all loci under the multispecies coalescent on a fixed
  * species tree, the per-locus loops of BPP's proposals hoisted into lock-step batches ("step j of
- * every locus").  Each move states the reference routine it follows; the window kernels are uniform
- * where BPP draws from a Bactrian-Laplace (legacy_rnd_symmetrical, random.c:230) — same target
- * distribution, our own random streams.
+ * every locus").  Each move states the reference routine it follows.  Two proposal kernels
+ * (a00_set_proposal_kernel): uniform windows on our own 64-bit streams (default; what the device-resident
+ * sampler runs too), or BPP's own — legacy_rndu streams and the Bactrian-Laplace window of
+ * legacy_rnd_symmetrical (random.c:104-122, 192-238), restated in bpp_amd_host.h.  BPP's trajectory itself
+ * is out of reach of ANY batched driver: gtree_propose_ages_serial / gtree_propose_spr_serial
+ * (gtree.c:5836 ff.) run locus by locus on ONE generator per thread, so the n-th number of the stream
+ * reaches "proposal j of locus i" in locus-major order, while "step j of every locus" — the batch the GPU
+ * needs — consumes in proposal-major order; streams here are per locus for that reason.
  */
 #define _POSIX_C_SOURCE 199309L     /* clock_gettime (the A00_PROF step profile) */
 #include <time.h>
@@ -24,6 +29,8 @@ struct a00_driver
   void * ctx;
   a00_rng_t * rng;                      /* one stream per locus */
   a00_rng_t grng;                       /* global stream (mixing step) */
+  int kernel;                           /* A00_KERNEL_UNIFORM / A00_KERNEL_BPP */
+  unsigned int * zrng, gz;              /* A00_KERNEL_BPP: legacy_rndu states, per locus and global */
   /* step scratch */
   unsigned * s_locus; a00_tree_t ** s_tree; unsigned * s_br_off, * s_nd_off;
   int * s_br, * s_nd; size_t cap_br, cap_nd;
@@ -58,6 +65,37 @@ static void swap_pmat(a00_tree_t * t, int i)
   t->pmat[i] = (t->pmat[i] + edges) % (2*edges);
 }
 
+/* ---- the two proposal kernels (bpp_amd_host.h); stream i >= 0: locus i, i < 0: the global one */
+static double draw_u(a00_driver_t * d, long i)
+{
+  if (d->kernel == A00_KERNEL_BPP) return a00_bpp_rndu(i < 0 ? &d->gz : d->zrng + i);
+  return a00_rndu(i < 0 ? &d->grng : d->rng + i);
+}
+/* a sliding-window step in units of the finetune: uniform on (-1/2, 1/2), or BPP's Bactrian-Laplace variate */
+static double draw_window(a00_driver_t * d, long i)
+{
+  if (d->kernel == A00_KERNEL_BPP) return a00_bpp_rnd_symmetrical(i < 0 ? &d->gz : d->zrng + i);
+  return a00_rndu(i < 0 ? &d->grng : d->rng + i) - 0.5;
+}
+/* a proposal that cannot be made: the uniform kernel keeps the streams in step with the device sampler (a fixed
+   number of draws per proposal); BPP draws nothing */
+static void skip_u(a00_driver_t * d, long i) { if (d->kernel != A00_KERNEL_BPP) (void)draw_u(d, i); }
+/* Metropolis-Hastings acceptance; u0: a uniform drawn in advance (uniform kernel, all-loci steps), < 0 = draw now */
+static int accept(a00_driver_t * d, long i, double lnacc, double u0)
+{
+  if (d->kernel == A00_KERNEL_BPP) return lnacc >= -1e-10 || a00_bpp_rndu(i < 0 ? &d->gz : d->zrng + i) < exp(lnacc);
+  if (u0 < 0) u0 = draw_u(d, i);
+  return lnacc >= 0 || u0 < exp(lnacc);
+}
+
+void a00_set_proposal_kernel(a00_driver_t * d, int kind) { d->kernel = kind == A00_KERNEL_BPP ? A00_KERNEL_BPP : A00_KERNEL_UNIFORM; }
+
+void a00_bpp_kernel_sequence(unsigned int seed, int symmetrical, int n, double * out)
+{
+  int k;
+  for (k = 0; k < n; ++k) out[k] = symmetrical ? a00_bpp_rnd_symmetrical(&seed) : a00_bpp_rndu(&seed);
+}
+
 static void snapshot(a00_driver_t * d, unsigned i)
 {
   a00_tree_t * t = d->trees + i; const size_t n = (size_t)t->n;
@@ -85,6 +123,10 @@ a00_driver_t * a00_create(unsigned nloci, a00_eval_fn eval, void * ctx, unsigned
   d->rng = (a00_rng_t *)calloc(nloci, sizeof(a00_rng_t));
   for (q = 0; q < nloci; ++q) d->rng[q] = a00_rng_seed(seed, q);
   d->grng = a00_rng_seed(seed, A00_GLOBAL_STREAM);
+  /* the legacy_rndu states of A00_KERNEL_BPP: 32 bits of the same seeding function */
+  d->zrng = (unsigned int *)calloc(nloci, sizeof(unsigned int));
+  for (q = 0; q < nloci; ++q) d->zrng[q] = (unsigned int)(d->rng[q] >> 16);
+  d->gz = (unsigned int)(d->grng >> 16);
   d->trees = (a00_tree_t *)calloc(nloci, sizeof(a00_tree_t));
   d->s_locus = (unsigned *)calloc(nloci, sizeof(unsigned));
   d->s_tree = (a00_tree_t **)calloc(nloci, sizeof(a00_tree_t *));
@@ -115,7 +157,7 @@ void a00_destroy(a00_driver_t * d)
     free(d->u_left[i]); free(d->u_right[i]); free(d->u_parent[i]); free(d->u_clv[i]); free(d->u_pmat[i]);
     free(d->u_scaler[i]); free(d->u_time[i]);
   }
-  free(d->rng); free(d->trees); free(d->s_locus); free(d->s_tree); free(d->s_br_off); free(d->s_nd_off); free(d->s_br);
+  free(d->rng); free(d->zrng); free(d->trees); free(d->s_locus); free(d->s_tree); free(d->s_br_off); free(d->s_nd_off); free(d->s_br);
   free(d->s_logpr); free(d->p_logpr); free(d->p_delta); free(d->p_slot); free(d->u_pop);
   free(d->s_nd); free(d->s_lnl); free(d->s_hast); free(d->u_left); free(d->u_right); free(d->u_parent);
   free(d->u_clv); free(d->u_pmat); free(d->u_scaler); free(d->u_time); free(d->u_root); free(d);
@@ -350,9 +392,8 @@ static void decide(a00_driver_t * d, unsigned n)
   {
     const unsigned i = d->s_locus[s]; a00_tree_t * t = d->trees + i;
     const double lnacc = (d->s_logpr[s] - t->logpr) + (d->s_lnl[s] - t->lnl) + d->s_hast[s];
-    const double u = a00_rndu(&d->rng[i]);
     d->proposals++;
-    if (lnacc >= 0 || u < exp(lnacc)) { t->lnl = d->s_lnl[s]; t->logpr = d->s_logpr[s]; d->accepted++; }
+    if (accept(d, (long)i, lnacc, -1.0)) { t->lnl = d->s_lnl[s]; t->logpr = d->s_logpr[s]; d->accepted++; }
     else restore(d, i);                                  /* swap indices, ages, populations, topology back */
   }
 }
@@ -367,14 +408,14 @@ static int gage_step(a00_driver_t * d, int k)
     a00_tree_t * t = d->trees + i; int v = -1, c = 0, j, nb = 0, nn, p, l, r; double lo, hi, u, tnew;
     for (j = 0; j < t->n; ++j) if (t->left[j] >= 0 && c++ == k) { v = j; break; }
     if (v < 0) continue;
-    u = a00_rndu(&d->rng[i]);
+    u = draw_window(d, (long)i);
     l = t->left[v]; r = t->right[v]; p = t->parent[v];
     lo = fmax(t->time[l], t->time[r]);
     if (t->pop[l] != t->pop[r]) lo = fmax(lo, d->tau[lca_pop(d, t->pop[l], t->pop[r])]);
     hi = p >= 0 ? t->time[p] : 999.0;
-    if (!(hi > lo)) { (void)a00_rndu(&d->rng[i]); continue; }
+    if (!(hi > lo)) { skip_u(d, (long)i); continue; }
     snapshot(d, i);
-    tnew = a00_reflect(t->time[v] + d->ft_gage*(u - 0.5), lo, hi);
+    tnew = a00_reflect(t->time[v] + d->ft_gage*u, lo, hi);
     t->time[v] = tnew;
     t->pop[v] = climb(d, t->pop[l], tnew);
     d->s_hast[n] = 0;
@@ -426,7 +467,7 @@ static int gspr_step(a00_driver_t * d, int k)
     double lo, tnew, u1, u2;
     for (j = 0; j < t->n; ++j) if (j != t->root && c++ == k) { a = j; break; }
     if (a < 0) continue;
-    u1 = a00_rndu(&d->rng[i]); u2 = a00_rndu(&d->rng[i]);
+    u1 = draw_window(d, (long)i); u2 = draw_u(d, (long)i);
     p = t->parent[a]; s = t->left[p] == a ? t->right[p] : t->left[p]; g = t->parent[p];
     /* youngest population from a's upwards that holds gene tips outside a's subtree (gtree.c:6664-6669) */
     for (j = 0; j < d->npop; ++j) gl[j] = 0;
@@ -434,7 +475,7 @@ static int gspr_step(a00_driver_t * d, int k)
     leaves = count_tips(t, a);
     for (pop0 = t->pop[a]; gl[pop0] <= leaves && d->sp_parent[pop0] >= 0; pop0 = d->sp_parent[pop0]) ;
     lo = fmax(t->time[a], d->tau[pop0]);
-    tnew = a00_reflect(t->time[p] + d->ft_gspr*(u1 - 0.5), lo, 999.0);
+    tnew = a00_reflect(t->time[p] + d->ft_gspr*u1, lo, 999.0);
     popt = climb(d, t->pop[a], tnew);
     /* targets: the branches crossing tnew inside popt; above the root only the root */
     if (tnew >= t->time[t->root]) targets[ntg++] = t->root;
@@ -448,7 +489,7 @@ static int gspr_step(a00_driver_t * d, int k)
         if (j != a && j != t->root && j != s && j != p && t->time[j] <= t->time[p] && t->time[t->parent[j]] > t->time[p] &&
             ((d->anc[t->pop[j]] >> t->pop[p]) & 1u))
           ++nsrc;
-    if (!ntg) { (void)a00_rndu(&d->rng[i]); continue; }
+    if (!ntg) { skip_u(d, (long)i); continue; }
     tgt = targets[(int)(u2*ntg) % ntg];
     if (tgt == p) tgt = s;                                /* the father is the root and stays it: only its age moves */
     snapshot(d, i);
@@ -501,8 +542,8 @@ static int theta_step_all(a00_driver_t * d)
   {
     sum[p] = 0; tnew[p] = d->theta[p];
     if (!d->has_theta[p]) continue;
-    tnew[p] = a00_reflect(d->theta[p] + d->ft_theta*(a00_rndu(&d->grng) - 0.5), 0.0, 999.0);
-    uacc[p] = a00_rndu(&d->grng);
+    tnew[p] = a00_reflect(d->theta[p] + d->ft_theta*draw_window(d, -1), 0.0, 999.0);
+    uacc[p] = d->kernel == A00_KERNEL_BPP ? -1.0 : draw_u(d, -1);
   }
   for (i = 0; i < d->nloci; ++i)
   {
@@ -517,7 +558,7 @@ static int theta_step_all(a00_driver_t * d)
     if (!d->has_theta[p]) continue;
     lnacc = sum[p] + ((d->theta_alpha - 1)*log(tnew[p]/d->theta[p]) - d->theta_beta*(tnew[p] - d->theta[p]));
     d->proposals++;
-    if (tnew[p] > 0 && (lnacc >= 0 || uacc[p] < exp(lnacc))) { d->accepted++; d->theta[p] = tnew[p]; }
+    if (tnew[p] > 0 && accept(d, -1, lnacc, uacc[p])) { d->accepted++; d->theta[p] = tnew[p]; }
   }
   for (i = 0; i < d->nloci; ++i) d->trees[i].logpr = tree_logpr(d, d->trees + i);
   return 1;
@@ -532,8 +573,8 @@ static int tau_step(a00_driver_t * d, int q)
   unsigned i, n = 0; double sum = 0;
   const int cl = d->sp_left[q], cr = d->sp_right[q], pq = d->sp_parent[q];
   const double old = d->tau[q], lo = fmax(d->tau[cl], d->tau[cr]), hi = pq >= 0 ? d->tau[pq] : 999.0;
-  const double tnew = a00_reflect(old + d->ft_tau*(a00_rndu(&d->grng) - 0.5), lo, hi);
-  const double uacc = a00_rndu(&d->grng);
+  const double tnew = a00_reflect(old + d->ft_tau*draw_window(d, -1), lo, hi);
+  const double uacc = d->kernel == A00_KERNEL_BPP ? -1.0 : draw_u(d, -1);
   const double minf = (tnew - lo)/(old - lo), maxf = (tnew - hi)/(old - hi), lminf = log(minf), lmaxf = log(maxf);
   step_begin(d);
   d->tau[q] = tnew;
@@ -565,7 +606,7 @@ static int tau_step(a00_driver_t * d, int q)
     sum += d->p_slot[i] >= 0 ? (d->s_lnl[d->p_slot[i]] - d->trees[i].lnl) + d->p_delta[i] : d->p_delta[i];
   if (pq < 0) sum += root_tau_prior_ratio(d, old, tnew);
   d->proposals++;
-  if (sum >= 0 || uacc < exp(sum))
+  if (accept(d, -1, sum, uacc))
   {
     d->accepted++;
     for (i = 0; i < d->nloci; ++i) { d->trees[i].logpr = d->p_logpr[i]; if (d->p_slot[i] >= 0) d->trees[i].lnl = d->s_lnl[d->p_slot[i]]; }
@@ -583,8 +624,8 @@ static int tau_step(a00_driver_t * d, int q)
 static int mix_step(a00_driver_t * d)
 {
   unsigned i; int br[MAXN], nd[MAXN], p; double sum = 0, lnacc, oldtau[A00_MAXPOP];
-  const double lnc = d->ft_mix*(a00_rndu(&d->grng) - 0.5), c = exp(lnc);
-  const double uacc = a00_rndu(&d->grng);
+  const double lnc = d->ft_mix*(draw_u(d, -1) - 0.5), c = exp(lnc);        /* prop_mixing.c: log c uniform in both kernels */
+  const double uacc = d->kernel == A00_KERNEL_BPP ? -1.0 : draw_u(d, -1);
   step_begin(d);
   for (p = 0; p < d->npop; ++p) { oldtau[p] = d->tau[p]; d->tau[p] *= c; }
   for (i = 0; i < d->nloci; ++i)
@@ -606,7 +647,7 @@ static int mix_step(a00_driver_t * d)
   if (d->tau_alpha > 0)                    /* all taus scale together: the Dirichlet part is unchanged */
     lnacc += (d->tau_alpha - 1)*lnc - d->tau_beta*(d->tau[d->npop-1] - oldtau[d->npop-1]) - (double)(d->S - 2)*lnc;
   d->proposals++;
-  if (lnacc >= 0 || uacc < exp(lnacc))
+  if (accept(d, -1, lnacc, uacc))
   {
     d->accepted++;
     for (i = 0; i < d->nloci; ++i) { d->trees[i].lnl = d->s_lnl[i]; d->trees[i].logpr = d->p_logpr[i]; }

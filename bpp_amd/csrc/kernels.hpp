@@ -2031,61 +2031,118 @@ __global__ void __launch_bounds__(BS) step_jc69_kernel(const PlanDev P)
 // stride.  Workgroups are the ENGINE's packing (the same loci in the same workgroup in every plan: a locus's CLVs
 // stay in the L2 of the XCD that works on it); loci that are not part of the plan leave their lanes idle.
 // Arithmetic: the very statements of step_jc69_kernel.
-// One step of the workgroup's loci.  ls / S: the lane's entries of the engine's tables (S valid when the lane has a
-// slot), loaded by the caller — once per launch, whether the launch is one step (step_jc69_v2_kernel) or a chain of
-// steps (step_jc69_v2_chain_kernel).
-template <int BS>
-__device__ __forceinline__ void jc69_v2_step(const PlanDev & P, const LaneStatic & ls, const SlotStatic & S,
-                                             double * s_term, double2 * s_ab, double * s_lnl)
+//
+// Split in two so that a chain of steps (step_jc69_v2_chain_kernel) can have the NEXT step's records in flight while
+// this step computes: what a lane reads is (1) per launch — its entries of the engine's tables and the locus's
+// parameters (Jc69Lane), (2) per step — the step's records (Jc69Recs: jc69_v2_fetch), then the step itself
+// (jc69_v2_compute).
+constexpr int JC69_NPRE = 3;
+struct Jc69Lane
 {
-  constexpr int NPRE = 3;
+  LaneStatic ls;
+  SlotStatic S;                   // valid when the lane has a slot
+  uint32_t s0, s1;                // the workgroup's slots
+  uint32_t c_np, c_l0, c_unph, c_locus;       // the slot this lane sums in phase C (lane < s1 - s0)
+  double rate, rw;
+  double2 f01, f23;
+};
+struct Jc69Recs
+{
+  uint32_t e0, e1;                // the workgroup's fresh P-matrices of this step
+  MatRec2 m0; double m0_len;      // the one this lane computes (e0 + lane < e1)
+  uint32_t c_task;
+  StepRec hdr;
+  StepOp sl[JC69_NPRE];
+};
+
+template <int BS>
+__device__ __forceinline__ void jc69_v2_lane(const PlanDev & P, Jc69Lane & L)
+{
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  L.ls = P.lane_tab[b*BS + lane];
+  L.s0 = P.blk_slot_off[b]; L.s1 = P.blk_slot_off[b+1];
+  L.c_np = L.c_l0 = L.c_unph = L.c_locus = 0;
+  if (lane < L.s1 - L.s0)
+  {
+    const SlotStatic & C = P.slot_tab[L.s0 + lane];
+    L.c_np = C.np; L.c_l0 = C.lane0 - b*BS; L.c_unph = C.unphased_length; L.c_locus = C.locus;
+  }
+  L.rate = 1; L.rw = 0; L.f01 = double2{0, 0}; L.f23 = double2{0, 0};
+  if (L.ls.slot != 0xffffffffu)
+  {
+    const uint4 * sp = reinterpret_cast<const uint4 *>(P.slot_tab + L.ls.slot);
+    uint4 * sd = reinterpret_cast<uint4 *>(&L.S);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(SlotStatic)/16); ++i) sd[i] = sp[i];
+    const double * par = L.S.par;
+    L.rate = par[par_rates(1)];
+    L.rw = par[par_rate_weights(1)];
+    L.f01 = *reinterpret_cast<const double2 *>(par + par_matrix(1, 4, 0) + pm_freqs(4));   // param_idx 0 (R = 1)
+    L.f23 = *reinterpret_cast<const double2 *>(par + par_matrix(1, 4, 0) + pm_freqs(4) + 2);
+  }
+}
+
+// the step's records of this lane: requested here, waited for where they are first used
+template <int BS>
+__device__ __forceinline__ void jc69_v2_fetch(const PlanDev & P, const Jc69Lane & L, Jc69Recs & R)
+{
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  const bool has_slot = L.ls.slot != 0xffffffffu;
+  const bool do_mats = (P.flags & 1u) != 0;
+  R.e0 = do_mats ? P.blk_mat_off[b] : 0u; R.e1 = do_mats ? P.blk_mat_off[b+1] : 0u;
+  R.m0 = MatRec2{0, 0}; R.m0_len = 0;
+  if (R.e0 + lane < R.e1) { R.m0 = P.mat2[R.e0 + lane]; R.m0_len = P.mat_length[R.e0 + lane]; }
+  R.c_task = 0xffffffffu;
+  if ((P.flags & 4u) && lane < L.s1 - L.s0)
+    R.c_task = reinterpret_cast<const StepRec *>(P.recs2 + (size_t)(L.s0 + lane)*P.rec2_units)->task;
+  R.hdr = StepRec{};
+  R.hdr.task = 0xffffffffu;
+  if (has_slot && (P.flags & 6u))
+  {
+    const uint4 * rp = P.recs2 + (size_t)L.ls.slot*P.rec2_units;
+    *reinterpret_cast<uint4 *>(&R.hdr) = rp[0];
+    uint4 * ds = reinterpret_cast<uint4 *>(R.sl);
+#pragma unroll
+    for (int i = 0; i < JC69_NPRE; ++i) ds[i] = rp[1 + i];
+  }
+}
+
+template <int BS>
+__device__ __forceinline__ void jc69_v2_compute(const PlanDev & P, const Jc69Lane & L, const Jc69Recs & R,
+                                                double * s_term, double2 * s_ab, double * s_lnl)
+{
+  constexpr int NPRE = JC69_NPRE;
   constexpr uint32_t NAB = 2*BS;
   static_assert(sizeof(LaneStatic) == 16 && sizeof(SlotStatic) == 80 && sizeof(StepRec) == 16 && sizeof(StepOp) == 16 && sizeof(MatRec2) == 8, "compact records");
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
-  const uint32_t s0 = P.blk_slot_off[b], s1 = P.blk_slot_off[b+1];
+  const LaneStatic & ls = L.ls;
+  const SlotStatic & S = L.S;
+  const uint32_t s0 = L.s0, s1 = L.s1;
   const bool has_slot = ls.slot != 0xffffffffu;
   const bool do_mats = (P.flags & 1u) != 0;
-  const uint32_t e0 = do_mats ? P.blk_mat_off[b] : 0u, e1 = do_mats ? P.blk_mat_off[b+1] : 0u;
-  // K4 for this step's branches (locus.c:2342-2414), one branch per lane: requested now
+  const uint32_t e0 = R.e0, e1 = R.e1;
+  // K4 for this step's branches (locus.c:2342-2414), one branch per lane
   const bool have_m0 = e0 + lane < e1;
-  MatRec2 m0{0, 0};
-  double m0_len = 0;
-  if (have_m0) { m0 = P.mat2[e0 + lane]; m0_len = P.mat_length[e0 + lane]; }
-  // phase C bookkeeping
   const bool summer = (P.flags & 4u) && lane < s1 - s0;
   double c_lnl = 0;
-  uint32_t c_np = 0, c_l0 = 0, c_task = 0xffffffffu, c_unph = 0, c_locus = 0;
-  if (summer)
-  {
-    const SlotStatic & C = P.slot_tab[s0 + lane];
-    c_np = C.np; c_l0 = C.lane0 - b*BS; c_unph = C.unphased_length; c_locus = C.locus;
-    c_task = reinterpret_cast<const StepRec *>(P.recs2 + (size_t)(s0 + lane)*P.rec2_units)->task;
-  }
-  // this lane's records
-  StepRec hdr{};
-  hdr.task = 0xffffffffu;
-  StepOp sl[NPRE];
+  const uint32_t c_np = L.c_np, c_l0 = L.c_l0, c_task = R.c_task, c_unph = L.c_unph, c_locus = L.c_locus;
+  const StepRec & hdr = R.hdr;
+  const StepOp * sl = R.sl;
   const uint4 * rp = P.recs2 + (size_t)(has_slot ? ls.slot : 0u)*P.rec2_units;
-  if (has_slot && (P.flags & 6u))
-  {
-    *reinterpret_cast<uint4 *>(&hdr) = rp[0];
-    uint4 * ds = reinterpret_cast<uint4 *>(sl);
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) ds[i] = rp[1 + i];
-  }
   if (have_m0)
   {
-    const SlotStatic & M = P.slot_tab[m0.slot];
+    // the slot entry carries the locus's rate (engine_pack): one hop from the matrix record to the exponential
+    const SlotStatic & M = P.slot_tab[R.m0.slot];
     double2 ab;
-    jc69_ab(m0_len, M.par[par_rates(1)], ab.x, ab.y);
-    *reinterpret_cast<double2 *>(M.pmat + (size_t)m0.pmatrix*2) = ab;
+    jc69_ab(R.m0_len, M.rate0, ab.x, ab.y);
+    *reinterpret_cast<double2 *>(M.pmat + (size_t)R.m0.pmatrix*2) = ab;
     s_ab[lane] = ab;
     for (uint32_t e = e0 + lane + BS; e < e1; e += BS)
     {
       const MatRec2 m = P.mat2[e];
       const SlotStatic & M2 = P.slot_tab[m.slot];
       double2 ab2;
-      jc69_ab(P.mat_length[e], M2.par[par_rates(1)], ab2.x, ab2.y);
+      jc69_ab(P.mat_length[e], M2.rate0, ab2.x, ab2.y);
       *reinterpret_cast<double2 *>(M2.pmat + (size_t)m.pmatrix*2) = ab2;
       if (e - e0 < NAB) s_ab[e - e0] = ab2;
     }
@@ -2096,16 +2153,11 @@ __device__ __forceinline__ void jc69_v2_step(const PlanDev & P, const LaneStatic
   const uint32_t nops = (work && (P.flags & 2u)) ? hdr.nops : 0u;
   double inl[NPRE][4], inr[NPRE][4];          // child vectors (tips expanded / inner from HBM)
   uint32_t fwl[NPRE], fwr[NPRE];              // 0..NPRE-1: forwarded from that earlier update; 0xff: in inl/inr
-  double rate = 1, rw = 0;
-  double2 f01{0, 0}, f23{0, 0};
+  const double rate = L.rate, rw = L.rw;
+  const double2 f01 = L.f01, f23 = L.f23;
   if (work)
   {
     // ---- one wave of independent input loads (before the workgroup waits for the fresh (a, b) pairs)
-    const double * par = S.par;
-    rate = par[par_rates(1)];
-    rw = par[par_rate_weights(1)];
-    f01 = *reinterpret_cast<const double2 *>(par + par_matrix(1, 4, 0) + pm_freqs(4));   // param_idx 0 (R = 1)
-    f23 = *reinterpret_cast<const double2 *>(par + par_matrix(1, 4, 0) + pm_freqs(4) + 2);
 #pragma unroll
     for (int i = 0; i < NPRE; ++i)
     {
@@ -2275,34 +2327,23 @@ __device__ __forceinline__ void jc69_v2_step(const PlanDev & P, const LaneStatic
 }
 
 template <int BS>
-__device__ __forceinline__ void jc69_v2_statics(const PlanDev & P, LaneStatic & ls, SlotStatic & S)
-{
-  ls = P.lane_tab[blockIdx.x*BS + threadIdx.x];
-  if (ls.slot != 0xffffffffu)
-  {
-    const uint4 * sp = reinterpret_cast<const uint4 *>(P.slot_tab + ls.slot);
-    uint4 * sd = reinterpret_cast<uint4 *>(&S);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(SlotStatic)/16); ++i) sd[i] = sp[i];
-  }
-}
-
-template <int BS>
 __global__ void __launch_bounds__(BS) step_jc69_v2_kernel(const PlanDev P)
 {
   __shared__ double s_term[BS], s_lnl[BS];
   __shared__ double2 s_ab[2*BS];
-  LaneStatic ls; SlotStatic S{};
-  jc69_v2_statics<BS>(P, ls, S);
-  jc69_v2_step<BS>(P, ls, S, s_term, s_ab, s_lnl);
+  Jc69Lane L; Jc69Recs R;
+  jc69_v2_lane<BS>(P, L);
+  jc69_v2_fetch<BS>(P, L, R);
+  jc69_v2_compute<BS>(P, L, R, s_term, s_ab, s_lnl);
 }
 
 // A CHAIN of steps in one launch: the per-locus proposals of an iteration (GAGE, GSPR: gtree.c:4585, 6531) need nothing
 // from other loci, so a workgroup walks its loci through all of them without coming back to the host — the shape of
 // threads.c:87-200, where a worker walks its loci's proposals without a barrier.  Step k + 1 of a locus reads what step k
 // wrote: CLVs by the same lane, (a, b) pairs by lanes of the same workgroup (the engine's packing never splits a locus),
-// so a workgroup barrier between steps orders them; the tables' entries are loaded once.  Each step keeps its own
-// records and its own result arrays (ChainStep), i.e. a chain of resident plans is launched, not a new kind of plan.
+// so a workgroup barrier between steps orders them; the tables' entries and the parameters are loaded once, and the
+// records of step k + 1 are in flight while step k computes.  Each step keeps its own records and its own result arrays
+// (ChainStep), i.e. a chain of resident plans is launched, not a new kind of plan.
 struct ChainStep
 {
   const uint4 *    recs2;
@@ -2322,21 +2363,30 @@ struct ChainDev
   ChainStep st[BPA_CHAIN_MAX];
 };
 
+__device__ __forceinline__ void chain_plan(const ChainDev & C, uint32_t k, PlanDev & P)
+{
+  const ChainStep & st = C.st[k];
+  P.recs2 = st.recs2; P.mat2 = st.mat2; P.mat_length = st.mat_length; P.blk_mat_off = st.blk_mat_off;
+  P.site_term = st.site_term; P.lnl = st.lnl; P.wg_part = st.wg_part; P.rec2_units = st.rec2_units; P.flags = st.flags;
+}
+
 template <int BS>
 __global__ void __launch_bounds__(BS) step_jc69_v2_chain_kernel(const ChainDev C)
 {
   __shared__ double s_term[BS], s_lnl[BS];
   __shared__ double2 s_ab[2*BS];
-  LaneStatic ls; SlotStatic S{};
-  jc69_v2_statics<BS>(C.base, ls, S);
+  Jc69Lane L;
+  jc69_v2_lane<BS>(C.base, L);
+  PlanDev P = C.base, Pn = C.base;
+  Jc69Recs R, Rn;
+  chain_plan(C, 0, P);
+  jc69_v2_fetch<BS>(P, L, R);
   for (uint32_t k = 0; k < C.nsteps; ++k)
   {
-    PlanDev P = C.base;
-    const ChainStep & st = C.st[k];
-    P.recs2 = st.recs2; P.mat2 = st.mat2; P.mat_length = st.mat_length; P.blk_mat_off = st.blk_mat_off;
-    P.site_term = st.site_term; P.lnl = st.lnl; P.wg_part = st.wg_part; P.rec2_units = st.rec2_units; P.flags = st.flags;
-    jc69_v2_step<BS>(P, ls, S, s_term, s_ab, s_lnl);
+    if (k + 1 < C.nsteps) { chain_plan(C, k + 1, Pn); jc69_v2_fetch<BS>(Pn, L, Rn); }    // next step's records: in flight
+    jc69_v2_compute<BS>(P, L, R, s_term, s_ab, s_lnl);
     __syncthreads();                    // the next step reuses the LDS arrays and reads this step's (a, b) pairs
+    P = Pn; R = Rn;
   }
 }
 

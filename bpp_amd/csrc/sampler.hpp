@@ -20,9 +20,6 @@
 
 namespace smp {
 
-// section timing of the leader lane (BPA_SMP_DBG & 8): cycles of workgroup 0's first locus, per section
-#define SMP_PROF(S_, i_, t0_) do { if ((S_).prof_on) { const long long t1_ = clock64(); (S_).prof[i_] += t1_ - (t0_); (t0_) = t1_; } } while (0)
-
 constexpr int MAXTIPS = 8;
 constexpr int MAXN    = 16;               // 2*MAXTIPS-1 nodes, padded
 constexpr int MAXBUF  = 2*(MAXTIPS - 1);  // inner CLV buffers
@@ -63,25 +60,28 @@ struct Species
 
 struct TaskLDS
 {
-  Tree   tr, undo;
+  Tree   tr;                                      // what the lanes of the locus read; the leader's registers (LTree) are the master copy
   double ab[MAXPM][2];
   Op     ops[MAXBUF];
   int32_t nops, active;                           // active: 0 nothing to evaluate, 1 evaluate + decide, 2 rejected, 3 density only
-  double hast, hast2, logpr_new;
+  double hast;                                    // an all-loci step: this locus's term of the acceptance ratio
   uint32_t brm;                                   // branches whose (a,b) the proposal changes (bit = node below the branch)
+  uint32_t wclv;                                  // inner CLV buffers written since the load (bit = buffer): what the store brings back
   uint16_t pnodes[MAXPOP];                        // inner nodes of each population of the proposed tree
-  alignas(16) int8_t nin[MAXPOP];                 // lineages entering / coalescences / gene tips below, per population
-  alignas(16) int8_t gl[MAXPOP];
-  int8_t nc[MAXPOP];
-  int8_t nin_new[MAXPOP], nc_new[MAXPOP];
+  alignas(16) int8_t nin_new[MAXPOP];             // lineages entering / coalescences per population of the proposed tree (the lanes'
+  alignas(16) int8_t nc_new[MAXPOP];              // density terms read them; the leader's own copy is in registers)
   double contrib[MAXPOP], contrib_new[MAXPOP];    // per-population terms of the MSC density: current / proposed
   uint32_t chain;                                 // populations whose term the proposal changes
-  int32_t prof_on; long long prof[8];
 };
 
 // what a lane / a locus needs at every launch and never changes, flattened at upload: one 16-byte load per lane and
 // one record per locus instead of the chain lane -> task -> locus table -> parameter block -> weights / tip codes
-struct LaneRec { uint32_t task, wgt, tipcodes, n_np_tips; };       // task 0xffffffff: idle lane; n | np << 8 | tips << 16
+struct LaneRec                          // task 0xffffffff: idle lane; n | np << 8 | tips << 16
+{
+  uint32_t task, wgt, tipcodes, n_np_tips;
+  double * clv;                         // this lane's pattern in inner CLV buffer 0 of its locus (buffer c: + c*np*4 doubles)
+  double * pmat;                        // the locus's (a,b) table — both here so that the loads of the buffers go out one hop
+};                                      // after the lane record, not three (lane -> task record -> buffer addresses)
 struct TaskRec
 {
   double * clv, * pmat;
@@ -111,8 +111,17 @@ struct Args
                                           // the THETA kernels read one population's run of loci)
   uint32_t ntasks;
   uint32_t refresh_logpr;      // the thetas moved since the trees' densities were stored: recompute them from the statistics first
-  uint32_t dbg;                // timing experiments only (BPA_SMP_DBG): 1 skip the node updates, 2 skip the density, 4 skip the proposal
+  uint32_t dbg;                // timing experiments only (BPA_SMP_DBG): 1 skip the node updates, 4 skip the proposal, 16 phase cycles of workgroup 0
   double   bfbeta;             // 0 with opt_usedata == 0 (locus.c:2581): the sampler then draws from the MSC prior
+  // the decision of an all-loci step inside its own launch (one GPU): every workgroup leaves its sum and a stamp in
+  // uncached memory, the LAST workgroup of the grid waits for all stamps, adds the sums up in a fixed order and decides
+  // (no other workgroup ever waits: nothing can dead-lock, and the wait is bounded anyway)
+  uint32_t dec_on, dec_epoch;  // dec_epoch: this step's epoch = the stamp, and what *dec_flag becomes on rejection
+  double   dec_uacc;
+  uint32_t * dec_flag, * dec_counters;
+  double *   dec_taus;
+  unsigned long long * dec_stamps;   // [blocks], uncached like part_out
+  int *    dec_err;
   Species  sp;
 };
 
@@ -135,65 +144,138 @@ __host__ __device__ inline double reflect(double x, double a, double b)
   return b - e;
 }
 
-__device__ __forceinline__ void swap_clv(Tree & t, int i)
+// ---- the leader lane's copy of its locus's tree: REGISTERS ------------------------------------------------------------
+// A proposal is a chain of a few hundred dependent look-ups in arrays of at most 15 small integers (children, parent,
+// buffer indices, populations).  Out of LDS every one of them is a round trip of ~100 cycles for the ONE wave a SIMD
+// runs here — the sweep was waiting on the LDS 70 % of its time.  Packed one byte per node into 2 (<= 4 tips) or 4
+// (<= 8 tips) registers per array, a look-up is one v_perm_b32 (a byte select with a run-time selector), an update a
+// shift and a v_bfi_b32: the tree lives in the leader's registers for the whole launch, rolls back from a register
+// copy, and only what the OTHER lanes of the locus read (ages, parents, buffer indices) is mirrored to LDS — stores,
+// nobody waits for them.
+template <int W> struct ByteArr
+{
+  uint32_t w[W];
+  __device__ __forceinline__ int get(int i) const
+  {
+    uint32_t v;
+    if constexpr (W <= 2) v = __builtin_amdgcn_perm(w[W - 1], w[0], (uint32_t)i);          // selector 0-3: second operand, 4-7: first
+    else
+    {
+      const uint32_t lo = __builtin_amdgcn_perm(w[1], w[0], (uint32_t)i), hi = __builtin_amdgcn_perm(w[3], w[2], (uint32_t)i - 8u);
+      v = i < 8 ? lo : hi;
+    }
+    return (int)(int8_t)v;
+  }
+  __device__ __forceinline__ void set(int i, int v)
+  {
+    const uint32_t sh = ((uint32_t)i & 3u) << 3, m = 0xffu << sh, val = ((uint32_t)v & 0xffu) << sh, wi = (uint32_t)i >> 2;
+#pragma unroll
+    for (int k = 0; k < W; ++k) w[k] = wi == (uint32_t)k ? ((w[k] & ~m) | val) : w[k];
+  }
+  struct Ref
+  {
+    ByteArr & a; int i;
+    __device__ __forceinline__ operator int() const { return a.get(i); }
+    __device__ __forceinline__ Ref & operator=(int v) { a.set(i, v); return *this; }
+    __device__ __forceinline__ Ref & operator=(const Ref & o) { a.set(i, (int)o); return *this; }
+  };
+  __device__ __forceinline__ int operator[](int i) const { return get(i); }
+  __device__ __forceinline__ Ref operator[](int i) { return Ref{*this, i}; }
+  __device__ __forceinline__ void load(const int8_t * lds) { for (int k = 0; k < W; ++k) w[k] = reinterpret_cast<const uint32_t *>(lds)[k]; }
+  __device__ __forceinline__ void store(int8_t * lds) const { for (int k = 0; k < W; ++k) reinterpret_cast<uint32_t *>(lds)[k] = w[k]; }
+};
+
+template <int NT> struct LTree
+{
+  static constexpr int W = NT <= 4 ? 2 : 4;
+  ByteArr<W> left, right, parent, clv, pmat, pop;
+  double *   time;                                // the ages stay in LDS (S.tr.time): doubles, read a few times per proposal
+  a00_rng_t  rng;
+  int32_t    root, tips;
+  __device__ __forceinline__ void load(Tree & t)
+  {
+    left.load(t.left); right.load(t.right); parent.load(t.parent); clv.load(t.clv); pmat.load(t.pmat); pop.load(t.pop);
+    time = t.time; rng = t.rng; root = t.root; tips = t.tips;
+  }
+  // what the other lanes read, and what goes back to HBM at the end
+  __device__ __forceinline__ void mirror(Tree & t) const
+  {
+    left.store(t.left); right.store(t.right); parent.store(t.parent); clv.store(t.clv); pmat.store(t.pmat); pop.store(t.pop);
+    t.root = root;
+  }
+};
+// the integer part of a tree, for the roll-back of a rejected proposal
+template <int NT> struct LUndo { ByteArr<LTree<NT>::W> left, right, parent, clv, pmat, pop; int32_t root; };
+template <int NT> __device__ __forceinline__ void save(LUndo<NT> & u, const LTree<NT> & t)
+{ u.left = t.left; u.right = t.right; u.parent = t.parent; u.clv = t.clv; u.pmat = t.pmat; u.pop = t.pop; u.root = t.root; }
+template <int NT> __device__ __forceinline__ void restore(LTree<NT> & t, const LUndo<NT> & u)
+{ t.left = u.left; t.right = u.right; t.parent = u.parent; t.clv = u.clv; t.pmat = u.pmat; t.pop = u.pop; t.root = u.root; }
+
+// the species tree's topology (uniform over the launch) and the leader's per-population counts, the same way
+struct LSpecies { ByteArr<4> parent, left, right; int32_t S, npop; };
+struct LCounts  { ByteArr<4> nin, nc, nin_new, nc_new, gl; };
+
+template <class TT> __device__ __forceinline__ void swap_clv(TT & t, int i)
 {
   const int inner = t.tips - 1, c = t.clv[i] + inner;                     // the other of the node's two buffers
-  t.clv[i] = (int8_t)(c >= t.tips + 2*inner ? c - 2*inner : c);
+  t.clv[i] = c >= t.tips + 2*inner ? c - 2*inner : c;
 }
-__device__ __forceinline__ void swap_pmat(Tree & t, int i)
+template <class TT> __device__ __forceinline__ void swap_pmat(TT & t, int i)
 {
   const int edges = 2*t.tips - 2, c = t.pmat[i] + edges;
-  t.pmat[i] = (int8_t)(c >= 2*edges ? c - 2*edges : c);
+  t.pmat[i] = c >= 2*edges ? c - 2*edges : c;
 }
-// node sets are 16-bit masks (n <= 15): no private arrays, nothing spills to scratch.
-// (Tried: the integer tree arrays packed into 64-bit registers of the leader lane instead of LDS —
-//  211 us per sweep vs 157 us: variable 64-bit shifts cost more than the LDS round trips they save.
-//  A proposal is ~2-3 k dependent instructions of ONE wave per SIMD: instruction count is the lever.)
-__device__ __forceinline__ uint32_t path_mask(const Tree & t, int v)
+// node sets are 16-bit masks (n <= 15): no private arrays, nothing spills to scratch
+template <class TT> __device__ __forceinline__ uint32_t path_mask(const TT & t, int v)
 {
   uint32_t m = 0;
   for (; v >= 0; v = t.parent[v]) m |= 1u << v;
   return m;
 }
 // the nodes of the subtree below (and including) v
-__device__ __forceinline__ uint32_t subtree_mask(const Tree & t, int v)
+template <class TT> __device__ __forceinline__ uint32_t subtree_mask(const TT & t, int v)
 {
   uint32_t m = 1u << v;
   for (;;)
   {
     uint32_t add = 0;
-    for (uint32_t q = m; q; q &= q - 1) { const int x = __ffs(q) - 1; if (t.left[x] >= 0) add |= (1u << t.left[x]) | (1u << t.right[x]); }
+    for (uint32_t q = m; q; q &= q - 1) { const int x = __ffs(q) - 1; const int l = t.left[x]; if (l >= 0) add |= (1u << l) | (1u << (int)t.right[x]); }
     if (!(add & ~m)) return m;
     m |= add;
   }
 }
 // exchange the tree positions of node ids a and b, in place (buffer indices stay with the ids)
-__device__ void swap_ids(Tree & t, int a, int b)
+template <int NT> __device__ void swap_ids(LTree<NT> & t, int a, int b)
 {
-  const int n = 2*t.tips - 1;
-  for (int i = 0; i < n; ++i)
+#pragma unroll
+  for (int i = 0; i < 2*NT - 1; ++i)                 // (entries past the tree are -1: they match neither id)
   {
-    const int8_t l = t.left[i], r = t.right[i], p = t.parent[i];
-    t.left[i]   = l == a ? (int8_t)b : l == b ? (int8_t)a : l;
-    t.right[i]  = r == a ? (int8_t)b : r == b ? (int8_t)a : r;
-    t.parent[i] = p == a ? (int8_t)b : p == b ? (int8_t)a : p;
+    const int l = t.left[i], r = t.right[i], p = t.parent[i];
+    t.left[i]   = l == a ? b : l == b ? a : l;
+    t.right[i]  = r == a ? b : r == b ? a : r;
+    t.parent[i] = p == a ? b : p == b ? a : p;
   }
-  const int8_t l = t.left[a], r = t.right[a], p = t.parent[a], q = t.pop[a]; const double tm = t.time[a];
+  const int l = t.left[a], r = t.right[a], p = t.parent[a], q = t.pop[a]; const double tm = t.time[a];
   t.left[a] = t.left[b]; t.right[a] = t.right[b]; t.parent[a] = t.parent[b]; t.time[a] = t.time[b]; t.pop[a] = t.pop[b];
   t.left[b] = l; t.right[b] = r; t.parent[b] = p; t.time[b] = tm; t.pop[b] = q;
   t.root = t.root == a ? b : t.root == b ? a : t.root;
 }
 
-// ---- species tree helpers (lca_pop / climb of a00_driver.c); tau = this workgroup's LDS copy
-__device__ __forceinline__ int lca_pop(const Species & sp, int p, int q)
+// ---- species tree helpers (lca_pop / climb of a00_driver.c); tau / anc = this workgroup's LDS copies
+__device__ __forceinline__ int lca_pop(const LSpecies & sp, const uint16_t * anc, int p, int q)
 {
-  while (!((sp.anc[q] >> p) & 1u)) p = sp.parent[p];
+  const uint32_t aq = anc[q];
+  while (!((aq >> p) & 1u)) p = sp.parent[p];
   return p;
 }
-__device__ __forceinline__ int climb(const Species & sp, const double * tau, int p, double t)
+__device__ __forceinline__ int climb(const LSpecies & sp, const double * tau, int p, double t)
 {
-  while (sp.parent[p] >= 0 && tau[sp.parent[p]] <= t) p = sp.parent[p];
-  return p;
+  for (;;)
+  {
+    const int pp = sp.parent[p];
+    if (pp < 0 || !(tau[pp] <= t)) return p;
+    p = pp;
+  }
 }
 
 // MSC density of the tree in S.tr: tree_logpr of a00_driver.c = gtree_logprob (gtree.c:3957), the
@@ -204,17 +286,12 @@ __device__ __forceinline__ int climb(const Species & sp, const double * tau, int
 // Three parts: the leader lane counts (density_prepare), the lanes of the locus take one population
 // each for the floating-point part (lanes_density: the wave runs ONE term's instructions instead of the
 // union of every leader's population loop), the leader adds the terms up in population order (density_sum).
-template<int NT>                                    // NT: upper bound of the tips (the unrolled passes cover 2 NT - 1 nodes)
-__device__ void density_prepare(TaskLDS & S, const Species & sp, uint32_t mask)
+template <int NT>
+__device__ void density_prepare(TaskLDS & S, const LTree<NT> & t, LCounts & cn, const LSpecies & sp, uint32_t mask)
 {
   constexpr int NN = 2*NT - 1;
-  const Tree & t = S.tr;
   const int n = 2*t.tips - 1;
   S.chain = mask;
-  // the populations of all inner nodes in one unrolled pass (independent LDS reads)
-  int8_t pk[NN];
-#pragma unroll
-  for (int k = 0; k < NN; ++k) pk[k] = t.pop[k];
   for (uint32_t m = mask; m; m &= m - 1)             // ascending = children before parents
   {
     const int p = __ffs(m) - 1;
@@ -222,15 +299,17 @@ __device__ void density_prepare(TaskLDS & S, const Species & sp, uint32_t mask)
     if (p >= sp.S)
     {
       const int l = sp.left[p], r = sp.right[p];
-      const int nl = ((mask >> l) & 1u) ? S.nin_new[l] - S.nc_new[l] : S.nin[l] - S.nc[l];
-      const int nr = ((mask >> r) & 1u) ? S.nin_new[r] - S.nc_new[r] : S.nin[r] - S.nc[r];
+      const int nl = ((mask >> l) & 1u) ? cn.nin_new[l] - cn.nc_new[l] : cn.nin[l] - cn.nc[l];
+      const int nr = ((mask >> r) & 1u) ? cn.nin_new[r] - cn.nc_new[r] : cn.nin[r] - cn.nc[r];
       nin = nl + nr;
     }
-    else nin = S.nin[p];                          // gene tips of the species: fixed
+    else nin = cn.nin[p];                         // gene tips of the species: fixed
     uint32_t nodes = 0;
 #pragma unroll
-    for (int k = 0; k < NN; ++k) if (k >= t.tips && k < n && pk[k] == p) nodes |= 1u << k;
-    S.nin_new[p] = (int8_t)nin; S.nc_new[p] = (int8_t)__popc(nodes); S.pnodes[p] = (uint16_t)nodes;
+    for (int k = 0; k < NN; ++k) if (k >= t.tips && k < n && t.pop[k] == p) nodes |= 1u << k;
+    const int nc = __popc(nodes);
+    cn.nin_new[p] = nin; cn.nc_new[p] = nc;
+    S.nin_new[p] = (int8_t)nin; S.nc_new[p] = (int8_t)nc; S.pnodes[p] = (uint16_t)nodes;
   }
 }
 // the term of population p (any lane of the locus)
@@ -275,57 +354,65 @@ __device__ __forceinline__ void lanes_density(TaskLDS & S, const Species & sp, c
   const int cnt = __popc(mask);
   for (int j = (int)n; j < cnt; j += (int)np) density_term(S, sp, tau, nth_bit(mask, j), t2h_out, t2h_stride);
 }
-__device__ __forceinline__ double density_sum(const TaskLDS & S, const Species & sp)
+__device__ __forceinline__ double density_sum(const TaskLDS & S, int npop)
 {
   double logpr = 0;
-  for (int p = 0; p < sp.npop; ++p) logpr += ((S.chain >> p) & 1u) ? S.contrib_new[p] : S.contrib[p];
+  for (int p = 0; p < npop; ++p) logpr += ((S.chain >> p) & 1u) ? S.contrib_new[p] : S.contrib[p];
   return logpr;
 }
 // the proposal stands: its terms become the current ones
-__device__ __forceinline__ void commit_logpr(TaskLDS & S)
+__device__ __forceinline__ void commit_logpr(TaskLDS & S, LCounts & cn)
 {
   for (uint32_t m = S.chain; m; m &= m - 1)
   {
     const int p = __ffs(m) - 1;
-    S.contrib[p] = S.contrib_new[p]; S.nin[p] = S.nin_new[p]; S.nc[p] = S.nc_new[p];
+    S.contrib[p] = S.contrib_new[p]; cn.nin[p] = (int)cn.nin_new[p]; cn.nc[p] = (int)cn.nc_new[p];
   }
 }
 // populations on the path between two populations one of which is an ancestor (or self) of the other
-__device__ __forceinline__ uint32_t pop_chain(const Species & sp, int a, int b)
+__device__ __forceinline__ uint32_t pop_chain(const uint16_t * anc, int a, int b)
 {
-  const int lower = ((sp.anc[a] >> b) & 1u) ? a : b, higher = lower == a ? b : a;
-  return sp.anc[lower] & ~(sp.anc[higher] & ~(1u << higher));
+  const uint32_t aa = anc[a], ab = anc[b];
+  const bool a_lower = (aa >> b) & 1u;
+  const uint32_t lo = a_lower ? aa : ab, hi = a_lower ? ab : aa;
+  const int higher = a_lower ? b : a;
+  return lo & ~(hi & ~(1u << higher));
 }
 
 // install a proposal: toggle buffers, node-update list of the nodes in mask ndm in children-first order
 // (= by age) — step_add of a00_driver.c; the fresh (a,b) of the changed branches (mask brm) are left to the
 // lanes of the locus (lanes_branches)
-__device__ void install(TaskLDS & S, uint32_t brm, uint32_t ndm)
+template <int NT>
+__device__ void install(TaskLDS & S, LTree<NT> & t, uint32_t brm, uint32_t ndm)
 {
-  Tree & t = S.tr;
   S.brm = brm;
   for (; brm; brm &= brm - 1) swap_pmat(t, __ffs(brm) - 1);
+  // the ages of the inner nodes, all at once (independent LDS reads): the youngest remaining node comes next
+  // (a parent is always older than its children)
+  double tk[NT - 1];
+#pragma unroll
+  for (int j = 0; j < NT - 1; ++j) tk[j] = t.time[t.tips + j < MAXN ? t.tips + j : 0];
   int nn = 0;
+  uint32_t wclv = S.wclv;
   while (ndm)
   {
-    // the youngest remaining node next (a parent is always older than its children)
     int best = -1; double tb = 0;
-    for (uint32_t m = ndm; m; m &= m - 1)
+#pragma unroll
+    for (int j = 0; j < NT - 1; ++j)
     {
-      const int x = __ffs(m) - 1;
-      if (best < 0 || t.time[x] < tb) { best = x; tb = t.time[x]; }
+      const int x = t.tips + j;
+      if (((ndm >> x) & 1u) && (best < 0 || tk[j] < tb)) { best = x; tb = tk[j]; }
     }
     ndm &= ~(1u << best);
     swap_clv(t, best);
-    S.ops[nn] = (Op)best;                       // node ids for now; buffer indices below, once all toggles are done
+    const int l = t.left[best], r = t.right[best];
+    const int pc = t.clv[best];
+    // children first: a child of this node that is itself recomputed was toggled in an earlier round
+    S.ops[nn] = make_op(pc, t.clv[l], t.pmat[l], t.clv[r], t.pmat[r]);
+    wclv |= 1u << (pc - t.tips);
     ++nn;
   }
-  for (int a = 0; a < nn; ++a)
-  {
-    const int x = (int)S.ops[a], l = t.left[x], r = t.right[x];
-    S.ops[a] = make_op(t.clv[x], t.clv[l], t.pmat[l], t.clv[r], t.pmat[r]);
-  }
-  S.nops = nn;
+  S.nops = nn; S.wclv = wclv;
 }
 
 // lane n of the locus's np lanes: (a,b) of the n-th, (n+np)-th ... changed branch, into its (already toggled) buffer
@@ -344,33 +431,46 @@ __device__ __forceinline__ void lanes_branches(TaskLDS & S, double rate, uint32_
   }
 }
 
-// GAGE on the k-th inner node (gage_step of a00_driver.c; propose_ages, gtree.c:4585)
-template<int NT>
-__device__ bool propose_gage(TaskLDS & S, int k, const Species & sp, const double * tau)
+// what a rejected per-locus proposal puts back besides the integer arrays: the ages it moved (at most three nodes)
+struct TimeUndo { double t0, ta, tb; int32_t n0, na, nb; };
+// section cycles of ONE leader lane (BPA_SMP_DBG & 16: lane 0 of workgroup 0)
+struct Prof
 {
-  Tree & t = S.tr;
-  long long tp = clock64();
+  long long t, acc[12]; bool on;
+  __device__ __forceinline__ void tick(int i) { if (on) { const long long t1 = clock64(); acc[i] += t1 - t; t = t1; } }
+};
+
+// GAGE on the k-th inner node (gage_step of a00_driver.c; propose_ages, gtree.c:4585)
+template <int NT>
+__device__ bool propose_gage(TaskLDS & S, LTree<NT> & t, LCounts & cn, TimeUndo & tu, double & hast, int k, const LSpecies & sp,
+                             const Species & spl, const double * tau, Prof & pf)
+{
+  if (pf.on) pf.t = clock64();
   const int n = 2*t.tips - 1;
   const int v = t.tips + k;                          // the k-th inner node: tips are nodes 0..tips-1 (bpa_sampler_set_tree checks)
   if (v >= n) return false;
   const double u = rndu(&t.rng);
   const int l = t.left[v], r = t.right[v], p = t.parent[v];
-  double lo = fmax(t.time[l], t.time[r]);
-  if (t.pop[l] != t.pop[r]) lo = fmax(lo, tau[lca_pop(sp, t.pop[l], t.pop[r])]);
-  const double hi = p >= 0 ? t.time[p] : 999.0;
+  const double tl = t.time[l], tr = t.time[r], told = t.time[v], tpar = t.time[p < 0 ? 0 : p];
+  const int pl = t.pop[l], pr = t.pop[r];
+  double lo = fmax(tl, tr);
+  if (pl != pr) lo = fmax(lo, tau[lca_pop(sp, spl.anc, pl, pr)]);
+  const double hi = p >= 0 ? tpar : 999.0;
   if (!(hi > lo)) { (void)rndu(&t.rng); return false; }
-  const double tnew = reflect(t.time[v] + sp.ft_gage*(u - 0.5), lo, hi);
+  const double tnew = reflect(told + spl.ft_gage*(u - 0.5), lo, hi);
   const int oldpop = t.pop[v];
+  tu.n0 = v; tu.t0 = told; tu.na = -1;
   t.time[v] = tnew;
-  t.pop[v] = (int8_t)climb(sp, tau, t.pop[l], tnew);
-  S.hast = 0;
-  SMP_PROF(S, 0, tp);
-  density_prepare<NT>(S, sp, pop_chain(sp, oldpop, t.pop[v]));
-  SMP_PROF(S, 1, tp);
+  const int newpop = climb(sp, tau, pl, tnew);
+  t.pop[v] = newpop;
+  hast = 0;
+  pf.tick(8);
+  density_prepare<NT>(S, t, cn, sp, pop_chain(spl.anc, oldpop, newpop));
+  pf.tick(9);
   uint32_t brm = (1u << l) | (1u << r);
   if (p >= 0) brm |= 1u << v;
-  install(S, brm, path_mask(t, v));
-  SMP_PROF(S, 2, tp);
+  install<NT>(S, t, brm, path_mask(t, v));
+  pf.tick(10);
   return true;
 }
 
@@ -383,56 +483,65 @@ __global__ void lograt_kernel(double * tab)
   tab[threadIdx.x] = (i && j) ? log((double)i/(double)j) : 0.0;
 }
 
-template<int NT>
-__device__ bool propose_gspr(TaskLDS & S, int k, const Species & sp, const double * tau, const double * lograt)
+template <int NT>
+__device__ bool propose_gspr(TaskLDS & S, LTree<NT> & t, LCounts & cn, TimeUndo & tu, double & hast, int k, const LSpecies & sp,
+                             const Species & spl, const double * tau, const double * lograt, Prof & pf)
 {
-  Tree & t = S.tr;
-  long long tp = clock64();
+  if (pf.on) pf.t = clock64();
   const int n = 2*t.tips - 1;
   const int a = k < t.root ? k : k + 1;              // the k-th node that is not the root
   if (a >= n) return false;
   const double u1 = rndu(&t.rng), u2 = rndu(&t.rng);
   const int root_before = t.root;
-  const int p = t.parent[a], s = t.left[p] == a ? t.right[p] : t.left[p], g = t.parent[p];
+  const int p = t.parent[a], lp = t.left[p], s = lp == a ? (int)t.right[p] : lp, g = t.parent[p];
+  pf.tick(0);
   // youngest population from a's upwards that holds gene tips outside a's subtree
   const int leaves = __popc(subtree_mask(t, a) & ((1u << t.tips) - 1u));
   int pop0 = t.pop[a];
-  while (S.gl[pop0] <= leaves && sp.parent[pop0] >= 0) pop0 = sp.parent[pop0];
-  const double lo = fmax(t.time[a], tau[pop0]);
-  const double tnew = reflect(t.time[p] + sp.ft_gspr*(u1 - 0.5), lo, 999.0);
-  const int popt = climb(sp, tau, t.pop[a], tnew);
+  const int popa = pop0;
+  while (cn.gl[pop0] <= leaves && sp.parent[pop0] >= 0) pop0 = sp.parent[pop0];
+  pf.tick(1);
+  const double ta = t.time[a], tpo = t.time[p], troot = t.time[root_before];       // (independent LDS reads)
+  const double lo = fmax(ta, tau[pop0]);
+  const double tnew = reflect(tpo + spl.ft_gspr*(u1 - 0.5), lo, 999.0);
+  const int popt = climb(sp, tau, popa, tnew);
   // targets (bit j = branch above node j; the father's own branch stands for the sibling's) and sources, in ONE
-  // fully unrolled scan: the LDS reads of all nodes are independent and go out together
+  // fully unrolled scan: the LDS reads of all nodes' ages are independent and go out together
+  pf.tick(2);
   uint32_t tmask = 0; int nsrc = 1;
   {
-    const double tp = t.time[p], troot = t.time[t.root]; const int pp = t.pop[p], root = t.root;
-    const bool above_root = tnew >= troot, src_on = p != root;
+    const int pp = t.pop[p];
+    const bool above_root = tnew >= troot, src_on = p != root_before;
 #pragma unroll
     for (int j = 0; j < 2*NT - 1; ++j)
     {
       const int pj = t.parent[j];
       const double tj = t.time[j], tpj = t.time[pj < 0 ? 0 : pj];
-      const uint32_t aj = sp.anc[t.pop[j] & (MAXPOP - 1)];
-      const bool in = j < n && j != a && j != root;
+      const uint32_t aj = spl.anc[t.pop[j] & (MAXPOP - 1)];
+      const bool in = j < n && j != a && j != root_before;
       if (in && !above_root && tj <= tnew && tpj > tnew && ((aj >> popt) & 1u)) tmask |= 1u << j;
-      if (in && src_on && j != s && j != p && tj <= tp && tpj > tp && ((aj >> pp) & 1u)) ++nsrc;
+      if (in && src_on && j != s && j != p && tj <= tpo && tpj > tpo && ((aj >> pp) & 1u)) ++nsrc;
     }
-    if (above_root) tmask = 1u << root;
+    if (above_root) tmask = 1u << root_before;
   }
+  pf.tick(3);
   const int ntg = __popc(tmask);
   if (!ntg) { (void)rndu(&t.rng); return false; }
-  int pick = (int)(u2*ntg) % ntg, tgt = -1;
-  for (uint32_t m = tmask; m; m &= m - 1) if (pick-- == 0) { tgt = __ffs(m) - 1; break; }
+  int pick = (int)(u2*ntg);
+  if (pick == ntg) pick = 0;                          // (int)(u2*ntg) % ntg of the host driver
+  int tgt = nth_bit(tmask, pick);
   if (tgt == p) tgt = s;
   // prune: the sibling takes p's place; regraft p (with a below it) above tgt at tnew in popt
-  t.parent[s] = (int8_t)g;
-  if (g >= 0) { if (t.left[g] == p) t.left[g] = (int8_t)s; else t.right[g] = (int8_t)s; } else t.root = s;
+  t.parent[s] = g;
+  if (g >= 0) { if (t.left[g] == p) t.left[g] = s; else t.right[g] = s; } else t.root = s;
   const int pc = t.parent[tgt];
-  const uint32_t chain = pop_chain(sp, t.pop[p], popt);
-  t.time[p] = tnew; t.pop[p] = (int8_t)popt;
-  t.left[p] = (int8_t)a; t.right[p] = (int8_t)tgt; t.parent[a] = (int8_t)p; t.parent[tgt] = (int8_t)p;
-  t.parent[p] = (int8_t)pc;
-  if (pc >= 0) { if (t.left[pc] == tgt) t.left[pc] = (int8_t)p; else t.right[pc] = (int8_t)p; } else t.root = p;
+  const uint32_t chain = pop_chain(spl.anc, t.pop[p], popt);
+  tu.n0 = p; tu.t0 = tpo; tu.na = -1;
+  t.time[p] = tnew; t.pop[p] = popt;
+  t.left[p] = a; t.right[p] = tgt; t.parent[a] = p; t.parent[tgt] = p;
+  t.parent[p] = pc;
+  if (pc >= 0) { if (t.left[pc] == tgt) t.left[pc] = p; else t.right[pc] = p; } else t.root = p;
+  pf.tick(4);
   uint32_t ndm = path_mask(t, p);
   if (g >= 0) ndm |= path_mask(t, g);
   uint32_t bset = (1u << a) | (1u << tgt) | (1u << p) | (1u << s);
@@ -440,7 +549,8 @@ __device__ bool propose_gspr(TaskLDS & S, int k, const Species & sp, const doubl
   {
     // the root node object keeps its identity (gtree.c:6129-6175): rename the two ids in the sets
     const int newtop = t.root;
-    swap_ids(t, newtop, root_before);
+    tu.na = newtop; tu.nb = root_before; tu.ta = t.time[newtop]; tu.tb = t.time[root_before];
+    swap_ids<NT>(t, newtop, root_before);
     const uint32_t bn = 1u << newtop, br_ = 1u << root_before;
     auto ren = [&](uint32_t m) { const uint32_t hn = m & bn, hr = m & br_; m &= ~(bn | br_); if (hn) m |= br_; if (hr) m |= bn; return m; };
     ndm = ren(ndm) | path_mask(t, newtop);
@@ -448,13 +558,12 @@ __device__ bool propose_gspr(TaskLDS & S, int k, const Species & sp, const doubl
   }
   uint32_t brm = 0;
   for (uint32_t m = bset; m; m &= m - 1) { const int x = __ffs(m) - 1; if (t.parent[x] >= 0) brm |= 1u << x; }
-  SMP_PROF(S, 3, tp);
-  S.hast = lograt[ntg*(2*NT) + nsrc];
-  SMP_PROF(S, 4, tp);
-  density_prepare<NT>(S, sp, chain);
-  SMP_PROF(S, 5, tp);
-  install(S, brm, ndm);
-  SMP_PROF(S, 6, tp);
+  hast = lograt[ntg*(2*NT) + nsrc];
+  pf.tick(5);
+  density_prepare<NT>(S, t, cn, sp, chain);
+  pf.tick(6);
+  install<NT>(S, t, brm, ndm);
+  pf.tick(7);
   return true;
 }
 
@@ -466,6 +575,9 @@ __device__ __forceinline__ double msc_term(int ncoal, double T2h, double theta, 
   if (T2h) c -= T2h/(theta*1.0);
   return c;
 }
+
+__device__ void decide(double lnacc, double u, uint32_t epoch, uint32_t * flag, uint32_t * counters, double * taus,
+                       const Species & sp, int tau_q, int theta_p, double win_u, double mix_c, double mix_lnc);
 
 template<int NT>
 __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
@@ -486,15 +598,27 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   const uint32_t ts = active ? task - t0 : 0u;
   const bool leader = active && (lrec.n_np_tips & 255u) == 0;
   const bool restore_mix = A.epoch != 0 && *A.mix_flag == A.epoch;      // epoch 0: nothing pending
-  // the species tree is indexed with run-time population numbers all over the leader's code: out of LDS, not
-  // out of the kernel-argument segment (a dynamic index into a by-value argument is a global load each time)
+  // the species tree is indexed with run-time population numbers by every lane (density terms) and by the leaders
+  // (ancestor sets): out of LDS, not out of the kernel-argument segment (a dynamic index into a by-value argument is
+  // a global load each time); its topology also sits in the leaders' registers (LSpecies)
   __shared__ Species s_sp;
   {
     const uint32_t * src = reinterpret_cast<const uint32_t *>(&A.sp);
     uint32_t * dst = reinterpret_cast<uint32_t *>(&s_sp);
     for (uint32_t i = lane; i < sizeof(Species)/4; i += BS) dst[i] = src[i];
   }
-  const Species & sp = s_sp;
+  const Species & spl = s_sp;
+  LSpecies sp;
+  {
+    const uint32_t * q = reinterpret_cast<const uint32_t *>(A.sp.parent);
+    for (int k = 0; k < 4; ++k) sp.parent.w[k] = q[k];
+    q = reinterpret_cast<const uint32_t *>(A.sp.left);
+    for (int k = 0; k < 4; ++k) sp.left.w[k] = q[k];
+    q = reinterpret_cast<const uint32_t *>(A.sp.right);
+    for (int k = 0; k < 4; ++k) sp.right.w[k] = q[k];
+    sp.S = A.sp.S; sp.npop = A.sp.npop;
+  }
+  const int npop = sp.npop;
 
   // ---- load: tree (or its pre-step snapshot), (a,b) table, this lane's CLV buffers and constants
   uint32_t np = 0, tips = 0, n = 0, tipcodes = 0, wgt = 0;
@@ -503,25 +627,31 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   if (lane < (uint32_t)(3*MAXPOP)) s_tau[lane] = A.taus[lane];
   __shared__ double s_lograt[(2*NT)*(2*NT)];
   if (A.mode == 0) for (uint32_t i = lane; i < (uint32_t)((2*NT)*(2*NT)); i += BS) s_lograt[i] = A.lograt[(i/(2*NT))*MAXN + i % (2*NT)];
+  LCounts cn;
+  for (int k = 0; k < 4; ++k) cn.nin.w[k] = cn.nc.w[k] = cn.nin_new.w[k] = cn.nc_new.w[k] = cn.gl.w[k] = 0u;
+  // an all-loci step that recomputes every inner node (mixing, start-up) reads no inner CLV: nothing to load
+  const bool load_clv = A.mode == 0 || A.mode == 4;
   if (active)
   {
     const TaskRec & R = A.task_rec[task];
     n = lrec.n_np_tips & 255u; np = (lrec.n_np_tips >> 8) & 255u; tips = lrec.n_np_tips >> 16;
     wgt = lrec.wgt; tipcodes = lrec.tipcodes;
-    g_clv = R.clv; g_pmat = R.pmat; rate = R.rate; rw = R.rw; f0 = R.f0; f1 = R.f1; f2 = R.f2; f3 = R.f3;
+    g_clv = lrec.clv; g_pmat = lrec.pmat;
     // the (a,b) table of the locus: its lanes share the copy
     for (uint32_t i = n; i < 4*(2*tips - 2); i += np) (&s_task[ts].ab[0][0])[i] = g_pmat[i];
-    if (n == 0)
-    {
-      *reinterpret_cast<uint4 *>(s_task[ts].gl)  = *reinterpret_cast<const uint4 *>(R.gl);
-      *reinterpret_cast<uint4 *>(s_task[ts].nin) = *reinterpret_cast<const uint4 *>(R.nin);
-    }
-    const uint32_t nbuf = A.mode == 2 ? 0u : 2*(tips - 1);        // no likelihood work when only settling
+    const uint32_t nbuf = load_clv ? 2*(tips - 1) : 0u;
     for (uint32_t c = 0; c < nbuf; ++c)
     {
-      const double2 * p = reinterpret_cast<const double2 *>(g_clv + ((size_t)c*np + n)*4);
+      const double2 * p = reinterpret_cast<const double2 *>(g_clv + (size_t)c*np*4);
       const double2 u = p[0], w = p[1];
       s_clv[c][lane][0] = u.x; s_clv[c][lane][1] = u.y; s_clv[c][lane][2] = w.x; s_clv[c][lane][3] = w.y;
+    }
+    rate = R.rate; rw = R.rw; f0 = R.f0; f1 = R.f1; f2 = R.f2; f3 = R.f3;
+    if (n == 0)
+    {
+      const uint4 g4 = *reinterpret_cast<const uint4 *>(R.gl), n4 = *reinterpret_cast<const uint4 *>(R.nin);
+      cn.gl.w[0] = g4.x; cn.gl.w[1] = g4.y; cn.gl.w[2] = g4.z; cn.gl.w[3] = g4.w;
+      cn.nin.w[0] = n4.x; cn.nin.w[1] = n4.y; cn.nin.w[2] = n4.z; cn.nin.w[3] = n4.w;
     }
   }
   // trees of this workgroup's loci: all lanes copy, 16 B at a time
@@ -537,13 +667,13 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     // THETA moved thetas after these densities were stored: every tree's density again, from its statistics — one
     // population's term per lane, added up in population order (what theta_step_all of a00_driver.c recomputes)
     if (active)
-      for (int p = (int)n; p < sp.npop; p += (int)np)
+      for (int p = (int)n; p < npop; p += (int)np)
         s_task[ts].contrib_new[p] = msc_term(A.pop_nc[(size_t)p*A.ntasks + task], A.pop_t2h[(size_t)p*A.ntasks + task], s_tau[MAXPOP + p], s_tau[2*MAXPOP + p]);
     __syncthreads();
     if (leader)
     {
       double lp = 0;
-      for (int p = 0; p < sp.npop; ++p) lp += s_task[ts].contrib_new[p];
+      for (int p = 0; p < npop; ++p) lp += s_task[ts].contrib_new[p];
       s_task[ts].tr.logpr = lp;
     }
     __syncthreads();
@@ -552,9 +682,9 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   double lminf = 0, lmaxf = 0, tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1;
   if (A.mode == 4)
   {
-    const int q = (int)A.tau_q, pq = sp.parent[q];
-    tq_old = s_tau[q]; tq_lo = fmax(s_tau[sp.left[q]], s_tau[sp.right[q]]); tq_hi = pq >= 0 ? s_tau[pq] : 999.0;
-    const double tnew = reflect(tq_old + sp.ft_tau*(A.tau_u - 0.5), tq_lo, tq_hi);
+    const int q = (int)A.tau_q, pq = spl.parent[q];
+    tq_old = s_tau[q]; tq_lo = fmax(s_tau[spl.left[q]], s_tau[spl.right[q]]); tq_hi = pq >= 0 ? s_tau[pq] : 999.0;
+    const double tnew = reflect(tq_old + spl.ft_tau*(A.tau_u - 0.5), tq_lo, tq_hi);
     minf = (tnew - tq_lo)/(tq_old - tq_lo); maxf = (tnew - tq_hi)/(tq_old - tq_hi);
     lminf = log(minf); lmaxf = log(maxf);
     __syncthreads();
@@ -563,96 +693,98 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
   else if (A.mode == 1)
   {
     __syncthreads();
-    if (lane < (uint32_t)sp.npop) s_tau[lane] *= A.mix_c;
+    if (lane < (uint32_t)npop) s_tau[lane] *= A.mix_c;
   }
+  // ---- the leader takes its tree into registers
+  LTree<NT> T;
+  LUndo<NT> U;
+  TimeUndo tu{0, 0, 0, -1, -1, -1};
+  double lnl_cur = 0, logpr_cur = 0, hast = 0, hast2 = 0;
+  uint32_t nprop_done = 0, nacc = 0, w_nupd = 0, w_nbr = 0;
   if (leader)
   {
     TaskLDS & S = s_task[ts];
     if (restore_mix) { S.tr.rng = A.trees[task].rng; S.tr.proposals = A.trees[task].proposals; S.tr.accepted = A.trees[task].accepted;
                        S.tr.sw_nupd = A.trees[task].sw_nupd; S.tr.sw_nbr = A.trees[task].sw_nbr; }
-    if (A.mode == 0) density_prepare<NT>(S, sp, (1u << sp.npop) - 1u);      // the current terms: counts here, terms by the lanes below
-    S.nops = 0; S.active = 0;
-    S.prof_on = (A.dbg & 8u) && b == 0 && ts == 0; for (int i = 0; i < 8; ++i) S.prof[i] = 0;
+    T.load(S.tr);
+    lnl_cur = S.tr.lnl; logpr_cur = S.tr.logpr;
+    if (A.mode == 0) density_prepare<NT>(S, T, cn, sp, (1u << npop) - 1u);      // the current terms: counts here, terms by the lanes below
+    S.nops = 0; S.active = 0; S.wclv = 0; S.brm = 0;
   }
+  else { T.time = nullptr; T.rng = 0; T.root = 0; T.tips = 0; }
   __syncthreads();
   if (A.mode == 0)
   {
-    if (active) lanes_density(s_task[ts], sp, s_tau, n, np);
+    if (active) lanes_density(s_task[ts], spl, s_tau, n, np);
     __syncthreads();
-    if (leader) commit_logpr(s_task[ts]);
+    if (leader) commit_logpr(s_task[ts], cn);
     __syncthreads();
   }
 
   const uint32_t nprop = A.mode == 0 ? A.nsteps_gage + A.nsteps_gspr : (A.mode == 2 ? 0u : 1u);
-  // phase timing of workgroup 0 (BPA_SMP_DBG & 16): undo copy | proposal | lanes' share | node updates | decision | roll-back
+  // phase timing of workgroup 0 (BPA_SMP_DBG & 16): proposal | lanes' share | node updates | decision
   const bool ph_on = (A.dbg & 16u) && b == 0 && lane == 0;
+  Prof pf; pf.on = ph_on; pf.t = 0; for (int i = 0; i < 12; ++i) pf.acc[i] = 0;
   long long ph[6] = {0, 0, 0, 0, 0, 0}, ph_t = ph_on ? clock64() : 0;
   if (ph_on) A.mix_delta[14] = (double)(ph_t - ph_start);
 #define SMP_PHASE(i_) do { if (ph_on) { const long long t1_ = clock64(); ph[i_] += t1_ - ph_t; ph_t = t1_; } } while (0)
   for (uint32_t step = 0; step < nprop; ++step)
   {
-    // ---- undo copy of every tree of the workgroup (all lanes, 16 B at a time)
-    {
-      constexpr uint32_t U = sizeof(Tree)/16;
-      for (uint32_t i = lane; i < ntask*U; i += BS)
-        reinterpret_cast<uint4 *>(&s_task[i/U].undo)[i % U] = reinterpret_cast<const uint4 *>(&s_task[i/U].tr)[i % U];
-    }
-    __syncthreads();
-    SMP_PHASE(0);
-    // ---- phase 1: the locus's leader lane proposes
+    // ---- phase 1: the locus's leader lane proposes (registers), then mirrors the tree for the other lanes
     if (leader)
     {
       TaskLDS & S = s_task[ts];
       bool ok; int act = 1;
+      if (A.mode == 0) save<NT>(U, T);
       if (A.mode == 0 && (A.dbg & 4u)) ok = false;
       else if (A.mode == 0)
-        ok = step < A.nsteps_gage ? propose_gage<NT>(S, (int)step, sp, s_tau) : propose_gspr<NT>(S, (int)(step - A.nsteps_gage), sp, s_tau, s_lograt);
+        ok = step < A.nsteps_gage ? propose_gage<NT>(S, T, cn, tu, hast, (int)step, sp, spl, s_tau, pf)
+                                  : propose_gspr<NT>(S, T, cn, tu, hast, (int)(step - A.nsteps_gage), sp, spl, s_tau, s_lograt, pf);
       else if (A.mode == 4)
       {
         // TAU q (tau_step of a00_driver.c): the gene nodes of q and its children between the bounds move
-        Tree & t = S.tr;
-        const int nn_ = 2*t.tips - 1, q = (int)A.tau_q, cl = sp.left[q], cr = sp.right[q];
-        A.snap[task] = t;
+        const int nn_ = 2*T.tips - 1, q = (int)A.tau_q, cl = sp.left[q], cr = sp.right[q];
+        A.snap[task] = S.tr;
         uint32_t brm = 0, ndm = 0; int above = 0, below = 0;
-        for (int k = t.tips; k < nn_; ++k)
+        for (int k = T.tips; k < nn_; ++k)
         {
-          const int pk = t.pop[k]; const double tk = t.time[k];
+          const int pk = T.pop[k]; const double tk = T.time[k];
           if ((pk != q && pk != cl && pk != cr) || tk < tq_lo || tk > tq_hi) continue;
-          if (tk >= tq_old) { t.time[k] = tq_hi + maxf*(tk - tq_hi); ++above; } else { t.time[k] = tq_lo + minf*(tk - tq_lo); ++below; }
-          brm |= (1u << t.left[k]) | (1u << t.right[k]);
-          if (t.parent[k] >= 0) brm |= 1u << k;
-          ndm |= path_mask(t, k);
+          if (tk >= tq_old) { T.time[k] = tq_hi + maxf*(tk - tq_hi); ++above; } else { T.time[k] = tq_lo + minf*(tk - tq_lo); ++below; }
+          brm |= (1u << (int)T.left[k]) | (1u << (int)T.right[k]);
+          if (T.parent[k] >= 0) brm |= 1u << k;
+          ndm |= path_mask(T, k);
         }
-        density_prepare<NT>(S, sp, (1u << sp.npop) - 1u);
-        S.hast = below*lminf; S.hast2 = above*lmaxf;     // p_delta of the host driver = (density difference + hast) + hast2, below
+        density_prepare<NT>(S, T, cn, sp, (1u << npop) - 1u);
+        hast = below*lminf; hast2 = above*lmaxf;       // p_delta of the host driver = (density difference + hast) + hast2, below
         ok = true;
-        if (ndm) install(S, brm, ndm);
+        if (ndm) install<NT>(S, T, brm, ndm);
         else { S.brm = 0; S.nops = 0; act = 3; }         // no gene node moves here: only the density changes
       }
       else
       {
         // mixing (mix_step of a00_driver.c) or start-up: every branch, every inner node
-        Tree & t = S.tr;
-        const int nn_ = 2*t.tips - 1;
-        if (A.mode == 1) A.snap[task] = t;
+        const int nn_ = 2*T.tips - 1;
+        if (A.mode == 1) A.snap[task] = S.tr;
         uint32_t brm = 0, ndm = 0; int ninner = 0;
         for (int k = 0; k < nn_; ++k)
         {
-          if (t.left[k] >= 0) { if (A.mode == 1) t.time[k] *= A.mix_c; ndm |= 1u << k; ++ninner; }
-          if (t.parent[k] >= 0) brm |= 1u << k;
+          if (T.left[k] >= 0) { if (A.mode == 1) T.time[k] *= A.mix_c; ndm |= 1u << k; ++ninner; }
+          if (T.parent[k] >= 0) brm |= 1u << k;
         }
         if (A.mode == 3)
         {
-          for (uint32_t m = brm; m; m &= m - 1) swap_pmat(t, __ffs(m) - 1);       // start-up evaluates in place:
-          for (uint32_t m = ndm; m; m &= m - 1) swap_clv(t, __ffs(m) - 1);        // toggle twice = no toggle
+          for (uint32_t m = brm; m; m &= m - 1) swap_pmat(T, __ffs(m) - 1);       // start-up evaluates in place:
+          for (uint32_t m = ndm; m; m &= m - 1) swap_clv(T, __ffs(m) - 1);        // toggle twice = no toggle
         }
-        density_prepare<NT>(S, sp, (1u << sp.npop) - 1u);
-        S.hast = (double)ninner*A.mix_lnc;
-        install(S, brm, ndm);
+        density_prepare<NT>(S, T, cn, sp, (1u << npop) - 1u);
+        hast = (double)ninner*A.mix_lnc;
+        install<NT>(S, T, brm, ndm);
         ok = true;
       }
       S.active = ok ? act : 0;
       if (!ok) S.nops = 0;
+      else T.mirror(S.tr);
     }
     __syncthreads();
     SMP_PHASE(1);
@@ -661,7 +793,7 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     if (active && s_task[ts].active)
     {
       TaskLDS & S = s_task[ts];
-      lanes_density(S, sp, s_tau, n, np);
+      lanes_density(S, spl, s_tau, n, np);
       lanes_branches(S, rate, n, np);
     }
     __syncthreads();
@@ -671,23 +803,28 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     if (active && s_task[ts].active == 1 && !(A.dbg & 1u))
     {
       const TaskLDS & S = s_task[ts];
-      for (int o = 0; o < S.nops; ++o)
+      const int nops = S.nops;
+      double last[4] = {0, 0, 0, 0}; uint32_t last_c = 0xffffffffu;
+      for (int o = 0; o < nops; ++o)
       {
         const Op opw = S.ops[o];
         const struct { uint32_t parent, lc, lp, rc, rp; } op = {(uint32_t)opw & 255u, (uint32_t)(opw >> 8) & 255u, (uint32_t)(opw >> 16) & 255u,
                                                                 (uint32_t)(opw >> 24) & 255u, (uint32_t)(opw >> 32) & 255u};
         double lv[4], rv[4], x[4], y[4];
-        if ((uint32_t)op.lc < tips) expand_code((tipcodes >> (4*op.lc)) & 15u, lv);
+        if (op.lc < tips) expand_code((tipcodes >> (4*op.lc)) & 15u, lv);
+        else if (op.lc == last_c) { lv[0] = last[0]; lv[1] = last[1]; lv[2] = last[2]; lv[3] = last[3]; }
         else { const double * c = s_clv[op.lc - tips][lane]; lv[0] = c[0]; lv[1] = c[1]; lv[2] = c[2]; lv[3] = c[3]; }
-        if ((uint32_t)op.rc < tips) expand_code((tipcodes >> (4*op.rc)) & 15u, rv);
+        if (op.rc < tips) expand_code((tipcodes >> (4*op.rc)) & 15u, rv);
+        else if (op.rc == last_c) { rv[0] = last[0]; rv[1] = last[1]; rv[2] = last[2]; rv[3] = last[3]; }
         else { const double * c = s_clv[op.rc - tips][lane]; rv[0] = c[0]; rv[1] = c[1]; rv[2] = c[2]; rv[3] = c[3]; }
         matvec4_ab(S.ab[op.lp][0], S.ab[op.lp][1], lv, x);
         matvec4_ab(S.ab[op.rp][0], S.ab[op.rp][1], rv, y);
+        last[0] = x[0]*y[0]; last[1] = x[1]*y[1]; last[2] = x[2]*y[2]; last[3] = x[3]*y[3]; last_c = op.parent;
         double * out = s_clv[op.parent - tips][lane];
-        out[0] = x[0]*y[0]; out[1] = x[1]*y[1]; out[2] = x[2]*y[2]; out[3] = x[3]*y[3];
+        out[0] = last[0]; out[1] = last[1]; out[2] = last[2]; out[3] = last[3];
       }
-      const double * c = s_clv[S.tr.clv[S.tr.root] - tips][lane];
-      const double tr_ = dot4_pair(f0, f1, f2, f3, c);
+      // the last update is the root's (children first, the root is the oldest node of every update list)
+      const double tr_ = dot4_pair(f0, f1, f2, f3, last);
       term = log(0 + tr_*rw)*wgt;
     }
     s_term[lane] = term;
@@ -698,10 +835,11 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     {
       // TAU without a moving gene node in this locus
       TaskLDS & S = s_task[ts];
-      S.logpr_new = density_sum(S, sp);
-      const double dl = ((S.logpr_new - S.tr.logpr) + S.hast) + S.hast2;
+      const double lp_new = density_sum(S, npop);
+      const double dl = ((lp_new - logpr_cur) + hast) + hast2;
       A.mix_delta[task] = dl; S.hast = dl;
-      S.tr.logpr = S.logpr_new;
+      logpr_cur = lp_new;
+      commit_logpr(S, cn);
     }
     else if (leader && s_task[ts].active)
     {
@@ -709,54 +847,62 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
       double lnl = 0;
       for (uint32_t q = 0; q < np; ++q) lnl += s_term[lane + q];
       lnl = A.bfbeta == 1.0 ? lnl : A.bfbeta == 0.0 ? 0.0 : A.bfbeta*lnl;
-      long long tp3 = clock64();
-      S.logpr_new = density_sum(S, sp);
+      const double lp_new = density_sum(S, npop);
       if (A.mode == 0)
       {
-        S.tr.sw_nupd += (uint32_t)S.nops; S.tr.sw_nbr += (uint32_t)__popc(S.brm);
-        const double lnacc = (S.logpr_new - S.tr.logpr) + (lnl - S.tr.lnl) + S.hast;
-        const double u = rndu(&S.tr.rng);
-        S.tr.proposals++;
-        if (lnacc >= 0 || u < exp(lnacc)) { S.tr.lnl = lnl; S.tr.logpr = S.logpr_new; S.tr.accepted++; S.active = 1; commit_logpr(S); }
-        else S.active = 2;                               // rejected: restore below
-        SMP_PROF(S, 7, tp3);
+        w_nupd += (uint32_t)S.nops; w_nbr += (uint32_t)__popc(S.brm);
+        const double lnacc = (lp_new - logpr_cur) + (lnl - lnl_cur) + hast;
+        const double u = rndu(&T.rng);
+        ++nprop_done;
+        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; commit_logpr(S, cn); }
+        else
+        {
+          // rejected: topology, populations and buffer indices come back from the register copy, the moved ages from tu
+          restore<NT>(T, U);
+          if (tu.na >= 0) { T.time[tu.na] = tu.ta; T.time[tu.nb] = tu.tb; }
+          T.time[tu.n0] = tu.t0;
+          T.mirror(S.tr);
+        }
       }
       else
       {
-        const double dpr = S.logpr_new - S.tr.logpr;
-        const double h = A.mode == 4 ? (dpr + S.hast) + S.hast2 : dpr + S.hast;
-        const double dl = A.mode == 3 ? 0.0 : (lnl - S.tr.lnl) + h;
+        const double dpr = lp_new - logpr_cur;
+        const double h = A.mode == 4 ? (dpr + hast) + hast2 : dpr + hast;
+        const double dl = A.mode == 3 ? 0.0 : (lnl - lnl_cur) + h;
         A.mix_delta[task] = dl; S.hast = dl;
-        S.tr.lnl = lnl; S.tr.logpr = S.logpr_new;
+        lnl_cur = lnl; logpr_cur = lp_new;
+        commit_logpr(S, cn);
       }
     }
     __syncthreads();
     SMP_PHASE(4);
-    // ---- rejected proposals: topology, ages, populations and buffer indices come back from the undo copy (all lanes)
-    if (A.mode == 0)
-    {
-      constexpr uint32_t U = (uint32_t)(offsetof(Tree, lnl)/16);      // everything before lnl/logpr/rng/counters
-      for (uint32_t i = lane; i < ntask*U; i += BS)
-        if (s_task[i/U].active == 2)
-          reinterpret_cast<uint4 *>(&s_task[i/U].tr)[i % U] = reinterpret_cast<const uint4 *>(&s_task[i/U].undo)[i % U];
-      __syncthreads();
-      if (leader && s_task[ts].active == 2) s_task[ts].tr.root = s_task[ts].undo.root;
-    }
-    SMP_PHASE(5);
   }
-  __syncthreads();
   if (ph_on) for (int i = 0; i < 6; ++i) A.mix_delta[8 + i] = (double)ph[i];
+  if (ph_on) for (int i = 0; i < 12; ++i) A.mix_delta[16 + i] = (double)pf.acc[i];
   const long long ph_store = clock64();
 #undef SMP_PHASE
 
-  // ---- an all-loci step leaves the sum of its loci's terms (task order): 839 values for the decision kernel instead of 10 000
+  // ---- an all-loci step leaves the sum of its loci's terms (task order): 839 values for the decision instead of 10 000
   if ((A.mode == 1 || A.mode == 4) && lane == 0)
   {
     double part = 0;
     for (uint32_t k = 0; k < ntask; ++k) part += s_task[k].hast;
-    A.part_out[b] = part;
+    if (!A.dec_on) A.part_out[b] = part;
+    else
+    {
+      __hip_atomic_store(A.part_out + b, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the sum is out before the stamp says so
+      __hip_atomic_store(A.dec_stamps + b, (unsigned long long)A.dec_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   // ---- store
+  if (leader)
+  {
+    // the scalars the leader kept in registers go back into the LDS tree that is copied out below
+    TaskLDS & S = s_task[ts];
+    S.tr.rng = T.rng; S.tr.lnl = lnl_cur; S.tr.logpr = logpr_cur;
+    S.tr.proposals += nprop_done; S.tr.accepted += nacc; S.tr.sw_nupd += w_nupd; S.tr.sw_nbr += w_nbr;
+  }
   if (A.mode == 0)
   {
     // the sufficient statistics of the final state, for the THETA kernels (not kept in LDS along the way: a workgroup
@@ -764,34 +910,62 @@ __global__ void __launch_bounds__(BS) sweep_kernel(const Args A)
     if (leader)
     {
       TaskLDS & S = s_task[ts];
-      density_prepare<NT>(S, sp, (1u << sp.npop) - 1u);
-      for (int p = 0; p < sp.npop; ++p) A.pop_nc[(size_t)p*A.ntasks + task] = S.nc_new[p];
+      density_prepare<NT>(S, T, cn, sp, (1u << npop) - 1u);
+      for (int p = 0; p < npop; ++p) A.pop_nc[(size_t)p*A.ntasks + task] = (int8_t)(int)cn.nc_new[p];
     }
     __syncthreads();
-    if (active) lanes_density(s_task[ts], sp, s_tau, n, np, A.pop_t2h + task, A.ntasks);
+    if (active) lanes_density(s_task[ts], spl, s_tau, n, np, A.pop_t2h + task, A.ntasks);
   }
+  __syncthreads();
   {
-    constexpr uint32_t U = sizeof(Tree)/16;
-    for (uint32_t i = lane; i < ntask*U; i += BS)
-      reinterpret_cast<uint4 *>(A.trees + t0 + i/U)[i % U] = reinterpret_cast<const uint4 *>(&s_task[i/U].tr)[i % U];
-  }
-  if (leader)
-  {
-    const TaskLDS & S = s_task[ts];
-    if (S.prof_on) for (int i = 0; i < 8; ++i) A.mix_delta[i] = (double)S.prof[i];
+    constexpr uint32_t U4 = sizeof(Tree)/16;
+    for (uint32_t i = lane; i < ntask*U4; i += BS)
+      reinterpret_cast<uint4 *>(A.trees + t0 + i/U4)[i % U4] = reinterpret_cast<const uint4 *>(&s_task[i/U4].tr)[i % U4];
   }
   if (active && nprop)
   {
     for (uint32_t i = n; i < 4*(2*tips - 2); i += np) g_pmat[i] = (&s_task[ts].ab[0][0])[i];
-    const uint32_t nbuf = 2*(tips - 1);
-    for (uint32_t c = 0; c < nbuf; ++c)
+    // only the CLV buffers a node update wrote go back
+    const uint32_t wclv = s_task[ts].wclv;
+    for (uint32_t m = wclv; m; m &= m - 1)
     {
-      double2 * p = reinterpret_cast<double2 *>(g_clv + ((size_t)c*np + n)*4);
+      const uint32_t c = (uint32_t)__ffs(m) - 1u;
+      double2 * p = reinterpret_cast<double2 *>(g_clv + (size_t)c*np*4);
       double2 u, w; u.x = s_clv[c][lane][0]; u.y = s_clv[c][lane][1]; w.x = s_clv[c][lane][2]; w.y = s_clv[c][lane][3];
       p[0] = u; p[1] = w;
     }
   }
   if (ph_on) A.mix_delta[15] = (double)(clock64() - ph_store);
+
+  // ---- the decision, by the last workgroup of the grid (its own state is stored: it has nothing else to do)
+  if (A.dec_on && (A.mode == 1 || A.mode == 4) && b == gridDim.x - 1)
+  {
+    const uint32_t nb = gridDim.x;
+    const unsigned long long stamp = A.dec_epoch, t_wait = wall_clock64();
+    bool timed_out = false;
+    for (;;)
+    {
+      bool all = true;
+      for (uint32_t i = lane; i < nb; i += BS)
+        all = all && __hip_atomic_load(A.dec_stamps + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stamp;
+      if (__all(all)) break;
+      if (wall_clock64() - t_wait > 20000000ull) { timed_out = true; break; }       // 0.2 s at 100 MHz
+      __builtin_amdgcn_s_sleep(2);
+    }
+    double acc = 0;
+    for (uint32_t i = lane; i < nb; i += BS) acc += __hip_atomic_load(A.part_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    s_term[lane] = acc;
+    __syncthreads();
+    if (lane == 0)
+    {
+      double tot = 0;
+      for (int q = 0; q < BS; ++q) tot += s_term[q];
+      if (timed_out) { *A.dec_err = 1; tot = -1e300; }              // a lost stamp: reject (the trees roll back) and tell the host
+      decide(tot, A.dec_uacc, A.dec_epoch, A.dec_flag, A.dec_counters, A.dec_taus, spl, A.mode == 4 ? (int)A.tau_q : -1, -1,
+             A.tau_u, A.mix_c, A.mix_lnc);
+    }
+  }
 }
 
 // the single decision of an all-loci step (tau_step / mix_step of a00_driver.c; stree.c:6280,
@@ -915,7 +1089,26 @@ struct bpa_sampler
   DevBuf<smp::LaneRec> lane_rec;
   DevBuf<smp::TaskRec> task_rec;
   DevBuf<smp::Tree> trees, snap;
-  DevBuf<double> mix_delta, mix_sum, taus, pop_t2h, theta_sums, lograt, wg_part;
+  DevBuf<double> mix_delta, mix_sum, taus, pop_t2h, theta_sums, lograt;
+  // per-workgroup sums of an all-loci step and their stamps: UNCACHED device memory — the deciding workgroup reads what
+  // workgroups on other XCDs (other L2s) wrote during the same launch (Args::dec_*)
+  struct Uncached
+  {
+    void * p = nullptr;
+    bool reserve(size_t bytes)
+    {
+      if (p) return true;
+      if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess)
+      {
+        (void)hipGetLastError(); p = nullptr;
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+      }
+      return p && hipMemset(p, 0, bytes) == hipSuccess;
+    }
+    void free() { if (p) (void)hipFree(p); p = nullptr; }
+  } uc;
+  double * wg_part = nullptr; unsigned long long * stamps = nullptr; int * dec_err = nullptr;
+  bool fuse_decision = false;           // BPA_SMP_FUSE=1: the decision inside the step launch (measured: slower)
   DevBuf<int8_t> pop_nc;
   smp::Species sp{};                    // species tree (host copy; the taus below are only the start values)
   bool has_theta[smp::MAXPOP] = {};     // populations that can hold a coalescence (a00_initialize)
@@ -967,6 +1160,7 @@ extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * co
   if (const char * dv = getenv("BPA_SMP_DBG")) s->env_dbg = (uint32_t)atoi(dv);
   if (const char * st = getenv("BPA_SMP_STEPS")) { unsigned g = 0, q = 0; if (sscanf(st, "%u,%u", &g, &q) == 2) { s->env_gage = (int)g; s->env_gspr = (int)q; } }
   s->env_trace = getenv("BPA_SMP_TRACE") != nullptr; s->env_nomix = getenv("BPA_SMP_NOMIX") != nullptr;
+  s->fuse_decision = getenv("BPA_SMP_FUSE") != nullptr;
   s->sp.ft_gage = 0.004; s->sp.ft_gspr = 0.004; s->sp.ft_tau = 0.001; s->sp.ft_mix = 0.3;      // a00_create's defaults
   return s;
 }
@@ -979,7 +1173,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   (void)hipStreamSynchronize(s->eng->stream);
   for (auto & t : s->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   s->blk_task_off.free(); s->lane_rec.free(); s->task_rec.free(); s->flag.free();
-  s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free(); s->wg_part.free();
+  s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free(); s->uc.free();
   delete s;
 }
 
@@ -1038,7 +1232,7 @@ static int sampler_upload(bpa_sampler * s)
   std::vector<uint32_t> blk_off{0};
   std::vector<smp::LaneRec> lane_rec;
   std::vector<smp::TaskRec> task_rec(T);
-  const smp::LaneRec idle{0xffffffffu, 0, 0, 0};
+  const smp::LaneRec idle{0xffffffffu, 0, 0, 0, nullptr, nullptr};
   unsigned used = 0, ntask = 0;
   for (unsigned t = 0; t < T; ++t)
   {
@@ -1050,7 +1244,7 @@ static int sampler_upload(bpa_sampler * s)
     {
       uint32_t codes = 0;
       for (unsigned tip = 0; tip < tips; ++tip) codes |= (uint32_t)(l->tipcodes[(size_t)tip*np + n] & 15u) << (4*tip);
-      lane_rec.push_back(smp::LaneRec{t, l->weights[n], codes, n | np << 8 | tips << 16});
+      lane_rec.push_back(smp::LaneRec{t, l->weights[n], codes, n | np << 8 | tips << 16, l->dev.clv + (size_t)n*4, l->dev.pmat});
     }
     used += np; ++ntask;
     smp::TaskRec & r = task_rec[t];
@@ -1074,8 +1268,17 @@ static int sampler_upload(bpa_sampler * s)
       !upload(s->trees, s->h_trees.data(), T) || !upload(s->snap, s->h_trees.data(), T) ||
       !upload(s->flag, zero2, 1) || !upload(s->counters, zero2, 2) || !s->mix_delta.reserve(T) || !s->mix_sum.reserve(1) ||
       !upload(s->taus, s->h_taus.data(), s->h_taus.size()) || !s->pop_t2h.reserve((size_t)T*smp::MAXPOP) ||
-      !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP) || !s->lograt.reserve(smp::MAXN*smp::MAXN) || !s->wg_part.reserve(s->nblocks))
+      !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP) || !s->lograt.reserve(smp::MAXN*smp::MAXN))
     return 0;
+  {
+    // [nblocks] sums | [nblocks] stamps | error flag
+    const size_t nb = ((size_t)s->nblocks + 1)*8;
+    s->uc.free();
+    if (!s->uc.reserve(2*nb + 64)) return fail("bpa_sampler: out of (uncached) device memory");
+    s->wg_part = reinterpret_cast<double *>(s->uc.p);
+    s->stamps = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(s->uc.p) + nb);
+    s->dec_err = reinterpret_cast<int *>(reinterpret_cast<char *>(s->uc.p) + 2*nb);
+  }
   if (s->allreduce)
   {
     // Sharded run: which populations can hold a coalescence is a property of ALL loci, not of this rank's — every rank
@@ -1112,10 +1315,17 @@ static int sampler_timing_drain(bpa_sampler * s)
   return 1;
 }
 
-static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double mix_lnc = 0, unsigned tau_q = 0, double tau_u = 0)
+// dec_uacc >= 0: an all-loci step (mode 1 / 4) that takes its own decision (Args::dec_*)
+static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double mix_lnc = 0, unsigned tau_q = 0, double tau_u = 0,
+                          double dec_uacc = -1.0)
 {
   bpa_engine * e = s->eng;
   smp::Args a{};
+  if (dec_uacc >= 0)
+  {
+    a.dec_on = 1u; a.dec_epoch = s->epoch + 1; a.dec_uacc = dec_uacc;
+    a.dec_flag = s->flag.p; a.dec_counters = s->counters.p; a.dec_taus = s->taus.p; a.dec_stamps = s->stamps; a.dec_err = s->dec_err;
+  }
   a.lane_rec = s->lane_rec.p; a.task_rec = s->task_rec.p; a.blk_task_off = s->blk_task_off.p;
   a.trees = s->trees.p; a.snap = s->snap.p;
   a.mix_delta = s->mix_delta.p; a.mix_flag = s->flag.p; a.mode = mode;
@@ -1125,7 +1335,7 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
   s->mix_pending = false;
   a.bfbeta = e->usedata ? e->bfbeta : 0.0;
   a.refresh_logpr = s->logpr_stale ? 1u : 0u; s->logpr_stale = false;
-  a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p; a.lograt = s->lograt.p; a.ntasks = s->nloci; a.part_out = s->wg_part.p;
+  a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p; a.lograt = s->lograt.p; a.ntasks = s->nloci; a.part_out = s->wg_part;
   a.dbg = s->env_dbg;
   a.taus = s->taus.p; a.tau_q = tau_q; a.tau_u = tau_u; a.sp = s->sp; a.mix_lnc = mix_lnc;
   a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2; a.mix_c = mix_c;
@@ -1140,23 +1350,17 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
     (void)hipStreamSynchronize(e->stream);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     fprintf(stderr, "[smp] mode %u gage %u gspr %u epoch %u blocks %u: %.1f us\n", mode, a.nsteps_gage, a.nsteps_gspr, a.epoch, s->nblocks, ms*1e3);
-    if ((a.dbg & 16u) && mode != 0)
+    if (a.dbg & 16u)
     {
       double ph[8]; (void)hipMemcpy(ph, s->mix_delta.p + 8, sizeof ph, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[smp] cycles of workgroup 0: load %.0f undo copy %.0f proposal %.0f lanes %.0f node updates %.0f decision %.0f store %.0f\n",
-              ph[6], ph[0], ph[1], ph[2], ph[3], ph[4], ph[7]);
-    }
-    if ((a.dbg & 8u) && mode == 0)
-    {
-      double pr[8]; (void)hipMemcpy(pr, s->mix_delta.p, sizeof pr, hipMemcpyDeviceToHost);
-      if (a.dbg & 16u)
+      fprintf(stderr, "[smp] cycles of workgroup 0: load %.0f proposal %.0f lanes %.0f node updates %.0f decision %.0f store %.0f\n",
+              ph[6], ph[1], ph[2], ph[3], ph[4], ph[7]);
+      if (mode == 0)
       {
-        double ph[8]; (void)hipMemcpy(ph, s->mix_delta.p + 8, sizeof ph, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[smp] cycles of workgroup 0: load %.0f undo copy %.0f proposal %.0f lanes %.0f node updates %.0f decision %.0f roll-back %.0f store %.0f\n",
-                ph[6], ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[7]);
+        double pr[12]; (void)hipMemcpy(pr, s->mix_delta.p + 16, sizeof pr, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[smp] leader of locus 0, all proposals: gspr links %.0f subtree/pop0 %.0f bounds %.0f scan %.0f surgery %.0f masks %.0f density %.0f install %.0f | gage pre %.0f density %.0f install %.0f\n",
+                pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10]);
       }
-      fprintf(stderr, "[smp] cycles of one locus: gage pre %.0f density %.0f install %.0f | gspr pre %.0f log %.0f density %.0f install %.0f | decide %.0f\n",
-              pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7]);
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     s->launches++;
@@ -1270,7 +1474,7 @@ static int sampler_sum(bpa_sampler * s)
 {
   bpa_engine * e = s->eng;
   double * out = s->sum_ext ? s->sum_ext : s->mix_sum.p;
-  hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->wg_part.p, s->nblocks, out);
+  hipLaunchKernelGGL(lnl_sum_kernel, dim3(1), dim3(1024), 0, e->stream, s->wg_part, s->nblocks, out);
   HIPCHK(hipGetLastError());
   if (s->allreduce && !s->allreduce(s->allreduce_ctx, out, 1u, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
   return 1;
@@ -1282,7 +1486,7 @@ static int sampler_decide(bpa_sampler * s, double uacc, int tau_q, int theta_p, 
   bpa_engine * e = s->eng;
   s->epoch++;
   if (!s->allreduce)
-    hipLaunchKernelGGL(smp::sum_decide_kernel, dim3(1), dim3(1024), 0, e->stream, s->wg_part.p, s->nblocks, uacc, s->epoch,
+    hipLaunchKernelGGL(smp::sum_decide_kernel, dim3(1), dim3(1024), 0, e->stream, s->wg_part, s->nblocks, uacc, s->epoch,
                        s->flag.p, s->counters.p, s->taus.p, s->sp, tau_q, theta_p, win_u, mix_c, mix_lnc);
   else
   {
@@ -1291,6 +1495,7 @@ static int sampler_decide(bpa_sampler * s, double uacc, int tau_q, int theta_p, 
                        s->flag.p, s->counters.p, s->taus.p, s->sp, tau_q, theta_p, win_u, mix_c, mix_lnc);
   }
   HIPCHK(hipGetLastError());
+  s->launches += s->allreduce ? 2 : 1;
   s->mix_pending = true;
   return 1;
 }
@@ -1314,6 +1519,7 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
   bpa_engine * e = s->eng;
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   if (!sampler_upload(s)) return 0;
+  const bool fused = s->fuse_decision && !s->allreduce && !s->env_trace;      // (several GPUs: sum -> all-reduce -> decide)
   for (unsigned it = 0; it < iterations; ++it)
   {
     if (!sampler_launch(s, 0, 1.0)) return 0;                    // GAGE + GSPR of every locus (settles a pending mix first)
@@ -1349,11 +1555,24 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
     for (int q = s->sp.S; q < s->sp.npop; ++q)                    // one rubber-band step per species divergence
     {
       const double uprop = a00_rndu(&s->grng), uacc_t = a00_rndu(&s->grng);
+      if (fused)
+      {
+        // the step's launch decides for itself (its last workgroup): no kernel of its own for the decision
+        if (!sampler_launch(s, 4, 1.0, 0.0, (unsigned)q, uprop, uacc_t)) return 0;
+        s->epoch++; s->mix_pending = true;
+        continue;
+      }
       if (!sampler_launch(s, 4, 1.0, 0.0, (unsigned)q, uprop)) return 0;
       if (!sampler_decide(s, uacc_t, q, -1, uprop, 1.0, 0.0)) return 0;
     }
     const double lnc = s->sp.ft_mix*(a00_rndu(&s->grng) - 0.5), c = std::exp(lnc);
     const double uacc = a00_rndu(&s->grng);
+    if (fused)
+    {
+      if (!sampler_launch(s, 1, c, lnc, 0, 0.0, uacc)) return 0;
+      s->epoch++; s->mix_pending = true;
+      continue;
+    }
     if (!sampler_launch(s, 1, c, lnc)) return 0;                 // mixing proposal of every locus
     if (!sampler_decide(s, uacc, -1, -1, 0.0, c, lnc)) return 0;
   }
@@ -1368,6 +1587,9 @@ static int sampler_download(bpa_sampler * s)
   if (!sampler_launch(s, 2, 1.0)) return 0;
   HIPCHK(hipMemcpyAsync(s->h_trees.data(), s->trees.p, s->nloci*sizeof(smp::Tree), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  int err = 0;
+  HIPCHK(hipMemcpy(&err, s->dec_err, sizeof err, hipMemcpyDeviceToHost));
+  if (err) return fail("bpa_sampler: an in-launch decision timed out waiting for a workgroup's sum (BPA_SMP_FUSE is set: unset it)");
   return 1;
 }
 

@@ -60,6 +60,30 @@ static inline double a00_rndu(a00_rng_t * r)
 }
 #define A00_GLOBAL_STREAM 0xFFFFFFFFu
 
+/* BPP's OWN generator and window kernel, restated (a00_set_proposal_kernel(d, A00_KERNEL_BPP) makes the driver use
+   them): legacy_rndu (random.c:104-122: z = z*69069 + 1 on 32 bits, 0 replaced by 12345671, value z*2^-32) and
+   legacy_rnd_symmetrical (random.c:230-238) = the Bactrian-Laplace variate rndBactrianLaplace (random.c:201-213;
+   rndLaplace :192-199; mBactrian = 0.90, random.c:24-25): mean 0, variance 1, two draws of the generator.  Bit-equal
+   to the reference's functions on the same state (tests/test_bpp_kernel.py).                                      */
+static inline double a00_bpp_rndu(unsigned int * z)
+{
+  *z = *z*69069u + 1u;
+  if (*z == 0) *z = 12345671u;
+  return ldexp((double)(*z), -32);
+}
+static inline double a00_bpp_rnd_laplace(unsigned int * z)
+{
+  const double u = a00_bpp_rndu(z) - 0.5;
+  const double r = log(1 - 2*fabs(u))*0.70710678118654752440;
+  return u >= 0 ? -r : r;
+}
+static inline double a00_bpp_rnd_symmetrical(unsigned int * z)
+{
+  double v = 0.90 + a00_bpp_rnd_laplace(z)*sqrt(1 - 0.90*0.90);
+  if (a00_bpp_rndu(z) < 0.5) v = -v;
+  return v;
+}
+
 /* gene tree of one locus: tips 0..tips-1, inner nodes after; the root node object stays
    the root (gtree.c:6129-6175), so pmatrix indices never collide */
 typedef struct a00_tree
@@ -105,6 +129,19 @@ int            a00_set_species_tree(a00_driver_t *, int species, const int * par
                                     const double * theta);
 /* species of the tips of locus i (default: tip k belongs to species k) */
 int            a00_set_tip_species(a00_driver_t *, unsigned i, const int * species);
+/* Which generator and window kernel the moves draw from.
+   A00_KERNEL_UNIFORM (default): a00_rndu streams, a step = finetune x (u - 1/2), acceptance "lnacc >= 0 or u < exp(lnacc)"
+     with u always drawn — the kernel the device-resident sampler (bpa_sampler_t) also runs: same streams, same trajectory.
+   A00_KERNEL_BPP: the reference's — legacy_rndu streams (one 32-bit state per locus + one global), a step =
+     finetune x legacy_rnd_symmetrical() for the ages, the taus and the thetas (gtree.c:4722, 6666; stree.c:5632, 3848),
+     finetune x (rndu - 1/2) for log c of the mixing step (prop_mixing.c), acceptance "lnacc >= -1e-10 or rndu < exp(lnacc)"
+     with the uniform drawn only when needed (gtree.c:5476, stree.c:6286).  The finetunes then mean what they mean in a
+     BPP control file.  Call before a00_initialize.                                                                   */
+#define A00_KERNEL_UNIFORM 0
+#define A00_KERNEL_BPP     1
+void           a00_set_proposal_kernel(a00_driver_t *, int kind);
+/* the first n values of the restated generator / window variate from state `seed` (tests) */
+void           a00_bpp_kernel_sequence(unsigned int seed, int symmetrical, int n, double * out);
 /* window widths of the four moves (defaults 0.004, 0.004, 0.001, 0.3) */
 void           a00_set_finetune(a00_driver_t *, double gage, double gspr, double tau, double mix);
 /* prior on the divergence times as BPP's 'tauprior = gamma a b': gamma(alpha, beta) on the root tau, the

@@ -85,6 +85,11 @@ class Driver:
     def set_finetune(self, gage, gspr, tau, mix):
         lib().a00_set_finetune(self.h, gage, gspr, tau, mix)
 
+    def set_proposal_kernel(self, kind):
+        """0 uniform windows on the a00 streams (default), 1 BPP's legacy_rndu + Bactrian-Laplace (A00_KERNEL_BPP)"""
+        lib().a00_set_proposal_kernel.argtypes = [C.c_void_p, C.c_int]
+        lib().a00_set_proposal_kernel(self.h, int(kind))
+
     def set_tau_prior(self, alpha, beta):
         lib().a00_set_tau_prior(self.h, alpha, beta)
 

@@ -109,7 +109,8 @@ def test_host_driver_library_exports():
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     inline = set(re.findall(r"static inline [a-z_0-9 ]+?\b(a00_[a-z0-9_]+)\s*\(", src))
     names = sorted(set(re.findall(r"\b(a00_[a-z0-9_]+)\s*\(", src)) - inline)
-    assert inline == {"a00_rng_seed", "a00_rndu", "a00_reflect", "a00_msc_contrib", "a00_msc_t2h", "a00_msc_term"}
+    assert inline == {"a00_rng_seed", "a00_rndu", "a00_reflect", "a00_msc_contrib", "a00_msc_t2h", "a00_msc_term",
+                      "a00_bpp_rndu", "a00_bpp_rnd_laplace", "a00_bpp_rnd_symmetrical"}
     assert "a00_iterate" in names and "a00_backend_hip" in names
     for n in names:
         assert hasattr(L, n), n
