@@ -1007,7 +1007,11 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       d.flags &= 6u;
       if (d.flags)
       {
+        static const bool klane_direct = getenv("BPA_KLANE_DIRECT") != nullptr;     // A/B: no LDS staging of the P-matrices
+        if (klane_direct) d.flags |= 16u;
         if ((mode & 4) && p->sum_out && p->sum_parts == e->pack_blocks) { d.flags |= 8u; d.wg_part = p->sum_out; summed = true; }
+        // (register budget, measured with BPA_KLANE_OCC builds: the compiler's 126 VGPRs = 4 waves per SIMD 105 us; held to
+        //  5 waves 121 us and to 6 waves 187 us (spills), to 3 waves 119 us)
         hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), g2, dim3(PACK_BS), 0, e->stream, k0, k1, 0, d);
       }
     }

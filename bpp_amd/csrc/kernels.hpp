@@ -2393,8 +2393,12 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_chain_kernel(const ChainDev C
 // step_s4_klane_kernel on the compact records over the engine's packing (device_types.hpp; see step_jc69_v2_kernel):
 // several rate categories, any 4-state model, no scalers, no phase averaging.  WITH_A: the P-matrix phase as its own
 // launch (its eigen / closed-form code needs twice the registers of the node updates).
-template <int BS, bool WITH_A>
-__global__ void __launch_bounds__(BS) step_s4_klane_v2_kernel(const PlanDev P)
+// A/B switch of the staging below: flags bit 4 = every lane fetches its matrices itself (BPA_KLANE_DIRECT=1)
+__device__ __forceinline__ bool getenv_klane_direct(const PlanDev & P) { return (P.flags & 16u) != 0; }
+
+template <int BS, bool WITH_A, int OCC = 0>        // OCC: waves per SIMD the register allocation is held to (0: the compiler's choice)
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(OCC ? OCC : 1, OCC ? OCC : 8)))
+step_s4_klane_v2_kernel(const PlanDev P)
 {
   __shared__ double s_term[BS], s_tr[BS];
   const uint32_t b = blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
@@ -2443,8 +2447,45 @@ __global__ void __launch_bounds__(BS) step_s4_klane_v2_kernel(const PlanDev P)
   const uint32_t k = (ls.n_np_tips >> 23) & 7u, R = ls.n_np_tips >> 26;
 
   // ---- node updates of this lane's (pattern, category) + its root term
+  // The two 4x4 P-matrices of an update are the same 256 bytes for all lanes of one (locus, category) — np lanes in a
+  // row — yet fetched by every lane they are 32 16-byte load instructions per update through the CU's one
+  // texture-address path (64 B/clk): with 20 waves per CU that path, not HBM, set the kernel's time.  Here each WAVE
+  // stages the matrices of the (at most four) groups it spans in its own LDS corner — ONE 16-byte load per lane per
+  // update: lane j brings chunk j % 16 of group j / 16 — and every lane reads its group's rows back as LDS broadcasts.
+  // No workgroup barrier: writer and readers are the same wave, whose LDS instructions execute in order.  Loci of one
+  // wave have different update lists, so a staging lane follows the list of the locus it stages FOR.
+  __shared__ double2 s_pm[BS/64][4][16];
+  const uint32_t wave = lane >> 6, wl = lane & 63u;
+  bool use_lds;
+  uint32_t my_g = 0;
+  const uint4 * st_rp = nullptr; const double * st_pmat = nullptr; uint32_t st_R = 0, st_k = 0, st_nops = 0;
+  {
+    static const uint32_t none = 0xffffffffu;
+    const bool grouped = work && (P.flags & 2u);
+    const uint32_t gkey = grouped ? (ls.slot << 3 | k) : none;
+    const uint32_t prevkey = __shfl_up(gkey, 1);
+    const bool first = grouped && (wl == 0 || gkey != prevkey);
+    const unsigned long long fmask = __ballot(first);
+    const unsigned long long odd = __ballot(grouped && S.pstride != 16u);      // (a, b) pairs of JC69 loci: nothing to stage
+    const uint32_t ngroups = (uint32_t)__popcll(fmask);
+    use_lds = ngroups >= 1 && ngroups <= 4 && odd == 0 && !getenv_klane_direct(P);
+    my_g = (uint32_t)__popcll(fmask & ((2ull << wl) - 1ull)) - 1u;
+    // the group this lane stages for: its first lane holds slot, category, R and the buffer address
+    const uint32_t gs = wl >> 4;
+    uint32_t src = 0;
+    { unsigned long long m = fmask; for (uint32_t i = 0; i < gs; ++i) m &= m - 1ull; src = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u; }
+    const uint32_t s_slot = __shfl(ls.slot, (int)src), s_kR = __shfl(k | R << 3, (int)src);
+    const unsigned long long s_pm_lo = __shfl((uint32_t)reinterpret_cast<uintptr_t>(S.pmat), (int)src);
+    const unsigned long long s_pm_hi = __shfl((uint32_t)(reinterpret_cast<uintptr_t>(S.pmat) >> 32), (int)src);
+    const uint32_t s_n = __shfl((uint32_t)hdr.nops, (int)src);
+    if (use_lds && gs < ngroups)
+    {
+      st_rp = P.recs2 + (size_t)s_slot*P.rec2_units;
+      st_pmat = reinterpret_cast<const double *>(s_pm_lo | s_pm_hi << 32);
+      st_k = s_kR & 7u; st_R = s_kR >> 3; st_nops = s_n;
+    }
+  }
   double tr = 0;
-  if (work)
   {
     double fwd[4] = {0, 0, 0, 0};
     uint32_t fwd_clv = 0xffffffffu;
@@ -2463,31 +2504,81 @@ __global__ void __launch_bounds__(BS) step_s4_klane_v2_kernel(const PlanDev P)
     };
     if (P.flags & 2u)
     {
-      for (uint32_t o = 0; o < hdr.nops; ++o)
+      const uint32_t nops = work ? hdr.nops : 0u;
+      // the wave walks update index o together: its lanes' loci may have lists of different lengths
+      // (requesting the records of update o + 1 while update o runs was tried: no gain, 106 vs 105 us)
+      for (uint32_t o = 0; __any(o < nops); ++o)
       {
-        StepOp op;
-        *reinterpret_cast<uint4 *>(&op) = rp[1 + o];
-        double lv[4], rv[4], x[4], y[4];
-        vec_of(op.left_clv, lv);
-        vec_of(op.right_clv, rv);
-        matvec4_p(S.pmat, S.pstride, (size_t)op.left_pmatrix*R  + k, lv, x);
-        matvec4_p(S.pmat, S.pstride, (size_t)op.right_pmatrix*R + k, rv, y);
-        double2 o0, o1;
-        o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
-        double2 * dst = reinterpret_cast<double2 *>(S.clv + ((((size_t)(op.parent_clv - tips)*R) + k)*np + n)*4);
-        { typedef double d2v __attribute__((ext_vector_type(2))); d2v a0, a1; a0.x = o0.x; a0.y = o0.y; a1.x = o1.x; a1.y = o1.y;
-          __builtin_nontemporal_store(a0, reinterpret_cast<d2v *>(dst)); __builtin_nontemporal_store(a1, reinterpret_cast<d2v *>(dst) + 1); }
-        fwd[0] = o0.x; fwd[1] = o0.y; fwd[2] = o1.x; fwd[3] = o1.y;
-        fwd_clv = op.parent_clv;
+        if (use_lds)
+        {
+          if (o < st_nops)
+          {
+            StepOp so;
+            *reinterpret_cast<uint4 *>(&so) = st_rp[1 + o];
+            const uint32_t c = wl & 15u, pm = c < 8u ? so.left_pmatrix : so.right_pmatrix;
+            s_pm[wave][wl >> 4][c] = *reinterpret_cast<const double2 *>(st_pmat + ((size_t)pm*st_R + st_k)*16 + (size_t)(c & 7u)*2);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (o < nops)
+        {
+          StepOp op;
+          *reinterpret_cast<uint4 *>(&op) = rp[1 + o];
+          double lv[4], rv[4], x[4], y[4];
+          vec_of(op.left_clv, lv);
+          vec_of(op.right_clv, rv);
+          if (use_lds)
+          {
+            // one matrix at a time (16 doubles live, not 32: the kernel keeps 5 waves per SIMD)
+            const double2 * r = &s_pm[wave][my_g][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+              const double2 a0 = r[2*i], b0 = r[2*i+1];
+              x[i] = dot4_pair(a0.x, a0.y, b0.x, b0.y, lv);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+              const double2 a1 = r[8 + 2*i], b1 = r[8 + 2*i+1];
+              y[i] = dot4_pair(a1.x, a1.y, b1.x, b1.y, rv);
+            }
+          }
+          else
+          {
+            matvec4_p(S.pmat, S.pstride, (size_t)op.left_pmatrix*R  + k, lv, x);
+            matvec4_p(S.pmat, S.pstride, (size_t)op.right_pmatrix*R + k, rv, y);
+          }
+          double2 o0, o1;
+          o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
+          double2 * dst = reinterpret_cast<double2 *>(S.clv + ((((size_t)(op.parent_clv - tips)*R) + k)*np + n)*4);
+          { typedef double d2v __attribute__((ext_vector_type(2))); d2v a0, a1; a0.x = o0.x; a0.y = o0.y; a1.x = o1.x; a1.y = o1.y;
+            __builtin_nontemporal_store(a0, reinterpret_cast<d2v *>(dst)); __builtin_nontemporal_store(a1, reinterpret_cast<d2v *>(dst) + 1); }
+          fwd[0] = o0.x; fwd[1] = o0.y; fwd[2] = o1.x; fwd[3] = o1.y;
+          fwd_clv = op.parent_clv;
+        }
+        if (use_lds)
+        {
+          // the next round's staging must not overtake this round's reads (compiler: LDS order of one wave is the hardware's)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
       }
     }
-    // K2 at the root (core_likelihood_avx.c:117-150): this category's frequency-weighted sum
-    const double * par = S.par;
-    double c[4];
-    vec_of(hdr.root_clv, c);
-    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
-    const double * f = par + par_matrix(R, 4, m) + pm_freqs(4);
-    tr = dot4_pair(f[0], f[1], f[2], f[3], c);
+    if (work)
+    {
+      // K2 at the root (core_likelihood_avx.c:117-150): this category's frequency-weighted sum
+      const double * par = S.par;
+      double c[4];
+      vec_of(hdr.root_clv, c);
+      const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+      const double * f = par + par_matrix(R, 4, m) + pm_freqs(4);
+      tr = dot4_pair(f[0], f[1], f[2], f[3], c);
+    }
   }
   s_tr[lane] = tr;
   __syncthreads();
