@@ -1,0 +1,379 @@
+// gsampler.hpp — the device-resident A00 sampler for loci outside the LDS sweep kernel's scope (sampler.hpp: JC69,
+// one rate category, <= 8 tips, <= 64 patterns): any 4-state model of the engine's packing — several rate categories,
+// GTR, up to 16 tips, up to 255 lanes (patterns x categories) per locus — i.e. BASELINE configs 3 and 5.
+//
+// Same moves, same random streams, same arithmetic as the C host driver (csrc/host/a00_driver.c) and as the sweep
+// kernel — the proposal code IS the sweep kernel's (propose_gage / propose_gspr / density_prepare / install are
+// templates over the tree size and over what a proposal leaves behind) — but the likelihood of a step is not computed
+// in LDS by the sampler itself: the step is written, on the device, as the compact records of the engine's batched
+// kernels (device_types.hpp: StepRec / StepOp / MatRec2) and evaluated by step_jc69_v2_kernel /
+// step_s4_klane_v2_kernel, the kernels every other path uses.  One proposal step of all loci is
+//
+//     gstep_kernel     one LANE per locus: settle the previous step (accept / roll back), propose, MSC density, records
+//     (P-matrix launch + ) the engine's step kernel over the records                  -> lnL per locus
+//     all-loci steps only: gsum_decide_kernel (sum of the per-locus terms, ONE decision)
+//
+// with the trees in HBM between launches (496 B per locus) and nothing on the host but the launch loop.
+// Reference: gtree.c:4585 (ages), 6531 (SPR), stree.c:5512 / 4338 (tau + rubber band), prop_mixing.c:52, gtree.c:3957.
+#pragma once
+
+namespace gsm {
+using smp::Op; using smp::make_op; using smp::Species; using smp::LSpecies; using smp::LCounts; using smp::LTree;
+using smp::LUndo; using smp::TimeUndo; using smp::Prof; using smp::MAXPOP; using smp::rndu; using smp::reflect;
+
+constexpr int NT = 16;                    // tips per locus (2 NT - 1 = 31 nodes: node sets are 32-bit masks)
+constexpr int NN = 2*NT;
+constexpr int GBS = 64;                   // loci per workgroup
+
+struct GTree                              // one per locus, in HBM
+{
+  int8_t   left[NN], right[NN], parent[NN], clv[NN], pmat[NN], pop[NN];
+  double   time[NN];
+  double   lnl, logpr;
+  a00_rng_t rng;
+  int32_t  root, tips;
+  uint32_t proposals, accepted;
+  uint32_t work_nupd, work_nbr;           // node updates / fresh branches of the per-locus steps (bpa_sampler_work)
+};
+static_assert(sizeof(GTree) % 16 == 0, "GTree is copied as uint4");
+
+struct GLocus                             // what never changes, per locus
+{
+  uint32_t slot, pat_off;                 // its slot of the engine's packing, first pattern in the step's term array
+  uint32_t np, pad;
+  alignas(16) int8_t gl[MAXPOP];          // gene tips below each population
+  alignas(16) int8_t nin[MAXPOP];         // gene tips of each species
+};
+
+struct GState                             // one per lane, in LDS: what a proposal leaves for its evaluation
+{
+  double   time[NN];                      // the lane's ages (LTree::time points here)
+  Op       ops[NT - 1];
+  int32_t  nops;
+  uint32_t brm, wclv, chain;
+  uint32_t pnodes[MAXPOP];
+  int8_t   nin_new[MAXPOP], nc_new[MAXPOP];
+};
+
+struct GArgs
+{
+  GTree * trees, * undo;                  // [T] current (or proposed, while a step is being evaluated) / the state before the pending step
+  const GLocus * loc;                     // [T]
+  uint32_t T;
+  uint32_t mode;                          // 0 GAGE k, 1 GSPR k, 2 TAU, 3 MIX, 4 settle (+ THETA statistics), 5 start-up evaluation
+  uint32_t k;
+  uint32_t pend;                          // the step to settle first: 0 none, 1 per-locus decisions, 2 an all-loci decision (flag / epoch), 3 commit (start-up)
+  const double * lnl_new;                 // [T] lnL of the pending step's evaluation (task = locus)
+  double * hast, * logpr_new;             // [T] Hastings term / proposed MSC density of the step being proposed (read back when it is settled)
+  double * delta;                         // [T] an all-loci step: this locus's density + Jacobian term
+  uint8_t * active;                       // [T] the locus has a likelihood evaluation pending
+  const uint32_t * flag; uint32_t epoch;  // an all-loci step was REJECTED when *flag == epoch
+  // the step's records for the engine's kernels
+  uint4 * recs2; uint32_t units;          // [slots*units]
+  MatRec2 * mat2; double * mat_length; uint32_t maxmat;     // [slots*maxmat]
+  const double * taus; const double * lograt;
+  uint32_t tau_q; double tau_u, mix_c, mix_lnc;
+  int8_t * pop_nc; double * pop_t2h;      // [MAXPOP][T] mode 4: the statistics the THETA kernel reads
+  uint32_t refresh_logpr;
+  Species sp;
+};
+
+// the MSC density term of population p from the lane's own state (density_term of sampler.hpp, ages in S.time)
+__device__ __forceinline__ double gdensity_term(const GState & S, const Species & sp, const double * tau, int p, double & T2h_out)
+{
+  uint32_t nodes = S.pnodes[p];
+  const int ncoal = S.nc_new[p], nin = S.nin_new[p];
+  const double ptau = sp.parent[p] >= 0 ? tau[sp.parent[p]] : -1.0;
+  int steps = ncoal + (ptau >= 0 ? 1 : 0);
+  if (nin == steps) --steps;
+  double T2h = 0, prev = tau[p];
+  int nn = nin;
+  for (int k = 0; k < steps; ++k, --nn)
+  {
+    double tk = ptau;
+    if (k < ncoal)
+    {
+      int best = -1; double tb = 0;
+      for (uint32_t m = nodes; m; m &= m - 1) { const int x = __ffs(m) - 1; const double tx = S.time[x]; if (best < 0 || tx < tb) { best = x; tb = tx; } }
+      tk = tb; nodes &= ~(1u << best);
+    }
+    T2h += nn*(nn - 1)*(tk - prev);
+    prev = tk;
+  }
+  double c = 0;
+  if (ncoal) c += ncoal*tau[2*MAXPOP + p];
+  if (T2h) c -= T2h/(tau[MAXPOP + p]*1.0);
+  T2h_out = T2h;
+  return c;
+}
+
+// the whole density, populations in order (tree_logpr of a00_driver.c); optionally leaves the THETA statistics
+__device__ double gdensity(GState & S, const LTree<NT> & T, LCounts & cn, const LSpecies & sp, const Species & spl, const double * tau,
+                           int8_t * nc_out, double * t2h_out, uint32_t stride)
+{
+  smp::density_prepare<NT>(S, T, cn, sp, (1u << sp.npop) - 1u);
+  double logpr = 0;
+  for (int p = 0; p < sp.npop; ++p)
+  {
+    double t2h;
+    logpr += gdensity_term(S, spl, tau, p, t2h);
+    if (nc_out) { nc_out[(size_t)p*stride] = S.nc_new[p]; t2h_out[(size_t)p*stride] = t2h; }
+  }
+  return logpr;
+}
+
+__global__ void glograt_kernel(double * tab)         // log(i/j), i, j < NN
+{
+  const int i = threadIdx.x / NN, j = threadIdx.x % NN;
+  tab[threadIdx.x] = (i && j) ? log((double)i/(double)j) : 0.0;
+}
+
+__global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
+{
+  __shared__ GState s_st[GBS];
+  __shared__ double s_tau[3*MAXPOP];
+  __shared__ double s_lograt[NN*NN];
+  __shared__ Species s_sp;
+  const uint32_t lane = threadIdx.x, i = blockIdx.x*GBS + lane;
+  const bool valid = i < A.T;
+  {
+    const uint32_t * src = reinterpret_cast<const uint32_t *>(&A.sp);
+    uint32_t * dst = reinterpret_cast<uint32_t *>(&s_sp);
+    for (uint32_t q = lane; q < sizeof(Species)/4; q += GBS) dst[q] = src[q];
+  }
+  if (lane < (uint32_t)(3*MAXPOP)) s_tau[lane] = A.taus[lane];
+  if (A.mode == 1) for (uint32_t q = lane; q < (uint32_t)(NN*NN); q += GBS) s_lograt[q] = A.lograt[q];
+  const Species & spl = s_sp;
+  LSpecies sp;
+  {
+    const uint32_t * q = reinterpret_cast<const uint32_t *>(A.sp.parent);
+    for (int k = 0; k < 4; ++k) sp.parent.w[k] = q[k];
+    q = reinterpret_cast<const uint32_t *>(A.sp.left);
+    for (int k = 0; k < 4; ++k) sp.left.w[k] = q[k];
+    q = reinterpret_cast<const uint32_t *>(A.sp.right);
+    for (int k = 0; k < 4; ++k) sp.right.w[k] = q[k];
+    sp.S = A.sp.S; sp.npop = A.sp.npop;
+  }
+  const int npop = sp.npop;
+  GState & S = s_st[lane];
+  LTree<NT> T;
+  LCounts cn;
+  for (int k = 0; k < 4; ++k) cn.nin.w[k] = cn.nc.w[k] = cn.nin_new.w[k] = cn.nc_new.w[k] = cn.gl.w[k] = 0u;
+  T.time = S.time; T.rng = 0; T.root = 0; T.tips = 2;
+  double lnl_cur = 0, logpr_cur = 0;
+  uint32_t nprop = 0, nacc = 0, w_nupd = 0, w_nbr = 0;
+  GLocus L{};
+  if (valid)
+  {
+    GTree & g = A.trees[i];
+    L = A.loc[i];
+    T.left.load(g.left); T.right.load(g.right); T.parent.load(g.parent); T.clv.load(g.clv); T.pmat.load(g.pmat); T.pop.load(g.pop);
+    for (int k = 0; k < NN; ++k) S.time[k] = g.time[k];
+    T.rng = g.rng; T.root = g.root; T.tips = g.tips;
+    lnl_cur = g.lnl; logpr_cur = g.logpr; nprop = g.proposals; nacc = g.accepted; w_nupd = g.work_nupd; w_nbr = g.work_nbr;
+    const uint4 g4 = *reinterpret_cast<const uint4 *>(L.gl), n4 = *reinterpret_cast<const uint4 *>(L.nin);
+    cn.gl.w[0] = g4.x; cn.gl.w[1] = g4.y; cn.gl.w[2] = g4.z; cn.gl.w[3] = g4.w;
+    cn.nin.w[0] = n4.x; cn.nin.w[1] = n4.y; cn.nin.w[2] = n4.z; cn.nin.w[3] = n4.w;
+    S.nops = 0; S.brm = 0; S.wclv = 0; S.chain = 0;
+  }
+  __syncthreads();
+
+  // ---- 1. settle the step whose evaluation just finished
+  if (valid && A.pend)
+  {
+    bool back = false;
+    if (A.pend == 1)
+    {
+      if (A.active[i])
+      {
+        const double lnl = A.lnl_new[i], lp_new = A.logpr_new[i];
+        const double lnacc = (lp_new - logpr_cur) + (lnl - lnl_cur) + A.hast[i];
+        const double u = rndu(&T.rng);
+        ++nprop;
+        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; }
+        else back = true;
+      }
+    }
+    else if (A.pend == 2)
+    {
+      if (*A.flag == A.epoch) back = true;
+      else { logpr_cur = A.logpr_new[i]; if (A.active[i]) lnl_cur = A.lnl_new[i]; }
+    }
+    else { lnl_cur = A.lnl_new[i]; logpr_cur = A.logpr_new[i]; }
+    if (back)
+    {
+      const GTree & u = A.undo[i];
+      T.left.load(u.left); T.right.load(u.right); T.parent.load(u.parent); T.clv.load(u.clv); T.pmat.load(u.pmat); T.pop.load(u.pop);
+      for (int k = 0; k < NN; ++k) S.time[k] = u.time[k];
+      T.root = u.root;
+    }
+  }
+  // ---- 2. THETA moved the thetas since this density was stored
+  if (valid && A.refresh_logpr) logpr_cur = gdensity(S, T, cn, sp, spl, s_tau, nullptr, nullptr, 0);
+  __syncthreads();
+
+  // ---- 3. the proposed species tree of an all-loci step is this workgroup's copy of the taus
+  double lminf = 0, lmaxf = 0, tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1;
+  if (A.mode == 2)
+  {
+    const int q = (int)A.tau_q, pq = spl.parent[q];
+    tq_old = s_tau[q]; tq_lo = fmax(s_tau[spl.left[q]], s_tau[spl.right[q]]); tq_hi = pq >= 0 ? s_tau[pq] : 999.0;
+    const double tnew = reflect(tq_old + spl.ft_tau*(A.tau_u - 0.5), tq_lo, tq_hi);
+    minf = (tnew - tq_lo)/(tq_old - tq_lo); maxf = (tnew - tq_hi)/(tq_old - tq_hi);
+    lminf = log(minf); lmaxf = log(maxf);
+    __syncthreads();
+    if (lane == 0) s_tau[q] = tnew;
+    __syncthreads();
+  }
+  else if (A.mode == 3)
+  {
+    if (lane < (uint32_t)npop) s_tau[lane] *= A.mix_c;
+    __syncthreads();
+  }
+
+  // ---- 4. propose
+  bool evaluate = false;
+  if (valid && A.mode != 4)
+  {
+    // the state a rejection comes back to
+    {
+      GTree & u = A.undo[i];
+      T.left.store(u.left); T.right.store(u.right); T.parent.store(u.parent); T.clv.store(u.clv); T.pmat.store(u.pmat); T.pop.store(u.pop);
+      for (int k = 0; k < NN; ++k) u.time[k] = S.time[k];
+      u.root = T.root;
+    }
+    TimeUndo tu{0, 0, 0, -1, -1, -1};
+    Prof pf; pf.on = false; pf.t = 0;
+    double hast = 0;
+    bool ok = true;
+    if (A.mode == 0)      ok = smp::propose_gage<NT>(S, T, cn, tu, hast, (int)A.k, sp, spl, s_tau, pf);
+    else if (A.mode == 1) ok = smp::propose_gspr<NT>(S, T, cn, tu, hast, (int)A.k, sp, spl, s_tau, s_lograt, pf);
+    else if (A.mode == 2)
+    {
+      // TAU q (tau_step of a00_driver.c): the gene nodes of q and its children between the bounds move
+      const int nn_ = 2*T.tips - 1, q = (int)A.tau_q, cl = sp.left[q], cr = sp.right[q];
+      uint32_t brm = 0, ndm = 0; int above = 0, below = 0;
+      for (int k = T.tips; k < nn_; ++k)
+      {
+        const int pk = T.pop[k]; const double tk = S.time[k];
+        if ((pk != q && pk != cl && pk != cr) || tk < tq_lo || tk > tq_hi) continue;
+        if (tk >= tq_old) { S.time[k] = tq_hi + maxf*(tk - tq_hi); ++above; } else { S.time[k] = tq_lo + minf*(tk - tq_lo); ++below; }
+        brm |= (1u << (int)T.left[k]) | (1u << (int)T.right[k]);
+        if (T.parent[k] >= 0) brm |= 1u << k;
+        ndm |= smp::path_mask(T, k);
+      }
+      const double lp_new = gdensity(S, T, cn, sp, spl, s_tau, nullptr, nullptr, 0);
+      A.logpr_new[i] = lp_new;
+      A.delta[i] = ((lp_new - logpr_cur) + below*lminf) + above*lmaxf;          // p_delta of the host driver
+      if (ndm) smp::install<NT>(S, T, brm, ndm);
+      else { S.brm = 0; S.nops = 0; ok = false; }                              // no gene node moves here: only the density changes
+    }
+    else
+    {
+      // mixing (mix_step of a00_driver.c) or start-up: every branch, every inner node
+      const int nn_ = 2*T.tips - 1;
+      uint32_t brm = 0, ndm = 0; int ninner = 0;
+      for (int k = 0; k < nn_; ++k)
+      {
+        if (T.left[k] >= 0) { if (A.mode == 3) S.time[k] *= A.mix_c; ndm |= 1u << k; ++ninner; }
+        if (T.parent[k] >= 0) brm |= 1u << k;
+      }
+      if (A.mode == 5)
+      {
+        for (uint32_t m = brm; m; m &= m - 1) smp::swap_pmat(T, __ffs(m) - 1);       // start-up evaluates in place:
+        for (uint32_t m = ndm; m; m &= m - 1) smp::swap_clv(T, __ffs(m) - 1);        // toggle twice = no toggle
+      }
+      const double lp_new = gdensity(S, T, cn, sp, spl, s_tau, nullptr, nullptr, 0);
+      A.logpr_new[i] = lp_new;
+      A.delta[i] = (lp_new - logpr_cur) + (double)ninner*A.mix_lnc;
+      smp::install<NT>(S, T, brm, ndm);
+    }
+    if (ok && A.mode <= 1)
+    {
+      A.logpr_new[i] = gdensity(S, T, cn, sp, spl, s_tau, nullptr, nullptr, 0);
+      A.hast[i] = hast;
+      w_nupd += (uint32_t)S.nops; w_nbr += (uint32_t)__popc(S.brm);
+    }
+    evaluate = ok;
+    A.active[i] = ok ? 1 : 0;
+  }
+  else if (valid) A.active[i] = 0;
+
+  // ---- 5. the step's records for the engine's kernels
+  if (valid && A.mode != 4)
+  {
+    uint4 * rec = A.recs2 + (size_t)L.slot*A.units;
+    MatRec2 * m2 = A.mat2 + (size_t)L.slot*A.maxmat;
+    double * ml = A.mat_length + (size_t)L.slot*A.maxmat;
+    const uint32_t e0 = L.slot*A.maxmat;
+    StepRec h{};
+    h.task = evaluate ? i : 0xffffffffu; h.pat_off = L.pat_off;
+    h.root_clv = (uint8_t)(int)T.clv[T.root]; h.root_scaler = (int8_t)BPA_SCALE_BUFFER_NONE; h.nops = (uint8_t)(evaluate ? S.nops : 0);
+    *reinterpret_cast<StepRec *>(rec) = h;
+    uint32_t nm = 0;
+    if (evaluate)
+    {
+      for (uint32_t m = S.brm; m; m &= m - 1, ++nm)
+      {
+        const int x = __ffs(m) - 1;
+        m2[nm] = MatRec2{L.slot, (uint32_t)(int)T.pmat[x]};
+        ml[nm] = (S.time[(int)T.parent[x]] - S.time[x])*1.0;                   // rate_mui = 1 (locus.c:2350)
+      }
+      for (int o = 0; o < S.nops; ++o)
+      {
+        const Op w = S.ops[o];
+        StepOp q{};
+        q.parent_clv = (uint8_t)(w & 255u); q.left_clv = (uint8_t)((w >> 8) & 255u); q.left_pmatrix = (uint8_t)((w >> 16) & 255u);
+        q.right_clv = (uint8_t)((w >> 24) & 255u); q.right_pmatrix = (uint8_t)((w >> 32) & 255u);
+        q.parent_scaler = q.left_scaler = q.right_scaler = (int8_t)BPA_SCALE_BUFFER_NONE;
+        q.left_e = q.right_e = -1;
+        uint32_t j = 0;
+        for (uint32_t m = S.brm; m; m &= m - 1, ++j)
+        {
+          const uint32_t pm = (uint32_t)(int)T.pmat[__ffs(m) - 1];
+          if (pm == q.left_pmatrix)  q.left_e = (int32_t)(e0 + j);
+          if (pm == q.right_pmatrix) q.right_e = (int32_t)(e0 + j);
+        }
+        *reinterpret_cast<StepOp *>(rec + 1 + o) = q;
+      }
+    }
+    for (; nm < A.maxmat; ++nm) m2[nm] = MatRec2{0xffffffffu, 0u};              // entries of the last step this one does not use
+  }
+
+  // ---- 6. mode 4: the sufficient statistics of the settled state, for the THETA kernel
+  if (valid && A.mode == 4) (void)gdensity(S, T, cn, sp, spl, s_tau, A.pop_nc + i, A.pop_t2h + i, A.T);
+
+  // ---- 7. store
+  if (valid)
+  {
+    GTree & g = A.trees[i];
+    T.left.store(g.left); T.right.store(g.right); T.parent.store(g.parent); T.clv.store(g.clv); T.pmat.store(g.pmat); T.pop.store(g.pop);
+    for (int k = 0; k < NN; ++k) g.time[k] = S.time[k];
+    g.rng = T.rng; g.root = T.root; g.lnl = lnl_cur; g.logpr = logpr_cur; g.proposals = nprop; g.accepted = nacc;
+    g.work_nupd = w_nupd; g.work_nbr = w_nbr;
+  }
+}
+
+// an all-loci step: the sum of the loci's terms (fixed order) and the ONE decision (tau_step / mix_step of a00_driver.c)
+__global__ void __launch_bounds__(1024) gsum_decide_kernel(const GTree * __restrict__ trees, const double * __restrict__ lnl_new,
+                                                           const double * __restrict__ delta, const uint8_t * __restrict__ active,
+                                                           uint32_t T, double * sum_out, int decide_on, double u, uint32_t epoch,
+                                                           uint32_t * flag, uint32_t * counters, double * taus, Species sp, int tau_q,
+                                                           double win_u, double mix_c, double mix_lnc)
+{
+  __shared__ double sh[1024];
+  double acc = 0;
+  for (uint32_t i = threadIdx.x; i < T; i += 1024) acc += (active[i] ? lnl_new[i] - trees[i].lnl : 0.0) + delta[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (uint32_t w = 512; w > 0; w >>= 1)
+  {
+    if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x) return;
+  if (sum_out) sum_out[0] = sh[0];
+  if (decide_on) smp::decide(sh[0], u, epoch, flag, counters, taus, sp, tau_q, -1, win_u, mix_c, mix_lnc);
+}
+
+} // namespace gsm

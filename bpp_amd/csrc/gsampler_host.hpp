@@ -1,0 +1,221 @@
+// gsampler_host.hpp — host side of the generic device-resident sampler (gsampler.hpp): uploads, the launch loop of an
+// iteration, downloads.  Included at the end of sampler.hpp (same translation unit as engine.hip).
+#pragma once
+
+static int gs_upload(bpa_sampler * s)
+{
+  bpa_engine * e = s->eng;
+  const unsigned T = s->nloci;
+  if (!engine_pack(e)) return 0;
+  for (unsigned i = 0; i < T; ++i) if (!assign_pops_host(s, s->g_trees[i])) return 0;
+  for (int p = 0; p < smp::MAXPOP; ++p) s->has_theta[p] = p >= s->sp.S && p < s->sp.npop;
+  std::vector<gsm::GLocus> loc(T);
+  unsigned npat = 0;
+  for (unsigned i = 0; i < T; ++i)
+  {
+    const bpa_locus * l = s->loci[i];
+    const gsm::GTree & t = s->g_trees[i];
+    int cnt[smp::MAXPOP] = {0};
+    for (int k = 0; k < t.tips; ++k) if (++cnt[t.pop[k]] >= 2) s->has_theta[t.pop[k]] = true;
+    if (e->slot_of[l->id] < 0) return fail("bpa_sampler: a locus is not on the engine's packing");
+    gsm::GLocus & g = loc[i];
+    g.slot = (uint32_t)e->slot_of[l->id]; g.pat_off = npat; g.np = l->sites; g.pad = 0;
+    for (int p = 0; p < smp::MAXPOP; ++p) g.gl[p] = g.nin[p] = 0;
+    for (int k = 0; k < t.tips; ++k)
+    {
+      g.nin[t.pop[k]]++;
+      for (int q = t.pop[k]; q >= 0; q = s->sp.parent[q]) g.gl[q]++;
+    }
+    npat += l->sites;
+  }
+  s->g_npat = npat;
+  s->g_units = 1 + std::max(s->maxtips - 1, 3u);
+  s->g_maxmat = 2*s->maxtips - 2;
+  s->g_pack_epoch = e->pack_epoch;
+  const size_t nrec = (size_t)e->pack_slots*s->g_units, nmat = (size_t)e->pack_slots*s->g_maxmat;
+  std::vector<uint32_t> bmo(e->pack_blocks + 1);
+  for (unsigned b = 0; b <= e->pack_blocks; ++b) bmo[b] = e->h_blk_slot_off[b]*s->g_maxmat;
+  uint32_t zero2[2] = {0, 0};
+  if (!upload(s->g_dev, s->g_trees.data(), T) || !s->g_undo.reserve(T) || !upload(s->g_loc, loc.data(), T) ||
+      !s->g_lnl.reserve(T) || !s->g_hast.reserve(T) || !s->g_logpr.reserve(T) || !s->g_delta.reserve(T) || !s->g_active.reserve(T) ||
+      !s->g_site.reserve(npat) || !s->g_recs.reserve(nrec) || !s->g_mat2.reserve(nmat) || !s->g_len.reserve(nmat) ||
+      !upload(s->g_bmo, bmo.data(), bmo.size()) || !s->g_lograt.reserve(gsm::NN*gsm::NN) ||
+      !upload(s->flag, zero2, 1) || !upload(s->counters, zero2, 2) || !s->mix_sum.reserve(1) ||
+      !upload(s->taus, s->h_taus.data(), s->h_taus.size()) || !s->pop_t2h.reserve((size_t)T*smp::MAXPOP) ||
+      !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP))
+    return 0;
+  // every slot starts as "not part of the step", every matrix entry as a hole
+  HIPCHK(hipMemsetAsync(s->g_recs.p, 0xff, nrec*sizeof(uint4), e->stream));
+  HIPCHK(hipMemsetAsync(s->g_mat2.p, 0xff, nmat*sizeof(MatRec2), e->stream));
+  HIPCHK(hipMemsetAsync(s->g_len.p, 0, nmat*sizeof(double), e->stream));
+  HIPCHK(hipMemsetAsync(s->g_lnl.p, 0, T*sizeof(double), e->stream));
+  HIPCHK(hipMemsetAsync(s->g_hast.p, 0, T*sizeof(double), e->stream));
+  HIPCHK(hipMemsetAsync(s->g_logpr.p, 0, T*sizeof(double), e->stream));
+  HIPCHK(hipMemsetAsync(s->g_delta.p, 0, T*sizeof(double), e->stream));
+  HIPCHK(hipMemsetAsync(s->g_active.p, 0, T, e->stream));
+  if (s->allreduce)
+  {
+    // the THETA mask is a property of all ranks' loci (see sampler_upload)
+    double m[smp::MAXPOP];
+    for (int p = 0; p < smp::MAXPOP; ++p) m[p] = s->has_theta[p] ? 1.0 : 0.0;
+    double * ar = s->sum_ext ? s->sum_ext : s->theta_sums.p;
+    HIPCHK(hipMemcpyAsync(ar, m, sizeof m, hipMemcpyHostToDevice, e->stream));
+    if (!s->allreduce(s->allreduce_ctx, ar, (unsigned)smp::MAXPOP, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
+    HIPCHK(hipMemcpyAsync(m, ar, sizeof m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int p = 0; p < smp::MAXPOP; ++p) s->has_theta[p] = m[p] > 0.5;
+  }
+  hipLaunchKernelGGL(gsm::glograt_kernel, dim3(1), dim3(gsm::NN*gsm::NN), 0, e->stream, s->g_lograt.p);
+  HIPCHK(hipGetLastError());
+  s->epoch = 0; s->mix_pending = false; s->g_pend = 0;
+  s->uploaded = true;
+  return 1;
+}
+
+// one gstep_kernel launch: settle what is pending, then propose `mode`
+static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u = 0, double mix_c = 1.0, double mix_lnc = 0)
+{
+  bpa_engine * e = s->eng;
+  if (s->g_pack_epoch != e->pack_epoch) return fail("bpa_sampler: the engine's loci changed since the sampler was set up");
+  gsm::GArgs a{};
+  a.trees = s->g_dev.p; a.undo = s->g_undo.p; a.loc = s->g_loc.p; a.T = s->nloci; a.mode = mode; a.k = k;
+  a.pend = s->g_pend; a.lnl_new = s->g_lnl.p; a.hast = s->g_hast.p; a.logpr_new = s->g_logpr.p; a.delta = s->g_delta.p;
+  a.active = s->g_active.p; a.flag = s->flag.p; a.epoch = s->epoch;
+  a.recs2 = s->g_recs.p; a.units = s->g_units; a.mat2 = s->g_mat2.p; a.mat_length = s->g_len.p; a.maxmat = s->g_maxmat;
+  a.taus = s->taus.p; a.lograt = s->g_lograt.p; a.tau_q = k; a.tau_u = tau_u; a.mix_c = mix_c; a.mix_lnc = mix_lnc;
+  a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p;
+  a.refresh_logpr = s->logpr_stale ? 1u : 0u; s->logpr_stale = false;
+  a.sp = s->sp;
+  hipLaunchKernelGGL(gsm::gstep_kernel, dim3((s->nloci + gsm::GBS - 1)/gsm::GBS), dim3(gsm::GBS), 0, e->stream, a);
+  HIPCHK(hipGetLastError());
+  s->launches++;
+  s->g_pend = mode <= 1 ? 1u : (mode == 2 || mode == 3) ? 2u : mode == 5 ? 3u : 0u;
+  return 1;
+}
+
+// the step's likelihood: the engine's kernels over the records the step kernel wrote
+static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci step */)
+{
+  bpa_engine * e = s->eng;
+  if (!e->usedata) return 1;                       // lnL = 0 for every locus (the buffer was zeroed): the MSC prior
+  PlanDev d{};
+  d.loci = e->d_loci.p; d.bfbeta = e->bfbeta;
+  d.site_term = s->g_site.p; d.lnl = s->g_lnl.p; d.ntasks = s->nloci; d.npatterns = s->g_npat; d.nmat = e->pack_slots*s->g_maxmat;
+  d.recs2 = s->g_recs.p; d.mat2 = s->g_mat2.p; d.mat_length = s->g_len.p; d.blk_mat_off = s->g_bmo.p; d.rec2_units = s->g_units;
+  d.lane_tab = e->d_lane_tab.p; d.slot_tab = e->d_slot_tab.p; d.blk_slot_off = e->d_blk_slot_off.p; d.nblocks2 = e->pack_blocks;
+  hipEvent_t k0 = nullptr, k1 = nullptr;
+  if (s->timing_stride && (s->timing_phase++ % s->timing_stride) == 0)
+  {
+    if (s->timed.size() >= 4096 && !sampler_timing_drain(s)) return 0;
+    bpa_sampler::Timed t{nullptr, nullptr, kind};
+    HIPCHK(hipEventCreate(&t.e0)); HIPCHK(hipEventCreate(&t.e1));
+    s->timed.push_back(t);
+    k0 = t.e0; k1 = t.e1;
+  }
+  const dim3 grid(e->pack_blocks), block(PACK_BS);
+  if (s->g_alljc)
+  {
+    d.flags = 1u | 2u | 4u;
+    hipExtLaunchKernelGGL((step_jc69_v2_kernel<PACK_BS>), grid, block, 0, e->stream, k0, k1, 0, d);
+    s->launches += 1;
+  }
+  else
+  {
+    d.pad = s->g_rmax;
+    d.flags = 1u;
+    hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, true>), grid, block, 0, e->stream, d);
+    d.flags = 2u | 4u;
+    hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), grid, block, 0, e->stream, k0, k1, 0, d);
+    s->launches += 2;
+  }
+  HIPCHK(hipGetLastError());
+  return 1;
+}
+
+// the ONE decision of an all-loci step
+static int gs_decide(bpa_sampler * s, double uacc, int tau_q, double win_u, double mix_c, double mix_lnc)
+{
+  bpa_engine * e = s->eng;
+  s->epoch++;
+  if (!s->allreduce)
+    hipLaunchKernelGGL(gsm::gsum_decide_kernel, dim3(1), dim3(1024), 0, e->stream, s->g_dev.p, s->g_lnl.p, s->g_delta.p, s->g_active.p, s->nloci,
+                       (double *)nullptr, 1, uacc, s->epoch, s->flag.p, s->counters.p, s->taus.p, s->sp, tau_q, win_u, mix_c, mix_lnc);
+  else
+  {
+    double * out = s->sum_ext ? s->sum_ext : s->mix_sum.p;
+    hipLaunchKernelGGL(gsm::gsum_decide_kernel, dim3(1), dim3(1024), 0, e->stream, s->g_dev.p, s->g_lnl.p, s->g_delta.p, s->g_active.p, s->nloci,
+                       out, 0, uacc, s->epoch, s->flag.p, s->counters.p, s->taus.p, s->sp, tau_q, win_u, mix_c, mix_lnc);
+    if (!s->allreduce(s->allreduce_ctx, out, 1u, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
+    hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, out, uacc, s->epoch, s->flag.p, s->counters.p, s->taus.p, s->sp,
+                       tau_q, -1, win_u, mix_c, mix_lnc);
+    s->launches++;
+  }
+  HIPCHK(hipGetLastError());
+  s->launches++;
+  return 1;
+}
+
+static int gs_initialize(bpa_sampler * s)
+{
+  if (!gs_step(s, 5)) return 0;
+  return gs_eval(s, 1);
+}
+
+static int gs_iterate(bpa_sampler * s, unsigned iterations)
+{
+  bpa_engine * e = s->eng;
+  for (unsigned it = 0; it < iterations; ++it)
+  {
+    // the per-locus proposals, "step j of every locus" (gage_step / gspr_step of a00_driver.c): each launch first settles
+    // the step before it
+    for (unsigned k = 0; k + 1 < s->maxtips; ++k)     { if (!gs_step(s, 0, k) || !gs_eval(s, 0)) return 0; }
+    for (unsigned k = 0; k + 2 < 2*s->maxtips; ++k)   { if (!gs_step(s, 1, k) || !gs_eval(s, 0)) return 0; }
+    s->sweeps++;
+    if (s->env_nomix) continue;
+    if (s->sp.theta_alpha > 0)
+    {
+      // settle the last per-locus step and leave the statistics of every tree's density; then THETA as in the sweep path
+      if (!gs_step(s, 4)) return 0;
+      smp::ThetaArgs ta{};
+      for (int p = 0; p < s->sp.npop; ++p)
+        if (s->has_theta[p]) { ta.on[p] = 1u; ta.win_u[p] = a00_rndu(&s->grng); ta.uacc[p] = a00_rndu(&s->grng); }
+      if (!s->allreduce)
+        hipLaunchKernelGGL(smp::theta_sum_decide_kernel, dim3(s->sp.npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p,
+                           s->nloci, s->taus.p, s->sp, ta, s->counters.p, (double *)nullptr, (const double *)nullptr, 1);
+      else
+      {
+        hipLaunchKernelGGL(smp::theta_sum_decide_kernel, dim3(s->sp.npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p,
+                           s->nloci, s->taus.p, s->sp, ta, s->counters.p, s->theta_sums.p, (const double *)nullptr, 0);
+        double * ar = s->sum_ext ? s->sum_ext : s->theta_sums.p;
+        const size_t nb = (size_t)s->sp.npop*sizeof(double);
+        if (ar != s->theta_sums.p) HIPCHK(hipMemcpyAsync(ar, s->theta_sums.p, nb, hipMemcpyDeviceToDevice, e->stream));
+        if (!s->allreduce(s->allreduce_ctx, ar, (unsigned)s->sp.npop, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
+        if (ar != s->theta_sums.p) HIPCHK(hipMemcpyAsync(s->theta_sums.p, ar, nb, hipMemcpyDeviceToDevice, e->stream));
+        hipLaunchKernelGGL(smp::theta_sum_decide_kernel, dim3(s->sp.npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p,
+                           s->nloci, s->taus.p, s->sp, ta, s->counters.p, (double *)nullptr, (const double *)s->theta_sums.p, 1);
+      }
+      HIPCHK(hipGetLastError());
+      s->logpr_stale = true;
+      s->launches += 1;
+    }
+    for (int q = s->sp.S; q < s->sp.npop; ++q)                    // one rubber-band step per species divergence
+    {
+      const double uprop = a00_rndu(&s->grng), uacc_t = a00_rndu(&s->grng);
+      if (!gs_step(s, 2, (unsigned)q, uprop) || !gs_eval(s, 1) || !gs_decide(s, uacc_t, q, uprop, 1.0, 0.0)) return 0;
+    }
+    const double lnc = s->sp.ft_mix*(a00_rndu(&s->grng) - 0.5), c = std::exp(lnc);
+    const double uacc = a00_rndu(&s->grng);
+    if (!gs_step(s, 3, 0, 0.0, c, lnc) || !gs_eval(s, 1) || !gs_decide(s, uacc, -1, 0.0, c, lnc)) return 0;
+  }
+  return 1;
+}
+
+// settle whatever is pending and bring the trees to the host
+static int gs_download(bpa_sampler * s)
+{
+  bpa_engine * e = s->eng;
+  if (!gs_step(s, 4)) return 0;
+  HIPCHK(hipMemcpyAsync(s->g_trees.data(), s->g_dev.p, s->nloci*sizeof(gsm::GTree), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 1;
+}

@@ -2122,6 +2122,8 @@ __device__ __forceinline__ void jc69_v2_compute(const PlanDev & P, const Jc69Lan
   const bool do_mats = (P.flags & 1u) != 0;
   const uint32_t e0 = R.e0, e1 = R.e1;
   // K4 for this step's branches (locus.c:2342-2414), one branch per lane
+  // (an entry with slot 0xffffffff is a hole: the device-written step images of gsampler.hpp keep a fixed number of
+  //  entries per locus)
   const bool have_m0 = e0 + lane < e1;
   const bool summer = (P.flags & 4u) && lane < s1 - s0;
   double c_lnl = 0;
@@ -2131,15 +2133,19 @@ __device__ __forceinline__ void jc69_v2_compute(const PlanDev & P, const Jc69Lan
   const uint4 * rp = P.recs2 + (size_t)(has_slot ? ls.slot : 0u)*P.rec2_units;
   if (have_m0)
   {
-    // the slot entry carries the locus's rate (engine_pack): one hop from the matrix record to the exponential
-    const SlotStatic & M = P.slot_tab[R.m0.slot];
-    double2 ab;
-    jc69_ab(R.m0_len, M.rate0, ab.x, ab.y);
-    *reinterpret_cast<double2 *>(M.pmat + (size_t)R.m0.pmatrix*2) = ab;
-    s_ab[lane] = ab;
+    if (R.m0.slot != 0xffffffffu)
+    {
+      // the slot entry carries the locus's rate (engine_pack): one hop from the matrix record to the exponential
+      const SlotStatic & M = P.slot_tab[R.m0.slot];
+      double2 ab;
+      jc69_ab(R.m0_len, M.rate0, ab.x, ab.y);
+      *reinterpret_cast<double2 *>(M.pmat + (size_t)R.m0.pmatrix*2) = ab;
+      s_ab[lane] = ab;
+    }
     for (uint32_t e = e0 + lane + BS; e < e1; e += BS)
     {
       const MatRec2 m = P.mat2[e];
+      if (m.slot == 0xffffffffu) continue;
       const SlotStatic & M2 = P.slot_tab[m.slot];
       double2 ab2;
       jc69_ab(P.mat_length[e], M2.rate0, ab2.x, ab2.y);
@@ -2410,6 +2416,7 @@ step_s4_klane_v2_kernel(const PlanDev P)
     {
       const uint32_t e = e0 + i/rmax, k = i % rmax;
       const MatRec2 m2 = P.mat2[e];
+      if (m2.slot == 0xffffffffu) continue;                  // a hole of a device-written step image (gsampler.hpp)
       const SlotStatic & M = P.slot_tab[m2.slot];
       if (k >= M.rate_cats) continue;
       MatRec m;

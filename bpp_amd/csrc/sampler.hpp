@@ -157,12 +157,12 @@ template <int W> struct ByteArr
   uint32_t w[W];
   __device__ __forceinline__ int get(int i) const
   {
-    uint32_t v;
-    if constexpr (W <= 2) v = __builtin_amdgcn_perm(w[W - 1], w[0], (uint32_t)i);          // selector 0-3: second operand, 4-7: first
-    else
+    uint32_t v = __builtin_amdgcn_perm(w[W > 1 ? 1 : 0], w[0], (uint32_t)i);               // selector 0-3: second operand, 4-7: first
+#pragma unroll
+    for (int q = 1; q < W/2; ++q)                                                            // entries 8q .. 8q+7 (a selector out of range yields a byte nobody keeps)
     {
-      const uint32_t lo = __builtin_amdgcn_perm(w[1], w[0], (uint32_t)i), hi = __builtin_amdgcn_perm(w[3], w[2], (uint32_t)i - 8u);
-      v = i < 8 ? lo : hi;
+      const uint32_t h = __builtin_amdgcn_perm(w[2*q + 1], w[2*q], (uint32_t)i - 8u*(uint32_t)q);
+      v = (i >> 3) == q ? h : v;
     }
     return (int)(int8_t)v;
   }
@@ -187,18 +187,18 @@ template <int W> struct ByteArr
 
 template <int NT> struct LTree
 {
-  static constexpr int W = NT <= 4 ? 2 : 4;
+  static constexpr int W = NT <= 4 ? 2 : NT <= 8 ? 4 : 8;
   ByteArr<W> left, right, parent, clv, pmat, pop;
   double *   time;                                // the ages stay in LDS (S.tr.time): doubles, read a few times per proposal
   a00_rng_t  rng;
   int32_t    root, tips;
-  __device__ __forceinline__ void load(Tree & t)
+  template <class TR> __device__ __forceinline__ void load(TR & t)
   {
     left.load(t.left); right.load(t.right); parent.load(t.parent); clv.load(t.clv); pmat.load(t.pmat); pop.load(t.pop);
     time = t.time; rng = t.rng; root = t.root; tips = t.tips;
   }
   // what the other lanes read, and what goes back to HBM at the end
-  __device__ __forceinline__ void mirror(Tree & t) const
+  template <class TR> __device__ __forceinline__ void mirror(TR & t) const
   {
     left.store(t.left); right.store(t.right); parent.store(t.parent); clv.store(t.clv); pmat.store(t.pmat); pop.store(t.pop);
     t.root = root;
@@ -286,8 +286,8 @@ __device__ __forceinline__ int climb(const LSpecies & sp, const double * tau, in
 // Three parts: the leader lane counts (density_prepare), the lanes of the locus take one population
 // each for the floating-point part (lanes_density: the wave runs ONE term's instructions instead of the
 // union of every leader's population loop), the leader adds the terms up in population order (density_sum).
-template <int NT>
-__device__ void density_prepare(TaskLDS & S, const LTree<NT> & t, LCounts & cn, const LSpecies & sp, uint32_t mask)
+template <int NT, class ST>                           // ST: what a proposal leaves for its evaluation (TaskLDS here, gsm::GState in gsampler.hpp)
+__device__ void density_prepare(ST & S, const LTree<NT> & t, LCounts & cn, const LSpecies & sp, uint32_t mask)
 {
   constexpr int NN = 2*NT - 1;
   const int n = 2*t.tips - 1;
@@ -309,7 +309,7 @@ __device__ void density_prepare(TaskLDS & S, const LTree<NT> & t, LCounts & cn, 
     for (int k = 0; k < NN; ++k) if (k >= t.tips && k < n && t.pop[k] == p) nodes |= 1u << k;
     const int nc = __popc(nodes);
     cn.nin_new[p] = nin; cn.nc_new[p] = nc;
-    S.nin_new[p] = (int8_t)nin; S.nc_new[p] = (int8_t)nc; S.pnodes[p] = (uint16_t)nodes;
+    S.nin_new[p] = (int8_t)nin; S.nc_new[p] = (int8_t)nc; S.pnodes[p] = (decltype(S.pnodes[p] + 0u))nodes;
   }
 }
 // the term of population p (any lane of the locus)
@@ -382,8 +382,8 @@ __device__ __forceinline__ uint32_t pop_chain(const uint16_t * anc, int a, int b
 // install a proposal: toggle buffers, node-update list of the nodes in mask ndm in children-first order
 // (= by age) — step_add of a00_driver.c; the fresh (a,b) of the changed branches (mask brm) are left to the
 // lanes of the locus (lanes_branches)
-template <int NT>
-__device__ void install(TaskLDS & S, LTree<NT> & t, uint32_t brm, uint32_t ndm)
+template <int NT, class ST>
+__device__ void install(ST & S, LTree<NT> & t, uint32_t brm, uint32_t ndm)
 {
   S.brm = brm;
   for (; brm; brm &= brm - 1) swap_pmat(t, __ffs(brm) - 1);
@@ -391,7 +391,7 @@ __device__ void install(TaskLDS & S, LTree<NT> & t, uint32_t brm, uint32_t ndm)
   // (a parent is always older than its children)
   double tk[NT - 1];
 #pragma unroll
-  for (int j = 0; j < NT - 1; ++j) tk[j] = t.time[t.tips + j < MAXN ? t.tips + j : 0];
+  for (int j = 0; j < NT - 1; ++j) tk[j] = t.time[t.tips + j < 2*NT ? t.tips + j : 0];
   int nn = 0;
   uint32_t wclv = S.wclv;
   while (ndm)
@@ -441,8 +441,8 @@ struct Prof
 };
 
 // GAGE on the k-th inner node (gage_step of a00_driver.c; propose_ages, gtree.c:4585)
-template <int NT>
-__device__ bool propose_gage(TaskLDS & S, LTree<NT> & t, LCounts & cn, TimeUndo & tu, double & hast, int k, const LSpecies & sp,
+template <int NT, class ST>
+__device__ bool propose_gage(ST & S, LTree<NT> & t, LCounts & cn, TimeUndo & tu, double & hast, int k, const LSpecies & sp,
                              const Species & spl, const double * tau, Prof & pf)
 {
   if (pf.on) pf.t = clock64();
@@ -483,8 +483,8 @@ __global__ void lograt_kernel(double * tab)
   tab[threadIdx.x] = (i && j) ? log((double)i/(double)j) : 0.0;
 }
 
-template <int NT>
-__device__ bool propose_gspr(TaskLDS & S, LTree<NT> & t, LCounts & cn, TimeUndo & tu, double & hast, int k, const LSpecies & sp,
+template <int NT, class ST>
+__device__ bool propose_gspr(ST & S, LTree<NT> & t, LCounts & cn, TimeUndo & tu, double & hast, int k, const LSpecies & sp,
                              const Species & spl, const double * tau, const double * lograt, Prof & pf)
 {
   if (pf.on) pf.t = clock64();
@@ -1079,6 +1079,8 @@ __global__ void __launch_bounds__(1024) theta_sum_decide_kernel(const int8_t * _
 
 } // namespace smp
 
+#include "gsampler.hpp"
+
 // ------------------------------------------------------------------------------------ host ---
 struct bpa_sampler
 {
@@ -1123,6 +1125,18 @@ struct bpa_sampler
   unsigned locus_offset = 0;            // global index of this rank's first locus (random streams)
   std::vector<double> h_taus;
   std::vector<smp::Tree> h_trees;
+  // ---- the generic path (gsampler.hpp): loci outside the sweep kernel's scope, evaluated by the engine's step kernels
+  bool generic = false;
+  std::vector<gsm::GTree> g_trees;      // host copies (instead of h_trees)
+  DevBuf<gsm::GTree> g_dev, g_undo;
+  DevBuf<gsm::GLocus> g_loc;
+  DevBuf<double> g_lnl, g_hast, g_logpr, g_delta, g_site, g_len, g_lograt;
+  DevBuf<uint8_t> g_active;
+  DevBuf<uint4> g_recs;
+  DevBuf<MatRec2> g_mat2;
+  DevBuf<uint32_t> g_bmo;
+  unsigned g_units = 0, g_maxmat = 0, g_pend = 0, g_npat = 0, g_rmax = 1, g_pack_epoch = 0;
+  bool g_alljc = true;
   unsigned nblocks = 0, epoch = 0;
   bool logpr_stale = false;     // thetas moved since the trees' densities were stored (Args::refresh_logpr)
   // diagnostic switches, read once at creation: BPA_SMP_DBG (bit mask, see Args::dbg), BPA_SMP_STEPS=g,q (proposal counts),
@@ -1142,19 +1156,36 @@ extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * co
   bpa_sampler * s = new bpa_sampler();
   s->eng = e; s->nloci = nloci; s->seed = seed; s->grng = a00_rng_seed(seed, A00_GLOBAL_STREAM);
   s->loci.assign(loci, loci + nloci);
+  // the LDS sweep kernel (JC69, one rate category, <= 8 tips, <= 64 patterns) where every locus fits it, else the generic
+  // path over the engine's step kernels (any 4-state model on the engine's packing, <= 16 tips; BPA_SMP_GENERIC=1 forces it)
+  bool fits_sweep = getenv("BPA_SMP_GENERIC") == nullptr, fits_generic = true, all_jc = true, all_kl = true;
   for (unsigned i = 0; i < nloci; ++i)
   {
     const bpa_locus * l = loci[i];
-    const bool ok = l && l->eng == e && l->alive && l->states == 4 && l->rate_cats == 1 && l->dev.model == 0 &&
-                    l->scale_buffers == 0 && !l->dev.unphased_length && l->tips >= 2 && l->tips <= (unsigned)smp::MAXTIPS &&
-                    l->sites <= (unsigned)smp::BS && l->clv_buffers == 2*(l->tips - 1) && l->prob_matrices == 2*(2*l->tips - 2);
-    if (!ok)
+    const bool base = l && l->eng == e && l->alive && l->states == 4 && l->scale_buffers == 0 && !l->dev.unphased_length && l->tips >= 2 &&
+                      l->clv_buffers == 2*(l->tips - 1) && l->prob_matrices == 2*(2*l->tips - 2);
+    if (!base)
     {
-      fail("bpa_sampler_create: loci must be JC69, 1 rate category, no scalers, not diploid, <= 8 tips, <= 64 patterns, "
-           "with the buffer counts of method.c:4110-4146");
+      fail("bpa_sampler_create: loci must be 4-state, without scalers, not diploid, with the buffer counts of method.c:4110-4146");
       delete s; return nullptr;
     }
+    fits_sweep = fits_sweep && l->rate_cats == 1 && l->dev.model == 0 && l->tips <= (unsigned)smp::MAXTIPS && l->sites <= (unsigned)smp::BS;
+    fits_generic = fits_generic && l->tips <= (unsigned)gsm::NT && l->rate_cats <= 8 && l->sites*l->rate_cats < PACK_BS;
+    all_jc = all_jc && l->rate_cats == 1 && l->dev.model == 0;
+    all_kl = all_kl && l->rate_cats > 1;
     s->maxtips = std::max(s->maxtips, l->tips);
+    s->g_rmax = std::max(s->g_rmax, l->rate_cats);
+  }
+  if (!fits_sweep)
+  {
+    if (!fits_generic || !(all_jc || all_kl))
+    {
+      fail("bpa_sampler_create: beyond the sweep kernel (JC69, 1 rate category, <= 8 tips, <= 64 patterns) the loci must all be JC69 with "
+           "one rate category or all have several categories, with <= 16 tips and < 256 patterns x categories");
+      delete s; return nullptr;
+    }
+    s->generic = true; s->g_alljc = all_jc;
+    s->g_trees.assign(nloci, gsm::GTree{});
   }
   s->h_trees.assign(nloci, smp::Tree{});
   if (const char * dv = getenv("BPA_SMP_DBG")) s->env_dbg = (uint32_t)atoi(dv);
@@ -1174,17 +1205,17 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   for (auto & t : s->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   s->blk_task_off.free(); s->lane_rec.free(); s->task_rec.free(); s->flag.free();
   s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free(); s->uc.free();
+  s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
+  s->g_len.free(); s->g_lograt.free(); s->g_active.free(); s->g_recs.free(); s->g_mat2.free(); s->g_bmo.free();
   delete s;
 }
 
-extern "C" int bpa_sampler_set_tree(bpa_sampler_t * s, unsigned i, const int * left, const int * right,
-                                    const double * times, int root)
+template <class TR, int MAXNODES>
+static int set_tree_fields(TR & t, int tips, const int * left, const int * right, const double * times, int root, a00_rng_t rng)
 {
-  if (i >= s->nloci) return fail("bpa_sampler_set_tree: locus index out of range");
-  const int tips = (int)s->loci[i]->tips, n = 2*tips - 1;
-  smp::Tree & t = s->h_trees[i];
+  const int n = 2*tips - 1;
   std::memset(&t, 0, sizeof(t));
-  for (int k = 0; k < smp::MAXN; ++k) { t.left[k] = t.right[k] = t.parent[k] = -1; t.clv[k] = t.pmat[k] = (int8_t)k; t.pop[k] = (int8_t)(k < tips ? k : -1); }
+  for (int k = 0; k < MAXNODES; ++k) { t.left[k] = t.right[k] = t.parent[k] = -1; t.clv[k] = t.pmat[k] = (int8_t)k; t.pop[k] = (int8_t)(k < tips ? k : -1); }
   for (int k = 0; k < n; ++k)
   {
     t.left[k] = (int8_t)left[k]; t.right[k] = (int8_t)right[k]; t.time[k] = times[k];
@@ -1192,10 +1223,44 @@ extern "C" int bpa_sampler_set_tree(bpa_sampler_t * s, unsigned i, const int * l
       return fail("bpa_sampler_set_tree: nodes 0..tips-1 are the tips (no children), the others have two");
     if (left[k] >= 0) { t.parent[left[k]] = (int8_t)k; t.parent[right[k]] = (int8_t)k; }
   }
-  t.root = root; t.tips = tips; t.rng = a00_rng_seed(s->seed, s->locus_offset + i); t.lnl = 0;
-  s->uploaded = false;
+  t.root = root; t.tips = tips; t.rng = rng; t.lnl = 0;
   return 1;
 }
+
+extern "C" int bpa_sampler_set_tree(bpa_sampler_t * s, unsigned i, const int * left, const int * right,
+                                    const double * times, int root)
+{
+  if (i >= s->nloci) return fail("bpa_sampler_set_tree: locus index out of range");
+  const int tips = (int)s->loci[i]->tips;
+  const a00_rng_t rng = a00_rng_seed(s->seed, s->locus_offset + i);
+  s->uploaded = false;
+  if (s->generic) return set_tree_fields<gsm::GTree, gsm::NN>(s->g_trees[i], tips, left, right, times, root, rng);
+  return set_tree_fields<smp::Tree, smp::MAXN>(s->h_trees[i], tips, left, right, times, root, rng);
+}
+
+// populations of the inner nodes (assign_pops of a00_driver.c): common population of the children, then up to the age
+template <class TR>
+static int assign_pops_host(const bpa_sampler * s, TR & t)
+{
+  const int n = 2*t.tips - 1;
+  std::vector<int> order;
+  for (int k = t.tips; k < n; ++k) order.push_back(k);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return t.time[a] < t.time[b]; });
+  for (int k = 0; k < t.tips; ++k) if (t.pop[k] < 0 || t.pop[k] >= s->sp.S) return fail("bpa_sampler: tip species out of range");
+  for (int v : order)
+  {
+    int c = t.pop[t.left[v]];
+    while (!((s->sp.anc[t.pop[t.right[v]]] >> c) & 1u)) c = s->sp.parent[c];
+    if (t.time[v] < s->h_taus[c]) return fail("bpa_sampler: a gene-tree node is younger than the divergence of its descendants' species");
+    while (s->sp.parent[c] >= 0 && s->h_taus[s->sp.parent[c]] <= t.time[v]) c = s->sp.parent[c];
+    t.pop[v] = (int8_t)c;
+  }
+  return 1;
+}
+static int gs_upload(bpa_sampler * s);
+static int gs_initialize(bpa_sampler * s);
+static int gs_iterate(bpa_sampler * s, unsigned iterations);
+static int gs_download(bpa_sampler * s);
 
 static int sampler_upload(bpa_sampler * s)
 {
@@ -1204,24 +1269,8 @@ static int sampler_upload(bpa_sampler * s)
   if (!set_device(e) || !flush(e)) return 0;
   const unsigned T = s->nloci;
   if (!s->sp.npop) return fail("bpa_sampler: set the species tree first (bpa_sampler_set_species_tree)");
-  // populations of the inner nodes (assign_pops of a00_driver.c): common population of the children, then up to the age
-  for (unsigned i = 0; i < T; ++i)
-  {
-    smp::Tree & t = s->h_trees[i];
-    const int n = 2*t.tips - 1;
-    std::vector<int> order;
-    for (int k = t.tips; k < n; ++k) order.push_back(k);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return t.time[a] < t.time[b]; });
-    for (int k = 0; k < t.tips; ++k) if (t.pop[k] < 0 || t.pop[k] >= s->sp.S) return fail("bpa_sampler: tip species out of range");
-    for (int v : order)
-    {
-      int c = t.pop[t.left[v]];
-      while (!((s->sp.anc[t.pop[t.right[v]]] >> c) & 1u)) c = s->sp.parent[c];
-      if (t.time[v] < s->h_taus[c]) return fail("bpa_sampler: a gene-tree node is younger than the divergence of its descendants' species");
-      while (s->sp.parent[c] >= 0 && s->h_taus[s->sp.parent[c]] <= t.time[v]) c = s->sp.parent[c];
-      t.pop[v] = (int8_t)c;
-    }
-  }
+  if (s->generic) return gs_upload(s);
+  for (unsigned i = 0; i < T; ++i) if (!assign_pops_host(s, s->h_trees[i])) return 0;
   for (int p = 0; p < smp::MAXPOP; ++p) s->has_theta[p] = p >= s->sp.S && p < s->sp.npop;
   for (unsigned i = 0; i < T; ++i)
   {
@@ -1422,10 +1471,17 @@ extern "C" int bpa_sampler_set_tip_species(bpa_sampler_t * s, unsigned i, const 
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (i >= s->nloci) return fail("bpa_sampler_set_tip_species: locus index out of range");
+  s->uploaded = false;
+  if (s->generic)
+  {
+    gsm::GTree & t = s->g_trees[i];
+    if (!t.tips) return fail("bpa_sampler_set_tip_species: set the tree first");
+    for (int k = 0; k < t.tips; ++k) t.pop[k] = (int8_t)species[k];
+    return 1;
+  }
   smp::Tree & t = s->h_trees[i];
   if (!t.tips) return fail("bpa_sampler_set_tip_species: set the tree first");
   for (int k = 0; k < t.tips; ++k) t.pop[k] = (int8_t)species[k];
-  s->uploaded = false;
   return 1;
 }
 
@@ -1466,6 +1522,7 @@ extern "C" int bpa_sampler_initialize(bpa_sampler_t * s)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (!sampler_upload(s)) return 0;
+  if (s->generic) return gs_initialize(s);
   return sampler_launch(s, 3, 1.0);
 }
 
@@ -1508,7 +1565,8 @@ extern "C" int bpa_sampler_set_allreduce(bpa_sampler_t * s, bpa_allreduce_fn fn,
   if (first_locus != s->locus_offset)
   {
     s->locus_offset = first_locus;
-    for (unsigned i = 0; i < s->nloci; ++i) s->h_trees[i].rng = a00_rng_seed(s->seed, first_locus + i);
+    for (unsigned i = 0; i < s->nloci; ++i)
+      (s->generic ? s->g_trees[i].rng : s->h_trees[i].rng) = a00_rng_seed(s->seed, first_locus + i);
     s->uploaded = false;
   }
   return 1;
@@ -1519,6 +1577,7 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
   bpa_engine * e = s->eng;
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   if (!sampler_upload(s)) return 0;
+  if (s->generic) return gs_iterate(s, iterations);
   const bool fused = s->fuse_decision && !s->allreduce && !s->env_trace;      // (several GPUs: sum -> all-reduce -> decide)
   for (unsigned it = 0; it < iterations; ++it)
   {
@@ -1584,6 +1643,7 @@ static int sampler_download(bpa_sampler * s)
 {
   bpa_engine * e = s->eng;
   if (!sampler_upload(s)) return 0;
+  if (s->generic) return gs_download(s);
   if (!sampler_launch(s, 2, 1.0)) return 0;
   HIPCHK(hipMemcpyAsync(s->h_trees.data(), s->trees.p, s->nloci*sizeof(smp::Tree), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1599,15 +1659,18 @@ extern "C" int bpa_sampler_get_tree(bpa_sampler_t * s, unsigned i, int * left, i
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (i >= s->nloci) return fail("bpa_sampler_get_tree: locus index out of range");
   if (i == 0 || !s->uploaded) { if (!sampler_download(s)) return 0; }      // refreshed when locus 0 is asked for
-  const smp::Tree & t = s->h_trees[i];
-  const int n = 2*t.tips - 1;
-  for (int k = 0; k < n; ++k)
+  auto out = [&](const auto & t)
   {
-    if (left) left[k] = t.left[k]; if (right) right[k] = t.right[k]; if (parent) parent[k] = t.parent[k];
-    if (times) times[k] = t.time[k]; if (clv) clv[k] = t.clv[k]; if (pmat) pmat[k] = t.pmat[k];
-  }
-  if (root) *root = t.root;
-  if (lnl) *lnl = t.lnl;
+    const int n = 2*t.tips - 1;
+    for (int k = 0; k < n; ++k)
+    {
+      if (left) left[k] = t.left[k]; if (right) right[k] = t.right[k]; if (parent) parent[k] = t.parent[k];
+      if (times) times[k] = t.time[k]; if (clv) clv[k] = t.clv[k]; if (pmat) pmat[k] = t.pmat[k];
+    }
+    if (root) *root = t.root;
+    if (lnl) *lnl = t.lnl;
+  };
+  if (s->generic) out(s->g_trees[i]); else out(s->h_trees[i]);
   return 1;
 }
 
@@ -1616,9 +1679,12 @@ extern "C" int bpa_sampler_get_tree_msc(bpa_sampler_t * s, unsigned i, int * pop
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (i >= s->nloci) return fail("bpa_sampler_get_tree_msc: locus index out of range");
   if (i == 0 || !s->uploaded) { if (!sampler_download(s)) return 0; }
-  const smp::Tree & t = s->h_trees[i];
-  if (pop) for (int k = 0; k < 2*t.tips - 1; ++k) pop[k] = t.pop[k];
-  if (logpr) *logpr = t.logpr;
+  auto out = [&](const auto & t)
+  {
+    if (pop) for (int k = 0; k < 2*t.tips - 1; ++k) pop[k] = t.pop[k];
+    if (logpr) *logpr = t.logpr;
+  };
+  if (s->generic) out(s->g_trees[i]); else out(s->h_trees[i]);
   return 1;
 }
 
@@ -1653,10 +1719,12 @@ extern "C" int bpa_sampler_work(bpa_sampler_t * s, double * bytes, unsigned long
   double by = 0; unsigned long nu = 0, pu = 0;
   for (unsigned i = 0; i < s->nloci; ++i)
   {
-    const smp::Tree & t = s->h_trees[i];
-    const double np = s->loci[i]->sites;
-    by += t.sw_nupd*(96.0*np + 256.0) + t.proposals*36.0*np + t.sw_nbr*128.0;
-    nu += t.sw_nupd; pu += (unsigned long)t.sw_nupd*s->loci[i]->sites;
+    // K1 3 Np R S 8 + 2 R S^2 8 bytes per node update, K2 (Np R S 8 + 4 Np) per evaluated proposal, K4 R S^2 8 per fresh P-matrix
+    const double np = s->loci[i]->sites, R = s->loci[i]->rate_cats;
+    const double nupd = s->generic ? s->g_trees[i].work_nupd : s->h_trees[i].sw_nupd, nbr = s->generic ? s->g_trees[i].work_nbr : s->h_trees[i].sw_nbr;
+    const double nprop = s->generic ? s->g_trees[i].proposals : s->h_trees[i].proposals;
+    by += nupd*(96.0*np*R + 256.0*R) + nprop*(32.0*R + 4.0)*np + nbr*128.0*R;
+    nu += (unsigned long)nupd; pu += (unsigned long)(nupd*np);
   }
   if (bytes) *bytes = by;
   if (node_updates) *node_updates = nu;
@@ -1673,10 +1741,13 @@ extern "C" int bpa_sampler_summary(bpa_sampler_t * s, double * total_lnl, unsign
   uint32_t c[2];
   HIPCHK(hipMemcpy(c, s->counters.p, 8, hipMemcpyDeviceToHost));
   double tot = 0; unsigned long pr = c[0], ac = c[1];
-  for (const auto & t : s->h_trees) { tot += t.lnl; pr += t.proposals; ac += t.accepted; }
+  if (s->generic) for (const auto & t : s->g_trees) { tot += t.lnl; pr += t.proposals; ac += t.accepted; }
+  else for (const auto & t : s->h_trees) { tot += t.lnl; pr += t.proposals; ac += t.accepted; }
   if (total_lnl) *total_lnl = tot;
   if (proposals) *proposals = pr;
   if (accepted) *accepted = ac;
   if (launches) *launches = s->launches;
   return 1;
 }
+
+#include "gsampler_host.hpp"

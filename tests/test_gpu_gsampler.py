@@ -1,0 +1,114 @@
+"""The generic device-resident sampler (csrc/gsampler.hpp: loci outside the LDS sweep kernel's scope — several rate
+categories, GTR, up to 16 tips — proposed on the device as records for the engine's step kernels) walks the trajectory
+of the C host driver on libbpp_amd.so with the same seeds, which is the host driver's on the REAL reference
+(test_gpu_host_driver.py): same accept/reject history, same trees, populations, buffer indices, taus and thetas."""
+import os
+
+import numpy as np
+import pytest
+
+import bpp_amd
+from bpp_amd import synth
+import oraclelib as O
+import hostdrv
+import tape
+from common import rel
+
+pytestmark = pytest.mark.gpu
+
+
+def walk(host, dev, iters, nloci, check_every=1):
+    host.initialize(); dev.initialize()
+    s = dev.summary()
+    assert rel(s["total_lnl"], host.total_lnl()) < 1e-13
+    for it in range(iters):
+        host.iterate(); dev.iterate(1)
+        if it % check_every:
+            continue
+        s = dev.summary()
+        hp, ha, _ = host.counters()
+        assert (s["proposals"], s["accepted"]) == (hp, ha), it
+        assert rel(s["total_lnl"], host.total_lnl()) < 1e-11, it
+    assert np.allclose(dev.taus(), host.taus(), rtol=1e-12, atol=0)
+    assert np.allclose(dev.thetas(), host.thetas(), rtol=1e-12, atol=0)
+    for i in range(nloci):
+        a, b = dev.tree(i), host.tree(i)
+        assert a["root"] == b["root"]
+        for key in ("left", "right", "parent", "clv", "pmat", "pop"):
+            assert [int(x) for x in a[key]] == [int(x) for x in b[key]], (i, key)
+        assert np.allclose(a["time"], b["time"], rtol=1e-12, atol=0)
+        assert rel(a["lnl"], b["lnl"]) < 1e-11 and rel(a["logpr"], b["logpr"]) < 1e-11
+
+
+@pytest.mark.parametrize("taxa,model,R,nloci,iters,forced", [(4, "jc69", 1, 300, 5, True), (8, "gtr", 4, 60, 3, False),
+                                                             (8, "jc69", 1, 40, 3, True)])
+def test_generic_sampler_equals_host_driver(taxa, model, R, nloci, iters, forced):
+    eng = bpp_amd.Engine(0)
+    data = synth.make_dataset(nloci, 300, taxa, model, R, seed=19)
+    loci_a = tape.make_engine_loci(eng, data)
+    loci_b = tape.make_engine_loci(eng, data)
+    host = hostdrv.hip_driver(eng, loci_a, data, seed=29)
+    if forced:
+        os.environ["BPA_SMP_GENERIC"] = "1"            # these loci would fit the sweep kernel
+    try:
+        dev = bpp_amd.Sampler(eng, loci_b, data, seed=29)
+    finally:
+        os.environ.pop("BPA_SMP_GENERIC", None)
+    parent, tau0, thetas = synth.species_tree_arrays(taxa)
+    for drv in (host, dev):
+        drv.set_species_tree(parent, tau0, thetas)
+        drv.set_tau_prior(3.0, 3.0 / tau0[-1])
+        drv.set_theta_prior(2.0, 1000.0, 0.001)
+        drv.set_finetune(0.003, 0.005, 0.0008, 0.2)
+    walk(host, dev, iters, nloci)
+    assert dev.taus() != list(tau0) and dev.thetas() != list(thetas)
+    # the device state is the state of the explicit-index API: buffers hold what the indices say
+    for i in range(0, nloci, max(1, nloci // 8)):
+        t = dev.tree(i)
+        d = data[i]
+        have = loci_b[i].root_loglikelihood(int(t["clv"][t["root"]]), -1)
+        ol = O.OracleLocus(4, R, d["seqs"], d["weights"], model=d["model"], freqs=None if model == "jc69" else d["freqs"],
+                           qrates=None if model == "jc69" else d["exch"], rates=d["rates"])
+        full = ol.full_lnl(list(t["left"]), list(t["right"]), list(t["time"]), t["root"])
+        assert rel(have, full) < 1e-12 and rel(t["lnl"], full) < 1e-12
+    w = dev.work()
+    assert w["sweeps"] == iters and w["node_updates"] > 0 and w["bytes"] > 0
+    dev.close(); host.close(); eng.close()
+
+
+def test_generic_sampler_on_the_anopheles_data():
+    """BASELINE config 5's data (examples/anopheles: 100 loci x 12 sequences, 6 species with two sequences each, JC69,
+    cleandata = 1; priors and step lengths of anopheles-bpp-msci.ctl, the MSC on the control file's tree): 12 tips are
+    beyond the sweep kernel — the generic sampler takes them, and walks the host driver's trajectory"""
+    from bpp_amd import seqio
+    from test_gpu_host_driver import _msc_start_tree
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    species = ["G", "C", "R", "L", "A", "Q"]
+    recs = seqio.load_dataset(os.path.join(G, "anopheles", "loci_realign.txt"), os.path.join(G, "anopheles", "Imap.txt"),
+                              species, None, model="jc69", cleandata=True)
+    parent = [6, 6, 10, 8, 7, 7, 9, 8, 9, 10, -1]
+    tau0 = [0.0] * 6 + [0.004, 0.004, 0.008, 0.012, 0.016]
+    thetas = [0.02] * 11
+    rng = np.random.default_rng(77)
+    data = []
+    for r in recs:
+        left, right, times, root = _msc_start_tree(r["species"], parent, tau0, thetas, rng)
+        data.append(dict(seqs=r["seqs"], weights=r["weights"], left=left, right=right, times=times, root=root, states=4,
+                         rate_cats=1, model="jc69", rates=np.ones(1)))
+    eng = bpp_amd.Engine(0)
+    loci_a = tape.make_engine_loci(eng, data)
+    loci_b = tape.make_engine_loci(eng, data)
+    host = hostdrv.hip_driver(eng, loci_a, data, seed=21)
+    dev = bpp_amd.Sampler(eng, loci_b, data, seed=21)
+    for drv in (host, dev):
+        drv.set_species_tree(parent, tau0, thetas)
+        for i, r in enumerate(recs):
+            drv.set_tip_species(i, r["species"])
+        drv.set_tau_prior(2.0, 10.0)
+        drv.set_theta_prior(2.0, 100.0, 0.002)
+        drv.set_finetune(0.003, 0.003, 0.00002, 0.9)
+    walk(host, dev, 5, len(data))
+    assert dev.thetas() != thetas
+    s = dev.summary()
+    assert 0.1 < s["accepted"] / s["proposals"] < 0.95
+    dev.close(); host.close(); eng.close()

@@ -142,7 +142,13 @@ def test_device_sampler_draws_from_the_msc_prior():
 
 
 def test_sampler_rejects_unsupported_loci(engine):
+    """GTR+G loci are the generic sampler's (tests/test_gpu_gsampler.py); scalers and a mix of one- and several-category
+    loci are refused loudly"""
     data = synth.make_dataset(2, 200, 8, "gtr", 4, seed=1)
-    loci = tape.make_engine_loci(engine, data)
-    with pytest.raises(bpp_amd.BpaError, match="JC69"):
+    loci = tape.make_engine_loci(engine, data, True)                  # with scale buffers
+    with pytest.raises(bpp_amd.BpaError, match="without scalers"):
         bpp_amd.Sampler(engine, loci, data)
+    mixed = data[:1] + synth.make_dataset(1, 200, 8, "jc69", 1, seed=2)
+    loci = tape.make_engine_loci(engine, mixed)
+    with pytest.raises(bpp_amd.BpaError, match="all be JC69"):
+        bpp_amd.Sampler(engine, loci, mixed)
