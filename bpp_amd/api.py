@@ -141,6 +141,9 @@ def lib():
                                      C.POINTER(i), C.POINTER(i), dp]),
         "bpa_sampler_summary": (i, [vp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
         "bpa_sampler_enable_timing": (i, [vp, u]),
+        "bpa_sampler_set_subst_model": (i, [vp, u, dp, dp, d]),
+        "bpa_sampler_get_subst_model": (i, [vp, u, dp, dp, dp]),
+        "bpa_sampler_set_subst_moves": (None, [vp, d, d, d, d, d]),
         "bpa_sampler_timing": (i, [vp, dp, C.POINTER(C.c_ulong), dp, C.POINTER(C.c_ulong)]),
         "bpa_sampler_work": (i, [vp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
         "bpa_engine_enable_timing": (None, [vp, i]),
@@ -177,7 +180,8 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_sampler_set_tau_prior", "bpa_sampler_get_taus", "bpa_sampler_get_tree_msc",
             "bpa_sampler_set_theta_prior", "bpa_sampler_get_thetas", "bpa_sampler_set_allreduce",
             "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary",
-            "bpa_sampler_enable_timing", "bpa_sampler_timing", "bpa_sampler_work"]
+            "bpa_sampler_enable_timing", "bpa_sampler_timing", "bpa_sampler_work",
+            "bpa_sampler_set_subst_model", "bpa_sampler_get_subst_model", "bpa_sampler_set_subst_moves"]
 
 
 def _err():
@@ -614,6 +618,19 @@ class Sampler:
         p, a, l = C.c_ulong(), C.c_ulong(), C.c_ulong()
         _chk(lib().bpa_sampler_summary(self.h, C.byref(tot), C.byref(p), C.byref(a), C.byref(l)))
         return dict(total_lnl=tot.value, proposals=p.value, accepted=a.value, launches=l.value)
+
+    def set_subst_model(self, k, freqs, qrates, alpha):
+        """starting values of locus k's substitution parameters (the moves of set_subst_moves change them)"""
+        _chk(lib().bpa_sampler_set_subst_model(self.h, k, _dp(_f64(freqs)), _dp(_f64(qrates)), float(alpha)))
+
+    def get_subst_model(self, k):
+        f, q, a = np.zeros(4), np.zeros(6), C.c_double()
+        _chk(lib().bpa_sampler_get_subst_model(self.h, k, _dp(f), _dp(q), C.byref(a)))
+        return f, q, a.value
+
+    def set_subst_moves(self, ft_freqs, ft_qrates, ft_alpha, alpha_a=1.0, alpha_b=1.0):
+        """window widths of the per-locus frequency / exchangeability / alpha moves (0: off), gamma prior of alpha"""
+        lib().bpa_sampler_set_subst_moves(self.h, ft_freqs, ft_qrates, ft_alpha, alpha_a, alpha_b)
 
     def enable_timing(self, stride=1):
         """HIP events on every stride-th sweep / all-loci launch (0: off)"""

@@ -16,6 +16,7 @@
 // with the trees in HBM between launches (496 B per locus) and nothing on the host but the launch loop.
 // Reference: gtree.c:4585 (ages), 6531 (SPR), stree.c:5512 / 4338 (tau + rubber band), prop_mixing.c:52, gtree.c:3957.
 #pragma once
+#include "gamma_dev.hpp"
 
 namespace gsm {
 using smp::Op; using smp::make_op; using smp::Species; using smp::LSpecies; using smp::LCounts; using smp::LTree;
@@ -40,7 +41,8 @@ static_assert(sizeof(GTree) % 16 == 0, "GTree is copied as uint4");
 struct GLocus                             // what never changes, per locus
 {
   uint32_t slot, pat_off;                 // its slot of the engine's packing, first pattern in the step's term array
-  uint32_t np, pad;
+  uint32_t R, pad;                        // rate categories
+  double * par;                           // the locus's parameter block (device_types.hpp): the substitution-parameter moves write it
   alignas(16) int8_t gl[MAXPOP];          // gene tips below each population
   alignas(16) int8_t nin[MAXPOP];         // gene tips of each species
 };
@@ -60,9 +62,14 @@ struct GArgs
   GTree * trees, * undo;                  // [T] current (or proposed, while a step is being evaluated) / the state before the pending step
   const GLocus * loc;                     // [T]
   uint32_t T;
-  uint32_t mode;                          // 0 GAGE k, 1 GSPR k, 2 TAU, 3 MIX, 4 settle (+ THETA statistics), 5 start-up evaluation
+  uint32_t mode;                          // 0 GAGE k, 1 GSPR k, 2 TAU, 3 MIX, 4 settle (+ THETA statistics), 5 start-up evaluation,
+                                          // 6 base frequency k, 7 exchangeability k, 8 alpha (locus.c:2782, 3168; prop_gamma.c:52)
   uint32_t k;
-  uint32_t pend;                          // the step to settle first: 0 none, 1 per-locus decisions, 2 an all-loci decision (flag / epoch), 3 commit (start-up)
+  uint32_t pend;                          // the step to settle first: 0 none, 1 per-locus decisions, 2 an all-loci decision (flag / epoch),
+                                          // 3 commit (start-up), 4 per-locus decisions of a substitution-parameter step
+  uint32_t pend_mode, pend_k;             // pend 4: which component that step proposed
+  double * sm, * sm_old;                  // [T][11] freqs | exchangeabilities | alpha of every locus; [T][2] the pending step's old values
+  double ft_freqs, ft_qrates, ft_alpha, alpha_a, alpha_b;
   const double * lnl_new;                 // [T] lnL of the pending step's evaluation (task = locus)
   double * hast, * logpr_new;             // [T] Hastings term / proposed MSC density of the step being proposed (read back when it is settled)
   double * delta;                         // [T] an all-loci step: this locus's density + Jacobian term
@@ -128,6 +135,19 @@ __global__ void glograt_kernel(double * tab)         // log(i/j), i, j < NN
   tab[threadIdx.x] = (i && j) ? log((double)i/(double)j) : 0.0;
 }
 
+// component `mode` (6 frequencies, 7 exchangeabilities, 8 alpha -> category rates) of a locus's values into its parameter block
+__device__ __forceinline__ void write_par(double * par, uint32_t R, uint32_t mode, const double * m)
+{
+  if (mode == 6)      for (int q = 0; q < 4; ++q) par[par_matrix(R, 4, 0) + pm_freqs(4) + q] = m[q];
+  else if (mode == 7) for (int q = 0; q < 6; ++q) par[par_matrix(R, 4, 0) + pm_subst(4) + q] = m[4 + q];
+  else
+  {
+    double rates[8];
+    gdev::gamma_cats(m[10], R, rates);                   // prop_gamma.c:93-97
+    for (uint32_t q = 0; q < R; ++q) par[par_rates(R) + q] = rates[q];
+  }
+}
+
 __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
 {
   __shared__ GState s_st[GBS];
@@ -178,6 +198,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
   }
   __syncthreads();
 
+  bool restore_par = false, propose_par = false;       // the locus's parameter block is written in ONE place, below (step 4b)
   // ---- 1. settle the step whose evaluation just finished
   if (valid && A.pend)
   {
@@ -198,6 +219,26 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     {
       if (*A.flag == A.epoch) back = true;
       else { logpr_cur = A.logpr_new[i]; if (A.active[i]) lnl_cur = A.lnl_new[i]; }
+    }
+    else if (A.pend == 4)
+    {
+      if (A.active[i])
+      {
+        const double lnl = A.lnl_new[i];
+        const double lnacc = (lnl - lnl_cur) + A.hast[i];
+        const double u = rndu(&T.rng);
+        ++nprop;
+        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = lnl; ++nacc; }
+        else
+        {
+          // the old values come back, in the sampler's copy and in the locus's parameter block
+          back = true;
+          double * m = A.sm + (size_t)i*11;
+          if (A.pend_mode == 8) m[10] = A.sm_old[2*i];
+          else { double * v = A.pend_mode == 6 ? m : m + 4; const int ref = A.pend_mode == 6 ? 3 : 1; v[A.pend_k] = A.sm_old[2*i]; v[ref] = A.sm_old[2*i + 1]; }
+          restore_par = true;
+        }
+      }
     }
     else { lnl_cur = A.lnl_new[i]; logpr_cur = A.logpr_new[i]; }
     if (back)
@@ -268,6 +309,46 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
       if (ndm) smp::install<NT>(S, T, brm, ndm);
       else { S.brm = 0; S.nops = 0; ok = false; }                              // no gene node moves here: only the density changes
     }
+    else if (A.mode >= 6)
+    {
+      // a substitution-parameter move (param_step of a00_driver.c): new value, then every branch, every inner node
+      double * m = A.sm + (size_t)i*11;
+      if (A.mode == 8 && L.R < 2) ok = false;
+      else
+      {
+        if (A.mode == 8)
+        {
+          const double a_old = m[10], la_old = log(a_old);
+          const double la_new = reflect(la_old + A.ft_alpha*(rndu(&T.rng) - 0.5), -99.0, 99.0);
+          const double a_new = exp(la_new);
+          A.sm_old[2*i] = a_old;
+          m[10] = a_new;
+          hast = (la_new - la_old) + ((A.alpha_a - 1)*log(a_new/a_old) - A.alpha_b*(a_new - a_old));
+        }
+        else
+        {
+          double * v = A.mode == 6 ? m : m + 4;
+          const int j = (int)A.k, ref = A.mode == 6 ? 3 : 1;
+          const double sum = v[j] + v[ref], lo = log(1e-5), hi = log(sum);
+          const double l_old = log(v[j]);
+          const double l_new = reflect(l_old + (A.mode == 6 ? A.ft_freqs : A.ft_qrates)*(rndu(&T.rng) - 0.5), lo, hi);
+          A.sm_old[2*i] = v[j]; A.sm_old[2*i + 1] = v[ref];
+          v[j] = exp(l_new); v[ref] = sum - v[j];
+          hast = l_new - l_old;
+        }
+        propose_par = true;
+        const int nn_ = 2*T.tips - 1;
+        uint32_t brm = 0, ndm = 0;
+        for (int k = 0; k < nn_; ++k)
+        {
+          if (T.left[k] >= 0) ndm |= 1u << k;
+          if (T.parent[k] >= 0) brm |= 1u << k;
+        }
+        A.hast[i] = hast;
+        A.logpr_new[i] = logpr_cur;
+        smp::install<NT>(S, T, brm, ndm);
+      }
+    }
     else
     {
       // mixing (mix_step of a00_driver.c) or start-up: every branch, every inner node
@@ -298,6 +379,21 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     A.active[i] = ok ? 1 : 0;
   }
   else if (valid) A.active[i] = 0;
+
+  // ---- 4b. the parameter block follows the sampler's copy: first what a rejected step puts back, then the new proposal
+  if (valid && (restore_par || propose_par))
+  {
+    const double * m = A.sm + (size_t)i*11;
+    for (int pass = 0; pass < 2; ++pass)
+    {
+      const bool on = pass == 0 ? restore_par : propose_par;
+      const uint32_t md = pass == 0 ? A.pend_mode : A.mode;
+      if (!on) continue;
+      // (restored and proposed component may be the same one: this order leaves the proposal in the block.  NB the
+      //  values of `m` are final here — a restored component and a newly proposed one never overlap in time)
+      write_par(L.par, L.R, md, m);
+    }
+  }
 
   // ---- 5. the step's records for the engine's kernels
   if (valid && A.mode != 4)

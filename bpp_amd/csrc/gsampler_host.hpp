@@ -19,7 +19,7 @@ static int gs_upload(bpa_sampler * s)
     for (int k = 0; k < t.tips; ++k) if (++cnt[t.pop[k]] >= 2) s->has_theta[t.pop[k]] = true;
     if (e->slot_of[l->id] < 0) return fail("bpa_sampler: a locus is not on the engine's packing");
     gsm::GLocus & g = loc[i];
-    g.slot = (uint32_t)e->slot_of[l->id]; g.pat_off = npat; g.np = l->sites; g.pad = 0;
+    g.slot = (uint32_t)e->slot_of[l->id]; g.pat_off = npat; g.R = l->rate_cats; g.pad = 0; g.par = l->dev.par;
     for (int p = 0; p < smp::MAXPOP; ++p) g.gl[p] = g.nin[p] = 0;
     for (int k = 0; k < t.tips; ++k)
     {
@@ -44,6 +44,14 @@ static int gs_upload(bpa_sampler * s)
       !upload(s->taus, s->h_taus.data(), s->h_taus.size()) || !s->pop_t2h.reserve((size_t)T*smp::MAXPOP) ||
       !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP))
     return 0;
+  if (s->g_ft[0] > 0 || s->g_ft[1] > 0 || s->g_ft[2] > 0)
+  {
+    if (s->g_alljc) return fail("bpa_sampler: the substitution-parameter moves need loci with an eigendecomposition (GTR) and several rate categories");
+    if (s->g_sm_host.size() != (size_t)T*11) return fail("bpa_sampler: call bpa_sampler_set_subst_model for every locus before the substitution-parameter moves");
+    std::vector<uint32_t> ids(T);
+    for (unsigned i = 0; i < T; ++i) ids[i] = s->loci[i]->id;
+    if (!upload(s->g_sm, s->g_sm_host.data(), (size_t)T*11) || !s->g_sm_old.reserve((size_t)T*2) || !upload(s->g_ids, ids.data(), T)) return 0;
+  }
   // every slot starts as "not part of the step", every matrix entry as a hole
   HIPCHK(hipMemsetAsync(s->g_recs.p, 0xff, nrec*sizeof(uint4), e->stream));
   HIPCHK(hipMemsetAsync(s->g_mat2.p, 0xff, nmat*sizeof(MatRec2), e->stream));
@@ -86,10 +94,18 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p;
   a.refresh_logpr = s->logpr_stale ? 1u : 0u; s->logpr_stale = false;
   a.sp = s->sp;
+  a.pend_mode = s->g_pend_mode; a.pend_k = s->g_pend_k; a.sm = s->g_sm.p; a.sm_old = s->g_sm_old.p;
+  a.ft_freqs = s->g_ft[0]; a.ft_qrates = s->g_ft[1]; a.ft_alpha = s->g_ft[2]; a.alpha_a = s->g_alpha_a; a.alpha_b = s->g_alpha_b;
+  // a frequency / exchangeability step — proposed now, or rolled back now for the loci that rejected it — leaves
+  // parameter blocks whose eigensystems are stale: refreshed before the next evaluation (gs_eval)
+  if (mode == 6 || mode == 7 || (s->g_pend == 4 && (s->g_pend_mode == 6 || s->g_pend_mode == 7))) s->g_eigen_dirty = true;
   hipLaunchKernelGGL(gsm::gstep_kernel, dim3((s->nloci + gsm::GBS - 1)/gsm::GBS), dim3(gsm::GBS), 0, e->stream, a);
   HIPCHK(hipGetLastError());
+  static const bool dbg_sync = getenv("BPA_GS_SYNC") != nullptr;        // diagnostics: wait for every launch and say which it was
+  if (dbg_sync) { HIPCHK(hipStreamSynchronize(e->stream)); fprintf(stderr, "[gs] step mode %u k %u pend %u done\n", mode, k, a.pend); }
   s->launches++;
-  s->g_pend = mode <= 1 ? 1u : (mode == 2 || mode == 3) ? 2u : mode == 5 ? 3u : 0u;
+  s->g_pend = mode <= 1 ? 1u : (mode == 2 || mode == 3) ? 2u : mode == 5 ? 3u : mode >= 6 ? 4u : 0u;
+  s->g_pend_mode = mode; s->g_pend_k = k;
   return 1;
 }
 
@@ -98,6 +114,15 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
 {
   bpa_engine * e = s->eng;
   if (!e->usedata) return 1;                       // lnL = 0 for every locus (the buffer was zeroed): the MSC prior
+  if (s->g_eigen_dirty)
+  {
+    // K6 for every locus of the sampler from the values now in its parameter block (pll_update_eigen, locus.c:2462-2476)
+    hipLaunchKernelGGL(eigen_kernel, dim3((s->nloci + 63)/64), dim3(64), 0, e->stream, e->d_loci.p, s->g_ids.p, (uint32_t)s->nloci);
+    HIPCHK(hipGetLastError());
+    s->g_eigen_dirty = false;
+    s->launches++;
+    if (getenv("BPA_GS_SYNC")) { HIPCHK(hipStreamSynchronize(e->stream)); fprintf(stderr, "[gs] eigen done\n"); }
+  }
   PlanDev d{};
   d.loci = e->d_loci.p; d.bfbeta = e->bfbeta;
   d.site_term = s->g_site.p; d.lnl = s->g_lnl.p; d.ntasks = s->nloci; d.npatterns = s->g_npat; d.nmat = e->pack_slots*s->g_maxmat;
@@ -129,6 +154,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     s->launches += 2;
   }
   HIPCHK(hipGetLastError());
+  if (getenv("BPA_GS_SYNC")) { HIPCHK(hipStreamSynchronize(e->stream)); fprintf(stderr, "[gs] eval done\n"); }
   return 1;
 }
 
@@ -206,6 +232,12 @@ static int gs_iterate(bpa_sampler * s, unsigned iterations)
     const double lnc = s->sp.ft_mix*(a00_rndu(&s->grng) - 0.5), c = std::exp(lnc);
     const double uacc = a00_rndu(&s->grng);
     if (!gs_step(s, 3, 0, 0.0, c, lnc) || !gs_eval(s, 1) || !gs_decide(s, uacc, -1, 0.0, c, lnc)) return 0;
+    // the substitution-parameter moves come last (method.c:5699-5735; param_step of a00_driver.c)
+    if (s->g_ft[0] > 0) for (unsigned j = 0; j < 3; ++j)  { if (!gs_step(s, 6, j) || !gs_eval(s, 0)) return 0; }
+    if (s->g_ft[1] > 0) for (unsigned j = 0; j < 6; ++j)  { if (j != 1 && (!gs_step(s, 7, j) || !gs_eval(s, 0))) return 0; }
+    if (s->g_ft[2] > 0)                                   { if (!gs_step(s, 8, 0) || !gs_eval(s, 0)) return 0; }
+    if (s->g_ft[0] > 0 || s->g_ft[1] > 0 || s->g_ft[2] > 0)
+      for (bpa_locus * l : s->loci) l->host_par_stale = true;            // the device blocks moved ahead of the host mirrors
   }
   return 1;
 }
@@ -216,6 +248,40 @@ static int gs_download(bpa_sampler * s)
   bpa_engine * e = s->eng;
   if (!gs_step(s, 4)) return 0;
   HIPCHK(hipMemcpyAsync(s->g_trees.data(), s->g_dev.p, s->nloci*sizeof(gsm::GTree), hipMemcpyDeviceToHost, e->stream));
+  if (s->g_sm.p && !s->g_sm_host.empty())
+    HIPCHK(hipMemcpyAsync(s->g_sm_host.data(), s->g_sm.p, s->g_sm_host.size()*sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return 1;
+}
+
+// ---- substitution-parameter moves: the sampler's copy of every locus's values and the window widths
+extern "C" int bpa_sampler_set_subst_model(bpa_sampler_t * s, unsigned i, const double * freqs, const double * qrates, double alpha)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (i >= s->nloci || !freqs || !qrates || !(alpha > 0)) return fail("bpa_sampler_set_subst_model: bad argument");
+  if (!s->generic) return fail("bpa_sampler_set_subst_model: the loci are JC69 (no substitution parameters to move)");
+  if (s->g_sm_host.size() != (size_t)s->nloci*11) s->g_sm_host.assign((size_t)s->nloci*11, 0.0);
+  double * m = s->g_sm_host.data() + (size_t)i*11;
+  std::copy(freqs, freqs + 4, m); std::copy(qrates, qrates + 6, m + 4); m[10] = alpha;
+  s->uploaded = false;
+  return 1;
+}
+
+extern "C" int bpa_sampler_get_subst_model(bpa_sampler_t * s, unsigned i, double * freqs, double * qrates, double * alpha)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (i >= s->nloci || s->g_sm_host.size() != (size_t)s->nloci*11) return fail("bpa_sampler_get_subst_model: no substitution model set");
+  if (i == 0 && s->uploaded && !sampler_download(s)) return 0;          // refreshed when locus 0 is asked for
+  const double * m = s->g_sm_host.data() + (size_t)i*11;
+  if (freqs) std::copy(m, m + 4, freqs);
+  if (qrates) std::copy(m + 4, m + 10, qrates);
+  if (alpha) *alpha = m[10];
+  return 1;
+}
+
+extern "C" void bpa_sampler_set_subst_moves(bpa_sampler_t * s, double ft_freqs, double ft_qrates, double ft_alpha, double alpha_a, double alpha_b)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  s->g_ft[0] = ft_freqs; s->g_ft[1] = ft_qrates; s->g_ft[2] = ft_alpha; s->g_alpha_a = alpha_a; s->g_alpha_b = alpha_b;
+  s->uploaded = false;
 }

@@ -49,6 +49,10 @@ struct a00_driver
   double * s_logpr;                     /* proposed MSC density per slot */
   double * p_logpr, * p_delta; int * p_slot;     /* all-loci steps: per locus */
   int ** u_pop;
+  /* substitution-model parameters per locus (a00_set_subst_model): freqs[4] | qrates[6] | alpha, and their moves */
+  double * sm; int * sm_ncat; a00_param_fn setpar;
+  double ft_freqs, ft_qrates, ft_alpha, alpha_a, alpha_b;
+  double * sm_old;                      /* proposed component's old values per slot: [2] for freqs / qrates, alpha */
 };
 
 
@@ -157,7 +161,7 @@ void a00_destroy(a00_driver_t * d)
     free(d->u_left[i]); free(d->u_right[i]); free(d->u_parent[i]); free(d->u_clv[i]); free(d->u_pmat[i]);
     free(d->u_scaler[i]); free(d->u_time[i]);
   }
-  free(d->rng); free(d->zrng); free(d->trees); free(d->s_locus); free(d->s_tree); free(d->s_br_off); free(d->s_nd_off); free(d->s_br);
+  free(d->rng); free(d->zrng); free(d->sm); free(d->sm_ncat); free(d->sm_old); free(d->trees); free(d->s_locus); free(d->s_tree); free(d->s_br_off); free(d->s_nd_off); free(d->s_br);
   free(d->s_logpr); free(d->p_logpr); free(d->p_delta); free(d->p_slot); free(d->u_pop);
   free(d->s_nd); free(d->s_lnl); free(d->s_hast); free(d->u_left); free(d->u_right); free(d->u_parent);
   free(d->u_clv); free(d->u_pmat); free(d->u_scaler); free(d->u_time); free(d->u_root); free(d);
@@ -660,6 +664,109 @@ static int mix_step(a00_driver_t * d)
   return 1;
 }
 
+/* ---- substitution-parameter moves (bpp_amd_host.h) */
+void a00_set_param_backend(a00_driver_t * d, a00_param_fn fn) { d->setpar = fn; }
+void a00_set_subst_moves(a00_driver_t * d, double ft_freqs, double ft_qrates, double ft_alpha, double alpha_a, double alpha_b)
+{ d->ft_freqs = ft_freqs; d->ft_qrates = ft_qrates; d->ft_alpha = ft_alpha; d->alpha_a = alpha_a; d->alpha_b = alpha_b; }
+
+int a00_set_subst_model(a00_driver_t * d, unsigned i, const double * freqs, const double * qrates, double alpha, int ncat)
+{
+  double * m;
+  if (i >= d->nloci || ncat < 0 || ncat > 16) return 0;
+  if (!d->sm)
+  {
+    d->sm = (double *)calloc((size_t)d->nloci*11, sizeof(double));
+    d->sm_ncat = (int *)calloc(d->nloci, sizeof(int));
+    d->sm_old = (double *)calloc((size_t)d->nloci*2, sizeof(double));
+  }
+  m = d->sm + (size_t)i*11;
+  memcpy(m, freqs, 4*sizeof(double)); memcpy(m + 4, qrates, 6*sizeof(double)); m[10] = alpha;
+  d->sm_ncat[i] = ncat;
+  return 1;
+}
+int a00_get_subst_model(const a00_driver_t * d, unsigned i, double * freqs, double * qrates, double * alpha)
+{
+  const double * m;
+  if (i >= d->nloci || !d->sm) return 0;
+  m = d->sm + (size_t)i*11;
+  if (freqs) memcpy(freqs, m, 4*sizeof(double));
+  if (qrates) memcpy(qrates, m + 4, 6*sizeof(double));
+  if (alpha) *alpha = m[10];
+  return 1;
+}
+/* hand the current values of component `which` of locus i to the likelihood back-end */
+static int push_param(a00_driver_t * d, unsigned i, int which)
+{
+  double * m = d->sm + (size_t)i*11;
+  if (which == 1) return d->setpar(d->ctx, i, 1, m, 4);
+  if (which == 2) return d->setpar(d->ctx, i, 2, m + 4, 6);
+  {
+    double rates[16];
+    const int nc = d->sm_ncat[i];
+    if (nc < 2) return 1;
+    if (!bpa_compute_gamma_cats(m[10], m[10], (unsigned)nc, rates)) return 0;       /* prop_gamma.c:93-97 */
+    return d->setpar(d->ctx, i, 4, rates, (unsigned)nc);
+  }
+}
+
+/* one component (which = 1 frequency j, 2 exchangeability j, 4 alpha) of every locus: propose, full recomputation, decide */
+static int param_step(a00_driver_t * d, int which, int j)
+{
+  unsigned i, n = 0, s;
+  const int ref = which == 1 ? 3 : 1;                      /* T / the A<->G rate (locus.c:2791, 3222) */
+  step_begin(d);
+  for (i = 0; i < d->nloci; ++i)
+  {
+    a00_tree_t * t = d->trees + i; double * m = d->sm + (size_t)i*11;
+    int br[MAXN], nd[MAXN], nb = 0, nn = 0, k;
+    double hast;
+    if (which == 4 && d->sm_ncat[i] < 2) continue;
+    if (which == 4)
+    {
+      const double a_old = m[10], la_old = log(a_old);
+      const double la_new = a00_reflect(la_old + d->ft_alpha*draw_window(d, (long)i), -99.0, 99.0);
+      const double a_new = exp(la_new);
+      d->sm_old[2*n] = a_old;
+      m[10] = a_new;
+      hast = (la_new - la_old) + ((d->alpha_a - 1)*log(a_new/a_old) - d->alpha_b*(a_new - a_old));      /* prop_gamma.c:72, 133 */
+    }
+    else
+    {
+      double * v = which == 1 ? m : m + 4;
+      const double sum = v[j] + v[ref], lo = log(1e-5), hi = log(sum);
+      const double l_old = log(v[j]);
+      const double l_new = a00_reflect(l_old + (which == 1 ? d->ft_freqs : d->ft_qrates)*draw_window(d, (long)i), lo, hi);
+      d->sm_old[2*n] = v[j]; d->sm_old[2*n+1] = v[ref];
+      v[j] = exp(l_new); v[ref] = sum - v[j];
+      hast = l_new - l_old;                                                                              /* locus.c:2867, 3296 */
+    }
+    if (!push_param(d, i, which)) return 0;
+    snapshot(d, i);
+    for (k = 0; k < t->n; ++k)
+    {
+      if (t->left[k] >= 0) nd[nn++] = k;
+      if (t->parent[k] >= 0) br[nb++] = k;
+    }
+    d->s_hast[n] = hast;
+    d->s_logpr[n] = t->logpr;
+    step_add(d, n, i, br, nb, nd, nn);
+    ++n;
+  }
+  if (!step_eval(d, n)) return 0;
+  for (s = 0; s < n; ++s)
+  {
+    const unsigned li = d->s_locus[s]; a00_tree_t * t = d->trees + li; double * m = d->sm + (size_t)li*11;
+    const double lnacc = (d->s_lnl[s] - t->lnl) + d->s_hast[s];
+    d->proposals++;
+    if (accept(d, (long)li, lnacc, -1.0)) { t->lnl = d->s_lnl[s]; d->accepted++; continue; }
+    restore(d, li);
+    if (which == 4) m[10] = d->sm_old[2*s];
+    else { double * v = which == 1 ? m : m + 4; v[j] = d->sm_old[2*s]; v[ref] = d->sm_old[2*s+1]; }
+    if (!push_param(d, li, which)) return 0;
+  }
+  return 1;
+}
+
 int a00_iterate(a00_driver_t * d)
 {
   unsigned i; int k, maxtips = 0;
@@ -668,7 +775,15 @@ int a00_iterate(a00_driver_t * d)
   for (k = 0; k < 2*maxtips - 2; ++k) if (!gspr_step(d, k)) return 0;
   if (d->theta_alpha > 0 && !theta_step_all(d)) return 0;
   for (k = d->S; k < d->npop; ++k)    if (!tau_step(d, k)) return 0;
-  return mix_step(d);
+  if (!mix_step(d)) return 0;
+  /* the substitution-parameter moves come last (method.c:5699-5735) */
+  if (d->sm && d->setpar)
+  {
+    if (d->ft_freqs > 0)  for (k = 0; k < 3; ++k) if (!param_step(d, 1, k)) return 0;
+    if (d->ft_qrates > 0) for (k = 0; k < 6; ++k) if (k != 1 && !param_step(d, 2, k)) return 0;
+    if (d->ft_alpha > 0 && !param_step(d, 4, 0)) return 0;
+  }
+  return 1;
 }
 
 int a00_backend_prior(void * ctx, const a00_step_t * step, double * lnl)
@@ -714,6 +829,11 @@ int a00_backend_hip(void * vctx, const a00_step_t * s, double * lnl)
   unsigned * rc = (unsigned *)malloc(n*sizeof(unsigned));
   int * rs = (int *)malloc(n*sizeof(int));
   bpa_batch_t b;
+  if (!loci || !mp || !ml || !ops || !rc || !rs)
+  {
+    free(loci); free(mp); free(ml); free(ops); free(rc); free(rs);
+    return 0;
+  }
   for (i = 0; i < n; ++i)
   {
     const a00_tree_t * t = s->tree[i];
@@ -750,4 +870,16 @@ int a00_backend_hip(void * vctx, const a00_step_t * s, double * lnl)
   }
   free(loci); free(mp); free(ml); free(ops); free(rc); free(rs);
   return ok;
+}
+
+/* the driver's substitution-parameter moves on libbpp_amd.so: the library's setters (the eigensystem of a locus whose
+   frequencies / exchangeabilities changed is refreshed on the device before the next evaluation) */
+int a00_backend_hip_params(void * vctx, unsigned locus, int which, const double * values, unsigned n)
+{
+  a00_hip_ctx_t * c = (a00_hip_ctx_t *)vctx;
+  (void)n;
+  if (which == 1) bpa_set_frequencies(c->loci[locus], 0, values);
+  else if (which == 2) bpa_set_subst_params(c->loci[locus], 0, values);
+  else bpa_set_category_rates(c->loci[locus], values);
+  return 1;
 }

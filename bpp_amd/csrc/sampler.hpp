@@ -1137,6 +1137,13 @@ struct bpa_sampler
   DevBuf<uint32_t> g_bmo;
   unsigned g_units = 0, g_maxmat = 0, g_pend = 0, g_npat = 0, g_rmax = 1, g_pack_epoch = 0;
   bool g_alljc = true;
+  // substitution-parameter moves (bpa_sampler_set_subst_moves): freqs | exchangeabilities | alpha per locus
+  std::vector<double> g_sm_host;
+  DevBuf<double> g_sm, g_sm_old;
+  DevBuf<uint32_t> g_ids;
+  double g_ft[3] = {0, 0, 0}, g_alpha_a = 1, g_alpha_b = 1;
+  unsigned g_pend_mode = 0, g_pend_k = 0;
+  bool g_eigen_dirty = false;
   unsigned nblocks = 0, epoch = 0;
   bool logpr_stale = false;     // thetas moved since the trees' densities were stored (Args::refresh_logpr)
   // diagnostic switches, read once at creation: BPA_SMP_DBG (bit mask, see Args::dbg), BPA_SMP_STEPS=g,q (proposal counts),
@@ -1207,6 +1214,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free(); s->uc.free();
   s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
   s->g_len.free(); s->g_lograt.free(); s->g_active.free(); s->g_recs.free(); s->g_mat2.free(); s->g_bmo.free();
+  s->g_sm.free(); s->g_sm_old.free(); s->g_ids.free();
   delete s;
 }
 

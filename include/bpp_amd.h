@@ -261,9 +261,12 @@ int          bpa_batch_evaluate(bpa_engine_t *, const bpa_batch_t *, double * ln
    prop_mixing.c:52), the MSC density (gtree_logprob, gtree.c:3957), the gene trees with their
    populations and buffer-index bookkeeping, the random streams and the accept/reject decisions:
    same arithmetic, same streams, same trajectory as the host driver, without a host round trip per
-   proposal.  Round-1 scope: JC69, one rate category, no scalers, <= 8 tips, <= 8 species, <= 64
-   patterns per locus.  Trees use the node numbering of a00_tree_t (tips first; arrays of 2*tips-1
-   entries); the species tree that of a00_set_species_tree.                                       */
+   proposal.  Two implementations behind the one interface: where every locus is JC69 with one rate category, <= 8
+   tips and <= 64 patterns, a sweep kernel that keeps trees and CLVs in LDS and runs all per-locus proposals of an
+   iteration in one launch (csrc/sampler.hpp); otherwise — several rate categories, GTR, up to 16 tips, < 256
+   patterns x categories — a generic path that proposes on the device and evaluates with the engine's batched step
+   kernels (csrc/gsampler.hpp).  No scalers, <= 8 species.  Trees use the node numbering of a00_tree_t (tips first;
+   arrays of 2*tips-1 entries); the species tree that of a00_set_species_tree.                                   */
 typedef struct bpa_sampler bpa_sampler_t;
 bpa_sampler_t * bpa_sampler_create(bpa_engine_t *, bpa_locus_t * const * loci, unsigned nloci,
                                    unsigned long seed);
@@ -301,6 +304,16 @@ int  bpa_sampler_get_tree(bpa_sampler_t *, unsigned i, int * left, int * right, 
 int  bpa_sampler_get_tree_msc(bpa_sampler_t *, unsigned i, int * pop, double * logpr);
 int  bpa_sampler_summary(bpa_sampler_t *, double * total_lnl, unsigned long * proposals,
                          unsigned long * accepted, unsigned long * launches);
+/* The per-locus substitution-parameter moves of a GTR + Gamma analysis (propose_freqs locus.c:2782, propose_qrates
+   locus.c:3168, propose_alpha prop_gamma.c:52; after the mixing step as in cmd_run, method.c:5699-5735): each base
+   frequency but T and each exchangeability but A<->G in turn — a sliding window on its logarithm, the reference
+   component taking up the difference — and the gamma shape alpha with a gamma(alpha_a, alpha_b) prior; every proposal
+   a full recomputation of the locus with a per-locus decision, all on the device (the category rates of a proposed
+   alpha by pll_compute_gamma_cats there).  Loci with several rate categories and an eigendecomposition only (the
+   generic path); set every locus's starting values first.  Window width 0 = that move is off (default: all off).   */
+int  bpa_sampler_set_subst_model(bpa_sampler_t *, unsigned i, const double * freqs /* 4 */, const double * qrates /* 6 */, double alpha);
+int  bpa_sampler_get_subst_model(bpa_sampler_t *, unsigned i, double * freqs, double * qrates, double * alpha);
+void bpa_sampler_set_subst_moves(bpa_sampler_t *, double ft_freqs, double ft_qrates, double ft_alpha, double alpha_a, double alpha_b);
 /* measurement: HIP start/stop events on every stride-th launch of the sampler's likelihood-carrying kernels
    (stride 0 = off); bpa_sampler_timing returns the milliseconds and launch counts accumulated since, by kind: the
    sweep (the per-locus GAGE + GSPR proposals of an iteration, one launch) and the all-loci steps (TAU, MIX)       */

@@ -200,6 +200,24 @@ static inline double a00_msc_contrib(double tau, double ptau, double theta, doub
 {
   return a00_msc_term(ncoal, a00_msc_t2h(tau, ptau, nin, times, ncoal), theta, heredity);
 }
+/* ---- the per-locus substitution-parameter moves of a GTR(+Gamma) analysis (locus.c:2782-3419, prop_gamma.c:52-224;
+   cmd_run runs them after the mixing step, method.c:5699-5735).  Every move is a full recomputation of the locus
+   (every P-matrix, every partial) with the proposed value and a per-locus decision:
+     FREQS   each base frequency j != T in turn: sliding window on log pi_j, reflected into (log 1e-5, log(pi_j + pi_T)),
+             pi_T takes up the difference; lnacc = delta log pi_j + delta lnL                       (propose_freqs, locus.c:2782)
+     QRATES  each exchangeability j != reference (AG for GTR) in turn, the same way               (propose_qrates, locus.c:3168)
+     ALPHA   the shape of the discrete-gamma site rates: sliding window on log alpha, category rates by
+             pll_compute_gamma_cats, gamma(a, b) prior: lnacc = delta log alpha + prior ratio + delta lnL   (prop_gamma.c:52)
+   The parameters live in the driver (a00_set_subst_model); the likelihood back-end learns new values through the
+   a00_param_fn it registers (which = 1 frequencies [4], 2 exchangeabilities [6], 4 category rates [ncat]).          */
+typedef int (*a00_param_fn)(void * ctx, unsigned locus, int which, const double * values, unsigned n);
+void           a00_set_param_backend(a00_driver_t *, a00_param_fn);
+int            a00_set_subst_model(a00_driver_t *, unsigned i, const double * freqs, const double * qrates, double alpha, int ncat);
+int            a00_get_subst_model(const a00_driver_t *, unsigned i, double * freqs, double * qrates, double * alpha);
+/* window widths (0 = that move is off; all off by default) and the gamma(a, b) prior on alpha ('alphaprior = a b ncat') */
+void           a00_set_subst_moves(a00_driver_t *, double ft_freqs, double ft_qrates, double ft_alpha, double alpha_a, double alpha_b);
+int            a00_backend_hip_params(void * ctx /* a00_hip_ctx_t* */, unsigned locus, int which, const double * values, unsigned n);
+
 /* start-up evaluation: all matrices, all partials, lnL (method.c:4285-4297) */
 int            a00_initialize(a00_driver_t *);
 /* one iteration: GAGE over inner nodes, GSPR over non-root nodes, THETA per population (if a prior is set),

@@ -428,3 +428,15 @@ int ref_backend_eval(void * vctx, const a00_step_t * s, double * lnl)
   }
   return 1;
 }
+
+/* the driver's substitution-parameter moves on the reference back-end: the reference's own setters (locus.c:877, 889:
+   they invalidate the eigendecomposition; pll_set_category_rates, locus.c:265) */
+int ref_backend_params(void * vctx, unsigned locus, int which, const double * values, unsigned n)
+{
+  refctx_t * c = ((refctx_t **)vctx)[locus];
+  (void)n;
+  if (which == 1) pll_set_frequencies(c->locus, 0, values);
+  else if (which == 2) pll_set_subst_params(c->locus, 0, values);
+  else pll_set_category_rates(c->locus, values);
+  return 1;
+}

@@ -85,6 +85,28 @@ class Driver:
     def set_finetune(self, gage, gspr, tau, mix):
         lib().a00_set_finetune(self.h, gage, gspr, tau, mix)
 
+    def set_subst_model(self, i, freqs, qrates, alpha, ncat):
+        L = lib()
+        L.a00_set_subst_model.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int]
+        assert L.a00_set_subst_model(self.h, i, (C.c_double * 4)(*freqs), (C.c_double * 6)(*qrates), float(alpha), int(ncat))
+
+    def get_subst_model(self, i):
+        L = lib()
+        L.a00_get_subst_model.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        f, q, a = (C.c_double * 4)(), (C.c_double * 6)(), C.c_double()
+        assert L.a00_get_subst_model(self.h, i, f, q, C.byref(a))
+        return list(f), list(q), a.value
+
+    def set_subst_moves(self, ft_freqs, ft_qrates, ft_alpha, alpha_a=1.0, alpha_b=1.0):
+        L = lib()
+        L.a00_set_subst_moves.argtypes = [C.c_void_p] + [C.c_double] * 5
+        L.a00_set_subst_moves(self.h, ft_freqs, ft_qrates, ft_alpha, alpha_a, alpha_b)
+
+    def set_param_backend(self, fn_addr):
+        L = lib()
+        L.a00_set_param_backend.argtypes = [C.c_void_p, C.c_void_p]
+        L.a00_set_param_backend(self.h, fn_addr)
+
     def set_proposal_kernel(self, kind):
         """0 uniform windows on the a00 streams (default), 1 BPP's legacy_rndu + Bactrian-Laplace (A00_KERNEL_BPP)"""
         lib().a00_set_proposal_kernel.argtypes = [C.c_void_p, C.c_int]
@@ -146,6 +168,7 @@ def reference_driver(data, seed=1, scaling=False):
     fn = C.cast(O.ref().ref_backend_eval, C.c_void_p)
     drv = Driver(data, fn, C.cast(arr, C.c_void_p), seed, scaling)
     drv._keep = (rls, arr)
+    drv.set_param_backend(C.cast(O.ref().ref_backend_params, C.c_void_p))
     return drv
 
 
@@ -156,6 +179,7 @@ def hip_driver(engine, loci, data, seed=1, scaling=False):
     fn = C.cast(lib().a00_backend_hip, C.c_void_p)
     drv = Driver(data, fn, C.cast(C.pointer(ctx), C.c_void_p), seed, scaling)
     drv._keep = (arr, ctx)
+    drv.set_param_backend(C.cast(lib().a00_backend_hip_params, C.c_void_p))
     return drv
 
 

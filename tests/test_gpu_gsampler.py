@@ -112,3 +112,44 @@ def test_generic_sampler_on_the_anopheles_data():
     s = dev.summary()
     assert 0.1 < s["accepted"] / s["proposals"] < 0.95
     dev.close(); host.close(); eng.close()
+
+
+def test_generic_sampler_with_parameter_moves_equals_host_driver():
+    """the per-locus frequency / exchangeability / alpha moves (locus.c:2782-3419, prop_gamma.c:52-224) on the device —
+    new values into the loci's parameter blocks, eigensystems and category rates refreshed there — against the host
+    driver's param_step over libbpp_amd.so's setters: same decisions, same parameters (the category rates of a proposed
+    alpha come from device libm here and from glibc there: equal to ~1e-14, not to the bit)"""
+    taxa, R, nloci, iters = 8, 4, 40, 3
+    eng = bpp_amd.Engine(0)
+    data = synth.make_dataset(nloci, 300, taxa, "gtr", R, seed=23)
+    loci_a = tape.make_engine_loci(eng, data)
+    loci_b = tape.make_engine_loci(eng, data)
+    host = hostdrv.hip_driver(eng, loci_a, data, seed=31)
+    dev = bpp_amd.Sampler(eng, loci_b, data, seed=31)
+    parent, tau0, thetas = synth.species_tree_arrays(taxa)
+    for drv in (host, dev):
+        drv.set_species_tree(parent, tau0, thetas)
+        drv.set_tau_prior(3.0, 3.0 / tau0[-1])
+        drv.set_theta_prior(2.0, 1000.0, 0.001)
+        drv.set_finetune(0.003, 0.005, 0.0008, 0.2)
+        drv.set_subst_moves(0.3, 0.4, 0.8, 1.0, 1.0)
+    for i, d in enumerate(data):
+        host.set_subst_model(i, list(d["freqs"]), list(d["exch"]), 0.5, R)
+        dev.set_subst_model(i, d["freqs"], d["exch"], 0.5)
+    walk(host, dev, iters, nloci)
+    moved = 0
+    for i in range(nloci):
+        fh, qh, ah = host.get_subst_model(i)
+        fd, qd, ad = dev.get_subst_model(i)
+        assert np.allclose(fd, fh, rtol=1e-11, atol=0) and np.allclose(qd, qh, rtol=1e-11, atol=0) and rel(ad, ah) < 1e-11, i
+        moved += (ah != 0.5) + (not np.allclose(fh, data[i]["freqs"])) + (not np.allclose(qh, data[i]["exch"]))
+    assert moved > nloci
+    # the loci's device state is what the explicit-index API would hold for those parameters
+    for i in range(0, nloci, 7):
+        t = dev.tree(i)
+        f, q, a = dev.get_subst_model(i)
+        rates = bpp_amd.compute_gamma_cats(a, a, R)
+        ol = O.OracleLocus(4, R, data[i]["seqs"], data[i]["weights"], model="gtr", freqs=f, qrates=q, rates=rates)
+        full = ol.full_lnl(list(t["left"]), list(t["right"]), list(t["time"]), t["root"])
+        assert rel(t["lnl"], full) < 1e-10
+    dev.close(); host.close(); eng.close()
