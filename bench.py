@@ -515,6 +515,12 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
     smp.set_species_tree(sp_parent, sp_tau, sp_theta)
     smp.set_tau_prior(3.0, 3.0 / sp_tau[-1])
     smp.set_theta_prior(2.0, 2.0 / sp_theta[0], 0.5 * sp_theta[0])
+    generic = cfg["model"] != "jc69"
+    if generic:
+        # the per-locus substitution-parameter moves of a GTR + Gamma analysis (3 frequencies, 5 exchangeabilities, alpha)
+        for i, d in enumerate(data):
+            smp.set_subst_model(i, d["freqs"], d["exch"], 0.5)
+        smp.set_subst_moves(0.2, 0.3, 0.5, 1.0, 1.0)
     smp.initialize()
     sync = D.sync if D else eng.synchronize
     while True:
@@ -545,7 +551,23 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
     sm = smp.summary()
     npop_inner = cfg["taxa"] - 1
     roofline = None
-    if tm["sweep_launches"]:
+    if generic and (tm["sweep_launches"] + tm["allloci_launches"]):
+        # the engine's step kernel, launched once per proposal step by the sampler: all timed launches together
+        nl = max(w1["sweeps"] - w0["sweeps"], 1)
+        bytes_per_launch = (w1["bytes"] - w0["bytes"]) / nl
+        us = 1e3 * (tm["sweep_ms"] + tm["allloci_ms"]) / (tm["sweep_launches"] + tm["allloci_launches"])
+        achieved = bytes_per_launch / (us * 1e-6) / 1e9
+        kern = dominant_kernel(cfg)
+        traffic, src = traffic_from_profiles("c3", kern) if args.loci is None else (None, None)
+        roofline = dict(bound="hbm", kernel=kern, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=src, avg_kernel_us=round(us, 3),
+                        algorithmic_bytes_per_launch=round(bytes_per_launch), launches=tm["sweep_launches"] + tm["allloci_launches"],
+                        node_updates_per_launch=round((w1["node_updates"] - w0["node_updates"]) / nl),
+                        timing=f"hipExtLaunchKernelGGL start/stop events on the engine stream, every {args.event_stride}-th launch of the step kernel in the timed region",
+                        note="the generic device-resident sampler (csrc/gsampler.hpp): every proposal step = one launch of a per-locus "
+                             "proposal kernel (trees in HBM) + the engine's step kernel over the records it wrote; algorithmic bytes = K1 + K2 "
+                             "of the node updates the proposals actually asked for (device counters)")
+    elif tm["sweep_launches"]:
         sweeps = max(w1["sweeps"] - w0["sweeps"], 1)
         bytes_per_sweep = (w1["bytes"] - w0["bytes"]) / sweeps
         us = 1e3 * tm["sweep_ms"] / tm["sweep_launches"]
@@ -563,12 +585,15 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
                              "set lives in LDS for the whole launch: latency-bound by the leader lanes' serial proposal code, not by HBM")
     out = dict(iterations_per_s=round(steps / dt, 3), iterations_per_s_10k_loci=round(steps / dt * total_loci / 10000.0, 3),
                ms_per_iteration=round(1e3 * dt / steps, 5), steps=steps, warmup=warmup, n_gpus=world, loci_total=total_loci,
-               proposals_per_locus_iteration=3 * cfg["taxa"] - 3,
+               proposals_per_locus_iteration=3 * cfg["taxa"] - 3 + (9 if generic else 0),
                launches_per_iteration=round((l1 - l0 - 1) / steps, 2),      # (-1: the settle launch of the first summary)
                acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
                taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
                thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],
                roofline=roofline,
+               implementation=("generic path (csrc/gsampler.hpp): proposals on the device as records for the engine's step kernels; "
+                               "tree moves + 3 frequency, 5 exchangeability and 1 alpha move per locus" if generic else
+                               "LDS sweep kernel (csrc/sampler.hpp): all per-locus proposals of an iteration in one launch"),
                note="the A00 sampler (species tree fixed) resident on the device: population-aware GAGE+GSPR per locus, a THETA "
                     "step per population, a rubber-band TAU step per divergence and one MIX step per iteration, "
                     "Metropolis-Hastings on priors x MSC density x likelihood (density bit-equal to gtree_logprob); reproduces "
@@ -650,9 +675,9 @@ def main():
 
     tape_sec = sampler_sec = None
     tape_steps = None
-    if not (args.config == "c2" and args.no_tape):
+    if not (args.config in ("c2", "c3") and args.no_tape):
         tape_sec, tape_steps = run_tape(eng, cfg, args.config, data, loci, args, D, args.steps, args.warmup)
-    if args.config == "c2" and not args.no_sampler:
+    if args.config in ("c2", "c3") and not args.no_sampler:
         sampler_sec = run_sampler(eng, cfg, data, loci, args, D, first_locus, args.steps, args.warmup)
         if "error" in sampler_sec:
             log(sampler_sec["error"])
@@ -706,6 +731,8 @@ def main():
                 a2.loci = None
                 sec, _ = run_tape(e2, oc, key, d2, l2, a2, None, k_steps, k_warm)
                 sec["unit"] = f"iterations/s (one iteration = the A00 proposal schedule over this config's {oc['loci']} loci)"
+                if key == "c3":
+                    sec["device_resident_sampler"] = run_sampler(e2, oc, d2, l2, a2, None, 0, k_steps, k_warm)
                 sec["seconds"] = round(time.time() - t0, 1)
                 others[key] = sec
                 e2.close()
@@ -729,7 +756,7 @@ def main():
             ms_per_step = tape_sec["ms_per_step"]
             roofline = tape_sec["roofline"]
             metric = "A00 iterations/sec of the likelihood hot path (proposal tape)"
-        loci_unit = 10000 if args.config == "c2" else nloci_cfg
+        loci_unit = 10000 if args.config in ("c2", "c3") else nloci_cfg
         out = {
             "metric": metric + " + site-lnL updates/sec, 10k loci, 1/2/4/8 GPU",
             "value": value,

@@ -34,7 +34,8 @@ struct GTree                              // one per locus, in HBM
   a00_rng_t rng;
   int32_t  root, tips;
   uint32_t proposals, accepted;
-  uint32_t work_nupd, work_nbr;           // node updates / fresh branches of the per-locus steps (bpa_sampler_work)
+  uint32_t work_nupd, work_nbr;           // node updates / fresh P-matrices / evaluations of all steps so far (bpa_sampler_work)
+  uint32_t work_neval, pad_[3];
 };
 static_assert(sizeof(GTree) % 16 == 0, "GTree is copied as uint4");
 
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
   for (int k = 0; k < 4; ++k) cn.nin.w[k] = cn.nc.w[k] = cn.nin_new.w[k] = cn.nc_new.w[k] = cn.gl.w[k] = 0u;
   T.time = S.time; T.rng = 0; T.root = 0; T.tips = 2;
   double lnl_cur = 0, logpr_cur = 0;
-  uint32_t nprop = 0, nacc = 0, w_nupd = 0, w_nbr = 0;
+  uint32_t nprop = 0, nacc = 0, w_nupd = 0, w_nbr = 0, w_nev = 0;
   GLocus L{};
   if (valid)
   {
@@ -190,7 +191,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     T.left.load(g.left); T.right.load(g.right); T.parent.load(g.parent); T.clv.load(g.clv); T.pmat.load(g.pmat); T.pop.load(g.pop);
     for (int k = 0; k < NN; ++k) S.time[k] = g.time[k];
     T.rng = g.rng; T.root = g.root; T.tips = g.tips;
-    lnl_cur = g.lnl; logpr_cur = g.logpr; nprop = g.proposals; nacc = g.accepted; w_nupd = g.work_nupd; w_nbr = g.work_nbr;
+    lnl_cur = g.lnl; logpr_cur = g.logpr; nprop = g.proposals; nacc = g.accepted; w_nupd = g.work_nupd; w_nbr = g.work_nbr; w_nev = g.work_neval;
     const uint4 g4 = *reinterpret_cast<const uint4 *>(L.gl), n4 = *reinterpret_cast<const uint4 *>(L.nin);
     cn.gl.w[0] = g4.x; cn.gl.w[1] = g4.y; cn.gl.w[2] = g4.z; cn.gl.w[3] = g4.w;
     cn.nin.w[0] = n4.x; cn.nin.w[1] = n4.y; cn.nin.w[2] = n4.z; cn.nin.w[3] = n4.w;
@@ -373,8 +374,8 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     {
       A.logpr_new[i] = gdensity(S, T, cn, sp, spl, s_tau, nullptr, nullptr, 0);
       A.hast[i] = hast;
-      w_nupd += (uint32_t)S.nops; w_nbr += (uint32_t)__popc(S.brm);
     }
+    if (ok && A.mode != 5) { w_nupd += (uint32_t)S.nops; w_nbr += (uint32_t)__popc(S.brm); ++w_nev; }
     evaluate = ok;
     A.active[i] = ok ? 1 : 0;
   }
@@ -446,7 +447,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     T.left.store(g.left); T.right.store(g.right); T.parent.store(g.parent); T.clv.store(g.clv); T.pmat.store(g.pmat); T.pop.store(g.pop);
     for (int k = 0; k < NN; ++k) g.time[k] = S.time[k];
     g.rng = T.rng; g.root = T.root; g.lnl = lnl_cur; g.logpr = logpr_cur; g.proposals = nprop; g.accepted = nacc;
-    g.work_nupd = w_nupd; g.work_nbr = w_nbr;
+    g.work_nupd = w_nupd; g.work_nbr = w_nbr; g.work_neval = w_nev;
   }
 }
 

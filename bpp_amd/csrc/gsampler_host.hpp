@@ -154,6 +154,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     s->launches += 2;
   }
   HIPCHK(hipGetLastError());
+  s->g_evals++;
   if (getenv("BPA_GS_SYNC")) { HIPCHK(hipStreamSynchronize(e->stream)); fprintf(stderr, "[gs] eval done\n"); }
   return 1;
 }

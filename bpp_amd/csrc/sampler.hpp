@@ -1144,6 +1144,7 @@ struct bpa_sampler
   double g_ft[3] = {0, 0, 0}, g_alpha_a = 1, g_alpha_b = 1;
   unsigned g_pend_mode = 0, g_pend_k = 0;
   bool g_eigen_dirty = false;
+  unsigned long g_evals = 0;            // launches of the likelihood step kernel (bpa_sampler_work reports them as `sweeps`)
   unsigned nblocks = 0, epoch = 0;
   bool logpr_stale = false;     // thetas moved since the trees' densities were stored (Args::refresh_logpr)
   // diagnostic switches, read once at creation: BPA_SMP_DBG (bit mask, see Args::dbg), BPA_SMP_STEPS=g,q (proposal counts),
@@ -1730,14 +1731,16 @@ extern "C" int bpa_sampler_work(bpa_sampler_t * s, double * bytes, unsigned long
     // K1 3 Np R S 8 + 2 R S^2 8 bytes per node update, K2 (Np R S 8 + 4 Np) per evaluated proposal, K4 R S^2 8 per fresh P-matrix
     const double np = s->loci[i]->sites, R = s->loci[i]->rate_cats;
     const double nupd = s->generic ? s->g_trees[i].work_nupd : s->h_trees[i].sw_nupd, nbr = s->generic ? s->g_trees[i].work_nbr : s->h_trees[i].sw_nbr;
-    const double nprop = s->generic ? s->g_trees[i].proposals : s->h_trees[i].proposals;
-    by += nupd*(96.0*np*R + 256.0*R) + nprop*(32.0*R + 4.0)*np + nbr*128.0*R;
+    const double nprop = s->generic ? s->g_trees[i].work_neval : s->h_trees[i].proposals;
+    // (the generic path counts every evaluated step; where the P-matrix phase is a launch of its own — several rate
+    //  categories — the K4 bytes are not the timed kernel's)
+    by += nupd*(96.0*np*R + 256.0*R) + nprop*(32.0*R + 4.0)*np + ((s->generic && !s->g_alljc) ? 0.0 : nbr*128.0*R);
     nu += (unsigned long)nupd; pu += (unsigned long)(nupd*np);
   }
   if (bytes) *bytes = by;
   if (node_updates) *node_updates = nu;
   if (pattern_updates) *pattern_updates = pu;
-  if (sweeps) *sweeps = s->sweeps;
+  if (sweeps) *sweeps = s->generic ? s->g_evals : s->sweeps;
   return 1;
 }
 

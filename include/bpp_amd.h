@@ -320,8 +320,10 @@ void bpa_sampler_set_subst_moves(bpa_sampler_t *, double ft_freqs, double ft_qra
 int  bpa_sampler_enable_timing(bpa_sampler_t *, unsigned stride);
 int  bpa_sampler_timing(bpa_sampler_t *, double * sweep_ms, unsigned long * sweep_launches,
                         double * allloci_ms, unsigned long * allloci_launches);
-/* algorithmic work of all sweep launches so far (K1 bytes per node update actually run, K2 per
-   evaluated proposal, K4 per fresh P-matrix), their node and pattern-node updates, and the number of sweeps        */
+/* algorithmic work of the sampler's likelihood launches so far (K1 bytes per node update actually
+   run, K2 per evaluated proposal, K4 per fresh P-matrix where the step kernel computes them itself), their node and
+   pattern-node updates, and the number of those launches: the sweeps of the LDS kernel (its per-locus proposals only),
+   or, on the generic path, every launch of the engine's step kernel                                                */
 int  bpa_sampler_work(bpa_sampler_t *, double * bytes, unsigned long * node_updates,
                       unsigned long * pattern_updates, unsigned long * sweeps);
 

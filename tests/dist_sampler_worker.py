@@ -18,7 +18,8 @@ def main():
     import tape
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    data = synth.make_dataset(160, 300, 4, "jc69", 1, seed=3)
+    gtr = bool(os.environ.get("DIST_GTR"))           # the generic sampler (8 taxa, GTR + Gamma4) with its parameter moves
+    data = synth.make_dataset(48, 300, 8, "gtr", 4, seed=3) if gtr else synth.make_dataset(160, 300, 4, "jc69", 1, seed=3)
     per = len(data) // world
     first = rank * per
     mine = data[first:first + per]
@@ -42,13 +43,17 @@ def main():
         for i in range(per):
             smp.set_tip_species(i, [0, 0, 1, 2] if first + i < len(data)//2 else [0, 1, 1, 2])
     else:
-        parent, tau, theta = synth.species_tree_arrays(4)
+        parent, tau, theta = synth.species_tree_arrays(8 if gtr else 4)
         smp.set_species_tree(parent, tau, theta)
+    if gtr:
+        for i, d in enumerate(mine):
+            smp.set_subst_model(i, d["freqs"], d["exch"], 0.5)
+        smp.set_subst_moves(0.3, 0.4, 0.8, 1.0, 1.0)
     smp.set_tau_prior(3.0, 1000.0)
     smp.set_theta_prior(2.0, 1000.0, 0.001)
     smp.set_finetune(0.003, 0.005, 0.0008, 0.2)
     smp.initialize()
-    smp.iterate(12)
+    smp.iterate(4 if gtr else 12)
     res = dict(rank=rank, first=first, taus=smp.taus(), thetas=smp.thetas(), summary=smp.summary(),
                times=[[float(x) for x in smp.tree(i)["time"]] for i in range(per)],
                lnl=[smp.tree(i)["lnl"] for i in range(per)])

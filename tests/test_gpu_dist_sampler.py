@@ -56,3 +56,20 @@ def test_ranks_with_different_sampling_configurations(tmp_path):
     assert one["thetas"][0] != 0.002 and one["thetas"][1] != 0.002 and one["thetas"][2] == 0.002
     lnl = two[0]["lnl"] + two[1]["lnl"]
     assert np.allclose(lnl, one["lnl"], rtol=1e-10, atol=0)
+
+
+def test_two_ranks_generic_sampler_with_parameter_moves(tmp_path):
+    """the generic sampler (8 taxa, GTR + Gamma4, frequency / exchangeability / alpha moves: csrc/gsampler.hpp) sharded over
+    two ranks walks the single-rank trajectory: the per-locus moves need no exchange, the all-loci steps one sum each"""
+    one = run(1, str(tmp_path / "one"), 29811, DIST_GTR="1")[0]
+    two = run(2, str(tmp_path / "two"), 29812 + os.getpid() % 500, DIST_GTR="1")
+    assert two[0]["taus"] == two[1]["taus"] and two[0]["thetas"] == two[1]["thetas"]
+    for r in two:
+        assert np.allclose(r["taus"], one["taus"], rtol=1e-10, atol=0) and r["taus"][8:] != [0.001, 0.0012, 0.0025, 0.0011, 0.0013, 0.003, 0.005]
+        assert np.allclose(r["thetas"], one["thetas"], rtol=1e-10, atol=0)
+    times = two[0]["times"] + two[1]["times"]
+    lnl = two[0]["lnl"] + two[1]["lnl"]
+    assert len(times) == len(one["times"])
+    for a, b in zip(times, one["times"]):
+        assert np.allclose(a, b, rtol=1e-10, atol=0)
+    assert np.allclose(lnl, one["lnl"], rtol=1e-10, atol=0)

@@ -72,7 +72,7 @@ def test_generic_sampler_equals_host_driver(taxa, model, R, nloci, iters, forced
         full = ol.full_lnl(list(t["left"]), list(t["right"]), list(t["time"]), t["root"])
         assert rel(have, full) < 1e-12 and rel(t["lnl"], full) < 1e-12
     w = dev.work()
-    assert w["sweeps"] == iters and w["node_updates"] > 0 and w["bytes"] > 0
+    assert w["sweeps"] >= iters*(3*taxa - 3) and w["node_updates"] > 0 and w["bytes"] > 0      # (generic path: launches of the step kernel)
     dev.close(); host.close(); eng.close()
 
 
