@@ -7,8 +7,10 @@
 //       "pattern-major": for one (buffer, rate) the Np patterns are contiguous,
 //       32 B per pattern, so lane n of a wave reads one aligned 32-B chunk and a
 //       wave reads 2 KiB contiguous.
-//   inner CLV buffer c, 20-state                    : clv[((c*R + k)*S + s)*Np + n]
-//       state-major planes so that lanes (patterns) are contiguous for each state.
+//   inner CLV buffer c, 20-state                    : clv[((c*R + k)*S + s)*Ld + n],  Ld = Np rounded up to 16
+//       state-major planes so that lanes (patterns) are contiguous for each state; the plane stride is a whole
+//       number of 128-byte lines, so every wave's 8-byte loads of a plane start on a line (with Ld = Np = 105 a
+//       no-arithmetic kernel of this access shape streams 4.0 TB/s, with Ld = 112: 5.2 TB/s — tools/probe_bw.hip).
 //   tip "CLVs" are never materialised: tip t keeps its state code per pattern
 //       (uint8 for 4 states, uint32 for 20) and is expanded to 0.0/1.0 in registers
 //       — arithmetic identical to the reference's one-hot tip CLVs (locus.c:525-559).
@@ -43,7 +45,8 @@ struct LocusDev
   uint32_t   rate_matrices;
   uint32_t   unphased_length; // 0 when not diploid
   uint32_t   pstride;         // doubles per (P-matrix, rate): 16, or 2 for JC69 loci, whose matrices are
-  uint32_t   pad_;            // kept as their (diagonal a, off-diagonal b) pair (locus.c:2384-2411)
+  uint32_t   ld;              // kept as their (diagonal a, off-diagonal b) pair (locus.c:2384-2411).  ld: CLV plane stride
+                              // (patterns) of a 20-state locus; = np for 4-state loci (pattern-major, no planes)
 };
 
 // offsets inside the parameter block

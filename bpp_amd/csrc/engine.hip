@@ -325,7 +325,11 @@ extern "C" bpa_locus_t * bpa_locus_create(bpa_engine_t * e, unsigned dtype, unsi
   const size_t w_bytes = up16(Np*sizeof(uint32_t)), tip_bytes = up16((size_t)tips*Np*l->code_bytes());
   const size_t pm_bytes = (size_t)prob_matrices*R*d.pstride*sizeof(double);
   char * hot = (char *)e->arena.alloc(par_bytes + w_bytes + tip_bytes + (jc69 ? pm_bytes : 0), 128);
-  d.clv    = (double *)e->arena.alloc(std::max<size_t>(clv_buffers, 1)*R*Np*S*sizeof(double), 128);
+  // 20-state CLVs are state-major planes: pad the plane stride to whole 128-byte lines (BPA_NO_PLANE_PAD=1: the first layout)
+  static const bool no_pad = getenv("BPA_NO_PLANE_PAD") && atoi(getenv("BPA_NO_PLANE_PAD"));
+  const size_t Ld = (S == 20 && !no_pad) ? up16(Np) : Np;
+  d.ld = (uint32_t)Ld;
+  d.clv    = (double *)e->arena.alloc(std::max<size_t>(clv_buffers, 1)*R*Ld*S*sizeof(double), 128);
   d.scaler = scale_buffers ? (uint32_t *)e->arena.alloc((size_t)scale_buffers*Np*sizeof(uint32_t), 128) : nullptr;
   if (!hot || !d.clv || (scale_buffers && !d.scaler))
   { fail("bpa_locus_create: out of device memory"); delete l; return nullptr; }
@@ -742,11 +746,11 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   //   category) | scalarp / scalark (P through the scalar path) | generic (no staging)
   {
     const char * v = getenv("BPA_S20_KERNEL");
-    p->s20_kernel = v ? v : "tiledk";
+    p->s20_kernel = v ? v : "pipe";
   }
   p->s20_mfma = p->s20_kernel == "mfma";
   p->s20_scalarp = p->s20_kernel == "scalarp";
-  p->s20_tiledk = p->s20_kernel == "tiledk" || p->s20_kernel == "mfmak" || p->s20_kernel == "scalark" || p->s20_kernel == "tiledk1" || p->s20_kernel == "tiledkb" || p->s20_kernel == "tiledk2";
+  p->s20_tiledk = p->s20_kernel == "pipe" || p->s20_kernel == "tiledk" || p->s20_kernel == "mfmak" || p->s20_kernel == "scalark" || p->s20_kernel == "tiledk1" || p->s20_kernel == "tiledkb" || p->s20_kernel == "tiledk2" || p->s20_kernel == "tiledknt";
   if (p->s20_tiledk && p->rmax > 4) { p->s20_tiledk = false; p->s20_kernel = "tiled"; }     // 64 x R lanes must fit a 256-lane workgroup
   p->tile = p->s20_mfma ? 32 : (p->s20_scalarp || p->s20_tiledk) ? 64 : 128;
   if (p->s20_kernel == "tiledk2") p->tile = 128;                   // two 64-pattern sub-tiles per workgroup
@@ -1117,7 +1121,9 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       d.flags = 4u; d.pad = p->rmax;
       const size_t lds = ((size_t)2*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double);
       const dim3 grid(p->ntiles), block(64*p->rmax);
-      if (p->s20_kernel == "mfmak")        hipLaunchKernelGGL(partials_lnl_mfma20k_kernel, grid, block, lds, e->stream, d);
+      if (p->s20_kernel == "pipe")
+        hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
+      else if (p->s20_kernel == "mfmak")   hipLaunchKernelGGL(partials_lnl_mfma20k_kernel, grid, block, lds, e->stream, d);
       else if (p->s20_kernel == "scalark" && p->rmax <= 4)
                                            hipLaunchKernelGGL((partials_lnl_scalark_kernel<20>), grid, block, 0, e->stream, d);
       else if (p->s20_kernel == "tiledk2")
@@ -1125,6 +1131,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
                            ((size_t)2*p->rmax*400 + (size_t)2*p->rmax*64)*sizeof(double), e->stream, d);
       else if (p->s20_kernel == "tiledk1") hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 1>), grid, block, lds, e->stream, d);
       else if (p->s20_kernel == "tiledkb") hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 4>), grid, block, lds, e->stream, d);
+      else if (p->s20_kernel == "tiledknt") hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 5>), grid, block, lds, e->stream, d);
       else                                 hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 3>), grid, block, lds, e->stream, d);
     }
     else if (p->ntiles && p->s20_scalarp)
@@ -1849,12 +1856,13 @@ extern "C" int bpa_locus_get_clv(bpa_locus_t * l, unsigned idx, double * out)
     }
     return 1;
   }
-  std::vector<double> tmp(R*Np*S);
-  HIPCHK(hipMemcpy(tmp.data(), l->dev.clv + (size_t)(idx - l->tips)*R*Np*S, tmp.size()*8, hipMemcpyDeviceToHost));
+  const size_t Ld = l->dev.ld;
+  std::vector<double> tmp(R*Ld*S);
+  HIPCHK(hipMemcpy(tmp.data(), l->dev.clv + (size_t)(idx - l->tips)*R*Ld*S, tmp.size()*8, hipMemcpyDeviceToHost));
   for (size_t n = 0; n < Np; ++n)
     for (size_t k = 0; k < R; ++k)
       for (size_t s = 0; s < S; ++s)
-        out[(n*R + k)*S + s] = S == 4 ? tmp[(k*Np + n)*4 + s] : tmp[(k*S + s)*Np + n];
+        out[(n*R + k)*S + s] = S == 4 ? tmp[(k*Np + n)*4 + s] : tmp[(k*S + s)*Ld + n];
   return 1;
 }
 
@@ -1864,12 +1872,13 @@ extern "C" int bpa_locus_set_clv(bpa_locus_t * l, unsigned idx, const double * i
   if (!sync_for_access(l)) return 0;
   const size_t S = l->states, R = l->rate_cats, Np = l->sites;
   if (idx < l->tips || idx >= l->tips + l->clv_buffers) return fail("bpa_locus_set_clv: only inner buffers can be written (tips are state codes)");
-  std::vector<double> tmp(R*Np*S);
+  const size_t Ld = l->dev.ld;
+  std::vector<double> tmp(R*Ld*S, 0.0);
   for (size_t n = 0; n < Np; ++n)
     for (size_t k = 0; k < R; ++k)
       for (size_t s = 0; s < S; ++s)
-        (S == 4 ? tmp[(k*Np + n)*4 + s] : tmp[(k*S + s)*Np + n]) = in[(n*R + k)*S + s];
-  HIPCHK(hipMemcpy(l->dev.clv + (size_t)(idx - l->tips)*R*Np*S, tmp.data(), tmp.size()*8, hipMemcpyHostToDevice));
+        (S == 4 ? tmp[(k*Np + n)*4 + s] : tmp[(k*S + s)*Ld + n]) = in[(n*R + k)*S + s];
+  HIPCHK(hipMemcpy(l->dev.clv + (size_t)(idx - l->tips)*R*Ld*S, tmp.data(), tmp.size()*8, hipMemcpyHostToDevice));
   return 1;
 }
 

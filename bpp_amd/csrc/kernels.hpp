@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(BPA_BLOCK) partials_lnl_s4_kernel(const PlanDe
 
 // ============================================================ K1+K2, generic S ==
 // state-major planes: clv[((buffer*R + k)*S + s)*Np + n]; one lane = one pattern.
-template <int S, typename CODE>
+template <int S, typename CODE, bool NTL = false>
 __device__ __forceinline__ void load_childN(const LocusDev & L, uint32_t clv_index, uint32_t k,
                                             uint32_t n, double * v)
 {
@@ -212,9 +212,9 @@ __device__ __forceinline__ void load_childN(const LocusDev & L, uint32_t clv_ind
   }
   else
   {
-    const double * p = L.clv + (((size_t)(clv_index - L.tips_n)*L.rate_cats + k)*S)*L.np + n;
+    const double * p = L.clv + (((size_t)(clv_index - L.tips_n)*L.rate_cats + k)*S)*L.ld + n;
 #pragma unroll
-    for (int s = 0; s < S; ++s) v[s] = p[(size_t)s*L.np];
+    for (int s = 0; s < S; ++s) v[s] = NTL ? __builtin_nontemporal_load(p + (size_t)s*L.ld) : p[(size_t)s*L.ld];
   }
 }
 
@@ -226,13 +226,13 @@ __global__ void __launch_bounds__(BPA_BLOCK) partials_lnl_sN_kernel(const PlanDe
   const uint32_t t = P.thr_task[g];
   const uint32_t n = g - P.task_pat_off[t];
   const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np;
+  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld;
 
   const uint32_t op_end = P.op_off[t+1];
   for (uint32_t o = P.op_off[t]; o < op_end; ++o)
   {
     const OpDev op = P.ops[o];
-    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*np + n;
+    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*ld + n;
     bool all_small = true;
     for (uint32_t k = 0; k < R; ++k)
     {
@@ -241,14 +241,14 @@ __global__ void __launch_bounds__(BPA_BLOCK) partials_lnl_sN_kernel(const PlanDe
       load_childN<S, uint32_t>(L, op.right_clv, k, n, rv);
       const double * lm = L.pmat + ((size_t)op.left_pmatrix*R  + k)*S*S;
       const double * rm = L.pmat + ((size_t)op.right_pmatrix*R + k)*S*S;
-      double * dst = out + (size_t)k*S*np;
+      double * dst = out + (size_t)k*S*ld;
       for (int i = 0; i < S; ++i)
       {
         const double x = dot_fma4<S>(lm + i*S, lv);
         const double y = dot_fma4<S>(rm + i*S, rv);
         const double v = x*y;
         all_small = all_small && (v < BPA_SCALE_THRESHOLD);
-        dst[(size_t)i*np] = v;
+        dst[(size_t)i*ld] = v;
       }
     }
     if (op.parent_scaler >= 0)
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(BPA_BLOCK) partials_lnl_sN_kernel(const PlanDe
       if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + n];
       if (all_small)
       {
-        for (uint32_t e = 0; e < R*S; ++e) out[(size_t)e*np] *= BPA_SCALE_FACTOR;
+        for (uint32_t e = 0; e < R*S; ++e) out[(size_t)e*ld] *= BPA_SCALE_FACTOR;
         s += 1;
       }
       L.scaler[(size_t)op.parent_scaler*np + n] = s;
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(TILE) partials_lnl_tiled_kernel(const PlanDev 
   const uint32_t t = P.tile_task[b];
   const uint32_t n = P.tile_n0[b] + lane;
   const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np;
+  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld;
   const bool active = n < np;
   constexpr uint32_t SS = S*S;
 
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(TILE) partials_lnl_tiled_kernel(const PlanDev 
     __syncthreads();
     if (active)
     {
-      double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*np + n;
+      double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*ld + n;
       bool all_small = true;
       for (uint32_t k = 0; k < R; ++k)
       {
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(TILE) partials_lnl_tiled_kernel(const PlanDev 
         load_childN<S, uint32_t>(L, op.right_clv, k, n, rv);
         const double * lm = s_p + (size_t)k*SS;
         const double * rm = s_p + (size_t)(R + k)*SS;
-        double * dst = out + (size_t)k*S*np;
+        double * dst = out + (size_t)k*S*ld;
 #pragma unroll 4
         for (int i = 0; i < S; ++i)
         {
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(TILE) partials_lnl_tiled_kernel(const PlanDev 
           const double y = dot_fma4<S>(rm + i*S, rv);
           const double v = x*y;
           all_small = all_small && (v < BPA_SCALE_THRESHOLD);
-          dst[(size_t)i*np] = v;
+          dst[(size_t)i*ld] = v;
         }
       }
       if (op.parent_scaler >= 0)
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(TILE) partials_lnl_tiled_kernel(const PlanDev 
         if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + n];
         if (all_small)
         {
-          for (uint32_t e = 0; e < R*S; ++e) out[(size_t)e*np] *= BPA_SCALE_FACTOR;
+          for (uint32_t e = 0; e < R*S; ++e) out[(size_t)e*ld] *= BPA_SCALE_FACTOR;
           s += 1;
         }
         L.scaler[(size_t)op.parent_scaler*np + n] = s;
@@ -401,16 +401,17 @@ __global__ void __launch_bounds__(TILE) partials_lnl_tiled_kernel(const PlanDev 
 // waves in category order (same fma chain as the one-wave version); same arithmetic per element.
 // NT = 64-pattern sub-tiles per workgroup (NT x R waves share one staging of the P-matrices)
 template <int S, int V, int NT = 1>
-__global__ void __launch_bounds__(256*NT) __attribute__((amdgpu_waves_per_eu((V == 2 || V == 3) ? 4 : 1, (V == 2 || V == 3) ? 4 : 8)))
+__global__ void __launch_bounds__(256*NT) __attribute__((amdgpu_waves_per_eu((V == 2 || V == 3 || V == 5) ? 4 : 1, (V == 2 || V == 3 || V == 5) ? 4 : 8)))
 partials_lnl_tiledk_kernel(const PlanDev P)
 {
+  constexpr bool NTA = V == 5;       // V = 5: V = 3 with the CLV planes streamed (nontemporal loads and stores: each is touched once per step)
   extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2][R][S][S], then [NT][R][64] scratch
   const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   const uint32_t k = NT == 1 ? w : w % P.pad, sub = NT == 1 ? 0u : w / P.pad;
   const uint32_t t = P.tile_task[b];
   const uint32_t n = P.tile_n0[b] + sub*64 + lane;
   const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np, nthr = blockDim.x;
+  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld, nthr = blockDim.x;
   const bool active = n < np && k < R;
   constexpr uint32_t SS = S*S;
   double * s_x = s_p + (size_t)2*P.pad*SS + (size_t)sub*P.pad*64;    // P.pad = largest R of the plan
@@ -428,7 +429,7 @@ partials_lnl_tiledk_kernel(const PlanDev P)
       for (uint32_t i = threadIdx.x; i < R*SS/2; i += nthr) { sl[i] = gl[i]; sr[i] = gr[i]; }
     }
     __syncthreads();
-    double * out = L.clv + ((((size_t)(op.parent_clv - L.tips_n)*R) + k)*S)*np + n;
+    double * out = L.clv + ((((size_t)(op.parent_clv - L.tips_n)*R) + k)*S)*ld + n;
     bool all_small = true;
     if (active)
     {
@@ -453,8 +454,8 @@ partials_lnl_tiledk_kernel(const PlanDev P)
         rfast = __all(__popc(code) == 1);
       }
       double lv[S], rv[S];
-      if (!lfast) load_childN<S, uint32_t>(L, op.left_clv,  k, n, lv);
-      if (!rfast) load_childN<S, uint32_t>(L, op.right_clv, k, n, rv);
+      if (!lfast) load_childN<S, uint32_t, NTA>(L, op.left_clv,  k, n, lv);
+      if (!rfast) load_childN<S, uint32_t, NTA>(L, op.right_clv, k, n, rv);
       if (V == 4)
       {
         // both P rows of an output state are requested in one burst of LDS reads (20 ds_read_b128) and
@@ -474,7 +475,7 @@ partials_lnl_tiledk_kernel(const PlanDev P)
           const double y = rfast ? rm[i*S + rs] : dot_fma4<S>(pr, rv);
           const double v = x*y;
           all_small = all_small && (v < BPA_SCALE_THRESHOLD);
-          out[(size_t)i*np] = v;
+          out[(size_t)i*ld] = v;
         }
       }
       else
@@ -486,7 +487,7 @@ partials_lnl_tiledk_kernel(const PlanDev P)
           const double y = rfast ? rm[i*S + rs] : dot_fma4<S>(rm + i*S, rv);
           const double v = x*y;
           all_small = all_small && (v < BPA_SCALE_THRESHOLD);
-          out[(size_t)i*np] = v;
+          if (NTA) __builtin_nontemporal_store(v, out + (size_t)i*ld); else out[(size_t)i*ld] = v;
         }
       }
     }
@@ -498,7 +499,7 @@ partials_lnl_tiledk_kernel(const PlanDev P)
       {
         bool all = true;
         for (uint32_t q = 0; q < R; ++q) all = all && reinterpret_cast<const uint32_t *>(s_x)[q*64 + lane] != 0u;
-        if (all) for (int i = 0; i < S; ++i) out[(size_t)i*np] *= BPA_SCALE_FACTOR;
+        if (all) for (int i = 0; i < S; ++i) out[(size_t)i*ld] *= BPA_SCALE_FACTOR;
         if (k == 0)
         {
           uint32_t sc = all ? 1u : 0u;
@@ -540,6 +541,242 @@ partials_lnl_tiledk_kernel(const PlanDev P)
   P.site_term[P.task_pat_off[t] + n] = term;
 }
 
+// ================================== K1+K2, 20 states, pipelined (default since round 2) ==
+// partials_lnl_tiledk_kernel's arithmetic and workgroup shape (64 patterns x R categories, wave k owns plane k), with
+// the serial chain of an update cut down — what the round-1 kernel waited for was not bandwidth (a kernel of this
+// access shape with no arithmetic streams the same bytes in 230-300 us, tools/probe_bw.hip) but round trips in series:
+//   * everything wave-uniform — tile, locus record, update records — comes through the scalar data path (s_load into
+//     SGPRs; was: one vector load per update, waited for with vmcnt(0), which also drained the previous update's stores);
+//   * the two children's P-matrices go global -> LDS directly (global_load_lds_dwordx4: no registers, no ds_write),
+//     DOUBLE-BUFFERED: update o+1's matrices are requested together with update o's child CLVs (was: four dependent
+//     load -> wait -> ds_write rounds between two barriers);
+//   * ONE workgroup barrier per update and it orders LDS only (s_waitcnt lgkmcnt(0); s_barrier): CLV stores are never
+//     waited for — a lane only ever re-reads what it wrote itself (same pattern, same category);
+//   * a parent that is a child of the next update (or the root) is forwarded in registers instead of re-read.
+typedef const uint32_t __attribute__((address_space(4))) * cu32_p;
+typedef const int32_t  __attribute__((address_space(4))) * ci32_p;
+typedef const uint64_t __attribute__((address_space(4))) * cu64_p;
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+struct OpS { uint32_t parent_clv; int32_t parent_scaler; uint32_t left_clv, left_pmatrix; int32_t left_scaler; uint32_t right_clv, right_pmatrix; int32_t right_scaler; };
+__device__ __forceinline__ OpS load_op_scalar(const OpDev * ops, const uint32_t o)
+{
+  cu32_p q = (cu32_p)(ops + o);
+  OpS r;
+  r.parent_clv = q[0]; r.parent_scaler = (int32_t)q[1]; r.left_clv = q[2]; r.left_pmatrix = q[3]; r.left_scaler = (int32_t)q[4];
+  r.right_clv = q[5]; r.right_pmatrix = q[6]; r.right_scaler = (int32_t)q[7];
+  return r;
+}
+// the 2 x R x S x S doubles of an update's two P-matrix sets, global -> LDS, 1 KB (64 lanes x 16 B) per instruction
+template <int S>
+__device__ __forceinline__ void stage_pmats_async(double * s_dst, const double * gl, const double * gr, const uint32_t R,
+                                                  const uint32_t w, const uint32_t nw, const uint32_t lane)
+{
+  const uint32_t half = R*S*S/2, total = 2*half;                 // 16-byte units
+  for (uint32_t c = w; c*64 < total; c += nw)
+  {
+    const uint32_t idx = c*64 + lane;
+    if (idx < total)
+    {
+      const double * src = idx < half ? gl + 2*(size_t)idx : gr + 2*(size_t)(idx - half);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(s_dst + (size_t)c*128), 16, 0, 0);
+    }
+  }
+}
+
+typedef double   __attribute__((address_space(1))) * gdbl_p;
+typedef const double   __attribute__((address_space(1))) * gcdbl_p;
+typedef uint32_t __attribute__((address_space(1))) * gu32_p;
+typedef const uint32_t __attribute__((address_space(1))) * gcu32_p;
+typedef const double __attribute__((address_space(4))) * cdbl4_p;
+template <int S>
+__device__ __forceinline__ double dot_fma4_s(cdbl4_p row, const double * v)     // dot_fma4 with the row in SGPRs
+{
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+  for (int j = 0; j < S; j += 4)
+  {
+    a0 = __builtin_fma(row[j+0], v[j+0], a0);
+    a1 = __builtin_fma(row[j+1], v[j+1], a1);
+    a2 = __builtin_fma(row[j+2], v[j+2], a2);
+    a3 = __builtin_fma(row[j+3], v[j+3], a3);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+template <int S>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+partials_lnl_pipe20_kernel(const PlanDev P)
+{
+  extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2 buffers][2 children][R][S][S], then [R][64] scratch
+  constexpr uint32_t SS = S*S;
+  const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
+  const uint32_t k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t t = ((cu32_p)P.tile_task)[b];
+  const uint32_t n = ((cu32_p)P.tile_n0)[b] + lane;
+  const uint32_t lid = ((cu32_p)P.task_locus)[t];
+  cu64_p L64 = (cu64_p)(P.loci + lid);
+  cu32_p L32 = (cu32_p)(P.loci + lid);
+  const gdbl_p   Lclv    = (gdbl_p)L64[0];
+  const double * Lpmat   = (const double *)L64[1];
+  const gu32_p   Lscaler = (gu32_p)L64[2];
+  const gcu32_p  Ltips   = (gcu32_p)L64[3];
+  const gcu32_p  Lwgt    = (gcu32_p)L64[4];
+  const cdbl4_p  par     = (cdbl4_p)L64[5];
+  static_assert(offsetof(LocusDev, np) == 72 && offsetof(LocusDev, ld) == 108, "LocusDev layout");
+  const uint32_t np = L32[18], tips_n = L32[19], R = L32[20], unphased = L32[25], ld = L32[27];
+  const bool active = n < np && k < R;
+  const uint32_t bufsz = 2*P.pad*SS;                                 // doubles per staging buffer (P.pad = largest R of the plan)
+  double * s_x = s_p + (size_t)2*bufsz;
+
+  const uint32_t op_begin = ((cu32_p)P.op_off)[t], op_end = ((cu32_p)P.op_off)[t+1];
+  uint32_t cur = 0;
+  if (op_begin < op_end)
+  {
+    const OpS op0 = load_op_scalar(P.ops, op_begin);
+    stage_pmats_async<S>(s_p, Lpmat + (size_t)op0.left_pmatrix*R*SS, Lpmat + (size_t)op0.right_pmatrix*R*SS, R, k, nw, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+  }
+  double ov[S];                                                      // the parent just computed (forwarded)
+  uint32_t ov_clv = 0xffffffffu;
+  for (uint32_t o = op_begin; o < op_end; ++o)
+  {
+    const OpS op = load_op_scalar(P.ops, o);
+    const double * lm = s_p + (size_t)cur*bufsz + (size_t)k*SS;
+    const double * rm = s_p + (size_t)cur*bufsz + (size_t)(R + k)*SS;
+    const bool ltip = op.left_clv < tips_n, rtip = op.right_clv < tips_n;
+    const bool lfwd = op.left_clv == ov_clv, rfwd = op.right_clv == ov_clv;
+    double lv[S], rv[S];
+    uint32_t lcode = 1u, rcode = 1u;
+    bool all_small = true;
+    // every request of this update first: tip codes, child planes, the next update's matrices
+    if (active)
+    {
+      if (ltip) lcode = Ltips[(size_t)op.left_clv*np + n];
+      if (rtip) rcode = Ltips[(size_t)op.right_clv*np + n];
+      if (!ltip && !lfwd)
+      {
+        const gcdbl_p p = Lclv + (((size_t)(op.left_clv - tips_n)*R + k)*S)*ld + n;
+#pragma unroll
+        for (int s = 0; s < S; ++s) lv[s] = p[(size_t)s*ld];
+      }
+      if (!rtip && !rfwd)
+      {
+        const gcdbl_p p = Lclv + (((size_t)(op.right_clv - tips_n)*R + k)*S)*ld + n;
+#pragma unroll
+        for (int s = 0; s < S; ++s) rv[s] = p[(size_t)s*ld];
+      }
+    }
+    if (o + 1 < op_end)
+    {
+      const OpS nx = load_op_scalar(P.ops, o + 1);
+      stage_pmats_async<S>(s_p + (size_t)(cur ^ 1u)*bufsz, Lpmat + (size_t)nx.left_pmatrix*R*SS, Lpmat + (size_t)nx.right_pmatrix*R*SS, R, k, nw, lane);
+    }
+    if (active)
+    {
+      // tip children: partials_lnl_tiledk_kernel's tip-code fast path (wave-uniform), else the 0/1 expansion of the code
+      const bool lfast = ltip && __all(__popc(lcode) == 1), rfast = rtip && __all(__popc(rcode) == 1);
+      const int ls = __ffs(lcode) - 1, rs = __ffs(rcode) - 1;
+      if (ltip && !lfast) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) lv[s] = (double)((lcode >> s) & 1u); }
+      if (rtip && !rfast) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) rv[s] = (double)((rcode >> s) & 1u); }
+      if (lfwd) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) lv[s] = ov[s]; }
+      if (rfwd) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) rv[s] = ov[s]; }
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+      {
+        const double x = lfast ? lm[i*S + ls] : dot_fma4<S>(lm + i*S, lv);
+        const double y = rfast ? rm[i*S + rs] : dot_fma4<S>(rm + i*S, rv);
+        const double v = x*y;
+        all_small = all_small && (v < BPA_SCALE_THRESHOLD);
+        ov[i] = v;
+      }
+      ov_clv = op.parent_clv;
+    }
+    if (op.parent_scaler >= 0)                         // uniform: the scaling test couples the categories
+    {
+      reinterpret_cast<uint32_t *>(s_x)[k*64 + lane] = all_small ? 1u : 0u;
+      lds_barrier();
+      if (active)
+      {
+        bool all = true;
+        for (uint32_t q = 0; q < R; ++q) all = all && reinterpret_cast<const uint32_t *>(s_x)[q*64 + lane] != 0u;
+        if (all) {
+#pragma unroll
+          for (int i = 0; i < S; ++i) ov[i] *= BPA_SCALE_FACTOR; }
+        if (k == 0)
+        {
+          uint32_t sc = all ? 1u : 0u;
+          if (op.left_scaler  >= 0) sc += Lscaler[(size_t)op.left_scaler*np  + n];
+          if (op.right_scaler >= 0) sc += Lscaler[(size_t)op.right_scaler*np + n];
+          Lscaler[(size_t)op.parent_scaler*np + n] = sc;
+        }
+      }
+    }
+    if (active)
+    {
+      const gdbl_p out = Lclv + ((((size_t)(op.parent_clv - tips_n)*R) + k)*S)*ld + n;
+#pragma unroll
+      for (int i = 0; i < S; ++i) out[(size_t)i*ld] = ov[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next matrices has landed (stores drain with it)
+    lds_barrier();                                     // everyone is done reading buffer `cur` and has filled the other
+    cur ^= 1u;
+  }
+  if (!(P.flags & 4u)) return;
+
+  // K2 / K3 (core_likelihood_avx2.c:45-87): every wave its category's term, wave 0 the fma chain over them
+  const uint32_t root = ((cu32_p)P.root_clv)[t];
+  if (active)
+  {
+    double c[S];
+    if (root == ov_clv) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) c[s] = ov[s]; }
+    else if (root < tips_n)
+    {
+      const uint32_t code = Ltips[(size_t)root*np + n];
+#pragma unroll
+      for (int s = 0; s < S; ++s) c[s] = (double)((code >> s) & 1u);
+    }
+    else
+    {
+      const gcdbl_p p = Lclv + (((size_t)(root - tips_n)*R + k)*S)*ld + n;
+#pragma unroll
+      for (int s = 0; s < S; ++s) c[s] = p[(size_t)s*ld];
+    }
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+    s_x[k*64 + lane] = dot_fma4_s<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
+  }
+  lds_barrier();
+  if (!active || k) return;
+  double term = 0;
+  for (uint32_t q = 0; q < R; ++q) term = __builtin_fma(s_x[q*64 + lane], par[par_rate_weights(R) + q], term);
+  if (!unphased)
+  {
+    double lt = log(term);
+    const int32_t rsc = ((ci32_p)P.root_scaler)[t];
+    if (rsc >= 0)
+    {
+      const uint32_t sc = Lscaler[(size_t)rsc*np + n];
+      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
+    }
+    term = lt*Lwgt[n];
+  }
+  P.site_term[((cu32_p)P.task_pat_off)[t] + n] = term;
+}
+
 // ====================================== K1+K2, 20 states, P through the scalar path ==
 // One wave (= one workgroup) = one tile of 64 consecutive patterns of ONE locus; one lane = one
 // pattern.  Everything about the node update except the CLV values is wave-uniform, so the two
@@ -572,7 +809,7 @@ __global__ void __launch_bounds__(64) partials_lnl_scalarp_kernel(const PlanDev 
   const uint32_t t = P.tile_task[b];
   const uint32_t n = P.tile_n0[b] + lane;
   const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np;
+  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld;
   const bool active = n < np;
   constexpr uint32_t SS = S*S;
   const uint32_t nn = active ? n : np - 1;               // idle lanes shadow the last pattern (no divergence, no stores)
@@ -581,7 +818,7 @@ __global__ void __launch_bounds__(64) partials_lnl_scalarp_kernel(const PlanDev 
   for (uint32_t o = P.op_off[t]; o < op_end; ++o)
   {
     const OpDev op = P.ops[o];
-    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*np + nn;
+    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*ld + nn;
     bool all_small = true;
     for (uint32_t k = 0; k < R; ++k)
     {
@@ -590,7 +827,7 @@ __global__ void __launch_bounds__(64) partials_lnl_scalarp_kernel(const PlanDev 
       load_childN<S, uint32_t>(L, op.right_clv, k, nn, rv);
       cdouble_p lm = (cdouble_p)(L.pmat + ((size_t)op.left_pmatrix*R  + k)*SS);
       cdouble_p rm = (cdouble_p)(L.pmat + ((size_t)op.right_pmatrix*R + k)*SS);
-      double * dst = out + (size_t)k*S*np;
+      double * dst = out + (size_t)k*S*ld;
 #pragma unroll 2
       for (int i = 0; i < S; ++i)
       {
@@ -598,7 +835,7 @@ __global__ void __launch_bounds__(64) partials_lnl_scalarp_kernel(const PlanDev 
         const double y = dot_fma4_c<S>(rm + i*S, rv);
         const double v = x*y;
         all_small = all_small && (v < BPA_SCALE_THRESHOLD);
-        if (active) dst[(size_t)i*np] = v;
+        if (active) dst[(size_t)i*ld] = v;
       }
     }
     if (op.parent_scaler >= 0 && active)
@@ -608,7 +845,7 @@ __global__ void __launch_bounds__(64) partials_lnl_scalarp_kernel(const PlanDev 
       if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + n];
       if (all_small)
       {
-        for (uint32_t e = 0; e < R*S; ++e) out[(size_t)e*np] *= BPA_SCALE_FACTOR;
+        for (uint32_t e = 0; e < R*S; ++e) out[(size_t)e*ld] *= BPA_SCALE_FACTOR;
         s += 1;
       }
       L.scaler[(size_t)op.parent_scaler*np + n] = s;
@@ -673,12 +910,12 @@ __device__ __forceinline__ void load_b20k(const LocusDev & L, const uint32_t clv
   }
   else
   {
-    const double * p = L.clv + (((size_t)(clv_index - L.tips_n)*L.rate_cats + k)*20)*L.np + pat;
+    const double * p = L.clv + (((size_t)(clv_index - L.tips_n)*L.rate_cats + k)*20)*L.ld + pat;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
     {
-      b[a]  = p[(size_t)(a + 4*kq)*L.np];
-      bt[a] = p[(size_t)(16 + a)*L.np];
+      b[a]  = p[(size_t)(a + 4*kq)*L.ld];
+      bt[a] = p[(size_t)(16 + a)*L.ld];
     }
   }
 }
@@ -691,7 +928,7 @@ __global__ void __launch_bounds__(256) partials_lnl_mfma20k_kernel(const PlanDev
   const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t t = P.tile_task[b], n0 = P.tile_n0[b];
   const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np, nthr = blockDim.x;
+  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld, nthr = blockDim.x;
   const uint32_t kq = l >> 4, pl = l & 15, ri = l & 3;
   const bool wave_on = k < R;
   double * s_x = s_p + (size_t)2*P.pad*SS;
@@ -709,7 +946,7 @@ __global__ void __launch_bounds__(256) partials_lnl_mfma20k_kernel(const PlanDev
       for (uint32_t i = threadIdx.x; i < R*SS/2; i += nthr) { sl[i] = gl[i]; sr[i] = gr[i]; }
     }
     __syncthreads();
-    double * out = L.clv + ((((size_t)(op.parent_clv - L.tips_n)*R) + k)*S)*np;
+    double * out = L.clv + ((((size_t)(op.parent_clv - L.tips_n)*R) + k)*S)*ld;
     uint32_t small = 0xfu;                             // bit g: everything this lane produced for group g is < 2^-256
     if (wave_on)
     {
@@ -753,7 +990,7 @@ __global__ void __launch_bounds__(256) partials_lnl_mfma20k_kernel(const PlanDev
           const double y = (ya[0] + ya[1]) + (ya[2] + ya[3]);
           const double v = x*y;
           if (!(v < BPA_SCALE_THRESHOLD)) small &= ~(1u << g);
-          if (pat < np) out[(size_t)(4*r + kq)*np + pat] = v;            // D: row = lane >> 4
+          if (pat < np) out[(size_t)(4*r + kq)*ld + pat] = v;            // D: row = lane >> 4
         }
       }
     }
@@ -775,7 +1012,7 @@ __global__ void __launch_bounds__(256) partials_lnl_mfma20k_kernel(const PlanDev
           const bool rescale = (all >> g) & 1u;
           if (rescale)
 #pragma unroll
-            for (int r = 0; r < 5; ++r) out[(size_t)(4*r + kq)*np + pat] *= BPA_SCALE_FACTOR;
+            for (int r = 0; r < 5; ++r) out[(size_t)(4*r + kq)*ld + pat] *= BPA_SCALE_FACTOR;
           if (k == 0 && kq == 0)
           {
             uint32_t sc = rescale ? 1u : 0u;
@@ -835,7 +1072,7 @@ __global__ void __launch_bounds__(256) partials_lnl_scalark_kernel(const PlanDev
   const uint32_t t = P.tile_task[b];
   const uint32_t n = P.tile_n0[b] + lane;
   const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np;
+  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld;
   const bool wave_on = k < R;
   const bool active = n < np && wave_on;
   constexpr uint32_t SS = S*S;
@@ -845,7 +1082,7 @@ __global__ void __launch_bounds__(256) partials_lnl_scalark_kernel(const PlanDev
   for (uint32_t o = P.op_off[t]; o < op_end; ++o)
   {
     const OpDev op = P.ops[o];
-    double * out = L.clv + ((((size_t)(op.parent_clv - L.tips_n)*R) + k)*S)*np + nn;
+    double * out = L.clv + ((((size_t)(op.parent_clv - L.tips_n)*R) + k)*S)*ld + nn;
     bool all_small = true;
     if (wave_on)
     {
@@ -861,7 +1098,7 @@ __global__ void __launch_bounds__(256) partials_lnl_scalark_kernel(const PlanDev
         const double y = dot_fma4_c<S>(rm + i*S, rv);
         const double v = x*y;
         all_small = all_small && (v < BPA_SCALE_THRESHOLD);
-        if (active) out[(size_t)i*np] = v;
+        if (active) out[(size_t)i*ld] = v;
       }
     }
     if (op.parent_scaler >= 0)                         // uniform: the scaling test couples the categories
@@ -873,7 +1110,7 @@ __global__ void __launch_bounds__(256) partials_lnl_scalark_kernel(const PlanDev
       {
         bool all = true;
         for (uint32_t q = 0; q < R; ++q) all = all && reinterpret_cast<const uint32_t *>(&s_x[q][0])[lane] != 0u;
-        if (all) for (int i = 0; i < S; ++i) out[(size_t)i*np] *= BPA_SCALE_FACTOR;
+        if (all) for (int i = 0; i < S; ++i) out[(size_t)i*ld] *= BPA_SCALE_FACTOR;
         if (k == 0)
         {
           uint32_t sc = all ? 1u : 0u;
@@ -971,12 +1208,12 @@ __device__ __forceinline__ void load_b20(const LocusDev & L, const uint32_t clv_
   }
   else
   {
-    const double * p = L.clv + (((size_t)(clv_index - L.tips_n)*L.rate_cats + k)*20)*L.np + pat;
+    const double * p = L.clv + (((size_t)(clv_index - L.tips_n)*L.rate_cats + k)*20)*L.ld + pat;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
     {
-      b[a]  = p[(size_t)(a + 4*kq)*L.np];
-      b2[a] = kq == 0 ? p[(size_t)(16 + a)*L.np] : 0.0;
+      b[a]  = p[(size_t)(a + 4*kq)*L.ld];
+      b2[a] = kq == 0 ? p[(size_t)(16 + a)*L.ld] : 0.0;
     }
   }
 }
@@ -989,7 +1226,7 @@ __global__ void __launch_bounds__(64) partials_lnl_mfma20_kernel(const PlanDev P
   const uint32_t b = blockIdx.x, l = threadIdx.x;
   const uint32_t t = P.tile_task[b], n0 = P.tile_n0[b];
   const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np;
+  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld;
   const uint32_t kq = l >> 4, pl = l & 15, ri = l & 3;
   const uint32_t npat = min((uint32_t)TILE, np - n0), ngroups = (npat + 15)/16;
 
@@ -997,7 +1234,7 @@ __global__ void __launch_bounds__(64) partials_lnl_mfma20_kernel(const PlanDev P
   for (uint32_t o = P.op_off[t]; o < op_end; ++o)
   {
     const OpDev op = P.ops[o];
-    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*np;
+    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*ld;
     uint32_t small = 0xffffffffu;                 // bit g: everything this lane produced for group g is < 2^-256
     for (uint32_t k = 0; k < R; ++k)
     {
@@ -1033,7 +1270,7 @@ __global__ void __launch_bounds__(64) partials_lnl_mfma20_kernel(const PlanDev P
           const double y = tile_dot20(s_p + S*S, (4*r + ri)*S, kq, br[g], br2[g]);
           const double v = x*y;
           sm = sm && (v < BPA_SCALE_THRESHOLD);
-          if (valid) out[((size_t)k*S + 4*r + kq)*np + pat] = v;      // D: row = lane >> 4
+          if (valid) out[((size_t)k*S + 4*r + kq)*ld + pat] = v;      // D: row = lane >> 4
         }
         if (!sm) small &= ~(1u << g);
       }
@@ -1051,7 +1288,7 @@ __global__ void __launch_bounds__(64) partials_lnl_mfma20_kernel(const PlanDev P
         if (rescale)
           for (uint32_t k = 0; k < R; ++k)
 #pragma unroll
-            for (int r = 0; r < 5; ++r) out[((size_t)k*S + 4*r + kq)*np + pat] *= BPA_SCALE_FACTOR;
+            for (int r = 0; r < 5; ++r) out[((size_t)k*S + 4*r + kq)*ld + pat] *= BPA_SCALE_FACTOR;
         if (kq == 0)
         {
           uint32_t s = rescale ? 1u : 0u;
