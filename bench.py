@@ -221,7 +221,10 @@ def dominant_kernel(cfg):
         return "step_jc69_v2_chain_kernel<256> + step_jc69_v2_kernel<256>" if not os.environ.get("BPA_NO_CHAIN") else "step_jc69_v2_kernel<256>"
     if cfg["model"] == "gtr":
         return "step_s4_klane_v2_kernel<256,false>"
-    return "partials_lnl_tiledk_kernel<20,3>"
+    k = os.environ.get("BPA_S20_KERNEL", "pipe")
+    return {"pipe": "partials_lnl_pipe20_kernel<20,true,2>", "pipe2c": "partials_lnl_pipe20_kernel<20,false,2>",
+            "pipe3": "partials_lnl_pipe20_kernel<20,true,3>", "pipe3c": "partials_lnl_pipe20_kernel<20,false,3>",
+            "tiledk": "partials_lnl_tiledk_kernel<20,3>", "mfmak": "partials_lnl_mfma20k_kernel"}.get(k, f"20-state kernel `{k}`")
 
 
 def traffic_from_profiles(config, kernel):

@@ -740,17 +740,19 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
 
   // tiled path (20 states): one workgroup per 128-pattern tile of one locus
   p->ntiles = 0; d.tile_task = d.tile_n0 = nullptr;
-  // 20-state partials kernel (kernels.hpp): default = LDS-staged P, one wave per rate category
-  // (partials_lnl_tiledk_kernel); BPA_S20_KERNEL selects the others for A/B timing:
-  //   tiled (first version, one wave runs all categories) | mfma (first MFMA version) | mfmak (MFMA, wave per
-  //   category) | scalarp / scalark (P through the scalar path) | generic (no staging)
+  // 20-state partials kernel (kernels.hpp): default = the pipelined kernel (partials_lnl_pipe20_kernel: P-matrices
+  // global -> LDS direct and double-buffered, one wave per rate category, CLV planes streamed, 2 waves per SIMD);
+  // BPA_S20_KERNEL selects the others for A/B timing:
+  //   pipe2c / pipe3 / pipe3c (cached CLV accesses / 3 waves per SIMD) | tiledk (round 1's default) | tiled (first
+  //   version, one wave runs all categories) | mfma (first MFMA version) | mfmak (MFMA, wave per category) |
+  //   scalarp / scalark (P through the scalar path) | generic (no staging)
   {
     const char * v = getenv("BPA_S20_KERNEL");
     p->s20_kernel = v ? v : "pipe";
   }
   p->s20_mfma = p->s20_kernel == "mfma";
   p->s20_scalarp = p->s20_kernel == "scalarp";
-  p->s20_tiledk = p->s20_kernel == "pipe" || p->s20_kernel == "tiledk" || p->s20_kernel == "mfmak" || p->s20_kernel == "scalark" || p->s20_kernel == "tiledk1" || p->s20_kernel == "tiledkb" || p->s20_kernel == "tiledk2" || p->s20_kernel == "tiledknt";
+  p->s20_tiledk = p->s20_kernel.compare(0, 4, "pipe") == 0 || p->s20_kernel == "tiledk" || p->s20_kernel == "mfmak" || p->s20_kernel == "scalark" || p->s20_kernel == "tiledk1" || p->s20_kernel == "tiledkb" || p->s20_kernel == "tiledk2" || p->s20_kernel == "tiledknt";
   if (p->s20_tiledk && p->rmax > 4) { p->s20_tiledk = false; p->s20_kernel = "tiled"; }     // 64 x R lanes must fit a 256-lane workgroup
   p->tile = p->s20_mfma ? 32 : (p->s20_scalarp || p->s20_tiledk) ? 64 : 128;
   if (p->s20_kernel == "tiledk2") p->tile = 128;                   // two 64-pattern sub-tiles per workgroup
@@ -1121,8 +1123,11 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       d.flags = 4u; d.pad = p->rmax;
       const size_t lds = ((size_t)2*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double);
       const dim3 grid(p->ntiles), block(64*p->rmax);
-      if (p->s20_kernel == "pipe")
-        hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
+      const size_t lds2 = ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double);
+      if (p->s20_kernel == "pipe")         hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), grid, block, lds2, e->stream, d);     // default
+      else if (p->s20_kernel == "pipe2c")  hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, false, 2>), grid, block, lds2, e->stream, d);    // cached CLV accesses
+      else if (p->s20_kernel == "pipe3")   hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 3>), grid, block, lds2, e->stream, d);     // 168 registers, 3 waves per SIMD
+      else if (p->s20_kernel == "pipe3c")  hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, false, 3>), grid, block, lds2, e->stream, d);
       else if (p->s20_kernel == "mfmak")   hipLaunchKernelGGL(partials_lnl_mfma20k_kernel, grid, block, lds, e->stream, d);
       else if (p->s20_kernel == "scalark" && p->rmax <= 4)
                                            hipLaunchKernelGGL((partials_lnl_scalark_kernel<20>), grid, block, 0, e->stream, d);

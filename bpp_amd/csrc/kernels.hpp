@@ -607,8 +607,8 @@ __device__ __forceinline__ double dot_fma4_s(cdbl4_p row, const double * v)     
   return (a0 + a1) + (a2 + a3);
 }
 
-template <int S>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+template <int S, bool NTA = false, int OCC = 3>      // NTA: CLV planes streamed (nontemporal); OCC: waves per SIMD of the register budget
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 partials_lnl_pipe20_kernel(const PlanDev P)
 {
   extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2 buffers][2 children][R][S][S], then [R][64] scratch
@@ -662,13 +662,13 @@ partials_lnl_pipe20_kernel(const PlanDev P)
       {
         const gcdbl_p p = Lclv + (((size_t)(op.left_clv - tips_n)*R + k)*S)*ld + n;
 #pragma unroll
-        for (int s = 0; s < S; ++s) lv[s] = p[(size_t)s*ld];
+        for (int s = 0; s < S; ++s) lv[s] = NTA ? __builtin_nontemporal_load(p + (size_t)s*ld) : p[(size_t)s*ld];
       }
       if (!rtip && !rfwd)
       {
         const gcdbl_p p = Lclv + (((size_t)(op.right_clv - tips_n)*R + k)*S)*ld + n;
 #pragma unroll
-        for (int s = 0; s < S; ++s) rv[s] = p[(size_t)s*ld];
+        for (int s = 0; s < S; ++s) rv[s] = NTA ? __builtin_nontemporal_load(p + (size_t)s*ld) : p[(size_t)s*ld];
       }
     }
     if (o + 1 < op_end)
@@ -728,7 +728,7 @@ partials_lnl_pipe20_kernel(const PlanDev P)
     {
       const gdbl_p out = Lclv + ((((size_t)(op.parent_clv - tips_n)*R) + k)*S)*ld + n;
 #pragma unroll
-      for (int i = 0; i < S; ++i) out[(size_t)i*ld] = ov[i];
+      for (int i = 0; i < S; ++i) { if (NTA) __builtin_nontemporal_store(ov[i], out + (size_t)i*ld); else out[(size_t)i*ld] = ov[i]; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next matrices has landed (stores drain with it)
     lds_barrier();                                     // everyone is done reading buffer `cur` and has filled the other

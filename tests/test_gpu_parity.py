@@ -392,7 +392,7 @@ def test_against_the_reference_itself(engine, spec):
     rl.free()
 
 
-@pytest.mark.parametrize("kernel", ["tiledk", "mfmak", "mfma", "tiled", "tiledk1", "tiledkb", "tiledknt", "tiledk2", "scalarp", "scalark", "generic"])
+@pytest.mark.parametrize("kernel", ["tiledk", "pipe2c", "pipe3", "pipe3c", "mfmak", "mfma", "tiled", "tiledk1", "tiledkb", "tiledknt", "tiledk2", "scalarp", "scalark", "generic"])
 def test_20_state_kernel_variants_are_bit_exact(engine, monkeypatch, kernel):
     """every 20-state node-update kernel (BPA_S20_KERNEL; the FP64-MFMA ones included) reproduces the
     reference's AVX2 summation order exactly: same CLVs, scalers and lnL bits as the default kernel"""

@@ -2,9 +2,9 @@
 # config 4 A/B: CLV plane stride padded to 128-byte lines (default) vs the first layout, plain vs streamed CLV accesses
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_edges.py -m gpu -x -q > gpurun_out/c4_tests.txt 2>&1
+python -m pytest tests/test_gpu_parity.py -k 20_state -m gpu -x -q > gpurun_out/c4_tests.txt 2>&1
 tail -3 gpurun_out/c4_tests.txt
-for v in "pad:pipe" "pad:tiledk" "nopad:pipe"; do
+for v in "pad:pipe" "pad:pipent" "pad:pipe2" "pad:pipe2nt"; do
   lay=${v%%:*}; k=${v##*:}
   if [ $lay = nopad ]; then export BPA_NO_PLANE_PAD=1; else unset BPA_NO_PLANE_PAD; fi
   BPA_S20_KERNEL=$k python bench.py --config c4 --steps 8 --warmup 2 --no-cpu-baseline --no-bpp-program > gpurun_out/c4_${lay}_${k}.json 2> gpurun_out/c4_${lay}_${k}.err
