@@ -1102,8 +1102,10 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       const unsigned n = d.nmat*p->rmax*20;
       if (getenv("BPA_PMAT_ROWS"))      // one lane per row (the first version), kept for A/B timing
         hipLaunchKernelGGL(pmatrix_sN_kernel<20>, dim3((n + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d, p->rmax);
-      else
+      else if (getenv("BPA_PMAT_WG1"))  // round 1's workgroup-per-branch kernel
         hipLaunchKernelGGL(pmatrix_wg_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d, p->rmax);
+      else
+        hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d);
     }
     HIPCHK(hipGetLastError());
   }

@@ -2947,6 +2947,86 @@ __global__ void __launch_bounds__(256) pmatrix_wg_kernel(const PlanDev P, const 
   (void)rmax;
 }
 
+// pmatrix_wg_kernel with its serial chain cut down the way partials_lnl_pipe20_kernel's was: the wave-uniform chain
+// (branch entry -> task -> locus record -> parameter block -> matrix index) runs through the scalar data path, the two
+// eigenvector matrices go global -> LDS directly (no registers, no ds_write), barriers order LDS only and the output
+// stores are not waited for.  Same arithmetic, same bits.
+template <int S>
+__global__ void __launch_bounds__(256) pmatrix_wg2_kernel(const PlanDev P)
+{
+  static_assert((S*S*8) % 16 == 0, "16-byte staging units");
+  __shared__ __attribute__((aligned(16))) double s_evs[2*S*S], s_tmp[4][S*S], s_e[4][S];
+  double * const s_ev = s_evs, * const s_iev = s_evs + S*S;
+  const uint32_t e = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lid = ((cu32_p)P.task_locus)[((cu32_p)P.mat_task)[e]];
+  cu64_p L64 = (cu64_p)(P.loci + lid);
+  cu32_p L32 = (cu32_p)(P.loci + lid);
+  const uint32_t R = L32[20];
+  const cdbl4_p par = (cdbl4_p)L64[5];
+  const double * parg = (const double *)L64[5];
+  const double t = ((cdbl4_p)P.mat_length)[e];
+  const gdbl_p pbase = (gdbl_p)L64[1] + (size_t)((cu32_p)P.mat_pmatrix)[e]*R*S*S;
+  for (uint32_t k0 = 0; k0 < R; )
+  {
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k0];
+    uint32_t k1 = k0 + 1;
+    while (k1 < R && k1 - k0 < 4 && (uint32_t)par[par_param_idx(R) + k1] == m) ++k1;
+    const uint32_t nk = k1 - k0;
+    const uint32_t pmo = par_matrix(R, S, m);
+    if (k0) lds_barrier();                                     // the previous group's LDS reads are done
+    {
+      // evecs | ievecs are adjacent in the parameter block: 2*S*S doubles = S*S 16-byte units, 64 per instruction
+      const double * src = parg + pmo + pm_evecs(S);
+      constexpr uint32_t total = S*S;                          // 16-byte units
+      if (((pmo + pm_evecs(S)) & 1u) == 0)                    // 16-byte aligned in the parameter block (R even)
+        for (uint32_t c = w; c*64 < total; c += 4)
+        {
+          const uint32_t idx = c*64 + lane;
+          if (idx < total)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 2*(size_t)idx),
+                                             (__attribute__((address_space(3))) void *)(s_evs + (size_t)c*128), 16, 0, 0);
+        }
+      else
+        for (uint32_t i = tid; i < 2*S*S; i += 256) s_evs[i] = ((gcdbl_p)src)[i];
+    }
+    if (tid < nk*S)
+    {
+      const uint32_t k = k0 + tid/S, mm = tid % S;
+      s_e[tid/S][mm] = expm1(((gcdbl_p)parg)[pmo + pm_evals(S) + mm]*(t*((gcdbl_p)parg)[par_rates(R) + k]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    // temp = inv_eigenvecs * expd (core_pmatrix.c:741-747), once per element
+    for (uint32_t i = tid; i < nk*S*S; i += 256) s_tmp[i/(S*S)][i % (S*S)] = s_iev[i % (S*S)]*s_e[i/(S*S)][i % S];
+    lds_barrier();
+    // pmat = I + temp * eigenvecs (core_pmatrix.c:749-756): one lane = 4 consecutive columns of a row
+    constexpr uint32_t Q = S/4;
+    for (uint32_t idx = tid; idx < nk*S*Q; idx += 256)
+    {
+      const uint32_t kk = idx/(S*Q), j = (idx % (S*Q))/Q, c0 = 4*(idx % Q), k = k0 + kk;
+      double acc[4] = {j == c0 ? 1.0 : 0.0, j == c0 + 1 ? 1.0 : 0.0, j == c0 + 2 ? 1.0 : 0.0, j == c0 + 3 ? 1.0 : 0.0};
+      if (!(t*par[par_rates(R) + k] < 1e-100))
+      {
+        const double * tr = &s_tmp[kk][j*S];
+#pragma unroll
+        for (int mm = 0; mm < S; ++mm)
+        {
+          const double tv = tr[mm];
+          const double2 * ev = reinterpret_cast<const double2 *>(&s_ev[mm*S + c0]);
+          const double2 a = ev[0], c = ev[1];
+          acc[0] += tv*a.x; acc[1] += tv*a.y; acc[2] += tv*c.x; acc[3] += tv*c.y;
+        }
+      }
+      typedef double d2v __attribute__((ext_vector_type(2)));
+      d2v o0, o1; o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
+      __attribute__((address_space(1))) d2v * dst = (__attribute__((address_space(1))) d2v *)(pbase + (size_t)k*S*S + j*S + c0);
+      dst[0] = o0; dst[1] = o1;
+    }
+    k0 = k1;
+  }
+}
+
 // pll_core_update_pmatrix (core_pmatrix.c:785) over staged host arrays:
 // one lane per (matrix i, rate k, row j).
 template <int S>

@@ -183,3 +183,23 @@ def compare_runs(ctl_text, files, timeout=900):
     all_err = max(rel(x, y) for a, b in zip(r0, r1) for x, y in zip(a, b))
     return dict(logl0_ref=log_l0(out0), logl0_hip=log_l0(out1), lnl_err=lnl_err, all_err=all_err,
                 identical=(m0 == m1), samples=len(r0), stdout_hip=out1)
+
+
+_NUM = re.compile(r"-?\d+\.\d+(?:[eE][-+]?\d+)?")
+
+
+def compare_text_runs(ctl_text, files, timeout=900):
+    """as compare_runs for sample files that are not tables (species trees of A01 / A10 / A11 with their annotations):
+    the text around the decimal numbers must be the same, the numbers are compared relatively"""
+    rc0, out0, f0 = run_program(REF_BIN, ctl_text, files, timeout)
+    assert rc0 == 0, out0[-2000:]
+    rc1, out1, f1 = run_program(HIP_BIN, ctl_text, files, timeout)
+    assert rc1 == 0, out1[-2000:]
+    assert "Likelihood back-end: bpp_amd" in out1
+    m0, m1 = f0["out.mcmc.txt"], f1["out.mcmc.txt"]
+    assert _NUM.sub("#", m0) == _NUM.sub("#", m1), "the sample files differ in more than their decimal numbers"
+    n0, n1 = [float(x) for x in _NUM.findall(m0)], [float(x) for x in _NUM.findall(m1)]
+    assert len(n0) == len(n1) and len(n0) > 0
+    err = max(abs(a - b)/max(abs(a), abs(b), 1e-300) for a, b in zip(n0, n1))
+    return dict(logl0_ref=log_l0(out0), logl0_hip=log_l0(out1), all_err=err, identical=(m0 == m1),
+                samples=len([ln for ln in m0.splitlines() if ln.strip()]), stdout_hip=out1)

@@ -83,3 +83,52 @@ def test_threads_2():
                            burnin=10, sampfreq=2, nsample=30, extra="threads = 2 1 1")
     res = B.compare_runs(ctl, files)
     check(res)
+
+
+def _syn4(nloci=24, sites=300, seed=3):
+    return B.simulate(B.SIM_CTL.format(seed=seed, species=B.SPECIES4_SIM, phase="0 0 0 0", nloci=nloci, sites=sites, simmodel=0, extra=""))
+
+
+def _a00(nloci, model="jc69", alpha="", extra="", nsample=30):
+    return B.A00_CTL.format(species=B.SPECIES4, phase="0 0 0 0", nloci=nloci, model=model, alpha=alpha, taub=500,
+                            burnin=10, sampfreq=2, nsample=nsample, extra=extra)
+
+
+@pytest.mark.parametrize("clock", ["clock = 2 10 100 5 iid G", "clock = 3 10 100 5 iid G"])
+def test_relaxed_clocks(clock):
+    """independent- and correlated-rates clocks with estimated locus rates: branch lengths come from the reference's own
+    update_branchlength_relaxed_clock (locus.c:1150) inside the shim, the branch-rate and locus-rate proposals
+    (stree.c: prop_branch_rates, prop_locusrate_*) call the library through the same three entry points"""
+    res = B.compare_runs(_a00(24, extra=clock + "\nlocusrate = 1 5 5 2 iid"), _syn4())
+    check(res)
+
+
+def test_locusrate_and_heredity():
+    """strict clock with per-locus rates (gtree->rate_mui in every branch length, locus.c:2347) and heredity scalars"""
+    res = B.compare_runs(_a00(24, extra="locusrate = 1 5 5 2 iid\nheredity = 1 4 4"), _syn4())
+    check(res)
+
+
+@pytest.mark.parametrize("model,alpha", [("hky", "alphaprior = 1 1 4"), ("k80", ""), ("tn93", ""), ("f81", ""), ("t92", ""), ("f84", "")])
+def test_closed_form_models_through_the_program(model, alpha):
+    """K7 (locus.c:1981-2323) as the reference program drives it: model-specific parameter proposals included"""
+    res = B.compare_runs(_a00(16, model=model, alpha=alpha, nsample=20), _syn4(16))
+    check(res)
+
+
+def test_species_tree_inference_a01():
+    """A01: the species-tree SPR / NNI moves (stree.c) re-evaluate gene trees of all loci through the library"""
+    ctl = _a00(16, nsample=25).replace("speciestree = 0\n", "speciestree = 1\n")
+    res = B.compare_text_runs(ctl, _syn4(16))
+    assert abs(res["logl0_ref"] - res["logl0_hip"]) <= 1e-10*abs(res["logl0_ref"])
+    assert res["all_err"] <= 1e-10, res
+    print(f"A01: {res['samples']} samples, numbers agree to {res['all_err']:.1e}, byte-identical: {res['identical']}")
+
+
+def test_species_delimitation_a11():
+    """A11: rjMCMC species delimitation + species-tree moves on the library"""
+    ctl = _a00(16, nsample=25).replace("speciesdelimitation = 0\n", "speciesdelimitation = 1 1 2 1\n").replace("speciestree = 0\n", "speciestree = 1\nspeciesmodelprior = 1\n")
+    res = B.compare_text_runs(ctl, _syn4(16))
+    assert abs(res["logl0_ref"] - res["logl0_hip"]) <= 1e-10*abs(res["logl0_ref"])
+    assert res["all_err"] <= 1e-10, res
+    print(f"A11: {res['samples']} samples, numbers agree to {res['all_err']:.1e}, byte-identical: {res['identical']}")
