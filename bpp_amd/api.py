@@ -100,6 +100,7 @@ def lib():
         "bpa_locus_get_pmatrix": (i, [vp, u, dp]),
         "bpa_locus_set_pmatrix": (i, [vp, u, dp]),
         "bpa_locus_get_scaler": (i, [vp, u, up]),
+        "bpa_locus_set_scaler": (i, [vp, u, up]),
         "bpa_locus_get_eigen": (i, [vp, u, dp, dp, dp]),
         "bpa_plan_create": (vp, [vp, C.POINTER(Batch)]),
         "bpa_plan_destroy": (None, [vp]),
@@ -168,7 +169,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_locus_update_all_matrices", "bpa_locus_update_all_partials",
             "bpa_core_update_pmatrix", "bpa_update_eigen", "bpa_compute_gamma_cats",
             "bpa_compress_site_patterns", "bpa_locus_get_clv", "bpa_locus_set_clv",
-            "bpa_locus_get_pmatrix", "bpa_locus_set_pmatrix", "bpa_locus_get_scaler",
+            "bpa_locus_get_pmatrix", "bpa_locus_set_pmatrix", "bpa_locus_get_scaler", "bpa_locus_set_scaler",
             "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
             "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate",
             "bpa_plan_enable_sum", "bpa_plan_enable_partial_sums", "bpa_plan_get_sum",
@@ -410,6 +411,11 @@ class Locus:
         out = np.zeros(self.sites, dtype=np.uint32)
         _chk(lib().bpa_locus_get_scaler(self.h, idx, _up(out)))
         return out
+
+    def set_scaler(self, idx, values):
+        v = np.ascontiguousarray(values, dtype=np.uint32)
+        assert v.size == self.sites
+        _chk(lib().bpa_locus_set_scaler(self.h, idx, _up(v)))
 
     def get_eigen(self, index=0):
         S = self.states

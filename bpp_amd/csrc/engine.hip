@@ -1246,7 +1246,10 @@ extern "C" int bpa_plan_probe(bpa_plan_t * p, double * out)
 static bool chainable(bpa_plan * p)
 {
   bpa_engine * e = p->eng;
-  return p->fused_bs && p->jc69_v2 && !p->pd.dbg && !p->sum_out && p->has_lnl && p->pack_epoch == e->pack_epoch;
+  // a plan that leaves its total as per-workgroup partial sums (written by the step kernel itself) chains like any other;
+  // one whose total is a launch of its own (lnl_sum_kernel) ends a chain
+  const bool sum_in_kernel = p->sum_out && p->sum_parts == e->pack_blocks;
+  return p->fused_bs && p->jc69_v2 && !p->pd.dbg && (!p->sum_out || sum_in_kernel) && p->has_lnl && p->pack_epoch == e->pack_epoch;
 }
 
 // plans[0..count) as ONE launch
@@ -1264,8 +1267,8 @@ static int chain_launch(bpa_plan * const * plans, unsigned count)
     const bpa_plan * p = plans[i];
     ChainStep & st = c.st[i];
     st.recs2 = p->pd.recs2; st.mat2 = p->pd.mat2; st.mat_length = p->pd.mat_length; st.blk_mat_off = p->pd.blk_mat_off;
-    st.site_term = p->pd.site_term; st.lnl = p->pd.lnl; st.wg_part = nullptr; st.rec2_units = p->pd.rec2_units;
-    st.flags = (p->has_mats ? 1u : 0u) | 2u | 4u;
+    st.site_term = p->pd.site_term; st.lnl = p->pd.lnl; st.wg_part = p->sum_out; st.rec2_units = p->pd.rec2_units;
+    st.flags = (p->has_mats ? 1u : 0u) | 2u | 4u | (p->sum_out ? 8u : 0u);
     bytes += p->bytes_partials + p->bytes_pmatrix;
   }
   TimingSlot * ts = nullptr;
@@ -1934,6 +1937,15 @@ extern "C" int bpa_locus_get_scaler(bpa_locus_t * l, unsigned idx, unsigned * ou
   if (!sync_for_access(l)) return 0;
   if (idx >= l->scale_buffers) return fail("scaler index out of range");
   HIPCHK(hipMemcpy(out, l->dev.scaler + (size_t)idx*l->sites, l->sites*4, hipMemcpyDeviceToHost));
+  return 1;
+}
+
+extern "C" int bpa_locus_set_scaler(bpa_locus_t * l, unsigned idx, const unsigned * in)
+{
+  std::lock_guard<std::recursive_mutex> lock_(l->eng->mtx);
+  if (!sync_for_access(l)) return 0;
+  if (idx >= l->scale_buffers) return fail("scaler index out of range");
+  HIPCHK(hipMemcpy(l->dev.scaler + (size_t)idx*l->sites, in, l->sites*4, hipMemcpyHostToDevice));
   return 1;
 }
 

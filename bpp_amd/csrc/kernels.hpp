@@ -60,6 +60,38 @@ __device__ __forceinline__ double dot_fma4(const double * __restrict__ row, cons
   return (a0 + a1) + (a2 + a3);
 }
 
+// 16-byte accesses in the GLOBAL address space: a pointer that comes out of a record is generic to the compiler, and a generic
+// (flat) access also counts against lgkmcnt — every wait for LDS or scalar data then waits for the HBM accesses in flight
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 gld2(const double * p)
+{
+  const d2v_t v = *reinterpret_cast<const __attribute__((address_space(1))) d2v_t *>(reinterpret_cast<uintptr_t>(p));
+  double2 r; r.x = v.x; r.y = v.y; return r;
+}
+__device__ __forceinline__ void gst2(double * p, const double2 v)
+{
+  d2v_t w; w.x = v.x; w.y = v.y;
+  *reinterpret_cast<__attribute__((address_space(1))) d2v_t *>(reinterpret_cast<uintptr_t>(p)) = w;
+}
+typedef uint32_t u4v_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 gld4(const uint4 * p)
+{
+  const u4v_t v = *reinterpret_cast<const __attribute__((address_space(1))) u4v_t *>(reinterpret_cast<uintptr_t>(p));
+  uint4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
+}
+template <typename T> __device__ __forceinline__ T gld(const T * p)
+{ return *reinterpret_cast<const __attribute__((address_space(1))) T *>(reinterpret_cast<uintptr_t>(p)); }
+template <typename T> __device__ __forceinline__ void gst(T * p, const T v)
+{ *reinterpret_cast<__attribute__((address_space(1))) T *>(reinterpret_cast<uintptr_t>(p)) = v; }
+
+// a workgroup barrier that orders LDS traffic only: outstanding global loads and stores are NOT waited for (a plain
+// __syncthreads() drains vmcnt, i.e. exposes the latency of every store issued before it).  For hand-overs through LDS.
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ================================================================ K1+K2, S=4 ==
 // one lane = one (task, pattern); CLV plane layout [buffer][rate][pattern][4]
 __device__ __forceinline__ void load_child4(const LocusDev & L, uint32_t clv_index, uint32_t k,
@@ -556,10 +588,6 @@ partials_lnl_tiledk_kernel(const PlanDev P)
 typedef const uint32_t __attribute__((address_space(4))) * cu32_p;
 typedef const int32_t  __attribute__((address_space(4))) * ci32_p;
 typedef const uint64_t __attribute__((address_space(4))) * cu64_p;
-__device__ __forceinline__ void lds_barrier()
-{
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 struct OpS { uint32_t parent_clv; int32_t parent_scaler; uint32_t left_clv, left_pmatrix; int32_t left_scaler; uint32_t right_clv, right_pmatrix; int32_t right_scaler; };
 __device__ __forceinline__ OpS load_op_scalar(const OpDev * ops, const uint32_t o)
 {
@@ -2326,21 +2354,25 @@ __device__ __forceinline__ void jc69_v2_fetch(const PlanDev & P, const Jc69Lane 
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
   const bool has_slot = L.ls.slot != 0xffffffffu;
   const bool do_mats = (P.flags & 1u) != 0;
-  R.e0 = do_mats ? P.blk_mat_off[b] : 0u; R.e1 = do_mats ? P.blk_mat_off[b+1] : 0u;
+  R.e0 = do_mats ? gld(P.blk_mat_off + b) : 0u; R.e1 = do_mats ? gld(P.blk_mat_off + b + 1) : 0u;
   R.m0 = MatRec2{0, 0}; R.m0_len = 0;
-  if (R.e0 + lane < R.e1) { R.m0 = P.mat2[R.e0 + lane]; R.m0_len = P.mat_length[R.e0 + lane]; }
+  if (R.e0 + lane < R.e1)
+  {
+    const u2v_t m = *reinterpret_cast<const __attribute__((address_space(1))) u2v_t *>(reinterpret_cast<uintptr_t>(P.mat2 + R.e0 + lane));
+    R.m0.slot = m.x; R.m0.pmatrix = m.y; R.m0_len = gld(P.mat_length + R.e0 + lane);
+  }
   R.c_task = 0xffffffffu;
   if ((P.flags & 4u) && lane < L.s1 - L.s0)
-    R.c_task = reinterpret_cast<const StepRec *>(P.recs2 + (size_t)(L.s0 + lane)*P.rec2_units)->task;
+    R.c_task = gld(reinterpret_cast<const uint32_t *>(P.recs2 + (size_t)(L.s0 + lane)*P.rec2_units));
   R.hdr = StepRec{};
   R.hdr.task = 0xffffffffu;
   if (has_slot && (P.flags & 6u))
   {
     const uint4 * rp = P.recs2 + (size_t)L.ls.slot*P.rec2_units;
-    *reinterpret_cast<uint4 *>(&R.hdr) = rp[0];
+    *reinterpret_cast<uint4 *>(&R.hdr) = gld4(rp);
     uint4 * ds = reinterpret_cast<uint4 *>(R.sl);
 #pragma unroll
-    for (int i = 0; i < JC69_NPRE; ++i) ds[i] = rp[1 + i];
+    for (int i = 0; i < JC69_NPRE; ++i) ds[i] = gld4(rp + 1 + i);
   }
 }
 
@@ -2376,7 +2408,7 @@ __device__ __forceinline__ void jc69_v2_compute(const PlanDev & P, const Jc69Lan
       const SlotStatic & M = P.slot_tab[R.m0.slot];
       double2 ab;
       jc69_ab(R.m0_len, M.rate0, ab.x, ab.y);
-      *reinterpret_cast<double2 *>(M.pmat + (size_t)R.m0.pmatrix*2) = ab;
+      gst2(M.pmat + (size_t)R.m0.pmatrix*2, ab);
       s_ab[lane] = ab;
     }
     for (uint32_t e = e0 + lane + BS; e < e1; e += BS)
@@ -2386,7 +2418,7 @@ __device__ __forceinline__ void jc69_v2_compute(const PlanDev & P, const Jc69Lan
       const SlotStatic & M2 = P.slot_tab[m.slot];
       double2 ab2;
       jc69_ab(P.mat_length[e], M2.rate0, ab2.x, ab2.y);
-      *reinterpret_cast<double2 *>(M2.pmat + (size_t)m.pmatrix*2) = ab2;
+      gst2(M2.pmat + (size_t)m.pmatrix*2, ab2);
       if (e - e0 < NAB) s_ab[e - e0] = ab2;
     }
   }
@@ -2419,8 +2451,8 @@ __device__ __forceinline__ void jc69_v2_compute(const PlanDev & P, const Jc69Lan
           if (op.left_clv < tips) expand_code(tips <= 8 ? (ls.tipcodes >> (4*op.left_clv)) & 15u : (uint32_t)S.tips[(size_t)op.left_clv*np + n], inl[i]);
           else
           {
-            const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((size_t)(op.left_clv - tips)*np + n)*4);
-            const double2 u = p[0], w = p[1];
+            const double * p = S.clv + ((size_t)(op.left_clv - tips)*np + n)*4;
+            const double2 u = gld2(p), w = gld2(p + 2);
             inl[i][0] = u.x; inl[i][1] = u.y; inl[i][2] = w.x; inl[i][3] = w.y;
           }
         }
@@ -2429,15 +2461,16 @@ __device__ __forceinline__ void jc69_v2_compute(const PlanDev & P, const Jc69Lan
           if (op.right_clv < tips) expand_code(tips <= 8 ? (ls.tipcodes >> (4*op.right_clv)) & 15u : (uint32_t)S.tips[(size_t)op.right_clv*np + n], inr[i]);
           else
           {
-            const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((size_t)(op.right_clv - tips)*np + n)*4);
-            const double2 u = p[0], w = p[1];
+            const double * p = S.clv + ((size_t)(op.right_clv - tips)*np + n)*4;
+            const double2 u = gld2(p), w = gld2(p + 2);
             inr[i][0] = u.x; inr[i][1] = u.y; inr[i][2] = w.x; inr[i][3] = w.y;
           }
         }
       }
     }
   }
-  if (do_mats) __syncthreads();
+  if (do_mats) __syncthreads();                 // the fresh pairs: handed over through LDS, and their HBM copies (read by later steps of a
+                                                // chain, by lanes other than the writer) are complete before anyone goes on
 
   double term = 0;
   if (work)
@@ -2446,9 +2479,9 @@ __device__ __forceinline__ void jc69_v2_compute(const PlanDev & P, const Jc69Lan
     // or the stored pair
     auto pair_of = [&](int32_t e, uint32_t pm, double & a_, double & b_)
     {
-      if (e < 0) { const double2 ab = *reinterpret_cast<const double2 *>(S.pmat + (size_t)pm*2); a_ = ab.x; b_ = ab.y; }
+      if (e < 0) { const double2 ab = gld2(S.pmat + (size_t)pm*2); a_ = ab.x; b_ = ab.y; }
       else if (do_mats && (uint32_t)e - e0 < NAB) { const double2 ab = s_ab[(uint32_t)e - e0]; a_ = ab.x; b_ = ab.y; }
-      else jc69_ab(P.mat_length[e], rate, a_, b_);
+      else jc69_ab(gld(P.mat_length + e), rate, a_, b_);
     };
     double res[NPRE][4];
     uint32_t last_clv = 0xffffffffu;
@@ -2458,15 +2491,15 @@ __device__ __forceinline__ void jc69_v2_compute(const PlanDev & P, const Jc69Lan
       if (op.parent_scaler >= 0)
       {
         uint32_t sc = 0;
-        if (op.left_scaler  >= 0) sc += S.scaler[(size_t)op.left_scaler*np  + n];
-        if (op.right_scaler >= 0) sc += S.scaler[(size_t)op.right_scaler*np + n];
+        if (op.left_scaler  >= 0) sc += gld(S.scaler + (size_t)op.left_scaler*np  + n);
+        if (op.right_scaler >= 0) sc += gld(S.scaler + (size_t)op.right_scaler*np + n);
         if (r0 < BPA_SCALE_THRESHOLD && r1 < BPA_SCALE_THRESHOLD && r2 < BPA_SCALE_THRESHOLD && r3 < BPA_SCALE_THRESHOLD)
         { r0 *= BPA_SCALE_FACTOR; r1 *= BPA_SCALE_FACTOR; r2 *= BPA_SCALE_FACTOR; r3 *= BPA_SCALE_FACTOR; sc += 1; }
-        S.scaler[(size_t)op.parent_scaler*np + n] = sc;
+        gst(S.scaler + (size_t)op.parent_scaler*np + n, sc);
       }
-      double2 * dst = reinterpret_cast<double2 *>(S.clv + ((size_t)(op.parent_clv - tips)*np + n)*4);
+      double * dst = S.clv + ((size_t)(op.parent_clv - tips)*np + n)*4;
       double2 u, w; u.x = r0; u.y = r1; w.x = r2; w.y = r3;
-      dst[0] = u; dst[1] = w;
+      gst2(dst, u); gst2(dst + 2, w);
       last_clv = op.parent_clv; last[0] = r0; last[1] = r1; last[2] = r2; last[3] = r3;
     };
 #pragma unroll
@@ -2502,15 +2535,15 @@ __device__ __forceinline__ void jc69_v2_compute(const PlanDev & P, const Jc69Lan
       else if (c < tips) expand_code(tips <= 8 ? (ls.tipcodes >> (4*c)) & 15u : (uint32_t)S.tips[(size_t)c*np + n], v);
       else
       {
-        const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((size_t)(c - tips)*np + n)*4);
-        const double2 u = p[0], w = p[1];
+        const double * p = S.clv + ((size_t)(c - tips)*np + n)*4;
+        const double2 u = gld2(p), w = gld2(p + 2);
         v[0] = u.x; v[1] = u.y; v[2] = w.x; v[3] = w.y;
       }
     };
     for (uint32_t o = NPRE; o < nops; ++o)
     {
       StepOp op;
-      *reinterpret_cast<uint4 *>(&op) = rp[1 + o];
+      *reinterpret_cast<uint4 *>(&op) = gld4(rp + 1 + o);
       double lv[4], rv[4], x[4], y[4], al, bl_, ar, br;
       vec_of(op.left_clv, lv);
       vec_of(op.right_clv, rv);
@@ -2532,25 +2565,25 @@ __device__ __forceinline__ void jc69_v2_compute(const PlanDev & P, const Jc69Lan
       double lt = log(term);
       if (hdr.root_scaler >= 0)
       {
-        const uint32_t sc = S.scaler[(size_t)hdr.root_scaler*np + n];
+        const uint32_t sc = gld(S.scaler + (size_t)hdr.root_scaler*np + n);
         if (sc) lt += sc*BPA_LOG_SCALE_THRESHOLD;
       }
       term = lt*ls.wgt;
     }
-    P.site_term[hdr.pat_off + n] = term;
+    gst(P.site_term + hdr.pat_off + n, term);
   }
 
   // ---- phase C: per-locus sum in pattern order
   if (P.flags & 4u)
   {
     s_term[lane] = term;
-    __syncthreads();
+    lds_barrier();
     if (summer && c_task != 0xffffffffu)
     {
       double logl = 0;
       if (c_unph) logl = reduce_locus(P.loci[c_locus], s_term + c_l0);
       else for (uint32_t q = 0; q < c_np; ++q) logl += s_term[c_l0 + q];
-      P.lnl[c_task] = P.bfbeta*logl;
+      gst(P.lnl + c_task, P.bfbeta*logl);
       c_lnl = P.bfbeta*logl;
     }
     // ---- partial sums of the plan's total (bpa_plan_enable_partial_sums): this workgroup's loci in slot order; the
@@ -2558,12 +2591,12 @@ __device__ __forceinline__ void jc69_v2_compute(const PlanDev & P, const Jc69Lan
     if (P.flags & 8u)
     {
       s_lnl[lane] = c_lnl;
-      __syncthreads();
+      lds_barrier();
       if (lane == 0)
       {
         double part = 0;
         for (uint32_t q = 0; q < s1 - s0; ++q) part += s_lnl[q];
-        P.wg_part[b] = part;
+        gst(P.wg_part + b, part);
       }
     }
   }
@@ -2628,7 +2661,8 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_chain_kernel(const ChainDev C
   {
     if (k + 1 < C.nsteps) { chain_plan(C, k + 1, Pn); jc69_v2_fetch<BS>(Pn, L, Rn); }    // next step's records: in flight
     jc69_v2_compute<BS>(P, L, R, s_term, s_ab, s_lnl);
-    __syncthreads();                    // the next step reuses the LDS arrays and reads this step's (a, b) pairs
+    lds_barrier();                      // the next step reuses the LDS arrays.  No wait for this step's stores: CLVs are re-read only by the
+                                        // lane that wrote them (program order), the (a, b) pairs were completed at the barrier inside the step
     P = Pn; R = Rn;
   }
 }

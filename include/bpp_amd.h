@@ -186,6 +186,8 @@ int  bpa_locus_set_clv(bpa_locus_t *, unsigned clv_index, const double * in);
 int  bpa_locus_get_pmatrix(bpa_locus_t *, unsigned pmatrix_index, double * out);
 int  bpa_locus_set_pmatrix(bpa_locus_t *, unsigned pmatrix_index, const double * in);
 int  bpa_locus_get_scaler(bpa_locus_t *, unsigned scaler_index, unsigned * out);
+/* write scale buffer `scaler_index` ([sites] counters, locus->scale_buffer[i] of locus.c:800): test access, as bpa_locus_set_clv */
+int  bpa_locus_set_scaler(bpa_locus_t *, unsigned scaler_index, const unsigned * in);
 int  bpa_locus_get_eigen(bpa_locus_t *, unsigned index, double * eigenvecs,
                          double * inv_eigenvecs, double * eigenvals);
 

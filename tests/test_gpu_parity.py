@@ -123,17 +123,23 @@ def test_golden_k1_vectors(engine):
         loc.set_clv(3, r)
         loc.set_pmatrix(0, unhex(v["lmat"], (R, S, S)))
         loc.set_pmatrix(1, unhex(v["rmat"], (R, S, S)))
-        # left scaler content: run through a trivial path — write via an op chain is not
-        # possible, so emulate: scaler 0 := lscaler by a first op on crafted inputs is
-        # overkill; instead compare against the oracle with the same (zero) child scalers
+        # the reference vector as it is: the left child carries the vector's own scale counters
+        loc.set_scaler(0, np.array(v["lscaler"], dtype=np.uint32))
+        ops = np.array([(4, 2, 2, 0, 0, 3, 1, -1)], dtype=OP_DTYPE)
+        loc.update_partials(ops)
+        p, ps = O.orc_partial(l, r, unhex(v["lmat"], (R, S, S)), unhex(v["rmat"], (R, S, S)),
+                              lscaler=np.array(v["lscaler"], dtype=np.uint32), scaling=True,
+                              order=O.ORDER_PAIR if S == 4 else O.ORDER_FMA4)
+        assert (loc.get_clv(4) == p).all()
+        assert (p == unhex(v["parent"], (n, R, S))).all()
+        assert list(loc.get_scaler(2)) == v["pscaler"] and list(ps) == v["pscaler"]
+        # and without child scalers (the counters only add)
         ops = np.array([(4, 2, 2, 0, -1, 3, 1, -1)], dtype=OP_DTYPE)
         loc.update_partials(ops)
         p, ps = O.orc_partial(l, r, unhex(v["lmat"], (R, S, S)), unhex(v["rmat"], (R, S, S)),
                               scaling=True, order=O.ORDER_PAIR if S == 4 else O.ORDER_FMA4)
         assert (loc.get_clv(4) == p).all()
         assert (loc.get_scaler(2) == ps).all()
-        # reference parent = same values (its lscaler only offsets the counters)
-        assert (p == unhex(v["parent"], (n, R, S))).all()
         assert list(ps + np.array(v["lscaler"], dtype=np.uint32)) == v["pscaler"]
         # chained scalers: parent of (4,4) adds both children's counters
         ops = np.array([(5, 3, 4, 0, 2, 4, 1, 2)], dtype=OP_DTYPE)

@@ -100,7 +100,7 @@ def test_chain_launch_equals_step_by_step(taxa, scaling, nloci):
         for st in steps:
             p = tape.plan_for_step(eng, loci, st)
             if st.global_decision is not None:
-                p.enable_partial_sums()                  # an all-loci step: its own launch, never a link of a chain
+                p.enable_partial_sums()                  # an all-loci step leaves its total as per-workgroup sums: still a link
             plans.append(p)
         if chained:
             eng.enable_timing(True)
@@ -114,11 +114,12 @@ def test_chain_launch_equals_step_by_step(taxa, scaling, nloci):
             for p in plans:
                 p.launch()
         lnl = [p.lnl() for p in plans]
+        sums = [p.lnl_sum() for st, p in zip(steps, plans) if st.global_decision is not None]
         tr = sch.trees[0]
         clv = [loci[0].get_clv(len(data[0]["seqs"]) + c) for c in range(2*(taxa - 1))]
         pm = [loci[0].get_pmatrix(c) for c in range(2*(2*taxa - 2))]
         sc = [loci[0].get_scaler(c) for c in range(2*(taxa - 1))] if scaling else []
-        runs.append((lnl, clv, pm, sc, loci[0].root_loglikelihood(tr.clv[tr.root], tr.scaler[tr.root])))
+        runs.append((lnl, clv, pm, sc, loci[0].root_loglikelihood(tr.clv[tr.root], tr.scaler[tr.root]), sums))
         for p in plans:
             p.close()
         eng.close()
@@ -128,3 +129,4 @@ def test_chain_launch_equals_step_by_step(taxa, scaling, nloci):
     assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
     assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
     assert a[4] == b[4]
+    assert len(a[5]) > 0 and a[5] == b[5]            # the all-loci steps' totals: same bits from inside a chain
