@@ -235,7 +235,7 @@ def traffic_from_profiles(config, kernel):
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"profile_{config}.json")))
         pm = json.load(open(cands[-1]))["pmc_per_dispatch"]
         want = kernel.split(" + ")[0].replace(" ", "")
-        key = [k for k in pm if want in k.replace(" ", "") and "FETCH_SIZE" in pm[k]]
+        key = [k for k in pm if want.rstrip(">") in k.replace(" ", "") and "FETCH_SIZE" in pm[k]]
         key = (key or [k for k in pm if want.split("<")[0] in k and "FETCH_SIZE" in pm[k]])[0]
         return (round((2 * pm[key]["FETCH_SIZE"]["mean"] + pm[key]["WRITE_SIZE"]["mean"]) * 1024),
                 os.path.relpath(cands[-1], ROOT) + f" ({key.split('(')[0]}; separate --pmc passes; FETCH_SIZE doubled per the gfx950 note)")

@@ -1008,7 +1008,9 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       if (d.flags & 1u)
       {
         PlanDev da = d; da.flags = 1u;
-        hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, true>), g2, dim3(PACK_BS), 0, e->stream, da);
+        static const bool pm_packed = getenv("BPA_PMAT_PACKED") != nullptr;        // A/B: the phase on the packing's workgroups
+        if (pm_packed) hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, true>), g2, dim3(PACK_BS), 0, e->stream, da);
+        else hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((d.nmat*da.pad + 255u)/256u), dim3(256), 0, e->stream, da, d.nmat);
       }
       d.flags &= 6u;
       if (d.flags)
@@ -1564,7 +1566,7 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
     if (nmat)
     {
       d.flags = 1u;
-      hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, true>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, d);
+      hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((nmat*rmax + 255u)/256u), dim3(256), 0, e->stream, d, (uint32_t)nmat);
     }
     d.flags = 2u | 4u;
     hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, d);

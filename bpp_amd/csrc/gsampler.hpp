@@ -149,6 +149,7 @@ __device__ __forceinline__ void write_par(double * par, uint32_t R, uint32_t mod
   }
 }
 
+template <uint32_t MODE>       // GArgs::mode as a compile-time constant: one instance per move (the whole kernel is 17 k instructions otherwise)
 __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
 {
   __shared__ GState s_st[GBS];
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     for (uint32_t q = lane; q < sizeof(Species)/4; q += GBS) dst[q] = src[q];
   }
   if (lane < (uint32_t)(3*MAXPOP)) s_tau[lane] = A.taus[lane];
-  if (A.mode == 1) for (uint32_t q = lane; q < (uint32_t)(NN*NN); q += GBS) s_lograt[q] = A.lograt[q];
+  if (MODE == 1) for (uint32_t q = lane; q < (uint32_t)(NN*NN); q += GBS) s_lograt[q] = A.lograt[q];
   const Species & spl = s_sp;
   LSpecies sp;
   {
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
 
   // ---- 3. the proposed species tree of an all-loci step is this workgroup's copy of the taus
   double lminf = 0, lmaxf = 0, tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1;
-  if (A.mode == 2)
+  if (MODE == 2)
   {
     const int q = (int)A.tau_q, pq = spl.parent[q];
     tq_old = s_tau[q]; tq_lo = fmax(s_tau[spl.left[q]], s_tau[spl.right[q]]); tq_hi = pq >= 0 ? s_tau[pq] : 999.0;
@@ -267,7 +268,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     if (lane == 0) s_tau[q] = tnew;
     __syncthreads();
   }
-  else if (A.mode == 3)
+  else if (MODE == 3)
   {
     if (lane < (uint32_t)npop) s_tau[lane] *= A.mix_c;
     __syncthreads();
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
 
   // ---- 4. propose
   bool evaluate = false;
-  if (valid && A.mode != 4)
+  if (valid && MODE != 4)
   {
     // the state a rejection comes back to
     {
@@ -288,9 +289,9 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     Prof pf; pf.on = false; pf.t = 0;
     double hast = 0;
     bool ok = true;
-    if (A.mode == 0)      ok = smp::propose_gage<NT>(S, T, cn, tu, hast, (int)A.k, sp, spl, s_tau, pf);
-    else if (A.mode == 1) ok = smp::propose_gspr<NT>(S, T, cn, tu, hast, (int)A.k, sp, spl, s_tau, s_lograt, pf);
-    else if (A.mode == 2)
+    if (MODE == 0)      ok = smp::propose_gage<NT>(S, T, cn, tu, hast, (int)A.k, sp, spl, s_tau, pf);
+    else if (MODE == 1) ok = smp::propose_gspr<NT>(S, T, cn, tu, hast, (int)A.k, sp, spl, s_tau, s_lograt, pf);
+    else if (MODE == 2)
     {
       // TAU q (tau_step of a00_driver.c): the gene nodes of q and its children between the bounds move
       const int nn_ = 2*T.tips - 1, q = (int)A.tau_q, cl = sp.left[q], cr = sp.right[q];
@@ -310,14 +311,14 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
       if (ndm) smp::install<NT>(S, T, brm, ndm);
       else { S.brm = 0; S.nops = 0; ok = false; }                              // no gene node moves here: only the density changes
     }
-    else if (A.mode >= 6)
+    else if (MODE >= 6)
     {
       // a substitution-parameter move (param_step of a00_driver.c): new value, then every branch, every inner node
       double * m = A.sm + (size_t)i*11;
-      if (A.mode == 8 && L.R < 2) ok = false;
+      if (MODE == 8 && L.R < 2) ok = false;
       else
       {
-        if (A.mode == 8)
+        if (MODE == 8)
         {
           const double a_old = m[10], la_old = log(a_old);
           const double la_new = reflect(la_old + A.ft_alpha*(rndu(&T.rng) - 0.5), -99.0, 99.0);
@@ -328,11 +329,11 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
         }
         else
         {
-          double * v = A.mode == 6 ? m : m + 4;
-          const int j = (int)A.k, ref = A.mode == 6 ? 3 : 1;
+          double * v = MODE == 6 ? m : m + 4;
+          const int j = (int)A.k, ref = MODE == 6 ? 3 : 1;
           const double sum = v[j] + v[ref], lo = log(1e-5), hi = log(sum);
           const double l_old = log(v[j]);
-          const double l_new = reflect(l_old + (A.mode == 6 ? A.ft_freqs : A.ft_qrates)*(rndu(&T.rng) - 0.5), lo, hi);
+          const double l_new = reflect(l_old + (MODE == 6 ? A.ft_freqs : A.ft_qrates)*(rndu(&T.rng) - 0.5), lo, hi);
           A.sm_old[2*i] = v[j]; A.sm_old[2*i + 1] = v[ref];
           v[j] = exp(l_new); v[ref] = sum - v[j];
           hast = l_new - l_old;
@@ -357,10 +358,10 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
       uint32_t brm = 0, ndm = 0; int ninner = 0;
       for (int k = 0; k < nn_; ++k)
       {
-        if (T.left[k] >= 0) { if (A.mode == 3) S.time[k] *= A.mix_c; ndm |= 1u << k; ++ninner; }
+        if (T.left[k] >= 0) { if (MODE == 3) S.time[k] *= A.mix_c; ndm |= 1u << k; ++ninner; }
         if (T.parent[k] >= 0) brm |= 1u << k;
       }
-      if (A.mode == 5)
+      if (MODE == 5)
       {
         for (uint32_t m = brm; m; m &= m - 1) smp::swap_pmat(T, __ffs(m) - 1);       // start-up evaluates in place:
         for (uint32_t m = ndm; m; m &= m - 1) smp::swap_clv(T, __ffs(m) - 1);        // toggle twice = no toggle
@@ -370,12 +371,12 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
       A.delta[i] = (lp_new - logpr_cur) + (double)ninner*A.mix_lnc;
       smp::install<NT>(S, T, brm, ndm);
     }
-    if (ok && A.mode <= 1)
+    if (ok && MODE <= 1)
     {
       A.logpr_new[i] = gdensity(S, T, cn, sp, spl, s_tau, nullptr, nullptr, 0);
       A.hast[i] = hast;
     }
-    if (ok && A.mode != 5) { w_nupd += (uint32_t)S.nops; w_nbr += (uint32_t)__popc(S.brm); ++w_nev; }
+    if (ok && MODE != 5) { w_nupd += (uint32_t)S.nops; w_nbr += (uint32_t)__popc(S.brm); ++w_nev; }
     evaluate = ok;
     A.active[i] = ok ? 1 : 0;
   }
@@ -388,7 +389,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     for (int pass = 0; pass < 2; ++pass)
     {
       const bool on = pass == 0 ? restore_par : propose_par;
-      const uint32_t md = pass == 0 ? A.pend_mode : A.mode;
+      const uint32_t md = pass == 0 ? A.pend_mode : MODE;
       if (!on) continue;
       // (restored and proposed component may be the same one: this order leaves the proposal in the block.  NB the
       //  values of `m` are final here — a restored component and a newly proposed one never overlap in time)
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
   }
 
   // ---- 5. the step's records for the engine's kernels
-  if (valid && A.mode != 4)
+  if (valid && MODE != 4)
   {
     uint4 * rec = A.recs2 + (size_t)L.slot*A.units;
     MatRec2 * m2 = A.mat2 + (size_t)L.slot*A.maxmat;
@@ -438,7 +439,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
   }
 
   // ---- 6. mode 4: the sufficient statistics of the settled state, for the THETA kernel
-  if (valid && A.mode == 4) (void)gdensity(S, T, cn, sp, spl, s_tau, A.pop_nc + i, A.pop_t2h + i, A.T);
+  if (valid && MODE == 4) (void)gdensity(S, T, cn, sp, spl, s_tau, A.pop_nc + i, A.pop_t2h + i, A.T);
 
   // ---- 7. store
   if (valid)

@@ -99,7 +99,16 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   // a frequency / exchangeability step — proposed now, or rolled back now for the loci that rejected it — leaves
   // parameter blocks whose eigensystems are stale: refreshed before the next evaluation (gs_eval)
   if (mode == 6 || mode == 7 || (s->g_pend == 4 && (s->g_pend_mode == 6 || s->g_pend_mode == 7))) s->g_eigen_dirty = true;
-  hipLaunchKernelGGL(gsm::gstep_kernel, dim3((s->nloci + gsm::GBS - 1)/gsm::GBS), dim3(gsm::GBS), 0, e->stream, a);
+  {
+    const dim3 grid((s->nloci + gsm::GBS - 1)/gsm::GBS), block(gsm::GBS);
+    switch (a.mode)
+    {
+#define GS_CASE(M_) case M_: hipLaunchKernelGGL(gsm::gstep_kernel<M_>, grid, block, 0, e->stream, a); break
+      GS_CASE(0); GS_CASE(1); GS_CASE(2); GS_CASE(3); GS_CASE(4); GS_CASE(5); GS_CASE(6); GS_CASE(7); GS_CASE(8);
+#undef GS_CASE
+      default: return fail("bpa_sampler: unknown step mode");
+    }
+  }
   HIPCHK(hipGetLastError());
   static const bool dbg_sync = getenv("BPA_GS_SYNC") != nullptr;        // diagnostics: wait for every launch and say which it was
   if (dbg_sync) { HIPCHK(hipStreamSynchronize(e->stream)); fprintf(stderr, "[gs] step mode %u k %u pend %u done\n", mode, k, a.pend); }
@@ -148,7 +157,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
   {
     d.pad = s->g_rmax;
     d.flags = 1u;
-    hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, true>), grid, block, 0, e->stream, d);
+    hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((d.nmat*d.pad + 255u)/256u), dim3(256), 0, e->stream, d, d.nmat);
     d.flags = 2u | 4u;
     hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), grid, block, 0, e->stream, k0, k1, 0, d);
     s->launches += 2;

@@ -2673,6 +2673,26 @@ __global__ void __launch_bounds__(BS) step_jc69_v2_chain_kernel(const ChainDev C
 // A/B switch of the staging below: flags bit 4 = every lane fetches its matrices itself (BPA_KLANE_DIRECT=1)
 __device__ __forceinline__ bool getenv_klane_direct(const PlanDev & P) { return (P.flags & 16u) != 0; }
 
+// The P-matrix phase of the compact-record path as a DENSE grid: one lane per (fresh branch entry, rate category).
+// step_s4_klane_v2_kernel<.., true> walks the entries workgroup by workgroup of the engine's packing — a workgroup there
+// is 256 (pattern, category) lanes = two or three loci, i.e. ~40 entries for 256 lanes, and every mostly-empty wave still
+// runs the whole eigen / closed-form code: config 3 measured 27 us per step at 16 % lane use.  Nothing in this phase needs
+// the packing (entries carry their slot), so the lanes are dealt out over the entries themselves.
+__global__ void __launch_bounds__(256) pmatrix_s4_dense_kernel(const PlanDev P, const uint32_t nent)
+{
+  const uint32_t rmax = P.pad, i = blockIdx.x*256u + threadIdx.x;
+  const uint32_t e = i/rmax, k = i % rmax;
+  if (e >= nent) return;
+  const u2v_t mm = *reinterpret_cast<const __attribute__((address_space(1))) u2v_t *>(reinterpret_cast<uintptr_t>(P.mat2 + e));
+  if (mm.x == 0xffffffffu) return;                           // a hole of a device-written step image (gsampler.hpp)
+  const SlotStatic & M = P.slot_tab[mm.x];
+  const uint32_t R = M.rate_cats;
+  if (k >= R) return;
+  MatRec m;
+  m.dst = M.pmat + (size_t)mm.y*R*M.pstride; m.par = M.par; m.rate_cats = R; m.model = M.model; m.entry = e; m.pad = 0;
+  pmatrix_s4_rec(m, P.mat_length, k);
+}
+
 template <int BS, bool WITH_A, int OCC = 0>        // OCC: waves per SIMD the register allocation is held to (0: the compiler's choice)
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(OCC ? OCC : 1, OCC ? OCC : 8)))
 step_s4_klane_v2_kernel(const PlanDev P)
@@ -2773,9 +2793,10 @@ step_s4_klane_v2_kernel(const PlanDev P)
       else if (c < tips) expand_code(tips <= 8 ? (ls.tipcodes >> (4*c)) & 15u : (uint32_t)S.tips[(size_t)c*np + n], v);
       else
       {
-        const double2 * p = reinterpret_cast<const double2 *>(S.clv + ((((size_t)(c - tips)*R) + k)*np + n)*4);
         typedef double d2v __attribute__((ext_vector_type(2)));
-        const d2v uu = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p)), ww = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p) + 1);
+        const __attribute__((address_space(1))) d2v * p = reinterpret_cast<const __attribute__((address_space(1))) d2v *>(
+            reinterpret_cast<uintptr_t>(S.clv + ((((size_t)(c - tips)*R) + k)*np + n)*4));
+        const d2v uu = __builtin_nontemporal_load(p), ww = __builtin_nontemporal_load(p + 1);
         double2 u, w; u.x = uu.x; u.y = uu.y; w.x = ww.x; w.y = ww.y;
         v[0] = u.x; v[1] = u.y; v[2] = w.x; v[3] = w.y;
       }
@@ -2792,9 +2813,9 @@ step_s4_klane_v2_kernel(const PlanDev P)
           if (o < st_nops)
           {
             StepOp so;
-            *reinterpret_cast<uint4 *>(&so) = st_rp[1 + o];
+            *reinterpret_cast<uint4 *>(&so) = gld4(st_rp + 1 + o);
             const uint32_t c = wl & 15u, pm = c < 8u ? so.left_pmatrix : so.right_pmatrix;
-            s_pm[wave][wl >> 4][c] = *reinterpret_cast<const double2 *>(st_pmat + ((size_t)pm*st_R + st_k)*16 + (size_t)(c & 7u)*2);
+            s_pm[wave][wl >> 4][c] = gld2(st_pmat + ((size_t)pm*st_R + st_k)*16 + (size_t)(c & 7u)*2);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -2803,7 +2824,7 @@ step_s4_klane_v2_kernel(const PlanDev P)
         if (o < nops)
         {
           StepOp op;
-          *reinterpret_cast<uint4 *>(&op) = rp[1 + o];
+          *reinterpret_cast<uint4 *>(&op) = gld4(rp + 1 + o);
           double lv[4], rv[4], x[4], y[4];
           vec_of(op.left_clv, lv);
           vec_of(op.right_clv, rv);
@@ -2832,9 +2853,10 @@ step_s4_klane_v2_kernel(const PlanDev P)
           }
           double2 o0, o1;
           o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
-          double2 * dst = reinterpret_cast<double2 *>(S.clv + ((((size_t)(op.parent_clv - tips)*R) + k)*np + n)*4);
           { typedef double d2v __attribute__((ext_vector_type(2))); d2v a0, a1; a0.x = o0.x; a0.y = o0.y; a1.x = o1.x; a1.y = o1.y;
-            __builtin_nontemporal_store(a0, reinterpret_cast<d2v *>(dst)); __builtin_nontemporal_store(a1, reinterpret_cast<d2v *>(dst) + 1); }
+            __attribute__((address_space(1))) d2v * dst = reinterpret_cast<__attribute__((address_space(1))) d2v *>(
+                reinterpret_cast<uintptr_t>(S.clv + ((((size_t)(op.parent_clv - tips)*R) + k)*np + n)*4));
+            __builtin_nontemporal_store(a0, dst); __builtin_nontemporal_store(a1, dst + 1); }
           fwd[0] = o0.x; fwd[1] = o0.y; fwd[2] = o1.x; fwd[3] = o1.y;
           fwd_clv = op.parent_clv;
         }
@@ -2866,7 +2888,7 @@ step_s4_klane_v2_kernel(const PlanDev P)
     const double * par = S.par;
     for (uint32_t q = 0; q < R; ++q) term += s_tr[lane + q*np]*par[par_rate_weights(R) + q];
     term = log(term)*ls.wgt;
-    P.site_term[hdr.pat_off + n] = term;
+    gst(P.site_term + hdr.pat_off + n, term);
   }
   if (!(P.flags & 4u)) return;
 
