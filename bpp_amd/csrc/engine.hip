@@ -561,7 +561,11 @@ static int flush_state(bpa_engine * e)
     if (!e->d_eigen_list.reserve(eig.size())) return fail("out of device memory (eigen list)");
     HIPCHK(hipMemcpy(e->d_eigen_list.p, eig.data(), eig.size()*4, hipMemcpyHostToDevice));
     const unsigned blocks = (unsigned)((eig.size() + 63)/64);
-    hipLaunchKernelGGL(eigen_kernel, dim3(blocks), dim3(64), 0, e->stream, e->d_loci.p, e->d_eigen_list.p, (uint32_t)eig.size());
+    bool all4 = true, all20 = true;
+    for (uint32_t id : eig) { all4 = all4 && e->loci[id]->states == 4; all20 = all20 && e->loci[id]->states == 20; }
+    if (all4)       hipLaunchKernelGGL(eigen_kernel<4>,  dim3(blocks), dim3(64), 0, e->stream, e->d_loci.p, e->d_eigen_list.p, (uint32_t)eig.size());
+    else if (all20) hipLaunchKernelGGL(eigen_kernel<20>, dim3(blocks), dim3(64), 0, e->stream, e->d_loci.p, e->d_eigen_list.p, (uint32_t)eig.size());
+    else            hipLaunchKernelGGL(eigen_kernel<0>,  dim3(blocks), dim3(64), 0, e->stream, e->d_loci.p, e->d_eigen_list.p, (uint32_t)eig.size());
     HIPCHK(hipGetLastError());
   }
   return 1;
@@ -1372,8 +1376,14 @@ static int plan_set_params(bpa_plan * p, int which, const double * host_values, 
     dev_values = p->param_stage.p;
   }
   else for (unsigned t = 0; t < T; ++t) e->loci[p->h_locus[t]]->host_par_stale = true;      // the device block is ahead of the mirror
-  hipLaunchKernelGGL(params_install_kernel, dim3((T + 63)/64), dim3(64), 0, e->stream, e->d_loci.p, p->task_locus.p, T,
-                     (uint32_t)which, dev_values, len);
+  {
+    bool all4 = true, all20 = true;
+    for (unsigned t = 0; t < T; ++t) { const unsigned S = e->loci[p->h_locus[t]]->states; all4 = all4 && S == 4; all20 = all20 && S == 20; }
+    const dim3 grid((T + 63)/64), block(64);
+    if (all4)       hipLaunchKernelGGL(params_install_kernel<4>,  grid, block, 0, e->stream, e->d_loci.p, p->task_locus.p, T, (uint32_t)which, dev_values, len);
+    else if (all20) hipLaunchKernelGGL(params_install_kernel<20>, grid, block, 0, e->stream, e->d_loci.p, p->task_locus.p, T, (uint32_t)which, dev_values, len);
+    else            hipLaunchKernelGGL(params_install_kernel<0>,  grid, block, 0, e->stream, e->d_loci.p, p->task_locus.p, T, (uint32_t)which, dev_values, len);
+  }
   HIPCHK(hipGetLastError());
   return 1;
 }

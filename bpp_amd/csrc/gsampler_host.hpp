@@ -126,7 +126,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
   if (s->g_eigen_dirty)
   {
     // K6 for every locus of the sampler from the values now in its parameter block (pll_update_eigen, locus.c:2462-2476)
-    hipLaunchKernelGGL(eigen_kernel, dim3((s->nloci + 63)/64), dim3(64), 0, e->stream, e->d_loci.p, s->g_ids.p, (uint32_t)s->nloci);
+    hipLaunchKernelGGL(eigen_kernel<4>, dim3((s->nloci + 63)/64), dim3(64), 0, e->stream, e->d_loci.p, s->g_ids.p, (uint32_t)s->nloci);     // the generic sampler's loci are 4-state
     HIPCHK(hipGetLastError());
     s->g_eigen_dirty = false;
     s->launches++;

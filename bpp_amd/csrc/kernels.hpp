@@ -3271,16 +3271,19 @@ __device__ void update_eigen_dev(const double * __restrict__ freqs, const double
 }
 
 // refresh the eigensystems of the listed loci (locus.c:2462-2476)
+// SK = 4 / 20: every listed locus has that many states (the instance carries only that eigensolver: the 20-state one needs
+// 10 KB of scratch per lane, which the all-in-one kernel reserved for 4-state loci too); SK = 0: mixed list
+template <int SK>
 __global__ void __launch_bounds__(64) eigen_kernel(const LocusDev * loci, const uint32_t * list, uint32_t count)
 {
   const uint32_t i = blockIdx.x*64 + threadIdx.x;
   if (i >= count) return;
   const LocusDev & L = loci[list[i]];
-  const uint32_t R = L.rate_cats, S = L.states;
+  const uint32_t R = L.rate_cats, S = SK ? (uint32_t)SK : L.states;
   for (uint32_t m = 0; m < L.rate_matrices; ++m)
   {
     double * pm = L.par + par_matrix(R, S, m);
-    if (S == 4)
+    if (SK == 4 || (SK == 0 && S == 4))
       update_eigen_dev<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
     else
       update_eigen_dev<20>(pm + pm_freqs(20), pm + pm_subst(20), pm + pm_evals(20), pm + pm_evecs(20), pm + pm_ievecs(20));
@@ -3291,21 +3294,22 @@ __global__ void __launch_bounds__(64) eigen_kernel(const LocusDev * loci, const 
 // new values (which: 1 base frequencies of rate matrix 0, 2 its exchangeabilities, 4 category rates) in the
 // locus's parameter block and, when the rate matrix changed, refreshes its eigensystem in place
 // (pll_update_eigen on the next locus_update_matrices, locus.c:2462-2476) — K6 on the device, no host trip.
+template <int SK>                                 // as eigen_kernel: the state count of every locus of the plan, or 0
 __global__ void __launch_bounds__(64) params_install_kernel(const LocusDev * loci, const uint32_t * task_locus, uint32_t ntasks,
                                                            uint32_t which, const double * __restrict__ values, uint32_t len)
 {
   const uint32_t t = blockIdx.x*64 + threadIdx.x;
   if (t >= ntasks) return;
   const LocusDev & L = loci[task_locus[t]];
-  const uint32_t R = L.rate_cats, S = L.states;
+  const uint32_t R = L.rate_cats, S = SK ? (uint32_t)SK : L.states;
   const double * v = values + (size_t)t*len;
   double * pm = L.par + par_matrix(R, S, 0);
   if (which == 4u) { for (uint32_t k = 0; k < R; ++k) L.par[par_rates(R) + k] = v[k]; return; }
   if (which == 1u) for (uint32_t i = 0; i < S; ++i) pm[pm_freqs(S) + i] = v[i];
   if (which == 2u) for (uint32_t i = 0; i < S*(S-1)/2; ++i) pm[pm_subst(S) + i] = v[i];
   if (L.model == 0) return;                       // JC69: no eigensystem
-  if (S == 4) update_eigen_dev<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
-  else        update_eigen_dev<20>(pm + pm_freqs(20), pm + pm_subst(20), pm + pm_evals(20), pm + pm_evecs(20), pm + pm_ievecs(20));
+  if (SK == 4 || (SK == 0 && S == 4)) update_eigen_dev<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
+  else                                update_eigen_dev<20>(pm + pm_freqs(20), pm + pm_subst(20), pm + pm_evals(20), pm + pm_evecs(20), pm + pm_ievecs(20));
 }
 
 // pll_update_eigen over staged arrays (bpa_update_eigen)
