@@ -1014,7 +1014,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
         PlanDev da = d; da.flags = 1u;
         static const bool pm_packed = getenv("BPA_PMAT_PACKED") != nullptr;        // A/B: the phase on the packing's workgroups
         if (pm_packed) hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, true>), g2, dim3(PACK_BS), 0, e->stream, da);
-        else hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((d.nmat*da.pad + 255u)/256u), dim3(256), 0, e->stream, da, d.nmat);
+        else hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((d.nmat*std::max(da.pad, 1u) + 255u)/256u), dim3(256), 0, e->stream, da, d.nmat);
       }
       d.flags &= 6u;
       if (d.flags)

@@ -2680,7 +2680,7 @@ __device__ __forceinline__ bool getenv_klane_direct(const PlanDev & P) { return 
 // the packing (entries carry their slot), so the lanes are dealt out over the entries themselves.
 __global__ void __launch_bounds__(256) pmatrix_s4_dense_kernel(const PlanDev P, const uint32_t nent)
 {
-  const uint32_t rmax = P.pad, i = blockIdx.x*256u + threadIdx.x;
+  const uint32_t rmax = P.pad ? P.pad : 1u, i = blockIdx.x*256u + threadIdx.x;
   const uint32_t e = i/rmax, k = i % rmax;
   if (e >= nent) return;
   const u2v_t mm = *reinterpret_cast<const __attribute__((address_space(1))) u2v_t *>(reinterpret_cast<uintptr_t>(P.mat2 + e));
