@@ -216,9 +216,12 @@ def make_loci(eng, data):
     return loci
 
 
-def dominant_kernel(cfg):
+def dominant_kernel(cfg, one_gpu=True):
     if cfg["model"] == "jc69":
-        return "step_jc69_v2_chain_kernel<256> + step_jc69_v2_kernel<256>" if not os.environ.get("BPA_NO_CHAIN") else "step_jc69_v2_kernel<256>"
+        if os.environ.get("BPA_NO_CHAIN"):
+            return "step_jc69_v2_kernel<256>"
+        # one GPU: the whole iteration is one chain launch; several: the chain breaks at the steps whose sums are exchanged
+        return "step_jc69_v2_chain_kernel<256>" if one_gpu else "step_jc69_v2_chain_kernel<256> + step_jc69_v2_kernel<256>"
     if cfg["model"] == "gtr":
         return "step_s4_klane_v2_kernel<256,false>"
     k = os.environ.get("BPA_S20_KERNEL", "pipe")
@@ -466,7 +469,7 @@ def run_tape(eng, cfg, config_key, data, loci, args, D, steps, warmup):
     if tm and tm["launches"]:
         # achieved = algorithmic bytes of the kernels the events bracketed / their time: the chain
         # and step kernels (K4 + K1 + K2) for JC69, the K1 + K2 kernel where the P-matrix phase is its own launch
-        kern = dominant_kernel(cfg)
+        kern = dominant_kernel(cfg, D is None)
         achieved = tm["bytes"] / (tm["partials_ms"] * 1e-3) / 1e9
         traffic, src = traffic_from_profiles(config_key, kern) if args.loci is None else (None, None)
         roofline = dict(bound="hbm", kernel=kern, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
