@@ -58,6 +58,21 @@ def plan_for_step(engine, loci, step):
                         step.mat_length, step.op_off, step.ops, step.root_clv, step.root_scaler)
 
 
+def root_lnl_all(engine, loci, sch):
+    """the root term of every locus on the schedule's current trees as ONE batched launch with empty matrix and
+    update lists: what locus_root_loglikelihood (locus.c:2573) returns for the CLVs that are there"""
+    n = len(loci)
+    zeros = np.zeros(n + 1, dtype=np.uint32)
+    p = bpp_amd.Plan(engine, list(loci), zeros, np.zeros(0, dtype=np.uint32), np.zeros(0), zeros,
+                     np.zeros(0, dtype=bpp_amd.OP_DTYPE),
+                     np.array([t.clv[t.root] for t in sch.trees], dtype=np.uint32),
+                     np.array([t.scaler[t.root] for t in sch.trees], dtype=np.int32))
+    p.launch()
+    v = p.lnl()
+    p.close()
+    return v
+
+
 def locus_subtape(steps, li):
     """the steps that involve locus li, flattened for ref_run_tape / oracle replay"""
     out = []
