@@ -1129,6 +1129,8 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     else if (p->ntiles && p->s20_tiledk)
     {
       d.flags = 4u; d.pad = p->rmax;
+      static const bool no_xcd = getenv("BPA_NO_XCD_MAP") != nullptr;       // A/B: workgroup b = tile b
+      if (no_xcd) d.flags |= 32u;
       const size_t lds = ((size_t)2*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double);
       const dim3 grid(p->ntiles), block(64*p->rmax);
       const size_t lds2 = ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double);

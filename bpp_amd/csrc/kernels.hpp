@@ -85,6 +85,15 @@ template <typename T> __device__ __forceinline__ T gld(const T * p)
 template <typename T> __device__ __forceinline__ void gst(T * p, const T v)
 { *reinterpret_cast<__attribute__((address_space(1))) T *>(reinterpret_cast<uintptr_t>(p)) = v; }
 
+// XCD-aware workgroup -> tile mapping (MI355X: 8 XCDs, each with its own L2; workgroup b is dispatched to XCD b % 8):
+// consecutive TILES go to the same XCD, so workgroups that share inputs (the tiles of one locus share its P-matrices)
+// find them in that XCD's L2 instead of fetching them once per XCD
+__device__ __forceinline__ uint32_t xcd_tile(const uint32_t b, const uint32_t nb)
+{
+  const uint32_t per = nb >> 3;
+  return b < (per << 3) ? (b & 7u)*per + (b >> 3) : b;
+}
+
 // a workgroup barrier that orders LDS traffic only: outstanding global loads and stores are NOT waited for (a plain
 // __syncthreads() drains vmcnt, i.e. exposes the latency of every store issued before it).  For hand-overs through LDS.
 __device__ __forceinline__ void lds_barrier()
@@ -641,7 +650,7 @@ partials_lnl_pipe20_kernel(const PlanDev P)
 {
   extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2 buffers][2 children][R][S][S], then [R][64] scratch
   constexpr uint32_t SS = S*S;
-  const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
+  const uint32_t b = (P.flags & 32u) ? blockIdx.x : xcd_tile(blockIdx.x, gridDim.x), lane = threadIdx.x & 63u, nw = blockDim.x >> 6;     // flags bit 5: plain mapping (A/B)
   const uint32_t k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t t = ((cu32_p)P.tile_task)[b];
   const uint32_t n = ((cu32_p)P.tile_n0)[b] + lane;
