@@ -116,10 +116,11 @@ __device__ __forceinline__ double gdensity_term(const GState & S, const Species 
 }
 
 // the whole density, populations in order (tree_logpr of a00_driver.c); optionally leaves the THETA statistics
-__device__ double gdensity(GState & S, const LTree<NT> & T, LCounts & cn, const LSpecies & sp, const Species & spl, const double * tau,
+template <int TT>
+__device__ double gdensity(GState & S, const LTree<TT> & T, LCounts & cn, const LSpecies & sp, const Species & spl, const double * tau,
                            int8_t * nc_out, double * t2h_out, uint32_t stride)
 {
-  smp::density_prepare<NT>(S, T, cn, sp, (1u << sp.npop) - 1u);
+  smp::density_prepare<TT>(S, T, cn, sp, (1u << sp.npop) - 1u);
   double logpr = 0;
   for (int p = 0; p < sp.npop; ++p)
   {
@@ -149,12 +150,15 @@ __device__ __forceinline__ void write_par(double * par, uint32_t R, uint32_t mod
   }
 }
 
-template <uint32_t MODE>       // GArgs::mode as a compile-time constant: one instance per move (the whole kernel is 17 k instructions otherwise)
+// MODE: GArgs::mode as a compile-time constant, one instance per move (the whole kernel is 17 k instructions otherwise);
+// TT: a bound on the tips of the sampler's loci (8 or 16) — the register trees and the unrolled node passes are sized by it
+template <uint32_t MODE, int TT>
 __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
 {
   __shared__ GState s_st[GBS];
   __shared__ double s_tau[3*MAXPOP];
-  __shared__ double s_lograt[NN*NN];
+  constexpr int TN = 2*TT;
+  __shared__ double s_lograt[TN*TN];
   __shared__ Species s_sp;
   const uint32_t lane = threadIdx.x, i = blockIdx.x*GBS + lane;
   const bool valid = i < A.T;
@@ -164,7 +168,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     for (uint32_t q = lane; q < sizeof(Species)/4; q += GBS) dst[q] = src[q];
   }
   if (lane < (uint32_t)(3*MAXPOP)) s_tau[lane] = A.taus[lane];
-  if (MODE == 1) for (uint32_t q = lane; q < (uint32_t)(NN*NN); q += GBS) s_lograt[q] = A.lograt[q];
+  if (MODE == 1) for (uint32_t q = lane; q < (uint32_t)(TN*TN); q += GBS) s_lograt[q] = A.lograt[(q/TN)*NN + q % TN];
   const Species & spl = s_sp;
   LSpecies sp;
   {
@@ -178,7 +182,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
   }
   const int npop = sp.npop;
   GState & S = s_st[lane];
-  LTree<NT> T;
+  LTree<TT> T;
   LCounts cn;
   for (int k = 0; k < 4; ++k) cn.nin.w[k] = cn.nc.w[k] = cn.nin_new.w[k] = cn.nc_new.w[k] = cn.gl.w[k] = 0u;
   T.time = S.time; T.rng = 0; T.root = 0; T.tips = 2;
@@ -190,7 +194,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     GTree & g = A.trees[i];
     L = A.loc[i];
     T.left.load(g.left); T.right.load(g.right); T.parent.load(g.parent); T.clv.load(g.clv); T.pmat.load(g.pmat); T.pop.load(g.pop);
-    for (int k = 0; k < NN; ++k) S.time[k] = g.time[k];
+    for (int k = 0; k < TN; ++k) S.time[k] = g.time[k];
     T.rng = g.rng; T.root = g.root; T.tips = g.tips;
     lnl_cur = g.lnl; logpr_cur = g.logpr; nprop = g.proposals; nacc = g.accepted; w_nupd = g.work_nupd; w_nbr = g.work_nbr; w_nev = g.work_neval;
     const uint4 g4 = *reinterpret_cast<const uint4 *>(L.gl), n4 = *reinterpret_cast<const uint4 *>(L.nin);
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     {
       const GTree & u = A.undo[i];
       T.left.load(u.left); T.right.load(u.right); T.parent.load(u.parent); T.clv.load(u.clv); T.pmat.load(u.pmat); T.pop.load(u.pop);
-      for (int k = 0; k < NN; ++k) S.time[k] = u.time[k];
+      for (int k = 0; k < TN; ++k) S.time[k] = u.time[k];
       T.root = u.root;
     }
   }
@@ -282,15 +286,15 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
     {
       GTree & u = A.undo[i];
       T.left.store(u.left); T.right.store(u.right); T.parent.store(u.parent); T.clv.store(u.clv); T.pmat.store(u.pmat); T.pop.store(u.pop);
-      for (int k = 0; k < NN; ++k) u.time[k] = S.time[k];
+      for (int k = 0; k < TN; ++k) u.time[k] = S.time[k];
       u.root = T.root;
     }
     TimeUndo tu{0, 0, 0, -1, -1, -1};
     Prof pf; pf.on = false; pf.t = 0;
     double hast = 0;
     bool ok = true;
-    if (MODE == 0)      ok = smp::propose_gage<NT>(S, T, cn, tu, hast, (int)A.k, sp, spl, s_tau, pf);
-    else if (MODE == 1) ok = smp::propose_gspr<NT>(S, T, cn, tu, hast, (int)A.k, sp, spl, s_tau, s_lograt, pf);
+    if (MODE == 0)      ok = smp::propose_gage<TT>(S, T, cn, tu, hast, (int)A.k, sp, spl, s_tau, pf);
+    else if (MODE == 1) ok = smp::propose_gspr<TT>(S, T, cn, tu, hast, (int)A.k, sp, spl, s_tau, s_lograt, pf);
     else if (MODE == 2)
     {
       // TAU q (tau_step of a00_driver.c): the gene nodes of q and its children between the bounds move
@@ -308,7 +312,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
       const double lp_new = gdensity(S, T, cn, sp, spl, s_tau, nullptr, nullptr, 0);
       A.logpr_new[i] = lp_new;
       A.delta[i] = ((lp_new - logpr_cur) + below*lminf) + above*lmaxf;          // p_delta of the host driver
-      if (ndm) smp::install<NT>(S, T, brm, ndm);
+      if (ndm) smp::install<TT>(S, T, brm, ndm);
       else { S.brm = 0; S.nops = 0; ok = false; }                              // no gene node moves here: only the density changes
     }
     else if (MODE >= 6)
@@ -348,7 +352,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
         }
         A.hast[i] = hast;
         A.logpr_new[i] = logpr_cur;
-        smp::install<NT>(S, T, brm, ndm);
+        smp::install<TT>(S, T, brm, ndm);
       }
     }
     else
@@ -369,7 +373,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
       const double lp_new = gdensity(S, T, cn, sp, spl, s_tau, nullptr, nullptr, 0);
       A.logpr_new[i] = lp_new;
       A.delta[i] = (lp_new - logpr_cur) + (double)ninner*A.mix_lnc;
-      smp::install<NT>(S, T, brm, ndm);
+      smp::install<TT>(S, T, brm, ndm);
     }
     if (ok && MODE <= 1)
     {
@@ -446,7 +450,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
   {
     GTree & g = A.trees[i];
     T.left.store(g.left); T.right.store(g.right); T.parent.store(g.parent); T.clv.store(g.clv); T.pmat.store(g.pmat); T.pop.store(g.pop);
-    for (int k = 0; k < NN; ++k) g.time[k] = S.time[k];
+    for (int k = 0; k < TN; ++k) g.time[k] = S.time[k];
     g.rng = T.rng; g.root = T.root; g.lnl = lnl_cur; g.logpr = logpr_cur; g.proposals = nprop; g.accepted = nacc;
     g.work_nupd = w_nupd; g.work_nbr = w_nbr; g.work_neval = w_nev;
   }

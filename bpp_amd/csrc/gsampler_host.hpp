@@ -103,7 +103,8 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
     const dim3 grid((s->nloci + gsm::GBS - 1)/gsm::GBS), block(gsm::GBS);
     switch (a.mode)
     {
-#define GS_CASE(M_) case M_: hipLaunchKernelGGL(gsm::gstep_kernel<M_>, grid, block, 0, e->stream, a); break
+#define GS_CASE(M_) case M_: if (s->maxtips <= 8) hipLaunchKernelGGL((gsm::gstep_kernel<M_, 8>), grid, block, 0, e->stream, a); \
+                            else                 hipLaunchKernelGGL((gsm::gstep_kernel<M_, 16>), grid, block, 0, e->stream, a); break
       GS_CASE(0); GS_CASE(1); GS_CASE(2); GS_CASE(3); GS_CASE(4); GS_CASE(5); GS_CASE(6); GS_CASE(7); GS_CASE(8);
 #undef GS_CASE
       default: return fail("bpa_sampler: unknown step mode");
