@@ -216,6 +216,48 @@ def make_loci(eng, data):
     return loci
 
 
+def cpu_quota():
+    """CPUs this container may use at once (cgroup v2 cpu.max), or None: the GPU box shows 256 logical cores but grants 16"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:       # noqa: BLE001
+        return None
+
+
+def run_host_control(eng, cfg, data, threads, iters=30, warm=3):
+    """north_star's literal architecture: MCMC control on the host in C (a00_driver.c: proposals, MSC density,
+    bookkeeping, decisions), every proposal step ONE batched bpa_batch_evaluate on the GPU, per-locus lnL back over PCIe.
+    Own loci on the same engine (the driver toggles their buffers)."""
+    # the worker threads stay where they are (without it the same run is 25 % slower on this 256-logical-core host);
+    # libgomp reads this when it is loaded, i.e. with the host library below
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hostdrv
+    from bpp_amd import synth
+    loci = make_loci(eng, data)
+    g = hostdrv.hip_driver(eng, loci, data, seed=1)
+    g.set_threads(threads)
+    parent, tau, theta = synth.species_tree_arrays(cfg["taxa"])
+    g.set_species_tree(parent, tau, theta)
+    g.set_tau_prior(3.0, 3.0 / tau[-1])
+    g.set_theta_prior(2.0, 2.0 / theta[0], 0.5 * theta[0])
+    g.initialize()
+    for _ in range(warm):
+        g.iterate()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        g.iterate()
+    dt = time.perf_counter() - t0
+    p, a, st = g.counters()
+    g.close()
+    return dict(iterations_per_s=round(iters / dt, 2), ms_per_iteration=round(1e3 * dt / iters, 3), iterations=iters,
+                host_threads=threads, launches_per_iteration=round(st / (iters + warm), 1), acceptance=round(a / max(p, 1), 3),
+                note="host MCMC control in C (csrc/host/a00_driver.c, per-locus loops on OpenMP worker threads; the trajectory does "
+                     "not depend on their number), one batched launch + one synchronisation + 80 KB D2H per proposal step: the "
+                     "PCIe-inclusive rate of the drop-in architecture with the control left on the host")
+
+
 def dominant_kernel(cfg, one_gpu=True):
     if cfg["model"] == "jc69":
         if os.environ.get("BPA_NO_CHAIN"):
@@ -625,6 +667,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true", help="c2: skip the device-resident sampler (`value` is then the tape's)")
     ap.add_argument("--no-tape", action="store_true", help="c2: skip the likelihood-only tape section")
+    ap.add_argument("--no-host-control", action="store_true", help="c2: skip the host-driven section (a00_driver.c on the GPU back-end)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the c3 / c4 tape sections of the default run")
     ap.add_argument("--no-bpp-program", action="store_true",
                     help="skip timing the unmodified reference program (thread sweep) on the host cores")
@@ -688,6 +731,14 @@ def main():
         if "error" in sampler_sec:
             log(sampler_sec["error"])
 
+    host_sec = None
+    if rank == 0 and world == 1 and D is None and args.config == "c2" and not args.no_host_control:
+        try:
+            q = cpu_quota()
+            host_sec = run_host_control(eng, cfg, data, max(1, min(16, int(q) if q else (os.cpu_count() or 1))))
+        except Exception as ex:       # noqa: BLE001
+            host_sec = dict(error=str(ex)[:300])
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and tape_steps is not None:
         init, iters = tape_steps
@@ -701,7 +752,7 @@ def main():
                    sample=f"{cb['sampled_loci']} loci x {n_cpu_iter} tape iterations x {cb['repeats']} repeats "
                           f"({cb['seconds']:.1f}s incl. the all-cores leg), same tape as the GPU, AVX2 back-end",
                    all_cores=dict(value=round(1.0 / (ac["sec_per_locus_iter"] * scale), 3), cores=ac["workers"],
-                                  host_logical_cores=ac["host_logical_cores"],
+                                  host_logical_cores=ac["host_logical_cores"], host_cpu_quota=cpu_quota(),
                                   sample=f"{ac['sampled_loci']} loci x {n_cpu_iter} tape iterations x {ac['repeats']} repeats, "
                                          f"one locus per worker thread at a time (loci are independent: threads.c:87-200)"))
 
@@ -715,7 +766,7 @@ def main():
                 best = max((k for k in r if k > 1), key=lambda k: r[k]["median"], default=1)
                 bpp_prog = dict(unit="whole MCMC iterations/s of the unmodified reference program (10k loci, A00 JC69), incl. its MCMC control",
                                 threads={str(k): v for k, v in r.items()}, best_threads=best, best_median=r[best]["median"],
-                                host_logical_cores=ncores, kind="reference",
+                                host_logical_cores=ncores, host_cpu_quota=cpu_quota(), kind="reference",
                                 sample="bpp --simulate data (seed 12345), differential wall time of 20- vs 100-iteration runs, "
                                        "median / min / max of 3 measurements per thread count (1 thread: one)")
         except Exception as ex:       # noqa: BLE001
@@ -779,6 +830,7 @@ def main():
             "cpu_baseline": cpu,
             "reference_program_on_host": bpp_prog,
             "device_resident_sampler": sampler_sec,
+            "host_control_in_c": host_sec,
             "likelihood_only": tape_sec,
             "other_configs": others,
             "allreduce_check": tape_sec["allreduce_check"] if tape_sec else None,

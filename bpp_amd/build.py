@@ -41,7 +41,7 @@ def build_host(force=False, verbose=False):
     deps = [HOST_SRC, os.path.join(ROOT, "include", "bpp_amd_host.h"), os.path.join(ROOT, "include", "bpp_amd.h"), OUT]
     if not force and os.path.exists(HOST_OUT) and all(os.path.getmtime(f) <= os.path.getmtime(HOST_OUT) for f in deps):
         return HOST_OUT
-    cmd = ["gcc", "-O2", "-std=c99", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"),
+    cmd = ["gcc", "-O2", "-std=c99", "-fopenmp", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"),
            HOST_SRC, "-o", HOST_OUT, "-L", HERE, "-lbpp_amd", "-Wl,-rpath,$ORIGIN", "-lm"]
     if verbose:
         print(" ".join(cmd))

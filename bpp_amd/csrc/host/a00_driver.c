@@ -53,6 +53,13 @@ struct a00_driver
   double * sm; int * sm_ncat; a00_param_fn setpar;
   double ft_freqs, ft_qrates, ft_alpha, alpha_a, alpha_b;
   double * sm_old;                      /* proposed component's old values per slot: [2] for freqs / qrates, alpha */
+  /* per-locus staging of a step (a00_set_threads): the loci of a step are proposed in parallel — every draw of a
+     per-locus proposal comes from that locus's own stream, so the trajectory does not depend on the thread count —
+     each into its own row; `compact` then lines the rows up as the step's slots in locus order */
+  int threads, w_cap;                   /* w_cap: ints per locus row (the largest tree's node count) */
+  int * w_br, * w_nd, * w_nb, * w_nn;   /* [nloci][w_cap] changed branches / nodes to recompute, and their counts (-1: no proposal) */
+  double * w_hast, * w_logpr;
+  double * w_diff;                      /* [nloci][A00_MAXPOP] THETA: term differences per locus, summed in locus order afterwards */
 };
 
 
@@ -142,6 +149,11 @@ a00_driver_t * a00_create(unsigned nloci, a00_eval_fn eval, void * ctx, unsigned
   d->p_logpr = (double *)calloc(nloci, sizeof(double)); d->p_delta = (double *)calloc(nloci, sizeof(double));
   d->p_slot = (int *)calloc(nloci, sizeof(int)); d->u_pop = (int **)calloc(nloci, sizeof(int *));
   d->ft_gage = 0.004; d->ft_gspr = 0.004; d->ft_tau = 0.001; d->ft_mix = 0.3;
+  d->threads = 1;
+  { const char * ev = getenv("A00_THREADS"); if (ev && atoi(ev) > 0) a00_set_threads(d, atoi(ev)); }
+  d->w_nb = (int *)calloc(nloci, sizeof(int)); d->w_nn = (int *)calloc(nloci, sizeof(int));
+  d->w_hast = (double *)calloc(nloci, sizeof(double)); d->w_logpr = (double *)calloc(nloci, sizeof(double));
+  d->w_diff = (double *)calloc((size_t)nloci*A00_MAXPOP, sizeof(double));
   d->u_left = (int **)calloc(nloci, sizeof(int *)); d->u_right = (int **)calloc(nloci, sizeof(int *));
   d->u_parent = (int **)calloc(nloci, sizeof(int *)); d->u_clv = (int **)calloc(nloci, sizeof(int *));
   d->u_pmat = (int **)calloc(nloci, sizeof(int *)); d->u_scaler = (int **)calloc(nloci, sizeof(int *));
@@ -163,6 +175,7 @@ void a00_destroy(a00_driver_t * d)
   }
   free(d->rng); free(d->zrng); free(d->sm); free(d->sm_ncat); free(d->sm_old); free(d->trees); free(d->s_locus); free(d->s_tree); free(d->s_br_off); free(d->s_nd_off); free(d->s_br);
   free(d->s_logpr); free(d->p_logpr); free(d->p_delta); free(d->p_slot); free(d->u_pop);
+  free(d->w_br); free(d->w_nd); free(d->w_nb); free(d->w_nn); free(d->w_hast); free(d->w_logpr); free(d->w_diff);
   free(d->s_nd); free(d->s_lnl); free(d->s_hast); free(d->u_left); free(d->u_right); free(d->u_parent);
   free(d->u_clv); free(d->u_pmat); free(d->u_scaler); free(d->u_time); free(d->u_root); free(d);
 }
@@ -198,17 +211,33 @@ int a00_set_tree(a00_driver_t * d, unsigned i, int tips, const int * left, const
 const a00_tree_t * a00_tree(const a00_driver_t * d, unsigned i) { return d->trees + i; }
 
 /* ---- step assembly */
-static void step_begin(a00_driver_t * d) { d->s_br_off[0] = d->s_nd_off[0] = 0; }
 static void reserve(a00_driver_t * d, size_t br, size_t nd)
 {
   if (br > d->cap_br) { d->cap_br = 2*br + 1024; d->s_br = (int *)realloc(d->s_br, d->cap_br*sizeof(int)); }
   if (nd > d->cap_nd) { d->cap_nd = 2*nd + 1024; d->s_nd = (int *)realloc(d->s_nd, d->cap_nd*sizeof(int)); }
 }
 
+static int marshal_threads = 1;      /* a00_backend_hip's marshalling loop (its context carries no driver): the last a00_set_threads */
+void a00_set_threads(a00_driver_t * d, int threads) { d->threads = threads > 0 ? threads : 1; marshal_threads = d->threads; }
+
+/* rows of the per-locus staging: sized by the largest tree, (re)allocated when a larger one arrives */
+static int staging_ready(a00_driver_t * d)
+{
+  unsigned i; int cap = 0;
+  for (i = 0; i < d->nloci; ++i) if (d->trees[i].n > cap) cap = d->trees[i].n;
+  if (cap <= d->w_cap && d->w_br) return 1;
+  free(d->w_br); free(d->w_nd);
+  d->w_cap = cap;
+  d->w_br = (int *)malloc((size_t)d->nloci*(size_t)cap*sizeof(int));
+  d->w_nd = (int *)malloc((size_t)d->nloci*(size_t)cap*sizeof(int));
+  return d->w_br && d->w_nd;
+}
+
 /* install a proposal on locus i: toggle the buffers of the changed branches and of the nodes
-   to recompute (sorted children-first = by age), append it to the step */
-static void step_add(a00_driver_t * d, unsigned slot, unsigned i, const int * branches, int nb,
-                     int * nodes, int nn)
+   to recompute (sorted children-first = by age) and leave both lists in the locus's staging row.
+   Touches nothing but locus i: safe from any thread. */
+static void install_local(a00_driver_t * d, unsigned i, const int * branches, int nb, int * nodes, int nn,
+                          double hast, double logpr)
 {
   a00_tree_t * t = d->trees + i; int a, b;
   /* unique + sort nodes by age (a parent is always older than its children) */
@@ -216,12 +245,37 @@ static void step_add(a00_driver_t * d, unsigned slot, unsigned i, const int * br
   for (a = 1; a < nn; ++a) { int v = nodes[a]; for (b = a; b > 0 && t->time[nodes[b-1]] > t->time[v]; --b) nodes[b] = nodes[b-1]; nodes[b] = v; }
   for (a = 0; a < nb; ++a) swap_pmat(t, branches[a]);
   for (a = 0; a < nn; ++a) swap_clv(t, nodes[a]);
-  reserve(d, d->s_br_off[slot] + (size_t)nb, d->s_nd_off[slot] + (size_t)nn);
-  memcpy(d->s_br + d->s_br_off[slot], branches, (size_t)nb*sizeof(int));
-  memcpy(d->s_nd + d->s_nd_off[slot], nodes, (size_t)nn*sizeof(int));
-  d->s_locus[slot] = i; d->s_tree[slot] = t;
-  d->s_br_off[slot+1] = d->s_br_off[slot] + (unsigned)nb;
-  d->s_nd_off[slot+1] = d->s_nd_off[slot] + (unsigned)nn;
+  memcpy(d->w_br + (size_t)i*(size_t)d->w_cap, branches, (size_t)nb*sizeof(int));
+  memcpy(d->w_nd + (size_t)i*(size_t)d->w_cap, nodes, (size_t)nn*sizeof(int));
+  d->w_nb[i] = nb; d->w_nn[i] = nn; d->w_hast[i] = hast; d->w_logpr[i] = logpr;
+}
+
+/* the staged rows as the step's slots, in locus order; p_slot[i] = the slot of locus i or -1; returns the slot count */
+static unsigned compact(a00_driver_t * d)
+{
+  unsigned i, n = 0; long li;
+  /* slots and offsets: a running count in locus order (cheap, serial) ... */
+  d->s_br_off[0] = d->s_nd_off[0] = 0;
+  for (i = 0; i < d->nloci; ++i)
+  {
+    d->p_slot[i] = -1;
+    if (d->w_nb[i] < 0) continue;
+    d->s_br_off[n+1] = d->s_br_off[n] + (unsigned)d->w_nb[i];
+    d->s_nd_off[n+1] = d->s_nd_off[n] + (unsigned)d->w_nn[i];
+    d->p_slot[i] = (int)n++;
+  }
+  reserve(d, d->s_br_off[n], d->s_nd_off[n]);
+  /* ... then every row to its place */
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+  for (li = 0; li < (long)d->nloci; ++li)
+  {
+    const int sl = d->p_slot[li];
+    if (sl < 0) continue;
+    memcpy(d->s_br + d->s_br_off[sl], d->w_br + (size_t)li*(size_t)d->w_cap, (size_t)d->w_nb[li]*sizeof(int));
+    memcpy(d->s_nd + d->s_nd_off[sl], d->w_nd + (size_t)li*(size_t)d->w_cap, (size_t)d->w_nn[li]*sizeof(int));
+    d->s_locus[sl] = (unsigned)li; d->s_tree[sl] = d->trees + li; d->s_hast[sl] = d->w_hast[li]; d->s_logpr[sl] = d->w_logpr[li];
+  }
+  return n;
 }
 
 static int step_eval(a00_driver_t * d, unsigned n)
@@ -370,7 +424,7 @@ int a00_initialize(a00_driver_t * d)
     int cnt[A00_MAXPOP] = {0}, k;
     for (k = 0; k < d->trees[i].tips; ++k) if (++cnt[d->trees[i].pop[k]] >= 2) d->has_theta[d->trees[i].pop[k]] = 1;
   }
-  step_begin(d);
+  if (!staging_ready(d)) return 0;
   for (i = 0; i < d->nloci; ++i)
   {
     a00_tree_t * t = d->trees + i; int nb = 0, nn = 0, k;
@@ -381,9 +435,9 @@ int a00_initialize(a00_driver_t * d)
     /* start-up evaluates into the current buffers: toggle twice = no toggle */
     for (k = 0; k < nb; ++k) swap_pmat(t, br[k]);
     for (k = 0; k < nn; ++k) swap_clv(t, nd[k]);
-    step_add(d, i, i, br, nb, nd, nn);
+    install_local(d, i, br, nb, nd, nn, 0.0, t->logpr);
   }
-  if (!step_eval(d, d->nloci)) return 0;
+  if (compact(d) != d->nloci || !step_eval(d, d->nloci)) return 0;
   for (i = 0; i < d->nloci; ++i) d->trees[i].lnl = d->s_lnl[i];
   return 1;
 }
@@ -391,25 +445,29 @@ int a00_initialize(a00_driver_t * d)
 /* per-locus Metropolis-Hastings decision on  MSC density x likelihood  (gtree.c:5476-5480) */
 static void decide(a00_driver_t * d, unsigned n)
 {
-  unsigned s;
-  for (s = 0; s < n; ++s)
+  long s; unsigned long acc = 0;
+#pragma omp parallel for schedule(static) num_threads(d->threads) reduction(+:acc) if (d->threads > 1)
+  for (s = 0; s < (long)n; ++s)
   {
     const unsigned i = d->s_locus[s]; a00_tree_t * t = d->trees + i;
     const double lnacc = (d->s_logpr[s] - t->logpr) + (d->s_lnl[s] - t->lnl) + d->s_hast[s];
-    d->proposals++;
-    if (accept(d, (long)i, lnacc, -1.0)) { t->lnl = d->s_lnl[s]; t->logpr = d->s_logpr[s]; d->accepted++; }
+    if (accept(d, (long)i, lnacc, -1.0)) { t->lnl = d->s_lnl[s]; t->logpr = d->s_logpr[s]; ++acc; }
     else restore(d, i);                                  /* swap indices, ages, populations, topology back */
   }
+  d->proposals += n; d->accepted += acc;
 }
 
 /* GAGE: the k-th inner node of every locus (propose_ages, gtree.c:4585-5532, the MSC branch) */
 static int gage_step(a00_driver_t * d, int k)
 {
-  unsigned i, n = 0; int br[4], nd[MAXN];
-  step_begin(d);
-  for (i = 0; i < d->nloci; ++i)
+  long li; unsigned n;
+  if (!staging_ready(d)) return 0;
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+  for (li = 0; li < (long)d->nloci; ++li)
   {
-    a00_tree_t * t = d->trees + i; int v = -1, c = 0, j, nb = 0, nn, p, l, r; double lo, hi, u, tnew;
+    const unsigned i = (unsigned)li;
+    a00_tree_t * t = d->trees + i; int v = -1, c = 0, j, nb = 0, nn, p, l, r, br[4], nd[MAXN]; double lo, hi, u, tnew;
+    d->w_nb[i] = -1;
     for (j = 0; j < t->n; ++j) if (t->left[j] >= 0 && c++ == k) { v = j; break; }
     if (v < 0) continue;
     u = draw_window(d, (long)i);
@@ -422,13 +480,11 @@ static int gage_step(a00_driver_t * d, int k)
     tnew = a00_reflect(t->time[v] + d->ft_gage*u, lo, hi);
     t->time[v] = tnew;
     t->pop[v] = climb(d, t->pop[l], tnew);
-    d->s_hast[n] = 0;
-    d->s_logpr[n] = tree_logpr(d, t);
     br[nb++] = l; br[nb++] = r; if (p >= 0) br[nb++] = v;
     nn = path_to_root(t, v, nd);
-    step_add(d, n, i, br, nb, nd, nn);
-    ++n;
+    install_local(d, i, br, nb, nd, nn, 0.0, tree_logpr(d, t));
   }
+  n = compact(d);
   if (!step_eval(d, n)) return 0;
   decide(d, n);
   return 1;
@@ -461,14 +517,17 @@ static int count_tips(const a00_tree_t * t, int v)
    the MSC branch with the plain target choice) */
 static int gspr_step(a00_driver_t * d, int k)
 {
-  unsigned i, n = 0;
-  step_begin(d);
-  for (i = 0; i < d->nloci; ++i)
+  long li; unsigned n;
+  if (!staging_ready(d)) return 0;
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+  for (li = 0; li < (long)d->nloci; ++li)
   {
+    const unsigned i = (unsigned)li;
     a00_tree_t * t = d->trees + i;
     int a = -1, c = 0, j, p, s, g, pc, tgt, ntg = 0, nsrc = 1, targets[MAXN], pop0, popt, leaves, gl[A00_MAXPOP];
     int bset[4], br[4], nb = 0, nd[2*MAXN], nn = 0, root_before;
     double lo, tnew, u1, u2;
+    d->w_nb[i] = -1;
     for (j = 0; j < t->n; ++j) if (j != t->root && c++ == k) { a = j; break; }
     if (a < 0) continue;
     u1 = draw_window(d, (long)i); u2 = draw_u(d, (long)i);
@@ -524,11 +583,9 @@ static int gspr_step(a00_driver_t * d, int k)
       for (q = 0; q < nb; ++q) if (br[q] == bset[j]) dup = 1;
       if (!dup && t->parent[bset[j]] >= 0) br[nb++] = bset[j];
     }
-    d->s_hast[n] = log((double)ntg/(double)nsrc);
-    d->s_logpr[n] = tree_logpr(d, t);
-    step_add(d, n, i, br, nb, nd, nn);
-    ++n;
+    install_local(d, i, br, nb, nd, nn, log((double)ntg/(double)nsrc), tree_logpr(d, t));
   }
+  n = compact(d);
   if (!step_eval(d, n)) return 0;
   decide(d, n);
   return 1;
@@ -540,7 +597,7 @@ static int gspr_step(a00_driver_t * d, int k)
    decided on its own  sum over loci of [term(theta') - term(theta)] + prior ratio  (stree.c:3464-3560 family). */
 static int theta_step_all(a00_driver_t * d)
 {
-  unsigned i; int p;
+  unsigned i; int p; long li;
   double tnew[A00_MAXPOP], uacc[A00_MAXPOP], sum[A00_MAXPOP];
   for (p = 0; p < d->npop; ++p)
   {
@@ -549,13 +606,18 @@ static int theta_step_all(a00_driver_t * d)
     tnew[p] = a00_reflect(d->theta[p] + d->ft_theta*draw_window(d, -1), 0.0, 999.0);
     uacc[p] = d->kernel == A00_KERNEL_BPP ? -1.0 : draw_u(d, -1);
   }
-  for (i = 0; i < d->nloci; ++i)
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+  for (li = 0; li < (long)d->nloci; ++li)
   {
-    int nc[A00_MAXPOP]; double t2h[A00_MAXPOP];
-    (void)tree_logpr_stats(d, d->trees + i, nc, t2h);
-    for (p = 0; p < d->npop; ++p)
-      if (d->has_theta[p]) sum[p] += a00_msc_term(nc[p], t2h[p], tnew[p], 1.0) - a00_msc_term(nc[p], t2h[p], d->theta[p], 1.0);
+    int nc[A00_MAXPOP], pp; double t2h[A00_MAXPOP];
+    (void)tree_logpr_stats(d, d->trees + li, nc, t2h);
+    for (pp = 0; pp < d->npop; ++pp)
+      if (d->has_theta[pp])
+        d->w_diff[(size_t)li*A00_MAXPOP + pp] = a00_msc_term(nc[pp], t2h[pp], tnew[pp], 1.0) - a00_msc_term(nc[pp], t2h[pp], d->theta[pp], 1.0);
   }
+  for (i = 0; i < d->nloci; ++i)                          /* the sums in locus order, whatever the thread count */
+    for (p = 0; p < d->npop; ++p)
+      if (d->has_theta[p]) sum[p] += d->w_diff[(size_t)i*A00_MAXPOP + p];
   for (p = 0; p < d->npop; ++p)
   {
     double lnacc;
@@ -564,7 +626,8 @@ static int theta_step_all(a00_driver_t * d)
     d->proposals++;
     if (tnew[p] > 0 && accept(d, -1, lnacc, uacc[p])) { d->accepted++; d->theta[p] = tnew[p]; }
   }
-  for (i = 0; i < d->nloci; ++i) d->trees[i].logpr = tree_logpr(d, d->trees + i);
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+  for (li = 0; li < (long)d->nloci; ++li) d->trees[li].logpr = tree_logpr(d, d->trees + li);
   return 1;
 }
 
@@ -574,18 +637,21 @@ static int theta_step_all(a00_driver_t * d)
    sum(dlogpr + dlnL) + below*log(minfactor) + above*log(maxfactor)   (stree.c:6280) */
 static int tau_step(a00_driver_t * d, int q)
 {
-  unsigned i, n = 0; double sum = 0;
+  unsigned i, n; long li; double sum = 0;
   const int cl = d->sp_left[q], cr = d->sp_right[q], pq = d->sp_parent[q];
   const double old = d->tau[q], lo = fmax(d->tau[cl], d->tau[cr]), hi = pq >= 0 ? d->tau[pq] : 999.0;
   const double tnew = a00_reflect(old + d->ft_tau*draw_window(d, -1), lo, hi);
   const double uacc = d->kernel == A00_KERNEL_BPP ? -1.0 : draw_u(d, -1);
   const double minf = (tnew - lo)/(old - lo), maxf = (tnew - hi)/(old - hi), lminf = log(minf), lmaxf = log(maxf);
-  step_begin(d);
+  if (!staging_ready(d)) return 0;
   d->tau[q] = tnew;
-  for (i = 0; i < d->nloci; ++i)
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+  for (li = 0; li < (long)d->nloci; ++li)
   {
+    const unsigned i = (unsigned)li;
     a00_tree_t * t = d->trees + i; int br[MAXN], nd[MAXN], nb = 0, nn = 0, k, v, above = 0, below = 0;
     char isbr[MAXN], isnd[MAXN];
+    d->w_nb[i] = -1;
     snapshot(d, i);
     memset(isbr, 0, (size_t)t->n); memset(isnd, 0, (size_t)t->n);
     for (k = t->tips; k < t->n; ++k)
@@ -598,13 +664,11 @@ static int tau_step(a00_driver_t * d, int q)
     }
     d->p_logpr[i] = tree_logpr(d, t);
     d->p_delta[i] = (d->p_logpr[i] - t->logpr) + below*lminf + above*lmaxf;
-    d->p_slot[i] = -1;
     if (!(above + below)) continue;
     for (k = 0; k < t->n; ++k) { if (isbr[k]) br[nb++] = k; if (isnd[k]) nd[nn++] = k; }
-    d->p_slot[i] = (int)n;
-    step_add(d, n, i, br, nb, nd, nn);
-    ++n;
+    install_local(d, i, br, nb, nd, nn, 0.0, d->p_logpr[i]);
   }
+  n = compact(d);
   if (!step_eval(d, n)) return 0;
   for (i = 0; i < d->nloci; ++i)
     sum += d->p_slot[i] >= 0 ? (d->s_lnl[d->p_slot[i]] - d->trees[i].lnl) + d->p_delta[i] : d->p_delta[i];
@@ -613,12 +677,14 @@ static int tau_step(a00_driver_t * d, int q)
   if (accept(d, -1, sum, uacc))
   {
     d->accepted++;
-    for (i = 0; i < d->nloci; ++i) { d->trees[i].logpr = d->p_logpr[i]; if (d->p_slot[i] >= 0) d->trees[i].lnl = d->s_lnl[d->p_slot[i]]; }
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+    for (li = 0; li < (long)d->nloci; ++li) { d->trees[li].logpr = d->p_logpr[li]; if (d->p_slot[li] >= 0) d->trees[li].lnl = d->s_lnl[d->p_slot[li]]; }
   }
   else
   {
     d->tau[q] = old;
-    for (i = 0; i < d->nloci; ++i) if (d->p_slot[i] >= 0) restore(d, i);
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+    for (li = 0; li < (long)d->nloci; ++li) if (d->p_slot[li] >= 0) restore(d, (unsigned)li);
   }
   return 1;
 }
@@ -627,14 +693,16 @@ static int tau_step(a00_driver_t * d, int q)
    sum(dlogpr + dlnL) + (ages + taus)*log c   (prop_mixing.c:203-205; thetas stay) */
 static int mix_step(a00_driver_t * d)
 {
-  unsigned i; int br[MAXN], nd[MAXN], p; double sum = 0, lnacc, oldtau[A00_MAXPOP];
+  unsigned i; long li; int p; double sum = 0, lnacc, oldtau[A00_MAXPOP];
   const double lnc = d->ft_mix*(draw_u(d, -1) - 0.5), c = exp(lnc);        /* prop_mixing.c: log c uniform in both kernels */
   const double uacc = d->kernel == A00_KERNEL_BPP ? -1.0 : draw_u(d, -1);
-  step_begin(d);
+  if (!staging_ready(d)) return 0;
   for (p = 0; p < d->npop; ++p) { oldtau[p] = d->tau[p]; d->tau[p] *= c; }
-  for (i = 0; i < d->nloci; ++i)
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+  for (li = 0; li < (long)d->nloci; ++li)
   {
-    a00_tree_t * t = d->trees + i; int nb = 0, nn = 0, k;
+    const unsigned i = (unsigned)li;
+    a00_tree_t * t = d->trees + i; int br[MAXN], nd[MAXN], nb = 0, nn = 0, k;
     snapshot(d, i);
     for (k = 0; k < t->n; ++k)
     {
@@ -643,9 +711,9 @@ static int mix_step(a00_driver_t * d)
     }
     d->p_logpr[i] = tree_logpr(d, t);
     d->p_delta[i] = (d->p_logpr[i] - t->logpr) + (double)nn*lnc;
-    step_add(d, i, i, br, nb, nd, nn);
+    install_local(d, i, br, nb, nd, nn, 0.0, d->p_logpr[i]);
   }
-  if (!step_eval(d, d->nloci)) return 0;
+  if (compact(d) != d->nloci || !step_eval(d, d->nloci)) return 0;          /* every locus has a slot: slot i = locus i */
   for (i = 0; i < d->nloci; ++i) sum += (d->s_lnl[i] - d->trees[i].lnl) + d->p_delta[i];
   lnacc = sum + (double)(d->S - 1)*lnc;
   if (d->tau_alpha > 0)                    /* all taus scale together: the Dirichlet part is unchanged */
@@ -654,12 +722,14 @@ static int mix_step(a00_driver_t * d)
   if (accept(d, -1, lnacc, uacc))
   {
     d->accepted++;
-    for (i = 0; i < d->nloci; ++i) { d->trees[i].lnl = d->s_lnl[i]; d->trees[i].logpr = d->p_logpr[i]; }
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+    for (li = 0; li < (long)d->nloci; ++li) { d->trees[li].lnl = d->s_lnl[li]; d->trees[li].logpr = d->p_logpr[li]; }
   }
   else
   {
     for (p = 0; p < d->npop; ++p) d->tau[p] = oldtau[p];
-    for (i = 0; i < d->nloci; ++i) restore(d, i);
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+    for (li = 0; li < (long)d->nloci; ++li) restore(d, (unsigned)li);
   }
   return 1;
 }
@@ -714,7 +784,8 @@ static int param_step(a00_driver_t * d, int which, int j)
 {
   unsigned i, n = 0, s;
   const int ref = which == 1 ? 3 : 1;                      /* T / the A<->G rate (locus.c:2791, 3222) */
-  step_begin(d);
+  if (!staging_ready(d)) return 0;
+  for (i = 0; i < d->nloci; ++i) d->w_nb[i] = -1;
   for (i = 0; i < d->nloci; ++i)
   {
     a00_tree_t * t = d->trees + i; double * m = d->sm + (size_t)i*11;
@@ -747,12 +818,10 @@ static int param_step(a00_driver_t * d, int which, int j)
       if (t->left[k] >= 0) nd[nn++] = k;
       if (t->parent[k] >= 0) br[nb++] = k;
     }
-    d->s_hast[n] = hast;
-    d->s_logpr[n] = t->logpr;
-    step_add(d, n, i, br, nb, nd, nn);
-    ++n;
+    install_local(d, i, br, nb, nd, nn, hast, t->logpr);
+    ++n;                                           /* (sm_old is indexed by the slot this locus is about to get) */
   }
-  if (!step_eval(d, n)) return 0;
+  if (compact(d) != n || !step_eval(d, n)) return 0;
   for (s = 0; s < n; ++s)
   {
     const unsigned li = d->s_locus[s]; a00_tree_t * t = d->trees + li; double * m = d->sm + (size_t)li*11;
@@ -834,6 +903,7 @@ int a00_backend_hip(void * vctx, const a00_step_t * s, double * lnl)
     free(loci); free(mp); free(ml); free(ops); free(rc); free(rs);
     return 0;
   }
+#pragma omp parallel for schedule(static) private(j) num_threads(marshal_threads) if (marshal_threads > 1)
   for (i = 0; i < n; ++i)
   {
     const a00_tree_t * t = s->tree[i];

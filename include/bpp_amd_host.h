@@ -140,6 +140,10 @@ int            a00_set_tip_species(a00_driver_t *, unsigned i, const int * speci
 #define A00_KERNEL_UNIFORM 0
 #define A00_KERNEL_BPP     1
 void           a00_set_proposal_kernel(a00_driver_t *, int kind);
+/* worker threads of the per-locus loops (proposal, MSC density, bookkeeping, roll-back; OpenMP).  Every draw of a per-locus
+   proposal comes from that locus's own stream and sums over loci are taken in locus order afterwards, so the trajectory
+   does not depend on the count.  Default 1, or the environment's A00_THREADS; threads.c:87-200 is the reference's form */
+void           a00_set_threads(a00_driver_t *, int threads);
 /* the first n values of the restated generator / window variate from state `seed` (tests) */
 void           a00_bpp_kernel_sequence(unsigned int seed, int symmetrical, int n, double * out);
 /* window widths of the four moves (defaults 0.004, 0.004, 0.001, 0.3) */

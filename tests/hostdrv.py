@@ -107,6 +107,11 @@ class Driver:
         L.a00_set_param_backend.argtypes = [C.c_void_p, C.c_void_p]
         L.a00_set_param_backend(self.h, fn_addr)
 
+    def set_threads(self, n):
+        """worker threads of the per-locus loops (the trajectory does not depend on the count)"""
+        lib().a00_set_threads.argtypes = [C.c_void_p, C.c_int]
+        lib().a00_set_threads(self.h, int(n))
+
     def set_proposal_kernel(self, kind):
         """0 uniform windows on the a00 streams (default), 1 BPP's legacy_rndu + Bactrian-Laplace (A00_KERNEL_BPP)"""
         lib().a00_set_proposal_kernel.argtypes = [C.c_void_p, C.c_int]

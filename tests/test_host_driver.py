@@ -61,3 +61,27 @@ def test_driver_on_reference_backend(taxa, model, R, scaling):
     assert rel(drv.total_lnl(), total) < 1e-13
     assert drv.total_lnl() > l0 - 50        # a likelihood-driven sampler does not run away downhill
     drv.close()
+
+
+@pytest.mark.parametrize("threads", [2, 5])
+def test_thread_count_does_not_change_the_trajectory(threads):
+    """the per-locus loops of a step run on worker threads (a00_set_threads): every draw of a per-locus proposal comes
+    from that locus's own stream and the sums of the all-loci steps are taken in locus order afterwards, so a
+    threaded run walks the one-thread trajectory exactly — decisions, trees, populations, densities, taus, thetas"""
+    data = synth.make_dataset(37, 200, 6, "jc69", 1, seed=5)
+    runs = []
+    for n in (1, threads):
+        drv = hostdrv.reference_driver(data, seed=11)
+        drv.set_threads(n)
+        parent, tau0, thetas = synth.species_tree_arrays(6)
+        drv.set_species_tree(parent, tau0, thetas)
+        drv.set_tau_prior(3.0, 3.0 / tau0[-1])
+        drv.set_theta_prior(2.0, 1000.0, 0.0004)
+        drv.initialize()
+        for _ in range(6):
+            drv.iterate()
+        runs.append((drv.counters(), drv.taus(), drv.thetas(), [drv.tree(i) for i in range(len(data))], drv.total_lnl()))
+    a, b = runs
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[4] == b[4]
+    for x, y in zip(a[3], b[3]):
+        assert x == y

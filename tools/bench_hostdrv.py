@@ -1,6 +1,7 @@
 """the C host driver (a00_driver.c: host MCMC control, one batched bpa_batch_evaluate per proposal step) on config 2:
 whole A00 iterations per second of the host-driven drop-in path"""
 import os, sys, time
+os.environ.setdefault("OMP_PROC_BIND", "close")     # worker threads of the driver stay put (A00_THREADS=n sets their number)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bpp_amd

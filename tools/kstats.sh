@@ -6,7 +6,7 @@ shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 W=/tmp/ks_$TAG; rm -rf $W; mkdir -p $W $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d $W -o p -- python $R/bench.py "$@" --no-cpu-baseline --no-bpp-program --no-other-configs > $W/bench.json 2> $W/log
+rocprofv3 --kernel-trace --stats -f csv -d $W -o p -- python $R/bench.py "$@" --no-cpu-baseline --no-bpp-program --no-other-configs --no-host-control > $W/bench.json 2> $W/log
 python3 - <<PY
 import csv, glob
 ks = glob.glob("$W/**/*kernel_stats.csv", recursive=True)
