@@ -51,6 +51,15 @@ def log(*a):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines ---
+def cpu_quota():
+    """CPUs this container may use at once (cgroup v2 cpu.max), or None: the GPU box shows 256 logical cores but grants 16"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:       # noqa: BLE001
+        return None
+
+
 def cpu_baseline(data, steps_init, steps_iter, n_iter, budget_s=10.0, sample=192):
     """The same tape on the host CPU through the REAL reference's update API when oracle/_ref travelled (kind
     "reference"), else through the oracle's C loop (kind "port"), on a bounded sample of the loci: one core, then —
@@ -102,21 +111,30 @@ def cpu_baseline(data, steps_init, steps_iter, n_iter, budget_s=10.0, sample=192
     # ---- all cores: the C calls release the GIL; every worker replays whole loci (full tape), wall time of the sample;
     # the start-up evaluation's share of a replay is known from the one-core leg
     cores = os.cpu_count() or 1
-    workers = max(1, min(cores, len(jobs)))
     share_iter = float(np.sum([max(f - i, 0.0) for f, i in legs]) / max(np.sum([f for f, _ in legs]), 1e-12))
-    reps_all = int(max(5, min(20000, reps * min(workers, 16))))
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(workers) as ex:
-        list(ex.map(lambda j: run_full(j, reps_all), jobs))
-    wall = time.perf_counter() - t0
-    all_sec_per_locus_iter = wall * share_iter / (len(jobs) * reps_all * n_iter)
+    # worker counts: what the container's CPU quota grants (cgroup cpu.max; more threads than that are only throttled)
+    # and every logical core the sample can feed; the better of the two is the baseline, both are reported
+    q = cpu_quota()
+    cands = sorted({max(1, min(cores, len(jobs)))} | ({max(1, min(int(q), len(jobs)))} if q else set()))
+    tried, best = {}, None
+    for workers in cands:
+        reps_all = int(max(5, min(20000, reps * min(workers, 16))))
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(lambda j: run_full(j, reps_all), jobs))
+        wall = time.perf_counter() - t0
+        spli = wall * share_iter / (len(jobs) * reps_all * n_iter)
+        tried[str(workers)] = spli
+        if best is None or spli < best[0]:
+            best = (spli, workers, reps_all)
+    all_sec_per_locus_iter, workers, reps_all = best
     if use_ref:
         for rl, _, _ in jobs:
             rl.free()
     return dict(sec_per_locus_iter=one, kind="reference" if use_ref else "port", cores=1, sampled_loci=len(per_locus),
                 repeats=reps, seconds=time.time() - t_start,
                 all_cores=dict(sec_per_locus_iter=all_sec_per_locus_iter, workers=workers, host_logical_cores=cores,
-                               repeats=reps_all, sampled_loci=len(jobs)))
+                               repeats=reps_all, sampled_loci=len(jobs), tried=tried))
 
 
 SIM_CTL = """seed = 12345
@@ -214,15 +232,6 @@ def make_loci(eng, data):
         loc.set_category_rates(d["rates"])
         loci.append(loc)
     return loci
-
-
-def cpu_quota():
-    """CPUs this container may use at once (cgroup v2 cpu.max), or None: the GPU box shows 256 logical cores but grants 16"""
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        return None if q == "max" else round(int(q) / int(per), 2)
-    except Exception:       # noqa: BLE001
-        return None
 
 
 def run_host_control(eng, cfg, data, threads, iters=30, warm=3):
@@ -731,14 +740,6 @@ def main():
         if "error" in sampler_sec:
             log(sampler_sec["error"])
 
-    host_sec = None
-    if rank == 0 and world == 1 and D is None and args.config == "c2" and not args.no_host_control:
-        try:
-            q = cpu_quota()
-            host_sec = run_host_control(eng, cfg, data, max(1, min(16, int(q) if q else (os.cpu_count() or 1))))
-        except Exception as ex:       # noqa: BLE001
-            host_sec = dict(error=str(ex)[:300])
-
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and tape_steps is not None:
         init, iters = tape_steps
@@ -753,6 +754,7 @@ def main():
                           f"({cb['seconds']:.1f}s incl. the all-cores leg), same tape as the GPU, AVX2 back-end",
                    all_cores=dict(value=round(1.0 / (ac["sec_per_locus_iter"] * scale), 3), cores=ac["workers"],
                                   host_logical_cores=ac["host_logical_cores"], host_cpu_quota=cpu_quota(),
+                                  workers_tried={k: round(1.0 / (v * scale), 3) for k, v in ac["tried"].items()},
                                   sample=f"{ac['sampled_loci']} loci x {n_cpu_iter} tape iterations x {ac['repeats']} repeats, "
                                          f"one locus per worker thread at a time (loci are independent: threads.c:87-200)"))
 
@@ -795,6 +797,19 @@ def main():
                 e2.close()
             except Exception as ex:       # noqa: BLE001
                 others[key] = dict(error=str(ex)[:300])
+
+    # ---- MCMC control on the host in C (last: libgomp pins the calling thread under OMP_PROC_BIND, and threads or
+    # processes started afterwards would inherit that one-CPU mask — the CPU baselines above must not)
+    host_sec = None
+    if rank == 0 and world == 1 and D is None and args.config == "c2" and not args.no_host_control:
+        mask = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+        try:
+            q = cpu_quota()
+            host_sec = run_host_control(eng, cfg, data, max(1, min(16, int(q) if q else (os.cpu_count() or 1))))
+        except Exception as ex:       # noqa: BLE001
+            host_sec = dict(error=str(ex)[:300])
+        if mask is not None:
+            os.sched_setaffinity(0, mask)
 
     if rank == 0:
         headline_sampler = sampler_sec is not None and "error" not in sampler_sec
