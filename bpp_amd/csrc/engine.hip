@@ -1461,6 +1461,10 @@ extern "C" int bpa_plan_work(bpa_plan_t * p, double * bytes_partials, double * f
 static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double * lnl, bool & handled)
 {
   handled = false;
+  static const bool prof = getenv("BPA_PLAN_PROF") != nullptr;       // section timers (stderr, every 130 calls)
+  static double pt[4] = {0, 0, 0, 0}; static unsigned pcalls = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_0 = prof ? now() : 0;
   static const bool off = getenv("BPA_JC69_V1") != nullptr || getenv("BPA_NO_JC69_FAST") != nullptr;
   if (off || !b->root_clv || !b->nloci) return 1;
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
@@ -1485,6 +1489,7 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
     all_jc = all_jc && l->rate_cats == 1 && l->dev.model == 0;
     all_kl = all_kl && l->rate_cats > 1 && l->scale_buffers == 0 && !l->dev.unphased_length && (!b->root_scaler || b->root_scaler[t] < 0);
   }
+  const double t_1 = prof ? now() : 0;
   static const bool no_klane = getenv("BPA_KLANE_V1") != nullptr || getenv("BPA_NO_KLANE") != nullptr;
   if (!all_jc && (!all_kl || no_klane)) return 1;
   if (maxops > 255) return 1;                    // StepRec counts a locus's updates in a byte
@@ -1557,6 +1562,7 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
     pat += l->sites;
   }
   while (blk <= e->pack_blocks) bm[blk++] = nmat;
+  const double t_2 = prof ? now() : 0;
   HIPCHK(hipMemcpyAsync(e->d_step.p, img, total, hipMemcpyHostToDevice, e->stream));
   PlanDev d{};
   d.loci = e->d_loci.p; d.bfbeta = e->bfbeta;
@@ -1585,6 +1591,7 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
   }
   HIPCHK(hipGetLastError());
   handled = true;
+  const double t_3 = prof ? now() : 0;
   if (!lnl) { HIPCHK(hipStreamSynchronize(e->stream)); return 1; }
   if (!e->usedata) { HIPCHK(hipStreamSynchronize(e->stream)); std::fill(lnl, lnl + T, 0.0); return 1; }
   const size_t nb = (size_t)T*sizeof(double);
@@ -1599,6 +1606,17 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
   HIPCHK(hipMemcpyAsync(e->h_stage, e->d_step_lnl.p, nb, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   std::memcpy(lnl, e->h_stage, nb);
+  if (prof)
+  {
+    const double t_4 = now();
+    pt[0] += t_1 - t_0; pt[1] += t_2 - t_1; pt[2] += t_3 - t_2; pt[3] += t_4 - t_3;
+    if (++pcalls % 130 == 0)
+    {
+      fprintf(stderr, "[bpa] batch_evaluate per call: checks %.3f ms, record image %.3f ms, enqueue %.3f ms, wait + lnL back %.3f ms\n",
+              1e3*pt[0]/130, 1e3*pt[1]/130, 1e3*pt[2]/130, 1e3*pt[3]/130);
+      pt[0] = pt[1] = pt[2] = pt[3] = 0;
+    }
+  }
   return 1;
 }
 
