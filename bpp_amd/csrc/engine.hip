@@ -1490,7 +1490,6 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
     all_kl = all_kl && l->rate_cats > 1 && l->scale_buffers == 0 && !l->dev.unphased_length && (!b->root_scaler || b->root_scaler[t] < 0);
   }
   const double t_1 = prof ? now() : 0;
-  const double t_1 = prof ? now() : 0;
   static const bool no_klane = getenv("BPA_KLANE_V1") != nullptr || getenv("BPA_NO_KLANE") != nullptr;
   if (!all_jc && (!all_kl || no_klane)) return 1;
   if (maxops > 255) return 1;                    // StepRec counts a locus's updates in a byte
