@@ -83,7 +83,7 @@ def test_gtr_tape_with_substitution_parameter_proposals(engine, taxa, R, nloci):
     allp.close()
 
 
-@pytest.mark.parametrize("taxa,scaling,nloci", [(4, False, 700), (8, True, 90)])
+@pytest.mark.parametrize("taxa,scaling,nloci", [(4, False, 700), (8, True, 90), (4, False, 10000)])
 def test_chain_launch_equals_step_by_step(taxa, scaling, nloci):
     """bpa_plans_launch sends consecutive per-locus steps out as ONE chain launch (step_jc69_v2_chain_kernel): every
     step's per-locus lnL, and the CLVs / scalers / P-matrices left behind, are the bits of the launches one by one"""
