@@ -816,7 +816,8 @@ def main():
         parallelism = "1 GPU"
         if D is not None:
             parallelism = (f"loci sharded over {world} GPU(s) ({args.scaling}), " +
-                           ("one-shot p2p all-reduce over xGMI (RCCL-checked at start-up)" if D.p2p is not None else "RCCL all-reduce") +
+                           ("one-shot p2p all-reduce over xGMI (RCCL-checked at start-up)" if D.p2p is not None else
+                            ("RCCL all-reduce" if os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" else "gloo all-reduce (test switch)")) +
                            " of the sums the THETA / TAU / MIX steps are decided on")
         if headline_sampler:
             value = sampler_sec["iterations_per_s_10k_loci"] if args.scaling == "weak" else sampler_sec["iterations_per_s"]
