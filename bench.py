@@ -588,8 +588,10 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
         smp.enable_timing(args.event_stride if not args.no_timing_events else 0)
         t0 = time.perf_counter()
         smp.iterate(steps)
+        enq = time.perf_counter() - t0            # host time to enqueue the timed region (the GPU is still running)
         sync()
         dt = time.perf_counter() - t0
+        log(f"sampler: host enqueue {1e3 * enq / steps:.4f} ms/iteration of {1e3 * dt / steps:.4f} ms/iteration")
         tm = smp.timing()
         smp.enable_timing(0)
         l1 = smp.summary()["launches"]
