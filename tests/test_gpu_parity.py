@@ -154,7 +154,7 @@ def test_golden_k1_vectors(engine):
 @pytest.mark.parametrize("spec", [(4, 1, "jc69", 4, 5), (4, 1, "jc69", 4, 6), (4, 4, "gtr", 8, 29),
                                   (4, 2, "jc69", 3, 1), (4, 1, "jc69", 2, 1), (4, 4, "gtr", 16, 257),
                                   (4, 8, "gtr", 7, 300), (20, 4, "lg", 6, 200), (20, 1, "lg", 3, 2),
-                                  (20, 4, "lg", 5, 513)])
+                                  (20, 4, "lg", 5, 513), (20, 2, "lg", 5, 70), (20, 3, "lg", 4, 129), (20, 3, "lg", 7, 64)])
 def test_seeded_vs_oracle(engine, spec):
     S, R, model, tips, sites = spec
     rng = np.random.default_rng(sum(x if isinstance(x, int) else len(x) for x in spec) * 7919)
@@ -326,6 +326,33 @@ def test_batched_plan_equals_single_locus_and_oracle(engine, S, R, model):
     nodes = sum(t.inner_count for t in trees)
     assert wk["node_updates"] == nodes
     assert wk["pattern_updates"] == sum(t.inner_count * l.sites for t, l in zip(trees, loci))
+    plan.close()
+
+
+def test_batched_20_state_plan_with_mixed_rate_categories(engine):
+    """one plan, 20-state loci with 1, 2, 3 and 4 rate categories and ragged pattern counts (1 ... 260: partial tiles,
+    partial staging chunks of the P-matrices, idle waves of a workgroup): oracle, and the single-locus bits"""
+    rng = np.random.default_rng(2024)
+    q, freqs = lg_model()
+    loci, trees, want = [], [], []
+    for i, (R, sites) in enumerate([(1, 1), (4, 64), (2, 65), (3, 129), (4, 260), (1, 128), (3, 7), (2, 200)]):
+        tips = int(rng.integers(3, 8))
+        seqs = rand_seqs(tips, sites, AA, rng, extra="-X")
+        w = rng.integers(1, 1000, sites)
+        left, right, times, root = rand_tree(tips, rng, 0.3)
+        rates = bpp_amd.compute_gamma_cats(0.5 + 0.1 * i, 0.5 + 0.1 * i, R) if R > 1 else np.ones(1)
+        scaling = i % 3 == 0
+        loci.append(make_locus(engine, 20, R, "lg", seqs, w, freqs, q, rates, scaling=scaling))
+        trees.append(GTree(left, right, times, root, scaling=scaling))
+        want.append(O.OracleLocus(20, R, seqs, w, model="lg", freqs=freqs, qrates=q, rates=rates,
+                                  scaling=scaling).full_lnl(left, right, times, root))
+    plan = Plan(engine, loci, *build_batch(loci, trees))
+    plan.launch()
+    got = plan.lnl()
+    for a, b in zip(got, want):
+        assert rel(a, b) < LNL_RTOL_TIGHT
+    for loc, gt, a in zip(loci, trees, got):
+        assert full_eval(loc, gt) == a
     plan.close()
 
 
