@@ -53,6 +53,8 @@ typedef struct twin_s
   unsigned int * param_indices;            /* rate_cats */
   int pushed;                              /* 0 until the first push */
   int diploid_done;
+  unsigned char * tip_set;                 /* [tips] 1: the tip's states reached the twin through pll_set_tip_states */
+  int weights_set;                         /* likewise pll_set_pattern_weights */
   /* scratch for one call */
   unsigned int * idx; double * len; bpa_op_t * ops; unsigned int cap;
 } twin_t;
@@ -148,6 +150,7 @@ locus_t * locus_create(unsigned int dtype, unsigned int model, unsigned int tips
   t->param_indices = (unsigned int *)xcalloc(rate_cats, sizeof(unsigned int));
   t->freqs = (double *)xcalloc((size_t)rate_matrices*states, sizeof(double));
   t->subst = (double *)xcalloc((size_t)rate_matrices*nsub, sizeof(double));
+  t->tip_set = (unsigned char *)xcalloc(tips ? tips : 1, 1);
 
   pthread_rwlock_wrlock(&table_lock);
   table_insert_nolock(t);
@@ -174,7 +177,7 @@ void locus_destroy(locus_t * locus)
 
   bpa_locus_destroy(t->dev);
   free(t->rates); free(t->rate_weights); free(t->param_indices); free(t->freqs); free(t->subst);
-  free(t->idx); free(t->len); free(t->ops);
+  free(t->idx); free(t->len); free(t->ops); free(t->tip_set);
   free(t);
   bppref_locus_destroy(locus);
 }
@@ -183,18 +186,65 @@ int pll_set_tip_states(locus_t * locus, unsigned int tip_index, const unsigned i
                        const char * sequence)
 {
   int rc = bppref_pll_set_tip_states(locus, tip_index, map, sequence);
-  if (rc == BPP_SUCCESS && !bpa_set_tip_states(twin_of(locus)->dev, tip_index, map, sequence))
+  twin_t * t = twin_of(locus);
+  if (rc == BPP_SUCCESS && !bpa_set_tip_states(t->dev, tip_index, map, sequence))
     fatal("[bpp_hip] %s", bpa_last_error());
+  if (rc == BPP_SUCCESS && tip_index < locus->tips) t->tip_set[tip_index] = 1;
   return rc;
 }
 
 void pll_set_pattern_weights(locus_t * locus, const unsigned int * pattern_weights)
 {
+  twin_t * t = twin_of(locus);
   bppref_pll_set_pattern_weights(locus, pattern_weights);
-  bpa_set_pattern_weights(twin_of(locus)->dev, pattern_weights);
+  bpa_set_pattern_weights(t->dev, pattern_weights);
+  t->weights_set = 1;
 }
 
 /* ------------------------------------------------------------------- host -> device -- */
+/* A locus restored from a checkpoint (load.c:2016-2140, `bpp --resume`) gets its tip CLVs and its pattern weights written
+   straight into the host struct — no pll_set_tip_states, no pll_set_pattern_weights.  Before the first update, whatever
+   did not arrive through those calls is read off the host struct: a tip's state code per pattern is the set of states its
+   0/1 CLV entries mark (set_tipclv, locus.c:525-559, backwards); the codes go through bpa_set_tip_states with a map made
+   on the spot (one character per distinct code). */
+static void sync_loaded_locus(locus_t * l, twin_t * t)
+{
+  unsigned int tip, n, s;
+  const unsigned int S = l->states, R = l->rate_cats;
+  char * seq = NULL;
+  for (tip = 0; tip < l->tips; ++tip)
+  {
+    unsigned int map[256], used = 1;                 /* character 0 stays unmapped */
+    const double * clv = l->clv[tip];
+    if (t->tip_set[tip]) continue;
+    if (!seq) seq = (char *)xmalloc((size_t)l->sites + 1);
+    memset(map, 0, sizeof(map));
+    for (n = 0; n < l->sites; ++n)
+    {
+      unsigned int code = 0, c;
+      for (s = 0; s < S; ++s) if (clv[((size_t)n*R)*l->states_padded + s] != 0.0) code |= 1u << s;
+      if (!code) fatal("[bpp_hip] tip %u of a restored locus has an empty state set at pattern %u", tip, n);
+      for (c = 1; c < used && map[c] != code; ++c) ;
+      if (c == used)
+      {
+        if (used == 256) fatal("[bpp_hip] more than 255 distinct state sets in one tip sequence");
+        map[used++] = code;
+      }
+      seq[n] = (char)c;
+    }
+    seq[l->sites] = 0;
+    if (!bpa_set_tip_states(t->dev, tip, map, seq))
+      fatal("[bpp_hip] %s", bpa_last_error());
+    t->tip_set[tip] = 1;
+  }
+  free(seq);
+  if (!t->weights_set && !l->diploid)
+  {
+    bpa_set_pattern_weights(t->dev, l->pattern_weights);
+    t->weights_set = 1;
+  }
+}
+
 /* the fields the reference's callers edit in place, pushed when they differ from what the device holds */
 static void push_state(locus_t * l, twin_t * t)
 {
@@ -203,6 +253,7 @@ static void push_state(locus_t * l, twin_t * t)
   const size_t nsub = (size_t)S*(S - 1)/2;
   const int first = !t->pushed;
 
+  if (first) sync_loaded_locus(l, t);
   if (l->diploid && !t->diploid_done)
   {
     /* method.c:4173-4196 installs these after locus_create without a call */

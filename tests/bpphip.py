@@ -203,3 +203,29 @@ def compare_text_runs(ctl_text, files, timeout=900):
     err = max(abs(a - b)/max(abs(a), abs(b), 1e-300) for a, b in zip(n0, n1))
     return dict(logl0_ref=log_l0(out0), logl0_hip=log_l0(out1), all_err=err, identical=(m0 == m1),
                 samples=len([ln for ln in m0.splitlines() if ln.strip()]), stdout_hip=out1)
+
+
+def run_checkpointed(first_bin, resume_bin, ctl_text, files, timeout=900):
+    """`first_bin --cfile a.ctl` with a `checkpoint = ...` line (writes out.1.chk on the way and runs to the end), then
+    `resume_bin --resume out.1.chk` in the same directory (runs from the checkpoint to the end, rewriting the sample
+    file from there).  Returns (sample file after the first run, sample file after the resumed run, resumed stdout)."""
+    d = tempfile.mkdtemp(prefix="bppchk_")
+    try:
+        for name, src in files.items():
+            if os.path.exists(src):
+                shutil.copy(src, os.path.join(d, name))
+            else:
+                open(os.path.join(d, name), "w").write(src)
+        open(os.path.join(d, "a.ctl"), "w").write(ctl_text)
+        r = subprocess.run([first_bin, "--cfile", "a.ctl"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           timeout=timeout, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        assert os.path.exists(os.path.join(d, "out.1.chk")), sorted(os.listdir(d))
+        m0 = open(os.path.join(d, "out.mcmc.txt")).read()
+        r2 = subprocess.run([resume_bin, "--resume", "out.1.chk"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                            timeout=timeout, text=True)
+        assert r2.returncode == 0, r2.stdout[-2000:]
+        m1 = open(os.path.join(d, "out.mcmc.txt")).read()
+        return m0, m1, r2.stdout
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

@@ -132,3 +132,36 @@ def test_species_delimitation_a11():
     assert abs(res["logl0_ref"] - res["logl0_hip"]) <= 1e-10*abs(res["logl0_ref"])
     assert res["all_err"] <= 1e-10, res
     print(f"A11: {res['samples']} samples, numbers agree to {res['all_err']:.1e}, byte-identical: {res['identical']}")
+
+
+@pytest.mark.parametrize("first,second", [("hip", "hip"), ("ref", "hip"), ("hip", "ref")])
+def test_checkpoint_and_resume(first, second):
+    """`checkpoint = 30 1000` + `--resume` (dump.c / load.c:2016-2140): a restored locus gets its tip CLVs and pattern
+    weights written straight into the host struct, with no setter call — the shim reads them off the struct before the
+    first update.  A run resumed from its checkpoint ends with the sample file of the uninterrupted run, whichever of the
+    two programs wrote the checkpoint and whichever resumed it (the checkpoint holds no likelihood state: load.c
+    recomputes all matrices and partials through the locus API)."""
+    bins = {"ref": B.REF_BIN, "hip": B.HIP_BIN}
+    files = B.simulate(B.SIM_CTL.format(seed=9, species=B.SPECIES8_SIM, phase="0 0 0 0 0 0 0 0", nloci=12, sites=300, simmodel=7,
+                                        extra="alpha_siterate = 1 0.5 4\nqrates = 1 1 2 1 0.5 1.5 1\nbasefreqs = 1 0.3 0.2 0.2 0.3\nmodelparafile = syn.para.txt\n"))
+    ctl = B.A00_CTL.format(species=B.SPECIES8, phase="0 0 0 0 0 0 0 0", nloci=12, model="gtr", alpha="alphaprior = 1 1 4",
+                           taub=300, burnin=10, sampfreq=2, nsample=40, extra="checkpoint = 30 1000")
+    rc, out, outs = B.run_program(B.REF_BIN, ctl.replace("checkpoint = 30 1000", ""), files)
+    assert rc == 0
+    want = outs["out.mcmc.txt"]
+    m0, m1, out2 = B.run_checkpointed(bins[first], bins[second], ctl, files)
+    assert m0 == want                      # the checkpointing run itself
+    assert m1 == want                      # ... and the run resumed from the checkpoint
+    if second == "hip":
+        assert "Likelihood back-end: bpp_amd" in out2
+
+
+def test_checkpoint_and_resume_diploid():
+    """the same on the frogs files (unphased diploids: the restored loci also carry the A1 -> A3 mapping, resolution
+    counts and unphased weights, which load.c writes into the struct and the shim hands to bpa_set_diploid)"""
+    ctl = B.FROGS_CTL.format(burnin=10, sampfreq=2, nsample=40, extra="checkpoint = 30 1000")
+    rc, out, outs = B.run_program(B.REF_BIN, ctl.replace("checkpoint = 30 1000", ""), FROGS)
+    assert rc == 0
+    m0, m1, out2 = B.run_checkpointed(B.HIP_BIN, B.HIP_BIN, ctl, FROGS)
+    assert m0 == outs["out.mcmc.txt"] and m1 == outs["out.mcmc.txt"]
+    assert "Likelihood back-end: bpp_amd" in out2
