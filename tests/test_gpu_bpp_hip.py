@@ -165,3 +165,25 @@ def test_checkpoint_and_resume_diploid():
     m0, m1, out2 = B.run_checkpointed(B.HIP_BIN, B.HIP_BIN, ctl, FROGS)
     assert m0 == outs["out.mcmc.txt"] and m1 == outs["out.mcmc.txt"]
     assert "Likelihood back-end: bpp_amd" in out2
+
+
+def test_anopheles_mscm_migration():
+    """examples/anopheles, the MSC-M model of anopheles-bpp-mscm.ctl (two migration bands): the migration-rate and
+    migration-event proposals are the reference's own code, every likelihood they ask for is the library's"""
+    tree = "(R, ((C, G) b, ((A, Q) d, L) c ) a) o;"
+    ctl = B.ANOPHELES_CTL.format(tree=tree, phiprior="wprior = 20 1\nmigration = 2\n  A b\n  R Q", burnin=10, sampfreq=2, nsample=20, extra="")
+    res = B.compare_runs(ctl, ANOPH)
+    check(res)
+    assert res["identical"]
+
+
+def test_bayes_factor_beta_and_prior_only():
+    """`BayesFactorBeta = b` (opt_bfbeta: locus_root_loglikelihood returns b x lnL, locus.c:2630) and `usedata = 0` (it
+    returns 0 and the update calls do nothing, locus.c:2420, 2533, 2580): both reach the library through
+    bpa_engine_set_options"""
+    f = _syn4(16)
+    res = B.compare_runs(_a00(16, nsample=20, extra="BayesFactorBeta = 0.4"), f)
+    check(res)
+    assert res["identical"]
+    res = B.compare_text_runs(_a00(16, nsample=20).replace("usedata = 1\n", "usedata = 0\n"), f)      # (no lnL column)
+    assert res["identical"] and res["all_err"] == 0.0
