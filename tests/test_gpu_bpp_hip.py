@@ -187,3 +187,35 @@ def test_bayes_factor_beta_and_prior_only():
     assert res["identical"]
     res = B.compare_text_runs(_a00(16, nsample=20).replace("usedata = 1\n", "usedata = 0\n"), f)      # (no lnL column)
     assert res["identical"] and res["all_err"] == 0.0
+
+
+SPECIES6 = """6  A B C D E F
+                  1 1 1 1 1 1
+                  ((((A, B), C), (D, E)), F);"""
+
+
+def _aa_files(nloci, sites, seed=3):
+    """amino-acid alignments (the reference's simulator makes DNA only): bpp_amd.synth's LG + Gamma data, the patterns
+    written out `weight` times each, in the reference's sequential PHYLIP + Imap form"""
+    from bpp_amd import synth
+    data = synth.make_dataset(nloci, sites, 6, "lg", 4, seed=seed)
+    names = "ABCDEF"
+    txt = ""
+    for d in data:
+        cols = [j for j, w in enumerate(d["weights"]) for _ in range(int(w))]
+        txt += f"\n6 {len(cols)}\n\n"
+        for t in range(6):
+            txt += f"{names[t]}^{names[t].lower()}1        " + "".join(d["seqs"][t][j] for j in cols) + "\n"
+        txt += "\n"
+    return {"syn.txt": txt, "syn.Imap.txt": "".join(f"{c.lower()}1\t{c}\n" for c in names)}
+
+
+@pytest.mark.parametrize("model,alpha", [("lg", "alphaprior = 1 1 4"), ("wag", ""), ("jtt", "alphaprior = 1 1 4")])
+def test_amino_acid_models_through_the_program(model, alpha):
+    """config 4's kind of locus as the reference program drives it: 20 states, empirical rate matrices (K6 on the device),
+    one or four rate categories with the alpha proposal — the 20-state pipelined K1+K2 kernel and the workgroup-per-branch
+    K5 kernel under method.c's MCMC loop"""
+    ctl = B.A00_CTL.format(species=SPECIES6, phase="0 0 0 0 0 0", nloci=10, model=model, alpha=alpha, taub=40, burnin=10,
+                           sampfreq=2, nsample=25, extra="").replace("thetaprior = gamma 2 1000", "thetaprior = gamma 2 100")
+    res = B.compare_runs(ctl, _aa_files(10, 250))
+    check(res)
