@@ -984,6 +984,9 @@ static int timing_drain(bpa_engine * e)
 // mode bits: 1 = P-matrices, 2 = partials (+ per-pattern lnL terms), 4 = per-locus reduction
 static int plan_launch_mode(bpa_plan * p, int mode)
 {
+  // A/B switches of DESIGN.md's appendix, read once
+  static const bool env_fused_split = getenv("BPA_FUSED_SPLIT") != nullptr, env_pmat_rows = getenv("BPA_PMAT_ROWS") != nullptr,
+                    env_pmat_wg1 = getenv("BPA_PMAT_WG1") != nullptr, env_reduce_thread = getenv("BPA_REDUCE_THREAD") != nullptr;
   bpa_engine * e = p->eng;
   if (!flush(e)) return 0;
   PlanDev d = p->pd;
@@ -1060,7 +1063,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       else if (p->fused_bs == 64) hipExtLaunchKernelGGL((step_jc69_kernel<64, true>), grid, dim3(64), 0, e->stream, k0, k1, 0, d);
       else                        hipExtLaunchKernelGGL((step_jc69_kernel<256, true>), grid, dim3(256), 0, e->stream, k0, k1, 0, d);
     }
-    else if (p->fused_bs == 64 && p->fused_rt == 4 && (d.flags & 1u) && (d.flags & 6u) && getenv("BPA_FUSED_SPLIT"))
+    else if (p->fused_bs == 64 && p->fused_rt == 4 && (d.flags & 1u) && (d.flags & 6u) && env_fused_split)
     {
       // phase A on its own (no events), then B+C with the lighter register footprint
       PlanDev da = d; da.flags = 1u;
@@ -1106,9 +1109,9 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     else
     {
       const unsigned n = d.nmat*p->rmax*20;
-      if (getenv("BPA_PMAT_ROWS"))      // one lane per row (the first version), kept for A/B timing
+      if (env_pmat_rows)                // one lane per row (the first version), kept for A/B timing
         hipLaunchKernelGGL(pmatrix_sN_kernel<20>, dim3((n + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d, p->rmax);
-      else if (getenv("BPA_PMAT_WG1"))  // round 1's workgroup-per-branch kernel
+      else if (env_pmat_wg1)            // round 1's workgroup-per-branch kernel
         hipLaunchKernelGGL(pmatrix_wg_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d, p->rmax);
       else
         hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d);
@@ -1167,7 +1170,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
   if (ts) HIPCHK(hipEventRecord(ts->ev[2], e->stream));
   if (mode & 4)
   {
-    if (getenv("BPA_REDUCE_THREAD"))
+    if (env_reduce_thread)
       hipLaunchKernelGGL(lnl_reduce_kernel, dim3((d.ntasks + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d);
     else
       hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(d.ntasks), dim3(64), 0, e->stream, d);

@@ -131,7 +131,8 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     HIPCHK(hipGetLastError());
     s->g_eigen_dirty = false;
     s->launches++;
-    if (getenv("BPA_GS_SYNC")) { HIPCHK(hipStreamSynchronize(e->stream)); fprintf(stderr, "[gs] eigen done\n"); }
+    static const bool dbg_sync_e = getenv("BPA_GS_SYNC") != nullptr;
+    if (dbg_sync_e) { HIPCHK(hipStreamSynchronize(e->stream)); fprintf(stderr, "[gs] eigen done\n"); }
   }
   PlanDev d{};
   d.loci = e->d_loci.p; d.bfbeta = e->bfbeta;
@@ -165,7 +166,8 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
   }
   HIPCHK(hipGetLastError());
   s->g_evals++;
-  if (getenv("BPA_GS_SYNC")) { HIPCHK(hipStreamSynchronize(e->stream)); fprintf(stderr, "[gs] eval done\n"); }
+  static const bool dbg_sync_v = getenv("BPA_GS_SYNC") != nullptr;
+  if (dbg_sync_v) { HIPCHK(hipStreamSynchronize(e->stream)); fprintf(stderr, "[gs] eval done\n"); }
   return 1;
 }
 
