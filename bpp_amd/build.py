@@ -17,7 +17,7 @@ OUT = os.path.join(HERE, "libbpp_amd.so")
 HOST_OUT = os.path.join(HERE, "libbpp_amd_host.so")      # host-side MCMC control in C (gcc), links libbpp_amd.so
 HOST_SRC = os.path.join(CSRC, "host", "a00_driver.c")
 SOURCES = ["engine.hip", "host_math.cpp", "host_input.cpp"]
-DEPS = ["kernels.hpp", "device_types.hpp", "sampler.hpp", "gsampler.hpp", "gsampler_host.hpp", "gamma_dev.hpp", "p2p.hpp", os.path.join(ROOT, "include", "bpp_amd.h"),
+DEPS = ["kernels.hpp", "device_types.hpp", "sampler.hpp", "sweep2.hpp", "gsampler.hpp", "gsampler_host.hpp", "gamma_dev.hpp", "p2p.hpp", os.path.join(ROOT, "include", "bpp_amd.h"),
         os.path.join(ROOT, "include", "bpp_amd_host.h"), os.path.join(ROOT, "include", "bpp_amd_input.h")]
 
 

@@ -1079,6 +1079,7 @@ __global__ void __launch_bounds__(1024) theta_sum_decide_kernel(const int8_t * _
 
 } // namespace smp
 
+#include "sweep2.hpp"
 #include "gsampler.hpp"
 
 // ------------------------------------------------------------------------------------ host ---
@@ -1154,6 +1155,19 @@ struct bpa_sampler
   a00_rng_t grng = 0;
   unsigned long seed = 0, launches = 0, sweeps = 0;
   bool uploaded = false;
+  // ---- the persistent iteration kernel (sweep2.hpp): one GPU, loci that fit the sweep kernel, root = the last node
+  bool v2_ok = false, env_v1 = false;
+  int v2_nt = 0;                        // its instance: 4 or 8 tips
+  unsigned v2_nwaves = 0, v2_nwg = 0;
+  size_t v2_lds = 0;
+  DevBuf<uint32_t> v2_wave_off;
+  DevBuf<smp2::Loc> v2_loc;
+  DevBuf<uint2> v2_pat;
+  DevBuf<unsigned long long> v2_xbuf;
+  DevBuf<a00_rng_t> v2_grng;
+  DevBuf<int> v2_err;
+  DevBuf<double> v2_prof;
+  unsigned long v2_iters = 0;           // iterations run by persistent launches (bpa_sampler_timing)
 };
 
 extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * const * loci, unsigned nloci,
@@ -1200,6 +1214,7 @@ extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * co
   if (const char * st = getenv("BPA_SMP_STEPS")) { unsigned g = 0, q = 0; if (sscanf(st, "%u,%u", &g, &q) == 2) { s->env_gage = (int)g; s->env_gspr = (int)q; } }
   s->env_trace = getenv("BPA_SMP_TRACE") != nullptr; s->env_nomix = getenv("BPA_SMP_NOMIX") != nullptr;
   s->fuse_decision = getenv("BPA_SMP_FUSE") != nullptr;
+  s->env_v1 = getenv("BPA_SMP_V1") != nullptr;
   s->sp.ft_gage = 0.004; s->sp.ft_gspr = 0.004; s->sp.ft_tau = 0.001; s->sp.ft_mix = 0.3;      // a00_create's defaults
   return s;
 }
@@ -1216,6 +1231,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
   s->g_len.free(); s->g_lograt.free(); s->g_active.free(); s->g_recs.free(); s->g_mat2.free(); s->g_bmo.free();
   s->g_sm.free(); s->g_sm_old.free(); s->g_ids.free();
+  s->v2_wave_off.free(); s->v2_loc.free(); s->v2_pat.free(); s->v2_xbuf.free(); s->v2_grng.free(); s->v2_err.free(); s->v2_prof.free();
   delete s;
 }
 
@@ -1267,9 +1283,85 @@ static int assign_pops_host(const bpa_sampler * s, TR & t)
   return 1;
 }
 static int gs_upload(bpa_sampler * s);
+static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double mix_lnc, unsigned tau_q, double tau_u, double dec_uacc);
 static int gs_initialize(bpa_sampler * s);
 static int gs_iterate(bpa_sampler * s, unsigned iterations);
 static int gs_download(bpa_sampler * s);
+
+// ---- the persistent iteration kernel (sweep2.hpp): tables, eligibility, launch
+template <int NT> static size_t v2_lds_base()
+{
+  return ((sizeof(smp2::WgLDS<NT>) + 15) & ~(size_t)15) + sizeof(smp2::WaveLDS<NT>)*(size_t)smp2::Cfg<NT>::WAVES;
+}
+// v2_ok stays false where the kernel does not apply (the one-launch-per-step path of this file then runs): more loci than
+// stay resident on the device at once, a tree whose root is not its last node or whose buffer indices are not the
+// reference's start values toggled (gtree.c:2398, 2433: clv_index = pmatrix_index = node index), BPA_SMP_V1=1
+static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & task_rec)
+{
+  s->v2_ok = false;
+  if (s->env_v1 || s->generic) return 1;
+  const unsigned T = s->nloci;
+  const int npop = s->sp.npop;
+  if (s->maxtips > 8 || npop > 15) return 1;
+  const int NT = (s->maxtips <= 4 && npop <= 7) ? 4 : 8;
+  for (unsigned i = 0; i < T; ++i)
+  {
+    const smp::Tree & t = s->h_trees[i];
+    const int n = 2*t.tips - 1, inner = t.tips - 1, edges = 2*t.tips - 2;
+    if (t.root != n - 1) return 1;
+    for (int k = 0; k < n; ++k)
+    {
+      if (k < t.tips ? t.clv[k] != k : (t.clv[k] != k && t.clv[k] != k + inner)) return 1;
+      if (k != t.root && t.pmat[k] != k && t.pmat[k] != k + edges) return 1;
+    }
+  }
+  const unsigned G = NT == 4 ? 8 : 16, LPW = 64/G, WAVES = NT == 4 ? (unsigned)smp2::Cfg<4>::WAVES : (unsigned)smp2::Cfg<8>::WAVES;
+  std::vector<uint32_t> woff{0};
+  std::vector<smp2::Loc> loc(T);
+  std::vector<uint2> pat;
+  unsigned cnt = 0, used = 0;
+  for (unsigned t = 0; t < T; ++t)
+  {
+    const bpa_locus * l = s->loci[t];
+    const unsigned np = l->sites, tips = l->tips;
+    if (cnt == LPW || used + np > 64u) { woff.push_back(t); cnt = 0; used = 0; }
+    ++cnt; used += np;
+    smp2::Loc & L = loc[t];
+    const smp::TaskRec & r = task_rec[t];
+    L.clv = r.clv; L.pmat = r.pmat; L.rate = r.rate; L.rw = r.rw; L.f0 = r.f0; L.f1 = r.f1; L.f2 = r.f2; L.f3 = r.f3;
+    L.np = np; L.tips = tips; L.pat_off = (uint32_t)pat.size(); L.pad = 0;
+    for (int p = 0; p < 16; ++p) L.gl[p] = r.gl[p];
+    for (unsigned n = 0; n < np; ++n)
+    {
+      uint32_t codes = 0;
+      for (unsigned tip = 0; tip < tips; ++tip) codes |= (uint32_t)(l->tipcodes[(size_t)tip*np + n] & 15u) << (4*tip);
+      pat.push_back(make_uint2(l->weights[n], codes));
+    }
+  }
+  woff.push_back(T);
+  const unsigned nwaves = (unsigned)woff.size() - 1, nwg = (nwaves + WAVES - 1)/WAVES;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, s->eng->device));
+  // every workgroup must be resident (they wait for each other's sums): one per CU — a workgroup takes most of a CU's LDS
+  const size_t base = NT == 4 ? v2_lds_base<4>() : v2_lds_base<8>();
+  const size_t lds_max = std::min<size_t>((size_t)prop.sharedMemPerBlock > 65536 ? (size_t)prop.sharedMemPerBlock : 160*1024, 160*1024) - 256;
+  if (base > lds_max) return 1;
+  // (the LDS decides how many workgroups a CU holds; two waves per SIMD at most are counted on)
+  const unsigned per_cu = (unsigned)std::min<size_t>(std::max<size_t>(lds_max/base, 1), 8/WAVES ? 8/WAVES : 1);
+  if (nwg > per_cu*(unsigned)prop.multiProcessorCount) return 1;
+  s->v2_lds = base;
+  s->v2_nt = NT; s->v2_nwaves = nwaves; s->v2_nwg = nwg;
+  const int zero = 0;
+  if (!upload(s->v2_wave_off, woff.data(), woff.size()) || !upload(s->v2_loc, loc.data(), loc.size()) ||
+      !upload(s->v2_pat, pat.data(), pat.size()) || !s->v2_xbuf.reserve((size_t)2*smp2::XN) || !s->v2_grng.reserve(1) ||
+      !upload(s->v2_err, &zero, 1) || !s->v2_prof.reserve(16 + (size_t)nwg))
+    return 0;
+  HIPCHK(hipMemset(s->v2_prof.p, 0, (16 + (size_t)nwg)*sizeof(double)));
+  void (*kern)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4> : smp2::iter_kernel<8>;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->v2_lds));
+  s->v2_ok = true;
+  return 1;
+}
 
 static int sampler_upload(bpa_sampler * s)
 {
@@ -1354,6 +1446,7 @@ static int sampler_upload(bpa_sampler * s)
   hipLaunchKernelGGL(smp::lograt_kernel, dim3(1), dim3(smp::MAXN*smp::MAXN), 0, e->stream, s->lograt.p);
   HIPCHK(hipGetLastError());
   s->epoch = 0; s->mix_pending = false;
+  if (!sampler_upload_v2(s, task_rec)) return 0;
   s->uploaded = true;
   return 1;
 }
@@ -1581,12 +1674,60 @@ extern "C" int bpa_sampler_set_allreduce(bpa_sampler_t * s, bpa_allreduce_fn fn,
   return 1;
 }
 
+// the whole iteration(s) as persistent launches: GAGE + GSPR of every locus, THETA, TAU per divergence, MIX — state in
+// LDS from the first proposal to the last decision (sweep2.hpp)
+static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations)
+{
+  bpa_engine * e = s->eng;
+  // anything the one-launch-per-step path left pending is settled first (decision of an all-loci step, stale densities)
+  if ((s->mix_pending || s->logpr_stale) && !sampler_launch(s, 2, 1.0, 0.0, 0, 0.0, -1.0)) return 0;
+  const int npop = s->sp.npop, S = s->sp.S;
+  uint32_t theta_mask = 0;
+  if (s->sp.theta_alpha > 0) for (int p = 0; p < npop; ++p) if (s->has_theta[p]) theta_mask |= 1u << p;
+  const bool allloci = !s->env_nomix;
+  const unsigned draws_per_iter = allloci ? 2u*(unsigned)__builtin_popcount(theta_mask) + 2u*(unsigned)(npop - S) + 2u : 0u;
+  void (*kern)(const smp2::Args) = s->v2_nt == 4 ? smp2::iter_kernel<4> : smp2::iter_kernel<8>;
+  const unsigned bs = s->v2_nt == 4 ? smp2::Cfg<4>::BS : smp2::Cfg<8>::BS;
+  while (iterations)
+  {
+    const unsigned chunk = std::min(iterations, 4096u);          // (bounds one launch's duration)
+    smp2::Args a{};
+    a.wave_off = s->v2_wave_off.p; a.loc = s->v2_loc.p; a.pat = s->v2_pat.p; a.trees = s->trees.p; a.taus = s->taus.p;
+    a.counters = s->counters.p; a.lograt = s->lograt.p; a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p;
+    a.ntasks = s->nloci; a.nwaves = s->v2_nwaves; a.nwg = s->v2_nwg; a.xbuf = s->v2_xbuf.p;
+    a.err = s->v2_err.p; a.grng = s->v2_grng.p; a.niter = chunk;
+    a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2;
+    if (s->env_gage >= 0) { a.nsteps_gage = (uint32_t)s->env_gage; a.nsteps_gspr = (uint32_t)s->env_gspr; }
+    a.theta_mask = theta_mask; a.do_allloci = allloci ? 1u : 0u; a.dbg = s->env_dbg;
+    a.bfbeta = e->usedata ? e->bfbeta : 0.0; a.prof = s->v2_prof.p; a.sp = s->sp;
+    HIPCHK(hipMemcpyAsync(s->v2_grng.p, &s->grng, sizeof(a00_rng_t), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(s->v2_xbuf.p, 0, (size_t)2*smp2::XN*sizeof(unsigned long long), e->stream));
+    if (s->timing_stride && (s->timing_phase++ % s->timing_stride) == 0)
+    {
+      if (s->timed.size() >= 4096 && !sampler_timing_drain(s)) return 0;
+      bpa_sampler::Timed t{nullptr, nullptr, 0};
+      HIPCHK(hipEventCreate(&t.e0)); HIPCHK(hipEventCreate(&t.e1));
+      hipExtLaunchKernelGGL(kern, dim3(s->v2_nwg), dim3(bs), s->v2_lds, e->stream, t.e0, t.e1, 0, a);
+      s->timed.push_back(t);
+    }
+    else
+      hipLaunchKernelGGL(kern, dim3(s->v2_nwg), dim3(bs), s->v2_lds, e->stream, a);
+    HIPCHK(hipGetLastError());
+    // the host's copy of the global stream follows the kernel's draws
+    for (unsigned long k = 0; k < (unsigned long)chunk*draws_per_iter; ++k) (void)a00_rndu(&s->grng);
+    s->launches++; s->sweeps += chunk; s->v2_iters += chunk;
+    iterations -= chunk;
+  }
+  return 1;
+}
+
 extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
 {
   bpa_engine * e = s->eng;
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   if (!sampler_upload(s)) return 0;
   if (s->generic) return gs_iterate(s, iterations);
+  if (s->v2_ok && !s->allreduce && !s->env_trace) return sampler_iterate_v2(s, iterations);
   const bool fused = s->fuse_decision && !s->allreduce && !s->env_trace;      // (several GPUs: sum -> all-reduce -> decide)
   for (unsigned it = 0; it < iterations; ++it)
   {
@@ -1659,6 +1800,24 @@ static int sampler_download(bpa_sampler * s)
   int err = 0;
   HIPCHK(hipMemcpy(&err, s->dec_err, sizeof err, hipMemcpyDeviceToHost));
   if (err) return fail("bpa_sampler: an in-launch decision timed out waiting for a workgroup's sum (BPA_SMP_FUSE is set: unset it)");
+  if (s->v2_ok)
+  {
+    if (s->env_dbg & 16u)
+    {
+      double pr[16]; HIPCHK(hipMemcpy(pr, s->v2_prof.p, sizeof pr, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[smp2] cycles of lane 0 of workgroup 0, last launch: propose %.0f evaluate %.0f decide %.0f theta %.0f tau %.0f mix %.0f | exchange: theta %.0f tau+mix %.0f | inside the exchanges: first barrier %.0f sums %.0f barrier %.0f arrival + poll %.0f last barrier %.0f\n",
+              pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11], pr[12]);
+    }
+    if (s->env_dbg & 32u)
+    {
+      std::vector<double> w(s->v2_nwg); HIPCHK(hipMemcpy(w.data(), s->v2_prof.p + 16, w.size()*sizeof(double), hipMemcpyDeviceToHost));
+      double mn = 1e300, mx = 0, sm = 0; unsigned imx = 0;
+      for (unsigned i = 0; i < w.size(); ++i) { mn = std::min(mn, w[i]); if (w[i] > mx) { mx = w[i]; imx = i; } sm += w[i]; }
+      fprintf(stderr, "[smp2] sweep cycles per workgroup, last launch: min %.0f mean %.0f max %.0f (workgroup %u of %u)\n", mn, sm/w.size(), mx, imx, s->v2_nwg);
+    }
+    HIPCHK(hipMemcpy(&err, s->v2_err.p, sizeof err, hipMemcpyDeviceToHost));
+    if (err) return fail("bpa_sampler: the persistent iteration kernel timed out waiting for a workgroup's sum (is the device shared? BPA_SMP_V1=1 selects one launch per step)");
+  }
   return 1;
 }
 

@@ -1,0 +1,865 @@
+// sweep2.hpp — the A00 iteration as ONE persistent launch (round 3).
+//
+// sampler.hpp's sweep kernel gives every locus one LEADER lane that runs the proposal bookkeeping of propose_ages /
+// propose_spr (gtree.c:4585, 6531) alone while the other lanes of its wave wait: one wave per SIMD, <= 12 of 64 lanes
+// busy, and the launch lasts as long as that lane's instruction stream.  Here
+//
+//  * a locus owns an ALIGNED GROUP of G = 8 (<= 4 tips) or 16 (<= 8 tips) lanes.  Every lane of the group runs the
+//    proposal (the integer tree — children, parent, population of <= 15 nodes — is replicated in its registers as byte
+//    arrays, so a look-up is one v_perm_b32 and costs nothing extra: a wave instruction is paid for 64 lanes anyway),
+//    but every LOOP of the leader's code is gone: lane i IS node i, population i, branch i and pattern i (+G, +2G ...),
+//    a loop over nodes or populations is one predicate per lane + one wave ballot whose group's byte is the node set.
+//    Per-population lineage counts come from nin_p = (gene tips below p) - (coalescences strictly below p), so the
+//    children-first chain of gtree_update_logprob_contrib's bookkeeping is one pass too;
+//  * buffer toggles are two bit masks: clv_index of inner node i is i or i + inner, pmatrix_index i or i + edges
+//    (locus.c:24-26 with the start values of gtree.c:2398, 2433) — a toggle of a node set is one XOR;
+//  * the state of ALL loci (trees, CLV buffers, (a,b) tables: 17 MB for config 2) stays in LDS for the whole launch —
+//    many iterations — instead of going to HBM and back ten times per iteration;
+//  * the single decision of an all-loci step (TAU, MIX, THETA: stree.c:5512, prop_mixing.c:52, stree.c:3464) needs the
+//    sum over every locus: each workgroup publishes its partial sum as 8-byte {epoch, half} granules with write-through
+//    stores, wave 0 of every workgroup gathers all of them (relaxed agent-scope loads until every tag is this step's),
+//    adds them up in workgroup order and takes the same decision bit for bit — an all-gather, no second broadcast hop.
+//    Every spin is bounded (wall clock); a time-out raises the error word and every workgroup leaves.
+//
+// Arithmetic (proposal windows, reflections, density terms, JC69 exponentials, 4x4 mat-vecs, ordered sums, Metropolis-
+// Hastings ratios) is sampler.hpp's, operation for operation: same per-locus streams, same trajectory as the host
+// driver csrc/host/a00_driver.c (tests/test_gpu_sampler.py).  One GPU; with an all-reduce callback installed (several
+// ranks) bpa_sampler_iterate keeps to sampler.hpp's one-launch-per-step path.
+#pragma once
+
+namespace smp2 {
+
+using smp::Tree; using smp::Species; using smp::ByteArr; using smp::MAXPOP; using smp::MAXN;
+using smp::rndu; using smp::reflect; using smp::msc_term; using smp::nth_bit; using smp::Op; using smp::make_op;
+
+template <int NT> struct Cfg
+{
+  static constexpr int G     = NT <= 4 ? 8 : 16;     // lanes per locus = node slots = population slots
+  static constexpr int LPW   = 64/G;                 // loci per wave
+  static constexpr int NN    = 2*NT;                 // node slots (2 NT - 1 nodes)
+  static constexpr int W     = NN/4;                 // 32-bit words of a byte array
+  static constexpr int NBUF  = 2*(NT - 1);
+  static constexpr int NPM   = 2*(2*NT - 2);
+#ifndef SMP2_WAVES
+#define SMP2_WAVES 8
+#endif
+  static constexpr int WAVES = NT <= 4 ? SMP2_WAVES : 4;      // per workgroup: 64 / 16 loci
+  static constexpr int BS    = 64*WAVES;
+  static_assert(G == NN, "lane i of a group is node i");
+};
+
+struct Loc                               // per locus, constant over the run (flattened at upload)
+{
+  double * clv, * pmat;                  // inner CLV buffer 0 / the (a,b) table
+  double rate, rw, f0, f1, f2, f3;
+  uint32_t np, tips, pat_off, pad;
+  int8_t gl[16];                         // gene tips below each population
+};
+
+struct Args
+{
+  const uint32_t * wave_off;             // [nwaves + 1] first locus of every wave
+  const Loc * loc;
+  const uint2 * pat;                     // per pattern: weight, tip codes (4 bits per tip)
+  Tree * trees;
+  double * taus;                         // [3 MAXPOP] tau | theta | log(2/theta): read at entry, written back by workgroup 0
+  uint32_t * counters;                   // all-loci proposals / accepted
+  const double * lograt;
+  int8_t * pop_nc; double * pop_t2h;     // sufficient statistics of the final state (sampler.hpp's THETA kernels read them)
+  uint32_t ntasks, nwaves, nwg;
+  unsigned long long * xbuf;             // [2][XN] accumulators of the all-loci steps' sums
+  int * err;
+  a00_rng_t * grng;                      // the global stream: read at entry, written back by workgroup 0
+  uint32_t niter, nsteps_gage, nsteps_gspr, theta_mask, do_allloci, dbg;
+  double bfbeta;
+  double * prof;
+  Species sp;
+};
+
+constexpr int XN = 64;                   // words per accumulator set: 8 shards x (7 sums + the arrival counter)
+
+template <int NT> struct Slot
+{
+  double time[Cfg<NT>::NN];
+  double ab[Cfg<NT>::NPM][2];
+  double contrib[Cfg<NT>::G], contrib_new[Cfg<NT>::G];
+  double dl, pad;
+};
+template <int NT> struct WaveLDS
+{
+  double clv[Cfg<NT>::NBUF][64][4];
+  double term[64];
+  uint2  pat[64];
+  Slot<NT> slot[Cfg<NT>::LPW];
+};
+template <int NT> struct WgLDS
+{
+  double tau[3*MAXPOP];
+  double lograt[(2*NT)*(2*NT)];
+  unsigned long long accfx[16];                  // this workgroup's sums of an all-loci step, 2^-44 fixed point (LDS atomics)
+  double xtot[16];
+  uint32_t anc[16];
+  uint32_t abort_, bad_;
+};
+
+template <int G> __device__ __forceinline__ uint32_t gballot(bool p, uint32_t gbase)
+{
+  return (uint32_t)(__ballot(p) >> gbase) & ((1u << G) - 1u);
+}
+// LDS traffic between the lanes of ONE wave: the hardware runs a wave's DS instructions in order; this keeps the
+// compiler from moving accesses across the hand-over
+__device__ __forceinline__ void wsync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// the integer part of a gene tree, replicated in every lane of the locus's group
+template <int NT> struct GTree
+{
+  ByteArr<Cfg<NT>::W> left, right, parent, pop;
+  uint32_t cf, pf;                       // toggle flags per node: CLV buffer / P-matrix buffer
+  int32_t root, tips;
+  __device__ __forceinline__ int cidx(int i) const { return i + (((cf >> i) & 1u) ? tips - 1 : 0); }
+  __device__ __forceinline__ int pidx(int i) const { return i + (((pf >> i) & 1u) ? 2*tips - 2 : 0); }
+};
+
+__device__ __forceinline__ uint32_t splat(int v) { return (uint32_t)(v & 0xff)*0x01010101u; }
+// 0xff in every byte of w that equals the byte splatted in s
+__device__ __forceinline__ uint32_t byte_eq(uint32_t w, uint32_t s)
+{
+  const uint32_t x = w ^ s;
+  const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);      // 0x80 where the byte is zero
+  return (z - (z >> 7)) | z;
+}
+// exchange the tree positions of node ids a and b (swap_ids of a00_driver.c): every reference to a becomes b and
+// vice versa — on all bytes of a word at once —, then the two entries change places; buffer flags stay with the ids
+template <int NT> __device__ __forceinline__ void swap_ids(GTree<NT> & t, double * time, int a, int b)
+{
+  constexpr int W = Cfg<NT>::W;
+  const uint32_t sa = splat(a), sb = splat(b), x = sa ^ sb;
+#pragma unroll
+  for (int k = 0; k < W; ++k)
+  {
+    t.left.w[k]   ^= x & (byte_eq(t.left.w[k], sa)   | byte_eq(t.left.w[k], sb));
+    t.right.w[k]  ^= x & (byte_eq(t.right.w[k], sa)  | byte_eq(t.right.w[k], sb));
+    t.parent.w[k] ^= x & (byte_eq(t.parent.w[k], sa) | byte_eq(t.parent.w[k], sb));
+  }
+  const int la = t.left[a], ra = t.right[a], pa = t.parent[a], qa = t.pop[a];
+  const int lb = t.left[b], rb = t.right[b], pb = t.parent[b], qb = t.pop[b];
+  t.left.set(a, lb); t.right.set(a, rb); t.parent.set(a, pb); t.pop.set(a, qb);
+  t.left.set(b, la); t.right.set(b, ra); t.parent.set(b, pa); t.pop.set(b, qa);
+  const double ta = time[a], tb = time[b];
+  time[a] = tb; time[b] = ta;
+  t.root = t.root == a ? b : t.root == b ? a : t.root;
+}
+template <int NT> __device__ __forceinline__ uint32_t path_mask(const GTree<NT> & t, int v)
+{
+  uint32_t m = 0;
+#pragma unroll
+  for (int d = 0; d < NT; ++d) { if (v >= 0) { m |= 1u << v; v = t.parent[v]; } }
+  return m;
+}
+
+// what the lanes keep about the species tree: lane i is population i
+struct PopLane
+{
+  double tau, ptau, theta, l2t;          // this launch's current (or, inside an all-loci step, proposed) values
+  int32_t parent;
+  uint32_t anc, below;                   // ancestors-or-self / strict descendants of population i
+};
+
+// the proposal of one per-locus step, as left by propose_*: what to recompute
+struct Prop { uint32_t chain, brm, ndm; double hast; };
+
+// GAGE on the k-th inner node (gage_step of a00_driver.c; propose_ages, gtree.c:4585) — all lanes of the group
+template <int NT>
+__device__ __forceinline__ bool propose_gage(GTree<NT> & t, a00_rng_t & rng, double * time, int k, const PopLane & pl,
+                                             const uint32_t * anc, const double * tau, double ft, int li, uint32_t gbase, Prop & pr)
+{
+  constexpr int G = Cfg<NT>::G;
+  const int n = 2*t.tips - 1, v = t.tips + k;
+  if (v >= n) return false;
+  const double u = rndu(&rng);
+  const int l = t.left[v], r = t.right[v], p = t.parent[v];
+  const double tl = time[l], tr = time[r], told = time[v], tpar = time[p < 0 ? 0 : p];
+  const int pol = t.pop[l], por = t.pop[r];
+  const uint32_t al = anc[pol], ar = anc[por];
+  double lo = fmax(tl, tr);
+  if (pol != por) lo = fmax(lo, tau[__ffs(al & ar) - 1]);          // the youngest common ancestor: the lowest common bit
+  const double hi = p >= 0 ? tpar : 999.0;
+  if (!(hi > lo)) { (void)rndu(&rng); return false; }
+  const double tnew = reflect(told + ft*(u - 0.5), lo, hi);
+  const int oldpop = t.pop[v];
+  time[v] = tnew;
+  // climb (gtree.c:4790-4797): the highest ancestor-or-self of the left child's population that has started by tnew
+  const uint32_t cm = gballot<G>(li == pol || (((al >> li) & 1u) && pl.tau <= tnew), gbase);
+  const int newpop = 31 - __clz(cm);
+  t.pop.set(v, newpop);
+  {
+    const uint32_t aa = anc[oldpop], ab = anc[newpop];
+    const bool a_lower = (aa >> newpop) & 1u;
+    const uint32_t lw = a_lower ? aa : ab, hg = a_lower ? ab : aa;
+    const int higher = a_lower ? newpop : oldpop;
+    pr.chain = lw & ~(hg & ~(1u << higher));
+  }
+  pr.hast = 0;
+  pr.brm = (1u << l) | (1u << r) | (p >= 0 ? 1u << v : 0u);
+  pr.ndm = path_mask<NT>(t, v);
+  return true;
+}
+
+// GSPR on the k-th non-root node (gspr_step of a00_driver.c; propose_spr, gtree.c:6531) — all lanes of the group
+template <int NT>
+__device__ __forceinline__ bool propose_gspr(GTree<NT> & t, a00_rng_t & rng, double * time, int k, const PopLane & pl, int gl_i,
+                                             const uint32_t * anc, const double * tau, const double * lograt, double ft,
+                                             int li, uint32_t gbase, Prop & pr)
+{
+  constexpr int G = Cfg<NT>::G;
+  const int n = 2*t.tips - 1;
+  const int a = k < t.root ? k : k + 1;
+  if (a >= n) return false;
+  const double u1 = rndu(&rng), u2 = rndu(&rng);
+  const int root_before = t.root;
+  const int p = t.parent[a], lp = t.left[p], s = lp == a ? (int)t.right[p] : lp, g = t.parent[p];
+  // gene tips below a: lane i walks up from node i
+  uint32_t sub;
+  {
+    int x = li; bool in = false;
+#pragma unroll
+    for (int d = 0; d < NT; ++d) { in = in || x == a; x = x >= 0 ? (int)t.parent[x] : x; }
+    sub = gballot<G>(in && li < n, gbase);
+  }
+  const int leaves = __popc(sub & ((1u << t.tips) - 1u));
+  const int popa = t.pop[a];
+  const uint32_t apa = anc[popa];
+  // youngest population from a's upwards that holds gene tips outside a's subtree (gtree.c:6664-6669)
+  const int pop0 = __ffs(gballot<G>(((apa >> li) & 1u) && (gl_i > leaves || pl.parent < 0), gbase)) - 1;
+  const double ta = time[a], tpo = time[p], troot = time[root_before];
+  const double lo = fmax(ta, tau[pop0]);
+  const double tnew = reflect(tpo + ft*(u1 - 0.5), lo, 999.0);
+  const int popt = 31 - __clz(gballot<G>(li == popa || (((apa >> li) & 1u) && pl.tau <= tnew), gbase));
+  // targets (bit j = branch above node j; the father's own branch stands for the sibling's) and sources: lane j looks at node j
+  uint32_t tmask; int nsrc;
+  {
+    const int pp = t.pop[p];
+    const bool above_root = tnew >= troot, src_on = p != root_before;
+    const int j = li, pj = t.parent[j];
+    const double tj = time[j], tpj = time[pj < 0 ? 0 : pj];
+    const uint32_t aj = anc[(int)t.pop[j] & 15];
+    const bool in = j < n && j != a && j != root_before;
+    tmask = gballot<G>(in && !above_root && tj <= tnew && tpj > tnew && ((aj >> popt) & 1u), gbase);
+    nsrc = 1 + __popc(gballot<G>(in && src_on && j != s && j != p && tj <= tpo && tpj > tpo && ((aj >> pp) & 1u), gbase));
+    if (above_root) tmask = 1u << root_before;
+  }
+  const int ntg = __popc(tmask);
+  if (!ntg) { (void)rndu(&rng); return false; }
+  int pick = (int)(u2*ntg);
+  if (pick == ntg) pick = 0;
+  int tgt = nth_bit(tmask, pick);
+  if (tgt == p) tgt = s;
+  // prune: the sibling takes p's place; regraft p (with a below it) above tgt at tnew in popt
+  t.parent.set(s, g);
+  if (g >= 0) { if (t.left[g] == p) t.left.set(g, s); else t.right.set(g, s); } else t.root = s;
+  const int pc = t.parent[tgt];
+  {
+    const int pp = t.pop[p];
+    const uint32_t aa = anc[pp], ab = anc[popt];
+    const bool a_lower = (aa >> popt) & 1u;
+    const uint32_t lw = a_lower ? aa : ab, hg = a_lower ? ab : aa;
+    const int higher = a_lower ? popt : pp;
+    pr.chain = lw & ~(hg & ~(1u << higher));
+  }
+  time[p] = tnew; t.pop.set(p, popt);
+  t.left.set(p, a); t.right.set(p, tgt); t.parent.set(a, p); t.parent.set(tgt, p);
+  t.parent.set(p, pc);
+  if (pc >= 0) { if (t.left[pc] == tgt) t.left.set(pc, p); else t.right.set(pc, p); } else t.root = p;
+  uint32_t ndm = path_mask<NT>(t, p);
+  if (g >= 0) ndm |= path_mask<NT>(t, g);
+  uint32_t bset = (1u << a) | (1u << tgt) | (1u << p) | (1u << s);
+  if (t.root != root_before)
+  {
+    // the root node object keeps its identity (gtree.c:6129-6175): rename the two ids in the sets
+    const int newtop = t.root;
+    wsync();
+    swap_ids<NT>(t, time, newtop, root_before);
+    const uint32_t bn = 1u << newtop, br_ = 1u << root_before;
+    auto ren = [&](uint32_t m) { const uint32_t hn = m & bn, hr = m & br_; m &= ~(bn | br_); if (hn) m |= br_; if (hr) m |= bn; return m; };
+    ndm = ren(ndm) | path_mask<NT>(t, newtop);
+    bset = ren(bset);
+  }
+  // branches of the set that exist (the root has none): lane j answers for node j
+  pr.brm = bset & gballot<G>((int)t.parent[li] >= 0 && li < n, gbase);
+  pr.ndm = ndm;
+  pr.hast = lograt[ntg*(2*NT) + nsrc];
+  return true;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
+{
+  using C = Cfg<NT>;
+  constexpr int G = C::G, LPW = C::LPW, NN = C::NN, W = C::W, NBUF = C::NBUF, NPM = C::NPM, WAVES = C::WAVES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  WgLDS<NT> & wg = *reinterpret_cast<WgLDS<NT> *>(smem);
+  WaveLDS<NT> * wl_all = reinterpret_cast<WaveLDS<NT> *>(smem + ((sizeof(WgLDS<NT>) + 15) & ~(size_t)15));
+  const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63u, b = blockIdx.x;
+  const int li = (int)(lane & (uint32_t)(G - 1)); const uint32_t gbase = lane - (uint32_t)li, slot = lane/(uint32_t)G;
+  WaveLDS<NT> & wl = wl_all[wv];
+  Slot<NT> & S = wl.slot[slot];
+  const uint32_t gw = b*WAVES + wv;                               // global wave
+  const int npop = A.sp.npop, nsp = A.sp.S;
+
+  // ---- species tree: the workgroup's copy of the parameters, the topology per lane
+  for (uint32_t i = tid; i < (uint32_t)(3*MAXPOP); i += C::BS) wg.tau[i] = A.taus[i];
+  for (uint32_t i = tid; i < (uint32_t)((2*NT)*(2*NT)); i += C::BS) wg.lograt[i] = A.lograt[(i/(2*NT))*MAXN + i % (2*NT)];
+  if (tid < 16u) wg.anc[tid] = tid < (uint32_t)MAXPOP ? (uint32_t)A.sp.anc[tid] : 0u;
+  if (tid == 0) { wg.abort_ = 0; wg.bad_ = 0; }
+  if (tid < 16u) wg.accfx[tid] = 0ull;
+  PopLane pl;
+  ByteArr<4> sp_left, sp_right;
+  {
+    const uint32_t * q = reinterpret_cast<const uint32_t *>(A.sp.left);
+    for (int k = 0; k < 4; ++k) sp_left.w[k] = q[k];
+    q = reinterpret_cast<const uint32_t *>(A.sp.right);
+    for (int k = 0; k < 4; ++k) sp_right.w[k] = q[k];
+    pl.parent = li < npop ? (int)A.sp.parent[li < MAXPOP ? li : 0] : -1;
+    pl.anc = li < npop ? (uint32_t)A.sp.anc[li < MAXPOP ? li : 0] : 0u;
+    uint32_t below = 0;
+    for (int q2 = 0; q2 < npop; ++q2) if (q2 != li && (((uint32_t)A.sp.anc[q2] >> li) & 1u)) below |= 1u << q2;
+    pl.below = li < npop ? below : 0u;
+  }
+  __syncthreads();
+  auto load_pop = [&]()
+  {
+    const int i = li < MAXPOP ? li : 0;
+    pl.tau = wg.tau[i]; pl.theta = wg.tau[MAXPOP + i]; pl.l2t = wg.tau[2*MAXPOP + i];
+    pl.ptau = pl.parent >= 0 ? wg.tau[pl.parent] : -1.0;
+  };
+  load_pop();
+  a00_rng_t grng = *A.grng;
+
+  // ---- load: the loci of this wave
+  const uint32_t t0 = gw < A.nwaves ? A.wave_off[gw] : 0u, nt = gw < A.nwaves ? A.wave_off[gw + 1] - t0 : 0u;
+  const bool act = slot < nt;
+  const uint32_t task = t0 + (act ? slot : 0u);
+  GTree<NT> T;
+  a00_rng_t rng = 0;
+  double lnl_cur = 0, logpr_cur = 0, rate = 1, rw = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+  uint32_t np = 0, pb = 0, nprop_done = 0, nacc = 0, w_nupd = 0, w_nbr = 0;
+  int gl_i = 0;
+  double * g_clv = nullptr, * g_pmat = nullptr;
+  for (int k = 0; k < W; ++k) { T.left.w[k] = T.right.w[k] = T.parent.w[k] = T.pop.w[k] = 0xffffffffu; }
+  T.cf = T.pf = 0; T.root = 0; T.tips = 2;
+  if (act && nt)
+  {
+    const Loc & L = A.loc[task];
+    const Tree & tr = A.trees[task];
+    np = L.np; rate = L.rate; rw = L.rw; f0 = L.f0; f1 = L.f1; f2 = L.f2; f3 = L.f3; g_clv = L.clv; g_pmat = L.pmat;
+    gl_i = L.gl[li & 15];
+    for (int k = 0; k < W; ++k)
+    {
+      T.left.w[k] = reinterpret_cast<const uint32_t *>(tr.left)[k]; T.right.w[k] = reinterpret_cast<const uint32_t *>(tr.right)[k];
+      T.parent.w[k] = reinterpret_cast<const uint32_t *>(tr.parent)[k]; T.pop.w[k] = reinterpret_cast<const uint32_t *>(tr.pop)[k];
+    }
+    T.root = tr.root; T.tips = tr.tips; rng = tr.rng; lnl_cur = tr.lnl; logpr_cur = tr.logpr;
+    const int n = 2*T.tips - 1;
+    T.cf = gballot<G>(li >= T.tips && li < n && tr.clv[li] != li, gbase);
+    T.pf = gballot<G>(li < n && tr.pmat[li] != li, gbase);
+    S.time[li] = li < n ? tr.time[li] : 0.0;
+    for (uint32_t i = (uint32_t)li; i < (uint32_t)(4*(2*T.tips - 2)); i += G) (&S.ab[0][0])[i] = g_pmat[i];
+  }
+  // pattern slots of the wave: the loci one after the other
+  {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < LPW; ++s2)
+    {
+      const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)np, s2*G);
+      if ((uint32_t)s2 == slot) pb = acc;
+      acc += n2;
+    }
+  }
+  if (act)
+  {
+    const Loc & L = A.loc[task];
+    for (uint32_t q = (uint32_t)li; q < np; q += G) wl.pat[pb + q] = A.pat[L.pat_off + q];
+    const uint32_t nbuf = 2u*(uint32_t)(T.tips - 1);
+    for (uint32_t i = (uint32_t)li; i < nbuf*np; i += G)
+    {
+      const uint32_t c = i/np, q = i - c*np;
+      const double2 * src = reinterpret_cast<const double2 *>(g_clv + ((size_t)c*np + q)*4);
+      const double2 u = src[0], w = src[1];
+      double * d = wl.clv[c][pb + q];
+      d[0] = u.x; d[1] = u.y; d[2] = w.x; d[3] = w.y;
+    }
+  }
+  const int tips = T.tips, n = 2*tips - 1;
+  const bool inner_i = li >= tips && li < n;
+
+  // lane-private density state: population li of this locus
+  uint32_t mync = 0; double t2h_cur = 0, t2h_new = 0;
+  uint32_t mynodes = 0, mync_new = 0; int mynin_new = 0;
+  Op opw[NT - 1]; int nops = 0;
+  for (int k = 0; k < NT - 1; ++k) opw[k] = 0;
+
+  // inner nodes per population, lineages entering, coalescences — the counting part of gtree_update_logprob_contrib
+  auto density_counts = [&]()
+  {
+    const int pop_i = T.pop[li];
+    int below = 0;
+#pragma unroll
+    for (int q = 0; q < G - 1; ++q)
+    {
+      const uint32_t m = gballot<G>(inner_i && pop_i == q, gbase);
+      if (li == q) mynodes = m;
+      below += ((pl.below >> q) & 1u) ? __popc(m) : 0;
+    }
+    mync_new = (uint32_t)__popc(mynodes);
+    mynin_new = gl_i - below;
+  };
+  // the term of population li (density_term of sampler.hpp); tk = ages of the inner nodes
+  auto density_term = [&](const double * tk)
+  {
+    uint32_t nodes = mynodes;
+    const int ncoal = (int)mync_new, nin = mynin_new;
+    int steps = ncoal + (pl.ptau >= 0 ? 1 : 0);
+    if (nin == steps) --steps;
+    double T2h = 0, prev = pl.tau;
+    int nn = nin;
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+      if (k < steps)
+      {
+        double tkk = pl.ptau;
+        if (k < ncoal)
+        {
+          int best = -1; double tb = 0;
+#pragma unroll
+          for (int j = 0; j < NT - 1; ++j)
+            if (((nodes >> (tips + j)) & 1u) && (best < 0 || tk[j] < tb)) { best = tips + j; tb = tk[j]; }
+          tkk = tb; nodes &= ~(1u << best);
+        }
+        T2h += nn*(nn - 1)*(tkk - prev);
+        prev = tkk; --nn;
+      }
+    double c = 0;
+    if (ncoal) c += ncoal*pl.l2t;
+    if (T2h) c -= T2h/(pl.theta*1.0);
+    S.contrib_new[li] = c; t2h_new = T2h;
+  };
+  // everything a proposal leaves to do before the decision: density terms, buffer toggles, fresh (a,b), node updates,
+  // the ordered sum over the patterns.  Returns the log-likelihood; lp_new = the density.
+  auto evaluate = [&](const Prop & pr, bool with_lnl, double & lp_new) -> double
+  {
+    double tk[NT - 1];
+#pragma unroll
+    for (int j = 0; j < NT - 1; ++j) tk[j] = S.time[(tips + j) & (NN - 1)];
+    const double myage = S.time[li];
+    density_counts();
+    if ((pr.chain >> li) & 1u) density_term(tk);
+    T.pf ^= pr.brm; T.cf ^= pr.ndm;
+    if ((pr.brm >> li) & 1u)
+    {
+      const int par = T.parent[li];
+      const double len = (S.time[par & (NN - 1)] - myage)*1.0;                       // rate_mui = 1 (locus.c:2350)
+      double a_, b_;
+      jc69_ab(len, rate, a_, b_);
+      const int pi = T.pidx(li);
+      S.ab[pi][0] = a_; S.ab[pi][1] = b_;
+    }
+    // node updates, children first = by age: the rank of node li among the nodes to recompute
+    nops = __popc(pr.ndm);
+    {
+      int rank = 0;
+#pragma unroll
+      for (int j = 0; j < NT - 1; ++j)
+        rank += (((pr.ndm >> (tips + j)) & 1u) && (tk[j] < myage || (tk[j] == myage && tips + j < li))) ? 1 : 0;
+      const bool mine = (pr.ndm >> li) & 1u;
+#pragma unroll
+      for (int k = 0; k < NT - 1; ++k)
+        if (k < nops)
+        {
+          const int x = __ffs(gballot<G>(mine && rank == k, gbase)) - 1;
+          const int l = T.left[x], r = T.right[x];
+          opw[k] = make_op(T.cidx(x), T.cidx(l), T.pidx(l), T.cidx(r), T.pidx(r));
+        }
+    }
+    wsync();
+    double lnl = 0;
+    if (with_lnl)
+    {
+      for (uint32_t base = 0; base < np; base += G)
+      {
+        const uint32_t q = base + (uint32_t)li; const bool pact = q < np;
+        const uint32_t ps = pb + (pact ? q : 0u);
+        const uint2 pi = wl.pat[ps];
+        double last[4] = {0, 0, 0, 0}; uint32_t last_c = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < NT - 1; ++k)
+          if (k < nops)
+          {
+            const Op o = opw[k];
+            const uint32_t opar = (uint32_t)o & 255u, lc = (uint32_t)(o >> 8) & 255u, lp = (uint32_t)(o >> 16) & 255u,
+                           rc = (uint32_t)(o >> 24) & 255u, rp = (uint32_t)(o >> 32) & 255u;
+            double lv[4], rv[4], x[4], y[4];
+            if (lc < (uint32_t)tips) expand_code((pi.y >> (4*lc)) & 15u, lv);
+            else if (lc == last_c) { lv[0] = last[0]; lv[1] = last[1]; lv[2] = last[2]; lv[3] = last[3]; }
+            else { const double * c = wl.clv[lc - tips][ps]; lv[0] = c[0]; lv[1] = c[1]; lv[2] = c[2]; lv[3] = c[3]; }
+            if (rc < (uint32_t)tips) expand_code((pi.y >> (4*rc)) & 15u, rv);
+            else if (rc == last_c) { rv[0] = last[0]; rv[1] = last[1]; rv[2] = last[2]; rv[3] = last[3]; }
+            else { const double * c = wl.clv[rc - tips][ps]; rv[0] = c[0]; rv[1] = c[1]; rv[2] = c[2]; rv[3] = c[3]; }
+            matvec4_ab(S.ab[lp][0], S.ab[lp][1], lv, x);
+            matvec4_ab(S.ab[rp][0], S.ab[rp][1], rv, y);
+            last[0] = x[0]*y[0]; last[1] = x[1]*y[1]; last[2] = x[2]*y[2]; last[3] = x[3]*y[3]; last_c = opar;
+            if (pact) { double * out = wl.clv[opar - tips][ps]; out[0] = last[0]; out[1] = last[1]; out[2] = last[2]; out[3] = last[3]; }
+          }
+        // the last update is the root's (children first, the root is the oldest node of every update list)
+        const double tr_ = dot4_pair(f0, f1, f2, f3, last);
+        if (pact) wl.term[ps] = log(0 + tr_*rw)*pi.x;
+      }
+      wsync();
+      for (uint32_t q = 0; q < np; ++q) lnl += wl.term[pb + q];
+      lnl = A.bfbeta == 1.0 ? lnl : A.bfbeta == 0.0 ? 0.0 : A.bfbeta*lnl;
+    }
+    else wsync();
+    double lp = 0;
+    for (int p = 0; p < npop; ++p) lp += ((pr.chain >> p) & 1u) ? S.contrib_new[p] : S.contrib[p];
+    lp_new = lp;
+    return lnl;
+  };
+  auto commit_density = [&](uint32_t chain)
+  {
+    if ((chain >> li) & 1u) { S.contrib[li] = S.contrib_new[li]; t2h_cur = t2h_new; }
+    mync = mync_new;
+  };
+
+  // ---- the current density terms (all populations): the trees arrive with their sum only
+  const uint32_t allpop = (1u << npop) - 1u;
+  if (act)
+  {
+    wsync();
+    double tk[NT - 1];
+#pragma unroll
+    for (int j = 0; j < NT - 1; ++j) tk[j] = S.time[(tips + j) & (NN - 1)];
+    density_counts();
+    if (li < npop) density_term(tk);
+    commit_density(allpop);
+    wsync();
+  }
+
+  const bool prof_on = (A.dbg & 16u) && b == 0 && tid == 0;
+  long long pf_t = prof_on ? clock64() : 0, pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SMP2_TICK(i_) do { if (prof_on) { const long long t1_ = clock64(); pf_acc[i_] += t1_ - pf_t; pf_t = t1_; } } while (0)
+
+  // ---- the sum over ALL loci of one all-loci step's terms.  A term enters as 2^-40 fixed point, so a total does not
+  // depend on the order of the additions: the lanes add theirs to the workgroup's accumulators (LDS atomics, fx_add),
+  // the workgroup adds those to the step's device accumulators (device-scope atomics) and then bumps the arrival
+  // counter; wave 0 polls until every workgroup has arrived.  Device accumulators and counter only ever grow (the host
+  // zeroes them before the launch) and two sets alternate, so a workgroup already in the next step never touches what
+  // a slower one still reads.  Up to 7 values share one 64-byte block with the counter: the poll's ONE load brings the
+  // totals with the count (they landed before the arrival was counted).  False: timed out.
+  constexpr double FX = 1099511627776.0;             // 2^40: totals up to 2^23 = 8.4e6, 9e-13 per term
+  constexpr double FXC = 256.0;                      // the coarse companion sum of a TAU / MIX step: catches a wrapped fine sum
+  auto fx_add = [&](int v, double x, bool coarse)
+  {
+    if (!(fabs(x) < 4194304.0)) { wg.bad_ = 1u; return; }                    // (also NaN): the step is rejected
+    (void)__hip_atomic_fetch_add(&wg.accfx[v], (unsigned long long)__double2ll_rn(x*FX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (coarse) (void)__hip_atomic_fetch_add(&wg.accfx[v + 1], (unsigned long long)__double2ll_rn(x*FXC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  uint32_t nx = 0;
+  unsigned long long xprev0 = 0, xprev1 = 0;       // wave 0, lane 8 x + k: word k of shard x of each set when its previous use completed
+  long long xp[5] = {0, 0, 0, 0, 0};
+  auto exchange = [&](int nval, int want, double & mine_tot) -> bool
+  {
+    long long xt0 = prof_on ? clock64() : 0;
+#define XT(i_) do { if (prof_on) { const long long t1_ = clock64(); xp[i_] += t1_ - xt0; xt0 = t1_; } } while (0)
+    __syncthreads();                                 // every lane's term is in wg.accfx
+    XT(0);
+    for (int v0 = 0; v0 < nval; v0 += 7)             // (7 sums + the counter = one 64-byte block)
+    {
+      const int nv = nval - v0 < 7 ? nval - v0 : 7;
+      const uint32_t par = nx & 1u; ++nx;
+      // 8 shards, a workgroup adds to shard b mod 8: atomics on one word are served one after the other
+      unsigned long long * set = A.xbuf + (size_t)par*XN;
+      unsigned long long * acc = set + (size_t)(b & 7u)*8u;
+      if (tid < (uint32_t)nv)
+      {
+        const unsigned long long fx = wg.accfx[v0 + (int)tid];
+        wg.accfx[v0 + (int)tid] = 0ull;
+        const unsigned long long old = __hip_atomic_fetch_add(acc + tid, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(old) : "memory");          // the sums have landed before the arrival is counted
+      }
+      XT(1);
+      __syncthreads();
+      XT(2);
+      if (wv == 0)
+      {
+        // arrival: + 1, and + 2^32 when a term of this workgroup was unusable
+        if (lane == 0) (void)__hip_atomic_fetch_add(acc + 7, 1ull + ((unsigned long long)wg.bad_ << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t_wait = wall_clock64();
+        const unsigned long long prev = par ? xprev1 : xprev0;
+        bool ok = true;
+        unsigned long long cur = 0, d = 0;
+        for (uint32_t rounds = 1;; ++rounds)
+        {
+          // ONE load: lane 8 x + k reads word k of shard x; the shards' growth since the set's previous use, added up
+          cur = __hip_atomic_load(set + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          d = cur - prev;
+          d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 16, 64); d += __shfl_xor(d, 32, 64);
+          if ((uint32_t)__shfl(d, 7, 64) >= A.nwg) break;
+          if ((rounds & 63u) == 0 && wall_clock64() - t_wait > 50000000ull) { ok = false; break; }     // 0.5 s at 100 MHz
+          __builtin_amdgcn_s_sleep(1);
+        }
+        XT(3);
+        if (ok)
+        {
+          const bool anybad = (__shfl(d, 7, 64) >> 32) != 0;
+          if (lane < (uint32_t)nv) wg.xtot[v0 + (int)lane] = anybad ? __longlong_as_double(0x7ff8000000000000ll) : (double)(long long)d*(1.0/FX);
+          if (par) xprev1 = cur; else xprev0 = cur;
+          if (lane == 0) wg.bad_ = 0;
+        }
+        else if (lane == 0) { wg.abort_ = 1; *A.err = 1; }
+      }
+      __syncthreads();
+      XT(4);
+      if (wg.abort_) return false;
+    }
+#undef XT
+    mine_tot = wg.xtot[want & 15];
+    return true;
+  };
+  uint32_t cnt_prop = 0, cnt_acc = 0;              // all-loci proposals / accepted (the same in every workgroup)
+  const bool wgprof = (A.dbg & 32u) && tid == 0;
+  long long wg_sweep = 0;
+  bool aborted = false;
+
+  for (uint32_t it = 0; it < A.niter && !aborted; ++it)
+  {
+    // ================= GAGE + GSPR of every locus
+    const uint32_t nprop = A.nsteps_gage + A.nsteps_gspr;
+    const long long wg_t0 = wgprof ? clock64() : 0;
+    for (uint32_t step = 0; step < nprop; ++step)
+    {
+      if (!act) continue;
+      // roll-back copies: registers, and the age of node li
+      const GTree<NT> U = T;
+      const double tsave = S.time[li];
+      Prop pr{0, 0, 0, 0.0};
+      const bool ok = step < A.nsteps_gage
+        ? propose_gage<NT>(T, rng, S.time, (int)step, pl, wg.anc, wg.tau, A.sp.ft_gage, li, gbase, pr)
+        : propose_gspr<NT>(T, rng, S.time, (int)(step - A.nsteps_gage), pl, gl_i, wg.anc, wg.tau, wg.lograt, A.sp.ft_gspr, li, gbase, pr);
+      SMP2_TICK(0);
+      if (ok)
+      {
+        wsync();
+        double lp_new;
+        const double lnl = evaluate(pr, true, lp_new);
+        SMP2_TICK(1);
+        w_nupd += (uint32_t)nops; w_nbr += (uint32_t)__popc(pr.brm);
+        const double lnacc = (lp_new - logpr_cur) + (lnl - lnl_cur) + pr.hast;
+        const double u = rndu(&rng);
+        ++nprop_done;
+        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; commit_density(pr.chain); }
+        else { T = U; S.time[li] = tsave; }
+        wsync();
+        SMP2_TICK(2);
+      }
+      else { T = U; S.time[li] = tsave; wsync(); }
+    }
+    if (wgprof) wg_sweep += clock64() - wg_t0;
+    if (!A.do_allloci) continue;
+
+    // ================= THETA: every population that can hold a coalescence, decided independently (theta_step_all)
+    if (A.sp.theta_alpha > 0 && A.theta_mask)
+    {
+      double win_u = 0, uacc = 0;
+      for (int p = 0; p < npop; ++p)
+        if ((A.theta_mask >> p) & 1u) { const double a_ = rndu(&grng), b_ = rndu(&grng); if (p == li) { win_u = a_; uacc = b_; } }
+      const bool on = li < npop && ((A.theta_mask >> li) & 1u);
+      const double told = pl.theta, l2t_old = pl.l2t;
+      const double tnew = reflect(told + A.sp.ft_theta*(win_u - 0.5), 0.0, 999.0);
+      const double l2t_new = log(2.0/(1.0*tnew));
+      if (act && on) fx_add(li, msc_term((int)mync, t2h_cur, tnew, l2t_new) - msc_term((int)mync, t2h_cur, told, l2t_old), false);
+      SMP2_TICK(3);
+      double th_tot = 0;
+      if (!exchange(npop, li, th_tot)) { aborted = true; break; }
+      SMP2_TICK(6);
+      // every wave takes the (same) decisions for itself: lane li decides population li
+      bool accept = false;
+      if (on)
+      {
+        const double lnacc = th_tot + ((A.sp.theta_alpha - 1)*log(tnew/told) - A.sp.theta_beta*(tnew - told));
+        accept = tnew > 0 && (lnacc >= 0 || uacc < exp(lnacc));
+      }
+      if (accept) { pl.theta = tnew; pl.l2t = l2t_new; }
+      {
+        const uint32_t onm = gballot<G>(on, gbase), accm = gballot<G>(accept, gbase);
+        cnt_prop += (uint32_t)__popc(onm); cnt_acc += (uint32_t)__popc(accm);
+      }
+      __syncthreads();                                        // everyone has read the totals and the old thetas
+      if (tid < (uint32_t)G && accept) { wg.tau[MAXPOP + li] = tnew; wg.tau[2*MAXPOP + li] = l2t_new; }
+      __syncthreads();
+      // every tree's density with the new thetas, from its statistics, in population order
+      if (act)
+      {
+        if (li < npop) S.contrib[li] = msc_term((int)mync, t2h_cur, pl.theta, pl.l2t);
+        wsync();
+        double lp = 0;
+        for (int p = 0; p < npop; ++p) lp += S.contrib[p];
+        logpr_cur = lp;
+        wsync();
+      }
+    }
+    SMP2_TICK(3);
+
+    // ================= TAU per species divergence, then MIX: one decision each for all loci
+    for (int stepq = nsp; stepq <= npop && !aborted; ++stepq)
+    {
+      const bool mix = stepq == npop;
+      const int q = mix ? -1 : stepq;
+      const double uprop = rndu(&grng), uacc = rndu(&grng);
+      // the proposed species tree: in the lanes' registers only
+      double tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1, lminf = 0, lmaxf = 0, tq_new = 0, mix_c = 1, mix_lnc = 0;
+      if (!mix)
+      {
+        const int pq = A.sp.parent[q], cl = sp_left[q], cr = sp_right[q];
+        tq_old = wg.tau[q]; tq_lo = fmax(wg.tau[cl], wg.tau[cr]); tq_hi = pq >= 0 ? wg.tau[pq] : 999.0;
+        tq_new = reflect(tq_old + A.sp.ft_tau*(uprop - 0.5), tq_lo, tq_hi);
+        minf = (tq_new - tq_lo)/(tq_old - tq_lo); maxf = (tq_new - tq_hi)/(tq_old - tq_hi);
+        lminf = log(minf); lmaxf = log(maxf);
+        if (li == q) pl.tau = tq_new;
+        if (pl.parent == q) pl.ptau = tq_new;
+      }
+      else
+      {
+        mix_lnc = A.sp.ft_mix*(uprop - 0.5); mix_c = exp(mix_lnc);
+        pl.tau *= mix_c;
+        if (pl.parent >= 0) pl.ptau *= mix_c;
+      }
+      const uint32_t cf0 = T.cf, pf0 = T.pf;
+      const double tsave = act ? S.time[li] : 0.0;
+      double lnl_new = lnl_cur, lp_new = logpr_cur;
+      bool evaluated = false;
+      if (act)
+      {
+        Prop pr{allpop, 0, 0, 0.0};
+        double hast = 0, hast2 = 0;
+        if (!mix)
+        {
+          // the gene nodes of q and its children between the bounds ride the rubber band (stree.c:4338-4479)
+          const int cl = sp_left[q], cr = sp_right[q];
+          const int pk = T.pop[li];
+          const double tk_ = tsave;
+          const bool moved = inner_i && (pk == q || pk == cl || pk == cr) && !(tk_ < tq_lo || tk_ > tq_hi);
+          const bool up = moved && tk_ >= tq_old;
+          if (moved) S.time[li] = up ? tq_hi + maxf*(tk_ - tq_hi) : tq_lo + minf*(tk_ - tq_lo);
+          const uint32_t mm = gballot<G>(moved, gbase);
+          const int above = __popc(gballot<G>(up, gbase)), below = __popc(mm) - above;
+          const int par = T.parent[li];
+          pr.brm = gballot<G>(li < n && par >= 0 && (((mm >> li) & 1u) || ((mm >> (par & 31)) & 1u)), gbase);
+          uint32_t m = mm;
+          const int l = T.left[li], r = T.right[li];
+#pragma unroll
+          for (int d = 0; d < NT - 2; ++d) m |= gballot<G>(inner_i && (((m >> (l & 31)) & 1u) || ((m >> (r & 31)) & 1u)), gbase);
+          pr.ndm = m;
+          hast = below*lminf; hast2 = above*lmaxf;
+        }
+        else
+        {
+          if (inner_i) S.time[li] = tsave*mix_c;
+          pr.ndm = gballot<G>(inner_i, gbase);
+          pr.brm = gballot<G>(li < n && (int)T.parent[li] >= 0, gbase);
+          hast = (double)(tips - 1)*mix_lnc;
+        }
+        wsync();
+        evaluated = pr.ndm != 0;
+        const double lnl = evaluate(pr, evaluated, lp_new);
+        if (evaluated) lnl_new = lnl;
+        const double dpr = lp_new - logpr_cur;
+        const double h = mix ? dpr + hast : (dpr + hast) + hast2;
+        const double dl = evaluated ? (lnl_new - lnl_cur) + h : h;
+        if (li == 0) fx_add(0, dl, true);
+      }
+      if (mix) SMP2_TICK(5); else SMP2_TICK(4);
+      double dl_tot = 0;
+      if (!exchange(2, 0, dl_tot)) { aborted = true; break; }
+      if (A.dbg & 64u) { SMP2_TICK(7); double dummy; if (!exchange(2, 0, dummy)) { aborted = true; break; } SMP2_TICK(6); }     // (the protocol alone: nobody is late)
+      // (a fine sum that wrapped disagrees with the coarse one: the coarse one then stands — its 0.004 of precision
+      //  does not matter for a total beyond 8e6)
+      { const double dl_coarse = wg.xtot[1]*(FX/FXC); if (fabs(dl_coarse - dl_tot) > 1.0) dl_tot = dl_coarse; }
+      SMP2_TICK(7);
+      // the decision (decide of sampler.hpp; stree.c:6280, prop_mixing.c:203-205) — the same in every lane
+      double lnacc = dl_tot;
+      if (!mix)
+      {
+        if (A.sp.parent[q] < 0 && A.sp.tau_alpha > 0)
+          lnacc += (A.sp.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - A.sp.tau_beta*(tq_new - tq_old);
+      }
+      else
+      {
+        lnacc += (double)(nsp - 1)*mix_lnc;
+        if (A.sp.tau_alpha > 0)
+        {
+          const double troot = wg.tau[npop - 1];
+          lnacc += (A.sp.tau_alpha - 1)*mix_lnc - A.sp.tau_beta*(troot*mix_c - troot) - (double)(nsp - 2)*mix_lnc;
+        }
+      }
+      const bool accept = lnacc >= 0 || uacc < exp(lnacc);
+      ++cnt_prop; cnt_acc += accept ? 1u : 0u;
+      __syncthreads();                                        // everyone has read the old taus
+      if (accept)
+      {
+        if (!mix) { if (tid == 0) wg.tau[q] = tq_new; }
+        else if (tid < (uint32_t)npop) wg.tau[tid] *= mix_c;
+        if (act) { lnl_cur = lnl_new; logpr_cur = lp_new; commit_density(allpop); }
+      }
+      else if (act) { T.cf = cf0; T.pf = pf0; S.time[li] = tsave; }
+      __syncthreads();
+      load_pop();
+      wsync();
+      if (mix) SMP2_TICK(5); else SMP2_TICK(4);
+    }
+  }
+#undef SMP2_TICK
+  if (aborted || wg.abort_) return;                 // (HBM still holds the state the launch started from)
+
+  // ---- store
+  if (act)
+  {
+    Tree & tr = A.trees[task];
+    if (li < W)
+    {
+      reinterpret_cast<uint32_t *>(tr.left)[li] = T.left.w[li < W ? li : 0]; reinterpret_cast<uint32_t *>(tr.right)[li] = T.right.w[li < W ? li : 0];
+      reinterpret_cast<uint32_t *>(tr.parent)[li] = T.parent.w[li < W ? li : 0]; reinterpret_cast<uint32_t *>(tr.pop)[li] = T.pop.w[li < W ? li : 0];
+    }
+    if (li < n) { tr.time[li] = S.time[li]; tr.clv[li] = (int8_t)T.cidx(li); tr.pmat[li] = (int8_t)T.pidx(li); }
+    if (li == 0)
+    {
+      tr.lnl = lnl_cur; tr.logpr = logpr_cur; tr.rng = rng; tr.root = T.root;
+      tr.proposals += nprop_done; tr.accepted += nacc; tr.sw_nupd += w_nupd; tr.sw_nbr += w_nbr;
+    }
+    if (li < npop) { A.pop_nc[(size_t)li*A.ntasks + task] = (int8_t)mync; A.pop_t2h[(size_t)li*A.ntasks + task] = t2h_cur; }
+    for (uint32_t i = (uint32_t)li; i < (uint32_t)(4*(2*tips - 2)); i += G) g_pmat[i] = (&S.ab[0][0])[i];
+    const uint32_t nbuf = 2u*(uint32_t)(tips - 1);
+    for (uint32_t i = (uint32_t)li; i < nbuf*np; i += G)
+    {
+      const uint32_t c = i/np, q = i - c*np;
+      const double * d = wl.clv[c][pb + q];
+      double2 u, w; u.x = d[0]; u.y = d[1]; w.x = d[2]; w.y = d[3];
+      double2 * dst = reinterpret_cast<double2 *>(g_clv + ((size_t)c*np + q)*4);
+      dst[0] = u; dst[1] = w;
+    }
+  }
+  if (b == 0 && tid == 0)
+  {
+    *A.grng = grng;
+    A.counters[0] += cnt_prop; A.counters[1] += cnt_acc;
+  }
+  if (b == 0 && tid < (uint32_t)(3*MAXPOP)) A.taus[tid] = wg.tau[tid];
+  if (prof_on) for (int i = 0; i < 8; ++i) A.prof[i] = (double)pf_acc[i];
+  if (prof_on) for (int i = 0; i < 5; ++i) A.prof[8 + i] = (double)xp[i];
+  if (wgprof) A.prof[16 + b] = (double)wg_sweep;
+}
+
+} // namespace smp2

@@ -20,7 +20,7 @@ for sub in ("a", "b", "c"):
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, d in acc.items():
-            if "smp" in k:
+            if "smp" in k or "iter_kernel" in k:
                 print(sub, k, {c: (round(sum(v)/len(v)), len(v)) for c, v in d.items()})
 PY
 tail -3 $OUT/c.log >> $R/gpurun_out/pmc_smp_$TAG.txt
