@@ -99,6 +99,14 @@ static int accept(a00_driver_t * d, long i, double lnacc, double u0)
   return lnacc >= 0 || u0 < exp(lnacc);
 }
 
+/* A00_DECLOG=1: every all-loci decision on stderr (what the device samplers are compared with when a trajectory splits) */
+static void declog(const char * what, int k, double lnacc, double u, int acc)
+{
+  static int on = -1;
+  if (on < 0) on = getenv("A00_DECLOG") != NULL;
+  if (on) fprintf(stderr, "[a00] %s %d lnacc %.17g u %.17g -> %d\n", what, k, lnacc, u, acc);
+}
+
 void a00_set_proposal_kernel(a00_driver_t * d, int kind) { d->kernel = kind == A00_KERNEL_BPP ? A00_KERNEL_BPP : A00_KERNEL_UNIFORM; }
 
 void a00_bpp_kernel_sequence(unsigned int seed, int symmetrical, int n, double * out)
@@ -624,7 +632,7 @@ static int theta_step_all(a00_driver_t * d)
     if (!d->has_theta[p]) continue;
     lnacc = sum[p] + ((d->theta_alpha - 1)*log(tnew[p]/d->theta[p]) - d->theta_beta*(tnew[p] - d->theta[p]));
     d->proposals++;
-    if (tnew[p] > 0 && accept(d, -1, lnacc, uacc[p])) { d->accepted++; d->theta[p] = tnew[p]; }
+    { const int acc_ = tnew[p] > 0 && accept(d, -1, lnacc, uacc[p]); declog("theta", p, lnacc, uacc[p], acc_); if (acc_) { d->accepted++; d->theta[p] = tnew[p]; } }
   }
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
   for (li = 0; li < (long)d->nloci; ++li) d->trees[li].logpr = tree_logpr(d, d->trees + li);
@@ -637,7 +645,7 @@ static int theta_step_all(a00_driver_t * d)
    sum(dlogpr + dlnL) + below*log(minfactor) + above*log(maxfactor)   (stree.c:6280) */
 static int tau_step(a00_driver_t * d, int q)
 {
-  unsigned i, n; long li; double sum = 0;
+  unsigned i, n; long li; double sum = 0; int acc_;
   const int cl = d->sp_left[q], cr = d->sp_right[q], pq = d->sp_parent[q];
   const double old = d->tau[q], lo = fmax(d->tau[cl], d->tau[cr]), hi = pq >= 0 ? d->tau[pq] : 999.0;
   const double tnew = a00_reflect(old + d->ft_tau*draw_window(d, -1), lo, hi);
@@ -674,7 +682,9 @@ static int tau_step(a00_driver_t * d, int q)
     sum += d->p_slot[i] >= 0 ? (d->s_lnl[d->p_slot[i]] - d->trees[i].lnl) + d->p_delta[i] : d->p_delta[i];
   if (pq < 0) sum += root_tau_prior_ratio(d, old, tnew);
   d->proposals++;
-  if (accept(d, -1, sum, uacc))
+  acc_ = accept(d, -1, sum, uacc);
+  declog("tau", q, sum, uacc, acc_);
+  if (acc_)
   {
     d->accepted++;
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
@@ -693,7 +703,7 @@ static int tau_step(a00_driver_t * d, int q)
    sum(dlogpr + dlnL) + (ages + taus)*log c   (prop_mixing.c:203-205; thetas stay) */
 static int mix_step(a00_driver_t * d)
 {
-  unsigned i; long li; int p; double sum = 0, lnacc, oldtau[A00_MAXPOP];
+  unsigned i; long li; int p, acc_; double sum = 0, lnacc, oldtau[A00_MAXPOP];
   const double lnc = d->ft_mix*(draw_u(d, -1) - 0.5), c = exp(lnc);        /* prop_mixing.c: log c uniform in both kernels */
   const double uacc = d->kernel == A00_KERNEL_BPP ? -1.0 : draw_u(d, -1);
   if (!staging_ready(d)) return 0;
@@ -719,7 +729,9 @@ static int mix_step(a00_driver_t * d)
   if (d->tau_alpha > 0)                    /* all taus scale together: the Dirichlet part is unchanged */
     lnacc += (d->tau_alpha - 1)*lnc - d->tau_beta*(d->tau[d->npop-1] - oldtau[d->npop-1]) - (double)(d->S - 2)*lnc;
   d->proposals++;
-  if (accept(d, -1, lnacc, uacc))
+  acc_ = accept(d, -1, lnacc, uacc);
+  declog("mix", 0, lnacc, uacc, acc_);
+  if (acc_)
   {
     d->accepted++;
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)

@@ -72,7 +72,7 @@ struct Args
   a00_rng_t * grng;                      // the global stream: read at entry, written back by workgroup 0
   uint32_t niter, nsteps_gage, nsteps_gspr, theta_mask, do_allloci, dbg;
   double bfbeta;
-  double * prof;
+  double * prof, * declog;
   Species sp;
 };
 
@@ -552,20 +552,22 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   long long pf_t = prof_on ? clock64() : 0, pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define SMP2_TICK(i_) do { if (prof_on) { const long long t1_ = clock64(); pf_acc[i_] += t1_ - pf_t; pf_t = t1_; } } while (0)
 
-  // ---- the sum over ALL loci of one all-loci step's terms.  A term enters as 2^-40 fixed point, so a total does not
-  // depend on the order of the additions: the lanes add theirs to the workgroup's accumulators (LDS atomics, fx_add),
+  // ---- the sum over ALL loci of one all-loci step's terms.  A term enters as 2^-40 fixed point (what the host driver adds
+  // up in doubles, locus by locus: the totals agree to ~1e-11), so a total does not depend on the order of the additions: the lanes add theirs to the workgroup's accumulators (LDS atomics, fx_add),
   // the workgroup adds those to the step's device accumulators (device-scope atomics) and then bumps the arrival
   // counter; wave 0 polls until every workgroup has arrived.  Device accumulators and counter only ever grow (the host
   // zeroes them before the launch) and two sets alternate, so a workgroup already in the next step never touches what
   // a slower one still reads.  Up to 7 values share one 64-byte block with the counter: the poll's ONE load brings the
   // totals with the count (they landed before the arrival was counted).  False: timed out.
-  constexpr double FX = 1099511627776.0;             // 2^40: totals up to 2^23 = 8.4e6, 9e-13 per term
-  constexpr double FXC = 256.0;                      // the coarse companion sum of a TAU / MIX step: catches a wrapped fine sum
+  constexpr double FX = 1099511627776.0;             // 2^40: 9e-13 per term; |term| < 256 and <= 2^14 loci: the sum cannot wrap
+  constexpr double FXC = 1024.0;                     // a TAU / MIX term beyond that goes to a coarse companion sum (2^-10, |term| < 2^38)
   auto fx_add = [&](int v, double x, bool coarse)
   {
-    if (!(fabs(x) < 4194304.0)) { wg.bad_ = 1u; return; }                    // (also NaN): the step is rejected
-    (void)__hip_atomic_fetch_add(&wg.accfx[v], (unsigned long long)__double2ll_rn(x*FX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (coarse) (void)__hip_atomic_fetch_add(&wg.accfx[v + 1], (unsigned long long)__double2ll_rn(x*FXC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (fabs(x) < 256.0)
+      (void)__hip_atomic_fetch_add(&wg.accfx[v], (unsigned long long)__double2ll_rn(x*FX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if (coarse && fabs(x) < 274877906944.0)
+      (void)__hip_atomic_fetch_add(&wg.accfx[v + 1], (unsigned long long)__double2ll_rn(x*FXC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else wg.bad_ = 1u;                                                       // (also NaN): the step is rejected
   };
   uint32_t nx = 0;
   unsigned long long xprev0 = 0, xprev1 = 0;       // wave 0, lane 8 x + k: word k of shard x of each set when its previous use completed
@@ -630,6 +632,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     return true;
   };
   uint32_t cnt_prop = 0, cnt_acc = 0;              // all-loci proposals / accepted (the same in every workgroup)
+  const bool declog = (A.dbg & 256u) && b == 0;    // every all-loci decision of this launch: A.declog[4 k] = what, lnacc, u, accepted
+  uint32_t ndec = 0;
   const bool wgprof = (A.dbg & 32u) && tid == 0;
   long long wg_sweep = 0;
   bool aborted = false;
@@ -693,6 +697,12 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         accept = tnew > 0 && (lnacc >= 0 || uacc < exp(lnacc));
       }
       if (accept) { pl.theta = tnew; pl.l2t = l2t_new; }
+      if (declog && tid < (uint32_t)G && on)
+      {
+        const uint32_t k = ndec + (uint32_t)__popc(A.theta_mask & ((1u << li) - 1u));
+        if (k < 2048u) { double * r = A.declog + 4*k; r[0] = 100 + li; r[1] = th_tot + ((A.sp.theta_alpha - 1)*log(tnew/told) - A.sp.theta_beta*(tnew - told)); r[2] = uacc; r[3] = accept ? 1 : 0; }
+      }
+      ndec += (uint32_t)__popc(A.theta_mask);
       {
         const uint32_t onm = gballot<G>(on, gbase), accm = gballot<G>(accept, gbase);
         cnt_prop += (uint32_t)__popc(onm); cnt_acc += (uint32_t)__popc(accm);
@@ -784,10 +794,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       if (mix) SMP2_TICK(5); else SMP2_TICK(4);
       double dl_tot = 0;
       if (!exchange(2, 0, dl_tot)) { aborted = true; break; }
+      dl_tot += wg.xtot[1]*(FX/FXC);                  // (the coarse sum: terms of 256 and more — none in any run worth the name)
       if (A.dbg & 64u) { SMP2_TICK(7); double dummy; if (!exchange(2, 0, dummy)) { aborted = true; break; } SMP2_TICK(6); }     // (the protocol alone: nobody is late)
-      // (a fine sum that wrapped disagrees with the coarse one: the coarse one then stands — its 0.004 of precision
-      //  does not matter for a total beyond 8e6)
-      { const double dl_coarse = wg.xtot[1]*(FX/FXC); if (fabs(dl_coarse - dl_tot) > 1.0) dl_tot = dl_coarse; }
       SMP2_TICK(7);
       // the decision (decide of sampler.hpp; stree.c:6280, prop_mixing.c:203-205) — the same in every lane
       double lnacc = dl_tot;
@@ -807,6 +815,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       }
       const bool accept = lnacc >= 0 || uacc < exp(lnacc);
       ++cnt_prop; cnt_acc += accept ? 1u : 0u;
+      if (declog && tid == 0 && ndec < 2048u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
+      ++ndec;
       __syncthreads();                                        // everyone has read the old taus
       if (accept)
       {

@@ -62,6 +62,48 @@ def test_sampler_equals_host_driver(taxa, nloci, iters):
     host.close(); dev.close(); eng.close()
 
 
+def _sampler(eng, data, taxa, seed, v1, monkeypatch):
+    if v1:
+        monkeypatch.setenv("BPA_SMP_V1", "1")
+    else:
+        monkeypatch.delenv("BPA_SMP_V1", raising=False)
+    smp = bpp_amd.Sampler(eng, tape.make_engine_loci(eng, data), data, seed=seed)
+    parent, tau0, thetas = synth.species_tree_arrays(taxa)
+    smp.set_species_tree(parent, tau0, thetas)
+    smp.set_tau_prior(3.0, 3.0 / tau0[-1])
+    smp.set_theta_prior(3.0, 1500.0, 8e-5)
+    smp.set_finetune(0.004, 0.004, 4e-5, 0.006)
+    smp.initialize()
+    return smp
+
+
+@pytest.mark.parametrize("taxa,nloci,iters", [(4, 3000, 12), (8, 150, 6)])
+def test_persistent_kernel_equals_one_launch_per_step(taxa, nloci, iters, monkeypatch):
+    """the persistent iteration kernel (csrc/sweep2.hpp: state in LDS for the whole launch, all-loci decisions from
+    fixed-point device accumulators over several workgroups) and the one-launch-per-step path (BPA_SMP_V1=1) walk the
+    same trajectory: every tree, every tau and theta, bit for bit — also when one call runs several iterations"""
+    eng = bpp_amd.Engine(0)
+    data = synth.make_dataset(nloci, 600, taxa, "jc69", 1, seed=5)
+    new = _sampler(eng, data, taxa, 11, False, monkeypatch)
+    old = _sampler(eng, data, taxa, 11, True, monkeypatch)
+    for it in range(iters):
+        n = 1 if it % 3 else 4
+        new.iterate(n); old.iterate(n)
+        assert new.taus() == old.taus() and new.thetas() == old.thetas(), it
+        a, b = new.summary(), old.summary()
+        assert (a["proposals"], a["accepted"]) == (b["proposals"], b["accepted"]), it
+        assert a["launches"] < b["launches"]
+    assert new.taus() != list(synth.species_tree_arrays(taxa)[1])
+    for i in range(nloci):
+        x, y = new.tree(i), old.tree(i)
+        for key in ("left", "right", "parent", "clv", "pmat", "pop", "time"):
+            assert list(x[key]) == list(y[key]), (i, key)
+        assert x["root"] == y["root"] and x["lnl"] == y["lnl"] and x["logpr"] == y["logpr"], i
+    w_new, w_old = new.work(), old.work()
+    assert (w_new["node_updates"], w_new["pattern_updates"]) == (w_old["node_updates"], w_old["pattern_updates"])
+    new.close(); old.close(); eng.close()
+
+
 def test_several_sequences_per_species():
     """two species with three sequences each: tip populations hold coalescences (and a theta that moves),
     gene nodes cross the species boundary both ways; device == host driver, step for step"""
