@@ -1167,6 +1167,7 @@ struct bpa_sampler
   DevBuf<a00_rng_t> v2_grng;
   DevBuf<int> v2_err;
   DevBuf<double> v2_prof, v2_declog;
+  DevBuf<smp::Species> v2_sp;
   unsigned long v2_iters = 0;           // iterations run by persistent launches (bpa_sampler_timing)
 };
 
@@ -1231,7 +1232,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
   s->g_len.free(); s->g_lograt.free(); s->g_active.free(); s->g_recs.free(); s->g_mat2.free(); s->g_bmo.free();
   s->g_sm.free(); s->g_sm_old.free(); s->g_ids.free();
-  s->v2_wave_off.free(); s->v2_loc.free(); s->v2_pat.free(); s->v2_xbuf.free(); s->v2_grng.free(); s->v2_err.free(); s->v2_prof.free(); s->v2_declog.free();
+  s->v2_wave_off.free(); s->v2_loc.free(); s->v2_pat.free(); s->v2_xbuf.free(); s->v2_grng.free(); s->v2_err.free(); s->v2_prof.free(); s->v2_declog.free(); s->v2_sp.free();
   delete s;
 }
 
@@ -1354,7 +1355,7 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
   const int zero = 0;
   if (!upload(s->v2_wave_off, woff.data(), woff.size()) || !upload(s->v2_loc, loc.data(), loc.size()) ||
       !upload(s->v2_pat, pat.data(), pat.size()) || !s->v2_xbuf.reserve((size_t)2*smp2::XN) || !s->v2_grng.reserve(1) ||
-      !upload(s->v2_err, &zero, 1) || !s->v2_prof.reserve(16 + (size_t)nwg) || !s->v2_declog.reserve(4*2048))
+      !upload(s->v2_err, &zero, 1) || !s->v2_prof.reserve(16 + (size_t)nwg) || !s->v2_declog.reserve(4*2048) || !s->v2_sp.reserve(1))
     return 0;
   HIPCHK(hipMemset(s->v2_prof.p, 0, (16 + (size_t)nwg)*sizeof(double)));
   void (*kern)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4> : smp2::iter_kernel<8>;
@@ -1699,7 +1700,8 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations)
     a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2;
     if (s->env_gage >= 0) { a.nsteps_gage = (uint32_t)s->env_gage; a.nsteps_gspr = (uint32_t)s->env_gspr; }
     a.theta_mask = theta_mask; a.do_allloci = allloci ? 1u : 0u; a.dbg = s->env_dbg;
-    a.bfbeta = e->usedata ? e->bfbeta : 0.0; a.prof = s->v2_prof.p; a.declog = s->v2_declog.p; a.sp = s->sp;
+    a.bfbeta = e->usedata ? e->bfbeta : 0.0; a.prof = s->v2_prof.p; a.declog = s->v2_declog.p; a.sp = s->v2_sp.p;
+    HIPCHK(hipMemcpyAsync(s->v2_sp.p, &s->sp, sizeof(smp::Species), hipMemcpyHostToDevice, e->stream));
     if (s->env_dbg & 256u) HIPCHK(hipMemsetAsync(s->v2_declog.p, 0, 4*2048*sizeof(double), e->stream));
     HIPCHK(hipMemcpyAsync(s->v2_grng.p, &s->grng, sizeof(a00_rng_t), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemsetAsync(s->v2_xbuf.p, 0, (size_t)2*smp2::XN*sizeof(unsigned long long), e->stream));

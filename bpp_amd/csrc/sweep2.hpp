@@ -73,7 +73,7 @@ struct Args
   uint32_t niter, nsteps_gage, nsteps_gspr, theta_mask, do_allloci, dbg;
   double bfbeta;
   double * prof, * declog;
-  Species sp;
+  const Species * sp;                    // (device memory: by value it would sit in ~50 SGPRs for the whole launch)
 };
 
 constexpr int XN = 64;                   // words per accumulator set: 8 shards x (7 sums + the arrival counter)
@@ -83,7 +83,7 @@ template <int NT> struct Slot
   double time[Cfg<NT>::NN];
   double ab[Cfg<NT>::NPM][2];
   double contrib[Cfg<NT>::G], contrib_new[Cfg<NT>::G];
-  double dl, pad;
+  double rate, rw, f[4];                 // the locus's constants (Loc), read where they are used
 };
 template <int NT> struct WaveLDS
 {
@@ -100,6 +100,8 @@ template <int NT> struct WgLDS
   double xtot[16];
   uint32_t anc[16];
   uint32_t abort_, bad_;
+  Species sp;
+  long long prof[16];                            // BPA_SMP_DBG & 16: cycle counters of thread 0 of workgroup 0
 };
 
 template <int G> __device__ __forceinline__ uint32_t gballot(bool p, uint32_t gbase)
@@ -308,25 +310,28 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   WaveLDS<NT> & wl = wl_all[wv];
   Slot<NT> & S = wl.slot[slot];
   const uint32_t gw = b*WAVES + wv;                               // global wave
-  const int npop = A.sp.npop, nsp = A.sp.S;
+  {
+    const uint32_t * src = reinterpret_cast<const uint32_t *>(A.sp);
+    uint32_t * dst = reinterpret_cast<uint32_t *>(&wg.sp);
+    for (uint32_t i = tid; i < sizeof(Species)/4; i += C::BS) dst[i] = src[i];
+    if (tid < 16u) wg.prof[tid] = 0;
+  }
+  __syncthreads();
+  const Species & SP = wg.sp;
+  const int npop = SP.npop, nsp = SP.S;
 
   // ---- species tree: the workgroup's copy of the parameters, the topology per lane
   for (uint32_t i = tid; i < (uint32_t)(3*MAXPOP); i += C::BS) wg.tau[i] = A.taus[i];
   for (uint32_t i = tid; i < (uint32_t)((2*NT)*(2*NT)); i += C::BS) wg.lograt[i] = A.lograt[(i/(2*NT))*MAXN + i % (2*NT)];
-  if (tid < 16u) wg.anc[tid] = tid < (uint32_t)MAXPOP ? (uint32_t)A.sp.anc[tid] : 0u;
+  if (tid < 16u) wg.anc[tid] = tid < (uint32_t)MAXPOP ? (uint32_t)SP.anc[tid] : 0u;
   if (tid == 0) { wg.abort_ = 0; wg.bad_ = 0; }
   if (tid < 16u) wg.accfx[tid] = 0ull;
   PopLane pl;
-  ByteArr<4> sp_left, sp_right;
   {
-    const uint32_t * q = reinterpret_cast<const uint32_t *>(A.sp.left);
-    for (int k = 0; k < 4; ++k) sp_left.w[k] = q[k];
-    q = reinterpret_cast<const uint32_t *>(A.sp.right);
-    for (int k = 0; k < 4; ++k) sp_right.w[k] = q[k];
-    pl.parent = li < npop ? (int)A.sp.parent[li < MAXPOP ? li : 0] : -1;
-    pl.anc = li < npop ? (uint32_t)A.sp.anc[li < MAXPOP ? li : 0] : 0u;
+    pl.parent = li < npop ? (int)SP.parent[li < MAXPOP ? li : 0] : -1;
+    pl.anc = li < npop ? (uint32_t)SP.anc[li < MAXPOP ? li : 0] : 0u;
     uint32_t below = 0;
-    for (int q2 = 0; q2 < npop; ++q2) if (q2 != li && (((uint32_t)A.sp.anc[q2] >> li) & 1u)) below |= 1u << q2;
+    for (int q2 = 0; q2 < npop; ++q2) if (q2 != li && (((uint32_t)SP.anc[q2] >> li) & 1u)) below |= 1u << q2;
     pl.below = li < npop ? below : 0u;
   }
   __syncthreads();
@@ -345,17 +350,18 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   const uint32_t task = t0 + (act ? slot : 0u);
   GTree<NT> T;
   a00_rng_t rng = 0;
-  double lnl_cur = 0, logpr_cur = 0, rate = 1, rw = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+  double lnl_cur = 0, logpr_cur = 0;
   uint32_t np = 0, pb = 0, nprop_done = 0, nacc = 0, w_nupd = 0, w_nbr = 0;
   int gl_i = 0;
-  double * g_clv = nullptr, * g_pmat = nullptr;
   for (int k = 0; k < W; ++k) { T.left.w[k] = T.right.w[k] = T.parent.w[k] = T.pop.w[k] = 0xffffffffu; }
   T.cf = T.pf = 0; T.root = 0; T.tips = 2;
   if (act && nt)
   {
     const Loc & L = A.loc[task];
     const Tree & tr = A.trees[task];
-    np = L.np; rate = L.rate; rw = L.rw; f0 = L.f0; f1 = L.f1; f2 = L.f2; f3 = L.f3; g_clv = L.clv; g_pmat = L.pmat;
+    np = L.np;
+    double * g_pmat = L.pmat;
+    if (li == 0) { S.rate = L.rate; S.rw = L.rw; S.f[0] = L.f0; S.f[1] = L.f1; S.f[2] = L.f2; S.f[3] = L.f3; }
     gl_i = L.gl[li & 15];
     for (int k = 0; k < W; ++k)
     {
@@ -383,6 +389,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   if (act)
   {
     const Loc & L = A.loc[task];
+    const double * g_clv = L.clv;
     for (uint32_t q = (uint32_t)li; q < np; q += G) wl.pat[pb + q] = A.pat[L.pat_off + q];
     const uint32_t nbuf = 2u*(uint32_t)(T.tips - 1);
     for (uint32_t i = (uint32_t)li; i < nbuf*np; i += G)
@@ -464,7 +471,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       const int par = T.parent[li];
       const double len = (S.time[par & (NN - 1)] - myage)*1.0;                       // rate_mui = 1 (locus.c:2350)
       double a_, b_;
-      jc69_ab(len, rate, a_, b_);
+      jc69_ab(len, S.rate, a_, b_);
       const int pi = T.pidx(li);
       S.ab[pi][0] = a_; S.ab[pi][1] = b_;
     }
@@ -515,8 +522,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
             if (pact) { double * out = wl.clv[opar - tips][ps]; out[0] = last[0]; out[1] = last[1]; out[2] = last[2]; out[3] = last[3]; }
           }
         // the last update is the root's (children first, the root is the oldest node of every update list)
-        const double tr_ = dot4_pair(f0, f1, f2, f3, last);
-        if (pact) wl.term[ps] = log(0 + tr_*rw)*pi.x;
+        const double tr_ = dot4_pair(S.f[0], S.f[1], S.f[2], S.f[3], last);
+        if (pact) wl.term[ps] = log(0 + tr_*S.rw)*pi.x;
       }
       wsync();
       for (uint32_t q = 0; q < np; ++q) lnl += wl.term[pb + q];
@@ -549,8 +556,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   }
 
   const bool prof_on = (A.dbg & 16u) && b == 0 && tid == 0;
-  long long pf_t = prof_on ? clock64() : 0, pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define SMP2_TICK(i_) do { if (prof_on) { const long long t1_ = clock64(); pf_acc[i_] += t1_ - pf_t; pf_t = t1_; } } while (0)
+  long long pf_t = prof_on ? clock64() : 0;
+#define SMP2_TICK(i_) do { if (prof_on) { const long long t1_ = clock64(); wg.prof[i_] += t1_ - pf_t; pf_t = t1_; } } while (0)
 
   // ---- the sum over ALL loci of one all-loci step's terms.  A term enters as 2^-40 fixed point (what the host driver adds
   // up in doubles, locus by locus: the totals agree to ~1e-11), so a total does not depend on the order of the additions: the lanes add theirs to the workgroup's accumulators (LDS atomics, fx_add),
@@ -571,11 +578,10 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   };
   uint32_t nx = 0;
   unsigned long long xprev0 = 0, xprev1 = 0;       // wave 0, lane 8 x + k: word k of shard x of each set when its previous use completed
-  long long xp[5] = {0, 0, 0, 0, 0};
   auto exchange = [&](int nval, int want, double & mine_tot) -> bool
   {
     long long xt0 = prof_on ? clock64() : 0;
-#define XT(i_) do { if (prof_on) { const long long t1_ = clock64(); xp[i_] += t1_ - xt0; xt0 = t1_; } } while (0)
+#define XT(i_) do { if (prof_on) { const long long t1_ = clock64(); wg.prof[8 + i_] += t1_ - xt0; xt0 = t1_; } } while (0)
     __syncthreads();                                 // every lane's term is in wg.accfx
     XT(0);
     for (int v0 = 0; v0 < nval; v0 += 7)             // (7 sums + the counter = one 64-byte block)
@@ -651,8 +657,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       const double tsave = S.time[li];
       Prop pr{0, 0, 0, 0.0};
       const bool ok = step < A.nsteps_gage
-        ? propose_gage<NT>(T, rng, S.time, (int)step, pl, wg.anc, wg.tau, A.sp.ft_gage, li, gbase, pr)
-        : propose_gspr<NT>(T, rng, S.time, (int)(step - A.nsteps_gage), pl, gl_i, wg.anc, wg.tau, wg.lograt, A.sp.ft_gspr, li, gbase, pr);
+        ? propose_gage<NT>(T, rng, S.time, (int)step, pl, wg.anc, wg.tau, SP.ft_gage, li, gbase, pr)
+        : propose_gspr<NT>(T, rng, S.time, (int)(step - A.nsteps_gage), pl, gl_i, wg.anc, wg.tau, wg.lograt, SP.ft_gspr, li, gbase, pr);
       SMP2_TICK(0);
       if (ok)
       {
@@ -675,14 +681,14 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     if (!A.do_allloci) continue;
 
     // ================= THETA: every population that can hold a coalescence, decided independently (theta_step_all)
-    if (A.sp.theta_alpha > 0 && A.theta_mask)
+    if (SP.theta_alpha > 0 && A.theta_mask)
     {
       double win_u = 0, uacc = 0;
       for (int p = 0; p < npop; ++p)
         if ((A.theta_mask >> p) & 1u) { const double a_ = rndu(&grng), b_ = rndu(&grng); if (p == li) { win_u = a_; uacc = b_; } }
       const bool on = li < npop && ((A.theta_mask >> li) & 1u);
       const double told = pl.theta, l2t_old = pl.l2t;
-      const double tnew = reflect(told + A.sp.ft_theta*(win_u - 0.5), 0.0, 999.0);
+      const double tnew = reflect(told + SP.ft_theta*(win_u - 0.5), 0.0, 999.0);
       const double l2t_new = log(2.0/(1.0*tnew));
       if (act && on) fx_add(li, msc_term((int)mync, t2h_cur, tnew, l2t_new) - msc_term((int)mync, t2h_cur, told, l2t_old), false);
       SMP2_TICK(3);
@@ -693,14 +699,14 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       bool accept = false;
       if (on)
       {
-        const double lnacc = th_tot + ((A.sp.theta_alpha - 1)*log(tnew/told) - A.sp.theta_beta*(tnew - told));
+        const double lnacc = th_tot + ((SP.theta_alpha - 1)*log(tnew/told) - SP.theta_beta*(tnew - told));
         accept = tnew > 0 && (lnacc >= 0 || uacc < exp(lnacc));
       }
       if (accept) { pl.theta = tnew; pl.l2t = l2t_new; }
       if (declog && tid < (uint32_t)G && on)
       {
         const uint32_t k = ndec + (uint32_t)__popc(A.theta_mask & ((1u << li) - 1u));
-        if (k < 2048u) { double * r = A.declog + 4*k; r[0] = 100 + li; r[1] = th_tot + ((A.sp.theta_alpha - 1)*log(tnew/told) - A.sp.theta_beta*(tnew - told)); r[2] = uacc; r[3] = accept ? 1 : 0; }
+        if (k < 2048u) { double * r = A.declog + 4*k; r[0] = 100 + li; r[1] = th_tot + ((SP.theta_alpha - 1)*log(tnew/told) - SP.theta_beta*(tnew - told)); r[2] = uacc; r[3] = accept ? 1 : 0; }
       }
       ndec += (uint32_t)__popc(A.theta_mask);
       {
@@ -733,9 +739,9 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       double tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1, lminf = 0, lmaxf = 0, tq_new = 0, mix_c = 1, mix_lnc = 0;
       if (!mix)
       {
-        const int pq = A.sp.parent[q], cl = sp_left[q], cr = sp_right[q];
+        const int pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
         tq_old = wg.tau[q]; tq_lo = fmax(wg.tau[cl], wg.tau[cr]); tq_hi = pq >= 0 ? wg.tau[pq] : 999.0;
-        tq_new = reflect(tq_old + A.sp.ft_tau*(uprop - 0.5), tq_lo, tq_hi);
+        tq_new = reflect(tq_old + SP.ft_tau*(uprop - 0.5), tq_lo, tq_hi);
         minf = (tq_new - tq_lo)/(tq_old - tq_lo); maxf = (tq_new - tq_hi)/(tq_old - tq_hi);
         lminf = log(minf); lmaxf = log(maxf);
         if (li == q) pl.tau = tq_new;
@@ -743,7 +749,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       }
       else
       {
-        mix_lnc = A.sp.ft_mix*(uprop - 0.5); mix_c = exp(mix_lnc);
+        mix_lnc = SP.ft_mix*(uprop - 0.5); mix_c = exp(mix_lnc);
         pl.tau *= mix_c;
         if (pl.parent >= 0) pl.ptau *= mix_c;
       }
@@ -758,7 +764,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         if (!mix)
         {
           // the gene nodes of q and its children between the bounds ride the rubber band (stree.c:4338-4479)
-          const int cl = sp_left[q], cr = sp_right[q];
+          const int cl = SP.left[q], cr = SP.right[q];
           const int pk = T.pop[li];
           const double tk_ = tsave;
           const bool moved = inner_i && (pk == q || pk == cl || pk == cr) && !(tk_ < tq_lo || tk_ > tq_hi);
@@ -801,16 +807,16 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       double lnacc = dl_tot;
       if (!mix)
       {
-        if (A.sp.parent[q] < 0 && A.sp.tau_alpha > 0)
-          lnacc += (A.sp.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - A.sp.tau_beta*(tq_new - tq_old);
+        if (SP.parent[q] < 0 && SP.tau_alpha > 0)
+          lnacc += (SP.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - SP.tau_beta*(tq_new - tq_old);
       }
       else
       {
         lnacc += (double)(nsp - 1)*mix_lnc;
-        if (A.sp.tau_alpha > 0)
+        if (SP.tau_alpha > 0)
         {
           const double troot = wg.tau[npop - 1];
-          lnacc += (A.sp.tau_alpha - 1)*mix_lnc - A.sp.tau_beta*(troot*mix_c - troot) - (double)(nsp - 2)*mix_lnc;
+          lnacc += (SP.tau_alpha - 1)*mix_lnc - SP.tau_beta*(troot*mix_c - troot) - (double)(nsp - 2)*mix_lnc;
         }
       }
       const bool accept = lnacc >= 0 || uacc < exp(lnacc);
@@ -838,10 +844,17 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   if (act)
   {
     Tree & tr = A.trees[task];
-    if (li < W)
+    double * g_clv = A.loc[task].clv, * g_pmat = A.loc[task].pmat;
     {
-      reinterpret_cast<uint32_t *>(tr.left)[li] = T.left.w[li < W ? li : 0]; reinterpret_cast<uint32_t *>(tr.right)[li] = T.right.w[li < W ? li : 0];
-      reinterpret_cast<uint32_t *>(tr.parent)[li] = T.parent.w[li < W ? li : 0]; reinterpret_cast<uint32_t *>(tr.pop)[li] = T.pop.w[li < W ? li : 0];
+      // (word li of each byte array: selected, not indexed — a run-time index would put the whole tree into scratch memory)
+      uint32_t wl_ = 0, wr_ = 0, wp_ = 0, wq_ = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) if (li == k) { wl_ = T.left.w[k]; wr_ = T.right.w[k]; wp_ = T.parent.w[k]; wq_ = T.pop.w[k]; }
+      if (li < W)
+      {
+        reinterpret_cast<uint32_t *>(tr.left)[li] = wl_; reinterpret_cast<uint32_t *>(tr.right)[li] = wr_;
+        reinterpret_cast<uint32_t *>(tr.parent)[li] = wp_; reinterpret_cast<uint32_t *>(tr.pop)[li] = wq_;
+      }
     }
     if (li < n) { tr.time[li] = S.time[li]; tr.clv[li] = (int8_t)T.cidx(li); tr.pmat[li] = (int8_t)T.pidx(li); }
     if (li == 0)
@@ -867,8 +880,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     A.counters[0] += cnt_prop; A.counters[1] += cnt_acc;
   }
   if (b == 0 && tid < (uint32_t)(3*MAXPOP)) A.taus[tid] = wg.tau[tid];
-  if (prof_on) for (int i = 0; i < 8; ++i) A.prof[i] = (double)pf_acc[i];
-  if (prof_on) for (int i = 0; i < 5; ++i) A.prof[8 + i] = (double)xp[i];
+  if (prof_on) for (int i = 0; i < 13; ++i) A.prof[i] = (double)wg.prof[i];
   if (wgprof) A.prof[16 + b] = (double)wg_sweep;
 }
 
