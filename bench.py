@@ -4,18 +4,22 @@ synthetic 10 000 loci x 1 000 sites, 4 taxa, JC69, 1 rate category, at N GPUs.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4] [--scaling weak|strong] ...
 
-A "step" is ONE MCMC ITERATION of the device-resident A00 sampler over all loci (config c2): per locus tips-1 gene-node
-age proposals and 2 tips-2 prune/regraft proposals (the sweep, one launch), a theta step per population, a rubber-band tau
-step per divergence and one mixing step — every proposal, density, likelihood and accept/reject on the GPU
-(bpa_sampler_t; same posterior as the unmodified program, tests/test_a00_posterior.py).  `value` is that rate; `roofline`
-is the sweep kernel's.  Next to it, as before:
+A "step" is `iterations_per_step` MCMC ITERATIONS of the device-resident A00 sampler over all loci (config c2) — an
+iteration: per locus tips-1 gene-node age proposals and 2 tips-2 prune/regraft proposals, a theta step per population, a
+rubber-band tau step per divergence and one mixing step, every proposal, density, likelihood and accept/reject on the
+GPU (bpa_sampler_t; same posterior as the unmodified program, tests/test_a00_posterior.py).  The count is chosen so that
+the timed region lasts >= 0.25 s whatever --steps is (an iteration takes ~0.1 ms).  On one GPU all iterations of a step
+are ONE persistent launch (csrc/sweep2.hpp).  `value` is iterations/s; `roofline` is that kernel's; `cpu_baseline` is the
+unmodified reference program's whole MCMC iterations/s at its best thread count on this box (like for like with `value`).
+Next to it, as before:
 
   likelihood_only   the hot path alone on a pre-recorded proposal tape (bpp_amd/schedule.py; accept/reject by a seeded
                     coin): resident batched plans, the per-locus steps of an iteration as one chain launch, the all-loci
                     steps one launch each.  This is also what `--config c3|c4` time (`value` then: tape iterations/s of
                     that config's own loci), and what `other_configs` carries for c3 / c4 in the default run.
-  cpu_baseline      the same tape through the REAL reference's locus API (oracle/_ref, AVX2), one core and all cores.
-  reference_program_on_host   the unmodified program's whole MCMC iterations/s over a sweep of thread counts.
+  cpu_tape_replay   the same tape through the REAL reference's locus API (oracle/_ref, AVX2), one core and all cores
+                    (comparable with likelihood_only; `speedups` holds both ratios).
+  reference_program_on_host   the unmodified program's whole MCMC iterations/s by thread count (`cpu_baseline` = its best).
 
 N > 1 (torch.distributed, one rank per GPU): loci sharded, no data-path collective; the only exchange is the sum an
 all-loci step is decided on.  --scaling weak (default; every rank owns the config's loci, `value` in 10k-locus
@@ -174,11 +178,13 @@ nsample = {nsample}
 """
 
 
-def bpp_program_baseline(nloci, sites, threads_list, n1=20, n2=100, reps=3, budget_s=150.0):
+def bpp_program_baseline(nloci, sites, threads_list, reps=2, budget_s=150.0):
     """The unmodified reference PROGRAM (oracle/_ref/bpp, built in place from /root/reference) on this box's host
-    cores: data from its own simulator, A00 JC69, whole MCMC iterations/s from the differential wall time of an n1-
-    and an n2-iteration run, per thread count: median and spread of `reps` measurements (north_star's comparison is
-    with the multi-thread AVX2 program: the best thread count is what counts)."""
+    cores: data from its own simulator, A00 JC69, whole MCMC iterations/s from the differential wall time of a short
+    and a long run (start-up — reading and compressing 10 000 loci, the first likelihoods — cancels), per thread count:
+    median and spread of `reps` measurements.  The long run has 800 iterations more than the short one with several
+    threads (>= 10 s of MCMC on this box; round 2's 80-iteration differentials scattered by 2x), 130 more with one.
+    north_star's comparison is with the multi-thread AVX2 program: the best thread count is what counts."""
     import subprocess
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -201,6 +207,7 @@ def bpp_program_baseline(nloci, sites, threads_list, n1=20, n2=100, reps=3, budg
 
         for th in threads_list:
             tl = f"threads = {th} 1 1" if th > 1 else ""
+            n1, n2 = (100, 900) if th > 1 else (20, 150)
             rates = []
             for _ in range(reps if th > 1 else 1):
                 if time.time() - t_start > budget_s and rates:
@@ -208,7 +215,7 @@ def bpp_program_baseline(nloci, sites, threads_list, n1=20, n2=100, reps=3, budg
                 t1, t2 = wall(n1, tl), wall(n2, tl)
                 rates.append((n2 - n1) / max(t2 - t1, 1e-9) * nloci / 10000.0)
             out[th] = dict(median=round(float(np.median(rates)), 2), min=round(min(rates), 2), max=round(max(rates), 2),
-                           runs=len(rates))
+                           runs=len(rates), iterations=f"{n2} vs {n1}")
     return out
 
 
@@ -579,19 +586,34 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
             smp.set_subst_model(i, d["freqs"], d["exch"], 0.5)
         smp.set_subst_moves(0.2, 0.3, 0.5, 1.0, 1.0)
     smp.initialize()
+    kind = smp.kind()
     sync = D.sync if D else eng.synchronize
+    # A step = `ips` MCMC iterations, chosen so that the timed region lasts >= 0.25 s whatever --steps is (an iteration
+    # of config 2 takes ~0.1 ms: 20 of them would be a 2 ms region); the rate does not depend on it.  Every rank takes
+    # the same count (the ranks enter the same collectives).
+    smp.iterate(max(warmup, 1))
+    sync()
+    probe = 2 if generic else 20
+    t0 = time.perf_counter()
+    smp.iterate(probe)
+    sync()
+    est = (time.perf_counter() - t0) / probe
+    if D is not None:
+        est = D.max(est)
+    ips = max(1, int(np.ceil(0.3 / max(est * steps, 1e-9))))      # (0.3: the probe runs a little slower than the long launch)
+    niter = steps * ips
     while True:
         smp.iterate(warmup)
         sync()
         w0 = smp.work()
         l0 = smp.summary()["launches"]
-        smp.enable_timing(args.event_stride if not args.no_timing_events else 0)
+        smp.enable_timing(0 if args.no_timing_events else (1 if kind == "persistent" else args.event_stride))
         t0 = time.perf_counter()
-        smp.iterate(steps)
+        smp.iterate(niter)
         enq = time.perf_counter() - t0            # host time to enqueue the timed region (the GPU is still running)
         sync()
         dt = time.perf_counter() - t0
-        log(f"sampler: host enqueue {1e3 * enq / steps:.4f} ms/iteration of {1e3 * dt / steps:.4f} ms/iteration")
+        log(f"sampler ({kind}): {steps} steps x {ips} iterations in {dt:.3f} s; host enqueue {1e3 * enq / niter:.4f} ms/iteration of {1e3 * dt / niter:.4f} ms/iteration")
         tm = smp.timing()
         smp.enable_timing(0)
         l1 = smp.summary()["launches"]
@@ -626,6 +648,27 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
                         note="the generic device-resident sampler (csrc/gsampler.hpp): every proposal step = one launch of a per-locus "
                              "proposal kernel (trees in HBM) + the engine's step kernel over the records it wrote; algorithmic bytes = K1 + K2 "
                              "of the node updates the proposals actually asked for (device counters)")
+    elif kind == "persistent" and tm["sweep_launches"]:
+        # every launch of the timed region carries events; a launch = up to 4096 whole iterations of all loci
+        nl = tm["sweep_launches"]
+        bytes_per_launch = (w1["bytes"] - w0["bytes"]) / nl
+        us = 1e3 * tm["sweep_ms"] / nl
+        achieved = bytes_per_launch / (us * 1e-6) / 1e9
+        kname = f"smp2::iter_kernel<{4 if cfg['taxa'] <= 4 else 8}>"
+        traffic, src = traffic_from_profiles("c2", "iter_kernel") if args.loci is None else (None, None)
+        roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=src,
+                        avg_kernel_us=round(us, 3), algorithmic_bytes_per_launch=round(bytes_per_launch), launches=nl,
+                        iterations_per_launch=round(niter / nl, 1), kernel_us_per_iteration=round(us * nl / niter, 3),
+                        algorithmic_bytes_per_iteration=round((w1["bytes"] - w0["bytes"]) / niter),
+                        node_updates_per_iteration=round((w1["node_updates"] - w0["node_updates"]) / niter),
+                        timing="hipExtLaunchKernelGGL start/stop events on the engine stream around EVERY launch of the timed region",
+                        note=f"one launch = whole MCMC iterations of every locus ({3 * cfg['taxa'] - 3} per-locus proposals, the theta step, "
+                             f"{cfg['taxa'] - 1} tau steps and the mixing step each, proposal control and decisions included); algorithmic "
+                             "bytes = K1 + K2 + K4 (SURVEY 8d) of the node updates the proposals actually ran, per-locus AND all-loci steps "
+                             "(device counters).  The loci's state stays in LDS for the whole launch: HBM sees one load and one store of it "
+                             "per LAUNCH (`traffic`), so the fraction says how fast the likelihood work is done, not how busy the HBM is — "
+                             "the kernel is bound by the latency of one wave's dependent instruction stream (DESIGN 6)")
     elif tm["sweep_launches"]:
         sweeps = max(w1["sweeps"] - w0["sweeps"], 1)
         bytes_per_sweep = (w1["bytes"] - w0["bytes"]) / sweeps
@@ -642,17 +685,20 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
                         note=f"one launch = the {3 * cfg['taxa'] - 3} per-locus proposals of an iteration for every locus, proposal control included; "
                              "algorithmic bytes = K1 + K2 + K4 of the node updates the proposals actually ran (device counters); the working "
                              "set lives in LDS for the whole launch: latency-bound by the leader lanes' serial proposal code, not by HBM")
-    out = dict(iterations_per_s=round(steps / dt, 3), iterations_per_s_10k_loci=round(steps / dt * total_loci / 10000.0, 3),
-               ms_per_iteration=round(1e3 * dt / steps, 5), steps=steps, warmup=warmup, n_gpus=world, loci_total=total_loci,
+    out = dict(iterations_per_s=round(niter / dt, 3), iterations_per_s_10k_loci=round(niter / dt * total_loci / 10000.0, 3),
+               ms_per_iteration=round(1e3 * dt / niter, 5), ms_per_step=round(1e3 * dt / steps, 4), iterations_per_step=ips,
+               timed_region_s=round(dt, 4), steps=steps, warmup=warmup, n_gpus=world, loci_total=total_loci,
                proposals_per_locus_iteration=3 * cfg["taxa"] - 3 + (9 if generic else 0),
-               launches_per_iteration=round((l1 - l0 - 1) / steps, 2),      # (-1: the settle launch of the first summary)
+               launches_per_iteration=round(max(l1 - l0 - (0 if kind == "persistent" else 1), 0) / niter, 4),      # (-1: the settle launch of the first summary)
                acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
                taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
                thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],
                roofline=roofline,
                implementation=("generic path (csrc/gsampler.hpp): proposals on the device as records for the engine's step kernels; "
                                "tree moves + 3 frequency, 5 exchangeability and 1 alpha move per locus" if generic else
-                               "LDS sweep kernel (csrc/sampler.hpp): all per-locus proposals of an iteration in one launch"),
+                               "persistent iteration kernel (csrc/sweep2.hpp): all iterations of a call in one launch, the loci's state in "
+                               "LDS, a group of lanes per locus, all-loci decisions from device-scope fixed-point accumulators" if kind == "persistent" else
+                               "LDS sweep kernel (csrc/sampler.hpp): all per-locus proposals of an iteration in one launch, one launch per all-loci step"),
                note="the A00 sampler (species tree fixed) resident on the device: population-aware GAGE+GSPR per locus, a THETA "
                     "step per population, a rubber-band TAU step per divergence and one MIX step per iteration, "
                     "Metropolis-Hastings on priors x MSC density x likelihood (density bit-equal to gtree_logprob); reproduces "
@@ -764,15 +810,18 @@ def main():
     if rank == 0 and world == 1 and args.config == "c2" and not args.no_cpu_baseline and not args.no_bpp_program:
         try:
             ncores = os.cpu_count() or 1
-            sweep = [1] + [t for t in (8, 16, 32, 64, 128) if t <= ncores]
+            # one thread, what the CPU quota grants (the box shows 256 logical cores and grants 16: more threads than that are
+            # only throttled) and twice that — round 2's sweep over 8 ... 128 found the best there every time
+            q = int(cpu_quota() or ncores)
+            sweep = sorted({1, max(2, min(q, ncores)), max(2, min(2 * q, ncores))})
             r = bpp_program_baseline(nloci_cfg, cfg["sites"], sweep)
             if r:
                 best = max((k for k in r if k > 1), key=lambda k: r[k]["median"], default=1)
                 bpp_prog = dict(unit="whole MCMC iterations/s of the unmodified reference program (10k loci, A00 JC69), incl. its MCMC control",
                                 threads={str(k): v for k, v in r.items()}, best_threads=best, best_median=r[best]["median"],
                                 host_logical_cores=ncores, host_cpu_quota=cpu_quota(), kind="reference",
-                                sample="bpp --simulate data (seed 12345), differential wall time of 20- vs 100-iteration runs, "
-                                       "median / min / max of 3 measurements per thread count (1 thread: one)")
+                                sample="bpp --simulate data (seed 12345), differential wall time of 100- vs 900-iteration runs (1 thread: "
+                                       "20 vs 150), median / min / max of 2 measurements per thread count (1 thread: one)")
         except Exception as ex:       # noqa: BLE001
             bpp_prog = dict(error=str(ex)[:200])
 
@@ -823,7 +872,7 @@ def main():
                            " of the sums the THETA / TAU / MIX steps are decided on")
         if headline_sampler:
             value = sampler_sec["iterations_per_s_10k_loci"] if args.scaling == "weak" else sampler_sec["iterations_per_s"]
-            ms_per_step = sampler_sec["ms_per_iteration"]
+            ms_per_step = sampler_sec["ms_per_step"]
             roofline = sampler_sec.pop("roofline")
             metric = "MCMC iterations/sec (A00), every decision on the device"
         else:
@@ -832,20 +881,54 @@ def main():
             roofline = tape_sec["roofline"]
             metric = "A00 iterations/sec of the likelihood hot path (proposal tape)"
         loci_unit = 10000 if args.config in ("c2", "c3") else nloci_cfg
+        # ---- `cpu_baseline` is like-for-like with `value`: whole MCMC iterations/s of the unmodified reference program at
+        # its best thread count on this box's host cores; the tape replay through the reference's locus API (likelihood
+        # path only, comparable with `likelihood_only`) keeps its own key
+        cpu_like = cpu
+        vs_baseline = None
+        ratios = None
+        if headline_sampler and bpp_prog and "error" not in bpp_prog:
+            b = bpp_prog["threads"][str(bpp_prog["best_threads"])]
+            cpu_like = dict(value=b["median"], unit="iterations/s (whole A00 MCMC iterations over 10000 loci, MCMC control included: like `value`)",
+                            cores=bpp_prog["best_threads"], kind="reference",
+                            sample=f"the unmodified program (oracle/_ref/bpp, AVX2, threads = {bpp_prog['best_threads']} 1 1) on its own simulated "
+                                   f"10000-locus data set, {b['iterations']} iterations differential, {b['runs']} measurements",
+                            spread=dict(min=b["min"], max=b["max"]), one_thread=bpp_prog["threads"].get("1", {}).get("median"),
+                            host_logical_cores=bpp_prog["host_logical_cores"], host_cpu_quota=bpp_prog["host_cpu_quota"],
+                            note="the box grants this container `host_cpu_quota` CPUs (cgroup cpu.max) of its logical cores: the thread "
+                                 "count is the best inside that quota, and the ratio below holds against THAT many cores")
+        if headline_sampler and args.config == "c2" and args.scaling == "weak":
+            # the reference program measured in the survey container (other hardware: 8-vCPU Xeon
+            # 2.1 GHz), threads = 8, this metric on this configuration
+            vs_baseline = round(value / 25.9, 2)
+        if cpu_like and cpu_like.get("value"):
+            ratios = dict(value_over_cpu_baseline=round(value / cpu_like["value"], 1))
+            if cpu and tape_sec and cpu is not cpu_like:
+                ratios["likelihood_only_over_tape_replay_all_cores"] = round(
+                    (tape_sec["iterations_per_s_10k_loci"] if args.config == "c2" else tape_sec["iterations_per_s"]) / cpu["all_cores"]["value"], 1)
+                ratios["likelihood_only_over_tape_replay_one_core"] = round(
+                    (tape_sec["iterations_per_s_10k_loci"] if args.config == "c2" else tape_sec["iterations_per_s"]) / cpu["value"], 1)
         out = {
             "metric": metric + " + site-lnL updates/sec, 10k loci, 1/2/4/8 GPU",
             "value": value,
             "unit": (f"iterations/s (one iteration = one A00 MCMC iteration over {loci_unit} loci" +
                      ("; weak scaling: N data sets of that size, value = N x per-rank rate)" if (D is not None and args.scaling == "weak") else ")")),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "ms_per_step": ms_per_step,
+            "iterations_per_step": sampler_sec["iterations_per_step"] if headline_sampler else 1,
+            "ms_per_iteration": sampler_sec["ms_per_iteration"] if headline_sampler else ms_per_step, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": vs_baseline,
+            "vs_baseline_ref": ("BASELINE.md section 2: 25.9 iterations/s = the unmodified program, threads = 8, on the survey "
+                                "container's 8-vCPU Xeon 2.1 GHz (other hardware); the same-box figure is cpu_baseline") if vs_baseline else None,
+            "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["name"] + f"; {nloci} loci on rank 0, {npat / nloci:.2f} patterns/locus" +
                        (f"; {3 * cfg['taxa'] - 3} gene-tree proposals per locus + {2 * cfg['taxa'] - 1} theta + {cfg['taxa'] - 1} tau + 1 mixing step per iteration" if headline_sampler else ""),
                        "parallelism": parallelism},
             "site_lnl_updates_per_s": tape_sec["site_lnl_updates_per_s"] if tape_sec else None,
             "roofline": roofline,
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu_like,
+            "speedups": ratios,
+            "cpu_tape_replay": cpu if cpu is not cpu_like else None,
             "reference_program_on_host": bpp_prog,
             "device_resident_sampler": sampler_sec,
             "host_control_in_c": host_sec,

@@ -147,6 +147,7 @@ def lib():
         "bpa_sampler_set_subst_moves": (None, [vp, d, d, d, d, d]),
         "bpa_sampler_timing": (i, [vp, dp, C.POINTER(C.c_ulong), dp, C.POINTER(C.c_ulong)]),
         "bpa_sampler_work": (i, [vp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
+        "bpa_sampler_kind": (i, [vp]),
         "bpa_engine_enable_timing": (None, [vp, i]),
         "bpa_engine_set_timing_stride": (None, [vp, u]),
         "bpa_engine_timing": (i, [vp, dp, dp, dp, C.POINTER(C.c_ulong)]),
@@ -181,7 +182,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_sampler_set_tau_prior", "bpa_sampler_get_taus", "bpa_sampler_get_tree_msc",
             "bpa_sampler_set_theta_prior", "bpa_sampler_get_thetas", "bpa_sampler_set_allreduce",
             "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary",
-            "bpa_sampler_enable_timing", "bpa_sampler_timing", "bpa_sampler_work",
+            "bpa_sampler_enable_timing", "bpa_sampler_timing", "bpa_sampler_work", "bpa_sampler_kind",
             "bpa_sampler_set_subst_model", "bpa_sampler_get_subst_model", "bpa_sampler_set_subst_moves"]
 
 
@@ -654,6 +655,13 @@ class Sampler:
         nu, pu, sw = C.c_ulong(), C.c_ulong(), C.c_ulong()
         _chk(lib().bpa_sampler_work(self.h, C.byref(by), C.byref(nu), C.byref(pu), C.byref(sw)))
         return dict(bytes=by.value, node_updates=nu.value, pattern_updates=pu.value, sweeps=sw.value)
+
+    def kind(self):
+        """'sweep' (one launch per step), 'generic' or 'persistent' (the whole iteration(s) of a call as one launch)"""
+        k = lib().bpa_sampler_kind(self.h)
+        if k < 0:
+            raise BpaError(_err())
+        return ("sweep", "generic", "persistent")[k]
 
     def close(self):
         if self.h and self.engine.h:

@@ -37,6 +37,7 @@ struct Tree                                // one per locus, in HBM and (while s
   int32_t  root, tips;
   uint32_t proposals, accepted;
   uint32_t sw_nupd, sw_nbr;                // work of the sweep launches: node updates run / fresh branches (bpa_sampler_work)
+  uint32_t al_nupd, al_nbr, al_neval, pad_; // the same of the all-loci steps + their evaluations (counted by the persistent kernel, sweep2.hpp)
 };
 static_assert(sizeof(Tree) % 16 == 0 && offsetof(Tree, lnl) % 16 == 0, "Tree is copied as uint4");
 
@@ -1899,8 +1900,9 @@ extern "C" int bpa_sampler_work(bpa_sampler_t * s, double * bytes, unsigned long
   {
     // K1 3 Np R S 8 + 2 R S^2 8 bytes per node update, K2 (Np R S 8 + 4 Np) per evaluated proposal, K4 R S^2 8 per fresh P-matrix
     const double np = s->loci[i]->sites, R = s->loci[i]->rate_cats;
-    const double nupd = s->generic ? s->g_trees[i].work_nupd : s->h_trees[i].sw_nupd, nbr = s->generic ? s->g_trees[i].work_nbr : s->h_trees[i].sw_nbr;
-    const double nprop = s->generic ? s->g_trees[i].work_neval : s->h_trees[i].proposals;
+    const double nupd = s->generic ? s->g_trees[i].work_nupd : (double)s->h_trees[i].sw_nupd + s->h_trees[i].al_nupd,
+                 nbr = s->generic ? s->g_trees[i].work_nbr : (double)s->h_trees[i].sw_nbr + s->h_trees[i].al_nbr;
+    const double nprop = s->generic ? s->g_trees[i].work_neval : (double)s->h_trees[i].proposals + s->h_trees[i].al_neval;
     // (the generic path counts every evaluated step; where the P-matrix phase is a launch of its own — several rate
     //  categories — the K4 bytes are not the timed kernel's)
     by += nupd*(96.0*np*R + 256.0*R) + nprop*(32.0*R + 4.0)*np + ((s->generic && !s->g_alljc) ? 0.0 : nbr*128.0*R);
@@ -1911,6 +1913,13 @@ extern "C" int bpa_sampler_work(bpa_sampler_t * s, double * bytes, unsigned long
   if (pattern_updates) *pattern_updates = pu;
   if (sweeps) *sweeps = s->generic ? s->g_evals : s->sweeps;
   return 1;
+}
+
+extern "C" int bpa_sampler_kind(bpa_sampler_t * s)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (!sampler_upload(s)) return -1;
+  return s->generic ? BPA_SAMPLER_GENERIC : (s->v2_ok && !s->allreduce && !s->env_trace) ? BPA_SAMPLER_PERSISTENT : BPA_SAMPLER_SWEEP;
 }
 
 extern "C" int bpa_sampler_summary(bpa_sampler_t * s, double * total_lnl, unsigned long * proposals,

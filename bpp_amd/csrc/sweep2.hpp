@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   GTree<NT> T;
   a00_rng_t rng = 0;
   double lnl_cur = 0, logpr_cur = 0;
-  uint32_t np = 0, pb = 0, nprop_done = 0, nacc = 0, w_nupd = 0, w_nbr = 0;
+  uint32_t np = 0, pb = 0, nprop_done = 0, nacc = 0, w_nupd = 0, w_nbr = 0, a_nupd = 0, a_nbr = 0, a_neval = 0;
   int gl_i = 0;
   for (int k = 0; k < W; ++k) { T.left.w[k] = T.right.w[k] = T.parent.w[k] = T.pop.w[k] = 0xffffffffu; }
   T.cf = T.pf = 0; T.root = 0; T.tips = 2;
@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         wsync();
         evaluated = pr.ndm != 0;
         const double lnl = evaluate(pr, evaluated, lp_new);
-        if (evaluated) lnl_new = lnl;
+        if (evaluated) { lnl_new = lnl; a_nupd += (uint32_t)nops; a_nbr += (uint32_t)__popc(pr.brm); ++a_neval; }
         const double dpr = lp_new - logpr_cur;
         const double h = mix ? dpr + hast : (dpr + hast) + hast2;
         const double dl = evaluated ? (lnl_new - lnl_cur) + h : h;
@@ -861,6 +861,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     {
       tr.lnl = lnl_cur; tr.logpr = logpr_cur; tr.rng = rng; tr.root = T.root;
       tr.proposals += nprop_done; tr.accepted += nacc; tr.sw_nupd += w_nupd; tr.sw_nbr += w_nbr;
+      tr.al_nupd += a_nupd; tr.al_nbr += a_nbr; tr.al_neval += a_neval;
     }
     if (li < npop) { A.pop_nc[(size_t)li*A.ntasks + task] = (int8_t)mync; A.pop_t2h[(size_t)li*A.ntasks + task] = t2h_cur; }
     for (uint32_t i = (uint32_t)li; i < (uint32_t)(4*(2*tips - 2)); i += G) g_pmat[i] = (&S.ab[0][0])[i];

@@ -263,9 +263,12 @@ int          bpa_batch_evaluate(bpa_engine_t *, const bpa_batch_t *, double * ln
    prop_mixing.c:52), the MSC density (gtree_logprob, gtree.c:3957), the gene trees with their
    populations and buffer-index bookkeeping, the random streams and the accept/reject decisions:
    same arithmetic, same streams, same trajectory as the host driver, without a host round trip per
-   proposal.  Two implementations behind the one interface: where every locus is JC69 with one rate category, <= 8
-   tips and <= 64 patterns, a sweep kernel that keeps trees and CLVs in LDS and runs all per-locus proposals of an
-   iteration in one launch (csrc/sampler.hpp); otherwise — several rate categories, GTR, up to 16 tips, < 256
+   proposal.  Three implementations behind the one interface (bpa_sampler_kind tells which one runs).  Where every
+   locus is JC69 with one rate category, <= 8 tips and <= 64 patterns: on one GPU the PERSISTENT ITERATION KERNEL
+   (csrc/sweep2.hpp: the state of all loci stays in LDS for a whole call of bpa_sampler_iterate — many iterations —,
+   a group of 8 or 16 lanes per locus runs the proposals, the all-loci decisions come from device-scope fixed-point
+   accumulators inside the launch); with an all-reduce callback installed (several ranks), more loci than stay
+   resident at once or BPA_SMP_V1=1, the sweep kernel with one launch per step (csrc/sampler.hpp); otherwise — several rate categories, GTR, up to 16 tips, < 256
    patterns x categories — a generic path that proposes on the device and evaluates with the engine's batched step
    kernels (csrc/gsampler.hpp).  No scalers, <= 8 species.  Trees use the node numbering of a00_tree_t (tips first;
    arrays of 2*tips-1 entries); the species tree that of a00_set_species_tree.                                   */
@@ -328,6 +331,14 @@ int  bpa_sampler_timing(bpa_sampler_t *, double * sweep_ms, unsigned long * swee
    or, on the generic path, every launch of the engine's step kernel                                                */
 int  bpa_sampler_work(bpa_sampler_t *, double * bytes, unsigned long * node_updates,
                       unsigned long * pattern_updates, unsigned long * sweeps);
+/* which implementation bpa_sampler_iterate runs (known after bpa_sampler_initialize): BPA_SAMPLER_SWEEP (one launch per
+   step, csrc/sampler.hpp), BPA_SAMPLER_GENERIC (csrc/gsampler.hpp) or BPA_SAMPLER_PERSISTENT (csrc/sweep2.hpp: its
+   launches are what bpa_sampler_timing reports as `sweep`, its `sweeps` of bpa_sampler_work are iterations, and the
+   work includes the all-loci steps' node updates) */
+#define BPA_SAMPLER_SWEEP      0
+#define BPA_SAMPLER_GENERIC    1
+#define BPA_SAMPLER_PERSISTENT 2
+int  bpa_sampler_kind(bpa_sampler_t *);
 
 /* ------------------------------------------------------ work / measurement --- */
 /* Algorithmic work of one launch of the plan, by the formulas of SURVEY.md §8(d):

@@ -32,7 +32,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, d in acc.items():
-            if any(w in k for w in ("partials", "step_", "pmatrix", "reduce", "sweep", "decide")):
+            if any(w in k for w in ("partials", "step_", "pmatrix", "reduce", "sweep", "decide", "iter_kernel", "gstep", "eigen")):
                 pm.setdefault(k, {}).update({c: {"mean": sum(v)/len(v), "dispatches": len(v)} for c, v in d.items()})
 out["pmc_per_dispatch"] = pm
 json.dump(out, open("$R/gpurun_out/profile_${CFG}_$TAG.json", "w"), indent=1)
