@@ -408,9 +408,19 @@ extern "C" void bpa_set_pattern_weights(bpa_locus_t * l, const unsigned * w)
   l->weights_dirty = true; mark_dirty(l);
 }
 
-// a per-locus setter after bpa_plan_set_params_device: bring the host mirror level with the device block first
-static void refresh_host_par(bpa_locus * l)
+// The single-locus update API is lazy (bpa_locus_update_matrices / _partials only queue): what is queued on a locus was
+// asked for with the parameters it had THEN, so a setter lets the queue run before it changes them (the eager
+// semantics the header documents)
+static int run_queued(bpa_locus * l, bool want_lnl, unsigned root_clv, int root_scaler, double * lnl, bool persite);
+static void settle_queue(bpa_locus * l)
 {
+  if (l->pending && l->alive) (void)run_queued(l, false, 0, BPA_SCALE_BUFFER_NONE, nullptr, false);
+}
+
+// a per-locus setter after bpa_plan_set_params_device: bring the host mirror level with the device block first
+static void refresh_host_par(bpa_locus * l, bool settle = true)
+{
+  if (settle) settle_queue(l);
   if (!l->host_par_stale) return;
   bpa_engine * e = l->eng;
   (void)hipSetDevice(e->device);
@@ -608,6 +618,7 @@ static int engine_pack(bpa_engine * e)
     st.clv = l->dev.clv; st.pmat = l->dev.pmat; st.scaler = l->dev.scaler; st.par = l->dev.par;
     st.np = np; st.tips_n = l->tips; st.lane0 = (uint32_t)((blk.size() - 1)*PACK_BS + used); st.locus = l->id;
     st.unphased_length = l->dev.unphased_length; st.rate_cats = R; st.model = l->dev.model; st.pstride = l->dev.pstride; st.tips = l->dev.tips;
+    refresh_host_par(l, false);                   // (bpa_plan_set_params_device may have moved the device block ahead)
     st.rate0 = l->par[par_rates(R)];
     slots.push_back(st);
     slot_of[l->id] = (int32_t)slot;
@@ -1381,6 +1392,9 @@ static int plan_set_params(bpa_plan * p, int which, const double * host_values, 
     dev_values = p->param_stage.p;
   }
   else for (unsigned t = 0; t < T; ++t) e->loci[p->h_locus[t]]->host_par_stale = true;      // the device block is ahead of the mirror
+  // the packing's slot table carries a copy of a one-category locus's rate (SlotStatic::rate0, what the JC69 step kernels
+  // build fresh P-matrices from): it has to follow
+  if (which == 4 && len == 1) e->pack_dirty = true;
   {
     bool all4 = true, all20 = true;
     for (unsigned t = 0; t < T; ++t) { const unsigned S = e->loci[p->h_locus[t]]->states; all4 = all4 && S == 4; all20 = all20 && S == 20; }
@@ -1708,6 +1722,17 @@ static void queue_locus(bpa_locus * l)
   if (!l->pending) { l->pending = true; l->eng->pending.push_back(l); }
 }
 
+// a queue whose run failed goes back on the locus (in front of anything queued since): a retry then computes over updated
+// buffers instead of returning a value over buffers that never saw the updates
+static int requeue(bpa_locus * l, std::vector<unsigned> & pm, std::vector<double> & len, std::vector<bpa_op_t> & ops)
+{
+  pm.insert(pm.end(), l->pend_pm.begin(), l->pend_pm.end());    l->pend_pm.swap(pm);
+  len.insert(len.end(), l->pend_len.begin(), l->pend_len.end()); l->pend_len.swap(len);
+  ops.insert(ops.end(), l->pend_ops.begin(), l->pend_ops.end()); l->pend_ops.swap(ops);
+  if (!l->pending) { l->pending = true; l->eng->pending.push_back(l); }
+  return 0;
+}
+
 // run what is queued on l (and, with want_lnl, the root term at root_clv / root_scaler: *lnl receives it).
 // persite: the caller wants the per-pattern terms, which only the scratch plan keeps.
 static int run_queued(bpa_locus * l, bool want_lnl, unsigned root_clv, int root_scaler, double * lnl, bool persite)
@@ -1729,10 +1754,10 @@ static int run_queued(bpa_locus * l, bool want_lnl, unsigned root_clv, int root_
     b.op_off = op_off; b.ops = ops.data();
     b.root_clv = &root_clv; b.root_scaler = &root_scaler;
     bool handled = false;
-    if (!batch_evaluate_packed(e, &b, lnl, handled)) return 0;
+    if (!batch_evaluate_packed(e, &b, lnl, handled)) return requeue(l, pm, len, ops);
     if (handled) return 1;
   }
-  if (!scratch_run(l, pm.data(), len.data(), nmat, ops.data(), nops, want_lnl, root_clv, root_scaler)) return 0;
+  if (!scratch_run(l, pm.data(), len.data(), nmat, ops.data(), nops, want_lnl, root_clv, root_scaler)) return requeue(l, pm, len, ops);
   if (want_lnl && !bpa_plan_get_lnl(l->scratch.get(), lnl)) return 0;
   return 1;
 }

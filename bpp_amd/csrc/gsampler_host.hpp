@@ -2,6 +2,40 @@
 // iteration, downloads.  Included at the end of sampler.hpp (same translation unit as engine.hip).
 #pragma once
 
+// the substitution-parameter moves' device tables (every locus's frequencies | exchangeabilities | alpha, the roll-back
+// pairs, the loci's ids): made when a window width first becomes positive — the widths themselves travel with every
+// launch, so switching a move on or changing a width in mid-run (BPP's burn-in finetune adjustment) touches no state
+static int gs_subst_ready(bpa_sampler * s)
+{
+  if (!(s->g_ft[0] > 0 || s->g_ft[1] > 0 || s->g_ft[2] > 0) || s->g_sm.p) return 1;
+  const unsigned T = s->nloci;
+  if (s->g_alljc) return fail("bpa_sampler: the substitution-parameter moves need loci with an eigendecomposition (GTR) and several rate categories");
+  if (s->g_sm_host.size() != (size_t)T*11) return fail("bpa_sampler: call bpa_sampler_set_subst_model for every locus before the substitution-parameter moves");
+  std::vector<uint32_t> ids(T);
+  for (unsigned i = 0; i < T; ++i) ids[i] = s->loci[i]->id;
+  // (no move has run yet: the host copy is what bpa_sampler_set_subst_model left)
+  if (!upload(s->g_sm, s->g_sm_host.data(), (size_t)T*11) || !s->g_sm_old.reserve((size_t)T*2) || !upload(s->g_ids, ids.data(), T)) return 0;
+  return 1;
+}
+
+// K6 for every locus of the sampler from the values now in its parameter block (pll_update_eigen, locus.c:2462-2476)
+static int gs_refresh_eigen(bpa_sampler * s)
+{
+  bpa_engine * e = s->eng;
+  if (!s->g_eigen_dirty) return 1;
+  if (!s->g_ids.p)
+  {
+    std::vector<uint32_t> ids(s->nloci);
+    for (unsigned i = 0; i < s->nloci; ++i) ids[i] = s->loci[i]->id;
+    if (!upload(s->g_ids, ids.data(), s->nloci)) return 0;
+  }
+  hipLaunchKernelGGL(eigen_kernel<4>, dim3((s->nloci + 63)/64), dim3(64), 0, e->stream, e->d_loci.p, s->g_ids.p, (uint32_t)s->nloci);     // the generic sampler's loci are 4-state
+  HIPCHK(hipGetLastError());
+  s->g_eigen_dirty = false;
+  s->launches++;
+  return 1;
+}
+
 static int gs_upload(bpa_sampler * s)
 {
   bpa_engine * e = s->eng;
@@ -40,18 +74,12 @@ static int gs_upload(bpa_sampler * s)
       !s->g_lnl.reserve(T) || !s->g_hast.reserve(T) || !s->g_logpr.reserve(T) || !s->g_delta.reserve(T) || !s->g_active.reserve(T) ||
       !s->g_site.reserve(npat) || !s->g_recs.reserve(nrec) || !s->g_mat2.reserve(nmat) || !s->g_len.reserve(nmat) ||
       !upload(s->g_bmo, bmo.data(), bmo.size()) || !s->g_lograt.reserve(gsm::NN*gsm::NN) ||
-      !upload(s->flag, zero2, 1) || !upload(s->counters, zero2, 2) || !s->mix_sum.reserve(1) ||
+      !upload(s->flag, zero2, 1) || !upload(s->counters, s->h_counters, 2) || !s->mix_sum.reserve(1) ||
       !upload(s->taus, s->h_taus.data(), s->h_taus.size()) || !s->pop_t2h.reserve((size_t)T*smp::MAXPOP) ||
       !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP))
     return 0;
-  if (s->g_ft[0] > 0 || s->g_ft[1] > 0 || s->g_ft[2] > 0)
-  {
-    if (s->g_alljc) return fail("bpa_sampler: the substitution-parameter moves need loci with an eigendecomposition (GTR) and several rate categories");
-    if (s->g_sm_host.size() != (size_t)T*11) return fail("bpa_sampler: call bpa_sampler_set_subst_model for every locus before the substitution-parameter moves");
-    std::vector<uint32_t> ids(T);
-    for (unsigned i = 0; i < T; ++i) ids[i] = s->loci[i]->id;
-    if (!upload(s->g_sm, s->g_sm_host.data(), (size_t)T*11) || !s->g_sm_old.reserve((size_t)T*2) || !upload(s->g_ids, ids.data(), T)) return 0;
-  }
+  s->g_sm.free();                                    // (re-made from the host copy by gs_subst_ready when a move is on)
+  if (!gs_subst_ready(s)) return 0;
   // every slot starts as "not part of the step", every matrix entry as a hole
   HIPCHK(hipMemsetAsync(s->g_recs.p, 0xff, nrec*sizeof(uint4), e->stream));
   HIPCHK(hipMemsetAsync(s->g_mat2.p, 0xff, nmat*sizeof(MatRec2), e->stream));
@@ -124,16 +152,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
 {
   bpa_engine * e = s->eng;
   if (!e->usedata) return 1;                       // lnL = 0 for every locus (the buffer was zeroed): the MSC prior
-  if (s->g_eigen_dirty)
-  {
-    // K6 for every locus of the sampler from the values now in its parameter block (pll_update_eigen, locus.c:2462-2476)
-    hipLaunchKernelGGL(eigen_kernel<4>, dim3((s->nloci + 63)/64), dim3(64), 0, e->stream, e->d_loci.p, s->g_ids.p, (uint32_t)s->nloci);     // the generic sampler's loci are 4-state
-    HIPCHK(hipGetLastError());
-    s->g_eigen_dirty = false;
-    s->launches++;
-    static const bool dbg_sync_e = getenv("BPA_GS_SYNC") != nullptr;
-    if (dbg_sync_e) { HIPCHK(hipStreamSynchronize(e->stream)); fprintf(stderr, "[gs] eigen done\n"); }
-  }
+  if (!gs_refresh_eigen(s)) return 0;
   PlanDev d{};
   d.loci = e->d_loci.p; d.bfbeta = e->bfbeta;
   d.site_term = s->g_site.p; d.lnl = s->g_lnl.p; d.ntasks = s->nloci; d.npatterns = s->g_npat; d.nmat = e->pack_slots*s->g_maxmat;
@@ -203,6 +222,8 @@ static int gs_initialize(bpa_sampler * s)
 static int gs_iterate(bpa_sampler * s, unsigned iterations)
 {
   bpa_engine * e = s->eng;
+  if (!gs_subst_ready(s)) return 0;
+  s->host_current = false;
   for (unsigned it = 0; it < iterations; ++it)
   {
     // the per-locus proposals, "step j of every locus" (gage_step / gspr_step of a00_driver.c): each launch first settles
@@ -260,6 +281,9 @@ static int gs_download(bpa_sampler * s)
 {
   bpa_engine * e = s->eng;
   if (!gs_step(s, 4)) return 0;
+  // the settle launch rolls rejected frequency / exchangeability proposals back in the parameter blocks: the loci's
+  // eigensystems must follow before anyone else (bpa_batch_evaluate, a plan) computes P-matrices from them
+  if (!gs_refresh_eigen(s)) return 0;
   HIPCHK(hipMemcpyAsync(s->g_trees.data(), s->g_dev.p, s->nloci*sizeof(gsm::GTree), hipMemcpyDeviceToHost, e->stream));
   if (s->g_sm.p && !s->g_sm_host.empty())
     HIPCHK(hipMemcpyAsync(s->g_sm_host.data(), s->g_sm.p, s->g_sm_host.size()*sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -274,9 +298,10 @@ extern "C" int bpa_sampler_set_subst_model(bpa_sampler_t * s, unsigned i, const 
   if (i >= s->nloci || !freqs || !qrates || !(alpha > 0)) return fail("bpa_sampler_set_subst_model: bad argument");
   if (!s->generic) return fail("bpa_sampler_set_subst_model: the loci are JC69 (no substitution parameters to move)");
   if (s->g_sm_host.size() != (size_t)s->nloci*11) s->g_sm_host.assign((size_t)s->nloci*11, 0.0);
+  if (s->uploaded)
+    return fail("bpa_sampler_set_subst_model: the sampler is running — set every locus's starting values before bpa_sampler_initialize");
   double * m = s->g_sm_host.data() + (size_t)i*11;
   std::copy(freqs, freqs + 4, m); std::copy(qrates, qrates + 6, m + 4); m[10] = alpha;
-  s->uploaded = false;
   return 1;
 }
 
@@ -284,7 +309,7 @@ extern "C" int bpa_sampler_get_subst_model(bpa_sampler_t * s, unsigned i, double
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (i >= s->nloci || s->g_sm_host.size() != (size_t)s->nloci*11) return fail("bpa_sampler_get_subst_model: no substitution model set");
-  if (i == 0 && s->uploaded && !sampler_download(s)) return 0;          // refreshed when locus 0 is asked for
+  if (s->uploaded && !s->host_current && !sampler_download(s)) return 0;
   const double * m = s->g_sm_host.data() + (size_t)i*11;
   if (freqs) std::copy(m, m + 4, freqs);
   if (qrates) std::copy(m + 4, m + 10, qrates);
@@ -295,6 +320,6 @@ extern "C" int bpa_sampler_get_subst_model(bpa_sampler_t * s, unsigned i, double
 extern "C" void bpa_sampler_set_subst_moves(bpa_sampler_t * s, double ft_freqs, double ft_qrates, double ft_alpha, double alpha_a, double alpha_b)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  // (nothing to upload: the widths travel with every launch, the moves' tables are made when first needed — gs_subst_ready)
   s->g_ft[0] = ft_freqs; s->g_ft[1] = ft_qrates; s->g_ft[2] = ft_alpha; s->g_alpha_a = alpha_a; s->g_alpha_b = alpha_b;
-  s->uploaded = false;
 }

@@ -1156,6 +1156,8 @@ struct bpa_sampler
   a00_rng_t grng = 0;
   unsigned long seed = 0, launches = 0, sweeps = 0;
   bool uploaded = false;
+  uint32_t h_counters[2] = {0, 0};      // all-loci proposals / accepted at the last invalidation (re-uploaded)
+  bool host_current = false;            // the host copies (h_trees / g_trees, g_sm_host) hold the device's state: set by a download, cleared by iterate
   // ---- the persistent iteration kernel (sweep2.hpp): one GPU, loci that fit the sweep kernel, root = the last node
   bool v2_ok = false, env_v1 = false;
   int v2_nt = 0;                        // its instance: 4 or 8 tips
@@ -1237,6 +1239,23 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   delete s;
 }
 
+// A setter that makes the next call upload the host copies again (a new tree, species tree, tip assignment, stream
+// offset) first brings them level with the device: trees with their random streams and counters, taus and thetas, the
+// all-loci counters — a run that is reconfigured half-way continues from where it was, not from the last download
+static int sampler_download(bpa_sampler * s);
+static int sampler_invalidate(bpa_sampler * s)
+{
+  if (s->uploaded)
+  {
+    bpa_engine * e = s->eng;
+    if (!set_device(e) || !sampler_download(s)) return 0;
+    HIPCHK(hipMemcpy(s->h_taus.data(), s->taus.p, s->h_taus.size()*sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(s->h_counters, s->counters.p, sizeof s->h_counters, hipMemcpyDeviceToHost));
+  }
+  s->uploaded = false; s->host_current = false;
+  return 1;
+}
+
 template <class TR, int MAXNODES>
 static int set_tree_fields(TR & t, int tips, const int * left, const int * right, const double * times, int root, a00_rng_t rng)
 {
@@ -1260,7 +1279,7 @@ extern "C" int bpa_sampler_set_tree(bpa_sampler_t * s, unsigned i, const int * l
   if (i >= s->nloci) return fail("bpa_sampler_set_tree: locus index out of range");
   const int tips = (int)s->loci[i]->tips;
   const a00_rng_t rng = a00_rng_seed(s->seed, s->locus_offset + i);
-  s->uploaded = false;
+  if (!sampler_invalidate(s)) return 0;
   if (s->generic) return set_tree_fields<gsm::GTree, gsm::NN>(s->g_trees[i], tips, left, right, times, root, rng);
   return set_tree_fields<smp::Tree, smp::MAXN>(s->h_trees[i], tips, left, right, times, root, rng);
 }
@@ -1418,7 +1437,7 @@ static int sampler_upload(bpa_sampler * s)
   if (!upload(s->blk_task_off, blk_off.data(), blk_off.size()) ||
       !upload(s->lane_rec, lane_rec.data(), lane_rec.size()) || !upload(s->task_rec, task_rec.data(), T) ||
       !upload(s->trees, s->h_trees.data(), T) || !upload(s->snap, s->h_trees.data(), T) ||
-      !upload(s->flag, zero2, 1) || !upload(s->counters, zero2, 2) || !s->mix_delta.reserve(T) || !s->mix_sum.reserve(1) ||
+      !upload(s->flag, zero2, 1) || !upload(s->counters, s->h_counters, 2) || !s->mix_delta.reserve(T) || !s->mix_sum.reserve(1) ||
       !upload(s->taus, s->h_taus.data(), s->h_taus.size()) || !s->pop_t2h.reserve((size_t)T*smp::MAXPOP) ||
       !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP) || !s->lograt.reserve(smp::MAXN*smp::MAXN))
     return 0;
@@ -1540,6 +1559,7 @@ extern "C" int bpa_sampler_set_species_tree(bpa_sampler_t * s, int species, cons
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   const int np = 2*species - 1;
   if (species < 1 || species > smp::MAXTIPS) return fail("bpa_sampler_set_species_tree: 1..8 species");
+  if (!sampler_invalidate(s)) return 0;           // (the trees keep their state; taus and thetas are replaced below)
   smp::Species & sp = s->sp;
   for (int p = 0; p < np; ++p)
   {
@@ -1567,7 +1587,7 @@ extern "C" int bpa_sampler_set_species_tree(bpa_sampler_t * s, int species, cons
   }
   for (int p = species; p < np; ++p) if (sp.right[p] < 0) return fail("bpa_sampler_set_species_tree: an inner population needs two children");
   for (int p = 0; p < np; ++p) for (int q = p; q >= 0; q = parent[q]) sp.anc[p] |= (uint16_t)(1u << q);
-  s->uploaded = false;
+  s->uploaded = false; s->host_current = false;
   return 1;
 }
 
@@ -1575,7 +1595,7 @@ extern "C" int bpa_sampler_set_tip_species(bpa_sampler_t * s, unsigned i, const 
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (i >= s->nloci) return fail("bpa_sampler_set_tip_species: locus index out of range");
-  s->uploaded = false;
+  if (!sampler_invalidate(s)) return 0;
   if (s->generic)
   {
     gsm::GTree & t = s->g_trees[i];
@@ -1626,6 +1646,7 @@ extern "C" int bpa_sampler_initialize(bpa_sampler_t * s)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (!sampler_upload(s)) return 0;
+  s->host_current = false;
   if (s->generic) return gs_initialize(s);
   return sampler_launch(s, 3, 1.0);
 }
@@ -1668,6 +1689,7 @@ extern "C" int bpa_sampler_set_allreduce(bpa_sampler_t * s, bpa_allreduce_fn fn,
   s->allreduce = fn; s->allreduce_ctx = ctx; s->sum_ext = device_sum;
   if (first_locus != s->locus_offset)
   {
+    if (!sampler_invalidate(s)) return 0;
     s->locus_offset = first_locus;
     for (unsigned i = 0; i < s->nloci; ++i)
       (s->generic ? s->g_trees[i].rng : s->h_trees[i].rng) = a00_rng_seed(s->seed, first_locus + i);
@@ -1730,6 +1752,7 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
   bpa_engine * e = s->eng;
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   if (!sampler_upload(s)) return 0;
+  s->host_current = false;
   if (s->generic) return gs_iterate(s, iterations);
   if (s->v2_ok && !s->allreduce && !s->env_trace) return sampler_iterate_v2(s, iterations);
   const bool fused = s->fuse_decision && !s->allreduce && !s->env_trace;      // (several GPUs: sum -> all-reduce -> decide)
@@ -1797,7 +1820,8 @@ static int sampler_download(bpa_sampler * s)
 {
   bpa_engine * e = s->eng;
   if (!sampler_upload(s)) return 0;
-  if (s->generic) return gs_download(s);
+  if (s->host_current) return 1;                  // nothing has run since the last download
+  if (s->generic) { if (!gs_download(s)) return 0; s->host_current = true; return 1; }
   if (!sampler_launch(s, 2, 1.0)) return 0;
   HIPCHK(hipMemcpyAsync(s->h_trees.data(), s->trees.p, s->nloci*sizeof(smp::Tree), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1829,6 +1853,7 @@ static int sampler_download(bpa_sampler * s)
     HIPCHK(hipMemcpy(&err, s->v2_err.p, sizeof err, hipMemcpyDeviceToHost));
     if (err) return fail("bpa_sampler: the persistent iteration kernel timed out waiting for a workgroup's sum (is the device shared? BPA_SMP_V1=1 selects one launch per step)");
   }
+  s->host_current = true;
   return 1;
 }
 
@@ -1837,7 +1862,7 @@ extern "C" int bpa_sampler_get_tree(bpa_sampler_t * s, unsigned i, int * left, i
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (i >= s->nloci) return fail("bpa_sampler_get_tree: locus index out of range");
-  if (i == 0 || !s->uploaded) { if (!sampler_download(s)) return 0; }      // refreshed when locus 0 is asked for
+  if (!sampler_download(s)) return 0;                   // (a no-op while the host copy is current)
   auto out = [&](const auto & t)
   {
     const int n = 2*t.tips - 1;
@@ -1857,7 +1882,7 @@ extern "C" int bpa_sampler_get_tree_msc(bpa_sampler_t * s, unsigned i, int * pop
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (i >= s->nloci) return fail("bpa_sampler_get_tree_msc: locus index out of range");
-  if (i == 0 || !s->uploaded) { if (!sampler_download(s)) return 0; }
+  if (!sampler_download(s)) return 0;
   auto out = [&](const auto & t)
   {
     if (pop) for (int k = 0; k < 2*t.tips - 1; ++k) pop[k] = t.pop[k];

@@ -429,3 +429,30 @@ double locus_root_loglikelihood(locus_t * locus, gnode_t * root, const unsigned 
     fatal("[bpp_hip] %s", bpa_last_error());
   return logl;
 }
+
+/* ------------------------------------------------ pll_core_update_pmatrix (bpp.h:2349) --
+ * The library form of the eigen P-matrix update (core_pmatrix.c:785-872): explicit arrays, no locus_t.  Its one
+ * caller in the program is the sequence simulator (evolve_gtr_recursive, simulate.c:694-705: one 4x4 matrix per
+ * branch and site rate).  The reference's definition is made WEAK in core_pmatrix.o (oracle/Makefile); this one
+ * forwards to the device (bpa_core_update_pmatrix: expm1(lambda rate t) per eigenvalue, inv_eigenvecs x diag x
+ * eigenvecs in the reference's order, identity for a zero length), so `bpp_hip --simulate` draws its GTR sequences
+ * from P-matrices made on the MI355X.  One launch + one synchronisation per call: the parity path, not a fast one.  */
+int pll_core_update_pmatrix(double ** pmatrix,
+                            unsigned int states,
+                            unsigned int rate_cats,
+                            const double * rates,
+                            const double * branch_lengths,
+                            const unsigned int * matrix_indices,
+                            const unsigned int * param_indices,
+                            double * const * eigenvals,
+                            double * const * eigenvecs,
+                            double * const * inv_eigenvecs,
+                            unsigned int count,
+                            unsigned int attrib)
+{
+  pthread_once(&engine_once, engine_init);
+  if (!bpa_core_update_pmatrix(engine, pmatrix, states, rate_cats, rates, branch_lengths, matrix_indices,
+                               param_indices, eigenvals, eigenvecs, inv_eigenvecs, count, attrib))
+    fatal("[bpp_hip] pll_core_update_pmatrix: %s", bpa_last_error());
+  return BPP_SUCCESS;
+}

@@ -137,14 +137,16 @@ def run_program(binary, ctl_text, files, timeout=900, env=None):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def simulate(ctl_text, timeout=600):
-    """the reference's own simulator (`bpp --simulate`): returns {file name: text} of the alignment and the Imap"""
+def simulate(ctl_text, timeout=600, binary=None):
+    """the reference's own simulator (`bpp --simulate`; binary = HIP_BIN: the same simulator with its P-matrices made by
+    the library): returns {file name: text} of the alignment and the Imap (+ the model-parameter file if one is written)"""
     d = tempfile.mkdtemp(prefix="bppsim_")
     try:
         open(os.path.join(d, "sim.ctl"), "w").write(ctl_text)
-        subprocess.run([REF_BIN, "--simulate", "sim.ctl"], cwd=d, check=True, stdout=subprocess.DEVNULL,
+        subprocess.run([binary or REF_BIN, "--simulate", "sim.ctl"], cwd=d, check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL, timeout=timeout)
-        return {fn: open(os.path.join(d, fn)).read() for fn in ("syn.txt", "syn.Imap.txt")}
+        return {fn: open(os.path.join(d, fn)).read() for fn in ("syn.txt", "syn.Imap.txt", "syn.para.txt")
+                if os.path.exists(os.path.join(d, fn))}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

@@ -10,7 +10,8 @@ import bpphip as B
 pytestmark = pytest.mark.skipif(not B.have_binaries(), reason="oracle/_ref/bpp{,_hip} not built (needs /root/reference)")
 
 API = ["locus_update_matrices", "locus_update_all_matrices", "locus_update_partials", "locus_update_all_partials",
-       "locus_root_loglikelihood", "locus_create", "locus_destroy", "pll_set_tip_states", "pll_set_pattern_weights"]
+       "locus_root_loglikelihood", "locus_create", "locus_destroy", "pll_set_tip_states", "pll_set_pattern_weights",
+       "pll_core_update_pmatrix"]
 
 
 def test_symbols_resolve_to_the_shim():
@@ -24,11 +25,15 @@ def test_symbols_resolve_to_the_shim():
         assert s in sym and sym[s][1] == "T", s            # one strong definition: the shim's
     for s in ("locus_create", "locus_destroy", "pll_set_tip_states", "pll_set_pattern_weights"):
         assert "bppref_" + s in sym                           # the reference's host-side originals
-    for s in ("bpa_locus_create", "bpa_locus_update_matrices", "bpa_locus_update_partials", "bpa_locus_root_loglikelihood"):
+    for s in ("bpa_locus_create", "bpa_locus_update_matrices", "bpa_locus_update_partials", "bpa_locus_root_loglikelihood",
+              "bpa_core_update_pmatrix"):
         assert f" U {s}" in nm                                # bound to libbpp_amd.so
     # the reference's own locus.o code lies between its renamed functions; the shim's definitions come after it
     lo = min(sym["bppref_locus_create"][0], sym["bppref_pll_set_pattern_weights"][0])
     assert all(sym[s][0] > lo for s in API)
+    # the simulator's call of the library form (simulate.c:694) goes to the shim as well
+    assert any("call" in ln and "<pll_core_update_pmatrix>" in ln for ln in subprocess.run(
+        ["objdump", "-d", "--no-show-raw-insn", B.HIP_BIN], check=True, stdout=subprocess.PIPE, text=True).stdout.splitlines())
     # calls inside locus.c (its substitution-parameter proposals) go to the shim too: the weakened originals are gone
     dis = subprocess.run(["objdump", "-d", "--no-show-raw-insn", B.HIP_BIN], check=True, stdout=subprocess.PIPE, text=True).stdout
     callers = [ln for ln in dis.splitlines() if "call" in ln and "<locus_update_partials>" in ln]

@@ -76,6 +76,20 @@ def test_synthetic_gtr_gamma():
     check(res)
 
 
+def test_simulator_runs_pll_core_update_pmatrix_on_the_device():
+    """`--simulate` with GTR + Gamma site rates draws every branch's sequence from a P-matrix made by
+    pll_core_update_pmatrix (simulate.c:694-705, one call per branch and site rate): in bpp_hip that is the shim's
+    definition -> bpa_core_update_pmatrix on the GPU.  Same seed: the two programs write the same alignment, byte for
+    byte, and the same model-parameter file"""
+    ctl = B.SIM_CTL.format(seed=11, species=B.SPECIES4_SIM, phase="0 0 0 0", nloci=6, sites=120, simmodel=7,
+                           extra="alpha_siterate = 1 0.5 4\nqrates = 1 1 2 1 0.5 1.5 1\nbasefreqs = 1 0.3 0.2 0.2 0.3\nmodelparafile = syn.para.txt\n")
+    cpu = B.simulate(ctl)
+    gpu = B.simulate(ctl, binary=B.HIP_BIN)
+    assert cpu["syn.txt"] == gpu["syn.txt"] and len(cpu["syn.txt"]) > 6 * 4 * 120
+    assert cpu.get("syn.para.txt") == gpu.get("syn.para.txt")
+    assert len(set(cpu["syn.txt"].split()[3])) > 1         # (sequences evolved, not constant)
+
+
 def test_threads_2():
     """threads.c shards the loci over pthreads: calls for different loci arrive concurrently"""
     files = B.simulate(B.SIM_CTL.format(seed=3, species=B.SPECIES4_SIM, phase="0 0 0 0", nloci=64, sites=400, simmodel=0, extra=""))

@@ -153,3 +153,45 @@ def test_generic_sampler_with_parameter_moves_equals_host_driver():
         full = ol.full_lnl(list(t["left"]), list(t["right"]), list(t["time"]), t["root"])
         assert rel(t["lnl"], full) < 1e-10
     dev.close(); host.close(); eng.close()
+
+
+def test_window_widths_change_in_mid_run():
+    """BPP adjusts its step lengths during the burn-in: switching the substitution-parameter moves on after two
+    iterations and changing their widths after two more must not touch the chain's state (trees, streams, counters,
+    taus, thetas, parameters) — the device sampler keeps walking the host driver's trajectory.  Also: any locus's
+    parameters can be asked for first (not only locus 0's) and are current"""
+    taxa, R, nloci = 8, 4, 30
+    eng = bpp_amd.Engine(0)
+    data = synth.make_dataset(nloci, 300, taxa, "gtr", R, seed=41)
+    loci_a = tape.make_engine_loci(eng, data)
+    loci_b = tape.make_engine_loci(eng, data)
+    host = hostdrv.hip_driver(eng, loci_a, data, seed=37)
+    dev = bpp_amd.Sampler(eng, loci_b, data, seed=37)
+    parent, tau0, thetas = synth.species_tree_arrays(taxa)
+    for drv in (host, dev):
+        drv.set_species_tree(parent, tau0, thetas)
+        drv.set_tau_prior(3.0, 3.0 / tau0[-1])
+        drv.set_theta_prior(2.0, 1000.0, 0.001)
+        drv.set_finetune(0.003, 0.005, 0.0008, 0.2)
+    for i, d in enumerate(data):
+        host.set_subst_model(i, list(d["freqs"]), list(d["exch"]), 0.5, R)
+        dev.set_subst_model(i, d["freqs"], d["exch"], 0.5)
+    host.initialize(); dev.initialize()
+    for phase, widths in enumerate([None, (0.3, 0.4, 0.8), (0.1, 0.2, 0.3)]):
+        if widths:
+            host.set_subst_moves(*widths, 1.0, 1.0); dev.set_subst_moves(*widths, 1.0, 1.0)
+        for it in range(2):
+            host.iterate(); dev.iterate(1)
+            s = dev.summary()
+            hp, ha, _ = host.counters()
+            assert (s["proposals"], s["accepted"]) == (hp, ha), (phase, it)
+            assert rel(s["total_lnl"], host.total_lnl()) < 1e-10, (phase, it)
+        # a locus other than 0 first
+        fh, qh, ah = host.get_subst_model(nloci - 1)
+        fd, qd, ad = dev.get_subst_model(nloci - 1)
+        assert np.allclose(fd, fh, rtol=1e-11, atol=0) and np.allclose(qd, qh, rtol=1e-11, atol=0) and rel(ad, ah) < 1e-11, phase
+    assert np.allclose(dev.taus(), host.taus(), rtol=1e-12, atol=0) and np.allclose(dev.thetas(), host.thetas(), rtol=1e-12, atol=0)
+    assert any(host.get_subst_model(i)[2] != 0.5 for i in range(nloci))
+    with pytest.raises(bpp_amd.BpaError):
+        dev.set_subst_model(0, data[0]["freqs"], data[0]["exch"], 0.7)          # not while the sampler runs
+    dev.close(); host.close(); eng.close()
