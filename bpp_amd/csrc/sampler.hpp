@@ -1700,15 +1700,15 @@ extern "C" int bpa_sampler_set_allreduce(bpa_sampler_t * s, bpa_allreduce_fn fn,
 
 // the whole iteration(s) as persistent launches: GAGE + GSPR of every locus, THETA, TAU per divergence, MIX — state in
 // LDS from the first proposal to the last decision (sweep2.hpp)
-static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations)
+// in_kernel_allloci = false (several ranks): only the per-locus sweep of ONE iteration; the all-loci steps then run as
+// launches of sampler.hpp's kernels with the sums all-reduced in between
+static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kernel_allloci)
 {
   bpa_engine * e = s->eng;
-  // anything the one-launch-per-step path left pending is settled first (decision of an all-loci step, stale densities)
-  if ((s->mix_pending || s->logpr_stale) && !sampler_launch(s, 2, 1.0, 0.0, 0, 0.0, -1.0)) return 0;
   const int npop = s->sp.npop, S = s->sp.S;
   uint32_t theta_mask = 0;
   if (s->sp.theta_alpha > 0) for (int p = 0; p < npop; ++p) if (s->has_theta[p]) theta_mask |= 1u << p;
-  const bool allloci = !s->env_nomix;
+  const bool allloci = in_kernel_allloci && !s->env_nomix;
   const unsigned draws_per_iter = allloci ? 2u*(unsigned)__builtin_popcount(theta_mask) + 2u*(unsigned)(npop - S) + 2u : 0u;
   void (*kern)(const smp2::Args) = s->v2_nt == 4 ? smp2::iter_kernel<4> : smp2::iter_kernel<8>;
   const unsigned bs = s->v2_nt == 4 ? smp2::Cfg<4>::BS : smp2::Cfg<8>::BS;
@@ -1717,6 +1717,9 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations)
     const unsigned chunk = std::min(iterations, 4096u);          // (bounds one launch's duration)
     smp2::Args a{};
     a.wave_off = s->v2_wave_off.p; a.loc = s->v2_loc.p; a.pat = s->v2_pat.p; a.trees = s->trees.p; a.taus = s->taus.p;
+    // what the one-launch-per-step path left pending is settled while this launch loads (Args::snap ...)
+    a.snap = s->snap.p; a.mix_flag = s->flag.p; a.epoch = s->mix_pending ? s->epoch : 0u; a.refresh_logpr = s->logpr_stale ? 1u : 0u;
+    s->mix_pending = false; s->logpr_stale = false;
     a.counters = s->counters.p; a.lograt = s->lograt.p; a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p;
     a.ntasks = s->nloci; a.nwaves = s->v2_nwaves; a.nwg = s->v2_nwg; a.xbuf = s->v2_xbuf.p;
     a.err = s->v2_err.p; a.grng = s->v2_grng.p; a.niter = chunk;
@@ -1754,12 +1757,18 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
   if (!sampler_upload(s)) return 0;
   s->host_current = false;
   if (s->generic) return gs_iterate(s, iterations);
-  if (s->v2_ok && !s->allreduce && !s->env_trace) return sampler_iterate_v2(s, iterations);
+  if (s->v2_ok && !s->allreduce && !s->env_trace) return sampler_iterate_v2(s, iterations, true);
+  // several ranks: the per-locus sweep by the persistent kernel (one launch), the all-loci steps one launch each
+  const bool v2_sweep = s->v2_ok && !s->env_trace;
   const bool fused = s->fuse_decision && !s->allreduce && !s->env_trace;      // (several GPUs: sum -> all-reduce -> decide)
   for (unsigned it = 0; it < iterations; ++it)
   {
-    if (!sampler_launch(s, 0, 1.0)) return 0;                    // GAGE + GSPR of every locus (settles a pending mix first)
-    s->sweeps++;
+    if (v2_sweep) { if (!sampler_iterate_v2(s, 1, false)) return 0; }
+    else
+    {
+      if (!sampler_launch(s, 0, 1.0)) return 0;                  // GAGE + GSPR of every locus (settles a pending mix first)
+      s->sweeps++;
+    }
     if (s->env_nomix) continue;
     if (s->sp.theta_alpha > 0)
     {
@@ -1944,7 +1953,7 @@ extern "C" int bpa_sampler_kind(bpa_sampler_t * s)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (!sampler_upload(s)) return -1;
-  return s->generic ? BPA_SAMPLER_GENERIC : (s->v2_ok && !s->allreduce && !s->env_trace) ? BPA_SAMPLER_PERSISTENT : BPA_SAMPLER_SWEEP;
+  return s->generic ? BPA_SAMPLER_GENERIC : (s->v2_ok && !s->allreduce && !s->env_trace) ? BPA_SAMPLER_PERSISTENT : BPA_SAMPLER_SWEEP;      // (several ranks: the sweep launches are the persistent kernel's, the all-loci steps sampler.hpp's)
 }
 
 extern "C" int bpa_sampler_summary(bpa_sampler_t * s, double * total_lnl, unsigned long * proposals,

@@ -62,6 +62,10 @@ struct Args
   const Loc * loc;
   const uint2 * pat;                     // per pattern: weight, tip codes (4 bits per tip)
   Tree * trees;
+  // what the one-launch-per-step path (sampler.hpp) may have left pending when this launch starts (several ranks: its
+  // all-loci steps alternate with this kernel's sweeps): the decision of an all-loci step, applied here as there — a
+  // rejected step's trees come from the pre-step snapshot — and thetas that moved after the trees' densities were stored
+  const Tree * snap; const uint32_t * mix_flag; uint32_t epoch, refresh_logpr;
   double * taus;                         // [3 MAXPOP] tau | theta | log(2/theta): read at entry, written back by workgroup 0
   uint32_t * counters;                   // all-loci proposals / accepted
   const double * lograt;
@@ -358,7 +362,14 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   if (act && nt)
   {
     const Loc & L = A.loc[task];
-    const Tree & tr = A.trees[task];
+    // (an explicit load and pointer: as `restore ? A.snap[task] : A.trees[task]` bound to a reference the selection
+    //  came out as "epoch != 0" alone — trees of an ACCEPTED step were taken from the snapshot)
+    const uint32_t flag_now = __hip_atomic_load(A.mix_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool restore_mix = A.epoch != 0u && flag_now == A.epoch;
+    const Tree * trp = A.trees + task;
+    if (restore_mix) trp = A.snap + task;
+    const Tree & tr = *trp;
+    const Tree & cur = A.trees[task];               // (streams and counters survive a rejected all-loci step)
     np = L.np;
     double * g_pmat = L.pmat;
     if (li == 0) { S.rate = L.rate; S.rw = L.rw; S.f[0] = L.f0; S.f[1] = L.f1; S.f[2] = L.f2; S.f[3] = L.f3; }
@@ -368,7 +379,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       T.left.w[k] = reinterpret_cast<const uint32_t *>(tr.left)[k]; T.right.w[k] = reinterpret_cast<const uint32_t *>(tr.right)[k];
       T.parent.w[k] = reinterpret_cast<const uint32_t *>(tr.parent)[k]; T.pop.w[k] = reinterpret_cast<const uint32_t *>(tr.pop)[k];
     }
-    T.root = tr.root; T.tips = tr.tips; rng = tr.rng; lnl_cur = tr.lnl; logpr_cur = tr.logpr;
+    T.root = tr.root; T.tips = tr.tips; rng = cur.rng; lnl_cur = tr.lnl; logpr_cur = tr.logpr;
     const int n = 2*T.tips - 1;
     T.cf = gballot<G>(li >= T.tips && li < n && tr.clv[li] != li, gbase);
     T.pf = gballot<G>(li < n && tr.pmat[li] != li, gbase);
@@ -553,6 +564,12 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     if (li < npop) density_term(tk);
     commit_density(allpop);
     wsync();
+    if (A.refresh_logpr)
+    {
+      double lp = 0;
+      for (int p = 0; p < npop; ++p) lp += S.contrib[p];
+      logpr_cur = lp;
+    }
   }
 
   const bool prof_on = (A.dbg & 16u) && b == 0 && tid == 0;

@@ -104,6 +104,40 @@ def test_persistent_kernel_equals_one_launch_per_step(taxa, nloci, iters, monkey
     new.close(); old.close(); eng.close()
 
 
+def test_sweeps_of_the_persistent_kernel_between_one_launch_all_loci_steps(monkeypatch):
+    """several ranks: an all-reduce callback is installed, so the all-loci steps run one launch each (their sums go
+    through the callback) while the per-locus sweep is the persistent kernel's — which then applies the pending decision
+    of the previous iteration's last step while it loads (rejected: the trees come from the pre-step snapshot).  One rank
+    with an identity callback, several iterations per call (no download in between): the one-launch-per-step trajectory"""
+    eng = bpp_amd.Engine(0)
+    data = synth.make_dataset(400, 400, 4, "jc69", 1, seed=3)
+
+    def make(v1):
+        if v1:
+            monkeypatch.setenv("BPA_SMP_V1", "1")
+        else:
+            monkeypatch.delenv("BPA_SMP_V1", raising=False)
+        smp = bpp_amd.Sampler(eng, tape.make_engine_loci(eng, data), data, seed=7)
+        smp.set_allreduce(lambda p, n, st: True, None, 0)          # (the sums stay in the sampler's own device memory)
+        parent, tau0, thetas = synth.species_tree_arrays(4)
+        smp.set_species_tree(parent, tau0, thetas)
+        smp.set_tau_prior(3.0, 1000.0); smp.set_theta_prior(2.0, 1000.0, 0.001); smp.set_finetune(0.003, 0.005, 0.0008, 0.2)
+        smp.initialize()
+        return smp
+    hyb, old = make(False), make(True)
+    for call in range(8):
+        hyb.iterate(3); old.iterate(3)
+        a, b = hyb.summary(), old.summary()
+        assert (a["proposals"], a["accepted"]) == (b["proposals"], b["accepted"]), call
+        assert hyb.taus() == old.taus() and hyb.thetas() == old.thetas(), call
+    for i in range(len(data)):
+        x, y = hyb.tree(i), old.tree(i)
+        for key in ("left", "right", "parent", "clv", "pmat", "pop", "time"):
+            assert list(x[key]) == list(y[key]), (i, key)
+        assert x["lnl"] == y["lnl"] and x["logpr"] == y["logpr"], i
+    hyb.close(); old.close(); eng.close()
+
+
 def test_several_sequences_per_species():
     """two species with three sequences each: tip populations hold coalescences (and a theta that moves),
     gene nodes cross the species boundary both ways; device == host driver, step for step"""
