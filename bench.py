@@ -283,9 +283,7 @@ def dominant_kernel(cfg, one_gpu=True):
     if cfg["model"] == "gtr":
         return "step_s4_klane_v2_kernel<256,false>"
     k = os.environ.get("BPA_S20_KERNEL", "pipe")
-    return {"pipe": "partials_lnl_pipe20_kernel<20,true,2>", "pipe2c": "partials_lnl_pipe20_kernel<20,false,2>",
-            "pipe3": "partials_lnl_pipe20_kernel<20,true,3>", "pipe3c": "partials_lnl_pipe20_kernel<20,false,3>",
-            "tiledk": "partials_lnl_tiledk_kernel<20,3>", "mfmak": "partials_lnl_mfma20k_kernel"}.get(k, f"20-state kernel `{k}`")
+    return {"pipe": "partials_lnl_pipe20_kernel<20,true,2>", "mfmak": "partials_lnl_mfma20k_kernel"}.get(k, f"20-state kernel `{k}`")
 
 
 def traffic_from_profiles(config, kernel):
@@ -328,6 +326,8 @@ class Dist:
         torch.cuda.set_stream(self.tstream)
         self.stream = self.tstream.cuda_stream
         self.p2p = None
+        self.tape_p2p = False          # --p2p-sums: the tape's exchanges over the p2p mailboxes too (default: RCCL)
+        self.sampler_exchange = None
 
     def max(self, x):
         t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
@@ -424,7 +424,7 @@ def run_tape(eng, cfg, config_key, data, loci, args, D, steps, warmup):
         cnt = D.torch.tensor([max(sum_parts)], dtype=D.torch.int64, device="cuda")
         D.dist.all_reduce(cnt, op=D.dist.ReduceOp.MAX)
         sum_view = sum_buf[:int(cnt.item())]
-    p2p = D.p2p if (D and sum_view is not None and sum_view.numel() <= 512) else None
+    p2p = D.p2p if (D and D.tape_p2p and sum_view is not None and sum_view.numel() <= 512) else None
 
     # parameter installs of the tape, resident in HBM: (which, device address) per step, applied through p_init
     # (which holds every locus) right before the step's launch
@@ -574,7 +574,32 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
             else:
                 D.dist.all_reduce(smp_sum[:count])
             return True
-        smp.set_allreduce(smp_allreduce, smp_sum.data_ptr(), first_locus)
+        # RCCL backend: the exchange as NATIVE code (libbpp_amd_rccl.so: ncclAllReduce on the engine's stream behind the
+        # library's callback type, its own communicator) — no Python runs inside bpa_sampler_iterate; the Python callback
+        # (torch.distributed / the p2p exchange) otherwise
+        native = None
+        use_p2p = D.p2p is not None and cfg["model"] == "jc69" and not os.environ.get("BENCH_PY_ALLREDUCE")
+        if use_p2p:
+            pass
+        elif D.p2p is None and os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" and not os.environ.get("BENCH_PY_ALLREDUCE"):
+            try:
+                uid = D.torch.zeros(128, dtype=D.torch.uint8, device=f"cuda:{D.local_rank}")
+                if D.rank == 0:
+                    uid.copy_(D.torch.tensor(list(bpp_amd.RcclExchange.unique_id()), dtype=D.torch.uint8))
+                D.dist.broadcast(uid, 0)
+                native = bpp_amd.RcclExchange(bytes(uid.cpu().tolist()), D.world, D.rank, D.local_rank)
+            except Exception as ex:       # noqa: BLE001
+                log(f"native RCCL exchange unavailable ({str(ex)[:120]}): torch.distributed instead")
+                native = None
+        if use_p2p:
+            smp.set_p2p(D.p2p, first_locus)
+        elif native is not None:
+            smp.set_allreduce_native(native, None, first_locus)
+        else:
+            smp.set_allreduce(smp_allreduce, smp_sum.data_ptr(), first_locus)
+        D.sampler_exchange = ("inside the persistent kernel, through the ranks' peer-mapped mailboxes over xGMI (bpa_sampler_set_p2p; self-tested against RCCL at start-up)" if use_p2p else
+                              "native RCCL (libbpp_amd_rccl.so: ncclAllReduce on the engine stream, no Python in the loop)" if native is not None else
+                              "p2p one-shot exchange kernel per step" if D.p2p is not None else "torch.distributed")
     sp_parent, sp_tau, sp_theta = synth.species_tree_arrays(cfg["taxa"])
     smp.set_species_tree(sp_parent, sp_tau, sp_theta)
     smp.set_tau_prior(3.0, 3.0 / sp_tau[-1])
@@ -614,18 +639,26 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
         sync()
         dt = time.perf_counter() - t0
         log(f"sampler ({kind}): {steps} steps x {ips} iterations in {dt:.3f} s; host enqueue {1e3 * enq / niter:.4f} ms/iteration of {1e3 * dt / niter:.4f} ms/iteration")
+        if D is not None and D.p2p is not None:
+            # a p2p exchange that timed out on ANY rank voids the run (checked before anything reads the sampler's state)
+            bad = D.torch.tensor([1 if D.p2p.status() != 0 else 0], dtype=D.torch.int64, device="cuda")
+            D.dist.all_reduce(bad, op=D.dist.ReduceOp.MAX)
+            if int(bad.item()) != 0:
+                log("p2p exchange timed out during the sampler section: repeating it over RCCL")
+                D.p2p = None
+                if use_p2p:
+                    # the exchange lived inside the kernel: a fresh sampler on the callback path
+                    try:
+                        smp.close()
+                    except Exception:       # noqa: BLE001
+                        pass
+                    return run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup)
+                continue
         tm = smp.timing()
         smp.enable_timing(0)
         l1 = smp.summary()["launches"]
         w1 = smp.work()
-        if D is None or D.p2p is None:
-            break
-        bad = D.torch.tensor([1 if D.p2p.status() != 0 else 0], dtype=D.torch.int64, device="cuda")
-        D.dist.all_reduce(bad, op=D.dist.ReduceOp.MAX)
-        if int(bad.item()) == 0:
-            break
-        log("p2p all-reduce timed out during the sampler section: repeating it over RCCL")
-        D.p2p = None
+        break
     if D is not None:
         dt = D.max(dt)
     total_loci = D.sum_int(nloci) if D else nloci
@@ -675,7 +708,9 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
         us = 1e3 * tm["sweep_ms"] / tm["sweep_launches"]
         achieved = bytes_per_sweep / (us * 1e-6) / 1e9
         traffic, src = traffic_from_profiles("c2", "sweep_kernel") if args.loci is None else (None, None)
-        roofline = dict(bound="hbm", kernel=f"smp::sweep_kernel<{4 if cfg['taxa'] <= 4 else 8}>", achieved=round(achieved, 2),
+        nt_ = 4 if cfg['taxa'] <= 4 else 8
+        roofline = dict(bound="hbm", kernel=(f"smp2::iter_kernel<{nt_}> (the per-locus sweep of one iteration per launch; the all-loci steps: smp::sweep_kernel<{nt_}>)"
+                                             if kind == "hybrid" else f"smp::sweep_kernel<{nt_}>"), achieved=round(achieved, 2),
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=src,
                         avg_kernel_us=round(us, 3), algorithmic_bytes_per_launch=round(bytes_per_sweep),
                         launches=tm["sweep_launches"],
@@ -698,6 +733,8 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
                                "tree moves + 3 frequency, 5 exchangeability and 1 alpha move per locus" if generic else
                                "persistent iteration kernel (csrc/sweep2.hpp): all iterations of a call in one launch, the loci's state in "
                                "LDS, a group of lanes per locus, all-loci decisions from device-scope fixed-point accumulators" if kind == "persistent" else
+                               "several ranks: the per-locus sweep of an iteration = one launch of the persistent kernel (csrc/sweep2.hpp), the "
+                               "all-loci steps one launch each (csrc/sampler.hpp) with the sums all-reduced in between" if kind == "hybrid" else
                                "LDS sweep kernel (csrc/sampler.hpp): all per-locus proposals of an iteration in one launch, one launch per all-loci step"),
                note="the A00 sampler (species tree fixed) resident on the device: population-aware GAGE+GSPR per locus, a THETA "
                     "step per population, a rubber-band TAU step per divergence and one MIX step per iteration, "
@@ -732,6 +769,9 @@ def main():
     ap.add_argument("--p2p-sums", action="store_true",
                     help="N > 1: exchange the sums with the one-shot p2p all-reduce over xGMI peer mappings (self-tested "
                          "against RCCL at start-up) instead of RCCL (torch.distributed), the default")
+    ap.add_argument("--no-p2p", action="store_true",
+                    help="N > 1: no peer-mapped mailboxes at all — the sampler then runs its all-loci steps one launch each with a "
+                         "native RCCL all-reduce in between (the persistent kernel only for the per-locus sweeps)")
     ap.add_argument("--sum-launch", action="store_true",
                     help="produce the total of an all-loci step with a launch of its own (default: per-workgroup partial sums written by the step kernel)")
     ap.add_argument("--event-stride", type=int, default=7,
@@ -776,8 +816,11 @@ def main():
     npat = sum(len(d["weights"]) for d in data)
     log(f"dataset: {nloci} loci on rank 0, {npat} patterns ({npat / nloci:.2f}/locus) in {time.time() - t0:.1f}s ({args.scaling})")
     loci = make_loci(eng, data)
-    if D is not None and args.p2p_sums:
+    if D is not None and not args.no_p2p:
+        # the mailboxes of the one-shot exchange over xGMI peer mappings (self-tested against RCCL on every rank): the
+        # device-resident sampler exchanges its sums through them INSIDE its persistent kernel; the tape only with --p2p-sums
         D.setup_p2p(eng, 256)
+        D.tape_p2p = bool(args.p2p_sums) and D.p2p is not None
 
     tape_sec = sampler_sec = None
     tape_steps = None
@@ -867,9 +910,9 @@ def main():
         parallelism = "1 GPU"
         if D is not None:
             parallelism = (f"loci sharded over {world} GPU(s) ({args.scaling}), " +
-                           ("one-shot p2p all-reduce over xGMI (RCCL-checked at start-up)" if D.p2p is not None else
-                            ("RCCL all-reduce" if os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" else "gloo all-reduce (test switch)")) +
-                           " of the sums the THETA / TAU / MIX steps are decided on")
+                           (("the sums of the THETA / TAU / MIX steps exchanged " + (D.sampler_exchange or "over RCCL")) if headline_sampler else
+                            ("one-shot p2p all-reduce over xGMI (RCCL-checked at start-up)" if D.tape_p2p else "RCCL all-reduce") +
+                            " of the sums the THETA / TAU / MIX steps are decided on"))
         if headline_sampler:
             value = sampler_sec["iterations_per_s_10k_loci"] if args.scaling == "weak" else sampler_sec["iterations_per_s"]
             ms_per_step = sampler_sec["ms_per_step"]
@@ -935,7 +978,10 @@ def main():
             "likelihood_only": tape_sec,
             "other_configs": others,
             "allreduce_check": tape_sec["allreduce_check"] if tape_sec else None,
-            "allreduce": (None if D is None else "p2p one-shot over xGMI peer mappings (bpa_p2p_*), self-tested against RCCL at start-up" if D.p2p is not None else "RCCL (torch.distributed)"),
+            "allreduce": (None if D is None else dict(
+                sampler=D.sampler_exchange,
+                tape=("p2p one-shot exchange kernel over xGMI peer mappings (bpa_p2p_*), self-tested against RCCL at start-up" if D.tape_p2p and D.p2p is not None
+                      else "RCCL (torch.distributed)" if os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" else "gloo (test switch)"))),
         }
     if D is not None and D.p2p is not None:
         D.p2p.close()

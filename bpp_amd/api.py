@@ -148,6 +148,7 @@ def lib():
         "bpa_sampler_timing": (i, [vp, dp, C.POINTER(C.c_ulong), dp, C.POINTER(C.c_ulong)]),
         "bpa_sampler_work": (i, [vp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
         "bpa_sampler_kind": (i, [vp]),
+        "bpa_sampler_set_p2p": (i, [vp, vp, u]),
         "bpa_engine_enable_timing": (None, [vp, i]),
         "bpa_engine_set_timing_stride": (None, [vp, u]),
         "bpa_engine_timing": (i, [vp, dp, dp, dp, C.POINTER(C.c_ulong)]),
@@ -182,7 +183,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_sampler_set_tau_prior", "bpa_sampler_get_taus", "bpa_sampler_get_tree_msc",
             "bpa_sampler_set_theta_prior", "bpa_sampler_get_thetas", "bpa_sampler_set_allreduce",
             "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary",
-            "bpa_sampler_enable_timing", "bpa_sampler_timing", "bpa_sampler_work", "bpa_sampler_kind",
+            "bpa_sampler_enable_timing", "bpa_sampler_timing", "bpa_sampler_work", "bpa_sampler_kind", "bpa_sampler_set_p2p",
             "bpa_sampler_set_subst_model", "bpa_sampler_get_subst_model", "bpa_sampler_set_subst_moves"]
 
 
@@ -588,6 +589,16 @@ class Sampler:
         _chk(lib().bpa_sampler_set_allreduce(self.h, C.cast(self._ar, C.c_void_p), None,
                                              C.c_void_p(device_sum_ptr), first_locus))
 
+    def set_allreduce_native(self, exchange, device_sum_ptr, first_locus):
+        """the all-reduce as native code: `exchange` is an RcclExchange (libbpp_amd_rccl.so) — no Python runs inside iterate"""
+        self._ar = exchange                       # (keeps the communicator alive)
+        _chk(lib().bpa_sampler_set_allreduce(self.h, exchange.callback, exchange.h, C.c_void_p(device_sum_ptr), first_locus))
+
+    def set_p2p(self, p2p, first_locus):
+        """several GPUs with the sums exchanged inside the persistent kernel over the mailboxes of a connected P2P (None: off)"""
+        self._p2p = p2p
+        _chk(lib().bpa_sampler_set_p2p(self.h, p2p.h if p2p is not None else None, first_locus))
+
     def taus(self):
         out = np.zeros(getattr(self, "_npop", 0))
         if len(out):
@@ -657,15 +668,64 @@ class Sampler:
         return dict(bytes=by.value, node_updates=nu.value, pattern_updates=pu.value, sweeps=sw.value)
 
     def kind(self):
-        """'sweep' (one launch per step), 'generic' or 'persistent' (the whole iteration(s) of a call as one launch)"""
+        """'sweep' (one launch per step), 'generic', 'persistent' (the whole iteration(s) of a call as one launch) or 'hybrid'
+        (several ranks: the persistent kernel's sweep + one launch per all-loci step)"""
         k = lib().bpa_sampler_kind(self.h)
         if k < 0:
             raise BpaError(_err())
-        return ("sweep", "generic", "persistent")[k]
+        return ("sweep", "generic", "persistent", "hybrid")[k]
 
     def close(self):
         if self.h and self.engine.h:
             lib().bpa_sampler_destroy(self.h)
+        self.h = None
+
+
+class RcclExchange:
+    """include/bpp_amd_rccl.h: a native RCCL communicator whose sum all-reduce is a bpa_allreduce_fn.  rank 0 makes the
+    id (RcclExchange.unique_id()), every rank gets its 128 bytes somehow and constructs with it (collective)."""
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbpp_amd_rccl.so")
+            if not os.path.exists(path):
+                raise BpaError("libbpp_amd_rccl.so is not built (python -m bpp_amd.build)")
+            L = C.CDLL(path)
+            L.bpa_rccl_unique_id.restype = C.c_int; L.bpa_rccl_unique_id.argtypes = [C.c_char_p]
+            L.bpa_rccl_create.restype = C.c_void_p; L.bpa_rccl_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+            L.bpa_rccl_destroy.restype = None; L.bpa_rccl_destroy.argtypes = [C.c_void_p]
+            L.bpa_rccl_allreduce_sum.restype = C.c_int; L.bpa_rccl_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
+            L.bpa_rccl_calls.restype = C.c_ulong; L.bpa_rccl_calls.argtypes = [C.c_void_p]
+            L.bpa_rccl_last_error.restype = C.c_char_p
+            cls._lib = L
+        return cls._lib
+
+    @classmethod
+    def unique_id(cls):
+        buf = C.create_string_buffer(128)
+        if not cls.lib().bpa_rccl_unique_id(buf):
+            raise BpaError(cls.lib().bpa_rccl_last_error().decode())
+        return buf.raw
+
+    def __init__(self, unique_id, nranks, rank, device):
+        L = self.lib()
+        self.h = L.bpa_rccl_create(C.c_char_p(bytes(unique_id)), nranks, rank, device)
+        if not self.h:
+            raise BpaError(L.bpa_rccl_last_error().decode())
+        self.callback = C.cast(L.bpa_rccl_allreduce, C.c_void_p)
+
+    def allreduce(self, device_ptr, count, stream=None):
+        if not self.lib().bpa_rccl_allreduce_sum(self.h, C.c_void_p(device_ptr), count, C.c_void_p(stream)):
+            raise BpaError(self.lib().bpa_rccl_last_error().decode())
+
+    def calls(self):
+        return self.lib().bpa_rccl_calls(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib().bpa_rccl_destroy(self.h)
         self.h = None
 
 

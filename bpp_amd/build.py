@@ -16,6 +16,8 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libbpp_amd.so")
 HOST_OUT = os.path.join(HERE, "libbpp_amd_host.so")      # host-side MCMC control in C (gcc), links libbpp_amd.so
 HOST_SRC = os.path.join(CSRC, "host", "a00_driver.c")
+RCCL_OUT = os.path.join(HERE, "libbpp_amd_rccl.so")      # the several-GPU exchange as native code (links librccl), a library of its own
+RCCL_SRC = os.path.join(CSRC, "rccl_exchange.c")
 SOURCES = ["engine.hip", "host_math.cpp", "host_input.cpp"]
 DEPS = ["kernels.hpp", "device_types.hpp", "sampler.hpp", "sweep2.hpp", "gsampler.hpp", "gsampler_host.hpp", "gamma_dev.hpp", "p2p.hpp", os.path.join(ROOT, "include", "bpp_amd.h"),
         os.path.join(ROOT, "include", "bpp_amd_host.h"), os.path.join(ROOT, "include", "bpp_amd_input.h")]
@@ -49,7 +51,21 @@ def build_host(force=False, verbose=False):
     return HOST_OUT
 
 
+def build_rccl(force=False, verbose=False):
+    deps = [RCCL_SRC, os.path.join(ROOT, "include", "bpp_amd_rccl.h")]
+    if not force and os.path.exists(RCCL_OUT) and all(os.path.getmtime(f) <= os.path.getmtime(RCCL_OUT) for f in deps):
+        return RCCL_OUT
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["gcc", "-O2", "-std=gnu99", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(rocm, "include"),
+           RCCL_SRC, "-o", RCCL_OUT, "-L", os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return RCCL_OUT
+
+
 def build(force=False, verbose=False):
+    build_rccl(force, verbose)
     if not force and not stale():
         build_host(False, verbose)
         return OUT

@@ -169,7 +169,7 @@ struct bpa_plan
   DevBuf<uint32_t> tile_task, tile_n0;
   DevBuf<unsigned long long> dbg;
   unsigned ntiles = 0, tile = 128;    // tiled 20-state path
-  bool s20_mfma = false, s20_scalarp = false, s20_tiledk = true;
+  bool s20_tiledk = true;               // a workgroup = 64 patterns x R categories (pipe, mfmak)
   std::string s20_kernel;
   bool fused_klane = false;
   DevBuf<MatRec>   mat_recs;
@@ -755,22 +755,18 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
 
   // tiled path (20 states): one workgroup per 128-pattern tile of one locus
   p->ntiles = 0; d.tile_task = d.tile_n0 = nullptr;
-  // 20-state partials kernel (kernels.hpp): default = the pipelined kernel (partials_lnl_pipe20_kernel: P-matrices
-  // global -> LDS direct and double-buffered, one wave per rate category, CLV planes streamed, 2 waves per SIMD);
-  // BPA_S20_KERNEL selects the others for A/B timing:
-  //   pipe2c / pipe3 / pipe3c (cached CLV accesses / 3 waves per SIMD) | tiledk (round 1's default) | tiled (first
-  //   version, one wave runs all categories) | mfma (first MFMA version) | mfmak (MFMA, wave per category) |
-  //   scalarp / scalark (P through the scalar path) | generic (no staging)
+  // 20-state partials kernel (kernels.hpp): the pipelined kernel (partials_lnl_pipe20_kernel: P-matrices global -> LDS
+  // direct and double-buffered, one wave per rate category, CLV planes streamed, 2 waves per SIMD).  BPA_S20_KERNEL
+  // selects the others, kept for comparison and as fall-backs: mfmak (the same update on the matrix cores, wave per
+  // category) | tiled (one wave runs all categories: what loci of more than 4 categories get) | generic (no staging)
   {
     const char * v = getenv("BPA_S20_KERNEL");
     p->s20_kernel = v ? v : "pipe";
+    if (p->s20_kernel != "pipe" && p->s20_kernel != "mfmak" && p->s20_kernel != "tiled" && p->s20_kernel != "generic") p->s20_kernel = "pipe";
   }
-  p->s20_mfma = p->s20_kernel == "mfma";
-  p->s20_scalarp = p->s20_kernel == "scalarp";
-  p->s20_tiledk = p->s20_kernel.compare(0, 4, "pipe") == 0 || p->s20_kernel == "tiledk" || p->s20_kernel == "mfmak" || p->s20_kernel == "scalark" || p->s20_kernel == "tiledk1" || p->s20_kernel == "tiledkb" || p->s20_kernel == "tiledk2" || p->s20_kernel == "tiledknt";
+  p->s20_tiledk = p->s20_kernel == "pipe" || p->s20_kernel == "mfmak";
   if (p->s20_tiledk && p->rmax > 4) { p->s20_tiledk = false; p->s20_kernel = "tiled"; }     // 64 x R lanes must fit a 256-lane workgroup
-  p->tile = p->s20_mfma ? 32 : (p->s20_scalarp || p->s20_tiledk) ? 64 : 128;
-  if (p->s20_kernel == "tiledk2") p->tile = 128;                   // two 64-pattern sub-tiles per workgroup
+  p->tile = p->s20_tiledk ? 64 : 128;
   if (p->states == 20)
   {
     std::vector<uint32_t> tt, tn;
@@ -996,8 +992,7 @@ static int timing_drain(bpa_engine * e)
 static int plan_launch_mode(bpa_plan * p, int mode)
 {
   // A/B switches of DESIGN.md's appendix, read once
-  static const bool env_fused_split = getenv("BPA_FUSED_SPLIT") != nullptr, env_pmat_rows = getenv("BPA_PMAT_ROWS") != nullptr,
-                    env_pmat_wg1 = getenv("BPA_PMAT_WG1") != nullptr, env_reduce_thread = getenv("BPA_REDUCE_THREAD") != nullptr;
+  static const bool env_fused_split = getenv("BPA_FUSED_SPLIT") != nullptr;
   bpa_engine * e = p->eng;
   if (!flush(e)) return 0;
   PlanDev d = p->pd;
@@ -1065,13 +1060,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     }
     else if (p->fused_jc69)
     {
-      static const bool late = getenv("BPA_JC69_LATE") != nullptr;       // A/B: the exponentials on the update lanes, tail at the end
-      if (late)
-      {
-        if (p->fused_bs == 64) hipExtLaunchKernelGGL((step_jc69_kernel<64, false>), grid, dim3(64), 0, e->stream, k0, k1, 0, d);
-        else                   hipExtLaunchKernelGGL((step_jc69_kernel<256, false>), grid, dim3(256), 0, e->stream, k0, k1, 0, d);
-      }
-      else if (p->fused_bs == 64) hipExtLaunchKernelGGL((step_jc69_kernel<64, true>), grid, dim3(64), 0, e->stream, k0, k1, 0, d);
+      if (p->fused_bs == 64) hipExtLaunchKernelGGL((step_jc69_kernel<64, true>), grid, dim3(64), 0, e->stream, k0, k1, 0, d);
       else                        hipExtLaunchKernelGGL((step_jc69_kernel<256, true>), grid, dim3(256), 0, e->stream, k0, k1, 0, d);
     }
     else if (p->fused_bs == 64 && p->fused_rt == 4 && (d.flags & 1u) && (d.flags & 6u) && env_fused_split)
@@ -1119,13 +1108,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     }
     else
     {
-      const unsigned n = d.nmat*p->rmax*20;
-      if (env_pmat_rows)                // one lane per row (the first version), kept for A/B timing
-        hipLaunchKernelGGL(pmatrix_sN_kernel<20>, dim3((n + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d, p->rmax);
-      else if (env_pmat_wg1)            // round 1's workgroup-per-branch kernel
-        hipLaunchKernelGGL(pmatrix_wg_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d, p->rmax);
-      else
-        hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d);
+      hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d);
     }
     HIPCHK(hipGetLastError());
   }
@@ -1135,38 +1118,16 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     const unsigned blocks = (d.npatterns + BPA_BLOCK - 1)/BPA_BLOCK;
     if (p->states == 4)
       hipLaunchKernelGGL(partials_lnl_s4_kernel, dim3(blocks), dim3(BPA_BLOCK), 0, e->stream, d);
-    else if (p->ntiles && p->s20_mfma)
-    {
-      d.flags = 4u;                                      // always produce the site terms
-      hipLaunchKernelGGL((partials_lnl_mfma20_kernel<32>), dim3(p->ntiles), dim3(64), 0, e->stream, d);
-    }
     else if (p->ntiles && p->s20_tiledk)
     {
       d.flags = 4u; d.pad = p->rmax;
       static const bool no_xcd = getenv("BPA_NO_XCD_MAP") != nullptr;       // A/B: workgroup b = tile b
       if (no_xcd) d.flags |= 32u;
-      const size_t lds = ((size_t)2*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double);
       const dim3 grid(p->ntiles), block(64*p->rmax);
-      const size_t lds2 = ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double);
-      if (p->s20_kernel == "pipe")         hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), grid, block, lds2, e->stream, d);     // default
-      else if (p->s20_kernel == "pipe2c")  hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, false, 2>), grid, block, lds2, e->stream, d);    // cached CLV accesses
-      else if (p->s20_kernel == "pipe3")   hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 3>), grid, block, lds2, e->stream, d);     // 168 registers, 3 waves per SIMD
-      else if (p->s20_kernel == "pipe3c")  hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, false, 3>), grid, block, lds2, e->stream, d);
-      else if (p->s20_kernel == "mfmak")   hipLaunchKernelGGL(partials_lnl_mfma20k_kernel, grid, block, lds, e->stream, d);
-      else if (p->s20_kernel == "scalark" && p->rmax <= 4)
-                                           hipLaunchKernelGGL((partials_lnl_scalark_kernel<20>), grid, block, 0, e->stream, d);
-      else if (p->s20_kernel == "tiledk2")
-        hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 3, 2>), grid, dim3(128*p->rmax),
-                           ((size_t)2*p->rmax*400 + (size_t)2*p->rmax*64)*sizeof(double), e->stream, d);
-      else if (p->s20_kernel == "tiledk1") hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 1>), grid, block, lds, e->stream, d);
-      else if (p->s20_kernel == "tiledkb") hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 4>), grid, block, lds, e->stream, d);
-      else if (p->s20_kernel == "tiledknt") hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 5>), grid, block, lds, e->stream, d);
-      else                                 hipLaunchKernelGGL((partials_lnl_tiledk_kernel<20, 3>), grid, block, lds, e->stream, d);
-    }
-    else if (p->ntiles && p->s20_scalarp)
-    {
-      d.flags = 4u;
-      hipLaunchKernelGGL((partials_lnl_scalarp_kernel<20>), dim3(p->ntiles), dim3(64), 0, e->stream, d);
+      if (p->s20_kernel == "mfmak")
+        hipLaunchKernelGGL(partials_lnl_mfma20k_kernel, grid, block, ((size_t)2*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
+      else
+        hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
     }
     else if (p->ntiles && p->tile == 128 && p->s20_kernel == "tiled")
     {
@@ -1181,10 +1142,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
   if (ts) HIPCHK(hipEventRecord(ts->ev[2], e->stream));
   if (mode & 4)
   {
-    if (env_reduce_thread)
-      hipLaunchKernelGGL(lnl_reduce_kernel, dim3((d.ntasks + BPA_BLOCK - 1)/BPA_BLOCK), dim3(BPA_BLOCK), 0, e->stream, d);
-    else
-      hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(d.ntasks), dim3(64), 0, e->stream, d);
+    hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(d.ntasks), dim3(64), 0, e->stream, d);
     HIPCHK(hipGetLastError());
   }
   if ((mode & 4) && p->sum_out)
@@ -2099,5 +2057,5 @@ extern "C" int bpa_update_eigen(bpa_engine_t * e, double * eigenvecs, double * i
 }
 
 // device-resident per-locus proposal control
-#include "sampler.hpp"
 #include "p2p.hpp"
+#include "sampler.hpp"

@@ -433,155 +433,6 @@ __global__ void __launch_bounds__(TILE) partials_lnl_tiled_kernel(const PlanDev 
   P.site_term[P.task_pat_off[t] + n] = term;
 }
 
-// ============================ K1+K2, 20 states, LDS-staged P, one wave per rate category ==
-// As partials_lnl_tiled_kernel, but a workgroup = 64 patterns x R rate categories: wave k of the
-// workgroup owns the k-th plane of every CLV of its 64 patterns.  The planes of a node update are
-// independent (K1 couples the categories only through the scaling test), so the serial chain of a
-// wave is R times shorter and R times more waves are in flight to hide the CLV load latency —
-// config 4 has only ~2 tiles of 64 patterns per locus.  The root term is combined across the
-// waves in category order (same fma chain as the one-wave version); same arithmetic per element.
-// NT = 64-pattern sub-tiles per workgroup (NT x R waves share one staging of the P-matrices)
-template <int S, int V, int NT = 1>
-__global__ void __launch_bounds__(256*NT) __attribute__((amdgpu_waves_per_eu((V == 2 || V == 3 || V == 5) ? 4 : 1, (V == 2 || V == 3 || V == 5) ? 4 : 8)))
-partials_lnl_tiledk_kernel(const PlanDev P)
-{
-  constexpr bool NTA = V == 5;       // V = 5: V = 3 with the CLV planes streamed (nontemporal loads and stores: each is touched once per step)
-  extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2][R][S][S], then [NT][R][64] scratch
-  const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-  const uint32_t k = NT == 1 ? w : w % P.pad, sub = NT == 1 ? 0u : w / P.pad;
-  const uint32_t t = P.tile_task[b];
-  const uint32_t n = P.tile_n0[b] + sub*64 + lane;
-  const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld, nthr = blockDim.x;
-  const bool active = n < np && k < R;
-  constexpr uint32_t SS = S*S;
-  double * s_x = s_p + (size_t)2*P.pad*SS + (size_t)sub*P.pad*64;    // P.pad = largest R of the plan
-
-  const uint32_t op_end = P.op_off[t+1];
-  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
-  {
-    const OpDev op = P.ops[o];
-    __syncthreads();                                   // previous update's LDS reads are done
-    {
-      const double2 * gl = reinterpret_cast<const double2 *>(L.pmat + (size_t)op.left_pmatrix*R*SS);
-      const double2 * gr = reinterpret_cast<const double2 *>(L.pmat + (size_t)op.right_pmatrix*R*SS);
-      double2 * sl = reinterpret_cast<double2 *>(s_p);
-      double2 * sr = reinterpret_cast<double2 *>(s_p + (size_t)R*SS);
-      for (uint32_t i = threadIdx.x; i < R*SS/2; i += nthr) { sl[i] = gl[i]; sr[i] = gr[i]; }
-    }
-    __syncthreads();
-    double * out = L.clv + ((((size_t)(op.parent_clv - L.tips_n)*R) + k)*S)*ld + n;
-    bool all_small = true;
-    if (active)
-    {
-      const double * lm = s_p + (size_t)k*SS;
-      const double * rm = s_p + (size_t)(R + k)*SS;
-      // Tip children (the tip-code fast path, core_partials.c:48-583 in spirit): a tip's CLV is the 0/1 expansion of
-      // its state code, so for an unambiguous state s the reference's dot product adds exact zeros to P[i][s] — the
-      // result IS P[i][s], bit for bit, and the 20 multiply-adds and 19 of the 20 P reads are skipped.  Taken when
-      // every lane of the wave holds an unambiguous code (wave-uniform branch); ambiguity codes take the full dot.
-      int ls = -1, rs = -1;
-      bool lfast = false, rfast = false;
-      if (op.left_clv < L.tips_n)
-      {
-        const uint32_t code = reinterpret_cast<const uint32_t *>(L.tips)[(size_t)op.left_clv*np + n];
-        ls = __ffs(code) - 1;
-        lfast = __all(__popc(code) == 1);
-      }
-      if (op.right_clv < L.tips_n)
-      {
-        const uint32_t code = reinterpret_cast<const uint32_t *>(L.tips)[(size_t)op.right_clv*np + n];
-        rs = __ffs(code) - 1;
-        rfast = __all(__popc(code) == 1);
-      }
-      double lv[S], rv[S];
-      if (!lfast) load_childN<S, uint32_t, NTA>(L, op.left_clv,  k, n, lv);
-      if (!rfast) load_childN<S, uint32_t, NTA>(L, op.right_clv, k, n, rv);
-      if (V == 4)
-      {
-        // both P rows of an output state are requested in one burst of LDS reads (20 ds_read_b128) and
-        // consumed as they land: one LDS round trip per 40 FMAs instead of one per two
-#pragma unroll 1
-        for (int i = 0; i < S; ++i)
-        {
-          double pl[S], pr[S];
-          const double2 * ql = reinterpret_cast<const double2 *>(lm + i*S);
-          const double2 * qr = reinterpret_cast<const double2 *>(rm + i*S);
-#pragma unroll
-          for (int j = 0; j < S/2; ++j) { const double2 a = ql[j]; pl[2*j] = a.x; pl[2*j+1] = a.y; }
-#pragma unroll
-          for (int j = 0; j < S/2; ++j) { const double2 a = qr[j]; pr[2*j] = a.x; pr[2*j+1] = a.y; }
-          __builtin_amdgcn_sched_barrier(0);
-          const double x = lfast ? lm[i*S + ls] : dot_fma4<S>(pl, lv);
-          const double y = rfast ? rm[i*S + rs] : dot_fma4<S>(pr, rv);
-          const double v = x*y;
-          all_small = all_small && (v < BPA_SCALE_THRESHOLD);
-          out[(size_t)i*ld] = v;
-        }
-      }
-      else
-      {
-#pragma unroll 2
-        for (int i = 0; i < S; ++i)
-        {
-          const double x = lfast ? lm[i*S + ls] : dot_fma4<S>(lm + i*S, lv);
-          const double y = rfast ? rm[i*S + rs] : dot_fma4<S>(rm + i*S, rv);
-          const double v = x*y;
-          all_small = all_small && (v < BPA_SCALE_THRESHOLD);
-          if (NTA) __builtin_nontemporal_store(v, out + (size_t)i*ld); else out[(size_t)i*ld] = v;
-        }
-      }
-    }
-    if (op.parent_scaler >= 0)                         // uniform: the scaling test couples the categories
-    {
-      reinterpret_cast<uint32_t *>(s_x)[k*64 + lane] = all_small ? 1u : 0u;
-      __syncthreads();
-      if (active)
-      {
-        bool all = true;
-        for (uint32_t q = 0; q < R; ++q) all = all && reinterpret_cast<const uint32_t *>(s_x)[q*64 + lane] != 0u;
-        if (all) for (int i = 0; i < S; ++i) out[(size_t)i*ld] *= BPA_SCALE_FACTOR;
-        if (k == 0)
-        {
-          uint32_t sc = all ? 1u : 0u;
-          if (op.left_scaler  >= 0) sc += L.scaler[(size_t)op.left_scaler*np  + n];
-          if (op.right_scaler >= 0) sc += L.scaler[(size_t)op.right_scaler*np + n];
-          L.scaler[(size_t)op.parent_scaler*np + n] = sc;
-        }
-      }
-    }
-  }
-  if (!(P.flags & 4u)) return;
-
-  // K2 / K3 (core_likelihood_avx2.c:45-87): every wave its category's term, wave 0 the fma chain over them
-  const uint32_t root = P.root_clv[t];
-  const double * par = L.par;
-  __syncthreads();
-  if (active)
-  {
-    double c[S];
-    load_childN<S, uint32_t>(L, root, k, n, c);
-    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
-    s_x[k*64 + lane] = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
-  }
-  __syncthreads();
-  if (!active || k) return;
-  double term = 0;
-  for (uint32_t q = 0; q < R; ++q) term = __builtin_fma(s_x[q*64 + lane], par[par_rate_weights(R) + q], term);
-  if (!L.unphased_length)
-  {
-    double lt = log(term);
-    const int32_t rs = P.root_scaler[t];
-    if (rs >= 0)
-    {
-      const uint32_t sc = L.scaler[(size_t)rs*np + n];
-      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
-    }
-    term = lt*L.weights[n];
-  }
-  P.site_term[P.task_pat_off[t] + n] = term;
-}
-
 // ================================== K1+K2, 20 states, pipelined (default since round 2) ==
 // partials_lnl_tiledk_kernel's arithmetic and workgroup shape (64 patterns x R categories, wave k owns plane k), with
 // the serial chain of an update cut down — what the round-1 kernel waited for was not bandwidth (a kernel of this
@@ -814,108 +665,6 @@ partials_lnl_pipe20_kernel(const PlanDev P)
   P.site_term[((cu32_p)P.task_pat_off)[t] + n] = term;
 }
 
-// ====================================== K1+K2, 20 states, P through the scalar path ==
-// One wave (= one workgroup) = one tile of 64 consecutive patterns of ONE locus; one lane = one
-// pattern.  Everything about the node update except the CLV values is wave-uniform, so the two
-// P-matrices are read through the scalar data path (constant address space -> s_load_dwordx*
-// into SGPRs, served by the scalar cache / L2) and enter v_fma_f64 as its SGPR operand: no LDS
-// traffic, no staging barriers, no per-lane P loads; the vector memory pipe carries only the
-// coalesced CLV planes.  The P-matrices were written by an earlier launch (pmatrix_sN_kernel), so the
-// scalar cache cannot hold stale lines.  Summation order = dot_fma4 (the reference's AVX2 order).
-typedef const double __attribute__((address_space(4))) * cdouble_p;
-
-template <int S>
-__device__ __forceinline__ double dot_fma4_c(cdouble_p row, const double * v)
-{
-  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-  for (int j = 0; j < S; j += 4)
-  {
-    a0 = __builtin_fma(row[j+0], v[j+0], a0);
-    a1 = __builtin_fma(row[j+1], v[j+1], a1);
-    a2 = __builtin_fma(row[j+2], v[j+2], a2);
-    a3 = __builtin_fma(row[j+3], v[j+3], a3);
-  }
-  return (a0 + a1) + (a2 + a3);
-}
-
-template <int S>
-__global__ void __launch_bounds__(64) partials_lnl_scalarp_kernel(const PlanDev P)
-{
-  const uint32_t b = blockIdx.x, lane = threadIdx.x;
-  const uint32_t t = P.tile_task[b];
-  const uint32_t n = P.tile_n0[b] + lane;
-  const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld;
-  const bool active = n < np;
-  constexpr uint32_t SS = S*S;
-  const uint32_t nn = active ? n : np - 1;               // idle lanes shadow the last pattern (no divergence, no stores)
-
-  const uint32_t op_end = P.op_off[t+1];
-  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
-  {
-    const OpDev op = P.ops[o];
-    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*ld + nn;
-    bool all_small = true;
-    for (uint32_t k = 0; k < R; ++k)
-    {
-      double lv[S], rv[S];
-      load_childN<S, uint32_t>(L, op.left_clv,  k, nn, lv);
-      load_childN<S, uint32_t>(L, op.right_clv, k, nn, rv);
-      cdouble_p lm = (cdouble_p)(L.pmat + ((size_t)op.left_pmatrix*R  + k)*SS);
-      cdouble_p rm = (cdouble_p)(L.pmat + ((size_t)op.right_pmatrix*R + k)*SS);
-      double * dst = out + (size_t)k*S*ld;
-#pragma unroll 2
-      for (int i = 0; i < S; ++i)
-      {
-        const double x = dot_fma4_c<S>(lm + i*S, lv);
-        const double y = dot_fma4_c<S>(rm + i*S, rv);
-        const double v = x*y;
-        all_small = all_small && (v < BPA_SCALE_THRESHOLD);
-        if (active) dst[(size_t)i*ld] = v;
-      }
-    }
-    if (op.parent_scaler >= 0 && active)
-    {
-      uint32_t s = 0;
-      if (op.left_scaler  >= 0) s += L.scaler[(size_t)op.left_scaler*np  + n];
-      if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + n];
-      if (all_small)
-      {
-        for (uint32_t e = 0; e < R*S; ++e) out[(size_t)e*ld] *= BPA_SCALE_FACTOR;
-        s += 1;
-      }
-      L.scaler[(size_t)op.parent_scaler*np + n] = s;
-    }
-  }
-  if (!active || !(P.flags & 4u)) return;
-
-  // K2 / K3 (core_likelihood_avx2.c:45-87)
-  const uint32_t root = P.root_clv[t];
-  const double * par = L.par;
-  double term = 0;
-  for (uint32_t k = 0; k < R; ++k)
-  {
-    double c[S];
-    load_childN<S, uint32_t>(L, root, k, n, c);
-    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
-    const double tr = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
-    term = __builtin_fma(tr, par[par_rate_weights(R) + k], term);
-  }
-  if (!L.unphased_length)
-  {
-    double lt = log(term);
-    const int32_t rs = P.root_scaler[t];
-    if (rs >= 0)
-    {
-      const uint32_t sc = L.scaler[(size_t)rs*np + n];
-      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
-    }
-    term = lt*L.weights[n];
-  }
-  P.site_term[P.task_pat_off[t] + n] = term;
-}
-
 // ======================= K1+K2, 20 states, FP64 MFMA, one wave per rate category ==
 // The contraction parent[i][n] = (sum_j Pl[i][j] L[j][n]) (sum_j Pr[i][j] R[j][n]) on the matrix cores
 // with v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction: blocks = four groups of
@@ -1095,280 +844,6 @@ __global__ void __launch_bounds__(256) partials_lnl_mfma20k_kernel(const PlanDev
   P.site_term[P.task_pat_off[t] + n] = term;
 }
 
-// ========================= K1+K2, 20 states, scalar-path P, one wave per rate category ==
-// partials_lnl_tiledk_kernel with the P-matrices read through the scalar path instead of LDS: an
-// LDS broadcast read per v_fma_f64 caps the LDS-staged kernels at about a quarter of the FP64 rate
-// (one 512-byte LDS access per 4 cycles per CU against four SIMDs' FMAs); SGPR operands cost no LDS
-// bandwidth and no staging barriers.  LDS only carries the scaling flags and the root terms.
-template <int S>
-__global__ void __launch_bounds__(256) partials_lnl_scalark_kernel(const PlanDev P)
-{
-  __shared__ double s_x[4][64];
-  const uint32_t b = blockIdx.x, lane = threadIdx.x & 63u;
-  const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform, in an SGPR
-  const uint32_t t = P.tile_task[b];
-  const uint32_t n = P.tile_n0[b] + lane;
-  const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld;
-  const bool wave_on = k < R;
-  const bool active = n < np && wave_on;
-  constexpr uint32_t SS = S*S;
-  const uint32_t nn = n < np ? n : np - 1;               // idle lanes shadow the last pattern: no divergence in the FMA loop
-
-  const uint32_t op_end = P.op_off[t+1];
-  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
-  {
-    const OpDev op = P.ops[o];
-    double * out = L.clv + ((((size_t)(op.parent_clv - L.tips_n)*R) + k)*S)*ld + nn;
-    bool all_small = true;
-    if (wave_on)
-    {
-      double lv[S], rv[S];
-      load_childN<S, uint32_t>(L, op.left_clv,  k, nn, lv);
-      load_childN<S, uint32_t>(L, op.right_clv, k, nn, rv);
-      cdouble_p lm = (cdouble_p)(L.pmat + ((size_t)op.left_pmatrix*R  + k)*SS);
-      cdouble_p rm = (cdouble_p)(L.pmat + ((size_t)op.right_pmatrix*R + k)*SS);
-#pragma unroll 2
-      for (int i = 0; i < S; ++i)
-      {
-        const double x = dot_fma4_c<S>(lm + i*S, lv);
-        const double y = dot_fma4_c<S>(rm + i*S, rv);
-        const double v = x*y;
-        all_small = all_small && (v < BPA_SCALE_THRESHOLD);
-        if (active) out[(size_t)i*ld] = v;
-      }
-    }
-    if (op.parent_scaler >= 0)                         // uniform: the scaling test couples the categories
-    {
-      __syncthreads();
-      reinterpret_cast<uint32_t *>(&s_x[k & 3u][0])[lane] = all_small ? 1u : 0u;
-      __syncthreads();
-      if (active)
-      {
-        bool all = true;
-        for (uint32_t q = 0; q < R; ++q) all = all && reinterpret_cast<const uint32_t *>(&s_x[q][0])[lane] != 0u;
-        if (all) for (int i = 0; i < S; ++i) out[(size_t)i*ld] *= BPA_SCALE_FACTOR;
-        if (k == 0)
-        {
-          uint32_t sc = all ? 1u : 0u;
-          if (op.left_scaler  >= 0) sc += L.scaler[(size_t)op.left_scaler*np  + n];
-          if (op.right_scaler >= 0) sc += L.scaler[(size_t)op.right_scaler*np + n];
-          L.scaler[(size_t)op.parent_scaler*np + n] = sc;
-        }
-      }
-    }
-  }
-  if (!(P.flags & 4u)) return;
-
-  // K2 / K3 (core_likelihood_avx2.c:45-87): every wave its category's term, wave 0 the fma chain over them
-  const uint32_t root = P.root_clv[t];
-  const double * par = L.par;
-  __syncthreads();
-  if (active)
-  {
-    double c[S];
-    load_childN<S, uint32_t>(L, root, k, n, c);
-    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
-    s_x[k][lane] = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
-  }
-  __syncthreads();
-  if (!active || k) return;
-  double term = 0;
-  for (uint32_t q = 0; q < R; ++q) term = __builtin_fma(s_x[q][lane], par[par_rate_weights(R) + q], term);
-  if (!L.unphased_length)
-  {
-    double lt = log(term);
-    const int32_t rs = P.root_scaler[t];
-    if (rs >= 0)
-    {
-      const uint32_t sc = L.scaler[(size_t)rs*np + n];
-      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
-    }
-    term = lt*L.weights[n];
-  }
-  P.site_term[P.task_pat_off[t] + n] = term;
-}
-
-// ================================================= K1+K2, 20 states, FP64 MFMA ==
-// The 20-state node update is a real dense contraction: parent[i][n] = (sum_j Pl[i][j] L[j][n]) *
-// (sum_j Pr[i][j] R[j][n]).  It runs on the matrix cores with v_mfma_f64_4x4x4_4b_f64
-// (4 independent 4x4x4 blocks per instruction; measured 67.6 TFLOP/s on MI355X vs 42 for
-// v_fma_f64): blocks = four groups of 4 site patterns, A = a 4-row x 4-column piece of P
-// (replicated over the blocks), B = 4 states x 16 patterns of the child CLV, so 20 states
-// tile exactly (5 row tiles, no padding in M).  Lane layout (tools/mfma_layout.hip):
-//   A[blk][i][k] @ lane k*16+blk*4+i   B[blk][k][j] @ lane k*16+blk*4+j   D[blk][i][j] @ lane i*16+blk*4+j
-// i.e. for B and D, lane & 15 = pattern within the group of 16 and lane >> 4 = k resp. row.
-// The instruction accumulates k = 0..3 as an ascending fma chain seeded with C
-// (tools/mfma_order.hip, bit-exact), so the reference's AVX2 summation order is kept
-// exactly: lane-accumulator a (a = 0..3) takes the columns j = a, a+4, a+8, a+12 in one
-// MFMA and j = a+16 (k = 1..3 zero-padded: fma(0,0,acc) = acc) in a second one; then
-// (acc0+acc1)+(acc2+acc3) and the product on the VALU (core_partials_avx2.c:666-745).
-// 8 MFMAs per (4 rows x 16 patterns) instead of the minimal 5: at 62 % of the MFMA peak the
-// kernel is still far above what HBM can feed (3.3 flop/B), so exactness is free.
-// One wave (= one workgroup) = one tile of TILE = 32 patterns of one locus.  For every
-// (update, rate) the wave stages the two 20x20 P-matrices in 6.4 KB of LDS (A operands: one
-// ds_read_b64 per MFMA) and requests all CLV operands of the tile in one burst.
-// STATUS (round 1): correct and bit-exact (same tests as the VALU kernel), but at config-4
-// sizes it is latency-bound (short per-wave chains of load -> 160 MFMA -> store) and
-// 1.3x slower than the LDS-broadcast VALU kernel above, which therefore stays the default;
-// opt in with BPA_S20_MFMA=1.  Variants tried: A in registers, 128-pattern tiles (542 us),
-// A in LDS (578 us), A in registers + 32-pattern tiles (827 us) vs VALU 437 us per launch.
-// Children written by other lanes of the same wave are re-read after s_waitcnt vmcnt(0).
-// A operands come from the wave's LDS copy of the two P-matrices (row-major 20x20 each)
-__device__ __forceinline__ double tile_dot20(const double * __restrict__ sp, const uint32_t rowoff,
-                                             const uint32_t kq, const double (&b)[4], const double (&b2)[4])
-{
-  double acc[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-  {
-    const double a0 = sp[rowoff + a + 4*kq];
-    const double a1 = kq == 0 ? sp[rowoff + 16 + a] : 0.0;
-    acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, b[a], 0.0, 0, 0, 0);
-    acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b2[a], acc[a], 0, 0, 0);
-  }
-  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
-}
-
-__device__ __forceinline__ void load_b20(const LocusDev & L, const uint32_t clv_index, const uint32_t k,
-                                         const uint32_t pat, const uint32_t kq, double (&b)[4], double (&b2)[4])
-{
-  if (clv_index < L.tips_n)
-  {
-    const uint32_t code = reinterpret_cast<const uint32_t *>(L.tips)[(size_t)clv_index*L.np + pat];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-    {
-      b[a]  = ((code >> (a + 4*kq)) & 1u) ? 1.0 : 0.0;
-      b2[a] = (kq == 0 && ((code >> (16 + a)) & 1u)) ? 1.0 : 0.0;
-    }
-  }
-  else
-  {
-    const double * p = L.clv + (((size_t)(clv_index - L.tips_n)*L.rate_cats + k)*20)*L.ld + pat;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-    {
-      b[a]  = p[(size_t)(a + 4*kq)*L.ld];
-      b2[a] = kq == 0 ? p[(size_t)(16 + a)*L.ld] : 0.0;
-    }
-  }
-}
-
-template <int TILE>
-__global__ void __launch_bounds__(64) partials_lnl_mfma20_kernel(const PlanDev P)
-{
-  constexpr int S = 20;
-  __shared__ __attribute__((aligned(16))) double s_p[2*S*S];
-  const uint32_t b = blockIdx.x, l = threadIdx.x;
-  const uint32_t t = P.tile_task[b], n0 = P.tile_n0[b];
-  const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld;
-  const uint32_t kq = l >> 4, pl = l & 15, ri = l & 3;
-  const uint32_t npat = min((uint32_t)TILE, np - n0), ngroups = (npat + 15)/16;
-
-  const uint32_t op_end = P.op_off[t+1];
-  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
-  {
-    const OpDev op = P.ops[o];
-    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*ld;
-    uint32_t small = 0xffffffffu;                 // bit g: everything this lane produced for group g is < 2^-256
-    for (uint32_t k = 0; k < R; ++k)
-    {
-      {
-        const double2 * lm = reinterpret_cast<const double2 *>(L.pmat + ((size_t)op.left_pmatrix*R  + k)*S*S);
-        const double2 * rm = reinterpret_cast<const double2 *>(L.pmat + ((size_t)op.right_pmatrix*R + k)*S*S);
-        __syncthreads();                                 // (one wave) previous rate's LDS reads are done
-        double2 * sl = reinterpret_cast<double2 *>(s_p), * sr = reinterpret_cast<double2 *>(s_p + S*S);
-        for (uint32_t i = l; i < S*S/2; i += 64) { sl[i] = lm[i]; sr[i] = rm[i]; }
-        __syncthreads();
-      }
-      // all CLV operands of the tile first (one wave of independent loads), then the MFMAs
-      constexpr int NG = TILE/16;
-      double bl[NG][4], bl2[NG][4], br[NG][4], br2[NG][4];
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-      {
-        const uint32_t pat = n0 + 16*g + pl;
-        const uint32_t pc = pat < np ? pat : np - 1;
-        load_b20(L, op.left_clv,  k, pc, kq, bl[g], bl2[g]);
-        load_b20(L, op.right_clv, k, pc, kq, br[g], br2[g]);
-      }
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-      {
-        const uint32_t pat = n0 + 16*g + pl;
-        const bool valid = pat < np;
-        bool sm = true;
-#pragma unroll
-        for (int r = 0; r < 5; ++r)
-        {
-          const double x = tile_dot20(s_p,       (4*r + ri)*S, kq, bl[g], bl2[g]);
-          const double y = tile_dot20(s_p + S*S, (4*r + ri)*S, kq, br[g], br2[g]);
-          const double v = x*y;
-          sm = sm && (v < BPA_SCALE_THRESHOLD);
-          if (valid) out[((size_t)k*S + 4*r + kq)*ld + pat] = v;      // D: row = lane >> 4
-        }
-        if (!sm) small &= ~(1u << g);
-      }
-    }
-    if (op.parent_scaler >= 0)
-    {
-      // a pattern's 20*R entries sit in the 4 lanes with the same (lane & 15)
-      small &= __shfl_xor(small, 16);
-      small &= __shfl_xor(small, 32);
-      for (uint32_t g = 0; g < ngroups; ++g)
-      {
-        const uint32_t pat = n0 + 16*g + pl;
-        if (pat >= np) continue;
-        const bool rescale = (small >> g) & 1u;
-        if (rescale)
-          for (uint32_t k = 0; k < R; ++k)
-#pragma unroll
-            for (int r = 0; r < 5; ++r) out[((size_t)k*S + 4*r + kq)*ld + pat] *= BPA_SCALE_FACTOR;
-        if (kq == 0)
-        {
-          uint32_t s = rescale ? 1u : 0u;
-          if (op.left_scaler  >= 0) s += L.scaler[(size_t)op.left_scaler*np  + pat];
-          if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + pat];
-          L.scaler[(size_t)op.parent_scaler*np + pat] = s;
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next update reads these through other lanes
-  }
-  if (!(P.flags & 4u)) return;
-
-  // K2 / K3 (core_likelihood_avx2.c:45-87): one lane per pattern
-  const uint32_t root = P.root_clv[t];
-  const double * par = L.par;
-  for (uint32_t q = l; q < npat; q += 64)
-  {
-    const uint32_t n = n0 + q;
-    double term = 0;
-    for (uint32_t k = 0; k < R; ++k)
-    {
-      double c[S];
-      load_childN<S, uint32_t>(L, root, k, n, c);
-      const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
-      const double tr = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
-      term = __builtin_fma(tr, par[par_rate_weights(R) + k], term);
-    }
-    if (!L.unphased_length)
-    {
-      double lt = log(term);
-      const int32_t rs = P.root_scaler[t];
-      if (rs >= 0)
-      {
-        const uint32_t sc = L.scaler[(size_t)rs*np + n];
-        if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
-      }
-      term = lt*L.weights[n];
-    }
-    P.site_term[P.task_pat_off[t] + n] = term;
-  }
-}
-
 // ====================================================== per-locus lnL reduction ==
 // Sum of the per-pattern terms in pattern order (core_likelihood.c:206-210); the
 // diploid branch averages the phase resolutions first (locus.c:2600-2614).
@@ -1421,13 +896,6 @@ __global__ void __launch_bounds__(64) lnl_reduce_wave_kernel(const PlanDev P)
   if (lane == 0) P.lnl[t] = P.bfbeta*logl;
 }
 
-__global__ void __launch_bounds__(BPA_BLOCK) lnl_reduce_kernel(const PlanDev P)
-{
-  const uint32_t t = blockIdx.x*BPA_BLOCK + threadIdx.x;
-  if (t >= P.ntasks) return;
-  const LocusDev & L = P.loci[P.task_locus[t]];
-  P.lnl[t] = P.bfbeta*reduce_locus(L, P.site_term + P.task_pat_off[t]);
-}
 
 // sum over the tasks of a plan, deterministic (fixed strided order + LDS tree): the
 // quantity threads.c:544-559 / 583-591 reduces over workers for the all-loci
@@ -2923,93 +2391,6 @@ step_s4_klane_v2_kernel(const PlanDev P)
       P.wg_part[b] = part;
     }
   }
-}
-
-// generic S: one lane per (branch, rate, row)
-template <int S>
-__global__ void __launch_bounds__(BPA_BLOCK) pmatrix_sN_kernel(const PlanDev P, const uint32_t rmax)
-{
-  const uint32_t tid = blockIdx.x*BPA_BLOCK + threadIdx.x;
-  const uint32_t j = tid % S, ek = tid / S;
-  const uint32_t e = ek / rmax, k = ek % rmax;
-  if (e >= P.nmat) return;
-  const LocusDev & L = P.loci[P.task_locus[P.mat_task[e]]];
-  const uint32_t R = L.rate_cats;
-  if (k >= R) return;
-  const double * par = L.par;
-  const double t = P.mat_length[e];
-  const double rate = par[par_rates(R) + k];
-  double * prow = L.pmat + ((size_t)P.mat_pmatrix[e]*R + k)*S*S + j*S;
-  if (t*rate < 1e-100)
-  {
-    for (int c = 0; c < S; ++c) prow[c] = ((int)j == c) ? 1.0 : 0.0;
-    return;
-  }
-  const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
-  const double * pm = par + par_matrix(R, S, m);
-  pmatrix_eigen_row<S>(prow, (int)j, t, rate, pm + pm_evals(S), pm + pm_evecs(S), pm + pm_ievecs(S), false);
-}
-
-// K5 for S = 20, one workgroup per branch: lanes = output elements.  The eigenvector matrices of the
-// rate matrix are staged once per workgroup (coalesced), the S expm1 per category are computed once
-// (not once per row), every lane accumulates its element in the reference's order
-// (temp = inv_eigenvecs*expd, then pmat += temp*eigenvecs, core_pmatrix.c:741-756) and the matrix is
-// written with consecutive lanes on consecutive addresses.
-template <int S>
-__global__ void __launch_bounds__(256) pmatrix_wg_kernel(const PlanDev P, const uint32_t rmax)
-{
-  __shared__ __attribute__((aligned(16))) double s_ev[S*S], s_iev[S*S], s_tmp[4][S*S], s_e[4][S];
-  const uint32_t e = blockIdx.x, tid = threadIdx.x;
-  const LocusDev & L = P.loci[P.task_locus[P.mat_task[e]]];
-  const uint32_t R = L.rate_cats;
-  const double * par = L.par;
-  const double t = P.mat_length[e];
-  double * pbase = L.pmat + (size_t)P.mat_pmatrix[e]*R*S*S;
-  // the categories of BPP's loci share one rate matrix (param_indices all 0, locus.c:852); a locus
-  // with several is handled in groups of categories with the same matrix
-  for (uint32_t k0 = 0; k0 < R; )
-  {
-    const uint32_t m = (uint32_t)par[par_param_idx(R) + k0];
-    uint32_t k1 = k0 + 1;
-    while (k1 < R && k1 - k0 < 4 && (uint32_t)par[par_param_idx(R) + k1] == m) ++k1;
-    const uint32_t nk = k1 - k0;
-    const double * pm = par + par_matrix(R, S, m);
-    __syncthreads();
-    for (uint32_t i = tid; i < S*S; i += 256) { s_ev[i] = pm[pm_evecs(S) + i]; s_iev[i] = pm[pm_ievecs(S) + i]; }
-    if (tid < nk*S)
-    {
-      const uint32_t k = k0 + tid/S, mm = tid % S;
-      s_e[tid/S][mm] = expm1(pm[pm_evals(S) + mm]*(t*par[par_rates(R) + k]));
-    }
-    __syncthreads();
-    // temp = inv_eigenvecs * expd (core_pmatrix.c:741-747), once per element
-    for (uint32_t i = tid; i < nk*S*S; i += 256) s_tmp[i/(S*S)][i % (S*S)] = s_iev[i % (S*S)]*s_e[i/(S*S)][i % S];
-    __syncthreads();
-    // pmat = I + temp * eigenvecs (core_pmatrix.c:749-756): one lane = 4 consecutive columns of a row
-    constexpr uint32_t Q = S/4;
-    for (uint32_t idx = tid; idx < nk*S*Q; idx += 256)
-    {
-      const uint32_t kk = idx/(S*Q), j = (idx % (S*Q))/Q, c0 = 4*(idx % Q), k = k0 + kk;
-      double acc[4] = {j == c0 ? 1.0 : 0.0, j == c0 + 1 ? 1.0 : 0.0, j == c0 + 2 ? 1.0 : 0.0, j == c0 + 3 ? 1.0 : 0.0};
-      if (!(t*par[par_rates(R) + k] < 1e-100))
-      {
-        const double * tr = &s_tmp[kk][j*S];
-#pragma unroll
-        for (int mm = 0; mm < S; ++mm)
-        {
-          const double tv = tr[mm];
-          const double2 * ev = reinterpret_cast<const double2 *>(&s_ev[mm*S + c0]);
-          const double2 a = ev[0], c = ev[1];
-          acc[0] += tv*a.x; acc[1] += tv*a.y; acc[2] += tv*c.x; acc[3] += tv*c.y;
-        }
-      }
-      double2 * dst = reinterpret_cast<double2 *>(pbase + (size_t)k*S*S + j*S + c0);
-      double2 o0, o1; o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
-      dst[0] = o0; dst[1] = o1;
-    }
-    k0 = k1;
-  }
-  (void)rmax;
 }
 
 // pmatrix_wg_kernel with its serial chain cut down the way partials_lnl_pipe20_kernel's was: the wave-uniform chain

@@ -1171,6 +1171,8 @@ struct bpa_sampler
   DevBuf<int> v2_err;
   DevBuf<double> v2_prof, v2_declog;
   DevBuf<smp::Species> v2_sp;
+  smp::Species v2_sp_sent{};            // what v2_sp holds
+  bpa_p2p * p2p = nullptr;              // several GPUs, the sums exchanged INSIDE the persistent kernel over xGMI mailboxes (bpa_sampler_set_p2p)
   unsigned long v2_iters = 0;           // iterations run by persistent launches (bpa_sampler_timing)
 };
 
@@ -1380,6 +1382,7 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
   HIPCHK(hipMemset(s->v2_prof.p, 0, (16 + (size_t)nwg)*sizeof(double)));
   void (*kern)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4> : smp2::iter_kernel<8>;
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->v2_lds));
+  std::memset(&s->v2_sp_sent, 0xff, sizeof s->v2_sp_sent);       // (nothing sent yet)
   s->v2_ok = true;
   return 1;
 }
@@ -1464,10 +1467,25 @@ static int sampler_upload(bpa_sampler * s)
     HIPCHK(hipStreamSynchronize(e->stream));
     for (int p = 0; p < smp::MAXPOP; ++p) s->has_theta[p] = m[p] > 0.5;
   }
+  if (s->p2p && !s->allreduce)
+  {
+    // (the same OR over the ranks through the mailboxes)
+    double m[smp::MAXPOP];
+    for (int p = 0; p < smp::MAXPOP; ++p) m[p] = s->has_theta[p] ? 1.0 : 0.0;
+    HIPCHK(hipMemcpyAsync(s->theta_sums.p, m, sizeof m, hipMemcpyHostToDevice, e->stream));
+    if (!bpa_p2p_allreduce(s->p2p, s->theta_sums.p, (unsigned)smp::MAXPOP)) return 0;
+    HIPCHK(hipMemcpyAsync(m, s->theta_sums.p, sizeof m, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (bpa_p2p_status(s->p2p) != 0) return fail("bpa_sampler: the p2p exchange timed out while the ranks agreed on the THETA mask");
+    for (int p = 0; p < smp::MAXPOP; ++p) s->has_theta[p] = m[p] > 0.5;
+  }
   hipLaunchKernelGGL(smp::lograt_kernel, dim3(1), dim3(smp::MAXN*smp::MAXN), 0, e->stream, s->lograt.p);
   HIPCHK(hipGetLastError());
   s->epoch = 0; s->mix_pending = false;
   if (!sampler_upload_v2(s, task_rec)) return 0;
+  if (s->p2p && !s->allreduce && !s->v2_ok)
+    return fail("bpa_sampler_set_p2p: the in-kernel exchange needs the persistent iteration kernel (JC69 loci of <= 8 tips and <= 64 patterns, "
+                "root = last node, every workgroup resident); install an all-reduce callback instead");
   s->uploaded = true;
   return 1;
 }
@@ -1709,6 +1727,8 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
   uint32_t theta_mask = 0;
   if (s->sp.theta_alpha > 0) for (int p = 0; p < npop; ++p) if (s->has_theta[p]) theta_mask |= 1u << p;
   const bool allloci = in_kernel_allloci && !s->env_nomix;
+  // exchanges of an iteration: THETA in chunks of 7 populations, one per TAU, one for MIX (sweep2.hpp: exchange)
+  const unsigned x_per_iter = allloci ? (theta_mask ? ((unsigned)npop + 6u)/7u : 0u) + (unsigned)(npop - S) + 1u : 0u;
   const unsigned draws_per_iter = allloci ? 2u*(unsigned)__builtin_popcount(theta_mask) + 2u*(unsigned)(npop - S) + 2u : 0u;
   void (*kern)(const smp2::Args) = s->v2_nt == 4 ? smp2::iter_kernel<4> : smp2::iter_kernel<8>;
   const unsigned bs = s->v2_nt == 4 ? smp2::Cfg<4>::BS : smp2::Cfg<8>::BS;
@@ -1726,11 +1746,26 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
     a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2;
     if (s->env_gage >= 0) { a.nsteps_gage = (uint32_t)s->env_gage; a.nsteps_gspr = (uint32_t)s->env_gspr; }
     a.theta_mask = theta_mask; a.do_allloci = allloci ? 1u : 0u; a.dbg = s->env_dbg;
+    if (s->p2p && allloci)
+    {
+      a.peers = s->p2p->d_peer.p; a.mail = s->p2p->mail; a.rank = s->p2p->rank; a.world = s->p2p->world; a.slot_bytes = s->p2p->slot_bytes;
+      a.seq0 = s->p2p->seq; a.spin_limit = s->p2p->spin_limit; a.p2p_err = s->p2p->d_err.p;
+      s->p2p->seq += (unsigned long long)chunk*x_per_iter;
+    }
+    else { a.world = 1; a.rank = 0; }
     a.bfbeta = e->usedata ? e->bfbeta : 0.0; a.prof = s->v2_prof.p; a.declog = s->v2_declog.p; a.sp = s->v2_sp.p;
-    HIPCHK(hipMemcpyAsync(s->v2_sp.p, &s->sp, sizeof(smp::Species), hipMemcpyHostToDevice, e->stream));
+    if (std::memcmp(&s->v2_sp_sent, &s->sp, sizeof(smp::Species)) != 0)          // (finetune / prior setters change it between calls)
+    {
+      HIPCHK(hipMemcpyAsync(s->v2_sp.p, &s->sp, sizeof(smp::Species), hipMemcpyHostToDevice, e->stream));
+      s->v2_sp_sent = s->sp;
+    }
     if (s->env_dbg & 256u) HIPCHK(hipMemsetAsync(s->v2_declog.p, 0, 4*2048*sizeof(double), e->stream));
-    HIPCHK(hipMemcpyAsync(s->v2_grng.p, &s->grng, sizeof(a00_rng_t), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemsetAsync(s->v2_xbuf.p, 0, (size_t)2*smp2::XN*sizeof(unsigned long long), e->stream));
+    if (allloci)
+    {
+      // (a sweep-only launch draws nothing from the global stream and exchanges nothing)
+      HIPCHK(hipMemcpyAsync(s->v2_grng.p, &s->grng, sizeof(a00_rng_t), hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemsetAsync(s->v2_xbuf.p, 0, (size_t)2*smp2::XN*sizeof(unsigned long long), e->stream));
+    }
     if (s->timing_stride && (s->timing_phase++ % s->timing_stride) == 0)
     {
       if (s->timed.size() >= 4096 && !sampler_timing_drain(s)) return 0;
@@ -1746,6 +1781,21 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
     for (unsigned long k = 0; k < (unsigned long)chunk*draws_per_iter; ++k) (void)a00_rndu(&s->grng);
     s->launches++; s->sweeps += chunk; s->v2_iters += chunk;
     iterations -= chunk;
+  }
+  return 1;
+}
+
+extern "C" int bpa_sampler_set_p2p(bpa_sampler_t * s, bpa_p2p_t * p, unsigned first_locus)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (p && (!p->connected || p->eng != s->eng)) return fail("bpa_sampler_set_p2p: connect the exchange first (same engine)");
+  if (p && p->nmax < 8u) return fail("bpa_sampler_set_p2p: the mailboxes must hold at least 8 values");
+  if (!sampler_invalidate(s)) return 0;
+  s->p2p = p;
+  if (first_locus != s->locus_offset)
+  {
+    s->locus_offset = first_locus;
+    for (unsigned i = 0; i < s->nloci; ++i) s->h_trees[i].rng = a00_rng_seed(s->seed, first_locus + i);
   }
   return 1;
 }
@@ -1860,6 +1910,7 @@ static int sampler_download(bpa_sampler * s)
       fprintf(stderr, "[smp2] sweep cycles per workgroup, last launch: min %.0f mean %.0f max %.0f (workgroup %u of %u)\n", mn, sm/w.size(), mx, imx, s->v2_nwg);
     }
     HIPCHK(hipMemcpy(&err, s->v2_err.p, sizeof err, hipMemcpyDeviceToHost));
+    if (!err && s->p2p) { HIPCHK(hipMemcpy(&err, s->p2p->d_err.p, sizeof err, hipMemcpyDeviceToHost)); if (err) return fail("bpa_sampler: the exchange between the GPUs timed out inside the persistent kernel (a rank is missing or slow; install an all-reduce callback instead)"); }
     if (err) return fail("bpa_sampler: the persistent iteration kernel timed out waiting for a workgroup's sum (is the device shared? BPA_SMP_V1=1 selects one launch per step)");
   }
   s->host_current = true;
@@ -1953,7 +2004,9 @@ extern "C" int bpa_sampler_kind(bpa_sampler_t * s)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (!sampler_upload(s)) return -1;
-  return s->generic ? BPA_SAMPLER_GENERIC : (s->v2_ok && !s->allreduce && !s->env_trace) ? BPA_SAMPLER_PERSISTENT : BPA_SAMPLER_SWEEP;      // (several ranks: the sweep launches are the persistent kernel's, the all-loci steps sampler.hpp's)
+  if (s->generic) return BPA_SAMPLER_GENERIC;
+  if (s->v2_ok && !s->env_trace) return s->allreduce ? BPA_SAMPLER_HYBRID : BPA_SAMPLER_PERSISTENT;
+  return BPA_SAMPLER_SWEEP;
 }
 
 extern "C" int bpa_sampler_summary(bpa_sampler_t * s, double * total_lnl, unsigned long * proposals,

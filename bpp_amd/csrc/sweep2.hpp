@@ -77,6 +77,9 @@ struct Args
   uint32_t niter, nsteps_gage, nsteps_gspr, theta_mask, do_allloci, dbg;
   double bfbeta;
   double * prof, * declog;
+  // several GPUs (bpa_sampler_set_p2p): every rank's mailbox as mapped here (p2p.hpp: [2][world] slots of slot_bytes,
+  // a sequence flag + values each), this rank's own, the sequence number before this launch's first exchange
+  unsigned char * const * peers; unsigned char * mail; int32_t rank, world; unsigned long long slot_bytes, seq0, spin_limit; int * p2p_err;
   const Species * sp;                    // (device memory: by value it would sit in ~50 SGPRs for the whole launch)
 };
 
@@ -594,6 +597,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     else wg.bad_ = 1u;                                                       // (also NaN): the step is rejected
   };
   uint32_t nx = 0;
+  unsigned long long gseq = A.seq0;                 // several GPUs: the mailboxes' sequence number
   unsigned long long xprev0 = 0, xprev1 = 0;       // wave 0, lane 8 x + k: word k of shard x of each set when its previous use completed
   auto exchange = [&](int nval, int want, double & mine_tot) -> bool
   {
@@ -625,7 +629,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         const unsigned long long t_wait = wall_clock64();
         const unsigned long long prev = par ? xprev1 : xprev0;
         bool ok = true;
-        unsigned long long cur = 0, d = 0;
+        unsigned long long cur = 0, d = 0, gd = 0;
         for (uint32_t rounds = 1;; ++rounds)
         {
           // ONE load: lane 8 x + k reads word k of shard x; the shards' growth since the set's previous use, added up
@@ -636,11 +640,54 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           if ((rounds & 63u) == 0 && wall_clock64() - t_wait > 50000000ull) { ok = false; break; }     // 0.5 s at 100 MHz
           __builtin_amdgcn_s_sleep(1);
         }
+        bool anybad = ok && (__shfl(d, 7, 64) >> 32) != 0;
+        if (ok && A.world > 1)
+        {
+          // ---- several GPUs: this rank's sums (lanes 0..6) and its unusable-term flag (lane 7) go to slot `rank` of
+          // EVERY rank's mailbox over the xGMI peer mappings — workgroup 0 publishes, values first, then the sequence
+          // flag —, and every workgroup adds up the N slots of its own mailbox once their flags show this exchange.
+          // Fixed point: the same total on every rank whatever the order.  Mailboxes alternate by sequence parity.
+          ++gseq;
+          const size_t slot = ((size_t)(gseq & 1ull)*(size_t)A.world)*A.slot_bytes;
+          if (b == 0)
+          {
+            const unsigned long long v = lane < (uint32_t)nv ? d : (lane == 7u && anybad) ? 1ull : 0ull;
+            if (lane < 8u)
+              for (int pr_ = 0; pr_ < A.world; ++pr_)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(A.peers[pr_] + slot + (size_t)A.rank*A.slot_bytes + p2p::HDR) + lane, v,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __builtin_amdgcn_wave_barrier();
+            if (lane < (uint32_t)A.world)
+              __hip_atomic_store(reinterpret_cast<unsigned long long *>(A.peers[lane] + slot + (size_t)A.rank*A.slot_bytes), gseq,
+                                 __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          bool here = true;
+          if (lane < (uint32_t)A.world)
+          {
+            const unsigned long long * f = reinterpret_cast<const unsigned long long *>(A.mail + slot + (size_t)lane*A.slot_bytes);
+            const unsigned long long tw = wall_clock64();
+            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != gseq)
+            {
+              if (wall_clock64() - tw > A.spin_limit) { here = false; break; }
+              __builtin_amdgcn_s_sleep(2);
+            }
+          }
+          if (!__all(here ? 1 : 0)) { ok = false; if (lane == 0) *A.p2p_err = 1; }
+          else
+          {
+            unsigned long long tot = 0;
+            for (int r = 0; r < A.world; ++r)
+              tot += __hip_atomic_load(reinterpret_cast<const unsigned long long *>(A.mail + slot + (size_t)r*A.slot_bytes + p2p::HDR) + (lane & 7u),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            gd = tot; anybad = __shfl(tot, 7, 64) != 0;
+          }
+        }
         XT(3);
         if (ok)
         {
-          const bool anybad = (__shfl(d, 7, 64) >> 32) != 0;
-          if (lane < (uint32_t)nv) wg.xtot[v0 + (int)lane] = anybad ? __longlong_as_double(0x7ff8000000000000ll) : (double)(long long)d*(1.0/FX);
+          const unsigned long long dd = A.world > 1 ? gd : d;
+          if (lane < (uint32_t)nv) wg.xtot[v0 + (int)lane] = anybad ? __longlong_as_double(0x7ff8000000000000ll) : (double)(long long)dd*(1.0/FX);
           if (par) xprev1 = cur; else xprev0 = cur;
           if (lane == 0) wg.bad_ = 0;
         }

@@ -301,6 +301,15 @@ int  bpa_sampler_get_taus(bpa_sampler_t *, double * tau);     /* 2*species-1 ent
 typedef int (*bpa_allreduce_fn)(void * ctx, double * device_sums, unsigned count, void * stream);
 int  bpa_sampler_set_allreduce(bpa_sampler_t *, bpa_allreduce_fn fn, void * ctx, double * device_sums,
                                unsigned first_locus);
+/* The same with the exchange INSIDE the persistent iteration kernel (no callback, no launch boundary): `p2p` is a
+   connected bpa_p2p_t of this engine (below: mailboxes in every rank's memory, mapped over xGMI).  After its own
+   workgroups' sums are complete a rank stores them — 2^-40 fixed point, so the total is the same on every rank whatever
+   the order — into its slot of every rank's mailbox, raises the slot's sequence flag, and every workgroup adds up the N
+   slots of its own mailbox once their flags show the exchange.  Waits are bounded by bpa_p2p_set_timeout; a time-out is
+   reported by the next call that reads the sampler's state.  Needs the persistent kernel (bpa_sampler_kind); every
+   rank must call bpa_sampler_iterate with the same counts.  NULL takes it out again.                                  */
+struct bpa_p2p;
+int  bpa_sampler_set_p2p(bpa_sampler_t *, struct bpa_p2p * p2p, unsigned first_locus);
 int  bpa_sampler_initialize(bpa_sampler_t *);                 /* all matrices, partials, lnL */
 int  bpa_sampler_iterate(bpa_sampler_t *, unsigned iterations); /* asynchronous on the engine stream */
 /* current state of locus i (any output may be NULL); asking for locus 0 refreshes the host copy */
@@ -338,6 +347,8 @@ int  bpa_sampler_work(bpa_sampler_t *, double * bytes, unsigned long * node_upda
 #define BPA_SAMPLER_SWEEP      0
 #define BPA_SAMPLER_GENERIC    1
 #define BPA_SAMPLER_PERSISTENT 2
+#define BPA_SAMPLER_HYBRID     3       /* an all-reduce callback is installed (several ranks): the per-locus sweep of an iteration is
+                                          ONE launch of the persistent kernel, the all-loci steps one launch each of csrc/sampler.hpp's */
 int  bpa_sampler_kind(bpa_sampler_t *);
 
 /* ------------------------------------------------------ work / measurement --- */

@@ -33,7 +33,16 @@ def main():
         dist.all_reduce(t[:count])
         torch.cuda.synchronize()
         return True
-    if world > 1:
+    p2p = None
+    if world > 1 and os.environ.get("DIST_P2P"):
+        # the sums exchanged INSIDE the persistent kernel over peer-mapped mailboxes (the handles travel over gloo)
+        p2p = bpp_amd.P2P(eng, rank, world, 64)
+        handles = [None] * world
+        dist.all_gather_object(handles, p2p.handle)
+        p2p.connect(handles)
+        p2p.set_timeout_ms(20000)                # (two processes time-share the one test GPU)
+        smp.set_p2p(p2p, first)
+    elif world > 1:
         smp.set_allreduce(allreduce, t.data_ptr(), first)
     if os.environ.get("DIST_MIXED"):
         # three species ((0,1),2); the gene tips A,B,C,D sit in species 0,0,1,2 in the first half of the loci and in
@@ -54,12 +63,16 @@ def main():
     smp.set_finetune(0.003, 0.005, 0.0008, 0.2)
     smp.initialize()
     smp.iterate(4 if gtr else 12)
-    res = dict(rank=rank, first=first, taus=smp.taus(), thetas=smp.thetas(), summary=smp.summary(),
+    res = dict(rank=rank, first=first, kind=smp.kind(), taus=smp.taus(), thetas=smp.thetas(), summary=smp.summary(),
                times=[[float(x) for x in smp.tree(i)["time"]] for i in range(per)],
                lnl=[smp.tree(i)["lnl"] for i in range(per)])
     with open(f"{out}.{rank}.json", "w") as f:
         json.dump(res, f)
-    smp.close(); eng.close()
+    smp.close()
+    if p2p is not None:
+        dist.barrier()
+        p2p.close()
+    eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

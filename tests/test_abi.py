@@ -114,3 +114,14 @@ def test_host_driver_library_exports():
     assert "a00_iterate" in names and "a00_backend_hip" in names
     for n in names:
         assert hasattr(L, n), n
+
+
+def test_rccl_header_symbols_exported():
+    """include/bpp_amd_rccl.h (the several-GPU exchange as native code, a library of its own: libbpp_amd_rccl.so)"""
+    src = open(os.path.join(ROOT, "include", "bpp_amd_rccl.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(bpa_rccl_[a-z0-9_]+)\s*\(", src)))
+    L = bpp_amd.RcclExchange.lib()
+    assert len(names) == 7
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/bpp_amd_rccl.h but not exported"

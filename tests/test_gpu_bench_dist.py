@@ -34,8 +34,10 @@ def test_two_rank_bench_line(scaling, p2p):
     d, err = run_bench(["--scaling", scaling] + (["--p2p-sums"] if p2p else []))
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == scaling and d["value"] > 0
     assert d["allreduce_check"] == "ok"
-    assert ("p2p" in d["allreduce"]) == p2p, (d["allreduce"], err[-1500:])
-    assert d["roofline"]["frac"] > 0 and "sweep_kernel" in d["roofline"]["kernel"] and d["cpu_baseline"] is None
+    assert ("p2p" in d["allreduce"]["tape"]) == p2p, (d["allreduce"], err[-1500:])
+    # the sampler's sums travel inside its persistent kernel through the peer-mapped mailboxes whenever those passed their self-test
+    assert "persistent kernel" in d["allreduce"]["sampler"] and d["device_resident_sampler"]["implementation"].startswith("persistent"), d["allreduce"]
+    assert d["roofline"]["frac"] > 0 and "iter_kernel" in d["roofline"]["kernel"] and d["cpu_baseline"] is None
     smp, tp = d["device_resident_sampler"], d["likelihood_only"]
     # strong: the 1 500 loci are shared out (750 each); weak: 1 500 per rank
     total = 1500 if scaling == "strong" else 3000

@@ -73,3 +73,21 @@ def test_two_ranks_generic_sampler_with_parameter_moves(tmp_path):
     for a, b in zip(times, one["times"]):
         assert np.allclose(a, b, rtol=1e-10, atol=0)
     assert np.allclose(lnl, one["lnl"], rtol=1e-10, atol=0)
+
+
+def test_two_ranks_exchange_inside_the_persistent_kernel(tmp_path):
+    """bpa_sampler_set_p2p: both ranks run the persistent iteration kernel for the whole call and exchange the all-loci
+    steps' sums inside it, through each other's mailboxes (here: two processes on the one GPU, the mailboxes mapped
+    through hipIpc handles) — the single-rank trajectory again"""
+    one = run(1, str(tmp_path / "one"), 29911)[0]
+    two = run(2, str(tmp_path / "two"), 29912 + os.getpid() % 500, DIST_P2P="1")
+    assert one["kind"] == "persistent" and all(r["kind"] == "persistent" for r in two)
+    assert two[0]["taus"] == two[1]["taus"] and two[0]["thetas"] == two[1]["thetas"]
+    for r in two:
+        assert np.allclose(r["taus"], one["taus"], rtol=1e-10, atol=0) and r["taus"] != [0, 0, 0, 0, 0.001, 0.002, 0.003]
+        assert np.allclose(r["thetas"], one["thetas"], rtol=1e-10, atol=0)
+    lnl = two[0]["lnl"] + two[1]["lnl"]
+    assert np.allclose(lnl, one["lnl"], rtol=1e-10, atol=0)
+    times = two[0]["times"] + two[1]["times"]
+    for a, b in zip(times, one["times"]):
+        assert np.allclose(a, b, rtol=1e-10, atol=0)

@@ -425,10 +425,11 @@ def test_against_the_reference_itself(engine, spec):
     rl.free()
 
 
-@pytest.mark.parametrize("kernel", ["tiledk", "pipe2c", "pipe3", "pipe3c", "mfmak", "mfma", "tiled", "tiledk1", "tiledkb", "tiledknt", "tiledk2", "scalarp", "scalark", "generic"])
+@pytest.mark.parametrize("kernel", ["mfmak", "tiled", "generic"])
 def test_20_state_kernel_variants_are_bit_exact(engine, monkeypatch, kernel):
-    """every 20-state node-update kernel (BPA_S20_KERNEL; the FP64-MFMA ones included) reproduces the
-    reference's AVX2 summation order exactly: same CLVs, scalers and lnL bits as the default kernel"""
+    """every 20-state node-update kernel kept next to the default (BPA_S20_KERNEL: the FP64-MFMA one, the one-wave
+    fall-back of loci with more than 4 categories, the unstaged one) reproduces the reference's AVX2 summation order
+    exactly: same CLVs, scalers and lnL bits as the default pipelined kernel"""
     c = load_golden("loci.json")
     for idx in (6, 7, 11):                      # the three 20-state golden loci (11: with scaling)
         case = c[idx]

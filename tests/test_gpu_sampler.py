@@ -125,6 +125,7 @@ def test_sweeps_of_the_persistent_kernel_between_one_launch_all_loci_steps(monke
         smp.initialize()
         return smp
     hyb, old = make(False), make(True)
+    assert hyb.kind() == "hybrid" and old.kind() == "sweep"
     for call in range(8):
         hyb.iterate(3); old.iterate(3)
         a, b = hyb.summary(), old.summary()
@@ -228,3 +229,36 @@ def test_sampler_rejects_unsupported_loci(engine):
     loci = tape.make_engine_loci(engine, mixed)
     with pytest.raises(bpp_amd.BpaError, match="all be JC69"):
         bpp_amd.Sampler(engine, loci, mixed)
+
+
+def test_native_rccl_callback(monkeypatch):
+    """the several-GPU exchange as native code (include/bpp_amd_rccl.h, libbpp_amd_rccl.so): ncclAllReduce on the
+    engine's stream behind bpa_allreduce_fn — no Python inside bpa_sampler_iterate.  A one-rank communicator (two ranks
+    cannot share the test box's single GPU under RCCL; the two-process tests use gloo): the sums come back unchanged, so
+    the sampler walks the single-GPU trajectory, and every all-loci step went through the collective"""
+    eng = bpp_amd.Engine(0)
+    data = synth.make_dataset(300, 400, 4, "jc69", 1, seed=13)
+    x = bpp_amd.RcclExchange(bpp_amd.RcclExchange.unique_id(), 1, 0, 0)
+
+    def make(v1, native):
+        if v1:
+            monkeypatch.setenv("BPA_SMP_V1", "1")
+        else:
+            monkeypatch.delenv("BPA_SMP_V1", raising=False)
+        smp = bpp_amd.Sampler(eng, tape.make_engine_loci(eng, data), data, seed=5)
+        if native:
+            smp.set_allreduce_native(x, None, 0)
+        parent, tau0, thetas = synth.species_tree_arrays(4)
+        smp.set_species_tree(parent, tau0, thetas)
+        smp.set_tau_prior(3.0, 1000.0); smp.set_theta_prior(2.0, 1000.0, 0.001); smp.set_finetune(0.003, 0.005, 0.0008, 0.2)
+        smp.initialize()
+        return smp
+    nat, ref = make(False, True), make(True, False)
+    c0 = x.calls()
+    for call in range(4):
+        nat.iterate(3); ref.iterate(3)
+        a, b = nat.summary(), ref.summary()
+        assert (a["proposals"], a["accepted"]) == (b["proposals"], b["accepted"]), call
+        assert nat.taus() == ref.taus() and nat.thetas() == ref.thetas(), call
+    assert x.calls() - c0 == 12 * (1 + 3 + 1)            # THETA (all populations in one collective), 3 TAU, MIX per iteration
+    nat.close(); ref.close(); x.close(); eng.close()
