@@ -44,7 +44,9 @@ CONFIGS = {
                name="C2: A00, 10000 loci x 1000 sites, 4 taxa, JC69, 1 rate cat"),
     "c3": dict(taxa=8, model="gtr", rate_cats=4, sites=1000, loci=10000, taus=(0.0011, 0.0025, 0.005),
                name="C3: A00, 10000 loci x 1000 sites, 8 taxa, GTR+G4"),
-    "c4": dict(taxa=6, model="lg", rate_cats=4, sites=500, loci=2000, taus=(0.01, 0.015, 0.02, 0.035, 0.05),
+    # divergence 3: theta 0.06, tau_root 0.15 — ~195 distinct patterns per locus, the per-locus work BASELINE.md's reference
+    # row was measured on (its ad-hoc alignment: ~200); SURVEY 8d's literal theta 0.02 / tau_root 0.05 gives 105 (--c4-divergence 1)
+    "c4": dict(taxa=6, model="lg", rate_cats=4, sites=500, loci=2000, taus=(0.01, 0.015, 0.02, 0.035, 0.05), divergence=3.0,
                name="C4: A00, 2000 loci x 500 aa sites, 6 taxa, LG+G4"),
 }
 
@@ -394,7 +396,7 @@ def run_tape(eng, cfg, config_key, data, loci, args, D, steps, warmup):
         R_ = cfg["rate_cats"]
         subst = dict(freqs=[d["freqs"] for d in data], exch=[d["exch"] for d in data], alpha=[0.5] * nloci, rate_cats=R_,
                      gamma=lambda a, cats: bpp_amd.compute_gamma_cats(a, a, cats) if cats > 1 else np.ones(1))
-    sch = A00Schedule(trees, seed=1 + rank, taus=cfg["taus"], subst=subst)
+    sch = A00Schedule(trees, seed=1 + rank, taus=tuple(t * cfg.get("divergence", 1.0) for t in cfg["taus"]), subst=subst)
     init = sch.initial_step()
     iters = [sch.iteration() for _ in range(args.tape_iters)]
     log(f"{config_key} tape: {args.tape_iters} iterations x {len(iters[0])} batched steps in {time.time() - t0:.1f}s")
@@ -769,6 +771,8 @@ def main():
     ap.add_argument("--p2p-sums", action="store_true",
                     help="N > 1: exchange the sums with the one-shot p2p all-reduce over xGMI peer mappings (self-tested "
                          "against RCCL at start-up) instead of RCCL (torch.distributed), the default")
+    ap.add_argument("--c4-divergence", type=float, default=None,
+                    help="config 4: divergence factor of the synthetic amino-acid set (default 3: ~195 patterns per locus; 1: SURVEY 8d's literal theta 0.02 / tau_root 0.05, 105 patterns)")
     ap.add_argument("--no-p2p", action="store_true",
                     help="N > 1: no peer-mapped mailboxes at all — the sampler then runs its all-loci steps one launch each with a "
                          "native RCCL all-reduce in between (the persistent kernel only for the per-locus sweeps)")
@@ -787,6 +791,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world == 1 and args.gpus > 1:
         sys.exit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.c4_divergence is not None:
+        CONFIGS["c4"]["divergence"] = args.c4_divergence
     cfg = CONFIGS[args.config]
     nloci_cfg = args.loci or cfg["loci"]
 
@@ -804,13 +810,13 @@ def main():
     first_locus = 0
     if args.scaling == "strong" and world > 1:
         # ONE data set; the reference's zig-zag deal by work = tips x patterns (threads.c:265-353)
-        full = synth.make_dataset(nloci_cfg, cfg["sites"], cfg["taxa"], cfg["model"], cfg["rate_cats"], seed=12345)
+        full = synth.make_dataset(nloci_cfg, cfg["sites"], cfg["taxa"], cfg["model"], cfg["rate_cats"], seed=12345, divergence=cfg.get("divergence", 1.0))
         mine = shard.partition([len(d["seqs"]) * len(d["weights"]) for d in full], world)[rank]
         data = [full[i] for i in mine]
         first_locus = int(1 << 20) * rank          # distinct per-locus random streams on every rank
         del full
     else:
-        data = synth.make_dataset(nloci_cfg, cfg["sites"], cfg["taxa"], cfg["model"], cfg["rate_cats"], seed=12345 + 1000 * rank)
+        data = synth.make_dataset(nloci_cfg, cfg["sites"], cfg["taxa"], cfg["model"], cfg["rate_cats"], seed=12345 + 1000 * rank, divergence=cfg.get("divergence", 1.0))
         first_locus = rank * nloci_cfg
     nloci = len(data)
     npat = sum(len(d["weights"]) for d in data)
@@ -877,7 +883,7 @@ def main():
                 oc = CONFIGS[key]
                 t0 = time.time()
                 e2 = bpp_amd.Engine(local_rank, None)
-                d2 = synth.make_dataset(oc["loci"], oc["sites"], oc["taxa"], oc["model"], oc["rate_cats"], seed=12345)
+                d2 = synth.make_dataset(oc["loci"], oc["sites"], oc["taxa"], oc["model"], oc["rate_cats"], seed=12345, divergence=oc.get("divergence", 1.0))
                 l2 = make_loci(e2, d2)
                 a2 = argparse.Namespace(**vars(args))
                 a2.tape_iters = 2

@@ -163,15 +163,22 @@ def lg_model():
     return np.array(g["rates"]), np.array(g["freqs"])
 
 
+def scaled_tree(t, f):
+    """SPECIES_TREES entry with every divergence time x f"""
+    return t if isinstance(t, str) else (scaled_tree(t[0], f), scaled_tree(t[1], f), t[2]*f)
+
+
 def make_dataset(nloci, sites, taxa=4, model="jc69", rate_cats=1, alpha=0.5, theta=None, seed=12345,
-                 freqs=None, exch=None):
-    """returns a list of loci: dict(seqs (compressed), weights, left, right, times, root, ...)"""
+                 freqs=None, exch=None, divergence=1.0):
+    """returns a list of loci: dict(seqs (compressed), weights, left, right, times, root, ...).
+    divergence: every tau of SPECIES_TREES[taxa] and the default theta times this factor (more substitutions per site:
+    more distinct site patterns per locus)"""
     rng = np.random.default_rng(seed)
-    stree = SPECIES_TREES[taxa]
+    stree = scaled_tree(SPECIES_TREES[taxa], divergence)
     dna = model in ("jc69", "gtr")
     S = 4 if dna else 20
     if theta is None:
-        theta = 0.002 if dna else 0.02
+        theta = (0.002 if dna else 0.02)*divergence
     if model == "jc69":
         freqs, exch = np.full(4, 0.25), np.ones(6)
     elif model == "gtr":
