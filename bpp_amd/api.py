@@ -149,6 +149,7 @@ def lib():
         "bpa_sampler_work": (i, [vp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
         "bpa_sampler_kind": (i, [vp]),
         "bpa_sampler_set_p2p": (i, [vp, vp, u]),
+        "bpa_sampler_set_proposal_kernel": (i, [vp, i]),
         "bpa_engine_enable_timing": (None, [vp, i]),
         "bpa_engine_set_timing_stride": (None, [vp, u]),
         "bpa_engine_timing": (i, [vp, dp, dp, dp, C.POINTER(C.c_ulong)]),
@@ -183,7 +184,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_sampler_set_tau_prior", "bpa_sampler_get_taus", "bpa_sampler_get_tree_msc",
             "bpa_sampler_set_theta_prior", "bpa_sampler_get_thetas", "bpa_sampler_set_allreduce",
             "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary",
-            "bpa_sampler_enable_timing", "bpa_sampler_timing", "bpa_sampler_work", "bpa_sampler_kind", "bpa_sampler_set_p2p",
+            "bpa_sampler_enable_timing", "bpa_sampler_timing", "bpa_sampler_work", "bpa_sampler_kind", "bpa_sampler_set_p2p", "bpa_sampler_set_proposal_kernel",
             "bpa_sampler_set_subst_model", "bpa_sampler_get_subst_model", "bpa_sampler_set_subst_moves"]
 
 
@@ -574,6 +575,10 @@ class Sampler:
 
     def set_finetune(self, gage, gspr, tau, mix):
         lib().bpa_sampler_set_finetune(self.h, gage, gspr, tau, mix)
+
+    def set_proposal_kernel(self, kind):
+        """0 uniform windows on our streams (default), 1 BPP's legacy_rndu + Bactrian-Laplace (before initialize)"""
+        _chk(lib().bpa_sampler_set_proposal_kernel(self.h, int(kind)))
 
     def set_tau_prior(self, alpha, beta):
         lib().bpa_sampler_set_tau_prior(self.h, alpha, beta)

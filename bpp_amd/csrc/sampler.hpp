@@ -1172,6 +1172,7 @@ struct bpa_sampler
   DevBuf<double> v2_prof, v2_declog;
   DevBuf<smp::Species> v2_sp;
   smp::Species v2_sp_sent{};            // what v2_sp holds
+  bool kernel_bpp = false, v2_grng_sent = false;   // BPP's own generator + Bactrian-Laplace windows (bpa_sampler_set_proposal_kernel); the global stream then lives on the device
   bpa_p2p * p2p = nullptr;              // several GPUs, the sums exchanged INSIDE the persistent kernel over xGMI mailboxes (bpa_sampler_set_p2p)
   unsigned long v2_iters = 0;           // iterations run by persistent launches (bpa_sampler_timing)
 };
@@ -1275,12 +1276,33 @@ static int set_tree_fields(TR & t, int tips, const int * left, const int * right
   return 1;
 }
 
+// start state of a stream (index = global locus index, or A00_GLOBAL_STREAM): our 64-bit one, or — BPP's kernel — the
+// 32-bit legacy_rndu state the host driver derives from the same seeding function (a00_create: rng >> 16)
+static a00_rng_t stream_seed(const bpa_sampler * s, unsigned stream)
+{
+  const a00_rng_t z = a00_rng_seed(s->seed, stream);
+  return s->kernel_bpp ? (a00_rng_t)(unsigned int)(z >> 16) : z;
+}
+
+extern "C" int bpa_sampler_set_proposal_kernel(bpa_sampler_t * s, int kind)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (kind != BPA_KERNEL_UNIFORM && kind != BPA_KERNEL_BPP) return fail("bpa_sampler_set_proposal_kernel: BPA_KERNEL_UNIFORM or BPA_KERNEL_BPP");
+  if (s->uploaded) return fail("bpa_sampler_set_proposal_kernel: before bpa_sampler_initialize (as a00_set_proposal_kernel)");
+  if (s->generic && kind == BPA_KERNEL_BPP) return fail("bpa_sampler_set_proposal_kernel: BPP's kernel runs in the persistent iteration kernel (JC69 loci of <= 8 tips and <= 64 patterns)");
+  s->kernel_bpp = kind == BPA_KERNEL_BPP;
+  for (unsigned i = 0; i < s->nloci; ++i) s->h_trees[i].rng = stream_seed(s, s->locus_offset + i);
+  s->grng = stream_seed(s, A00_GLOBAL_STREAM);
+  s->v2_grng_sent = false;
+  return 1;
+}
+
 extern "C" int bpa_sampler_set_tree(bpa_sampler_t * s, unsigned i, const int * left, const int * right,
                                     const double * times, int root)
 {
   if (i >= s->nloci) return fail("bpa_sampler_set_tree: locus index out of range");
   const int tips = (int)s->loci[i]->tips;
-  const a00_rng_t rng = a00_rng_seed(s->seed, s->locus_offset + i);
+  const a00_rng_t rng = stream_seed(s, s->locus_offset + i);
   if (!sampler_invalidate(s)) return 0;
   if (s->generic) return set_tree_fields<gsm::GTree, gsm::NN>(s->g_trees[i], tips, left, right, times, root, rng);
   return set_tree_fields<smp::Tree, smp::MAXN>(s->h_trees[i], tips, left, right, times, root, rng);
@@ -1380,8 +1402,12 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
       !upload(s->v2_err, &zero, 1) || !s->v2_prof.reserve(16 + (size_t)nwg) || !s->v2_declog.reserve(4*2048) || !s->v2_sp.reserve(1))
     return 0;
   HIPCHK(hipMemset(s->v2_prof.p, 0, (16 + (size_t)nwg)*sizeof(double)));
-  void (*kern)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4> : smp2::iter_kernel<8>;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->v2_lds));
+  {
+    void (*k0)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4, false> : smp2::iter_kernel<8, false>;
+    void (*k1)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4, true> : smp2::iter_kernel<8, true>;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->v2_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->v2_lds));
+  }
   std::memset(&s->v2_sp_sent, 0xff, sizeof s->v2_sp_sent);       // (nothing sent yet)
   s->v2_ok = true;
   return 1;
@@ -1710,7 +1736,7 @@ extern "C" int bpa_sampler_set_allreduce(bpa_sampler_t * s, bpa_allreduce_fn fn,
     if (!sampler_invalidate(s)) return 0;
     s->locus_offset = first_locus;
     for (unsigned i = 0; i < s->nloci; ++i)
-      (s->generic ? s->g_trees[i].rng : s->h_trees[i].rng) = a00_rng_seed(s->seed, first_locus + i);
+      (s->generic ? s->g_trees[i].rng : s->h_trees[i].rng) = stream_seed(s, first_locus + i);
     s->uploaded = false;
   }
   return 1;
@@ -1730,7 +1756,8 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
   // exchanges of an iteration: THETA in chunks of 7 populations, one per TAU, one for MIX (sweep2.hpp: exchange)
   const unsigned x_per_iter = allloci ? (theta_mask ? ((unsigned)npop + 6u)/7u : 0u) + (unsigned)(npop - S) + 1u : 0u;
   const unsigned draws_per_iter = allloci ? 2u*(unsigned)__builtin_popcount(theta_mask) + 2u*(unsigned)(npop - S) + 2u : 0u;
-  void (*kern)(const smp2::Args) = s->v2_nt == 4 ? smp2::iter_kernel<4> : smp2::iter_kernel<8>;
+  void (*kern)(const smp2::Args) = s->kernel_bpp ? (s->v2_nt == 4 ? smp2::iter_kernel<4, true> : smp2::iter_kernel<8, true>)
+                                                 : (s->v2_nt == 4 ? smp2::iter_kernel<4, false> : smp2::iter_kernel<8, false>);
   const unsigned bs = s->v2_nt == 4 ? smp2::Cfg<4>::BS : smp2::Cfg<8>::BS;
   while (iterations)
   {
@@ -1763,7 +1790,11 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
     if (allloci)
     {
       // (a sweep-only launch draws nothing from the global stream and exchanges nothing)
-      HIPCHK(hipMemcpyAsync(s->v2_grng.p, &s->grng, sizeof(a00_rng_t), hipMemcpyHostToDevice, e->stream));
+      // (BPP's kernel draws a data-dependent count from the global stream — an acceptance number only when needed —, so
+      //  the device's word is the master after the first launch; our kernel's fixed count is mirrored on the host below)
+      if (!s->kernel_bpp || !s->v2_grng_sent)
+        HIPCHK(hipMemcpyAsync(s->v2_grng.p, &s->grng, sizeof(a00_rng_t), hipMemcpyHostToDevice, e->stream));
+      s->v2_grng_sent = true;
       HIPCHK(hipMemsetAsync(s->v2_xbuf.p, 0, (size_t)2*smp2::XN*sizeof(unsigned long long), e->stream));
     }
     if (s->timing_stride && (s->timing_phase++ % s->timing_stride) == 0)
@@ -1778,7 +1809,7 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
       hipLaunchKernelGGL(kern, dim3(s->v2_nwg), dim3(bs), s->v2_lds, e->stream, a);
     HIPCHK(hipGetLastError());
     // the host's copy of the global stream follows the kernel's draws
-    for (unsigned long k = 0; k < (unsigned long)chunk*draws_per_iter; ++k) (void)a00_rndu(&s->grng);
+    if (!s->kernel_bpp) for (unsigned long k = 0; k < (unsigned long)chunk*draws_per_iter; ++k) (void)a00_rndu(&s->grng);
     s->launches++; s->sweeps += chunk; s->v2_iters += chunk;
     iterations -= chunk;
   }
@@ -1795,7 +1826,7 @@ extern "C" int bpa_sampler_set_p2p(bpa_sampler_t * s, bpa_p2p_t * p, unsigned fi
   if (first_locus != s->locus_offset)
   {
     s->locus_offset = first_locus;
-    for (unsigned i = 0; i < s->nloci; ++i) s->h_trees[i].rng = a00_rng_seed(s->seed, first_locus + i);
+    for (unsigned i = 0; i < s->nloci; ++i) s->h_trees[i].rng = stream_seed(s, first_locus + i);
   }
   return 1;
 }
@@ -1808,6 +1839,7 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
   s->host_current = false;
   if (s->generic) return gs_iterate(s, iterations);
   if (s->v2_ok && !s->allreduce && !s->env_trace) return sampler_iterate_v2(s, iterations, true);
+  if (s->kernel_bpp) return fail("bpa_sampler: BPP's proposal kernel runs in the persistent iteration kernel only (one GPU, or several with bpa_sampler_set_p2p)");
   // several ranks: the per-locus sweep by the persistent kernel (one launch), the all-loci steps one launch each
   const bool v2_sweep = s->v2_ok && !s->env_trace;
   const bool fused = s->fuse_decision && !s->allreduce && !s->env_trace;      // (several GPUs: sum -> all-reduce -> decide)

@@ -181,15 +181,52 @@ struct PopLane
 // the proposal of one per-locus step, as left by propose_*: what to recompute
 struct Prop { uint32_t chain, brm, ndm; double hast; };
 
+// The two proposal kernels of a00_driver.c (bpp_amd_host.h: A00_KERNEL_UNIFORM / A00_KERNEL_BPP), per stream:
+//   uniform  our 64-bit streams (a00_rndu), a window = finetune x (u - 1/2), the acceptance number always drawn;
+//   BPP      the reference's own: legacy_rndu (z = 69069 z + 1 on 32 bits, random.c:104-122) and, for a window,
+//            legacy_rnd_symmetrical = the Bactrian-Laplace variate (m = 0.90: random.c:192-238), mean 0, variance 1, two
+//            draws; a proposal that cannot be made draws nothing, the acceptance number is drawn only when needed
+//            (lnacc < -1e-10: gtree.c:5476, stree.c:6286).  The state lives in the low 32 bits of the stream word.
+template <bool BPP> struct Stream
+{
+  a00_rng_t r;
+  __device__ __forceinline__ double u()
+  {
+    if (!BPP) return rndu(&r);
+    uint32_t z = (uint32_t)r*69069u + 1u;
+    if (z == 0u) z = 12345671u;
+    r = z;
+    return (double)z*(1.0/4294967296.0);                    // ldexp(z, -32), exact
+  }
+  // a sliding-window step in units of the finetune
+  __device__ __forceinline__ double window()
+  {
+    if (!BPP) return rndu(&r) - 0.5;
+    const double uu = u() - 0.5;
+    const double rr = log(1 - 2*fabs(uu))*0.70710678118654752440;
+    const double lap = uu >= 0 ? -rr : rr;
+    double v = 0.90 + lap*sqrt(1 - 0.90*0.90);
+    if (u() < 0.5) v = -v;
+    return v;
+  }
+  __device__ __forceinline__ void skip() { if (!BPP) (void)rndu(&r); }
+  __device__ __forceinline__ bool accept(double lnacc)
+  {
+    if (BPP) return lnacc >= -1e-10 || u() < exp(lnacc);
+    const double uu = rndu(&r);
+    return lnacc >= 0 || uu < exp(lnacc);
+  }
+};
+
 // GAGE on the k-th inner node (gage_step of a00_driver.c; propose_ages, gtree.c:4585) — all lanes of the group
-template <int NT>
-__device__ __forceinline__ bool propose_gage(GTree<NT> & t, a00_rng_t & rng, double * time, int k, const PopLane & pl,
+template <int NT, bool BPP>
+__device__ __forceinline__ bool propose_gage(GTree<NT> & t, Stream<BPP> & rng, double * time, int k, const PopLane & pl,
                                              const uint32_t * anc, const double * tau, double ft, int li, uint32_t gbase, Prop & pr)
 {
   constexpr int G = Cfg<NT>::G;
   const int n = 2*t.tips - 1, v = t.tips + k;
   if (v >= n) return false;
-  const double u = rndu(&rng);
+  const double u = rng.window();
   const int l = t.left[v], r = t.right[v], p = t.parent[v];
   const double tl = time[l], tr = time[r], told = time[v], tpar = time[p < 0 ? 0 : p];
   const int pol = t.pop[l], por = t.pop[r];
@@ -197,8 +234,8 @@ __device__ __forceinline__ bool propose_gage(GTree<NT> & t, a00_rng_t & rng, dou
   double lo = fmax(tl, tr);
   if (pol != por) lo = fmax(lo, tau[__ffs(al & ar) - 1]);          // the youngest common ancestor: the lowest common bit
   const double hi = p >= 0 ? tpar : 999.0;
-  if (!(hi > lo)) { (void)rndu(&rng); return false; }
-  const double tnew = reflect(told + ft*(u - 0.5), lo, hi);
+  if (!(hi > lo)) { rng.skip(); return false; }
+  const double tnew = reflect(told + ft*u, lo, hi);
   const int oldpop = t.pop[v];
   time[v] = tnew;
   // climb (gtree.c:4790-4797): the highest ancestor-or-self of the left child's population that has started by tnew
@@ -219,8 +256,8 @@ __device__ __forceinline__ bool propose_gage(GTree<NT> & t, a00_rng_t & rng, dou
 }
 
 // GSPR on the k-th non-root node (gspr_step of a00_driver.c; propose_spr, gtree.c:6531) — all lanes of the group
-template <int NT>
-__device__ __forceinline__ bool propose_gspr(GTree<NT> & t, a00_rng_t & rng, double * time, int k, const PopLane & pl, int gl_i,
+template <int NT, bool BPP>
+__device__ __forceinline__ bool propose_gspr(GTree<NT> & t, Stream<BPP> & rng, double * time, int k, const PopLane & pl, int gl_i,
                                              const uint32_t * anc, const double * tau, const double * lograt, double ft,
                                              int li, uint32_t gbase, Prop & pr)
 {
@@ -228,7 +265,7 @@ __device__ __forceinline__ bool propose_gspr(GTree<NT> & t, a00_rng_t & rng, dou
   const int n = 2*t.tips - 1;
   const int a = k < t.root ? k : k + 1;
   if (a >= n) return false;
-  const double u1 = rndu(&rng), u2 = rndu(&rng);
+  const double u1 = rng.window(), u2 = rng.u();
   const int root_before = t.root;
   const int p = t.parent[a], lp = t.left[p], s = lp == a ? (int)t.right[p] : lp, g = t.parent[p];
   // gene tips below a: lane i walks up from node i
@@ -246,7 +283,7 @@ __device__ __forceinline__ bool propose_gspr(GTree<NT> & t, a00_rng_t & rng, dou
   const int pop0 = __ffs(gballot<G>(((apa >> li) & 1u) && (gl_i > leaves || pl.parent < 0), gbase)) - 1;
   const double ta = time[a], tpo = time[p], troot = time[root_before];
   const double lo = fmax(ta, tau[pop0]);
-  const double tnew = reflect(tpo + ft*(u1 - 0.5), lo, 999.0);
+  const double tnew = reflect(tpo + ft*u1, lo, 999.0);
   const int popt = 31 - __clz(gballot<G>(li == popa || (((apa >> li) & 1u) && pl.tau <= tnew), gbase));
   // targets (bit j = branch above node j; the father's own branch stands for the sibling's) and sources: lane j looks at node j
   uint32_t tmask; int nsrc;
@@ -262,7 +299,7 @@ __device__ __forceinline__ bool propose_gspr(GTree<NT> & t, a00_rng_t & rng, dou
     if (above_root) tmask = 1u << root_before;
   }
   const int ntg = __popc(tmask);
-  if (!ntg) { (void)rndu(&rng); return false; }
+  if (!ntg) { rng.skip(); return false; }
   int pick = (int)(u2*ntg);
   if (pick == ntg) pick = 0;
   int tgt = nth_bit(tmask, pick);
@@ -304,7 +341,7 @@ __device__ __forceinline__ bool propose_gspr(GTree<NT> & t, a00_rng_t & rng, dou
   return true;
 }
 
-template <int NT>
+template <int NT, bool BPP>
 __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
 {
   using C = Cfg<NT>;
@@ -349,14 +386,14 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     pl.ptau = pl.parent >= 0 ? wg.tau[pl.parent] : -1.0;
   };
   load_pop();
-  a00_rng_t grng = *A.grng;
+  Stream<BPP> grng{*A.grng};
 
   // ---- load: the loci of this wave
   const uint32_t t0 = gw < A.nwaves ? A.wave_off[gw] : 0u, nt = gw < A.nwaves ? A.wave_off[gw + 1] - t0 : 0u;
   const bool act = slot < nt;
   const uint32_t task = t0 + (act ? slot : 0u);
   GTree<NT> T;
-  a00_rng_t rng = 0;
+  Stream<BPP> rng{0};
   double lnl_cur = 0, logpr_cur = 0;
   uint32_t np = 0, pb = 0, nprop_done = 0, nacc = 0, w_nupd = 0, w_nbr = 0, a_nupd = 0, a_nbr = 0, a_neval = 0;
   int gl_i = 0;
@@ -382,7 +419,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       T.left.w[k] = reinterpret_cast<const uint32_t *>(tr.left)[k]; T.right.w[k] = reinterpret_cast<const uint32_t *>(tr.right)[k];
       T.parent.w[k] = reinterpret_cast<const uint32_t *>(tr.parent)[k]; T.pop.w[k] = reinterpret_cast<const uint32_t *>(tr.pop)[k];
     }
-    T.root = tr.root; T.tips = tr.tips; rng = cur.rng; lnl_cur = tr.lnl; logpr_cur = tr.logpr;
+    T.root = tr.root; T.tips = tr.tips; rng.r = cur.rng; lnl_cur = tr.lnl; logpr_cur = tr.logpr;
     const int n = 2*T.tips - 1;
     T.cf = gballot<G>(li >= T.tips && li < n && tr.clv[li] != li, gbase);
     T.pf = gballot<G>(li < n && tr.pmat[li] != li, gbase);
@@ -721,8 +758,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       const double tsave = S.time[li];
       Prop pr{0, 0, 0, 0.0};
       const bool ok = step < A.nsteps_gage
-        ? propose_gage<NT>(T, rng, S.time, (int)step, pl, wg.anc, wg.tau, SP.ft_gage, li, gbase, pr)
-        : propose_gspr<NT>(T, rng, S.time, (int)(step - A.nsteps_gage), pl, gl_i, wg.anc, wg.tau, wg.lograt, SP.ft_gspr, li, gbase, pr);
+        ? propose_gage<NT, BPP>(T, rng, S.time, (int)step, pl, wg.anc, wg.tau, SP.ft_gage, li, gbase, pr)
+        : propose_gspr<NT, BPP>(T, rng, S.time, (int)(step - A.nsteps_gage), pl, gl_i, wg.anc, wg.tau, wg.lograt, SP.ft_gspr, li, gbase, pr);
       SMP2_TICK(0);
       if (ok)
       {
@@ -732,9 +769,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         SMP2_TICK(1);
         w_nupd += (uint32_t)nops; w_nbr += (uint32_t)__popc(pr.brm);
         const double lnacc = (lp_new - logpr_cur) + (lnl - lnl_cur) + pr.hast;
-        const double u = rndu(&rng);
         ++nprop_done;
-        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; commit_density(pr.chain); }
+        if (rng.accept(lnacc)) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; commit_density(pr.chain); }
         else { T = U; S.time[li] = tsave; }
         wsync();
         SMP2_TICK(2);
@@ -747,30 +783,52 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     // ================= THETA: every population that can hold a coalescence, decided independently (theta_step_all)
     if (SP.theta_alpha > 0 && A.theta_mask)
     {
-      double win_u = 0, uacc = 0;
+      // the windows of all populations first (theta_step_all of a00_driver.c: the uniform kernel draws the acceptance
+      // number right behind each window, BPP's kernel only when a decision needs it)
+      double win = 0, uacc = -1.0;
       for (int p = 0; p < npop; ++p)
-        if ((A.theta_mask >> p) & 1u) { const double a_ = rndu(&grng), b_ = rndu(&grng); if (p == li) { win_u = a_; uacc = b_; } }
+        if ((A.theta_mask >> p) & 1u)
+        {
+          const double w_ = grng.window(), a_ = BPP ? -1.0 : grng.u();
+          if (p == li) { win = w_; uacc = a_; }
+        }
       const bool on = li < npop && ((A.theta_mask >> li) & 1u);
       const double told = pl.theta, l2t_old = pl.l2t;
-      const double tnew = reflect(told + SP.ft_theta*(win_u - 0.5), 0.0, 999.0);
+      const double tnew = reflect(told + SP.ft_theta*win, 0.0, 999.0);
       const double l2t_new = log(2.0/(1.0*tnew));
       if (act && on) fx_add(li, msc_term((int)mync, t2h_cur, tnew, l2t_new) - msc_term((int)mync, t2h_cur, told, l2t_old), false);
       SMP2_TICK(3);
       double th_tot = 0;
       if (!exchange(npop, li, th_tot)) { aborted = true; break; }
       SMP2_TICK(6);
-      // every wave takes the (same) decisions for itself: lane li decides population li
+      // every wave takes the (same) decisions for itself: lane li decides population li; BPP's kernel draws its
+      // acceptance numbers now, in population order, so every lane walks through all of them
       bool accept = false;
-      if (on)
+      double my_lnacc = 0;
+      if (BPP)
       {
-        const double lnacc = th_tot + ((SP.theta_alpha - 1)*log(tnew/told) - SP.theta_beta*(tnew - told));
-        accept = tnew > 0 && (lnacc >= 0 || uacc < exp(lnacc));
+        if (on) { wl.term[li] = tnew; wl.term[16 + li] = told; }
+        wsync();
+        for (int p = 0; p < npop; ++p)
+          if ((A.theta_mask >> p) & 1u)
+          {
+            const double tn = wl.term[p], to = wl.term[16 + p];
+            const double lnacc = wg.xtot[p] + ((SP.theta_alpha - 1)*log(tn/to) - SP.theta_beta*(tn - to));
+            const bool acc = tn > 0 && grng.accept(lnacc);
+            if (p == li) { accept = acc; my_lnacc = lnacc; }
+          }
+        wsync();
+      }
+      else if (on)
+      {
+        my_lnacc = th_tot + ((SP.theta_alpha - 1)*log(tnew/told) - SP.theta_beta*(tnew - told));
+        accept = tnew > 0 && (my_lnacc >= 0 || uacc < exp(my_lnacc));
       }
       if (accept) { pl.theta = tnew; pl.l2t = l2t_new; }
       if (declog && tid < (uint32_t)G && on)
       {
         const uint32_t k = ndec + (uint32_t)__popc(A.theta_mask & ((1u << li) - 1u));
-        if (k < 2048u) { double * r = A.declog + 4*k; r[0] = 100 + li; r[1] = th_tot + ((SP.theta_alpha - 1)*log(tnew/told) - SP.theta_beta*(tnew - told)); r[2] = uacc; r[3] = accept ? 1 : 0; }
+        if (k < 2048u) { double * r = A.declog + 4*k; r[0] = 100 + li; r[1] = my_lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
       }
       ndec += (uint32_t)__popc(A.theta_mask);
       {
@@ -798,14 +856,15 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     {
       const bool mix = stepq == npop;
       const int q = mix ? -1 : stepq;
-      const double uprop = rndu(&grng), uacc = rndu(&grng);
+      // (log c of the mixing step is uniform in both kernels: prop_mixing.c)
+      const double wprop = mix ? grng.u() - 0.5 : grng.window(), uacc = BPP ? -1.0 : grng.u();
       // the proposed species tree: in the lanes' registers only
       double tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1, lminf = 0, lmaxf = 0, tq_new = 0, mix_c = 1, mix_lnc = 0;
       if (!mix)
       {
         const int pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
         tq_old = wg.tau[q]; tq_lo = fmax(wg.tau[cl], wg.tau[cr]); tq_hi = pq >= 0 ? wg.tau[pq] : 999.0;
-        tq_new = reflect(tq_old + SP.ft_tau*(uprop - 0.5), tq_lo, tq_hi);
+        tq_new = reflect(tq_old + SP.ft_tau*wprop, tq_lo, tq_hi);
         minf = (tq_new - tq_lo)/(tq_old - tq_lo); maxf = (tq_new - tq_hi)/(tq_old - tq_hi);
         lminf = log(minf); lmaxf = log(maxf);
         if (li == q) pl.tau = tq_new;
@@ -813,7 +872,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       }
       else
       {
-        mix_lnc = SP.ft_mix*(uprop - 0.5); mix_c = exp(mix_lnc);
+        mix_lnc = SP.ft_mix*wprop; mix_c = exp(mix_lnc);
         pl.tau *= mix_c;
         if (pl.parent >= 0) pl.ptau *= mix_c;
       }
@@ -883,7 +942,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           lnacc += (SP.tau_alpha - 1)*mix_lnc - SP.tau_beta*(troot*mix_c - troot) - (double)(nsp - 2)*mix_lnc;
         }
       }
-      const bool accept = lnacc >= 0 || uacc < exp(lnacc);
+      const bool accept = BPP ? grng.accept(lnacc) : (lnacc >= 0 || uacc < exp(lnacc));
       ++cnt_prop; cnt_acc += accept ? 1u : 0u;
       if (declog && tid == 0 && ndec < 2048u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
       ++ndec;
@@ -923,7 +982,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     if (li < n) { tr.time[li] = S.time[li]; tr.clv[li] = (int8_t)T.cidx(li); tr.pmat[li] = (int8_t)T.pidx(li); }
     if (li == 0)
     {
-      tr.lnl = lnl_cur; tr.logpr = logpr_cur; tr.rng = rng; tr.root = T.root;
+      tr.lnl = lnl_cur; tr.logpr = logpr_cur; tr.rng = rng.r; tr.root = T.root;
       tr.proposals += nprop_done; tr.accepted += nacc; tr.sw_nupd += w_nupd; tr.sw_nbr += w_nbr;
       tr.al_nupd += a_nupd; tr.al_nbr += a_nbr; tr.al_neval += a_neval;
     }
@@ -941,7 +1000,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   }
   if (b == 0 && tid == 0)
   {
-    *A.grng = grng;
+    *A.grng = grng.r;
     A.counters[0] += cnt_prop; A.counters[1] += cnt_acc;
   }
   if (b == 0 && tid < (uint32_t)(3*MAXPOP)) A.taus[tid] = wg.tau[tid];

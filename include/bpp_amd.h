@@ -284,6 +284,16 @@ int  bpa_sampler_set_species_tree(bpa_sampler_t *, int species, const int * pare
                                   const double * theta);
 int  bpa_sampler_set_tip_species(bpa_sampler_t *, unsigned i, const int * species);   /* default: tip k = species k */
 void bpa_sampler_set_finetune(bpa_sampler_t *, double gage, double gspr, double tau, double mix);
+/* which generator and window the moves draw from (a00_set_proposal_kernel of bpp_amd_host.h; before initialize):
+   BPA_KERNEL_UNIFORM (default) our 64-bit streams, window = finetune x (u - 1/2), the acceptance number always drawn;
+   BPA_KERNEL_BPP     the reference's own — legacy_rndu (random.c:104-122) and the Bactrian-Laplace variate of
+                      legacy_rnd_symmetrical (random.c:192-238) for the ages, taus and thetas, acceptance "lnacc >= -1e-10 or
+                      rndu < exp(lnacc)" with the number drawn only when needed (gtree.c:5476, stree.c:6286): the finetunes
+                      then mean what they mean in a BPP control file.  Same trajectory as the host driver with
+                      A00_KERNEL_BPP.  Persistent iteration kernel only (bpa_sampler_kind).                              */
+#define BPA_KERNEL_UNIFORM 0
+#define BPA_KERNEL_BPP     1
+int  bpa_sampler_set_proposal_kernel(bpa_sampler_t *, int kind);
 void bpa_sampler_set_tau_prior(bpa_sampler_t *, double alpha, double beta);           /* a00_set_tau_prior */
 void bpa_sampler_set_theta_prior(bpa_sampler_t *, double alpha, double beta, double finetune); /* a00_set_theta_prior */
 int  bpa_sampler_get_thetas(bpa_sampler_t *, double * theta); /* 2*species-1 entries; returns their number */

@@ -262,3 +262,43 @@ def test_native_rccl_callback(monkeypatch):
         assert nat.taus() == ref.taus() and nat.thetas() == ref.thetas(), call
     assert x.calls() - c0 == 12 * (1 + 3 + 1)            # THETA (all populations in one collective), 3 TAU, MIX per iteration
     nat.close(); ref.close(); x.close(); eng.close()
+
+
+@pytest.mark.parametrize("taxa,nloci,iters", [(4, 400, 8), (8, 60, 4)])
+def test_bpp_proposal_kernel_on_the_device(taxa, nloci, iters):
+    """bpa_sampler_set_proposal_kernel(BPA_KERNEL_BPP): the reference's own generator (legacy_rndu, random.c:104-122) and
+    window (Bactrian-Laplace, random.c:192-238) and its acceptance rule (a number drawn only when lnacc < -1e-10) inside the
+    persistent kernel — the trajectory of the host driver with A00_KERNEL_BPP (whose generator and variate are bit-equal
+    to the reference's functions: tests/test_bpp_kernel.py), per-locus and global streams alike"""
+    eng = bpp_amd.Engine(0)
+    data = synth.make_dataset(nloci, 400, taxa, "jc69", 1, seed=21)
+    host = hostdrv.hip_driver(eng, tape.make_engine_loci(eng, data), data, seed=31)
+    dev = bpp_amd.Sampler(eng, tape.make_engine_loci(eng, data), data, seed=31)
+    parent, tau0, thetas = synth.species_tree_arrays(taxa)
+    for drv in (host, dev):
+        drv.set_proposal_kernel(1)
+        drv.set_species_tree(parent, tau0, thetas)
+        drv.set_tau_prior(3.0, 3.0 / tau0[-1])
+        drv.set_theta_prior(2.0, 1000.0, 0.0003)
+        drv.set_finetune(0.0012, 0.0015, 0.0002, 0.05)
+    host.initialize(); dev.initialize()
+    assert dev.kind() == "persistent"
+    for it in range(iters):
+        host.iterate(); dev.iterate(1)
+        s = dev.summary()
+        hp, ha, _ = host.counters()
+        assert (s["proposals"], s["accepted"]) == (hp, ha), it
+        assert rel(s["total_lnl"], host.total_lnl()) < 1e-10, it
+    assert np.allclose(dev.taus(), host.taus(), rtol=1e-11, atol=0) and dev.taus() != list(tau0)
+    assert np.allclose(dev.thetas(), host.thetas(), rtol=1e-11, atol=0)
+    for i in range(nloci):
+        a, b = dev.tree(i), host.tree(i)
+        for key in ("left", "right", "parent", "clv", "pmat", "pop"):
+            assert [int(x) for x in a[key]] == [int(x) for x in b[key]], (i, key)
+        assert np.allclose(a["time"], b["time"], rtol=1e-11, atol=0)
+    # several iterations per call: the global stream's state stays on the device between launches
+    host.iterate(); host.iterate(); host.iterate(); dev.iterate(3)
+    assert np.allclose(dev.taus(), host.taus(), rtol=1e-11, atol=0) and np.allclose(dev.thetas(), host.thetas(), rtol=1e-11, atol=0)
+    hp, ha, _ = host.counters(); s = dev.summary()
+    assert (s["proposals"], s["accepted"]) == (hp, ha)
+    host.close(); dev.close(); eng.close()
