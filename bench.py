@@ -180,7 +180,7 @@ nsample = {nsample}
 """
 
 
-def bpp_program_baseline(nloci, sites, threads_list, reps=2, budget_s=150.0):
+def bpp_program_baseline(nloci, sites, threads_list, reps=2, budget_s=150.0, chain_samples=0):
     """The unmodified reference PROGRAM (oracle/_ref/bpp, built in place from /root/reference) on this box's host
     cores: data from its own simulator, A00 JC69, whole MCMC iterations/s from the differential wall time of a short
     and a long run (start-up — reading and compressing 10 000 loci, the first likelihoods — cancels), per thread count:
@@ -218,7 +218,102 @@ def bpp_program_baseline(nloci, sites, threads_list, reps=2, budget_s=150.0):
                 rates.append((n2 - n1) / max(t2 - t1, 1e-9) * nloci / 10000.0)
             out[th] = dict(median=round(float(np.median(rates)), 2), min=round(min(rates), 2), max=round(max(rates), 2),
                            runs=len(rates), iterations=f"{n2} vs {n1}")
+        # ---- one chain of the program at its best thread count WITH its burn-in (finetune = 1: BPP adjusts its step
+        # lengths there), for the statistical efficiency: the trace of tau_root / theta_root and the tuned step lengths
+        if chain_samples:
+            try:
+                best = max((k for k in out if k > 1), key=lambda k: out[k]["median"], default=1)
+                tl = f"threads = {best} 1 1" if best > 1 else ""
+                ctl = A00_CTL.format(nloci=nloci, nsample=chain_samples, threads=tl).replace("burnin = 0", "burnin = 400")
+                open(os.path.join(d, "a00.ctl"), "w").write(ctl)
+                r = subprocess.run([O.REF_BIN, "--cfile", "a00.ctl"], cwd=d, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                   timeout=900, text=True)
+                import re
+                ft = re.findall(r"finetune = 1 Gage:(\S+) Gspr:(\S+) th1:(\S+) th2:(\S+) tau:(\S+) mix:([0-9.eE+-]+)", r.stdout)
+                rows = [ln.split() for ln in open(os.path.join(d, "out.mcmc.txt")).read().splitlines()]
+                head, rows = rows[0], rows[1:]
+                col = {h.split(":")[0] + ":" + h.split(":")[1]: i for i, h in enumerate(head) if ":" in h}
+                tr = {k: [float(rw[i]) for rw in rows] for k, i in col.items()}
+                out["chain"] = dict(threads=best, samples=len(rows), burnin=400,
+                                    finetune=dict(zip(("gage", "gspr", "th1", "th2", "tau", "mix"), map(float, ft[-1]))) if ft else None,
+                                    trace=tr)
+            except Exception as ex:       # noqa: BLE001
+                out["chain"] = dict(error=str(ex)[:200])
     return out
+
+
+def ess(x):
+    """effective sample size of a trace: n / (1 + 2 sum of autocorrelations), Geyer's initial positive sequence"""
+    x = np.asarray(x, dtype=float)
+    n = len(x)
+    x = x - x.mean()
+    if n < 16 or not np.any(x):
+        return float(n)
+    f = np.fft.rfft(x, 2 * n)
+    acf = np.fft.irfft(f * np.conj(f))[:n]
+    acf = acf / acf[0]
+    tau = -1.0
+    for k in range(n // 2):
+        g = acf[2 * k] + acf[2 * k + 1]
+        if g <= 0:
+            break
+        tau += 2.0 * g
+    return float(n / max(tau, 1e-9))
+
+
+def run_efficiency(eng, cfg, data, loci, chain, prog_rate, steps_hint=4000):
+    """BPP's own move kernel on the device (bpa_sampler_set_proposal_kernel: Bactrian-Laplace windows, legacy_rndu) with the
+    step lengths the program's burn-in arrived at, priors of the program's control file: effective samples per second of
+    tau_root and theta_root next to the program's (equal statistical work per iteration by construction)"""
+    import bpp_amd
+    from bpp_amd import synth
+    ft = chain["finetune"]
+    smp = bpp_amd.Sampler(eng, loci, data, seed=11)
+    smp.set_proposal_kernel(1)
+    smp.set_theta_slide_prob(0.1)                                  # the program's THETA mix (bpp.c:650): window 1 in 10, Gibbs draw otherwise
+    smp.set_mix_theta_update(1)                                    # ... and its mixing step: thetas re-drawn with the scaled trees (bpp.c:581)
+    parent, tau, theta = synth.species_tree_arrays(cfg["taxa"])
+    smp.set_species_tree(parent, tau, theta)
+    smp.set_tau_prior(2.0, 500.0)                                  # A00_CTL: tauprior = gamma 2 500
+    smp.set_theta_prior(2.0, 1000.0, ft["th2"])                    #          thetaprior = gamma 2 1000
+    smp.set_finetune(ft["gage"], ft["gspr"], ft["tau"], ft["mix"])
+    smp.initialize()
+    smp.iterate(500)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    smp.iterate(3000)
+    eng.synchronize()
+    rate = 3000 / (time.perf_counter() - t0)
+    S = cfg["taxa"]
+    tr_tau, tr_theta = [], []
+    for _ in range(steps_hint):
+        smp.iterate(1)
+        tr_tau.append(smp.taus()[-1]); tr_theta.append(smp.thetas()[-1])
+    sm = smp.summary()
+    gibbs = smp.gibbs_counters()
+    smp.close()
+    root = f"{S + 1}"
+    p_tau, p_theta = chain["trace"].get("tau:" + root), chain["trace"].get("theta:" + root)
+    dev = dict(iterations_per_s=round(rate, 1), samples=steps_hint, acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
+               theta_gibbs_draws=dict(proposed=gibbs[0], accepted=gibbs[1]),
+               tau_root=dict(mean=float(np.mean(tr_tau)), sd=float(np.std(tr_tau)), ess_per_iteration=round(ess(tr_tau) / steps_hint, 4)),
+               theta_root=dict(mean=float(np.mean(tr_theta)), sd=float(np.std(tr_theta)), ess_per_iteration=round(ess(tr_theta) / steps_hint, 4)))
+    prog = dict(iterations_per_s=prog_rate, samples=chain["samples"], threads=chain["threads"],
+                tau_root=dict(mean=float(np.mean(p_tau)), sd=float(np.std(p_tau)), ess_per_iteration=round(ess(p_tau) / len(p_tau), 4)),
+                theta_root=dict(mean=float(np.mean(p_theta)), sd=float(np.std(p_theta)), ess_per_iteration=round(ess(p_theta) / len(p_theta), 4)))
+    for d_ in (dev, prog):
+        for k in ("tau_root", "theta_root"):
+            d_[k]["ess_per_s"] = round(d_[k]["ess_per_iteration"] * d_["iterations_per_s"], 2)
+    return dict(device=dev, reference_program=prog, step_lengths=ft,
+                ratio_ess_per_s=dict(tau_root=round(dev["tau_root"]["ess_per_s"] / max(prog["tau_root"]["ess_per_s"], 1e-9), 1),
+                                     theta_root=round(dev["theta_root"]["ess_per_s"] / max(prog["theta_root"]["ess_per_s"], 1e-9), 1)),
+                note="the device sampler with BPP's own proposal kernel (Bactrian-Laplace m = 0.9 windows, legacy_rndu, acceptance number "
+                     "drawn only when needed; THETA as the program mixes it: sliding window 1 time in 10, metropolized Gibbs draw otherwise; its mixing step, "
+                     "which re-draws the thetas with the scaled trees) "
+                     "and the step lengths the program's burn-in (finetune = 1) tuned itself to, the program's priors; "
+                     "ESS = n / (1 + 2 sum of autocorrelations) (initial positive sequence) of the traces of tau_root and theta_root, one sample per "
+                     "iteration; the program on its own simulated 10000-locus set, the device on the bench's synthetic set of the same model and "
+                     "size (the program's trace prints 6 decimals)")
 
 
 # ------------------------------------------------------------------------------------------------ the workload ---
@@ -765,6 +860,8 @@ def main():
     ap.add_argument("--no-tape", action="store_true", help="c2: skip the likelihood-only tape section")
     ap.add_argument("--no-host-control", action="store_true", help="c2: skip the host-driven section (a00_driver.c on the GPU back-end)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the c3 / c4 tape sections of the default run")
+    ap.add_argument("--no-efficiency", action="store_true",
+                    help="skip the ESS/s section (one more 1 900-iteration run of the reference program with its burn-in, BPP's move kernel on the device)")
     ap.add_argument("--no-bpp-program", action="store_true",
                     help="skip timing the unmodified reference program (thread sweep) on the host cores")
     ap.add_argument("--no-timing-events", action="store_true")
@@ -856,6 +953,7 @@ def main():
                                          f"one locus per worker thread at a time (loci are independent: threads.c:87-200)"))
 
     bpp_prog = None
+    chain = None
     if rank == 0 and world == 1 and args.config == "c2" and not args.no_cpu_baseline and not args.no_bpp_program:
         try:
             ncores = os.cpu_count() or 1
@@ -863,7 +961,8 @@ def main():
             # only throttled) and twice that — round 2's sweep over 8 ... 128 found the best there every time
             q = int(cpu_quota() or ncores)
             sweep = sorted({1, max(2, min(q, ncores)), max(2, min(2 * q, ncores))})
-            r = bpp_program_baseline(nloci_cfg, cfg["sites"], sweep)
+            r = bpp_program_baseline(nloci_cfg, cfg["sites"], sweep, chain_samples=0 if args.no_efficiency else 1500)
+            chain = r.pop("chain", None) if r else None
             if r:
                 best = max((k for k in r if k > 1), key=lambda k: r[k]["median"], default=1)
                 bpp_prog = dict(unit="whole MCMC iterations/s of the unmodified reference program (10k loci, A00 JC69), incl. its MCMC control",
@@ -873,6 +972,16 @@ def main():
                                        "20 vs 150), median / min / max of 2 measurements per thread count (1 thread: one)")
         except Exception as ex:       # noqa: BLE001
             bpp_prog = dict(error=str(ex)[:200])
+
+    # ---- statistical efficiency: BPP's own move kernel and tuned step lengths on the device, ESS/s next to the program's
+    efficiency = None
+    if bpp_prog and "error" not in bpp_prog and chain and "error" not in chain and chain.get("finetune"):
+        try:
+            efficiency = run_efficiency(eng, cfg, data, make_loci(eng, data), chain, bpp_prog["best_median"])
+        except Exception as ex:       # noqa: BLE001
+            efficiency = dict(error=str(ex)[:300])
+    elif chain and "error" in chain:
+        efficiency = dict(error=chain["error"])
 
     # ---- the other single-GPU configurations of BASELINE.json on the same box (tape = likelihood path)
     others = None
@@ -979,6 +1088,7 @@ def main():
             "speedups": ratios,
             "cpu_tape_replay": cpu if cpu is not cpu_like else None,
             "reference_program_on_host": bpp_prog,
+            "statistical_efficiency": efficiency,
             "device_resident_sampler": sampler_sec,
             "host_control_in_c": host_sec,
             "likelihood_only": tape_sec,

@@ -74,7 +74,7 @@ static int gs_upload(bpa_sampler * s)
       !s->g_lnl.reserve(T) || !s->g_hast.reserve(T) || !s->g_logpr.reserve(T) || !s->g_delta.reserve(T) || !s->g_active.reserve(T) ||
       !s->g_site.reserve(npat) || !s->g_recs.reserve(nrec) || !s->g_mat2.reserve(nmat) || !s->g_len.reserve(nmat) ||
       !upload(s->g_bmo, bmo.data(), bmo.size()) || !s->g_lograt.reserve(gsm::NN*gsm::NN) ||
-      !upload(s->flag, zero2, 1) || !upload(s->counters, s->h_counters, 2) || !s->mix_sum.reserve(1) ||
+      !upload(s->flag, zero2, 1) || !upload(s->counters, s->h_counters, 4) || !s->mix_sum.reserve(1) ||
       !upload(s->taus, s->h_taus.data(), s->h_taus.size()) || !s->pop_t2h.reserve((size_t)T*smp::MAXPOP) ||
       !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP))
     return 0;

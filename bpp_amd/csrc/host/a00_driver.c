@@ -30,6 +30,8 @@ struct a00_driver
   a00_rng_t * rng;                      /* one stream per locus */
   a00_rng_t grng;                       /* global stream (mixing step) */
   int kernel;                           /* A00_KERNEL_UNIFORM / A00_KERNEL_BPP */
+  double theta_slide_prob;              /* A00_KERNEL_BPP: share of sliding-window THETA proposals, the rest Gibbs draws (1: all) */
+  int mix_theta_update;                 /* A00_KERNEL_BPP: the mixing step re-draws the thetas (prop_mixing.c:272) */
   unsigned int * zrng, gz;              /* A00_KERNEL_BPP: legacy_rndu states, per locus and global */
   /* step scratch */
   unsigned * s_locus; a00_tree_t ** s_tree; unsigned * s_br_off, * s_nd_off;
@@ -38,6 +40,7 @@ struct a00_driver
   /* per-locus undo snapshot (whole small tree) */
   int ** u_left, ** u_right, ** u_parent, ** u_clv, ** u_pmat, ** u_scaler; double ** u_time; int * u_root;
   unsigned long proposals, accepted, steps;
+  unsigned long gibbs_proposals, gibbs_accepted;     /* of those: THETA Gibbs draws */
   /* species tree (stree->nodes order: tips, then inner populations, children before parents) */
   int S, npop, sp_parent[A00_MAXPOP], sp_left[A00_MAXPOP], sp_right[A00_MAXPOP];
   double tau[A00_MAXPOP], theta[A00_MAXPOP];
@@ -109,11 +112,22 @@ static void declog(const char * what, int k, double lnacc, double u, int acc)
 
 void a00_set_proposal_kernel(a00_driver_t * d, int kind) { d->kernel = kind == A00_KERNEL_BPP ? A00_KERNEL_BPP : A00_KERNEL_UNIFORM; }
 
-void a00_bpp_kernel_sequence(unsigned int seed, int symmetrical, int n, double * out)
+void a00_set_theta_slide_prob(a00_driver_t * d, double p) { d->theta_slide_prob = p < 0 ? 0 : p > 1 ? 1 : p; }
+void a00_set_mix_theta_update(a00_driver_t * d, int on) { d->mix_theta_update = on != 0; }
+void a00_gibbs_counters(const a00_driver_t * d, unsigned long * proposals, unsigned long * accepted)
+{ if (proposals) *proposals = d->gibbs_proposals; if (accepted) *accepted = d->gibbs_accepted; }
+
+void a00_bpp_kernel_sequence(unsigned int seed, int what, int n, double * out)
 {
   int k;
-  for (k = 0; k < n; ++k) out[k] = symmetrical ? a00_bpp_rnd_symmetrical(&seed) : a00_bpp_rndu(&seed);
+  for (k = 0; k < n; ++k) out[k] = what == 1 ? a00_bpp_rnd_symmetrical(&seed) : what == 2 ? a00_bpp_rndnormal(&seed) : a00_bpp_rndu(&seed);
 }
+void a00_bpp_gamma_sequence(unsigned int seed, double shape, int n, double * out)
+{
+  int k;
+  for (k = 0; k < n; ++k) out[k] = a00_bpp_rndgamma(&seed, shape);
+}
+void a00_theta_conditional(double a, double b, long k, double T, double * a1b1) { a00_theta_conditional_invgamma(a, b, k, T, a1b1, a1b1 + 1); }
 
 static void snapshot(a00_driver_t * d, unsigned i)
 {
@@ -158,6 +172,7 @@ a00_driver_t * a00_create(unsigned nloci, a00_eval_fn eval, void * ctx, unsigned
   d->p_slot = (int *)calloc(nloci, sizeof(int)); d->u_pop = (int **)calloc(nloci, sizeof(int *));
   d->ft_gage = 0.004; d->ft_gspr = 0.004; d->ft_tau = 0.001; d->ft_mix = 0.3;
   d->threads = 1;
+  d->theta_slide_prob = 1.0;
   { const char * ev = getenv("A00_THREADS"); if (ev && atoi(ev) > 0) a00_set_threads(d, atoi(ev)); }
   d->w_nb = (int *)calloc(nloci, sizeof(int)); d->w_nn = (int *)calloc(nloci, sizeof(int));
   d->w_hast = (double *)calloc(nloci, sizeof(double)); d->w_logpr = (double *)calloc(nloci, sizeof(double));
@@ -603,10 +618,12 @@ static int gspr_step(a00_driver_t * d, int k)
    gamma(alpha, beta) prior; only the MSC density changes — no likelihood call.  Given the gene trees the thetas are
    independent (the density is a sum of per-population terms), so all are proposed from the same state and each is
    decided on its own  sum over loci of [term(theta') - term(theta)] + prior ratio  (stree.c:3464-3560 family). */
+static int theta_step_gibbs(a00_driver_t * d);
 static int theta_step_all(a00_driver_t * d)
 {
   unsigned i; int p; long li;
   double tnew[A00_MAXPOP], uacc[A00_MAXPOP], sum[A00_MAXPOP];
+  if (d->kernel == A00_KERNEL_BPP && d->theta_slide_prob < 1.0) return theta_step_gibbs(d);
   for (p = 0; p < d->npop; ++p)
   {
     sum[p] = 0; tnew[p] = d->theta[p];
@@ -633,6 +650,84 @@ static int theta_step_all(a00_driver_t * d)
     lnacc = sum[p] + ((d->theta_alpha - 1)*log(tnew[p]/d->theta[p]) - d->theta_beta*(tnew[p] - d->theta[p]));
     d->proposals++;
     { const int acc_ = tnew[p] > 0 && accept(d, -1, lnacc, uacc[p]); declog("theta", p, lnacc, uacc[p], acc_); if (acc_) { d->accepted++; d->theta[p] = tnew[p]; } }
+  }
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+  for (li = 0; li < (long)d->nloci; ++li) d->trees[li].logpr = tree_logpr(d, d->trees + li);
+  return 1;
+}
+
+/* k_p = coalescences in p, T_p = sum of T2h (2^-40 fixed point) over all loci, for the populations with a theta;
+   returns 0 when a term is unusable (the device's rule: |T2h| >= 256) */
+static int theta_sums(a00_driver_t * d, long long * ksum, long long * tsum)
+{
+  int p, bad = 0; long li;
+  for (p = 0; p < d->npop; ++p) { ksum[p] = 0; tsum[p] = 0; }
+#pragma omp parallel num_threads(d->threads) if (d->threads > 1)
+  {
+    long long kl[A00_MAXPOP], tl[A00_MAXPOP]; int pp, badl = 0;
+    for (pp = 0; pp < d->npop; ++pp) { kl[pp] = 0; tl[pp] = 0; }
+#pragma omp for schedule(static)
+    for (li = 0; li < (long)d->nloci; ++li)
+    {
+      int nc[A00_MAXPOP]; double t2h[A00_MAXPOP];
+      (void)tree_logpr_stats(d, d->trees + li, nc, t2h);
+      for (pp = 0; pp < d->npop; ++pp)
+        if (d->has_theta[pp])
+        {
+          if (!(fabs(t2h[pp]) < 256.0)) badl = 1;
+          else { kl[pp] += nc[pp]; tl[pp] += llrint(t2h[pp]*1099511627776.0); }
+        }
+    }
+#pragma omp critical
+    { for (pp = 0; pp < d->npop; ++pp) { ksum[pp] += kl[pp]; tsum[pp] += tl[pp]; } bad |= badl; }
+  }
+  return !bad;
+}
+
+/* THETA the program's way (a00_set_theta_slide_prob < 1, A00_KERNEL_BPP): per theta, in population order, the sliding
+   window with probability slide_prob, else the metropolized Gibbs draw of bpp_amd_host.h — both decided from
+   k_p = sum over loci of the coalescences in p and T_p = sum of T2h (2^-40 fixed point: no order).  Global stream:
+   the choices (and the windows of the sliding ones) of all populations first, then per population the Gibbs variate
+   and the acceptance number (drawn only when needed) — the order the device kernel can follow with ONE exchange.   */
+static int theta_step_gibbs(a00_driver_t * d)
+{
+  int p, slide[A00_MAXPOP], bad = 0; long li;
+  double tnew[A00_MAXPOP];
+  long long ksum[A00_MAXPOP], tsum[A00_MAXPOP];
+  for (p = 0; p < d->npop; ++p)
+  {
+    slide[p] = 0; tnew[p] = d->theta[p];
+    if (!d->has_theta[p]) continue;
+    slide[p] = a00_bpp_rndu(&d->gz) < d->theta_slide_prob;
+    if (slide[p]) tnew[p] = a00_reflect(d->theta[p] + d->ft_theta*draw_window(d, -1), 0.0, 999.0);
+  }
+  bad = !theta_sums(d, ksum, tsum);
+  for (p = 0; p < d->npop; ++p)
+  {
+    double lnacc = NAN, T; int acc_ = 0;
+    if (!d->has_theta[p]) continue;
+    d->proposals++;
+    T = (double)tsum[p]*(1.0/1099511627776.0);
+    if (!bad)
+    {
+      if (slide[p]) lnacc = a00_theta_lnacc((long)ksum[p], T, d->theta[p], tnew[p], d->theta_alpha, d->theta_beta);
+      else
+      {
+        double a1, b1, g;
+        a00_theta_conditional_invgamma(d->theta_alpha, d->theta_beta, (long)ksum[p], T, &a1, &b1);
+        if (a1 == a1)
+        {
+          g = a00_bpp_rndgamma(&d->gz, a1);
+          tnew[p] = 1/(g/b1);
+          lnacc = a00_theta_lnacc((long)ksum[p], T, d->theta[p], tnew[p], d->theta_alpha, d->theta_beta)
+                + a00_theta_gibbs_hastings(a1, b1, d->theta[p], tnew[p]);
+        }
+      }
+      acc_ = lnacc == lnacc && tnew[p] > 0 && accept(d, -1, lnacc, -1.0);
+    }
+    declog(slide[p] ? "theta" : "thetag", p, lnacc, -1.0, acc_);
+    if (acc_) { d->accepted++; d->theta[p] = tnew[p]; if (!slide[p]) d->gibbs_accepted++; }
+    if (!slide[p]) d->gibbs_proposals++;
   }
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
   for (li = 0; li < (long)d->nloci; ++li) d->trees[li].logpr = tree_logpr(d, d->trees + li);
@@ -703,10 +798,34 @@ static int tau_step(a00_driver_t * d, int q)
    sum(dlogpr + dlnL) + (ages + taus)*log c   (prop_mixing.c:203-205; thetas stay) */
 static int mix_step(a00_driver_t * d)
 {
-  unsigned i; long li; int p, acc_; double sum = 0, lnacc, oldtau[A00_MAXPOP];
-  const double lnc = d->ft_mix*(draw_u(d, -1) - 0.5), c = exp(lnc);        /* prop_mixing.c: log c uniform in both kernels */
+  unsigned i; long li; int p, acc_; double sum = 0, lnacc, oldtau[A00_MAXPOP], oldtheta[A00_MAXPOP], lnacc_theta = 0;
+  /* log c: finetune x BPP's window variate with its kernel (prop_mixing.c:300), uniform with ours */
+  const double lnc = d->ft_mix*(d->kernel == A00_KERNEL_BPP ? draw_window(d, -1) : draw_u(d, -1) - 0.5), c = exp(lnc);
   const double uacc = d->kernel == A00_KERNEL_BPP ? -1.0 : draw_u(d, -1);
+  const int theta_update = d->kernel == A00_KERNEL_BPP && d->mix_theta_update && d->theta_alpha > 0;
   if (!staging_ready(d)) return 0;
+  for (p = 0; p < d->npop; ++p) oldtheta[p] = d->theta[p];
+  if (theta_update)
+  {
+    /* the thetas from their conditionals given the scaled trees (prop_mixing.c:272-425), in population order */
+    long long ksum[A00_MAXPOP], tsum[A00_MAXPOP];
+    const int usable = theta_sums(d, ksum, tsum);
+    for (p = 0; p < d->npop; ++p)
+    {
+      double a1, b1, a1o, b1o, Ts, g, tn;
+      if (!d->has_theta[p]) continue;
+      if (!usable) { lnacc_theta = NAN; continue; }
+      Ts = (double)tsum[p]*(1.0/1099511627776.0)*c;
+      a00_theta_conditional_invgamma(d->theta_alpha, d->theta_beta, (long)ksum[p], Ts, &a1, &b1);
+      a00_theta_conditional_invgamma(d->theta_alpha, d->theta_beta, (long)ksum[p], Ts/c, &a1o, &b1o);
+      if (!(a1 == a1 && a1o == a1o)) { lnacc_theta = NAN; continue; }
+      g = a00_bpp_rndgamma(&d->gz, a1);
+      tn = 1.0/(g/b1);
+      lnacc_theta += (a00_invgamma_logpdf(oldtheta[p], a1o, b1o) - a00_invgamma_logpdf(tn, a1, b1))
+                   + ((d->theta_alpha - 1)*log(tn/oldtheta[p]) - d->theta_beta*(tn - oldtheta[p]));
+      d->theta[p] = tn;
+    }
+  }
   for (p = 0; p < d->npop; ++p) { oldtau[p] = d->tau[p]; d->tau[p] *= c; }
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
   for (li = 0; li < (long)d->nloci; ++li)
@@ -728,6 +847,7 @@ static int mix_step(a00_driver_t * d)
   lnacc = sum + (double)(d->S - 1)*lnc;
   if (d->tau_alpha > 0)                    /* all taus scale together: the Dirichlet part is unchanged */
     lnacc += (d->tau_alpha - 1)*lnc - d->tau_beta*(d->tau[d->npop-1] - oldtau[d->npop-1]) - (double)(d->S - 2)*lnc;
+  lnacc += lnacc_theta;
   d->proposals++;
   acc_ = accept(d, -1, lnacc, uacc);
   declog("mix", 0, lnacc, uacc, acc_);
@@ -739,7 +859,7 @@ static int mix_step(a00_driver_t * d)
   }
   else
   {
-    for (p = 0; p < d->npop; ++p) d->tau[p] = oldtau[p];
+    for (p = 0; p < d->npop; ++p) { d->tau[p] = oldtau[p]; d->theta[p] = oldtheta[p]; }
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
     for (li = 0; li < (long)d->nloci; ++li) restore(d, (unsigned)li);
   }

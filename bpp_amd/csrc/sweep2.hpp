@@ -67,7 +67,7 @@ struct Args
   // rejected step's trees come from the pre-step snapshot — and thetas that moved after the trees' densities were stored
   const Tree * snap; const uint32_t * mix_flag; uint32_t epoch, refresh_logpr;
   double * taus;                         // [3 MAXPOP] tau | theta | log(2/theta): read at entry, written back by workgroup 0
-  uint32_t * counters;                   // all-loci proposals / accepted
+  uint32_t * counters;                   // all-loci proposals / accepted, Gibbs draws of a theta / accepted
   const double * lograt;
   int8_t * pop_nc; double * pop_t2h;     // sufficient statistics of the final state (sampler.hpp's THETA kernels read them)
   uint32_t ntasks, nwaves, nwg;
@@ -103,8 +103,8 @@ template <int NT> struct WgLDS
 {
   double tau[3*MAXPOP];
   double lograt[(2*NT)*(2*NT)];
-  unsigned long long accfx[16];                  // this workgroup's sums of an all-loci step, 2^-44 fixed point (LDS atomics)
-  double xtot[16];
+  unsigned long long accfx[32];                  // this workgroup's sums of an all-loci step, 2^-44 fixed point (LDS atomics)
+  double xtot[32];
   uint32_t anc[16];
   uint32_t abort_, bad_;
   Species sp;
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   for (uint32_t i = tid; i < (uint32_t)((2*NT)*(2*NT)); i += C::BS) wg.lograt[i] = A.lograt[(i/(2*NT))*MAXN + i % (2*NT)];
   if (tid < 16u) wg.anc[tid] = tid < (uint32_t)MAXPOP ? (uint32_t)SP.anc[tid] : 0u;
   if (tid == 0) { wg.abort_ = 0; wg.bad_ = 0; }
-  if (tid < 16u) wg.accfx[tid] = 0ull;
+  if (tid < 32u) wg.accfx[tid] = 0ull;
   PopLane pl;
   {
     pl.parent = li < npop ? (int)SP.parent[li < MAXPOP ? li : 0] : -1;
@@ -735,10 +735,11 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       if (wg.abort_) return false;
     }
 #undef XT
-    mine_tot = wg.xtot[want & 15];
+    mine_tot = wg.xtot[want & 31];
     return true;
   };
   uint32_t cnt_prop = 0, cnt_acc = 0;              // all-loci proposals / accepted (the same in every workgroup)
+  uint32_t cnt_gprop = 0, cnt_gacc = 0;            // of those: Gibbs draws of a theta
   const bool declog = (A.dbg & 256u) && b == 0;    // every all-loci decision of this launch: A.declog[4 k] = what, lnacc, u, accepted
   uint32_t ndec = 0;
   const bool wgprof = (A.dbg & 32u) && tid == 0;
@@ -783,57 +784,117 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     // ================= THETA: every population that can hold a coalescence, decided independently (theta_step_all)
     if (SP.theta_alpha > 0 && A.theta_mask)
     {
-      // the windows of all populations first (theta_step_all of a00_driver.c: the uniform kernel draws the acceptance
-      // number right behind each window, BPP's kernel only when a decision needs it)
-      double win = 0, uacc = -1.0;
-      for (int p = 0; p < npop; ++p)
-        if ((A.theta_mask >> p) & 1u)
-        {
-          const double w_ = grng.window(), a_ = BPP ? -1.0 : grng.u();
-          if (p == li) { win = w_; uacc = a_; }
-        }
+      const bool gibbs = BPP && SP.theta_slide_prob < 1.0;      // the program's own mix of moves (theta_step_gibbs of a00_driver.c)
       const bool on = li < npop && ((A.theta_mask >> li) & 1u);
       const double told = pl.theta, l2t_old = pl.l2t;
-      const double tnew = reflect(told + SP.ft_theta*win, 0.0, 999.0);
-      const double l2t_new = log(2.0/(1.0*tnew));
-      if (act && on) fx_add(li, msc_term((int)mync, t2h_cur, tnew, l2t_new) - msc_term((int)mync, t2h_cur, told, l2t_old), false);
-      SMP2_TICK(3);
-      double th_tot = 0;
-      if (!exchange(npop, li, th_tot)) { aborted = true; break; }
-      SMP2_TICK(6);
-      // every wave takes the (same) decisions for itself: lane li decides population li; BPP's kernel draws its
-      // acceptance numbers now, in population order, so every lane walks through all of them
-      bool accept = false;
-      double my_lnacc = 0;
-      if (BPP)
+      double tnew = told, uacc = -1.0, my_lnacc = 0;
+      bool accept = false, gibbs_me = false;
+      if (!gibbs)
       {
-        if (on) { wl.term[li] = tnew; wl.term[16 + li] = told; }
-        wsync();
+        // the windows of all populations first (theta_step_all of a00_driver.c: the uniform kernel draws the acceptance
+        // number right behind each window, BPP's kernel only when a decision needs it)
+        double win = 0;
         for (int p = 0; p < npop; ++p)
           if ((A.theta_mask >> p) & 1u)
           {
-            const double tn = wl.term[p], to = wl.term[16 + p];
-            const double lnacc = wg.xtot[p] + ((SP.theta_alpha - 1)*log(tn/to) - SP.theta_beta*(tn - to));
-            const bool acc = tn > 0 && grng.accept(lnacc);
-            if (p == li) { accept = acc; my_lnacc = lnacc; }
+            const double w_ = grng.window(), a_ = BPP ? -1.0 : grng.u();
+            if (p == li) { win = w_; uacc = a_; }
+          }
+        tnew = reflect(told + SP.ft_theta*win, 0.0, 999.0);
+        const double l2t_new = log(2.0/(1.0*tnew));
+        if (act && on) fx_add(li, msc_term((int)mync, t2h_cur, tnew, l2t_new) - msc_term((int)mync, t2h_cur, told, l2t_old), false);
+        SMP2_TICK(3);
+        double th_tot = 0;
+        if (!exchange(npop, li, th_tot)) { aborted = true; break; }
+        SMP2_TICK(6);
+        // every wave takes the (same) decisions for itself: lane li decides population li; BPP's kernel draws its
+        // acceptance numbers now, in population order, so every lane walks through all of them
+        if (BPP)
+        {
+          if (on) { wl.term[li] = tnew; wl.term[16 + li] = told; }
+          wsync();
+          for (int p = 0; p < npop; ++p)
+            if ((A.theta_mask >> p) & 1u)
+            {
+              const double tn = wl.term[p], to = wl.term[16 + p];
+              const double lnacc = wg.xtot[p] + ((SP.theta_alpha - 1)*log(tn/to) - SP.theta_beta*(tn - to));
+              const bool acc = tn > 0 && grng.accept(lnacc);
+              if (p == li) { accept = acc; my_lnacc = lnacc; }
+            }
+          wsync();
+        }
+        else if (on)
+        {
+          my_lnacc = th_tot + ((SP.theta_alpha - 1)*log(tnew/told) - SP.theta_beta*(tnew - told));
+          accept = tnew > 0 && (my_lnacc >= 0 || uacc < exp(my_lnacc));
+        }
+      }
+      else
+      {
+        // ---- sliding window with probability slide_prob, else BPP's metropolized Gibbs draw (stree.c:3957, 3645): both are
+        // decided from k_p = the coalescences in p over all loci and T_p = the sum of T2h — two sums that do not depend on
+        // the thetas, so ONE exchange serves every population.  Global stream: choice (+ window) per population first,
+        // then per population the gamma variate of a Gibbs draw and the acceptance number when one is needed.
+        uint32_t slidem = 0;
+        for (int p = 0; p < npop; ++p)
+          if ((A.theta_mask >> p) & 1u)
+          {
+            if (!(grng.u() < SP.theta_slide_prob)) continue;
+            slidem |= 1u << p;
+            const double tn = reflect(wg.tau[MAXPOP + p] + SP.ft_theta*grng.window(), 0.0, 999.0);
+            if (p == li) tnew = tn;
+          }
+        const int kidx = __popc(A.theta_mask & ((1u << li) - 1u));
+        if (act && on) { fx_add(2*kidx, (double)mync, false); fx_add(2*kidx + 1, t2h_cur, false); }
+        SMP2_TICK(3);
+        double dummy = 0;
+        if (!exchange(2*__popc(A.theta_mask), 0, dummy)) { aborted = true; break; }
+        SMP2_TICK(6);
+        if (on) wl.term[li] = tnew;
+        wsync();
+        int kk = 0;
+        for (int p = 0; p < npop; ++p)
+          if ((A.theta_mask >> p) & 1u)
+          {
+            const double ks = wg.xtot[2*kk], Ts = wg.xtot[2*kk + 1]; ++kk;
+            const double to = wg.tau[MAXPOP + p];
+            const bool sl = (slidem >> p) & 1u;
+            double tn = wl.term[p], lnacc = __longlong_as_double(0x7ff8000000000000ll);
+            if (ks == ks && Ts == Ts)                                          // (an unusable term anywhere: every decision is a rejection, nothing drawn)
+            {
+              const long k = (long)ks;
+              if (sl) lnacc = a00_theta_lnacc(k, Ts, to, tn, SP.theta_alpha, SP.theta_beta);
+              else
+              {
+                double a1, b1;
+                a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, k, Ts, &a1, &b1);
+                if (a1 == a1)
+                {
+                  unsigned int z = (unsigned int)grng.r;
+                  const double g = a00_bpp_rndgamma(&z, a1);
+                  grng.r = z;
+                  tn = 1/(g/b1);
+                  lnacc = a00_theta_lnacc(k, Ts, to, tn, SP.theta_alpha, SP.theta_beta) + a00_theta_gibbs_hastings(a1, b1, to, tn);
+                }
+              }
+            }
+            const bool acc = lnacc == lnacc && tn > 0 && grng.accept(lnacc);
+            if (p == li) { accept = acc; my_lnacc = lnacc; tnew = tn; gibbs_me = !sl; }
           }
         wsync();
       }
-      else if (on)
-      {
-        my_lnacc = th_tot + ((SP.theta_alpha - 1)*log(tnew/told) - SP.theta_beta*(tnew - told));
-        accept = tnew > 0 && (my_lnacc >= 0 || uacc < exp(my_lnacc));
-      }
+      const double l2t_new = log(2.0/(1.0*tnew));
       if (accept) { pl.theta = tnew; pl.l2t = l2t_new; }
       if (declog && tid < (uint32_t)G && on)
       {
         const uint32_t k = ndec + (uint32_t)__popc(A.theta_mask & ((1u << li) - 1u));
-        if (k < 2048u) { double * r = A.declog + 4*k; r[0] = 100 + li; r[1] = my_lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
+        if (k < 2048u) { double * r = A.declog + 4*k; r[0] = (gibbs_me ? 200 : 100) + li; r[1] = my_lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
       }
       ndec += (uint32_t)__popc(A.theta_mask);
       {
-        const uint32_t onm = gballot<G>(on, gbase), accm = gballot<G>(accept, gbase);
+        const uint32_t onm = gballot<G>(on, gbase), accm = gballot<G>(accept, gbase), gm = gballot<G>(on && gibbs_me, gbase);
         cnt_prop += (uint32_t)__popc(onm); cnt_acc += (uint32_t)__popc(accm);
+        cnt_gprop += (uint32_t)__popc(gm); cnt_gacc += (uint32_t)__popc(gm & accm);
       }
       __syncthreads();                                        // everyone has read the totals and the old thetas
       if (tid < (uint32_t)G && accept) { wg.tau[MAXPOP + li] = tnew; wg.tau[2*MAXPOP + li] = l2t_new; }
@@ -856,10 +917,11 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     {
       const bool mix = stepq == npop;
       const int q = mix ? -1 : stepq;
-      // (log c of the mixing step is uniform in both kernels: prop_mixing.c)
-      const double wprop = mix ? grng.u() - 0.5 : grng.window(), uacc = BPP ? -1.0 : grng.u();
+      // (log c of the mixing step: finetune x BPP's window variate with its kernel, prop_mixing.c:300; uniform with ours)
+      const double wprop = mix && !BPP ? grng.u() - 0.5 : grng.window(), uacc = BPP ? -1.0 : grng.u();
       // the proposed species tree: in the lanes' registers only
       double tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1, lminf = 0, lmaxf = 0, tq_new = 0, mix_c = 1, mix_lnc = 0;
+      double lnacc_theta = 0; bool th_upd = false;
       if (!mix)
       {
         const int pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
@@ -875,6 +937,38 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         mix_lnc = SP.ft_mix*wprop; mix_c = exp(mix_lnc);
         pl.tau *= mix_c;
         if (pl.parent >= 0) pl.ptau *= mix_c;
+        if (BPP && SP.mix_theta_update && SP.theta_alpha > 0 && A.theta_mask)
+        {
+          // ---- the program's mixing step re-draws the thetas (prop_mixing.c:272-425): each from the inverse-gamma fitted to
+          // its conditional given the SCALED trees, k_p and c T_p — one more exchange brings the two sums per theta —; the
+          // densities of the step are then taken with the new thetas (mix_step of a00_driver.c)
+          th_upd = true;
+          const bool on = li < npop && ((A.theta_mask >> li) & 1u);
+          const int kidx = __popc(A.theta_mask & ((1u << li) - 1u));
+          if (act && on) { fx_add(2*kidx, (double)mync, false); fx_add(2*kidx + 1, t2h_cur, false); }
+          double dummy = 0;
+          if (!exchange(2*__popc(A.theta_mask), 0, dummy)) { aborted = true; break; }
+          int kk = 0;
+          for (int p = 0; p < npop; ++p)
+            if ((A.theta_mask >> p) & 1u)
+            {
+              const double ks = wg.xtot[2*kk], Tsum = wg.xtot[2*kk + 1]; ++kk;
+              if (!(ks == ks && Tsum == Tsum)) { lnacc_theta = __longlong_as_double(0x7ff8000000000000ll); continue; }
+              const double to = wg.tau[MAXPOP + p], Ts = Tsum*mix_c;
+              double a1, b1, a1o, b1o;
+              a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)ks, Ts, &a1, &b1);
+              a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)ks, Ts/mix_c, &a1o, &b1o);
+              if (!(a1 == a1 && a1o == a1o)) { lnacc_theta = __longlong_as_double(0x7ff8000000000000ll); continue; }
+              unsigned int z = (unsigned int)grng.r;
+              const double g = a00_bpp_rndgamma(&z, a1);
+              grng.r = z;
+              const double tn = 1.0/(g/b1);
+              lnacc_theta += (a00_invgamma_logpdf(to, a1o, b1o) - a00_invgamma_logpdf(tn, a1, b1))
+                           + ((SP.theta_alpha - 1)*log(tn/to) - SP.theta_beta*(tn - to));
+              if (p == li) { pl.theta = tn; pl.l2t = log(2.0/(1.0*tn)); }
+            }
+          __syncthreads();                              // (the totals are read: the step's own exchange may overwrite them)
+        }
       }
       const uint32_t cf0 = T.cf, pf0 = T.pf;
       const double tsave = act ? S.time[li] : 0.0;
@@ -941,6 +1035,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           const double troot = wg.tau[npop - 1];
           lnacc += (SP.tau_alpha - 1)*mix_lnc - SP.tau_beta*(troot*mix_c - troot) - (double)(nsp - 2)*mix_lnc;
         }
+        lnacc += lnacc_theta;
       }
       const bool accept = BPP ? grng.accept(lnacc) : (lnacc >= 0 || uacc < exp(lnacc));
       ++cnt_prop; cnt_acc += accept ? 1u : 0u;
@@ -950,7 +1045,11 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       if (accept)
       {
         if (!mix) { if (tid == 0) wg.tau[q] = tq_new; }
-        else if (tid < (uint32_t)npop) wg.tau[tid] *= mix_c;
+        else
+        {
+          if (tid < (uint32_t)npop) wg.tau[tid] *= mix_c;
+          if (th_upd && tid < (uint32_t)G && li < npop && ((A.theta_mask >> li) & 1u)) { wg.tau[MAXPOP + li] = pl.theta; wg.tau[2*MAXPOP + li] = pl.l2t; }
+        }
         if (act) { lnl_cur = lnl_new; logpr_cur = lp_new; commit_density(allpop); }
       }
       else if (act) { T.cf = cf0; T.pf = pf0; S.time[li] = tsave; }
@@ -1001,7 +1100,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   if (b == 0 && tid == 0)
   {
     *A.grng = grng.r;
-    A.counters[0] += cnt_prop; A.counters[1] += cnt_acc;
+    A.counters[0] += cnt_prop; A.counters[1] += cnt_acc; A.counters[2] += cnt_gprop; A.counters[3] += cnt_gacc;
   }
   if (b == 0 && tid < (uint32_t)(3*MAXPOP)) A.taus[tid] = wg.tau[tid];
   if (prof_on) for (int i = 0; i < 13; ++i) A.prof[i] = (double)wg.prof[i];

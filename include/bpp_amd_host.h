@@ -84,6 +84,113 @@ static inline double a00_bpp_rnd_symmetrical(unsigned int * z)
   return v;
 }
 
+/* BPP's THETA move is, nine times out of ten, not the sliding window but a METROPOLIZED GIBBS draw
+   (stree_propose_theta, stree.c:3957-4060: sliding window with probability opt_theta_slide_prob = 0.1, bpp.c:650;
+   propose_theta_gibbs, stree.c:3645-3826).  Given the gene trees, theta_p's conditional depends on two sums over the
+   loci only: k = the coalescences in p and T = sum of C2ji/heredity (the T2h of a00_msc_term).  Under the gamma(a, b)
+   prior the program fits an INVERSE-GAMMA(a1, b1) to that conditional (get_gamma_conditional_approx, stree.c:3384-3459,
+   the branch of opt_theta_prop = MG_INVG, which bpp.c:975 makes the default for a gamma prior): its mode m and
+   curvature give mmv = m^2/v, a1 is the root of x^3 - (4 + mmv) x^2 + (5 - 2 mmv) x - (2 + mmv) between (mmv + 2)/2
+   and 2 (mmv + 2) found by bisection to 1e-6 (cubic_root, stree.c:3360), b1 = m (a1 + 1).  The proposal
+   theta' = b1 / gamma(a1, 1) (legacy_rndgamma, random.c:240-275: Marsaglia-Tsang with the Box-Muller-Marsaglia normal
+   of rndNormal, random.c:215-232) is accepted on
+       k log(theta/theta') - T (1/theta' - 1/theta)  +  (a - 1) log(theta'/theta) - b (theta' - theta)
+                                                      +  (-a1 - 1) log(theta/theta') - b1 (1/theta - 1/theta').
+   The functions below restate the three pieces; they are bit-equal to the reference's on the same state and the same
+   arguments (tests/test_bpp_kernel.py) and compile for the host driver and the device kernel alike (A00_HD).  The two
+   rejection loops are bounded (64 rounds each: a round fails with probability < 0.22 resp. < 0.05); a draw that runs
+   out returns NaN and the step is rejected.                                                                         */
+#ifdef __HIPCC__
+#define A00_HD __host__ __device__
+#else
+#define A00_HD
+#endif
+static inline A00_HD double a00_bpp_rndu_hd(unsigned int * z)
+{
+  *z = *z*69069u + 1u;
+  if (*z == 0) *z = 12345671u;
+  return (double)(*z)*(1.0/4294967296.0);                       /* = ldexp(z, -32), exact */
+}
+static inline A00_HD double a00_bpp_rndnormal(unsigned int * z)
+{
+  int round_;
+  for (round_ = 0; round_ < 64; ++round_)
+  {
+    const double u = 2*a00_bpp_rndu_hd(z) - 1, v = 2*a00_bpp_rndu_hd(z) - 1;
+    const double s = u*u + v*v;
+    if (s > 0 && s < 1) return u*sqrt(-2*log(s)/s);             /* (the second variate of the pair is not used) */
+  }
+  return NAN;
+}
+static inline A00_HD double a00_bpp_rndgamma(unsigned int * z, double shape)
+{
+  const double a = shape < 1 ? shape + 1 : shape;
+  const double d = a - 1.0/3.0, c = (1.0/3.0)/sqrt(d);
+  double x, v = NAN, u;
+  int round_, inner;
+  for (round_ = 0; round_ < 64; ++round_)
+  {
+    for (inner = 0; inner < 64; ++inner)
+    {
+      x = a00_bpp_rndnormal(z);
+      v = 1.0 + c*x;
+      if (!(v <= 0)) break;
+    }
+    if (!(v > 0)) return NAN;
+    v *= v*v;
+    u = a00_bpp_rndu_hd(z);
+    if (u < 1 - 0.0331*x*x*x*x) break;
+    if (log(u) < 0.5*x*x + d*(1 - v + log(v))) break;
+  }
+  if (round_ == 64) return NAN;
+  v *= d;
+  if (shape < 1) v *= pow(a00_bpp_rndu_hd(z), 1/shape);
+  if (v == 0) v = 1E-300;
+  return v;
+}
+static inline A00_HD double a00_cubic_value(const double * c, double x) { return c[0]*x*x*x + c[1]*x*x + c[2]*x + c[3]; }
+static inline A00_HD void a00_theta_conditional_invgamma(double a, double b, long k, double T, double * a1, double * b1)
+{
+  double c[4], lo, hi, flo, x = 0, f;
+  int i;
+  if (T == 0) { *a1 = a + 2; *b1 = a*(a + 1)/b; return; }
+  {
+    const double a1k = a - 1 - k;
+    const double m = (a1k + sqrt(a1k*a1k + 4*b*T))/(2*b);       /* the conditional's mode */
+    const double ddl = -(a1k + 2*T/m)/(m*m);
+    const double v = -1/ddl, mmv = m*m/v;
+    c[0] = 1; c[1] = -(4 + mmv); c[2] = 5 - 2*mmv; c[3] = -(2 + mmv);
+    lo = (mmv + 2)/2; hi = (mmv + 2)*2;
+    flo = a00_cubic_value(c, lo);
+    if (!(flo*a00_cubic_value(c, hi) <= 0)) { *a1 = NAN; *b1 = NAN; return; }        /* (the program stops here: 'bounds error') */
+    for (i = 0; i < 100; ++i)
+    {
+      x = (lo + hi)/2;
+      if (fabs(lo - hi) < 1e-6) break;
+      f = a00_cubic_value(c, x);
+      if (flo*f > 0) { lo = x; flo = f; } else hi = x;
+    }
+    *a1 = x; *b1 = m*(x + 1);
+  }
+}
+/* ln of the acceptance ratio of a theta proposal from the two sums (both moves: the density's change is the first line) */
+static inline A00_HD double a00_theta_lnacc(long k, double T, double told, double tnew, double a, double b)
+{
+  return (k*(log(2.0/tnew) - log(2.0/told)) - (T/tnew - T/told)) + ((a - 1)*log(tnew/told) - b*(tnew - told));
+}
+static inline A00_HD double a00_theta_gibbs_hastings(double a1, double b1, double told, double tnew)
+{
+  return (-a1 - 1)*log(told/tnew) - b1*(1/told - 1/tnew);
+}
+/* The program's MIXING step moves the thetas too (proposal_mixing, prop_mixing.c:272-425; opt_mix_theta_update = 1,
+   bpp.c:581): with all ages and taus times c, every theta is drawn from the inverse-gamma fitted to its conditional given
+   the SCALED trees (k, c T); the proposal ratio is  invgamma(theta | fit(k, T)) / invgamma(theta' | fit(k, c T))
+   (logPDFInvG, prop_mixing.c:254-263), the prior ratio the gamma prior's; log c is finetune x the Bactrian-Laplace variate. */
+static inline A00_HD double a00_invgamma_logpdf(double x, double a, double b)
+{
+  return a*log(b) - lgamma(a) + (-a - 1)*log(x) - b/x;
+}
+
 /* gene tree of one locus: tips 0..tips-1, inner nodes after; the root node object stays
    the root (gtree.c:6129-6175), so pmatrix indices never collide */
 typedef struct a00_tree
@@ -140,12 +247,24 @@ int            a00_set_tip_species(a00_driver_t *, unsigned i, const int * speci
 #define A00_KERNEL_UNIFORM 0
 #define A00_KERNEL_BPP     1
 void           a00_set_proposal_kernel(a00_driver_t *, int kind);
+/* THETA as the program does it (needs A00_KERNEL_BPP): each theta gets the sliding window with probability slide_prob
+   and the metropolized Gibbs draw above otherwise (BPP: 0.1).  1 (default): sliding window only.  With slide_prob < 1
+   BOTH moves are decided from the two sums over loci (k exactly, T as a sum of 2^-40 fixed-point terms, so that the
+   device kernel's order-free sum is the same number).                                                              */
+void           a00_set_theta_slide_prob(a00_driver_t *, double slide_prob);
+void           a00_gibbs_counters(const a00_driver_t *, unsigned long * proposals, unsigned long * accepted);
+/* MIX as the program does it (needs A00_KERNEL_BPP and a theta prior): the thetas are re-drawn with the scaled trees
+   inside the mixing proposal, see a00_invgamma_logpdf.  0 (default): ages and taus only. */
+void           a00_set_mix_theta_update(a00_driver_t *, int on);
 /* worker threads of the per-locus loops (proposal, MSC density, bookkeeping, roll-back; OpenMP).  Every draw of a per-locus
    proposal comes from that locus's own stream and sums over loci are taken in locus order afterwards, so the trajectory
    does not depend on the count.  Default 1, or the environment's A00_THREADS; threads.c:87-200 is the reference's form */
 void           a00_set_threads(a00_driver_t *, int threads);
-/* the first n values of the restated generator / window variate from state `seed` (tests) */
-void           a00_bpp_kernel_sequence(unsigned int seed, int symmetrical, int n, double * out);
+/* the first n values of the restated generator (what = 0) / window variate (1) / gamma(shape, 1) variate (2) from
+   state `seed` (tests) */
+void           a00_bpp_kernel_sequence(unsigned int seed, int what, int n, double * out);
+void           a00_bpp_gamma_sequence(unsigned int seed, double shape, int n, double * out);
+void           a00_theta_conditional(double a, double b, long k, double T, double * a1b1);
 /* window widths of the four moves (defaults 0.004, 0.004, 0.001, 0.3) */
 void           a00_set_finetune(a00_driver_t *, double gage, double gspr, double tau, double mix);
 /* prior on the divergence times as BPP's 'tauprior = gamma a b': gamma(alpha, beta) on the root tau, the

@@ -112,6 +112,21 @@ class Driver:
         lib().a00_set_threads.argtypes = [C.c_void_p, C.c_int]
         lib().a00_set_threads(self.h, int(n))
 
+    def set_theta_slide_prob(self, p):
+        """THETA the program's way: sliding window with this probability, the metropolized Gibbs draw otherwise"""
+        lib().a00_set_theta_slide_prob.argtypes = [C.c_void_p, C.c_double]
+        lib().a00_set_theta_slide_prob(self.h, float(p))
+
+    def set_mix_theta_update(self, on):
+        lib().a00_set_mix_theta_update.argtypes = [C.c_void_p, C.c_int]
+        lib().a00_set_mix_theta_update(self.h, int(bool(on)))
+
+    def gibbs_counters(self):
+        a, b = C.c_ulong(), C.c_ulong()
+        lib().a00_gibbs_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]
+        lib().a00_gibbs_counters(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def set_proposal_kernel(self, kind):
         """0 uniform windows on the a00 streams (default), 1 BPP's legacy_rndu + Bactrian-Laplace (A00_KERNEL_BPP)"""
         lib().a00_set_proposal_kernel.argtypes = [C.c_void_p, C.c_int]

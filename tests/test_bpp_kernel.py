@@ -50,6 +50,56 @@ def test_generator_and_window_bit_equal_to_the_reference(seed):
     assert abs(x.mean()) < 0.05 and abs(x.var() - 1.0) < 0.08                    # mean 0, variance 1 (random.c:203-205)
 
 
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed", [7, 2654435769])
+def test_gibbs_theta_pieces_bit_equal_to_the_reference(seed):
+    """the three pieces of the program's metropolized Gibbs draw of a theta (propose_theta_gibbs, stree.c:3645): rndNormal
+    (random.c:215), legacy_rndgamma (random.c:240) and the inverse-gamma fit get_gamma_conditional_approx (stree.c:3384,
+    opt_theta_prop = MG_INVG under a gamma prior) — restated in include/bpp_amd_host.h for the host driver AND the device
+    kernel, bit-equal to the reference's functions on the same state / arguments"""
+    R = O.ref()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    R.rndNormal.restype = C.c_double; R.rndNormal.argtypes = [C.c_long]
+    R.legacy_rndgamma.restype = C.c_double; R.legacy_rndgamma.argtypes = [C.c_long, C.c_double]
+    R.set_legacy_rndu_array.argtypes = [C.c_void_p]
+    L = hostdrv.lib()
+    L.a00_bpp_kernel_sequence.argtypes = [C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.a00_bpp_gamma_sequence.argtypes = [C.c_uint, C.c_double, C.c_int, C.POINTER(C.c_double)]
+    n = 3000
+
+    def reseed():
+        z = libc.malloc(16)
+        C.cast(z, C.POINTER(C.c_uint))[0] = seed
+        R.set_legacy_rndu_array(z)
+    reseed()
+    want = np.array([R.rndNormal(0) for _ in range(n)])
+    got = np.zeros(n)
+    L.a00_bpp_kernel_sequence(seed, 2, n, got.ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    for shape in (0.3, 1.0, 2.5, 31.0, 1234.5, 30001.0):
+        reseed()
+        want = np.array([R.legacy_rndgamma(0, shape) for _ in range(n)])
+        L.a00_bpp_gamma_sequence(seed, shape, n, got.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), shape
+        assert abs(got.mean() / shape - 1) < 0.1
+    # the conditional's inverse-gamma fit
+    C.c_long.in_dll(R, "opt_theta_prior").value = 2                     # BPP_THETA_PRIOR_GAMMA (bpp.h:275)
+    C.c_long.in_dll(R, "opt_theta_prop").value = 1                      # BPP_THETA_PROP_MG_INVG (bpp.h:277)
+    R.get_gamma_conditional_approx.argtypes = [C.c_double, C.c_double, C.c_long, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.a00_theta_conditional.argtypes = [C.c_double, C.c_double, C.c_long, C.c_double, C.POINTER(C.c_double)]
+    rng = np.random.default_rng(seed)
+    for _ in range(300):
+        a, b = float(rng.choice([2.0, 3.0, 21.0])), float(rng.choice([100.0, 1000.0, 2000.0]))
+        k = int(rng.integers(0, 40000))
+        T = float(rng.choice([0.0, rng.uniform(0, 1e-3), rng.uniform(0, 80.0)]))
+        a1, b1 = C.c_double(), C.c_double()
+        R.get_gamma_conditional_approx(a, b, k, T, C.byref(a1), C.byref(b1))
+        mine = np.zeros(2)
+        L.a00_theta_conditional(a, b, k, T, mine.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.array_equal(mine.view(np.uint64), np.array([a1.value, b1.value]).view(np.uint64)), (a, b, k, T)
+
+
 def test_prior_sampling_with_the_bpp_kernel_matches_direct_msc_simulation():
     taxa, theta = 4, 0.004
     nloci, iters, burn = 400, 60, 10
@@ -94,12 +144,16 @@ def test_prior_sampling_with_the_bpp_kernel_matches_direct_msc_simulation():
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
-def test_host_driver_with_the_bpp_kernel_reproduces_bpp_posterior():
+@pytest.mark.parametrize("slide_prob", [1.0, 0.1])
+def test_host_driver_with_the_bpp_kernel_reproduces_bpp_posterior(slide_prob):
+    """slide_prob 0.1: the program's own THETA mix (stree.c:3957: sliding window 1 time in 10, metropolized Gibbs draw otherwise)"""
     gold = json.load(open(os.path.join(HERE, "golden", "a00_posterior.json")))
     c = gold["config"]
     data = dataset(gold)
     drv = hostdrv.reference_driver(data, seed=6)
     drv.set_proposal_kernel(1)
+    drv.set_theta_slide_prob(slide_prob)
+    drv.set_mix_theta_update(slide_prob < 1)                         # ... and its mixing step, which re-draws the thetas (prop_mixing.c:272)
     parent, tau, thetas = synth.species_tree_arrays(c["taxa"], c["theta"])
     drv.set_species_tree(parent, tau, thetas)
     drv.set_tau_prior(*c["tau_prior"])
@@ -114,4 +168,9 @@ def test_host_driver_with_the_bpp_kernel_reproduces_bpp_posterior():
     compare(S, gold)
     p, a, _ = drv.counters()
     assert 0.15 < a / p < 0.9
+    gp, ga = drv.gibbs_counters()
+    if slide_prob < 1:
+        assert 0.85 < gp / (16000 * 3 * 0.9) < 1.15 and 0.3 < ga / gp <= 1.0, (gp, ga)
+    else:
+        assert gp == 0
     drv.close()
