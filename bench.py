@@ -28,6 +28,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -268,48 +269,62 @@ def run_efficiency(eng, cfg, data, loci, chain, prog_rate, steps_hint=4000):
     import bpp_amd
     from bpp_amd import synth
     ft = chain["finetune"]
-    smp = bpp_amd.Sampler(eng, loci, data, seed=11)
-    smp.set_proposal_kernel(1)
-    smp.set_theta_slide_prob(0.1)                                  # the program's THETA mix (bpp.c:650): window 1 in 10, Gibbs draw otherwise
-    smp.set_mix_theta_update(1)                                    # ... and its mixing step: thetas re-drawn with the scaled trees (bpp.c:581)
-    parent, tau, theta = synth.species_tree_arrays(cfg["taxa"])
-    smp.set_species_tree(parent, tau, theta)
-    smp.set_tau_prior(2.0, 500.0)                                  # A00_CTL: tauprior = gamma 2 500
-    smp.set_theta_prior(2.0, 1000.0, ft["th2"])                    #          thetaprior = gamma 2 1000
-    smp.set_finetune(ft["gage"], ft["gspr"], ft["tau"], ft["mix"])
-    smp.initialize()
-    smp.iterate(500)
-    eng.synchronize()
-    t0 = time.perf_counter()
-    smp.iterate(3000)
-    eng.synchronize()
-    rate = 3000 / (time.perf_counter() - t0)
     S = cfg["taxa"]
-    tr_tau, tr_theta = [], []
-    for _ in range(steps_hint):
-        smp.iterate(1)
-        tr_tau.append(smp.taus()[-1]); tr_theta.append(smp.thetas()[-1])
-    sm = smp.summary()
-    gibbs = smp.gibbs_counters()
-    smp.close()
+
+    def chain_on_device(program):
+        smp = bpp_amd.Sampler(eng, make_loci(eng, data), data, seed=11)
+        parent, tau, theta = synth.species_tree_arrays(cfg["taxa"])
+        smp.set_species_tree(parent, tau, theta)
+        smp.set_tau_prior(2.0, 500.0)                                  # A00_CTL: tauprior = gamma 2 500
+        if program:
+            smp.set_proposal_kernel(1)
+            smp.set_program_moves(True, 0.1)                           # THETA / TAU / MIX as the program runs them (bpp.c:650, 618, 581)
+            smp.set_theta_prior(2.0, 1000.0, ft["th2"])                #          thetaprior = gamma 2 1000
+            smp.set_finetune(ft["gage"], ft["gspr"], ft["tau"], ft["mix"])
+        else:
+            scale = 1.0 / math.sqrt(len(data))                         # (the headline section's step lengths)
+            smp.set_theta_prior(2.0, 1000.0, 0.008 * scale)
+            smp.set_finetune(0.004, 0.004, 0.004 * scale, 0.6 * scale)
+        smp.initialize()
+        smp.iterate(500)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        smp.iterate(3000)
+        eng.synchronize()
+        rate = 3000 / (time.perf_counter() - t0)
+        tr_tau, tr_theta = [], []
+        for _ in range(steps_hint):
+            smp.iterate(1)
+            tr_tau.append(smp.taus()[-1]); tr_theta.append(smp.thetas()[-1])
+        sm = smp.summary()
+        gibbs = smp.gibbs_counters()
+        smp.close()
+        d_ = dict(iterations_per_s=round(rate, 1), samples=steps_hint, acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
+                  tau_root=dict(mean=float(np.mean(tr_tau)), sd=float(np.std(tr_tau)), ess_per_iteration=round(ess(tr_tau) / steps_hint, 4)),
+                  theta_root=dict(mean=float(np.mean(tr_theta)), sd=float(np.std(tr_theta)), ess_per_iteration=round(ess(tr_theta) / steps_hint, 4)))
+        if program:
+            d_["theta_gibbs_draws"] = dict(proposed=gibbs[0], accepted=gibbs[1])
+        return d_
+    dev = chain_on_device(True)
+    dev_uniform = chain_on_device(False)
     root = f"{S + 1}"
     p_tau, p_theta = chain["trace"].get("tau:" + root), chain["trace"].get("theta:" + root)
-    dev = dict(iterations_per_s=round(rate, 1), samples=steps_hint, acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
-               theta_gibbs_draws=dict(proposed=gibbs[0], accepted=gibbs[1]),
-               tau_root=dict(mean=float(np.mean(tr_tau)), sd=float(np.std(tr_tau)), ess_per_iteration=round(ess(tr_tau) / steps_hint, 4)),
-               theta_root=dict(mean=float(np.mean(tr_theta)), sd=float(np.std(tr_theta)), ess_per_iteration=round(ess(tr_theta) / steps_hint, 4)))
     prog = dict(iterations_per_s=prog_rate, samples=chain["samples"], threads=chain["threads"],
                 tau_root=dict(mean=float(np.mean(p_tau)), sd=float(np.std(p_tau)), ess_per_iteration=round(ess(p_tau) / len(p_tau), 4)),
                 theta_root=dict(mean=float(np.mean(p_theta)), sd=float(np.std(p_theta)), ess_per_iteration=round(ess(p_theta) / len(p_theta), 4)))
-    for d_ in (dev, prog):
+    for d_ in (dev, dev_uniform, prog):
         for k in ("tau_root", "theta_root"):
             d_[k]["ess_per_s"] = round(d_[k]["ess_per_iteration"] * d_["iterations_per_s"], 2)
-    return dict(device=dev, reference_program=prog, step_lengths=ft,
+    return dict(device=dev, device_uniform_kernel=dev_uniform, reference_program=prog, step_lengths=ft,
                 ratio_ess_per_s=dict(tau_root=round(dev["tau_root"]["ess_per_s"] / max(prog["tau_root"]["ess_per_s"], 1e-9), 1),
                                      theta_root=round(dev["theta_root"]["ess_per_s"] / max(prog["theta_root"]["ess_per_s"], 1e-9), 1)),
-                note="the device sampler with BPP's own proposal kernel (Bactrian-Laplace m = 0.9 windows, legacy_rndu, acceptance number "
-                     "drawn only when needed; THETA as the program mixes it: sliding window 1 time in 10, metropolized Gibbs draw otherwise; its mixing step, "
-                     "which re-draws the thetas with the scaled trees) "
+                note_uniform_kernel="device_uniform_kernel: the headline section's sampler (our 64-bit streams, uniform windows, sliding-window THETA, "
+                     "TAU and MIX without theta re-draws; step lengths 0.004, 0.004 and 0.008, 0.004, 0.6 over sqrt(loci)) on the program's priors: "
+                     "the same work per iteration, fewer effective samples per iteration than the program's moves",
+                note="device: the device sampler with BPP's own proposal kernel (Bactrian-Laplace m = 0.9 windows, legacy_rndu, acceptance number "
+                     "drawn only when needed; and the program's THETA / TAU / MIX (bpa_sampler_set_program_moves: sliding window 1 time in 10 and the metropolized "
+                     "Gibbs draw otherwise, thetas re-drawn inside the rubber-band and the mixing proposals): the program's iteration move for move, "
+                     "equal effective samples per iteration on the same data (tools/ess_compare.py), "
                      "and the step lengths the program's burn-in (finetune = 1) tuned itself to, the program's priors; "
                      "ESS = n / (1 + 2 sum of autocorrelations) (initial positive sequence) of the traces of tau_root and theta_root, one sample per "
                      "iteration; the program on its own simulated 10000-locus set, the device on the bench's synthetic set of the same model and "
@@ -700,8 +715,16 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
     sp_parent, sp_tau, sp_theta = synth.species_tree_arrays(cfg["taxa"])
     smp.set_species_tree(sp_parent, sp_tau, sp_theta)
     smp.set_tau_prior(3.0, 3.0 / sp_tau[-1])
-    smp.set_theta_prior(2.0, 2.0 / sp_theta[0], 0.5 * sp_theta[0])
     generic = cfg["model"] != "jc69"
+    if generic:
+        smp.set_theta_prior(2.0, 2.0 / sp_theta[0], 0.5 * sp_theta[0])
+    else:
+        # step lengths of the all-loci moves at which the chain moves (acceptance of THETA / TAU / MIX around 0.3): they shrink
+        # with the square root of the number of loci (all ranks' loci: one decision for the whole data set).  The work of an
+        # iteration does not depend on them — every proposal is evaluated in full before its decision.
+        scale = 1.0 / math.sqrt(max(D.sum_int(len(data)) if D else len(data), 1))
+        smp.set_theta_prior(2.0, 2.0 / sp_theta[0], 0.008 * scale)
+        smp.set_finetune(0.004, 0.004, 0.004 * scale, 0.6 * scale)
     if generic:
         # the per-locus substitution-parameter moves of a GTR + Gamma analysis (3 frequencies, 5 exchangeabilities, alpha)
         for i, d in enumerate(data):
@@ -977,7 +1000,7 @@ def main():
     efficiency = None
     if bpp_prog and "error" not in bpp_prog and chain and "error" not in chain and chain.get("finetune"):
         try:
-            efficiency = run_efficiency(eng, cfg, data, make_loci(eng, data), chain, bpp_prog["best_median"])
+            efficiency = run_efficiency(eng, cfg, data, None, chain, bpp_prog["best_median"])
         except Exception as ex:       # noqa: BLE001
             efficiency = dict(error=str(ex)[:300])
     elif chain and "error" in chain:

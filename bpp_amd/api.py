@@ -150,8 +150,7 @@ def lib():
         "bpa_sampler_kind": (i, [vp]),
         "bpa_sampler_set_p2p": (i, [vp, vp, u]),
         "bpa_sampler_set_proposal_kernel": (i, [vp, i]),
-        "bpa_sampler_set_theta_slide_prob": (i, [vp, d]),
-        "bpa_sampler_set_mix_theta_update": (i, [vp, i]),
+        "bpa_sampler_set_program_moves": (i, [vp, i, d]),
         "bpa_sampler_gibbs_counters": (i, [vp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
         "bpa_engine_enable_timing": (None, [vp, i]),
         "bpa_engine_set_timing_stride": (None, [vp, u]),
@@ -188,7 +187,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_sampler_set_theta_prior", "bpa_sampler_get_thetas", "bpa_sampler_set_allreduce",
             "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary",
             "bpa_sampler_enable_timing", "bpa_sampler_timing", "bpa_sampler_work", "bpa_sampler_kind", "bpa_sampler_set_p2p", "bpa_sampler_set_proposal_kernel",
-            "bpa_sampler_set_theta_slide_prob", "bpa_sampler_gibbs_counters", "bpa_sampler_set_mix_theta_update",
+            "bpa_sampler_set_program_moves", "bpa_sampler_gibbs_counters",
             "bpa_sampler_set_subst_model", "bpa_sampler_get_subst_model", "bpa_sampler_set_subst_moves"]
 
 
@@ -584,13 +583,10 @@ class Sampler:
         """0 uniform windows on our streams (default), 1 BPP's legacy_rndu + Bactrian-Laplace (before initialize)"""
         _chk(lib().bpa_sampler_set_proposal_kernel(self.h, int(kind)))
 
-    def set_theta_slide_prob(self, p):
-        """THETA the program's way (BPP kernel): sliding window with probability p (BPP: 0.1), metropolized Gibbs draw otherwise"""
-        _chk(lib().bpa_sampler_set_theta_slide_prob(self.h, float(p)))
-
-    def set_mix_theta_update(self, on):
-        """MIX the program's way (BPP kernel): the thetas are re-drawn with the scaled trees inside the mixing proposal"""
-        _chk(lib().bpa_sampler_set_mix_theta_update(self.h, int(bool(on))))
+    def set_program_moves(self, on, slide_prob=0.1):
+        """THETA / TAU / MIX as the program runs them (BPP kernel): sliding window with probability slide_prob and the
+        metropolized Gibbs draw otherwise, thetas re-drawn inside the rubber-band and the mixing proposals"""
+        _chk(lib().bpa_sampler_set_program_moves(self.h, int(bool(on)), float(slide_prob)))
 
     def gibbs_counters(self):
         a, b = C.c_ulong(), C.c_ulong()

@@ -30,8 +30,11 @@ struct a00_driver
   a00_rng_t * rng;                      /* one stream per locus */
   a00_rng_t grng;                       /* global stream (mixing step) */
   int kernel;                           /* A00_KERNEL_UNIFORM / A00_KERNEL_BPP */
-  double theta_slide_prob;              /* A00_KERNEL_BPP: share of sliding-window THETA proposals, the rest Gibbs draws (1: all) */
-  int mix_theta_update;                 /* A00_KERNEL_BPP: the mixing step re-draws the thetas (prop_mixing.c:272) */
+  int program_moves;                    /* A00_KERNEL_BPP: THETA / TAU / MIX as the program runs them (a00_set_program_moves) */
+  double theta_slide_prob;              /*   share of sliding-window THETA proposals, the rest Gibbs draws */
+  long long run_k[A00_MAXPOP];          /*   k_p and T_p of the current gene trees, from the THETA step's sums on: an accepted */
+  double run_T[A00_MAXPOP];             /*   TAU puts the new sums of its three populations in, an accepted MIX multiplies by c */
+  int run_ok;
   unsigned int * zrng, gz;              /* A00_KERNEL_BPP: legacy_rndu states, per locus and global */
   /* step scratch */
   unsigned * s_locus; a00_tree_t ** s_tree; unsigned * s_br_off, * s_nd_off;
@@ -112,8 +115,8 @@ static void declog(const char * what, int k, double lnacc, double u, int acc)
 
 void a00_set_proposal_kernel(a00_driver_t * d, int kind) { d->kernel = kind == A00_KERNEL_BPP ? A00_KERNEL_BPP : A00_KERNEL_UNIFORM; }
 
-void a00_set_theta_slide_prob(a00_driver_t * d, double p) { d->theta_slide_prob = p < 0 ? 0 : p > 1 ? 1 : p; }
-void a00_set_mix_theta_update(a00_driver_t * d, int on) { d->mix_theta_update = on != 0; }
+void a00_set_program_moves(a00_driver_t * d, int on, double slide_prob)
+{ d->program_moves = on != 0; d->theta_slide_prob = slide_prob < 0 ? 0 : slide_prob > 1 ? 1 : slide_prob; }
 void a00_gibbs_counters(const a00_driver_t * d, unsigned long * proposals, unsigned long * accepted)
 { if (proposals) *proposals = d->gibbs_proposals; if (accepted) *accepted = d->gibbs_accepted; }
 
@@ -172,7 +175,7 @@ a00_driver_t * a00_create(unsigned nloci, a00_eval_fn eval, void * ctx, unsigned
   d->p_slot = (int *)calloc(nloci, sizeof(int)); d->u_pop = (int **)calloc(nloci, sizeof(int *));
   d->ft_gage = 0.004; d->ft_gspr = 0.004; d->ft_tau = 0.001; d->ft_mix = 0.3;
   d->threads = 1;
-  d->theta_slide_prob = 1.0;
+  d->theta_slide_prob = 0.1;
   { const char * ev = getenv("A00_THREADS"); if (ev && atoi(ev) > 0) a00_set_threads(d, atoi(ev)); }
   d->w_nb = (int *)calloc(nloci, sizeof(int)); d->w_nn = (int *)calloc(nloci, sizeof(int));
   d->w_hast = (double *)calloc(nloci, sizeof(double)); d->w_logpr = (double *)calloc(nloci, sizeof(double));
@@ -623,7 +626,7 @@ static int theta_step_all(a00_driver_t * d)
 {
   unsigned i; int p; long li;
   double tnew[A00_MAXPOP], uacc[A00_MAXPOP], sum[A00_MAXPOP];
-  if (d->kernel == A00_KERNEL_BPP && d->theta_slide_prob < 1.0) return theta_step_gibbs(d);
+  if (d->kernel == A00_KERNEL_BPP && d->program_moves) return theta_step_gibbs(d);
   for (p = 0; p < d->npop; ++p)
   {
     sum[p] = 0; tnew[p] = d->theta[p];
@@ -684,7 +687,7 @@ static int theta_sums(a00_driver_t * d, long long * ksum, long long * tsum)
   return !bad;
 }
 
-/* THETA the program's way (a00_set_theta_slide_prob < 1, A00_KERNEL_BPP): per theta, in population order, the sliding
+/* THETA the program's way (a00_set_program_moves, A00_KERNEL_BPP): per theta, in population order, the sliding
    window with probability slide_prob, else the metropolized Gibbs draw of bpp_amd_host.h — both decided from
    k_p = sum over loci of the coalescences in p and T_p = sum of T2h (2^-40 fixed point: no order).  Global stream:
    the choices (and the windows of the sliding ones) of all populations first, then per population the Gibbs variate
@@ -702,6 +705,8 @@ static int theta_step_gibbs(a00_driver_t * d)
     if (slide[p]) tnew[p] = a00_reflect(d->theta[p] + d->ft_theta*draw_window(d, -1), 0.0, 999.0);
   }
   bad = !theta_sums(d, ksum, tsum);
+  d->run_ok = !bad;
+  for (p = 0; p < d->npop; ++p) { d->run_k[p] = ksum[p]; d->run_T[p] = (double)tsum[p]*(1.0/1099511627776.0); }
   for (p = 0; p < d->npop; ++p)
   {
     double lnacc = NAN, T; int acc_ = 0;
@@ -740,8 +745,16 @@ static int theta_step_gibbs(a00_driver_t * d)
    sum(dlogpr + dlnL) + below*log(minfactor) + above*log(maxfactor)   (stree.c:6280) */
 static int tau_step(a00_driver_t * d, int q)
 {
-  unsigned i, n; long li; double sum = 0; int acc_;
+  unsigned i, n; long li; double sum = 0; int acc_, j, bad = 0;
   const int cl = d->sp_left[q], cr = d->sp_right[q], pq = d->sp_parent[q];
+  /* the program's rubber band also re-draws the thetas of q and its two children (opt_rb_theta_update = 1, bpp.c:618;
+     propose_tau, stree.c:5840-5990): each from the inverse-gamma fitted to its conditional given k_p and the sum of the
+     T2h AFTER the move; the densities' change over all loci then follows from the sums, the loci contribute their
+     likelihood change and their three new T2h */
+  const int program = d->kernel == A00_KERNEL_BPP && d->program_moves && d->theta_alpha > 0;
+  const int aff[3] = { q, cl, cr };
+  long long cnew[3] = { 0, 0, 0 };
+  double oldtheta[3];
   const double old = d->tau[q], lo = fmax(d->tau[cl], d->tau[cr]), hi = pq >= 0 ? d->tau[pq] : 999.0;
   const double tnew = a00_reflect(old + d->ft_tau*draw_window(d, -1), lo, hi);
   const double uacc = d->kernel == A00_KERNEL_BPP ? -1.0 : draw_u(d, -1);
@@ -765,8 +778,18 @@ static int tau_step(a00_driver_t * d, int q)
       isbr[t->left[k]] = isbr[t->right[k]] = 1; if (t->parent[k] >= 0) isbr[k] = 1;
       for (v = k; v >= 0; v = t->parent[v]) isnd[v] = 1;              /* gtree_return_partials, gtree.c:145-175 */
     }
-    d->p_logpr[i] = tree_logpr(d, t);
-    d->p_delta[i] = (d->p_logpr[i] - t->logpr) + below*lminf + above*lmaxf;
+    if (program)
+    {
+      int nc[A00_MAXPOP]; double t2h[A00_MAXPOP]; int jj;
+      d->p_logpr[i] = tree_logpr_stats(d, t, nc, t2h);
+      for (jj = 0; jj < 3; ++jj) d->w_diff[(size_t)i*A00_MAXPOP + jj] = d->p_logpr[i] == d->p_logpr[i] ? t2h[aff[jj]] : NAN;
+      d->p_delta[i] = below*lminf + above*lmaxf;
+    }
+    else
+    {
+      d->p_logpr[i] = tree_logpr(d, t);
+      d->p_delta[i] = (d->p_logpr[i] - t->logpr) + below*lminf + above*lmaxf;
+    }
     if (!(above + below)) continue;
     for (k = 0; k < t->n; ++k) { if (isbr[k]) br[nb++] = k; if (isnd[k]) nd[nn++] = k; }
     install_local(d, i, br, nb, nd, nn, 0.0, d->p_logpr[i]);
@@ -776,18 +799,51 @@ static int tau_step(a00_driver_t * d, int q)
   for (i = 0; i < d->nloci; ++i)
     sum += d->p_slot[i] >= 0 ? (d->s_lnl[d->p_slot[i]] - d->trees[i].lnl) + d->p_delta[i] : d->p_delta[i];
   if (pq < 0) sum += root_tau_prior_ratio(d, old, tnew);
+  if (program)
+  {
+    for (i = 0; i < d->nloci; ++i)
+      for (j = 0; j < 3; ++j)
+      {
+        const double x = d->w_diff[(size_t)i*A00_MAXPOP + j];
+        if (!(fabs(x) < 256.0)) bad = 1; else cnew[j] += llrint(x*1099511627776.0);
+      }
+    for (j = 0; j < 3; ++j)
+    {
+      const int p = aff[j]; double a1, b1, a1o, b1o, g, tn, Cn; const double to = d->theta[p]; const long k = (long)d->run_k[p];
+      oldtheta[j] = to;
+      if (!d->has_theta[p]) continue;
+      if (bad || !d->run_ok) { sum = NAN; continue; }
+      Cn = (double)cnew[j]*(1.0/1099511627776.0);
+      a00_theta_conditional_invgamma(d->theta_alpha, d->theta_beta, k, Cn, &a1, &b1);
+      a00_theta_conditional_invgamma(d->theta_alpha, d->theta_beta, k, d->run_T[p], &a1o, &b1o);
+      if (!(a1 == a1 && a1o == a1o)) { sum = NAN; continue; }
+      g = a00_bpp_rndgamma(&d->gz, a1);
+      tn = 1.0/(g/b1);
+      sum += (a00_invgamma_logpdf(to, a1o, b1o) - a00_invgamma_logpdf(tn, a1, b1))
+           + ((d->theta_alpha - 1)*log(tn/to) - d->theta_beta*(tn - to))
+           + (k*(log(2.0/tn) - log(2.0/to)) - (Cn/tn - d->run_T[p]/to));
+      d->theta[p] = tn;
+    }
+  }
   d->proposals++;
   acc_ = accept(d, -1, sum, uacc);
   declog("tau", q, sum, uacc, acc_);
   if (acc_)
   {
     d->accepted++;
+    if (program)
+    {
+      for (j = 0; j < 3; ++j) if (d->has_theta[aff[j]]) d->run_T[aff[j]] = (double)cnew[j]*(1.0/1099511627776.0);
+#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+      for (li = 0; li < (long)d->nloci; ++li) d->p_logpr[li] = tree_logpr(d, d->trees + li);        /* (with the new thetas) */
+    }
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
     for (li = 0; li < (long)d->nloci; ++li) { d->trees[li].logpr = d->p_logpr[li]; if (d->p_slot[li] >= 0) d->trees[li].lnl = d->s_lnl[d->p_slot[li]]; }
   }
   else
   {
     d->tau[q] = old;
+    if (program) for (j = 0; j < 3; ++j) d->theta[aff[j]] = oldtheta[j];
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
     for (li = 0; li < (long)d->nloci; ++li) if (d->p_slot[li] >= 0) restore(d, (unsigned)li);
   }
@@ -802,27 +858,27 @@ static int mix_step(a00_driver_t * d)
   /* log c: finetune x BPP's window variate with its kernel (prop_mixing.c:300), uniform with ours */
   const double lnc = d->ft_mix*(d->kernel == A00_KERNEL_BPP ? draw_window(d, -1) : draw_u(d, -1) - 0.5), c = exp(lnc);
   const double uacc = d->kernel == A00_KERNEL_BPP ? -1.0 : draw_u(d, -1);
-  const int theta_update = d->kernel == A00_KERNEL_BPP && d->mix_theta_update && d->theta_alpha > 0;
+  const int program = d->kernel == A00_KERNEL_BPP && d->program_moves && d->theta_alpha > 0;
   if (!staging_ready(d)) return 0;
   for (p = 0; p < d->npop; ++p) oldtheta[p] = d->theta[p];
-  if (theta_update)
+  if (program)
   {
-    /* the thetas from their conditionals given the scaled trees (prop_mixing.c:272-425), in population order */
-    long long ksum[A00_MAXPOP], tsum[A00_MAXPOP];
-    const int usable = theta_sums(d, ksum, tsum);
+    /* the thetas from their conditionals given the scaled trees (prop_mixing.c:272-425), in population order; the
+       densities' change over all loci follows from the sums: k (log 2/theta' - log 2/theta) - (c T/theta' - T/theta) */
     for (p = 0; p < d->npop; ++p)
     {
-      double a1, b1, a1o, b1o, Ts, g, tn;
+      double a1, b1, a1o, b1o, Ts, g, tn; const double to = oldtheta[p]; const long k = (long)d->run_k[p];
       if (!d->has_theta[p]) continue;
-      if (!usable) { lnacc_theta = NAN; continue; }
-      Ts = (double)tsum[p]*(1.0/1099511627776.0)*c;
-      a00_theta_conditional_invgamma(d->theta_alpha, d->theta_beta, (long)ksum[p], Ts, &a1, &b1);
-      a00_theta_conditional_invgamma(d->theta_alpha, d->theta_beta, (long)ksum[p], Ts/c, &a1o, &b1o);
+      if (!d->run_ok) { lnacc_theta = NAN; continue; }
+      Ts = d->run_T[p]*c;
+      a00_theta_conditional_invgamma(d->theta_alpha, d->theta_beta, k, Ts, &a1, &b1);
+      a00_theta_conditional_invgamma(d->theta_alpha, d->theta_beta, k, Ts/c, &a1o, &b1o);
       if (!(a1 == a1 && a1o == a1o)) { lnacc_theta = NAN; continue; }
       g = a00_bpp_rndgamma(&d->gz, a1);
       tn = 1.0/(g/b1);
-      lnacc_theta += (a00_invgamma_logpdf(oldtheta[p], a1o, b1o) - a00_invgamma_logpdf(tn, a1, b1))
-                   + ((d->theta_alpha - 1)*log(tn/oldtheta[p]) - d->theta_beta*(tn - oldtheta[p]));
+      lnacc_theta += (a00_invgamma_logpdf(to, a1o, b1o) - a00_invgamma_logpdf(tn, a1, b1))
+                   + ((d->theta_alpha - 1)*log(tn/to) - d->theta_beta*(tn - to))
+                   + (k*(log(2.0/tn) - log(2.0/to)) - (Ts/tn - d->run_T[p]/to));
       d->theta[p] = tn;
     }
   }
@@ -839,7 +895,7 @@ static int mix_step(a00_driver_t * d)
       if (t->parent[k] >= 0) br[nb++] = k;
     }
     d->p_logpr[i] = tree_logpr(d, t);
-    d->p_delta[i] = (d->p_logpr[i] - t->logpr) + (double)nn*lnc;
+    d->p_delta[i] = (program ? 0.0 : d->p_logpr[i] - t->logpr) + (double)nn*lnc;
     install_local(d, i, br, nb, nd, nn, 0.0, d->p_logpr[i]);
   }
   if (compact(d) != d->nloci || !step_eval(d, d->nloci)) return 0;          /* every locus has a slot: slot i = locus i */
@@ -856,6 +912,7 @@ static int mix_step(a00_driver_t * d)
     d->accepted++;
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
     for (li = 0; li < (long)d->nloci; ++li) { d->trees[li].lnl = d->s_lnl[li]; d->trees[li].logpr = d->p_logpr[li]; }
+    if (program) for (p = 0; p < d->npop; ++p) d->run_T[p] *= c;
   }
   else
   {

@@ -57,8 +57,8 @@ struct Species
   uint16_t anc[MAXPOP];                    // bit q: q is p or an ancestor of p
   double   ft_gage, ft_gspr, ft_tau, ft_mix, tau_alpha, tau_beta;
   double   ft_theta, theta_alpha, theta_beta;
-  int32_t  mix_theta_update, pad_;         // persistent kernel with BPP's proposal kernel: the mixing step re-draws the thetas (prop_mixing.c:272)
-  double   theta_slide_prob;               // persistent kernel with BPP's proposal kernel: share of sliding-window THETA proposals (1: all), the rest Gibbs draws
+  int32_t  program_moves, pad_;            // persistent kernel with BPP's proposal kernel: THETA / TAU / MIX as the program runs them (bpa_sampler_set_program_moves)
+  double   theta_slide_prob;               //   share of sliding-window THETA proposals, the rest Gibbs draws
 };
 
 struct TaskLDS
@@ -1186,7 +1186,7 @@ extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * co
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   bpa_sampler * s = new bpa_sampler();
   s->eng = e; s->nloci = nloci; s->seed = seed; s->grng = a00_rng_seed(seed, A00_GLOBAL_STREAM);
-  s->sp.theta_slide_prob = 1.0;
+  s->sp.theta_slide_prob = 0.1;
   s->loci.assign(loci, loci + nloci);
   // the LDS sweep kernel (JC69, one rate category, <= 8 tips, <= 64 patterns) where every locus fits it, else the generic
   // path over the engine's step kernels (any 4-state model on the engine's packing, <= 16 tips; BPA_SMP_GENERIC=1 forces it)
@@ -1300,20 +1300,13 @@ extern "C" int bpa_sampler_set_proposal_kernel(bpa_sampler_t * s, int kind)
   return 1;
 }
 
-extern "C" int bpa_sampler_set_theta_slide_prob(bpa_sampler_t * s, double slide_prob)
+extern "C" int bpa_sampler_set_program_moves(bpa_sampler_t * s, int on, double slide_prob)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
-  if (!(slide_prob >= 0 && slide_prob <= 1)) return fail("bpa_sampler_set_theta_slide_prob: a probability");
-  if (slide_prob < 1 && !s->kernel_bpp) return fail("bpa_sampler_set_theta_slide_prob: the Gibbs draw of a theta belongs to BPP's proposal kernel (bpa_sampler_set_proposal_kernel(s, BPA_KERNEL_BPP) first)");
-  s->sp.theta_slide_prob = slide_prob;
-  return 1;
-}
-
-extern "C" int bpa_sampler_set_mix_theta_update(bpa_sampler_t * s, int on)
-{
-  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
-  if (on && !s->kernel_bpp) return fail("bpa_sampler_set_mix_theta_update: the program's mixing step belongs to BPP's proposal kernel (bpa_sampler_set_proposal_kernel(s, BPA_KERNEL_BPP) first)");
-  s->sp.mix_theta_update = on ? 1 : 0;
+  if (on && !(slide_prob >= 0 && slide_prob <= 1)) return fail("bpa_sampler_set_program_moves: slide_prob is a probability");
+  if (on && !s->kernel_bpp) return fail("bpa_sampler_set_program_moves: the program's moves draw from BPP's proposal kernel (bpa_sampler_set_proposal_kernel(s, BPA_KERNEL_BPP) first)");
+  s->sp.program_moves = on ? 1 : 0;
+  if (on) s->sp.theta_slide_prob = slide_prob;
   return 1;
 }
 
@@ -1785,10 +1778,9 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
   if (s->sp.theta_alpha > 0) for (int p = 0; p < npop; ++p) if (s->has_theta[p]) theta_mask |= 1u << p;
   const bool allloci = in_kernel_allloci && !s->env_nomix;
   // exchanges of an iteration: THETA in chunks of 7 populations, one per TAU, one for MIX (sweep2.hpp: exchange)
-  const bool theta_gibbs = s->kernel_bpp && s->sp.theta_slide_prob < 1.0;       // (k, T) per theta instead of one difference per population
-  const unsigned x_theta = !theta_mask ? 0u : theta_gibbs ? (2u*(unsigned)__builtin_popcount(theta_mask) + 6u)/7u : ((unsigned)npop + 6u)/7u;
-  const unsigned x_mix_theta = s->kernel_bpp && s->sp.mix_theta_update && theta_mask ? (2u*(unsigned)__builtin_popcount(theta_mask) + 6u)/7u : 0u;
-  const unsigned x_per_iter = allloci ? x_theta + (unsigned)(npop - S) + 1u + x_mix_theta : 0u;
+  const bool program = s->kernel_bpp && s->sp.program_moves;       // (k, T) per theta instead of one difference per population
+  const unsigned x_theta = !theta_mask ? 0u : program ? (2u*(unsigned)__builtin_popcount(theta_mask) + 6u)/7u : ((unsigned)npop + 6u)/7u;
+  const unsigned x_per_iter = allloci ? x_theta + (unsigned)(npop - S) + 1u : 0u;      // (a TAU of the program's moves: 5 values, one block)
   const unsigned draws_per_iter = allloci ? 2u*(unsigned)__builtin_popcount(theta_mask) + 2u*(unsigned)(npop - S) + 2u : 0u;
   void (*kern)(const smp2::Args) = s->kernel_bpp ? (s->v2_nt == 4 ? smp2::iter_kernel<4, true> : smp2::iter_kernel<8, true>)
                                                  : (s->v2_nt == 4 ? smp2::iter_kernel<4, false> : smp2::iter_kernel<8, false>);

@@ -105,6 +105,8 @@ template <int NT> struct WgLDS
   double lograt[(2*NT)*(2*NT)];
   unsigned long long accfx[32];                  // this workgroup's sums of an all-loci step, 2^-44 fixed point (LDS atomics)
   double xtot[32];
+  double run_k[MAXPOP], run_T[MAXPOP];             // program moves: k_p and T_p of the current gene trees, from the THETA step's sums on (a00_driver.c: run_k, run_T)
+  uint32_t run_ok, pad2_;
   uint32_t anc[16];
   uint32_t abort_, bad_;
   Species sp;
@@ -784,7 +786,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     // ================= THETA: every population that can hold a coalescence, decided independently (theta_step_all)
     if (SP.theta_alpha > 0 && A.theta_mask)
     {
-      const bool gibbs = BPP && SP.theta_slide_prob < 1.0;      // the program's own mix of moves (theta_step_gibbs of a00_driver.c)
+      const bool gibbs = BPP && SP.program_moves;               // the program's own mix of moves (theta_step_gibbs of a00_driver.c)
       const bool on = li < npop && ((A.theta_mask >> li) & 1u);
       const double told = pl.theta, l2t_old = pl.l2t;
       double tnew = told, uacc = -1.0, my_lnacc = 0;
@@ -836,6 +838,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         // the thetas, so ONE exchange serves every population.  Global stream: choice (+ window) per population first,
         // then per population the gamma variate of a Gibbs draw and the acceptance number when one is needed.
         uint32_t slidem = 0;
+        const double qnan_ = __longlong_as_double(0x7ff8000000000000ll);
         for (int p = 0; p < npop; ++p)
           if ((A.theta_mask >> p) & 1u)
           {
@@ -852,6 +855,14 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         SMP2_TICK(6);
         if (on) wl.term[li] = tnew;
         wsync();
+        // the fits of all thetas side by side: lane p of the wave fits population p (the bisection is the long part)
+        double fa = qnan_, fb = qnan_;
+        if (lane < (uint32_t)npop && ((A.theta_mask >> lane) & 1u) && !((slidem >> lane) & 1u))
+        {
+          const int kx = __popc(A.theta_mask & ((1u << lane) - 1u));
+          const double ks = wg.xtot[2*kx], Ts = wg.xtot[2*kx + 1];
+          if (ks == ks && Ts == Ts) a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)ks, Ts, &fa, &fb);
+        }
         int kk = 0;
         for (int p = 0; p < npop; ++p)
           if ((A.theta_mask >> p) & 1u)
@@ -859,6 +870,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
             const double ks = wg.xtot[2*kk], Ts = wg.xtot[2*kk + 1]; ++kk;
             const double to = wg.tau[MAXPOP + p];
             const bool sl = (slidem >> p) & 1u;
+            if (tid == 0) { wg.run_k[p] = ks; wg.run_T[p] = Ts; wg.run_ok = ks == ks && Ts == Ts ? 1u : 0u; }   // (read by TAU and MIX, behind barriers)
             double tn = wl.term[p], lnacc = __longlong_as_double(0x7ff8000000000000ll);
             if (ks == ks && Ts == Ts)                                          // (an unusable term anywhere: every decision is a rejection, nothing drawn)
             {
@@ -866,8 +878,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
               if (sl) lnacc = a00_theta_lnacc(k, Ts, to, tn, SP.theta_alpha, SP.theta_beta);
               else
               {
-                double a1, b1;
-                a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, k, Ts, &a1, &b1);
+                const double a1 = __shfl(fa, p, 64), b1 = __shfl(fb, p, 64);
                 if (a1 == a1)
                 {
                   unsigned int z = (unsigned int)grng.r;
@@ -921,7 +932,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       const double wprop = mix && !BPP ? grng.u() - 0.5 : grng.window(), uacc = BPP ? -1.0 : grng.u();
       // the proposed species tree: in the lanes' registers only
       double tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1, lminf = 0, lmaxf = 0, tq_new = 0, mix_c = 1, mix_lnc = 0;
-      double lnacc_theta = 0; bool th_upd = false;
+      double lnacc_theta = 0;
       if (!mix)
       {
         const int pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
@@ -937,38 +948,68 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         mix_lnc = SP.ft_mix*wprop; mix_c = exp(mix_lnc);
         pl.tau *= mix_c;
         if (pl.parent >= 0) pl.ptau *= mix_c;
-        if (BPP && SP.mix_theta_update && SP.theta_alpha > 0 && A.theta_mask)
-        {
-          // ---- the program's mixing step re-draws the thetas (prop_mixing.c:272-425): each from the inverse-gamma fitted to
-          // its conditional given the SCALED trees, k_p and c T_p — one more exchange brings the two sums per theta —; the
-          // densities of the step are then taken with the new thetas (mix_step of a00_driver.c)
-          th_upd = true;
-          const bool on = li < npop && ((A.theta_mask >> li) & 1u);
-          const int kidx = __popc(A.theta_mask & ((1u << li) - 1u));
-          if (act && on) { fx_add(2*kidx, (double)mync, false); fx_add(2*kidx + 1, t2h_cur, false); }
-          double dummy = 0;
-          if (!exchange(2*__popc(A.theta_mask), 0, dummy)) { aborted = true; break; }
-          int kk = 0;
-          for (int p = 0; p < npop; ++p)
-            if ((A.theta_mask >> p) & 1u)
-            {
-              const double ks = wg.xtot[2*kk], Tsum = wg.xtot[2*kk + 1]; ++kk;
-              if (!(ks == ks && Tsum == Tsum)) { lnacc_theta = __longlong_as_double(0x7ff8000000000000ll); continue; }
-              const double to = wg.tau[MAXPOP + p], Ts = Tsum*mix_c;
-              double a1, b1, a1o, b1o;
-              a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)ks, Ts, &a1, &b1);
-              a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)ks, Ts/mix_c, &a1o, &b1o);
-              if (!(a1 == a1 && a1o == a1o)) { lnacc_theta = __longlong_as_double(0x7ff8000000000000ll); continue; }
-              unsigned int z = (unsigned int)grng.r;
-              const double g = a00_bpp_rndgamma(&z, a1);
-              grng.r = z;
-              const double tn = 1.0/(g/b1);
-              lnacc_theta += (a00_invgamma_logpdf(to, a1o, b1o) - a00_invgamma_logpdf(tn, a1, b1))
-                           + ((SP.theta_alpha - 1)*log(tn/to) - SP.theta_beta*(tn - to));
-              if (p == li) { pl.theta = tn; pl.l2t = log(2.0/(1.0*tn)); }
-            }
-          __syncthreads();                              // (the totals are read: the step's own exchange may overwrite them)
-        }
+      }
+      // ---- the program's TAU and MIX re-draw thetas inside the proposal (a00_set_program_moves: opt_rb_theta_update,
+      // opt_mix_theta_update): the densities' change over all loci then follows from k_p and the T2h sums, the loci contribute
+      // their likelihood change (and, in TAU, the new T2h of the three populations around the divergence)
+      const bool program = BPP && SP.program_moves && SP.theta_alpha > 0 && A.theta_mask;
+      const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+      double th_new = 0; bool th_me = false;
+      // one theta of the step: drawn from its fitted inverse-gamma (a1, b1; c = a log b - lgamma a), (a1o, b1o, co) the fit to the
+      // current trees; what it adds to ln of the acceptance ratio.  The fits themselves are made side by side, one per lane.
+      auto invg = [](double x, double a, double b, double c) { return (c + (-a - 1)*log(x)) - b/x; };     // a00_invgamma_logpdf
+      auto fit_lane = [&](bool have, int p, double Tv, double & a, double & b, double & c)
+      {
+        a = b = c = qnan;
+        if (!have || !(Tv == Tv)) return;
+        a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)wg.run_k[p], Tv, &a, &b);
+        c = a*log(b) - lgamma(a);
+      };
+      // the variate of one theta (the global stream: one after the other, by every lane); NaN without a fit
+      auto draw_theta = [&](int p, double a1, double b1) -> double
+      {
+        if (!(a1 == a1)) return qnan;
+        unsigned int z = (unsigned int)grng.r;
+        const double g = a00_bpp_rndgamma(&z, a1);
+        grng.r = z;
+        const double tn = 1.0/(g/b1);
+        if (p == li) { th_new = tn; th_me = true; }
+        return tn;
+      };
+      // ... and what it adds to ln of the acceptance ratio (side by side again: the lane that holds the fit)
+      auto theta_ratio = [&](int p, double tn, double a1, double b1, double c1, double a1o, double b1o, double c1o, double Tn, double Told) -> double
+      {
+        if (!(a1 == a1 && a1o == a1o)) return qnan;
+        const double to = wg.tau[MAXPOP + p];
+        const long k = (long)wg.run_k[p];
+        return (invg(to, a1o, b1o, c1o) - invg(tn, a1, b1, c1))
+             + ((SP.theta_alpha - 1)*log(tn/to) - SP.theta_beta*(tn - to))
+             + (k*(log(2.0/tn) - log(2.0/to)) - (Tn/tn - Told/to));
+      };
+      if (program && mix)
+      {
+        // lane p: the fit to the scaled trees of population p, lane 16 + p: to the current ones (prop_mixing.c: Cjstar / c)
+        double fa, fb, fc;
+        const int pm = (int)(lane & 15u);
+        const bool have = lane < 32u && pm < npop && ((A.theta_mask >> pm) & 1u) && wg.run_ok;
+        const double Ts = have ? wg.run_T[pm]*mix_c : 0.0;
+        fit_lane(have, pm, lane < 16u ? Ts : Ts/mix_c, fa, fb, fc);
+        const double fao = __shfl(fa, (lane + 16u) & 63u, 64), fbo = __shfl(fb, (lane + 16u) & 63u, 64), fco = __shfl(fc, (lane + 16u) & 63u, 64);
+        double tn_mine = qnan;
+        for (int p = 0; p < npop; ++p)
+          if (((A.theta_mask >> p) & 1u) && wg.run_ok)
+          {
+            const double a1 = __shfl(fa, p, 64), b1 = __shfl(fb, p, 64), a1o = __shfl(fa, 16 + p, 64);
+            const double tn = a1o == a1o ? draw_theta(p, a1, b1) : qnan;
+            if ((int)lane == p) tn_mine = tn;
+          }
+        const double x = have && lane < 16u ? theta_ratio(pm, tn_mine, fa, fb, fc, fao, fbo, fco, Ts, wg.run_T[pm]) : 0.0;
+        for (int p = 0; p < npop; ++p)
+          if ((A.theta_mask >> p) & 1u)
+          {
+            if (!wg.run_ok) { lnacc_theta = qnan; continue; }
+            lnacc_theta += __shfl(x, p, 64);
+          }
       }
       const uint32_t cf0 = T.cf, pf0 = T.pf;
       const double tsave = act ? S.time[li] : 0.0;
@@ -1009,14 +1050,19 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         evaluated = pr.ndm != 0;
         const double lnl = evaluate(pr, evaluated, lp_new);
         if (evaluated) { lnl_new = lnl; a_nupd += (uint32_t)nops; a_nbr += (uint32_t)__popc(pr.brm); ++a_neval; }
-        const double dpr = lp_new - logpr_cur;
+        const double dpr = program ? 0.0 : lp_new - logpr_cur;
         const double h = mix ? dpr + hast : (dpr + hast) + hast2;
         const double dl = evaluated ? (lnl_new - lnl_cur) + h : h;
         if (li == 0) fx_add(0, dl, true);
+        if (program && !mix && li < npop && ((A.theta_mask >> li) & 1u))
+        {
+          const int slot = li == q ? 2 : li == SP.left[q] ? 3 : li == SP.right[q] ? 4 : -1;
+          if (slot >= 0) fx_add(slot, t2h_new, false);
+        }
       }
       if (mix) SMP2_TICK(5); else SMP2_TICK(4);
       double dl_tot = 0;
-      if (!exchange(2, 0, dl_tot)) { aborted = true; break; }
+      if (!exchange(program && !mix ? 5 : 2, 0, dl_tot)) { aborted = true; break; }
       dl_tot += wg.xtot[1]*(FX/FXC);                  // (the coarse sum: terms of 256 and more — none in any run worth the name)
       if (A.dbg & 64u) { SMP2_TICK(7); double dummy; if (!exchange(2, 0, dummy)) { aborted = true; break; } SMP2_TICK(6); }     // (the protocol alone: nobody is late)
       SMP2_TICK(7);
@@ -1026,6 +1072,35 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       {
         if (SP.parent[q] < 0 && SP.tau_alpha > 0)
           lnacc += (SP.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - SP.tau_beta*(tq_new - tq_old);
+        if (program)
+        {
+          // lane j < 3: the fit to the sums after the move of q / its left / its right child, lane 3 + j: to the current ones
+          double fa, fb, fc;
+          const int jm = (int)(lane % 3u);
+          const int pm = jm == 0 ? q : jm == 1 ? SP.left[q] : SP.right[q];
+          const bool have = lane < 6u && ((A.theta_mask >> pm) & 1u) && wg.run_ok;
+          const double Cm = wg.xtot[2 + jm];
+          fit_lane(have, pm, lane < 3u ? Cm : wg.run_T[pm], fa, fb, fc);
+          const double fao = __shfl(fa, (lane + 3u) & 63u, 64), fbo = __shfl(fb, (lane + 3u) & 63u, 64), fco = __shfl(fc, (lane + 3u) & 63u, 64);
+          double tn_mine = qnan;
+          for (int j = 0; j < 3; ++j)
+          {
+            const int p = j == 0 ? q : j == 1 ? SP.left[q] : SP.right[q];
+            if (!((A.theta_mask >> p) & 1u) || !wg.run_ok) continue;
+            const double Cn = wg.xtot[2 + j];
+            const double a1 = __shfl(fa, j, 64), b1 = __shfl(fb, j, 64), a1o = __shfl(fa, 3 + j, 64);
+            const double tn = Cn == Cn && a1o == a1o ? draw_theta(p, a1, b1) : qnan;
+            if ((int)lane == j) tn_mine = tn;
+          }
+          const double x = have && lane < 3u ? (Cm == Cm ? theta_ratio(pm, tn_mine, fa, fb, fc, fao, fbo, fco, Cm, wg.run_T[pm]) : qnan) : 0.0;
+          for (int j = 0; j < 3; ++j)
+          {
+            const int p = j == 0 ? q : j == 1 ? SP.left[q] : SP.right[q];
+            if (!((A.theta_mask >> p) & 1u)) continue;
+            if (!wg.run_ok) { lnacc = qnan; continue; }
+            lnacc += __shfl(x, j, 64);
+          }
+        }
       }
       else
       {
@@ -1045,10 +1120,15 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       if (accept)
       {
         if (!mix) { if (tid == 0) wg.tau[q] = tq_new; }
-        else
+        else if (tid < (uint32_t)npop) wg.tau[tid] *= mix_c;
+        if (program)
         {
-          if (tid < (uint32_t)npop) wg.tau[tid] *= mix_c;
-          if (th_upd && tid < (uint32_t)G && li < npop && ((A.theta_mask >> li) & 1u)) { wg.tau[MAXPOP + li] = pl.theta; wg.tau[2*MAXPOP + li] = pl.l2t; }
+          if (tid < (uint32_t)G && th_me) { wg.tau[MAXPOP + li] = th_new; wg.tau[2*MAXPOP + li] = log(2.0/(1.0*th_new)); }
+          if (tid < (uint32_t)G && li < npop && ((A.theta_mask >> li) & 1u))
+          {
+            if (mix) wg.run_T[li] *= mix_c;
+            else { const int slot = li == q ? 2 : li == SP.left[q] ? 3 : li == SP.right[q] ? 4 : -1; if (slot >= 0) wg.run_T[li] = wg.xtot[slot]; }
+          }
         }
         if (act) { lnl_cur = lnl_new; logpr_cur = lp_new; commit_density(allpop); }
       }
@@ -1056,6 +1136,16 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       __syncthreads();
       load_pop();
       wsync();
+      if (program && accept && act)
+      {
+        // the densities with the re-drawn thetas, from the statistics of the accepted trees (as after THETA)
+        if (li < npop) S.contrib[li] = msc_term((int)mync, t2h_cur, pl.theta, pl.l2t);
+        wsync();
+        double lp = 0;
+        for (int p = 0; p < npop; ++p) lp += S.contrib[p];
+        logpr_cur = lp;
+        wsync();
+      }
       if (mix) SMP2_TICK(5); else SMP2_TICK(4);
     }
   }

@@ -294,17 +294,16 @@ void bpa_sampler_set_finetune(bpa_sampler_t *, double gage, double gspr, double 
 #define BPA_KERNEL_UNIFORM 0
 #define BPA_KERNEL_BPP     1
 int  bpa_sampler_set_proposal_kernel(bpa_sampler_t *, int kind);
-/* THETA as the program mixes it (a00_set_theta_slide_prob of bpp_amd_host.h; needs BPA_KERNEL_BPP): each theta gets the
-   sliding window with probability slide_prob (stree_propose_theta, stree.c:3957: opt_theta_slide_prob = 0.1) and the
-   metropolized Gibbs draw of propose_theta_gibbs (stree.c:3645: an inverse-gamma fitted to the conditional given the gene
-   trees, get_gamma_conditional_approx stree.c:3384) otherwise.  Both are decided inside the persistent kernel from two
-   sums over the loci per theta — coalescences and T2h —, ONE exchange for all thetas.  Default 1: sliding window only. */
-int  bpa_sampler_set_theta_slide_prob(bpa_sampler_t *, double slide_prob);
+/* THETA, TAU and MIX as the program runs them (a00_set_program_moves of bpp_amd_host.h; needs BPA_KERNEL_BPP; default off):
+     THETA  sliding window with probability slide_prob (stree_propose_theta, stree.c:3957: opt_theta_slide_prob = 0.1), the
+            metropolized Gibbs draw of propose_theta_gibbs (stree.c:3645: an inverse-gamma fitted to the conditional given the
+            gene trees, get_gamma_conditional_approx stree.c:3384) otherwise;
+     TAU    the rubber band re-draws the thetas of the population and its two children (opt_rb_theta_update, stree.c:5840);
+     MIX    re-draws every theta with the scaled trees (opt_mix_theta_update, prop_mixing.c:272).
+   All decided inside the persistent kernel from two sums over the loci per theta — coalescences and T2h, carried through
+   the iteration —: one exchange per step, as without.                                                                  */
+int  bpa_sampler_set_program_moves(bpa_sampler_t *, int on, double slide_prob);
 int  bpa_sampler_gibbs_counters(bpa_sampler_t *, unsigned long * proposals, unsigned long * accepted);
-/* MIX as the program does it (a00_set_mix_theta_update; needs BPA_KERNEL_BPP): the thetas are re-drawn from their
-   conditionals given the scaled trees inside the mixing proposal (proposal_mixing, prop_mixing.c:272-425;
-   opt_mix_theta_update = 1 is the program's default).  0 (default): ages and taus only.                              */
-int  bpa_sampler_set_mix_theta_update(bpa_sampler_t *, int on);
 void bpa_sampler_set_tau_prior(bpa_sampler_t *, double alpha, double beta);           /* a00_set_tau_prior */
 void bpa_sampler_set_theta_prior(bpa_sampler_t *, double alpha, double beta, double finetune); /* a00_set_theta_prior */
 int  bpa_sampler_get_thetas(bpa_sampler_t *, double * theta); /* 2*species-1 entries; returns their number */

@@ -247,15 +247,19 @@ int            a00_set_tip_species(a00_driver_t *, unsigned i, const int * speci
 #define A00_KERNEL_UNIFORM 0
 #define A00_KERNEL_BPP     1
 void           a00_set_proposal_kernel(a00_driver_t *, int kind);
-/* THETA as the program does it (needs A00_KERNEL_BPP): each theta gets the sliding window with probability slide_prob
-   and the metropolized Gibbs draw above otherwise (BPP: 0.1).  1 (default): sliding window only.  With slide_prob < 1
-   BOTH moves are decided from the two sums over loci (k exactly, T as a sum of 2^-40 fixed-point terms, so that the
-   device kernel's order-free sum is the same number).                                                              */
-void           a00_set_theta_slide_prob(a00_driver_t *, double slide_prob);
+/* THETA, TAU and MIX as the program runs them (needs A00_KERNEL_BPP and a theta prior; default off):
+     THETA  each theta gets the sliding window with probability slide_prob (BPP: 0.1) and the metropolized Gibbs draw
+            above otherwise; both are decided from the two sums over loci (k exactly, T as a sum of 2^-40 fixed-point
+            terms, so that the device kernel's order-free sum is the same number);
+     TAU    the rubber band also re-draws the thetas of the population and its two children (opt_rb_theta_update = 1,
+            bpp.c:618; propose_tau, stree.c:5840-5990), each from the inverse-gamma fitted to (k, sum of the T2h after
+            the move), proposal ratio by a00_invgamma_logpdf;
+     MIX    likewise every theta, from (k, c T) (opt_mix_theta_update = 1, bpp.c:581; prop_mixing.c:272-425).
+   In TAU and MIX the change of the gene-tree densities over all loci is taken from the sums:
+   k (log 2/theta' - log 2/theta) - (T'/theta' - T/theta) per re-drawn theta; the loci contribute their likelihood change
+   (and, in TAU, their three new T2h).  k and T are carried from the THETA step's sums through the iteration.          */
+void           a00_set_program_moves(a00_driver_t *, int on, double slide_prob);
 void           a00_gibbs_counters(const a00_driver_t *, unsigned long * proposals, unsigned long * accepted);
-/* MIX as the program does it (needs A00_KERNEL_BPP and a theta prior): the thetas are re-drawn with the scaled trees
-   inside the mixing proposal, see a00_invgamma_logpdf.  0 (default): ages and taus only. */
-void           a00_set_mix_theta_update(a00_driver_t *, int on);
 /* worker threads of the per-locus loops (proposal, MSC density, bookkeeping, roll-back; OpenMP).  Every draw of a per-locus
    proposal comes from that locus's own stream and sums over loci are taken in locus order afterwards, so the trajectory
    does not depend on the count.  Default 1, or the environment's A00_THREADS; threads.c:87-200 is the reference's form */

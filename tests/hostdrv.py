@@ -112,14 +112,10 @@ class Driver:
         lib().a00_set_threads.argtypes = [C.c_void_p, C.c_int]
         lib().a00_set_threads(self.h, int(n))
 
-    def set_theta_slide_prob(self, p):
-        """THETA the program's way: sliding window with this probability, the metropolized Gibbs draw otherwise"""
-        lib().a00_set_theta_slide_prob.argtypes = [C.c_void_p, C.c_double]
-        lib().a00_set_theta_slide_prob(self.h, float(p))
-
-    def set_mix_theta_update(self, on):
-        lib().a00_set_mix_theta_update.argtypes = [C.c_void_p, C.c_int]
-        lib().a00_set_mix_theta_update(self.h, int(bool(on)))
+    def set_program_moves(self, on, slide_prob=0.1):
+        """THETA / TAU / MIX as the program runs them (BPP kernel): Gibbs draws of the thetas, thetas re-drawn inside TAU and MIX"""
+        lib().a00_set_program_moves.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        lib().a00_set_program_moves(self.h, int(bool(on)), float(slide_prob))
 
     def gibbs_counters(self):
         a, b = C.c_ulong(), C.c_ulong()

@@ -144,16 +144,16 @@ def test_prior_sampling_with_the_bpp_kernel_matches_direct_msc_simulation():
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
-@pytest.mark.parametrize("slide_prob", [1.0, 0.1])
+@pytest.mark.parametrize("slide_prob", [None, 0.1, 1.0])
 def test_host_driver_with_the_bpp_kernel_reproduces_bpp_posterior(slide_prob):
-    """slide_prob 0.1: the program's own THETA mix (stree.c:3957: sliding window 1 time in 10, metropolized Gibbs draw otherwise)"""
+    """slide_prob not None: THETA / TAU / MIX as the program runs them (a00_set_program_moves) — 0.1 is the program's own THETA mix
+    (stree.c:3957: sliding window 1 time in 10, metropolized Gibbs draw otherwise); thetas re-drawn inside TAU and MIX"""
     gold = json.load(open(os.path.join(HERE, "golden", "a00_posterior.json")))
     c = gold["config"]
     data = dataset(gold)
     drv = hostdrv.reference_driver(data, seed=6)
     drv.set_proposal_kernel(1)
-    drv.set_theta_slide_prob(slide_prob)
-    drv.set_mix_theta_update(slide_prob < 1)                         # ... and its mixing step, which re-draws the thetas (prop_mixing.c:272)
+    drv.set_program_moves(slide_prob is not None, slide_prob or 0.0)     # THETA / TAU / MIX as the program runs them
     parent, tau, thetas = synth.species_tree_arrays(c["taxa"], c["theta"])
     drv.set_species_tree(parent, tau, thetas)
     drv.set_tau_prior(*c["tau_prior"])
@@ -169,7 +169,7 @@ def test_host_driver_with_the_bpp_kernel_reproduces_bpp_posterior(slide_prob):
     p, a, _ = drv.counters()
     assert 0.15 < a / p < 0.9
     gp, ga = drv.gibbs_counters()
-    if slide_prob < 1:
+    if slide_prob is not None and slide_prob < 1:
         assert 0.85 < gp / (16000 * 3 * 0.9) < 1.15 and 0.3 < ga / gp <= 1.0, (gp, ga)
     else:
         assert gp == 0

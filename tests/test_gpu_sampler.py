@@ -264,7 +264,7 @@ def test_native_rccl_callback(monkeypatch):
     nat.close(); ref.close(); x.close(); eng.close()
 
 
-@pytest.mark.parametrize("taxa,nloci,iters,slide_prob", [(4, 400, 8, 1.0), (8, 60, 4, 1.0), (4, 400, 12, 0.1), (8, 60, 8, 0.1), (4, 300, 8, 0.0)])
+@pytest.mark.parametrize("taxa,nloci,iters,slide_prob", [(4, 400, 8, None), (8, 60, 4, None), (4, 400, 12, 0.1), (8, 60, 8, 0.1), (4, 300, 8, 0.0), (4, 300, 8, 1.0)])
 def test_bpp_proposal_kernel_on_the_device(taxa, nloci, iters, slide_prob):
     """bpa_sampler_set_proposal_kernel(BPA_KERNEL_BPP): the reference's own generator (legacy_rndu, random.c:104-122) and
     window (Bactrian-Laplace, random.c:192-238) and its acceptance rule (a number drawn only when lnacc < -1e-10) inside the
@@ -277,10 +277,10 @@ def test_bpp_proposal_kernel_on_the_device(taxa, nloci, iters, slide_prob):
     parent, tau0, thetas = synth.species_tree_arrays(taxa)
     for drv in (host, dev):
         drv.set_proposal_kernel(1)
-        # slide_prob < 1: the program's THETA mix — sliding window with that probability, else the metropolized Gibbs draw
-        # (stree.c:3957, 3645), decided in the kernel from the coalescence counts and the T2h sums of all loci
-        drv.set_theta_slide_prob(slide_prob)
-        drv.set_mix_theta_update(slide_prob < 1)                     # ... and its mixing step, which re-draws the thetas (prop_mixing.c:272)
+        # slide_prob not None: the program's moves — THETA by the sliding window with that probability, else the metropolized
+        # Gibbs draw (stree.c:3957, 3645); thetas re-drawn inside TAU (stree.c:5840) and MIX (prop_mixing.c:272) —, decided in
+        # the kernel from the coalescence counts and the T2h sums of all loci
+        drv.set_program_moves(slide_prob is not None, slide_prob or 0.0)     # THETA / TAU / MIX as the program runs them
         drv.set_species_tree(parent, tau0, thetas)
         drv.set_tau_prior(3.0, 3.0 / tau0[-1])
         drv.set_theta_prior(2.0, 1000.0, 0.0003)
@@ -310,7 +310,7 @@ def test_bpp_proposal_kernel_on_the_device(taxa, nloci, iters, slide_prob):
     ntheta = taxa - 1                                        # one sequence per species: only the inner populations hold coalescences
     if slide_prob == 0.0:
         assert gp == (iters + 3) * ntheta and ga > 0
-    elif slide_prob < 1:
+    elif slide_prob is not None and slide_prob < 1:
         assert 0 < gp < (iters + 3) * ntheta and ga > 0
     else:
         assert gp == 0

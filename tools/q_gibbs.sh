@@ -1,2 +1,3 @@
-timeout 900 python -m pytest tests/test_gpu_sampler.py -x -q -m gpu -k "bpp_proposal_kernel or persistent_kernel_equals" 2>&1 | tail -15
-timeout 800 python bench.py > gpurun_out/r3_bench_eff.json 2> gpurun_out/r3_bench_eff.err; tail -c 300 gpurun_out/r3_bench_eff.err
+timeout 900 python -m pytest tests/test_gpu_sampler.py -x -q -m gpu -k "bpp_proposal_kernel or persistent_kernel_equals" 2>&1 | tail -5
+timeout 600 python tools/q_prog.py 2>&1 | grep -v "^\[bpp_amd\] smp2" | tail -8
+BPA_SMP_DBG=16 timeout 600 python tools/q_prog.py program 2>&1 | tail -30
