@@ -725,7 +725,8 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
         scale = 1.0 / math.sqrt(max(D.sum_int(len(data)) if D else len(data), 1))
         smp.set_theta_prior(2.0, 2.0 / sp_theta[0], 0.008 * scale)
         smp.set_finetune(0.004, 0.004, 0.004 * scale, 0.6 * scale)
-    if generic:
+    gtr = cfg["model"] == "gtr"
+    if gtr:
         # the per-locus substitution-parameter moves of a GTR + Gamma analysis (3 frequencies, 5 exchangeabilities, alpha)
         for i, d in enumerate(data):
             smp.set_subst_model(i, d["freqs"], d["exch"], 0.5)
@@ -792,7 +793,7 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
         us = 1e3 * (tm["sweep_ms"] + tm["allloci_ms"]) / (tm["sweep_launches"] + tm["allloci_launches"])
         achieved = bytes_per_launch / (us * 1e-6) / 1e9
         kern = dominant_kernel(cfg)
-        traffic, src = traffic_from_profiles("c3", kern) if args.loci is None else (None, None)
+        traffic, src = traffic_from_profiles("c3" if gtr else "c4", kern) if args.loci is None else (None, None)
         roofline = dict(bound="hbm", kernel=kern, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=src, avg_kernel_us=round(us, 3),
                         algorithmic_bytes_per_launch=round(bytes_per_launch), launches=tm["sweep_launches"] + tm["allloci_launches"],
@@ -843,14 +844,17 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
     out = dict(iterations_per_s=round(niter / dt, 3), iterations_per_s_10k_loci=round(niter / dt * total_loci / 10000.0, 3),
                ms_per_iteration=round(1e3 * dt / niter, 5), ms_per_step=round(1e3 * dt / steps, 4), iterations_per_step=ips,
                timed_region_s=round(dt, 4), steps=steps, warmup=warmup, n_gpus=world, loci_total=total_loci,
-               proposals_per_locus_iteration=3 * cfg["taxa"] - 3 + (9 if generic else 0),
+               proposals_per_locus_iteration=3 * cfg["taxa"] - 3 + (9 if gtr else 0),
                launches_per_iteration=round(max(l1 - l0 - (0 if kind == "persistent" else 1), 0) / niter, 4),      # (-1: the settle launch of the first summary)
                acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
                taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
                thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],
                roofline=roofline,
                implementation=("generic path (csrc/gsampler.hpp): proposals on the device as records for the engine's step kernels; "
-                               "tree moves + 3 frequency, 5 exchangeability and 1 alpha move per locus" if generic else
+                               "tree moves + 3 frequency, 5 exchangeability and 1 alpha move per locus" if gtr else
+                               "generic path (csrc/gsampler.hpp): proposals on the device as the records of the tiled 20-state kernels "
+                               "(pmatrix_wg2_kernel, partials_lnl_pipe20_kernel, lnl_reduce_wave_kernel); tree moves only (the empirical "
+                               "amino-acid models have no free parameters)" if generic else
                                "persistent iteration kernel (csrc/sweep2.hpp): all iterations of a call in one launch, the loci's state in "
                                "LDS, a group of lanes per locus, all-loci decisions from device-scope fixed-point accumulators" if kind == "persistent" else
                                "several ranks: the per-locus sweep of an iteration = one launch of the persistent kernel (csrc/sweep2.hpp), the "
@@ -952,7 +956,7 @@ def main():
     tape_steps = None
     if not (args.config in ("c2", "c3") and args.no_tape):
         tape_sec, tape_steps = run_tape(eng, cfg, args.config, data, loci, args, D, args.steps, args.warmup)
-    if args.config in ("c2", "c3") and not args.no_sampler:
+    if args.config in ("c2", "c3", "c4") and not args.no_sampler:
         sampler_sec = run_sampler(eng, cfg, data, loci, args, D, first_locus, args.steps, args.warmup)
         if "error" in sampler_sec:
             log(sampler_sec["error"])
@@ -1022,8 +1026,7 @@ def main():
                 a2.loci = None
                 sec, _ = run_tape(e2, oc, key, d2, l2, a2, None, k_steps, k_warm)
                 sec["unit"] = f"iterations/s (one iteration = the A00 proposal schedule over this config's {oc['loci']} loci)"
-                if key == "c3":
-                    sec["device_resident_sampler"] = run_sampler(e2, oc, d2, l2, a2, None, 0, k_steps, k_warm)
+                sec["device_resident_sampler"] = run_sampler(e2, oc, d2, l2, a2, None, 0, k_steps, k_warm)
                 sec["seconds"] = round(time.time() - t0, 1)
                 others[key] = sec
                 e2.close()
@@ -1052,7 +1055,7 @@ def main():
                             ("one-shot p2p all-reduce over xGMI (RCCL-checked at start-up)" if D.tape_p2p else "RCCL all-reduce") +
                             " of the sums the THETA / TAU / MIX steps are decided on"))
         if headline_sampler:
-            value = sampler_sec["iterations_per_s_10k_loci"] if args.scaling == "weak" else sampler_sec["iterations_per_s"]
+            value = sampler_sec["iterations_per_s_10k_loci"] if (args.scaling == "weak" and args.config in ("c2", "c3")) else sampler_sec["iterations_per_s"]
             ms_per_step = sampler_sec["ms_per_step"]
             roofline = sampler_sec.pop("roofline")
             metric = "MCMC iterations/sec (A00), every decision on the device"

@@ -83,6 +83,11 @@ struct GArgs
   uint32_t tau_q; double tau_u, mix_c, mix_lnc;
   int8_t * pop_nc; double * pop_t2h;      // [MAXPOP][T] mode 4: the statistics the THETA kernel reads
   uint32_t refresh_logpr;
+  // 20-state loci (fmt20): the step as the records of the tiled kernels — partials_lnl_pipe20_kernel reads ops20[op_rng20[2 i]
+  // .. op_rng20[2 i + 1]) and root20[i], pmatrix_wg2_kernel the entries mat_task20 / mat_pm20 / mat_length [i maxmat + j]
+  // (task 0xffffffff: a hole) — one task per locus
+  OpDev * ops20; uint32_t * op_rng20, * root20, * mat_task20, * mat_pm20;
+  uint32_t fmt20, maxops20;
   Species sp;
 };
 
@@ -402,7 +407,33 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
   }
 
   // ---- 5. the step's records for the engine's kernels
-  if (valid && MODE != 4)
+  if (valid && MODE != 4 && A.fmt20)
+  {
+    const uint32_t e0 = i*A.maxmat, o0 = i*A.maxops20;
+    uint32_t nm = 0;
+    if (evaluate)
+    {
+      for (uint32_t m = S.brm; m; m &= m - 1, ++nm)
+      {
+        const int x = __ffs(m) - 1;
+        A.mat_task20[e0 + nm] = i; A.mat_pm20[e0 + nm] = (uint32_t)(int)T.pmat[x];
+        A.mat_length[e0 + nm] = (S.time[(int)T.parent[x]] - S.time[x])*1.0;      // rate_mui = 1 (locus.c:2350)
+      }
+      for (int o = 0; o < S.nops; ++o)
+      {
+        const Op w = S.ops[o];
+        OpDev q;
+        q.parent_clv = (uint32_t)(w & 255u); q.left_clv = (uint32_t)((w >> 8) & 255u); q.left_pmatrix = (uint32_t)((w >> 16) & 255u);
+        q.right_clv = (uint32_t)((w >> 24) & 255u); q.right_pmatrix = (uint32_t)((w >> 32) & 255u);
+        q.parent_scaler = q.left_scaler = q.right_scaler = BPA_SCALE_BUFFER_NONE;
+        A.ops20[o0 + o] = q;
+      }
+    }
+    for (; nm < A.maxmat; ++nm) A.mat_task20[e0 + nm] = 0xffffffffu;
+    A.op_rng20[2*i] = o0; A.op_rng20[2*i + 1] = o0 + (evaluate ? (uint32_t)S.nops : 0u);
+    A.root20[i] = (uint32_t)(int)T.clv[T.root];
+  }
+  else if (valid && MODE != 4)
   {
     uint4 * rec = A.recs2 + (size_t)L.slot*A.units;
     MatRec2 * m2 = A.mat2 + (size_t)L.slot*A.maxmat;

@@ -10,6 +10,7 @@ static int gs_subst_ready(bpa_sampler * s)
   if (!(s->g_ft[0] > 0 || s->g_ft[1] > 0 || s->g_ft[2] > 0) || s->g_sm.p) return 1;
   const unsigned T = s->nloci;
   if (s->g_alljc) return fail("bpa_sampler: the substitution-parameter moves need loci with an eigendecomposition (GTR) and several rate categories");
+  if (s->g_s20) return fail("bpa_sampler: no substitution-parameter moves for amino-acid loci (the empirical models have none; the alpha move is 4-state only here)");
   if (s->g_sm_host.size() != (size_t)T*11) return fail("bpa_sampler: call bpa_sampler_set_subst_model for every locus before the substitution-parameter moves");
   std::vector<uint32_t> ids(T);
   for (unsigned i = 0; i < T; ++i) ids[i] = s->loci[i]->id;
@@ -40,7 +41,8 @@ static int gs_upload(bpa_sampler * s)
 {
   bpa_engine * e = s->eng;
   const unsigned T = s->nloci;
-  if (!engine_pack(e)) return 0;
+  if (!s->g_s20 && !engine_pack(e)) return 0;
+  if (s->g_s20 && !flush_state(e)) return 0;        // (tip states, weights, parameter blocks, eigensystems on the device)
   for (unsigned i = 0; i < T; ++i) if (!assign_pops_host(s, s->g_trees[i])) return 0;
   for (int p = 0; p < smp::MAXPOP; ++p) s->has_theta[p] = p >= s->sp.S && p < s->sp.npop;
   std::vector<gsm::GLocus> loc(T);
@@ -51,9 +53,9 @@ static int gs_upload(bpa_sampler * s)
     const gsm::GTree & t = s->g_trees[i];
     int cnt[smp::MAXPOP] = {0};
     for (int k = 0; k < t.tips; ++k) if (++cnt[t.pop[k]] >= 2) s->has_theta[t.pop[k]] = true;
-    if (e->slot_of[l->id] < 0) return fail("bpa_sampler: a locus is not on the engine's packing");
+    if (!s->g_s20 && e->slot_of[l->id] < 0) return fail("bpa_sampler: a locus is not on the engine's packing");
     gsm::GLocus & g = loc[i];
-    g.slot = (uint32_t)e->slot_of[l->id]; g.pat_off = npat; g.R = l->rate_cats; g.pad = 0; g.par = l->dev.par;
+    g.slot = s->g_s20 ? i : (uint32_t)e->slot_of[l->id]; g.pat_off = npat; g.R = l->rate_cats; g.pad = 0; g.par = l->dev.par;
     for (int p = 0; p < smp::MAXPOP; ++p) g.gl[p] = g.nin[p] = 0;
     for (int k = 0; k < t.tips; ++k)
     {
@@ -66,9 +68,32 @@ static int gs_upload(bpa_sampler * s)
   s->g_units = 1 + std::max(s->maxtips - 1, 3u);
   s->g_maxmat = 2*s->maxtips - 2;
   s->g_pack_epoch = e->pack_epoch;
-  const size_t nrec = (size_t)e->pack_slots*s->g_units, nmat = (size_t)e->pack_slots*s->g_maxmat;
-  std::vector<uint32_t> bmo(e->pack_blocks + 1);
-  for (unsigned b = 0; b <= e->pack_blocks; ++b) bmo[b] = e->h_blk_slot_off[b]*s->g_maxmat;
+  const size_t nslots = s->g_s20 ? T : e->pack_slots;
+  const size_t nrec = s->g_s20 ? 1 : nslots*s->g_units, nmat = nslots*s->g_maxmat;
+  std::vector<uint32_t> bmo(s->g_s20 ? 1 : e->pack_blocks + 1);
+  if (!s->g_s20) for (unsigned b = 0; b <= e->pack_blocks; ++b) bmo[b] = e->h_blk_slot_off[b]*s->g_maxmat;
+  if (s->g_s20)
+  {
+    // the static part of the tiled kernels' plan: one task per locus, 64-pattern tiles, no scalers
+    std::vector<uint32_t> tl(T), tp(T + 1), tt, tn;
+    std::vector<int32_t> rs(T, BPA_SCALE_BUFFER_NONE);
+    unsigned off = 0;
+    for (unsigned i = 0; i < T; ++i)
+    {
+      tl[i] = s->loci[i]->id; tp[i] = off; off += s->loci[i]->sites;
+      for (unsigned n0 = 0; n0 < s->loci[i]->sites; n0 += 64) { tt.push_back(i); tn.push_back(n0); }
+    }
+    tp[T] = off;
+    s->g_ntiles = (unsigned)tt.size(); s->g_maxops = s->maxtips - 1;
+    if (!upload(s->g_tlocus, tl.data(), T) || !upload(s->g_tpat, tp.data(), T + 1) || !upload(s->g_ttask, tt.data(), tt.size()) ||
+        !upload(s->g_tn0, tn.data(), tn.size()) || !upload(s->g_rscaler, rs.data(), T) || !s->g_ops20.reserve((size_t)T*s->g_maxops) ||
+        !s->g_oprng.reserve((size_t)2*T) || !s->g_root20.reserve(T) || !s->g_mtask.reserve(nmat) || !s->g_mpm.reserve(nmat))
+      return 0;
+    HIPCHK(hipMemsetAsync(s->g_oprng.p, 0, (size_t)2*T*sizeof(uint32_t), e->stream));
+    HIPCHK(hipMemsetAsync(s->g_root20.p, 0, (size_t)T*sizeof(uint32_t), e->stream));
+    HIPCHK(hipMemsetAsync(s->g_mtask.p, 0xff, nmat*sizeof(uint32_t), e->stream));
+    HIPCHK(hipMemsetAsync(s->g_mpm.p, 0, nmat*sizeof(uint32_t), e->stream));
+  }
   uint32_t zero2[2] = {0, 0};
   if (!upload(s->g_dev, s->g_trees.data(), T) || !s->g_undo.reserve(T) || !upload(s->g_loc, loc.data(), T) ||
       !s->g_lnl.reserve(T) || !s->g_hast.reserve(T) || !s->g_logpr.reserve(T) || !s->g_delta.reserve(T) || !s->g_active.reserve(T) ||
@@ -123,6 +148,8 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   a.refresh_logpr = s->logpr_stale ? 1u : 0u; s->logpr_stale = false;
   a.sp = s->sp;
   a.pend_mode = s->g_pend_mode; a.pend_k = s->g_pend_k; a.sm = s->g_sm.p; a.sm_old = s->g_sm_old.p;
+  a.fmt20 = s->g_s20 ? 1u : 0u; a.maxops20 = s->g_maxops;
+  a.ops20 = s->g_ops20.p; a.op_rng20 = s->g_oprng.p; a.root20 = s->g_root20.p; a.mat_task20 = s->g_mtask.p; a.mat_pm20 = s->g_mpm.p;
   a.ft_freqs = s->g_ft[0]; a.ft_qrates = s->g_ft[1]; a.ft_alpha = s->g_ft[2]; a.alpha_a = s->g_alpha_a; a.alpha_b = s->g_alpha_b;
   // a frequency / exchangeability step — proposed now, or rolled back now for the loci that rejected it — leaves
   // parameter blocks whose eigensystems are stale: refreshed before the next evaluation (gs_eval)
@@ -152,6 +179,34 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
 {
   bpa_engine * e = s->eng;
   if (!e->usedata) return 1;                       // lnL = 0 for every locus (the buffer was zeroed): the MSC prior
+  if (s->g_s20)
+  {
+    // amino-acid loci: fresh P-matrices (pmatrix_wg2_kernel, one workgroup per entry, holes return at once), the tiled
+    // node-update + site-term kernel over the loci that have updates, the per-locus sums in pattern order
+    PlanDev d{};
+    d.loci = e->d_loci.p; d.bfbeta = e->bfbeta; d.task_locus = s->g_tlocus.p; d.task_pat_off = s->g_tpat.p;
+    d.tile_task = s->g_ttask.p; d.tile_n0 = s->g_tn0.p; d.op_off = s->g_oprng.p; d.ops = s->g_ops20.p; d.root_clv = s->g_root20.p;
+    d.root_scaler = s->g_rscaler.p; d.site_term = s->g_site.p; d.lnl = s->g_lnl.p; d.mat_task = s->g_mtask.p; d.mat_pmatrix = s->g_mpm.p;
+    d.mat_length = s->g_len.p; d.nmat = s->nloci*s->g_maxmat; d.ntasks = s->nloci; d.npatterns = s->g_npat; d.pad = s->g_rmax;
+    hipEvent_t k0 = nullptr, k1 = nullptr;
+    if (s->timing_stride && (s->timing_phase++ % s->timing_stride) == 0)
+    {
+      if (s->timed.size() >= 4096 && !sampler_timing_drain(s)) return 0;
+      bpa_sampler::Timed t{nullptr, nullptr, kind};
+      HIPCHK(hipEventCreate(&t.e0)); HIPCHK(hipEventCreate(&t.e1));
+      s->timed.push_back(t);
+      k0 = t.e0; k1 = t.e1;
+    }
+    d.flags = 1u;
+    hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d);
+    d.flags = 4u | 64u;
+    hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax),
+                          ((size_t)4*s->g_rmax*400 + (size_t)s->g_rmax*64)*sizeof(double), e->stream, k0, k1, 0, d);
+    hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(s->nloci), dim3(64), 0, e->stream, d);
+    HIPCHK(hipGetLastError());
+    s->launches += 3; s->g_evals++;
+    return 1;
+  }
   if (!gs_refresh_eigen(s)) return 0;
   PlanDev d{};
   d.loci = e->d_loci.p; d.bfbeta = e->bfbeta;

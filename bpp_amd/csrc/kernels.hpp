@@ -520,7 +520,11 @@ partials_lnl_pipe20_kernel(const PlanDev P)
   const uint32_t bufsz = 2*P.pad*SS;                                 // doubles per staging buffer (P.pad = largest R of the plan)
   double * s_x = s_p + (size_t)2*bufsz;
 
-  const uint32_t op_begin = ((cu32_p)P.op_off)[t], op_end = ((cu32_p)P.op_off)[t+1];
+  // flags bit 6: op_off holds a (begin, end) pair per task — the device-written steps of the generic sampler, where a task
+  // with no update is not part of the step at all
+  const bool ranges = (P.flags & 64u) != 0;
+  const uint32_t op_begin = ((cu32_p)P.op_off)[ranges ? 2*t : t], op_end = ((cu32_p)P.op_off)[ranges ? 2*t + 1 : t + 1];
+  if (ranges && op_begin == op_end) return;
   uint32_t cur = 0;
   if (op_begin < op_end)
   {
@@ -2871,6 +2875,7 @@ __global__ void __launch_bounds__(256) pmatrix_wg2_kernel(const PlanDev P)
   double * const s_ev = s_evs, * const s_iev = s_evs + S*S;
   const uint32_t e = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
   const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (((cu32_p)P.mat_task)[e] == 0xffffffffu) return;            // a hole of a device-written step (gsampler.hpp)
   const uint32_t lid = ((cu32_p)P.task_locus)[((cu32_p)P.mat_task)[e]];
   cu64_p L64 = (cu64_p)(P.loci + lid);
   cu32_p L32 = (cu32_p)(P.loci + lid);

@@ -1141,6 +1141,12 @@ struct bpa_sampler
   DevBuf<uint32_t> g_bmo;
   unsigned g_units = 0, g_maxmat = 0, g_pend = 0, g_npat = 0, g_rmax = 1, g_pack_epoch = 0;
   bool g_alljc = true;
+  // 20-state loci: the generic sampler's steps as the records of the tiled kernels (gsampler.hpp: fmt20)
+  bool g_s20 = false;
+  unsigned g_ntiles = 0, g_maxops = 0;
+  DevBuf<OpDev> g_ops20;
+  DevBuf<uint32_t> g_oprng, g_root20, g_mtask, g_mpm, g_tlocus, g_tpat, g_ttask, g_tn0;
+  DevBuf<int32_t> g_rscaler;
   // substitution-parameter moves (bpa_sampler_set_subst_moves): freqs | exchangeabilities | alpha per locus
   std::vector<double> g_sm_host;
   DevBuf<double> g_sm, g_sm_old;
@@ -1191,16 +1197,19 @@ extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * co
   // the LDS sweep kernel (JC69, one rate category, <= 8 tips, <= 64 patterns) where every locus fits it, else the generic
   // path over the engine's step kernels (any 4-state model on the engine's packing, <= 16 tips; BPA_SMP_GENERIC=1 forces it)
   bool fits_sweep = getenv("BPA_SMP_GENERIC") == nullptr, fits_generic = true, all_jc = true, all_kl = true;
+  unsigned n20 = 0;
   for (unsigned i = 0; i < nloci; ++i)
   {
     const bpa_locus * l = loci[i];
-    const bool base = l && l->eng == e && l->alive && l->states == 4 && l->scale_buffers == 0 && !l->dev.unphased_length && l->tips >= 2 &&
+    const bool base = l && l->eng == e && l->alive && (l->states == 4 || l->states == 20) && l->scale_buffers == 0 && !l->dev.unphased_length && l->tips >= 2 &&
                       l->clv_buffers == 2*(l->tips - 1) && l->prob_matrices == 2*(2*l->tips - 2);
     if (!base)
     {
-      fail("bpa_sampler_create: loci must be 4-state, without scalers, not diploid, with the buffer counts of method.c:4110-4146");
+      fail("bpa_sampler_create: loci must be 4- or 20-state, without scalers, not diploid, with the buffer counts of method.c:4110-4146");
       delete s; return nullptr;
     }
+    if (l->states == 20) { ++n20; fits_sweep = false; fits_generic = fits_generic && l->tips <= (unsigned)gsm::NT && l->rate_cats <= 4; all_jc = false;
+                           s->maxtips = std::max(s->maxtips, l->tips); s->g_rmax = std::max(s->g_rmax, l->rate_cats); continue; }
     fits_sweep = fits_sweep && l->rate_cats == 1 && l->dev.model == 0 && l->tips <= (unsigned)smp::MAXTIPS && l->sites <= (unsigned)smp::BS;
     fits_generic = fits_generic && l->tips <= (unsigned)gsm::NT && l->rate_cats <= 8 && l->sites*l->rate_cats < PACK_BS;
     all_jc = all_jc && l->rate_cats == 1 && l->dev.model == 0;
@@ -1208,7 +1217,18 @@ extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * co
     s->maxtips = std::max(s->maxtips, l->tips);
     s->g_rmax = std::max(s->g_rmax, l->rate_cats);
   }
-  if (!fits_sweep)
+  if (n20)
+  {
+    // amino-acid loci: the generic sampler's proposal control, the likelihood by the tiled 20-state kernels
+    if (n20 != nloci || !fits_generic)
+    {
+      fail("bpa_sampler_create: 20-state loci go together (no 4-state locus in the same sampler), with <= 16 tips and <= 4 rate categories");
+      delete s; return nullptr;
+    }
+    s->generic = true; s->g_alljc = false; s->g_s20 = true;
+    s->g_trees.assign(nloci, gsm::GTree{});
+  }
+  else if (!fits_sweep)
   {
     if (!fits_generic || !(all_jc || all_kl))
     {
@@ -1241,6 +1261,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
   s->g_len.free(); s->g_lograt.free(); s->g_active.free(); s->g_recs.free(); s->g_mat2.free(); s->g_bmo.free();
   s->g_sm.free(); s->g_sm_old.free(); s->g_ids.free();
+  s->g_ops20.free(); s->g_oprng.free(); s->g_root20.free(); s->g_mtask.free(); s->g_mpm.free(); s->g_tlocus.free(); s->g_tpat.free(); s->g_ttask.free(); s->g_tn0.free(); s->g_rscaler.free();
   s->v2_wave_off.free(); s->v2_loc.free(); s->v2_pat.free(); s->v2_xbuf.free(); s->v2_grng.free(); s->v2_err.free(); s->v2_prof.free(); s->v2_declog.free(); s->v2_sp.free();
   delete s;
 }
@@ -2048,7 +2069,8 @@ extern "C" int bpa_sampler_work(bpa_sampler_t * s, double * bytes, unsigned long
     const double nprop = s->generic ? s->g_trees[i].work_neval : (double)s->h_trees[i].proposals + s->h_trees[i].al_neval;
     // (the generic path counts every evaluated step; where the P-matrix phase is a launch of its own — several rate
     //  categories — the K4 bytes are not the timed kernel's)
-    by += nupd*(96.0*np*R + 256.0*R) + nprop*(32.0*R + 4.0)*np + ((s->generic && !s->g_alljc) ? 0.0 : nbr*128.0*R);
+    const double S = s->loci[i]->states;
+    by += nupd*(3.0*np*R*S*8.0 + 2.0*R*S*S*8.0) + nprop*(R*S*8.0 + 4.0)*np + ((s->generic && !s->g_alljc) ? 0.0 : nbr*R*S*S*8.0);
     nu += (unsigned long)nupd; pu += (unsigned long)(nupd*np);
   }
   if (bytes) *bytes = by;

@@ -41,8 +41,10 @@ def walk(host, dev, iters, nloci, check_every=1):
 
 
 @pytest.mark.parametrize("taxa,model,R,nloci,iters,forced", [(4, "jc69", 1, 300, 5, True), (8, "gtr", 4, 60, 3, False),
-                                                             (8, "jc69", 1, 40, 3, True)])
+                                                             (8, "jc69", 1, 40, 3, True), (6, "lg", 4, 40, 3, False), (6, "lg", 1, 24, 2, False)])
 def test_generic_sampler_equals_host_driver(taxa, model, R, nloci, iters, forced):
+    """(lg: amino-acid loci — BASELINE config 4's kind —, the steps written on the device as the records of the tiled 20-state
+    kernels: pmatrix_wg2_kernel, partials_lnl_pipe20_kernel)"""
     eng = bpp_amd.Engine(0)
     data = synth.make_dataset(nloci, 300, taxa, model, R, seed=19)
     loci_a = tape.make_engine_loci(eng, data)
@@ -67,7 +69,7 @@ def test_generic_sampler_equals_host_driver(taxa, model, R, nloci, iters, forced
         t = dev.tree(i)
         d = data[i]
         have = loci_b[i].root_loglikelihood(int(t["clv"][t["root"]]), -1)
-        ol = O.OracleLocus(4, R, d["seqs"], d["weights"], model=d["model"], freqs=None if model == "jc69" else d["freqs"],
+        ol = O.OracleLocus(d["states"], R, d["seqs"], d["weights"], model=d["model"], freqs=None if model == "jc69" else d["freqs"],
                            qrates=None if model == "jc69" else d["exch"], rates=d["rates"])
         full = ol.full_lnl(list(t["left"]), list(t["right"]), list(t["time"]), t["root"])
         assert rel(have, full) < 1e-12 and rel(t["lnl"], full) < 1e-12

@@ -16,6 +16,8 @@ rocprofv3 --kernel-trace --stats -f csv -d $W/trace -o p -- $BENCH > $W/bench_tr
 rocprofv3 --pmc FETCH_SIZE -f csv -d $W/pmc_fetch -o p -- $BENCH > /dev/null 2> $W/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE -f csv -d $W/pmc_write -o p -- $BENCH > /dev/null 2> $W/pmc_write.log
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CYCLES -f csv -d $W/pmc_sq -o p -- $BENCH > /dev/null 2> $W/pmc_sq.log
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT -f csv -d $W/pmc_sq2 -o p -- $BENCH > /dev/null 2> $W/pmc_sq2.log
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_F64 -f csv -d $W/pmc_sq3 -o p -- $BENCH > /dev/null 2> $W/pmc_sq3.log
 python3 - <<PY
 import csv, collections, glob, json
 out = {"config": "$CFG", "tag": "$TAG", "env": "$*", "command": "$BENCH"}
@@ -26,7 +28,7 @@ except Exception as e:
 ks = glob.glob("$W/trace/**/*kernel_stats.csv", recursive=True)
 out["kernel_stats"] = [r for r in csv.DictReader(open(ks[0]))][:8] if ks else None
 pm = {}
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3"):
     for f in glob.glob("$W/%s/**/*counter_collection.csv" % sub, recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
