@@ -395,7 +395,7 @@ def dominant_kernel(cfg, one_gpu=True):
     if cfg["model"] == "gtr":
         return "step_s4_klane_v2_kernel<256,false>"
     k = os.environ.get("BPA_S20_KERNEL", "pipe")
-    return {"pipe": "partials_lnl_pipe20_kernel<20,true,2>", "mfmak": "partials_lnl_mfma20k_kernel"}.get(k, f"20-state kernel `{k}`")
+    return {"pipe": "partials_lnl_pipe20_kernel<20,true,2>", "pipemfma": "partials_lnl_pipemfma20_kernel<false,2>"}.get(k, f"20-state kernel `{k}`")
 
 
 def traffic_from_profiles(config, kernel):
@@ -412,6 +412,15 @@ def traffic_from_profiles(config, kernel):
                 os.path.relpath(cands[-1], ROOT) + f" ({key.split('(')[0]}; separate --pmc passes; FETCH_SIZE doubled per the gfx950 note)")
     except Exception:
         return None, None
+
+
+def add_frac_pmc(r):
+    """`frac_pmc`: HBM bytes actually MOVED per launch (the PMC passes under profiles/) / the launch's duration / the HBM peak —
+    next to `frac`, which prices the algorithmic bytes"""
+    if isinstance(r, dict) and r.get("traffic") and r.get("avg_kernel_us"):
+        r["moved_GBps"] = round(r["traffic"] / (r["avg_kernel_us"] * 1e-6) / 1e9, 2)
+        r["frac_pmc"] = round(r["moved_GBps"] / r["peak"], 5)
+    return r
 
 
 class Dist:
@@ -660,7 +669,7 @@ def run_tape(eng, cfg, config_key, data, loci, args, D, steps, warmup):
         site_lnl_updates_per_s=round(it_pattern_updates * (total_loci / nloci) * steps / elapsed),
         node_updates_per_iteration=round(float(it_node_updates)),
         gflops_partials=round(it_flops * (total_loci / nloci) * steps / elapsed / 1e9, 2),
-        roofline=roofline, allreduce_check=allreduce_check,
+        roofline=add_frac_pmc(roofline), allreduce_check=allreduce_check,
         note="pre-recorded proposal tape, accept/reject by a seeded coin: the likelihood path alone (no MCMC decision)")
     for it in plans:
         for p in it:
@@ -849,7 +858,7 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
                acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
                taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
                thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],
-               roofline=roofline,
+               roofline=add_frac_pmc(roofline),
                implementation=("generic path (csrc/gsampler.hpp): proposals on the device as records for the engine's step kernels; "
                                "tree moves + 3 frequency, 5 exchangeability and 1 alpha move per locus" if gtr else
                                "generic path (csrc/gsampler.hpp): proposals on the device as the records of the tiled 20-state kernels "

@@ -757,16 +757,16 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   p->ntiles = 0; d.tile_task = d.tile_n0 = nullptr;
   // 20-state partials kernel (kernels.hpp): the pipelined kernel (partials_lnl_pipe20_kernel: P-matrices global -> LDS
   // direct and double-buffered, one wave per rate category, CLV planes streamed, 2 waves per SIMD).  BPA_S20_KERNEL
-  // selects the others, kept for comparison and as fall-backs: mfmak (the same update on the matrix cores, wave per
-  // category) | tiled (one wave runs all categories: what loci of more than 4 categories get) | generic (no staging)
+  // selects the others, kept for comparison and as fall-backs: pipemfma (the same update on the matrix cores, on the same
+  // memory pipeline) | tiled (one wave runs all categories: what loci of more than 4 categories get) | generic (no staging)
   {
     const char * v = getenv("BPA_S20_KERNEL");
     p->s20_kernel = v ? v : "pipe";
-    if (p->s20_kernel != "pipe" && p->s20_kernel != "pipe2" && p->s20_kernel != "pipe2w" && p->s20_kernel != "pipes" && p->s20_kernel != "pipemfma" && p->s20_kernel != "mfmak" && p->s20_kernel != "tiled" && p->s20_kernel != "generic") p->s20_kernel = "pipe";
+    if (p->s20_kernel != "pipe" && p->s20_kernel != "pipemfma" && p->s20_kernel != "tiled" && p->s20_kernel != "generic") p->s20_kernel = "pipe";
   }
-  p->s20_tiledk = p->s20_kernel == "pipe" || p->s20_kernel == "pipe2" || p->s20_kernel == "pipe2w" || p->s20_kernel == "pipes" || p->s20_kernel == "pipemfma" || p->s20_kernel == "mfmak";
+  p->s20_tiledk = p->s20_kernel == "pipe" || p->s20_kernel == "pipemfma";
   if (p->s20_tiledk && p->rmax > 4) { p->s20_tiledk = false; p->s20_kernel = "tiled"; }     // 64 x R lanes must fit a 256-lane workgroup
-  p->tile = p->s20_tiledk && p->s20_kernel != "pipe2" && p->s20_kernel != "pipe2w" ? 64 : 128;     // (pipe2: 128-pattern tiles, two patterns per lane)
+  p->tile = p->s20_tiledk ? 64 : 128;
   if (p->states == 20)
   {
     std::vector<uint32_t> tt, tn;
@@ -1124,16 +1124,8 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       static const bool no_xcd = getenv("BPA_NO_XCD_MAP") != nullptr;       // A/B: workgroup b = tile b
       if (no_xcd) d.flags |= 32u;
       const dim3 grid(p->ntiles), block(64*p->rmax);
-      if (p->s20_kernel == "pipe2w")
-        hipLaunchKernelGGL((partials_lnl_pipe20x2_kernel<20, true, 1, true>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*128)*sizeof(double), e->stream, d);
-      else if (p->s20_kernel == "pipe2")
-        hipLaunchKernelGGL((partials_lnl_pipe20x2_kernel<20, true, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*128)*sizeof(double), e->stream, d);
-      else if (p->s20_kernel == "pipes")
-        hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2, true>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
-      else if (p->s20_kernel == "pipemfma")
+      if (p->s20_kernel == "pipemfma")
         hipLaunchKernelGGL((partials_lnl_pipemfma20_kernel<false, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
-      else if (p->s20_kernel == "mfmak")
-        hipLaunchKernelGGL(partials_lnl_mfma20k_kernel, grid, block, ((size_t)2*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
       else
         hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
     }

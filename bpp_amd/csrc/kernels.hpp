@@ -495,8 +495,8 @@ __device__ __forceinline__ double dot_fma4_s(cdbl4_p row, const double * v)     
   return (a0 + a1) + (a2 + a3);
 }
 
-template <int S, bool NTA = false, int OCC = 3, bool PSC = false>      // NTA: CLV planes streamed (nontemporal); OCC: waves per SIMD of the register budget;
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))      // PSC: the P rows of inner children through the scalar data path (SGPR operands)
+template <int S, bool NTA = false, int OCC = 3>      // NTA: CLV planes streamed (nontemporal); OCC: waves per SIMD of the register budget
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 partials_lnl_pipe20_kernel(const PlanDev P)
 {
   extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2 buffers][2 children][R][S][S], then [R][64] scratch
@@ -585,15 +585,11 @@ partials_lnl_pipe20_kernel(const PlanDev P)
       if (rfwd) {
 #pragma unroll
         for (int s = 0; s < S; ++s) rv[s] = ov[s]; }
-      // PSC: a wave's P rows are wave-uniform — they can be SGPR operands of v_fma_f64 (s_load through the scalar cache)
-      // instead of LDS broadcasts, whose return path (64 lanes x 8 B per operand) is what bounds this kernel
-      const cdbl4_p gl4 = (cdbl4_p)L64[1] + (size_t)op.left_pmatrix*R*SS + (size_t)k*SS;
-      const cdbl4_p gr4 = (cdbl4_p)L64[1] + (size_t)op.right_pmatrix*R*SS + (size_t)k*SS;
 #pragma unroll
       for (int i = 0; i < S; ++i)
       {
-        const double x = lfast ? lm[i*S + ls] : PSC ? dot_fma4_s<S>(gl4 + i*S, lv) : dot_fma4<S>(lm + i*S, lv);
-        const double y = rfast ? rm[i*S + rs] : PSC ? dot_fma4_s<S>(gr4 + i*S, rv) : dot_fma4<S>(rm + i*S, rv);
+        const double x = lfast ? lm[i*S + ls] : dot_fma4<S>(lm + i*S, lv);
+        const double y = rfast ? rm[i*S + rs] : dot_fma4<S>(rm + i*S, rv);
         const double v = x*y;
         all_small = all_small && (v < BPA_SCALE_THRESHOLD);
         ov[i] = v;
@@ -673,432 +669,26 @@ partials_lnl_pipe20_kernel(const PlanDev P)
   P.site_term[((cu32_p)P.task_pat_off)[t] + n] = term;
 }
 
-// ======================= K1+K2, 20 states, FP64 MFMA, one wave per rate category ==
-// The contraction parent[i][n] = (sum_j Pl[i][j] L[j][n]) (sum_j Pr[i][j] R[j][n]) on the matrix cores
-// with v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction: blocks = four groups of
-// 4 patterns, A = a 4-row x 4-column piece of P replicated over the blocks, B = 4 states x 16
-// patterns; 20 states = 5 row tiles, no padding in M).  Both operands live in VGPRs, so unlike the
-// LDS-broadcast VALU kernels (one LDS access per v_fma_f64: the LDS pipe, shared by the four SIMDs,
-// caps them near a quarter of the FP64 rate) the P-matrix costs ONE LDS read per (row tile,
-// accumulator) and rate category — 16x fewer.  A workgroup = 64 patterns x R categories, wave k owns
-// the k-th plane.  Lane layout (tools/mfma_layout.hip):
+// ======================= K1+K2, 20 states, FP64 MFMA (north_star's matrix-core path), one wave per rate category ==
+// The contraction parent[i][n] = (sum_j Pl[i][j] L[j][n]) (sum_j Pr[i][j] R[j][n]) on the matrix cores with
+// v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction: blocks = four groups of 4 patterns, A = a 4-row x
+// 4-column piece of P replicated over the blocks, B = 4 states x 16 patterns; 20 states = 5 row tiles, no padding in M), ON
+// the memory pipeline of partials_lnl_pipe20_kernel: tile / locus / update records through the scalar data path, the two
+// children's P-matrices global -> LDS direct and double-buffered, one LDS-only barrier per update, the XCD-aware tile map.
+// Lane layout (tools/mfma_layout.hip):
 //   A[blk][i][kk] @ lane kk*16+blk*4+i   B[blk][kk][j] @ lane kk*16+blk*4+j   D[blk][i][j] @ lane i*16+blk*4+j
-// Bit-exactness: the instruction accumulates kk = 0..3 as an ascending fma chain seeded with C
-// (tools/mfma_order.hip), which IS the reference's AVX2 lane accumulator over its first four
-// column blocks: accumulator a takes columns a, a+4, a+8, a+12 in one MFMA; its fifth term
-// (column a+16) is one v_fma_f64 in the D layout; then (acc0+acc1)+(acc2+acc3) and the product
-// (core_partials_avx2.c:666-745).  5 row tiles x 4 accumulators = 20 MFMAs per child per 16 patterns:
-// every MFMA slot is useful work.
-__device__ __forceinline__ void load_b20k(const LocusDev & L, const uint32_t clv_index, const uint32_t k,
-                                          const uint32_t pat, const uint32_t kq, double (&b)[4], double (&bt)[4])
-{
-  if (clv_index < L.tips_n)
-  {
-    const uint32_t code = reinterpret_cast<const uint32_t *>(L.tips)[(size_t)clv_index*L.np + pat];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-    {
-      b[a]  = ((code >> (a + 4*kq)) & 1u) ? 1.0 : 0.0;
-      bt[a] = ((code >> (16 + a)) & 1u) ? 1.0 : 0.0;
-    }
-  }
-  else
-  {
-    const double * p = L.clv + (((size_t)(clv_index - L.tips_n)*L.rate_cats + k)*20)*L.ld + pat;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-    {
-      b[a]  = p[(size_t)(a + 4*kq)*L.ld];
-      bt[a] = p[(size_t)(16 + a)*L.ld];
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256) partials_lnl_mfma20k_kernel(const PlanDev P)
-{
-  constexpr int S = 20, SS = 400, NG = 4;
-  extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2][R][S][S], then [R][64] scratch
-  const uint32_t b = blockIdx.x, l = threadIdx.x & 63u;
-  const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t t = P.tile_task[b], n0 = P.tile_n0[b];
-  const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld, nthr = blockDim.x;
-  const uint32_t kq = l >> 4, pl = l & 15, ri = l & 3;
-  const bool wave_on = k < R;
-  double * s_x = s_p + (size_t)2*P.pad*SS;
-
-  const uint32_t op_end = P.op_off[t+1];
-  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
-  {
-    const OpDev op = P.ops[o];
-    __syncthreads();                                   // previous update's LDS reads are done
-    {
-      const double2 * gl = reinterpret_cast<const double2 *>(L.pmat + (size_t)op.left_pmatrix*R*SS);
-      const double2 * gr = reinterpret_cast<const double2 *>(L.pmat + (size_t)op.right_pmatrix*R*SS);
-      double2 * sl = reinterpret_cast<double2 *>(s_p);
-      double2 * sr = reinterpret_cast<double2 *>(s_p + (size_t)R*SS);
-      for (uint32_t i = threadIdx.x; i < R*SS/2; i += nthr) { sl[i] = gl[i]; sr[i] = gr[i]; }
-    }
-    __syncthreads();
-    double * out = L.clv + ((((size_t)(op.parent_clv - L.tips_n)*R) + k)*S)*ld;
-    uint32_t small = 0xfu;                             // bit g: everything this lane produced for group g is < 2^-256
-    if (wave_on)
-    {
-      const double * lm = s_p + (size_t)k*SS;
-      const double * rm = s_p + (size_t)(R + k)*SS;
-      // 16 patterns at a time: their CLV operands (B and the tail column's), then the five row tiles
-#pragma unroll 2
-      for (int g = 0; g < NG; ++g)
-      {
-        const uint32_t pat = n0 + 16*g + pl;
-        const uint32_t pc = pat < np ? pat : np - 1;
-        double bl[4], blt[4], br[4], brt[4];
-        load_b20k(L, op.left_clv,  k, pc, kq, bl, blt);
-        load_b20k(L, op.right_clv, k, pc, kq, br, brt);
-#pragma unroll
-        for (int r = 0; r < 5; ++r)
-        {
-          // A operands of this row tile: the MFMA piece P[4r+ri][a+4kq] and the tail column P[4r+kq][16+a]
-          const double2 * pl0 = reinterpret_cast<const double2 *>(lm + (4*r + ri)*S + 4*kq);
-          const double2 * pr0 = reinterpret_cast<const double2 *>(rm + (4*r + ri)*S + 4*kq);
-          const double2 * pl1 = reinterpret_cast<const double2 *>(lm + (4*r + kq)*S + 16);
-          const double2 * pr1 = reinterpret_cast<const double2 *>(rm + (4*r + kq)*S + 16);
-          const double2 l01 = pl0[0], l23 = pl0[1], r01 = pr0[0], r23 = pr0[1];
-          const double2 lt01 = pl1[0], lt23 = pl1[1], rt01 = pr1[0], rt23 = pr1[1];
-          const double al[4] = {l01.x, l01.y, l23.x, l23.y}, ar[4] = {r01.x, r01.y, r23.x, r23.y};
-          const double alt[4] = {lt01.x, lt01.y, lt23.x, lt23.y}, art[4] = {rt01.x, rt01.y, rt23.x, rt23.y};
-          double xa[4], ya[4];
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-          {
-            xa[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(al[a], bl[a], 0.0, 0, 0, 0);
-            ya[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(ar[a], br[a], 0.0, 0, 0, 0);
-          }
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-          {
-            xa[a] = __builtin_fma(alt[a], blt[a], xa[a]);
-            ya[a] = __builtin_fma(art[a], brt[a], ya[a]);
-          }
-          const double x = (xa[0] + xa[1]) + (xa[2] + xa[3]);
-          const double y = (ya[0] + ya[1]) + (ya[2] + ya[3]);
-          const double v = x*y;
-          if (!(v < BPA_SCALE_THRESHOLD)) small &= ~(1u << g);
-          if (pat < np) out[(size_t)(4*r + kq)*ld + pat] = v;            // D: row = lane >> 4
-        }
-      }
-    }
-    if (op.parent_scaler >= 0)                         // uniform: the scaling test couples rows, lanes and categories
-    {
-      small &= __shfl_xor(small, 16);
-      small &= __shfl_xor(small, 32);                  // the 4 lanes of a pattern hold its 20 rows
-      __syncthreads();
-      if (kq == 0) reinterpret_cast<uint32_t *>(s_x)[k*16 + pl] = small;
-      __syncthreads();
-      if (wave_on)
-      {
-        uint32_t all = 0xfu;
-        for (uint32_t q = 0; q < R; ++q) all &= reinterpret_cast<const uint32_t *>(s_x)[q*16 + pl];
-        for (int g = 0; g < NG; ++g)
-        {
-          const uint32_t pat = n0 + 16*g + pl;
-          if (pat >= np) continue;
-          const bool rescale = (all >> g) & 1u;
-          if (rescale)
-#pragma unroll
-            for (int r = 0; r < 5; ++r) out[(size_t)(4*r + kq)*ld + pat] *= BPA_SCALE_FACTOR;
-          if (k == 0 && kq == 0)
-          {
-            uint32_t sc = rescale ? 1u : 0u;
-            if (op.left_scaler  >= 0) sc += L.scaler[(size_t)op.left_scaler*np  + pat];
-            if (op.right_scaler >= 0) sc += L.scaler[(size_t)op.right_scaler*np + pat];
-            L.scaler[(size_t)op.parent_scaler*np + pat] = sc;
-          }
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next update reads these through other lanes
-  }
-  if (!(P.flags & 4u)) return;
-
-  // K2 / K3 (core_likelihood_avx2.c:45-87): every wave its category's term, wave 0 the fma chain over them
-  const uint32_t root = P.root_clv[t];
-  const double * par = L.par;
-  const uint32_t n = n0 + l;
-  const bool active = wave_on && n < np;
-  __syncthreads();
-  if (active)
-  {
-    double c[S];
-    load_childN<S, uint32_t>(L, root, k, n, c);
-    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
-    s_x[k*64 + l] = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
-  }
-  __syncthreads();
-  if (!active || k) return;
-  double term = 0;
-  for (uint32_t q = 0; q < R; ++q) term = __builtin_fma(s_x[q*64 + l], par[par_rate_weights(R) + q], term);
-  if (!L.unphased_length)
-  {
-    double lt = log(term);
-    const int32_t rs = P.root_scaler[t];
-    if (rs >= 0)
-    {
-      const uint32_t sc = L.scaler[(size_t)rs*np + n];
-      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
-    }
-    term = lt*L.weights[n];
-  }
-  P.site_term[P.task_pat_off[t] + n] = term;
-}
-
-// ======================= K1+K2, 20 states, TWO patterns per lane.  partials_lnl_pipe20_kernel takes one P operand out of LDS per
-// v_fma_f64; the LDS return path (64 lanes x 8 B per operand, one path for the CU's four SIMDs) then holds the kernel near
-// a quarter of the FP64 rate whatever else is tuned.  Here a lane owns patterns n and n + 64 of a 128-pattern tile: every P
-// row read from LDS feeds two fma chains (half the LDS operand traffic per flop).  To stay inside 256 VGPRs (2 waves per
-// SIMD) the two children are taken one after the other — first child: its 2 x 20 values in, the 2 x 20 row sums x out; second
-// child: its values in, x[i] *= y_i — and the forwarded child (the parent the previous update left in registers), if any,
-// goes first, so that at most 80 doubles are live (x y = y x bit for bit).  Everything else is pipe20's: scalar-path
-// records, P-matrices global -> LDS direct and double-buffered, one LDS-only barrier per update, XCD-aware tile map,
-// the reference's summation order (core_partials_avx2.c:666-745).
-template <int S>
-__device__ __forceinline__ void dot_fma4_x2(const double * __restrict__ row, const double * v0, const double * v1, double & r0, double & r1)
-{
-  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-#pragma unroll
-  for (int j = 0; j < S; j += 4)
-  {
-    const double p0 = row[j+0], p1 = row[j+1], p2 = row[j+2], p3 = row[j+3];
-    a0 = __builtin_fma(p0, v0[j+0], a0); b0 = __builtin_fma(p0, v1[j+0], b0);
-    a1 = __builtin_fma(p1, v0[j+1], a1); b1 = __builtin_fma(p1, v1[j+1], b1);
-    a2 = __builtin_fma(p2, v0[j+2], a2); b2 = __builtin_fma(p2, v1[j+2], b2);
-    a3 = __builtin_fma(p3, v0[j+3], a3); b3 = __builtin_fma(p3, v1[j+3], b3);
-  }
-  r0 = (a0 + a1) + (a2 + a3); r1 = (b0 + b1) + (b2 + b3);
-}
-
-template <int S, bool NTA = false, int OCC = 2, bool FWD = false>      // FWD: the parent just computed stays in registers for the next update (40 more live doubles)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
-partials_lnl_pipe20x2_kernel(const PlanDev P)
-{
-  extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2 buffers][2 children][R][S][S], then [R][128] scratch
-  constexpr uint32_t SS = S*S;
-  const uint32_t b = (P.flags & 32u) ? blockIdx.x : xcd_tile(blockIdx.x, gridDim.x), lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
-  const uint32_t k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t t = ((cu32_p)P.tile_task)[b];
-  const uint32_t n0 = ((cu32_p)P.tile_n0)[b] + lane;
-  const uint32_t lid = ((cu32_p)P.task_locus)[t];
-  cu64_p L64 = (cu64_p)(P.loci + lid);
-  cu32_p L32 = (cu32_p)(P.loci + lid);
-  const gdbl_p   Lclv    = (gdbl_p)L64[0];
-  const double * Lpmat   = (const double *)L64[1];
-  const gu32_p   Lscaler = (gu32_p)L64[2];
-  const gcu32_p  Ltips   = (gcu32_p)L64[3];
-  const gcu32_p  Lwgt    = (gcu32_p)L64[4];
-  const cdbl4_p  par     = (cdbl4_p)L64[5];
-  const uint32_t np = L32[18], tips_n = L32[19], R = L32[20], unphased = L32[25], ld = L32[27];
-  const bool on0 = n0 < np && k < R, on1 = n0 + 64u < np && k < R;       // (on1 implies on0)
-  const uint32_t n1 = on1 ? n0 + 64u : n0;                               // the second pattern, or the first once more (never stored)
-  const uint32_t bufsz = 2*P.pad*SS;
-  double * s_x = s_p + (size_t)2*bufsz;
-
-  const uint32_t op_begin = ((cu32_p)P.op_off)[t], op_end = ((cu32_p)P.op_off)[t+1];
-  uint32_t cur = 0;
-  if (op_begin < op_end)
-  {
-    const OpS op0 = load_op_scalar(P.ops, op_begin);
-    stage_pmats_async<S>(s_p, Lpmat + (size_t)op0.left_pmatrix*R*SS, Lpmat + (size_t)op0.right_pmatrix*R*SS, R, k, nw, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-  }
-  double ov0[S], ov1[S];                                             // the parent just computed (forwarded), both patterns
-  uint32_t ov_clv = 0xffffffffu;
-  for (uint32_t o = op_begin; o < op_end; ++o)
-  {
-    const OpS op = load_op_scalar(P.ops, o);
-    // the forwarded child first (so that its registers are free when the other child's values arrive)
-    const bool swap = FWD && op.right_clv == ov_clv && op.left_clv != ov_clv;
-    const uint32_t c1 = swap ? op.right_clv : op.left_clv, c2 = swap ? op.left_clv : op.right_clv;
-    const double * m1 = s_p + (size_t)cur*bufsz + (size_t)((swap ? R : 0u) + k)*SS;
-    const double * m2 = s_p + (size_t)cur*bufsz + (size_t)((swap ? 0u : R) + k)*SS;
-    const bool tip1 = c1 < tips_n, tip2 = c2 < tips_n, fwd1 = FWD && c1 == ov_clv, fwd2 = FWD && c2 == ov_clv;       // (fwd2: both children are the forwarded node — never in a tree)
-    double x0[S], x1[S];
-    bool small0 = true, small1 = true;
-    // ---- first child
-    {
-      double u0[S], u1[S];
-      uint32_t code0 = 1u, code1 = 1u;
-      if (on0)
-      {
-        if (tip1) { code0 = Ltips[(size_t)c1*np + n0]; code1 = Ltips[(size_t)c1*np + n1]; }
-        else if (!fwd1)
-        {
-          const gcdbl_p p0 = Lclv + (((size_t)(c1 - tips_n)*R + k)*S)*ld + n0, p1 = Lclv + (((size_t)(c1 - tips_n)*R + k)*S)*ld + n1;
-#pragma unroll
-          for (int s = 0; s < S; ++s) { u0[s] = NTA ? __builtin_nontemporal_load(p0 + (size_t)s*ld) : p0[(size_t)s*ld]; u1[s] = NTA ? __builtin_nontemporal_load(p1 + (size_t)s*ld) : p1[(size_t)s*ld]; }
-        }
-      }
-      if (o + 1 < op_end)
-      {
-        const OpS nx = load_op_scalar(P.ops, o + 1);
-        stage_pmats_async<S>(s_p + (size_t)(cur ^ 1u)*bufsz, Lpmat + (size_t)nx.left_pmatrix*R*SS, Lpmat + (size_t)nx.right_pmatrix*R*SS, R, k, nw, lane);
-      }
-      if (on0)
-      {
-        const bool fast = tip1 && __all(__popc(code0) == 1 && __popc(code1) == 1);
-        const int s0 = __ffs(code0) - 1, s1 = __ffs(code1) - 1;
-        if (tip1 && !fast) {
-#pragma unroll
-          for (int s = 0; s < S; ++s) { u0[s] = (double)((code0 >> s) & 1u); u1[s] = (double)((code1 >> s) & 1u); } }
-        if (fwd1) {
-#pragma unroll
-          for (int s = 0; s < S; ++s) { u0[s] = ov0[s]; u1[s] = ov1[s]; } }
-#pragma unroll
-        for (int i = 0; i < S; ++i)
-        {
-          if (fast) { x0[i] = m1[i*S + s0]; x1[i] = m1[i*S + s1]; }
-          else dot_fma4_x2<S>(m1 + i*S, u0, u1, x0[i], x1[i]);
-        }
-      }
-    }
-    // ---- second child (its loads stay behind the first child's arithmetic: the register budget holds one child's values)
-    asm volatile("" ::: "memory");
-    {
-      double u0[S], u1[S];
-      uint32_t code0 = 1u, code1 = 1u;
-      if (on0)
-      {
-        if (tip2) { code0 = Ltips[(size_t)c2*np + n0]; code1 = Ltips[(size_t)c2*np + n1]; }
-        else if (!fwd2)
-        {
-          const gcdbl_p p0 = Lclv + (((size_t)(c2 - tips_n)*R + k)*S)*ld + n0, p1 = Lclv + (((size_t)(c2 - tips_n)*R + k)*S)*ld + n1;
-#pragma unroll
-          for (int s = 0; s < S; ++s) { u0[s] = NTA ? __builtin_nontemporal_load(p0 + (size_t)s*ld) : p0[(size_t)s*ld]; u1[s] = NTA ? __builtin_nontemporal_load(p1 + (size_t)s*ld) : p1[(size_t)s*ld]; }
-        }
-        const bool fast = tip2 && __all(__popc(code0) == 1 && __popc(code1) == 1);
-        const int s0 = __ffs(code0) - 1, s1 = __ffs(code1) - 1;
-        if (tip2 && !fast) {
-#pragma unroll
-          for (int s = 0; s < S; ++s) { u0[s] = (double)((code0 >> s) & 1u); u1[s] = (double)((code1 >> s) & 1u); } }
-        if (fwd2) {
-#pragma unroll
-          for (int s = 0; s < S; ++s) { u0[s] = ov0[s]; u1[s] = ov1[s]; } }
-#pragma unroll
-        for (int i = 0; i < S; ++i)
-        {
-          double y0, y1;
-          if (fast) { y0 = m2[i*S + s0]; y1 = m2[i*S + s1]; }
-          else dot_fma4_x2<S>(m2 + i*S, u0, u1, y0, y1);
-          // (left x right in the reference; the product commutes bit for bit)
-          const double v0 = x0[i]*y0, v1 = x1[i]*y1;
-          small0 = small0 && (v0 < BPA_SCALE_THRESHOLD); small1 = small1 && (v1 < BPA_SCALE_THRESHOLD);
-          ov0[i] = v0; ov1[i] = v1;
-        }
-        ov_clv = op.parent_clv;
-      }
-    }
-    if (op.parent_scaler >= 0)                         // uniform: the scaling test couples the categories
-    {
-      reinterpret_cast<uint32_t *>(s_x)[k*128 + lane] = small0 ? 1u : 0u;
-      reinterpret_cast<uint32_t *>(s_x)[k*128 + 64 + lane] = small1 ? 1u : 0u;
-      lds_barrier();
-      if (on0)
-      {
-        bool all0 = true, all1 = true;
-        for (uint32_t q = 0; q < R; ++q)
-        {
-          all0 = all0 && reinterpret_cast<const uint32_t *>(s_x)[q*128 + lane] != 0u;
-          all1 = all1 && reinterpret_cast<const uint32_t *>(s_x)[q*128 + 64 + lane] != 0u;
-        }
-        if (all0) {
-#pragma unroll
-          for (int i = 0; i < S; ++i) ov0[i] *= BPA_SCALE_FACTOR; }
-        if (all1) {
-#pragma unroll
-          for (int i = 0; i < S; ++i) ov1[i] *= BPA_SCALE_FACTOR; }
-        if (k == 0)
-        {
-          uint32_t sc0 = all0 ? 1u : 0u, sc1 = all1 ? 1u : 0u;
-          if (op.left_scaler  >= 0) { sc0 += Lscaler[(size_t)op.left_scaler*np  + n0]; sc1 += Lscaler[(size_t)op.left_scaler*np  + n1]; }
-          if (op.right_scaler >= 0) { sc0 += Lscaler[(size_t)op.right_scaler*np + n0]; sc1 += Lscaler[(size_t)op.right_scaler*np + n1]; }
-          Lscaler[(size_t)op.parent_scaler*np + n0] = sc0;
-          if (on1) Lscaler[(size_t)op.parent_scaler*np + n1] = sc1;
-        }
-      }
-    }
-    if (on0)
-    {
-      const gdbl_p out = Lclv + ((((size_t)(op.parent_clv - tips_n)*R) + k)*S)*ld;
-#pragma unroll
-      for (int i = 0; i < S; ++i)
-      {
-        if (NTA) __builtin_nontemporal_store(ov0[i], out + (size_t)i*ld + n0); else out[(size_t)i*ld + n0] = ov0[i];
-        if (on1) { if (NTA) __builtin_nontemporal_store(ov1[i], out + (size_t)i*ld + n1); else out[(size_t)i*ld + n1] = ov1[i]; }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next matrices has landed (stores drain with it)
-    lds_barrier();                                     // everyone is done reading buffer `cur` and has filled the other
-    cur ^= 1u;
-  }
-  if (!(P.flags & 4u)) return;
-
-  // K2 / K3 (core_likelihood_avx2.c:45-87): every wave its category's terms, wave 0 the fma chain over them
-  const uint32_t root = ((cu32_p)P.root_clv)[t];
-  if (on0)
-  {
-    double c0[S], c1[S];
-    if (FWD && root == ov_clv) {
-#pragma unroll
-      for (int s = 0; s < S; ++s) { c0[s] = ov0[s]; c1[s] = ov1[s]; } }
-    else if (root < tips_n)
-    {
-      const uint32_t code0 = Ltips[(size_t)root*np + n0], code1 = Ltips[(size_t)root*np + n1];
-#pragma unroll
-      for (int s = 0; s < S; ++s) { c0[s] = (double)((code0 >> s) & 1u); c1[s] = (double)((code1 >> s) & 1u); }
-    }
-    else
-    {
-      const gcdbl_p p0 = Lclv + (((size_t)(root - tips_n)*R + k)*S)*ld + n0, p1 = Lclv + (((size_t)(root - tips_n)*R + k)*S)*ld + n1;
-#pragma unroll
-      for (int s = 0; s < S; ++s) { c0[s] = p0[(size_t)s*ld]; c1[s] = p1[(size_t)s*ld]; }
-    }
-    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
-    s_x[k*128 + lane] = dot_fma4_s<S>(par + par_matrix(R, S, m) + pm_freqs(S), c0);
-    s_x[k*128 + 64 + lane] = dot_fma4_s<S>(par + par_matrix(R, S, m) + pm_freqs(S), c1);
-  }
-  lds_barrier();
-  if (!on0 || k) return;
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-  {
-    if (j && !on1) break;
-    const uint32_t n = j ? n1 : n0;
-    double term = 0;
-    for (uint32_t q = 0; q < R; ++q) term = __builtin_fma(s_x[q*128 + 64*j + lane], par[par_rate_weights(R) + q], term);
-    if (!unphased)
-    {
-      double lt = log(term);
-      const int32_t rsc = ((ci32_p)P.root_scaler)[t];
-      if (rsc >= 0)
-      {
-        const uint32_t sc = Lscaler[(size_t)rsc*np + n];
-        if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
-      }
-      term = lt*Lwgt[n];
-    }
-    P.site_term[((cu32_p)P.task_pat_off)[t] + n] = term;
-  }
-}
-
-// ======================= K1+K2, 20 states: the matrix-core contraction of partials_lnl_mfma20k_kernel ON the memory
-// pipeline of partials_lnl_pipe20_kernel.  What moves is pipe20's: tile / locus / update records through the scalar data
-// path, the two children's P-matrices global -> LDS direct and double-buffered, one LDS-only barrier per update, the
-// XCD-aware tile map.  What computes is mfma20k's bit-exact order (v_mfma_f64_4x4x4, kk ascending = the AVX2 lane
-// accumulator over four column blocks, the fifth column block one v_fma_f64 in the D layout, (a0+a1)+(a2+a3), the product:
-// core_partials_avx2.c:666-745) — with the loops turned inside out: the CLV operands of all four 16-pattern groups of the
-// tile are requested first (64 loads in flight per lane), then each row tile's A operands come out of LDS ONCE (8
-// ds_read_b128) and serve the four groups.  P costs 40 LDS reads per update and wave instead of pipe20's 800.
-// No register forwarding (D and B layouts differ): the next update re-reads the parent through L2.
+// Bit-exactness: the instruction accumulates kk = 0..3 as an ascending fma chain seeded with C (tools/mfma_order.hip),
+// which IS the reference's AVX2 lane accumulator over its first four column blocks: accumulator a takes columns a, a+4,
+// a+8, a+12 in one MFMA; its fifth term (column a+16) is one v_fma_f64 in the D layout; then (acc0+acc1)+(acc2+acc3) and
+// the product (core_partials_avx2.c:666-745).  The CLV operands of all four 16-pattern groups of the tile are requested
+// first (64 loads in flight per lane), then each row tile's A operands come out of LDS ONCE (8 ds_read_b128) and serve
+// the four groups: P costs 40 LDS reads per update and wave instead of pipe20's 400.  No register forwarding (D and B
+// layouts differ): the next update re-reads the parent through L2.
+// NOT the default: on gfx950 the FP64 matrix rate is the FP64 vector rate (tools/f64_rate.hip, measured on the box:
+// v_fma_f64 58.5, v_mfma_f64_4x4x4 72.0, v_mfma_f64_16x16x4 49.1 TFLOP/s), so the matrix cores can only save operand
+// traffic, and the layout costs more than that saves: config 4, per launch, 499-528 us against pipe20's 353-366 us
+// (profiles/r3: SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_LDS 3.3 M against 18.7 M).  An earlier form without pipe20's pipeline
+// (partials_lnl_mfma20k_kernel, rounds 1-2) took 575 us.
 template <bool NTA = false, int OCC = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 partials_lnl_pipemfma20_kernel(const PlanDev P)

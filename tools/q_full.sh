@@ -1,3 +1,2 @@
-( time timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -8 ) > gpurun_out/r3_gpu_tests.log 2>&1
-timeout 800 python bench.py > gpurun_out/r3_bench.json 2> gpurun_out/r3_bench.err
-tail -3 gpurun_out/r3_gpu_tests.log
+( time timeout 1500 python -m pytest tests -q -m gpu -x --durations=25 2>&1 | grep -v "^$" | tail -45 ) > gpurun_out/r3_gpu_tests.log 2>&1
+grep -E "passed|failed" gpurun_out/r3_gpu_tests.log | tail -2
