@@ -1068,11 +1068,14 @@ def main():
             ms_per_step = sampler_sec["ms_per_step"]
             roofline = sampler_sec.pop("roofline")
             metric = "MCMC iterations/sec (A00), every decision on the device"
-        else:
+        elif tape_sec is not None:
             value = (tape_sec["iterations_per_s_10k_loci"] if (args.config == "c2" and args.scaling == "weak") else tape_sec["iterations_per_s"])
             ms_per_step = tape_sec["ms_per_step"]
             roofline = tape_sec["roofline"]
             metric = "A00 iterations/sec of the likelihood hot path (proposal tape)"
+        else:                                    # (--no-sampler --no-tape: only the side sections were asked for)
+            value, ms_per_step, roofline = None, None, None
+            metric = "no headline section was run (--no-sampler --no-tape)"
         loci_unit = 10000 if args.config in ("c2", "c3") else nloci_cfg
         # ---- `cpu_baseline` is like-for-like with `value`: whole MCMC iterations/s of the unmodified reference program at
         # its best thread count on this box's host cores; the tape replay through the reference's locus API (likelihood

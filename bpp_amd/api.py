@@ -120,6 +120,9 @@ def lib():
         "bpa_plans_launch_exchange": (i, [vp, u, vp, vp, u]),
         "bpa_p2p_destroy": (None, [vp]),
         "bpa_batch_evaluate": (i, [vp, C.POINTER(Batch), dp]),
+        "bpa_batch_begin": (i, [vp, C.POINTER(Batch)]),
+        "bpa_batch_fill": (i, [vp, C.POINTER(Batch), u, u]),
+        "bpa_batch_end": (i, [vp, C.POINTER(Batch), dp]),
         "bpa_engine_stage": (vp, [vp, vp, C.c_size_t]),
         "bpa_plan_set_params": (i, [vp, i, dp]),
         "bpa_plan_set_params_device": (i, [vp, i, vp]),
@@ -176,7 +179,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_compress_site_patterns", "bpa_locus_get_clv", "bpa_locus_set_clv",
             "bpa_locus_get_pmatrix", "bpa_locus_set_pmatrix", "bpa_locus_get_scaler", "bpa_locus_set_scaler",
             "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
-            "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate",
+            "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate", "bpa_batch_begin", "bpa_batch_fill", "bpa_batch_end",
             "bpa_plan_enable_sum", "bpa_plan_enable_partial_sums", "bpa_plan_get_sum",
             "bpa_p2p_create", "bpa_p2p_connect", "bpa_p2p_allreduce", "bpa_p2p_status", "bpa_p2p_destroy", "bpa_p2p_set_timeout", "bpa_plans_launch_exchange", "bpa_plans_launch",
             "bpa_plan_set_params", "bpa_plan_set_params_device", "bpa_engine_stage",

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <memory>
 #include <mutex>
+#include <atomic>
 
 #include "bpp_amd.h"
 #include "device_types.hpp"
@@ -129,6 +130,11 @@ struct bpa_engine
   // bpa_batch_evaluate on the engine's packing: one pinned image of the step's compact records, one upload, persistent
   // device buffers (no plan object, no allocation in steady state)
   void * h_step = nullptr; size_t h_step_bytes = 0;
+  // the batch between bpa_batch_begin and bpa_batch_end
+  unsigned bc_T = 0, bc_units = 0, bc_nmat = 0, bc_npat = 0, bc_rmax = 1; bool bc_alljc = false;
+  size_t bc_o_mat2 = 0, bc_o_len = 0, bc_o_bm = 0, bc_total = 0;
+  std::vector<uint32_t> bc_pat;
+  std::atomic<int> bc_failed{0}; std::mutex bc_mtx; std::string bc_msg;
   DevBuf<unsigned char> d_step;
   DevBuf<double> d_step_terms, d_step_lnl;
   // engine-level packing of the JC69 / one-category loci for step_jc69_v2_kernel (device_types.hpp): shared by all plans
@@ -648,6 +654,14 @@ static int engine_pack(bpa_engine * e)
   return 1;
 }
 
+static bool validate_op_quiet(const bpa_locus * l, const bpa_op_t & o)      // (callable from several threads: leaves the error text to the caller)
+{
+  const unsigned nclv = l->tips + l->clv_buffers;
+  const int ns = (int)l->scale_buffers;
+  return !(o.parent_clv < l->tips || o.parent_clv >= nclv || o.left_clv >= nclv || o.right_clv >= nclv ||
+           o.left_pmatrix >= l->prob_matrices || o.right_pmatrix >= l->prob_matrices ||
+           o.parent_scaler >= ns || o.left_scaler >= ns || o.right_scaler >= ns);
+}
 static int validate_op(const bpa_locus * l, const bpa_op_t & o)
 {
   const unsigned nclv = l->tips + l->clv_buffers;
@@ -1433,16 +1447,15 @@ extern "C" int bpa_plan_work(bpa_plan_t * p, double * bytes_partials, double * f
 // list | branch lengths | per-workgroup matrix offsets), uploaded with ONE copy into persistent device memory and
 // launched — no plan object, no device allocation, no per-array copies (a plan costs ~2.3 ms to build for 10 000
 // loci, this ~0.1 ms).  handled = false: not eligible, the caller takes the general path.
-static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double * lnl, bool & handled)
+// bpa_batch_evaluate's packed path in three parts (bpa_batch_begin / _fill / _end of the header): checks + sizing, the
+// record image of a range of the batch's loci (disjoint ranges from several threads at once: a locus's records go to its own
+// slot and its own range of the matrix list, nothing else is written), upload + launch + results.
+static double batch_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static int batch_begin_packed(bpa_engine * e, const bpa_batch_t * b, bool & handled)
 {
   handled = false;
-  static const bool prof = getenv("BPA_PLAN_PROF") != nullptr;       // section timers (stderr, every 130 calls)
-  static double pt[4] = {0, 0, 0, 0}; static unsigned pcalls = 0;
-  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t_0 = prof ? now() : 0;
   static const bool off = getenv("BPA_JC69_V1") != nullptr || getenv("BPA_NO_JC69_FAST") != nullptr;
   if (off || !b->root_clv || !b->nloci) return 1;
-  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   if (!flush(e) || !engine_pack(e)) return 0;
   if (!e->pack_slots || e->timing) return 1;
   const unsigned T = b->nloci;
@@ -1451,6 +1464,7 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
   int prev = -1;
   unsigned maxops = 0, npat = 0, rmax = 1;
   bool all_jc = true, all_kl = true;
+  e->bc_pat.resize((size_t)T + 1);
   for (unsigned t = 0; t < T; ++t)
   {
     const bpa_locus * l = b->loci[t];
@@ -1459,18 +1473,19 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
     if (sl <= prev) return 1;
     prev = sl;
     maxops = std::max(maxops, b->op_off ? b->op_off[t+1] - b->op_off[t] : 0u);
+    e->bc_pat[t] = npat;
     npat += l->sites;
     rmax = std::max(rmax, l->rate_cats);
     all_jc = all_jc && l->rate_cats == 1 && l->dev.model == 0;
     all_kl = all_kl && l->rate_cats > 1 && l->scale_buffers == 0 && !l->dev.unphased_length && (!b->root_scaler || b->root_scaler[t] < 0);
   }
-  const double t_1 = prof ? now() : 0;
+  e->bc_pat[T] = npat;
   static const bool no_klane = getenv("BPA_KLANE_V1") != nullptr || getenv("BPA_NO_KLANE") != nullptr;
   if (!all_jc && (!all_kl || no_klane)) return 1;
   if (maxops > 255) return 1;                    // StepRec counts a locus's updates in a byte
   const unsigned nmat = b->mat_off ? b->mat_off[T] : 0;
   const unsigned units = 1 + std::max(maxops, 3u);
-  const size_t o_recs = 0, n_recs = (size_t)e->pack_slots*units*16;
+  const size_t n_recs = (size_t)e->pack_slots*units*16;
   const size_t o_mat2 = n_recs, n_mat2 = ((size_t)nmat*sizeof(MatRec2) + 15) & ~(size_t)15;
   const size_t o_len = o_mat2 + n_mat2, n_len = ((size_t)nmat*sizeof(double) + 15) & ~(size_t)15;
   const size_t o_bm = o_len + n_len, n_bm = ((size_t)(e->pack_blocks + 1)*4 + 15) & ~(size_t)15;
@@ -1487,41 +1502,54 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
     return fail("out of device memory (step image)");
   // the previous step's image may still be in flight only if the caller did not read its results: drain
   HIPCHK(hipStreamSynchronize(e->stream));
+  e->bc_T = T; e->bc_units = units; e->bc_nmat = nmat; e->bc_npat = npat; e->bc_rmax = rmax; e->bc_alljc = all_jc;
+  e->bc_o_mat2 = o_mat2; e->bc_o_len = o_len; e->bc_o_bm = o_bm; e->bc_total = total;
+  e->bc_failed.store(0);
+  handled = true;
+  return 1;
+}
+
+static int batch_fill_packed(bpa_engine * e, const bpa_batch_t * b, unsigned t0, unsigned t1)
+{
+  const unsigned T = e->bc_T, units = e->bc_units;
+  if (t1 > T) t1 = T;
+  if (t0 >= t1) return 1;
   unsigned char * img = (unsigned char *)e->h_step;
-  uint4 * recs = reinterpret_cast<uint4 *>(img + o_recs);
-  MatRec2 * m2 = reinterpret_cast<MatRec2 *>(img + o_mat2);
-  double * len = reinterpret_cast<double *>(img + o_len);
-  uint32_t * bm = reinterpret_cast<uint32_t *>(img + o_bm);
-  std::memset(recs, 0, n_recs);
-  for (unsigned sl = 0; sl < e->pack_slots; ++sl) reinterpret_cast<StepRec *>(recs + (size_t)sl*units)->task = 0xffffffffu;
-  unsigned pat = 0, blk = 0;
-  for (unsigned t = 0; t < T; ++t)
+  uint4 * recs = reinterpret_cast<uint4 *>(img);
+  MatRec2 * m2 = reinterpret_cast<MatRec2 *>(img + e->bc_o_mat2);
+  double * len = reinterpret_cast<double *>(img + e->bc_o_len);
+  // the slots from this range's first locus up to the next range's first: cleared, marked "not part of the step"
+  {
+    const unsigned s_lo = t0 == 0 ? 0u : (unsigned)e->slot_of[b->loci[t0]->id], s_hi = t1 == T ? e->pack_slots : (unsigned)e->slot_of[b->loci[t1]->id];
+    std::memset(recs + (size_t)s_lo*units, 0, (size_t)(s_hi - s_lo)*units*16);
+    for (unsigned sl = s_lo; sl < s_hi; ++sl) reinterpret_cast<StepRec *>(recs + (size_t)sl*units)->task = 0xffffffffu;
+  }
+  auto bad = [&](const char * msg) { std::lock_guard<std::mutex> g(e->bc_mtx); e->bc_failed.store(1); e->bc_msg = msg; return 0; };
+  for (unsigned t = t0; t < t1; ++t)
   {
     const bpa_locus * l = b->loci[t];
     const unsigned sl = (unsigned)e->slot_of[l->id];
     const unsigned o0 = b->op_off ? b->op_off[t] : 0, o1 = b->op_off ? b->op_off[t+1] : 0;
     const unsigned m0 = b->mat_off ? b->mat_off[t] : 0, m1 = b->mat_off ? b->mat_off[t+1] : 0;
-    if (b->root_clv[t] < l->tips || b->root_clv[t] >= l->tips + l->clv_buffers) return fail("plan: root clv index out of range");
-    if (b->root_scaler && b->root_scaler[t] >= (int)l->scale_buffers) return fail("plan: root scaler index out of range");
-    // workgroups up to this locus's start their matrix range here
-    while (blk <= e->pack_blocks && e->h_blk_slot_off[blk] <= sl) bm[blk++] = m0;
+    if (b->root_clv[t] < l->tips || b->root_clv[t] >= l->tips + l->clv_buffers) return bad("plan: root clv index out of range");
+    if (b->root_scaler && b->root_scaler[t] >= (int)l->scale_buffers) return bad("plan: root scaler index out of range");
     for (unsigned i = m0; i < m1; ++i)
     {
-      if (b->mat_pmatrix[i] >= l->prob_matrices) return fail("plan: pmatrix index out of range");
-      if (!(b->mat_length[i] >= 0)) return fail("plan: negative branch length");   // assert(t >= 0), core_pmatrix.c:723
+      if (b->mat_pmatrix[i] >= l->prob_matrices) return bad("plan: pmatrix index out of range");
+      if (!(b->mat_length[i] >= 0)) return bad("plan: negative branch length");   // assert(t >= 0), core_pmatrix.c:723
       for (unsigned j = m0; j < i; ++j)
-        if (b->mat_pmatrix[j] == b->mat_pmatrix[i]) return fail("plan: a P-matrix buffer is listed twice for one locus");
+        if (b->mat_pmatrix[j] == b->mat_pmatrix[i]) return bad("plan: a P-matrix buffer is listed twice for one locus");
       m2[i] = MatRec2{sl, b->mat_pmatrix[i]};
       len[i] = b->mat_length[i];
     }
     StepRec h{};
-    h.task = t; h.pat_off = pat; h.root_clv = (uint8_t)b->root_clv[t];
+    h.task = t; h.pat_off = e->bc_pat[t]; h.root_clv = (uint8_t)b->root_clv[t];
     h.root_scaler = (int8_t)(b->root_scaler ? b->root_scaler[t] : BPA_SCALE_BUFFER_NONE); h.nops = (uint8_t)(o1 - o0);
     std::memcpy(recs + (size_t)sl*units, &h, sizeof(h));
     for (unsigned o = o0; o < o1; ++o)
     {
       const bpa_op_t & s = b->ops[o];
-      if (!validate_op(l, s)) return 0;
+      if (!validate_op_quiet(l, s)) return bad("plan: a node update's buffer index is out of range");
       StepOp q{};
       q.parent_clv = (uint8_t)s.parent_clv; q.left_clv = (uint8_t)s.left_clv; q.right_clv = (uint8_t)s.right_clv;
       q.left_pmatrix = (uint8_t)s.left_pmatrix; q.right_pmatrix = (uint8_t)s.right_pmatrix;
@@ -1534,21 +1562,37 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
       }
       std::memcpy(recs + (size_t)sl*units + 1 + (o - o0), &q, sizeof(q));
     }
-    pat += l->sites;
   }
-  while (blk <= e->pack_blocks) bm[blk++] = nmat;
-  const double t_2 = prof ? now() : 0;
-  HIPCHK(hipMemcpyAsync(e->d_step.p, img, total, hipMemcpyHostToDevice, e->stream));
+  return 1;
+}
+
+static int batch_end_packed(bpa_engine * e, const bpa_batch_t * b, double * lnl)
+{
+  if (e->bc_failed.load()) return fail(e->bc_msg.c_str());
+  const unsigned T = e->bc_T, nmat = e->bc_nmat, npat = e->bc_npat, rmax = e->bc_rmax, units = e->bc_units;
+  unsigned char * img = (unsigned char *)e->h_step;
+  uint32_t * bm = reinterpret_cast<uint32_t *>(img + e->bc_o_bm);
+  {
+    // workgroups up to a locus's start their matrix range at that locus's first entry
+    unsigned blk = 0;
+    for (unsigned t = 0; t < T; ++t)
+    {
+      const unsigned sl = (unsigned)e->slot_of[b->loci[t]->id], m0 = b->mat_off ? b->mat_off[t] : 0;
+      while (blk <= e->pack_blocks && e->h_blk_slot_off[blk] <= sl) bm[blk++] = m0;
+    }
+    while (blk <= e->pack_blocks) bm[blk++] = nmat;
+  }
+  HIPCHK(hipMemcpyAsync(e->d_step.p, img, e->bc_total, hipMemcpyHostToDevice, e->stream));
   PlanDev d{};
   d.loci = e->d_loci.p; d.bfbeta = e->bfbeta;
   d.site_term = e->d_step_terms.p; d.lnl = e->d_step_lnl.p; d.ntasks = T; d.npatterns = npat; d.nmat = nmat;
-  d.recs2 = reinterpret_cast<const uint4 *>(e->d_step.p + o_recs);
-  d.mat2 = reinterpret_cast<const MatRec2 *>(e->d_step.p + o_mat2);
-  d.mat_length = reinterpret_cast<const double *>(e->d_step.p + o_len);
-  d.blk_mat_off = reinterpret_cast<const uint32_t *>(e->d_step.p + o_bm);
+  d.recs2 = reinterpret_cast<const uint4 *>(e->d_step.p);
+  d.mat2 = reinterpret_cast<const MatRec2 *>(e->d_step.p + e->bc_o_mat2);
+  d.mat_length = reinterpret_cast<const double *>(e->d_step.p + e->bc_o_len);
+  d.blk_mat_off = reinterpret_cast<const uint32_t *>(e->d_step.p + e->bc_o_bm);
   d.rec2_units = units;
   d.lane_tab = e->d_lane_tab.p; d.slot_tab = e->d_slot_tab.p; d.blk_slot_off = e->d_blk_slot_off.p; d.nblocks2 = e->pack_blocks;
-  if (all_jc)
+  if (e->bc_alljc)
   {
     d.flags = (nmat ? 1u : 0u) | 2u | 4u;
     hipLaunchKernelGGL((step_jc69_v2_kernel<PACK_BS>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, d);
@@ -1565,8 +1609,6 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
     hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, d);
   }
   HIPCHK(hipGetLastError());
-  handled = true;
-  const double t_3 = prof ? now() : 0;
   if (!lnl) { HIPCHK(hipStreamSynchronize(e->stream)); return 1; }
   if (!e->usedata) { HIPCHK(hipStreamSynchronize(e->stream)); std::fill(lnl, lnl + T, 0.0); return 1; }
   const size_t nb = (size_t)T*sizeof(double);
@@ -1581,18 +1623,48 @@ static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double *
   HIPCHK(hipMemcpyAsync(e->h_stage, e->d_step_lnl.p, nb, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   std::memcpy(lnl, e->h_stage, nb);
+  return 1;
+}
+
+static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double * lnl, bool & handled)
+{
+  static const bool prof = getenv("BPA_PLAN_PROF") != nullptr;       // section timers (stderr, every 130 calls)
+  static double pt[3] = {0, 0, 0}; static unsigned pcalls = 0;
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  const double t_0 = prof ? batch_now() : 0;
+  if (!batch_begin_packed(e, b, handled)) return 0;
+  if (!handled) return 1;
+  const double t_1 = prof ? batch_now() : 0;
+  (void)batch_fill_packed(e, b, 0, e->bc_T);
+  const double t_2 = prof ? batch_now() : 0;
+  if (!batch_end_packed(e, b, lnl)) return 0;
   if (prof)
   {
-    const double t_4 = now();
-    pt[0] += t_1 - t_0; pt[1] += t_2 - t_1; pt[2] += t_3 - t_2; pt[3] += t_4 - t_3;
+    const double t_3 = batch_now();
+    pt[0] += t_1 - t_0; pt[1] += t_2 - t_1; pt[2] += t_3 - t_2;
     if (++pcalls % 130 == 0)
     {
-      fprintf(stderr, "[bpa] batch_evaluate per call: checks %.3f ms, record image %.3f ms, enqueue %.3f ms, wait + lnL back %.3f ms\n",
-              1e3*pt[0]/130, 1e3*pt[1]/130, 1e3*pt[2]/130, 1e3*pt[3]/130);
-      pt[0] = pt[1] = pt[2] = pt[3] = 0;
+      fprintf(stderr, "[bpa] batch_evaluate per call: checks %.3f ms, record image %.3f ms, upload + launch + lnL back %.3f ms\n",
+              1e3*pt[0]/130, 1e3*pt[1]/130, 1e3*pt[2]/130);
+      pt[0] = pt[1] = pt[2] = 0;
     }
   }
   return 1;
+}
+
+extern "C" int bpa_batch_begin(bpa_engine_t * e, const bpa_batch_t * b)
+{
+  if (!e || !b) return fail("bpa_batch_begin: null argument");
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  bool handled = false;
+  if (!batch_begin_packed(e, b, handled)) return 0;
+  return handled ? 1 : 2;
+}
+extern "C" int bpa_batch_fill(bpa_engine_t * e, const bpa_batch_t * b, unsigned t0, unsigned t1) { return batch_fill_packed(e, b, t0, t1); }
+extern "C" int bpa_batch_end(bpa_engine_t * e, const bpa_batch_t * b, double * lnl)
+{
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  return batch_end_packed(e, b, lnl);
 }
 
 extern "C" int bpa_batch_evaluate(bpa_engine_t * e, const bpa_batch_t * b, double * lnl)

@@ -1116,7 +1116,17 @@ int a00_backend_hip(void * vctx, const a00_step_t * s, double * lnl)
   b.op_off = s->nd_off; b.ops = ops; b.root_clv = rc; b.root_scaler = rs;
   {
     const double t1 = prof ? now_s() : 0;
-    ok = bpa_batch_evaluate(c->engine, &b, lnl);
+    /* the record image of the step: the worker threads write it, a share of the loci each (bpa_batch_fill) */
+    const int how = marshal_threads > 1 ? bpa_batch_begin(c->engine, &b) : 2;
+    if (how == 1)
+    {
+      const int parts = marshal_threads; int q;
+#pragma omp parallel for schedule(static) num_threads(marshal_threads)
+      for (q = 0; q < parts; ++q)
+        (void)bpa_batch_fill(c->engine, &b, (unsigned)((unsigned long long)n*(unsigned)q/(unsigned)parts), (unsigned)((unsigned long long)n*(unsigned)(q + 1)/(unsigned)parts));
+      ok = bpa_batch_end(c->engine, &b, lnl);
+    }
+    else ok = how == 2 ? bpa_batch_evaluate(c->engine, &b, lnl) : 0;
     if (prof)
     {
       const double t2 = now_s();

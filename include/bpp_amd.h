@@ -255,6 +255,18 @@ int          bpa_plan_set_params(bpa_plan_t *, int which, const double * values)
 int          bpa_plan_set_params_device(bpa_plan_t *, int which, const double * device_values);
 /* convenience: create + launch + get + destroy                                    */
 int          bpa_batch_evaluate(bpa_engine_t *, const bpa_batch_t *, double * lnl);
+/* The same in three parts, for a caller with worker threads (the C host driver's: csrc/host/a00_driver.c) — the step's
+   record image is the serial part of a host-driven step, and the records of a locus touch nothing but that locus's slot:
+     bpa_batch_begin   checks and sizes; returns 1 = go on with fill + end, 2 = this batch does not take the one-image path
+                       (loci outside the engine's packing, 20 states, scalers with several categories ...): call
+                       bpa_batch_evaluate instead, 0 = error;
+     bpa_batch_fill    writes the records of the batch's loci [t0, t1); disjoint ranges may be filled from several threads
+                       at once (no lock is taken); an invalid index makes bpa_batch_end fail;
+     bpa_batch_end     uploads the image (one copy), launches, returns the per-locus lnL like bpa_batch_evaluate.
+   One batch at a time per engine; nothing else may touch the engine between begin and end.                              */
+int          bpa_batch_begin(bpa_engine_t *, const bpa_batch_t *);
+int          bpa_batch_fill(bpa_engine_t *, const bpa_batch_t *, unsigned t0, unsigned t1);
+int          bpa_batch_end(bpa_engine_t *, const bpa_batch_t *, double * lnl);
 
 /* ------------------------------------- device-resident proposal control (next) --- */
 /* The multispecies-coalescent sampler of include/bpp_amd_host.h with everything resident on the

@@ -315,3 +315,37 @@ def test_bpp_proposal_kernel_on_the_device(taxa, nloci, iters, slide_prob):
     else:
         assert gp == 0
     host.close(); dev.close(); eng.close()
+
+
+@pytest.mark.parametrize("taxa", [4, 6, 8])
+@pytest.mark.parametrize("program", [False, True])
+def test_persistent_kernel_at_edge_sizes(taxa, program):
+    """1, 2, 13, 64, 65 loci (one lane group, one partial wave, a workgroup boundary) on the persistent kernel, several
+    iterations per launch, with our kernel and with the program's moves: the host driver's decisions, trees, taus and thetas"""
+    for nloci in (1, 2, 13, 64, 65):
+        eng = bpp_amd.Engine(0)
+        data = synth.make_dataset(nloci, 300, taxa, "jc69", 1, seed=100 + nloci)
+        host = hostdrv.hip_driver(eng, tape.make_engine_loci(eng, data), data, seed=5)
+        dev = bpp_amd.Sampler(eng, tape.make_engine_loci(eng, data), data, seed=5)
+        parent, tau0, thetas = synth.species_tree_arrays(taxa)
+        for drv in (host, dev):
+            if program:
+                drv.set_proposal_kernel(1)
+                drv.set_program_moves(True, 0.3)
+            drv.set_species_tree(parent, tau0, thetas)
+            drv.set_tau_prior(3.0, 3.0 / tau0[-1])
+            drv.set_theta_prior(2.0, 1000.0, 0.0004)
+            drv.set_finetune(0.003, 0.004, 0.0004, 0.1)
+        host.initialize(); dev.initialize()
+        assert dev.kind() == "persistent"
+        for chunk in (1, 4, 7):
+            for _ in range(chunk):
+                host.iterate()
+            dev.iterate(chunk)
+            s = dev.summary(); hp, ha, _ = host.counters()
+            assert (s["proposals"], s["accepted"]) == (hp, ha), (nloci, chunk)
+        assert np.allclose(dev.taus(), host.taus(), rtol=1e-10, atol=0) and np.allclose(dev.thetas(), host.thetas(), rtol=1e-10, atol=0), nloci
+        for i in range(nloci):
+            a, b = dev.tree(i), host.tree(i)
+            assert [int(x) for x in a["parent"]] == [int(x) for x in b["parent"]] and np.allclose(a["time"], b["time"], rtol=1e-10, atol=0), (nloci, i)
+        host.close(); dev.close(); eng.close()

@@ -90,8 +90,10 @@ def test_oracle_compress_vs_golden():
         assert int(w.sum()) == len(g["seqs"][0])
         # the merged classes are the same classes (representative may differ: rand() pivot)
         a, b = canon(s2, w, g["jc69"], g["dna"]), canon(g["patterns"], g["weights"], g["jc69"], g["dna"])
-        if not (g["jc69"] and any("M" in s or "R" in s or "Y" in s for s in g["seqs"])):
-            assert a == b
+        # ... in every case, the reference's quirk included: under JC69 it relabels a column of plain nucleotides by order of first
+        # appearance with the COUNTERS 1, 2, 3, 4 — so a third nucleotide is spelled like the code of M (= 3) and such a column
+        # merges with a literal (x, y, M) column; `canon` states exactly that labelling, and the classes agree under it
+        assert a == b
 
 
 def test_maps_and_tipclv():
