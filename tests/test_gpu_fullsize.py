@@ -15,13 +15,6 @@ from common import rel
 pytestmark = pytest.mark.gpu
 
 
-def pmap(fn, items, workers=12):
-    """the C oracle of every locus, several loci at a time (ctypes calls release the interpreter lock; loci are independent)"""
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=workers) as ex:
-        return list(ex.map(fn, items))
-
-
 def oracle_full(d, tr=None, scaling=False):
     ol = O.OracleLocus(d["states"], d["rate_cats"], d["seqs"], d["weights"], model=d["model"],
                        freqs=None if d["model"] == "jc69" else d["freqs"],
@@ -50,7 +43,7 @@ def test_full_size_properties(name, nloci, sites, taxa, model, R, taus):
     assert rel(p0.lnl_sum(), float(np.sum(lnl0))) < 1e-12                      # (5)
     rng = np.random.default_rng(1)
     sample = rng.choice(nloci, 24, replace=False)
-    want0 = np.array(pmap(oracle_full, data))                                 # (1): all loci
+    want0 = np.array([oracle_full(d) for d in data])                          # (1): all loci
     err0 = np.abs(lnl0 - want0)/np.abs(want0)
     assert err0.max() < 1e-13, (int(err0.argmax()), float(err0.max()))
     for li in sample[:8]:                                                     # (2)
@@ -68,7 +61,7 @@ def test_full_size_properties(name, nloci, sites, taxa, model, R, taus):
     # every locus on its tree after the iteration: one batched root evaluation (no update: the CLVs are what the
     # incremental steps left) against the oracle's recompute from scratch
     have = tape.root_lnl_all(eng, loci, sch)
-    want = np.array(pmap(lambda a: oracle_full(a[1], sch.trees[a[0]]), list(enumerate(data))))
+    want = np.array([oracle_full(d, sch.trees[li]) for li, d in enumerate(data)])
     err = np.abs(have - want)/np.abs(want)
     assert err.max() < 1e-12, (int(err.argmax()), float(err.max()))
     for li in sample[:8]:

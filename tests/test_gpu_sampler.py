@@ -139,9 +139,11 @@ def test_sweeps_of_the_persistent_kernel_between_one_launch_all_loci_steps(monke
     hyb.close(); old.close(); eng.close()
 
 
-def test_several_sequences_per_species():
+@pytest.mark.parametrize("program", [False, True])
+def test_several_sequences_per_species(program):
     """two species with three sequences each: tip populations hold coalescences (and a theta that moves),
-    gene nodes cross the species boundary both ways; device == host driver, step for step"""
+    gene nodes cross the species boundary both ways; device == host driver, step for step.  program: BPP's kernel with the
+    program's moves — the rubber band then re-draws the thetas of the two TIP populations next to the root's"""
     eng = bpp_amd.Engine(0)
     rng = np.random.default_rng(8)
     nloci, tips = 120, 6
@@ -165,6 +167,9 @@ def test_several_sequences_per_species():
     host = hostdrv.hip_driver(eng, loci_a, data, seed=4)
     dev = bpp_amd.Sampler(eng, loci_b, data, seed=4)
     for drv in (host, dev):
+        if program:
+            drv.set_proposal_kernel(1)
+            drv.set_program_moves(True, 0.5)
         drv.set_species_tree(parent, tau0, thetas)
         for i in range(nloci):
             drv.set_tip_species(i, species)
@@ -177,15 +182,16 @@ def test_several_sequences_per_species():
         s = dev.summary()
         hp, ha, _ = host.counters()
         assert (s["proposals"], s["accepted"]) == (hp, ha), it
-    assert np.allclose(dev.thetas(), host.thetas(), rtol=1e-12, atol=0) and all(a != b for a, b in zip(dev.thetas(), thetas))
-    assert np.allclose(dev.taus(), host.taus(), rtol=1e-12, atol=0)
+    tol = 1e-10 if program else 1e-12          # (the program's theta re-draws go through libm's log / lgamma on both sides)
+    assert np.allclose(dev.thetas(), host.thetas(), rtol=tol, atol=0) and all(a != b for a, b in zip(dev.thetas(), thetas))
+    assert np.allclose(dev.taus(), host.taus(), rtol=tol, atol=0)
     moved = 0
     for i in range(nloci):
         a, b = dev.tree(i), host.tree(i)
         for key in ("left", "right", "parent", "clv", "pmat", "pop"):
             assert [int(x) for x in a[key]] == [int(x) for x in b[key]], (i, key)
-        assert np.allclose(a["time"], b["time"], rtol=1e-12, atol=0)
-        assert rel(a["logpr"], b["logpr"]) < 1e-11 and rel(a["lnl"], b["lnl"]) < 1e-11
+        assert np.allclose(a["time"], b["time"], rtol=tol, atol=0)
+        assert rel(a["logpr"], b["logpr"]) < 10*tol and rel(a["lnl"], b["lnl"]) < 10*tol
         moved += sum(int(x) == 2 for x in a["pop"][6:]) != 1          # more than the root node above the divergence
     assert moved > 0
     host.close(); dev.close(); eng.close()
