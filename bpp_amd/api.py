@@ -694,7 +694,7 @@ class Sampler:
         k = lib().bpa_sampler_kind(self.h)
         if k < 0:
             raise BpaError(_err())
-        return ("sweep", "generic", "persistent", "hybrid")[k]
+        return ("sweep", "generic", "persistent", "hybrid", "big")[k]
 
     def close(self):
         if self.h and self.engine.h:

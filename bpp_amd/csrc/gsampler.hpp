@@ -488,7 +488,8 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
 }
 
 // an all-loci step: the sum of the loci's terms (fixed order) and the ONE decision (tau_step / mix_step of a00_driver.c)
-__global__ void __launch_bounds__(1024) gsum_decide_kernel(const GTree * __restrict__ trees, const double * __restrict__ lnl_new,
+template <class TREE>                     // (GTree, or the big-tree sampler's BTree: only the current lnL is read)
+__global__ void __launch_bounds__(1024) gsum_decide_kernel(const TREE * __restrict__ trees, const double * __restrict__ lnl_new,
                                                            const double * __restrict__ delta, const uint8_t * __restrict__ active,
                                                            uint32_t T, double * sum_out, int decide_on, double u, uint32_t epoch,
                                                            uint32_t * flag, uint32_t * counters, double * taus, Species sp, int tau_q,

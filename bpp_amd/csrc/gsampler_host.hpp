@@ -251,12 +251,12 @@ static int gs_decide(bpa_sampler * s, double uacc, int tau_q, double win_u, doub
   bpa_engine * e = s->eng;
   s->epoch++;
   if (!s->allreduce)
-    hipLaunchKernelGGL(gsm::gsum_decide_kernel, dim3(1), dim3(1024), 0, e->stream, s->g_dev.p, s->g_lnl.p, s->g_delta.p, s->g_active.p, s->nloci,
+    hipLaunchKernelGGL((gsm::gsum_decide_kernel<gsm::GTree>), dim3(1), dim3(1024), 0, e->stream, (const gsm::GTree *)s->g_dev.p, s->g_lnl.p, s->g_delta.p, s->g_active.p, s->nloci,
                        (double *)nullptr, 1, uacc, s->epoch, s->flag.p, s->counters.p, s->taus.p, s->sp, tau_q, win_u, mix_c, mix_lnc);
   else
   {
     double * out = s->sum_ext ? s->sum_ext : s->mix_sum.p;
-    hipLaunchKernelGGL(gsm::gsum_decide_kernel, dim3(1), dim3(1024), 0, e->stream, s->g_dev.p, s->g_lnl.p, s->g_delta.p, s->g_active.p, s->nloci,
+    hipLaunchKernelGGL((gsm::gsum_decide_kernel<gsm::GTree>), dim3(1), dim3(1024), 0, e->stream, (const gsm::GTree *)s->g_dev.p, s->g_lnl.p, s->g_delta.p, s->g_active.p, s->nloci,
                        out, 0, uacc, s->epoch, s->flag.p, s->counters.p, s->taus.p, s->sp, tau_q, win_u, mix_c, mix_lnc);
     if (!s->allreduce(s->allreduce_ctx, out, 1u, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
     hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, out, uacc, s->epoch, s->flag.p, s->counters.p, s->taus.p, s->sp,

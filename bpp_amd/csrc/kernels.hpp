@@ -163,8 +163,9 @@ __device__ __forceinline__ double walk_s4(const PlanDev & P, const uint32_t t, c
   const uint32_t R = L.rate_cats, np = L.np;
   if (do_ops)
   {
-    const uint32_t op_end = P.op_off[t+1];
-    for (uint32_t o = P.op_off[t]; o < op_end; ++o)
+    const bool ranges = (P.flags & 64u) != 0;        // a (begin, end) pair per task: the device-written steps of the big-tree sampler
+    const uint32_t op_end = P.op_off[ranges ? 2*t + 1 : t + 1];
+    for (uint32_t o = P.op_off[ranges ? 2*t : t]; o < op_end; ++o)
     {
       const OpDev op = P.ops[o];
       double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*np + n)*4;
@@ -1111,6 +1112,7 @@ __device__ __forceinline__ void pmatrix_dna_closed(const uint32_t model, const d
 
 __device__ __forceinline__ void pmatrix_s4_entry(const PlanDev & P, const uint32_t e, const uint32_t k)
 {
+  if (P.mat_task[e] == 0xffffffffu) return;          // a hole of a device-written step (bigsampler.hpp)
   const LocusDev & L = P.loci[P.task_locus[P.mat_task[e]]];
   const uint32_t R = L.rate_cats;
   if (k >= R) return;

@@ -1084,6 +1084,7 @@ __global__ void __launch_bounds__(1024) theta_sum_decide_kernel(const int8_t * _
 
 #include "sweep2.hpp"
 #include "gsampler.hpp"
+#include "bigsampler.hpp"
 
 // ------------------------------------------------------------------------------------ host ---
 struct bpa_sampler
@@ -1141,6 +1142,11 @@ struct bpa_sampler
   DevBuf<uint32_t> g_bmo;
   unsigned g_units = 0, g_maxmat = 0, g_pend = 0, g_npat = 0, g_rmax = 1, g_pack_epoch = 0;
   bool g_alljc = true;
+  // more than 16 tips, scalers, diploid loci: the big-tree sampler (bigsampler.hpp), trees in HBM, the engine's general kernels
+  bool big = false;
+  std::vector<gbig::BTree> b_trees;
+  DevBuf<gbig::BTree> b_dev, b_undo;
+  DevBuf<uint32_t> b_thr;
   // 20-state loci: the generic sampler's steps as the records of the tiled kernels (gsampler.hpp: fmt20)
   bool g_s20 = false;
   unsigned g_ntiles = 0, g_maxops = 0;
@@ -1197,15 +1203,28 @@ extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * co
   // the LDS sweep kernel (JC69, one rate category, <= 8 tips, <= 64 patterns) where every locus fits it, else the generic
   // path over the engine's step kernels (any 4-state model on the engine's packing, <= 16 tips; BPA_SMP_GENERIC=1 forces it)
   bool fits_sweep = getenv("BPA_SMP_GENERIC") == nullptr, fits_generic = true, all_jc = true, all_kl = true;
-  unsigned n20 = 0;
+  unsigned n20 = 0, nbig = 0;
+  const bool force_big = getenv("BPA_SMP_BIG") != nullptr;
   for (unsigned i = 0; i < nloci; ++i)
   {
     const bpa_locus * l = loci[i];
-    const bool base = l && l->eng == e && l->alive && (l->states == 4 || l->states == 20) && l->scale_buffers == 0 && !l->dev.unphased_length && l->tips >= 2 &&
-                      l->clv_buffers == 2*(l->tips - 1) && l->prob_matrices == 2*(2*l->tips - 2);
+    const bool counts = l && l->eng == e && l->alive && l->tips >= 2 && l->clv_buffers == 2*(l->tips - 1) && l->prob_matrices == 2*(2*l->tips - 2);
+    // beyond 16 tips, with scalers or as an unphased diploid a 4-state locus takes the big-tree sampler (bigsampler.hpp)
+    const bool wants_big = counts && l->states == 4 && (force_big || l->tips > (unsigned)gsm::NT || l->scale_buffers != 0 || l->dev.unphased_length);
+    if (wants_big)
+    {
+      if (l->tips > (unsigned)gbig::BT || (l->scale_buffers != 0 && l->scale_buffers != 2*(l->tips - 1)))
+      {
+        fail("bpa_sampler_create: a locus of the big-tree sampler has <= 64 tips and no or 2 (tips - 1) scale buffers (method.c:4110-4146)");
+        delete s; return nullptr;
+      }
+      ++nbig; s->maxtips = std::max(s->maxtips, l->tips); s->g_rmax = std::max(s->g_rmax, l->rate_cats);
+      continue;
+    }
+    const bool base = counts && (l->states == 4 || l->states == 20) && l->scale_buffers == 0 && !l->dev.unphased_length;
     if (!base)
     {
-      fail("bpa_sampler_create: loci must be 4- or 20-state, without scalers, not diploid, with the buffer counts of method.c:4110-4146");
+      fail("bpa_sampler_create: loci must be 4- or 20-state (20-state: without scalers, not diploid), with the buffer counts of method.c:4110-4146");
       delete s; return nullptr;
     }
     if (l->states == 20) { ++n20; fits_sweep = false; fits_generic = fits_generic && l->tips <= (unsigned)gsm::NT && l->rate_cats <= 4; all_jc = false;
@@ -1217,7 +1236,20 @@ extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * co
     s->maxtips = std::max(s->maxtips, l->tips);
     s->g_rmax = std::max(s->g_rmax, l->rate_cats);
   }
-  if (n20)
+  if (nbig)
+  {
+    // one big locus makes the whole sampler the big-tree one (its kernels take any 4-state locus)
+    for (unsigned i = 0; i < nloci; ++i)
+      if (loci[i]->states != 4 || loci[i]->tips > (unsigned)gbig::BT || (loci[i]->scale_buffers != 0 && loci[i]->scale_buffers != 2*(loci[i]->tips - 1)))
+      {
+        fail("bpa_sampler_create: the loci of a big-tree sampler are all 4-state with <= 64 tips");
+        delete s; return nullptr;
+      }
+    for (unsigned i = 0; i < nloci; ++i) { s->maxtips = std::max(s->maxtips, loci[i]->tips); s->g_rmax = std::max(s->g_rmax, loci[i]->rate_cats); }
+    s->big = true;
+    s->b_trees.assign(nloci, gbig::BTree{});
+  }
+  else if (n20)
   {
     // amino-acid loci: the generic sampler's proposal control, the likelihood by the tiled 20-state kernels
     if (n20 != nloci || !fits_generic)
@@ -1261,6 +1293,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
   s->g_len.free(); s->g_lograt.free(); s->g_active.free(); s->g_recs.free(); s->g_mat2.free(); s->g_bmo.free();
   s->g_sm.free(); s->g_sm_old.free(); s->g_ids.free();
+  s->b_dev.free(); s->b_undo.free(); s->b_thr.free();
   s->g_ops20.free(); s->g_oprng.free(); s->g_root20.free(); s->g_mtask.free(); s->g_mpm.free(); s->g_tlocus.free(); s->g_tpat.free(); s->g_ttask.free(); s->g_tn0.free(); s->g_rscaler.free();
   s->v2_wave_off.free(); s->v2_loc.free(); s->v2_pat.free(); s->v2_xbuf.free(); s->v2_grng.free(); s->v2_err.free(); s->v2_prof.free(); s->v2_declog.free(); s->v2_sp.free();
   delete s;
@@ -1313,7 +1346,7 @@ extern "C" int bpa_sampler_set_proposal_kernel(bpa_sampler_t * s, int kind)
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (kind != BPA_KERNEL_UNIFORM && kind != BPA_KERNEL_BPP) return fail("bpa_sampler_set_proposal_kernel: BPA_KERNEL_UNIFORM or BPA_KERNEL_BPP");
   if (s->uploaded) return fail("bpa_sampler_set_proposal_kernel: before bpa_sampler_initialize (as a00_set_proposal_kernel)");
-  if (s->generic && kind == BPA_KERNEL_BPP) return fail("bpa_sampler_set_proposal_kernel: BPP's kernel runs in the persistent iteration kernel (JC69 loci of <= 8 tips and <= 64 patterns)");
+  if ((s->generic || s->big) && kind == BPA_KERNEL_BPP) return fail("bpa_sampler_set_proposal_kernel: BPP's kernel runs in the persistent iteration kernel (JC69 loci of <= 8 tips and <= 64 patterns)");
   s->kernel_bpp = kind == BPA_KERNEL_BPP;
   for (unsigned i = 0; i < s->nloci; ++i) s->h_trees[i].rng = stream_seed(s, s->locus_offset + i);
   s->grng = stream_seed(s, A00_GLOBAL_STREAM);
@@ -1349,6 +1382,7 @@ extern "C" int bpa_sampler_set_tree(bpa_sampler_t * s, unsigned i, const int * l
   const int tips = (int)s->loci[i]->tips;
   const a00_rng_t rng = stream_seed(s, s->locus_offset + i);
   if (!sampler_invalidate(s)) return 0;
+  if (s->big) return set_tree_fields<gbig::BTree, gbig::BN>(s->b_trees[i], tips, left, right, times, root, rng);
   if (s->generic) return set_tree_fields<gsm::GTree, gsm::NN>(s->g_trees[i], tips, left, right, times, root, rng);
   return set_tree_fields<smp::Tree, smp::MAXN>(s->h_trees[i], tips, left, right, times, root, rng);
 }
@@ -1377,6 +1411,10 @@ static int sampler_launch(bpa_sampler * s, unsigned mode, double mix_c, double m
 static int gs_initialize(bpa_sampler * s);
 static int gs_iterate(bpa_sampler * s, unsigned iterations);
 static int gs_download(bpa_sampler * s);
+static int gb_upload(bpa_sampler * s);
+static int gb_initialize(bpa_sampler * s);
+static int gb_iterate(bpa_sampler * s, unsigned iterations);
+static int gb_download(bpa_sampler * s);
 
 // ---- the persistent iteration kernel (sweep2.hpp): tables, eligibility, launch
 template <int NT> static size_t v2_lds_base()
@@ -1389,7 +1427,7 @@ template <int NT> static size_t v2_lds_base()
 static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & task_rec)
 {
   s->v2_ok = false;
-  if (s->env_v1 || s->generic) return 1;
+  if (s->env_v1 || s->generic || s->big) return 1;
   const unsigned T = s->nloci;
   const int npop = s->sp.npop;
   if (s->maxtips > 8 || npop > 15) return 1;
@@ -1465,6 +1503,7 @@ static int sampler_upload(bpa_sampler * s)
   if (!set_device(e) || !flush(e)) return 0;
   const unsigned T = s->nloci;
   if (!s->sp.npop) return fail("bpa_sampler: set the species tree first (bpa_sampler_set_species_tree)");
+  if (s->big) return gb_upload(s);
   if (s->generic) return gs_upload(s);
   for (unsigned i = 0; i < T; ++i) if (!assign_pops_host(s, s->h_trees[i])) return 0;
   for (int p = 0; p < smp::MAXPOP; ++p) s->has_theta[p] = p >= s->sp.S && p < s->sp.npop;
@@ -1685,6 +1724,13 @@ extern "C" int bpa_sampler_set_tip_species(bpa_sampler_t * s, unsigned i, const 
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (i >= s->nloci) return fail("bpa_sampler_set_tip_species: locus index out of range");
   if (!sampler_invalidate(s)) return 0;
+  if (s->big)
+  {
+    gbig::BTree & t = s->b_trees[i];
+    if (!t.tips) return fail("bpa_sampler_set_tip_species: set the tree first");
+    for (int k = 0; k < t.tips; ++k) t.pop[k] = (int16_t)species[k];
+    return 1;
+  }
   if (s->generic)
   {
     gsm::GTree & t = s->g_trees[i];
@@ -1736,6 +1782,7 @@ extern "C" int bpa_sampler_initialize(bpa_sampler_t * s)
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (!sampler_upload(s)) return 0;
   s->host_current = false;
+  if (s->big) return gb_initialize(s);
   if (s->generic) return gs_initialize(s);
   return sampler_launch(s, 3, 1.0);
 }
@@ -1781,7 +1828,7 @@ extern "C" int bpa_sampler_set_allreduce(bpa_sampler_t * s, bpa_allreduce_fn fn,
     if (!sampler_invalidate(s)) return 0;
     s->locus_offset = first_locus;
     for (unsigned i = 0; i < s->nloci; ++i)
-      (s->generic ? s->g_trees[i].rng : s->h_trees[i].rng) = stream_seed(s, first_locus + i);
+      (s->big ? s->b_trees[i].rng : s->generic ? s->g_trees[i].rng : s->h_trees[i].rng) = stream_seed(s, first_locus + i);
     s->uploaded = false;
   }
   return 1;
@@ -1884,6 +1931,7 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   if (!sampler_upload(s)) return 0;
   s->host_current = false;
+  if (s->big) return gb_iterate(s, iterations);
   if (s->generic) return gs_iterate(s, iterations);
   if (s->v2_ok && !s->allreduce && !s->env_trace) return sampler_iterate_v2(s, iterations, true);
   if (s->kernel_bpp) return fail("bpa_sampler: BPP's proposal kernel runs in the persistent iteration kernel only (one GPU, or several with bpa_sampler_set_p2p)");
@@ -1959,6 +2007,7 @@ static int sampler_download(bpa_sampler * s)
   bpa_engine * e = s->eng;
   if (!sampler_upload(s)) return 0;
   if (s->host_current) return 1;                  // nothing has run since the last download
+  if (s->big) { if (!gb_download(s)) return 0; s->host_current = true; return 1; }
   if (s->generic) { if (!gs_download(s)) return 0; s->host_current = true; return 1; }
   if (!sampler_launch(s, 2, 1.0)) return 0;
   HIPCHK(hipMemcpyAsync(s->h_trees.data(), s->trees.p, s->nloci*sizeof(smp::Tree), hipMemcpyDeviceToHost, e->stream));
@@ -2013,7 +2062,7 @@ extern "C" int bpa_sampler_get_tree(bpa_sampler_t * s, unsigned i, int * left, i
     if (root) *root = t.root;
     if (lnl) *lnl = t.lnl;
   };
-  if (s->generic) out(s->g_trees[i]); else out(s->h_trees[i]);
+  if (s->big) out(s->b_trees[i]); else if (s->generic) out(s->g_trees[i]); else out(s->h_trees[i]);
   return 1;
 }
 
@@ -2027,7 +2076,7 @@ extern "C" int bpa_sampler_get_tree_msc(bpa_sampler_t * s, unsigned i, int * pop
     if (pop) for (int k = 0; k < 2*t.tips - 1; ++k) pop[k] = t.pop[k];
     if (logpr) *logpr = t.logpr;
   };
-  if (s->generic) out(s->g_trees[i]); else out(s->h_trees[i]);
+  if (s->big) out(s->b_trees[i]); else if (s->generic) out(s->g_trees[i]); else out(s->h_trees[i]);
   return 1;
 }
 
@@ -2064,9 +2113,9 @@ extern "C" int bpa_sampler_work(bpa_sampler_t * s, double * bytes, unsigned long
   {
     // K1 3 Np R S 8 + 2 R S^2 8 bytes per node update, K2 (Np R S 8 + 4 Np) per evaluated proposal, K4 R S^2 8 per fresh P-matrix
     const double np = s->loci[i]->sites, R = s->loci[i]->rate_cats;
-    const double nupd = s->generic ? s->g_trees[i].work_nupd : (double)s->h_trees[i].sw_nupd + s->h_trees[i].al_nupd,
-                 nbr = s->generic ? s->g_trees[i].work_nbr : (double)s->h_trees[i].sw_nbr + s->h_trees[i].al_nbr;
-    const double nprop = s->generic ? s->g_trees[i].work_neval : (double)s->h_trees[i].proposals + s->h_trees[i].al_neval;
+    const double nupd = s->big ? s->b_trees[i].work_nupd : s->generic ? s->g_trees[i].work_nupd : (double)s->h_trees[i].sw_nupd + s->h_trees[i].al_nupd,
+                 nbr = s->big ? s->b_trees[i].work_nbr : s->generic ? s->g_trees[i].work_nbr : (double)s->h_trees[i].sw_nbr + s->h_trees[i].al_nbr;
+    const double nprop = s->big ? s->b_trees[i].work_neval : s->generic ? s->g_trees[i].work_neval : (double)s->h_trees[i].proposals + s->h_trees[i].al_neval;
     // (the generic path counts every evaluated step; where the P-matrix phase is a launch of its own — several rate
     //  categories — the K4 bytes are not the timed kernel's)
     const double S = s->loci[i]->states;
@@ -2076,7 +2125,7 @@ extern "C" int bpa_sampler_work(bpa_sampler_t * s, double * bytes, unsigned long
   if (bytes) *bytes = by;
   if (node_updates) *node_updates = nu;
   if (pattern_updates) *pattern_updates = pu;
-  if (sweeps) *sweeps = s->generic ? s->g_evals : s->sweeps;
+  if (sweeps) *sweeps = (s->generic || s->big) ? s->g_evals : s->sweeps;
   return 1;
 }
 
@@ -2084,6 +2133,7 @@ extern "C" int bpa_sampler_kind(bpa_sampler_t * s)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (!sampler_upload(s)) return -1;
+  if (s->big) return BPA_SAMPLER_BIG;
   if (s->generic) return BPA_SAMPLER_GENERIC;
   if (s->v2_ok && !s->env_trace) return s->allreduce ? BPA_SAMPLER_HYBRID : BPA_SAMPLER_PERSISTENT;
   return BPA_SAMPLER_SWEEP;
@@ -2097,7 +2147,8 @@ extern "C" int bpa_sampler_summary(bpa_sampler_t * s, double * total_lnl, unsign
   uint32_t c[2];
   HIPCHK(hipMemcpy(c, s->counters.p, 8, hipMemcpyDeviceToHost));
   double tot = 0; unsigned long pr = c[0], ac = c[1];
-  if (s->generic) for (const auto & t : s->g_trees) { tot += t.lnl; pr += t.proposals; ac += t.accepted; }
+  if (s->big) for (const auto & t : s->b_trees) { tot += t.lnl; pr += t.proposals; ac += t.accepted; }
+  else if (s->generic) for (const auto & t : s->g_trees) { tot += t.lnl; pr += t.proposals; ac += t.accepted; }
   else for (const auto & t : s->h_trees) { tot += t.lnl; pr += t.proposals; ac += t.accepted; }
   if (total_lnl) *total_lnl = tot;
   if (proposals) *proposals = pr;
@@ -2107,3 +2158,4 @@ extern "C" int bpa_sampler_summary(bpa_sampler_t * s, double * total_lnl, unsign
 }
 
 #include "gsampler_host.hpp"
+#include "bigsampler_host.hpp"
