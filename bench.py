@@ -331,6 +331,52 @@ def run_efficiency(eng, cfg, data, loci, chain, prog_rate, steps_hint=4000):
                      "size (the program's trace prints 6 decimals)")
 
 
+def run_config1(eng, iters=12):
+    """BASELINE configs[0] (examples/frogs A00 JC69: 5 loci of unphased diploid sequences, 42-60 tips after phasing, from the
+    files the reference ships: tests/golden/frogs) as real MCMC on the device — the big-tree sampler (csrc/bigsampler.hpp)"""
+    import bpp_amd
+    from bpp_amd import seqio, synth
+    g = os.path.join(ROOT, "tests", "golden", "frogs")
+    recs = seqio.load_dataset(os.path.join(g, "frogs.txt"), os.path.join(g, "frogs.Imap.txt"), ["K", "C", "L", "H"], [1, 1, 1, 1], model="jc69")
+    parent = [4, 4, 5, 6, 5, 6, -1]                       # K C L H | KC KCL root: (((K, C), L), H) of the example's control file
+    tau0 = [0.0] * 4 + [0.01, 0.02, 0.03]
+    thetas = [0.02] * 7
+    rng = np.random.default_rng(9)
+    data = []
+    for r in recs:
+        left, right, times, root = synth.msc_start_tree(r["species"], parent, tau0, thetas, rng)
+        data.append(dict(seqs=r["seqs"], weights=r.get("weights", np.ones(len(r["seqs"][0]))), left=left, right=right, times=times, root=root,
+                         states=4, rate_cats=1, model="jc69", rates=np.ones(1)))
+    smp = bpp_amd.Sampler(eng, [seqio.make_locus(eng, r) for r in recs], data, seed=1)
+    smp.set_species_tree(parent, tau0, thetas)
+    for i, r in enumerate(recs):
+        smp.set_tip_species(i, r["species"])
+    smp.set_tau_prior(3.0, 100.0)
+    smp.set_theta_prior(3.0, 150.0, 0.003)
+    smp.set_finetune(0.004, 0.004, 0.002, 0.1)
+    smp.initialize()
+    lnl0 = smp.summary()["total_lnl"]
+    smp.iterate(2)
+    eng.synchronize()
+    l0 = smp.summary()["launches"]
+    t0 = time.perf_counter()
+    smp.iterate(iters)
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    sm = smp.summary()
+    out = dict(iterations_per_s=round(iters / dt, 2), ms_per_iteration=round(1e3 * dt / iters, 3), iterations=iters, loci=len(recs),
+               tips=[len(r["seqs"]) for r in recs], patterns=[len(r["seqs"][0]) for r in recs], implementation=smp.kind(),
+               launches_per_iteration=round((sm["launches"] - l0 - 1) / iters, 1), start_lnl=round(lnl0, 6),
+               acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
+               reference_program="BASELINE.md: the unmodified program on this example, one thread: ~270 iterations/s on the survey container "
+                                 "(690 on this box's host: tools/bench_bpp_hip.py, round 2)",
+               note="five loci are no work for a GPU: every proposal step of an iteration (tips - 1 ages, 2 tips - 2 prunings, the "
+                    "all-loci steps) is a handful of dependent launches over 5 lanes — the lock-step batched form pays off from "
+                    "thousands of loci on (configs 2-4); here it shows that the device path covers the reference's own example")
+    smp.close()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ the workload ---
 def make_loci(eng, data):
     import bpp_amd
@@ -1041,6 +1087,16 @@ def main():
                 e2.close()
             except Exception as ex:       # noqa: BLE001
                 others[key] = dict(error=str(ex)[:300])
+
+    if others is not None:
+        try:
+            t0 = time.time()
+            e1 = bpp_amd.Engine(local_rank, None)
+            others["c1"] = dict(device_resident_sampler=run_config1(e1), seconds=None)
+            others["c1"]["seconds"] = round(time.time() - t0, 1)
+            e1.close()
+        except Exception as ex:       # noqa: BLE001
+            others["c1"] = dict(error=str(ex)[:300])
 
     # ---- MCMC control on the host in C (last: libgomp pins the calling thread under OMP_PROC_BIND, and threads or
     # processes started afterwards would inherit that one-CPU mask — the CPU baselines above must not)

@@ -166,84 +166,11 @@ __device__ void swap_ids(BTree & t, int a, int b)
   t.root = BIGM(t.root);
 #undef BIGM
 }
-__device__ inline void copy_tree(BTree & dst, const BTree & src)
+// ---- 4. propose (gage_step / gspr_step / tau_step / mix_step / a00_initialize of a00_driver.c, one locus), then 5. the records
+__device__ void big_propose(const BArgs & A, const uint32_t i, BTree & t, const Species & sp, const double * s_tau, const uint32_t MODE,
+                            const double lminf, const double lmaxf, const double tq_old, const double tq_lo, const double tq_hi,
+                            const double minf, const double maxf)
 {
-  const int n = 2*src.tips - 1;
-  for (int k = 0; k < n; ++k)
-  {
-    dst.left[k] = src.left[k]; dst.right[k] = src.right[k]; dst.parent[k] = src.parent[k]; dst.clv[k] = src.clv[k];
-    dst.pmat[k] = src.pmat[k]; dst.pop[k] = src.pop[k]; dst.scaler[k] = src.scaler[k]; dst.time[k] = src.time[k];
-  }
-  dst.root = src.root; dst.tips = src.tips;
-}
-
-__global__ void __launch_bounds__(BBS) big_step_kernel(const BArgs A)
-{
-  __shared__ double s_tau[3*MAXPOP];
-  __shared__ Species s_sp;
-  const uint32_t lane = threadIdx.x, i = blockIdx.x*BBS + lane;
-  const bool valid = i < A.T;
-  {
-    const uint32_t * src = reinterpret_cast<const uint32_t *>(&A.sp);
-    uint32_t * dst = reinterpret_cast<uint32_t *>(&s_sp);
-    for (uint32_t q = lane; q < sizeof(Species)/4; q += BBS) dst[q] = src[q];
-  }
-  if (lane < (uint32_t)(3*MAXPOP)) s_tau[lane] = A.taus[lane];
-  __syncthreads();
-  const Species & sp = s_sp;
-  const uint32_t MODE = A.mode;
-
-  // ---- 1. settle the step whose evaluation just finished
-  if (valid && A.pend)
-  {
-    BTree & t = A.trees[i];
-    bool back = false;
-    if (A.pend == 1)
-    {
-      if (A.active[i])
-      {
-        const double lnl = A.lnl_new[i], lp_new = A.logpr_new[i];
-        const double lnacc = (lp_new - t.logpr) + (lnl - t.lnl) + A.hast[i];
-        const double u = rndu(&t.rng);
-        t.proposals++;
-        if (lnacc >= 0 || u < exp(lnacc)) { t.lnl = lnl; t.logpr = lp_new; t.accepted++; }
-        else back = true;
-      }
-    }
-    else if (A.pend == 2)
-    {
-      if (*A.flag == A.epoch) back = true;
-      else { t.logpr = A.logpr_new[i]; if (A.active[i]) t.lnl = A.lnl_new[i]; }
-    }
-    else { t.lnl = A.lnl_new[i]; t.logpr = A.logpr_new[i]; }
-    if (back) copy_tree(t, A.undo[i]);
-  }
-  // ---- 2. THETA moved the thetas since this density was stored
-  if (valid && A.refresh_logpr) A.trees[i].logpr = tree_logpr(A.trees[i], sp, s_tau, nullptr, nullptr, 0);
-  __syncthreads();
-
-  // ---- 3. the proposed species tree of an all-loci step is this workgroup's copy of the taus
-  double lminf = 0, lmaxf = 0, tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1;
-  if (MODE == 2)
-  {
-    const int q = (int)A.tau_q, pq = sp.parent[q];
-    tq_old = s_tau[q]; tq_lo = fmax(s_tau[sp.left[q]], s_tau[sp.right[q]]); tq_hi = pq >= 0 ? s_tau[pq] : 999.0;
-    const double tnew = reflect(tq_old + sp.ft_tau*(A.tau_u - 0.5), tq_lo, tq_hi);
-    minf = (tnew - tq_lo)/(tq_old - tq_lo); maxf = (tnew - tq_hi)/(tq_old - tq_hi);
-    lminf = log(minf); lmaxf = log(maxf);
-    __syncthreads();
-    if (lane == 0) s_tau[q] = tnew;
-    __syncthreads();
-  }
-  else if (MODE == 3)
-  {
-    if (lane < (uint32_t)sp.npop) s_tau[lane] *= A.mix_c;
-    __syncthreads();
-  }
-
-  // ---- 4. propose (gage_step / gspr_step / tau_step / mix_step / a00_initialize of a00_driver.c, one locus)
-  if (!valid) return;
-  BTree & t = A.trees[i];
   const int n = 2*t.tips - 1;
   bool evaluate = false;
   int br[BN], nd[2*BN], nb = 0, nn = 0;
@@ -267,7 +194,7 @@ __global__ void __launch_bounds__(BBS) big_step_kernel(const BArgs A)
       if (!(hi > lo)) (void)rndu(&t.rng);
       else
       {
-        copy_tree(A.undo[i], t);
+        
         const double tnew = reflect(t.time[v] + sp.ft_gage*u, lo, hi);
         t.time[v] = tnew;
         t.pop[v] = (int16_t)climb(sp, s_tau, t.pop[l], tnew);
@@ -311,7 +238,7 @@ __global__ void __launch_bounds__(BBS) big_step_kernel(const BArgs A)
       {
         int tgt = targets[(int)(u2*ntg) % ntg];
         if (tgt == p) tgt = s;
-        copy_tree(A.undo[i], t);
+        
         const int root_before = t.root;
         t.parent[s] = (int16_t)g;
         if (g >= 0) { if (t.left[g] == p) t.left[g] = (int16_t)s; else t.right[g] = (int16_t)s; } else t.root = s;
@@ -346,7 +273,7 @@ __global__ void __launch_bounds__(BBS) big_step_kernel(const BArgs A)
   {
     const int q = (int)A.tau_q, cl = sp.left[q], cr = sp.right[q];
     int above = 0, below = 0;
-    copy_tree(A.undo[i], t);
+    
     bool isbr[BN], isnd[BN];
     for (int k = 0; k < n; ++k) isbr[k] = isnd[k] = false;
     for (int k = t.tips; k < n; ++k)
@@ -370,7 +297,6 @@ __global__ void __launch_bounds__(BBS) big_step_kernel(const BArgs A)
   else
   {
     // mixing or start-up: every branch, every inner node
-    if (MODE == 3) copy_tree(A.undo[i], t);
     int ninner = 0;
     for (int k = 0; k < n; ++k)
     {
@@ -415,6 +341,102 @@ __global__ void __launch_bounds__(BBS) big_step_kernel(const BArgs A)
   for (; nm < A.maxmat; ++nm) A.mat_task[e0 + nm] = 0xffffffffu;
   A.op_rng[2*i] = o0; A.op_rng[2*i + 1] = o0 + (evaluate ? (uint32_t)nn : 0u);
   A.root_clv[i] = (uint32_t)t.clv[t.root]; A.root_scaler[i] = t.scaler[t.root];
+}
+
+// One workgroup (one wave) per locus: the 64 lanes move the locus's tree between HBM and LDS and take the roll-back copies,
+// lane 0 runs the host driver's proposal code on the LDS copy (a lone lane working on a tree in HBM waits a memory round
+// trip per node access: 130 us per step on the frogs loci, against 15 with the tree in LDS)
+constexpr uint32_t NODE_WORDS = (7*BN*sizeof(int16_t) + BN*sizeof(double))/4;      // the node arrays of a BTree, as 32-bit words
+static_assert(offsetof(BTree, lnl) == NODE_WORDS*4, "BTree: the node arrays come first");
+__device__ inline void copy_nodes(BTree & dst, const BTree & src, uint32_t lane)
+{
+  const uint32_t * a = reinterpret_cast<const uint32_t *>(&src);
+  uint32_t * b = reinterpret_cast<uint32_t *>(&dst);
+  for (uint32_t q = lane; q < NODE_WORDS; q += BBS) b[q] = a[q];
+  if (lane == 0) { dst.root = src.root; dst.tips = src.tips; }
+}
+
+__global__ void __launch_bounds__(BBS) big_step_kernel(const BArgs A)
+{
+  __shared__ double s_tau[3*MAXPOP];
+  __shared__ Species s_sp;
+  __shared__ BTree s_t;
+  __shared__ int s_back;
+  const uint32_t lane = threadIdx.x, i = blockIdx.x;
+  {
+    const uint32_t * src = reinterpret_cast<const uint32_t *>(&A.sp);
+    uint32_t * dst = reinterpret_cast<uint32_t *>(&s_sp);
+    for (uint32_t q = lane; q < sizeof(Species)/4; q += BBS) dst[q] = src[q];
+    const uint32_t * tsrc = reinterpret_cast<const uint32_t *>(A.trees + i);
+    uint32_t * tdst = reinterpret_cast<uint32_t *>(&s_t);
+    for (uint32_t q = lane; q < sizeof(BTree)/4; q += BBS) tdst[q] = tsrc[q];
+  }
+  if (lane < (uint32_t)(3*MAXPOP)) s_tau[lane] = A.taus[lane];
+  if (lane == 0) s_back = 0;
+  __syncthreads();
+  const Species & sp = s_sp;
+  const uint32_t MODE = A.mode;
+  BTree & t = s_t;
+
+  // ---- 1. settle the step whose evaluation just finished
+  if (lane == 0 && A.pend)
+  {
+    bool back = false;
+    if (A.pend == 1)
+    {
+      if (A.active[i])
+      {
+        const double lnl = A.lnl_new[i], lp_new = A.logpr_new[i];
+        const double lnacc = (lp_new - t.logpr) + (lnl - t.lnl) + A.hast[i];
+        const double u = rndu(&t.rng);
+        t.proposals++;
+        if (lnacc >= 0 || u < exp(lnacc)) { t.lnl = lnl; t.logpr = lp_new; t.accepted++; }
+        else back = true;
+      }
+    }
+    else if (A.pend == 2)
+    {
+      if (*A.flag == A.epoch) back = true;
+      else { t.logpr = A.logpr_new[i]; if (A.active[i]) t.lnl = A.lnl_new[i]; }
+    }
+    else { t.lnl = A.lnl_new[i]; t.logpr = A.logpr_new[i]; }
+    s_back = back ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_back) copy_nodes(t, A.undo[i], lane);
+  __syncthreads();
+  // ---- 2. THETA moved the thetas since this density was stored
+  if (lane == 0 && A.refresh_logpr) t.logpr = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0);
+  __syncthreads();
+
+  // ---- 3. the proposed species tree of an all-loci step is this workgroup's copy of the taus
+  double lminf = 0, lmaxf = 0, tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1;
+  if (MODE == 2)
+  {
+    const int q = (int)A.tau_q, pq = sp.parent[q];
+    tq_old = s_tau[q]; tq_lo = fmax(s_tau[sp.left[q]], s_tau[sp.right[q]]); tq_hi = pq >= 0 ? s_tau[pq] : 999.0;
+    const double tnew = reflect(tq_old + sp.ft_tau*(A.tau_u - 0.5), tq_lo, tq_hi);
+    minf = (tnew - tq_lo)/(tq_old - tq_lo); maxf = (tnew - tq_hi)/(tq_old - tq_hi);
+    lminf = log(minf); lmaxf = log(maxf);
+    __syncthreads();
+    if (lane == 0) s_tau[q] = tnew;
+    __syncthreads();
+  }
+  else if (MODE == 3)
+  {
+    if (lane < (uint32_t)sp.npop) s_tau[lane] *= A.mix_c;
+    __syncthreads();
+  }
+  // the state a rejection comes back to (every proposing mode; a step that proposes nothing for this locus never reads it)
+  if (MODE <= 3) copy_nodes(A.undo[i], t, lane);
+  __syncthreads();
+  if (lane == 0) big_propose(A, i, t, sp, s_tau, MODE, lminf, lmaxf, tq_old, tq_lo, tq_hi, minf, maxf);
+  __syncthreads();
+  {
+    const uint32_t * tsrc = reinterpret_cast<const uint32_t *>(&s_t);
+    uint32_t * tdst = reinterpret_cast<uint32_t *>(A.trees + i);
+    for (uint32_t q = lane; q < sizeof(BTree)/4; q += BBS) tdst[q] = tsrc[q];
+  }
 }
 
 } // namespace gbig

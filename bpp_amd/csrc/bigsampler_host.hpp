@@ -69,7 +69,7 @@ static int gb_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p;
   a.refresh_logpr = s->logpr_stale ? 1u : 0u; s->logpr_stale = false;
   a.sp = s->sp;
-  hipLaunchKernelGGL(gbig::big_step_kernel, dim3((s->nloci + gbig::BBS - 1)/gbig::BBS), dim3(gbig::BBS), 0, e->stream, a);
+  hipLaunchKernelGGL(gbig::big_step_kernel, dim3(s->nloci), dim3(gbig::BBS), 0, e->stream, a);       // one workgroup per locus
   HIPCHK(hipGetLastError());
   s->launches++;
   s->g_pend = mode <= 1 ? 1u : (mode == 2 || mode == 3) ? 2u : mode == 5 ? 3u : 0u;

@@ -275,14 +275,17 @@ int          bpa_batch_end(bpa_engine_t *, const bpa_batch_t *, double * lnl);
    prop_mixing.c:52), the MSC density (gtree_logprob, gtree.c:3957), the gene trees with their
    populations and buffer-index bookkeeping, the random streams and the accept/reject decisions:
    same arithmetic, same streams, same trajectory as the host driver, without a host round trip per
-   proposal.  Three implementations behind the one interface (bpa_sampler_kind tells which one runs).  Where every
+   proposal.  Four implementations behind the one interface (bpa_sampler_kind tells which one runs).  Where every
    locus is JC69 with one rate category, <= 8 tips and <= 64 patterns: on one GPU the PERSISTENT ITERATION KERNEL
    (csrc/sweep2.hpp: the state of all loci stays in LDS for a whole call of bpa_sampler_iterate — many iterations —,
    a group of 8 or 16 lanes per locus runs the proposals, the all-loci decisions come from device-scope fixed-point
    accumulators inside the launch); with an all-reduce callback installed (several ranks), more loci than stay
    resident at once or BPA_SMP_V1=1, the sweep kernel with one launch per step (csrc/sampler.hpp); otherwise — several rate categories, GTR, up to 16 tips, < 256
    patterns x categories — a generic path that proposes on the device and evaluates with the engine's batched step
-   kernels (csrc/gsampler.hpp).  No scalers, <= 8 species.  Trees use the node numbering of a00_tree_t (tips first;
+   kernels (csrc/gsampler.hpp; 20-state loci too: their steps are written as the records of the tiled kernels); a
+   4-state locus of more than 16 tips (<= 64), with scale buffers or as an unphased diploid makes it the big-tree path
+   (csrc/bigsampler.hpp: the host driver's proposal code on trees in HBM / LDS, the engine's general kernels with
+   scaling and phase averaging; one rank).  <= 15 populations.  Trees use the node numbering of a00_tree_t (tips first;
    arrays of 2*tips-1 entries); the species tree that of a00_set_species_tree.                                   */
 typedef struct bpa_sampler bpa_sampler_t;
 bpa_sampler_t * bpa_sampler_create(bpa_engine_t *, bpa_locus_t * const * loci, unsigned nloci,

@@ -63,37 +63,7 @@ def test_driver_incremental_equals_scratch_on_gpu(engine):
     g.close()
 
 
-def _msc_start_tree(tip_species, parent, tau, theta, rng):
-    """a gene tree drawn from the MSC for tips with the given species (several per species allowed): tips
-    0..n-1, inner nodes by increasing age, root last"""
-    npop, n = len(parent), len(tip_species)
-    kids = {p: [c for c in range(npop) if parent[c] == p] for p in range(npop)}
-    events = []
-
-    def run(p):
-        lin = [k for k in range(n) if tip_species[k] == p]
-        for c in kids[p]:
-            lin += run(c)
-        now, end = tau[p], (tau[parent[p]] if parent[p] >= 0 else None)
-        while len(lin) > 1:
-            k = len(lin)
-            now += rng.exponential(theta[p] / (k * (k - 1)))
-            if end is not None and now >= end:
-                break
-            i, j = rng.choice(k, 2, replace=False)
-            events.append((now, lin[i], lin[j]))
-            lin = [x for q, x in enumerate(lin) if q not in (i, j)] + [("ev", len(events) - 1)]
-        return lin
-
-    run(npop - 1)
-    order = sorted(range(len(events)), key=lambda e: events[e][0])
-    ident = {e: n + rank for rank, e in enumerate(order)}
-    nid = lambda x: x if isinstance(x, int) else ident[x[1]]
-    left, right, times = [-1] * (2 * n - 1), [-1] * (2 * n - 1), [0.0] * (2 * n - 1)
-    for e in order:
-        t, a, b = events[e]
-        left[ident[e]], right[ident[e]], times[ident[e]] = nid(a), nid(b), t
-    return left, right, times, 2 * n - 2
+_msc_start_tree = synth.msc_start_tree
 
 
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref did not travel")
