@@ -57,6 +57,15 @@ struct BArgs
   Species sp;
 };
 
+// lane 0's work arrays, in LDS (as private arrays they would live in scratch memory: a round trip to HBM per access)
+struct Work
+{
+  int nd[2*BN], br[BN], targets[BN], stack[BN];
+  int gl[MAXPOP], nin[MAXPOP], nc[MAXPOP];
+  double times[BN];
+  unsigned char isbr[BN], isnd[BN];
+};
+
 // ---- the host driver's helpers (a00_driver.c: swap_clv / swap_pmat, lca_pop, climb, tree_logpr_stats, install_local)
 __device__ inline void swap_clv(BTree & t, int i)
 {
@@ -81,10 +90,10 @@ __device__ inline int climb(const Species & sp, const double * tau, int p, doubl
 }
 // gtree_logprob (gtree.c:3957) = the sum over populations, in stree->nodes order, of gtree_update_logprob_contrib; NaN if the
 // tree does not fit the species tree.  Optionally leaves the coalescence counts and T2h of every population (THETA)
-__device__ double tree_logpr(const BTree & t, const Species & sp, const double * tau, int8_t * nc_out, double * t2h_out, uint32_t stride)
+__device__ double tree_logpr(const BTree & t, const Species & sp, const double * tau, int8_t * nc_out, double * t2h_out, uint32_t stride, Work & W)
 {
-  int nin[MAXPOP], nc[MAXPOP];
-  double times[BN], logpr = 0;
+  int * nin = W.nin, * nc = W.nc;
+  double * times = W.times, logpr = 0;
   const int n = 2*t.tips - 1;
   for (int p = 0; p < sp.npop; ++p) nin[p] = 0;
   for (int k = 0; k < t.tips; ++k) nin[t.pop[k]]++;
@@ -138,10 +147,10 @@ __device__ inline int path_to_root(const BTree & t, int v, int * out)
   for (; v >= 0; v = t.parent[v]) out[k++] = v;
   return k;
 }
-__device__ int count_tips(const BTree & t, int v)
+__device__ int count_tips(const BTree & t, int v, int * stack)
 {
   // (iterative: a stack of the subtree's pending nodes)
-  int stack[BN], top = 0, tips = 0;
+  int top = 0, tips = 0;
   stack[top++] = v;
   while (top)
   {
@@ -150,34 +159,40 @@ __device__ int count_tips(const BTree & t, int v)
   }
   return tips;
 }
-// exchange the tree positions of node ids a and b (buffer indices stay with the ids) — swap_ids of a00_driver.c
+// exchange the tree positions of node ids a and b (buffer indices stay with the ids) — swap_ids of a00_driver.c, in place:
+// every reference to a or b renamed, then the two rows exchanged (new row i = old row M(i) with M-renamed references)
 __device__ void swap_ids(BTree & t, int a, int b)
 {
   const int n = 2*t.tips - 1;
-  int16_t L[BN], R[BN], P[BN], Q[BN]; double Tm[BN];
 #define BIGM(x) ((x) == a ? b : (x) == b ? a : (x))
   for (int i = 0; i < n; ++i)
   {
-    const int o = BIGM(i);
-    L[i] = (int16_t)(t.left[o] >= 0 ? BIGM(t.left[o]) : -1); R[i] = (int16_t)(t.right[o] >= 0 ? BIGM(t.right[o]) : -1);
-    P[i] = (int16_t)(t.parent[o] >= 0 ? BIGM(t.parent[o]) : -1); Tm[i] = t.time[o]; Q[i] = t.pop[o];
+    const int l = t.left[i], r = t.right[i], p = t.parent[i];
+    if (l >= 0) t.left[i] = (int16_t)BIGM(l);
+    if (r >= 0) t.right[i] = (int16_t)BIGM(r);
+    if (p >= 0) t.parent[i] = (int16_t)BIGM(p);
   }
-  for (int i = 0; i < n; ++i) { t.left[i] = L[i]; t.right[i] = R[i]; t.parent[i] = P[i]; t.time[i] = Tm[i]; t.pop[i] = Q[i]; }
+  { const int16_t x = t.left[a];   t.left[a] = t.left[b];     t.left[b] = x; }
+  { const int16_t x = t.right[a];  t.right[a] = t.right[b];   t.right[b] = x; }
+  { const int16_t x = t.parent[a]; t.parent[a] = t.parent[b]; t.parent[b] = x; }
+  { const int16_t x = t.pop[a];    t.pop[a] = t.pop[b];       t.pop[b] = x; }
+  { const double x = t.time[a];    t.time[a] = t.time[b];     t.time[b] = x; }
   t.root = BIGM(t.root);
 #undef BIGM
 }
+
 // ---- 4. propose (gage_step / gspr_step / tau_step / mix_step / a00_initialize of a00_driver.c, one locus), then 5. the records
 __device__ void big_propose(const BArgs & A, const uint32_t i, BTree & t, const Species & sp, const double * s_tau, const uint32_t MODE,
                             const double lminf, const double lmaxf, const double tq_old, const double tq_lo, const double tq_hi,
-                            const double minf, const double maxf)
+                            const double minf, const double maxf, Work & W)
 {
   const int n = 2*t.tips - 1;
   bool evaluate = false;
-  int br[BN], nd[2*BN], nb = 0, nn = 0;
+  int * br = W.br, * nd = W.nd, nb = 0, nn = 0;
   if (MODE == 4)
   {
     A.active[i] = 0;
-    (void)tree_logpr(t, sp, s_tau, A.pop_nc + i, A.pop_t2h + i, A.T);
+    (void)tree_logpr(t, sp, s_tau, A.pop_nc + i, A.pop_t2h + i, A.T, W);
     return;
   }
   if (MODE == 0)
@@ -201,7 +216,7 @@ __device__ void big_propose(const BArgs & A, const uint32_t i, BTree & t, const 
         br[nb++] = l; br[nb++] = r; if (p >= 0) br[nb++] = v;
         nn = path_to_root(t, v, nd);
         install(t, br, nb, nd, nn);
-        A.hast[i] = 0.0; A.logpr_new[i] = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0);
+        A.hast[i] = 0.0; A.logpr_new[i] = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0, W);
         evaluate = true;
       }
     }
@@ -214,10 +229,10 @@ __device__ void big_propose(const BArgs & A, const uint32_t i, BTree & t, const 
     {
       const double u1 = rndu(&t.rng) - 0.5, u2 = rndu(&t.rng);
       const int p = t.parent[a], s = t.left[p] == a ? t.right[p] : t.left[p], g = t.parent[p];
-      int gl[MAXPOP], targets[BN], ntg = 0, nsrc = 1;
+      int * gl = W.gl, * targets = W.targets, ntg = 0, nsrc = 1;
       for (int j = 0; j < sp.npop; ++j) gl[j] = 0;
       for (int j = 0; j < t.tips; ++j) for (int q = t.pop[j]; q >= 0; q = sp.parent[q]) gl[q]++;
-      const int leaves = count_tips(t, a);
+      const int leaves = count_tips(t, a, W.stack);
       int pop0 = t.pop[a];
       for (; gl[pop0] <= leaves && sp.parent[pop0] >= 0; pop0 = sp.parent[pop0]) ;
       const double lo = fmax(t.time[a], s_tau[pop0]);
@@ -264,7 +279,7 @@ __device__ void big_propose(const BArgs & A, const uint32_t i, BTree & t, const 
           if (!dup && t.parent[bset[j]] >= 0) br[nb++] = bset[j];
         }
         install(t, br, nb, nd, nn);
-        A.hast[i] = log((double)ntg/(double)nsrc); A.logpr_new[i] = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0);
+        A.hast[i] = log((double)ntg/(double)nsrc); A.logpr_new[i] = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0, W);
         evaluate = true;
       }
     }
@@ -274,17 +289,17 @@ __device__ void big_propose(const BArgs & A, const uint32_t i, BTree & t, const 
     const int q = (int)A.tau_q, cl = sp.left[q], cr = sp.right[q];
     int above = 0, below = 0;
     
-    bool isbr[BN], isnd[BN];
-    for (int k = 0; k < n; ++k) isbr[k] = isnd[k] = false;
+    unsigned char * isbr = W.isbr, * isnd = W.isnd;
+    for (int k = 0; k < n; ++k) isbr[k] = isnd[k] = 0;
     for (int k = t.tips; k < n; ++k)
     {
       const int pk = t.pop[k]; const double tk = t.time[k];
       if ((pk != q && pk != cl && pk != cr) || tk < tq_lo || tk > tq_hi) continue;
       if (tk >= tq_old) { t.time[k] = tq_hi + maxf*(tk - tq_hi); ++above; } else { t.time[k] = tq_lo + minf*(tk - tq_lo); ++below; }
-      isbr[t.left[k]] = isbr[t.right[k]] = true; if (t.parent[k] >= 0) isbr[k] = true;
-      for (int v = k; v >= 0; v = t.parent[v]) isnd[v] = true;
+      isbr[t.left[k]] = isbr[t.right[k]] = 1; if (t.parent[k] >= 0) isbr[k] = 1;
+      for (int v = k; v >= 0; v = t.parent[v]) isnd[v] = 1;
     }
-    const double lp_new = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0);
+    const double lp_new = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0, W);
     A.logpr_new[i] = lp_new;
     A.delta[i] = ((lp_new - t.logpr) + below*lminf) + above*lmaxf;
     if (above + below)
@@ -308,7 +323,7 @@ __device__ void big_propose(const BArgs & A, const uint32_t i, BTree & t, const 
       for (int k = 0; k < nb; ++k) swap_pmat(t, br[k]);          // start-up evaluates in place: toggle twice = no toggle
       for (int k = 0; k < nn; ++k) swap_clv(t, nd[k]);
     }
-    const double lp_new = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0);
+    const double lp_new = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0, W);
     A.logpr_new[i] = lp_new;
     A.delta[i] = (lp_new - t.logpr) + (double)ninner*A.mix_lnc;
     install(t, br, nb, nd, nn);
@@ -361,6 +376,7 @@ __global__ void __launch_bounds__(BBS) big_step_kernel(const BArgs A)
   __shared__ double s_tau[3*MAXPOP];
   __shared__ Species s_sp;
   __shared__ BTree s_t;
+  __shared__ Work s_w;
   __shared__ int s_back;
   const uint32_t lane = threadIdx.x, i = blockIdx.x;
   {
@@ -406,7 +422,7 @@ __global__ void __launch_bounds__(BBS) big_step_kernel(const BArgs A)
   if (s_back) copy_nodes(t, A.undo[i], lane);
   __syncthreads();
   // ---- 2. THETA moved the thetas since this density was stored
-  if (lane == 0 && A.refresh_logpr) t.logpr = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0);
+  if (lane == 0 && A.refresh_logpr) t.logpr = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0, s_w);
   __syncthreads();
 
   // ---- 3. the proposed species tree of an all-loci step is this workgroup's copy of the taus
@@ -430,7 +446,7 @@ __global__ void __launch_bounds__(BBS) big_step_kernel(const BArgs A)
   // the state a rejection comes back to (every proposing mode; a step that proposes nothing for this locus never reads it)
   if (MODE <= 3) copy_nodes(A.undo[i], t, lane);
   __syncthreads();
-  if (lane == 0) big_propose(A, i, t, sp, s_tau, MODE, lminf, lmaxf, tq_old, tq_lo, tq_hi, minf, maxf);
+  if (lane == 0) big_propose(A, i, t, sp, s_tau, MODE, lminf, lmaxf, tq_old, tq_lo, tq_hi, minf, maxf, s_w);
   __syncthreads();
   {
     const uint32_t * tsrc = reinterpret_cast<const uint32_t *>(&s_t);

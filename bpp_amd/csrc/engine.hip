@@ -136,6 +136,7 @@ struct bpa_engine
   std::vector<uint32_t> bc_pat;
   std::atomic<int> bc_failed{0}; std::mutex bc_mtx; std::string bc_msg;
   DevBuf<unsigned char> d_step;
+  DevBuf<unsigned char> d_upload;         // flush_state's staged set-up uploads (records | payload)
   DevBuf<double> d_step_terms, d_step_lnl;
   // engine-level packing of the JC69 / one-category loci for step_jc69_v2_kernel (device_types.hpp): shared by all plans
   bool pack_dirty = true;               // a locus appeared / went away / changed its tip states or weights
@@ -258,7 +259,7 @@ extern "C" void bpa_engine_destroy(bpa_engine_t * e)
   e->d_lane_tab.free(); e->d_slot_tab.free(); e->d_blk_slot_off.free();
   if (e->h_stage) (void)hipHostFree(e->h_stage);
   if (e->h_step) (void)hipHostFree(e->h_step);
-  e->d_step.free(); e->d_step_terms.free(); e->d_step_lnl.free();
+  e->d_step.free(); e->d_step_terms.free(); e->d_step_lnl.free(); e->d_upload.free();
   for (void * q : e->staged) (void)hipFree(q);
   for (auto & s : e->slots) for (auto & ev : s.ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -544,13 +545,27 @@ static int flush_state(bpa_engine * e)
   if (e->dirty.empty()) return 1;
   std::vector<uint32_t> eig;
   HIPCHK(hipStreamSynchronize(e->stream));
+  // many loci at once (set-up: every locus of a data set): the pieces are staged and go up in ONE copy + a scatter kernel
+  const bool staged = e->dirty.size() >= 8;
+  std::vector<UpRec> up_recs;
+  std::vector<unsigned char> up_data;
+  auto put = [&](void * dst, const void * src, size_t bytes) -> int
+  {
+    if (!bytes) return 1;
+    if (!staged) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 1; }
+    const size_t off = (up_data.size() + 15) & ~(size_t)15;
+    up_data.resize(off + bytes);
+    std::memcpy(up_data.data() + off, src, bytes);
+    up_recs.push_back(UpRec{(unsigned char *)dst, (uint64_t)off, (uint32_t)bytes, 0u});
+    return 1;
+  };
   for (bpa_locus * l : e->dirty)
   {
     l->queued = false;
     if (l->tips_dirty)
-    { HIPCHK(hipMemcpy(l->dev.tips, l->tipcodes.data(), l->tipcodes.size(), hipMemcpyHostToDevice)); l->tips_dirty = false; e->pack_dirty = true; }
+    { if (!put(l->dev.tips, l->tipcodes.data(), l->tipcodes.size())) return 0; l->tips_dirty = false; e->pack_dirty = true; }
     if (l->weights_dirty)
-    { HIPCHK(hipMemcpy(l->dev.weights, l->weights.data(), l->weights.size()*4, hipMemcpyHostToDevice)); l->weights_dirty = false; e->pack_dirty = true; }
+    { if (!put(l->dev.weights, l->weights.data(), l->weights.size()*4)) return 0; l->weights_dirty = false; e->pack_dirty = true; }
     bool need_eig = false;
     if (l->needs_eigen())
       for (int v : l->eigen_valid) if (!v) need_eig = true;
@@ -560,11 +575,11 @@ static int flush_state(bpa_engine * e)
       // eigensystem part of the block is device-owned and only overwritten
       // when it is about to be recomputed anyway.
       const unsigned S = l->states, R = l->rate_cats;
-      HIPCHK(hipMemcpy(l->dev.par, l->par.data(), 3*R*sizeof(double), hipMemcpyHostToDevice));
+      if (!put(l->dev.par, l->par.data(), 3*R*sizeof(double))) return 0;
       for (unsigned m = 0; m < l->rate_matrices; ++m)
       {
         const size_t off = par_matrix(R, S, m);
-        HIPCHK(hipMemcpy(l->dev.par + off, l->par.data() + off, (S + S*(S-1)/2)*sizeof(double), hipMemcpyHostToDevice));
+        if (!put(l->dev.par + off, l->par.data() + off, (S + S*(S-1)/2)*sizeof(double))) return 0;
       }
       l->par_dirty = false;
       if (l->rate_cats == 1 && l->dev.model == 0) e->pack_dirty = true;       // the slot table carries a JC69 locus's rate
@@ -572,6 +587,17 @@ static int flush_state(bpa_engine * e)
     if (need_eig) { eig.push_back(l->id); std::fill(l->eigen_valid.begin(), l->eigen_valid.end(), 1); }
   }
   e->dirty.clear();
+  if (!up_recs.empty())
+  {
+    const size_t rb = (up_recs.size()*sizeof(UpRec) + 15) & ~(size_t)15;
+    if (!e->d_upload.reserve(rb + up_data.size())) return fail("out of device memory (set-up staging)");
+    HIPCHK(hipMemcpy(e->d_upload.p, up_recs.data(), up_recs.size()*sizeof(UpRec), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_upload.p + rb, up_data.data(), up_data.size(), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(scatter_upload_kernel, dim3((unsigned)up_recs.size()), dim3(64), 0, e->stream,
+                       reinterpret_cast<const UpRec *>(e->d_upload.p), (const unsigned char *)(e->d_upload.p + rb));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));          // (the staging buffer is reused by the next flush)
+  }
   if (!eig.empty())
   {
     if (!e->d_eigen_list.reserve(eig.size())) return fail("out of device memory (eigen list)");

@@ -905,6 +905,24 @@ partials_lnl_pipemfma20_kernel(const PlanDev P)
   P.site_term[((cu32_p)P.task_pat_off)[t] + n] = term;
 }
 
+// ================================================== batched host -> device set-up ==
+// flush_state's uploads (tip codes, weights, parameter blocks of every locus that changed) as ONE staged copy + this scatter:
+// record r says where payload bytes [src_off, src_off + bytes) go.  (10 000 loci = 40 000 separate copies otherwise.)
+struct UpRec { unsigned char * dst; uint64_t src_off; uint32_t bytes, pad; };
+__global__ void __launch_bounds__(64) scatter_upload_kernel(const UpRec * __restrict__ recs, const unsigned char * __restrict__ payload)
+{
+  const UpRec r = recs[blockIdx.x];
+  const unsigned char * src = payload + r.src_off;
+  if (((reinterpret_cast<uintptr_t>(r.dst) | reinterpret_cast<uintptr_t>(src)) & 3u) == 0)
+  {
+    const uint32_t nw = r.bytes >> 2;
+    for (uint32_t q = threadIdx.x; q < nw; q += 64) reinterpret_cast<uint32_t *>(r.dst)[q] = reinterpret_cast<const uint32_t *>(src)[q];
+    for (uint32_t b = (nw << 2) + threadIdx.x; b < r.bytes; b += 64) r.dst[b] = src[b];
+  }
+  else
+    for (uint32_t b = threadIdx.x; b < r.bytes; b += 64) r.dst[b] = src[b];
+}
+
 // ====================================================== per-locus lnL reduction ==
 // Sum of the per-pattern terms in pattern order (core_likelihood.c:206-210); the
 // diploid branch averages the phase resolutions first (locus.c:2600-2614).

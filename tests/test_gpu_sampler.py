@@ -225,12 +225,19 @@ def test_device_sampler_draws_from_the_msc_prior():
 
 
 def test_sampler_rejects_unsupported_loci(engine):
-    """GTR+G loci are the generic sampler's (tests/test_gpu_gsampler.py); scalers and a mix of one- and several-category
-    loci are refused loudly"""
+    """GTR+G loci are the generic sampler's (tests/test_gpu_gsampler.py), loci with scale buffers the big-tree sampler's
+    (tests/test_gpu_bigsampler.py); amino-acid loci with scalers and a mix of one- and several-category loci are refused loudly"""
     data = synth.make_dataset(2, 200, 8, "gtr", 4, seed=1)
     loci = tape.make_engine_loci(engine, data, True)                  # with scale buffers
+    smp = bpp_amd.Sampler(engine, loci, data)
+    parent, tau0, thetas = synth.species_tree_arrays(8)
+    smp.set_species_tree(parent, tau0, thetas)
+    smp.initialize()
+    assert smp.kind() == "big"
+    smp.close()
+    aa = synth.make_dataset(2, 100, 6, "lg", 1, seed=3)
     with pytest.raises(bpp_amd.BpaError, match="without scalers"):
-        bpp_amd.Sampler(engine, loci, data)
+        bpp_amd.Sampler(engine, tape.make_engine_loci(engine, aa, True), aa)
     mixed = data[:1] + synth.make_dataset(1, 200, 8, "jc69", 1, seed=2)
     loci = tape.make_engine_loci(engine, mixed)
     with pytest.raises(bpp_amd.BpaError, match="all be JC69"):
