@@ -66,14 +66,23 @@ def test_host_driver_on_reference_backend_reproduces_bpp_posterior(gold):
 
 
 @pytest.mark.gpu
-def test_device_sampler_reproduces_bpp_posterior(gold):
+@pytest.mark.parametrize("program", [False, True])
+def test_device_sampler_reproduces_bpp_posterior(gold, program):
+    """program: BPP's own generator and windows and its THETA / TAU / MIX move for move (bpa_sampler_set_program_moves)"""
     import bpp_amd
     import tape
     data = dataset(gold)
     eng = bpp_amd.Engine(0)
     loci = tape.make_engine_loci(eng, data)
     dev = bpp_amd.Sampler(eng, loci, data, seed=9)
+    if program:
+        dev.set_proposal_kernel(1)
+        dev.set_program_moves(True, 0.1)
     setup(dev, gold)
+    if program:
+        c = gold["config"]
+        dev.set_theta_prior(c["theta_prior"][0], c["theta_prior"][1], 0.0012)
+        dev.set_finetune(0.0012, 0.0012, 0.0004, 0.3)            # (step lengths of the order BPP's burn-in tuning settles on)
     dev.initialize()
     dev.iterate(3000)
     S = []
@@ -85,10 +94,12 @@ def test_device_sampler_reproduces_bpp_posterior(gold):
 
 
 @pytest.mark.gpu
-def test_device_sampler_reproduces_bpp_posterior_at_benchmark_scale():
+@pytest.mark.parametrize("program", [False, True])
+def test_device_sampler_reproduces_bpp_posterior_at_benchmark_scale(program):
     """BASELINE config 2 itself — 10 000 loci x 1 000 sites: the unmodified program (8 threads, ~3 minutes) and the
     device-resident sampler (seconds) land on the same posterior; with this much data it is 1-4 % wide, so the
-    comparison is tight in absolute terms"""
+    comparison is tight in absolute terms.  program: BPP's kernel with the program's moves and the step lengths the
+    program's own burn-in arrives at on such data"""
     import bpp_amd
     import tape
     gold = json.load(open(os.path.join(HERE, "golden", "a00_posterior_10k.json")))
@@ -97,10 +108,16 @@ def test_device_sampler_reproduces_bpp_posterior_at_benchmark_scale():
     eng = bpp_amd.Engine(0)
     loci = tape.make_engine_loci(eng, data)
     dev = bpp_amd.Sampler(eng, loci, data, seed=3)
+    if program:
+        dev.set_proposal_kernel(1)
+        dev.set_program_moves(True, 0.1)
     dev.set_species_tree(*synth.species_tree_arrays(c["taxa"]))
-    dev.set_theta_prior(c["theta_prior"][0], c["theta_prior"][1], 8e-5)
+    dev.set_theta_prior(c["theta_prior"][0], c["theta_prior"][1], 3e-5 if program else 8e-5)
     dev.set_tau_prior(*c["tau_prior"])
-    dev.set_finetune(0.004, 0.004, 4e-5, 0.006)
+    if program:
+        dev.set_finetune(18.5, 0.0019, 1.9e-5, 0.0059)
+    else:
+        dev.set_finetune(0.004, 0.004, 4e-5, 0.006)
     dev.initialize()
     dev.iterate(1000)
     S = []
