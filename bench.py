@@ -1043,7 +1043,7 @@ def main():
             # only throttled) and twice that — round 2's sweep over 8 ... 128 found the best there every time
             q = int(cpu_quota() or ncores)
             sweep = sorted({1, max(2, min(q, ncores)), max(2, min(2 * q, ncores))})
-            r = bpp_program_baseline(nloci_cfg, cfg["sites"], sweep, chain_samples=0 if args.no_efficiency else 1500)
+            r = bpp_program_baseline(nloci_cfg, cfg["sites"], sweep, chain_samples=0 if args.no_efficiency else 2500)
             chain = r.pop("chain", None) if r else None
             if r:
                 best = max((k for k in r if k > 1), key=lambda k: r[k]["median"], default=1)
