@@ -32,6 +32,7 @@ struct BTree                              // one per locus, in HBM (and its copy
   int32_t  root, tips;
   uint32_t proposals, accepted;
   uint32_t work_nupd, work_nbr, work_neval, pad_;
+  int8_t   gl[MAXPOP];                    // gene tips below each population (never changes: tips stay in their species)
 };
 
 struct BArgs
@@ -64,6 +65,10 @@ struct Work
   int gl[MAXPOP], nin[MAXPOP], nc[MAXPOP];
   double times[BN];
   unsigned char isbr[BN], isnd[BN];
+  // a prune-and-regraft between its two lane-0 parts: what the scan of all nodes (64 lanes) needs and leaves
+  int g_a, g_p, g_s, g_g, g_popt, g_popp, g_ok;
+  double g_tnew, g_tp, g_u2;
+  unsigned long long g_tmask[2], g_smask[2];
 };
 
 // ---- the host driver's helpers (a00_driver.c: swap_clv / swap_pmat, lca_pop, climb, tree_logpr_stats, install_local)
@@ -181,6 +186,48 @@ __device__ void swap_ids(BTree & t, int a, int b)
 #undef BIGM
 }
 
+// GSPR, lane 0's first part (gspr_step of a00_driver.c up to the target / source scans): the pruned node, the draws, the new
+// age of its father and the population it falls in
+__device__ void gspr_pre(const BArgs & A, BTree & t, const Species & sp, const double * s_tau, Work & W)
+{
+  const int n = 2*t.tips - 1;
+  int a = -1, c = 0;
+  for (int j = 0; j < n; ++j) if (j != t.root && c++ == (int)A.k) { a = j; break; }
+  W.g_a = a; W.g_ok = 0;
+  if (a < 0) return;
+  const double u1 = rndu(&t.rng) - 0.5, u2 = rndu(&t.rng);
+  const int p = t.parent[a], s = t.left[p] == a ? t.right[p] : t.left[p], g = t.parent[p];
+  // youngest population from a's upwards that holds gene tips outside a's subtree (gtree.c:6664-6669)
+  const int leaves = count_tips(t, a, W.stack);
+  int pop0 = t.pop[a];
+  for (; t.gl[pop0] <= leaves && sp.parent[pop0] >= 0; pop0 = sp.parent[pop0]) ;
+  const double lo = fmax(t.time[a], s_tau[pop0]);
+  const double tnew = reflect(t.time[p] + sp.ft_gspr*u1, lo, 999.0);
+  W.g_p = p; W.g_s = s; W.g_g = g; W.g_popt = climb(sp, s_tau, t.pop[a], tnew); W.g_popp = t.pop[p];
+  W.g_tnew = tnew; W.g_tp = t.time[p]; W.g_u2 = u2; W.g_ok = 1;
+}
+// ... the scans, by all 64 lanes (two nodes each): the branches crossing the new age inside the target population, and
+// the branches the reverse move could pick at the old age (gtree.c:6760-6775), as bit masks in node order
+__device__ void gspr_scan(const BTree & t, const Species & sp, Work & W, const uint32_t lane)
+{
+  const int n = 2*t.tips - 1, a = W.g_a, p = W.g_p, s = W.g_s, root = t.root;
+  const double tnew = W.g_tnew, tp = W.g_tp;
+  for (int h = 0; h < 2; ++h)
+  {
+    const int j = 64*h + (int)lane;
+    bool ct = false, cs = false;
+    if (j < n && j != a && j != root)
+    {
+      const double tj = t.time[j], tpar = t.time[t.parent[j]];
+      const uint32_t anc = sp.anc[t.pop[j]];
+      ct = tj <= tnew && tpar > tnew && ((anc >> W.g_popt) & 1u);
+      cs = j != s && j != p && tj <= tp && tpar > tp && ((anc >> W.g_popp) & 1u);
+    }
+    const unsigned long long mt = __ballot(ct), ms = __ballot(cs);
+    if (lane == 0) { W.g_tmask[h] = mt; W.g_smask[h] = ms; }
+  }
+}
+
 // ---- 4. propose (gage_step / gspr_step / tau_step / mix_step / a00_initialize of a00_driver.c, one locus), then 5. the records
 __device__ void big_propose(const BArgs & A, const uint32_t i, BTree & t, const Species & sp, const double * s_tau, const uint32_t MODE,
                             const double lminf, const double lmaxf, const double tq_old, const double tq_lo, const double tq_hi,
@@ -223,31 +270,17 @@ __device__ void big_propose(const BArgs & A, const uint32_t i, BTree & t, const 
   }
   else if (MODE == 1)
   {
-    int a = -1, c = 0;
-    for (int j = 0; j < n; ++j) if (j != t.root && c++ == (int)A.k) { a = j; break; }
-    if (a >= 0)
+    const int a = W.g_a;
+    if (W.g_ok)
     {
-      const double u1 = rndu(&t.rng) - 0.5, u2 = rndu(&t.rng);
-      const int p = t.parent[a], s = t.left[p] == a ? t.right[p] : t.left[p], g = t.parent[p];
-      int * gl = W.gl, * targets = W.targets, ntg = 0, nsrc = 1;
-      for (int j = 0; j < sp.npop; ++j) gl[j] = 0;
-      for (int j = 0; j < t.tips; ++j) for (int q = t.pop[j]; q >= 0; q = sp.parent[q]) gl[q]++;
-      const int leaves = count_tips(t, a, W.stack);
-      int pop0 = t.pop[a];
-      for (; gl[pop0] <= leaves && sp.parent[pop0] >= 0; pop0 = sp.parent[pop0]) ;
-      const double lo = fmax(t.time[a], s_tau[pop0]);
-      const double tnew = reflect(t.time[p] + sp.ft_gspr*u1, lo, 999.0);
-      const int popt = climb(sp, s_tau, t.pop[a], tnew);
+      const double u2 = W.g_u2, tnew = W.g_tnew;
+      const int p = W.g_p, s = W.g_s, g = W.g_g, popt = W.g_popt;
+      int * targets = W.targets, ntg = 0, nsrc = 1;
       if (tnew >= t.time[t.root]) targets[ntg++] = t.root;
       else
-        for (int j = 0; j < n; ++j)
-          if (j != a && j != t.root && t.time[j] <= tnew && t.time[t.parent[j]] > tnew && ((sp.anc[t.pop[j]] >> popt) & 1u))
-            targets[ntg++] = j == p ? s : j;
-      if (p != t.root)
-        for (int j = 0; j < n; ++j)
-          if (j != a && j != t.root && j != s && j != p && t.time[j] <= t.time[p] && t.time[t.parent[j]] > t.time[p] &&
-              ((sp.anc[t.pop[j]] >> t.pop[p]) & 1u))
-            ++nsrc;
+        for (int h = 0; h < 2; ++h)
+          for (unsigned long long m = W.g_tmask[h]; m; m &= m - 1) { const int j = 64*h + __ffsll((long long)m) - 1; targets[ntg++] = j == p ? s : j; }
+      if (p != t.root) nsrc += __popcll(W.g_smask[0]) + __popcll(W.g_smask[1]);
       if (!ntg) (void)rndu(&t.rng);
       else
       {
@@ -446,6 +479,13 @@ __global__ void __launch_bounds__(BBS) big_step_kernel(const BArgs A)
   // the state a rejection comes back to (every proposing mode; a step that proposes nothing for this locus never reads it)
   if (MODE <= 3) copy_nodes(A.undo[i], t, lane);
   __syncthreads();
+  if (MODE == 1)
+  {
+    if (lane == 0) gspr_pre(A, t, sp, s_tau, s_w);
+    __syncthreads();
+    if (s_w.g_ok) gspr_scan(t, sp, s_w, lane);
+    __syncthreads();
+  }
   if (lane == 0) big_propose(A, i, t, sp, s_tau, MODE, lminf, lmaxf, tq_old, tq_lo, tq_hi, minf, maxf, s_w);
   __syncthreads();
   {
