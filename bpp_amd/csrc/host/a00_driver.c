@@ -52,6 +52,7 @@ struct a00_driver
   double tau_alpha, tau_beta;           /* gamma prior on the root tau (0,0: flat) */
   double theta_alpha, theta_beta, ft_theta;   /* gamma prior on every theta (alpha 0: thetas fixed, no THETA steps) */
   int has_theta[A00_MAXPOP];
+  double l2t[A00_MAXPOP], l2t_of[A00_MAXPOP];   /* log(2/theta_p) and the theta it belongs to (tree_logpr_stats) */
   double * s_logpr;                     /* proposed MSC density per slot */
   double * p_logpr, * p_delta; int * p_slot;     /* all-loci steps: per locus */
   int ** u_pop;
@@ -134,21 +135,15 @@ void a00_theta_conditional(double a, double b, long k, double T, double * a1b1) 
 
 static void snapshot(a00_driver_t * d, unsigned i)
 {
-  a00_tree_t * t = d->trees + i; const size_t n = (size_t)t->n;
-  memcpy(d->u_left[i], t->left, n*sizeof(int));   memcpy(d->u_right[i], t->right, n*sizeof(int));
-  memcpy(d->u_parent[i], t->parent, n*sizeof(int)); memcpy(d->u_time[i], t->time, n*sizeof(double));
-  memcpy(d->u_clv[i], t->clv, n*sizeof(int));     memcpy(d->u_pmat[i], t->pmat, n*sizeof(int));
-  memcpy(d->u_scaler[i], t->scaler, n*sizeof(int)); d->u_root[i] = t->root;
-  memcpy(d->u_pop[i], t->pop, n*sizeof(int));
+  a00_tree_t * t = d->trees + i;
+  memcpy(d->u_time[i], t->time, (size_t)t->n*(sizeof(double) + 7*sizeof(int)));     /* the whole block (a00_set_tree) */
+  d->u_root[i] = t->root;
 }
 static void restore(a00_driver_t * d, unsigned i)
 {
-  a00_tree_t * t = d->trees + i; const size_t n = (size_t)t->n;
-  memcpy(t->left, d->u_left[i], n*sizeof(int));   memcpy(t->right, d->u_right[i], n*sizeof(int));
-  memcpy(t->parent, d->u_parent[i], n*sizeof(int)); memcpy(t->time, d->u_time[i], n*sizeof(double));
-  memcpy(t->clv, d->u_clv[i], n*sizeof(int));     memcpy(t->pmat, d->u_pmat[i], n*sizeof(int));
-  memcpy(t->scaler, d->u_scaler[i], n*sizeof(int)); t->root = d->u_root[i];
-  memcpy(t->pop, d->u_pop[i], n*sizeof(int));
+  a00_tree_t * t = d->trees + i;
+  memcpy(t->time, d->u_time[i], (size_t)t->n*(sizeof(double) + 7*sizeof(int)));
+  t->root = d->u_root[i];
 }
 
 a00_driver_t * a00_create(unsigned nloci, a00_eval_fn eval, void * ctx, unsigned long seed)
@@ -194,10 +189,8 @@ void a00_destroy(a00_driver_t * d)
   for (i = 0; i < d->nloci; ++i)
   {
     a00_tree_t * t = d->trees + i;
-    free(t->left); free(t->right); free(t->parent); free(t->time); free(t->clv); free(t->pmat); free(t->scaler); free(t->pop);
-    free(d->u_pop[i]);
-    free(d->u_left[i]); free(d->u_right[i]); free(d->u_parent[i]); free(d->u_clv[i]); free(d->u_pmat[i]);
-    free(d->u_scaler[i]); free(d->u_time[i]);
+    free(t->time);                     /* (the locus's block starts with the ages) */
+    free(d->u_time[i]);
   }
   free(d->rng); free(d->zrng); free(d->sm); free(d->sm_ncat); free(d->sm_old); free(d->trees); free(d->s_locus); free(d->s_tree); free(d->s_br_off); free(d->s_nd_off); free(d->s_br);
   free(d->s_logpr); free(d->p_logpr); free(d->p_delta); free(d->p_slot); free(d->u_pop);
@@ -213,12 +206,22 @@ int a00_set_tree(a00_driver_t * d, unsigned i, int tips, const int * left, const
   const int n = 2*tips - 1; int k;
   if (i >= d->nloci || n > MAXN || tips < 2) return 0;
   t->tips = tips; t->n = n; t->root = root; t->rate_mui = 1.0; t->lnl = 0;
-#define DUP(dst, src, T) do { dst = (T *)malloc((size_t)n*sizeof(T)); memcpy(dst, src, (size_t)n*sizeof(T)); } while (0)
-  DUP(t->left, left, int); DUP(t->right, right, int); DUP(t->time, times, double);
-#undef DUP
-  t->parent = (int *)malloc((size_t)n*sizeof(int)); t->clv = (int *)malloc((size_t)n*sizeof(int));
-  t->pmat = (int *)malloc((size_t)n*sizeof(int)); t->scaler = (int *)malloc((size_t)n*sizeof(int));
-  t->pop = (int *)malloc((size_t)n*sizeof(int)); d->u_pop[i] = (int *)malloc((size_t)n*sizeof(int));
+  /* one block per locus — time | left | right | parent | clv | pmat | scaler | pop — and one of the same shape for the
+     roll-back copy: a snapshot is ONE memcpy of 36 n bytes (was eight of separately allocated arrays) */
+  {
+    const size_t bytes = (size_t)n*(sizeof(double) + 7*sizeof(int));
+    char * blk, * ublk;
+    free(t->time); free(d->u_time[i]);                    /* (a tree set again) */
+    t->time = NULL; d->u_time[i] = NULL;
+    blk = (char *)malloc(bytes); ublk = (char *)malloc(bytes);
+    int * ip = (int *)(blk + (size_t)n*sizeof(double)), * up = (int *)(ublk + (size_t)n*sizeof(double));
+    if (!blk || !ublk) { free(blk); free(ublk); return 0; }
+    t->time = (double *)blk; t->left = ip; t->right = ip + n; t->parent = ip + 2*n; t->clv = ip + 3*n; t->pmat = ip + 4*n;
+    t->scaler = ip + 5*n; t->pop = ip + 6*n;
+    d->u_time[i] = (double *)ublk; d->u_left[i] = up; d->u_right[i] = up + n; d->u_parent[i] = up + 2*n; d->u_clv[i] = up + 3*n;
+    d->u_pmat[i] = up + 4*n; d->u_scaler[i] = up + 5*n; d->u_pop[i] = up + 6*n;
+    memcpy(t->left, left, (size_t)n*sizeof(int)); memcpy(t->right, right, (size_t)n*sizeof(int)); memcpy(t->time, times, (size_t)n*sizeof(double));
+  }
   for (k = 0; k < n; ++k) t->pop[k] = k < tips ? k : -1;
   for (k = 0; k < n; ++k) t->parent[k] = -1;
   for (k = 0; k < n; ++k)
@@ -227,10 +230,6 @@ int a00_set_tree(a00_driver_t * d, unsigned i, int tips, const int * left, const
     t->clv[k] = k; t->pmat[k] = k;                               /* gtree.c:2433-2439, 2398 */
     t->scaler[k] = (scaling && k >= tips) ? k - tips : BPA_SCALE_BUFFER_NONE;
   }
-  d->u_left[i] = (int *)malloc((size_t)n*sizeof(int)); d->u_right[i] = (int *)malloc((size_t)n*sizeof(int));
-  d->u_parent[i] = (int *)malloc((size_t)n*sizeof(int)); d->u_clv[i] = (int *)malloc((size_t)n*sizeof(int));
-  d->u_pmat[i] = (int *)malloc((size_t)n*sizeof(int)); d->u_scaler[i] = (int *)malloc((size_t)n*sizeof(int));
-  d->u_time[i] = (double *)malloc((size_t)n*sizeof(double));
   return 1;
 }
 
@@ -414,7 +413,19 @@ static double tree_logpr_stats(const a00_driver_t * d, const a00_tree_t * t, int
     {
       const double T2h = a00_msc_t2h(d->tau[p], d->sp_parent[p] >= 0 ? d->tau[d->sp_parent[p]] : -1.0, nin[p], times, n);
       if (nc_out) { nc_out[p] = n; t2h_out[p] = T2h; }
-      logpr += a00_msc_term(n, T2h, d->theta[p], 1.0);
+      /* a00_msc_term(n, T2h, theta, 1) with log(2/theta) taken from a cache keyed by the theta it was made from (thetas
+         stand still during a step's per-locus loop: every locus would take the same logarithm again) */
+      {
+        const double th = d->theta[p]; double term = 0;
+        if (n)
+        {
+          a00_driver_t * dm = (a00_driver_t *)d;
+          if (dm->l2t_of[p] != th) { dm->l2t[p] = log(2.0/(1.0*th)); dm->l2t_of[p] = th; }      /* (threads race to store the same value) */
+          term += n*dm->l2t[p];
+        }
+        if (T2h) term -= T2h/(th*1.0);
+        logpr += term;
+      }
     }
   }
   return logpr;
@@ -1125,6 +1136,7 @@ int a00_backend_hip(void * vctx, const a00_step_t * s, double * lnl)
       for (q = 0; q < parts; ++q)
         (void)bpa_batch_fill(c->engine, &b, (unsigned)((unsigned long long)n*(unsigned)q/(unsigned)parts), (unsigned)((unsigned long long)n*(unsigned)(q + 1)/(unsigned)parts));
       ok = bpa_batch_end(c->engine, &b, lnl);
+      if (ok == 2) ok = bpa_batch_evaluate(c->engine, &b, lnl);          /* (not the one-image path after all) */
     }
     else ok = how == 2 ? bpa_batch_evaluate(c->engine, &b, lnl) : 0;
     if (prof)

@@ -262,7 +262,8 @@ int          bpa_batch_evaluate(bpa_engine_t *, const bpa_batch_t *, double * ln
                        bpa_batch_evaluate instead, 0 = error;
      bpa_batch_fill    writes the records of the batch's loci [t0, t1); disjoint ranges may be filled from several threads
                        at once (no lock is taken); an invalid index makes bpa_batch_end fail;
-     bpa_batch_end     uploads the image (one copy), launches, returns the per-locus lnL like bpa_batch_evaluate.
+     bpa_batch_end     uploads the image (one copy), launches, returns the per-locus lnL like bpa_batch_evaluate (1), or 2 when
+                       a fill found a locus this path does not take (call bpa_batch_evaluate instead), 0 = error.
    One batch at a time per engine; nothing else may touch the engine between begin and end.                              */
 int          bpa_batch_begin(bpa_engine_t *, const bpa_batch_t *);
 int          bpa_batch_fill(bpa_engine_t *, const bpa_batch_t *, unsigned t0, unsigned t1);
