@@ -579,12 +579,27 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         if (pact) wl.term[ps] = log(0 + tr_*S.rw)*pi.x;
       }
       wsync();
-      for (uint32_t q = 0; q < np; ++q) lnl += wl.term[pb + q];
+      // the terms in pattern order (core_likelihood.c:206-210): eight loads in flight, then the adds (+ 0.0 past the end)
+      for (uint32_t base = 0; base < np; base += 8)
+      {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = base + (uint32_t)j < np ? wl.term[pb + base + (uint32_t)j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lnl += v[j];
+      }
       lnl = A.bfbeta == 1.0 ? lnl : A.bfbeta == 0.0 ? 0.0 : A.bfbeta*lnl;
     }
     else wsync();
     double lp = 0;
-    for (int p = 0; p < npop; ++p) lp += ((pr.chain >> p) & 1u) ? S.contrib_new[p] : S.contrib[p];
+    {
+      // the density terms in population order, loads first (npop < G)
+      double v[G];
+#pragma unroll
+      for (int p = 0; p < G; ++p) v[p] = p < npop ? (((pr.chain >> p) & 1u) ? S.contrib_new[p] : S.contrib[p]) : 0.0;
+#pragma unroll
+      for (int p = 0; p < G; ++p) lp += v[p];
+    }
     lp_new = lp;
     return lnl;
   };
