@@ -26,6 +26,10 @@ def main():
     eng = bpp_amd.Engine(0)
     loci = tape.make_engine_loci(eng, mine)
     smp = bpp_amd.Sampler(eng, loci, mine, seed=7)
+    if os.environ.get("DIST_PROGRAM"):
+        # BPP's kernel with the program's THETA / TAU / MIX: two sums per theta in the THETA exchange, five values per TAU
+        smp.set_proposal_kernel(1)
+        smp.set_program_moves(True, 0.3)
     t = torch.zeros(16, dtype=torch.float64, device="cuda")        # BPA_SAMPLER_SUMS
 
     def allreduce(ptr, count, stream):

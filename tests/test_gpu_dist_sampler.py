@@ -75,12 +75,15 @@ def test_two_ranks_generic_sampler_with_parameter_moves(tmp_path):
     assert np.allclose(lnl, one["lnl"], rtol=1e-10, atol=0)
 
 
-def test_two_ranks_exchange_inside_the_persistent_kernel(tmp_path):
+@pytest.mark.parametrize("program", [False, True])
+def test_two_ranks_exchange_inside_the_persistent_kernel(tmp_path, program):
     """bpa_sampler_set_p2p: both ranks run the persistent iteration kernel for the whole call and exchange the all-loci
     steps' sums inside it, through each other's mailboxes (here: two processes on the one GPU, the mailboxes mapped
-    through hipIpc handles) — the single-rank trajectory again"""
-    one = run(1, str(tmp_path / "one"), 29911)[0]
-    two = run(2, str(tmp_path / "two"), 29912 + os.getpid() % 500, DIST_P2P="1")
+    through hipIpc handles) — the single-rank trajectory again.  program: with BPP's kernel and the program's moves (the
+    thetas' Gibbs draws and re-draws then come from sums that crossed the mailboxes)"""
+    extra = dict(DIST_PROGRAM="1") if program else {}
+    one = run(1, str(tmp_path / "one"), 29911, **extra)[0]
+    two = run(2, str(tmp_path / "two"), 29912 + os.getpid() % 500, DIST_P2P="1", **extra)
     assert one["kind"] == "persistent" and all(r["kind"] == "persistent" for r in two)
     assert two[0]["taus"] == two[1]["taus"] and two[0]["thetas"] == two[1]["thetas"]
     for r in two:
