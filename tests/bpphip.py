@@ -137,6 +137,15 @@ def run_program(binary, ctl_text, files, timeout=900, env=None):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def run_both(ctl_text, files, timeout=900):
+    """the unmodified program (host CPU) and bpp_hip (the same program on the library) side by side — they share nothing"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        a = ex.submit(run_program, REF_BIN, ctl_text, files, timeout)
+        b = ex.submit(run_program, HIP_BIN, ctl_text, files, timeout)
+        return a.result(), b.result()
+
+
 def simulate(ctl_text, timeout=600, binary=None):
     """the reference's own simulator (`bpp --simulate`; binary = HIP_BIN: the same simulator with its P-matrices made by
     the library): returns {file name: text} of the alignment and the Imap (+ the model-parameter file if one is written)"""
@@ -170,9 +179,8 @@ def mcmc_table(text):
 def compare_runs(ctl_text, files, timeout=900):
     """both programs on the same control file; returns a dict with the two log-L0, the lnL columns' largest relative
     difference, the largest relative difference over all columns, and whether mcmc.txt is byte-identical"""
-    rc0, out0, f0 = run_program(REF_BIN, ctl_text, files, timeout)
+    (rc0, out0, f0), (rc1, out1, f1) = run_both(ctl_text, files, timeout)
     assert rc0 == 0, out0[-2000:]
-    rc1, out1, f1 = run_program(HIP_BIN, ctl_text, files, timeout)
     assert rc1 == 0, out1[-2000:]
     assert "Likelihood back-end: bpp_amd" in out1
     m0, m1 = f0["out.mcmc.txt"], f1["out.mcmc.txt"]
@@ -193,9 +201,8 @@ _NUM = re.compile(r"-?\d+\.\d+(?:[eE][-+]?\d+)?")
 def compare_text_runs(ctl_text, files, timeout=900):
     """as compare_runs for sample files that are not tables (species trees of A01 / A10 / A11 with their annotations):
     the text around the decimal numbers must be the same, the numbers are compared relatively"""
-    rc0, out0, f0 = run_program(REF_BIN, ctl_text, files, timeout)
+    (rc0, out0, f0), (rc1, out1, f1) = run_both(ctl_text, files, timeout)
     assert rc0 == 0, out0[-2000:]
-    rc1, out1, f1 = run_program(HIP_BIN, ctl_text, files, timeout)
     assert rc1 == 0, out1[-2000:]
     assert "Likelihood back-end: bpp_amd" in out1
     m0, m1 = f0["out.mcmc.txt"], f1["out.mcmc.txt"]
