@@ -45,6 +45,7 @@ struct BArgs
   const double * lnl_new;                 // [T] lnL of the pending step's evaluation (task = locus)
   double * hast, * logpr_new;             // [T] Hastings term / proposed MSC density of the step being proposed
   double * delta;                         // [T] an all-loci step: this locus's density + Jacobian term
+  double * lnl_cur;                       // [T] ... and its current lnL (the sum kernel reads compact arrays)
   uint8_t * active;                       // [T] the locus has a likelihood evaluation pending
   const uint32_t * flag; uint32_t epoch;  // an all-loci step was REJECTED when *flag == epoch
   // the step's records: ops[op_rng[2 i] .. op_rng[2 i + 1]), root_clv[i], root_scaler[i]; matrix entries [i maxmat + j]
@@ -335,6 +336,7 @@ __device__ void big_propose(const BArgs & A, const uint32_t i, BTree & t, const 
     const double lp_new = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0, W);
     A.logpr_new[i] = lp_new;
     A.delta[i] = ((lp_new - t.logpr) + below*lminf) + above*lmaxf;
+    A.lnl_cur[i] = t.lnl;
     if (above + below)
     {
       for (int k = 0; k < n; ++k) { if (isbr[k]) br[nb++] = k; if (isnd[k]) nd[nn++] = k; }
@@ -359,6 +361,7 @@ __device__ void big_propose(const BArgs & A, const uint32_t i, BTree & t, const 
     const double lp_new = tree_logpr(t, sp, s_tau, nullptr, nullptr, 0, W);
     A.logpr_new[i] = lp_new;
     A.delta[i] = (lp_new - t.logpr) + (double)ninner*A.mix_lnc;
+    A.lnl_cur[i] = t.lnl;
     install(t, br, nb, nd, nn);
     evaluate = true;
   }

@@ -35,7 +35,7 @@ static int gb_upload(bpa_sampler * s)
   if (!upload(s->b_dev, s->b_trees.data(), T) || !s->b_undo.reserve(T) || !upload(s->g_tlocus, tl.data(), T) || !upload(s->g_tpat, tp.data(), T + 1) ||
       !upload(s->b_thr, thr.data(), thr.size()) || !s->g_rscaler.reserve(T) || !s->g_ops20.reserve((size_t)T*s->g_maxops) ||
       !s->g_oprng.reserve((size_t)2*T) || !s->g_root20.reserve(T) || !s->g_mtask.reserve(nmat) || !s->g_mpm.reserve(nmat) || !s->g_len.reserve(nmat) ||
-      !s->g_lnl.reserve(T) || !s->g_hast.reserve(T) || !s->g_logpr.reserve(T) || !s->g_delta.reserve(T) || !s->g_active.reserve(T) ||
+      !s->g_lnl.reserve(T) || !s->g_lnlcur.reserve(T) || !s->g_hast.reserve(T) || !s->g_logpr.reserve(T) || !s->g_delta.reserve(T) || !s->g_active.reserve(T) ||
       !s->g_site.reserve(off) || !upload(s->flag, zero2, 1) || !upload(s->counters, s->h_counters, 4) || !s->mix_sum.reserve(1) ||
       !upload(s->taus, s->h_taus.data(), s->h_taus.size()) || !s->pop_t2h.reserve((size_t)T*smp::MAXPOP) ||
       !s->pop_nc.reserve((size_t)T*smp::MAXPOP) || !s->theta_sums.reserve(smp::MAXPOP))
@@ -64,7 +64,7 @@ static int gb_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   gbig::BArgs a{};
   a.trees = s->b_dev.p; a.undo = s->b_undo.p; a.T = s->nloci; a.mode = mode; a.k = k;
   a.pend = s->g_pend; a.lnl_new = s->g_lnl.p; a.hast = s->g_hast.p; a.logpr_new = s->g_logpr.p; a.delta = s->g_delta.p;
-  a.active = s->g_active.p; a.flag = s->flag.p; a.epoch = s->epoch;
+  a.active = s->g_active.p; a.flag = s->flag.p; a.epoch = s->epoch; a.lnl_cur = s->g_lnlcur.p;
   a.ops = s->g_ops20.p; a.op_rng = s->g_oprng.p; a.root_clv = s->g_root20.p; a.root_scaler = s->g_rscaler.p;
   a.mat_task = s->g_mtask.p; a.mat_pm = s->g_mpm.p; a.mat_length = s->g_len.p; a.maxmat = s->g_maxmat; a.maxops = s->g_maxops;
   a.taus = s->taus.p; a.tau_q = k; a.tau_u = tau_u; a.mix_c = mix_c; a.mix_lnc = mix_lnc;
@@ -111,7 +111,7 @@ static int gb_decide(bpa_sampler * s, double uacc, int tau_q, double win_u, doub
 {
   bpa_engine * e = s->eng;
   s->epoch++;
-  hipLaunchKernelGGL((gsm::gsum_decide_kernel<gbig::BTree>), dim3(1), dim3(1024), 0, e->stream, (const gbig::BTree *)s->b_dev.p, s->g_lnl.p, s->g_delta.p,
+  hipLaunchKernelGGL(gsm::gsum_decide_kernel, dim3(1), dim3(1024), 0, e->stream, (const double *)s->g_lnlcur.p, s->g_lnl.p, s->g_delta.p,
                      s->g_active.p, s->nloci, (double *)nullptr, 1, uacc, s->epoch, s->flag.p, s->counters.p, s->taus.p, s->sp, tau_q, win_u, mix_c, mix_lnc);
   HIPCHK(hipGetLastError());
   s->launches++;

@@ -74,6 +74,7 @@ struct GArgs
   const double * lnl_new;                 // [T] lnL of the pending step's evaluation (task = locus)
   double * hast, * logpr_new;             // [T] Hastings term / proposed MSC density of the step being proposed (read back when it is settled)
   double * delta;                         // [T] an all-loci step: this locus's density + Jacobian term
+  double * lnl_cur;                       // [T] an all-loci step: the locus's current lnL, next to delta (the sum kernel reads compact arrays, not the trees)
   uint8_t * active;                       // [T] the locus has a likelihood evaluation pending
   const uint32_t * flag; uint32_t epoch;  // an all-loci step was REJECTED when *flag == epoch
   // the step's records for the engine's kernels
@@ -317,6 +318,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
       const double lp_new = gdensity(S, T, cn, sp, spl, s_tau, nullptr, nullptr, 0);
       A.logpr_new[i] = lp_new;
       A.delta[i] = ((lp_new - logpr_cur) + below*lminf) + above*lmaxf;          // p_delta of the host driver
+      A.lnl_cur[i] = lnl_cur;
       if (ndm) smp::install<TT>(S, T, brm, ndm);
       else { S.brm = 0; S.nops = 0; ok = false; }                              // no gene node moves here: only the density changes
     }
@@ -378,6 +380,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
       const double lp_new = gdensity(S, T, cn, sp, spl, s_tau, nullptr, nullptr, 0);
       A.logpr_new[i] = lp_new;
       A.delta[i] = (lp_new - logpr_cur) + (double)ninner*A.mix_lnc;
+      A.lnl_cur[i] = lnl_cur;
       smp::install<TT>(S, T, brm, ndm);
     }
     if (ok && MODE <= 1)
@@ -488,8 +491,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
 }
 
 // an all-loci step: the sum of the loci's terms (fixed order) and the ONE decision (tau_step / mix_step of a00_driver.c)
-template <class TREE>                     // (GTree, or the big-tree sampler's BTree: only the current lnL is read)
-__global__ void __launch_bounds__(1024) gsum_decide_kernel(const TREE * __restrict__ trees, const double * __restrict__ lnl_new,
+__global__ void __launch_bounds__(1024) gsum_decide_kernel(const double * __restrict__ lnl_cur, const double * __restrict__ lnl_new,
                                                            const double * __restrict__ delta, const uint8_t * __restrict__ active,
                                                            uint32_t T, double * sum_out, int decide_on, double u, uint32_t epoch,
                                                            uint32_t * flag, uint32_t * counters, double * taus, Species sp, int tau_q,
@@ -497,7 +499,7 @@ __global__ void __launch_bounds__(1024) gsum_decide_kernel(const TREE * __restri
 {
   __shared__ double sh[1024];
   double acc = 0;
-  for (uint32_t i = threadIdx.x; i < T; i += 1024) acc += (active[i] ? lnl_new[i] - trees[i].lnl : 0.0) + delta[i];
+  for (uint32_t i = threadIdx.x; i < T; i += 1024) acc += (active[i] ? lnl_new[i] - lnl_cur[i] : 0.0) + delta[i];
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (uint32_t w = 512; w > 0; w >>= 1)

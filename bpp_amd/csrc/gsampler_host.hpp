@@ -96,7 +96,7 @@ static int gs_upload(bpa_sampler * s)
   }
   uint32_t zero2[2] = {0, 0};
   if (!upload(s->g_dev, s->g_trees.data(), T) || !s->g_undo.reserve(T) || !upload(s->g_loc, loc.data(), T) ||
-      !s->g_lnl.reserve(T) || !s->g_hast.reserve(T) || !s->g_logpr.reserve(T) || !s->g_delta.reserve(T) || !s->g_active.reserve(T) ||
+      !s->g_lnl.reserve(T) || !s->g_lnlcur.reserve(T) || !s->g_hast.reserve(T) || !s->g_logpr.reserve(T) || !s->g_delta.reserve(T) || !s->g_active.reserve(T) ||
       !s->g_site.reserve(npat) || !s->g_recs.reserve(nrec) || !s->g_mat2.reserve(nmat) || !s->g_len.reserve(nmat) ||
       !upload(s->g_bmo, bmo.data(), bmo.size()) || !s->g_lograt.reserve(gsm::NN*gsm::NN) ||
       !upload(s->flag, zero2, 1) || !upload(s->counters, s->h_counters, 4) || !s->mix_sum.reserve(1) ||
@@ -141,7 +141,7 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   gsm::GArgs a{};
   a.trees = s->g_dev.p; a.undo = s->g_undo.p; a.loc = s->g_loc.p; a.T = s->nloci; a.mode = mode; a.k = k;
   a.pend = s->g_pend; a.lnl_new = s->g_lnl.p; a.hast = s->g_hast.p; a.logpr_new = s->g_logpr.p; a.delta = s->g_delta.p;
-  a.active = s->g_active.p; a.flag = s->flag.p; a.epoch = s->epoch;
+  a.active = s->g_active.p; a.flag = s->flag.p; a.epoch = s->epoch; a.lnl_cur = s->g_lnlcur.p;
   a.recs2 = s->g_recs.p; a.units = s->g_units; a.mat2 = s->g_mat2.p; a.mat_length = s->g_len.p; a.maxmat = s->g_maxmat;
   a.taus = s->taus.p; a.lograt = s->g_lograt.p; a.tau_q = k; a.tau_u = tau_u; a.mix_c = mix_c; a.mix_lnc = mix_lnc;
   a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p;
@@ -251,12 +251,12 @@ static int gs_decide(bpa_sampler * s, double uacc, int tau_q, double win_u, doub
   bpa_engine * e = s->eng;
   s->epoch++;
   if (!s->allreduce)
-    hipLaunchKernelGGL((gsm::gsum_decide_kernel<gsm::GTree>), dim3(1), dim3(1024), 0, e->stream, (const gsm::GTree *)s->g_dev.p, s->g_lnl.p, s->g_delta.p, s->g_active.p, s->nloci,
+    hipLaunchKernelGGL(gsm::gsum_decide_kernel, dim3(1), dim3(1024), 0, e->stream, (const double *)s->g_lnlcur.p, s->g_lnl.p, s->g_delta.p, s->g_active.p, s->nloci,
                        (double *)nullptr, 1, uacc, s->epoch, s->flag.p, s->counters.p, s->taus.p, s->sp, tau_q, win_u, mix_c, mix_lnc);
   else
   {
     double * out = s->sum_ext ? s->sum_ext : s->mix_sum.p;
-    hipLaunchKernelGGL((gsm::gsum_decide_kernel<gsm::GTree>), dim3(1), dim3(1024), 0, e->stream, (const gsm::GTree *)s->g_dev.p, s->g_lnl.p, s->g_delta.p, s->g_active.p, s->nloci,
+    hipLaunchKernelGGL(gsm::gsum_decide_kernel, dim3(1), dim3(1024), 0, e->stream, (const double *)s->g_lnlcur.p, s->g_lnl.p, s->g_delta.p, s->g_active.p, s->nloci,
                        out, 0, uacc, s->epoch, s->flag.p, s->counters.p, s->taus.p, s->sp, tau_q, win_u, mix_c, mix_lnc);
     if (!s->allreduce(s->allreduce_ctx, out, 1u, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
     hipLaunchKernelGGL(smp::decide_kernel, dim3(1), dim3(1), 0, e->stream, out, uacc, s->epoch, s->flag.p, s->counters.p, s->taus.p, s->sp,

@@ -2702,12 +2702,15 @@ __device__ void eigen_sym(double (&a)[N][N], double (&d)[N], double (&e)[N])
 }
 
 // freqs/subst -> eigenvals, eigenvecs (u_m[k] sqrt(pi_k)), inv_eigenvecs (u_m[j]/sqrt(pi_j))
+// work space of one lane's eigensystem: the solver indexes it with run-time indices, so as private arrays it lives in scratch
+// memory (a round trip through the memory hierarchy per access); the 4-state kernels keep one per lane in LDS instead
+template <int N> struct EigenWork { double a[N][N], d[N], e[N]; double pad_; };
 template <int N>
 __device__ void update_eigen_dev(const double * __restrict__ freqs, const double * __restrict__ subst,
                                  double * __restrict__ evals, double * __restrict__ evecs,
-                                 double * __restrict__ ievecs)
+                                 double * __restrict__ ievecs, EigenWork<N> & W)
 {
-  double a[N][N], d[N], e[N];
+  double (&a)[N][N] = W.a; double (&d)[N] = W.d; double (&e)[N] = W.e;
   constexpr int NP = N*(N-1)/2;
   const double last = subst[NP-1];
   for (int i = 0; i < N; ++i)
@@ -2741,12 +2744,21 @@ __device__ void update_eigen_dev(const double * __restrict__ freqs, const double
   }
 }
 
+template <int N>
+__device__ void update_eigen_dev(const double * __restrict__ freqs, const double * __restrict__ subst,
+                                 double * __restrict__ evals, double * __restrict__ evecs, double * __restrict__ ievecs)
+{
+  EigenWork<N> w;
+  update_eigen_dev<N>(freqs, subst, evals, evecs, ievecs, w);
+}
+
 // refresh the eigensystems of the listed loci (locus.c:2462-2476)
 // SK = 4 / 20: every listed locus has that many states (the instance carries only that eigensolver: the 20-state one needs
 // 10 KB of scratch per lane, which the all-in-one kernel reserved for 4-state loci too); SK = 0: mixed list
 template <int SK>
 __global__ void __launch_bounds__(64) eigen_kernel(const LocusDev * loci, const uint32_t * list, uint32_t count)
 {
+  __shared__ EigenWork<4> s_w4[SK == 20 ? 1 : 64];
   const uint32_t i = blockIdx.x*64 + threadIdx.x;
   if (i >= count) return;
   const LocusDev & L = loci[list[i]];
@@ -2755,7 +2767,7 @@ __global__ void __launch_bounds__(64) eigen_kernel(const LocusDev * loci, const 
   {
     double * pm = L.par + par_matrix(R, S, m);
     if (SK == 4 || (SK == 0 && S == 4))
-      update_eigen_dev<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
+      update_eigen_dev<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4), s_w4[SK == 20 ? 0 : threadIdx.x]);
     else
       update_eigen_dev<20>(pm + pm_freqs(20), pm + pm_subst(20), pm + pm_evals(20), pm + pm_evecs(20), pm + pm_ievecs(20));
   }

@@ -1135,7 +1135,7 @@ struct bpa_sampler
   std::vector<gsm::GTree> g_trees;      // host copies (instead of h_trees)
   DevBuf<gsm::GTree> g_dev, g_undo;
   DevBuf<gsm::GLocus> g_loc;
-  DevBuf<double> g_lnl, g_hast, g_logpr, g_delta, g_site, g_len, g_lograt;
+  DevBuf<double> g_lnl, g_lnlcur, g_hast, g_logpr, g_delta, g_site, g_len, g_lograt;
   DevBuf<uint8_t> g_active;
   DevBuf<uint4> g_recs;
   DevBuf<MatRec2> g_mat2;
@@ -1290,7 +1290,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   for (auto & t : s->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   s->blk_task_off.free(); s->lane_rec.free(); s->task_rec.free(); s->flag.free();
   s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free(); s->uc.free();
-  s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
+  s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_lnlcur.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
   s->g_len.free(); s->g_lograt.free(); s->g_active.free(); s->g_recs.free(); s->g_mat2.free(); s->g_bmo.free();
   s->g_sm.free(); s->g_sm_old.free(); s->g_ids.free();
   s->b_dev.free(); s->b_undo.free(); s->b_thr.free();
