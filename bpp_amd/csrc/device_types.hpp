@@ -176,5 +176,7 @@ struct PlanDev
   uint32_t         npatterns;
   uint32_t         nmat;
   uint32_t         pad;
+  uint32_t         blk0;        // compact path: the launch covers workgroups blk0 .. blk0 + gridDim.x of the packing (a half-batch launch)
+  uint32_t         ent0;        // dense P-matrix launch: first branch entry of the launch's range
   double           bfbeta;
 };

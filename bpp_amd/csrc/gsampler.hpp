@@ -63,6 +63,7 @@ struct GArgs
   GTree * trees, * undo;                  // [T] current (or proposed, while a step is being evaluated) / the state before the pending step
   const GLocus * loc;                     // [T]
   uint32_t T;
+  uint32_t i0, iend;                      // the launch's loci [i0, iend) (a half-batch launch; all loci: 0, T)
   uint32_t mode;                          // 0 GAGE k, 1 GSPR k, 2 TAU, 3 MIX, 4 settle (+ THETA statistics), 5 start-up evaluation,
                                           // 6 base frequency k, 7 exchangeability k, 8 alpha (locus.c:2782, 3168; prop_gamma.c:52)
   uint32_t k;
@@ -166,8 +167,8 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
   constexpr int TN = 2*TT;
   __shared__ double s_lograt[TN*TN];
   __shared__ Species s_sp;
-  const uint32_t lane = threadIdx.x, i = blockIdx.x*GBS + lane;
-  const bool valid = i < A.T;
+  const uint32_t lane = threadIdx.x, i = A.i0 + blockIdx.x*GBS + lane;
+  const bool valid = i < A.iend;
   {
     const uint32_t * src = reinterpret_cast<const uint32_t *>(&A.sp);
     uint32_t * dst = reinterpret_cast<uint32_t *>(&s_sp);

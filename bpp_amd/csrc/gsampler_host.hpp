@@ -30,10 +30,42 @@ static int gs_refresh_eigen(bpa_sampler * s)
     for (unsigned i = 0; i < s->nloci; ++i) ids[i] = s->loci[i]->id;
     if (!upload(s->g_ids, ids.data(), s->nloci)) return 0;
   }
-  hipLaunchKernelGGL(eigen_kernel<4>, dim3((s->nloci + 63)/64), dim3(64), 0, e->stream, e->d_loci.p, s->g_ids.p, (uint32_t)s->nloci);     // the generic sampler's loci are 4-state
+  // the generic sampler's loci are 4-state; forked: each half on its own stream
+  for (int h = 0; h < (s->g_forked ? 2 : 1); ++h)
+  {
+    const unsigned lo = h ? s->g_isplit : 0u, hi = s->g_forked && !h ? s->g_isplit : s->nloci;
+    hipLaunchKernelGGL(eigen_kernel<4>, dim3((hi - lo + 63)/64), dim3(64), 0, h ? s->g_stream2 : e->stream, e->d_loci.p, s->g_ids.p + lo, (uint32_t)(hi - lo));
+    s->launches++;
+  }
   HIPCHK(hipGetLastError());
   s->g_eigen_dirty = false;
-  s->launches++;
+  return 1;
+}
+
+// The per-locus steps (gene-tree ages, SPR, the substitution-parameter moves) of the two halves of the loci are
+// independent chains of launches — propose, P-matrices, node updates + lnL, settle-and-propose ... — so they go to two
+// streams: one half's (latency-bound, 16-wave) step kernel runs under the other half's likelihood kernels, which are
+// throughput-bound (config 3: 88 us for all loci, 48 us for half of them).  Measured on config 3: 175.6 -> 185.4 it/s with
+// the streams left to themselves — they settle into running nearly in phase, and the step kernel under load takes 30-80 us
+// instead of 29; making the halves' likelihood launches take turns through a pair of events (before the P-matrix
+// launch: 169 it/s, before the node-update launch: 178) or starting the second stream half a step late (184-185) was no
+// better, so there are no events between the halves.  All-loci steps (THETA, TAU, MIX, the downloads) run on the engine's
+// stream over all loci after a join; the trajectory does not depend on any of this.
+static int gs_fork(bpa_sampler * s)
+{
+  if (s->g_forked) return 1;
+  HIPCHK(hipEventRecord(s->g_ev_fork, s->eng->stream));
+  HIPCHK(hipStreamWaitEvent(s->g_stream2, s->g_ev_fork, 0));
+  s->g_forked = true;
+  return 1;
+}
+
+static int gs_join(bpa_sampler * s)
+{
+  if (!s->g_forked) return 1;
+  HIPCHK(hipEventRecord(s->g_ev_join, s->g_stream2));
+  HIPCHK(hipStreamWaitEvent(s->eng->stream, s->g_ev_join, 0));
+  s->g_forked = false;
   return 1;
 }
 
@@ -129,6 +161,27 @@ static int gs_upload(bpa_sampler * s)
   hipLaunchKernelGGL(gsm::glograt_kernel, dim3(1), dim3(gsm::NN*gsm::NN), 0, e->stream, s->g_lograt.p);
   HIPCHK(hipGetLastError());
   s->epoch = 0; s->mix_pending = false; s->g_pend = 0;
+  // two half-batches when there is enough of the packing to halve and the sampler's loci are in slot order
+  s->g_split = false; s->g_forked = false;
+  static const bool no_split = getenv("BPA_GS_NOSPLIT") != nullptr;
+  if (!s->g_s20 && !s->g_alljc && !no_split && e->usedata && T >= 2)
+  {
+    bool mono = true;
+    for (unsigned i = 0; i + 1 < T && mono; ++i) mono = loc[i].slot < loc[i + 1].slot;
+    // the workgroup of the packing that holds the middle locus starts the second half
+    auto block_of = [&](uint32_t slot) { return (unsigned)(std::upper_bound(e->h_blk_slot_off.begin(), e->h_blk_slot_off.end(), slot) - e->h_blk_slot_off.begin()) - 1u; };
+    const unsigned bs = block_of(loc[T/2].slot), ss = e->h_blk_slot_off[bs];
+    const unsigned span = block_of(loc[T - 1].slot) + 1u - block_of(loc[0].slot);
+    unsigned is = 0;
+    while (is < T && loc[is].slot < ss) ++is;
+    if (mono && span >= 96 && is > 0 && is < T)
+    {
+      if (!s->g_stream2) HIPCHK(hipStreamCreateWithFlags(&s->g_stream2, hipStreamNonBlocking));
+      if (!s->g_ev_fork) HIPCHK(hipEventCreateWithFlags(&s->g_ev_fork, hipEventDisableTiming));
+      if (!s->g_ev_join) HIPCHK(hipEventCreateWithFlags(&s->g_ev_join, hipEventDisableTiming));
+      s->g_split = true; s->g_isplit = is; s->g_ssplit = ss; s->g_bsplit = bs;
+    }
+  }
   s->uploaded = true;
   return 1;
 }
@@ -138,6 +191,8 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
 {
   bpa_engine * e = s->eng;
   if (s->g_pack_epoch != e->pack_epoch) return fail("bpa_sampler: the engine's loci changed since the sampler was set up");
+  if (s->g_split && (mode <= 1 || mode >= 6)) { if (!gs_fork(s)) return 0; }
+  else if (!gs_join(s)) return 0;
   gsm::GArgs a{};
   a.trees = s->g_dev.p; a.undo = s->g_undo.p; a.loc = s->g_loc.p; a.T = s->nloci; a.mode = mode; a.k = k;
   a.pend = s->g_pend; a.lnl_new = s->g_lnl.p; a.hast = s->g_hast.p; a.logpr_new = s->g_logpr.p; a.delta = s->g_delta.p;
@@ -154,21 +209,29 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   // a frequency / exchangeability step — proposed now, or rolled back now for the loci that rejected it — leaves
   // parameter blocks whose eigensystems are stale: refreshed before the next evaluation (gs_eval)
   if (mode == 6 || mode == 7 || (s->g_pend == 4 && (s->g_pend_mode == 6 || s->g_pend_mode == 7))) s->g_eigen_dirty = true;
+  for (int h = 0; h < (s->g_forked ? 2 : 1); ++h)
   {
-    const dim3 grid((s->nloci + gsm::GBS - 1)/gsm::GBS), block(gsm::GBS);
+    a.i0 = h ? s->g_isplit : 0u; a.iend = s->g_forked && !h ? s->g_isplit : s->nloci;
+    const dim3 grid((a.iend - a.i0 + gsm::GBS - 1)/gsm::GBS), block(gsm::GBS);
+    hipStream_t st = h ? s->g_stream2 : e->stream;
     switch (a.mode)
     {
-#define GS_CASE(M_) case M_: if (s->maxtips <= 8) hipLaunchKernelGGL((gsm::gstep_kernel<M_, 8>), grid, block, 0, e->stream, a); \
-                            else                 hipLaunchKernelGGL((gsm::gstep_kernel<M_, 16>), grid, block, 0, e->stream, a); break
+#define GS_CASE(M_) case M_: if (s->maxtips <= 8) hipLaunchKernelGGL((gsm::gstep_kernel<M_, 8>), grid, block, 0, st, a); \
+                            else                 hipLaunchKernelGGL((gsm::gstep_kernel<M_, 16>), grid, block, 0, st, a); break
       GS_CASE(0); GS_CASE(1); GS_CASE(2); GS_CASE(3); GS_CASE(4); GS_CASE(5); GS_CASE(6); GS_CASE(7); GS_CASE(8);
 #undef GS_CASE
       default: return fail("bpa_sampler: unknown step mode");
     }
+    s->launches++;
   }
   HIPCHK(hipGetLastError());
   static const bool dbg_sync = getenv("BPA_GS_SYNC") != nullptr;        // diagnostics: wait for every launch and say which it was
-  if (dbg_sync) { HIPCHK(hipStreamSynchronize(e->stream)); fprintf(stderr, "[gs] step mode %u k %u pend %u done\n", mode, k, a.pend); }
-  s->launches++;
+  if (dbg_sync)
+  {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (s->g_forked) HIPCHK(hipStreamSynchronize(s->g_stream2));
+    fprintf(stderr, "[gs] step mode %u k %u pend %u done\n", mode, k, a.pend);
+  }
   s->g_pend = mode <= 1 ? 1u : (mode == 2 || mode == 3) ? 2u : mode == 5 ? 3u : mode >= 6 ? 4u : 0u;
   s->g_pend_mode = mode; s->g_pend_k = k;
   return 1;
@@ -232,6 +295,23 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
   else
   {
     d.pad = s->g_rmax;
+    if (s->g_forked)
+    {
+      for (int h = 0; h < 2; ++h)
+      {
+        const unsigned b0 = h ? s->g_bsplit : 0u, b1 = h ? e->pack_blocks : s->g_bsplit;
+        const unsigned e0 = (h ? s->g_ssplit : 0u)*s->g_maxmat, e1 = (h ? e->pack_slots : s->g_ssplit)*s->g_maxmat;
+        hipStream_t st = h ? s->g_stream2 : e->stream;
+        d.blk0 = b0; d.ent0 = e0;
+        d.flags = 1u;
+        hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3(((e1 - e0)*d.pad + 255u)/256u), dim3(256), 0, st, d, e1);
+        d.flags = 2u | 4u;
+        hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), dim3(b1 - b0), block, 0, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
+      }
+      HIPCHK(hipGetLastError());
+      s->launches += 4; s->g_evals += 2;
+      return 1;
+    }
     d.flags = 1u;
     hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((d.nmat*d.pad + 255u)/256u), dim3(256), 0, e->stream, d, d.nmat);
     d.flags = 2u | 4u;
@@ -328,7 +408,7 @@ static int gs_iterate(bpa_sampler * s, unsigned iterations)
     if (s->g_ft[0] > 0 || s->g_ft[1] > 0 || s->g_ft[2] > 0)
       for (bpa_locus * l : s->loci) l->host_par_stale = true;            // the device blocks moved ahead of the host mirrors
   }
-  return 1;
+  return gs_join(s);                 // whoever uses the engine's stream next sees both halves
 }
 
 // settle whatever is pending and bring the trees to the host

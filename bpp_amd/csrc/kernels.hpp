@@ -2238,7 +2238,7 @@ __device__ __forceinline__ bool getenv_klane_direct(const PlanDev & P) { return 
 __global__ void __launch_bounds__(256) pmatrix_s4_dense_kernel(const PlanDev P, const uint32_t nent)
 {
   const uint32_t rmax = P.pad ? P.pad : 1u, i = blockIdx.x*256u + threadIdx.x;
-  const uint32_t e = i/rmax, k = i % rmax;
+  const uint32_t e = P.ent0 + i/rmax, k = i % rmax;
   if (e >= nent) return;
   const u2v_t mm = *reinterpret_cast<const __attribute__((address_space(1))) u2v_t *>(reinterpret_cast<uintptr_t>(P.mat2 + e));
   if (mm.x == 0xffffffffu) return;                           // a hole of a device-written step image (gsampler.hpp)
@@ -2255,7 +2255,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(OCC ? O
 step_s4_klane_v2_kernel(const PlanDev P)
 {
   __shared__ double s_term[BS], s_tr[BS];
-  const uint32_t b = blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
+  const uint32_t b = P.blk0 + blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
   if (WITH_A)
   {
     if (!(P.flags & 1u)) return;

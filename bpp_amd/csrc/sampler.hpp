@@ -1136,6 +1136,12 @@ struct bpa_sampler
   DevBuf<gsm::GTree> g_dev, g_undo;
   DevBuf<gsm::GLocus> g_loc;
   DevBuf<double> g_lnl, g_lnlcur, g_hast, g_logpr, g_delta, g_site, g_len, g_lograt;
+  // two half-batches of the per-locus steps on two streams (gsampler_host.hpp: gs_fork / gs_join): loci [0, g_isplit) are the
+  // slots [0, g_ssplit) = workgroups [0, g_bsplit) of the engine's packing, the rest the other half
+  bool g_split = false, g_forked = false;
+  unsigned g_isplit = 0, g_ssplit = 0, g_bsplit = 0;
+  hipStream_t g_stream2 = nullptr;
+  hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
   DevBuf<uint8_t> g_active;
   DevBuf<uint4> g_recs;
   DevBuf<MatRec2> g_mat2;
@@ -1290,6 +1296,9 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   for (auto & t : s->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   s->blk_task_off.free(); s->lane_rec.free(); s->task_rec.free(); s->flag.free();
   s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free(); s->uc.free();
+  if (s->g_stream2) { (void)hipStreamSynchronize(s->g_stream2); (void)hipStreamDestroy(s->g_stream2); s->g_stream2 = nullptr; }
+  if (s->g_ev_fork) { (void)hipEventDestroy(s->g_ev_fork); s->g_ev_fork = nullptr; }
+  if (s->g_ev_join) { (void)hipEventDestroy(s->g_ev_join); s->g_ev_join = nullptr; }
   s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_lnlcur.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
   s->g_len.free(); s->g_lograt.free(); s->g_active.free(); s->g_recs.free(); s->g_mat2.free(); s->g_bmo.free();
   s->g_sm.free(); s->g_sm_old.free(); s->g_ids.free();

@@ -125,15 +125,23 @@ def _q_matrix(freqs, exch):
     return Q / -(freqs * np.diag(Q)).sum()
 
 
-def _evolve(left, right, times, root, sites, rng, freqs, Q, site_rate):
-    """states[node, site]"""
+def _evolve(left, right, times, root, sites, rng, freqs, Q, site_rate, eig=None):
+    """states[node, site].  eig: (lam, V, Vi) of Q when the caller has them (the same Q for every locus)"""
     S = len(freqs)
     n = len(left)
     states = np.zeros((n, sites), dtype=np.int8)
     states[root] = rng.choice(S, sites, p=freqs)
-    lam, V = np.linalg.eig(Q)
-    Vi = np.linalg.inv(V)
-    urates = np.unique(site_rate)
+    if eig is None:
+        lam, V = np.linalg.eig(Q)
+        Vi = np.linalg.inv(V)
+    else:
+        lam, V, Vi = eig
+    # the uniforms of a branch are drawn rate class by rate class (classes by increasing rate): one draw of `sites`
+    # numbers dealt out in that order is the same stream
+    urates, ridx = np.unique(site_rate, return_inverse=True)
+    order = np.argsort(ridx, kind="stable")
+    u_site = np.empty(sites)
+    cum = np.empty((len(urates), S, S))
     stack = [root]
     while stack:
         p = stack.pop()
@@ -141,15 +149,12 @@ def _evolve(left, right, times, root, sites, rng, freqs, Q, site_rate):
             if c < 0:
                 continue
             t = times[p] - times[c]
-            out = np.empty(sites, dtype=np.int8)
-            for r in urates:
-                m = site_rate == r
+            for k, r in enumerate(urates):
                 P = np.real((V * np.exp(lam * t * r)) @ Vi)
                 P = np.clip(P, 0, None)
-                cum = np.cumsum(P / P.sum(1, keepdims=True), axis=1)
-                u = rng.random(m.sum())
-                out[m] = (u[:, None] > cum[states[p][m]]).sum(1).clip(0, S - 1)
-            states[c] = out
+                cum[k] = np.cumsum(P / P.sum(1, keepdims=True), axis=1)
+            u_site[order] = rng.random(sites)
+            states[c] = np.minimum((u_site[:, None] > cum[ridx, states[p]]).sum(1), S - 1)
             stack.append(c)
     return states
 
@@ -191,12 +196,15 @@ def make_dataset(nloci, sites, taxa=4, model="jc69", rate_cats=1, alpha=0.5, the
     Q = _q_matrix(freqs, exch)
     rates = _discrete_gamma(alpha, rate_cats)
     alphabet = NT if dna else AA
+    letters = np.frombuffer(alphabet.encode(), dtype="S1")
+    lam, V = np.linalg.eig(Q)
+    eig = (lam, V, np.linalg.inv(V))
     out = []
     for _ in range(nloci):
         left, right, times, root = _msc_gene_tree(stree, theta, rng)
         site_rate = rates[rng.integers(0, rate_cats, sites)]
-        st = _evolve(left, right, times, root, sites, rng, freqs, Q, site_rate)
-        seqs = ["".join(alphabet[c] for c in st[i]) for i in range(taxa)]
+        st = _evolve(left, right, times, root, sites, rng, freqs, Q, site_rate, eig)
+        seqs = [letters[st[i]].tobytes().decode() for i in range(taxa)]
         pats, w = api.compress_site_patterns(seqs, dna, model == "jc69")
         out.append(dict(seqs=pats, weights=w, left=left, right=right, times=times, root=root,
                         states=S, rate_cats=rate_cats, model=model, freqs=freqs, exch=exch,

@@ -40,11 +40,12 @@ def walk(host, dev, iters, nloci, check_every=1):
         assert rel(a["lnl"], b["lnl"]) < 1e-11 and rel(a["logpr"], b["logpr"]) < 1e-11
 
 
-@pytest.mark.parametrize("taxa,model,R,nloci,iters,forced", [(4, "jc69", 1, 300, 5, True), (8, "gtr", 4, 60, 3, False),
+@pytest.mark.parametrize("taxa,model,R,nloci,iters,forced", [(4, "jc69", 1, 300, 5, True), (8, "gtr", 4, 60, 3, False), (8, "gtr", 4, 700, 2, False),
                                                              (8, "jc69", 1, 40, 3, True), (6, "lg", 4, 40, 3, False), (6, "lg", 1, 24, 2, False)])
 def test_generic_sampler_equals_host_driver(taxa, model, R, nloci, iters, forced):
     """(lg: amino-acid loci — BASELINE config 4's kind —, the steps written on the device as the records of the tiled 20-state
-    kernels: pmatrix_wg2_kernel, partials_lnl_pipe20_kernel)"""
+    kernels: pmatrix_wg2_kernel, partials_lnl_pipe20_kernel; 700 GTR loci: enough workgroups of the packing for the per-locus
+    steps to run as two half-batches on two streams — more launches, the same trajectory)"""
     eng = bpp_amd.Engine(0)
     data = synth.make_dataset(nloci, 300, taxa, model, R, seed=19)
     loci_a = tape.make_engine_loci(eng, data)
@@ -75,6 +76,8 @@ def test_generic_sampler_equals_host_driver(taxa, model, R, nloci, iters, forced
         assert rel(have, full) < 1e-12 and rel(t["lnl"], full) < 1e-12
     w = dev.work()
     assert w["sweeps"] >= iters*(3*taxa - 3) and w["node_updates"] > 0 and w["bytes"] > 0      # (generic path: launches of the step kernel)
+    if model == "gtr":
+        assert (w["sweeps"] >= iters*2*(3*taxa - 3)) == (nloci >= 700)                           # two half-batch launches per per-locus step
     dev.close(); host.close(); eng.close()
 
 
@@ -116,12 +119,13 @@ def test_generic_sampler_on_the_anopheles_data():
     dev.close(); host.close(); eng.close()
 
 
-def test_generic_sampler_with_parameter_moves_equals_host_driver():
+@pytest.mark.parametrize("nloci,iters", [(40, 3), (700, 2)])
+def test_generic_sampler_with_parameter_moves_equals_host_driver(nloci, iters):
     """the per-locus frequency / exchangeability / alpha moves (locus.c:2782-3419, prop_gamma.c:52-224) on the device —
     new values into the loci's parameter blocks, eigensystems and category rates refreshed there — against the host
     driver's param_step over libbpp_amd.so's setters: same decisions, same parameters (the category rates of a proposed
     alpha come from device libm here and from glibc there: equal to ~1e-14, not to the bit)"""
-    taxa, R, nloci, iters = 8, 4, 40, 3
+    taxa, R = 8, 4
     eng = bpp_amd.Engine(0)
     data = synth.make_dataset(nloci, 300, taxa, "gtr", R, seed=23)
     loci_a = tape.make_engine_loci(eng, data)
