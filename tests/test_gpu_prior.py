@@ -3,7 +3,7 @@ multispecies coalescent itself, so the gene trees they visit must look like dire
 how many coalescences fall inside each species.  With SEVERAL sequences per species the tip populations hold
 coalescences, prunings regraft across the divergences in both directions and the rubber band moves nodes of tip
 populations: bounds, population bookkeeping, Hastings ratios and Jacobians of every move are in this check, on each of the
-device implementations (persistent kernel: 6 tips; generic: 12 tips; big-tree: 24 tips)."""
+device implementations (persistent kernel: 6 tips; generic: 12 tips and 16 tips on an 8-species tree; big-tree: 24 tips)."""
 import numpy as np
 import pytest
 
@@ -17,6 +17,8 @@ CASES = {
     # species tree (stree->nodes order), sequences per species
     "persistent-2x3": dict(parent=[2, 2, -1], tau=[0, 0, 0.003], per=3, kind="persistent", nloci=1600, burn=40, snaps=14),
     "generic-3x4": dict(parent=[3, 3, 4, 4, -1], tau=[0, 0, 0, 0.002, 0.004], per=4, kind="generic", nloci=1200, burn=40, snaps=12),
+    "generic-8x2": dict(parent=[8, 8, 9, 9, 11, 11, 12, 12, 10, 10, 14, 13, 13, 14, -1],
+                        tau=[0]*8 + [0.001, 0.0012, 0.0022, 0.0009, 0.0011, 0.002, 0.004], per=2, kind="generic", nloci=900, burn=40, snaps=10),
     "big-4x6": dict(parent=[4, 4, 5, 6, 5, 6, -1], tau=[0, 0, 0, 0, 0.0015, 0.003, 0.0045], per=6, kind="big", nloci=500, burn=30, snaps=10),
 }
 

@@ -89,13 +89,13 @@ def test_chain_launch_equals_step_by_step(taxa, scaling, nloci):
     step's per-locus lnL, and the CLVs / scalers / P-matrices left behind, are the bits of the launches one by one"""
     data = synth.make_dataset(nloci, 500, taxa, "jc69", 1, seed=33)
     runs = []
+    sch = tape.make_schedule(data, seed=9, scaling=scaling)           # (the same steps for both runs: indices only)
+    steps = [sch.initial_step()]
+    for _ in range(2):
+        steps += sch.iteration()
     for chained in (False, True):
         eng = bpp_amd.Engine(0)
         loci = tape.make_engine_loci(eng, data, scaling)
-        sch = tape.make_schedule(data, seed=9, scaling=scaling)
-        steps = [sch.initial_step()]
-        for _ in range(2):
-            steps += sch.iteration()
         plans = []
         for st in steps:
             p = tape.plan_for_step(eng, loci, st)
