@@ -409,8 +409,18 @@ def run_host_control(eng, cfg, data, threads, iters=30, warm=3):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import hostdrv
     from bpp_amd import synth
-    loci = make_loci(eng, data)
-    g = hostdrv.hip_driver(eng, loci, data, seed=1)
+    cohorts = not os.environ.get("A00_NO_COHORTS") and len(data) >= 64
+    if cohorts:
+        # two cohorts of loci on two engines of this GPU (a00_set_cohorts): one cohort's step is proposed and marshalled
+        # while the other's launch runs — the same trajectory as one engine (tests/test_gpu_host_driver.py)
+        import bpp_amd
+        eng2 = bpp_amd.Engine(0)
+        split = len(data) // 2
+        loci = make_loci(eng, data[:split]) + make_loci(eng2, data[split:])
+        g = hostdrv.hip_driver_cohorts([eng, eng2], loci, data, split, seed=1)
+    else:
+        loci = make_loci(eng, data)
+        g = hostdrv.hip_driver(eng, loci, data, seed=1)
     g.set_threads(threads)
     parent, tau, theta = synth.species_tree_arrays(cfg["taxa"])
     g.set_species_tree(parent, tau, theta)
@@ -429,12 +439,16 @@ def run_host_control(eng, cfg, data, threads, iters=30, warm=3):
     rate = float(np.median(rates))
     p, a, st = g.counters()
     g.close()
-    return dict(iterations_per_s=round(rate, 2), ms_per_iteration=round(1e3 / rate, 3), iterations=iters, blocks=len(rates),
+    if cohorts:
+        eng2.close()
+    return dict(cohorts=2 if cohorts else 1, iterations_per_s=round(rate, 2), ms_per_iteration=round(1e3 / rate, 3), iterations=iters, blocks=len(rates),
                 spread=dict(min=round(min(rates), 2), max=round(max(rates), 2)),
                 host_threads=threads, launches_per_iteration=round(st / (5 * iters + warm), 1), acceptance=round(a / max(p, 1), 3),
                 note="host MCMC control in C (csrc/host/a00_driver.c, per-locus loops on OpenMP worker threads; the trajectory does "
                      "not depend on their number), one batched launch + one synchronisation + 80 KB D2H per proposal step: the "
-                     "PCIe-inclusive rate of the drop-in architecture with the control left on the host")
+                     "PCIe-inclusive rate of the drop-in architecture with the control left on the host"
+                     + ("; the loci in two cohorts on two engines of the GPU: a per-locus step of one cohort is proposed and marshalled while "
+                        "the other's launch runs (a00_set_cohorts; `launches_per_iteration` counts both cohorts' launches)" if cohorts else ""))
 
 
 def dominant_kernel(cfg, one_gpu=True):
@@ -854,6 +868,10 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
         achieved = bytes_per_launch / (us * 1e-6) / 1e9
         kern = dominant_kernel(cfg)
         traffic, src = traffic_from_profiles("c3" if gtr else "c4", kern) if args.loci is None else (None, None)
+        if traffic and smp.streams() == 2:
+            # the profile's dispatches are whole-batch launches (tape + BPA_GS_NOSPLIT=1 sampler); the launches timed here
+            # cover half the loci: no PMC figure for a launch of this size
+            traffic, src = None, f"{src}: {traffic} B per launch over ALL loci; the launches timed here are half-batches"
         roofline = dict(bound="hbm", kernel=kern, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=src, avg_kernel_us=round(us, 3),
                         algorithmic_bytes_per_launch=round(bytes_per_launch), launches=tm["sweep_launches"] + tm["allloci_launches"],
@@ -861,7 +879,11 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
                         timing=f"hipExtLaunchKernelGGL start/stop events on the engine stream, every {args.event_stride}-th launch of the step kernel in the timed region",
                         note="the generic device-resident sampler (csrc/gsampler.hpp): every proposal step = one launch of a per-locus "
                              "proposal kernel (trees in HBM) + the engine's step kernel over the records it wrote; algorithmic bytes = K1 + K2 "
-                             "of the node updates the proposals actually asked for (device counters)")
+                             "of the node updates the proposals actually asked for (device counters)"
+                             + ("; the per-locus steps run as TWO half-batch launches on two streams that overlap in time "
+                                "(csrc/gsampler_host.hpp gs_fork): a launch here covers half the loci and its duration includes the "
+                                "time it shares the chip with the other half's launch — the kernel alone: likelihood_only" if smp.streams() == 2 else ""),
+                        streams=smp.streams())
     elif kind == "persistent" and tm["sweep_launches"]:
         # every launch of the timed region carries events; a launch = up to 4096 whole iterations of all loci
         nl = tm["sweep_launches"]

@@ -123,6 +123,8 @@ def lib():
         "bpa_batch_begin": (i, [vp, C.POINTER(Batch)]),
         "bpa_batch_fill": (i, [vp, C.POINTER(Batch), u, u]),
         "bpa_batch_end": (i, [vp, C.POINTER(Batch), dp]),
+        "bpa_batch_end_async": (i, [vp, C.POINTER(Batch)]),
+        "bpa_batch_wait": (i, [vp, dp]),
         "bpa_engine_stage": (vp, [vp, vp, C.c_size_t]),
         "bpa_plan_set_params": (i, [vp, i, dp]),
         "bpa_plan_set_params_device": (i, [vp, i, vp]),
@@ -151,6 +153,7 @@ def lib():
         "bpa_sampler_timing": (i, [vp, dp, C.POINTER(C.c_ulong), dp, C.POINTER(C.c_ulong)]),
         "bpa_sampler_work": (i, [vp, dp, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]),
         "bpa_sampler_kind": (i, [vp]),
+        "bpa_sampler_streams": (i, [vp]),
         "bpa_sampler_set_p2p": (i, [vp, vp, u]),
         "bpa_sampler_set_proposal_kernel": (i, [vp, i]),
         "bpa_sampler_set_program_moves": (i, [vp, i, d]),
@@ -179,7 +182,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_compress_site_patterns", "bpa_locus_get_clv", "bpa_locus_set_clv",
             "bpa_locus_get_pmatrix", "bpa_locus_set_pmatrix", "bpa_locus_get_scaler", "bpa_locus_set_scaler",
             "bpa_locus_get_eigen", "bpa_plan_create", "bpa_plan_destroy", "bpa_plan_set_lengths",
-            "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate", "bpa_batch_begin", "bpa_batch_fill", "bpa_batch_end",
+            "bpa_plan_launch", "bpa_plan_get_lnl", "bpa_plan_lnl_device", "bpa_batch_evaluate", "bpa_batch_begin", "bpa_batch_fill", "bpa_batch_end", "bpa_batch_end_async", "bpa_batch_wait",
             "bpa_plan_enable_sum", "bpa_plan_enable_partial_sums", "bpa_plan_get_sum",
             "bpa_p2p_create", "bpa_p2p_connect", "bpa_p2p_allreduce", "bpa_p2p_status", "bpa_p2p_destroy", "bpa_p2p_set_timeout", "bpa_plans_launch_exchange", "bpa_plans_launch",
             "bpa_plan_set_params", "bpa_plan_set_params_device", "bpa_engine_stage",
@@ -189,7 +192,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_sampler_set_tau_prior", "bpa_sampler_get_taus", "bpa_sampler_get_tree_msc",
             "bpa_sampler_set_theta_prior", "bpa_sampler_get_thetas", "bpa_sampler_set_allreduce",
             "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary",
-            "bpa_sampler_enable_timing", "bpa_sampler_timing", "bpa_sampler_work", "bpa_sampler_kind", "bpa_sampler_set_p2p", "bpa_sampler_set_proposal_kernel",
+            "bpa_sampler_enable_timing", "bpa_sampler_timing", "bpa_sampler_work", "bpa_sampler_kind", "bpa_sampler_streams", "bpa_sampler_set_p2p", "bpa_sampler_set_proposal_kernel",
             "bpa_sampler_set_program_moves", "bpa_sampler_gibbs_counters",
             "bpa_sampler_set_subst_model", "bpa_sampler_get_subst_model", "bpa_sampler_set_subst_moves"]
 
@@ -695,6 +698,13 @@ class Sampler:
         if k < 0:
             raise BpaError(_err())
         return ("sweep", "generic", "persistent", "hybrid", "big")[k]
+
+    def streams(self):
+        """2 when the generic sampler runs its per-locus steps as two overlapping half-batch launches, else 1"""
+        k = lib().bpa_sampler_streams(self.h)
+        if k < 0:
+            raise BpaError(_err())
+        return k
 
     def close(self):
         if self.h and self.engine.h:

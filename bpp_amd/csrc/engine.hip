@@ -134,6 +134,7 @@ struct bpa_engine
   unsigned bc_T = 0, bc_units = 0, bc_nmat = 0, bc_npat = 0, bc_rmax = 1; bool bc_alljc = false;
   size_t bc_o_mat2 = 0, bc_o_len = 0, bc_o_bm = 0, bc_total = 0;
   std::vector<uint32_t> bc_pat;
+  unsigned bc_wait_T = 0; bool bc_wait_zero = false;      // bpa_batch_end_async's batch, collected by bpa_batch_wait
   bool bc_fast = false;                 // sized from the packing's own bounds: no pass over the batch in begin, its checks are fill's
   std::atomic<int> bc_fallback{0};      // fill found a locus the one-image path does not take
   std::vector<uint32_t> pack_slot_pat;  // first pattern of every slot in a term array over ALL packed loci
@@ -1621,7 +1622,7 @@ static int batch_fill_packed(bpa_engine * e, const bpa_batch_t * b, unsigned t0,
   return 1;
 }
 
-static int batch_end_packed(bpa_engine * e, const bpa_batch_t * b, double * lnl)
+static int batch_end_packed(bpa_engine * e, const bpa_batch_t * b, double * lnl, bool async = false)
 {
   if (e->bc_failed.load()) return fail(e->bc_msg.c_str());
   if (e->bc_fallback.load()) return 2;             // not the one-image path after all: the caller evaluates the batch the general way
@@ -1665,8 +1666,10 @@ static int batch_end_packed(bpa_engine * e, const bpa_batch_t * b, double * lnl)
     hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, d);
   }
   HIPCHK(hipGetLastError());
-  if (!lnl) { HIPCHK(hipStreamSynchronize(e->stream)); return 1; }
-  if (!e->usedata) { HIPCHK(hipStreamSynchronize(e->stream)); std::fill(lnl, lnl + T, 0.0); return 1; }
+  if (async) e->bc_wait_T = 0;
+  if (!lnl && !async) { HIPCHK(hipStreamSynchronize(e->stream)); return 1; }
+  if (!e->usedata) { HIPCHK(hipStreamSynchronize(e->stream)); if (async) { e->bc_wait_T = T; e->bc_wait_zero = true; } else std::fill(lnl, lnl + T, 0.0); return 1; }
+  e->bc_wait_zero = false;
   const size_t nb = (size_t)T*sizeof(double);
   if (nb > e->h_stage_bytes)
   {
@@ -1677,6 +1680,7 @@ static int batch_end_packed(bpa_engine * e, const bpa_batch_t * b, double * lnl)
     e->h_stage_bytes = want;
   }
   HIPCHK(hipMemcpyAsync(e->h_stage, e->d_step_lnl.p, nb, hipMemcpyDeviceToHost, e->stream));
+  if (async) { e->bc_wait_T = T; return 1; }       // bpa_batch_wait collects
   HIPCHK(hipStreamSynchronize(e->stream));
   std::memcpy(lnl, e->h_stage, nb);
   return 1;
@@ -1732,6 +1736,24 @@ extern "C" int bpa_batch_end(bpa_engine_t * e, const bpa_batch_t * b, double * l
 {
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   return batch_end_packed(e, b, lnl);
+}
+
+extern "C" int bpa_batch_end_async(bpa_engine_t * e, const bpa_batch_t * b)
+{
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  return batch_end_packed(e, b, nullptr, true);
+}
+extern "C" int bpa_batch_wait(bpa_engine_t * e, double * lnl)
+{
+  if (!e || !lnl) return fail("bpa_batch_wait: null argument");
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  if (!set_device(e)) return 0;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  const unsigned T = e->bc_wait_T;
+  e->bc_wait_T = 0;
+  if (e->bc_wait_zero) std::fill(lnl, lnl + T, 0.0);
+  else if (T) std::memcpy(lnl, e->h_stage, (size_t)T*sizeof(double));
+  return 1;
 }
 
 extern "C" int bpa_batch_evaluate(bpa_engine_t * e, const bpa_batch_t * b, double * lnl)

@@ -67,8 +67,20 @@ struct a00_driver
   int * w_br, * w_nd, * w_nb, * w_nn;   /* [nloci][w_cap] changed branches / nodes to recompute, and their counts (-1: no proposal) */
   double * w_hast, * w_logpr;
   double * w_diff;                      /* [nloci][A00_MAXPOP] THETA: term differences per locus, summed in locus order afterwards */
+  /* two cohorts of loci (a00_set_cohorts): [0, co_split) evaluated through co_ctx[0], the rest through co_ctx[1] — two
+     engines, one batch in flight on each.  A per-locus step of cohort B is proposed and marshalled while cohort A's
+     launch runs and the other way round; a `view` is a cohort's share of the slot arrays (its loci, its slots from 0). */
+  int ncohort; unsigned co_split;
+  a00_submit_fn co_submit; a00_wait_fn co_wait; void * co_ctx[2];
+  unsigned c_lo, c_hi;                  /* the loci the per-locus loops and `compact` cover: the current view's */
+  int cur_view;
+  struct a00_view { int * s_br, * s_nd; size_t cap_br, cap_nd; unsigned n; int inflight; } view[3];   /* 0: all loci; 1, 2: the cohorts */
+  unsigned * b_locus; a00_tree_t ** b_tree; unsigned * b_br_off, * b_nd_off; double * b_lnl, * b_hast, * b_logpr;   /* the slot arrays as allocated */
+  unsigned * t_br_off, * t_nd_off;      /* an all-loci step's second half with its offsets from 0 */
 };
 
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9*ts.tv_nsec; }
 
 /* the reference's buffer toggles (locus.c:24-26) */
 static void swap_clv(a00_tree_t * t, int i)
@@ -161,13 +173,18 @@ a00_driver_t * a00_create(unsigned nloci, a00_eval_fn eval, void * ctx, unsigned
   d->trees = (a00_tree_t *)calloc(nloci, sizeof(a00_tree_t));
   d->s_locus = (unsigned *)calloc(nloci, sizeof(unsigned));
   d->s_tree = (a00_tree_t **)calloc(nloci, sizeof(a00_tree_t *));
-  d->s_br_off = (unsigned *)calloc(nloci + 1, sizeof(unsigned));
-  d->s_nd_off = (unsigned *)calloc(nloci + 1, sizeof(unsigned));
+  d->s_br_off = (unsigned *)calloc(nloci + 2, sizeof(unsigned));
+  d->s_nd_off = (unsigned *)calloc(nloci + 2, sizeof(unsigned));
+  d->t_br_off = (unsigned *)calloc(nloci + 2, sizeof(unsigned));
+  d->t_nd_off = (unsigned *)calloc(nloci + 2, sizeof(unsigned));
   d->s_lnl = (double *)calloc(nloci, sizeof(double));
   d->s_hast = (double *)calloc(nloci, sizeof(double));
   d->s_logpr = (double *)calloc(nloci, sizeof(double));
   d->p_logpr = (double *)calloc(nloci, sizeof(double)); d->p_delta = (double *)calloc(nloci, sizeof(double));
   d->p_slot = (int *)calloc(nloci, sizeof(int)); d->u_pop = (int **)calloc(nloci, sizeof(int *));
+  d->b_locus = d->s_locus; d->b_tree = d->s_tree; d->b_br_off = d->s_br_off; d->b_nd_off = d->s_nd_off;
+  d->b_lnl = d->s_lnl; d->b_hast = d->s_hast; d->b_logpr = d->s_logpr;
+  d->c_lo = 0; d->c_hi = nloci;
   d->ft_gage = 0.004; d->ft_gspr = 0.004; d->ft_tau = 0.001; d->ft_mix = 0.3;
   d->threads = 1;
   d->theta_slide_prob = 0.1;
@@ -192,10 +209,13 @@ void a00_destroy(a00_driver_t * d)
     free(t->time);                     /* (the locus's block starts with the ages) */
     free(d->u_time[i]);
   }
-  free(d->rng); free(d->zrng); free(d->sm); free(d->sm_ncat); free(d->sm_old); free(d->trees); free(d->s_locus); free(d->s_tree); free(d->s_br_off); free(d->s_nd_off); free(d->s_br);
-  free(d->s_logpr); free(d->p_logpr); free(d->p_delta); free(d->p_slot); free(d->u_pop);
+  d->view[d->cur_view].s_br = d->s_br; d->view[d->cur_view].s_nd = d->s_nd;
+  { int v; for (v = 0; v < 3; ++v) { free(d->view[v].s_br); free(d->view[v].s_nd); } }
+  free(d->rng); free(d->zrng); free(d->sm); free(d->sm_ncat); free(d->sm_old); free(d->trees); free(d->b_locus); free(d->b_tree); free(d->b_br_off); free(d->b_nd_off);
+  free(d->t_br_off); free(d->t_nd_off);
+  free(d->b_logpr); free(d->p_logpr); free(d->p_delta); free(d->p_slot); free(d->u_pop);
   free(d->w_br); free(d->w_nd); free(d->w_nb); free(d->w_nn); free(d->w_hast); free(d->w_logpr); free(d->w_diff);
-  free(d->s_nd); free(d->s_lnl); free(d->s_hast); free(d->u_left); free(d->u_right); free(d->u_parent);
+  free(d->b_lnl); free(d->b_hast); free(d->u_left); free(d->u_right); free(d->u_parent);
   free(d->u_clv); free(d->u_pmat); free(d->u_scaler); free(d->u_time); free(d->u_root); free(d);
 }
 
@@ -275,13 +295,27 @@ static void install_local(a00_driver_t * d, unsigned i, const int * branches, in
   d->w_nb[i] = nb; d->w_nn[i] = nn; d->w_hast[i] = hast; d->w_logpr[i] = logpr;
 }
 
+/* the slot arrays of view v (0: all loci; 1, 2: the cohorts): a cohort's slots start at its first locus's place in the
+   arrays (its offsets one further, past the other cohort's end mark), its branch / node lists are its own */
+static void set_view(a00_driver_t * d, int v)
+{
+  struct a00_view * o = d->view + d->cur_view, * w = d->view + v;
+  const unsigned lo = v == 2 ? d->co_split : 0u;
+  o->s_br = d->s_br; o->s_nd = d->s_nd; o->cap_br = d->cap_br; o->cap_nd = d->cap_nd;
+  d->s_br = w->s_br; d->s_nd = w->s_nd; d->cap_br = w->cap_br; d->cap_nd = w->cap_nd;
+  d->cur_view = v;
+  d->c_lo = lo; d->c_hi = v == 1 ? d->co_split : d->nloci;
+  d->s_locus = d->b_locus + lo; d->s_tree = d->b_tree + lo; d->s_lnl = d->b_lnl + lo; d->s_hast = d->b_hast + lo; d->s_logpr = d->b_logpr + lo;
+  d->s_br_off = d->b_br_off + lo + (v == 2); d->s_nd_off = d->b_nd_off + lo + (v == 2);
+}
+
 /* the staged rows as the step's slots, in locus order; p_slot[i] = the slot of locus i or -1; returns the slot count */
 static unsigned compact(a00_driver_t * d)
 {
   unsigned i, n = 0; long li;
   /* slots and offsets: a running count in locus order (cheap, serial) ... */
   d->s_br_off[0] = d->s_nd_off[0] = 0;
-  for (i = 0; i < d->nloci; ++i)
+  for (i = d->c_lo; i < d->c_hi; ++i)
   {
     d->p_slot[i] = -1;
     if (d->w_nb[i] < 0) continue;
@@ -292,7 +326,7 @@ static unsigned compact(a00_driver_t * d)
   reserve(d, d->s_br_off[n], d->s_nd_off[n]);
   /* ... then every row to its place */
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
-  for (li = 0; li < (long)d->nloci; ++li)
+  for (li = (long)d->c_lo; li < (long)d->c_hi; ++li)
   {
     const int sl = d->p_slot[li];
     if (sl < 0) continue;
@@ -303,13 +337,33 @@ static unsigned compact(a00_driver_t * d)
   return n;
 }
 
+static void view_step(const a00_driver_t * d, unsigned n, a00_step_t * s)
+{
+  s->nloci = n; s->locus = d->s_locus; s->tree = d->s_tree; s->br_off = d->s_br_off; s->branches = d->s_br;
+  s->nd_off = d->s_nd_off; s->nodes = d->s_nd;
+}
+
 static int step_eval(a00_driver_t * d, unsigned n)
 {
   a00_step_t s;
   if (!n) return 1;
-  s.nloci = n; s.locus = d->s_locus; s.tree = d->s_tree; s.br_off = d->s_br_off; s.branches = d->s_br;
-  s.nd_off = d->s_nd_off; s.nodes = d->s_nd;
+  view_step(d, n, &s);
   d->steps++;
+  if (d->ncohort == 2 && d->cur_view == 0)
+  {
+    /* an all-loci step (slots in locus order): each cohort's slots to its engine, both in flight together */
+    a00_step_t s1; unsigned n0 = 0, j; int r0 = 2, r1 = 2;
+    while (n0 < n && d->s_locus[n0] < d->co_split) ++n0;
+    for (j = n0; j <= n; ++j) { d->t_br_off[j - n0] = d->s_br_off[j] - d->s_br_off[n0]; d->t_nd_off[j - n0] = d->s_nd_off[j] - d->s_nd_off[n0]; }
+    s1.nloci = n - n0; s1.locus = d->s_locus + n0; s1.tree = d->s_tree + n0; s1.br_off = d->t_br_off; s1.branches = d->s_br + d->s_br_off[n0];
+    s1.nd_off = d->t_nd_off; s1.nodes = d->s_nd + d->s_nd_off[n0];
+    s.nloci = n0;
+    if (n0 && !(r0 = d->co_submit(d->co_ctx[0], &s, d->s_lnl))) return 0;
+    if (n - n0 && !(r1 = d->co_submit(d->co_ctx[1], &s1, d->s_lnl + n0))) { if (r0 == 1) (void)d->co_wait(d->co_ctx[0], d->s_lnl, n0); return 0; }
+    if (r0 == 1 && !d->co_wait(d->co_ctx[0], d->s_lnl, n0)) { if (r1 == 1) (void)d->co_wait(d->co_ctx[1], d->s_lnl + n0, n - n0); return 0; }
+    if (r1 == 1 && !d->co_wait(d->co_ctx[1], d->s_lnl + n0, n - n0)) return 0;
+    return 1;
+  }
   return d->eval(d->ctx, &s, d->s_lnl);
 }
 
@@ -495,12 +549,11 @@ static void decide(a00_driver_t * d, unsigned n)
 }
 
 /* GAGE: the k-th inner node of every locus (propose_ages, gtree.c:4585-5532, the MSC branch) */
-static int gage_step(a00_driver_t * d, int k)
+static void gage_propose(a00_driver_t * d, int k)
 {
-  long li; unsigned n;
-  if (!staging_ready(d)) return 0;
+  long li;
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
-  for (li = 0; li < (long)d->nloci; ++li)
+  for (li = (long)d->c_lo; li < (long)d->c_hi; ++li)
   {
     const unsigned i = (unsigned)li;
     a00_tree_t * t = d->trees + i; int v = -1, c = 0, j, nb = 0, nn, p, l, r, br[4], nd[MAXN]; double lo, hi, u, tnew;
@@ -521,10 +574,6 @@ static int gage_step(a00_driver_t * d, int k)
     nn = path_to_root(t, v, nd);
     install_local(d, i, br, nb, nd, nn, 0.0, tree_logpr(d, t));
   }
-  n = compact(d);
-  if (!step_eval(d, n)) return 0;
-  decide(d, n);
-  return 1;
 }
 
 /* exchange the tree positions of node ids a and b (buffer indices stay with the ids) */
@@ -552,12 +601,11 @@ static int count_tips(const a00_tree_t * t, int v)
 
 /* GSPR: the k-th non-root node of every locus is pruned and regrafted (propose_spr, gtree.c:6531-7610,
    the MSC branch with the plain target choice) */
-static int gspr_step(a00_driver_t * d, int k)
+static void gspr_propose(a00_driver_t * d, int k)
 {
-  long li; unsigned n;
-  if (!staging_ready(d)) return 0;
+  long li;
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
-  for (li = 0; li < (long)d->nloci; ++li)
+  for (li = (long)d->c_lo; li < (long)d->c_hi; ++li)
   {
     const unsigned i = (unsigned)li;
     a00_tree_t * t = d->trees + i;
@@ -622,9 +670,118 @@ static int gspr_step(a00_driver_t * d, int k)
     }
     install_local(d, i, br, nb, nd, nn, log((double)ntg/(double)nsrc), tree_logpr(d, t));
   }
-  n = compact(d);
-  if (!step_eval(d, n)) return 0;
-  decide(d, n);
+}
+
+/* settle the cohorts' launches in flight: results, then the per-locus decisions */
+static int flush_cohorts(a00_driver_t * d)
+{
+  int c, ok = 1;
+  if (d->ncohort != 2) return 1;
+  for (c = 0; c < 2; ++c)
+  {
+    struct a00_view * w = d->view + 1 + c;
+    if (!w->inflight) continue;
+    set_view(d, 1 + c);
+    if (w->inflight == 1 && !d->co_wait(d->co_ctx[c], d->s_lnl, w->n)) ok = 0;
+    if (ok) decide(d, w->n);
+    w->inflight = 0;
+  }
+  set_view(d, 0);
+  return ok;
+}
+
+/* an all-loci step with cohorts: each cohort's share is staged in its view and sent off as soon as it is there (the
+   other cohort is proposed for meanwhile); cohort_collect waits for both.  The slots of a view sit at its first locus's
+   place in the arrays: slot_lnl finds a locus's result in either form. */
+static int cohort_submit(a00_driver_t * d, int c, unsigned n)
+{
+  struct a00_view * w = d->view + 1 + c; a00_step_t s;
+  w->n = n; w->inflight = 0;
+  if (!n) return 1;
+  view_step(d, n, &s);
+  d->steps++;
+  return (w->inflight = d->co_submit(d->co_ctx[c], &s, d->s_lnl)) != 0;
+}
+
+static int cohort_collect(a00_driver_t * d)
+{
+  int c, ok = 1;
+  for (c = 0; c < 2; ++c)
+  {
+    struct a00_view * w = d->view + 1 + c;
+    set_view(d, 1 + c);
+    if (w->inflight == 1 && !d->co_wait(d->co_ctx[c], d->s_lnl, w->n)) ok = 0;
+    w->inflight = 0;
+  }
+  set_view(d, 0);
+  return ok;
+}
+
+static double slot_lnl(const a00_driver_t * d, unsigned i)
+{ return d->b_lnl[(d->ncohort == 2 && i >= d->co_split ? d->co_split : 0u) + (unsigned)d->p_slot[i]]; }
+
+/* one per-locus step (kind 0: GAGE k, 1: GSPR k).  With cohorts: for each cohort in turn — collect its previous step
+   (whose launch ran while the other cohort was being proposed for), decide it, propose this step, send it off. */
+static int per_locus_step(a00_driver_t * d, int kind, int k)
+{
+  unsigned n; int c;
+  if (!staging_ready(d)) return 0;
+  if (d->ncohort != 2)
+  {
+    if (kind) gspr_propose(d, k); else gage_propose(d, k);
+    n = compact(d);
+    if (!step_eval(d, n)) return 0;
+    decide(d, n);
+    return 1;
+  }
+  for (c = 0; c < 2; ++c)
+  {
+    struct a00_view * w = d->view + 1 + c;
+    a00_step_t s; int r;
+    static int prof = -1; static double tp[5]; static unsigned calls;
+    double t0, t1, t2, t3, t4;
+    if (prof < 0) prof = getenv("A00_PROF") != NULL;
+    set_view(d, 1 + c);
+    t0 = prof ? now_s() : 0;
+    if (w->inflight)
+    {
+      if (w->inflight == 1 && !d->co_wait(d->co_ctx[c], d->s_lnl, w->n)) { w->inflight = 0; set_view(d, 0); return 0; }
+      t1 = prof ? now_s() : 0;
+      decide(d, w->n);
+      w->inflight = 0;
+    }
+    else t1 = t0;
+    t2 = prof ? now_s() : 0;
+    if (kind) gspr_propose(d, k); else gage_propose(d, k);
+    t3 = prof ? now_s() : 0;
+    w->n = n = compact(d);
+    t4 = prof ? now_s() : 0;
+    if (!n) continue;
+    view_step(d, n, &s);
+    d->steps++;
+    if (!(r = d->co_submit(d->co_ctx[c], &s, d->s_lnl))) { set_view(d, 0); return 0; }
+    w->inflight = r;                                  /* 1: in flight, 2: evaluated already (the lnL are there) */
+    if (prof)
+    {
+      const double t5 = now_s();
+      tp[0] += t1 - t0; tp[1] += t2 - t1; tp[2] += t3 - t2; tp[3] += t4 - t3; tp[4] += t5 - t4;
+      if (++calls % 260 == 0)
+      {
+        fprintf(stderr, "[a00] per cohort step: wait %.3f ms, decide %.3f, propose %.3f, compact %.3f, submit %.3f\n",
+                1e3*tp[0]/260, 1e3*tp[1]/260, 1e3*tp[2]/260, 1e3*tp[3]/260, 1e3*tp[4]/260);
+        tp[0] = tp[1] = tp[2] = tp[3] = tp[4] = 0;
+      }
+    }
+  }
+  set_view(d, 0);
+  return 1;
+}
+
+int a00_set_cohorts(a00_driver_t * d, unsigned split, a00_submit_fn submit, a00_wait_fn wait, void * ctx0, void * ctx1)
+{
+  if (!submit || !wait || split == 0 || split >= d->nloci) { d->ncohort = 0; return split == 0; }
+  if (!flush_cohorts(d)) return 0;
+  d->ncohort = 2; d->co_split = split; d->co_submit = submit; d->co_wait = wait; d->co_ctx[0] = ctx0; d->co_ctx[1] = ctx1;
   return 1;
 }
 
@@ -756,7 +913,8 @@ static int theta_step_gibbs(a00_driver_t * d)
    sum(dlogpr + dlnL) + below*log(minfactor) + above*log(maxfactor)   (stree.c:6280) */
 static int tau_step(a00_driver_t * d, int q)
 {
-  unsigned i, n; long li; double sum = 0; int acc_, j, bad = 0;
+  unsigned i, n = 0; long li; double sum = 0; int acc_, j, bad = 0, co;
+  const int nco = d->ncohort == 2 ? 2 : 1;
   const int cl = d->sp_left[q], cr = d->sp_right[q], pq = d->sp_parent[q];
   /* the program's rubber band also re-draws the thetas of q and its two children (opt_rb_theta_update = 1, bpp.c:618;
      propose_tau, stree.c:5840-5990): each from the inverse-gamma fitted to its conditional given k_p and the sum of the
@@ -772,8 +930,11 @@ static int tau_step(a00_driver_t * d, int q)
   const double minf = (tnew - lo)/(old - lo), maxf = (tnew - hi)/(old - hi), lminf = log(minf), lmaxf = log(maxf);
   if (!staging_ready(d)) return 0;
   d->tau[q] = tnew;
+  for (co = 0; co < nco; ++co)
+  {
+  if (nco == 2) set_view(d, 1 + co);
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
-  for (li = 0; li < (long)d->nloci; ++li)
+  for (li = (long)d->c_lo; li < (long)d->c_hi; ++li)
   {
     const unsigned i = (unsigned)li;
     a00_tree_t * t = d->trees + i; int br[MAXN], nd[MAXN], nb = 0, nn = 0, k, v, above = 0, below = 0;
@@ -806,9 +967,12 @@ static int tau_step(a00_driver_t * d, int q)
     install_local(d, i, br, nb, nd, nn, 0.0, d->p_logpr[i]);
   }
   n = compact(d);
-  if (!step_eval(d, n)) return 0;
+  if (nco == 2 && !cohort_submit(d, co, n)) { set_view(d, 0); return 0; }
+  }
+  if (nco == 2) { if (!cohort_collect(d)) return 0; }
+  else if (!step_eval(d, n)) return 0;
   for (i = 0; i < d->nloci; ++i)
-    sum += d->p_slot[i] >= 0 ? (d->s_lnl[d->p_slot[i]] - d->trees[i].lnl) + d->p_delta[i] : d->p_delta[i];
+    sum += d->p_slot[i] >= 0 ? (slot_lnl(d, i) - d->trees[i].lnl) + d->p_delta[i] : d->p_delta[i];
   if (pq < 0) sum += root_tau_prior_ratio(d, old, tnew);
   if (program)
   {
@@ -849,7 +1013,7 @@ static int tau_step(a00_driver_t * d, int q)
       for (li = 0; li < (long)d->nloci; ++li) d->p_logpr[li] = tree_logpr(d, d->trees + li);        /* (with the new thetas) */
     }
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
-    for (li = 0; li < (long)d->nloci; ++li) { d->trees[li].logpr = d->p_logpr[li]; if (d->p_slot[li] >= 0) d->trees[li].lnl = d->s_lnl[d->p_slot[li]]; }
+    for (li = 0; li < (long)d->nloci; ++li) { d->trees[li].logpr = d->p_logpr[li]; if (d->p_slot[li] >= 0) d->trees[li].lnl = slot_lnl(d, (unsigned)li); }
   }
   else
   {
@@ -865,7 +1029,8 @@ static int tau_step(a00_driver_t * d, int q)
    sum(dlogpr + dlnL) + (ages + taus)*log c   (prop_mixing.c:203-205; thetas stay) */
 static int mix_step(a00_driver_t * d)
 {
-  unsigned i; long li; int p, acc_; double sum = 0, lnacc, oldtau[A00_MAXPOP], oldtheta[A00_MAXPOP], lnacc_theta = 0;
+  unsigned i; long li; int p, acc_, co; double sum = 0, lnacc, oldtau[A00_MAXPOP], oldtheta[A00_MAXPOP], lnacc_theta = 0;
+  const int nco = d->ncohort == 2 ? 2 : 1;
   /* log c: finetune x BPP's window variate with its kernel (prop_mixing.c:300), uniform with ours */
   const double lnc = d->ft_mix*(d->kernel == A00_KERNEL_BPP ? draw_window(d, -1) : draw_u(d, -1) - 0.5), c = exp(lnc);
   const double uacc = d->kernel == A00_KERNEL_BPP ? -1.0 : draw_u(d, -1);
@@ -894,8 +1059,11 @@ static int mix_step(a00_driver_t * d)
     }
   }
   for (p = 0; p < d->npop; ++p) { oldtau[p] = d->tau[p]; d->tau[p] *= c; }
+  for (co = 0; co < nco; ++co)
+  {
+  if (nco == 2) set_view(d, 1 + co);
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
-  for (li = 0; li < (long)d->nloci; ++li)
+  for (li = (long)d->c_lo; li < (long)d->c_hi; ++li)
   {
     const unsigned i = (unsigned)li;
     a00_tree_t * t = d->trees + i; int br[MAXN], nd[MAXN], nb = 0, nn = 0, k;
@@ -909,8 +1077,12 @@ static int mix_step(a00_driver_t * d)
     d->p_delta[i] = (program ? 0.0 : d->p_logpr[i] - t->logpr) + (double)nn*lnc;
     install_local(d, i, br, nb, nd, nn, 0.0, d->p_logpr[i]);
   }
-  if (compact(d) != d->nloci || !step_eval(d, d->nloci)) return 0;          /* every locus has a slot: slot i = locus i */
-  for (i = 0; i < d->nloci; ++i) sum += (d->s_lnl[i] - d->trees[i].lnl) + d->p_delta[i];
+  if (compact(d) != d->c_hi - d->c_lo) { set_view(d, 0); return 0; }       /* every locus has a slot: slot i = locus i (a cohort's slots start at its first locus's place) */
+  if (nco == 2 && !cohort_submit(d, co, d->c_hi - d->c_lo)) { set_view(d, 0); return 0; }
+  }
+  if (nco == 2) { if (!cohort_collect(d)) return 0; }
+  else if (!step_eval(d, d->nloci)) return 0;
+  for (i = 0; i < d->nloci; ++i) sum += (d->b_lnl[i] - d->trees[i].lnl) + d->p_delta[i];
   lnacc = sum + (double)(d->S - 1)*lnc;
   if (d->tau_alpha > 0)                    /* all taus scale together: the Dirichlet part is unchanged */
     lnacc += (d->tau_alpha - 1)*lnc - d->tau_beta*(d->tau[d->npop-1] - oldtau[d->npop-1]) - (double)(d->S - 2)*lnc;
@@ -922,7 +1094,7 @@ static int mix_step(a00_driver_t * d)
   {
     d->accepted++;
 #pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
-    for (li = 0; li < (long)d->nloci; ++li) { d->trees[li].lnl = d->s_lnl[li]; d->trees[li].logpr = d->p_logpr[li]; }
+    for (li = 0; li < (long)d->nloci; ++li) { d->trees[li].lnl = d->b_lnl[li]; d->trees[li].logpr = d->p_logpr[li]; }
     if (program) for (p = 0; p < d->npop; ++p) d->run_T[p] *= c;
   }
   else
@@ -968,14 +1140,15 @@ int a00_get_subst_model(const a00_driver_t * d, unsigned i, double * freqs, doub
 static int push_param(a00_driver_t * d, unsigned i, int which)
 {
   double * m = d->sm + (size_t)i*11;
-  if (which == 1) return d->setpar(d->ctx, i, 1, m, 4);
-  if (which == 2) return d->setpar(d->ctx, i, 2, m + 4, 6);
+  void * ctx = d->ncohort == 2 ? d->co_ctx[i >= d->co_split] : d->ctx;
+  if (which == 1) return d->setpar(ctx, i, 1, m, 4);
+  if (which == 2) return d->setpar(ctx, i, 2, m + 4, 6);
   {
     double rates[16];
     const int nc = d->sm_ncat[i];
     if (nc < 2) return 1;
     if (!bpa_compute_gamma_cats(m[10], m[10], (unsigned)nc, rates)) return 0;       /* prop_gamma.c:93-97 */
-    return d->setpar(d->ctx, i, 4, rates, (unsigned)nc);
+    return d->setpar(ctx, i, 4, rates, (unsigned)nc);
   }
 }
 
@@ -1040,8 +1213,9 @@ int a00_iterate(a00_driver_t * d)
 {
   unsigned i; int k, maxtips = 0;
   for (i = 0; i < d->nloci; ++i) if (d->trees[i].tips > maxtips) maxtips = d->trees[i].tips;
-  for (k = 0; k < maxtips - 1; ++k)   if (!gage_step(d, k)) return 0;
-  for (k = 0; k < 2*maxtips - 2; ++k) if (!gspr_step(d, k)) return 0;
+  for (k = 0; k < maxtips - 1; ++k)   if (!per_locus_step(d, 0, k)) return 0;
+  for (k = 0; k < 2*maxtips - 2; ++k) if (!per_locus_step(d, 1, k)) return 0;
+  if (!flush_cohorts(d)) return 0;
   if (d->theta_alpha > 0 && !theta_step_all(d)) return 0;
   for (k = d->S; k < d->npop; ++k)    if (!tau_step(d, k)) return 0;
   if (!mix_step(d)) return 0;
@@ -1082,9 +1256,8 @@ void a00_counters(const a00_driver_t * d, unsigned long * proposals, unsigned lo
  * / locus_update_partials read off gnode_t, locus.c:2350, 2549-2569) -> one batched launch
  * ---------------------------------------------------------------------------------------- */
 /* A00_PROF=1: where a step's wall time goes (marshalling here / bpa_batch_evaluate), printed every 130 steps */
-static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9*ts.tv_nsec; }
 
-int a00_backend_hip(void * vctx, const a00_step_t * s, double * lnl)
+static int backend_hip_run(void * vctx, const a00_step_t * s, double * lnl, int async)
 {
   static int prof = -1; static double t_marsh = 0, t_eval = 0, t_last = 0, t_between = 0; static unsigned calls = 0;
   const double t0 = (prof < 0 ? (prof = getenv("A00_PROF") != NULL) : prof) ? now_s() : 0;
@@ -1135,10 +1308,10 @@ int a00_backend_hip(void * vctx, const a00_step_t * s, double * lnl)
 #pragma omp parallel for schedule(static) num_threads(marshal_threads)
       for (q = 0; q < parts; ++q)
         (void)bpa_batch_fill(c->engine, &b, (unsigned)((unsigned long long)n*(unsigned)q/(unsigned)parts), (unsigned)((unsigned long long)n*(unsigned)(q + 1)/(unsigned)parts));
-      ok = bpa_batch_end(c->engine, &b, lnl);
-      if (ok == 2) ok = bpa_batch_evaluate(c->engine, &b, lnl);          /* (not the one-image path after all) */
+      ok = async ? bpa_batch_end_async(c->engine, &b) : bpa_batch_end(c->engine, &b, lnl);
+      if (ok == 2) ok = bpa_batch_evaluate(c->engine, &b, lnl) ? (async ? 2 : 1) : 0;          /* (not the one-image path after all) */
     }
-    else ok = how == 2 ? bpa_batch_evaluate(c->engine, &b, lnl) : 0;
+    else ok = how == 2 ? (bpa_batch_evaluate(c->engine, &b, lnl) ? (async ? 2 : 1) : 0) : 0;
     if (prof)
     {
       const double t2 = now_s();
@@ -1151,6 +1324,21 @@ int a00_backend_hip(void * vctx, const a00_step_t * s, double * lnl)
   }
   free(loci); free(mp); free(ml); free(ops); free(rc); free(rs);
   return ok;
+}
+
+int a00_backend_hip(void * vctx, const a00_step_t * s, double * lnl) { return backend_hip_run(vctx, s, lnl, 0); }
+
+/* the wait of a backend whose evaluation function is its own submit (it returns with the lnL in place) */
+int a00_backend_wait_none(void * ctx, double * lnl, unsigned n) { (void)ctx; (void)lnl; (void)n; return 1; }
+
+/* the cohort form (a00_set_cohorts): the step's image is written and sent, the launch queued — 1: bpa_batch_wait will have
+   the lnL (a00_backend_hip_wait), 2: the batch took the general path and lnl is filled already, 0: error */
+int a00_backend_hip_submit(void * vctx, const a00_step_t * s, double * lnl) { return backend_hip_run(vctx, s, lnl, 1); }
+int a00_backend_hip_wait(void * vctx, double * lnl, unsigned n)
+{
+  a00_hip_ctx_t * c = (a00_hip_ctx_t *)vctx;
+  (void)n;
+  return bpa_batch_wait(c->engine, lnl);
 }
 
 /* the driver's substitution-parameter moves on libbpp_amd.so: the library's setters (the eigensystem of a locus whose

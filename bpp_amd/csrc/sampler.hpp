@@ -2148,6 +2148,13 @@ extern "C" int bpa_sampler_kind(bpa_sampler_t * s)
   return BPA_SAMPLER_SWEEP;
 }
 
+extern "C" int bpa_sampler_streams(bpa_sampler_t * s)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (!sampler_upload(s)) return -1;
+  return s->generic && s->g_split ? 2 : 1;
+}
+
 extern "C" int bpa_sampler_summary(bpa_sampler_t * s, double * total_lnl, unsigned long * proposals,
                                    unsigned long * accepted, unsigned long * launches)
 {

@@ -268,6 +268,12 @@ int          bpa_batch_evaluate(bpa_engine_t *, const bpa_batch_t *, double * ln
 int          bpa_batch_begin(bpa_engine_t *, const bpa_batch_t *);
 int          bpa_batch_fill(bpa_engine_t *, const bpa_batch_t *, unsigned t0, unsigned t1);
 int          bpa_batch_end(bpa_engine_t *, const bpa_batch_t *, double * lnl);
+/* bpa_batch_end without the wait: upload, launch and the copy of the results back are queued on the engine's stream and the
+   call returns (1; 2 and 0 as bpa_batch_end) — the caller proposes for OTHER loci (another engine's: the host driver's
+   cohorts, a00_set_cohorts) meanwhile; bpa_batch_wait then waits for the stream and hands out the per-locus lnL of that
+   batch.  Nothing else may touch this engine between the two calls.                                                   */
+int          bpa_batch_end_async(bpa_engine_t *, const bpa_batch_t *);
+int          bpa_batch_wait(bpa_engine_t *, double * lnl);
 
 /* ------------------------------------- device-resident proposal control (next) --- */
 /* The multispecies-coalescent sampler of include/bpp_amd_host.h with everything resident on the
@@ -388,6 +394,10 @@ int  bpa_sampler_work(bpa_sampler_t *, double * bytes, unsigned long * node_upda
 #define BPA_SAMPLER_BIG        4       /* loci of more than 16 tips, with scalers or unphased diploids (csrc/bigsampler.hpp: trees in HBM,
                                           one lane per locus, the engine's general 4-state kernels; <= 64 tips) */
 int  bpa_sampler_kind(bpa_sampler_t *);
+/* 2 when the generic sampler runs its per-locus steps as two half-batches of the loci on two streams (enough workgroups of
+   the packing to halve, loci in slot order: csrc/gsampler_host.hpp gs_fork) — twice the launches of bpa_sampler_work's
+   `sweeps`, each over half the loci, overlapping in time —, else 1 */
+int  bpa_sampler_streams(bpa_sampler_t *);
 
 /* ------------------------------------------------------ work / measurement --- */
 /* Algorithmic work of one launch of the plan, by the formulas of SURVEY.md §8(d):

@@ -358,6 +358,22 @@ void           a00_counters(const a00_driver_t *, unsigned long * proposals, uns
    counts of method.c:4110-4146 (2*inner CLVs, 2*edges P-matrices, 2*inner scalers)       */
 typedef struct a00_hip_ctx { bpa_engine_t * engine; bpa_locus_t ** loci; } a00_hip_ctx_t;
 int a00_backend_hip(void * ctx /* a00_hip_ctx_t* */, const a00_step_t * step, double * lnl);
+
+/* Two cohorts of loci on two engines (one GPU, two streams): loci [0, split) are evaluated through ctx0, the others
+   through ctx1 — the loci's handles in a context's array sit at their DRIVER index, whichever engine made them.  A
+   per-locus step (GAGE k, GSPR k) of one cohort is proposed, marshalled and sent off while the other cohort's launch
+   runs; an all-loci step sends each cohort's share to its engine and waits for both.  Every draw of a per-locus step
+   comes from that locus's own stream and the all-loci sums run in locus order, so the trajectory is the one of the
+   plain driver (tests/test_gpu_host_driver.py).
+     submit   1: in flight (wait will deliver the per-locus lnL), 2: evaluated already, lnl filled, 0: error
+     wait     the lnL of the context's batch in flight                                                                  */
+typedef int (*a00_submit_fn)(void * ctx, const a00_step_t * step, double * lnl /* [nloci] */);
+typedef int (*a00_wait_fn)(void * ctx, double * lnl /* [n] */, unsigned n);
+int a00_set_cohorts(a00_driver_t *, unsigned split, a00_submit_fn, a00_wait_fn, void * ctx0, void * ctx1);
+int a00_backend_hip_submit(void * ctx /* a00_hip_ctx_t* */, const a00_step_t * step, double * lnl);
+int a00_backend_hip_wait(void * ctx /* a00_hip_ctx_t* */, double * lnl, unsigned n);
+/* for a synchronous backend used as its own submit (an a00_eval_fn has submit's signature): nothing to wait for */
+int a00_backend_wait_none(void * ctx, double * lnl, unsigned n);
 /* lnL = 0 for every locus: the sampler then draws gene trees from the MSC prior (BPP's usedata = 0) */
 int a00_backend_prior(void * ctx, const a00_step_t * step, double * lnl);
 

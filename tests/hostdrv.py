@@ -188,6 +188,17 @@ def reference_driver(data, seed=1, scaling=False):
     return drv
 
 
+def reference_driver_cohorts(data, split, seed=1, scaling=False):
+    """the reference-API driver with its loci in two cohorts (a00_set_cohorts; the synchronous backend is its own submit)"""
+    import oraclelib as O
+    drv = reference_driver(data, seed, scaling)
+    L = lib()
+    L.a00_set_cohorts.argtypes = [C.c_void_p, C.c_uint] + [C.c_void_p] * 4
+    arr = C.cast(drv._keep[1], C.c_void_p)
+    assert L.a00_set_cohorts(drv.h, split, C.cast(O.ref().ref_backend_eval, C.c_void_p), C.cast(L.a00_backend_wait_none, C.c_void_p), arr, arr)
+    return drv
+
+
 def hip_driver(engine, loci, data, seed=1, scaling=False):
     """driver on libbpp_amd.so (a00_backend_hip)"""
     arr = (C.c_void_p * len(loci))(*[l.h for l in loci])
@@ -196,6 +207,22 @@ def hip_driver(engine, loci, data, seed=1, scaling=False):
     drv = Driver(data, fn, C.cast(C.pointer(ctx), C.c_void_p), seed, scaling)
     drv._keep = (arr, ctx)
     drv.set_param_backend(C.cast(lib().a00_backend_hip_params, C.c_void_p))
+    return drv
+
+
+def hip_driver_cohorts(engines, loci, data, split, seed=1, scaling=False):
+    """driver on TWO engines (a00_set_cohorts): loci[:split] were made on engines[0], loci[split:] on engines[1] — a
+    per-locus step of one cohort is proposed while the other cohort's launch runs"""
+    L = lib()
+    arr = (C.c_void_p * len(loci))(*[l.h for l in loci])
+    ctxs = [HipCtx(e.h, arr) for e in engines]
+    drv = Driver(data, C.cast(L.a00_backend_hip, C.c_void_p), C.cast(C.pointer(ctxs[0]), C.c_void_p), seed, scaling)
+    drv._keep = (arr, ctxs)
+    drv.set_param_backend(C.cast(L.a00_backend_hip_params, C.c_void_p))
+    L.a00_set_cohorts.argtypes = [C.c_void_p, C.c_uint] + [C.c_void_p] * 4
+    if not L.a00_set_cohorts(drv.h, split, C.cast(L.a00_backend_hip_submit, C.c_void_p), C.cast(L.a00_backend_hip_wait, C.c_void_p),
+                             C.cast(C.pointer(ctxs[0]), C.c_void_p), C.cast(C.pointer(ctxs[1]), C.c_void_p)):
+        raise RuntimeError("a00_set_cohorts failed")
     return drv
 
 

@@ -44,6 +44,46 @@ def test_same_trajectory_on_gpu_and_reference(engine, taxa, model, R, scaling, n
     g.close(); r.close()
 
 
+@pytest.mark.parametrize("taxa,model,R,nloci,split,threads,params", [(4, "jc69", 1, 300, 150, 4, False), (8, "gtr", 4, 50, 17, 1, True),
+                                                                 (6, "jc69", 2, 40, 39, 3, False)])
+def test_cohorts_on_two_engines_walk_the_plain_drivers_trajectory(taxa, model, R, nloci, split, threads, params):
+    """a00_set_cohorts: the loci in two cohorts on two engines, a per-locus step of one proposed and marshalled while the
+    other's launch runs (bpa_batch_end_async / bpa_batch_wait), all-loci steps sent to both engines at once — per-locus
+    random streams and sums in locus order: the same decisions, trees and parameters as the plain driver on one engine,
+    to the bit"""
+    data = synth.make_dataset(nloci, 400, taxa, model, R, seed=5, theta=0.004 if taxa == 6 else None)
+    e0, e1, e2 = bpp_amd.Engine(0), bpp_amd.Engine(0), bpp_amd.Engine(0)
+    plain = hostdrv.hip_driver(e0, tape.make_engine_loci(e0, data), data, seed=11)
+    loci = tape.make_engine_loci(e1, data[:split]) + tape.make_engine_loci(e2, data[split:])
+    co = hostdrv.hip_driver_cohorts([e1, e2], loci, data, split, seed=11)
+    parent, tau0, thetas = synth.species_tree_arrays(taxa, 0.004 if taxa == 6 else 0.002)
+    for drv in (plain, co):
+        drv.set_species_tree(parent, tau0, thetas)
+        drv.set_tau_prior(3.0, 3.0 / tau0[-1])
+        drv.set_theta_prior(2.0, 1000.0, 0.001)
+        if taxa == 6:
+            drv.set_finetune(0.02, 0.02, 0.005, 0.3)
+        if params:
+            drv.set_subst_moves(0.3, 0.4, 0.8, 1.0, 1.0)
+            for i, d in enumerate(data):
+                drv.set_subst_model(i, list(d["freqs"]), list(d["exch"]), 0.5, R)
+    co.set_threads(threads)
+    plain.initialize(); co.initialize()
+    assert plain.total_lnl() == co.total_lnl()
+    for it in range(4):
+        plain.iterate(); co.iterate()
+        assert plain.total_lnl() == co.total_lnl(), it
+        assert plain.counters()[:2] == co.counters()[:2], it
+    assert plain.taus() == co.taus() and plain.thetas() == co.thetas() and co.taus() != list(tau0)
+    for i in range(nloci):
+        a, b = plain.tree(i), co.tree(i)
+        assert a == b, i
+        if params:
+            fa, fb = plain.get_subst_model(i), co.get_subst_model(i)
+            assert all(np.array_equal(x, y) for x, y in zip(fa, fb))
+    plain.close(); co.close(); e0.close(); e1.close(); e2.close()
+
+
 def test_driver_incremental_equals_scratch_on_gpu(engine):
     data = synth.make_dataset(500, 500, 4, "jc69", 1, seed=9)
     loci = tape.make_engine_loci(engine, data)

@@ -85,3 +85,32 @@ def test_thread_count_does_not_change_the_trajectory(threads):
     assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[4] == b[4]
     for x, y in zip(a[3], b[3]):
         assert x == y
+
+
+@pytest.mark.parametrize("split,threads", [(1, 1), (18, 3), (36, 2)])
+def test_cohorts_do_not_change_the_trajectory(split, threads):
+    """a00_set_cohorts: the per-locus steps of the two cohorts of loci are proposed, evaluated and decided in turns (on
+    the GPU: one cohort's launch runs while the other is proposed for — tests/test_gpu_host_driver.py), all-loci steps
+    are evaluated in two shares: the one-cohort trajectory exactly, substitution-parameter moves included"""
+    data = synth.make_dataset(37, 200, 6, "gtr", 2, seed=5)
+    runs = []
+    for co in (False, True):
+        drv = hostdrv.reference_driver_cohorts(data, split, seed=11) if co else hostdrv.reference_driver(data, seed=11)
+        drv.set_threads(threads if co else 1)
+        parent, tau0, thetas = synth.species_tree_arrays(6)
+        drv.set_species_tree(parent, tau0, thetas)
+        drv.set_tau_prior(3.0, 3.0 / tau0[-1])
+        drv.set_theta_prior(2.0, 1000.0, 0.0004)
+        drv.set_subst_moves(0.3, 0.4, 0.8, 1.0, 1.0)
+        for i, d in enumerate(data):
+            drv.set_subst_model(i, list(d["freqs"]), list(d["exch"]), 0.5, 2)
+        drv.initialize()
+        for _ in range(5):
+            drv.iterate()
+        runs.append((drv.counters()[:2], drv.taus(), drv.thetas(), [drv.tree(i) for i in range(len(data))], drv.total_lnl(),
+                     [tuple(map(tuple, map(np.atleast_1d, drv.get_subst_model(i)))) for i in range(len(data))]))
+        drv.close()
+    a, b = runs
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[4] == b[4] and a[5] == b[5]
+    for x, y in zip(a[3], b[3]):
+        assert x == y
