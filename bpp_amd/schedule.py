@@ -147,6 +147,7 @@ class A00Schedule:
         self.taus = list(taus)
         self.subst = None
         self.revert = set()               # parameter kinds whose current values must be re-installed (rejections)
+        self.keep_records = True          # the node records a replay on the REFERENCE's API needs (tests/tape.py): off for launch-only use
         if subst is not None:
             self.subst = dict(gamma=subst["gamma"], rate_cats=int(subst["rate_cats"]))
             self.cur = {1: np.array(subst["freqs"], dtype=np.float64), 2: np.array(subst["exch"], dtype=np.float64),
@@ -171,17 +172,19 @@ class A00Schedule:
         step.op_off.append(len(step.ops))
         step.root_clv.append(tr.clv[tr.root])
         step.root_scaler.append(tr.scaler[tr.root])
+        if not self.keep_records:
+            return None
         allnodes = sorted(set(touched) | set(branches) | set(nodes))
         step.pre.append(dict(records=[tr.record(i) for i in allnodes], root=tr.root,
                              branches=list(branches), nodes=list(nodes)))
         return allnodes
 
     def _decide(self, step, tr, snap, root_before, allnodes, accept):
-        if accept:
-            step.post.append(dict(records=[], root=tr.root))
-        else:
+        if not accept:
             tr.restore(snap, root_before)
-            step.post.append(dict(records=[tr.record(i) for i in allnodes], root=tr.root))
+        if not self.keep_records:
+            return
+        step.post.append(dict(records=[] if accept else [tr.record(i) for i in allnodes], root=tr.root))
 
     # ---- GAGE: gtree.c:4585 propose_ages — one inner node per step
     def gage_step(self, k):

@@ -34,6 +34,7 @@ def test_full_size_properties(name, nloci, sites, taxa, model, R, taus):
     data = synth.make_dataset(nloci, sites, taxa, model, R, seed=777, divergence=3.0 if name == "C4" else 1.0)     # (C4: the bench's data, ~190 patterns per locus)
     loci = tape.make_engine_loci(eng, data)
     sch = tape.make_schedule(data, seed=11, taus=tuple(t*(3.0 if name == "C4" else 1.0) for t in taus))
+    sch.keep_records = False                                                  # (launches only: no replay on the reference's API here)
     init = sch.initial_step()
     p0 = tape.plan_for_step(eng, loci, init)
     p0.enable_sum()
