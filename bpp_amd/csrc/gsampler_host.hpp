@@ -49,7 +49,8 @@ static int gs_refresh_eigen(bpa_sampler * s)
 // the streams left to themselves — they settle into running nearly in phase, and the step kernel under load takes 30-80 us
 // instead of 29; making the halves' likelihood launches take turns through a pair of events (before the P-matrix
 // launch: 169 it/s, before the node-update launch: 178) or starting the second stream half a step late (184-185) was no
-// better, so there are no events between the halves.  All-loci steps (THETA, TAU, MIX, the downloads) run on the engine's
+// better, and neither was one stream for all likelihood launches + one for all proposal launches with an event each way per
+// half (166: a cross-stream event costs ~11 us between the kernels it separates), so there are no events between the halves.  All-loci steps (THETA, TAU, MIX, the downloads) run on the engine's
 // stream over all loci after a join; the trajectory does not depend on any of this.
 static int gs_fork(bpa_sampler * s)
 {

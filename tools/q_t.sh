@@ -1,9 +1,12 @@
 cd /tmp && export TMPDIR=/tmp
-for i in 1 2; do
-python /root/repo/bench.py --config c3 --steps 8 --warmup 1 --no-cpu-baseline --no-tape > /tmp/c3.json 2> /tmp/c3.err
+rocprofv3 --kernel-trace -f csv -d /tmp/p3 -o p -- python /root/repo/bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline --no-tape > /tmp/c3.json 2> /tmp/c3.err
 python3 - <<'PY'
-import json
-j = json.loads(open('/tmp/c3.json').read().strip().split('\n')[-1])
-print("c3 sampler", j["value"], j["roofline"]["avg_kernel_us"])
+import csv, glob, json
+f = glob.glob('/tmp/p3/**/*kernel_trace.csv', recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+n = len(rows); w = rows[int(n*0.8)+30:int(n*0.8)+62]
+t0 = int(w[0]["Start_Timestamp"])
+for r in w:
+    print(r["Queue_Id"], r["Kernel_Name"][:34].ljust(34), round((int(r["Start_Timestamp"])-t0)/1e3,1), round((int(r["End_Timestamp"])-t0)/1e3,1))
 PY
-done
