@@ -7,6 +7,8 @@ semantics of compress_site_patterns (compress.c:218; JC69 relabel-merge for JC69
 This is the bench/test input generator (the reference's own simulator is DNA-only
 and does not travel to the GPU box).  Plain numpy; deterministic for a seed.
 """
+import os
+
 import numpy as np
 
 from . import api
@@ -178,6 +180,11 @@ def make_dataset(nloci, sites, taxa=4, model="jc69", rate_cats=1, alpha=0.5, the
     """returns a list of loci: dict(seqs (compressed), weights, left, right, times, root, ...).
     divergence: every tau of SPECIES_TREES[taxa] and the default theta times this factor (more substitutions per site:
     more distinct site patterns per locus)"""
+    cached = _cache_file(nloci, sites, taxa, model, rate_cats, alpha, theta, seed, divergence) if freqs is None and exch is None else None
+    if cached and os.path.exists(cached):
+        import pickle
+        with open(cached, "rb") as f:
+            return pickle.load(f)
     rng = np.random.default_rng(seed)
     stree = scaled_tree(SPECIES_TREES[taxa], divergence)
     dna = model in ("jc69", "gtr")
@@ -210,6 +217,29 @@ def make_dataset(nloci, sites, taxa=4, model="jc69", rate_cats=1, alpha=0.5, the
                         states=S, rate_cats=rate_cats, model=model, freqs=freqs, exch=exch,
                         rates=rates, raw_sites=sites))
     return out
+
+
+def _cache_file(*key):
+    """BPP_AMD_SYNTH_CACHE=<dir>: data sets made ahead of time (precompute, below) are read from there — the GPU test
+    session starts the 10 000-locus sets of the full-size tests in background processes while the other tests run"""
+    d = os.environ.get("BPP_AMD_SYNTH_CACHE")
+    if not d:
+        return None
+    import hashlib
+    return os.path.join(d, "synth_" + hashlib.sha1(repr(key).encode()).hexdigest()[:20] + ".pkl")
+
+
+def precompute(nloci, sites, taxa, model, rate_cats, seed, divergence=1.0):
+    """make one data set and leave it in the cache directory (called in a process of its own: tests/conftest.py)"""
+    import pickle
+    path = _cache_file(nloci, sites, taxa, model, rate_cats, 0.5, None, seed, divergence)
+    if not path or os.path.exists(path):
+        return
+    os.environ.pop("BPP_AMD_SYNTH_CACHE")
+    data = make_dataset(nloci, sites, taxa, model, rate_cats, seed=seed, divergence=divergence)
+    with open(path + ".tmp%d" % os.getpid(), "wb") as f:
+        pickle.dump(data, f, protocol=pickle.HIGHEST_PROTOCOL)
+    os.replace(path + ".tmp%d" % os.getpid(), path)
 
 
 def msc_start_tree(tip_species, parent, tau, theta, rng):

@@ -29,3 +29,36 @@ def engine():
     e = bpp_amd.Engine(0)
     yield e
     e.close()
+
+
+# the 10 000-locus data sets of the full-size tests take 3-8 s each to make (numpy, one core): started in background
+# processes when the session's selection holds those tests, read back from BPP_AMD_SYNTH_CACHE when the tests get there
+_BIG_SETS = {"test_gpu_fullsize.py::test_full_size_properties[C2": (10000, 1000, 4, "jc69", 1, 777, 1.0),
+             "test_gpu_fullsize.py::test_full_size_properties[C3": (10000, 1000, 8, "gtr", 4, 777, 1.0),
+             "test_gpu_fullsize.py::test_full_size_properties[C4": (2000, 500, 6, "lg", 4, 777, 3.0),
+             "test_gpu_tape.py::test_chain_launch_equals_step_by_step[4-False-10000]": (10000, 500, 4, "jc69", 1, 33, 1.0)}
+_bg = []
+
+
+def pytest_collection_finish(session):
+    import subprocess
+    import tempfile
+    want = [a for k, a in _BIG_SETS.items() if any(k in it.nodeid for it in session.items)]
+    if not want or len(session.items) < 8:
+        return
+    d = tempfile.mkdtemp(prefix="bpp_amd_synth_")
+    os.environ["BPP_AMD_SYNTH_CACHE"] = d
+    for a in want:
+        _bg.append(subprocess.Popen([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); from bpp_amd import synth; synth.precompute(*{a!r})"],
+                                    env=dict(os.environ), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import shutil
+    for p in _bg:
+        if p.poll() is None:
+            p.kill()
+        p.wait()          # (our own children, by handle)
+    d = os.environ.pop("BPP_AMD_SYNTH_CACHE", None)
+    if d and _bg:
+        shutil.rmtree(d, ignore_errors=True)

@@ -20,6 +20,24 @@ FROGS = {"frogs.txt": os.path.join(G, "frogs", "frogs.txt"), "frogs.Imap.txt": o
 ANOPH = {"loci_realign.txt": os.path.join(G, "anopheles", "loci_realign.txt"), "Imap.txt": os.path.join(G, "anopheles", "Imap.txt")}
 
 
+@pytest.fixture(scope="module", autouse=True)
+def all_program_runs_side_by_side(request):
+    """every run of `bpp` / `bpp_hip` this module's selected tests will ask for, started together (six tests' worth at a
+    time: the runs share nothing, one at a time they are 70 s of mostly waiting) — each test function is called once here
+    with its assertions ignored, its runs are remembered by tests/bpphip.py, and the test proper then reads them"""
+    from concurrent.futures import ThreadPoolExecutor
+    items = [it for it in request.session.items if getattr(it, "module", None) is request.module]
+
+    def dry(it):
+        try:
+            it.obj(**(it.callspec.params if hasattr(it, "callspec") else {}))
+        except BaseException:      # noqa: BLE001  (the test proper reports it)
+            pass
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        list(ex.map(dry, items))
+    yield
+
+
 def check(res, logl0=None):
     assert res["logl0_ref"] is not None and res["logl0_hip"] is not None
     assert abs(res["logl0_ref"] - res["logl0_hip"]) <= 1e-10*abs(res["logl0_ref"]), res
