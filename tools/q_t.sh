@@ -1,11 +1,5 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_gsampler.py tests/test_gpu_tape.py tests/test_gpu_host_driver.py tests/test_gpu_params.py "tests/test_gpu_fullsize.py::test_full_size_properties[C3-10000-1000-8-gtr-4-taus1]" -x -q -m gpu 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d /tmp/p3 -o p -- python /root/repo/bench.py --config c3 --steps 6 --warmup 1 --no-cpu-baseline > /tmp/c3.json 2> /tmp/c3.err
-python3 - <<'PY'
-import csv, glob, json
-f = glob.glob('/tmp/p3/**/*kernel_stats.csv', recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:3]:
-    print(r["Name"][:70], r["Calls"], round(float(r["AverageNs"])/1e3, 2), r["Percentage"])
-j = json.loads(open('/tmp/c3.json').read().strip().split('\n')[-1])
-print("c3 sampler", j["value"], "tape", j["likelihood_only"]["iterations_per_s"])
-PY
+for nc in 0 1; do
+if [ $nc = 1 ]; then export A00_NO_COHORTS=1; echo "--- A00_NO_COHORTS=1 (one engine, one batch per step)"; else echo "--- default: two cohorts on two engines"; fi
+A00_PROF=1 timeout 600 python bench.py --no-tape --no-other-configs --no-cpu-baseline --no-efficiency --no-sampler 2>gpurun_out/hc.err | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.readline()); h=j.get('host_control_in_c'); h.pop('note',None); print(json.dumps(h))"
+grep "a00\]" gpurun_out/hc.err | tail -2
+done
