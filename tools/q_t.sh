@@ -1,5 +1,10 @@
-for nc in 0 1; do
-if [ $nc = 1 ]; then export A00_NO_COHORTS=1; echo "--- A00_NO_COHORTS=1 (one engine, one batch per step)"; else echo "--- default: two cohorts on two engines"; fi
-A00_PROF=1 timeout 600 python bench.py --no-tape --no-other-configs --no-cpu-baseline --no-efficiency --no-sampler 2>gpurun_out/hc.err | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.readline()); h=j.get('host_control_in_c'); h.pop('note',None); print(json.dumps(h))"
-grep "a00\]" gpurun_out/hc.err | tail -2
+cd /tmp && export TMPDIR=/tmp
+for f in 0.5 0.4 0.33 0.25; do
+export BPA_GS_SPLIT_AT=$f
+python /root/repo/bench.py --config c3 --steps 8 --warmup 1 --no-cpu-baseline --no-tape > /tmp/c3.json 2> /tmp/c3.err
+python3 - <<'PY'
+import json, os
+j = json.loads(open('/tmp/c3.json').read().strip().split('\n')[-1])
+print("split at", os.environ["BPA_GS_SPLIT_AT"], "c3 sampler", j["value"])
+PY
 done
