@@ -1572,6 +1572,16 @@ static int batch_fill_packed(bpa_engine * e, const bpa_batch_t * b, unsigned t0,
     for (unsigned sl = s_lo; sl < s_hi; ++sl) reinterpret_cast<StepRec *>(recs + (size_t)sl*units)->task = 0xffffffffu;
   }
   auto bad = [&](const char * msg) { std::lock_guard<std::mutex> g(e->bc_mtx); e->bc_failed.store(1); e->bc_msg = msg; return 0; };
+  // workgroups up to a locus's start their matrix range at that locus's first entry: this range writes the entries of the
+  // workgroups whose first slot lies past the slot of the locus before it, up to its own last locus (the last range: all the rest)
+  uint32_t * bm = reinterpret_cast<uint32_t *>(img + e->bc_o_bm);
+  unsigned blk = 0;
+  if (t0)
+  {
+    const bpa_locus * lp = b->loci[t0 - 1];
+    if (!lp || lp->eng != e || lp->id >= e->slot_of.size() || e->slot_of[lp->id] < 0) { e->bc_fallback.store(1); return 1; }
+    blk = (unsigned)(std::upper_bound(e->h_blk_slot_off.begin(), e->h_blk_slot_off.end(), (uint32_t)e->slot_of[lp->id]) - e->h_blk_slot_off.begin());
+  }
   for (unsigned t = t0; t < t1; ++t)
   {
     const bpa_locus * l = b->loci[t];
@@ -1587,6 +1597,7 @@ static int batch_fill_packed(bpa_engine * e, const bpa_batch_t * b, unsigned t0,
     const unsigned sl = (unsigned)e->slot_of[l->id];
     const unsigned o0 = b->op_off ? b->op_off[t] : 0, o1 = b->op_off ? b->op_off[t+1] : 0;
     const unsigned m0 = b->mat_off ? b->mat_off[t] : 0, m1 = b->mat_off ? b->mat_off[t+1] : 0;
+    while (blk <= e->pack_blocks && e->h_blk_slot_off[blk] <= sl) bm[blk++] = m0;
     if (b->root_clv[t] < l->tips || b->root_clv[t] >= l->tips + l->clv_buffers) return bad("plan: root clv index out of range");
     if (b->root_scaler && b->root_scaler[t] >= (int)l->scale_buffers) return bad("plan: root scaler index out of range");
     for (unsigned i = m0; i < m1; ++i)
@@ -1619,6 +1630,7 @@ static int batch_fill_packed(bpa_engine * e, const bpa_batch_t * b, unsigned t0,
       std::memcpy(recs + (size_t)sl*units + 1 + (o - o0), &q, sizeof(q));
     }
   }
+  if (t1 == T) while (blk <= e->pack_blocks) bm[blk++] = e->bc_nmat;
   return 1;
 }
 
@@ -1628,17 +1640,7 @@ static int batch_end_packed(bpa_engine * e, const bpa_batch_t * b, double * lnl,
   if (e->bc_fallback.load()) return 2;             // not the one-image path after all: the caller evaluates the batch the general way
   const unsigned T = e->bc_T, nmat = e->bc_nmat, npat = e->bc_npat, rmax = e->bc_rmax, units = e->bc_units;
   unsigned char * img = (unsigned char *)e->h_step;
-  uint32_t * bm = reinterpret_cast<uint32_t *>(img + e->bc_o_bm);
-  {
-    // workgroups up to a locus's start their matrix range at that locus's first entry
-    unsigned blk = 0;
-    for (unsigned t = 0; t < T; ++t)
-    {
-      const unsigned sl = (unsigned)e->slot_of[b->loci[t]->id], m0 = b->mat_off ? b->mat_off[t] : 0;
-      while (blk <= e->pack_blocks && e->h_blk_slot_off[blk] <= sl) bm[blk++] = m0;
-    }
-    while (blk <= e->pack_blocks) bm[blk++] = nmat;
-  }
+  // (the workgroups' matrix ranges — blk_mat_off — were written by the fills, each for the workgroups that start in its loci's slots)
   HIPCHK(hipMemcpyAsync(e->d_step.p, img, e->bc_total, hipMemcpyHostToDevice, e->stream));
   PlanDev d{};
   d.loci = e->d_loci.p; d.bfbeta = e->bfbeta;

@@ -1,10 +1,4 @@
-cd /tmp && export TMPDIR=/tmp
-for f in 0.5 0.4 0.33 0.25; do
-export BPA_GS_SPLIT_AT=$f
-python /root/repo/bench.py --config c3 --steps 8 --warmup 1 --no-cpu-baseline --no-tape > /tmp/c3.json 2> /tmp/c3.err
-python3 - <<'PY'
-import json, os
-j = json.loads(open('/tmp/c3.json').read().strip().split('\n')[-1])
-print("split at", os.environ["BPA_GS_SPLIT_AT"], "c3 sampler", j["value"])
-PY
+timeout 900 python -m pytest tests/test_gpu_host_driver.py tests/test_gpu_edges.py tests/test_gpu_gsampler.py tests/test_gpu_packing.py tests/test_gpu_parity.py tests/test_gpu_sampler.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
+for i in 1 2; do
+timeout 600 python bench.py --no-tape --no-other-configs --no-cpu-baseline --no-efficiency --no-sampler 2>/dev/null | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.readline()); h=j.get('host_control_in_c'); h.pop('note',None); print(json.dumps(h))"
 done
