@@ -549,14 +549,26 @@ static void decide(a00_driver_t * d, unsigned n)
 }
 
 /* GAGE: the k-th inner node of every locus (propose_ages, gtree.c:4585-5532, the MSC branch) */
-static void gage_propose(a00_driver_t * d, int k)
+/* the decision of locus i's pending per-locus proposal (slot p_slot[i] of the view's last step), as `decide` takes it */
+static int settle_one(a00_driver_t * d, unsigned i)
 {
-  long li;
-#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+  const int s = d->p_slot[i]; a00_tree_t * t = d->trees + i;
+  if (s < 0) return 0;
+  if (accept(d, (long)i, (d->s_logpr[s] - t->logpr) + (d->s_lnl[s] - t->lnl) + d->s_hast[s], -1.0)) { t->lnl = d->s_lnl[s]; t->logpr = d->s_logpr[s]; return 1; }
+  restore(d, i);
+  return 0;
+}
+
+/* settle != 0: the locus's pending decision first, in the same pass (the cohort pipeline: one parallel region instead of two) */
+static unsigned long gage_propose(a00_driver_t * d, int k, int settle)
+{
+  long li; unsigned long acc = 0;
+#pragma omp parallel for schedule(static) num_threads(d->threads) reduction(+:acc) if (d->threads > 1)
   for (li = (long)d->c_lo; li < (long)d->c_hi; ++li)
   {
     const unsigned i = (unsigned)li;
     a00_tree_t * t = d->trees + i; int v = -1, c = 0, j, nb = 0, nn, p, l, r, br[4], nd[MAXN]; double lo, hi, u, tnew;
+    if (settle) acc += (unsigned long)settle_one(d, i);
     d->w_nb[i] = -1;
     for (j = 0; j < t->n; ++j) if (t->left[j] >= 0 && c++ == k) { v = j; break; }
     if (v < 0) continue;
@@ -574,6 +586,7 @@ static void gage_propose(a00_driver_t * d, int k)
     nn = path_to_root(t, v, nd);
     install_local(d, i, br, nb, nd, nn, 0.0, tree_logpr(d, t));
   }
+  return acc;
 }
 
 /* exchange the tree positions of node ids a and b (buffer indices stay with the ids) */
@@ -601,10 +614,10 @@ static int count_tips(const a00_tree_t * t, int v)
 
 /* GSPR: the k-th non-root node of every locus is pruned and regrafted (propose_spr, gtree.c:6531-7610,
    the MSC branch with the plain target choice) */
-static void gspr_propose(a00_driver_t * d, int k)
+static unsigned long gspr_propose(a00_driver_t * d, int k, int settle)
 {
-  long li;
-#pragma omp parallel for schedule(static) num_threads(d->threads) if (d->threads > 1)
+  long li; unsigned long acc = 0;
+#pragma omp parallel for schedule(static) num_threads(d->threads) reduction(+:acc) if (d->threads > 1)
   for (li = (long)d->c_lo; li < (long)d->c_hi; ++li)
   {
     const unsigned i = (unsigned)li;
@@ -612,6 +625,7 @@ static void gspr_propose(a00_driver_t * d, int k)
     int a = -1, c = 0, j, p, s, g, pc, tgt, ntg = 0, nsrc = 1, targets[MAXN], pop0, popt, leaves, gl[A00_MAXPOP];
     int bset[4], br[4], nb = 0, nd[2*MAXN], nn = 0, root_before;
     double lo, tnew, u1, u2;
+    if (settle) acc += (unsigned long)settle_one(d, i);
     d->w_nb[i] = -1;
     for (j = 0; j < t->n; ++j) if (j != t->root && c++ == k) { a = j; break; }
     if (a < 0) continue;
@@ -670,6 +684,7 @@ static void gspr_propose(a00_driver_t * d, int k)
     }
     install_local(d, i, br, nb, nd, nn, log((double)ntg/(double)nsrc), tree_logpr(d, t));
   }
+  return acc;
 }
 
 /* settle the cohorts' launches in flight: results, then the per-locus decisions */
@@ -728,7 +743,7 @@ static int per_locus_step(a00_driver_t * d, int kind, int k)
   if (!staging_ready(d)) return 0;
   if (d->ncohort != 2)
   {
-    if (kind) gspr_propose(d, k); else gage_propose(d, k);
+    if (kind) (void)gspr_propose(d, k, 0); else (void)gage_propose(d, k, 0);
     n = compact(d);
     if (!step_eval(d, n)) return 0;
     decide(d, n);
@@ -743,16 +758,15 @@ static int per_locus_step(a00_driver_t * d, int kind, int k)
     if (prof < 0) prof = getenv("A00_PROF") != NULL;
     set_view(d, 1 + c);
     t0 = prof ? now_s() : 0;
-    if (w->inflight)
     {
+      const int settle = w->inflight != 0; unsigned long acc;
       if (w->inflight == 1 && !d->co_wait(d->co_ctx[c], d->s_lnl, w->n)) { w->inflight = 0; set_view(d, 0); return 0; }
-      t1 = prof ? now_s() : 0;
-      decide(d, w->n);
+      t1 = t2 = prof ? now_s() : 0;
+      /* the pending decisions and the new proposals of the cohort's loci in ONE pass: a locus's decision, then its proposal */
+      acc = kind ? gspr_propose(d, k, settle) : gage_propose(d, k, settle);
+      if (settle) { d->proposals += w->n; d->accepted += acc; }
       w->inflight = 0;
     }
-    else t1 = t0;
-    t2 = prof ? now_s() : 0;
-    if (kind) gspr_propose(d, k); else gage_propose(d, k);
     t3 = prof ? now_s() : 0;
     w->n = n = compact(d);
     t4 = prof ? now_s() : 0;
@@ -1305,10 +1319,18 @@ static int backend_hip_run(void * vctx, const a00_step_t * s, double * lnl, int 
     if (how == 1)
     {
       const int parts = marshal_threads; int q;
+      static double tb[3]; static unsigned nb_;
+      const double u0 = prof ? now_s() : 0; double u1, u2;
 #pragma omp parallel for schedule(static) num_threads(marshal_threads)
       for (q = 0; q < parts; ++q)
         (void)bpa_batch_fill(c->engine, &b, (unsigned)((unsigned long long)n*(unsigned)q/(unsigned)parts), (unsigned)((unsigned long long)n*(unsigned)(q + 1)/(unsigned)parts));
+      u1 = prof ? now_s() : 0;
       ok = async ? bpa_batch_end_async(c->engine, &b) : bpa_batch_end(c->engine, &b, lnl);
+      if (prof)
+      {
+        u2 = now_s(); tb[0] += u0 - t1; tb[1] += u1 - u0; tb[2] += u2 - u1;
+        if (++nb_ % 260 == 0) { fprintf(stderr, "[a00] per batch: begin %.3f ms, fill %.3f, end %.3f\n", 1e3*tb[0]/260, 1e3*tb[1]/260, 1e3*tb[2]/260); tb[0] = tb[1] = tb[2] = 0; }
+      }
       if (ok == 2) ok = bpa_batch_evaluate(c->engine, &b, lnl) ? (async ? 2 : 1) : 0;          /* (not the one-image path after all) */
     }
     else ok = how == 2 ? (bpa_batch_evaluate(c->engine, &b, lnl) ? (async ? 2 : 1) : 0) : 0;
