@@ -97,3 +97,54 @@ def test_device_samplers_draw_gene_trees_from_the_msc(name):
         assert abs((gi[:, s] == 0).mean() - (si[:, s] == 0).mean()) < 0.03, (name, s)
     eng.set_options(usedata=1, bfbeta=1.0)
     dev.close(); eng.close()
+
+
+def _batch_se(x, nb=40):
+    m = len(x) // nb
+    bm = np.array([x[i * m:(i + 1) * m].mean() for i in range(nb)])
+    return bm.std(ddof=1) / np.sqrt(nb)
+
+
+@pytest.mark.parametrize("taxa,model,R,mode,samples,thin,kind", [(4, "jc69", 1, "uniform", 4000, 4, "persistent"),
+                                                                 (4, "jc69", 1, "program", 4000, 4, "persistent"),
+                                                                 (8, "gtr", 4, "uniform", 1100, 2, "generic")])
+def test_all_loci_moves_leave_the_priors_of_theta_and_tau(taxa, model, R, mode, samples, thin, kind):
+    """usedata = 0 with ALL moves on: the joint is p(taus) p(thetas) p(G | taus, thetas), so the marginal of every theta is
+    its gamma prior and that of the root tau its gamma prior — exactly, whatever the loci.  The THETA windows / Gibbs
+    draws, the rubber band with its Jacobian (and the program's theta re-draws inside it), the mixing step: a wrong factor
+    in any of them moves these means (tools/prior_marginals.py prints the table)."""
+    data = synth.make_dataset(3, 100, taxa, model, R, seed=3)
+    eng = bpp_amd.Engine(0)
+    eng.set_options(usedata=0, bfbeta=1.0)
+    dev = bpp_amd.Sampler(eng, tape.make_engine_loci(eng, data), data, seed=17)
+    parent, tau0, thetas = synth.species_tree_arrays(taxa)
+    a_th, b_th = 3.0, 3.0 / 0.002
+    a_tau, b_tau = 4.0, 4.0 / tau0[-1]
+    dev.set_species_tree(parent, tau0, thetas)
+    dev.set_tau_prior(a_tau, b_tau)
+    dev.set_theta_prior(a_th, b_th, 0.002)
+    dev.set_finetune(0.004, 0.004, 0.5 * tau0[-1], 0.6)
+    if mode == "program":
+        dev.set_proposal_kernel(1)
+        dev.set_program_moves(True, 0.1)
+    dev.initialize()
+    assert dev.kind() == kind
+    dev.iterate(2000)
+    S = []
+    for _ in range(samples):
+        dev.iterate(thin)
+        S.append(dev.thetas() + dev.taus())
+    S = np.array(S)
+    npop = len(parent)
+    for p in range(taxa, npop):                                  # the inner populations' thetas (one sequence per species)
+        x = S[:, p]
+        assert abs(x.mean() - a_th / b_th) < 4.5 * _batch_se(x), (p, x.mean(), _batch_se(x))
+        assert 0.8 < x.std() / (np.sqrt(a_th) / b_th) < 1.2, (p, x.std())
+    x = S[:, 2 * npop - 1]
+    assert abs(x.mean() - a_tau / b_tau) < 4.5 * _batch_se(x), (x.mean(), _batch_se(x))
+    assert 0.85 < x.std() / (np.sqrt(a_tau) / b_tau) < 1.15
+    if mode == "program":
+        g = dev.gibbs_counters()
+        assert g[0] > samples and g[1] > 0.5 * g[0]          # (three loci: the inverse-gamma fit is rougher than with thousands)
+    eng.set_options(usedata=1, bfbeta=1.0)
+    dev.close(); eng.close()

@@ -114,3 +114,48 @@ def test_cohorts_do_not_change_the_trajectory(split, threads):
     assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[4] == b[4] and a[5] == b[5]
     for x, y in zip(a[3], b[3]):
         assert x == y
+
+
+def _batch_se(x, nb=40):
+    m = len(x) // nb
+    bm = np.array([x[i * m:(i + 1) * m].mean() for i in range(nb)])
+    return bm.std(ddof=1) / np.sqrt(nb)
+
+
+@pytest.mark.parametrize("mode", ["uniform", "bpp", "program"])
+def test_prior_only_run_leaves_the_priors_of_theta_and_tau(mode):
+    """lnL = 0 (a00_backend_prior) with ALL moves on: the joint is p(taus) p(thetas) p(G | taus, thetas), so the marginal
+    of every theta is its gamma prior and that of the root tau its gamma prior, exactly — the THETA windows / Gibbs
+    draws, the rubber band with its Jacobian (and the program's theta re-draws), the mixing step all enter (the device
+    samplers' twin: tests/test_gpu_prior.py)"""
+    taxa = 4
+    data = synth.make_dataset(3, 60, taxa, "jc69", 1, seed=3)
+    drv = hostdrv.prior_driver(data, seed=17)
+    parent, tau0, thetas = synth.species_tree_arrays(taxa)
+    a_th, b_th, a_tau, b_tau = 3.0, 3.0 / 0.002, 4.0, 4.0 / tau0[-1]
+    drv.set_species_tree(parent, tau0, thetas)
+    drv.set_tau_prior(a_tau, b_tau)
+    drv.set_theta_prior(a_th, b_th, 0.002)
+    drv.set_finetune(0.004, 0.004, 0.5 * tau0[-1], 0.6)
+    if mode != "uniform":
+        drv.set_proposal_kernel(1)
+    if mode == "program":
+        drv.set_program_moves(True, 0.1)
+    drv.initialize()
+    for _ in range(2000):
+        drv.iterate()
+    S = []
+    for _ in range(4000):
+        for _ in range(4):
+            drv.iterate()
+        S.append(drv.thetas() + drv.taus())
+    S = np.array(S)
+    npop = len(parent)
+    for p in range(taxa, npop):
+        x = S[:, p]
+        assert abs(x.mean() - a_th / b_th) < 4.5 * _batch_se(x), (p, x.mean(), _batch_se(x))
+        assert 0.8 < x.std() / (np.sqrt(a_th) / b_th) < 1.2, (p, x.std())
+    x = S[:, 2 * npop - 1]
+    assert abs(x.mean() - a_tau / b_tau) < 4.5 * _batch_se(x), (x.mean(), _batch_se(x))
+    assert 0.85 < x.std() / (np.sqrt(a_tau) / b_tau) < 1.15
+    drv.close()
