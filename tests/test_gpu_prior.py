@@ -148,3 +148,49 @@ def test_all_loci_moves_leave_the_priors_of_theta_and_tau(taxa, model, R, mode, 
         assert g[0] > samples and g[1] > 0.5 * g[0]          # (three loci: the inverse-gamma fit is rougher than with thousands)
     eng.set_options(usedata=1, bfbeta=1.0)
     dev.close(); eng.close()
+
+
+@pytest.mark.parametrize("name,samples,thin", [("big-4x6", 700, 2), ("generic-3x4", 1000, 2)])
+def test_all_loci_moves_leave_the_priors_with_several_sequences_per_species(name, samples, thin):
+    """the same with several sequences per species (the tip populations have thetas too, the rubber band moves nodes inside
+    them) — on the big-tree sampler (24 tips) and on the generic one (12 tips)"""
+    c = CASES[name]
+    nsp = (len(c["parent"]) + 1) // 2
+    tips = nsp * c["per"]
+    species = [k // c["per"] for k in range(tips)]
+    npop = len(c["parent"])
+    a_th, b_th = 3.0, 3.0 / 0.002
+    a_tau, b_tau = 4.0, 4.0 / c["tau"][-1]
+    thetas = [a_th / b_th] * npop
+    rng = np.random.default_rng(5)
+    data = []
+    for _ in range(2):
+        left, right, times, root = synth.msc_start_tree(species, c["parent"], c["tau"], thetas, rng)
+        pats, w = bpp_amd.compress_site_patterns(["ACGT"] * tips, True, True)
+        data.append(dict(seqs=pats, weights=w, left=left, right=right, times=times, root=root, states=4, rate_cats=1, model="jc69", rates=np.ones(1)))
+    eng = bpp_amd.Engine(0)
+    eng.set_options(usedata=0, bfbeta=1.0)
+    dev = bpp_amd.Sampler(eng, tape.make_engine_loci(eng, data), data, seed=23)
+    dev.set_species_tree(c["parent"], c["tau"], thetas)
+    for i in range(len(data)):
+        dev.set_tip_species(i, species)
+    dev.set_tau_prior(a_tau, b_tau)
+    dev.set_theta_prior(a_th, b_th, 0.002)
+    dev.set_finetune(0.004, 0.004, 0.4 * c["tau"][-1], 0.5)
+    dev.initialize()
+    assert dev.kind() == c["kind"]
+    dev.iterate(600)
+    S = []
+    for _ in range(samples):
+        dev.iterate(thin)
+        S.append(dev.thetas() + dev.taus())
+    S = np.array(S)
+    for p in range(npop):
+        x = S[:, p]
+        assert abs(x.mean() - a_th / b_th) < 4.5 * _batch_se(x), (name, p, x.mean(), _batch_se(x))
+        assert 0.75 < x.std() / (np.sqrt(a_th) / b_th) < 1.25, (name, p, x.std())
+    x = S[:, 2 * npop - 1]
+    assert abs(x.mean() - a_tau / b_tau) < 4.5 * _batch_se(x), (name, x.mean(), _batch_se(x))
+    assert 0.8 < x.std() / (np.sqrt(a_tau) / b_tau) < 1.2
+    eng.set_options(usedata=1, bfbeta=1.0)
+    dev.close(); eng.close()
