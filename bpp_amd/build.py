@@ -64,10 +64,20 @@ def build_rccl(force=False, verbose=False):
     return RCCL_OUT
 
 
+def build_rccl_optional(force=False, verbose=False):
+    """libbpp_amd_rccl.so is a library of its own so that libbpp_amd.so does not depend on RCCL: a box without
+    rccl.h / librccl gets the core libraries and a warning (RcclExchange.lib() reports the missing .so)."""
+    try:
+        return build_rccl(force, verbose)
+    except (subprocess.CalledProcessError, OSError) as ex:
+        print(f"[bpp_amd.build] libbpp_amd_rccl.so not built ({ex}); the RCCL exchange is unavailable", file=sys.stderr)
+        return None
+
+
 def build(force=False, verbose=False):
-    build_rccl(force, verbose)
     if not force and not stale():
         build_host(False, verbose)
+        build_rccl_optional(False, verbose)
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
            "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-Wno-pass-failed",
@@ -77,6 +87,7 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
     build_host(True, verbose)
+    build_rccl_optional(force, verbose)
     return OUT
 
 

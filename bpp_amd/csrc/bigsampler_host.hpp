@@ -11,8 +11,9 @@ static int gb_upload(bpa_sampler * s)
   {
     gbig::BTree & t = s->b_trees[i];
     if (!assign_pops_host(s, t)) return 0;
-    // the scaler of an inner node's start buffer (gtree.c:2433-2439): its index among the inner nodes
-    for (int k = 0; k < 2*t.tips - 1; ++k) t.scaler[k] = (int16_t)((s->loci[i]->scale_buffers && k >= t.tips) ? k - t.tips : BPA_SCALE_BUFFER_NONE);
+    // the scaler that goes with an inner node's CURRENT CLV buffer (gtree.c:2433-2439 at the start: its index among the
+    // inner nodes; swap_clv toggles the two together, so scaler = clv - tips holds in mid-run too)
+    for (int k = 0; k < 2*t.tips - 1; ++k) t.scaler[k] = (int16_t)((s->loci[i]->scale_buffers && k >= t.tips) ? t.clv[k] - t.tips : BPA_SCALE_BUFFER_NONE);
     for (int p = 0; p < smp::MAXPOP; ++p) t.gl[p] = 0;
     for (int k = 0; k < t.tips; ++k) for (int q = t.pop[k]; q >= 0; q = s->sp.parent[q]) t.gl[q]++;
   }

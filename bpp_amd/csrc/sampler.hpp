@@ -1387,6 +1387,7 @@ extern "C" int bpa_sampler_gibbs_counters(bpa_sampler_t * s, unsigned long * pro
 extern "C" int bpa_sampler_set_tree(bpa_sampler_t * s, unsigned i, const int * left, const int * right,
                                     const double * times, int root)
 {
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (i >= s->nloci) return fail("bpa_sampler_set_tree: locus index out of range");
   const int tips = (int)s->loci[i]->tips;
   const a00_rng_t rng = stream_seed(s, s->locus_offset + i);
@@ -1924,12 +1925,18 @@ extern "C" int bpa_sampler_set_p2p(bpa_sampler_t * s, bpa_p2p_t * p, unsigned fi
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (p && (!p->connected || p->eng != s->eng)) return fail("bpa_sampler_set_p2p: connect the exchange first (same engine)");
   if (p && p->nmax < 8u) return fail("bpa_sampler_set_p2p: the mailboxes must hold at least 8 values");
+  // only the persistent kernel reads the mailboxes: a generic or big-tree sampler would decide from its own shard's sums
+  if (p && (s->generic || s->big)) return fail("bpa_sampler_set_p2p: the in-kernel exchange needs the persistent kernel (JC69 loci of <= 8 tips, <= 64 patterns); use bpa_sampler_set_allreduce");
   if (!sampler_invalidate(s)) return 0;
   s->p2p = p;
   if (first_locus != s->locus_offset)
   {
     s->locus_offset = first_locus;
-    for (unsigned i = 0; i < s->nloci; ++i) s->h_trees[i].rng = stream_seed(s, first_locus + i);
+    for (unsigned i = 0; i < s->nloci; ++i)
+    {
+      const a00_rng_t r = stream_seed(s, first_locus + i);
+      if (s->big) s->b_trees[i].rng = r; else if (s->generic) s->g_trees[i].rng = r; else s->h_trees[i].rng = r;
+    }
   }
   return 1;
 }

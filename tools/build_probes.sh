@@ -3,7 +3,7 @@
 # cross-compiled here, run on the GPU box through gpurun (e.g. gpurun -- tools/mfma_probe.bin)
 set -e
 cd "$(dirname "$0")"
-for f in probe probe2 probe_bw mfma_probe mfma_layout mfma_order; do
+for f in probe2 probe_bw mfma_order f64_rate; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o $f.bin $f.hip
 done
 ls -la *.bin
