@@ -743,8 +743,17 @@ def run_tape(eng, cfg, config_key, data, loci, args, D, steps, warmup):
     return out, (init, iters)
 
 
-def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
-    """BASELINE's metric proper: whole A00 MCMC iterations/s with every decision on the device"""
+# step lengths the unmodified program's burn-in (finetune = 1) tunes itself to on a 10 000-locus set of this shape (the
+# `statistical_efficiency` section measures them again on the box: `step_lengths`); the all-loci ones shrink with sqrt(loci)
+PROGRAM_FT = dict(gage=18.5, gspr=0.0019, theta=3e-5, tau=1.9e-5, mix=0.0059)
+
+
+def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves="program"):
+    """BASELINE's metric proper: whole A00 MCMC iterations/s with every decision on the device.
+    moves = "program" (JC69 loci on the persistent kernel): BPP's own iteration — its generator and Bactrian-Laplace windows
+    (bpa_sampler_set_proposal_kernel), theta by the metropolized Gibbs draw 9 times in 10, thetas re-drawn inside the
+    rubber-band and the mixing step (bpa_sampler_set_program_moves: stree.c:3957, 5840; prop_mixing.c:272);
+    "uniform": our 64-bit streams, uniform windows, a sliding-window theta, no re-draws (rounds 1-3's headline)."""
     import bpp_amd
     from bpp_amd import synth
     nloci = len(data)
@@ -790,8 +799,16 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
     smp.set_species_tree(sp_parent, sp_tau, sp_theta)
     smp.set_tau_prior(3.0, 3.0 / sp_tau[-1])
     generic = cfg["model"] != "jc69"
+    # the program's moves run inside the persistent kernel: one rank, or several exchanging through the in-kernel mailboxes
+    program = (not generic) and moves == "program" and (D is None or (D.p2p is not None and not os.environ.get("BENCH_PY_ALLREDUCE")))
     if generic:
         smp.set_theta_prior(2.0, 2.0 / sp_theta[0], 0.5 * sp_theta[0])
+    elif program:
+        scale = math.sqrt(10000.0 / max(D.sum_int(len(data)) if D else len(data), 1))
+        smp.set_proposal_kernel(1)
+        smp.set_program_moves(True, 0.1)                                 # (bpp.c:650: the sliding window 1 time in 10)
+        smp.set_theta_prior(2.0, 2.0 / sp_theta[0], PROGRAM_FT["theta"] * scale)
+        smp.set_finetune(PROGRAM_FT["gage"], PROGRAM_FT["gspr"], PROGRAM_FT["tau"] * scale, PROGRAM_FT["mix"] * scale)
     else:
         # step lengths of the all-loci moves at which the chain moves (acceptance of THETA / TAU / MIX around 0.3): they shrink
         # with the square root of the number of loci (all ranks' loci: one decision for the whole data set).  The work of an
@@ -929,6 +946,12 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup):
                proposals_per_locus_iteration=3 * cfg["taxa"] - 3 + (9 if gtr else 0),
                launches_per_iteration=round(max(l1 - l0 - (0 if kind == "persistent" else 1), 0) / niter, 4),      # (-1: the settle launch of the first summary)
                acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
+               moves=("the program's (BPP v4.8.7 defaults): legacy_rndu + Bactrian-Laplace windows, theta by the metropolized Gibbs draw 9 times in 10 "
+                      "(stree.c:3957), thetas re-drawn inside the rubber band (stree.c:5840) and the mixing step (prop_mixing.c:272); step lengths "
+                      f"of the program's own burn-in ({PROGRAM_FT})" if program else
+                      "uniform windows on the library's 64-bit streams, sliding-window theta, no theta re-draws in TAU / MIX" if not generic else
+                      "uniform windows on the library's 64-bit streams (generic sampler)"),
+               theta_gibbs_draws=(dict(zip(("proposed", "accepted"), smp.gibbs_counters())) if program else None),
                taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
                thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],
                roofline=add_frac_pmc(roofline),
@@ -973,6 +996,7 @@ def main():
                     help="skip the ESS/s section (one more 1 900-iteration run of the reference program with its burn-in, BPP's move kernel on the device)")
     ap.add_argument("--no-bpp-program", action="store_true",
                     help="skip timing the unmodified reference program (thread sweep) on the host cores")
+    ap.add_argument("--no-uniform-kernel", action="store_true", help="c2: skip the companion run with the library's uniform-window moves")
     ap.add_argument("--no-timing-events", action="store_true")
     ap.add_argument("--p2p-sums", action="store_true",
                     help="N > 1: exchange the sums with the one-shot p2p all-reduce over xGMI peer mappings (self-tested "
@@ -1042,6 +1066,10 @@ def main():
         sampler_sec = run_sampler(eng, cfg, data, loci, args, D, first_locus, args.steps, args.warmup)
         if "error" in sampler_sec:
             log(sampler_sec["error"])
+        elif args.config == "c2" and D is None and not args.no_uniform_kernel:
+            # rounds 1-3's headline iteration (half the program's effective samples per iteration), for comparison
+            u = run_sampler(eng, cfg, data, make_loci(eng, data), args, None, first_locus, max(args.steps // 4, 5), args.warmup, moves="uniform")
+            sampler_sec["device_uniform_kernel"] = {k: u[k] for k in ("iterations_per_s", "ms_per_iteration", "acceptance", "moves", "roofline") if k in u}
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and tape_steps is not None:
@@ -1201,7 +1229,7 @@ def main():
                                 "container's 8-vCPU Xeon 2.1 GHz (other hardware); the same-box figure is cpu_baseline") if vs_baseline else None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["name"] + f"; {nloci} loci on rank 0, {npat / nloci:.2f} patterns/locus" +
-                       (f"; {3 * cfg['taxa'] - 3} gene-tree proposals per locus + {2 * cfg['taxa'] - 1} theta + {cfg['taxa'] - 1} tau + 1 mixing step per iteration" if headline_sampler else ""),
+                       (f"; {3 * cfg['taxa'] - 3} gene-tree proposals per locus + a theta step per population + {cfg['taxa'] - 1} tau + 1 mixing step per iteration; moves: " + sampler_sec.get("moves", "?") if headline_sampler else ""),
                        "parallelism": parallelism},
             "site_lnl_updates_per_s": tape_sec["site_lnl_updates_per_s"] if tape_sec else None,
             "roofline": roofline,

@@ -877,7 +877,7 @@ static int theta_sums(a00_driver_t * d, long long * ksum, long long * tsum)
 static int theta_step_gibbs(a00_driver_t * d)
 {
   int p, slide[A00_MAXPOP], bad = 0; long li;
-  double tnew[A00_MAXPOP];
+  double tnew[A00_MAXPOP], fa[A00_MAXPOP], fb[A00_MAXPOP];
   long long ksum[A00_MAXPOP], tsum[A00_MAXPOP];
   for (p = 0; p < d->npop; ++p)
   {
@@ -889,27 +889,26 @@ static int theta_step_gibbs(a00_driver_t * d)
   bad = !theta_sums(d, ksum, tsum);
   d->run_ok = !bad;
   for (p = 0; p < d->npop; ++p) { d->run_k[p] = ksum[p]; d->run_T[p] = (double)tsum[p]*(1.0/1099511627776.0); }
+  /* the Gibbs variates of all populations first (the device takes them side by side), then the decisions */
+  for (p = 0; p < d->npop; ++p)
+  {
+    fa[p] = fb[p] = NAN;
+    if (!d->has_theta[p] || bad || slide[p]) continue;
+    a00_theta_conditional_invgamma(d->theta_alpha, d->theta_beta, (long)ksum[p], d->run_T[p], &fa[p], &fb[p]);
+    if (fa[p] == fa[p]) tnew[p] = 1/(a00_bpp_rndgamma(&d->gz, fa[p])/fb[p]);
+  }
   for (p = 0; p < d->npop; ++p)
   {
     double lnacc = NAN, T; int acc_ = 0;
     if (!d->has_theta[p]) continue;
     d->proposals++;
-    T = (double)tsum[p]*(1.0/1099511627776.0);
+    T = d->run_T[p];
     if (!bad)
     {
       if (slide[p]) lnacc = a00_theta_lnacc((long)ksum[p], T, d->theta[p], tnew[p], d->theta_alpha, d->theta_beta);
-      else
-      {
-        double a1, b1, g;
-        a00_theta_conditional_invgamma(d->theta_alpha, d->theta_beta, (long)ksum[p], T, &a1, &b1);
-        if (a1 == a1)
-        {
-          g = a00_bpp_rndgamma(&d->gz, a1);
-          tnew[p] = 1/(g/b1);
-          lnacc = a00_theta_lnacc((long)ksum[p], T, d->theta[p], tnew[p], d->theta_alpha, d->theta_beta)
-                + a00_theta_gibbs_hastings(a1, b1, d->theta[p], tnew[p]);
-        }
-      }
+      else if (fa[p] == fa[p])
+        lnacc = a00_theta_lnacc((long)ksum[p], T, d->theta[p], tnew[p], d->theta_alpha, d->theta_beta)
+              + a00_theta_gibbs_hastings(fa[p], fb[p], d->theta[p], tnew[p]);
       acc_ = lnacc == lnacc && tnew[p] > 0 && accept(d, -1, lnacc, -1.0);
     }
     declog(slide[p] ? "theta" : "thetag", p, lnacc, -1.0, acc_);

@@ -2036,13 +2036,14 @@ static int sampler_download(bpa_sampler * s)
     if (s->env_dbg & 16u)
     {
       double pr[16]; HIPCHK(hipMemcpy(pr, s->v2_prof.p, sizeof pr, hipMemcpyDeviceToHost));
-      fprintf(stderr, "[smp2] cycles of lane 0 of workgroup 0, last launch: propose %.0f evaluate %.0f decide %.0f theta %.0f tau %.0f mix %.0f | exchange: theta %.0f tau+mix %.0f | inside the exchanges: first barrier %.0f sums %.0f barrier %.0f arrival + poll %.0f last barrier %.0f\n",
-              pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11], pr[12]);
+      fprintf(stderr, "[smp2] cycles of lane 0 of workgroup 0, last launch: propose %.0f evaluate %.0f decide %.0f theta %.0f tau %.0f mix %.0f | exchange: theta %.0f tau+mix %.0f | inside the exchanges: first barrier %.0f sums %.0f barrier %.0f arrival + poll %.0f last barrier %.0f | of theta / tau / mix: the decision's arithmetic after the totals %.0f %.0f, MIX's re-draws inside the wait %.0f\n",
+              pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11], pr[12], pr[13], pr[14], pr[15]);
     }
     if (s->env_dbg & 256u)
     {
       std::vector<double> r(4*2048); HIPCHK(hipMemcpy(r.data(), s->v2_declog.p, r.size()*sizeof(double), hipMemcpyDeviceToHost));
-      for (unsigned k = 0; k < 2048 && r[4*k] != 0; ++k)
+      for (unsigned k = 1000; k < 2048; ++k) if (r[4*k] != 0) fprintf(stderr, "[smp2dbg] %u: %g %.17g %.17g %.17g\n", k, r[4*k], r[4*k+1], r[4*k+2], r[4*k+3]);
+      for (unsigned k = 0; k < 1000 && r[4*k] != 0; ++k)
         fprintf(stderr, "[smp2] %s %d lnacc %.17g u %.17g -> %d\n", r[4*k] >= 300 ? "mix" : r[4*k] >= 200 ? "tau" : "theta",
                 (int)r[4*k] % 100, r[4*k + 1], r[4*k + 2], (int)r[4*k + 3]);
     }

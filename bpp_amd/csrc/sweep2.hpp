@@ -108,7 +108,7 @@ template <int NT> struct WgLDS
   double run_k[MAXPOP], run_T[MAXPOP];             // program moves: k_p and T_p of the current gene trees, from the THETA step's sums on (a00_driver.c: run_k, run_T)
   uint32_t run_ok, pad2_;
   uint32_t anc[16];
-  uint32_t abort_, bad_;
+  uint32_t abort_, bad_, xbad_, pad3_;
   Species sp;
   long long prof[16];                            // BPA_SMP_DBG & 16: cycle counters of thread 0 of workgroup 0
 };
@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   for (uint32_t i = tid; i < (uint32_t)(3*MAXPOP); i += C::BS) wg.tau[i] = A.taus[i];
   for (uint32_t i = tid; i < (uint32_t)((2*NT)*(2*NT)); i += C::BS) wg.lograt[i] = A.lograt[(i/(2*NT))*MAXN + i % (2*NT)];
   if (tid < 16u) wg.anc[tid] = tid < (uint32_t)MAXPOP ? (uint32_t)SP.anc[tid] : 0u;
-  if (tid == 0) { wg.abort_ = 0; wg.bad_ = 0; }
+  if (tid == 0) { wg.abort_ = 0; wg.bad_ = 0; wg.xbad_ = 0; }
   if (tid < 32u) wg.accfx[tid] = 0ull;
   PopLane pl;
   {
@@ -632,6 +632,9 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   const bool prof_on = (A.dbg & 16u) && b == 0 && tid == 0;
   long long pf_t = prof_on ? clock64() : 0;
 #define SMP2_TICK(i_) do { if (prof_on) { const long long t1_ = clock64(); wg.prof[i_] += t1_ - pf_t; pf_t = t1_; } } while (0)
+  long long pf_s = 0;
+#define SMP2_SUB0() do { if (prof_on) pf_s = clock64(); } while (0)
+#define SMP2_SUB(i_) do { if (prof_on) wg.prof[i_] += clock64() - pf_s; } while (0)
 
   // ---- the sum over ALL loci of one all-loci step's terms.  A term enters as 2^-40 fixed point (what the host driver adds
   // up in doubles, locus by locus: the totals agree to ~1e-11), so a total does not depend on the order of the additions: the lanes add theirs to the workgroup's accumulators (LDS atomics, fx_add),
@@ -653,107 +656,245 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   uint32_t nx = 0;
   unsigned long long gseq = A.seq0;                 // several GPUs: the mailboxes' sequence number
   unsigned long long xprev0 = 0, xprev1 = 0;       // wave 0, lane 8 x + k: word k of shard x of each set when its previous use completed
-  auto exchange = [&](int nval, int want, double & mine_tot) -> bool
-  {
-    long long xt0 = prof_on ? clock64() : 0;
 #define XT(i_) do { if (prof_on) { const long long t1_ = clock64(); wg.prof[8 + i_] += t1_ - xt0; xt0 = t1_; } } while (0)
+  long long xt0 = 0;
+  // one block of <= 7 values (7 sums + the counter = one 64-byte block): the workgroup's sums go to its shard, then its arrival
+  auto xpush = [&](int v0, int nv)
+  {
+    const uint32_t par = nx & 1u; ++nx;
+    // 8 shards, a workgroup adds to shard b mod 8: atomics on one word are served one after the other
+    unsigned long long * acc = A.xbuf + (size_t)par*XN + (size_t)(b & 7u)*8u;
+    if (tid < (uint32_t)nv)
+    {
+      const unsigned long long fx = wg.accfx[v0 + (int)tid];
+      wg.accfx[v0 + (int)tid] = 0ull;
+      const unsigned long long old = __hip_atomic_fetch_add(acc + tid, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" :: "v"(old) : "memory");          // the sums have landed before the arrival is counted
+    }
+    XT(1);
+    __syncthreads();
+    XT(2);
+    // arrival: + 1, and + 2^32 when a term of this workgroup was unusable
+    if (tid == 0) (void)__hip_atomic_fetch_add(acc + 7, 1ull + ((unsigned long long)wg.bad_ << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // ... and the wait for everybody's: wave 0 polls, the totals go to wg.xtot[v0 ..]; last = the exchange's last block.  False: timed out
+  auto xpoll = [&](int v0, int nv, bool last) -> bool
+  {
+    const uint32_t par = (nx - 1u) & 1u;
+    unsigned long long * set = A.xbuf + (size_t)par*XN;
+    if (wv == 0)
+    {
+      const unsigned long long t_wait = wall_clock64();
+      const unsigned long long prev = par ? xprev1 : xprev0;
+      bool ok = true;
+      unsigned long long cur = 0, d = 0, gd = 0;
+      for (uint32_t rounds = 1;; ++rounds)
+      {
+        // ONE load: lane 8 x + k reads word k of shard x; the shards' growth since the set's previous use, added up
+        cur = __hip_atomic_load(set + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        d = cur - prev;
+        d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 16, 64); d += __shfl_xor(d, 32, 64);
+        if ((uint32_t)__shfl(d, 7, 64) >= A.nwg) break;
+        if ((rounds & 63u) == 0 && wall_clock64() - t_wait > 50000000ull) { ok = false; break; }     // 0.5 s at 100 MHz
+        __builtin_amdgcn_s_sleep(1);
+      }
+      bool anybad = ok && (__shfl(d, 7, 64) >> 32) != 0;
+      if (ok && A.world > 1)
+      {
+        // ---- several GPUs: this rank's sums (lanes 0..6) and its unusable-term flag (lane 7) go to slot `rank` of
+        // EVERY rank's mailbox over the xGMI peer mappings — workgroup 0 publishes, values first, then the sequence
+        // flag —, and every workgroup adds up the N slots of its own mailbox once their flags show this exchange.
+        // Fixed point: the same total on every rank whatever the order.  Mailboxes alternate by sequence parity.
+        ++gseq;
+        const size_t slot = ((size_t)(gseq & 1ull)*(size_t)A.world)*A.slot_bytes;
+        if (b == 0)
+        {
+          const unsigned long long v = lane < (uint32_t)nv ? d : (lane == 7u && anybad) ? 1ull : 0ull;
+          if (lane < 8u)
+            for (int pr_ = 0; pr_ < A.world; ++pr_)
+              __hip_atomic_store(reinterpret_cast<unsigned long long *>(A.peers[pr_] + slot + (size_t)A.rank*A.slot_bytes + p2p::HDR) + lane, v,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __threadfence_system();
+          __builtin_amdgcn_wave_barrier();
+          if (lane < (uint32_t)A.world)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(A.peers[lane] + slot + (size_t)A.rank*A.slot_bytes), gseq,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        bool here = true;
+        if (lane < (uint32_t)A.world)
+        {
+          const unsigned long long * f = reinterpret_cast<const unsigned long long *>(A.mail + slot + (size_t)lane*A.slot_bytes);
+          const unsigned long long tw = wall_clock64();
+          while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != gseq)
+          {
+            if (wall_clock64() - tw > A.spin_limit) { here = false; break; }
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        if (!__all(here ? 1 : 0)) { ok = false; if (lane == 0) *A.p2p_err = 1; }
+        else
+        {
+          unsigned long long tot = 0;
+          for (int r = 0; r < A.world; ++r)
+            tot += __hip_atomic_load(reinterpret_cast<const unsigned long long *>(A.mail + slot + (size_t)r*A.slot_bytes + p2p::HDR) + (lane & 7u),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          gd = tot; anybad = __shfl(tot, 7, 64) != 0;
+        }
+      }
+      XT(3);
+      if (ok)
+      {
+        const unsigned long long dd = A.world > 1 ? gd : d;
+        if (lane < (uint32_t)nv) wg.xtot[v0 + (int)lane] = anybad ? __longlong_as_double(0x7ff8000000000000ll) : (double)(long long)dd*(1.0/FX);
+        if (par) xprev1 = cur; else xprev0 = cur;
+        // (an unusable term stays flagged through every block of the exchange: its value may lie in a later one)
+        if (lane == 0) { if (anybad) wg.xbad_ = 1u; if (last) wg.bad_ = 0; }
+      }
+      else if (lane == 0) { wg.abort_ = 1; *A.err = 1; }
+    }
+    __syncthreads();
+    XT(4);
+    return !wg.abort_;
+  };
+  // an exchange of nval sums: begin = this workgroup's part (its first block is on its way when this returns), end = the wait
+  // (and the blocks after the first, one after the other: two accumulator sets alternate).  What lies between the two
+  // runs while the slower workgroups are still at their loci.  If any term of any block was unusable, EVERY total is NaN.
+  int x_nval = 0;
+  auto exchange_begin = [&](int nval)
+  {
+    xt0 = prof_on ? clock64() : 0;
     __syncthreads();                                 // every lane's term is in wg.accfx
     XT(0);
-    for (int v0 = 0; v0 < nval; v0 += 7)             // (7 sums + the counter = one 64-byte block)
+    x_nval = nval;
+    if (tid == 0) wg.xbad_ = 0;
+    xpush(0, nval < 7 ? nval : 7);
+  };
+  auto exchange_end = [&](int want, double & mine_tot) -> bool
+  {
+    const int nval = x_nval;
+    xt0 = prof_on ? clock64() : 0;
+    if (!xpoll(0, nval < 7 ? nval : 7, nval <= 7)) return false;
+    for (int v0 = 7; v0 < nval; v0 += 7)
     {
       const int nv = nval - v0 < 7 ? nval - v0 : 7;
-      const uint32_t par = nx & 1u; ++nx;
-      // 8 shards, a workgroup adds to shard b mod 8: atomics on one word are served one after the other
-      unsigned long long * set = A.xbuf + (size_t)par*XN;
-      unsigned long long * acc = set + (size_t)(b & 7u)*8u;
-      if (tid < (uint32_t)nv)
-      {
-        const unsigned long long fx = wg.accfx[v0 + (int)tid];
-        wg.accfx[v0 + (int)tid] = 0ull;
-        const unsigned long long old = __hip_atomic_fetch_add(acc + tid, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" :: "v"(old) : "memory");          // the sums have landed before the arrival is counted
-      }
-      XT(1);
-      __syncthreads();
-      XT(2);
-      if (wv == 0)
-      {
-        // arrival: + 1, and + 2^32 when a term of this workgroup was unusable
-        if (lane == 0) (void)__hip_atomic_fetch_add(acc + 7, 1ull + ((unsigned long long)wg.bad_ << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t_wait = wall_clock64();
-        const unsigned long long prev = par ? xprev1 : xprev0;
-        bool ok = true;
-        unsigned long long cur = 0, d = 0, gd = 0;
-        for (uint32_t rounds = 1;; ++rounds)
-        {
-          // ONE load: lane 8 x + k reads word k of shard x; the shards' growth since the set's previous use, added up
-          cur = __hip_atomic_load(set + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          d = cur - prev;
-          d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 16, 64); d += __shfl_xor(d, 32, 64);
-          if ((uint32_t)__shfl(d, 7, 64) >= A.nwg) break;
-          if ((rounds & 63u) == 0 && wall_clock64() - t_wait > 50000000ull) { ok = false; break; }     // 0.5 s at 100 MHz
-          __builtin_amdgcn_s_sleep(1);
-        }
-        bool anybad = ok && (__shfl(d, 7, 64) >> 32) != 0;
-        if (ok && A.world > 1)
-        {
-          // ---- several GPUs: this rank's sums (lanes 0..6) and its unusable-term flag (lane 7) go to slot `rank` of
-          // EVERY rank's mailbox over the xGMI peer mappings — workgroup 0 publishes, values first, then the sequence
-          // flag —, and every workgroup adds up the N slots of its own mailbox once their flags show this exchange.
-          // Fixed point: the same total on every rank whatever the order.  Mailboxes alternate by sequence parity.
-          ++gseq;
-          const size_t slot = ((size_t)(gseq & 1ull)*(size_t)A.world)*A.slot_bytes;
-          if (b == 0)
-          {
-            const unsigned long long v = lane < (uint32_t)nv ? d : (lane == 7u && anybad) ? 1ull : 0ull;
-            if (lane < 8u)
-              for (int pr_ = 0; pr_ < A.world; ++pr_)
-                __hip_atomic_store(reinterpret_cast<unsigned long long *>(A.peers[pr_] + slot + (size_t)A.rank*A.slot_bytes + p2p::HDR) + lane, v,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __threadfence_system();
-            __builtin_amdgcn_wave_barrier();
-            if (lane < (uint32_t)A.world)
-              __hip_atomic_store(reinterpret_cast<unsigned long long *>(A.peers[lane] + slot + (size_t)A.rank*A.slot_bytes), gseq,
-                                 __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
-          bool here = true;
-          if (lane < (uint32_t)A.world)
-          {
-            const unsigned long long * f = reinterpret_cast<const unsigned long long *>(A.mail + slot + (size_t)lane*A.slot_bytes);
-            const unsigned long long tw = wall_clock64();
-            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != gseq)
-            {
-              if (wall_clock64() - tw > A.spin_limit) { here = false; break; }
-              __builtin_amdgcn_s_sleep(2);
-            }
-          }
-          if (!__all(here ? 1 : 0)) { ok = false; if (lane == 0) *A.p2p_err = 1; }
-          else
-          {
-            unsigned long long tot = 0;
-            for (int r = 0; r < A.world; ++r)
-              tot += __hip_atomic_load(reinterpret_cast<const unsigned long long *>(A.mail + slot + (size_t)r*A.slot_bytes + p2p::HDR) + (lane & 7u),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            gd = tot; anybad = __shfl(tot, 7, 64) != 0;
-          }
-        }
-        XT(3);
-        if (ok)
-        {
-          const unsigned long long dd = A.world > 1 ? gd : d;
-          if (lane < (uint32_t)nv) wg.xtot[v0 + (int)lane] = anybad ? __longlong_as_double(0x7ff8000000000000ll) : (double)(long long)dd*(1.0/FX);
-          if (par) xprev1 = cur; else xprev0 = cur;
-          if (lane == 0) wg.bad_ = 0;
-        }
-        else if (lane == 0) { wg.abort_ = 1; *A.err = 1; }
-      }
-      __syncthreads();
-      XT(4);
-      if (wg.abort_) return false;
+      xpush(v0, nv);
+      if (!xpoll(v0, nv, v0 + 7 >= nval)) return false;
     }
-#undef XT
+    if (nval > 7 && wg.xbad_)
+    {
+      __syncthreads();
+      if (tid < (uint32_t)nval) wg.xtot[tid] = __longlong_as_double(0x7ff8000000000000ll);
+      __syncthreads();
+    }
     mine_tot = wg.xtot[want & 31];
     return true;
+  };
+  auto exchange = [&](int nval, int want, double & mine_tot) -> bool
+  {
+    exchange_begin(nval);
+    return exchange_end(want, mine_tot);
+  };
+#undef XT
+  // ---- the program's moves (a00_set_program_moves): what every wave keeps on lane p < 16 about population p — k_p and T_p,
+  // the sums over ALL loci of the coalescences in p and of T2h (from the THETA step's exchange on, carried through TAU and
+  // MIX: run_k / run_T of a00_driver.c), and the inverse gamma fitted to the theta's conditional given them (a, b,
+  // c = a log b - lgamma a): the "current" side of every re-draw's proposal ratio — always a fit some step already made
+  // from exactly these two numbers (THETA: every theta; an accepted TAU / MIX: the fits to the sums it installed).
+  const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+  double runK = 0, runT = 0, fitA = qnan, fitB = qnan, fitC = qnan;
+  bool run_ok = false;
+  const uint32_t pl16 = lane & 15u, role = lane >> 4;
+  // lgamma(a) from log(a) (Stirling's series: |error| < 1e-16 from 16 on), so that it shares a log call with its neighbours
+  auto lgamma_with_log = [](double a, double la) -> double
+  {
+    if (!(a >= 16.0)) return lgamma(a);
+    const double r = 1.0/a, r2 = r*r;
+    const double ser = r*(1.0/12 - r2*(1.0/360 - r2*(1.0/1260 - r2*(1.0/1680 - r2*(1.0/1188)))));
+    return ((a - 0.5)*la - a) + (0.91893853320467274178 + ser);
+  };
+  auto lcg = [](uint32_t & z) -> double                          // a00_bpp_rndu_hd (legacy_rndu, random.c:104-122)
+  {
+    z = z*69069u + 1u;
+    if (z == 0u) z = 12345671u;
+    return (double)z*(1.0/4294967296.0);
+  };
+  // gamma(shape, 1) variates for the populations of `list` (4 bits each, n entries) whose bit is set in `want`, from the global
+  // stream in list order, exactly the numbers a00_bpp_rndgamma (legacy_rndgamma, random.c:240-275: Marsaglia-Tsang on the
+  // polar normal) gives one after the other — but side by side: WHICH uniforms a variate takes is settled by cheap
+  // arithmetic alone (a polar pair is taken when s = u^2 + v^2 lies in (0, 1); then one uniform for the test) as long as
+  // every variate passes its test at the first round, so every wave walks the stream through all of them first and
+  // lane p then does population p's square root, logs and test.  A variate that does not pass (about one draw in a
+  // hundred) sends everybody back to the start of the block and through the draws one after the other.
+  // shape: lane p.  xarg / xlog: a number per lane >= 16 whose log rides along in the same call.  Returns the variate on lane p.
+  auto draw_gammas = [&](unsigned long long list, int n, uint32_t want, double shape, double xarg, double & xlog) -> double
+  {
+    const uint32_t z0 = (uint32_t)grng.r;
+    uint32_t z = z0;
+    double mu = 0, ms = 0.5, m3 = 0; bool scan_ok = true;
+    for (int i = 0; i < n; ++i)
+    {
+      const uint32_t p = (uint32_t)(list >> (4*i)) & 15u;
+      if (!((want >> p) & 1u)) continue;
+      double u = 0, s2 = 0; bool got = false;
+      for (int rd = 0; rd < 64 && !got; ++rd)
+      {
+        u = 2*lcg(z) - 1; const double v = 2*lcg(z) - 1;
+        s2 = u*u + v*v;
+        got = s2 > 0 && s2 < 1;
+      }
+      scan_ok = scan_ok && got;
+      const double u3 = lcg(z);
+      if (lane == p) { mu = u; ms = s2; m3 = u3; }
+    }
+    const bool mine = lane < 16u && ((want >> lane) & 1u);
+    const double d = shape - 1.0/3.0, c = (1.0/3.0)/sqrt(d);
+    const double L = log(lane < 16u ? ms : xarg);
+    xlog = L;
+    double g = qnan; bool ok = true;
+    if (mine)
+    {
+      const double x = mu*sqrt(-2*L/ms);
+      double v = 1.0 + c*x;
+      ok = v > 0 && shape >= 1;
+      v *= v*v;
+      if (ok && !(m3 < 1 - 0.0331*x*x*x*x)) ok = log(m3) < 0.5*x*x + d*(1 - v + log(v));
+      v *= d;
+      if (v == 0) v = 1E-300;
+      g = v;
+    }
+    if (!scan_ok || __any(mine && !ok))
+    {
+      z = z0;
+      for (int i = 0; i < n; ++i)
+      {
+        const uint32_t p = (uint32_t)(list >> (4*i)) & 15u;
+        if (!((want >> p) & 1u)) continue;
+        const double gi = a00_bpp_rndgamma(&z, __shfl(shape, (int)p, 64));
+        if (lane == p) g = gi;
+      }
+    }
+    grng.r = z;
+    return g;
+  };
+  // A re-drawn theta's part of ln(acceptance ratio) (tau_step / mix_step of a00_driver.c; stree.c:5840-5990, prop_mixing.c:272-425), lane p < 16 for population p:
+  //   [invgamma(theta | old fit) - invgamma(theta' | new fit)] + [gamma prior ratio] + [k (log 2/theta' - log 2/theta) - (T'/theta' - T/theta)]
+  // Its four logs and four quotients are taken side by side: lane p + 16 m computes piece m.  l2t_new = log(2/theta') comes out too.
+  auto redraw_ratio = [&](double tn, double a1, double b1, double c1, double Tn, double ao, double bo, double co, double Told, double & l2t_new) -> double
+  {
+    const int p = (int)pl16;
+    const double tn_p = __shfl(tn, p, 64), to_p = wg.tau[MAXPOP + (p < MAXPOP ? p : 0)];
+    // (every shuffle by every lane: a lane that sits out a branch hands nothing over)
+    const double s_b1 = __shfl(b1, p, 64), s_Tn = __shfl(Tn, p, 64), s_To = __shfl(Told, p, 64), s_bo = __shfl(bo, p, 64);
+    const double num = role == 0u ? s_b1 : role == 1u ? s_Tn : role == 2u ? s_To : s_bo;
+    const double q = role == 1u ? tn_p/to_p : 2.0/tn_p;
+    const double L = log(role == 0u ? tn_p : role == 3u ? to_p : q);         // log theta' | log(theta'/theta) | log(2/theta') | log theta
+    const double r = num/((role & 2u) ? to_p : tn_p);                        // b'/theta'  | T'/theta'         | T/theta       | b/theta
+    const double L0 = __shfl(L, p, 64), L1 = __shfl(L, 16 + p, 64), L2 = __shfl(L, 32 + p, 64), L3 = __shfl(L, 48 + p, 64);
+    const double r0 = __shfl(r, p, 64), r1 = __shfl(r, 16 + p, 64), r2 = __shfl(r, 32 + p, 64), r3 = __shfl(r, 48 + p, 64);
+    l2t_new = L2;
+    const double l2t_old = wg.tau[2*MAXPOP + (p < MAXPOP ? p : 0)];
+    const double anew = (c1 + (-a1 - 1)*L0) - r0, aold = (co + (-ao - 1)*L3) - r3;
+    return (aold - anew) + ((SP.theta_alpha - 1)*L1 - SP.theta_beta*(tn - to_p)) + (runK*(L2 - l2t_old) - (r1 - r2));
   };
   uint32_t cnt_prop = 0, cnt_acc = 0;              // all-loci proposals / accepted (the same in every workgroup)
   uint32_t cnt_gprop = 0, cnt_gacc = 0;            // of those: Gibbs draws of a theta
@@ -804,7 +945,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       const bool gibbs = BPP && SP.program_moves;               // the program's own mix of moves (theta_step_gibbs of a00_driver.c)
       const bool on = li < npop && ((A.theta_mask >> li) & 1u);
       const double told = pl.theta, l2t_old = pl.l2t;
-      double tnew = told, uacc = -1.0, my_lnacc = 0;
+      double tnew = told, uacc = -1.0, my_lnacc = 0, l2t_gibbs = 0;
       bool accept = false, gibbs_me = false;
       if (!gibbs)
       {
@@ -853,14 +994,14 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         // the thetas, so ONE exchange serves every population.  Global stream: choice (+ window) per population first,
         // then per population the gamma variate of a Gibbs draw and the acceptance number when one is needed.
         uint32_t slidem = 0;
-        const double qnan_ = __longlong_as_double(0x7ff8000000000000ll);
+        double tslide = 0;                                                   // lane p < 16: the window's theta of population p
         for (int p = 0; p < npop; ++p)
           if ((A.theta_mask >> p) & 1u)
           {
             if (!(grng.u() < SP.theta_slide_prob)) continue;
             slidem |= 1u << p;
             const double tn = reflect(wg.tau[MAXPOP + p] + SP.ft_theta*grng.window(), 0.0, 999.0);
-            if (p == li) tnew = tn;
+            if (p == (int)lane) tslide = tn;
           }
         const int kidx = __popc(A.theta_mask & ((1u << li) - 1u));
         if (act && on) { fx_add(2*kidx, (double)mync, false); fx_add(2*kidx + 1, t2h_cur, false); }
@@ -868,48 +1009,74 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         double dummy = 0;
         if (!exchange(2*__popc(A.theta_mask), 0, dummy)) { aborted = true; break; }
         SMP2_TICK(6);
-        if (on) wl.term[li] = tnew;
-        wsync();
-        // the fits of all thetas side by side: lane p of the wave fits population p (the bisection is the long part)
-        double fa = qnan_, fb = qnan_;
-        if (lane < (uint32_t)npop && ((A.theta_mask >> lane) & 1u) && !((slidem >> lane) & 1u))
+        SMP2_SUB0();
+        // ---- lane p < 16 is population p from here on: its sums, its fit, its draw, its ratio
+        const bool mine = lane < (uint32_t)npop && ((A.theta_mask >> lane) & 1u);
         {
           const int kx = __popc(A.theta_mask & ((1u << lane) - 1u));
-          const double ks = wg.xtot[2*kx], Ts = wg.xtot[2*kx + 1];
-          if (ks == ks && Ts == Ts) a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)ks, Ts, &fa, &fb);
+          runK = mine ? wg.xtot[(2*kx) & 31] : 0.0; runT = mine ? wg.xtot[(2*kx + 1) & 31] : 0.0;
         }
-        int kk = 0;
+        run_ok = !__any(mine && !(runK == runK && runT == runT));              // (an unusable term anywhere: every decision is a rejection, nothing drawn)
+        fitA = fitB = fitC = qnan;
+        double tn = mine ? ((slidem >> lane) & 1u ? tslide : qnan) : 0.0, lnacc_p = qnan, e_p = 0;
+        if (run_ok)
+        {
+          // the fits of all thetas side by side (the 35-step bisection is the long part), then the Gibbs variates
+          if (mine) a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)runK, runT, &fitA, &fitB);
+          const uint32_t fitm = (uint32_t)__ballot(mine && fitA == fitA) & 0xffffu;
+          const uint32_t gm = A.theta_mask & ~slidem & fitm;
+          double xl;
+          const double s_fa = __shfl(fitA, (int)pl16, 64), s_fb = __shfl(fitB, (int)pl16, 64);
+          const double g = draw_gammas(0xfedcba9876543210ull, npop, gm, fitA, role == 1u ? s_fb : s_fa, xl);
+          {
+            const double lb = __shfl(xl, 16 + (int)pl16, 64), la = __shfl(xl, 32 + (int)pl16, 64);
+            if (lane < 16u && fitA == fitA) fitC = fitA*lb - lgamma_with_log(fitA, la);
+          }
+          if ((gm >> lane) & 1u && lane < 16u) tn = 1/(g/fitB);
+          // ln of the acceptance ratio (a00_theta_lnacc, + a00_theta_gibbs_hastings for a Gibbs draw): lane p + 16 m takes piece m
+          {
+            const int p = (int)pl16;
+            const double tn_p = __shfl(tn, p, 64), to_p = wg.tau[MAXPOP + (p < MAXPOP ? p : 0)], T_p = __shfl(runT, p, 64);
+            const double q = role == 0u ? 2.0/tn_p : role == 1u ? tn_p/to_p : to_p/tn_p;
+            const double L = log(q);                                             // log(2/theta') | log(theta'/theta) | log(theta/theta')
+            const double r = (role < 2u ? T_p : 1.0)/((role & 1u) ? to_p : tn_p);    // T/theta' | T/theta | 1/theta' | 1/theta
+            const double L2 = __shfl(L, p, 64), L1 = __shfl(L, 16 + p, 64), L3 = __shfl(L, 32 + p, 64);
+            const double r0 = __shfl(r, p, 64), r1 = __shfl(r, 16 + p, 64), r2 = __shfl(r, 32 + p, 64), r3 = __shfl(r, 48 + p, 64);
+            const double l2t_old = wg.tau[2*MAXPOP + (p < MAXPOP ? p : 0)];
+            if (mine && tn == tn)
+            {
+              lnacc_p = (runK*(L2 - l2t_old) - (r0 - r1)) + ((SP.theta_alpha - 1)*L1 - SP.theta_beta*(tn - to_p));
+              if ((gm >> lane) & 1u) lnacc_p += (-fitA - 1)*L3 - fitB*(r3 - r2);
+            }
+            e_p = exp(lnacc_p);
+            wl.term[lane] = lane < 16u ? tn : lane < 32u ? L2 : 0.0;            // (the groups' lanes pick their population's up below)
+          }
+        }
+        else wl.term[lane] = lane < 16u ? tn : 0.0;
+        // the acceptance numbers, in population order, drawn only when needed
+        uint32_t accm = 0;
         for (int p = 0; p < npop; ++p)
           if ((A.theta_mask >> p) & 1u)
           {
-            const double ks = wg.xtot[2*kk], Ts = wg.xtot[2*kk + 1]; ++kk;
-            const double to = wg.tau[MAXPOP + p];
-            const bool sl = (slidem >> p) & 1u;
-            if (tid == 0) { wg.run_k[p] = ks; wg.run_T[p] = Ts; wg.run_ok = ks == ks && Ts == Ts ? 1u : 0u; }   // (read by TAU and MIX, behind barriers)
-            double tn = wl.term[p], lnacc = __longlong_as_double(0x7ff8000000000000ll);
-            if (ks == ks && Ts == Ts)                                          // (an unusable term anywhere: every decision is a rejection, nothing drawn)
-            {
-              const long k = (long)ks;
-              if (sl) lnacc = a00_theta_lnacc(k, Ts, to, tn, SP.theta_alpha, SP.theta_beta);
-              else
-              {
-                const double a1 = __shfl(fa, p, 64), b1 = __shfl(fb, p, 64);
-                if (a1 == a1)
-                {
-                  unsigned int z = (unsigned int)grng.r;
-                  const double g = a00_bpp_rndgamma(&z, a1);
-                  grng.r = z;
-                  tn = 1/(g/b1);
-                  lnacc = a00_theta_lnacc(k, Ts, to, tn, SP.theta_alpha, SP.theta_beta) + a00_theta_gibbs_hastings(a1, b1, to, tn);
-                }
-              }
-            }
-            const bool acc = lnacc == lnacc && tn > 0 && grng.accept(lnacc);
-            if (p == li) { accept = acc; my_lnacc = lnacc; tnew = tn; gibbs_me = !sl; }
+            const double la_ = __shfl(lnacc_p, p, 64), tn_ = __shfl(tn, p, 64);
+            bool acc = la_ == la_ && tn_ > 0;
+            if (acc && !(la_ >= -1e-10)) acc = grng.u() < __shfl(e_p, p, 64);
+            accm |= acc ? 1u << p : 0u;
           }
         wsync();
+        const double s_lnacc = __shfl(lnacc_p, li, 64);
+        if (on)
+        {
+          accept = (accm >> li) & 1u; gibbs_me = !((slidem >> li) & 1u);
+          tnew = wl.term[li]; my_lnacc = s_lnacc;
+          if (!(tnew == tnew)) tnew = told;
+        }
+        l2t_gibbs = run_ok ? wl.term[16 + (li & 15)] : 0.0;
+        wsync();
+        SMP2_SUB(13);
       }
-      const double l2t_new = log(2.0/(1.0*tnew));
+      // (log(2/theta') of the program's moves came out of the ratio's log call)
+      const double l2t_new = gibbs ? l2t_gibbs : log(2.0/(1.0*tnew));
       if (accept) { pl.theta = tnew; pl.l2t = l2t_new; }
       if (declog && tid < (uint32_t)G && on)
       {
@@ -968,64 +1135,36 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       // opt_mix_theta_update): the densities' change over all loci then follows from k_p and the T2h sums, the loci contribute
       // their likelihood change (and, in TAU, the new T2h of the three populations around the divergence)
       const bool program = BPP && SP.program_moves && SP.theta_alpha > 0 && A.theta_mask;
-      const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-      double th_new = 0; bool th_me = false;
-      // one theta of the step: drawn from its fitted inverse-gamma (a1, b1; c = a log b - lgamma a), (a1o, b1o, co) the fit to the
-      // current trees; what it adds to ln of the acceptance ratio.  The fits themselves are made side by side, one per lane.
-      auto invg = [](double x, double a, double b, double c) { return (c + (-a - 1)*log(x)) - b/x; };     // a00_invgamma_logpdf
-      auto fit_lane = [&](bool have, int p, double Tv, double & a, double & b, double & c)
-      {
-        a = b = c = qnan;
-        if (!have || !(Tv == Tv)) return;
-        a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)wg.run_k[p], Tv, &a, &b);
-        c = a*log(b) - lgamma(a);
-      };
-      // the variate of one theta (the global stream: one after the other, by every lane); NaN without a fit
-      auto draw_theta = [&](int p, double a1, double b1) -> double
-      {
-        if (!(a1 == a1)) return qnan;
-        unsigned int z = (unsigned int)grng.r;
-        const double g = a00_bpp_rndgamma(&z, a1);
-        grng.r = z;
-        const double tn = 1.0/(g/b1);
-        if (p == li) { th_new = tn; th_me = true; }
-        return tn;
-      };
-      // ... and what it adds to ln of the acceptance ratio (side by side again: the lane that holds the fit)
-      auto theta_ratio = [&](int p, double tn, double a1, double b1, double c1, double a1o, double b1o, double c1o, double Tn, double Told) -> double
-      {
-        if (!(a1 == a1 && a1o == a1o)) return qnan;
-        const double to = wg.tau[MAXPOP + p];
-        const long k = (long)wg.run_k[p];
-        return (invg(to, a1o, b1o, c1o) - invg(tn, a1, b1, c1))
-             + ((SP.theta_alpha - 1)*log(tn/to) - SP.theta_beta*(tn - to))
-             + (k*(log(2.0/tn) - log(2.0/to)) - (Tn/tn - Told/to));
-      };
-      if (program && mix)
+      // what a re-draw leaves on lane p < 16 for population p: theta', log(2/theta'), the new sum T' and the fit to it
+      double rd_tn = qnan, rd_l2t = 0, rd_T = 0, rd_a = qnan, rd_b = qnan, rd_c = qnan;
+      uint32_t rd_mask = 0;                                   // populations whose theta the step re-draws
+      // MIX: every theta from the fit to its conditional given the SCALED trees (k, c T) — nothing of it depends on the loci's
+      // sums, so it runs between this workgroup's arrival at the exchange and the totals' (below)
+      auto mix_redraw = [&]()
       {
         // lane p: the fit to the scaled trees of population p, lane 16 + p: to the current ones (prop_mixing.c: Cjstar / c)
-        double fa, fb, fc;
-        const int pm = (int)(lane & 15u);
-        const bool have = lane < 32u && pm < npop && ((A.theta_mask >> pm) & 1u) && wg.run_ok;
-        const double Ts = have ? wg.run_T[pm]*mix_c : 0.0;
-        fit_lane(have, pm, lane < 16u ? Ts : Ts/mix_c, fa, fb, fc);
-        const double fao = __shfl(fa, (lane + 16u) & 63u, 64), fbo = __shfl(fb, (lane + 16u) & 63u, 64), fco = __shfl(fc, (lane + 16u) & 63u, 64);
-        double tn_mine = qnan;
-        for (int p = 0; p < npop; ++p)
-          if (((A.theta_mask >> p) & 1u) && wg.run_ok)
-          {
-            const double a1 = __shfl(fa, p, 64), b1 = __shfl(fb, p, 64), a1o = __shfl(fa, 16 + p, 64);
-            const double tn = a1o == a1o ? draw_theta(p, a1, b1) : qnan;
-            if ((int)lane == p) tn_mine = tn;
-          }
-        const double x = have && lane < 16u ? theta_ratio(pm, tn_mine, fa, fb, fc, fao, fbo, fco, Ts, wg.run_T[pm]) : 0.0;
+        const int pm = (int)pl16;
+        const bool have = lane < 32u && pm < npop && ((A.theta_mask >> pm) & 1u) && run_ok;
+        const double Ts = __shfl(runT, pm, 64)*mix_c, kk = __shfl(runK, pm, 64);
+        double fa = qnan, fb = qnan;
+        if (have) a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)kk, role == 0u ? Ts : Ts/mix_c, &fa, &fb);
+        const double fao = __shfl(fa, 16 + pm, 64), fbo = __shfl(fb, 16 + pm, 64);
+        rd_mask = (uint32_t)__ballot(lane < 16u && have && fa == fa && fao == fao) & 0xffffu;
+        double xl;
+        const double s_fa = __shfl(fa, pm, 64), s_fb = __shfl(fb, pm, 64);
+        const double g = draw_gammas(0xfedcba9876543210ull, npop, rd_mask, fa, role == 1u ? s_fb : role == 2u ? s_fa : fbo, xl);
+        const double lb = __shfl(xl, 16 + pm, 64), la = __shfl(xl, 32 + pm, 64), lbo = __shfl(xl, 48 + pm, 64), lao = log(fao);
+        const double c1 = fa*lb - lgamma_with_log(fa, la), co = fao*lbo - lgamma_with_log(fao, lao);
+        if (lane < 16u && ((rd_mask >> lane) & 1u)) rd_tn = 1.0/(g/fb);
+        const double x = redraw_ratio(rd_tn, fa, fb, c1, Ts, fao, fbo, co, runT, rd_l2t);
+        rd_T = Ts; rd_a = fa; rd_b = fb; rd_c = c1;
         for (int p = 0; p < npop; ++p)
           if ((A.theta_mask >> p) & 1u)
           {
-            if (!wg.run_ok) { lnacc_theta = qnan; continue; }
-            lnacc_theta += __shfl(x, p, 64);
+            const double xp = __shfl(x, p, 64);
+            lnacc_theta += run_ok && ((rd_mask >> p) & 1u) ? xp : qnan;
           }
-      }
+      };
       const uint32_t cf0 = T.cf, pf0 = T.pf;
       const double tsave = act ? S.time[li] : 0.0;
       double lnl_new = lnl_cur, lp_new = logpr_cur;
@@ -1077,43 +1216,51 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       }
       if (mix) SMP2_TICK(5); else SMP2_TICK(4);
       double dl_tot = 0;
-      if (!exchange(program && !mix ? 5 : 2, 0, dl_tot)) { aborted = true; break; }
+      exchange_begin(program && !mix ? 5 : 2);
+      // ---- between the arrival and the totals: what does not depend on them
+      double lnprior = 0;
+      SMP2_SUB0();
+      if (program && mix) { mix_redraw(); SMP2_SUB(15); }
+      if (!mix && SP.parent[q] < 0 && SP.tau_alpha > 0)
+        lnprior = (SP.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - SP.tau_beta*(tq_new - tq_old);
+      if (mix) SMP2_TICK(5); else SMP2_TICK(4);
+      if (!exchange_end(0, dl_tot)) { aborted = true; break; }
       dl_tot += wg.xtot[1]*(FX/FXC);                  // (the coarse sum: terms of 256 and more — none in any run worth the name)
       if (A.dbg & 64u) { SMP2_TICK(7); double dummy; if (!exchange(2, 0, dummy)) { aborted = true; break; } SMP2_TICK(6); }     // (the protocol alone: nobody is late)
       SMP2_TICK(7);
       // the decision (decide of sampler.hpp; stree.c:6280, prop_mixing.c:203-205) — the same in every lane
+      SMP2_SUB0();
       double lnacc = dl_tot;
       if (!mix)
       {
-        if (SP.parent[q] < 0 && SP.tau_alpha > 0)
-          lnacc += (SP.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - SP.tau_beta*(tq_new - tq_old);
+        if (SP.parent[q] < 0 && SP.tau_alpha > 0) lnacc += lnprior;
         if (program)
         {
-          // lane j < 3: the fit to the sums after the move of q / its left / its right child, lane 3 + j: to the current ones
-          double fa, fb, fc;
-          const int jm = (int)(lane % 3u);
-          const int pm = jm == 0 ? q : jm == 1 ? SP.left[q] : SP.right[q];
-          const bool have = lane < 6u && ((A.theta_mask >> pm) & 1u) && wg.run_ok;
-          const double Cm = wg.xtot[2 + jm];
-          fit_lane(have, pm, lane < 3u ? Cm : wg.run_T[pm], fa, fb, fc);
-          const double fao = __shfl(fa, (lane + 3u) & 63u, 64), fbo = __shfl(fb, (lane + 3u) & 63u, 64), fco = __shfl(fc, (lane + 3u) & 63u, 64);
-          double tn_mine = qnan;
+          // lane p = q / its left / its right child: the fit to the sums after the move (the exchange brought them), the
+          // draw, the ratio against the fit to the current sums (the lane's own)
+          const int cl = SP.left[q], cr = SP.right[q];
+          const bool aff = lane < 16u && ((int)lane == q || (int)lane == cl || (int)lane == cr);
+          const bool have = aff && ((A.theta_mask >> lane) & 1u) && run_ok;
+          const double Cn = have ? wg.xtot[(int)lane == q ? 2 : (int)lane == cl ? 3 : 4] : qnan;
+          double fa = qnan, fb = qnan;
+          if (have && Cn == Cn) a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)runK, Cn, &fa, &fb);
+          rd_mask = (uint32_t)__ballot(have && fa == fa && fitA == fitA) & 0xffffu;
+          double xl;
+          const double s_fa = __shfl(fa, (int)pl16, 64), s_fb = __shfl(fb, (int)pl16, 64);
+          const double g = draw_gammas((unsigned long long)q | ((unsigned long long)cl << 4) | ((unsigned long long)cr << 8), 3, rd_mask, fa, role == 1u ? s_fb : s_fa, xl);
+          const double lb = __shfl(xl, 16 + (int)pl16, 64), la = __shfl(xl, 32 + (int)pl16, 64);
+          const double c1 = fa*lb - lgamma_with_log(fa, la);
+          if (lane < 16u && ((rd_mask >> lane) & 1u)) rd_tn = 1.0/(g/fb);
+          const double x = redraw_ratio(rd_tn, fa, fb, c1, Cn, fitA, fitB, fitC, runT, rd_l2t);
+          rd_T = Cn; rd_a = fa; rd_b = fb; rd_c = c1;
+          if (declog && wv == 0 && lane < 3u) { double * r = A.declog + 4*(1000 + 4*ndec*3 + 4*lane); r[0] = 400 + lane; r[1] = x; r[2] = rd_tn; r[3] = (double)rd_mask;
+            r[4] = 401; r[5] = fa; r[6] = fb; r[7] = c1; r[8] = 402; r[9] = fitA; r[10] = fitB; r[11] = fitC; r[12] = 403; r[13] = Cn; r[14] = runT; r[15] = g; }
           for (int j = 0; j < 3; ++j)
           {
-            const int p = j == 0 ? q : j == 1 ? SP.left[q] : SP.right[q];
-            if (!((A.theta_mask >> p) & 1u) || !wg.run_ok) continue;
-            const double Cn = wg.xtot[2 + j];
-            const double a1 = __shfl(fa, j, 64), b1 = __shfl(fb, j, 64), a1o = __shfl(fa, 3 + j, 64);
-            const double tn = Cn == Cn && a1o == a1o ? draw_theta(p, a1, b1) : qnan;
-            if ((int)lane == j) tn_mine = tn;
-          }
-          const double x = have && lane < 3u ? (Cm == Cm ? theta_ratio(pm, tn_mine, fa, fb, fc, fao, fbo, fco, Cm, wg.run_T[pm]) : qnan) : 0.0;
-          for (int j = 0; j < 3; ++j)
-          {
-            const int p = j == 0 ? q : j == 1 ? SP.left[q] : SP.right[q];
+            const int p = j == 0 ? q : j == 1 ? cl : cr;
             if (!((A.theta_mask >> p) & 1u)) continue;
-            if (!wg.run_ok) { lnacc = qnan; continue; }
-            lnacc += __shfl(x, j, 64);
+            const double xp = __shfl(x, p, 64);
+            lnacc += run_ok && ((rd_mask >> p) & 1u) ? xp : qnan;
           }
         }
       }
@@ -1128,6 +1275,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         lnacc += lnacc_theta;
       }
       const bool accept = BPP ? grng.accept(lnacc) : (lnacc >= 0 || uacc < exp(lnacc));
+      SMP2_SUB(14);
       ++cnt_prop; cnt_acc += accept ? 1u : 0u;
       if (declog && tid == 0 && ndec < 2048u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
       ++ndec;
@@ -1138,12 +1286,11 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         else if (tid < (uint32_t)npop) wg.tau[tid] *= mix_c;
         if (program)
         {
-          if (tid < (uint32_t)G && th_me) { wg.tau[MAXPOP + li] = th_new; wg.tau[2*MAXPOP + li] = log(2.0/(1.0*th_new)); }
-          if (tid < (uint32_t)G && li < npop && ((A.theta_mask >> li) & 1u))
-          {
-            if (mix) wg.run_T[li] *= mix_c;
-            else { const int slot = li == q ? 2 : li == SP.left[q] ? 3 : li == SP.right[q] ? 4 : -1; if (slot >= 0) wg.run_T[li] = wg.xtot[slot]; }
-          }
+          // the re-drawn thetas; the sums and the fits the next steps start from (lane p < 16 of every wave)
+          if (tid < 16u && ((rd_mask >> tid) & 1u)) { wg.tau[MAXPOP + tid] = rd_tn; wg.tau[2*MAXPOP + tid] = rd_l2t; }
+          const bool moved = lane < 16u && (mix ? lane < (uint32_t)npop && ((A.theta_mask >> lane) & 1u)
+                                                : ((A.theta_mask >> lane) & 1u) && ((int)lane == q || (int)lane == SP.left[q] || (int)lane == SP.right[q]));
+          if (moved) { runT = rd_T; fitA = rd_a; fitB = rd_b; fitC = rd_c; }
         }
         if (act) { lnl_cur = lnl_new; logpr_cur = lp_new; commit_density(allpop); }
       }
@@ -1165,6 +1312,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     }
   }
 #undef SMP2_TICK
+#undef SMP2_SUB0
+#undef SMP2_SUB
   if (aborted || wg.abort_) return;                 // (HBM still holds the state the launch started from)
 
   // ---- store
@@ -1208,7 +1357,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     A.counters[0] += cnt_prop; A.counters[1] += cnt_acc; A.counters[2] += cnt_gprop; A.counters[3] += cnt_gacc;
   }
   if (b == 0 && tid < (uint32_t)(3*MAXPOP)) A.taus[tid] = wg.tau[tid];
-  if (prof_on) for (int i = 0; i < 13; ++i) A.prof[i] = (double)wg.prof[i];
+  if (prof_on) for (int i = 0; i < 16; ++i) A.prof[i] = (double)wg.prof[i];
   if (wgprof) A.prof[16 + b] = (double)wg_sweep;
 }
 
