@@ -109,6 +109,8 @@ template <int NT> struct WgLDS
   uint32_t run_ok, pad2_;
   uint32_t anc[16];
   uint32_t abort_, bad_, xbad_, pad3_;
+  // the program's moves: wave 0 takes an all-loci step's decision alone (the others wait at the barrier: a SIMD to itself) and leaves it here
+  struct { unsigned long long grng; uint32_t accm, rd_mask; double tn[16], l2t[16], lnacc[16]; } dec;
   Species sp;
   long long prof[16];                            // BPA_SMP_DBG & 16: cycle counters of thread 0 of workgroup 0
 };
@@ -678,7 +680,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     if (tid == 0) (void)__hip_atomic_fetch_add(acc + 7, 1ull + ((unsigned long long)wg.bad_ << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // ... and the wait for everybody's: wave 0 polls, the totals go to wg.xtot[v0 ..]; last = the exchange's last block.  False: timed out
-  auto xpoll = [&](int v0, int nv, bool last) -> bool
+  auto xpoll = [&](int v0, int nv, bool last, bool hold) -> bool
   {
     const uint32_t par = (nx - 1u) & 1u;
     unsigned long long * set = A.xbuf + (size_t)par*XN;
@@ -751,7 +753,9 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         if (lane == 0) { if (anybad) wg.xbad_ = 1u; if (last) wg.bad_ = 0; }
       }
       else if (lane == 0) { wg.abort_ = 1; *A.err = 1; }
+      if (hold) { wsync(); return ok; }                // (wave 0 goes on to the decision; the caller's barrier publishes everything)
     }
+    else if (hold) return true;
     __syncthreads();
     XT(4);
     return !wg.abort_;
@@ -769,16 +773,23 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     if (tid == 0) wg.xbad_ = 0;
     xpush(0, nval < 7 ? nval : 7);
   };
-  auto exchange_end = [&](int want, double & mine_tot) -> bool
+  // hold: wave 0 returns from the last block's poll without the closing barrier (and is the only one that may read the
+  // totals before the caller's own barrier); the other waves come straight through
+  auto exchange_end = [&](int want, double & mine_tot, bool hold = false) -> bool
   {
     const int nval = x_nval;
     xt0 = prof_on ? clock64() : 0;
-    if (!xpoll(0, nval < 7 ? nval : 7, nval <= 7)) return false;
+    if (!xpoll(0, nval < 7 ? nval : 7, nval <= 7, hold && nval <= 7)) return false;
     for (int v0 = 7; v0 < nval; v0 += 7)
     {
       const int nv = nval - v0 < 7 ? nval - v0 : 7;
       xpush(v0, nv);
-      if (!xpoll(v0, nv, v0 + 7 >= nval)) return false;
+      if (!xpoll(v0, nv, v0 + 7 >= nval, hold && v0 + 7 >= nval)) return false;
+    }
+    if (hold)
+    {
+      if (wv == 0 && nval > 7 && wg.xbad_) { if (lane < (uint32_t)nval) wg.xtot[lane] = __longlong_as_double(0x7ff8000000000000ll); wsync(); }
+      return true;
     }
     if (nval > 7 && wg.xbad_)
     {
@@ -1007,72 +1018,77 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         if (act && on) { fx_add(2*kidx, (double)mync, false); fx_add(2*kidx + 1, t2h_cur, false); }
         SMP2_TICK(3);
         double dummy = 0;
-        if (!exchange(2*__popc(A.theta_mask), 0, dummy)) { aborted = true; break; }
+        exchange_begin(2*__popc(A.theta_mask));
+        const bool okx = exchange_end(0, dummy, true);
         SMP2_TICK(6);
         SMP2_SUB0();
-        // ---- lane p < 16 is population p from here on: its sums, its fit, its draw, its ratio
-        const bool mine = lane < (uint32_t)npop && ((A.theta_mask >> lane) & 1u);
+        // ---- wave 0 decides (the others wait at the barrier below: its SIMD is its own meanwhile)
+        if (wv == 0 && okx)
         {
-          const int kx = __popc(A.theta_mask & ((1u << lane) - 1u));
-          runK = mine ? wg.xtot[(2*kx) & 31] : 0.0; runT = mine ? wg.xtot[(2*kx + 1) & 31] : 0.0;
-        }
-        run_ok = !__any(mine && !(runK == runK && runT == runT));              // (an unusable term anywhere: every decision is a rejection, nothing drawn)
-        fitA = fitB = fitC = qnan;
-        double tn = mine ? ((slidem >> lane) & 1u ? tslide : qnan) : 0.0, lnacc_p = qnan, e_p = 0;
-        if (run_ok)
-        {
-          // the fits of all thetas side by side (the 35-step bisection is the long part), then the Gibbs variates
-          if (mine) a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)runK, runT, &fitA, &fitB);
-          const uint32_t fitm = (uint32_t)__ballot(mine && fitA == fitA) & 0xffffu;
-          const uint32_t gm = A.theta_mask & ~slidem & fitm;
-          double xl;
-          const double s_fa = __shfl(fitA, (int)pl16, 64), s_fb = __shfl(fitB, (int)pl16, 64);
-          const double g = draw_gammas(0xfedcba9876543210ull, npop, gm, fitA, role == 1u ? s_fb : s_fa, xl);
+          // ---- lane p < 16 is population p from here on: its sums, its fit, its draw, its ratio
+          const bool mine = lane < (uint32_t)npop && ((A.theta_mask >> lane) & 1u);
           {
-            const double lb = __shfl(xl, 16 + (int)pl16, 64), la = __shfl(xl, 32 + (int)pl16, 64);
-            if (lane < 16u && fitA == fitA) fitC = fitA*lb - lgamma_with_log(fitA, la);
+            const int kx = __popc(A.theta_mask & ((1u << lane) - 1u));
+            runK = mine ? wg.xtot[(2*kx) & 31] : 0.0; runT = mine ? wg.xtot[(2*kx + 1) & 31] : 0.0;
           }
-          if ((gm >> lane) & 1u && lane < 16u) tn = 1/(g/fitB);
-          // ln of the acceptance ratio (a00_theta_lnacc, + a00_theta_gibbs_hastings for a Gibbs draw): lane p + 16 m takes piece m
+          run_ok = !__any(mine && !(runK == runK && runT == runT));              // (an unusable term anywhere: every decision is a rejection, nothing drawn)
+          fitA = fitB = fitC = qnan;
+          double tn = mine ? ((slidem >> lane) & 1u ? tslide : qnan) : 0.0, lnacc_p = qnan, e_p = 0, l2_p = 0;
+          if (run_ok)
           {
-            const int p = (int)pl16;
-            const double tn_p = __shfl(tn, p, 64), to_p = wg.tau[MAXPOP + (p < MAXPOP ? p : 0)], T_p = __shfl(runT, p, 64);
-            const double q = role == 0u ? 2.0/tn_p : role == 1u ? tn_p/to_p : to_p/tn_p;
-            const double L = log(q);                                             // log(2/theta') | log(theta'/theta) | log(theta/theta')
-            const double r = (role < 2u ? T_p : 1.0)/((role & 1u) ? to_p : tn_p);    // T/theta' | T/theta | 1/theta' | 1/theta
-            const double L2 = __shfl(L, p, 64), L1 = __shfl(L, 16 + p, 64), L3 = __shfl(L, 32 + p, 64);
-            const double r0 = __shfl(r, p, 64), r1 = __shfl(r, 16 + p, 64), r2 = __shfl(r, 32 + p, 64), r3 = __shfl(r, 48 + p, 64);
-            const double l2t_old = wg.tau[2*MAXPOP + (p < MAXPOP ? p : 0)];
-            if (mine && tn == tn)
+            // the fits of all thetas side by side (the 35-step bisection is the long part), then the Gibbs variates
+            if (mine) a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)runK, runT, &fitA, &fitB);
+            const uint32_t fitm = (uint32_t)__ballot(mine && fitA == fitA) & 0xffffu;
+            const uint32_t gm = A.theta_mask & ~slidem & fitm;
+            double xl;
+            const double s_fa = __shfl(fitA, (int)pl16, 64), s_fb = __shfl(fitB, (int)pl16, 64);
+            const double g = draw_gammas(0xfedcba9876543210ull, npop, gm, fitA, role == 1u ? s_fb : s_fa, xl);
             {
-              lnacc_p = (runK*(L2 - l2t_old) - (r0 - r1)) + ((SP.theta_alpha - 1)*L1 - SP.theta_beta*(tn - to_p));
-              if ((gm >> lane) & 1u) lnacc_p += (-fitA - 1)*L3 - fitB*(r3 - r2);
+              const double lb = __shfl(xl, 16 + (int)pl16, 64), la = __shfl(xl, 32 + (int)pl16, 64);
+              if (lane < 16u && fitA == fitA) fitC = fitA*lb - lgamma_with_log(fitA, la);
             }
-            e_p = exp(lnacc_p);
-            wl.term[lane] = lane < 16u ? tn : lane < 32u ? L2 : 0.0;            // (the groups' lanes pick their population's up below)
+            if ((gm >> lane) & 1u && lane < 16u) tn = 1/(g/fitB);
+            // ln of the acceptance ratio (a00_theta_lnacc, + a00_theta_gibbs_hastings for a Gibbs draw): lane p + 16 m takes piece m
+            {
+              const int p = (int)pl16;
+              const double tn_p = __shfl(tn, p, 64), to_p = wg.tau[MAXPOP + (p < MAXPOP ? p : 0)], T_p = __shfl(runT, p, 64);
+              const double q = role == 0u ? 2.0/tn_p : role == 1u ? tn_p/to_p : to_p/tn_p;
+              const double L = log(q);                                             // log(2/theta') | log(theta'/theta) | log(theta/theta')
+              const double r = (role < 2u ? T_p : 1.0)/((role & 1u) ? to_p : tn_p);    // T/theta' | T/theta | 1/theta' | 1/theta
+              const double L2 = __shfl(L, p, 64), L1 = __shfl(L, 16 + p, 64), L3 = __shfl(L, 32 + p, 64);
+              const double r0 = __shfl(r, p, 64), r1 = __shfl(r, 16 + p, 64), r2 = __shfl(r, 32 + p, 64), r3 = __shfl(r, 48 + p, 64);
+              const double l2t_old = wg.tau[2*MAXPOP + (p < MAXPOP ? p : 0)];
+              if (mine && tn == tn)
+              {
+                lnacc_p = (runK*(L2 - l2t_old) - (r0 - r1)) + ((SP.theta_alpha - 1)*L1 - SP.theta_beta*(tn - to_p));
+                if ((gm >> lane) & 1u) lnacc_p += (-fitA - 1)*L3 - fitB*(r3 - r2);
+              }
+              e_p = exp(lnacc_p);
+              l2_p = L2;
+            }
           }
+          // the acceptance numbers, in population order, drawn only when needed
+          uint32_t accm = 0;
+          for (int p = 0; p < npop; ++p)
+            if ((A.theta_mask >> p) & 1u)
+            {
+              const double la_ = __shfl(lnacc_p, p, 64), tn_ = __shfl(tn, p, 64);
+              bool acc = la_ == la_ && tn_ > 0;
+              if (acc && !(la_ >= -1e-10)) acc = grng.u() < __shfl(e_p, p, 64);
+              accm |= acc ? 1u << p : 0u;
+            }
+          if (lane < 16u) { wg.dec.tn[lane] = tn == tn ? tn : wg.tau[MAXPOP + (lane < (uint32_t)MAXPOP ? lane : 0u)]; wg.dec.lnacc[lane] = lnacc_p; wg.dec.l2t[lane] = l2_p; }
+          if (lane == 0) { wg.dec.accm = accm; wg.dec.grng = grng.r; }
         }
-        else wl.term[lane] = lane < 16u ? tn : 0.0;
-        // the acceptance numbers, in population order, drawn only when needed
-        uint32_t accm = 0;
-        for (int p = 0; p < npop; ++p)
-          if ((A.theta_mask >> p) & 1u)
-          {
-            const double la_ = __shfl(lnacc_p, p, 64), tn_ = __shfl(tn, p, 64);
-            bool acc = la_ == la_ && tn_ > 0;
-            if (acc && !(la_ >= -1e-10)) acc = grng.u() < __shfl(e_p, p, 64);
-            accm |= acc ? 1u << p : 0u;
-          }
-        wsync();
-        const double s_lnacc = __shfl(lnacc_p, li, 64);
+        __syncthreads();
+        if (wg.abort_) { aborted = true; break; }
+        grng.r = (a00_rng_t)wg.dec.grng;
         if (on)
         {
-          accept = (accm >> li) & 1u; gibbs_me = !((slidem >> li) & 1u);
-          tnew = wl.term[li]; my_lnacc = s_lnacc;
-          if (!(tnew == tnew)) tnew = told;
+          accept = (wg.dec.accm >> li) & 1u; gibbs_me = !((slidem >> li) & 1u);
+          tnew = wg.dec.tn[li & 15]; my_lnacc = wg.dec.lnacc[li & 15];
         }
-        l2t_gibbs = run_ok ? wl.term[16 + (li & 15)] : 0.0;
-        wsync();
+        l2t_gibbs = wg.dec.l2t[li & 15];
         SMP2_SUB(13);
       }
       // (log(2/theta') of the program's moves came out of the ratio's log call)
@@ -1089,7 +1105,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         cnt_prop += (uint32_t)__popc(onm); cnt_acc += (uint32_t)__popc(accm);
         cnt_gprop += (uint32_t)__popc(gm); cnt_gacc += (uint32_t)__popc(gm & accm);
       }
-      __syncthreads();                                        // everyone has read the totals and the old thetas
+      if (!gibbs) __syncthreads();                            // everyone has read the totals and the old thetas (Gibbs: the decision's barrier was that)
       if (tid < (uint32_t)G && accept) { wg.tau[MAXPOP + li] = tnew; wg.tau[2*MAXPOP + li] = l2t_new; }
       __syncthreads();
       // every tree's density with the new thetas, from its statistics, in population order
@@ -1215,82 +1231,104 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         }
       }
       if (mix) SMP2_TICK(5); else SMP2_TICK(4);
-      double dl_tot = 0;
+      double dl_tot = 0, lnacc = 0;
+      bool accept = false;
       exchange_begin(program && !mix ? 5 : 2);
       // ---- between the arrival and the totals: what does not depend on them
       double lnprior = 0;
       SMP2_SUB0();
-      if (program && mix) { mix_redraw(); SMP2_SUB(15); }
-      if (!mix && SP.parent[q] < 0 && SP.tau_alpha > 0)
+      if (program && mix && wv == 0) { mix_redraw(); SMP2_SUB(15); }
+      if (!mix && SP.parent[q] < 0 && SP.tau_alpha > 0 && (!program || wv == 0))
         lnprior = (SP.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - SP.tau_beta*(tq_new - tq_old);
       if (mix) SMP2_TICK(5); else SMP2_TICK(4);
-      if (!exchange_end(0, dl_tot)) { aborted = true; break; }
-      dl_tot += wg.xtot[1]*(FX/FXC);                  // (the coarse sum: terms of 256 and more — none in any run worth the name)
-      if (A.dbg & 64u) { SMP2_TICK(7); double dummy; if (!exchange(2, 0, dummy)) { aborted = true; break; } SMP2_TICK(6); }     // (the protocol alone: nobody is late)
-      SMP2_TICK(7);
-      // the decision (decide of sampler.hpp; stree.c:6280, prop_mixing.c:203-205) — the same in every lane
-      SMP2_SUB0();
-      double lnacc = dl_tot;
-      if (!mix)
+      // the decision (decide of sampler.hpp; stree.c:6280, prop_mixing.c:203-205)
+      auto decide = [&]()
       {
-        if (SP.parent[q] < 0 && SP.tau_alpha > 0) lnacc += lnprior;
-        if (program)
+        dl_tot = wg.xtot[0] + wg.xtot[1]*(FX/FXC);      // (+ the coarse sum: terms of 256 and more — none in any run worth the name)
+        lnacc = dl_tot;
+        if (!mix)
         {
-          // lane p = q / its left / its right child: the fit to the sums after the move (the exchange brought them), the
-          // draw, the ratio against the fit to the current sums (the lane's own)
-          const int cl = SP.left[q], cr = SP.right[q];
-          const bool aff = lane < 16u && ((int)lane == q || (int)lane == cl || (int)lane == cr);
-          const bool have = aff && ((A.theta_mask >> lane) & 1u) && run_ok;
-          const double Cn = have ? wg.xtot[(int)lane == q ? 2 : (int)lane == cl ? 3 : 4] : qnan;
-          double fa = qnan, fb = qnan;
-          if (have && Cn == Cn) a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)runK, Cn, &fa, &fb);
-          rd_mask = (uint32_t)__ballot(have && fa == fa && fitA == fitA) & 0xffffu;
-          double xl;
-          const double s_fa = __shfl(fa, (int)pl16, 64), s_fb = __shfl(fb, (int)pl16, 64);
-          const double g = draw_gammas((unsigned long long)q | ((unsigned long long)cl << 4) | ((unsigned long long)cr << 8), 3, rd_mask, fa, role == 1u ? s_fb : s_fa, xl);
-          const double lb = __shfl(xl, 16 + (int)pl16, 64), la = __shfl(xl, 32 + (int)pl16, 64);
-          const double c1 = fa*lb - lgamma_with_log(fa, la);
-          if (lane < 16u && ((rd_mask >> lane) & 1u)) rd_tn = 1.0/(g/fb);
-          const double x = redraw_ratio(rd_tn, fa, fb, c1, Cn, fitA, fitB, fitC, runT, rd_l2t);
-          rd_T = Cn; rd_a = fa; rd_b = fb; rd_c = c1;
-          if (declog && wv == 0 && lane < 3u) { double * r = A.declog + 4*(1000 + 4*ndec*3 + 4*lane); r[0] = 400 + lane; r[1] = x; r[2] = rd_tn; r[3] = (double)rd_mask;
-            r[4] = 401; r[5] = fa; r[6] = fb; r[7] = c1; r[8] = 402; r[9] = fitA; r[10] = fitB; r[11] = fitC; r[12] = 403; r[13] = Cn; r[14] = runT; r[15] = g; }
-          for (int j = 0; j < 3; ++j)
+          if (SP.parent[q] < 0 && SP.tau_alpha > 0) lnacc += lnprior;
+          if (program)
           {
-            const int p = j == 0 ? q : j == 1 ? cl : cr;
-            if (!((A.theta_mask >> p) & 1u)) continue;
-            const double xp = __shfl(x, p, 64);
-            lnacc += run_ok && ((rd_mask >> p) & 1u) ? xp : qnan;
+            // lane p = q / its left / its right child: the fit to the sums after the move (the exchange brought them), the
+            // draw, the ratio against the fit to the current sums (the lane's own)
+            const int cl = SP.left[q], cr = SP.right[q];
+            const bool aff = lane < 16u && ((int)lane == q || (int)lane == cl || (int)lane == cr);
+            const bool have = aff && ((A.theta_mask >> lane) & 1u) && run_ok;
+            const double Cn = have ? wg.xtot[(int)lane == q ? 2 : (int)lane == cl ? 3 : 4] : qnan;
+            double fa = qnan, fb = qnan;
+            if (have && Cn == Cn) a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)runK, Cn, &fa, &fb);
+            rd_mask = (uint32_t)__ballot(have && fa == fa && fitA == fitA) & 0xffffu;
+            double xl;
+            const double s_fa = __shfl(fa, (int)pl16, 64), s_fb = __shfl(fb, (int)pl16, 64);
+            const double g = draw_gammas((unsigned long long)q | ((unsigned long long)cl << 4) | ((unsigned long long)cr << 8), 3, rd_mask, fa, role == 1u ? s_fb : s_fa, xl);
+            const double lb = __shfl(xl, 16 + (int)pl16, 64), la = __shfl(xl, 32 + (int)pl16, 64);
+            const double c1 = fa*lb - lgamma_with_log(fa, la);
+            if (lane < 16u && ((rd_mask >> lane) & 1u)) rd_tn = 1.0/(g/fb);
+            const double x = redraw_ratio(rd_tn, fa, fb, c1, Cn, fitA, fitB, fitC, runT, rd_l2t);
+            rd_T = Cn; rd_a = fa; rd_b = fb; rd_c = c1;
+            for (int j = 0; j < 3; ++j)
+            {
+              const int p = j == 0 ? q : j == 1 ? cl : cr;
+              if (!((A.theta_mask >> p) & 1u)) continue;
+              const double xp = __shfl(x, p, 64);
+              lnacc += run_ok && ((rd_mask >> p) & 1u) ? xp : qnan;
+            }
           }
         }
+        else
+        {
+          lnacc += (double)(nsp - 1)*mix_lnc;
+          if (SP.tau_alpha > 0)
+          {
+            const double troot = wg.tau[npop - 1];
+            lnacc += (SP.tau_alpha - 1)*mix_lnc - SP.tau_beta*(troot*mix_c - troot) - (double)(nsp - 2)*mix_lnc;
+          }
+          lnacc += lnacc_theta;
+        }
+        accept = BPP ? grng.accept(lnacc) : (lnacc >= 0 || uacc < exp(lnacc));
+      };
+      if (program)
+      {
+        // wave 0 decides alone — the other waves wait at the barrier, its SIMD is its own for the fits, the variates and the logs
+        const bool okx = exchange_end(0, dl_tot, true);
+        SMP2_TICK(7);
+        SMP2_SUB0();
+        if (wv == 0 && okx)
+        {
+          decide();
+          if (lane == 0) { wg.dec.accm = accept ? 1u : 0u; wg.dec.rd_mask = rd_mask; wg.dec.grng = grng.r; }
+        }
+        __syncthreads();
+        if (wg.abort_) { aborted = true; break; }
+        accept = wg.dec.accm != 0u; rd_mask = wg.dec.rd_mask; grng.r = (a00_rng_t)wg.dec.grng;
+        SMP2_SUB(14);
       }
       else
       {
-        lnacc += (double)(nsp - 1)*mix_lnc;
-        if (SP.tau_alpha > 0)
-        {
-          const double troot = wg.tau[npop - 1];
-          lnacc += (SP.tau_alpha - 1)*mix_lnc - SP.tau_beta*(troot*mix_c - troot) - (double)(nsp - 2)*mix_lnc;
-        }
-        lnacc += lnacc_theta;
+        if (!exchange_end(0, dl_tot)) { aborted = true; break; }
+        if (A.dbg & 64u) { SMP2_TICK(7); double dummy; if (!exchange(2, 0, dummy)) { aborted = true; break; } SMP2_TICK(6); }     // (the protocol alone: nobody is late)
+        SMP2_TICK(7);
+        SMP2_SUB0();
+        decide();
+        SMP2_SUB(14);
       }
-      const bool accept = BPP ? grng.accept(lnacc) : (lnacc >= 0 || uacc < exp(lnacc));
-      SMP2_SUB(14);
       ++cnt_prop; cnt_acc += accept ? 1u : 0u;
-      if (declog && tid == 0 && ndec < 2048u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
+      if (declog && tid == 0 && ndec < 1000u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
       ++ndec;
-      __syncthreads();                                        // everyone has read the old taus
+      if (!program) __syncthreads();                          // everyone has read the old taus (the program's moves: the decision's barrier was that)
       if (accept)
       {
         if (!mix) { if (tid == 0) wg.tau[q] = tq_new; }
         else if (tid < (uint32_t)npop) wg.tau[tid] *= mix_c;
         if (program)
         {
-          // the re-drawn thetas; the sums and the fits the next steps start from (lane p < 16 of every wave)
+          // the re-drawn thetas; the sums and the fits the next steps start from (lane p < 16 of wave 0)
           if (tid < 16u && ((rd_mask >> tid) & 1u)) { wg.tau[MAXPOP + tid] = rd_tn; wg.tau[2*MAXPOP + tid] = rd_l2t; }
           const bool moved = lane < 16u && (mix ? lane < (uint32_t)npop && ((A.theta_mask >> lane) & 1u)
                                                 : ((A.theta_mask >> lane) & 1u) && ((int)lane == q || (int)lane == SP.left[q] || (int)lane == SP.right[q]));
-          if (moved) { runT = rd_T; fitA = rd_a; fitB = rd_b; fitC = rd_c; }
+          if (moved && wv == 0) { runT = rd_T; fitA = rd_a; fitB = rd_b; fitC = rd_c; }
         }
         if (act) { lnl_cur = lnl_new; logpr_cur = lp_new; commit_density(allpop); }
       }
