@@ -82,7 +82,7 @@ def build(force=False, verbose=False):
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
            "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-Wno-pass-failed",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", OUT] + os.environ.get("BPA_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

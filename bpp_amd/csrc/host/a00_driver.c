@@ -144,6 +144,7 @@ void a00_bpp_gamma_sequence(unsigned int seed, double shape, int n, double * out
   for (k = 0; k < n; ++k) out[k] = a00_bpp_rndgamma(&seed, shape);
 }
 void a00_theta_conditional(double a, double b, long k, double T, double * a1b1) { a00_theta_conditional_invgamma(a, b, k, T, a1b1, a1b1 + 1); }
+void a00_theta_conditional_fast(double a, double b, long k, double T, double * a1b1) { a00_theta_conditional_invgamma_fast(a, b, k, T, a1b1, a1b1 + 1); }
 
 static void snapshot(a00_driver_t * d, unsigned i)
 {

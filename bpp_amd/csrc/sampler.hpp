@@ -1492,9 +1492,9 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
   const int zero = 0;
   if (!upload(s->v2_wave_off, woff.data(), woff.size()) || !upload(s->v2_loc, loc.data(), loc.size()) ||
       !upload(s->v2_pat, pat.data(), pat.size()) || !s->v2_xbuf.reserve((size_t)2*smp2::XN) || !s->v2_grng.reserve(1) ||
-      !upload(s->v2_err, &zero, 1) || !s->v2_prof.reserve(16 + (size_t)nwg) || !s->v2_declog.reserve(4*2048) || !s->v2_sp.reserve(1))
+      !upload(s->v2_err, &zero, 1) || !s->v2_prof.reserve(24 + (size_t)nwg) || !s->v2_declog.reserve(4*2048) || !s->v2_sp.reserve(1))
     return 0;
-  HIPCHK(hipMemset(s->v2_prof.p, 0, (16 + (size_t)nwg)*sizeof(double)));
+  HIPCHK(hipMemset(s->v2_prof.p, 0, (24 + (size_t)nwg)*sizeof(double)));
   {
     void (*k0)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4, false> : smp2::iter_kernel<8, false>;
     void (*k1)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4, true> : smp2::iter_kernel<8, true>;
@@ -2038,6 +2038,8 @@ static int sampler_download(bpa_sampler * s)
       double pr[16]; HIPCHK(hipMemcpy(pr, s->v2_prof.p, sizeof pr, hipMemcpyDeviceToHost));
       fprintf(stderr, "[smp2] cycles of lane 0 of workgroup 0, last launch: propose %.0f evaluate %.0f decide %.0f theta %.0f tau %.0f mix %.0f | exchange: theta %.0f tau+mix %.0f | inside the exchanges: first barrier %.0f sums %.0f barrier %.0f arrival + poll %.0f last barrier %.0f | of theta / tau / mix: the decision's arithmetic after the totals %.0f %.0f, MIX's re-draws inside the wait %.0f\n",
               pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11], pr[12], pr[13], pr[14], pr[15]);
+      double p2[8]; HIPCHK(hipMemcpy(p2, s->v2_prof.p + 16 + s->v2_nwg, sizeof p2, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[smp2] a TAU's decision: fit %.0f variates %.0f c + theta' %.0f ratio %.0f\n", p2[0], p2[1], p2[2], p2[3]);
     }
     if (s->env_dbg & 256u)
     {

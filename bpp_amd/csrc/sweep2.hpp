@@ -112,7 +112,7 @@ template <int NT> struct WgLDS
   // the program's moves: wave 0 takes an all-loci step's decision alone (the others wait at the barrier: a SIMD to itself) and leaves it here
   struct { unsigned long long grng; uint32_t accm, rd_mask; double tn[16], l2t[16], lnacc[16]; } dec;
   Species sp;
-  long long prof[16];                            // BPA_SMP_DBG & 16: cycle counters of thread 0 of workgroup 0
+  long long prof[24];                            // BPA_SMP_DBG & 16: cycle counters of thread 0 of workgroup 0
 };
 
 template <int G> __device__ __forceinline__ uint32_t gballot(bool p, uint32_t gbase)
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     const uint32_t * src = reinterpret_cast<const uint32_t *>(A.sp);
     uint32_t * dst = reinterpret_cast<uint32_t *>(&wg.sp);
     for (uint32_t i = tid; i < sizeof(Species)/4; i += C::BS) dst[i] = src[i];
-    if (tid < 16u) wg.prof[tid] = 0;
+    if (tid < 24u) wg.prof[tid] = 0;
   }
   __syncthreads();
   const Species & SP = wg.sp;
@@ -1037,7 +1037,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           if (run_ok)
           {
             // the fits of all thetas side by side (the 35-step bisection is the long part), then the Gibbs variates
-            if (mine) a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)runK, runT, &fitA, &fitB);
+            if (mine) a00_theta_conditional_invgamma_fast(SP.theta_alpha, SP.theta_beta, (long)runK, runT, &fitA, &fitB);
             const uint32_t fitm = (uint32_t)__ballot(mine && fitA == fitA) & 0xffffu;
             const uint32_t gm = A.theta_mask & ~slidem & fitm;
             double xl;
@@ -1163,7 +1163,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         const bool have = lane < 32u && pm < npop && ((A.theta_mask >> pm) & 1u) && run_ok;
         const double Ts = __shfl(runT, pm, 64)*mix_c, kk = __shfl(runK, pm, 64);
         double fa = qnan, fb = qnan;
-        if (have) a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)kk, role == 0u ? Ts : Ts/mix_c, &fa, &fb);
+        if (have) a00_theta_conditional_invgamma_fast(SP.theta_alpha, SP.theta_beta, (long)kk, role == 0u ? Ts : Ts/mix_c, &fa, &fb);
         const double fao = __shfl(fa, 16 + pm, 64), fbo = __shfl(fb, 16 + pm, 64);
         rd_mask = (uint32_t)__ballot(lane < 16u && have && fa == fa && fao == fao) & 0xffffu;
         double xl;
@@ -1258,15 +1258,22 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
             const bool have = aff && ((A.theta_mask >> lane) & 1u) && run_ok;
             const double Cn = have ? wg.xtot[(int)lane == q ? 2 : (int)lane == cl ? 3 : 4] : qnan;
             double fa = qnan, fb = qnan;
-            if (have && Cn == Cn) a00_theta_conditional_invgamma(SP.theta_alpha, SP.theta_beta, (long)runK, Cn, &fa, &fb);
+            long long q0_ = prof_on ? clock64() : 0;
+#define QT(i_) do { if (prof_on) { const long long t1_ = clock64(); wg.prof[i_] += t1_ - q0_; q0_ = t1_; } } while (0)
+            if (have && Cn == Cn) a00_theta_conditional_invgamma_fast(SP.theta_alpha, SP.theta_beta, (long)runK, Cn, &fa, &fb);
+            QT(16);
             rd_mask = (uint32_t)__ballot(have && fa == fa && fitA == fitA) & 0xffffu;
             double xl;
             const double s_fa = __shfl(fa, (int)pl16, 64), s_fb = __shfl(fb, (int)pl16, 64);
             const double g = draw_gammas((unsigned long long)q | ((unsigned long long)cl << 4) | ((unsigned long long)cr << 8), 3, rd_mask, fa, role == 1u ? s_fb : s_fa, xl);
             const double lb = __shfl(xl, 16 + (int)pl16, 64), la = __shfl(xl, 32 + (int)pl16, 64);
+            QT(17);
             const double c1 = fa*lb - lgamma_with_log(fa, la);
             if (lane < 16u && ((rd_mask >> lane) & 1u)) rd_tn = 1.0/(g/fb);
+            QT(18);
             const double x = redraw_ratio(rd_tn, fa, fb, c1, Cn, fitA, fitB, fitC, runT, rd_l2t);
+            QT(19);
+#undef QT
             rd_T = Cn; rd_a = fa; rd_b = fb; rd_c = c1;
             for (int j = 0; j < 3; ++j)
             {
@@ -1395,7 +1402,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     A.counters[0] += cnt_prop; A.counters[1] += cnt_acc; A.counters[2] += cnt_gprop; A.counters[3] += cnt_gacc;
   }
   if (b == 0 && tid < (uint32_t)(3*MAXPOP)) A.taus[tid] = wg.tau[tid];
-  if (prof_on) for (int i = 0; i < 16; ++i) A.prof[i] = (double)wg.prof[i];
+  if (prof_on) for (int i = 0; i < 24; ++i) A.prof[(i < 16 ? 0 : (int)A.nwg) + i] = (double)wg.prof[i];
   if (wgprof) A.prof[16 + b] = (double)wg_sweep;
 }
 

@@ -173,6 +173,71 @@ static inline A00_HD void a00_theta_conditional_invgamma(double a, double b, lon
     *a1 = x; *b1 = m*(x + 1);
   }
 }
+/* The same fit — the same midpoints, the same decisions, the same bits — with the bisection's 35 cubic evaluations replaced by
+   comparisons: between the bounds the cubic falls to one minimum and rises through its only root r there (for m^2/v > 2.5:
+   its local maximum then lies left of 0), so "the cubic at x has the sign it has at lo" is "x < r".  r comes from a few
+   Newton steps started right of it (r = M + 6 - 16/M + ...; convex there: monotone convergence); a midpoint closer to r than
+   2^-44 r — a hundred times the rounding error of either r or the cubic — sends the whole search back to the plain loop
+   (two cases in a thousand).  Anything outside that picture (small m^2/v, other signs at the bounds, no convergence) takes the plain
+   loop.  The device samplers' form of a00_theta_conditional_invgamma (tests/test_bpp_kernel.py: bit-equal on 10^5 cases). */
+static inline A00_HD void a00_theta_conditional_invgamma_fast(double a, double b, long k, double T, double * a1, double * b1)
+{
+  double c[4], lo, hi, flo, fhi, x = 0, f, r, s = 0, guard, m, mmv;
+  int i, fast;
+  if (T == 0) { *a1 = a + 2; *b1 = a*(a + 1)/b; return; }
+  {
+    const double a1k = a - 1 - k;
+    double ddl, v;
+    m = (a1k + sqrt(a1k*a1k + 4*b*T))/(2*b);
+    ddl = -(a1k + 2*T/m)/(m*m);
+    v = -1/ddl; mmv = m*m/v;
+  }
+  c[0] = 1; c[1] = -(4 + mmv); c[2] = 5 - 2*mmv; c[3] = -(2 + mmv);
+  lo = (mmv + 2)/2; hi = (mmv + 2)*2;
+  flo = a00_cubic_value(c, lo); fhi = a00_cubic_value(c, hi);
+  if (!(flo*fhi <= 0)) { *a1 = NAN; *b1 = NAN; return; }
+  fast = mmv > 2.5 && flo < 0 && fhi > 0;
+  r = mmv + 6;
+  if (fast)
+  {
+    for (i = 0; i < 40; ++i)
+    {
+      const double fr = ((r + c[1])*r + c[2])*r + c[3], dr = (3*r + 2*c[1])*r + c[2];
+      s = fr/dr;
+      r -= s;
+      if (!(fabs(s) > 1e-13*r)) break;
+    }
+    fast = fabs(s) <= 1e-13*r && r > lo && r < hi;
+  }
+  if (fast)
+  {
+    /* 48 steps without a branch (bounds of up to 2^48 x 1e-6 apart; a step past the end changes nothing): the chain a
+       step waits for is add, halve, compare, select */
+    const double lo0 = lo, hi0 = hi;
+    int done = 0, amb = 0;
+    guard = r*5.684341886080802e-14;                            /* 2^-44 r: a hundred times either rounding error */
+    for (i = 0; i < 48; ++i)
+    {
+      int same;
+      x = (lo + hi)/2;
+      done |= fabs(lo - hi) < 1e-6;
+      amb |= !done && !(fabs(x - r) > guard);
+      same = x < r;
+      lo = !done && same ? x : lo;
+      hi = !done && !same ? x : hi;
+    }
+    if (done && !amb) { x = (lo + hi)/2; *a1 = x; *b1 = m*(x + 1); return; }
+    lo = lo0; hi = hi0;                                          /* (a midpoint too close to call, or bounds too wide: the plain loop) */
+  }
+  for (i = 0; i < 100; ++i)
+  {
+    x = (lo + hi)/2;
+    if (fabs(lo - hi) < 1e-6) break;
+    f = a00_cubic_value(c, x);
+    if (flo*f > 0) { lo = x; flo = f; } else hi = x;
+  }
+  *a1 = x; *b1 = m*(x + 1);
+}
 /* ln of the acceptance ratio of a theta proposal from the two sums (both moves: the density's change is the first line) */
 static inline A00_HD double a00_theta_lnacc(long k, double T, double told, double tnew, double a, double b)
 {
@@ -269,6 +334,7 @@ void           a00_set_threads(a00_driver_t *, int threads);
 void           a00_bpp_kernel_sequence(unsigned int seed, int what, int n, double * out);
 void           a00_bpp_gamma_sequence(unsigned int seed, double shape, int n, double * out);
 void           a00_theta_conditional(double a, double b, long k, double T, double * a1b1);
+void           a00_theta_conditional_fast(double a, double b, long k, double T, double * a1b1);
 /* window widths of the four moves (defaults 0.004, 0.004, 0.001, 0.3) */
 void           a00_set_finetune(a00_driver_t *, double gage, double gspr, double tau, double mix);
 /* prior on the divergence times as BPP's 'tauprior = gamma a b': gamma(alpha, beta) on the root tau, the

@@ -98,6 +98,18 @@ def test_gibbs_theta_pieces_bit_equal_to_the_reference(seed):
         mine = np.zeros(2)
         L.a00_theta_conditional(a, b, k, T, mine.ctypes.data_as(C.POINTER(C.c_double)))
         assert np.array_equal(mine.view(np.uint64), np.array([a1.value, b1.value]).view(np.uint64)), (a, b, k, T)
+    # ... and the comparison-driven form the device samplers run (a00_theta_conditional_invgamma_fast): the same bits as the
+    # plain bisection on a wide sweep of cases, incl. tiny data sets (the plain loop's domain) and huge ones
+    L.a00_theta_conditional_fast.argtypes = L.a00_theta_conditional.argtypes
+    fast, plain = np.zeros(2), np.zeros(2)
+    nfast = 0
+    for i in range(100000):
+        a, b = float(rng.choice([2.0, 3.0, 21.0])), float(rng.choice([100.0, 1000.0, 2000.0, 7.0]))
+        k = int(rng.choice([rng.integers(0, 6), rng.integers(0, 300), rng.integers(0, 40000), rng.integers(0, 3000000)]))
+        T = float(rng.choice([0.0, rng.uniform(0, 1e-3), rng.uniform(0, 80.0), rng.uniform(0, 1e4), 10.0**rng.uniform(-12, 3)]))
+        L.a00_theta_conditional(a, b, k, T, plain.ctypes.data_as(C.POINTER(C.c_double)))
+        L.a00_theta_conditional_fast(a, b, k, T, fast.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.array_equal(fast.view(np.uint64), plain.view(np.uint64)), (a, b, k, T, fast, plain)
 
 
 def test_prior_sampling_with_the_bpp_kernel_matches_direct_msc_simulation():
