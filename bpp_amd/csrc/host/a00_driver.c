@@ -30,6 +30,7 @@ struct a00_driver
   a00_rng_t * rng;                      /* one stream per locus */
   a00_rng_t grng;                       /* global stream (mixing step) */
   int kernel;                           /* A00_KERNEL_UNIFORM / A00_KERNEL_BPP */
+  int pre_valid; double pre_window;     /* the program's moves: the first TAU's window, drawn before the THETA step's numbers (a00_iterate) */
   int program_moves;                    /* A00_KERNEL_BPP: THETA / TAU / MIX as the program runs them (a00_set_program_moves) */
   double theta_slide_prob;              /*   share of sliding-window THETA proposals, the rest Gibbs draws */
   long long run_k[A00_MAXPOP];          /*   k_p and T_p of the current gene trees, from the THETA step's sums on: an accepted */
@@ -939,9 +940,10 @@ static int tau_step(a00_driver_t * d, int q)
   long long cnew[3] = { 0, 0, 0 };
   double oldtheta[3];
   const double old = d->tau[q], lo = fmax(d->tau[cl], d->tau[cr]), hi = pq >= 0 ? d->tau[pq] : 999.0;
-  const double tnew = a00_reflect(old + d->ft_tau*draw_window(d, -1), lo, hi);
+  const double tnew = a00_reflect(old + d->ft_tau*(d->pre_valid ? d->pre_window : draw_window(d, -1)), lo, hi);
   const double uacc = d->kernel == A00_KERNEL_BPP ? -1.0 : draw_u(d, -1);
   const double minf = (tnew - lo)/(old - lo), maxf = (tnew - hi)/(old - hi), lminf = log(minf), lmaxf = log(maxf);
+  d->pre_valid = 0;
   if (!staging_ready(d)) return 0;
   d->tau[q] = tnew;
   for (co = 0; co < nco; ++co)
@@ -1230,6 +1232,14 @@ int a00_iterate(a00_driver_t * d)
   for (k = 0; k < maxtips - 1; ++k)   if (!per_locus_step(d, 0, k)) return 0;
   for (k = 0; k < 2*maxtips - 2; ++k) if (!per_locus_step(d, 1, k)) return 0;
   if (!flush_cohorts(d)) return 0;
+  /* the program's moves: the first TAU's window comes before the THETA step's numbers in the global stream — the device
+     kernel makes that TAU's proposal at the loci right after the sweep and brings its sums with THETA's in ONE exchange */
+  if (d->kernel == A00_KERNEL_BPP && d->program_moves && d->theta_alpha > 0 && d->S < d->npop)
+  {
+    int p, any = 0;
+    for (p = 0; p < d->npop; ++p) any |= d->has_theta[p];
+    if (any) { d->pre_window = draw_window(d, -1); d->pre_valid = 1; }
+  }
   if (d->theta_alpha > 0 && !theta_step_all(d)) return 0;
   for (k = d->S; k < d->npop; ++k)    if (!tau_step(d, k)) return 0;
   if (!mix_step(d)) return 0;

@@ -1492,9 +1492,9 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
   const int zero = 0;
   if (!upload(s->v2_wave_off, woff.data(), woff.size()) || !upload(s->v2_loc, loc.data(), loc.size()) ||
       !upload(s->v2_pat, pat.data(), pat.size()) || !s->v2_xbuf.reserve((size_t)2*smp2::XN) || !s->v2_grng.reserve(1) ||
-      !upload(s->v2_err, &zero, 1) || !s->v2_prof.reserve(24 + (size_t)nwg) || !s->v2_declog.reserve(4*2048) || !s->v2_sp.reserve(1))
+      !upload(s->v2_err, &zero, 1) || !s->v2_prof.reserve(40 + (size_t)nwg) || !s->v2_declog.reserve(4*2048) || !s->v2_sp.reserve(1))
     return 0;
-  HIPCHK(hipMemset(s->v2_prof.p, 0, (24 + (size_t)nwg)*sizeof(double)));
+  HIPCHK(hipMemset(s->v2_prof.p, 0, (40 + (size_t)nwg)*sizeof(double)));
   {
     void (*k0)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4, false> : smp2::iter_kernel<8, false>;
     void (*k1)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4, true> : smp2::iter_kernel<8, true>;
@@ -1855,10 +1855,13 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
   uint32_t theta_mask = 0;
   if (s->sp.theta_alpha > 0) for (int p = 0; p < npop; ++p) if (s->has_theta[p]) theta_mask |= 1u << p;
   const bool allloci = in_kernel_allloci && !s->env_nomix;
-  // exchanges of an iteration: THETA in chunks of 7 populations, one per TAU, one for MIX (sweep2.hpp: exchange)
+  // exchanges of an iteration: THETA in blocks of 15 values, one per TAU, one for MIX (sweep2.hpp: exchange)
   const bool program = s->kernel_bpp && s->sp.program_moves;       // (k, T) per theta instead of one difference per population
-  const unsigned x_theta = !theta_mask ? 0u : program ? (2u*(unsigned)__builtin_popcount(theta_mask) + 6u)/7u : ((unsigned)npop + 6u)/7u;
-  const unsigned x_per_iter = allloci ? x_theta + (unsigned)(npop - S) + 1u : 0u;      // (a TAU of the program's moves: 5 values, one block)
+  const unsigned XV = (unsigned)smp2::XV;
+  // (the program's moves: the first TAU's five sums ride on the THETA step's exchange, sweep2.hpp)
+  const bool merged = program && theta_mask && npop > S;
+  const unsigned x_theta = !theta_mask ? 0u : program ? (2u*(unsigned)__builtin_popcount(theta_mask) + (merged ? 5u : 0u) + XV - 1u)/XV : ((unsigned)npop + XV - 1u)/XV;
+  const unsigned x_per_iter = allloci ? x_theta + (unsigned)(npop - S) - (merged ? 1u : 0u) + 1u : 0u;
   const unsigned draws_per_iter = allloci ? 2u*(unsigned)__builtin_popcount(theta_mask) + 2u*(unsigned)(npop - S) + 2u : 0u;
   void (*kern)(const smp2::Args) = s->kernel_bpp ? (s->v2_nt == 4 ? smp2::iter_kernel<4, true> : smp2::iter_kernel<8, true>)
                                                  : (s->v2_nt == 4 ? smp2::iter_kernel<4, false> : smp2::iter_kernel<8, false>);
@@ -1924,7 +1927,7 @@ extern "C" int bpa_sampler_set_p2p(bpa_sampler_t * s, bpa_p2p_t * p, unsigned fi
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (p && (!p->connected || p->eng != s->eng)) return fail("bpa_sampler_set_p2p: connect the exchange first (same engine)");
-  if (p && p->nmax < 8u) return fail("bpa_sampler_set_p2p: the mailboxes must hold at least 8 values");
+  if (p && p->nmax < 16u) return fail("bpa_sampler_set_p2p: the mailboxes must hold at least 16 values");
   // only the persistent kernel reads the mailboxes: a generic or big-tree sampler would decide from its own shard's sums
   if (p && (s->generic || s->big)) return fail("bpa_sampler_set_p2p: the in-kernel exchange needs the persistent kernel (JC69 loci of <= 8 tips, <= 64 patterns); use bpa_sampler_set_allreduce");
   if (!sampler_invalidate(s)) return 0;
@@ -2038,7 +2041,10 @@ static int sampler_download(bpa_sampler * s)
       double pr[16]; HIPCHK(hipMemcpy(pr, s->v2_prof.p, sizeof pr, hipMemcpyDeviceToHost));
       fprintf(stderr, "[smp2] cycles of lane 0 of workgroup 0, last launch: propose %.0f evaluate %.0f decide %.0f theta %.0f tau %.0f mix %.0f | exchange: theta %.0f tau+mix %.0f | inside the exchanges: first barrier %.0f sums %.0f barrier %.0f arrival + poll %.0f last barrier %.0f | of theta / tau / mix: the decision's arithmetic after the totals %.0f %.0f, MIX's re-draws inside the wait %.0f\n",
               pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11], pr[12], pr[13], pr[14], pr[15]);
-      double p2[8]; HIPCHK(hipMemcpy(p2, s->v2_prof.p + 16 + s->v2_nwg, sizeof p2, hipMemcpyDeviceToHost));
+      double p2[24]; HIPCHK(hipMemcpy(p2, s->v2_prof.p + 16 + s->v2_nwg, sizeof p2, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[smp2] sweep cycles of the waves of workgroup 0:");
+      for (int w = 0; w < 16 && p2[8 + w] != 0; ++w) fprintf(stderr, " %.0f", p2[8 + w]);
+      fprintf(stderr, "\n");
       fprintf(stderr, "[smp2] a TAU's decision: fit %.0f variates %.0f c + theta' %.0f ratio %.0f\n", p2[0], p2[1], p2[2], p2[3]);
     }
     if (s->env_dbg & 256u)

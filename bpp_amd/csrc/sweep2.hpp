@@ -83,7 +83,8 @@ struct Args
   const Species * sp;                    // (device memory: by value it would sit in ~50 SGPRs for the whole launch)
 };
 
-constexpr int XN = 64;                   // words per accumulator set: 8 shards x (7 sums + the arrival counter)
+constexpr int XN = 128;                  // words per accumulator set: 8 shards x (15 sums + the arrival counter) = 8 x 128 bytes
+constexpr int XV = 15;                   // sums per block of an exchange
 
 template <int NT> struct Slot
 {
@@ -99,20 +100,33 @@ template <int NT> struct WaveLDS
   uint2  pat[64];
   Slot<NT> slot[Cfg<NT>::LPW];
 };
-template <int NT> struct WgLDS
+// what the program's moves keep about population p (wave 0's business): k_p and T_p — the sums over ALL loci of the
+// coalescences in p and of T2h, from the THETA step's exchange on, carried through TAU and MIX (run_k / run_T of
+// a00_driver.c) — and the inverse gamma fitted to the theta's conditional given them (a, b, c = a log b - lgamma a): the
+// "current" side of every re-draw's proposal ratio, always a fit some step already made from exactly these two numbers
+struct PopFit { double k, T, a, b, c; };
+// what a re-draw leaves for population p: theta', log(2/theta'), the new sum T' and the fit to it
+struct Redraw { double tn, l2t, T, a, b, c; };
+// the part of the workgroup's LDS that the decision functions below (not inlined: their registers are their own) read by name
+struct WgBase
 {
   double tau[3*MAXPOP];
+  double xtot[32];
+  Species sp;
+  // the program's moves: wave 0 takes an all-loci step's decision alone (the others wait at the barrier: a SIMD to itself) and leaves it here
+  struct { unsigned long long grng; uint32_t accm, rd_mask, acc_step, run_ok; double lnacc_step, lnacc_theta; double tn[16], l2t[16], lnacc[16]; } dec;
+  PopFit pf[16];
+  Redraw rd[16];
+};
+template <int NT> struct WgLDS : WgBase
+{
   double lograt[(2*NT)*(2*NT)];
   unsigned long long accfx[32];                  // this workgroup's sums of an all-loci step, 2^-44 fixed point (LDS atomics)
-  double xtot[32];
-  double run_k[MAXPOP], run_T[MAXPOP];             // program moves: k_p and T_p of the current gene trees, from the THETA step's sums on (a00_driver.c: run_k, run_T)
-  uint32_t run_ok, pad2_;
   uint32_t anc[16];
   uint32_t abort_, bad_, xbad_, pad3_;
-  // the program's moves: wave 0 takes an all-loci step's decision alone (the others wait at the barrier: a SIMD to itself) and leaves it here
-  struct { unsigned long long grng; uint32_t accm, rd_mask; double tn[16], l2t[16], lnacc[16]; } dec;
-  Species sp;
+  unsigned long long xprev[2][XN];               // wave 0: every word of either accumulator set as its previous use left it
   long long prof[24];                            // BPA_SMP_DBG & 16: cycle counters of thread 0 of workgroup 0
+  long long wsweep[16];                          // BPA_SMP_DBG & 16: sweep cycles of every wave of workgroup 0
 };
 
 template <int G> __device__ __forceinline__ uint32_t gballot(bool p, uint32_t gbase)
@@ -345,6 +359,268 @@ __device__ __forceinline__ bool propose_gspr(GTree<NT> & t, Stream<BPP> & rng, d
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The program's moves (a00_set_program_moves; THETA by the metropolized Gibbs draw, thetas re-drawn inside TAU and MIX:
+// stree.c:3957, 5840; prop_mixing.c:272) — the decisions.  Wave 0 of every workgroup takes them, alone (all 64 lanes; the
+// other waves wait at a barrier, so its SIMD is its own), in functions of their own: their square roots, logarithms and
+// loops want ~200 registers, which inside the iteration kernel came out of the sweep's (230 spilled registers; with the
+// functions apart: 7).  Lane p < 16 is population p; lane p + 16 m (m = 1, 2, 3) takes further pieces of p's arithmetic, so
+// that every logarithm / quotient of a step is ONE call for all populations.  State between steps: WgBase::pf.
+__device__ __forceinline__ WgBase & wg_base()
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  return *reinterpret_cast<WgBase *>(smem);
+}
+__device__ __forceinline__ double prog_qnan() { return __longlong_as_double(0x7ff8000000000000ll); }
+// lgamma(a) from log(a) (Stirling's series: |error| < 1e-16 from 16 on), so that it shares a log call with its neighbours
+__device__ __forceinline__ double lgamma_with_log(double a, double la)
+{
+  if (!(a >= 16.0)) return lgamma(a);
+  const double r = 1.0/a, r2 = r*r;
+  const double ser = r*(1.0/12 - r2*(1.0/360 - r2*(1.0/1260 - r2*(1.0/1680 - r2*(1.0/1188)))));
+  return ((a - 0.5)*la - a) + (0.91893853320467274178 + ser);
+}
+__device__ __forceinline__ double prog_lcg(uint32_t & z)                   // a00_bpp_rndu_hd (legacy_rndu, random.c:104-122)
+{
+  z = z*69069u + 1u;
+  if (z == 0u) z = 12345671u;
+  return (double)z*(1.0/4294967296.0);
+}
+// gamma(shape, 1) variates for the populations of `list` (4 bits each, n entries) whose bit is set in `want`, from the global
+// stream in list order, exactly the numbers a00_bpp_rndgamma (legacy_rndgamma, random.c:240-275: Marsaglia-Tsang on the
+// polar normal) gives one after the other — but side by side: WHICH uniforms a variate takes is settled by cheap
+// arithmetic alone (a polar pair is taken when s = u^2 + v^2 lies in (0, 1); then one uniform for the test) as long as
+// every variate passes its test at the first round, so the wave walks the stream through all of them first and
+// lane p then does population p's square root, logs and test.  A variate that does not pass (about one draw in a
+// hundred) sends everybody back to the start of the block and through the draws one after the other.
+// shape: lane p.  xarg / xlog: a number per lane >= 16 whose log rides along in the same call.  Returns the variate on lane p.
+__device__ __forceinline__ double draw_gammas(uint32_t & zz, uint32_t lane, unsigned long long list, int n, uint32_t want, double shape, double xarg, double & xlog)
+{
+  const uint32_t z0 = zz;
+  uint32_t z = z0;
+  double mu = 0, ms = 0.5, m3 = 0; bool scan_ok = true;
+  for (int i = 0; i < n; ++i)
+  {
+    const uint32_t p = (uint32_t)(list >> (4*i)) & 15u;
+    if (!((want >> p) & 1u)) continue;
+    double u = 0, s2 = 0; bool got = false;
+    for (int rd = 0; rd < 64 && !got; ++rd)
+    {
+      u = 2*prog_lcg(z) - 1; const double v = 2*prog_lcg(z) - 1;
+      s2 = u*u + v*v;
+      got = s2 > 0 && s2 < 1;
+    }
+    scan_ok = scan_ok && got;
+    const double u3 = prog_lcg(z);
+    if (lane == p) { mu = u; ms = s2; m3 = u3; }
+  }
+  const bool mine = lane < 16u && ((want >> (lane & 15u)) & 1u);
+  const double d = shape - 1.0/3.0, c = (1.0/3.0)/sqrt(d);
+  const double L = log(lane < 16u ? ms : xarg);
+  xlog = L;
+  double g = prog_qnan(); bool ok = true;
+  if (mine)
+  {
+    const double x = mu*sqrt(-2*L/ms);
+    double v = 1.0 + c*x;
+    ok = v > 0 && shape >= 1;
+    v *= v*v;
+    if (ok && !(m3 < 1 - 0.0331*x*x*x*x)) ok = log(m3) < 0.5*x*x + d*(1 - v + log(v));
+    v *= d;
+    if (v == 0) v = 1E-300;
+    g = v;
+  }
+  if (!scan_ok || __any(mine && !ok))
+  {
+    z = z0;
+    for (int i = 0; i < n; ++i)
+    {
+      const uint32_t p = (uint32_t)(list >> (4*i)) & 15u;
+      if (!((want >> p) & 1u)) continue;
+      const double gi = a00_bpp_rndgamma(&z, __shfl(shape, (int)p, 64));
+      if (lane == p) g = gi;
+    }
+  }
+  zz = z;
+  return g;
+}
+// A re-drawn theta's part of ln(acceptance ratio) (tau_step / mix_step of a00_driver.c; stree.c:5840-5990, prop_mixing.c:272-425), lane p < 16 for population p:
+//   [invgamma(theta | old fit) - invgamma(theta' | new fit)] + [gamma prior ratio] + [k (log 2/theta' - log 2/theta) - (T'/theta' - T/theta)]
+// Its four logs and four quotients are taken side by side: lane p + 16 m computes piece m.  l2t_new = log(2/theta') comes out too.
+__device__ __forceinline__ double redraw_ratio(const WgBase & wg, uint32_t lane, double kk, double tn, double a1, double b1, double c1, double Tn,
+                                               double ao, double bo, double co, double Told, double & l2t_new)
+{
+  const int p = (int)(lane & 15u); const uint32_t role = lane >> 4;
+  const double tn_p = __shfl(tn, p, 64), to_p = wg.tau[MAXPOP + (p < MAXPOP ? p : 0)];
+  // (every shuffle by every lane: a lane that sits out a branch hands nothing over)
+  const double s_b1 = __shfl(b1, p, 64), s_Tn = __shfl(Tn, p, 64), s_To = __shfl(Told, p, 64), s_bo = __shfl(bo, p, 64);
+  const double num = role == 0u ? s_b1 : role == 1u ? s_Tn : role == 2u ? s_To : s_bo;
+  const double q = role == 1u ? tn_p/to_p : 2.0/tn_p;
+  const double L = log(role == 0u ? tn_p : role == 3u ? to_p : q);         // log theta' | log(theta'/theta) | log(2/theta') | log theta
+  const double r = num/((role & 2u) ? to_p : tn_p);                        // b'/theta'  | T'/theta'         | T/theta       | b/theta
+  const double L0 = __shfl(L, p, 64), L1 = __shfl(L, 16 + p, 64), L2 = __shfl(L, 32 + p, 64), L3 = __shfl(L, 48 + p, 64);
+  const double r0 = __shfl(r, p, 64), r1 = __shfl(r, 16 + p, 64), r2 = __shfl(r, 32 + p, 64), r3 = __shfl(r, 48 + p, 64);
+  l2t_new = L2;
+  const double l2t_old = wg.tau[2*MAXPOP + (p < MAXPOP ? p : 0)];
+  const double anew = (c1 + (-a1 - 1)*L0) - r0, aold = (co + (-ao - 1)*L3) - r3;
+  return (aold - anew) + ((wg.sp.theta_alpha - 1)*L1 - wg.sp.theta_beta*(tn - to_p)) + (kk*(L2 - l2t_old) - (r1 - r2));
+}
+
+// THETA (theta_step_gibbs of a00_driver.c): the sums the exchange brought (xtot[0 .. 2 n): k_p, T_p of the populations of the
+// mask, in order) -> pf; the fits of all thetas side by side; the Gibbs variates (populations outside slidem; a sliding
+// one proposes tslide, lane p); ln of the acceptance ratios (a00_theta_lnacc + a00_theta_gibbs_hastings); the acceptance
+// numbers in population order, drawn only when needed.  Leaves dec.accm / tn / l2t / lnacc; apply_now: and the accepted
+// thetas in tau[] (a TAU decision follows at once).  z: the global stream.
+__device__ __noinline__ __attribute__((cold)) uint32_t prog_theta_decide(uint32_t z, uint32_t theta_mask, uint32_t slidem, double tslide, int apply_now)
+{
+  WgBase & wg = wg_base();
+  const uint32_t lane = threadIdx.x & 63u, pl16 = lane & 15u, role = lane >> 4;
+  const int npop = wg.sp.npop;
+  const double qnan = prog_qnan();
+  const bool mine = lane < (uint32_t)npop && ((theta_mask >> pl16) & 1u);
+  double runK = 0, runT = 0, fitA = qnan, fitB = qnan, fitC = qnan;
+  {
+    const int kx = __popc(theta_mask & ((1u << pl16) - 1u));
+    runK = mine ? wg.xtot[(2*kx) & 31] : 0.0; runT = mine ? wg.xtot[(2*kx + 1) & 31] : 0.0;
+  }
+  const bool run_ok = !__any(mine && !(runK == runK && runT == runT));      // (an unusable term anywhere: every decision is a rejection, nothing drawn)
+  double tn = mine ? ((slidem >> pl16) & 1u ? tslide : qnan) : 0.0, lnacc_p = qnan, e_p = 0, l2_p = 0;
+  if (run_ok)
+  {
+    if (mine) a00_theta_conditional_invgamma_fast(wg.sp.theta_alpha, wg.sp.theta_beta, (long)runK, runT, &fitA, &fitB);
+    const uint32_t fitm = (uint32_t)__ballot(mine && fitA == fitA) & 0xffffu;
+    const uint32_t gm = theta_mask & ~slidem & fitm;
+    double xl;
+    const double s_fa = __shfl(fitA, (int)pl16, 64), s_fb = __shfl(fitB, (int)pl16, 64);
+    const double g = draw_gammas(z, lane, 0xfedcba9876543210ull, npop, gm, fitA, role == 1u ? s_fb : s_fa, xl);
+    {
+      const double lb = __shfl(xl, 16 + (int)pl16, 64), la = __shfl(xl, 32 + (int)pl16, 64);
+      if (lane < 16u && fitA == fitA) fitC = fitA*lb - lgamma_with_log(fitA, la);
+    }
+    if (lane < 16u && ((gm >> pl16) & 1u)) tn = 1/(g/fitB);
+    // ln of the acceptance ratio: lane p + 16 m takes piece m
+    {
+      const int p = (int)pl16;
+      const double tn_p = __shfl(tn, p, 64), to_p = wg.tau[MAXPOP + (p < MAXPOP ? p : 0)], T_p = __shfl(runT, p, 64);
+      const double q = role == 0u ? 2.0/tn_p : role == 1u ? tn_p/to_p : to_p/tn_p;
+      const double L = log(q);                                             // log(2/theta') | log(theta'/theta) | log(theta/theta')
+      const double r = (role < 2u ? T_p : 1.0)/((role & 1u) ? to_p : tn_p);    // T/theta' | T/theta | 1/theta' | 1/theta
+      const double L2 = __shfl(L, p, 64), L1 = __shfl(L, 16 + p, 64), L3 = __shfl(L, 32 + p, 64);
+      const double r0 = __shfl(r, p, 64), r1 = __shfl(r, 16 + p, 64), r2 = __shfl(r, 32 + p, 64), r3 = __shfl(r, 48 + p, 64);
+      const double l2t_old = wg.tau[2*MAXPOP + (p < MAXPOP ? p : 0)];
+      if (mine && tn == tn)
+      {
+        lnacc_p = (runK*(L2 - l2t_old) - (r0 - r1)) + ((wg.sp.theta_alpha - 1)*L1 - wg.sp.theta_beta*(tn - to_p));
+        if ((gm >> pl16) & 1u) lnacc_p += (-fitA - 1)*L3 - fitB*(r3 - r2);
+      }
+      e_p = exp(lnacc_p);
+      l2_p = L2;
+    }
+  }
+  uint32_t accm = 0;
+  for (int p = 0; p < npop; ++p)
+    if ((theta_mask >> p) & 1u)
+    {
+      const double la_ = __shfl(lnacc_p, p, 64), tn_ = __shfl(tn, p, 64), ep_ = __shfl(e_p, p, 64);
+      bool acc = la_ == la_ && tn_ > 0;
+      if (acc && !(la_ >= -1e-10)) acc = prog_lcg(z) < ep_;
+      accm |= acc ? 1u << p : 0u;
+    }
+  if (lane < 16u)
+  {
+    PopFit & f = wg.pf[lane];
+    f.k = runK; f.T = runT; f.a = fitA; f.b = fitB; f.c = fitC;
+    wg.dec.tn[lane] = tn == tn ? tn : wg.tau[MAXPOP + (lane < (uint32_t)MAXPOP ? lane : 0u)];
+    wg.dec.lnacc[lane] = lnacc_p; wg.dec.l2t[lane] = l2_p;
+    if (apply_now && ((accm >> lane) & 1u)) { wg.tau[MAXPOP + lane] = tn; wg.tau[2*MAXPOP + lane] = l2_p; }
+  }
+  if (lane == 0) { wg.dec.accm = accm; wg.dec.run_ok = run_ok ? 1u : 0u; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return z;
+}
+
+// TAU of population q (tau_step of a00_driver.c, the program's form): the exchange brought the loci's likelihood change
+// (xtot[base], + the coarse companion) and the new T2h sums of q and its two children (xtot[base + 2 .. 4]); each of their
+// thetas is re-drawn from the fit to (k, new sum) and enters the ratio against the fit to the current sums (pf).
+// lnacc0 = the window's prior term.  Leaves dec.acc_step / rd_mask / lnacc_step and rd[] (installed by the caller on acceptance).
+__device__ __noinline__ __attribute__((cold)) uint32_t prog_tau_decide(uint32_t z, uint32_t theta_mask, int q, int base, double lnacc0)
+{
+  WgBase & wg = wg_base();
+  const uint32_t lane = threadIdx.x & 63u, pl16 = lane & 15u, role = lane >> 4;
+  const double qnan = prog_qnan();
+  constexpr double FX = 1099511627776.0, FXC = 1024.0;
+  double lnacc = (wg.xtot[base] + wg.xtot[base + 1]*(FX/FXC)) + lnacc0;
+  const int cl = wg.sp.left[q], cr = wg.sp.right[q];
+  const bool run_ok = wg.dec.run_ok != 0u;
+  const PopFit f = wg.pf[pl16];
+  const bool aff = lane < 16u && ((int)lane == q || (int)lane == cl || (int)lane == cr);
+  const bool have = aff && ((theta_mask >> pl16) & 1u) && run_ok;
+  const double Cn = have ? wg.xtot[base + ((int)lane == q ? 2 : (int)lane == cl ? 3 : 4)] : qnan;
+  double fa = qnan, fb = qnan, tn = qnan, l2t = 0;
+  if (have && Cn == Cn) a00_theta_conditional_invgamma_fast(wg.sp.theta_alpha, wg.sp.theta_beta, (long)f.k, Cn, &fa, &fb);
+  const uint32_t rd_mask = (uint32_t)__ballot(have && fa == fa && f.a == f.a) & 0xffffu;
+  double xl;
+  const double s_fa = __shfl(fa, (int)pl16, 64), s_fb = __shfl(fb, (int)pl16, 64);
+  const double g = draw_gammas(z, lane, (unsigned long long)q | ((unsigned long long)cl << 4) | ((unsigned long long)cr << 8), 3, rd_mask, fa, role == 1u ? s_fb : s_fa, xl);
+  const double lb = __shfl(xl, 16 + (int)pl16, 64), la = __shfl(xl, 32 + (int)pl16, 64);
+  const double c1 = fa*lb - lgamma_with_log(fa, la);
+  if (lane < 16u && ((rd_mask >> pl16) & 1u)) tn = 1.0/(g/fb);
+  const double x = redraw_ratio(wg, lane, f.k, tn, fa, fb, c1, Cn, f.a, f.b, f.c, f.T, l2t);
+  for (int j = 0; j < 3; ++j)
+  {
+    const int p = j == 0 ? q : j == 1 ? cl : cr;
+    if (!((theta_mask >> p) & 1u)) continue;
+    const double xp = __shfl(x, p, 64);
+    lnacc += run_ok && ((rd_mask >> p) & 1u) ? xp : qnan;
+  }
+  const bool accept = lnacc >= -1e-10 || prog_lcg(z) < exp(lnacc);        // (Stream<true>::accept)
+  if (lane < 16u) { Redraw & r = wg.rd[lane]; r.tn = tn; r.l2t = l2t; r.T = Cn; r.a = fa; r.b = fb; r.c = c1; }
+  if (lane == 0) { wg.dec.acc_step = accept ? 1u : 0u; wg.dec.rd_mask = rd_mask; wg.dec.lnacc_step = lnacc; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return z;
+}
+
+// MIX: every theta from the fit to its conditional given the SCALED trees (k, c T) (mix_step of a00_driver.c;
+// prop_mixing.c: Cjstar / c) — nothing of it depends on the loci's sums, so the caller runs it between its workgroup's
+// arrival at the exchange and the totals'.  Leaves rd[], dec.rd_mask and dec.lnacc_theta.
+__device__ __noinline__ __attribute__((cold)) uint32_t prog_mix_redraw(uint32_t z, uint32_t theta_mask, double mix_c)
+{
+  WgBase & wg = wg_base();
+  const uint32_t lane = threadIdx.x & 63u, pl16 = lane & 15u, role = lane >> 4;
+  const int npop = wg.sp.npop, pm = (int)pl16;
+  const double qnan = prog_qnan();
+  const bool run_ok = wg.dec.run_ok != 0u;
+  const PopFit f = wg.pf[pl16];
+  // lane p: the fit to the scaled trees of population p, lane 16 + p: to the current ones
+  const bool have = lane < 32u && pm < npop && ((theta_mask >> pm) & 1u) && run_ok;
+  const double Ts = f.T*mix_c;
+  double fa = qnan, fb = qnan, tn = qnan, l2t = 0;
+  if (have) a00_theta_conditional_invgamma_fast(wg.sp.theta_alpha, wg.sp.theta_beta, (long)f.k, role == 0u ? Ts : Ts/mix_c, &fa, &fb);
+  const double fao = __shfl(fa, 16 + pm, 64), fbo = __shfl(fb, 16 + pm, 64);
+  const uint32_t rd_mask = (uint32_t)__ballot(lane < 16u && have && fa == fa && fao == fao) & 0xffffu;
+  double xl;
+  const double s_fa = __shfl(fa, pm, 64), s_fb = __shfl(fb, pm, 64);
+  const double g = draw_gammas(z, lane, 0xfedcba9876543210ull, npop, rd_mask, fa, role == 1u ? s_fb : role == 2u ? s_fa : fbo, xl);
+  const double lb = __shfl(xl, 16 + pm, 64), la = __shfl(xl, 32 + pm, 64), lbo = __shfl(xl, 48 + pm, 64), lao = log(fao);
+  const double c1 = fa*lb - lgamma_with_log(fa, la), co = fao*lbo - lgamma_with_log(fao, lao);
+  if (lane < 16u && ((rd_mask >> pl16) & 1u)) tn = 1.0/(g/fb);
+  const double x = redraw_ratio(wg, lane, f.k, tn, fa, fb, c1, Ts, fao, fbo, co, f.T, l2t);
+  double lnacc_theta = 0;
+  for (int p = 0; p < npop; ++p)
+    if ((theta_mask >> p) & 1u)
+    {
+      const double xp = __shfl(x, p, 64);
+      lnacc_theta += run_ok && ((rd_mask >> p) & 1u) ? xp : qnan;
+    }
+  if (lane < 16u) { Redraw & r = wg.rd[lane]; r.tn = tn; r.l2t = l2t; r.T = Ts; r.a = fa; r.b = fb; r.c = c1; }
+  if (lane == 0) { wg.dec.rd_mask = rd_mask; wg.dec.lnacc_theta = lnacc_theta; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return z;
+}
+
 template <int NT, bool BPP>
 __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
 {
@@ -363,6 +639,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     uint32_t * dst = reinterpret_cast<uint32_t *>(&wg.sp);
     for (uint32_t i = tid; i < sizeof(Species)/4; i += C::BS) dst[i] = src[i];
     if (tid < 24u) wg.prof[tid] = 0;
+    if (tid < 16u) wg.wsweep[tid] = 0;
   }
   __syncthreads();
   const Species & SP = wg.sp;
@@ -374,6 +651,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   if (tid < 16u) wg.anc[tid] = tid < (uint32_t)MAXPOP ? (uint32_t)SP.anc[tid] : 0u;
   if (tid == 0) { wg.abort_ = 0; wg.bad_ = 0; wg.xbad_ = 0; }
   if (tid < 32u) wg.accfx[tid] = 0ull;
+  for (uint32_t i = tid; i < 2u*XN; i += C::BS) (&wg.xprev[0][0])[i] = 0ull;
   PopLane pl;
   {
     pl.parent = li < npop ? (int)SP.parent[li < MAXPOP ? li : 0] : -1;
@@ -657,15 +935,14 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   };
   uint32_t nx = 0;
   unsigned long long gseq = A.seq0;                 // several GPUs: the mailboxes' sequence number
-  unsigned long long xprev0 = 0, xprev1 = 0;       // wave 0, lane 8 x + k: word k of shard x of each set when its previous use completed
 #define XT(i_) do { if (prof_on) { const long long t1_ = clock64(); wg.prof[8 + i_] += t1_ - xt0; xt0 = t1_; } } while (0)
   long long xt0 = 0;
-  // one block of <= 7 values (7 sums + the counter = one 64-byte block): the workgroup's sums go to its shard, then its arrival
+  // one block of <= 15 values (15 sums + the counter = one 128-byte block): the workgroup's sums go to its shard, then its arrival
   auto xpush = [&](int v0, int nv)
   {
     const uint32_t par = nx & 1u; ++nx;
     // 8 shards, a workgroup adds to shard b mod 8: atomics on one word are served one after the other
-    unsigned long long * acc = A.xbuf + (size_t)par*XN + (size_t)(b & 7u)*8u;
+    unsigned long long * acc = A.xbuf + (size_t)par*XN + (size_t)(b & 7u)*16u;
     if (tid < (uint32_t)nv)
     {
       const unsigned long long fx = wg.accfx[v0 + (int)tid];
@@ -677,7 +954,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     __syncthreads();
     XT(2);
     // arrival: + 1, and + 2^32 when a term of this workgroup was unusable
-    if (tid == 0) (void)__hip_atomic_fetch_add(acc + 7, 1ull + ((unsigned long long)wg.bad_ << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) (void)__hip_atomic_fetch_add(acc + XV, 1ull + ((unsigned long long)wg.bad_ << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // ... and the wait for everybody's: wave 0 polls, the totals go to wg.xtot[v0 ..]; last = the exchange's last block.  False: timed out
   auto xpoll = [&](int v0, int nv, bool last, bool hold) -> bool
@@ -687,23 +964,24 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     if (wv == 0)
     {
       const unsigned long long t_wait = wall_clock64();
-      const unsigned long long prev = par ? xprev1 : xprev0;
+      const unsigned long long prev0 = wg.xprev[par][lane], prev1 = wg.xprev[par][64u + lane];
       bool ok = true;
-      unsigned long long cur = 0, d = 0, gd = 0;
+      unsigned long long cur0 = 0, cur1 = 0, d = 0, gd = 0;
       for (uint32_t rounds = 1;; ++rounds)
       {
-        // ONE load: lane 8 x + k reads word k of shard x; the shards' growth since the set's previous use, added up
-        cur = __hip_atomic_load(set + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        d = cur - prev;
-        d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 16, 64); d += __shfl_xor(d, 32, 64);
-        if ((uint32_t)__shfl(d, 7, 64) >= A.nwg) break;
+        // TWO loads: lane 16 x + k reads word k of shards x and x + 4; the shards' growth since the set's previous use, added up
+        cur0 = __hip_atomic_load(set + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur1 = __hip_atomic_load(set + 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        d = (cur0 - prev0) + (cur1 - prev1);
+        d += __shfl_xor(d, 16, 64); d += __shfl_xor(d, 32, 64);
+        if ((uint32_t)__shfl(d, XV, 64) >= A.nwg) break;
         if ((rounds & 63u) == 0 && wall_clock64() - t_wait > 50000000ull) { ok = false; break; }     // 0.5 s at 100 MHz
         __builtin_amdgcn_s_sleep(1);
       }
-      bool anybad = ok && (__shfl(d, 7, 64) >> 32) != 0;
+      bool anybad = ok && (__shfl(d, XV, 64) >> 32) != 0;
       if (ok && A.world > 1)
       {
-        // ---- several GPUs: this rank's sums (lanes 0..6) and its unusable-term flag (lane 7) go to slot `rank` of
+        // ---- several GPUs: this rank's sums (lanes 0..14) and its unusable-term flag (lane 15) go to slot `rank` of
         // EVERY rank's mailbox over the xGMI peer mappings — workgroup 0 publishes, values first, then the sequence
         // flag —, and every workgroup adds up the N slots of its own mailbox once their flags show this exchange.
         // Fixed point: the same total on every rank whatever the order.  Mailboxes alternate by sequence parity.
@@ -711,8 +989,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         const size_t slot = ((size_t)(gseq & 1ull)*(size_t)A.world)*A.slot_bytes;
         if (b == 0)
         {
-          const unsigned long long v = lane < (uint32_t)nv ? d : (lane == 7u && anybad) ? 1ull : 0ull;
-          if (lane < 8u)
+          const unsigned long long v = lane < (uint32_t)nv ? d : (lane == (uint32_t)XV && anybad) ? 1ull : 0ull;
+          if (lane < 16u)
             for (int pr_ = 0; pr_ < A.world; ++pr_)
               __hip_atomic_store(reinterpret_cast<unsigned long long *>(A.peers[pr_] + slot + (size_t)A.rank*A.slot_bytes + p2p::HDR) + lane, v,
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -738,9 +1016,9 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         {
           unsigned long long tot = 0;
           for (int r = 0; r < A.world; ++r)
-            tot += __hip_atomic_load(reinterpret_cast<const unsigned long long *>(A.mail + slot + (size_t)r*A.slot_bytes + p2p::HDR) + (lane & 7u),
+            tot += __hip_atomic_load(reinterpret_cast<const unsigned long long *>(A.mail + slot + (size_t)r*A.slot_bytes + p2p::HDR) + (lane & 15u),
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          gd = tot; anybad = __shfl(tot, 7, 64) != 0;
+          gd = tot; anybad = __shfl(tot, XV, 64) != 0;
         }
       }
       XT(3);
@@ -748,7 +1026,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       {
         const unsigned long long dd = A.world > 1 ? gd : d;
         if (lane < (uint32_t)nv) wg.xtot[v0 + (int)lane] = anybad ? __longlong_as_double(0x7ff8000000000000ll) : (double)(long long)dd*(1.0/FX);
-        if (par) xprev1 = cur; else xprev0 = cur;
+        wg.xprev[par][lane] = cur0; wg.xprev[par][64u + lane] = cur1;
         // (an unusable term stays flagged through every block of the exchange: its value may lie in a later one)
         if (lane == 0) { if (anybad) wg.xbad_ = 1u; if (last) wg.bad_ = 0; }
       }
@@ -771,7 +1049,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     XT(0);
     x_nval = nval;
     if (tid == 0) wg.xbad_ = 0;
-    xpush(0, nval < 7 ? nval : 7);
+    xpush(0, nval < XV ? nval : XV);
   };
   // hold: wave 0 returns from the last block's poll without the closing barrier (and is the only one that may read the
   // totals before the caller's own barrier); the other waves come straight through
@@ -779,19 +1057,19 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   {
     const int nval = x_nval;
     xt0 = prof_on ? clock64() : 0;
-    if (!xpoll(0, nval < 7 ? nval : 7, nval <= 7, hold && nval <= 7)) return false;
-    for (int v0 = 7; v0 < nval; v0 += 7)
+    if (!xpoll(0, nval < XV ? nval : XV, nval <= XV, hold && nval <= XV)) return false;
+    for (int v0 = XV; v0 < nval; v0 += XV)
     {
-      const int nv = nval - v0 < 7 ? nval - v0 : 7;
+      const int nv = nval - v0 < XV ? nval - v0 : XV;
       xpush(v0, nv);
-      if (!xpoll(v0, nv, v0 + 7 >= nval, hold && v0 + 7 >= nval)) return false;
+      if (!xpoll(v0, nv, v0 + XV >= nval, hold && v0 + XV >= nval)) return false;
     }
     if (hold)
     {
-      if (wv == 0 && nval > 7 && wg.xbad_) { if (lane < (uint32_t)nval) wg.xtot[lane] = __longlong_as_double(0x7ff8000000000000ll); wsync(); }
+      if (wv == 0 && nval > XV && wg.xbad_) { if (lane < (uint32_t)nval) wg.xtot[lane] = __longlong_as_double(0x7ff8000000000000ll); wsync(); }
       return true;
     }
-    if (nval > 7 && wg.xbad_)
+    if (nval > XV && wg.xbad_)
     {
       __syncthreads();
       if (tid < (uint32_t)nval) wg.xtot[tid] = __longlong_as_double(0x7ff8000000000000ll);
@@ -806,107 +1084,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     return exchange_end(want, mine_tot);
   };
 #undef XT
-  // ---- the program's moves (a00_set_program_moves): what every wave keeps on lane p < 16 about population p — k_p and T_p,
-  // the sums over ALL loci of the coalescences in p and of T2h (from the THETA step's exchange on, carried through TAU and
-  // MIX: run_k / run_T of a00_driver.c), and the inverse gamma fitted to the theta's conditional given them (a, b,
-  // c = a log b - lgamma a): the "current" side of every re-draw's proposal ratio — always a fit some step already made
-  // from exactly these two numbers (THETA: every theta; an accepted TAU / MIX: the fits to the sums it installed).
   const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-  double runK = 0, runT = 0, fitA = qnan, fitB = qnan, fitC = qnan;
-  bool run_ok = false;
-  const uint32_t pl16 = lane & 15u, role = lane >> 4;
-  // lgamma(a) from log(a) (Stirling's series: |error| < 1e-16 from 16 on), so that it shares a log call with its neighbours
-  auto lgamma_with_log = [](double a, double la) -> double
-  {
-    if (!(a >= 16.0)) return lgamma(a);
-    const double r = 1.0/a, r2 = r*r;
-    const double ser = r*(1.0/12 - r2*(1.0/360 - r2*(1.0/1260 - r2*(1.0/1680 - r2*(1.0/1188)))));
-    return ((a - 0.5)*la - a) + (0.91893853320467274178 + ser);
-  };
-  auto lcg = [](uint32_t & z) -> double                          // a00_bpp_rndu_hd (legacy_rndu, random.c:104-122)
-  {
-    z = z*69069u + 1u;
-    if (z == 0u) z = 12345671u;
-    return (double)z*(1.0/4294967296.0);
-  };
-  // gamma(shape, 1) variates for the populations of `list` (4 bits each, n entries) whose bit is set in `want`, from the global
-  // stream in list order, exactly the numbers a00_bpp_rndgamma (legacy_rndgamma, random.c:240-275: Marsaglia-Tsang on the
-  // polar normal) gives one after the other — but side by side: WHICH uniforms a variate takes is settled by cheap
-  // arithmetic alone (a polar pair is taken when s = u^2 + v^2 lies in (0, 1); then one uniform for the test) as long as
-  // every variate passes its test at the first round, so every wave walks the stream through all of them first and
-  // lane p then does population p's square root, logs and test.  A variate that does not pass (about one draw in a
-  // hundred) sends everybody back to the start of the block and through the draws one after the other.
-  // shape: lane p.  xarg / xlog: a number per lane >= 16 whose log rides along in the same call.  Returns the variate on lane p.
-  auto draw_gammas = [&](unsigned long long list, int n, uint32_t want, double shape, double xarg, double & xlog) -> double
-  {
-    const uint32_t z0 = (uint32_t)grng.r;
-    uint32_t z = z0;
-    double mu = 0, ms = 0.5, m3 = 0; bool scan_ok = true;
-    for (int i = 0; i < n; ++i)
-    {
-      const uint32_t p = (uint32_t)(list >> (4*i)) & 15u;
-      if (!((want >> p) & 1u)) continue;
-      double u = 0, s2 = 0; bool got = false;
-      for (int rd = 0; rd < 64 && !got; ++rd)
-      {
-        u = 2*lcg(z) - 1; const double v = 2*lcg(z) - 1;
-        s2 = u*u + v*v;
-        got = s2 > 0 && s2 < 1;
-      }
-      scan_ok = scan_ok && got;
-      const double u3 = lcg(z);
-      if (lane == p) { mu = u; ms = s2; m3 = u3; }
-    }
-    const bool mine = lane < 16u && ((want >> lane) & 1u);
-    const double d = shape - 1.0/3.0, c = (1.0/3.0)/sqrt(d);
-    const double L = log(lane < 16u ? ms : xarg);
-    xlog = L;
-    double g = qnan; bool ok = true;
-    if (mine)
-    {
-      const double x = mu*sqrt(-2*L/ms);
-      double v = 1.0 + c*x;
-      ok = v > 0 && shape >= 1;
-      v *= v*v;
-      if (ok && !(m3 < 1 - 0.0331*x*x*x*x)) ok = log(m3) < 0.5*x*x + d*(1 - v + log(v));
-      v *= d;
-      if (v == 0) v = 1E-300;
-      g = v;
-    }
-    if (!scan_ok || __any(mine && !ok))
-    {
-      z = z0;
-      for (int i = 0; i < n; ++i)
-      {
-        const uint32_t p = (uint32_t)(list >> (4*i)) & 15u;
-        if (!((want >> p) & 1u)) continue;
-        const double gi = a00_bpp_rndgamma(&z, __shfl(shape, (int)p, 64));
-        if (lane == p) g = gi;
-      }
-    }
-    grng.r = z;
-    return g;
-  };
-  // A re-drawn theta's part of ln(acceptance ratio) (tau_step / mix_step of a00_driver.c; stree.c:5840-5990, prop_mixing.c:272-425), lane p < 16 for population p:
-  //   [invgamma(theta | old fit) - invgamma(theta' | new fit)] + [gamma prior ratio] + [k (log 2/theta' - log 2/theta) - (T'/theta' - T/theta)]
-  // Its four logs and four quotients are taken side by side: lane p + 16 m computes piece m.  l2t_new = log(2/theta') comes out too.
-  auto redraw_ratio = [&](double tn, double a1, double b1, double c1, double Tn, double ao, double bo, double co, double Told, double & l2t_new) -> double
-  {
-    const int p = (int)pl16;
-    const double tn_p = __shfl(tn, p, 64), to_p = wg.tau[MAXPOP + (p < MAXPOP ? p : 0)];
-    // (every shuffle by every lane: a lane that sits out a branch hands nothing over)
-    const double s_b1 = __shfl(b1, p, 64), s_Tn = __shfl(Tn, p, 64), s_To = __shfl(Told, p, 64), s_bo = __shfl(bo, p, 64);
-    const double num = role == 0u ? s_b1 : role == 1u ? s_Tn : role == 2u ? s_To : s_bo;
-    const double q = role == 1u ? tn_p/to_p : 2.0/tn_p;
-    const double L = log(role == 0u ? tn_p : role == 3u ? to_p : q);         // log theta' | log(theta'/theta) | log(2/theta') | log theta
-    const double r = num/((role & 2u) ? to_p : tn_p);                        // b'/theta'  | T'/theta'         | T/theta       | b/theta
-    const double L0 = __shfl(L, p, 64), L1 = __shfl(L, 16 + p, 64), L2 = __shfl(L, 32 + p, 64), L3 = __shfl(L, 48 + p, 64);
-    const double r0 = __shfl(r, p, 64), r1 = __shfl(r, 16 + p, 64), r2 = __shfl(r, 32 + p, 64), r3 = __shfl(r, 48 + p, 64);
-    l2t_new = L2;
-    const double l2t_old = wg.tau[2*MAXPOP + (p < MAXPOP ? p : 0)];
-    const double anew = (c1 + (-a1 - 1)*L0) - r0, aold = (co + (-ao - 1)*L3) - r3;
-    return (aold - anew) + ((SP.theta_alpha - 1)*L1 - SP.theta_beta*(tn - to_p)) + (runK*(L2 - l2t_old) - (r1 - r2));
-  };
   uint32_t cnt_prop = 0, cnt_acc = 0;              // all-loci proposals / accepted (the same in every workgroup)
   uint32_t cnt_gprop = 0, cnt_gacc = 0;            // of those: Gibbs draws of a theta
   const bool declog = (A.dbg & 256u) && b == 0;    // every all-loci decision of this launch: A.declog[4 k] = what, lnacc, u, accepted
@@ -920,9 +1098,15 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     // ================= GAGE + GSPR of every locus
     const uint32_t nprop = A.nsteps_gage + A.nsteps_gspr;
     const long long wg_t0 = wgprof ? clock64() : 0;
+    const bool wvprof = (A.dbg & 16u) && b == 0 && lane == 0;
+    const long long wv_t0 = wvprof ? clock64() : 0;
     for (uint32_t step = 0; step < nprop; ++step)
     {
+      // two waves share a SIMD (wave w and w + WAVES/2) and its arbiter serves the older one first: left alone, the younger
+      // waves finish a sweep a third later than the older ones, and every exchange waits for them.  The two take turns.
+      if (WAVES > 4) { if (A.dbg & 2048u) { if (wv >= (uint32_t)(WAVES/2)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); } else if (((step ^ (wv/(uint32_t)(WAVES/2))) & 1u)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
       if (!act) continue;
+      if (((A.dbg & 512u) && wv < (uint32_t)(WAVES/2)) || ((A.dbg & 1024u) && wv >= (uint32_t)(WAVES/2))) continue;      // (timing experiments: half the waves sit the sweep out)
       // roll-back copies: registers, and the age of node li
       const GTree<NT> U = T;
       const double tsave = S.time[li];
@@ -947,9 +1131,173 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       }
       else { T = U; S.time[li] = tsave; wsync(); }
     }
+    if (WAVES > 4) __builtin_amdgcn_s_setprio(0);
     if (wgprof) wg_sweep += clock64() - wg_t0;
+    if (wvprof) wg.wsweep[wv] += clock64() - wv_t0;
     if (!A.do_allloci) continue;
 
+    // ================= TAU per species divergence, then MIX: one decision each for all loci.  A step in four parts — the
+    // proposal of the species tree (step_begin), every locus's share (step_locus: its terms go to the exchange's slots
+    // base ...), the decision (step_decide: whoever decides, from wg.xtot[base ...]) and its consequences (step_apply) —
+    // so that the program's first TAU can ride on the THETA step's exchange (below).
+    // ---- the program's TAU and MIX re-draw thetas inside the proposal (a00_set_program_moves: opt_rb_theta_update,
+    // opt_mix_theta_update): the densities' change over all loci then follows from k_p and the T2h sums, the loci contribute
+    // their likelihood change (and, in TAU, the new T2h of the three populations around the divergence)
+    const bool program = BPP && SP.program_moves && SP.theta_alpha > 0 && A.theta_mask;
+    bool mix = false; int q = -1;
+    double wprop = 0, uacc = -1.0;
+    double tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1, lminf = 0, lmaxf = 0, tq_new = 0, mix_c = 1, mix_lnc = 0;
+    double lnacc_theta = 0;
+    // what a re-draw leaves on lane p < 16 for population p: theta', log(2/theta'), the new sum T' and the fit to it
+    double rd_tn = qnan, rd_l2t = 0, rd_T = 0, rd_a = qnan, rd_b = qnan, rd_c = qnan;
+    uint32_t rd_mask = 0;                                   // populations whose theta the step re-draws
+    uint32_t cf0 = 0, pf0 = 0;
+    double tsave = 0, lnl_new = 0, lp_new = 0, lnprior = 0, dl_tot = 0, lnacc = 0;
+    bool evaluated = false, accept = false;
+    auto step_begin = [&](int stepq)
+    {
+      mix = stepq == npop;
+      q = mix ? -1 : stepq;
+      // (log c of the mixing step: finetune x BPP's window variate with its kernel, prop_mixing.c:300; uniform with ours)
+      wprop = mix && !BPP ? grng.u() - 0.5 : grng.window(); uacc = BPP ? -1.0 : grng.u();
+      rd_tn = qnan; rd_l2t = 0; rd_T = 0; rd_a = rd_b = rd_c = qnan; rd_mask = 0; lnprior = 0; accept = false;
+      // the proposed species tree: in the lanes' registers only
+      tq_old = 0; tq_lo = 0; tq_hi = 0; minf = 1; maxf = 1; lminf = 0; lmaxf = 0; tq_new = 0; mix_c = 1; mix_lnc = 0;
+      lnacc_theta = 0;
+      if (!mix)
+      {
+        const int pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
+        tq_old = wg.tau[q]; tq_lo = fmax(wg.tau[cl], wg.tau[cr]); tq_hi = pq >= 0 ? wg.tau[pq] : 999.0;
+        tq_new = reflect(tq_old + SP.ft_tau*wprop, tq_lo, tq_hi);
+        minf = (tq_new - tq_lo)/(tq_old - tq_lo); maxf = (tq_new - tq_hi)/(tq_old - tq_hi);
+        lminf = log(minf); lmaxf = log(maxf);
+        if (li == q) pl.tau = tq_new;
+        if (pl.parent == q) pl.ptau = tq_new;
+      }
+      else
+      {
+        mix_lnc = SP.ft_mix*wprop; mix_c = exp(mix_lnc);
+        pl.tau *= mix_c;
+        if (pl.parent >= 0) pl.ptau *= mix_c;
+      }
+    };
+    auto step_locus = [&](int base)
+    {
+      cf0 = T.cf; pf0 = T.pf;
+      tsave = act ? S.time[li] : 0.0;
+      lnl_new = lnl_cur; lp_new = logpr_cur;
+      evaluated = false;
+      if (act)
+      {
+        Prop pr{allpop, 0, 0, 0.0};
+        double hast = 0, hast2 = 0;
+        if (!mix)
+        {
+          // the gene nodes of q and its children between the bounds ride the rubber band (stree.c:4338-4479)
+          const int cl = SP.left[q], cr = SP.right[q];
+          const int pk = T.pop[li];
+          const double tk_ = tsave;
+          const bool moved = inner_i && (pk == q || pk == cl || pk == cr) && !(tk_ < tq_lo || tk_ > tq_hi);
+          const bool up = moved && tk_ >= tq_old;
+          if (moved) S.time[li] = up ? tq_hi + maxf*(tk_ - tq_hi) : tq_lo + minf*(tk_ - tq_lo);
+          const uint32_t mm = gballot<G>(moved, gbase);
+          const int above = __popc(gballot<G>(up, gbase)), below = __popc(mm) - above;
+          const int par = T.parent[li];
+          pr.brm = gballot<G>(li < n && par >= 0 && (((mm >> li) & 1u) || ((mm >> (par & 31)) & 1u)), gbase);
+          uint32_t m = mm;
+          const int l = T.left[li], r = T.right[li];
+#pragma unroll
+          for (int d = 0; d < NT - 2; ++d) m |= gballot<G>(inner_i && (((m >> (l & 31)) & 1u) || ((m >> (r & 31)) & 1u)), gbase);
+          pr.ndm = m;
+          hast = below*lminf; hast2 = above*lmaxf;
+        }
+        else
+        {
+          if (inner_i) S.time[li] = tsave*mix_c;
+          pr.ndm = gballot<G>(inner_i, gbase);
+          pr.brm = gballot<G>(li < n && (int)T.parent[li] >= 0, gbase);
+          hast = (double)(tips - 1)*mix_lnc;
+        }
+        wsync();
+        evaluated = pr.ndm != 0;
+        const double lnl = evaluate(pr, evaluated, lp_new);
+        if (evaluated) { lnl_new = lnl; a_nupd += (uint32_t)nops; a_nbr += (uint32_t)__popc(pr.brm); ++a_neval; }
+        const double dpr = program ? 0.0 : lp_new - logpr_cur;
+        const double h = mix ? dpr + hast : (dpr + hast) + hast2;
+        const double dl = evaluated ? (lnl_new - lnl_cur) + h : h;
+        if (li == 0) fx_add(base, dl, true);
+        if (program && !mix && li < npop && ((A.theta_mask >> li) & 1u))
+        {
+          const int slot = li == q ? 2 : li == SP.left[q] ? 3 : li == SP.right[q] ? 4 : -1;
+          if (slot >= 0) fx_add(base + slot, t2h_new, false);
+        }
+      }
+    };
+    // the decision (decide of sampler.hpp; stree.c:6280, prop_mixing.c:203-205)
+    auto step_decide = [&](int base)
+    {
+      if (program && !mix)
+      {
+        // (wave 0) the thetas of q and its two children re-drawn, the ratio, the decision: prog_tau_decide
+        grng.r = prog_tau_decide((uint32_t)grng.r, A.theta_mask, q, base, lnprior);
+        accept = wg.dec.acc_step != 0u; rd_mask = wg.dec.rd_mask; lnacc = wg.dec.lnacc_step;
+        return;
+      }
+      dl_tot = wg.xtot[base] + wg.xtot[base + 1]*(FX/FXC);      // (+ the coarse sum: terms of 256 and more — none in any run worth the name)
+      lnacc = dl_tot;
+      if (!mix) lnacc += lnprior;
+      else
+      {
+        lnacc += (double)(nsp - 1)*mix_lnc;
+        if (SP.tau_alpha > 0)
+        {
+          const double troot = wg.tau[npop - 1];
+          lnacc += (SP.tau_alpha - 1)*mix_lnc - SP.tau_beta*(troot*mix_c - troot) - (double)(nsp - 2)*mix_lnc;
+        }
+        if (program) { lnacc += wg.dec.lnacc_theta; rd_mask = wg.dec.rd_mask; }
+      }
+      accept = BPP ? grng.accept(lnacc) : (lnacc >= 0 || uacc < exp(lnacc));
+    };
+    auto step_apply = [&]()
+    {
+      ++cnt_prop; cnt_acc += accept ? 1u : 0u;
+      if (declog && tid == 0 && ndec < 1000u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
+      ++ndec;
+      if (!program) __syncthreads();                          // everyone has read the old taus (the program's moves: the decision's barrier was that)
+      if (accept)
+      {
+        if (!mix) { if (tid == 0) wg.tau[q] = tq_new; }
+        else if (tid < (uint32_t)npop) wg.tau[tid] *= mix_c;
+        if (program)
+        {
+          // the re-drawn thetas; the sums and the fits the next steps start from (wave 0, lane p < 16: population p)
+          if (tid < 16u)
+          {
+            const Redraw r = wg.rd[tid];
+            if ((rd_mask >> tid) & 1u) { wg.tau[MAXPOP + tid] = r.tn; wg.tau[2*MAXPOP + tid] = r.l2t; }
+            const bool moved = mix ? tid < (uint32_t)npop && ((A.theta_mask >> tid) & 1u)
+                                   : ((A.theta_mask >> tid) & 1u) && ((int)tid == q || (int)tid == SP.left[q] || (int)tid == SP.right[q]);
+            if (moved) { PopFit & f = wg.pf[tid]; f.T = r.T; f.a = r.a; f.b = r.b; f.c = r.c; }
+          }
+        }
+        if (act) { lnl_cur = lnl_new; logpr_cur = lp_new; commit_density(allpop); }
+      }
+      else if (act) { T.cf = cf0; T.pf = pf0; S.time[li] = tsave; }
+      __syncthreads();
+      load_pop();
+      wsync();
+      if (program && accept && act)
+      {
+        // the densities with the re-drawn thetas, from the statistics of the accepted trees (as after THETA)
+        if (li < npop) S.contrib[li] = msc_term((int)mync, t2h_cur, pl.theta, pl.l2t);
+        wsync();
+        double lp = 0;
+        for (int p = 0; p < npop; ++p) lp += S.contrib[p];
+        logpr_cur = lp;
+        wsync();
+      }
+    };
+    bool merged_done = false, accept_step1 = false;
     // ================= THETA: every population that can hold a coalescence, decided independently (theta_step_all)
     if (SP.theta_alpha > 0 && A.theta_mask)
     {
@@ -1004,6 +1352,11 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         // decided from k_p = the coalescences in p over all loci and T_p = the sum of T2h — two sums that do not depend on
         // the thetas, so ONE exchange serves every population.  Global stream: choice (+ window) per population first,
         // then per population the gamma variate of a Gibbs draw and the acceptance number when one is needed.
+        // the program's first TAU rides on this exchange: its window comes first in the stream, the loci make its proposal
+        // right after the sweep, and ONE exchange brings k_p, T_p and the TAU's five sums (tau_step + theta_step_gibbs of
+        // a00_driver.c draw in this order too)
+        const bool merged = program && nsp < npop;
+        if (merged) step_begin(nsp);
         uint32_t slidem = 0;
         double tslide = 0;                                                   // lane p < 16: the window's theta of population p
         for (int p = 0; p < npop; ++p)
@@ -1015,74 +1368,28 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
             if (p == (int)lane) tslide = tn;
           }
         const int kidx = __popc(A.theta_mask & ((1u << li) - 1u));
+        const int nth = 2*__popc(A.theta_mask);
         if (act && on) { fx_add(2*kidx, (double)mync, false); fx_add(2*kidx + 1, t2h_cur, false); }
+        if (merged) step_locus(nth);
         SMP2_TICK(3);
         double dummy = 0;
-        exchange_begin(2*__popc(A.theta_mask));
+        exchange_begin(nth + (merged ? 5 : 0));
+        if (merged && wv == 0 && SP.parent[q] < 0 && SP.tau_alpha > 0)
+          lnprior = (SP.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - SP.tau_beta*(tq_new - tq_old);
         const bool okx = exchange_end(0, dummy, true);
         SMP2_TICK(6);
         SMP2_SUB0();
         // ---- wave 0 decides (the others wait at the barrier below: its SIMD is its own meanwhile)
-        if (wv == 0 && okx)
+        if (__builtin_expect(wv == 0 && okx, 0))
         {
-          // ---- lane p < 16 is population p from here on: its sums, its fit, its draw, its ratio
-          const bool mine = lane < (uint32_t)npop && ((A.theta_mask >> lane) & 1u);
-          {
-            const int kx = __popc(A.theta_mask & ((1u << lane) - 1u));
-            runK = mine ? wg.xtot[(2*kx) & 31] : 0.0; runT = mine ? wg.xtot[(2*kx + 1) & 31] : 0.0;
-          }
-          run_ok = !__any(mine && !(runK == runK && runT == runT));              // (an unusable term anywhere: every decision is a rejection, nothing drawn)
-          fitA = fitB = fitC = qnan;
-          double tn = mine ? ((slidem >> lane) & 1u ? tslide : qnan) : 0.0, lnacc_p = qnan, e_p = 0, l2_p = 0;
-          if (run_ok)
-          {
-            // the fits of all thetas side by side (the 35-step bisection is the long part), then the Gibbs variates
-            if (mine) a00_theta_conditional_invgamma_fast(SP.theta_alpha, SP.theta_beta, (long)runK, runT, &fitA, &fitB);
-            const uint32_t fitm = (uint32_t)__ballot(mine && fitA == fitA) & 0xffffu;
-            const uint32_t gm = A.theta_mask & ~slidem & fitm;
-            double xl;
-            const double s_fa = __shfl(fitA, (int)pl16, 64), s_fb = __shfl(fitB, (int)pl16, 64);
-            const double g = draw_gammas(0xfedcba9876543210ull, npop, gm, fitA, role == 1u ? s_fb : s_fa, xl);
-            {
-              const double lb = __shfl(xl, 16 + (int)pl16, 64), la = __shfl(xl, 32 + (int)pl16, 64);
-              if (lane < 16u && fitA == fitA) fitC = fitA*lb - lgamma_with_log(fitA, la);
-            }
-            if ((gm >> lane) & 1u && lane < 16u) tn = 1/(g/fitB);
-            // ln of the acceptance ratio (a00_theta_lnacc, + a00_theta_gibbs_hastings for a Gibbs draw): lane p + 16 m takes piece m
-            {
-              const int p = (int)pl16;
-              const double tn_p = __shfl(tn, p, 64), to_p = wg.tau[MAXPOP + (p < MAXPOP ? p : 0)], T_p = __shfl(runT, p, 64);
-              const double q = role == 0u ? 2.0/tn_p : role == 1u ? tn_p/to_p : to_p/tn_p;
-              const double L = log(q);                                             // log(2/theta') | log(theta'/theta) | log(theta/theta')
-              const double r = (role < 2u ? T_p : 1.0)/((role & 1u) ? to_p : tn_p);    // T/theta' | T/theta | 1/theta' | 1/theta
-              const double L2 = __shfl(L, p, 64), L1 = __shfl(L, 16 + p, 64), L3 = __shfl(L, 32 + p, 64);
-              const double r0 = __shfl(r, p, 64), r1 = __shfl(r, 16 + p, 64), r2 = __shfl(r, 32 + p, 64), r3 = __shfl(r, 48 + p, 64);
-              const double l2t_old = wg.tau[2*MAXPOP + (p < MAXPOP ? p : 0)];
-              if (mine && tn == tn)
-              {
-                lnacc_p = (runK*(L2 - l2t_old) - (r0 - r1)) + ((SP.theta_alpha - 1)*L1 - SP.theta_beta*(tn - to_p));
-                if ((gm >> lane) & 1u) lnacc_p += (-fitA - 1)*L3 - fitB*(r3 - r2);
-              }
-              e_p = exp(lnacc_p);
-              l2_p = L2;
-            }
-          }
-          // the acceptance numbers, in population order, drawn only when needed
-          uint32_t accm = 0;
-          for (int p = 0; p < npop; ++p)
-            if ((A.theta_mask >> p) & 1u)
-            {
-              const double la_ = __shfl(lnacc_p, p, 64), tn_ = __shfl(tn, p, 64);
-              bool acc = la_ == la_ && tn_ > 0;
-              if (acc && !(la_ >= -1e-10)) acc = grng.u() < __shfl(e_p, p, 64);
-              accm |= acc ? 1u << p : 0u;
-            }
-          if (lane < 16u) { wg.dec.tn[lane] = tn == tn ? tn : wg.tau[MAXPOP + (lane < (uint32_t)MAXPOP ? lane : 0u)]; wg.dec.lnacc[lane] = lnacc_p; wg.dec.l2t[lane] = l2_p; }
-          if (lane == 0) { wg.dec.accm = accm; wg.dec.grng = grng.r; }
+          grng.r = prog_theta_decide((uint32_t)grng.r, A.theta_mask, slidem, tslide, merged ? 1 : 0);
+          if (merged) { SMP2_SUB(13); SMP2_SUB0(); step_decide(nth); SMP2_SUB(14); SMP2_SUB0(); }
+          if (lane == 0) wg.dec.grng = grng.r;
         }
         __syncthreads();
         if (wg.abort_) { aborted = true; break; }
         grng.r = (a00_rng_t)wg.dec.grng;
+        if (merged) { accept_step1 = wg.dec.acc_step != 0u; rd_mask = wg.dec.rd_mask; lnacc = wg.dec.lnacc_step; merged_done = true; }
         if (on)
         {
           accept = (wg.dec.accm >> li) & 1u; gibbs_me = !((slidem >> li) & 1u);
@@ -1121,190 +1428,29 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     }
     SMP2_TICK(3);
 
-    // ================= TAU per species divergence, then MIX: one decision each for all loci
-    for (int stepq = nsp; stepq <= npop && !aborted; ++stepq)
+    // ================= the TAU steps (the program's first one: decided with THETA, its consequences now) and MIX
+    if (merged_done && !aborted) { accept = accept_step1; step_apply(); SMP2_TICK(4); }
+    for (int stepq = nsp + (merged_done ? 1 : 0); stepq <= npop && !aborted; ++stepq)
     {
-      const bool mix = stepq == npop;
-      const int q = mix ? -1 : stepq;
-      // (log c of the mixing step: finetune x BPP's window variate with its kernel, prop_mixing.c:300; uniform with ours)
-      const double wprop = mix && !BPP ? grng.u() - 0.5 : grng.window(), uacc = BPP ? -1.0 : grng.u();
-      // the proposed species tree: in the lanes' registers only
-      double tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1, lminf = 0, lmaxf = 0, tq_new = 0, mix_c = 1, mix_lnc = 0;
-      double lnacc_theta = 0;
-      if (!mix)
-      {
-        const int pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
-        tq_old = wg.tau[q]; tq_lo = fmax(wg.tau[cl], wg.tau[cr]); tq_hi = pq >= 0 ? wg.tau[pq] : 999.0;
-        tq_new = reflect(tq_old + SP.ft_tau*wprop, tq_lo, tq_hi);
-        minf = (tq_new - tq_lo)/(tq_old - tq_lo); maxf = (tq_new - tq_hi)/(tq_old - tq_hi);
-        lminf = log(minf); lmaxf = log(maxf);
-        if (li == q) pl.tau = tq_new;
-        if (pl.parent == q) pl.ptau = tq_new;
-      }
-      else
-      {
-        mix_lnc = SP.ft_mix*wprop; mix_c = exp(mix_lnc);
-        pl.tau *= mix_c;
-        if (pl.parent >= 0) pl.ptau *= mix_c;
-      }
-      // ---- the program's TAU and MIX re-draw thetas inside the proposal (a00_set_program_moves: opt_rb_theta_update,
-      // opt_mix_theta_update): the densities' change over all loci then follows from k_p and the T2h sums, the loci contribute
-      // their likelihood change (and, in TAU, the new T2h of the three populations around the divergence)
-      const bool program = BPP && SP.program_moves && SP.theta_alpha > 0 && A.theta_mask;
-      // what a re-draw leaves on lane p < 16 for population p: theta', log(2/theta'), the new sum T' and the fit to it
-      double rd_tn = qnan, rd_l2t = 0, rd_T = 0, rd_a = qnan, rd_b = qnan, rd_c = qnan;
-      uint32_t rd_mask = 0;                                   // populations whose theta the step re-draws
-      // MIX: every theta from the fit to its conditional given the SCALED trees (k, c T) — nothing of it depends on the loci's
-      // sums, so it runs between this workgroup's arrival at the exchange and the totals' (below)
-      auto mix_redraw = [&]()
-      {
-        // lane p: the fit to the scaled trees of population p, lane 16 + p: to the current ones (prop_mixing.c: Cjstar / c)
-        const int pm = (int)pl16;
-        const bool have = lane < 32u && pm < npop && ((A.theta_mask >> pm) & 1u) && run_ok;
-        const double Ts = __shfl(runT, pm, 64)*mix_c, kk = __shfl(runK, pm, 64);
-        double fa = qnan, fb = qnan;
-        if (have) a00_theta_conditional_invgamma_fast(SP.theta_alpha, SP.theta_beta, (long)kk, role == 0u ? Ts : Ts/mix_c, &fa, &fb);
-        const double fao = __shfl(fa, 16 + pm, 64), fbo = __shfl(fb, 16 + pm, 64);
-        rd_mask = (uint32_t)__ballot(lane < 16u && have && fa == fa && fao == fao) & 0xffffu;
-        double xl;
-        const double s_fa = __shfl(fa, pm, 64), s_fb = __shfl(fb, pm, 64);
-        const double g = draw_gammas(0xfedcba9876543210ull, npop, rd_mask, fa, role == 1u ? s_fb : role == 2u ? s_fa : fbo, xl);
-        const double lb = __shfl(xl, 16 + pm, 64), la = __shfl(xl, 32 + pm, 64), lbo = __shfl(xl, 48 + pm, 64), lao = log(fao);
-        const double c1 = fa*lb - lgamma_with_log(fa, la), co = fao*lbo - lgamma_with_log(fao, lao);
-        if (lane < 16u && ((rd_mask >> lane) & 1u)) rd_tn = 1.0/(g/fb);
-        const double x = redraw_ratio(rd_tn, fa, fb, c1, Ts, fao, fbo, co, runT, rd_l2t);
-        rd_T = Ts; rd_a = fa; rd_b = fb; rd_c = c1;
-        for (int p = 0; p < npop; ++p)
-          if ((A.theta_mask >> p) & 1u)
-          {
-            const double xp = __shfl(x, p, 64);
-            lnacc_theta += run_ok && ((rd_mask >> p) & 1u) ? xp : qnan;
-          }
-      };
-      const uint32_t cf0 = T.cf, pf0 = T.pf;
-      const double tsave = act ? S.time[li] : 0.0;
-      double lnl_new = lnl_cur, lp_new = logpr_cur;
-      bool evaluated = false;
-      if (act)
-      {
-        Prop pr{allpop, 0, 0, 0.0};
-        double hast = 0, hast2 = 0;
-        if (!mix)
-        {
-          // the gene nodes of q and its children between the bounds ride the rubber band (stree.c:4338-4479)
-          const int cl = SP.left[q], cr = SP.right[q];
-          const int pk = T.pop[li];
-          const double tk_ = tsave;
-          const bool moved = inner_i && (pk == q || pk == cl || pk == cr) && !(tk_ < tq_lo || tk_ > tq_hi);
-          const bool up = moved && tk_ >= tq_old;
-          if (moved) S.time[li] = up ? tq_hi + maxf*(tk_ - tq_hi) : tq_lo + minf*(tk_ - tq_lo);
-          const uint32_t mm = gballot<G>(moved, gbase);
-          const int above = __popc(gballot<G>(up, gbase)), below = __popc(mm) - above;
-          const int par = T.parent[li];
-          pr.brm = gballot<G>(li < n && par >= 0 && (((mm >> li) & 1u) || ((mm >> (par & 31)) & 1u)), gbase);
-          uint32_t m = mm;
-          const int l = T.left[li], r = T.right[li];
-#pragma unroll
-          for (int d = 0; d < NT - 2; ++d) m |= gballot<G>(inner_i && (((m >> (l & 31)) & 1u) || ((m >> (r & 31)) & 1u)), gbase);
-          pr.ndm = m;
-          hast = below*lminf; hast2 = above*lmaxf;
-        }
-        else
-        {
-          if (inner_i) S.time[li] = tsave*mix_c;
-          pr.ndm = gballot<G>(inner_i, gbase);
-          pr.brm = gballot<G>(li < n && (int)T.parent[li] >= 0, gbase);
-          hast = (double)(tips - 1)*mix_lnc;
-        }
-        wsync();
-        evaluated = pr.ndm != 0;
-        const double lnl = evaluate(pr, evaluated, lp_new);
-        if (evaluated) { lnl_new = lnl; a_nupd += (uint32_t)nops; a_nbr += (uint32_t)__popc(pr.brm); ++a_neval; }
-        const double dpr = program ? 0.0 : lp_new - logpr_cur;
-        const double h = mix ? dpr + hast : (dpr + hast) + hast2;
-        const double dl = evaluated ? (lnl_new - lnl_cur) + h : h;
-        if (li == 0) fx_add(0, dl, true);
-        if (program && !mix && li < npop && ((A.theta_mask >> li) & 1u))
-        {
-          const int slot = li == q ? 2 : li == SP.left[q] ? 3 : li == SP.right[q] ? 4 : -1;
-          if (slot >= 0) fx_add(slot, t2h_new, false);
-        }
-      }
+      step_begin(stepq);
+      step_locus(0);
       if (mix) SMP2_TICK(5); else SMP2_TICK(4);
-      double dl_tot = 0, lnacc = 0;
-      bool accept = false;
       exchange_begin(program && !mix ? 5 : 2);
       // ---- between the arrival and the totals: what does not depend on them
-      double lnprior = 0;
       SMP2_SUB0();
-      if (program && mix && wv == 0) { mix_redraw(); SMP2_SUB(15); }
+      if (__builtin_expect(program && mix && wv == 0, 0)) { grng.r = prog_mix_redraw((uint32_t)grng.r, A.theta_mask, mix_c); SMP2_SUB(15); }
       if (!mix && SP.parent[q] < 0 && SP.tau_alpha > 0 && (!program || wv == 0))
         lnprior = (SP.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - SP.tau_beta*(tq_new - tq_old);
       if (mix) SMP2_TICK(5); else SMP2_TICK(4);
-      // the decision (decide of sampler.hpp; stree.c:6280, prop_mixing.c:203-205)
-      auto decide = [&]()
-      {
-        dl_tot = wg.xtot[0] + wg.xtot[1]*(FX/FXC);      // (+ the coarse sum: terms of 256 and more — none in any run worth the name)
-        lnacc = dl_tot;
-        if (!mix)
-        {
-          if (SP.parent[q] < 0 && SP.tau_alpha > 0) lnacc += lnprior;
-          if (program)
-          {
-            // lane p = q / its left / its right child: the fit to the sums after the move (the exchange brought them), the
-            // draw, the ratio against the fit to the current sums (the lane's own)
-            const int cl = SP.left[q], cr = SP.right[q];
-            const bool aff = lane < 16u && ((int)lane == q || (int)lane == cl || (int)lane == cr);
-            const bool have = aff && ((A.theta_mask >> lane) & 1u) && run_ok;
-            const double Cn = have ? wg.xtot[(int)lane == q ? 2 : (int)lane == cl ? 3 : 4] : qnan;
-            double fa = qnan, fb = qnan;
-            long long q0_ = prof_on ? clock64() : 0;
-#define QT(i_) do { if (prof_on) { const long long t1_ = clock64(); wg.prof[i_] += t1_ - q0_; q0_ = t1_; } } while (0)
-            if (have && Cn == Cn) a00_theta_conditional_invgamma_fast(SP.theta_alpha, SP.theta_beta, (long)runK, Cn, &fa, &fb);
-            QT(16);
-            rd_mask = (uint32_t)__ballot(have && fa == fa && fitA == fitA) & 0xffffu;
-            double xl;
-            const double s_fa = __shfl(fa, (int)pl16, 64), s_fb = __shfl(fb, (int)pl16, 64);
-            const double g = draw_gammas((unsigned long long)q | ((unsigned long long)cl << 4) | ((unsigned long long)cr << 8), 3, rd_mask, fa, role == 1u ? s_fb : s_fa, xl);
-            const double lb = __shfl(xl, 16 + (int)pl16, 64), la = __shfl(xl, 32 + (int)pl16, 64);
-            QT(17);
-            const double c1 = fa*lb - lgamma_with_log(fa, la);
-            if (lane < 16u && ((rd_mask >> lane) & 1u)) rd_tn = 1.0/(g/fb);
-            QT(18);
-            const double x = redraw_ratio(rd_tn, fa, fb, c1, Cn, fitA, fitB, fitC, runT, rd_l2t);
-            QT(19);
-#undef QT
-            rd_T = Cn; rd_a = fa; rd_b = fb; rd_c = c1;
-            for (int j = 0; j < 3; ++j)
-            {
-              const int p = j == 0 ? q : j == 1 ? cl : cr;
-              if (!((A.theta_mask >> p) & 1u)) continue;
-              const double xp = __shfl(x, p, 64);
-              lnacc += run_ok && ((rd_mask >> p) & 1u) ? xp : qnan;
-            }
-          }
-        }
-        else
-        {
-          lnacc += (double)(nsp - 1)*mix_lnc;
-          if (SP.tau_alpha > 0)
-          {
-            const double troot = wg.tau[npop - 1];
-            lnacc += (SP.tau_alpha - 1)*mix_lnc - SP.tau_beta*(troot*mix_c - troot) - (double)(nsp - 2)*mix_lnc;
-          }
-          lnacc += lnacc_theta;
-        }
-        accept = BPP ? grng.accept(lnacc) : (lnacc >= 0 || uacc < exp(lnacc));
-      };
       if (program)
       {
         // wave 0 decides alone — the other waves wait at the barrier, its SIMD is its own for the fits, the variates and the logs
         const bool okx = exchange_end(0, dl_tot, true);
         SMP2_TICK(7);
         SMP2_SUB0();
-        if (wv == 0 && okx)
+        if (__builtin_expect(wv == 0 && okx, 0))
         {
-          decide();
+          step_decide(0);
           if (lane == 0) { wg.dec.accm = accept ? 1u : 0u; wg.dec.rd_mask = rd_mask; wg.dec.grng = grng.r; }
         }
         __syncthreads();
@@ -1318,41 +1464,10 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         if (A.dbg & 64u) { SMP2_TICK(7); double dummy; if (!exchange(2, 0, dummy)) { aborted = true; break; } SMP2_TICK(6); }     // (the protocol alone: nobody is late)
         SMP2_TICK(7);
         SMP2_SUB0();
-        decide();
+        step_decide(0);
         SMP2_SUB(14);
       }
-      ++cnt_prop; cnt_acc += accept ? 1u : 0u;
-      if (declog && tid == 0 && ndec < 1000u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
-      ++ndec;
-      if (!program) __syncthreads();                          // everyone has read the old taus (the program's moves: the decision's barrier was that)
-      if (accept)
-      {
-        if (!mix) { if (tid == 0) wg.tau[q] = tq_new; }
-        else if (tid < (uint32_t)npop) wg.tau[tid] *= mix_c;
-        if (program)
-        {
-          // the re-drawn thetas; the sums and the fits the next steps start from (lane p < 16 of wave 0)
-          if (tid < 16u && ((rd_mask >> tid) & 1u)) { wg.tau[MAXPOP + tid] = rd_tn; wg.tau[2*MAXPOP + tid] = rd_l2t; }
-          const bool moved = lane < 16u && (mix ? lane < (uint32_t)npop && ((A.theta_mask >> lane) & 1u)
-                                                : ((A.theta_mask >> lane) & 1u) && ((int)lane == q || (int)lane == SP.left[q] || (int)lane == SP.right[q]));
-          if (moved && wv == 0) { runT = rd_T; fitA = rd_a; fitB = rd_b; fitC = rd_c; }
-        }
-        if (act) { lnl_cur = lnl_new; logpr_cur = lp_new; commit_density(allpop); }
-      }
-      else if (act) { T.cf = cf0; T.pf = pf0; S.time[li] = tsave; }
-      __syncthreads();
-      load_pop();
-      wsync();
-      if (program && accept && act)
-      {
-        // the densities with the re-drawn thetas, from the statistics of the accepted trees (as after THETA)
-        if (li < npop) S.contrib[li] = msc_term((int)mync, t2h_cur, pl.theta, pl.l2t);
-        wsync();
-        double lp = 0;
-        for (int p = 0; p < npop; ++p) lp += S.contrib[p];
-        logpr_cur = lp;
-        wsync();
-      }
+      step_apply();
       if (mix) SMP2_TICK(5); else SMP2_TICK(4);
     }
   }
@@ -1403,6 +1518,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   }
   if (b == 0 && tid < (uint32_t)(3*MAXPOP)) A.taus[tid] = wg.tau[tid];
   if (prof_on) for (int i = 0; i < 24; ++i) A.prof[(i < 16 ? 0 : (int)A.nwg) + i] = (double)wg.prof[i];
+  if (prof_on) for (int i = 0; i < 16; ++i) A.prof[(int)A.nwg + 24 + i] = (double)wg.wsweep[i];
   if (wgprof) A.prof[16 + b] = (double)wg_sweep;
 }
 
