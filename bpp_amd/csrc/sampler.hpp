@@ -1181,6 +1181,7 @@ struct bpa_sampler
   // ---- the persistent iteration kernel (sweep2.hpp): one GPU, loci that fit the sweep kernel, root = the last node
   bool v2_ok = false, env_v1 = false;
   int v2_nt = 0;                        // its instance: 4 or 8 tips
+  bool v2_prog = false;                 // ... with the program's moves: wave 0 of every workgroup is the control wave (no loci)
   unsigned v2_nwaves = 0, v2_nwg = 0;
   size_t v2_lds = 0;
   DevBuf<uint32_t> v2_wave_off;
@@ -1312,6 +1313,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
 // offset) first brings them level with the device: trees with their random streams and counters, taus and thetas, the
 // all-loci counters — a run that is reconfigured half-way continues from where it was, not from the last download
 static int sampler_download(bpa_sampler * s);
+static bool v2_wants_prog(const bpa_sampler * s);
 static int sampler_invalidate(bpa_sampler * s)
 {
   if (s->uploaded)
@@ -1370,6 +1372,8 @@ extern "C" int bpa_sampler_set_program_moves(bpa_sampler_t * s, int on, double s
   if (on && !s->kernel_bpp) return fail("bpa_sampler_set_program_moves: the program's moves draw from BPP's proposal kernel (bpa_sampler_set_proposal_kernel(s, BPA_KERNEL_BPP) first)");
   s->sp.program_moves = on ? 1 : 0;
   if (on) s->sp.theta_slide_prob = slide_prob;
+  // (the persistent kernel's form — with or without a control wave — is chosen at upload)
+  if (s->uploaded && s->v2_ok && v2_wants_prog(s) != s->v2_prog) return sampler_invalidate(s);
   return 1;
 }
 
@@ -1427,9 +1431,17 @@ static int gb_iterate(bpa_sampler * s, unsigned iterations);
 static int gb_download(bpa_sampler * s);
 
 // ---- the persistent iteration kernel (sweep2.hpp): tables, eligibility, launch
-template <int NT> static size_t v2_lds_base()
+template <int NT> static size_t v2_lds_base(bool prog)
 {
-  return ((sizeof(smp2::WgLDS<NT>) + 15) & ~(size_t)15) + sizeof(smp2::WaveLDS<NT>)*(size_t)smp2::Cfg<NT>::WAVES;
+  return ((sizeof(smp2::WgLDS<NT>) + 15) & ~(size_t)15) + sizeof(smp2::WaveLDS<NT>)*(size_t)(smp2::Cfg<NT>::WAVES - (prog ? 1 : 0));
+}
+// the program's moves (BPP's kernel + bpa_sampler_set_program_moves + a theta prior + a theta to move): the persistent kernel's
+// form with a control wave per workgroup
+static bool v2_wants_prog(const bpa_sampler * s)
+{
+  if (!(s->kernel_bpp && s->sp.program_moves && s->sp.theta_alpha > 0 && s->sp.npop > s->sp.S)) return false;
+  for (int p = 0; p < s->sp.npop; ++p) if (s->has_theta[p]) return true;
+  return false;
 }
 // v2_ok stays false where the kernel does not apply (the one-launch-per-step path of this file then runs): more loci than
 // stay resident on the device at once, a tree whose root is not its last node or whose buffer indices are not the
@@ -1477,18 +1489,20 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
     }
   }
   woff.push_back(T);
-  const unsigned nwaves = (unsigned)woff.size() - 1, nwg = (nwaves + WAVES - 1)/WAVES;
+  const bool prog = v2_wants_prog(s);
+  const unsigned LWAVES = WAVES - (prog ? 1u : 0u);              // waves with loci per workgroup
+  const unsigned nwaves = (unsigned)woff.size() - 1, nwg = (nwaves + LWAVES - 1)/LWAVES;
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, s->eng->device));
   // every workgroup must be resident (they wait for each other's sums): one per CU — a workgroup takes most of a CU's LDS
-  const size_t base = NT == 4 ? v2_lds_base<4>() : v2_lds_base<8>();
+  const size_t base = NT == 4 ? v2_lds_base<4>(prog) : v2_lds_base<8>(prog);
   const size_t lds_max = std::min<size_t>((size_t)prop.sharedMemPerBlock > 65536 ? (size_t)prop.sharedMemPerBlock : 160*1024, 160*1024) - 256;
   if (base > lds_max) return 1;
   // (the LDS decides how many workgroups a CU holds; two waves per SIMD at most are counted on)
   const unsigned per_cu = (unsigned)std::min<size_t>(std::max<size_t>(lds_max/base, 1), 8/WAVES ? 8/WAVES : 1);
   if (nwg > per_cu*(unsigned)prop.multiProcessorCount) return 1;
   s->v2_lds = base;
-  s->v2_nt = NT; s->v2_nwaves = nwaves; s->v2_nwg = nwg;
+  s->v2_nt = NT; s->v2_nwaves = nwaves; s->v2_nwg = nwg; s->v2_prog = prog;
   const int zero = 0;
   if (!upload(s->v2_wave_off, woff.data(), woff.size()) || !upload(s->v2_loc, loc.data(), loc.size()) ||
       !upload(s->v2_pat, pat.data(), pat.size()) || !s->v2_xbuf.reserve((size_t)2*smp2::XN) || !s->v2_grng.reserve(1) ||
@@ -1500,6 +1514,8 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
     void (*k1)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4, true> : smp2::iter_kernel<8, true>;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->v2_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->v2_lds));
+    void (*k2)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4, true, true> : smp2::iter_kernel<8, true, true>;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->v2_lds));
   }
   std::memset(&s->v2_sp_sent, 0xff, sizeof s->v2_sp_sent);       // (nothing sent yet)
   s->v2_ok = true;
@@ -1761,7 +1777,11 @@ extern "C" void bpa_sampler_set_tau_prior(bpa_sampler_t * s, double alpha, doubl
 { s->sp.tau_alpha = alpha; s->sp.tau_beta = beta; }
 
 extern "C" void bpa_sampler_set_theta_prior(bpa_sampler_t * s, double alpha, double beta, double finetune)
-{ s->sp.theta_alpha = alpha; s->sp.theta_beta = beta; s->sp.ft_theta = finetune; }
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  s->sp.theta_alpha = alpha; s->sp.theta_beta = beta; s->sp.ft_theta = finetune;
+  if (s->uploaded && s->v2_ok && v2_wants_prog(s) != s->v2_prog) (void)sampler_invalidate(s);      // (the kernel's form is chosen at upload)
+}
 
 extern "C" int bpa_sampler_get_thetas(bpa_sampler_t * s, double * theta)
 {
@@ -1856,14 +1876,15 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
   if (s->sp.theta_alpha > 0) for (int p = 0; p < npop; ++p) if (s->has_theta[p]) theta_mask |= 1u << p;
   const bool allloci = in_kernel_allloci && !s->env_nomix;
   // exchanges of an iteration: THETA in blocks of 15 values, one per TAU, one for MIX (sweep2.hpp: exchange)
-  const bool program = s->kernel_bpp && s->sp.program_moves;       // (k, T) per theta instead of one difference per population
+  const bool program = s->v2_prog;                                 // (k, T) per theta instead of one difference per population
   const unsigned XV = (unsigned)smp2::XV;
   // (the program's moves: the first TAU's five sums ride on the THETA step's exchange, sweep2.hpp)
-  const bool merged = program && theta_mask && npop > S;
+  const bool merged = program;
   const unsigned x_theta = !theta_mask ? 0u : program ? (2u*(unsigned)__builtin_popcount(theta_mask) + (merged ? 5u : 0u) + XV - 1u)/XV : ((unsigned)npop + XV - 1u)/XV;
   const unsigned x_per_iter = allloci ? x_theta + (unsigned)(npop - S) - (merged ? 1u : 0u) + 1u : 0u;
   const unsigned draws_per_iter = allloci ? 2u*(unsigned)__builtin_popcount(theta_mask) + 2u*(unsigned)(npop - S) + 2u : 0u;
-  void (*kern)(const smp2::Args) = s->kernel_bpp ? (s->v2_nt == 4 ? smp2::iter_kernel<4, true> : smp2::iter_kernel<8, true>)
+  void (*kern)(const smp2::Args) = s->v2_prog   ? (s->v2_nt == 4 ? smp2::iter_kernel<4, true, true> : smp2::iter_kernel<8, true, true>)
+                                 : s->kernel_bpp ? (s->v2_nt == 4 ? smp2::iter_kernel<4, true> : smp2::iter_kernel<8, true>)
                                                  : (s->v2_nt == 4 ? smp2::iter_kernel<4, false> : smp2::iter_kernel<8, false>);
   const unsigned bs = s->v2_nt == 4 ? smp2::Cfg<4>::BS : smp2::Cfg<8>::BS;
   while (iterations)
@@ -2043,9 +2064,10 @@ static int sampler_download(bpa_sampler * s)
               pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9], pr[10], pr[11], pr[12], pr[13], pr[14], pr[15]);
       double p2[24]; HIPCHK(hipMemcpy(p2, s->v2_prof.p + 16 + s->v2_nwg, sizeof p2, hipMemcpyDeviceToHost));
       fprintf(stderr, "[smp2] sweep cycles of the waves of workgroup 0:");
-      for (int w = 0; w < 16 && p2[8 + w] != 0; ++w) fprintf(stderr, " %.0f", p2[8 + w]);
+      for (int w = 0; w < 8; ++w) fprintf(stderr, " %.0f", p2[8 + w]);
       fprintf(stderr, "\n");
-      fprintf(stderr, "[smp2] a TAU's decision: fit %.0f variates %.0f c + theta' %.0f ratio %.0f\n", p2[0], p2[1], p2[2], p2[3]);
+      if (s->v2_prog)
+        fprintf(stderr, "[smp2] (program-moves kernel: the numbers above are the control wave's — before B1 | wait for the loci | push | poll | THETA decision | TAU decisions | MIX decision | next proposal)\n");
     }
     if (s->env_dbg & 256u)
     {

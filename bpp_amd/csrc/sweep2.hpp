@@ -117,6 +117,8 @@ struct WgBase
   struct { unsigned long long grng; uint32_t accm, rd_mask, acc_step, run_ok; double lnacc_step, lnacc_theta; double tn[16], l2t[16], lnacc[16]; } dec;
   PopFit pf[16];
   Redraw rd[16];
+  // the proposal of the species tree of the coming all-loci step, as the control wave publishes it (program-moves kernel)
+  struct { int32_t q, mix; double tq_old, tq_lo, tq_hi, tq_new, minf, maxf, lminf, lmaxf, mix_c, mix_lnc; } stepp;
 };
 template <int NT> struct WgLDS : WgBase
 {
@@ -621,7 +623,7 @@ __device__ __noinline__ __attribute__((cold)) uint32_t prog_mix_redraw(uint32_t 
   return z;
 }
 
-template <int NT, bool BPP>
+template <int NT, bool BPP, bool PROG = false>
 __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
 {
   using C = Cfg<NT>;
@@ -631,9 +633,10 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   WaveLDS<NT> * wl_all = reinterpret_cast<WaveLDS<NT> *>(smem + ((sizeof(WgLDS<NT>) + 15) & ~(size_t)15));
   const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63u, b = blockIdx.x;
   const int li = (int)(lane & (uint32_t)(G - 1)); const uint32_t gbase = lane - (uint32_t)li, slot = lane/(uint32_t)G;
-  WaveLDS<NT> & wl = wl_all[wv];
+  // (PROG: wave 0 is the control wave — no loci, no per-wave block)
+  WaveLDS<NT> & wl = wl_all[PROG ? (wv ? wv - 1u : 0u) : wv];
   Slot<NT> & S = wl.slot[slot];
-  const uint32_t gw = b*WAVES + wv;                               // global wave
+  const uint32_t gw = PROG ? b*(uint32_t)(WAVES - 1) + (wv - 1u) : b*WAVES + wv;       // global wave of loci
   {
     const uint32_t * src = reinterpret_cast<const uint32_t *>(A.sp);
     uint32_t * dst = reinterpret_cast<uint32_t *>(&wg.sp);
@@ -669,6 +672,337 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   };
   load_pop();
   Stream<BPP> grng{*A.grng};
+
+  const bool prof_on = (A.dbg & 16u) && b == 0 && tid == 0;
+  long long pf_t = prof_on ? clock64() : 0;
+#define SMP2_TICK(i_) do { if (prof_on) { const long long t1_ = clock64(); wg.prof[i_] += t1_ - pf_t; pf_t = t1_; } } while (0)
+  long long pf_s = 0;
+#define SMP2_SUB0() do { if (prof_on) pf_s = clock64(); } while (0)
+#define SMP2_SUB(i_) do { if (prof_on) wg.prof[i_] += clock64() - pf_s; } while (0)
+
+  // ---- the sum over ALL loci of one all-loci step's terms.  A term enters as 2^-40 fixed point (what the host driver adds
+  // up in doubles, locus by locus: the totals agree to ~1e-11), so a total does not depend on the order of the additions: the lanes add theirs to the workgroup's accumulators (LDS atomics, fx_add),
+  // the workgroup adds those to the step's device accumulators (device-scope atomics) and then bumps the arrival
+  // counter; wave 0 polls until every workgroup has arrived.  Device accumulators and counter only ever grow (the host
+  // zeroes them before the launch) and two sets alternate, so a workgroup already in the next step never touches what
+  // a slower one still reads.  Up to 7 values share one 64-byte block with the counter: the poll's ONE load brings the
+  // totals with the count (they landed before the arrival was counted).  False: timed out.
+  constexpr double FX = 1099511627776.0;             // 2^40: 9e-13 per term; |term| < 256 and <= 2^14 loci: the sum cannot wrap
+  constexpr double FXC = 1024.0;                     // a TAU / MIX term beyond that goes to a coarse companion sum (2^-10, |term| < 2^38)
+  auto fx_add = [&](int v, double x, bool coarse)
+  {
+    if (fabs(x) < 256.0)
+      (void)__hip_atomic_fetch_add(&wg.accfx[v], (unsigned long long)__double2ll_rn(x*FX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else if (coarse && fabs(x) < 274877906944.0)
+      (void)__hip_atomic_fetch_add(&wg.accfx[v + 1], (unsigned long long)__double2ll_rn(x*FXC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else wg.bad_ = 1u;                                                       // (also NaN): the step is rejected
+  };
+  uint32_t nx = 0;
+  unsigned long long gseq = A.seq0;                 // several GPUs: the mailboxes' sequence number
+#define XT(i_) do { if (prof_on) { const long long t1_ = clock64(); wg.prof[8 + i_] += t1_ - xt0; xt0 = t1_; } } while (0)
+  long long xt0 = 0;
+  // one block of <= 15 values (15 sums + the counter = one 128-byte block): the workgroup's sums go to its shard, then its arrival
+  // solo (the program-moves kernel): the control wave runs the exchange alone — no workgroup barrier inside
+  constexpr bool solo = PROG;
+  auto xpush = [&](int v0, int nv)
+  {
+    const uint32_t par = nx & 1u; ++nx;
+    // 8 shards, a workgroup adds to shard b mod 8: atomics on one word are served one after the other
+    unsigned long long * acc = A.xbuf + (size_t)par*XN + (size_t)(b & 7u)*16u;
+    if (tid < (uint32_t)nv)
+    {
+      const unsigned long long fx = wg.accfx[v0 + (int)tid];
+      wg.accfx[v0 + (int)tid] = 0ull;
+      const unsigned long long old = __hip_atomic_fetch_add(acc + tid, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" :: "v"(old) : "memory");          // the sums have landed before the arrival is counted
+    }
+    XT(1);
+    if (!solo) __syncthreads();
+    XT(2);
+    // arrival: + 1, and + 2^32 when a term of this workgroup was unusable
+    if (tid == 0) (void)__hip_atomic_fetch_add(acc + XV, 1ull + ((unsigned long long)wg.bad_ << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // ... and the wait for everybody's: wave 0 polls, the totals go to wg.xtot[v0 ..]; last = the exchange's last block.  False: timed out
+  auto xpoll = [&](int v0, int nv, bool last, bool hold) -> bool
+  {
+    const uint32_t par = (nx - 1u) & 1u;
+    unsigned long long * set = A.xbuf + (size_t)par*XN;
+    if (wv == 0)
+    {
+      const unsigned long long t_wait = wall_clock64();
+      const unsigned long long prev0 = wg.xprev[par][lane], prev1 = wg.xprev[par][64u + lane];
+      bool ok = true;
+      unsigned long long cur0 = 0, cur1 = 0, d = 0, gd = 0;
+      for (uint32_t rounds = 1;; ++rounds)
+      {
+        // TWO loads: lane 16 x + k reads word k of shards x and x + 4; the shards' growth since the set's previous use, added up
+        cur0 = __hip_atomic_load(set + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur1 = __hip_atomic_load(set + 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        d = (cur0 - prev0) + (cur1 - prev1);
+        d += __shfl_xor(d, 16, 64); d += __shfl_xor(d, 32, 64);
+        if ((uint32_t)__shfl(d, XV, 64) >= A.nwg) break;
+        if ((rounds & 63u) == 0 && wall_clock64() - t_wait > 50000000ull) { ok = false; break; }     // 0.5 s at 100 MHz
+        __builtin_amdgcn_s_sleep(1);
+      }
+      bool anybad = ok && (__shfl(d, XV, 64) >> 32) != 0;
+      if (ok && A.world > 1)
+      {
+        // ---- several GPUs: this rank's sums (lanes 0..14) and its unusable-term flag (lane 15) go to slot `rank` of
+        // EVERY rank's mailbox over the xGMI peer mappings — workgroup 0 publishes, values first, then the sequence
+        // flag —, and every workgroup adds up the N slots of its own mailbox once their flags show this exchange.
+        // Fixed point: the same total on every rank whatever the order.  Mailboxes alternate by sequence parity.
+        ++gseq;
+        const size_t slot = ((size_t)(gseq & 1ull)*(size_t)A.world)*A.slot_bytes;
+        if (b == 0)
+        {
+          const unsigned long long v = lane < (uint32_t)nv ? d : (lane == (uint32_t)XV && anybad) ? 1ull : 0ull;
+          if (lane < 16u)
+            for (int pr_ = 0; pr_ < A.world; ++pr_)
+              __hip_atomic_store(reinterpret_cast<unsigned long long *>(A.peers[pr_] + slot + (size_t)A.rank*A.slot_bytes + p2p::HDR) + lane, v,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __threadfence_system();
+          __builtin_amdgcn_wave_barrier();
+          if (lane < (uint32_t)A.world)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(A.peers[lane] + slot + (size_t)A.rank*A.slot_bytes), gseq,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        bool here = true;
+        if (lane < (uint32_t)A.world)
+        {
+          const unsigned long long * f = reinterpret_cast<const unsigned long long *>(A.mail + slot + (size_t)lane*A.slot_bytes);
+          const unsigned long long tw = wall_clock64();
+          while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != gseq)
+          {
+            if (wall_clock64() - tw > A.spin_limit) { here = false; break; }
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        if (!__all(here ? 1 : 0)) { ok = false; if (lane == 0) *A.p2p_err = 1; }
+        else
+        {
+          unsigned long long tot = 0;
+          for (int r = 0; r < A.world; ++r)
+            tot += __hip_atomic_load(reinterpret_cast<const unsigned long long *>(A.mail + slot + (size_t)r*A.slot_bytes + p2p::HDR) + (lane & 15u),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          gd = tot; anybad = __shfl(tot, XV, 64) != 0;
+        }
+      }
+      XT(3);
+      if (ok)
+      {
+        const unsigned long long dd = A.world > 1 ? gd : d;
+        if (lane < (uint32_t)nv) wg.xtot[v0 + (int)lane] = anybad ? __longlong_as_double(0x7ff8000000000000ll) : (double)(long long)dd*(1.0/FX);
+        wg.xprev[par][lane] = cur0; wg.xprev[par][64u + lane] = cur1;
+        // (an unusable term stays flagged through every block of the exchange: its value may lie in a later one)
+        if (lane == 0) { if (anybad) wg.xbad_ = 1u; if (last) wg.bad_ = 0; }
+      }
+      else if (lane == 0) { wg.abort_ = 1; *A.err = 1; }
+      if (hold || solo) { wsync(); return ok; }                // (wave 0 goes on to the decision; the caller's barrier publishes everything)
+    }
+    else if (hold || solo) return true;
+    __syncthreads();
+    XT(4);
+    return !wg.abort_;
+  };
+  // an exchange of nval sums: begin = this workgroup's part (its first block is on its way when this returns), end = the wait
+  // (and the blocks after the first, one after the other: two accumulator sets alternate).  What lies between the two
+  // runs while the slower workgroups are still at their loci.  If any term of any block was unusable, EVERY total is NaN.
+  int x_nval = 0;
+  auto exchange_begin = [&](int nval)
+  {
+    xt0 = prof_on ? clock64() : 0;
+    if (!solo) __syncthreads();                      // every lane's term is in wg.accfx
+    XT(0);
+    x_nval = nval;
+    if (tid == 0) wg.xbad_ = 0;
+    xpush(0, nval < XV ? nval : XV);
+  };
+  // hold: wave 0 returns from the last block's poll without the closing barrier (and is the only one that may read the
+  // totals before the caller's own barrier); the other waves come straight through
+  auto exchange_end = [&](int want, double & mine_tot, bool hold = false) -> bool
+  {
+    const int nval = x_nval;
+    xt0 = prof_on ? clock64() : 0;
+    if (!xpoll(0, nval < XV ? nval : XV, nval <= XV, hold && nval <= XV)) return false;
+    for (int v0 = XV; v0 < nval; v0 += XV)
+    {
+      const int nv = nval - v0 < XV ? nval - v0 : XV;
+      xpush(v0, nv);
+      if (!xpoll(v0, nv, v0 + XV >= nval, hold && v0 + XV >= nval)) return false;
+    }
+    if (hold || solo)
+    {
+      if (wv == 0 && nval > XV && wg.xbad_) { if (lane < (uint32_t)nval) wg.xtot[lane] = __longlong_as_double(0x7ff8000000000000ll); wsync(); }
+      return true;
+    }
+    if (nval > XV && wg.xbad_)
+    {
+      __syncthreads();
+      if (tid < (uint32_t)nval) wg.xtot[tid] = __longlong_as_double(0x7ff8000000000000ll);
+      __syncthreads();
+    }
+    mine_tot = wg.xtot[want & 31];
+    return true;
+  };
+  auto exchange = [&](int nval, int want, double & mine_tot) -> bool
+  {
+    exchange_begin(nval);
+    return exchange_end(want, mine_tot);
+  };
+#undef XT
+
+  // =====================================================================================================================
+  // The program's moves (PROG): wave 0 of every workgroup has no loci — it is the CONTROL wave.  It owns the global stream,
+  // makes the proposal of the species tree of every all-loci step (window, factors -> wg.stepp), runs the exchange alone
+  // (the workgroup's sums -> device accumulators -> everybody's totals), takes the decision (prog_theta_decide /
+  // prog_tau_decide, MIX here) and installs its consequences for the species tree (wg.tau, wg.pf) — all between the two
+  // barriers of a step: B1 "the loci's terms are in wg.accfx" and B3 "the decision and the next step's proposal are out".
+  // While the loci waves work it does what does not depend on them (MIX's re-draws).  Its registers are its own: none of a
+  // locus's state is alive here, none of the decisions' arithmetic in the loci waves' code (one code path cost the
+  // sweep 230 spilled registers).  Stream order = a00_driver.c's: [first TAU's window] [THETA: choices + windows]
+  // [THETA: variates, acceptance numbers] [TAU: variates, acceptance number] [next window] ...
+  if constexpr (PROG)
+  {
+    if (wv == 0)
+    {
+      Stream<true> g{*A.grng};
+      const uint32_t tm = A.theta_mask;
+      const int nth = 2*__popc(tm);
+      const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+      uint32_t cnt_prop = 0, cnt_acc = 0, cnt_gprop = 0, cnt_gacc = 0, ndec = 0;
+      const bool declog = (A.dbg & 256u) && b == 0;
+      int q = -1; bool mix = false;
+      double tq_old = 0, tq_new = 0, mix_c = 1, mix_lnc = 0, lnprior = 0;
+      // the species-tree proposal of step `stepq` (TAU of population stepq; MIX: npop), from the current wg.tau
+      auto make_step = [&](int stepq)
+      {
+        mix = stepq == npop; q = mix ? -1 : stepq;
+        const double wprop = g.window();                         // (log c of the mixing step: finetune x the window variate, prop_mixing.c:300)
+        double tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1, lminf = 0, lmaxf = 0;
+        tq_old = 0; tq_new = 0; mix_c = 1; mix_lnc = 0; lnprior = 0;
+        if (!mix)
+        {
+          const int pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
+          tq_old = wg.tau[q]; tq_lo = fmax(wg.tau[cl], wg.tau[cr]); tq_hi = pq >= 0 ? wg.tau[pq] : 999.0;
+          tq_new = reflect(tq_old + SP.ft_tau*wprop, tq_lo, tq_hi);
+          minf = (tq_new - tq_lo)/(tq_old - tq_lo); maxf = (tq_new - tq_hi)/(tq_old - tq_hi);
+          lminf = log(minf); lmaxf = log(maxf);
+          if (pq < 0 && SP.tau_alpha > 0) lnprior = (SP.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - SP.tau_beta*(tq_new - tq_old);
+        }
+        else { mix_lnc = SP.ft_mix*wprop; mix_c = exp(mix_lnc); }
+        if (lane == 0)
+        {
+          wg.stepp.q = q; wg.stepp.mix = mix ? 1 : 0; wg.stepp.tq_old = tq_old; wg.stepp.tq_lo = tq_lo; wg.stepp.tq_hi = tq_hi; wg.stepp.tq_new = tq_new;
+          wg.stepp.minf = minf; wg.stepp.maxf = maxf; wg.stepp.lminf = lminf; wg.stepp.lmaxf = lmaxf; wg.stepp.mix_c = mix_c; wg.stepp.mix_lnc = mix_lnc;
+        }
+      };
+      // THETA's choices: which thetas slide (and where to), which take the Gibbs draw
+      uint32_t slidem = 0; double tslide = 0;
+      auto theta_choices = [&]()
+      {
+        slidem = 0; tslide = 0;
+        for (int p = 0; p < npop; ++p)
+          if ((tm >> p) & 1u)
+          {
+            if (!(g.u() < SP.theta_slide_prob)) continue;
+            slidem |= 1u << p;
+            const double tn = reflect(wg.tau[MAXPOP + p] + SP.ft_theta*g.window(), 0.0, 999.0);
+            if (p == (int)lane) tslide = tn;
+          }
+      };
+      bool aborted = false;
+      if (A.do_allloci && A.niter) { make_step(nsp); theta_choices(); }
+      __syncthreads();                                                  // B0: the first step's proposal is out
+      for (uint32_t it = 0; it < A.niter && A.do_allloci && !aborted; ++it)
+      {
+        for (int stepq = nsp; stepq <= npop && !aborted; ++stepq)
+        {
+          const bool first = stepq == nsp;                           // (the THETA step's sums come with the first TAU's)
+          const int base = first ? nth : 0;
+          // while the loci work: what does not depend on them
+          if (mix) { SMP2_SUB0(); g.r = prog_mix_redraw((uint32_t)g.r, tm, mix_c); SMP2_SUB(15); }
+          SMP2_TICK(0);
+          __syncthreads();                                              // B1: every locus's terms are in wg.accfx
+          SMP2_TICK(1);
+          double dummy = 0;
+          exchange_begin(base + (mix ? 2 : 5));
+          SMP2_TICK(2);
+          const bool okx = exchange_end(0, dummy);
+          SMP2_TICK(3);
+          if (!okx) { aborted = true; __syncthreads(); break; }
+          bool accept = false; double lnacc = 0; uint32_t rd_mask = 0;
+          if (first)
+          {
+            g.r = prog_theta_decide((uint32_t)g.r, tm, slidem, tslide, 1);
+            const uint32_t accm = wg.dec.accm;
+            cnt_prop += (uint32_t)__popc(tm); cnt_acc += (uint32_t)__popc(accm);
+            cnt_gprop += (uint32_t)__popc(tm & ~slidem); cnt_gacc += (uint32_t)__popc(accm & tm & ~slidem);
+            if (declog && lane < (uint32_t)npop && ((tm >> lane) & 1u))
+            {
+              const uint32_t k = ndec + (uint32_t)__popc(tm & ((1u << lane) - 1u));
+              if (k < 1000u) { double * r = A.declog + 4*k; r[0] = (((slidem >> lane) & 1u) ? 100 : 200) + (int)lane; r[1] = wg.dec.lnacc[lane]; r[2] = -1.0; r[3] = (accm >> lane) & 1u ? 1 : 0; }
+            }
+            ndec += (uint32_t)__popc(tm);
+            SMP2_TICK(4);
+          }
+          if (!mix)
+          {
+            g.r = prog_tau_decide((uint32_t)g.r, tm, q, base, lnprior);
+            accept = wg.dec.acc_step != 0u; rd_mask = wg.dec.rd_mask; lnacc = wg.dec.lnacc_step;
+          }
+          else
+          {
+            lnacc = (wg.xtot[0] + wg.xtot[1]*(FX/FXC)) + (double)(nsp - 1)*mix_lnc;
+            if (SP.tau_alpha > 0)
+            {
+              const double troot = wg.tau[npop - 1];
+              lnacc += (SP.tau_alpha - 1)*mix_lnc - SP.tau_beta*(troot*mix_c - troot) - (double)(nsp - 2)*mix_lnc;
+            }
+            lnacc += wg.dec.lnacc_theta; rd_mask = wg.dec.rd_mask;
+            accept = g.accept(lnacc);
+            if (lane == 0) wg.dec.acc_step = accept ? 1u : 0u;
+          }
+          ++cnt_prop; cnt_acc += accept ? 1u : 0u;
+          if (declog && lane == 0 && ndec < 1000u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = -1.0; r[3] = accept ? 1 : 0; }
+          ++ndec;
+          // the consequences for the species tree: tau(s), the re-drawn thetas, the sums and the fits the next steps start from
+          if (accept)
+          {
+            if (!mix) { if (lane == 0) wg.tau[q] = tq_new; }
+            else if (lane < (uint32_t)npop) wg.tau[lane] *= mix_c;
+            if (lane < 16u)
+            {
+              const Redraw r = wg.rd[lane];
+              if ((rd_mask >> lane) & 1u) { wg.tau[MAXPOP + lane] = r.tn; wg.tau[2*MAXPOP + lane] = r.l2t; }
+              const bool moved = mix ? lane < (uint32_t)npop && ((tm >> lane) & 1u)
+                                     : ((tm >> lane) & 1u) && ((int)lane == q || (int)lane == SP.left[q] || (int)lane == SP.right[q]);
+              if (moved) { PopFit & f = wg.pf[lane]; f.T = r.T; f.a = r.a; f.b = r.b; f.c = r.c; }
+            }
+          }
+          wsync();
+          if (mix) SMP2_TICK(6); else SMP2_TICK(5);
+          // the next step's proposal (after MIX: the next iteration's first TAU and THETA's choices — unless the launch ends here:
+          // the next launch's prologue draws them, the same numbers of the stream)
+          if (stepq < npop) make_step(stepq + 1);
+          else if (it + 1 < A.niter) { make_step(nsp); theta_choices(); }
+          SMP2_TICK(7);
+          __syncthreads();                                              // B3: the decision and the next proposal are out
+        }
+      }
+      if (b == 0)
+      {
+        if (lane == 0 && !aborted)
+        {
+          *A.grng = g.r;
+          A.counters[0] += cnt_prop; A.counters[1] += cnt_acc; A.counters[2] += cnt_gprop; A.counters[3] += cnt_gacc;
+        }
+        if (!aborted && lane < (uint32_t)(3*MAXPOP)) A.taus[lane] = wg.tau[lane];
+        if (prof_on) for (int i = 0; i < 24; ++i) A.prof[(i < 16 ? 0 : (int)A.nwg) + i] = (double)wg.prof[i];
+        if (prof_on) for (int i = 0; i < 16; ++i) A.prof[(int)A.nwg + 24 + i] = (double)wg.wsweep[i];
+      }
+      return;
+    }
+  }
 
   // ---- load: the loci of this wave
   const uint32_t t0 = gw < A.nwaves ? A.wave_off[gw] : 0u, nt = gw < A.nwaves ? A.wave_off[gw + 1] - t0 : 0u;
@@ -909,181 +1243,6 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     }
   }
 
-  const bool prof_on = (A.dbg & 16u) && b == 0 && tid == 0;
-  long long pf_t = prof_on ? clock64() : 0;
-#define SMP2_TICK(i_) do { if (prof_on) { const long long t1_ = clock64(); wg.prof[i_] += t1_ - pf_t; pf_t = t1_; } } while (0)
-  long long pf_s = 0;
-#define SMP2_SUB0() do { if (prof_on) pf_s = clock64(); } while (0)
-#define SMP2_SUB(i_) do { if (prof_on) wg.prof[i_] += clock64() - pf_s; } while (0)
-
-  // ---- the sum over ALL loci of one all-loci step's terms.  A term enters as 2^-40 fixed point (what the host driver adds
-  // up in doubles, locus by locus: the totals agree to ~1e-11), so a total does not depend on the order of the additions: the lanes add theirs to the workgroup's accumulators (LDS atomics, fx_add),
-  // the workgroup adds those to the step's device accumulators (device-scope atomics) and then bumps the arrival
-  // counter; wave 0 polls until every workgroup has arrived.  Device accumulators and counter only ever grow (the host
-  // zeroes them before the launch) and two sets alternate, so a workgroup already in the next step never touches what
-  // a slower one still reads.  Up to 7 values share one 64-byte block with the counter: the poll's ONE load brings the
-  // totals with the count (they landed before the arrival was counted).  False: timed out.
-  constexpr double FX = 1099511627776.0;             // 2^40: 9e-13 per term; |term| < 256 and <= 2^14 loci: the sum cannot wrap
-  constexpr double FXC = 1024.0;                     // a TAU / MIX term beyond that goes to a coarse companion sum (2^-10, |term| < 2^38)
-  auto fx_add = [&](int v, double x, bool coarse)
-  {
-    if (fabs(x) < 256.0)
-      (void)__hip_atomic_fetch_add(&wg.accfx[v], (unsigned long long)__double2ll_rn(x*FX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else if (coarse && fabs(x) < 274877906944.0)
-      (void)__hip_atomic_fetch_add(&wg.accfx[v + 1], (unsigned long long)__double2ll_rn(x*FXC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else wg.bad_ = 1u;                                                       // (also NaN): the step is rejected
-  };
-  uint32_t nx = 0;
-  unsigned long long gseq = A.seq0;                 // several GPUs: the mailboxes' sequence number
-#define XT(i_) do { if (prof_on) { const long long t1_ = clock64(); wg.prof[8 + i_] += t1_ - xt0; xt0 = t1_; } } while (0)
-  long long xt0 = 0;
-  // one block of <= 15 values (15 sums + the counter = one 128-byte block): the workgroup's sums go to its shard, then its arrival
-  auto xpush = [&](int v0, int nv)
-  {
-    const uint32_t par = nx & 1u; ++nx;
-    // 8 shards, a workgroup adds to shard b mod 8: atomics on one word are served one after the other
-    unsigned long long * acc = A.xbuf + (size_t)par*XN + (size_t)(b & 7u)*16u;
-    if (tid < (uint32_t)nv)
-    {
-      const unsigned long long fx = wg.accfx[v0 + (int)tid];
-      wg.accfx[v0 + (int)tid] = 0ull;
-      const unsigned long long old = __hip_atomic_fetch_add(acc + tid, fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" :: "v"(old) : "memory");          // the sums have landed before the arrival is counted
-    }
-    XT(1);
-    __syncthreads();
-    XT(2);
-    // arrival: + 1, and + 2^32 when a term of this workgroup was unusable
-    if (tid == 0) (void)__hip_atomic_fetch_add(acc + XV, 1ull + ((unsigned long long)wg.bad_ << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  // ... and the wait for everybody's: wave 0 polls, the totals go to wg.xtot[v0 ..]; last = the exchange's last block.  False: timed out
-  auto xpoll = [&](int v0, int nv, bool last, bool hold) -> bool
-  {
-    const uint32_t par = (nx - 1u) & 1u;
-    unsigned long long * set = A.xbuf + (size_t)par*XN;
-    if (wv == 0)
-    {
-      const unsigned long long t_wait = wall_clock64();
-      const unsigned long long prev0 = wg.xprev[par][lane], prev1 = wg.xprev[par][64u + lane];
-      bool ok = true;
-      unsigned long long cur0 = 0, cur1 = 0, d = 0, gd = 0;
-      for (uint32_t rounds = 1;; ++rounds)
-      {
-        // TWO loads: lane 16 x + k reads word k of shards x and x + 4; the shards' growth since the set's previous use, added up
-        cur0 = __hip_atomic_load(set + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cur1 = __hip_atomic_load(set + 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        d = (cur0 - prev0) + (cur1 - prev1);
-        d += __shfl_xor(d, 16, 64); d += __shfl_xor(d, 32, 64);
-        if ((uint32_t)__shfl(d, XV, 64) >= A.nwg) break;
-        if ((rounds & 63u) == 0 && wall_clock64() - t_wait > 50000000ull) { ok = false; break; }     // 0.5 s at 100 MHz
-        __builtin_amdgcn_s_sleep(1);
-      }
-      bool anybad = ok && (__shfl(d, XV, 64) >> 32) != 0;
-      if (ok && A.world > 1)
-      {
-        // ---- several GPUs: this rank's sums (lanes 0..14) and its unusable-term flag (lane 15) go to slot `rank` of
-        // EVERY rank's mailbox over the xGMI peer mappings — workgroup 0 publishes, values first, then the sequence
-        // flag —, and every workgroup adds up the N slots of its own mailbox once their flags show this exchange.
-        // Fixed point: the same total on every rank whatever the order.  Mailboxes alternate by sequence parity.
-        ++gseq;
-        const size_t slot = ((size_t)(gseq & 1ull)*(size_t)A.world)*A.slot_bytes;
-        if (b == 0)
-        {
-          const unsigned long long v = lane < (uint32_t)nv ? d : (lane == (uint32_t)XV && anybad) ? 1ull : 0ull;
-          if (lane < 16u)
-            for (int pr_ = 0; pr_ < A.world; ++pr_)
-              __hip_atomic_store(reinterpret_cast<unsigned long long *>(A.peers[pr_] + slot + (size_t)A.rank*A.slot_bytes + p2p::HDR) + lane, v,
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __threadfence_system();
-          __builtin_amdgcn_wave_barrier();
-          if (lane < (uint32_t)A.world)
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(A.peers[lane] + slot + (size_t)A.rank*A.slot_bytes), gseq,
-                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        bool here = true;
-        if (lane < (uint32_t)A.world)
-        {
-          const unsigned long long * f = reinterpret_cast<const unsigned long long *>(A.mail + slot + (size_t)lane*A.slot_bytes);
-          const unsigned long long tw = wall_clock64();
-          while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != gseq)
-          {
-            if (wall_clock64() - tw > A.spin_limit) { here = false; break; }
-            __builtin_amdgcn_s_sleep(2);
-          }
-        }
-        if (!__all(here ? 1 : 0)) { ok = false; if (lane == 0) *A.p2p_err = 1; }
-        else
-        {
-          unsigned long long tot = 0;
-          for (int r = 0; r < A.world; ++r)
-            tot += __hip_atomic_load(reinterpret_cast<const unsigned long long *>(A.mail + slot + (size_t)r*A.slot_bytes + p2p::HDR) + (lane & 15u),
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          gd = tot; anybad = __shfl(tot, XV, 64) != 0;
-        }
-      }
-      XT(3);
-      if (ok)
-      {
-        const unsigned long long dd = A.world > 1 ? gd : d;
-        if (lane < (uint32_t)nv) wg.xtot[v0 + (int)lane] = anybad ? __longlong_as_double(0x7ff8000000000000ll) : (double)(long long)dd*(1.0/FX);
-        wg.xprev[par][lane] = cur0; wg.xprev[par][64u + lane] = cur1;
-        // (an unusable term stays flagged through every block of the exchange: its value may lie in a later one)
-        if (lane == 0) { if (anybad) wg.xbad_ = 1u; if (last) wg.bad_ = 0; }
-      }
-      else if (lane == 0) { wg.abort_ = 1; *A.err = 1; }
-      if (hold) { wsync(); return ok; }                // (wave 0 goes on to the decision; the caller's barrier publishes everything)
-    }
-    else if (hold) return true;
-    __syncthreads();
-    XT(4);
-    return !wg.abort_;
-  };
-  // an exchange of nval sums: begin = this workgroup's part (its first block is on its way when this returns), end = the wait
-  // (and the blocks after the first, one after the other: two accumulator sets alternate).  What lies between the two
-  // runs while the slower workgroups are still at their loci.  If any term of any block was unusable, EVERY total is NaN.
-  int x_nval = 0;
-  auto exchange_begin = [&](int nval)
-  {
-    xt0 = prof_on ? clock64() : 0;
-    __syncthreads();                                 // every lane's term is in wg.accfx
-    XT(0);
-    x_nval = nval;
-    if (tid == 0) wg.xbad_ = 0;
-    xpush(0, nval < XV ? nval : XV);
-  };
-  // hold: wave 0 returns from the last block's poll without the closing barrier (and is the only one that may read the
-  // totals before the caller's own barrier); the other waves come straight through
-  auto exchange_end = [&](int want, double & mine_tot, bool hold = false) -> bool
-  {
-    const int nval = x_nval;
-    xt0 = prof_on ? clock64() : 0;
-    if (!xpoll(0, nval < XV ? nval : XV, nval <= XV, hold && nval <= XV)) return false;
-    for (int v0 = XV; v0 < nval; v0 += XV)
-    {
-      const int nv = nval - v0 < XV ? nval - v0 : XV;
-      xpush(v0, nv);
-      if (!xpoll(v0, nv, v0 + XV >= nval, hold && v0 + XV >= nval)) return false;
-    }
-    if (hold)
-    {
-      if (wv == 0 && nval > XV && wg.xbad_) { if (lane < (uint32_t)nval) wg.xtot[lane] = __longlong_as_double(0x7ff8000000000000ll); wsync(); }
-      return true;
-    }
-    if (nval > XV && wg.xbad_)
-    {
-      __syncthreads();
-      if (tid < (uint32_t)nval) wg.xtot[tid] = __longlong_as_double(0x7ff8000000000000ll);
-      __syncthreads();
-    }
-    mine_tot = wg.xtot[want & 31];
-    return true;
-  };
-  auto exchange = [&](int nval, int want, double & mine_tot) -> bool
-  {
-    exchange_begin(nval);
-    return exchange_end(want, mine_tot);
-  };
-#undef XT
   const double qnan = __longlong_as_double(0x7ff8000000000000ll);
   uint32_t cnt_prop = 0, cnt_acc = 0;              // all-loci proposals / accepted (the same in every workgroup)
   uint32_t cnt_gprop = 0, cnt_gacc = 0;            // of those: Gibbs draws of a theta
@@ -1093,6 +1252,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   long long wg_sweep = 0;
   bool aborted = false;
 
+  if constexpr (PROG) __syncthreads();             // B0: the control wave's first proposal is out
   for (uint32_t it = 0; it < A.niter && !aborted; ++it)
   {
     // ================= GAGE + GSPR of every locus
@@ -1143,7 +1303,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     // ---- the program's TAU and MIX re-draw thetas inside the proposal (a00_set_program_moves: opt_rb_theta_update,
     // opt_mix_theta_update): the densities' change over all loci then follows from k_p and the T2h sums, the loci contribute
     // their likelihood change (and, in TAU, the new T2h of the three populations around the divergence)
-    const bool program = BPP && SP.program_moves && SP.theta_alpha > 0 && A.theta_mask;
+    constexpr bool program = PROG;
     bool mix = false; int q = -1;
     double wprop = 0, uacc = -1.0;
     double tq_old = 0, tq_lo = 0, tq_hi = 0, minf = 1, maxf = 1, lminf = 0, lmaxf = 0, tq_new = 0, mix_c = 1, mix_lnc = 0;
@@ -1156,27 +1316,40 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     bool evaluated = false, accept = false;
     auto step_begin = [&](int stepq)
     {
-      mix = stepq == npop;
-      q = mix ? -1 : stepq;
-      // (log c of the mixing step: finetune x BPP's window variate with its kernel, prop_mixing.c:300; uniform with ours)
-      wprop = mix && !BPP ? grng.u() - 0.5 : grng.window(); uacc = BPP ? -1.0 : grng.u();
-      rd_tn = qnan; rd_l2t = 0; rd_T = 0; rd_a = rd_b = rd_c = qnan; rd_mask = 0; lnprior = 0; accept = false;
+      rd_mask = 0; lnprior = 0; accept = false; lnacc_theta = 0;
+      if constexpr (PROG)
+      {
+        // the control wave's proposal of the species tree (wg.stepp, out since the last barrier)
+        (void)stepq;
+        mix = wg.stepp.mix != 0; q = wg.stepp.q;
+        tq_old = wg.stepp.tq_old; tq_lo = wg.stepp.tq_lo; tq_hi = wg.stepp.tq_hi; tq_new = wg.stepp.tq_new;
+        minf = wg.stepp.minf; maxf = wg.stepp.maxf; lminf = wg.stepp.lminf; lmaxf = wg.stepp.lmaxf; mix_c = wg.stepp.mix_c; mix_lnc = wg.stepp.mix_lnc;
+      }
+      else
+      {
+        mix = stepq == npop;
+        q = mix ? -1 : stepq;
+        // (log c of the mixing step: finetune x BPP's window variate with its kernel, prop_mixing.c:300; uniform with ours)
+        wprop = mix && !BPP ? grng.u() - 0.5 : grng.window(); uacc = BPP ? -1.0 : grng.u();
+        tq_old = 0; tq_lo = 0; tq_hi = 0; minf = 1; maxf = 1; lminf = 0; lmaxf = 0; tq_new = 0; mix_c = 1; mix_lnc = 0;
+        if (!mix)
+        {
+          const int pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
+          tq_old = wg.tau[q]; tq_lo = fmax(wg.tau[cl], wg.tau[cr]); tq_hi = pq >= 0 ? wg.tau[pq] : 999.0;
+          tq_new = reflect(tq_old + SP.ft_tau*wprop, tq_lo, tq_hi);
+          minf = (tq_new - tq_lo)/(tq_old - tq_lo); maxf = (tq_new - tq_hi)/(tq_old - tq_hi);
+          lminf = log(minf); lmaxf = log(maxf);
+        }
+        else { mix_lnc = SP.ft_mix*wprop; mix_c = exp(mix_lnc); }
+      }
       // the proposed species tree: in the lanes' registers only
-      tq_old = 0; tq_lo = 0; tq_hi = 0; minf = 1; maxf = 1; lminf = 0; lmaxf = 0; tq_new = 0; mix_c = 1; mix_lnc = 0;
-      lnacc_theta = 0;
       if (!mix)
       {
-        const int pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
-        tq_old = wg.tau[q]; tq_lo = fmax(wg.tau[cl], wg.tau[cr]); tq_hi = pq >= 0 ? wg.tau[pq] : 999.0;
-        tq_new = reflect(tq_old + SP.ft_tau*wprop, tq_lo, tq_hi);
-        minf = (tq_new - tq_lo)/(tq_old - tq_lo); maxf = (tq_new - tq_hi)/(tq_old - tq_hi);
-        lminf = log(minf); lmaxf = log(maxf);
         if (li == q) pl.tau = tq_new;
         if (pl.parent == q) pl.ptau = tq_new;
       }
       else
       {
-        mix_lnc = SP.ft_mix*wprop; mix_c = exp(mix_lnc);
         pl.tau *= mix_c;
         if (pl.parent >= 0) pl.ptau *= mix_c;
       }
@@ -1234,15 +1407,9 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       }
     };
     // the decision (decide of sampler.hpp; stree.c:6280, prop_mixing.c:203-205)
+    // the decision where every wave takes it for itself (decide of sampler.hpp; stree.c:6280, prop_mixing.c:203-205)
     auto step_decide = [&](int base)
     {
-      if (program && !mix)
-      {
-        // (wave 0) the thetas of q and its two children re-drawn, the ratio, the decision: prog_tau_decide
-        grng.r = prog_tau_decide((uint32_t)grng.r, A.theta_mask, q, base, lnprior);
-        accept = wg.dec.acc_step != 0u; rd_mask = wg.dec.rd_mask; lnacc = wg.dec.lnacc_step;
-        return;
-      }
       dl_tot = wg.xtot[base] + wg.xtot[base + 1]*(FX/FXC);      // (+ the coarse sum: terms of 256 and more — none in any run worth the name)
       lnacc = dl_tot;
       if (!mix) lnacc += lnprior;
@@ -1254,41 +1421,33 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           const double troot = wg.tau[npop - 1];
           lnacc += (SP.tau_alpha - 1)*mix_lnc - SP.tau_beta*(troot*mix_c - troot) - (double)(nsp - 2)*mix_lnc;
         }
-        if (program) { lnacc += wg.dec.lnacc_theta; rd_mask = wg.dec.rd_mask; }
       }
       accept = BPP ? grng.accept(lnacc) : (lnacc >= 0 || uacc < exp(lnacc));
     };
-    auto step_apply = [&]()
+    // the consequences: every wave's copy of the species tree (non-PROG: workgroup's LDS copy by its first lanes; PROG: the
+    // control wave has done that), the loci's trees — commit or roll back —, the densities where thetas moved
+    auto step_apply = [&](bool refresh)
     {
-      ++cnt_prop; cnt_acc += accept ? 1u : 0u;
-      if (declog && tid == 0 && ndec < 1000u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
-      ++ndec;
-      if (!program) __syncthreads();                          // everyone has read the old taus (the program's moves: the decision's barrier was that)
-      if (accept)
+      if constexpr (!PROG)
       {
-        if (!mix) { if (tid == 0) wg.tau[q] = tq_new; }
-        else if (tid < (uint32_t)npop) wg.tau[tid] *= mix_c;
-        if (program)
+        ++cnt_prop; cnt_acc += accept ? 1u : 0u;
+        if (declog && tid == 0 && ndec < 1000u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
+        ++ndec;
+        __syncthreads();                                      // everyone has read the old taus
+        if (accept)
         {
-          // the re-drawn thetas; the sums and the fits the next steps start from (wave 0, lane p < 16: population p)
-          if (tid < 16u)
-          {
-            const Redraw r = wg.rd[tid];
-            if ((rd_mask >> tid) & 1u) { wg.tau[MAXPOP + tid] = r.tn; wg.tau[2*MAXPOP + tid] = r.l2t; }
-            const bool moved = mix ? tid < (uint32_t)npop && ((A.theta_mask >> tid) & 1u)
-                                   : ((A.theta_mask >> tid) & 1u) && ((int)tid == q || (int)tid == SP.left[q] || (int)tid == SP.right[q]);
-            if (moved) { PopFit & f = wg.pf[tid]; f.T = r.T; f.a = r.a; f.b = r.b; f.c = r.c; }
-          }
+          if (!mix) { if (tid == 0) wg.tau[q] = tq_new; }
+          else if (tid < (uint32_t)npop) wg.tau[tid] *= mix_c;
         }
-        if (act) { lnl_cur = lnl_new; logpr_cur = lp_new; commit_density(allpop); }
       }
+      if (accept) { if (act) { lnl_cur = lnl_new; logpr_cur = lp_new; commit_density(allpop); } }
       else if (act) { T.cf = cf0; T.pf = pf0; S.time[li] = tsave; }
-      __syncthreads();
+      if constexpr (!PROG) __syncthreads();
       load_pop();
       wsync();
-      if (program && accept && act)
+      if (PROG && (refresh || accept) && act)
       {
-        // the densities with the re-drawn thetas, from the statistics of the accepted trees (as after THETA)
+        // the densities with the thetas as they are now (THETA's decisions, a TAU's or MIX's re-draws), from the statistics of the trees as settled
         if (li < npop) S.contrib[li] = msc_term((int)mync, t2h_cur, pl.theta, pl.l2t);
         wsync();
         double lp = 0;
@@ -1297,16 +1456,34 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         wsync();
       }
     };
-    bool merged_done = false, accept_step1 = false;
+    if constexpr (PROG)
+    {
+      // ================= the program's moves, a loci wave's part: its loci's terms of every all-loci step; the control wave
+      // (above) does the rest between the step's two barriers.  THETA's sums ride with the first TAU's.
+      const bool on = li < npop && ((A.theta_mask >> li) & 1u);
+      const int kidx = __popc(A.theta_mask & ((1u << li) - 1u)), nth = 2*__popc(A.theta_mask);
+      for (int stepq = nsp; stepq <= npop && !aborted; ++stepq)
+      {
+        const bool first = stepq == nsp;
+        step_begin(stepq);
+        if (first && act && on) { fx_add(2*kidx, (double)mync, false); fx_add(2*kidx + 1, t2h_cur, false); }
+        step_locus(first ? nth : 0);
+        __syncthreads();                                                // B1: the terms are in
+        __syncthreads();                                                // B3: the decision is out (and the species tree as it now is, and the next proposal)
+        if (wg.abort_) { aborted = true; break; }
+        accept = wg.dec.acc_step != 0u;
+        step_apply(first);
+      }
+    }
+    else
+    {
     // ================= THETA: every population that can hold a coalescence, decided independently (theta_step_all)
     if (SP.theta_alpha > 0 && A.theta_mask)
     {
-      const bool gibbs = BPP && SP.program_moves;               // the program's own mix of moves (theta_step_gibbs of a00_driver.c)
       const bool on = li < npop && ((A.theta_mask >> li) & 1u);
       const double told = pl.theta, l2t_old = pl.l2t;
-      double tnew = told, uacc = -1.0, my_lnacc = 0, l2t_gibbs = 0;
+      double tnew = told, uacc = -1.0, my_lnacc = 0;
       bool accept = false, gibbs_me = false;
-      if (!gibbs)
       {
         // the windows of all populations first (theta_step_all of a00_driver.c: the uniform kernel draws the acceptance
         // number right behind each window, BPP's kernel only when a decision needs it)
@@ -1346,60 +1523,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           accept = tnew > 0 && (my_lnacc >= 0 || uacc < exp(my_lnacc));
         }
       }
-      else
-      {
-        // ---- sliding window with probability slide_prob, else BPP's metropolized Gibbs draw (stree.c:3957, 3645): both are
-        // decided from k_p = the coalescences in p over all loci and T_p = the sum of T2h — two sums that do not depend on
-        // the thetas, so ONE exchange serves every population.  Global stream: choice (+ window) per population first,
-        // then per population the gamma variate of a Gibbs draw and the acceptance number when one is needed.
-        // the program's first TAU rides on this exchange: its window comes first in the stream, the loci make its proposal
-        // right after the sweep, and ONE exchange brings k_p, T_p and the TAU's five sums (tau_step + theta_step_gibbs of
-        // a00_driver.c draw in this order too)
-        const bool merged = program && nsp < npop;
-        if (merged) step_begin(nsp);
-        uint32_t slidem = 0;
-        double tslide = 0;                                                   // lane p < 16: the window's theta of population p
-        for (int p = 0; p < npop; ++p)
-          if ((A.theta_mask >> p) & 1u)
-          {
-            if (!(grng.u() < SP.theta_slide_prob)) continue;
-            slidem |= 1u << p;
-            const double tn = reflect(wg.tau[MAXPOP + p] + SP.ft_theta*grng.window(), 0.0, 999.0);
-            if (p == (int)lane) tslide = tn;
-          }
-        const int kidx = __popc(A.theta_mask & ((1u << li) - 1u));
-        const int nth = 2*__popc(A.theta_mask);
-        if (act && on) { fx_add(2*kidx, (double)mync, false); fx_add(2*kidx + 1, t2h_cur, false); }
-        if (merged) step_locus(nth);
-        SMP2_TICK(3);
-        double dummy = 0;
-        exchange_begin(nth + (merged ? 5 : 0));
-        if (merged && wv == 0 && SP.parent[q] < 0 && SP.tau_alpha > 0)
-          lnprior = (SP.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - SP.tau_beta*(tq_new - tq_old);
-        const bool okx = exchange_end(0, dummy, true);
-        SMP2_TICK(6);
-        SMP2_SUB0();
-        // ---- wave 0 decides (the others wait at the barrier below: its SIMD is its own meanwhile)
-        if (__builtin_expect(wv == 0 && okx, 0))
-        {
-          grng.r = prog_theta_decide((uint32_t)grng.r, A.theta_mask, slidem, tslide, merged ? 1 : 0);
-          if (merged) { SMP2_SUB(13); SMP2_SUB0(); step_decide(nth); SMP2_SUB(14); SMP2_SUB0(); }
-          if (lane == 0) wg.dec.grng = grng.r;
-        }
-        __syncthreads();
-        if (wg.abort_) { aborted = true; break; }
-        grng.r = (a00_rng_t)wg.dec.grng;
-        if (merged) { accept_step1 = wg.dec.acc_step != 0u; rd_mask = wg.dec.rd_mask; lnacc = wg.dec.lnacc_step; merged_done = true; }
-        if (on)
-        {
-          accept = (wg.dec.accm >> li) & 1u; gibbs_me = !((slidem >> li) & 1u);
-          tnew = wg.dec.tn[li & 15]; my_lnacc = wg.dec.lnacc[li & 15];
-        }
-        l2t_gibbs = wg.dec.l2t[li & 15];
-        SMP2_SUB(13);
-      }
-      // (log(2/theta') of the program's moves came out of the ratio's log call)
-      const double l2t_new = gibbs ? l2t_gibbs : log(2.0/(1.0*tnew));
+      const double l2t_new = log(2.0/(1.0*tnew));
       if (accept) { pl.theta = tnew; pl.l2t = l2t_new; }
       if (declog && tid < (uint32_t)G && on)
       {
@@ -1412,7 +1536,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         cnt_prop += (uint32_t)__popc(onm); cnt_acc += (uint32_t)__popc(accm);
         cnt_gprop += (uint32_t)__popc(gm); cnt_gacc += (uint32_t)__popc(gm & accm);
       }
-      if (!gibbs) __syncthreads();                            // everyone has read the totals and the old thetas (Gibbs: the decision's barrier was that)
+      __syncthreads();                                        // everyone has read the totals and the old thetas
       if (tid < (uint32_t)G && accept) { wg.tau[MAXPOP + li] = tnew; wg.tau[2*MAXPOP + li] = l2t_new; }
       __syncthreads();
       // every tree's density with the new thetas, from its statistics, in population order
@@ -1428,47 +1552,23 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     }
     SMP2_TICK(3);
 
-    // ================= the TAU steps (the program's first one: decided with THETA, its consequences now) and MIX
-    if (merged_done && !aborted) { accept = accept_step1; step_apply(); SMP2_TICK(4); }
-    for (int stepq = nsp + (merged_done ? 1 : 0); stepq <= npop && !aborted; ++stepq)
+    // ================= TAU per species divergence, then MIX
+    for (int stepq = nsp; stepq <= npop && !aborted; ++stepq)
     {
       step_begin(stepq);
       step_locus(0);
       if (mix) SMP2_TICK(5); else SMP2_TICK(4);
-      exchange_begin(program && !mix ? 5 : 2);
-      // ---- between the arrival and the totals: what does not depend on them
-      SMP2_SUB0();
-      if (__builtin_expect(program && mix && wv == 0, 0)) { grng.r = prog_mix_redraw((uint32_t)grng.r, A.theta_mask, mix_c); SMP2_SUB(15); }
-      if (!mix && SP.parent[q] < 0 && SP.tau_alpha > 0 && (!program || wv == 0))
+      if (!mix && SP.parent[q] < 0 && SP.tau_alpha > 0)
         lnprior = (SP.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - SP.tau_beta*(tq_new - tq_old);
+      if (!exchange(2, 0, dl_tot)) { aborted = true; break; }
+      if (A.dbg & 64u) { SMP2_TICK(7); double dummy; if (!exchange(2, 0, dummy)) { aborted = true; break; } SMP2_TICK(6); }     // (the protocol alone: nobody is late)
+      SMP2_TICK(7);
+      SMP2_SUB0();
+      step_decide(0);
+      SMP2_SUB(14);
+      step_apply(false);
       if (mix) SMP2_TICK(5); else SMP2_TICK(4);
-      if (program)
-      {
-        // wave 0 decides alone — the other waves wait at the barrier, its SIMD is its own for the fits, the variates and the logs
-        const bool okx = exchange_end(0, dl_tot, true);
-        SMP2_TICK(7);
-        SMP2_SUB0();
-        if (__builtin_expect(wv == 0 && okx, 0))
-        {
-          step_decide(0);
-          if (lane == 0) { wg.dec.accm = accept ? 1u : 0u; wg.dec.rd_mask = rd_mask; wg.dec.grng = grng.r; }
-        }
-        __syncthreads();
-        if (wg.abort_) { aborted = true; break; }
-        accept = wg.dec.accm != 0u; rd_mask = wg.dec.rd_mask; grng.r = (a00_rng_t)wg.dec.grng;
-        SMP2_SUB(14);
-      }
-      else
-      {
-        if (!exchange_end(0, dl_tot)) { aborted = true; break; }
-        if (A.dbg & 64u) { SMP2_TICK(7); double dummy; if (!exchange(2, 0, dummy)) { aborted = true; break; } SMP2_TICK(6); }     // (the protocol alone: nobody is late)
-        SMP2_TICK(7);
-        SMP2_SUB0();
-        step_decide(0);
-        SMP2_SUB(14);
-      }
-      step_apply();
-      if (mix) SMP2_TICK(5); else SMP2_TICK(4);
+    }
     }
   }
 #undef SMP2_TICK
