@@ -129,6 +129,7 @@ template <int NT> struct WgLDS : WgBase
   unsigned long long xprev[2][XN];               // wave 0: every word of either accumulator set as its previous use left it
   long long prof[24];                            // BPA_SMP_DBG & 16: cycle counters of thread 0 of workgroup 0
   long long wsweep[16];                          // BPA_SMP_DBG & 16: sweep cycles of every wave of workgroup 0
+  uint32_t prog[16];                             // how far every wave has come in its sweeps (pair_sync)
 };
 
 template <int G> __device__ __forceinline__ uint32_t gballot(bool p, uint32_t gbase)
@@ -642,7 +643,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     uint32_t * dst = reinterpret_cast<uint32_t *>(&wg.sp);
     for (uint32_t i = tid; i < sizeof(Species)/4; i += C::BS) dst[i] = src[i];
     if (tid < 24u) wg.prof[tid] = 0;
-    if (tid < 16u) wg.wsweep[tid] = 0;
+    if (tid < 16u) { wg.wsweep[tid] = 0; wg.prog[tid] = 0; }
   }
   __syncthreads();
   const Species & SP = wg.sp;
@@ -856,7 +857,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   // makes the proposal of the species tree of every all-loci step (window, factors -> wg.stepp), runs the exchange alone
   // (the workgroup's sums -> device accumulators -> everybody's totals), takes the decision (prog_theta_decide /
   // prog_tau_decide, MIX here) and installs its consequences for the species tree (wg.tau, wg.pf) — all between the two
-  // barriers of a step: B1 "the loci's terms are in wg.accfx" and B3 "the decision and the next step's proposal are out".
+  // barriers of a step: B1 "the loci's terms are in wg.accfx" and B3 "the decision is out" (+ B4 "the next proposal is out",
+  // which it makes while the loci settle the decision).
   // While the loci waves work it does what does not depend on them (MIX's re-draws).  Its registers are its own: none of a
   // locus's state is alive here, none of the decisions' arithmetic in the loci waves' code (one code path cost the
   // sweep 230 spilled registers).  Stream order = a00_driver.c's: [first TAU's window] [THETA: choices + windows]
@@ -929,7 +931,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           SMP2_TICK(2);
           const bool okx = exchange_end(0, dummy);
           SMP2_TICK(3);
-          if (!okx) { aborted = true; __syncthreads(); break; }
+          if (!okx) { aborted = true; __syncthreads(); __syncthreads(); break; }
           bool accept = false; double lnacc = 0; uint32_t rd_mask = 0;
           if (first)
           {
@@ -981,12 +983,13 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           }
           wsync();
           if (mix) SMP2_TICK(6); else SMP2_TICK(5);
-          // the next step's proposal (after MIX: the next iteration's first TAU and THETA's choices — unless the launch ends here:
-          // the next launch's prologue draws them, the same numbers of the stream)
+          SMP2_TICK(7);
+          __syncthreads();                                              // B3: the decision is out, the species tree as it now is
+          // the next step's proposal, while the loci settle this one (after MIX: the next iteration's first TAU and THETA's
+          // choices — unless the launch ends here: the next launch's prologue draws them, the same numbers of the stream)
           if (stepq < npop) make_step(stepq + 1);
           else if (it + 1 < A.niter) { make_step(nsp); theta_choices(); }
-          SMP2_TICK(7);
-          __syncthreads();                                              // B3: the decision and the next proposal are out
+          __syncthreads();                                              // B4: the next proposal is out
         }
       }
       if (b == 0)
@@ -1252,6 +1255,21 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   long long wg_sweep = 0;
   bool aborted = false;
 
+  // Two waves share a SIMD (wave w and w + WAVES/2) and its arbiter serves the older one first: the older runs as if alone,
+  // the younger in the gaps — it finishes a sweep a third later, and every exchange waits for it (priorities, s_setprio,
+  // change nothing).  So the older of a pair waits (asleep: the SIMD is the younger's meanwhile) at three points of every
+  // proposal until its partner has come as far: both then finish together, 15 % sooner than the younger alone did.
+  const bool pair_older = WAVES > 4 && wv < (uint32_t)(WAVES/2) && !(PROG && wv == 0) && gw + (uint32_t)(WAVES/2) < A.nwaves && nt > 0;
+  const bool pair_younger = WAVES > 4 && wv >= (uint32_t)(WAVES/2) && !(PROG && wv == (uint32_t)(WAVES/2)) && nt > 0;
+  uint32_t pcnt = 0;
+  auto pair_sync = [&]()
+  {
+    if (!(pair_older || pair_younger) || (A.dbg & 4096u)) return;
+    ++pcnt;
+    if (pair_younger) { if (lane == 0) __hip_atomic_store(&wg.prog[wv], pcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
+    while ((int32_t)(pcnt - __hip_atomic_load(&wg.prog[wv + (uint32_t)(WAVES/2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) > 0)
+      __builtin_amdgcn_s_sleep(2);
+  };
   if constexpr (PROG) __syncthreads();             // B0: the control wave's first proposal is out
   for (uint32_t it = 0; it < A.niter && !aborted; ++it)
   {
@@ -1262,25 +1280,31 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     const long long wv_t0 = wvprof ? clock64() : 0;
     for (uint32_t step = 0; step < nprop; ++step)
     {
-      // two waves share a SIMD (wave w and w + WAVES/2) and its arbiter serves the older one first: left alone, the younger
-      // waves finish a sweep a third later than the older ones, and every exchange waits for them.  The two take turns.
-      if (WAVES > 4) { if (A.dbg & 2048u) { if (wv >= (uint32_t)(WAVES/2)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); } else if (((step ^ (wv/(uint32_t)(WAVES/2))) & 1u)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
-      if (!act) continue;
-      if (((A.dbg & 512u) && wv < (uint32_t)(WAVES/2)) || ((A.dbg & 1024u) && wv >= (uint32_t)(WAVES/2))) continue;      // (timing experiments: half the waves sit the sweep out)
+      pair_sync();
       // roll-back copies: registers, and the age of node li
       const GTree<NT> U = T;
-      const double tsave = S.time[li];
+      double tsave = 0, lnl = 0, lp_new = 0;
       Prop pr{0, 0, 0, 0.0};
-      const bool ok = step < A.nsteps_gage
-        ? propose_gage<NT, BPP>(T, rng, S.time, (int)step, pl, wg.anc, wg.tau, SP.ft_gage, li, gbase, pr)
-        : propose_gspr<NT, BPP>(T, rng, S.time, (int)(step - A.nsteps_gage), pl, gl_i, wg.anc, wg.tau, wg.lograt, SP.ft_gspr, li, gbase, pr);
+      bool ok = false;
+      const bool sit_out = ((A.dbg & 512u) && wv < (uint32_t)(WAVES/2)) || ((A.dbg & 1024u) && wv >= (uint32_t)(WAVES/2));      // (timing experiments: half the waves sit the sweep out)
+      if (act && !sit_out)
+      {
+        tsave = S.time[li];
+        ok = step < A.nsteps_gage
+          ? propose_gage<NT, BPP>(T, rng, S.time, (int)step, pl, wg.anc, wg.tau, SP.ft_gage, li, gbase, pr)
+          : propose_gspr<NT, BPP>(T, rng, S.time, (int)(step - A.nsteps_gage), pl, gl_i, wg.anc, wg.tau, wg.lograt, SP.ft_gspr, li, gbase, pr);
+      }
       SMP2_TICK(0);
+      pair_sync();
       if (ok)
       {
         wsync();
-        double lp_new;
-        const double lnl = evaluate(pr, true, lp_new);
+        lnl = evaluate(pr, true, lp_new);
         SMP2_TICK(1);
+      }
+      pair_sync();
+      if (ok)
+      {
         w_nupd += (uint32_t)nops; w_nbr += (uint32_t)__popc(pr.brm);
         const double lnacc = (lp_new - logpr_cur) + (lnl - lnl_cur) + pr.hast;
         ++nprop_done;
@@ -1289,9 +1313,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         wsync();
         SMP2_TICK(2);
       }
-      else { T = U; S.time[li] = tsave; wsync(); }
+      else if (act && !sit_out) { T = U; S.time[li] = tsave; wsync(); }
     }
-    if (WAVES > 4) __builtin_amdgcn_s_setprio(0);
     if (wgprof) wg_sweep += clock64() - wg_t0;
     if (wvprof) wg.wsweep[wv] += clock64() - wv_t0;
     if (!A.do_allloci) continue;
@@ -1470,9 +1493,11 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         step_locus(first ? nth : 0);
         __syncthreads();                                                // B1: the terms are in
         __syncthreads();                                                // B3: the decision is out (and the species tree as it now is, and the next proposal)
-        if (wg.abort_) { aborted = true; break; }
+        const bool ab = wg.abort_ != 0u;
         accept = wg.dec.acc_step != 0u;
-        step_apply(first);
+        if (!ab) step_apply(first);
+        __syncthreads();                                                // B4: the next proposal is out
+        if (ab) { aborted = true; break; }
       }
     }
     else

@@ -177,8 +177,7 @@ static inline A00_HD void a00_theta_conditional_invgamma(double a, double b, lon
    comparisons: between the bounds the cubic falls to one minimum and rises through its only root r there (for m^2/v > 2.5:
    its local maximum then lies left of 0), so "the cubic at x has the sign it has at lo" is "x < r".  r comes from a few
    Newton steps started right of it (r = M + 6 - 16/M + ...; convex there: monotone convergence); a midpoint closer to r than
-   2^-44 r — a hundred times the rounding error of either r or the cubic — sends the whole search back to the plain loop
-   (two cases in a thousand).  Anything outside that picture (small m^2/v, other signs at the bounds, no convergence) takes the plain
+   2^-44 r — a hundred times the rounding error of either r or the cubic — sends the whole search back to the plain loop.  Anything outside that picture (small m^2/v, other signs at the bounds, no convergence) takes the plain
    loop.  The device samplers' form of a00_theta_conditional_invgamma (tests/test_bpp_kernel.py: bit-equal on 10^5 cases). */
 static inline A00_HD void a00_theta_conditional_invgamma_fast(double a, double b, long k, double T, double * a1, double * b1)
 {
@@ -211,23 +210,31 @@ static inline A00_HD void a00_theta_conditional_invgamma_fast(double a, double b
   }
   if (fast)
   {
-    /* 48 steps without a branch (bounds of up to 2^48 x 1e-6 apart; a step past the end changes nothing): the chain a
-       step waits for is add, halve, compare, select */
-    const double lo0 = lo, hi0 = hi;
-    int done = 0, amb = 0;
-    guard = r*5.684341886080802e-14;                            /* 2^-44 r: a hundred times either rounding error */
-    for (i = 0; i < 48; ++i)
+    /* the number of halvings until the bounds are closer than 1e-6 follows from their distance (a width differs from
+       w0 / 2^k by a few roundings of the midpoints: ~1e-11): n = the smallest k with w0 / 2^k < 1e-6.  Then n steps of
+       add, halve, compare, select — nothing else in the loop.  Checked afterwards: the widths fall on either side of 1e-6
+       with room to spare (1e-9), and no midpoint came closer to r than 2^-44 r (a hundred times either rounding error:
+       such a midpoint is one of the final bounds) — else (one case in a few hundred) the plain loop below. */
+    const double lo0 = lo, hi0 = hi, w0 = hi - lo;
+    int n = 0;
+    if (w0 >= 1e-6)
     {
-      int same;
-      x = (lo + hi)/2;
-      done |= fabs(lo - hi) < 1e-6;
-      amb |= !done && !(fabs(x - r) > guard);
-      same = x < r;
-      lo = !done && same ? x : lo;
-      hi = !done && !same ? x : hi;
+      n = ilogb(w0) + 20;                                       /* (ilogb(1e-6) = -20) */
+      if (n < 1) n = 1;
+      if (ldexp(w0, -(n - 1)) < 1e-6) --n; else if (!(ldexp(w0, -n) < 1e-6)) ++n;
     }
-    if (done && !amb) { x = (lo + hi)/2; *a1 = x; *b1 = m*(x + 1); return; }
-    lo = lo0; hi = hi0;                                          /* (a midpoint too close to call, or bounds too wide: the plain loop) */
+    for (i = 0; i < n; ++i)
+    {
+      x = (lo + hi)/2;
+      if (x < r) lo = x; else hi = x;
+    }
+    guard = r*5.684341886080802e-14;                            /* 2^-44 r */
+    {
+      const double w = hi - lo;
+      if (n <= 90 && w < 1e-6 - 1e-9 && (n == 0 || 2*w > 1e-6 + 1e-9) && r - lo > guard && hi - r > guard)
+      { x = (lo + hi)/2; *a1 = x; *b1 = m*(x + 1); return; }
+    }
+    lo = lo0; hi = hi0;
   }
   for (i = 0; i < 100; ++i)
   {
