@@ -377,6 +377,148 @@ def run_config1(eng, iters=12):
     return out
 
 
+# ------------------------------------------------------- the unmodified program on the other configs' data (same box) ---
+def _phylip_from_data(data, names):
+    """bpp_amd.synth loci (patterns + weights) as the reference's sequential PHYLIP + Imap: every pattern written `weight` times"""
+    out = []
+    for d in data:
+        cols = [j for j, w in enumerate(d["weights"]) for _ in range(int(w))]
+        out.append(f"\n{len(names)} {len(cols)}\n\n")
+        for t, nm in enumerate(names):
+            out.append(f"{nm}^{nm.lower()}1        " + "".join(d["seqs"][t][j] for j in cols) + "\n")
+        out.append("\n")
+    return {"syn.txt": "".join(out), "syn.Imap.txt": "".join(f"{c.lower()}1\t{c}\n" for c in names)}
+
+
+def program_rate(files, ctl, n1, n2, threads_list, scale_to, nloci, budget_s=60.0):
+    """whole MCMC iterations/s of oracle/_ref/bpp (the unmodified reference program, AVX2) on the given input files and
+    control file (fields {nsample}, {threads}): differential wall time of an n1- and an n2-iteration run per thread
+    count, scaled to `scale_to` loci.  Returns the best thread count's rate and what was tried."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib as O
+    if not os.path.exists(O.REF_BIN):
+        return None
+    tried = {}
+    t_start = time.time()
+    with tempfile.TemporaryDirectory() as d:
+        for name, text in files.items():
+            open(os.path.join(d, name), "w").write(text)
+
+        def wall(ns, th):
+            open(os.path.join(d, "a00.ctl"), "w").write(ctl.format(nsample=ns, threads=(f"threads = {th} 1 1" if th > 1 else "")))
+            t0 = time.perf_counter()
+            subprocess.run([O.REF_BIN, "--cfile", "a00.ctl"], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+            return time.perf_counter() - t0
+        for th in threads_list:
+            if tried and time.time() - t_start > budget_s:
+                break
+            t1, t2 = wall(n1, th), wall(n2, th)
+            tried[th] = round((n2 - n1) / max(t2 - t1, 1e-9) * nloci / scale_to, 3)
+    best = max(tried, key=lambda k: tried[k])
+    return dict(value=tried[best], unit=f"iterations/s (whole A00 MCMC iterations of the unmodified program, scaled from {nloci} to {scale_to} loci)",
+                cores=best, kind="reference", threads_tried={str(k): v for k, v in tried.items()}, host_cpu_quota=cpu_quota(),
+                sample=f"oracle/_ref/bpp (AVX2) on {nloci} loci of this config's data, {n2} vs {n1} iterations differential, burnin 0, finetune = 1")
+
+
+def other_config_cpu_baseline(key, data):
+    """`other_configs.<key>.cpu_baseline`: the unmodified program at its best thread count on (a share of) the config's own data"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bpphip as B
+    q = int(cpu_quota() or os.cpu_count() or 1)
+    threads = sorted({max(2, q), max(2, 2 * q)})
+    if key == "c3":
+        n = min(len(data), 1000)
+        ctl = B.A00_CTL.format(species=B.SPECIES8, phase="0 0 0 0 0 0 0 0", nloci=n, model="gtr", alpha="alphaprior = 1 1 4", taub=300,
+                               burnin=0, sampfreq=1, nsample="{nsample}", extra="{threads}")
+        return program_rate(_phylip_from_data(data[:n], "ABCDEFGH"), ctl, 10, 60, threads, len(data), n)
+    if key == "c4":
+        n = min(len(data), 128)
+        sp6 = "6  A B C D E F\n                  1 1 1 1 1 1\n                  ((((A, B), C), (D, E)), F);"
+        ctl = B.A00_CTL.format(species=sp6, phase="0 0 0 0 0 0", nloci=n, model="lg", alpha="alphaprior = 1 1 4", taub=40,
+                               burnin=0, sampfreq=1, nsample="{nsample}", extra="{threads}").replace("thetaprior = gamma 2 1000", "thetaprior = gamma 2 100")
+        return program_rate(_phylip_from_data(data[:n], "ABCDEF"), ctl, 4, 24, threads, len(data), n)
+    if key == "c5":
+        g = os.path.join(ROOT, "tests", "golden", "anopheles")
+        files = {"loci_realign.txt": open(os.path.join(g, "loci_realign.txt")).read(), "Imap.txt": open(os.path.join(g, "Imap.txt")).read()}
+        ctl = B.ANOPHELES_CTL.format(tree=B.ANOPHELES_MSCI_TREE, phiprior="phiprior = 1 1", burnin=0, sampfreq=1, nsample="{nsample}", extra="{threads}")
+        return program_rate(files, ctl, 100, 600, sorted({1, min(4, q)}), 100, 100)
+    if key == "c1":
+        g = os.path.join(ROOT, "tests", "golden", "frogs")
+        files = {"frogs.txt": open(os.path.join(g, "frogs.txt")).read(), "frogs.Imap.txt": open(os.path.join(g, "frogs.Imap.txt")).read()}
+        ctl = B.FROGS_CTL.format(burnin=0, sampfreq=1, nsample="{nsample}", extra="{threads}")
+        return program_rate(files, ctl, 200, 1700, [1], 5, 5)
+    return None
+
+
+def run_config5(eng, iters=40):
+    """BASELINE configs[4] (examples/anopheles: 100 loci x 12 sequences, 6 species with two sequences each, JC69,
+    cleandata = 1; priors and step lengths of anopheles-bpp-msci.ctl) as real MCMC on the device: the generic sampler
+    (12 tips), the MSC on the control file's species tree (R,((C,G),((A,Q),L))) — the introgression model's own species-tree
+    proposals are host control of the reference and out of scope"""
+    import bpp_amd
+    from bpp_amd import seqio, synth
+    g = os.path.join(ROOT, "tests", "golden", "anopheles")
+    species = ["G", "C", "R", "L", "A", "Q"]
+    recs = seqio.load_dataset(os.path.join(g, "loci_realign.txt"), os.path.join(g, "Imap.txt"), species, None, model="jc69", cleandata=True)
+    parent = [6, 6, 10, 8, 7, 7, 9, 8, 9, 10, -1]
+    tau0 = [0.0] * 6 + [0.004, 0.004, 0.008, 0.012, 0.016]
+    thetas = [0.02] * 11
+    rng = np.random.default_rng(77)
+    data = []
+    for r in recs:
+        left, right, times, root = synth.msc_start_tree(r["species"], parent, tau0, thetas, rng)
+        data.append(dict(seqs=r["seqs"], weights=r["weights"], left=left, right=right, times=times, root=root, states=4, rate_cats=1, model="jc69", rates=np.ones(1)))
+    smp = bpp_amd.Sampler(eng, [seqio.make_locus(eng, r) for r in recs], data, seed=1)
+    smp.set_species_tree(parent, tau0, thetas)
+    for i, r in enumerate(recs):
+        smp.set_tip_species(i, r["species"])
+    smp.set_tau_prior(2.0, 10.0)
+    smp.set_theta_prior(2.0, 100.0, 0.002)
+    smp.set_finetune(0.003, 0.003, 0.00002, 0.9)
+    smp.initialize()
+    lnl0 = smp.summary()["total_lnl"]
+    smp.iterate(3)
+    eng.synchronize()
+    l0 = smp.summary()["launches"]
+    t0 = time.perf_counter()
+    smp.iterate(iters)
+    eng.synchronize()
+    dt = time.perf_counter() - t0
+    sm = smp.summary()
+    out = dict(iterations_per_s=round(iters / dt, 2), ms_per_iteration=round(1e3 * dt / iters, 3), iterations=iters, loci=len(recs),
+               tips=12, patterns_mean=round(float(np.mean([len(r["seqs"][0]) for r in recs])), 1), implementation=smp.kind(),
+               launches_per_iteration=round((sm["launches"] - l0 - 1) / iters, 1), start_lnl=round(lnl0, 6),
+               acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
+               note="100 loci x 12 tips: 33 per-locus proposals + 11 thetas + 5 taus + mixing per iteration, every step a handful of "
+                    "launches over 100 lanes of work — a plumbing / parity configuration (SURVEY 8d), not a throughput one")
+    smp.close()
+    return out
+
+
+def scale_projection(key, cfg, data, args, shares=(2, 4, 8)):
+    """What ONE rank of an N-GPU strong-scaling run of this config works on, measured on this one GPU: the loci the reference's
+    zig-zag deal (threads.c:265-353, bpp_amd/shard.py) gives rank 0 of N, through the device-resident sampler.  iterations/s of
+    that share = the upper bound of the N-GPU rate of the WHOLE data set (before the per-step exchange over xGMI)."""
+    import bpp_amd
+    from bpp_amd import shard
+    out = {}
+    for n in shares:
+        try:
+            mine = shard.partition([len(d["seqs"]) * len(d["weights"]) for d in data], n)[0]
+            sub = [data[i] for i in mine]
+            e = bpp_amd.Engine(0, None)
+            a2 = argparse.Namespace(**vars(args))
+            a2.loci = len(sub)
+            r = run_sampler(e, cfg, sub, make_loci(e, sub), a2, None, 0, 6 if cfg["model"] != "jc69" else 40, 1 if cfg["model"] != "jc69" else 5)
+            out[str(n)] = dict(loci_on_rank0=len(sub), iterations_per_s=r["iterations_per_s"], ms_per_iteration=r["ms_per_iteration"], implementation_kind=r.get("kind"))
+            e.close()
+        except Exception as ex:       # noqa: BLE001
+            out[str(n)] = dict(error=str(ex)[:200])
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ the workload ---
 def make_loci(eng, data):
     import bpp_amd
@@ -474,7 +616,7 @@ def traffic_from_profiles(config, kernel):
         key = [k for k in pm if want.rstrip(">") in k.replace(" ", "") and "FETCH_SIZE" in pm[k]]
         key = (key or [k for k in pm if want.split("<")[0] in k and "FETCH_SIZE" in pm[k]])[0]
         return (round((2 * pm[key]["FETCH_SIZE"]["mean"] + pm[key]["WRITE_SIZE"]["mean"]) * 1024),
-                os.path.relpath(cands[-1], ROOT) + f" ({key.split('(')[0]}; separate --pmc passes; FETCH_SIZE doubled per the gfx950 note)")
+                "traffic_from_committed_profile: " + os.path.relpath(cands[-1], ROOT) + f" ({key.split('(')[0]}; separate --pmc passes; FETCH_SIZE doubled per the gfx950 note)")
     except Exception:
         return None, None
 
@@ -483,6 +625,7 @@ def add_frac_pmc(r):
     """`frac_pmc`: HBM bytes actually MOVED per launch (the PMC passes under profiles/) / the launch's duration / the HBM peak —
     next to `frac`, which prices the algorithmic bytes"""
     if isinstance(r, dict) and r.get("traffic") and r.get("avg_kernel_us"):
+        r["traffic_from_committed_profile"] = True      # (a builder-run rocprofv3 PMC number inside a driver-run line: profiles/)
         r["moved_GBps"] = round(r["traffic"] / (r["avg_kernel_us"] * 1e-6) / 1e9, 2)
         r["frac_pmc"] = round(r["moved_GBps"] / r["peak"], 5)
     return r
@@ -942,7 +1085,7 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves
                              "set lives in LDS for the whole launch: latency-bound by the leader lanes' serial proposal code, not by HBM")
     out = dict(iterations_per_s=round(niter / dt, 3), iterations_per_s_10k_loci=round(niter / dt * total_loci / 10000.0, 3),
                ms_per_iteration=round(1e3 * dt / niter, 5), ms_per_step=round(1e3 * dt / steps, 4), iterations_per_step=ips,
-               timed_region_s=round(dt, 4), steps=steps, warmup=warmup, n_gpus=world, loci_total=total_loci,
+               timed_region_s=round(dt, 4), steps=steps, warmup=warmup, n_gpus=world, loci_total=total_loci, kind=kind,
                proposals_per_locus_iteration=3 * cfg["taxa"] - 3 + (9 if gtr else 0),
                launches_per_iteration=round(max(l1 - l0 - (0 if kind == "persistent" else 1), 0) / niter, 4),      # (-1: the settle launch of the first summary)
                acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
@@ -983,7 +1126,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--loci", type=int, default=None, help="loci of the data set (default: the config's)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="N > 1: weak = every rank owns its own data set of the config's size; strong = ONE data set of the "
                          "config's size, loci dealt to the ranks by the reference's zig-zag (threads.c:265-353)")
     ap.add_argument("--tape-iters", type=int, default=4, help="distinct A00 iterations in the resident tape")
@@ -996,6 +1139,7 @@ def main():
                     help="skip the ESS/s section (one more 1 900-iteration run of the reference program with its burn-in, BPP's move kernel on the device)")
     ap.add_argument("--no-bpp-program", action="store_true",
                     help="skip timing the unmodified reference program (thread sweep) on the host cores")
+    ap.add_argument("--no-scale-projection", action="store_true", help="skip the one-GPU measurements of the per-rank shares of N = 2, 4, 8")
     ap.add_argument("--no-uniform-kernel", action="store_true", help="c2: skip the companion run with the library's uniform-window moves")
     ap.add_argument("--no-timing-events", action="store_true")
     ap.add_argument("--p2p-sums", action="store_true",
@@ -1003,6 +1147,10 @@ def main():
                          "against RCCL at start-up) instead of RCCL (torch.distributed), the default")
     ap.add_argument("--c4-divergence", type=float, default=None,
                     help="config 4: divergence factor of the synthetic amino-acid set (default 3: ~195 patterns per locus; 1: SURVEY 8d's literal theta 0.02 / tau_root 0.05, 105 patterns)")
+    ap.add_argument("--p2p", action="store_true",
+                    help="N > 1: exchange the all-loci sums INSIDE the persistent kernel through peer-mapped mailboxes over xGMI (self-tested "
+                         "against RCCL at start-up; the program's moves then run at N > 1 too).  Default: a native RCCL all-reduce per "
+                         "all-loci step (north_star's wording) — opt-in until the mailboxes have run on two physical GPUs")
     ap.add_argument("--no-p2p", action="store_true",
                     help="N > 1: no peer-mapped mailboxes at all — the sampler then runs its all-loci steps one launch each with a "
                          "native RCCL all-reduce in between (the persistent kernel only for the per-locus sweeps)")
@@ -1025,6 +1173,12 @@ def main():
         CONFIGS["c4"]["divergence"] = args.c4_divergence
     cfg = CONFIGS[args.config]
     nloci_cfg = args.loci or cfg["loci"]
+    # N > 1: `value` is the weak-scaling figure for c2 (BASELINE configs[1] is "on 1 MI355X": every rank gets that workload)
+    # and the strong-scaling one for c3 / c4 (configs[2]: "10 000 loci ... sharded across 8 MI355X"); the OTHER mode's sampler
+    # rate is measured in the same run and reported as value_strong / value_weak — never one silently for the other
+    scaling_given = args.scaling is not None
+    if args.scaling is None:
+        args.scaling = "weak" if args.config == "c2" else "strong"
 
     import bpp_amd
     from bpp_amd import synth, shard
@@ -1036,23 +1190,21 @@ def main():
     eng = bpp_amd.Engine(local_rank, D.stream if D else None)
 
     # ---- synthetic input, resident in HBM
+    def make_data(mode):
+        if mode == "strong" and world > 1:
+            # ONE data set; the reference's zig-zag deal by work = tips x patterns (threads.c:265-353)
+            full = synth.make_dataset(nloci_cfg, cfg["sites"], cfg["taxa"], cfg["model"], cfg["rate_cats"], seed=12345, divergence=cfg.get("divergence", 1.0))
+            mine = shard.partition([len(d["seqs"]) * len(d["weights"]) for d in full], world)[rank]
+            return [full[i] for i in mine], int(1 << 20) * rank          # distinct per-locus random streams on every rank
+        return (synth.make_dataset(nloci_cfg, cfg["sites"], cfg["taxa"], cfg["model"], cfg["rate_cats"], seed=12345 + 1000 * rank, divergence=cfg.get("divergence", 1.0)),
+                rank * nloci_cfg)
     t0 = time.time()
-    first_locus = 0
-    if args.scaling == "strong" and world > 1:
-        # ONE data set; the reference's zig-zag deal by work = tips x patterns (threads.c:265-353)
-        full = synth.make_dataset(nloci_cfg, cfg["sites"], cfg["taxa"], cfg["model"], cfg["rate_cats"], seed=12345, divergence=cfg.get("divergence", 1.0))
-        mine = shard.partition([len(d["seqs"]) * len(d["weights"]) for d in full], world)[rank]
-        data = [full[i] for i in mine]
-        first_locus = int(1 << 20) * rank          # distinct per-locus random streams on every rank
-        del full
-    else:
-        data = synth.make_dataset(nloci_cfg, cfg["sites"], cfg["taxa"], cfg["model"], cfg["rate_cats"], seed=12345 + 1000 * rank, divergence=cfg.get("divergence", 1.0))
-        first_locus = rank * nloci_cfg
+    data, first_locus = make_data(args.scaling)
     nloci = len(data)
     npat = sum(len(d["weights"]) for d in data)
     log(f"dataset: {nloci} loci on rank 0, {npat} patterns ({npat / nloci:.2f}/locus) in {time.time() - t0:.1f}s ({args.scaling})")
     loci = make_loci(eng, data)
-    if D is not None and not args.no_p2p:
+    if D is not None and args.p2p and not args.no_p2p:
         # the mailboxes of the one-shot exchange over xGMI peer mappings (self-tested against RCCL on every rank): the
         # device-resident sampler exchanges its sums through them INSIDE its persistent kernel; the tape only with --p2p-sums
         D.setup_p2p(eng, 256)
@@ -1070,6 +1222,19 @@ def main():
             # rounds 1-3's headline iteration (half the program's effective samples per iteration), for comparison
             u = run_sampler(eng, cfg, data, make_loci(eng, data), args, None, first_locus, max(args.steps // 4, 5), args.warmup, moves="uniform")
             sampler_sec["device_uniform_kernel"] = {k: u[k] for k in ("iterations_per_s", "ms_per_iteration", "acceptance", "moves", "roofline") if k in u}
+
+    other_mode = None
+    if D is not None and world > 1 and sampler_sec is not None and "error" not in sampler_sec and not scaling_given:
+        om = "strong" if args.scaling == "weak" else "weak"
+        try:
+            d_o, fl_o = make_data(om)
+            e_o = bpp_amd.Engine(local_rank, D.stream)
+            s_o = run_sampler(e_o, cfg, d_o, make_loci(e_o, d_o), args, D, fl_o, max(args.steps // 2, 5), args.warmup)
+            e_o.close()
+            other_mode = dict(scaling=om, iterations_per_s=s_o.get("iterations_per_s"), iterations_per_s_10k_loci=s_o.get("iterations_per_s_10k_loci"),
+                              loci_total=s_o.get("loci_total"), ms_per_iteration=s_o.get("ms_per_iteration"), kind=s_o.get("kind"), error=s_o.get("error"))
+        except Exception as ex:       # noqa: BLE001
+            other_mode = dict(scaling=om, error=str(ex)[:300])
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and tape_steps is not None:
@@ -1137,9 +1302,16 @@ def main():
                 sec, _ = run_tape(e2, oc, key, d2, l2, a2, None, k_steps, k_warm)
                 sec["unit"] = f"iterations/s (one iteration = the A00 proposal schedule over this config's {oc['loci']} loci)"
                 sec["device_resident_sampler"] = run_sampler(e2, oc, d2, l2, a2, None, 0, k_steps, k_warm)
+                e2.close()
+                if not args.no_cpu_baseline:
+                    sec["cpu_baseline"] = other_config_cpu_baseline(key, d2)
+                    if sec["cpu_baseline"]:
+                        sec["ratio"] = dict(sampler_over_cpu_baseline=round(sec["device_resident_sampler"]["iterations_per_s"] / sec["cpu_baseline"]["value"], 1),
+                                            tape_over_cpu_baseline=round(sec["iterations_per_s"] / sec["cpu_baseline"]["value"], 1))
+                if not args.no_scale_projection:
+                    sec["scale_projection"] = scale_projection(key, oc, d2, a2)
                 sec["seconds"] = round(time.time() - t0, 1)
                 others[key] = sec
-                e2.close()
             except Exception as ex:       # noqa: BLE001
                 others[key] = dict(error=str(ex)[:300])
 
@@ -1148,10 +1320,26 @@ def main():
             t0 = time.time()
             e1 = bpp_amd.Engine(local_rank, None)
             others["c1"] = dict(device_resident_sampler=run_config1(e1), seconds=None)
-            others["c1"]["seconds"] = round(time.time() - t0, 1)
             e1.close()
+            if not args.no_cpu_baseline:
+                others["c1"]["cpu_baseline"] = other_config_cpu_baseline("c1", None)
+                if others["c1"]["cpu_baseline"]:
+                    others["c1"]["ratio"] = dict(sampler_over_cpu_baseline=round(others["c1"]["device_resident_sampler"]["iterations_per_s"] / others["c1"]["cpu_baseline"]["value"], 3))
+            others["c1"]["seconds"] = round(time.time() - t0, 1)
         except Exception as ex:       # noqa: BLE001
             others["c1"] = dict(error=str(ex)[:300])
+        try:
+            t0 = time.time()
+            e5 = bpp_amd.Engine(local_rank, None)
+            others["c5"] = dict(device_resident_sampler=run_config5(e5), seconds=None)
+            e5.close()
+            if not args.no_cpu_baseline:
+                others["c5"]["cpu_baseline"] = other_config_cpu_baseline("c5", None)
+                if others["c5"]["cpu_baseline"]:
+                    others["c5"]["ratio"] = dict(sampler_over_cpu_baseline=round(others["c5"]["device_resident_sampler"]["iterations_per_s"] / others["c5"]["cpu_baseline"]["value"], 3))
+            others["c5"]["seconds"] = round(time.time() - t0, 1)
+        except Exception as ex:       # noqa: BLE001
+            others["c5"] = dict(error=str(ex)[:300])
 
     # ---- MCMC control on the host in C (last: libgomp pins the calling thread under OMP_PROC_BIND, and threads or
     # processes started afterwards would inherit that one-CPU mask — the CPU baselines above must not)
@@ -1165,6 +1353,14 @@ def main():
             host_sec = dict(error=str(ex)[:300])
         if mask is not None:
             os.sched_setaffinity(0, mask)
+
+    # ---- what one rank of an N-GPU strong-scaling run of this config would work on, measured here (N = 1 only)
+    projection = None
+    if rank == 0 and world == 1 and D is None and args.config in ("c2", "c3", "c4") and not args.no_scale_projection and not args.no_sampler:
+        try:
+            projection = scale_projection(args.config, cfg, data, args)
+        except Exception as ex:       # noqa: BLE001
+            projection = dict(error=str(ex)[:300])
 
     if rank == 0:
         headline_sampler = sampler_sec is not None and "error" not in sampler_sec
@@ -1224,6 +1420,10 @@ def main():
             "ms_per_step": ms_per_step,
             "iterations_per_step": sampler_sec["iterations_per_step"] if headline_sampler else 1,
             "ms_per_iteration": sampler_sec["ms_per_iteration"] if headline_sampler else ms_per_step, "higher_is_better": True, "scaling": args.scaling,
+            "value_weak": (None if D is None else (value if args.scaling == "weak" else
+                                                   (other_mode or {}).get("iterations_per_s_10k_loci" if args.config in ("c2", "c3") else "iterations_per_s"))),
+            "value_strong": (None if D is None else (value if args.scaling == "strong" else (other_mode or {}).get("iterations_per_s"))),
+            "scaling_other_mode": other_mode,
             "vs_baseline": vs_baseline,
             "vs_baseline_ref": ("BASELINE.md section 2: 25.9 iterations/s = the unmodified program, threads = 8, on the survey "
                                 "container's 8-vCPU Xeon 2.1 GHz (other hardware); the same-box figure is cpu_baseline") if vs_baseline else None,
@@ -1238,6 +1438,11 @@ def main():
             "cpu_tape_replay": cpu if cpu is not cpu_like else None,
             "reference_program_on_host": bpp_prog,
             "statistical_efficiency": efficiency,
+            "ess_per_s": (None if not efficiency or "error" in efficiency else dict(
+                device=dict(tau_root=efficiency["device"]["tau_root"]["ess_per_s"], theta_root=efficiency["device"]["theta_root"]["ess_per_s"]),
+                reference_program=dict(tau_root=efficiency["reference_program"]["tau_root"]["ess_per_s"], theta_root=efficiency["reference_program"]["theta_root"]["ess_per_s"]),
+                ratio=efficiency["ratio_ess_per_s"])),
+            "scale_projection": projection,
             "device_resident_sampler": sampler_sec,
             "host_control_in_c": host_sec,
             "likelihood_only": tape_sec,

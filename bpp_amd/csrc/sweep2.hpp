@@ -129,7 +129,6 @@ template <int NT> struct WgLDS : WgBase
   unsigned long long xprev[2][XN];               // wave 0: every word of either accumulator set as its previous use left it
   long long prof[24];                            // BPA_SMP_DBG & 16: cycle counters of thread 0 of workgroup 0
   long long wsweep[16];                          // BPA_SMP_DBG & 16: sweep cycles of every wave of workgroup 0
-  uint32_t prog[16];                             // how far every wave has come in its sweeps (pair_sync)
 };
 
 template <int G> __device__ __forceinline__ uint32_t gballot(bool p, uint32_t gbase)
@@ -474,7 +473,7 @@ __device__ __forceinline__ double redraw_ratio(const WgBase & wg, uint32_t lane,
 // one proposes tslide, lane p); ln of the acceptance ratios (a00_theta_lnacc + a00_theta_gibbs_hastings); the acceptance
 // numbers in population order, drawn only when needed.  Leaves dec.accm / tn / l2t / lnacc; apply_now: and the accepted
 // thetas in tau[] (a TAU decision follows at once).  z: the global stream.
-__device__ __noinline__ __attribute__((cold)) uint32_t prog_theta_decide(uint32_t z, uint32_t theta_mask, uint32_t slidem, double tslide, int apply_now)
+__device__ __forceinline__ uint32_t prog_theta_decide(uint32_t z, uint32_t theta_mask, uint32_t slidem, double tslide, int apply_now)
 {
   WgBase & wg = wg_base();
   const uint32_t lane = threadIdx.x & 63u, pl16 = lane & 15u, role = lane >> 4;
@@ -547,7 +546,7 @@ __device__ __noinline__ __attribute__((cold)) uint32_t prog_theta_decide(uint32_
 // (xtot[base], + the coarse companion) and the new T2h sums of q and its two children (xtot[base + 2 .. 4]); each of their
 // thetas is re-drawn from the fit to (k, new sum) and enters the ratio against the fit to the current sums (pf).
 // lnacc0 = the window's prior term.  Leaves dec.acc_step / rd_mask / lnacc_step and rd[] (installed by the caller on acceptance).
-__device__ __noinline__ __attribute__((cold)) uint32_t prog_tau_decide(uint32_t z, uint32_t theta_mask, int q, int base, double lnacc0)
+__device__ __forceinline__ uint32_t prog_tau_decide(uint32_t z, uint32_t theta_mask, int q, int base, double lnacc0)
 {
   WgBase & wg = wg_base();
   const uint32_t lane = threadIdx.x & 63u, pl16 = lane & 15u, role = lane >> 4;
@@ -588,7 +587,7 @@ __device__ __noinline__ __attribute__((cold)) uint32_t prog_tau_decide(uint32_t 
 // MIX: every theta from the fit to its conditional given the SCALED trees (k, c T) (mix_step of a00_driver.c;
 // prop_mixing.c: Cjstar / c) — nothing of it depends on the loci's sums, so the caller runs it between its workgroup's
 // arrival at the exchange and the totals'.  Leaves rd[], dec.rd_mask and dec.lnacc_theta.
-__device__ __noinline__ __attribute__((cold)) uint32_t prog_mix_redraw(uint32_t z, uint32_t theta_mask, double mix_c)
+__device__ __forceinline__ uint32_t prog_mix_redraw(uint32_t z, uint32_t theta_mask, double mix_c)
 {
   WgBase & wg = wg_base();
   const uint32_t lane = threadIdx.x & 63u, pl16 = lane & 15u, role = lane >> 4;
@@ -643,7 +642,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     uint32_t * dst = reinterpret_cast<uint32_t *>(&wg.sp);
     for (uint32_t i = tid; i < sizeof(Species)/4; i += C::BS) dst[i] = src[i];
     if (tid < 24u) wg.prof[tid] = 0;
-    if (tid < 16u) { wg.wsweep[tid] = 0; wg.prog[tid] = 0; }
+    if (tid < 16u) wg.wsweep[tid] = 0;
   }
   __syncthreads();
   const Species & SP = wg.sp;
@@ -1255,21 +1254,11 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   long long wg_sweep = 0;
   bool aborted = false;
 
-  // Two waves share a SIMD (wave w and w + WAVES/2) and its arbiter serves the older one first: the older runs as if alone,
-  // the younger in the gaps — it finishes a sweep a third later, and every exchange waits for it (priorities, s_setprio,
-  // change nothing).  So the older of a pair waits (asleep: the SIMD is the younger's meanwhile) at three points of every
-  // proposal until its partner has come as far: both then finish together, 15 % sooner than the younger alone did.
-  const bool pair_older = WAVES > 4 && wv < (uint32_t)(WAVES/2) && !(PROG && wv == 0) && gw + (uint32_t)(WAVES/2) < A.nwaves && nt > 0;
-  const bool pair_younger = WAVES > 4 && wv >= (uint32_t)(WAVES/2) && !(PROG && wv == (uint32_t)(WAVES/2)) && nt > 0;
-  uint32_t pcnt = 0;
-  auto pair_sync = [&]()
-  {
-    if (!(pair_older || pair_younger) || (A.dbg & 4096u)) return;
-    ++pcnt;
-    if (pair_younger) { if (lane == 0) __hip_atomic_store(&wg.prog[wv], pcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
-    while ((int32_t)(pcnt - __hip_atomic_load(&wg.prog[wv + (uint32_t)(WAVES/2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) > 0)
-      __builtin_amdgcn_s_sleep(2);
-  };
+  // (Two waves share a SIMD — wave w and w + WAVES/2 — and the pair is bound by instruction issue: a sweep asks for ~0.68 of a
+  // SIMD's issue slots, the arbiter serves the older wave first, so the older runs as if alone and the younger finishes a
+  // third later: 325 M vs 441 M cycles per 3 000 sweeps.  Priorities (s_setprio) change nothing, and making the older wait
+  // for the younger at three points of every proposal only moves both to 441 M: the SUM of their instructions is what the
+  // SIMD takes.  10 000 four-taxon loci need five waves of loci per CU, i.e. a pair in every workgroup.)
   if constexpr (PROG) __syncthreads();             // B0: the control wave's first proposal is out
   for (uint32_t it = 0; it < A.niter && !aborted; ++it)
   {
@@ -1280,14 +1269,12 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     const long long wv_t0 = wvprof ? clock64() : 0;
     for (uint32_t step = 0; step < nprop; ++step)
     {
-      pair_sync();
       // roll-back copies: registers, and the age of node li
       const GTree<NT> U = T;
       double tsave = 0, lnl = 0, lp_new = 0;
       Prop pr{0, 0, 0, 0.0};
       bool ok = false;
-      const bool sit_out = ((A.dbg & 512u) && wv < (uint32_t)(WAVES/2)) || ((A.dbg & 1024u) && wv >= (uint32_t)(WAVES/2));      // (timing experiments: half the waves sit the sweep out)
-      if (act && !sit_out)
+      if (act)
       {
         tsave = S.time[li];
         ok = step < A.nsteps_gage
@@ -1295,14 +1282,12 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           : propose_gspr<NT, BPP>(T, rng, S.time, (int)(step - A.nsteps_gage), pl, gl_i, wg.anc, wg.tau, wg.lograt, SP.ft_gspr, li, gbase, pr);
       }
       SMP2_TICK(0);
-      pair_sync();
       if (ok)
       {
         wsync();
         lnl = evaluate(pr, true, lp_new);
         SMP2_TICK(1);
       }
-      pair_sync();
       if (ok)
       {
         w_nupd += (uint32_t)nops; w_nbr += (uint32_t)__popc(pr.brm);
@@ -1313,7 +1298,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         wsync();
         SMP2_TICK(2);
       }
-      else if (act && !sit_out) { T = U; S.time[li] = tsave; wsync(); }
+      else if (act) { T = U; S.time[li] = tsave; wsync(); }
     }
     if (wgprof) wg_sweep += clock64() - wg_t0;
     if (wvprof) wg.wsweep[wv] += clock64() - wv_t0;
