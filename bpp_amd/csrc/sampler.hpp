@@ -1181,6 +1181,7 @@ struct bpa_sampler
   // ---- the persistent iteration kernel (sweep2.hpp): one GPU, loci that fit the sweep kernel, root = the last node
   bool v2_ok = false, env_v1 = false;
   int v2_nt = 0;                        // its instance: 4 or 8 tips
+  int v2_retries = 0;                   // persistent launches that timed out in a row (sampler_download runs their iterations again)
   bool v2_prog = false;                 // ... with the program's moves: wave 0 of every workgroup is the control wave (no loci)
   unsigned v2_nwaves = 0, v2_nwg = 0;
   size_t v2_lds = 0;
@@ -1503,10 +1504,10 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
   if (nwg > per_cu*(unsigned)prop.multiProcessorCount) return 1;
   s->v2_lds = base;
   s->v2_nt = NT; s->v2_nwaves = nwaves; s->v2_nwg = nwg; s->v2_prog = prog;
-  const int zero = 0;
+  const int zero2v[3] = {0, 0, 0};
   if (!upload(s->v2_wave_off, woff.data(), woff.size()) || !upload(s->v2_loc, loc.data(), loc.size()) ||
       !upload(s->v2_pat, pat.data(), pat.size()) || !s->v2_xbuf.reserve((size_t)2*smp2::XN) || !s->v2_grng.reserve(1) ||
-      !upload(s->v2_err, &zero, 1) || !s->v2_prof.reserve(40 + (size_t)nwg) || !s->v2_declog.reserve(4*2048) || !s->v2_sp.reserve(1))
+      !upload(s->v2_err, zero2v, 3) || !s->v2_prof.reserve(40 + (size_t)nwg) || !s->v2_declog.reserve(4*2048) || !s->v2_sp.reserve(1))
     return 0;
   HIPCHK(hipMemset(s->v2_prof.p, 0, (40 + (size_t)nwg)*sizeof(double)));
   {
@@ -2084,9 +2085,35 @@ static int sampler_download(bpa_sampler * s)
       for (unsigned i = 0; i < w.size(); ++i) { mn = std::min(mn, w[i]); if (w[i] > mx) { mx = w[i]; imx = i; } sm += w[i]; }
       fprintf(stderr, "[smp2] sweep cycles per workgroup, last launch: min %.0f mean %.0f max %.0f (workgroup %u of %u)\n", mn, sm/w.size(), mx, imx, s->v2_nwg);
     }
-    HIPCHK(hipMemcpy(&err, s->v2_err.p, sizeof err, hipMemcpyDeviceToHost));
+    int verr[3] = {0, 0, 0};
+    HIPCHK(hipMemcpy(verr, s->v2_err.p, sizeof verr, hipMemcpyDeviceToHost));
+    err = verr[0];
     if (!err && s->p2p) { HIPCHK(hipMemcpy(&err, s->p2p->d_err.p, sizeof err, hipMemcpyDeviceToHost)); if (err) return fail("bpa_sampler: the exchange between the GPUs timed out inside the persistent kernel (a rank is missing or slow; install an all-reduce callback instead)"); }
-    if (err) return fail("bpa_sampler: the persistent iteration kernel timed out waiting for a workgroup's sum (is the device shared? BPA_SMP_V1=1 selects one launch per step)");
+    if (err)
+    {
+      // A launch whose workgroups were not all resident together (the device is shared: another process, a partitioned GPU) gave
+      // up after 0.5 s and left every locus as it found it; verr[1] = the iterations such launches did not run.  They are run
+      // again: up to three times by the persistent kernel (the co-tenant may be gone), then — our own kernel's moves — by the
+      // one-launch-per-step path, which needs no co-residency; this sampler keeps to that path from then on.
+      const int zero2[2] = {0, 0};
+      HIPCHK(hipMemcpy(s->v2_err.p, zero2, sizeof zero2, hipMemcpyHostToDevice));
+      if (s->p2p || verr[1] <= 0) return fail("bpa_sampler: the persistent iteration kernel timed out waiting for a workgroup's sum (is the device shared? BPA_SMP_V1=1 selects one launch per step)");
+      fprintf(stderr, "[bpp_amd] the persistent iteration kernel timed out waiting for a workgroup (is the device shared?): %d iterations are run again\n", verr[1]);
+      if (++s->v2_retries > 3)
+      {
+        if (s->kernel_bpp) return fail("bpa_sampler: the persistent iteration kernel keeps timing out (a shared device: its workgroups must all be resident at once) and BPP's proposal kernel has no other path");
+        s->v2_ok = false;
+      }
+      if (!bpa_sampler_iterate(s, (unsigned)verr[1])) return 0;
+      return sampler_download(s);
+    }
+    s->v2_retries = 0;
+    if (verr[2])
+    {
+      const int z = 0;
+      HIPCHK(hipMemcpy(s->v2_err.p + 2, &z, sizeof z, hipMemcpyHostToDevice));
+      return fail("bpa_sampler: an all-loci step was ACCEPTED with a locus's term of 256 log units or more in its sum (the coarse companion accumulator: 2^-10 resolution); the chain is not to be trusted from there on");
+    }
   }
   s->host_current = true;
   return 1;

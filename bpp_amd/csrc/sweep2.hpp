@@ -72,7 +72,7 @@ struct Args
   int8_t * pop_nc; double * pop_t2h;     // sufficient statistics of the final state (sampler.hpp's THETA kernels read them)
   uint32_t ntasks, nwaves, nwg;
   unsigned long long * xbuf;             // [2][XN] accumulators of the all-loci steps' sums
-  int * err;
+  int * err;                             // [0] a wait timed out: the launch left everything as it found it; [1] += the iterations it did not run; [2] += all-loci steps accepted with a term summed through the coarse companion
   a00_rng_t * grng;                      // the global stream: read at entry, written back by workgroup 0
   uint32_t niter, nsteps_gage, nsteps_gspr, theta_mask, do_allloci, dbg;
   double bfbeta;
@@ -125,10 +125,11 @@ template <int NT> struct WgLDS : WgBase
   double lograt[(2*NT)*(2*NT)];
   unsigned long long accfx[32];                  // this workgroup's sums of an all-loci step, 2^-44 fixed point (LDS atomics)
   uint32_t anc[16];
-  uint32_t abort_, bad_, xbad_, pad3_;
+  uint32_t abort_, bad_, xbad_, coarse_;         // coarse_: a term of this workgroup went to the coarse companion sum; xcoarse_: of any
   unsigned long long xprev[2][XN];               // wave 0: every word of either accumulator set as its previous use left it
   long long prof[24];                            // BPA_SMP_DBG & 16: cycle counters of thread 0 of workgroup 0
   long long wsweep[16];                          // BPA_SMP_DBG & 16: sweep cycles of every wave of workgroup 0
+  uint32_t xcoarse_, pad4_;
 };
 
 template <int G> __device__ __forceinline__ uint32_t gballot(bool p, uint32_t gbase)
@@ -652,7 +653,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   for (uint32_t i = tid; i < (uint32_t)(3*MAXPOP); i += C::BS) wg.tau[i] = A.taus[i];
   for (uint32_t i = tid; i < (uint32_t)((2*NT)*(2*NT)); i += C::BS) wg.lograt[i] = A.lograt[(i/(2*NT))*MAXN + i % (2*NT)];
   if (tid < 16u) wg.anc[tid] = tid < (uint32_t)MAXPOP ? (uint32_t)SP.anc[tid] : 0u;
-  if (tid == 0) { wg.abort_ = 0; wg.bad_ = 0; wg.xbad_ = 0; }
+  if (tid == 0) { wg.abort_ = 0; wg.bad_ = 0; wg.xbad_ = 0; wg.coarse_ = 0; wg.xcoarse_ = 0; }
   if (tid < 32u) wg.accfx[tid] = 0ull;
   for (uint32_t i = tid; i < 2u*XN; i += C::BS) (&wg.xprev[0][0])[i] = 0ull;
   PopLane pl;
@@ -694,7 +695,10 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     if (fabs(x) < 256.0)
       (void)__hip_atomic_fetch_add(&wg.accfx[v], (unsigned long long)__double2ll_rn(x*FX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if (coarse && fabs(x) < 274877906944.0)
+    {
+      wg.coarse_ = 1u;
       (void)__hip_atomic_fetch_add(&wg.accfx[v + 1], (unsigned long long)__double2ll_rn(x*FXC), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     else wg.bad_ = 1u;                                                       // (also NaN): the step is rejected
   };
   uint32_t nx = 0;
@@ -720,7 +724,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     if (!solo) __syncthreads();
     XT(2);
     // arrival: + 1, and + 2^32 when a term of this workgroup was unusable
-    if (tid == 0) (void)__hip_atomic_fetch_add(acc + XV, 1ull + ((unsigned long long)wg.bad_ << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) (void)__hip_atomic_fetch_add(acc + XV, 1ull + ((unsigned long long)wg.bad_ << 32) + ((unsigned long long)wg.coarse_ << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // ... and the wait for everybody's: wave 0 polls, the totals go to wg.xtot[v0 ..]; last = the exchange's last block.  False: timed out
   auto xpoll = [&](int v0, int nv, bool last, bool hold) -> bool
@@ -744,7 +748,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         if ((rounds & 63u) == 0 && wall_clock64() - t_wait > 50000000ull) { ok = false; break; }     // 0.5 s at 100 MHz
         __builtin_amdgcn_s_sleep(1);
       }
-      bool anybad = ok && (__shfl(d, XV, 64) >> 32) != 0;
+      bool anybad = ok && ((__shfl(d, XV, 64) >> 32) & 0xffffull) != 0;
+      const bool anycoarse = ok && (__shfl(d, XV, 64) >> 48) != 0;     // (one rank's; several ranks: each reports its own)
       if (ok && A.world > 1)
       {
         // ---- several GPUs: this rank's sums (lanes 0..14) and its unusable-term flag (lane 15) go to slot `rank` of
@@ -794,9 +799,9 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         if (lane < (uint32_t)nv) wg.xtot[v0 + (int)lane] = anybad ? __longlong_as_double(0x7ff8000000000000ll) : (double)(long long)dd*(1.0/FX);
         wg.xprev[par][lane] = cur0; wg.xprev[par][64u + lane] = cur1;
         // (an unusable term stays flagged through every block of the exchange: its value may lie in a later one)
-        if (lane == 0) { if (anybad) wg.xbad_ = 1u; if (last) wg.bad_ = 0; }
+        if (lane == 0) { if (anybad) wg.xbad_ = 1u; wg.xcoarse_ = anycoarse ? 1u : 0u; if (last) { wg.bad_ = 0; wg.coarse_ = 0; } }
       }
-      else if (lane == 0) { wg.abort_ = 1; *A.err = 1; }
+      else if (lane == 0) { wg.abort_ = 1; *A.err = 1; if (b == 0) (void)atomicAdd(A.err + 1, (int)A.niter); }
       if (hold || solo) { wsync(); return ok; }                // (wave 0 goes on to the decision; the caller's barrier publishes everything)
     }
     else if (hold || solo) return true;
@@ -963,6 +968,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
             accept = g.accept(lnacc);
             if (lane == 0) wg.dec.acc_step = accept ? 1u : 0u;
           }
+          if (accept && wg.xcoarse_ && b == 0 && lane == 0) (void)atomicAdd(A.err + 2, 1);      // (a run worth the name never has one)
           ++cnt_prop; cnt_acc += accept ? 1u : 0u;
           if (declog && lane == 0 && ndec < 1000u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = -1.0; r[3] = accept ? 1 : 0; }
           ++ndec;
@@ -1438,6 +1444,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     {
       if constexpr (!PROG)
       {
+        if (accept && wg.xcoarse_ && b == 0 && tid == 0) (void)atomicAdd(A.err + 2, 1);      // (a run worth the name never has one)
         ++cnt_prop; cnt_acc += accept ? 1u : 0u;
         if (declog && tid == 0 && ndec < 1000u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
         ++ndec;

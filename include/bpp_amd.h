@@ -353,7 +353,15 @@ int  bpa_sampler_set_allreduce(bpa_sampler_t *, bpa_allreduce_fn fn, void * ctx,
 struct bpa_p2p;
 int  bpa_sampler_set_p2p(bpa_sampler_t *, struct bpa_p2p * p2p, unsigned first_locus);
 int  bpa_sampler_initialize(bpa_sampler_t *);                 /* all matrices, partials, lnL */
-int  bpa_sampler_iterate(bpa_sampler_t *, unsigned iterations); /* asynchronous on the engine stream */
+/* asynchronous on the engine stream.  The persistent iteration kernel's workgroups wait for each other's sums inside the
+   launch, so ALL of them must be resident at once: the library checks the workgroup count against the device's compute
+   units, not against other tenants — on a GPU shared with another process (or partitioned: CPX) some may never start.
+   Every wait is bounded (0.5 s); a launch that times out leaves all loci as it found them, and the next call that reads
+   the sampler's state runs its iterations again — by the same kernel (up to three times), then, with the library's own
+   proposal kernel, by the one-launch-per-step path (BPA_SAMPLER_SWEEP), which the sampler then keeps to; BPP's proposal
+   kernel has no such path: the call fails.  An all-loci step ACCEPTED with some locus's term summed through the coarse
+   companion accumulator (|term| >= 256 log units: resolution 2^-10) is reported as an error by that same call. */
+int  bpa_sampler_iterate(bpa_sampler_t *, unsigned iterations);
 /* current state of locus i (any output may be NULL); asking for locus 0 refreshes the host copy */
 int  bpa_sampler_get_tree(bpa_sampler_t *, unsigned i, int * left, int * right, int * parent,
                           double * times, int * clv, int * pmat, int * root, double * lnl);

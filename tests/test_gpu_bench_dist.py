@@ -31,17 +31,32 @@ def run_bench(extra):
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 @pytest.mark.parametrize("p2p", [False, True])
 def test_two_rank_bench_line(scaling, p2p):
-    d, err = run_bench(["--scaling", scaling] + (["--p2p-sums"] if p2p else []))
+    """p2p = False: the DEFAULT N > 1 path — one all-reduce per all-loci step through the library's callback (RCCL on the
+    driver's box, the framework's gloo collective here), the per-locus sweeps by the persistent kernel ("hybrid");
+    p2p = True (--p2p): the sums exchanged inside the persistent kernel through peer-mapped mailboxes, the program's moves"""
+    d, err = run_bench(["--scaling", scaling] + (["--p2p", "--p2p-sums"] if p2p else []))
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == scaling and d["value"] > 0
     assert d["allreduce_check"] == "ok"
     assert ("p2p" in d["allreduce"]["tape"]) == p2p, (d["allreduce"], err[-1500:])
-    # the sampler's sums travel inside its persistent kernel through the peer-mapped mailboxes whenever those passed their self-test
-    assert "persistent kernel" in d["allreduce"]["sampler"] and d["device_resident_sampler"]["implementation"].startswith("persistent"), d["allreduce"]
-    assert d["roofline"]["frac"] > 0 and "iter_kernel" in d["roofline"]["kernel"] and d["cpu_baseline"] is None
     smp, tp = d["device_resident_sampler"], d["likelihood_only"]
+    if p2p:
+        assert "persistent kernel" in d["allreduce"]["sampler"] and smp["implementation"].startswith("persistent"), d["allreduce"]
+        assert smp["moves"].startswith("the program's")
+    else:
+        assert "mailboxes" not in d["allreduce"]["sampler"] and smp["kind"] == "hybrid", d["allreduce"]
+    assert d["roofline"]["frac"] > 0 and "iter_kernel" in d["roofline"]["kernel"] and d["cpu_baseline"] is None
     # strong: the 1 500 loci are shared out (750 each); weak: 1 500 per rank
     total = 1500 if scaling == "strong" else 3000
     assert smp["loci_total"] == total and tp["loci_total"] == total
     assert smp["n_gpus"] == 2 and smp["iterations_per_s"] > 0 and 0.2 < smp["acceptance"] < 0.9
     assert d["value"] == (smp["iterations_per_s"] if scaling == "strong" else smp["iterations_per_s_10k_loci"])
+    assert d["value_" + scaling] == d["value"]
     assert tp["roofline"]["frac"] > 0 and tp["roofline"]["proposal_steps"] >= tp["roofline"]["launches"]
+
+
+def test_two_rank_bench_line_carries_both_scalings():
+    """without --scaling: `value` = the config's own mode (c2: weak) and the other mode's sampler rate is measured in the same run"""
+    d, err = run_bench(["--no-tape"])
+    assert d["scaling"] == "weak" and d["value"] == d["value_weak"] > 0
+    assert d["value_strong"] and d["value_strong"] > 0, (d.get("scaling_other_mode"), err[-1500:])
+    assert d["scaling_other_mode"]["scaling"] == "strong" and d["scaling_other_mode"]["loci_total"] == 1500
