@@ -1183,7 +1183,7 @@ struct bpa_sampler
   int v2_nt = 0;                        // its instance: 4 or 8 tips
   int v2_retries = 0;                   // persistent launches that timed out in a row (sampler_download runs their iterations again)
   bool v2_prog = false;                 // ... with the program's moves: wave 0 of every workgroup is the control wave (no loci)
-  unsigned v2_nwaves = 0, v2_nwg = 0;
+  unsigned v2_nwaves = 0, v2_nwg = 0, v2_lwaves = 0;
   size_t v2_lds = 0;
   DevBuf<uint32_t> v2_wave_off;
   DevBuf<smp2::Loc> v2_loc;
@@ -1491,10 +1491,14 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
   }
   woff.push_back(T);
   const bool prog = v2_wants_prog(s);
-  const unsigned LWAVES = WAVES - (prog ? 1u : 0u);              // waves with loci per workgroup
-  const unsigned nwaves = (unsigned)woff.size() - 1, nwg = (nwaves + LWAVES - 1)/LWAVES;
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, s->eng->device));
+  // waves with loci per workgroup: as few as put every wave's workgroup on a CU of its own (two waves on one SIMD share its
+  // issue slots: the pair takes a third longer than a wave alone) — 4 where the loci allow, i.e. up to 4 x 8 x CUs loci
+  const unsigned nwaves = (unsigned)woff.size() - 1;
+  const unsigned LMAX = WAVES - (prog ? 1u : 0u), ncu = (unsigned)std::max(prop.multiProcessorCount, 1);
+  const unsigned LWAVES = (LMAX > 4u && nwaves <= 4u*ncu) ? 4u : LMAX;       // (a pair in every workgroup anyway beyond that: then as few workgroups as possible)
+  const unsigned nwg = (nwaves + LWAVES - 1)/LWAVES;
   // every workgroup must be resident (they wait for each other's sums): one per CU — a workgroup takes most of a CU's LDS
   const size_t base = NT == 4 ? v2_lds_base<4>(prog) : v2_lds_base<8>(prog);
   const size_t lds_max = std::min<size_t>((size_t)prop.sharedMemPerBlock > 65536 ? (size_t)prop.sharedMemPerBlock : 160*1024, 160*1024) - 256;
@@ -1503,7 +1507,7 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
   const unsigned per_cu = (unsigned)std::min<size_t>(std::max<size_t>(lds_max/base, 1), 8/WAVES ? 8/WAVES : 1);
   if (nwg > per_cu*(unsigned)prop.multiProcessorCount) return 1;
   s->v2_lds = base;
-  s->v2_nt = NT; s->v2_nwaves = nwaves; s->v2_nwg = nwg; s->v2_prog = prog;
+  s->v2_nt = NT; s->v2_nwaves = nwaves; s->v2_nwg = nwg; s->v2_prog = prog; s->v2_lwaves = LWAVES;
   const int zero2v[3] = {0, 0, 0};
   if (!upload(s->v2_wave_off, woff.data(), woff.size()) || !upload(s->v2_loc, loc.data(), loc.size()) ||
       !upload(s->v2_pat, pat.data(), pat.size()) || !s->v2_xbuf.reserve((size_t)2*smp2::XN) || !s->v2_grng.reserve(1) ||
@@ -1897,7 +1901,7 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
     a.snap = s->snap.p; a.mix_flag = s->flag.p; a.epoch = s->mix_pending ? s->epoch : 0u; a.refresh_logpr = s->logpr_stale ? 1u : 0u;
     s->mix_pending = false; s->logpr_stale = false;
     a.counters = s->counters.p; a.lograt = s->lograt.p; a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p;
-    a.ntasks = s->nloci; a.nwaves = s->v2_nwaves; a.nwg = s->v2_nwg; a.xbuf = s->v2_xbuf.p;
+    a.ntasks = s->nloci; a.nwaves = s->v2_nwaves; a.nwg = s->v2_nwg; a.lwaves = s->v2_lwaves; a.xbuf = s->v2_xbuf.p;
     a.err = s->v2_err.p; a.grng = s->v2_grng.p; a.niter = chunk;
     a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2;
     if (s->env_gage >= 0) { a.nsteps_gage = (uint32_t)s->env_gage; a.nsteps_gspr = (uint32_t)s->env_gspr; }

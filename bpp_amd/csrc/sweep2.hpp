@@ -71,6 +71,7 @@ struct Args
   const double * lograt;
   int8_t * pop_nc; double * pop_t2h;     // sufficient statistics of the final state (sampler.hpp's THETA kernels read them)
   uint32_t ntasks, nwaves, nwg;
+  uint32_t lwaves;                       // waves with loci per workgroup (<= WAVES, PROG: <= WAVES - 1): fewer where the loci allow — one wave per SIMD has the SIMD to itself
   unsigned long long * xbuf;             // [2][XN] accumulators of the all-loci steps' sums
   int * err;                             // [0] a wait timed out: the launch left everything as it found it; [1] += the iterations it did not run; [2] += all-loci steps accepted with a term summed through the coarse companion
   a00_rng_t * grng;                      // the global stream: read at entry, written back by workgroup 0
@@ -637,7 +638,8 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   // (PROG: wave 0 is the control wave — no loci, no per-wave block)
   WaveLDS<NT> & wl = wl_all[PROG ? (wv ? wv - 1u : 0u) : wv];
   Slot<NT> & S = wl.slot[slot];
-  const uint32_t gw = PROG ? b*(uint32_t)(WAVES - 1) + (wv - 1u) : b*WAVES + wv;       // global wave of loci
+  const uint32_t lw = PROG ? wv - 1u : wv;                       // this wave's place among the workgroup's waves of loci (PROG, wave 0: none)
+  const uint32_t gw = lw < A.lwaves ? b*A.lwaves + lw : 0xffffffffu;       // global wave of loci
   {
     const uint32_t * src = reinterpret_cast<const uint32_t *>(A.sp);
     uint32_t * dst = reinterpret_cast<uint32_t *>(&wg.sp);
