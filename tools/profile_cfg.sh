@@ -10,7 +10,7 @@ W=/tmp/prof_${CFG}_$TAG
 rm -rf $W; mkdir -p $W $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-6}
-BENCH="python $R/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-other-configs --no-host-control --no-bpp-program --no-efficiency"
+BENCH="python $R/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-other-configs --no-host-control --no-bpp-program --no-efficiency --no-scale-projection"
 $BENCH > $W/bench_plain.json 2> $W/plain.log
 rocprofv3 --kernel-trace --stats -f csv -d $W/trace -o p -- $BENCH > $W/bench_trace.json 2> $W/trace.log
 rocprofv3 --pmc FETCH_SIZE -f csv -d $W/pmc_fetch -o p -- $BENCH > /dev/null 2> $W/pmc_fetch.log
