@@ -475,7 +475,9 @@ __device__ __forceinline__ double redraw_ratio(const WgBase & wg, uint32_t lane,
 // one proposes tslide, lane p); ln of the acceptance ratios (a00_theta_lnacc + a00_theta_gibbs_hastings); the acceptance
 // numbers in population order, drawn only when needed.  Leaves dec.accm / tn / l2t / lnacc; apply_now: and the accepted
 // thetas in tau[] (a TAU decision follows at once).  z: the global stream.
-__device__ __forceinline__ uint32_t prog_theta_decide(uint32_t z, uint32_t theta_mask, uint32_t slidem, double tslide, int apply_now)
+// tau_q >= 0: the fits the TAU decision that follows at once will want (populations tau_q and its children against the sums
+// xtot[tau_base + 2 .. 4]) are made in the same call, on lanes 16 + p, and left in rd[p].a / .b.
+__device__ __forceinline__ uint32_t prog_theta_decide(uint32_t z, uint32_t theta_mask, uint32_t slidem, double tslide, int apply_now, int tau_q = -1, int tau_base = 0)
 {
   WgBase & wg = wg_base();
   const uint32_t lane = threadIdx.x & 63u, pl16 = lane & 15u, role = lane >> 4;
@@ -491,7 +493,17 @@ __device__ __forceinline__ uint32_t prog_theta_decide(uint32_t z, uint32_t theta
   double tn = mine ? ((slidem >> pl16) & 1u ? tslide : qnan) : 0.0, lnacc_p = qnan, e_p = 0, l2_p = 0;
   if (run_ok)
   {
-    if (mine) a00_theta_conditional_invgamma_fast(wg.sp.theta_alpha, wg.sp.theta_beta, (long)runK, runT, &fitA, &fitB);
+    {
+      // lane p: THETA's fit (k_p, T_p); lane 16 + p: the coming TAU's (k_p, T'_p)
+      const int tcl = tau_q >= 0 ? (int)wg.sp.left[tau_q] : -1, tcr = tau_q >= 0 ? (int)wg.sp.right[tau_q] : -1;
+      const bool taff = role == 1u && tau_q >= 0 && ((int)pl16 == tau_q || (int)pl16 == tcl || (int)pl16 == tcr) && ((theta_mask >> pl16) & 1u);
+      const double kk = __shfl(runK, (int)pl16, 64);
+      const double Cn = taff ? wg.xtot[tau_base + ((int)pl16 == tau_q ? 2 : (int)pl16 == tcl ? 3 : 4)] : qnan;
+      double fa = qnan, fb = qnan;
+      if (mine || (taff && Cn == Cn)) a00_theta_conditional_invgamma_fast(wg.sp.theta_alpha, wg.sp.theta_beta, (long)kk, mine ? runT : Cn, &fa, &fb);
+      if (mine) { fitA = fa; fitB = fb; }
+      if (role == 1u) { wg.rd[pl16].a = fa; wg.rd[pl16].b = fb; }
+    }
     const uint32_t fitm = (uint32_t)__ballot(mine && fitA == fitA) & 0xffffu;
     const uint32_t gm = theta_mask & ~slidem & fitm;
     double xl;
@@ -548,7 +560,7 @@ __device__ __forceinline__ uint32_t prog_theta_decide(uint32_t z, uint32_t theta
 // (xtot[base], + the coarse companion) and the new T2h sums of q and its two children (xtot[base + 2 .. 4]); each of their
 // thetas is re-drawn from the fit to (k, new sum) and enters the ratio against the fit to the current sums (pf).
 // lnacc0 = the window's prior term.  Leaves dec.acc_step / rd_mask / lnacc_step and rd[] (installed by the caller on acceptance).
-__device__ __forceinline__ uint32_t prog_tau_decide(uint32_t z, uint32_t theta_mask, int q, int base, double lnacc0)
+__device__ __forceinline__ uint32_t prog_tau_decide(uint32_t z, uint32_t theta_mask, int q, int base, double lnacc0, bool prefit = false)
 {
   WgBase & wg = wg_base();
   const uint32_t lane = threadIdx.x & 63u, pl16 = lane & 15u, role = lane >> 4;
@@ -562,7 +574,8 @@ __device__ __forceinline__ uint32_t prog_tau_decide(uint32_t z, uint32_t theta_m
   const bool have = aff && ((theta_mask >> pl16) & 1u) && run_ok;
   const double Cn = have ? wg.xtot[base + ((int)lane == q ? 2 : (int)lane == cl ? 3 : 4)] : qnan;
   double fa = qnan, fb = qnan, tn = qnan, l2t = 0;
-  if (have && Cn == Cn) a00_theta_conditional_invgamma_fast(wg.sp.theta_alpha, wg.sp.theta_beta, (long)f.k, Cn, &fa, &fb);
+  if (prefit) { if (have && Cn == Cn) { fa = wg.rd[pl16].a; fb = wg.rd[pl16].b; } }           // (made with THETA's: prog_theta_decide)
+  else if (have && Cn == Cn) a00_theta_conditional_invgamma_fast(wg.sp.theta_alpha, wg.sp.theta_beta, (long)f.k, Cn, &fa, &fb);
   const uint32_t rd_mask = (uint32_t)__ballot(have && fa == fa && f.a == f.a) & 0xffffu;
   double xl;
   const double s_fa = __shfl(fa, (int)pl16, 64), s_fb = __shfl(fb, (int)pl16, 64);
@@ -894,8 +907,10 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           tq_old = wg.tau[q]; tq_lo = fmax(wg.tau[cl], wg.tau[cr]); tq_hi = pq >= 0 ? wg.tau[pq] : 999.0;
           tq_new = reflect(tq_old + SP.ft_tau*wprop, tq_lo, tq_hi);
           minf = (tq_new - tq_lo)/(tq_old - tq_lo); maxf = (tq_new - tq_hi)/(tq_old - tq_hi);
-          lminf = log(minf); lmaxf = log(maxf);
-          if (pq < 0 && SP.tau_alpha > 0) lnprior = (SP.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - SP.tau_beta*(tq_new - tq_old);
+          // (the three logs side by side: lane 0, 1, 2)
+          const double lg = log(lane == 0 ? minf : lane == 1u ? maxf : tq_new/tq_old);
+          lminf = __shfl(lg, 0, 64); lmaxf = __shfl(lg, 1, 64);
+          if (pq < 0 && SP.tau_alpha > 0) lnprior = (SP.tau_alpha - 1 - (nsp - 1) + 1)*__shfl(lg, 2, 64) - SP.tau_beta*(tq_new - tq_old);
         }
         else { mix_lnc = SP.ft_mix*wprop; mix_c = exp(mix_lnc); }
         if (lane == 0)
@@ -941,7 +956,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           bool accept = false; double lnacc = 0; uint32_t rd_mask = 0;
           if (first)
           {
-            g.r = prog_theta_decide((uint32_t)g.r, tm, slidem, tslide, 1);
+            g.r = prog_theta_decide((uint32_t)g.r, tm, slidem, tslide, 1, q, base);
             const uint32_t accm = wg.dec.accm;
             cnt_prop += (uint32_t)__popc(tm); cnt_acc += (uint32_t)__popc(accm);
             cnt_gprop += (uint32_t)__popc(tm & ~slidem); cnt_gacc += (uint32_t)__popc(accm & tm & ~slidem);
@@ -955,7 +970,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           }
           if (!mix)
           {
-            g.r = prog_tau_decide((uint32_t)g.r, tm, q, base, lnprior);
+            g.r = prog_tau_decide((uint32_t)g.r, tm, q, base, lnprior, first);
             accept = wg.dec.acc_step != 0u; rd_mask = wg.dec.rd_mask; lnacc = wg.dec.lnacc_step;
           }
           else
