@@ -697,7 +697,7 @@ class Sampler:
         k = lib().bpa_sampler_kind(self.h)
         if k < 0:
             raise BpaError(_err())
-        return ("sweep", "generic", "persistent", "hybrid", "big")[k]
+        return ("sweep", "generic", "persistent", "hybrid", "big", "composite")[k]
 
     def streams(self):
         """2 when the generic sampler runs its per-locus steps as two overlapping half-batch launches, else 1"""

@@ -431,6 +431,7 @@ static int gs_download(bpa_sampler * s)
 extern "C" int bpa_sampler_set_subst_model(bpa_sampler_t * s, unsigned i, const double * freqs, const double * qrates, double alpha)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) { unsigned j; bpa_sampler * p = comp_part(s, i, &j); if (!p) return fail("bpa_sampler_set_subst_model: bad argument"); return bpa_sampler_set_subst_model(p, j, freqs, qrates, alpha); }
   if (i >= s->nloci || !freqs || !qrates || !(alpha > 0)) return fail("bpa_sampler_set_subst_model: bad argument");
   if (!s->generic) return fail("bpa_sampler_set_subst_model: the loci are JC69 (no substitution parameters to move)");
   if (s->g_sm_host.size() != (size_t)s->nloci*11) s->g_sm_host.assign((size_t)s->nloci*11, 0.0);
@@ -444,6 +445,7 @@ extern "C" int bpa_sampler_set_subst_model(bpa_sampler_t * s, unsigned i, const 
 extern "C" int bpa_sampler_get_subst_model(bpa_sampler_t * s, unsigned i, double * freqs, double * qrates, double * alpha)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) { unsigned j; bpa_sampler * p = comp_part(s, i, &j); if (!p) return fail("bpa_sampler_get_subst_model: bad argument"); return comp_upload(s) && bpa_sampler_get_subst_model(p, j, freqs, qrates, alpha); }
   if (i >= s->nloci || s->g_sm_host.size() != (size_t)s->nloci*11) return fail("bpa_sampler_get_subst_model: no substitution model set");
   if (s->uploaded && !s->host_current && !sampler_download(s)) return 0;
   const double * m = s->g_sm_host.data() + (size_t)i*11;
@@ -456,6 +458,7 @@ extern "C" int bpa_sampler_get_subst_model(bpa_sampler_t * s, unsigned i, double
 extern "C" void bpa_sampler_set_subst_moves(bpa_sampler_t * s, double ft_freqs, double ft_qrates, double ft_alpha, double alpha_a, double alpha_b)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) { (void)comp_each(s, [&](bpa_sampler * p) { if (p->generic) bpa_sampler_set_subst_moves(p, ft_freqs, ft_qrates, ft_alpha, alpha_a, alpha_b); return 1; }); return; }
   // (nothing to upload: the widths travel with every launch, the moves' tables are made when first needed — gs_subst_ready)
   s->g_ft[0] = ft_freqs; s->g_ft[1] = ft_qrates; s->g_ft[2] = ft_alpha; s->g_alpha_a = alpha_a; s->g_alpha_b = alpha_b;
 }

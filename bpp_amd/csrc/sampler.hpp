@@ -1128,6 +1128,8 @@ struct bpa_sampler
   void * allreduce_ctx = nullptr;
   double * sum_ext = nullptr;           // caller-owned device scalar for that sum (NULL: internal)
   unsigned locus_offset = 0;            // global index of this rank's first locus (random streams)
+  std::vector<unsigned> stream_index;   // a part of a composite: every locus's index in the whole set (its random stream)
+  struct bpa_composite * comp = nullptr; // loci of several kinds: the parts (composite.hpp); this object then only dispatches
   std::vector<double> h_taus;
   std::vector<smp::Tree> h_trees;
   // ---- the generic path (gsampler.hpp): loci outside the sweep kernel's scope, evaluated by the engine's step kernels
@@ -1199,11 +1201,34 @@ struct bpa_sampler
   unsigned long v2_iters = 0;           // iterations run by persistent launches (bpa_sampler_timing)
 };
 
+static bpa_sampler * comp_create(bpa_engine_t * e, bpa_locus_t * const * loci, unsigned nloci, unsigned long seed, bool * plain);
+static void comp_destroy(bpa_sampler * s);
+static int comp_invalidate(bpa_sampler * s);
+static int comp_upload(bpa_sampler * s);
+static int comp_run(bpa_sampler * s, int what, unsigned n);
+static int comp_summary(bpa_sampler * s, double * total_lnl, unsigned long * proposals, unsigned long * accepted, unsigned long * launches);
+static int comp_timing(bpa_sampler * s, double * sweep_ms, unsigned long * sweep_launches, double * allloci_ms, unsigned long * allloci_launches);
+static int comp_work(bpa_sampler * s, double * bytes, unsigned long * node_updates, unsigned long * pattern_updates, unsigned long * sweeps);
+static bpa_sampler * comp_part(bpa_sampler * s, unsigned i, unsigned * j);
+static bpa_sampler * comp_part0(bpa_sampler * s);
+template <class F> static int comp_each(bpa_sampler * s, F f);
+#define COMP_FAIL(msg) do { if (s->comp) return fail(msg); } while (0)
+
+static bpa_sampler * sampler_create_plain(bpa_engine_t * e, bpa_locus_t * const * loci, unsigned nloci, unsigned long seed);
 extern "C" bpa_sampler_t * bpa_sampler_create(bpa_engine_t * e, bpa_locus_t * const * loci, unsigned nloci,
                                               unsigned long seed)
 {
   if (!e || !loci || !nloci) { fail("bpa_sampler_create: null argument"); return nullptr; }
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  // loci of more than one kind: a part per kind, stepped together (composite.hpp)
+  bool plain = true;
+  bpa_sampler * c = comp_create(e, loci, nloci, seed, &plain);
+  if (c || !plain) return c;
+  return sampler_create_plain(e, loci, nloci, seed);
+}
+
+static bpa_sampler * sampler_create_plain(bpa_engine_t * e, bpa_locus_t * const * loci, unsigned nloci, unsigned long seed)
+{
   bpa_sampler * s = new bpa_sampler();
   s->eng = e; s->nloci = nloci; s->seed = seed; s->grng = a00_rng_seed(seed, A00_GLOBAL_STREAM);
   s->sp.theta_slide_prob = 0.1;
@@ -1293,6 +1318,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
 {
   if (!s) return;
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) comp_destroy(s);
   (void)set_device(s->eng);
   (void)hipStreamSynchronize(s->eng->stream);
   for (auto & t : s->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
@@ -1347,6 +1373,7 @@ static int set_tree_fields(TR & t, int tips, const int * left, const int * right
 
 // start state of a stream (index = global locus index, or A00_GLOBAL_STREAM): our 64-bit one, or — BPP's kernel — the
 // 32-bit legacy_rndu state the host driver derives from the same seeding function (a00_create: rng >> 16)
+static unsigned stream_of(const bpa_sampler * s, unsigned i) { return s->stream_index.empty() ? s->locus_offset + i : s->stream_index[i]; }
 static a00_rng_t stream_seed(const bpa_sampler * s, unsigned stream)
 {
   const a00_rng_t z = a00_rng_seed(s->seed, stream);
@@ -1356,11 +1383,13 @@ static a00_rng_t stream_seed(const bpa_sampler * s, unsigned stream)
 extern "C" int bpa_sampler_set_proposal_kernel(bpa_sampler_t * s, int kind)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp && kind != BPA_KERNEL_UNIFORM) return fail("bpa_sampler_set_proposal_kernel: loci of several kinds run the library's own proposal kernel (BPP's lives inside the persistent kernel's single launch)");
+  if (s->comp) return 1;
   if (kind != BPA_KERNEL_UNIFORM && kind != BPA_KERNEL_BPP) return fail("bpa_sampler_set_proposal_kernel: BPA_KERNEL_UNIFORM or BPA_KERNEL_BPP");
   if (s->uploaded) return fail("bpa_sampler_set_proposal_kernel: before bpa_sampler_initialize (as a00_set_proposal_kernel)");
   if ((s->generic || s->big) && kind == BPA_KERNEL_BPP) return fail("bpa_sampler_set_proposal_kernel: BPP's kernel runs in the persistent iteration kernel (JC69 loci of <= 8 tips and <= 64 patterns)");
   s->kernel_bpp = kind == BPA_KERNEL_BPP;
-  for (unsigned i = 0; i < s->nloci; ++i) s->h_trees[i].rng = stream_seed(s, s->locus_offset + i);
+  for (unsigned i = 0; i < s->nloci; ++i) s->h_trees[i].rng = stream_seed(s, stream_of(s, i));
   s->grng = stream_seed(s, A00_GLOBAL_STREAM);
   s->v2_grng_sent = false;
   return 1;
@@ -1369,6 +1398,7 @@ extern "C" int bpa_sampler_set_proposal_kernel(bpa_sampler_t * s, int kind)
 extern "C" int bpa_sampler_set_program_moves(bpa_sampler_t * s, int on, double slide_prob)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) return on ? fail("bpa_sampler_set_program_moves: loci of several kinds run the library's own moves") : 1;
   if (on && !(slide_prob >= 0 && slide_prob <= 1)) return fail("bpa_sampler_set_program_moves: slide_prob is a probability");
   if (on && !s->kernel_bpp) return fail("bpa_sampler_set_program_moves: the program's moves draw from BPP's proposal kernel (bpa_sampler_set_proposal_kernel(s, BPA_KERNEL_BPP) first)");
   s->sp.program_moves = on ? 1 : 0;
@@ -1381,6 +1411,7 @@ extern "C" int bpa_sampler_set_program_moves(bpa_sampler_t * s, int on, double s
 extern "C" int bpa_sampler_gibbs_counters(bpa_sampler_t * s, unsigned long * proposals, unsigned long * accepted)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) { if (proposals) *proposals = 0; if (accepted) *accepted = 0; return 1; }
   if (!sampler_download(s)) return 0;
   uint32_t c[4];
   HIPCHK(hipMemcpy(c, s->counters.p, sizeof c, hipMemcpyDeviceToHost));
@@ -1393,9 +1424,10 @@ extern "C" int bpa_sampler_set_tree(bpa_sampler_t * s, unsigned i, const int * l
                                     const double * times, int root)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) { unsigned j; bpa_sampler * p = comp_part(s, i, &j); if (!p) return fail("bpa_sampler_set_tree: locus index out of range"); return comp_invalidate(s) && bpa_sampler_set_tree(p, j, left, right, times, root); }
   if (i >= s->nloci) return fail("bpa_sampler_set_tree: locus index out of range");
   const int tips = (int)s->loci[i]->tips;
-  const a00_rng_t rng = stream_seed(s, s->locus_offset + i);
+  const a00_rng_t rng = stream_seed(s, stream_of(s, i));
   if (!sampler_invalidate(s)) return 0;
   if (s->big) return set_tree_fields<gbig::BTree, gbig::BN>(s->b_trees[i], tips, left, right, times, root, rng);
   if (s->generic) return set_tree_fields<gsm::GTree, gsm::NN>(s->g_trees[i], tips, left, right, times, root, rng);
@@ -1497,7 +1529,8 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
   // issue slots: the pair takes a third longer than a wave alone) — 4 where the loci allow, i.e. up to 4 x 8 x CUs loci
   const unsigned nwaves = (unsigned)woff.size() - 1;
   const unsigned LMAX = WAVES - (prog ? 1u : 0u), ncu = (unsigned)std::max(prop.multiProcessorCount, 1);
-  const unsigned LWAVES = (LMAX > 4u && nwaves <= 4u*ncu) ? 4u : LMAX;       // (a pair in every workgroup anyway beyond that: then as few workgroups as possible)
+  unsigned LWAVES = (LMAX > 4u && nwaves <= 4u*ncu) ? 4u : LMAX;
+  if (const char * ev = std::getenv("BPA_SMP_LWAVES")) { const unsigned v = (unsigned)std::atoi(ev); if (v >= 1 && v <= LMAX) LWAVES = v; }     // (experiments)       // (a pair in every workgroup anyway beyond that: then as few workgroups as possible)
   const unsigned nwg = (nwaves + LWAVES - 1)/LWAVES;
   // every workgroup must be resident (they wait for each other's sums): one per CU — a workgroup takes most of a CU's LDS
   const size_t base = NT == 4 ? v2_lds_base<4>(prog) : v2_lds_base<8>(prog);
@@ -1716,6 +1749,7 @@ extern "C" int bpa_sampler_set_species_tree(bpa_sampler_t * s, int species, cons
                                             const double * theta)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) { const int ok = comp_invalidate(s) && comp_each(s, [&](bpa_sampler * p) { return bpa_sampler_set_species_tree(p, species, parent, tau, theta); }); if (ok) s->sp = comp_part0(s)->sp; return ok; }
   const int np = 2*species - 1;
   if (species < 1 || species > smp::MAXTIPS) return fail("bpa_sampler_set_species_tree: 1..8 species");
   if (!sampler_invalidate(s)) return 0;           // (the trees keep their state; taus and thetas are replaced below)
@@ -1753,6 +1787,7 @@ extern "C" int bpa_sampler_set_species_tree(bpa_sampler_t * s, int species, cons
 extern "C" int bpa_sampler_set_tip_species(bpa_sampler_t * s, unsigned i, const int * species)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) { unsigned j; bpa_sampler * p = comp_part(s, i, &j); if (!p) return fail("bpa_sampler_set_tip_species: locus index out of range"); return comp_invalidate(s) && bpa_sampler_set_tip_species(p, j, species); }
   if (i >= s->nloci) return fail("bpa_sampler_set_tip_species: locus index out of range");
   if (!sampler_invalidate(s)) return 0;
   if (s->big)
@@ -1776,14 +1811,22 @@ extern "C" int bpa_sampler_set_tip_species(bpa_sampler_t * s, unsigned i, const 
 }
 
 extern "C" void bpa_sampler_set_finetune(bpa_sampler_t * s, double gage, double gspr, double tau, double mix)
-{ s->sp.ft_gage = gage; s->sp.ft_gspr = gspr; s->sp.ft_tau = tau; s->sp.ft_mix = mix; }
+{
+  if (s->comp) (void)comp_each(s, [&](bpa_sampler * p) { bpa_sampler_set_finetune(p, gage, gspr, tau, mix); return 1; });
+  s->sp.ft_gage = gage; s->sp.ft_gspr = gspr; s->sp.ft_tau = tau; s->sp.ft_mix = mix;
+}
 
 extern "C" void bpa_sampler_set_tau_prior(bpa_sampler_t * s, double alpha, double beta)
-{ s->sp.tau_alpha = alpha; s->sp.tau_beta = beta; }
+{
+  if (s->comp) (void)comp_each(s, [&](bpa_sampler * p) { bpa_sampler_set_tau_prior(p, alpha, beta); return 1; });
+  s->sp.tau_alpha = alpha; s->sp.tau_beta = beta;
+}
 
 extern "C" void bpa_sampler_set_theta_prior(bpa_sampler_t * s, double alpha, double beta, double finetune)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  // (a composite: whether there is a THETA step at all is part of what the parts agree on at upload)
+  if (s->comp) { const bool had = s->sp.theta_alpha > 0; if (had != (alpha > 0)) (void)comp_invalidate(s); (void)comp_each(s, [&](bpa_sampler * p) { bpa_sampler_set_theta_prior(p, alpha, beta, finetune); return 1; }); }
   s->sp.theta_alpha = alpha; s->sp.theta_beta = beta; s->sp.ft_theta = finetune;
   if (s->uploaded && s->v2_ok && v2_wants_prog(s) != s->v2_prog) (void)sampler_invalidate(s);      // (the kernel's form is chosen at upload)
 }
@@ -1792,6 +1835,7 @@ extern "C" int bpa_sampler_get_thetas(bpa_sampler_t * s, double * theta)
 {
   bpa_engine * e = s->eng;
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  if (s->comp) return comp_upload(s) && bpa_sampler_get_thetas(comp_part0(s), theta);
   if (!set_device(e)) return 0;
   const size_t np = (size_t)s->sp.npop;
   if (!s->uploaded) { for (size_t i = 0; i < np; ++i) theta[i] = s->h_taus[smp::MAXPOP + i]; return (int)np; }
@@ -1804,6 +1848,7 @@ extern "C" int bpa_sampler_get_taus(bpa_sampler_t * s, double * taus)
 {
   bpa_engine * e = s->eng;
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  if (s->comp) return comp_upload(s) && bpa_sampler_get_taus(comp_part0(s), taus);
   if (!set_device(e)) return 0;
   const size_t np = (size_t)s->sp.npop;
   if (!s->uploaded) { for (size_t i = 0; i < np; ++i) taus[i] = s->h_taus[i]; return (int)np; }
@@ -1815,6 +1860,7 @@ extern "C" int bpa_sampler_get_taus(bpa_sampler_t * s, double * taus)
 extern "C" int bpa_sampler_initialize(bpa_sampler_t * s)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) return comp_run(s, 0, 0);
   if (!sampler_upload(s)) return 0;
   s->host_current = false;
   if (s->big) return gb_initialize(s);
@@ -1857,6 +1903,7 @@ extern "C" int bpa_sampler_set_allreduce(bpa_sampler_t * s, bpa_allreduce_fn fn,
                                          unsigned first_locus)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  COMP_FAIL("bpa_sampler_set_allreduce: a sampler over loci of several kinds runs on one rank");
   s->allreduce = fn; s->allreduce_ctx = ctx; s->sum_ext = device_sum;
   if (first_locus != s->locus_offset)
   {
@@ -1952,6 +1999,7 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
 extern "C" int bpa_sampler_set_p2p(bpa_sampler_t * s, bpa_p2p_t * p, unsigned first_locus)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  COMP_FAIL("bpa_sampler_set_p2p: a sampler over loci of several kinds runs on one rank");
   if (p && (!p->connected || p->eng != s->eng)) return fail("bpa_sampler_set_p2p: connect the exchange first (same engine)");
   if (p && p->nmax < 16u) return fail("bpa_sampler_set_p2p: the mailboxes must hold at least 16 values");
   // only the persistent kernel reads the mailboxes: a generic or big-tree sampler would decide from its own shard's sums
@@ -1974,6 +2022,7 @@ extern "C" int bpa_sampler_iterate(bpa_sampler_t * s, unsigned iterations)
 {
   bpa_engine * e = s->eng;
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  if (s->comp) return comp_run(s, 1, iterations);
   if (!sampler_upload(s)) return 0;
   s->host_current = false;
   if (s->big) return gb_iterate(s, iterations);
@@ -2127,6 +2176,7 @@ extern "C" int bpa_sampler_get_tree(bpa_sampler_t * s, unsigned i, int * left, i
                                     double * times, int * clv, int * pmat, int * root, double * lnl)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) { unsigned j; bpa_sampler * p = comp_part(s, i, &j); if (!p) return fail("bpa_sampler_get_tree: locus index out of range"); return comp_upload(s) && bpa_sampler_get_tree(p, j, left, right, parent, times, clv, pmat, root, lnl); }
   if (i >= s->nloci) return fail("bpa_sampler_get_tree: locus index out of range");
   if (!sampler_download(s)) return 0;                   // (a no-op while the host copy is current)
   auto out = [&](const auto & t)
@@ -2147,6 +2197,7 @@ extern "C" int bpa_sampler_get_tree(bpa_sampler_t * s, unsigned i, int * left, i
 extern "C" int bpa_sampler_get_tree_msc(bpa_sampler_t * s, unsigned i, int * pop, double * logpr)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) { unsigned j; bpa_sampler * p = comp_part(s, i, &j); if (!p) return fail("bpa_sampler_get_tree_msc: locus index out of range"); return comp_upload(s) && bpa_sampler_get_tree_msc(p, j, pop, logpr); }
   if (i >= s->nloci) return fail("bpa_sampler_get_tree_msc: locus index out of range");
   if (!sampler_download(s)) return 0;
   auto out = [&](const auto & t)
@@ -2161,6 +2212,7 @@ extern "C" int bpa_sampler_get_tree_msc(bpa_sampler_t * s, unsigned i, int * pop
 extern "C" int bpa_sampler_enable_timing(bpa_sampler_t * s, unsigned stride)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) return comp_each(s, [&](bpa_sampler * p) { return bpa_sampler_enable_timing(p, stride); });
   if (!set_device(s->eng) || !sampler_timing_drain(s)) return 0;
   s->timing_stride = stride; s->timing_phase = 0;
   s->timed_ms[0] = s->timed_ms[1] = 0; s->timed_n[0] = s->timed_n[1] = 0;
@@ -2171,6 +2223,7 @@ extern "C" int bpa_sampler_timing(bpa_sampler_t * s, double * sweep_ms, unsigned
                                   double * allloci_ms, unsigned long * allloci_launches)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) return comp_timing(s, sweep_ms, sweep_launches, allloci_ms, allloci_launches);
   if (!set_device(s->eng) || !sampler_timing_drain(s)) return 0;
   if (sweep_ms) *sweep_ms = s->timed_ms[0];
   if (sweep_launches) *sweep_launches = s->timed_n[0];
@@ -2185,6 +2238,7 @@ extern "C" int bpa_sampler_work(bpa_sampler_t * s, double * bytes, unsigned long
                                 unsigned long * pattern_updates, unsigned long * sweeps)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) return comp_work(s, bytes, node_updates, pattern_updates, sweeps);
   if (!sampler_download(s)) return 0;
   double by = 0; unsigned long nu = 0, pu = 0;
   for (unsigned i = 0; i < s->nloci; ++i)
@@ -2210,6 +2264,7 @@ extern "C" int bpa_sampler_work(bpa_sampler_t * s, double * bytes, unsigned long
 extern "C" int bpa_sampler_kind(bpa_sampler_t * s)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) return comp_upload(s) ? BPA_SAMPLER_COMPOSITE : -1;
   if (!sampler_upload(s)) return -1;
   if (s->big) return BPA_SAMPLER_BIG;
   if (s->generic) return BPA_SAMPLER_GENERIC;
@@ -2220,6 +2275,7 @@ extern "C" int bpa_sampler_kind(bpa_sampler_t * s)
 extern "C" int bpa_sampler_streams(bpa_sampler_t * s)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) return comp_upload(s) ? 1 : -1;
   if (!sampler_upload(s)) return -1;
   return s->generic && s->g_split ? 2 : 1;
 }
@@ -2228,6 +2284,7 @@ extern "C" int bpa_sampler_summary(bpa_sampler_t * s, double * total_lnl, unsign
                                    unsigned long * accepted, unsigned long * launches)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp) return comp_summary(s, total_lnl, proposals, accepted, launches);
   if (!sampler_download(s)) return 0;
   uint32_t c[2];
   HIPCHK(hipMemcpy(c, s->counters.p, 8, hipMemcpyDeviceToHost));
@@ -2244,3 +2301,4 @@ extern "C" int bpa_sampler_summary(bpa_sampler_t * s, double * total_lnl, unsign
 
 #include "gsampler_host.hpp"
 #include "bigsampler_host.hpp"
+#include "composite.hpp"

@@ -399,6 +399,8 @@ int  bpa_sampler_work(bpa_sampler_t *, double * bytes, unsigned long * node_upda
 #define BPA_SAMPLER_PERSISTENT 2
 #define BPA_SAMPLER_HYBRID     3       /* an all-reduce callback is installed (several ranks): the per-locus sweep of an iteration is
                                           ONE launch of the persistent kernel, the all-loci steps one launch each of csrc/sampler.hpp's */
+#define BPA_SAMPLER_COMPOSITE  5       /* loci of several kinds (JC69 LDS-kernel loci, generic JC69, multi-category, 20-state): a part per kind,
+                                          stepped together through the parts' all-reduce callbacks (csrc/composite.hpp); one rank, the library's own moves */
 #define BPA_SAMPLER_BIG        4       /* loci of more than 16 tips, with scalers or unphased diploids (csrc/bigsampler.hpp: trees in HBM,
                                           one lane per locus, the engine's general 4-state kernels; <= 64 tips) */
 int  bpa_sampler_kind(bpa_sampler_t *);

@@ -201,3 +201,39 @@ def test_window_widths_change_in_mid_run():
     with pytest.raises(bpp_amd.BpaError):
         dev.set_subst_model(0, data[0]["freqs"], data[0]["exch"], 0.7)          # not while the sampler runs
     dev.close(); host.close(); eng.close()
+
+
+def test_loci_of_several_kinds_in_one_sampler():
+    """A data set no single device sampler takes (BPP: a partition list with a model per locus, loci of any size —
+    method.c:3320-3346): JC69 loci that fit the LDS kernels, JC69 loci with more than 64 patterns, GTR+Gamma4 loci.  The
+    sampler deals them to a part per kind (csrc/composite.hpp: persistent-kernel sweeps + one launch per all-loci step for the
+    first, the generic path's two record formats for the others) and steps the parts together; the whole walks the host
+    driver's trajectory — every decision, every tree."""
+    eng = bpp_amd.Engine(0)
+    fit = synth.make_dataset(96, 300, 8, "jc69", 1, seed=5)
+    wide = synth.make_dataset(7, 8000, 8, "jc69", 1, seed=6, divergence=20.0)
+    gtr = synth.make_dataset(30, 300, 8, "gtr", 4, seed=7)
+    assert all(len(d["weights"]) <= 64 for d in fit) and all(64 < len(d["weights"]) < 256 for d in wide), [len(d["weights"]) for d in wide]
+    # interleaved: the parts' loci are not contiguous ranges of the whole set
+    data = []
+    for i in range(96):
+        data.append(fit[i])
+        if i % 14 == 0: data.append(wide[i // 14])
+        if i % 3 == 0 and i // 3 < 30: data.append(gtr[i // 3])
+    nloci = len(data)
+    loci_a = tape.make_engine_loci(eng, data)
+    loci_b = tape.make_engine_loci(eng, data)
+    host = hostdrv.hip_driver(eng, loci_a, data, seed=31)
+    dev = bpp_amd.Sampler(eng, loci_b, data, seed=31)
+    parent, tau0, thetas = synth.species_tree_arrays(8)
+    for drv in (host, dev):
+        drv.set_species_tree(parent, tau0, thetas)
+        drv.set_tau_prior(3.0, 3.0 / tau0[-1])
+        drv.set_theta_prior(2.0, 1000.0, 0.001)
+        drv.set_finetune(0.003, 0.005, 0.0008, 0.2)
+    assert dev.kind() == "composite"
+    walk(host, dev, 6, nloci)
+    assert dev.taus() != list(tau0) and dev.thetas() != list(thetas)
+    w = dev.work()
+    assert w["node_updates"] > 0 and w["bytes"] > 0
+    dev.close(); host.close(); eng.close()
