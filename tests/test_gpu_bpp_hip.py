@@ -33,7 +33,7 @@ def all_program_runs_side_by_side(request):
             it.obj(**(it.callspec.params if hasattr(it, "callspec") else {}))
         except BaseException:      # noqa: BLE001  (the test proper reports it)
             pass
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=12) as ex:
         list(ex.map(dry, items))
     yield
 

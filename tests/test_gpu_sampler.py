@@ -3,6 +3,8 @@ driver on libbpp_amd.so with the same seed — which in turn equals the host dri
 reference (test_gpu_host_driver.py).  Same proposals (integer random streams), same
 accept/reject history, same trees; ages and log-likelihoods to ~1e-12 (device exp/log vs glibc
 in the root-age and mixing multipliers)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -226,7 +228,9 @@ def test_device_sampler_draws_from_the_msc_prior():
 
 def test_sampler_rejects_unsupported_loci(engine):
     """GTR+G loci are the generic sampler's (tests/test_gpu_gsampler.py), loci with scale buffers the big-tree sampler's
-    (tests/test_gpu_bigsampler.py); amino-acid loci with scalers and a mix of one- and several-category loci are refused loudly"""
+    (tests/test_gpu_bigsampler.py); amino-acid loci with scalers are refused loudly; a mix of one- and several-category loci —
+    refused until round 4 — is dealt to a part per kind (csrc/composite.hpp; trajectory: tests/test_gpu_gsampler.py), and with
+    BPA_SMP_NO_COMPOSITE=1 refused as before"""
     data = synth.make_dataset(2, 200, 8, "gtr", 4, seed=1)
     loci = tape.make_engine_loci(engine, data, True)                  # with scale buffers
     smp = bpp_amd.Sampler(engine, loci, data)
@@ -240,8 +244,19 @@ def test_sampler_rejects_unsupported_loci(engine):
         bpp_amd.Sampler(engine, tape.make_engine_loci(engine, aa, True), aa)
     mixed = data[:1] + synth.make_dataset(1, 200, 8, "jc69", 1, seed=2)
     loci = tape.make_engine_loci(engine, mixed)
-    with pytest.raises(bpp_amd.BpaError, match="all be JC69"):
-        bpp_amd.Sampler(engine, loci, mixed)
+    smp = bpp_amd.Sampler(engine, loci, mixed)
+    smp.set_species_tree(parent, tau0, thetas)
+    smp.initialize()
+    assert smp.kind() == "composite"
+    with pytest.raises(bpp_amd.BpaError, match="several kinds"):
+        smp.set_proposal_kernel(1)
+    smp.close()
+    os.environ["BPA_SMP_NO_COMPOSITE"] = "1"
+    try:
+        with pytest.raises(bpp_amd.BpaError, match="all be JC69"):
+            bpp_amd.Sampler(engine, tape.make_engine_loci(engine, mixed), mixed)
+    finally:
+        os.environ.pop("BPA_SMP_NO_COMPOSITE", None)
 
 
 def test_native_rccl_callback(monkeypatch):
