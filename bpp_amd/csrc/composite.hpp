@@ -33,7 +33,12 @@ struct bpa_composite
   std::function<int(bpa_sampler *)> job;
   int cur = -1;
   bool failed = false;
-  DevBuf<double *> d_ptrs;
+  // a stream per part (the engine's own for part 0): a part's launches go to its stream — the engine's stream field is
+  // switched while the part's fiber runs —, so a small part's launch latency overlaps with a big part's kernels; events
+  // order the sum of a step after every part's share and every part's continuation after the sum
+  std::vector<hipStream_t> stream;
+  std::vector<hipEvent_t> ev_part;
+  hipEvent_t ev_sum = nullptr;
 };
 
 namespace comp {
@@ -85,7 +90,13 @@ static int run_all(bpa_composite * c, bpa_engine * e, std::function<int(bpa_samp
   for (;;)
   {
     for (int i = 0; i < n; ++i)
-      if (c->state[i] == 0) { c->cur = i; swapcontext(&c->main_ctx, &c->ctx[i]); }
+      if (c->state[i] == 0)
+      {
+        c->cur = i;
+        e->stream = c->stream[i];
+        swapcontext(&c->main_ctx, &c->ctx[i]);
+        e->stream = c->stream[0];
+      }
     int waiting = 0, done = 0;
     for (int i = 0; i < n; ++i) { waiting += c->state[i] == 1; done += c->state[i] == 2; }
     if (!waiting) break;
@@ -97,11 +108,18 @@ static int run_all(bpa_composite * c, bpa_engine * e, std::function<int(bpa_samp
     {
       Ptrs P{};
       for (int i = 0; i < n; ++i) P.p[i] = c->pend_ptr[i];
-      hipLaunchKernelGGL(sum_parts_kernel, dim3((cnt + 63)/64), dim3(64), 0, e->stream, P, n, cnt);
-      if (hipGetLastError() != hipSuccess) c->failed = true;
+      bool okq = true;
+      for (int i = 1; i < n; ++i)
+        okq = okq && hipEventRecord(c->ev_part[i], c->stream[i]) == hipSuccess && hipStreamWaitEvent(c->stream[0], c->ev_part[i], 0) == hipSuccess;
+      hipLaunchKernelGGL(sum_parts_kernel, dim3((cnt + 63)/64), dim3(64), 0, c->stream[0], P, n, cnt);
+      okq = okq && hipGetLastError() == hipSuccess && hipEventRecord(c->ev_sum, c->stream[0]) == hipSuccess;
+      for (int i = 1; i < n; ++i) okq = okq && hipStreamWaitEvent(c->stream[i], c->ev_sum, 0) == hipSuccess;
+      if (!okq) c->failed = true;
     }
     for (int i = 0; i < n; ++i) if (c->state[i] == 1) c->state[i] = 0;
   }
+  for (int i = 1; i < n; ++i)
+    if (hipEventRecord(c->ev_part[i], c->stream[i]) != hipSuccess || hipStreamWaitEvent(c->stream[0], c->ev_part[i], 0) != hipSuccess) c->failed = true;
   int ok = !c->failed;
   for (int i = 0; i < n; ++i) ok = ok && c->result[i];
   if (c->failed) fail("bpa_sampler (composite): the parts did not reach the same all-loci step together");
@@ -172,6 +190,13 @@ static bpa_sampler * comp_create(bpa_engine_t * e, bpa_locus_t * const * loci, u
   const size_t n = c->parts.size();
   c->cb.resize(n); c->ctx.resize(n); c->state.assign(n, 2); c->result.assign(n, 0); c->pend_ptr.assign(n, nullptr); c->pend_n.assign(n, 0);
   c->stacks.resize(n);
+  c->stream.assign(n, e->stream); c->ev_part.assign(n, nullptr);
+  const bool one_stream = getenv("BPA_COMP_ONE_STREAM") != nullptr;
+  if (hipEventCreateWithFlags(&c->ev_sum, hipEventDisableTiming) != hipSuccess) c->ev_sum = nullptr;
+  for (size_t i = 1; i < n && !one_stream; ++i)
+    if (hipStreamCreateWithFlags(&c->stream[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_part[i], hipEventDisableTiming) != hipSuccess)
+    { (void)hipGetLastError(); c->stream[i] = e->stream; }
+  for (size_t i = 1; i < n; ++i) if (!c->ev_part[i]) (void)hipEventCreateWithFlags(&c->ev_part[i], hipEventDisableTiming);
   for (size_t i = 0; i < n; ++i)
   {
     c->stacks[i].resize((size_t)1 << 20);
@@ -183,6 +208,13 @@ static bpa_sampler * comp_create(bpa_engine_t * e, bpa_locus_t * const * loci, u
 
 static void comp_destroy(bpa_sampler * s)
 {
+  bpa_composite * c = s->comp;
+  for (size_t i = 1; i < c->stream.size(); ++i)
+  {
+    if (c->stream[i] != s->eng->stream) { (void)hipStreamSynchronize(c->stream[i]); (void)hipStreamDestroy(c->stream[i]); }
+    if (c->ev_part[i]) (void)hipEventDestroy(c->ev_part[i]);
+  }
+  if (c->ev_sum) (void)hipEventDestroy(c->ev_sum);
   for (auto * p : s->comp->parts) bpa_sampler_destroy(p);
   delete s->comp; s->comp = nullptr;
 }
