@@ -111,7 +111,7 @@ def test_host_driver_library_exports():
     names = sorted(set(re.findall(r"\b(a00_[a-z0-9_]+)\s*\(", src)) - inline)
     assert inline == {"a00_rng_seed", "a00_rndu", "a00_reflect", "a00_msc_contrib", "a00_msc_t2h", "a00_msc_term",
                       "a00_bpp_rndu", "a00_bpp_rnd_laplace", "a00_bpp_rnd_symmetrical",
-                      "a00_bpp_rndu_hd", "a00_bpp_rndnormal", "a00_bpp_rndgamma", "a00_cubic_value", "a00_theta_conditional_invgamma",
+                      "a00_bpp_rndu_hd", "a00_bpp_rndnormal", "a00_bpp_rndgamma", "a00_cubic_value", "a00_theta_conditional_invgamma", "a00_theta_conditional_invgamma_fast",
                       "a00_theta_lnacc", "a00_theta_gibbs_hastings", "a00_invgamma_logpdf"}
     assert "a00_iterate" in names and "a00_backend_hip" in names
     for n in names:
