@@ -1,0 +1,373 @@
+// gsampler2.hpp — the generic sampler's per-locus proposal steps (GAGE, GSPR) with a GROUP of lanes per locus.
+//
+// gsampler.hpp's gstep_kernel gives every locus ONE lane that runs the host driver's proposal code alone: ~3 500 dependent
+// instructions, 24-36 us for a launch whatever the number of loci — the fixed cost of every step of configs 3 / 5, of a
+// strong-scaling rank's share, of a composite's small parts.  Here a locus owns 2 NT lanes (16 for <= 8 tips, 32 for <= 16)
+// and the proposal is sweep2.hpp's: the integer tree replicated in every lane's registers (byte arrays), lane i = node i,
+// population i, branch i; loops over nodes and populations are ballots restricted to the group (propose_gage /
+// propose_gspr of sweep2.hpp, the persistent kernel's own functions: same streams, same draws, same arithmetic as the host
+// driver — tests/test_gpu_gsampler.py walks its trajectory).  Everything around the proposal is gstep_kernel's, statement for
+// statement: the previous step is settled first (its decision, or the roll-back from the undo copy), the state a rejection
+// comes back to is saved, the step is written as the records of the engine's kernels (StepRec / StepOp / MatRec2, or the
+// 20-state kernels' OpDev ranges), the tree goes back to HBM.  The other modes (TAU, MIX, settle, start-up, the
+// substitution-parameter moves) stay with gstep_kernel.
+#pragma once
+
+namespace gsm2 {
+using smp::MAXPOP; using smp::Op; using smp::make_op; using smp::nth_bit; using smp::rndu;
+
+template <int NT> struct LocLDS
+{
+  double time[2*NT];
+  double contrib[2*NT], contrib_new[2*NT];
+};
+
+template <uint32_t MODE, int NT>
+__global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
+{
+  static_assert(MODE <= 1, "GAGE and GSPR");
+  using C = smp2::Cfg<NT>;
+  constexpr int G = C::G, LPW = C::LPW, NN = C::NN, W = C::W;
+  __shared__ LocLDS<NT> s_loc[LPW];
+  __shared__ double s_tau[3*MAXPOP];
+  __shared__ double s_lograt[NN*NN];
+  __shared__ uint32_t s_anc[16];
+  const uint32_t lane = threadIdx.x;
+#ifdef GS2_PROF
+  uint64_t tp_[9]; tp_[0] = wall_clock64();
+#define GS2_T(k_) tp_[k_] = wall_clock64()
+#else
+#define GS2_T(k_)
+#endif
+  const int li = (int)(lane & (uint32_t)(G - 1)); const uint32_t gbase = lane - (uint32_t)li, slot = lane/(uint32_t)G;
+  const uint32_t i = A.i0 + blockIdx.x*(uint32_t)LPW + slot;
+  const bool valid = i < A.iend;
+  const smp::Species & SP = A.sp;
+  const int npop = SP.npop;
+  if (lane < (uint32_t)(3*MAXPOP)) s_tau[lane] = A.taus[lane];
+  if (lane < 16u) s_anc[lane] = lane < (uint32_t)MAXPOP ? (uint32_t)SP.anc[lane] : 0u;
+  if (MODE == 1) for (uint32_t q = lane; q < (uint32_t)(NN*NN); q += 64u) s_lograt[q] = A.lograt[(q/NN)*gsm::NN + q % NN];
+  smp2::PopLane pl;
+  {
+    const int lp = li < MAXPOP ? li : 0;
+    pl.parent = li < npop ? (int)SP.parent[lp] : -1;
+    pl.anc = li < npop ? (uint32_t)SP.anc[lp] : 0u;
+    uint32_t below = 0;
+    for (int q2 = 0; q2 < npop; ++q2) if (q2 != li && (((uint32_t)SP.anc[q2] >> li) & 1u)) below |= 1u << q2;
+    pl.below = li < npop ? below : 0u;
+  }
+  __syncthreads();
+  {
+    const int lp = li < MAXPOP ? li : 0;
+    pl.tau = s_tau[lp]; pl.theta = s_tau[MAXPOP + lp]; pl.l2t = s_tau[2*MAXPOP + lp];
+    pl.ptau = pl.parent >= 0 ? s_tau[pl.parent] : -1.0;
+  }
+  LocLDS<NT> & S = s_loc[slot];
+  GS2_T(1);
+
+  // ---- load (the tree of an idle group: all -1, two tips)
+  smp2::GTree<NT> T;
+  for (int k = 0; k < W; ++k) { T.left.w[k] = T.right.w[k] = T.parent.w[k] = T.pop.w[k] = 0xffffffffu; }
+  T.cf = T.pf = 0; T.root = 0; T.tips = 2;
+  smp2::Stream<false> rng{0};
+  double lnl_cur = 0, logpr_cur = 0;
+  uint32_t nprop = 0, nacc = 0, w_nupd = 0, w_nbr = 0, w_nev = 0;
+  int gl_i = 0;
+  gsm::GLocus L{};
+  auto load_tree = [&](const gsm::GTree & g, int tips_)            // (an undo copy carries no tip count: the caller's)
+  {
+    for (int k = 0; k < W; ++k)
+    {
+      T.left.w[k] = reinterpret_cast<const uint32_t *>(g.left)[k]; T.right.w[k] = reinterpret_cast<const uint32_t *>(g.right)[k];
+      T.parent.w[k] = reinterpret_cast<const uint32_t *>(g.parent)[k]; T.pop.w[k] = reinterpret_cast<const uint32_t *>(g.pop)[k];
+    }
+    T.root = g.root; T.tips = tips_;
+    const int n = 2*T.tips - 1;
+    T.cf = smp2::gballot<G>(li >= T.tips && li < n && g.clv[li] != li, gbase);
+    T.pf = smp2::gballot<G>(li < n && g.pmat[li] != li, gbase);
+    S.time[li] = li < n ? g.time[li] : 0.0;
+  };
+  if (valid)
+  {
+    const gsm::GTree & g = A.trees[i];
+    L = A.loc[i];
+    load_tree(g, g.tips);
+    rng.r = g.rng; lnl_cur = g.lnl; logpr_cur = g.logpr; nprop = g.proposals; nacc = g.accepted;
+    w_nupd = g.work_nupd; w_nbr = g.work_nbr; w_nev = g.work_neval;
+    gl_i = li < MAXPOP ? (int)L.gl[li] : 0;
+  }
+  else { (void)smp2::gballot<G>(false, gbase); (void)smp2::gballot<G>(false, gbase); }
+  smp2::wsync();
+  GS2_T(2);
+
+  // ---- 1. settle the step whose evaluation just finished (gstep_kernel's step 1)
+  bool restore_par = false;
+  if (valid && A.pend)
+  {
+    bool back = false;
+    if (A.pend == 1)
+    {
+      if (A.active[i])
+      {
+        const double lnl = A.lnl_new[i], lp_new = A.logpr_new[i];
+        const double lnacc = (lp_new - logpr_cur) + (lnl - lnl_cur) + A.hast[i];
+        const double u = rndu(&rng.r);
+        ++nprop;
+        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; }
+        else back = true;
+      }
+    }
+    else if (A.pend == 2)
+    {
+      if (*A.flag == A.epoch) back = true;
+      else { logpr_cur = A.logpr_new[i]; if (A.active[i]) lnl_cur = A.lnl_new[i]; }
+    }
+    else if (A.pend == 4)
+    {
+      if (A.active[i])
+      {
+        const double lnl = A.lnl_new[i];
+        const double lnacc = (lnl - lnl_cur) + A.hast[i];
+        const double u = rndu(&rng.r);
+        ++nprop;
+        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = lnl; ++nacc; }
+        else
+        {
+          back = true;
+          if (li == 0)
+          {
+            double * m = A.sm + (size_t)i*11;
+            if (A.pend_mode == 8) m[10] = A.sm_old[2*i];
+            else { double * v = A.pend_mode == 6 ? m : m + 4; const int ref = A.pend_mode == 6 ? 3 : 1; v[A.pend_k] = A.sm_old[2*i]; v[ref] = A.sm_old[2*i + 1]; }
+          }
+          restore_par = true;
+        }
+      }
+    }
+    else { lnl_cur = A.lnl_new[i]; logpr_cur = A.logpr_new[i]; }
+    // (every lane of a group takes the same branch: the conditions are the locus's)
+    if (back) { smp2::wsync(); load_tree(A.undo[i], T.tips); }
+  }
+  smp2::wsync();
+  if (valid && restore_par && li == 0) gsm::write_par(L.par, L.R, A.pend_mode, A.sm + (size_t)i*11);
+
+  GS2_T(3);
+  const int tips = T.tips, n = 2*tips - 1;
+  const bool inner_i = li >= tips && li < n;
+  // ---- the density's pieces, lane li = population li (sweep2.hpp's density_counts / density_term, ages from LDS)
+  uint32_t mynodes = 0; int mync = 0, mynin = 0;
+  auto density_counts = [&]()
+  {
+    const int pop_i = T.pop[li];
+    int below = 0;
+    for (int q = 0; q < npop; ++q)
+    {
+      const uint32_t m = smp2::gballot<G>(inner_i && pop_i == q, gbase);
+      if (li == q) mynodes = m;
+      below += ((pl.below >> q) & 1u) ? __popc(m) : 0;
+    }
+    mync = __popc(mynodes);
+    mynin = gl_i - below;
+  };
+  auto density_term = [&]() -> double
+  {
+    uint32_t nodes = mynodes;
+    const int ncoal = mync, nin = mynin;
+    int steps = ncoal + (pl.ptau >= 0 ? 1 : 0);
+    if (nin == steps) --steps;
+    double T2h = 0, prev = pl.tau;
+    int nn = nin;
+    for (int k = 0; k < steps; ++k, --nn)
+    {
+      double tk = pl.ptau;
+      if (k < ncoal)
+      {
+        int best = -1; double tb = 0;
+        for (uint32_t m = nodes; m; m &= m - 1) { const int x = __ffs(m) - 1; const double tx = S.time[x]; if (best < 0 || tx < tb) { best = x; tb = tx; } }
+        tk = tb; nodes &= ~(1u << best);
+      }
+      T2h += nn*(nn - 1)*(tk - prev);
+      prev = tk;
+    }
+    double c = 0;
+    if (ncoal) c += ncoal*pl.l2t;
+    if (T2h) c -= T2h/(pl.theta*1.0);
+    return c;
+  };
+  // the current tree's terms (the tree arrives with their sum only); THETA moved the thetas since that sum was stored: again
+  density_counts();
+  if (li < npop) S.contrib[li] = density_term();
+  smp2::wsync();
+  if (valid && A.refresh_logpr)
+  {
+    double lp = 0;
+    for (int p = 0; p < npop; ++p) lp += S.contrib[p];
+    logpr_cur = lp;
+  }
+
+  // ---- 2. the state a rejection comes back to
+  if (valid)
+  {
+    gsm::GTree & u = A.undo[i];
+    {
+      uint32_t wl_ = 0, wr_ = 0, wp_ = 0, wq_ = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) if (li == k) { wl_ = T.left.w[k]; wr_ = T.right.w[k]; wp_ = T.parent.w[k]; wq_ = T.pop.w[k]; }
+      if (li < W)
+      {
+        reinterpret_cast<uint32_t *>(u.left)[li] = wl_; reinterpret_cast<uint32_t *>(u.right)[li] = wr_;
+        reinterpret_cast<uint32_t *>(u.parent)[li] = wp_; reinterpret_cast<uint32_t *>(u.pop)[li] = wq_;
+      }
+    }
+    if (li < n) { u.time[li] = S.time[li]; u.clv[li] = (int8_t)T.cidx(li); u.pmat[li] = (int8_t)T.pidx(li); }
+    if (li == 0) u.root = T.root;
+  }
+
+  GS2_T(4);
+  // ---- 3. propose (sweep2.hpp), the proposed tree's density, buffer toggles, the node updates children first
+  smp2::Prop pr{0, 0, 0, 0.0};
+  bool ok = false;
+  const smp2::GTree<NT> U = T;
+  const double tsave = S.time[li];
+  if (valid)
+    ok = MODE == 0 ? smp2::propose_gage<NT, false>(T, rng, S.time, (int)A.k, pl, s_anc, s_tau, SP.ft_gage, li, gbase, pr)
+                   : smp2::propose_gspr<NT, false>(T, rng, S.time, (int)A.k, pl, gl_i, s_anc, s_tau, s_lograt, SP.ft_gspr, li, gbase, pr);
+  GS2_T(5);
+  Op opw[NT - 1]; int nops = 0;
+  for (int k = 0; k < NT - 1; ++k) opw[k] = 0;
+  double lp_new = logpr_cur;
+  if (ok)
+  {
+    smp2::wsync();
+    density_counts();
+    if ((pr.chain >> li) & 1u) S.contrib_new[li] = density_term();
+    T.pf ^= pr.brm; T.cf ^= pr.ndm;
+    const double myage = S.time[li];
+    nops = __popc(pr.ndm);
+    {
+      int rank = 0;
+      for (uint32_t m = pr.ndm; m; m &= m - 1)
+      {
+        const int x = __ffs(m) - 1; const double tx = S.time[x];
+        rank += (tx < myage || (tx == myage && x < li)) ? 1 : 0;
+      }
+      const bool mine = (pr.ndm >> li) & 1u;
+#pragma unroll
+      for (int k = 0; k < NT - 1; ++k)
+        if (k < nops)
+        {
+          const int x = __ffs(smp2::gballot<G>(mine && rank == k, gbase)) - 1;
+          const int l = T.left[x], r = T.right[x];
+          opw[k] = make_op(T.cidx(x), T.cidx(l), T.pidx(l), T.cidx(r), T.pidx(r));
+        }
+    }
+    smp2::wsync();
+    double lp = 0;
+    for (int p = 0; p < npop; ++p) lp += ((pr.chain >> p) & 1u) ? S.contrib_new[p] : S.contrib[p];
+    lp_new = lp;
+  }
+  else if (valid) { T = U; S.time[li] = tsave; }
+  smp2::wsync();
+  if (valid && li == 0)
+  {
+    if (ok) { A.logpr_new[i] = lp_new; A.hast[i] = pr.hast; w_nupd += (uint32_t)nops; w_nbr += (uint32_t)__popc(pr.brm); ++w_nev; }
+    A.active[i] = ok ? 1 : 0;
+  }
+
+  GS2_T(6);
+  // ---- 4. the step's records for the engine's kernels (gstep_kernel's step 5): fresh branch j by lane j, node update k by lane k
+  const uint32_t brm = ok ? pr.brm : 0u;
+  const int nbr = __popc(brm);
+  if (valid && A.fmt20)
+  {
+    const uint32_t e0 = i*A.maxmat, o0 = i*A.maxops20;
+    if (li < nbr)
+    {
+      const int x = nth_bit(brm, li);
+      A.mat_task20[e0 + li] = i; A.mat_pm20[e0 + li] = (uint32_t)T.pidx(x);
+      A.mat_length[e0 + li] = (S.time[(int)T.parent[x]] - S.time[x])*1.0;                 // rate_mui = 1 (locus.c:2350)
+    }
+    else if ((uint32_t)li < A.maxmat) A.mat_task20[e0 + li] = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < NT - 1; ++k)
+      if (k < nops && li == k)
+      {
+        const Op w = opw[k];
+        OpDev q;
+        q.parent_clv = (uint32_t)(w & 255u); q.left_clv = (uint32_t)((w >> 8) & 255u); q.left_pmatrix = (uint32_t)((w >> 16) & 255u);
+        q.right_clv = (uint32_t)((w >> 24) & 255u); q.right_pmatrix = (uint32_t)((w >> 32) & 255u);
+        q.parent_scaler = q.left_scaler = q.right_scaler = BPA_SCALE_BUFFER_NONE;
+        A.ops20[o0 + k] = q;
+      }
+    if (li == 0) { A.op_rng20[2*i] = o0; A.op_rng20[2*i + 1] = o0 + (uint32_t)nops; A.root20[i] = (uint32_t)T.cidx(T.root); }
+  }
+  else if (valid)
+  {
+    uint4 * rec = A.recs2 + (size_t)L.slot*A.units;
+    MatRec2 * m2 = A.mat2 + (size_t)L.slot*A.maxmat;
+    double * ml = A.mat_length + (size_t)L.slot*A.maxmat;
+    const uint32_t e0 = L.slot*A.maxmat;
+    if (li == 0)
+    {
+      StepRec h{};
+      h.task = ok ? i : 0xffffffffu; h.pat_off = L.pat_off;
+      h.root_clv = (uint8_t)T.cidx(T.root); h.root_scaler = (int8_t)BPA_SCALE_BUFFER_NONE; h.nops = (uint8_t)nops;
+      *reinterpret_cast<StepRec *>(rec) = h;
+    }
+    if (li < nbr)
+    {
+      const int x = nth_bit(brm, li);
+      m2[li] = MatRec2{L.slot, (uint32_t)T.pidx(x)};
+      ml[li] = (S.time[(int)T.parent[x]] - S.time[x])*1.0;                                // rate_mui = 1 (locus.c:2350)
+    }
+    else if ((uint32_t)li < A.maxmat) m2[li] = MatRec2{0xffffffffu, 0u};                    // entries of the last step this one does not use
+#pragma unroll
+    for (int k = 0; k < NT - 1; ++k)
+      if (k < nops && li == k)
+      {
+        const Op w = opw[k];
+        StepOp q{};
+        q.parent_clv = (uint8_t)(w & 255u); q.left_clv = (uint8_t)((w >> 8) & 255u); q.left_pmatrix = (uint8_t)((w >> 16) & 255u);
+        q.right_clv = (uint8_t)((w >> 24) & 255u); q.right_pmatrix = (uint8_t)((w >> 32) & 255u);
+        q.parent_scaler = q.left_scaler = q.right_scaler = (int8_t)BPA_SCALE_BUFFER_NONE;
+        q.left_e = q.right_e = -1;
+        uint32_t j = 0;
+        for (uint32_t m = brm; m; m &= m - 1, ++j)
+        {
+          const uint32_t pm = (uint32_t)T.pidx(__ffs(m) - 1);
+          if (pm == q.left_pmatrix)  q.left_e = (int32_t)(e0 + j);
+          if (pm == q.right_pmatrix) q.right_e = (int32_t)(e0 + j);
+        }
+        *reinterpret_cast<StepOp *>(rec + 1 + k) = q;
+      }
+  }
+
+  GS2_T(7);
+  // ---- 5. store
+  if (valid)
+  {
+    gsm::GTree & g = A.trees[i];
+    {
+      uint32_t wl_ = 0, wr_ = 0, wp_ = 0, wq_ = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) if (li == k) { wl_ = T.left.w[k]; wr_ = T.right.w[k]; wp_ = T.parent.w[k]; wq_ = T.pop.w[k]; }
+      if (li < W)
+      {
+        reinterpret_cast<uint32_t *>(g.left)[li] = wl_; reinterpret_cast<uint32_t *>(g.right)[li] = wr_;
+        reinterpret_cast<uint32_t *>(g.parent)[li] = wp_; reinterpret_cast<uint32_t *>(g.pop)[li] = wq_;
+      }
+    }
+    if (li < n) { g.time[li] = S.time[li]; g.clv[li] = (int8_t)T.cidx(li); g.pmat[li] = (int8_t)T.pidx(li); }
+    if (li == 0)
+    {
+      g.rng = rng.r; g.root = T.root; g.lnl = lnl_cur; g.logpr = logpr_cur; g.proposals = nprop; g.accepted = nacc;
+      g.work_nupd = w_nupd; g.work_nbr = w_nbr; g.work_neval = w_nev;
+    }
+  }
+#ifdef GS2_PROF
+  __builtin_amdgcn_s_waitcnt(0); GS2_T(8);
+  if (valid && li == 0) { A.delta[i] = (double)(tp_[1 + (i & 7u)] - tp_[0]); A.lnl_cur[i] = (double)(tp_[(i & 1u) ? 8 : 0] & 0xffffffffffffull); }
+#endif
+}
+
+} // namespace gsm2

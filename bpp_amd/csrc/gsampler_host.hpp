@@ -210,11 +210,123 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   // a frequency / exchangeability step — proposed now, or rolled back now for the loci that rejected it — leaves
   // parameter blocks whose eigensystems are stale: refreshed before the next evaluation (gs_eval)
   if (mode == 6 || mode == 7 || (s->g_pend == 4 && (s->g_pend_mode == 6 || s->g_pend_mode == 7))) s->g_eigen_dirty = true;
+  // diagnostics (BPA_GS_DIFF=1): a GAGE / GSPR step by both kernels from the same state, whatever differs is reported;
+  // the run goes on with the one-lane kernel's result
+  static const bool gs_diff = getenv("BPA_GS_DIFF") != nullptr;
+  if (gs_diff && mode <= 1 && !s->g_forked)
+  {
+    const unsigned n = s->nloci;
+    std::vector<gsm::GTree> t0(n), u0(n), t2(n), u2(n), t1(n), u1(n);
+    std::vector<double> lp2(n), h2(n), lp1(n), h1(n); std::vector<uint8_t> a2(n), a1(n);
+    const size_t nrec = (size_t)e->pack_slots*s->g_units, nmat = (size_t)e->pack_slots*s->g_maxmat;
+    std::vector<uint4> r2(nrec), r1(nrec); std::vector<MatRec2> m2(nmat), m1(nmat); std::vector<double> l2(nmat), l1(nmat);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(t0.data(), s->g_dev.p, n*sizeof(gsm::GTree), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(u0.data(), s->g_undo.p, n*sizeof(gsm::GTree), hipMemcpyDeviceToHost));
+    std::vector<double> lp0(n), h0(n); std::vector<uint8_t> a0(n);             // the step reads the last step's, then writes its own
+    HIPCHK(hipMemcpy(lp0.data(), s->g_logpr.p, n*sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h0.data(), s->g_hast.p, n*sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(a0.data(), s->g_active.p, n, hipMemcpyDeviceToHost));
+    a.i0 = 0; a.iend = n;
+    for (int pass = 0; pass < 2; ++pass)
+    {
+      if (pass == 0)
+      {
+        const unsigned lpw = s->maxtips <= 8 ? 4u : 2u;
+        const dim3 g2((n + lpw - 1)/lpw), b2(64);
+        if (s->maxtips <= 8) { if (a.mode == 0) hipLaunchKernelGGL((gsm2::gstep2_kernel<0, 8>), g2, b2, 0, e->stream, a); else hipLaunchKernelGGL((gsm2::gstep2_kernel<1, 8>), g2, b2, 0, e->stream, a); }
+        else                 { if (a.mode == 0) hipLaunchKernelGGL((gsm2::gstep2_kernel<0, 16>), g2, b2, 0, e->stream, a); else hipLaunchKernelGGL((gsm2::gstep2_kernel<1, 16>), g2, b2, 0, e->stream, a); }
+      }
+      else
+      {
+        HIPCHK(hipMemcpy(s->g_dev.p, t0.data(), n*sizeof(gsm::GTree), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->g_undo.p, u0.data(), n*sizeof(gsm::GTree), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->g_logpr.p, lp0.data(), n*sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->g_hast.p, h0.data(), n*sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->g_active.p, a0.data(), n, hipMemcpyHostToDevice));
+        const dim3 grid((n + gsm::GBS - 1)/gsm::GBS), block(gsm::GBS);
+        if (s->maxtips <= 8) { if (a.mode == 0) hipLaunchKernelGGL((gsm::gstep_kernel<0, 8>), grid, block, 0, e->stream, a); else hipLaunchKernelGGL((gsm::gstep_kernel<1, 8>), grid, block, 0, e->stream, a); }
+        else                 { if (a.mode == 0) hipLaunchKernelGGL((gsm::gstep_kernel<0, 16>), grid, block, 0, e->stream, a); else hipLaunchKernelGGL((gsm::gstep_kernel<1, 16>), grid, block, 0, e->stream, a); }
+      }
+      HIPCHK(hipStreamSynchronize(e->stream));
+      HIPCHK(hipMemcpy((pass ? t1 : t2).data(), s->g_dev.p, n*sizeof(gsm::GTree), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy((pass ? u1 : u2).data(), s->g_undo.p, n*sizeof(gsm::GTree), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy((pass ? lp1 : lp2).data(), s->g_logpr.p, n*sizeof(double), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy((pass ? h1 : h2).data(), s->g_hast.p, n*sizeof(double), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy((pass ? a1 : a2).data(), s->g_active.p, n, hipMemcpyDeviceToHost));
+      if (!s->g_s20)
+      {
+        HIPCHK(hipMemcpy((pass ? r1 : r2).data(), s->g_recs.p, nrec*sizeof(uint4), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy((pass ? m1 : m2).data(), s->g_mat2.p, nmat*sizeof(MatRec2), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy((pass ? l1 : l2).data(), s->g_len.p, nmat*sizeof(double), hipMemcpyDeviceToHost));
+      }
+    }
+    int shown = 0;
+    auto dump = [&](const char * name, const gsm::GTree & g)
+    {
+      const int nn = 2*g.tips - 1;
+      fprintf(stderr, "   %s root %d tips %d lnl %.17g logpr %.17g rng %llx prop %u acc %u\n", name, g.root, g.tips, g.lnl, g.logpr, (unsigned long long)g.rng, g.proposals, g.accepted);
+      for (int k = 0; k < nn && k < gsm::NN; ++k)
+        fprintf(stderr, "     %2d l %3d r %3d p %3d clv %3d pm %3d pop %3d t %.17g\n", k, g.left[k], g.right[k], g.parent[k], g.clv[k], g.pmat[k], g.pop[k], g.time[k]);
+    };
+    auto tree_differs = [&](const gsm::GTree & x, const gsm::GTree & y, bool head)
+    {
+      const int m = 2*y.tips - 1;
+      bool d = x.root != y.root;
+      if (head) d = d || x.tips != y.tips || x.lnl != y.lnl || x.logpr != y.logpr || x.rng != y.rng || x.proposals != y.proposals || x.accepted != y.accepted
+                      || x.work_nupd != y.work_nupd || x.work_nbr != y.work_nbr || x.work_neval != y.work_neval;
+      for (int k = 0; k < m && k < gsm::NN; ++k)
+        d = d || x.left[k] != y.left[k] || x.right[k] != y.right[k] || x.parent[k] != y.parent[k] || x.clv[k] != y.clv[k] || x.pmat[k] != y.pmat[k]
+              || x.pop[k] != y.pop[k] || x.time[k] != y.time[k];
+      return d;
+    };
+    for (unsigned i = 0; i < n; ++i)
+    {
+      gsm::GTree uu2 = u2[i], uu1 = u1[i]; uu2.tips = uu1.tips = t1[i].tips;
+      const bool dt = tree_differs(t2[i], t1[i], true), du = tree_differs(uu2, uu1, false);
+      const bool da = a2[i] != a1[i], dl = a1[i] && (lp2[i] != lp1[i] || h2[i] != h1[i]);
+      if ((dt || du || da || dl) && shown++ < 3)
+      {
+        fprintf(stderr, "[gs diff] mode %u k %u pend %u locus %u: tree %d undo %d active %d/%d logpr %.17g/%.17g hast %.17g/%.17g\n", mode, k, a.pend, i,
+                (int)dt, (int)du, (int)a2[i], (int)a1[i], lp2[i], lp1[i], h2[i], h1[i]);
+        dump("before ", t0[i]); dump("group  ", t2[i]); dump("one    ", t1[i]);
+        if (du) { dump("undo g ", uu2); dump("undo 1 ", uu1); }
+      }
+    }
+    if (!s->g_s20)
+    {
+      int nr = 0;
+      for (size_t q = 0; q < nrec; ++q)
+        if (memcmp(&r2[q], &r1[q], sizeof(uint4)) && nr++ < 4)
+          fprintf(stderr, "[gs diff] mode %u k %u rec slot %zu unit %zu: %08x %08x %08x %08x / %08x %08x %08x %08x\n", mode, k, q/s->g_units, q % s->g_units,
+                  r2[q].x, r2[q].y, r2[q].z, r2[q].w, r1[q].x, r1[q].y, r1[q].z, r1[q].w);
+      for (size_t q = 0; q < nmat; ++q)
+        if ((m2[q].slot != m1[q].slot || (m1[q].slot != 0xffffffffu && (m2[q].pmatrix != m1[q].pmatrix || l2[q] != l1[q]))) && nr++ < 8)
+          fprintf(stderr, "[gs diff] mode %u k %u mat slot %zu entry %zu: %x %u %.17g / %x %u %.17g\n", mode, k, q/s->g_maxmat, q % s->g_maxmat,
+                  m2[q].slot, m2[q].pmatrix, l2[q], m1[q].slot, m1[q].pmatrix, l1[q]);
+      if (nr) shown += nr;
+    }
+    fprintf(stderr, "[gs diff] mode %u k %u pend %u: %d differences\n", mode, k, a.pend, shown);
+    s->launches++;
+    s->g_pend = 1u; s->g_pend_mode = mode; s->g_pend_k = k;
+    return 1;
+  }
   for (int h = 0; h < (s->g_forked ? 2 : 1); ++h)
   {
     a.i0 = h ? s->g_isplit : 0u; a.iend = s->g_forked && !h ? s->g_isplit : s->nloci;
     const dim3 grid((a.iend - a.i0 + gsm::GBS - 1)/gsm::GBS), block(gsm::GBS);
     hipStream_t st = h ? s->g_stream2 : e->stream;
+    // GAGE / GSPR: a group of lanes per locus (gsampler2.hpp; BPA_GS_V1=1: the one-lane-per-locus kernel)
+    static const bool gs_v1 = getenv("BPA_GS_V1") != nullptr;
+    if (a.mode <= 1 && !gs_v1)
+    {
+      const unsigned lpw = s->maxtips <= 8 ? 4u : 2u;
+      const dim3 g2((a.iend - a.i0 + lpw - 1)/lpw), b2(64);
+      if (s->maxtips <= 8) { if (a.mode == 0) hipLaunchKernelGGL((gsm2::gstep2_kernel<0, 8>), g2, b2, 0, st, a); else hipLaunchKernelGGL((gsm2::gstep2_kernel<1, 8>), g2, b2, 0, st, a); }
+      else                 { if (a.mode == 0) hipLaunchKernelGGL((gsm2::gstep2_kernel<0, 16>), g2, b2, 0, st, a); else hipLaunchKernelGGL((gsm2::gstep2_kernel<1, 16>), g2, b2, 0, st, a); }
+      s->launches++;
+      continue;
+    }
     switch (a.mode)
     {
 #define GS_CASE(M_) case M_: if (s->maxtips <= 8) hipLaunchKernelGGL((gsm::gstep_kernel<M_, 8>), grid, block, 0, st, a); \
@@ -233,6 +345,20 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
     if (s->g_forked) HIPCHK(hipStreamSynchronize(s->g_stream2));
     fprintf(stderr, "[gs] step mode %u k %u pend %u done\n", mode, k, a.pend);
   }
+#ifdef GS2_PROF
+  if (mode <= 1)
+  {
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<double> d(s->nloci), c(s->nloci);
+    HIPCHK(hipMemcpy(d.data(), s->g_delta.p, s->nloci*sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c.data(), s->g_lnlcur.p, s->nloci*sizeof(double), hipMemcpyDeviceToHost));
+    double sum[8] = {0}; int cnt[8] = {0}; double t0 = 1e300, t1 = 0;
+    for (unsigned i = 0; i < s->nloci; ++i) { sum[i & 7] += d[i]; cnt[i & 7]++; if (i & 1) t1 = std::max(t1, c[i]); else t0 = std::min(t0, c[i]); }
+    fprintf(stderr, "[gs2 prof] mode %u k %u: phases (us)", mode, k);
+    for (int q = 0; q < 8; ++q) fprintf(stderr, " %.2f", cnt[q] ? sum[q]/cnt[q]*0.01 : 0.0);
+    fprintf(stderr, "  first start -> last end %.2f us\n", (t1 - t0)*0.01);
+  }
+#endif
   s->g_pend = mode <= 1 ? 1u : (mode == 2 || mode == 3) ? 2u : mode == 5 ? 3u : mode >= 6 ? 4u : 0u;
   s->g_pend_mode = mode; s->g_pend_k = k;
   return 1;

@@ -1084,6 +1084,7 @@ __global__ void __launch_bounds__(1024) theta_sum_decide_kernel(const int8_t * _
 
 #include "sweep2.hpp"
 #include "gsampler.hpp"
+#include "gsampler2.hpp"
 #include "bigsampler.hpp"
 
 // ------------------------------------------------------------------------------------ host ---

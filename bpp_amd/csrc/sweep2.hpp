@@ -34,7 +34,7 @@ using smp::rndu; using smp::reflect; using smp::msc_term; using smp::nth_bit; us
 
 template <int NT> struct Cfg
 {
-  static constexpr int G     = NT <= 4 ? 8 : 16;     // lanes per locus = node slots = population slots
+  static constexpr int G     = NT <= 4 ? 8 : NT <= 8 ? 16 : 32;     // lanes per locus = node slots = population slots (32: the generic sampler's group proposals, gsampler2.hpp)
   static constexpr int LPW   = 64/G;                 // loci per wave
   static constexpr int NN    = 2*NT;                 // node slots (2 NT - 1 nodes)
   static constexpr int W     = NN/4;                 // 32-bit words of a byte array
@@ -135,7 +135,7 @@ template <int NT> struct WgLDS : WgBase
 
 template <int G> __device__ __forceinline__ uint32_t gballot(bool p, uint32_t gbase)
 {
-  return (uint32_t)(__ballot(p) >> gbase) & ((1u << G) - 1u);
+  return (uint32_t)(__ballot(p) >> gbase) & (G >= 32 ? 0xffffffffu : ((1u << (G & 31)) - 1u));
 }
 // LDS traffic between the lanes of ONE wave: the hardware runs a wave's DS instructions in order; this keeps the
 // compiler from moving accesses across the hand-over
