@@ -370,9 +370,10 @@ def run_config1(eng, iters=12):
                acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
                reference_program="BASELINE.md: the unmodified program on this example, one thread: ~270 iterations/s on the survey container "
                                  "(690 on this box's host: tools/bench_bpp_hip.py, round 2)",
-               note="five loci are no work for a GPU: every proposal step of an iteration (tips - 1 ages, 2 tips - 2 prunings, the "
-                    "all-loci steps) is a handful of dependent launches over 5 lanes — the lock-step batched form pays off from "
-                    "thousands of loci on (configs 2-4); here it shows that the device path covers the reference's own example")
+               note="five loci are no work for a GPU: ~107 us of every ~130 us step is the proposal code of ONE lane per locus (measured "
+                    "inside a one-launch-per-call variant that ran at the same 42 it/s: profiles/r4/c1_resident_phases.txt), not the 730 "
+                    "launches; a host core does such a step in 1.6 us.  The lock-step batched form pays off from thousands of loci on "
+                    "(configs 2-4); here it shows that the device path covers the reference's own example")
     smp.close()
     return out
 
@@ -511,7 +512,7 @@ def scale_projection(key, cfg, data, args, shares=(2, 4, 8)):
             e = bpp_amd.Engine(0, None)
             a2 = argparse.Namespace(**vars(args))
             a2.loci = len(sub)
-            r = run_sampler(e, cfg, sub, make_loci(e, sub), a2, None, 0, 6 if cfg["model"] != "jc69" else 40, 1 if cfg["model"] != "jc69" else 5)
+            r = run_sampler(e, cfg, sub, make_loci(e, sub), a2, None, 0, args.projection_iters if cfg["model"] != "jc69" else 40, 3 if cfg["model"] != "jc69" else 5)
             out[str(n)] = dict(loci_on_rank0=len(sub), iterations_per_s=r["iterations_per_s"], ms_per_iteration=r["ms_per_iteration"], implementation_kind=r.get("kind"))
             e.close()
         except Exception as ex:       # noqa: BLE001
@@ -1140,6 +1141,7 @@ def main():
     ap.add_argument("--no-bpp-program", action="store_true",
                     help="skip timing the unmodified reference program (thread sweep) on the host cores")
     ap.add_argument("--no-scale-projection", action="store_true", help="skip the one-GPU measurements of the per-rank shares of N = 2, 4, 8")
+    ap.add_argument("--projection-iters", type=int, default=20, help="iterations timed per share of the scale projection (c3 / c4)")
     ap.add_argument("--no-uniform-kernel", action="store_true", help="c2: skip the companion run with the library's uniform-window moves")
     ap.add_argument("--no-timing-events", action="store_true")
     ap.add_argument("--p2p-sums", action="store_true",

@@ -38,11 +38,44 @@ _BIG_SETS = {"test_gpu_fullsize.py::test_full_size_properties[C2": (10000, 1000,
              "test_gpu_fullsize.py::test_full_size_properties[C4": (2000, 500, 6, "lg", 4, 777, 3.0),
              "test_gpu_tape.py::test_chain_launch_equals_step_by_step[4-False-10000]": (10000, 500, 4, "jc69", 1, 33, 1.0)}
 _bg = []
+_program_runs = {}          # the whole-program runs of test_gpu_bpp_hip.py, started at collection (see its fixture)
+
+
+def pytest_collection_modifyitems(session, config, items):
+    # the whole-program module goes last: its ~30 runs of `bpp` / `bpp_hip` (subprocesses, started below when the
+    # collection is done) then overlap the rest of the session instead of being 30 s of waiting of their own
+    last = [it for it in items if it.nodeid.split("::")[0].endswith("test_gpu_bpp_hip.py")]
+    if last and len(last) < len(items):
+        items[:] = [it for it in items if it not in last] + last
+
+
+def _start_program_runs(session):
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    items = [it for it in session.items if it.nodeid.split("::")[0].endswith("test_gpu_bpp_hip.py")]
+    if not items or _program_runs or any(it.get_closest_marker("skipif") and it.get_closest_marker("skipif").args[0] for it in items):
+        return
+
+    def dry(it):
+        try:
+            it.obj(**(it.callspec.params if hasattr(it, "callspec") else {}))
+        except BaseException:      # noqa: BLE001  (the test proper reports it)
+            pass
+
+    def run():
+        with ThreadPoolExecutor(max_workers=8 if len(session.items) > len(items) else 12) as ex:
+            list(ex.map(dry, items))
+    t = threading.Thread(target=run, daemon=True)
+    _program_runs["thread"] = t
+    t.start()
 
 
 def pytest_collection_finish(session):
     import subprocess
     import tempfile
+    if session.config.getoption("collectonly", False):
+        return
+    _start_program_runs(session)
     want = [a for k, a in _BIG_SETS.items() if any(k in it.nodeid for it in session.items)]
     if not want or len(session.items) < 8:
         return

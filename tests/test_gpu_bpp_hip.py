@@ -22,19 +22,17 @@ ANOPH = {"loci_realign.txt": os.path.join(G, "anopheles", "loci_realign.txt"), "
 
 @pytest.fixture(scope="module", autouse=True)
 def all_program_runs_side_by_side(request):
-    """every run of `bpp` / `bpp_hip` this module's selected tests will ask for, started together (six tests' worth at a
-    time: the runs share nothing, one at a time they are 70 s of mostly waiting) — each test function is called once here
-    with its assertions ignored, its runs are remembered by tests/bpphip.py, and the test proper then reads them"""
-    from concurrent.futures import ThreadPoolExecutor
-    items = [it for it in request.session.items if getattr(it, "module", None) is request.module]
-
-    def dry(it):
-        try:
-            it.obj(**(it.callspec.params if hasattr(it, "callspec") else {}))
-        except BaseException:      # noqa: BLE001  (the test proper reports it)
-            pass
-    with ThreadPoolExecutor(max_workers=12) as ex:
-        list(ex.map(dry, items))
+    """every run of `bpp` / `bpp_hip` this module's selected tests will ask for, started together (the runs share nothing,
+    one at a time they are 70 s of mostly waiting) — each test function is called once with its assertions ignored, its
+    runs are remembered by tests/bpphip.py, and the test proper then reads them.  tests/conftest.py starts this when the
+    collection is done and runs this module last, so the runs overlap the rest of the session; here they are waited for."""
+    import conftest
+    t = conftest._program_runs.get("thread")
+    if t is None:
+        conftest._start_program_runs(request.session)
+        t = conftest._program_runs.get("thread")
+    if t is not None:
+        t.join()
     yield
 
 
