@@ -6,10 +6,10 @@
 // and the proposal is sweep2.hpp's: the integer tree replicated in every lane's registers (byte arrays), lane i = node i,
 // population i, branch i; loops over nodes and populations are ballots restricted to the group (propose_gage /
 // propose_gspr of sweep2.hpp, the persistent kernel's own functions: same streams, same draws, same arithmetic as the host
-// driver — tests/test_gpu_gsampler.py walks its trajectory).  Everything around the proposal is gstep_kernel's, statement for
+// driver — tests/test_gpu_gsampler.py walks its trajectory); TAU and MIX are sweep2.hpp's step_locus.  Everything around the proposal is gstep_kernel's, statement for
 // statement: the previous step is settled first (its decision, or the roll-back from the undo copy), the state a rejection
 // comes back to is saved, the step is written as the records of the engine's kernels (StepRec / StepOp / MatRec2, or the
-// 20-state kernels' OpDev ranges), the tree goes back to HBM.  The other modes (TAU, MIX, settle, start-up, the
+// 20-state kernels' OpDev ranges), the tree goes back to HBM.  The other modes (settle + THETA statistics, start-up, the
 // substitution-parameter moves) stay with gstep_kernel.
 #pragma once
 
@@ -25,7 +25,7 @@ template <int NT> struct LocLDS
 template <uint32_t MODE, int NT>
 __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
 {
-  static_assert(MODE <= 1, "GAGE and GSPR");
+  static_assert(MODE <= 3, "GAGE, GSPR, TAU, MIX");
   using C = smp2::Cfg<NT>;
   constexpr int G = C::G, LPW = C::LPW, NN = C::NN, W = C::W;
   __shared__ LocLDS<NT> s_loc[LPW];
@@ -229,22 +229,67 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
   bool ok = false;
   const smp2::GTree<NT> U = T;
   const double tsave = S.time[li];
-  if (valid)
-    ok = MODE == 0 ? smp2::propose_gage<NT, false>(T, rng, S.time, (int)A.k, pl, s_anc, s_tau, SP.ft_gage, li, gbase, pr)
-                   : smp2::propose_gspr<NT, false>(T, rng, S.time, (int)A.k, pl, gl_i, s_anc, s_tau, s_lograt, SP.ft_gspr, li, gbase, pr);
+  int above = 0, below = 0;
+  double lminf = 0, lmaxf = 0;
+  if (MODE <= 1)
+  {
+    if (valid)
+      ok = MODE == 0 ? smp2::propose_gage<NT, false>(T, rng, S.time, (int)A.k, pl, s_anc, s_tau, SP.ft_gage, li, gbase, pr)
+                     : smp2::propose_gspr<NT, false>(T, rng, S.time, (int)A.k, pl, gl_i, s_anc, s_tau, s_lograt, SP.ft_gspr, li, gbase, pr);
+  }
+  else if (valid)
+  {
+    // an all-loci step (sweep2.hpp's step_locus): the proposed species tree in the lanes' registers, every population's term
+    pr.chain = (1u << npop) - 1u;
+    if (MODE == 2)
+    {
+      // TAU q (tau_step of a00_driver.c): the gene nodes of q and its children between the bounds ride the rubber band
+      const int q = (int)A.tau_q, pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
+      const double tq_old = s_tau[q], tq_lo = fmax(s_tau[cl], s_tau[cr]), tq_hi = pq >= 0 ? s_tau[pq] : 999.0;
+      const double tnew = smp::reflect(tq_old + SP.ft_tau*(A.tau_u - 0.5), tq_lo, tq_hi);
+      const double minf = (tnew - tq_lo)/(tq_old - tq_lo), maxf = (tnew - tq_hi)/(tq_old - tq_hi);
+      lminf = log(minf); lmaxf = log(maxf);
+      if (li == q) pl.tau = tnew;
+      if (pl.parent == q) pl.ptau = tnew;
+      const int pk = T.pop[li];
+      const bool moved = inner_i && (pk == q || pk == cl || pk == cr) && !(tsave < tq_lo || tsave > tq_hi);
+      const bool up = moved && tsave >= tq_old;
+      if (moved) S.time[li] = up ? tq_hi + maxf*(tsave - tq_hi) : tq_lo + minf*(tsave - tq_lo);
+      const uint32_t mm = smp2::gballot<G>(moved, gbase);
+      above = __popc(smp2::gballot<G>(up, gbase)); below = __popc(mm) - above;
+      const int par = T.parent[li];
+      pr.brm = smp2::gballot<G>(li < n && par >= 0 && (((mm >> li) & 1u) || ((mm >> (par & 31)) & 1u)), gbase);
+      uint32_t m = mm;
+      const int l = T.left[li], r = T.right[li];
+#pragma unroll
+      for (int d = 0; d < NT - 2; ++d) m |= smp2::gballot<G>(inner_i && (((m >> (l & 31)) & 1u) || ((m >> (r & 31)) & 1u)), gbase);
+      pr.ndm = m;
+    }
+    else
+    {
+      // mixing (mix_step of a00_driver.c): every tau, every age times c
+      pl.tau *= A.mix_c;
+      if (pl.parent >= 0) pl.ptau *= A.mix_c;
+      if (inner_i) S.time[li] = tsave*A.mix_c;
+      pr.ndm = smp2::gballot<G>(inner_i, gbase);
+      pr.brm = smp2::gballot<G>(li < n && (int)T.parent[li] >= 0, gbase);
+    }
+    ok = pr.ndm != 0;                      // no gene node moves here: only the density changes
+  }
   GS2_T(5);
   Op opw[NT - 1]; int nops = 0;
   for (int k = 0; k < NT - 1; ++k) opw[k] = 0;
   double lp_new = logpr_cur;
-  if (ok)
+  if (ok || (MODE >= 2 && valid))
   {
     smp2::wsync();
     density_counts();
     if ((pr.chain >> li) & 1u) S.contrib_new[li] = density_term();
-    T.pf ^= pr.brm; T.cf ^= pr.ndm;
-    const double myage = S.time[li];
-    nops = __popc(pr.ndm);
+    if (ok)
     {
+      T.pf ^= pr.brm; T.cf ^= pr.ndm;
+      const double myage = S.time[li];
+      nops = __popc(pr.ndm);
       int rank = 0;
       for (uint32_t m = pr.ndm; m; m &= m - 1)
       {
@@ -270,7 +315,14 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
   smp2::wsync();
   if (valid && li == 0)
   {
-    if (ok) { A.logpr_new[i] = lp_new; A.hast[i] = pr.hast; w_nupd += (uint32_t)nops; w_nbr += (uint32_t)__popc(pr.brm); ++w_nev; }
+    if (MODE <= 1) { if (ok) { A.logpr_new[i] = lp_new; A.hast[i] = pr.hast; } }
+    else
+    {
+      A.logpr_new[i] = lp_new;
+      A.delta[i] = MODE == 2 ? ((lp_new - logpr_cur) + below*lminf) + above*lmaxf : (lp_new - logpr_cur) + (double)(tips - 1)*A.mix_lnc;       // p_delta of the host driver
+      A.lnl_cur[i] = lnl_cur;
+    }
+    if (ok) { w_nupd += (uint32_t)nops; w_nbr += (uint32_t)__popc(pr.brm); ++w_nev; }
     A.active[i] = ok ? 1 : 0;
   }
 

@@ -212,12 +212,22 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   if (mode == 6 || mode == 7 || (s->g_pend == 4 && (s->g_pend_mode == 6 || s->g_pend_mode == 7))) s->g_eigen_dirty = true;
   // diagnostics (BPA_GS_DIFF=1): a GAGE / GSPR step by both kernels from the same state, whatever differs is reported;
   // the run goes on with the one-lane kernel's result
+#define GS2_LAUNCH(GRID_, ST_) do { \
+    if (s->maxtips <= 8) switch (a.mode) { case 0: hipLaunchKernelGGL((gsm2::gstep2_kernel<0, 8>), GRID_, dim3(64), 0, ST_, a); break; case 1: hipLaunchKernelGGL((gsm2::gstep2_kernel<1, 8>), GRID_, dim3(64), 0, ST_, a); break; \
+                                           case 2: hipLaunchKernelGGL((gsm2::gstep2_kernel<2, 8>), GRID_, dim3(64), 0, ST_, a); break; default: hipLaunchKernelGGL((gsm2::gstep2_kernel<3, 8>), GRID_, dim3(64), 0, ST_, a); break; } \
+    else switch (a.mode) { case 0: hipLaunchKernelGGL((gsm2::gstep2_kernel<0, 16>), GRID_, dim3(64), 0, ST_, a); break; case 1: hipLaunchKernelGGL((gsm2::gstep2_kernel<1, 16>), GRID_, dim3(64), 0, ST_, a); break; \
+                           case 2: hipLaunchKernelGGL((gsm2::gstep2_kernel<2, 16>), GRID_, dim3(64), 0, ST_, a); break; default: hipLaunchKernelGGL((gsm2::gstep2_kernel<3, 16>), GRID_, dim3(64), 0, ST_, a); break; } } while (0)
+#define GS1_LAUNCH(GRID_, ST_) do { \
+    if (s->maxtips <= 8) switch (a.mode) { case 0: hipLaunchKernelGGL((gsm::gstep_kernel<0, 8>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; case 1: hipLaunchKernelGGL((gsm::gstep_kernel<1, 8>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; \
+                                           case 2: hipLaunchKernelGGL((gsm::gstep_kernel<2, 8>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; default: hipLaunchKernelGGL((gsm::gstep_kernel<3, 8>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; } \
+    else switch (a.mode) { case 0: hipLaunchKernelGGL((gsm::gstep_kernel<0, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; case 1: hipLaunchKernelGGL((gsm::gstep_kernel<1, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; \
+                           case 2: hipLaunchKernelGGL((gsm::gstep_kernel<2, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; default: hipLaunchKernelGGL((gsm::gstep_kernel<3, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; } } while (0)
   static const bool gs_diff = getenv("BPA_GS_DIFF") != nullptr;
-  if (gs_diff && mode <= 1 && !s->g_forked)
+  if (gs_diff && mode <= 3 && !s->g_forked)
   {
     const unsigned n = s->nloci;
     std::vector<gsm::GTree> t0(n), u0(n), t2(n), u2(n), t1(n), u1(n);
-    std::vector<double> lp2(n), h2(n), lp1(n), h1(n); std::vector<uint8_t> a2(n), a1(n);
+    std::vector<double> lp2(n), h2(n), lp1(n), h1(n), dd1(n), dd2(n), lc1(n), lc2(n); std::vector<uint8_t> a2(n), a1(n);
     const size_t nrec = (size_t)e->pack_slots*s->g_units, nmat = (size_t)e->pack_slots*s->g_maxmat;
     std::vector<uint4> r2(nrec), r1(nrec); std::vector<MatRec2> m2(nmat), m1(nmat); std::vector<double> l2(nmat), l1(nmat);
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -233,9 +243,7 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
       if (pass == 0)
       {
         const unsigned lpw = s->maxtips <= 8 ? 4u : 2u;
-        const dim3 g2((n + lpw - 1)/lpw), b2(64);
-        if (s->maxtips <= 8) { if (a.mode == 0) hipLaunchKernelGGL((gsm2::gstep2_kernel<0, 8>), g2, b2, 0, e->stream, a); else hipLaunchKernelGGL((gsm2::gstep2_kernel<1, 8>), g2, b2, 0, e->stream, a); }
-        else                 { if (a.mode == 0) hipLaunchKernelGGL((gsm2::gstep2_kernel<0, 16>), g2, b2, 0, e->stream, a); else hipLaunchKernelGGL((gsm2::gstep2_kernel<1, 16>), g2, b2, 0, e->stream, a); }
+        GS2_LAUNCH(dim3((n + lpw - 1)/lpw), e->stream);
       }
       else
       {
@@ -244,9 +252,7 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
         HIPCHK(hipMemcpy(s->g_logpr.p, lp0.data(), n*sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(s->g_hast.p, h0.data(), n*sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(s->g_active.p, a0.data(), n, hipMemcpyHostToDevice));
-        const dim3 grid((n + gsm::GBS - 1)/gsm::GBS), block(gsm::GBS);
-        if (s->maxtips <= 8) { if (a.mode == 0) hipLaunchKernelGGL((gsm::gstep_kernel<0, 8>), grid, block, 0, e->stream, a); else hipLaunchKernelGGL((gsm::gstep_kernel<1, 8>), grid, block, 0, e->stream, a); }
-        else                 { if (a.mode == 0) hipLaunchKernelGGL((gsm::gstep_kernel<0, 16>), grid, block, 0, e->stream, a); else hipLaunchKernelGGL((gsm::gstep_kernel<1, 16>), grid, block, 0, e->stream, a); }
+        GS1_LAUNCH(dim3((n + gsm::GBS - 1)/gsm::GBS), e->stream);
       }
       HIPCHK(hipStreamSynchronize(e->stream));
       HIPCHK(hipMemcpy((pass ? t1 : t2).data(), s->g_dev.p, n*sizeof(gsm::GTree), hipMemcpyDeviceToHost));
@@ -254,6 +260,11 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
       HIPCHK(hipMemcpy((pass ? lp1 : lp2).data(), s->g_logpr.p, n*sizeof(double), hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy((pass ? h1 : h2).data(), s->g_hast.p, n*sizeof(double), hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy((pass ? a1 : a2).data(), s->g_active.p, n, hipMemcpyDeviceToHost));
+      if (mode >= 2)
+      {
+        HIPCHK(hipMemcpy((pass ? dd1 : dd2).data(), s->g_delta.p, n*sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy((pass ? lc1 : lc2).data(), s->g_lnlcur.p, n*sizeof(double), hipMemcpyDeviceToHost));
+      }
       if (!s->g_s20)
       {
         HIPCHK(hipMemcpy((pass ? r1 : r2).data(), s->g_recs.p, nrec*sizeof(uint4), hipMemcpyDeviceToHost));
@@ -284,11 +295,11 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
     {
       gsm::GTree uu2 = u2[i], uu1 = u1[i]; uu2.tips = uu1.tips = t1[i].tips;
       const bool dt = tree_differs(t2[i], t1[i], true), du = tree_differs(uu2, uu1, false);
-      const bool da = a2[i] != a1[i], dl = a1[i] && (lp2[i] != lp1[i] || h2[i] != h1[i]);
+      const bool da = a2[i] != a1[i], dl = (a1[i] && (lp2[i] != lp1[i] || h2[i] != h1[i])) || (mode >= 2 && (lp2[i] != lp1[i] || dd2[i] != dd1[i] || lc2[i] != lc1[i]));
       if ((dt || du || da || dl) && shown++ < 3)
       {
-        fprintf(stderr, "[gs diff] mode %u k %u pend %u locus %u: tree %d undo %d active %d/%d logpr %.17g/%.17g hast %.17g/%.17g\n", mode, k, a.pend, i,
-                (int)dt, (int)du, (int)a2[i], (int)a1[i], lp2[i], lp1[i], h2[i], h1[i]);
+        fprintf(stderr, "[gs diff] mode %u k %u pend %u locus %u: tree %d undo %d active %d/%d logpr %.17g/%.17g hast %.17g/%.17g delta %.17g/%.17g\n", mode, k, a.pend, i,
+                (int)dt, (int)du, (int)a2[i], (int)a1[i], lp2[i], lp1[i], h2[i], h1[i], dd2[i], dd1[i]);
         dump("before ", t0[i]); dump("group  ", t2[i]); dump("one    ", t1[i]);
         if (du) { dump("undo g ", uu2); dump("undo 1 ", uu1); }
       }
@@ -308,7 +319,7 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
     }
     fprintf(stderr, "[gs diff] mode %u k %u pend %u: %d differences\n", mode, k, a.pend, shown);
     s->launches++;
-    s->g_pend = 1u; s->g_pend_mode = mode; s->g_pend_k = k;
+    s->g_pend = mode <= 1 ? 1u : 2u; s->g_pend_mode = mode; s->g_pend_k = k;
     return 1;
   }
   for (int h = 0; h < (s->g_forked ? 2 : 1); ++h)
@@ -316,14 +327,12 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
     a.i0 = h ? s->g_isplit : 0u; a.iend = s->g_forked && !h ? s->g_isplit : s->nloci;
     const dim3 grid((a.iend - a.i0 + gsm::GBS - 1)/gsm::GBS), block(gsm::GBS);
     hipStream_t st = h ? s->g_stream2 : e->stream;
-    // GAGE / GSPR: a group of lanes per locus (gsampler2.hpp; BPA_GS_V1=1: the one-lane-per-locus kernel)
+    // GAGE / GSPR / TAU / MIX: a group of lanes per locus (gsampler2.hpp; BPA_GS_V1=1: the one-lane-per-locus kernel)
     static const bool gs_v1 = getenv("BPA_GS_V1") != nullptr;
-    if (a.mode <= 1 && !gs_v1)
+    if (a.mode <= 3 && !gs_v1)
     {
       const unsigned lpw = s->maxtips <= 8 ? 4u : 2u;
-      const dim3 g2((a.iend - a.i0 + lpw - 1)/lpw), b2(64);
-      if (s->maxtips <= 8) { if (a.mode == 0) hipLaunchKernelGGL((gsm2::gstep2_kernel<0, 8>), g2, b2, 0, st, a); else hipLaunchKernelGGL((gsm2::gstep2_kernel<1, 8>), g2, b2, 0, st, a); }
-      else                 { if (a.mode == 0) hipLaunchKernelGGL((gsm2::gstep2_kernel<0, 16>), g2, b2, 0, st, a); else hipLaunchKernelGGL((gsm2::gstep2_kernel<1, 16>), g2, b2, 0, st, a); }
+      GS2_LAUNCH(dim3((a.iend - a.i0 + lpw - 1)/lpw), st);
       s->launches++;
       continue;
     }
