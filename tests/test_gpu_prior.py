@@ -19,6 +19,8 @@ CASES = {
     "generic-3x4": dict(parent=[3, 3, 4, 4, -1], tau=[0, 0, 0, 0.002, 0.004], per=4, kind="generic", nloci=1200, burn=40, snaps=12),
     "generic-8x2": dict(parent=[8, 8, 9, 9, 11, 11, 12, 12, 10, 10, 14, 13, 13, 14, -1],
                         tau=[0]*8 + [0.001, 0.0012, 0.0022, 0.0009, 0.0011, 0.002, 0.004], per=2, kind="generic", nloci=900, burn=40, snaps=10),
+    "persistent-4x2": dict(parent=[4, 4, 5, 6, 5, 6, -1], tau=[0, 0, 0, 0, 0.0015, 0.003, 0.0045], per=2, kind="persistent", nloci=1200, burn=40, snaps=12),
+    "persistent-2x4": dict(parent=[2, 2, -1], tau=[0, 0, 0.003], per=4, kind="persistent", nloci=1200, burn=40, snaps=12),
     "big-4x6": dict(parent=[4, 4, 5, 6, 5, 6, -1], tau=[0, 0, 0, 0, 0.0015, 0.003, 0.0045], per=6, kind="big", nloci=500, burn=30, snaps=10),
 }
 
@@ -150,10 +152,14 @@ def test_all_loci_moves_leave_the_priors_of_theta_and_tau(taxa, model, R, mode, 
     dev.close(); eng.close()
 
 
-@pytest.mark.parametrize("name,samples,thin", [("big-4x6", 700, 2), ("generic-3x4", 1000, 2)])
+@pytest.mark.parametrize("name,samples,thin", [("big-4x6", 700, 2), ("generic-3x4", 1000, 2), ("persistent-4x2+program", 3000, 3), ("persistent-2x4+program", 3000, 3)])
 def test_all_loci_moves_leave_the_priors_with_several_sequences_per_species(name, samples, thin):
     """the same with several sequences per species (the tip populations have thetas too, the rubber band moves nodes inside
-    them) — on the big-tree sampler (24 tips) and on the generic one (12 tips)"""
+    them) — on the big-tree sampler (24 tips), on the generic one (12 tips), and on the persistent kernel with 8 tips (4 species
+    x 2, 2 species x 4) under BPP's move kernel and the program's moves: Gibbs thetas of tip populations, re-draws inside the
+    rubber band and the mixing step"""
+    program = name.endswith("+program")
+    name = name.split("+")[0]
     c = CASES[name]
     nsp = (len(c["parent"]) + 1) // 2
     tips = nsp * c["per"]
@@ -177,6 +183,9 @@ def test_all_loci_moves_leave_the_priors_with_several_sequences_per_species(name
     dev.set_tau_prior(a_tau, b_tau)
     dev.set_theta_prior(a_th, b_th, 0.002)
     dev.set_finetune(0.004, 0.004, 0.4 * c["tau"][-1], 0.5)
+    if program:
+        dev.set_proposal_kernel(1)
+        dev.set_program_moves(True, 0.1)
     dev.initialize()
     assert dev.kind() == c["kind"]
     dev.iterate(600)
