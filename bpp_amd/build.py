@@ -19,8 +19,10 @@ HOST_SRC = os.path.join(CSRC, "host", "a00_driver.c")
 RCCL_OUT = os.path.join(HERE, "libbpp_amd_rccl.so")      # the several-GPU exchange as native code (links librccl), a library of its own
 RCCL_SRC = os.path.join(CSRC, "rccl_exchange.c")
 SOURCES = ["engine.hip", "host_math.cpp", "host_input.cpp"]
-DEPS = ["kernels.hpp", "device_types.hpp", "sampler.hpp", "sweep2.hpp", "gsampler.hpp", "gsampler_host.hpp", "bigsampler.hpp", "bigsampler_host.hpp", "gamma_dev.hpp", "p2p.hpp", os.path.join(ROOT, "include", "bpp_amd.h"),
-        os.path.join(ROOT, "include", "bpp_amd_host.h"), os.path.join(ROOT, "include", "bpp_amd_input.h")]
+# every header the library's sources include: all of csrc/*.hpp and include/*.h (a header missing from a hand-kept list is a
+# stale library that looks built)
+import glob as _glob
+DEPS = sorted(_glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(_glob.glob(os.path.join(ROOT, "include", "*.h")))
 
 
 def hipcc():

@@ -44,9 +44,46 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
   const bool valid = i < A.iend;
   const smp::Species & SP = A.sp;
   const int npop = SP.npop;
-  if (lane < (uint32_t)(3*MAXPOP)) s_tau[lane] = A.taus[lane];
+  // ---- every load of the step, issued together: ONE round trip to HBM where the species tree, the tree, the last step's
+  // decision inputs and the undo copy (a rejection is the common case) one after the other were four
+  const uint32_t ic = valid ? i : A.i0;                         // (an idle group reads a locus that exists; nothing of it is used)
+  const double tau_r = lane < (uint32_t)(3*MAXPOP) ? A.taus[lane] : 0.0;
+  constexpr int NLR = MODE == 1 ? (NN*NN + 63)/64 : 1;
+  double lr_[NLR];
+  if (MODE == 1)
+  {
+#pragma unroll
+    for (int k = 0; k < NLR; ++k) { const uint32_t q = lane + 64u*(uint32_t)k; lr_[k] = q < (uint32_t)(NN*NN) ? A.lograt[(q/NN)*gsm::NN + q % NN] : 0.0; }
+  }
+  const gsm::GTree & g = A.trees[ic];
+  const gsm::GTree & ud = A.undo[ic];
+  uint32_t gw[4][W], uw[4][W];
+#pragma unroll
+  for (int k = 0; k < W; ++k)
+  {
+    gw[0][k] = reinterpret_cast<const uint32_t *>(g.left)[k];   gw[1][k] = reinterpret_cast<const uint32_t *>(g.right)[k];
+    gw[2][k] = reinterpret_cast<const uint32_t *>(g.parent)[k]; gw[3][k] = reinterpret_cast<const uint32_t *>(g.pop)[k];
+    uw[0][k] = reinterpret_cast<const uint32_t *>(ud.left)[k];   uw[1][k] = reinterpret_cast<const uint32_t *>(ud.right)[k];
+    uw[2][k] = reinterpret_cast<const uint32_t *>(ud.parent)[k]; uw[3][k] = reinterpret_cast<const uint32_t *>(ud.pop)[k];
+  }
+  const int g_clv = g.clv[li], g_pm = g.pmat[li], u_clv = ud.clv[li], u_pm = ud.pmat[li];
+  const double g_time = g.time[li], u_time = ud.time[li];
+  const int g_root = g.root, g_tips = g.tips, u_root = ud.root;
+  smp2::Stream<false> rng{g.rng};
+  double lnl_cur = g.lnl, logpr_cur = g.logpr;
+  uint32_t nprop = g.proposals, nacc = g.accepted, w_nupd = g.work_nupd, w_nbr = g.work_nbr, w_nev = g.work_neval;
+  const gsm::GLocus L = A.loc[ic];
+  const int gl_i = li < MAXPOP ? (int)L.gl[li] : 0;
+  const uint32_t d_active = A.active[ic], d_flag = *A.flag;
+  const double d_lnl = A.lnl_new[ic], d_logpr = A.logpr_new[ic], d_hast = A.hast[ic];
+
+  if (lane < (uint32_t)(3*MAXPOP)) s_tau[lane] = tau_r;
   if (lane < 16u) s_anc[lane] = lane < (uint32_t)MAXPOP ? (uint32_t)SP.anc[lane] : 0u;
-  if (MODE == 1) for (uint32_t q = lane; q < (uint32_t)(NN*NN); q += 64u) s_lograt[q] = A.lograt[(q/NN)*gsm::NN + q % NN];
+  if (MODE == 1)
+  {
+#pragma unroll
+    for (int k = 0; k < NLR; ++k) { const uint32_t q = lane + 64u*(uint32_t)k; if (q < (uint32_t)(NN*NN)) s_lograt[q] = lr_[k]; }
+  }
   smp2::PopLane pl;
   {
     const int lp = li < MAXPOP ? li : 0;
@@ -65,72 +102,34 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
   LocLDS<NT> & S = s_loc[slot];
   GS2_T(1);
 
-  // ---- load (the tree of an idle group: all -1, two tips)
-  smp2::GTree<NT> T;
-  for (int k = 0; k < W; ++k) { T.left.w[k] = T.right.w[k] = T.parent.w[k] = T.pop.w[k] = 0xffffffffu; }
-  T.cf = T.pf = 0; T.root = 0; T.tips = 2;
-  smp2::Stream<false> rng{0};
-  double lnl_cur = 0, logpr_cur = 0;
-  uint32_t nprop = 0, nacc = 0, w_nupd = 0, w_nbr = 0, w_nev = 0;
-  int gl_i = 0;
-  gsm::GLocus L{};
-  auto load_tree = [&](const gsm::GTree & g, int tips_)            // (an undo copy carries no tip count: the caller's)
-  {
-    for (int k = 0; k < W; ++k)
-    {
-      T.left.w[k] = reinterpret_cast<const uint32_t *>(g.left)[k]; T.right.w[k] = reinterpret_cast<const uint32_t *>(g.right)[k];
-      T.parent.w[k] = reinterpret_cast<const uint32_t *>(g.parent)[k]; T.pop.w[k] = reinterpret_cast<const uint32_t *>(g.pop)[k];
-    }
-    T.root = g.root; T.tips = tips_;
-    const int n = 2*T.tips - 1;
-    T.cf = smp2::gballot<G>(li >= T.tips && li < n && g.clv[li] != li, gbase);
-    T.pf = smp2::gballot<G>(li < n && g.pmat[li] != li, gbase);
-    S.time[li] = li < n ? g.time[li] : 0.0;
-  };
-  if (valid)
-  {
-    const gsm::GTree & g = A.trees[i];
-    L = A.loc[i];
-    load_tree(g, g.tips);
-    rng.r = g.rng; lnl_cur = g.lnl; logpr_cur = g.logpr; nprop = g.proposals; nacc = g.accepted;
-    w_nupd = g.work_nupd; w_nbr = g.work_nbr; w_nev = g.work_neval;
-    gl_i = li < MAXPOP ? (int)L.gl[li] : 0;
-  }
-  else { (void)smp2::gballot<G>(false, gbase); (void)smp2::gballot<G>(false, gbase); }
-  smp2::wsync();
-  GS2_T(2);
-
-  // ---- 1. settle the step whose evaluation just finished (gstep_kernel's step 1)
-  bool restore_par = false;
+  // ---- 1. settle the step whose evaluation just finished (gstep_kernel's step 1): the decision, from registers
+  bool restore_par = false, back = false;
   if (valid && A.pend)
   {
-    bool back = false;
     if (A.pend == 1)
     {
-      if (A.active[i])
+      if (d_active)
       {
-        const double lnl = A.lnl_new[i], lp_new = A.logpr_new[i];
-        const double lnacc = (lp_new - logpr_cur) + (lnl - lnl_cur) + A.hast[i];
+        const double lnacc = (d_logpr - logpr_cur) + (d_lnl - lnl_cur) + d_hast;
         const double u = rndu(&rng.r);
         ++nprop;
-        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; }
+        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = d_lnl; logpr_cur = d_logpr; ++nacc; }
         else back = true;
       }
     }
     else if (A.pend == 2)
     {
-      if (*A.flag == A.epoch) back = true;
-      else { logpr_cur = A.logpr_new[i]; if (A.active[i]) lnl_cur = A.lnl_new[i]; }
+      if (d_flag == A.epoch) back = true;
+      else { logpr_cur = d_logpr; if (d_active) lnl_cur = d_lnl; }
     }
     else if (A.pend == 4)
     {
-      if (A.active[i])
+      if (d_active)
       {
-        const double lnl = A.lnl_new[i];
-        const double lnacc = (lnl - lnl_cur) + A.hast[i];
+        const double lnacc = (d_lnl - lnl_cur) + d_hast;
         const double u = rndu(&rng.r);
         ++nprop;
-        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = lnl; ++nacc; }
+        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = d_lnl; ++nacc; }
         else
         {
           back = true;
@@ -144,9 +143,26 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
         }
       }
     }
-    else { lnl_cur = A.lnl_new[i]; logpr_cur = A.logpr_new[i]; }
+    else { lnl_cur = d_lnl; logpr_cur = d_logpr; }
     // (every lane of a group takes the same branch: the conditions are the locus's)
-    if (back) { smp2::wsync(); load_tree(A.undo[i], T.tips); }
+  }
+  GS2_T(2);
+  // ---- the tree as settled: the arriving one, or the undo copy (the tree of an idle group: all -1, two tips)
+  smp2::GTree<NT> T;
+#pragma unroll
+  for (int k = 0; k < W; ++k)
+  {
+    T.left.w[k]   = !valid ? 0xffffffffu : back ? uw[0][k] : gw[0][k];
+    T.right.w[k]  = !valid ? 0xffffffffu : back ? uw[1][k] : gw[1][k];
+    T.parent.w[k] = !valid ? 0xffffffffu : back ? uw[2][k] : gw[2][k];
+    T.pop.w[k]    = !valid ? 0xffffffffu : back ? uw[3][k] : gw[3][k];
+  }
+  T.root = !valid ? 0 : back ? u_root : g_root; T.tips = valid ? g_tips : 2;
+  {
+    const int n0 = 2*T.tips - 1;
+    T.cf = smp2::gballot<G>(valid && li >= T.tips && li < n0 && (back ? u_clv : g_clv) != li, gbase);
+    T.pf = smp2::gballot<G>(valid && li < n0 && (back ? u_pm : g_pm) != li, gbase);
+    S.time[li] = valid && li < n0 ? (back ? u_time : g_time) : 0.0;
   }
   smp2::wsync();
   if (valid && restore_par && li == 0) gsm::write_par(L.par, L.R, A.pend_mode, A.sm + (size_t)i*11);
@@ -418,7 +434,8 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
   }
 #ifdef GS2_PROF
   __builtin_amdgcn_s_waitcnt(0); GS2_T(8);
-  if (valid && li == 0) { A.delta[i] = (double)(tp_[1 + (i & 7u)] - tp_[0]); A.lnl_cur[i] = (double)(tp_[(i & 1u) ? 8 : 0] & 0xffffffffffffull); }
+  if (MODE <= 1 && valid && li == 0) { A.delta[i] = (double)(tp_[1 + (i & 7u)] - tp_[0]);      // (GAGE / GSPR do not use the two arrays)
+    A.lnl_cur[i] = (double)(tp_[(i & 1u) ? 8 : 0] & 0xffffffffffffull); }
 #endif
 }
 
