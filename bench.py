@@ -498,6 +498,30 @@ def run_config5(eng, iters=40):
     return out
 
 
+def run_mixed_set(data, nodd=10, iters=200):
+    """config 2's loci with a few loci of another kind among them (GTR+Gamma4, 4 rate categories): ONE sampler — the composite
+    (csrc/composite.hpp): the JC69 loci on the persistent kernel's part, the others on the generic part, stepped together —
+    next to what such a set cost before round 4 (refused; or, forced, all 10 000 loci on the generic path)"""
+    import bpp_amd
+    from bpp_amd import synth
+    eng = bpp_amd.Engine(0, None)
+    odd = synth.make_dataset(nodd, 1000, 4, "gtr", 4, seed=99)
+    mixed = list(data[:len(data) - nodd]) + odd
+    smp = bpp_amd.Sampler(eng, make_loci(eng, mixed), mixed, seed=3)
+    par, tau, theta = synth.species_tree_arrays(4)
+    smp.set_species_tree(par, tau, theta)
+    smp.set_theta_prior(2.0, 1000.0, 8e-5); smp.set_tau_prior(2.0, 500.0)
+    smp.set_finetune(0.004, 0.004, 4e-5, 0.006)
+    smp.initialize(); smp.iterate(20); eng.synchronize()
+    t0 = time.perf_counter(); smp.iterate(iters); eng.synchronize(); dt = time.perf_counter() - t0
+    sm = smp.summary()
+    out = dict(loci=f"{len(data) - nodd} config-2 JC69 loci + {nodd} GTR+G4 loci", implementation=smp.kind(), iterations_per_s=round(iters / dt, 1),
+               ms_per_iteration=round(1e3 * dt / iters, 4), acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3), moves="the library's uniform-window moves",
+               note="the generic part's per-step launches set the pace (a few loci cost a step's latency, not the other loci's throughput)")
+    smp.close(); eng.close()
+    return out
+
+
 def scale_projection(key, cfg, data, args, shares=(2, 4, 8)):
     """What ONE rank of an N-GPU strong-scaling run of this config works on, measured on this one GPU: the loci the reference's
     zig-zag deal (threads.c:265-353, bpp_amd/shard.py) gives rank 0 of N, through the device-resident sampler.  iterations/s of
@@ -1342,6 +1366,12 @@ def main():
             others["c5"]["seconds"] = round(time.time() - t0, 1)
         except Exception as ex:       # noqa: BLE001
             others["c5"] = dict(error=str(ex)[:300])
+
+        if args.config == "c2" and args.loci is None:
+            try:
+                others["mixed_set"] = run_mixed_set(data)
+            except Exception as ex:       # noqa: BLE001
+                others["mixed_set"] = dict(error=str(ex)[:300])
 
     # ---- MCMC control on the host in C (last: libgomp pins the calling thread under OMP_PROC_BIND, and threads or
     # processes started afterwards would inherit that one-CPU mask — the CPU baselines above must not)
