@@ -22,17 +22,28 @@ template <int NT> struct LocLDS
   double contrib[2*NT], contrib_new[2*NT];
 };
 
-template <uint32_t MODE, int NT>
-__global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
+// what changes from step to step (a launch takes it from its arguments, the chain kernel below counts it itself)
+struct StepCtl { uint32_t k, pend, refresh_logpr, fmt20; };
+
+template <int NT> struct Step2LDS
+{
+  LocLDS<NT> loc[smp2::Cfg<NT>::LPW];
+  double tau[3*MAXPOP];
+  double lograt[smp2::Cfg<NT>::NN*smp2::Cfg<NT>::NN];
+  uint32_t anc[16];
+};
+
+// one step of the loci of ONE wave (lane = threadIdx.x & 63; group `slot` of the wave holds locus i when valid).  WAVE_ONLY:
+// the caller's other waves do not take part — the hand-overs through LDS are the wave's own (chain kernel)
+template <uint32_t MODE, int NT, bool WAVE_ONLY>
+__device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl & C, Step2LDS<NT> & SH, const uint32_t lane, const uint32_t i, const bool valid)
 {
   static_assert(MODE <= 3, "GAGE, GSPR, TAU, MIX");
-  using C = smp2::Cfg<NT>;
-  constexpr int G = C::G, LPW = C::LPW, NN = C::NN, W = C::W;
-  __shared__ LocLDS<NT> s_loc[LPW];
-  __shared__ double s_tau[3*MAXPOP];
-  __shared__ double s_lograt[NN*NN];
-  __shared__ uint32_t s_anc[16];
-  const uint32_t lane = threadIdx.x;
+  using Cf = smp2::Cfg<NT>;
+  constexpr int G = Cf::G, NN = Cf::NN, W = Cf::W;
+  LocLDS<NT> * s_loc = SH.loc;
+  double * s_tau = SH.tau, * s_lograt = SH.lograt;
+  uint32_t * s_anc = SH.anc;
 #ifdef GS2_PROF
   uint64_t tp_[9]; tp_[0] = wall_clock64();
 #define GS2_T(k_) tp_[k_] = wall_clock64()
@@ -40,8 +51,6 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
 #define GS2_T(k_)
 #endif
   const int li = (int)(lane & (uint32_t)(G - 1)); const uint32_t gbase = lane - (uint32_t)li, slot = lane/(uint32_t)G;
-  const uint32_t i = A.i0 + blockIdx.x*(uint32_t)LPW + slot;
-  const bool valid = i < A.iend;
   const smp::Species & SP = A.sp;
   const int npop = SP.npop;
   // ---- every load of the step, issued together: ONE round trip to HBM where the species tree, the tree, the last step's
@@ -93,7 +102,7 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
     for (int q2 = 0; q2 < npop; ++q2) if (q2 != li && (((uint32_t)SP.anc[q2] >> li) & 1u)) below |= 1u << q2;
     pl.below = li < npop ? below : 0u;
   }
-  __syncthreads();
+  if (WAVE_ONLY) smp2::wsync(); else __syncthreads();
   {
     const int lp = li < MAXPOP ? li : 0;
     pl.tau = s_tau[lp]; pl.theta = s_tau[MAXPOP + lp]; pl.l2t = s_tau[2*MAXPOP + lp];
@@ -104,9 +113,9 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
 
   // ---- 1. settle the step whose evaluation just finished (gstep_kernel's step 1): the decision, from registers
   bool restore_par = false, back = false;
-  if (valid && A.pend)
+  if (valid && C.pend)
   {
-    if (A.pend == 1)
+    if (C.pend == 1)
     {
       if (d_active)
       {
@@ -117,12 +126,12 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
         else back = true;
       }
     }
-    else if (A.pend == 2)
+    else if (C.pend == 2)
     {
       if (d_flag == A.epoch) back = true;
       else { logpr_cur = d_logpr; if (d_active) lnl_cur = d_lnl; }
     }
-    else if (A.pend == 4)
+    else if (C.pend == 4)
     {
       if (d_active)
       {
@@ -214,7 +223,7 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
   density_counts();
   if (li < npop) S.contrib[li] = density_term();
   smp2::wsync();
-  if (valid && A.refresh_logpr)
+  if (valid && C.refresh_logpr)
   {
     double lp = 0;
     for (int p = 0; p < npop; ++p) lp += S.contrib[p];
@@ -250,8 +259,8 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
   if (MODE <= 1)
   {
     if (valid)
-      ok = MODE == 0 ? smp2::propose_gage<NT, false>(T, rng, S.time, (int)A.k, pl, s_anc, s_tau, SP.ft_gage, li, gbase, pr)
-                     : smp2::propose_gspr<NT, false>(T, rng, S.time, (int)A.k, pl, gl_i, s_anc, s_tau, s_lograt, SP.ft_gspr, li, gbase, pr);
+      ok = MODE == 0 ? smp2::propose_gage<NT, false>(T, rng, S.time, (int)C.k, pl, s_anc, s_tau, SP.ft_gage, li, gbase, pr)
+                     : smp2::propose_gspr<NT, false>(T, rng, S.time, (int)C.k, pl, gl_i, s_anc, s_tau, s_lograt, SP.ft_gspr, li, gbase, pr);
   }
   else if (valid)
   {
@@ -260,7 +269,7 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
     if (MODE == 2)
     {
       // TAU q (tau_step of a00_driver.c): the gene nodes of q and its children between the bounds ride the rubber band
-      const int q = (int)A.tau_q, pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
+      const int q = (int)C.k, pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
       const double tq_old = s_tau[q], tq_lo = fmax(s_tau[cl], s_tau[cr]), tq_hi = pq >= 0 ? s_tau[pq] : 999.0;
       const double tnew = smp::reflect(tq_old + SP.ft_tau*(A.tau_u - 0.5), tq_lo, tq_hi);
       const double minf = (tnew - tq_lo)/(tq_old - tq_lo), maxf = (tnew - tq_hi)/(tq_old - tq_hi);
@@ -346,7 +355,7 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
   // ---- 4. the step's records for the engine's kernels (gstep_kernel's step 5): fresh branch j by lane j, node update k by lane k
   const uint32_t brm = ok ? pr.brm : 0u;
   const int nbr = __popc(brm);
-  if (valid && A.fmt20)
+  if (valid && C.fmt20)
   {
     const uint32_t e0 = i*A.maxmat, o0 = i*A.maxops20;
     if (li < nbr)
@@ -432,11 +441,65 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
       g.work_nupd = w_nupd; g.work_nbr = w_nbr; g.work_neval = w_nev;
     }
   }
+  if (WAVE_ONLY) smp2::wsync();                  // (the next step of a chain reuses the LDS block)
 #ifdef GS2_PROF
   __builtin_amdgcn_s_waitcnt(0); GS2_T(8);
   if (MODE <= 1 && valid && li == 0) { A.delta[i] = (double)(tp_[1 + (i & 7u)] - tp_[0]);      // (GAGE / GSPR do not use the two arrays)
     A.lnl_cur[i] = (double)(tp_[(i & 1u) ? 8 : 0] & 0xffffffffffffull); }
 #endif
+}
+
+template <uint32_t MODE, int NT>
+__global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
+{
+  __shared__ Step2LDS<NT> SH;
+  constexpr uint32_t LPW = (uint32_t)smp2::Cfg<NT>::LPW, G = (uint32_t)smp2::Cfg<NT>::G;
+  const uint32_t i = A.i0 + blockIdx.x*LPW + threadIdx.x/G;
+  const StepCtl C{MODE >= 2 ? A.tau_q : A.k, A.pend, A.refresh_logpr, A.fmt20};
+  gstep2_body<MODE, NT, false>(A, C, SH, threadIdx.x, i, i < A.iend);
+}
+
+
+// ---- the per-locus steps of an iteration as ONE launch ------------------------------------------------------------------------
+// GAGE and GSPR of a locus need nothing from other loci (threads.c:87-200: a worker walks its loci's proposals without a
+// barrier), so a workgroup that owns the locus can walk all of them: propose (the lane group above, in the workgroup's first
+// wave), the step's P-matrices, node updates and pattern terms by the workgroup's threads with the engine's own device
+// functions (pmatrix_s4_entry, walk_s4, lnl_reduce_wave of kernels.hpp: the arithmetic of every 4-state path, one lane per
+// pattern — the records are written in the OpDev form those read), the decision at the head of the next step.  No barrier
+// between workgroups, so no residency condition; the last step's decision is left pending exactly as the launch loop leaves
+// it.  What this buys is the launches: a small set (a strong-scaling rank's share, a composite's small part, config 5) pays
+// 12-30 us per launch three times per step, whatever the work.
+struct GChain { uint32_t ngage, ngspr, pend, refresh_logpr; };
+constexpr uint32_t GCHAIN_THREADS = 64;          // one wave per locus: the lane group proposes, the 64 lanes share the patterns
+
+template <int NT>
+__global__ void __launch_bounds__(GCHAIN_THREADS) gchain_kernel(const gsm::GArgs A, const PlanDev P, const GChain ch)
+{
+  __shared__ Step2LDS<NT> SH;
+  constexpr uint32_t G = (uint32_t)smp2::Cfg<NT>::G;
+  const uint32_t i = A.i0 + blockIdx.x, tid = threadIdx.x;
+  StepCtl C{0, ch.pend, ch.refresh_logpr, 1u};
+  const LocusDev & L = P.loci[P.task_locus[i]];
+  const uint32_t np = L.np, R = L.rate_cats, e0 = i*A.maxmat, poff = P.task_pat_off[i];
+  const uint32_t nsteps = ch.ngage + ch.ngspr;
+  for (uint32_t st = 0; st < nsteps; ++st)
+  {
+    const bool gage = st < ch.ngage;
+    C.k = gage ? st : st - ch.ngage;
+    if (gage) gstep2_body<0, NT, true>(A, C, SH, tid, i, tid < G);
+    else      gstep2_body<1, NT, true>(A, C, SH, tid, i, tid < G);
+    C.pend = 1u; C.refresh_logpr = 0u;
+    __syncthreads();                                  // the step's records are out (written and read on this CU)
+    if (A.active[i])
+    {
+      for (uint32_t q = tid; q < A.maxmat*R; q += GCHAIN_THREADS) pmatrix_s4_entry(P, e0 + q/R, q % R);
+      __syncthreads();
+      for (uint32_t n = tid; n < np; n += GCHAIN_THREADS) P.site_term[poff + n] = walk_s4(P, i, n, L, true);
+      __syncthreads();
+      lnl_reduce_wave(P, i, tid);
+    }
+    __syncthreads();
+  }
 }
 
 } // namespace gsm2

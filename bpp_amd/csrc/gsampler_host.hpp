@@ -102,7 +102,7 @@ static int gs_upload(bpa_sampler * s)
   s->g_maxmat = 2*s->maxtips - 2;
   s->g_pack_epoch = e->pack_epoch;
   const size_t nslots = s->g_s20 ? T : e->pack_slots;
-  const size_t nrec = s->g_s20 ? 1 : nslots*s->g_units, nmat = nslots*s->g_maxmat;
+  const size_t nrec = s->g_s20 ? 1 : nslots*s->g_units, nmat = std::max(nslots, (size_t)T)*s->g_maxmat;
   std::vector<uint32_t> bmo(s->g_s20 ? 1 : e->pack_blocks + 1);
   if (!s->g_s20) for (unsigned b = 0; b <= e->pack_blocks; ++b) bmo[b] = e->h_blk_slot_off[b]*s->g_maxmat;
   if (s->g_s20)
@@ -126,6 +126,26 @@ static int gs_upload(bpa_sampler * s)
     HIPCHK(hipMemsetAsync(s->g_root20.p, 0, (size_t)T*sizeof(uint32_t), e->stream));
     HIPCHK(hipMemsetAsync(s->g_mtask.p, 0xff, nmat*sizeof(uint32_t), e->stream));
     HIPCHK(hipMemsetAsync(s->g_mpm.p, 0, nmat*sizeof(uint32_t), e->stream));
+  }
+  if (!s->g_s20)
+  {
+    // the chain launch of the per-locus steps (gchain_kernel) evaluates with the engine's one-lane-per-pattern functions:
+    // a task per locus and the step's records in the OpDev form, next to the packing's compact records
+    if (!flush_state(e)) return 0;
+    std::vector<uint32_t> tl(T), tp(T + 1);
+    std::vector<int32_t> rs(T, BPA_SCALE_BUFFER_NONE);
+    unsigned off = 0;
+    for (unsigned i = 0; i < T; ++i) { tl[i] = s->loci[i]->id; tp[i] = off; off += s->loci[i]->sites; }
+    tp[T] = off;
+    s->g_maxops = s->maxtips - 1;
+    const size_t nm = (size_t)T*s->g_maxmat;
+    if (!upload(s->g_tlocus, tl.data(), T) || !upload(s->g_tpat, tp.data(), T + 1) || !upload(s->g_rscaler, rs.data(), T) ||
+        !s->g_ops20.reserve((size_t)T*s->g_maxops) || !s->g_oprng.reserve((size_t)2*T) || !s->g_root20.reserve(T) || !s->g_mtask.reserve(nm) || !s->g_mpm.reserve(nm))
+      return 0;
+    HIPCHK(hipMemsetAsync(s->g_oprng.p, 0, (size_t)2*T*sizeof(uint32_t), e->stream));
+    HIPCHK(hipMemsetAsync(s->g_root20.p, 0, (size_t)T*sizeof(uint32_t), e->stream));
+    HIPCHK(hipMemsetAsync(s->g_mtask.p, 0xff, nm*sizeof(uint32_t), e->stream));
+    HIPCHK(hipMemsetAsync(s->g_mpm.p, 0, nm*sizeof(uint32_t), e->stream));
   }
   uint32_t zero2[2] = {0, 0};
   if (!upload(s->g_dev, s->g_trees.data(), T) || !s->g_undo.reserve(T) || !upload(s->g_loc, loc.data(), T) ||
@@ -461,6 +481,51 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
   return 1;
 }
 
+// GAGE + GSPR of every locus in one launch (gsampler2.hpp: gchain_kernel).  BPA_GS_CHAIN=0 / 1: never / whenever possible;
+// default: sets of up to 4 096 loci (above, the packing's throughput kernels win back what the launches cost)
+static bool gs_chain_wanted(const bpa_sampler * s)
+{
+  const char * env = getenv("BPA_GS_CHAIN");
+  if (s->g_s20 || !s->eng->usedata || s->maxtips < 2) return false;
+  if (env) return env[0] != '0';
+  return s->nloci <= 4096u;
+}
+static int gs_chain(bpa_sampler * s)
+{
+  bpa_engine * e = s->eng;
+  if (s->g_pack_epoch != e->pack_epoch) return fail("bpa_sampler: the engine's loci changed since the sampler was set up");
+  // a pending parameter move is settled by a launch of its own: what it rolls back needs the eigensystems refreshed
+  if (s->g_pend == 4) { if (!gs_step(s, 4) || !gs_refresh_eigen(s)) return 0; }
+  if (!gs_join(s)) return 0;
+  if (!gs_refresh_eigen(s)) return 0;
+  gsm::GArgs a{};
+  a.trees = s->g_dev.p; a.undo = s->g_undo.p; a.loc = s->g_loc.p; a.T = s->nloci;
+  a.lnl_new = s->g_lnl.p; a.hast = s->g_hast.p; a.logpr_new = s->g_logpr.p; a.delta = s->g_delta.p;
+  a.active = s->g_active.p; a.flag = s->flag.p; a.epoch = s->epoch; a.lnl_cur = s->g_lnlcur.p;
+  a.recs2 = s->g_recs.p; a.units = s->g_units; a.mat2 = s->g_mat2.p; a.mat_length = s->g_len.p; a.maxmat = s->g_maxmat;
+  a.taus = s->taus.p; a.lograt = s->g_lograt.p;
+  a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p;
+  a.sp = s->sp;
+  a.pend_mode = s->g_pend_mode; a.pend_k = s->g_pend_k; a.sm = s->g_sm.p; a.sm_old = s->g_sm_old.p;
+  a.fmt20 = 1u; a.maxops20 = s->g_maxops;
+  a.ops20 = s->g_ops20.p; a.op_rng20 = s->g_oprng.p; a.root20 = s->g_root20.p; a.mat_task20 = s->g_mtask.p; a.mat_pm20 = s->g_mpm.p;
+  a.i0 = 0; a.iend = s->nloci;
+  PlanDev d{};
+  d.loci = e->d_loci.p; d.bfbeta = e->bfbeta; d.task_locus = s->g_tlocus.p; d.task_pat_off = s->g_tpat.p;
+  d.op_off = s->g_oprng.p; d.ops = s->g_ops20.p; d.root_clv = s->g_root20.p; d.root_scaler = s->g_rscaler.p;
+  d.site_term = s->g_site.p; d.lnl = s->g_lnl.p; d.mat_task = s->g_mtask.p; d.mat_pmatrix = s->g_mpm.p; d.mat_length = s->g_len.p;
+  d.nmat = s->nloci*s->g_maxmat; d.ntasks = s->nloci; d.npatterns = s->g_npat; d.pad = s->g_rmax;
+  d.flags = 2u | 4u | 64u;
+  gsm2::GChain ch{s->maxtips - 1, 2*s->maxtips - 2, s->g_pend, s->logpr_stale ? 1u : 0u};
+  s->logpr_stale = false;
+  if (s->maxtips <= 8) hipLaunchKernelGGL((gsm2::gchain_kernel<8>), dim3(s->nloci), dim3(gsm2::GCHAIN_THREADS), 0, e->stream, a, d, ch);
+  else                 hipLaunchKernelGGL((gsm2::gchain_kernel<16>), dim3(s->nloci), dim3(gsm2::GCHAIN_THREADS), 0, e->stream, a, d, ch);
+  HIPCHK(hipGetLastError());
+  s->launches++; s->g_evals += ch.ngage + ch.ngspr;
+  s->g_pend = 1u; s->g_pend_mode = 1u; s->g_pend_k = ch.ngspr - 1;
+  return 1;
+}
+
 // the ONE decision of an all-loci step
 static int gs_decide(bpa_sampler * s, double uacc, int tau_q, double win_u, double mix_c, double mix_lnc)
 {
@@ -499,8 +564,12 @@ static int gs_iterate(bpa_sampler * s, unsigned iterations)
   {
     // the per-locus proposals, "step j of every locus" (gage_step / gspr_step of a00_driver.c): each launch first settles
     // the step before it
-    for (unsigned k = 0; k + 1 < s->maxtips; ++k)     { if (!gs_step(s, 0, k) || !gs_eval(s, 0)) return 0; }
-    for (unsigned k = 0; k + 2 < 2*s->maxtips; ++k)   { if (!gs_step(s, 1, k) || !gs_eval(s, 0)) return 0; }
+    if (gs_chain_wanted(s)) { if (!gs_chain(s)) return 0; }
+    else
+    {
+      for (unsigned k = 0; k + 1 < s->maxtips; ++k)     { if (!gs_step(s, 0, k) || !gs_eval(s, 0)) return 0; }
+      for (unsigned k = 0; k + 2 < 2*s->maxtips; ++k)   { if (!gs_step(s, 1, k) || !gs_eval(s, 0)) return 0; }
+    }
     s->sweeps++;
     if (s->env_nomix) continue;
     if (s->sp.theta_alpha > 0)

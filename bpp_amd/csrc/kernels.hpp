@@ -952,9 +952,8 @@ __device__ __forceinline__ double reduce_locus(const LocusDev & L, TERMPTR term)
 
 // one wave per locus: the terms are fetched 64 at a time (coalesced) and added in pattern order —
 // the reference's sequential sum (core_likelihood.c:85) — by broadcasting them lane by lane
-__global__ void __launch_bounds__(64) lnl_reduce_wave_kernel(const PlanDev P)
+__device__ __forceinline__ void lnl_reduce_wave(const PlanDev & P, const uint32_t t, const uint32_t lane)
 {
-  const uint32_t t = blockIdx.x, lane = threadIdx.x;
   const LocusDev & L = P.loci[P.task_locus[t]];
   const double * term = P.site_term + P.task_pat_off[t];
   if (L.unphased_length)
@@ -973,6 +972,10 @@ __global__ void __launch_bounds__(64) lnl_reduce_wave_kernel(const PlanDev P)
       logl += __hiloint2double(__builtin_amdgcn_readlane(hi, (int)q), __builtin_amdgcn_readlane(lo, (int)q));
   }
   if (lane == 0) P.lnl[t] = P.bfbeta*logl;
+}
+__global__ void __launch_bounds__(64) lnl_reduce_wave_kernel(const PlanDev P)
+{
+  lnl_reduce_wave(P, blockIdx.x, threadIdx.x);
 }
 
 
