@@ -481,14 +481,16 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
   return 1;
 }
 
-// GAGE + GSPR of every locus in one launch (gsampler2.hpp: gchain_kernel).  BPA_GS_CHAIN=0 / 1: never / whenever possible;
-// default: sets of up to 4 096 loci (above, the packing's throughput kernels win back what the launches cost)
+// GAGE + GSPR of every locus in one launch (gsampler2.hpp: gchain_kernel).  BPA_GS_CHAIN=0 / 1: never / whenever possible.
+// Default: small JC69 sets only — up to 1 024 loci of at most 64 patterns on average (config 5: 913 -> 1 096 it/s).  With
+// several rate categories or hundreds of patterns a wave per locus walking one pattern per lane loses to the packing's
+// kernels even when those are launch-bound (config 3's share of 1 250 loci: 516 it/s by launches, 337 chained).
 static bool gs_chain_wanted(const bpa_sampler * s)
 {
   const char * env = getenv("BPA_GS_CHAIN");
   if (s->g_s20 || !s->eng->usedata || s->maxtips < 2) return false;
   if (env) return env[0] != '0';
-  return s->nloci <= 4096u;
+  return s->g_alljc && s->nloci <= 1024u && s->g_npat <= 64u*s->nloci;
 }
 static int gs_chain(bpa_sampler * s)
 {

@@ -40,14 +40,14 @@ def walk(host, dev, iters, nloci, check_every=1):
         assert rel(a["lnl"], b["lnl"]) < 1e-11 and rel(a["logpr"], b["logpr"]) < 1e-11
 
 
-@pytest.mark.parametrize("taxa,model,R,nloci,iters,forced,chain", [(4, "jc69", 1, 300, 5, True, None), (8, "gtr", 4, 60, 3, False, None), (8, "gtr", 4, 60, 3, False, "0"),
-                                                                   (8, "gtr", 4, 700, 2, False, "0"), (8, "gtr", 4, 700, 2, False, None), (8, "jc69", 1, 40, 3, True, "0"),
+@pytest.mark.parametrize("taxa,model,R,nloci,iters,forced,chain", [(4, "jc69", 1, 300, 5, True, None), (8, "gtr", 4, 60, 3, False, "1"), (8, "gtr", 4, 60, 3, False, "0"),
+                                                                   (8, "gtr", 4, 700, 2, False, "0"), (8, "gtr", 4, 700, 2, False, "1"), (8, "jc69", 1, 40, 3, True, "0"),
                                                                    (8, "jc69", 1, 40, 3, True, None), (6, "lg", 4, 40, 3, False, None), (6, "lg", 1, 24, 2, False, None)])
 def test_generic_sampler_equals_host_driver(taxa, model, R, nloci, iters, forced, chain, monkeypatch):
     """(lg: amino-acid loci — BASELINE config 4's kind —, the steps written on the device as the records of the tiled 20-state
     kernels: pmatrix_wg2_kernel, partials_lnl_pipe20_kernel; 700 GTR loci: enough workgroups of the packing for the per-locus
     steps to run as two half-batches on two streams — more launches, the same trajectory; chain None: the per-locus steps
-    of 4-state sets of this size as ONE launch (gsm2::gchain_kernel), "0": a launch per step (BPA_GS_CHAIN))"""
+    as ONE launch (gsm2::gchain_kernel: the default for small JC69 sets, "1": forced), "0": a launch per step (BPA_GS_CHAIN))"""
     if chain is not None:
         monkeypatch.setenv("BPA_GS_CHAIN", chain)
     eng = bpp_amd.Engine(0)
@@ -83,7 +83,7 @@ def test_generic_sampler_equals_host_driver(taxa, model, R, nloci, iters, forced
     if model == "gtr" and chain == "0":
         assert (w["sweeps"] >= iters*2*(3*taxa - 3)) == (nloci >= 700) == (dev.streams() == 2)   # two half-batch launches per per-locus step
     if model != "lg":
-        assert (dev.summary()["launches"] < iters*2*(3*taxa - 3)) == (chain is None)             # the chain: one launch for the per-locus steps (else >= 2 each)
+        assert (dev.summary()["launches"] < iters*2*(3*taxa - 3)) == (chain != "0")             # the chain: one launch for the per-locus steps (else >= 2 each)
     dev.close(); host.close(); eng.close()
 
 
