@@ -28,9 +28,8 @@ def run_bench(extra):
     return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-@pytest.mark.parametrize("p2p", [False, True])
-def test_two_rank_bench_line(scaling, p2p):
+@pytest.mark.parametrize("p2p,scaling", [(False, "weak"), (True, "weak"), (True, "strong")])      # (the default exchange with ONE data set: the test below)
+def test_two_rank_bench_line(p2p, scaling):
     """p2p = False: the DEFAULT N > 1 path — one all-reduce per all-loci step through the library's callback (RCCL on the
     driver's box, the framework's gloo collective here), the per-locus sweeps by the persistent kernel ("hybrid");
     p2p = True (--p2p): the sums exchanged inside the persistent kernel through peer-mapped mailboxes, the program's moves"""
