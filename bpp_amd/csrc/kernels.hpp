@@ -2712,15 +2712,218 @@ __device__ void eigen_sym(double (&a)[N][N], double (&d)[N], double (&e)[N])
   }
 }
 
+// The same operations in the same order with every array index a compile-time constant (all loops unrolled, the QL sweep's
+// run-time bounds l <= i < m as predicates, d[m] / e[m] as selects): the 4x4 system then lives in REGISTERS.  With run-time
+// indices it was LDS (or scratch) — a round trip per access on a chain of ~600 dependent accesses, 35 us a launch for any
+// number of loci; the chain of the arithmetic alone is a quarter of that.
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F && f)
+{
+  if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
+template <int N>
+__device__ __forceinline__ void eigen_sym_static(double (&a)[N][N], double (&d)[N], double (&e)[N])
+{
+  static_for<0, N - 1>([&](auto T_)
+  {
+    constexpr int i = N - 1 - decltype(T_)::value;
+    constexpr int l = i;
+    double h = 0, scale = 0;
+    if constexpr (l > 1)
+    {
+#pragma unroll
+      for (int k = 0; k < l; ++k) scale += fabs(a[k][i]);
+      if (scale == 0.0)
+        e[i] = a[l-1][i];
+      else
+      {
+#pragma unroll
+        for (int k = 0; k < l; ++k) { a[k][i] /= scale; h += a[k][i]*a[k][i]; }
+        double f = a[l-1][i];
+        double g = (f > 0) ? -sqrt(h) : sqrt(h);
+        e[i] = scale*g;
+        h -= f*g;
+        a[l-1][i] = f - g;
+        f = 0.0;
+#pragma unroll
+        for (int j = 0; j < l; ++j)
+        {
+          a[i][j] = a[j][i]/h;
+          g = 0.0;
+#pragma unroll
+          for (int k = 0; k <= j; ++k)    g += a[k][j]*a[k][i];
+#pragma unroll
+          for (int k = j + 1; k < l; ++k) g += a[j][k]*a[k][i];
+          e[j] = g/h;
+          f += e[j]*a[j][i];
+        }
+        const double hh = f/(h + h);
+#pragma unroll
+        for (int j = 0; j < l; ++j)
+        {
+          f = a[j][i];
+          g = e[j] - hh*f;
+          e[j] = g;
+#pragma unroll
+          for (int k = 0; k <= j; ++k) a[k][j] -= (f*e[k] + g*a[k][i]);
+        }
+      }
+    }
+    else
+      e[i] = a[l-1][i];
+    d[i] = h;
+  });
+  d[0] = 0.0; e[0] = 0.0;
+  static_for<0, N>([&](auto I_)
+  {
+    constexpr int i = decltype(I_)::value;
+    constexpr int l = i;
+    if (d[i] != 0.0)
+    {
+#pragma unroll
+      for (int j = 0; j < l; ++j)
+      {
+        double g = 0.0;
+#pragma unroll
+        for (int k = 0; k < l; ++k) g += a[k][i]*a[j][k];
+#pragma unroll
+        for (int k = 0; k < l; ++k) a[j][k] -= g*a[i][k];
+      }
+    }
+    d[i] = a[i][i];
+    a[i][i] = 1.0;
+#pragma unroll
+    for (int j = 0; j < l; ++j) a[i][j] = a[j][i] = 0.0;
+  });
+#pragma unroll
+  for (int i = 1; i < N; ++i) e[i-1] = e[i];
+  e[N-1] = 0.0;
+  static_for<0, N - 1>([&](auto L_)               // (l = N - 1: nothing to do, m = l at once)
+  {
+    constexpr int l = decltype(L_)::value;
+    for (int iter = 0; iter < 60; ++iter)
+    {
+      int m = N - 1;
+      bool found = false;
+#pragma unroll
+      for (int mm = 0; mm + 1 < N; ++mm)
+        if (mm >= l && !found)
+        {
+          const double dd = fabs(d[mm]) + fabs(d[mm+1]);
+          if (fabs(e[mm]) + dd == dd) { m = mm; found = true; }
+        }
+      if (m == l) break;
+      double g = (d[l+1] - d[l])/(2.0*e[l]);
+      double r = sqrt(g*g + 1.0);
+      double dm = d[N-1];
+#pragma unroll
+      for (int mm = 0; mm + 1 < N; ++mm) if (mm == m) dm = d[mm];
+      g = dm - d[l] + e[l]/(g + ((g < 0) ? -fabs(r) : fabs(r)));
+      double s = 1.0, c = 1.0, p = 0.0;
+#pragma unroll
+      for (int i = N - 2; i >= 0; --i)
+        if (i <= m - 1 && i >= l)
+        {
+          double f = s*e[i];
+          const double b = c*e[i];
+          if (fabs(f) >= fabs(g))
+          {
+            c = g/f;
+            r = sqrt(c*c + 1.0);
+            e[i+1] = f*r;
+            c *= (s = 1.0/r);
+          }
+          else
+          {
+            s = f/g;
+            r = sqrt(s*s + 1.0);
+            e[i+1] = g*r;
+            s *= (c = 1.0/r);
+          }
+          g = d[i+1] - p;
+          r = (d[i] - g)*s + 2.0*c*b;
+          p = s*r;
+          d[i+1] = g + p;
+          g = c*r - b;
+#pragma unroll
+          for (int k = 0; k < N; ++k)
+          {
+            f = a[i+1][k];
+            a[i+1][k] = s*a[i][k] + c*f;
+            a[i][k]   = c*a[i][k] - s*f;
+          }
+        }
+      d[l] = d[l] - p;
+      e[l] = g;
+#pragma unroll
+      for (int mm = 0; mm < N; ++mm) if (mm == m) e[mm] = 0.0;
+    }
+  });
+}
+
 // freqs/subst -> eigenvals, eigenvecs (u_m[k] sqrt(pi_k)), inv_eigenvecs (u_m[j]/sqrt(pi_j))
 // work space of one lane's eigensystem: the solver indexes it with run-time indices, so as private arrays it lives in scratch
 // memory (a round trip through the memory hierarchy per access); the 4-state kernels keep one per lane in LDS instead
 template <int N> struct EigenWork { double a[N][N], d[N], e[N]; double pad_; };
+// the 4-state system in registers (eigen_sym_static), inlined into its kernels
+template <int N>
+__device__ __forceinline__ void update_eigen_regs(const double * __restrict__ freqs, const double * __restrict__ subst,
+                                                  double * __restrict__ evals, double * __restrict__ evecs, double * __restrict__ ievecs)
+{
+  {
+    double a[N][N], d[N], e[N], fr[N];
+    constexpr int NP = N*(N-1)/2;
+    const double last = subst[NP-1];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { fr[i] = freqs[i];
+#pragma unroll
+      for (int j = 0; j < N; ++j) a[i][j] = 0.0; }
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = i + 1; j < N; ++j)
+      {
+        double x = subst[k++];
+        if (last > 0.0) x /= last;                 // core_pmatrix.c:198-202
+        a[i][j] = a[j][i] = x*sqrt(fr[i]*fr[j]);
+        a[i][i] -= x*fr[j];
+        a[j][j] -= x*fr[i];
+      }
+    double mean = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) mean += fr[i]*(-a[i][i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) a[i][j] /= mean;
+    eigen_sym_static<N>(a, d, e);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+      evals[i] = d[i];
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+      {
+        const double sq = sqrt(fr[j]);
+        ievecs[j*N + i] = a[i][j]/sq;
+        evecs[i*N + j]  = a[i][j]*sq;
+      }
+    }
+  }
+}
 template <int N>
 __device__ void update_eigen_dev(const double * __restrict__ freqs, const double * __restrict__ subst,
                                  double * __restrict__ evals, double * __restrict__ evecs,
                                  double * __restrict__ ievecs, EigenWork<N> & W)
 {
+  if constexpr (N == 4)
+  {
+    update_eigen_regs<4>(freqs, subst, evals, evecs, ievecs);
+    return;
+  }
+  else
+  {
   double (&a)[N][N] = W.a; double (&d)[N] = W.d; double (&e)[N] = W.e;
   constexpr int NP = N*(N-1)/2;
   const double last = subst[NP-1];
@@ -2753,6 +2956,7 @@ __device__ void update_eigen_dev(const double * __restrict__ freqs, const double
       evecs[i*N + j]  = a[i][j]*sq;
     }
   }
+  }
 }
 
 template <int N>
@@ -2769,7 +2973,6 @@ __device__ void update_eigen_dev(const double * __restrict__ freqs, const double
 template <int SK>
 __global__ void __launch_bounds__(64) eigen_kernel(const LocusDev * loci, const uint32_t * list, uint32_t count)
 {
-  __shared__ EigenWork<4> s_w4[SK == 20 ? 1 : 64];
   const uint32_t i = blockIdx.x*64 + threadIdx.x;
   if (i >= count) return;
   const LocusDev & L = loci[list[i]];
@@ -2778,7 +2981,7 @@ __global__ void __launch_bounds__(64) eigen_kernel(const LocusDev * loci, const 
   {
     double * pm = L.par + par_matrix(R, S, m);
     if (SK == 4 || (SK == 0 && S == 4))
-      update_eigen_dev<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4), s_w4[SK == 20 ? 0 : threadIdx.x]);
+      update_eigen_regs<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
     else
       update_eigen_dev<20>(pm + pm_freqs(20), pm + pm_subst(20), pm + pm_evals(20), pm + pm_evecs(20), pm + pm_ievecs(20));
   }
@@ -2802,7 +3005,7 @@ __global__ void __launch_bounds__(64) params_install_kernel(const LocusDev * loc
   if (which == 1u) for (uint32_t i = 0; i < S; ++i) pm[pm_freqs(S) + i] = v[i];
   if (which == 2u) for (uint32_t i = 0; i < S*(S-1)/2; ++i) pm[pm_subst(S) + i] = v[i];
   if (L.model == 0) return;                       // JC69: no eigensystem
-  if (SK == 4 || (SK == 0 && S == 4)) update_eigen_dev<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
+  if (SK == 4 || (SK == 0 && S == 4)) update_eigen_regs<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
   else                                update_eigen_dev<20>(pm + pm_freqs(20), pm + pm_subst(20), pm + pm_evals(20), pm + pm_evecs(20), pm + pm_ievecs(20));
 }
 
