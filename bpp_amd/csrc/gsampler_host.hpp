@@ -459,20 +459,43 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
         const unsigned e0 = (h ? s->g_ssplit : 0u)*s->g_maxmat, e1 = (h ? e->pack_slots : s->g_ssplit)*s->g_maxmat;
         hipStream_t st = h ? s->g_stream2 : e->stream;
         d.blk0 = b0; d.ent0 = e0;
+        static const char * fa_env = getenv("BPA_GS_FUSEA");
+        const bool fuse_a = fa_env ? fa_env[0] != '0' : e->pack_blocks <= 1536u;
+        if (fuse_a)
+        {
+          d.flags = 1u | 2u | 4u;
+          hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false, 0, true>), dim3(b1 - b0), block, 0, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
+          s->launches += 1;
+          continue;
+        }
         d.flags = 1u;
         hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3(((e1 - e0)*d.pad + 255u)/256u), dim3(256), 0, st, d, e1);
         d.flags = 2u | 4u;
         hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), dim3(b1 - b0), block, 0, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
+        s->launches += 2;
       }
       HIPCHK(hipGetLastError());
-      s->launches += 4; s->g_evals += 2;
+      s->g_evals += 2;
       return 1;
     }
-    d.flags = 1u;
-    hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((d.nmat*d.pad + 255u)/256u), dim3(256), 0, e->stream, d, d.nmat);
-    d.flags = 2u | 4u;
-    hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), grid, block, 0, e->stream, k0, k1, 0, d);
-    s->launches += 2;
+    // a small set: the P-matrix phase inside the step launch (BPA_GS_FUSEA=0 / 1: never / always).  Measured on config 3:
+    // 1 250 loci 546 -> 567 it/s, 5 000 loci 308 -> 296, 10 000 loci 189 -> 173: up to 1 536 workgroups of the packing
+    static const char * fa_env = getenv("BPA_GS_FUSEA");
+    const bool fuse_a = fa_env ? fa_env[0] != '0' : e->pack_blocks <= 1536u;
+    if (fuse_a)
+    {
+      d.flags = 1u | 2u | 4u;
+      hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false, 0, true>), grid, block, 0, e->stream, k0, k1, 0, d);
+      s->launches += 1;
+    }
+    else
+    {
+      d.flags = 1u;
+      hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((d.nmat*d.pad + 255u)/256u), dim3(256), 0, e->stream, d, d.nmat);
+      d.flags = 2u | 4u;
+      hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), grid, block, 0, e->stream, k0, k1, 0, d);
+      s->launches += 2;
+    }
   }
   HIPCHK(hipGetLastError());
   s->g_evals++;

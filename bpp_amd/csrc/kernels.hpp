@@ -2261,13 +2261,16 @@ __global__ void __launch_bounds__(256) pmatrix_s4_dense_kernel(const PlanDev P, 
   pmatrix_s4_rec(m, P.mat_length, k);
 }
 
-template <int BS, bool WITH_A, int OCC = 0>        // OCC: waves per SIMD the register allocation is held to (0: the compiler's choice)
+// FUSE_A: the block's P-matrix entries first, a workgroup barrier, then its node updates — ONE launch for a step of a small
+// set (a strong-scaling rank's share), where the dense P-matrix launch is 6.6 us + a launch boundary for microseconds of work;
+// the registers of both phases in one kernel cost occupancy, so large sets keep the two launches
+template <int BS, bool WITH_A, int OCC = 0, bool FUSE_A = false>        // OCC: waves per SIMD the register allocation is held to (0: the compiler's choice)
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(OCC ? OCC : 1, OCC ? OCC : 8)))
 step_s4_klane_v2_kernel(const PlanDev P)
 {
   __shared__ double s_term[BS], s_tr[BS];
   const uint32_t b = P.blk0 + blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
-  if (WITH_A)
+  if (WITH_A || (FUSE_A && (P.flags & 1u)))
   {
     if (!(P.flags & 1u)) return;
     const uint32_t e0 = P.blk_mat_off[b], e1 = P.blk_mat_off[b+1], rmax = P.pad;
@@ -2282,7 +2285,8 @@ step_s4_klane_v2_kernel(const PlanDev P)
       m.dst = M.pmat + (size_t)m2.pmatrix*M.rate_cats*M.pstride; m.par = M.par; m.rate_cats = M.rate_cats; m.model = M.model; m.entry = e; m.pad = 0;
       pmatrix_s4_rec(m, P.mat_length, k);
     }
-    return;
+    if (WITH_A) return;
+    __syncthreads();                                         // the block's fresh P-matrices are out (written and read on this CU)
   }
   const uint32_t s0 = P.blk_slot_off[b], s1 = P.blk_slot_off[b+1];
   const LaneStatic ls = P.lane_tab[gl];
