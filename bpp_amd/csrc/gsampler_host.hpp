@@ -426,7 +426,14 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     s->launches += 3; s->g_evals++;
     return 1;
   }
-  if (!gs_refresh_eigen(s)) return 0;
+  // a small multi-category set: the eigensystem refresh and the P-matrix phase inside the step launch (BPA_GS_FUSEA=0 / 1: never /
+  // always).  Measured on config 3: 1 250 loci 546 -> 567 it/s (P-matrix phase), 5 000 loci 308 -> 296, 10 000 loci 189 -> 173:
+  // up to 1 536 workgroups of the packing
+  static const char * fa_env = getenv("BPA_GS_FUSEA");
+  const bool fuse_a = !s->g_alljc && (fa_env ? fa_env[0] != '0' : e->pack_blocks <= 1536u);
+  const bool fuse_eigen = fuse_a && s->g_eigen_dirty;
+  if (fuse_eigen) s->g_eigen_dirty = false;
+  else if (!gs_refresh_eigen(s)) return 0;
   PlanDev d{};
   d.loci = e->d_loci.p; d.bfbeta = e->bfbeta;
   d.site_term = s->g_site.p; d.lnl = s->g_lnl.p; d.ntasks = s->nloci; d.npatterns = s->g_npat; d.nmat = e->pack_slots*s->g_maxmat;
@@ -459,11 +466,9 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
         const unsigned e0 = (h ? s->g_ssplit : 0u)*s->g_maxmat, e1 = (h ? e->pack_slots : s->g_ssplit)*s->g_maxmat;
         hipStream_t st = h ? s->g_stream2 : e->stream;
         d.blk0 = b0; d.ent0 = e0;
-        static const char * fa_env = getenv("BPA_GS_FUSEA");
-        const bool fuse_a = fa_env ? fa_env[0] != '0' : e->pack_blocks <= 1536u;
         if (fuse_a)
         {
-          d.flags = 1u | 2u | 4u;
+          d.flags = 1u | 2u | 4u | (fuse_eigen ? 32u : 0u);
           hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false, 0, true>), dim3(b1 - b0), block, 0, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
           s->launches += 1;
           continue;
@@ -478,13 +483,9 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
       s->g_evals += 2;
       return 1;
     }
-    // a small set: the P-matrix phase inside the step launch (BPA_GS_FUSEA=0 / 1: never / always).  Measured on config 3:
-    // 1 250 loci 546 -> 567 it/s, 5 000 loci 308 -> 296, 10 000 loci 189 -> 173: up to 1 536 workgroups of the packing
-    static const char * fa_env = getenv("BPA_GS_FUSEA");
-    const bool fuse_a = fa_env ? fa_env[0] != '0' : e->pack_blocks <= 1536u;
     if (fuse_a)
     {
-      d.flags = 1u | 2u | 4u;
+      d.flags = 1u | 2u | 4u | (fuse_eigen ? 32u : 0u);
       hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false, 0, true>), grid, block, 0, e->stream, k0, k1, 0, d);
       s->launches += 1;
     }

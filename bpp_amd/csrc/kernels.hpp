@@ -2261,6 +2261,9 @@ __global__ void __launch_bounds__(256) pmatrix_s4_dense_kernel(const PlanDev P, 
   pmatrix_s4_rec(m, P.mat_length, k);
 }
 
+template <int N>
+__device__ __forceinline__ void update_eigen_regs(const double * __restrict__ freqs, const double * __restrict__ subst,
+                                                  double * __restrict__ evals, double * __restrict__ evecs, double * __restrict__ ievecs);
 // FUSE_A: the block's P-matrix entries first, a workgroup barrier, then its node updates — ONE launch for a step of a small
 // set (a strong-scaling rank's share), where the dense P-matrix launch is 6.6 us + a launch boundary for microseconds of work;
 // the registers of both phases in one kernel cost occupancy, so large sets keep the two launches
@@ -2270,6 +2273,22 @@ step_s4_klane_v2_kernel(const PlanDev P)
 {
   __shared__ double s_term[BS], s_tr[BS];
   const uint32_t b = P.blk0 + blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
+  if (FUSE_A && (P.flags & 32u))
+  {
+    // K6 first: the block's loci had their frequencies / exchangeabilities moved since their eigensystems were made
+    // (a parameter step of the device sampler: the launch of eigen_kernel it replaces was 16 us + a launch boundary)
+    const uint32_t q0 = P.blk_slot_off[b], q1 = P.blk_slot_off[b+1];
+    if (lane < q1 - q0)
+    {
+      const LocusDev & L = P.loci[P.slot_tab[q0 + lane].locus];
+      for (uint32_t m = 0; m < L.rate_matrices; ++m)
+      {
+        double * pm = L.par + par_matrix(L.rate_cats, 4, m);
+        update_eigen_regs<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
+      }
+    }
+    __syncthreads();
+  }
   if (WITH_A || (FUSE_A && (P.flags & 1u)))
   {
     if (!(P.flags & 1u)) return;
