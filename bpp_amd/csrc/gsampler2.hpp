@@ -1,16 +1,19 @@
-// gsampler2.hpp — the generic sampler's per-locus proposal steps (GAGE, GSPR) with a GROUP of lanes per locus.
+// gsampler2.hpp — the generic sampler's proposal steps (GAGE, GSPR, TAU, MIX) with a GROUP of lanes per locus, and the
+// per-locus steps of an iteration as one launch for small JC69 sets.
 //
 // gsampler.hpp's gstep_kernel gives every locus ONE lane that runs the host driver's proposal code alone: ~3 500 dependent
-// instructions, 24-36 us for a launch whatever the number of loci — the fixed cost of every step of configs 3 / 5, of a
+// instructions, 24-50 us for a launch whatever the number of loci — the fixed cost of every step of configs 3 / 5, of a
 // strong-scaling rank's share, of a composite's small parts.  Here a locus owns 2 NT lanes (16 for <= 8 tips, 32 for <= 16)
 // and the proposal is sweep2.hpp's: the integer tree replicated in every lane's registers (byte arrays), lane i = node i,
-// population i, branch i; loops over nodes and populations are ballots restricted to the group (propose_gage /
-// propose_gspr of sweep2.hpp, the persistent kernel's own functions: same streams, same draws, same arithmetic as the host
-// driver — tests/test_gpu_gsampler.py walks its trajectory); TAU and MIX are sweep2.hpp's step_locus.  Everything around the proposal is gstep_kernel's, statement for
-// statement: the previous step is settled first (its decision, or the roll-back from the undo copy), the state a rejection
-// comes back to is saved, the step is written as the records of the engine's kernels (StepRec / StepOp / MatRec2, or the
-// 20-state kernels' OpDev ranges), the tree goes back to HBM.  The other modes (settle + THETA statistics, start-up, the
-// substitution-parameter moves) stay with gstep_kernel.
+// population i, branch i; loops over nodes and populations are ballots restricted to the group (propose_gage / propose_gspr
+// of sweep2.hpp, the persistent kernel's own functions: same streams, same draws, same arithmetic as the host driver —
+// tests/test_gpu_gsampler.py walks its trajectory); TAU and MIX are sweep2.hpp's step_locus.  Everything around the
+// proposal is gstep_kernel's, statement for statement: the previous step is settled first (its decision, or the roll-back
+// from the undo copy), the state a rejection comes back to is saved, the step is written as the records of the engine's
+// kernels (StepRec / StepOp / MatRec2, or the OpDev ranges of the 20-state kernels and of the chain below), the tree goes
+// back to HBM.  BPA_GS_DIFF=1 (gsampler_host.hpp) runs a step by both kernels from the same state and compares all of that.
+// The other modes (settle + THETA statistics, start-up, the substitution-parameter moves) stay with gstep_kernel.
+// 12-14 us a launch for <= 8 tips, 15-20 for <= 16 (profiles/r4/gstep2.txt): one wave's ~9 500 instructions.
 #pragma once
 
 namespace gsm2 {
