@@ -74,7 +74,8 @@ static int gs_upload(bpa_sampler * s)
 {
   bpa_engine * e = s->eng;
   const unsigned T = s->nloci;
-  if (!s->g_s20 && !engine_pack(e)) return 0;
+  // (the locus table first: flush_state marks the packing stale when it had to send the table)
+  if (!s->g_s20 && (!flush_state(e) || !engine_pack(e))) return 0;
   if (s->g_s20 && !flush_state(e)) return 0;        // (tip states, weights, parameter blocks, eigensystems on the device)
   for (unsigned i = 0; i < T; ++i) if (!assign_pops_host(s, s->g_trees[i])) return 0;
   for (int p = 0; p < smp::MAXPOP; ++p) s->has_theta[p] = p >= s->sp.S && p < s->sp.npop;
@@ -131,7 +132,6 @@ static int gs_upload(bpa_sampler * s)
   {
     // the chain launch of the per-locus steps (gchain_kernel) evaluates with the engine's one-lane-per-pattern functions:
     // a task per locus and the step's records in the OpDev form, next to the packing's compact records
-    if (!flush_state(e)) return 0;
     std::vector<uint32_t> tl(T), tp(T + 1);
     std::vector<int32_t> rs(T, BPA_SCALE_BUFFER_NONE);
     unsigned off = 0;
