@@ -203,6 +203,19 @@ static int gs_upload(bpa_sampler * s)
       s->g_split = true; s->g_isplit = is; s->g_ssplit = ss; s->g_bsplit = bs;
     }
   }
+  // 20-state sets: two halves of the loci (the step's records are per locus, the tiles in locus order): the proposal, P-matrix
+  // and sum launches of one half — latency, 70 us of a 385 us step on config 4 — run under the other half's node updates
+  static const bool no_split20 = getenv("BPA_GS_NOSPLIT") != nullptr;
+  if (s->g_s20 && !no_split20 && e->usedata && T >= 128)
+  {
+    if (!s->g_stream2) HIPCHK(hipStreamCreateWithFlags(&s->g_stream2, hipStreamNonBlocking));
+    if (!s->g_ev_fork) HIPCHK(hipEventCreateWithFlags(&s->g_ev_fork, hipEventDisableTiming));
+    if (!s->g_ev_join) HIPCHK(hipEventCreateWithFlags(&s->g_ev_join, hipEventDisableTiming));
+    s->g_split = true; s->g_isplit = T/2; s->g_ssplit = 0; s->g_bsplit = 0;
+    unsigned nt = 0;
+    for (unsigned i = 0; i < T/2; ++i) nt += (s->loci[i]->sites + 63u)/64u;
+    s->g_tsplit = nt;
+  }
   s->uploaded = true;
   return 1;
 }
@@ -416,11 +429,30 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
       s->timed.push_back(t);
       k0 = t.e0; k1 = t.e1;
     }
+    const size_t lds20 = ((size_t)4*s->g_rmax*400 + (size_t)s->g_rmax*64)*sizeof(double);
+    if (s->g_forked)
+    {
+      for (int h = 0; h < 2; ++h)
+      {
+        const unsigned i0 = h ? s->g_isplit : 0u, i1 = h ? s->nloci : s->g_isplit, t0 = h ? s->g_tsplit : 0u, t1 = h ? s->g_ntiles : s->g_tsplit;
+        hipStream_t st = h ? s->g_stream2 : e->stream;
+        d.ent0 = i0*s->g_maxmat;
+        d.flags = 1u | 256u;
+        hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3((i1 - i0)*s->g_maxmat), dim3(256), 0, st, d);
+        d.blk0 = t0;
+        d.flags = 4u | 64u | 256u;
+        hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
+        d.blk0 = i0;
+        hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(i1 - i0), dim3(64), 0, st, d);
+      }
+      HIPCHK(hipGetLastError());
+      s->launches += 6; s->g_evals += 2;
+      return 1;
+    }
     d.flags = 1u;
     hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d);
     d.flags = 4u | 64u;
-    hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax),
-                          ((size_t)4*s->g_rmax*400 + (size_t)s->g_rmax*64)*sizeof(double), e->stream, k0, k1, 0, d);
+    hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
     hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(s->nloci), dim3(64), 0, e->stream, d);
     HIPCHK(hipGetLastError());
     s->launches += 3; s->g_evals++;

@@ -502,7 +502,8 @@ partials_lnl_pipe20_kernel(const PlanDev P)
 {
   extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2 buffers][2 children][R][S][S], then [R][64] scratch
   constexpr uint32_t SS = S*S;
-  const uint32_t b = (P.flags & 32u) ? blockIdx.x : xcd_tile(blockIdx.x, gridDim.x), lane = threadIdx.x & 63u, nw = blockDim.x >> 6;     // flags bit 5: plain mapping (A/B)
+  // flags bit 5: plain mapping (A/B); bit 8: the launch covers tiles blk0 .. blk0 + gridDim.x (a half-batch of the device sampler)
+  const uint32_t b = ((P.flags & 256u) ? P.blk0 : 0u) + ((P.flags & 32u) ? blockIdx.x : xcd_tile(blockIdx.x, gridDim.x)), lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
   const uint32_t k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t t = ((cu32_p)P.tile_task)[b];
   const uint32_t n = ((cu32_p)P.tile_n0)[b] + lane;
@@ -975,7 +976,7 @@ __device__ __forceinline__ void lnl_reduce_wave(const PlanDev & P, const uint32_
 }
 __global__ void __launch_bounds__(64) lnl_reduce_wave_kernel(const PlanDev P)
 {
-  lnl_reduce_wave(P, blockIdx.x, threadIdx.x);
+  lnl_reduce_wave(P, blockIdx.x + ((P.flags & 256u) ? P.blk0 : 0u), threadIdx.x);       // (bit 8: a half-batch's loci)
 }
 
 
@@ -2517,7 +2518,7 @@ __global__ void __launch_bounds__(256) pmatrix_wg2_kernel(const PlanDev P)
   static_assert((S*S*8) % 16 == 0, "16-byte staging units");
   __shared__ __attribute__((aligned(16))) double s_evs[2*S*S], s_tmp[4][S*S], s_e[4][S];
   double * const s_ev = s_evs, * const s_iev = s_evs + S*S;
-  const uint32_t e = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t e = blockIdx.x + ((P.flags & 256u) ? P.ent0 : 0u), tid = threadIdx.x, lane = tid & 63u;      // (bit 8: a half-batch's entries)
   const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (((cu32_p)P.mat_task)[e] == 0xffffffffu) return;            // a hole of a device-written step (gsampler.hpp)
   const uint32_t lid = ((cu32_p)P.task_locus)[((cu32_p)P.mat_task)[e]];

@@ -1142,7 +1142,7 @@ struct bpa_sampler
   // two half-batches of the per-locus steps on two streams (gsampler_host.hpp: gs_fork / gs_join): loci [0, g_isplit) are the
   // slots [0, g_ssplit) = workgroups [0, g_bsplit) of the engine's packing, the rest the other half
   bool g_split = false, g_forked = false;
-  unsigned g_isplit = 0, g_ssplit = 0, g_bsplit = 0;
+  unsigned g_isplit = 0, g_ssplit = 0, g_bsplit = 0, g_tsplit = 0;      // (g_tsplit: 20-state sets, the first tile of the second half)
   hipStream_t g_stream2 = nullptr;
   hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
   DevBuf<uint8_t> g_active;

@@ -42,11 +42,13 @@ def walk(host, dev, iters, nloci, check_every=1):
 
 @pytest.mark.parametrize("taxa,model,R,nloci,iters,forced,chain", [(4, "jc69", 1, 300, 5, True, None), (8, "gtr", 4, 60, 3, False, "1"), (8, "gtr", 4, 60, 3, False, "0"),
                                                                    (8, "gtr", 4, 700, 2, False, "0"), (8, "gtr", 4, 700, 2, False, "1"), (8, "jc69", 1, 40, 3, True, "0"),
-                                                                   (8, "jc69", 1, 40, 3, True, None), (6, "lg", 4, 40, 3, False, None), (6, "lg", 1, 24, 2, False, None)])
+                                                                   (8, "jc69", 1, 40, 3, True, None), (6, "lg", 4, 40, 3, False, None), (6, "lg", 1, 24, 2, False, None),
+                                                                   (6, "lg", 4, 300, 2, False, None)])
 def test_generic_sampler_equals_host_driver(taxa, model, R, nloci, iters, forced, chain, monkeypatch):
     """(lg: amino-acid loci — BASELINE config 4's kind —, the steps written on the device as the records of the tiled 20-state
     kernels: pmatrix_wg2_kernel, partials_lnl_pipe20_kernel; 700 GTR loci: enough workgroups of the packing for the per-locus
-    steps to run as two half-batches on two streams — more launches, the same trajectory; chain None: the per-locus steps
+    steps to run as two half-batches on two streams — more launches, the same trajectory; 300 amino-acid loci: the 20-state
+    form of the same, two halves of the loci; chain None: the per-locus steps
     as ONE launch (gsm2::gchain_kernel: the default for small JC69 sets, "1": forced), "0": a launch per step (BPA_GS_CHAIN))"""
     if chain is not None:
         monkeypatch.setenv("BPA_GS_CHAIN", chain)
@@ -82,6 +84,8 @@ def test_generic_sampler_equals_host_driver(taxa, model, R, nloci, iters, forced
     assert w["sweeps"] >= iters*(3*taxa - 3) and w["node_updates"] > 0 and w["bytes"] > 0      # (generic path: evaluated steps)
     if model == "gtr" and chain == "0":
         assert (w["sweeps"] >= iters*2*(3*taxa - 3)) == (nloci >= 700) == (dev.streams() == 2)   # two half-batch launches per per-locus step
+    if model == "lg":
+        assert (dev.streams() == 2) == (nloci >= 128)
     if model != "lg":
         assert (dev.summary()["launches"] < iters*2*(3*taxa - 3)) == (chain != "0")             # the chain: one launch for the per-locus steps (else >= 2 each)
     dev.close(); host.close(); eng.close()
