@@ -391,7 +391,7 @@ int  bpa_sampler_timing(bpa_sampler_t *, double * sweep_ms, unsigned long * swee
 int  bpa_sampler_work(bpa_sampler_t *, double * bytes, unsigned long * node_updates,
                       unsigned long * pattern_updates, unsigned long * sweeps);
 /* which implementation bpa_sampler_iterate runs (known after bpa_sampler_initialize): BPA_SAMPLER_SWEEP (one launch per
-   step, csrc/sampler.hpp), BPA_SAMPLER_GENERIC (csrc/gsampler.hpp) or BPA_SAMPLER_PERSISTENT (csrc/sweep2.hpp: its
+   step, csrc/sampler.hpp), BPA_SAMPLER_GENERIC (csrc/gsampler.hpp, gsampler2.hpp) or BPA_SAMPLER_PERSISTENT (csrc/sweep2.hpp: its
    launches are what bpa_sampler_timing reports as `sweep`, its `sweeps` of bpa_sampler_work are iterations, and the
    work includes the all-loci steps' node updates) */
 #define BPA_SAMPLER_SWEEP      0
