@@ -461,7 +461,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
   // a small multi-category set: the eigensystem refresh and the P-matrix phase inside the step launch (BPA_GS_FUSEA=0 / 1: never /
   // always).  Measured on config 3: 1 250 loci 546 -> 567 it/s (P-matrix phase), 5 000 loci 308 -> 296, 10 000 loci 189 -> 173:
   // up to 1 536 workgroups of the packing
-  static const char * fa_env = getenv("BPA_GS_FUSEA");
+  const char * fa_env = getenv("BPA_GS_FUSEA");
   const bool fuse_a = !s->g_alljc && (fa_env ? fa_env[0] != '0' : e->pack_blocks <= 1536u);
   const bool fuse_eigen = fuse_a && s->g_eigen_dirty;
   if (fuse_eigen) s->g_eigen_dirty = false;
