@@ -40,6 +40,133 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
+FP64_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md: FP64 vector peak (the FP64 matrix rate is the same on gfx950)
+HBM_ACHIEVABLE_FRAC = 0.79   # ~6.3 of 8 TB/s is what a streaming kernel reaches (MI355X_MICROARCH.md): a `frac` above it is an accounting artefact
+LINE_LIMIT = 6000            # bytes of the final stdout line (the driver's capture parsed 18.5 KB in round 3 and lost a 26 KB line in round 4)
+
+
+def _rl_compact(r):
+    """the roofline object of the compact line: the contract's keys + the two honest companions of `frac`"""
+    if not isinstance(r, dict):
+        return None
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_pmc", "frac_codes", "flops_frac",
+            "avg_kernel_us", "launches", "algorithmic_bytes_per_launch", "codes_bytes_per_launch", "profile_head", "warning")
+    o = {k: r[k] for k in keep if r.get(k) is not None}
+    o.setdefault("traffic", None)
+    if isinstance(o.get("kernel"), str) and len(o["kernel"]) > 60:
+        o["kernel"] = o["kernel"][:57] + "..."
+    return o
+
+
+def _num(x, nd=3):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(full):
+    """The ONE line the driver parses: the contract's keys, `roofline`, `cpu_baseline`, and per BASELINE config a handful of
+    numbers.  Everything else is in bench_full.json (written next to this file and under gpurun_out/)."""
+    g = full.get
+    cb = g("cpu_baseline") or {}
+    eff = g("ess_per_s") or {}
+    se = g("statistical_efficiency") or {}
+    lo = g("likelihood_only") or {}
+    out = {
+        "metric": g("metric"), "value": g("value"), "unit": "iterations/s", "n_gpus": g("n_gpus"), "steps": g("steps"), "warmup": g("warmup"),
+        "ms_per_step": g("ms_per_step"), "iterations_per_step": g("iterations_per_step"), "ms_per_iteration": g("ms_per_iteration"),
+        "higher_is_better": True, "scaling": g("scaling"), "vs_baseline": g("vs_baseline"), "dtype": g("dtype"), "data": g("data"),
+        "config": {"workload": (g("config") or {}).get("workload_short") or (g("config") or {}).get("workload", "")[:160],
+                   "parallelism": ((g("config") or {}).get("parallelism") or "")[:120], "moves": (g("config") or {}).get("moves")},
+        "roofline": _rl_compact(g("roofline")),
+        "cpu_baseline": ({"value": cb.get("value"), "unit": "iterations/s", "cores": cb.get("cores"), "kind": cb.get("kind"),
+                          "sample": (cb.get("sample_short") or cb.get("sample") or "")[:200], "one_thread": cb.get("one_thread"),
+                          "host_cpu_quota": cb.get("host_cpu_quota")} if cb else None),
+        "value_over_cpu_baseline": (g("speedups") or {}).get("value_over_cpu_baseline"),
+        "site_lnl_updates_per_s": g("site_lnl_updates_per_s"),
+    }
+    if g("value_weak") is not None or g("value_strong") is not None:
+        out["value_weak"], out["value_strong"] = g("value_weak"), g("value_strong")
+        out["allreduce"] = ((g("allreduce") or {}).get("sampler") or "")[:100] or None
+        out["allreduce_check"] = g("allreduce_check")
+    if eff:
+        out["ess_per_s"] = {"ratio": eff.get("ratio"), "device": eff.get("device"), "reference_program": eff.get("reference_program")}
+        epi = {}
+        for who in ("device", "reference_program"):
+            for p in ("tau_root", "theta_root"):
+                v = ((se.get(who) or {}).get(p) or {})
+                if v.get("ess_per_iteration") is not None:
+                    epi.setdefault(who, {})[p] = [v.get("ess_per_iteration"), v.get("ess_per_iteration_se")]
+        if epi:
+            out["ess_per_iteration"] = epi
+    if lo:
+        r = lo.get("roofline") or {}
+        out["likelihood_only"] = {"it_s": lo.get("iterations_per_s"), "kernel": (r.get("kernel") or "")[:50], "frac": r.get("frac"),
+                                  "frac_codes": r.get("frac_codes"), "frac_pmc": r.get("frac_pmc"), "flops_frac": r.get("flops_frac"),
+                                  "avg_kernel_us": r.get("avg_kernel_us")}
+    hc = g("host_control_in_c") or {}
+    if hc.get("iterations_per_s"):
+        out["host_control_in_c_it_s"] = hc["iterations_per_s"]
+    uk = (g("device_resident_sampler") or {}).get("device_uniform_kernel") or {}
+    if uk.get("iterations_per_s"):
+        out["uniform_moves_it_s"] = uk["iterations_per_s"]
+    proj = g("scale_projection")
+    if isinstance(proj, dict) and "error" not in proj:
+        out["share_it_s"] = {k: _num(v.get("iterations_per_s"), 1) for k, v in proj.items() if isinstance(v, dict)}
+    cfgs = {}
+    for key, sec in (g("other_configs") or {}).items():
+        if not isinstance(sec, dict):
+            continue
+        if "error" in sec:
+            cfgs[key] = {"error": str(sec["error"])[:80]}
+            continue
+        smp = sec.get("device_resident_sampler") or {}
+        c = {"it_s": _num(smp.get("iterations_per_s", sec.get("iterations_per_s")), 2)}
+        if sec.get("iterations_per_s") is not None and smp:
+            c["tape_it_s"] = _num(sec.get("iterations_per_s"), 2)
+        if isinstance(sec.get("cpu_baseline"), dict):
+            c["cpu_it_s"] = _num(sec["cpu_baseline"].get("value"), 3)
+            c["cpu_cores"] = sec["cpu_baseline"].get("cores")
+            if c["cpu_it_s"] and c["it_s"]:
+                c["ratio"] = round(c["it_s"] / c["cpu_it_s"], 2)
+        if smp.get("moves_short") or sec.get("moves"):
+            c["moves"] = smp.get("moves_short") or str(sec.get("moves"))[:40]
+        if smp.get("launches_per_iteration") is not None:
+            c["launches_per_it"] = _num(smp.get("launches_per_iteration"), 1)
+        r = sec.get("roofline") or {}
+        for k in ("frac", "frac_codes", "frac_pmc", "flops_frac", "avg_kernel_us"):
+            if r.get(k) is not None:
+                c[k] = r[k]
+        if r.get("kernel"):
+            c["kernel"] = r["kernel"].split("<")[0]
+        rs = smp.get("roofline") or {}
+        if rs.get("frac") is not None:
+            c["sampler_frac"] = rs.get("frac")
+            if rs.get("frac_codes") is not None:
+                c["sampler_frac_codes"] = rs.get("frac_codes")
+        sp = sec.get("scale_projection")
+        if isinstance(sp, dict) and "error" not in sp:
+            c["share_it_s"] = {k: _num(v.get("iterations_per_s"), 1) for k, v in sp.items() if isinstance(v, dict)}
+        cfgs[key] = c
+    if cfgs:
+        out["configs"] = cfgs
+    out["full_record"] = "bench_full.json"
+    # never let the line outgrow the driver's capture: drop the optional parts, least important first
+    for victim in ("share_it_s", "host_control_in_c_it_s", "uniform_moves_it_s", "ess_per_iteration", "likelihood_only", "configs", "ess_per_s"):
+        if len(json.dumps(out, separators=(",", ":"))) <= LINE_LIMIT:
+            break
+        out.pop(victim, None)
+    return out
+
+
+def write_full_record(full, where=None):
+    for path in ((where,) if where else (os.path.join(ROOT, "bench_full.json"), os.path.join(ROOT, "gpurun_out", "bench_full.json"))):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    json.dump(full, f, indent=1)
+        except OSError as ex:
+            log(f"bench_full.json not written to {path}: {ex}")
+
+
 CONFIGS = {
     "c2": dict(taxa=4, model="jc69", rate_cats=1, sites=1000, loci=10000, taus=(0.001, 0.002, 0.003),
                name="C2: A00, 10000 loci x 1000 sites, 4 taxa, JC69, 1 rate cat"),
@@ -646,6 +773,41 @@ def traffic_from_profiles(config, kernel):
         return None, None
 
 
+def add_honest_fracs(r, codes_ratio=None, flops_per_launch=None, codes_note=None):
+    """next to SURVEY 8d's `frac`: `frac_codes` (the same launches priced as the kernels hold the data: tip children as codes,
+    forwarded parents not re-read — bpa_plan_work_codes) and `flops_frac` (K1's Np R (4S^2 - S) flops / the kernel's time / the
+    FP64 peak); a `frac` above what HBM can stream is flagged as the accounting artefact it is"""
+    if not isinstance(r, dict):
+        return r
+    if codes_ratio:
+        r["codes_bytes_per_launch"] = round(r["algorithmic_bytes_per_launch"] * codes_ratio)
+        r["frac_codes"] = round(r["frac"] * codes_ratio, 5)
+        if codes_note:
+            r["frac_codes_note"] = codes_note
+    if flops_per_launch and r.get("avg_kernel_us"):
+        r["flops_per_launch"] = round(flops_per_launch)
+        r["tflops"] = round(flops_per_launch / (r["avg_kernel_us"] * 1e-6) / 1e12, 3)
+        r["flops_frac"] = round(r["tflops"] / FP64_PEAK_TFLOPS, 5)
+        r["flops_peak"] = FP64_PEAK_TFLOPS
+    if r.get("frac", 0) > HBM_ACHIEVABLE_FRAC:
+        r["warning"] = (f"frac {r['frac']} > {HBM_ACHIEVABLE_FRAC}: more than HBM can stream; SURVEY 8d's bytes charge a tip child as a one-hot "
+                        "CLV the kernel reads as codes - read frac_codes / frac_pmc")
+    return r
+
+
+def profile_head(config):
+    """the source hash (tools/src_hash.py) the committed profile of `config` was taken on, and whether it is this tree's"""
+    try:
+        import glob
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from src_hash import src_hash
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"profile_{config}.json")))
+        sha = json.load(open(cands[-1])).get("kernels_sha")
+        return f"{sha} ({'= this build' if sha == src_hash() else 'NOT this build: ' + src_hash()})"
+    except Exception:       # noqa: BLE001
+        return None
+
+
 def add_frac_pmc(r):
     """`frac_pmc`: HBM bytes actually MOVED per launch (the PMC passes under profiles/) / the launch's duration / the HBM peak —
     next to `frac`, which prices the algorithmic bytes"""
@@ -792,6 +954,9 @@ def run_tape(eng, cfg, config_key, data, loci, args, D, steps, warmup):
     it_node_updates = np.mean([sum(w["node_updates"] for w in it) for it in work])
     it_flops = np.mean([sum(w["flops_partials"] for w in it) for it in work])
     steps_per_iter = float(np.mean([len(it) for it in plans]))
+    tot_b = sum(w["bytes_partials"] for it in work for w in it)
+    codes_ratio_k1k2 = sum(w["bytes_codes"] for it in work for w in it) / max(tot_b, 1.0)   # (handed to the sampler sections of the same config)
+    flops_per_byte = sum(w["flops_partials"] for it in work for w in it) / max(tot_b, 1.0)
 
     # launch segments: consecutive steps up to and including an all-loci step (TAU/MIX), whose summed lnL is then
     # all-reduced across ranks — the per-proposal reduction of threads.c:544-591.  Inside a segment bpa_plans_launch
@@ -889,8 +1054,9 @@ def run_tape(eng, cfg, config_key, data, loci, args, D, steps, warmup):
                         avg_kernel_us=round(1e3 * tm["partials_ms"] / tm["launches"], 3),
                         avg_us_per_proposal_step=round(1e3 * tm["partials_ms"] / max(tm["steps"], 1), 3),
                         algorithmic_bytes_per_launch=round(tm["bytes"] / tm["launches"]),
-                        launches=tm["launches"], proposal_steps=tm["steps"],
+                        launches=tm["launches"], proposal_steps=tm["steps"], profile_head=profile_head(config_key) if traffic else None,
                         timing=f"hipExtLaunchKernelGGL start/stop events on the engine stream, every {args.event_stride}-th launch of the timed region")
+        add_honest_fracs(roofline, tm["bytes_codes"] / max(tm["bytes"], 1.0), flops_per_byte * tm["bytes"] / tm["launches"])
     out = dict(
         workload=cfg["name"] + f"; {nloci} loci on this rank, {sum(len(d['weights']) for d in data) / nloci:.2f} patterns/locus, "
                  f"{steps_per_iter:.0f} batched proposal steps/iteration ({it_node_updates / nloci:.1f} node updates + "
@@ -902,7 +1068,7 @@ def run_tape(eng, cfg, config_key, data, loci, args, D, steps, warmup):
         site_lnl_updates_per_s=round(it_pattern_updates * (total_loci / nloci) * steps / elapsed),
         node_updates_per_iteration=round(float(it_node_updates)),
         gflops_partials=round(it_flops * (total_loci / nloci) * steps / elapsed / 1e9, 2),
-        roofline=add_frac_pmc(roofline), allreduce_check=allreduce_check,
+        roofline=add_frac_pmc(roofline), allreduce_check=allreduce_check, codes_ratio=round(codes_ratio_k1k2, 5),
         note="pre-recorded proposal tape, accept/reject by a seeded coin: the likelihood path alone (no MCMC decision)")
     for it in plans:
         for p in it:
@@ -916,7 +1082,7 @@ def run_tape(eng, cfg, config_key, data, loci, args, D, steps, warmup):
 PROGRAM_FT = dict(gage=18.5, gspr=0.0019, theta=3e-5, tau=1.9e-5, mix=0.0059)
 
 
-def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves="program"):
+def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves="program", codes_ratio=None):
     """BASELINE's metric proper: whole A00 MCMC iterations/s with every decision on the device.
     moves = "program" (JC69 loci on the persistent kernel): BPP's own iteration — its generator and Bactrian-Laplace windows
     (bpa_sampler_set_proposal_kernel), theta by the metropolized Gibbs draw 9 times in 10, thetas re-drawn inside the
@@ -1108,6 +1274,15 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves
                         note=f"one launch = the {3 * cfg['taxa'] - 3} per-locus proposals of an iteration for every locus, proposal control included; "
                              "algorithmic bytes = K1 + K2 + K4 of the node updates the proposals actually ran (device counters); the working "
                              "set lives in LDS for the whole launch: latency-bound by the leader lanes' serial proposal code, not by HBM")
+    if roofline is not None:
+        # K1 flops of the timed launches: pattern updates x R x (4 S^2 - S) (device counters); `codes_ratio`: the same config's
+        # tape (exact per plan: bpa_plan_work_codes) — the samplers count node updates, not which children were tips
+        S_ = 20 if cfg["model"] == "lg" else 4
+        fl = (w1["pattern_updates"] - w0["pattern_updates"]) * cfg["rate_cats"] * (4 * S_ * S_ - S_)
+        nl_ = max(round((w1["bytes"] - w0["bytes"]) / max(roofline["algorithmic_bytes_per_launch"], 1)), 1)
+        add_honest_fracs(roofline, codes_ratio, fl / nl_, "codes / algorithmic byte ratio of this config's tape (likelihood_only.codes_ratio)" if codes_ratio else None)
+        if roofline.get("traffic"):
+            roofline["profile_head"] = profile_head("c2" if cfg["model"] == "jc69" else "c3" if gtr else "c4")
     out = dict(iterations_per_s=round(niter / dt, 3), iterations_per_s_10k_loci=round(niter / dt * total_loci / 10000.0, 3),
                ms_per_iteration=round(1e3 * dt / niter, 5), ms_per_step=round(1e3 * dt / steps, 4), iterations_per_step=ips,
                timed_region_s=round(dt, 4), steps=steps, warmup=warmup, n_gpus=world, loci_total=total_loci, kind=kind,
@@ -1154,6 +1329,8 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="N > 1: weak = every rank owns its own data set of the config's size; strong = ONE data set of the "
                          "config's size, loci dealt to the ranks by the reference's zig-zag (threads.c:265-353)")
+    ap.add_argument("--full-record", default=None,
+                    help="where the full record goes (default: bench_full.json next to this file and under gpurun_out/); the stdout line is the compact one")
     ap.add_argument("--tape-iters", type=int, default=4, help="distinct A00 iterations in the resident tape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sampler", action="store_true", help="c2: skip the device-resident sampler (`value` is then the tape's)")
@@ -1241,12 +1418,12 @@ def main():
     if not (args.config in ("c2", "c3") and args.no_tape):
         tape_sec, tape_steps = run_tape(eng, cfg, args.config, data, loci, args, D, args.steps, args.warmup)
     if args.config in ("c2", "c3", "c4") and not args.no_sampler:
-        sampler_sec = run_sampler(eng, cfg, data, loci, args, D, first_locus, args.steps, args.warmup)
+        sampler_sec = run_sampler(eng, cfg, data, loci, args, D, first_locus, args.steps, args.warmup, codes_ratio=(tape_sec or {}).get("codes_ratio"))
         if "error" in sampler_sec:
             log(sampler_sec["error"])
         elif args.config == "c2" and D is None and not args.no_uniform_kernel:
             # rounds 1-3's headline iteration (half the program's effective samples per iteration), for comparison
-            u = run_sampler(eng, cfg, data, make_loci(eng, data), args, None, first_locus, max(args.steps // 4, 5), args.warmup, moves="uniform")
+            u = run_sampler(eng, cfg, data, make_loci(eng, data), args, None, first_locus, max(args.steps // 4, 5), args.warmup, moves="uniform", codes_ratio=(tape_sec or {}).get("codes_ratio"))
             sampler_sec["device_uniform_kernel"] = {k: u[k] for k in ("iterations_per_s", "ms_per_iteration", "acceptance", "moves", "roofline") if k in u}
 
     other_mode = None
@@ -1327,7 +1504,7 @@ def main():
                 a2.loci = None
                 sec, _ = run_tape(e2, oc, key, d2, l2, a2, None, k_steps, k_warm)
                 sec["unit"] = f"iterations/s (one iteration = the A00 proposal schedule over this config's {oc['loci']} loci)"
-                sec["device_resident_sampler"] = run_sampler(e2, oc, d2, l2, a2, None, 0, k_steps, k_warm)
+                sec["device_resident_sampler"] = run_sampler(e2, oc, d2, l2, a2, None, 0, k_steps, k_warm, codes_ratio=sec.get("codes_ratio"))
                 e2.close()
                 if not args.no_cpu_baseline:
                     sec["cpu_baseline"] = other_config_cpu_baseline(key, d2)
@@ -1495,7 +1672,8 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        write_full_record(out, args.full_record)
+        print(json.dumps(compact_line(out), separators=(",", ":")), flush=True)
 
 
 if __name__ == "__main__":

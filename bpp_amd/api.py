@@ -162,6 +162,8 @@ def lib():
         "bpa_engine_set_timing_stride": (None, [vp, u]),
         "bpa_engine_timing": (i, [vp, dp, dp, dp, C.POINTER(C.c_ulong)]),
         "bpa_engine_timing_work": (i, [vp, C.POINTER(C.c_ulong), dp]),
+        "bpa_engine_timing_work_codes": (i, [vp, dp]),
+        "bpa_plan_work_codes": (i, [vp, dp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -186,7 +188,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_plan_enable_sum", "bpa_plan_enable_partial_sums", "bpa_plan_get_sum",
             "bpa_p2p_create", "bpa_p2p_connect", "bpa_p2p_allreduce", "bpa_p2p_status", "bpa_p2p_destroy", "bpa_p2p_set_timeout", "bpa_plans_launch_exchange", "bpa_plans_launch",
             "bpa_plan_set_params", "bpa_plan_set_params_device", "bpa_engine_stage",
-            "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride", "bpa_engine_timing_work",
+            "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride", "bpa_engine_timing_work", "bpa_engine_timing_work_codes", "bpa_plan_work_codes",
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
             "bpa_sampler_set_species_tree", "bpa_sampler_set_tip_species", "bpa_sampler_set_finetune",
             "bpa_sampler_set_tau_prior", "bpa_sampler_get_taus", "bpa_sampler_get_tree_msc",
@@ -282,8 +284,10 @@ class Engine:
         _chk(lib().bpa_engine_timing(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
         st, by = C.c_ulong(), C.c_double()
         _chk(lib().bpa_engine_timing_work(self.h, C.byref(st), C.byref(by)))
+        bc = C.c_double()
+        _chk(lib().bpa_engine_timing_work_codes(self.h, C.byref(bc)))
         return {"pmatrix_ms": a.value, "partials_ms": b.value, "reduce_ms": c.value,
-                "launches": n.value, "steps": st.value, "bytes": by.value}
+                "launches": n.value, "steps": st.value, "bytes": by.value, "bytes_codes": bc.value}
 
     def update_eigen(self, freqs, subst, states):
         ev, iev, evals = np.zeros((states, states)), np.zeros((states, states)), np.zeros(states)
@@ -883,8 +887,10 @@ class Plan:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         n, p = C.c_ulong(), C.c_ulong()
         lib().bpa_plan_work(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(n), C.byref(p))
+        bc = C.c_double()
+        lib().bpa_plan_work_codes(self.h, C.byref(bc))
         return {"bytes_partials": a.value, "flops_partials": b.value, "bytes_pmatrix": c.value,
-                "node_updates": n.value, "pattern_updates": p.value}
+                "node_updates": n.value, "pattern_updates": p.value, "bytes_codes": bc.value}
 
     def close(self):
         if self.h and self.engine.h:

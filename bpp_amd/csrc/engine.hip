@@ -110,7 +110,7 @@ struct bpa_locus
   bool pending = false;
 };
 
-struct TimingSlot { hipEvent_t ev[4]; int ev_used = 4; unsigned steps = 1; double bytes = 0; };   // ev_used 2: only ev[1],ev[2] (kernel-attached); steps / bytes: proposal steps and algorithmic bytes the launch covers
+struct TimingSlot { hipEvent_t ev[4]; int ev_used = 4; unsigned steps = 1; double bytes = 0, bytes_codes = 0; };   // ev_used 2: only ev[1],ev[2] (kernel-attached); steps / bytes: proposal steps and algorithmic bytes the launch covers
 
 struct bpa_engine
 {
@@ -164,6 +164,7 @@ struct bpa_engine
   double acc_ms[3] = {0, 0, 0};
   unsigned long acc_launches = 0, acc_steps = 0;      // launches that carried events, proposal steps they covered
   double acc_bytes = 0;                               // algorithmic bytes of the kernels the events bracketed
+  double acc_bytes_codes = 0;                         // ... priced as the kernels hold the data: tip children as codes, a forwarded parent not re-read
   // calls for different loci may come from different host threads (threads.c:87-200 shards loci
   // over pthreads): engine-wide state (dirty list, locus table, stream order, timing) is serialised
   std::recursive_mutex mtx;
@@ -201,6 +202,7 @@ struct bpa_plan
   DevBuf<OpDev>    ops;
   std::vector<uint32_t> h_locus;      // host copy of task -> locus id
   double bytes_partials = 0, bytes_pmatrix = 0, flops_partials = 0;
+  double bytes_codes = 0;      // K1 + K2 bytes with a tip child priced as its codes (1 B DNA / 4 B AA per pattern) and no re-read of a parent the next update consumes
   unsigned long node_updates = 0, pattern_updates = 0;
   void free_all()
   {
@@ -718,7 +720,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   const unsigned T = b->nloci;
   if (!T) return fail("plan: empty batch");
   p->eng = e;
-  p->bytes_partials = p->bytes_pmatrix = p->flops_partials = 0; p->node_updates = p->pattern_updates = 0;     // (a plan object may be rebuilt)
+  p->bytes_partials = p->bytes_pmatrix = p->flops_partials = p->bytes_codes = 0; p->node_updates = p->pattern_updates = 0;     // (a plan object may be rebuilt)
   p->fused_klane = p->fused_jc69 = p->jc69_v2 = p->klane_v2 = false; p->fused_rt = 0;
   static const bool prof = getenv("BPA_PLAN_PROF") != nullptr;
   auto tprev = std::chrono::steady_clock::now();
@@ -761,6 +763,15 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
         if (!validate_op(l, b->ops[i])) return 0;
         // bytes = 3*Np*R*S*8 + 2*R*S^2*8 (+12*Np with scaling); flops = Np*R*(4S^2-S)
         p->bytes_partials += 3*Np*R*S*8 + 2*R*S*S*8 + (b->ops[i].parent_scaler >= 0 ? 12*Np : 0);
+        // the same update as the kernels hold the data (`frac_codes`): a tip child is its state codes (1 B DNA, 4 B AA per
+        // pattern, once for all R categories), a child that is the previous update's parent is forwarded in registers
+        {
+          const unsigned prev = i > b->op_off[t] ? b->ops[i-1].parent_clv : ~0u;
+          const double code = S == 4 ? 1.0 : 4.0;
+          for (const unsigned c : {b->ops[i].left_clv, b->ops[i].right_clv})
+            p->bytes_codes += c < l->tips ? Np*code : c == prev ? 0.0 : Np*R*S*8;
+          p->bytes_codes += Np*R*S*8 + 2*R*S*S*8 + (b->ops[i].parent_scaler >= 0 ? 12*Np : 0);
+        }
         p->flops_partials += Np*R*(4*S*S - S);
         p->node_updates += 1;
         p->pattern_updates += (unsigned long)Np;
@@ -770,6 +781,8 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
       if (b->root_clv[t] < l->tips || b->root_clv[t] >= l->tips + l->clv_buffers) return fail("plan: root clv index out of range");
       if (b->root_scaler && b->root_scaler[t] >= (int)l->scale_buffers) return fail("plan: root scaler index out of range");
       p->bytes_partials += Np*R*S*8 + 4*Np;            // K2
+      const bool fwd = b->op_off && b->op_off[t+1] > b->op_off[t] && b->ops[b->op_off[t+1]-1].parent_clv == b->root_clv[t];
+      p->bytes_codes += (fwd ? 0.0 : Np*R*S*8) + 4*Np;
     }
   }
   lap("validate");
@@ -1035,7 +1048,7 @@ static int timing_drain(bpa_engine * e)
       e->acc_ms[j] += ms;
     }
     e->acc_launches++;
-    e->acc_steps += e->slots[i].steps; e->acc_bytes += e->slots[i].bytes;
+    e->acc_steps += e->slots[i].steps; e->acc_bytes += e->slots[i].bytes; e->acc_bytes_codes += e->slots[i].bytes_codes;
   }
   e->slots_used = 0;
   return 1;
@@ -1147,10 +1160,11 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       const bool split_a = p->klane_v2 || p->fused_klane;
       ts->ev_used = 2; ts->steps = 1;
       ts->bytes = ((mode & 2) ? p->bytes_partials : 0.0) + ((!split_a && (mode & 1) && p->has_mats) ? p->bytes_pmatrix : 0.0);
+      ts->bytes_codes = ((mode & 2) ? p->bytes_codes : 0.0) + ((!split_a && (mode & 1) && p->has_mats) ? p->bytes_pmatrix : 0.0);
     }
     return 1;
   }
-  if (ts) { ts->ev_used = 4; ts->steps = 1; ts->bytes = (mode & 2) ? p->bytes_partials : 0.0; }
+  if (ts) { ts->ev_used = 4; ts->steps = 1; ts->bytes = (mode & 2) ? p->bytes_partials : 0.0; ts->bytes_codes = (mode & 2) ? p->bytes_codes : 0.0; }
   if (ts) HIPCHK(hipEventRecord(ts->ev[0], e->stream));
   if ((mode & 1) && p->has_mats)
   {
@@ -1294,10 +1308,11 @@ static int chain_launch(bpa_plan * const * plans, unsigned count)
   c.base.loci = e->d_loci.p; c.base.bfbeta = e->bfbeta;
   c.base.lane_tab = e->d_lane_tab.p; c.base.slot_tab = e->d_slot_tab.p; c.base.blk_slot_off = e->d_blk_slot_off.p; c.base.nblocks2 = e->pack_blocks;
   c.nsteps = count;
-  double bytes = 0;
+  double bytes = 0, bytes_codes = 0;
   for (unsigned i = 0; i < count; ++i)
   {
     const bpa_plan * p = plans[i];
+    bytes_codes += p->bytes_codes + p->bytes_pmatrix;
     ChainStep & st = c.st[i];
     st.recs2 = p->pd.recs2; st.mat2 = p->pd.mat2; st.mat_length = p->pd.mat_length; st.blk_mat_off = p->pd.blk_mat_off;
     st.site_term = p->pd.site_term; st.lnl = p->pd.lnl; st.wg_part = p->sum_out; st.rec2_units = p->pd.rec2_units;
@@ -1313,7 +1328,7 @@ static int chain_launch(bpa_plan * const * plans, unsigned count)
   hipEvent_t k0 = ts ? ts->ev[1] : nullptr, k1 = ts ? ts->ev[2] : nullptr;
   hipExtLaunchKernelGGL((step_jc69_v2_chain_kernel<PACK_BS>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, k0, k1, 0, c);
   HIPCHK(hipGetLastError());
-  if (ts) { ts->ev_used = 2; ts->steps = count; ts->bytes = bytes; }
+  if (ts) { ts->ev_used = 2; ts->steps = count; ts->bytes = bytes; ts->bytes_codes = bytes_codes; }
   return 1;
 }
 
@@ -1466,6 +1481,13 @@ extern "C" int bpa_plan_get_sum(bpa_plan_t * p, double * sum)
   double total = 0;
   for (double v : parts) total += v;
   *sum = total;
+  return 1;
+}
+
+extern "C" int bpa_plan_work_codes(bpa_plan_t * p, double * bytes_codes)
+{
+  if (!p) return fail("plan_work_codes: null plan");
+  if (bytes_codes) *bytes_codes = p->bytes_codes;
   return 1;
 }
 
@@ -1780,7 +1802,7 @@ extern "C" void bpa_engine_enable_timing(bpa_engine_t * e, int on)
   (void)hipSetDevice(e->device);
   (void)timing_drain(e);
   e->timing = on != 0;
-  e->acc_ms[0] = e->acc_ms[1] = e->acc_ms[2] = 0; e->acc_launches = 0; e->acc_steps = 0; e->acc_bytes = 0;
+  e->acc_ms[0] = e->acc_ms[1] = e->acc_ms[2] = 0; e->acc_launches = 0; e->acc_steps = 0; e->acc_bytes = 0; e->acc_bytes_codes = 0;
 }
 
 extern "C" void bpa_engine_set_timing_stride(bpa_engine_t * e, unsigned stride)
@@ -1798,6 +1820,15 @@ extern "C" int bpa_engine_timing_work(bpa_engine_t * e, unsigned long * steps, d
   if (!timing_drain(e)) return 0;
   if (steps) *steps = e->acc_steps;
   if (bytes) *bytes = e->acc_bytes;
+  return 1;
+}
+
+extern "C" int bpa_engine_timing_work_codes(bpa_engine_t * e, double * bytes_codes)
+{
+  std::lock_guard<std::recursive_mutex> lock_(e->mtx);
+  if (!set_device(e)) return 0;
+  if (!timing_drain(e)) return 0;
+  if (bytes_codes) *bytes_codes = e->acc_bytes_codes;
   return 1;
 }
 

@@ -1175,6 +1175,7 @@ struct bpa_sampler
   // diagnostic switches, read once at creation: BPA_SMP_DBG (bit mask, see Args::dbg), BPA_SMP_STEPS=g,q (proposal counts),
   // BPA_SMP_TRACE (per-launch times on stderr), BPA_SMP_NOMIX (sweeps only)
   uint32_t env_dbg = 0; int env_gage = -1, env_gspr = -1; bool env_trace = false, env_nomix = false;
+  long env_inject = 0; uint32_t env_inject_bit = 1024u; long v2_launch_no = 0;    // BPA_SMP_INJECT=k[,w]: the k-th persistent launch with all-loci steps gives up at its first wait (w: workgroup 0 alone) — tests of the run-again path
   bool mix_pending = false;             // a mixing decision taken on the device has not been applied yet
   a00_rng_t grng = 0;
   unsigned long seed = 0, launches = 0, sweeps = 0;
@@ -1197,6 +1198,9 @@ struct bpa_sampler
   DevBuf<double> v2_prof, v2_declog;
   DevBuf<smp::Species> v2_sp;
   smp::Species v2_sp_sent{};            // what v2_sp holds
+  // the persistent launches since the last download, oldest first: what a launch that gave up (a shared device) is run again from
+  struct V2Launch { a00_rng_t grng_before; unsigned chunk; bool mix_pending, logpr_stale; };
+  std::vector<V2Launch> v2_log;
   bool kernel_bpp = false, v2_grng_sent = false;   // BPP's own generator + Bactrian-Laplace windows (bpa_sampler_set_proposal_kernel); the global stream then lives on the device
   bpa_p2p * p2p = nullptr;              // several GPUs, the sums exchanged INSIDE the persistent kernel over xGMI mailboxes (bpa_sampler_set_p2p)
   unsigned long v2_iters = 0;           // iterations run by persistent launches (bpa_sampler_timing)
@@ -1309,6 +1313,7 @@ static bpa_sampler * sampler_create_plain(bpa_engine_t * e, bpa_locus_t * const 
   if (const char * dv = getenv("BPA_SMP_DBG")) s->env_dbg = (uint32_t)atoi(dv);
   if (const char * st = getenv("BPA_SMP_STEPS")) { unsigned g = 0, q = 0; if (sscanf(st, "%u,%u", &g, &q) == 2) { s->env_gage = (int)g; s->env_gspr = (int)q; } }
   s->env_trace = getenv("BPA_SMP_TRACE") != nullptr; s->env_nomix = getenv("BPA_SMP_NOMIX") != nullptr;
+  if (const char * inj = getenv("BPA_SMP_INJECT")) { s->env_inject = atol(inj); s->env_inject_bit = strstr(inj, ",w") ? 2048u : 1024u; }
   s->fuse_decision = getenv("BPA_SMP_FUSE") != nullptr;
   s->env_v1 = getenv("BPA_SMP_V1") != nullptr;
   s->sp.ft_gage = 0.004; s->sp.ft_gspr = 0.004; s->sp.ft_tau = 0.001; s->sp.ft_mix = 0.3;      // a00_create's defaults
@@ -1945,6 +1950,8 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
     const unsigned chunk = std::min(iterations, 4096u);          // (bounds one launch's duration)
     smp2::Args a{};
     a.wave_off = s->v2_wave_off.p; a.loc = s->v2_loc.p; a.pat = s->v2_pat.p; a.trees = s->trees.p; a.taus = s->taus.p;
+    if (s->v2_log.size() >= 65536u && !sampler_download(s)) return 0;            // (bounds the log of a caller that never looks)
+    s->v2_log.push_back({s->grng, chunk, s->mix_pending, s->logpr_stale});
     // what the one-launch-per-step path left pending is settled while this launch loads (Args::snap ...)
     a.snap = s->snap.p; a.mix_flag = s->flag.p; a.epoch = s->mix_pending ? s->epoch : 0u; a.refresh_logpr = s->logpr_stale ? 1u : 0u;
     s->mix_pending = false; s->logpr_stale = false;
@@ -1954,6 +1961,7 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
     a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2;
     if (s->env_gage >= 0) { a.nsteps_gage = (uint32_t)s->env_gage; a.nsteps_gspr = (uint32_t)s->env_gspr; }
     a.theta_mask = theta_mask; a.do_allloci = allloci ? 1u : 0u; a.dbg = s->env_dbg;
+    if (allloci && ++s->v2_launch_no == s->env_inject) a.dbg |= s->env_inject_bit;
     if (s->p2p && allloci)
     {
       a.peers = s->p2p->d_peer.p; a.mail = s->p2p->mail; a.rank = s->p2p->rank; a.world = s->p2p->world; a.slot_bytes = s->p2p->slot_bytes;
@@ -2153,6 +2161,24 @@ static int sampler_download(bpa_sampler * s)
       HIPCHK(hipMemcpy(s->v2_err.p, zero2, sizeof zero2, hipMemcpyHostToDevice));
       if (s->p2p || verr[1] <= 0) return fail("bpa_sampler: the persistent iteration kernel timed out waiting for a workgroup's sum (is the device shared? BPA_SMP_V1=1 selects one launch per step)");
       fprintf(stderr, "[bpp_amd] the persistent iteration kernel timed out waiting for a workgroup (is the device shared?): %d iterations are run again\n", verr[1]);
+      // The launches that did not run are the LAST ones of the log (a launch that finds the error word set gives up at once,
+      // sweep2.hpp): they are taken off the counters and the host's copy of the global stream goes back to where the first of
+      // them started, so that the iterations run again with the random numbers they would have had — the chain is the one a
+      // run without the time-out walks (our own kernel's stream is mirrored on the host; BPP's lives on the device, where a
+      // launch that gives up leaves it alone)
+      {
+        long left = verr[1];
+        while (left > 0 && !s->v2_log.empty())
+        {
+          const bpa_sampler::V2Launch l = s->v2_log.back(); s->v2_log.pop_back();
+          left -= (long)l.chunk;
+          s->launches--; s->sweeps -= l.chunk; s->v2_iters -= l.chunk;
+          if (!s->kernel_bpp) s->grng = l.grng_before;
+          s->mix_pending = l.mix_pending; s->logpr_stale = l.logpr_stale;
+        }
+        if (left != 0) return fail("bpa_sampler: the persistent kernel reports iterations it did not run that no launch of the log accounts for");
+      }
+      s->v2_log.clear();
       if (++s->v2_retries > 3)
       {
         if (s->kernel_bpp) return fail("bpa_sampler: the persistent iteration kernel keeps timing out (a shared device: its workgroups must all be resident at once) and BPP's proposal kernel has no other path");
@@ -2161,7 +2187,7 @@ static int sampler_download(bpa_sampler * s)
       if (!bpa_sampler_iterate(s, (unsigned)verr[1])) return 0;
       return sampler_download(s);
     }
-    s->v2_retries = 0;
+    s->v2_retries = 0; s->v2_log.clear();
     if (verr[2])
     {
       const int z = 0;

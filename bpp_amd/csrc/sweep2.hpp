@@ -130,7 +130,7 @@ template <int NT> struct WgLDS : WgBase
   unsigned long long xprev[2][XN];               // wave 0: every word of either accumulator set as its previous use left it
   long long prof[24];                            // BPA_SMP_DBG & 16: cycle counters of thread 0 of workgroup 0
   long long wsweep[16];                          // BPA_SMP_DBG & 16: sweep cycles of every wave of workgroup 0
-  uint32_t xcoarse_, pad4_;
+  uint32_t xcoarse_, late_;                      // late_: another workgroup gave up in this launch (read from Args::err before the store)
 };
 
 template <int G> __device__ __forceinline__ uint32_t gballot(bool p, uint32_t gbase)
@@ -668,7 +668,9 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   for (uint32_t i = tid; i < (uint32_t)(3*MAXPOP); i += C::BS) wg.tau[i] = A.taus[i];
   for (uint32_t i = tid; i < (uint32_t)((2*NT)*(2*NT)); i += C::BS) wg.lograt[i] = A.lograt[(i/(2*NT))*MAXN + i % (2*NT)];
   if (tid < 16u) wg.anc[tid] = tid < (uint32_t)MAXPOP ? (uint32_t)SP.anc[tid] : 0u;
-  if (tid == 0) { wg.abort_ = 0; wg.bad_ = 0; wg.xbad_ = 0; wg.coarse_ = 0; wg.xcoarse_ = 0; }
+  // an earlier launch of the stream that gave up (Args::err, cleared by the host when it has dealt with it) voids this one as
+  // well: the iterations then run again IN ORDER, from the state and the random numbers the first of them started from
+  if (tid == 0) { wg.abort_ = __hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 2u : 0u; wg.late_ = 0; wg.bad_ = 0; wg.xbad_ = 0; wg.coarse_ = 0; wg.xcoarse_ = 0; }
   if (tid < 32u) wg.accfx[tid] = 0ull;
   for (uint32_t i = tid; i < 2u*XN; i += C::BS) (&wg.xprev[0][0])[i] = 0ull;
   PopLane pl;
@@ -680,6 +682,11 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
     pl.below = li < npop ? below : 0u;
   }
   __syncthreads();
+  if (wg.abort_ == 2u)
+  {
+    if (b == 0 && tid == 0) (void)atomicAdd(A.err + 1, (int)A.niter);
+    return;
+  }
   auto load_pop = [&]()
   {
     const int i = li < MAXPOP ? li : 0;
@@ -759,6 +766,9 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         cur1 = __hip_atomic_load(set + 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         d = (cur0 - prev0) + (cur1 - prev1);
         d += __shfl_xor(d, 16, 64); d += __shfl_xor(d, 32, 64);
+        // (test switches, BPA_SMP_INJECT: dbg bit 1024 = every workgroup gives up at its first wait, 2048 = workgroup 0 alone — the
+        //  others then run into the real time-out at the next exchange)
+        if ((A.dbg & 1024u) || ((A.dbg & 2048u) && b == 0)) { ok = false; break; }
         if ((uint32_t)__shfl(d, XV, 64) >= A.nwg) break;
         if ((rounds & 63u) == 0 && wall_clock64() - t_wait > 50000000ull) { ok = false; break; }     // 0.5 s at 100 MHz
         __builtin_amdgcn_s_sleep(1);
@@ -1013,6 +1023,14 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           else if (it + 1 < A.niter) { make_step(nsp); theta_choices(); }
           __syncthreads();                                              // B4: the next proposal is out
         }
+      }
+      // a workgroup that became resident late can pass the launch's last exchange after the others gave up there: nobody
+      // stores unless the launch's error word is still clear (the loci waves wait at the same barrier)
+      if (!aborted)
+      {
+        if (lane == 0) wg.late_ = __hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1u : 0u;
+        __syncthreads();                                                // BF
+        if (wg.late_) { aborted = true; if (b == 0 && lane == 0) (void)atomicAdd(A.err + 1, (int)A.niter); }      // (workgroup 0 counts the launch's iterations exactly once: here, or where it gave up itself)
       }
       if (b == 0)
       {
@@ -1609,6 +1627,14 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
 #undef SMP2_SUB0
 #undef SMP2_SUB
   if (aborted || wg.abort_) return;                 // (HBM still holds the state the launch started from)
+  if constexpr (!PROG) { if (tid == 0) wg.late_ = __hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1u : 0u; }
+  __syncthreads();                                  // BF: the error word as it stands after the last exchange (PROG: read by the control wave)
+  if (wg.late_)
+  {
+    // (workgroup 0 counts the launch's iterations exactly once: where it gave up itself, or here)
+    if constexpr (!PROG) { if (b == 0 && tid == 0) (void)atomicAdd(A.err + 1, (int)A.niter); }
+    return;
+  }
 
   // ---- store
   if (act)

@@ -428,6 +428,12 @@ int  bpa_engine_timing(bpa_engine_t *, double * pmatrix_ms, double * partials_ms
 /* what those timed launches covered: the proposal steps (a chain launch of bpa_plans_launch covers several) and the
    algorithmic bytes, by the formulas above, of the kernels partials_ms is the time of                              */
 int  bpa_engine_timing_work(bpa_engine_t *, unsigned long * steps, double * bytes);
+/* The same K1 + K2 work priced as the kernels hold the data (bench.py's `frac_codes`): a tip child is its state codes —
+   1 B (DNA) / 4 B (amino acids) per pattern, once for all rate categories, where SURVEY 8(d) charges the one-hot CLV of
+   core_partials.c:585's tip-as-CLV form, Np*R*S*8 —, and a child that is the previous node update's parent is forwarded
+   in registers, not read again.  Parent stores, P-matrices, weights and scalers as above.                         */
+int  bpa_plan_work_codes(bpa_plan_t *, double * bytes_codes);
+int  bpa_engine_timing_work_codes(bpa_engine_t *, double * bytes_codes);
 
 /* ---- several GPUs of one node: one-shot sum all-reduce of a few hundred doubles over xGMI peer mappings -----------
    The only exchange of a sharded run is the sum an all-loci proposal is decided on (SURVEY.md section 8e;

@@ -1,0 +1,54 @@
+"""The line bench.py prints must stay readable by the driver: round 4's 26 KB line was cut by its capture and the round had no
+driver-recorded figure.  The compact line is built from the full record by bench.compact_line; here: the committed full records
+of earlier rounds -> a line of <= 8 192 bytes that parses and carries the contract's keys, `roofline` and `cpu_baseline`."""
+import glob
+import importlib.util
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+RECORDS = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_default.json")) + glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_full.json")))
+
+
+@pytest.mark.parametrize("path", RECORDS, ids=[os.path.relpath(p, ROOT) for p in RECORDS])
+def test_compact_line_of_a_committed_record(path):
+    b = _bench()
+    full = json.load(open(path))
+    line = json.dumps(b.compact_line(full), separators=(",", ":"))
+    assert len(line) <= 8192, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["value"] == full["value"] and d["config"]["workload"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+
+
+def test_an_oversized_record_still_gives_a_short_line():
+    """whatever a section grows to, the line drops optional parts rather than outgrow the capture"""
+    b = _bench()
+    full = json.load(open(RECORDS[-1]))
+    full["other_configs"] = {f"x{i}": dict(full["other_configs"]["c3"]) for i in range(60)}
+    line = json.dumps(b.compact_line(full), separators=(",", ":"))
+    assert len(line) <= 8192
+    d = json.loads(line)
+    assert "roofline" in d and "cpu_baseline" in d and d["value"] == full["value"]
+
+
+def test_bench_prints_the_compact_line_only():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("print(json.dumps(") == 1 and "print(json.dumps(compact_line(out)" in src

@@ -15,17 +15,29 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(extra):
+def run_bench(extra, tmp=None):
+    """-> (the full record bench.py wrote to --full-record, stderr); the stdout line is the compact one the driver parses:
+    checked here to be the last line, small, and to carry the contract's keys"""
+    import tempfile
+    full_path = os.path.join(tempfile.mkdtemp(prefix="bench_"), "full.json")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--loci", "1500", "--no-cpu-baseline"] + extra
+           "--loci", "1500", "--no-cpu-baseline", "--full-record", full_path] + extra
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+    last = r.stdout.strip().splitlines()[-1]
+    line = json.loads(last)
+    assert len(last) <= 8192, len(last)
+    full = json.load(open(full_path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["n_gpus"] == 2 and line["roofline"]["frac"] == full["roofline"]["frac"]
+    assert line["value_weak"] == full["value_weak"] and line["value_strong"] == full["value_strong"]
+    return full, r.stderr
 
 
 @pytest.mark.parametrize("p2p,scaling", [(False, "weak"), (True, "weak"), (True, "strong")])      # (the default exchange with ONE data set: the test below)

@@ -377,3 +377,49 @@ def test_persistent_kernel_at_edge_sizes(taxa, program):
             a, b = dev.tree(i), host.tree(i)
             assert [int(x) for x in a["parent"]] == [int(x) for x in b["parent"]] and np.allclose(a["time"], b["time"], rtol=1e-10, atol=0), (nloci, i)
         host.close(); dev.close(); eng.close()
+
+
+@pytest.mark.parametrize("moves", ["uniform", "bpp", "program"])
+@pytest.mark.parametrize("inject", ["2", "3,w"])
+def test_a_launch_that_gives_up_is_run_again_on_the_same_random_numbers(moves, inject, monkeypatch):
+    """A persistent launch whose workgroups are not all resident together (a shared device) gives up and leaves the loci as it
+    found them; the launches queued behind it give up at once and the iterations run again, in order, from the state and the
+    global stream the first of them started from: the chain is the one a run without the time-out walks, to the bit.
+    BPA_SMP_INJECT=k makes the k-th launch give up at its first wait (",w": workgroup 0 alone, the others then meet the real
+    0.5 s time-out at the next exchange and workgroup 0's copy of the decision is thrown away with theirs)."""
+    eng = bpp_amd.Engine(0)
+    data = synth.make_dataset(1100, 400, 4, "jc69", 1, seed=29)
+    parent, tau0, thetas = synth.species_tree_arrays(4)
+
+    def run(env):
+        if env:
+            monkeypatch.setenv("BPA_SMP_INJECT", env)
+        else:
+            monkeypatch.delenv("BPA_SMP_INJECT", raising=False)
+        smp = bpp_amd.Sampler(eng, tape.make_engine_loci(eng, data), data, seed=31)
+        if moves != "uniform":
+            smp.set_proposal_kernel(1)
+        if moves == "program":
+            smp.set_program_moves(True, 0.1)
+        smp.set_species_tree(parent, tau0, thetas)
+        smp.set_tau_prior(3.0, 3.0 / tau0[-1])
+        smp.set_theta_prior(2.0, 1000.0, 0.001)
+        smp.set_finetune(0.003, 0.005, 0.0008, 0.2)
+        smp.initialize()
+        assert smp.kind() == "persistent"
+        for n in (2, 3, 1, 4):                 # four launches queued before anything is read back
+            smp.iterate(n)
+        sm = smp.summary()
+        out = (sm, smp.taus(), smp.thetas(), [smp.tree(i) for i in range(0, len(data), 37)])
+        smp.close()
+        return out
+
+    want, got = run(None), run(inject)
+    assert got[0]["proposals"] == want[0]["proposals"] and got[0]["accepted"] == want[0]["accepted"]
+    assert got[0]["total_lnl"] == want[0]["total_lnl"]
+    assert got[1] == want[1] and got[2] == want[2] and got[1] != list(tau0)
+    for a, b in zip(got[3], want[3]):
+        for key in ("left", "right", "parent", "clv", "pmat", "pop", "time"):
+            assert list(a[key]) == list(b[key]), key
+        assert a["lnl"] == b["lnl"] and a["root"] == b["root"]
+    eng.close()

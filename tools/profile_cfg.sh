@@ -10,8 +10,8 @@ W=/tmp/prof_${CFG}_$TAG
 rm -rf $W; mkdir -p $W $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-6}
-BENCH="python $R/bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-other-configs --no-host-control --no-bpp-program --no-efficiency --no-scale-projection"
-$BENCH > $W/bench_plain.json 2> $W/plain.log
+BENCH="python $R/bench.py --full-record $W/full.json --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-other-configs --no-host-control --no-bpp-program --no-efficiency --no-scale-projection"
+$BENCH --full-record $W/full_plain.json > $W/bench_plain.json 2> $W/plain.log
 rocprofv3 --kernel-trace --stats -f csv -d $W/trace -o p -- $BENCH > $W/bench_trace.json 2> $W/trace.log
 rocprofv3 --pmc FETCH_SIZE -f csv -d $W/pmc_fetch -o p -- $BENCH > /dev/null 2> $W/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE -f csv -d $W/pmc_write -o p -- $BENCH > /dev/null 2> $W/pmc_write.log
@@ -20,9 +20,12 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_
 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_MFMA_MOPS_F64 -f csv -d $W/pmc_sq3 -o p -- $BENCH > /dev/null 2> $W/pmc_sq3.log
 python3 - <<PY
 import csv, collections, glob, json
-out = {"config": "$CFG", "tag": "$TAG", "env": "$*", "command": "$BENCH"}
+import subprocess
+out = {"config": "$CFG", "tag": "$TAG", "env": "$*", "command": "$BENCH",
+       "kernels_sha": subprocess.run(["python3", "$R/tools/src_hash.py"], capture_output=True, text=True).stdout.strip()}
 try:
-    out["bench_unprofiled"] = json.loads(open("$W/bench_plain.json").read())
+    out["bench_unprofiled"] = json.loads(open("$W/bench_plain.json").read().strip().splitlines()[-1])
+    out["bench_unprofiled_full"] = json.load(open("$W/full_plain.json"))
 except Exception as e:
     out["bench_unprofiled"] = str(e)
 ks = glob.glob("$W/trace/**/*kernel_stats.csv", recursive=True)
