@@ -827,12 +827,12 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   // memory pipeline) | tiled (one wave runs all categories: what loci of more than 4 categories get) | generic (no staging)
   {
     const char * v = getenv("BPA_S20_KERNEL");
-    p->s20_kernel = v ? v : "pipe";
-    if (p->s20_kernel != "pipe" && p->s20_kernel != "pipemfma" && p->s20_kernel != "tiled" && p->s20_kernel != "generic") p->s20_kernel = "pipe";
+    p->s20_kernel = v ? v : "wave";
+    if (p->s20_kernel != "wave" && p->s20_kernel != "wave2" && p->s20_kernel != "pipe" && p->s20_kernel != "pipemfma" && p->s20_kernel != "tiled" && p->s20_kernel != "generic") p->s20_kernel = "wave";
   }
-  p->s20_tiledk = p->s20_kernel == "pipe" || p->s20_kernel == "pipemfma";
+  p->s20_tiledk = p->s20_kernel == "wave" || p->s20_kernel == "wave2" || p->s20_kernel == "pipe" || p->s20_kernel == "pipemfma";
   if (p->s20_tiledk && p->rmax > 4) { p->s20_tiledk = false; p->s20_kernel = "tiled"; }     // 64 x R lanes must fit a 256-lane workgroup
-  p->tile = p->s20_tiledk ? 64 : 128;
+  p->tile = (p->s20_tiledk && p->s20_kernel != "wave2") ? 64 : 128;       // (wave2: two patterns per lane)
   if (p->states == 20)
   {
     std::vector<uint32_t> tt, tn;
@@ -1055,6 +1055,22 @@ static int timing_drain(bpa_engine * e)
 }
 
 // mode bits: 1 = P-matrices, 2 = partials (+ per-pattern lnL terms), 4 = per-locus reduction
+// the K1 + K2 launch of the compact-record path for loci of several rate categories: step_s4_klane_v3_kernel (the step's
+// records and all its P-matrices in LDS, three global round trips per step) wherever a slot record fits the 16 units a
+// lane group brings in one load — loci of up to 16 tips —, step_s4_klane_v2_kernel otherwise (BPA_KLANE_V2=1: always, A/B)
+template <bool FUSE_A>
+static void launch_klane(const dim3 grid, hipStream_t st, hipEvent_t k0, hipEvent_t k1, const PlanDev & d)
+{
+  static const bool env_v2 = getenv("BPA_KLANE_V2") != nullptr;
+  if (!env_v2 && d.rec2_units >= 2u && d.rec2_units <= 16u)
+  {
+    const size_t lds = (size_t)(PACK_BS/64)*(d.rec2_units - 1u)*1024u;
+    hipExtLaunchKernelGGL((step_s4_klane_v3_kernel<PACK_BS, FUSE_A>), grid, dim3(PACK_BS), lds, st, k0, k1, 0, d);
+  }
+  else
+    hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false, 0, FUSE_A>), grid, dim3(PACK_BS), 0, st, k0, k1, 0, d);
+}
+
 static int plan_launch_mode(bpa_plan * p, int mode)
 {
   // A/B switches of DESIGN.md's appendix, read once
@@ -1099,7 +1115,7 @@ static int plan_launch_mode(bpa_plan * p, int mode)
         if ((mode & 4) && p->sum_out && p->sum_parts == e->pack_blocks) { d.flags |= 8u; d.wg_part = p->sum_out; summed = true; }
         // (register budget, measured with BPA_KLANE_OCC builds: the compiler's 126 VGPRs = 4 waves per SIMD 105 us; held to
         //  5 waves 121 us and to 6 waves 187 us (spills), to 3 waves 119 us)
-        hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), g2, dim3(PACK_BS), 0, e->stream, k0, k1, 0, d);
+        launch_klane<false>(g2, e->stream, k0, k1, d);
       }
     }
     else if (p->fused_klane)
@@ -1193,8 +1209,12 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       const dim3 grid(p->ntiles), block(64*p->rmax);
       if (p->s20_kernel == "pipemfma")
         hipLaunchKernelGGL((partials_lnl_pipemfma20_kernel<false, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
-      else
+      else if (p->s20_kernel == "pipe")
         hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
+      else if (p->s20_kernel == "wave2")
+        hipLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)2*p->rmax*64)*sizeof(double), e->stream, d);
+      else
+        hipLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
     }
     else if (p->ntiles && p->tile == 128 && p->s20_kernel == "tiled")
     {
@@ -1265,7 +1285,7 @@ extern "C" int bpa_plan_probe(bpa_plan_t * p, double * out)
   std::lock_guard<std::recursive_mutex> lock_(p->eng->mtx);
   bpa_engine * e = p->eng;
   if (!set_device(e) || !p->fused_bs) return fail("probe: fused plans only");
-  const unsigned B = p->pd.nblocks;
+  const unsigned B = (p->klane_v2 || p->jc69_v2) ? e->pack_blocks : p->pd.nblocks;
   if (!p->dbg.reserve((size_t)B*8)) return fail("oom");
   HIPCHK(hipMemset(p->dbg.p, 0, (size_t)B*8*8));
   p->pd.dbg = p->dbg.p;
@@ -1284,6 +1304,16 @@ extern "C" int bpa_plan_probe(bpa_plan_t * p, double * out)
     out[i] = cnt ? acc/cnt : -1;
   }
   out[8] = (double)(last - first)*0.01;
+  // out[9..16]: mean over workgroups of (stamp i - the workgroup's OWN stamp 0): where a workgroup's life goes; out[17]: workgroups stamped
+  unsigned nb = 0;
+  for (int i = 0; i < 8; ++i)
+  {
+    double acc = 0; unsigned cnt = 0;
+    for (unsigned b = 0; b < B; ++b) if (h[b*8+i] && h[b*8]) { acc += (double)(h[b*8+i] - h[b*8])*0.01; ++cnt; }
+    out[9 + i] = cnt ? acc/cnt : -1;
+    if (i == 0) nb = cnt;
+  }
+  out[17] = nb;
   return 1;
 }
 
@@ -1687,7 +1717,7 @@ static int batch_end_packed(bpa_engine * e, const bpa_batch_t * b, double * lnl,
       hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((nmat*rmax + 255u)/256u), dim3(256), 0, e->stream, d, (uint32_t)nmat);
     }
     d.flags = 2u | 4u;
-    hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), dim3(e->pack_blocks), dim3(PACK_BS), 0, e->stream, d);
+    launch_klane<false>(dim3(e->pack_blocks), e->stream, nullptr, nullptr, d);
   }
   HIPCHK(hipGetLastError());
   if (async) e->bc_wait_T = 0;

@@ -5,6 +5,11 @@
 // the substitution-parameter moves' device tables (every locus's frequencies | exchangeabilities | alpha, the roll-back
 // pairs, the loci's ids): made when a window width first becomes positive — the widths themselves travel with every
 // launch, so switching a move on or changing a width in mid-run (BPP's burn-in finetune adjustment) touches no state
+// BPA_S20_KERNEL=pipe: round 4's 20-state node-update kernel (a workgroup barrier per update) instead of partials_lnl_wave20_kernel (A/B)
+// BPA_S20_KERNEL=wave2: partials_lnl_wave20_kernel with two patterns per lane (tiles of 128 patterns, one wave per SIMD)
+static unsigned gs_tile20() { static const unsigned v = (getenv("BPA_S20_KERNEL") && std::string(getenv("BPA_S20_KERNEL")) == "wave2") ? 128u : 64u; return v; }
+static bool gs_pipe20() { static const bool v = getenv("BPA_S20_KERNEL") && std::string(getenv("BPA_S20_KERNEL")) == "pipe"; return v; }
+
 static int gs_subst_ready(bpa_sampler * s)
 {
   if (!(s->g_ft[0] > 0 || s->g_ft[1] > 0 || s->g_ft[2] > 0) || s->g_sm.p) return 1;
@@ -115,7 +120,7 @@ static int gs_upload(bpa_sampler * s)
     for (unsigned i = 0; i < T; ++i)
     {
       tl[i] = s->loci[i]->id; tp[i] = off; off += s->loci[i]->sites;
-      for (unsigned n0 = 0; n0 < s->loci[i]->sites; n0 += 64) { tt.push_back(i); tn.push_back(n0); }
+      for (unsigned n0 = 0; n0 < s->loci[i]->sites; n0 += gs_tile20()) { tt.push_back(i); tn.push_back(n0); }
     }
     tp[T] = off;
     s->g_ntiles = (unsigned)tt.size(); s->g_maxops = s->maxtips - 1;
@@ -213,7 +218,7 @@ static int gs_upload(bpa_sampler * s)
     if (!s->g_ev_join) HIPCHK(hipEventCreateWithFlags(&s->g_ev_join, hipEventDisableTiming));
     s->g_split = true; s->g_isplit = T/2; s->g_ssplit = 0; s->g_bsplit = 0;
     unsigned nt = 0;
-    for (unsigned i = 0; i < T/2; ++i) nt += (s->loci[i]->sites + 63u)/64u;
+    for (unsigned i = 0; i < T/2; ++i) nt += (s->loci[i]->sites + gs_tile20() - 1u)/gs_tile20();
     s->g_tsplit = nt;
   }
   s->uploaded = true;
@@ -441,7 +446,9 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
         hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3((i1 - i0)*s->g_maxmat), dim3(256), 0, st, d);
         d.blk0 = t0;
         d.flags = 4u | 64u | 256u;
-        hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
+        if (gs_pipe20()) hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
+        else if (gs_tile20() == 128u) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20 + (size_t)s->g_rmax*64*sizeof(double), st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
+        else hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
         d.blk0 = i0;
         hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(i1 - i0), dim3(64), 0, st, d);
       }
@@ -452,7 +459,9 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     d.flags = 1u;
     hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d);
     d.flags = 4u | 64u;
-    hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
+    if (gs_pipe20()) hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
+    else if (gs_tile20() == 128u) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20 + (size_t)s->g_rmax*64*sizeof(double), e->stream, k0, k1, 0, d);
+    else hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
     hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(s->nloci), dim3(64), 0, e->stream, d);
     HIPCHK(hipGetLastError());
     s->launches += 3; s->g_evals++;
@@ -501,14 +510,14 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
         if (fuse_a)
         {
           d.flags = 1u | 2u | 4u | (fuse_eigen ? 32u : 0u);
-          hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false, 0, true>), dim3(b1 - b0), block, 0, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
+          launch_klane<true>(dim3(b1 - b0), st, h ? nullptr : k0, h ? nullptr : k1, d);
           s->launches += 1;
           continue;
         }
         d.flags = 1u;
         hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3(((e1 - e0)*d.pad + 255u)/256u), dim3(256), 0, st, d, e1);
         d.flags = 2u | 4u;
-        hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), dim3(b1 - b0), block, 0, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
+        launch_klane<false>(dim3(b1 - b0), st, h ? nullptr : k0, h ? nullptr : k1, d);
         s->launches += 2;
       }
       HIPCHK(hipGetLastError());
@@ -518,7 +527,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     if (fuse_a)
     {
       d.flags = 1u | 2u | 4u | (fuse_eigen ? 32u : 0u);
-      hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false, 0, true>), grid, block, 0, e->stream, k0, k1, 0, d);
+      launch_klane<true>(grid, e->stream, k0, k1, d);
       s->launches += 1;
     }
     else
@@ -526,7 +535,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
       d.flags = 1u;
       hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((d.nmat*d.pad + 255u)/256u), dim3(256), 0, e->stream, d, d.nmat);
       d.flags = 2u | 4u;
-      hipExtLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, false>), grid, block, 0, e->stream, k0, k1, 0, d);
+      launch_klane<false>(grid, e->stream, k0, k1, d);
       s->launches += 2;
     }
   }

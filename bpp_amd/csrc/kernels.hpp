@@ -671,6 +671,390 @@ partials_lnl_pipe20_kernel(const PlanDev P)
   P.site_term[((cu32_p)P.task_pat_off)[t] + n] = term;
 }
 
+// ================================== K1+K2, 20 states, waves on their own (default since round 5) ==
+// partials_lnl_pipe20_kernel with what still ran in series taken apart.  In that kernel a tile's four waves (one per rate
+// category) met at a workgroup barrier every update because the P-matrix staging was dealt out over all of them, every
+// update began by requesting its child planes and waiting for them, and ended by waiting for vmcnt(0) — i.e. for its own
+// 20 plane stores — before the barrier: load latency, arithmetic and store drain one after the other, on all four SIMDs at
+// once, at two waves per SIMD (rocprofv3, round 4: 53 % of the wave-cycles waiting, VALU busy 16 %, LDS 40 %, 0.39 of the
+// HBM peak by bytes moved).  Here:
+//   * a wave stages ITS category's two matrices itself (7 global_load_lds_dwordx4 per update into its own LDS corner,
+//     double-buffered): wave k only ever reads category k, so NO workgroup barrier is left in the update loop — the eight
+//     waves of a CU drift apart and one's memory phase lies beside another's arithmetic;
+//   * the inputs of update o + 1 — the tip codes and the one inner plane that is neither forwarded nor written earlier in
+//     this step — are requested BEFORE update o's arithmetic, into registers of their own (the first update's: in the
+//     prologue, together with its matrices; its second inner plane lands in the registers of the not yet computed parent);
+//   * the wait at the top of an update is s_waitcnt vmcnt(20): everything older than the previous update's 20 stores —
+//     matrices and prefetch — has landed; stores are never waited for (a lane re-reads only what it wrote itself).
+// Arithmetic, summation order, scaling rule and stores are pipe20's: same bits (tests/test_gpu_parity.py).
+template <int S>
+__device__ __forceinline__ void stage_pmats_wave(double * s_dst, const double * gl, const double * gr, const uint32_t lane)
+{
+  constexpr uint32_t half = S*S/2, total = 2*half;               // 16-byte units of one category's two matrices
+#pragma unroll
+  for (uint32_t c = 0; c*64 < total; ++c)
+  {
+    const uint32_t idx = c*64 + lane;
+    if (idx < total)
+    {
+      const double * src = idx < half ? gl + 2*(size_t)idx : gr + 2*(size_t)(idx - half);
+      // as inline assembly, NOT __builtin_amdgcn_global_load_lds: the compiler's wait-count pass cannot tell which LDS bytes a
+      // global -> LDS load writes and puts s_waitcnt vmcnt(0) in front of EVERY later ds_read — this update's matrix reads would
+      // wait for the coming update's matrices, its prefetched plane and the previous update's stores (seen in the disassembly:
+      // tools/disasm.py).  The waits for these loads are the kernel's own (vmcnt(20) at the top of an update); the pass still
+      // counts its own loads correctly (it then waits for a few more than it must, never fewer: the returns are in order).
+      const uint32_t lds_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(s_dst + (size_t)c*128);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                   :: "v"((const __attribute__((address_space(1))) void *)src), "s"(lds_off) : "memory", "m0");
+    }
+  }
+}
+
+// PP patterns per lane (tile = 64 PP patterns): with PP = 2 every matrix element read from LDS feeds two fused multiply-adds per
+// lane instead of one.  The kernel's roof is neither HBM nor FP64 but the LDS pipe: a broadcast ds_read_b128 occupies it for 4
+// cycles and brings the 2 matrix entries of 2 FMAs per lane — 25 M such reads per config-4 launch = 390 k LDS cycles per CU,
+// ~190 us of the launch's 320 (SQ_LDS_IDX_ACTIVE agrees), against ~100 us of FP64 issue.  Two patterns per lane at one wave per
+// SIMD (the registers of two: 512 per lane) halve the reads per pattern; the wave's latency cover is the requests-ahead above.
+template <int S, bool NTA = false, int OCC = 2, int PP = 1>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
+partials_lnl_wave20_kernel(const PlanDev P)
+{
+  extern __shared__ __attribute__((aligned(16))) double s_p[];      // [R waves][2 buffers][2 children][S][S], then [PP][R][64] scratch
+  constexpr uint32_t SS = S*S;
+  static_assert(S == 20 && (PP == 1 || PP == 2), "vmcnt immediates below are written for 20 PP plane stores per update");
+  const uint32_t b = ((P.flags & 256u) ? P.blk0 : 0u) + ((P.flags & 32u) ? blockIdx.x : xcd_tile(blockIdx.x, gridDim.x)), lane = threadIdx.x & 63u;
+  const uint32_t k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t t = ((cu32_p)P.tile_task)[b];
+  const uint32_t n_tile = ((cu32_p)P.tile_n0)[b] + lane;
+  const uint32_t lid = ((cu32_p)P.task_locus)[t];
+  cu64_p L64 = (cu64_p)(P.loci + lid);
+  cu32_p L32 = (cu32_p)(P.loci + lid);
+  const gdbl_p   Lclv    = (gdbl_p)L64[0];
+  const double * Lpmat   = (const double *)L64[1];
+  const gu32_p   Lscaler = (gu32_p)L64[2];
+  const gcu32_p  Ltips   = (gcu32_p)L64[3];
+  const gcu32_p  Lwgt    = (gcu32_p)L64[4];
+  const cdbl4_p  par     = (cdbl4_p)L64[5];
+  const uint32_t np = L32[18], tips_n = L32[19], R = L32[20], unphased = L32[25], ld = L32[27];
+  const bool wave_on = k < R;                                        // (wave-uniform)
+  // The lanes past the locus's last pattern run the LAST pattern again (same loads, same arithmetic, the same values stored to
+  // the same addresses) instead of being masked off: no exec-masked region is left in the update loop, so every path through
+  // it issues the same vector-memory instructions and the wait counts are the same on all of them (the compiler's wait-count
+  // pass merges paths; a path that could skip the stores would turn the vmcnt(20) at the top into vmcnt(0)).
+  bool real[PP]; uint32_t n[PP];
+#pragma unroll
+  for (int q = 0; q < PP; ++q) { const uint32_t nn = n_tile + 64u*q; real[q] = nn < np && wave_on; n[q] = nn < np ? nn : np - 1u; }
+  const bool active = wave_on;
+  double * myp = s_p + (size_t)k*4*SS;                               // this wave's [2][2][SS]
+  double * s_x = s_p + (size_t)4*P.pad*SS;                           // [PP][R][64]
+
+  const bool ranges = (P.flags & 64u) != 0;
+  const uint32_t op_begin = ((cu32_p)P.op_off)[ranges ? 2*t : t], op_end = ((cu32_p)P.op_off)[ranges ? 2*t + 1 : t + 1];
+  if (ranges && op_begin == op_end) return;
+  static const uint32_t none = 0xffffffffu;
+  double ov[PP][S];                                                  // the parent just computed (forwarded)
+  uint32_t ov_clv = none;
+  double pfv[PP][S];                                                 // the plane requested ahead for the coming update
+  uint32_t pf_clv = none, pf2_clv = none;                            // pf2: the first update's second inner plane, parked in ov
+  uint32_t pf_lcode[PP], pf_rcode[PP];
+#pragma unroll
+  for (int q = 0; q < PP; ++q) { pf_lcode[q] = 1u; pf_rcode[q] = 1u; }
+  uint32_t written = 0;                                              // CLV buffers this step has written (5 bits; aliases are taken as written: a late read)
+  auto plane = [&](uint32_t c, int q) { return Lclv + (((size_t)(c - tips_n)*R + k)*S)*ld + n[q]; };
+  // the requests for update `nx` whose predecessor writes `prevp` (forwarded): codes, one inner plane
+  auto request = [&](const OpS & nx, const uint32_t prevp, const bool first)
+  {
+    const bool lt = nx.left_clv < tips_n, rt = nx.right_clv < tips_n;
+#pragma unroll
+    for (int q = 0; q < PP; ++q)
+    {
+      pf_lcode[q] = (active && lt) ? Ltips[(size_t)nx.left_clv*np + n[q]] : 1u;
+      pf_rcode[q] = (active && rt) ? Ltips[(size_t)nx.right_clv*np + n[q]] : 1u;
+    }
+    const bool pl = !lt && nx.left_clv != prevp && !((written >> (nx.left_clv & 31u)) & 1u);
+    const bool pr = !rt && nx.right_clv != prevp && !((written >> (nx.right_clv & 31u)) & 1u);
+    pf_clv = pl ? nx.left_clv : pr ? nx.right_clv : none;
+    pf2_clv = (first && pl && pr) ? nx.right_clv : none;
+    if (active && pf_clv != none)
+    {
+#pragma unroll
+      for (int q = 0; q < PP; ++q)
+      {
+        const gcdbl_p p = plane(pf_clv, q);
+#pragma unroll
+        for (int s = 0; s < S; ++s) pfv[q][s] = NTA ? __builtin_nontemporal_load(p + (size_t)s*ld) : p[(size_t)s*ld];
+      }
+    }
+    if (active && pf2_clv != none)
+    {
+#pragma unroll
+      for (int q = 0; q < PP; ++q)
+      {
+        const gcdbl_p p = plane(pf2_clv, q);
+#pragma unroll
+        for (int s = 0; s < S; ++s) ov[q][s] = NTA ? __builtin_nontemporal_load(p + (size_t)s*ld) : p[(size_t)s*ld];
+      }
+    }
+  };
+  uint32_t cur = 0;
+  if (op_begin < op_end && wave_on)
+  {
+    const OpS op0 = load_op_scalar(P.ops, op_begin);
+    stage_pmats_wave<S>(myp, Lpmat + ((size_t)op0.left_pmatrix*R + k)*SS, Lpmat + ((size_t)op0.right_pmatrix*R + k)*SS, lane);
+    request(op0, none, true);
+    // the first update's inputs are waited for HERE, visibly to the compiler (the empty statements below read-modify every
+    // requested register): the loop header then merges "nothing pending" with the back edge's "stores behind the requests"
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < PP; ++q)
+    {
+      asm volatile("" : "+v"(pf_lcode[q]), "+v"(pf_rcode[q]));
+#pragma unroll
+      for (int s = 0; s < S; ++s) { asm volatile("" : "+v"(pfv[q][s])); asm volatile("" : "+v"(ov[q][s])); }
+    }
+  }
+  bool drain = false;                                                // the wait at the top of the coming update is for everything (after a scaling update)
+  for (uint32_t o = op_begin; o < op_end; ++o)
+  {
+    const OpS op = load_op_scalar(P.ops, o);
+    bool all_small[PP];
+#pragma unroll
+    for (int q = 0; q < PP; ++q) all_small[q] = true;
+    if (wave_on)
+    {
+      if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (PP == 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");    // all but the previous update's plane stores
+      else              asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+      drain = false;
+      // (an opaque read-modify of every prefetched register: without it the compiler rotates the loop and copies the requested
+      //  plane into the coming update's operand registers right behind the requests — with an s_waitcnt vmcnt(0) in front)
+#pragma unroll
+      for (int q = 0; q < PP; ++q)
+      {
+        asm volatile("" : "+v"(pf_lcode[q]), "+v"(pf_rcode[q]));
+#pragma unroll
+        for (int s = 0; s < S; ++s) asm volatile("" : "+v"(pfv[q][s]));
+      }
+      const double * lm = myp + (size_t)cur*2*SS;
+      const double * rm = lm + SS;
+      const bool ltip = op.left_clv < tips_n, rtip = op.right_clv < tips_n;
+      const bool lfwd = op.left_clv == ov_clv, rfwd = op.right_clv == ov_clv;
+      const bool lpf = !ltip && !lfwd && op.left_clv == pf_clv, rpf = !rtip && !rfwd && !lpf && op.right_clv == pf_clv;
+      const bool lp2 = !ltip && !lfwd && !lpf && op.left_clv == pf2_clv, rp2 = !rtip && !rfwd && !rpf && op.right_clv == pf2_clv;
+      double lv[PP][S], rv[PP][S];
+      // everything requested ahead is taken over HERE, before the coming update's requests reuse the registers
+      bool lfast = ltip, rfast = rtip;
+      int ls[PP], rs[PP];
+#pragma unroll
+      for (int q = 0; q < PP; ++q)
+      {
+        const uint32_t lcode = pf_lcode[q], rcode = pf_rcode[q];
+        lfast = lfast && __all(__popc(lcode) == 1); rfast = rfast && __all(__popc(rcode) == 1);
+        ls[q] = __ffs(lcode) - 1; rs[q] = __ffs(rcode) - 1;
+      }
+#pragma unroll
+      for (int q = 0; q < PP; ++q)
+      {
+        const uint32_t lcode = pf_lcode[q], rcode = pf_rcode[q];
+        if (ltip && !lfast) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) lv[q][s] = (double)((lcode >> s) & 1u); }
+        if (rtip && !rfast) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) rv[q][s] = (double)((rcode >> s) & 1u); }
+        // what was not requested ahead (a plane an earlier update of this step wrote; a later update's second inner plane)
+        if (!ltip && !lfwd && !lpf && !lp2)
+        {
+          const gcdbl_p p = plane(op.left_clv, q);
+#pragma unroll
+          for (int s = 0; s < S; ++s) lv[q][s] = NTA ? __builtin_nontemporal_load(p + (size_t)s*ld) : p[(size_t)s*ld];
+#pragma unroll
+          for (int s = 0; s < S; ++s) asm volatile("" : "+v"(lv[q][s]));      // (waited for inside the branch, every one of them: see the prologue)
+        }
+        if (!rtip && !rfwd && !rpf && !rp2)
+        {
+          const gcdbl_p p = plane(op.right_clv, q);
+#pragma unroll
+          for (int s = 0; s < S; ++s) rv[q][s] = NTA ? __builtin_nontemporal_load(p + (size_t)s*ld) : p[(size_t)s*ld];
+#pragma unroll
+          for (int s = 0; s < S; ++s) asm volatile("" : "+v"(rv[q][s]));
+        }
+        if (lfwd || lp2) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) lv[q][s] = ov[q][s]; }
+        if (rfwd || rp2) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) rv[q][s] = ov[q][s]; }
+        if (lpf) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) lv[q][s] = pfv[q][s]; }
+        if (rpf) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) rv[q][s] = pfv[q][s]; }
+      }
+      // ---- the coming update's matrices and inputs, before this one's arithmetic
+      written |= 1u << (op.parent_clv & 31u);
+      if (o + 1 < op_end)
+      {
+        const OpS nx = load_op_scalar(P.ops, o + 1);
+        stage_pmats_wave<S>(myp + (size_t)(cur ^ 1u)*2*SS, Lpmat + ((size_t)nx.left_pmatrix*R + k)*SS, Lpmat + ((size_t)nx.right_pmatrix*R + k)*SS, lane);
+        request(nx, op.parent_clv, false);
+      }
+      else { pf_clv = none; pf2_clv = none; }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+      {
+        // the row's entries come out of LDS once and serve the lane's PP patterns (same 4-accumulator fma order per pattern)
+        double x[PP], y[PP];
+        if (lfast) {
+#pragma unroll
+          for (int q = 0; q < PP; ++q) x[q] = lm[i*S + ls[q]]; }
+        else
+        {
+          double a[PP][4];
+#pragma unroll
+          for (int q = 0; q < PP; ++q) a[q][0] = a[q][1] = a[q][2] = a[q][3] = 0;
+#pragma unroll
+          for (int j = 0; j < S; j += 4)
+          {
+            const double m0 = lm[i*S + j], m1 = lm[i*S + j + 1], m2 = lm[i*S + j + 2], m3 = lm[i*S + j + 3];
+#pragma unroll
+            for (int q = 0; q < PP; ++q)
+            {
+              a[q][0] = __builtin_fma(m0, lv[q][j+0], a[q][0]); a[q][1] = __builtin_fma(m1, lv[q][j+1], a[q][1]);
+              a[q][2] = __builtin_fma(m2, lv[q][j+2], a[q][2]); a[q][3] = __builtin_fma(m3, lv[q][j+3], a[q][3]);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < PP; ++q) x[q] = (a[q][0] + a[q][1]) + (a[q][2] + a[q][3]);
+        }
+        if (rfast) {
+#pragma unroll
+          for (int q = 0; q < PP; ++q) y[q] = rm[i*S + rs[q]]; }
+        else
+        {
+          double a[PP][4];
+#pragma unroll
+          for (int q = 0; q < PP; ++q) a[q][0] = a[q][1] = a[q][2] = a[q][3] = 0;
+#pragma unroll
+          for (int j = 0; j < S; j += 4)
+          {
+            const double m0 = rm[i*S + j], m1 = rm[i*S + j + 1], m2 = rm[i*S + j + 2], m3 = rm[i*S + j + 3];
+#pragma unroll
+            for (int q = 0; q < PP; ++q)
+            {
+              a[q][0] = __builtin_fma(m0, rv[q][j+0], a[q][0]); a[q][1] = __builtin_fma(m1, rv[q][j+1], a[q][1]);
+              a[q][2] = __builtin_fma(m2, rv[q][j+2], a[q][2]); a[q][3] = __builtin_fma(m3, rv[q][j+3], a[q][3]);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < PP; ++q) y[q] = (a[q][0] + a[q][1]) + (a[q][2] + a[q][3]);
+        }
+#pragma unroll
+        for (int q = 0; q < PP; ++q)
+        {
+          const double v = x[q]*y[q];
+          all_small[q] = all_small[q] && (v < BPA_SCALE_THRESHOLD);
+          ov[q][i] = v;
+        }
+      }
+      ov_clv = op.parent_clv;
+    }
+    if (op.parent_scaler >= 0)                         // uniform: the scaling test couples the categories
+    {
+#pragma unroll
+      for (int q = 0; q < PP; ++q) reinterpret_cast<uint32_t *>(s_x)[(q*P.pad + k)*64 + lane] = all_small[q] ? 1u : 0u;
+      lds_barrier();
+      if (active)
+      {
+#pragma unroll
+        for (int q = 0; q < PP; ++q)
+        {
+          bool all = true;
+          for (uint32_t c = 0; c < R; ++c) all = all && reinterpret_cast<const uint32_t *>(s_x)[(q*P.pad + c)*64 + lane] != 0u;
+          if (all) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) ov[q][i] *= BPA_SCALE_FACTOR; }
+          if (k == 0)
+          {
+            uint32_t sc = all ? 1u : 0u;
+            if (op.left_scaler  >= 0) sc += Lscaler[(size_t)op.left_scaler*np  + n[q]];
+            if (op.right_scaler >= 0) sc += Lscaler[(size_t)op.right_scaler*np + n[q]];
+            Lscaler[(size_t)op.parent_scaler*np + n[q]] = sc;
+          }
+        }
+      }
+      lds_barrier();                                   // (the scratch is free again)
+      drain = true;                                    // (more than the plane stores were issued behind the requests)
+    }
+    if (wave_on)
+    {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < PP; ++q)
+      {
+        const gdbl_p out = Lclv + ((((size_t)(op.parent_clv - tips_n)*R) + k)*S)*ld + n[q];
+#pragma unroll
+        for (int i = 0; i < S; ++i) { if (NTA) __builtin_nontemporal_store(ov[q][i], out + (size_t)i*ld); else out[(size_t)i*ld] = ov[q][i]; }
+      }
+      asm volatile("" ::: "memory");
+    }
+    cur ^= 1u;
+  }
+  if (!(P.flags & 4u)) return;
+
+  // K2 / K3 (core_likelihood_avx2.c:45-87): every wave its category's term, wave 0 the fma chain over them
+  const uint32_t root = ((cu32_p)P.root_clv)[t];
+  if (active)
+  {
+    if (root != ov_clv && root >= tips_n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (a root this step wrote before its last update: its stores first)
+#pragma unroll
+    for (int q = 0; q < PP; ++q)
+    {
+      double c[S];
+      if (root == ov_clv) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) c[s] = ov[q][s]; }
+      else if (root < tips_n)
+      {
+        const uint32_t code = Ltips[(size_t)root*np + n[q]];
+#pragma unroll
+        for (int s = 0; s < S; ++s) c[s] = (double)((code >> s) & 1u);
+      }
+      else
+      {
+        const gcdbl_p p = plane(root, q);
+#pragma unroll
+        for (int s = 0; s < S; ++s) c[s] = p[(size_t)s*ld];
+      }
+      const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+      s_x[(q*P.pad + k)*64 + lane] = dot_fma4_s<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
+    }
+  }
+  lds_barrier();
+  if (k) return;
+#pragma unroll
+  for (int q = 0; q < PP; ++q)
+  {
+    if (!real[q]) continue;
+    double term = 0;
+    for (uint32_t c = 0; c < R; ++c) term = __builtin_fma(s_x[(q*P.pad + c)*64 + lane], par[par_rate_weights(R) + c], term);
+    if (!unphased)
+    {
+      double lt = log(term);
+      const int32_t rsc = ((ci32_p)P.root_scaler)[t];
+      if (rsc >= 0)
+      {
+        const uint32_t sc = Lscaler[(size_t)rsc*np + n[q]];
+        if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
+      }
+      term = lt*Lwgt[n[q]];
+    }
+    P.site_term[((cu32_p)P.task_pat_off)[t] + n[q]] = term;      // (real lanes: n = the lane's own pattern)
+  }
+}
+
 // ======================= K1+K2, 20 states, FP64 MFMA (north_star's matrix-core path), one wave per rate category ==
 // The contraction parent[i][n] = (sum_j Pl[i][j] L[j][n]) (sum_j Pr[i][j] R[j][n]) on the matrix cores with
 // v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction: blocks = four groups of 4 patterns, A = a 4-row x
@@ -2499,6 +2883,349 @@ step_s4_klane_v2_kernel(const PlanDev P)
     __shared__ double s_lnl[BS];
     s_lnl[lane] = c_lnl;
     __syncthreads();
+    if (lane == 0)
+    {
+      double part = 0;
+      for (uint32_t q = 0; q < s1 - s0; ++q) part += s_lnl[q];
+      P.wg_part[b] = part;
+    }
+  }
+}
+
+// ================================================================ step_s4_klane_v3_kernel (round 5) ==
+// step_s4_klane_v2_kernel with its dependent round trips cut from ~2 per node update to 3 per STEP.  v2 walks a locus's update
+// list one record at a time: record -> (child CLV, the wave's P-matrix chunks) -> compute -> next record ..., i.e. 2 nops + 2
+// global round trips in series with ~150 cycles of arithmetic between them — rocprofv3 had 82 % of its wave-cycles waiting and
+// 32 % of its LDS cycles in bank conflicts (profiles/r4/profile_c3.json).  Here:
+//   trip 1  the lane's table entry (as before);
+//   trip 2  the slot record and header AND every record of the step for the (at most four) groups the wave spans: lanes
+//           16 g .. 16 g + 15 bring the 16 sixteen-byte units of group g's record (header + up to 15 updates) into LDS — the
+//           update list is then read from LDS by index, no global load per update;
+//   trip 3  the P-matrices of ALL updates of the step, global -> LDS directly (global_load_lds_dwordx4: no registers, so the
+//           number in flight is not bounded by a static unroll) and the children of the first four updates that can be read
+//           ahead: inner nodes that no update of this step writes (a bit mask of the step's parents decides; a child that is
+//           the previous update's parent is forwarded in registers as before, a child written earlier in the step is read
+//           when it is used, after the lane's own store).
+// Bank conflicts: the chunk j of group g sits at position 16 g + (j ^ g) of the wave's 1-KB corner, so lanes of different
+// groups reading "their" chunk j hit different banks (v2: all four groups on the same banks whenever a 16-lane service group
+// of ds_read_b128 spans two groups).  Arithmetic, operation order and stores are v2's: same bits.
+#ifndef BPA_KLANE_OCC
+#define BPA_KLANE_OCC 4
+#endif
+#ifndef BPA_KLANE_CH
+#define BPA_KLANE_CH 4
+#endif
+template <int BS, bool FUSE_A = false>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(FUSE_A ? 3 : BPA_KLANE_OCC, 8)))
+step_s4_klane_v3_kernel(const PlanDev P)
+{
+  extern __shared__ __attribute__((aligned(16))) double2 s_pmx[];    // [BS/64][rec2_units - 1][64]: every update's two matrices, per wave
+  __shared__ double s_term[BS], s_tr[BS];
+  __shared__ uint4 s_rec[BS/64][4][16];                               // per wave: the step records of the groups it spans
+  const uint32_t b = P.blk0 + blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
+  if (FUSE_A && (P.flags & 32u))
+  {
+    const uint32_t q0 = P.blk_slot_off[b], q1 = P.blk_slot_off[b+1];
+    if (lane < q1 - q0)
+    {
+      const LocusDev & L = P.loci[P.slot_tab[q0 + lane].locus];
+      for (uint32_t m = 0; m < L.rate_matrices; ++m)
+      {
+        double * pm = L.par + par_matrix(L.rate_cats, 4, m);
+        update_eigen_regs<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
+      }
+    }
+    __syncthreads();
+  }
+  if (FUSE_A && (P.flags & 1u))
+  {
+    const uint32_t e0 = P.blk_mat_off[b], e1 = P.blk_mat_off[b+1], rmax = P.pad;
+    for (uint32_t i = lane; i < (e1 - e0)*rmax; i += BS)
+    {
+      const uint32_t e = e0 + i/rmax, k = i % rmax;
+      const MatRec2 m2 = P.mat2[e];
+      if (m2.slot == 0xffffffffu) continue;
+      const SlotStatic & M = P.slot_tab[m2.slot];
+      if (k >= M.rate_cats) continue;
+      MatRec m;
+      m.dst = M.pmat + (size_t)m2.pmatrix*M.rate_cats*M.pstride; m.par = M.par; m.rate_cats = M.rate_cats; m.model = M.model; m.entry = e; m.pad = 0;
+      pmatrix_s4_rec(m, P.mat_length, k);
+    }
+    __syncthreads();                                         // the block's fresh P-matrices are out (written and read on this CU)
+  }
+  BPA_STAMP(P, b, lane, 0);
+  const uint32_t s0 = P.blk_slot_off[b], s1 = P.blk_slot_off[b+1];
+  const LaneStatic ls = P.lane_tab[gl];
+  const bool has_slot = ls.slot != 0xffffffffu;
+  const bool summer = (P.flags & 4u) && lane < s1 - s0;
+  const uint32_t n = ls.n_np_tips & 511u, np = (ls.n_np_tips >> 9) & 511u;
+  const uint32_t k = (ls.n_np_tips >> 23) & 7u, R = ls.n_np_tips >> 26;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(lane >> 6), wl = lane & 63u;
+  const uint32_t units = P.rec2_units, maxops = units - 1u;
+  static const uint32_t none = 0xffffffffu;
+
+  // ---- the groups of this wave (a group = the lanes of one (locus, category)), from the lane table alone
+  const bool grouped = has_slot && (P.flags & 2u);
+  const uint32_t gkey = grouped ? (ls.slot << 3 | k) : none;
+  const uint32_t prevkey = __shfl_up(gkey, 1);
+  const bool first = grouped && (wl == 0 || gkey != prevkey);
+  const unsigned long long fmask = __ballot(first);
+  const uint32_t ngroups = (uint32_t)__popcll(fmask);
+  const uint32_t my_g = (uint32_t)__popcll(fmask & ((2ull << wl) - 1ull)) - 1u;
+  const uint32_t gs = wl >> 4, gu = wl & 15u;
+  uint32_t src = 0;
+  { unsigned long long m = fmask; for (uint32_t i = 0; i < gs; ++i) m &= m - 1ull; src = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u; }
+  const uint32_t s_slot = __shfl(ls.slot, (int)src), s_kR = __shfl(k | R << 3, (int)src);
+  const bool stager = ngroups >= 1 && ngroups <= 4 && gs < ngroups;
+
+  BPA_STAMP(P, b, lane, 1);
+  // ---- trip 2: slot record, header, the step's records of the wave's groups, the summing lanes' task
+  uint32_t c_np = 0, c_l0 = 0, c_task = none;
+  double c_lnl = 0;
+  if (summer)
+  {
+    const SlotStatic & C = P.slot_tab[s0 + lane];
+    c_np = C.np; c_l0 = C.lane0 - b*BS;
+    c_task = reinterpret_cast<const StepRec *>(P.recs2 + (size_t)(s0 + lane)*units)->task;
+  }
+  SlotStatic S{};
+  StepRec hdr{};
+  hdr.task = none;
+  const uint4 * rp = P.recs2 + (size_t)(has_slot ? ls.slot : 0u)*units;
+  uint4 st_unit = make_uint4(none, 0, 0, 0);
+  if (stager && gu < units) st_unit = gld4(P.recs2 + (size_t)s_slot*units + gu);
+  if (has_slot && (P.flags & 6u))
+  {
+    const uint4 * sp = reinterpret_cast<const uint4 *>(P.slot_tab + ls.slot);
+    uint4 * sd = reinterpret_cast<uint4 *>(&S);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(SlotStatic)/16); ++i) sd[i] = sp[i];
+    *reinterpret_cast<uint4 *>(&hdr) = rp[0];
+  }
+  if (stager) s_rec[wave][gs][gu] = st_unit;
+  const bool work = has_slot && hdr.task != none && (P.flags & 6u);
+  const uint32_t tips = S.tips_n;
+  const unsigned long long odd = __ballot(grouped && work && S.pstride != 16u);      // (a, b) pairs of JC69 loci: nothing to stage
+  const bool use_lds = ngroups >= 1 && ngroups <= 4 && odd == 0 && !getenv_klane_direct(P);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  BPA_STAMP(P, b, lane, 2);
+  // ---- trip 3, part 1: every update's two matrices, global -> LDS (lane 16 g + p brings chunk p ^ g of group g)
+  double2 * pmw = s_pmx + (size_t)wave*maxops*64u;
+  if (use_lds)
+  {
+    const unsigned long long s_pm_lo = __shfl((uint32_t)reinterpret_cast<uintptr_t>(S.pmat), (int)src);
+    const unsigned long long s_pm_hi = __shfl((uint32_t)(reinterpret_cast<uintptr_t>(S.pmat) >> 32), (int)src);
+    const double * st_pmat = reinterpret_cast<const double *>(s_pm_lo | s_pm_hi << 32);
+    const uint32_t st_k = s_kR & 7u, st_R = s_kR >> 3;
+    uint32_t st_nops = 0;
+    if (stager)
+    {
+      const StepRec sh = *reinterpret_cast<const StepRec *>(&s_rec[wave][gs][0]);
+      st_nops = sh.task != none ? sh.nops : 0u;
+    }
+    const uint32_t c = gu ^ gs;
+    for (uint32_t o = 0; __any(o < st_nops); ++o)
+    {
+      if (o < st_nops)
+      {
+        const StepOp so = *reinterpret_cast<const StepOp *>(&s_rec[wave][gs][1 + o]);
+        const uint32_t pm = c < 8u ? so.left_pmatrix : so.right_pmatrix;
+        const double * g = st_pmat + ((size_t)pm*st_R + st_k)*16 + (size_t)(c & 7u)*2;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(pmw + (size_t)o*64u), 16, 0, 0);
+      }
+    }
+  }
+
+  double tr = 0;
+  {
+    double fwd[4] = {0, 0, 0, 0};
+    uint32_t fwd_clv = none;
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    auto clv_ptr = [&](uint32_t c)
+    {
+      return reinterpret_cast<const __attribute__((address_space(1))) d2v *>(
+          reinterpret_cast<uintptr_t>(S.clv + ((((size_t)(c - tips)*R) + k)*np + n)*4));
+    };
+    auto code_of = [&](uint32_t c) { return tips <= 8 ? (ls.tipcodes >> (4*c)) & 15u : (uint32_t)S.tips[(size_t)c*np + n]; };
+    auto store_parent = [&](uint32_t pc, const double x[4], const double y[4])
+    {
+      double2 o0, o1;
+      o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
+      d2v a0, a1; a0.x = o0.x; a0.y = o0.y; a1.x = o1.x; a1.y = o1.y;
+      __attribute__((address_space(1))) d2v * dst = reinterpret_cast<__attribute__((address_space(1))) d2v *>(
+          reinterpret_cast<uintptr_t>(S.clv + ((((size_t)(pc - tips)*R) + k)*np + n)*4));
+      __builtin_nontemporal_store(a0, dst); __builtin_nontemporal_store(a1, dst + 1);
+      fwd[0] = o0.x; fwd[1] = o0.y; fwd[2] = o1.x; fwd[3] = o1.y;
+      fwd_clv = pc;
+    };
+    const uint32_t nops = (work && (P.flags & 2u)) ? hdr.nops : 0u;
+    if (use_lds)
+    {
+      uint32_t written = 0;                                    // the CLV buffers (< 32: byte indices of <= 8-tip loci, 5 bits) this lane's step has written
+      bool dma_waited = false;
+      constexpr int CH = BPA_KLANE_CH;
+      for (uint32_t o0 = 0; __any(o0 < nops); o0 += (uint32_t)CH)
+      {
+        // ---- trip 3, part 2 (and one more trip per further four updates): the children that can be read ahead
+        uint2 opw[CH];
+        d2v ch[CH][2], chb[2];
+        uint32_t pf[CH];
+        uint32_t w2 = written, prevp = fwd_clv;
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+        {
+          pf[j] = 0; opw[j] = make_uint2(0, 0);
+          if (o0 + j < nops)
+          {
+            opw[j] = *reinterpret_cast<const uint2 *>(&s_rec[wave][my_g][1 + o0 + j]);
+            const uint32_t pc = opw[j].x & 255u, lc = (opw[j].x >> 8) & 255u, rc = (opw[j].x >> 16) & 255u;
+            const bool pl = lc >= tips && lc != prevp && !((w2 >> (lc & 31u)) & 1u);
+            const bool pr = rc >= tips && rc != prevp && !((w2 >> (rc & 31u)) & 1u);
+            if (pl)
+            {
+              const auto p = clv_ptr(lc);
+              ch[j][0] = __builtin_nontemporal_load(p); ch[j][1] = __builtin_nontemporal_load(p + 1);
+              pf[j] = 1;
+              if (j == 0 && pr) { const auto q = clv_ptr(rc); chb[0] = __builtin_nontemporal_load(q); chb[1] = __builtin_nontemporal_load(q + 1); pf[j] = 3; }
+            }
+            else if (pr)
+            {
+              const auto p = clv_ptr(rc);
+              ch[j][0] = __builtin_nontemporal_load(p); ch[j][1] = __builtin_nontemporal_load(p + 1);
+              pf[j] = 2;
+            }
+            w2 |= 1u << (pc & 31u);
+            prevp = pc;
+          }
+        }
+        if (!dma_waited)
+        {
+          // the matrices have landed (this wave's own requests: vmcnt; the children come back with them)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          dma_waited = true;
+          BPA_STAMP(P, b, lane, 3);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+        {
+          if (o0 + j < nops)
+          {
+            const uint32_t pc = opw[j].x & 255u, lc = (opw[j].x >> 8) & 255u, rc = (opw[j].x >> 16) & 255u;
+            double lv[4], rv[4], x[4], y[4];
+            if (lc == fwd_clv) { lv[0] = fwd[0]; lv[1] = fwd[1]; lv[2] = fwd[2]; lv[3] = fwd[3]; }
+            else if (lc < tips) expand_code(code_of(lc), lv);
+            else
+            {
+              d2v uu, ww;
+              if (pf[j] & 1u) { uu = ch[j][0]; ww = ch[j][1]; }
+              else { const auto p = clv_ptr(lc); uu = __builtin_nontemporal_load(p); ww = __builtin_nontemporal_load(p + 1); }
+              lv[0] = uu.x; lv[1] = uu.y; lv[2] = ww.x; lv[3] = ww.y;
+            }
+            if (rc == fwd_clv) { rv[0] = fwd[0]; rv[1] = fwd[1]; rv[2] = fwd[2]; rv[3] = fwd[3]; }
+            else if (rc < tips) expand_code(code_of(rc), rv);
+            else
+            {
+              d2v uu, ww;
+              if (pf[j] == 2u) { uu = ch[j][0]; ww = ch[j][1]; }
+              else if (j == 0 && pf[j] == 3u) { uu = chb[0]; ww = chb[1]; }
+              else { const auto p = clv_ptr(rc); uu = __builtin_nontemporal_load(p); ww = __builtin_nontemporal_load(p + 1); }
+              rv[0] = uu.x; rv[1] = uu.y; rv[2] = ww.x; rv[3] = ww.y;
+            }
+            const double2 * r = pmw + (size_t)(o0 + j)*64u + my_g*16u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+              const double2 a0 = r[(2*i) ^ my_g], b0 = r[(2*i + 1) ^ my_g];
+              x[i] = dot4_pair(a0.x, a0.y, b0.x, b0.y, lv);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+              const double2 a1 = r[(8 + 2*i) ^ my_g], b1 = r[(8 + 2*i + 1) ^ my_g];
+              y[i] = dot4_pair(a1.x, a1.y, b1.x, b1.y, rv);
+            }
+            store_parent(pc, x, y);
+            written |= 1u << (pc & 31u);
+          }
+        }
+      }
+    }
+    else
+    {
+      // more than four groups in the wave (loci of a handful of patterns) or (a, b) pairs: v2's direct form, a record at a time
+      for (uint32_t o = 0; __any(o < nops); ++o)
+      {
+        if (o < nops)
+        {
+          StepOp op;
+          *reinterpret_cast<uint4 *>(&op) = gld4(rp + 1 + o);
+          double lv[4], rv[4], x[4], y[4];
+          auto vec_of = [&](uint32_t c, double v[4])
+          {
+            if (c == fwd_clv) { v[0] = fwd[0]; v[1] = fwd[1]; v[2] = fwd[2]; v[3] = fwd[3]; }
+            else if (c < tips) expand_code(code_of(c), v);
+            else { const auto p = clv_ptr(c); const d2v uu = __builtin_nontemporal_load(p), ww = __builtin_nontemporal_load(p + 1); v[0] = uu.x; v[1] = uu.y; v[2] = ww.x; v[3] = ww.y; }
+          };
+          vec_of(op.left_clv, lv);
+          vec_of(op.right_clv, rv);
+          matvec4_p(S.pmat, S.pstride, (size_t)op.left_pmatrix*R  + k, lv, x);
+          matvec4_p(S.pmat, S.pstride, (size_t)op.right_pmatrix*R + k, rv, y);
+          store_parent(op.parent_clv, x, y);
+        }
+      }
+    }
+    BPA_STAMP(P, b, lane, 4);
+    if (work)
+    {
+      // K2 at the root (core_likelihood_avx.c:117-150): this category's frequency-weighted sum
+      const double * par = S.par;
+      double c[4];
+      const uint32_t rc = hdr.root_clv;
+      if (rc == fwd_clv) { c[0] = fwd[0]; c[1] = fwd[1]; c[2] = fwd[2]; c[3] = fwd[3]; }
+      else if (rc < tips) expand_code(code_of(rc), c);
+      else { const auto p = clv_ptr(rc); const d2v uu = __builtin_nontemporal_load(p), ww = __builtin_nontemporal_load(p + 1); c[0] = uu.x; c[1] = uu.y; c[2] = ww.x; c[3] = ww.y; }
+      const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
+      const double * f = par + par_matrix(R, 4, m) + pm_freqs(4);
+      tr = dot4_pair(f[0], f[1], f[2], f[3], c);
+    }
+  }
+  s_tr[lane] = tr;
+  lds_barrier();                                   // (LDS only: a plain __syncthreads() would wait for this wave's CLV stores to be acknowledged)
+  BPA_STAMP(P, b, lane, 5);
+  double term = 0;
+  if (work && k == 0)
+  {
+    const double * par = S.par;
+    for (uint32_t q = 0; q < R; ++q) term += s_tr[lane + q*np]*par[par_rate_weights(R) + q];
+    term = log(term)*ls.wgt;
+    gst(P.site_term + hdr.pat_off + n, term);
+  }
+  if (!(P.flags & 4u)) return;
+
+  // ---- per-locus sum in pattern order (the k = 0 lanes are the first np lanes of a locus)
+  s_term[lane] = term;
+  lds_barrier();
+  BPA_STAMP(P, b, lane, 6);
+  if (summer && c_task != none)
+  {
+    double logl = 0;
+    for (uint32_t q = 0; q < c_np; ++q) logl += s_term[c_l0 + q];
+    P.lnl[c_task] = P.bfbeta*logl;
+    c_lnl = P.bfbeta*logl;
+  }
+  if (P.flags & 8u)
+  {
+    __shared__ double s_lnl[BS];
+    s_lnl[lane] = c_lnl;
+    lds_barrier();
     if (lane == 0)
     {
       double part = 0;
