@@ -97,6 +97,8 @@ def compact_line(full):
                     epi.setdefault(who, {})[p] = [v.get("ess_per_iteration"), v.get("ess_per_iteration_se")]
         if epi:
             out["ess_per_iteration"] = epi
+        if se.get("ratio_ess_per_iteration"):
+            out["ess_per_iteration_ratio"] = {k: [v["value"], v["se"]] for k, v in se["ratio_ess_per_iteration"].items() if isinstance(v, dict)}
     if lo:
         r = lo.get("roofline") or {}
         out["likelihood_only"] = {"it_s": lo.get("iterations_per_s"), "kernel": (r.get("kernel") or "")[:50], "frac": r.get("frac"),
@@ -389,6 +391,13 @@ def ess(x):
     return float(n / max(tau, 1e-9))
 
 
+def ess_batches(x, batches=5):
+    """ESS per iteration as the mean over consecutive batches of the trace, with its standard error"""
+    x = np.asarray(x, dtype=float)
+    per = [ess(b) / len(b) for b in np.array_split(x, batches)]
+    return dict(ess_per_iteration=round(float(np.mean(per)), 4), ess_per_iteration_se=round(float(np.std(per, ddof=1) / np.sqrt(len(per))), 4))
+
+
 def run_efficiency(eng, cfg, data, loci, chain, prog_rate, steps_hint=4000):
     """BPP's own move kernel on the device (bpa_sampler_set_proposal_kernel: Bactrian-Laplace windows, legacy_rndu) with the
     step lengths the program's burn-in arrived at, priors of the program's control file: effective samples per second of
@@ -406,13 +415,14 @@ def run_efficiency(eng, cfg, data, loci, chain, prog_rate, steps_hint=4000):
         if program:
             smp.set_proposal_kernel(1)
             smp.set_program_moves(True, 0.1)                           # THETA / TAU / MIX as the program runs them (bpp.c:650, 618, 581)
-            smp.set_theta_prior(2.0, 1000.0, ft["th2"])                #          thetaprior = gamma 2 1000
-            smp.set_finetune(ft["gage"], ft["gspr"], ft["tau"], ft["mix"])
+            smp.set_theta_prior(2.0, 1000.0, 0.001)                    #          thetaprior = gamma 2 1000; the program's default step lengths
+            smp.set_finetune(5.0, 0.001, 0.001, 0.3)                   #          (bpp.c:530-549): its burn-in rule tunes them below
         else:
             scale = 1.0 / math.sqrt(len(data))                         # (the headline section's step lengths)
             smp.set_theta_prior(2.0, 1000.0, 0.008 * scale)
             smp.set_finetune(0.004, 0.004, 0.004 * scale, 0.6 * scale)
         smp.initialize()
+        own_ft = smp.burnin(400) if program else None                  # (the program's chain: burnin = 400 as well)
         smp.iterate(500)
         eng.synchronize()
         t0 = time.perf_counter()
@@ -426,23 +436,32 @@ def run_efficiency(eng, cfg, data, loci, chain, prog_rate, steps_hint=4000):
         sm = smp.summary()
         gibbs = smp.gibbs_counters()
         smp.close()
+        tr_tau, tr_theta = np.round(tr_tau, 6), np.round(tr_theta, 6)       # (the program prints 6 decimals)
         d_ = dict(iterations_per_s=round(rate, 1), samples=steps_hint, acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
-                  tau_root=dict(mean=float(np.mean(tr_tau)), sd=float(np.std(tr_tau)), ess_per_iteration=round(ess(tr_tau) / steps_hint, 4)),
-                  theta_root=dict(mean=float(np.mean(tr_theta)), sd=float(np.std(tr_theta)), ess_per_iteration=round(ess(tr_theta) / steps_hint, 4)))
+                  tau_root=dict(mean=float(np.mean(tr_tau)), sd=float(np.std(tr_tau)), **ess_batches(tr_tau)),
+                  theta_root=dict(mean=float(np.mean(tr_theta)), sd=float(np.std(tr_theta)), **ess_batches(tr_theta)))
         if program:
             d_["theta_gibbs_draws"] = dict(proposed=gibbs[0], accepted=gibbs[1])
+            d_["step_lengths_after_burnin"] = {k: float(f"{v:.4g}") for k, v in own_ft.items()}
         return d_
     dev = chain_on_device(True)
     dev_uniform = chain_on_device(False)
     root = f"{S + 1}"
     p_tau, p_theta = chain["trace"].get("tau:" + root), chain["trace"].get("theta:" + root)
     prog = dict(iterations_per_s=prog_rate, samples=chain["samples"], threads=chain["threads"],
-                tau_root=dict(mean=float(np.mean(p_tau)), sd=float(np.std(p_tau)), ess_per_iteration=round(ess(p_tau) / len(p_tau), 4)),
-                theta_root=dict(mean=float(np.mean(p_theta)), sd=float(np.std(p_theta)), ess_per_iteration=round(ess(p_theta) / len(p_theta), 4)))
+                tau_root=dict(mean=float(np.mean(p_tau)), sd=float(np.std(p_tau)), **ess_batches(p_tau)),
+                theta_root=dict(mean=float(np.mean(p_theta)), sd=float(np.std(p_theta)), **ess_batches(p_theta)))
     for d_ in (dev, dev_uniform, prog):
         for k in ("tau_root", "theta_root"):
             d_[k]["ess_per_s"] = round(d_[k]["ess_per_iteration"] * d_["iterations_per_s"], 2)
+    def ratio_it(k):
+        a, b = dev[k], prog[k]
+        r_ = a["ess_per_iteration"] / max(b["ess_per_iteration"], 1e-12)
+        return dict(value=round(r_, 3), se=round(r_ * math.hypot(a["ess_per_iteration_se"] / max(a["ess_per_iteration"], 1e-12),
+                                                                 b["ess_per_iteration_se"] / max(b["ess_per_iteration"], 1e-12)), 3))
     return dict(device=dev, device_uniform_kernel=dev_uniform, reference_program=prog, step_lengths=ft,
+                ratio_ess_per_iteration=dict(tau_root=ratio_it("tau_root"), theta_root=ratio_it("theta_root"),
+                                             longer_runs="profiles/r5/ess_*.json: 1 000 loci x 100 000 samples and 10 000 loci x 20 000 samples, both chains on the SAME data (tools/ess_device_vs_program.py)"),
                 ratio_ess_per_s=dict(tau_root=round(dev["tau_root"]["ess_per_s"] / max(prog["tau_root"]["ess_per_s"], 1e-9), 1),
                                      theta_root=round(dev["theta_root"]["ess_per_s"] / max(prog["theta_root"]["ess_per_s"], 1e-9), 1)),
                 note_uniform_kernel="device_uniform_kernel: the headline section's sampler (our 64-bit streams, uniform windows, sliding-window THETA, "
@@ -1159,6 +1178,11 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves
     smp.initialize()
     kind = smp.kind()
     sync = D.sync if D else eng.synchronize
+    burnin_ft = None
+    if program and D is None and kind == "persistent":
+        # the program's burn-in (finetune = 1): 800 iterations, the step lengths reset from the acceptance proportions after every
+        # quarter and at the end (bpa_sampler_burnin: reset_finetune, method.c:1508-1516, 5364) — outside the timed region
+        burnin_ft = smp.burnin(800)
     # A step = `ips` MCMC iterations, chosen so that the timed region lasts >= 0.25 s whatever --steps is (an iteration
     # of config 2 takes ~0.1 ms: 20 of them would be a 2 ms region); the rate does not depend on it.  Every rank takes
     # the same count (the ranks enter the same collectives).
@@ -1291,10 +1315,11 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves
                acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
                moves=("the program's (BPP v4.8.7 defaults): legacy_rndu + Bactrian-Laplace windows, theta by the metropolized Gibbs draw 9 times in 10 "
                       "(stree.c:3957), thetas re-drawn inside the rubber band (stree.c:5840) and the mixing step (prop_mixing.c:272); step lengths "
-                      f"of the program's own burn-in ({PROGRAM_FT})" if program else
+                      "from the program's burn-in rule run on the device (bpa_sampler_burnin, 800 iterations)" if program else
                       "uniform windows on the library's 64-bit streams, sliding-window theta, no theta re-draws in TAU / MIX" if not generic else
                       "uniform windows on the library's 64-bit streams (generic sampler)"),
                theta_gibbs_draws=(dict(zip(("proposed", "accepted"), smp.gibbs_counters())) if program else None),
+               step_lengths_after_burnin=({k: float(f"{v:.4g}") for k, v in burnin_ft.items()} if burnin_ft else None),
                taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
                thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],
                roofline=add_frac_pmc(roofline),

@@ -135,6 +135,9 @@ def lib():
         "bpa_sampler_set_species_tree": (i, [vp, i, C.POINTER(i), dp, dp]),
         "bpa_sampler_set_tip_species": (i, [vp, u, C.POINTER(i)]),
         "bpa_sampler_set_finetune": (None, [vp, d, d, d, d]),
+        "bpa_finetune_onestep": (d, [d, d]),
+        "bpa_sampler_adapt_finetune": (i, [vp, dp, dp]),
+        "bpa_sampler_burnin": (i, [vp, u, dp]),
         "bpa_sampler_set_tau_prior": (None, [vp, d, d]),
         "bpa_sampler_set_theta_prior": (None, [vp, d, d, d]),
         "bpa_sampler_get_thetas": (i, [vp, dp]),
@@ -191,6 +194,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride", "bpa_engine_timing_work", "bpa_engine_timing_work_codes", "bpa_plan_work_codes",
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
             "bpa_sampler_set_species_tree", "bpa_sampler_set_tip_species", "bpa_sampler_set_finetune",
+            "bpa_finetune_onestep", "bpa_sampler_adapt_finetune", "bpa_sampler_burnin",
             "bpa_sampler_set_tau_prior", "bpa_sampler_get_taus", "bpa_sampler_get_tree_msc",
             "bpa_sampler_set_theta_prior", "bpa_sampler_get_thetas", "bpa_sampler_set_allreduce",
             "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary",
@@ -588,6 +592,21 @@ class Sampler:
 
     def set_finetune(self, gage, gspr, tau, mix):
         lib().bpa_sampler_set_finetune(self.h, gage, gspr, tau, mix)
+
+    FT_NAMES = ("gage", "gspr", "tau", "mix", "theta")
+
+    def adapt_finetune(self):
+        """the burn-in's step-length rule on the acceptance proportions since the last call (reset_finetune, method.c:1508-1516);
+        -> (pjump, finetune) dicts by move type; pjump < 0: never proposed"""
+        pj, ft = (C.c_double * 5)(), (C.c_double * 5)()
+        _chk(lib().bpa_sampler_adapt_finetune(self.h, pj, ft))
+        return dict(zip(self.FT_NAMES, pj)), dict(zip(self.FT_NAMES, ft))
+
+    def burnin(self, iterations):
+        """`iterations` iterations with the program's step-length resets (after every quarter and at the end, method.c:5364)"""
+        ft = (C.c_double * 5)()
+        _chk(lib().bpa_sampler_burnin(self.h, int(iterations), ft))
+        return dict(zip(self.FT_NAMES, ft))
 
     def set_proposal_kernel(self, kind):
         """0 uniform windows on our streams (default), 1 BPP's legacy_rndu + Bactrian-Laplace (before initialize)"""

@@ -1195,6 +1195,7 @@ struct bpa_sampler
   DevBuf<unsigned long long> v2_xbuf;
   DevBuf<a00_rng_t> v2_grng;
   DevBuf<int> v2_err;
+  DevBuf<unsigned long long> v2_pj;      // proposals / accepted by move type since the last bpa_sampler_adapt_finetune (sweep2.hpp Args::pj)
   DevBuf<double> v2_prof, v2_declog;
   DevBuf<smp::Species> v2_sp;
   smp::Species v2_sp_sent{};            // what v2_sp holds
@@ -1550,8 +1551,9 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
   const int zero2v[3] = {0, 0, 0};
   if (!upload(s->v2_wave_off, woff.data(), woff.size()) || !upload(s->v2_loc, loc.data(), loc.size()) ||
       !upload(s->v2_pat, pat.data(), pat.size()) || !s->v2_xbuf.reserve((size_t)2*smp2::XN) || !s->v2_grng.reserve(1) ||
-      !upload(s->v2_err, zero2v, 3) || !s->v2_prof.reserve(40 + (size_t)nwg) || !s->v2_declog.reserve(4*2048) || !s->v2_sp.reserve(1))
+      !upload(s->v2_err, zero2v, 3) || !s->v2_prof.reserve(40 + (size_t)nwg) || !s->v2_declog.reserve(4*2048) || !s->v2_sp.reserve(1) || !s->v2_pj.reserve(16))
     return 0;
+  HIPCHK(hipMemset(s->v2_pj.p, 0, 16*sizeof(unsigned long long)));
   HIPCHK(hipMemset(s->v2_prof.p, 0, (40 + (size_t)nwg)*sizeof(double)));
   {
     void (*k0)(const smp2::Args) = NT == 4 ? smp2::iter_kernel<4, false> : smp2::iter_kernel<8, false>;
@@ -1822,6 +1824,58 @@ extern "C" void bpa_sampler_set_finetune(bpa_sampler_t * s, double gage, double 
   s->sp.ft_gage = gage; s->sp.ft_gspr = gspr; s->sp.ft_tau = tau; s->sp.ft_mix = mix;
 }
 
+// ---- the burn-in's step-length rule (reset_finetune_onestep, method.c:1122-1136; called by reset_finetune, method.c:1508-1516,
+// four times during the burn-in and once at its end: method.c:5364-5377) on the persistent kernel's move-type counters
+static double finetune_onestep(const double pjump, const double ft)
+{
+  const double maxstep = 99, optimum = 0.3, half_pi = 1.5707963267948966;          // (pj_optimum, method.c:45)
+  if (pjump < 0.001) return ft/100;
+  if (pjump > 0.999) return std::min(maxstep, ft*100);
+  return std::min(maxstep, ft*std::tan(half_pi*pjump)/std::tan(half_pi*optimum));
+}
+
+extern "C" double bpa_finetune_onestep(double pjump, double finetune) { return finetune_onestep(pjump, finetune); }
+
+extern "C" int bpa_sampler_adapt_finetune(bpa_sampler_t * s, double * pjump, double * finetune)
+{
+  std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+  if (s->comp || s->generic || s->big) return fail("bpa_sampler_adapt_finetune: the move-type counters are the persistent iteration kernel's (JC69 loci of <= 8 tips and <= 64 patterns)");
+  if (!sampler_download(s)) return 0;                 // (settles the launches in flight; the counters are then final)
+  if (!s->v2_ok || !s->v2_pj.p) return fail("bpa_sampler_adapt_finetune: the sampler does not run the persistent iteration kernel");
+  unsigned long long c[16];
+  HIPCHK(hipMemcpy(c, s->v2_pj.p, sizeof c, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(s->v2_pj.p, 0, sizeof c));          // pjump_reset (method.c:5377)
+  double * ft[5] = { &s->sp.ft_gage, &s->sp.ft_gspr, &s->sp.ft_tau, &s->sp.ft_mix, &s->sp.ft_theta };
+  for (int m = 0; m < 5; ++m)
+  {
+    const double pj = c[2*m] ? (double)c[2*m + 1]/(double)c[2*m] : -1.0;
+    // (a move that was never proposed keeps its step length: the program has no such case — every active one runs every iteration;
+    //  the theta window is proposed once in ten, opt_theta_slide_prob)
+    if (pj >= 0 && *ft[m] > 0) *ft[m] = finetune_onestep(pj, *ft[m]);
+    if (pjump) pjump[m] = pj;
+    if (finetune) finetune[m] = *ft[m];
+  }
+  return 1;                                            // (the species record goes to the device with the next launch: v2_sp_sent)
+}
+
+// the program's burn-in: `iterations` iterations with the step lengths reset from the acceptance proportions after every
+// quarter (method.c:5364: i % (burnin/4) == 0 with at least 100 iterations since the last reset) and at the end
+extern "C" int bpa_sampler_burnin(bpa_sampler_t * s, unsigned iterations, double * finetune)
+{
+  const unsigned q = iterations/4;
+  unsigned done = 0;
+  if (iterations >= 200 && q >= 100)
+    for (int r = 0; r < 3; ++r)
+    {
+      if (!bpa_sampler_iterate(s, q) || !bpa_sampler_adapt_finetune(s, nullptr, nullptr)) return 0;
+      done += q;
+    }
+  if (iterations > done && !bpa_sampler_iterate(s, iterations - done)) return 0;
+  if (iterations >= 200) return bpa_sampler_adapt_finetune(s, nullptr, finetune);
+  if (finetune) { finetune[0] = s->sp.ft_gage; finetune[1] = s->sp.ft_gspr; finetune[2] = s->sp.ft_tau; finetune[3] = s->sp.ft_mix; finetune[4] = s->sp.ft_theta; }
+  return 1;
+}
+
 extern "C" void bpa_sampler_set_tau_prior(bpa_sampler_t * s, double alpha, double beta)
 {
   if (s->comp) (void)comp_each(s, [&](bpa_sampler * p) { bpa_sampler_set_tau_prior(p, alpha, beta); return 1; });
@@ -1957,7 +2011,7 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
     s->mix_pending = false; s->logpr_stale = false;
     a.counters = s->counters.p; a.lograt = s->lograt.p; a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p;
     a.ntasks = s->nloci; a.nwaves = s->v2_nwaves; a.nwg = s->v2_nwg; a.lwaves = s->v2_lwaves; a.xbuf = s->v2_xbuf.p;
-    a.err = s->v2_err.p; a.grng = s->v2_grng.p; a.niter = chunk;
+    a.err = s->v2_err.p; a.grng = s->v2_grng.p; a.niter = chunk; a.pj = s->v2_pj.p;
     a.nsteps_gage = s->maxtips - 1; a.nsteps_gspr = 2*s->maxtips - 2;
     if (s->env_gage >= 0) { a.nsteps_gage = (uint32_t)s->env_gage; a.nsteps_gspr = (uint32_t)s->env_gspr; }
     a.theta_mask = theta_mask; a.do_allloci = allloci ? 1u : 0u; a.dbg = s->env_dbg;

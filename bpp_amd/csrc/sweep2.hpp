@@ -82,6 +82,7 @@ struct Args
   // a sequence flag + values each), this rank's own, the sequence number before this launch's first exchange
   unsigned char * const * peers; unsigned char * mail; int32_t rank, world; unsigned long long slot_bytes, seq0, spin_limit; int * p2p_err;
   const Species * sp;                    // (device memory: by value it would sit in ~50 SGPRs for the whole launch)
+  unsigned long long * pj;               // proposals / accepted by move type since the host last cleared them (bpa_sampler_adapt_finetune): gage, gspr, tau, mix, theta window
 };
 
 constexpr int XN = 128;                  // words per accumulator set: 8 shards x (15 sums + the arrival counter) = 8 x 128 bytes
@@ -901,6 +902,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       const int nth = 2*__popc(tm);
       const double qnan = __longlong_as_double(0x7ff8000000000000ll);
       uint32_t cnt_prop = 0, cnt_acc = 0, cnt_gprop = 0, cnt_gacc = 0, ndec = 0;
+      uint32_t pj_tau = 0, pj_tau_acc = 0, pj_mix = 0, pj_mix_acc = 0;
       const bool declog = (A.dbg & 256u) && b == 0;
       int q = -1; bool mix = false;
       double tq_old = 0, tq_new = 0, mix_c = 1, mix_lnc = 0, lnprior = 0;
@@ -997,6 +999,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
           }
           if (accept && wg.xcoarse_ && b == 0 && lane == 0) (void)atomicAdd(A.err + 2, 1);      // (a run worth the name never has one)
           ++cnt_prop; cnt_acc += accept ? 1u : 0u;
+          if (mix) { ++pj_mix; pj_mix_acc += accept ? 1u : 0u; } else { ++pj_tau; pj_tau_acc += accept ? 1u : 0u; }
           if (declog && lane == 0 && ndec < 1000u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = -1.0; r[3] = accept ? 1 : 0; }
           ++ndec;
           // the consequences for the species tree: tau(s), the re-drawn thetas, the sums and the fits the next steps start from
@@ -1038,6 +1041,9 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         {
           *A.grng = g.r;
           A.counters[0] += cnt_prop; A.counters[1] += cnt_acc; A.counters[2] += cnt_gprop; A.counters[3] += cnt_gacc;
+          // (by move type: the theta window's = the THETA step's proposals that were not Gibbs draws)
+          A.pj[4] += pj_tau; A.pj[5] += pj_tau_acc; A.pj[6] += pj_mix; A.pj[7] += pj_mix_acc;
+          A.pj[8] += (cnt_prop - pj_tau - pj_mix) - cnt_gprop; A.pj[9] += (cnt_acc - pj_tau_acc - pj_mix_acc) - cnt_gacc;
         }
         if (!aborted && lane < (uint32_t)(3*MAXPOP)) A.taus[lane] = wg.tau[lane];
         if (prof_on) for (int i = 0; i < 24; ++i) A.prof[(i < 16 ? 0 : (int)A.nwg) + i] = (double)wg.prof[i];
@@ -1289,6 +1295,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   const double qnan = __longlong_as_double(0x7ff8000000000000ll);
   uint32_t cnt_prop = 0, cnt_acc = 0;              // all-loci proposals / accepted (the same in every workgroup)
   uint32_t cnt_gprop = 0, cnt_gacc = 0;            // of those: Gibbs draws of a theta
+  uint32_t pj_tau = 0, pj_tau_acc = 0, pj_mix = 0, pj_mix_acc = 0, pj_gage = 0, pj_gage_acc = 0;
   const bool declog = (A.dbg & 256u) && b == 0;    // every all-loci decision of this launch: A.declog[4 k] = what, lnacc, u, accepted
   uint32_t ndec = 0;
   const bool wgprof = (A.dbg & 32u) && tid == 0;
@@ -1334,7 +1341,9 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         w_nupd += (uint32_t)nops; w_nbr += (uint32_t)__popc(pr.brm);
         const double lnacc = (lp_new - logpr_cur) + (lnl - lnl_cur) + pr.hast;
         ++nprop_done;
-        if (rng.accept(lnacc)) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; commit_density(pr.chain); }
+        const bool gage_step = step < A.nsteps_gage;
+        pj_gage += gage_step ? 1u : 0u;
+        if (rng.accept(lnacc)) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; pj_gage_acc += gage_step ? 1u : 0u; commit_density(pr.chain); }
         else { T = U; S.time[li] = tsave; }
         wsync();
         SMP2_TICK(2);
@@ -1481,6 +1490,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       {
         if (accept && wg.xcoarse_ && b == 0 && tid == 0) (void)atomicAdd(A.err + 2, 1);      // (a run worth the name never has one)
         ++cnt_prop; cnt_acc += accept ? 1u : 0u;
+        if (mix) { ++pj_mix; pj_mix_acc += accept ? 1u : 0u; } else { ++pj_tau; pj_tau_acc += accept ? 1u : 0u; }
         if (declog && tid == 0 && ndec < 1000u) { double * r = A.declog + 4*ndec; r[0] = mix ? 300 : 200 + q; r[1] = lnacc; r[2] = uacc; r[3] = accept ? 1 : 0; }
         ++ndec;
         __syncthreads();                                      // everyone has read the old taus
@@ -1658,6 +1668,9 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       tr.lnl = lnl_cur; tr.logpr = logpr_cur; tr.rng = rng.r; tr.root = T.root;
       tr.proposals += nprop_done; tr.accepted += nacc; tr.sw_nupd += w_nupd; tr.sw_nbr += w_nbr;
       tr.al_nupd += a_nupd; tr.al_nbr += a_nbr; tr.al_neval += a_neval;
+      // by move type, over all loci (what the burn-in's step-length rule reads: bpa_sampler_adapt_finetune)
+      (void)atomicAdd(A.pj + 0, (unsigned long long)pj_gage); (void)atomicAdd(A.pj + 1, (unsigned long long)pj_gage_acc);
+      (void)atomicAdd(A.pj + 2, (unsigned long long)(nprop_done - pj_gage)); (void)atomicAdd(A.pj + 3, (unsigned long long)(nacc - pj_gage_acc));
     }
     if (li < npop) { A.pop_nc[(size_t)li*A.ntasks + task] = (int8_t)mync; A.pop_t2h[(size_t)li*A.ntasks + task] = t2h_cur; }
     for (uint32_t i = (uint32_t)li; i < (uint32_t)(4*(2*tips - 2)); i += G) g_pmat[i] = (&S.ab[0][0])[i];
@@ -1675,6 +1688,11 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
   {
     *A.grng = grng.r;
     A.counters[0] += cnt_prop; A.counters[1] += cnt_acc; A.counters[2] += cnt_gprop; A.counters[3] += cnt_gacc;
+    if constexpr (!PROG)
+    {
+      A.pj[4] += pj_tau; A.pj[5] += pj_tau_acc; A.pj[6] += pj_mix; A.pj[7] += pj_mix_acc;
+      A.pj[8] += (cnt_prop - pj_tau - pj_mix) - cnt_gprop; A.pj[9] += (cnt_acc - pj_tau_acc - pj_mix_acc) - cnt_gacc;
+    }
   }
   if (b == 0 && tid < (uint32_t)(3*MAXPOP)) A.taus[tid] = wg.tau[tid];
   if (prof_on) for (int i = 0; i < 24; ++i) A.prof[(i < 16 ? 0 : (int)A.nwg) + i] = (double)wg.prof[i];

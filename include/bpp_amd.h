@@ -306,6 +306,16 @@ int  bpa_sampler_set_species_tree(bpa_sampler_t *, int species, const int * pare
                                   const double * theta);
 int  bpa_sampler_set_tip_species(bpa_sampler_t *, unsigned i, const int * species);   /* default: tip k = species k */
 void bpa_sampler_set_finetune(bpa_sampler_t *, double gage, double gspr, double tau, double mix);
+/* The burn-in's step-length rule (reset_finetune_onestep, method.c:1122-1136: step *= tan(pi/2 pjump) / tan(pi/2 0.3), / 100
+   below 0.001, x 100 above 0.999, at most 99).  bpa_sampler_adapt_finetune applies it to the five step lengths — gene-node
+   age, prune/regraft, tau, mixing, theta window, in that order — from the acceptance proportions of each move type since
+   the last call (counted by the persistent iteration kernel; pjump[m] < 0: never proposed, step length kept) and clears the
+   counters, as reset_finetune + pjump_reset do (method.c:1508-1516, 5364-5377); pjump / finetune (5 each) may be null.
+   bpa_sampler_burnin runs `iterations` iterations the program's way: the rule after every quarter of them (when a quarter
+   is at least 100 iterations) and once more at the end; finetune (5, may be null) receives the step lengths it ends with. */
+double bpa_finetune_onestep(double pjump, double finetune);
+int  bpa_sampler_adapt_finetune(bpa_sampler_t *, double * pjump, double * finetune);
+int  bpa_sampler_burnin(bpa_sampler_t *, unsigned iterations, double * finetune);
 /* which generator and window the moves draw from (a00_set_proposal_kernel of bpp_amd_host.h; before initialize):
    BPA_KERNEL_UNIFORM (default) our 64-bit streams, window = finetune x (u - 1/2), the acceptance number always drawn;
    BPA_KERNEL_BPP     the reference's own — legacy_rndu (random.c:104-122) and the Bactrian-Laplace variate of
