@@ -78,6 +78,11 @@ static int run_all(bpa_composite * c, bpa_engine * e, std::function<int(bpa_samp
 {
   const int n = (int)c->parts.size();
   c->job = std::move(job); c->failed = false;
+  // The engine's tables are uploaded synchronously on whatever stream a part's fiber has made current (flush / engine_pack
+  // wait for e->stream only): when an upload is due, every part's stream is drained first, so that no kernel of ANOTHER part
+  // still reads the old tables while they are replaced
+  if (e->table_dirty || e->pack_dirty)
+    for (int i = 0; i < n; ++i) if (c->stream[i] && hipStreamSynchronize(c->stream[i]) != hipSuccess) { c->failed = true; }
   for (int i = 0; i < n; ++i)
   {
     c->state[i] = 0; c->result[i] = 0;
@@ -194,8 +199,13 @@ static bpa_sampler * comp_create(bpa_engine_t * e, bpa_locus_t * const * loci, u
   const bool one_stream = getenv("BPA_COMP_ONE_STREAM") != nullptr;
   if (hipEventCreateWithFlags(&c->ev_sum, hipEventDisableTiming) != hipSuccess) c->ev_sum = nullptr;
   for (size_t i = 1; i < n && !one_stream; ++i)
-    if (hipStreamCreateWithFlags(&c->stream[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_part[i], hipEventDisableTiming) != hipSuccess)
-    { (void)hipGetLastError(); c->stream[i] = e->stream; }
+  {
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); continue; }        // (the part then runs on the engine's stream)
+    if (hipEventCreateWithFlags(&c->ev_part[i], hipEventDisableTiming) != hipSuccess)
+    { (void)hipGetLastError(); (void)hipStreamDestroy(st); c->ev_part[i] = nullptr; continue; }                          // (no stream without its event: nothing leaks)
+    c->stream[i] = st;
+  }
   for (size_t i = 1; i < n; ++i) if (!c->ev_part[i]) (void)hipEventCreateWithFlags(&c->ev_part[i], hipEventDisableTiming);
   for (size_t i = 0; i < n; ++i)
   {

@@ -49,22 +49,35 @@ def pytest_collection_modifyitems(session, config, items):
         items[:] = [it for it in items if it not in last] + last
 
 
-def _start_program_runs(session):
+def _start_program_runs(session, cpu_only=True):
+    """cpu_only (the pass started at collection, overlapping the rest of the session): only the runs of the unmodified CPU
+    program are made; the bpp_hip runs — GPU processes, which must not share the device with the persistent-kernel tests
+    (a launch that waits for a co-tenant's workgroups gives up and is run again: correct, but it moves the rate tests) —
+    wait for the second pass, which tests/test_gpu_bpp_hip.py starts when its turn comes (last)."""
     import threading
     from concurrent.futures import ThreadPoolExecutor
+    import bpphip
     items = [it for it in session.items if it.nodeid.split("::")[0].endswith("test_gpu_bpp_hip.py")]
-    if not items or _program_runs or any(it.get_closest_marker("skipif") and it.get_closest_marker("skipif").args[0] for it in items):
+    if not items or any(it.get_closest_marker("skipif") and it.get_closest_marker("skipif").args[0] for it in items):
+        return
+    if cpu_only and _program_runs:
         return
 
     def dry(it):
         try:
             it.obj(**(it.callspec.params if hasattr(it, "callspec") else {}))
-        except BaseException:      # noqa: BLE001  (the test proper reports it)
-            pass
+        except (AssertionError, bpphip.DeferredHip):
+            pass                   # (the test proper reports a failed assertion; a deferred run is the second pass's)
+        except BaseException as ex:      # noqa: BLE001  (the test proper will meet it again: say so now)
+            print(f"[conftest] dry run of {it.nodeid}: {type(ex).__name__}: {ex}", file=sys.stderr)
 
     def run():
-        with ThreadPoolExecutor(max_workers=8 if len(session.items) > len(items) else 12) as ex:
-            list(ex.map(dry, items))
+        bpphip.CPU_ONLY = cpu_only
+        try:
+            with ThreadPoolExecutor(max_workers=8 if len(session.items) > len(items) else 12) as ex:
+                list(ex.map(dry, items))
+        finally:
+            bpphip.CPU_ONLY = False
     t = threading.Thread(target=run, daemon=True)
     _program_runs["thread"] = t
     t.start()

@@ -28,9 +28,11 @@ def all_program_runs_side_by_side(request):
     collection is done and runs this module last, so the runs overlap the rest of the session; here they are waited for."""
     import conftest
     t = conftest._program_runs.get("thread")
-    if t is None:
-        conftest._start_program_runs(request.session)
-        t = conftest._program_runs.get("thread")
+    if t is not None:
+        t.join()                  # the early pass: the CPU program's runs, made while the rest of the session ran
+    # ... and now, with no persistent-kernel test left to disturb, the bpp_hip runs side by side
+    conftest._start_program_runs(request.session, cpu_only=False)
+    t = conftest._program_runs.get("thread")
     if t is not None:
         t.join()
     yield
