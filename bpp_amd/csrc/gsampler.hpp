@@ -90,8 +90,24 @@ struct GArgs
   // (task 0xffffffff: a hole) — one task per locus
   OpDev * ops20; uint32_t * op_rng20, * root20, * mat_task20, * mat_pm20;
   uint32_t fmt20, maxops20;
+  double tau_w;                           // bpp: the TAU window itself (the host's Bactrian-Laplace variate; tau_u - 1/2 would round)
+  uint32_t bpp, prog;                     // the reference's generator / windows / acceptance rule (bpa_sampler_set_proposal_kernel); the program's THETA / TAU / MIX, decided on the host
+  double * t2h3;                          // [T][3] prog, TAU q: the T2h of q and of its two children after the move
   Species sp;
 };
+
+// the one-lane kernel's draws under either proposal kernel (smp2::Stream, sweep2.hpp), chosen at run time: GArgs::bpp
+__device__ __forceinline__ double g_window(a00_rng_t & r, const uint32_t bpp)
+{
+  if (bpp) { smp2::Stream<true> st{r}; const double w = st.window(); r = st.r; return w; }
+  return rndu(&r) - 0.5;
+}
+__device__ __forceinline__ bool g_accept(a00_rng_t & r, const uint32_t bpp, const double lnacc)
+{
+  if (bpp) { smp2::Stream<true> st{r}; const bool a = st.accept(lnacc); r = st.r; return a; }
+  const double u = rndu(&r);
+  return lnacc >= 0 || u < exp(lnacc);
+}
 
 // the MSC density term of population p from the lane's own state (density_term of sampler.hpp, ages in S.time)
 __device__ __forceinline__ double gdensity_term(const GState & S, const Species & sp, const double * tau, int p, double & T2h_out)
@@ -222,9 +238,8 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
       {
         const double lnl = A.lnl_new[i], lp_new = A.logpr_new[i];
         const double lnacc = (lp_new - logpr_cur) + (lnl - lnl_cur) + A.hast[i];
-        const double u = rndu(&T.rng);
         ++nprop;
-        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; }
+        if (g_accept(T.rng, A.bpp, lnacc)) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; }
         else back = true;
       }
     }
@@ -239,9 +254,8 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
       {
         const double lnl = A.lnl_new[i];
         const double lnacc = (lnl - lnl_cur) + A.hast[i];
-        const double u = rndu(&T.rng);
         ++nprop;
-        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = lnl; ++nacc; }
+        if (g_accept(T.rng, A.bpp, lnacc)) { lnl_cur = lnl; ++nacc; }
         else
         {
           // the old values come back, in the sampler's copy and in the locus's parameter block
@@ -333,7 +347,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
         if (MODE == 8)
         {
           const double a_old = m[10], la_old = log(a_old);
-          const double la_new = reflect(la_old + A.ft_alpha*(rndu(&T.rng) - 0.5), -99.0, 99.0);
+          const double la_new = reflect(la_old + A.ft_alpha*g_window(T.rng, A.bpp), -99.0, 99.0);
           const double a_new = exp(la_new);
           A.sm_old[2*i] = a_old;
           m[10] = a_new;
@@ -345,7 +359,7 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
           const int j = (int)A.k, ref = MODE == 6 ? 3 : 1;
           const double sum = v[j] + v[ref], lo = log(1e-5), hi = log(sum);
           const double l_old = log(v[j]);
-          const double l_new = reflect(l_old + (MODE == 6 ? A.ft_freqs : A.ft_qrates)*(rndu(&T.rng) - 0.5), lo, hi);
+          const double l_new = reflect(l_old + (MODE == 6 ? A.ft_freqs : A.ft_qrates)*g_window(T.rng, A.bpp), lo, hi);
           A.sm_old[2*i] = v[j]; A.sm_old[2*i + 1] = v[ref];
           v[j] = exp(l_new); v[ref] = sum - v[j];
           hast = l_new - l_old;
@@ -511,6 +525,87 @@ __global__ void __launch_bounds__(1024) gsum_decide_kernel(const double * __rest
   if (threadIdx.x) return;
   if (sum_out) sum_out[0] = sh[0];
   if (decide_on) smp::decide(sh[0], u, epoch, flag, counters, taus, sp, tau_q, -1, win_u, mix_c, mix_lnc);
+}
+
+// ---- the program's THETA / TAU / MIX for the generic samplers: the loci's sums on the device, the decision on the host ----
+// (bpa_sampler_set_program_moves on a generic sampler; theta_step_gibbs / tau_step / mix_step of a00_driver.c are the model.)
+// The decisions are long scalar chains — a 35-step bisection per theta fit, gamma variates, a dozen logarithms — over a few
+// numbers; the persistent kernel gives them a control wave, here they run on the host between two launches: 8 to 72 bytes
+// come back per all-loci step, one synchronisation each, 9 per iteration of config 3 against its ~230 launches.
+// out[0] = sum over the loci of (lnL' - lnL, where a likelihood was evaluated) + delta — gsum_decide_kernel's sum, same order;
+// TAU: out[1..3] = the T2h of q and its two children after the move, summed as 2^-40 fixed point (a00_driver.c: llrint(x 2^40)),
+// out[4] = 1 when a term was unusable (NaN or >= 256)
+__global__ void __launch_bounds__(1024) gprog_sums_kernel(const double * __restrict__ lnl_cur, const double * __restrict__ lnl_new,
+                                                          const double * __restrict__ delta, const uint8_t * __restrict__ active,
+                                                          const double * __restrict__ t2h3, uint32_t T, int with_t2h, double * out)
+{
+  __shared__ double sh[1024];
+  __shared__ long long shl[3][1024];
+  __shared__ int shb[1024];
+  double acc = 0; long long c[3] = {0, 0, 0}; int bad = 0;
+  for (uint32_t i = threadIdx.x; i < T; i += 1024)
+  {
+    acc += (active[i] ? lnl_new[i] - lnl_cur[i] : 0.0) + delta[i];
+    if (with_t2h)
+      for (int j = 0; j < 3; ++j)
+      {
+        const double x = t2h3[(size_t)3*i + j];
+        if (!(fabs(x) < 256.0)) bad = 1; else c[j] += llrint(x*1099511627776.0);
+      }
+  }
+  sh[threadIdx.x] = acc; shb[threadIdx.x] = bad;
+  for (int j = 0; j < 3; ++j) shl[j][threadIdx.x] = c[j];
+  __syncthreads();
+  for (uint32_t w = 512; w > 0; w >>= 1)
+  {
+    if (threadIdx.x < w)
+    {
+      sh[threadIdx.x] += sh[threadIdx.x + w]; shb[threadIdx.x] |= shb[threadIdx.x + w];
+      for (int j = 0; j < 3; ++j) shl[j][threadIdx.x] += shl[j][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x) return;
+  out[0] = sh[0];
+  for (int j = 0; j < 3; ++j) reinterpret_cast<long long *>(out)[1 + j] = shl[j][0];
+  reinterpret_cast<long long *>(out)[4] = shb[0];
+}
+
+// THETA: per population the coalescences and the T2h over all loci (theta_sums of a00_driver.c: integers, no order)
+__global__ void __launch_bounds__(1024) gprog_theta_sums_kernel(const int8_t * __restrict__ pop_nc, const double * __restrict__ pop_t2h,
+                                                                uint32_t T, uint32_t onmask, long long * out)
+{
+  __shared__ long long shk[1024], sht[1024];
+  __shared__ int shb[1024];
+  const int p = (int)blockIdx.x;
+  long long k = 0, t = 0; int bad = 0;
+  if ((onmask >> p) & 1u)
+    for (uint32_t i = threadIdx.x; i < T; i += 1024)
+    {
+      const double x = pop_t2h[(size_t)p*T + i];
+      if (!(fabs(x) < 256.0)) bad = 1; else { k += pop_nc[(size_t)p*T + i]; t += llrint(x*1099511627776.0); }
+    }
+  shk[threadIdx.x] = k; sht[threadIdx.x] = t; shb[threadIdx.x] = bad;
+  __syncthreads();
+  for (uint32_t w = 512; w > 0; w >>= 1)
+  {
+    if (threadIdx.x < w) { shk[threadIdx.x] += shk[threadIdx.x + w]; sht[threadIdx.x] += sht[threadIdx.x + w]; shb[threadIdx.x] |= shb[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[3*p] = shk[0]; out[3*p + 1] = sht[0]; out[3*p + 2] = shb[0]; }
+}
+
+// the host's decision brought to the device: the rejection flag, the species tree as it now is, the counters
+struct GApply { uint32_t accept, set_tau_q, scale_taus, nprop, nacc, ngprop, ngacc, theta_mask; double tau_new, mix_c; double theta[MAXPOP]; };
+__global__ void gprog_apply_kernel(const GApply a, uint32_t epoch, uint32_t * flag, uint32_t * counters, double * taus, int npop)
+{
+  if (threadIdx.x || blockIdx.x) return;
+  counters[0] += a.nprop; counters[1] += a.nacc; counters[2] += a.ngprop; counters[3] += a.ngacc;
+  if (!a.accept) { *flag = epoch; return; }
+  if (a.set_tau_q != 0xffffffffu) taus[a.set_tau_q] = a.tau_new;
+  if (a.scale_taus) for (int p = 0; p < npop; ++p) taus[p] *= a.mix_c;
+  for (int p = 0; p < npop; ++p)
+    if ((a.theta_mask >> p) & 1u) { taus[MAXPOP + p] = a.theta[p]; taus[2*MAXPOP + p] = log(2.0/(1.0*a.theta[p])); }
 }
 
 } // namespace gsm

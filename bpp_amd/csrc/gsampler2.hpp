@@ -38,7 +38,7 @@ template <int NT> struct Step2LDS
 
 // one step of the loci of ONE wave (lane = threadIdx.x & 63; group `slot` of the wave holds locus i when valid).  WAVE_ONLY:
 // the caller's other waves do not take part — the hand-overs through LDS are the wave's own (chain kernel)
-template <uint32_t MODE, int NT, bool WAVE_ONLY>
+template <uint32_t MODE, int NT, bool WAVE_ONLY, bool BPP = false>
 __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl & C, Step2LDS<NT> & SH, const uint32_t lane, const uint32_t i, const bool valid)
 {
   static_assert(MODE <= 3, "GAGE, GSPR, TAU, MIX");
@@ -81,7 +81,7 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
   const int g_clv = g.clv[li], g_pm = g.pmat[li], u_clv = ud.clv[li], u_pm = ud.pmat[li];
   const double g_time = g.time[li], u_time = ud.time[li];
   const int g_root = g.root, g_tips = g.tips, u_root = ud.root;
-  smp2::Stream<false> rng{g.rng};
+  smp2::Stream<BPP> rng{g.rng};                                // (BPP: the reference's generator, Bactrian-Laplace windows, its acceptance rule)
   double lnl_cur = g.lnl, logpr_cur = g.logpr;
   uint32_t nprop = g.proposals, nacc = g.accepted, w_nupd = g.work_nupd, w_nbr = g.work_nbr, w_nev = g.work_neval;
   const gsm::GLocus L = A.loc[ic];
@@ -123,9 +123,8 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
       if (d_active)
       {
         const double lnacc = (d_logpr - logpr_cur) + (d_lnl - lnl_cur) + d_hast;
-        const double u = rndu(&rng.r);
         ++nprop;
-        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = d_lnl; logpr_cur = d_logpr; ++nacc; }
+        if (rng.accept(lnacc)) { lnl_cur = d_lnl; logpr_cur = d_logpr; ++nacc; }
         else back = true;
       }
     }
@@ -139,9 +138,8 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
       if (d_active)
       {
         const double lnacc = (d_lnl - lnl_cur) + d_hast;
-        const double u = rndu(&rng.r);
         ++nprop;
-        if (lnacc >= 0 || u < exp(lnacc)) { lnl_cur = d_lnl; ++nacc; }
+        if (rng.accept(lnacc)) { lnl_cur = d_lnl; ++nacc; }
         else
         {
           back = true;
@@ -197,6 +195,7 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
     mync = __popc(mynodes);
     mynin = gl_i - below;
   };
+  double my_t2h = 0;                                             // the T2h of the lane's population, as density_term last left it
   auto density_term = [&]() -> double
   {
     uint32_t nodes = mynodes;
@@ -220,6 +219,7 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
     double c = 0;
     if (ncoal) c += ncoal*pl.l2t;
     if (T2h) c -= T2h/(pl.theta*1.0);
+    my_t2h = T2h;
     return c;
   };
   // the current tree's terms (the tree arrives with their sum only); THETA moved the thetas since that sum was stored: again
@@ -262,8 +262,8 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
   if (MODE <= 1)
   {
     if (valid)
-      ok = MODE == 0 ? smp2::propose_gage<NT, false>(T, rng, S.time, (int)C.k, pl, s_anc, s_tau, SP.ft_gage, li, gbase, pr)
-                     : smp2::propose_gspr<NT, false>(T, rng, S.time, (int)C.k, pl, gl_i, s_anc, s_tau, s_lograt, SP.ft_gspr, li, gbase, pr);
+      ok = MODE == 0 ? smp2::propose_gage<NT, BPP>(T, rng, S.time, (int)C.k, pl, s_anc, s_tau, SP.ft_gage, li, gbase, pr)
+                     : smp2::propose_gspr<NT, BPP>(T, rng, S.time, (int)C.k, pl, gl_i, s_anc, s_tau, s_lograt, SP.ft_gspr, li, gbase, pr);
   }
   else if (valid)
   {
@@ -274,7 +274,7 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
       // TAU q (tau_step of a00_driver.c): the gene nodes of q and its children between the bounds ride the rubber band
       const int q = (int)C.k, pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
       const double tq_old = s_tau[q], tq_lo = fmax(s_tau[cl], s_tau[cr]), tq_hi = pq >= 0 ? s_tau[pq] : 999.0;
-      const double tnew = smp::reflect(tq_old + SP.ft_tau*(A.tau_u - 0.5), tq_lo, tq_hi);
+      const double tnew = smp::reflect(tq_old + SP.ft_tau*(A.bpp ? A.tau_w : A.tau_u - 0.5), tq_lo, tq_hi);
       const double minf = (tnew - tq_lo)/(tq_old - tq_lo), maxf = (tnew - tq_hi)/(tq_old - tq_hi);
       lminf = log(minf); lmaxf = log(maxf);
       if (li == q) pl.tau = tnew;
@@ -341,13 +341,23 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
   }
   else if (valid) { T = U; S.time[li] = tsave; }
   smp2::wsync();
+  if (MODE == 2 && valid && A.prog)
+  {
+    // the program's rubber band re-draws the thetas of q and its two children from (k, sum of the T2h AFTER the move)
+    const int q = (int)C.k, cl = SP.left[q], cr = SP.right[q];
+    const int j = li == q ? 0 : li == cl ? 1 : li == cr ? 2 : -1;
+    if (j >= 0) A.t2h3[(size_t)3*i + j] = lp_new == lp_new ? my_t2h : __longlong_as_double(0x7ff8000000000000ll);
+  }
   if (valid && li == 0)
   {
     if (MODE <= 1) { if (ok) { A.logpr_new[i] = lp_new; A.hast[i] = pr.hast; } }
     else
     {
       A.logpr_new[i] = lp_new;
-      A.delta[i] = MODE == 2 ? ((lp_new - logpr_cur) + below*lminf) + above*lmaxf : (lp_new - logpr_cur) + (double)(tips - 1)*A.mix_lnc;       // p_delta of the host driver
+      // p_delta of the host driver; the program's moves (A.prog): the densities' change over all loci follows from the sums of
+      // k and T2h with the re-drawn thetas, on the host (tau_step / mix_step of a00_driver.c) — the loci bring their Jacobian only
+      if (A.prog) A.delta[i] = MODE == 2 ? below*lminf + above*lmaxf : (double)(tips - 1)*A.mix_lnc;
+      else A.delta[i] = MODE == 2 ? ((lp_new - logpr_cur) + below*lminf) + above*lmaxf : (lp_new - logpr_cur) + (double)(tips - 1)*A.mix_lnc;
       A.lnl_cur[i] = lnl_cur;
     }
     if (ok) { w_nupd += (uint32_t)nops; w_nbr += (uint32_t)__popc(pr.brm); ++w_nev; }
@@ -452,14 +462,14 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
 #endif
 }
 
-template <uint32_t MODE, int NT>
+template <uint32_t MODE, int NT, bool BPP = false>
 __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
 {
   __shared__ Step2LDS<NT> SH;
   constexpr uint32_t LPW = (uint32_t)smp2::Cfg<NT>::LPW, G = (uint32_t)smp2::Cfg<NT>::G;
   const uint32_t i = A.i0 + blockIdx.x*LPW + threadIdx.x/G;
   const StepCtl C{MODE >= 2 ? A.tau_q : A.k, A.pend, A.refresh_logpr, A.fmt20};
-  gstep2_body<MODE, NT, false>(A, C, SH, threadIdx.x, i, i < A.iend);
+  gstep2_body<MODE, NT, false, BPP>(A, C, SH, threadIdx.x, i, i < A.iend);
 }
 
 

@@ -221,12 +221,15 @@ static int gs_upload(bpa_sampler * s)
     for (unsigned i = 0; i < T/2; ++i) nt += (s->loci[i]->sites + gs_tile20() - 1u)/gs_tile20();
     s->g_tsplit = nt;
   }
-  s->uploaded = true;
+  s->uploaded = true; s->gp_mirror = false;
   return 1;
 }
 
 // one gstep_kernel launch: settle what is pending, then propose `mode`
-static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u = 0, double mix_c = 1.0, double mix_lnc = 0)
+// the program's THETA / TAU / MIX, decided on the host (BPP's proposal kernel + bpa_sampler_set_program_moves + a theta prior + a theta to move)
+static bool gs_prog(const bpa_sampler * s) { return s->kernel_bpp && s->sp.program_moves && s->sp.theta_alpha > 0 && s->sp.npop > s->sp.S; }
+
+static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u = 0, double mix_c = 1.0, double mix_lnc = 0, double tau_w = 0)
 {
   bpa_engine * e = s->eng;
   if (s->g_pack_epoch != e->pack_epoch) return fail("bpa_sampler: the engine's loci changed since the sampler was set up");
@@ -245,22 +248,25 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   a.fmt20 = s->g_s20 ? 1u : 0u; a.maxops20 = s->g_maxops;
   a.ops20 = s->g_ops20.p; a.op_rng20 = s->g_oprng.p; a.root20 = s->g_root20.p; a.mat_task20 = s->g_mtask.p; a.mat_pm20 = s->g_mpm.p;
   a.ft_freqs = s->g_ft[0]; a.ft_qrates = s->g_ft[1]; a.ft_alpha = s->g_ft[2]; a.alpha_a = s->g_alpha_a; a.alpha_b = s->g_alpha_b;
+  a.bpp = s->kernel_bpp ? 1u : 0u; a.prog = gs_prog(s) ? 1u : 0u; a.t2h3 = s->g_t2h3.p; a.tau_w = tau_w;
   // a frequency / exchangeability step — proposed now, or rolled back now for the loci that rejected it — leaves
   // parameter blocks whose eigensystems are stale: refreshed before the next evaluation (gs_eval)
   if (mode == 6 || mode == 7 || (s->g_pend == 4 && (s->g_pend_mode == 6 || s->g_pend_mode == 7))) s->g_eigen_dirty = true;
   // diagnostics (BPA_GS_DIFF=1): a GAGE / GSPR step by both kernels from the same state, whatever differs is reported;
   // the run goes on with the one-lane kernel's result
+#define GS2_CASES(NT_, BPP_, GRID_, ST_) switch (a.mode) { \
+      case 0: hipLaunchKernelGGL((gsm2::gstep2_kernel<0, NT_, BPP_>), GRID_, dim3(64), 0, ST_, a); break; case 1: hipLaunchKernelGGL((gsm2::gstep2_kernel<1, NT_, BPP_>), GRID_, dim3(64), 0, ST_, a); break; \
+      case 2: hipLaunchKernelGGL((gsm2::gstep2_kernel<2, NT_, BPP_>), GRID_, dim3(64), 0, ST_, a); break; default: hipLaunchKernelGGL((gsm2::gstep2_kernel<3, NT_, BPP_>), GRID_, dim3(64), 0, ST_, a); break; }
 #define GS2_LAUNCH(GRID_, ST_) do { \
-    if (s->maxtips <= 8) switch (a.mode) { case 0: hipLaunchKernelGGL((gsm2::gstep2_kernel<0, 8>), GRID_, dim3(64), 0, ST_, a); break; case 1: hipLaunchKernelGGL((gsm2::gstep2_kernel<1, 8>), GRID_, dim3(64), 0, ST_, a); break; \
-                                           case 2: hipLaunchKernelGGL((gsm2::gstep2_kernel<2, 8>), GRID_, dim3(64), 0, ST_, a); break; default: hipLaunchKernelGGL((gsm2::gstep2_kernel<3, 8>), GRID_, dim3(64), 0, ST_, a); break; } \
-    else switch (a.mode) { case 0: hipLaunchKernelGGL((gsm2::gstep2_kernel<0, 16>), GRID_, dim3(64), 0, ST_, a); break; case 1: hipLaunchKernelGGL((gsm2::gstep2_kernel<1, 16>), GRID_, dim3(64), 0, ST_, a); break; \
-                           case 2: hipLaunchKernelGGL((gsm2::gstep2_kernel<2, 16>), GRID_, dim3(64), 0, ST_, a); break; default: hipLaunchKernelGGL((gsm2::gstep2_kernel<3, 16>), GRID_, dim3(64), 0, ST_, a); break; } } while (0)
+    if (s->kernel_bpp) { if (s->maxtips <= 8) GS2_CASES(8, true, GRID_, ST_) else GS2_CASES(16, true, GRID_, ST_) } \
+    else               { if (s->maxtips <= 8) GS2_CASES(8, false, GRID_, ST_) else GS2_CASES(16, false, GRID_, ST_) } } while (0)
 #define GS1_LAUNCH(GRID_, ST_) do { \
     if (s->maxtips <= 8) switch (a.mode) { case 0: hipLaunchKernelGGL((gsm::gstep_kernel<0, 8>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; case 1: hipLaunchKernelGGL((gsm::gstep_kernel<1, 8>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; \
                                            case 2: hipLaunchKernelGGL((gsm::gstep_kernel<2, 8>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; default: hipLaunchKernelGGL((gsm::gstep_kernel<3, 8>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; } \
     else switch (a.mode) { case 0: hipLaunchKernelGGL((gsm::gstep_kernel<0, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; case 1: hipLaunchKernelGGL((gsm::gstep_kernel<1, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; \
                            case 2: hipLaunchKernelGGL((gsm::gstep_kernel<2, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; default: hipLaunchKernelGGL((gsm::gstep_kernel<3, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; } } while (0)
   static const bool gs_diff = getenv("BPA_GS_DIFF") != nullptr;
+  if (s->kernel_bpp && mode <= 3 && (gs_diff || getenv("BPA_GS_V1"))) return fail("bpa_sampler: BPP's proposal kernel has no one-lane form (BPA_GS_DIFF / BPA_GS_V1 are the uniform kernel's diagnostics)");
   if (gs_diff && mode <= 3 && !s->g_forked)
   {
     const unsigned n = s->nloci;
@@ -553,7 +559,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
 static bool gs_chain_wanted(const bpa_sampler * s)
 {
   const char * env = getenv("BPA_GS_CHAIN");
-  if (s->g_s20 || !s->eng->usedata || s->maxtips < 2) return false;
+  if (s->g_s20 || !s->eng->usedata || s->maxtips < 2 || s->kernel_bpp) return false;       // (the chain kernel draws from the uniform kernel only)
   if (env) return env[0] != '0';
   return s->g_alljc && s->nloci <= 1024u && s->g_npat <= 64u*s->nloci;
 }
@@ -622,11 +628,219 @@ static int gs_initialize(bpa_sampler * s)
   return gs_eval(s, 1);
 }
 
+// ======================= the program's THETA / TAU / MIX on a generic sampler: decisions on the host =======================
+// theta_step_gibbs / tau_step / mix_step of csrc/host/a00_driver.c, statement for statement on the host side (same global
+// stream, same order of draws: [first TAU's window] [THETA: choices + windows] [Gibbs variates] [acceptance numbers] [TAU:
+// variates, acceptance] [next window] ...), the loci's part — proposal, likelihood, the sums — on the device.
+static void gs_declog(const char * what, int k, double lnacc, int acc)
+{
+  static const bool on = getenv("A00_DECLOG") != nullptr;          // (the host driver's switch: the two logs line up)
+  if (on) fprintf(stderr, "[gsp] %s %d lnacc %.17g u -1 -> %d\n", what, k, lnacc, acc);
+}
+
+static int gs_prog_ready(bpa_sampler * s)
+{
+  bpa_engine * e = s->eng;
+  if (s->allreduce) return fail("bpa_sampler: the program's moves on a generic sampler run on one rank (the host decides from this GPU's sums)");
+  if (!s->g_t2h3.p && (!s->g_t2h3.reserve((size_t)3*s->nloci) || !s->g_progout.reserve(64))) return fail("out of device memory (program moves)");
+  if (!s->gp_mirror)
+  {
+    double t[3*smp::MAXPOP];
+    HIPCHK(hipMemcpyAsync(t, s->taus.p, sizeof t, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int p = 0; p < smp::MAXPOP; ++p) { s->gp_tau[p] = t[p]; s->gp_theta[p] = t[smp::MAXPOP + p]; }
+    s->gp_mirror = true; s->gp_ok = false;
+  }
+  return 1;
+}
+
+static int gs_prog_apply(bpa_sampler * s, const gsm::GApply & a, bool with_flag)
+{
+  bpa_engine * e = s->eng;
+  if (with_flag) s->epoch++;
+  hipLaunchKernelGGL(gsm::gprog_apply_kernel, dim3(1), dim3(1), 0, e->stream, a, s->epoch, s->flag.p, s->counters.p, s->taus.p, s->sp.npop);
+  HIPCHK(hipGetLastError());
+  s->launches++;
+  return 1;
+}
+
+static int gs_prog_theta(bpa_sampler * s)
+{
+  bpa_engine * e = s->eng;
+  const int npop = s->sp.npop;
+  unsigned int gz = (unsigned int)s->grng;
+  int slide[smp::MAXPOP]; double tnew[smp::MAXPOP], fa[smp::MAXPOP], fb[smp::MAXPOP];
+  uint32_t onmask = 0;
+  for (int p = 0; p < npop; ++p)
+  {
+    slide[p] = 0; tnew[p] = s->gp_theta[p];
+    if (!s->has_theta[p]) continue;
+    onmask |= 1u << p;
+    slide[p] = a00_bpp_rndu(&gz) < s->sp.theta_slide_prob;
+    if (slide[p]) tnew[p] = a00_reflect(s->gp_theta[p] + s->sp.ft_theta*a00_bpp_rnd_symmetrical(&gz), 0.0, 999.0);
+  }
+  long long h[3*smp::MAXPOP];
+  hipLaunchKernelGGL(gsm::gprog_theta_sums_kernel, dim3(npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p, s->nloci, onmask,
+                     reinterpret_cast<long long *>(s->g_progout.p));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h, s->g_progout.p, (size_t)3*npop*sizeof(long long), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  s->launches++;
+  bool bad = false;
+  for (int p = 0; p < npop; ++p) { bad = bad || h[3*p + 2] != 0; s->gp_k[p] = h[3*p]; s->gp_T[p] = (double)h[3*p + 1]*(1.0/1099511627776.0); }
+  s->gp_ok = !bad;
+  for (int p = 0; p < npop; ++p)
+  {
+    fa[p] = fb[p] = NAN;
+    if (!s->has_theta[p] || bad || slide[p]) continue;
+    a00_theta_conditional_invgamma(s->sp.theta_alpha, s->sp.theta_beta, (long)s->gp_k[p], s->gp_T[p], &fa[p], &fb[p]);
+    if (fa[p] == fa[p]) tnew[p] = 1/(a00_bpp_rndgamma(&gz, fa[p])/fb[p]);
+  }
+  gsm::GApply a{};
+  a.accept = 1u; a.set_tau_q = 0xffffffffu;
+  for (int p = 0; p < npop; ++p)
+  {
+    double lnacc = NAN; bool acc = false;
+    if (!s->has_theta[p]) continue;
+    a.nprop++;
+    const double T = s->gp_T[p];
+    if (!bad)
+    {
+      if (slide[p]) lnacc = a00_theta_lnacc((long)s->gp_k[p], T, s->gp_theta[p], tnew[p], s->sp.theta_alpha, s->sp.theta_beta);
+      else if (fa[p] == fa[p])
+        lnacc = a00_theta_lnacc((long)s->gp_k[p], T, s->gp_theta[p], tnew[p], s->sp.theta_alpha, s->sp.theta_beta)
+              + a00_theta_gibbs_hastings(fa[p], fb[p], s->gp_theta[p], tnew[p]);
+      acc = lnacc == lnacc && tnew[p] > 0 && (lnacc >= -1e-10 || a00_bpp_rndu(&gz) < std::exp(lnacc));
+    }
+    gs_declog(slide[p] ? "theta" : "thetag", p, lnacc, acc);
+    if (acc) { a.nacc++; s->gp_theta[p] = tnew[p]; a.theta_mask |= 1u << p; a.theta[p] = tnew[p]; if (!slide[p]) a.ngacc++; }
+    if (!slide[p]) a.ngprop++;
+  }
+  s->grng = (a00_rng_t)gz;
+  s->logpr_stale = true;
+  return gs_prog_apply(s, a, false);
+}
+
+static int gs_prog_tau(bpa_sampler * s, int q)
+{
+  bpa_engine * e = s->eng;
+  unsigned int gz = (unsigned int)s->grng;
+  const int cl = s->sp.left[q], cr = s->sp.right[q], pq = s->sp.parent[q];
+  const int aff[3] = { q, cl, cr };
+  const double old = s->gp_tau[q], lo = std::fmax(s->gp_tau[cl], s->gp_tau[cr]), hi = pq >= 0 ? s->gp_tau[pq] : 999.0;
+  const double w = s->gp_pre_valid ? s->gp_pre_window : a00_bpp_rnd_symmetrical(&gz);
+  s->gp_pre_valid = false;
+  const double tnew = a00_reflect(old + s->sp.ft_tau*w, lo, hi);
+  s->grng = (a00_rng_t)gz;
+  if (!gs_step(s, 2, (unsigned)q, 0.0, 1.0, 0.0, w) || !gs_eval(s, 1)) return 0;
+  double out[8];
+  hipLaunchKernelGGL(gsm::gprog_sums_kernel, dim3(1), dim3(1024), 0, e->stream, (const double *)s->g_lnlcur.p, (const double *)s->g_lnl.p, (const double *)s->g_delta.p,
+                     (const uint8_t *)s->g_active.p, (const double *)s->g_t2h3.p, s->nloci, 1, s->g_progout.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, s->g_progout.p, 5*sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  s->launches++;
+  double sum = out[0];
+  const long long * ol = reinterpret_cast<const long long *>(out);
+  const bool bad = ol[4] != 0;
+  if (pq < 0 && s->sp.tau_alpha > 0) sum += (s->sp.tau_alpha - 1 - (s->sp.S - 1) + 1)*std::log(tnew/old) - s->sp.tau_beta*(tnew - old);
+  gsm::GApply a{};
+  a.set_tau_q = (uint32_t)q; a.tau_new = tnew; a.nprop = 1;
+  double oldtheta[3], Cn[3] = {0, 0, 0};
+  for (int j = 0; j < 3; ++j)
+  {
+    const int p = aff[j]; const double to = s->gp_theta[p]; const long k = (long)s->gp_k[p];
+    oldtheta[j] = to;
+    if (!s->has_theta[p]) continue;
+    if (bad || !s->gp_ok) { sum = NAN; continue; }
+    double a1, b1, a1o, b1o;
+    Cn[j] = (double)ol[1 + j]*(1.0/1099511627776.0);
+    a00_theta_conditional_invgamma(s->sp.theta_alpha, s->sp.theta_beta, k, Cn[j], &a1, &b1);
+    a00_theta_conditional_invgamma(s->sp.theta_alpha, s->sp.theta_beta, k, s->gp_T[p], &a1o, &b1o);
+    if (!(a1 == a1 && a1o == a1o)) { sum = NAN; continue; }
+    const double g = a00_bpp_rndgamma(&gz, a1);
+    const double tn = 1.0/(g/b1);
+    sum += (a00_invgamma_logpdf(to, a1o, b1o) - a00_invgamma_logpdf(tn, a1, b1))
+         + ((s->sp.theta_alpha - 1)*std::log(tn/to) - s->sp.theta_beta*(tn - to))
+         + (k*(std::log(2.0/tn) - std::log(2.0/to)) - (Cn[j]/tn - s->gp_T[p]/to));
+    s->gp_theta[p] = tn;
+  }
+  const bool acc = sum >= -1e-10 || a00_bpp_rndu(&gz) < std::exp(sum);
+  gs_declog("tau", q, sum, acc);
+  s->grng = (a00_rng_t)gz;
+  if (acc)
+  {
+    a.accept = 1u; a.nacc = 1;
+    s->gp_tau[q] = tnew;
+    for (int j = 0; j < 3; ++j) if (s->has_theta[aff[j]]) { s->gp_T[aff[j]] = Cn[j]; a.theta_mask |= 1u << aff[j]; a.theta[aff[j]] = s->gp_theta[aff[j]]; }
+    s->logpr_stale = true;                         // (the accepted trees' densities were taken with the old thetas)
+  }
+  else for (int j = 0; j < 3; ++j) s->gp_theta[aff[j]] = oldtheta[j];
+  return gs_prog_apply(s, a, true);
+}
+
+static int gs_prog_mix(bpa_sampler * s)
+{
+  bpa_engine * e = s->eng;
+  unsigned int gz = (unsigned int)s->grng;
+  const int npop = s->sp.npop;
+  const double lnc = s->sp.ft_mix*a00_bpp_rnd_symmetrical(&gz), c = std::exp(lnc);
+  double oldtheta[smp::MAXPOP], lnacc_theta = 0;
+  for (int p = 0; p < npop; ++p) oldtheta[p] = s->gp_theta[p];
+  for (int p = 0; p < npop; ++p)
+  {
+    const double to = oldtheta[p]; const long k = (long)s->gp_k[p];
+    if (!s->has_theta[p]) continue;
+    if (!s->gp_ok) { lnacc_theta = NAN; continue; }
+    double a1, b1, a1o, b1o;
+    const double Ts = s->gp_T[p]*c;
+    a00_theta_conditional_invgamma(s->sp.theta_alpha, s->sp.theta_beta, k, Ts, &a1, &b1);
+    a00_theta_conditional_invgamma(s->sp.theta_alpha, s->sp.theta_beta, k, Ts/c, &a1o, &b1o);
+    if (!(a1 == a1 && a1o == a1o)) { lnacc_theta = NAN; continue; }
+    const double g = a00_bpp_rndgamma(&gz, a1);
+    const double tn = 1.0/(g/b1);
+    lnacc_theta += (a00_invgamma_logpdf(to, a1o, b1o) - a00_invgamma_logpdf(tn, a1, b1))
+                 + ((s->sp.theta_alpha - 1)*std::log(tn/to) - s->sp.theta_beta*(tn - to))
+                 + (k*(std::log(2.0/tn) - std::log(2.0/to)) - (Ts/tn - s->gp_T[p]/to));
+    s->gp_theta[p] = tn;
+  }
+  s->grng = (a00_rng_t)gz;
+  if (!gs_step(s, 3, 0, 0.0, c, lnc) || !gs_eval(s, 1)) return 0;
+  double out[8];
+  hipLaunchKernelGGL(gsm::gprog_sums_kernel, dim3(1), dim3(1024), 0, e->stream, (const double *)s->g_lnlcur.p, (const double *)s->g_lnl.p, (const double *)s->g_delta.p,
+                     (const uint8_t *)s->g_active.p, (const double *)s->g_t2h3.p, s->nloci, 0, s->g_progout.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, s->g_progout.p, 5*sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  s->launches++;
+  const int root = npop - 1;
+  double lnacc = out[0] + (double)(s->sp.S - 1)*lnc;
+  if (s->sp.tau_alpha > 0)
+    lnacc += (s->sp.tau_alpha - 1)*lnc - s->sp.tau_beta*(s->gp_tau[root]*c - s->gp_tau[root]) - (double)(s->sp.S - 2)*lnc;
+  lnacc += lnacc_theta;
+  const bool acc = lnacc >= -1e-10 || a00_bpp_rndu(&gz) < std::exp(lnacc);
+  gs_declog("mix", 0, lnacc, acc);
+  s->grng = (a00_rng_t)gz;
+  gsm::GApply a{};
+  a.set_tau_q = 0xffffffffu; a.nprop = 1;
+  if (acc)
+  {
+    a.accept = 1u; a.nacc = 1; a.scale_taus = 1u; a.mix_c = c;
+    for (int p = 0; p < npop; ++p) { s->gp_tau[p] *= c; s->gp_T[p] *= c; if (s->has_theta[p]) { a.theta_mask |= 1u << p; a.theta[p] = s->gp_theta[p]; } }
+    s->logpr_stale = true;
+  }
+  else for (int p = 0; p < npop; ++p) s->gp_theta[p] = oldtheta[p];
+  return gs_prog_apply(s, a, true);
+}
+
 static int gs_iterate(bpa_sampler * s, unsigned iterations)
 {
   bpa_engine * e = s->eng;
   if (!gs_subst_ready(s)) return 0;
   s->host_current = false;
+  const bool prog = gs_prog(s);
+  if (s->kernel_bpp && !prog) return fail("bpa_sampler: on a generic sampler BPP's proposal kernel comes with the program's moves (bpa_sampler_set_program_moves) and a theta prior");
+  if (prog && !gs_prog_ready(s)) return 0;
   for (unsigned it = 0; it < iterations; ++it)
   {
     // the per-locus proposals, "step j of every locus" (gage_step / gspr_step of a00_driver.c): each launch first settles
@@ -639,6 +853,18 @@ static int gs_iterate(bpa_sampler * s, unsigned iterations)
     }
     s->sweeps++;
     if (s->env_nomix) continue;
+    if (prog)
+    {
+      // (a00_iterate: the first TAU's window comes before the THETA step's numbers in the global stream)
+      bool any = false;
+      for (int p = 0; p < s->sp.npop; ++p) any = any || s->has_theta[p];
+      if (any) { unsigned int gz = (unsigned int)s->grng; s->gp_pre_window = a00_bpp_rnd_symmetrical(&gz); s->gp_pre_valid = true; s->grng = (a00_rng_t)gz; }
+      if (!gs_step(s, 4) || !gs_prog_theta(s)) return 0;
+      for (int q = s->sp.S; q < s->sp.npop; ++q) if (!gs_prog_tau(s, q)) return 0;
+      if (!gs_prog_mix(s)) return 0;
+    }
+    else
+    {
     if (s->sp.theta_alpha > 0)
     {
       // settle the last per-locus step and leave the statistics of every tree's density; then THETA as in the sweep path
@@ -673,6 +899,7 @@ static int gs_iterate(bpa_sampler * s, unsigned iterations)
     const double lnc = s->sp.ft_mix*(a00_rndu(&s->grng) - 0.5), c = std::exp(lnc);
     const double uacc = a00_rndu(&s->grng);
     if (!gs_step(s, 3, 0, 0.0, c, lnc) || !gs_eval(s, 1) || !gs_decide(s, uacc, -1, 0.0, c, lnc)) return 0;
+    }
     // the substitution-parameter moves come last (method.c:5699-5735; param_step of a00_driver.c)
     if (s->g_ft[0] > 0) for (unsigned j = 0; j < 3; ++j)  { if (!gs_step(s, 6, j) || !gs_eval(s, 0)) return 0; }
     if (s->g_ft[1] > 0) for (unsigned j = 0; j < 6; ++j)  { if (j != 1 && (!gs_step(s, 7, j) || !gs_eval(s, 0))) return 0; }

@@ -1139,6 +1139,10 @@ struct bpa_sampler
   DevBuf<gsm::GTree> g_dev, g_undo;
   DevBuf<gsm::GLocus> g_loc;
   DevBuf<double> g_lnl, g_lnlcur, g_hast, g_logpr, g_delta, g_site, g_len, g_lograt;
+  // the program's THETA / TAU / MIX on a generic sampler (decided on the host: gsampler_host.hpp gs_prog_*)
+  DevBuf<double> g_t2h3, g_progout;
+  long long gp_k[smp::MAXPOP] = {}; double gp_T[smp::MAXPOP] = {}; bool gp_ok = false, gp_pre_valid = false; double gp_pre_window = 0;
+  double gp_tau[smp::MAXPOP] = {}, gp_theta[smp::MAXPOP] = {}; bool gp_mirror = false;      // the host's copy of the species tree (it takes every decision)
   // two half-batches of the per-locus steps on two streams (gsampler_host.hpp: gs_fork / gs_join): loci [0, g_isplit) are the
   // slots [0, g_ssplit) = workgroups [0, g_bsplit) of the engine's packing, the rest the other half
   bool g_split = false, g_forked = false;
@@ -1334,6 +1338,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   if (s->g_stream2) { (void)hipStreamSynchronize(s->g_stream2); (void)hipStreamDestroy(s->g_stream2); s->g_stream2 = nullptr; }
   if (s->g_ev_fork) { (void)hipEventDestroy(s->g_ev_fork); s->g_ev_fork = nullptr; }
   if (s->g_ev_join) { (void)hipEventDestroy(s->g_ev_join); s->g_ev_join = nullptr; }
+  s->g_t2h3.free(); s->g_progout.free(); s->gp_mirror = false;
   s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_lnlcur.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
   s->g_len.free(); s->g_lograt.free(); s->g_active.free(); s->g_recs.free(); s->g_mat2.free(); s->g_bmo.free();
   s->g_sm.free(); s->g_sm_old.free(); s->g_ids.free();
@@ -1394,9 +1399,10 @@ extern "C" int bpa_sampler_set_proposal_kernel(bpa_sampler_t * s, int kind)
   if (s->comp) return 1;
   if (kind != BPA_KERNEL_UNIFORM && kind != BPA_KERNEL_BPP) return fail("bpa_sampler_set_proposal_kernel: BPA_KERNEL_UNIFORM or BPA_KERNEL_BPP");
   if (s->uploaded) return fail("bpa_sampler_set_proposal_kernel: before bpa_sampler_initialize (as a00_set_proposal_kernel)");
-  if ((s->generic || s->big) && kind == BPA_KERNEL_BPP) return fail("bpa_sampler_set_proposal_kernel: BPP's kernel runs in the persistent iteration kernel (JC69 loci of <= 8 tips and <= 64 patterns)");
+  if (s->big && kind == BPA_KERNEL_BPP) return fail("bpa_sampler_set_proposal_kernel: BPP's kernel runs in the persistent iteration kernel and in the generic sampler (loci of <= 16 tips)");
   s->kernel_bpp = kind == BPA_KERNEL_BPP;
-  for (unsigned i = 0; i < s->nloci; ++i) s->h_trees[i].rng = stream_seed(s, stream_of(s, i));
+  // (the generic sampler: together with bpa_sampler_set_program_moves and a theta prior — checked when the run starts)
+  for (unsigned i = 0; i < s->nloci; ++i) (s->generic ? s->g_trees[i].rng : s->h_trees[i].rng) = stream_seed(s, stream_of(s, i));
   s->grng = stream_seed(s, A00_GLOBAL_STREAM);
   s->v2_grng_sent = false;
   return 1;
