@@ -622,10 +622,14 @@ def run_config5(eng, iters=40):
     for i, r in enumerate(recs):
         smp.set_tip_species(i, r["species"])
     smp.set_tau_prior(2.0, 10.0)
-    smp.set_theta_prior(2.0, 100.0, 0.002)
-    smp.set_finetune(0.003, 0.003, 0.00002, 0.9)
+    # BPP's own iteration (see run_sampler): the control file's priors, the program's default step lengths and its burn-in rule
+    smp.set_proposal_kernel(1)
+    smp.set_program_moves(True, 0.1)
+    smp.set_theta_prior(2.0, 100.0, 0.001)
+    smp.set_finetune(5.0, 0.001, 0.001, 0.3)
     smp.initialize()
     lnl0 = smp.summary()["total_lnl"]
+    ft5 = smp.burnin(400)
     smp.iterate(3)
     eng.synchronize()
     l0 = smp.summary()["launches"]
@@ -637,7 +641,8 @@ def run_config5(eng, iters=40):
     out = dict(iterations_per_s=round(iters / dt, 2), ms_per_iteration=round(1e3 * dt / iters, 3), iterations=iters, loci=len(recs),
                tips=12, patterns_mean=round(float(np.mean([len(r["seqs"][0]) for r in recs])), 1), implementation=smp.kind(),
                launches_per_iteration=round((sm["launches"] - l0 - 1) / iters, 1), start_lnl=round(lnl0, 6),
-               acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
+               acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3), moves_short="program",
+               step_lengths_after_burnin={k: float(f"{v:.4g}") for k, v in ft5.items()},
                note="100 loci x 12 tips: 33 per-locus proposals + 11 thetas + 5 taus + mixing per iteration, every step a handful of "
                     "launches over 100 lanes of work — a plumbing / parity configuration (SURVEY 8d), not a throughput one")
     smp.close()
@@ -1149,12 +1154,23 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves
                               "native RCCL (libbpp_amd_rccl.so: ncclAllReduce on the engine stream, no Python in the loop)" if native is not None else
                               "p2p one-shot exchange kernel per step" if D.p2p is not None else "torch.distributed")
     sp_parent, sp_tau, sp_theta = synth.species_tree_arrays(cfg["taxa"])
+    div = cfg.get("divergence", 1.0)                  # (config 4's set is simulated at 3 x the default divergence: the chain starts where the data were made)
+    sp_tau, sp_theta = [t * div for t in sp_tau], [t * div for t in sp_theta]
     smp.set_species_tree(sp_parent, sp_tau, sp_theta)
     smp.set_tau_prior(3.0, 3.0 / sp_tau[-1])
     generic = cfg["model"] != "jc69"
     # the program's moves run inside the persistent kernel: one rank, or several exchanging through the in-kernel mailboxes
     program = (not generic) and moves == "program" and (D is None or (D.p2p is not None and not os.environ.get("BENCH_PY_ALLREDUCE")))
-    if generic:
+    generic_program = generic and moves == "program" and D is None
+    if generic_program:
+        # BPP's own iteration on the generic sampler: its generator / Bactrian-Laplace windows / acceptance rule in the per-locus
+        # kernels, THETA / TAU / MIX with their theta re-draws decided on the host from the loci's device sums (gs_prog_*); the
+        # program's default step lengths (bpp.c:530-549), tuned below by its burn-in rule
+        smp.set_proposal_kernel(1)
+        smp.set_program_moves(True, 0.1)
+        smp.set_theta_prior(2.0, 2.0 / sp_theta[0], 0.001)
+        smp.set_finetune(5.0, 0.001, 0.001, 0.3)
+    elif generic:
         smp.set_theta_prior(2.0, 2.0 / sp_theta[0], 0.5 * sp_theta[0])
     elif program:
         scale = math.sqrt(10000.0 / max(D.sum_int(len(data)) if D else len(data), 1))
@@ -1179,6 +1195,8 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves
     kind = smp.kind()
     sync = D.sync if D else eng.synchronize
     burnin_ft = None
+    if generic_program:
+        burnin_ft = smp.burnin(400)
     if program and D is None and kind == "persistent":
         # the program's burn-in (finetune = 1): 800 iterations, the step lengths reset from the acceptance proportions after every
         # quarter and at the end (bpa_sampler_burnin: reset_finetune, method.c:1508-1516, 5364) — outside the timed region
@@ -1317,9 +1335,14 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves
                       "(stree.c:3957), thetas re-drawn inside the rubber band (stree.c:5840) and the mixing step (prop_mixing.c:272); step lengths "
                       "from the program's burn-in rule run on the device (bpa_sampler_burnin, 800 iterations)" if program else
                       "uniform windows on the library's 64-bit streams, sliding-window theta, no theta re-draws in TAU / MIX" if not generic else
+                      "the program's (BPP v4.8.7 defaults) on the generic sampler: legacy_rndu + Bactrian-Laplace windows in the per-locus kernels, "
+                      "THETA (Gibbs 9 in 10) / TAU / MIX with their theta re-draws decided on the host from the loci's device sums; step lengths from "
+                      "the program's burn-in rule (bpa_sampler_burnin, 400 iterations)" if generic_program else
                       "uniform windows on the library's 64-bit streams (generic sampler)"),
+               moves_short=("program" if (program or generic_program) else "uniform"),
                theta_gibbs_draws=(dict(zip(("proposed", "accepted"), smp.gibbs_counters())) if program else None),
                step_lengths_after_burnin=({k: float(f"{v:.4g}") for k, v in burnin_ft.items()} if burnin_ft else None),
+               theta_gibbs_draws_generic=(dict(zip(("proposed", "accepted"), smp.gibbs_counters())) if generic_program else None),
                taus_after=[float(x) for x in smp.taus()[cfg["taxa"]:]],
                thetas_after=[float(x) for x in smp.thetas()[cfg["taxa"]:]],
                roofline=add_frac_pmc(roofline),

@@ -35,7 +35,8 @@ struct GTree                              // one per locus, in HBM
   int32_t  root, tips;
   uint32_t proposals, accepted;
   uint32_t work_nupd, work_nbr;           // node updates / fresh P-matrices / evaluations of all steps so far (bpa_sampler_work)
-  uint32_t work_neval, pad_[3];
+  uint32_t work_neval;
+  uint32_t pj_gage, pj_gage_acc, pj_gspr, pj_gspr_acc, pad_[3];    // of the proposals / accepted: the gene-node age and the prune-regraft moves (the burn-in's step-length rule wants the move types apart)
 };
 static_assert(sizeof(GTree) % 16 == 0, "GTree is copied as uint4");
 
@@ -239,7 +240,10 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
         const double lnl = A.lnl_new[i], lp_new = A.logpr_new[i];
         const double lnacc = (lp_new - logpr_cur) + (lnl - lnl_cur) + A.hast[i];
         ++nprop;
-        if (g_accept(T.rng, A.bpp, lnacc)) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; }
+        const bool acc_ = g_accept(T.rng, A.bpp, lnacc);
+        if (A.pend_mode == 0) { A.trees[i].pj_gage += 1; A.trees[i].pj_gage_acc += acc_ ? 1u : 0u; }
+        else if (A.pend_mode == 1) { A.trees[i].pj_gspr += 1; A.trees[i].pj_gspr_acc += acc_ ? 1u : 0u; }
+        if (acc_) { lnl_cur = lnl; logpr_cur = lp_new; ++nacc; }
         else back = true;
       }
     }

@@ -26,7 +26,7 @@ template <int NT> struct LocLDS
 };
 
 // what changes from step to step (a launch takes it from its arguments, the chain kernel below counts it itself)
-struct StepCtl { uint32_t k, pend, refresh_logpr, fmt20; };
+struct StepCtl { uint32_t k, pend, refresh_logpr, fmt20, pend_mode; };     // pend_mode: the kind of the step being settled (0: a gene-node age move)
 
 template <int NT> struct Step2LDS
 {
@@ -83,7 +83,7 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
   const int g_root = g.root, g_tips = g.tips, u_root = ud.root;
   smp2::Stream<BPP> rng{g.rng};                                // (BPP: the reference's generator, Bactrian-Laplace windows, its acceptance rule)
   double lnl_cur = g.lnl, logpr_cur = g.logpr;
-  uint32_t nprop = g.proposals, nacc = g.accepted, w_nupd = g.work_nupd, w_nbr = g.work_nbr, w_nev = g.work_neval;
+  uint32_t nprop = g.proposals, nacc = g.accepted, w_nupd = g.work_nupd, w_nbr = g.work_nbr, w_nev = g.work_neval, pj_gage = g.pj_gage, pj_gage_acc = g.pj_gage_acc, pj_gspr = g.pj_gspr, pj_gspr_acc = g.pj_gspr_acc;
   const gsm::GLocus L = A.loc[ic];
   const int gl_i = li < MAXPOP ? (int)L.gl[li] : 0;
   const uint32_t d_active = A.active[ic], d_flag = *A.flag;
@@ -124,7 +124,9 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
       {
         const double lnacc = (d_logpr - logpr_cur) + (d_lnl - lnl_cur) + d_hast;
         ++nprop;
-        if (rng.accept(lnacc)) { lnl_cur = d_lnl; logpr_cur = d_logpr; ++nacc; }
+        const bool acc_ = rng.accept(lnacc);
+        if (C.pend_mode == 0) { ++pj_gage; pj_gage_acc += acc_ ? 1u : 0u; } else if (C.pend_mode == 1) { ++pj_gspr; pj_gspr_acc += acc_ ? 1u : 0u; }
+        if (acc_) { lnl_cur = d_lnl; logpr_cur = d_logpr; ++nacc; }
         else back = true;
       }
     }
@@ -451,7 +453,7 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
     if (li == 0)
     {
       g.rng = rng.r; g.root = T.root; g.lnl = lnl_cur; g.logpr = logpr_cur; g.proposals = nprop; g.accepted = nacc;
-      g.work_nupd = w_nupd; g.work_nbr = w_nbr; g.work_neval = w_nev;
+      g.work_nupd = w_nupd; g.work_nbr = w_nbr; g.work_neval = w_nev; g.pj_gage = pj_gage; g.pj_gage_acc = pj_gage_acc; g.pj_gspr = pj_gspr; g.pj_gspr_acc = pj_gspr_acc;
     }
   }
   if (WAVE_ONLY) smp2::wsync();                  // (the next step of a chain reuses the LDS block)
@@ -468,7 +470,7 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
   __shared__ Step2LDS<NT> SH;
   constexpr uint32_t LPW = (uint32_t)smp2::Cfg<NT>::LPW, G = (uint32_t)smp2::Cfg<NT>::G;
   const uint32_t i = A.i0 + blockIdx.x*LPW + threadIdx.x/G;
-  const StepCtl C{MODE >= 2 ? A.tau_q : A.k, A.pend, A.refresh_logpr, A.fmt20};
+  const StepCtl C{MODE >= 2 ? A.tau_q : A.k, A.pend, A.refresh_logpr, A.fmt20, A.pend_mode};
   gstep2_body<MODE, NT, false, BPP>(A, C, SH, threadIdx.x, i, i < A.iend);
 }
 
@@ -491,7 +493,7 @@ __global__ void __launch_bounds__(GCHAIN_THREADS) gchain_kernel(const gsm::GArgs
   __shared__ Step2LDS<NT> SH;
   constexpr uint32_t G = (uint32_t)smp2::Cfg<NT>::G;
   const uint32_t i = A.i0 + blockIdx.x, tid = threadIdx.x;
-  StepCtl C{0, ch.pend, ch.refresh_logpr, 1u};
+  StepCtl C{0, ch.pend, ch.refresh_logpr, 1u, A.pend_mode};
   const LocusDev & L = P.loci[P.task_locus[i]];
   const uint32_t np = L.np, R = L.rate_cats, e0 = i*A.maxmat, poff = P.task_pat_off[i];
   const uint32_t nsteps = ch.ngage + ch.ngspr;
@@ -501,7 +503,7 @@ __global__ void __launch_bounds__(GCHAIN_THREADS) gchain_kernel(const gsm::GArgs
     C.k = gage ? st : st - ch.ngage;
     if (gage) gstep2_body<0, NT, true>(A, C, SH, tid, i, tid < G);
     else      gstep2_body<1, NT, true>(A, C, SH, tid, i, tid < G);
-    C.pend = 1u; C.refresh_logpr = 0u;
+    C.pend = 1u; C.refresh_logpr = 0u; C.pend_mode = gage ? 0u : 1u;
     __syncthreads();                                  // the step's records are out (written and read on this CU)
     if (A.active[i])
     {

@@ -713,6 +713,7 @@ static int gs_prog_theta(bpa_sampler * s)
       acc = lnacc == lnacc && tnew[p] > 0 && (lnacc >= -1e-10 || a00_bpp_rndu(&gz) < std::exp(lnacc));
     }
     gs_declog(slide[p] ? "theta" : "thetag", p, lnacc, acc);
+    if (slide[p]) { s->gp_pj[8]++; s->gp_pj[9] += acc ? 1u : 0u; }
     if (acc) { a.nacc++; s->gp_theta[p] = tnew[p]; a.theta_mask |= 1u << p; a.theta[p] = tnew[p]; if (!slide[p]) a.ngacc++; }
     if (!slide[p]) a.ngprop++;
   }
@@ -767,6 +768,7 @@ static int gs_prog_tau(bpa_sampler * s, int q)
   }
   const bool acc = sum >= -1e-10 || a00_bpp_rndu(&gz) < std::exp(sum);
   gs_declog("tau", q, sum, acc);
+  s->gp_pj[4]++; s->gp_pj[5] += acc ? 1u : 0u;
   s->grng = (a00_rng_t)gz;
   if (acc)
   {
@@ -820,6 +822,7 @@ static int gs_prog_mix(bpa_sampler * s)
   lnacc += lnacc_theta;
   const bool acc = lnacc >= -1e-10 || a00_bpp_rndu(&gz) < std::exp(lnacc);
   gs_declog("mix", 0, lnacc, acc);
+  s->gp_pj[6]++; s->gp_pj[7] += acc ? 1u : 0u;
   s->grng = (a00_rng_t)gz;
   gsm::GApply a{};
   a.set_tau_q = 0xffffffffu; a.nprop = 1;

@@ -1142,7 +1142,8 @@ struct bpa_sampler
   // the program's THETA / TAU / MIX on a generic sampler (decided on the host: gsampler_host.hpp gs_prog_*)
   DevBuf<double> g_t2h3, g_progout;
   long long gp_k[smp::MAXPOP] = {}; double gp_T[smp::MAXPOP] = {}; bool gp_ok = false, gp_pre_valid = false; double gp_pre_window = 0;
-  double gp_tau[smp::MAXPOP] = {}, gp_theta[smp::MAXPOP] = {}; bool gp_mirror = false;      // the host's copy of the species tree (it takes every decision)
+  double gp_tau[smp::MAXPOP] = {}, gp_theta[smp::MAXPOP] = {}; bool gp_mirror = false;
+  unsigned long long gp_pj[10] = {}, gp_pj_base[4] = {};     // by move type since the last bpa_sampler_adapt_finetune: tau / mix / theta window on the host, the loci's age and prune-regraft moves from the trees (base: their totals at that call)      // the host's copy of the species tree (it takes every decision)
   // two half-batches of the per-locus steps on two streams (gsampler_host.hpp: gs_fork / gs_join): loci [0, g_isplit) are the
   // slots [0, g_ssplit) = workgroups [0, g_bsplit) of the engine's packing, the rest the other half
   bool g_split = false, g_forked = false;
@@ -1845,8 +1846,26 @@ extern "C" double bpa_finetune_onestep(double pjump, double finetune) { return f
 extern "C" int bpa_sampler_adapt_finetune(bpa_sampler_t * s, double * pjump, double * finetune)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
-  if (s->comp || s->generic || s->big) return fail("bpa_sampler_adapt_finetune: the move-type counters are the persistent iteration kernel's (JC69 loci of <= 8 tips and <= 64 patterns)");
+  if (s->comp || s->big) return fail("bpa_sampler_adapt_finetune: the move-type counters are the persistent iteration kernel's and the generic sampler's (with the program's moves)");
   if (!sampler_download(s)) return 0;                 // (settles the launches in flight; the counters are then final)
+  if (s->generic)
+  {
+    if (!(s->kernel_bpp && s->sp.program_moves)) return fail("bpa_sampler_adapt_finetune: on a generic sampler the step-length rule runs with the program's moves (bpa_sampler_set_program_moves)");
+    unsigned long long tot[4] = {0, 0, 0, 0};          // gage proposed / accepted, gspr proposed / accepted over all loci
+    for (const auto & t : s->g_trees) { tot[0] += t.pj_gage; tot[1] += t.pj_gage_acc; tot[2] += t.pj_gspr; tot[3] += t.pj_gspr_acc; }
+    unsigned long long c[10];
+    for (int k = 0; k < 4; ++k) { c[k] = tot[k] - s->gp_pj_base[k]; s->gp_pj_base[k] = tot[k]; }
+    for (int k = 4; k < 10; ++k) { c[k] = s->gp_pj[k]; s->gp_pj[k] = 0; }
+    double * ft[5] = { &s->sp.ft_gage, &s->sp.ft_gspr, &s->sp.ft_tau, &s->sp.ft_mix, &s->sp.ft_theta };
+    for (int m = 0; m < 5; ++m)
+    {
+      const double pj = c[2*m] ? (double)c[2*m + 1]/(double)c[2*m] : -1.0;
+      if (pj >= 0 && *ft[m] > 0) *ft[m] = finetune_onestep(pj, *ft[m]);
+      if (pjump) pjump[m] = pj;
+      if (finetune) finetune[m] = *ft[m];
+    }
+    return 1;
+  }
   if (!s->v2_ok || !s->v2_pj.p) return fail("bpa_sampler_adapt_finetune: the sampler does not run the persistent iteration kernel");
   unsigned long long c[16];
   HIPCHK(hipMemcpy(c, s->v2_pj.p, sizeof c, hipMemcpyDeviceToHost));

@@ -97,11 +97,39 @@ def test_burnin_arrives_where_the_program_s_does():
 
 
 @pytest.mark.gpu
-def test_adaptation_is_the_persistent_kernel_s():
+def test_the_rule_on_the_generic_sampler():
+    """GTR + Gamma loci (the generic sampler, the program's moves decided on the host): the uniform-window iteration has no
+    step-length rule; with the program's moves the burn-in from the program's defaults brings every move type to the rule's aim"""
     import tape
     eng = bpp_amd.Engine(0)
-    data = synth.make_dataset(20, 300, 4, "gtr", 4, seed=3)
+    data = synth.make_dataset(300, 500, 8, "gtr", 4, seed=3)
     smp = bpp_amd.Sampler(eng, tape.make_engine_loci(eng, data), data, seed=1)
+    parent, tau, theta = synth.species_tree_arrays(8)
+    smp.set_species_tree(parent, tau, theta)
+    smp.set_tau_prior(3.0, 3.0 / tau[-1])
+    smp.set_theta_prior(2.0, 1000.0, 0.001)
+    smp.set_finetune(5.0, 0.001, 0.001, 0.3)
+    smp.initialize()
+    smp.iterate(2)
     with pytest.raises(bpp_amd.BpaError):
         smp.adapt_finetune()
+    smp.close()
+    smp = bpp_amd.Sampler(eng, tape.make_engine_loci(eng, data), data, seed=1)
+    smp.set_proposal_kernel(1)
+    smp.set_program_moves(True, 0.1)
+    smp.set_species_tree(parent, tau, theta)
+    smp.set_tau_prior(3.0, 3.0 / tau[-1])
+    smp.set_theta_prior(2.0, 1000.0, 0.001)
+    smp.set_finetune(5.0, 0.001, 0.001, 0.3)
+    smp.initialize()
+    assert smp.kind() == "generic"
+    ft = smp.burnin(800)
+    assert ft["gage"] != 5.0 and ft["tau"] != 0.001 and ft["mix"] != 0.3
+    smp.iterate(300)
+    pj, _ = smp.adapt_finetune()
+    for k in ("gspr", "tau", "mix"):
+        assert 0.15 < pj[k] < 0.45, (k, pj, ft)
+    assert 0.2 < pj["gage"] < 0.6, (pj, ft)
+    g = smp.gibbs_counters()
+    assert g[0] > 0 and g[1] > 0.9 * g[0]             # (the metropolized Gibbs draws are nearly always accepted)
     smp.close(); eng.close()
