@@ -89,7 +89,12 @@ def test_host_driver_with_parameter_moves_reproduces_bpp_posterior(gold):
 
 
 @pytest.mark.gpu
-def test_device_sampler_with_parameter_moves_reproduces_bpp_posterior(gold):
+@pytest.mark.parametrize("moves", ["uniform", "program"])
+def test_device_sampler_with_parameter_moves_reproduces_bpp_posterior(gold, moves):
+    """moves = "program": BPP's own iteration on the generic sampler — its generator, Bactrian-Laplace windows and acceptance rule
+    in every per-locus move (tree and parameter moves), THETA by the metropolized Gibbs draw, the thetas re-drawn inside the
+    rubber band and the mixing step (decided on the host from the device's sums), the step lengths tuned by its burn-in rule
+    from its defaults (bpa_sampler_burnin) — must sample the same posterior as the program"""
     import bpp_amd
     import tape
     data = dataset(gold)
@@ -100,9 +105,21 @@ def test_device_sampler_with_parameter_moves_reproduces_bpp_posterior(gold):
     eng = bpp_amd.Engine(0)
     loci = tape.make_engine_loci(eng, data)
     dev = bpp_amd.Sampler(eng, loci, data, seed=9)
+    if moves == "program":
+        dev.set_proposal_kernel(1)
+        dev.set_program_moves(True, 0.1)
     setup(dev, gold, data, False)
+    if moves == "program":
+        dev.set_theta_prior(c["theta_prior"][0], c["theta_prior"][1], 0.001)       # the program's defaults (bpp.c:530-549)
+        dev.set_finetune(5.0, 0.001, 0.001, 0.3)
     dev.initialize()
-    dev.iterate(2000)
+    if moves == "program":
+        ft = dev.burnin(2000)
+        assert ft["gage"] != 5.0 and ft["mix"] != 0.3
+        g = dev.gibbs_counters()
+        assert g[0] > 0 and g[1] > 0.8 * g[0]
+    else:
+        dev.iterate(2000)
     S = []
     for _ in range(4000):
         dev.iterate(2)
