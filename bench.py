@@ -776,9 +776,10 @@ def dominant_kernel(cfg, one_gpu=True):
         # one GPU: the whole iteration is one chain launch; several: the chain breaks at the steps whose sums are exchanged
         return "step_jc69_v2_chain_kernel<256>" if one_gpu else "step_jc69_v2_chain_kernel<256> + step_jc69_v2_kernel<256>"
     if cfg["model"] == "gtr":
-        return "step_s4_klane_v2_kernel<256,false>"
-    k = os.environ.get("BPA_S20_KERNEL", "pipe")
-    return {"pipe": "partials_lnl_pipe20_kernel<20,true,2>", "pipemfma": "partials_lnl_pipemfma20_kernel<false,2>"}.get(k, f"20-state kernel `{k}`")
+        return "step_s4_klane_v2_kernel<256,false>" if os.environ.get("BPA_KLANE_V2") else "step_s4_klane_v3_kernel<256,false>"
+    k = os.environ.get("BPA_S20_KERNEL", "wave")
+    return {"wave": "partials_lnl_wave20_kernel<20,true,2,1>", "wave2": "partials_lnl_wave20_kernel<20,true,1,2>", "pipe": "partials_lnl_pipe20_kernel<20,true,2>",
+            "pipemfma": "partials_lnl_pipemfma20_kernel<false,2>"}.get(k, f"20-state kernel `{k}`")
 
 
 def traffic_from_profiles(config, kernel):

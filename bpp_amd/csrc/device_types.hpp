@@ -159,6 +159,7 @@ struct PlanDev
   // tiled path (20 states): workgroup b owns patterns tile_n0[b] .. +TILE of task tile_task[b]
   const uint32_t * tile_task;   // [NT]
   const uint32_t * tile_n0;     // [NT]
+  uint32_t *       tile_arrive; // [T] flags bit 9 (partials_lnl_wave20_kernel): tiles of task t that have written their terms, ever (a multiple of the task's tile count between launches): the last one adds the locus's terms up
   // compact JC69 path
   const LaneStatic * lane_tab;  // engine table [B2*256]
   const SlotStatic * slot_tab;  // engine table [slots]

@@ -441,6 +441,20 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
       k0 = t.e0; k1 = t.e1;
     }
     const size_t lds20 = ((size_t)4*s->g_rmax*400 + (size_t)s->g_rmax*64)*sizeof(double);
+    // BPA_S20_SUM_FUSED=1: the per-locus sum inside the node-update kernel (its last tile of a locus adds the terms up; one launch
+    // fewer per step and half).  Measured on config 4 and NOT the default: 119 it/s against 132 with lnl_reduce_wave_kernel as
+    // a launch of its own — the arriving wave must drain its CLV stores before its arrival atomic, holding the workgroup's
+    // registers and LDS meanwhile, and the last tile adds alone; with an agent-scope release fence instead of write-through
+    // terms: 72 it/s (the fence writes back the XCD's whole L2, i.e. the CLV planes just stored)
+    static const bool sum_fused = getenv("BPA_S20_SUM_FUSED") != nullptr;
+    const bool fuse_sum = sum_fused && !gs_pipe20() && gs_tile20() == 64u;
+    if (fuse_sum && !s->g_arrive.p)
+    {
+      if (!s->g_arrive.reserve(s->nloci)) return fail("out of device memory (arrival counters)");
+      HIPCHK(hipMemsetAsync(s->g_arrive.p, 0, (size_t)s->nloci*sizeof(uint32_t), e->stream));
+    }
+    d.tile_arrive = s->g_arrive.p;
+    const uint32_t fsum = fuse_sum ? 512u : 0u;
     if (s->g_forked)
     {
       for (int h = 0; h < 2; ++h)
@@ -451,26 +465,26 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
         d.flags = 1u | 256u;
         hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3((i1 - i0)*s->g_maxmat), dim3(256), 0, st, d);
         d.blk0 = t0;
-        d.flags = 4u | 64u | 256u;
+        d.flags = 4u | 64u | 256u | fsum;
         if (gs_pipe20()) hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
         else if (gs_tile20() == 128u) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20 + (size_t)s->g_rmax*64*sizeof(double), st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
         else hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
         d.blk0 = i0;
-        hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(i1 - i0), dim3(64), 0, st, d);
+        if (!fuse_sum) hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(i1 - i0), dim3(64), 0, st, d);
       }
       HIPCHK(hipGetLastError());
-      s->launches += 6; s->g_evals += 2;
+      s->launches += fuse_sum ? 4 : 6; s->g_evals += 2;
       return 1;
     }
     d.flags = 1u;
     hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d);
-    d.flags = 4u | 64u;
+    d.flags = 4u | 64u | fsum;
     if (gs_pipe20()) hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
     else if (gs_tile20() == 128u) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20 + (size_t)s->g_rmax*64*sizeof(double), e->stream, k0, k1, 0, d);
     else hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
-    hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(s->nloci), dim3(64), 0, e->stream, d);
+    if (!fuse_sum) hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(s->nloci), dim3(64), 0, e->stream, d);
     HIPCHK(hipGetLastError());
-    s->launches += 3; s->g_evals++;
+    s->launches += fuse_sum ? 2 : 3; s->g_evals++;
     return 1;
   }
   // a small multi-category set: the eigensystem refresh and the P-matrix phase inside the step launch (BPA_GS_FUSEA=0 / 1: never /

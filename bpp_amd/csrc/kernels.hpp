@@ -715,6 +715,7 @@ __device__ __forceinline__ void stage_pmats_wave(double * s_dst, const double * 
 // cycles and brings the 2 matrix entries of 2 FMAs per lane — 25 M such reads per config-4 launch = 390 k LDS cycles per CU,
 // ~190 us of the launch's 320 (SQ_LDS_IDX_ACTIVE agrees), against ~100 us of FP64 issue.  Two patterns per lane at one wave per
 // SIMD (the registers of two: 512 per lane) halve the reads per pattern; the wave's latency cover is the requests-ahead above.
+template <bool COHERENT = false> __device__ __forceinline__ void lnl_reduce_wave(const PlanDev & P, const uint32_t t, const uint32_t lane);
 template <int S, bool NTA = false, int OCC = 2, int PP = 1>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 partials_lnl_wave20_kernel(const PlanDev P)
@@ -1051,7 +1052,23 @@ partials_lnl_wave20_kernel(const PlanDev P)
       }
       term = lt*Lwgt[n[q]];
     }
-    P.site_term[((cu32_p)P.task_pat_off)[t] + n[q]] = term;      // (real lanes: n = the lane's own pattern)
+    double * dst = P.site_term + ((cu32_p)P.task_pat_off)[t] + n[q];      // (real lanes: n = the lane's own pattern)
+    if (P.flags & 512u) __hip_atomic_store(dst, term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *dst = term;
+  }
+  if (P.flags & 512u)
+  {
+    // the per-locus sum without a launch of its own: the tile that arrives LAST adds the locus's terms up in pattern order
+    // (the reference's sequential sum).  Hand-over by 8-byte agent-scope atomics on both sides (MI355X_MICROARCH.md, inter-
+    // workgroup visibility: write-through stores, loads past the reader's L1) — NOT a release fence, which writes back
+    // every dirty line of the XCD's L2, i.e. the CLV planes this kernel has just stored: measured 72 against 131 it/s —, the
+    // wave's stores drained (vmcnt(0)) before its returning arrival atomic.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t old = 0;
+    if (lane == 0) old = atomicAdd(P.tile_arrive + t, 1u);
+    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+    const uint32_t ntile = (np + 64u*PP - 1u)/(64u*PP);
+    if ((old + 1u) % ntile == 0u) lnl_reduce_wave<true>(P, t, lane);
   }
 }
 
@@ -1337,6 +1354,8 @@ __device__ __forceinline__ double reduce_locus(const LocusDev & L, TERMPTR term)
 
 // one wave per locus: the terms are fetched 64 at a time (coalesced) and added in pattern order —
 // the reference's sequential sum (core_likelihood.c:85) — by broadcasting them lane by lane
+// (COHERENT: the terms were written by other workgroups of this launch — 8-byte agent-scope atomic loads, past this CU's L1)
+template <bool COHERENT>
 __device__ __forceinline__ void lnl_reduce_wave(const PlanDev & P, const uint32_t t, const uint32_t lane)
 {
   const LocusDev & L = P.loci[P.task_locus[t]];
@@ -1350,7 +1369,7 @@ __device__ __forceinline__ void lnl_reduce_wave(const PlanDev & P, const uint32_
   double logl = 0;
   for (uint32_t base = 0; base < np; base += 64)
   {
-    const double v = base + lane < np ? term[base + lane] : 0.0;
+    const double v = base + lane >= np ? 0.0 : COHERENT ? __hip_atomic_load(term + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : term[base + lane];
     const int lo = __double2loint(v), hi = __double2hiint(v);
     const uint32_t cnt = np - base < 64u ? np - base : 64u;
     for (uint32_t q = 0; q < cnt; ++q)

@@ -1141,6 +1141,7 @@ struct bpa_sampler
   DevBuf<double> g_lnl, g_lnlcur, g_hast, g_logpr, g_delta, g_site, g_len, g_lograt;
   // the program's THETA / TAU / MIX on a generic sampler (decided on the host: gsampler_host.hpp gs_prog_*)
   DevBuf<double> g_t2h3, g_progout;
+  DevBuf<uint32_t> g_arrive;            // 20-state loci: tiles arrived per locus (the per-locus sum inside partials_lnl_wave20_kernel)
   long long gp_k[smp::MAXPOP] = {}; double gp_T[smp::MAXPOP] = {}; bool gp_ok = false, gp_pre_valid = false; double gp_pre_window = 0;
   double gp_tau[smp::MAXPOP] = {}, gp_theta[smp::MAXPOP] = {}; bool gp_mirror = false;
   unsigned long long gp_pj[10] = {}, gp_pj_base[4] = {};     // by move type since the last bpa_sampler_adapt_finetune: tau / mix / theta window on the host, the loci's age and prune-regraft moves from the trees (base: their totals at that call)      // the host's copy of the species tree (it takes every decision)
@@ -1339,7 +1340,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   if (s->g_stream2) { (void)hipStreamSynchronize(s->g_stream2); (void)hipStreamDestroy(s->g_stream2); s->g_stream2 = nullptr; }
   if (s->g_ev_fork) { (void)hipEventDestroy(s->g_ev_fork); s->g_ev_fork = nullptr; }
   if (s->g_ev_join) { (void)hipEventDestroy(s->g_ev_join); s->g_ev_join = nullptr; }
-  s->g_t2h3.free(); s->g_progout.free(); s->gp_mirror = false;
+  s->g_t2h3.free(); s->g_progout.free(); s->g_arrive.free(); s->gp_mirror = false;
   s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_lnlcur.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
   s->g_len.free(); s->g_lograt.free(); s->g_active.free(); s->g_recs.free(); s->g_mat2.free(); s->g_bmo.free();
   s->g_sm.free(); s->g_sm_old.free(); s->g_ids.free();

@@ -312,7 +312,9 @@ void bpa_sampler_set_finetune(bpa_sampler_t *, double gage, double gspr, double 
    the last call (counted by the persistent iteration kernel; pjump[m] < 0: never proposed, step length kept) and clears the
    counters, as reset_finetune + pjump_reset do (method.c:1508-1516, 5364-5377); pjump / finetune (5 each) may be null.
    bpa_sampler_burnin runs `iterations` iterations the program's way: the rule after every quarter of them (when a quarter
-   is at least 100 iterations) and once more at the end; finetune (5, may be null) receives the step lengths it ends with. */
+   is at least 100 iterations) and once more at the end; finetune (5, may be null) receives the step lengths it ends with.
+   Where: the persistent iteration kernel (device counters by move type) and the generic sampler with the program's moves
+   (the trees carry the age / prune-regraft counts, the host its own decisions').                                       */
 double bpa_finetune_onestep(double pjump, double finetune);
 int  bpa_sampler_adapt_finetune(bpa_sampler_t *, double * pjump, double * finetune);
 int  bpa_sampler_burnin(bpa_sampler_t *, unsigned iterations, double * finetune);
@@ -322,7 +324,8 @@ int  bpa_sampler_burnin(bpa_sampler_t *, unsigned iterations, double * finetune)
                       legacy_rnd_symmetrical (random.c:192-238) for the ages, taus and thetas, acceptance "lnacc >= -1e-10 or
                       rndu < exp(lnacc)" with the number drawn only when needed (gtree.c:5476, stree.c:6286): the finetunes
                       then mean what they mean in a BPP control file.  Same trajectory as the host driver with
-                      A00_KERNEL_BPP.  Persistent iteration kernel only (bpa_sampler_kind).                              */
+                      A00_KERNEL_BPP.  The persistent iteration kernel, and (round 5) the generic sampler — there together
+                      with bpa_sampler_set_program_moves and a theta prior; not the big-tree sampler (bpa_sampler_kind).  */
 #define BPA_KERNEL_UNIFORM 0
 #define BPA_KERNEL_BPP     1
 int  bpa_sampler_set_proposal_kernel(bpa_sampler_t *, int kind);
@@ -332,8 +335,11 @@ int  bpa_sampler_set_proposal_kernel(bpa_sampler_t *, int kind);
             gene trees, get_gamma_conditional_approx stree.c:3384) otherwise;
      TAU    the rubber band re-draws the thetas of the population and its two children (opt_rb_theta_update, stree.c:5840);
      MIX    re-draws every theta with the scaled trees (opt_mix_theta_update, prop_mixing.c:272).
-   All decided inside the persistent kernel from two sums over the loci per theta — coalescences and T2h, carried through
-   the iteration —: one exchange per step, as without.                                                                  */
+   All decided from two sums over the loci per theta — coalescences and T2h, carried through the iteration.  The persistent
+   kernel decides inside the launch (its control wave): one exchange per step, as without.  The generic sampler (any model,
+   <= 16 tips) brings the sums to the HOST — 24 to 72 bytes and one synchronisation per all-loci step — which takes the
+   decision with the statements of a00_driver.c (theta_step_gibbs / tau_step / mix_step) and sends it back as a one-lane
+   launch; one rank only (no all-reduce callback).  Same trajectory as the host driver with a00_set_program_moves.      */
 int  bpa_sampler_set_program_moves(bpa_sampler_t *, int on, double slide_prob);
 int  bpa_sampler_gibbs_counters(bpa_sampler_t *, unsigned long * proposals, unsigned long * accepted);
 void bpa_sampler_set_tau_prior(bpa_sampler_t *, double alpha, double beta);           /* a00_set_tau_prior */

@@ -74,7 +74,9 @@ def _start_program_runs(session, cpu_only=True):
     def run():
         bpphip.CPU_ONLY = cpu_only
         try:
-            with ThreadPoolExecutor(max_workers=8 if len(session.items) > len(items) else 12) as ex:
+            # (the second pass is GPU processes only: more than four of them at once time-slice the device so badly that a
+            #  run of seconds takes minutes — the first pass had CPU runs between them)
+            with ThreadPoolExecutor(max_workers=(8 if len(session.items) > len(items) else 12) if cpu_only else 4) as ex:
                 list(ex.map(dry, items))
         finally:
             bpphip.CPU_ONLY = False
