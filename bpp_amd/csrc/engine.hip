@@ -828,9 +828,9 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   {
     const char * v = getenv("BPA_S20_KERNEL");
     p->s20_kernel = v ? v : "wave";
-    if (p->s20_kernel != "wave" && p->s20_kernel != "wave2" && p->s20_kernel != "pipe" && p->s20_kernel != "pipemfma" && p->s20_kernel != "tiled" && p->s20_kernel != "generic") p->s20_kernel = "wave";
+    if (p->s20_kernel != "wave" && p->s20_kernel != "waverl" && p->s20_kernel != "wave2" && p->s20_kernel != "pipe" && p->s20_kernel != "pipemfma" && p->s20_kernel != "tiled" && p->s20_kernel != "generic") p->s20_kernel = "wave";
   }
-  p->s20_tiledk = p->s20_kernel == "wave" || p->s20_kernel == "wave2" || p->s20_kernel == "pipe" || p->s20_kernel == "pipemfma";
+  p->s20_tiledk = p->s20_kernel == "wave" || p->s20_kernel == "waverl" || p->s20_kernel == "wave2" || p->s20_kernel == "pipe" || p->s20_kernel == "pipemfma";
   if (p->s20_tiledk && p->rmax > 4) { p->s20_tiledk = false; p->s20_kernel = "tiled"; }     // 64 x R lanes must fit a 256-lane workgroup
   p->tile = (p->s20_tiledk && p->s20_kernel != "wave2") ? 64 : 128;       // (wave2: two patterns per lane)
   if (p->states == 20)
@@ -1211,6 +1211,8 @@ static int plan_launch_mode(bpa_plan * p, int mode)
         hipLaunchKernelGGL((partials_lnl_pipemfma20_kernel<false, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
       else if (p->s20_kernel == "pipe")
         hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
+      else if (p->s20_kernel == "waverl")
+        hipLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2, 1, true>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
       else if (p->s20_kernel == "wave2")
         hipLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)2*p->rmax*64)*sizeof(double), e->stream, d);
       else

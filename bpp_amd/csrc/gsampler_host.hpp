@@ -8,6 +8,7 @@
 // BPA_S20_KERNEL=pipe: round 4's 20-state node-update kernel (a workgroup barrier per update) instead of partials_lnl_wave20_kernel (A/B)
 // BPA_S20_KERNEL=wave2: partials_lnl_wave20_kernel with two patterns per lane (tiles of 128 patterns, one wave per SIMD)
 static unsigned gs_tile20() { static const unsigned v = (getenv("BPA_S20_KERNEL") && std::string(getenv("BPA_S20_KERNEL")) == "wave2") ? 128u : 64u; return v; }
+static bool gs_waverl() { static const bool v = getenv("BPA_S20_KERNEL") && std::string(getenv("BPA_S20_KERNEL")) == "waverl"; return v; }
 static bool gs_pipe20() { static const bool v = getenv("BPA_S20_KERNEL") && std::string(getenv("BPA_S20_KERNEL")) == "pipe"; return v; }
 
 static int gs_subst_ready(bpa_sampler * s)
@@ -468,6 +469,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
         d.flags = 4u | 64u | 256u | fsum;
         if (gs_pipe20()) hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
         else if (gs_tile20() == 128u) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20 + (size_t)s->g_rmax*64*sizeof(double), st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
+        else if (gs_waverl()) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2, 1, true>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
         else hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
         d.blk0 = i0;
         if (!fuse_sum) hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(i1 - i0), dim3(64), 0, st, d);
@@ -481,6 +483,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     d.flags = 4u | 64u | fsum;
     if (gs_pipe20()) hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
     else if (gs_tile20() == 128u) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20 + (size_t)s->g_rmax*64*sizeof(double), e->stream, k0, k1, 0, d);
+    else if (gs_waverl()) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2, 1, true>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
     else hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
     if (!fuse_sum) hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(s->nloci), dim3(64), 0, e->stream, d);
     HIPCHK(hipGetLastError());

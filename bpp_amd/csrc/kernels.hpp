@@ -716,7 +716,7 @@ __device__ __forceinline__ void stage_pmats_wave(double * s_dst, const double * 
 // ~190 us of the launch's 320 (SQ_LDS_IDX_ACTIVE agrees), against ~100 us of FP64 issue.  Two patterns per lane at one wave per
 // SIMD (the registers of two: 512 per lane) halve the reads per pattern; the wave's latency cover is the requests-ahead above.
 template <bool COHERENT = false> __device__ __forceinline__ void lnl_reduce_wave(const PlanDev & P, const uint32_t t, const uint32_t lane);
-template <int S, bool NTA = false, int OCC = 2, int PP = 1>
+template <int S, bool NTA = false, int OCC = 2, int PP = 1, bool RL = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 partials_lnl_wave20_kernel(const PlanDev P)
 {
@@ -916,10 +916,23 @@ partials_lnl_wave20_kernel(const PlanDev P)
           double a[PP][4];
 #pragma unroll
           for (int q = 0; q < PP; ++q) a[q][0] = a[q][1] = a[q][2] = a[q][3] = 0;
+          // RL: the row comes out of LDS with ONE read (lane l brings entry l % S) and goes to the multiply-adds as scalar
+          // operands through v_readlane — 40 LDS reads per update instead of 400 broadcast reads of two entries each, whose
+          // latency (three in flight is what the registers allow) is what the wave waits for
+          const double prow = RL ? lm[i*S + (int)(lane % S)] : 0.0;
+          const int plo = __double2loint(prow), phi = __double2hiint(prow);
 #pragma unroll
           for (int j = 0; j < S; j += 4)
           {
-            const double m0 = lm[i*S + j], m1 = lm[i*S + j + 1], m2 = lm[i*S + j + 2], m3 = lm[i*S + j + 3];
+            double m0, m1, m2, m3;
+            if (RL)
+            {
+              m0 = __hiloint2double(__builtin_amdgcn_readlane(phi, j), __builtin_amdgcn_readlane(plo, j));
+              m1 = __hiloint2double(__builtin_amdgcn_readlane(phi, j + 1), __builtin_amdgcn_readlane(plo, j + 1));
+              m2 = __hiloint2double(__builtin_amdgcn_readlane(phi, j + 2), __builtin_amdgcn_readlane(plo, j + 2));
+              m3 = __hiloint2double(__builtin_amdgcn_readlane(phi, j + 3), __builtin_amdgcn_readlane(plo, j + 3));
+            }
+            else { m0 = lm[i*S + j]; m1 = lm[i*S + j + 1]; m2 = lm[i*S + j + 2]; m3 = lm[i*S + j + 3]; }
 #pragma unroll
             for (int q = 0; q < PP; ++q)
             {
@@ -938,10 +951,20 @@ partials_lnl_wave20_kernel(const PlanDev P)
           double a[PP][4];
 #pragma unroll
           for (int q = 0; q < PP; ++q) a[q][0] = a[q][1] = a[q][2] = a[q][3] = 0;
+          const double prow = RL ? rm[i*S + (int)(lane % S)] : 0.0;
+          const int plo = __double2loint(prow), phi = __double2hiint(prow);
 #pragma unroll
           for (int j = 0; j < S; j += 4)
           {
-            const double m0 = rm[i*S + j], m1 = rm[i*S + j + 1], m2 = rm[i*S + j + 2], m3 = rm[i*S + j + 3];
+            double m0, m1, m2, m3;
+            if (RL)
+            {
+              m0 = __hiloint2double(__builtin_amdgcn_readlane(phi, j), __builtin_amdgcn_readlane(plo, j));
+              m1 = __hiloint2double(__builtin_amdgcn_readlane(phi, j + 1), __builtin_amdgcn_readlane(plo, j + 1));
+              m2 = __hiloint2double(__builtin_amdgcn_readlane(phi, j + 2), __builtin_amdgcn_readlane(plo, j + 2));
+              m3 = __hiloint2double(__builtin_amdgcn_readlane(phi, j + 3), __builtin_amdgcn_readlane(plo, j + 3));
+            }
+            else { m0 = rm[i*S + j]; m1 = rm[i*S + j + 1]; m2 = rm[i*S + j + 2]; m3 = rm[i*S + j + 3]; }
 #pragma unroll
             for (int q = 0; q < PP; ++q)
             {

@@ -425,7 +425,7 @@ def test_against_the_reference_itself(engine, spec):
     rl.free()
 
 
-@pytest.mark.parametrize("kernel", ["wave2", "pipe", "pipemfma", "tiled", "generic"])
+@pytest.mark.parametrize("kernel", ["waverl", "wave2", "pipe", "pipemfma", "tiled", "generic"])
 def test_20_state_kernel_variants_are_bit_exact(engine, monkeypatch, kernel):
     """every 20-state node-update kernel kept next to the default (BPA_S20_KERNEL: the FP64-MFMA one, the one-wave
     fall-back of loci with more than 4 categories, the unstaged one) reproduces the reference's AVX2 summation order
