@@ -1855,7 +1855,8 @@ extern "C" int bpa_sampler_adapt_finetune(bpa_sampler_t * s, double * pjump, dou
     unsigned long long tot[4] = {0, 0, 0, 0};          // gage proposed / accepted, gspr proposed / accepted over all loci
     for (const auto & t : s->g_trees) { tot[0] += t.pj_gage; tot[1] += t.pj_gage_acc; tot[2] += t.pj_gspr; tot[3] += t.pj_gspr_acc; }
     unsigned long long c[10];
-    for (int k = 0; k < 4; ++k) { c[k] = tot[k] - s->gp_pj_base[k]; s->gp_pj_base[k] = tot[k]; }
+    for (int k = 0; k < 4; ++k) { if (tot[k] < s->gp_pj_base[k]) s->gp_pj_base[k] = 0;      /* (the trees were set again: their counts start over) */
+                                  c[k] = tot[k] - s->gp_pj_base[k]; s->gp_pj_base[k] = tot[k]; }
     for (int k = 4; k < 10; ++k) { c[k] = s->gp_pj[k]; s->gp_pj[k] = 0; }
     double * ft[5] = { &s->sp.ft_gage, &s->sp.ft_gspr, &s->sp.ft_tau, &s->sp.ft_mix, &s->sp.ft_theta };
     for (int m = 0; m < 5; ++m)
