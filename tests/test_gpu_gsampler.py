@@ -292,3 +292,35 @@ def test_generic_sampler_with_the_program_s_moves_equals_host_driver(taxa, model
     gh, gd = host.gibbs_counters(), dev.gibbs_counters()
     assert tuple(gd) == tuple(gh) and gd[0] > 0, (gd, gh)
     dev.close(); host.close(); eng.close()
+
+
+def test_what_the_generic_sampler_refuses_with_bpp_s_kernel():
+    """BPP's proposal kernel on a generic sampler comes with the program's moves and a theta prior, on one rank: anything else
+    fails loudly when the run starts (no silent fall-back to the uniform kernel)"""
+    eng = bpp_amd.Engine(0)
+    data = synth.make_dataset(12, 200, 8, "gtr", 4, seed=5)
+    parent, tau0, thetas = synth.species_tree_arrays(8)
+
+    def make(program, theta_prior):
+        smp = bpp_amd.Sampler(eng, tape.make_engine_loci(eng, data), data, seed=3)
+        smp.set_proposal_kernel(1)
+        if program:
+            smp.set_program_moves(True, 0.1)
+        smp.set_species_tree(parent, tau0, thetas)
+        smp.set_tau_prior(3.0, 3.0 / tau0[-1])
+        if theta_prior:
+            smp.set_theta_prior(2.0, 1000.0, 0.001)
+        smp.set_finetune(0.003, 0.005, 0.0008, 0.2)
+        smp.initialize()
+        return smp
+
+    for program, theta_prior in ((False, True), (True, False)):
+        smp = make(program, theta_prior)
+        with pytest.raises(bpp_amd.BpaError, match="program's moves"):
+            smp.iterate(1)
+        smp.close()
+    smp = make(True, True)
+    smp.iterate(2)                                   # the supported combination runs
+    assert smp.gibbs_counters()[0] > 0
+    smp.close()
+    eng.close()
