@@ -37,6 +37,9 @@ static constexpr int BPA_BLOCK = 256;
 // profiling aid: drain outstanding memory ops, then stamp the 100-MHz wall clock
 #define BPA_STAMP(P, b, lane, i) do { if ((P).dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if ((lane) == 0) (P).dbg[(size_t)(b)*8 + (i)] = wall_clock64(); } } while (0)
 
+// the same without draining anything: what the wave has ISSUED by then (explicit waits before it still show)
+#define BPA_STAMP_NW(P, b, lane, i) do { if ((P).dbg) { if ((lane) == 0) (P).dbg[(size_t)(b)*8 + (i)] = wall_clock64(); } } while (0)
+
 // ------------------------------------------------------------------ helpers --
 __device__ __forceinline__ double dot4_pair(const double m0, const double m1, const double m2,
                                             const double m3, const double * v)
@@ -99,6 +102,18 @@ __device__ __forceinline__ uint32_t xcd_tile(const uint32_t b, const uint32_t nb
 __device__ __forceinline__ void lds_barrier()
 {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// 16 bytes per lane, global -> LDS directly (global_load_lds_dwordx4: the wave's 64 lanes land at lds_base + 16 lane), as INLINE
+// ASSEMBLY: behind __builtin_amdgcn_global_load_lds the compiler's wait-count pass cannot tell which LDS bytes the load writes
+// and puts s_waitcnt vmcnt(0) in front of every later ds_read of the kernel — which then also waits for every global STORE issued
+// in between (seen in the disassembly of both round-5 step kernels, tools/disasm.py).  The caller waits for these loads itself
+// (s_waitcnt vmcnt); the compiler's own counts stay safe (it waits for a few more than it must: returns are in order).
+__device__ __forceinline__ void lds_dma16(const void * gsrc, const void * lds_base)
+{
+  const uint32_t lds_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)lds_base;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :: "v"((const __attribute__((address_space(1))) void *)gsrc), "s"(lds_off) : "memory", "m0");
 }
 
 // ================================================================ K1+K2, S=4 ==
@@ -2995,7 +3010,7 @@ step_s4_klane_v3_kernel(const PlanDev P)
     }
     __syncthreads();                                         // the block's fresh P-matrices are out (written and read on this CU)
   }
-  BPA_STAMP(P, b, lane, 0);
+  BPA_STAMP_NW(P, b, lane, 0);
   const uint32_t s0 = P.blk_slot_off[b], s1 = P.blk_slot_off[b+1];
   const LaneStatic ls = P.lane_tab[gl];
   const bool has_slot = ls.slot != 0xffffffffu;
@@ -3020,7 +3035,7 @@ step_s4_klane_v3_kernel(const PlanDev P)
   const uint32_t s_slot = __shfl(ls.slot, (int)src), s_kR = __shfl(k | R << 3, (int)src);
   const bool stager = ngroups >= 1 && ngroups <= 4 && gs < ngroups;
 
-  BPA_STAMP(P, b, lane, 1);
+  BPA_STAMP_NW(P, b, lane, 1);
   // ---- trip 2: slot record, header, the step's records of the wave's groups, the summing lanes' task
   uint32_t c_np = 0, c_l0 = 0, c_task = none;
   double c_lnl = 0;
@@ -3053,7 +3068,7 @@ step_s4_klane_v3_kernel(const PlanDev P)
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  BPA_STAMP(P, b, lane, 2);
+  BPA_STAMP_NW(P, b, lane, 2);
   // ---- trip 3, part 1: every update's two matrices, global -> LDS (lane 16 g + p brings chunk p ^ g of group g)
   double2 * pmw = s_pmx + (size_t)wave*maxops*64u;
   if (use_lds)
@@ -3076,8 +3091,7 @@ step_s4_klane_v3_kernel(const PlanDev P)
         const StepOp so = *reinterpret_cast<const StepOp *>(&s_rec[wave][gs][1 + o]);
         const uint32_t pm = c < 8u ? so.left_pmatrix : so.right_pmatrix;
         const double * g = st_pmat + ((size_t)pm*st_R + st_k)*16 + (size_t)(c & 7u)*2;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                         (__attribute__((address_space(3))) void *)(pmw + (size_t)o*64u), 16, 0, 0);
+        lds_dma16(g, pmw + (size_t)o*64u);
       }
     }
   }
@@ -3144,15 +3158,21 @@ step_s4_klane_v3_kernel(const PlanDev P)
             prevp = pc;
           }
         }
+        // the matrices have landed (this wave's own requests: vmcnt; the children read ahead come back with them).  The wait is
+        // made HERE, once per four updates, and shown to the compiler (the empty statements read-modify every register read
+        // ahead): left to its wait-count pass the first use of a child in update j is an s_waitcnt vmcnt(0) at a branch merge,
+        // i.e. every update would wait for the previous update's STORES to be acknowledged
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { asm volatile("" : "+v"(ch[j][0])); asm volatile("" : "+v"(ch[j][1])); }
+        asm volatile("" : "+v"(chb[0])); asm volatile("" : "+v"(chb[1]));
         if (!dma_waited)
         {
-          // the matrices have landed (this wave's own requests: vmcnt; the children come back with them)
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           dma_waited = true;
-          BPA_STAMP(P, b, lane, 3);
+          BPA_STAMP_NW(P, b, lane, 3);
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j)
@@ -3167,7 +3187,8 @@ step_s4_klane_v3_kernel(const PlanDev P)
             {
               d2v uu, ww;
               if (pf[j] & 1u) { uu = ch[j][0]; ww = ch[j][1]; }
-              else { const auto p = clv_ptr(lc); uu = __builtin_nontemporal_load(p); ww = __builtin_nontemporal_load(p + 1); }
+              else { const auto p = clv_ptr(lc); uu = __builtin_nontemporal_load(p); ww = __builtin_nontemporal_load(p + 1);
+                     asm volatile("" : "+v"(uu)); asm volatile("" : "+v"(ww)); }      // (a read at use: waited for inside its branch)
               lv[0] = uu.x; lv[1] = uu.y; lv[2] = ww.x; lv[3] = ww.y;
             }
             if (rc == fwd_clv) { rv[0] = fwd[0]; rv[1] = fwd[1]; rv[2] = fwd[2]; rv[3] = fwd[3]; }
@@ -3177,7 +3198,8 @@ step_s4_klane_v3_kernel(const PlanDev P)
               d2v uu, ww;
               if (pf[j] == 2u) { uu = ch[j][0]; ww = ch[j][1]; }
               else if (j == 0 && pf[j] == 3u) { uu = chb[0]; ww = chb[1]; }
-              else { const auto p = clv_ptr(rc); uu = __builtin_nontemporal_load(p); ww = __builtin_nontemporal_load(p + 1); }
+              else { const auto p = clv_ptr(rc); uu = __builtin_nontemporal_load(p); ww = __builtin_nontemporal_load(p + 1);
+                     asm volatile("" : "+v"(uu)); asm volatile("" : "+v"(ww)); }
               rv[0] = uu.x; rv[1] = uu.y; rv[2] = ww.x; rv[3] = ww.y;
             }
             const double2 * r = pmw + (size_t)(o0 + j)*64u + my_g*16u;
@@ -3224,7 +3246,7 @@ step_s4_klane_v3_kernel(const PlanDev P)
         }
       }
     }
-    BPA_STAMP(P, b, lane, 4);
+    BPA_STAMP_NW(P, b, lane, 4);
     if (work)
     {
       // K2 at the root (core_likelihood_avx.c:117-150): this category's frequency-weighted sum
@@ -3234,19 +3256,28 @@ step_s4_klane_v3_kernel(const PlanDev P)
       if (rc == fwd_clv) { c[0] = fwd[0]; c[1] = fwd[1]; c[2] = fwd[2]; c[3] = fwd[3]; }
       else if (rc < tips) expand_code(code_of(rc), c);
       else { const auto p = clv_ptr(rc); const d2v uu = __builtin_nontemporal_load(p), ww = __builtin_nontemporal_load(p + 1); c[0] = uu.x; c[1] = uu.y; c[2] = ww.x; c[3] = ww.y; }
-      const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
-      const double * f = par + par_matrix(R, 4, m) + pm_freqs(4);
-      tr = dot4_pair(f[0], f[1], f[2], f[3], c);
+      // (the category's matrix index and — in the same round trip — matrix 0's frequencies, which it names nearly always)
+      const double md = par[par_param_idx(R) + k];
+      const double * f0 = par + par_matrix(R, 4, 0) + pm_freqs(4);
+      double fr[4] = {f0[0], f0[1], f0[2], f0[3]};
+      const uint32_t m = (uint32_t)md;
+      if (m != 0u) { const double * f = par + par_matrix(R, 4, m) + pm_freqs(4); fr[0] = f[0]; fr[1] = f[1]; fr[2] = f[2]; fr[3] = f[3]; }
+      tr = dot4_pair(fr[0], fr[1], fr[2], fr[3], c);
     }
   }
   s_tr[lane] = tr;
   lds_barrier();                                   // (LDS only: a plain __syncthreads() would wait for this wave's CLV stores to be acknowledged)
-  BPA_STAMP(P, b, lane, 5);
+  BPA_STAMP_NW(P, b, lane, 5);
   double term = 0;
   if (work && k == 0)
   {
+    // (the category weights in ONE round trip: a load per turn of a loop with a run-time bound waits for each in turn)
     const double * par = S.par;
-    for (uint32_t q = 0; q < R; ++q) term += s_tr[lane + q*np]*par[par_rate_weights(R) + q];
+    double rwv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) rwv[q] = (uint32_t)q < R ? par[par_rate_weights(R) + q] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if ((uint32_t)q < R) term += s_tr[lane + q*np]*rwv[q];
     term = log(term)*ls.wgt;
     gst(P.site_term + hdr.pat_off + n, term);
   }
@@ -3255,11 +3286,22 @@ step_s4_klane_v3_kernel(const PlanDev P)
   // ---- per-locus sum in pattern order (the k = 0 lanes are the first np lanes of a locus)
   s_term[lane] = term;
   lds_barrier();
-  BPA_STAMP(P, b, lane, 6);
+  BPA_STAMP_NW(P, b, lane, 6);
   if (summer && c_task != none)
   {
+    // (pattern order, the reference's sequential sum; the terms come out of LDS eight at a time — one at a time every add
+    //  waited for its own read: ~100 cycles x np)
     double logl = 0;
-    for (uint32_t q = 0; q < c_np; ++q) logl += s_term[c_l0 + q];
+    uint32_t q = 0;
+    for (; q + 8u <= c_np; q += 8u)
+    {
+      double t8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t8[j] = s_term[c_l0 + q + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) logl += t8[j];
+    }
+    for (; q < c_np; ++q) logl += s_term[c_l0 + q];
     P.lnl[c_task] = P.bfbeta*logl;
     c_lnl = P.bfbeta*logl;
   }
@@ -3275,6 +3317,7 @@ step_s4_klane_v3_kernel(const PlanDev P)
       P.wg_part[b] = part;
     }
   }
+  BPA_STAMP_NW(P, b, lane, 7);
 }
 
 // pmatrix_wg_kernel with its serial chain cut down the way partials_lnl_pipe20_kernel's was: the wave-uniform chain

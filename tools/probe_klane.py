@@ -21,7 +21,7 @@ def mk(st):
 p0 = mk(init); p0.launch(); p0.lnl()
 L = bpp_amd.lib()
 L.bpa_plan_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]; L.bpa_plan_probe.restype = C.c_int
-names = ["entry", "lane table in", "slot + records in LDS", "matrices + children in", "updates done", "K2 + barrier", "site terms + barrier", "-"]
+names = ["entry", "lane table in", "slot + records in LDS", "matrices + children in", "updates issued", "K2 + barrier", "site terms + barrier", "end"]
 for st in it[:6]:
     p = mk(st)
     for _ in range(3): p.launch()
@@ -30,6 +30,6 @@ for st in it[:6]:
     assert L.bpa_plan_probe(p.h, out), bpp_amd.api._err()
     w = p.work()
     print(f"step: {w['node_updates']} node updates, {out[17]:.0f} workgroups, span {out[8]:.1f} us")
-    print("   since kernel start: " + " | ".join(f"{out[i]:.1f}" for i in range(7)))
-    print("   since own start:    " + " | ".join(f"{names[i]} {out[9+i]:.1f}" for i in range(7)))
+    print("   since kernel start: " + " | ".join(f"{out[i]:.1f}" for i in range(8)))
+    print("   since own start:    " + " | ".join(f"{names[i]} {out[9+i]:.1f}" for i in range(8)))
     p.close()
