@@ -1,5 +1,7 @@
+"""the burn-in rule round by round on a config-shaped set with the program's moves: python tools/burnin_trace.py [c3|c4] [loci]"""
 import sys, os
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, bpp_amd, bench
 from bpp_amd import synth
 key = sys.argv[1] if len(sys.argv) > 1 else "c4"
