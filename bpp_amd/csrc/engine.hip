@@ -1064,7 +1064,7 @@ static void launch_klane(const dim3 grid, hipStream_t st, hipEvent_t k0, hipEven
   static const bool env_v2 = getenv("BPA_KLANE_V2") != nullptr;
   if (!env_v2 && d.rec2_units >= 2u && d.rec2_units <= 16u)
   {
-    const size_t lds = (size_t)(PACK_BS/64)*(d.rec2_units - 1u)*1024u;
+    const size_t lds = (size_t)(PACK_BS/64)*BPA_KLANE_CH*1024u;            // (the wave's corner holds the matrices of BPA_KLANE_CH updates at a time)
     hipExtLaunchKernelGGL((step_s4_klane_v3_kernel<PACK_BS, FUSE_A>), grid, dim3(PACK_BS), lds, st, k0, k1, 0, d);
   }
   else

@@ -2953,16 +2953,18 @@ step_s4_klane_v2_kernel(const PlanDev P)
 // step_s4_klane_v2_kernel with its dependent round trips cut from ~2 per node update to 3 per STEP.  v2 walks a locus's update
 // list one record at a time: record -> (child CLV, the wave's P-matrix chunks) -> compute -> next record ..., i.e. 2 nops + 2
 // global round trips in series with ~150 cycles of arithmetic between them — rocprofv3 had 82 % of its wave-cycles waiting and
-// 32 % of its LDS cycles in bank conflicts (profiles/r4/profile_c3.json).  Here:
+// 32 % of its LDS cycles in bank conflicts (profiles/r4/profile_c3.json).  Here (a step of nops updates: 2 + ceil(nops / CH) trips):
 //   trip 1  the lane's table entry (as before);
 //   trip 2  the slot record and header AND every record of the step for the (at most four) groups the wave spans: lanes
 //           16 g .. 16 g + 15 bring the 16 sixteen-byte units of group g's record (header + up to 15 updates) into LDS — the
 //           update list is then read from LDS by index, no global load per update;
-//   trip 3  the P-matrices of ALL updates of the step, global -> LDS directly (global_load_lds_dwordx4: no registers, so the
-//           number in flight is not bounded by a static unroll) and the children of the first four updates that can be read
-//           ahead: inner nodes that no update of this step writes (a bit mask of the step's parents decides; a child that is
-//           the previous update's parent is forwarded in registers as before, a child written earlier in the step is read
-//           when it is used, after the lane's own store).
+//   trip 3  (once per CH = 2 updates) their P-matrices, global -> LDS directly (global_load_lds_dwordx4 from inline assembly,
+//           lds_dma16: no registers, and no s_waitcnt vmcnt(0) of the compiler's in front of every later ds_read) and their
+//           children that can be read ahead: inner nodes that no update of this step writes (a bit mask of the step's parents
+//           decides; a child that is the previous update's parent is forwarded in registers as before, a child written earlier
+//           in the step is read when it is used, after the lane's own store).  ONE explicit wait for all of it, shown to the
+//           compiler (empty read-modify statements on the registers read ahead), so that no update waits for an earlier
+//           update's stores.
 // Bank conflicts: the chunk j of group g sits at position 16 g + (j ^ g) of the wave's 1-KB corner, so lanes of different
 // groups reading "their" chunk j hit different banks (v2: all four groups on the same banks whenever a 16-lane service group
 // of ds_read_b128 spans two groups).  Arithmetic, operation order and stores are v2's: same bits.
@@ -2970,7 +2972,7 @@ step_s4_klane_v2_kernel(const PlanDev P)
 #define BPA_KLANE_OCC 4
 #endif
 #ifndef BPA_KLANE_CH
-#define BPA_KLANE_CH 4
+#define BPA_KLANE_CH 2
 #endif
 template <int BS, bool FUSE_A = false>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(FUSE_A ? 3 : BPA_KLANE_OCC, 8)))
@@ -3018,7 +3020,7 @@ step_s4_klane_v3_kernel(const PlanDev P)
   const uint32_t n = ls.n_np_tips & 511u, np = (ls.n_np_tips >> 9) & 511u;
   const uint32_t k = (ls.n_np_tips >> 23) & 7u, R = ls.n_np_tips >> 26;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(lane >> 6), wl = lane & 63u;
-  const uint32_t units = P.rec2_units, maxops = units - 1u;
+  const uint32_t units = P.rec2_units;
   static const uint32_t none = 0xffffffffu;
 
   // ---- the groups of this wave (a group = the lanes of one (locus, category)), from the lane table alone
@@ -3070,29 +3072,24 @@ step_s4_klane_v3_kernel(const PlanDev P)
 
   BPA_STAMP_NW(P, b, lane, 2);
   // ---- trip 3, part 1: every update's two matrices, global -> LDS (lane 16 g + p brings chunk p ^ g of group g)
-  double2 * pmw = s_pmx + (size_t)wave*maxops*64u;
+  // (the matrices of CH updates at a time — CH = 2, measured on config 3's full set: 87 us; CH = 4: 96 us with 10 spilled registers at
+  //  the 128 of four waves per SIMD; everything at once, round 5's first form: 90 us, 38 KB of LDS per workgroup; five or six waves per
+  //  SIMD spill 30-86 registers: 139-199 us — tools/ab_klane_occ.sh)
+  constexpr int CH = BPA_KLANE_CH;
+  double2 * pmw = s_pmx + (size_t)wave*CH*64u;
+  const double * st_pmat = nullptr;
+  uint32_t st_k = 0, st_R = 0, st_nops = 0;
+  const uint32_t st_c = gu ^ gs;
   if (use_lds)
   {
     const unsigned long long s_pm_lo = __shfl((uint32_t)reinterpret_cast<uintptr_t>(S.pmat), (int)src);
     const unsigned long long s_pm_hi = __shfl((uint32_t)(reinterpret_cast<uintptr_t>(S.pmat) >> 32), (int)src);
-    const double * st_pmat = reinterpret_cast<const double *>(s_pm_lo | s_pm_hi << 32);
-    const uint32_t st_k = s_kR & 7u, st_R = s_kR >> 3;
-    uint32_t st_nops = 0;
+    st_pmat = reinterpret_cast<const double *>(s_pm_lo | s_pm_hi << 32);
+    st_k = s_kR & 7u; st_R = s_kR >> 3;
     if (stager)
     {
       const StepRec sh = *reinterpret_cast<const StepRec *>(&s_rec[wave][gs][0]);
       st_nops = sh.task != none ? sh.nops : 0u;
-    }
-    const uint32_t c = gu ^ gs;
-    for (uint32_t o = 0; __any(o < st_nops); ++o)
-    {
-      if (o < st_nops)
-      {
-        const StepOp so = *reinterpret_cast<const StepOp *>(&s_rec[wave][gs][1 + o]);
-        const uint32_t pm = c < 8u ? so.left_pmatrix : so.right_pmatrix;
-        const double * g = st_pmat + ((size_t)pm*st_R + st_k)*16 + (size_t)(c & 7u)*2;
-        lds_dma16(g, pmw + (size_t)o*64u);
-      }
     }
   }
 
@@ -3123,10 +3120,19 @@ step_s4_klane_v3_kernel(const PlanDev P)
     {
       uint32_t written = 0;                                    // the CLV buffers (< 32: byte indices of <= 8-tip loci, 5 bits) this lane's step has written
       bool dma_waited = false;
-      constexpr int CH = BPA_KLANE_CH;
       for (uint32_t o0 = 0; __any(o0 < nops); o0 += (uint32_t)CH)
       {
-        // ---- trip 3, part 2 (and one more trip per further four updates): the children that can be read ahead
+        // ---- trip 3, part 1 (once per CH updates): these updates' matrices, global -> LDS
+        // (lane 16 g + p brings chunk p ^ g of group g; the reads of the previous four are behind this wave in program order)
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+          if (o0 + j < st_nops)
+          {
+            const StepOp so = *reinterpret_cast<const StepOp *>(&s_rec[wave][gs][1 + o0 + j]);
+            const uint32_t pm = st_c < 8u ? so.left_pmatrix : so.right_pmatrix;
+            lds_dma16(st_pmat + ((size_t)pm*st_R + st_k)*16 + (size_t)(st_c & 7u)*2, pmw + (size_t)j*64u);
+          }
+        // ---- trip 3, part 2: their children that can be read ahead
         uint2 opw[CH];
         d2v ch[CH][2], chb[2];
         uint32_t pf[CH];
@@ -3159,21 +3165,17 @@ step_s4_klane_v3_kernel(const PlanDev P)
           }
         }
         // the matrices have landed (this wave's own requests: vmcnt; the children read ahead come back with them).  The wait is
-        // made HERE, once per four updates, and shown to the compiler (the empty statements read-modify every register read
+        // made HERE, once per CH updates, and shown to the compiler (the empty statements read-modify every register read
         // ahead): left to its wait-count pass the first use of a child in update j is an s_waitcnt vmcnt(0) at a branch merge,
         // i.e. every update would wait for the previous update's STORES to be acknowledged
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int j = 0; j < CH; ++j) { asm volatile("" : "+v"(ch[j][0])); asm volatile("" : "+v"(ch[j][1])); }
         asm volatile("" : "+v"(chb[0])); asm volatile("" : "+v"(chb[1]));
-        if (!dma_waited)
-        {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          dma_waited = true;
-          BPA_STAMP_NW(P, b, lane, 3);
-        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!dma_waited) { dma_waited = true; BPA_STAMP_NW(P, b, lane, 3); }
 #pragma unroll
         for (int j = 0; j < CH; ++j)
         {
@@ -3202,7 +3204,7 @@ step_s4_klane_v3_kernel(const PlanDev P)
                      asm volatile("" : "+v"(uu)); asm volatile("" : "+v"(ww)); }
               rv[0] = uu.x; rv[1] = uu.y; rv[2] = ww.x; rv[3] = ww.y;
             }
-            const double2 * r = pmw + (size_t)(o0 + j)*64u + my_g*16u;
+            const double2 * r = pmw + (size_t)j*64u + my_g*16u;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
             {
