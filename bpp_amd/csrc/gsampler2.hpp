@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(64) gstep2_kernel(const gsm::GArgs A)
 struct GChain { uint32_t ngage, ngspr, pend, refresh_logpr; };
 constexpr uint32_t GCHAIN_THREADS = 64;          // one wave per locus: the lane group proposes, the 64 lanes share the patterns
 
-template <int NT>
+template <int NT, bool BPP = false>
 __global__ void __launch_bounds__(GCHAIN_THREADS) gchain_kernel(const gsm::GArgs A, const PlanDev P, const GChain ch)
 {
   __shared__ Step2LDS<NT> SH;
@@ -501,8 +501,8 @@ __global__ void __launch_bounds__(GCHAIN_THREADS) gchain_kernel(const gsm::GArgs
   {
     const bool gage = st < ch.ngage;
     C.k = gage ? st : st - ch.ngage;
-    if (gage) gstep2_body<0, NT, true>(A, C, SH, tid, i, tid < G);
-    else      gstep2_body<1, NT, true>(A, C, SH, tid, i, tid < G);
+    if (gage) gstep2_body<0, NT, true, BPP>(A, C, SH, tid, i, tid < G);
+    else      gstep2_body<1, NT, true, BPP>(A, C, SH, tid, i, tid < G);
     C.pend = 1u; C.refresh_logpr = 0u; C.pend_mode = gage ? 0u : 1u;
     __syncthreads();                                  // the step's records are out (written and read on this CU)
     if (A.active[i])

@@ -576,7 +576,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
 static bool gs_chain_wanted(const bpa_sampler * s)
 {
   const char * env = getenv("BPA_GS_CHAIN");
-  if (s->g_s20 || !s->eng->usedata || s->maxtips < 2 || s->kernel_bpp) return false;       // (the chain kernel draws from the uniform kernel only)
+  if (s->g_s20 || !s->eng->usedata || s->maxtips < 2) return false;
   if (env) return env[0] != '0';
   return s->g_alljc && s->nloci <= 1024u && s->g_npat <= 64u*s->nloci;
 }
@@ -597,6 +597,7 @@ static int gs_chain(bpa_sampler * s)
   a.pop_nc = s->pop_nc.p; a.pop_t2h = s->pop_t2h.p;
   a.sp = s->sp;
   a.pend_mode = s->g_pend_mode; a.pend_k = s->g_pend_k; a.sm = s->g_sm.p; a.sm_old = s->g_sm_old.p;
+  a.bpp = s->kernel_bpp ? 1u : 0u; a.prog = gs_prog(s) ? 1u : 0u; a.t2h3 = s->g_t2h3.p;
   a.fmt20 = 1u; a.maxops20 = s->g_maxops;
   a.ops20 = s->g_ops20.p; a.op_rng20 = s->g_oprng.p; a.root20 = s->g_root20.p; a.mat_task20 = s->g_mtask.p; a.mat_pm20 = s->g_mpm.p;
   a.i0 = 0; a.iend = s->nloci;
@@ -608,7 +609,12 @@ static int gs_chain(bpa_sampler * s)
   d.flags = 2u | 4u | 64u;
   gsm2::GChain ch{s->maxtips - 1, 2*s->maxtips - 2, s->g_pend, s->logpr_stale ? 1u : 0u};
   s->logpr_stale = false;
-  if (s->maxtips <= 8) hipLaunchKernelGGL((gsm2::gchain_kernel<8>), dim3(s->nloci), dim3(gsm2::GCHAIN_THREADS), 0, e->stream, a, d, ch);
+  if (s->kernel_bpp)
+  {
+    if (s->maxtips <= 8) hipLaunchKernelGGL((gsm2::gchain_kernel<8, true>), dim3(s->nloci), dim3(gsm2::GCHAIN_THREADS), 0, e->stream, a, d, ch);
+    else                 hipLaunchKernelGGL((gsm2::gchain_kernel<16, true>), dim3(s->nloci), dim3(gsm2::GCHAIN_THREADS), 0, e->stream, a, d, ch);
+  }
+  else if (s->maxtips <= 8) hipLaunchKernelGGL((gsm2::gchain_kernel<8>), dim3(s->nloci), dim3(gsm2::GCHAIN_THREADS), 0, e->stream, a, d, ch);
   else                 hipLaunchKernelGGL((gsm2::gchain_kernel<16>), dim3(s->nloci), dim3(gsm2::GCHAIN_THREADS), 0, e->stream, a, d, ch);
   HIPCHK(hipGetLastError());
   s->launches++; s->g_evals += ch.ngage + ch.ngspr;
