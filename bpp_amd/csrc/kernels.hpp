@@ -2723,7 +2723,10 @@ step_s4_klane_v2_kernel(const PlanDev P)
     if (lane < q1 - q0)
     {
       const LocusDev & L = P.loci[P.slot_tab[q0 + lane].locus];
-      for (uint32_t m = 0; m < L.rate_matrices; ++m)
+      // (a JC69 locus — the other loci of a composite's packing — has no eigensystem.  NOT "only the loci with a record in this
+      //  step": a locus whose rejected parameter proposal was just rolled back may sit this step out, and the refresh is owed once)
+      const bool mine = L.model != 0u;
+      for (uint32_t m = 0; mine && m < L.rate_matrices; ++m)
       {
         double * pm = L.par + par_matrix(L.rate_cats, 4, m);
         update_eigen_regs<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
@@ -2988,7 +2991,10 @@ step_s4_klane_v3_kernel(const PlanDev P)
     if (lane < q1 - q0)
     {
       const LocusDev & L = P.loci[P.slot_tab[q0 + lane].locus];
-      for (uint32_t m = 0; m < L.rate_matrices; ++m)
+      // (a JC69 locus — the other loci of a composite's packing — has no eigensystem.  NOT "only the loci with a record in this
+      //  step": a locus whose rejected parameter proposal was just rolled back may sit this step out, and the refresh is owed once)
+      const bool mine = L.model != 0u;
+      for (uint32_t m = 0; mine && m < L.rate_matrices; ++m)
       {
         double * pm = L.par + par_matrix(L.rate_cats, 4, m);
         update_eigen_regs<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
