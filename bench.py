@@ -99,6 +99,19 @@ def compact_line(full):
             out["ess_per_iteration"] = epi
         if se.get("ratio_ess_per_iteration"):
             out["ess_per_iteration_ratio"] = {k: [v["value"], v["se"]] for k, v in se["ratio_ess_per_iteration"].items() if isinstance(v, dict)}
+            out["ess_per_iteration_ratio"]["samples"] = [(se.get("device") or {}).get("samples"), (se.get("reference_program") or {}).get("samples")]
+        # the committed long runs on the SAME data for both chains (tools/ess_device_vs_program.py): [ratio, standard error] — a
+        # builder-run measurement inside a driver-run line, labelled as such
+        try:
+            import glob
+            lr = {}
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "ess_*.json"))):
+                e_ = json.load(open(f))
+                lr[f"{e_['nloci']}x{e_['samples']}"] = {k: [e_[k + "_ratio"]["value"], e_[k + "_ratio"]["se"]] for k in ("tau_root", "theta_root")}
+            if lr:
+                out["ess_per_iteration_ratio_committed_runs"] = lr
+        except Exception:       # noqa: BLE001
+            pass
     if lo:
         r = lo.get("roofline") or {}
         out["likelihood_only"] = {"it_s": lo.get("iterations_per_s"), "kernel": (r.get("kernel") or "")[:50], "frac": r.get("frac"),
@@ -152,7 +165,7 @@ def compact_line(full):
         out["configs"] = cfgs
     out["full_record"] = "bench_full.json"
     # never let the line outgrow the driver's capture: drop the optional parts, least important first
-    for victim in ("share_it_s", "host_control_in_c_it_s", "uniform_moves_it_s", "ess_per_iteration", "likelihood_only", "configs", "ess_per_s"):
+    for victim in ("share_it_s", "host_control_in_c_it_s", "uniform_moves_it_s", "ess_per_iteration_ratio_committed_runs", "ess_per_iteration", "likelihood_only", "configs", "ess_per_s"):
         if len(json.dumps(out, separators=(",", ":"))) <= LINE_LIMIT:
             break
         out.pop(victim, None)
