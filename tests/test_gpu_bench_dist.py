@@ -71,3 +71,27 @@ def test_two_rank_bench_line_carries_both_scalings():
     assert d["scaling"] == "weak" and d["value"] == d["value_weak"] > 0
     assert d["value_strong"] and d["value_strong"] > 0, (d.get("scaling_other_mode"), err[-1500:])
     assert d["scaling_other_mode"]["scaling"] == "strong" and d["scaling_other_mode"]["loci_total"] == 1500
+
+
+def test_one_gpu_bench_line_quick():
+    """the driver's own form (`python bench.py --gpus 1 --steps K --warmup W`) with the side sections switched off: the last
+    stdout line is the compact object with the contract's keys, `roofline` with its three fractions and a warning-free `frac`,
+    the full record goes where --full-record says"""
+    import tempfile
+    full_path = os.path.join(tempfile.mkdtemp(prefix="bench1_"), "full.json")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--loci", "2000", "--no-cpu-baseline",
+           "--no-other-configs", "--no-host-control", "--no-scale-projection", "--no-uniform-kernel", "--full-record", full_path]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) <= 8192
+    d = json.loads(last)
+    full = json.load(open(full_path))
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["value"] == full["value"] > 0
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["higher_is_better"] is True and d["config"]["workload"]
+    rl = d["roofline"]
+    assert rl["bound"] == "hbm" and 0 < rl["frac"] < 0.79 and "warning" not in rl and rl["frac_codes"] <= rl["frac"] and rl["flops_frac"] > 0
+    smp = full["device_resident_sampler"]
+    assert smp["kind"] == "persistent" and smp["moves"].startswith("the program's") and smp["step_lengths_after_burnin"]["gage"] > 0
+    lo = d["likelihood_only"]
+    assert lo["it_s"] > 0 and lo["frac_codes"] <= lo["frac"]
