@@ -152,6 +152,8 @@ def compact_line(full):
                 c[k] = r[k]
         if r.get("kernel"):
             c["kernel"] = r["kernel"].split("<")[0]
+        if r.get("warning"):
+            c["frac_warning"] = "frac > 0.79 of HBM peak is an accounting artefact (8d charges tip children as CLVs): read frac_codes / frac_pmc"
         rs = smp.get("roofline") or {}
         if rs.get("frac") is not None:
             c["sampler_frac"] = rs.get("frac")
