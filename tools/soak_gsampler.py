@@ -20,7 +20,12 @@ co = hostdrv.hip_driver_cohorts([e1, e2], tape.make_engine_loci(e1, data[:split]
 ldev = tape.make_engine_loci(e3, data)
 dev = bpp_amd.Sampler(e3, ldev, data, seed=5)
 parent, tau0, thetas = synth.species_tree_arrays(taxa)
+PROGRAM = bool(os.environ.get("SOAK_PROGRAM"))       # BPP's own iteration (its proposal kernel + the program's THETA / TAU / MIX) on all three
+TOL = 1e-8 if PROGRAM else 1e-10                      # (the program's windows and re-draws go through libm on both sides: ~1e-13 per draw)
 for d in (plain, co, dev):
+    if PROGRAM:
+        d.set_proposal_kernel(1)
+        d.set_program_moves(True, 0.1)
     d.set_species_tree(parent, tau0, thetas)
     d.set_tau_prior(3.0, 3.0 / tau0[-1])
     d.set_theta_prior(2.0, 1000.0, 0.0004)
@@ -38,20 +43,31 @@ for b in range(blocks):
         plain.iterate(); co.iterate()
     dev.iterate(per)
     s = dev.summary(); hp, ha, _ = plain.counters(); cp, ca, _ = co.counters()
-    same_co = (hp, ha) == (cp, ca) and plain.taus() == co.taus() and plain.thetas() == co.thetas() and plain.total_lnl() == co.total_lnl()
-    same_dev = (s["proposals"], s["accepted"]) == (hp, ha) and bool(np.allclose(dev.taus(), plain.taus(), rtol=1e-10, atol=0)) \
-        and bool(np.allclose(dev.thetas(), plain.thetas(), rtol=1e-10, atol=0))
+    same_co = (hp, ha) == (cp, ca) and (PROGRAM or (plain.taus() == co.taus() and plain.thetas() == co.thetas() and plain.total_lnl() == co.total_lnl()))
+    same_dev = (s["proposals"], s["accepted"]) == (hp, ha) and bool(np.allclose(dev.taus(), plain.taus(), rtol=TOL, atol=0)) \
+        and bool(np.allclose(dev.thetas(), plain.thetas(), rtol=TOL, atol=0))
     bad = worst = 0
     for i in range(nloci):
         a, h, c = dev.tree(i), plain.tree(i), co.tree(i)
-        if h != c:
+        if h != c and not PROGRAM:
             bad += 1
-        if [int(x) for x in a["parent"]] != list(h["parent"]) or not np.allclose(a["time"], h["time"], rtol=1e-10, atol=0):
+        if [int(x) for x in a["parent"]] != list(h["parent"]) or not np.allclose(a["time"], h["time"], rtol=TOL, atol=0):
             bad += 1
+            ta, th = np.array(a["time"]), np.array(h["time"]); m = th > 0
+            print(f"   locus {i}: topology equal {[int(x) for x in a['parent']] == list(h['parent'])}, worst relative age difference {float(np.max(np.abs(ta[m] - th[m]) / th[m])):.2e}", flush=True)
         if i % 10 == 0:
             have = ldev[i].root_loglikelihood(int(a["clv"][a["root"]]), -1)
             worst = max(worst, abs(have - a["lnl"]) / abs(have))
     print(f"block {b}: {per*(b+1)} iterations, proposals {s['proposals']} accepted {s['accepted']}; cohorts == plain: {same_co}; device == plain: {same_dev}; "
           f"loci that differ: {bad}; device lnL vs its buffers, worst rel: {worst:.1e}; lnL {s['total_lnl']:.4f} / {plain.total_lnl():.4f}", flush=True)
+    if PROGRAM:
+        # BPP's windows go through log / sqrt on the device and through glibc on the host driver: every proposal differs in its last
+        # bit, the chain's own dynamics (rubber-band factors, mixing) grow that to ~1e-7 in 10-20 iterations, and some decision with
+        # ln(alpha) within that of ln(u) then falls the other way — from there on the two are different chains of the same sampler.
+        # What is asserted: the first block (10 iterations: ~900 000 proposals) takes the same decisions, every state is consistent
+        assert worst < 1e-11 and same_co
+        if b == 0:
+            assert (s["proposals"], s["accepted"]) == (hp, ha)
+        continue
     assert same_co and same_dev and bad == 0 and worst < 1e-11
 print("soak ok")
