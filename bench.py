@@ -930,7 +930,7 @@ class Dist:
         if int(flag.item()) != 1:
             p2p = None
         elif p2p is not None:
-            p2p.set_timeout_ms(200)       # inside timed regions a lost flag costs 0.2 s once, then the run is repeated over RCCL
+            p2p.set_timeout_ms(1000)      # inside timed regions a lost flag costs 1 s once, then the section is repeated over RCCL
         self.p2p = p2p
         log("sums between ranks: " + ("one-shot p2p all-reduce (self-test against RCCL passed)" if p2p else "RCCL all-reduce"))
 
@@ -1415,12 +1415,13 @@ def main():
     ap.add_argument("--c4-divergence", type=float, default=None,
                     help="config 4: divergence factor of the synthetic amino-acid set (default 3: ~195 patterns per locus; 1: SURVEY 8d's literal theta 0.02 / tau_root 0.05, 105 patterns)")
     ap.add_argument("--p2p", action="store_true",
-                    help="N > 1: exchange the all-loci sums INSIDE the persistent kernel through peer-mapped mailboxes over xGMI (self-tested "
-                         "against RCCL at start-up; the program's moves then run at N > 1 too).  Default: a native RCCL all-reduce per "
-                         "all-loci step (north_star's wording) — opt-in until the mailboxes have run on two physical GPUs")
+                    help="(the default at N > 1 since round 5; accepted for old command lines) exchange the all-loci sums INSIDE the "
+                         "persistent kernel through peer-mapped mailboxes over xGMI: the program's moves then run at N > 1 too.  The "
+                         "mailboxes are self-tested against RCCL on every rank at start-up, every wait is bounded, and a rank that "
+                         "times out sends the whole section back over RCCL (--no-p2p's path)")
     ap.add_argument("--no-p2p", action="store_true",
                     help="N > 1: no peer-mapped mailboxes at all — the sampler then runs its all-loci steps one launch each with a "
-                         "native RCCL all-reduce in between (the persistent kernel only for the per-locus sweeps)")
+                         "native RCCL all-reduce in between (the persistent kernel only for the per-locus sweeps; north_star's wording)")
     ap.add_argument("--sum-launch", action="store_true",
                     help="produce the total of an all-loci step with a launch of its own (default: per-workgroup partial sums written by the step kernel)")
     ap.add_argument("--event-stride", type=int, default=7,
@@ -1471,7 +1472,7 @@ def main():
     npat = sum(len(d["weights"]) for d in data)
     log(f"dataset: {nloci} loci on rank 0, {npat} patterns ({npat / nloci:.2f}/locus) in {time.time() - t0:.1f}s ({args.scaling})")
     loci = make_loci(eng, data)
-    if D is not None and args.p2p and not args.no_p2p:
+    if D is not None and not args.no_p2p and not os.environ.get("BENCH_NO_P2P"):
         # the mailboxes of the one-shot exchange over xGMI peer mappings (self-tested against RCCL on every rank): the
         # device-resident sampler exchanges its sums through them INSIDE its persistent kernel; the tape only with --p2p-sums
         D.setup_p2p(eng, 256)
@@ -1495,9 +1496,11 @@ def main():
         om = "strong" if args.scaling == "weak" else "weak"
         try:
             d_o, fl_o = make_data(om)
-            e_o = bpp_amd.Engine(local_rank, D.stream)
+            # (the mailboxes belong to the first engine: with them the other mode's loci live there too)
+            e_o = eng if D.p2p is not None else bpp_amd.Engine(local_rank, D.stream)
             s_o = run_sampler(e_o, cfg, d_o, make_loci(e_o, d_o), args, D, fl_o, max(args.steps // 2, 5), args.warmup)
-            e_o.close()
+            if e_o is not eng:
+                e_o.close()
             other_mode = dict(scaling=om, iterations_per_s=s_o.get("iterations_per_s"), iterations_per_s_10k_loci=s_o.get("iterations_per_s_10k_loci"),
                               loci_total=s_o.get("loci_total"), ms_per_iteration=s_o.get("ms_per_iteration"), kind=s_o.get("kind"), error=s_o.get("error"))
         except Exception as ex:       # noqa: BLE001

@@ -42,10 +42,11 @@ def run_bench(extra, tmp=None):
 
 @pytest.mark.parametrize("p2p,scaling", [(False, "weak"), (True, "weak"), (True, "strong")])      # (the default exchange with ONE data set: the test below)
 def test_two_rank_bench_line(p2p, scaling):
-    """p2p = False: the DEFAULT N > 1 path — one all-reduce per all-loci step through the library's callback (RCCL on the
-    driver's box, the framework's gloo collective here), the per-locus sweeps by the persistent kernel ("hybrid");
-    p2p = True (--p2p): the sums exchanged inside the persistent kernel through peer-mapped mailboxes, the program's moves"""
-    d, err = run_bench(["--scaling", scaling] + (["--p2p", "--p2p-sums"] if p2p else []))
+    """p2p = False (--no-p2p, also what a failed mailbox self-test falls back to): one all-reduce per all-loci step through the
+    library's callback (RCCL on the driver's box, the framework's gloo collective here), the per-locus sweeps by the persistent
+    kernel ("hybrid"); p2p = True, the DEFAULT at N > 1: the sums exchanged inside the persistent kernel through peer-mapped
+    mailboxes, the program's moves"""
+    d, err = run_bench(["--scaling", scaling] + (["--p2p-sums"] if p2p else ["--no-p2p"]))
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == scaling and d["value"] > 0
     assert d["allreduce_check"] == "ok"
     assert ("p2p" in d["allreduce"]["tape"]) == p2p, (d["allreduce"], err[-1500:])
@@ -69,6 +70,7 @@ def test_two_rank_bench_line_carries_both_scalings():
     """without --scaling: `value` = the config's own mode (c2: weak) and the other mode's sampler rate is measured in the same run"""
     d, err = run_bench(["--no-tape"])
     assert d["scaling"] == "weak" and d["value"] == d["value_weak"] > 0
+    assert "persistent kernel" in d["allreduce"]["sampler"], d["allreduce"]          # (no flag: the in-kernel exchange)
     assert d["value_strong"] and d["value_strong"] > 0, (d.get("scaling_other_mode"), err[-1500:])
     assert d["scaling_other_mode"]["scaling"] == "strong" and d["scaling_other_mode"]["loci_total"] == 1500
 
