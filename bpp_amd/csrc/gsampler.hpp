@@ -94,6 +94,9 @@ struct GArgs
   double tau_w;                           // bpp: the TAU window itself (the host's Bactrian-Laplace variate; tau_u - 1/2 would round)
   uint32_t bpp, prog;                     // the reference's generator / windows / acceptance rule (bpa_sampler_set_proposal_kernel); the program's THETA / TAU / MIX, decided on the host
   double * t2h3;                          // [T][3] prog, TAU q: the T2h of q and of its two children after the move
+  // 4-state loci on the engine's packing: the lane group that wrote the step's fresh branches also fills their P-matrices
+  // (what pmatrix_s4_dense_kernel did as a launch of its own between the proposal and the node updates)
+  const SlotStatic * slot_tab; uint32_t fuse_pm;
   Species sp;
 };
 

@@ -23,6 +23,7 @@ template <int NT> struct LocLDS
 {
   double time[2*NT];
   double contrib[2*NT], contrib_new[2*NT];
+  alignas(16) double pmblk[48];           // fuse_pm: the parameter block of the locus's first substitution matrix (46 doubles)
 };
 
 // what changes from step to step (a launch takes it from its arguments, the chain kernel below counts it itself)
@@ -112,6 +113,21 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
     pl.ptau = pl.parent >= 0 ? s_tau[pl.parent] : -1.0;
   }
   LocLDS<NT> & S = s_loc[slot];
+  // fuse_pm (step 4 fills the fresh branches' P-matrices): what that needs of the locus is asked for NOW and arrives while
+  // the proposal is made — the lane's category rate, the matrix index, the first matrix's parameter block (dealt over the
+  // group's lanes, handed over through LDS), the P-matrix buffer
+  constexpr uint32_t PMB = 46;                                  // par_matrix_stride(4)
+  constexpr int NPF = (int)((PMB + (uint32_t)G - 1u)/(uint32_t)G);
+  double pf_pm[NPF], pf_rate = 0; uint32_t pf_mi = 0, pf_model = 0, pf_pstride = 0; double * pf_pmat = nullptr;
+  if (A.fuse_pm)
+  {
+    const uint32_t R = L.R, k0 = (uint32_t)li % R;
+    pf_rate = L.par[par_rates(R) + k0]; pf_mi = (uint32_t)L.par[par_param_idx(R) + k0];
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) { const uint32_t x = (uint32_t)li + (uint32_t)(q*G); pf_pm[q] = L.par[par_matrix(R, 4, 0) + (x < PMB ? x : 0u)]; }
+    const SlotStatic & M = A.slot_tab[L.slot];
+    pf_pmat = M.pmat; pf_model = M.model; pf_pstride = M.pstride;
+  }
   GS2_T(1);
 
   // ---- 1. settle the step whose evaluation just finished (gstep_kernel's step 1): the decision, from registers
@@ -413,6 +429,38 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
       ml[li] = (S.time[(int)T.parent[x]] - S.time[x])*1.0;                                // rate_mui = 1 (locus.c:2350)
     }
     else if ((uint32_t)li < A.maxmat) m2[li] = MatRec2{0xffffffffu, 0u};                    // entries of the last step this one does not use
+    if (A.fuse_pm)
+    {
+      // the fresh branches' P-matrices, one (branch, rate category) per lane of the group and round: the arithmetic of
+      // pmatrix_s4_dense_kernel (pmatrix_s4_core), the launch it was is gone.  The host leaves this off while a
+      // substitution-parameter step is pending (its roll-back and the eigensystems' refresh come first: gs_step)
+#pragma unroll
+      for (int q = 0; q < NPF; ++q) { const uint32_t x = (uint32_t)li + (uint32_t)(q*G); if (x < PMB) S.pmblk[x] = pf_pm[q]; }
+      smp2::wsync();
+      const uint32_t R = L.R, k0 = (uint32_t)li % R;
+      for (uint32_t q = (uint32_t)li; q < (uint32_t)nbr*R; q += (uint32_t)G)
+      {
+        const uint32_t j = q/R, k = q - j*R;
+        const int x = nth_bit(brm, (int)j);
+        double * dst = pf_pmat + (size_t)T.pidx(x)*R*pf_pstride;
+        const double t = (S.time[(int)T.parent[x]] - S.time[x])*1.0;
+        const double rate = k == k0 ? pf_rate : L.par[par_rates(R) + k];
+        const uint32_t mi = pf_model == 0 ? 0u : k == k0 ? pf_mi : (uint32_t)L.par[par_param_idx(R) + k];
+        double pmv[PMB];                                        // (constant indices below: registers)
+        if (mi == 0)
+        {
+#pragma unroll
+          for (uint32_t u = 0; u < PMB; u += 2) { const d2v_t v = *(const __attribute__((address_space(3))) d2v_t *)(&S.pmblk[u]); pmv[u] = v.x; pmv[u + 1] = v.y; }
+        }
+        else
+        {
+          const double * gp = L.par + par_matrix(R, 4, mi);
+#pragma unroll
+          for (uint32_t u = 0; u < PMB; ++u) pmv[u] = *(const __attribute__((address_space(1))) double *)(gp + u);
+        }
+        pmatrix_s4_core(dst, pf_model, rate, pmv, t, k);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < NT - 1; ++k)
       if (k < nops && li == k)

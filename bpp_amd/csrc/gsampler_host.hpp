@@ -230,6 +230,16 @@ static int gs_upload(bpa_sampler * s)
 // the program's THETA / TAU / MIX, decided on the host (BPP's proposal kernel + bpa_sampler_set_program_moves + a theta prior + a theta to move)
 static bool gs_prog(const bpa_sampler * s) { return s->kernel_bpp && s->sp.program_moves && s->sp.theta_alpha > 0 && s->sp.npop > s->sp.S; }
 
+// BPA_GS_FUSEA=1: the eigensystem refresh and the P-matrix phase inside the node-update launch (step_s4_klane kernels with
+// FUSE_A).  Rounds 4's default for sets of up to 1 536 workgroups of the packing (config 3, 1 250 loci: 546 -> 567 it/s; slower
+// above: 10 000 loci 189 -> 173); since round 5 the proposal's lane groups fill the step's P-matrices (gs_step: fuse_pm), which
+// is ahead at every size (1 250 loci 507 -> 513 it/s, 2 500: 408 -> 423, 10 000: 194 -> 207), so this is a switch only
+static bool gs_fuse_a(const bpa_sampler * s)
+{
+  const char * fa_env = getenv("BPA_GS_FUSEA");
+  return !s->g_alljc && !s->g_s20 && fa_env && fa_env[0] == '1';
+}
+
 static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u = 0, double mix_c = 1.0, double mix_lnc = 0, double tau_w = 0)
 {
   bpa_engine * e = s->eng;
@@ -250,6 +260,7 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   a.ops20 = s->g_ops20.p; a.op_rng20 = s->g_oprng.p; a.root20 = s->g_root20.p; a.mat_task20 = s->g_mtask.p; a.mat_pm20 = s->g_mpm.p;
   a.ft_freqs = s->g_ft[0]; a.ft_qrates = s->g_ft[1]; a.ft_alpha = s->g_ft[2]; a.alpha_a = s->g_alpha_a; a.alpha_b = s->g_alpha_b;
   a.bpp = s->kernel_bpp ? 1u : 0u; a.prog = gs_prog(s) ? 1u : 0u; a.t2h3 = s->g_t2h3.p; a.tau_w = tau_w;
+  a.slot_tab = e->d_slot_tab.p;
   // a frequency / exchangeability step — proposed now, or rolled back now for the loci that rejected it — leaves
   // parameter blocks whose eigensystems are stale: refreshed before the next evaluation (gs_eval)
   if (mode == 6 || mode == 7 || (s->g_pend == 4 && (s->g_pend_mode == 6 || s->g_pend_mode == 7))) s->g_eigen_dirty = true;
@@ -267,6 +278,17 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
     else switch (a.mode) { case 0: hipLaunchKernelGGL((gsm::gstep_kernel<0, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; case 1: hipLaunchKernelGGL((gsm::gstep_kernel<1, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; \
                            case 2: hipLaunchKernelGGL((gsm::gstep_kernel<2, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; default: hipLaunchKernelGGL((gsm::gstep_kernel<3, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; } } while (0)
   static const bool gs_diff = getenv("BPA_GS_DIFF") != nullptr;
+  static const bool gs_v1 = getenv("BPA_GS_V1") != nullptr;
+  // the step's P-matrices by the proposal's lane groups (gstep2_body) instead of a launch of their own: 4-state loci on the
+  // packing whose step launch does not make them itself (gs_fuse_a), no substitution-parameter step pending or rolled back
+  // since the eigensystems were last refreshed (BPA_GS_FUSEPM=0: the dense launch)
+  s->g_pm_fused = false;
+  if (mode <= 3 && !gs_v1 && !gs_diff && !s->g_s20 && !s->g_alljc && e->usedata && s->g_pend != 4 && !s->g_eigen_dirty && !gs_fuse_a(s))
+  {
+    const char * pf_env = getenv("BPA_GS_FUSEPM");
+    s->g_pm_fused = !(pf_env && pf_env[0] == '0');
+  }
+  a.fuse_pm = s->g_pm_fused ? 1u : 0u;
   if (s->kernel_bpp && mode <= 3 && (gs_diff || getenv("BPA_GS_V1"))) return fail("bpa_sampler: BPP's proposal kernel has no one-lane form (BPA_GS_DIFF / BPA_GS_V1 are the uniform kernel's diagnostics)");
   if (gs_diff && mode <= 3 && !s->g_forked)
   {
@@ -373,7 +395,6 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
     const dim3 grid((a.iend - a.i0 + gsm::GBS - 1)/gsm::GBS), block(gsm::GBS);
     hipStream_t st = h ? s->g_stream2 : e->stream;
     // GAGE / GSPR / TAU / MIX: a group of lanes per locus (gsampler2.hpp; BPA_GS_V1=1: the one-lane-per-locus kernel)
-    static const bool gs_v1 = getenv("BPA_GS_V1") != nullptr;
     if (a.mode <= 3 && !gs_v1)
     {
       const unsigned lpw = s->maxtips <= 8 ? 4u : 2u;
@@ -490,11 +511,9 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     s->launches += fuse_sum ? 2 : 3; s->g_evals++;
     return 1;
   }
-  // a small multi-category set: the eigensystem refresh and the P-matrix phase inside the step launch (BPA_GS_FUSEA=0 / 1: never /
-  // always).  Measured on config 3: 1 250 loci 546 -> 567 it/s (P-matrix phase), 5 000 loci 308 -> 296, 10 000 loci 189 -> 173:
-  // up to 1 536 workgroups of the packing
-  const char * fa_env = getenv("BPA_GS_FUSEA");
-  const bool fuse_a = !s->g_alljc && (fa_env ? fa_env[0] != '0' : e->pack_blocks <= 1536u);
+  const bool fuse_a = gs_fuse_a(s);
+  const bool pm_done = s->g_pm_fused && !fuse_a;
+  s->g_pm_fused = false;
   const bool fuse_eigen = fuse_a && s->g_eigen_dirty;
   if (fuse_eigen) s->g_eigen_dirty = false;
   else if (!gs_refresh_eigen(s)) return 0;
@@ -538,10 +557,10 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
           continue;
         }
         d.flags = 1u;
-        hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3(((e1 - e0)*d.pad + 255u)/256u), dim3(256), 0, st, d, e1);
+        if (!pm_done) hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3(((e1 - e0)*d.pad + 255u)/256u), dim3(256), 0, st, d, e1);
         d.flags = 2u | 4u;
         launch_klane<false>(dim3(b1 - b0), st, h ? nullptr : k0, h ? nullptr : k1, d);
-        s->launches += 2;
+        s->launches += pm_done ? 1 : 2;
       }
       HIPCHK(hipGetLastError());
       s->g_evals += 2;
@@ -556,10 +575,10 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     else
     {
       d.flags = 1u;
-      hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((d.nmat*d.pad + 255u)/256u), dim3(256), 0, e->stream, d, d.nmat);
+      if (!pm_done) hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((d.nmat*d.pad + 255u)/256u), dim3(256), 0, e->stream, d, d.nmat);
       d.flags = 2u | 4u;
       launch_klane<false>(grid, e->stream, k0, k1, d);
-      s->launches += 2;
+      s->launches += pm_done ? 1 : 2;
     }
   }
   HIPCHK(hipGetLastError());

@@ -1638,15 +1638,14 @@ __global__ void __launch_bounds__(BPA_BLOCK) pmatrix_s4_kernel(const PlanDev P, 
 // Latency is the enemy here (config 2: 5 patterns x 2 updates per locus), so the
 // descriptors are flattened (TaskRec/MatRec) and every load that does not depend on
 // phase A is issued before it.
-__device__ __forceinline__ void pmatrix_s4_rec(const MatRec & m, const double * __restrict__ mat_length, const uint32_t k)
+// one (branch, rate category) P-matrix from the category's rate and the parameter block of its matrix (device_types.hpp:
+// freqs | substitution parameters | eigenvalues | eigenvectors | inverse eigenvectors; not read for JC69)
+__device__ __forceinline__ void pmatrix_s4_core(double * dst_base, const uint32_t model, const double rate, const double * __restrict__ pm,
+                                                const double t, const uint32_t k)
 {
-  const uint32_t R = m.rate_cats;
-  const double * par = m.par;
-  const double t = mat_length[m.entry];
-  const double rate = par[par_rates(R) + k];
   double q[16];
   const double bl = t*rate;
-  if (m.model == 0 /* JC69, locus.c:2342-2414: stored as the pair (a, b) */)
+  if (model == 0 /* JC69, locus.c:2342-2414: stored as the pair (a, b) */)
   {
     double2 ab; ab.x = 1.0; ab.y = 0.0;
     if (!(bl < 1e-100))
@@ -1654,26 +1653,34 @@ __device__ __forceinline__ void pmatrix_s4_rec(const MatRec & m, const double * 
       ab.x = (1 + 3*exp(-4*bl/3))/4;
       ab.y = (1 - ab.x)/3;
     }
-    *reinterpret_cast<double2 *>(m.dst + (size_t)k*2) = ab;
+    d2v_t abv; abv.x = ab.x; abv.y = ab.y;
+    *reinterpret_cast<__attribute__((address_space(1))) d2v_t *>(reinterpret_cast<uintptr_t>(dst_base + (size_t)k*2)) = abv;
     return;
   }
-  else if (m.model >= 1 && m.model <= 6)
-  {
-    const uint32_t mi = (uint32_t)par[par_param_idx(R) + k];
-    const double * pm = par + par_matrix(R, 4, mi);
-    pmatrix_dna_closed(m.model, pm + pm_freqs(4), pm + pm_subst(4), bl, q);
-  }
+  else if (model >= 1 && model <= 6)
+    pmatrix_dna_closed(model, pm + pm_freqs(4), pm + pm_subst(4), bl, q);
   else if (bl < 1e-100)
     pmatrix_identity(q, 4);
   else
-  {
-    const uint32_t mi = (uint32_t)par[par_param_idx(R) + k];
-    const double * pm = par + par_matrix(R, 4, mi);
     pmatrix_eigen_4x4(q, t, rate, pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
-  }
-  double2 * dst = reinterpret_cast<double2 *>(m.dst + (size_t)k*16);
+  // (the P-matrix buffers are device memory: a global store, not a flat one that the wave's next LDS wait would wait for)
+  auto * dst = reinterpret_cast<__attribute__((address_space(1))) d2v_t *>(reinterpret_cast<uintptr_t>(dst_base + (size_t)k*16));
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { double2 v; v.x = q[2*i]; v.y = q[2*i+1]; dst[i] = v; }
+  for (int i = 0; i < 8; ++i) { d2v_t v; v.x = q[2*i]; v.y = q[2*i+1]; dst[i] = v; }
+}
+
+__device__ __forceinline__ void pmatrix_s4_rec_t(const MatRec & m, const double t, const uint32_t k)
+{
+  const uint32_t R = m.rate_cats;
+  const double * par = m.par;
+  const double rate = par[par_rates(R) + k];
+  const double * pm = par;
+  if (m.model != 0) pm = par + par_matrix(R, 4, (uint32_t)par[par_param_idx(R) + k]);
+  pmatrix_s4_core(m.dst, m.model, rate, pm, t, k);
+}
+__device__ __forceinline__ void pmatrix_s4_rec(const MatRec & m, const double * __restrict__ mat_length, const uint32_t k)
+{
+  pmatrix_s4_rec_t(m, mat_length[m.entry], k);
 }
 
 __device__ __forceinline__ void load_vec4(const TaskRec & T, const uint32_t clv_index, const uint32_t k,

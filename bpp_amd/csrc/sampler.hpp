@@ -1175,6 +1175,7 @@ struct bpa_sampler
   double g_ft[3] = {0, 0, 0}, g_alpha_a = 1, g_alpha_b = 1;
   unsigned g_pend_mode = 0, g_pend_k = 0;
   bool g_eigen_dirty = false;
+  bool g_pm_fused = false;              // the proposal launch just issued filled the step's P-matrices itself (gs_step -> gs_eval)
   unsigned long g_evals = 0;            // launches of the likelihood step kernel (bpa_sampler_work reports them as `sweeps`)
   unsigned nblocks = 0, epoch = 0;
   bool logpr_stale = false;     // thetas moved since the trees' densities were stored (Args::refresh_logpr)

@@ -129,17 +129,17 @@ def test_generic_sampler_on_the_anopheles_data():
     dev.close(); host.close(); eng.close()
 
 
-@pytest.mark.parametrize("nloci,iters,fuse", [(40, 3, None), (700, 2, None), (700, 2, "0")])
+@pytest.mark.parametrize("nloci,iters,fuse", [(40, 3, None), (700, 2, None), (700, 2, "BPA_GS_FUSEA=1"), (700, 2, "BPA_GS_FUSEPM=0")])
 def test_generic_sampler_with_parameter_moves_equals_host_driver(nloci, iters, fuse, monkeypatch):
-    """(fuse None: a set of this size refreshes the eigensystems and makes the step's P-matrices inside the node-update launch,
-    "0": as launches of their own — BPA_GS_FUSEA)
+    """(fuse None: the proposal's lane groups fill the step's P-matrices themselves, the eigensystems are refreshed by a launch
+    of their own; BPA_GS_FUSEA=1: both inside the node-update launch; BPA_GS_FUSEPM=0: the P-matrices as a launch of their own)
     the per-locus frequency / exchangeability / alpha moves (locus.c:2782-3419, prop_gamma.c:52-224) on the device —
     new values into the loci's parameter blocks, eigensystems and category rates refreshed there — against the host
     driver's param_step over libbpp_amd.so's setters: same decisions, same parameters (the category rates of a proposed
     alpha come from device libm here and from glibc there: equal to ~1e-14, not to the bit)"""
     taxa, R = 8, 4
     if fuse is not None:
-        monkeypatch.setenv("BPA_GS_FUSEA", fuse)
+        monkeypatch.setenv(*fuse.split("="))
     eng = bpp_amd.Engine(0)
     data = synth.make_dataset(nloci, 300, taxa, "gtr", R, seed=23)
     loci_a = tape.make_engine_loci(eng, data)
