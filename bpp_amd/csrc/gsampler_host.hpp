@@ -696,6 +696,34 @@ static int gs_prog_ready(bpa_sampler * s)
   return 1;
 }
 
+// where the sum kernels of the program's moves write and how the host gets it: pinned host memory the kernel stores into
+// itself, read after the stream's synchronisation — no copy launch between the two (BPA_GS_PINOUT=0: device buffer + hipMemcpy)
+static double * gs_prog_out(bpa_sampler * s)
+{
+  const char * env = getenv("BPA_GS_PINOUT");
+  if (env && env[0] == '0') return s->g_progout.p;
+  if (!s->gp_pin)
+  {
+    if (hipHostMalloc((void **)&s->gp_pin, 64*sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&s->gp_pin_dev, s->gp_pin, 0) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      if (s->gp_pin) (void)hipHostFree(s->gp_pin);
+      s->gp_pin = s->gp_pin_dev = nullptr;
+      return s->g_progout.p;
+    }
+  }
+  return s->gp_pin_dev;
+}
+static int gs_prog_fetch(bpa_sampler * s, const double * dev, void * host, size_t bytes)
+{
+  bpa_engine * e = s->eng;
+  if (dev != s->gp_pin_dev || !s->gp_pin) HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (dev == s->gp_pin_dev && s->gp_pin) std::memcpy(host, s->gp_pin, bytes);
+  return 1;
+}
+
 static int gs_prog_apply(bpa_sampler * s, const gsm::GApply & a, bool with_flag)
 {
   bpa_engine * e = s->eng;
@@ -722,11 +750,11 @@ static int gs_prog_theta(bpa_sampler * s)
     if (slide[p]) tnew[p] = a00_reflect(s->gp_theta[p] + s->sp.ft_theta*a00_bpp_rnd_symmetrical(&gz), 0.0, 999.0);
   }
   long long h[3*smp::MAXPOP];
+  double * pout = gs_prog_out(s);
   hipLaunchKernelGGL(gsm::gprog_theta_sums_kernel, dim3(npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p, s->nloci, onmask,
-                     reinterpret_cast<long long *>(s->g_progout.p));
+                     reinterpret_cast<long long *>(pout));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(h, s->g_progout.p, (size_t)3*npop*sizeof(long long), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (!gs_prog_fetch(s, pout, h, (size_t)3*npop*sizeof(long long))) return 0;
   s->launches++;
   bool bad = false;
   for (int p = 0; p < npop; ++p) { bad = bad || h[3*p + 2] != 0; s->gp_k[p] = h[3*p]; s->gp_T[p] = (double)h[3*p + 1]*(1.0/1099511627776.0); }
@@ -777,11 +805,11 @@ static int gs_prog_tau(bpa_sampler * s, int q)
   s->grng = (a00_rng_t)gz;
   if (!gs_step(s, 2, (unsigned)q, 0.0, 1.0, 0.0, w) || !gs_eval(s, 1)) return 0;
   double out[8];
+  double * pout = gs_prog_out(s);
   hipLaunchKernelGGL(gsm::gprog_sums_kernel, dim3(1), dim3(1024), 0, e->stream, (const double *)s->g_lnlcur.p, (const double *)s->g_lnl.p, (const double *)s->g_delta.p,
-                     (const uint8_t *)s->g_active.p, (const double *)s->g_t2h3.p, s->nloci, 1, s->g_progout.p);
+                     (const uint8_t *)s->g_active.p, (const double *)s->g_t2h3.p, s->nloci, 1, pout);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(out, s->g_progout.p, 5*sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (!gs_prog_fetch(s, pout, out, 5*sizeof(double))) return 0;
   s->launches++;
   double sum = out[0];
   const long long * ol = reinterpret_cast<const long long *>(out);
@@ -851,11 +879,11 @@ static int gs_prog_mix(bpa_sampler * s)
   s->grng = (a00_rng_t)gz;
   if (!gs_step(s, 3, 0, 0.0, c, lnc) || !gs_eval(s, 1)) return 0;
   double out[8];
+  double * pout = gs_prog_out(s);
   hipLaunchKernelGGL(gsm::gprog_sums_kernel, dim3(1), dim3(1024), 0, e->stream, (const double *)s->g_lnlcur.p, (const double *)s->g_lnl.p, (const double *)s->g_delta.p,
-                     (const uint8_t *)s->g_active.p, (const double *)s->g_t2h3.p, s->nloci, 0, s->g_progout.p);
+                     (const uint8_t *)s->g_active.p, (const double *)s->g_t2h3.p, s->nloci, 0, pout);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(out, s->g_progout.p, 5*sizeof(double), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (!gs_prog_fetch(s, pout, out, 5*sizeof(double))) return 0;
   s->launches++;
   const int root = npop - 1;
   double lnacc = out[0] + (double)(s->sp.S - 1)*lnc;
