@@ -477,6 +477,9 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     }
     d.tile_arrive = s->g_arrive.p;
     const uint32_t fsum = fuse_sum ? 512u : 0u;
+    // the step's P-matrices: one workgroup per locus (its entries are adjacent in the step image), BPA_S20_PMGROUP=0: per entry
+    const char * pg_env = getenv("BPA_S20_PMGROUP");
+    const bool pm_group = !(pg_env && pg_env[0] == '0');
     if (s->g_forked)
     {
       for (int h = 0; h < 2; ++h)
@@ -485,7 +488,8 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
         hipStream_t st = h ? s->g_stream2 : e->stream;
         d.ent0 = i0*s->g_maxmat;
         d.flags = 1u | 256u;
-        hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3((i1 - i0)*s->g_maxmat), dim3(256), 0, st, d);
+        if (pm_group) hipLaunchKernelGGL(pmatrix_wg2_group_kernel<20>, dim3(i1 - i0), dim3(256), 0, st, d, s->g_maxmat);
+        else hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3((i1 - i0)*s->g_maxmat), dim3(256), 0, st, d);
         d.blk0 = t0;
         d.flags = 4u | 64u | 256u | fsum;
         if (gs_pipe20()) hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
@@ -500,7 +504,8 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
       return 1;
     }
     d.flags = 1u;
-    hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d);
+    if (pm_group) hipLaunchKernelGGL(pmatrix_wg2_group_kernel<20>, dim3(s->nloci), dim3(256), 0, e->stream, d, s->g_maxmat);
+    else hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d);
     d.flags = 4u | 64u | fsum;
     if (gs_pipe20()) hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
     else if (gs_tile20() == 128u) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20 + (size_t)s->g_rmax*64*sizeof(double), e->stream, k0, k1, 0, d);

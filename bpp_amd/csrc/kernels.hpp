@@ -3416,6 +3416,96 @@ __global__ void __launch_bounds__(256) pmatrix_wg2_kernel(const PlanDev P)
   }
 }
 
+// pmatrix_wg2_kernel for step images that keep a locus's branch entries together (the generic sampler's: entries
+// [i*group, (i + 1)*group) are locus i's, unused ones holes): ONE workgroup per locus.  The wave-uniform chain (entry -> task ->
+// locus record -> parameter block) and the two eigenvector matrices' trip into LDS are paid once per locus instead of once per
+// branch — they are most of a workgroup's life in pmatrix_wg2_kernel (config 4: 3 fresh branches per locus and step) —, the
+// eigenvector matrices come through lds_dma16 (no s_waitcnt vmcnt(0) of the compiler's in front of the LDS reads: an entry's
+// output stores are never waited for).  Same arithmetic per element, same bits.
+template <int S>
+__global__ void __launch_bounds__(256) pmatrix_wg2_group_kernel(const PlanDev P, const uint32_t group)
+{
+  static_assert((S*S*8) % 16 == 0, "16-byte staging units");
+  __shared__ __attribute__((aligned(16))) double s_evs[2*S*S], s_tmp[4][S*S], s_e[4][S];
+  double * const s_ev = s_evs, * const s_iev = s_evs + S*S;
+  const uint32_t e0 = ((P.flags & 256u) ? P.ent0 : 0u) + blockIdx.x*group, tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t task = 0xffffffffu;
+  for (uint32_t q = 0; q < group && task == 0xffffffffu; ++q) task = ((cu32_p)P.mat_task)[e0 + q];
+  if (task == 0xffffffffu) return;                              // the locus proposed nothing this step
+  const uint32_t lid = ((cu32_p)P.task_locus)[task];
+  cu64_p L64 = (cu64_p)(P.loci + lid);
+  cu32_p L32 = (cu32_p)(P.loci + lid);
+  const uint32_t R = L32[20];
+  const cdbl4_p par = (cdbl4_p)L64[5];
+  const double * parg = (const double *)L64[5];
+  const gdbl_p pmat = (gdbl_p)L64[1];
+  for (uint32_t k0 = 0; k0 < R; )
+  {
+    const uint32_t m = (uint32_t)par[par_param_idx(R) + k0];
+    uint32_t k1 = k0 + 1;
+    while (k1 < R && k1 - k0 < 4 && (uint32_t)par[par_param_idx(R) + k1] == m) ++k1;
+    const uint32_t nk = k1 - k0;
+    const uint32_t pmo = par_matrix(R, S, m);
+    if (k0) lds_barrier();                                     // the previous group's LDS reads are done
+    {
+      const double * src = parg + pmo + pm_evecs(S);
+      constexpr uint32_t total = S*S;                          // 16-byte units
+      if (((pmo + pm_evecs(S)) & 1u) == 0)                    // 16-byte aligned in the parameter block (R even)
+        for (uint32_t c = w; c*64 < total; c += 4)
+        {
+          const uint32_t idx = c*64 + lane;
+          if (idx < total) lds_dma16(src + 2*(size_t)idx, s_evs + (size_t)c*128);
+        }
+      else
+        for (uint32_t i = tid; i < 2*S*S; i += 256) s_evs[i] = ((gcdbl_p)src)[i];
+    }
+    bool first = true;
+    for (uint32_t q = 0; q < group; ++q)
+    {
+      const uint32_t e = e0 + q;
+      if (((cu32_p)P.mat_task)[e] != task) continue;           // a hole (or, in a foreign layout, another locus's entry: not this kernel's)
+      const double t = ((cdbl4_p)P.mat_length)[e];
+      const gdbl_p pbase = pmat + (size_t)((cu32_p)P.mat_pmatrix)[e]*R*S*S;
+      // (s_e is read between the two barriers below only, s_tmp after the second: the next entry's writes of s_e may start
+      //  while other waves still multiply, its writes of s_tmp come after its first barrier)
+      if (tid < nk*S)
+      {
+        const uint32_t k = k0 + tid/S, mm = tid % S;
+        s_e[tid/S][mm] = expm1(((gcdbl_p)parg)[pmo + pm_evals(S) + mm]*(t*((gcdbl_p)parg)[par_rates(R) + k]));
+      }
+      if (first) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); first = false; }      // the eigenvector matrices are in LDS
+      lds_barrier();
+      // temp = inv_eigenvecs * expd (core_pmatrix.c:741-747), once per element
+      for (uint32_t i = tid; i < nk*S*S; i += 256) s_tmp[i/(S*S)][i % (S*S)] = s_iev[i % (S*S)]*s_e[i/(S*S)][i % S];
+      lds_barrier();
+      // pmat = I + temp * eigenvecs (core_pmatrix.c:749-756): one lane = 4 consecutive columns of a row
+      constexpr uint32_t Q = S/4;
+      for (uint32_t idx = tid; idx < nk*S*Q; idx += 256)
+      {
+        const uint32_t kk = idx/(S*Q), j = (idx % (S*Q))/Q, c0 = 4*(idx % Q), k = k0 + kk;
+        double acc[4] = {j == c0 ? 1.0 : 0.0, j == c0 + 1 ? 1.0 : 0.0, j == c0 + 2 ? 1.0 : 0.0, j == c0 + 3 ? 1.0 : 0.0};
+        if (!(t*par[par_rates(R) + k] < 1e-100))
+        {
+          const double * tr = &s_tmp[kk][j*S];
+#pragma unroll
+          for (int mm = 0; mm < S; ++mm)
+          {
+            const double tv = tr[mm];
+            const double2 * ev = reinterpret_cast<const double2 *>(&s_ev[mm*S + c0]);
+            const double2 a = ev[0], c = ev[1];
+            acc[0] += tv*a.x; acc[1] += tv*a.y; acc[2] += tv*c.x; acc[3] += tv*c.y;
+          }
+        }
+        d2v_t o0, o1; o0.x = acc[0]; o0.y = acc[1]; o1.x = acc[2]; o1.y = acc[3];
+        __attribute__((address_space(1))) d2v_t * dst = (__attribute__((address_space(1))) d2v_t *)(pbase + (size_t)k*S*S + j*S + c0);
+        dst[0] = o0; dst[1] = o1;
+      }
+    }
+    k0 = k1;
+  }
+}
+
 // pll_core_update_pmatrix (core_pmatrix.c:785) over staged host arrays:
 // one lane per (matrix i, rate k, row j).
 template <int S>
