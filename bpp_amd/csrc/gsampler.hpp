@@ -542,9 +542,11 @@ __global__ void __launch_bounds__(1024) gsum_decide_kernel(const double * __rest
 // out[0] = sum over the loci of (lnL' - lnL, where a likelihood was evaluated) + delta — gsum_decide_kernel's sum, same order;
 // TAU: out[1..3] = the T2h of q and its two children after the move, summed as 2^-40 fixed point (a00_driver.c: llrint(x 2^40)),
 // out[4] = 1 when a term was unusable (NaN or >= 256)
+constexpr int GPROG_FLAG0 = 3*MAXPOP;          // the sum kernels' output block: [0, 3 MAXPOP) values, then one arrival word per workgroup
 __global__ void __launch_bounds__(1024) gprog_sums_kernel(const double * __restrict__ lnl_cur, const double * __restrict__ lnl_new,
                                                           const double * __restrict__ delta, const uint8_t * __restrict__ active,
-                                                          const double * __restrict__ t2h3, uint32_t T, int with_t2h, double * out)
+                                                          const double * __restrict__ t2h3, uint32_t T, int with_t2h, double * out,
+                                                          unsigned long long seq)
 {
   __shared__ double sh[1024];
   __shared__ long long shl[3][1024];
@@ -576,11 +578,13 @@ __global__ void __launch_bounds__(1024) gprog_sums_kernel(const double * __restr
   out[0] = sh[0];
   for (int j = 0; j < 3; ++j) reinterpret_cast<long long *>(out)[1 + j] = shl[j][0];
   reinterpret_cast<long long *>(out)[4] = shb[0];
+  // out in pinned host memory (gs_prog_out): the host polls this word instead of waiting for the launch to retire
+  if (seq) { __threadfence_system(); __hip_atomic_store(reinterpret_cast<unsigned long long *>(out) + GPROG_FLAG0, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 
 // THETA: per population the coalescences and the T2h over all loci (theta_sums of a00_driver.c: integers, no order)
 __global__ void __launch_bounds__(1024) gprog_theta_sums_kernel(const int8_t * __restrict__ pop_nc, const double * __restrict__ pop_t2h,
-                                                                uint32_t T, uint32_t onmask, long long * out)
+                                                                uint32_t T, uint32_t onmask, long long * out, unsigned long long seq)
 {
   __shared__ long long shk[1024], sht[1024];
   __shared__ int shb[1024];
@@ -599,7 +603,11 @@ __global__ void __launch_bounds__(1024) gprog_theta_sums_kernel(const int8_t * _
     if (threadIdx.x < w) { shk[threadIdx.x] += shk[threadIdx.x + w]; sht[threadIdx.x] += sht[threadIdx.x + w]; shb[threadIdx.x] |= shb[threadIdx.x + w]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out[3*p] = shk[0]; out[3*p + 1] = sht[0]; out[3*p + 2] = shb[0]; }
+  if (threadIdx.x == 0)
+  {
+    out[3*p] = shk[0]; out[3*p + 1] = sht[0]; out[3*p + 2] = shb[0];
+    if (seq) { __threadfence_system(); __hip_atomic_store(reinterpret_cast<unsigned long long *>(out) + GPROG_FLAG0 + p, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+  }
 }
 
 // the host's decision brought to the device: the rejection flag, the species tree as it now is, the counters

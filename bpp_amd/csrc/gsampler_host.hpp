@@ -702,11 +702,19 @@ static int gs_prog_ready(bpa_sampler * s)
 }
 
 // where the sum kernels of the program's moves write and how the host gets it: pinned host memory the kernel stores into
-// itself, read after the stream's synchronisation — no copy launch between the two (BPA_GS_PINOUT=0: device buffer + hipMemcpy)
-static double * gs_prog_out(bpa_sampler * s)
+// itself, its last store an arrival word the host polls — no copy launch, no wait for the launch to retire between the sums and
+// the host's decision (config 5: a synchronisation 25 -> 16 -> ~8 us).  BPA_GS_PINOUT=1: pinned memory + hipStreamSynchronize,
+// =0: device buffer + hipMemcpy.  A poll that sees nothing for 20 ms falls back to the stream's synchronisation (and its errors).
+static int gs_prog_mode()
 {
   const char * env = getenv("BPA_GS_PINOUT");
-  if (env && env[0] == '0') return s->g_progout.p;
+  return env ? (env[0] == '0' ? 0 : env[0] == '1' ? 1 : 2) : 2;
+}
+static double * gs_prog_out(bpa_sampler * s, unsigned long long * seq)
+{
+  *seq = 0;
+  const int mode = gs_prog_mode();
+  if (mode == 0) return s->g_progout.p;
   if (!s->gp_pin)
   {
     if (hipHostMalloc((void **)&s->gp_pin, 64*sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -717,15 +725,30 @@ static double * gs_prog_out(bpa_sampler * s)
       s->gp_pin = s->gp_pin_dev = nullptr;
       return s->g_progout.p;
     }
+    std::memset(s->gp_pin, 0, 64*sizeof(double));
   }
+  if (mode == 2) *seq = ++s->gp_seq;
   return s->gp_pin_dev;
 }
-static int gs_prog_fetch(bpa_sampler * s, const double * dev, void * host, size_t bytes)
+static int gs_prog_fetch(bpa_sampler * s, const double * dev, void * host, size_t bytes, unsigned long long seq, int nflags)
 {
   bpa_engine * e = s->eng;
-  if (dev != s->gp_pin_dev || !s->gp_pin) HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  if (dev == s->gp_pin_dev && s->gp_pin) std::memcpy(host, s->gp_pin, bytes);
+  const bool pinned = s->gp_pin && dev == s->gp_pin_dev;
+  if (!pinned) HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, e->stream));
+  bool arrived = false;
+  if (pinned && seq)
+  {
+    const unsigned long long * f = reinterpret_cast<const unsigned long long *>(s->gp_pin) + gsm::GPROG_FLAG0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long spins = 0; !arrived; ++spins)
+    {
+      arrived = true;
+      for (int q = 0; q < nflags; ++q) arrived = arrived && __atomic_load_n(f + q, __ATOMIC_ACQUIRE) == seq;
+      if (!arrived && (spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+  }
+  if (!arrived) HIPCHK(hipStreamSynchronize(e->stream));
+  if (pinned) std::memcpy(host, s->gp_pin, bytes);
   return 1;
 }
 
@@ -755,11 +778,12 @@ static int gs_prog_theta(bpa_sampler * s)
     if (slide[p]) tnew[p] = a00_reflect(s->gp_theta[p] + s->sp.ft_theta*a00_bpp_rnd_symmetrical(&gz), 0.0, 999.0);
   }
   long long h[3*smp::MAXPOP];
-  double * pout = gs_prog_out(s);
+  unsigned long long pseq = 0;
+  double * pout = gs_prog_out(s, &pseq);
   hipLaunchKernelGGL(gsm::gprog_theta_sums_kernel, dim3(npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p, s->nloci, onmask,
-                     reinterpret_cast<long long *>(pout));
+                     reinterpret_cast<long long *>(pout), pseq);
   HIPCHK(hipGetLastError());
-  if (!gs_prog_fetch(s, pout, h, (size_t)3*npop*sizeof(long long))) return 0;
+  if (!gs_prog_fetch(s, pout, h, (size_t)3*npop*sizeof(long long), pseq, npop)) return 0;
   s->launches++;
   bool bad = false;
   for (int p = 0; p < npop; ++p) { bad = bad || h[3*p + 2] != 0; s->gp_k[p] = h[3*p]; s->gp_T[p] = (double)h[3*p + 1]*(1.0/1099511627776.0); }
@@ -810,11 +834,12 @@ static int gs_prog_tau(bpa_sampler * s, int q)
   s->grng = (a00_rng_t)gz;
   if (!gs_step(s, 2, (unsigned)q, 0.0, 1.0, 0.0, w) || !gs_eval(s, 1)) return 0;
   double out[8];
-  double * pout = gs_prog_out(s);
+  unsigned long long pseq = 0;
+  double * pout = gs_prog_out(s, &pseq);
   hipLaunchKernelGGL(gsm::gprog_sums_kernel, dim3(1), dim3(1024), 0, e->stream, (const double *)s->g_lnlcur.p, (const double *)s->g_lnl.p, (const double *)s->g_delta.p,
-                     (const uint8_t *)s->g_active.p, (const double *)s->g_t2h3.p, s->nloci, 1, pout);
+                     (const uint8_t *)s->g_active.p, (const double *)s->g_t2h3.p, s->nloci, 1, pout, pseq);
   HIPCHK(hipGetLastError());
-  if (!gs_prog_fetch(s, pout, out, 5*sizeof(double))) return 0;
+  if (!gs_prog_fetch(s, pout, out, 5*sizeof(double), pseq, 1)) return 0;
   s->launches++;
   double sum = out[0];
   const long long * ol = reinterpret_cast<const long long *>(out);
@@ -884,11 +909,12 @@ static int gs_prog_mix(bpa_sampler * s)
   s->grng = (a00_rng_t)gz;
   if (!gs_step(s, 3, 0, 0.0, c, lnc) || !gs_eval(s, 1)) return 0;
   double out[8];
-  double * pout = gs_prog_out(s);
+  unsigned long long pseq = 0;
+  double * pout = gs_prog_out(s, &pseq);
   hipLaunchKernelGGL(gsm::gprog_sums_kernel, dim3(1), dim3(1024), 0, e->stream, (const double *)s->g_lnlcur.p, (const double *)s->g_lnl.p, (const double *)s->g_delta.p,
-                     (const uint8_t *)s->g_active.p, (const double *)s->g_t2h3.p, s->nloci, 0, pout);
+                     (const uint8_t *)s->g_active.p, (const double *)s->g_t2h3.p, s->nloci, 0, pout, pseq);
   HIPCHK(hipGetLastError());
-  if (!gs_prog_fetch(s, pout, out, 5*sizeof(double))) return 0;
+  if (!gs_prog_fetch(s, pout, out, 5*sizeof(double), pseq, 1)) return 0;
   s->launches++;
   const int root = npop - 1;
   double lnacc = out[0] + (double)(s->sp.S - 1)*lnc;

@@ -1141,6 +1141,7 @@ struct bpa_sampler
   DevBuf<double> g_lnl, g_lnlcur, g_hast, g_logpr, g_delta, g_site, g_len, g_lograt;
   // the program's THETA / TAU / MIX on a generic sampler (decided on the host: gsampler_host.hpp gs_prog_*)
   DevBuf<double> g_t2h3, g_progout;
+  unsigned long long gp_seq = 0;        // ... and the number of the launch whose arrival words the host polls (gs_prog_fetch)
   double * gp_pin = nullptr, * gp_pin_dev = nullptr;   // 64 doubles of pinned host memory the program's sum kernels write straight into (gs_prog_out)
   DevBuf<uint32_t> g_arrive;            // 20-state loci: tiles arrived per locus (the per-locus sum inside partials_lnl_wave20_kernel)
   long long gp_k[smp::MAXPOP] = {}; double gp_T[smp::MAXPOP] = {}; bool gp_ok = false, gp_pre_valid = false; double gp_pre_window = 0;
