@@ -253,9 +253,13 @@ def test_loci_of_several_kinds_in_one_sampler():
     dev.close(); host.close(); eng.close()
 
 
-@pytest.mark.parametrize("taxa,model,R,nloci,iters,subst", [(8, "gtr", 4, 60, 4, True), (8, "gtr", 4, 700, 2, True), (6, "lg", 4, 40, 3, False),
-                                                            (8, "jc69", 1, 40, 4, False)])
-def test_generic_sampler_with_the_program_s_moves_equals_host_driver(taxa, model, R, nloci, iters, subst, monkeypatch):
+@pytest.mark.parametrize("taxa,model,R,nloci,iters,subst,env", [(8, "gtr", 4, 60, 4, True, None), (8, "gtr", 4, 700, 2, True, None), (6, "lg", 4, 40, 3, False, None),
+                                                                (8, "jc69", 1, 40, 4, False, None),
+                                                                # the paths kept next to the defaults: the sums through a device buffer and a copy /
+                                                                # waited for with the stream, 20-state P-matrices a workgroup per branch entry
+                                                                (8, "gtr", 4, 60, 3, True, "BPA_GS_PINOUT=0"), (8, "gtr", 4, 60, 3, True, "BPA_GS_PINOUT=1"),
+                                                                (6, "lg", 4, 40, 3, False, "BPA_S20_PMGROUP=0")])
+def test_generic_sampler_with_the_program_s_moves_equals_host_driver(taxa, model, R, nloci, iters, subst, env, monkeypatch):
     """BPP's own iteration on the generic sampler (bpa_sampler_set_proposal_kernel(BPP) + bpa_sampler_set_program_moves): the
     per-locus proposals draw from the reference's generator with its Bactrian-Laplace windows and acceptance rule on the device
     (gsm2::gstep2_kernel<.., BPP>), THETA by the metropolized Gibbs draw, the thetas re-drawn inside the rubber band and the
@@ -263,6 +267,8 @@ def test_generic_sampler_with_the_program_s_moves_equals_host_driver(taxa, model
     tau_step / mix_step of a00_driver.c).  Same trajectory as the C host driver with a00_set_program_moves on the same library."""
     if model == "jc69":
         monkeypatch.setenv("BPA_SMP_GENERIC", "1")
+    if env:
+        monkeypatch.setenv(*env.split("="))
     eng = bpp_amd.Engine(0)
     data = synth.make_dataset(nloci, 300, taxa, model, R, seed=41)
     loci_a = tape.make_engine_loci(eng, data)
