@@ -1177,7 +1177,8 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves
     generic = cfg["model"] != "jc69"
     # the program's moves run inside the persistent kernel: one rank, or several exchanging through the in-kernel mailboxes
     program = (not generic) and moves == "program" and (D is None or (D.p2p is not None and not os.environ.get("BENCH_PY_ALLREDUCE")))
-    generic_program = generic and moves == "program" and D is None
+    # ... on the generic sampler the host of every rank decides from the sums over all ranks' loci (through the all-reduce callback)
+    generic_program = generic and moves == "program"
     if generic_program:
         # BPP's own iteration on the generic sampler: its generator / Bactrian-Laplace windows / acceptance rule in the per-locus
         # kernels, THETA / TAU / MIX with their theta re-draws decided on the host from the loci's device sums (gs_prog_*); the

@@ -688,7 +688,6 @@ static void gs_declog(const char * what, int k, double lnacc, int acc)
 static int gs_prog_ready(bpa_sampler * s)
 {
   bpa_engine * e = s->eng;
-  if (s->allreduce) return fail("bpa_sampler: the program's moves on a generic sampler run on one rank (the host decides from this GPU's sums)");
   if (!s->g_t2h3.p && (!s->g_t2h3.reserve((size_t)3*s->nloci) || !s->g_progout.reserve(64))) return fail("out of device memory (program moves)");
   if (!s->gp_mirror)
   {
@@ -752,6 +751,27 @@ static int gs_prog_fetch(bpa_sampler * s, const double * dev, void * host, size_
   return 1;
 }
 
+// several ranks (bpa_sampler_set_allreduce): the host decides from the sums over ALL ranks' loci.  This rank's sums go through the
+// caller's collective as doubles, BPA_SAMPLER_SUMS at a time: a likelihood / Jacobian sum as it is (the same bits on every rank
+// after the all-reduce), a non-negative 64-bit integer sum (coalescence counts, 2^-40 fixed-point T2h) as two doubles holding its
+// upper and lower 32 bits — exact for any number of ranks the double's 53 bits can count to
+static int gs_prog_allreduce(bpa_sampler * s, double * v, unsigned n)
+{
+  bpa_engine * e = s->eng;
+  double * ar = s->sum_ext ? s->sum_ext : s->theta_sums.p;
+  for (unsigned o = 0; o < n; o += BPA_SAMPLER_SUMS)
+  {
+    const unsigned c = std::min<unsigned>(BPA_SAMPLER_SUMS, n - o);
+    HIPCHK(hipMemcpyAsync(ar, v + o, c*sizeof(double), hipMemcpyHostToDevice, e->stream));
+    if (!s->allreduce(s->allreduce_ctx, ar, c, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
+    HIPCHK(hipMemcpyAsync(v + o, ar, c*sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  return 1;
+}
+static void gs_split64(long long x, double * hi, double * lo) { *hi = (double)(x >> 32); *lo = (double)(x & 0xffffffffll); }
+static long long gs_join64(double hi, double lo) { return (long long)hi*4294967296ll + (long long)lo; }
+
 static int gs_prog_apply(bpa_sampler * s, const gsm::GApply & a, bool with_flag)
 {
   bpa_engine * e = s->eng;
@@ -784,6 +804,17 @@ static int gs_prog_theta(bpa_sampler * s)
                      reinterpret_cast<long long *>(pout), pseq);
   HIPCHK(hipGetLastError());
   if (!gs_prog_fetch(s, pout, h, (size_t)3*npop*sizeof(long long), pseq, npop)) return 0;
+  if (s->allreduce)
+  {
+    double v[4*smp::MAXPOP];
+    for (int p = 0; p < npop; ++p)
+    {
+      const bool neg = h[3*p] < 0 || h[3*p + 1] < 0;         // (never: counts and waiting times)
+      v[4*p] = (double)(neg ? 0 : h[3*p]); gs_split64(neg ? 0 : h[3*p + 1], &v[4*p + 1], &v[4*p + 2]); v[4*p + 3] = (neg || h[3*p + 2] != 0) ? 1.0 : 0.0;
+    }
+    if (!gs_prog_allreduce(s, v, 4u*(unsigned)npop)) return 0;
+    for (int p = 0; p < npop; ++p) { h[3*p] = (long long)v[4*p]; h[3*p + 1] = gs_join64(v[4*p + 1], v[4*p + 2]); h[3*p + 2] = v[4*p + 3] != 0.0 ? 1 : 0; }
+  }
   s->launches++;
   bool bad = false;
   for (int p = 0; p < npop; ++p) { bad = bad || h[3*p + 2] != 0; s->gp_k[p] = h[3*p]; s->gp_T[p] = (double)h[3*p + 1]*(1.0/1099511627776.0); }
@@ -841,6 +872,18 @@ static int gs_prog_tau(bpa_sampler * s, int q)
   HIPCHK(hipGetLastError());
   if (!gs_prog_fetch(s, pout, out, 5*sizeof(double), pseq, 1)) return 0;
   s->launches++;
+  if (s->allreduce)
+  {
+    long long * ow = reinterpret_cast<long long *>(out);
+    bool neg = false;
+    for (int j = 1; j <= 3; ++j) neg = neg || ow[j] < 0;
+    double v[8] = { out[0], 0, 0, 0, 0, 0, 0, (neg || ow[4] != 0) ? 1.0 : 0.0 };
+    for (int j = 0; j < 3; ++j) gs_split64(neg ? 0 : ow[1 + j], &v[1 + 2*j], &v[2 + 2*j]);
+    if (!gs_prog_allreduce(s, v, 8u)) return 0;
+    out[0] = v[0];
+    for (int j = 0; j < 3; ++j) ow[1 + j] = gs_join64(v[1 + 2*j], v[2 + 2*j]);
+    ow[4] = v[7] != 0.0 ? 1 : 0;
+  }
   double sum = out[0];
   const long long * ol = reinterpret_cast<const long long *>(out);
   const bool bad = ol[4] != 0;
@@ -916,6 +959,7 @@ static int gs_prog_mix(bpa_sampler * s)
   HIPCHK(hipGetLastError());
   if (!gs_prog_fetch(s, pout, out, 5*sizeof(double), pseq, 1)) return 0;
   s->launches++;
+  if (s->allreduce && !gs_prog_allreduce(s, out, 1u)) return 0;
   const int root = npop - 1;
   double lnacc = out[0] + (double)(s->sp.S - 1)*lnc;
   if (s->sp.tau_alpha > 0)

@@ -339,7 +339,10 @@ int  bpa_sampler_set_proposal_kernel(bpa_sampler_t *, int kind);
    kernel decides inside the launch (its control wave): one exchange per step, as without.  The generic sampler (any model,
    <= 16 tips) brings the sums to the HOST — 24 to 72 bytes and one synchronisation per all-loci step — which takes the
    decision with the statements of a00_driver.c (theta_step_gibbs / tau_step / mix_step) and sends it back as a one-lane
-   launch; one rank only (no all-reduce callback).  Same trajectory as the host driver with a00_set_program_moves.      */
+   launch.  With an all-reduce callback (several ranks) every rank's host decides from the sums over ALL ranks' loci: they go
+   through the callback first, BPA_SAMPLER_SUMS doubles at a time — the integer sums (counts, 2^-40 fixed-point T2h) as two
+   doubles each, exact; the likelihood + Jacobian sum as a double.  Same trajectory as the host driver with
+   a00_set_program_moves.                                                                                                */
 int  bpa_sampler_set_program_moves(bpa_sampler_t *, int on, double slide_prob);
 int  bpa_sampler_gibbs_counters(bpa_sampler_t *, unsigned long * proposals, unsigned long * accepted);
 void bpa_sampler_set_tau_prior(bpa_sampler_t *, double alpha, double beta);           /* a00_set_tau_prior */

@@ -66,6 +66,17 @@ def test_two_rank_bench_line(p2p, scaling):
     assert tp["roofline"]["frac"] > 0 and tp["roofline"]["proposal_steps"] >= tp["roofline"]["launches"]
 
 
+def test_two_rank_bench_line_config3_runs_the_program_s_moves():
+    """--config c3 on two ranks: the generic sampler's loci dealt out (strong scaling), BPP's own iteration on every rank — the
+    hosts decide THETA / TAU / MIX from sums that went through the collective"""
+    d, err = run_bench(["--config", "c3", "--loci", "400", "--no-tape", "--projection-iters", "2", "--no-scale-projection"])
+    smp = d["device_resident_sampler"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0, err[-1500:]
+    assert smp["moves"].startswith("the program's") and smp["moves_short"] == "program" and smp["kind"] == "generic", smp["moves"]
+    assert smp["loci_total"] == 400 and 0.1 < smp["acceptance"] < 0.9
+    assert smp["theta_gibbs_draws_generic"]["proposed"] > 0
+
+
 def test_two_rank_bench_line_carries_both_scalings():
     """without --scaling: `value` = the config's own mode (c2: weak) and the other mode's sampler rate is measured in the same run"""
     d, err = run_bench(["--no-tape"])

@@ -75,6 +75,28 @@ def test_two_ranks_generic_sampler_with_parameter_moves(tmp_path):
     assert np.allclose(lnl, one["lnl"], rtol=1e-10, atol=0)
 
 
+def test_two_ranks_generic_sampler_with_the_program_s_moves(tmp_path):
+    """BPP's own iteration on the generic sampler over two ranks: the per-locus kernels draw BPP's windows, the host of EVERY rank
+    takes the THETA / TAU / MIX decisions from the sums over all ranks' loci — the coalescence counts and fixed-point T2h as exact
+    integers (two doubles each through the collective), the likelihood + Jacobian sum as a double (summed in rank order here, in
+    locus order on one rank: the tolerance below) — and draws the same thetas from the same global stream"""
+    one = run(1, str(tmp_path / "one"), 30011, DIST_GTR="1", DIST_PROGRAM="1")[0]
+    two = run(2, str(tmp_path / "two"), 30012 + os.getpid() % 500, DIST_GTR="1", DIST_PROGRAM="1")
+    assert one["kind"] == "generic" and all(r["kind"] == "generic" for r in two)
+    assert two[0]["taus"] == two[1]["taus"] and two[0]["thetas"] == two[1]["thetas"]      # replicated decisions, the same bits
+    for r in two:
+        assert np.allclose(r["taus"], one["taus"], rtol=1e-9, atol=0) and r["taus"][8:] != [0.001, 0.0012, 0.0025, 0.0011, 0.0013, 0.003, 0.005]
+        assert np.allclose(r["thetas"], one["thetas"], rtol=1e-9, atol=0) and r["thetas"] != one["thetas"][:0]
+    assert one["thetas"][8:] != [0.002]*7 if len(one["thetas"]) >= 15 else True
+    times = two[0]["times"] + two[1]["times"]
+    lnl = two[0]["lnl"] + two[1]["lnl"]
+    assert len(times) == len(one["times"])
+    for a, b in zip(times, one["times"]):
+        assert np.allclose(a, b, rtol=1e-9, atol=0)
+    assert np.allclose(lnl, one["lnl"], rtol=1e-9, atol=0)
+    assert sum(r["summary"]["accepted"] for r in two) > 0
+
+
 @pytest.mark.parametrize("program", [False, True])
 def test_two_ranks_exchange_inside_the_persistent_kernel(tmp_path, program):
     """bpa_sampler_set_p2p: both ranks run the persistent iteration kernel for the whole call and exchange the all-loci
