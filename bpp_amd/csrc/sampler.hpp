@@ -1848,6 +1848,25 @@ static double finetune_onestep(const double pjump, const double ft)
 
 extern "C" double bpa_finetune_onestep(double pjump, double finetune) { return finetune_onestep(pjump, finetune); }
 
+// several ranks: the program's rule sees the acceptance proportions over ALL loci (one finetune per move for the whole data
+// set), so the per-locus moves' counts are pooled over the ranks first — through the callback, or through the mailboxes' one-shot
+// exchange when the sums live inside the persistent kernel.  Every rank calls bpa_sampler_adapt_finetune at the same point.
+static int sampler_pool_counts(bpa_sampler * s, unsigned long long * c, unsigned n)
+{
+  if ((!s->allreduce && !s->p2p) || !n || n > (unsigned)smp::MAXPOP || !s->theta_sums.p) return 1;
+  bpa_engine * e = s->eng;
+  double v[smp::MAXPOP];
+  for (unsigned i = 0; i < n; ++i) v[i] = (double)c[i];
+  double * ar = (s->allreduce && s->sum_ext) ? s->sum_ext : s->theta_sums.p;
+  HIPCHK(hipMemcpyAsync(ar, v, n*sizeof(double), hipMemcpyHostToDevice, e->stream));
+  if (s->allreduce) { if (!s->allreduce(s->allreduce_ctx, ar, n, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed"); }
+  else if (!bpa_p2p_allreduce(s->p2p, ar, n)) return 0;
+  HIPCHK(hipMemcpyAsync(v, ar, n*sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (unsigned i = 0; i < n; ++i) c[i] = (unsigned long long)(v[i] + 0.5);
+  return 1;
+}
+
 extern "C" int bpa_sampler_adapt_finetune(bpa_sampler_t * s, double * pjump, double * finetune)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
@@ -1862,6 +1881,7 @@ extern "C" int bpa_sampler_adapt_finetune(bpa_sampler_t * s, double * pjump, dou
     for (int k = 0; k < 4; ++k) { if (tot[k] < s->gp_pj_base[k]) s->gp_pj_base[k] = 0;      /* (the trees were set again: their counts start over) */
                                   c[k] = tot[k] - s->gp_pj_base[k]; s->gp_pj_base[k] = tot[k]; }
     for (int k = 4; k < 10; ++k) { c[k] = s->gp_pj[k]; s->gp_pj[k] = 0; }
+    if (!sampler_pool_counts(s, c, 4)) return 0;          // (the all-loci moves' counts are every rank's own copy of the same decisions)
     double * ft[5] = { &s->sp.ft_gage, &s->sp.ft_gspr, &s->sp.ft_tau, &s->sp.ft_mix, &s->sp.ft_theta };
     for (int m = 0; m < 5; ++m)
     {
@@ -1876,6 +1896,7 @@ extern "C" int bpa_sampler_adapt_finetune(bpa_sampler_t * s, double * pjump, dou
   unsigned long long c[16];
   HIPCHK(hipMemcpy(c, s->v2_pj.p, sizeof c, hipMemcpyDeviceToHost));
   HIPCHK(hipMemset(s->v2_pj.p, 0, sizeof c));          // pjump_reset (method.c:5377)
+  if (!sampler_pool_counts(s, c, 4)) return 0;
   double * ft[5] = { &s->sp.ft_gage, &s->sp.ft_gspr, &s->sp.ft_tau, &s->sp.ft_mix, &s->sp.ft_theta };
   for (int m = 0; m < 5; ++m)
   {

@@ -314,7 +314,9 @@ void bpa_sampler_set_finetune(bpa_sampler_t *, double gage, double gspr, double 
    bpa_sampler_burnin runs `iterations` iterations the program's way: the rule after every quarter of them (when a quarter
    is at least 100 iterations) and once more at the end; finetune (5, may be null) receives the step lengths it ends with.
    Where: the persistent iteration kernel (device counters by move type) and the generic sampler with the program's moves
-   (the trees carry the age / prune-regraft counts, the host its own decisions').                                       */
+   (the trees carry the age / prune-regraft counts, the host its own decisions').  Several ranks: the per-locus moves' counts
+   are pooled over the ranks first (the callback, or the mailboxes' one-shot exchange), so every rank ends at the same step
+   lengths, the whole data set's — every rank calls it at the same point of its run.                                      */
 double bpa_finetune_onestep(double pjump, double finetune);
 int  bpa_sampler_adapt_finetune(bpa_sampler_t *, double * pjump, double * finetune);
 int  bpa_sampler_burnin(bpa_sampler_t *, unsigned iterations, double * finetune);

@@ -66,8 +66,11 @@ def main():
     smp.set_theta_prior(2.0, 1000.0, 0.001)
     smp.set_finetune(0.003, 0.005, 0.0008, 0.2)
     smp.initialize()
+    ft = None
+    if os.environ.get("DIST_BURNIN"):
+        ft = smp.burnin(200)                     # the program's step-length rule at the end of 200 iterations (every rank calls it)
     smp.iterate(4 if gtr else 12)
-    res = dict(rank=rank, first=first, kind=smp.kind(), taus=smp.taus(), thetas=smp.thetas(), summary=smp.summary(),
+    res = dict(ft=ft, rank=rank, first=first, kind=smp.kind(), taus=smp.taus(), thetas=smp.thetas(), summary=smp.summary(),
                times=[[float(x) for x in smp.tree(i)["time"]] for i in range(per)],
                lnl=[smp.tree(i)["lnl"] for i in range(per)])
     with open(f"{out}.{rank}.json", "w") as f:

@@ -116,3 +116,17 @@ def test_two_ranks_exchange_inside_the_persistent_kernel(tmp_path, program):
     times = two[0]["times"] + two[1]["times"]
     for a, b in zip(times, one["times"]):
         assert np.allclose(a, b, rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("how", ["mailboxes", "callback"])
+def test_two_ranks_pool_the_step_length_rule(tmp_path, how):
+    """the program's burn-in rule sets ONE step length per move for the whole data set from the acceptance proportions over all
+    loci: on two ranks the per-locus moves' counts are pooled first (through the mailboxes' one-shot exchange next to the persistent
+    kernel, through the callback on the generic sampler), so both ranks end at the same five step lengths — and those moved"""
+    extra = dict(DIST_PROGRAM="1", DIST_BURNIN="1", **(dict(DIST_P2P="1") if how == "mailboxes" else dict(DIST_GTR="1")))
+    two = run(2, str(tmp_path / "two"), 30112 + os.getpid() % 500, **extra)
+    a, b = two[0]["ft"], two[1]["ft"]
+    assert a == b, (a, b)
+    start = dict(gage=0.003, gspr=0.005, tau=0.0008, mix=0.2, theta=0.001)
+    assert all(a[k] != start[k] for k in ("gage", "gspr", "tau", "mix")), a
+    assert two[0]["taus"] == two[1]["taus"] and two[0]["thetas"] == two[1]["thetas"]
