@@ -1214,7 +1214,7 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves
     burnin_ft = None
     if generic_program:
         burnin_ft = smp.burnin(400)
-    if program and D is None and kind == "persistent":
+    if program and kind == "persistent":       # (N > 1: every rank runs it; the per-locus moves' counts are pooled through the mailboxes)
         # the program's burn-in (finetune = 1): 800 iterations, the step lengths reset from the acceptance proportions after every
         # quarter and at the end (bpa_sampler_burnin: reset_finetune, method.c:1508-1516, 5364) — outside the timed region
         burnin_ft = smp.burnin(800)
