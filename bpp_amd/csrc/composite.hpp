@@ -10,9 +10,13 @@
 // on exchanged through the all-reduce callback every part already has (bpa_sampler_set_allreduce).  The "collective" is a
 // launch on the one engine stream that adds the parts' device sums; the parts' launch loops run as fibers of the calling
 // thread (ucontext), each suspended inside its callback until every part has reached the same step.
+// Several ranks (round 5; threads.c:234-353 shards ANY loci over its workers): the caller's all-reduce
+// (bpa_sampler_set_allreduce on the composite) is called ONCE per step on the parts' total, between the launch that adds
+// the parts and the launch that hands the result to each of them — a rank whose share is of one kind (a plain sampler:
+// one collective per step) and a rank whose share is mixed therefore issue the same collectives in the same order.
 // A part of LDS-kernel loci therefore runs the several-rank ("hybrid") form: its per-locus sweeps as launches of the
-// persistent kernel, its all-loci steps one launch each.  One rank, the library's own proposal kernel (BPP's kernel and the
-// program's moves live inside the persistent kernel's single launch: homogeneous sets only).
+// persistent kernel, its all-loci steps one launch each.  The library's own proposal kernel (BPP's kernel and the program's
+// moves decide inside the persistent kernel's single launch or on the generic sampler's host: homogeneous sets only).
 #pragma once
 #include <ucontext.h>
 #include <functional>
@@ -39,19 +43,31 @@ struct bpa_composite
   std::vector<hipStream_t> stream;
   std::vector<hipEvent_t> ev_part;
   hipEvent_t ev_sum = nullptr;
+  // several ranks: the caller's collective over the ranks, the device doubles it wants the totals in (or null), and the
+  // global index of this rank's first locus
+  bpa_allreduce_fn ext = nullptr; void * ext_ctx = nullptr; double * ext_sum = nullptr; unsigned first = 0;
 };
 
 namespace comp {
 constexpr int MAXPARTS = 8;
 struct Ptrs { double * p[MAXPARTS]; };
-// the parts' sums of one step, added up and handed back to every part (one thread per value)
-__global__ void sum_parts_kernel(const Ptrs P, int nparts, unsigned count)
+// the parts' sums of one step, added up and handed back to every part (one thread per value); total != null: the totals go
+// there only (the ranks' collective runs on them before hand_parts_kernel gives every part the result)
+__global__ void sum_parts_kernel(const Ptrs P, int nparts, unsigned count, double * total)
 {
   const unsigned j = blockIdx.x*blockDim.x + threadIdx.x;
   if (j >= count) return;
   double t = 0;
   for (int p = 0; p < nparts; ++p) t += P.p[p][j];
+  if (total) { total[j] = t; return; }
   for (int p = 0; p < nparts; ++p) P.p[p][j] = t;
+}
+__global__ void hand_parts_kernel(const Ptrs P, int nparts, unsigned count, const double * total)
+{
+  const unsigned j = blockIdx.x*blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  const double t = total[j];
+  for (int p = 0; p < nparts; ++p) if (P.p[p] != total) P.p[p][j] = t;
 }
 
 static int callback(void * vctx, double * sums, unsigned count, void * /*stream*/)
@@ -116,8 +132,17 @@ static int run_all(bpa_composite * c, bpa_engine * e, std::function<int(bpa_samp
       bool okq = true;
       for (int i = 1; i < n; ++i)
         okq = okq && hipEventRecord(c->ev_part[i], c->stream[i]) == hipSuccess && hipStreamWaitEvent(c->stream[0], c->ev_part[i], 0) == hipSuccess;
-      hipLaunchKernelGGL(sum_parts_kernel, dim3((cnt + 63)/64), dim3(64), 0, c->stream[0], P, n, cnt);
-      okq = okq && hipGetLastError() == hipSuccess && hipEventRecord(c->ev_sum, c->stream[0]) == hipSuccess;
+      // (several ranks: the totals in the caller's doubles — or part 0's — go through its collective on the same stream)
+      double * total = !c->ext ? nullptr : (c->ext_sum && cnt <= (unsigned)BPA_SAMPLER_SUMS) ? c->ext_sum : c->pend_ptr[0];
+      hipLaunchKernelGGL(sum_parts_kernel, dim3((cnt + 63)/64), dim3(64), 0, c->stream[0], P, n, cnt, total);
+      okq = okq && hipGetLastError() == hipSuccess;
+      if (okq && c->ext)
+      {
+        if (!c->ext(c->ext_ctx, total, cnt, (void *)c->stream[0])) { okq = false; fail("bpa_sampler (composite): the all-reduce callback failed"); }
+        hipLaunchKernelGGL(hand_parts_kernel, dim3((cnt + 63)/64), dim3(64), 0, c->stream[0], P, n, cnt, total);
+        okq = okq && hipGetLastError() == hipSuccess;
+      }
+      okq = okq && hipEventRecord(c->ev_sum, c->stream[0]) == hipSuccess;
       for (int i = 1; i < n; ++i) okq = okq && hipStreamWaitEvent(c->stream[i], c->ev_sum, 0) == hipSuccess;
       if (!okq) c->failed = true;
     }
@@ -238,6 +263,26 @@ static int comp_upload(bpa_sampler * s)
   if (all) return 1;
   if (!comp_invalidate(s)) return 0;
   return comp::run_all(s->comp, s->eng, [](bpa_sampler * p) { return sampler_upload(p); });
+}
+
+// several ranks: the caller's collective over the ranks (run_all calls it once per step on the parts' total); the per-locus
+// streams re-keyed by the loci's indices in the whole data set (this rank's share starts at first_locus)
+static int comp_set_allreduce(bpa_sampler * s, bpa_allreduce_fn fn, void * ctx, double * device_sum, unsigned first_locus)
+{
+  bpa_composite * c = s->comp;
+  c->ext = fn; c->ext_ctx = ctx; c->ext_sum = device_sum;
+  if (first_locus == c->first) return 1;
+  if (!comp_invalidate(s)) return 0;
+  c->first = first_locus;
+  for (unsigned i = 0; i < s->nloci; ++i)
+  {
+    bpa_sampler * p = c->parts[c->part_of[i]];
+    const unsigned j = c->idx_in[i];
+    p->stream_index[j] = first_locus + i;
+    const a00_rng_t r = stream_seed(p, first_locus + i);
+    if (p->generic) p->g_trees[j].rng = r; else p->h_trees[j].rng = r;
+  }
+  return 1;
 }
 
 static bpa_sampler * comp_part(bpa_sampler * s, unsigned i, unsigned * j)

@@ -1220,6 +1220,7 @@ static bpa_sampler * comp_create(bpa_engine_t * e, bpa_locus_t * const * loci, u
 static void comp_destroy(bpa_sampler * s);
 static int comp_invalidate(bpa_sampler * s);
 static int comp_upload(bpa_sampler * s);
+static int comp_set_allreduce(bpa_sampler * s, bpa_allreduce_fn fn, void * ctx, double * device_sum, unsigned first_locus);
 static int comp_run(bpa_sampler * s, int what, unsigned n);
 static int comp_summary(bpa_sampler * s, double * total_lnl, unsigned long * proposals, unsigned long * accepted, unsigned long * launches);
 static int comp_timing(bpa_sampler * s, double * sweep_ms, unsigned long * sweep_launches, double * allloci_ms, unsigned long * allloci_launches);
@@ -2015,7 +2016,7 @@ extern "C" int bpa_sampler_set_allreduce(bpa_sampler_t * s, bpa_allreduce_fn fn,
                                          unsigned first_locus)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
-  COMP_FAIL("bpa_sampler_set_allreduce: a sampler over loci of several kinds runs on one rank");
+  if (s->comp) return comp_set_allreduce(s, fn, ctx, device_sum, first_locus);
   s->allreduce = fn; s->allreduce_ctx = ctx; s->sum_ext = device_sum;
   if (first_locus != s->locus_offset)
   {
@@ -2114,7 +2115,7 @@ static int sampler_iterate_v2(bpa_sampler * s, unsigned iterations, bool in_kern
 extern "C" int bpa_sampler_set_p2p(bpa_sampler_t * s, bpa_p2p_t * p, unsigned first_locus)
 {
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
-  COMP_FAIL("bpa_sampler_set_p2p: a sampler over loci of several kinds runs on one rank");
+  COMP_FAIL("bpa_sampler_set_p2p: loci of several kinds exchange through bpa_sampler_set_allreduce (the mailboxes are read by the persistent kernel's single launch)");
   if (p && (!p->connected || p->eng != s->eng)) return fail("bpa_sampler_set_p2p: connect the exchange first (same engine)");
   if (p && p->nmax < 16u) return fail("bpa_sampler_set_p2p: the mailboxes must hold at least 16 values");
   // only the persistent kernel reads the mailboxes: a generic or big-tree sampler would decide from its own shard's sums

@@ -359,7 +359,9 @@ int  bpa_sampler_get_taus(bpa_sampler_t *, double * tau);     /* 2*species-1 ent
    MIX step and the number of populations for the THETA step (one sum per theta: one collective for all of them).
    device_sums: caller-owned device memory for BPA_SAMPLER_SUMS doubles to use for the sums (e.g. memory a
    framework's collective can address) or NULL.  first_locus: global index of this rank's first locus — the
-   per-locus random streams are keyed by global index, so a sharded run walks the trajectory of the single-GPU run. */
+   per-locus random streams are keyed by global index, so a sharded run walks the trajectory of the single-GPU run.
+   A sampler over loci of several kinds (BPA_SAMPLER_COMPOSITE) calls fn once per step on the total of its parts, i.e. as
+   a plain sampler does: ranks with mixed shares and ranks with shares of one kind can be paired.                    */
 #define BPA_SAMPLER_SUMS 16
 typedef int (*bpa_allreduce_fn)(void * ctx, double * device_sums, unsigned count, void * stream);
 int  bpa_sampler_set_allreduce(bpa_sampler_t *, bpa_allreduce_fn fn, void * ctx, double * device_sums,
@@ -421,7 +423,8 @@ int  bpa_sampler_work(bpa_sampler_t *, double * bytes, unsigned long * node_upda
 #define BPA_SAMPLER_HYBRID     3       /* an all-reduce callback is installed (several ranks): the per-locus sweep of an iteration is
                                           ONE launch of the persistent kernel, the all-loci steps one launch each of csrc/sampler.hpp's */
 #define BPA_SAMPLER_COMPOSITE  5       /* loci of several kinds (JC69 LDS-kernel loci, generic JC69, multi-category, 20-state): a part per kind,
-                                          stepped together through the parts' all-reduce callbacks (csrc/composite.hpp); one rank, the library's own moves */
+                                          stepped together through the parts' all-reduce callbacks (csrc/composite.hpp); the library's own moves;
+                                          several ranks through bpa_sampler_set_allreduce (one call per step on the parts' total), not the mailboxes */
 #define BPA_SAMPLER_BIG        4       /* loci of more than 16 tips, with scalers or unphased diploids (csrc/bigsampler.hpp: trees in HBM,
                                           one lane per locus, the engine's general 4-state kernels; <= 64 tips) */
 int  bpa_sampler_kind(bpa_sampler_t *);

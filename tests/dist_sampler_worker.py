@@ -19,7 +19,21 @@ def main():
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     gtr = bool(os.environ.get("DIST_GTR"))           # the generic sampler (8 taxa, GTR + Gamma4) with its parameter moves
-    data = synth.make_dataset(48, 300, 8, "gtr", 4, seed=3) if gtr else synth.make_dataset(160, 300, 4, "jc69", 1, seed=3)
+    mixed_kinds = os.environ.get("DIST_COMPOSITE")   # loci of several kinds: "both" ranks' shares mixed, or only rank 0's ("one")
+    if mixed_kinds:
+        # 8 taxa: JC69 loci of the persistent kernel's size with a GTR + Gamma4 locus after every eighth (in the first half only
+        # for "one": rank 1's share is then of one kind, a plain sampler next to rank 0's composite)
+        fit = synth.make_dataset(136 if mixed_kinds == "one" else 128, 300, 8, "jc69", 1, seed=5)
+        gtrs = synth.make_dataset(16, 300, 8, "gtr", 4, seed=7)
+        data = []
+        for i, d in enumerate(fit):
+            data.append(d)
+            if i % 8 == 0 and i // 8 < (8 if mixed_kinds == "one" else 16):
+                data.append(gtrs[i // 8])
+        assert len(data) == 144
+        gtr = True                                   # (the 8-taxon species tree below)
+    else:
+        data = synth.make_dataset(48, 300, 8, "gtr", 4, seed=3) if gtr else synth.make_dataset(160, 300, 4, "jc69", 1, seed=3)
     per = len(data) // world
     first = rank * per
     mine = data[first:first + per]
@@ -58,7 +72,7 @@ def main():
     else:
         parent, tau, theta = synth.species_tree_arrays(8 if gtr else 4)
         smp.set_species_tree(parent, tau, theta)
-    if gtr:
+    if gtr and not mixed_kinds:
         for i, d in enumerate(mine):
             smp.set_subst_model(i, d["freqs"], d["exch"], 0.5)
         smp.set_subst_moves(0.3, 0.4, 0.8, 1.0, 1.0)

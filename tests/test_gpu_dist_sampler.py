@@ -97,6 +97,30 @@ def test_two_ranks_generic_sampler_with_the_program_s_moves(tmp_path):
     assert sum(r["summary"]["accepted"] for r in two) > 0
 
 
+@pytest.mark.parametrize("shares", ["both", "one"])
+def test_two_ranks_with_loci_of_several_kinds(tmp_path, shares):
+    """a data set of JC69 loci (persistent-kernel size) and GTR + Gamma4 loci over two ranks (threads.c:234-353 shards any loci,
+    method.c:3320-3346 a model per locus): a rank whose share is mixed runs the composite sampler (csrc/composite.hpp) and calls the
+    ranks' all-reduce ONCE per all-loci step on its parts' total, so it pairs with a rank whose share is of one kind (`one`: rank 1
+    is a plain persistent-kernel sampler in its several-rank form) collective for collective — the single-rank trajectory again"""
+    one = run(1, str(tmp_path / "one"), 30211, DIST_COMPOSITE=shares)[0]
+    two = run(2, str(tmp_path / "two"), 30212 + os.getpid() % 500, DIST_COMPOSITE=shares)
+    assert one["kind"] == "composite" and two[0]["kind"] == "composite"
+    assert two[1]["kind"] == ("composite" if shares == "both" else "hybrid")
+    assert two[0]["taus"] == two[1]["taus"] and two[0]["thetas"] == two[1]["thetas"]      # replicated decisions
+    for r in two:
+        assert np.allclose(r["taus"], one["taus"], rtol=1e-10, atol=0) and r["taus"][8:] != [0.001, 0.0012, 0.0025, 0.0011, 0.0013, 0.003, 0.005]
+        assert np.allclose(r["thetas"], one["thetas"], rtol=1e-10, atol=0)
+    times = two[0]["times"] + two[1]["times"]
+    lnl = two[0]["lnl"] + two[1]["lnl"]
+    assert len(times) == len(one["times"]) == 144
+    for a, b in zip(times, one["times"]):
+        assert np.allclose(a, b, rtol=1e-10, atol=0)
+    assert np.allclose(lnl, one["lnl"], rtol=1e-10, atol=0)
+    tot = sum(r["summary"]["total_lnl"] for r in two)
+    assert abs(tot - one["summary"]["total_lnl"]) < 1e-9 * abs(tot)
+
+
 @pytest.mark.parametrize("program", [False, True])
 def test_two_ranks_exchange_inside_the_persistent_kernel(tmp_path, program):
     """bpa_sampler_set_p2p: both ranks run the persistent iteration kernel for the whole call and exchange the all-loci
