@@ -177,6 +177,29 @@ def test_lg_table_matches_fixture():
 
 
 @needs_ref
+def test_gamma_cats_sweep_vs_reference():
+    """pll_compute_gamma_cats (gamma.c:221, discrete-gamma category means) of the reference compiled in place, the oracle's
+    restatement and the library's host routine (csrc/host_math.cpp: what alpha moves install, and what the device copy in
+    gamma_dev.hpp is tested against): the same bits over the whole range an alpha move can reach — 6 000 random shapes from
+    0.005 to 500 (log-uniform), 2 to 16 categories; the golden file holds 32 fixed points"""
+    import ctypes as C
+    import bpp_amd
+    L = O.ref()
+    L.pll_compute_gamma_cats.argtypes = [C.c_double, C.c_double, C.c_uint, C.POINTER(C.c_double), C.c_int]
+    L.pll_compute_gamma_cats.restype = C.c_int
+    rng = np.random.default_rng(20250930)
+    shapes = [(float(np.exp(rng.uniform(np.log(0.005), np.log(500.0)))), int(rng.integers(2, 17))) for _ in range(6000)]
+    shapes += [(a, k) for a in (0.005, 0.0101, 0.999999, 1.0, 1.000001, 499.5) for k in (2, 3, 16)]
+    for a, k in shapes:
+        out = (C.c_double * k)()
+        L.pll_compute_gamma_cats(a, a, k, out, 0)                  # PLL_GAMMA_RATES_MEAN (bpp.h:384), the only mode the program uses
+        ref = np.array(out[:])
+        assert (O.orc_gamma_cats(a, k) == ref).all(), (a, k)
+        assert (np.asarray(bpp_amd.compute_gamma_cats(a, a, k)) == ref).all(), (a, k)
+        assert abs(ref.mean() - 1.0) < 1e-9 and (np.diff(ref) > 0).all(), (a, k)      # mean-one, increasing rates
+
+
+@needs_ref
 def test_compress_vs_reference():
     rng = np.random.default_rng(5)
     for _ in range(10):
@@ -187,6 +210,32 @@ def test_compress_vs_reference():
             b, wb = O.ref_compress(seqs, True, jc)
             assert len(wa) == len(wb) and sorted(wa) == sorted(wb)
             assert canon(a, wa, jc) == canon(b, wb, jc)
+
+
+@needs_ref
+def test_library_compress_sweep_vs_reference():
+    """compress_site_patterns (compress.c:218) of the reference compiled in place against the LIBRARY's host routine
+    (bpa_compress_site_patterns, csrc/host_math.cpp) on 500 random alignments — 1 to 8 sequences, 1 to 600 sites, DNA with
+    ambiguity codes and gaps / amino acids with X, B, Z, low to high divergence, with and without the JC69 merge: the weights in
+    the reference's ORDER; without the merge the pattern columns too (same state codes, same order); with it the same classes
+    (which member of a merged class is kept depends on the reference's rand() pivot: any of them has the class's likelihood)"""
+    import bpp_amd
+    rng = np.random.default_rng(7)
+
+    def codes(p, dna):
+        m = O.orc_map(dna)
+        return [[int(m[ord(c)]) for c in s] for s in p]
+    for it in range(300):
+        dna = it % 3 != 0
+        tips, L = int(rng.integers(1, 9)), int(rng.integers(1, 600))
+        seqs = rand_seqs(tips, L, NT if dna else AA, rng, extra="-NRYKMSW" if dna else "-XBZ", pmut=float(rng.choice([0.02, 0.15, 0.5])))
+        for jc in ((0, 1) if dna else (0,)):
+            pa, wa = bpp_amd.compress_site_patterns(seqs, dna, bool(jc))
+            pb, wb = O.ref_compress(seqs, dna, jc)
+            assert list(wa) == list(wb) and int(np.sum(wa)) == L, (it, jc)
+            if not jc:
+                assert codes(pa, dna) == codes(pb, dna), (it, jc)
+            assert canon(pa, wa, jc, dna) == canon(pb, wb, jc, dna), (it, jc)
 
 
 @needs_ref
