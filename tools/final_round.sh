@@ -2,6 +2,8 @@
 # the round's closing GPU call (run through gpurun from the repo root): the two-rank tests of this build's new paths, the
 # rocprofv3 profiles of the three benched configs on THIS build (tests/test_profiles_current.py), then the default bench line.
 # Every part under its own timeout; what is finished is under gpurun_out/ whatever happens to the rest.
+# tools/composite_ranks.patch, when present, is the newest library change as a patch: taken out again on the box when its tests
+# fail (round 5: they passed — the file is gone again).
 # usage: tools/final_round.sh <tag>
 TAG=${1:-r5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
