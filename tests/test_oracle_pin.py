@@ -138,6 +138,32 @@ def test_k1_vs_reference(S, R, order, arch):
 
 
 @needs_ref
+def test_k1_scaling_sweep_vs_reference():
+    """K1 + fill_parent_scaler (core_partials_avx.c:26, core_partials.c:585) around the scaling threshold: 400 random node updates,
+    every pattern's children at its own magnitude between 1e-80 and 1 (a product falls below 2^-256 for some patterns and not for
+    others), 1 to 8 categories, 1 to 69 patterns, child scalers present or not — parent CLVs and scaler counts equal the
+    reference's (AVX2 / AVX / plain C kernels, 4 and 20 states) to the bit; most of the cases cross the threshold"""
+    rng = np.random.default_rng(5)
+    combos = [(4, O.ORDER_PAIR, O.ARCH_AVX2), (4, O.ORDER_PAIR, O.ARCH_AVX), (20, O.ORDER_FMA4, O.ARCH_AVX2),
+              (4, O.ORDER_SEQ, O.ARCH_CPU), (20, O.ORDER_SEQ, O.ARCH_CPU)]
+    crossed = 0
+    for it in range(400):
+        S, order, arch = combos[it % 5]
+        R, n = int(rng.integers(1, 9)), int(rng.integers(1, 70))
+        l = rng.random((n, R, S)) * 10.0 ** rng.uniform(-80, 0, (n, 1, 1))
+        r = rng.random((n, R, S)) * 10.0 ** rng.uniform(-80, 0, (n, 1, 1))
+        lm, rm = rng.random((R, S, S)), rng.random((R, S, S))
+        ls = rng.integers(0, 5, n).astype(np.uint32) if rng.integers(0, 2) else None
+        rs = rng.integers(0, 5, n).astype(np.uint32) if rng.integers(0, 2) else None
+        a, sa = O.orc_partial(l, r, lm, rm, lscaler=ls, rscaler=rs, scaling=True, order=order)
+        b, sb = O.ref_partial(l, r, lm, rm, lscaler=ls, rscaler=rs, scaling=True, arch=arch)
+        assert (a == b).all() and (sa == sb).all(), (it, S, R, n)
+        base = (0 if ls is None else ls.astype(np.int64)) + (0 if rs is None else rs.astype(np.int64))
+        crossed += bool((sa.astype(np.int64) > base).any())
+    assert crossed > 300
+
+
+@needs_ref
 @pytest.mark.parametrize("spec", [(4, 1, "jc69", 4, 9), (4, 4, "jc69", 8, 31), (4, 4, "gtr", 8, 31),
                                   (4, 1, "gtr", 5, 17), (20, 4, "lg", 6, 40), (20, 1, "lg", 4, 11)])
 def test_full_locus_vs_reference(spec):
@@ -167,6 +193,45 @@ def test_full_locus_vs_reference(spec):
     if R > 1:
         assert (O.orc_gamma_cats(0.5, R) == rl.rates()).all()
     rl.free()
+
+
+@needs_ref
+def test_full_locus_sweep_vs_reference():
+    """the six fixed shapes above, widened: 150 random loci — JC69 / GTR with 1, 2, 4, 5 or 8 categories and 2 to 12 tips, LG with
+    1 or 4 categories and 2 to 7 tips, 1 to 120 patterns with ambiguity codes and gaps, tree heights from 1e-6 to 3 (P-matrices
+    from the identity's neighbourhood to near stationarity), shapes 0.05 to 20, exchangeabilities spread over 1 : 200 — the
+    oracle's eigensystem, every P-matrix, every CLV and the log-likelihood equal the reference's to the bit"""
+    rng = np.random.default_rng(99)
+    for it in range(150):
+        S = 4 if it % 4 else 20
+        model = "lg" if S == 20 else ("jc69", "gtr")[it % 2]
+        R = int(rng.choice([1, 2, 4, 5, 8])) if S == 4 else int(rng.choice([1, 4]))
+        tips, sites = int(rng.integers(2, 13 if S == 4 else 8)), int(rng.integers(1, 120))
+        height = float(rng.choice([1e-6, 0.002, 0.02, 0.3, 3.0] if S == 4 else [1e-5, 0.03, 0.3, 2.0]))
+        seqs = rand_seqs(tips, sites, NT if S == 4 else AA, rng, extra="-NRY" if S == 4 else "-XB")
+        w = rng.integers(1, 50, sites)
+        left, right, times, root = rand_tree(tips, rng, height)
+        freqs = q = None
+        if model == "gtr":
+            freqs, q = rng.dirichlet([5] * 4), rng.random(6) * float(rng.choice([1, 10])) + 0.05
+        if model == "lg":
+            q, freqs = O.lg_model()
+        alpha = float(np.exp(rng.uniform(np.log(0.05), np.log(20.0)))) if R > 1 else None
+        rl = O.RefLocus(S, R, seqs, w, model=model, freqs=freqs, qrates=q, alpha=alpha)
+        rl.set_tree(left, right, times, root)
+        ol = O.OracleLocus(S, R, seqs, w, model=model, freqs=freqs, qrates=q, rates=rl.rates())
+        what = (it, S, R, model, tips, sites, height)
+        assert ol.full_lnl(left, right, times, root) == rl.full_lnl(), what
+        for i in range(2 * tips - 2):
+            assert (rl.pmatrix(i) == ol.pmat[i]).all(), what
+        for i in range(2 * tips - 1):
+            assert (rl.clv(i) == ol.clv[i]).all(), what
+        if model != "jc69":
+            for x, y in zip(rl.eigen(), ol.eig):
+                assert (x == y).all(), what
+        if R > 1:
+            assert (O.orc_gamma_cats(alpha, R) == rl.rates()).all(), what
+        rl.free()
 
 
 @needs_ref
