@@ -439,11 +439,24 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   return 1;
 }
 
+// flags bit 11 of the node-update kernels (step_s4_klane_v3_kernel, partials_lnl_wave20_kernel): the root's CLV of a step is not
+// stored — no step of a sampler reads a root's buffer (the root term is taken from registers in the same launch; a node that
+// stops being the root is recomputed by the step that moves it).  What else may read the loci's buffers (the single-locus API,
+// a plan, bpa_batch_evaluate) comes after a download, which recomputes every buffer in place first (gs_download).
+// BPA_GS_ROOTSTORE=1: every parent stored (A/B).
+static uint32_t gs_skip_root_flag()
+{
+  static const uint32_t v = getenv("BPA_GS_ROOTSTORE") ? 0u : 2048u;
+  return v;
+}
+static uint32_t gs_root_flag(const bpa_sampler * s) { return s->g_level_eval ? 0u : gs_skip_root_flag(); }
+
 // the step's likelihood: the engine's kernels over the records the step kernel wrote
 static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci step */)
 {
   bpa_engine * e = s->eng;
   if (!e->usedata) return 1;                       // lnL = 0 for every locus (the buffer was zeroed): the MSC prior
+  if (!s->g_alljc && !s->g_level_eval && gs_skip_root_flag()) s->g_root_stale = true;
   if (s->g_s20)
   {
     // amino-acid loci: fresh P-matrices (pmatrix_wg2_kernel, one workgroup per entry, holes return at once), the tiled
@@ -491,7 +504,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
         if (pm_group) hipLaunchKernelGGL(pmatrix_wg2_group_kernel<20>, dim3(i1 - i0), dim3(256), 0, st, d, s->g_maxmat);
         else hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3((i1 - i0)*s->g_maxmat), dim3(256), 0, st, d);
         d.blk0 = t0;
-        d.flags = 4u | 64u | 256u | fsum;
+        d.flags = 4u | 64u | 256u | fsum | gs_root_flag(s);
         if (gs_pipe20()) hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
         else if (gs_tile20() == 128u) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20 + (size_t)s->g_rmax*64*sizeof(double), st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
         else if (gs_waverl()) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2, 1, true>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
@@ -506,7 +519,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     d.flags = 1u;
     if (pm_group) hipLaunchKernelGGL(pmatrix_wg2_group_kernel<20>, dim3(s->nloci), dim3(256), 0, e->stream, d, s->g_maxmat);
     else hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d);
-    d.flags = 4u | 64u | fsum;
+    d.flags = 4u | 64u | fsum | gs_root_flag(s);
     if (gs_pipe20()) hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
     else if (gs_tile20() == 128u) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20 + (size_t)s->g_rmax*64*sizeof(double), e->stream, k0, k1, 0, d);
     else if (gs_waverl()) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2, 1, true>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
@@ -556,14 +569,14 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
         d.blk0 = b0; d.ent0 = e0;
         if (fuse_a)
         {
-          d.flags = 1u | 2u | 4u | (fuse_eigen ? 32u : 0u);
+          d.flags = 1u | 2u | 4u | (fuse_eigen ? 32u : 0u) | gs_root_flag(s);
           launch_klane<true>(dim3(b1 - b0), st, h ? nullptr : k0, h ? nullptr : k1, d);
           s->launches += 1;
           continue;
         }
         d.flags = 1u;
         if (!pm_done) hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3(((e1 - e0)*d.pad + 255u)/256u), dim3(256), 0, st, d, e1);
-        d.flags = 2u | 4u;
+        d.flags = 2u | 4u | gs_root_flag(s);
         launch_klane<false>(dim3(b1 - b0), st, h ? nullptr : k0, h ? nullptr : k1, d);
         s->launches += pm_done ? 1 : 2;
       }
@@ -573,7 +586,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     }
     if (fuse_a)
     {
-      d.flags = 1u | 2u | 4u | (fuse_eigen ? 32u : 0u);
+      d.flags = 1u | 2u | 4u | (fuse_eigen ? 32u : 0u) | gs_root_flag(s);
       launch_klane<true>(grid, e->stream, k0, k1, d);
       s->launches += 1;
     }
@@ -581,7 +594,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     {
       d.flags = 1u;
       if (!pm_done) hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((d.nmat*d.pad + 255u)/256u), dim3(256), 0, e->stream, d, d.nmat);
-      d.flags = 2u | 4u;
+      d.flags = 2u | 4u | gs_root_flag(s);
       launch_klane<false>(grid, e->stream, k0, k1, d);
       s->launches += pm_done ? 1 : 2;
     }
@@ -1058,11 +1071,26 @@ static int gs_iterate(bpa_sampler * s, unsigned iterations)
   return gs_join(s);                 // whoever uses the engine's stream next sees both halves
 }
 
+// The steps' evaluations left the roots' CLV buffers unstored (gs_skip_root_flag): with the last step settled, every buffer of
+// every locus is recomputed in place from the settled trees — the start-up evaluation (mode 5: no toggles, nothing drawn, nothing
+// counted), every parent stored, its result committed (same P-matrices, same CLVs, same sums: the values the chain already
+// holds, tests/test_gpu_gsampler.py) — so that what reads a locus's buffers after a download finds them as a step-by-step
+// caller of the reference's API would have left them.
+static int gs_level_roots(bpa_sampler * s)
+{
+  if (!s->g_root_stale) return 1;
+  s->g_level_eval = true;
+  const int ok = gs_step(s, 5) && gs_eval(s, 1) && gs_step(s, 4);
+  s->g_level_eval = false;
+  if (ok) s->g_root_stale = false;
+  return ok;
+}
+
 // settle whatever is pending and bring the trees to the host
 static int gs_download(bpa_sampler * s)
 {
   bpa_engine * e = s->eng;
-  if (!gs_step(s, 4)) return 0;
+  if (!gs_step(s, 4) || !gs_level_roots(s)) return 0;
   // the settle launch rolls rejected frequency / exchangeability proposals back in the parameter blocks: the loci's
   // eigensystems must follow before anyone else (bpa_batch_evaluate, a plan) computes P-matrices from them
   if (!gs_refresh_eigen(s)) return 0;

@@ -768,6 +768,10 @@ partials_lnl_wave20_kernel(const PlanDev P)
   const uint32_t op_begin = ((cu32_p)P.op_off)[ranges ? 2*t : t], op_end = ((cu32_p)P.op_off)[ranges ? 2*t + 1 : t + 1];
   if (ranges && op_begin == op_end) return;
   static const uint32_t none = 0xffffffffu;
+  // (round 6) flags bit 11: the step's last update is not stored when it makes the root's planes (step_s4_klane_v3_kernel has the
+  // reasons): nothing but the root term below reads them, and it has them in registers — 20 R plane stores per pattern less,
+  // a third to a half of what a per-locus step writes (rocprofv3, round 5: 59 % of this kernel's HBM bytes were writes)
+  const uint32_t skip_root = (P.flags & 2048u) ? ((cu32_p)P.root_clv)[t] : none;
   double ov[PP][S];                                                  // the parent just computed (forwarded)
   uint32_t ov_clv = none;
   double pfv[PP][S];                                                 // the plane requested ahead for the coming update
@@ -1027,6 +1031,9 @@ partials_lnl_wave20_kernel(const PlanDev P)
       lds_barrier();                                   // (the scratch is free again)
       drain = true;                                    // (more than the plane stores were issued behind the requests)
     }
+    // (the skipped store LEAVES the loop: every path around the back edge issues the same stores, so the compiler's wait
+    //  counts at the top of an update stay what the explicit vmcnt(20) assumes — see the note on masked regions above)
+    if (o + 1u == op_end && op.parent_clv == skip_root) break;
     if (wave_on)
     {
       asm volatile("" ::: "memory");
@@ -2991,6 +2998,8 @@ step_s4_klane_v3_kernel(const PlanDev P)
   extern __shared__ __attribute__((aligned(16))) double2 s_pmx[];    // [BS/64][rec2_units - 1][64]: every update's two matrices, per wave
   __shared__ double s_term[BS], s_tr[BS];
   __shared__ uint4 s_rec[BS/64][4][16];                               // per wave: the step records of the groups it spans
+  __shared__ double2 s_par[BS/64][4][16];                             // per wave and group: what the root term and the site term read of the parameter block (round 6)
+  __shared__ double2 s_ring[2][2][BS];                                // per lane: the parents of the updates two and three back (round 6)
   const uint32_t b = P.blk0 + blockIdx.x, lane = threadIdx.x, gl = b*BS + lane;
   if (FUSE_A && (P.flags & 32u))
   {
@@ -3105,6 +3114,24 @@ step_s4_klane_v3_kernel(const PlanDev P)
       st_nops = sh.task != none ? sh.nops : 0u;
     }
   }
+  // ---- (round 6) what the root term and the site term read of the locus's parameter block — matrix 0's frequencies, the
+  // categories' matrix indices, the category weights: 10 sixteen-byte units per group — is requested HERE, with trip 3, by the
+  // group's staging lanes and handed over through LDS.  Before, the root term began with a dependent round trip (index, then
+  // frequencies) and the site term with another (the weights): ~1.5 of a workgroup's 11 us (profiles/r5/probe_klane.txt).
+  // Global -> LDS directly (lds_dma16: lane 16 g + u lands at unit u of group g's corner, no registers); the units are 16-byte
+  // aligned when the category count is even (the block begins rates[R] | weights[R] | indices[R] | matrix 0), else the old way.
+  const bool have_par = use_lds && (P.flags & 2u) && __ballot(grouped && (R & 1u)) == 0ull;
+  if (have_par)                                    // (wave-uniform: every lane takes part in the shuffles)
+  {
+    const unsigned long long s_pa_lo = __shfl((uint32_t)reinterpret_cast<uintptr_t>(S.par), (int)src);
+    const unsigned long long s_pa_hi = __shfl((uint32_t)(reinterpret_cast<uintptr_t>(S.par) >> 32), (int)src);
+    const double * st_par = reinterpret_cast<const double *>(s_pa_lo | s_pa_hi << 32);
+    if (stager && st_nops != 0u && gu < 10u)
+    {
+      const uint32_t off = gu < 2u ? par_matrix(st_R, 4, 0) + pm_freqs(4) + 2u*gu : gu < 6u ? par_param_idx(st_R) + 2u*(gu - 2u) : par_rate_weights(st_R) + 2u*(gu - 6u);
+      lds_dma16(st_par + off, &s_par[wave][0][0]);
+    }
+  }
 
   double tr = 0;
   {
@@ -3117,14 +3144,18 @@ step_s4_klane_v3_kernel(const PlanDev P)
           reinterpret_cast<uintptr_t>(S.clv + ((((size_t)(c - tips)*R) + k)*np + n)*4));
     };
     auto code_of = [&](uint32_t c) { return tips <= 8 ? (ls.tipcodes >> (4*c)) & 15u : (uint32_t)S.tips[(size_t)c*np + n]; };
-    auto store_parent = [&](uint32_t pc, const double x[4], const double y[4])
+    // (round 6) flags bit 11: the step's LAST update is not stored when it makes the root's CLV — nothing reads a root's
+    // buffer but the root term below, which has it in registers; the device samplers set it (gsampler_host.hpp: gs_eval) and
+    // bring the buffers level before anything else may read them (gs_download).  A third of a step's parent stores.
+    const bool skip_root = (P.flags & 2048u) != 0;
+    auto store_parent = [&](uint32_t pc, const double x[4], const double y[4], const bool keep)
     {
       double2 o0, o1;
       o0.x = x[0]*y[0]; o0.y = x[1]*y[1]; o1.x = x[2]*y[2]; o1.y = x[3]*y[3];
       d2v a0, a1; a0.x = o0.x; a0.y = o0.y; a1.x = o1.x; a1.y = o1.y;
       __attribute__((address_space(1))) d2v * dst = reinterpret_cast<__attribute__((address_space(1))) d2v *>(
           reinterpret_cast<uintptr_t>(S.clv + ((((size_t)(pc - tips)*R) + k)*np + n)*4));
-      __builtin_nontemporal_store(a0, dst); __builtin_nontemporal_store(a1, dst + 1);
+      if (keep) { __builtin_nontemporal_store(a0, dst); __builtin_nontemporal_store(a1, dst + 1); }
       fwd[0] = o0.x; fwd[1] = o0.y; fwd[2] = o1.x; fwd[3] = o1.y;
       fwd_clv = pc;
     };
@@ -3133,6 +3164,12 @@ step_s4_klane_v3_kernel(const PlanDev P)
     {
       uint32_t written = 0;                                    // the CLV buffers (< 32: byte indices of <= 8-tip loci, 5 bits) this lane's step has written
       bool dma_waited = false;
+      // (round 6) the parents of the last three updates stay with the lane: the last one in registers (fwd, as before), the two
+      // before it in the lane's own LDS words (s_ring[update & 1]; hist: their buffer indices, a byte each).  A prune-and-regraft
+      // step walks TWO root paths whose updates alternate in age order, so a child is often the parent of the update before
+      // the last: read back from HBM "when used, after the lane's own store" that was a store -> load round trip (~2 us) in
+      // one locus-step in four (config 3; tools/opstat.py: distances 1 / 2 / 3 / more = 52 752 / 6 665 / 2 313 / 1 172).
+      uint32_t hist = 0xffffffu;
       for (uint32_t o0 = 0; __any(o0 < nops); o0 += (uint32_t)CH)
       {
         // ---- trip 3, part 1 (once per CH updates): these updates' matrices, global -> LDS
@@ -3195,9 +3232,19 @@ step_s4_klane_v3_kernel(const PlanDev P)
           if (o0 + j < nops)
           {
             const uint32_t pc = opw[j].x & 255u, lc = (opw[j].x >> 8) & 255u, rc = (opw[j].x >> 16) & 255u;
+            const uint32_t oi = o0 + (uint32_t)j;
+            // the parents two / three updates back and where they lie (three back shares the LDS word of the last one, which
+            // is still in registers and moves out below, after this update's reads)
+            const uint32_t h2 = (hist >> 8) & 255u, h3 = (hist >> 16) & 255u;
             double lv[4], rv[4], x[4], y[4];
             if (lc == fwd_clv) { lv[0] = fwd[0]; lv[1] = fwd[1]; lv[2] = fwd[2]; lv[3] = fwd[3]; }
             else if (lc < tips) expand_code(code_of(lc), lv);
+            else if (lc == h2 || lc == h3)
+            {
+              const uint32_t lvl = lc == h2 ? (oi & 1u) : ((oi + 1u) & 1u);
+              const double2 uu = s_ring[lvl][0][lane], ww = s_ring[lvl][1][lane];
+              lv[0] = uu.x; lv[1] = uu.y; lv[2] = ww.x; lv[3] = ww.y;
+            }
             else
             {
               d2v uu, ww;
@@ -3208,6 +3255,12 @@ step_s4_klane_v3_kernel(const PlanDev P)
             }
             if (rc == fwd_clv) { rv[0] = fwd[0]; rv[1] = fwd[1]; rv[2] = fwd[2]; rv[3] = fwd[3]; }
             else if (rc < tips) expand_code(code_of(rc), rv);
+            else if (rc == h2 || rc == h3)
+            {
+              const uint32_t lvl = rc == h2 ? (oi & 1u) : ((oi + 1u) & 1u);
+              const double2 uu = s_ring[lvl][0][lane], ww = s_ring[lvl][1][lane];
+              rv[0] = uu.x; rv[1] = uu.y; rv[2] = ww.x; rv[3] = ww.y;
+            }
             else
             {
               d2v uu, ww;
@@ -3216,6 +3269,14 @@ step_s4_klane_v3_kernel(const PlanDev P)
               else { const auto p = clv_ptr(rc); uu = __builtin_nontemporal_load(p); ww = __builtin_nontemporal_load(p + 1);
                      asm volatile("" : "+v"(uu)); asm volatile("" : "+v"(ww)); }
               rv[0] = uu.x; rv[1] = uu.y; rv[2] = ww.x; rv[3] = ww.y;
+            }
+            // the last update's parent leaves the registers for its LDS word (level (oi - 1) & 1: the update three back has been
+            // read if it was wanted).  HERE, between the children and the arithmetic: at the end of the update, with x and y
+            // live, the same two writes cost 200 spilled registers
+            if (oi != 0u)
+            {
+              double2 m0, m1; m0.x = fwd[0]; m0.y = fwd[1]; m1.x = fwd[2]; m1.y = fwd[3];
+              s_ring[(oi + 1u) & 1u][0][lane] = m0; s_ring[(oi + 1u) & 1u][1][lane] = m1;
             }
             const double2 * r = pmw + (size_t)j*64u + my_g*16u;
 #pragma unroll
@@ -3231,7 +3292,8 @@ step_s4_klane_v3_kernel(const PlanDev P)
               const double2 a1 = r[(8 + 2*i) ^ my_g], b1 = r[(8 + 2*i + 1) ^ my_g];
               y[i] = dot4_pair(a1.x, a1.y, b1.x, b1.y, rv);
             }
-            store_parent(pc, x, y);
+            store_parent(pc, x, y, !(skip_root && oi + 1u == nops && pc == (uint32_t)hdr.root_clv));
+            hist = (hist << 8) | pc;
             written |= 1u << (pc & 31u);
           }
         }
@@ -3257,7 +3319,7 @@ step_s4_klane_v3_kernel(const PlanDev P)
           vec_of(op.right_clv, rv);
           matvec4_p(S.pmat, S.pstride, (size_t)op.left_pmatrix*R  + k, lv, x);
           matvec4_p(S.pmat, S.pstride, (size_t)op.right_pmatrix*R + k, rv, y);
-          store_parent(op.parent_clv, x, y);
+          store_parent(op.parent_clv, x, y, !(skip_root && o + 1u == nops && op.parent_clv == hdr.root_clv));
         }
       }
     }
@@ -3271,10 +3333,20 @@ step_s4_klane_v3_kernel(const PlanDev P)
       if (rc == fwd_clv) { c[0] = fwd[0]; c[1] = fwd[1]; c[2] = fwd[2]; c[3] = fwd[3]; }
       else if (rc < tips) expand_code(code_of(rc), c);
       else { const auto p = clv_ptr(rc); const d2v uu = __builtin_nontemporal_load(p), ww = __builtin_nontemporal_load(p + 1); c[0] = uu.x; c[1] = uu.y; c[2] = ww.x; c[3] = ww.y; }
-      // (the category's matrix index and — in the same round trip — matrix 0's frequencies, which it names nearly always)
-      const double md = par[par_param_idx(R) + k];
-      const double * f0 = par + par_matrix(R, 4, 0) + pm_freqs(4);
-      double fr[4] = {f0[0], f0[1], f0[2], f0[3]};
+      // (the category's matrix index and — in the same round trip — matrix 0's frequencies, which it names nearly always;
+      //  round 6: both out of the group's LDS corner, requested with the step's matrices)
+      double md, fr[4];
+      if (have_par && nops != 0u)
+      {
+        const double2 mi = s_par[wave][my_g][2u + (k >> 1)], fa = s_par[wave][my_g][0], fb = s_par[wave][my_g][1];
+        md = (k & 1u) ? mi.y : mi.x; fr[0] = fa.x; fr[1] = fa.y; fr[2] = fb.x; fr[3] = fb.y;
+      }
+      else
+      {
+        md = par[par_param_idx(R) + k];
+        const double * f0 = par + par_matrix(R, 4, 0) + pm_freqs(4);
+        fr[0] = f0[0]; fr[1] = f0[1]; fr[2] = f0[2]; fr[3] = f0[3];
+      }
       const uint32_t m = (uint32_t)md;
       if (m != 0u) { const double * f = par + par_matrix(R, 4, m) + pm_freqs(4); fr[0] = f[0]; fr[1] = f[1]; fr[2] = f[2]; fr[3] = f[3]; }
       tr = dot4_pair(fr[0], fr[1], fr[2], fr[3], c);
@@ -3289,8 +3361,16 @@ step_s4_klane_v3_kernel(const PlanDev P)
     // (the category weights in ONE round trip: a load per turn of a loop with a run-time bound waits for each in turn)
     const double * par = S.par;
     double rwv[8];
+    if (have_par && hdr.nops != 0u)
+    {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) rwv[q] = (uint32_t)q < R ? par[par_rate_weights(R) + q] : 0.0;
+      for (int q = 0; q < 8; q += 2) { const double2 w2 = s_par[wave][my_g][6 + (q >> 1)]; rwv[q] = w2.x; rwv[q + 1] = w2.y; }
+    }
+    else
+    {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rwv[q] = (uint32_t)q < R ? par[par_rate_weights(R) + q] : 0.0;
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) if ((uint32_t)q < R) term += s_tr[lane + q*np]*rwv[q];
     term = log(term)*ls.wgt;

@@ -1177,6 +1177,8 @@ struct bpa_sampler
   double g_ft[3] = {0, 0, 0}, g_alpha_a = 1, g_alpha_b = 1;
   unsigned g_pend_mode = 0, g_pend_k = 0;
   bool g_eigen_dirty = false;
+  bool g_level_eval = false;            // gs_level_roots: this evaluation stores every parent
+  bool g_root_stale = false;            // a step's evaluation left the root's CLV unstored (flags bit 11): gs_download brings the buffers level
   bool g_pm_fused = false;              // the proposal launch just issued filled the step's P-matrices itself (gs_step -> gs_eval)
   unsigned long g_evals = 0;            // launches of the likelihood step kernel (bpa_sampler_work reports them as `sweeps`)
   unsigned nblocks = 0, epoch = 0;
@@ -1331,12 +1333,15 @@ static bpa_sampler * sampler_create_plain(bpa_engine_t * e, bpa_locus_t * const 
   return s;
 }
 
+static int sampler_download(bpa_sampler * s);
 extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
 {
   if (!s) return;
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (s->comp) comp_destroy(s);
   (void)set_device(s->eng);
+  // (the loci outlive the sampler: their buffers are left as a step-by-step caller would have left them, gs_level_roots)
+  if (s->generic && s->uploaded && s->g_root_stale && s->g_pack_epoch == s->eng->pack_epoch && !sampler_download(s)) fprintf(stderr, "[bpp_amd] bpa_sampler_destroy: the loci's root buffers could not be brought level (%s)\n", bpa_last_error());
   (void)hipStreamSynchronize(s->eng->stream);
   for (auto & t : s->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   s->blk_task_off.free(); s->lane_rec.free(); s->task_rec.free(); s->flag.free();
