@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+BASELINE_METRIC = "MCMC iterations/sec (A00) + site-lnL updates/sec, 10k loci, 1/2/4/8 GPU"      # BASELINE.json's `metric`, verbatim
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md: FP64 vector peak (the FP64 matrix rate is the same on gfx950)
 HBM_ACHIEVABLE_FRAC = 0.79   # ~6.3 of 8 TB/s is what a streaming kernel reaches (MI355X_MICROARCH.md): a `frac` above it is an accounting artefact
@@ -114,7 +115,8 @@ def compact_line(full):
             pass
     if lo:
         r = lo.get("roofline") or {}
-        out["likelihood_only"] = {"it_s": lo.get("iterations_per_s"), "kernel": (r.get("kernel") or "")[:50], "frac": r.get("frac"),
+        out["likelihood_only"] = {"it_s": lo.get("iterations_per_s"), "site_lnl_updates_per_s": lo.get("site_lnl_updates_per_s"),
+                                  "kernel": (r.get("kernel") or "")[:50], "frac": r.get("frac"),
                                   "frac_codes": r.get("frac_codes"), "frac_pmc": r.get("frac_pmc"), "flops_frac": r.get("flops_frac"),
                                   "avg_kernel_us": r.get("avg_kernel_us")}
     hc = g("host_control_in_c") or {}
@@ -1348,6 +1350,8 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves
                proposals_per_locus_iteration=3 * cfg["taxa"] - 3 + (9 if gtr else 0),
                launches_per_iteration=round(max(l1 - l0 - (0 if kind == "persistent" else 1), 0) / niter, 4),      # (-1: the settle launch of the first summary)
                acceptance=round(sm["accepted"] / max(sm["proposals"], 1), 3),
+               # pattern (site) log-likelihood updates of THIS run: node updates x the locus's patterns, device counters over the timed region
+               site_lnl_updates_per_s=round((w1["pattern_updates"] - w0["pattern_updates"]) * (total_loci / nloci) / dt),
                moves=("the program's (BPP v4.8.7 defaults): legacy_rndu + Bactrian-Laplace windows, theta by the metropolized Gibbs draw 9 times in 10 "
                       "(stree.c:3957), thetas re-drawn inside the rubber band (stree.c:5840) and the mixing step (prop_mixing.c:272); step lengths "
                       "from the program's burn-in rule run on the device (bpa_sampler_burnin, 800 iterations)" if program else
@@ -1651,12 +1655,12 @@ def main():
             value = sampler_sec["iterations_per_s_10k_loci"] if (args.scaling == "weak" and args.config in ("c2", "c3")) else sampler_sec["iterations_per_s"]
             ms_per_step = sampler_sec["ms_per_step"]
             roofline = sampler_sec.pop("roofline")
-            metric = "MCMC iterations/sec (A00), every decision on the device"
+            metric = BASELINE_METRIC
         elif tape_sec is not None:
             value = (tape_sec["iterations_per_s_10k_loci"] if (args.config == "c2" and args.scaling == "weak") else tape_sec["iterations_per_s"])
             ms_per_step = tape_sec["ms_per_step"]
             roofline = tape_sec["roofline"]
-            metric = "A00 iterations/sec of the likelihood hot path (proposal tape)"
+            metric = BASELINE_METRIC + " [likelihood hot path only: proposal tape]"
         else:                                    # (--no-sampler --no-tape: only the side sections were asked for)
             value, ms_per_step, roofline = None, None, None
             metric = "no headline section was run (--no-sampler --no-tape)"
@@ -1689,7 +1693,7 @@ def main():
                 ratios["likelihood_only_over_tape_replay_one_core"] = round(
                     (tape_sec["iterations_per_s_10k_loci"] if args.config == "c2" else tape_sec["iterations_per_s"]) / cpu["value"], 1)
         out = {
-            "metric": metric + " + site-lnL updates/sec, 10k loci, 1/2/4/8 GPU",
+            "metric": metric,
             "value": value,
             "unit": (f"iterations/s (one iteration = one A00 MCMC iteration over {loci_unit} loci" +
                      ("; weak scaling: N data sets of that size, value = N x per-rank rate)" if (D is not None and args.scaling == "weak") else ")")),
@@ -1707,8 +1711,13 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["name"] + f"; {nloci} loci on rank 0, {npat / nloci:.2f} patterns/locus" +
                        (f"; {3 * cfg['taxa'] - 3} gene-tree proposals per locus + a theta step per population + {cfg['taxa'] - 1} tau + 1 mixing step per iteration; moves: " + sampler_sec.get("moves", "?") if headline_sampler else ""),
-                       "parallelism": parallelism},
-            "site_lnl_updates_per_s": tape_sec["site_lnl_updates_per_s"] if tape_sec else None,
+                       "workload_short": cfg["name"] + f"; {nloci} loci on rank 0, {npat / nloci:.1f} patterns/locus",
+                       "parallelism": parallelism,
+                       "moves": (sampler_sec.get("moves_short") if headline_sampler else "tape (accept/reject by a seeded coin)"),
+                       "decisions": ("every proposal, density, likelihood and accept/reject on the device" if headline_sampler else None)},
+            # the second half of the metric comes from the SAME run as `value` (the sampler's device counters); the tape's own
+            # figure stays under likelihood_only
+            "site_lnl_updates_per_s": (sampler_sec.get("site_lnl_updates_per_s") if headline_sampler else tape_sec["site_lnl_updates_per_s"] if tape_sec else None),
             "roofline": roofline,
             "cpu_baseline": cpu_like,
             "speedups": ratios,

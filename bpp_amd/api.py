@@ -138,6 +138,7 @@ def lib():
         "bpa_finetune_onestep": (d, [d, d]),
         "bpa_sampler_adapt_finetune": (i, [vp, dp, dp]),
         "bpa_sampler_burnin": (i, [vp, u, dp]),
+        "bpa_burnin_schedule": (u, [u, C.POINTER(u), u]),
         "bpa_sampler_set_tau_prior": (None, [vp, d, d]),
         "bpa_sampler_set_theta_prior": (None, [vp, d, d, d]),
         "bpa_sampler_get_thetas": (i, [vp, dp]),
@@ -194,7 +195,7 @@ EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_cre
             "bpa_plan_work", "bpa_engine_enable_timing", "bpa_engine_timing", "bpa_engine_set_timing_stride", "bpa_engine_timing_work", "bpa_engine_timing_work_codes", "bpa_plan_work_codes",
             "bpa_sampler_create", "bpa_sampler_destroy", "bpa_sampler_set_tree", "bpa_sampler_initialize",
             "bpa_sampler_set_species_tree", "bpa_sampler_set_tip_species", "bpa_sampler_set_finetune",
-            "bpa_finetune_onestep", "bpa_sampler_adapt_finetune", "bpa_sampler_burnin",
+            "bpa_finetune_onestep", "bpa_sampler_adapt_finetune", "bpa_sampler_burnin", "bpa_burnin_schedule",
             "bpa_sampler_set_tau_prior", "bpa_sampler_get_taus", "bpa_sampler_get_tree_msc",
             "bpa_sampler_set_theta_prior", "bpa_sampler_get_thetas", "bpa_sampler_set_allreduce",
             "bpa_sampler_iterate", "bpa_sampler_get_tree", "bpa_sampler_summary",

@@ -97,6 +97,7 @@ struct GArgs
   // 4-state loci on the engine's packing: the lane group that wrote the step's fresh branches also fills their P-matrices
   // (what pmatrix_s4_dense_kernel did as a launch of its own between the proposal and the node updates)
   const SlotStatic * slot_tab; uint32_t fuse_pm;
+  const struct GDecState * dstep;         // the program's moves decided on the device: the TAU window / MIX factor of this step (else null: tau_w, mix_c, mix_lnc)
   Species sp;
 };
 
@@ -621,6 +622,235 @@ __global__ void gprog_apply_kernel(const GApply a, uint32_t epoch, uint32_t * fl
   if (a.scale_taus) for (int p = 0; p < npop; ++p) taus[p] *= a.mix_c;
   for (int p = 0; p < npop; ++p)
     if ((a.theta_mask >> p) & 1u) { taus[MAXPOP + p] = a.theta[p]; taus[2*MAXPOP + p] = log(2.0/(1.0*a.theta[p])); }
+}
+
+
+// ======================= the program's THETA / TAU / MIX decided ON THE DEVICE (round 6) =======================================
+// The host-decided form above costs an iteration nine synchronisations: the stream drains, the host fits inverse gammas and
+// draws, a one-lane launch installs the result — 25-40 us each during which the GPU has nothing queued, and the reason an
+// iteration of the generic sampler could not be one uninterrupted sequence of launches (config 3, 193 launches and
+// 9 host synchronisations).  Here ONE WAVE takes the decision where the sums are: gdec_kernel runs the persistent kernel's
+// control-wave functions (sweep2.hpp: prog_theta_decide / prog_tau_decide / prog_mix_redraw — lane p = population p, the fits of
+// all thetas side by side, the gamma variates drawn in parallel, bit-equal to get_gamma_conditional_approx on 1e5 cases,
+// tests/test_bpp_kernel.py), installs it (rejection flag, taus, thetas, counters: gprog_apply_kernel's job) and makes the NEXT
+// step's species-tree proposal (the window variate of the coming TAU; log c and the theta re-draws of the coming MIX), which the
+// step kernels read from GDecState instead of their arguments.  The global stream, the fits (k, T, a, b, c per population) and
+// the move-type counters live in GDecState between launches.  Stream order = a00_driver.c's = the host form's:
+// [first TAU's window] [THETA: choices + windows] [Gibbs variates] [acceptance numbers] [TAU: variates, acceptance] [next window] ...
+// The host form stays as the trajectory reference (BPA_GS_HOSTDEC=1) — same decisions, tests/test_gpu_gsampler.py.
+//
+// The sums arrive as DOUBLES in the all-reduce callback's format (gs_prog_allreduce): a likelihood / Jacobian sum as it is, a
+// non-negative 64-bit integer sum as two doubles holding its upper and lower 32 bits (exact for any number of ranks) — so several
+// ranks put their collective between the sum kernel and this one, on the stream, and no host is in the loop either.
+struct GDecState
+{
+  uint32_t z, run_ok, rd_mask, pad0;                 // the global stream (legacy_rndu); THETA's sums were usable; MIX's re-drawn thetas
+  double tau_w, mix_c, mix_lnc, lnacc_theta;         // the coming step's proposal (step kernels: GArgs::dstep) and MIX's theta part
+  smp2::PopFit pf[16];
+  smp2::Redraw rd[16];
+  unsigned long long pj[10];                         // [4..9] tau / mix / theta-window proposals and acceptances since the last adapt_finetune
+};
+
+__device__ __forceinline__ void gdec_split64(long long x, double * hi, double * lo) { *hi = (double)(x >> 32); *lo = (double)(x & 0xffffffffll); }
+__device__ __forceinline__ long long gdec_join64(double hi, double lo) { return (long long)hi*4294967296ll + (long long)lo; }
+
+// gprog_sums_kernel / gprog_theta_sums_kernel with their results as doubles in a device buffer
+__global__ void __launch_bounds__(1024) gdec_sums_kernel(const double * __restrict__ lnl_cur, const double * __restrict__ lnl_new,
+                                                         const double * __restrict__ delta, const uint8_t * __restrict__ active,
+                                                         const double * __restrict__ t2h3, uint32_t T, int with_t2h, double * out)
+{
+  __shared__ double sh[1024];
+  __shared__ long long shl[3][1024];
+  __shared__ int shb[1024];
+  double acc = 0; long long c[3] = {0, 0, 0}; int bad = 0;
+  for (uint32_t i = threadIdx.x; i < T; i += 1024)
+  {
+    acc += (active[i] ? lnl_new[i] - lnl_cur[i] : 0.0) + delta[i];
+    if (with_t2h)
+      for (int j = 0; j < 3; ++j)
+      {
+        const double x = t2h3[(size_t)3*i + j];
+        if (!(fabs(x) < 256.0)) bad = 1; else c[j] += llrint(x*1099511627776.0);
+      }
+  }
+  sh[threadIdx.x] = acc; shb[threadIdx.x] = bad;
+  for (int j = 0; j < 3; ++j) shl[j][threadIdx.x] = c[j];
+  __syncthreads();
+  for (uint32_t w = 512; w > 0; w >>= 1)
+  {
+    if (threadIdx.x < w)
+    {
+      sh[threadIdx.x] += sh[threadIdx.x + w]; shb[threadIdx.x] |= shb[threadIdx.x + w];
+      for (int j = 0; j < 3; ++j) shl[j][threadIdx.x] += shl[j][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x) return;
+  bool neg = false;
+  for (int j = 0; j < 3; ++j) neg = neg || shl[j][0] < 0;
+  out[0] = sh[0];
+  for (int j = 0; j < 3; ++j) gdec_split64(neg ? 0 : shl[j][0], &out[1 + 2*j], &out[2 + 2*j]);
+  out[7] = (neg || shb[0]) ? 1.0 : 0.0;
+}
+
+__global__ void __launch_bounds__(1024) gdec_theta_sums_kernel(const int8_t * __restrict__ pop_nc, const double * __restrict__ pop_t2h,
+                                                               uint32_t T, uint32_t onmask, double * out)
+{
+  __shared__ long long shk[1024], sht[1024];
+  __shared__ int shb[1024];
+  const int p = (int)blockIdx.x;
+  long long k = 0, t = 0; int bad = 0;
+  if ((onmask >> p) & 1u)
+    for (uint32_t i = threadIdx.x; i < T; i += 1024)
+    {
+      const double x = pop_t2h[(size_t)p*T + i];
+      if (!(fabs(x) < 256.0)) bad = 1; else { k += pop_nc[(size_t)p*T + i]; t += llrint(x*1099511627776.0); }
+    }
+  shk[threadIdx.x] = k; sht[threadIdx.x] = t; shb[threadIdx.x] = bad;
+  __syncthreads();
+  for (uint32_t w = 512; w > 0; w >>= 1)
+  {
+    if (threadIdx.x < w) { shk[threadIdx.x] += shk[threadIdx.x + w]; sht[threadIdx.x] += sht[threadIdx.x + w]; shb[threadIdx.x] |= shb[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+  {
+    const bool neg = shk[0] < 0 || sht[0] < 0;         // (never: counts and waiting times)
+    out[4*p] = (double)(neg ? 0 : shk[0]); gdec_split64(neg ? 0 : sht[0], &out[4*p + 1], &out[4*p + 2]); out[4*p + 3] = (neg || shb[0]) ? 1.0 : 0.0;
+  }
+}
+
+// PHASE 0: THETA (v: 4 doubles per population) + the first TAU's window; 1: TAU q (v: 8 doubles) + the next step's proposal
+// (next < npop: TAU `next`, next == npop: MIX with its re-draws); 2: MIX (v: 1 double).  One wave; dynamic LDS = smp2::WgBase.
+template <int PHASE>
+__global__ void __launch_bounds__(64) gdec_kernel(GDecState * __restrict__ st, const double * __restrict__ v, const Species sp, const uint32_t tm,
+                                                  const int q, const int next, const uint32_t epoch, uint32_t * __restrict__ flag,
+                                                  uint32_t * __restrict__ counters, double * __restrict__ taus)
+{
+  smp2::WgBase & wg = smp2::wg_base();
+  const uint32_t lane = threadIdx.x & 63u;
+  const int npop = sp.npop, nsp = sp.S;
+  const double qnan = smp2::prog_qnan();
+  {
+    const uint32_t * src = reinterpret_cast<const uint32_t *>(&sp);
+    uint32_t * dst = reinterpret_cast<uint32_t *>(&wg.sp);
+    for (uint32_t i = lane; i < sizeof(Species)/4; i += 64u) dst[i] = src[i];
+  }
+  if (lane < (uint32_t)(3*MAXPOP)) wg.tau[lane] = taus[lane];
+  if (lane < 16u) { wg.pf[lane] = st->pf[lane]; wg.rd[lane] = st->rd[lane]; }
+  if (lane < 32u) wg.xtot[lane] = 0.0;
+  if (lane == 0) { wg.dec.run_ok = st->run_ok; wg.dec.rd_mask = st->rd_mask; wg.dec.lnacc_theta = st->lnacc_theta; wg.dec.accm = 0; wg.dec.acc_step = 0; }
+  smp2::wsync();
+  smp2::Stream<true> g{(a00_rng_t)st->z};
+  uint32_t c_prop = 0, c_acc = 0, c_gprop = 0, c_gacc = 0;
+  unsigned long long pj4 = 0, pj5 = 0, pj6 = 0, pj7 = 0, pj8 = 0, pj9 = 0;
+  double tau_w = st->tau_w, mix_c = st->mix_c, mix_lnc = st->mix_lnc;
+
+  if (PHASE == 0)
+  {
+    // (a00_iterate: the first TAU's window comes before the THETA step's numbers in the global stream)
+    const double pre = tm ? g.window() : 0.0;
+    uint32_t slidem = 0; double tslide = 0;
+    for (int p = 0; p < npop; ++p)
+      if ((tm >> p) & 1u)
+      {
+        if (!(g.u() < sp.theta_slide_prob)) continue;
+        slidem |= 1u << p;
+        const double tn = reflect(wg.tau[MAXPOP + p] + sp.ft_theta*g.window(), 0.0, 999.0);
+        if (p == (int)lane) tslide = tn;
+      }
+    // the sums: k_p, T_p of the populations of the mask, in order; an unusable term anywhere: every total is NaN
+    bool bad = false;
+    for (int p = 0; p < npop; ++p) bad = bad || v[4*p + 3] != 0.0;
+    if (lane < (uint32_t)npop && ((tm >> lane) & 1u))
+    {
+      const int kx = __popc(tm & ((1u << lane) - 1u));
+      wg.xtot[(2*kx) & 31] = bad ? qnan : (double)(long long)v[4*lane];
+      wg.xtot[(2*kx + 1) & 31] = bad ? qnan : (double)gdec_join64(v[4*lane + 1], v[4*lane + 2])*(1.0/1099511627776.0);
+    }
+    smp2::wsync();
+    g.r = smp2::prog_theta_decide((uint32_t)g.r, tm, slidem, tslide, 1, -1, 0);
+    const uint32_t accm = wg.dec.accm;
+    c_prop = (uint32_t)__popc(tm); c_acc = (uint32_t)__popc(accm);
+    c_gprop = (uint32_t)__popc(tm & ~slidem); c_gacc = (uint32_t)__popc(accm & tm & ~slidem);
+    pj8 = (unsigned long long)__popc(tm & slidem); pj9 = (unsigned long long)__popc(accm & tm & slidem);
+    // the first TAU's window: drawn above when there is a theta to move, here otherwise (the host form's gs_prog_tau)
+    tau_w = tm ? pre : g.window();
+  }
+  else if (PHASE == 1)
+  {
+    const int pq = sp.parent[q], cl = sp.left[q], cr = sp.right[q];
+    const double tq_old = wg.tau[q], tq_lo = fmax(wg.tau[cl], wg.tau[cr]), tq_hi = pq >= 0 ? wg.tau[pq] : 999.0;
+    const double tq_new = reflect(tq_old + sp.ft_tau*tau_w, tq_lo, tq_hi);
+    double lnprior = 0;
+    if (pq < 0 && sp.tau_alpha > 0) lnprior = (sp.tau_alpha - 1 - (nsp - 1) + 1)*log(tq_new/tq_old) - sp.tau_beta*(tq_new - tq_old);
+    const bool bad = v[7] != 0.0;
+    if (lane == 0) { wg.xtot[0] = v[0]; wg.xtot[1] = 0.0; }
+    if (lane >= 2u && lane <= 4u) wg.xtot[lane] = bad ? qnan : (double)gdec_join64(v[2*lane - 3], v[2*lane - 2])*(1.0/1099511627776.0);
+    smp2::wsync();
+    g.r = smp2::prog_tau_decide((uint32_t)g.r, tm, q, 0, lnprior, false);
+    const bool accept = wg.dec.acc_step != 0u;
+    const uint32_t rd_mask = wg.dec.rd_mask;
+    c_prop = 1; c_acc = accept ? 1u : 0u; pj4 = 1; pj5 = accept ? 1ull : 0ull;
+    if (accept)
+    {
+      if (lane == 0) wg.tau[q] = tq_new;
+      if (lane < 16u)
+      {
+        const smp2::Redraw r = wg.rd[lane];
+        if ((rd_mask >> lane) & 1u) { wg.tau[MAXPOP + lane] = r.tn; wg.tau[2*MAXPOP + lane] = r.l2t; }
+        const bool moved = ((tm >> lane) & 1u) && ((int)lane == q || (int)lane == cl || (int)lane == cr);
+        if (moved) { smp2::PopFit & f = wg.pf[lane]; f.T = r.T; f.a = r.a; f.b = r.b; f.c = r.c; }
+      }
+    }
+    else if (lane == 0) *flag = epoch;
+    smp2::wsync();
+    // the coming step's proposal: the next TAU's window, or MIX's log c and — nothing of it depends on the loci — its re-draws
+    const double wprop = g.window();
+    if (next < npop) tau_w = wprop;
+    else
+    {
+      mix_lnc = sp.ft_mix*wprop; mix_c = exp(mix_lnc);
+      g.r = smp2::prog_mix_redraw((uint32_t)g.r, tm, mix_c);
+    }
+  }
+  else
+  {
+    double lnacc = (v[0] + 0.0) + (double)(nsp - 1)*mix_lnc;
+    if (sp.tau_alpha > 0)
+    {
+      const double troot = wg.tau[npop - 1];
+      lnacc += (sp.tau_alpha - 1)*mix_lnc - sp.tau_beta*(troot*mix_c - troot) - (double)(nsp - 2)*mix_lnc;
+    }
+    lnacc += wg.dec.lnacc_theta;
+    const uint32_t rd_mask = wg.dec.rd_mask;
+    const bool accept = g.accept(lnacc);
+    c_prop = 1; c_acc = accept ? 1u : 0u; pj6 = 1; pj7 = accept ? 1ull : 0ull;
+    if (accept)
+    {
+      if (lane < (uint32_t)npop) wg.tau[lane] *= mix_c;
+      if (lane < 16u)
+      {
+        const smp2::Redraw r = wg.rd[lane];
+        if ((rd_mask >> lane) & 1u) { wg.tau[MAXPOP + lane] = r.tn; wg.tau[2*MAXPOP + lane] = r.l2t; }
+        smp2::PopFit & f = wg.pf[lane];
+        if (lane < (uint32_t)npop && ((tm >> lane) & 1u)) { f.T = r.T; f.a = r.a; f.b = r.b; f.c = r.c; }
+        else if (lane < (uint32_t)npop) f.T *= mix_c;
+      }
+    }
+    else if (lane == 0) *flag = epoch;
+  }
+  smp2::wsync();
+  // ---- the state for the launches that follow
+  if (lane < (uint32_t)(3*MAXPOP)) taus[lane] = wg.tau[lane];
+  if (lane < 16u) { st->pf[lane] = wg.pf[lane]; st->rd[lane] = wg.rd[lane]; }
+  if (lane == 0)
+  {
+    st->z = (uint32_t)g.r; st->run_ok = wg.dec.run_ok; st->rd_mask = wg.dec.rd_mask; st->lnacc_theta = wg.dec.lnacc_theta;
+    st->tau_w = tau_w; st->mix_c = mix_c; st->mix_lnc = mix_lnc;
+    counters[0] += c_prop; counters[1] += c_acc; counters[2] += c_gprop; counters[3] += c_gacc;
+    st->pj[4] += pj4; st->pj[5] += pj5; st->pj[6] += pj6; st->pj[7] += pj7; st->pj[8] += pj8; st->pj[9] += pj9;
+  }
 }
 
 } // namespace gsm

@@ -88,6 +88,9 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
   const gsm::GLocus L = A.loc[ic];
   const int gl_i = li < MAXPOP ? (int)L.gl[li] : 0;
   const uint32_t d_active = A.active[ic], d_flag = *A.flag;
+  // (the program's moves decided on the device, gdec_kernel: this step's window variate / factor lies in its state)
+  const double d_tau_w = (MODE == 2 && A.dstep) ? A.dstep->tau_w : A.tau_w;
+  const double d_mix_c = (MODE == 3 && A.dstep) ? A.dstep->mix_c : A.mix_c, d_mix_lnc = (MODE == 3 && A.dstep) ? A.dstep->mix_lnc : A.mix_lnc;
   const double d_lnl = A.lnl_new[ic], d_logpr = A.logpr_new[ic], d_hast = A.hast[ic];
 
   if (lane < (uint32_t)(3*MAXPOP)) s_tau[lane] = tau_r;
@@ -292,7 +295,7 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
       // TAU q (tau_step of a00_driver.c): the gene nodes of q and its children between the bounds ride the rubber band
       const int q = (int)C.k, pq = SP.parent[q], cl = SP.left[q], cr = SP.right[q];
       const double tq_old = s_tau[q], tq_lo = fmax(s_tau[cl], s_tau[cr]), tq_hi = pq >= 0 ? s_tau[pq] : 999.0;
-      const double tnew = smp::reflect(tq_old + SP.ft_tau*(A.bpp ? A.tau_w : A.tau_u - 0.5), tq_lo, tq_hi);
+      const double tnew = smp::reflect(tq_old + SP.ft_tau*(A.bpp ? d_tau_w : A.tau_u - 0.5), tq_lo, tq_hi);
       const double minf = (tnew - tq_lo)/(tq_old - tq_lo), maxf = (tnew - tq_hi)/(tq_old - tq_hi);
       lminf = log(minf); lmaxf = log(maxf);
       if (li == q) pl.tau = tnew;
@@ -314,9 +317,9 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
     else
     {
       // mixing (mix_step of a00_driver.c): every tau, every age times c
-      pl.tau *= A.mix_c;
-      if (pl.parent >= 0) pl.ptau *= A.mix_c;
-      if (inner_i) S.time[li] = tsave*A.mix_c;
+      pl.tau *= d_mix_c;
+      if (pl.parent >= 0) pl.ptau *= d_mix_c;
+      if (inner_i) S.time[li] = tsave*d_mix_c;
       pr.ndm = smp2::gballot<G>(inner_i, gbase);
       pr.brm = smp2::gballot<G>(li < n && (int)T.parent[li] >= 0, gbase);
     }
@@ -374,8 +377,8 @@ __device__ __forceinline__ void gstep2_body(const gsm::GArgs & A, const StepCtl 
       A.logpr_new[i] = lp_new;
       // p_delta of the host driver; the program's moves (A.prog): the densities' change over all loci follows from the sums of
       // k and T2h with the re-drawn thetas, on the host (tau_step / mix_step of a00_driver.c) — the loci bring their Jacobian only
-      if (A.prog) A.delta[i] = MODE == 2 ? below*lminf + above*lmaxf : (double)(tips - 1)*A.mix_lnc;
-      else A.delta[i] = MODE == 2 ? ((lp_new - logpr_cur) + below*lminf) + above*lmaxf : (lp_new - logpr_cur) + (double)(tips - 1)*A.mix_lnc;
+      if (A.prog) A.delta[i] = MODE == 2 ? below*lminf + above*lmaxf : (double)(tips - 1)*d_mix_lnc;
+      else A.delta[i] = MODE == 2 ? ((lp_new - logpr_cur) + below*lminf) + above*lmaxf : (lp_new - logpr_cur) + (double)(tips - 1)*d_mix_lnc;
       A.lnl_cur[i] = lnl_cur;
     }
     if (ok) { w_nupd += (uint32_t)nops; w_nbr += (uint32_t)__popc(pr.brm); ++w_nev; }

@@ -236,8 +236,8 @@ static bool gs_prog(const bpa_sampler * s) { return s->kernel_bpp && s->sp.progr
 // is ahead at every size (1 250 loci 507 -> 513 it/s, 2 500: 408 -> 423, 10 000: 194 -> 207), so this is a switch only
 static bool gs_fuse_a(const bpa_sampler * s)
 {
-  const char * fa_env = getenv("BPA_GS_FUSEA");
-  return !s->g_alljc && !s->g_s20 && fa_env && fa_env[0] == '1';
+  static const bool on = [] { const char * v = getenv("BPA_GS_FUSEA"); return v && v[0] == '1'; }();     // (read once: this runs per launch)
+  return !s->g_alljc && !s->g_s20 && on;
 }
 
 static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u = 0, double mix_c = 1.0, double mix_lnc = 0, double tau_w = 0)
@@ -261,6 +261,7 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   a.ft_freqs = s->g_ft[0]; a.ft_qrates = s->g_ft[1]; a.ft_alpha = s->g_ft[2]; a.alpha_a = s->g_alpha_a; a.alpha_b = s->g_alpha_b;
   a.bpp = s->kernel_bpp ? 1u : 0u; a.prog = gs_prog(s) ? 1u : 0u; a.t2h3 = s->g_t2h3.p; a.tau_w = tau_w;
   a.slot_tab = e->d_slot_tab.p;
+  a.dstep = (s->gp_dev && (mode == 2 || mode == 3)) ? s->g_dst.p : nullptr;
   // a frequency / exchangeability step — proposed now, or rolled back now for the loci that rejected it — leaves
   // parameter blocks whose eigensystems are stale: refreshed before the next evaluation (gs_eval)
   if (mode == 6 || mode == 7 || (s->g_pend == 4 && (s->g_pend_mode == 6 || s->g_pend_mode == 7))) s->g_eigen_dirty = true;
@@ -285,11 +286,11 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   s->g_pm_fused = false;
   if (mode <= 3 && !gs_v1 && !gs_diff && !s->g_s20 && !s->g_alljc && e->usedata && s->g_pend != 4 && !s->g_eigen_dirty && !gs_fuse_a(s))
   {
-    const char * pf_env = getenv("BPA_GS_FUSEPM");
-    s->g_pm_fused = !(pf_env && pf_env[0] == '0');
+    static const bool pm_fuse = [] { const char * v = getenv("BPA_GS_FUSEPM"); return !(v && v[0] == '0'); }();
+    s->g_pm_fused = pm_fuse;
   }
   a.fuse_pm = s->g_pm_fused ? 1u : 0u;
-  if (s->kernel_bpp && mode <= 3 && (gs_diff || getenv("BPA_GS_V1"))) return fail("bpa_sampler: BPP's proposal kernel has no one-lane form (BPA_GS_DIFF / BPA_GS_V1 are the uniform kernel's diagnostics)");
+  if (s->kernel_bpp && mode <= 3 && (gs_diff || gs_v1)) return fail("bpa_sampler: BPP's proposal kernel has no one-lane form (BPA_GS_DIFF / BPA_GS_V1 are the uniform kernel's diagnostics)");
   if (gs_diff && mode <= 3 && !s->g_forked)
   {
     const unsigned n = s->nloci;
@@ -491,8 +492,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     d.tile_arrive = s->g_arrive.p;
     const uint32_t fsum = fuse_sum ? 512u : 0u;
     // the step's P-matrices: one workgroup per locus (its entries are adjacent in the step image), BPA_S20_PMGROUP=0: per entry
-    const char * pg_env = getenv("BPA_S20_PMGROUP");
-    const bool pm_group = !(pg_env && pg_env[0] == '0');
+    static const bool pm_group = [] { const char * v = getenv("BPA_S20_PMGROUP"); return !(v && v[0] == '0'); }();
     if (s->g_forked)
     {
       for (int h = 0; h < 2; ++h)
@@ -612,7 +612,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
 // kernels even when those are launch-bound (config 3's share of 1 250 loci: 516 it/s by launches, 337 chained).
 static bool gs_chain_wanted(const bpa_sampler * s)
 {
-  const char * env = getenv("BPA_GS_CHAIN");
+  static const char * const env = getenv("BPA_GS_CHAIN");            // (read once: asked every iteration)
   if (s->g_s20 || !s->eng->usedata || s->maxtips < 2) return false;
   if (env) return env[0] != '0';
   return s->g_alljc && s->nloci <= 1024u && s->g_npat <= 64u*s->nloci;
@@ -698,12 +698,49 @@ static void gs_declog(const char * what, int k, double lnacc, int acc)
   if (on) fprintf(stderr, "[gsp] %s %d lnacc %.17g u -1 -> %d\n", what, k, lnacc, acc);
 }
 
+// the decisions on the device (gdec_kernel, gsampler.hpp) unless BPA_GS_HOSTDEC=1 (the host form below: the trajectory
+// reference) or an all-reduce callback is installed (several ranks: the host form, its sums through the callback)
+static bool gs_prog_dev_wanted(const bpa_sampler * s)
+{
+  static const bool hostdec = getenv("BPA_GS_HOSTDEC") != nullptr;
+  return !hostdec && !s->allreduce;
+}
+
+// the device's counters by move type and its copy of the global stream come back to the host's (adapt_finetune, a download)
+static int gs_prog_pull(bpa_sampler * s)
+{
+  if (!s->gp_dev || !s->gp_mirror || !s->g_dst.p) return 1;
+  bpa_engine * e = s->eng;
+  gsm::GDecState st;
+  HIPCHK(hipMemcpyAsync(&st, s->g_dst.p, sizeof st, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int k = 4; k < 10; ++k) s->gp_pj[k] += st.pj[k];
+  s->grng = (a00_rng_t)st.z;
+  HIPCHK(hipMemsetAsync(reinterpret_cast<char *>(s->g_dst.p) + offsetof(gsm::GDecState, pj), 0, sizeof st.pj, e->stream));
+  return 1;
+}
+
 static int gs_prog_ready(bpa_sampler * s)
 {
   bpa_engine * e = s->eng;
   if (!s->g_t2h3.p && (!s->g_t2h3.reserve((size_t)3*s->nloci) || !s->g_progout.reserve(64))) return fail("out of device memory (program moves)");
+  if (!s->gp_mirror && gs_prog_dev_wanted(s))
+  {
+    // the decisions' state starts on the device: the global stream where the host left it, no sums yet
+    if (!s->g_dst.reserve(1) || !s->g_dsum.reserve(4*smp::MAXPOP)) return fail("out of device memory (program moves)");
+    gsm::GDecState st;
+    std::memset(&st, 0, sizeof st);
+    st.z = (uint32_t)(unsigned int)s->grng; st.mix_c = 1.0;
+    const double qn = std::nan("");
+    for (int p = 0; p < 16; ++p) { st.pf[p].a = st.pf[p].b = st.pf[p].c = qn; }
+    HIPCHK(hipMemcpyAsync(s->g_dst.p, &st, sizeof st, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));            // (st is on this frame)
+    s->gp_dev = true; s->gp_mirror = true; s->gp_ok = false;
+    return 1;
+  }
   if (!s->gp_mirror)
   {
+    s->gp_dev = false;
     double t[3*smp::MAXPOP];
     HIPCHK(hipMemcpyAsync(t, s->taus.p, sizeof t, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -719,8 +756,8 @@ static int gs_prog_ready(bpa_sampler * s)
 // =0: device buffer + hipMemcpy.  A poll that sees nothing for 20 ms falls back to the stream's synchronisation (and its errors).
 static int gs_prog_mode()
 {
-  const char * env = getenv("BPA_GS_PINOUT");
-  return env ? (env[0] == '0' ? 0 : env[0] == '1' ? 1 : 2) : 2;
+  static const int mode = [] { const char * env = getenv("BPA_GS_PINOUT"); return env ? (env[0] == '0' ? 0 : env[0] == '1' ? 1 : 2) : 2; }();
+  return mode;
 }
 static double * gs_prog_out(bpa_sampler * s, unsigned long long * seq)
 {
@@ -994,6 +1031,47 @@ static int gs_prog_mix(bpa_sampler * s)
   return gs_prog_apply(s, a, true);
 }
 
+// ---- the same three steps with the decision on the device: sums -> [the ranks' collective] -> gdec_kernel, no synchronisation
+static uint32_t gs_theta_mask(const bpa_sampler * s)
+{
+  uint32_t m = 0;
+  for (int p = 0; p < s->sp.npop; ++p) if (s->has_theta[p]) m |= 1u << p;
+  return m;
+}
+template <int PHASE>
+static int gs_dec_launch(bpa_sampler * s, int q, int next)
+{
+  bpa_engine * e = s->eng;
+  hipLaunchKernelGGL((gsm::gdec_kernel<PHASE>), dim3(1), dim3(64), sizeof(smp2::WgBase), e->stream, s->g_dst.p, (const double *)s->g_dsum.p, s->sp,
+                     gs_theta_mask(s), q, next, s->epoch, s->flag.p, s->counters.p, s->taus.p);
+  HIPCHK(hipGetLastError());
+  s->launches++;
+  return 1;
+}
+static int gs_dev_theta(bpa_sampler * s)
+{
+  bpa_engine * e = s->eng;
+  hipLaunchKernelGGL(gsm::gdec_theta_sums_kernel, dim3(s->sp.npop), dim3(1024), 0, e->stream, s->pop_nc.p, s->pop_t2h.p, s->nloci, gs_theta_mask(s), s->g_dsum.p);
+  HIPCHK(hipGetLastError());
+  s->launches++;
+  s->logpr_stale = true;
+  return gs_dec_launch<0>(s, -1, s->sp.S);
+}
+static int gs_dev_allloci(bpa_sampler * s, int q /* -1: MIX */)
+{
+  bpa_engine * e = s->eng;
+  const bool mix = q < 0;
+  if (!gs_step(s, mix ? 3u : 2u, mix ? 0u : (unsigned)q) || !gs_eval(s, 1)) return 0;
+  hipLaunchKernelGGL(gsm::gdec_sums_kernel, dim3(1), dim3(1024), 0, e->stream, (const double *)s->g_lnlcur.p, (const double *)s->g_lnl.p, (const double *)s->g_delta.p,
+                     (const uint8_t *)s->g_active.p, (const double *)s->g_t2h3.p, s->nloci, mix ? 0 : 1, s->g_dsum.p);
+  HIPCHK(hipGetLastError());
+  s->launches++;
+  s->epoch++;
+  // (the host does not know the decision: the next step takes every tree's density again — the lane groups compute its terms anyway)
+  s->logpr_stale = true;
+  return mix ? gs_dec_launch<2>(s, -1, -1) : gs_dec_launch<1>(s, q, q + 1);
+}
+
 static int gs_iterate(bpa_sampler * s, unsigned iterations)
 {
   bpa_engine * e = s->eng;
@@ -1019,10 +1097,19 @@ static int gs_iterate(bpa_sampler * s, unsigned iterations)
       // (a00_iterate: the first TAU's window comes before the THETA step's numbers in the global stream)
       bool any = false;
       for (int p = 0; p < s->sp.npop; ++p) any = any || s->has_theta[p];
+      if (s->gp_dev)
+      {
+        if (!gs_step(s, 4) || !gs_dev_theta(s)) return 0;
+        for (int q = s->sp.S; q < s->sp.npop; ++q) if (!gs_dev_allloci(s, q)) return 0;
+        if (!gs_dev_allloci(s, -1)) return 0;
+      }
+      else
+      {
       if (any) { unsigned int gz = (unsigned int)s->grng; s->gp_pre_window = a00_bpp_rnd_symmetrical(&gz); s->gp_pre_valid = true; s->grng = (a00_rng_t)gz; }
       if (!gs_step(s, 4) || !gs_prog_theta(s)) return 0;
       for (int q = s->sp.S; q < s->sp.npop; ++q) if (!gs_prog_tau(s, q)) return 0;
       if (!gs_prog_mix(s)) return 0;
+      }
     }
     else
     {
@@ -1090,7 +1177,7 @@ static int gs_level_roots(bpa_sampler * s)
 static int gs_download(bpa_sampler * s)
 {
   bpa_engine * e = s->eng;
-  if (!gs_step(s, 4) || !gs_level_roots(s)) return 0;
+  if (!gs_step(s, 4) || !gs_level_roots(s) || !gs_prog_pull(s)) return 0;
   // the settle launch rolls rejected frequency / exchangeability proposals back in the parameter blocks: the loci's
   // eigensystems must follow before anyone else (bpa_batch_evaluate, a plan) computes P-matrices from them
   if (!gs_refresh_eigen(s)) return 0;

@@ -1141,6 +1141,7 @@ struct bpa_sampler
   DevBuf<double> g_lnl, g_lnlcur, g_hast, g_logpr, g_delta, g_site, g_len, g_lograt;
   // the program's THETA / TAU / MIX on a generic sampler (decided on the host: gsampler_host.hpp gs_prog_*)
   DevBuf<double> g_t2h3, g_progout;
+  DevBuf<gsm::GDecState> g_dst; DevBuf<double> g_dsum; bool gp_dev = false;      // the program's all-loci decisions on the device (gdec_kernel): state, the sums' buffer
   unsigned long long gp_seq = 0;        // ... and the number of the launch whose arrival words the host polls (gs_prog_fetch)
   double * gp_pin = nullptr, * gp_pin_dev = nullptr;   // 64 doubles of pinned host memory the program's sum kernels write straight into (gs_prog_out)
   DevBuf<uint32_t> g_arrive;            // 20-state loci: tiles arrived per locus (the per-locus sum inside partials_lnl_wave20_kernel)
@@ -1349,7 +1350,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   if (s->g_stream2) { (void)hipStreamSynchronize(s->g_stream2); (void)hipStreamDestroy(s->g_stream2); s->g_stream2 = nullptr; }
   if (s->g_ev_fork) { (void)hipEventDestroy(s->g_ev_fork); s->g_ev_fork = nullptr; }
   if (s->g_ev_join) { (void)hipEventDestroy(s->g_ev_join); s->g_ev_join = nullptr; }
-  s->g_t2h3.free(); s->g_progout.free(); s->g_arrive.free(); s->gp_mirror = false;
+  s->g_t2h3.free(); s->g_progout.free(); s->g_arrive.free(); s->gp_mirror = false; s->g_dst.free(); s->g_dsum.free();
   if (s->gp_pin) { (void)hipHostFree(s->gp_pin); s->gp_pin = s->gp_pin_dev = nullptr; }
   s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_lnlcur.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
   s->g_len.free(); s->g_lograt.free(); s->g_active.free(); s->g_recs.free(); s->g_mat2.free(); s->g_bmo.free();
@@ -1859,7 +1860,9 @@ extern "C" double bpa_finetune_onestep(double pjump, double finetune) { return f
 // exchange when the sums live inside the persistent kernel.  Every rank calls bpa_sampler_adapt_finetune at the same point.
 static int sampler_pool_counts(bpa_sampler * s, unsigned long long * c, unsigned n)
 {
-  if ((!s->allreduce && !s->p2p) || !n || n > (unsigned)smp::MAXPOP || !s->theta_sums.p) return 1;
+  if ((!s->allreduce && !s->p2p) || !n) return 1;
+  // (several ranks: a rank that went on with its own counts would end at step lengths of its own)
+  if (n > (unsigned)smp::MAXPOP || !s->theta_sums.p) return fail("bpa_sampler_adapt_finetune: the ranks' counts cannot be pooled (no exchange buffer)");
   bpa_engine * e = s->eng;
   double v[smp::MAXPOP];
   for (unsigned i = 0; i < n; ++i) v[i] = (double)c[i];
@@ -1899,6 +1902,9 @@ extern "C" int bpa_sampler_adapt_finetune(bpa_sampler_t * s, double * pjump, dou
     return 1;
   }
   if (!s->v2_ok || !s->v2_pj.p) return fail("bpa_sampler_adapt_finetune: the sampler does not run the persistent iteration kernel");
+  // the all-reduce callback's form of several ranks runs the all-loci steps as launches of their own (smp::decide_kernel), which keep
+  // no counts by move type: the rule would silently leave the tau / mixing / theta windows where they are
+  if (s->allreduce && !s->p2p) return fail("bpa_sampler_adapt_finetune: with an all-reduce callback the persistent kernel's all-loci steps are launches of their own, which do not count proposals by move type — use the mailboxes (bpa_sampler_set_p2p) or the generic sampler");
   unsigned long long c[16];
   HIPCHK(hipMemcpy(c, s->v2_pj.p, sizeof c, hipMemcpyDeviceToHost));
   HIPCHK(hipMemset(s->v2_pj.p, 0, sizeof c));          // pjump_reset (method.c:5377)
@@ -1916,21 +1922,52 @@ extern "C" int bpa_sampler_adapt_finetune(bpa_sampler_t * s, double * pjump, dou
   return 1;                                            // (the species record goes to the device with the next launch: v2_sp_sent)
 }
 
-// the program's burn-in: `iterations` iterations with the step lengths reset from the acceptance proportions after every
-// quarter (method.c:5364: i % (burnin/4) == 0 with at least 100 iterations since the last reset) and at the end
+// the program's burn-in: `iterations` iterations with the step lengths reset from the acceptance proportions exactly where the
+// program's loop resets them (method.c:5364-5417): its counter i runs from -burnin, a reset happens at the TOP of iteration i
+// when i % (burnin/4) == 0 and at least 100 iterations have run since the last one (ft_round, method.c:5417), and once more at
+// i == 0 — burnin 400: after 100 / 200 / 300 / 400 iterations; 300: after 150 / 300; 402: after 102 / 202 / 302 / 402; below 200:
+// the program resets nothing (opt_burnin >= 200), nor does this.  bpa_burnin_schedule lists the points (tests/test_finetune_adaptation.py).
+extern "C" unsigned bpa_burnin_schedule(unsigned burnin, unsigned * after, unsigned cap)
+{
+  unsigned n = 0;
+  if (burnin < 200) return 0;
+  const long q = (long)(burnin/4);
+  long ft_round = 0;
+  for (long i = -(long)burnin; i < 0; ++i)
+  {
+    if (ft_round >= 100 && i % q == 0) { if (after && n < cap) after[n] = (unsigned)(i + (long)burnin); ++n; ft_round = 0; }
+    ++ft_round;
+  }
+  if (after && n < cap) after[n] = burnin;
+  return n + 1;
+}
+
 extern "C" int bpa_sampler_burnin(bpa_sampler_t * s, unsigned iterations, double * finetune)
 {
-  const unsigned q = iterations/4;
-  unsigned done = 0;
-  if (iterations >= 200 && q >= 100)
-    for (int r = 0; r < 3; ++r)
+  // what the rule needs is checked BEFORE the chain moves (a sampler that cannot adapt must not be left half-way through)
+  if (iterations >= 200)
+  {
+    if (s->comp || s->big) return fail("bpa_sampler_burnin: the step-length rule runs on the persistent iteration kernel and on the generic sampler with the program's moves (not on loci of several kinds or of more than 16 tips)");
+    if (s->generic && !(s->kernel_bpp && s->sp.program_moves)) return fail("bpa_sampler_burnin: on a generic sampler the step-length rule runs with the program's moves (bpa_sampler_set_program_moves)");
+    if (!s->generic)
     {
-      if (!bpa_sampler_iterate(s, q) || !bpa_sampler_adapt_finetune(s, nullptr, nullptr)) return 0;
-      done += q;
+      std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
+      if (!set_device(s->eng) || !sampler_upload(s)) return 0;           // (which kernel runs the loci is settled at upload)
+      if (!s->v2_ok || !s->v2_pj.p) return fail("bpa_sampler_burnin: the sampler does not run the persistent iteration kernel (its move-type counters feed the rule)");
+      if (s->allreduce && !s->p2p) return fail("bpa_sampler_burnin: with an all-reduce callback the persistent kernel's all-loci steps keep no counts by move type — use the mailboxes (bpa_sampler_set_p2p) or the generic sampler");
     }
+  }
+  unsigned pts[16];
+  const unsigned npts = bpa_burnin_schedule(iterations, pts, 16);
+  unsigned done = 0;
+  for (unsigned r = 0; r < npts && r < 16u; ++r)
+  {
+    if (pts[r] > done && !bpa_sampler_iterate(s, pts[r] - done)) return 0;
+    done = pts[r];
+    if (!bpa_sampler_adapt_finetune(s, nullptr, r + 1 == npts ? finetune : nullptr)) return 0;
+  }
   if (iterations > done && !bpa_sampler_iterate(s, iterations - done)) return 0;
-  if (iterations >= 200) return bpa_sampler_adapt_finetune(s, nullptr, finetune);
-  if (finetune) { finetune[0] = s->sp.ft_gage; finetune[1] = s->sp.ft_gspr; finetune[2] = s->sp.ft_tau; finetune[3] = s->sp.ft_mix; finetune[4] = s->sp.ft_theta; }
+  if (!npts && finetune) { finetune[0] = s->sp.ft_gage; finetune[1] = s->sp.ft_gspr; finetune[2] = s->sp.ft_tau; finetune[3] = s->sp.ft_mix; finetune[4] = s->sp.ft_theta; }
   return 1;
 }
 

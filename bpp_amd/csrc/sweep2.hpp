@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
         // (an unusable term stays flagged through every block of the exchange: its value may lie in a later one)
         if (lane == 0) { if (anybad) wg.xbad_ = 1u; wg.xcoarse_ = anycoarse ? 1u : 0u; if (last) { wg.bad_ = 0; wg.coarse_ = 0; } }
       }
-      else if (lane == 0) { wg.abort_ = 1; *A.err = 1; if (b == 0) (void)atomicAdd(A.err + 1, (int)A.niter); }
+      else if (lane == 0) { wg.abort_ = 1; (void)__hip_atomic_exchange(A.err, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); if (b == 0) (void)atomicAdd(A.err + 1, (int)A.niter); }
       if (hold || solo) { wsync(); return ok; }                // (wave 0 goes on to the decision; the caller's barrier publishes everything)
     }
     else if (hold || solo) return true;
@@ -1031,7 +1031,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
       // stores unless the launch's error word is still clear (the loci waves wait at the same barrier)
       if (!aborted)
       {
-        if (lane == 0) wg.late_ = __hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1u : 0u;
+        if (lane == 0) wg.late_ = __hip_atomic_load(A.err, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1u : 0u;      // (the giving-up workgroup's exchange is a release at the coherence point: no plain store lingering in its XCD's L2)
         __syncthreads();                                                // BF
         if (wg.late_) { aborted = true; if (b == 0 && lane == 0) (void)atomicAdd(A.err + 1, (int)A.niter); }      // (workgroup 0 counts the launch's iterations exactly once: here, or where it gave up itself)
       }
@@ -1637,7 +1637,7 @@ __global__ void __launch_bounds__(Cfg<NT>::BS) iter_kernel(const Args A)
 #undef SMP2_SUB0
 #undef SMP2_SUB
   if (aborted || wg.abort_) return;                 // (HBM still holds the state the launch started from)
-  if constexpr (!PROG) { if (tid == 0) wg.late_ = __hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1u : 0u; }
+  if constexpr (!PROG) { if (tid == 0) wg.late_ = __hip_atomic_load(A.err, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1u : 0u; }
   __syncthreads();                                  // BF: the error word as it stands after the last exchange (PROG: read by the control wave)
   if (wg.late_)
   {

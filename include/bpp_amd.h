@@ -311,8 +311,13 @@ void bpa_sampler_set_finetune(bpa_sampler_t *, double gage, double gspr, double 
    age, prune/regraft, tau, mixing, theta window, in that order — from the acceptance proportions of each move type since
    the last call (counted by the persistent iteration kernel; pjump[m] < 0: never proposed, step length kept) and clears the
    counters, as reset_finetune + pjump_reset do (method.c:1508-1516, 5364-5377); pjump / finetune (5 each) may be null.
-   bpa_sampler_burnin runs `iterations` iterations the program's way: the rule after every quarter of them (when a quarter
-   is at least 100 iterations) and once more at the end; finetune (5, may be null) receives the step lengths it ends with.
+   bpa_sampler_burnin runs `iterations` iterations the program's way: the rule where the program's loop applies it
+   (method.c:5364-5417: at the top of iteration i = -burnin .. -1 when i % (burnin/4) == 0 and at least 100 iterations have run
+   since the last reset, and at i = 0 — 400: after 100 / 200 / 300 / 400 iterations, 300: after 150 / 300, 402: after 102 / 202 /
+   302 / 402; below 200 iterations the program resets nothing and neither does this); bpa_burnin_schedule writes those points
+   (at most cap of them) and returns their number.  finetune (5, may be null) receives the step lengths the burn-in ends with.
+   A sampler the rule cannot run on (loci of several kinds, the big-tree sampler, a generic sampler without the program's moves)
+   fails BEFORE any iteration has run.
    Where: the persistent iteration kernel (device counters by move type) and the generic sampler with the program's moves
    (the trees carry the age / prune-regraft counts, the host its own decisions').  Several ranks: the per-locus moves' counts
    are pooled over the ranks first (the callback, or the mailboxes' one-shot exchange), so every rank ends at the same step
@@ -320,6 +325,7 @@ void bpa_sampler_set_finetune(bpa_sampler_t *, double gage, double gspr, double 
 double bpa_finetune_onestep(double pjump, double finetune);
 int  bpa_sampler_adapt_finetune(bpa_sampler_t *, double * pjump, double * finetune);
 int  bpa_sampler_burnin(bpa_sampler_t *, unsigned iterations, double * finetune);
+unsigned bpa_burnin_schedule(unsigned burnin, unsigned * after, unsigned cap);
 /* which generator and window the moves draw from (a00_set_proposal_kernel of bpp_amd_host.h; before initialize):
    BPA_KERNEL_UNIFORM (default) our 64-bit streams, window = finetune x (u - 1/2), the acceptance number always drawn;
    BPA_KERNEL_BPP     the reference's own — legacy_rndu (random.c:104-122) and the Bactrian-Laplace variate of

@@ -41,6 +41,33 @@ def test_onestep_rule_is_the_reference_s():
     assert L.bpa_finetune_onestep(0.6, 98.0) == 99.0                                  # maxstep
 
 
+def reference_reset_points(burnin):
+    """the iterations after which the program's loop resets the step lengths (method.c:5343-5417: i runs from -burnin; the reset
+    is at the top of iteration i when i == 0, or i < 0, opt_burnin >= 200, ft_round >= 100 and i % (opt_burnin/4) == 0 — C's
+    remainder, which is 0 for the same i as Python's; ++ft_round at the end of the body)"""
+    pts, ft_round = [], 0
+    for i in range(-burnin, 1):
+        if i == 0 or (burnin >= 200 and ft_round >= 100 and i % (burnin // 4) == 0):
+            if burnin >= 200:
+                pts.append(i + burnin)
+            ft_round = 0
+        ft_round += 1
+    return pts
+
+
+def test_burnin_resets_where_the_program_s_loop_does():
+    import ctypes as C
+    L = bpp_amd.lib()
+    assert reference_reset_points(400) == [100, 200, 300, 400]
+    assert reference_reset_points(300) == [150, 300]          # (a quarter is 75 < 100 iterations: every second one)
+    assert reference_reset_points(402) == [102, 202, 302, 402]
+    assert reference_reset_points(199) == []
+    for burnin in list(range(0, 1300)) + [2000, 4000, 8000, 10007, 100000]:
+        buf = (C.c_uint * 16)()
+        n = L.bpa_burnin_schedule(burnin, buf, 16)
+        assert list(buf[:n]) == reference_reset_points(burnin), burnin
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
 def test_burnin_arrives_where_the_program_s_does():

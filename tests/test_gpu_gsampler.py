@@ -258,12 +258,16 @@ def test_loci_of_several_kinds_in_one_sampler():
                                                                 # the paths kept next to the defaults: the sums through a device buffer and a copy /
                                                                 # waited for with the stream, 20-state P-matrices a workgroup per branch entry
                                                                 (8, "gtr", 4, 60, 3, True, "BPA_GS_PINOUT=0"), (8, "gtr", 4, 60, 3, True, "BPA_GS_PINOUT=1"),
+                                                                # the all-loci decisions on the HOST (round 5's form, the trajectory reference of
+                                                                # the device's gdec_kernel, which is the default since round 6)
+                                                                (8, "gtr", 4, 60, 4, True, "BPA_GS_HOSTDEC=1"), (6, "lg", 4, 40, 3, False, "BPA_GS_HOSTDEC=1"),
                                                                 (6, "lg", 4, 40, 3, False, "BPA_S20_PMGROUP=0")])
 def test_generic_sampler_with_the_program_s_moves_equals_host_driver(taxa, model, R, nloci, iters, subst, env, monkeypatch):
     """BPP's own iteration on the generic sampler (bpa_sampler_set_proposal_kernel(BPP) + bpa_sampler_set_program_moves): the
     per-locus proposals draw from the reference's generator with its Bactrian-Laplace windows and acceptance rule on the device
     (gsm2::gstep2_kernel<.., BPP>), THETA by the metropolized Gibbs draw, the thetas re-drawn inside the rubber band and the
-    mixing step — decided on the HOST from the loci's sums (gs_prog_theta / _tau / _mix, the statements of theta_step_gibbs /
+    mixing step — decided ON THE DEVICE by one wave from the loci's sums (gsm::gdec_kernel: the persistent kernel's control-wave
+    functions; round 6) or, BPA_GS_HOSTDEC=1, on the host (gs_prog_theta / _tau / _mix, the statements of theta_step_gibbs /
     tau_step / mix_step of a00_driver.c).  Same trajectory as the C host driver with a00_set_program_moves on the same library."""
     if model == "jc69":
         monkeypatch.setenv("BPA_SMP_GENERIC", "1")

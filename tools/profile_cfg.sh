@@ -51,16 +51,47 @@ except Exception as e:
     out["bench_unprofiled"] = str(e)
 ks = glob.glob("$W/trace/**/*kernel_stats.csv", recursive=True)
 out["kernel_stats"] = [r for r in csv.DictReader(open(ks[0]))][:8] if ks else None
+WANT = ("partials", "step_", "pmatrix", "reduce", "sweep", "decide", "iter_kernel", "gstep", "eigen", "gdec")
+# Bytes and time of a kernel must share a denominator (round 5: the per-dispatch MEAN over full-batch tape launches and half-batch
+# sampler launches was divided by a full launch's time).  Every figure below is over the dispatches of the kernel's LARGEST grid
+# only — the full-batch launches — and the trace pass gives the mean duration of exactly those (`full_batch`).
+def grid_of(r):
+    for k in ("Grid_Size", "Grid_Size_X"):
+        if r.get(k) not in (None, ""):
+            try: return int(float(r[k]))
+            except ValueError: pass
+    return 0
+full = {}
+for f in glob.glob("$W/trace/**/*kernel_trace.csv", recursive=True):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:60]
+        if any(w in k for w in WANT):
+            acc[k][grid_of(r)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))*1e-3)
+    for k, d in acc.items():
+        g = max(d)
+        allv = [x for v in d.values() for x in v]
+        full[k] = {"grid": g, "dispatches": len(d[g]), "mean_us": round(sum(d[g])/len(d[g]), 3), "all_grids_dispatches": len(allv), "all_grids_mean_us": round(sum(allv)/len(allv), 3)}
+out["full_batch"] = full
 pm = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3"):
     for f in glob.glob("$W/%s/**/*counter_collection.csv" % sub, recursive=True):
-        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        acc = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
         for r in csv.DictReader(open(f)):
-            acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, d in acc.items():
-            if any(w in k for w in ("partials", "step_", "pmatrix", "reduce", "sweep", "decide", "iter_kernel", "gstep", "eigen")):
-                pm.setdefault(k, {}).update({c: {"mean": sum(v)/len(v), "dispatches": len(v)} for c, v in d.items()})
+            acc[r["Kernel_Name"][:60]][grid_of(r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, bygrid in acc.items():
+            if any(w in k for w in WANT):
+                g = max(bygrid)
+                pm.setdefault(k, {}).update({c: {"mean": sum(v)/len(v), "dispatches": len(v), "grid": g} for c, v in bygrid[g].items()})
 out["pmc_per_dispatch"] = pm
+out["pmc_buckets"] = "largest grid of each kernel only (full-batch launches); full_batch[kernel].mean_us is the trace pass's mean over the same launches"
+# moved bytes / time of the SAME launches, per kernel that has both counters
+same = {}
+for k, c in pm.items():
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c and k in full:
+        b = (2*c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"])*1024
+        same[k] = {"moved_bytes": round(b), "mean_us": full[k]["mean_us"], "TBps": round(b/(full[k]["mean_us"]*1e-6)/1e12, 3), "frac_of_8TBps": round(b/(full[k]["mean_us"]*1e-6)/8e12, 4)}
+out["moved_same_file"] = same
 json.dump(out, open("$R/gpurun_out/profile_${CFG}_$TAG.json", "w"), indent=1)
 print("wrote profile_${CFG}_$TAG.json")
 PY
