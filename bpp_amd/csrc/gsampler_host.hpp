@@ -236,8 +236,18 @@ static bool gs_prog(const bpa_sampler * s) { return s->kernel_bpp && s->sp.progr
 // is ahead at every size (1 250 loci 507 -> 513 it/s, 2 500: 408 -> 423, 10 000: 194 -> 207), so this is a switch only
 static bool gs_fuse_a(const bpa_sampler * s)
 {
-  static const bool on = [] { const char * v = getenv("BPA_GS_FUSEA"); return v && v[0] == '1'; }();     // (read once: this runs per launch)
-  return !s->g_alljc && !s->g_s20 && on;
+  return !s->g_alljc && !s->g_s20 && s->env_fusea == 1;         // (read at the sampler's creation: this runs per launch)
+}
+// Round 6: a step whose P-matrices the proposal kernel could NOT fill — a substitution-parameter step (every matrix of every locus
+// from a moved parameter block, the eigensystems first) and the step after one (the rejected proposals rolled back) — was four
+// launches: proposal, eigen_kernel, pmatrix_s4_dense_kernel, node updates.  On a small set (a strong-scaling rank's share: every
+// launch ~15-25 us whatever it does, an iteration a chain of them) the FUSE_A form of the node-update kernel takes the middle two
+// inside: two launches.  Sets of more than 1 536 workgroups of the packing keep the separate launches (the fused kernel's registers
+// cost it a wave per SIMD: round 4's threshold).  BPA_GS_FUSEA=0: never.
+static bool gs_fuse_a_step(const bpa_sampler * s)
+{
+  if (gs_fuse_a(s)) return true;
+  return s->env_fusea != 0 && !s->g_alljc && !s->g_s20 && !s->g_pm_fused && s->eng->pack_blocks <= 1536u;
 }
 
 static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u = 0, double mix_c = 1.0, double mix_lnc = 0, double tau_w = 0)
@@ -286,8 +296,7 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   s->g_pm_fused = false;
   if (mode <= 3 && !gs_v1 && !gs_diff && !s->g_s20 && !s->g_alljc && e->usedata && s->g_pend != 4 && !s->g_eigen_dirty && !gs_fuse_a(s))
   {
-    static const bool pm_fuse = [] { const char * v = getenv("BPA_GS_FUSEPM"); return !(v && v[0] == '0'); }();
-    s->g_pm_fused = pm_fuse;
+    s->g_pm_fused = s->env_fusepm;
   }
   a.fuse_pm = s->g_pm_fused ? 1u : 0u;
   if (s->kernel_bpp && mode <= 3 && (gs_diff || gs_v1)) return fail("bpa_sampler: BPP's proposal kernel has no one-lane form (BPA_GS_DIFF / BPA_GS_V1 are the uniform kernel's diagnostics)");
@@ -445,19 +454,15 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
 // stops being the root is recomputed by the step that moves it).  What else may read the loci's buffers (the single-locus API,
 // a plan, bpa_batch_evaluate) comes after a download, which recomputes every buffer in place first (gs_download).
 // BPA_GS_ROOTSTORE=1: every parent stored (A/B).
-static uint32_t gs_skip_root_flag()
-{
-  static const uint32_t v = getenv("BPA_GS_ROOTSTORE") ? 0u : 2048u;
-  return v;
-}
-static uint32_t gs_root_flag(const bpa_sampler * s) { return s->g_level_eval ? 0u : gs_skip_root_flag(); }
+static uint32_t gs_skip_root_flag(const bpa_sampler * s) { return s->env_rootstore ? 0u : 2048u; }
+static uint32_t gs_root_flag(const bpa_sampler * s) { return s->g_level_eval ? 0u : gs_skip_root_flag(s); }
 
 // the step's likelihood: the engine's kernels over the records the step kernel wrote
 static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci step */)
 {
   bpa_engine * e = s->eng;
   if (!e->usedata) return 1;                       // lnL = 0 for every locus (the buffer was zeroed): the MSC prior
-  if (!s->g_alljc && !s->g_level_eval && gs_skip_root_flag()) s->g_root_stale = true;
+  if (!s->g_alljc && !s->g_level_eval && gs_skip_root_flag(s)) s->g_root_stale = true;
   if (s->g_s20)
   {
     // amino-acid loci: fresh P-matrices (pmatrix_wg2_kernel, one workgroup per entry, holes return at once), the tiled
@@ -492,7 +497,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     d.tile_arrive = s->g_arrive.p;
     const uint32_t fsum = fuse_sum ? 512u : 0u;
     // the step's P-matrices: one workgroup per locus (its entries are adjacent in the step image), BPA_S20_PMGROUP=0: per entry
-    static const bool pm_group = [] { const char * v = getenv("BPA_S20_PMGROUP"); return !(v && v[0] == '0'); }();
+    const bool pm_group = s->env_pmgroup;
     if (s->g_forked)
     {
       for (int h = 0; h < 2; ++h)
@@ -529,7 +534,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     s->launches += fuse_sum ? 2 : 3; s->g_evals++;
     return 1;
   }
-  const bool fuse_a = gs_fuse_a(s);
+  const bool fuse_a = gs_fuse_a_step(s);
   const bool pm_done = s->g_pm_fused && !fuse_a;
   s->g_pm_fused = false;
   const bool fuse_eigen = fuse_a && s->g_eigen_dirty;
@@ -612,9 +617,8 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
 // kernels even when those are launch-bound (config 3's share of 1 250 loci: 516 it/s by launches, 337 chained).
 static bool gs_chain_wanted(const bpa_sampler * s)
 {
-  static const char * const env = getenv("BPA_GS_CHAIN");            // (read once: asked every iteration)
   if (s->g_s20 || !s->eng->usedata || s->maxtips < 2) return false;
-  if (env) return env[0] != '0';
+  if (s->env_chain >= 0) return s->env_chain != 0;
   return s->g_alljc && s->nloci <= 1024u && s->g_npat <= 64u*s->nloci;
 }
 static int gs_chain(bpa_sampler * s)
@@ -702,8 +706,7 @@ static void gs_declog(const char * what, int k, double lnacc, int acc)
 // reference) or an all-reduce callback is installed (several ranks: the host form, its sums through the callback)
 static bool gs_prog_dev_wanted(const bpa_sampler * s)
 {
-  static const bool hostdec = getenv("BPA_GS_HOSTDEC") != nullptr;
-  return !hostdec && !s->allreduce;
+  return !s->env_hostdec && !s->allreduce;
 }
 
 // the device's counters by move type and its copy of the global stream come back to the host's (adapt_finetune, a download)
@@ -754,15 +757,11 @@ static int gs_prog_ready(bpa_sampler * s)
 // itself, its last store an arrival word the host polls — no copy launch, no wait for the launch to retire between the sums and
 // the host's decision (config 5: a synchronisation 25 -> 16 -> ~8 us).  BPA_GS_PINOUT=1: pinned memory + hipStreamSynchronize,
 // =0: device buffer + hipMemcpy.  A poll that sees nothing for 20 ms falls back to the stream's synchronisation (and its errors).
-static int gs_prog_mode()
-{
-  static const int mode = [] { const char * env = getenv("BPA_GS_PINOUT"); return env ? (env[0] == '0' ? 0 : env[0] == '1' ? 1 : 2) : 2; }();
-  return mode;
-}
+static int gs_prog_mode(const bpa_sampler * s) { return s->env_pinout; }
 static double * gs_prog_out(bpa_sampler * s, unsigned long long * seq)
 {
   *seq = 0;
-  const int mode = gs_prog_mode();
+  const int mode = gs_prog_mode(s);
   if (mode == 0) return s->g_progout.p;
   if (!s->gp_pin)
   {

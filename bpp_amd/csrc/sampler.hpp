@@ -1187,6 +1187,9 @@ struct bpa_sampler
   // diagnostic switches, read once at creation: BPA_SMP_DBG (bit mask, see Args::dbg), BPA_SMP_STEPS=g,q (proposal counts),
   // BPA_SMP_TRACE (per-launch times on stderr), BPA_SMP_NOMIX (sweeps only)
   uint32_t env_dbg = 0; int env_gage = -1, env_gspr = -1; bool env_trace = false, env_nomix = false;
+  // the generic sampler's switches (A/B and kept paths; read ONCE, at creation: nothing reads the environment on the launch path,
+  // and a test can still make samplers of either kind in one process)
+  int env_fusea = -1; bool env_fusepm = true, env_pmgroup = true, env_hostdec = false, env_rootstore = false; int env_chain = -1, env_pinout = 2;
   long env_inject = 0; uint32_t env_inject_bit = 1024u; long v2_launch_no = 0;    // BPA_SMP_INJECT=k[,w]: the k-th persistent launch with all-loci steps gives up at its first wait (w: workgroup 0 alone) — tests of the run-again path
   bool mix_pending = false;             // a mixing decision taken on the device has not been applied yet
   a00_rng_t grng = 0;
@@ -1329,6 +1332,14 @@ static bpa_sampler * sampler_create_plain(bpa_engine_t * e, bpa_locus_t * const 
   s->env_trace = getenv("BPA_SMP_TRACE") != nullptr; s->env_nomix = getenv("BPA_SMP_NOMIX") != nullptr;
   if (const char * inj = getenv("BPA_SMP_INJECT")) { s->env_inject = atol(inj); s->env_inject_bit = strstr(inj, ",w") ? 2048u : 1024u; }
   s->fuse_decision = getenv("BPA_SMP_FUSE") != nullptr;
+  { const char * v;
+    v = getenv("BPA_GS_FUSEA");     s->env_fusea = v ? (v[0] == '1' ? 1 : 0) : -1;
+    v = getenv("BPA_GS_FUSEPM");    s->env_fusepm = !(v && v[0] == '0');
+    v = getenv("BPA_S20_PMGROUP");  s->env_pmgroup = !(v && v[0] == '0');
+    v = getenv("BPA_GS_CHAIN");     s->env_chain = v ? (v[0] != '0' ? 1 : 0) : -1;
+    v = getenv("BPA_GS_PINOUT");    s->env_pinout = v ? (v[0] == '0' ? 0 : v[0] == '1' ? 1 : 2) : 2;
+    s->env_hostdec = getenv("BPA_GS_HOSTDEC") != nullptr;
+    s->env_rootstore = getenv("BPA_GS_ROOTSTORE") != nullptr; }
   s->env_v1 = getenv("BPA_SMP_V1") != nullptr;
   s->sp.ft_gage = 0.004; s->sp.ft_gspr = 0.004; s->sp.ft_tau = 0.001; s->sp.ft_mix = 0.3;      // a00_create's defaults
   return s;

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(extra, tmp=None):
+def run_bench(extra, tmp=None, world=2):
     """-> (the full record bench.py wrote to --full-record, stderr); the stdout line is the compact one the driver parses:
     checked here to be the last line, small, and to carry the contract's keys"""
     import tempfile
@@ -24,9 +24,9 @@ def run_bench(extra, tmp=None):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--loci", "1500", "--no-cpu-baseline", "--full-record", full_path] + extra
+    cmd = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2"] +
+           ([] if "--loci" in extra else ["--loci", "1500"]) + ["--no-cpu-baseline", "--full-record", full_path] + extra)
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
@@ -35,7 +35,7 @@ def run_bench(extra, tmp=None):
     full = json.load(open(full_path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in line, k
-    assert line["value"] == full["value"] and line["n_gpus"] == 2 and line["roofline"]["frac"] == full["roofline"]["frac"]
+    assert line["value"] == full["value"] and line["n_gpus"] == world and line["roofline"]["frac"] == full["roofline"]["frac"]
     assert line["value_weak"] == full["value_weak"] and line["value_strong"] == full["value_strong"]
     return full, r.stderr
 
@@ -75,6 +75,25 @@ def test_two_rank_bench_line_config3_runs_the_program_s_moves():
     assert smp["moves"].startswith("the program's") and smp["moves_short"] == "program" and smp["kind"] == "generic", smp["moves"]
     assert smp["loci_total"] == 400 and 0.1 < smp["acceptance"] < 0.9
     assert smp["theta_gibbs_draws_generic"]["proposed"] > 0
+
+
+@pytest.mark.parametrize("p2p", [True])
+def test_eight_rank_bench_line(p2p):
+    """`bench.py --gpus 8` as the driver launches it (torch.distributed.run, one rank per GPU — here eight ranks on device 0 over
+    gloo): n_gpus 8, the whole-job rate under both scalings (weak = eight data sets, strong = one dealt out by the reference's
+    zig-zag over eight parts), the tape's all-reduce self-check over eight ranks; p2p: the mailboxes' start-up self-test must have
+    all eight ranks agree before the in-kernel exchange is used"""
+    d, err = run_bench(["--loci", "640", "--no-scale-projection"] + (["--p2p-sums"] if p2p else ["--no-p2p"]), world=8)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] == d["value_weak"] > 0, err[-1500:]
+    assert d["value_strong"] and d["value_strong"] > 0, (d.get("scaling_other_mode"), err[-1500:])
+    assert d["allreduce_check"] == "ok"
+    smp, tp = d["device_resident_sampler"], d["likelihood_only"]
+    assert smp["n_gpus"] == 8 and smp["loci_total"] == 8*640 and tp["loci_total"] == 8*640
+    assert d["scaling_other_mode"]["scaling"] == "strong" and d["scaling_other_mode"]["loci_total"] == 640
+    if p2p:
+        assert "persistent kernel" in d["allreduce"]["sampler"] and smp["moves"].startswith("the program's"), (d["allreduce"], err[-1500:])
+    else:
+        assert smp["kind"] == "hybrid"
 
 
 def test_two_rank_bench_line_carries_both_scalings():

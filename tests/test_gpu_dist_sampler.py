@@ -154,3 +154,61 @@ def test_two_ranks_pool_the_step_length_rule(tmp_path, how):
     start = dict(gage=0.003, gspr=0.005, tau=0.0008, mix=0.2, theta=0.001)
     assert all(a[k] != start[k] for k in ("gage", "gspr", "tau", "mix")), a
     assert two[0]["taus"] == two[1]["taus"] and two[0]["thetas"] == two[1]["thetas"]
+
+
+# ---- eight ranks (round 6): no 8-GPU node is to be had, so the world size BASELINE's configs name is exercised the only way one GPU
+# allows — eight processes on it, small shares.  What two ranks cannot show: sums over eight mailbox slots added in rank order, a
+# share an eighth of the set, eight hosts taking one decision, counts pooled over eight.
+def _eight_against_one(rs, one, rtol):
+    assert len(rs) == 8
+    for r in rs:
+        assert r["taus"] == rs[0]["taus"] and r["thetas"] == rs[0]["thetas"]               # replicated decisions, the same bits on every rank
+        assert np.allclose(r["taus"], one["taus"], rtol=rtol, atol=0) and np.allclose(r["thetas"], one["thetas"], rtol=rtol, atol=0)
+    assert [r["first"] for r in rs] == sorted(r["first"] for r in rs) and rs[1]["first"] == len(rs[0]["lnl"])
+    times = [t for r in rs for t in r["times"]]
+    lnl = [x for r in rs for x in r["lnl"]]
+    assert len(times) == len(one["times"])
+    for a, b in zip(times, one["times"]):
+        assert np.allclose(a, b, rtol=rtol, atol=0)
+    assert np.allclose(lnl, one["lnl"], rtol=rtol, atol=0)
+    assert one["taus"] != [0, 0, 0, 0, 0.001, 0.002, 0.003]
+
+
+@pytest.mark.parametrize("how", ["callback", "mailboxes-program"])
+def test_eight_ranks_walk_the_single_rank_trajectory(tmp_path, how):
+    """160 four-taxon loci over EIGHT ranks (20 each): through the all-reduce callback (one collective per all-loci step between
+    the launches), through the mailboxes inside the persistent kernel (every control wave adds eight slots in rank order), and
+    the latter with BPP's moves (fixed-point sums of counts and waiting times from eight ranks feed the Gibbs draws)"""
+    extra = {}
+    if how != "callback":
+        extra["DIST_P2P"] = "1"
+    if how == "mailboxes-program":
+        extra["DIST_PROGRAM"] = "1"
+    one_extra = {k: v for k, v in extra.items() if k != "DIST_P2P"}
+    one = run(1, str(tmp_path / "one"), 31011, **one_extra)[0]
+    rs = run(8, str(tmp_path / "eight"), 31012 + os.getpid() % 500, **extra)
+    assert all(r["kind"] == ("hybrid" if how == "callback" else "persistent") for r in rs), [r["kind"] for r in rs]
+    _eight_against_one(rs, one, 1e-10 if how != "mailboxes-program" else 1e-9)
+    tot = sum(r["summary"]["total_lnl"] for r in rs)
+    assert abs(tot - one["summary"]["total_lnl"]) < 1e-9 * abs(tot)
+
+
+def test_eight_ranks_generic_sampler_with_the_program_s_moves(tmp_path):
+    """48 eight-taxon GTR + Gamma4 loci over eight ranks (6 each), BPP's own iteration with the parameter moves: eight hosts
+    take every THETA / TAU / MIX decision from the same all-reduced sums (the integer sums exact, the likelihood sum in rank
+    order); one rank decides on the device (gdec_kernel) — the same chain"""
+    one = run(1, str(tmp_path / "one"), 31111, DIST_GTR="1", DIST_PROGRAM="1")[0]
+    rs = run(8, str(tmp_path / "eight"), 31112 + os.getpid() % 500, DIST_GTR="1", DIST_PROGRAM="1")
+    assert one["kind"] == "generic" and all(r["kind"] == "generic" for r in rs)
+    _eight_against_one(rs, one, 1e-9)
+    assert sum(r["summary"]["accepted"] for r in rs) > 0
+
+
+def test_eight_ranks_pool_the_step_length_rule(tmp_path):
+    """the burn-in rule over eight ranks' mailboxes: the per-locus moves' counts of eight shares pooled in one exchange, every
+    rank ends at the same five step lengths"""
+    rs = run(8, str(tmp_path / "eight"), 31212 + os.getpid() % 500, DIST_PROGRAM="1", DIST_BURNIN="1", DIST_P2P="1")
+    assert all(r["ft"] == rs[0]["ft"] for r in rs), [r["ft"] for r in rs]
+    start = dict(gage=0.003, gspr=0.005, tau=0.0008, mix=0.2, theta=0.001)
+    assert all(rs[0]["ft"][k] != start[k] for k in ("gage", "gspr", "tau", "mix")), rs[0]["ft"]
+    assert all(r["taus"] == rs[0]["taus"] and r["thetas"] == rs[0]["thetas"] for r in rs)
