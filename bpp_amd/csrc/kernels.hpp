@@ -2991,6 +2991,9 @@ step_s4_klane_v2_kernel(const PlanDev P)
 #ifndef BPA_KLANE_CH
 #define BPA_KLANE_CH 2
 #endif
+#ifndef BPA_KLANE_DEFER
+#define BPA_KLANE_DEFER 1
+#endif
 template <int BS, bool FUSE_A = false>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(FUSE_A ? 3 : BPA_KLANE_OCC, 8)))
 step_s4_klane_v3_kernel(const PlanDev P)
@@ -3170,6 +3173,36 @@ step_s4_klane_v3_kernel(const PlanDev P)
       // the last: read back from HBM "when used, after the lane's own store" that was a store -> load round trip (~2 us) in
       // one locus-step in four (config 3; tools/opstat.py: distances 1 / 2 / 3 / more = 52 752 / 6 665 / 2 313 / 1 172).
       uint32_t hist = 0xffffffu;
+      // (round 6) the parents of a chunk of updates are STORED one chunk late: after the wait for the next chunk's matrices and
+      // children — which, being s_waitcnt vmcnt(0), used to wait for the acknowledgement of this chunk's stores as well (stores
+      // and loads leave the counter in order) — or after the last chunk.  They come from where they lie anyway: the last
+      // update's in registers, the one or two before it in the lane's LDS words.  A child at distance >= 4 (read back from HBM)
+      // lies at least a chunk behind its flush: the lane's store precedes its load as before.
+      static_assert(!BPA_KLANE_DEFER || CH <= 3, "a chunk's parents must still lie in registers / the two LDS levels when they are stored");
+      uint32_t c_last = 0;
+      auto flush_chunk = [&](const uint32_t c0, const uint32_t done_end)
+      {
+        // done_end: the updates [0, min(nops, done_end)) of this lane are complete
+        const uint32_t done = nops < done_end ? nops : done_end;
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+        {
+          const uint32_t u = c0 + (uint32_t)j;
+          if (u < done)
+          {
+            const uint32_t pc = reinterpret_cast<const uint2 *>(&s_rec[wave][my_g][1 + u])->x & 255u;
+            if (!(skip_root && u + 1u == nops && pc == (uint32_t)hdr.root_clv))
+            {
+              d2v a0, a1;
+              if (u + 1u == done) { a0.x = fwd[0]; a0.y = fwd[1]; a1.x = fwd[2]; a1.y = fwd[3]; }
+              else { const double2 m0 = s_ring[u & 1u][0][lane], m1 = s_ring[u & 1u][1][lane]; a0.x = m0.x; a0.y = m0.y; a1.x = m1.x; a1.y = m1.y; }
+              __attribute__((address_space(1))) d2v * dst = reinterpret_cast<__attribute__((address_space(1))) d2v *>(
+                  reinterpret_cast<uintptr_t>(S.clv + ((((size_t)(pc - tips)*R) + k)*np + n)*4));
+              __builtin_nontemporal_store(a0, dst); __builtin_nontemporal_store(a1, dst + 1);
+            }
+          }
+        }
+      };
       for (uint32_t o0 = 0; __any(o0 < nops); o0 += (uint32_t)CH)
       {
         // ---- trip 3, part 1 (once per CH updates): these updates' matrices, global -> LDS
@@ -3226,6 +3259,8 @@ step_s4_klane_v3_kernel(const PlanDev P)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (!dma_waited) { dma_waited = true; BPA_STAMP_NW(P, b, lane, 3); }
+        if (BPA_KLANE_DEFER && o0 != 0u) flush_chunk(o0 - (uint32_t)CH, o0);
+        c_last = o0;
 #pragma unroll
         for (int j = 0; j < CH; ++j)
         {
@@ -3292,12 +3327,13 @@ step_s4_klane_v3_kernel(const PlanDev P)
               const double2 a1 = r[(8 + 2*i) ^ my_g], b1 = r[(8 + 2*i + 1) ^ my_g];
               y[i] = dot4_pair(a1.x, a1.y, b1.x, b1.y, rv);
             }
-            store_parent(pc, x, y, !(skip_root && oi + 1u == nops && pc == (uint32_t)hdr.root_clv));
+            store_parent(pc, x, y, !BPA_KLANE_DEFER && !(skip_root && oi + 1u == nops && pc == (uint32_t)hdr.root_clv));
             hist = (hist << 8) | pc;
             written |= 1u << (pc & 31u);
           }
         }
       }
+      if (BPA_KLANE_DEFER) flush_chunk(c_last, c_last + (uint32_t)CH);
     }
     else
     {
