@@ -198,9 +198,12 @@ CONFIGS = {
 }
 
 
+_T0 = time.perf_counter()
+
+
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
-        print("[bench]", *a, file=sys.stderr, flush=True)
+        print(f"[bench +{time.perf_counter() - _T0:6.1f}s]", *a, file=sys.stderr, flush=True)
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines ---
@@ -1486,8 +1489,10 @@ def main():
     tape_sec = sampler_sec = None
     tape_steps = None
     if not (args.config in ("c2", "c3") and args.no_tape):
+        log("section: likelihood-only tape")
         tape_sec, tape_steps = run_tape(eng, cfg, args.config, data, loci, args, D, args.steps, args.warmup)
     if args.config in ("c2", "c3", "c4") and not args.no_sampler:
+        log("section: device-resident sampler (headline)")
         sampler_sec = run_sampler(eng, cfg, data, loci, args, D, first_locus, args.steps, args.warmup, codes_ratio=(tape_sec or {}).get("codes_ratio"))
         if "error" in sampler_sec:
             log(sampler_sec["error"])
@@ -1515,6 +1520,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and tape_steps is not None:
         init, iters = tape_steps
         n_cpu_iter = min(2, len(iters))
+        log("section: CPU tape replay")
         cb = cpu_baseline(data, [init], [s for it in iters[:n_cpu_iter] for s in it], n_cpu_iter)
         scale = nloci_cfg if args.config != "c2" else 10000.0
         ac = cb["all_cores"]
@@ -1538,6 +1544,7 @@ def main():
             # only throttled) and twice that — round 2's sweep over 8 ... 128 found the best there every time
             q = int(cpu_quota() or ncores)
             sweep = sorted({1, max(2, min(q, ncores)), max(2, min(2 * q, ncores))})
+            log("section: the unmodified program on the host (thread sweep)")
             r = bpp_program_baseline(nloci_cfg, cfg["sites"], sweep, chain_samples=0 if args.no_efficiency else 2500)
             chain = r.pop("chain", None) if r else None
             if r:
@@ -1554,6 +1561,7 @@ def main():
     efficiency = None
     if bpp_prog and "error" not in bpp_prog and chain and "error" not in chain and chain.get("finetune"):
         try:
+            log("section: statistical efficiency")
             efficiency = run_efficiency(eng, cfg, data, None, chain, bpp_prog["best_median"])
         except Exception as ex:       # noqa: BLE001
             efficiency = dict(error=str(ex)[:300])
@@ -1569,6 +1577,7 @@ def main():
                 oc = CONFIGS[key]
                 t0 = time.time()
                 e2 = bpp_amd.Engine(local_rank, None)
+                log(f"section: other config {key}")
                 d2 = synth.make_dataset(oc["loci"], oc["sites"], oc["taxa"], oc["model"], oc["rate_cats"], seed=12345, divergence=oc.get("divergence", 1.0))
                 l2 = make_loci(e2, d2)
                 a2 = argparse.Namespace(**vars(args))
@@ -1594,6 +1603,7 @@ def main():
         try:
             t0 = time.time()
             e1 = bpp_amd.Engine(local_rank, None)
+            log("section: config 1")
             others["c1"] = dict(device_resident_sampler=run_config1(e1), seconds=None)
             e1.close()
             if not args.no_cpu_baseline:
@@ -1606,6 +1616,7 @@ def main():
         try:
             t0 = time.time()
             e5 = bpp_amd.Engine(local_rank, None)
+            log("section: config 5")
             others["c5"] = dict(device_resident_sampler=run_config5(e5), seconds=None)
             e5.close()
             if not args.no_cpu_baseline:
@@ -1618,6 +1629,7 @@ def main():
 
         if args.config == "c2" and args.loci is None:
             try:
+                log("section: mixed set")
                 others["mixed_set"] = run_mixed_set(data)
             except Exception as ex:       # noqa: BLE001
                 others["mixed_set"] = dict(error=str(ex)[:300])
@@ -1629,6 +1641,7 @@ def main():
         mask = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
         try:
             q = cpu_quota()
+            log("section: host control in C")
             host_sec = run_host_control(eng, cfg, data, max(1, min(16, int(q) if q else (os.cpu_count() or 1))))
         except Exception as ex:       # noqa: BLE001
             host_sec = dict(error=str(ex)[:300])
@@ -1639,6 +1652,7 @@ def main():
     projection = None
     if rank == 0 and world == 1 and D is None and args.config in ("c2", "c3", "c4") and not args.no_scale_projection and not args.no_sampler:
         try:
+            log("section: scale projection")
             projection = scale_projection(args.config, cfg, data, args)
         except Exception as ex:       # noqa: BLE001
             projection = dict(error=str(ex)[:300])

@@ -68,6 +68,7 @@ def lib():
     sig = {
         "bpa_version": (C.c_char_p, []),
         "bpa_last_error": (C.c_char_p, []),
+        "bpa_experimental_build": (i, []),
         "bpa_device_count": (i, []),
         "bpa_engine_create": (vp, [i, vp]),
         "bpa_engine_destroy": (None, [vp]),
@@ -176,7 +177,7 @@ def lib():
     return L
 
 
-EXPORTED = ["bpa_version", "bpa_last_error", "bpa_device_count", "bpa_engine_create",
+EXPORTED = ["bpa_version", "bpa_last_error", "bpa_experimental_build", "bpa_device_count", "bpa_engine_create",
             "bpa_engine_destroy", "bpa_engine_synchronize", "bpa_engine_set_options",
             "bpa_locus_create", "bpa_locus_destroy", "bpa_set_tip_states",
             "bpa_set_pattern_weights", "bpa_set_frequencies", "bpa_set_subst_params",

@@ -22,7 +22,7 @@ SOURCES = ["engine.hip", "host_math.cpp", "host_input.cpp"]
 # every header the library's sources include: all of csrc/*.hpp and include/*.h (a header missing from a hand-kept list is a
 # stale library that looks built)
 import glob as _glob
-DEPS = sorted(_glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(_glob.glob(os.path.join(ROOT, "include", "*.h")))
+DEPS = sorted(_glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(_glob.glob(os.path.join(CSRC, "experimental", "*.hpp"))) + sorted(_glob.glob(os.path.join(ROOT, "include", "*.h")))
 
 
 def hipcc():
@@ -45,7 +45,8 @@ def build_host(force=False, verbose=False):
     deps = [HOST_SRC, os.path.join(ROOT, "include", "bpp_amd_host.h"), os.path.join(ROOT, "include", "bpp_amd.h"), OUT]
     if not force and os.path.exists(HOST_OUT) and all(os.path.getmtime(f) <= os.path.getmtime(HOST_OUT) for f in deps):
         return HOST_OUT
-    cmd = ["gcc", "-O2", "-std=c99", "-fopenmp", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"),
+    cmd = ["gcc", "-O2", "-std=c99", "-fopenmp", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include")] + \
+          (["-DBPA_EXPERIMENTAL"] if experimental() else []) + [
            HOST_SRC, "-o", HOST_OUT, "-L", HERE, "-lbpp_amd", "-Wl,-rpath,$ORIGIN", "-lm"]
     if verbose:
         print(" ".join(cmd))
@@ -76,6 +77,12 @@ def build_rccl_optional(force=False, verbose=False):
         return None
 
 
+def experimental():
+    """BPA_EXPERIMENTAL=1 (or -DBPA_EXPERIMENTAL among BPA_HIPCC_FLAGS): the build that also compiles csrc/experimental/ and
+    reads the A/B switches of superseded variants (csrc/device_types.hpp: BPA_EXP_SWITCH)"""
+    return bool(os.environ.get("BPA_EXPERIMENTAL")) or "-DBPA_EXPERIMENTAL" in os.environ.get("BPA_HIPCC_FLAGS", "").split()
+
+
 def build(force=False, verbose=False):
     if not force and not stale():
         build_host(False, verbose)
@@ -84,7 +91,8 @@ def build(force=False, verbose=False):
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
            "-fPIC", "-shared", "-Wall", "-Wno-unused-result", "-Wno-pass-failed",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           "-o", OUT] + os.environ.get("BPA_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", OUT] + os.environ.get("BPA_HIPCC_FLAGS", "").split() + (["-DBPA_EXPERIMENTAL"] if os.environ.get("BPA_EXPERIMENTAL") else []) + \
+          [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -169,7 +169,7 @@ static int comp_kind_of(const bpa_locus * l, bpa_engine * e)
   if (l->states == 20) return (l->tips <= (unsigned)gsm::NT && l->rate_cats <= 4) ? 3 : -1;
   if (l->states != 4) return -1;
   const bool jc1 = l->rate_cats == 1 && l->dev.model == 0;
-  if (jc1 && l->tips <= (unsigned)smp::MAXTIPS && l->sites <= (unsigned)smp::BS && getenv("BPA_SMP_GENERIC") == nullptr) return 0;      // the LDS kernels
+  if (jc1 && l->tips <= (unsigned)smp::MAXTIPS && l->sites <= (unsigned)smp::BS && !smp_env_generic()) return 0;      // the LDS kernels
   if (!(l->tips <= (unsigned)gsm::NT && l->rate_cats <= 8 && l->sites*l->rate_cats < PACK_BS)) return -1;
   if (jc1) return 1;                                     // generic path, JC69 records
   if (l->rate_cats > 1) return 2;                        // generic path, multi-category records
@@ -180,7 +180,7 @@ static int comp_kind_of(const bpa_locus * l, bpa_engine * e)
 static bpa_sampler * comp_create(bpa_engine_t * e, bpa_locus_t * const * loci, unsigned nloci, unsigned long seed, bool * plain)
 {
   *plain = true;
-  if (getenv("BPA_SMP_NO_COMPOSITE") || getenv("BPA_SMP_BIG")) return nullptr;
+  if (getenv("BPA_SMP_NO_COMPOSITE") || smp_env_big()) return nullptr;
   std::vector<unsigned> grp[4];
   for (unsigned i = 0; i < nloci; ++i)
   {
@@ -221,7 +221,7 @@ static bpa_sampler * comp_create(bpa_engine_t * e, bpa_locus_t * const * loci, u
   c->cb.resize(n); c->ctx.resize(n); c->state.assign(n, 2); c->result.assign(n, 0); c->pend_ptr.assign(n, nullptr); c->pend_n.assign(n, 0);
   c->stacks.resize(n);
   c->stream.assign(n, e->stream); c->ev_part.assign(n, nullptr);
-  const bool one_stream = getenv("BPA_COMP_ONE_STREAM") != nullptr;
+  const bool one_stream = BPA_EXP_SWITCH("BPA_COMP_ONE_STREAM") != nullptr;
   if (hipEventCreateWithFlags(&c->ev_sum, hipEventDisableTiming) != hipSuccess) c->ev_sum = nullptr;
   for (size_t i = 1; i < n && !one_stream; ++i)
   {

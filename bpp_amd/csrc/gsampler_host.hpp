@@ -7,9 +7,17 @@
 // launch, so switching a move on or changing a width in mid-run (BPP's burn-in finetune adjustment) touches no state
 // BPA_S20_KERNEL=pipe: round 4's 20-state node-update kernel (a workgroup barrier per update) instead of partials_lnl_wave20_kernel (A/B)
 // BPA_S20_KERNEL=wave2: partials_lnl_wave20_kernel with two patterns per lane (tiles of 128 patterns, one wave per SIMD)
+// (the A/B forms of the 20-state node-update kernel inside the sampler: an experimental build's; the default build launches
+//  partials_lnl_wave20_kernel)
+#ifdef BPA_EXPERIMENTAL
 static unsigned gs_tile20() { static const unsigned v = (getenv("BPA_S20_KERNEL") && std::string(getenv("BPA_S20_KERNEL")) == "wave2") ? 128u : 64u; return v; }
 static bool gs_waverl() { static const bool v = getenv("BPA_S20_KERNEL") && std::string(getenv("BPA_S20_KERNEL")) == "waverl"; return v; }
 static bool gs_pipe20() { static const bool v = getenv("BPA_S20_KERNEL") && std::string(getenv("BPA_S20_KERNEL")) == "pipe"; return v; }
+#else
+static constexpr unsigned gs_tile20() { return 64u; }
+static constexpr bool gs_waverl() { return false; }
+static constexpr bool gs_pipe20() { return false; }
+#endif
 
 static int gs_subst_ready(bpa_sampler * s)
 {
@@ -190,7 +198,7 @@ static int gs_upload(bpa_sampler * s)
   s->epoch = 0; s->mix_pending = false; s->g_pend = 0;
   // two half-batches when there is enough of the packing to halve and the sampler's loci are in slot order
   s->g_split = false; s->g_forked = false;
-  static const bool no_split = getenv("BPA_GS_NOSPLIT") != nullptr;
+  static const bool no_split = BPA_EXP_SWITCH("BPA_GS_NOSPLIT") != nullptr;
   if (!s->g_s20 && !s->g_alljc && !no_split && e->usedata && T >= 2)
   {
     bool mono = true;
@@ -211,7 +219,7 @@ static int gs_upload(bpa_sampler * s)
   }
   // 20-state sets: two halves of the loci (the step's records are per locus, the tiles in locus order): the proposal, P-matrix
   // and sum launches of one half — latency, 70 us of a 385 us step on config 4 — run under the other half's node updates
-  static const bool no_split20 = getenv("BPA_GS_NOSPLIT") != nullptr;
+  static const bool no_split20 = BPA_EXP_SWITCH("BPA_GS_NOSPLIT") != nullptr;
   if (s->g_s20 && !no_split20 && e->usedata && T >= 128)
   {
     if (!s->g_stream2) HIPCHK(hipStreamCreateWithFlags(&s->g_stream2, hipStreamNonBlocking));
@@ -289,7 +297,7 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
     else switch (a.mode) { case 0: hipLaunchKernelGGL((gsm::gstep_kernel<0, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; case 1: hipLaunchKernelGGL((gsm::gstep_kernel<1, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; \
                            case 2: hipLaunchKernelGGL((gsm::gstep_kernel<2, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; default: hipLaunchKernelGGL((gsm::gstep_kernel<3, 16>), GRID_, dim3(gsm::GBS), 0, ST_, a); break; } } while (0)
   static const bool gs_diff = getenv("BPA_GS_DIFF") != nullptr;
-  static const bool gs_v1 = getenv("BPA_GS_V1") != nullptr;
+  static const bool gs_v1 = BPA_EXP_SWITCH("BPA_GS_V1") != nullptr;
   // the step's P-matrices by the proposal's lane groups (gstep2_body) instead of a launch of their own: 4-state loci on the
   // packing whose step launch does not make them itself (gs_fuse_a), no substitution-parameter step pending or rolled back
   // since the eigensystems were last refreshed (BPA_GS_FUSEPM=0: the dense launch)
@@ -423,7 +431,7 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
     s->launches++;
   }
   HIPCHK(hipGetLastError());
-  static const bool dbg_sync = getenv("BPA_GS_SYNC") != nullptr;        // diagnostics: wait for every launch and say which it was
+  static const bool dbg_sync = BPA_EXP_SWITCH("BPA_GS_SYNC") != nullptr;        // diagnostics: wait for every launch and say which it was
   if (dbg_sync)
   {
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -487,7 +495,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     // a launch of its own — the arriving wave must drain its CLV stores before its arrival atomic, holding the workgroup's
     // registers and LDS meanwhile, and the last tile adds alone; with an agent-scope release fence instead of write-through
     // terms: 72 it/s (the fence writes back the XCD's whole L2, i.e. the CLV planes just stored)
-    static const bool sum_fused = getenv("BPA_S20_SUM_FUSED") != nullptr;
+    static const bool sum_fused = BPA_EXP_SWITCH("BPA_S20_SUM_FUSED") != nullptr;
     const bool fuse_sum = sum_fused && !gs_pipe20() && gs_tile20() == 64u;
     if (fuse_sum && !s->g_arrive.p)
     {
@@ -510,10 +518,13 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
         else hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3((i1 - i0)*s->g_maxmat), dim3(256), 0, st, d);
         d.blk0 = t0;
         d.flags = 4u | 64u | 256u | fsum | gs_root_flag(s);
+#ifdef BPA_EXPERIMENTAL
         if (gs_pipe20()) hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
         else if (gs_tile20() == 128u) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20 + (size_t)s->g_rmax*64*sizeof(double), st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
         else if (gs_waverl()) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2, 1, true>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
-        else hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
+        else
+#endif
+        hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2>), dim3(t1 - t0), dim3(64*s->g_rmax), lds20, st, h ? nullptr : k0, h ? nullptr : k1, 0, d);
         d.blk0 = i0;
         if (!fuse_sum) hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(i1 - i0), dim3(64), 0, st, d);
       }
@@ -525,10 +536,13 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     if (pm_group) hipLaunchKernelGGL(pmatrix_wg2_group_kernel<20>, dim3(s->nloci), dim3(256), 0, e->stream, d, s->g_maxmat);
     else hipLaunchKernelGGL(pmatrix_wg2_kernel<20>, dim3(d.nmat), dim3(256), 0, e->stream, d);
     d.flags = 4u | 64u | fsum | gs_root_flag(s);
+#ifdef BPA_EXPERIMENTAL
     if (gs_pipe20()) hipExtLaunchKernelGGL((partials_lnl_pipe20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
     else if (gs_tile20() == 128u) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 1, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20 + (size_t)s->g_rmax*64*sizeof(double), e->stream, k0, k1, 0, d);
     else if (gs_waverl()) hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2, 1, true>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
-    else hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
+    else
+#endif
+    hipExtLaunchKernelGGL((partials_lnl_wave20_kernel<20, true, 2>), dim3(s->g_ntiles), dim3(64*s->g_rmax), lds20, e->stream, k0, k1, 0, d);
     if (!fuse_sum) hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(s->nloci), dim3(64), 0, e->stream, d);
     HIPCHK(hipGetLastError());
     s->launches += fuse_sum ? 2 : 3; s->g_evals++;
@@ -606,7 +620,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
   }
   HIPCHK(hipGetLastError());
   s->g_evals++;
-  static const bool dbg_sync_v = getenv("BPA_GS_SYNC") != nullptr;
+  static const bool dbg_sync_v = BPA_EXP_SWITCH("BPA_GS_SYNC") != nullptr;
   if (dbg_sync_v) { HIPCHK(hipStreamSynchronize(e->stream)); fprintf(stderr, "[gs] eval done\n"); }
   return 1;
 }

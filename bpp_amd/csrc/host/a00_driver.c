@@ -19,6 +19,13 @@
 #include <math.h>
 #include "bpp_amd_host.h"
 
+/* section timers of the launch loop: an experimental build's (-DBPA_EXPERIMENTAL), like the library's A/B switches (csrc/device_types.hpp) */
+#ifdef BPA_EXPERIMENTAL
+#define A00_EXP_SWITCH(name_) getenv(name_)
+#else
+#define A00_EXP_SWITCH(name_) ((const char *)0)
+#endif
+
 #define MAXN 512                          /* nodes per gene tree handled on the stack */
 
 struct a00_driver
@@ -757,7 +764,7 @@ static int per_locus_step(a00_driver_t * d, int kind, int k)
     a00_step_t s; int r;
     static int prof = -1; static double tp[5]; static unsigned calls;
     double t0, t1, t2, t3, t4;
-    if (prof < 0) prof = getenv("A00_PROF") != NULL;
+    if (prof < 0) prof = A00_EXP_SWITCH("A00_PROF") != NULL;
     set_view(d, 1 + c);
     t0 = prof ? now_s() : 0;
     {
@@ -1284,7 +1291,7 @@ void a00_counters(const a00_driver_t * d, unsigned long * proposals, unsigned lo
 static int backend_hip_run(void * vctx, const a00_step_t * s, double * lnl, int async)
 {
   static int prof = -1; static double t_marsh = 0, t_eval = 0, t_last = 0, t_between = 0; static unsigned calls = 0;
-  const double t0 = (prof < 0 ? (prof = getenv("A00_PROF") != NULL) : prof) ? now_s() : 0;
+  const double t0 = (prof < 0 ? (prof = A00_EXP_SWITCH("A00_PROF") != NULL) : prof) ? now_s() : 0;
   a00_hip_ctx_t * c = (a00_hip_ctx_t *)vctx;
   const unsigned n = s->nloci, nbr = s->br_off[n], nnd = s->nd_off[n];
   unsigned i, j; int ok;

@@ -275,81 +275,9 @@ __device__ __forceinline__ void load_childN(const LocusDev & L, uint32_t clv_ind
   }
 }
 
-template <int S>
-__global__ void __launch_bounds__(BPA_BLOCK) partials_lnl_sN_kernel(const PlanDev P)
-{
-  const uint32_t g = blockIdx.x*BPA_BLOCK + threadIdx.x;
-  if (g >= P.npatterns) return;
-  const uint32_t t = P.thr_task[g];
-  const uint32_t n = g - P.task_pat_off[t];
-  const LocusDev L = P.loci[P.task_locus[t]];
-  const uint32_t R = L.rate_cats, np = L.np, ld = L.ld;
-
-  const uint32_t op_end = P.op_off[t+1];
-  for (uint32_t o = P.op_off[t]; o < op_end; ++o)
-  {
-    const OpDev op = P.ops[o];
-    double * out = L.clv + (((size_t)(op.parent_clv - L.tips_n)*R)*S)*ld + n;
-    bool all_small = true;
-    for (uint32_t k = 0; k < R; ++k)
-    {
-      double lv[S], rv[S];
-      load_childN<S, uint32_t>(L, op.left_clv,  k, n, lv);
-      load_childN<S, uint32_t>(L, op.right_clv, k, n, rv);
-      const double * lm = L.pmat + ((size_t)op.left_pmatrix*R  + k)*S*S;
-      const double * rm = L.pmat + ((size_t)op.right_pmatrix*R + k)*S*S;
-      double * dst = out + (size_t)k*S*ld;
-      for (int i = 0; i < S; ++i)
-      {
-        const double x = dot_fma4<S>(lm + i*S, lv);
-        const double y = dot_fma4<S>(rm + i*S, rv);
-        const double v = x*y;
-        all_small = all_small && (v < BPA_SCALE_THRESHOLD);
-        dst[(size_t)i*ld] = v;
-      }
-    }
-    if (op.parent_scaler >= 0)
-    {
-      uint32_t s = 0;
-      if (op.left_scaler  >= 0) s += L.scaler[(size_t)op.left_scaler*np  + n];
-      if (op.right_scaler >= 0) s += L.scaler[(size_t)op.right_scaler*np + n];
-      if (all_small)
-      {
-        for (uint32_t e = 0; e < R*S; ++e) out[(size_t)e*ld] *= BPA_SCALE_FACTOR;
-        s += 1;
-      }
-      L.scaler[(size_t)op.parent_scaler*np + n] = s;
-    }
-  }
-
-  // K2 / K3 (core_likelihood_avx2.c:45-87; that file is built with -mfma, so the
-  // rate-weight accumulation and the scaler correction are fused there too)
-  const uint32_t root = P.root_clv[t];
-  const double * par = L.par;
-  double term = 0;
-  for (uint32_t k = 0; k < R; ++k)
-  {
-    double c[S];
-    load_childN<S, uint32_t>(L, root, k, n, c);
-    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
-    const double tr = dot_fma4<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
-    term = __builtin_fma(tr, par[par_rate_weights(R) + k], term);
-  }
-  if (L.unphased_length)
-    P.site_term[g] = term;
-  else
-  {
-    double lt = log(term);
-    const int32_t rs = P.root_scaler[t];
-    if (rs >= 0)
-    {
-      const uint32_t sc = L.scaler[(size_t)rs*np + n];
-      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
-    }
-    lt *= L.weights[n];
-    P.site_term[g] = lt;
-  }
-}
+#ifdef BPA_EXPERIMENTAL
+#include "experimental/kernels_s20_generic_exp.hpp"   // partials_lnl_sN_kernel (one lane per pattern, no staging)
+#endif
 
 // ============================================== K1+K2, 20 states, LDS-staged P ==
 // One workgroup = one tile of TILE consecutive patterns of ONE locus; one lane = one
@@ -511,180 +439,9 @@ __device__ __forceinline__ double dot_fma4_s(cdbl4_p row, const double * v)     
   return (a0 + a1) + (a2 + a3);
 }
 
-template <int S, bool NTA = false, int OCC = 3>      // NTA: CLV planes streamed (nontemporal); OCC: waves per SIMD of the register budget
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
-partials_lnl_pipe20_kernel(const PlanDev P)
-{
-  extern __shared__ __attribute__((aligned(16))) double s_p[];      // [2 buffers][2 children][R][S][S], then [R][64] scratch
-  constexpr uint32_t SS = S*S;
-  // flags bit 5: plain mapping (A/B); bit 8: the launch covers tiles blk0 .. blk0 + gridDim.x (a half-batch of the device sampler)
-  const uint32_t b = ((P.flags & 256u) ? P.blk0 : 0u) + ((P.flags & 32u) ? blockIdx.x : xcd_tile(blockIdx.x, gridDim.x)), lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
-  const uint32_t k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t t = ((cu32_p)P.tile_task)[b];
-  const uint32_t n = ((cu32_p)P.tile_n0)[b] + lane;
-  const uint32_t lid = ((cu32_p)P.task_locus)[t];
-  cu64_p L64 = (cu64_p)(P.loci + lid);
-  cu32_p L32 = (cu32_p)(P.loci + lid);
-  const gdbl_p   Lclv    = (gdbl_p)L64[0];
-  const double * Lpmat   = (const double *)L64[1];
-  const gu32_p   Lscaler = (gu32_p)L64[2];
-  const gcu32_p  Ltips   = (gcu32_p)L64[3];
-  const gcu32_p  Lwgt    = (gcu32_p)L64[4];
-  const cdbl4_p  par     = (cdbl4_p)L64[5];
-  static_assert(offsetof(LocusDev, np) == 72 && offsetof(LocusDev, ld) == 108, "LocusDev layout");
-  const uint32_t np = L32[18], tips_n = L32[19], R = L32[20], unphased = L32[25], ld = L32[27];
-  const bool active = n < np && k < R;
-  const uint32_t bufsz = 2*P.pad*SS;                                 // doubles per staging buffer (P.pad = largest R of the plan)
-  double * s_x = s_p + (size_t)2*bufsz;
-
-  // flags bit 6: op_off holds a (begin, end) pair per task — the device-written steps of the generic sampler, where a task
-  // with no update is not part of the step at all
-  const bool ranges = (P.flags & 64u) != 0;
-  const uint32_t op_begin = ((cu32_p)P.op_off)[ranges ? 2*t : t], op_end = ((cu32_p)P.op_off)[ranges ? 2*t + 1 : t + 1];
-  if (ranges && op_begin == op_end) return;
-  uint32_t cur = 0;
-  if (op_begin < op_end)
-  {
-    const OpS op0 = load_op_scalar(P.ops, op_begin);
-    stage_pmats_async<S>(s_p, Lpmat + (size_t)op0.left_pmatrix*R*SS, Lpmat + (size_t)op0.right_pmatrix*R*SS, R, k, nw, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-  }
-  double ov[S];                                                      // the parent just computed (forwarded)
-  uint32_t ov_clv = 0xffffffffu;
-  for (uint32_t o = op_begin; o < op_end; ++o)
-  {
-    const OpS op = load_op_scalar(P.ops, o);
-    const double * lm = s_p + (size_t)cur*bufsz + (size_t)k*SS;
-    const double * rm = s_p + (size_t)cur*bufsz + (size_t)(R + k)*SS;
-    const bool ltip = op.left_clv < tips_n, rtip = op.right_clv < tips_n;
-    const bool lfwd = op.left_clv == ov_clv, rfwd = op.right_clv == ov_clv;
-    double lv[S], rv[S];
-    uint32_t lcode = 1u, rcode = 1u;
-    bool all_small = true;
-    // every request of this update first: tip codes, child planes, the next update's matrices
-    if (active)
-    {
-      if (ltip) lcode = Ltips[(size_t)op.left_clv*np + n];
-      if (rtip) rcode = Ltips[(size_t)op.right_clv*np + n];
-      if (!ltip && !lfwd)
-      {
-        const gcdbl_p p = Lclv + (((size_t)(op.left_clv - tips_n)*R + k)*S)*ld + n;
-#pragma unroll
-        for (int s = 0; s < S; ++s) lv[s] = NTA ? __builtin_nontemporal_load(p + (size_t)s*ld) : p[(size_t)s*ld];
-      }
-      if (!rtip && !rfwd)
-      {
-        const gcdbl_p p = Lclv + (((size_t)(op.right_clv - tips_n)*R + k)*S)*ld + n;
-#pragma unroll
-        for (int s = 0; s < S; ++s) rv[s] = NTA ? __builtin_nontemporal_load(p + (size_t)s*ld) : p[(size_t)s*ld];
-      }
-    }
-    if (o + 1 < op_end)
-    {
-      const OpS nx = load_op_scalar(P.ops, o + 1);
-      stage_pmats_async<S>(s_p + (size_t)(cur ^ 1u)*bufsz, Lpmat + (size_t)nx.left_pmatrix*R*SS, Lpmat + (size_t)nx.right_pmatrix*R*SS, R, k, nw, lane);
-    }
-    if (active)
-    {
-      // tip children: partials_lnl_tiledk_kernel's tip-code fast path (wave-uniform), else the 0/1 expansion of the code
-      const bool lfast = ltip && __all(__popc(lcode) == 1), rfast = rtip && __all(__popc(rcode) == 1);
-      const int ls = __ffs(lcode) - 1, rs = __ffs(rcode) - 1;
-      if (ltip && !lfast) {
-#pragma unroll
-        for (int s = 0; s < S; ++s) lv[s] = (double)((lcode >> s) & 1u); }
-      if (rtip && !rfast) {
-#pragma unroll
-        for (int s = 0; s < S; ++s) rv[s] = (double)((rcode >> s) & 1u); }
-      if (lfwd) {
-#pragma unroll
-        for (int s = 0; s < S; ++s) lv[s] = ov[s]; }
-      if (rfwd) {
-#pragma unroll
-        for (int s = 0; s < S; ++s) rv[s] = ov[s]; }
-#pragma unroll
-      for (int i = 0; i < S; ++i)
-      {
-        const double x = lfast ? lm[i*S + ls] : dot_fma4<S>(lm + i*S, lv);
-        const double y = rfast ? rm[i*S + rs] : dot_fma4<S>(rm + i*S, rv);
-        const double v = x*y;
-        all_small = all_small && (v < BPA_SCALE_THRESHOLD);
-        ov[i] = v;
-      }
-      ov_clv = op.parent_clv;
-    }
-    if (op.parent_scaler >= 0)                         // uniform: the scaling test couples the categories
-    {
-      reinterpret_cast<uint32_t *>(s_x)[k*64 + lane] = all_small ? 1u : 0u;
-      lds_barrier();
-      if (active)
-      {
-        bool all = true;
-        for (uint32_t q = 0; q < R; ++q) all = all && reinterpret_cast<const uint32_t *>(s_x)[q*64 + lane] != 0u;
-        if (all) {
-#pragma unroll
-          for (int i = 0; i < S; ++i) ov[i] *= BPA_SCALE_FACTOR; }
-        if (k == 0)
-        {
-          uint32_t sc = all ? 1u : 0u;
-          if (op.left_scaler  >= 0) sc += Lscaler[(size_t)op.left_scaler*np  + n];
-          if (op.right_scaler >= 0) sc += Lscaler[(size_t)op.right_scaler*np + n];
-          Lscaler[(size_t)op.parent_scaler*np + n] = sc;
-        }
-      }
-    }
-    if (active)
-    {
-      const gdbl_p out = Lclv + ((((size_t)(op.parent_clv - tips_n)*R) + k)*S)*ld + n;
-#pragma unroll
-      for (int i = 0; i < S; ++i) { if (NTA) __builtin_nontemporal_store(ov[i], out + (size_t)i*ld); else out[(size_t)i*ld] = ov[i]; }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next matrices has landed (stores drain with it)
-    lds_barrier();                                     // everyone is done reading buffer `cur` and has filled the other
-    cur ^= 1u;
-  }
-  if (!(P.flags & 4u)) return;
-
-  // K2 / K3 (core_likelihood_avx2.c:45-87): every wave its category's term, wave 0 the fma chain over them
-  const uint32_t root = ((cu32_p)P.root_clv)[t];
-  if (active)
-  {
-    double c[S];
-    if (root == ov_clv) {
-#pragma unroll
-      for (int s = 0; s < S; ++s) c[s] = ov[s]; }
-    else if (root < tips_n)
-    {
-      const uint32_t code = Ltips[(size_t)root*np + n];
-#pragma unroll
-      for (int s = 0; s < S; ++s) c[s] = (double)((code >> s) & 1u);
-    }
-    else
-    {
-      const gcdbl_p p = Lclv + (((size_t)(root - tips_n)*R + k)*S)*ld + n;
-#pragma unroll
-      for (int s = 0; s < S; ++s) c[s] = p[(size_t)s*ld];
-    }
-    const uint32_t m = (uint32_t)par[par_param_idx(R) + k];
-    s_x[k*64 + lane] = dot_fma4_s<S>(par + par_matrix(R, S, m) + pm_freqs(S), c);
-  }
-  lds_barrier();
-  if (!active || k) return;
-  double term = 0;
-  for (uint32_t q = 0; q < R; ++q) term = __builtin_fma(s_x[q*64 + lane], par[par_rate_weights(R) + q], term);
-  if (!unphased)
-  {
-    double lt = log(term);
-    const int32_t rsc = ((ci32_p)P.root_scaler)[t];
-    if (rsc >= 0)
-    {
-      const uint32_t sc = Lscaler[(size_t)rsc*np + n];
-      if (sc) lt = __builtin_fma((double)sc, BPA_LOG_SCALE_THRESHOLD, lt);
-    }
-    term = lt*Lwgt[n];
-  }
-  P.site_term[((cu32_p)P.task_pat_off)[t] + n] = term;
-}
+#ifdef BPA_EXPERIMENTAL
+#include "experimental/kernels_s20_pipe_exp.hpp"      // partials_lnl_pipe20_kernel (rounds 2-4's default)
+#endif
 
 // ================================== K1+K2, 20 states, waves on their own (default since round 5) ==
 // partials_lnl_pipe20_kernel with what still ran in series taken apart.  In that kernel a tile's four waves (one per rate
@@ -2991,9 +2748,6 @@ step_s4_klane_v2_kernel(const PlanDev P)
 #ifndef BPA_KLANE_CH
 #define BPA_KLANE_CH 2
 #endif
-#ifndef BPA_KLANE_DEFER
-#define BPA_KLANE_DEFER 1
-#endif
 template <int BS, bool FUSE_A = false>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(FUSE_A ? 3 : BPA_KLANE_OCC, 8)))
 step_s4_klane_v3_kernel(const PlanDev P)
@@ -3173,36 +2927,6 @@ step_s4_klane_v3_kernel(const PlanDev P)
       // the last: read back from HBM "when used, after the lane's own store" that was a store -> load round trip (~2 us) in
       // one locus-step in four (config 3; tools/opstat.py: distances 1 / 2 / 3 / more = 52 752 / 6 665 / 2 313 / 1 172).
       uint32_t hist = 0xffffffu;
-      // (round 6) the parents of a chunk of updates are STORED one chunk late: after the wait for the next chunk's matrices and
-      // children — which, being s_waitcnt vmcnt(0), used to wait for the acknowledgement of this chunk's stores as well (stores
-      // and loads leave the counter in order) — or after the last chunk.  They come from where they lie anyway: the last
-      // update's in registers, the one or two before it in the lane's LDS words.  A child at distance >= 4 (read back from HBM)
-      // lies at least a chunk behind its flush: the lane's store precedes its load as before.
-      static_assert(!BPA_KLANE_DEFER || CH <= 3, "a chunk's parents must still lie in registers / the two LDS levels when they are stored");
-      uint32_t c_last = 0;
-      auto flush_chunk = [&](const uint32_t c0, const uint32_t done_end)
-      {
-        // done_end: the updates [0, min(nops, done_end)) of this lane are complete
-        const uint32_t done = nops < done_end ? nops : done_end;
-#pragma unroll
-        for (int j = 0; j < CH; ++j)
-        {
-          const uint32_t u = c0 + (uint32_t)j;
-          if (u < done)
-          {
-            const uint32_t pc = reinterpret_cast<const uint2 *>(&s_rec[wave][my_g][1 + u])->x & 255u;
-            if (!(skip_root && u + 1u == nops && pc == (uint32_t)hdr.root_clv))
-            {
-              d2v a0, a1;
-              if (u + 1u == done) { a0.x = fwd[0]; a0.y = fwd[1]; a1.x = fwd[2]; a1.y = fwd[3]; }
-              else { const double2 m0 = s_ring[u & 1u][0][lane], m1 = s_ring[u & 1u][1][lane]; a0.x = m0.x; a0.y = m0.y; a1.x = m1.x; a1.y = m1.y; }
-              __attribute__((address_space(1))) d2v * dst = reinterpret_cast<__attribute__((address_space(1))) d2v *>(
-                  reinterpret_cast<uintptr_t>(S.clv + ((((size_t)(pc - tips)*R) + k)*np + n)*4));
-              __builtin_nontemporal_store(a0, dst); __builtin_nontemporal_store(a1, dst + 1);
-            }
-          }
-        }
-      };
       for (uint32_t o0 = 0; __any(o0 < nops); o0 += (uint32_t)CH)
       {
         // ---- trip 3, part 1 (once per CH updates): these updates' matrices, global -> LDS
@@ -3259,8 +2983,6 @@ step_s4_klane_v3_kernel(const PlanDev P)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (!dma_waited) { dma_waited = true; BPA_STAMP_NW(P, b, lane, 3); }
-        if (BPA_KLANE_DEFER && o0 != 0u) flush_chunk(o0 - (uint32_t)CH, o0);
-        c_last = o0;
 #pragma unroll
         for (int j = 0; j < CH; ++j)
         {
@@ -3327,13 +3049,12 @@ step_s4_klane_v3_kernel(const PlanDev P)
               const double2 a1 = r[(8 + 2*i) ^ my_g], b1 = r[(8 + 2*i + 1) ^ my_g];
               y[i] = dot4_pair(a1.x, a1.y, b1.x, b1.y, rv);
             }
-            store_parent(pc, x, y, !BPA_KLANE_DEFER && !(skip_root && oi + 1u == nops && pc == (uint32_t)hdr.root_clv));
+            store_parent(pc, x, y, !(skip_root && oi + 1u == nops && pc == (uint32_t)hdr.root_clv));
             hist = (hist << 8) | pc;
             written |= 1u << (pc & 31u);
           }
         }
       }
-      if (BPA_KLANE_DEFER) flush_chunk(c_last, c_last + (uint32_t)CH);
     }
     else
     {

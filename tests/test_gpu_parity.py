@@ -435,6 +435,7 @@ def test_20_state_kernel_variants_are_bit_exact(engine, monkeypatch, kernel):
         case = c[idx]
         S, R = case["states"], case["rate_cats"]
         ol, _ = __import__("test_oracle_pin").oracle_locus(case)
+        __import__("common").skip_unless_experimental(kernel)
         monkeypatch.setenv("BPA_S20_KERNEL", kernel)
         loc, gt = golden_case(engine, case)
         for nd in gt.branches():
