@@ -101,18 +101,18 @@ def compact_line(full):
         if se.get("ratio_ess_per_iteration"):
             out["ess_per_iteration_ratio"] = {k: [v["value"], v["se"]] for k, v in se["ratio_ess_per_iteration"].items() if isinstance(v, dict)}
             out["ess_per_iteration_ratio"]["samples"] = [(se.get("device") or {}).get("samples"), (se.get("reference_program") or {}).get("samples")]
-        # the committed long runs on the SAME data for both chains (tools/ess_device_vs_program.py): [ratio, standard error] — a
-        # builder-run measurement inside a driver-run line, labelled as such
-        try:
-            import glob
-            lr = {}
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "ess_*.json"))):
-                e_ = json.load(open(f))
-                lr[f"{e_['nloci']}x{e_['samples']}"] = {k: [e_[k + "_ratio"]["value"], e_[k + "_ratio"]["se"]] for k in ("tau_root", "theta_root")}
-            if lr:
-                out["ess_per_iteration_ratio_committed_runs"] = lr
-        except Exception:       # noqa: BLE001
-            pass
+    # the committed long runs on the SAME data for both chains (tools/ess_device_vs_program.py): [ratio, standard error] — a
+    # builder-run measurement inside a driver-run line, labelled as such (the bench's own ESS section is opt-in: --efficiency)
+    try:
+        import glob
+        lr = {}
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "ess_*.json"))):
+            e_ = json.load(open(f))
+            lr[f"{e_['nloci']}x{e_['samples']}"] = {k: [e_[k + "_ratio"]["value"], e_[k + "_ratio"]["se"]] for k in ("tau_root", "theta_root")}
+        if lr:
+            out["ess_per_iteration_ratio_committed_runs"] = lr
+    except Exception:       # noqa: BLE001
+        pass
     if lo:
         r = lo.get("roofline") or {}
         out["likelihood_only"] = {"it_s": lo.get("iterations_per_s"), "site_lnl_updates_per_s": lo.get("site_lnl_updates_per_s"),
@@ -330,7 +330,7 @@ nsample = {nsample}
 """
 
 
-def bpp_program_baseline(nloci, sites, threads_list, reps=2, budget_s=150.0, chain_samples=0):
+def bpp_program_baseline(nloci, sites, threads_list, reps=1, budget_s=60.0, chain_samples=0, long_short=(100, 500)):
     """The unmodified reference PROGRAM (oracle/_ref/bpp, built in place from /root/reference) on this box's host
     cores: data from its own simulator, A00 JC69, whole MCMC iterations/s from the differential wall time of a short
     and a long run (start-up — reading and compressing 10 000 loci, the first likelihoods — cancels), per thread count:
@@ -359,7 +359,7 @@ def bpp_program_baseline(nloci, sites, threads_list, reps=2, budget_s=150.0, cha
 
         for th in threads_list:
             tl = f"threads = {th} 1 1" if th > 1 else ""
-            n1, n2 = (100, 900) if th > 1 else (20, 150)
+            n1, n2 = long_short if th > 1 else (10, 70)
             rates = []
             for _ in range(reps if th > 1 else 1):
                 if time.time() - t_start > budget_s and rates:
@@ -599,13 +599,13 @@ def other_config_cpu_baseline(key, data):
         n = min(len(data), 1000)
         ctl = B.A00_CTL.format(species=B.SPECIES8, phase="0 0 0 0 0 0 0 0", nloci=n, model="gtr", alpha="alphaprior = 1 1 4", taub=300,
                                burnin=0, sampfreq=1, nsample="{nsample}", extra="{threads}")
-        return program_rate(_phylip_from_data(data[:n], "ABCDEFGH"), ctl, 10, 60, threads, len(data), n)
+        return program_rate(_phylip_from_data(data[:n], "ABCDEFGH"), ctl, 10, 40, threads, len(data), n, budget_s=20.0)
     if key == "c4":
         n = min(len(data), 128)
         sp6 = "6  A B C D E F\n                  1 1 1 1 1 1\n                  ((((A, B), C), (D, E)), F);"
         ctl = B.A00_CTL.format(species=sp6, phase="0 0 0 0 0 0", nloci=n, model="lg", alpha="alphaprior = 1 1 4", taub=40,
                                burnin=0, sampfreq=1, nsample="{nsample}", extra="{threads}").replace("thetaprior = gamma 2 1000", "thetaprior = gamma 2 100")
-        return program_rate(_phylip_from_data(data[:n], "ABCDEF"), ctl, 4, 24, threads, len(data), n)
+        return program_rate(_phylip_from_data(data[:n], "ABCDEF"), ctl, 4, 16, threads, len(data), n, budget_s=20.0)
     if key == "c5":
         g = os.path.join(ROOT, "tests", "golden", "anopheles")
         files = {"loci_realign.txt": open(os.path.join(g, "loci_realign.txt")).read(), "Imap.txt": open(os.path.join(g, "Imap.txt")).read()}
@@ -1409,6 +1409,8 @@ def main():
     ap.add_argument("--no-tape", action="store_true", help="c2: skip the likelihood-only tape section")
     ap.add_argument("--no-host-control", action="store_true", help="c2: skip the host-driven section (a00_driver.c on the GPU back-end)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the c3 / c4 tape sections of the default run")
+    ap.add_argument("--efficiency", action="store_true",
+                    help="run the ESS/s section (the program's chain with its burn-in next to the device's: ~50 s more) and the long thread sweep")
     ap.add_argument("--no-efficiency", action="store_true",
                     help="skip the ESS/s section (one more 1 900-iteration run of the reference program with its burn-in, BPP's move kernel on the device)")
     ap.add_argument("--no-bpp-program", action="store_true",
@@ -1537,6 +1539,10 @@ def main():
 
     bpp_prog = None
     chain = None
+    # the ESS/s section (a 2 900-iteration run of the program with its burn-in + the device's chain: ~50 s) is opt-in since round 6
+    # (--efficiency): the default run must finish in about two minutes; the line carries the committed long runs' ESS-per-iteration
+    # ratios (profiles/r*/ess_*.json) either way
+    want_eff = args.efficiency and not args.no_efficiency
     if rank == 0 and world == 1 and args.config == "c2" and not args.no_cpu_baseline and not args.no_bpp_program:
         try:
             ncores = os.cpu_count() or 1
@@ -1545,15 +1551,16 @@ def main():
             q = int(cpu_quota() or ncores)
             sweep = sorted({1, max(2, min(q, ncores)), max(2, min(2 * q, ncores))})
             log("section: the unmodified program on the host (thread sweep)")
-            r = bpp_program_baseline(nloci_cfg, cfg["sites"], sweep, chain_samples=0 if args.no_efficiency else 2500)
+            r = (bpp_program_baseline(nloci_cfg, cfg["sites"], sweep, reps=2, budget_s=150.0, chain_samples=2500, long_short=(100, 900)) if want_eff
+                 else bpp_program_baseline(nloci_cfg, cfg["sites"], sweep))
             chain = r.pop("chain", None) if r else None
             if r:
                 best = max((k for k in r if k > 1), key=lambda k: r[k]["median"], default=1)
                 bpp_prog = dict(unit="whole MCMC iterations/s of the unmodified reference program (10k loci, A00 JC69), incl. its MCMC control",
                                 threads={str(k): v for k, v in r.items()}, best_threads=best, best_median=r[best]["median"],
                                 host_logical_cores=ncores, host_cpu_quota=cpu_quota(), kind="reference",
-                                sample="bpp --simulate data (seed 12345), differential wall time of 100- vs 900-iteration runs (1 thread: "
-                                       "20 vs 150), median / min / max of 2 measurements per thread count (1 thread: one)")
+                                sample="bpp --simulate data (seed 12345), differential wall time of a 100- and a 500-iteration run per thread count "
+                                       "(1 thread: 10 vs 70): ~30 s of CPU work (--efficiency: 900-iteration runs, two measurements each, as in rounds 3-5)")
         except Exception as ex:       # noqa: BLE001
             bpp_prog = dict(error=str(ex)[:200])
 
