@@ -717,10 +717,11 @@ static void gs_declog(const char * what, int k, double lnacc, int acc)
 }
 
 // the decisions on the device (gdec_kernel, gsampler.hpp) unless BPA_GS_HOSTDEC=1 (the host form below: the trajectory
-// reference) or an all-reduce callback is installed (several ranks: the host form, its sums through the callback)
+// reference).  Several ranks: the sums — doubles in the callback's own format — go through the all-reduce callback ON THE STREAM
+// between the sum kernel and gdec_kernel (gs_dev_allreduce): with a stream-ordered collective (RCCL) no host waits for anything
 static bool gs_prog_dev_wanted(const bpa_sampler * s)
 {
-  return !s->env_hostdec && !s->allreduce;
+  return !s->env_hostdec;
 }
 
 // the device's counters by move type and its copy of the global stream come back to the host's (adapt_finetune, a download)
@@ -1051,6 +1052,22 @@ static uint32_t gs_theta_mask(const bpa_sampler * s)
   for (int p = 0; p < s->sp.npop; ++p) if (s->has_theta[p]) m |= 1u << p;
   return m;
 }
+// n doubles of g_dsum summed over the ranks, BPA_SAMPLER_SUMS at a time, in the callback's buffer (the caller's device_sums or
+// the sampler's own): copy in, collective, copy back — all enqueued on the engine's stream
+static int gs_dev_allreduce(bpa_sampler * s, unsigned n)
+{
+  if (!s->allreduce) return 1;
+  bpa_engine * e = s->eng;
+  double * ar = s->sum_ext ? s->sum_ext : s->theta_sums.p;
+  for (unsigned o = 0; o < n; o += BPA_SAMPLER_SUMS)
+  {
+    const unsigned c = std::min<unsigned>(BPA_SAMPLER_SUMS, n - o);
+    HIPCHK(hipMemcpyAsync(ar, s->g_dsum.p + o, c*sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    if (!s->allreduce(s->allreduce_ctx, ar, c, (void *)e->stream)) return fail("bpa_sampler: the all-reduce callback failed");
+    HIPCHK(hipMemcpyAsync(s->g_dsum.p + o, ar, c*sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  }
+  return 1;
+}
 template <int PHASE>
 static int gs_dec_launch(bpa_sampler * s, int q, int next)
 {
@@ -1068,6 +1085,7 @@ static int gs_dev_theta(bpa_sampler * s)
   HIPCHK(hipGetLastError());
   s->launches++;
   s->logpr_stale = true;
+  if (!gs_dev_allreduce(s, 4u*(unsigned)s->sp.npop)) return 0;
   return gs_dec_launch<0>(s, -1, s->sp.S);
 }
 static int gs_dev_allloci(bpa_sampler * s, int q /* -1: MIX */)
@@ -1082,6 +1100,7 @@ static int gs_dev_allloci(bpa_sampler * s, int q /* -1: MIX */)
   s->epoch++;
   // (the host does not know the decision: the next step takes every tree's density again — the lane groups compute its terms anyway)
   s->logpr_stale = true;
+  if (!gs_dev_allreduce(s, mix ? 1u : 8u)) return 0;
   return mix ? gs_dec_launch<2>(s, -1, -1) : gs_dec_launch<1>(s, q, q + 1);
 }
 

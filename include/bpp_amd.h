@@ -348,7 +348,11 @@ int  bpa_sampler_set_proposal_kernel(bpa_sampler_t *, int kind);
      MIX    re-draws every theta with the scaled trees (opt_mix_theta_update, prop_mixing.c:272).
    All decided from two sums over the loci per theta — coalescences and T2h, carried through the iteration.  The persistent
    kernel decides inside the launch (its control wave): one exchange per step, as without.  The generic sampler (any model,
-   <= 16 tips) brings the sums to the HOST — 24 to 72 bytes and one synchronisation per all-loci step — which takes the
+   <= 16 tips) takes the decision ON THE DEVICE since round 6 — one wave (gsm::gdec_kernel) runs the persistent kernel's
+   control-wave functions on the loci's sums, installs the decision and makes the coming step's species-tree proposal: no host
+   synchronisation inside an iteration (several ranks: the sums pass through the all-reduce callback on the stream first, so
+   with a stream-ordered collective none either).  BPA_GS_HOSTDEC=1 keeps round 5's form:
+   the sums come to the HOST — 24 to 72 bytes and one synchronisation per all-loci step — which takes the
    decision with the statements of a00_driver.c (theta_step_gibbs / tau_step / mix_step) and sends it back as a one-lane
    launch.  With an all-reduce callback (several ranks) every rank's host decides from the sums over ALL ranks' loci: they go
    through the callback first, BPA_SAMPLER_SUMS doubles at a time — the integer sums (counts, 2^-40 fixed-point T2h) as two

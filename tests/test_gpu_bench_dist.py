@@ -68,7 +68,7 @@ def test_two_rank_bench_line(p2p, scaling):
 
 def test_two_rank_bench_line_config3_runs_the_program_s_moves():
     """--config c3 on two ranks: the generic sampler's loci dealt out (strong scaling), BPP's own iteration on every rank — the
-    hosts decide THETA / TAU / MIX from sums that went through the collective"""
+    ranks' decision kernels take THETA / TAU / MIX from sums that went through the collective"""
     d, err = run_bench(["--config", "c3", "--loci", "400", "--no-tape", "--projection-iters", "2", "--no-scale-projection"])
     smp = d["device_resident_sampler"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0, err[-1500:]

@@ -158,7 +158,7 @@ def test_two_ranks_pool_the_step_length_rule(tmp_path, how):
 
 # ---- eight ranks (round 6): no 8-GPU node is to be had, so the world size BASELINE's configs name is exercised the only way one GPU
 # allows — eight processes on it, small shares.  What two ranks cannot show: sums over eight mailbox slots added in rank order, a
-# share an eighth of the set, eight hosts taking one decision, counts pooled over eight.
+# share an eighth of the set, eight ranks taking one decision, counts pooled over eight.
 def _eight_against_one(rs, one, rtol):
     assert len(rs) == 8
     for r in rs:
@@ -202,9 +202,9 @@ def test_eight_ranks_walk_the_single_rank_trajectory(tmp_path, how):
 
 
 def test_eight_ranks_generic_sampler_with_the_program_s_moves(tmp_path):
-    """48 eight-taxon GTR + Gamma4 loci over eight ranks (6 each), BPP's own iteration with the parameter moves: eight hosts
-    take every THETA / TAU / MIX decision from the same all-reduced sums (the integer sums exact, the likelihood sum in rank
-    order); one rank decides on the device (gdec_kernel) — the same chain"""
+    """48 eight-taxon GTR + Gamma4 loci over eight ranks (6 each), BPP's own iteration with the parameter moves: eight ranks'
+    decision waves (gdec_kernel) take every THETA / TAU / MIX decision from the same all-reduced sums (the integer sums exact, the
+    likelihood sum in rank order) — the single rank's chain"""
     one = run(1, str(tmp_path / "one"), 31111, DIST_GTR="1", DIST_PROGRAM="1")[0]
     rs = run(8, str(tmp_path / "eight"), 31112 + os.getpid() % 500, DIST_GTR="1", DIST_PROGRAM="1")
     assert one["kind"] == "generic" and all(r["kind"] == "generic" for r in rs)

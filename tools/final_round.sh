@@ -8,8 +8,20 @@ TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R; mkdir -p gpurun_out
 date +%s > gpurun_out/final_t0
+# a step that overruns its deadline is ended WITH its children (its own process group: a bench left running under rocprofv3 would
+# share the GPU with everything after it — round 6's first closing call measured a 4.8x slower mixed set that way)
+deadline() {   # deadline <seconds> <log> <command...>
+  local secs=$1 log=$2; shift 2
+  setsid "$@" > $log 2>&1 &
+  local pid=$! t=0
+  while kill -0 $pid 2>/dev/null; do
+    sleep 2; t=$((t + 2))
+    if [ $t -ge $secs ]; then kill -TERM -- -$pid 2>/dev/null; sleep 3; kill -KILL -- -$pid 2>/dev/null; wait $pid 2>/dev/null; return 124; fi
+  done
+  wait $pid
+}
 for c in c2 c4 c3; do
-  timeout 420 bash tools/profile_cfg.sh $c $TAG > gpurun_out/final_profile_$c.log 2>&1
+  PROFILE_DEADLINE_S=${PROFILE_DEADLINE_S:-420} deadline 600 gpurun_out/final_profile_$c.log bash tools/profile_cfg.sh $c $TAG
   echo "profile $c rc=$? t=$(( $(date +%s) - $(cat gpurun_out/final_t0) ))"
 done
 cd $R
@@ -18,7 +30,7 @@ cd $R
 mkdir -p profiles/$TAG
 for c in c2 c3 c4; do [ -f gpurun_out/profile_${c}_$TAG.json ] && cp -f gpurun_out/profile_${c}_$TAG.json profiles/$TAG/profile_$c.json; done
 for c in c3 c4; do
-  timeout 300 bash tools/timeline.sh $c > gpurun_out/timeline_$c.txt 2>&1
+  deadline 300 gpurun_out/timeline_$c.txt bash tools/timeline.sh $c
   echo "timeline $c rc=$? t=$(( $(date +%s) - $(cat gpurun_out/final_t0) ))"
 done
 cd $R

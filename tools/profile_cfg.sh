@@ -28,10 +28,14 @@ pass() {   # pass <name> <rocprofv3 arguments...>
   local name=$1; shift
   if [ $(( $(date +%s) - T0 )) -gt $DEADLINE ]; then SKIPPED="$SKIPPED $name"; return; fi
   rocprofv3 "$@" -f csv -d $W/$name -o p -- $BENCH > /dev/null 2> $W/$name.log
+  echo "[profile_cfg] $CFG $name done at +$(( $(date +%s) - T0 ))s"
 }
 BENCH="python $R/bench.py --full-record $W/full.json --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-other-configs --no-host-control --no-bpp-program --no-efficiency --no-scale-projection"
+echo "[profile_cfg] $CFG data set ready at +$(( $(date +%s) - T0 ))s"
 $BENCH --full-record $W/full_plain.json > $W/bench_plain.json 2> $W/plain.log
+echo "[profile_cfg] $CFG plain run done at +$(( $(date +%s) - T0 ))s"
 rocprofv3 --kernel-trace --stats -f csv -d $W/trace -o p -- $BENCH > $W/bench_trace.json 2> $W/trace.log
+echo "[profile_cfg] $CFG trace pass done at +$(( $(date +%s) - T0 ))s"
 pass pmc_fetch --pmc FETCH_SIZE
 pass pmc_write --pmc WRITE_SIZE
 pass pmc_sq --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CYCLES
@@ -54,7 +58,7 @@ out["kernel_stats"] = [r for r in csv.DictReader(open(ks[0]))][:8] if ks else No
 WANT = ("partials", "step_", "pmatrix", "reduce", "sweep", "decide", "iter_kernel", "gstep", "eigen", "gdec")
 # Bytes and time of a kernel must share a denominator (round 5: the per-dispatch MEAN over full-batch tape launches and half-batch
 # sampler launches was divided by a full launch's time).  Every figure below is over the dispatches of the kernel's LARGEST grid
-# only — the full-batch launches — and the trace pass gives the mean duration of exactly those (`full_batch`).
+# only — the full-batch launches — and the trace pass gives the mean duration of exactly those (key full_batch).
 def grid_of(r):
     for k in ("Grid_Size", "Grid_Size_X"):
         if r.get(k) not in (None, ""):
