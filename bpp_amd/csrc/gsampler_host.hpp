@@ -1131,9 +1131,18 @@ static int gs_iterate(bpa_sampler * s, unsigned iterations)
       for (int p = 0; p < s->sp.npop; ++p) any = any || s->has_theta[p];
       if (s->gp_dev)
       {
+        // Nothing in an iteration makes the host wait any more, so it would run thousands of launches ahead of the GPU (a 400-iteration
+        // burn-in of config 4 = 63 600 launches queued; under rocprofv3's counter collection that never finished).  It is paced
+        // instead: before an iteration's all-loci steps it waits for the END of the iteration before the last — work the GPU
+        // finished long ago unless the host is the faster of the two; no decision depends on this wait.
+        if (s->gp_pace_n >= 2) HIPCHK(hipEventSynchronize(s->gp_pace[(s->gp_pace_n - 2) & 3u]));
         if (!gs_step(s, 4) || !gs_dev_theta(s)) return 0;
         for (int q = s->sp.S; q < s->sp.npop; ++q) if (!gs_dev_allloci(s, q)) return 0;
         if (!gs_dev_allloci(s, -1)) return 0;
+        hipEvent_t & ev = s->gp_pace[s->gp_pace_n & 3u];
+        if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev, e->stream));
+        s->gp_pace_n++;
       }
       else
       {

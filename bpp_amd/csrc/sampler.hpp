@@ -1146,7 +1146,8 @@ struct bpa_sampler
   DevBuf<double> g_lnl, g_lnlcur, g_hast, g_logpr, g_delta, g_site, g_len, g_lograt;
   // the program's THETA / TAU / MIX on a generic sampler (decided on the host: gsampler_host.hpp gs_prog_*)
   DevBuf<double> g_t2h3, g_progout;
-  DevBuf<gsm::GDecState> g_dst; DevBuf<double> g_dsum; bool gp_dev = false;      // the program's all-loci decisions on the device (gdec_kernel): state, the sums' buffer
+  DevBuf<gsm::GDecState> g_dst; DevBuf<double> g_dsum; bool gp_dev = false;
+  hipEvent_t gp_pace[4] = {nullptr, nullptr, nullptr, nullptr}; unsigned long gp_pace_n = 0;      // the end of each of the last iterations (gs_iterate: the host stays <= 2 iterations ahead)      // the program's all-loci decisions on the device (gdec_kernel): state, the sums' buffer
   unsigned long long gp_seq = 0;        // ... and the number of the launch whose arrival words the host polls (gs_prog_fetch)
   double * gp_pin = nullptr, * gp_pin_dev = nullptr;   // 64 doubles of pinned host memory the program's sum kernels write straight into (gs_prog_out)
   DevBuf<uint32_t> g_arrive;            // 20-state loci: tiles arrived per locus (the per-locus sum inside partials_lnl_wave20_kernel)
@@ -1368,6 +1369,7 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   if (s->g_ev_join) { (void)hipEventDestroy(s->g_ev_join); s->g_ev_join = nullptr; }
   s->g_t2h3.free(); s->g_progout.free(); s->g_arrive.free(); s->gp_mirror = false; s->g_dst.free(); s->g_dsum.free();
   if (s->gp_pin) { (void)hipHostFree(s->gp_pin); s->gp_pin = s->gp_pin_dev = nullptr; }
+  for (auto & ev : s->gp_pace) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
   s->g_dev.free(); s->g_undo.free(); s->g_loc.free(); s->g_lnl.free(); s->g_lnlcur.free(); s->g_hast.free(); s->g_logpr.free(); s->g_delta.free(); s->g_site.free();
   s->g_len.free(); s->g_lograt.free(); s->g_active.free(); s->g_recs.free(); s->g_mat2.free(); s->g_bmo.free();
   s->g_sm.free(); s->g_sm_old.free(); s->g_ids.free();
