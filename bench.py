@@ -51,7 +51,7 @@ def _rl_compact(r):
     if not isinstance(r, dict):
         return None
     keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_pmc", "frac_codes", "flops_frac",
-            "avg_kernel_us", "launches", "algorithmic_bytes_per_launch", "codes_bytes_per_launch", "profile_head", "warning")
+            "avg_kernel_us", "launches", "algorithmic_bytes_per_launch", "codes_bytes_per_launch", "profile_head", "warning", "frac_pmc_time_us")
     o = {k: r[k] for k in keep if r.get(k) is not None}
     o.setdefault("traffic", None)
     if isinstance(o.get("kernel"), str) and len(o["kernel"]) > 60:
@@ -802,6 +802,9 @@ def dominant_kernel(cfg, one_gpu=True):
             "pipemfma": "partials_lnl_pipemfma20_kernel<false,2>"}.get(k, f"20-state kernel `{k}`")
 
 
+_PROFILE_US = {}       # (config, kernel) -> mean duration (us) of the full-batch launches in the committed profile's trace pass
+
+
 def traffic_from_profiles(config, kernel):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ (tools/profile_cfg.sh on
     this same command): 2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, both in KB"""
@@ -812,8 +815,15 @@ def traffic_from_profiles(config, kernel):
         want = kernel.split(" + ")[0].replace(" ", "")
         key = [k for k in pm if want.rstrip(">") in k.replace(" ", "") and "FETCH_SIZE" in pm[k]]
         key = (key or [k for k in pm if want.split("<")[0] in k and "FETCH_SIZE" in pm[k]])[0]
+        prof = json.load(open(cands[-1]))
+        same = (prof.get("moved_same_file") or {}).get(key)
+        if same:
+            # the profile's own duration of the SAME full-batch launches its counters were averaged over (tools/profile_cfg.sh buckets
+            # a kernel's dispatches by grid size): `frac_pmc` divides bytes and time of one file
+            _PROFILE_US[(config, kernel)] = same["mean_us"]
         return (round((2 * pm[key]["FETCH_SIZE"]["mean"] + pm[key]["WRITE_SIZE"]["mean"]) * 1024),
-                "traffic_from_committed_profile: " + os.path.relpath(cands[-1], ROOT) + f" ({key.split('(')[0]}; separate --pmc passes; FETCH_SIZE doubled per the gfx950 note)")
+                "traffic_from_committed_profile: " + os.path.relpath(cands[-1], ROOT) + f" ({key.split('(')[0]}; separate --pmc passes over the kernel's full-batch "
+                "dispatches; FETCH_SIZE doubled per the gfx950 note)")
     except Exception:
         return None, None
 
@@ -858,7 +868,12 @@ def add_frac_pmc(r):
     next to `frac`, which prices the algorithmic bytes"""
     if isinstance(r, dict) and r.get("traffic") and r.get("avg_kernel_us"):
         r["traffic_from_committed_profile"] = True      # (a builder-run rocprofv3 PMC number inside a driver-run line: profiles/)
-        r["moved_GBps"] = round(r["traffic"] / (r["avg_kernel_us"] * 1e-6) / 1e9, 2)
+        # bytes and time of the SAME launches: the profile's own mean duration of the full-batch dispatches its counters were
+        # averaged over, when it has one (round 6); else this run's event time (a persistent launch: its length is the run's)
+        us = next((v for (c_, k_), v in _PROFILE_US.items() if k_ == r.get("kernel")), None) if (r.get("launches", 0) or 0) > 1 else None
+        r["frac_pmc_time_us"] = us if us else r["avg_kernel_us"]
+        r["frac_pmc_basis"] = "committed profile: bytes and duration of its full-batch dispatches" if us else "committed profile's bytes / this run's event time"
+        r["moved_GBps"] = round(r["traffic"] / (r["frac_pmc_time_us"] * 1e-6) / 1e9, 2)
         r["frac_pmc"] = round(r["moved_GBps"] / r["peak"], 5)
     return r
 
