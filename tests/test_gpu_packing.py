@@ -155,3 +155,66 @@ def test_mixed_models_share_the_packing():
         assert api.lib().bpa_batch_evaluate(eng.h, C.byref(b), api._dp(out)), api._err()
         assert np.all(np.abs(out - want[idx]) <= 1e-12 * np.abs(want[idx]))
     eng.close()
+
+
+@pytest.mark.parametrize("taxa,R,model", [(8, 4, "gtr"), (8, 2, "gtr"), (4, 4, "gtr"), (6, 3, "gtr")])
+def test_update_lists_in_any_order_on_the_multi_category_kernel(taxa, R, model):
+    """step_s4_klane_v3_kernel keeps the parents of a step's last three updates with the lane (registers + two LDS words, round
+    6) and reads an older one back from HBM: whatever the order of a step's updates — here random linear extensions of the tree's
+    partial order, so a child lies 1, 2, 3 ... 6 updates behind its parent, in chunks of every phase — the CLVs are the ones a
+    step in age order leaves (bit for bit, read back through the single-locus API) and lnL the oracle's"""
+    eng = bpp_amd.Engine(0)
+    data = synth.make_dataset(90, 400, taxa, model, R, seed=1000 + taxa + R)
+    loci = tape.make_engine_loci(eng, data)
+    rng = np.random.default_rng(5)
+    want = []
+    for d in data:
+        ol = O.OracleLocus(4, R, d["seqs"], d["weights"], model=d["model"], freqs=d["freqs"], qrates=d["exch"], rates=d["rates"])
+        want.append(ol.full_lnl(d["left"], d["right"], d["times"], d["root"]))
+    want = np.array(want)
+
+    def step(order_of):
+        mat_off, mat_pm, mat_len, op_off, ops, root = [0], [], [], [0], [], []
+        for d in data:
+            tips = len(d["seqs"]); n = 2 * tips - 1
+            parent = [-1] * n
+            for k in range(tips, n):
+                parent[d["left"][k]] = parent[d["right"][k]] = k
+            pm = lambda k: k if k < d["root"] else k - 1
+            for k in range(n):
+                if parent[k] >= 0:
+                    mat_pm.append(pm(k)); mat_len.append(d["times"][parent[k]] - d["times"][k])
+            mat_off.append(len(mat_pm))
+            for k in order_of(d, tips, n):
+                l, r = d["left"][k], d["right"][k]
+                ops.append((k, -1, l, pm(l), -1, r, pm(r), -1))
+            op_off.append(len(ops))
+            root.append(d["root"])
+        return bpp_amd.Plan(eng, loci, mat_off, mat_pm, mat_len, op_off, np.array(ops, dtype=api.OP_DTYPE), root)
+
+    def by_age(d, tips, n):
+        return sorted(range(tips, n), key=lambda k: d["times"][k])
+
+    def random_extension(d, tips, n):
+        done, out = set(range(tips)), []
+        while len(out) < n - tips:
+            ready = [k for k in range(tips, n) if k not in done and d["left"][k] in done and d["right"][k] in done]
+            k = ready[int(rng.integers(len(ready)))]
+            out.append(k); done.add(k)
+        return out
+
+    p = step(by_age)
+    p.launch()
+    got = p.lnl()
+    assert np.max(np.abs(got - want) / np.abs(want)) < 1e-12
+    ref_clv = [[loci[i].get_clv(k).copy() for k in range(taxa, 2 * taxa - 1)] for i in range(0, len(data), 9)]
+    p.close()
+    for _ in range(6):
+        p = step(random_extension)
+        p.launch()
+        assert (p.lnl() == got).all()                      # same CLVs -> same site terms -> same sums, to the bit
+        for j, i in enumerate(range(0, len(data), 9)):
+            for a, k in zip(ref_clv[j], range(taxa, 2 * taxa - 1)):
+                assert (loci[i].get_clv(k) == a).all()
+        p.close()
+    eng.close()
