@@ -1,4 +1,4 @@
-"""N>1 path on CPU: loci sharded over 2 ranks (gloo), per-rank sums of per-locus
+"""N>1 path on CPU: loci sharded over 2 and over 8 ranks (gloo; 8 = the world size BASELINE's configs name), per-rank sums of per-locus
 log-likelihoods (computed here with the oracle standing in for the GPU engine),
 all-reduced — must equal the single-process total whatever the partition."""
 import os
@@ -44,13 +44,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_allreduce_of_locus_sums():
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_allreduce_of_locus_sums(world):
     import oraclelib as O
     from bpp_amd import synth
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port += 13*world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -63,4 +65,4 @@ def test_two_rank_gloo_allreduce_of_locus_sums():
     assert sorted(i for _, _, m in res for i in m) == list(range(24))
     for _, packed, _ in res:
         assert abs(packed[0] - total) <= 1e-12 * abs(total)
-        assert packed[1] == 12.0 and packed[2] == 24.0 and packed[3] == 2.0
+        assert packed[1] == 12.0 and packed[2] == 24.0 and packed[3] == float(world)        # (8 ranks: the zig-zag's eight parts of 24 loci)
