@@ -82,7 +82,7 @@ def compact_line(full):
                           "sample": (cb.get("sample_short") or cb.get("sample") or "")[:200], "one_thread": cb.get("one_thread"),
                           "host_cpu_quota": cb.get("host_cpu_quota")} if cb else None),
         "value_over_cpu_baseline": (g("speedups") or {}).get("value_over_cpu_baseline"),
-        "vs_survey_measurement": (g("vs_survey_measurement") or {}).get("ratio"),
+        "vs_survey_measurement": (g("vs_survey_measurement").get("ratio") if isinstance(g("vs_survey_measurement"), dict) else g("vs_survey_measurement")),
         "site_lnl_updates_per_s": g("site_lnl_updates_per_s"),
     }
     if g("value_weak") is not None or g("value_strong") is not None:
