@@ -98,6 +98,7 @@ struct GArgs
   // (what pmatrix_s4_dense_kernel did as a launch of its own between the proposal and the node updates)
   const SlotStatic * slot_tab; uint32_t fuse_pm;
   const struct GDecState * dstep;         // the program's moves decided on the device: the TAU window / MIX factor of this step (else null: tau_w, mix_c, mix_lnc)
+  uint32_t fuse_eigen, pad_fe;            // gstep_kernel: a lane that writes frequencies / exchangeabilities into its locus's parameter block refreshes the block's eigensystem itself
   Species sp;
 };
 
@@ -429,6 +430,16 @@ __global__ void __launch_bounds__(GBS) gstep_kernel(const GArgs A)
       // (restored and proposed component may be the same one: this order leaves the proposal in the block.  NB the
       //  values of `m` are final here — a restored component and a newly proposed one never overlap in time)
       write_par(L.par, L.R, md, m);
+    }
+    // (round 6) K6 right here: the lane that moved its locus's frequencies / exchangeabilities (proposed new ones, or put a rejected
+    // proposal's back) refreshes the eigensystem of the block's rate matrix 0 — the one these moves write — in the same launch.
+    // It was a launch of its own (eigen_kernel over ALL loci: 20 us + a launch boundary) between every parameter proposal and its
+    // P-matrices: 16 launches of an iteration of config 3.  Same routine, same inputs, same bits.
+    const bool eig = (restore_par && (A.pend_mode == 6 || A.pend_mode == 7)) || (propose_par && (MODE == 6 || MODE == 7));
+    if (A.fuse_eigen && eig)
+    {
+      double * pm = L.par + par_matrix(L.R, 4, 0);
+      update_eigen_regs<4>(pm + pm_freqs(4), pm + pm_subst(4), pm + pm_evals(4), pm + pm_evecs(4), pm + pm_ievecs(4));
     }
   }
 

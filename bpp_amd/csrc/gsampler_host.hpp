@@ -282,7 +282,11 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   a.dstep = (s->gp_dev && (mode == 2 || mode == 3)) ? s->g_dst.p : nullptr;
   // a frequency / exchangeability step — proposed now, or rolled back now for the loci that rejected it — leaves
   // parameter blocks whose eigensystems are stale: refreshed before the next evaluation (gs_eval)
-  if (mode == 6 || mode == 7 || (s->g_pend == 4 && (s->g_pend_mode == 6 || s->g_pend_mode == 7))) s->g_eigen_dirty = true;
+  // ... unless the launch is the one-lane kernel (settle, start-up, the parameter moves) on 4-state loci whose eigensystems are
+  // level now: its lanes then refresh what they write themselves (GArgs::fuse_eigen, round 6) and nothing is left stale
+  const bool touches_eigen = mode == 6 || mode == 7 || (s->g_pend == 4 && (s->g_pend_mode == 6 || s->g_pend_mode == 7));
+  a.fuse_eigen = (touches_eigen && mode >= 4 && !s->g_s20 && !s->g_alljc && e->usedata && !s->g_eigen_dirty && !s->env_noeigfuse) ? 1u : 0u;
+  if (touches_eigen && !a.fuse_eigen) s->g_eigen_dirty = true;
   // diagnostics (BPA_GS_DIFF=1): a GAGE / GSPR step by both kernels from the same state, whatever differs is reported;
   // the run goes on with the one-lane kernel's result
 #define GS2_CASES(NT_, BPP_, GRID_, ST_) switch (a.mode) { \

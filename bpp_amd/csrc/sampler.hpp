@@ -1195,7 +1195,7 @@ struct bpa_sampler
   uint32_t env_dbg = 0; int env_gage = -1, env_gspr = -1; bool env_trace = false, env_nomix = false;
   // the generic sampler's switches (A/B and kept paths; read ONCE, at creation: nothing reads the environment on the launch path,
   // and a test can still make samplers of either kind in one process)
-  int env_fusea = -1; bool env_fusepm = true, env_pmgroup = true, env_hostdec = false, env_rootstore = false; int env_chain = -1, env_pinout = 2;
+  int env_fusea = -1; bool env_noeigfuse = false, env_fusepm = true, env_pmgroup = true, env_hostdec = false, env_rootstore = false; int env_chain = -1, env_pinout = 2;
   long env_inject = 0; uint32_t env_inject_bit = 1024u; long v2_launch_no = 0;    // BPA_SMP_INJECT=k[,w]: the k-th persistent launch with all-loci steps gives up at its first wait (w: workgroup 0 alone) — tests of the run-again path
   bool mix_pending = false;             // a mixing decision taken on the device has not been applied yet
   a00_rng_t grng = 0;
@@ -1342,6 +1342,7 @@ static bpa_sampler * sampler_create_plain(bpa_engine_t * e, bpa_locus_t * const 
     v = BPA_EXP_SWITCH("BPA_GS_FUSEA");     s->env_fusea = v ? (v[0] == '1' ? 1 : 0) : -1;
     v = BPA_EXP_SWITCH("BPA_GS_FUSEPM");    s->env_fusepm = !(v && v[0] == '0');
     v = BPA_EXP_SWITCH("BPA_S20_PMGROUP");  s->env_pmgroup = !(v && v[0] == '0');
+    s->env_noeigfuse = BPA_EXP_SWITCH("BPA_GS_NOEIGFUSE") != nullptr;        // (A/B: the eigensystem refresh as a launch of its own)
     v = getenv("BPA_GS_CHAIN");     s->env_chain = v ? (v[0] != '0' ? 1 : 0) : -1;
     v = BPA_EXP_SWITCH("BPA_GS_PINOUT");    s->env_pinout = v ? (v[0] == '0' ? 0 : v[0] == '1' ? 1 : 2) : 2;
     s->env_hostdec = getenv("BPA_GS_HOSTDEC") != nullptr;
