@@ -1334,7 +1334,7 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves
         achieved = bytes_per_launch / (us * 1e-6) / 1e9
         kern = dominant_kernel(cfg)
         traffic, src = traffic_from_profiles("c3" if gtr else "c4", kern) if args.loci is None else (None, None)
-        if traffic and smp.streams() == 2:
+        if traffic and smp.streams() >= 2:
             # the profile's dispatches are whole-batch launches (tape + BPA_GS_NOSPLIT=1 sampler); the launches timed here
             # cover half the loci: no PMC figure for a launch of this size
             traffic, src = None, f"{src}: {traffic} B per launch over ALL loci; the launches timed here are half-batches"
@@ -1346,9 +1346,9 @@ def run_sampler(eng, cfg, data, loci, args, D, first_locus, steps, warmup, moves
                         note="the generic device-resident sampler (csrc/gsampler.hpp): every proposal step = one launch of a per-locus "
                              "proposal kernel (trees in HBM) + the engine's step kernel over the records it wrote; algorithmic bytes = K1 + K2 "
                              "of the node updates the proposals actually asked for (device counters)"
-                             + ("; the per-locus steps run as TWO half-batch launches on two streams that overlap in time "
-                                "(csrc/gsampler_host.hpp gs_fork): a launch here covers half the loci and its duration includes the "
-                                "time it shares the chip with the other half's launch — the kernel alone: likelihood_only" if smp.streams() == 2 else ""),
+                             + (f"; the per-locus steps run as {smp.streams()} part-batch launches on as many streams that overlap in time "
+                                "(csrc/gsampler_host.hpp gs_fork): a launch here covers a part of the loci and its duration includes the "
+                                "time it shares the chip with the other parts' launches — the kernel alone: likelihood_only" if smp.streams() >= 2 else ""),
                         streams=smp.streams())
     elif kind == "persistent" and tm["sweep_launches"]:
         # every launch of the timed region carries events; a launch = up to 4096 whole iterations of all loci

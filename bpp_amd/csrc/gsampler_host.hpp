@@ -45,10 +45,10 @@ static int gs_refresh_eigen(bpa_sampler * s)
     if (!upload(s->g_ids, ids.data(), s->nloci)) return 0;
   }
   // the generic sampler's loci are 4-state; forked: each half on its own stream
-  for (int h = 0; h < (s->g_forked ? 2 : 1); ++h)
+  for (unsigned h = 0; h < (s->g_forked ? s->g_np : 1u); ++h)
   {
-    const unsigned lo = h ? s->g_isplit : 0u, hi = s->g_forked && !h ? s->g_isplit : s->nloci;
-    hipLaunchKernelGGL(eigen_kernel<4>, dim3((hi - lo + 63)/64), dim3(64), 0, h ? s->g_stream2 : e->stream, e->d_loci.p, s->g_ids.p + lo, (uint32_t)(hi - lo));
+    const unsigned lo = s->g_forked ? s->g_pi[h] : 0u, hi = s->g_forked ? s->g_pi[h + 1] : s->nloci;
+    hipLaunchKernelGGL(eigen_kernel<4>, dim3((hi - lo + 63)/64), dim3(64), 0, h ? s->g_st[h] : e->stream, e->d_loci.p, s->g_ids.p + lo, (uint32_t)(hi - lo));
     s->launches++;
   }
   HIPCHK(hipGetLastError());
@@ -70,7 +70,7 @@ static int gs_fork(bpa_sampler * s)
 {
   if (s->g_forked) return 1;
   HIPCHK(hipEventRecord(s->g_ev_fork, s->eng->stream));
-  HIPCHK(hipStreamWaitEvent(s->g_stream2, s->g_ev_fork, 0));
+  for (unsigned p = 1; p < s->g_np; ++p) HIPCHK(hipStreamWaitEvent(s->g_st[p], s->g_ev_fork, 0));
   s->g_forked = true;
   return 1;
 }
@@ -78,8 +78,11 @@ static int gs_fork(bpa_sampler * s)
 static int gs_join(bpa_sampler * s)
 {
   if (!s->g_forked) return 1;
-  HIPCHK(hipEventRecord(s->g_ev_join, s->g_stream2));
-  HIPCHK(hipStreamWaitEvent(s->eng->stream, s->g_ev_join, 0));
+  for (unsigned p = 1; p < s->g_np; ++p)
+  {
+    HIPCHK(hipEventRecord(s->g_ev_join[p], s->g_st[p]));
+    HIPCHK(hipStreamWaitEvent(s->eng->stream, s->g_ev_join[p], 0));
+  }
   s->g_forked = false;
   return 1;
 }
@@ -196,39 +199,66 @@ static int gs_upload(bpa_sampler * s)
   hipLaunchKernelGGL(gsm::glograt_kernel, dim3(1), dim3(gsm::NN*gsm::NN), 0, e->stream, s->g_lograt.p);
   HIPCHK(hipGetLastError());
   s->epoch = 0; s->mix_pending = false; s->g_pend = 0;
-  // two half-batches when there is enough of the packing to halve and the sampler's loci are in slot order
-  s->g_split = false; s->g_forked = false;
+  // part-batches (two by default) when there is enough of the packing to divide and the sampler's loci are in slot order
+  s->g_split = false; s->g_forked = false; s->g_np = 1;
   static const bool no_split = BPA_EXP_SWITCH("BPA_GS_NOSPLIT") != nullptr;
+  // Two part-batches by default; THREE for a 4-state set whose packing spans >= 2 400 workgroups (round 6, config 3: 10 000 loci 231.7 ->
+  // 241.1 it/s, 7 500: 287.6 -> 298.9, 5 000: 357.6 -> 362.7; below that the extra launches cost more than the overlap buys — 2 500:
+  // 491.7 -> 480.1, 1 250: 592.8 -> 562.8; four parts: 191 at 10 000 loci — and 20-state sets lose with three: config 4 139.7 -> 136.1)
+  unsigned want_np = (unsigned)std::min(std::max(s->env_parts > 0 ? s->env_parts : 2, 2), (int)bpa_sampler::GPARTS);
+  auto part_streams = [&](unsigned np) -> int
+  {
+    s->g_st[0] = e->stream;
+    for (unsigned p = 1; p < np; ++p)
+    {
+      if (!s->g_st[p]) HIPCHK(hipStreamCreateWithFlags(&s->g_st[p], hipStreamNonBlocking));
+      if (!s->g_ev_join[p]) HIPCHK(hipEventCreateWithFlags(&s->g_ev_join[p], hipEventDisableTiming));
+    }
+    if (!s->g_ev_fork) HIPCHK(hipEventCreateWithFlags(&s->g_ev_fork, hipEventDisableTiming));
+    return 1;
+  };
   if (!s->g_s20 && !s->g_alljc && !no_split && e->usedata && T >= 2)
   {
     bool mono = true;
     for (unsigned i = 0; i + 1 < T && mono; ++i) mono = loc[i].slot < loc[i + 1].slot;
-    // the workgroup of the packing that holds the middle locus starts the second half
     auto block_of = [&](uint32_t slot) { return (unsigned)(std::upper_bound(e->h_blk_slot_off.begin(), e->h_blk_slot_off.end(), slot) - e->h_blk_slot_off.begin()) - 1u; };
-    const unsigned bs = block_of(loc[T/2].slot), ss = e->h_blk_slot_off[bs];
-    const unsigned span = block_of(loc[T - 1].slot) + 1u - block_of(loc[0].slot);
-    unsigned is = 0;
-    while (is < T && loc[is].slot < ss) ++is;
-    if (mono && span >= 96 && is > 0 && is < T)
+    const unsigned b_lo = block_of(loc[0].slot), b_hi = block_of(loc[T - 1].slot) + 1u, span = b_hi - b_lo;
+    if (s->env_parts <= 0 && span >= 2400u) want_np = 3;
+    if (mono && span >= 48u*want_np)
     {
-      if (!s->g_stream2) HIPCHK(hipStreamCreateWithFlags(&s->g_stream2, hipStreamNonBlocking));
-      if (!s->g_ev_fork) HIPCHK(hipEventCreateWithFlags(&s->g_ev_fork, hipEventDisableTiming));
-      if (!s->g_ev_join) HIPCHK(hipEventCreateWithFlags(&s->g_ev_join, hipEventDisableTiming));
-      s->g_split = true; s->g_isplit = is; s->g_ssplit = ss; s->g_bsplit = bs;
+      // part p starts with the workgroup of the packing that holds locus p T / np
+      bool ok = true;
+      s->g_pi[0] = 0; s->g_ps[0] = 0; s->g_pb[0] = 0;
+      for (unsigned p = 1; p < want_np && ok; ++p)
+      {
+        const unsigned bs = block_of(loc[(size_t)T*p/want_np].slot), ss = e->h_blk_slot_off[bs];
+        unsigned is = s->g_pi[p - 1];
+        while (is < T && loc[is].slot < ss) ++is;
+        ok = is > s->g_pi[p - 1] && is < T && bs > s->g_pb[p - 1];
+        s->g_pi[p] = is; s->g_ps[p] = ss; s->g_pb[p] = bs;
+      }
+      s->g_pi[want_np] = T; s->g_ps[want_np] = e->pack_slots; s->g_pb[want_np] = e->pack_blocks;
+      if (ok)
+      {
+        if (!part_streams(want_np)) return 0;
+        s->g_split = true; s->g_np = want_np;
+      }
     }
   }
-  // 20-state sets: two halves of the loci (the step's records are per locus, the tiles in locus order): the proposal, P-matrix
-  // and sum launches of one half — latency, 70 us of a 385 us step on config 4 — run under the other half's node updates
-  static const bool no_split20 = BPA_EXP_SWITCH("BPA_GS_NOSPLIT") != nullptr;
-  if (s->g_s20 && !no_split20 && e->usedata && T >= 128)
+  // 20-state sets: parts of the loci (the step's records are per locus, the tiles in locus order): the proposal, P-matrix
+  // and sum launches of one part — latency, 70 us of a 385 us step on config 4 — run under the others' node updates
+  if (s->g_s20 && !no_split && e->usedata && T >= 64u*want_np)
   {
-    if (!s->g_stream2) HIPCHK(hipStreamCreateWithFlags(&s->g_stream2, hipStreamNonBlocking));
-    if (!s->g_ev_fork) HIPCHK(hipEventCreateWithFlags(&s->g_ev_fork, hipEventDisableTiming));
-    if (!s->g_ev_join) HIPCHK(hipEventCreateWithFlags(&s->g_ev_join, hipEventDisableTiming));
-    s->g_split = true; s->g_isplit = T/2; s->g_ssplit = 0; s->g_bsplit = 0;
-    unsigned nt = 0;
-    for (unsigned i = 0; i < T/2; ++i) nt += (s->loci[i]->sites + gs_tile20() - 1u)/gs_tile20();
-    s->g_tsplit = nt;
+    if (!part_streams(want_np)) return 0;
+    s->g_split = true; s->g_np = want_np;
+    unsigned nt = 0, p = 1;
+    s->g_pi[0] = 0; s->g_pt[0] = 0; s->g_ps[0] = 0; s->g_pb[0] = 0;
+    for (unsigned i = 0; i < T; ++i)
+    {
+      if (p < want_np && i == (unsigned)((size_t)T*p/want_np)) { s->g_pi[p] = i; s->g_pt[p] = nt; s->g_ps[p] = 0; s->g_pb[p] = 0; ++p; }
+      nt += (s->loci[i]->sites + gs_tile20() - 1u)/gs_tile20();
+    }
+    s->g_pi[want_np] = T; s->g_pt[want_np] = nt;
   }
   s->uploaded = true; s->gp_mirror = false;
   return 1;
@@ -411,11 +441,11 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
     s->g_pend = mode <= 1 ? 1u : 2u; s->g_pend_mode = mode; s->g_pend_k = k;
     return 1;
   }
-  for (int h = 0; h < (s->g_forked ? 2 : 1); ++h)
+  for (unsigned h = 0; h < (s->g_forked ? s->g_np : 1u); ++h)
   {
-    a.i0 = h ? s->g_isplit : 0u; a.iend = s->g_forked && !h ? s->g_isplit : s->nloci;
+    a.i0 = s->g_forked ? s->g_pi[h] : 0u; a.iend = s->g_forked ? s->g_pi[h + 1] : s->nloci;
     const dim3 grid((a.iend - a.i0 + gsm::GBS - 1)/gsm::GBS), block(gsm::GBS);
-    hipStream_t st = h ? s->g_stream2 : e->stream;
+    hipStream_t st = h ? s->g_st[h] : e->stream;
     // GAGE / GSPR / TAU / MIX: a group of lanes per locus (gsampler2.hpp; BPA_GS_V1=1: the one-lane-per-locus kernel)
     if (a.mode <= 3 && !gs_v1)
     {
@@ -439,7 +469,7 @@ static int gs_step(bpa_sampler * s, unsigned mode, unsigned k = 0, double tau_u 
   if (dbg_sync)
   {
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (s->g_forked) HIPCHK(hipStreamSynchronize(s->g_stream2));
+    if (s->g_forked) for (unsigned p = 1; p < s->g_np; ++p) HIPCHK(hipStreamSynchronize(s->g_st[p]));
     fprintf(stderr, "[gs] step mode %u k %u pend %u done\n", mode, k, a.pend);
   }
 #ifdef GS2_PROF
@@ -512,10 +542,10 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     const bool pm_group = s->env_pmgroup;
     if (s->g_forked)
     {
-      for (int h = 0; h < 2; ++h)
+      for (unsigned h = 0; h < s->g_np; ++h)
       {
-        const unsigned i0 = h ? s->g_isplit : 0u, i1 = h ? s->nloci : s->g_isplit, t0 = h ? s->g_tsplit : 0u, t1 = h ? s->g_ntiles : s->g_tsplit;
-        hipStream_t st = h ? s->g_stream2 : e->stream;
+        const unsigned i0 = s->g_pi[h], i1 = s->g_pi[h + 1], t0 = s->g_pt[h], t1 = s->g_pt[h + 1];
+        hipStream_t st = h ? s->g_st[h] : e->stream;
         d.ent0 = i0*s->g_maxmat;
         d.flags = 1u | 256u;
         if (pm_group) hipLaunchKernelGGL(pmatrix_wg2_group_kernel<20>, dim3(i1 - i0), dim3(256), 0, st, d, s->g_maxmat);
@@ -533,7 +563,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
         if (!fuse_sum) hipLaunchKernelGGL(lnl_reduce_wave_kernel, dim3(i1 - i0), dim3(64), 0, st, d);
       }
       HIPCHK(hipGetLastError());
-      s->launches += fuse_sum ? 4 : 6; s->g_evals += 2;
+      s->launches += (fuse_sum ? 2 : 3)*s->g_np; s->g_evals += s->g_np;
       return 1;
     }
     d.flags = 1u;
@@ -584,11 +614,11 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
     d.pad = s->g_rmax;
     if (s->g_forked)
     {
-      for (int h = 0; h < 2; ++h)
+      for (unsigned h = 0; h < s->g_np; ++h)
       {
-        const unsigned b0 = h ? s->g_bsplit : 0u, b1 = h ? e->pack_blocks : s->g_bsplit;
-        const unsigned e0 = (h ? s->g_ssplit : 0u)*s->g_maxmat, e1 = (h ? e->pack_slots : s->g_ssplit)*s->g_maxmat;
-        hipStream_t st = h ? s->g_stream2 : e->stream;
+        const unsigned b0 = s->g_pb[h], b1 = s->g_pb[h + 1];
+        const unsigned e0 = s->g_ps[h]*s->g_maxmat, e1 = s->g_ps[h + 1]*s->g_maxmat;
+        hipStream_t st = h ? s->g_st[h] : e->stream;
         d.blk0 = b0; d.ent0 = e0;
         if (fuse_a)
         {
@@ -604,7 +634,7 @@ static int gs_eval(bpa_sampler * s, int kind /* 0 per-locus step, 1 all-loci ste
         s->launches += pm_done ? 1 : 2;
       }
       HIPCHK(hipGetLastError());
-      s->g_evals += 2;
+      s->g_evals += s->g_np;
       return 1;
     }
     if (fuse_a)

@@ -1157,9 +1157,13 @@ struct bpa_sampler
   // two half-batches of the per-locus steps on two streams (gsampler_host.hpp: gs_fork / gs_join): loci [0, g_isplit) are the
   // slots [0, g_ssplit) = workgroups [0, g_bsplit) of the engine's packing, the rest the other half
   bool g_split = false, g_forked = false;
-  unsigned g_isplit = 0, g_ssplit = 0, g_bsplit = 0, g_tsplit = 0;      // (g_tsplit: 20-state sets, the first tile of the second half)
-  hipStream_t g_stream2 = nullptr;
-  hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+  // (round 6: g_np part-batches, 2 by default; part p = loci [g_pi[p], g_pi[p+1]) = slots [g_ps[p], ..) = workgroups [g_pb[p], ..) of the
+  //  packing — 20-state sets: tiles [g_pt[p], ..) —, launched on g_st[p]; g_st[0] is the engine's stream)
+  static constexpr int GPARTS = 4;
+  unsigned g_np = 1, g_pi[GPARTS + 1] = {}, g_ps[GPARTS + 1] = {}, g_pb[GPARTS + 1] = {}, g_pt[GPARTS + 1] = {};
+  hipStream_t g_st[GPARTS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t g_ev_fork = nullptr, g_ev_join[GPARTS] = {nullptr, nullptr, nullptr, nullptr};
+  int env_parts = 0;                    // BPA_GS_PARTS (experimental build): part-batches of the per-locus steps (default 2)
   DevBuf<uint8_t> g_active;
   DevBuf<uint4> g_recs;
   DevBuf<MatRec2> g_mat2;
@@ -1342,6 +1346,7 @@ static bpa_sampler * sampler_create_plain(bpa_engine_t * e, bpa_locus_t * const 
     v = BPA_EXP_SWITCH("BPA_GS_FUSEA");     s->env_fusea = v ? (v[0] == '1' ? 1 : 0) : -1;
     v = BPA_EXP_SWITCH("BPA_GS_FUSEPM");    s->env_fusepm = !(v && v[0] == '0');
     v = BPA_EXP_SWITCH("BPA_S20_PMGROUP");  s->env_pmgroup = !(v && v[0] == '0');
+    v = BPA_EXP_SWITCH("BPA_GS_PARTS");    s->env_parts = v ? atoi(v) : 0;
     s->env_noeigfuse = BPA_EXP_SWITCH("BPA_GS_NOEIGFUSE") != nullptr;        // (A/B: the eigensystem refresh as a launch of its own)
     v = getenv("BPA_GS_CHAIN");     s->env_chain = v ? (v[0] != '0' ? 1 : 0) : -1;
     v = BPA_EXP_SWITCH("BPA_GS_PINOUT");    s->env_pinout = v ? (v[0] == '0' ? 0 : v[0] == '1' ? 1 : 2) : 2;
@@ -1365,9 +1370,12 @@ extern "C" void bpa_sampler_destroy(bpa_sampler_t * s)
   for (auto & t : s->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
   s->blk_task_off.free(); s->lane_rec.free(); s->task_rec.free(); s->flag.free();
   s->counters.free(); s->trees.free(); s->snap.free(); s->mix_delta.free(); s->mix_sum.free(); s->taus.free(); s->pop_t2h.free(); s->theta_sums.free(); s->pop_nc.free(); s->lograt.free(); s->uc.free();
-  if (s->g_stream2) { (void)hipStreamSynchronize(s->g_stream2); (void)hipStreamDestroy(s->g_stream2); s->g_stream2 = nullptr; }
+  for (int p_ = 1; p_ < bpa_sampler::GPARTS; ++p_)
+  {
+    if (s->g_st[p_]) { (void)hipStreamSynchronize(s->g_st[p_]); (void)hipStreamDestroy(s->g_st[p_]); s->g_st[p_] = nullptr; }
+    if (s->g_ev_join[p_]) { (void)hipEventDestroy(s->g_ev_join[p_]); s->g_ev_join[p_] = nullptr; }
+  }
   if (s->g_ev_fork) { (void)hipEventDestroy(s->g_ev_fork); s->g_ev_fork = nullptr; }
-  if (s->g_ev_join) { (void)hipEventDestroy(s->g_ev_join); s->g_ev_join = nullptr; }
   s->g_t2h3.free(); s->g_progout.free(); s->g_arrive.free(); s->gp_mirror = false; s->g_dst.free(); s->g_dsum.free();
   if (s->gp_pin) { (void)hipHostFree(s->gp_pin); s->gp_pin = s->gp_pin_dev = nullptr; }
   for (auto & ev : s->gp_pace) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
@@ -2472,7 +2480,7 @@ extern "C" int bpa_sampler_streams(bpa_sampler_t * s)
   std::lock_guard<std::recursive_mutex> lock_(s->eng->mtx);
   if (s->comp) return comp_upload(s) ? 1 : -1;
   if (!sampler_upload(s)) return -1;
-  return s->generic && s->g_split ? 2 : 1;
+  return s->generic && s->g_split ? (int)s->g_np : 1;
 }
 
 extern "C" int bpa_sampler_summary(bpa_sampler_t * s, double * total_lnl, unsigned long * proposals,
