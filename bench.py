@@ -35,6 +35,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # as bpp_amd/__init__.py does (here too: torch may bring the HIP runtime in first when N > 1)
 
 import numpy as np  # noqa: E402
 

@@ -158,3 +158,17 @@ def test_the_default_build_reads_few_switches_from_the_environment():
     assert "#define BPA_EXP_SWITCH(name_) (static_cast<const char *>(nullptr))" in src
     L = bpp_amd.lib()
     assert L.bpa_experimental_build() in (0, 1)
+
+
+def test_package_import_raises_the_hardware_queue_count_unless_set():
+    """bpp_amd/__init__.py: GPU_MAX_HW_QUEUES defaults to 8 before the library (and the HIP runtime) loads; a user's value is kept."""
+    import subprocess
+    import sys
+    code = "import os, bpp_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip() == "8", out.stderr[-300:]
+    env["GPU_MAX_HW_QUEUES"] = "2"
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip() == "2", out.stderr[-300:]
