@@ -9,7 +9,8 @@ import os as _os
 # after the other.  A generic sampler of a large 4-state set runs three part-batches on three streams; with a
 # second engine alive in the process (bench.py's other-config sections) the fifth stream landed on a busy queue and config 3
 # ran at 188 instead of 235 it/s (NOTES.md 12).  The runtime reads the variable when it starts, so it is set here, before the
-# library — and with it the HIP runtime — is loaded; a value the user set is kept.  C hosts: INTEGRATION.md 4b.
+# library — and with it the HIP runtime — is loaded; a value the user set is kept.  (The library's first entry points do the same
+# for hosts that are not Python: engine.hip, hw_queues_default)
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .api import (BpaError, Engine, Locus, Plan, PlanSequence, Sampler, P2P, RcclExchange, GNode, GTree, Op, OP_DTYPE, lib,

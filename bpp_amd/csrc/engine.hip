@@ -239,8 +239,20 @@ extern "C" int bpa_experimental_build(void)
 }
 extern "C" void bpa_internal_set_error(const char * msg) { g_err = msg ? msg : ""; }   // host_input.cpp
 
+// HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless set) and streams that share one run one after the
+// other: a process with two engines alive put the third part-batch stream of a generic sampler on a busy queue (config 3 188 instead
+// of 235 it/s, NOTES.md 12).  The runtime reads the variable when it starts — on the process's first HIP call —, so the library's
+// entry points that can be that call set it to 8 first, unless the user has set it (Python hosts: bpp_amd/__init__.py does the same
+// before the library loads; a host that has used HIP already sets it itself).
+static void hw_queues_default()
+{
+  static std::once_flag once;
+  std::call_once(once, [] { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); });
+}
+
 extern "C" int bpa_device_count(void)
 {
+  hw_queues_default();
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
